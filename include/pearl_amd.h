@@ -1,0 +1,278 @@
+/*
+ * pearl_amd.h — C ABI of the MI355X-native replay/learner core for Pearl.
+ *
+ * This is the drop-in boundary.  The reference has no FFI: the
+ * hot path sits behind two Python ABCs,
+ *     pearl/replay_buffers/replay_buffer.py:18-91       (ReplayBuffer)
+ *     pearl/policy_learners/policy_learner.py:40-229    (PolicyLearner)
+ * so every entry point below cites the reference *method* it replaces.  The
+ * Python host side (pearl_amd/) mirrors those ABCs and binds this library with
+ * ctypes; INTEGRATION.md shows the stub a Pearl maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every device pointer is a raw HBM address owned by the
+ *     caller (torch owns batches, parameters and optimizer state; the arena is
+ *     owned by the library);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all
+ *     work is enqueued on it, nothing synchronises unless documented;
+ *   - return 0 on success, a negative pa_status otherwise; never throws.
+ *     pa_last_error() returns a thread-local human-readable message;
+ *   - handles are opaque, not re-entrant, one learner = one handle.
+ */
+#ifndef PEARL_AMD_H
+#define PEARL_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_ABI_VERSION 1
+
+typedef enum pa_status {
+  PA_OK = 0,
+  PA_ERR_INVALID = -1,     /* bad argument (shim raises AssertionError/TypeError)   */
+  PA_ERR_VALUE = -2,       /* the reference's ValueError (batch_size > len(buffer)) */
+  PA_ERR_HIP = -3,         /* a HIP runtime call failed                             */
+  PA_ERR_UNSUPPORTED = -4, /* shape outside what the kernels were built for         */
+  PA_ERR_NOMEM = -5
+} pa_status;
+
+typedef enum pa_dtype {
+  PA_F32 = 0,
+  PA_I64 = 1,
+  PA_I32 = 2,
+  PA_U8 = 3, /* torch.bool / torch.uint8 */
+  PA_F64 = 4
+} pa_dtype;
+
+const char* pa_last_error(void);
+int pa_abi_version(void);
+/* Number of visible HIP devices (0 on a CPU-only host; never fails). */
+int pa_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Replay arena: structure-of-arrays ring in HBM.                            */
+/* Replaces the deque of per-transition CPU tensors of                       */
+/* pearl/replay_buffers/tensor_based_replay_buffer.py:25-36 (+ basic_replay_ */
+/* buffer.py:21-48).  Logical index i (0 = oldest) lives in slot             */
+/* (head + i) % capacity, the same FIFO eviction as deque(maxlen=capacity).  */
+/* ------------------------------------------------------------------------ */
+typedef struct pa_arena pa_arena;
+
+typedef struct pa_arena_desc {
+  int64_t capacity;      /* transitions                                                    */
+  int32_t device;        /* HIP device ordinal                                             */
+  int32_t state_dim;     /* floats per state row (states are stored as float32, :353)       */
+  int32_t action_elems;  /* elements of one stored action (1 for tensor([a]))               */
+  int32_t action_dtype;  /* pa_dtype of the stored action (dtype is preserved, :354)        */
+  int32_t reward_dtype;  /* PA_F32 for python floats, PA_I64 for python ints (:165-166)     */
+  int32_t max_actions;   /* A: rows of the padded available-action table; 0 = none/continuous */
+  int32_t avail_dim;     /* floats per available-action row (action_dim, :236-239)          */
+  int32_t has_next_state;
+  int32_t has_cost;
+  int64_t staging_rows;  /* pinned host staging ring, rows (0 = default 4096)               */
+} pa_arena_desc;
+
+/* One transition as host pointers (what push() tensorises, :55-133).  NULL is
+ * allowed for the optional members the descriptor disabled. */
+typedef struct pa_transition {
+  const float* state;       /* [state_dim]                                         */
+  const void* action;       /* [action_elems] of action_dtype                      */
+  const void* reward;       /* one element of reward_dtype                         */
+  const float* next_state;  /* [state_dim]                                         */
+  const float* curr_avail;  /* [max_actions * avail_dim], zero padded (:236-245)   */
+  const uint8_t* curr_mask; /* [max_actions], 1 = unavailable (:247-251)           */
+  const float* next_avail;
+  const uint8_t* next_mask;
+  const float* cost;        /* one float                                           */
+  uint8_t terminated;
+  uint8_t truncated;
+} pa_transition;
+
+/* n transitions as host column pointers (batched ingest). */
+typedef struct pa_columns {
+  const float* state;       /* [n, state_dim]   */
+  const void* action;       /* [n, action_elems] */
+  const void* reward;       /* [n]              */
+  const uint8_t* terminated;/* [n]              */
+  const uint8_t* truncated; /* [n]              */
+  const float* next_state;  /* [n, state_dim]   */
+  const float* curr_avail;  /* [n, A, avail_dim] or NULL with *_bcast=1 -> [A, avail_dim] */
+  const uint8_t* curr_mask; /* [n, A]                                                      */
+  const float* next_avail;
+  const uint8_t* next_mask;
+  const float* cost;        /* [n]              */
+  int32_t avail_bcast;      /* 1: the four avail/mask pointers hold ONE row shared by all n */
+} pa_columns;
+
+/* Device pointers the gather writes (torch-allocated by the caller).  Any
+ * member may be NULL = not wanted.  Shapes are the TransitionBatch contract of
+ * pearl/replay_buffers/transition.py:89-132. */
+typedef struct pa_batch_out {
+  float* state;             /* [B, state_dim]                                            */
+  void* action;             /* [B, action_elems] action_dtype                            */
+  void* reward;             /* [B] reward_dtype                                          */
+  uint8_t* terminated;      /* [B]                                                       */
+  uint8_t* truncated;       /* [B]                                                       */
+  float* next_state;        /* [B, state_dim]                                            */
+  float* curr_avail;        /* [B, A, avail_dim]                                         */
+  uint8_t* curr_mask;       /* [B, A]                                                    */
+  float* next_avail;        /* [B, A, avail_dim]                                         */
+  uint8_t* next_mask;       /* [B, A]                                                    */
+  float* cost;              /* [B]                                                       */
+  /* Fused learner-side views (policy_learner.py:197-218 preprocess_batch folded
+   * into the gather): */
+  float* x;                 /* [B, state_dim + rep_dim]: state || rep(action)            */
+  float* next_avail_rep;    /* [B, A, rep_dim]: rep(next available actions)              */
+  float* reward_f32;        /* [B] reward converted to float32                           */
+  int32_t rep_dim;          /* representation width                                      */
+  int32_t rep_onehot;       /* 1: rep = one-hot(index) (one_hot_action_representation_module.py:27-34); 0: identity */
+} pa_batch_out;
+
+int pa_arena_create(pa_arena** out, const pa_arena_desc* desc);
+int pa_arena_destroy(pa_arena* a);
+/* TensorBasedReplayBuffer.push (:55-133) after tensorisation.  Host-side only:
+ * the row is packed into the pinned staging ring; it reaches HBM at the next
+ * pa_arena_flush (called implicitly by gather/sample). */
+int pa_arena_push(pa_arena* a, const pa_transition* t);
+int pa_arena_push_many(pa_arena* a, int64_t n, const pa_columns* cols);
+/* Device-resident ingest: columns already in HBM (same layout as pa_columns). */
+int pa_arena_push_many_device(pa_arena* a, int64_t n, const pa_columns* cols, void* stream);
+int pa_arena_flush(pa_arena* a, void* stream);
+/* len(replay_buffer) (:284-285) */
+int64_t pa_arena_len(const pa_arena* a);
+int64_t pa_arena_capacity(const pa_arena* a);
+/* slot of logical index 0 */
+int64_t pa_arena_head(const pa_arena* a);
+/* ReplayBuffer.clear (:287-288) */
+int pa_arena_clear(pa_arena* a);
+/* Parity mode of sample() (:253-282): caller supplies the B logical indices it
+ * drew with random.sample(range(len), B) (host pointer, int64).  Returns
+ * PA_ERR_VALUE if B > len.  idx_dev_scratch: device int64[B] scratch. */
+int pa_arena_gather(pa_arena* a, const int64_t* logical_idx_host, int32_t B,
+                    const pa_batch_out* out, int64_t* idx_dev_scratch, void* stream);
+/* Same with indices already on the device. */
+int pa_arena_gather_device(pa_arena* a, const int64_t* logical_idx_dev, int32_t B,
+                           const pa_batch_out* out, void* stream);
+/* Fast mode: uniform sampling WITHOUT replacement on the device (Philox4x32-10
+ * keyed by (seed, offset), rejection of duplicates in LDS).  Statistically, not
+ * bitwise, equivalent to random.sample.  idx_out_dev (int64[B], may be NULL)
+ * receives the logical indices that were drawn. */
+int pa_arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B,
+                    const pa_batch_out* out, int64_t* idx_out_dev, void* stream);
+/* Only the index draw of pa_arena_sample (for tests of the sampler). */
+int pa_sample_indices(int64_t population, uint64_t seed, uint64_t offset, int32_t B,
+                      int64_t* idx_out_dev, int32_t device, void* stream);
+
+/* OneHotActionTensorRepresentationModule.forward
+ * (one_hot_action_representation_module.py:27-34): idx[n] -> out[n, num_classes]. */
+int pa_one_hot(const void* idx_dev, int32_t idx_dtype, int64_t n, int32_t num_classes,
+               float* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* DQN learner: replaces DeepTDLearning.learn_batch / DeepQLearning           */
+/* .get_next_state_values for a VanillaQValueNetwork with two hidden layers.  */
+/* (deep_td_learning.py:269-360, deep_q_learning.py:130-167,                  */
+/*  q_value_networks.py:152-174, common/utils.py:75-152, :214-226)            */
+/* ------------------------------------------------------------------------ */
+typedef struct pa_dqn pa_dqn;
+
+typedef struct pa_dqn_desc {
+  int32_t device;
+  int32_t state_dim;   /* S                                                     */
+  int32_t action_dim;  /* AD: width of the action representation                */
+  int32_t hidden1;     /* H1                                                    */
+  int32_t hidden2;     /* H2                                                    */
+  int32_t max_batch;   /* largest B a step will see (workspace sizing)          */
+  int32_t max_actions; /* largest A a step will see                             */
+  float discount;      /* gamma (deep_td_learning.py:313-317)                   */
+  float tau;           /* soft_update_tau (common/utils.py:214-226)             */
+  double lr, beta1, beta2, eps, weight_decay; /* optim.AdamW defaults (:183-185) */
+  int32_t amsgrad;
+} pa_dqn_desc;
+
+/* Parameter storage, flat fp32.  Layout (floats), every tensor offset rounded
+ * up to 4: W1[H1, S+AD] | b1[H1] | W2[H2, H1] | b2[H2] | W3[1, H2] | b3[1].
+ * All five buffers are caller-owned (torch) so that state_dict()/compare()
+ * stay truthful (SURVEY.md §5 checkpoint row). */
+typedef struct pa_dqn_buffers {
+  float* q;        /* online parameters                                    */
+  float* q_target; /* target parameters                                    */
+  float* grad;     /* gradient of the mean-squared Bellman error           */
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* max_exp_avg_sq;
+} pa_dqn_buffers;
+
+/* One preprocessed batch (after policy_learner.py:197-218). */
+typedef struct pa_dqn_batch {
+  int32_t B;
+  int32_t A;                    /* available-action rows per transition                    */
+  const float* x;               /* [B, S+AD] state || rep(action); or NULL and use:        */
+  const float* state;           /* [B, S]                                                   */
+  const float* action_rep;      /* [B, AD]                                                  */
+  const float* reward;          /* [B] float32                                              */
+  const uint8_t* terminated;    /* [B]                                                      */
+  const float* next_state;      /* [B, S]                                                   */
+  const float* next_avail_rep;  /* [B, A, AD], or [A, AD] when next_avail_bcast             */
+  const uint8_t* next_mask;     /* [B, A] (1 = unavailable), or [A] when bcast, or NULL     */
+  int32_t next_avail_bcast;
+} pa_dqn_batch;
+
+int64_t pa_dqn_param_count(int32_t S, int32_t AD, int32_t H1, int32_t H2);
+/* offsets[6] of W1,b1,W2,b2,W3,b3 inside the flat buffer */
+int pa_dqn_param_offsets(int32_t S, int32_t AD, int32_t H1, int32_t H2, int64_t* offsets6);
+
+int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc);
+int pa_dqn_destroy(pa_dqn* h);
+int pa_dqn_bind(pa_dqn* h, const pa_dqn_buffers* bufs);
+
+/* Parity probe: Q(s,a) of the online net (q_out[B]), max_a' Q_target(s',a')
+ * (next_v_out[B]) and the Bellman target (target_out[B]).  Any output may be NULL. */
+int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out, float* next_v_out,
+                   float* target_out, void* stream);
+
+/* update_target_network (common/utils.py:214-226): theta' <- tau*theta + (1-tau)*theta'. */
+int pa_dqn_update_target(pa_dqn* h, void* stream);
+
+/* DeepTDLearning.learn_batch (:333-360) for one batch: optional target soft
+ * update first (forward(), :283-284), forward, loss, backward, AdamW step.
+ * adam_step is the 1-based optimizer step this call performs.  grad_world > 1:
+ * stop after the backward (gradients in bufs.grad, scaled by 1/grad_world) so
+ * the caller can all-reduce them; then call pa_dqn_apply.
+ * mean_abs_td_out: device float; receives mean |Q - target| (:358-359). */
+int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_target_update,
+                int64_t adam_step, int32_t grad_world, float* mean_abs_td_out, void* stream);
+/* AdamW(amsgrad) on bufs.grad (torch/optim/adam.py _single_tensor_adam). */
+int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream);
+
+/* PolicyLearner.learn (policy_learner.py:162-195) fused: `rounds` iterations of
+ * device-side sample -> gather(+one-hot) -> learn_batch on the arena, sampling
+ * on a side stream one step ahead.  training_steps0 / adam_step0: counters
+ * before the call.  losses_out: device float[rounds]. */
+typedef struct pa_learn_args {
+  int32_t rounds;
+  int32_t batch_size;
+  int32_t rep_onehot;          /* action representation: 1 one-hot, 0 identity          */
+  int32_t target_update_freq;
+  int64_t training_steps0;
+  int64_t adam_step0;
+  uint64_t seed;               /* Philox key                                            */
+  uint64_t offset0;            /* Philox counter base (advance by `rounds` per call)    */
+  float* losses_out;
+  const int64_t* idx_host;     /* optional parity mode: [rounds, batch_size] logical indices */
+} pa_learn_args;
+int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream);
+
+/* Kernel timing of the last pa_dqn_learn / pa_dqn_step when timing is enabled
+ * (HIP events on the launch stream; used by bench.py's roofline block). */
+int pa_dqn_enable_timing(pa_dqn* h, int32_t on);
+/* names: "gather","target","online_fwd","head","backward","adamw" -> avg ms, count */
+int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PEARL_AMD_H */

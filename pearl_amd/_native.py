@@ -1,0 +1,293 @@
+"""ctypes binding of libpearl_amd.so (the C ABI declared in include/pearl_amd.h).
+
+The library is the product: there is NO CPU or PyTorch fallback.  Loading fails
+loudly if the shared object is missing, and every compute entry point fails
+loudly (``NativeError``) when no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpearl_amd.so")
+
+# pa_status
+PA_OK = 0
+PA_ERR_INVALID = -1
+PA_ERR_VALUE = -2
+PA_ERR_HIP = -3
+PA_ERR_UNSUPPORTED = -4
+PA_ERR_NOMEM = -5
+
+# pa_dtype
+PA_F32, PA_I64, PA_I32, PA_U8, PA_F64 = 0, 1, 2, 3, 4
+
+_TORCH_TO_PA = {
+    torch.float32: PA_F32,
+    torch.int64: PA_I64,
+    torch.int32: PA_I32,
+    torch.uint8: PA_U8,
+    torch.bool: PA_U8,
+    torch.float64: PA_F64,
+}
+_PA_TO_TORCH = {PA_F32: torch.float32, PA_I64: torch.int64, PA_I32: torch.int32,
+                PA_U8: torch.uint8, PA_F64: torch.float64}
+
+
+class NativeError(RuntimeError):
+    """libpearl_amd reported a failure that has no reference-side exception type."""
+
+
+def pa_dtype_of(dt: torch.dtype) -> int:
+    try:
+        return _TORCH_TO_PA[dt]
+    except KeyError:
+        raise TypeError(f"pearl_amd: unsupported dtype {dt}") from None
+
+
+def torch_dtype_of(pa: int) -> torch.dtype:
+    return _PA_TO_TORCH[pa]
+
+
+class ArenaDesc(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int64),
+        ("device", C.c_int32),
+        ("state_dim", C.c_int32),
+        ("action_elems", C.c_int32),
+        ("action_dtype", C.c_int32),
+        ("reward_dtype", C.c_int32),
+        ("max_actions", C.c_int32),
+        ("avail_dim", C.c_int32),
+        ("has_next_state", C.c_int32),
+        ("has_cost", C.c_int32),
+        ("staging_rows", C.c_int64),
+    ]
+
+
+class Transition(C.Structure):
+    _fields_ = [
+        ("state", C.c_void_p),
+        ("action", C.c_void_p),
+        ("reward", C.c_void_p),
+        ("next_state", C.c_void_p),
+        ("curr_avail", C.c_void_p),
+        ("curr_mask", C.c_void_p),
+        ("next_avail", C.c_void_p),
+        ("next_mask", C.c_void_p),
+        ("cost", C.c_void_p),
+        ("terminated", C.c_uint8),
+        ("truncated", C.c_uint8),
+    ]
+
+
+class Columns(C.Structure):
+    _fields_ = [
+        ("state", C.c_void_p),
+        ("action", C.c_void_p),
+        ("reward", C.c_void_p),
+        ("terminated", C.c_void_p),
+        ("truncated", C.c_void_p),
+        ("next_state", C.c_void_p),
+        ("curr_avail", C.c_void_p),
+        ("curr_mask", C.c_void_p),
+        ("next_avail", C.c_void_p),
+        ("next_mask", C.c_void_p),
+        ("cost", C.c_void_p),
+        ("avail_bcast", C.c_int32),
+    ]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [
+        ("state", C.c_void_p),
+        ("action", C.c_void_p),
+        ("reward", C.c_void_p),
+        ("terminated", C.c_void_p),
+        ("truncated", C.c_void_p),
+        ("next_state", C.c_void_p),
+        ("curr_avail", C.c_void_p),
+        ("curr_mask", C.c_void_p),
+        ("next_avail", C.c_void_p),
+        ("next_mask", C.c_void_p),
+        ("cost", C.c_void_p),
+        ("x", C.c_void_p),
+        ("next_avail_rep", C.c_void_p),
+        ("reward_f32", C.c_void_p),
+        ("rep_dim", C.c_int32),
+        ("rep_onehot", C.c_int32),
+    ]
+
+
+class DqnDesc(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("state_dim", C.c_int32),
+        ("action_dim", C.c_int32),
+        ("hidden1", C.c_int32),
+        ("hidden2", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("max_actions", C.c_int32),
+        ("discount", C.c_float),
+        ("tau", C.c_float),
+        ("lr", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("eps", C.c_double),
+        ("weight_decay", C.c_double),
+        ("amsgrad", C.c_int32),
+    ]
+
+
+class DqnBuffers(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p),
+        ("q_target", C.c_void_p),
+        ("grad", C.c_void_p),
+        ("exp_avg", C.c_void_p),
+        ("exp_avg_sq", C.c_void_p),
+        ("max_exp_avg_sq", C.c_void_p),
+    ]
+
+
+class DqnBatch(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32),
+        ("A", C.c_int32),
+        ("x", C.c_void_p),
+        ("state", C.c_void_p),
+        ("action_rep", C.c_void_p),
+        ("reward", C.c_void_p),
+        ("terminated", C.c_void_p),
+        ("next_state", C.c_void_p),
+        ("next_avail_rep", C.c_void_p),
+        ("next_mask", C.c_void_p),
+        ("next_avail_bcast", C.c_int32),
+    ]
+
+
+class LearnArgs(C.Structure):
+    _fields_ = [
+        ("rounds", C.c_int32),
+        ("batch_size", C.c_int32),
+        ("rep_onehot", C.c_int32),
+        ("target_update_freq", C.c_int32),
+        ("training_steps0", C.c_int64),
+        ("adam_step0", C.c_int64),
+        ("seed", C.c_uint64),
+        ("offset0", C.c_uint64),
+        ("losses_out", C.c_void_p),
+        ("idx_host", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); also the export list the CPU test suite checks
+# against include/pearl_amd.h.
+_P = C.c_void_p
+SIGNATURES = {
+    "pa_last_error": (C.c_char_p, []),
+    "pa_abi_version": (C.c_int, []),
+    "pa_device_count": (C.c_int, []),
+    "pa_arena_create": (C.c_int, [C.POINTER(_P), C.POINTER(ArenaDesc)]),
+    "pa_arena_destroy": (C.c_int, [_P]),
+    "pa_arena_push": (C.c_int, [_P, C.POINTER(Transition)]),
+    "pa_arena_push_many": (C.c_int, [_P, C.c_int64, C.POINTER(Columns)]),
+    "pa_arena_push_many_device": (C.c_int, [_P, C.c_int64, C.POINTER(Columns), _P]),
+    "pa_arena_flush": (C.c_int, [_P, _P]),
+    "pa_arena_len": (C.c_int64, [_P]),
+    "pa_arena_capacity": (C.c_int64, [_P]),
+    "pa_arena_head": (C.c_int64, [_P]),
+    "pa_arena_clear": (C.c_int, [_P]),
+    "pa_arena_gather": (C.c_int, [_P, _P, C.c_int32, C.POINTER(BatchOut), _P, _P]),
+    "pa_arena_gather_device": (C.c_int, [_P, _P, C.c_int32, C.POINTER(BatchOut), _P]),
+    "pa_arena_sample": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(BatchOut), _P, _P]),
+    "pa_sample_indices": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, _P]),
+    "pa_one_hot": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
+    "pa_dqn_param_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pa_dqn_param_offsets": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "pa_dqn_create": (C.c_int, [C.POINTER(_P), C.POINTER(DqnDesc)]),
+    "pa_dqn_destroy": (C.c_int, [_P]),
+    "pa_dqn_bind": (C.c_int, [_P, C.POINTER(DqnBuffers)]),
+    "pa_dqn_qvalues": (C.c_int, [_P, C.POINTER(DqnBatch), _P, _P, _P, _P]),
+    "pa_dqn_update_target": (C.c_int, [_P, _P]),
+    "pa_dqn_step": (C.c_int, [_P, C.POINTER(DqnBatch), C.c_int32, C.c_int64, C.c_int32, _P, _P]),
+    "pa_dqn_apply": (C.c_int, [_P, C.c_int64, _P]),
+    "pa_dqn_learn": (C.c_int, [_P, _P, C.POINTER(LearnArgs), _P]),
+    "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
+    "pa_dqn_get_timing": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libpearl_amd.so once.  Raises ImportError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"pearl_amd: {LIB_PATH} is missing. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C pearl_amd/csrc` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the replay/"
+            "learner hot path."
+        )
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    if handle.pa_abi_version() != 1:
+        raise ImportError("pearl_amd: ABI version mismatch between _native.py and libpearl_amd.so")
+    _lib = handle
+    return handle
+
+
+def last_error() -> str:
+    msg = lib().pa_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> None:
+    """Translate a pa_status into the exception the reference would raise."""
+    if rc == PA_OK:
+        return
+    msg = last_error()
+    if rc == PA_ERR_VALUE:
+        raise ValueError(msg)  # tensor_based_replay_buffer.py:271-275
+    if rc == PA_ERR_INVALID:
+        raise AssertionError(msg)
+    if rc == PA_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == PA_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise NativeError(msg)
+
+
+def device_count() -> int:
+    return int(lib().pa_device_count())
+
+
+def require_gpu() -> None:
+    if device_count() <= 0 or not torch.cuda.is_available():
+        raise NativeError(
+            "pearl_amd: no HIP device visible. The replay arena and the learner step are HIP "
+            "kernels for gfx950; there is no CPU fallback."
+        )
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Raw address of a tensor's first element (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> Optional[int]:
+    """hipStream_t of torch's current stream on `device`, as an integer."""
+    s = torch.cuda.current_stream(device).cuda_stream
+    return s if s else None

@@ -1,0 +1,105 @@
+// Shared host/device helpers for the pearl_amd HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pearl_amd.h"
+
+namespace pa {
+
+// ---- error plumbing ------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define PA_HIP(expr)                                                             \
+  do {                                                                           \
+    hipError_t _e = (expr);                                                      \
+    if (_e != hipSuccess) {                                                      \
+      ::pa::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,         \
+                      hipGetErrorString(_e));                                    \
+      return PA_ERR_HIP;                                                         \
+    }                                                                            \
+  } while (0)
+
+#define PA_REQUIRE(cond, code, ...)  \
+  do {                               \
+    if (!(cond)) {                   \
+      ::pa::set_error(__VA_ARGS__);  \
+      return (code);                 \
+    }                                \
+  } while (0)
+
+#define PA_LAUNCH_CHECK()                                                        \
+  do {                                                                           \
+    hipError_t _e = hipGetLastError();                                           \
+    if (_e != hipSuccess) {                                                      \
+      ::pa::set_error("%s:%d: kernel launch failed: %s", __FILE__, __LINE__,     \
+                      hipGetErrorString(_e));                                    \
+      return PA_ERR_HIP;                                                         \
+    }                                                                            \
+  } while (0)
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return ceil_div(a, b) * b; }
+
+static inline int dtype_size(int dt) {
+  switch (dt) {
+    case PA_F32: return 4;
+    case PA_I64: return 8;
+    case PA_I32: return 4;
+    case PA_U8: return 1;
+    case PA_F64: return 8;
+    default: return 0;
+  }
+}
+
+// ---- arena internals shared between arena.hip and dqn.hip -----------------
+struct ArenaCols {
+  // device SoA columns (ring of `capacity` slots)
+  float* state;
+  uint8_t* action;  // action_elems * action_size bytes per slot
+  uint8_t* reward;  // reward_size bytes per slot
+  uint8_t* terminated;
+  uint8_t* truncated;
+  float* next_state;
+  float* curr_avail;
+  uint8_t* curr_mask;
+  float* next_avail;
+  uint8_t* next_mask;
+  float* cost;
+};
+
+}  // namespace pa
+
+struct pa_arena {
+  pa_arena_desc d;
+  pa::ArenaCols c;
+  int64_t head;     // slot of the oldest transition
+  int64_t size;     // transitions visible to sample (includes staged rows)
+  int action_size;  // bytes per action element
+  int reward_size;
+  // pinned staging ring (AoS rows) + device mirror
+  int64_t row_bytes;       // packed bytes per staged row
+  int64_t off_state, off_action, off_reward, off_term, off_trunc, off_next_state,
+      off_curr_avail, off_curr_mask, off_next_avail, off_next_mask, off_cost;
+  uint8_t* stage_host;     // pinned
+  uint8_t* stage_dev;
+  int64_t stage_rows;      // capacity of the staging ring (rows)
+  int64_t staged;          // rows waiting for a flush
+  int64_t stage_slot0;     // arena slot of the first staged row
+  hipEvent_t stage_done;   // recorded after the last ingest (H2D copy + scatter)
+  bool stage_busy;         // the pinned ring may still be read by that copy
+  hipStream_t ingest_stream;  // stream of the last ingest
+  bool has_ingest;
+};
+
+namespace pa {
+// Enqueue sample/gather into `out` (used by pa_dqn_learn).  Implemented in arena.hip.
+int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa_batch_out* out,
+                        hipStream_t s);
+int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const pa_batch_out* out,
+                 int64_t* idx_out_dev, hipStream_t s);
+// Make stream `s` wait for the last ingest if that ran on another stream.
+int arena_wait_ingest(pa_arena* a, hipStream_t s);
+}  // namespace pa

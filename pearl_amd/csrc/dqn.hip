@@ -1,0 +1,701 @@
+// Host orchestration of the DQN learner step: workspaces, launch sequence,
+// the fused learn() loop with the sampler one step ahead on a side stream, and
+// HIP-event kernel timers for bench.py's roofline block.
+//
+// Reference call stack being replaced:
+//   PolicyLearner.learn            pearl/policy_learners/policy_learner.py:162-195
+//   DeepTDLearning.learn_batch     .../sequential_decision_making/deep_td_learning.py:333-360
+//   DeepTDLearning.forward / loss  deep_td_learning.py:269-331
+//   DeepQLearning.get_next_state_values  deep_q_learning.py:130-167
+#include <math.h>
+
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dqn_kernels.hpp"
+
+using namespace pa;
+
+namespace {
+
+struct Timer {
+  std::string name;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+};
+
+constexpr size_t kMaxTimedPairs = 8192;
+
+}  // namespace
+
+struct pa_dqn {
+  pa_dqn_desc d;
+  pa_dqn_buffers bufs;
+  bool bound;
+  int64_t P;         // flat parameter count (with alignment gaps)
+  int64_t off[6];    // W1,b1,W2,b2,W3,b3
+  int IN;            // S + AD
+  // workspaces (HBM)
+  float *U, *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *slab, *xpack, *loss_scratch;
+  int nslab_max;
+  // fused learn(): double-buffered batch + streams/events
+  struct BatchBuf {
+    float* x;
+    float* next_state;
+    float* next_avail_rep;
+    uint8_t* next_mask;
+    float* reward;
+    uint8_t* term;
+    int64_t* idx;
+    hipEvent_t ready, consumed;
+    bool used;
+  } bb[2];
+  int bb_A;  // A the batch buffers were sized for
+  hipStream_t side;
+  hipEvent_t fork;
+  // timing
+  bool timing;
+  std::vector<Timer> timers;
+};
+
+namespace {
+
+int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+void param_layout(int S, int AD, int H1, int H2, int64_t off[6], int64_t* total) {
+  int64_t o = 0;
+  off[0] = o; o = align4(o + (int64_t)H1 * (S + AD));
+  off[1] = o; o = align4(o + H1);
+  off[2] = o; o = align4(o + (int64_t)H2 * H1);
+  off[3] = o; o = align4(o + H2);
+  off[4] = o; o = align4(o + H2);
+  off[5] = o; o = align4(o + 1);
+  *total = o;
+}
+
+Timer* find_timer(pa_dqn* h, const char* name) {
+  for (auto& t : h->timers)
+    if (t.name == name) return &t;
+  h->timers.push_back(Timer());
+  h->timers.back().name = name;
+  return &h->timers.back();
+}
+
+struct ScopedTimer {
+  pa_dqn* h;
+  Timer* t;
+  hipStream_t s;
+  bool active;
+  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_) : h(h_), t(nullptr), s(s_), active(false) {
+    if (!h->timing) return;
+    t = find_timer(h, name);
+    if (t->used + 2 > 2 * kMaxTimedPairs) return;
+    while (t->ev.size() < t->used + 2) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return;
+      t->ev.push_back(e);
+    }
+    (void)hipEventRecord(t->ev[t->used], s);
+    active = true;
+  }
+  ~ScopedTimer() {
+    if (!active) return;
+    (void)hipEventRecord(t->ev[t->used + 1], s);
+    t->used += 2;
+  }
+};
+
+template <typename K>
+int set_max_smem(K kernel, size_t bytes) {
+  PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  return PA_OK;
+}
+
+template <bool B_KS, int EPI>
+int launch_linear(const GemmArgs& g, hipStream_t s) {
+  constexpr int KW = 4;
+  static bool configured = false;
+  auto kern = linear_kernel<B_KS, EPI, KW>;
+  const size_t smem = linear_smem_bytes<B_KS, KW>();
+  if (!configured) {
+    int rc = set_max_smem(kern, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  dim3 grid((unsigned)ceil_div(g.N, G_BN), (unsigned)ceil_div(g.M, G_BM));
+  hipLaunchKernelGGL(kern, grid, dim3(128 * KW), smem, s, g);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+template <int TN1, int TN2>
+int launch_target_t(const TargetArgs& a, hipStream_t s) {
+  static bool configured = false;
+  auto kern = target_fused_kernel<TN1, TN2>;
+  const size_t smem = target_smem_bytes<TN1, TN2>();
+  if (!configured) {
+    int rc = set_max_smem(kern, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  const unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+int launch_target(const TargetArgs& a, hipStream_t s) {
+  const int tn1 = a.H1 <= 128 ? 1 : 2, tn2 = a.H2 <= 128 ? 1 : 2;
+  if (tn1 == 1 && tn2 == 1) return launch_target_t<1, 1>(a, s);
+  if (tn1 == 1 && tn2 == 2) return launch_target_t<1, 2>(a, s);
+  if (tn1 == 2 && tn2 == 1) return launch_target_t<2, 1>(a, s);
+  return launch_target_t<2, 2>(a, s);
+}
+
+struct NetPtrs {
+  const float *W1, *b1, *W2, *b2, *W3, *b3;
+};
+NetPtrs net_ptrs(const pa_dqn* h, const float* base) {
+  NetPtrs n;
+  n.W1 = base + h->off[0]; n.b1 = base + h->off[1]; n.W2 = base + h->off[2];
+  n.b2 = base + h->off[3]; n.W3 = base + h->off[4]; n.b3 = base + h->off[5];
+  return n;
+}
+
+int check_batch(const pa_dqn* h, const pa_dqn_batch* b) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
+  PA_REQUIRE(b, PA_ERR_INVALID, "null batch");
+  PA_REQUIRE(b->B > 0 && b->B <= h->d.max_batch, PA_ERR_INVALID,
+             "batch size %d outside (0, max_batch=%d]", b->B, h->d.max_batch);
+  PA_REQUIRE(b->A > 0 && b->A <= h->d.max_actions && b->A <= T_ROWS, PA_ERR_UNSUPPORTED,
+             "available-action count %d outside (0, min(max_actions=%d, %d)]", b->A,
+             h->d.max_actions, T_ROWS);
+  PA_REQUIRE(b->x || (b->state && b->action_rep), PA_ERR_INVALID,
+             "batch needs x or (state, action_rep)");
+  PA_REQUIRE(b->next_state && b->next_avail_rep && b->reward && b->terminated, PA_ERR_INVALID,
+             "batch needs next_state, next_avail_rep, reward, terminated");
+  return PA_OK;
+}
+
+// x operand of the online net: either supplied, or packed from (state, action_rep).
+int resolve_x(pa_dqn* h, const pa_dqn_batch* b, const float** x, hipStream_t s) {
+  if (b->x) {
+    *x = b->x;
+    return PA_OK;
+  }
+  const int64_t total = (int64_t)b->B * h->IN;
+  unsigned grid = (unsigned)(ceil_div(total, 256) > 1024 ? 1024 : ceil_div(total, 256));
+  hipLaunchKernelGGL(pack_x_kernel, dim3(grid), dim3(256), 0, s, b->state, b->action_rep,
+                     h->xpack, b->B, h->d.state_dim, h->d.action_dim);
+  PA_LAUNCH_CHECK();
+  *x = h->xpack;
+  return PA_OK;
+}
+
+// max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
+// deep_td_learning.py:313-317)
+int run_target(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const NetPtrs t = net_ptrs(h, h->bufs.q_target);
+  int rc;
+  {
+    ScopedTimer tm(h, "target_l1", s);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = b->next_state; g.lda = d.state_dim;
+    g.Bm = t.W1; g.ldb = h->IN;
+    g.C = h->U; g.ldc = d.hidden1;
+    g.bias = t.b1;
+    g.M = b->B; g.N = d.hidden1; g.K = d.state_dim;
+    rc = launch_linear<false, EPI_BIAS>(g, s);
+    if (rc != PA_OK) return rc;
+  }
+  {
+    ScopedTimer tm(h, "target", s);
+    TargetArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = h->U; a.ldu = d.hidden1;
+    a.feat = b->next_avail_rep;
+    a.feat_bstride = b->next_avail_bcast ? 0 : (int64_t)b->A * d.action_dim;
+    a.mask = b->next_mask;
+    a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
+    a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
+    a.W2 = t.W2; a.ldw2 = d.hidden1;
+    a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
+    a.reward = b->reward; a.term = b->terminated;
+    a.gamma = d.discount;
+    a.next_v = next_v; a.y = y;
+    a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
+    a.bpw = T_ROWS / b->A;
+    rc = launch_target(a, s);
+    if (rc != PA_OK) return rc;
+  }
+  return PA_OK;
+}
+
+// online forward: H1a = relu(x W1^T + b1), H2a = relu(H1a W2^T + b2)
+int run_online_fwd(pa_dqn* h, const float* x, int B, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const NetPtrs q = net_ptrs(h, h->bufs.q);
+  ScopedTimer tm(h, "online_fwd", s);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = x; g.lda = h->IN;
+  g.Bm = q.W1; g.ldb = h->IN;
+  g.C = h->H1a; g.ldc = d.hidden1;
+  g.bias = q.b1;
+  g.M = B; g.N = d.hidden1; g.K = h->IN;
+  int rc = launch_linear<false, EPI_BIAS_RELU>(g, s);
+  if (rc != PA_OK) return rc;
+  g.A = h->H1a; g.lda = d.hidden1;
+  g.Bm = q.W2; g.ldb = d.hidden1;
+  g.C = h->H2a; g.ldc = d.hidden2;
+  g.bias = q.b2;
+  g.M = B; g.N = d.hidden2; g.K = d.hidden1;
+  return launch_linear<false, EPI_BIAS_RELU>(g, s);
+}
+
+int run_head(pa_dqn* h, int B, const float* y, float* q_out, bool backward, int world,
+             hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const NetPtrs q = net_ptrs(h, h->bufs.q);
+  ScopedTimer tm(h, "head", s);
+  HeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H2a = h->H2a; a.ldh = d.hidden2;
+  a.w3 = q.W3; a.b3 = q.b3;
+  a.y = y;
+  a.q_out = q_out;
+  a.dZ2 = backward ? h->dZ2 : nullptr; a.ldz = d.hidden2;
+  a.slab = backward ? h->slab : nullptr;
+  a.norm = (float)(2.0 / ((double)B * (double)world));
+  a.B = B; a.H2 = d.hidden2;
+  hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)ceil_div(B, HEAD_ROWS)), dim3(256), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+int run_backward(pa_dqn* h, const float* x, int B, float* loss_out, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const NetPtrs q = net_ptrs(h, h->bufs.q);
+  float* G = h->bufs.grad;
+  ScopedTimer tm(h, "backward", s);
+  // dZ1 = (dZ2 W2) * [H1a > 0]
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = h->dZ2; g.lda = d.hidden2;
+  g.Bm = q.W2; g.ldb = d.hidden1;
+  g.C = h->dZ1; g.ldc = d.hidden1;
+  g.Hmask = h->H1a; g.ldh = d.hidden1;
+  g.M = B; g.N = d.hidden1; g.K = d.hidden2;
+  int rc = launch_linear<true, EPI_MASK>(g, s);
+  if (rc != PA_OK) return rc;
+  DwArgs a;
+  memset(&a, 0, sizeof(a));
+  // dW2 = dZ2^T H1a, db2
+  a.p[0].dZ = h->dZ2; a.p[0].ldz = d.hidden2;
+  a.p[0].X = h->H1a; a.p[0].ldx = d.hidden1;
+  a.p[0].dW = G + h->off[2]; a.p[0].ldw = d.hidden1;
+  a.p[0].db = G + h->off[3];
+  a.p[0].M = d.hidden2; a.p[0].N = d.hidden1;
+  a.p[0].tiles_n = (int)ceil_div(d.hidden1, 32);
+  a.p[0].tile0 = 0;
+  const int t0 = (int)ceil_div(d.hidden2, 32) * a.p[0].tiles_n;
+  // dW1 = dZ1^T x, db1
+  a.p[1].dZ = h->dZ1; a.p[1].ldz = d.hidden1;
+  a.p[1].X = x; a.p[1].ldx = h->IN;
+  a.p[1].dW = G + h->off[0]; a.p[1].ldw = h->IN;
+  a.p[1].db = G + h->off[1];
+  a.p[1].M = d.hidden1; a.p[1].N = h->IN;
+  a.p[1].tiles_n = (int)ceil_div(h->IN, 32);
+  a.p[1].tile0 = t0;
+  a.total_tiles = t0 + (int)ceil_div(d.hidden1, 32) * a.p[1].tiles_n;
+  a.B = B;
+  a.slab = h->slab; a.nslab = (int)ceil_div(B, HEAD_ROWS); a.H2 = d.hidden2;
+  a.dW3 = G + h->off[4]; a.db3 = G + h->off[5];
+  a.loss_out = loss_out;
+  a.inv_B = (float)(1.0 / (double)B);
+  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles + 1), dim3(512), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+int run_adamw(pa_dqn* h, int64_t step, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)", (long long)step);
+  ScopedTimer tm(h, "adamw", s);
+  AdamArgs a;
+  a.p = h->bufs.q; a.g = h->bufs.grad; a.m = h->bufs.exp_avg; a.v = h->bufs.exp_avg_sq;
+  a.vmax = h->bufs.max_exp_avg_sq;
+  a.n = h->P;
+  // python-float (double) scalars exactly as _single_tensor_adam forms them
+  const double bc1 = 1.0 - pow(d.beta1, (double)step);
+  const double bc2 = 1.0 - pow(d.beta2, (double)step);
+  a.decay = (float)(1.0 - d.lr * d.weight_decay);
+  a.w1 = (float)(1.0 - d.beta1);
+  a.beta2 = (float)d.beta2;
+  a.omb2 = (float)(1.0 - d.beta2);
+  a.bc2_sqrt = (float)sqrt(bc2);
+  a.neg_step = (float)(-(d.lr / bc1));
+  a.eps = (float)d.eps;
+  a.amsgrad = d.amsgrad;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+int run_soft_update(pa_dqn* h, hipStream_t s) {
+  ScopedTimer tm(h, "soft_update", s);
+  hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s,
+                     h->bufs.q_target, h->bufs.q, h->P, h->d.tau, (float)(1.0 - (double)h->d.tau));
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_t adam_step,
+              int grad_world, float* loss_out, hipStream_t s) {
+  int rc = check_batch(h, batch);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(grad_world >= 1, PA_ERR_INVALID, "grad_world must be >= 1");
+  if (do_target_update) {
+    rc = run_soft_update(h, s);
+    if (rc != PA_OK) return rc;
+  }
+  const float* x = nullptr;
+  rc = resolve_x(h, batch, &x, s);
+  if (rc != PA_OK) return rc;
+  rc = run_target(h, batch, h->nextv, h->y, s);
+  if (rc != PA_OK) return rc;
+  rc = run_online_fwd(h, x, batch->B, s);
+  if (rc != PA_OK) return rc;
+  rc = run_head(h, batch->B, h->y, h->qbuf, true, grad_world, s);
+  if (rc != PA_OK) return rc;
+  rc = run_backward(h, x, batch->B, loss_out ? loss_out : h->loss_scratch, s);
+  if (rc != PA_OK) return rc;
+  if (grad_world == 1) {
+    rc = run_adamw(h, adam_step, s);
+    if (rc != PA_OK) return rc;
+  }
+  return PA_OK;
+}
+
+void free_batchbufs(pa_dqn* h) {
+  for (int i = 0; i < 2; ++i) {
+    void* ptrs[] = {h->bb[i].x, h->bb[i].next_state, h->bb[i].next_avail_rep, h->bb[i].next_mask,
+                    h->bb[i].reward, h->bb[i].term, h->bb[i].idx};
+    for (void* p : ptrs)
+      if (p) (void)hipFree(p);
+    h->bb[i].x = nullptr; h->bb[i].next_state = nullptr; h->bb[i].next_avail_rep = nullptr;
+    h->bb[i].next_mask = nullptr; h->bb[i].reward = nullptr; h->bb[i].term = nullptr;
+    h->bb[i].idx = nullptr;
+  }
+  h->bb_A = 0;
+}
+
+int ensure_batchbufs(pa_dqn* h, int A) {
+  if (h->bb_A >= A && h->bb[0].x) return PA_OK;
+  free_batchbufs(h);
+  const pa_dqn_desc& d = h->d;
+  const int64_t B = d.max_batch;
+  for (int i = 0; i < 2; ++i) {
+    PA_HIP(hipMalloc((void**)&h->bb[i].x, (size_t)(B * h->IN * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[i].next_state, (size_t)(B * d.state_dim * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[i].next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[i].next_mask, (size_t)(B * A)));
+    PA_HIP(hipMalloc((void**)&h->bb[i].reward, (size_t)(B * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[i].term, (size_t)B));
+    PA_HIP(hipMalloc((void**)&h->bb[i].idx, (size_t)(B * 8)));
+  }
+  h->bb_A = A;
+  return PA_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t pa_dqn_param_count(int32_t S, int32_t AD, int32_t H1, int32_t H2) {
+  int64_t off[6], total;
+  param_layout(S, AD, H1, H2, off, &total);
+  return total;
+}
+
+extern "C" int pa_dqn_param_offsets(int32_t S, int32_t AD, int32_t H1, int32_t H2,
+                                    int64_t* offsets6) {
+  PA_REQUIRE(offsets6, PA_ERR_INVALID, "null output");
+  int64_t total;
+  param_layout(S, AD, H1, H2, offsets6, &total);
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
+  PA_REQUIRE(out && desc, PA_ERR_INVALID, "pa_dqn_create: null argument");
+  PA_REQUIRE(desc->state_dim > 0 && desc->action_dim > 0 && desc->hidden1 > 0 && desc->hidden2 > 0,
+             PA_ERR_INVALID, "dimensions must be positive");
+  PA_REQUIRE(desc->hidden1 <= 256 && desc->hidden2 <= 256, PA_ERR_UNSUPPORTED,
+             "hidden sizes above 256 are not built (got [%d, %d]); the fused target kernel keeps "
+             "a 64 x H1 tile and all H2 columns on one CU",
+             desc->hidden1, desc->hidden2);
+  PA_REQUIRE(desc->max_batch > 0 && desc->max_actions > 0, PA_ERR_INVALID,
+             "max_batch / max_actions must be positive");
+  const int ndev = pa_device_count();
+  PA_REQUIRE(desc->device >= 0 && desc->device < ndev, PA_ERR_HIP,
+             "HIP device %d not available (%d visible): the learner step is HIP-only and has no "
+             "CPU fallback",
+             desc->device, ndev);
+  PA_HIP(hipSetDevice(desc->device));
+  pa_dqn* h = new (std::nothrow) pa_dqn();
+  PA_REQUIRE(h, PA_ERR_NOMEM, "out of host memory");
+  h->d = *desc;
+  h->bound = false;
+  memset(&h->bufs, 0, sizeof(h->bufs));
+  h->IN = desc->state_dim + desc->action_dim;
+  param_layout(desc->state_dim, desc->action_dim, desc->hidden1, desc->hidden2, h->off, &h->P);
+  h->timing = false;
+  h->bb_A = 0;
+  memset(h->bb, 0, sizeof(h->bb));
+  h->side = nullptr;
+  h->fork = nullptr;
+  h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->slab = h->xpack =
+      h->loss_scratch = nullptr;
+  const int64_t B = desc->max_batch;
+  h->nslab_max = (int)ceil_div(B, HEAD_ROWS);
+#define PA_WS(ptr, floats)                                                       \
+  do {                                                                           \
+    hipError_t _e = hipMalloc((void**)&(ptr), (size_t)((floats) * 4));           \
+    if (_e != hipSuccess) {                                                      \
+      set_error("hipMalloc(workspace) failed: %s", hipGetErrorString(_e));       \
+      pa_dqn_destroy(h);                                                         \
+      return PA_ERR_NOMEM;                                                       \
+    }                                                                            \
+  } while (0)
+  PA_WS(h->U, B * desc->hidden1);
+  PA_WS(h->H1a, B * desc->hidden1);
+  PA_WS(h->H2a, B * desc->hidden2);
+  PA_WS(h->dZ2, B * desc->hidden2);
+  PA_WS(h->dZ1, B * desc->hidden1);
+  PA_WS(h->y, B);
+  PA_WS(h->nextv, B);
+  PA_WS(h->qbuf, B);
+  PA_WS(h->slab, (int64_t)h->nslab_max * (desc->hidden2 + 2));
+  PA_WS(h->xpack, B * h->IN);
+  PA_WS(h->loss_scratch, 4);
+#undef PA_WS
+  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess) {
+    set_error("stream/event creation failed");
+    pa_dqn_destroy(h);
+    return PA_ERR_HIP;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (hipEventCreateWithFlags(&h->bb[i].ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->bb[i].consumed, hipEventDisableTiming) != hipSuccess) {
+      set_error("event creation failed");
+      pa_dqn_destroy(h);
+      return PA_ERR_HIP;
+    }
+  }
+  *out = h;
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_destroy(pa_dqn* h) {
+  if (!h) return PA_OK;
+  (void)hipSetDevice(h->d.device);
+  (void)hipDeviceSynchronize();
+  void* ptrs[] = {h->U, h->H1a, h->H2a, h->dZ2, h->dZ1, h->y, h->nextv, h->qbuf, h->slab,
+                  h->xpack, h->loss_scratch};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  free_batchbufs(h);
+  for (int i = 0; i < 2; ++i) {
+    if (h->bb[i].ready) (void)hipEventDestroy(h->bb[i].ready);
+    if (h->bb[i].consumed) (void)hipEventDestroy(h->bb[i].consumed);
+  }
+  if (h->fork) (void)hipEventDestroy(h->fork);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  for (auto& t : h->timers)
+    for (auto e : t.ev) (void)hipEventDestroy(e);
+  delete h;
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_bind(pa_dqn* h, const pa_dqn_buffers* bufs) {
+  PA_REQUIRE(h && bufs, PA_ERR_INVALID, "pa_dqn_bind: null argument");
+  PA_REQUIRE(bufs->q && bufs->q_target && bufs->grad && bufs->exp_avg && bufs->exp_avg_sq,
+             PA_ERR_INVALID, "pa_dqn_bind: null buffer");
+  PA_REQUIRE(!h->d.amsgrad || bufs->max_exp_avg_sq, PA_ERR_INVALID,
+             "amsgrad needs max_exp_avg_sq");
+  const float* all[] = {bufs->q, bufs->q_target, bufs->grad, bufs->exp_avg, bufs->exp_avg_sq};
+  for (const float* p : all)
+    PA_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, PA_ERR_INVALID,
+               "flat buffers must be 16-byte aligned");
+  h->bufs = *bufs;
+  h->bound = true;
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out,
+                              float* next_v_out, float* target_out, void* stream) {
+  int rc = check_batch(h, batch);
+  if (rc != PA_OK) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(h->d.device));
+  if (next_v_out || target_out) {
+    rc = run_target(h, batch, next_v_out, target_out, s);
+    if (rc != PA_OK) return rc;
+  }
+  if (q_out) {
+    const float* x = nullptr;
+    rc = resolve_x(h, batch, &x, s);
+    if (rc != PA_OK) return rc;
+    rc = run_online_fwd(h, x, batch->B, s);
+    if (rc != PA_OK) return rc;
+    rc = run_head(h, batch->B, nullptr, q_out, false, 1, s);
+    if (rc != PA_OK) return rc;
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_update_target(pa_dqn* h, void* stream) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
+  PA_HIP(hipSetDevice(h->d.device));
+  return run_soft_update(h, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_target_update,
+                           int64_t adam_step, int32_t grad_world, float* mean_abs_td_out,
+                           void* stream) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  PA_HIP(hipSetDevice(h->d.device));
+  ScopedTimer tm(h, "step", reinterpret_cast<hipStream_t>(stream));
+  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out,
+                   reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
+  PA_HIP(hipSetDevice(h->d.device));
+  return run_adamw(h, adam_step, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
+  PA_REQUIRE(arena && args, PA_ERR_INVALID, "pa_dqn_learn: null argument");
+  const pa_dqn_desc& d = h->d;
+  const int B = args->batch_size;
+  const int A = arena->d.max_actions;
+  PA_REQUIRE(args->rounds >= 0, PA_ERR_INVALID, "negative rounds");
+  PA_REQUIRE(B > 0 && B <= d.max_batch, PA_ERR_INVALID, "batch size %d outside (0, %d]", B,
+             d.max_batch);
+  PA_REQUIRE((int64_t)B <= arena->size, PA_ERR_VALUE,
+             "Can't get a batch of size %d from a replay buffer with only %lld elements", B,
+             (long long)arena->size);
+  PA_REQUIRE(A > 0 && A <= d.max_actions && A <= T_ROWS, PA_ERR_UNSUPPORTED,
+             "arena max_actions %d outside (0, min(%d, %d)]", A, d.max_actions, T_ROWS);
+  PA_REQUIRE(arena->d.state_dim == d.state_dim, PA_ERR_INVALID, "state_dim mismatch: %d vs %d",
+             arena->d.state_dim, d.state_dim);
+  PA_REQUIRE(arena->d.has_next_state, PA_ERR_INVALID, "arena stores no next_state");
+  PA_REQUIRE(arena->d.device == d.device, PA_ERR_INVALID, "arena and learner on different devices");
+  PA_REQUIRE(args->target_update_freq > 0, PA_ERR_INVALID, "target_update_freq must be positive");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(d.device));
+  int rc = ensure_batchbufs(h, A);
+  if (rc != PA_OK) return rc;
+  rc = pa_arena_flush(arena, stream);
+  if (rc != PA_OK) return rc;
+  if (args->rounds == 0) return PA_OK;
+  ScopedTimer tm_all(h, "learn", s);
+  // fork: the side stream starts after everything already queued on `s`
+  PA_HIP(hipEventRecord(h->fork, s));
+  PA_HIP(hipStreamWaitEvent(h->side, h->fork, 0));
+  h->bb[0].used = h->bb[1].used = false;
+
+  auto issue_sample = [&](int r) -> int {
+    pa_dqn::BatchBuf& bb = h->bb[r & 1];
+    if (bb.used) PA_HIP(hipStreamWaitEvent(h->side, bb.consumed, 0));
+    pa_batch_out o;
+    memset(&o, 0, sizeof(o));
+    o.x = bb.x;
+    o.next_state = bb.next_state;
+    o.next_avail_rep = bb.next_avail_rep;
+    o.next_mask = bb.next_mask;
+    o.reward_f32 = bb.reward;
+    o.terminated = bb.term;
+    o.rep_dim = d.action_dim;
+    o.rep_onehot = args->rep_onehot;
+    int rc2;
+    {
+      ScopedTimer tm(h, "gather", h->side);
+      if (args->idx_host) {
+        PA_HIP(hipMemcpyAsync(bb.idx, args->idx_host + (int64_t)r * B, (size_t)B * 8,
+                              hipMemcpyHostToDevice, h->side));
+        rc2 = arena_gather_device(arena, bb.idx, B, &o, h->side);
+      } else {
+        rc2 = arena_sample(arena, args->seed, args->offset0 + (uint64_t)r, B, &o, bb.idx, h->side);
+      }
+    }
+    if (rc2 != PA_OK) return rc2;
+    PA_HIP(hipEventRecord(bb.ready, h->side));
+    return PA_OK;
+  };
+
+  rc = issue_sample(0);
+  if (rc != PA_OK) return rc;
+  for (int r = 0; r < args->rounds; ++r) {
+    if (r + 1 < args->rounds) {
+      rc = issue_sample(r + 1);
+      if (rc != PA_OK) return rc;
+    }
+    pa_dqn::BatchBuf& bb = h->bb[r & 1];
+    PA_HIP(hipStreamWaitEvent(s, bb.ready, 0));
+    pa_dqn_batch b;
+    memset(&b, 0, sizeof(b));
+    b.B = B; b.A = A;
+    b.x = bb.x;
+    b.reward = bb.reward;
+    b.terminated = bb.term;
+    b.next_state = bb.next_state;
+    b.next_avail_rep = bb.next_avail_rep;
+    b.next_mask = bb.next_mask;
+    // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
+    // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
+    const int64_t ts = args->training_steps0 + r + 1;
+    const int do_tu = ((ts + 1) % args->target_update_freq) == 0;
+    rc = step_impl(h, &b, do_tu, args->adam_step0 + r + 1, 1,
+                   args->losses_out ? args->losses_out + r : nullptr, s);
+    if (rc != PA_OK) return rc;
+    PA_HIP(hipEventRecord(bb.consumed, s));
+    bb.used = true;
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_enable_timing(pa_dqn* h, int32_t on) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  h->timing = on != 0;
+  for (auto& t : h->timers) t.used = 0;
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* count) {
+  PA_REQUIRE(h && name && avg_ms && count, PA_ERR_INVALID, "null argument");
+  *avg_ms = 0.0;
+  *count = 0;
+  for (auto& t : h->timers) {
+    if (t.name != name) continue;
+    double total = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < t.used; i += 2) {
+      PA_HIP(hipEventSynchronize(t.ev[i + 1]));
+      float ms = 0.f;
+      PA_HIP(hipEventElapsedTime(&ms, t.ev[i], t.ev[i + 1]));
+      total += ms;
+      ++n;
+    }
+    *count = n;
+    *avg_ms = n ? total / (double)n : 0.0;
+    return PA_OK;
+  }
+  return PA_OK;
+}

@@ -1,0 +1,110 @@
+"""The agent-side boundary of the hot path (pearl/pearl_agent.py:49-330).
+
+Only the wiring that touches the replay/learner path is mirrored: device selection
+(utils/device.py:48-59), propagating ``_is_action_continuous`` / ``device_for_batches`` to the
+buffer and moving the learner to the device (:97-128), ``observe -> replay_buffer.push``
+(:169-211), ``learn -> policy_learner.learn(replay_buffer)`` (+ clear when on-policy, :213-220),
+``learn_batch`` (:222-231), ``act`` and ``reset``.  Safety modules and history summarisation
+beyond the identity are outside SURVEY.md §8 and are not mirrored; the reference's own
+``PearlAgent`` can drive the pearl_amd buffer/learner instead.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from .policy_learners.policy_learner import PolicyLearner
+from .replay_buffers.replay_buffer import ReplayBuffer
+from .replay_buffers.transition import TransitionBatch
+
+
+@dataclass
+class ActionResult:
+    """pearl/api/action_result.py: what the environment hands back after a step."""
+    observation: Any
+    reward: Any = None
+    terminated: bool = False
+    truncated: bool = False
+    info: Optional[dict] = None
+    cost: Optional[float] = None
+    available_action_space: Any = None
+
+    @property
+    def done(self) -> bool:
+        return bool(self.terminated or self.truncated)
+
+
+def get_pearl_device(device_id: int = -1) -> torch.device:
+    """cuda:{device_id}, else cuda:{rank} when a GPU is visible, else cpu (utils/device.py:48-59)."""
+    if device_id != -1:
+        return torch.device(f"cuda:{device_id}")
+    rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    if torch.cuda.is_available():
+        return torch.device(f"cuda:{rank % max(torch.cuda.device_count(), 1)}")
+    return torch.device("cpu")
+
+
+class PearlAgent(torch.nn.Module):
+    def __init__(self, policy_learner: PolicyLearner, safety_module: Any = None,
+                 replay_buffer: Optional[ReplayBuffer] = None,
+                 history_summarization_module: Any = None, device_id: int = -1) -> None:
+        super().__init__()
+        if safety_module is not None or history_summarization_module is not None:
+            raise NotImplementedError(
+                "pearl_amd.PearlAgent mirrors only the replay/learner wiring; use the reference's "
+                "PearlAgent for safety / history-summarisation modules (INTEGRATION.md)")
+        assert replay_buffer is not None, "pearl_amd.PearlAgent needs an explicit replay buffer"
+        self.policy_learner = policy_learner
+        self.replay_buffer = replay_buffer
+        self._device_id = device_id
+        self.device = get_pearl_device(device_id)
+        self.replay_buffer._is_action_continuous = self.policy_learner._is_action_continuous
+        self.replay_buffer.device_for_batches = self.device
+        self._subjective_state: Any = None
+        self._latest_action: Any = None
+        self._action_space: Any = None
+        self.policy_learner.to(self.device)
+
+    def act(self, exploit: bool = False) -> Any:
+        assert self._action_space is not None
+        state = torch.as_tensor(self._subjective_state).to(self.device)
+        if hasattr(self._action_space, "to"):
+            self._action_space.to(self.device)
+        action = self.policy_learner.act(state, self._action_space, exploit=exploit)
+        self._latest_action = action
+        return action
+
+    def observe(self, action_result: ActionResult) -> None:
+        assert self._latest_action is not None and self._action_space is not None
+        new_state = action_result.observation
+        next_space = (self._action_space if action_result.available_action_space is None
+                      else action_result.available_action_space)
+        rep = self.policy_learner.action_representation_module
+        self.replay_buffer.push(
+            state=self._subjective_state, action=self._latest_action,
+            reward=action_result.reward, next_state=new_state,
+            curr_available_actions=self._action_space, next_available_actions=next_space,
+            terminated=action_result.terminated, truncated=action_result.truncated,
+            max_number_actions=(rep.max_number_actions
+                                if not self.policy_learner._is_action_continuous else None),
+            cost=action_result.cost)
+        self._action_space = next_space
+        self._subjective_state = new_state
+
+    def learn(self) -> Dict[str, Any]:
+        report = self.policy_learner.learn(self.replay_buffer)
+        if self.policy_learner.on_policy:
+            self.replay_buffer.clear()
+        return report
+
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        return self.policy_learner.learn_batch(self.policy_learner.preprocess_batch(batch))
+
+    def reset(self, observation: Any, available_action_space: Any) -> None:
+        self._latest_action = None
+        self._subjective_state = observation
+        self._action_space = available_action_space
+        self.policy_learner.reset(available_action_space)

@@ -1,0 +1,156 @@
+"""The ``PolicyLearner`` plugin interface and its generic ``learn`` loop
+(pearl/policy_learners/policy_learner.py:40-303).
+
+``learn`` = ``training_rounds`` x (sample -> preprocess_batch -> learn_batch) with the
+reference's batch-size clamp and report aggregation (:162-195); ``preprocess_batch`` applies the
+history-summarisation and action-representation modules in place (:197-218).  Learners in this
+package override ``learn`` with a fused device-side loop when the buffer is an HBM arena and keep
+this generic loop for any other ``ReplayBuffer``.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..action_representation_modules import (ActionRepresentationModule,
+                                             IdentityActionRepresentationModule)
+from ..replay_buffers.replay_buffer import ReplayBuffer
+from ..replay_buffers.transition import TransitionBatch
+from .exploration import ExplorationModule, NoExploration
+
+
+class IdentityHistorySummarizationModule(nn.Module):
+    """forward = x (pearl/history_summarization_modules/identity_history_summarization_module.py
+    :41-42); the only history module on the configured hot path."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.history: Any = None
+
+    def summarize_history(self, observation: Any, action: Any) -> Any:
+        self.history = observation
+        return observation
+
+    def get_history(self) -> Any:
+        return self.history
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x
+
+    def reset(self) -> None:
+        self.history = None
+
+    def compare(self, other: Any) -> str:
+        return "" if isinstance(other, IdentityHistorySummarizationModule) else (
+            "other is not an instance of IdentityHistorySummarizationModule")
+
+
+def _looks_like_batch(obj: Any) -> bool:
+    return isinstance(obj, TransitionBatch) or all(
+        hasattr(obj, k) for k in ("state", "action", "reward", "terminated", "next_state"))
+
+
+class PolicyLearner(nn.Module, ABC):
+    def __init__(self, on_policy: bool, is_action_continuous: bool, action_space: Any = None,
+                 training_rounds: int = 100, batch_size: int = 1, requires_tensors: bool = True,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 **options: Any) -> None:
+        super().__init__()
+        self.exploration_module = options.get("exploration_module") or NoExploration()
+        if action_representation_module is None:
+            if action_space is not None:
+                action_representation_module = IdentityActionRepresentationModule(
+                    max_number_actions=getattr(action_space, "n", None),
+                    representation_dim=action_space.action_dim)
+            else:
+                action_representation_module = IdentityActionRepresentationModule()
+        else:
+            assert action_representation_module.representation_dim is not None
+        self.action_representation_module = action_representation_module
+        self._history_summarization_module: nn.Module = IdentityHistorySummarizationModule()
+        self._training_rounds = training_rounds
+        self._batch_size = batch_size
+        self._training_steps = 0
+        self.on_policy = on_policy
+        self._is_action_continuous = is_action_continuous
+        self.distribution_enabled: bool = (torch.distributed.is_available()
+                                           and torch.distributed.is_initialized())
+        self.requires_tensors = requires_tensors
+
+    @property
+    def batch_size(self) -> int:
+        return self._batch_size
+
+    def get_action_representation_module(self) -> ActionRepresentationModule:
+        return self.action_representation_module
+
+    @abstractmethod
+    def set_history_summarization_module(self, value: nn.Module) -> None:
+        ...
+
+    def reset(self, action_space: Any) -> None:
+        pass
+
+    @abstractmethod
+    def act(self, subjective_state: Any, available_action_space: Any, exploit: bool = False) -> Any:
+        ...
+
+    def _clamped_batch_size(self, replay_buffer: ReplayBuffer) -> int:
+        n = len(replay_buffer)
+        return n if (self._batch_size == -1 or n < self._batch_size) else self._batch_size
+
+    def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
+        if len(replay_buffer) == 0:
+            return {}
+        batch_size = self._clamped_batch_size(replay_buffer)
+        report: Dict[str, List[Any]] = {}
+        for _ in range(self._training_rounds):
+            self._training_steps += 1
+            batch = replay_buffer.sample(batch_size)
+            single: Dict[str, Any] = {}
+            if _looks_like_batch(batch):
+                single = self.learn_batch(self.preprocess_batch(batch))
+            for k, v in single.items():
+                report.setdefault(k, []).append(v)
+        return report
+
+    def preprocess_batch(self, batch: TransitionBatch) -> TransitionBatch:
+        batch.state = self._history_summarization_module(batch.state)
+        with torch.no_grad():
+            batch.next_state = self._history_summarization_module(batch.next_state)
+        rep = self.action_representation_module
+        batch.action = rep(batch.action)
+        for name in ("next_action", "curr_available_actions", "next_available_actions"):
+            value = getattr(batch, name, None)
+            if value is not None:
+                setattr(batch, name, rep(value))
+        return batch
+
+    @abstractmethod
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        ...
+
+    def __str__(self) -> str:
+        return self.__class__.__name__
+
+    def compare(self, other: "PolicyLearner") -> str:
+        if not isinstance(other, PolicyLearner):
+            return "other is not an instance of PolicyLearner"
+        diffs: List[str] = []
+        for attr in ("_training_rounds", "_batch_size", "on_policy", "_is_action_continuous"):
+            a, b = getattr(self, attr), getattr(other, attr)
+            if a != b:
+                diffs.append(f"{attr} is different: {a} vs {b}")
+        for label, mine, theirs in (
+                ("exploration_module", self.exploration_module, other.exploration_module),
+                ("action_representation_module", self.action_representation_module,
+                 other.action_representation_module),
+                ("history summarization module", self._history_summarization_module,
+                 other._history_summarization_module)):
+            reason = mine.compare(theirs)
+            if reason:
+                diffs.append(f"{label} is different: {reason}")
+        return "\n".join(diffs)

@@ -1,0 +1,514 @@
+"""``DeepQLearning`` whose ``learn`` / ``learn_batch`` run as HIP kernels on MI355X.
+
+Drop-in for pearl/policy_learners/sequential_decision_making/deep_q_learning.py:35-189 on top
+of deep_td_learning.py:46-477 — same constructor arguments and defaults (AdamW lr 1e-3,
+amsgrad, weight decay 0.01; gamma 0.99; target_update_freq 10; soft_update_tau 0.75), same
+attributes other components read (``_Q``, ``_Q_target``, ``_optimizer``, ``_training_steps``,
+``on_policy``, ``_is_action_continuous`` ...), same report ``{"loss": mean |Q - target|}``.
+
+What differs is where the arithmetic happens.  The nn.Parameters of ``_Q`` / ``_Q_target`` stay
+the source of truth (``state_dict`` / ``compare`` keep working) but are re-pointed into flat fp32
+buffers; libpearl_amd.so reads and updates them in place:
+
+* ``learn_batch(batch)``  -> ``pa_dqn_step``: soft target update (deep_td_learning.py:283-284),
+  online forward, fused target-network forward + mask + max + Bellman target
+  (deep_q_learning.py:130-167), MSE, backward, AdamW(amsgrad);
+* ``learn(replay_buffer)`` on an arena-backed buffer -> ``pa_dqn_learn``: the whole
+  ``training_rounds`` loop on the device, sampling one step ahead on a side stream, one host
+  synchronisation per call (for the report) instead of one ``.item()`` per step.
+
+Data parallelism (not in the reference): if ``torch.distributed`` is initialised every rank keeps
+its own arena shard and local batch; gradients are pre-scaled by 1/world, summed with one RCCL
+all-reduce of the flat gradient buffer, then ``pa_dqn_apply`` runs AdamW.  The next sample is
+already queued on the side stream while the all-reduce is in flight.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+import random
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import optim
+
+from ... import _native as N
+from ...action_representation_modules import (ActionRepresentationModule,
+                                              OneHotActionTensorRepresentationModule)
+from ...neural_networks.sequential_decision_making.q_value_networks import (QValueNetwork,
+                                                                           VanillaQValueNetwork)
+from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
+from ...replay_buffers.replay_buffer import ReplayBuffer
+from ...replay_buffers.transition import TransitionBatch
+from ..exploration import EGreedyExploration, ExplorationModule
+from ..policy_learner import PolicyLearner
+
+_FLAT_NAMES = ("q", "q_target", "grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")
+
+
+class _NativeDqn:
+    """Owns the pa_dqn handle and the flat buffers; never deep-copied or pickled."""
+
+    def __init__(self) -> None:
+        self.handle: Optional[C.c_void_p] = None
+        self.flat: Dict[str, torch.Tensor] = {}
+        self.sig: Tuple = ()
+        self.desc_key: Tuple = ()
+        self.loss_buf: Optional[torch.Tensor] = None
+
+    def close(self) -> None:
+        h, self.handle = self.handle, None
+        if h:
+            N.lib().pa_dqn_destroy(h)
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo: dict) -> "_NativeDqn":
+        return _NativeDqn()
+
+    def __getstate__(self) -> dict:
+        return {}
+
+    def __setstate__(self, state: dict) -> None:
+        self.__init__()
+
+
+def world_size() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
+    """Sum a flat gradient buffer over the data-parallel group (RCCL on GPUs, gloo on CPU)."""
+    if world_size() > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat
+
+
+class DeepQLearning(PolicyLearner):
+    def __init__(self, action_space: Any = None, hidden_dims: Optional[List[int]] = None,
+                 exploration_module: Optional[ExplorationModule] = None,
+                 learning_rate: float = 0.001, discount_factor: float = 0.99,
+                 training_rounds: int = 10, batch_size: int = 128, target_update_freq: int = 10,
+                 soft_update_tau: float = 0.75, is_conservative: bool = False,
+                 conservative_alpha: Optional[float] = 2.0, state_dim: Optional[int] = None,
+                 network_type: type = VanillaQValueNetwork,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 network_instance: Optional[QValueNetwork] = None,
+                 optimizer: Optional[optim.Optimizer] = None, max_batch_size: Optional[int] = None,
+                 **kwargs: Any) -> None:
+        super().__init__(
+            training_rounds=training_rounds, batch_size=batch_size,
+            exploration_module=(exploration_module if exploration_module is not None
+                                else EGreedyExploration(0.05)),
+            on_policy=False, is_action_continuous=False,
+            action_representation_module=action_representation_module, action_space=action_space)
+        if is_conservative:
+            raise NotImplementedError("pearl_amd DeepQLearning: the CQL term is not built yet")
+        if optimizer is not None:
+            raise NotImplementedError(
+                "pearl_amd DeepQLearning owns its AdamW(amsgrad) step; custom optimizers are not "
+                "supported")
+        self._action_space = action_space
+        self._learning_rate = learning_rate
+        self._discount_factor = discount_factor
+        self._target_update_freq = target_update_freq
+        self._soft_update_tau = soft_update_tau
+        self._is_conservative = is_conservative
+        self._conservative_alpha = conservative_alpha
+        if network_instance is not None:
+            if not isinstance(network_instance, VanillaQValueNetwork):
+                raise NotImplementedError("only VanillaQValueNetwork instances are supported")
+            self._Q: VanillaQValueNetwork = network_instance
+        else:
+            if network_type is not VanillaQValueNetwork:
+                raise NotImplementedError(
+                    f"pearl_amd DeepQLearning: network_type {network_type.__name__} is not built; "
+                    "only VanillaQValueNetwork has HIP kernels")
+            assert state_dim is not None and hidden_dims is not None
+            self._Q = VanillaQValueNetwork(
+                state_dim=state_dim,
+                action_dim=self.action_representation_module.representation_dim,
+                hidden_dims=list(hidden_dims), output_dim=1)
+        if len(self._Q.linear_layers()) != 3:
+            raise NotImplementedError(
+                "pearl_amd DeepQLearning: exactly two hidden layers are built "
+                f"(got {len(self._Q.linear_layers()) - 1})")
+        self._Q_target: VanillaQValueNetwork = copy.deepcopy(self._Q)
+        self._optimizer: optim.Optimizer = optim.AdamW(self._Q.parameters(), lr=learning_rate,
+                                                       amsgrad=True)
+        self._max_batch_size = max_batch_size
+        self._native = _NativeDqn()
+        self.data_parallel = True
+
+    # ------------------------------------------------------------------ plumbing
+    @property
+    def optimizer(self) -> optim.Optimizer:
+        return self._optimizer
+
+    def set_history_summarization_module(self, value: torch.nn.Module) -> None:
+        if any(True for _ in value.parameters()):
+            raise NotImplementedError(
+                "pearl_amd DeepQLearning: trainable history summarisation modules are not built")
+        self._history_summarization_module = value
+
+    def reset(self, action_space: Any) -> None:
+        self._action_space = action_space
+
+    def _dims(self) -> Tuple[int, int, int, int]:
+        l1, l2, _ = self._Q.linear_layers()
+        return self._Q.state_dim, self._Q.action_dim, l1.out_features, l2.out_features
+
+    def _param_pairs(self) -> List[Tuple[torch.nn.Parameter, torch.nn.Parameter]]:
+        out = []
+        for lq, lt in zip(self._Q.linear_layers(), self._Q_target.linear_layers()):
+            out.append((lq.weight, lt.weight))
+            out.append((lq.bias, lt.bias))
+        return out
+
+    def _adam_steps(self) -> int:
+        for p in self._Q.parameters():
+            st = self._optimizer.state.get(p)
+            if st and "step" in st:
+                return int(float(st["step"]))
+        return 0
+
+    def _set_adam_steps(self, n: int) -> None:
+        for p in self._Q.parameters():
+            st = self._optimizer.state.get(p)
+            if st is not None and "step" in st:
+                st["step"].fill_(float(n))
+
+    def _signature(self) -> Tuple:
+        sig = []
+        for pq, pt in self._param_pairs():
+            st = self._optimizer.state.get(pq, {})
+            sig.append((pq.data_ptr(), pt.data_ptr(),
+                        tuple(st[k].data_ptr() if k in st else 0
+                              for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"))))
+        return tuple(sig)
+
+    def _ensure_bound(self, batch_hint: int = 0, actions_hint: int = 0) -> _NativeDqn:
+        """(Re)build the flat parameter/optimizer buffers and the pa_dqn handle when needed."""
+        nat = self._native
+        S, AD, H1, H2 = self._dims()
+        p0 = next(self._Q.parameters())
+        if not p0.is_cuda:
+            N.require_gpu()
+            raise N.NativeError(
+                "pearl_amd DeepQLearning: parameters are on the CPU; move the learner to a HIP "
+                "device first (PearlAgent does this) — there is no CPU learner path")
+        dev = p0.device
+        max_b = max(int(self._max_batch_size or 0), int(self._batch_size), int(batch_hint), 1)
+        max_a = max(int(getattr(self._action_space, "n", 0) or 0),
+                    int(self.action_representation_module.max_number_actions or 0),
+                    int(actions_hint), 1)
+        opt = self._optimizer.param_groups[0]
+        desc_key = (dev.index, S, AD, H1, H2, max_b, max_a, self._discount_factor,
+                    self._soft_update_tau, opt["lr"], tuple(opt["betas"]), opt["eps"],
+                    opt["weight_decay"], bool(opt["amsgrad"]))
+        if nat.handle is not None and nat.desc_key != desc_key:
+            torch.cuda.synchronize(dev)
+            nat.close()
+        if nat.handle is None:
+            desc = N.DqnDesc(device=dev.index, state_dim=S, action_dim=AD, hidden1=H1, hidden2=H2,
+                             max_batch=max_b, max_actions=max_a, discount=self._discount_factor,
+                             tau=self._soft_update_tau, lr=opt["lr"], beta1=opt["betas"][0],
+                             beta2=opt["betas"][1], eps=opt["eps"],
+                             weight_decay=opt["weight_decay"], amsgrad=int(opt["amsgrad"]))
+            handle = C.c_void_p()
+            N.check(N.lib().pa_dqn_create(C.byref(handle), C.byref(desc)))
+            nat.handle, nat.desc_key, nat.sig = handle, desc_key, ()
+            nat.loss_buf = torch.zeros(max(self._training_rounds, 1), dtype=torch.float32,
+                                       device=dev)
+        if nat.sig == self._signature() and nat.sig:
+            return nat
+        # ---- flatten: re-point every Parameter / grad / optimizer state into flat buffers
+        P = int(N.lib().pa_dqn_param_count(S, AD, H1, H2))
+        offs = (C.c_int64 * 6)()
+        N.check(N.lib().pa_dqn_param_offsets(S, AD, H1, H2, offs))
+        flat = {k: torch.zeros(P, dtype=torch.float32, device=dev) for k in _FLAT_NAMES}
+        steps = self._adam_steps()
+        with torch.no_grad():
+            for (pq, pt), off in zip(self._param_pairs(), list(offs)):
+                n = pq.numel()
+                sl = slice(int(off), int(off) + n)
+                flat["q"][sl].copy_(pq.data.reshape(-1).to(dev, torch.float32))
+                flat["q_target"][sl].copy_(pt.data.reshape(-1).to(dev, torch.float32))
+                st = self._optimizer.state.get(pq) or {}
+                for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                    if k in st:
+                        flat[k][sl].copy_(st[k].reshape(-1).to(dev, torch.float32))
+                pq.data = flat["q"][sl].view(pq.shape)
+                pt.data = flat["q_target"][sl].view(pt.shape)
+                pq.grad = flat["grad"][sl].view(pq.shape)
+                self._optimizer.state[pq] = {
+                    "step": torch.tensor(float(steps), dtype=torch.float32),
+                    "exp_avg": flat["exp_avg"][sl].view(pq.shape),
+                    "exp_avg_sq": flat["exp_avg_sq"][sl].view(pq.shape),
+                    "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(pq.shape),
+                }
+        bufs = N.DqnBuffers(**{k: flat[k].data_ptr() for k in _FLAT_NAMES})
+        N.check(N.lib().pa_dqn_bind(nat.handle, C.byref(bufs)))
+        nat.flat = flat
+        nat.sig = self._signature()
+        return nat
+
+    # ------------------------------------------------------------------ batches
+    def _default_next_actions(self, device: torch.device) -> torch.Tensor:
+        assert self._action_space is not None and hasattr(self._action_space, "actions_batch"), \
+            "next_available_actions missing and no discrete action space configured"
+        rep = self.action_representation_module(self._action_space.actions_batch.to(device))
+        return rep.to(torch.float32).contiguous()  # (A, AD)   deep_td_learning.py:362-372
+
+    def _native_batch(self, batch: TransitionBatch) -> Tuple[N.DqnBatch, list]:
+        S, AD, _, _ = self._dims()
+        dev = next(self._Q.parameters()).device
+
+        def f32(t: torch.Tensor) -> torch.Tensor:
+            return t.to(device=dev, dtype=torch.float32).contiguous()
+
+        state = f32(batch.state)
+        B = state.shape[0]
+        assert state.ndim == 2 and state.shape[1] == S, f"state must be ({B}, {S})"
+        action = f32(batch.action).reshape(B, -1)
+        assert action.shape[1] == AD, (
+            f"action representation has width {action.shape[1]}, expected {AD} "
+            "(did preprocess_batch run?)")
+        assert batch.next_state is not None, "Q-learning needs next_state"
+        next_state = f32(batch.next_state)
+        reward = f32(batch.reward).reshape(B)
+        term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
+        nav, mask = batch.next_available_actions, batch.next_unavailable_actions_mask
+        bcast = 0
+        if nav is None:
+            nav = self._default_next_actions(dev)
+            if mask is None:
+                bcast = 1
+            else:
+                nav = nav.unsqueeze(0).expand(B, -1, -1).contiguous()
+        else:
+            nav = f32(nav)
+            assert nav.ndim == 3 and nav.shape[0] == B and nav.shape[2] == AD, (
+                f"next_available_actions must be ({B}, A, {AD}) after preprocess_batch, got "
+                f"{tuple(nav.shape)}")
+        A = nav.shape[-2]
+        if mask is not None:
+            mask = mask.to(dev).reshape(B, A).to(torch.uint8).contiguous()
+        nb = N.DqnBatch(B=B, A=A, x=None, state=state.data_ptr(), action_rep=action.data_ptr(),
+                        reward=reward.data_ptr(), terminated=term.data_ptr(),
+                        next_state=next_state.data_ptr(), next_avail_rep=nav.data_ptr(),
+                        next_mask=N.ptr(mask), next_avail_bcast=bcast)
+        return nb, [state, action, next_state, reward, term, nav, mask]
+
+    # ------------------------------------------------------------------ API
+    def _target_update_due(self) -> bool:
+        return (self._training_steps + 1) % self._target_update_freq == 0
+
+    def forward(self, batch: TransitionBatch) -> torch.Tensor:
+        """Q(s, a) of the online network, after the conditional soft target update
+        (deep_td_learning.py:269-290)."""
+        nb, keep = self._native_batch(batch)
+        nat = self._ensure_bound(nb.B, nb.A)
+        stream = N.stream_ptr(keep[0].device)
+        if self._target_update_due():
+            N.check(N.lib().pa_dqn_update_target(nat.handle, stream))
+        q = torch.empty(nb.B, dtype=torch.float32, device=keep[0].device)
+        N.check(N.lib().pa_dqn_qvalues(nat.handle, C.byref(nb), q.data_ptr(), None, None, stream))
+        return q
+
+    @torch.no_grad()
+    def get_next_state_values(self, batch: TransitionBatch, batch_size: int) -> torch.Tensor:
+        """max over available next actions of Q_target(s', a') (deep_q_learning.py:130-167)."""
+        nb, keep = self._native_batch(batch)
+        nat = self._ensure_bound(nb.B, nb.A)
+        v = torch.empty(nb.B, dtype=torch.float32, device=keep[0].device)
+        N.check(N.lib().pa_dqn_qvalues(nat.handle, C.byref(nb), None, v.data_ptr(), None,
+                                       N.stream_ptr(keep[0].device)))
+        return v
+
+    def q_values_and_targets(self, batch: TransitionBatch) -> Dict[str, torch.Tensor]:
+        """Parity probe: Q(s,a), max_a' Q_target(s',a') and the Bellman target of a batch."""
+        nb, keep = self._native_batch(batch)
+        nat = self._ensure_bound(nb.B, nb.A)
+        dev = keep[0].device
+        q, v, y = (torch.empty(nb.B, dtype=torch.float32, device=dev) for _ in range(3))
+        N.check(N.lib().pa_dqn_qvalues(nat.handle, C.byref(nb), q.data_ptr(), v.data_ptr(),
+                                       y.data_ptr(), N.stream_ptr(dev)))
+        return {"q": q, "next_v": v, "target": y}
+
+    def _dp_world(self) -> int:
+        return world_size() if self.data_parallel else 1
+
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        """One TD(0) update on a preprocessed batch (deep_td_learning.py:333-360)."""
+        nb, keep = self._native_batch(batch)
+        nat = self._ensure_bound(nb.B, nb.A)
+        dev = keep[0].device
+        stream = N.stream_ptr(dev)
+        step = self._adam_steps() + 1
+        world = self._dp_world()
+        N.check(N.lib().pa_dqn_step(nat.handle, C.byref(nb), int(self._target_update_due()), step,
+                                    world, nat.loss_buf.data_ptr(), stream))
+        if world > 1:
+            allreduce_sum_(nat.flat["grad"])
+            N.check(N.lib().pa_dqn_apply(nat.handle, step, stream))
+        self._set_adam_steps(step)
+        return {"loss": nat.loss_buf[0].item()}  # the reference's per-step .item() (:359)
+
+    def _arena_path_ok(self, replay_buffer: ReplayBuffer) -> bool:
+        if not isinstance(replay_buffer, TensorBasedReplayBuffer) or replay_buffer.arena is None:
+            return False
+        rep = self.action_representation_module
+        z = replay_buffer._layout
+        onehot = isinstance(rep, OneHotActionTensorRepresentationModule)
+        if not z.has_next_state or z.max_actions <= 0 or not replay_buffer._has_next_avail:
+            return False
+        if onehot:
+            return z.action_elems == 1 and z.avail_dim == 1
+        return type(rep).__name__ == "IdentityActionRepresentationModule" and \
+            z.action_elems == self._Q.action_dim and z.avail_dim == self._Q.action_dim
+        # anything else goes through the generic sample -> preprocess -> learn_batch loop
+
+    def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
+        """``training_rounds`` x (sample, preprocess, learn_batch) — policy_learner.py:162-195."""
+        if len(replay_buffer) == 0:
+            return {}
+        if not self._arena_path_ok(replay_buffer):
+            return super().learn(replay_buffer)
+        batch_size = self._clamped_batch_size(replay_buffer)
+        rounds = int(self._training_rounds)
+        arena = replay_buffer.arena
+        nat = self._ensure_bound(batch_size, arena.layout.max_actions)
+        dev = arena.device
+        if nat.loss_buf.numel() < rounds:
+            nat.loss_buf = torch.zeros(rounds, dtype=torch.float32, device=dev)
+        onehot = isinstance(self.action_representation_module,
+                            OneHotActionTensorRepresentationModule)
+        if rounds == 0:
+            return {}
+        if self._dp_world() > 1:
+            return self._learn_data_parallel(replay_buffer, batch_size, rounds, onehot)
+        idx_host = None
+        if replay_buffer.sampler == "python":
+            n = len(replay_buffer)
+            idx_host = np.asarray([random.sample(range(n), batch_size) for _ in range(rounds)],
+                                  dtype=np.int64)
+        args = N.LearnArgs(
+            rounds=rounds, batch_size=batch_size, rep_onehot=int(onehot),
+            target_update_freq=int(self._target_update_freq),
+            training_steps0=int(self._training_steps), adam_step0=self._adam_steps(),
+            seed=random.getrandbits(64) if idx_host is None else 0, offset0=0,
+            losses_out=nat.loss_buf.data_ptr(),
+            idx_host=None if idx_host is None else idx_host.ctypes.data)
+        N.check(N.lib().pa_dqn_learn(nat.handle, arena.handle, C.byref(args), N.stream_ptr(dev)))
+        self._training_steps += rounds
+        self._set_adam_steps(args.adam_step0 + rounds)
+        losses = nat.loss_buf[:rounds].tolist()  # the single host sync of this call
+        return {"loss": losses}
+
+    def _learn_data_parallel(self, replay_buffer: TensorBasedReplayBuffer, batch_size: int,
+                             rounds: int, onehot: bool) -> Dict[str, Any]:
+        """world > 1: per-round step with an RCCL all-reduce between backward and AdamW; the
+        sample of round r+1 is enqueued on a side stream before round r's all-reduce."""
+        nat, arena = self._native, replay_buffer.arena
+        dev = arena.device
+        S, AD, _, _ = self._dims()
+        A = arena.layout.max_actions
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(main)
+        seed = random.getrandbits(64)
+        bufs = []
+        for _ in range(2):
+            bufs.append(dict(
+                x=torch.empty(batch_size, S + AD, device=dev), ns=torch.empty(batch_size, S, device=dev),
+                nav=torch.empty(batch_size, A, AD, device=dev),
+                nm=torch.empty(batch_size, A, dtype=torch.uint8, device=dev),
+                rw=torch.empty(batch_size, device=dev),
+                tm=torch.empty(batch_size, dtype=torch.uint8, device=dev),
+                ready=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False))
+        world = self._dp_world()
+
+        def prefetch(r: int) -> None:
+            b = bufs[r & 1]
+            with torch.cuda.stream(side):
+                if b["used"]:
+                    side.wait_event(b["consumed"])
+                out = N.BatchOut(x=b["x"].data_ptr(), next_state=b["ns"].data_ptr(),
+                                 next_avail_rep=b["nav"].data_ptr(), next_mask=b["nm"].data_ptr(),
+                                 reward_f32=b["rw"].data_ptr(), terminated=b["tm"].data_ptr(),
+                                 rep_dim=AD, rep_onehot=int(onehot))
+                if replay_buffer.sampler == "python":
+                    arena.gather(np.asarray(random.sample(range(len(replay_buffer)), batch_size),
+                                            dtype=np.int64), out)
+                else:
+                    arena.sample(seed, r, batch_size, out)
+                b["ready"].record(side)
+
+        step0 = self._adam_steps()
+        prefetch(0)
+        for r in range(rounds):
+            if r + 1 < rounds:
+                prefetch(r + 1)
+            b = bufs[r & 1]
+            main.wait_event(b["ready"])
+            self._training_steps += 1
+            nb = N.DqnBatch(B=batch_size, A=A, x=b["x"].data_ptr(), reward=b["rw"].data_ptr(),
+                            terminated=b["tm"].data_ptr(), next_state=b["ns"].data_ptr(),
+                            next_avail_rep=b["nav"].data_ptr(), next_mask=b["nm"].data_ptr(),
+                            next_avail_bcast=0)
+            N.check(N.lib().pa_dqn_step(nat.handle, C.byref(nb), int(self._target_update_due()),
+                                        step0 + r + 1, world,
+                                        nat.loss_buf[r:].data_ptr(), N.stream_ptr(dev)))
+            allreduce_sum_(nat.flat["grad"])
+            N.check(N.lib().pa_dqn_apply(nat.handle, step0 + r + 1, N.stream_ptr(dev)))
+            b["consumed"].record(main)
+            b["used"] = True
+        self._set_adam_steps(step0 + rounds)
+        return {"loss": nat.loss_buf[:rounds].tolist()}
+
+    # ------------------------------------------------------------------ act / compare
+    def act(self, subjective_state: torch.Tensor, available_action_space: Any,
+            exploit: bool = False) -> Any:
+        """Greedy action + exploration module (deep_td_learning.py:200-254).  Act-time only: a
+        single (1, A, S+AD) forward through torch, not part of the learner hot path."""
+        assert hasattr(available_action_space, "actions_batch")
+        if subjective_state.ndim == 1:
+            subjective_state = subjective_state.unsqueeze(0)
+        with torch.no_grad():
+            reps = self.action_representation_module(
+                available_action_space.actions_batch.to(subjective_state)).unsqueeze(0)
+            q_values = self._Q.get_q_values(subjective_state, reps.to(subjective_state.dtype))
+            q_values = q_values.squeeze(0)
+            exploit_action = available_action_space.actions[int(torch.argmax(q_values))]
+        if exploit:
+            return exploit_action
+        return self.exploration_module.act(
+            subjective_state=subjective_state, action_space=available_action_space,
+            exploit_action=exploit_action, values=q_values)
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, DeepQLearning):
+            diffs.append("other is not an instance of DeepQLearning")
+        else:
+            for attr in ("_learning_rate", "_discount_factor", "_target_update_freq",
+                         "_soft_update_tau", "_is_conservative", "_conservative_alpha"):
+                if getattr(self, attr) != getattr(other, attr):
+                    diffs.append(f"{attr} is different: {getattr(self, attr)} vs "
+                                 f"{getattr(other, attr)}")
+            for name in ("_Q", "_Q_target"):
+                mine, theirs = getattr(self, name).state_dict(), getattr(other, name).state_dict()
+                if mine.keys() != theirs.keys():
+                    diffs.append(f"{name} is different: state_dict keys differ")
+                    continue
+                for k in mine:
+                    if not torch.allclose(mine[k].cpu(), theirs[k].cpu(), rtol=1e-5, atol=1e-8):
+                        diffs.append(f"{name} is different: key {k} differs")
+        return "\n".join(d for d in diffs if d)

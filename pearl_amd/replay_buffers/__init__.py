@@ -1,0 +1,6 @@
+from .basic_replay_buffer import BasicReplayBuffer, TensorBasedReplayBuffer
+from .replay_buffer import ReplayBuffer
+from .transition import Transition, TransitionBatch
+
+__all__ = ["BasicReplayBuffer", "TensorBasedReplayBuffer", "ReplayBuffer", "Transition",
+           "TransitionBatch"]

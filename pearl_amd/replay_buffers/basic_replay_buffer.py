@@ -1,0 +1,350 @@
+"""``BasicReplayBuffer`` on the HBM arena.
+
+Drop-in for pearl/replay_buffers/basic_replay_buffer.py:17-48 +
+tensor_based_replay_buffer.py:25-400: same constructor, ``push`` signature, ``sample``
+contract (TransitionBatch shapes/dtypes, ``ValueError`` when ``batch_size > len``), FIFO
+eviction, ``clear``, ``len``.  Storage and the collate step are HIP kernels:
+
+* ``push`` tensorises exactly like the reference (:143-177, :179-251) but packs the row into
+  a pinned staging ring; rows reach the HBM ring in one H2D copy + one unpack kernel;
+* ``sample`` draws indices and runs ONE gather kernel instead of ~10 ``torch.cat`` over B
+  one-row tensors (:290-400).
+
+Index streams.  ``sampler="python"`` draws ``random.sample(range(len(self)), B)``: the same
+positions, and the same consumption of Python's global ``random`` state, as the reference's
+``random.sample(self.memory, B)`` (:276) — batches are bit-identical to the reference's.
+``sampler="device"`` (default) draws without replacement on the GPU with Philox keyed by 64
+bits taken from Python's ``random`` per call: reproducible under ``random.seed`` but a
+different (equally uniform) stream.
+"""
+from __future__ import annotations
+
+import random
+from typing import Any, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _native as N
+from .arena import ArenaLayout, HbmArena
+from .replay_buffer import ReplayBuffer
+from .transition import TransitionBatch
+
+
+def _default_batch_device() -> torch.device:
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def _as_host_array(x: Any, dtype: Optional[np.dtype] = None) -> np.ndarray:
+    """CPU, contiguous numpy view of a tensor / array / python number."""
+    if isinstance(x, Tensor):
+        x = x.detach()
+        if x.device.type != "cpu":
+            x = x.cpu()  # the reference also lands pushes on the CPU (:153-157)
+        arr = x.contiguous().numpy()
+    else:
+        arr = np.asarray(x)
+    if dtype is not None and arr.dtype != dtype:
+        arr = arr.astype(dtype)
+    return np.ascontiguousarray(arr)
+
+
+def _torch_dtype_of_value(x: Any) -> torch.dtype:
+    """dtype ``torch.tensor(x)`` would pick (reference :159-166)."""
+    if isinstance(x, Tensor):
+        return x.dtype
+    if isinstance(x, np.generic):  # numpy scalars keep their own width
+        return torch.as_tensor(x).dtype
+    if isinstance(x, bool):
+        return torch.bool
+    if isinstance(x, int):
+        return torch.int64
+    if isinstance(x, float):
+        return torch.float32
+    return torch.as_tensor(x).dtype
+
+
+_NP_OF_TORCH = {torch.float32: np.float32, torch.float64: np.float64, torch.int64: np.int64,
+                torch.int32: np.int32, torch.uint8: np.uint8, torch.bool: np.uint8}
+
+
+def create_action_tensor_and_mask(max_number_actions: Optional[int], available_action_space: Any
+                                  ) -> Tuple[Optional[Tensor], Optional[Tensor]]:
+    """Zero-padded (max_number_actions, action_dim) float32 table of the available actions and
+    the (max_number_actions,) bool mask that is True beyond ``space.n``
+    (tensor_based_replay_buffer.py:179-251)."""
+    if max_number_actions is None or available_action_space is None:
+        return (None, None)
+    n = int(available_action_space.n)
+    table = torch.zeros((max_number_actions, int(available_action_space.action_dim)),
+                        dtype=torch.float32)
+    table[:n, :] = available_action_space.actions_batch
+    mask = torch.zeros((max_number_actions,), dtype=torch.bool)
+    mask[n:] = True
+    return table, mask
+
+
+class TensorBasedReplayBuffer(ReplayBuffer):
+    """Arena-backed counterpart of tensor_based_replay_buffer.py:25-400."""
+
+    def __init__(self, capacity: int, sampler: str = "device", staging_rows: int = 0) -> None:
+        super().__init__()
+        if sampler not in ("device", "python"):
+            raise ValueError(f"sampler must be 'device' or 'python', got {sampler!r}")
+        self.capacity = int(capacity)
+        self.sampler = sampler
+        self._staging_rows = int(staging_rows)
+        self._device_for_batches: torch.device = _default_batch_device()
+        self._arena: Optional[HbmArena] = None
+        self._layout: Optional[ArenaLayout] = None
+        self._has_curr_avail = False
+        self._has_next_avail = False
+        self._space_cache: dict = {}
+
+    # -- ReplayBuffer interface -------------------------------------------------
+    @property
+    def device_for_batches(self) -> torch.device:
+        return self._device_for_batches
+
+    @device_for_batches.setter
+    def device_for_batches(self, new_device_for_batches: torch.device) -> None:
+        new = torch.device(new_device_for_batches)
+        if self._arena is not None and new.type == "cuda":
+            idx = new.index if new.index is not None else torch.cuda.current_device()
+            if idx != self._arena.device.index:
+                raise N.NativeError("pearl_amd: cannot move a populated HBM arena across devices")
+        self._device_for_batches = new
+
+    def __len__(self) -> int:
+        return 0 if self._arena is None else len(self._arena)
+
+    def clear(self) -> None:
+        if self._arena is not None:
+            self._arena.clear()
+
+    @property
+    def arena(self) -> Optional[HbmArena]:
+        return self._arena
+
+    # -- push ------------------------------------------------------------------
+    def _padded_tables(self, max_number_actions: int, space: Any) -> Tuple[np.ndarray, np.ndarray]:
+        if space is None:
+            z = self._layout
+            A = max_number_actions
+            d = z.avail_dim if z is not None else 1
+            return np.zeros((A, d), np.float32), np.zeros((A,), np.uint8)
+        key = (id(space), int(space.n), max_number_actions)
+        hit = self._space_cache.get(key)
+        if hit is None:
+            table, mask = create_action_tensor_and_mask(max_number_actions, space)
+            hit = (_as_host_array(table, np.float32), _as_host_array(mask.to(torch.uint8)))
+            if len(self._space_cache) > 64:
+                self._space_cache.clear()
+            self._space_cache[key] = hit
+        return hit
+
+    def _ensure_arena(self, layout: ArenaLayout) -> None:
+        if self._arena is None:
+            self._layout = layout
+            self._arena = HbmArena(self.capacity, layout, self._device_for_batches,
+                                   self._staging_rows)
+            return
+        assert layout == self._layout, (
+            f"transition layout changed after the first push: {layout} vs {self._layout}")
+
+    def push(self, state: Any, action: Any, reward: Any, terminated: bool, truncated: bool,
+             curr_available_actions: Any = None, next_state: Any = None,
+             next_available_actions: Any = None, max_number_actions: Optional[int] = None,
+             cost: Optional[float] = None) -> None:
+        A = 0
+        curr_tab = curr_mask = next_tab = next_mask = None
+        avail_dim = 0
+        if not self._is_action_continuous:
+            # static action space unless the caller says otherwise (:79-85)
+            if max_number_actions is None:
+                assert curr_available_actions is not None and hasattr(curr_available_actions, "n"), \
+                    "discrete replay buffer needs curr_available_actions or max_number_actions"
+                max_number_actions = int(curr_available_actions.n)
+            A = int(max_number_actions)
+            has_curr = curr_available_actions is not None
+            has_next = next_available_actions is not None
+            if self._arena is None:
+                self._has_curr_avail, self._has_next_avail = has_curr, has_next
+            else:
+                assert (has_curr, has_next) == (self._has_curr_avail, self._has_next_avail), \
+                    "availability of curr/next action spaces changed after the first push"
+            some = curr_available_actions if has_curr else next_available_actions
+            avail_dim = int(some.action_dim) if some is not None else 1
+            if not (has_curr or has_next):
+                A = 0
+            else:
+                curr_tab, curr_mask = self._padded_tables(A, curr_available_actions)
+                next_tab, next_mask = self._padded_tables(A, next_available_actions)
+
+        st = _as_host_array(state)
+        st32 = st.astype(np.float32, copy=False) if st.dtype != np.float32 else st
+        if isinstance(action, Tensor):
+            act_dtype = action.dtype
+        else:
+            act_dtype = torch.as_tensor(action).dtype
+        act = _as_host_array(action, _NP_OF_TORCH[act_dtype])
+        rew_dtype = _torch_dtype_of_value(reward)
+        if rew_dtype == torch.bool:
+            rew_dtype = torch.int64
+        rew = _as_host_array(reward, _NP_OF_TORCH[rew_dtype]).reshape(-1)[:1]
+        layout = ArenaLayout(
+            state_shape=tuple(st.shape), action_shape=tuple(act.shape), action_dtype=act_dtype,
+            reward_dtype=rew_dtype, max_actions=A, avail_dim=avail_dim if A else 0,
+            has_next_state=next_state is not None, has_cost=cost is not None)
+        self._ensure_arena(layout)
+
+        t = N.Transition()
+        keep = [st32, act, rew]  # keep the numpy buffers alive across the C call
+        t.state = st32.ctypes.data
+        t.action = act.ctypes.data
+        t.reward = rew.ctypes.data
+        if next_state is not None:
+            ns = _as_host_array(next_state)
+            ns = ns.astype(np.float32, copy=False) if ns.dtype != np.float32 else ns
+            assert ns.size == st32.size, "next_state and state differ in size"
+            keep.append(ns)
+            t.next_state = ns.ctypes.data
+        if A:
+            t.curr_avail, t.curr_mask = curr_tab.ctypes.data, curr_mask.ctypes.data
+            t.next_avail, t.next_mask = next_tab.ctypes.data, next_mask.ctypes.data
+        if cost is not None:
+            c = np.asarray([cost], np.float32)
+            keep.append(c)
+            t.cost = c.ctypes.data
+        t.terminated = 1 if bool(terminated) else 0
+        t.truncated = 1 if bool(truncated) else 0
+        self._arena.push_row(t)
+
+    def push_many(self, state: Tensor, action: Tensor, reward: Tensor, terminated: Tensor,
+                  truncated: Tensor, next_state: Optional[Tensor] = None,
+                  curr_available_actions: Any = None, next_available_actions: Any = None,
+                  max_number_actions: Optional[int] = None, cost: Optional[Tensor] = None) -> None:
+        """Batched ingest of n transitions (leading dim n) — SURVEY.md §8f rank 1.
+
+        Same per-row semantics as n successive ``push`` calls with one (static) action space.
+        Tensors may live on the arena's device (no host round trip) or on the CPU.
+        """
+        n = int(state.shape[0])
+        A = 0
+        avail_dim = 0
+        tabs = None
+        if not self._is_action_continuous:
+            if max_number_actions is None:
+                assert curr_available_actions is not None
+                max_number_actions = int(curr_available_actions.n)
+            A = int(max_number_actions)
+            has_curr = curr_available_actions is not None
+            has_next = next_available_actions is not None
+            if self._arena is None:
+                self._has_curr_avail, self._has_next_avail = has_curr, has_next
+            some = curr_available_actions if has_curr else next_available_actions
+            avail_dim = int(some.action_dim) if some is not None else 1
+            if not (has_curr or has_next):
+                A = 0
+            else:
+                tabs = (*self._padded_tables(A, curr_available_actions),
+                        *self._padded_tables(A, next_available_actions))
+        rew_dtype = reward.dtype
+        layout = ArenaLayout(
+            state_shape=tuple(state.shape[1:]), action_shape=tuple(action.shape[1:]),
+            action_dtype=action.dtype, reward_dtype=rew_dtype, max_actions=A,
+            avail_dim=avail_dim if A else 0, has_next_state=next_state is not None,
+            has_cost=cost is not None)
+        self._ensure_arena(layout)
+        dev = self._arena.device
+        on_device = state.is_cuda
+        target = dev if on_device else torch.device("cpu")
+
+        def col(x: Optional[Tensor], dtype: Optional[torch.dtype] = None) -> Optional[Tensor]:
+            if x is None:
+                return None
+            x = x.detach().to(device=target, dtype=dtype if dtype is not None else x.dtype)
+            return x.contiguous()
+
+        keep = [col(state, torch.float32), col(action), col(reward), col(terminated, torch.uint8),
+                col(truncated, torch.uint8), col(next_state, torch.float32),
+                col(cost, torch.float32)]
+        cols = N.Columns()
+        cols.state, cols.action, cols.reward = (N.ptr(keep[0]), N.ptr(keep[1]), N.ptr(keep[2]))
+        cols.terminated, cols.truncated = N.ptr(keep[3]), N.ptr(keep[4])
+        cols.next_state, cols.cost = N.ptr(keep[5]), N.ptr(keep[6])
+        if A:
+            tt = [torch.from_numpy(a).to(target) for a in tabs]
+            keep.extend(tt)
+            cols.curr_avail, cols.curr_mask = tt[0].data_ptr(), tt[1].data_ptr()
+            cols.next_avail, cols.next_mask = tt[2].data_ptr(), tt[3].data_ptr()
+            cols.avail_bcast = 1
+        self._arena.push_columns(n, cols, on_device)
+        if on_device:
+            # the source columns must outlive the enqueued scatter kernel
+            torch.cuda.current_stream(dev).synchronize()
+
+    # -- sample ----------------------------------------------------------------
+    def _draw_host_indices(self, batch_size: int) -> np.ndarray:
+        return np.fromiter(random.sample(range(len(self)), batch_size), dtype=np.int64,
+                           count=batch_size)
+
+    def sample(self, batch_size: int) -> TransitionBatch:
+        """Uniform sample without replacement -> ``TransitionBatch`` on ``device_for_batches``
+        (tensor_based_replay_buffer.py:253-282, :290-400)."""
+        if batch_size > len(self):
+            raise ValueError(
+                f"Can't get a batch of size {batch_size} from a replay buffer with "
+                f"only {len(self)} elements")
+        z, arena = self._layout, self._arena
+        assert z is not None and arena is not None
+        dev = arena.device
+        B = int(batch_size)
+        A = z.max_actions
+
+        def new(shape, dtype):
+            return torch.empty(shape, dtype=dtype, device=dev)
+
+        state = new((B, z.state_dim), torch.float32)
+        action = new((B,) + z.action_shape, z.action_dtype)
+        reward = new((B,), z.reward_dtype)
+        term, trunc = new((B,), torch.bool), new((B,), torch.bool)
+        next_state = new((B, z.state_dim), torch.float32) if z.has_next_state else None
+        cost = new((B,), torch.float32) if z.has_cost else None
+        ca = cm = na = nm = None
+        if A and not self._is_action_continuous:
+            if self._has_curr_avail:
+                ca, cm = new((B, A, z.avail_dim), torch.float32), new((B, A), torch.bool)
+            if self._has_next_avail:
+                na, nm = new((B, A, z.avail_dim), torch.float32), new((B, A), torch.bool)
+        out = N.BatchOut()
+        out.state, out.action, out.reward = state.data_ptr(), action.data_ptr(), reward.data_ptr()
+        out.terminated, out.truncated = term.data_ptr(), trunc.data_ptr()
+        out.next_state, out.cost = N.ptr(next_state), N.ptr(cost)
+        out.curr_avail, out.curr_mask = N.ptr(ca), N.ptr(cm)
+        out.next_avail, out.next_mask = N.ptr(na), N.ptr(nm)
+        if B > 0:
+            if self.sampler == "python":
+                arena.gather(self._draw_host_indices(B), out)
+            else:
+                arena.sample(random.getrandbits(64), 0, B, out)
+        shape_s = (B,) + z.state_shape if len(z.state_shape) else (B, 1)
+        batch = TransitionBatch(
+            state=state.view(shape_s), action=action, reward=reward, terminated=term,
+            truncated=trunc,
+            next_state=None if next_state is None else next_state.view(shape_s),
+            curr_available_actions=ca, curr_unavailable_actions_mask=cm,
+            next_available_actions=na, next_unavailable_actions_mask=nm, cost=cost)
+        if self._device_for_batches != dev and self._device_for_batches.type != "cuda":
+            batch = batch.to(self._device_for_batches)
+        return batch
+
+
+class BasicReplayBuffer(TensorBasedReplayBuffer):
+    """Plain FIFO replay buffer (pearl/replay_buffers/basic_replay_buffer.py:17-48)."""
+
+    def __init__(self, capacity: int, sampler: str = "device", staging_rows: int = 0) -> None:
+        super().__init__(capacity, sampler=sampler, staging_rows=staging_rows)
