@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: learner transitions/sec through PolicyLearner.learn() for the DQN of
+BASELINE.json config 2 (128-dim obs, 16 discrete actions, hidden [256,256], replay 1M, B=1024).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one round of learn(): device-side sample + gather(+one-hot) + learn_batch on one
+batch of 1024 transitions that are already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+S, A, HIDDEN, N_REPLAY, B = 128, 16, [256, 256], 1_000_000, 1024
+# Algorithmic work:
+FLOP_PER_TRANSITION_STEP = 2.713e6          # whole learn step, one-hot-structured layer 1
+FLOP_TARGET_KERNEL_PER_TRANSITION = (2 * A * 256 * 256 + 2 * A * 256)   # layer 2 + layer 3 of the target net
+PEAK_F32_MFMA = 157.3e12                    # MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def space(n):
+    from pearl_amd import DiscreteActionSpace
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+def fill_arena(rb, dev, seed):
+    """SURVEY.md §8(d) cfg2 inputs: transition i = (S[i], i % 16, float(i % 7), i % 50 == 0,
+    False, S[i+1]), generated on the device and ingested with push_many."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    chunk = 250_000
+    prev_last = torch.randn(1, S, device=dev, generator=g)
+    for c in range(0, N_REPLAY, chunk):
+        n = min(chunk, N_REPLAY - c)
+        st = torch.cat([prev_last, torch.randn(n, S, device=dev, generator=g)])
+        ids = torch.arange(c, c + n, device=dev)
+        rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                     terminated=(ids % 50 == 0),
+                     truncated=torch.zeros(n, dtype=torch.bool, device=dev), next_state=st[1:],
+                     curr_available_actions=space(A), next_available_actions=space(A),
+                     max_number_actions=A)
+        prev_last = st[-1:].clone()
+
+
+def cpu_baseline(budget_s: float = 20.0):
+    """The oracle (reference-pinned CPU restatement, same deque/cat/MKL cost structure as the
+    reference) on the host cores, bounded sample of the same workload."""
+    from oracle.pearl_oracle import DqnOracle, ReplayOracle, PARAM_KEYS
+    from pearl_amd import DeepQLearning, OneHotActionTensorRepresentationModule
+    torch.manual_seed(0)
+    random.seed(0)
+    n = 50_000
+    states = torch.randn(n + 1, S)
+    rb = ReplayOracle(n)
+    t0 = time.perf_counter()
+    for i in range(n):
+        rb.push(states[i], torch.tensor([i % A]), float(i % 7), i % 50 == 0, False, A, states[i + 1],
+                A, A)
+    fill_s = time.perf_counter() - t0
+    pl = DeepQLearning(state_dim=S, action_space=space(A), hidden_dims=HIDDEN, batch_size=B,
+                       action_representation_module=OneHotActionTensorRepresentationModule(A))
+    orc = DqnOracle({k: v for k, v in pl._Q.state_dict().items()},
+                    {k: v for k, v in pl._Q_target.state_dict().items()})
+    orc.learn(rb, 3, B, A)  # warm-up
+    steps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        orc.learn(rb, 10, B, A)
+        steps += 10
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "transitions/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} learn steps (sample+preprocess+learn_batch, B={B}) on a {n}-entry "
+                      f"deque replay, {dt:.1f}s; fill {n / fill_s:.0f} push/s; "
+                      f"os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timing-level", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from pearl_amd import (BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule,
+                           PearlAgent, _native as N)
+    import ctypes as C
+
+    torch.manual_seed(0)          # identical initial parameters on every rank
+    random.seed(1000 + rank)      # rank-private sampling stream
+    pl = DeepQLearning(state_dim=S, action_space=space(A), hidden_dims=HIDDEN,
+                       training_rounds=args.warmup, batch_size=B,
+                       action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = BasicReplayBuffer(N_REPLAY, sampler="device")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=local_rank)
+    fill_arena(rb, dev, seed=rank)          # rank-private shard, resident in HBM
+    assert len(rb) == N_REPLAY
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    if args.warmup > 0:
+        agent.learn()
+    pl._training_rounds = args.steps
+    nat = pl._ensure_bound(B, A)
+    N.check(N.lib().pa_dqn_enable_timing(nat.handle, args.timing_level))
+    barrier()
+    t0 = time.perf_counter()
+    report = agent.learn()          # exactly `steps` rounds; returns after its single host sync
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
+
+    timers = {}
+    for name in ("target", "target_l1", "gather", "online_fwd", "head", "backward", "adamw",
+                 "soft_update"):
+        ms, cnt = C.c_double(), C.c_int64()
+        N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            timers[name] = {"avg_us": ms.value * 1e3, "n": cnt.value}
+    N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
+
+    if rank == 0:
+        value = B * args.steps * world / dt
+        line = {
+            "metric": "learner transitions/sec (DQN batch=1024, [256,256] MLP)",
+            "value": value, "unit": "transitions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: DeepQLearning synthetic 128-dim obs / "
+                                   "16 discrete actions, hidden=[256,256], replay 1M, batch=1024",
+                       "global_batch": B * world, "per_gpu_batch": B, "replay_per_gpu": N_REPLAY,
+                       "sampler": "device (Philox, without replacement)",
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "final_loss": report["loss"][-1]},
+        }
+        if "target" in timers:
+            dur = timers["target"]["avg_us"] * 1e-6
+            ach = FLOP_TARGET_KERNEL_PER_TRANSITION * B / dur
+            line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<2,2>",
+                                "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
+                                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                                "avg_launch_us": timers["target"]["avg_us"],
+                                "launches_timed": timers["target"]["n"],
+                                "step_frac": FLOP_PER_TRANSITION_STEP * B * args.steps / dt / PEAK_F32_MFMA}
+        if len(timers) > 1:
+            line["stage_us"] = {k: round(v["avg_us"], 2) for k, v in timers.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

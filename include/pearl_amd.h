@@ -268,9 +268,24 @@ int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* st
 
 /* Kernel timing of the last pa_dqn_learn / pa_dqn_step when timing is enabled
  * (HIP events on the launch stream; used by bench.py's roofline block). */
-int pa_dqn_enable_timing(pa_dqn* h, int32_t on);
-/* names: "gather","target","online_fwd","head","backward","adamw" -> avg ms, count */
+/* level 0: off; 1: only the dominant kernel ("target"); 2: every stage.  Resets the counters. */
+int pa_dqn_enable_timing(pa_dqn* h, int32_t level);
+/* names: "target", "target_l1", "gather", "online_fwd", "head", "backward", "adamw",
+ * "soft_update", "step", "learn" -> average milliseconds and sample count */
 int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* count);
+
+/* ------------------------------------------------------------------------ */
+/* Diagnostics: single-kernel entry points so the GPU test-suite can localise */
+/* a parity failure to one kernel (no reference counterpart).                 */
+/* ------------------------------------------------------------------------ */
+/* C[M,N] = epi(A[M,K] * op(B)).  b_is_kn = 0: B is [N,K] (y = x W^T); 1: B is [K,N].
+ * epi: 0 = +bias, 1 = relu(+bias), 2 = * (hmask > 0). */
+int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
+                    int32_t ldc, const float* bias, const float* hmask, int32_t ldh, int32_t M,
+                    int32_t N, int32_t K, int32_t b_is_kn, int32_t epi, void* stream);
+/* dW[M,N] = dZ[Bn,M]^T X[Bn,N], db[M] = column sums of dZ. */
+int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx, float* dW,
+                         int32_t ldw, float* db, int32_t M, int32_t N, int32_t Bn, void* stream);
 
 #ifdef __cplusplus
 }

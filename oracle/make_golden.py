@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REAL reference (facebookresearch/Pearl at
+/root/reference, CPU) on seeded synthetic data and writes tests/golden/*.pt.
+
+TEST INFRASTRUCTURE ONLY.  Run in the build container (the reference does not travel to the
+GPU box):
+
+    python oracle/make_golden.py            # needs /root/reference; uses oracle/gymstub
+
+Each fixture pins, for one configuration of SURVEY.md §8(d):
+  * the replay contract  — what `BasicReplayBuffer.sample()` returns for a known index list
+                           (tensor_based_replay_buffer.py:253-400), before and after
+                           `preprocess_batch` (policy_learner.py:197-218);
+  * the learner numerics — Q(s,a), max_a' Q_target(s',a'), Bellman target, MSE loss, gradients
+                           of one batch, and the parameter / optimizer / target-network state
+                           after `training_rounds` steps of `DeepQLearning.learn()` together with
+                           the per-step reported losses and the index lists it drew.
+"""
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("PEARL_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "gymstub"))
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+from pearl.action_representation_modules.one_hot_action_representation_module import (  # noqa: E402
+    OneHotActionTensorRepresentationModule,
+)
+from pearl.policy_learners.sequential_decision_making.deep_q_learning import DeepQLearning  # noqa: E402
+from pearl.replay_buffers import BasicReplayBuffer  # noqa: E402
+from pearl.utils.instantiations.spaces.discrete_action import DiscreteActionSpace  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+CONFIGS = {
+    # name: S, A, hidden, N (buffer fill), B, rounds, dynamic action spaces
+    "tiny": dict(S=6, A=3, hidden=[16, 24], N=40, B=8, rounds=12, dynamic=False),
+    "tiny_dynamic": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=True),
+    "cfg1_cartpole_shape": dict(S=4, A=2, hidden=[64, 64], N=600, B=128, rounds=12, dynamic=False),
+    "cfg2_shape_small_batch": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=12,
+                                   dynamic=False),
+}
+
+
+def synthetic_transitions(cfg, gen):
+    """states randn(N+1,S); transition i = (S[i], i % A, float(i % 7),
+    i % 50 == 0, False, S[i+1])."""
+    S, A, N = cfg["S"], cfg["A"], cfg["N"]
+    states = torch.randn(N + 1, S, generator=gen)
+    rows = []
+    for i in range(N):
+        n_curr = n_next = A
+        if cfg["dynamic"]:
+            n_curr = 1 + (i * 7) % A
+            n_next = 1 + (i * 3 + 1) % A
+        rows.append(dict(i=i, action=i % n_curr, reward=float(i % 7), terminated=(i % 50 == 0),
+                         truncated=(i % 13 == 5), n_curr=n_curr, n_next=n_next))
+    return states, rows
+
+
+def space(n):
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+def clone_sd(module):
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def batch_to_dict(batch):
+    out = {}
+    for k in ("state", "action", "reward", "terminated", "truncated", "next_state",
+              "curr_available_actions", "curr_unavailable_actions_mask",
+              "next_available_actions", "next_unavailable_actions_mask"):
+        v = getattr(batch, k)
+        out[k] = None if v is None else v.detach().clone()
+    return out
+
+
+def make(name, cfg):
+    torch.manual_seed(0)
+    random.seed(0)
+    gen = torch.Generator().manual_seed(1234)
+    S, A, B = cfg["S"], cfg["A"], cfg["B"]
+    states, rows = synthetic_transitions(cfg, gen)
+
+    rep = OneHotActionTensorRepresentationModule(A)
+    torch.manual_seed(7)  # the learner's parameter init
+    pl = DeepQLearning(state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
+                       training_rounds=cfg["rounds"], batch_size=B,
+                       action_representation_module=rep)
+    rb = BasicReplayBuffer(cfg["N"] + 10)
+    rb._is_action_continuous = False
+    rb.device_for_batches = torch.device("cpu")
+    for r in rows:
+        rb.push(state=states[r["i"]], action=torch.tensor([r["action"]]), reward=r["reward"],
+                terminated=r["terminated"], truncated=r["truncated"],
+                curr_available_actions=space(r["n_curr"]), next_state=states[r["i"] + 1],
+                next_available_actions=space(r["n_next"]), max_number_actions=A)
+
+    fx = {"config": dict(cfg), "states": states,
+          "rows": {k: torch.tensor([r[k] for r in rows]) for k in
+                   ("action", "reward", "terminated", "truncated", "n_curr", "n_next")}}
+
+    # ---- replay contract for a known index list
+    random.seed(11)
+    idx = random.sample(range(len(rb)), B)
+    random.seed(11)
+    raw = rb.sample(B)
+    fx["sample_seed"] = 11
+    fx["sample_idx"] = torch.tensor(idx)
+    fx["batch_raw"] = batch_to_dict(raw)
+    batch = pl.preprocess_batch(raw)
+    fx["batch_pre"] = batch_to_dict(batch)
+
+    # ---- one-batch numerics (no parameter change)
+    fx["params0"] = clone_sd(pl._Q)
+    fx["target0"] = clone_sd(pl._Q_target)
+    q = pl._Q.get_q_values(batch.state, batch.action)
+    next_v = pl.get_next_state_values(batch, B)
+    loss, target = pl.loss(batch, q)
+    pl._optimizer.zero_grad()
+    loss.backward()
+    fx["q"] = q.detach().clone()
+    fx["next_v"] = next_v.detach().clone()
+    fx["target"] = target.detach().clone()
+    fx["mse"] = loss.detach().clone()
+    fx["mean_abs_td"] = (q - target).abs().mean().detach().clone()
+    fx["grads"] = {k: p.grad.detach().clone() for k, p in pl._Q.named_parameters()}
+    pl._optimizer.zero_grad()
+
+    # ---- learn(): rounds steps with python-sampled indices
+    random.seed(23)
+    fx["learn_seed"] = 23
+    fx["learn_idx"] = torch.tensor([random.sample(range(len(rb)), B) for _ in range(cfg["rounds"])])
+    random.seed(23)
+    report = pl.learn(rb)
+    fx["learn_losses"] = torch.tensor(report["loss"])
+    fx["params_after"] = clone_sd(pl._Q)
+    fx["target_after"] = clone_sd(pl._Q_target)
+    fx["training_steps_after"] = pl._training_steps
+    opt_state = {}
+    for k, p in pl._Q.named_parameters():
+        st = pl._optimizer.state[p]
+        opt_state[k] = {n: st[n].detach().clone() for n in
+                        ("step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")}
+    fx["opt_after"] = opt_state
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"dqn_{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); "
+          f"losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")
+
+
+def main():
+    for name, cfg in CONFIGS.items():
+        make(name, cfg)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,281 @@
+"""CPU restatement of the reference's replay + DQN learner hot path.
+
+TEST INFRASTRUCTURE ONLY — the checker, never the product.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this file; pearl_amd/ must not (and does not).
+
+It restates, in plain PyTorch fp32 on the CPU, what these reference functions compute
+(file:line under /root/reference), with the same data structures on the replay side (a deque of
+per-transition one-row tensors, `random.sample`, `torch.cat` collation) so that it is also a fair
+CPU baseline of the reference's cost structure:
+
+  ReplayOracle.push            pearl/replay_buffers/tensor_based_replay_buffer.py:55-133,
+                               :143-177, :179-251; basic_replay_buffer.py:21-48
+  ReplayOracle.sample          tensor_based_replay_buffer.py:253-282 (random.sample on the deque)
+  ReplayOracle.collate         tensor_based_replay_buffer.py:290-400
+  one_hot / preprocess         action_representation_modules/one_hot_action_representation_module
+                               .py:27-34; policy_learners/policy_learner.py:197-218
+  DqnOracle.q_values           neural_networks/sequential_decision_making/q_value_networks.py:152-174
+                               (+ extend_state_feature.py:12-47, common/utils.py:75-152)
+  DqnOracle.next_state_values  policy_learners/sequential_decision_making/deep_q_learning.py:130-167
+  DqnOracle.bellman_target     deep_td_learning.py:313-317
+  DqnOracle.gradients          autograd of MSELoss(mean) through the MLP (deep_td_learning.py:319-355),
+                               written out by hand
+  DqnOracle.adamw              deep_td_learning.py:183-185 -> torch.optim.AdamW(amsgrad=True), i.e.
+                               torch/optim/adam.py::_single_tensor_adam op for op
+  DqnOracle.soft_update        neural_networks/common/utils.py:214-226
+  DqnOracle.learn_batch        deep_td_learning.py:269-290, :333-360
+  DqnOracle.learn              policy_learners/policy_learner.py:162-195
+
+Parity is PINNED: tests/test_oracle_golden.py checks every function here against fixtures minted by
+running the real reference (oracle/make_golden.py -> tests/golden/dqn_*.pt).
+
+`philox_sample_indices` restates the *device* sampler of pearl_amd (arena.hip) — that one has no
+reference counterpart (the reference uses Python's MT19937); it pins the kernel to its own spec.
+"""
+from __future__ import annotations
+
+import math
+import random
+from collections import deque
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+F32 = torch.float32
+
+
+# --------------------------------------------------------------------------------------
+# replay
+# --------------------------------------------------------------------------------------
+def padded_actions_and_mask(max_number_actions: int, n: int, actions_batch: torch.Tensor):
+    """(A, d) float32 table whose first n rows are the available actions, and the (A,) bool mask
+    that is True for the padding rows."""
+    table = torch.zeros((max_number_actions, actions_batch.shape[1]), dtype=F32)
+    table[:n] = actions_batch
+    mask = torch.zeros(max_number_actions, dtype=torch.bool)
+    mask[n:] = True
+    return table, mask
+
+
+class ReplayOracle:
+    FIELDS = ("state", "action", "reward", "terminated", "truncated", "next_state",
+              "curr_available_actions", "curr_unavailable_actions_mask",
+              "next_available_actions", "next_unavailable_actions_mask")
+
+    def __init__(self, capacity: int) -> None:
+        self.memory: deque = deque([], maxlen=capacity)
+
+    def __len__(self) -> int:
+        return len(self.memory)
+
+    def push(self, state, action, reward, terminated, truncated, n_curr: int, next_state,
+             n_next: int, max_number_actions: int) -> None:
+        """Discrete index actions 0..n-1 as (n, 1) tables, like DiscreteActionSpace of
+        tensor([k]) elements."""
+        ca, cm = padded_actions_and_mask(max_number_actions, n_curr,
+                                         torch.arange(n_curr, dtype=F32).view(-1, 1))
+        na, nm = padded_actions_and_mask(max_number_actions, n_next,
+                                         torch.arange(n_next, dtype=F32).view(-1, 1))
+        self.memory.append(dict(
+            state=state.clone().detach().unsqueeze(0),
+            action=action.clone().detach().unsqueeze(0),
+            reward=torch.tensor([reward]),
+            terminated=torch.tensor([terminated]),
+            truncated=torch.tensor([truncated]),
+            next_state=next_state.clone().detach().unsqueeze(0),
+            curr_available_actions=ca.unsqueeze(0), curr_unavailable_actions_mask=cm.unsqueeze(0),
+            next_available_actions=na.unsqueeze(0), next_unavailable_actions_mask=nm.unsqueeze(0)))
+
+    @staticmethod
+    def collate(rows: Sequence[dict]) -> Dict[str, torch.Tensor]:
+        out = {k: torch.cat([r[k] for r in rows]) for k in ReplayOracle.FIELDS}
+        out["state"] = out["state"].type(F32)
+        out["next_state"] = out["next_state"].type(F32)
+        return out
+
+    def sample(self, batch_size: int) -> Dict[str, torch.Tensor]:
+        if batch_size > len(self):
+            raise ValueError(f"Can't get a batch of size {batch_size} from a replay buffer with "
+                             f"only {len(self)} elements")
+        return self.collate(random.sample(self.memory, batch_size))
+
+    def sample_at(self, logical_indices: Sequence[int]) -> Dict[str, torch.Tensor]:
+        return self.collate([self.memory[int(i)] for i in logical_indices])
+
+
+def one_hot(x: torch.Tensor, n: int) -> torch.Tensor:
+    if x.ndim == 1:
+        x = x.unsqueeze(-1)
+    return torch.nn.functional.one_hot(x.long(), num_classes=n).squeeze(dim=-2).float()
+
+
+def preprocess(batch: Dict[str, torch.Tensor], n_actions: int) -> Dict[str, torch.Tensor]:
+    out = dict(batch)
+    out["action"] = one_hot(batch["action"], n_actions)
+    for k in ("curr_available_actions", "next_available_actions"):
+        if batch.get(k) is not None:
+            out[k] = one_hot(batch[k], n_actions)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# learner
+# --------------------------------------------------------------------------------------
+PARAM_KEYS = ("_model.0.0.weight", "_model.0.0.bias", "_model.1.0.weight", "_model.1.0.bias",
+              "_model.2.0.weight", "_model.2.0.bias")
+
+
+class DqnOracle:
+    """Two-hidden-layer VanillaQValueNetwork + target copy + AdamW(amsgrad), fp32 on the CPU."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor],
+                 gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.01, tau: float = 0.75, target_update_freq: int = 10):
+        self.p = {k: params[k].detach().clone().to(F32) for k in PARAM_KEYS}
+        self.t = {k: target[k].detach().clone().to(F32) for k in PARAM_KEYS}
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.vmax = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.gamma, self.lr, self.betas, self.eps = gamma, lr, betas, eps
+        self.weight_decay, self.tau, self.freq = weight_decay, tau, target_update_freq
+        self.adam_step = 0
+        self.training_steps = 0
+
+    # -- forward pieces
+    @staticmethod
+    def _mlp(w: Dict[str, torch.Tensor], x: torch.Tensor):
+        z1 = x @ w[PARAM_KEYS[0]].t() + w[PARAM_KEYS[1]]
+        h1 = torch.clamp_min(z1, 0)
+        z2 = h1 @ w[PARAM_KEYS[2]].t() + w[PARAM_KEYS[3]]
+        h2 = torch.clamp_min(z2, 0)
+        q = h2 @ w[PARAM_KEYS[4]].t() + w[PARAM_KEYS[5]]
+        return h1, h2, q.squeeze(-1)
+
+    def q_values(self, state: torch.Tensor, action_rep: torch.Tensor) -> torch.Tensor:
+        return self._mlp(self.p, torch.cat([state, action_rep], dim=-1))[2]
+
+    def next_state_values(self, next_state, next_avail_rep, next_mask) -> torch.Tensor:
+        B, A, _ = next_avail_rep.shape
+        s = next_state.unsqueeze(1).expand(B, A, next_state.shape[1])
+        q = self._mlp(self.t, torch.cat([s, next_avail_rep], dim=-1))[2]  # (B, A)
+        q = q.clone()
+        q[next_mask] = -float("inf")
+        return q.max(1)[0]
+
+    def bellman_target(self, batch) -> torch.Tensor:
+        nv = self.next_state_values(batch["next_state"], batch["next_available_actions"],
+                                    batch["next_unavailable_actions_mask"])
+        return nv * self.gamma * (1 - batch["terminated"].float()) + batch["reward"]
+
+    # -- backward, by hand
+    def gradients(self, batch, target: torch.Tensor, scale: float = 1.0):
+        x = torch.cat([batch["state"], batch["action"]], dim=-1)
+        h1, h2, q = self._mlp(self.p, x)
+        B = q.shape[0]
+        dq = (2.0 / B) * scale * (q - target)                      # d mean((q - y)^2) / dq
+        g = {}
+        g[PARAM_KEYS[4]] = (dq.unsqueeze(0) @ h2)                  # (1, H2)
+        g[PARAM_KEYS[5]] = dq.sum().reshape(1)
+        dz2 = (dq.unsqueeze(1) * self.p[PARAM_KEYS[4]]) * (h2 > 0)
+        g[PARAM_KEYS[2]] = dz2.t() @ h1
+        g[PARAM_KEYS[3]] = dz2.sum(0)
+        dz1 = (dz2 @ self.p[PARAM_KEYS[2]]) * (h1 > 0)
+        g[PARAM_KEYS[0]] = dz1.t() @ x
+        g[PARAM_KEYS[1]] = dz1.sum(0)
+        return q, g
+
+    def adamw(self, grads: Dict[str, torch.Tensor]) -> None:
+        self.adam_step += 1
+        t = self.adam_step
+        b1, b2 = self.betas
+        bc1 = 1 - b1 ** t
+        bc2 = 1 - b2 ** t
+        step_size = self.lr / bc1
+        bc2_sqrt = bc2 ** 0.5
+        for k in PARAM_KEYS:
+            p, g = self.p[k], grads[k]
+            p.mul_(1 - self.lr * self.weight_decay)
+            self.m[k].lerp_(g, 1 - b1)
+            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            torch.maximum(self.vmax[k], self.v[k], out=self.vmax[k])
+            denom = (self.vmax[k].sqrt() / bc2_sqrt).add_(self.eps)
+            p.addcdiv_(self.m[k], denom, value=-step_size)
+
+    def soft_update(self) -> None:
+        for k in PARAM_KEYS:
+            self.t[k].copy_(self.tau * self.p[k] + (1.0 - self.tau) * self.t[k])
+
+    def learn_batch(self, batch) -> float:
+        """`batch` is preprocessed (one-hot actions).  Returns mean |Q - target|."""
+        if (self.training_steps + 1) % self.freq == 0:
+            self.soft_update()
+        target = self.bellman_target(batch)
+        q, g = self.gradients(batch, target)
+        self.adamw(g)
+        return float((q - target).abs().mean())
+
+    def learn(self, replay: ReplayOracle, rounds: int, batch_size: int, n_actions: int,
+              index_lists: Optional[Sequence[Sequence[int]]] = None) -> List[float]:
+        losses = []
+        for r in range(rounds):
+            self.training_steps += 1
+            raw = replay.sample(batch_size) if index_lists is None else replay.sample_at(index_lists[r])
+            losses.append(self.learn_batch(preprocess(raw, n_actions)))
+        return losses
+
+
+# --------------------------------------------------------------------------------------
+# device sampler spec (no reference counterpart)
+# --------------------------------------------------------------------------------------
+_M0, _M1, _W0, _W1 = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85
+_U32 = 0xFFFFFFFF
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    for _ in range(10):
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & _U32, p1 & _U32, ((p0 >> 32) ^ c3 ^ k1) & _U32, p0 & _U32
+        k0 = (k0 + _W0) & _U32
+        k1 = (k1 + _W1) & _U32
+    return c0, c1, c2, c3
+
+
+def _bounded(words, n):
+    thresh = ((1 << 32) - n) % n
+    m = 0
+    for w in words:
+        m = w * n
+        if (m & _U32) >= thresh:
+            break
+    return m >> 32
+
+
+def philox_sample_indices(population: int, seed: int, offset: int, B: int) -> np.ndarray:
+    """The rule of arena.hip::sample_indices_kernel: in round t every unresolved position i
+    proposes draw(philox(i, t, offset; seed)); a proposal wins iff its value was not accepted in
+    an earlier round and i is the lowest position proposing it in this round."""
+    k0, k1 = seed & _U32, (seed >> 32) & _U32
+    o0, o1 = offset & _U32, (offset >> 32) & _U32
+    out = np.full(B, -1, dtype=np.int64)
+    taken = set()
+    pending = list(range(B))
+    t = 0
+    while pending:
+        proposals = {}
+        for i in pending:
+            v = _bounded(philox4x32_10(i, t, o0, o1, k0, k1), population)
+            proposals.setdefault(v, []).append(i)
+        nxt = []
+        for v, who in proposals.items():
+            if v in taken:
+                nxt.extend(who)
+                continue
+            w = min(who)
+            out[w] = v
+            taken.add(v)
+            nxt.extend(i for i in who if i != w)
+        pending = sorted(nxt)
+        t += 1
+    return out

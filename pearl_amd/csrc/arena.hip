@@ -344,7 +344,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_indices_kernel(
       val[q] = v;
       const unsigned long long entry = ((unsigned long long)v << 32) | (t << 16) | i;
       uint32_t h = (v * 0x9E3779B1u) & mask;
-      while (true) {
+      for (int probe = 0; probe < hs; ++probe) {  // the table is never more than half full
         const unsigned long long old = atomicCAS(&table[h], EMPTY_ENTRY, entry);
         if (old == EMPTY_ENTRY) break;
         if ((uint32_t)(old >> 32) == v) {
@@ -364,7 +364,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void sample_indices_kernel(
       const uint32_t i = tid + q * SAMPLE_THREADS;
       const uint32_t v = val[q];
       uint32_t h = (v * 0x9E3779B1u) & mask;
-      while ((uint32_t)(table[h] >> 32) != v) h = (h + 1) & mask;
+      for (int probe = 0; probe < hs && (uint32_t)(table[h] >> 32) != v; ++probe)
+        h = (h + 1) & mask;
       const unsigned long long e = table[h];
       if ((uint32_t)(e & 0xFFFFu) == i && (uint32_t)((e >> 16) & 0xFFFFu) == t) {
         done[q] = true;

@@ -55,7 +55,7 @@ struct pa_dqn {
   hipStream_t side;
   hipEvent_t fork;
   // timing
-  bool timing;
+  int timing;  // 0 off, 1 dominant kernel only, 2 every stage
   std::vector<Timer> timers;
 };
 
@@ -87,8 +87,9 @@ struct ScopedTimer {
   Timer* t;
   hipStream_t s;
   bool active;
-  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_) : h(h_), t(nullptr), s(s_), active(false) {
-    if (!h->timing) return;
+  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_, int level = 2)
+      : h(h_), t(nullptr), s(s_), active(false) {
+    if (h->timing < level) return;
     t = find_timer(h, name);
     if (t->used + 2 > 2 * kMaxTimedPairs) return;
     while (t->ev.size() < t->used + 2) {
@@ -213,7 +214,7 @@ int run_target(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStr
     if (rc != PA_OK) return rc;
   }
   {
-    ScopedTimer tm(h, "target", s);
+    ScopedTimer tm(h, "target", s, 1);
     TargetArgs a;
     memset(&a, 0, sizeof(a));
     a.U = h->U; a.ldu = d.hidden1;
@@ -451,7 +452,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   memset(&h->bufs, 0, sizeof(h->bufs));
   h->IN = desc->state_dim + desc->action_dim;
   param_layout(desc->state_dim, desc->action_dim, desc->hidden1, desc->hidden2, h->off, &h->P);
-  h->timing = false;
+  h->timing = 0;
   h->bb_A = 0;
   memset(h->bb, 0, sizeof(h->bb));
   h->side = nullptr;
@@ -673,7 +674,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
 
 extern "C" int pa_dqn_enable_timing(pa_dqn* h, int32_t on) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
-  h->timing = on != 0;
+  h->timing = on < 0 ? 0 : on;
   for (auto& t : h->timers) t.used = 0;
   return PA_OK;
 }
@@ -697,5 +698,43 @@ extern "C" int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, in
     *avg_ms = n ? total / (double)n : 0.0;
     return PA_OK;
   }
+  return PA_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------
+extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
+                               int32_t ldc, const float* bias, const float* hmask, int32_t ldh,
+                               int32_t M, int32_t N, int32_t K, int32_t b_is_kn, int32_t epi,
+                               void* stream) {
+  PA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0, PA_ERR_INVALID, "pa_debug_linear: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A; g.lda = lda; g.Bm = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.bias = bias; g.Hmask = hmask; g.ldh = ldh; g.M = M; g.N = N; g.K = K;
+  if (!b_is_kn && epi == EPI_BIAS) return launch_linear<false, EPI_BIAS>(g, s);
+  if (!b_is_kn && epi == EPI_BIAS_RELU) return launch_linear<false, EPI_BIAS_RELU>(g, s);
+  if (b_is_kn && epi == EPI_MASK) return launch_linear<true, EPI_MASK>(g, s);
+  set_error("pa_debug_linear: combination (b_is_kn=%d, epi=%d) is not instantiated", b_is_kn, epi);
+  return PA_ERR_UNSUPPORTED;
+}
+
+extern "C" int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
+                                    float* dW, int32_t ldw, float* db, int32_t M, int32_t N,
+                                    int32_t Bn, void* stream) {
+  PA_REQUIRE(dZ && X && dW && db && M > 0 && N > 0 && Bn > 0, PA_ERR_INVALID,
+             "pa_debug_weight_grad: bad argument");
+  DwArgs a;
+  memset(&a, 0, sizeof(a));
+  a.p[0].dZ = dZ; a.p[0].ldz = ldz; a.p[0].X = X; a.p[0].ldx = ldx;
+  a.p[0].dW = dW; a.p[0].ldw = ldw; a.p[0].db = db; a.p[0].M = M; a.p[0].N = N;
+  a.p[0].tiles_n = (int)ceil_div(N, 32); a.p[0].tile0 = 0;
+  a.total_tiles = (int)ceil_div(M, 32) * a.p[0].tiles_n;
+  a.p[1].tile0 = a.total_tiles; a.p[1].tiles_n = 0;
+  a.B = Bn;
+  // no slab fold: launch exactly the GEMM tiles
+  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -1,0 +1,22 @@
+"""Shared builders for the parity tests (oracle side and pearl_amd side) from a golden fixture."""
+import torch
+
+from oracle.pearl_oracle import DqnOracle, ReplayOracle
+
+
+def fill_oracle_replay(fx) -> ReplayOracle:
+    cfg, rows, states = fx["config"], fx["rows"], fx["states"]
+    rb = ReplayOracle(cfg["N"] + 10)
+    for i in range(cfg["N"]):
+        rb.push(states[i], torch.tensor([int(rows["action"][i])]), float(rows["reward"][i]),
+                bool(rows["terminated"][i]), bool(rows["truncated"][i]), int(rows["n_curr"][i]),
+                states[i + 1], int(rows["n_next"][i]), cfg["A"])
+    return rb
+
+
+def oracle_learner(fx) -> DqnOracle:
+    return DqnOracle(fx["params0"], fx["target0"])
+
+
+def batch_pre_as_oracle_dict(fx):
+    return {k: v for k, v in fx["batch_pre"].items()}

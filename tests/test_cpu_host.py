@@ -1,0 +1,265 @@
+"""CPU: host logic, the C-ABI surface, and loud failure without a GPU.  No kernel runs here."""
+import ctypes as C
+import os
+import random
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import GOLDEN_NAMES, REPO
+
+
+# ---------------------------------------------------------------------------- C ABI
+def _header_functions():
+    text = open(os.path.join(REPO, "include", "pearl_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pearl_amd import _native as N
+    declared = _header_functions()
+    assert len(declared) >= 30
+    assert sorted(N.SIGNATURES) == declared          # the ctypes table mirrors the header
+    lib = N.lib()
+    for name in declared:
+        assert hasattr(lib, name), name              # ... and the .so exports all of it
+    assert lib.pa_abi_version() == 1
+    assert lib.pa_device_count() >= 0
+
+
+def test_ctypes_structs_match_c_layout(tmp_path):
+    from pearl_amd import _native as N
+    exe = tmp_path / "abi_probe"
+    subprocess.run(["gcc", "-std=c99", "-o", str(exe), os.path.join(REPO, "tests", "abi_probe.c")],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    facts = dict(line.rsplit(" ", 1) for line in out.strip().splitlines())
+    pairs = {"pa_arena_desc": N.ArenaDesc, "pa_transition": N.Transition, "pa_columns": N.Columns,
+             "pa_batch_out": N.BatchOut, "pa_dqn_desc": N.DqnDesc, "pa_dqn_buffers": N.DqnBuffers,
+             "pa_dqn_batch": N.DqnBatch, "pa_learn_args": N.LearnArgs}
+    for cname, ctype in pairs.items():
+        assert C.sizeof(ctype) == int(facts[cname]), cname
+    for key, value in facts.items():
+        if "." in key:
+            cname, member = key.split(".")
+            assert getattr(pairs[cname], member).offset == int(value), key
+
+
+def test_param_layout_matches_reference_network():
+    from pearl_amd import _native as N
+    lib = N.lib()
+    offs = (C.c_int64 * 6)()
+    assert lib.pa_dqn_param_offsets(128, 16, 256, 256, offs) == 0
+    assert list(offs) == [0, 36864, 37120, 102656, 102912, 103168]
+    assert lib.pa_dqn_param_count(128, 16, 256, 256) == 103172       # 103169 params + tail pad
+    assert lib.pa_dqn_param_offsets(5, 5, 24, 16, offs) == 0
+    assert all(o % 4 == 0 for o in offs)
+
+
+# ---------------------------------------------------------------------------- loud failure
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_gpu_no_fallback():
+    from pearl_amd import (BasicReplayBuffer, DeepQLearning, DiscreteActionSpace,
+                           OneHotActionTensorRepresentationModule, TransitionBatch, _native as N)
+    sp = DiscreteActionSpace([torch.tensor([k]) for k in range(3)])
+    rb = BasicReplayBuffer(10)
+    with pytest.raises(N.NativeError, match="no HIP device"):
+        rb.push(torch.zeros(4), torch.tensor([1]), 1.0, False, False, sp, torch.zeros(4), sp, 3)
+    pl = DeepQLearning(state_dim=4, action_space=sp, hidden_dims=[8, 8],
+                       action_representation_module=OneHotActionTensorRepresentationModule(3))
+    batch = TransitionBatch(state=torch.zeros(2, 4), action=torch.zeros(2, 3), reward=torch.zeros(2),
+                            next_state=torch.zeros(2, 4))
+    with pytest.raises(N.NativeError, match="no HIP device|no CPU"):
+        pl.learn_batch(batch)
+    # the raw ABI refuses too (no hidden host path below the python layer)
+    h = C.c_void_p()
+    desc = N.ArenaDesc(capacity=4, device=0, state_dim=4, action_elems=1, action_dtype=N.PA_I64,
+                       reward_dtype=N.PA_F32, max_actions=0, avail_dim=0, has_next_state=1)
+    assert N.lib().pa_arena_create(C.byref(h), C.byref(desc)) == N.PA_ERR_HIP
+    assert "no CPU fallback" in N.last_error()
+
+
+def test_unsupported_configurations_fail_loudly():
+    from pearl_amd import DeepQLearning, DiscreteActionSpace, OneHotActionTensorRepresentationModule
+    sp = DiscreteActionSpace([torch.tensor([k]) for k in range(3)])
+    rep = OneHotActionTensorRepresentationModule(3)
+    with pytest.raises(NotImplementedError):
+        DeepQLearning(state_dim=4, action_space=sp, hidden_dims=[8, 8, 8], action_representation_module=rep)
+    with pytest.raises(NotImplementedError):
+        DeepQLearning(state_dim=4, action_space=sp, hidden_dims=[8, 8], is_conservative=True,
+                      action_representation_module=rep)
+
+
+# ---------------------------------------------------------------------------- batch contract
+def test_transition_batch_defaults_and_checks():
+    """test/unit/with_pytorch/test_transition.py semantics."""
+    from pearl_amd import TransitionBatch
+    b = TransitionBatch(state=torch.zeros(3, 2), action=torch.zeros(3, 1), reward=torch.zeros(3))
+    assert b.terminated.dtype == torch.bool and b.terminated.all() and b.terminated.shape == (3,)
+    assert b.truncated.dtype == torch.bool and not b.truncated.any()
+    assert len(b) == 3 and b.device.type == "cpu"
+    with pytest.raises(AssertionError):
+        TransitionBatch(state=torch.zeros(3), action=torch.zeros(3), reward=torch.zeros(3))
+    with pytest.raises(AssertionError):
+        TransitionBatch(state=torch.zeros(3, 2), action=torch.zeros(3), reward=torch.zeros(4))
+    with pytest.raises(AssertionError):
+        TransitionBatch(state=torch.zeros(3, 2), action=torch.zeros(3), reward=torch.zeros(3),
+                        terminated=torch.zeros(2, dtype=torch.bool))
+    TransitionBatch(state=torch.zeros(3, 2), action=torch.zeros(3), reward=torch.zeros(3),
+                    terminated=torch.zeros(3, 1, dtype=torch.bool))
+    assert b.to(torch.device("cpu")) is b
+
+
+def test_padded_action_table_and_mask():
+    """test/unit/with_pytorch/test_dynamic_action_space.py:28-157: actions {0,2,4} of 5."""
+    from pearl_amd import DiscreteActionSpace
+    from pearl_amd.replay_buffers.basic_replay_buffer import create_action_tensor_and_mask
+    sp = DiscreteActionSpace([torch.tensor([0]), torch.tensor([2]), torch.tensor([4])])
+    table, mask = create_action_tensor_and_mask(5, sp)
+    assert torch.equal(table, torch.tensor([[0.], [2.], [4.], [0.], [0.]]))
+    assert torch.equal(mask, torch.tensor([False, False, False, True, True]))
+    assert create_action_tensor_and_mask(None, sp) == (None, None)
+    assert create_action_tensor_and_mask(5, None) == (None, None)
+
+
+def test_one_hot_module_on_host_matches_reference_formula():
+    from pearl_amd import OneHotActionTensorRepresentationModule
+    rep = OneHotActionTensorRepresentationModule(5)
+    x = torch.tensor([[[0.], [2.], [4.], [0.], [0.]]])
+    want = torch.tensor([[[1., 0, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 1], [1, 0, 0, 0, 0],
+                          [1, 0, 0, 0, 0]]])
+    assert torch.equal(rep(x), want)
+    assert torch.equal(rep(torch.tensor([3, 1])), torch.eye(5)[[3, 1]])
+    assert rep.representation_dim == rep.max_number_actions == 5
+    assert rep.compare(OneHotActionTensorRepresentationModule(5)) == ""
+    assert rep.compare(OneHotActionTensorRepresentationModule(4)) != ""
+
+
+# ---------------------------------------------------------------------------- learner host logic
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_same_seed_same_initial_parameters_as_reference(golden, name):
+    """Construction consumes torch's RNG like the reference, and state_dict keys are the
+    reference's (`_model.{0,1,2}.0.{weight,bias}`)."""
+    from pearl_amd import DeepQLearning, DiscreteActionSpace, OneHotActionTensorRepresentationModule
+    fx = golden(name)
+    cfg = fx["config"]
+    torch.manual_seed(7)
+    pl = DeepQLearning(state_dim=cfg["S"],
+                       action_space=DiscreteActionSpace([torch.tensor([k]) for k in range(cfg["A"])]),
+                       hidden_dims=cfg["hidden"], training_rounds=cfg["rounds"], batch_size=cfg["B"],
+                       action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    sd = pl._Q.state_dict()
+    assert list(sd) == list(fx["params0"])
+    for k in sd:
+        assert torch.equal(sd[k], fx["params0"][k]), k
+        assert torch.equal(pl._Q_target.state_dict()[k], fx["target0"][k]), k
+    g = pl._optimizer.param_groups[0]
+    assert (g["lr"], g["amsgrad"], g["weight_decay"], g["betas"], g["eps"]) == (
+        1e-3, True, 0.01, (0.9, 0.999), 1e-8)
+    assert (pl._discount_factor, pl._target_update_freq, pl._soft_update_tau) == (0.99, 10, 0.75)
+    assert pl.on_policy is False and pl._is_action_continuous is False
+
+
+class _FakeBuffer:
+    """A ReplayBuffer that is NOT an HBM arena -> exercises the generic learn() loop."""
+
+    def __init__(self, n):
+        self.n, self.asked = n, []
+
+    def __len__(self):
+        return self.n
+
+    def sample(self, batch_size):
+        from pearl_amd import TransitionBatch
+        self.asked.append(batch_size)
+        return TransitionBatch(state=torch.zeros(batch_size, 2), action=torch.zeros(batch_size, 1),
+                               reward=torch.zeros(batch_size), next_state=torch.zeros(batch_size, 2))
+
+
+def _counting_learner(**kw):
+    from pearl_amd.policy_learners.policy_learner import PolicyLearner
+
+    class L(PolicyLearner):
+        def __init__(self, **kw):
+            super().__init__(on_policy=False, is_action_continuous=True, **kw)
+            self.seen = []
+
+        def set_history_summarization_module(self, value):
+            self._history_summarization_module = value
+
+        def act(self, *a, **k):
+            raise NotImplementedError
+
+        def learn_batch(self, batch):
+            self.seen.append((self._training_steps, len(batch)))
+            return {"loss": float(len(self.seen)), "aux": 1}
+
+    return L(**kw)
+
+
+def test_generic_learn_loop_semantics():
+    """policy_learner.py:162-195: {} on empty buffer, batch-size clamp, dict of lists."""
+    pl = _counting_learner(training_rounds=3, batch_size=8)
+    assert pl.learn(_FakeBuffer(0)) == {}
+    buf = _FakeBuffer(5)
+    rep = pl.learn(buf)
+    assert buf.asked == [5, 5, 5]                      # len < batch_size -> whole buffer
+    assert rep == {"loss": [1.0, 2.0, 3.0], "aux": [1, 1, 1]}
+    assert [s for s, _ in pl.seen] == [1, 2, 3] and pl._training_steps == 3
+    pl2 = _counting_learner(training_rounds=2, batch_size=-1)
+    buf = _FakeBuffer(7)
+    pl2.learn(buf)
+    assert buf.asked == [7, 7]
+    pl3 = _counting_learner(training_rounds=1, batch_size=4)
+    buf = _FakeBuffer(9)
+    pl3.learn(buf)
+    assert buf.asked == [4]
+
+
+def test_target_update_schedule():
+    """forward() soft-updates when (_training_steps + 1) % freq == 0 (deep_td_learning.py:283)."""
+    from pearl_amd import DeepQLearning, DiscreteActionSpace, OneHotActionTensorRepresentationModule
+    sp = DiscreteActionSpace([torch.tensor([k]) for k in range(2)])
+    pl = DeepQLearning(state_dim=3, action_space=sp, hidden_dims=[4, 4], target_update_freq=10,
+                       action_representation_module=OneHotActionTensorRepresentationModule(2))
+    due = []
+    for ts in range(1, 31):
+        pl._training_steps = ts
+        if pl._target_update_due():
+            due.append(ts)
+    assert due == [9, 19, 29]
+
+
+# ---------------------------------------------------------------------------- data parallel (gloo)
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pearl_amd.policy_learners.sequential_decision_making.deep_q_learning import (
+        allreduce_sum_, world_size)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    assert world_size() == world
+    # what pa_dqn_step leaves in the flat buffer on each rank: local gradient / world
+    local = torch.arange(8, dtype=torch.float32) * (rank + 1) / world
+    out = allreduce_sum_(local.clone())
+    q.put((rank, out.tolist()))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_is_a_mean_over_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = (torch.arange(8, dtype=torch.float32) * (1 + 2) / 2).tolist()   # mean of g and 2g
+    assert results[0] == want and results[1] == want

@@ -1,0 +1,241 @@
+"""GPU: the HIP DQN learner against the reference-minted fixtures and the CPU oracle.
+
+Tolerances.  BASELINE.json's bar is Q-values within 1e-5 relative of the reference on identical
+batches; one-batch quantities are held to that.  Multi-step trajectories accumulate fp32
+summation-order differences (MKL vs the MFMA fma chain) through AdamW's 1/sqrt(v) — they are held
+to 1e-3 relative / 2e-5 absolute, the same bound the CPU oracle meets against the reference
+(tests/test_oracle_golden.py).
+"""
+import copy
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_NAMES
+from helpers import fill_oracle_replay, oracle_learner
+from oracle import pearl_oracle as O
+from test_gpu_replay import _space, fill_arena_buffer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_learner(fx, **kw):
+    from pearl_amd import DeepQLearning, OneHotActionTensorRepresentationModule
+    cfg = fx["config"]
+    args = dict(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
+                training_rounds=cfg["rounds"], batch_size=cfg["B"],
+                action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    args.update(kw)
+    pl = DeepQLearning(**args)
+    pl._Q.load_state_dict(fx["params0"])
+    pl._Q_target.load_state_dict(fx["target0"])
+    return pl.to(DEV)
+
+
+def batch_from(fx, which):
+    from pearl_amd import TransitionBatch
+    d = {k: (None if v is None else v.to(DEV)) for k, v in fx[which].items()}
+    return TransitionBatch(**d)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_q_values_and_targets(golden, name):
+    fx = golden(name)
+    pl = make_learner(fx)
+    out = pl.q_values_and_targets(batch_from(fx, "batch_pre"))
+    torch.testing.assert_close(out["q"].cpu(), fx["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["next_v"].cpu(), fx["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["target"].cpu(), fx["target"], rtol=1e-5, atol=1e-6)
+    nv = pl.get_next_state_values(batch_from(fx, "batch_pre"), fx["config"]["B"])
+    assert torch.equal(nv, out["next_v"])
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_learn_batch_gradients_and_first_step(golden, name):
+    """One learn_batch: reported loss, gradients (p.grad views of the flat buffer) and the
+    AdamW(amsgrad) step against the reference-pinned oracle."""
+    fx = golden(name)
+    pl = make_learner(fx)
+    orc = oracle_learner(fx)
+    rep = pl.learn_batch(batch_from(fx, "batch_pre"))
+    assert abs(rep["loss"] - float(fx["mean_abs_td"])) <= 1e-5 * max(1.0, float(fx["mean_abs_td"]))
+    for k, p in pl._Q.named_parameters():
+        want = fx["grads"][k]
+        torch.testing.assert_close(p.grad.cpu(), want, rtol=2e-4, atol=2e-6, msg=k)
+    loss = orc.learn_batch(fx["batch_pre"])
+    assert abs(rep["loss"] - loss) <= 1e-5 * max(1.0, loss)
+    sd = pl._Q.state_dict()
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(sd[k].cpu(), orc.p[k], rtol=1e-4, atol=2e-6, msg=k)
+        st = pl._optimizer.state[dict(pl._Q.named_parameters())[k]]
+        assert float(st["step"]) == 1.0
+        torch.testing.assert_close(st["exp_avg"].cpu(), orc.m[k], rtol=2e-4, atol=1e-7, msg=k)
+        torch.testing.assert_close(st["exp_avg_sq"].cpu(), orc.v[k], rtol=4e-4, atol=1e-9, msg=k)
+        torch.testing.assert_close(st["max_exp_avg_sq"].cpu(), orc.vmax[k], rtol=4e-4, atol=1e-9, msg=k)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_learn_trajectory_python_sampler(golden, name):
+    """learn(): `rounds` fused steps with the reference's own index stream (random.seed) ->
+    per-step losses, parameters, target network and optimizer state of the reference run."""
+    fx = golden(name)
+    cfg = fx["config"]
+    pl = make_learner(fx)
+    rb = fill_arena_buffer(fx, "python")
+    random.seed(fx["learn_seed"])
+    report = pl.learn(rb)
+    assert len(report["loss"]) == cfg["rounds"]
+    torch.testing.assert_close(torch.tensor(report["loss"]), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    assert pl._training_steps == fx["training_steps_after"]
+    sd, sdt = pl._Q.state_dict(), pl._Q_target.state_dict()
+    named = dict(pl._Q.named_parameters())
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(sd[k].cpu(), fx["params_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(sdt[k].cpu(), fx["target_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+        st, want = pl._optimizer.state[named[k]], fx["opt_after"][k]
+        assert float(st["step"]) == float(want["step"]) == cfg["rounds"]
+        torch.testing.assert_close(st["exp_avg"].cpu(), want["exp_avg"], rtol=1e-3, atol=1e-6, msg=k)
+        torch.testing.assert_close(st["exp_avg_sq"].cpu(), want["exp_avg_sq"], rtol=1e-3, atol=1e-8, msg=k)
+        torch.testing.assert_close(st["max_exp_avg_sq"].cpu(), want["max_exp_avg_sq"], rtol=1e-3,
+                                   atol=1e-8, msg=k)
+    # the global python RNG was consumed exactly like the reference's learn()
+    after = random.getstate()
+    random.seed(fx["learn_seed"])
+    for _ in range(cfg["rounds"]):
+        random.sample(range(cfg["N"]), cfg["B"])
+    assert random.getstate() == after
+
+
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape"])
+def test_generic_loop_equals_fused_loop(golden, name):
+    """sample() + preprocess_batch() + learn_batch() (API path, per-step .item()) and the fused
+    pa_dqn_learn path are the same computation: bitwise-equal parameters."""
+    from pearl_amd.policy_learners.policy_learner import PolicyLearner
+    fx = golden(name)
+    a, b = make_learner(fx), make_learner(fx)
+    rb = fill_arena_buffer(fx, "python")
+    random.seed(4)
+    ra = a.learn(rb)
+    random.seed(4)
+    rb_report = PolicyLearner.learn(b, rb)
+    assert ra["loss"] == rb_report["loss"]
+    for (k, pa), (_, pb) in zip(a._Q.state_dict().items(), b._Q.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    for (k, pa), (_, pb) in zip(a._Q_target.state_dict().items(), b._Q_target.state_dict().items()):
+        assert torch.equal(pa, pb), k
+
+
+def test_device_sampler_learn_matches_oracle(golden):
+    """Fast mode: Philox indices on the device; the oracle replays the same index lists."""
+    fx = golden("cfg1_cartpole_shape")
+    cfg = fx["config"]
+    pl = make_learner(fx)
+    rb = fill_arena_buffer(fx, "device")
+    random.seed(99)
+    key = random.getrandbits(64)
+    random.seed(99)
+    report = pl.learn(rb)
+    lists = [O.philox_sample_indices(cfg["N"], key, r, cfg["B"]).tolist() for r in range(cfg["rounds"])]
+    orc = oracle_learner(fx)
+    losses = orc.learn(fill_oracle_replay(fx), cfg["rounds"], cfg["B"], cfg["A"], index_lists=lists)
+    torch.testing.assert_close(torch.tensor(report["loss"]), torch.tensor(losses), rtol=2e-4, atol=1e-5)
+    sd = pl._Q.state_dict()
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(sd[k].cpu(), orc.p[k], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(pl._Q_target.state_dict()[k].cpu(), orc.t[k], rtol=1e-3, atol=2e-5, msg=k)
+
+
+def test_masked_actions_and_terminal_rows(golden):
+    """-inf masking (deep_q_learning.py:164) and the (1 - terminated) factor: all-but-one action
+    masked forces the max; terminated rows reduce the target to the reward."""
+    fx = golden("tiny_dynamic")
+    pl = make_learner(fx)
+    b = batch_from(fx, "batch_pre")
+    B, A = b.next_unavailable_actions_mask.shape
+    b.next_unavailable_actions_mask = torch.ones(B, A, dtype=torch.bool, device=DEV)
+    b.next_unavailable_actions_mask[:, 2] = False
+    b.terminated = torch.arange(B, device=DEV) % 2 == 0
+    out = pl.q_values_and_targets(b)
+    orc = oracle_learner(fx)
+    d = {k: (None if getattr(b, k) is None else getattr(b, k).cpu()) for k in
+         ("state", "action", "reward", "terminated", "next_state", "next_available_actions",
+          "next_unavailable_actions_mask")}
+    torch.testing.assert_close(out["next_v"].cpu(), orc.next_state_values(
+        d["next_state"], d["next_available_actions"], d["next_unavailable_actions_mask"]),
+        rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["target"].cpu(), orc.bellman_target(d), rtol=1e-5, atol=1e-6)
+    assert torch.equal(out["target"].cpu()[0::2], d["reward"][0::2])
+
+
+def test_default_next_actions_when_batch_has_none(golden):
+    """next_available_actions = None -> all actions of the learner's space
+    (deep_td_learning.py:362-416)."""
+    fx = golden("cfg1_cartpole_shape")
+    pl = make_learner(fx)
+    b = batch_from(fx, "batch_pre")
+    want = pl.q_values_and_targets(b)
+    b.next_available_actions = None
+    b.next_unavailable_actions_mask = None
+    got = pl.q_values_and_targets(b)
+    assert torch.equal(got["target"], want["target"])
+
+
+def test_state_dict_round_trip_and_rebind(golden):
+    """README checkpoint flow: state_dict -> fresh learner -> identical continuation."""
+    fx = golden("tiny")
+    a = make_learner(fx)
+    rb = fill_arena_buffer(fx, "python")
+    random.seed(1)
+    a.learn(rb)
+    b = make_learner(fx)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
+    b._optimizer.load_state_dict(copy.deepcopy(a._optimizer.state_dict()))
+    b._training_steps = a._training_steps
+    assert a.compare(b) == ""
+    random.seed(2)
+    ra = a.learn(rb)
+    random.seed(2)
+    rb_ = b.learn(rb)
+    assert ra["loss"] == rb_["loss"]
+    assert a.compare(b) == ""
+
+
+def test_full_size_config2_learn_properties():
+    """BASELINE config 2 at full size (N=1M, B=1024, [256,256]): determinism (bitwise), the loss
+    goes down on a fixed replay, and the target net only moves on soft-update steps."""
+    from pearl_amd import BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule
+    dev = torch.device(DEV)
+    N, S, A, B = 1_000_000, 128, 16, 1024
+    rb = BasicReplayBuffer(N, sampler="device")
+    rb.device_for_batches = dev
+    g = torch.Generator(device=dev).manual_seed(0)
+    st = torch.randn(N + 1, S, device=dev, generator=g)
+    ids = torch.arange(N, device=dev)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=dev),
+                 next_state=st[1:], curr_available_actions=_space(A),
+                 next_available_actions=_space(A), max_number_actions=A)
+    del st
+
+    def run():
+        torch.manual_seed(0)
+        pl = DeepQLearning(state_dim=S, action_space=_space(A), hidden_dims=[256, 256],
+                           training_rounds=30, batch_size=B,
+                           action_representation_module=OneHotActionTensorRepresentationModule(A)).to(dev)
+        random.seed(0)
+        t0 = {k: v.clone() for k, v in pl._Q_target.state_dict().items()}
+        losses = pl.learn(rb)["loss"] + pl.learn(rb)["loss"]
+        return pl, losses, t0
+
+    p1, l1, t0 = run()
+    p2, l2, _ = run()
+    assert l1 == l2
+    for (k, a), (_, b) in zip(p1._Q.state_dict().items(), p2._Q.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert all(np.isfinite(l1))
+    assert np.mean(l1[-10:]) < np.mean(l1[:10])
+    assert p1._training_steps == 60
+    assert any(not torch.equal(t0[k], v) for k, v in p1._Q_target.state_dict().items())

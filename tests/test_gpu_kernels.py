@@ -1,0 +1,94 @@
+"""GPU: single-kernel checks through the C ABI (pa_debug_*), against fp64 torch on the same
+inputs.  Asymmetric operands so a transposed fragment map cannot pass."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from pearl_amd import _native as N
+    return N, N.lib()
+
+
+def _rand(*shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("M,N_,K", [(1024, 256, 144), (1024, 256, 256), (1024, 256, 128),
+                                   (128, 64, 6), (33, 70, 37), (7, 5, 3), (100, 24, 21)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_linear_xwT(M, N_, K, epi):
+    N, lib = _lib()
+    dev = torch.device("cuda:0")
+    x, w, b = _rand(M, K, seed=1), _rand(N_, K, seed=2), _rand(N_, seed=3)
+    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    out = torch.full((M, N_), float("nan"), device=dev)
+    N.check(lib.pa_debug_linear(xd.data_ptr(), K, wd.data_ptr(), K, out.data_ptr(), N_,
+                                bd.data_ptr(), None, 0, M, N_, K, 0, epi, N.stream_ptr(dev)))
+    ref = x.double() @ w.double().t() + b.double()
+    if epi == 1:
+        ref = ref.clamp_min(0)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N_,K", [(1024, 256, 256), (64, 24, 16), (45, 70, 33), (9, 3, 5)])
+def test_linear_dx_masked(M, N_, K):
+    """dX = (dY W) * [H > 0] with W stored [K, N]."""
+    N, lib = _lib()
+    dev = torch.device("cuda:0")
+    dy, w, hm = _rand(M, K, seed=4), _rand(K, N_, seed=5), _rand(M, N_, seed=6)
+    dyd, wd, hd = dy.to(dev), w.to(dev), hm.to(dev)
+    out = torch.full((M, N_), float("nan"), device=dev)
+    N.check(lib.pa_debug_linear(dyd.data_ptr(), K, wd.data_ptr(), N_, out.data_ptr(), N_, None,
+                                hd.data_ptr(), N_, M, N_, K, 1, 2, N.stream_ptr(dev)))
+    ref = (dy.double() @ w.double()) * (hm > 0)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-5 * K ** 0.5)
+
+
+@pytest.mark.parametrize("M,N_,B", [(256, 256, 1024), (256, 144, 1024), (64, 6, 128), (24, 21, 100),
+                                   (40, 33, 7), (5, 3, 1)])
+def test_weight_grad(M, N_, B):
+    N, lib = _lib()
+    dev = torch.device("cuda:0")
+    dz, x = _rand(B, M, seed=7), _rand(B, N_, seed=8)
+    dzd, xd = dz.to(dev), x.to(dev)
+    dw = torch.full((M, N_), float("nan"), device=dev)
+    db = torch.full((M,), float("nan"), device=dev)
+    N.check(lib.pa_debug_weight_grad(dzd.data_ptr(), M, xd.data_ptr(), N_, dw.data_ptr(), N_,
+                                     db.data_ptr(), M, N_, B, N.stream_ptr(dev)))
+    torch.testing.assert_close(dw.cpu().double(), dz.double().t() @ x.double(), rtol=1e-5,
+                               atol=1e-5 * B ** 0.5)
+    torch.testing.assert_close(db.cpu().double(), dz.double().sum(0), rtol=1e-5,
+                               atol=1e-5 * B ** 0.5)
+
+
+def test_linear_is_deterministic():
+    N, lib = _lib()
+    dev = torch.device("cuda:0")
+    x, w, b = _rand(1024, 256, seed=1).to(dev), _rand(256, 256, seed=2).to(dev), _rand(256, seed=3).to(dev)
+    outs = []
+    for _ in range(3):
+        out = torch.empty(1024, 256, device=dev)
+        N.check(lib.pa_debug_linear(x.data_ptr(), 256, w.data_ptr(), 256, out.data_ptr(), 256,
+                                    b.data_ptr(), None, 0, 1024, 256, 256, 0, 1, N.stream_ptr(dev)))
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("dtype", [torch.int64, torch.int32, torch.float32])
+def test_one_hot_kernel(dtype):
+    from pearl_amd import OneHotActionTensorRepresentationModule
+    dev = torch.device("cuda:0")
+    rep = OneHotActionTensorRepresentationModule(7)
+    idx = torch.tensor([[0], [6], [3], [3]], dtype=dtype)
+    got = rep(idx.to(dev)).cpu()
+    want = torch.nn.functional.one_hot(idx.long(), 7).squeeze(-2).float()
+    assert torch.equal(got, want)
+    tab = torch.tensor([[[0.], [2.], [4.], [0.], [0.]]])  # test_dynamic_action_space.py:28-157
+    got = OneHotActionTensorRepresentationModule(5)(tab.to(dev)).cpu()
+    assert torch.equal(got, torch.nn.functional.one_hot(tab.long(), 5).squeeze(-2).float())
+    assert got.shape == (1, 5, 5)

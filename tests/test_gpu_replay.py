@@ -1,0 +1,184 @@
+"""GPU: the HBM arena against the oracle's deque and the reference-minted fixtures.  Byte and
+index work: everything here is bit-exact."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_NAMES
+from helpers import fill_oracle_replay
+from oracle import pearl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _space(n):
+    from pearl_amd import DiscreteActionSpace
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+def fill_arena_buffer(fx, sampler="python", staging_rows=0, capacity=None):
+    from pearl_amd import BasicReplayBuffer
+    cfg, rows, states = fx["config"], fx["rows"], fx["states"]
+    rb = BasicReplayBuffer(capacity or cfg["N"] + 10, sampler=sampler, staging_rows=staging_rows)
+    rb.device_for_batches = torch.device("cuda:0")
+    spaces = {n: _space(n) for n in range(1, cfg["A"] + 1)}
+    for i in range(cfg["N"]):
+        rb.push(state=states[i], action=torch.tensor([int(rows["action"][i])]),
+                reward=float(rows["reward"][i]), terminated=bool(rows["terminated"][i]),
+                truncated=bool(rows["truncated"][i]),
+                curr_available_actions=spaces[int(rows["n_curr"][i])], next_state=states[i + 1],
+                next_available_actions=spaces[int(rows["n_next"][i])],
+                max_number_actions=cfg["A"])
+    return rb
+
+
+def assert_batch_equal(batch, want: dict):
+    for k, w in want.items():
+        g = getattr(batch, k)
+        if w is None:
+            assert g is None, k
+            continue
+        g = g.cpu()
+        assert g.dtype == w.dtype, (k, g.dtype, w.dtype)
+        assert tuple(g.shape) == tuple(w.shape), (k, g.shape, w.shape)
+        assert torch.equal(g, w), k
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+@pytest.mark.parametrize("staging_rows", [0, 7])
+def test_sample_matches_reference_fixture(golden, name, staging_rows):
+    """push -> sample with the reference's index stream -> identical TransitionBatch, then
+    preprocess_batch -> identical one-hot views (test_dynamic_action_space.py semantics)."""
+    from pearl_amd import DeepQLearning, OneHotActionTensorRepresentationModule
+    fx = golden(name)
+    cfg = fx["config"]
+    rb = fill_arena_buffer(fx, "python", staging_rows)
+    assert len(rb) == cfg["N"]
+    random.seed(fx["sample_seed"])
+    batch = rb.sample(cfg["B"])
+    assert batch.state.is_cuda
+    assert_batch_equal(batch, fx["batch_raw"])
+    pl = DeepQLearning(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
+                       action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    assert_batch_equal(pl.preprocess_batch(batch), fx["batch_pre"])
+
+
+def test_sample_too_large_raises_value_error(golden):
+    rb = fill_arena_buffer(golden("tiny"))
+    with pytest.raises(ValueError, match="Can't get a batch of size"):
+        rb.sample(len(rb) + 1)
+
+
+@pytest.mark.parametrize("capacity", [17, 40, 64])
+def test_fifo_eviction_matches_deque(golden, capacity):
+    """deque(maxlen) semantics incl. wrap-around inside one staging flush
+    (test_trajectories_in_replay_buffer.py:31-138)."""
+    fx = golden("tiny")
+    cfg = fx["config"]
+    rb = fill_arena_buffer(fx, "python", staging_rows=5, capacity=capacity)
+    orc = O.ReplayOracle(capacity)
+    rows, states = fx["rows"], fx["states"]
+    for i in range(cfg["N"]):
+        orc.push(states[i], torch.tensor([int(rows["action"][i])]), float(rows["reward"][i]),
+                 bool(rows["terminated"][i]), bool(rows["truncated"][i]), int(rows["n_curr"][i]),
+                 states[i + 1], int(rows["n_next"][i]), cfg["A"])
+    n = min(capacity, cfg["N"])
+    assert len(rb) == len(orc) == n
+    random.seed(3)
+    got = rb.sample(n)
+    random.seed(3)
+    want = orc.sample(n)
+    assert_batch_equal(got, want)
+    rb.clear()
+    assert len(rb) == 0
+
+
+def test_push_many_equals_push(golden):
+    from pearl_amd import BasicReplayBuffer
+    fx = golden("cfg1_cartpole_shape")
+    cfg, rows, states = fx["config"], fx["rows"], fx["states"]
+    one = fill_arena_buffer(fx, "python")
+    for where in ("cpu", "cuda:0"):
+        many = BasicReplayBuffer(cfg["N"] + 10, sampler="python")
+        many.device_for_batches = torch.device("cuda:0")
+        N = cfg["N"]
+        many.push_many(
+            state=states[:N].to(where), action=rows["action"].view(-1, 1).to(where),
+            reward=rows["reward"].float().to(where), terminated=rows["terminated"].to(where),
+            truncated=rows["truncated"].to(where), next_state=states[1:N + 1].to(where),
+            curr_available_actions=_space(cfg["A"]), next_available_actions=_space(cfg["A"]),
+            max_number_actions=cfg["A"])
+        assert len(many) == N
+        random.seed(5)
+        a = one.sample(200)
+        random.seed(5)
+        b = many.sample(200)
+        for k in ("state", "action", "reward", "terminated", "truncated", "next_state",
+                  "curr_available_actions", "curr_unavailable_actions_mask",
+                  "next_available_actions", "next_unavailable_actions_mask"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (where, k)
+
+
+@pytest.mark.parametrize("n,B,seed,off", [(1000, 256, 5, 0), (64, 64, 9, 3), (1_000_000, 1024, 77, 12),
+                                         (50, 1, 1, 1), (5000, 4096, 2, 2 ** 40 + 5)])
+def test_device_sampler_matches_spec(n, B, seed, off):
+    """The Philox sampler kernel is bit-identical to its CPU statement and never repeats."""
+    from pearl_amd import _native as N
+    dev = torch.device("cuda:0")
+    idx = torch.full((B,), -1, dtype=torch.int64, device=dev)
+    N.check(N.lib().pa_sample_indices(n, seed, off, B, idx.data_ptr(), 0, N.stream_ptr(dev)))
+    got = idx.cpu().numpy()
+    want = O.philox_sample_indices(n, seed, off, B)
+    assert np.array_equal(got, want)
+    assert len(set(got.tolist())) == B and got.min() >= 0 and got.max() < n
+
+
+def test_device_sampled_batch_is_consistent(golden):
+    """Fast mode: whatever indices the device draws, the gathered rows are those rows."""
+    fx = golden("cfg1_cartpole_shape")
+    rb = fill_arena_buffer(fx, "device")
+    random.seed(123)
+    key = random.getrandbits(64)
+    random.seed(123)
+    batch = rb.sample(128)
+    idx = O.philox_sample_indices(len(rb), key, 0, 128)
+    want = fill_oracle_replay(fx).sample_at(idx.tolist())
+    assert_batch_equal(batch, want)
+
+
+def test_full_size_gather_properties():
+    """BASELINE config 2 sizes (N = 1M, S = 128, B = 1024): row identity through the arena.
+    state[i, 0] = i, next_state = state[i + 1]; after FIFO wrap the logical order still holds."""
+    from pearl_amd import BasicReplayBuffer
+    dev = torch.device("cuda:0")
+    N, S, A, B = 1_000_000, 128, 16, 1024
+    rb = BasicReplayBuffer(N, sampler="device")
+    rb.device_for_batches = dev
+    g = torch.Generator(device=dev).manual_seed(0)
+    chunk = 250_000
+    for c in range(0, N + chunk, chunk):  # N + chunk rows: the ring wraps by one chunk
+        ids = torch.arange(c, c + chunk, device=dev, dtype=torch.float32)
+        st = torch.randn(chunk + 1, S, device=dev, generator=g)
+        st[:, 0] = torch.arange(c, c + chunk + 1, device=dev, dtype=torch.float32)
+        rb.push_many(state=st[:-1], action=(ids.long() % A).view(-1, 1), reward=(ids % 7),
+                     terminated=(ids.long() % 50 == 0), truncated=torch.zeros(chunk, dtype=torch.bool, device=dev),
+                     next_state=st[1:], curr_available_actions=_space(A),
+                     next_available_actions=_space(A), max_number_actions=A)
+    assert len(rb) == N
+    random.seed(1)
+    key = random.getrandbits(64)
+    random.seed(1)
+    batch = rb.sample(B)
+    idx = torch.from_numpy(O.philox_sample_indices(N, key, 0, B))
+    gid = (idx + chunk).float()  # oldest surviving transition has global id `chunk`
+    assert torch.equal(batch.state[:, 0].cpu(), gid)
+    assert torch.equal(batch.next_state[:, 0].cpu(), gid + 1)
+    assert torch.equal(batch.action.cpu().view(-1), (idx + chunk) % A)
+    assert torch.equal(batch.reward.cpu(), ((idx + chunk) % 7).float())
+    assert torch.equal(batch.terminated.cpu(), (idx + chunk) % 50 == 0)
+    assert torch.equal(batch.next_available_actions.cpu(),
+                       torch.arange(A).float().view(1, A, 1).expand(B, A, 1))
+    assert not batch.next_unavailable_actions_mask.any()
+    assert idx.unique().numel() == B

@@ -1,0 +1,115 @@
+"""CPU: pin the oracle (oracle/pearl_oracle.py) against fixtures minted by the REAL reference
+(oracle/make_golden.py).  Replay contract bit-exact; learner numerics to fp32 round-off."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_NAMES
+from helpers import fill_oracle_replay, oracle_learner
+from oracle import pearl_oracle as O
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_replay_contract_bit_exact(golden, name):
+    fx = golden(name)
+    rb = fill_oracle_replay(fx)
+    cfg = fx["config"]
+    assert len(rb) == cfg["N"]
+    # same seed -> random.sample on the deque picks the positions the fixture recorded
+    random.seed(fx["sample_seed"])
+    got = rb.sample(cfg["B"])
+    also = rb.sample_at(fx["sample_idx"].tolist())
+    for k, want in fx["batch_raw"].items():
+        assert got[k].dtype == want.dtype and got[k].shape == want.shape, k
+        assert torch.equal(got[k], want), k
+        assert torch.equal(also[k], want), k
+    pre = O.preprocess(got, cfg["A"])
+    for k, want in fx["batch_pre"].items():
+        assert torch.equal(pre[k], want), k
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_random_sample_range_equals_deque(golden, name):
+    """random.sample(range(n), k) and random.sample(deque_of_n, k) pick the same
+    positions and leave the global RNG in the same state."""
+    fx = golden(name)
+    n, B = fx["config"]["N"], fx["config"]["B"]
+    random.seed(fx["sample_seed"])
+    idx = random.sample(range(n), B)
+    state_after = random.getstate()
+    assert idx == fx["sample_idx"].tolist()
+    random.seed(fx["sample_seed"])
+    rb = fill_oracle_replay(fx)
+    random.sample(rb.memory, B)
+    assert random.getstate() == state_after
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_one_batch_numerics(golden, name):
+    fx = golden(name)
+    pl = oracle_learner(fx)
+    b = fx["batch_pre"]
+    q = pl.q_values(b["state"], b["action"])
+    nv = pl.next_state_values(b["next_state"], b["next_available_actions"],
+                              b["next_unavailable_actions_mask"])
+    y = pl.bellman_target(b)
+    torch.testing.assert_close(q, fx["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(nv, fx["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y, fx["target"], rtol=1e-5, atol=1e-6)
+    q2, g = pl.gradients(b, fx["target"])
+    torch.testing.assert_close(((q2 - fx["target"]) ** 2).mean(), fx["mse"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close((q2 - fx["target"]).abs().mean(), fx["mean_abs_td"], rtol=1e-5,
+                               atol=1e-6)
+    for k, want in fx["grads"].items():
+        torch.testing.assert_close(g[k].reshape(want.shape), want, rtol=2e-4, atol=2e-6, msg=k)
+
+
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
+def test_learn_trajectory(golden, name):
+    """`rounds` steps of learn(): losses, parameters, target network and AdamW state."""
+    fx = golden(name)
+    cfg = fx["config"]
+    pl = oracle_learner(fx)
+    rb = fill_oracle_replay(fx)
+    random.seed(fx["learn_seed"])
+    losses = pl.learn(rb, cfg["rounds"], cfg["B"], cfg["A"])
+    torch.testing.assert_close(torch.tensor(losses), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    assert pl.training_steps == fx["training_steps_after"]
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(pl.p[k], fx["params_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(pl.t[k], fx["target_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+        st = fx["opt_after"][k]
+        assert float(st["step"]) == cfg["rounds"]
+        torch.testing.assert_close(pl.m[k], st["exp_avg"], rtol=1e-3, atol=1e-6, msg=k)
+        torch.testing.assert_close(pl.v[k], st["exp_avg_sq"], rtol=1e-3, atol=1e-8, msg=k)
+        torch.testing.assert_close(pl.vmax[k], st["max_exp_avg_sq"], rtol=1e-3, atol=1e-8, msg=k)
+    # the index lists recorded by the generator are the ones this run drew
+    random.seed(fx["learn_seed"])
+    again = [random.sample(range(cfg["N"]), cfg["B"]) for _ in range(cfg["rounds"])]
+    assert again == fx["learn_idx"].tolist()
+
+
+def test_philox_known_answer():
+    """Philox4x32-10 KAT from the Random123 distribution (kat_vectors): counter/key all-ones."""
+    assert O.philox4x32_10(0, 0, 0, 0, 0, 0) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    assert O.philox4x32_10(0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff,
+                           0xffffffff) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert O.philox4x32_10(0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344, 0xa4093822,
+                           0x299f31d0) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+def test_philox_sampler_is_a_uniform_subset_sampler():
+    idx = O.philox_sample_indices(1000, seed=5, offset=0, B=256)
+    assert len(set(idx.tolist())) == 256 and idx.min() >= 0 and idx.max() < 1000
+    # dense case forces many collision rounds
+    idx = O.philox_sample_indices(64, seed=9, offset=3, B=64)
+    assert sorted(idx.tolist()) == list(range(64))
+    # marginal uniformity: chi-square over many draws of a small population
+    counts = np.zeros(20)
+    for off in range(400):
+        counts[O.philox_sample_indices(20, seed=1, offset=off, B=5)] += 1
+    expected = 400 * 5 / 20
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 43.8  # 99.9th percentile of chi2(19)
