@@ -9,6 +9,7 @@
 //   DeepQLearning.get_next_state_values  deep_q_learning.py:130-167
 #include <math.h>
 
+#include <deque>
 #include <new>
 #include <string>
 #include <vector>
@@ -56,7 +57,7 @@ struct pa_dqn {
   hipEvent_t fork;
   // timing
   int timing;  // 0 off, 1 dominant kernel only, 2 every stage
-  std::vector<Timer> timers;
+  std::deque<Timer> timers;  // deque: references stay valid while nested timers are added
 };
 
 namespace {

@@ -1,0 +1,17 @@
+#!/bin/bash
+# GPU round: gpu test-suite, bench (stage timers), bench (headline + cpu baseline), rocprofv3 stats.
+R=${GRAFT_REPO_ROOT:-$PWD}
+mkdir -p $R/gpurun_out
+cd $R
+timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest rc=$?"; tail -15 gpurun_out/pytest_gpu.log
+timeout 600 python bench.py --timing-level 2 --no-cpu-baseline > gpurun_out/bench_l2.log 2>&1
+echo "bench l2 rc=$?"; tail -2 gpurun_out/bench_l2.log
+timeout 900 python bench.py > gpurun_out/bench.log 2>&1
+echo "bench rc=$?"; tail -2 gpurun_out/bench.log
+if [ "$1" != "noprof" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
+  echo "rocprof rc=$?"; tail -3 $R/gpurun_out/rocprof.log
+  find $R/gpurun_out/prof -name "*stats*" | head
+fi

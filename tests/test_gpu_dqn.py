@@ -204,8 +204,11 @@ def test_state_dict_round_trip_and_rebind(golden):
 
 
 def test_full_size_config2_learn_properties():
-    """BASELINE config 2 at full size (N=1M, B=1024, [256,256]): determinism (bitwise), the loss
-    goes down on a fixed replay, and the target net only moves on soft-update steps."""
+    """BASELINE config 2 at full size (N=1M, B=1024, [256,256]):
+    * the first steps of the fused device-sampled learn() equal the CPU oracle replaying the same
+      Philox index lists on the same data (Q-value-level parity at the benchmark's exact shape);
+    * two identical runs are bitwise identical (deterministic reductions, no atomics);
+    * losses stay finite and the target network moves only through soft updates."""
     from pearl_amd import BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule
     dev = torch.device(DEV)
     N, S, A, B = 1_000_000, 128, 16, 1024
@@ -218,24 +221,47 @@ def test_full_size_config2_learn_properties():
                  terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=dev),
                  next_state=st[1:], curr_available_actions=_space(A),
                  next_available_actions=_space(A), max_number_actions=A)
+    st_cpu = st.cpu()
     del st
 
-    def run():
+    def fresh(rounds):
         torch.manual_seed(0)
-        pl = DeepQLearning(state_dim=S, action_space=_space(A), hidden_dims=[256, 256],
-                           training_rounds=30, batch_size=B,
-                           action_representation_module=OneHotActionTensorRepresentationModule(A)).to(dev)
+        return DeepQLearning(state_dim=S, action_space=_space(A), hidden_dims=[256, 256],
+                             training_rounds=rounds, batch_size=B,
+                             action_representation_module=OneHotActionTensorRepresentationModule(A)).to(dev)
+
+    # -- parity with the oracle at full size
+    pl = fresh(4)
+    orc = O.DqnOracle({k: v.cpu() for k, v in pl._Q.state_dict().items()},
+                      {k: v.cpu() for k, v in pl._Q_target.state_dict().items()})
+    random.seed(5)
+    key = random.getrandbits(64)
+    random.seed(5)
+    got = pl.learn(rb)["loss"]
+    want = []
+    for r in range(4):
+        idx = torch.from_numpy(O.philox_sample_indices(N, key, r, B))
+        batch = dict(state=st_cpu[idx], action=torch.eye(A)[idx % A], reward=(idx % 7).float(),
+                     terminated=(idx % 50 == 0), next_state=st_cpu[idx + 1],
+                     next_available_actions=torch.eye(A).expand(B, A, A),
+                     next_unavailable_actions_mask=torch.zeros(B, A, dtype=torch.bool))
+        orc.training_steps += 1
+        want.append(orc.learn_batch(batch))
+    torch.testing.assert_close(torch.tensor(got), torch.tensor(want), rtol=1e-4, atol=1e-5)
+    for k, v in pl._Q.state_dict().items():
+        torch.testing.assert_close(v.cpu(), orc.p[k], rtol=1e-3, atol=2e-5, msg=k)
+
+    # -- determinism + sanity over 60 steps
+    def run():
+        p = fresh(30)
         random.seed(0)
-        t0 = {k: v.clone() for k, v in pl._Q_target.state_dict().items()}
-        losses = pl.learn(rb)["loss"] + pl.learn(rb)["loss"]
-        return pl, losses, t0
+        t0 = {k: v.clone() for k, v in p._Q_target.state_dict().items()}
+        return p, p.learn(rb)["loss"] + p.learn(rb)["loss"], t0
 
     p1, l1, t0 = run()
     p2, l2, _ = run()
     assert l1 == l2
     for (k, a), (_, b) in zip(p1._Q.state_dict().items(), p2._Q.state_dict().items()):
         assert torch.equal(a, b), k
-    assert all(np.isfinite(l1))
-    assert np.mean(l1[-10:]) < np.mean(l1[:10])
-    assert p1._training_steps == 60
+    assert all(np.isfinite(l1)) and p1._training_steps == 60
     assert any(not torch.equal(t0[k], v) for k, v in p1._Q_target.state_dict().items())
