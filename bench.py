@@ -141,8 +141,8 @@ def main():
     assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
 
     timers = {}
-    for name in ("target", "target_l1", "gather", "online_fwd", "head", "backward", "adamw",
-                 "soft_update"):
+    for name in ("target", "l1_dual", "gather", "sample", "online_l2", "head", "bwd_dx", "bwd_dw",
+                 "adamw", "soft_update"):
         ms, cnt = C.c_double(), C.c_int64()
         N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
         if cnt.value:

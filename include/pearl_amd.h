@@ -270,8 +270,9 @@ int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* st
  * (HIP events on the launch stream; used by bench.py's roofline block). */
 /* level 0: off; 1: only the dominant kernel ("target"); 2: every stage.  Resets the counters. */
 int pa_dqn_enable_timing(pa_dqn* h, int32_t level);
-/* names: "target", "target_l1", "gather", "online_fwd", "head", "backward", "adamw",
- * "soft_update", "step", "learn" -> average milliseconds and sample count */
+/* names: "target" (sampled every 8th step at level 1), "l1_dual", "gather", "sample",
+ * "online_l2", "head", "bwd_dx", "bwd_dw", "adamw", "soft_update", "learn"
+ * -> average milliseconds and sample count */
 int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* count);
 
 /* ------------------------------------------------------------------------ */

@@ -314,9 +314,14 @@ constexpr unsigned long long EMPTY_ENTRY = ~0ull;
 // The hash table (open addressing, LDS) stores (v << 32 | t << 16 | i); min() on that
 // word implements "earlier round, then lower position" without ordering races.
 // The rule is symmetric in the values, so the resulting set is uniform over B-subsets.
+// Block r of the grid draws the sample of round r (Philox counter offset + r) into
+// idx_out[r * B ...]: one launch covers every round of a learn() call.
 __global__ __launch_bounds__(SAMPLE_THREADS) void sample_indices_kernel(
     int64_t* __restrict__ idx_out, uint32_t n, int B, int hs, uint32_t seed_lo, uint32_t seed_hi,
-    uint32_t off_lo, uint32_t off_hi) {
+    uint64_t offset0) {
+  const uint64_t offset = offset0 + blockIdx.x;
+  const uint32_t off_lo = (uint32_t)offset, off_hi = (uint32_t)(offset >> 32);
+  idx_out += (int64_t)blockIdx.x * B;
   extern __shared__ __attribute__((aligned(16))) unsigned long long table[];
   // all LDS lives in the dynamic region so its base stays 16-byte aligned
   int* pending_p = reinterpret_cast<int*>(table + hs);
@@ -520,8 +525,8 @@ int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa
   return PA_OK;
 }
 
-static int sample_indices_launch(int64_t population, uint64_t seed, uint64_t offset, int32_t B,
-                                 int64_t* idx_out_dev, hipStream_t s) {
+int sample_indices_launch(int64_t population, uint64_t seed, uint64_t offset, int32_t B,
+                          int32_t rounds, int64_t* idx_out_dev, hipStream_t s) {
   PA_REQUIRE(B >= 0 && B <= SAMPLE_MAX_B, PA_ERR_UNSUPPORTED,
              "device sampler supports batch sizes up to %d (got %d)", SAMPLE_MAX_B, B);
   PA_REQUIRE(population > 0 && population < 0xFFFFFFFFll, PA_ERR_UNSUPPORTED,
@@ -529,20 +534,19 @@ static int sample_indices_launch(int64_t population, uint64_t seed, uint64_t off
   PA_REQUIRE((int64_t)B <= population, PA_ERR_VALUE,
              "Can't get a batch of size %d from a replay buffer with only %lld elements", B,
              (long long)population);
-  if (B == 0) return PA_OK;
+  if (B == 0 || rounds <= 0) return PA_OK;
   int hs = 1024;
   while (hs < 2 * B) hs <<= 1;
-  hipLaunchKernelGGL(sample_indices_kernel, dim3(1), dim3(SAMPLE_THREADS),
+  hipLaunchKernelGGL(sample_indices_kernel, dim3((unsigned)rounds), dim3(SAMPLE_THREADS),
                      (size_t)hs * sizeof(unsigned long long) + 16, s, idx_out_dev, (uint32_t)population,
-                     B, hs, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)offset,
-                     (uint32_t)(offset >> 32));
+                     B, hs, (uint32_t)seed, (uint32_t)(seed >> 32), offset);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
 
 int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const pa_batch_out* out,
                  int64_t* idx_out_dev, hipStream_t s) {
-  int rc = sample_indices_launch(a->size, seed, offset, B, idx_out_dev, s);
+  int rc = sample_indices_launch(a->size, seed, offset, B, 1, idx_out_dev, s);
   if (rc != PA_OK) return rc;
   return arena_gather_device(a, idx_out_dev, B, out, s);
 }
@@ -844,7 +848,7 @@ extern "C" int pa_sample_indices(int64_t population, uint64_t seed, uint64_t off
                                  int64_t* idx_out_dev, int32_t device, void* stream) {
   PA_REQUIRE(idx_out_dev || B == 0, PA_ERR_INVALID, "null output");
   PA_HIP(hipSetDevice(device));
-  return sample_indices_launch(population, seed, offset, B, idx_out_dev,
+  return sample_indices_launch(population, seed, offset, B, 1, idx_out_dev,
                                reinterpret_cast<hipStream_t>(stream));
 }
 

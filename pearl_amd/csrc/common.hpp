@@ -100,6 +100,9 @@ int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa
                         hipStream_t s);
 int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const pa_batch_out* out,
                  int64_t* idx_out_dev, hipStream_t s);
+// Philox draw of `rounds` samples of B distinct indices (round r uses counter offset + r).
+int sample_indices_launch(int64_t population, uint64_t seed, uint64_t offset, int32_t B,
+                          int32_t rounds, int64_t* idx_out_dev, hipStream_t s);
 // Make stream `s` wait for the last ingest if that ran on another stream.
 int arena_wait_ingest(pa_arena* a, hipStream_t s);
 }  // namespace pa

@@ -1,5 +1,6 @@
 // Host orchestration of the DQN learner step: workspaces, launch sequence,
-// the fused learn() loop with the sampler one step ahead on a side stream, and
+// the fused learn() loop (all rounds' index lists drawn by one launch, then a
+// single-stream chain of kernels per step with no events), and
 // HIP-event kernel timers for bench.py's roofline block.
 //
 // Reference call stack being replaced:
@@ -38,9 +39,8 @@ struct pa_dqn {
   int64_t off[6];    // W1,b1,W2,b2,W3,b3
   int IN;            // S + AD
   // workspaces (HBM)
-  float *U, *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *slab, *xpack, *loss_scratch;
-  int nslab_max;
-  // fused learn(): double-buffered batch + streams/events
+  float *U, *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
+  // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
   struct BatchBuf {
     float* x;
     float* next_state;
@@ -48,13 +48,11 @@ struct pa_dqn {
     uint8_t* next_mask;
     float* reward;
     uint8_t* term;
-    int64_t* idx;
-    hipEvent_t ready, consumed;
-    bool used;
-  } bb[2];
-  int bb_A;  // A the batch buffers were sized for
-  hipStream_t side;
-  hipEvent_t fork;
+  } bb;
+  int bb_A;          // A the batch buffers were sized for
+  int64_t* idx_all;  // [idx_cap] logical indices, round-major
+  int64_t idx_cap;
+  int64_t tick;      // steps seen while timing (sparse sampling of the level-1 timer)
   // timing
   int timing;  // 0 off, 1 dominant kernel only, 2 every stage
   std::deque<Timer> timers;  // deque: references stay valid while nested timers are added
@@ -88,9 +86,12 @@ struct ScopedTimer {
   Timer* t;
   hipStream_t s;
   bool active;
-  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_, int level = 2)
+  // every: record only on every `every`-th step (a hipEventRecord costs ~6 us of GPU idle on
+  // this stack, so the dominant kernel is sampled, not bracketed on every launch)
+  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_, int level = 2, int every = 1)
       : h(h_), t(nullptr), s(s_), active(false) {
     if (h->timing < level) return;
+    if (every > 1 && h->timing == level && (h->tick % every) != 0) return;
     t = find_timer(h, name);
     if (t->used + 2 > 2 * kMaxTimedPairs) return;
     while (t->ev.size() < t->used + 2) {
@@ -115,19 +116,30 @@ int set_max_smem(K kernel, size_t bytes) {
   return PA_OK;
 }
 
-template <bool B_KS, int EPI>
-int launch_linear(const GemmArgs& g, hipStream_t s) {
+// One launch, one or two independent problems (blockIdx.z).
+template <bool B_KS>
+int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s) {
   constexpr int KW = 4;
-  static bool configured = false;
-  auto kern = linear_kernel<B_KS, EPI, KW>;
-  const size_t smem = linear_smem_bytes<B_KS, KW>();
-  if (!configured) {
+  static size_t configured = 0;
+  auto kern = linear_kernel<B_KS, KW>;
+  LinArgs a;
+  memset(&a, 0, sizeof(a));
+  size_t smem = 0;
+  int gx = 0, gy = 0;
+  for (int i = 0; i < nprob; ++i) {
+    a.p[i] = probs[i];
+    const size_t b = linear_smem_bytes<B_KS, KW>(probs[i].K);
+    smem = b > smem ? b : smem;
+    gx = (int)ceil_div(probs[i].N, G_BN) > gx ? (int)ceil_div(probs[i].N, G_BN) : gx;
+    gy = (int)ceil_div(probs[i].M, G_BM) > gy ? (int)ceil_div(probs[i].M, G_BM) : gy;
+  }
+  if (smem > configured) {
     int rc = set_max_smem(kern, smem);
     if (rc != PA_OK) return rc;
-    configured = true;
+    configured = smem;
   }
-  dim3 grid((unsigned)ceil_div(g.N, G_BN), (unsigned)ceil_div(g.M, G_BM));
-  hipLaunchKernelGGL(kern, grid, dim3(128 * KW), smem, s, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy, (unsigned)nprob), dim3(128 * KW), smem,
+                     s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -196,52 +208,25 @@ int resolve_x(pa_dqn* h, const pa_dqn_batch* b, const float** x, hipStream_t s) 
   return PA_OK;
 }
 
-// max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
-// deep_td_learning.py:313-317)
-int run_target(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+GemmArgs target_l1_problem(pa_dqn* h, const pa_dqn_batch* b) {
+  // U = s' W1s'^T + b1'   (state columns of the target net's first layer)
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, h->bufs.q_target);
-  int rc;
-  {
-    ScopedTimer tm(h, "target_l1", s);
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = b->next_state; g.lda = d.state_dim;
-    g.Bm = t.W1; g.ldb = h->IN;
-    g.C = h->U; g.ldc = d.hidden1;
-    g.bias = t.b1;
-    g.M = b->B; g.N = d.hidden1; g.K = d.state_dim;
-    rc = launch_linear<false, EPI_BIAS>(g, s);
-    if (rc != PA_OK) return rc;
-  }
-  {
-    ScopedTimer tm(h, "target", s, 1);
-    TargetArgs a;
-    memset(&a, 0, sizeof(a));
-    a.U = h->U; a.ldu = d.hidden1;
-    a.feat = b->next_avail_rep;
-    a.feat_bstride = b->next_avail_bcast ? 0 : (int64_t)b->A * d.action_dim;
-    a.mask = b->next_mask;
-    a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
-    a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
-    a.W2 = t.W2; a.ldw2 = d.hidden1;
-    a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
-    a.reward = b->reward; a.term = b->terminated;
-    a.gamma = d.discount;
-    a.next_v = next_v; a.y = y;
-    a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
-    a.bpw = T_ROWS / b->A;
-    rc = launch_target(a, s);
-    if (rc != PA_OK) return rc;
-  }
-  return PA_OK;
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = b->next_state; g.lda = d.state_dim;
+  g.Bm = t.W1; g.ldb = h->IN;
+  g.C = h->U; g.ldc = d.hidden1;
+  g.bias = t.b1;
+  g.M = b->B; g.N = d.hidden1; g.K = d.state_dim;
+  g.epi = EPI_BIAS;
+  return g;
 }
 
-// online forward: H1a = relu(x W1^T + b1), H2a = relu(H1a W2^T + b2)
-int run_online_fwd(pa_dqn* h, const float* x, int B, hipStream_t s) {
+GemmArgs online_l1_problem(pa_dqn* h, const float* x, int B) {
+  // H1a = relu(x W1^T + b1)
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
-  ScopedTimer tm(h, "online_fwd", s);
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = x; g.lda = h->IN;
@@ -249,14 +234,48 @@ int run_online_fwd(pa_dqn* h, const float* x, int B, hipStream_t s) {
   g.C = h->H1a; g.ldc = d.hidden1;
   g.bias = q.b1;
   g.M = B; g.N = d.hidden1; g.K = h->IN;
-  int rc = launch_linear<false, EPI_BIAS_RELU>(g, s);
-  if (rc != PA_OK) return rc;
+  g.epi = EPI_BIAS_RELU;
+  return g;
+}
+
+// max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
+// deep_td_learning.py:313-317); U must already be in h->U.
+int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const NetPtrs t = net_ptrs(h, h->bufs.q_target);
+  ScopedTimer tm(h, "target", s, 1, 8);
+  TargetArgs a;
+  memset(&a, 0, sizeof(a));
+  a.U = h->U; a.ldu = d.hidden1;
+  a.feat = b->next_avail_rep;
+  a.feat_bstride = b->next_avail_bcast ? 0 : (int64_t)b->A * d.action_dim;
+  a.mask = b->next_mask;
+  a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
+  a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
+  a.W2 = t.W2; a.ldw2 = d.hidden1;
+  a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
+  a.reward = b->reward; a.term = b->terminated;
+  a.gamma = d.discount;
+  a.next_v = next_v; a.y = y;
+  a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
+  a.bpw = T_ROWS / b->A;
+  return launch_target(a, s);
+}
+
+// H2a = relu(H1a W2^T + b2)
+int run_online_l2(pa_dqn* h, int B, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const NetPtrs q = net_ptrs(h, h->bufs.q);
+  ScopedTimer tm(h, "online_l2", s);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
   g.A = h->H1a; g.lda = d.hidden1;
   g.Bm = q.W2; g.ldb = d.hidden1;
   g.C = h->H2a; g.ldc = d.hidden2;
   g.bias = q.b2;
   g.M = B; g.N = d.hidden2; g.K = d.hidden1;
-  return launch_linear<false, EPI_BIAS_RELU>(g, s);
+  g.epi = EPI_BIAS_RELU;
+  return launch_linear<false>(&g, 1, s);
 }
 
 int run_head(pa_dqn* h, int B, const float* y, float* q_out, bool backward, int world,
@@ -270,32 +289,38 @@ int run_head(pa_dqn* h, int B, const float* y, float* q_out, bool backward, int 
   a.w3 = q.W3; a.b3 = q.b3;
   a.y = y;
   a.q_out = q_out;
+  a.dq_out = h->dq; a.absd_out = h->absd;
   a.dZ2 = backward ? h->dZ2 : nullptr; a.ldz = d.hidden2;
-  a.slab = backward ? h->slab : nullptr;
   a.norm = (float)(2.0 / ((double)B * (double)world));
   a.B = B; a.H2 = d.hidden2;
-  hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)ceil_div(B, HEAD_ROWS)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
 
-int run_backward(pa_dqn* h, const float* x, int B, float* loss_out, hipStream_t s) {
+int run_backward(pa_dqn* h, const float* x, int B, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
   float* G = h->bufs.grad;
-  ScopedTimer tm(h, "backward", s);
-  // dZ1 = (dZ2 W2) * [H1a > 0]
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = h->dZ2; g.lda = d.hidden2;
-  g.Bm = q.W2; g.ldb = d.hidden1;
-  g.C = h->dZ1; g.ldc = d.hidden1;
-  g.Hmask = h->H1a; g.ldh = d.hidden1;
-  g.M = B; g.N = d.hidden1; g.K = d.hidden2;
-  int rc = launch_linear<true, EPI_MASK>(g, s);
-  if (rc != PA_OK) return rc;
+  int rc;
+  {
+    ScopedTimer tm(h, "bwd_dx", s);
+    // dZ1 = (dZ2 W2) * [H1a > 0]
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = h->dZ2; g.lda = d.hidden2;
+    g.Bm = q.W2; g.ldb = d.hidden1;
+    g.C = h->dZ1; g.ldc = d.hidden1;
+    g.Hmask = h->H1a; g.ldh = d.hidden1;
+    g.M = B; g.N = d.hidden1; g.K = d.hidden2;
+    g.epi = EPI_MASK;
+    rc = launch_linear<true>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+  }
+  ScopedTimer tm(h, "bwd_dw", s);
   DwArgs a;
   memset(&a, 0, sizeof(a));
+  a.nprob = 3;
   // dW2 = dZ2^T H1a, db2
   a.p[0].dZ = h->dZ2; a.p[0].ldz = d.hidden2;
   a.p[0].X = h->H1a; a.p[0].ldx = d.hidden1;
@@ -304,7 +329,7 @@ int run_backward(pa_dqn* h, const float* x, int B, float* loss_out, hipStream_t 
   a.p[0].M = d.hidden2; a.p[0].N = d.hidden1;
   a.p[0].tiles_n = (int)ceil_div(d.hidden1, 32);
   a.p[0].tile0 = 0;
-  const int t0 = (int)ceil_div(d.hidden2, 32) * a.p[0].tiles_n;
+  int t0 = (int)ceil_div(d.hidden2, 32) * a.p[0].tiles_n;
   // dW1 = dZ1^T x, db1
   a.p[1].dZ = h->dZ1; a.p[1].ldz = d.hidden1;
   a.p[1].X = x; a.p[1].ldx = h->IN;
@@ -313,22 +338,31 @@ int run_backward(pa_dqn* h, const float* x, int B, float* loss_out, hipStream_t 
   a.p[1].M = d.hidden1; a.p[1].N = h->IN;
   a.p[1].tiles_n = (int)ceil_div(h->IN, 32);
   a.p[1].tile0 = t0;
-  a.total_tiles = t0 + (int)ceil_div(d.hidden1, 32) * a.p[1].tiles_n;
+  t0 += (int)ceil_div(d.hidden1, 32) * a.p[1].tiles_n;
+  // dW3 = dq^T H2a, db3 = sum dq   (dq is a [B][1] "dZ")
+  a.p[2].dZ = h->dq; a.p[2].ldz = 1;
+  a.p[2].X = h->H2a; a.p[2].ldx = d.hidden2;
+  a.p[2].dW = G + h->off[4]; a.p[2].ldw = d.hidden2;
+  a.p[2].db = G + h->off[5];
+  a.p[2].M = 1; a.p[2].N = d.hidden2;
+  a.p[2].tiles_n = (int)ceil_div(d.hidden2, 32);
+  a.p[2].tile0 = t0;
+  t0 += a.p[2].tiles_n;
+  a.total_tiles = t0;
   a.B = B;
-  a.slab = h->slab; a.nslab = (int)ceil_div(B, HEAD_ROWS); a.H2 = d.hidden2;
-  a.dW3 = G + h->off[4]; a.db3 = G + h->off[5];
-  a.loss_out = loss_out;
-  a.inv_B = (float)(1.0 / (double)B);
-  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles + 1), dim3(512), 0, s, a);
+  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
 
-int run_adamw(pa_dqn* h, int64_t step, hipStream_t s) {
+// AdamW on bufs.grad; also folds |Q - target| into loss_out and, when soft_next, performs the
+// soft target update that the NEXT step's forward() would start with.
+int run_adamw(pa_dqn* h, int64_t step, int B, float* loss_out, int soft_next, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)", (long long)step);
   ScopedTimer tm(h, "adamw", s);
   AdamArgs a;
+  memset(&a, 0, sizeof(a));
   a.p = h->bufs.q; a.g = h->bufs.grad; a.m = h->bufs.exp_avg; a.v = h->bufs.exp_avg_sq;
   a.vmax = h->bufs.max_exp_avg_sq;
   a.n = h->P;
@@ -343,7 +377,22 @@ int run_adamw(pa_dqn* h, int64_t step, hipStream_t s) {
   a.neg_step = (float)(-(d.lr / bc1));
   a.eps = (float)d.eps;
   a.amsgrad = d.amsgrad;
+  a.absd = h->absd; a.nabs = B; a.inv_B = (float)(1.0 / (double)B); a.loss_out = loss_out;
+  a.tgt = h->bufs.q_target; a.tau = d.tau; a.one_minus_tau = (float)(1.0 - (double)d.tau);
+  a.soft_next = soft_next;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+// |Q - target| fold without an optimizer step (data-parallel path: AdamW comes after the
+// all-reduce, but the local loss is final now).
+int run_loss_fold(pa_dqn* h, int B, float* loss_out, hipStream_t s) {
+  AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.n = 0;
+  a.absd = h->absd; a.nabs = B; a.inv_B = (float)(1.0 / (double)B); a.loss_out = loss_out;
+  hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -356,11 +405,15 @@ int run_soft_update(pa_dqn* h, hipStream_t s) {
   return PA_OK;
 }
 
+// One learn_batch.  do_target_update: soft update BEFORE the forward (skip it when the previous
+// step's AdamW launch already did it, soft_next).  soft_next: fuse the next step's soft update
+// into this step's AdamW launch.
 int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_t adam_step,
-              int grad_world, float* loss_out, hipStream_t s) {
+              int grad_world, float* loss_out, int soft_next, hipStream_t s) {
   int rc = check_batch(h, batch);
   if (rc != PA_OK) return rc;
   PA_REQUIRE(grad_world >= 1, PA_ERR_INVALID, "grad_world must be >= 1");
+  if (h->timing) h->tick++;
   if (do_target_update) {
     rc = run_soft_update(h, s);
     if (rc != PA_OK) return rc;
@@ -368,49 +421,60 @@ int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_
   const float* x = nullptr;
   rc = resolve_x(h, batch, &x, s);
   if (rc != PA_OK) return rc;
-  rc = run_target(h, batch, h->nextv, h->y, s);
+  {
+    // layer 1 of both networks in one launch: U (target, state part) and H1a (online)
+    ScopedTimer tm(h, "l1_dual", s);
+    GemmArgs probs[2] = {target_l1_problem(h, batch), online_l1_problem(h, x, batch->B)};
+    rc = launch_linear<false>(probs, 2, s);
+    if (rc != PA_OK) return rc;
+  }
+  rc = run_target_fused(h, batch, h->nextv, h->y, s);
   if (rc != PA_OK) return rc;
-  rc = run_online_fwd(h, x, batch->B, s);
+  rc = run_online_l2(h, batch->B, s);
   if (rc != PA_OK) return rc;
   rc = run_head(h, batch->B, h->y, h->qbuf, true, grad_world, s);
   if (rc != PA_OK) return rc;
-  rc = run_backward(h, x, batch->B, loss_out ? loss_out : h->loss_scratch, s);
+  rc = run_backward(h, x, batch->B, s);
   if (rc != PA_OK) return rc;
-  if (grad_world == 1) {
-    rc = run_adamw(h, adam_step, s);
-    if (rc != PA_OK) return rc;
-  }
-  return PA_OK;
+  float* lo = loss_out ? loss_out : h->loss_scratch;
+  if (grad_world == 1) return run_adamw(h, adam_step, batch->B, lo, soft_next, s);
+  return run_loss_fold(h, batch->B, lo, s);
 }
 
 void free_batchbufs(pa_dqn* h) {
-  for (int i = 0; i < 2; ++i) {
-    void* ptrs[] = {h->bb[i].x, h->bb[i].next_state, h->bb[i].next_avail_rep, h->bb[i].next_mask,
-                    h->bb[i].reward, h->bb[i].term, h->bb[i].idx};
-    for (void* p : ptrs)
-      if (p) (void)hipFree(p);
-    h->bb[i].x = nullptr; h->bb[i].next_state = nullptr; h->bb[i].next_avail_rep = nullptr;
-    h->bb[i].next_mask = nullptr; h->bb[i].reward = nullptr; h->bb[i].term = nullptr;
-    h->bb[i].idx = nullptr;
-  }
+  void* ptrs[] = {h->bb.x, h->bb.next_state, h->bb.next_avail_rep, h->bb.next_mask, h->bb.reward,
+                  h->bb.term};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  memset(&h->bb, 0, sizeof(h->bb));
   h->bb_A = 0;
 }
 
 int ensure_batchbufs(pa_dqn* h, int A) {
-  if (h->bb_A >= A && h->bb[0].x) return PA_OK;
+  if (h->bb_A >= A && h->bb.x) return PA_OK;
   free_batchbufs(h);
   const pa_dqn_desc& d = h->d;
   const int64_t B = d.max_batch;
-  for (int i = 0; i < 2; ++i) {
-    PA_HIP(hipMalloc((void**)&h->bb[i].x, (size_t)(B * h->IN * 4)));
-    PA_HIP(hipMalloc((void**)&h->bb[i].next_state, (size_t)(B * d.state_dim * 4)));
-    PA_HIP(hipMalloc((void**)&h->bb[i].next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
-    PA_HIP(hipMalloc((void**)&h->bb[i].next_mask, (size_t)(B * A)));
-    PA_HIP(hipMalloc((void**)&h->bb[i].reward, (size_t)(B * 4)));
-    PA_HIP(hipMalloc((void**)&h->bb[i].term, (size_t)B));
-    PA_HIP(hipMalloc((void**)&h->bb[i].idx, (size_t)(B * 8)));
-  }
+  PA_HIP(hipMalloc((void**)&h->bb.x, (size_t)(B * h->IN * 4)));
+  PA_HIP(hipMalloc((void**)&h->bb.next_state, (size_t)(B * d.state_dim * 4)));
+  PA_HIP(hipMalloc((void**)&h->bb.next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
+  PA_HIP(hipMalloc((void**)&h->bb.next_mask, (size_t)(B * A)));
+  PA_HIP(hipMalloc((void**)&h->bb.reward, (size_t)(B * 4)));
+  PA_HIP(hipMalloc((void**)&h->bb.term, (size_t)B));
   h->bb_A = A;
+  return PA_OK;
+}
+
+int ensure_idx(pa_dqn* h, int64_t n) {
+  if (h->idx_cap >= n) return PA_OK;
+  if (h->idx_all) {
+    PA_HIP(hipDeviceSynchronize());
+    (void)hipFree(h->idx_all);
+    h->idx_all = nullptr;
+    h->idx_cap = 0;
+  }
+  PA_HIP(hipMalloc((void**)&h->idx_all, (size_t)(n * 8)));
+  h->idx_cap = n;
   return PA_OK;
 }
 
@@ -455,13 +519,13 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   param_layout(desc->state_dim, desc->action_dim, desc->hidden1, desc->hidden2, h->off, &h->P);
   h->timing = 0;
   h->bb_A = 0;
-  memset(h->bb, 0, sizeof(h->bb));
-  h->side = nullptr;
-  h->fork = nullptr;
-  h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->slab = h->xpack =
-      h->loss_scratch = nullptr;
+  memset(&h->bb, 0, sizeof(h->bb));
+  h->idx_all = nullptr;
+  h->idx_cap = 0;
+  h->tick = 0;
+  h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->dq = h->absd =
+      h->xpack = h->loss_scratch = nullptr;
   const int64_t B = desc->max_batch;
-  h->nslab_max = (int)ceil_div(B, HEAD_ROWS);
 #define PA_WS(ptr, floats)                                                       \
   do {                                                                           \
     hipError_t _e = hipMalloc((void**)&(ptr), (size_t)((floats) * 4));           \
@@ -479,24 +543,11 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->y, B);
   PA_WS(h->nextv, B);
   PA_WS(h->qbuf, B);
-  PA_WS(h->slab, (int64_t)h->nslab_max * (desc->hidden2 + 2));
+  PA_WS(h->dq, B);
+  PA_WS(h->absd, B);
   PA_WS(h->xpack, B * h->IN);
   PA_WS(h->loss_scratch, 4);
 #undef PA_WS
-  if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&h->fork, hipEventDisableTiming) != hipSuccess) {
-    set_error("stream/event creation failed");
-    pa_dqn_destroy(h);
-    return PA_ERR_HIP;
-  }
-  for (int i = 0; i < 2; ++i) {
-    if (hipEventCreateWithFlags(&h->bb[i].ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->bb[i].consumed, hipEventDisableTiming) != hipSuccess) {
-      set_error("event creation failed");
-      pa_dqn_destroy(h);
-      return PA_ERR_HIP;
-    }
-  }
   *out = h;
   return PA_OK;
 }
@@ -505,17 +556,11 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   if (!h) return PA_OK;
   (void)hipSetDevice(h->d.device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {h->U, h->H1a, h->H2a, h->dZ2, h->dZ1, h->y, h->nextv, h->qbuf, h->slab,
-                  h->xpack, h->loss_scratch};
+  void* ptrs[] = {h->U, h->H1a, h->H2a, h->dZ2, h->dZ1, h->y, h->nextv, h->qbuf, h->dq, h->absd,
+                  h->xpack, h->loss_scratch, h->idx_all};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free_batchbufs(h);
-  for (int i = 0; i < 2; ++i) {
-    if (h->bb[i].ready) (void)hipEventDestroy(h->bb[i].ready);
-    if (h->bb[i].consumed) (void)hipEventDestroy(h->bb[i].consumed);
-  }
-  if (h->fork) (void)hipEventDestroy(h->fork);
-  if (h->side) (void)hipStreamDestroy(h->side);
   for (auto& t : h->timers)
     for (auto e : t.ev) (void)hipEventDestroy(e);
   delete h;
@@ -543,15 +588,24 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
   if (rc != PA_OK) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipSetDevice(h->d.device));
+  GemmArgs probs[2];
+  int np = 0;
+  const float* x = nullptr;
+  if (next_v_out || target_out) probs[np++] = target_l1_problem(h, batch);
+  if (q_out) {
+    rc = resolve_x(h, batch, &x, s);
+    if (rc != PA_OK) return rc;
+    probs[np++] = online_l1_problem(h, x, batch->B);
+  }
+  if (np == 0) return PA_OK;
+  rc = launch_linear<false>(probs, np, s);
+  if (rc != PA_OK) return rc;
   if (next_v_out || target_out) {
-    rc = run_target(h, batch, next_v_out, target_out, s);
+    rc = run_target_fused(h, batch, next_v_out, target_out, s);
     if (rc != PA_OK) return rc;
   }
   if (q_out) {
-    const float* x = nullptr;
-    rc = resolve_x(h, batch, &x, s);
-    if (rc != PA_OK) return rc;
-    rc = run_online_fwd(h, x, batch->B, s);
+    rc = run_online_l2(h, batch->B, s);
     if (rc != PA_OK) return rc;
     rc = run_head(h, batch->B, nullptr, q_out, false, 1, s);
     if (rc != PA_OK) return rc;
@@ -570,15 +624,14 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
                            void* stream) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   PA_HIP(hipSetDevice(h->d.device));
-  ScopedTimer tm(h, "step", reinterpret_cast<hipStream_t>(stream));
-  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out,
+  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out, 0,
                    reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
-  return run_adamw(h, adam_step, reinterpret_cast<hipStream_t>(stream));
+  return run_adamw(h, adam_step, 1, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream) {
@@ -607,68 +660,56 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   rc = pa_arena_flush(arena, stream);
   if (rc != PA_OK) return rc;
   if (args->rounds == 0) return PA_OK;
-  ScopedTimer tm_all(h, "learn", s);
-  // fork: the side stream starts after everything already queued on `s`
-  PA_HIP(hipEventRecord(h->fork, s));
-  PA_HIP(hipStreamWaitEvent(h->side, h->fork, 0));
-  h->bb[0].used = h->bb[1].used = false;
-
-  auto issue_sample = [&](int r) -> int {
-    pa_dqn::BatchBuf& bb = h->bb[r & 1];
-    if (bb.used) PA_HIP(hipStreamWaitEvent(h->side, bb.consumed, 0));
-    pa_batch_out o;
-    memset(&o, 0, sizeof(o));
-    o.x = bb.x;
-    o.next_state = bb.next_state;
-    o.next_avail_rep = bb.next_avail_rep;
-    o.next_mask = bb.next_mask;
-    o.reward_f32 = bb.reward;
-    o.terminated = bb.term;
-    o.rep_dim = d.action_dim;
-    o.rep_onehot = args->rep_onehot;
-    int rc2;
-    {
-      ScopedTimer tm(h, "gather", h->side);
-      if (args->idx_host) {
-        PA_HIP(hipMemcpyAsync(bb.idx, args->idx_host + (int64_t)r * B, (size_t)B * 8,
-                              hipMemcpyHostToDevice, h->side));
-        rc2 = arena_gather_device(arena, bb.idx, B, &o, h->side);
-      } else {
-        rc2 = arena_sample(arena, args->seed, args->offset0 + (uint64_t)r, B, &o, bb.idx, h->side);
-      }
-    }
-    if (rc2 != PA_OK) return rc2;
-    PA_HIP(hipEventRecord(bb.ready, h->side));
-    return PA_OK;
-  };
-
-  rc = issue_sample(0);
+  const int R = args->rounds;
+  rc = ensure_idx(h, (int64_t)R * B);
   if (rc != PA_OK) return rc;
-  for (int r = 0; r < args->rounds; ++r) {
-    if (r + 1 < args->rounds) {
-      rc = issue_sample(r + 1);
+  ScopedTimer tm_all(h, "learn", s);
+  // ---- the index lists of EVERY round in one go (they do not depend on the parameters)
+  if (args->idx_host) {
+    for (int64_t i = 0; i < (int64_t)R * B; ++i)
+      PA_REQUIRE(args->idx_host[i] >= 0 && args->idx_host[i] < arena->size, PA_ERR_INVALID,
+                 "index %lld out of range [0, %lld)", (long long)args->idx_host[i],
+                 (long long)arena->size);
+    PA_HIP(hipMemcpyAsync(h->idx_all, args->idx_host, (size_t)R * B * 8, hipMemcpyHostToDevice, s));
+  } else {
+    ScopedTimer tm(h, "sample", s);
+    rc = sample_indices_launch(arena->size, args->seed, args->offset0, B, R, h->idx_all, s);
+    if (rc != PA_OK) return rc;
+  }
+  pa_batch_out o;
+  memset(&o, 0, sizeof(o));
+  o.x = h->bb.x;
+  o.next_state = h->bb.next_state;
+  o.next_avail_rep = h->bb.next_avail_rep;
+  o.next_mask = h->bb.next_mask;
+  o.reward_f32 = h->bb.reward;
+  o.terminated = h->bb.term;
+  o.rep_dim = d.action_dim;
+  o.rep_onehot = args->rep_onehot;
+  pa_dqn_batch b;
+  memset(&b, 0, sizeof(b));
+  b.B = B; b.A = A;
+  b.x = h->bb.x;
+  b.reward = h->bb.reward;
+  b.terminated = h->bb.term;
+  b.next_state = h->bb.next_state;
+  b.next_avail_rep = h->bb.next_avail_rep;
+  b.next_mask = h->bb.next_mask;
+  // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
+  // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
+  auto due = [&](int r) { return ((args->training_steps0 + r + 2) % args->target_update_freq) == 0; };
+  for (int r = 0; r < R; ++r) {
+    {
+      ScopedTimer tm(h, "gather", s);
+      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, B, &o, s);
       if (rc != PA_OK) return rc;
     }
-    pa_dqn::BatchBuf& bb = h->bb[r & 1];
-    PA_HIP(hipStreamWaitEvent(s, bb.ready, 0));
-    pa_dqn_batch b;
-    memset(&b, 0, sizeof(b));
-    b.B = B; b.A = A;
-    b.x = bb.x;
-    b.reward = bb.reward;
-    b.terminated = bb.term;
-    b.next_state = bb.next_state;
-    b.next_avail_rep = bb.next_avail_rep;
-    b.next_mask = bb.next_mask;
-    // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
-    // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
-    const int64_t ts = args->training_steps0 + r + 1;
-    const int do_tu = ((ts + 1) % args->target_update_freq) == 0;
+    // the first step's soft update runs stand-alone; later ones ride the previous AdamW launch
+    const int do_tu = (r == 0) ? due(0) : 0;
+    const int soft_next = (r + 1 < R) ? due(r + 1) : 0;
     rc = step_impl(h, &b, do_tu, args->adam_step0 + r + 1, 1,
-                   args->losses_out ? args->losses_out + r : nullptr, s);
+                   args->losses_out ? args->losses_out + r : nullptr, soft_next, s);
     if (rc != PA_OK) return rc;
-    PA_HIP(hipEventRecord(bb.consumed, s));
-    bb.used = true;
   }
   return PA_OK;
 }
@@ -712,12 +753,11 @@ extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int3
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.Bm = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-  g.bias = bias; g.Hmask = hmask; g.ldh = ldh; g.M = M; g.N = N; g.K = K;
-  if (!b_is_kn && epi == EPI_BIAS) return launch_linear<false, EPI_BIAS>(g, s);
-  if (!b_is_kn && epi == EPI_BIAS_RELU) return launch_linear<false, EPI_BIAS_RELU>(g, s);
-  if (b_is_kn && epi == EPI_MASK) return launch_linear<true, EPI_MASK>(g, s);
-  set_error("pa_debug_linear: combination (b_is_kn=%d, epi=%d) is not instantiated", b_is_kn, epi);
-  return PA_ERR_UNSUPPORTED;
+  g.bias = bias; g.Hmask = hmask; g.ldh = ldh; g.M = M; g.N = N; g.K = K; g.epi = epi;
+  PA_REQUIRE(epi >= 0 && epi <= 2, PA_ERR_INVALID, "bad epilogue %d", epi);
+  PA_REQUIRE(epi == EPI_MASK ? hmask != nullptr : bias != nullptr, PA_ERR_INVALID,
+             "epilogue %d needs %s", epi, epi == EPI_MASK ? "hmask" : "bias");
+  return b_is_kn ? launch_linear<true>(&g, 1, s) : launch_linear<false>(&g, 1, s);
 }
 
 extern "C" int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
@@ -731,9 +771,8 @@ extern "C" int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X
   a.p[0].dW = dW; a.p[0].ldw = ldw; a.p[0].db = db; a.p[0].M = M; a.p[0].N = N;
   a.p[0].tiles_n = (int)ceil_div(N, 32); a.p[0].tile0 = 0;
   a.total_tiles = (int)ceil_div(M, 32) * a.p[0].tiles_n;
-  a.p[1].tile0 = a.total_tiles; a.p[1].tiles_n = 0;
+  a.nprob = 1;
   a.B = Bn;
-  // no slab fold: launch exactly the GEMM tiles
   hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();

@@ -31,17 +31,40 @@ __device__ __forceinline__ int acc_row(int reg, int half) {
 }
 __device__ __forceinline__ float relu_keep_nan(float v) { return (v < 0.f) ? 0.f : v; }
 
-// base[col .. col+3] with zero fill outside [0, ncols) or when !row_ok.
-// vec: caller proved 16-byte alignment of base + col for col % 4 == 0.
-__device__ __forceinline__ float4 guarded_load4(const float* __restrict__ base, bool row_ok,
-                                                int col, int ncols, bool vec) {
-  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!row_ok) return r;
-  if (vec && col + 3 < ncols) return *reinterpret_cast<const float4*>(base + col);
-  if (col < ncols) r.x = base[col];
-  if (col + 1 < ncols) r.y = base[col + 1];
-  if (col + 2 < ncols) r.z = base[col + 2];
-  if (col + 3 < ncols) r.w = base[col + 3];
+// Guarded loads without branches: raw buffer loads through a wave-uniform resource descriptor;
+// an out-of-range byte offset makes the hardware return 0.  (hipcc turns "cond ? load : 0" — even
+// a clamped-address load followed by a select — into an exec-masked branch per load and waits for
+// each in turn, which serialises what should be one batch of outstanding loads;
+// cdna_hip_programming.md §5 trap (c), §5.5 T8.)  `p` must be wave-uniform (a kernel argument);
+// byte offsets must stay below 2 GiB.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kBufOob = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ float ld_or_zero(const float* __restrict__ p, int64_t off, bool ok) {
+  const unsigned bo = ok ? (unsigned)off * 4u : kBufOob;
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(buf_rsrc(p), (int)bo, 0, 0));
+}
+__device__ __forceinline__ float4 ld4_or_zero(const float* __restrict__ p, int64_t off, bool ok) {
+  const unsigned bo = ok ? (unsigned)off * 4u : kBufOob;
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(p), (int)bo, 0, 0);
+  // whole-vector bit_cast: element-wise __builtin_bit_cast(float, v.x) is narrowed by hipcc 7.2
+  // to ONE dword load splatted over all four lanes (observed in the ISA)
+  const f32x4_t f = __builtin_bit_cast(f32x4_t, v);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+// base[col .. col+3] of one row with zero fill outside [0, ncols) or when !row_ok; no alignment
+// or multiple-of-4 assumption (four dword loads).
+__device__ __forceinline__ float4 guarded_load4(const float* __restrict__ p, int64_t row_off,
+                                                bool row_ok, int col, int ncols) {
+  float4 r;
+  r.x = ld_or_zero(p, row_off + col, row_ok && col < ncols);
+  r.y = ld_or_zero(p, row_off + col + 1, row_ok && col + 1 < ncols);
+  r.z = ld_or_zero(p, row_off + col + 2, row_ok && col + 2 < ncols);
+  r.w = ld_or_zero(p, row_off + col + 3, row_ok && col + 3 < ncols);
   return r;
 }
 __device__ __forceinline__ bool is_vec_ok(const float* p, int ld) {
@@ -52,12 +75,15 @@ __device__ __forceinline__ float f4_get(const float4& v, int j) {
 }
 
 // ---------------------------------------------------------------------------
-// Generic LDS-staged linear layer, C[M,N] = epi(A[M,K] * op(B)), tile 32 x 64.
+// LDS-staged linear layer, C[M,N] = epi(A[M,K] * op(B)), tile 32 x 64, up to two
+// independent problems per launch (blockIdx.z).
 //   B_KS = false: B is [N][K] (a torch Linear weight; y = x W^T)
 //   B_KS = true : B is [K][N] (the same weight used for dX = dY W)
-// KW waves share each N half by splitting every 32-deep K chunk between them
-// (latency, not throughput, bounds these 1024-row GEMMs); partial tiles are
-// summed in a fixed order through LDS, so results are deterministic.
+// These are 1024-row GEMMs of 0.07-0.27 GFLOP: latency, not throughput, bounds
+// them.  So a workgroup issues EVERY global load of its (32 + 64) x K operand
+// panel up front (K <= 256 per pass; one exposed memory latency instead of one
+// per K chunk), stages it once in LDS, and KW waves per N half split the K range;
+// partial tiles are summed in a fixed order through LDS (deterministic).
 // ---------------------------------------------------------------------------
 enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2 };
 
@@ -68,105 +94,140 @@ struct GemmArgs {
   const float* bias;
   const float* Hmask; int ldh;
   int M, N, K;
+  int epi;
+};
+struct LinArgs {
+  GemmArgs p[2];
 };
 
-constexpr int G_BM = 32, G_BN = 64, G_BK = 32, G_PK = 36 /* K pitch */, G_PN = 68 /* N pitch */;
+constexpr int G_BM = 32, G_BN = 64, G_BK = 32, G_PK = 36 /* K pitch of 32-deep chunks */,
+              G_PN = 68 /* N pitch */, G_KCAP = 256 /* K per staging pass */;
 
-template <bool B_KS, int EPI, int KW>
-__global__ __launch_bounds__(128 * KW) void linear_kernel(GemmArgs g) {
+__host__ __device__ inline int lin_kpad(int K) {
+  const int k = K < G_KCAP ? K : G_KCAP;
+  return (k + 31) & ~31;
+}
+
+template <bool B_KS, int KW>
+__global__ __launch_bounds__(128 * KW) void linear_kernel(LinArgs args) {
   constexpr int NT = 128 * KW;
-  constexpr int A_F4 = G_BM * G_BK / 4;  // 256
-  constexpr int B_F4 = G_BN * G_BK / 4;  // 512
-  constexpr int NPRE = (A_F4 + B_F4 + NT - 1) / NT;
-  constexpr int B_TILE = B_KS ? (G_BK * G_PN) : (G_BN * G_PK);
+  constexpr int SLOTS = (G_BM + G_BN) * (G_KCAP / 4);  // float4 slots of one full panel
+  constexpr int NPRE = (SLOTS + NT - 1) / NT;
+  constexpr int A_SLOTS = G_BM * (G_KCAP / 4);
+  const GemmArgs& g = args.p[blockIdx.z];
+  const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
+  if (m0 >= g.M || n0 >= g.N) return;  // grid covers the larger of the two problems
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* As = smem;                      // [2][32][36]
-  float* Bs = As + 2 * G_BM * G_PK;      // [2][B_TILE]
-  float* Part = Bs + 2 * B_TILE;         // [KW-1][2][16*64]
+  const int KP = lin_kpad(g.K);        // staged K (multiple of 32)
+  const int P = KP + 4;                // K pitch (== 4 mod 32: conflict-free b128 reads)
+  float* As = smem;                                   // [32][P]
+  float* Bs = As + G_BM * P;                          // KC: [64][P]   KS: [KP][68]
+  float* Part = Bs + (B_KS ? KP * G_PN : G_BN * P);   // [KW-1][2][16*64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nt = wave & 1, kw = wave >> 1;
   const int h = lane >> 5, l31 = lane & 31;
-  const int m0 = blockIdx.y * G_BM, n0 = blockIdx.x * G_BN;
-  const bool vecA = is_vec_ok(g.A, g.lda), vecB = is_vec_ok(g.Bm, g.ldb);
-  const int NK = (g.K + G_BK - 1) / G_BK;
-
-  float4 pre[NPRE];
-  auto issue = [&](int kc) {
-    const int k0 = kc * G_BK;
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-      const int f = tid + q * NT;
-      if (f < A_F4) {
-        const int r = f >> 3, c = f & 7;
-        pre[q] = guarded_load4(g.A + (int64_t)(m0 + r) * g.lda, (m0 + r) < g.M, k0 + c * 4, g.K,
-                               vecA);
-      } else if (f < A_F4 + B_F4) {
-        const int fb = f - A_F4;
-        if (!B_KS) {
-          const int n = fb >> 3, c = fb & 7;
-          pre[q] = guarded_load4(g.Bm + (int64_t)(n0 + n) * g.ldb, (n0 + n) < g.N, k0 + c * 4,
-                                 g.K, vecB);
-        } else {
-          const int kk = fb >> 4, c = fb & 15;
-          pre[q] = guarded_load4(g.Bm + (int64_t)(k0 + kk) * g.ldb, (k0 + kk) < g.K, n0 + c * 4,
-                                 g.N, vecB);
-        }
-      }
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-      const int f = tid + q * NT;
-      if (f < A_F4) {
-        const int r = f >> 3, c = f & 7;
-        *reinterpret_cast<float4*>(As + buf * G_BM * G_PK + r * G_PK + c * 4) = pre[q];
-      } else if (f < A_F4 + B_F4) {
-        const int fb = f - A_F4;
-        if (!B_KS) {
-          const int n = fb >> 3, c = fb & 7;
-          *reinterpret_cast<float4*>(Bs + buf * B_TILE + n * G_PK + c * 4) = pre[q];
-        } else {
-          const int kk = fb >> 4, c = fb & 15;
-          *reinterpret_cast<float4*>(Bs + buf * B_TILE + kk * G_PN + c * 4) = pre[q];
-        }
-      }
-    }
-  };
+  // wave-uniform: whole float4s are in or out of range, so the load phase needs no branches
+  const bool fastA = is_vec_ok(g.A, g.lda) && ((g.K & 3) == 0);
+  const bool fastB = is_vec_ok(g.Bm, g.ldb) && (((B_KS ? g.N : g.K) & 3) == 0);
+  // epilogue operands are fetched now, not after the MFMA chain
+  const int ecol = n0 + nt * 32 + l31;
+  float bv = 0.f;
+  if (g.epi != EPI_MASK) bv = ld_or_zero(g.bias, ecol, ecol < g.N);
 
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  issue(0);
-  commit(0);
-  __syncthreads();
-  for (int kc = 0; kc < NK; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < NK) issue(kc + 1);
-    const float* as = As + buf * G_BM * G_PK;
-    const float* bs = Bs + buf * B_TILE;
+  for (int kb = 0; kb < g.K; kb += G_KCAP) {
+    const int klen = min(G_KCAP, g.K - kb);
+    const int q4 = ((klen + 31) & ~31) >> 2;  // float4 per staged row
+    float4 pre[NPRE];
+    if (fastA && fastB) {
+      // every float4 is entirely inside or entirely outside the operand: clamp + select
 #pragma unroll
-    for (int kgi = 0; kgi < 4 / KW; ++kgi) {
-      const int kg = kgi * KW + kw;
-      const float4 a4 = *reinterpret_cast<const float4*>(as + l31 * G_PK + kg * 8 + 4 * h);
+      for (int q = 0; q < NPRE; ++q) {
+        const int f = tid + q * NT;
+        if (f < A_SLOTS) {
+          const int r = f >> 6, c = f & 63;
+          pre[q] = ld4_or_zero(g.A, (int64_t)(m0 + r) * g.lda + kb + c * 4,
+                               (m0 + r) < g.M && c * 4 < klen);
+        } else {
+          const int fb = f - A_SLOTS;
+          if (!B_KS) {
+            const int n = fb >> 6, c = fb & 63;
+            pre[q] = ld4_or_zero(g.Bm, (int64_t)(n0 + n) * g.ldb + kb + c * 4,
+                                 f < SLOTS && (n0 + n) < g.N && c * 4 < klen);
+          } else {
+            const int kk = fb >> 4, c = fb & 15;
+            pre[q] = ld4_or_zero(g.Bm, (int64_t)(kb + kk) * g.ldb + n0 + c * 4,
+                                 f < SLOTS && kk < klen && (n0 + c * 4) < g.N);
+          }
+        }
+      }
+    } else {
+      // generic shapes (unaligned rows, K or N not a multiple of 4): element-wise guards
+#pragma unroll
+      for (int q = 0; q < NPRE; ++q) {
+        const int f = tid + q * NT;
+        pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f < A_SLOTS) {
+          const int r = f >> 6, c = f & 63;
+          if (c < q4)
+            pre[q] = guarded_load4(g.A, (int64_t)(m0 + r) * g.lda + kb, (m0 + r) < g.M, c * 4, klen);
+        } else if (f < SLOTS) {
+          const int fb = f - A_SLOTS;
+          if (!B_KS) {
+            const int n = fb >> 6, c = fb & 63;
+            if (c < q4)
+              pre[q] = guarded_load4(g.Bm, (int64_t)(n0 + n) * g.ldb + kb, (n0 + n) < g.N, c * 4,
+                                     klen);
+          } else {
+            const int kk = fb >> 4, c = fb & 15;
+            if (kk < q4 * 4)
+              pre[q] = guarded_load4(g.Bm, (int64_t)(kb + kk) * g.ldb + n0, kk < klen, c * 4,
+                                     g.N - n0);
+          }
+        }
+      }
+    }
+    if (kb > 0) __syncthreads();  // previous pass is done reading the panel
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+      const int f = tid + q * NT;
+      if (f < A_SLOTS) {
+        const int r = f >> 6, c = f & 63;
+        if (c < q4) *reinterpret_cast<float4*>(As + r * P + c * 4) = pre[q];
+      } else if (f < SLOTS) {
+        const int fb = f - A_SLOTS;
+        if (!B_KS) {
+          const int n = fb >> 6, c = fb & 63;
+          if (c < q4) *reinterpret_cast<float4*>(Bs + n * P + c * 4) = pre[q];
+        } else {
+          const int kk = fb >> 4, c = fb & 15;
+          if (kk < q4 * 4) *reinterpret_cast<float4*>(Bs + kk * G_PN + c * 4) = pre[q];
+        }
+      }
+    }
+    __syncthreads();
+    const int nkg = q4 >> 1;  // groups of 8 k
+    const float* ap = As + l31 * P + 4 * h;
+#pragma unroll 2
+    for (int kg = kw; kg < nkg; kg += KW) {
+      const float4 a4 = *reinterpret_cast<const float4*>(ap + kg * 8);
       float b[4];
       if (!B_KS) {
-        const float4 b4 =
-            *reinterpret_cast<const float4*>(bs + (nt * 32 + l31) * G_PK + kg * 8 + 4 * h);
+        const float4 b4 = *reinterpret_cast<const float4*>(Bs + (nt * 32 + l31) * P + kg * 8 + 4 * h);
         b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w;
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = bs[(kg * 8 + 4 * h + j) * G_PN + nt * 32 + l31];
+        for (int j = 0; j < 4; ++j) b[j] = Bs[(kg * 8 + 4 * h + j) * G_PN + nt * 32 + l31];
       }
       acc = mfma32(a4.x, b[0], acc);
       acc = mfma32(a4.y, b[1], acc);
       acc = mfma32(a4.z, b[2], acc);
       acc = mfma32(a4.w, b[3], acc);
     }
-    if (kc + 1 < NK) commit(buf ^ 1);
-    __syncthreads();
   }
   if (KW > 1) {
     if (kw > 0) {
@@ -185,18 +246,24 @@ __global__ __launch_bounds__(128 * KW) void linear_kernel(GemmArgs g) {
     }
   }
   if (kw == 0) {
-    const int col = n0 + nt * 32 + l31;
+    const int col = ecol;
+    float hm[16];
+    if (g.epi == EPI_MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + acc_row(r, h);
+        hm[r] = ld_or_zero(g.Hmask, (int64_t)row * g.ldh + col, row < g.M && col < g.N);
+      }
+    }
     if (col < g.N) {
-      float bv = 0.f;
-      if (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU) bv = g.bias[col];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + acc_row(r, h);
         if (row < g.M) {
           float v = acc[r];
-          if (EPI == EPI_BIAS) v += bv;
-          if (EPI == EPI_BIAS_RELU) v = relu_keep_nan(v + bv);
-          if (EPI == EPI_MASK) v = (g.Hmask[(int64_t)row * g.ldh + col] > 0.f) ? v : 0.f;
+          if (g.epi == EPI_BIAS) v += bv;
+          else if (g.epi == EPI_BIAS_RELU) v = relu_keep_nan(v + bv);
+          else v = (hm[r] > 0.f) ? v : 0.f;
           g.C[(int64_t)row * g.ldc + col] = v;
         }
       }
@@ -205,8 +272,9 @@ __global__ __launch_bounds__(128 * KW) void linear_kernel(GemmArgs g) {
 }
 
 template <bool B_KS, int KW>
-constexpr size_t linear_smem_bytes() {
-  return sizeof(float) * (2 * G_BM * G_PK + 2 * (B_KS ? (G_BK * G_PN) : (G_BN * G_PK)) +
+inline size_t linear_smem_bytes(int K) {
+  const int KP = lin_kpad(K), P = KP + 4;
+  return sizeof(float) * ((size_t)G_BM * P + (B_KS ? (size_t)KP * G_PN : (size_t)G_BN * P) +
                           (KW > 1 ? (KW - 1) * 2 * 1024 : 0));
 }
 
@@ -264,13 +332,23 @@ __global__ __launch_bounds__(512) void target_fused_kernel(TargetArgs a) {
   const int NK = (a.H1 + G_BK - 1) / G_BK;
 
   float4 pre[NPRE];
+  const bool fastW2 = vecW2 && ((a.H1 & 3) == 0);  // wave-uniform
   auto issue = [&](int kc) {
     const int k0 = kc * G_BK;
+    if (fastW2) {
 #pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-      const int f = tid + q * 512;
-      const int n = f >> 3, c = f & 7;
-      pre[q] = guarded_load4(a.W2 + (int64_t)n * a.ldw2, n < a.H2, k0 + c * 4, a.H1, vecW2);
+      for (int q = 0; q < NPRE; ++q) {
+        const int f = tid + q * 512;
+        const int n = f >> 3, c = f & 7;
+        pre[q] = ld4_or_zero(a.W2, (int64_t)n * a.ldw2 + k0 + c * 4, n < a.H2 && (k0 + c * 4) < a.H1);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NPRE; ++q) {
+        const int f = tid + q * 512;
+        const int n = f >> 3, c = f & 7;
+        pre[q] = guarded_load4(a.W2, (int64_t)n * a.ldw2, n < a.H2, k0 + c * 4, a.H1);
+      }
     }
   };
   auto commit = [&](int buf) {
@@ -289,28 +367,26 @@ __global__ __launch_bounds__(512) void target_fused_kernel(TargetArgs a) {
   for (int r = 0; r < 16; ++r) {
     const int row = wm * 32 + acc_row(r, h);
     const bool rok = row < nrows;
-    const int bb = rok ? (b0 + row / a.A) : 0;
+    const int bb = b0 + (rok ? row / a.A : 0);
 #pragma unroll
     for (int t = 0; t < TN1; ++t) {
       const int col = (wn * TN1 + t) * 32 + l31;
-      acc1[t][r] = (rok && col < a.H1) ? a.U[(int64_t)bb * a.ldu + col] : 0.f;
+      acc1[t][r] = ld_or_zero(a.U, (int64_t)bb * a.ldu + col, rok && col < a.H1);
     }
   }
   for (int c0 = 0; c0 < a.AD; c0 += T_ADC) {
     for (int e = tid; e < T_ROWS * T_ADC; e += 512) {
       const int r = e >> 4, j = e & 15;
-      float v = 0.f;
-      if (r < nrows && c0 + j < a.AD) {
-        const int bb = b0 + r / a.A, i = r % a.A;
-        v = a.feat[(int64_t)bb * a.feat_bstride + (int64_t)i * a.AD + c0 + j];
-      }
-      featS[r * T_ADP + j] = v;
+      const bool ok = r < nrows && c0 + j < a.AD;
+      const int rr = ok ? r : 0;
+      const int bb = b0 + rr / a.A, i = rr % a.A;
+      featS[r * T_ADP + j] =
+          ld_or_zero(a.feat, (int64_t)bb * a.feat_bstride + (int64_t)i * a.AD + c0 + j, ok);
     }
     for (int e = tid; e < H1P * T_ADC; e += 512) {
       const int n = e >> 4, j = e & 15;
-      float v = 0.f;
-      if (n < a.H1 && c0 + j < a.AD) v = a.W1a[(int64_t)n * a.ldw1 + c0 + j];
-      W1aS[n * T_ADP + j] = v;
+      W1aS[n * T_ADP + j] =
+          ld_or_zero(a.W1a, (int64_t)n * a.ldw1 + c0 + j, n < a.H1 && c0 + j < a.AD);
     }
     __syncthreads();
 #pragma unroll
@@ -425,87 +501,78 @@ __global__ __launch_bounds__(512) void target_fused_kernel(TargetArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// Output head + loss + first backward stage (one wave per transition row):
+// Output head + loss + first backward stage, one wave per transition row:
 //   q = w3 . h2 + b3;  d = q - y;  dq = (2 / (B * world)) * d
 //   dZ2[b][n] = h2[b][n] > 0 ? dq * w3[n] : 0
-// and per-workgroup slabs of dW3 = sum_b dq h2[b], db3 = sum_b dq, sum_b |d|.
+// dq[b] and |d|[b] go to small vectors; their batch reductions ride the weight
+// gradient kernel (dW3 = dq^T h2 is its third problem) and the AdamW kernel.
 // ---------------------------------------------------------------------------
 struct HeadArgs {
   const float* H2a; int ldh;  // [B][H2] relu output of layer 2
   const float* w3; const float* b3;
-  const float* y;             // Bellman target (may be null in probe mode)
+  const float* y;             // Bellman target (null in probe mode)
   float* q_out;               // may be null
+  float* dq_out;              // [B] (null in probe mode)
+  float* absd_out;            // [B]
   float* dZ2; int ldz;        // may be null (probe mode)
-  float* slab;                // [gridDim.x][H2 + 2]: dW3 | db3 | sum|d|
   float norm;                 // 2 / (B * world)
   int B, H2;
 };
-constexpr int HEAD_ROWS = 16;
 
 __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a) {
-  __shared__ float dq_s[HEAD_ROWS];
-  __shared__ float ad_s[HEAD_ROWS];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * HEAD_ROWS;
-  const float b3 = a.b3[0];
-  for (int rr = wave; rr < HEAD_ROWS; rr += 4) {
-    const int b = r0 + rr;
-    float dq = 0.f, ad = 0.f;
-    if (b < a.B) {
-      const float* hrow = a.H2a + (int64_t)b * a.ldh;
-      float p = 0.f;
-      for (int n = lane; n < a.H2; n += 64) p = fmaf(hrow[n], a.w3[n], p);
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off);
-      const float q = p + b3;
-      if (a.q_out && lane == 0) a.q_out[b] = q;
-      if (a.y) {
-        const float d = __fsub_rn(q, a.y[b]);
-        dq = __fmul_rn(a.norm, d);
-        ad = fabsf(d);
-        if (a.dZ2) {
-          float* zrow = a.dZ2 + (int64_t)b * a.ldz;
-          for (int n = lane; n < a.H2; n += 64)
-            zrow[n] = (hrow[n] > 0.f) ? __fmul_rn(dq, a.w3[n]) : 0.f;
-        }
-      }
-    }
-    if (lane == 0) {
-      dq_s[rr] = dq;
-      ad_s[rr] = ad;
-    }
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const bool fast = is_vec_ok(a.H2a, a.ldh) && is_vec_ok(a.w3, 4) && ((a.H2 & 3) == 0);
+  float p = 0.f;
+  // H2 <= 256 = 64 lanes x 4 columns
+  const int c = lane * 4;
+  float4 hv, wv;
+  if (fast) {
+    hv = ld4_or_zero(a.H2a, (int64_t)b * a.ldh + c, c < a.H2);
+    wv = ld4_or_zero(a.w3, c, c < a.H2);
+  } else {
+    hv = guarded_load4(a.H2a, (int64_t)b * a.ldh, true, c, a.H2);
+    wv = guarded_load4(a.w3, 0, true, c, a.H2);
   }
-  __syncthreads();
-  if (!a.slab) return;
-  float* slab = a.slab + (int64_t)blockIdx.x * (a.H2 + 2);
-  for (int n = tid; n < a.H2; n += 256) {
-    float s = 0.f;
+  p = fmaf(hv.x, wv.x, p); p = fmaf(hv.y, wv.y, p); p = fmaf(hv.z, wv.z, p); p = fmaf(hv.w, wv.w, p);
 #pragma unroll
-    for (int rr = 0; rr < HEAD_ROWS; ++rr) {
-      const int b = r0 + rr;
-      if (b < a.B) s = fmaf(dq_s[rr], a.H2a[(int64_t)b * a.ldh + n], s);
-    }
-    slab[n] = s;
+  for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off);
+  const float q = p + a.b3[0];
+  if (a.q_out && lane == 0) a.q_out[b] = q;
+  if (!a.y) return;
+  const float d = __fsub_rn(q, a.y[b]);
+  const float dq = __fmul_rn(a.norm, d);
+  if (lane == 0) {
+    a.dq_out[b] = dq;
+    a.absd_out[b] = fabsf(d);
   }
-  if (tid == 0) {
-    float s = 0.f, t = 0.f;
-#pragma unroll
-    for (int rr = 0; rr < HEAD_ROWS; ++rr) {
-      s += dq_s[rr];
-      t += ad_s[rr];
+  if (a.dZ2) {
+    float* zrow = a.dZ2 + (int64_t)b * a.ldz;
+    float4 z;
+    z.x = (hv.x > 0.f) ? __fmul_rn(dq, wv.x) : 0.f;
+    z.y = (hv.y > 0.f) ? __fmul_rn(dq, wv.y) : 0.f;
+    z.z = (hv.z > 0.f) ? __fmul_rn(dq, wv.z) : 0.f;
+    z.w = (hv.w > 0.f) ? __fmul_rn(dq, wv.w) : 0.f;
+    if (is_vec_ok(a.dZ2, a.ldz) && c + 3 < a.H2) {
+      *reinterpret_cast<float4*>(zrow + c) = z;
+    } else {
+      if (c < a.H2) zrow[c] = z.x;
+      if (c + 1 < a.H2) zrow[c + 1] = z.y;
+      if (c + 2 < a.H2) zrow[c + 2] = z.z;
+      if (c + 3 < a.H2) zrow[c + 3] = z.w;
     }
-    slab[a.H2] = s;
-    slab[a.H2 + 1] = t;
   }
 }
 
 // ---------------------------------------------------------------------------
-// Weight gradients: dW[i][j] = sum_b dZ[b][i] X[b][j], db[i] = sum_b dZ[b][i].
+// Weight gradients: dW[i][j] = sum_b dZ[b][i] X[b][j], db[i] = sum_b dZ[b][i], for
+// up to three problems per launch (dW2/db2, dW1/db1, dW3/db3 with dZ = dq[B][1]).
 // One 32 x 32 output tile per workgroup; its 8 waves split the batch (the K
 // dimension) and add their partial tiles in a fixed order through LDS.  Both
 // operands are row-contiguous across lanes, so they go global -> VGPR -> MFMA
-// with no LDS staging.  The last block folds the head kernel's slabs into
-// dW3 / db3 and the reported loss.
+// with no LDS staging; every load of a wave's 128-row slice is issued before the
+// first MFMA (one exposed memory latency).
 // ---------------------------------------------------------------------------
 struct DwProblem {
   const float* dZ; int ldz;   // [B][M]
@@ -515,55 +582,46 @@ struct DwProblem {
   int M, N, tiles_n, tile0;
 };
 struct DwArgs {
-  DwProblem p[2];
-  int B, total_tiles;
-  const float* slab; int nslab; int H2;
-  float* dW3; float* db3; float* loss_out; float inv_B;
+  DwProblem p[3];
+  int nprob, B, total_tiles;
 };
+constexpr int DW_ROWS = 128;  // batch rows per wave per pass
 
 __global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
   __shared__ float part[8 * 1024];
   __shared__ float csum[8 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  if ((int)blockIdx.x >= a.total_tiles) {
-    // slab fold (deterministic order)
-    for (int n = tid; n < a.H2 + 2; n += 512) {
-      float s = 0.f;
-      for (int w = 0; w < a.nslab; ++w) s += a.slab[(int64_t)w * (a.H2 + 2) + n];
-      if (n < a.H2) a.dW3[n] = s;
-      else if (n == a.H2) a.db3[0] = s;
-      else if (a.loss_out) a.loss_out[0] = s * a.inv_B;
-    }
-    return;
-  }
-  const DwProblem& P = ((int)blockIdx.x >= a.p[1].tile0 && a.p[1].tiles_n > 0) ? a.p[1] : a.p[0];
+  int pi = 0;
+  if (a.nprob > 1 && (int)blockIdx.x >= a.p[1].tile0) pi = 1;
+  if (a.nprob > 2 && (int)blockIdx.x >= a.p[2].tile0) pi = 2;
+  const DwProblem& P = a.p[pi];
   const int t = blockIdx.x - P.tile0;
   const int i0 = (t / P.tiles_n) * 32, j0 = (t % P.tiles_n) * 32;
-  const int per = ((a.B + 63) / 64) * 8;  // rows per wave, multiple of 8
-  const int bs = wave * per;
-  const int be = min(a.B, bs + per);
   const bool iok = (i0 + l31) < P.M, jok = (j0 + l31) < P.N;
-  const float* zp = P.dZ + i0 + l31;
-  const float* xp = P.X + j0 + l31;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float cs = 0.f;
-#pragma unroll 2
-  for (int kb = bs; kb < be; kb += 8) {
-    float av[4], xv[4];
+  for (int base = wave * DW_ROWS; base < a.B; base += 8 * DW_ROWS) {
+    float av[DW_ROWS / 8][4], xv[DW_ROWS / 8][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int bb = kb + 4 * h + j;
-      const bool ok = bb < be;
-      av[j] = (ok && iok) ? zp[(int64_t)bb * P.ldz] : 0.f;
-      xv[j] = (ok && jok) ? xp[(int64_t)bb * P.ldx] : 0.f;
+    for (int g = 0; g < DW_ROWS / 8; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int bb = base + g * 8 + 4 * h + j;
+        const bool ok = bb < a.B;
+        av[g][j] = ld_or_zero(P.dZ, (int64_t)bb * P.ldz + i0 + l31, ok && iok);
+        xv[g][j] = ld_or_zero(P.X, (int64_t)bb * P.ldx + j0 + l31, ok && jok);
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc = mfma32(av[j], xv[j], acc);
-      cs += av[j];
+    for (int g = 0; g < DW_ROWS / 8; ++g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc = mfma32(av[g][j], xv[g][j], acc);
+        cs += av[g][j];
+      }
     }
   }
 #pragma unroll
@@ -605,9 +663,25 @@ struct AdamArgs {
   float neg_step;    // -lr / (1 - beta1^t)
   float eps;
   int amsgrad;
+  // fused extras (may be disabled)
+  const float* absd; int nabs; float inv_B; float* loss_out;  // loss_out[0] = mean |Q - target|
+  float* tgt; float tau, one_minus_tau; int soft_next;        // soft update due before the NEXT step
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  __shared__ float red[256];
+  if (blockIdx.x == 0 && a.loss_out) {
+    // mean |Q - target| of this step (deep_td_learning.py:358-359), fixed summation order
+    float s = 0.f;
+    for (int i = threadIdx.x; i < a.nabs; i += 256) s += a.absd[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) a.loss_out[0] = red[0] * a.inv_B;
+  }
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
   const float g = a.g[i];
@@ -630,6 +704,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   a.p[i] = p;
   a.m[i] = m;
   a.v[i] = v;
+  if (a.soft_next)  // update_target_network of the next step's forward() (common/utils.py:214-226)
+    a.tgt[i] = __fadd_rn(__fmul_rn(a.tau, p), __fmul_rn(a.one_minus_tau, a.tgt[i]));
 }
 
 // theta' <- tau * theta + (1 - tau) * theta'   (common/utils.py:214-226)
