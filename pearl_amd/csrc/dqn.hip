@@ -40,6 +40,7 @@ struct pa_dqn {
   int IN;            // S + AD
   // workspaces (HBM)
   float *U, *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
+  float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's B operand)
   // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
   struct BatchBuf {
     float* x;
@@ -144,28 +145,27 @@ int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s) {
   return PA_OK;
 }
 
-template <int TN1, int TN2>
+template <int NKG>
 int launch_target_t(const TargetArgs& a, hipStream_t s) {
   static bool configured = false;
-  auto kern = target_fused_kernel<TN1, TN2>;
-  const size_t smem = target_smem_bytes<TN1, TN2>();
+  const size_t smem = target_smem_bytes(a.H1);
   if (!configured) {
-    int rc = set_max_smem(kern, smem);
+    int rc = set_max_smem(target_fused_kernel<NKG>, smem);
     if (rc != PA_OK) return rc;
     configured = true;
   }
   const unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+  hipLaunchKernelGGL(target_fused_kernel<NKG>, dim3(grid), dim3(512), smem, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
 
 int launch_target(const TargetArgs& a, hipStream_t s) {
-  const int tn1 = a.H1 <= 128 ? 1 : 2, tn2 = a.H2 <= 128 ? 1 : 2;
-  if (tn1 == 1 && tn2 == 1) return launch_target_t<1, 1>(a, s);
-  if (tn1 == 1 && tn2 == 2) return launch_target_t<1, 2>(a, s);
-  if (tn1 == 2 && tn2 == 1) return launch_target_t<2, 1>(a, s);
-  return launch_target_t<2, 2>(a, s);
+  switch (t_nkg(a.H1)) {
+    case 8: return launch_target_t<8>(a, s);
+    case 16: return launch_target_t<16>(a, s);
+    default: return launch_target_t<32>(a, s);
+  }
 }
 
 struct NetPtrs {
@@ -252,7 +252,7 @@ int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, 
   a.mask = b->next_mask;
   a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
   a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
-  a.W2 = t.W2; a.ldw2 = d.hidden1;
+  a.W2f = h->w2f;
   a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
   a.reward = b->reward; a.term = b->terminated;
   a.gamma = d.discount;
@@ -380,6 +380,7 @@ int run_adamw(pa_dqn* h, int64_t step, int B, float* loss_out, int soft_next, hi
   a.absd = h->absd; a.nabs = B; a.inv_B = (float)(1.0 / (double)B); a.loss_out = loss_out;
   a.tgt = h->bufs.q_target; a.tau = d.tau; a.one_minus_tau = (float)(1.0 - (double)d.tau);
   a.soft_next = soft_next;
+  a.w2f = h->w2f; a.w2_off = h->off[2]; a.H1 = d.hidden1; a.H2 = d.hidden2;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -397,25 +398,40 @@ int run_loss_fold(pa_dqn* h, int B, float* loss_out, hipStream_t s) {
   return PA_OK;
 }
 
+// Refresh the fragment-major copy of the target W2 (after anything that changed the target net).
+int run_repack(pa_dqn* h, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const int64_t slots = w2f_floats(d.hidden2, d.hidden1) / 4;
+  hipLaunchKernelGGL(repack_w2_kernel, dim3((unsigned)ceil_div(slots, 256)), dim3(256), 0, s,
+                     h->bufs.q_target + h->off[2], d.hidden2, d.hidden1, h->w2f);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 int run_soft_update(pa_dqn* h, hipStream_t s) {
   ScopedTimer tm(h, "soft_update", s);
   hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s,
                      h->bufs.q_target, h->bufs.q, h->P, h->d.tau, (float)(1.0 - (double)h->d.tau));
   PA_LAUNCH_CHECK();
-  return PA_OK;
+  return run_repack(h, s);
 }
 
 // One learn_batch.  do_target_update: soft update BEFORE the forward (skip it when the previous
 // step's AdamW launch already did it, soft_next).  soft_next: fuse the next step's soft update
 // into this step's AdamW launch.
+// w2f_current: the fragment-major target W2 is known to match bufs.q_target (inside the fused
+// learn loop); otherwise it is rebuilt first (the caller may have loaded a checkpoint).
 int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_t adam_step,
-              int grad_world, float* loss_out, int soft_next, hipStream_t s) {
+              int grad_world, float* loss_out, int soft_next, bool w2f_current, hipStream_t s) {
   int rc = check_batch(h, batch);
   if (rc != PA_OK) return rc;
   PA_REQUIRE(grad_world >= 1, PA_ERR_INVALID, "grad_world must be >= 1");
   if (h->timing) h->tick++;
   if (do_target_update) {
-    rc = run_soft_update(h, s);
+    rc = run_soft_update(h, s);  // also repacks
+    if (rc != PA_OK) return rc;
+  } else if (!w2f_current) {
+    rc = run_repack(h, s);
     if (rc != PA_OK) return rc;
   }
   const float* x = nullptr;
@@ -524,7 +540,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->idx_cap = 0;
   h->tick = 0;
   h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->dq = h->absd =
-      h->xpack = h->loss_scratch = nullptr;
+      h->xpack = h->loss_scratch = h->w2f = nullptr;
   const int64_t B = desc->max_batch;
 #define PA_WS(ptr, floats)                                                       \
   do {                                                                           \
@@ -547,6 +563,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->absd, B);
   PA_WS(h->xpack, B * h->IN);
   PA_WS(h->loss_scratch, 4);
+  PA_WS(h->w2f, w2f_floats(desc->hidden2, desc->hidden1));
 #undef PA_WS
   *out = h;
   return PA_OK;
@@ -557,7 +574,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipSetDevice(h->d.device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->U, h->H1a, h->H2a, h->dZ2, h->dZ1, h->y, h->nextv, h->qbuf, h->dq, h->absd,
-                  h->xpack, h->loss_scratch, h->idx_all};
+                  h->xpack, h->loss_scratch, h->idx_all, h->w2f};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free_batchbufs(h);
@@ -601,6 +618,8 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
   rc = launch_linear<false>(probs, np, s);
   if (rc != PA_OK) return rc;
   if (next_v_out || target_out) {
+    rc = run_repack(h, s);
+    if (rc != PA_OK) return rc;
     rc = run_target_fused(h, batch, next_v_out, target_out, s);
     if (rc != PA_OK) return rc;
   }
@@ -624,7 +643,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
                            void* stream) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   PA_HIP(hipSetDevice(h->d.device));
-  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out, 0,
+  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out, 0, false,
                    reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -708,7 +727,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     const int do_tu = (r == 0) ? due(0) : 0;
     const int soft_next = (r + 1 < R) ? due(r + 1) : 0;
     rc = step_impl(h, &b, do_tu, args->adam_step0 + r + 1, 1,
-                   args->losses_out ? args->losses_out + r : nullptr, soft_next, s);
+                   args->losses_out ? args->losses_out + r : nullptr, soft_next, r > 0, s);
     if (rc != PA_OK) return rc;
   }
   return PA_OK;

@@ -284,16 +284,24 @@ inline size_t linear_smem_bytes(int K) {
 // then mask, row max over i, and the Bellman target.  One workgroup owns
 // bpw = floor(64 / A) whole transitions (<= 64 MFMA rows) and ALL H2 columns, so
 // h1/h2 never leave LDS/registers: the 16384 x 256 x 256 layer-2 product — 79 % of
-// a DQN step's FLOPs — runs out of one 64 x H1 LDS tile and a streamed W2'.
-// 8 waves = 2 (rows) x 4 (columns); TN1/TN2 = 32-wide column tiles per wave in
-// layer 1 / layer 2 (H1 <= 128*TN1, H2 <= 128*TN2).
+// a DQN step's FLOPs — runs out of one 64 x H1 LDS tile.
+//
+// Wave w of the 8 owns the 32-column tile w of h1 and of h2 for all 64 rows (two
+// 32 x 32 accumulators).  Its B operand, W2'[32 cols][all k], is read from a
+// FRAGMENT-MAJOR copy of W2' (W2f[tile][kgroup][lane] = the float4 that lane feeds
+// to the four MFMAs of that k-group): one fully coalesced 1 KiB buffer load per
+// k-group straight into VGPRs — no LDS staging of weights and NO barrier in the
+// main loop, so the eight waves run decoupled and the matrix pipes stay fed.
+// (PMC on the LDS-staged version: 53 % MFMA busy, 33 % of wave time in
+// s_waitcnt/s_barrier.)  W2f is refreshed whenever the target net changes
+// (repack_w2_kernel, or in place by the fused soft update of adamw_kernel).
 // ---------------------------------------------------------------------------
 struct TargetArgs {
   const float* U; int ldu;                  // [B][H1] = W1s' s' + b1'
   const float* feat; int64_t feat_bstride;  // rep(next_available_actions) [B][A][AD]
   const uint8_t* mask; int64_t mask_bstride;// [B][A], 1 = unavailable; may be null
   const float* W1a; int ldw1;               // W1' + S (action columns), row pitch S+AD
-  const float* W2; int ldw2;                // [H2][H1]
+  const float* W2f;                         // fragment-major W2' (see w2f_index)
   const float* b2; const float* w3; const float* b3;
   const float* reward; const uint8_t* term;
   float gamma;
@@ -301,179 +309,191 @@ struct TargetArgs {
   int B, A, AD, H1, H2, bpw;
 };
 
-constexpr int T_ROWS = 64, T_ADC = 16, T_ADP = 20;
+constexpr int T_ROWS = 64;
+constexpr int T_MAXH = 256;  // hidden widths the kernel is built for (8 waves x 32 columns)
 
-template <int TN1, int TN2>
-constexpr size_t target_smem_bytes() {
-  return sizeof(float) * (T_ROWS * (128 * TN1 + 4) + 2 * (128 * TN2) * G_PK + 4 * 64 + 64);
+// k-groups of layer 2, padded to the kernel instantiations (8 / 16 / 32 <-> H1 <= 64 / 128 / 256)
+__host__ __device__ inline int t_nkg(int H1) { return H1 <= 64 ? 8 : (H1 <= 128 ? 16 : 32); }
+// float index of W2'[n][k] inside the fragment-major copy; nkg = t_nkg(H1)
+__host__ __device__ inline int64_t w2f_index(int n, int k, int nkg) {
+  const int t = n >> 5, l31 = n & 31, g = k >> 3, h = (k >> 2) & 1, j = k & 3;
+  return ((((int64_t)t * nkg + g) * 64) + h * 32 + l31) * 4 + j;
+}
+__host__ __device__ inline int64_t w2f_floats(int H2, int H1) {
+  return (int64_t)((H2 + 31) / 32) * t_nkg(H1) * 256;
 }
 
-template <int TN1, int TN2>
+__global__ __launch_bounds__(256) void repack_w2_kernel(const float* __restrict__ W2, int H2,
+                                                        int H1, float* __restrict__ W2f) {
+  const int nkg = t_nkg(H1);
+  const int64_t total = w2f_floats(H2, H1) / 4;  // float4 slots
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(e & 63);
+    const int64_t tg = e >> 6;
+    const int g = (int)(tg % nkg), t = (int)(tg / nkg);
+    const int n = t * 32 + (lane & 31), k = g * 8 + 4 * (lane >> 5);
+    float4 v;
+    v.x = (n < H2 && k < H1) ? W2[(int64_t)n * H1 + k] : 0.f;
+    v.y = (n < H2 && k + 1 < H1) ? W2[(int64_t)n * H1 + k + 1] : 0.f;
+    v.z = (n < H2 && k + 2 < H1) ? W2[(int64_t)n * H1 + k + 2] : 0.f;
+    v.w = (n < H2 && k + 3 < H1) ? W2[(int64_t)n * H1 + k + 3] : 0.f;
+    reinterpret_cast<float4*>(W2f)[e] = v;
+  }
+}
+
+inline size_t target_smem_bytes(int H1) {
+  const int H1P = t_nkg(H1) * 8;
+  return sizeof(float) * ((size_t)T_ROWS * (H1P + 4) + 8 * 64 + 64);
+}
+
+template <int NKG>
 __global__ __launch_bounds__(512) void target_fused_kernel(TargetArgs a) {
-  constexpr int H1P = 128 * TN1, H2P = 128 * TN2, PA_ = H1P + 4;
-  constexpr int W2_F4 = H2P * 8;          // float4 per 32-deep chunk of W2'
-  constexpr int NPRE = W2_F4 / 512;       // 2 * TN2
-  static_assert((T_ROWS + H1P) * T_ADP <= 2 * H2P * G_PK, "layer-1 staging must fit in Bw");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ah = smem;                        // [64][H1P+4]   h1 tile (layer-2 A operand)
-  float* Bw = Ah + T_ROWS * PA_;           // [2][H2P][36]  streamed W2' chunks
-  float* qpart = Bw + 2 * H2P * G_PK;      // [4][64]
-  float* qv = qpart + 4 * 64;              // [64]
-  float* featS = Bw;                       // [64][20]   (aliases Bw during layer 1)
-  float* W1aS = Bw + T_ROWS * T_ADP;       // [H1P][20]
+  constexpr int H1P = NKG * 8;           // padded layer-2 K (64 / 128 / 256)
+  constexpr int PA_ = H1P + 4;           // == 4 mod 32: conflict-free ds_read_b128 down a column
+  float* Ah = smem;                      // [64][H1P+4]   h1 tile (layer-2 A operand)
+  float* qpart = Ah + T_ROWS * PA_;      // [8][64]
+  float* qv = qpart + 8 * 64;            // [64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
   const int h = lane >> 5, l31 = lane & 31;
   const int b0 = blockIdx.x * a.bpw;
   const int nb = min(a.bpw, a.B - b0);
   const int nrows = nb * a.A;
-  const bool vecW2 = is_vec_ok(a.W2, a.ldw2);
-  const int NK = (a.H1 + G_BK - 1) / G_BK;
+  const int nt1 = H1P >> 5, nt2 = (a.H2 + 31) >> 5;  // 32-column tiles of h1 (padded) / h2
+  const int col = wave * 32 + l31;                   // this lane's h1 / h2 column
 
-  float4 pre[NPRE];
-  const bool fastW2 = vecW2 && ((a.H1 & 3) == 0);  // wave-uniform
-  auto issue = [&](int kc) {
-    const int k0 = kc * G_BK;
-    if (fastW2) {
+  // ---- layer 1: acc1 = U[b(row)] + rep(row) . W1a'^T for column tile `wave`, rows 0..63.
+  // Its (small) operand loads are issued first; vmcnt retires in order, so layer 1 only waits
+  // for them while the layer-2 weight stream below is still arriving.
+  const bool l1 = wave < nt1;
+  f32x16 acc1[2];
 #pragma unroll
-      for (int q = 0; q < NPRE; ++q) {
-        const int f = tid + q * 512;
-        const int n = f >> 3, c = f & 7;
-        pre[q] = ld4_or_zero(a.W2, (int64_t)n * a.ldw2 + k0 + c * 4, n < a.H2 && (k0 + c * 4) < a.H1);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < NPRE; ++q) {
-        const int f = tid + q * 512;
-        const int n = f >> 3, c = f & 7;
-        pre[q] = guarded_load4(a.W2, (int64_t)n * a.ldw2, n < a.H2, k0 + c * 4, a.H1);
-      }
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < NPRE; ++q) {
-      const int f = tid + q * 512;
-      const int n = f >> 3, c = f & 7;
-      *reinterpret_cast<float4*>(Bw + buf * H2P * G_PK + n * G_PK + c * 4) = pre[q];
-    }
-  };
-  issue(0);  // in flight during layer 1
-
-  // ---- layer 1: acc1 = U[b(row)] + rep(row) . W1a'^T
-  f32x16 acc1[TN1];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = wm * 32 + acc_row(r, h);
-    const bool rok = row < nrows;
-    const int bb = b0 + (rok ? row / a.A : 0);
-#pragma unroll
-    for (int t = 0; t < TN1; ++t) {
-      const int col = (wn * TN1 + t) * 32 + l31;
-      acc1[t][r] = ld_or_zero(a.U, (int64_t)bb * a.ldu + col, rok && col < a.H1);
-    }
-  }
-  for (int c0 = 0; c0 < a.AD; c0 += T_ADC) {
-    for (int e = tid; e < T_ROWS * T_ADC; e += 512) {
-      const int r = e >> 4, j = e & 15;
-      const bool ok = r < nrows && c0 + j < a.AD;
-      const int rr = ok ? r : 0;
-      const int bb = b0 + rr / a.A, i = rr % a.A;
-      featS[r * T_ADP + j] =
-          ld_or_zero(a.feat, (int64_t)bb * a.feat_bstride + (int64_t)i * a.AD + c0 + j, ok);
-    }
-    for (int e = tid; e < H1P * T_ADC; e += 512) {
-      const int n = e >> 4, j = e & 15;
-      W1aS[n * T_ADP + j] =
-          ld_or_zero(a.W1a, (int64_t)n * a.ldw1 + c0 + j, n < a.H1 && c0 + j < a.AD);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kg = 0; kg < T_ADC / 8; ++kg) {
-      const float4 a4 =
-          *reinterpret_cast<const float4*>(featS + (wm * 32 + l31) * T_ADP + kg * 8 + 4 * h);
-#pragma unroll
-      for (int t = 0; t < TN1; ++t) {
-        const float4 b4 = *reinterpret_cast<const float4*>(
-            W1aS + ((wn * TN1 + t) * 32 + l31) * T_ADP + kg * 8 + 4 * h);
-        acc1[t] = mfma32(a4.x, b4.x, acc1[t]);
-        acc1[t] = mfma32(a4.y, b4.y, acc1[t]);
-        acc1[t] = mfma32(a4.z, b4.z, acc1[t]);
-        acc1[t] = mfma32(a4.w, b4.w, acc1[t]);
-      }
-    }
-    __syncthreads();
-  }
-  // h1 = relu(acc1) -> LDS A tile (columns >= H1 and rows >= nrows are exact zeros)
-#pragma unroll
-  for (int t = 0; t < TN1; ++t) {
-    const int col = (wn * TN1 + t) * 32 + l31;
+  for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = wm * 32 + acc_row(r, h);
-      Ah[row * PA_ + col] = relu_keep_nan(acc1[t][r]);
+      const int row = tm * 32 + acc_row(r, h);
+      const bool rok = row < nrows;
+      const int bb = b0 + (rok ? row / a.A : 0);
+      acc1[tm][r] = ld_or_zero(a.U, (int64_t)bb * a.ldu + col, l1 && rok && col < a.H1);
     }
   }
-  commit(0);  // staging region is dead: every wave passed the barrier above
-  __syncthreads();
-
-  // ---- layer 2: acc2 = h1 . W2'^T, W2' streamed in 32-deep chunks
-  f32x16 acc2[TN2];
+  int64_t foff[2];
+  bool fok[2];
 #pragma unroll
-  for (int t = 0; t < TN2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
-
-  for (int kc = 0; kc < NK; ++kc) {
-    const int buf = kc & 1;
-    if (kc + 1 < NK) issue(kc + 1);
-    const float* as = Ah + (wm * 32 + l31) * PA_ + kc * G_BK + 4 * h;
-    const float* bs = Bw + buf * H2P * G_PK + (wn * TN2 * 32 + l31) * G_PK + 4 * h;
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const float4 a4 = *reinterpret_cast<const float4*>(as + kg * 8);
-      float4 b4[TN2];
-#pragma unroll
-      for (int t = 0; t < TN2; ++t)
-        b4[t] = *reinterpret_cast<const float4*>(bs + t * 32 * G_PK + kg * 8);
-#pragma unroll
-      for (int t = 0; t < TN2; ++t) acc2[t] = mfma32(a4.x, b4[t].x, acc2[t]);
-#pragma unroll
-      for (int t = 0; t < TN2; ++t) acc2[t] = mfma32(a4.y, b4[t].y, acc2[t]);
-#pragma unroll
-      for (int t = 0; t < TN2; ++t) acc2[t] = mfma32(a4.z, b4[t].z, acc2[t]);
-#pragma unroll
-      for (int t = 0; t < TN2; ++t) acc2[t] = mfma32(a4.w, b4[t].w, acc2[t]);
+  for (int tm = 0; tm < 2; ++tm) {
+    const int row = tm * 32 + l31;
+    fok[tm] = l1 && row < nrows;
+    const int rr = fok[tm] ? row : 0;
+    foff[tm] = (int64_t)(b0 + rr / a.A) * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
+  }
+  const bool vfeat = ((reinterpret_cast<uintptr_t>(a.feat) & 15) == 0) && ((a.AD & 3) == 0) &&
+                     ((a.feat_bstride & 3) == 0);
+  const bool vw1 = ((reinterpret_cast<uintptr_t>(a.W1a) & 15) == 0) && ((a.ldw1 & 3) == 0) &&
+                   ((a.AD & 3) == 0);
+  const int64_t woff = (int64_t)col * a.ldw1;
+  const bool wok = l1 && col < a.H1;
+  auto l1_loads = [&](int k0, float4 (&a4)[2], float4& b4) {
+    const int k = k0 + 4 * h;
+    if (vfeat) {
+      a4[0] = ld4_or_zero(a.feat, foff[0] + k, fok[0] && k < a.AD);
+      a4[1] = ld4_or_zero(a.feat, foff[1] + k, fok[1] && k < a.AD);
+    } else {
+      a4[0] = guarded_load4(a.feat, foff[0], fok[0], k, a.AD);
+      a4[1] = guarded_load4(a.feat, foff[1], fok[1], k, a.AD);
     }
-    if (kc + 1 < NK) commit(buf ^ 1);
-    __syncthreads();
+    if (vw1) b4 = ld4_or_zero(a.W1a, woff + k, wok && k < a.AD);
+    else b4 = guarded_load4(a.W1a, woff, wok, k, a.AD);
+  };
+  auto l1_mfma = [&](const float4 (&a4)[2], const float4& b4) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      acc1[tm] = mfma32(a4[tm].x, b4.x, acc1[tm]);
+      acc1[tm] = mfma32(a4[tm].y, b4.y, acc1[tm]);
+      acc1[tm] = mfma32(a4[tm].z, b4.z, acc1[tm]);
+      acc1[tm] = mfma32(a4[tm].w, b4.w, acc1[tm]);
+    }
+  };
+  float4 fa[2][2], fb[2];  // the first two k-groups (AD <= 16 covers one-hot over 16 actions)
+  l1_loads(0, fa[0], fb[0]);
+  l1_loads(8, fa[1], fb[1]);
+
+  // ---- ALL of this wave's layer-2 B fragments (32 cols x H1P k = NKG KiB), one coalesced
+  // 1 KiB load each into their own registers: no register ring for the compiler to serialise,
+  // L2 paces the stream, and the main loop consumes it in arrival order.
+  float4 bfr[NKG];
+  const int64_t bbase = ((int64_t)wave * NKG) * 256 + lane * 4;
+#pragma unroll
+  for (int g = 0; g < NKG; ++g) bfr[g] = ld4_or_zero(a.W2f, bbase + (int64_t)g * 256, wave < nt2);
+
+  l1_mfma(fa[0], fb[0]);
+  l1_mfma(fa[1], fb[1]);
+  for (int k0 = 16; k0 < a.AD; k0 += 8) {  // wider action representations (rare)
+    float4 a4[2], b4;
+    l1_loads(k0, a4, b4);
+    l1_mfma(a4, b4);
+  }
+  if (l1) {
+    // h1 = relu(acc1) -> LDS A tile (columns >= H1 and rows >= nrows are exact zeros)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        Ah[(tm * 32 + acc_row(r, h)) * PA_ + col] = relu_keep_nan(acc1[tm][r]);
+  }
+  __syncthreads();  // the only workgroup barrier before the epilogue
+
+  // ---- layer 2: acc2 = h1 . W2'^T; A from LDS, B streamed from L2 in fragment order
+  f32x16 acc2[2];
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[tm][r] = 0.f;
+  if (wave < nt2) {
+    const float* ap0 = Ah + l31 * PA_ + 4 * h;
+    const float* ap1 = ap0 + 32 * PA_;
+#pragma unroll
+    for (int g = 0; g < NKG; ++g) {
+      const float4 b4 = bfr[g];
+      const float4 x0 = *reinterpret_cast<const float4*>(ap0 + g * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(ap1 + g * 8);
+      acc2[0] = mfma32(x0.x, b4.x, acc2[0]);
+      acc2[1] = mfma32(x1.x, b4.x, acc2[1]);
+      acc2[0] = mfma32(x0.y, b4.y, acc2[0]);
+      acc2[1] = mfma32(x1.y, b4.y, acc2[1]);
+      acc2[0] = mfma32(x0.z, b4.z, acc2[0]);
+      acc2[1] = mfma32(x1.z, b4.z, acc2[1]);
+      acc2[0] = mfma32(x0.w, b4.w, acc2[0]);
+      acc2[1] = mfma32(x1.w, b4.w, acc2[1]);
+    }
   }
 
   // ---- layer 3 + mask + max + Bellman target
-  float v[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = 0.f;
-#pragma unroll
-  for (int t = 0; t < TN2; ++t) {
-    const int col = (wn * TN2 + t) * 32 + l31;
+  {
     const bool cok = col < a.H2;
-    const float bv = cok ? a.b2[col] : 0.f;
-    const float wv = cok ? a.w3[col] : 0.f;
+    const float bv = ld_or_zero(a.b2, col, cok);
+    const float wv = ld_or_zero(a.w3, col, cok);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] += relu_keep_nan(acc2[t][r] + bv) * wv;
-  }
+    for (int tm = 0; tm < 2; ++tm) {
+      float v[16];
 #pragma unroll
-  for (int off = 16; off >= 1; off >>= 1)
+      for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(acc2[tm][r] + bv) * wv;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] += __shfl_xor(v[r], off);
-  if (l31 == 0) {
+      for (int off = 16; off >= 1; off >>= 1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) qpart[wn * 64 + wm * 32 + acc_row(r, h)] = v[r];
+        for (int r = 0; r < 16; ++r) v[r] += __shfl_xor(v[r], off);
+      if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) qpart[wave * 64 + tm * 32 + acc_row(r, h)] = v[r];
+      }
+    }
   }
   __syncthreads();
   if (tid < T_ROWS) {
-    float q = ((qpart[tid] + qpart[64 + tid]) + qpart[128 + tid]) + qpart[192 + tid];
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q += qpart[w * 64 + tid];
     q += a.b3[0];
     if (tid < nrows && a.mask) {
       const int bb = b0 + tid / a.A, i = tid % a.A;
@@ -666,6 +686,7 @@ struct AdamArgs {
   // fused extras (may be disabled)
   const float* absd; int nabs; float inv_B; float* loss_out;  // loss_out[0] = mean |Q - target|
   float* tgt; float tau, one_minus_tau; int soft_next;        // soft update due before the NEXT step
+  float* w2f; int64_t w2_off; int H1, H2;                     // fragment-major copy of the target W2
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
@@ -704,8 +725,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   a.p[i] = p;
   a.m[i] = m;
   a.v[i] = v;
-  if (a.soft_next)  // update_target_network of the next step's forward() (common/utils.py:214-226)
-    a.tgt[i] = __fadd_rn(__fmul_rn(a.tau, p), __fmul_rn(a.one_minus_tau, a.tgt[i]));
+  if (a.soft_next) {  // update_target_network of the next step's forward() (common/utils.py:214-226)
+    const float t = __fadd_rn(__fmul_rn(a.tau, p), __fmul_rn(a.one_minus_tau, a.tgt[i]));
+    a.tgt[i] = t;
+    const int64_t e = i - a.w2_off;
+    if (e >= 0 && e < (int64_t)a.H2 * a.H1) {
+      const int n = (int)(e / a.H1), k = (int)(e - (int64_t)n * a.H1);
+      a.w2f[w2f_index(n, k, t_nkg(a.H1))] = t;
+    }
+  }
 }
 
 // theta' <- tau * theta + (1 - tau) * theta'   (common/utils.py:214-226)

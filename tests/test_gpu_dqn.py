@@ -109,7 +109,7 @@ def test_learn_trajectory_python_sampler(golden, name):
     assert random.getstate() == after
 
 
-@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape"])
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch"])
 def test_generic_loop_equals_fused_loop(golden, name):
     """sample() + preprocess_batch() + learn_batch() (API path, per-step .item()) and the fused
     pa_dqn_learn path are the same computation: bitwise-equal parameters."""
