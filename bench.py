@@ -141,12 +141,13 @@ def main():
     assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
 
     timers = {}
-    for name in ("target", "l1_dual", "gather", "sample", "online_l2", "head", "bwd_dx", "bwd_dw",
-                 "adamw", "soft_update"):
-        ms, cnt = C.c_double(), C.c_int64()
+    for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "sample", "online_l2",
+                 "head", "bwd_dx", "bwd_dw", "adamw", "soft_update"):
+        ms, cnt, units = C.c_double(), C.c_int64(), C.c_int64()
         N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
+        N.check(N.lib().pa_dqn_get_timing_units(nat.handle, name.encode(), C.byref(units)))
         if cnt.value:
-            timers[name] = {"avg_us": ms.value * 1e3, "n": cnt.value}
+            timers[name] = {"avg_us": ms.value * 1e3, "n": cnt.value, "units": units.value}
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
 
     if rank == 0:
@@ -165,16 +166,22 @@ def main():
                        "final_loss": report["loss"][-1]},
         }
         if "target" in timers:
-            dur = timers["target"]["avg_us"] * 1e-6
-            ach = FLOP_TARGET_KERNEL_PER_TRANSITION * B / dur
-            line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<2,2>",
+            # one launch covers a window of rounds (target_update_freq, <= 16): algorithmic flops
+            # of the timed launches / their summed duration
+            tt = timers["target"]
+            dur = tt["avg_us"] * 1e-6
+            per_launch = tt["units"] / tt["n"]
+            ach = FLOP_TARGET_KERNEL_PER_TRANSITION * per_launch / dur
+            line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<32>",
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": None,
-                                "avg_launch_us": timers["target"]["avg_us"],
-                                "launches_timed": timers["target"]["n"],
+                                "avg_launch_us": tt["avg_us"],
+                                "transitions_per_launch": per_launch,
+                                "launches_timed": tt["n"],
                                 "step_frac": FLOP_PER_TRANSITION_STEP * B * args.steps / dt / PEAK_F32_MFMA}
         if len(timers) > 1:
             line["stage_us"] = {k: round(v["avg_us"], 2) for k, v in timers.items()}
+            line["stage_units"] = {k: v["units"] / v["n"] for k, v in timers.items() if v["units"]}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

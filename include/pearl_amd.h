@@ -249,9 +249,14 @@ int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_target_update,
 int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream);
 
 /* PolicyLearner.learn (policy_learner.py:162-195) fused: `rounds` iterations of
- * device-side sample -> gather(+one-hot) -> learn_batch on the arena, sampling
- * on a side stream one step ahead.  training_steps0 / adam_step0: counters
- * before the call.  losses_out: device float[rounds]. */
+ * device-side sample -> gather(+one-hot) -> learn_batch on the arena, all on
+ * `stream`.  The index lists of every round are drawn by one launch; because the
+ * target network only changes every target_update_freq rounds
+ * (deep_td_learning.py:283-284), the gather and the target-network pass
+ * (deep_q_learning.py:130-167) of a whole window of rounds run as ONE launch
+ * each (bit-identical to doing them round by round); only the online chain
+ * (forward, loss, backward, AdamW) is issued per round.  training_steps0 /
+ * adam_step0: counters before the call.  losses_out: device float[rounds]. */
 typedef struct pa_learn_args {
   int32_t rounds;
   int32_t batch_size;
@@ -270,10 +275,12 @@ int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* st
  * (HIP events on the launch stream; used by bench.py's roofline block). */
 /* level 0: off; 1: only the dominant kernel ("target"); 2: every stage.  Resets the counters. */
 int pa_dqn_enable_timing(pa_dqn* h, int32_t level);
-/* names: "target" (sampled every 8th step at level 1), "l1_dual", "gather", "sample",
- * "online_l2", "head", "bwd_dx", "bwd_dw", "adamw", "soft_update", "learn"
- * -> average milliseconds and sample count */
+/* names: "target" (every 4th launch at level 1), "target_l1", "l1_dual", "online_l1", "gather",
+ * "sample", "online_l2", "head", "bwd_dx", "bwd_dw", "adamw", "soft_update", "learn"
+ * -> average milliseconds per timed launch and the number of timed launches */
 int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* count);
+/* transitions covered by the timed launches of `name` (a window launch covers several rounds) */
+int pa_dqn_get_timing_units(pa_dqn* h, const char* name, int64_t* units);
 
 /* ------------------------------------------------------------------------ */
 /* Diagnostics: single-kernel entry points so the GPU test-suite can localise */

@@ -219,6 +219,7 @@ SIGNATURES = {
     "pa_dqn_learn": (C.c_int, [_P, _P, C.POINTER(LearnArgs), _P]),
     "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
     "pa_dqn_get_timing": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pa_dqn_get_timing_units": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
     "pa_debug_linear": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_debug_weight_grad": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32,

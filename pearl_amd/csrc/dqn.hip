@@ -25,6 +25,7 @@ struct Timer {
   std::string name;
   std::vector<hipEvent_t> ev;  // pairs
   size_t used = 0;
+  int64_t units = 0;  // transitions covered by the timed launches
 };
 
 constexpr size_t kMaxTimedPairs = 8192;
@@ -51,6 +52,8 @@ struct pa_dqn {
     uint8_t* term;
   } bb;
   int bb_A;          // A the batch buffers were sized for
+  int wcap;          // rounds whose target-network pass is batched into one launch (learn())
+  int64_t wrows;     // wcap * max_batch: rows of the window-sized workspaces (U, y, batch buffers)
   int64_t* idx_all;  // [idx_cap] logical indices, round-major
   int64_t idx_cap;
   int64_t tick;      // steps seen while timing (sparse sampling of the level-1 timer)
@@ -89,7 +92,8 @@ struct ScopedTimer {
   bool active;
   // every: record only on every `every`-th step (a hipEventRecord costs ~6 us of GPU idle on
   // this stack, so the dominant kernel is sampled, not bracketed on every launch)
-  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_, int level = 2, int every = 1)
+  ScopedTimer(pa_dqn* h_, const char* name, hipStream_t s_, int level = 2, int every = 1,
+              int64_t units = 0)
       : h(h_), t(nullptr), s(s_), active(false) {
     if (h->timing < level) return;
     if (every > 1 && h->timing == level && (h->tick % every) != 0) return;
@@ -101,6 +105,7 @@ struct ScopedTimer {
       t->ev.push_back(e);
     }
     (void)hipEventRecord(t->ev[t->used], s);
+    t->units += units;
     active = true;
   }
   ~ScopedTimer() {
@@ -208,17 +213,17 @@ int resolve_x(pa_dqn* h, const pa_dqn_batch* b, const float** x, hipStream_t s) 
   return PA_OK;
 }
 
-GemmArgs target_l1_problem(pa_dqn* h, const pa_dqn_batch* b) {
+GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows) {
   // U = s' W1s'^T + b1'   (state columns of the target net's first layer)
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, h->bufs.q_target);
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  g.A = b->next_state; g.lda = d.state_dim;
+  g.A = next_state; g.lda = d.state_dim;
   g.Bm = t.W1; g.ldb = h->IN;
   g.C = h->U; g.ldc = d.hidden1;
   g.bias = t.b1;
-  g.M = b->B; g.N = d.hidden1; g.K = d.state_dim;
+  g.M = rows; g.N = d.hidden1; g.K = d.state_dim;
   g.epi = EPI_BIAS;
   return g;
 }
@@ -239,11 +244,12 @@ GemmArgs online_l1_problem(pa_dqn* h, const float* x, int B) {
 }
 
 // max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
-// deep_td_learning.py:313-317); U must already be in h->U.
+// deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
+// U must already be in h->U.
 int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, h->bufs.q_target);
-  ScopedTimer tm(h, "target", s, 1, 8);
+  ScopedTimer tm(h, "target", s, 1, 4, b->B);
   TargetArgs a;
   memset(&a, 0, sizeof(a));
   a.U = h->U; a.ldu = d.hidden1;
@@ -416,45 +422,54 @@ int run_soft_update(pa_dqn* h, hipStream_t s) {
   return run_repack(h, s);
 }
 
-// One learn_batch.  do_target_update: soft update BEFORE the forward (skip it when the previous
-// step's AdamW launch already did it, soft_next).  soft_next: fuse the next step's soft update
-// into this step's AdamW launch.
-// w2f_current: the fragment-major target W2 is known to match bufs.q_target (inside the fused
-// learn loop); otherwise it is rebuilt first (the caller may have loaded a checkpoint).
+// Everything of one learn_batch that depends on the ONLINE parameters, given the Bellman targets
+// y[B] of the batch: (layer 1 unless l1_done) -> layer 2 -> head/loss -> backward -> AdamW.
+// soft_next: fuse the NEXT step's soft target update into this step's AdamW launch.
+int online_chain(pa_dqn* h, const float* x, int B, const float* y, bool l1_done, int64_t adam_step,
+                 int grad_world, float* loss_out, int soft_next, hipStream_t s) {
+  int rc;
+  if (!l1_done) {
+    ScopedTimer tm(h, "online_l1", s);
+    GemmArgs g = online_l1_problem(h, x, B);
+    rc = launch_linear<false>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+  }
+  rc = run_online_l2(h, B, s);
+  if (rc != PA_OK) return rc;
+  rc = run_head(h, B, y, h->qbuf, true, grad_world, s);
+  if (rc != PA_OK) return rc;
+  rc = run_backward(h, x, B, s);
+  if (rc != PA_OK) return rc;
+  float* lo = loss_out ? loss_out : h->loss_scratch;
+  if (grad_world == 1) return run_adamw(h, adam_step, B, lo, soft_next, s);
+  return run_loss_fold(h, B, lo, s);
+}
+
+// One stand-alone learn_batch (pa_dqn_step).  do_target_update: soft update BEFORE the forward
+// (deep_td_learning.py:283-284).  The fragment-major target W2 is rebuilt every time: the caller
+// may have loaded a checkpoint into the target network between calls.
 int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_t adam_step,
-              int grad_world, float* loss_out, int soft_next, bool w2f_current, hipStream_t s) {
+              int grad_world, float* loss_out, hipStream_t s) {
   int rc = check_batch(h, batch);
   if (rc != PA_OK) return rc;
   PA_REQUIRE(grad_world >= 1, PA_ERR_INVALID, "grad_world must be >= 1");
   if (h->timing) h->tick++;
-  if (do_target_update) {
-    rc = run_soft_update(h, s);  // also repacks
-    if (rc != PA_OK) return rc;
-  } else if (!w2f_current) {
-    rc = run_repack(h, s);
-    if (rc != PA_OK) return rc;
-  }
+  rc = do_target_update ? run_soft_update(h, s) /* also repacks */ : run_repack(h, s);
+  if (rc != PA_OK) return rc;
   const float* x = nullptr;
   rc = resolve_x(h, batch, &x, s);
   if (rc != PA_OK) return rc;
   {
     // layer 1 of both networks in one launch: U (target, state part) and H1a (online)
     ScopedTimer tm(h, "l1_dual", s);
-    GemmArgs probs[2] = {target_l1_problem(h, batch), online_l1_problem(h, x, batch->B)};
+    GemmArgs probs[2] = {target_l1_problem(h, batch->next_state, batch->B),
+                         online_l1_problem(h, x, batch->B)};
     rc = launch_linear<false>(probs, 2, s);
     if (rc != PA_OK) return rc;
   }
   rc = run_target_fused(h, batch, h->nextv, h->y, s);
   if (rc != PA_OK) return rc;
-  rc = run_online_l2(h, batch->B, s);
-  if (rc != PA_OK) return rc;
-  rc = run_head(h, batch->B, h->y, h->qbuf, true, grad_world, s);
-  if (rc != PA_OK) return rc;
-  rc = run_backward(h, x, batch->B, s);
-  if (rc != PA_OK) return rc;
-  float* lo = loss_out ? loss_out : h->loss_scratch;
-  if (grad_world == 1) return run_adamw(h, adam_step, batch->B, lo, soft_next, s);
-  return run_loss_fold(h, batch->B, lo, s);
+  return online_chain(h, x, batch->B, h->y, true, adam_step, grad_world, loss_out, 0, s);
 }
 
 void free_batchbufs(pa_dqn* h) {
@@ -470,7 +485,7 @@ int ensure_batchbufs(pa_dqn* h, int A) {
   if (h->bb_A >= A && h->bb.x) return PA_OK;
   free_batchbufs(h);
   const pa_dqn_desc& d = h->d;
-  const int64_t B = d.max_batch;
+  const int64_t B = h->wrows;
   PA_HIP(hipMalloc((void**)&h->bb.x, (size_t)(B * h->IN * 4)));
   PA_HIP(hipMalloc((void**)&h->bb.next_state, (size_t)(B * d.state_dim * 4)));
   PA_HIP(hipMalloc((void**)&h->bb.next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
@@ -542,6 +557,11 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->dq = h->absd =
       h->xpack = h->loss_scratch = h->w2f = nullptr;
   const int64_t B = desc->max_batch;
+  // learn() evaluates the target network for a whole window of rounds in one launch (the target
+  // parameters only change every target_update_freq rounds): up to 16 rounds / 16384 transitions
+  h->wcap = (int)(16384 / B);
+  h->wcap = h->wcap < 1 ? 1 : (h->wcap > 16 ? 16 : h->wcap);
+  h->wrows = (int64_t)h->wcap * B;
 #define PA_WS(ptr, floats)                                                       \
   do {                                                                           \
     hipError_t _e = hipMalloc((void**)&(ptr), (size_t)((floats) * 4));           \
@@ -551,13 +571,13 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
       return PA_ERR_NOMEM;                                                       \
     }                                                                            \
   } while (0)
-  PA_WS(h->U, B * desc->hidden1);
+  PA_WS(h->U, h->wrows * desc->hidden1);
   PA_WS(h->H1a, B * desc->hidden1);
   PA_WS(h->H2a, B * desc->hidden2);
   PA_WS(h->dZ2, B * desc->hidden2);
   PA_WS(h->dZ1, B * desc->hidden1);
-  PA_WS(h->y, B);
-  PA_WS(h->nextv, B);
+  PA_WS(h->y, h->wrows);
+  PA_WS(h->nextv, h->wrows);
   PA_WS(h->qbuf, B);
   PA_WS(h->dq, B);
   PA_WS(h->absd, B);
@@ -608,7 +628,8 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
   GemmArgs probs[2];
   int np = 0;
   const float* x = nullptr;
-  if (next_v_out || target_out) probs[np++] = target_l1_problem(h, batch);
+  if (next_v_out || target_out)
+    probs[np++] = target_l1_problem(h, batch->next_state, batch->B);
   if (q_out) {
     rc = resolve_x(h, batch, &x, s);
     if (rc != PA_OK) return rc;
@@ -643,7 +664,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
                            void* stream) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   PA_HIP(hipSetDevice(h->d.device));
-  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out, 0, false,
+  return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out,
                    reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -695,40 +716,63 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     rc = sample_indices_launch(arena->size, args->seed, args->offset0, B, R, h->idx_all, s);
     if (rc != PA_OK) return rc;
   }
-  pa_batch_out o;
-  memset(&o, 0, sizeof(o));
-  o.x = h->bb.x;
-  o.next_state = h->bb.next_state;
-  o.next_avail_rep = h->bb.next_avail_rep;
-  o.next_mask = h->bb.next_mask;
-  o.reward_f32 = h->bb.reward;
-  o.terminated = h->bb.term;
-  o.rep_dim = d.action_dim;
-  o.rep_onehot = args->rep_onehot;
-  pa_dqn_batch b;
-  memset(&b, 0, sizeof(b));
-  b.B = B; b.A = A;
-  b.x = h->bb.x;
-  b.reward = h->bb.reward;
-  b.terminated = h->bb.term;
-  b.next_state = h->bb.next_state;
-  b.next_avail_rep = h->bb.next_avail_rep;
-  b.next_mask = h->bb.next_mask;
   // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
   // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
   auto due = [&](int r) { return ((args->training_steps0 + r + 2) % args->target_update_freq) == 0; };
-  for (int r = 0; r < R; ++r) {
+  // The target network is constant between two soft updates, and the index lists of all rounds
+  // are already known: gather and run the (dominant) target-network pass for a whole WINDOW of
+  // rounds at once, then the per-round online chains, which are the only truly sequential part.
+  int r = 0;
+  while (r < R) {
+    int w = 1;
+    while (r + w < R && w < h->wcap && !due(r + w)) ++w;
+    const int rows = w * B;
+    pa_batch_out o;
+    memset(&o, 0, sizeof(o));
+    o.x = h->bb.x;
+    o.next_state = h->bb.next_state;
+    o.next_avail_rep = h->bb.next_avail_rep;
+    o.next_mask = h->bb.next_mask;
+    o.reward_f32 = h->bb.reward;
+    o.terminated = h->bb.term;
+    o.rep_dim = d.action_dim;
+    o.rep_onehot = args->rep_onehot;
     {
-      ScopedTimer tm(h, "gather", s);
-      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, B, &o, s);
+      ScopedTimer tm(h, "gather", s, 2, 1, rows);
+      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
       if (rc != PA_OK) return rc;
     }
-    // the first step's soft update runs stand-alone; later ones ride the previous AdamW launch
-    const int do_tu = (r == 0) ? due(0) : 0;
-    const int soft_next = (r + 1 < R) ? due(r + 1) : 0;
-    rc = step_impl(h, &b, do_tu, args->adam_step0 + r + 1, 1,
-                   args->losses_out ? args->losses_out + r : nullptr, soft_next, r > 0, s);
+    if (r == 0) {
+      // the first round's soft update runs stand-alone; later ones ride the previous AdamW launch
+      rc = due(0) ? run_soft_update(h, s) : run_repack(h, s);
+      if (rc != PA_OK) return rc;
+    }
+    if (h->timing) h->tick++;
+    pa_dqn_batch b;
+    memset(&b, 0, sizeof(b));
+    b.B = rows; b.A = A;
+    b.reward = h->bb.reward;
+    b.terminated = h->bb.term;
+    b.next_state = h->bb.next_state;
+    b.next_avail_rep = h->bb.next_avail_rep;
+    b.next_mask = h->bb.next_mask;
+    {
+      ScopedTimer tm(h, "target_l1", s, 2, 1, rows);
+      GemmArgs g = target_l1_problem(h, h->bb.next_state, rows);
+      rc = launch_linear<false>(&g, 1, s);
+      if (rc != PA_OK) return rc;
+    }
+    rc = run_target_fused(h, &b, h->nextv, h->y, s);
     if (rc != PA_OK) return rc;
+    for (int j = 0; j < w; ++j) {
+      const int round = r + j;
+      const int soft_next = (round + 1 < R) ? due(round + 1) : 0;
+      rc = online_chain(h, h->bb.x + (int64_t)j * B * h->IN, B, h->y + (int64_t)j * B, false,
+                        args->adam_step0 + round + 1, 1,
+                        args->losses_out ? args->losses_out + round : nullptr, soft_next, s);
+      if (rc != PA_OK) return rc;
+    }
+    r += w;
   }
   return PA_OK;
 }
@@ -736,7 +780,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
 extern "C" int pa_dqn_enable_timing(pa_dqn* h, int32_t on) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   h->timing = on < 0 ? 0 : on;
-  for (auto& t : h->timers) t.used = 0;
+  for (auto& t : h->timers) { t.used = 0; t.units = 0; }
   return PA_OK;
 }
 
@@ -759,6 +803,14 @@ extern "C" int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, in
     *avg_ms = n ? total / (double)n : 0.0;
     return PA_OK;
   }
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_get_timing_units(pa_dqn* h, const char* name, int64_t* units) {
+  PA_REQUIRE(h && name && units, PA_ERR_INVALID, "null argument");
+  *units = 0;
+  for (auto& t : h->timers)
+    if (t.name == name) *units = t.units;
   return PA_OK;
 }
 

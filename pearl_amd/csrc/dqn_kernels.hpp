@@ -286,8 +286,8 @@ inline size_t linear_smem_bytes(int K) {
 // h1/h2 never leave LDS/registers: the 16384 x 256 x 256 layer-2 product — 79 % of
 // a DQN step's FLOPs — runs out of one 64 x H1 LDS tile.
 //
-// Wave w of the 8 owns the 32-column tile w of h1 and of h2 for all 64 rows (two
-// 32 x 32 accumulators).  Its B operand, W2'[32 cols][all k], is read from a
+// Wave w of the 8 owns hidden units [32w, 32w+32) of h1 and of h2 for all 64 rows (two
+// 32 x 32 accumulators).  Its weight operand, W2'[32 units][all k], is read from a
 // FRAGMENT-MAJOR copy of W2' (W2f[tile][kgroup][lane] = the float4 that lane feeds
 // to the four MFMAs of that k-group): one fully coalesced 1 KiB buffer load per
 // k-group straight into VGPRs — no LDS staging of weights and NO barrier in the
@@ -347,12 +347,16 @@ inline size_t target_smem_bytes(int H1) {
   return sizeof(float) * ((size_t)T_ROWS * (H1P + 4) + 8 * 64 + 64);
 }
 
+// Waves per SIMD the kernel is compiled for: 4 (= two co-resident 8-wave workgroups per CU, <= 128
+// VGPRs) for the widest instantiation, so that one workgroup's prologue / epilogue overlaps the
+// other's MFMA stream when a launch covers many 64-row tiles (a window of learn() rounds).
 template <int NKG>
-__global__ __launch_bounds__(512) void target_fused_kernel(TargetArgs a) {
+__global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int H1P = NKG * 8;           // padded layer-2 K (64 / 128 / 256)
-  constexpr int PA_ = H1P + 4;           // == 4 mod 32: conflict-free ds_read_b128 down a column
-  float* Ah = smem;                      // [64][H1P+4]   h1 tile (layer-2 A operand)
+  constexpr int PA_ = H1P + 4;           // == 4 mod 32: conflict-free b128 reads AND writes by row
+  constexpr int RD = 8;                  // W2' fragment prefetch ring depth (k-groups in flight)
+  float* Ah = smem;                      // [64][H1P+4]   h1 tile (layer-2 B operand)
   float* qpart = Ah + T_ROWS * PA_;      // [8][64]
   float* qv = qpart + 8 * 64;            // [64]
 
@@ -361,133 +365,155 @@ __global__ __launch_bounds__(512) void target_fused_kernel(TargetArgs a) {
   const int b0 = blockIdx.x * a.bpw;
   const int nb = min(a.bpw, a.B - b0);
   const int nrows = nb * a.A;
-  const int nt1 = H1P >> 5, nt2 = (a.H2 + 31) >> 5;  // 32-column tiles of h1 (padded) / h2
-  const int col = wave * 32 + l31;                   // this lane's h1 / h2 column
+  const int nt1 = H1P >> 5, nt2 = (a.H2 + 31) >> 5;  // 32-wide tiles of h1 (padded) / h2 columns
+  const bool l1 = wave < nt1, l2 = wave < nt2;
 
-  // ---- layer 1: acc1 = U[b(row)] + rep(row) . W1a'^T for column tile `wave`, rows 0..63.
-  // Its (small) operand loads are issued first; vmcnt retires in order, so layer 1 only waits
-  // for them while the layer-2 weight stream below is still arriving.
-  const bool l1 = wave < nt1;
-  f32x16 acc1[2];
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = tm * 32 + acc_row(r, h);
-      const bool rok = row < nrows;
-      const int bb = b0 + (rok ? row / a.A : 0);
-      acc1[tm][r] = ld_or_zero(a.U, (int64_t)bb * a.ldu + col, l1 && rok && col < a.H1);
-    }
-  }
+  // TRANSPOSED tiles: the weights are the MFMA A operand (i = hidden unit n), the activations the
+  // B operand (j = batch row), so an accumulator register holds
+  //   C[n = 32*wave + acc_row(reg, h)][row = 32*tm + l31]
+  // i.e. a lane owns ONE batch row and 16 hidden units: the layer-1 output goes to LDS as four
+  // ds_write_b128 per tile, and layer 3 (a dot product over hidden units) is an in-lane fma chain
+  // instead of a cross-lane reduction.
+  const int nq0 = wave * 32 + 4 * h;     // this lane's hidden units: nq0 + 8*q + j, q,j in 0..3
+
+  // ---- layer 1 operands first (vmcnt retires in order: layer 1 never waits for the W2' stream)
+  f32x16 acc[2];
+  const bool vU = ((reinterpret_cast<uintptr_t>(a.U) & 15) == 0) && ((a.ldu & 3) == 0);
   int64_t foff[2];
   bool fok[2];
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
     const int row = tm * 32 + l31;
-    fok[tm] = l1 && row < nrows;
-    const int rr = fok[tm] ? row : 0;
-    foff[tm] = (int64_t)(b0 + rr / a.A) * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
+    const bool rok = l1 && row < nrows;
+    const int rr = rok ? row : 0;
+    const int bb = b0 + rr / a.A;
+    fok[tm] = rok;
+    foff[tm] = (int64_t)bb * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nq0 + 8 * q;
+      float4 u;
+      if (vU) u = ld4_or_zero(a.U, (int64_t)bb * a.ldu + n, rok && n < a.H1);  // H1 % 4 == 0 here
+      else u = guarded_load4(a.U, (int64_t)bb * a.ldu, rok, n, a.H1);
+      acc[tm][4 * q + 0] = u.x; acc[tm][4 * q + 1] = u.y;
+      acc[tm][4 * q + 2] = u.z; acc[tm][4 * q + 3] = u.w;
+    }
   }
   const bool vfeat = ((reinterpret_cast<uintptr_t>(a.feat) & 15) == 0) && ((a.AD & 3) == 0) &&
                      ((a.feat_bstride & 3) == 0);
   const bool vw1 = ((reinterpret_cast<uintptr_t>(a.W1a) & 15) == 0) && ((a.ldw1 & 3) == 0) &&
                    ((a.AD & 3) == 0);
-  const int64_t woff = (int64_t)col * a.ldw1;
-  const bool wok = l1 && col < a.H1;
-  auto l1_loads = [&](int k0, float4 (&a4)[2], float4& b4) {
+  const int wcol = wave * 32 + l31;      // hidden unit this lane feeds as the A operand
+  const int64_t woff = (int64_t)wcol * a.ldw1;
+  const bool wok = l1 && wcol < a.H1;
+  auto l1_loads = [&](int k0, float4 (&x4)[2], float4& w4) {
     const int k = k0 + 4 * h;
     if (vfeat) {
-      a4[0] = ld4_or_zero(a.feat, foff[0] + k, fok[0] && k < a.AD);
-      a4[1] = ld4_or_zero(a.feat, foff[1] + k, fok[1] && k < a.AD);
+      x4[0] = ld4_or_zero(a.feat, foff[0] + k, fok[0] && k < a.AD);
+      x4[1] = ld4_or_zero(a.feat, foff[1] + k, fok[1] && k < a.AD);
     } else {
-      a4[0] = guarded_load4(a.feat, foff[0], fok[0], k, a.AD);
-      a4[1] = guarded_load4(a.feat, foff[1], fok[1], k, a.AD);
+      x4[0] = guarded_load4(a.feat, foff[0], fok[0], k, a.AD);
+      x4[1] = guarded_load4(a.feat, foff[1], fok[1], k, a.AD);
     }
-    if (vw1) b4 = ld4_or_zero(a.W1a, woff + k, wok && k < a.AD);
-    else b4 = guarded_load4(a.W1a, woff, wok, k, a.AD);
+    if (vw1) w4 = ld4_or_zero(a.W1a, woff + k, wok && k < a.AD);
+    else w4 = guarded_load4(a.W1a, woff, wok, k, a.AD);
   };
-  auto l1_mfma = [&](const float4 (&a4)[2], const float4& b4) {
+  auto l1_mfma = [&](const float4 (&x4)[2], const float4& w4) {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
-      acc1[tm] = mfma32(a4[tm].x, b4.x, acc1[tm]);
-      acc1[tm] = mfma32(a4[tm].y, b4.y, acc1[tm]);
-      acc1[tm] = mfma32(a4[tm].z, b4.z, acc1[tm]);
-      acc1[tm] = mfma32(a4[tm].w, b4.w, acc1[tm]);
+      acc[tm] = mfma32(w4.x, x4[tm].x, acc[tm]);
+      acc[tm] = mfma32(w4.y, x4[tm].y, acc[tm]);
+      acc[tm] = mfma32(w4.z, x4[tm].z, acc[tm]);
+      acc[tm] = mfma32(w4.w, x4[tm].w, acc[tm]);
     }
   };
-  float4 fa[2][2], fb[2];  // the first two k-groups (AD <= 16 covers one-hot over 16 actions)
-  l1_loads(0, fa[0], fb[0]);
-  l1_loads(8, fa[1], fb[1]);
+  float4 fx[2][2], fw[2];  // the first two k-groups (AD <= 16 covers one-hot over 16 actions)
+  l1_loads(0, fx[0], fw[0]);
+  l1_loads(8, fx[1], fw[1]);
 
-  // ---- ALL of this wave's layer-2 B fragments (32 cols x H1P k = NKG KiB), one coalesced
-  // 1 KiB load each into their own registers: no register ring for the compiler to serialise,
-  // L2 paces the stream, and the main loop consumes it in arrival order.
-  float4 bfr[NKG];
-  const int64_t bbase = ((int64_t)wave * NKG) * 256 + lane * 4;
+  // ---- layer-2 A fragments: W2f[wave][g][lane], one coalesced 1 KiB load per k-group, RD
+  // k-groups in flight
+  float4 ring[RD];
+  const int64_t wbase = ((int64_t)wave * NKG) * 256 + lane * 4;
 #pragma unroll
-  for (int g = 0; g < NKG; ++g) bfr[g] = ld4_or_zero(a.W2f, bbase + (int64_t)g * 256, wave < nt2);
+  for (int g = 0; g < RD; ++g) ring[g] = ld4_or_zero(a.W2f, wbase + (int64_t)g * 256, l2);
+  // layer-3 constants of this lane's hidden units: fetched while the last RD k-groups run (they
+  // take over the registers of the drained prefetch ring)
+  float4 b2v[4], w3v[4];
+  const bool v2 = ((reinterpret_cast<uintptr_t>(a.b2) & 15) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(a.w3) & 15) == 0) && ((a.H2 & 3) == 0);
+  auto l3_load = [&](const float* p, int q) {
+    const int n = nq0 + 8 * q;
+    return v2 ? ld4_or_zero(p, n, n < a.H2) : guarded_load4(p, 0, true, n, a.H2);
+  };
 
-  l1_mfma(fa[0], fb[0]);
-  l1_mfma(fa[1], fb[1]);
+  l1_mfma(fx[0], fw[0]);
+  l1_mfma(fx[1], fw[1]);
   for (int k0 = 16; k0 < a.AD; k0 += 8) {  // wider action representations (rare)
-    float4 a4[2], b4;
-    l1_loads(k0, a4, b4);
-    l1_mfma(a4, b4);
+    float4 x4[2], w4;
+    l1_loads(k0, x4, w4);
+    l1_mfma(x4, w4);
   }
   if (l1) {
-    // h1 = relu(acc1) -> LDS A tile (columns >= H1 and rows >= nrows are exact zeros)
+    // h1 = relu(acc) -> LDS tile [row][k] (hidden units >= H1 and rows >= nrows are exact zeros)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < 2; ++tm) {
+      float* dst = Ah + (tm * 32 + l31) * PA_ + nq0;
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Ah[(tm * 32 + acc_row(r, h)) * PA_ + col] = relu_keep_nan(acc1[tm][r]);
+      for (int q = 0; q < 4; ++q) {
+        float4 v;
+        v.x = relu_keep_nan(acc[tm][4 * q + 0]); v.y = relu_keep_nan(acc[tm][4 * q + 1]);
+        v.z = relu_keep_nan(acc[tm][4 * q + 2]); v.w = relu_keep_nan(acc[tm][4 * q + 3]);
+        *reinterpret_cast<float4*>(dst + 8 * q) = v;
+      }
+    }
   }
   __syncthreads();  // the only workgroup barrier before the epilogue
 
-  // ---- layer 2: acc2 = h1 . W2'^T; A from LDS, B streamed from L2 in fragment order
-  f32x16 acc2[2];
+  // ---- layer 2: acc[n][row] = sum_k W2'[n][k] h1[row][k]
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[tm][r] = 0.f;
-  if (wave < nt2) {
-    const float* ap0 = Ah + l31 * PA_ + 4 * h;
-    const float* ap1 = ap0 + 32 * PA_;
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+  if (l2) {
+    const float* xp0 = Ah + l31 * PA_ + 4 * h;
+    const float* xp1 = xp0 + 32 * PA_;
 #pragma unroll
     for (int g = 0; g < NKG; ++g) {
-      const float4 b4 = bfr[g];
-      const float4 x0 = *reinterpret_cast<const float4*>(ap0 + g * 8);
-      const float4 x1 = *reinterpret_cast<const float4*>(ap1 + g * 8);
-      acc2[0] = mfma32(x0.x, b4.x, acc2[0]);
-      acc2[1] = mfma32(x1.x, b4.x, acc2[1]);
-      acc2[0] = mfma32(x0.y, b4.y, acc2[0]);
-      acc2[1] = mfma32(x1.y, b4.y, acc2[1]);
-      acc2[0] = mfma32(x0.z, b4.z, acc2[0]);
-      acc2[1] = mfma32(x1.z, b4.z, acc2[1]);
-      acc2[0] = mfma32(x0.w, b4.w, acc2[0]);
-      acc2[1] = mfma32(x1.w, b4.w, acc2[1]);
+      const float4 w4 = ring[g % RD];
+      if (g + RD < NKG) ring[g % RD] = ld4_or_zero(a.W2f, wbase + (int64_t)(g + RD) * 256, true);
+      else if (g + RD - NKG < 4) b2v[g + RD - NKG] = l3_load(a.b2, g + RD - NKG);
+      else w3v[g + RD - NKG - 4] = l3_load(a.w3, g + RD - NKG - 4);
+      const float4 x0 = *reinterpret_cast<const float4*>(xp0 + g * 8);
+      const float4 x1 = *reinterpret_cast<const float4*>(xp1 + g * 8);
+      acc[0] = mfma32(w4.x, x0.x, acc[0]);
+      acc[1] = mfma32(w4.x, x1.x, acc[1]);
+      acc[0] = mfma32(w4.y, x0.y, acc[0]);
+      acc[1] = mfma32(w4.y, x1.y, acc[1]);
+      acc[0] = mfma32(w4.z, x0.z, acc[0]);
+      acc[1] = mfma32(w4.z, x1.z, acc[1]);
+      acc[0] = mfma32(w4.w, x0.w, acc[0]);
+      acc[1] = mfma32(w4.w, x1.w, acc[1]);
     }
   }
 
-  // ---- layer 3 + mask + max + Bellman target
-  {
-    const bool cok = col < a.H2;
-    const float bv = ld_or_zero(a.b2, col, cok);
-    const float wv = ld_or_zero(a.w3, col, cok);
+  if (!l2) {
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
-      float v[16];
+    for (int q = 0; q < 4; ++q) b2v[q] = w3v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // ---- layer 3: in-lane over this lane's 16 hidden units, then the other half, then the waves
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = relu_keep_nan(acc2[tm][r] + bv) * wv;
+  for (int tm = 0; tm < 2; ++tm) {
+    float sum = 0.f;
 #pragma unroll
-      for (int off = 16; off >= 1; off >>= 1)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] += __shfl_xor(v[r], off);
-      if (l31 == 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) qpart[wave * 64 + tm * 32 + acc_row(r, h)] = v[r];
-      }
+    for (int q = 0; q < 4; ++q) {
+      sum = fmaf(relu_keep_nan(acc[tm][4 * q + 0] + b2v[q].x), w3v[q].x, sum);
+      sum = fmaf(relu_keep_nan(acc[tm][4 * q + 1] + b2v[q].y), w3v[q].y, sum);
+      sum = fmaf(relu_keep_nan(acc[tm][4 * q + 2] + b2v[q].z), w3v[q].z, sum);
+      sum = fmaf(relu_keep_nan(acc[tm][4 * q + 3] + b2v[q].w), w3v[q].w, sum);
     }
+    sum += __shfl_xor(sum, 32);
+    if (h == 0) qpart[wave * 64 + tm * 32 + l31] = sum;
   }
   __syncthreads();
   if (tid < T_ROWS) {
