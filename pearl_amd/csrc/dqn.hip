@@ -15,7 +15,7 @@
 #include <string>
 #include <vector>
 
-#include "dqn_kernels.hpp"
+#include "online_kernels.hpp"
 
 using namespace pa;
 
@@ -41,7 +41,8 @@ struct pa_dqn {
   int IN;            // S + AD
   // workspaces (HBM)
   float *U, *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
-  float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's B operand)
+  float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
+  float *W1f, *W2f16, *W2tf;  // fragment-major copies of the online weights (online_rowpass_kernel)
   // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
   struct BatchBuf {
     float* x;
@@ -228,21 +229,6 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows) {
   return g;
 }
 
-GemmArgs online_l1_problem(pa_dqn* h, const float* x, int B) {
-  // H1a = relu(x W1^T + b1)
-  const pa_dqn_desc& d = h->d;
-  const NetPtrs q = net_ptrs(h, h->bufs.q);
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = x; g.lda = h->IN;
-  g.Bm = q.W1; g.ldb = h->IN;
-  g.C = h->H1a; g.ldc = d.hidden1;
-  g.bias = q.b1;
-  g.M = B; g.N = d.hidden1; g.K = h->IN;
-  g.epi = EPI_BIAS_RELU;
-  return g;
-}
-
 // max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
 // deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
 // U must already be in h->U.
@@ -268,61 +254,90 @@ int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, 
   return launch_target(a, s);
 }
 
-// H2a = relu(H1a W2^T + b2)
-int run_online_l2(pa_dqn* h, int B, hipStream_t s) {
-  const pa_dqn_desc& d = h->d;
-  const NetPtrs q = net_ptrs(h, h->bufs.q);
-  ScopedTimer tm(h, "online_l2", s);
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  g.A = h->H1a; g.lda = d.hidden1;
-  g.Bm = q.W2; g.ldb = d.hidden1;
-  g.C = h->H2a; g.ldc = d.hidden2;
-  g.bias = q.b2;
-  g.M = B; g.N = d.hidden2; g.K = d.hidden1;
-  g.epi = EPI_BIAS_RELU;
-  return launch_linear<false>(&g, 1, s);
+PackedW packed(pa_dqn* h) {
+  PackedW pk;
+  pk.W1f = h->W1f; pk.W2f = h->W2f16; pk.W2tf = h->W2tf; pk.tW2f = h->w2f;
+  return pk;
 }
 
-int run_head(pa_dqn* h, int B, const float* y, float* q_out, bool backward, int world,
-             hipStream_t s) {
+// Rebuild the fragment-major weight copies from the row-major parameters.  Needed whenever the
+// parameters may have been changed by someone else (checkpoint load, stand-alone soft update,
+// the data-parallel AdamW); inside the fused learn loop the optimizer tail keeps them current.
+int run_repack(pa_dqn* h, bool online, bool target, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
-  const NetPtrs q = net_ptrs(h, h->bufs.q);
-  ScopedTimer tm(h, "head", s);
-  HeadArgs a;
+  RepackArgs a;
   memset(&a, 0, sizeof(a));
-  a.H2a = h->H2a; a.ldh = d.hidden2;
-  a.w3 = q.W3; a.b3 = q.b3;
-  a.y = y;
-  a.q_out = q_out;
-  a.dq_out = h->dq; a.absd_out = h->absd;
-  a.dZ2 = backward ? h->dZ2 : nullptr; a.ldz = d.hidden2;
-  a.norm = (float)(2.0 / ((double)B * (double)world));
-  a.B = B; a.H2 = d.hidden2;
-  hipLaunchKernelGGL(head_loss_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, a);
+  a.q = h->bufs.q; a.q_target = h->bufs.q_target;
+  a.off_w1 = h->off[0]; a.off_w2 = h->off[2];
+  a.IN = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
+  a.pk = packed(h);
+  a.do_online = online; a.do_target = target;
+  hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
 
-int run_backward(pa_dqn* h, const float* x, int B, hipStream_t s) {
+// Forward (+ loss + backward to dZ2 / dZ1 when y is given) of the online network.
+int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, float* q_out, int world,
+                hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
-  float* G = h->bufs.grad;
-  int rc;
-  {
-    ScopedTimer tm(h, "bwd_dx", s);
-    // dZ1 = (dZ2 W2) * [H1a > 0]
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = h->dZ2; g.lda = d.hidden2;
-    g.Bm = q.W2; g.ldb = d.hidden1;
-    g.C = h->dZ1; g.ldc = d.hidden1;
-    g.Hmask = h->H1a; g.ldh = d.hidden1;
-    g.M = B; g.N = d.hidden1; g.K = d.hidden2;
-    g.epi = EPI_MASK;
-    rc = launch_linear<true>(&g, 1, s);
+  ScopedTimer tm(h, "rowpass", s);
+  static size_t configured = 0;
+  const size_t smem = rowpass_smem_bytes(h->IN, d.hidden1, d.hidden2);
+  if (smem > configured) {
+    int rc = set_max_smem(online_rowpass_kernel, smem);
     if (rc != PA_OK) return rc;
+    configured = smem;
   }
+  RowArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.ldx = h->IN;
+  a.W1f = h->W1f; a.b1 = q.b1;
+  a.W2f = h->W2f16; a.b2 = q.b2;
+  a.W2tf = h->W2tf;
+  a.w3 = q.W3; a.b3 = q.b3;
+  a.y = y;
+  a.H1a = y ? h->H1a : nullptr; a.H2a = y ? h->H2a : nullptr;
+  a.dZ2 = h->dZ2; a.dZ1 = h->dZ1;
+  a.q_out = q_out; a.dq_out = h->dq; a.absd_out = h->absd;
+  a.norm = (float)(2.0 / ((double)B * (double)world));
+  a.B = B; a.K1 = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
+  hipLaunchKernelGGL(online_rowpass_kernel, dim3((unsigned)ceil_div(B, RP_ROWS)), dim3(512), smem,
+                     s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+AdamScalars adam_scalars(const pa_dqn_desc& d, int64_t step) {
+  // python-float (double) scalars exactly as _single_tensor_adam forms them
+  const double bc1 = 1.0 - pow(d.beta1, (double)step);
+  const double bc2 = 1.0 - pow(d.beta2, (double)step);
+  AdamScalars c;
+  c.decay = (float)(1.0 - d.lr * d.weight_decay);
+  c.w1 = (float)(1.0 - d.beta1);
+  c.beta2 = (float)d.beta2;
+  c.omb2 = (float)(1.0 - d.beta2);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.neg_step = (float)(-(d.lr / bc1));
+  c.eps = (float)d.eps;
+  c.amsgrad = d.amsgrad;
+  return c;
+}
+AdamState adam_state(pa_dqn* h) {
+  AdamState st;
+  st.p = h->bufs.q; st.m = h->bufs.exp_avg; st.v = h->bufs.exp_avg_sq;
+  st.vmax = h->bufs.max_exp_avg_sq;
+  return st;
+}
+
+// Weight gradients of all three layers; with fuse_adam the workgroup that finishes a tile also
+// applies AdamW to it (+ the next step's soft target update when soft_next) and the extra
+// workgroup folds |Q - target| into loss_out.
+int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t adam_step,
+                    float* loss_out, int soft_next, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  float* G = h->bufs.grad;
   ScopedTimer tm(h, "bwd_dw", s);
   DwArgs a;
   memset(&a, 0, sizeof(a));
@@ -335,6 +350,7 @@ int run_backward(pa_dqn* h, const float* x, int B, hipStream_t s) {
   a.p[0].M = d.hidden2; a.p[0].N = d.hidden1;
   a.p[0].tiles_n = (int)ceil_div(d.hidden1, 32);
   a.p[0].tile0 = 0;
+  a.p[0].kind = 0;
   int t0 = (int)ceil_div(d.hidden2, 32) * a.p[0].tiles_n;
   // dW1 = dZ1^T x, db1
   a.p[1].dZ = h->dZ1; a.p[1].ldz = d.hidden1;
@@ -344,6 +360,7 @@ int run_backward(pa_dqn* h, const float* x, int B, hipStream_t s) {
   a.p[1].M = d.hidden1; a.p[1].N = h->IN;
   a.p[1].tiles_n = (int)ceil_div(h->IN, 32);
   a.p[1].tile0 = t0;
+  a.p[1].kind = 1;
   t0 += (int)ceil_div(d.hidden1, 32) * a.p[1].tiles_n;
   // dW3 = dq^T H2a, db3 = sum dq   (dq is a [B][1] "dZ")
   a.p[2].dZ = h->dq; a.p[2].ldz = 1;
@@ -353,63 +370,43 @@ int run_backward(pa_dqn* h, const float* x, int B, hipStream_t s) {
   a.p[2].M = 1; a.p[2].N = d.hidden2;
   a.p[2].tiles_n = (int)ceil_div(d.hidden2, 32);
   a.p[2].tile0 = t0;
+  a.p[2].kind = 2;
   t0 += a.p[2].tiles_n;
   a.total_tiles = t0;
   a.B = B;
-  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
+  a.ad.absd = h->absd; a.ad.nabs = B; a.ad.inv_B = (float)(1.0 / (double)B);
+  a.ad.loss_out = loss_out;
+  if (fuse_adam) {
+    PA_REQUIRE(adam_step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)",
+               (long long)adam_step);
+    a.ad.enabled = 1;
+    a.ad.c = adam_scalars(d, adam_step);
+    a.ad.st = adam_state(h);
+    a.ad.grad_base = G;
+    a.ad.W1f = h->W1f; a.ad.W2f = h->W2f16; a.ad.W2tf = h->W2tf;
+    a.ad.nkg_w1 = wf16_nkg(h->IN); a.ad.nkg_w2 = wf16_nkg(d.hidden1);
+    a.ad.nkg_w2t = wf16_nkg(d.hidden2);
+    a.ad.soft_next = soft_next;
+    a.ad.tgt = h->bufs.q_target; a.ad.tau = d.tau;
+    a.ad.one_minus_tau = (float)(1.0 - (double)d.tau);
+    a.ad.tW2f = h->w2f; a.ad.nkg_t = t_nkg(d.hidden1);
+  }
+  const unsigned grid = (unsigned)a.total_tiles + (loss_out ? 1u : 0u);
+  hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
 
-// AdamW on bufs.grad; also folds |Q - target| into loss_out and, when soft_next, performs the
-// soft target update that the NEXT step's forward() would start with.
-int run_adamw(pa_dqn* h, int64_t step, int B, float* loss_out, int soft_next, hipStream_t s) {
-  const pa_dqn_desc& d = h->d;
+// Stand-alone AdamW on bufs.grad (data-parallel path, after the all-reduce).
+int run_adamw(pa_dqn* h, int64_t step, hipStream_t s) {
   PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)", (long long)step);
   ScopedTimer tm(h, "adamw", s);
   AdamArgs a;
   memset(&a, 0, sizeof(a));
-  a.p = h->bufs.q; a.g = h->bufs.grad; a.m = h->bufs.exp_avg; a.v = h->bufs.exp_avg_sq;
-  a.vmax = h->bufs.max_exp_avg_sq;
+  a.st = adam_state(h); a.g = h->bufs.grad;
   a.n = h->P;
-  // python-float (double) scalars exactly as _single_tensor_adam forms them
-  const double bc1 = 1.0 - pow(d.beta1, (double)step);
-  const double bc2 = 1.0 - pow(d.beta2, (double)step);
-  a.decay = (float)(1.0 - d.lr * d.weight_decay);
-  a.w1 = (float)(1.0 - d.beta1);
-  a.beta2 = (float)d.beta2;
-  a.omb2 = (float)(1.0 - d.beta2);
-  a.bc2_sqrt = (float)sqrt(bc2);
-  a.neg_step = (float)(-(d.lr / bc1));
-  a.eps = (float)d.eps;
-  a.amsgrad = d.amsgrad;
-  a.absd = h->absd; a.nabs = B; a.inv_B = (float)(1.0 / (double)B); a.loss_out = loss_out;
-  a.tgt = h->bufs.q_target; a.tau = d.tau; a.one_minus_tau = (float)(1.0 - (double)d.tau);
-  a.soft_next = soft_next;
-  a.w2f = h->w2f; a.w2_off = h->off[2]; a.H1 = d.hidden1; a.H2 = d.hidden2;
+  a.c = adam_scalars(h->d, step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s, a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
-}
-
-// |Q - target| fold without an optimizer step (data-parallel path: AdamW comes after the
-// all-reduce, but the local loss is final now).
-int run_loss_fold(pa_dqn* h, int B, float* loss_out, hipStream_t s) {
-  AdamArgs a;
-  memset(&a, 0, sizeof(a));
-  a.n = 0;
-  a.absd = h->absd; a.nabs = B; a.inv_B = (float)(1.0 / (double)B); a.loss_out = loss_out;
-  hipLaunchKernelGGL(adamw_kernel, dim3(1), dim3(256), 0, s, a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
-}
-
-// Refresh the fragment-major copy of the target W2 (after anything that changed the target net).
-int run_repack(pa_dqn* h, hipStream_t s) {
-  const pa_dqn_desc& d = h->d;
-  const int64_t slots = w2f_floats(d.hidden2, d.hidden1) / 4;
-  hipLaunchKernelGGL(repack_w2_kernel, dim3((unsigned)ceil_div(slots, 256)), dim3(256), 0, s,
-                     h->bufs.q_target + h->off[2], d.hidden2, d.hidden1, h->w2f);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -419,57 +416,47 @@ int run_soft_update(pa_dqn* h, hipStream_t s) {
   hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s,
                      h->bufs.q_target, h->bufs.q, h->P, h->d.tau, (float)(1.0 - (double)h->d.tau));
   PA_LAUNCH_CHECK();
-  return run_repack(h, s);
+  return PA_OK;
 }
 
 // Everything of one learn_batch that depends on the ONLINE parameters, given the Bellman targets
-// y[B] of the batch: (layer 1 unless l1_done) -> layer 2 -> head/loss -> backward -> AdamW.
-// soft_next: fuse the NEXT step's soft target update into this step's AdamW launch.
-int online_chain(pa_dqn* h, const float* x, int B, const float* y, bool l1_done, int64_t adam_step,
+// y[B] of the batch: row pass (forward, loss, dZ2, dZ1) -> weight gradients (+ AdamW).
+// soft_next: fuse the NEXT step's soft target update into this step's optimizer tail.
+int online_chain(pa_dqn* h, const float* x, int B, const float* y, int64_t adam_step,
                  int grad_world, float* loss_out, int soft_next, hipStream_t s) {
-  int rc;
-  if (!l1_done) {
-    ScopedTimer tm(h, "online_l1", s);
-    GemmArgs g = online_l1_problem(h, x, B);
-    rc = launch_linear<false>(&g, 1, s);
-    if (rc != PA_OK) return rc;
-  }
-  rc = run_online_l2(h, B, s);
-  if (rc != PA_OK) return rc;
-  rc = run_head(h, B, y, h->qbuf, true, grad_world, s);
-  if (rc != PA_OK) return rc;
-  rc = run_backward(h, x, B, s);
+  int rc = run_rowpass(h, x, B, y, h->qbuf, grad_world, s);
   if (rc != PA_OK) return rc;
   float* lo = loss_out ? loss_out : h->loss_scratch;
-  if (grad_world == 1) return run_adamw(h, adam_step, B, lo, soft_next, s);
-  return run_loss_fold(h, B, lo, s);
+  return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s);
 }
 
 // One stand-alone learn_batch (pa_dqn_step).  do_target_update: soft update BEFORE the forward
-// (deep_td_learning.py:283-284).  The fragment-major target W2 is rebuilt every time: the caller
-// may have loaded a checkpoint into the target network between calls.
+// (deep_td_learning.py:283-284).  The fragment-major weight copies are rebuilt every time: the
+// caller may have loaded a checkpoint or stepped the optimizer itself between calls.
 int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_t adam_step,
               int grad_world, float* loss_out, hipStream_t s) {
   int rc = check_batch(h, batch);
   if (rc != PA_OK) return rc;
   PA_REQUIRE(grad_world >= 1, PA_ERR_INVALID, "grad_world must be >= 1");
   if (h->timing) h->tick++;
-  rc = do_target_update ? run_soft_update(h, s) /* also repacks */ : run_repack(h, s);
+  if (do_target_update) {
+    rc = run_soft_update(h, s);
+    if (rc != PA_OK) return rc;
+  }
+  rc = run_repack(h, true, true, s);
   if (rc != PA_OK) return rc;
   const float* x = nullptr;
   rc = resolve_x(h, batch, &x, s);
   if (rc != PA_OK) return rc;
   {
-    // layer 1 of both networks in one launch: U (target, state part) and H1a (online)
-    ScopedTimer tm(h, "l1_dual", s);
-    GemmArgs probs[2] = {target_l1_problem(h, batch->next_state, batch->B),
-                         online_l1_problem(h, x, batch->B)};
-    rc = launch_linear<false>(probs, 2, s);
+    ScopedTimer tm(h, "target_l1", s);
+    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B);
+    rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
   }
   rc = run_target_fused(h, batch, h->nextv, h->y, s);
   if (rc != PA_OK) return rc;
-  return online_chain(h, x, batch->B, h->y, true, adam_step, grad_world, loss_out, 0, s);
+  return online_chain(h, x, batch->B, h->y, adam_step, grad_world, loss_out, 0, s);
 }
 
 void free_batchbufs(pa_dqn* h) {
@@ -555,7 +542,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->idx_cap = 0;
   h->tick = 0;
   h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->dq = h->absd =
-      h->xpack = h->loss_scratch = h->w2f = nullptr;
+      h->xpack = h->loss_scratch = h->w2f = h->W1f = h->W2f16 = h->W2tf = nullptr;
   const int64_t B = desc->max_batch;
   // learn() evaluates the target network for a whole window of rounds in one launch (the target
   // parameters only change every target_update_freq rounds): up to 16 rounds / 16384 transitions
@@ -584,6 +571,9 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->xpack, B * h->IN);
   PA_WS(h->loss_scratch, 4);
   PA_WS(h->w2f, w2f_floats(desc->hidden2, desc->hidden1));
+  PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
+  PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
+  PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
 #undef PA_WS
   *out = h;
   return PA_OK;
@@ -594,7 +584,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipSetDevice(h->d.device);
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->U, h->H1a, h->H2a, h->dZ2, h->dZ1, h->y, h->nextv, h->qbuf, h->dq, h->absd,
-                  h->xpack, h->loss_scratch, h->idx_all, h->w2f};
+                  h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f, h->W2f16, h->W2tf};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   free_batchbufs(h);
@@ -625,29 +615,20 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
   if (rc != PA_OK) return rc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipSetDevice(h->d.device));
-  GemmArgs probs[2];
-  int np = 0;
-  const float* x = nullptr;
-  if (next_v_out || target_out)
-    probs[np++] = target_l1_problem(h, batch->next_state, batch->B);
-  if (q_out) {
-    rc = resolve_x(h, batch, &x, s);
-    if (rc != PA_OK) return rc;
-    probs[np++] = online_l1_problem(h, x, batch->B);
-  }
-  if (np == 0) return PA_OK;
-  rc = launch_linear<false>(probs, np, s);
+  rc = run_repack(h, q_out != nullptr, next_v_out || target_out, s);
   if (rc != PA_OK) return rc;
   if (next_v_out || target_out) {
-    rc = run_repack(h, s);
+    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B);
+    rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
     rc = run_target_fused(h, batch, next_v_out, target_out, s);
     if (rc != PA_OK) return rc;
   }
   if (q_out) {
-    rc = run_online_l2(h, batch->B, s);
+    const float* x = nullptr;
+    rc = resolve_x(h, batch, &x, s);
     if (rc != PA_OK) return rc;
-    rc = run_head(h, batch->B, nullptr, q_out, false, 1, s);
+    rc = run_rowpass(h, x, batch->B, nullptr, q_out, 1, s);
     if (rc != PA_OK) return rc;
   }
   return PA_OK;
@@ -671,7 +652,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
 extern "C" int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
-  return run_adamw(h, adam_step, 1, nullptr, 0, reinterpret_cast<hipStream_t>(stream));
+  return run_adamw(h, adam_step, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream) {
@@ -744,7 +725,11 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     }
     if (r == 0) {
       // the first round's soft update runs stand-alone; later ones ride the previous AdamW launch
-      rc = due(0) ? run_soft_update(h, s) : run_repack(h, s);
+      if (due(0)) {
+        rc = run_soft_update(h, s);
+        if (rc != PA_OK) return rc;
+      }
+      rc = run_repack(h, true, true, s);
       if (rc != PA_OK) return rc;
     }
     if (h->timing) h->tick++;
@@ -767,7 +752,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     for (int j = 0; j < w; ++j) {
       const int round = r + j;
       const int soft_next = (round + 1 < R) ? due(round + 1) : 0;
-      rc = online_chain(h, h->bb.x + (int64_t)j * B * h->IN, B, h->y + (int64_t)j * B, false,
+      rc = online_chain(h, h->bb.x + (int64_t)j * B * h->IN, B, h->y + (int64_t)j * B,
                         args->adam_step0 + round + 1, 1,
                         args->losses_out ? args->losses_out + round : nullptr, soft_next, s);
       if (rc != PA_OK) return rc;

@@ -611,6 +611,104 @@ __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a) {
   }
 }
 
+// AdamW(amsgrad=True), the op order of torch/optim/adam.py::_single_tensor_adam
+// (param.mul_, exp_avg.lerp_, exp_avg_sq.mul_().addcmul_, maximum, sqrt/div/add,
+// addcdiv_), one rounding per op as ATen's CPU kernels do.
+struct AdamScalars {
+  float decay;       // 1 - lr * weight_decay
+  float w1;          // 1 - beta1
+  float beta2;
+  float omb2;        // 1 - beta2
+  float bc2_sqrt;    // sqrt(1 - beta2^t)
+  float neg_step;    // -lr / (1 - beta1^t)
+  float eps;
+  int amsgrad;
+};
+struct AdamState {
+  float* p; float* m; float* v; float* vmax;
+};
+__device__ __forceinline__ float adam_update(const AdamScalars& c, const AdamState& st, int64_t i,
+                                             float g) {
+  float p = __fmul_rn(st.p[i], c.decay);
+  float m = st.m[i];
+  m = __fadd_rn(m, __fmul_rn(c.w1, __fsub_rn(g, m)));
+  float v = __fmul_rn(st.v[i], c.beta2);
+  v = __fadd_rn(v, __fmul_rn(__fmul_rn(c.omb2, g), g));
+  float dn;
+  if (c.amsgrad) {
+    float vm = st.vmax[i];
+    vm = (v > vm || v != v) ? v : vm;
+    st.vmax[i] = vm;
+    dn = vm;
+  } else {
+    dn = v;
+  }
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(dn), c.bc2_sqrt), c.eps);
+  p = __fadd_rn(p, __fdiv_rn(__fmul_rn(c.neg_step, m), denom));
+  st.p[i] = p;
+  st.m[i] = m;
+  st.v[i] = v;
+  return p;
+}
+
+// Fused optimizer tail of the weight-gradient kernel (single-GPU learn path): the workgroup that
+// finishes a 32 x 32 tile of dW applies AdamW to those parameters at once, refreshes the MFMA
+// fragment-major copies the next step's kernels read, and — when the next step's forward() opens
+// with a soft target update (deep_td_learning.py:283-284) — performs that update too.
+struct AdamFuse {
+  int enabled;
+  AdamScalars c;
+  AdamState st;
+  const float* grad_base;            // flat gradient buffer (parameter index = dW - grad_base)
+  float* W1f; float* W2f; float* W2tf;  // online packed copies (16x16x4 fragment-major)
+  int nkg_w1, nkg_w2, nkg_w2t;
+  int soft_next; float* tgt; float tau, one_minus_tau;
+  float* tW2f; int nkg_t;            // target W2, 32x32x2 fragment-major
+  const float* absd; int nabs; float inv_B; float* loss_out;  // mean |Q - target| of this step
+};
+
+struct DwProblem {
+  const float* dZ; int ldz;   // [B][M]
+  const float* X; int ldx;    // [B][N]
+  float* dW; int ldw;         // [M][N]
+  float* db;                  // [M]
+  int M, N, tiles_n, tile0;
+  int kind;                   // 0: W2, 1: W1, 2: w3 (which packed copies a parameter feeds)
+};
+struct DwArgs {
+  DwProblem p[3];
+  int nprob, B, total_tiles;
+  AdamFuse ad;
+};
+constexpr int DW_ROWS = 128;  // batch rows per wave per pass
+
+// index of fragment-major slots (defined here, used by online_kernels.hpp as well)
+__host__ __device__ inline int64_t wf16_index_(int unit, int k, int nkg) {
+  return ((((int64_t)(unit >> 4) * nkg + (k >> 4)) * 64) + ((k >> 2) & 3) * 16 + (unit & 15)) * 4 +
+         (k & 3);
+}
+
+__device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, int64_t i, int row,
+                                                  int col, float g) {
+  const float p = adam_update(f.c, f.st, i, g);
+  if (kind == 0) {         // W2[n = row][k = col]
+    f.W2f[wf16_index_(row, col, f.nkg_w2)] = p;
+    f.W2tf[wf16_index_(col, row, f.nkg_w2t)] = p;
+  } else if (kind == 1) {  // W1[n = row][k = col]
+    f.W1f[wf16_index_(row, col, f.nkg_w1)] = p;
+  }
+  if (f.soft_next) {  // update_target_network (common/utils.py:214-226)
+    const float t = __fadd_rn(__fmul_rn(f.tau, p), __fmul_rn(f.one_minus_tau, f.tgt[i]));
+    f.tgt[i] = t;
+    if (kind == 0) f.tW2f[w2f_index(row, col, f.nkg_t)] = t;
+  }
+}
+__device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, float g) {
+  const float p = adam_update(f.c, f.st, i, g);
+  if (f.soft_next)
+    f.tgt[i] = __fadd_rn(__fmul_rn(f.tau, p), __fmul_rn(f.one_minus_tau, f.tgt[i]));
+}
+
 // ---------------------------------------------------------------------------
 // Weight gradients: dW[i][j] = sum_b dZ[b][i] X[b][j], db[i] = sum_b dZ[b][i], for
 // up to three problems per launch (dW2/db2, dW1/db1, dW3/db3 with dZ = dq[B][1]).
@@ -618,25 +716,26 @@ __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a) {
 // dimension) and add their partial tiles in a fixed order through LDS.  Both
 // operands are row-contiguous across lanes, so they go global -> VGPR -> MFMA
 // with no LDS staging; every load of a wave's 128-row slice is issued before the
-// first MFMA (one exposed memory latency).
+// first MFMA (one exposed memory latency).  One extra workgroup (blockIdx ==
+// total_tiles) folds |Q - target| into the reported loss when ad.loss_out is set.
 // ---------------------------------------------------------------------------
-struct DwProblem {
-  const float* dZ; int ldz;   // [B][M]
-  const float* X; int ldx;    // [B][N]
-  float* dW; int ldw;         // [M][N]
-  float* db;                  // [M]
-  int M, N, tiles_n, tile0;
-};
-struct DwArgs {
-  DwProblem p[3];
-  int nprob, B, total_tiles;
-};
-constexpr int DW_ROWS = 128;  // batch rows per wave per pass
-
 __global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
   __shared__ float part[8 * 1024];
   __shared__ float csum[8 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= a.total_tiles) {
+    // mean |Q - target| of this step (deep_td_learning.py:358-359), fixed summation order
+    float s = 0.f;
+    for (int i = tid; i < a.ad.nabs; i += 512) s += a.ad.absd[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int w = 256; w >= 1; w >>= 1) {
+      if (tid < w) part[tid] += part[tid + w];
+      __syncthreads();
+    }
+    if (tid == 0) a.ad.loss_out[0] = part[0] * a.ad.inv_B;
+    return;
+  }
   const int h = lane >> 5, l31 = lane & 31;
   int pi = 0;
   if (a.nprob > 1 && (int)blockIdx.x >= a.p[1].tile0) pi = 1;
@@ -683,36 +782,29 @@ __global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
     for (int w = 1; w < 8; ++w) s += part[w * 1024 + e];
     const int reg = e >> 6, ln = e & 63;
     const int row = i0 + acc_row(reg, ln >> 5), col = j0 + (ln & 31);
-    if (row < P.M && col < P.N) P.dW[(int64_t)row * P.ldw + col] = s;
+    if (row < P.M && col < P.N) {
+      float* dst = P.dW + (int64_t)row * P.ldw + col;
+      *dst = s;
+      if (a.ad.enabled) adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, row, col, s);
+    }
   }
   if (j0 == 0 && tid < 32 && (i0 + tid) < P.M) {
     float s = csum[tid];
 #pragma unroll
     for (int w = 1; w < 8; ++w) s += csum[w * 32 + tid];
     P.db[i0 + tid] = s;
+    if (a.ad.enabled) adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
   }
 }
 
 // ---------------------------------------------------------------------------
-// AdamW(amsgrad=True), the op order of torch/optim/adam.py::_single_tensor_adam
-// (param.mul_, exp_avg.lerp_, exp_avg_sq.mul_().addcmul_, maximum, sqrt/div/add,
-// addcdiv_), one rounding per op as ATen's CPU kernels do.
+// Stand-alone AdamW on a flat gradient buffer (data-parallel path: after the all-reduce).
 // ---------------------------------------------------------------------------
 struct AdamArgs {
-  float* p; const float* g; float* m; float* v; float* vmax;
+  AdamState st; const float* g;
   int64_t n;
-  float decay;       // 1 - lr * weight_decay
-  float w1;          // 1 - beta1
-  float beta2;
-  float omb2;        // 1 - beta2
-  float bc2_sqrt;    // sqrt(1 - beta2^t)
-  float neg_step;    // -lr / (1 - beta1^t)
-  float eps;
-  int amsgrad;
-  // fused extras (may be disabled)
+  AdamScalars c;
   const float* absd; int nabs; float inv_B; float* loss_out;  // loss_out[0] = mean |Q - target|
-  float* tgt; float tau, one_minus_tau; int soft_next;        // soft update due before the NEXT step
-  float* w2f; int64_t w2_off; int H1, H2;                     // fragment-major copy of the target W2
 };
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
@@ -731,35 +823,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   }
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= a.n) return;
-  const float g = a.g[i];
-  float p = __fmul_rn(a.p[i], a.decay);
-  float m = a.m[i];
-  m = __fadd_rn(m, __fmul_rn(a.w1, __fsub_rn(g, m)));
-  float v = __fmul_rn(a.v[i], a.beta2);
-  v = __fadd_rn(v, __fmul_rn(__fmul_rn(a.omb2, g), g));
-  float dn;
-  if (a.amsgrad) {
-    float vm = a.vmax[i];
-    vm = (v > vm || v != v) ? v : vm;
-    a.vmax[i] = vm;
-    dn = vm;
-  } else {
-    dn = v;
-  }
-  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(dn), a.bc2_sqrt), a.eps);
-  p = __fadd_rn(p, __fdiv_rn(__fmul_rn(a.neg_step, m), denom));
-  a.p[i] = p;
-  a.m[i] = m;
-  a.v[i] = v;
-  if (a.soft_next) {  // update_target_network of the next step's forward() (common/utils.py:214-226)
-    const float t = __fadd_rn(__fmul_rn(a.tau, p), __fmul_rn(a.one_minus_tau, a.tgt[i]));
-    a.tgt[i] = t;
-    const int64_t e = i - a.w2_off;
-    if (e >= 0 && e < (int64_t)a.H2 * a.H1) {
-      const int n = (int)(e / a.H1), k = (int)(e - (int64_t)n * a.H1);
-      a.w2f[w2f_index(n, k, t_nkg(a.H1))] = t;
-    }
-  }
+  (void)adam_update(a.c, a.st, i, a.g[i]);
 }
 
 // theta' <- tau * theta + (1 - tau) * theta'   (common/utils.py:214-226)

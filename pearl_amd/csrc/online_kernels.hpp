@@ -1,0 +1,328 @@
+// Online-network kernels of the DQN learner step (gfx950, fp32 MFMA 16x16x4):
+//
+//   online_rowpass_kernel   forward, loss and backward-to-pre-activations of the online Q network
+//                           for 16 batch rows per workgroup, everything row-local in LDS/registers
+//                           (deep_td_learning.py:269-290 forward, :319-320 MSE, :353-354 autograd)
+//   repack_online_kernel    MFMA fragment-major copies of the weights (built once; afterwards kept
+//                           current by the kernel that updates the weights)
+//
+// Why row-local: the online chain of one learn_batch is five dependent 1024-row stages of
+// 0.07-0.27 GFLOP each.  As separate launches each pays a kernel boundary plus an exposed
+// memory latency (5 x ~6-8 us measured); as one launch the activations of a row tile never leave
+// the CU and only the weights stream from L2.  16-row tiles (v_mfma_f32_16x16x4_f32) give 64
+// workgroups at B = 1024; the matrix pipe time of one workgroup (2 waves per SIMD) is the floor.
+//
+// Tiles are TRANSPOSED like target_fused_kernel's: the weights are the MFMA A operand
+// (i = hidden unit), the activations the B operand (j = batch row):
+//   A: lane l holds W[unit = l & 15][k-slot = l >> 4]
+//   B: lane l holds X[k-slot = l >> 4][row = l & 15]
+//   C: acc[reg] = C[unit = 4 * (l >> 4) + reg][row = l & 15]
+// so a lane owns ONE batch row (r16 = l & 15) and four consecutive hidden units per tile: layer
+// outputs are float4 stores, the output head is an in-lane fma chain, and the ReLU masks of the
+// backward pass are still in the lane's registers when they are needed.
+// K is consumed in groups of 16: lane quarter qd = l >> 4 owns k = 16 g + 4 qd + j for the j-th
+// MFMA of the group, so ONE float4 per operand feeds four MFMAs.
+#pragma once
+#include "dqn_kernels.hpp"
+
+namespace pa {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- fragment-major layout for the 16x16x4 tiles ------------------------------------------
+// Wf[(unit_tile * nkg + kgroup) * 64 + lane] = float4{ W[unit][16 g + 4 qd + 0..3] },
+// lane = qd * 16 + (unit & 15).  Entries outside the matrix are zero.
+__host__ __device__ inline int wf16_nkg(int K) { return (K + 15) >> 4; }
+__host__ __device__ inline int64_t wf16_index(int unit, int k, int nkg) {
+  return wf16_index_(unit, k, nkg);
+}
+__host__ __device__ inline int64_t wf16_floats(int units, int K) {
+  return (int64_t)((units + 15) >> 4) * wf16_nkg(K) * 256;
+}
+
+// All packed copies the learner keeps (device pointers; see pa_dqn in dqn.hip)
+struct PackedW {
+  float* W1f;    // online W1  [H1 units][S+AD]      (layer 1)
+  float* W2f;    // online W2  [H2 units][H1]        (layer 2)
+  float* W2tf;   // online W2^T [H1 units][H2]       (dX = dZ2 W2)
+  float* tW2f;   // target W2, 32x32x2 fragment-major (target_fused_kernel)
+};
+
+struct RepackArgs {
+  const float* q; const float* q_target;
+  int64_t off_w1, off_w2;
+  int IN, H1, H2;
+  PackedW pk;
+  int do_online, do_target;
+};
+
+__global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a) {
+  const int64_t gsz = (int64_t)gridDim.x * 256;
+  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (a.do_online) {
+    {  // W1f
+      const int nkg = wf16_nkg(a.IN);
+      const int64_t total = wf16_floats(a.H1, a.IN) / 4;
+      const float* W = a.q + a.off_w1;
+      for (int64_t e = t0; e < total; e += gsz) {
+        const int lane = (int)(e & 63);
+        const int64_t tg = e >> 6;
+        const int g = (int)(tg % nkg), T = (int)(tg / nkg);
+        const int n = T * 16 + (lane & 15), k = g * 16 + 4 * (lane >> 4);
+        float4 v;
+        v.x = (n < a.H1 && k < a.IN) ? W[(int64_t)n * a.IN + k] : 0.f;
+        v.y = (n < a.H1 && k + 1 < a.IN) ? W[(int64_t)n * a.IN + k + 1] : 0.f;
+        v.z = (n < a.H1 && k + 2 < a.IN) ? W[(int64_t)n * a.IN + k + 2] : 0.f;
+        v.w = (n < a.H1 && k + 3 < a.IN) ? W[(int64_t)n * a.IN + k + 3] : 0.f;
+        reinterpret_cast<float4*>(a.pk.W1f)[e] = v;
+      }
+    }
+    {  // W2f
+      const int nkg = wf16_nkg(a.H1);
+      const int64_t total = wf16_floats(a.H2, a.H1) / 4;
+      const float* W = a.q + a.off_w2;
+      for (int64_t e = t0; e < total; e += gsz) {
+        const int lane = (int)(e & 63);
+        const int64_t tg = e >> 6;
+        const int g = (int)(tg % nkg), T = (int)(tg / nkg);
+        const int n = T * 16 + (lane & 15), k = g * 16 + 4 * (lane >> 4);
+        float4 v;
+        v.x = (n < a.H2 && k < a.H1) ? W[(int64_t)n * a.H1 + k] : 0.f;
+        v.y = (n < a.H2 && k + 1 < a.H1) ? W[(int64_t)n * a.H1 + k + 1] : 0.f;
+        v.z = (n < a.H2 && k + 2 < a.H1) ? W[(int64_t)n * a.H1 + k + 2] : 0.f;
+        v.w = (n < a.H2 && k + 3 < a.H1) ? W[(int64_t)n * a.H1 + k + 3] : 0.f;
+        reinterpret_cast<float4*>(a.pk.W2f)[e] = v;
+      }
+    }
+    {  // W2tf: "unit" = k of W2 (an H1 unit), reduction index = n (an H2 unit)
+      const int nkg = wf16_nkg(a.H2);
+      const int64_t total = wf16_floats(a.H1, a.H2) / 4;
+      const float* W = a.q + a.off_w2;
+      for (int64_t e = t0; e < total; e += gsz) {
+        const int lane = (int)(e & 63);
+        const int64_t tg = e >> 6;
+        const int g = (int)(tg % nkg), T = (int)(tg / nkg);
+        const int k = T * 16 + (lane & 15), n = g * 16 + 4 * (lane >> 4);
+        float4 v;
+        v.x = (k < a.H1 && n < a.H2) ? W[(int64_t)n * a.H1 + k] : 0.f;
+        v.y = (k < a.H1 && n + 1 < a.H2) ? W[(int64_t)(n + 1) * a.H1 + k] : 0.f;
+        v.z = (k < a.H1 && n + 2 < a.H2) ? W[(int64_t)(n + 2) * a.H1 + k] : 0.f;
+        v.w = (k < a.H1 && n + 3 < a.H2) ? W[(int64_t)(n + 3) * a.H1 + k] : 0.f;
+        reinterpret_cast<float4*>(a.pk.W2tf)[e] = v;
+      }
+    }
+  }
+  if (a.do_target) {
+    const int nkg = t_nkg(a.H1);
+    const int64_t total = w2f_floats(a.H2, a.H1) / 4;
+    const float* W = a.q_target + a.off_w2;
+    for (int64_t e = t0; e < total; e += gsz) {
+      const int lane = (int)(e & 63);
+      const int64_t tg = e >> 6;
+      const int g = (int)(tg % nkg), t = (int)(tg / nkg);
+      const int n = t * 32 + (lane & 31), k = g * 8 + 4 * (lane >> 5);
+      float4 v;
+      v.x = (n < a.H2 && k < a.H1) ? W[(int64_t)n * a.H1 + k] : 0.f;
+      v.y = (n < a.H2 && k + 1 < a.H1) ? W[(int64_t)n * a.H1 + k + 1] : 0.f;
+      v.z = (n < a.H2 && k + 2 < a.H1) ? W[(int64_t)n * a.H1 + k + 2] : 0.f;
+      v.w = (n < a.H2 && k + 3 < a.H1) ? W[(int64_t)n * a.H1 + k + 3] : 0.f;
+      reinterpret_cast<float4*>(a.pk.tW2f)[e] = v;
+    }
+  }
+}
+
+// ---- the row pass ---------------------------------------------------------------------------
+struct RowArgs {
+  const float* x; int ldx;              // [B][K1] state || rep(action)
+  const float* W1f; const float* b1;
+  const float* W2f; const float* b2;
+  const float* W2tf;
+  const float* w3; const float* b3;
+  const float* y;                       // [B] Bellman targets; null = forward only (probe)
+  float* H1a; float* H2a;               // [B][H1], [B][H2] relu outputs (weight-gradient operands)
+  float* dZ2; float* dZ1;               // [B][H2], [B][H1] pre-activation gradients
+  float* q_out; float* dq_out; float* absd_out;  // [B]; q_out may be null
+  float norm;                           // 2 / (B * world)
+  int B, K1, H1, H2;
+};
+
+constexpr int RP_ROWS = 16;
+__host__ __device__ inline int rp_pad(int K) { return ((K + 63) & ~63) + 4; }  // LDS row pitch
+inline size_t rowpass_smem_bytes(int K1, int H1, int H2) {
+  return sizeof(float) * ((size_t)RP_ROWS * (rp_pad(K1) + rp_pad(H1) + rp_pad(H2)) + 8 * 16);
+}
+
+// acc[t] += sum_k Wf[tile0 + t][k] * act[row][k]; act points at this lane's (row, 4 qd) in LDS.
+// nkg is rounded up to a multiple of 4 by the caller's LDS padding (zeros), weights beyond the
+// matrix are zero through the out-of-range buffer load.
+template <int PD>
+__device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __restrict__ Wf, int nkg,
+                                            int tile0, int ntiles, const float* act, int lane) {
+  const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
+  const int64_t base0 = ((int64_t)tile0 * nkg) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)nkg * 256;
+  float4 r0[PD], r1[PD];
+#pragma unroll
+  for (int p = 0; p < PD; ++p) {
+    r0[p] = ld4_or_zero(Wf, base0 + (int64_t)p * 256, ok0 && p < nkg);
+    r1[p] = ld4_or_zero(Wf, base1 + (int64_t)p * 256, ok1 && p < nkg);
+  }
+  const int nkgp = (nkg + PD - 1) / PD * PD;
+  for (int g0 = 0; g0 < nkgp; g0 += PD) {
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int g = g0 + p;
+      const float4 w0 = r0[p], w1 = r1[p];
+      r0[p] = ld4_or_zero(Wf, base0 + (int64_t)(g + PD) * 256, ok0 && (g + PD) < nkg);
+      r1[p] = ld4_or_zero(Wf, base1 + (int64_t)(g + PD) * 256, ok1 && (g + PD) < nkg);
+      const float4 x4 = *reinterpret_cast<const float4*>(act + g * 16);
+      acc[0] = mfma16(w0.x, x4.x, acc[0]);
+      acc[1] = mfma16(w1.x, x4.x, acc[1]);
+      acc[0] = mfma16(w0.y, x4.y, acc[0]);
+      acc[1] = mfma16(w1.y, x4.y, acc[1]);
+      acc[0] = mfma16(w0.z, x4.z, acc[0]);
+      acc[1] = mfma16(w1.z, x4.z, acc[1]);
+      acc[0] = mfma16(w0.w, x4.w, acc[0]);
+      acc[1] = mfma16(w1.w, x4.w, acc[1]);
+    }
+  }
+}
+
+__device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t row_off, int col,
+                                               int ncols, bool vec_ok, const float4& v) {
+  if (vec_ok && col + 3 < ncols) {
+    *reinterpret_cast<float4*>(base + row_off + col) = v;
+  } else {
+    if (col < ncols) base[row_off + col] = v.x;
+    if (col + 1 < ncols) base[row_off + col + 1] = v.y;
+    if (col + 2 < ncols) base[row_off + col + 2] = v.z;
+    if (col + 3 < ncols) base[row_off + col + 3] = v.w;
+  }
+}
+
+__global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int P1 = rp_pad(a.K1), PH1 = rp_pad(a.H1), PH2 = rp_pad(a.H2);
+  float* xs = smem;                          // [16][P1]
+  float* h1s = xs + RP_ROWS * P1;            // [16][PH1]
+  float* d2s = h1s + RP_ROWS * PH1;          // [16][PH2]
+  float* qpart = d2s + RP_ROWS * PH2;        // [8][16]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, qd = lane >> 4;
+  const int m0 = blockIdx.x * RP_ROWS;
+  const int row = m0 + r16;
+  const bool rok = row < a.B;
+  const int u0 = wave * 32 + 4 * qd;         // this lane's units: u0 + 16 t + reg, t in {0,1}
+  const int tile0 = wave * 2;
+  const int nt1 = (a.H1 + 15) >> 4, nt2 = (a.H2 + 15) >> 4;
+
+  // ---- stage the x tile (zero padded to the LDS pitch; the k loops run over whole groups)
+  {
+    const bool vx = is_vec_ok(a.x, a.ldx) && ((a.K1 & 3) == 0);
+    const int c4 = (P1 - 4) >> 2;  // float4 slots per row
+    for (int e = tid; e < RP_ROWS * c4; e += 512) {
+      const int r = e / c4, c = (e - r * c4) * 4;
+      const bool ok = (m0 + r) < a.B;
+      float4 v;
+      if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < a.K1);
+      else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, a.K1);
+      *reinterpret_cast<float4*>(xs + r * P1 + c) = v;
+    }
+  }
+  const bool v1 = ((a.H1 & 3) == 0), v2 = ((a.H2 & 3) == 0);
+  f32x4v acc[2];
+  // ---- layer 1: h1 = relu(W1 x + b1)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
+    acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+  }
+  __syncthreads();
+  rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
+  float4 h1k[2];  // kept for the ReLU mask of dZ1
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int u = u0 + 16 * t;
+    h1k[t] = make_float4(relu_keep_nan(acc[t][0]), relu_keep_nan(acc[t][1]),
+                         relu_keep_nan(acc[t][2]), relu_keep_nan(acc[t][3]));
+    if (u < PH1 - 4) *reinterpret_cast<float4*>(h1s + r16 * PH1 + u) = h1k[t];
+    if (rok && a.H1a) store4_guarded(a.H1a, (int64_t)row * a.H1, u, a.H1, v1, h1k[t]);
+  }
+  // ---- layer 2: h2 = relu(W2 h1 + b2)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 b = guarded_load4(a.b2, 0, true, u0 + 16 * t, a.H2);
+    acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+  }
+  float4 w3v[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) w3v[t] = guarded_load4(a.w3, 0, true, u0 + 16 * t, a.H2);
+  __syncthreads();
+  rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
+  float4 h2k[2];
+  float part = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    h2k[t] = make_float4(relu_keep_nan(acc[t][0]), relu_keep_nan(acc[t][1]),
+                         relu_keep_nan(acc[t][2]), relu_keep_nan(acc[t][3]));
+    part = fmaf(h2k[t].x, w3v[t].x, part);
+    part = fmaf(h2k[t].y, w3v[t].y, part);
+    part = fmaf(h2k[t].z, w3v[t].z, part);
+    part = fmaf(h2k[t].w, w3v[t].w, part);
+    if (rok && a.H2a) store4_guarded(a.H2a, (int64_t)row * a.H2, u0 + 16 * t, a.H2, v2, h2k[t]);
+  }
+  // ---- head: q = w3 . h2 + b3 (lane quarters, then waves, fixed order)
+  part += __shfl_xor(part, 16);
+  part += __shfl_xor(part, 32);
+  if (qd == 0) qpart[wave * 16 + r16] = part;
+  __syncthreads();
+  float q = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
+  q += a.b3[0];
+  if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
+  if (!a.y) return;
+  // ---- loss and dZ2 = [h2 > 0] * dq * w3
+  const float yv = rok ? a.y[row] : q;
+  const float d = __fsub_rn(q, yv);
+  const float dq = __fmul_rn(a.norm, d);
+  if (wave == 0 && qd == 0 && rok) {
+    a.dq_out[row] = dq;
+    a.absd_out[row] = fabsf(d);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int u = u0 + 16 * t;
+    float4 z;
+    z.x = (h2k[t].x > 0.f) ? __fmul_rn(dq, w3v[t].x) : 0.f;
+    z.y = (h2k[t].y > 0.f) ? __fmul_rn(dq, w3v[t].y) : 0.f;
+    z.z = (h2k[t].z > 0.f) ? __fmul_rn(dq, w3v[t].z) : 0.f;
+    z.w = (h2k[t].w > 0.f) ? __fmul_rn(dq, w3v[t].w) : 0.f;
+    if (!rok) z = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (u < PH2 - 4) *reinterpret_cast<float4*>(d2s + r16 * PH2 + u) = z;
+    if (rok) store4_guarded(a.dZ2, (int64_t)row * a.H2, u, a.H2, v2, z);
+  }
+  __syncthreads();
+  // ---- dZ1 = (dZ2 W2) * [h1 > 0]
+#pragma unroll
+  for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+  rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+  if (rok) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float4 z;
+      z.x = (h1k[t].x > 0.f) ? acc[t][0] : 0.f;
+      z.y = (h1k[t].y > 0.f) ? acc[t][1] : 0.f;
+      z.z = (h1k[t].z > 0.f) ? acc[t][2] : 0.f;
+      z.w = (h1k[t].w > 0.f) ? acc[t][3] : 0.f;
+      store4_guarded(a.dZ1, (int64_t)row * a.H1, u0 + 16 * t, a.H1, v1, z);
+    }
+  }
+}
+
+}  // namespace pa
