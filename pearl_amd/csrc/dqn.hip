@@ -9,6 +9,7 @@
 //   DeepTDLearning.forward / loss  deep_td_learning.py:269-331
 //   DeepQLearning.get_next_state_values  deep_q_learning.py:130-167
 #include <math.h>
+#include <stdlib.h>
 
 #include <deque>
 #include <new>
@@ -283,13 +284,7 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, float* q_out, 
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
   ScopedTimer tm(h, "rowpass", s);
-  static size_t configured = 0;
   const size_t smem = rowpass_smem_bytes(h->IN, d.hidden1, d.hidden2);
-  if (smem > configured) {
-    int rc = set_max_smem(online_rowpass_kernel, smem);
-    if (rc != PA_OK) return rc;
-    configured = smem;
-  }
   RowArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.ldx = h->IN;
@@ -303,8 +298,24 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, float* q_out, 
   a.q_out = q_out; a.dq_out = h->dq; a.absd_out = h->absd;
   a.norm = (float)(2.0 / ((double)B * (double)world));
   a.B = B; a.K1 = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
-  hipLaunchKernelGGL(online_rowpass_kernel, dim3((unsigned)ceil_div(B, RP_ROWS)), dim3(512), smem,
-                     s, a);
+  const dim3 grid((unsigned)ceil_div(B, RP_ROWS));
+  const int g1 = wf16_nkg(h->IN), g2 = wf16_nkg(d.hidden1), g3 = wf16_nkg(d.hidden2);
+  // fully unrolled instantiations for the shapes that matter; anything else takes the run-time loops
+#define PA_ROWPASS(N1, N2, N3)                                                               \
+  do {                                                                                       \
+    static size_t configured = 0;                                                            \
+    if (smem > configured) {                                                                 \
+      int rc = set_max_smem(online_rowpass_kernel<N1, N2, N3>, smem);                        \
+      if (rc != PA_OK) return rc;                                                            \
+      configured = smem;                                                                     \
+    }                                                                                        \
+    hipLaunchKernelGGL((online_rowpass_kernel<N1, N2, N3>), grid, dim3(512), smem, s, a);    \
+  } while (0)
+  if (g2 == 16 && g3 == 16 && g1 == 9) PA_ROWPASS(9, 16, 16);
+  else if (g2 == 16 && g3 == 16) PA_ROWPASS(0, 16, 16);
+  else if (g2 == 4 && g3 == 4 && g1 == 1) PA_ROWPASS(1, 4, 4);
+  else PA_ROWPASS(0, 0, 0);
+#undef PA_ROWPASS
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -192,6 +192,57 @@ __device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __res
   }
 }
 
+// Compile-time k-group count: the whole k loop is unrolled, the weight fragments go through a
+// PD-deep register ring with static indices (a rolled loop makes hipcc rotate the ring with
+// v_mov behind s_waitcnt vmcnt(0), which exposes one memory latency per iteration), and the ring
+// of the NEXT layer is filled before the current layer's epilogue and barrier.
+constexpr int RP_PD = 8;
+struct WRing {
+  float4 r0[RP_PD], r1[RP_PD];
+};
+template <int NKG>
+__device__ __forceinline__ void ring_fill(WRing& R, const float* __restrict__ Wf, int tile0,
+                                          int ntiles, int lane) {
+  const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
+  const int64_t base0 = ((int64_t)tile0 * NKG) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)NKG * 256;
+#pragma unroll
+  for (int p = 0; p < RP_PD; ++p) {
+    if (p < NKG) {
+      R.r0[p] = ld4_or_zero(Wf, base0 + (int64_t)p * 256, ok0);
+      R.r1[p] = ld4_or_zero(Wf, base1 + (int64_t)p * 256, ok1);
+    }
+  }
+}
+template <int NKG>
+__device__ __forceinline__ void rows16_gemm_static(f32x4v (&acc)[2], WRing& R,
+                                                   const float* __restrict__ Wf, int tile0,
+                                                   int ntiles, const float* act, int lane) {
+  const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
+  const int64_t base0 = ((int64_t)tile0 * NKG) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)NKG * 256;
+#pragma unroll
+  for (int g = 0; g < NKG; ++g) {
+    const float4 w0 = R.r0[g % RP_PD], w1 = R.r1[g % RP_PD];
+    if (g + RP_PD < NKG) {
+      R.r0[g % RP_PD] = ld4_or_zero(Wf, base0 + (int64_t)(g + RP_PD) * 256, ok0);
+      R.r1[g % RP_PD] = ld4_or_zero(Wf, base1 + (int64_t)(g + RP_PD) * 256, ok1);
+    }
+    // keep the refill where it is: hipcc's scheduler otherwise sinks it next to its use (8 groups
+    // later) to shorten the live range, which turns the prefetch into an exposed latency
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 x4 = *reinterpret_cast<const float4*>(act + g * 16);
+    acc[0] = mfma16(w0.x, x4.x, acc[0]);
+    acc[1] = mfma16(w1.x, x4.x, acc[1]);
+    acc[0] = mfma16(w0.y, x4.y, acc[0]);
+    acc[1] = mfma16(w1.y, x4.y, acc[1]);
+    acc[0] = mfma16(w0.z, x4.z, acc[0]);
+    acc[1] = mfma16(w1.z, x4.z, acc[1]);
+    acc[0] = mfma16(w0.w, x4.w, acc[0]);
+    acc[1] = mfma16(w1.w, x4.w, acc[1]);
+  }
+}
+
 __device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t row_off, int col,
                                                int ncols, bool vec_ok, const float4& v) {
   if (vec_ok && col + 3 < ncols) {
@@ -204,6 +255,9 @@ __device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t
   }
 }
 
+// NG1/NG2/NG3: k-groups of layer 1 (K1), layer 2 (H1) and dX (H2) when known at compile time
+// (0 = run-time loop, any shape).
+template <int NG1, int NG2, int NG3>
 __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P1 = rp_pad(a.K1), PH1 = rp_pad(a.H1), PH2 = rp_pad(a.H2);
@@ -236,6 +290,8 @@ __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   }
   const bool v1 = ((a.H1 & 3) == 0), v2 = ((a.H2 & 3) == 0);
   f32x4v acc[2];
+  WRing R1;
+  if constexpr (NG1 > 0) ring_fill<NG1>(R1, a.W1f, tile0, nt1, lane);  // independent of x
   // ---- layer 1: h1 = relu(W1 x + b1)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -243,7 +299,13 @@ __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
   }
   __syncthreads();
-  rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
+  WRing R2;
+  if constexpr (NG1 > 0) {
+    rows16_gemm_static<NG1>(acc, R1, a.W1f, tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
+  } else {
+    rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
+  }
+  if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
   float4 h1k[2];  // kept for the ReLU mask of dZ1
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -263,7 +325,15 @@ __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) w3v[t] = guarded_load4(a.w3, 0, true, u0 + 16 * t, a.H2);
   __syncthreads();
-  rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
+  WRing R3;
+  if constexpr (NG2 > 0) {
+    rows16_gemm_static<NG2>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
+  } else {
+    rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
+  }
+  if constexpr (NG3 > 0) {
+    if (a.y) ring_fill<NG3>(R3, a.W2tf, tile0, nt1, lane);
+  }
   float4 h2k[2];
   float part = 0.f;
 #pragma unroll
@@ -311,7 +381,11 @@ __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   // ---- dZ1 = (dZ2 W2) * [h1 > 0]
 #pragma unroll
   for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-  rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+  if constexpr (NG3 > 0) {
+    rows16_gemm_static<NG3>(acc, R3, a.W2tf, tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+  } else {
+    rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+  }
   if (rok) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
