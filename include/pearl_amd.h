@@ -166,6 +166,11 @@ int pa_arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B,
 int pa_sample_indices(int64_t population, uint64_t seed, uint64_t offset, int32_t B,
                       int64_t* idx_out_dev, int32_t device, void* stream);
 
+/* out[b] = src[idx[b]] for rows of row_bytes bytes: per-transition columns kept beside the arena in
+ * logical order (PPOTransition's gae / lam_return / action_probs, ppo.py:47-82). */
+int pa_gather_rows(const void* src_dev, int32_t row_bytes, const int64_t* idx_dev, int32_t B,
+                   void* out_dev, void* stream);
+
 /* OneHotActionTensorRepresentationModule.forward
  * (one_hot_action_representation_module.py:27-34): idx[n] -> out[n, num_classes]. */
 int pa_one_hot(const void* idx_dev, int32_t idx_dtype, int64_t n, int32_t num_classes,
@@ -283,11 +288,101 @@ int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* coun
 int pa_dqn_get_timing_units(pa_dqn* h, const char* name, int64_t* units);
 
 /* ------------------------------------------------------------------------ */
+/* Generic fully-connected network: mlp_block(Linear+ReLU ..., Linear)       */
+/* (pearl/neural_networks/common/utils.py:75-152) over flat caller-owned     */
+/* fp32 buffers, W_l[d_{l+1}, d_l] | b_l[d_{l+1}] per layer, every tensor     */
+/* offset rounded up to 4 floats.  Used by VanillaValueNetwork               */
+/* (common/value_networks.py:35-59), VanillaActorNetwork / GaussianActor-    */
+/* Network (actor_networks.py:107-176, :488-629; fc_mu and fc_std are ONE    */
+/* last layer of 2A rows) and the VanillaQValueNetwork critics of TwinCritic */
+/* (twin_critic.py:22-91).                                                   */
+/* ------------------------------------------------------------------------ */
+typedef struct pa_mlp pa_mlp;
+#define PA_MLP_MAX_LAYERS 8
+typedef struct pa_mlp_desc {
+  int32_t device;
+  int32_t n_layers;                      /* Linear layers                                 */
+  int32_t dims[PA_MLP_MAX_LAYERS + 1];   /* d_0 (input) ... d_L (output)                   */
+  int32_t max_batch;
+  double lr, beta1, beta2, eps, weight_decay; /* optim.AdamW (actor_critic_base.py:159-167) */
+  int32_t amsgrad;
+} pa_mlp_desc;
+typedef struct pa_mlp_buffers {
+  float* p;
+  float* p_target;       /* NULL if the network has no target copy */
+  float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* max_exp_avg_sq;
+} pa_mlp_buffers;
+int64_t pa_mlp_param_count(const pa_mlp_desc* d);
+/* offsets[2 * n_layers]: W_0, b_0, W_1, b_1, ... */
+int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets);
+int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc);
+int pa_mlp_destroy(pa_mlp* h);
+int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* bufs);
+/* nn.Sequential forward; keep = 1 retains the hidden activations for pa_mlp_backward. */
+int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int32_t ldx, int32_t B,
+                   float* out, int32_t ldo, int32_t keep, void* stream);
+/* autograd of the kept forward: dW/db into bufs.grad (want_dw) and/or d_x[B, d_0] (nullable). */
+int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
+                    int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx, void* stream);
+int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream);
+/* update_target_network (common/utils.py:214-226) */
+int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);
+
+/* VanillaActorNetwork.get_action_prob (actor_networks.py:155-176): softmax(logits) . action_rep.
+ * probs_out [B, A] may be NULL. */
+int pa_softmax_action_prob(const float* logits, int32_t ldl, const float* action_rep, int32_t lda,
+                           int32_t B, int32_t A, float* probs_out, float* action_prob_out,
+                           void* stream);
+/* ProximalPolicyOptimization._actor_loss (ppo.py:152-183) and its gradient w.r.t. the logits:
+ * -sum min(r g, clamp(r, 1-eps, 1+eps) g) - entropy_scale * H(Categorical(p_batch)). */
+int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* action_rep, int32_t lda,
+                      const float* p_old, const float* gae, int32_t B, int32_t A, float epsilon,
+                      float entropy_scale, float* d_logits, int32_t ldd, float* loss_out,
+                      void* stream);
+/* nn.MSELoss head (critic_utils.py:139-203): d_pred = grad_scale * (pred - target);
+ * loss_out (=|+=) mean((pred - target)^2) * loss_scale. */
+int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B, float grad_scale,
+                float loss_scale, int32_t accumulate, float* d_pred, float* loss_out, void* stream);
+/* preprocess_replay_buffer's GAE / lambda-return recurrence (ppo.py:271-293), logical order
+ * (index 0 = oldest transition); parallel over episodes, sequential fp32 inside one. */
+int pa_ppo_gae(const float* reward, const uint8_t* terminated, const uint8_t* truncated,
+               const float* values, const float* next_value_last, float gamma, float lam, int64_t N,
+               float* gae_out, float* lam_return_out, void* stream);
+/* GaussianActorNetwork.sample_action(get_log_prob=True) (actor_networks.py:551-591) from the
+ * network head [B, 2A] = mean | raw log_std and caller-supplied standard-normal noise [B, A]. */
+int pa_gauss_sample(const float* head, int32_t ldh, const float* noise, int32_t ldn,
+                    const float* low, const float* high, int32_t B, int32_t A, float* action,
+                    int32_t lda, float* log_prob, void* stream);
+/* d/d head of mean(alpha * log_prob - q) given dL/d action through the critic(s). */
+int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* noise, int32_t ldn,
+                        const float* low, const float* high, const float* dl_daction,
+                        const float* dl_daction2, int32_t ldda, const float* alpha, int32_t B,
+                        int32_t A, float* d_head, int32_t lddh, void* stream);
+/* ContinuousSoftActorCritic twin-critic plumbing (soft_actor_critic_continuous.py:155-231).
+ * mode 0: loss_out = mean(alpha*log_prob - min(q1,q2)); out1/out2 = dL/dq1, dL/dq2.
+ * mode 1: out1 = (min(q1,q2) - alpha*log_prob) * gamma * (1 - terminated) + reward. */
+int pa_sac_twin(int32_t mode, const float* q1, const float* q2, const float* log_prob,
+                const float* alpha, const float* reward, const uint8_t* terminated, float gamma,
+                int32_t B, float* out1, float* out2, float* loss_out, void* stream);
+/* entropy autotune (soft_actor_critic_continuous.py:134-151): AdamW step `step` on the scalar
+ * log_alpha with gradient mean(-exp(log_alpha) * (log_prob + target_entropy)); alpha_out = exp. */
+int pa_sac_alpha_step(float* log_alpha, float* exp_avg, float* exp_avg_sq, float* max_exp_avg_sq,
+                      float* alpha_out, const float* log_prob, int32_t B, float target_entropy,
+                      double lr, double beta1, double beta2, double eps, double weight_decay,
+                      int32_t amsgrad, int64_t step, float* loss_out, void* stream);
+/* out[B, nl + nr] = left[B, nl] || right[B, nr]   (q_value_networks.py:166-168 torch.cat) */
+int pa_concat_cols(const float* left, int32_t ldl, const float* right, int32_t ldr, float* out,
+                   int32_t B, int32_t nl, int32_t nr, void* stream);
+
+/* ------------------------------------------------------------------------ */
 /* Diagnostics: single-kernel entry points so the GPU test-suite can localise */
 /* a parity failure to one kernel (no reference counterpart).                 */
 /* ------------------------------------------------------------------------ */
 /* C[M,N] = epi(A[M,K] * op(B)).  b_is_kn = 0: B is [N,K] (y = x W^T); 1: B is [K,N].
- * epi: 0 = +bias, 1 = relu(+bias), 2 = * (hmask > 0). */
+ * epi: 0 = +bias, 1 = relu(+bias), 2 = * (hmask > 0), 3 = none. */
 int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
                     int32_t ldc, const float* bias, const float* hmask, int32_t ldh, int32_t M,
                     int32_t N, int32_t K, int32_t b_is_kn, int32_t epi, void* stream);

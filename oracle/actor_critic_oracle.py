@@ -1,0 +1,190 @@
+"""CPU restatement of the reference's actor-critic learner paths (PPO, continuous SAC).
+
+TEST INFRASTRUCTURE ONLY — the checker, never the product.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this file; pearl_amd/ must not (and does not).
+
+Plain PyTorch fp32 on the CPU; forward formulas are written out, gradients come from torch
+autograd and the optimizer is ``torch.optim.AdamW(amsgrad=True)`` itself — that IS the reference's
+arithmetic (ATen), there is nothing lower to restate.  What each piece follows (file:line under
+/root/reference):
+
+  mlp                       pearl/neural_networks/common/utils.py:75-152 (Linear+ReLU ..., Linear)
+  PpoOracle.action_probs    neural_networks/sequential_decision_making/actor_networks.py:155-176
+  PpoOracle.preprocess      policy_learners/sequential_decision_making/ppo.py:201-293 (GAE, lambda return)
+  PpoOracle.actor_loss      ppo.py:152-183     PpoOracle.critic_loss  ppo.py:185-192 + critic_utils.py:139-167
+  PpoOracle.learn           ppo.py:194-199 + policy_learner.py:162-195 + actor_critic_base.py:309-366
+  SacOracle.sample_action   actor_networks.py:537-591
+  SacOracle.actor_loss      soft_actor_critic_continuous.py:208-231
+  SacOracle.critic_loss     :155-206 + critic_utils.py:170-203
+  SacOracle.learn_batch     actor_critic_base.py:309-366 + soft_actor_critic_continuous.py:131-153
+
+Parity is PINNED: tests/test_oracle_ac_golden.py checks these against fixtures minted by running
+the real reference (oracle/make_golden_ac.py -> tests/golden/ppo_*.pt, sac_*.pt).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+F32 = torch.float32
+
+
+def _layers(sd: Dict[str, Tensor], prefix: str = "_model.") -> List[Tuple[Tensor, Tensor]]:
+    """(weight, bias) leaf tensors of an mlp_block state dict, in layer order."""
+    out, i = [], 0
+    while f"{prefix}{i}.0.weight" in sd:
+        out.append((sd[f"{prefix}{i}.0.weight"].clone().requires_grad_(True),
+                    sd[f"{prefix}{i}.0.bias"].clone().requires_grad_(True)))
+        i += 1
+    return out
+
+
+def mlp(layers: Sequence[Tuple[Tensor, Tensor]], x: Tensor, last_relu: bool = False) -> Tensor:
+    for i, (w, b) in enumerate(layers):
+        x = torch.nn.functional.linear(x, w, b)
+        if i + 1 < len(layers) or last_relu:
+            x = torch.relu(x)
+    return x
+
+
+def _adamw(params: List[Tensor], lr: float) -> torch.optim.Optimizer:
+    return torch.optim.AdamW([{"params": params, "lr": lr, "amsgrad": True}])
+
+
+def _flat(layers) -> List[Tensor]:
+    return [t for wb in layers for t in wb]
+
+
+# --------------------------------------------------------------------------------------
+# PPO
+# --------------------------------------------------------------------------------------
+class PpoOracle:
+    def __init__(self, actor_sd, critic_sd, A: int, gamma: float = 0.99, lam: float = 0.95,
+                 epsilon: float = 0.0, entropy_scale: float = 0.01, lr: float = 1e-4) -> None:
+        self.actor, self.critic = _layers(actor_sd), _layers(critic_sd)
+        self.A, self.gamma, self.lam, self.eps, self.ent = A, gamma, lam, epsilon, entropy_scale
+        self.opt_a, self.opt_c = _adamw(_flat(self.actor), lr), _adamw(_flat(self.critic), lr)
+
+    def action_probs(self, state: Tensor, onehot: Tensor) -> Tensor:
+        probs = torch.softmax(mlp(self.actor, state), dim=-1)
+        return torch.sum(probs * onehot, dim=1, keepdim=True).view(-1)
+
+    @torch.no_grad()
+    def preprocess(self, states: Tensor, onehot: Tensor, reward: Tensor, term: Tensor,
+                   trunc: Tensor, last_next_state: Tensor):
+        """Logical order in (index 0 = oldest), logical order out."""
+        n = states.shape[0]
+        values = mlp(self.critic, states).view(-1)
+        aprob = self.action_probs(states, onehot)
+        next_value = mlp(self.critic, last_next_state.view(1, -1)).view(-1)[0]
+        gae = torch.tensor(0.0)
+        out_g, out_r = torch.empty(n), torch.empty(n)
+        for i in range(n - 1, -1, -1):
+            td = reward[i] + self.gamma * next_value * (~term[i]) - values[i]
+            gae = td + self.gamma * self.lam * (not (bool(term[i]) or bool(trunc[i]))) * gae
+            out_g[i], out_r[i] = gae, gae + values[i]
+            next_value = values[i]
+        return out_g, out_r, aprob
+
+    def actor_loss(self, state, onehot, p_old, gae) -> Tensor:
+        p = self.action_probs(state, onehot)
+        r = torch.div(p, p_old)
+        clip = torch.clamp(r, min=1.0 - self.eps, max=1.0 + self.eps)
+        loss = torch.sum(-torch.min(r * gae, clip * gae))
+        entropy = torch.distributions.Categorical(p.detach()).entropy()
+        return loss - torch.sum(self.ent * entropy)
+
+    def critic_loss(self, state, lam_return) -> Tensor:
+        vs = mlp(self.critic, state)
+        return torch.nn.MSELoss()(vs.reshape_as(lam_return), lam_return.detach())
+
+    def learn_batch(self, state, onehot, p_old, gae, lam_return) -> Tuple[float, float]:
+        la = self.actor_loss(state, onehot, p_old, gae)
+        self.opt_a.zero_grad()
+        la.backward()
+        self.opt_a.step()
+        self.opt_c.zero_grad()
+        lc = self.critic_loss(state, lam_return)
+        lc.backward()
+        self.opt_c.step()
+        return la.item(), lc.item()
+
+
+# --------------------------------------------------------------------------------------
+# continuous SAC
+# --------------------------------------------------------------------------------------
+class SacOracle:
+    def __init__(self, actor_sd, critic_sd, critic_target_sd, low: Tensor, high: Tensor,
+                 gamma: float = 0.99, tau: float = 0.005, lr: float = 1e-3) -> None:
+        self.trunk = _layers(actor_sd)
+        self.head = [actor_sd[k].clone().requires_grad_(True) for k in
+                     ("fc_mu.weight", "fc_mu.bias", "fc_std.weight", "fc_std.bias")]
+        self.c = [_layers(critic_sd, f"_critic_{i}._model.") for i in (1, 2)]
+        self.ct = [[(w.detach().clone(), b.detach().clone()) for w, b in
+                    _layers(critic_target_sd, f"_critic_{i}._model.")] for i in (1, 2)]
+        self.low, self.high = low, high
+        self.bound = (high - low) / 2
+        self.gamma, self.tau = gamma, tau
+        self.log_alpha = torch.zeros(1, requires_grad=True)
+        self.alpha = torch.exp(self.log_alpha).detach()
+        self.target_entropy = -torch.tensor(low.shape[0])
+        self.opt_a = _adamw(_flat(self.trunk) + self.head, lr)
+        self.opt_c = _adamw(_flat(self.c[0]) + _flat(self.c[1]), lr)
+        self.opt_e = torch.optim.AdamW([self.log_alpha], lr=lr, amsgrad=True)
+
+    def sample_action(self, state: Tensor, noise: Tensor) -> Tuple[Tensor, Tensor]:
+        x = mlp(self.trunk, state, last_relu=True)
+        mean = torch.nn.functional.linear(x, self.head[0], self.head[1])
+        log_std = torch.tanh(torch.nn.functional.linear(x, self.head[2], self.head[3]))
+        log_std = -5 + 0.5 * (2 - (-5)) * (log_std + 1)
+        std = log_std.exp()
+        sample = mean + noise * std                                   # Normal.rsample
+        n = torch.tanh(sample)
+        action = (((self.high - self.low) * (n + 1.0)) / 2) + self.low
+        var = std ** 2
+        log_prob = -((sample - mean) ** 2) / (2 * var) - std.log() - math.log(math.sqrt(2 * math.pi))
+        log_prob = log_prob - torch.log(self.bound * (1 - n.pow(2)) + 1e-6)
+        return action, log_prob.sum(dim=1, keepdim=True)
+
+    @staticmethod
+    def q(layers, state, action) -> Tensor:
+        return mlp(layers, torch.cat([state, action], dim=-1)).view(-1)
+
+    def learn_batch(self, batch: Dict[str, Tensor], noise_actor: Tensor, noise_critic: Tensor
+                    ) -> Dict[str, float]:
+        s, a, r, term, ns = (batch[k] for k in ("state", "action", "reward", "terminated", "next_state"))
+        # ---- actor (:208-231)
+        act, logp = self.sample_action(s, noise_actor)
+        qmin = torch.minimum(self.q(self.c[0], s, act), self.q(self.c[1], s, act)).unsqueeze(-1)
+        actor_loss = (self.alpha * logp - qmin).mean()
+        self.opt_a.zero_grad()
+        actor_loss.backward()
+        self.opt_a.step()
+        # ---- critic (:155-206)
+        self.opt_c.zero_grad()
+        with torch.no_grad():
+            nact, nlogp = self.sample_action(ns, noise_critic)
+            nq = torch.minimum(self.q(self.ct[0], ns, nact), self.q(self.ct[1], ns, nact)).unsqueeze(-1)
+            nv = (nq - self.alpha * nlogp).view(-1)
+            y = (nv * self.gamma * (1 - term.float())) + r
+        mse = torch.nn.MSELoss()
+        critic_loss = (mse(self.q(self.c[0], s, a), y) + mse(self.q(self.c[1], s, a), y)) / 2.0
+        critic_loss.backward()
+        self.opt_c.step()
+        # ---- targets (critic_utils.py:103-136)
+        with torch.no_grad():
+            for net, tgt in zip(self.c, self.ct):
+                for (w, b), (tw, tb) in zip(net, tgt):
+                    tw.copy_(self.tau * w + (1.0 - self.tau) * tw)
+                    tb.copy_(self.tau * b + (1.0 - self.tau) * tb)
+        # ---- entropy autotune (:134-151)
+        ent_loss = (-torch.exp(self.log_alpha) * (logp + self.target_entropy).detach()).mean()
+        self.opt_e.zero_grad()
+        ent_loss.backward()
+        self.opt_e.step()
+        self.alpha = torch.exp(self.log_alpha).detach()
+        return {"actor_loss": actor_loss.item(), "critic_loss": critic_loss.item(),
+                "entropy_coef": ent_loss.item()}

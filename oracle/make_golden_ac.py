@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Golden vectors for the actor-critic rows of SURVEY.md §8 (a13-a15): runs the REAL reference
+(/root/reference, CPU) for PPO and continuous SAC on seeded synthetic data and writes
+tests/golden/ppo_*.pt and tests/golden/sac_*.pt.
+
+TEST INFRASTRUCTURE ONLY (build container; the reference does not travel to the GPU box):
+
+    python oracle/make_golden_ac.py
+
+PPO fixture  (ppo.py:152-293): the rollout, the initial actor / critic parameters, what
+  preprocess_replay_buffer attaches to every transition (gae, lam_return, action_probs), the
+  index lists learn() drew, the per-round reported losses and the final parameters.
+SAC fixture  (soft_actor_critic_continuous.py:131-231): one fixed batch, the reparameterisation
+  noise of every step (the reference draws it from torch's global generator; it is replayed here
+  with the same seed), first-step intermediates (sampled action, log-prob, q1/q2, Bellman
+  target) and the parameters / entropy coefficient after K learn_batch calls.
+"""
+import os
+import random
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("PEARL_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "gymstub"))
+sys.path.insert(0, REF)
+
+import torch  # noqa: E402
+
+from pearl.action_representation_modules.one_hot_action_representation_module import (  # noqa: E402
+    OneHotActionTensorRepresentationModule,
+)
+from pearl.policy_learners.sequential_decision_making.ppo import (  # noqa: E402
+    PPOReplayBuffer,
+    ProximalPolicyOptimization,
+)
+from pearl.policy_learners.sequential_decision_making.soft_actor_critic_continuous import (  # noqa: E402
+    ContinuousSoftActorCritic,
+)
+from pearl.pearl_agent import PearlAgent  # noqa: E402
+from pearl.replay_buffers import BasicReplayBuffer  # noqa: E402
+from pearl.replay_buffers.transition import TransitionBatch  # noqa: E402
+from pearl.utils.instantiations.spaces.box_action import BoxActionSpace  # noqa: E402
+from pearl.utils.instantiations.spaces.discrete_action import DiscreteActionSpace  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+PPO_CONFIGS = {
+    "tiny": dict(S=5, A=3, hidden=[16, 12], N=37, B=8, rounds=6, epsilon=0.1),
+    "eps0": dict(S=6, A=4, hidden=[24, 24], N=64, B=64, rounds=4, epsilon=0.0),
+    "cfg4_shape_small": dict(S=256, A=16, hidden=[256, 256], N=400, B=128, rounds=5, epsilon=0.1),
+}
+SAC_CONFIGS = {
+    "tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=5),
+    "cfg3_shape_small": dict(S=64, A=8, hidden=[256, 256], B=128, steps=4),
+}
+
+
+def clone_sd(module):
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def space(n):
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+def make_ppo(name, cfg):
+    S, A, N, B = cfg["S"], cfg["A"], cfg["N"], cfg["B"]
+    gen = torch.Generator().manual_seed(4321)
+    states = torch.randn(N + 1, S, generator=gen)
+    actions = torch.randint(0, A, (N,), generator=gen)
+    rewards = torch.randn(N, generator=gen)
+    term = torch.tensor([(i % 17 == 16) for i in range(N)])
+    trunc = torch.tensor([(i % 23 == 11) for i in range(N)])
+    torch.manual_seed(5)
+    pl = ProximalPolicyOptimization(
+        action_space=space(A), state_dim=S, actor_hidden_dims=cfg["hidden"],
+        critic_hidden_dims=cfg["hidden"], training_rounds=cfg["rounds"], batch_size=B,
+        epsilon=cfg["epsilon"], action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = PPOReplayBuffer(N + 5)
+    PearlAgent(policy_learner=pl, replay_buffer=rb)   # wires safety / history modules, CPU
+    for i in range(N):
+        rb.push(state=states[i], action=torch.tensor([int(actions[i])]), reward=float(rewards[i]),
+                terminated=bool(term[i]), truncated=bool(trunc[i]),
+                curr_available_actions=space(A), next_state=states[i + 1],
+                next_available_actions=space(A), max_number_actions=A)
+    fx = {"config": dict(cfg), "states": states, "actions": actions, "rewards": rewards,
+          "terminated": term, "truncated": trunc,
+          "actor0": clone_sd(pl._actor), "critic0": clone_sd(pl._critic)}
+    # what preprocess_replay_buffer attaches
+    pl.preprocess_replay_buffer(rb)
+    fx["gae"] = torch.cat([t.gae for t in rb.memory]).detach().clone()
+    fx["lam_return"] = torch.cat([t.lam_return for t in rb.memory]).detach().clone()
+    fx["action_probs"] = torch.cat([t.action_probs for t in rb.memory]).detach().clone()
+    # learn(): preprocess again (same parameters -> same values) + rounds
+    random.seed(31)
+    fx["learn_seed"] = 31
+    fx["learn_idx"] = torch.tensor([random.sample(range(len(rb)), B) for _ in range(cfg["rounds"])])
+    random.seed(31)
+    report = pl.learn(rb)
+    fx["actor_losses"] = torch.tensor(report["actor_loss"])
+    fx["critic_losses"] = torch.tensor(report["critic_loss"])
+    fx["actor_after"] = clone_sd(pl._actor)
+    fx["critic_after"] = clone_sd(pl._critic)
+    path = os.path.join(OUT, f"ppo_{name}.pt")
+    torch.save(fx, path)
+    print(f"ppo {name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); actor_loss "
+          f"{report['actor_loss'][0]:.5f} -> {report['actor_loss'][-1]:.5f}; critic_loss "
+          f"{report['critic_loss'][0]:.5f} -> {report['critic_loss'][-1]:.5f}")
+
+
+def make_sac(name, cfg):
+    S, A, B, K = cfg["S"], cfg["A"], cfg["B"], cfg["steps"]
+    gen = torch.Generator().manual_seed(99)
+    low = -torch.ones(A) * torch.linspace(1.0, 2.0, A)
+    high = torch.ones(A) * torch.linspace(1.5, 1.0, A)
+    sp = BoxActionSpace(low=low, high=high)
+    batch = dict(
+        state=torch.randn(B, S, generator=gen),
+        action=low + (high - low) * torch.rand(B, A, generator=gen),
+        reward=torch.randn(B, generator=gen),
+        terminated=torch.rand(B, generator=gen) < 0.2,
+        truncated=torch.zeros(B, dtype=torch.bool),
+        next_state=torch.randn(B, S, generator=gen))
+    torch.manual_seed(6)
+    pl = ContinuousSoftActorCritic(action_space=sp, state_dim=S, actor_hidden_dims=cfg["hidden"],
+                                   critic_hidden_dims=cfg["hidden"], batch_size=B)
+    PearlAgent(policy_learner=pl, replay_buffer=BasicReplayBuffer(10))
+    fx = {"config": dict(cfg), "low": low, "high": high, "batch": batch,
+          "actor0": clone_sd(pl._actor), "critic0": clone_sd(pl._critic),
+          "critic_target0": clone_sd(pl._critic_target)}
+    # first-step intermediates with known noise
+    torch.manual_seed(1000)
+    n1 = torch.normal(torch.zeros(B, A), torch.ones(B, A))
+    torch.manual_seed(1000)
+    with torch.no_grad():
+        act, logp = pl._actor.sample_action(batch["state"], get_log_prob=True)
+        q1, q2 = pl._critic.get_q_values(batch["state"], act)
+    fx["probe"] = dict(noise=n1, action=act.clone(), log_prob=logp.view(-1).clone(), q1=q1.clone(),
+                       q2=q2.clone())
+    noises, reports = [], []
+    for k in range(K):
+        seed = 2000 + k
+        torch.manual_seed(seed)
+        na = torch.normal(torch.zeros(B, A), torch.ones(B, A))
+        nc = torch.normal(torch.zeros(B, A), torch.ones(B, A))
+        noises.append((na, nc))
+        torch.manual_seed(seed)
+        tb = TransitionBatch(**{k2: v.clone() for k2, v in batch.items()})
+        rep = pl.learn_batch(pl.preprocess_batch(tb))
+        reports.append({k2: float(v) for k2, v in rep.items()})
+    fx["noises"] = noises
+    fx["reports"] = reports
+    fx["actor_after"] = clone_sd(pl._actor)
+    fx["critic_after"] = clone_sd(pl._critic)
+    fx["critic_target_after"] = clone_sd(pl._critic_target)
+    fx["log_entropy_after"] = pl._log_entropy.detach().clone()
+    fx["entropy_coef_after"] = pl._entropy_coef.detach().clone()
+    path = os.path.join(OUT, f"sac_{name}.pt")
+    torch.save(fx, path)
+    print(f"sac {name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); reports {reports[0]} "
+          f"-> {reports[-1]}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    for name, cfg in PPO_CONFIGS.items():
+        make_ppo(name, cfg)
+    for name, cfg in SAC_CONFIGS.items():
+        make_sac(name, cfg)
+
+
+if __name__ == "__main__":
+    main()

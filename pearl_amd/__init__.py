@@ -1,14 +1,17 @@
 """pearl_amd — MI355X-native learner/replay core behind Pearl's plugin API.
 
-Scope: ``BasicReplayBuffer.sample()`` and ``PolicyLearner.learn()`` for DQN as
+Scope: ``BasicReplayBuffer.sample()`` and ``PolicyLearner.learn()`` for DQN, PPO and
+continuous SAC as
 hand-written HIP kernels (libpearl_amd.so, C ABI in include/pearl_amd.h) behind Python classes
 that mirror the reference's ``ReplayBuffer`` / ``PolicyLearner`` / ``PearlAgent`` interfaces.
 There is no CPU or PyTorch fallback for that path: it fails loudly without the library / a GPU.
 """
 from .pearl_agent import PearlAgent  # noqa: F401
 from .replay_buffers import BasicReplayBuffer, TransitionBatch  # noqa: F401
-from .policy_learners.sequential_decision_making import DeepQLearning  # noqa: F401
+from .policy_learners.sequential_decision_making import (ContinuousSoftActorCritic,  # noqa: F401
+                                                         DeepQLearning, PPOReplayBuffer,
+                                                         ProximalPolicyOptimization)
 from .action_representation_modules import OneHotActionTensorRepresentationModule  # noqa: F401
-from .utils.instantiations.spaces import DiscreteActionSpace  # noqa: F401
+from .utils.instantiations.spaces import BoxActionSpace, DiscreteActionSpace  # noqa: F401
 
 __version__ = "0.1.0"

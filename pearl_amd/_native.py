@@ -170,6 +170,35 @@ class DqnBatch(C.Structure):
     ]
 
 
+MLP_MAX_LAYERS = 8
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("dims", C.c_int32 * (MLP_MAX_LAYERS + 1)),
+        ("max_batch", C.c_int32),
+        ("lr", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("eps", C.c_double),
+        ("weight_decay", C.c_double),
+        ("amsgrad", C.c_int32),
+    ]
+
+
+class MlpBuffers(C.Structure):
+    _fields_ = [
+        ("p", C.c_void_p),
+        ("p_target", C.c_void_p),
+        ("grad", C.c_void_p),
+        ("exp_avg", C.c_void_p),
+        ("exp_avg_sq", C.c_void_p),
+        ("max_exp_avg_sq", C.c_void_p),
+    ]
+
+
 class LearnArgs(C.Structure):
     _fields_ = [
         ("rounds", C.c_int32),
@@ -220,6 +249,31 @@ SIGNATURES = {
     "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
     "pa_dqn_get_timing": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_dqn_get_timing_units": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),
+    "pa_gather_rows": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P]),
+    "pa_mlp_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
+    "pa_mlp_param_offsets": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_int64)]),
+    "pa_mlp_create": (C.c_int, [C.POINTER(_P), C.POINTER(MlpDesc)]),
+    "pa_mlp_destroy": (C.c_int, [_P]),
+    "pa_mlp_bind": (C.c_int, [_P, C.POINTER(MlpBuffers)]),
+    "pa_mlp_forward": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    "pa_mlp_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P,
+                                  C.c_int32, _P]),
+    "pa_mlp_adam": (C.c_int, [_P, C.c_int64, _P]),
+    "pa_mlp_soft_update": (C.c_int, [_P, C.c_float, _P]),
+    "pa_softmax_action_prob": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "pa_ppo_actor_loss": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32,
+                                    C.c_float, C.c_float, _P, C.c_int32, _P, _P]),
+    "pa_mse_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_float, C.c_float, C.c_int32, _P, _P, _P]),
+    "pa_ppo_gae": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int64, _P, _P, _P]),
+    "pa_gauss_sample": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P,
+                                  C.c_int32, _P, _P]),
+    "pa_gauss_actor_grad": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P,
+                                      C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    "pa_sac_twin": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, _P]),
+    "pa_sac_alpha_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_double,
+                                    C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
+                                    C.c_int64, _P, _P]),
+    "pa_concat_cols": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_debug_linear": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_debug_weight_grad": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32,

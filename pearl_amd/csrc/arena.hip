@@ -852,6 +852,30 @@ extern "C" int pa_sample_indices(int64_t population, uint64_t seed, uint64_t off
                                reinterpret_cast<hipStream_t>(stream));
 }
 
+// out[b] = src[idx[b]] for rows of row_bytes bytes (extra per-transition columns kept next to the
+// arena in logical order, e.g. PPO's gae / lam_return / action_probs, ppo.py:47-82)
+static __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ src,
+                                                                 int row_bytes,
+                                                                 const int64_t* __restrict__ idx,
+                                                                 int B, uint8_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  copy_bytes_wave(out + (int64_t)b * row_bytes, src + idx[b] * row_bytes, row_bytes, lane);
+}
+
+extern "C" int pa_gather_rows(const void* src_dev, int32_t row_bytes, const int64_t* idx_dev,
+                              int32_t B, void* out_dev, void* stream) {
+  PA_REQUIRE(src_dev && idx_dev && out_dev && row_bytes > 0 && B >= 0, PA_ERR_INVALID,
+             "pa_gather_rows: bad argument");
+  if (B == 0) return PA_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const uint8_t*>(src_dev),
+                     row_bytes, idx_dev, B, reinterpret_cast<uint8_t*>(out_dev));
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 extern "C" int pa_one_hot(const void* idx_dev, int32_t idx_dtype, int64_t n, int32_t num_classes,
                           float* out_dev, void* stream) {
   PA_REQUIRE(num_classes > 0 && n >= 0, PA_ERR_INVALID, "bad one-hot shape");

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "online_kernels.hpp"
+#include "host_launch.hpp"
 
 using namespace pa;
 
@@ -116,41 +117,6 @@ struct ScopedTimer {
     t->used += 2;
   }
 };
-
-template <typename K>
-int set_max_smem(K kernel, size_t bytes) {
-  PA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  return PA_OK;
-}
-
-// One launch, one or two independent problems (blockIdx.z).
-template <bool B_KS>
-int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s) {
-  constexpr int KW = 4;
-  static size_t configured = 0;
-  auto kern = linear_kernel<B_KS, KW>;
-  LinArgs a;
-  memset(&a, 0, sizeof(a));
-  size_t smem = 0;
-  int gx = 0, gy = 0;
-  for (int i = 0; i < nprob; ++i) {
-    a.p[i] = probs[i];
-    const size_t b = linear_smem_bytes<B_KS, KW>(probs[i].K);
-    smem = b > smem ? b : smem;
-    gx = (int)ceil_div(probs[i].N, G_BN) > gx ? (int)ceil_div(probs[i].N, G_BN) : gx;
-    gy = (int)ceil_div(probs[i].M, G_BM) > gy ? (int)ceil_div(probs[i].M, G_BM) : gy;
-  }
-  if (smem > configured) {
-    int rc = set_max_smem(kern, smem);
-    if (rc != PA_OK) return rc;
-    configured = smem;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)gy, (unsigned)nprob), dim3(128 * KW), smem,
-                     s, a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
-}
 
 template <int NKG>
 int launch_target_t(const TargetArgs& a, hipStream_t s) {
@@ -821,8 +787,8 @@ extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int3
   memset(&g, 0, sizeof(g));
   g.A = A; g.lda = lda; g.Bm = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.bias = bias; g.Hmask = hmask; g.ldh = ldh; g.M = M; g.N = N; g.K = K; g.epi = epi;
-  PA_REQUIRE(epi >= 0 && epi <= 2, PA_ERR_INVALID, "bad epilogue %d", epi);
-  PA_REQUIRE(epi == EPI_MASK ? hmask != nullptr : bias != nullptr, PA_ERR_INVALID,
+  PA_REQUIRE(epi >= 0 && epi <= 3, PA_ERR_INVALID, "bad epilogue %d", epi);
+  PA_REQUIRE(epi == EPI_NONE || (epi == EPI_MASK ? hmask != nullptr : bias != nullptr), PA_ERR_INVALID,
              "epilogue %d needs %s", epi, epi == EPI_MASK ? "hmask" : "bias");
   return b_is_kn ? launch_linear<true>(&g, 1, s) : launch_linear<false>(&g, 1, s);
 }

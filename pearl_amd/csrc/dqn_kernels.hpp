@@ -85,7 +85,7 @@ __device__ __forceinline__ float f4_get(const float4& v, int j) {
 // per K chunk), stages it once in LDS, and KW waves per N half split the K range;
 // partial tiles are summed in a fixed order through LDS (deterministic).
 // ---------------------------------------------------------------------------
-enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2 };
+enum { EPI_BIAS = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_NONE = 3 };
 
 struct GemmArgs {
   const float* A; int lda;
@@ -109,7 +109,7 @@ __host__ __device__ inline int lin_kpad(int K) {
 }
 
 template <bool B_KS, int KW>
-__global__ __launch_bounds__(128 * KW) void linear_kernel(LinArgs args) {
+static __global__ __launch_bounds__(128 * KW) void linear_kernel(LinArgs args) {
   constexpr int NT = 128 * KW;
   constexpr int SLOTS = (G_BM + G_BN) * (G_KCAP / 4);  // float4 slots of one full panel
   constexpr int NPRE = (SLOTS + NT - 1) / NT;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(128 * KW) void linear_kernel(LinArgs args) {
   // epilogue operands are fetched now, not after the MFMA chain
   const int ecol = n0 + nt * 32 + l31;
   float bv = 0.f;
-  if (g.epi != EPI_MASK) bv = ld_or_zero(g.bias, ecol, ecol < g.N);
+  if (g.epi == EPI_BIAS || g.epi == EPI_BIAS_RELU) bv = ld_or_zero(g.bias, ecol, ecol < g.N);
 
   f32x16 acc;
 #pragma unroll
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(128 * KW) void linear_kernel(LinArgs args) {
           float v = acc[r];
           if (g.epi == EPI_BIAS) v += bv;
           else if (g.epi == EPI_BIAS_RELU) v = relu_keep_nan(v + bv);
-          else v = (hm[r] > 0.f) ? v : 0.f;
+          else if (g.epi == EPI_MASK) v = (hm[r] > 0.f) ? v : 0.f;
           g.C[(int64_t)row * g.ldc + col] = v;
         }
       }
@@ -323,7 +323,7 @@ __host__ __device__ inline int64_t w2f_floats(int H2, int H1) {
   return (int64_t)((H2 + 31) / 32) * t_nkg(H1) * 256;
 }
 
-__global__ __launch_bounds__(256) void repack_w2_kernel(const float* __restrict__ W2, int H2,
+static __global__ __launch_bounds__(256) void repack_w2_kernel(const float* __restrict__ W2, int H2,
                                                         int H1, float* __restrict__ W2f) {
   const int nkg = t_nkg(H1);
   const int64_t total = w2f_floats(H2, H1) / 4;  // float4 slots
@@ -351,7 +351,7 @@ inline size_t target_smem_bytes(int H1) {
 // VGPRs) for the widest instantiation, so that one workgroup's prologue / epilogue overlaps the
 // other's MFMA stream when a launch covers many 64-row tiles (a window of learn() rounds).
 template <int NKG>
-__global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
+static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int H1P = NKG * 8;           // padded layer-2 K (64 / 128 / 256)
   constexpr int PA_ = H1P + 4;           // == 4 mod 32: conflict-free b128 reads AND writes by row
@@ -565,7 +565,7 @@ struct HeadArgs {
   int B, H2;
 };
 
-__global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a) {
+static __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= a.B) return;
@@ -719,7 +719,7 @@ __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, fl
 // first MFMA (one exposed memory latency).  One extra workgroup (blockIdx ==
 // total_tiles) folds |Q - target| into the reported loss when ad.loss_out is set.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
+static __global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
   __shared__ float part[8 * 1024];
   __shared__ float csum[8 * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -807,7 +807,7 @@ struct AdamArgs {
   const float* absd; int nabs; float inv_B; float* loss_out;  // loss_out[0] = mean |Q - target|
 };
 
-__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+static __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   __shared__ float red[256];
   if (blockIdx.x == 0 && a.loss_out) {
     // mean |Q - target| of this step (deep_td_learning.py:358-359), fixed summation order
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 }
 
 // theta' <- tau * theta + (1 - tau) * theta'   (common/utils.py:214-226)
-__global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ tgt,
+static __global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ tgt,
                                                           const float* __restrict__ src,
                                                           int64_t n, float tau,
                                                           float one_minus_tau) {
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ tg
 }
 
 // x[b] = state[b] || action_rep[b]   (q_value_networks.py:166-168 torch.cat)
-__global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ state,
+static __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restrict__ state,
                                                      const float* __restrict__ arep,
                                                      float* __restrict__ x, int B, int S, int AD) {
   const int W = S + AD;

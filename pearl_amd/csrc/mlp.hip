@@ -1,0 +1,745 @@
+// Generic fully-connected network engine + the actor-critic kernels (PPO, continuous SAC).
+//
+// Reference being replaced (file:line under /root/reference):
+//   mlp_block                         pearl/neural_networks/common/utils.py:75-152
+//   VanillaValueNetwork.forward       pearl/neural_networks/common/value_networks.py:35-59
+//   VanillaActorNetwork               .../sequential_decision_making/actor_networks.py:107-176
+//   GaussianActorNetwork              .../actor_networks.py:488-629
+//   TwinCritic / critic losses        .../twin_critic.py:22-91, utils/functional_utils/learning/critic_utils.py:139-203
+//   ActorCriticBase.learn_batch       policy_learners/sequential_decision_making/actor_critic_base.py:309-366
+//   PPO losses + GAE                  .../ppo.py:152-293
+//   ContinuousSoftActorCritic         .../soft_actor_critic_continuous.py:131-231
+//
+// A pa_mlp is Linear+ReLU hidden layers and a linear last layer over flat, caller-owned fp32
+// buffers (parameters, optional target copy, gradient, AdamW state) — the same ownership rule as
+// pa_dqn.  Forward/backward reuse the fp32-MFMA kernels of dqn_kernels.hpp (linear_kernel,
+// weight_grad_kernel, adamw_kernel); the algorithm heads below are small fused elementwise /
+// reduction kernels with torch's op order (one rounding per op, -ffp-contract=off).
+#include <math.h>
+
+#include <new>
+
+#include "host_launch.hpp"
+
+using namespace pa;
+
+struct pa_mlp {
+  pa_mlp_desc d;
+  pa_mlp_buffers bufs;
+  bool bound;
+  int L;
+  int64_t woff[PA_MLP_MAX_LAYERS], boff[PA_MLP_MAX_LAYERS], P;
+  float* act[PA_MLP_MAX_LAYERS];  // hidden activations kept for the backward pass [max_batch, d]
+  float* dz[2];                   // ping-pong pre-activation gradients [max_batch, max hidden]
+  float* loss_scratch;
+  int kept_B;                     // batch size of the kept forward (0 = none)
+};
+
+namespace {
+
+int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
+
+int layout(const pa_mlp_desc* d, int64_t* woff, int64_t* boff, int64_t* total) {
+  PA_REQUIRE(d && d->n_layers >= 1 && d->n_layers <= PA_MLP_MAX_LAYERS, PA_ERR_INVALID,
+             "n_layers must be in [1, %d]", PA_MLP_MAX_LAYERS);
+  int64_t o = 0;
+  for (int l = 0; l < d->n_layers; ++l) {
+    PA_REQUIRE(d->dims[l] > 0 && d->dims[l + 1] > 0, PA_ERR_INVALID, "layer dims must be positive");
+    woff[l] = o; o = align4(o + (int64_t)d->dims[l + 1] * d->dims[l]);
+    boff[l] = o; o = align4(o + d->dims[l + 1]);
+  }
+  *total = o;
+  return PA_OK;
+}
+
+AdamScalars adam_scalars(const pa_mlp_desc& d, int64_t step) {
+  const double bc1 = 1.0 - pow(d.beta1, (double)step);
+  const double bc2 = 1.0 - pow(d.beta2, (double)step);
+  AdamScalars c;
+  c.decay = (float)(1.0 - d.lr * d.weight_decay);
+  c.w1 = (float)(1.0 - d.beta1);
+  c.beta2 = (float)d.beta2;
+  c.omb2 = (float)(1.0 - d.beta2);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.neg_step = (float)(-(d.lr / bc1));
+  c.eps = (float)d.eps;
+  c.amsgrad = d.amsgrad;
+  return c;
+}
+
+}  // namespace
+
+extern "C" int64_t pa_mlp_param_count(const pa_mlp_desc* d) {
+  int64_t w[PA_MLP_MAX_LAYERS], b[PA_MLP_MAX_LAYERS], total = 0;
+  if (layout(d, w, b, &total) != PA_OK) return -1;
+  return total;
+}
+
+extern "C" int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets) {
+  PA_REQUIRE(offsets, PA_ERR_INVALID, "null output");
+  int64_t w[PA_MLP_MAX_LAYERS], b[PA_MLP_MAX_LAYERS], total = 0;
+  int rc = layout(d, w, b, &total);
+  if (rc != PA_OK) return rc;
+  for (int l = 0; l < d->n_layers; ++l) {
+    offsets[2 * l] = w[l];
+    offsets[2 * l + 1] = b[l];
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_mlp_destroy(pa_mlp* h) {
+  if (!h) return PA_OK;
+  (void)hipSetDevice(h->d.device);
+  (void)hipDeviceSynchronize();
+  for (int l = 0; l < PA_MLP_MAX_LAYERS; ++l)
+    if (h->act[l]) (void)hipFree(h->act[l]);
+  for (int i = 0; i < 2; ++i)
+    if (h->dz[i]) (void)hipFree(h->dz[i]);
+  if (h->loss_scratch) (void)hipFree(h->loss_scratch);
+  delete h;
+  return PA_OK;
+}
+
+extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
+  PA_REQUIRE(out && desc, PA_ERR_INVALID, "pa_mlp_create: null argument");
+  PA_REQUIRE(desc->max_batch > 0, PA_ERR_INVALID, "max_batch must be positive");
+  const int ndev = pa_device_count();
+  PA_REQUIRE(desc->device >= 0 && desc->device < ndev, PA_ERR_HIP,
+             "HIP device %d not available (%d visible): pa_mlp is HIP-only and has no CPU fallback",
+             desc->device, ndev);
+  pa_mlp* h = new (std::nothrow) pa_mlp();
+  PA_REQUIRE(h, PA_ERR_NOMEM, "out of host memory");
+  memset(h, 0, sizeof(*h));
+  h->d = *desc;
+  h->L = desc->n_layers;
+  int rc = layout(desc, h->woff, h->boff, &h->P);
+  if (rc != PA_OK) {
+    delete h;
+    return rc;
+  }
+  PA_HIP(hipSetDevice(desc->device));
+  int maxh = 1;
+  for (int l = 0; l < h->L; ++l) maxh = desc->dims[l + 1] > maxh ? desc->dims[l + 1] : maxh;
+  auto alloc = [&](float** p, int64_t floats) {
+    return hipMalloc((void**)p, (size_t)(floats * 4)) == hipSuccess;
+  };
+  bool ok = true;
+  for (int l = 0; l + 1 < h->L; ++l)
+    ok = ok && alloc(&h->act[l], (int64_t)desc->max_batch * desc->dims[l + 1]);
+  ok = ok && alloc(&h->dz[0], (int64_t)desc->max_batch * maxh);
+  ok = ok && alloc(&h->dz[1], (int64_t)desc->max_batch * maxh);
+  ok = ok && alloc(&h->loss_scratch, 4);
+  if (!ok) {
+    set_error("hipMalloc(mlp workspace) failed");
+    pa_mlp_destroy(h);
+    return PA_ERR_NOMEM;
+  }
+  *out = h;
+  return PA_OK;
+}
+
+extern "C" int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* b) {
+  PA_REQUIRE(h && b && b->p, PA_ERR_INVALID, "pa_mlp_bind: null argument");
+  const float* all[] = {b->p, b->p_target, b->grad, b->exp_avg, b->exp_avg_sq, b->max_exp_avg_sq};
+  for (const float* p : all)
+    PA_REQUIRE((reinterpret_cast<uintptr_t>(p) & 15) == 0, PA_ERR_INVALID,
+               "flat buffers must be 16-byte aligned");
+  h->bufs = *b;
+  h->bound = true;
+  return PA_OK;
+}
+
+// out = W_L-1(relu(... relu(W_0 x + b_0) ...)) + b_L-1.  keep = 1 retains the hidden activations for
+// pa_mlp_backward (one kept forward at a time).
+extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int32_t ldx, int32_t B,
+                              float* out, int32_t ldo, int32_t keep, void* stream) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "mlp has no bound parameter buffers");
+  PA_REQUIRE(x && out && B > 0 && B <= h->d.max_batch, PA_ERR_INVALID,
+             "pa_mlp_forward: bad argument (B=%d, max_batch=%d)", B, h->d.max_batch);
+  const float* P = use_target ? h->bufs.p_target : h->bufs.p;
+  PA_REQUIRE(P, PA_ERR_INVALID, "no target parameters bound");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(h->d.device));
+  const float* in = x;
+  int ldin = ldx;
+  for (int l = 0; l < h->L; ++l) {
+    const bool last = (l == h->L - 1);
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = in; g.lda = ldin;
+    g.Bm = P + h->woff[l]; g.ldb = h->d.dims[l];
+    g.C = last ? out : h->act[l]; g.ldc = last ? ldo : h->d.dims[l + 1];
+    g.bias = P + h->boff[l];
+    g.M = B; g.N = h->d.dims[l + 1]; g.K = h->d.dims[l];
+    g.epi = last ? EPI_BIAS : EPI_BIAS_RELU;
+    int rc = launch_linear<false>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+    in = h->act[l];
+    ldin = h->d.dims[l + 1];
+  }
+  h->kept_B = keep ? B : 0;
+  return PA_OK;
+}
+
+// Backward of the kept forward.  d_out[B, d_L] is the gradient w.r.t. the network output.
+// want_dw: write dW/db of every layer into bufs.grad.  d_x (nullable): gradient w.r.t. the input.
+extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
+                               int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx,
+                               void* stream) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "mlp has no bound parameter buffers");
+  PA_REQUIRE(h->kept_B == B && B > 0, PA_ERR_INVALID,
+             "pa_mlp_backward: no kept forward of batch %d (kept %d)", B, h->kept_B);
+  PA_REQUIRE(x && d_out, PA_ERR_INVALID, "pa_mlp_backward: null argument");
+  PA_REQUIRE(!want_dw || h->bufs.grad, PA_ERR_INVALID, "no gradient buffer bound");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(h->d.device));
+  const float* P = h->bufs.p;
+  const float* dz = d_out;
+  int lddz = ldd;
+  for (int l = h->L - 1; l >= 0; --l) {
+    const float* in = l > 0 ? h->act[l - 1] : x;
+    const int ldin = l > 0 ? h->d.dims[l] : ldx;
+    if (want_dw) {
+      DwArgs a;
+      memset(&a, 0, sizeof(a));
+      a.nprob = 1;
+      a.p[0].dZ = dz; a.p[0].ldz = lddz;
+      a.p[0].X = in; a.p[0].ldx = ldin;
+      a.p[0].dW = h->bufs.grad + h->woff[l]; a.p[0].ldw = h->d.dims[l];
+      a.p[0].db = h->bufs.grad + h->boff[l];
+      a.p[0].M = h->d.dims[l + 1]; a.p[0].N = h->d.dims[l];
+      a.p[0].tiles_n = (int)ceil_div(h->d.dims[l], 32);
+      a.p[0].tile0 = 0;
+      a.p[0].kind = 2;
+      a.total_tiles = (int)ceil_div(h->d.dims[l + 1], 32) * a.p[0].tiles_n;
+      a.B = B;
+      hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
+      PA_LAUNCH_CHECK();
+    }
+    if (l > 0 || d_x) {
+      // dIn = dZ W_l (masked by relu'(in) for hidden inputs)
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      g.A = dz; g.lda = lddz;
+      g.Bm = P + h->woff[l]; g.ldb = h->d.dims[l];
+      float* dst = l > 0 ? h->dz[l & 1] : d_x;
+      g.C = dst; g.ldc = l > 0 ? h->d.dims[l] : lddx;
+      g.M = B; g.N = h->d.dims[l]; g.K = h->d.dims[l + 1];
+      if (l > 0) {
+        g.Hmask = h->act[l - 1]; g.ldh = h->d.dims[l];
+        g.epi = EPI_MASK;
+      } else {
+        g.epi = EPI_NONE;
+      }
+      int rc = launch_linear<true>(&g, 1, s);
+      if (rc != PA_OK) return rc;
+      dz = dst;
+      lddz = l > 0 ? h->d.dims[l] : lddx;
+    }
+  }
+  return PA_OK;
+}
+
+// optim.AdamW(amsgrad) step `step` (1-based) on bufs.grad.
+extern "C" int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream) {
+  PA_REQUIRE(h && h->bound && h->bufs.grad && h->bufs.exp_avg && h->bufs.exp_avg_sq,
+             PA_ERR_INVALID, "pa_mlp_adam: optimizer buffers not bound");
+  PA_REQUIRE(!h->d.amsgrad || h->bufs.max_exp_avg_sq, PA_ERR_INVALID, "amsgrad needs max_exp_avg_sq");
+  PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1");
+  PA_HIP(hipSetDevice(h->d.device));
+  AdamArgs a;
+  memset(&a, 0, sizeof(a));
+  a.st.p = h->bufs.p; a.st.m = h->bufs.exp_avg; a.st.v = h->bufs.exp_avg_sq;
+  a.st.vmax = h->bufs.max_exp_avg_sq;
+  a.g = h->bufs.grad;
+  a.n = h->P;
+  a.c = adam_scalars(h->d, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+// update_target_network (common/utils.py:214-226)
+extern "C" int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream) {
+  PA_REQUIRE(h && h->bound && h->bufs.p_target, PA_ERR_INVALID, "no target parameters bound");
+  PA_HIP(hipSetDevice(h->d.device));
+  hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), h->bufs.p_target, h->bufs.p, h->P, tau,
+                     (float)(1.0 - (double)tau));
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+// =============================================================================================
+// heads
+// =============================================================================================
+namespace {
+
+// block-wide sum in a fixed order (256 threads)
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// softmax over A logits of one row, by one thread (A is an action count: small)
+__device__ __forceinline__ float softmax_row_prob(const float* __restrict__ z, int A,
+                                                  const float* __restrict__ arep, float* probs_out,
+                                                  float* sum_out) {
+  float m = z[0];
+  for (int j = 1; j < A; ++j) m = fmaxf(m, z[j]);
+  float s = 0.f;
+  for (int j = 0; j < A; ++j) s += expf(z[j] - m);
+  float p = 0.f;
+  for (int j = 0; j < A; ++j) {
+    const float pj = expf(z[j] - m) / s;
+    if (probs_out) probs_out[j] = pj;
+    p += pj * arep[j];
+  }
+  if (sum_out) *sum_out = s;
+  return p;
+}
+
+// VanillaActorNetwork.get_action_prob (actor_networks.py:155-176): softmax(logits) . action_rep
+__global__ __launch_bounds__(256) void action_prob_kernel(const float* __restrict__ logits, int ldl,
+                                                          const float* __restrict__ arep, int lda,
+                                                          int B, int A, float* __restrict__ probs,
+                                                          float* __restrict__ aprob) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  aprob[b] = softmax_row_prob(logits + (int64_t)b * ldl, A, arep + (int64_t)b * lda,
+                              probs ? probs + (int64_t)b * A : nullptr, nullptr);
+}
+
+// PPO clipped-surrogate actor loss and its gradient w.r.t. the logits (ppo.py:152-183).
+// Single workgroup: the entropy bonus treats the B chosen-action probabilities as ONE categorical
+// distribution (a detached scalar), which needs their batch sum first.
+struct PpoActorArgs {
+  const float* logits; int ldl;
+  const float* arep; int lda;
+  const float* p_old; const float* gae;
+  int B, A;
+  float eps, ent_scale;
+  float* d_logits; int ldd;
+  float* loss_out;
+};
+
+__global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
+  __shared__ float red[256];
+  const float lo = 1.0f - a.eps, hi = 1.0f + a.eps;
+  float part_loss = 0.f, part_p = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float* z = a.logits + (int64_t)b * a.ldl;
+    const float* ar = a.arep + (int64_t)b * a.lda;
+    float m = z[0];
+    for (int j = 1; j < a.A; ++j) m = fmaxf(m, z[j]);
+    float s = 0.f;
+    for (int j = 0; j < a.A; ++j) s += expf(z[j] - m);
+    float p = 0.f;
+    for (int j = 0; j < a.A; ++j) p += (expf(z[j] - m) / s) * ar[j];
+    const float g = a.gae[b];
+    const float r = p / a.p_old[b];
+    const float clip = fminf(fmaxf(r, lo), hi);
+    const float s1 = r * g, s2 = clip * g;
+    part_loss += -fminf(s1, s2);
+    part_p += p;
+    // d(-min(s1, s2))/dr: torch.minimum splits ties evenly; clamp passes the gradient inside
+    // [lo, hi] (bounds included)
+    const float inr = (r >= lo && r <= hi) ? 1.f : 0.f;
+    float dr;
+    if (s1 < s2) dr = g;
+    else if (s1 > s2) dr = g * inr;
+    else dr = 0.5f * g + 0.5f * g * inr;
+    const float dp = -dr / a.p_old[b];
+    // p = sum_j y_j ar_j, y = softmax(z): dz_j = y_j (dp ar_j - sum_k dp ar_k y_k)
+    const float dot = dp * p;
+    float* dz = a.d_logits + (int64_t)b * a.ldd;
+    for (int j = 0; j < a.A; ++j) {
+      const float yj = expf(z[j] - m) / s;
+      dz[j] = yj * (dp * ar[j] - dot);
+    }
+  }
+  const float loss = block_sum_256(part_loss, red);
+  const float psum = block_sum_256(part_p, red);
+  // entropy of Categorical(probs = p / sum p) with torch's clamping of probs / logits
+  float part_e = 0.f;
+  const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float* z = a.logits + (int64_t)b * a.ldl;
+    const float* ar = a.arep + (int64_t)b * a.lda;
+    float m = z[0];
+    for (int j = 1; j < a.A; ++j) m = fmaxf(m, z[j]);
+    float s = 0.f;
+    for (int j = 0; j < a.A; ++j) s += expf(z[j] - m);
+    float p = 0.f;
+    for (int j = 0; j < a.A; ++j) p += (expf(z[j] - m) / s) * ar[j];
+    const float pn = p / psum;
+    const float pc = fminf(fmaxf(pn, tiny), 1.0f - tiny);
+    float lg = logf(pc);
+    lg = fmaxf(lg, -3.4028234663852886e+38f);
+    part_e += lg * pn;
+  }
+  const float ent = -block_sum_256(part_e, red);
+  if (threadIdx.x == 0) a.loss_out[0] = loss - a.ent_scale * ent;
+}
+
+// MSELoss(mean) head: loss = mean((pred - target)^2) * scale_loss, d_pred = grad_scale * (pred - target)
+struct MseArgs {
+  const float* pred; int ldp;
+  const float* target;
+  int B;
+  float grad_scale;   // 2 / B (single critic) or 1 / B (each of the twin critics: (mse1 + mse2) / 2)
+  float* d_pred;
+  float* loss_out;    // += or = mean squared error * loss_scale
+  float loss_scale;
+  int accumulate;
+};
+__global__ __launch_bounds__(256) void mse_head_kernel(MseArgs a) {
+  __shared__ float red[256];
+  float part = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float d = __fsub_rn(a.pred[(int64_t)b * a.ldp], a.target[b]);
+    part += d * d;
+    if (a.d_pred) a.d_pred[b] = __fmul_rn(a.grad_scale, d);
+  }
+  const float s = block_sum_256(part, red);
+  if (threadIdx.x == 0 && a.loss_out) {
+    const float v = (s / (float)a.B) * a.loss_scale;
+    a.loss_out[0] = a.accumulate ? a.loss_out[0] + v : v;
+  }
+}
+
+// GAE / truncated lambda return (ppo.py:271-293).  The reference walks the rollout from the newest
+// transition to the oldest; gae_i = td_i + gamma*lambda*[not (term_i or trunc_i)] * gae_{i+1}.
+// The recurrence restarts wherever that factor is 0, so every such boundary starts an independent
+// backward walk: thread i is active iff it is a boundary (or the newest transition) and walks back
+// to the previous boundary — the same sequential fp32 arithmetic as the reference, in parallel
+// across episodes.  Index i is the LOGICAL index (0 = oldest).
+struct GaeArgs {
+  const float* reward; const uint8_t* term; const uint8_t* trunc;
+  const float* values;           // [N] critic(state_i)
+  const float* next_value_last;  // critic(next_state of the newest transition), device scalar
+  float gamma; float gl;         // gamma, (float)(gamma * lambda)
+  int64_t N;
+  float* gae; float* lam_return;
+};
+__global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
+  const int64_t i1 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i1 >= a.N) return;
+  const bool boundary = (i1 == a.N - 1) || a.term[i1] || a.trunc[i1];
+  if (!boundary) return;
+  float gae = 0.f;
+  for (int64_t i = i1; i >= 0; --i) {
+    const bool done = a.term[i] || a.trunc[i];
+    if (i != i1 && done) break;  // the previous boundary owns the rest
+    const float nv = (i == a.N - 1) ? a.next_value_last[0] : a.values[i + 1];
+    // td = reward + gamma * next_value * (~terminated) - V[i]
+    const float t0 = __fmul_rn(a.gamma, nv);
+    const float t1 = __fmul_rn(t0, a.term[i] ? 0.f : 1.f);
+    const float t2 = __fadd_rn(a.reward[i], t1);
+    const float td = __fsub_rn(t2, a.values[i]);
+    const float c = done ? 0.f : a.gl;
+    gae = __fadd_rn(td, __fmul_rn(c, gae));
+    a.gae[i] = gae;
+    a.lam_return[i] = __fadd_rn(gae, a.values[i]);
+  }
+}
+
+// ---- continuous SAC -------------------------------------------------------------------------
+// GaussianActorNetwork.forward tail + sample_action (actor_networks.py:537-591):
+//   log_std = -5 + 3.5 * (tanh(raw) + 1); u = mean + exp(log_std) * noise; n = tanh(u)
+//   action = ((high - low) * (n + 1)) / 2 + low
+//   log_prob = sum_j [ Normal(mean, std).log_prob(u) - log(bound * (1 - n^2) + 1e-6) ]
+struct GaussArgs {
+  const float* head; int ldh;      // [B, 2A]: mean | raw log_std
+  const float* noise; int ldn;     // [B, A] standard normal draws (host-supplied in parity mode)
+  const float* low; const float* high;  // [A]
+  int B, A;
+  float* action; int lda;          // [B, A] (may point into a [B, S+A] critic input)
+  float* log_prob;                 // [B]
+};
+__device__ __forceinline__ void gauss_elem(float mean, float raw, float eps, float low, float high,
+                                           float& t, float& log_std, float& stdv, float& u,
+                                           float& n) {
+  t = tanhf(raw);
+  log_std = -5.0f + 3.5f * (t + 1.0f);
+  stdv = expf(log_std);
+  u = mean + stdv * eps;
+  n = tanhf(u);
+}
+__global__ __launch_bounds__(256) void gauss_sample_kernel(GaussArgs a) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const float* hd = a.head + (int64_t)b * a.ldh;
+  float lp = 0.f;
+  for (int j = 0; j < a.A; ++j) {
+    float t, ls, sd, u, n;
+    const float eps = a.noise[(int64_t)b * a.ldn + j];
+    gauss_elem(hd[j], hd[a.A + j], eps, a.low[j], a.high[j], t, ls, sd, u, n);
+    const float act = (((a.high[j] - a.low[j]) * (n + 1.0f)) / 2.0f) + a.low[j];
+    a.action[(int64_t)b * a.lda + j] = act;
+    // Normal.log_prob: -((u - mean)^2) / (2 var) - log(std) - log(sqrt(2 pi))
+    const float var = sd * sd;
+    const float diff = u - hd[j];
+    float l = -(diff * diff) / (2.0f * var) - logf(sd) - 0.9189385332046727f;
+    const float bound = (a.high[j] - a.low[j]) / 2.0f;
+    l -= logf(bound * (1.0f - n * n) + 1e-6f);
+    lp += l;
+  }
+  a.log_prob[b] = lp;
+}
+
+// Gradient of mean_b(alpha * log_prob_b - q_b) w.r.t. the actor head, given dq_b/da (the critic's
+// input gradient, already scaled by dL/dq = -1/B * min-weights).
+struct GaussGradArgs {
+  const float* head; int ldh;
+  const float* noise; int ldn;
+  const float* low; const float* high;
+  const float* dl_da; const float* dl_da2; int ldda;  // [B, A] dL/d action through critic 1 (+ critic 2)
+  const float* alpha;              // device scalar (entropy coefficient)
+  int B, A;
+  float* d_head; int lddh;         // [B, 2A]
+};
+__global__ __launch_bounds__(256) void gauss_grad_kernel(GaussGradArgs a) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= a.B) return;
+  const float* hd = a.head + (int64_t)b * a.ldh;
+  const float coef = a.alpha[0] / (float)a.B;   // dL/dlog_prob_b
+  for (int j = 0; j < a.A; ++j) {
+    float t, ls, sd, u, n;
+    const float eps = a.noise[(int64_t)b * a.ldn + j];
+    gauss_elem(hd[j], hd[a.A + j], eps, a.low[j], a.high[j], t, ls, sd, u, n);
+    const float bound = (a.high[j] - a.low[j]) / 2.0f;
+    const float one_m_n2 = 1.0f - n * n;
+    // d log_prob / du (the Normal term is -noise^2/2: constant under the reparameterisation)
+    const float dlp_du = (2.0f * bound * n * one_m_n2) / (bound * one_m_n2 + 1e-6f);
+    const float da_du = bound * one_m_n2;
+    float dla = a.dl_da[(int64_t)b * a.ldda + j];
+    if (a.dl_da2) dla += a.dl_da2[(int64_t)b * a.ldda + j];
+    const float dl_du = coef * dlp_du + dla * da_du;
+    const float dl_dls = dl_du * eps * sd - coef;     // -log(std) term: -1
+    a.d_head[(int64_t)b * a.lddh + j] = dl_du;
+    a.d_head[(int64_t)b * a.lddh + a.A + j] = dl_dls * 3.5f * (1.0f - t * t);
+  }
+}
+
+// Twin-critic plumbing for SAC (soft_actor_critic_continuous.py:155-231).
+//   mode 0 (actor loss):  loss = mean(alpha * logp - min(q1, q2)); dq1/dq2 = -w/B with torch.minimum's
+//                         even split on ties
+//   mode 1 (critic target): y = (min(q1', q2') - alpha * logp') * gamma * (1 - term) + reward
+struct TwinArgs {
+  const float* q1; const float* q2; const float* logp; const float* alpha;
+  const float* reward; const uint8_t* term;
+  float gamma;
+  int B, mode;
+  float* out1; float* out2;   // mode 0: dq1, dq2; mode 1: out1 = y
+  float* loss_out;            // mode 0
+};
+__global__ __launch_bounds__(256) void twin_kernel(TwinArgs a) {
+  __shared__ float red[256];
+  const float al = a.alpha[0];
+  float part = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float x1 = a.q1[b], x2 = a.q2[b];
+    const float mn = fminf(x1, x2);
+    if (a.mode == 0) {
+      part += al * a.logp[b] - mn;
+      const float w1 = x1 < x2 ? 1.f : (x1 == x2 ? 0.5f : 0.f);
+      a.out1[b] = -w1 / (float)a.B;
+      a.out2[b] = -(1.f - w1) / (float)a.B;
+    } else {
+      const float v = mn - al * a.logp[b];
+      const float live = 1.0f - (a.term[b] ? 1.0f : 0.0f);
+      a.out1[b] = __fadd_rn(__fmul_rn(__fmul_rn(v, a.gamma), live), a.reward[b]);
+    }
+  }
+  if (a.mode == 0) {
+    const float s = block_sum_256(part, red);
+    if (threadIdx.x == 0) a.loss_out[0] = s / (float)a.B;
+  }
+}
+
+// Entropy-coefficient autotune (soft_actor_critic_continuous.py:134-151): scalar AdamW(amsgrad) on
+// log_alpha with gradient mean(-exp(log_alpha) * (logp + target_entropy)); alpha = exp(log_alpha).
+struct AlphaArgs {
+  float* log_alpha; float* m; float* v; float* vmax; float* alpha;
+  const float* logp; int B; float target_entropy;
+  AdamScalars c;
+  float* loss_out;
+};
+__global__ __launch_bounds__(256) void alpha_kernel(AlphaArgs a) {
+  __shared__ float red[256];
+  const float ea = expf(a.log_alpha[0]);
+  float part = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) part += -ea * (a.logp[b] + a.target_entropy);
+  const float s = block_sum_256(part, red);
+  if (threadIdx.x == 0) {
+    const float g = s / (float)a.B;   // d loss / d log_alpha == the loss itself
+    if (a.loss_out) a.loss_out[0] = g;
+    AdamState st;
+    st.p = a.log_alpha; st.m = a.m; st.v = a.v; st.vmax = a.vmax;
+    const float p = adam_update(a.c, st, 0, g);
+    a.alpha[0] = expf(p);
+  }
+}
+
+// out[b, 0:S] = state[b], out[b, S:S+A] = action[b]   (q_value_networks.py:166-168 torch.cat)
+__global__ __launch_bounds__(256) void concat_kernel(const float* __restrict__ s, int lds_,
+                                                     const float* __restrict__ act, int lda,
+                                                     float* __restrict__ out, int B, int S, int A) {
+  const int W = S + A;
+  const int64_t total = (int64_t)B * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / W;
+    const int j = (int)(e - b * W);
+    out[e] = (j < S) ? s[b * lds_ + j] : act[b * lda + (j - S)];
+  }
+}
+
+}  // namespace
+
+extern "C" int pa_softmax_action_prob(const float* logits, int32_t ldl, const float* action_rep,
+                                      int32_t lda, int32_t B, int32_t A, float* probs_out,
+                                      float* action_prob_out, void* stream) {
+  PA_REQUIRE(logits && action_rep && action_prob_out && B > 0 && A > 0, PA_ERR_INVALID,
+             "pa_softmax_action_prob: bad argument");
+  hipLaunchKernelGGL(action_prob_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), logits, ldl, action_rep, lda, B, A,
+                     probs_out, action_prob_out);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* action_rep,
+                                 int32_t lda, const float* p_old, const float* gae, int32_t B,
+                                 int32_t A, float epsilon, float entropy_scale, float* d_logits,
+                                 int32_t ldd, float* loss_out, void* stream) {
+  PA_REQUIRE(logits && action_rep && p_old && gae && d_logits && loss_out && B > 0 && A > 0,
+             PA_ERR_INVALID, "pa_ppo_actor_loss: bad argument");
+  PpoActorArgs a;
+  a.logits = logits; a.ldl = ldl; a.arep = action_rep; a.lda = lda; a.p_old = p_old; a.gae = gae;
+  a.B = B; a.A = A; a.eps = epsilon; a.ent_scale = entropy_scale;
+  a.d_logits = d_logits; a.ldd = ldd; a.loss_out = loss_out;
+  hipLaunchKernelGGL(ppo_actor_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B,
+                           float grad_scale, float loss_scale, int32_t accumulate, float* d_pred,
+                           float* loss_out, void* stream) {
+  PA_REQUIRE(pred && target && B > 0, PA_ERR_INVALID, "pa_mse_head: bad argument");
+  MseArgs a;
+  a.pred = pred; a.ldp = ldp; a.target = target; a.B = B; a.grad_scale = grad_scale;
+  a.d_pred = d_pred; a.loss_out = loss_out; a.loss_scale = loss_scale; a.accumulate = accumulate;
+  hipLaunchKernelGGL(mse_head_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_ppo_gae(const float* reward, const uint8_t* terminated, const uint8_t* truncated,
+                          const float* values, const float* next_value_last, float gamma, float lam,
+                          int64_t N, float* gae_out, float* lam_return_out, void* stream) {
+  PA_REQUIRE(reward && terminated && truncated && values && next_value_last && gae_out &&
+                 lam_return_out && N > 0,
+             PA_ERR_INVALID, "pa_ppo_gae: bad argument");
+  GaeArgs a;
+  a.reward = reward; a.term = terminated; a.trunc = truncated; a.values = values;
+  a.next_value_last = next_value_last;
+  a.gamma = gamma;
+  a.gl = (float)((double)gamma * (double)lam);
+  a.N = N; a.gae = gae_out; a.lam_return = lam_return_out;
+  hipLaunchKernelGGL(gae_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_gauss_sample(const float* head, int32_t ldh, const float* noise, int32_t ldn,
+                               const float* low, const float* high, int32_t B, int32_t A,
+                               float* action, int32_t lda, float* log_prob, void* stream) {
+  PA_REQUIRE(head && noise && low && high && action && log_prob && B > 0 && A > 0, PA_ERR_INVALID,
+             "pa_gauss_sample: bad argument");
+  GaussArgs a;
+  a.head = head; a.ldh = ldh; a.noise = noise; a.ldn = ldn; a.low = low; a.high = high;
+  a.B = B; a.A = A; a.action = action; a.lda = lda; a.log_prob = log_prob;
+  hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* noise, int32_t ldn,
+                                   const float* low, const float* high, const float* dl_daction,
+                                   const float* dl_daction2, int32_t ldda, const float* alpha,
+                                   int32_t B, int32_t A,
+                                   float* d_head, int32_t lddh, void* stream) {
+  PA_REQUIRE(head && noise && low && high && dl_daction && alpha && d_head && B > 0 && A > 0,
+             PA_ERR_INVALID, "pa_gauss_actor_grad: bad argument");
+  GaussGradArgs a;
+  a.head = head; a.ldh = ldh; a.noise = noise; a.ldn = ldn; a.low = low; a.high = high;
+  a.dl_da = dl_daction; a.dl_da2 = dl_daction2; a.ldda = ldda; a.alpha = alpha; a.B = B; a.A = A;
+  a.d_head = d_head; a.lddh = lddh;
+  hipLaunchKernelGGL(gauss_grad_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_sac_twin(int32_t mode, const float* q1, const float* q2, const float* log_prob,
+                           const float* alpha, const float* reward, const uint8_t* terminated,
+                           float gamma, int32_t B, float* out1, float* out2, float* loss_out,
+                           void* stream) {
+  PA_REQUIRE(q1 && q2 && log_prob && alpha && out1 && B > 0 && (mode == 0 || mode == 1),
+             PA_ERR_INVALID, "pa_sac_twin: bad argument");
+  PA_REQUIRE(mode == 0 ? (out2 && loss_out) : (reward && terminated), PA_ERR_INVALID,
+             "pa_sac_twin: missing mode-specific argument");
+  TwinArgs a;
+  a.q1 = q1; a.q2 = q2; a.logp = log_prob; a.alpha = alpha; a.reward = reward; a.term = terminated;
+  a.gamma = gamma; a.B = B; a.mode = mode; a.out1 = out1; a.out2 = out2; a.loss_out = loss_out;
+  hipLaunchKernelGGL(twin_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_sac_alpha_step(float* log_alpha, float* exp_avg, float* exp_avg_sq,
+                                 float* max_exp_avg_sq, float* alpha_out, const float* log_prob,
+                                 int32_t B, float target_entropy, double lr, double beta1,
+                                 double beta2, double eps, double weight_decay, int32_t amsgrad,
+                                 int64_t step, float* loss_out, void* stream) {
+  PA_REQUIRE(log_alpha && exp_avg && exp_avg_sq && alpha_out && log_prob && B > 0 && step >= 1,
+             PA_ERR_INVALID, "pa_sac_alpha_step: bad argument");
+  PA_REQUIRE(!amsgrad || max_exp_avg_sq, PA_ERR_INVALID, "amsgrad needs max_exp_avg_sq");
+  pa_mlp_desc d;
+  memset(&d, 0, sizeof(d));
+  d.lr = lr; d.beta1 = beta1; d.beta2 = beta2; d.eps = eps; d.weight_decay = weight_decay;
+  d.amsgrad = amsgrad;
+  AlphaArgs a;
+  a.log_alpha = log_alpha; a.m = exp_avg; a.v = exp_avg_sq; a.vmax = max_exp_avg_sq;
+  a.alpha = alpha_out; a.logp = log_prob; a.B = B; a.target_entropy = target_entropy;
+  a.c = adam_scalars(d, step);
+  a.loss_out = loss_out;
+  hipLaunchKernelGGL(alpha_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_concat_cols(const float* left, int32_t ldl, const float* right, int32_t ldr,
+                              float* out, int32_t B, int32_t nl, int32_t nr, void* stream) {
+  PA_REQUIRE(left && right && out && B > 0 && nl > 0 && nr > 0, PA_ERR_INVALID,
+             "pa_concat_cols: bad argument");
+  const int64_t total = (int64_t)B * (nl + nr);
+  const unsigned grid = (unsigned)(ceil_div(total, 256) > 2048 ? 2048 : ceil_div(total, 256));
+  hipLaunchKernelGGL(concat_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     left, ldl, right, ldr, out, B, nl, nr);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}

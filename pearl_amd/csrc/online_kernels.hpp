@@ -60,7 +60,7 @@ struct RepackArgs {
   int do_online, do_target;
 };
 
-__global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a) {
+static __global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a) {
   const int64_t gsz = (int64_t)gridDim.x * 256;
   const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (a.do_online) {
@@ -258,7 +258,7 @@ __device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t
 // NG1/NG2/NG3: k-groups of layer 1 (K1), layer 2 (H1) and dX (H2) when known at compile time
 // (0 = run-time loop, any shape).
 template <int NG1, int NG2, int NG3>
-__global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
+static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P1 = rp_pad(a.K1), PH1 = rp_pad(a.H1), PH2 = rp_pad(a.H2);
   float* xs = smem;                          // [16][P1]

@@ -11,7 +11,13 @@ from typing import List, Optional
 
 import torch.nn as nn
 
-_ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "linear": nn.Identity}
+class _Softmax(nn.Softmax):
+    def __init__(self) -> None:
+        super().__init__(dim=-1)
+
+
+_ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "linear": nn.Identity,
+                "softmax": _Softmax}
 
 
 def mlp_block(input_dim: int, hidden_dims: Optional[List[int]], output_dim: int = 1,

@@ -39,6 +39,17 @@ class NoExploration(ExplorationModule):
         return action_space.actions[int(torch.argmax(values))]
 
 
+class PropensityExploration(ExplorationModule):
+    """Sample an action from the policy's own distribution
+    (pearl/policy_learners/exploration_modules/common/propensity_exploration.py:25-52)."""
+
+    def act(self, subjective_state: Any, action_space: Any, exploit_action: Any = None,
+            values: Optional[torch.Tensor] = None, **kwargs: Any) -> Any:
+        assert values is not None, "PropensityExploration needs the action probabilities"
+        idx = int(torch.distributions.Categorical(values).sample())
+        return action_space.actions[idx]
+
+
 class EGreedyExploration(ExplorationModule):
     def __init__(self, epsilon: float, start_epsilon: Optional[float] = None,
                  end_epsilon: Optional[float] = None, warmup_steps: Optional[int] = None) -> None:

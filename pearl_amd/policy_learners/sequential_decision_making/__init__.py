@@ -1,3 +1,7 @@
+from .actor_critic_base import ActorCriticBase
 from .deep_q_learning import DeepQLearning
+from .ppo import PPOReplayBuffer, PPOTransitionBatch, ProximalPolicyOptimization
+from .soft_actor_critic_continuous import ContinuousSoftActorCritic
 
-__all__ = ["DeepQLearning"]
+__all__ = ["ActorCriticBase", "DeepQLearning", "PPOReplayBuffer", "PPOTransitionBatch",
+           "ProximalPolicyOptimization", "ContinuousSoftActorCritic"]

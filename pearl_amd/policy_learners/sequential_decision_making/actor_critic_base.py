@@ -1,0 +1,198 @@
+"""``ActorCriticBase`` on the HIP MLP engine.
+
+Mirror of pearl/policy_learners/sequential_decision_making/actor_critic_base.py:54-564: the same
+constructor arguments, network construction (xavier-uniform actor with bias 0.01, critic through
+``make_critic``, deep-copied targets), two ``optim.AdamW(amsgrad=True)`` optimizers whose state
+dicts stay live (``get_extra_state`` / ``set_extra_state``), and the ``learn_batch`` sequencing
+(:309-366): actor loss -> actor step, critic loss -> critic step, target soft updates.
+
+What differs is where the arithmetic runs: subclasses implement ``_actor_update`` /
+``_critic_update`` with ``pa_mlp_*`` and the fused heads of libpearl_amd on flat views of the
+parameters (``FlatMlp``); nothing in the step is a torch op.
+"""
+from __future__ import annotations
+
+import copy
+from abc import abstractmethod
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn, optim
+
+from ...action_representation_modules import ActionRepresentationModule
+from ...neural_networks.common.utils import xavier_init_weights
+from ...neural_networks.common.value_networks import VanillaValueNetwork
+from ...neural_networks.sequential_decision_making.actor_networks import (ActorNetwork,
+                                                                         VanillaActorNetwork)
+from ...neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
+from ...neural_networks.sequential_decision_making.twin_critic import TwinCritic
+from ...replay_buffers.transition import TransitionBatch
+from ..exploration import ExplorationModule
+from ..policy_learner import PolicyLearner
+
+
+def make_critic(state_dim: int, hidden_dims: Optional[List[int]], use_twin_critic: bool,
+                network_type: type, action_dim: Optional[int] = None) -> nn.Module:
+    """pearl/utils/functional_utils/learning/critic_utils.py:39-100."""
+    if use_twin_critic:
+        assert action_dim is not None and hidden_dims is not None
+        return TwinCritic(state_dim=state_dim, action_dim=action_dim, hidden_dims=hidden_dims,
+                          network_type=network_type, init_fn=xavier_init_weights)
+    if network_type is VanillaQValueNetwork:
+        return network_type(state_dim=state_dim, action_dim=action_dim, hidden_dims=hidden_dims,
+                            output_dim=1)
+    if network_type is VanillaValueNetwork:
+        return network_type(input_dim=state_dim, hidden_dims=hidden_dims, output_dim=1)
+    raise NotImplementedError(f"Type {network_type} cannot be used to instantiate a critic network.")
+
+
+class ActorCriticBase(PolicyLearner):
+    def __init__(self, exploration_module: ExplorationModule, state_dim: Optional[int] = None,
+                 actor_hidden_dims: Optional[List[int]] = None, use_critic: bool = True,
+                 critic_hidden_dims: Optional[List[int]] = None, action_space: Any = None,
+                 actor_learning_rate: float = 1e-3, critic_learning_rate: float = 1e-3,
+                 history_summarization_learning_rate: float = 1e-3,
+                 actor_network_type: type = VanillaActorNetwork,
+                 critic_network_type: type = VanillaQValueNetwork,
+                 use_actor_target: bool = False, use_critic_target: bool = False,
+                 actor_soft_update_tau: float = 0.005, critic_soft_update_tau: float = 0.005,
+                 use_twin_critic: bool = False, discount_factor: float = 0.99,
+                 training_rounds: int = 1, batch_size: int = 256,
+                 is_action_continuous: bool = False, on_policy: bool = False,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 actor_network_instance: Optional[ActorNetwork] = None,
+                 critic_network_instance: Optional[nn.Module] = None,
+                 actor_optimizer: Optional[optim.Optimizer] = None,
+                 critic_optimizer: Optional[optim.Optimizer] = None,
+                 history_summarization_optimizer: Optional[optim.Optimizer] = None) -> None:
+        super().__init__(on_policy=on_policy, is_action_continuous=is_action_continuous,
+                         training_rounds=training_rounds, batch_size=batch_size,
+                         exploration_module=exploration_module,
+                         action_representation_module=action_representation_module,
+                         action_space=action_space)
+        if actor_optimizer is not None or critic_optimizer is not None:
+            raise NotImplementedError("pearl_amd actor-critic learners own their AdamW(amsgrad) "
+                                      "steps; custom optimizers are not supported")
+        if use_actor_target:
+            raise NotImplementedError("pearl_amd: actor target networks (DDPG/TD3) are not built")
+        self._state_dim = state_dim
+        self._action_space = action_space
+        self._use_actor_target = use_actor_target
+        self._use_critic_target = use_critic_target
+        self._use_twin_critic = use_twin_critic
+        self._use_critic = use_critic
+        rep = self.action_representation_module
+        if actor_network_instance is not None:
+            self._actor: nn.Module = actor_network_instance
+        else:
+            assert state_dim is not None and actor_hidden_dims is not None
+            self._actor = actor_network_type(
+                input_dim=state_dim, hidden_dims=actor_hidden_dims,
+                output_dim=(rep.representation_dim if self._is_action_continuous
+                            else rep.max_number_actions),
+                action_space=action_space)
+        self._actor.apply(xavier_init_weights)
+        self._actor_optimizer: optim.Optimizer = optim.AdamW(
+            [{"params": self._actor.parameters(), "lr": actor_learning_rate, "amsgrad": True}])
+        self._actor_soft_update_tau = actor_soft_update_tau
+        self._critic_soft_update_tau = critic_soft_update_tau
+        if self._use_critic:
+            if critic_network_instance is not None:
+                self._critic: nn.Module = critic_network_instance
+            else:
+                assert state_dim is not None and critic_hidden_dims is not None
+                self._critic = make_critic(state_dim=state_dim, action_dim=rep.representation_dim,
+                                           hidden_dims=critic_hidden_dims,
+                                           use_twin_critic=use_twin_critic,
+                                           network_type=critic_network_type)
+            self._critic_optimizer: optim.Optimizer = optim.AdamW(
+                [{"params": self._critic.parameters(), "lr": critic_learning_rate, "amsgrad": True}])
+            if self._use_critic_target:
+                self._critic_target: nn.Module = copy.deepcopy(self._critic)
+        self._discount_factor = discount_factor
+        self._history_summarization_optimizer = history_summarization_optimizer
+        self._history_summarization_learning_rate = history_summarization_learning_rate
+        self._actor_learning_rate: float = self._actor_optimizer.param_groups[0]["lr"]
+        if self._use_critic:
+            self._critic_learning_rate: float = self._critic_optimizer.param_groups[0]["lr"]
+        self._flat: Dict[str, Any] = {}   # FlatMlp handles, built lazily on the device
+
+    # ------------------------------------------------------------------ plumbing
+    def set_history_summarization_module(self, value: nn.Module) -> None:
+        if any(True for _ in value.parameters()):
+            raise NotImplementedError("pearl_amd actor-critic learners: trainable history "
+                                      "summarisation modules are not built")
+        self._history_summarization_module = value
+
+    def reset(self, action_space: Any) -> None:
+        self._action_space = action_space
+
+    def __deepcopy__(self, memo: dict) -> "ActorCriticBase":
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, {} if k == "_flat" else copy.deepcopy(v, memo))
+        return new
+
+    # ------------------------------------------------------------------ learn_batch (:309-366)
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        report = {"actor_loss": self._actor_update(batch)}
+        if self._use_critic:
+            report["critic_loss"] = self._critic_update(batch)
+        if self._use_critic_target:
+            self._update_critic_target()
+        return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in report.items()}
+
+    def preprocess_batch(self, batch: TransitionBatch) -> TransitionBatch:
+        safety = getattr(self, "safety_module", None)
+        if safety is not None and hasattr(safety, "lambda_constraint"):
+            batch.reward = batch.reward - safety.lambda_constraint * batch.cost
+        return super().preprocess_batch(batch)
+
+    @abstractmethod
+    def _actor_update(self, batch: TransitionBatch) -> torch.Tensor:
+        """Actor loss, backward and AdamW step; returns the loss as a device scalar."""
+
+    @abstractmethod
+    def _critic_update(self, batch: TransitionBatch) -> torch.Tensor:
+        """Critic loss, backward and AdamW step; returns the loss as a device scalar."""
+
+    def _update_critic_target(self) -> None:
+        raise NotImplementedError
+
+    # ------------------------------------------------------------------ checkpoints (:411-428)
+    def get_extra_state(self) -> Dict[str, Any]:
+        state = {"actor_optimizer": self._actor_optimizer.state_dict()}
+        if self._use_critic:
+            state["critic_optimizer"] = self._critic_optimizer.state_dict()
+        return state
+
+    def set_extra_state(self, state: Dict[str, Any]) -> None:
+        self._actor_optimizer.load_state_dict(state["actor_optimizer"])
+        if self._use_critic and "critic_optimizer" in state:
+            self._critic_optimizer.load_state_dict(state["critic_optimizer"])
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, ActorCriticBase):
+            diffs.append("other is not an instance of ActorCriticBase")
+        else:
+            for attr in ("_state_dim", "_use_actor_target", "_use_critic_target",
+                         "_use_twin_critic", "_use_critic", "_actor_soft_update_tau",
+                         "_critic_soft_update_tau", "_discount_factor", "_actor_learning_rate"):
+                if getattr(self, attr) != getattr(other, attr):
+                    diffs.append(f"{attr} is different: {getattr(self, attr)} vs "
+                                 f"{getattr(other, attr)}")
+            names = ["_actor"] + (["_critic"] if self._use_critic else []) + (
+                ["_critic_target"] if self._use_critic_target else [])
+            for name in names:
+                mine, theirs = getattr(self, name).state_dict(), getattr(other, name).state_dict()
+                if mine.keys() != theirs.keys():
+                    diffs.append(f"{name} is different: state_dict keys differ")
+                    continue
+                for k in mine:
+                    if not torch.allclose(mine[k].cpu().float(), theirs[k].cpu().float(),
+                                          rtol=1e-5, atol=1e-8):
+                        diffs.append(f"{name} is different: key {k} differs")
+        return "\n".join(d for d in diffs if d)

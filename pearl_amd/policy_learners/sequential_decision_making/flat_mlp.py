@@ -1,0 +1,205 @@
+"""``FlatMlp``: an nn.Module's Linear layers re-pointed into flat fp32 buffers + a ``pa_mlp`` handle.
+
+The nn.Parameters stay the source of truth for ``state_dict`` / ``compare`` / checkpoints
+(SURVEY.md §5), but their storage becomes slices of one flat buffer per role (parameters, target
+parameters, gradient, AdamW ``exp_avg`` / ``exp_avg_sq`` / ``max_exp_avg_sq``) that libpearl_amd
+reads and updates in place — the same ownership rule as ``DeepQLearning`` (deep_q_learning.py).
+
+A "layer" is a list of weight parameters stacked along the output dimension plus the matching
+list of biases: one nn.Linear normally, two for the Gaussian actor head where ``fc_mu`` and
+``fc_std`` (actor_networks.py:516-517) form ONE last layer of 2A output rows.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import nn, optim
+
+from ... import _native as N
+
+Layer = Tuple[List[nn.Parameter], List[nn.Parameter]]  # (weights stacked by rows, biases)
+
+
+def layers_of(linears: Sequence[nn.Linear]) -> List[Layer]:
+    return [([l.weight], [l.bias]) for l in linears]
+
+
+class FlatMlp:
+    def __init__(self, layers: List[Layer], optimizer: Optional[optim.Optimizer], max_batch: int,
+                 target_layers: Optional[List[Layer]] = None) -> None:
+        self.layers = layers
+        self.target_layers = target_layers
+        self.optimizer = optimizer
+        self.max_batch = int(max_batch)
+        self.dims = [int(layers[0][0][0].shape[1])] + [
+            int(sum(w.shape[0] for w in ws)) for ws, _ in layers]
+        self.handle: Optional[C.c_void_p] = None
+        self.flat: Dict[str, torch.Tensor] = {}
+        self._sig: Tuple = ()
+        self._desc_key: Tuple = ()
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        h, self.handle = self.handle, None
+        if h:
+            N.lib().pa_mlp_destroy(h)
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __deepcopy__(self, memo: dict) -> None:
+        return None  # learners rebuild their FlatMlp lazily
+
+    # ------------------------------------------------------------------ binding
+    def _params(self) -> List[nn.Parameter]:
+        return [p for ws, bs in self.layers for p in (*ws, *bs)]
+
+    def _group(self) -> dict:
+        if self.optimizer is None:
+            return dict(lr=0.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False)
+        first = self._params()[0]
+        for g in self.optimizer.param_groups:
+            if any(p is first for p in g["params"]):
+                return g
+        raise AssertionError("the optimizer does not own this network's parameters")
+
+    def adam_steps(self) -> int:
+        if self.optimizer is None:
+            return 0
+        for p in self._params():
+            st = self.optimizer.state.get(p)
+            if st and "step" in st:
+                return int(float(st["step"]))
+        return 0
+
+    def _set_adam_steps(self, n: int) -> None:
+        for p in self._params():
+            st = self.optimizer.state.get(p)
+            if st is not None and "step" in st:
+                st["step"].fill_(float(n))
+
+    def _signature(self) -> Tuple:
+        sig = []
+        for p in self._params():
+            st = self.optimizer.state.get(p, {}) if self.optimizer is not None else {}
+            sig.append((p.data_ptr(), tuple(st[k].data_ptr() if k in st else 0
+                                            for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"))))
+        if self.target_layers is not None:
+            sig.extend(p.data_ptr() for ws, bs in self.target_layers for p in (*ws, *bs))
+        return tuple(sig)
+
+    def ensure(self, batch_hint: int = 0) -> "FlatMlp":
+        p0 = self._params()[0]
+        if not p0.is_cuda:
+            N.require_gpu()
+            raise N.NativeError("pearl_amd: network parameters are on the CPU; move the learner to "
+                                "a HIP device first — there is no CPU learner path")
+        dev = p0.device
+        g = self._group()
+        max_b = max(self.max_batch, int(batch_hint), 1)
+        key = (dev.index, tuple(self.dims), max_b, g["lr"], tuple(g["betas"]), g["eps"],
+               g["weight_decay"], bool(g.get("amsgrad", False)))
+        if self.handle is not None and key != self._desc_key:
+            torch.cuda.synchronize(dev)
+            self.close()
+        if self.handle is None:
+            desc = N.MlpDesc(device=dev.index, n_layers=len(self.layers), max_batch=max_b,
+                             lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
+                             weight_decay=g["weight_decay"], amsgrad=int(bool(g.get("amsgrad", False))))
+            for i, d in enumerate(self.dims):
+                desc.dims[i] = d
+            self._desc = desc
+            h = C.c_void_p()
+            N.check(N.lib().pa_mlp_create(C.byref(h), C.byref(desc)))
+            self.handle, self._desc_key, self._sig = h, key, ()
+            self.max_batch = max_b
+        if self._sig and self._sig == self._signature():
+            return self
+        # ---- flatten
+        P = int(N.lib().pa_mlp_param_count(C.byref(self._desc)))
+        offs = (C.c_int64 * (2 * len(self.layers)))()
+        N.check(N.lib().pa_mlp_param_offsets(C.byref(self._desc), offs))
+        names = ["p", "grad"]
+        if self.optimizer is not None:
+            names += ["exp_avg", "exp_avg_sq", "max_exp_avg_sq"]
+        if self.target_layers is not None:
+            names.append("p_target")
+        flat = {k: torch.zeros(P, dtype=torch.float32, device=dev) for k in names}
+        steps = self.adam_steps()
+        with torch.no_grad():
+            for li, (ws, bs) in enumerate(self.layers):
+                for kind, plist in ((0, ws), (1, bs)):
+                    o = int(offs[2 * li + kind])
+                    tl = None
+                    if self.target_layers is not None:
+                        tl = self.target_layers[li][kind]
+                    for pi, p in enumerate(plist):
+                        n = p.numel()
+                        sl = slice(o, o + n)
+                        flat["p"][sl].copy_(p.data.reshape(-1).to(dev, torch.float32))
+                        st = (self.optimizer.state.get(p) or {}) if self.optimizer is not None else {}
+                        for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                            if k in st and k in flat:
+                                flat[k][sl].copy_(st[k].reshape(-1).to(dev, torch.float32))
+                        p.data = flat["p"][sl].view(p.shape)
+                        p.grad = flat["grad"][sl].view(p.shape)
+                        if self.optimizer is not None:
+                            self.optimizer.state[p] = {
+                                "step": torch.tensor(float(steps), dtype=torch.float32),
+                                "exp_avg": flat["exp_avg"][sl].view(p.shape),
+                                "exp_avg_sq": flat["exp_avg_sq"][sl].view(p.shape),
+                                "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(p.shape),
+                            }
+                        if tl is not None:
+                            pt = tl[pi]
+                            flat["p_target"][sl].copy_(pt.data.reshape(-1).to(dev, torch.float32))
+                            pt.data = flat["p_target"][sl].view(pt.shape)
+                        o += n
+        bufs = N.MlpBuffers(p=flat["p"].data_ptr(), p_target=N.ptr(flat.get("p_target")),
+                            grad=flat["grad"].data_ptr(), exp_avg=N.ptr(flat.get("exp_avg")),
+                            exp_avg_sq=N.ptr(flat.get("exp_avg_sq")),
+                            max_exp_avg_sq=N.ptr(flat.get("max_exp_avg_sq")))
+        N.check(N.lib().pa_mlp_bind(self.handle, C.byref(bufs)))
+        self.flat = flat
+        self._sig = self._signature()
+        return self
+
+    # ------------------------------------------------------------------ ops (all enqueue on torch's stream)
+    @property
+    def device(self) -> torch.device:
+        return self._params()[0].device
+
+    def forward(self, x: torch.Tensor, out: Optional[torch.Tensor] = None, use_target: bool = False,
+                keep: bool = False) -> torch.Tensor:
+        assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1 and x.ndim == 2
+        B = int(x.shape[0])
+        self.ensure(B)
+        if out is None:
+            out = torch.empty(B, self.dims[-1], dtype=torch.float32, device=x.device)
+        N.check(N.lib().pa_mlp_forward(self.handle, int(use_target), x.data_ptr(), x.stride(0), B,
+                                       out.data_ptr(), out.stride(0), int(keep),
+                                       N.stream_ptr(x.device)))
+        return out
+
+    def backward(self, x: torch.Tensor, d_out: torch.Tensor, want_dw: bool = True,
+                 want_dx: bool = False) -> Optional[torch.Tensor]:
+        B = int(x.shape[0])
+        d_x = torch.empty(B, self.dims[0], dtype=torch.float32, device=x.device) if want_dx else None
+        N.check(N.lib().pa_mlp_backward(self.handle, x.data_ptr(), x.stride(0), B, d_out.data_ptr(),
+                                        d_out.stride(0) if d_out.ndim == 2 else 1, int(want_dw),
+                                        N.ptr(d_x), self.dims[0], N.stream_ptr(x.device)))
+        return d_x
+
+    def adam(self) -> None:
+        step = self.adam_steps() + 1
+        N.check(N.lib().pa_mlp_adam(self.handle, step, N.stream_ptr(self.device)))
+        self._set_adam_steps(step)
+
+    def soft_update(self, tau: float) -> None:
+        self.ensure()
+        N.check(N.lib().pa_mlp_soft_update(self.handle, float(tau), N.stream_ptr(self.device)))

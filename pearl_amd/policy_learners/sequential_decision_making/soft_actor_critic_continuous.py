@@ -1,0 +1,268 @@
+"""``ContinuousSoftActorCritic`` on HIP.
+
+Mirror of pearl/policy_learners/sequential_decision_making/soft_actor_critic_continuous.py:40-268
+(twin-Q SAC with a tanh-Gaussian actor and entropy autotune), same constructor and defaults.
+
+One ``learn_batch`` (actor_critic_base.py:309-366 + :131-153 here) is, on the device:
+
+  actor:   head = actor(s) ; (a, log pi) = pa_gauss_sample(head, noise)        actor_networks.py:551-591
+           q1, q2 = critics(s || a) ; loss = mean(alpha log pi - min(q1, q2))   :208-231   (pa_sac_twin 0)
+           d a through both critics (pa_mlp_backward, input gradient only), pa_gauss_actor_grad,
+           actor backward + AdamW(amsgrad)
+  critic:  (a', log pi') = sample(actor(s'))  with the UPDATED actor            :178-206
+           y = (min(q1', q2')_target - alpha log pi') * gamma * (1 - term) + r   :155-176   (pa_sac_twin 1)
+           loss = (mse(q1, y) + mse(q2, y)) / 2 ; backward + AdamW on both critics
+  targets: critic_target <- tau critic + (1 - tau) critic_target
+  alpha:   AdamW on log_alpha with mean(-exp(log_alpha)(log pi + target_entropy))  :134-151
+
+The reparameterisation noise is the one torch-side input: ``torch.randn`` on the learner's device
+(or ``noise_source`` for parity tests, which replays the reference's draws).
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional
+
+import torch
+from torch import Tensor, nn, optim
+
+from ... import _native as N
+from ...action_representation_modules import ActionRepresentationModule
+from ...neural_networks.sequential_decision_making.actor_networks import GaussianActorNetwork
+from ...neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
+from ...replay_buffers.transition import TransitionBatch
+from ..exploration import ExplorationModule, NoExploration
+from ..policy_learner import PolicyLearner
+from .actor_critic_base import ActorCriticBase
+from .flat_mlp import FlatMlp, layers_of
+
+
+class ContinuousSoftActorCritic(ActorCriticBase):
+    def __init__(self, action_space: Any, state_dim: Optional[int] = None,
+                 actor_hidden_dims: Optional[List[int]] = None,
+                 critic_hidden_dims: Optional[List[int]] = None, actor_learning_rate: float = 1e-3,
+                 critic_learning_rate: float = 1e-3,
+                 history_summarization_learning_rate: float = 1e-3,
+                 actor_network_type: type = GaussianActorNetwork,
+                 critic_network_type: type = VanillaQValueNetwork,
+                 critic_soft_update_tau: float = 0.005,
+                 exploration_module: Optional[ExplorationModule] = None,
+                 discount_factor: float = 0.99, training_rounds: int = 100, batch_size: int = 256,
+                 entropy_coef: float = 0.2, entropy_autotune: bool = True,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 actor_network_instance: Optional[nn.Module] = None,
+                 critic_network_instance: Optional[nn.Module] = None, **kwargs: Any) -> None:
+        if actor_network_type is not GaussianActorNetwork or critic_network_type is not VanillaQValueNetwork:
+            raise NotImplementedError("pearl_amd SAC: only GaussianActorNetwork actors and "
+                                      "VanillaQValueNetwork critics have HIP kernels")
+        super().__init__(
+            state_dim=state_dim, action_space=action_space, actor_hidden_dims=actor_hidden_dims,
+            critic_hidden_dims=critic_hidden_dims, actor_learning_rate=actor_learning_rate,
+            critic_learning_rate=critic_learning_rate,
+            history_summarization_learning_rate=history_summarization_learning_rate,
+            actor_network_type=actor_network_type, critic_network_type=critic_network_type,
+            use_actor_target=False, use_critic_target=True, actor_soft_update_tau=0.0,
+            critic_soft_update_tau=critic_soft_update_tau, use_twin_critic=True,
+            exploration_module=(exploration_module if exploration_module is not None
+                                else NoExploration()),
+            discount_factor=discount_factor, training_rounds=training_rounds, batch_size=batch_size,
+            is_action_continuous=True, on_policy=False,
+            action_representation_module=action_representation_module,
+            actor_network_instance=actor_network_instance,
+            critic_network_instance=critic_network_instance, **kwargs)
+        self._entropy_autotune = entropy_autotune
+        if entropy_autotune:
+            self.register_parameter("_log_entropy", nn.Parameter(torch.zeros(1, requires_grad=True)))
+            self._entropy_optimizer: optim.Optimizer = optim.AdamW(
+                [self._log_entropy], lr=self._critic_learning_rate, amsgrad=True)
+            self.register_buffer("_entropy_coef", torch.exp(self._log_entropy).detach())
+            self.register_buffer("_target_entropy", -torch.tensor(action_space.shape[0]))
+        else:
+            self.register_buffer("_entropy_coef", torch.tensor(entropy_coef))
+        self._action_batch_log_prob_cache: Tensor = torch.tensor(0.0)
+        # parity hook: callable (B, A, device) -> standard-normal tensor; default torch.randn
+        self.noise_source: Optional[Callable[[int, int, torch.device], Tensor]] = None
+
+    # ------------------------------------------------------------------ flat views
+    def _nets(self, batch_hint: int = 0):
+        if not self._flat:
+            mb = max(self._batch_size, 1)
+            a = self._actor
+            head = ([a.fc_mu.weight, a.fc_std.weight], [a.fc_mu.bias, a.fc_std.bias])
+            self._flat["actor"] = FlatMlp(layers_of(a.trunk_layers()) + [head],
+                                          self._actor_optimizer, mb)
+            for i, (c, ct) in enumerate(((self._critic._critic_1, self._critic_target._critic_1),
+                                         (self._critic._critic_2, self._critic_target._critic_2)), 1):
+                self._flat[f"critic{i}"] = FlatMlp(layers_of(c.linear_layers()),
+                                                   self._critic_optimizer, mb,
+                                                   target_layers=layers_of(ct.linear_layers()))
+        return (self._flat["actor"].ensure(batch_hint), self._flat["critic1"].ensure(batch_hint),
+                self._flat["critic2"].ensure(batch_hint))
+
+    def _alpha_state(self, dev: torch.device) -> Dict[str, Tensor]:
+        """Device scalars of the entropy coefficient and (autotune) its AdamW state."""
+        st = self._flat.get("alpha")
+        if st is not None and st["alpha"].device == dev:
+            return st
+        st = {"alpha": self._entropy_coef.detach().to(dev, torch.float32).reshape(1).clone()}
+        if self._entropy_autotune:
+            ost = self._entropy_optimizer.state.get(self._log_entropy, {})
+            for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                st[k] = (ost[k].to(dev, torch.float32).reshape(1).clone() if k in ost
+                         else torch.zeros(1, device=dev))
+            st["step"] = int(float(ost["step"])) if "step" in ost else 0
+            if self._log_entropy.device != dev:
+                self._log_entropy.data = self._log_entropy.data.to(dev)
+            self._entropy_optimizer.state[self._log_entropy] = {
+                "step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"],
+                "exp_avg_sq": st["exp_avg_sq"], "max_exp_avg_sq": st["max_exp_avg_sq"]}
+        self._entropy_coef = st["alpha"].reshape(self._entropy_coef.shape)
+        self._flat["alpha"] = st
+        return st
+
+    def _noise(self, B: int, A: int, dev: torch.device) -> Tensor:
+        if self.noise_source is not None:
+            return self.noise_source(B, A, dev).to(dev, torch.float32).contiguous()
+        return torch.randn(B, A, device=dev, dtype=torch.float32)
+
+    def _bounds(self, dev: torch.device):
+        sp = self._actor._action_space
+        return (sp.low.to(dev, torch.float32).contiguous(), sp.high.to(dev, torch.float32).contiguous())
+
+    @staticmethod
+    def _f32(t: Tensor, dev: torch.device) -> Tensor:
+        return t.to(device=dev, dtype=torch.float32).contiguous()
+
+    def _sample(self, actor: FlatMlp, state: Tensor, xa: Tensor, keep: bool):
+        """head = actor(state); writes the sampled action into xa[:, S:]; returns (head, noise,
+        log_prob)."""
+        dev = state.device
+        B, S = state.shape
+        A = actor.dims[-1] // 2
+        head = actor.forward(state, keep=keep)
+        noise = self._noise(B, A, dev)
+        low, high = self._bounds(dev)
+        logp = torch.empty(B, dtype=torch.float32, device=dev)
+        act_view = xa[:, S:]
+        N.check(N.lib().pa_gauss_sample(head.data_ptr(), head.stride(0), noise.data_ptr(),
+                                        noise.stride(0), low.data_ptr(), high.data_ptr(), B, A,
+                                        act_view.data_ptr(), xa.stride(0), logp.data_ptr(),
+                                        N.stream_ptr(dev)))
+        return head, noise, logp
+
+    # ------------------------------------------------------------------ losses
+    def _actor_update(self, batch: TransitionBatch) -> Tensor:
+        actor, c1, c2 = self._nets(len(batch))
+        dev = actor.device
+        al = self._alpha_state(dev)
+        state = self._f32(batch.state, dev)
+        B, S = state.shape
+        A = actor.dims[-1] // 2
+        s = N.stream_ptr(dev)
+        xa = torch.empty(B, S + A, dtype=torch.float32, device=dev)
+        xa[:, :S].copy_(state)
+        head, noise, logp = self._sample(actor, state, xa, keep=True)
+        self._action_batch_log_prob_cache = logp
+        q1 = c1.forward(xa, keep=True).reshape(B)
+        q2 = c2.forward(xa, keep=True).reshape(B)
+        dq1, dq2 = torch.empty_like(q1), torch.empty_like(q2)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(N.lib().pa_sac_twin(0, q1.data_ptr(), q2.data_ptr(), logp.data_ptr(),
+                                    al["alpha"].data_ptr(), None, None, 0.0, B, dq1.data_ptr(),
+                                    dq2.data_ptr(), loss.data_ptr(), s))
+        # the reference also forms (then discards) the critics' parameter gradients here
+        # (actor_critic_base.py:342-348); only the input gradient matters
+        dx1 = c1.backward(xa, dq1, want_dw=False, want_dx=True)
+        dx2 = c2.backward(xa, dq2, want_dw=False, want_dx=True)
+        d_head = torch.empty_like(head)
+        low, high = self._bounds(dev)
+        N.check(N.lib().pa_gauss_actor_grad(
+            head.data_ptr(), head.stride(0), noise.data_ptr(), noise.stride(0), low.data_ptr(),
+            high.data_ptr(), dx1[:, S:].data_ptr(), dx2[:, S:].data_ptr(), dx1.stride(0),
+            al["alpha"].data_ptr(), B, A, d_head.data_ptr(), d_head.stride(0), s))
+        actor.backward(state, d_head, want_dw=True)
+        actor.adam()
+        return loss[0]
+
+    def _critic_update(self, batch: TransitionBatch) -> Tensor:
+        actor, c1, c2 = self._nets(len(batch))
+        dev = actor.device
+        al = self._alpha_state(dev)
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        A = actor.dims[-1] // 2
+        s = N.stream_ptr(dev)
+        # ---- Bellman target with the updated actor and the target critics (:178-206)
+        xn = torch.empty(B, S + A, dtype=torch.float32, device=dev)
+        xn[:, :S].copy_(nstate)
+        _, _, nlogp = self._sample(actor, nstate, xn, keep=False)
+        nq1 = c1.forward(xn, use_target=True).reshape(B)
+        nq2 = c2.forward(xn, use_target=True).reshape(B)
+        y = torch.empty(B, dtype=torch.float32, device=dev)
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
+        N.check(N.lib().pa_sac_twin(1, nq1.data_ptr(), nq2.data_ptr(), nlogp.data_ptr(),
+                                    al["alpha"].data_ptr(), reward.data_ptr(), term.data_ptr(),
+                                    float(self._discount_factor), B, y.data_ptr(), None, None, s))
+        # ---- (mse(q1, y) + mse(q2, y)) / 2 (critic_utils.py:170-203)
+        xq = torch.empty(B, S + A, dtype=torch.float32, device=dev)
+        act = self._f32(batch.action, dev).reshape(B, A)
+        N.check(N.lib().pa_concat_cols(state.data_ptr(), state.stride(0), act.data_ptr(),
+                                       act.stride(0), xq.data_ptr(), B, S, A, s))
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        for i, c in enumerate((c1, c2)):
+            q = c.forward(xq, keep=True).reshape(B)
+            dq = torch.empty_like(q)
+            N.check(N.lib().pa_mse_head(q.data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
+                                        dq.data_ptr(), loss.data_ptr(), s))
+            c.backward(xq, dq, want_dw=True)
+            c.adam()
+        return loss[0]
+
+    def _update_critic_target(self) -> None:
+        _, c1, c2 = self._nets()
+        c1.soft_update(self._critic_soft_update_tau)
+        c2.soft_update(self._critic_soft_update_tau)
+
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        report = super().learn_batch(batch)
+        if self._entropy_autotune:
+            actor, _, _ = self._nets()
+            dev = actor.device
+            al = self._alpha_state(dev)
+            g = self._entropy_optimizer.param_groups[0]
+            al["step"] += 1
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+            logp = self._action_batch_log_prob_cache
+            N.check(N.lib().pa_sac_alpha_step(
+                self._log_entropy.data.data_ptr(), al["exp_avg"].data_ptr(),
+                al["exp_avg_sq"].data_ptr(), al["max_exp_avg_sq"].data_ptr(),
+                al["alpha"].data_ptr(), logp.data_ptr(), int(logp.numel()),
+                float(self._target_entropy), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                g["weight_decay"], int(bool(g["amsgrad"])), al["step"], loss.data_ptr(),
+                N.stream_ptr(dev)))
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(float(al["step"]))
+            report = {**report, "entropy_coef": loss[0]}
+        return report
+
+    def act(self, subjective_state: Tensor, available_action_space: Any, exploit: bool = False) -> Any:
+        with torch.no_grad():
+            exploit_action = self._actor.sample_action(subjective_state)
+        if exploit:
+            return exploit_action
+        return self.exploration_module.act(exploit_action=exploit_action,
+                                           action_space=available_action_space,
+                                           subjective_state=subjective_state, values=None)
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, ContinuousSoftActorCritic):
+            diffs.append("other is not an instance of ContinuousSoftActorCritic")
+        else:
+            if self._entropy_autotune != other._entropy_autotune:
+                diffs.append(f"_entropy_autotune is different: {self._entropy_autotune} vs "
+                             f"{other._entropy_autotune}")
+            if not torch.allclose(self._entropy_coef.cpu(), other._entropy_coef.cpu()):
+                diffs.append(f"_entropy_coef is different: {self._entropy_coef} vs "
+                             f"{other._entropy_coef}")
+        return "\n".join(d for d in diffs if d)

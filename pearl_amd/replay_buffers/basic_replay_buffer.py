@@ -103,6 +103,7 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         self._has_curr_avail = False
         self._has_next_avail = False
         self._space_cache: dict = {}
+        self._last_idx: Optional[Tensor] = None
 
     # -- ReplayBuffer interface -------------------------------------------------
     @property
@@ -299,10 +300,22 @@ class TensorBasedReplayBuffer(ReplayBuffer):
             raise ValueError(
                 f"Can't get a batch of size {batch_size} from a replay buffer with "
                 f"only {len(self)} elements")
+        return self._gather_batch(None, int(batch_size))
+
+    @property
+    def last_indices(self) -> Tensor:
+        """Logical indices (device int64) of the most recent ``sample`` / gather."""
+        assert self._last_idx is not None
+        return self._last_idx
+
+    def _gather_batch(self, idx_dev: Optional[Tensor], batch_size: Optional[int] = None
+                      ) -> TransitionBatch:
+        """One gather launch.  idx_dev: caller-chosen logical indices on the device, or None to
+        draw ``batch_size`` of them with the configured sampler."""
         z, arena = self._layout, self._arena
         assert z is not None and arena is not None
         dev = arena.device
-        B = int(batch_size)
+        B = int(idx_dev.numel()) if idx_dev is not None else int(batch_size)
         A = z.max_actions
 
         def new(shape, dtype):
@@ -327,10 +340,14 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         out.curr_avail, out.curr_mask = N.ptr(ca), N.ptr(cm)
         out.next_avail, out.next_mask = N.ptr(na), N.ptr(nm)
         if B > 0:
-            if self.sampler == "python":
+            if idx_dev is not None:
+                arena.gather_device(idx_dev, out)
+                self._last_idx = idx_dev
+            elif self.sampler == "python":
                 arena.gather(self._draw_host_indices(B), out)
+                self._last_idx = arena._scratch(B)[:B].clone()
             else:
-                arena.sample(random.getrandbits(64), 0, B, out)
+                self._last_idx = arena.sample(random.getrandbits(64), 0, B, out)
         shape_s = (B,) + z.state_shape if len(z.state_shape) else (B, 1)
         batch = TransitionBatch(
             state=state.view(shape_s), action=action, reward=reward, terminated=term,

@@ -1,3 +1,4 @@
+from .box_action import BoxActionSpace
 from .discrete_action import DiscreteActionSpace
 
-__all__ = ["DiscreteActionSpace"]
+__all__ = ["BoxActionSpace", "DiscreteActionSpace"]

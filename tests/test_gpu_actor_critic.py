@@ -1,0 +1,128 @@
+"""GPU: PPO and continuous SAC on the HIP MLP engine against the reference-minted fixtures and the
+CPU oracle.  One-batch quantities (action probabilities, GAE, sampled actions, log-probs, Q values,
+first-step losses) are held to 1e-5 relative; multi-step trajectories to the bound the oracle meets
+against the reference after fp32 summation-order differences pass through AdamW's 1/sqrt(v)."""
+import os
+import random
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def load(kind, name):
+    return torch.load(os.path.join(GOLDEN_DIR, f"{kind}_{name}.pt"), map_location="cpu",
+                      weights_only=False)
+
+
+def dspace(n):
+    from pearl_amd import DiscreteActionSpace
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+def make_ppo(fx):
+    from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
+                           ProximalPolicyOptimization)
+    cfg = fx["config"]
+    A, N = cfg["A"], cfg["N"]
+    pl = ProximalPolicyOptimization(
+        action_space=dspace(A), state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"],
+        critic_hidden_dims=cfg["hidden"], training_rounds=cfg["rounds"], batch_size=cfg["B"],
+        epsilon=cfg["epsilon"], action_representation_module=OneHotActionTensorRepresentationModule(A))
+    pl._actor.load_state_dict(fx["actor0"])
+    pl._critic.load_state_dict(fx["critic0"])
+    rb = PPOReplayBuffer(N + 5, sampler="python")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    for i in range(N):
+        rb.push(state=fx["states"][i], action=torch.tensor([int(fx["actions"][i])]),
+                reward=float(fx["rewards"][i]), terminated=bool(fx["terminated"][i]),
+                truncated=bool(fx["truncated"][i]), curr_available_actions=dspace(A),
+                next_state=fx["states"][i + 1], next_available_actions=dspace(A),
+                max_number_actions=A)
+    return pl, rb, agent
+
+
+@pytest.mark.parametrize("name", ["tiny", "eps0", "cfg4_shape_small"])
+def test_ppo_preprocess_replay_buffer(name):
+    fx = load("ppo", name)
+    pl, rb, _ = make_ppo(fx)
+    pl.preprocess_replay_buffer(rb)
+    torch.testing.assert_close(rb.extra["action_probs"].cpu(), fx["action_probs"].view(-1), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(rb.extra["gae"].cpu(), fx["gae"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(rb.extra["lam_return"].cpu(), fx["lam_return"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny", "eps0", "cfg4_shape_small"])
+def test_ppo_learn_trajectory(name):
+    fx = load("ppo", name)
+    pl, rb, agent = make_ppo(fx)
+    random.seed(fx["learn_seed"])
+    report = pl.learn(rb)
+    torch.testing.assert_close(torch.tensor(report["actor_loss"]), fx["actor_losses"], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(torch.tensor(report["critic_loss"]), fx["critic_losses"], rtol=2e-4, atol=1e-5)
+    for k, v in pl._actor.state_dict().items():
+        torch.testing.assert_close(v.cpu(), fx["actor_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+    for k, v in pl._critic.state_dict().items():
+        torch.testing.assert_close(v.cpu(), fx["critic_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+    # on-policy: PearlAgent.learn clears the rollout afterwards
+    random.seed(1)
+    agent.learn()
+    assert len(rb) == 0
+
+
+def make_sac(fx):
+    from pearl_amd import BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic, PearlAgent
+    cfg = fx["config"]
+    pl = ContinuousSoftActorCritic(action_space=BoxActionSpace(fx["low"], fx["high"]),
+                                   state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"],
+                                   critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"])
+    pl._actor.load_state_dict(fx["actor0"])
+    pl._critic.load_state_dict(fx["critic0"])
+    pl._critic_target.load_state_dict(fx["critic_target0"])
+    PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+    return pl
+
+
+def sac_batch(fx):
+    from pearl_amd import TransitionBatch
+    return TransitionBatch(**{k: v.to(DEV) for k, v in fx["batch"].items()})
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg3_shape_small"])
+def test_sac_sampled_action_logprob_qvalues(name):
+    fx = load("sac", name)
+    pl = make_sac(fx)
+    actor, c1, c2 = pl._nets(fx["config"]["B"])
+    b = sac_batch(fx)
+    S, A = fx["config"]["S"], fx["config"]["A"]
+    pl.noise_source = lambda B, A_, dev: fx["probe"]["noise"]
+    xa = torch.empty(b.state.shape[0], S + A, device=DEV)
+    xa[:, :S].copy_(b.state)
+    _, _, logp = pl._sample(actor, b.state.contiguous(), xa, keep=False)
+    torch.testing.assert_close(xa[:, S:].cpu(), fx["probe"]["action"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(logp.cpu(), fx["probe"]["log_prob"], rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(c1.forward(xa).view(-1).cpu(), fx["probe"]["q1"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(c2.forward(xa).view(-1).cpu(), fx["probe"]["q2"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg3_shape_small"])
+def test_sac_learn_batch_trajectory(name):
+    fx = load("sac", name)
+    pl = make_sac(fx)
+    for step, ((na, nc), want) in enumerate(zip(fx["noises"], fx["reports"])):
+        seq = iter([na, nc])
+        pl.noise_source = lambda B, A, dev: next(seq)
+        got = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+        tol = 1e-5 if step == 0 else 5e-4
+        for k in want:
+            assert abs(float(got[k]) - want[k]) <= tol * max(1.0, abs(want[k])), (step, k, float(got[k]), want[k])
+    torch.testing.assert_close(pl._log_entropy.detach().cpu(), fx["log_entropy_after"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pl._entropy_coef.cpu().view(-1), fx["entropy_coef_after"].view(-1), rtol=1e-4, atol=1e-6)
+    for name_, mod, key in (("actor", pl._actor, "actor_after"), ("critic", pl._critic, "critic_after"),
+                            ("critic_target", pl._critic_target, "critic_target_after")):
+        for k, v in mod.state_dict().items():
+            torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")

@@ -1,0 +1,104 @@
+"""CPU: the actor-critic oracle (oracle/actor_critic_oracle.py) against fixtures minted by the real
+reference (oracle/make_golden_ac.py).  This is what "parity pinned" means for PPO and SAC."""
+import os
+
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+from oracle.actor_critic_oracle import PpoOracle, SacOracle
+
+PPO = ["tiny", "eps0", "cfg4_shape_small"]
+SAC = ["tiny", "cfg3_shape_small"]
+
+
+def load(kind, name):
+    return torch.load(os.path.join(GOLDEN_DIR, f"{kind}_{name}.pt"), map_location="cpu",
+                      weights_only=False)
+
+
+def onehot(actions, A):
+    return torch.nn.functional.one_hot(actions.long(), A).float()
+
+
+@pytest.mark.parametrize("name", PPO)
+def test_ppo_preprocess_gae_lambda_return_action_probs(name):
+    fx = load("ppo", name)
+    cfg = fx["config"]
+    orc = PpoOracle(fx["actor0"], fx["critic0"], cfg["A"], epsilon=cfg["epsilon"])
+    N = cfg["N"]
+    gae, ret, ap = orc.preprocess(fx["states"][:N], onehot(fx["actions"], cfg["A"]), fx["rewards"],
+                                  fx["terminated"], fx["truncated"], fx["states"][N])
+    torch.testing.assert_close(gae, fx["gae"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ret, fx["lam_return"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ap, fx["action_probs"].view(-1), rtol=1e-6, atol=1e-7)
+
+
+def test_ppo_gae_known_answer():
+    """The reference's own KAT (test/unit/with_pytorch/test_ppo.py:48-115): gamma 0.6, lambda 0.5,
+    rewards 4, 6, 5, no terminal: gae_2 = td_2, gae_1 = td_1 + 0.3 gae_2, gae_0 = td_0 + 0.3 gae_1."""
+    fx = load("ppo", "tiny")
+    cfg = fx["config"]
+    orc = PpoOracle(fx["actor0"], fx["critic0"], cfg["A"], gamma=0.6, lam=0.5)
+    states = fx["states"][:4]
+    with torch.no_grad():
+        from oracle.actor_critic_oracle import mlp
+        v = mlp(orc.critic, states).view(-1)
+    r = torch.tensor([4.0, 6.0, 5.0])
+    f = torch.zeros(3, dtype=torch.bool)
+    gae, ret, _ = orc.preprocess(states[:3], onehot(torch.tensor([0, 1, 2]), cfg["A"]), r, f, f,
+                                 states[3])
+    td = [r[i] + 0.6 * v[i + 1] - v[i] for i in range(3)]
+    want2 = td[2]
+    want1 = td[1] + 0.3 * want2
+    want0 = td[0] + 0.3 * want1
+    torch.testing.assert_close(gae, torch.stack([want0, want1, want2]), rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ret, gae + v[:3], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", PPO)
+def test_ppo_learn_trajectory(name):
+    fx = load("ppo", name)
+    cfg = fx["config"]
+    A, N = cfg["A"], cfg["N"]
+    orc = PpoOracle(fx["actor0"], fx["critic0"], A, epsilon=cfg["epsilon"])
+    oh = onehot(fx["actions"], A)
+    gae, ret, ap = orc.preprocess(fx["states"][:N], oh, fx["rewards"], fx["terminated"],
+                                  fx["truncated"], fx["states"][N])
+    la, lc = [], []
+    for idx in fx["learn_idx"]:
+        a, c = orc.learn_batch(fx["states"][:N][idx], oh[idx], ap[idx], gae[idx], ret[idx])
+        la.append(a)
+        lc.append(c)
+    torch.testing.assert_close(torch.tensor(la), fx["actor_losses"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(torch.tensor(lc), fx["critic_losses"], rtol=1e-5, atol=1e-6)
+    for i, (w, b) in enumerate(orc.actor):
+        torch.testing.assert_close(w.detach(), fx["actor_after"][f"_model.{i}.0.weight"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(b.detach(), fx["actor_after"][f"_model.{i}.0.bias"], rtol=1e-5, atol=1e-6)
+    for i, (w, b) in enumerate(orc.critic):
+        torch.testing.assert_close(w.detach(), fx["critic_after"][f"_model.{i}.0.weight"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", SAC)
+def test_sac_probe_and_trajectory(name):
+    fx = load("sac", name)
+    orc = SacOracle(fx["actor0"], fx["critic0"], fx["critic_target0"], fx["low"], fx["high"])
+    b = fx["batch"]
+    with torch.no_grad():
+        act, logp = orc.sample_action(b["state"], fx["probe"]["noise"])
+        q1 = orc.q(orc.c[0], b["state"], act)
+        q2 = orc.q(orc.c[1], b["state"], act)
+    torch.testing.assert_close(act, fx["probe"]["action"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(logp.view(-1), fx["probe"]["log_prob"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(q1, fx["probe"]["q1"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(q2, fx["probe"]["q2"], rtol=1e-5, atol=1e-6)
+    for (na, nc), want in zip(fx["noises"], fx["reports"]):
+        got = orc.learn_batch(b, na, nc)
+        for k in want:
+            assert abs(got[k] - want[k]) <= 2e-5 * max(1.0, abs(want[k])), (k, got[k], want[k])
+    torch.testing.assert_close(orc.log_alpha.detach(), fx["log_entropy_after"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(orc.head[0].detach(), fx["actor_after"]["fc_mu.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.c[0][0][0].detach(),
+                               fx["critic_after"]["_critic_1._model.0.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.ct[1][0][0],
+                               fx["critic_target_after"]["_critic_2._model.0.0.weight"], rtol=1e-5, atol=1e-7)
