@@ -306,6 +306,10 @@ typedef struct pa_mlp_desc {
   int32_t max_batch;
   double lr, beta1, beta2, eps, weight_decay; /* optim.AdamW (actor_critic_base.py:159-167) */
   int32_t amsgrad;
+  int32_t no_last_bias; /* 1: the last layer is nn.Linear(bias=False) (linear_layer_e2e,
+                           neural_linear_regression.py:84-86); its bias slot stays zero */
+  int32_t identity_layers; /* bit l set: hidden layer l has NO ReLU (the output layer of
+                              NeuralLinearRegression._nn_layers, :65-75); the last layer never has */
 } pa_mlp_desc;
 typedef struct pa_mlp_buffers {
   float* p;
@@ -324,6 +328,8 @@ int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* bufs);
 /* nn.Sequential forward; keep = 1 retains the hidden activations for pa_mlp_backward. */
 int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int32_t ldx, int32_t B,
                    float* out, int32_t ldo, int32_t keep, void* stream);
+/* kept output (after ReLU) of hidden layer `layer` of the last keep = 1 forward */
+int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int32_t ldo, void* stream);
 /* autograd of the kept forward: dW/db into bufs.grad (want_dw) and/or d_x[B, d_0] (nullable). */
 int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
                     int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx, void* stream);
@@ -373,6 +379,26 @@ int pa_sac_alpha_step(float* log_alpha, float* exp_avg, float* exp_avg_sq, float
                       float* alpha_out, const float* log_prob, int32_t B, float target_entropy,
                       double lr, double beta1, double beta2, double eps, double weight_decay,
                       int32_t amsgrad, int64_t step, float* loss_out, void* stream);
+/* NeuralLinearBandit.learn_batch loss (neural_linear_bandit.py:176-199): weighted MSE
+ * sum w (pred - y)^2 / sum w and its gradient; w may be NULL (ones); wsum_out may be NULL. */
+int pa_weighted_mse_head(const float* pred, int32_t ldp, const float* y, const float* w, int32_t B,
+                         float* d_pred, float* loss_out, float* wsum_out, void* stream);
+/* LinearRegression.learn_batch (neural_networks/contextual_bandit/linear_regression.py:192-219)
+ * in three steps so that the host can all-reduce the packed delta in between (:207-210):
+ *   pa_linreg_delta: delta[D][D+1] = [1|f]^T [ [1|f] w | y w ], delta[D*(D+1)] = sum w   (D = d+1)
+ *                    scratch: x_scratch[B*D + D], r_scratch[B*(D+1)] floats
+ *   pa_linreg_apply: A += (dA + dA^T)/2, b += db, sum_weight += dsw
+ *   pa_linreg_solve: inv_A = inv(A + lambda I) (:154-170, fp64 Gauss-Jordan, work[D*2D] doubles),
+ *                    coefs = inv_A b (:252-259); *singular_out = 1 if a pivot vanished
+ *   pa_linreg_sigma: sqrt([1|f] inv_A [1|f]^T) per row (:261-270) */
+int pa_linreg_delta(const float* features, int32_t ldf, const float* y, const float* w, int32_t B,
+                    int32_t d, float* x_scratch, float* r_scratch, float* delta_out, void* stream);
+int pa_linreg_apply(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
+                    void* stream);
+int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t d, double* work,
+                    float* inv_A_out, float* coefs_out, int32_t* singular_out, void* stream);
+int pa_linreg_sigma(const float* features, int32_t ldf, const float* inv_A, int32_t B, int32_t d,
+                    float* sigma_out, void* stream);
 /* out[B, nl + nr] = left[B, nl] || right[B, nr]   (q_value_networks.py:166-168 torch.cat) */
 int pa_concat_cols(const float* left, int32_t ldl, const float* right, int32_t ldr, float* out,
                    int32_t B, int32_t nl, int32_t nr, void* stream);

@@ -188,3 +188,50 @@ class SacOracle:
         self.alpha = torch.exp(self.log_alpha).detach()
         return {"actor_loss": actor_loss.item(), "critic_loss": critic_loss.item(),
                 "entropy_coef": ent_loss.item()}
+
+
+# --------------------------------------------------------------------------------------
+# neural-linear contextual bandit
+# --------------------------------------------------------------------------------------
+class NeuralLinearOracle:
+    """NeuralLinearBandit.learn_batch (policy_learners/contextual_bandits/neural_linear_bandit.py
+    :159-225) over NeuralLinearRegression (neural_networks/contextual_bandit/
+    neural_linear_regression.py:125-157) and LinearRegression.learn_batch / calculate_coefs /
+    calculate_sigma (linear_regression.py:192-219, :252-270)."""
+
+    def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0) -> None:
+        self.trunk = _layers(model_sd, "_nn_layers._model.")
+        self.e2e = model_sd["linear_layer_e2e.weight"].clone().requires_grad_(True)
+        d = self.e2e.shape[1]
+        self.A, self.b = torch.zeros(d + 1, d + 1), torch.zeros(d + 1)
+        self.sum_weight = torch.zeros(1)
+        self.inv_A, self.coefs = torch.zeros(d + 1, d + 1), torch.zeros(d + 1)
+        self.lam = l2_reg_lambda
+        self.opt = torch.optim.AdamW(_flat(self.trunk) + [self.e2e], lr=lr, amsgrad=True)
+
+    def features(self, x: Tensor) -> Tensor:
+        return mlp(self.trunk, x)          # the trunk's own last layer has no activation
+
+    def learn_batch(self, x: Tensor, y: Tensor, w) -> Dict[str, Tensor]:
+        f = self.features(x)
+        pred = torch.nn.functional.linear(f, self.e2e)
+        weight = torch.ones_like(y) if w is None else w
+        loss = torch.nn.functional.mse_loss(pred.view(y.shape), y, reduction="none")
+        loss = (loss * weight).sum() / weight.sum()
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        X = torch.cat((torch.ones(x.shape[0], 1), f.detach()), dim=-1)
+        wc, yc = weight.unsqueeze(-1), y.unsqueeze(-1)
+        dA = torch.matmul(X.t(), X * wc)
+        self.A += (dA + dA.t()) / 2
+        self.b += torch.matmul(X.t(), yc * wc).squeeze(-1)
+        self.sum_weight += weight.sum()
+        self.inv_A = torch.linalg.inv(self.A + self.lam * torch.eye(self.A.shape[0]))
+        self.coefs = torch.matmul(self.inv_A, self.b)
+        return {"loss": loss.detach(), "prediction": pred.detach()}
+
+    @torch.no_grad()
+    def sigma(self, x: Tensor) -> Tensor:
+        X = torch.cat((torch.ones(x.shape[0], 1), self.features(x)), dim=-1)
+        return torch.sqrt((torch.matmul(X, self.inv_A) * X).sum(-1))

@@ -162,8 +162,47 @@ def make_sac(name, cfg):
           f"-> {reports[-1]}")
 
 
+BANDIT_CONFIGS = {
+    "tiny": dict(F=7, hidden=[12, 6], B=16, steps=4),
+    "cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3),
+}
+
+
+def make_bandit(name, cfg):
+    from pearl.policy_learners.contextual_bandits.neural_linear_bandit import NeuralLinearBandit
+    F, B, K = cfg["F"], cfg["B"], cfg["steps"]
+    gen = torch.Generator().manual_seed(77)
+    torch.manual_seed(8)
+    pl = NeuralLinearBandit(feature_dim=F, hidden_dims=cfg["hidden"], batch_size=B,
+                            learning_rate=1e-3)
+    fx = {"config": dict(cfg), "model0": clone_sd(pl.model), "batches": [], "reports": []}
+    wtrue = torch.randn(F, generator=gen) / F ** 0.5
+    for k in range(K):
+        x = torch.randn(B, F, generator=gen)
+        r = torch.sigmoid(x @ wtrue) + 0.05 * torch.randn(B, generator=gen)
+        w = None if k % 2 == 0 else torch.rand(B, generator=gen) + 0.5
+        tb = TransitionBatch(state=x, action=torch.zeros(B, 1), reward=r, weight=w)
+        rep = pl.learn_batch(tb)
+        fx["batches"].append(dict(state=x, reward=r, weight=w))
+        fx["reports"].append(dict(loss=float(rep["loss"]), mu=float(rep["mu_scores"]),
+                                  prediction=rep["prediction"].clone()))
+    fx["model_after"] = clone_sd(pl.model)
+    xq = torch.randn(9, F, generator=gen)
+    with torch.no_grad():
+        fx["query"] = dict(x=xq, sigma=pl.model.calculate_sigma(xq).clone(),
+                           mu=pl.model(xq).clone())
+    path = os.path.join(OUT, f"bandit_{name}.pt")
+    torch.save(fx, path)
+    print(f"bandit {name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); losses "
+          f"{[round(r['loss'], 5) for r in fx['reports']]}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    for name, cfg in BANDIT_CONFIGS.items():
+        make_bandit(name, cfg)
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "bandit":
+        return
     for name, cfg in PPO_CONFIGS.items():
         make_ppo(name, cfg)
     for name, cfg in SAC_CONFIGS.items():

@@ -11,6 +11,7 @@ from .replay_buffers import BasicReplayBuffer, TransitionBatch  # noqa: F401
 from .policy_learners.sequential_decision_making import (ContinuousSoftActorCritic,  # noqa: F401
                                                          DeepQLearning, PPOReplayBuffer,
                                                          ProximalPolicyOptimization)
+from .policy_learners.contextual_bandits import NeuralLinearBandit, SquareCBExploration  # noqa: F401
 from .action_representation_modules import OneHotActionTensorRepresentationModule  # noqa: F401
 from .utils.instantiations.spaces import BoxActionSpace, DiscreteActionSpace  # noqa: F401
 

@@ -185,6 +185,8 @@ class MlpDesc(C.Structure):
         ("eps", C.c_double),
         ("weight_decay", C.c_double),
         ("amsgrad", C.c_int32),
+        ("no_last_bias", C.c_int32),
+        ("identity_layers", C.c_int32),
     ]
 
 
@@ -256,6 +258,7 @@ SIGNATURES = {
     "pa_mlp_destroy": (C.c_int, [_P]),
     "pa_mlp_bind": (C.c_int, [_P, C.POINTER(MlpBuffers)]),
     "pa_mlp_forward": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    "pa_mlp_copy_activation": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "pa_mlp_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P,
                                   C.c_int32, _P]),
     "pa_mlp_adam": (C.c_int, [_P, C.c_int64, _P]),
@@ -273,6 +276,11 @@ SIGNATURES = {
     "pa_sac_alpha_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_double,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                     C.c_int64, _P, _P]),
+    "pa_weighted_mse_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "pa_linreg_delta": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "pa_linreg_apply": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
+    "pa_linreg_solve": (C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P, _P]),
+    "pa_linreg_sigma": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     "pa_concat_cols": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_debug_linear": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),

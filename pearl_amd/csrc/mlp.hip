@@ -171,13 +171,27 @@ extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int
     g.C = last ? out : h->act[l]; g.ldc = last ? ldo : h->d.dims[l + 1];
     g.bias = P + h->boff[l];
     g.M = B; g.N = h->d.dims[l + 1]; g.K = h->d.dims[l];
-    g.epi = last ? EPI_BIAS : EPI_BIAS_RELU;
+    const bool relu = !last && !((h->d.identity_layers >> l) & 1);
+    g.epi = relu ? EPI_BIAS_RELU : ((last && h->d.no_last_bias) ? EPI_NONE : EPI_BIAS);
     int rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
     in = h->act[l];
     ldin = h->d.dims[l + 1];
   }
   h->kept_B = keep ? B : 0;
+  return PA_OK;
+}
+
+// Copy the kept output of hidden layer `layer` (0-based, after its ReLU) of the last keep = 1
+// forward: e.g. NeuralLinearRegression's "nn_output" (neural_linear_regression.py:140-157).
+extern "C" int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int32_t ldo,
+                                      void* stream) {
+  PA_REQUIRE(h && out && layer >= 0 && layer + 1 < h->L, PA_ERR_INVALID,
+             "pa_mlp_copy_activation: bad layer");
+  PA_REQUIRE(h->kept_B == B && B > 0, PA_ERR_INVALID, "no kept forward of batch %d", B);
+  const int w = h->d.dims[layer + 1];
+  PA_HIP(hipMemcpy2DAsync(out, (size_t)ldo * 4, h->act[layer], (size_t)w * 4, (size_t)w * 4, (size_t)B,
+                          hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
   return PA_OK;
 }
 
@@ -206,7 +220,9 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       a.p[0].dZ = dz; a.p[0].ldz = lddz;
       a.p[0].X = in; a.p[0].ldx = ldin;
       a.p[0].dW = h->bufs.grad + h->woff[l]; a.p[0].ldw = h->d.dims[l];
-      a.p[0].db = h->bufs.grad + h->boff[l];
+      // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias slot:
+      // its column sums go to scratch so AdamW never moves it
+      a.p[0].db = (l == h->L - 1 && h->d.no_last_bias) ? h->dz[(l + 1) & 1] : h->bufs.grad + h->boff[l];
       a.p[0].M = h->d.dims[l + 1]; a.p[0].N = h->d.dims[l];
       a.p[0].tiles_n = (int)ceil_div(h->d.dims[l], 32);
       a.p[0].tile0 = 0;
@@ -225,7 +241,7 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       float* dst = l > 0 ? h->dz[l & 1] : d_x;
       g.C = dst; g.ldc = l > 0 ? h->d.dims[l] : lddx;
       g.M = B; g.N = h->d.dims[l]; g.K = h->d.dims[l + 1];
-      if (l > 0) {
+      if (l > 0 && !((h->d.identity_layers >> (l - 1)) & 1)) {
         g.Hmask = h->act[l - 1]; g.ldh = h->d.dims[l];
         g.epi = EPI_MASK;
       } else {
@@ -605,6 +621,270 @@ __global__ __launch_bounds__(256) void concat_kernel(const float* __restrict__ s
 }
 
 }  // namespace
+
+
+namespace {
+
+// Weighted MSE of the neural-linear bandit (neural_linear_bandit.py:176-199):
+//   loss = sum_b w_b (pred_b - y_b)^2 / sum_b w_b;  d_pred_b = 2 w_b (pred_b - y_b) / sum w
+struct WmseArgs {
+  const float* pred; int ldp; const float* y; const float* w;  // w may be null (= ones)
+  int B;
+  float* d_pred; float* loss_out; float* wsum_out;
+};
+__global__ __launch_bounds__(256) void wmse_kernel(WmseArgs a) {
+  __shared__ float red[256];
+  float pw = 0.f, pl = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float w = a.w ? a.w[b] : 1.0f;
+    const float d = a.pred[(int64_t)b * a.ldp] - a.y[b];
+    pw += w;
+    pl += (d * d) * w;
+  }
+  const float wsum = block_sum_256(pw, red);
+  const float lsum = block_sum_256(pl, red);
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float w = a.w ? a.w[b] : 1.0f;
+    const float d = a.pred[(int64_t)b * a.ldp] - a.y[b];
+    a.d_pred[b] = (wsum != 0.f) ? (2.0f * d * w) / wsum : 0.f;
+  }
+  if (threadIdx.x == 0) {
+    a.loss_out[0] = (wsum != 0.f) ? lsum / wsum : 0.f;
+    if (a.wsum_out) a.wsum_out[0] = wsum;
+  }
+}
+
+// LinearRegression.learn_batch operands (linear_regression.py:192-219): X = [1 | nn_out] and
+// R = [X * w | y * w], so that X^T R = [delta_A (before symmetrisation) | delta_b].
+__global__ __launch_bounds__(256) void linreg_operands_kernel(const float* __restrict__ f, int ldf,
+                                                              const float* __restrict__ y,
+                                                              const float* __restrict__ w, int B,
+                                                              int d, float* __restrict__ X,
+                                                              float* __restrict__ R) {
+  const int D = d + 1;
+  const int64_t total = (int64_t)B * (D + 1);
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t b = e / (D + 1);
+    const int j = (int)(e - b * (D + 1));
+    const float wb = w ? w[b] : 1.0f;
+    if (j < D) {
+      const float x = (j == 0) ? 1.0f : f[b * ldf + (j - 1)];
+      X[b * D + j] = x;
+      R[b * (D + 1) + j] = x * wb;
+    } else {
+      R[b * (D + 1) + D] = y[b] * wb;
+    }
+  }
+}
+
+// A += (dA + dA^T) / 2; b += db; sum_weight += dsw     (linear_regression.py:204-216)
+__global__ __launch_bounds__(256) void linreg_apply_kernel(const float* __restrict__ delta, int D,
+                                                           float* __restrict__ A,
+                                                           float* __restrict__ bvec,
+                                                           float* __restrict__ sw) {
+  const int64_t total = (int64_t)D * D;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / D), j = (int)(e - (int64_t)i * D);
+    const float s = (delta[(int64_t)i * (D + 1) + j] + delta[(int64_t)j * (D + 1) + i]) / 2.0f;
+    A[e] += s;
+    if (j == 0) bvec[i] += delta[(int64_t)i * (D + 1) + D];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) sw[0] += delta[(int64_t)D * (D + 1)];
+}
+
+// inv(A + lambda I) by Gauss-Jordan elimination with partial pivoting in fp64 (one workgroup; the
+// augmented [D x 2D] system lives in a caller-provided fp64 workspace), then coefs = inv_A b.
+// torch.linalg.inv (linear_regression.py:154-170, :252-259) is LAPACK's fp32 LU; working in fp64
+// keeps the result within fp32 rounding of the exact inverse, i.e. inside LAPACK's own error.
+struct SolveArgs {
+  const float* A; const float* bvec; float lambda; int D;
+  double* work;          // [D][2D]
+  float* invA; float* coefs;
+  int* singular;         // set to 1 if a pivot vanished
+};
+__global__ __launch_bounds__(1024) void linreg_solve_kernel(SolveArgs a) {
+  __shared__ double pv[1024];
+  __shared__ int pi_[1024];
+  __shared__ int prow;
+  const int D = a.D, W = 2 * D, tid = threadIdx.x;
+  for (int e = tid; e < D * W; e += 1024) {
+    const int i = e / W, j = e - i * W;
+    double v;
+    if (j < D) v = (double)a.A[i * D + j] + (i == j ? (double)a.lambda : 0.0);
+    else v = (j - D == i) ? 1.0 : 0.0;
+    a.work[e] = v;
+  }
+  __syncthreads();
+  for (int k = 0; k < D; ++k) {
+    // pivot search in column k over rows k..D-1
+    double best = -1.0;
+    int bi = k;
+    for (int i = k + tid; i < D; i += 1024) {
+      const double v = fabs(a.work[i * W + k]);
+      if (v > best) { best = v; bi = i; }
+    }
+    pv[tid] = best; pi_[tid] = bi;
+    __syncthreads();
+    for (int s = 512; s >= 1; s >>= 1) {
+      if (tid < s) {
+        if (pv[tid + s] > pv[tid] || (pv[tid + s] == pv[tid] && pi_[tid + s] < pi_[tid])) {
+          pv[tid] = pv[tid + s]; pi_[tid] = pi_[tid + s];
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      prow = pi_[0];
+      if (!(pv[0] > 0.0)) a.singular[0] = 1;
+    }
+    __syncthreads();
+    const int p = prow;
+    if (p != k) {
+      for (int j = tid; j < W; j += 1024) {
+        const double t = a.work[k * W + j];
+        a.work[k * W + j] = a.work[p * W + j];
+        a.work[p * W + j] = t;
+      }
+    }
+    __syncthreads();
+    const double piv = a.work[k * W + k];
+    __syncthreads();
+    for (int j = tid; j < W; j += 1024) a.work[k * W + j] /= piv;
+    __syncthreads();
+    // eliminate column k from every other row
+    for (int e = tid; e < D * W; e += 1024) {
+      const int i = e / W, j = e - i * W;
+      if (i == k || j == k) continue;
+      a.work[e] -= a.work[i * W + k] * a.work[k * W + j];
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += 1024)
+      if (i != k) a.work[i * W + k] = 0.0;
+    __syncthreads();
+  }
+  for (int e = tid; e < D * D; e += 1024) {
+    const int i = e / D, j = e - i * D;
+    a.invA[e] = (float)a.work[i * W + D + j];
+  }
+  __syncthreads();
+  for (int i = tid; i < D; i += 1024) {
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += a.work[i * W + D + j] * (double)a.bvec[j];
+    a.coefs[i] = (float)s;
+  }
+}
+
+// sigma[b] = sqrt([1 | f_b] inv_A [1 | f_b]^T)      (linear_regression.py:261-270)
+__global__ __launch_bounds__(256) void linreg_sigma_kernel(const float* __restrict__ f, int ldf,
+                                                           const float* __restrict__ invA, int B,
+                                                           int d, float* __restrict__ sigma) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int D = d + 1;
+  float acc = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    float t = 0.f;
+    for (int i = 0; i < D; ++i) {
+      const float xi = (i == 0) ? 1.0f : f[(int64_t)b * ldf + (i - 1)];
+      t += xi * invA[(int64_t)i * D + j];
+    }
+    const float xj = (j == 0) ? 1.0f : f[(int64_t)b * ldf + (j - 1)];
+    acc += t * xj;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+  if (lane == 0) sigma[b] = sqrtf(acc);
+}
+
+}  // namespace
+
+extern "C" int pa_weighted_mse_head(const float* pred, int32_t ldp, const float* y, const float* w,
+                                    int32_t B, float* d_pred, float* loss_out, float* wsum_out,
+                                    void* stream) {
+  PA_REQUIRE(pred && y && d_pred && loss_out && B > 0, PA_ERR_INVALID,
+             "pa_weighted_mse_head: bad argument");
+  WmseArgs a;
+  a.pred = pred; a.ldp = ldp; a.y = y; a.w = w; a.B = B; a.d_pred = d_pred; a.loss_out = loss_out;
+  a.wsum_out = wsum_out;
+  hipLaunchKernelGGL(wmse_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* y, const float* w,
+                               int32_t B, int32_t d, float* x_scratch, float* r_scratch,
+                               float* delta_out, void* stream) {
+  PA_REQUIRE(features && y && x_scratch && r_scratch && delta_out && B > 0 && d > 0, PA_ERR_INVALID,
+             "pa_linreg_delta: bad argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int D = d + 1;
+  const int64_t total = (int64_t)B * (D + 1);
+  const unsigned grid = (unsigned)(ceil_div(total, 256) > 2048 ? 2048 : ceil_div(total, 256));
+  hipLaunchKernelGGL(linreg_operands_kernel, dim3(grid), dim3(256), 0, s, features, ldf, y, w, B, d,
+                     x_scratch, r_scratch);
+  PA_LAUNCH_CHECK();
+  // X^T R = [delta_A | delta_b] ([D][D+1]); the "bias" output of the kernel (column sums of X) is
+  // written behind it and its first entry (the ones column sum) is NOT the weight sum, so the
+  // weight sum rides as delta_out[D * (D + 1)] = sum_b R[b][0] = sum_b w_b: it is column 0 of
+  // row 0 of delta_A as well; copy it in the apply kernel instead.
+  DwArgs a;
+  memset(&a, 0, sizeof(a));
+  a.nprob = 1;
+  a.p[0].dZ = x_scratch; a.p[0].ldz = D;
+  a.p[0].X = r_scratch; a.p[0].ldx = D + 1;
+  a.p[0].dW = delta_out; a.p[0].ldw = D + 1;
+  a.p[0].db = x_scratch + (int64_t)B * D;   // scratch tail: D floats
+  a.p[0].M = D; a.p[0].N = D + 1;
+  a.p[0].tiles_n = (int)ceil_div(D + 1, 32);
+  a.p[0].tile0 = 0;
+  a.p[0].kind = 2;
+  a.total_tiles = (int)ceil_div(D, 32) * a.p[0].tiles_n;
+  a.B = B;
+  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
+  PA_LAUNCH_CHECK();
+  // delta_A[0][0] = sum_b 1 * 1 * w_b = the weight sum of the batch
+  PA_HIP(hipMemcpyAsync(delta_out + (int64_t)D * (D + 1), delta_out, sizeof(float),
+                        hipMemcpyDeviceToDevice, s));
+  return PA_OK;
+}
+
+extern "C" int pa_linreg_apply(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
+                               void* stream) {
+  PA_REQUIRE(delta && A && b && sum_weight && d > 0, PA_ERR_INVALID, "pa_linreg_apply: bad argument");
+  const int D = d + 1;
+  hipLaunchKernelGGL(linreg_apply_kernel, dim3((unsigned)ceil_div((int64_t)D * D, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), delta, D, A, b, sum_weight);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t d,
+                               double* work, float* inv_A_out, float* coefs_out, int32_t* singular_out,
+                               void* stream) {
+  PA_REQUIRE(A && b && work && inv_A_out && coefs_out && singular_out && d > 0, PA_ERR_INVALID,
+             "pa_linreg_solve: bad argument");
+  SolveArgs a;
+  a.A = A; a.bvec = b; a.lambda = l2_reg_lambda; a.D = d + 1; a.work = work; a.invA = inv_A_out;
+  a.coefs = coefs_out; a.singular = singular_out;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipMemsetAsync(singular_out, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(linreg_solve_kernel, dim3(1), dim3(1024), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_linreg_sigma(const float* features, int32_t ldf, const float* inv_A, int32_t B,
+                               int32_t d, float* sigma_out, void* stream) {
+  PA_REQUIRE(features && inv_A && sigma_out && B > 0 && d > 0, PA_ERR_INVALID,
+             "pa_linreg_sigma: bad argument");
+  hipLaunchKernelGGL(linreg_sigma_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), features, ldf, inv_A, B, d, sigma_out);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
 
 extern "C" int pa_softmax_action_prob(const float* logits, int32_t ldl, const float* action_rep,
                                       int32_t lda, int32_t B, int32_t A, float* probs_out,

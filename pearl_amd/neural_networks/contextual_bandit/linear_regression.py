@@ -1,0 +1,92 @@
+"""LinUCB regression layer and the neural-linear model
+(pearl/neural_networks/contextual_bandit/linear_regression.py:21-290,
+ neural_linear_regression.py:25-157): containers of the buffers / parameters with the reference's
+names (``_A``, ``_b``, ``_sum_weight``, ``_inv_A``, ``_coefs``; ``_nn_layers``,
+``linear_layer_e2e``) so ``state_dict`` round-trips.  The learning step runs in libpearl_amd
+(``pa_linreg_delta`` / ``_apply`` / ``_solve``); the torch expressions below serve act-time."""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ..common.utils import _ACTIVATIONS
+from ..common.value_networks import VanillaValueNetwork
+
+
+class LinearRegression(nn.Module):
+    def __init__(self, feature_dim: int, l2_reg_lambda: float = 1.0, gamma: float = 1.0,
+                 force_pinv: bool = False) -> None:
+        super().__init__()
+        assert 0 < gamma <= 1, f"gamma should be in (0, 1]. Got gamma={gamma} instead"
+        if force_pinv:
+            raise NotImplementedError("pearl_amd LinearRegression: force_pinv is not built")
+        self._feature_dim = feature_dim
+        self.gamma, self.l2_reg_lambda, self.force_pinv = gamma, l2_reg_lambda, force_pinv
+        self.register_buffer("_A", torch.zeros(feature_dim + 1, feature_dim + 1))
+        self.register_buffer("_b", torch.zeros(feature_dim + 1))
+        self.register_buffer("_sum_weight", torch.zeros(1))
+        self.register_buffer("_inv_A", torch.zeros(feature_dim + 1, feature_dim + 1))
+        self.register_buffer("_coefs", torch.zeros(feature_dim + 1))
+
+    @property
+    def A(self) -> Tensor:
+        return self._A + self.l2_reg_lambda * torch.eye(self._feature_dim + 1, device=self._A.device)
+
+    @property
+    def coefs(self) -> Tensor:
+        return self._coefs
+
+    @staticmethod
+    def append_ones(x: Tensor) -> Tensor:
+        ones = torch.ones_like(torch.select(x, dim=-1, index=0).unsqueeze(-1))
+        return torch.cat((ones, x), dim=-1)
+
+    def forward(self, x: Tensor) -> Tensor:
+        batch_size = x.shape[0]
+        x = self.append_ones(x.reshape(-1, x.shape[-1]))
+        return torch.matmul(x, self.coefs.t()).reshape(batch_size, -1)
+
+    def calculate_sigma(self, x: Tensor) -> Tensor:
+        batch_size = x.shape[0]
+        x = self.append_ones(x.reshape(-1, x.shape[-1]))
+        return torch.sqrt((torch.matmul(x, self._inv_A) * x).sum(-1).unsqueeze(-1)).reshape(batch_size, -1)
+
+
+class NeuralLinearRegression(nn.Module):
+    def __init__(self, feature_dim: int, hidden_dims: List[int], l2_reg_lambda_linear: float = 1.0,
+                 gamma: float = 1.0, force_pinv: bool = False,
+                 output_activation_name: str = "linear", nn_e2e: bool = True, **mlp_kwargs) -> None:
+        super().__init__()
+        if not nn_e2e:
+            raise NotImplementedError("pearl_amd NeuralLinearRegression: nn_e2e=False is not built")
+        if output_activation_name != "linear":
+            raise NotImplementedError("pearl_amd NeuralLinearRegression: only the linear output "
+                                      "activation (MSE loss) has HIP kernels")
+        self._feature_dim = feature_dim
+        self._nn_layers = VanillaValueNetwork(input_dim=feature_dim, hidden_dims=hidden_dims,
+                                              output_dim=hidden_dims[-1], **mlp_kwargs)
+        self._linear_regression_layer = LinearRegression(feature_dim=hidden_dims[-1],
+                                                         l2_reg_lambda=l2_reg_lambda_linear,
+                                                         gamma=gamma, force_pinv=force_pinv)
+        self.output_activation: nn.Module = _ACTIVATIONS[output_activation_name]()
+        self.linear_layer_e2e = nn.Linear(in_features=hidden_dims[-1], out_features=1, bias=False)
+        self.nn_e2e = nn_e2e
+
+    def forward_with_intermediate_values(self, x: Tensor) -> Dict[str, Tensor]:
+        batch_size = x.shape[0]
+        nn_output = self._nn_layers(x.reshape(-1, x.shape[-1]))
+        out = self.linear_layer_e2e(nn_output)
+        return {"pred_label_pre_activation": out.reshape(batch_size, -1),
+                "pred_label": self.output_activation(out).reshape(batch_size, -1),
+                "nn_output": nn_output}
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.forward_with_intermediate_values(x)["pred_label"]
+
+    def calculate_sigma(self, x: Tensor) -> Tensor:
+        batch_size = x.shape[0]
+        return self._linear_regression_layer.calculate_sigma(
+            self._nn_layers(x.reshape(-1, x.shape[-1]))).reshape(batch_size, -1)

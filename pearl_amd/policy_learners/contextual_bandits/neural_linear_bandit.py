@@ -1,0 +1,219 @@
+"""``NeuralLinearBandit`` (+ ``SquareCBExploration``) on HIP.
+
+Mirror of pearl/policy_learners/contextual_bandits/neural_linear_bandit.py:44-330 and
+.../exploration_modules/contextual_bandits/squarecb_exploration.py:22-115.
+
+One ``learn_batch`` (:159-225) on the device:
+  features = _nn_layers(x) ; mu = linear_layer_e2e(features)               pa_mlp_forward (the e2e layer
+                                                                             is the bias-free last layer)
+  loss = sum w (mu - r)^2 / sum w ; backward ; AdamW(amsgrad)                pa_weighted_mse_head, pa_mlp_*
+  A += sym([1|f]^T ([1|f] w)) ; b += [1|f]^T (r w) ; sum_weight += sum w     pa_linreg_delta / _apply
+      (one packed all-reduce of the deltas when torch.distributed is up — the reference's three
+       all_reduce calls, linear_regression.py:207-210)
+  inv_A = inv(A + lambda I) ; coefs = inv_A b                                 pa_linreg_solve
+The regression operates on the features computed BEFORE the optimizer step, as in the reference.
+``act`` / SquareCB sampling are act-time (outside the learner path) and stay torch expressions.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, optim
+from torch.distributions import Categorical
+
+from ... import _native as N
+from ...action_representation_modules import ActionRepresentationModule
+from ...neural_networks.contextual_bandit.linear_regression import NeuralLinearRegression
+from ...replay_buffers.transition import TransitionBatch
+from ..exploration import ExplorationModule
+from ..policy_learner import PolicyLearner
+from ..sequential_decision_making.flat_mlp import FlatMlp, layers_of
+
+
+class SquareCBExploration(ExplorationModule):
+    """p_a = 1 / (K + gamma * gap_a) for a != argmax, the arg-max takes the remainder
+    (squarecb_exploration.py:59-115, including its whole-matrix ``complementary_sum``)."""
+
+    def __init__(self, gamma: float, reward_lb: float = 0.0, reward_ub: float = 1.0,
+                 clamp_values: bool = False) -> None:
+        super().__init__()
+        self._gamma, self.reward_lb, self.reward_ub = gamma, reward_lb, reward_ub
+        self.clamp_values = clamp_values
+
+    def clamp(self, values: Tensor) -> Tensor:
+        return torch.clamp(values, min=self.reward_lb, max=self.reward_ub) if self.clamp_values else values
+
+    def get_unnormalize_prob(self, empirical_gaps: Tensor, max_val: Any, action_num: int) -> Tensor:
+        return torch.div(1.0, action_num + self._gamma * empirical_gaps)
+
+    def act(self, subjective_state: Any, action_space: Any, values: Optional[Tensor] = None,
+            representation: Any = None, exploit_action: Any = None,
+            action_availability_mask: Any = None, **kwargs: Any) -> Tensor:
+        assert values is not None
+        values = self.clamp(values.view(-1, action_space.n))
+        max_val, max_indices = torch.max(values, dim=1)
+        empirical_gaps = max_val - values
+        selected = torch.zeros((values.size(0),), dtype=torch.int)
+        prob = self.get_unnormalize_prob(empirical_gaps, max_val, action_space.n)
+        for i in range(values.size(0)):
+            prob[i, max_indices[i]] = 0.0
+            prob[i, max_indices[i]] = 1.0 - torch.sum(prob)
+            selected[i] = Categorical(prob[i, :]).sample()
+        return selected.squeeze(-1)
+
+
+class NeuralLinearBandit(PolicyLearner):
+    def __init__(self, feature_dim: int, hidden_dims: List[int],
+                 exploration_module: Optional[ExplorationModule] = None,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 training_rounds: int = 100, batch_size: int = 128, learning_rate: float = 0.0003,
+                 l2_reg_lambda_linear: float = 1.0, gamma: float = 1.0,
+                 apply_discounting_interval: float = 0.0, force_pinv: bool = False,
+                 state_features_only: bool = True, loss_type: str = "mse",
+                 output_activation_name: str = "linear", nn_e2e: bool = True,
+                 separate_uncertainty: bool = False, **mlp_kwargs: Any) -> None:
+        assert len(hidden_dims) >= 1
+        if str(getattr(loss_type, "value", loss_type)).lower() != "mse":
+            raise NotImplementedError("pearl_amd NeuralLinearBandit: only the MSE loss has HIP kernels")
+        super().__init__(training_rounds=training_rounds, batch_size=batch_size,
+                         exploration_module=exploration_module, on_policy=False,
+                         is_action_continuous=False,
+                         action_representation_module=action_representation_module)
+        self._feature_dim = feature_dim
+        self.model = NeuralLinearRegression(
+            feature_dim=feature_dim, hidden_dims=hidden_dims,
+            l2_reg_lambda_linear=l2_reg_lambda_linear, gamma=gamma, force_pinv=force_pinv,
+            output_activation_name=output_activation_name, nn_e2e=nn_e2e, **mlp_kwargs)
+        self._optimizer: optim.Optimizer = optim.AdamW(self.model.parameters(), lr=learning_rate,
+                                                       amsgrad=True)
+        self._state_features_only = state_features_only
+        self.apply_discounting_interval = apply_discounting_interval
+        self.last_sum_weight_when_discounted = 0.0
+        self.separate_uncertainty = separate_uncertainty
+        self._flat: Dict[str, Any] = {}
+
+    @property
+    def feature_dim(self) -> int:
+        return self._feature_dim
+
+    @property
+    def optimizer(self) -> optim.Optimizer:
+        return self._optimizer
+
+    def set_history_summarization_module(self, value: torch.nn.Module) -> None:
+        if any(True for _ in value.parameters()):
+            raise NotImplementedError("trainable history summarisation modules are not built")
+        self._history_summarization_module = value
+
+    def _net(self, batch_hint: int = 0) -> FlatMlp:
+        if "net" not in self._flat:
+            layers = layers_of(self.model._nn_layers.linear_layers())
+            layers.append(([self.model.linear_layer_e2e.weight], []))     # bias-free last layer
+            # the trunk's own output layer (index len-2) has no activation (last_activation=None)
+            self._flat["net"] = FlatMlp(layers, self._optimizer, max(self._batch_size, 1),
+                                        identity_layers=1 << (len(layers) - 2))
+        return self._flat["net"].ensure(batch_hint)
+
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        net = self._net(len(batch))
+        dev = net.device
+        lib, s = N.lib(), N.stream_ptr(dev)
+        x = batch.state if self._state_features_only else torch.cat([batch.state, batch.action], dim=1)
+        x = x.to(dev, torch.float32).contiguous()
+        B = x.shape[0]
+        y = batch.reward.to(dev, torch.float32).reshape(B).contiguous()
+        w = None if batch.weight is None else batch.weight.to(dev, torch.float32).reshape(B).contiguous()
+        pred = net.forward(x, keep=True)                       # (B, 1); features stay in the engine
+        # features of this forward (before the optimizer step) feed the regression: copy them out
+        lr = self.model._linear_regression_layer
+        d = lr._feature_dim
+        D = d + 1
+        feats = torch.empty(B, d, dtype=torch.float32, device=dev)
+        N.check(lib.pa_mlp_copy_activation(net.handle, len(net.layers) - 2, B, feats.data_ptr(),
+                                           feats.stride(0), s))
+        dpred = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        wsum = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(lib.pa_weighted_mse_head(pred.data_ptr(), pred.stride(0), y.data_ptr(), N.ptr(w), B,
+                                         dpred.data_ptr(), loss.data_ptr(), wsum.data_ptr(), s))
+        if w is None or float(wsum.item()) != 0.0:     # all-zero weights: skip the optimizer (:171-175)
+            net.backward(x, dpred, want_dw=True)
+            net.adam()
+        # ---- LinUCB update on the detached features
+        xs = torch.empty(B * D + D, dtype=torch.float32, device=dev)
+        rs = torch.empty(B * (D + 1), dtype=torch.float32, device=dev)
+        delta = torch.empty(D * (D + 1) + 1, dtype=torch.float32, device=dev)
+        N.check(lib.pa_linreg_delta(feats.data_ptr(), feats.stride(0), y.data_ptr(), N.ptr(w), B, d,
+                                    xs.data_ptr(), rs.data_ptr(), delta.data_ptr(), s))
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(delta)          # delta_A | delta_b | delta_sum_weight in ONE message
+        for name in ("_A", "_b", "_sum_weight", "_inv_A", "_coefs"):
+            buf = getattr(lr, name)
+            if buf.device != dev or not buf.is_contiguous():
+                setattr(lr, name, buf.to(dev).contiguous())
+        N.check(lib.pa_linreg_apply(delta.data_ptr(), d, lr._A.data_ptr(), lr._b.data_ptr(),
+                                    lr._sum_weight.data_ptr(), s))
+        self._solve(lr, dev)
+        self._maybe_apply_discounting()
+        p = pred.detach().reshape(B, -1)
+        return {"label": y, "prediction": p, "weight": w if w is not None else torch.ones_like(y),
+                "loss": loss[0], "mu_scores": p.mean()}
+
+    def _solve(self, lr: Any, dev: torch.device) -> None:
+        d = lr._feature_dim
+        D = d + 1
+        work = torch.empty(D * 2 * D, dtype=torch.float64, device=dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        N.check(N.lib().pa_linreg_solve(lr._A.data_ptr(), lr._b.data_ptr(), float(lr.l2_reg_lambda), d,
+                                        work.data_ptr(), lr._inv_A.data_ptr(), lr._coefs.data_ptr(),
+                                        flag.data_ptr(), N.stream_ptr(dev)))
+
+    def _maybe_apply_discounting(self) -> None:
+        lr = self.model._linear_regression_layer
+        if self.apply_discounting_interval > 0:
+            sw = float(lr._sum_weight.item())
+            if sw - self.last_sum_weight_when_discounted >= self.apply_discounting_interval:
+                if lr.gamma < 1:
+                    lr._A *= lr.gamma
+                    lr._b *= lr.gamma
+                self._solve(lr, lr._A.device)
+                self.last_sum_weight_when_discounted = sw
+
+    def act(self, subjective_state: Tensor, available_action_space: Any,
+            action_availability_mask: Optional[Tensor] = None, exploit: bool = False) -> Any:
+        feats = self._concat_actions(subjective_state, available_action_space)
+        with torch.no_grad():
+            ret = self.model.forward_with_intermediate_values(feats)
+        return self.exploration_module.act(
+            subjective_state=ret["nn_output"], action_space=available_action_space,
+            values=ret["pred_label_pre_activation"], action_availability_mask=action_availability_mask,
+            representation=self.model._linear_regression_layer)
+
+    def _concat_actions(self, state: Tensor, space: Any) -> Tensor:
+        """utils/functional_utils/learning/action_utils.py concatenate_actions_to_state."""
+        if state.ndim == 1:
+            state = state.unsqueeze(0)
+        B, n = state.shape[0], space.n
+        exp = state.unsqueeze(1).repeat(1, n, 1)
+        if self._state_features_only:
+            return exp
+        acts = self.action_representation_module(space.actions_batch.to(state)).unsqueeze(0).repeat(B, 1, 1)
+        return torch.cat([exp, acts], dim=2)
+
+    def get_scores(self, subjective_state: Tensor, action_space_to_score: Any,
+                   exploit: bool = False) -> Tensor:
+        raise NotImplementedError("pearl_amd NeuralLinearBandit.get_scores: use the reference's "
+                                  "score-based exploration modules at act time")
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, NeuralLinearBandit):
+            diffs.append("other is not an instance of NeuralLinearBandit")
+        else:
+            a, b = self.model.state_dict(), other.model.state_dict()
+            for k in a:
+                if k not in b or not torch.allclose(a[k].cpu(), b[k].cpu(), rtol=1e-5, atol=1e-8):
+                    diffs.append(f"model is different: key {k} differs")
+        return "\n".join(d for d in diffs if d)

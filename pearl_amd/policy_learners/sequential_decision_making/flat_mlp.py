@@ -28,8 +28,9 @@ def layers_of(linears: Sequence[nn.Linear]) -> List[Layer]:
 
 class FlatMlp:
     def __init__(self, layers: List[Layer], optimizer: Optional[optim.Optimizer], max_batch: int,
-                 target_layers: Optional[List[Layer]] = None) -> None:
+                 target_layers: Optional[List[Layer]] = None, identity_layers: int = 0) -> None:
         self.layers = layers
+        self.identity_layers = int(identity_layers)   # bit l: hidden layer l has no ReLU
         self.target_layers = target_layers
         self.optimizer = optimizer
         self.max_batch = int(max_batch)
@@ -110,7 +111,9 @@ class FlatMlp:
         if self.handle is None:
             desc = N.MlpDesc(device=dev.index, n_layers=len(self.layers), max_batch=max_b,
                              lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
-                             weight_decay=g["weight_decay"], amsgrad=int(bool(g.get("amsgrad", False))))
+                             weight_decay=g["weight_decay"], amsgrad=int(bool(g.get("amsgrad", False))),
+                             no_last_bias=int(len(self.layers[-1][1]) == 0),
+                             identity_layers=self.identity_layers)
             for i, d in enumerate(self.dims):
                 desc.dims[i] = d
             self._desc = desc

@@ -102,3 +102,19 @@ def test_sac_probe_and_trajectory(name):
                                fx["critic_after"]["_critic_1._model.0.0.weight"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(orc.ct[1][0][0],
                                fx["critic_target_after"]["_critic_2._model.0.0.weight"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["tiny", "cfg5_shape_small"])
+def test_neural_linear_bandit_trajectory(name):
+    from oracle.actor_critic_oracle import NeuralLinearOracle
+    fx = load("bandit", name)
+    orc = NeuralLinearOracle(fx["model0"], lr=1e-3)
+    for b, want in zip(fx["batches"], fx["reports"]):
+        got = orc.learn_batch(b["state"], b["reward"], b["weight"])
+        assert abs(float(got["loss"]) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
+        torch.testing.assert_close(got["prediction"], want["prediction"], rtol=1e-5, atol=1e-6)
+    after = fx["model_after"]
+    torch.testing.assert_close(orc.A, after["_linear_regression_layer._A"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(orc.b, after["_linear_regression_layer._b"], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(orc.coefs, after["_linear_regression_layer._coefs"], rtol=1e-3, atol=1e-5)
+    torch.testing.assert_close(orc.sigma(fx["query"]["x"]), fx["query"]["sigma"].view(-1), rtol=1e-4, atol=1e-6)
