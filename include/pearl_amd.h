@@ -273,8 +273,33 @@ typedef struct pa_learn_args {
   uint64_t offset0;            /* Philox counter base (advance by `rounds` per call)    */
   float* losses_out;
   const int64_t* idx_host;     /* optional parity mode: [rounds, batch_size] logical indices */
+  /* Data parallelism (no reference counterpart).  grad_world > 1: gradients are
+   * pre-scaled by 1/grad_world and, every round, the library calls
+   *   allreduce_start(ctx, grad, n, stream)  — enqueue a SUM all-reduce of grad[n] ordered after
+   *                                            the work already on `stream` (RCCL over xGMI)
+   *   allreduce_wait(ctx, stream)            — make `stream` wait for that all-reduce
+   * with the NEXT round's target-network pass enqueued in between, so the exchange overlaps
+   * compute; AdamW runs after the wait.  The library itself links no communication library: the
+   * host passes the hooks (torch.distributed in pearl_amd, ncclAllReduce in a native host). */
+  int32_t grad_world;
+  int (*allreduce_start)(void* ctx, float* grad, int64_t n, void* stream);
+  int (*allreduce_wait)(void* ctx, void* stream);
+  void* allreduce_ctx;
 } pa_learn_args;
 int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream);
+
+/* Native all-reduce hooks for pa_learn_args, backed by RCCL (ncclAllReduce over xGMI) resolved at
+ * run time with dlopen (the library has no link-time dependency on it).  One communicator per
+ * process / GPU: rank 0 calls pa_comm_unique_id, the host broadcasts the 128 bytes to the other
+ * ranks (torch.distributed in pearl_amd), every rank calls pa_comm_create.  Pass
+ * pa_comm_allreduce_start / pa_comm_allreduce_wait and the pa_comm* as allreduce_ctx. */
+typedef struct pa_comm pa_comm;
+int pa_comm_available(void);
+int pa_comm_unique_id(void* id128_out);
+int pa_comm_create(pa_comm** out, int32_t device, int32_t world, int32_t rank, const void* id128);
+int pa_comm_destroy(pa_comm* c);
+int pa_comm_allreduce_start(void* comm, float* buf, int64_t n, void* stream);
+int pa_comm_allreduce_wait(void* comm, void* stream);
 
 /* Kernel timing of the last pa_dqn_learn / pa_dqn_step when timing is enabled
  * (HIP events on the launch stream; used by bench.py's roofline block). */

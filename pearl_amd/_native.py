@@ -213,7 +213,15 @@ class LearnArgs(C.Structure):
         ("offset0", C.c_uint64),
         ("losses_out", C.c_void_p),
         ("idx_host", C.c_void_p),
+        ("grad_world", C.c_int32),
+        ("allreduce_start", C.c_void_p),
+        ("allreduce_wait", C.c_void_p),
+        ("allreduce_ctx", C.c_void_p),
     ]
+
+
+ALLREDUCE_START_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+ALLREDUCE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
 # name -> (restype, argtypes); also the export list the CPU test suite checks
@@ -248,6 +256,12 @@ SIGNATURES = {
     "pa_dqn_step": (C.c_int, [_P, C.POINTER(DqnBatch), C.c_int32, C.c_int64, C.c_int32, _P, _P]),
     "pa_dqn_apply": (C.c_int, [_P, C.c_int64, _P]),
     "pa_dqn_learn": (C.c_int, [_P, _P, C.POINTER(LearnArgs), _P]),
+    "pa_comm_available": (C.c_int, []),
+    "pa_comm_unique_id": (C.c_int, [_P]),
+    "pa_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, _P]),
+    "pa_comm_destroy": (C.c_int, [_P]),
+    "pa_comm_allreduce_start": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "pa_comm_allreduce_wait": (C.c_int, [_P, _P]),
     "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
     "pa_dqn_get_timing": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_dqn_get_timing_units": (C.c_int, [_P, C.c_char_p, C.POINTER(C.c_int64)]),

@@ -199,13 +199,17 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows) {
 // max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
 // deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
 // U must already be in h->U.
-int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+struct TargetView {
+  int64_t u_row0 = 0;   // first row of h->U this launch reads (a round inside a window)
+};
+int run_target_fused_view(pa_dqn* h, const pa_dqn_batch* b, const TargetView& view, float* next_v,
+                          float* y, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, h->bufs.q_target);
   ScopedTimer tm(h, "target", s, 1, 4, b->B);
   TargetArgs a;
   memset(&a, 0, sizeof(a));
-  a.U = h->U; a.ldu = d.hidden1;
+  a.U = h->U + view.u_row0 * d.hidden1; a.ldu = d.hidden1;
   a.feat = b->next_avail_rep;
   a.feat_bstride = b->next_avail_bcast ? 0 : (int64_t)b->A * d.action_dim;
   a.mask = b->next_mask;
@@ -219,6 +223,9 @@ int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, 
   a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
   a.bpw = T_ROWS / b->A;
   return launch_target(a, s);
+}
+int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+  return run_target_fused_view(h, b, TargetView(), next_v, y, s);
 }
 
 PackedW packed(pa_dqn* h) {
@@ -374,16 +381,28 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   return PA_OK;
 }
 
-// Stand-alone AdamW on bufs.grad (data-parallel path, after the all-reduce).
-int run_adamw(pa_dqn* h, int64_t step, hipStream_t s) {
+// AdamW on bufs.grad after the data-parallel all-reduce: same optimizer tail as the fused
+// weight-gradient kernel (fragment-major copies, optional soft update for the next step).
+int run_adamw(pa_dqn* h, int64_t step, int soft_next, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
   PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)", (long long)step);
   ScopedTimer tm(h, "adamw", s);
-  AdamArgs a;
+  AdamDqnArgs a;
   memset(&a, 0, sizeof(a));
-  a.st = adam_state(h); a.g = h->bufs.grad;
+  a.f.enabled = 1;
+  a.f.c = adam_scalars(d, step);
+  a.f.st = adam_state(h);
+  a.f.grad_base = h->bufs.grad;
+  a.f.W1f = h->W1f; a.f.W2f = h->W2f16; a.f.W2tf = h->W2tf;
+  a.f.nkg_w1 = wf16_nkg(h->IN); a.f.nkg_w2 = wf16_nkg(d.hidden1); a.f.nkg_w2t = wf16_nkg(d.hidden2);
+  a.f.soft_next = soft_next;
+  a.f.tgt = h->bufs.q_target; a.f.tau = d.tau; a.f.one_minus_tau = (float)(1.0 - (double)d.tau);
+  a.f.tW2f = h->w2f; a.f.nkg_t = t_nkg(d.hidden1);
+  a.g = h->bufs.grad;
   a.n = h->P;
-  a.c = adam_scalars(h->d, step);
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s, a);
+  for (int i = 0; i < 6; ++i) a.off[i] = h->off[i];
+  a.IN = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
+  hipLaunchKernelGGL(adamw_dqn_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -401,7 +420,9 @@ int run_soft_update(pa_dqn* h, hipStream_t s) {
 // soft_next: fuse the NEXT step's soft target update into this step's optimizer tail.
 int online_chain(pa_dqn* h, const float* x, int B, const float* y, int64_t adam_step,
                  int grad_world, float* loss_out, int soft_next, hipStream_t s) {
-  int rc = run_rowpass(h, x, B, y, h->qbuf, grad_world, s);
+  // grad_world < 0: data-parallel split requested explicitly (|grad_world| ranks, AdamW later)
+  const int world = grad_world < 0 ? -grad_world : grad_world;
+  int rc = run_rowpass(h, x, B, y, h->qbuf, world, s);
   if (rc != PA_OK) return rc;
   float* lo = loss_out ? loss_out : h->loss_scratch;
   return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s);
@@ -629,7 +650,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
 extern "C" int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
-  return run_adamw(h, adam_step, reinterpret_cast<hipStream_t>(stream));
+  return run_adamw(h, adam_step, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream) {
@@ -724,14 +745,52 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       rc = launch_linear<false>(&g, 1, s);
       if (rc != PA_OK) return rc;
     }
-    rc = run_target_fused(h, &b, h->nextv, h->y, s);
-    if (rc != PA_OK) return rc;
+    const bool dp = args->allreduce_start != nullptr;
+    const int world = dp ? (args->grad_world > 0 ? args->grad_world : 1) : 1;
+    if (!dp) {
+      rc = run_target_fused(h, &b, h->nextv, h->y, s);
+      if (rc != PA_OK) return rc;
+    }
+    // data parallel: the target pass of round j + 1 is enqueued between the start and the wait
+    // of round j's gradient all-reduce (one round per launch), so the exchange hides behind it
+    auto target_round = [&](int j) {
+      pa_dqn_batch bj = b;
+      bj.B = B;
+      bj.reward = h->bb.reward + (int64_t)j * B;
+      bj.terminated = h->bb.term + (int64_t)j * B;
+      bj.next_avail_rep = h->bb.next_avail_rep + (int64_t)j * B * A * d.action_dim;
+      bj.next_mask = h->bb.next_mask + (int64_t)j * B * A;
+      TargetView v;
+      v.u_row0 = (int64_t)j * B;
+      return run_target_fused_view(h, &bj, v, h->nextv + (int64_t)j * B, h->y + (int64_t)j * B, s);
+    };
+    if (dp) {
+      rc = target_round(0);
+      if (rc != PA_OK) return rc;
+    }
     for (int j = 0; j < w; ++j) {
       const int round = r + j;
       const int soft_next = (round + 1 < R) ? due(round + 1) : 0;
-      rc = online_chain(h, h->bb.x + (int64_t)j * B * h->IN, B, h->y + (int64_t)j * B,
-                        args->adam_step0 + round + 1, 1,
-                        args->losses_out ? args->losses_out + round : nullptr, soft_next, s);
+      const float* xj = h->bb.x + (int64_t)j * B * h->IN;
+      float* lo = args->losses_out ? args->losses_out + round : nullptr;
+      if (!dp) {
+        rc = online_chain(h, xj, B, h->y + (int64_t)j * B, args->adam_step0 + round + 1, 1, lo,
+                          soft_next, s);
+        if (rc != PA_OK) return rc;
+        continue;
+      }
+      rc = online_chain(h, xj, B, h->y + (int64_t)j * B, args->adam_step0 + round + 1, -world, lo, 0, s);
+      if (rc != PA_OK) return rc;
+      PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
+                 PA_ERR_HIP, "allreduce_start hook failed");
+      if (j + 1 < w) {
+        rc = target_round(j + 1);
+        if (rc != PA_OK) return rc;
+      }
+      if (args->allreduce_wait)
+        PA_REQUIRE(args->allreduce_wait(args->allreduce_ctx, stream) == 0, PA_ERR_HIP,
+                   "allreduce_wait hook failed");
+      rc = run_adamw(h, args->adam_step0 + round + 1, soft_next, s);
       if (rc != PA_OK) return rc;
     }
     r += w;

@@ -826,6 +826,34 @@ static __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   (void)adam_update(a.c, a.st, i, a.g[i]);
 }
 
+// AdamW on the flat DQN gradient buffer AFTER a data-parallel all-reduce, with the same optimizer
+// tail as the fused weight-gradient kernel: fragment-major copies refreshed, optional soft update
+// of the target network for the next step.  The parameter index is decoded back to (tensor, row,
+// col) from the flat layout W1 | b1 | W2 | b2 | W3 | b3.
+struct AdamDqnArgs {
+  AdamFuse f;
+  const float* g;
+  int64_t n;
+  int64_t off[6];
+  int IN, H1, H2;
+};
+static __global__ __launch_bounds__(256) void adamw_dqn_kernel(AdamDqnArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float g = a.g[i];
+  if (i >= a.off[0] && i < a.off[0] + (int64_t)a.H1 * a.IN) {
+    const int64_t e = i - a.off[0];
+    adam_fused_weight(a.f, 1, i, (int)(e / a.IN), (int)(e % a.IN), g);
+  } else if (i >= a.off[2] && i < a.off[2] + (int64_t)a.H2 * a.H1) {
+    const int64_t e = i - a.off[2];
+    adam_fused_weight(a.f, 0, i, (int)(e / a.H1), (int)(e % a.H1), g);
+  } else if (i >= a.off[4] && i < a.off[4] + a.H2) {
+    adam_fused_weight(a.f, 2, i, 0, (int)(i - a.off[4]), g);
+  } else {
+    adam_fused_bias(a.f, i, g);   // biases (and the zero alignment gaps)
+  }
+}
+
 // theta' <- tau * theta + (1 - tau) * theta'   (common/utils.py:214-226)
 static __global__ __launch_bounds__(256) void soft_update_kernel(float* __restrict__ tgt,
                                                           const float* __restrict__ src,

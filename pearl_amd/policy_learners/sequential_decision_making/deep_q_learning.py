@@ -14,18 +14,21 @@ buffers; libpearl_amd.so reads and updates them in place:
   online forward, fused target-network forward + mask + max + Bellman target
   (deep_q_learning.py:130-167), MSE, backward, AdamW(amsgrad);
 * ``learn(replay_buffer)`` on an arena-backed buffer -> ``pa_dqn_learn``: the whole
-  ``training_rounds`` loop on the device, sampling one step ahead on a side stream, one host
-  synchronisation per call (for the report) instead of one ``.item()`` per step.
+  ``training_rounds`` loop on the device (index lists of all rounds in one launch, gather and
+  target-network pass batched per target-update window), one host synchronisation per call (for
+  the report) instead of one ``.item()`` per step.
 
 Data parallelism (not in the reference): if ``torch.distributed`` is initialised every rank keeps
-its own arena shard and local batch; gradients are pre-scaled by 1/world, summed with one RCCL
-all-reduce of the flat gradient buffer, then ``pa_dqn_apply`` runs AdamW.  The next sample is
-already queued on the side stream while the all-reduce is in flight.
+its own arena shard and local batch; ``pa_dqn_learn`` pre-scales gradients by 1/world and calls
+back into ``torch.distributed.all_reduce`` (RCCL) once per round through the all-reduce hooks of
+``pa_learn_args``, with the next round's target-network pass enqueued while the exchange is in
+flight; AdamW (``adamw_dqn_kernel``) runs after it.
 """
 from __future__ import annotations
 
 import copy
 import ctypes as C
+import os
 import random
 from typing import Any, Dict, List, Optional, Tuple
 
@@ -57,11 +60,15 @@ class _NativeDqn:
         self.sig: Tuple = ()
         self.desc_key: Tuple = ()
         self.loss_buf: Optional[torch.Tensor] = None
+        self.comm: Optional[C.c_void_p] = None
 
     def close(self) -> None:
         h, self.handle = self.handle, None
         if h:
             N.lib().pa_dqn_destroy(h)
+        c, self.comm = getattr(self, "comm", None), None
+        if c:
+            N.lib().pa_comm_destroy(c)
 
     def __del__(self) -> None:  # pragma: no cover
         try:
@@ -392,7 +399,9 @@ class DeepQLearning(PolicyLearner):
                             OneHotActionTensorRepresentationModule)
         if rounds == 0:
             return {}
-        if self._dp_world() > 1:
+        if self._dp_world() > 1 or (os.environ.get("PEARL_AMD_FORCE_DP") == "1"
+                                    and dist.is_available() and dist.is_initialized()):
+            # (the env override drives the hook path through RCCL with a single rank: a test aid)
             return self._learn_data_parallel(replay_buffer, batch_size, rounds, onehot)
         idx_host = None
         if replay_buffer.sampler == "python":
@@ -412,65 +421,98 @@ class DeepQLearning(PolicyLearner):
         losses = nat.loss_buf[:rounds].tolist()  # the single host sync of this call
         return {"loss": losses}
 
+    def _native_comm(self, dev: torch.device) -> Optional[C.c_void_p]:
+        """One RCCL communicator per process for the native all-reduce hooks (pa_comm_*): rank 0
+        mints the unique id, torch.distributed broadcasts its 128 bytes.  None when RCCL cannot
+        be loaded or PEARL_AMD_TORCH_ALLREDUCE=1 (then torch.distributed.all_reduce is used)."""
+        if os.environ.get("PEARL_AMD_TORCH_ALLREDUCE") == "1":
+            return None
+        if not (dist.is_available() and dist.is_initialized()):
+            return None
+        cached = getattr(self._native, "comm", None)
+        if cached is not None:
+            return cached
+        lib = N.lib()
+        if not lib.pa_comm_available():
+            return None
+        rank, world = dist.get_rank(), dist.get_world_size()
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * 128)()
+            N.check(lib.pa_comm_unique_id(buf))
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        on = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        ident = ident.to(on)
+        dist.broadcast(ident, src=0)
+        raw = bytes(ident.cpu().numpy().tobytes())
+        handle = C.c_void_p()
+        torch.cuda.synchronize(dev)
+        N.check(lib.pa_comm_create(C.byref(handle), dev.index, world, rank, raw))
+        self._native.comm = handle
+        return handle
+
     def _learn_data_parallel(self, replay_buffer: TensorBasedReplayBuffer, batch_size: int,
-                             rounds: int, onehot: bool) -> Dict[str, Any]:
-        """world > 1: per-round step with an RCCL all-reduce between backward and AdamW; the
-        sample of round r+1 is enqueued on a side stream before round r's all-reduce."""
+                             rounds: int, onehot: bool, force_world: Optional[int] = None
+                             ) -> Dict[str, Any]:
+        """world > 1: the same fused ``pa_dqn_learn`` loop with all-reduce hooks.  Every round the
+        library scales the local gradient by 1/world, calls ``allreduce_start`` (an asynchronous
+        ``torch.distributed.all_reduce`` = RCCL over xGMI on GPUs), enqueues the NEXT round's
+        target-network pass, calls ``allreduce_wait`` and runs AdamW.  Ranks sample their own arena
+        shard with their own index stream; parameters stay identical across ranks."""
         nat, arena = self._native, replay_buffer.arena
         dev = arena.device
-        S, AD, _, _ = self._dims()
-        A = arena.layout.max_actions
-        main = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(dev)
-        side.wait_stream(main)
-        seed = random.getrandbits(64)
-        bufs = []
-        for _ in range(2):
-            bufs.append(dict(
-                x=torch.empty(batch_size, S + AD, device=dev), ns=torch.empty(batch_size, S, device=dev),
-                nav=torch.empty(batch_size, A, AD, device=dev),
-                nm=torch.empty(batch_size, A, dtype=torch.uint8, device=dev),
-                rw=torch.empty(batch_size, device=dev),
-                tm=torch.empty(batch_size, dtype=torch.uint8, device=dev),
-                ready=torch.cuda.Event(), consumed=torch.cuda.Event(), used=False))
-        world = self._dp_world()
+        world = int(force_world) if force_world is not None else self._dp_world()
+        grad = nat.flat["grad"]
+        state: Dict[str, Any] = {"work": None, "error": None}
 
-        def prefetch(r: int) -> None:
-            b = bufs[r & 1]
-            with torch.cuda.stream(side):
-                if b["used"]:
-                    side.wait_event(b["consumed"])
-                out = N.BatchOut(x=b["x"].data_ptr(), next_state=b["ns"].data_ptr(),
-                                 next_avail_rep=b["nav"].data_ptr(), next_mask=b["nm"].data_ptr(),
-                                 reward_f32=b["rw"].data_ptr(), terminated=b["tm"].data_ptr(),
-                                 rep_dim=AD, rep_onehot=int(onehot))
-                if replay_buffer.sampler == "python":
-                    arena.gather(np.asarray(random.sample(range(len(replay_buffer)), batch_size),
-                                            dtype=np.int64), out)
-                else:
-                    arena.sample(seed, r, batch_size, out)
-                b["ready"].record(side)
+        def start(_ctx, _ptr, _n, _stream) -> int:
+            try:
+                if dist.is_available() and dist.is_initialized():
+                    state["work"] = dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True)
+                return 0
+            except BaseException as e:  # never unwind through the C frame
+                state["error"] = e
+                return 1
 
-        step0 = self._adam_steps()
-        prefetch(0)
-        for r in range(rounds):
-            if r + 1 < rounds:
-                prefetch(r + 1)
-            b = bufs[r & 1]
-            main.wait_event(b["ready"])
-            self._training_steps += 1
-            nb = N.DqnBatch(B=batch_size, A=A, x=b["x"].data_ptr(), reward=b["rw"].data_ptr(),
-                            terminated=b["tm"].data_ptr(), next_state=b["ns"].data_ptr(),
-                            next_avail_rep=b["nav"].data_ptr(), next_mask=b["nm"].data_ptr(),
-                            next_avail_bcast=0)
-            N.check(N.lib().pa_dqn_step(nat.handle, C.byref(nb), int(self._target_update_due()),
-                                        step0 + r + 1, world,
-                                        nat.loss_buf[r:].data_ptr(), N.stream_ptr(dev)))
-            allreduce_sum_(nat.flat["grad"])
-            N.check(N.lib().pa_dqn_apply(nat.handle, step0 + r + 1, N.stream_ptr(dev)))
-            b["consumed"].record(main)
-            b["used"] = True
-        self._set_adam_steps(step0 + rounds)
+        def wait(_ctx, _stream) -> int:
+            try:
+                w, state["work"] = state["work"], None
+                if w is not None:
+                    w.wait()
+                return 0
+            except BaseException as e:
+                state["error"] = e
+                return 1
+
+        cb_start, cb_wait = N.ALLREDUCE_START_FN(start), N.ALLREDUCE_WAIT_FN(wait)
+        fn_start, fn_wait, ctx = C.cast(cb_start, C.c_void_p), C.cast(cb_wait, C.c_void_p), None
+        comm = self._native_comm(dev) if force_world is None else None
+        if comm is not None:
+            # native path: ncclAllReduce enqueued from C on the library's exchange stream — no
+            # Python in the per-round loop
+            lib = N.lib()
+            fn_start = C.cast(lib.pa_comm_allreduce_start, C.c_void_p)
+            fn_wait = C.cast(lib.pa_comm_allreduce_wait, C.c_void_p)
+            ctx = comm
+        idx_host = None
+        if replay_buffer.sampler == "python":
+            n = len(replay_buffer)
+            idx_host = np.asarray([random.sample(range(n), batch_size) for _ in range(rounds)],
+                                  dtype=np.int64)
+        args = N.LearnArgs(
+            rounds=rounds, batch_size=batch_size, rep_onehot=int(onehot),
+            target_update_freq=int(self._target_update_freq),
+            training_steps0=int(self._training_steps), adam_step0=self._adam_steps(),
+            seed=random.getrandbits(64) if idx_host is None else 0, offset0=0,
+            losses_out=nat.loss_buf.data_ptr(),
+            idx_host=None if idx_host is None else idx_host.ctypes.data,
+            grad_world=world, allreduce_start=fn_start, allreduce_wait=fn_wait, allreduce_ctx=ctx)
+        rc = N.lib().pa_dqn_learn(nat.handle, arena.handle, C.byref(args), N.stream_ptr(dev))
+        if state["error"] is not None:
+            raise state["error"]
+        N.check(rc)
+        self._training_steps += rounds
+        self._set_adam_steps(args.adam_step0 + rounds)
         return {"loss": nat.loss_buf[:rounds].tolist()}
 
     # ------------------------------------------------------------------ act / compare

@@ -128,6 +128,31 @@ def test_generic_loop_equals_fused_loop(golden, name):
         assert torch.equal(pa, pb), k
 
 
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg2_shape_small_batch"])
+def test_data_parallel_loop_with_one_rank_equals_fused_loop(golden, name):
+    """The data-parallel form of pa_dqn_learn (gradient split at the all-reduce hooks, per-round
+    target launches, stand-alone adamw_dqn_kernel) with world = 1 is the same computation as the
+    fused single-GPU loop: bitwise-equal parameters, targets, optimizer state and losses."""
+    fx = golden(name)
+    a, b = make_learner(fx), make_learner(fx)
+    rb = fill_arena_buffer(fx, "python")
+    random.seed(4)
+    ra = a.learn(rb)
+    random.seed(4)
+    cfg = fx["config"]
+    b._ensure_bound(cfg["B"], cfg["A"])
+    rbr = b._learn_data_parallel(rb, cfg["B"], cfg["rounds"], True, force_world=1)
+    assert ra["loss"] == rbr["loss"]
+    for (k, pa), (_, pb) in zip(a._Q.state_dict().items(), b._Q.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    for (k, pa), (_, pb) in zip(a._Q_target.state_dict().items(), b._Q_target.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    for pa, pb in zip(a._Q.parameters(), b._Q.parameters()):
+        for key in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            assert torch.equal(a._optimizer.state[pa][key], b._optimizer.state[pb][key]), key
+    assert a._training_steps == b._training_steps
+
+
 def test_device_sampler_learn_matches_oracle(golden):
     """Fast mode: Philox indices on the device; the oracle replays the same index lists."""
     fx = golden("cfg1_cartpole_shape")
