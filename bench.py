@@ -142,7 +142,7 @@ def main():
     assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
 
     timers = {}
-    for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "sample", "online_l2",
+    for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "gather_x", "sample", "online_l2",
                  "head", "bwd_dx", "rowpass", "bwd_dw", "adamw", "soft_update"):
         ms, cnt, units = C.c_double(), C.c_int64(), C.c_int64()
         N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))

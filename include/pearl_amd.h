@@ -287,6 +287,12 @@ typedef struct pa_learn_args {
   void* allreduce_ctx;
 } pa_learn_args;
 int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* stream);
+/* pa_dqn_learn overlaps the target-network pass of a window (on an internal low-priority stream)
+ * with the per-round online chains on `stream`; the Bellman targets cross between the two as
+ * data-tagged words that the chain polls with a BOUNDED wait.  After synchronising `stream`, call
+ * pa_dqn_check: PA_ERR_HIP if such a wait expired during the last pa_dqn_learn (results invalid),
+ * PA_OK otherwise.  PEARL_AMD_OVERLAP=0 in the environment selects the single-stream loop. */
+int pa_dqn_check(pa_dqn* h);
 
 /* Native all-reduce hooks for pa_learn_args, backed by RCCL (ncclAllReduce over xGMI) resolved at
  * run time with dlopen (the library has no link-time dependency on it).  One communicator per

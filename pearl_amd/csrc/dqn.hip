@@ -31,6 +31,7 @@ struct Timer {
 };
 
 constexpr size_t kMaxTimedPairs = 8192;
+constexpr int kTileCtrs = 1024;
 
 }  // namespace
 
@@ -42,19 +43,36 @@ struct pa_dqn {
   int64_t off[6];    // W1,b1,W2,b2,W3,b3
   int IN;            // S + AD
   // workspaces (HBM)
-  float *U, *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
+  float *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
   float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
   float *W1f, *W2f16, *W2tf;  // fragment-major copies of the online weights (online_rowpass_kernel)
   // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
+  // learn(): the target-network side of a window (gather -> U -> Bellman targets y) runs on a
+  // low-priority side stream into one of TWO buffer sets, while the main stream runs the
+  // sequential online chain; x is only touched by the main stream and needs one copy.
   struct BatchBuf {
-    float* x;
     float* next_state;
     float* next_avail_rep;
     uint8_t* next_mask;
     float* reward;
     uint8_t* term;
-  } bb;
+  } bb[2];
+  float* bb_x;       // [wrows][IN] state || rep(action) of the current window
   int bb_A;          // A the batch buffers were sized for
+  float* Uw[2];      // [wrows][H1] per buffer set
+  float* yw[2];      // [wrows] Bellman targets, data-tagged (kYPending = not yet produced)
+  hipStream_t side;  // target-network stream of learn()
+  hipEvent_t ev_start, ev_tail, ev_chain[2];
+  int* err_dev;      // device error word (a bounded wait expired)
+  int* err_host;     // pinned mirror, copied at the end of learn()
+  int overlap;       // 0: single-stream learn loop (PEARL_AMD_OVERLAP=0 or timing level >= 2)
+  int split_first;   // rounds of a window whose target pass is issued first, as its own launch
+  bool y_clean;      // both yw buffers hold kYPendingBits everywhere (tagged hand-off invariant)
+  // CU partition of the overlapped loop: the persistent target kernel stays off `n_reserved` CUs
+  uint8_t* reserved_dev;   // [kCuKeys] or null (no partition)
+  int n_reserved, ncu;
+  int* tile_ctr;           // [kTileCtrs] work-stealing counters, one per persistent launch
+  int ctr_next;
   int wcap;          // rounds whose target-network pass is batched into one launch (learn())
   int64_t wrows;     // wcap * max_batch: rows of the window-sized workspaces (U, y, batch buffers)
   int64_t* idx_all;  // [idx_cap] logical indices, round-major
@@ -127,7 +145,10 @@ int launch_target_t(const TargetArgs& a, hipStream_t s) {
     if (rc != PA_OK) return rc;
     configured = true;
   }
-  const unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
+  // persistent mode: three workgroups per CU are offered; two fit (LDS), the surplus and the ones
+  // on reserved CUs exit immediately
+  const unsigned grid = a.tile_ctr ? (unsigned)(3 * a.ntiles < 3 * 256 ? 3 * a.ntiles : 3 * 256)
+                                   : (unsigned)ceil_div(a.B, a.bpw);
   hipLaunchKernelGGL(target_fused_kernel<NKG>, dim3(grid), dim3(512), smem, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -181,7 +202,7 @@ int resolve_x(pa_dqn* h, const pa_dqn_batch* b, const float** x, hipStream_t s) 
   return PA_OK;
 }
 
-GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows) {
+GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* U) {
   // U = s' W1s'^T + b1'   (state columns of the target net's first layer)
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, h->bufs.q_target);
@@ -189,7 +210,7 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows) {
   memset(&g, 0, sizeof(g));
   g.A = next_state; g.lda = d.state_dim;
   g.Bm = t.W1; g.ldb = h->IN;
-  g.C = h->U; g.ldc = d.hidden1;
+  g.C = U; g.ldc = d.hidden1;
   g.bias = t.b1;
   g.M = rows; g.N = d.hidden1; g.K = d.state_dim;
   g.epi = EPI_BIAS;
@@ -198,18 +219,15 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows) {
 
 // max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
 // deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
-// U must already be in h->U.
-struct TargetView {
-  int64_t u_row0 = 0;   // first row of h->U this launch reads (a round inside a window)
-};
-int run_target_fused_view(pa_dqn* h, const pa_dqn_batch* b, const TargetView& view, float* next_v,
-                          float* y, hipStream_t s) {
+// U (= W1s' s' + b1' of the same rows) must already be computed.
+int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
+                       hipStream_t s, bool persistent = false) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, h->bufs.q_target);
   ScopedTimer tm(h, "target", s, 1, 4, b->B);
   TargetArgs a;
   memset(&a, 0, sizeof(a));
-  a.U = h->U + view.u_row0 * d.hidden1; a.ldu = d.hidden1;
+  a.U = U; a.ldu = d.hidden1;
   a.feat = b->next_avail_rep;
   a.feat_bstride = b->next_avail_bcast ? 0 : (int64_t)b->A * d.action_dim;
   a.mask = b->next_mask;
@@ -222,10 +240,20 @@ int run_target_fused_view(pa_dqn* h, const pa_dqn_batch* b, const TargetView& vi
   a.next_v = next_v; a.y = y;
   a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
   a.bpw = T_ROWS / b->A;
+  a.ntiles = (int)ceil_div(b->B, a.bpw);
+  if (persistent) {
+    if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream
+      PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
+      h->ctr_next = 0;
+    }
+    a.tile_ctr = h->tile_ctr + h->ctr_next++;
+    a.reserved = h->reserved_dev;
+  }
   return launch_target(a, s);
 }
 int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
-  return run_target_fused_view(h, b, TargetView(), next_v, y, s);
+  h->y_clean = false;  // stand-alone paths use yw[0] as plain scratch
+  return run_target_fused_u(h, b, h->Uw[0], next_v, y, s);
 }
 
 PackedW packed(pa_dqn* h) {
@@ -252,8 +280,8 @@ int run_repack(pa_dqn* h, bool online, bool target, hipStream_t s) {
 }
 
 // Forward (+ loss + backward to dZ2 / dZ1 when y is given) of the online network.
-int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, float* q_out, int world,
-                hipStream_t s) {
+int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, float* q_out,
+                int world, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
   ScopedTimer tm(h, "rowpass", s);
@@ -266,6 +294,8 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, float* q_out, 
   a.W2tf = h->W2tf;
   a.w3 = q.W3; a.b3 = q.b3;
   a.y = y;
+  a.y_tagged = y_tagged ? 1 : 0;
+  a.err = h->err_dev;
   a.H1a = y ? h->H1a : nullptr; a.H2a = y ? h->H2a : nullptr;
   a.dZ2 = h->dZ2; a.dZ1 = h->dZ1;
   a.q_out = q_out; a.dq_out = h->dq; a.absd_out = h->absd;
@@ -418,11 +448,11 @@ int run_soft_update(pa_dqn* h, hipStream_t s) {
 // Everything of one learn_batch that depends on the ONLINE parameters, given the Bellman targets
 // y[B] of the batch: row pass (forward, loss, dZ2, dZ1) -> weight gradients (+ AdamW).
 // soft_next: fuse the NEXT step's soft target update into this step's optimizer tail.
-int online_chain(pa_dqn* h, const float* x, int B, const float* y, int64_t adam_step,
+int online_chain(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, int64_t adam_step,
                  int grad_world, float* loss_out, int soft_next, hipStream_t s) {
   // grad_world < 0: data-parallel split requested explicitly (|grad_world| ranks, AdamW later)
   const int world = grad_world < 0 ? -grad_world : grad_world;
-  int rc = run_rowpass(h, x, B, y, h->qbuf, world, s);
+  int rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s);
   if (rc != PA_OK) return rc;
   float* lo = loss_out ? loss_out : h->loss_scratch;
   return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s);
@@ -448,38 +478,140 @@ int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_
   if (rc != PA_OK) return rc;
   {
     ScopedTimer tm(h, "target_l1", s);
-    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B);
+    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B, h->Uw[0]);
     rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
   }
-  rc = run_target_fused(h, batch, h->nextv, h->y, s);
+  rc = run_target_fused(h, batch, h->nextv, h->yw[0], s);
   if (rc != PA_OK) return rc;
-  return online_chain(h, x, batch->B, h->y, adam_step, grad_world, loss_out, 0, s);
+  return online_chain(h, x, batch->B, h->yw[0], false, adam_step, grad_world, loss_out, 0, s);
 }
 
 void free_batchbufs(pa_dqn* h) {
-  void* ptrs[] = {h->bb.x, h->bb.next_state, h->bb.next_avail_rep, h->bb.next_mask, h->bb.reward,
-                  h->bb.term};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
-  memset(&h->bb, 0, sizeof(h->bb));
+  for (int p = 0; p < 2; ++p) {
+    void* ptrs[] = {h->bb[p].next_state, h->bb[p].next_avail_rep, h->bb[p].next_mask,
+                    h->bb[p].reward, h->bb[p].term};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+  }
+  if (h->bb_x) (void)hipFree(h->bb_x);
+  h->bb_x = nullptr;
+  memset(h->bb, 0, sizeof(h->bb));
   h->bb_A = 0;
 }
 
 int ensure_batchbufs(pa_dqn* h, int A) {
-  if (h->bb_A >= A && h->bb.x) return PA_OK;
+  if (h->bb_A >= A && h->bb_x) return PA_OK;
+  PA_HIP(hipDeviceSynchronize());
   free_batchbufs(h);
   const pa_dqn_desc& d = h->d;
   const int64_t B = h->wrows;
-  PA_HIP(hipMalloc((void**)&h->bb.x, (size_t)(B * h->IN * 4)));
-  PA_HIP(hipMalloc((void**)&h->bb.next_state, (size_t)(B * d.state_dim * 4)));
-  PA_HIP(hipMalloc((void**)&h->bb.next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
-  PA_HIP(hipMalloc((void**)&h->bb.next_mask, (size_t)(B * A)));
-  PA_HIP(hipMalloc((void**)&h->bb.reward, (size_t)(B * 4)));
-  PA_HIP(hipMalloc((void**)&h->bb.term, (size_t)B));
+  PA_HIP(hipMalloc((void**)&h->bb_x, (size_t)(B * h->IN * 4)));
+  for (int p = 0; p < 2; ++p) {
+    PA_HIP(hipMalloc((void**)&h->bb[p].next_state, (size_t)(B * d.state_dim * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[p].next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[p].next_mask, (size_t)(B * A)));
+    PA_HIP(hipMalloc((void**)&h->bb[p].reward, (size_t)(B * 4)));
+    PA_HIP(hipMalloc((void**)&h->bb[p].term, (size_t)B));
+  }
   h->bb_A = A;
   return PA_OK;
 }
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// Choose the compute units the online chain keeps for itself: a census kernel reports the
+// (XCC, SE, SH, CU) key of every CU; `want` of them, spread evenly over XCDs and shader engines,
+// are marked in the table the persistent target kernel consults.  Any surprise (fewer keys than
+// CUs, odd topology) leaves the table null: the loop then runs without a partition.
+int cu_partition(pa_dqn* h, int want, hipStream_t s) {
+  h->reserved_dev = nullptr;
+  h->n_reserved = 0;
+  if (want <= 0) return PA_OK;
+  const int G = 8 * h->ncu;
+  unsigned* keys_dev = nullptr;
+  PA_HIP(hipMalloc((void**)&keys_dev, (size_t)G * 4));
+  hipLaunchKernelGGL(cu_census_kernel, dim3((unsigned)G), dim3(512), 0, s, keys_dev, 100000);
+  std::vector<unsigned> keys((size_t)G);
+  hipError_t e = hipMemcpyAsync(keys.data(), keys_dev, (size_t)G * 4, hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(keys_dev);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return PA_OK;
+  }
+  std::vector<uint8_t> present(kCuKeys, 0), table(kCuKeys, 0);
+  int distinct = 0;
+  for (unsigned k : keys)
+    if (k < (unsigned)kCuKeys && !present[k]) { present[k] = 1; ++distinct; }
+  if (distinct != h->ncu || want >= h->ncu) return PA_OK;
+  // round-robin over (xcc, se) groups so that every XCD / shader engine gives up the same share
+  std::vector<std::vector<int>> groups;
+  for (int g = 0; g < kCuKeys / 32; ++g) {  // key = xcc[11:8] se[7:5] sh[4] cu[3:0]
+    std::vector<int> cus;
+    for (int c = 0; c < 32; ++c)
+      if (present[g * 32 + c]) cus.push_back(g * 32 + c);
+    if (!cus.empty()) groups.push_back(cus);
+  }
+  int taken = 0;
+  for (size_t depth = 0; taken < want; ++depth) {
+    bool any = false;
+    for (auto& cus : groups) {
+      if (taken >= want) break;
+      if (depth < cus.size()) {
+        table[cus[cus.size() - 1 - depth]] = 1;
+        ++taken;
+        any = true;
+      }
+    }
+    if (!any) break;
+  }
+  PA_HIP(hipMalloc((void**)&h->reserved_dev, kCuKeys));
+  PA_HIP(hipMemcpy(h->reserved_dev, table.data(), kCuKeys, hipMemcpyHostToDevice));
+  h->n_reserved = taken;
+  return PA_OK;
+}
+
+// Side stream + events of the overlapped learn loop (created on first use).
+int ensure_side(pa_dqn* h) {
+  if (h->side) return PA_OK;
+  // The target-network kernels saturate every CU they may run on (two 8-wave workgroups and
+  // 137 KB of LDS per CU), and the hardware does not preempt: a chain kernel launched while they
+  // run would wait for workgroup slots for most of the window (measured: a 14 us weight-gradient
+  // launch stretched to 125 us).  So the side stream is confined to `side_cus` of the 256 CUs with
+  // a CU mask (bit i = XCD i % 8: every XCD keeps (256 - side_cus) / 8 CUs free), and the chain
+  // always finds idle CUs.  PEARL_AMD_SIDE_CUS=0: no mask, lowest stream priority instead.
+  // (A CU-masked side stream, PEARL_AMD_SIDE_CUS=n, was the first attempt: on this stack kernels
+  // of a masked queue and of the main queue no longer overlap at all and every launch gains ~7 us.
+  // The partition is therefore done inside the target kernel: cu_partition + persistent tiles.)
+  const int side_cus = env_int("PEARL_AMD_SIDE_CUS", 0);
+  hipDeviceProp_t prop;
+  PA_HIP(hipGetDeviceProperties(&prop, h->d.device));
+  const int ncu = prop.multiProcessorCount;
+  h->ncu = ncu;
+  if (side_cus > 0 && side_cus < ncu) {
+    uint32_t mask[16];
+    memset(mask, 0, sizeof(mask));
+    for (int i = 0; i < side_cus && i < 512; ++i) mask[i >> 5] |= 1u << (i & 31);
+    PA_HIP(hipExtStreamCreateWithCUMask(&h->side, (uint32_t)((ncu + 31) / 32), mask));
+  } else {
+    int lo = 0, hi = 0;
+    PA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least urgent
+    PA_HIP(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo));
+  }
+  PA_HIP(hipEventCreateWithFlags(&h->ev_start, hipEventDisableTiming));
+  PA_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
+  PA_HIP(hipEventCreateWithFlags(&h->ev_chain[0], hipEventDisableTiming));
+  PA_HIP(hipEventCreateWithFlags(&h->ev_chain[1], hipEventDisableTiming));
+  PA_HIP(hipMalloc((void**)&h->tile_ctr, kTileCtrs * sizeof(int)));
+  PA_HIP(hipMemset(h->tile_ctr, 0, kTileCtrs * sizeof(int)));
+  h->ctr_next = 0;
+  return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", 64), h->side);
+}
+
 
 int ensure_idx(pa_dqn* h, int64_t n) {
   if (h->idx_cap >= n) return PA_OK;
@@ -539,8 +671,22 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->idx_all = nullptr;
   h->idx_cap = 0;
   h->tick = 0;
-  h->U = h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->y = h->nextv = h->qbuf = h->dq = h->absd =
+  h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->nextv = h->qbuf = h->dq = h->absd =
       h->xpack = h->loss_scratch = h->w2f = h->W1f = h->W2f16 = h->W2tf = nullptr;
+  h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
+  h->bb_x = nullptr;
+  h->side = nullptr;
+  h->ev_start = h->ev_tail = h->ev_chain[0] = h->ev_chain[1] = nullptr;
+  h->err_dev = nullptr;
+  h->err_host = nullptr;
+  h->overlap = env_int("PEARL_AMD_OVERLAP", 1);
+  h->split_first = env_int("PEARL_AMD_SPLIT_FIRST", 3);
+  h->y_clean = false;
+  h->reserved_dev = nullptr;
+  h->n_reserved = 0;
+  h->ncu = 0;
+  h->tile_ctr = nullptr;
+  h->ctr_next = 0;
   const int64_t B = desc->max_batch;
   // learn() evaluates the target network for a whole window of rounds in one launch (the target
   // parameters only change every target_update_freq rounds): up to 16 rounds / 16384 transitions
@@ -556,13 +702,23 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
       return PA_ERR_NOMEM;                                                       \
     }                                                                            \
   } while (0)
-  PA_WS(h->U, h->wrows * desc->hidden1);
+  PA_WS(h->Uw[0], h->wrows * desc->hidden1);
+  PA_WS(h->Uw[1], h->wrows * desc->hidden1);
   PA_WS(h->H1a, B * desc->hidden1);
   PA_WS(h->H2a, B * desc->hidden2);
   PA_WS(h->dZ2, B * desc->hidden2);
   PA_WS(h->dZ1, B * desc->hidden1);
-  PA_WS(h->y, h->wrows);
+  PA_WS(h->yw[0], h->wrows);
+  PA_WS(h->yw[1], h->wrows);
   PA_WS(h->nextv, h->wrows);
+  PA_WS(h->err_dev, 4);
+  if (hipMemset(h->err_dev, 0, 16) != hipSuccess ||
+      hipHostMalloc((void**)&h->err_host, 16, hipHostMallocDefault) != hipSuccess) {
+    set_error("pa_dqn_create: error-word allocation failed");
+    pa_dqn_destroy(h);
+    return PA_ERR_NOMEM;
+  }
+  h->err_host[0] = 0;
   PA_WS(h->qbuf, B);
   PA_WS(h->dq, B);
   PA_WS(h->absd, B);
@@ -581,11 +737,17 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   if (!h) return PA_OK;
   (void)hipSetDevice(h->d.device);
   (void)hipDeviceSynchronize();
-  void* ptrs[] = {h->U, h->H1a, h->H2a, h->dZ2, h->dZ1, h->y, h->nextv, h->qbuf, h->dq, h->absd,
-                  h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f, h->W2f16, h->W2tf};
+  void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
+                  h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
+                  h->W2f16, h->W2tf, h->err_dev, h->reserved_dev, h->tile_ctr};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->err_host) (void)hipHostFree(h->err_host);
   free_batchbufs(h);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  hipEvent_t evs[] = {h->ev_start, h->ev_tail, h->ev_chain[0], h->ev_chain[1]};
+  for (hipEvent_t e : evs)
+    if (e) (void)hipEventDestroy(e);
   for (auto& t : h->timers)
     for (auto e : t.ev) (void)hipEventDestroy(e);
   delete h;
@@ -616,7 +778,7 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
   rc = run_repack(h, q_out != nullptr, next_v_out || target_out, s);
   if (rc != PA_OK) return rc;
   if (next_v_out || target_out) {
-    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B);
+    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B, h->Uw[0]);
     rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
     rc = run_target_fused(h, batch, next_v_out, target_out, s);
@@ -626,7 +788,7 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
     const float* x = nullptr;
     rc = resolve_x(h, batch, &x, s);
     if (rc != PA_OK) return rc;
-    rc = run_rowpass(h, x, batch->B, nullptr, q_out, 1, s);
+    rc = run_rowpass(h, x, batch->B, nullptr, false, q_out, 1, s);
     if (rc != PA_OK) return rc;
   }
   return PA_OK;
@@ -682,6 +844,24 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   const int R = args->rounds;
   rc = ensure_idx(h, (int64_t)R * B);
   if (rc != PA_OK) return rc;
+  const bool dp = args->allreduce_start != nullptr;
+  const int world = dp ? (args->grad_world > 0 ? args->grad_world : 1) : 1;
+  // Two streams: the target-network side of a window (gather of the target inputs, U, Bellman
+  // targets y for every round of the window) runs on the low-priority side stream `t`; the main
+  // stream runs the only truly sequential part, the per-round online chain.  The chain needs
+  // nothing from `t` except y, which travels as data-tagged 4-byte granules (write-through
+  // stores in target_fused_kernel, polled L1-bypassing loads in online_rowpass_kernel): round j
+  // starts as soon as ITS targets exist, while the targets of rounds j+1.. are still being
+  // computed on the CUs the chain leaves idle.  Stream-level ordering (events) is only needed
+  // once per window: the next window's target pass must see the soft update that the last chain
+  // of this window performs.  Bit-identical to the single-stream loop (same kernels, same data).
+  const bool overlap = h->overlap && h->timing < 2;
+  rc = ensure_side(h);
+  if (rc != PA_OK) return rc;
+  // fresh work-stealing counters for this call's persistent target launches
+  PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
+  h->ctr_next = 0;
+  hipStream_t t = overlap ? h->side : s;
   ScopedTimer tm_all(h, "learn", s);
   // ---- the index lists of EVERY round in one go (they do not depend on the parameters)
   if (args->idx_host) {
@@ -698,103 +878,142 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
   // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
   auto due = [&](int r) { return ((args->training_steps0 + r + 2) % args->target_update_freq) == 0; };
+  // the first round's soft update runs stand-alone; later ones ride the previous optimizer launch
+  if (due(0)) {
+    rc = run_soft_update(h, s);
+    if (rc != PA_OK) return rc;
+  }
+  rc = run_repack(h, true, true, s);
+  if (rc != PA_OK) return rc;
+  if (overlap) {
+    // Tagged hand-off invariant: every word of both y buffers is kYPendingBits whenever no target
+    // pass is in flight.  The consumer (online_rowpass_kernel) restores the tag after reading, so
+    // back-to-back learn() calls need no refill; anything else that wrote y (pa_dqn_step,
+    // pa_dqn_qvalues, the single-stream loop) marks the buffers dirty.
+    if (!h->y_clean) {
+      for (int p = 0; p < 2; ++p)
+        PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->yw[p]), (int)kYPendingBits,
+                                 (size_t)h->wrows, s));
+      h->y_clean = true;
+    }
+    // fresh work-stealing counters for this call's persistent target launches
+    PA_HIP(hipEventRecord(h->ev_start, s));
+    PA_HIP(hipStreamWaitEvent(t, h->ev_start, 0));
+  } else {
+    h->y_clean = false;
+  }
   // The target network is constant between two soft updates, and the index lists of all rounds
   // are already known: gather and run the (dominant) target-network pass for a whole WINDOW of
-  // rounds at once, then the per-round online chains, which are the only truly sequential part.
-  int r = 0;
+  // rounds at once.
+  int r = 0, k = 0;
   while (r < R) {
     int w = 1;
     while (r + w < R && w < h->wcap && !due(r + w)) ++w;
     const int rows = w * B;
-    pa_batch_out o;
-    memset(&o, 0, sizeof(o));
-    o.x = h->bb.x;
-    o.next_state = h->bb.next_state;
-    o.next_avail_rep = h->bb.next_avail_rep;
-    o.next_mask = h->bb.next_mask;
-    o.reward_f32 = h->bb.reward;
-    o.terminated = h->bb.term;
-    o.rep_dim = d.action_dim;
-    o.rep_onehot = args->rep_onehot;
+    const int p = k & 1;
+    const pa_dqn::BatchBuf& bb = h->bb[p];
+    if (h->timing) h->tick++;
+    // ---- side stream: target inputs of the window
     {
-      ScopedTimer tm(h, "gather", s, 2, 1, rows);
-      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
+      pa_batch_out o;
+      memset(&o, 0, sizeof(o));
+      o.next_state = bb.next_state;
+      o.next_avail_rep = bb.next_avail_rep;
+      o.next_mask = bb.next_mask;
+      o.reward_f32 = bb.reward;
+      o.terminated = bb.term;
+      o.rep_dim = d.action_dim;
+      o.rep_onehot = args->rep_onehot;
+      if (!overlap) o.x = h->bb_x;
+      ScopedTimer tm(h, "gather", t, 2, 1, rows);
+      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, t);
       if (rc != PA_OK) return rc;
     }
-    if (r == 0) {
-      // the first round's soft update runs stand-alone; later ones ride the previous AdamW launch
-      if (due(0)) {
-        rc = run_soft_update(h, s);
+    // the previous window's last optimizer launch (soft update of the target net) must be done
+    if (overlap && k > 0) PA_HIP(hipStreamWaitEvent(t, h->ev_chain[(k - 1) & 1], 0));
+    // U and the Bellman targets; the first round of the window as its own pair of launches, so
+    // the chain can start after one round's worth of target work instead of the whole window's
+    // (the first piece runs as a classic grid on every CU — the chain is idle then anyway — the
+    // rest as persistent tiles that stay off the chain's CUs)
+    const int piece0 = (overlap && h->split_first > 0 && w > h->split_first) ? h->split_first : w;
+    const bool persist = env_int("PEARL_AMD_PERSIST", overlap ? 1 : 0) != 0;
+    for (int j0 = 0; j0 < w;) {
+      const int nj = (j0 == 0) ? piece0 : (w - j0);
+      const int64_t row0 = (int64_t)j0 * B;
+      const int prow = nj * B;
+      pa_dqn_batch b;
+      memset(&b, 0, sizeof(b));
+      b.B = prow; b.A = A;
+      b.reward = bb.reward + row0;
+      b.terminated = bb.term + row0;
+      b.next_state = bb.next_state + row0 * d.state_dim;
+      b.next_avail_rep = bb.next_avail_rep + row0 * A * d.action_dim;
+      b.next_mask = bb.next_mask + row0 * A;
+      float* Up = h->Uw[p] + row0 * d.hidden1;
+      {
+        ScopedTimer tm(h, "target_l1", t, 2, 1, prow);
+        GemmArgs g = target_l1_problem(h, b.next_state, prow, Up);
+        rc = launch_linear<false>(&g, 1, t);
         if (rc != PA_OK) return rc;
       }
-      rc = run_repack(h, true, true, s);
+      rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t,
+                              persist && (j0 > 0 || piece0 == w));
       if (rc != PA_OK) return rc;
+      j0 += nj;
     }
-    if (h->timing) h->tick++;
-    pa_dqn_batch b;
-    memset(&b, 0, sizeof(b));
-    b.B = rows; b.A = A;
-    b.reward = h->bb.reward;
-    b.terminated = h->bb.term;
-    b.next_state = h->bb.next_state;
-    b.next_avail_rep = h->bb.next_avail_rep;
-    b.next_mask = h->bb.next_mask;
-    {
-      ScopedTimer tm(h, "target_l1", s, 2, 1, rows);
-      GemmArgs g = target_l1_problem(h, h->bb.next_state, rows);
-      rc = launch_linear<false>(&g, 1, s);
-      if (rc != PA_OK) return rc;
-    }
-    const bool dp = args->allreduce_start != nullptr;
-    const int world = dp ? (args->grad_world > 0 ? args->grad_world : 1) : 1;
-    if (!dp) {
-      rc = run_target_fused(h, &b, h->nextv, h->y, s);
-      if (rc != PA_OK) return rc;
-    }
-    // data parallel: the target pass of round j + 1 is enqueued between the start and the wait
-    // of round j's gradient all-reduce (one round per launch), so the exchange hides behind it
-    auto target_round = [&](int j) {
-      pa_dqn_batch bj = b;
-      bj.B = B;
-      bj.reward = h->bb.reward + (int64_t)j * B;
-      bj.terminated = h->bb.term + (int64_t)j * B;
-      bj.next_avail_rep = h->bb.next_avail_rep + (int64_t)j * B * A * d.action_dim;
-      bj.next_mask = h->bb.next_mask + (int64_t)j * B * A;
-      TargetView v;
-      v.u_row0 = (int64_t)j * B;
-      return run_target_fused_view(h, &bj, v, h->nextv + (int64_t)j * B, h->y + (int64_t)j * B, s);
-    };
-    if (dp) {
-      rc = target_round(0);
+    // ---- main stream: x of the window, then the per-round chains
+    if (overlap) {
+      pa_batch_out o;
+      memset(&o, 0, sizeof(o));
+      o.x = h->bb_x;
+      o.rep_dim = d.action_dim;
+      o.rep_onehot = args->rep_onehot;
+      ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
+      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
       if (rc != PA_OK) return rc;
     }
     for (int j = 0; j < w; ++j) {
       const int round = r + j;
       const int soft_next = (round + 1 < R) ? due(round + 1) : 0;
-      const float* xj = h->bb.x + (int64_t)j * B * h->IN;
+      const float* xj = h->bb_x + (int64_t)j * B * h->IN;
+      const float* yj = h->yw[p] + (int64_t)j * B;
       float* lo = args->losses_out ? args->losses_out + round : nullptr;
       if (!dp) {
-        rc = online_chain(h, xj, B, h->y + (int64_t)j * B, args->adam_step0 + round + 1, 1, lo,
-                          soft_next, s);
+        rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, 1, lo, soft_next, s);
         if (rc != PA_OK) return rc;
         continue;
       }
-      rc = online_chain(h, xj, B, h->y + (int64_t)j * B, args->adam_step0 + round + 1, -world, lo, 0, s);
+      // data parallel: local gradients (pre-scaled by 1/world) -> SUM all-reduce -> AdamW.  The
+      // exchange hides behind the target work of the side stream.
+      rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, -world, lo, 0, s);
       if (rc != PA_OK) return rc;
       PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
                  PA_ERR_HIP, "allreduce_start hook failed");
-      if (j + 1 < w) {
-        rc = target_round(j + 1);
-        if (rc != PA_OK) return rc;
-      }
       if (args->allreduce_wait)
         PA_REQUIRE(args->allreduce_wait(args->allreduce_ctx, stream) == 0, PA_ERR_HIP,
                    "allreduce_wait hook failed");
       rc = run_adamw(h, args->adam_step0 + round + 1, soft_next, s);
       if (rc != PA_OK) return rc;
     }
+    if (overlap) PA_HIP(hipEventRecord(h->ev_chain[p], s));
     r += w;
+    ++k;
   }
+  if (overlap) {
+    // everything the side stream did is ordered before whatever the caller enqueues next
+    PA_HIP(hipEventRecord(h->ev_tail, t));
+    PA_HIP(hipStreamWaitEvent(s, h->ev_tail, 0));
+    PA_HIP(hipMemcpyAsync(h->err_host, h->err_dev, 4, hipMemcpyDeviceToHost, s));
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_dqn_check(pa_dqn* h) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  PA_REQUIRE(!h->err_host || h->err_host[0] == 0, PA_ERR_HIP,
+             "pa_dqn_learn: a bounded wait for the target-network stream expired (code %d); the "
+             "results of that call are invalid",
+             h->err_host[0]);
   return PA_OK;
 }
 

@@ -307,9 +307,61 @@ struct TargetArgs {
   float gamma;
   float* next_v; float* y;
   int B, A, AD, H1, H2, bpw;
+  // persistent mode (learn() with the overlapped online chain): workgroups pull 64-row tiles from
+  // a counter, and workgroups that land on a compute unit reserved for the chain exit at once
+  int* tile_ctr;             // null: classic grid, tile = blockIdx.x
+  int ntiles;
+  const uint8_t* reserved;   // [kCuKeys] 1 = this CU belongs to the online chain; may be null
 };
 
+// (XCC_ID, HW_ID.se_id|sh_id|cu_id) of the compute unit the calling wave runs on
+constexpr int kCuKeys = 4096;
+__device__ __forceinline__ unsigned cu_key() {
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+  return ((xcc & 0xFu) << 8) | ((hw >> 8) & 0xFFu);
+}
+// One record per workgroup; the spin keeps the slot busy so the dispatcher spreads the grid over
+// every CU.  Host side: cu_partition() in dqn.hip.
+static __global__ __launch_bounds__(512) void cu_census_kernel(unsigned* keys, int spin) {
+  if (threadIdx.x == 0) keys[blockIdx.x] = cu_key();
+  const long long t0 = clock64();
+  while (clock64() - t0 < spin) {}
+}
+
 constexpr int T_ROWS = 64;
+
+// Bellman targets travel from the target-network stream to the online chain of learn() as
+// data-tagged 4-byte granules (MI355X_MICROARCH.md, hand-off recipe R2): the buffer is pre-filled
+// with kYPendingBits (a NaN payload no arithmetic produces), the producer publishes each value with
+// ONE write-through (agent-scope) store, the consumer polls with L1-bypassing loads until the word
+// differs.  No flag, no fence: the value is its own tag.
+constexpr unsigned kYPendingBits = 0xFFC0DE5Au;
+__device__ __forceinline__ void publish_y(float* p, float v) {
+  unsigned bits = __builtin_bit_cast(unsigned, v);
+  if (bits == kYPendingBits) bits ^= 1u;  // still a NaN; keeps the tag unambiguous
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), bits, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// spins: ~0.6 us each; the bound only exists so that a broken producer cannot hang the GPU
+constexpr int kYPollSpins = 1 << 19;
+__device__ __forceinline__ float consume_y(const float* p, int* err) {
+  const unsigned* q = reinterpret_cast<const unsigned*>(p);
+  unsigned bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bits == kYPendingBits) {
+    const int limit = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                          ? 0 : kYPollSpins;
+    int spins = 0;
+    while (bits == kYPendingBits && spins < limit) {
+      __builtin_amdgcn_s_sleep(16);
+      bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++spins;
+    }
+    if (bits == kYPendingBits)
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __builtin_bit_cast(float, bits);
+}
 constexpr int T_MAXH = 256;  // hidden widths the kernel is built for (8 waves x 32 columns)
 
 // k-groups of layer 2, padded to the kernel instantiations (8 / 16 / 32 <-> H1 <= 64 / 128 / 256)
@@ -351,8 +403,7 @@ inline size_t target_smem_bytes(int H1) {
 // VGPRs) for the widest instantiation, so that one workgroup's prologue / epilogue overlaps the
 // other's MFMA stream when a launch covers many 64-row tiles (a window of learn() rounds).
 template <int NKG>
-static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float* smem) {
   constexpr int H1P = NKG * 8;           // padded layer-2 K (64 / 128 / 256)
   constexpr int PA_ = H1P + 4;           // == 4 mod 32: conflict-free b128 reads AND writes by row
   constexpr int RD = 8;                  // W2' fragment prefetch ring depth (k-groups in flight)
@@ -362,7 +413,7 @@ static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int b0 = blockIdx.x * a.bpw;
+  const int b0 = tile * a.bpw;
   const int nb = min(a.bpw, a.B - b0);
   const int nrows = nb * a.A;
   const int nt1 = H1P >> 5, nt2 = (a.H2 + 31) >> 5;  // 32-wide tiles of h1 (padded) / h2 columns
@@ -541,8 +592,27 @@ static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs 
       const float live = 1.0f - (a.term[bb] ? 1.0f : 0.0f);
       const float t0 = __fmul_rn(m, a.gamma);
       const float t1 = __fmul_rn(t0, live);
-      a.y[bb] = __fadd_rn(t1, a.reward[bb]);
+      publish_y(a.y + bb, __fadd_rn(t1, a.reward[bb]));
     }
+  }
+}
+
+template <int NKG>
+static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (a.tile_ctr == nullptr) {
+    target_tile<NKG>(a, blockIdx.x, smem);
+    return;
+  }
+  __shared__ int next_tile;
+  if (a.reserved && a.reserved[cu_key()]) return;
+  for (;;) {
+    if (threadIdx.x == 0) next_tile = atomicAdd(a.tile_ctr, 1);
+    __syncthreads();
+    const int tile = next_tile;
+    if (tile >= a.ntiles) return;
+    target_tile<NKG>(a, tile, smem);
+    __syncthreads();  // LDS (and next_tile) are reused by the next tile
   }
 }
 

@@ -143,6 +143,8 @@ struct RowArgs {
   const float* W2tf;
   const float* w3; const float* b3;
   const float* y;                       // [B] Bellman targets; null = forward only (probe)
+  int y_tagged;                         // y is produced concurrently by another stream (consume_y)
+  int* err;                             // device error word for the bounded wait
   float* H1a; float* H2a;               // [B][H1], [B][H2] relu outputs (weight-gradient operands)
   float* dZ2; float* dZ1;               // [B][H2], [B][H1] pre-activation gradients
   float* q_out; float* dq_out; float* absd_out;  // [B]; q_out may be null
@@ -358,7 +360,8 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
   if (!a.y) return;
   // ---- loss and dZ2 = [h2 > 0] * dq * w3
-  const float yv = rok ? a.y[row] : q;
+  float yv = q;
+  if (rok) yv = a.y_tagged ? consume_y(a.y + row, a.err) : a.y[row];
   const float d = __fsub_rn(q, yv);
   const float dq = __fmul_rn(a.norm, d);
   if (wave == 0 && qd == 0 && rok) {
@@ -378,6 +381,10 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     if (rok) store4_guarded(a.dZ2, (int64_t)row * a.H2, u, a.H2, v2, z);
   }
   __syncthreads();
+  // every wave of the workgroup has consumed y[row]: restore the tag for the buffer's next use
+  if (a.y_tagged && wave == 0 && qd == 0 && rok)
+    __hip_atomic_store(reinterpret_cast<unsigned*>(const_cast<float*>(a.y)) + row, kYPendingBits,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   // ---- dZ1 = (dZ2 W2) * [h1 > 0]
 #pragma unroll
   for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;

@@ -419,6 +419,7 @@ class DeepQLearning(PolicyLearner):
         self._training_steps += rounds
         self._set_adam_steps(args.adam_step0 + rounds)
         losses = nat.loss_buf[:rounds].tolist()  # the single host sync of this call
+        N.check(N.lib().pa_dqn_check(nat.handle))
         return {"loss": losses}
 
     def _native_comm(self, dev: torch.device) -> Optional[C.c_void_p]:
@@ -513,7 +514,9 @@ class DeepQLearning(PolicyLearner):
         N.check(rc)
         self._training_steps += rounds
         self._set_adam_steps(args.adam_step0 + rounds)
-        return {"loss": nat.loss_buf[:rounds].tolist()}
+        losses = nat.loss_buf[:rounds].tolist()
+        N.check(N.lib().pa_dqn_check(nat.handle))
+        return {"loss": losses}
 
     # ------------------------------------------------------------------ act / compare
     def act(self, subjective_state: torch.Tensor, available_action_space: Any,
