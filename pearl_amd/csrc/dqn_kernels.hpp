@@ -44,6 +44,11 @@ constexpr unsigned kBufOob = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, 0x7FFFFFF0, 0x00020000);
 }
+// Descriptor that covers exactly `bytes`: any byte offset at or beyond it (carried in the VGPR
+// offset; the hardware does not range-check the scalar offset) reads as zero.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc_n(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ float ld_or_zero(const float* __restrict__ p, int64_t off, bool ok) {
   const unsigned bo = ok ? (unsigned)off * 4u : kBufOob;
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(buf_rsrc(p), (int)bo, 0, 0));
@@ -750,7 +755,7 @@ struct DwArgs {
   int nprob, B, total_tiles;
   AdamFuse ad;
 };
-constexpr int DW_ROWS = 128;  // batch rows per wave per pass
+constexpr int DW_ROWS = 64;   // batch rows per wave per pass
 
 // index of fragment-major slots (defined here, used by online_kernels.hpp as well)
 __host__ __device__ inline int64_t wf16_index_(int unit, int k, int nkg) {
@@ -785,14 +790,20 @@ __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, fl
 // One 32 x 32 output tile per workgroup; its 8 waves split the batch (the K
 // dimension) and add their partial tiles in a fixed order through LDS.  Both
 // operands are row-contiguous across lanes, so they go global -> VGPR -> MFMA
-// with no LDS staging; every load of a wave's 128-row slice is issued before the
-// first MFMA (one exposed memory latency).  One extra workgroup (blockIdx ==
-// total_tiles) folds |Q - target| into the reported loss when ad.loss_out is set.
+// with no LDS staging; every load of a wave's 64-row pass is issued before its
+// first MFMA.  Addressing costs one VALU add per load: the buffer descriptors cover
+// exactly B rows (rows past the batch read as zero by range check) and the column
+// guard is folded into a loop-invariant lane offset.  <= 128 VGPRs so that two
+// workgroups share a CU: inside learn() the kernel runs on the 64 CUs the target
+// pass leaves free, and one workgroup's loads hide behind the other's MFMAs.
+// One extra workgroup (blockIdx == total_tiles) folds |Q - target| into the
+// reported loss when ad.loss_out is set.
 // ---------------------------------------------------------------------------
-static __global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
+static __global__ __launch_bounds__(512, 4) void weight_grad_kernel(DwArgs a) {
   __shared__ float part[8 * 1024];
   __shared__ float csum[8 * 32];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row offsets stay in SGPRs
   if ((int)blockIdx.x >= a.total_tiles) {
     // mean |Q - target| of this step (deep_td_learning.py:358-359), fixed summation order
     float s = 0.f;
@@ -818,16 +829,23 @@ static __global__ __launch_bounds__(512) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float cs = 0.f;
+  // byte sizes stay below 2^31 (max_batch * ld * 4; checked by the host)
+  const __amdgpu_buffer_rsrc_t ra = buf_rsrc_n(P.dZ, (unsigned)a.B * (unsigned)P.ldz * 4u);
+  const __amdgpu_buffer_rsrc_t rx = buf_rsrc_n(P.X, (unsigned)a.B * (unsigned)P.ldx * 4u);
+  const unsigned va = iok ? (unsigned)(4 * h * P.ldz + i0 + l31) * 4u : kBufOob;
+  const unsigned vx = jok ? (unsigned)(4 * h * P.ldx + j0 + l31) * 4u : kBufOob;
+  const unsigned sa = (unsigned)P.ldz * 4u, sx = (unsigned)P.ldx * 4u;  // row pitch in bytes
   for (int base = wave * DW_ROWS; base < a.B; base += 8 * DW_ROWS) {
     float av[DW_ROWS / 8][4], xv[DW_ROWS / 8][4];
 #pragma unroll
     for (int g = 0; g < DW_ROWS / 8; ++g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int bb = base + g * 8 + 4 * h + j;
-        const bool ok = bb < a.B;
-        av[g][j] = ld_or_zero(P.dZ, (int64_t)bb * P.ldz + i0 + l31, ok && iok);
-        xv[g][j] = ld_or_zero(P.X, (int64_t)bb * P.ldx + j0 + l31, ok && jok);
+        const unsigned row = (unsigned)(base + g * 8 + j);  // + 4 h inside va / vx
+        av[g][j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(va + row * sa), 0, 0));
+        xv[g][j] = __builtin_bit_cast(
+            float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(vx + row * sx), 0, 0));
       }
     }
 #pragma unroll

@@ -1,26 +1,30 @@
 #!/usr/bin/env python3
-"""Per-kernel averages of rocprofv3 --pmc CSV output (one directory per pass)."""
+"""Per-kernel averages of rocprofv3 --pmc counter_collection.csv files (one or more passes).
+
+    python tools/pmc_summary.py gpurun_out/pmc_*/dqn_counter_collection.csv
+"""
+import collections
 import csv
-import glob
-import os
 import sys
-from collections import defaultdict
 
 
-def main(root):
-    table = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values
-    for path in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
-        with open(path) as f:
+def main(paths):
+    acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    for p in paths:
+        with open(p) as f:
             for row in csv.DictReader(f):
-                k = row.get("Kernel_Name", "")
-                if not k.startswith(("pa::", "void pa::")):
-                    continue
-                table[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k in sorted(table, key=lambda k: -sum(table[k].get("GRBM_GUI_ACTIVE", [0]))):
-        print(k[:100])
-        for c, v in sorted(table[k].items()):
-            print(f"    {c:28s} n={len(v):5d} avg={sum(v) / len(v):16.1f}")
+                name = row["Kernel_Name"].split("(")[0][-46:]
+                c = acc[name][row["Counter_Name"]]
+                c[0] += float(row["Counter_Value"])
+                c[1] += 1
+    counters = sorted({c for k in acc.values() for c in k})
+    print(f"{'kernel':46s} " + " ".join(f"{c[-16:]:>16s}" for c in counters))
+    for name, cs in sorted(acc.items(), key=lambda kv: -kv[1].get("SQ_BUSY_CYCLES", [0, 1])[0]):
+        if not name.startswith(("pa::", "void pa::")) and "pa::" not in name:
+            continue
+        print(f"{name:46s} " + " ".join(
+            f"{(cs[c][0] / cs[c][1]) if c in cs and cs[c][1] else float('nan'):16.1f}" for c in counters))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1:])
