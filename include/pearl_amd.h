@@ -440,6 +440,14 @@ int pa_concat_cols(const float* left, int32_t ldl, const float* right, int32_t l
 /* ------------------------------------------------------------------------ */
 /* C[M,N] = epi(A[M,K] * op(B)).  b_is_kn = 0: B is [N,K] (y = x W^T); 1: B is [K,N].
  * epi: 0 = +bias, 1 = relu(+bias), 2 = * (hmask > 0), 3 = none. */
+/* Kernel tuning aid (tools/prof_chain.py): device buffers of int64[workgroups][8 waves][16] that
+ * online_rowpass_kernel / weight_grad_kernel fill with 100 MHz wall-clock stamps at their phase
+ * boundaries, on every launch (round < 0) or only in round `round` of a pa_dqn_learn call.  NULL
+ * (the default) disables the stamps. */
+int pa_debug_set_prof(pa_dqn* h, long long* rowpass_stamps, long long* dw_stamps, int32_t round);
+/* The same for target_fused_kernel: int64[max_tiles][8][16]; launches with more tiles than
+ * max_tiles are not stamped. */
+int pa_debug_set_prof_target(pa_dqn* h, long long* stamps, int32_t max_tiles);
 int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
                     int32_t ldc, const float* bias, const float* hmask, int32_t ldh, int32_t M,
                     int32_t N, int32_t K, int32_t b_is_kn, int32_t epi, void* stream);

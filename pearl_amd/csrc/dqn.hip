@@ -73,6 +73,10 @@ struct pa_dqn {
   int n_reserved, ncu;
   int* tile_ctr;           // [kTileCtrs] work-stealing counters, one per persistent launch
   int ctr_next;
+  long long *prof_row, *prof_dw;  // phase-stamp buffers (pa_debug_set_prof), normally null
+  long long* prof_tgt;            // target kernel stamps [tile][8][16] (pa_debug_set_prof_target)
+  int prof_tgt_tiles;
+  int prof_round, cur_round;      // stamp only this round of a learn() call (-1: every launch)
   int wcap;          // rounds whose target-network pass is batched into one launch (learn())
   int64_t wrows;     // wcap * max_batch: rows of the window-sized workspaces (U, y, batch buffers)
   int64_t* idx_all;  // [idx_cap] logical indices, round-major
@@ -84,6 +88,11 @@ struct pa_dqn {
 };
 
 namespace {
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
 
 int64_t align4(int64_t x) { return (x + 3) & ~int64_t(3); }
 
@@ -241,6 +250,7 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
+  a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
   if (persistent) {
     if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream
       PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
@@ -296,6 +306,7 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   a.y = y;
   a.y_tagged = y_tagged ? 1 : 0;
   a.err = h->err_dev;
+  a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_row : nullptr;
   a.H1a = y ? h->H1a : nullptr; a.H2a = y ? h->H2a : nullptr;
   a.dZ2 = h->dZ2; a.dZ1 = h->dZ1;
   a.q_out = q_out; a.dq_out = h->dq; a.absd_out = h->absd;
@@ -362,32 +373,33 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   a.p[0].dW = G + h->off[2]; a.p[0].ldw = d.hidden1;
   a.p[0].db = G + h->off[3];
   a.p[0].M = d.hidden2; a.p[0].N = d.hidden1;
-  a.p[0].tiles_n = (int)ceil_div(d.hidden1, 32);
+  a.p[0].tiles_n = (int)ceil_div(d.hidden1, DW_TN);
   a.p[0].tile0 = 0;
   a.p[0].kind = 0;
-  int t0 = (int)ceil_div(d.hidden2, 32) * a.p[0].tiles_n;
+  int t0 = (int)ceil_div(d.hidden2, DW_TM) * a.p[0].tiles_n;
   // dW1 = dZ1^T x, db1
   a.p[1].dZ = h->dZ1; a.p[1].ldz = d.hidden1;
   a.p[1].X = x; a.p[1].ldx = h->IN;
   a.p[1].dW = G + h->off[0]; a.p[1].ldw = h->IN;
   a.p[1].db = G + h->off[1];
   a.p[1].M = d.hidden1; a.p[1].N = h->IN;
-  a.p[1].tiles_n = (int)ceil_div(h->IN, 32);
+  a.p[1].tiles_n = (int)ceil_div(h->IN, DW_TN);
   a.p[1].tile0 = t0;
   a.p[1].kind = 1;
-  t0 += (int)ceil_div(d.hidden1, 32) * a.p[1].tiles_n;
+  t0 += (int)ceil_div(d.hidden1, DW_TM) * a.p[1].tiles_n;
   // dW3 = dq^T H2a, db3 = sum dq   (dq is a [B][1] "dZ")
   a.p[2].dZ = h->dq; a.p[2].ldz = 1;
   a.p[2].X = h->H2a; a.p[2].ldx = d.hidden2;
   a.p[2].dW = G + h->off[4]; a.p[2].ldw = d.hidden2;
   a.p[2].db = G + h->off[5];
   a.p[2].M = 1; a.p[2].N = d.hidden2;
-  a.p[2].tiles_n = (int)ceil_div(d.hidden2, 32);
+  a.p[2].tiles_n = (int)ceil_div(d.hidden2, DW_TN);
   a.p[2].tile0 = t0;
   a.p[2].kind = 2;
   t0 += a.p[2].tiles_n;
   a.total_tiles = t0;
   a.B = B;
+  a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_dw : nullptr;
   a.ad.absd = h->absd; a.ad.nabs = B; a.ad.inv_B = (float)(1.0 / (double)B);
   a.ad.loss_out = loss_out;
   if (fuse_adam) {
@@ -518,10 +530,6 @@ int ensure_batchbufs(pa_dqn* h, int A) {
   return PA_OK;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 // Choose the compute units the online chain keeps for itself: a census kernel reports the
 // (XCC, SE, SH, CU) key of every CU; `want` of them, spread evenly over XCDs and shader engines,
@@ -687,6 +695,10 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->ncu = 0;
   h->tile_ctr = nullptr;
   h->ctr_next = 0;
+  h->prof_row = h->prof_dw = nullptr;
+  h->prof_tgt = nullptr;
+  h->prof_tgt_tiles = 0;
+  h->prof_round = h->cur_round = -1;
   const int64_t B = desc->max_batch;
   // learn() evaluates the target network for a whole window of rounds in one launch (the target
   // parameters only change every target_update_freq rounds): up to 16 rounds / 16384 transitions
@@ -935,10 +947,25 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // the chain can start after one round's worth of target work instead of the whole window's
     // (the first piece runs as a classic grid on every CU — the chain is idle then anyway — the
     // rest as persistent tiles that stay off the chain's CUs)
-    const int piece0 = (overlap && h->split_first > 0 && w > h->split_first) ? h->split_first : w;
+    // Piece schedule of the overlapped loop (split_first = 12 means "1 round, then 2 rounds, then
+    // the rest"): the first pieces are classic grids on every CU — the chain is still waiting for
+    // its first targets — the last one runs as persistent tiles that stay off the chain's CUs.
+    // Small leading pieces shorten the wait of round 0 (one round = one workgroup per CU, ~20 us),
+    // and the second piece is sized so that it is done when round 0's chain is.
+    int sched[4] = {w, 0, 0, 0}, npieces = 1;
+    if (overlap && h->split_first > 0) {
+      int digits[3], nd = 0;
+      for (int v = h->split_first; v > 0 && nd < 3; v /= 10) digits[nd++] = v % 10;
+      int used = 0;
+      npieces = 0;
+      for (int i = nd - 1; i >= 0; --i)
+        if (digits[i] > 0 && used + digits[i] < w) { sched[npieces++] = digits[i]; used += digits[i]; }
+      sched[npieces++] = w - used;
+    }
     const bool persist = env_int("PEARL_AMD_PERSIST", overlap ? 1 : 0) != 0;
-    for (int j0 = 0; j0 < w;) {
-      const int nj = (j0 == 0) ? piece0 : (w - j0);
+    int pc = 0;
+    for (int j0 = 0; j0 < w; ++pc) {
+      const int nj = sched[pc];
       const int64_t row0 = (int64_t)j0 * B;
       const int prow = nj * B;
       pa_dqn_batch b;
@@ -957,7 +984,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         if (rc != PA_OK) return rc;
       }
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t,
-                              persist && (j0 > 0 || piece0 == w));
+                              persist && pc == npieces - 1);
       if (rc != PA_OK) return rc;
       j0 += nj;
     }
@@ -974,6 +1001,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     }
     for (int j = 0; j < w; ++j) {
       const int round = r + j;
+      h->cur_round = round;
       const int soft_next = (round + 1 < R) ? due(round + 1) : 0;
       const float* xj = h->bb_x + (int64_t)j * B * h->IN;
       const float* yj = h->yw[p] + (int64_t)j * B;
@@ -1055,6 +1083,21 @@ extern "C" int pa_dqn_get_timing_units(pa_dqn* h, const char* name, int64_t* uni
 }
 
 // ---- diagnostics ---------------------------------------------------------------
+extern "C" int pa_debug_set_prof_target(pa_dqn* h, long long* stamps, int32_t max_tiles) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  h->prof_tgt = stamps;
+  h->prof_tgt_tiles = max_tiles;
+  return PA_OK;
+}
+extern "C" int pa_debug_set_prof(pa_dqn* h, long long* rowpass_stamps, long long* dw_stamps,
+                                 int32_t round) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  h->prof_row = rowpass_stamps;
+  h->prof_dw = dw_stamps;
+  h->prof_round = round;
+  return PA_OK;
+}
+
 extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
                                int32_t ldc, const float* bias, const float* hmask, int32_t ldh,
                                int32_t M, int32_t N, int32_t K, int32_t b_is_kn, int32_t epi,
@@ -1080,8 +1123,8 @@ extern "C" int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X
   memset(&a, 0, sizeof(a));
   a.p[0].dZ = dZ; a.p[0].ldz = ldz; a.p[0].X = X; a.p[0].ldx = ldx;
   a.p[0].dW = dW; a.p[0].ldw = ldw; a.p[0].db = db; a.p[0].M = M; a.p[0].N = N;
-  a.p[0].tiles_n = (int)ceil_div(N, 32); a.p[0].tile0 = 0;
-  a.total_tiles = (int)ceil_div(M, 32) * a.p[0].tiles_n;
+  a.p[0].tiles_n = (int)ceil_div(N, DW_TN); a.p[0].tile0 = 0;
+  a.total_tiles = (int)ceil_div(M, DW_TM) * a.p[0].tiles_n;
   a.nprob = 1;
   a.B = Bn;
   hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0,

@@ -21,6 +21,14 @@
 
 namespace pa {
 
+// Phase stamps for kernel tuning: lane 0 of every wave stores the 100 MHz wall clock
+// (s_memrealtime) at slot i.  `prof` is null outside tools/prof_chain.py.
+#define PA_STAMP(prof, wg, wave, i)                                                     \
+  do {                                                                                  \
+    if ((prof) && (threadIdx.x & 63) == 0)                                              \
+      (prof)[((int64_t)(wg) * 8 + (wave)) * 16 + (i)] = (long long)wall_clock64();      \
+  } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -317,6 +325,7 @@ struct TargetArgs {
   int* tile_ctr;             // null: classic grid, tile = blockIdx.x
   int ntiles;
   const uint8_t* reserved;   // [kCuKeys] 1 = this CU belongs to the online chain; may be null
+  long long* prof;           // optional phase stamps [tile][wave][16] (tools/prof_chain.py)
 };
 
 // (XCC_ID, HW_ID.se_id|sh_id|cu_id) of the compute unit the calling wave runs on
@@ -431,6 +440,7 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
   // ds_write_b128 per tile, and layer 3 (a dot product over hidden units) is an in-lane fma chain
   // instead of a cross-lane reduction.
   const int nq0 = wave * 32 + 4 * h;     // this lane's hidden units: nq0 + 8*q + j, q,j in 0..3
+  PA_STAMP(a.prof, tile, wave, 0);
 
   // ---- layer 1 operands first (vmcnt retires in order: layer 1 never waits for the W2' stream)
   f32x16 acc[2];
@@ -503,6 +513,7 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
     return v2 ? ld4_or_zero(p, n, n < a.H2) : guarded_load4(p, 0, true, n, a.H2);
   };
 
+  PA_STAMP(a.prof, tile, wave, 1);
   l1_mfma(fx[0], fw[0]);
   l1_mfma(fx[1], fw[1]);
   for (int k0 = 16; k0 < a.AD; k0 += 8) {  // wider action representations (rare)
@@ -524,7 +535,9 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
       }
     }
   }
+  PA_STAMP(a.prof, tile, wave, 2);
   __syncthreads();  // the only workgroup barrier before the epilogue
+  PA_STAMP(a.prof, tile, wave, 3);
 
   // ---- layer 2: acc[n][row] = sum_k W2'[n][k] h1[row][k]
 #pragma unroll
@@ -553,6 +566,7 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
     }
   }
 
+  PA_STAMP(a.prof, tile, wave, 4);
   if (!l2) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) b2v[q] = w3v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -571,7 +585,9 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
     sum += __shfl_xor(sum, 32);
     if (h == 0) qpart[wave * 64 + tm * 32 + l31] = sum;
   }
+  PA_STAMP(a.prof, tile, wave, 5);
   __syncthreads();
+  PA_STAMP(a.prof, tile, wave, 6);
   if (tid < T_ROWS) {
     float q = 0.f;
 #pragma unroll
@@ -600,6 +616,8 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
       publish_y(a.y + bb, __fadd_rn(t1, a.reward[bb]));
     }
   }
+  PA_STAMP(a.prof, tile, wave, 7);
+  if (a.prof && (threadIdx.x & 63) == 0) a.prof[((int64_t)tile * 8 + wave) * 16 + 8] = cu_key();
 }
 
 template <int NKG>
@@ -611,13 +629,20 @@ static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs 
   }
   __shared__ int next_tile;
   if (a.reserved && a.reserved[cu_key()]) return;
-  for (;;) {
-    if (threadIdx.x == 0) next_tile = atomicAdd(a.tile_ctr, 1);
-    __syncthreads();
-    const int tile = next_tile;
-    if (tile >= a.ntiles) return;
+  // (Tried and measured without effect on this kernel: delaying every second workgroup of a CU by
+  // half a tile, and s_setprio 3 outside the MFMA main loop.)
+  // The index of the NEXT tile is requested while the current one is computed (a returning
+  // device-scope atomic costs 1-3 us under load; exposed, it would stretch every tile).
+  if (threadIdx.x == 0) next_tile = atomicAdd(a.tile_ctr, 1);
+  __syncthreads();
+  int tile = next_tile;
+  while (tile < a.ntiles) {
+    int ahead = 0;
+    if (threadIdx.x == 0) ahead = atomicAdd(a.tile_ctr, 1);
     target_tile<NKG>(a, tile, smem);
-    __syncthreads();  // LDS (and next_tile) are reused by the next tile
+    if (threadIdx.x == 0) next_tile = ahead;
+    __syncthreads();  // publishes next_tile; LDS is reused by the next tile
+    tile = next_tile;
   }
 }
 
@@ -702,6 +727,21 @@ struct AdamScalars {
 struct AdamState {
   float* p; float* m; float* v; float* vmax;
 };
+// The same update on values already in registers (vm is ignored unless amsgrad).
+__device__ __forceinline__ void adam_math(const AdamScalars& c, float g, float& p, float& m,
+                                          float& v, float& vm) {
+  p = __fmul_rn(p, c.decay);
+  m = __fadd_rn(m, __fmul_rn(c.w1, __fsub_rn(g, m)));
+  v = __fmul_rn(v, c.beta2);
+  v = __fadd_rn(v, __fmul_rn(__fmul_rn(c.omb2, g), g));
+  float dn = v;
+  if (c.amsgrad) {
+    vm = (v > vm || v != v) ? v : vm;
+    dn = vm;
+  }
+  const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(dn), c.bc2_sqrt), c.eps);
+  p = __fadd_rn(p, __fdiv_rn(__fmul_rn(c.neg_step, m), denom));
+}
 __device__ __forceinline__ float adam_update(const AdamScalars& c, const AdamState& st, int64_t i,
                                              float g) {
   float p = __fmul_rn(st.p[i], c.decay);
@@ -754,8 +794,8 @@ struct DwArgs {
   DwProblem p[3];
   int nprob, B, total_tiles;
   AdamFuse ad;
+  long long* prof;   // optional phase stamps (tools/prof_chain.py): [workgroup][wave][16]
 };
-constexpr int DW_ROWS = 64;   // batch rows per wave per pass
 
 // index of fragment-major slots (defined here, used by online_kernels.hpp as well)
 __host__ __device__ inline int64_t wf16_index_(int unit, int k, int nkg) {
@@ -787,21 +827,107 @@ __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, fl
 // ---------------------------------------------------------------------------
 // Weight gradients: dW[i][j] = sum_b dZ[b][i] X[b][j], db[i] = sum_b dZ[b][i], for
 // up to three problems per launch (dW2/db2, dW1/db1, dW3/db3 with dZ = dq[B][1]).
-// One 32 x 32 output tile per workgroup; its 8 waves split the batch (the K
-// dimension) and add their partial tiles in a fixed order through LDS.  Both
-// operands are row-contiguous across lanes, so they go global -> VGPR -> MFMA
-// with no LDS staging; every load of a wave's 64-row pass is issued before its
-// first MFMA.  Addressing costs one VALU add per load: the buffer descriptors cover
-// exactly B rows (rows past the batch read as zero by range check) and the column
-// guard is folded into a loop-invariant lane offset.  <= 128 VGPRs so that two
-// workgroups share a CU: inside learn() the kernel runs on the 64 CUs the target
-// pass leaves free, and one workgroup's loads hide behind the other's MFMAs.
-// One extra workgroup (blockIdx == total_tiles) folds |Q - target| into the
-// reported loss when ad.loss_out is set.
+//
+// One 64 x 32 output tile per workgroup, v_mfma_f32_16x16x4_f32; its 8 waves split the batch
+// (the K dimension) and add their partial tiles in a fixed order through LDS.  Both operands are
+// row-contiguous across lanes and go global -> VGPR -> MFMA with no LDS staging:
+//   lane (c = lane & 15, q = lane >> 4), step s (batch rows b0 .. b0 + 3):
+//     a4 = dZ[b0 + q][i0 + 4c .. 4c + 3]   one 16-byte load, A operand of 4 MFMAs (unit 4c + ja)
+//     x2 = X [b0 + q][j0 + 2c .. 2c + 1]   one  8-byte load, B operand of 2 MFMAs (col 2c + jx)
+//     acc[ja][jx] += A_ja (16 units x 4 rows) * B_jx (4 rows x 16 cols)         8 MFMAs
+// i.e. 256 MFMA cycles per pair of wide loads.  (The first version fed 32x32x2 MFMAs from dword
+// loads, one per operand per MFMA: the CU's address pipe, ~15 cycles per wave-load whatever its
+// width, was the bound — 6.4 us of issue per workgroup against 3.4 us of MFMA.)  Loads run
+// RING steps ahead of their use through a register ring with static indices.  The buffer
+// descriptors cover exactly B rows, so rows past the batch read as zero by range check, and the
+// column guards are loop-invariant lane offsets.  One extra workgroup (blockIdx == total_tiles)
+// folds |Q - target| into the reported loss when ad.loss_out is set.
 // ---------------------------------------------------------------------------
-static __global__ __launch_bounds__(512, 4) void weight_grad_kernel(DwArgs a) {
-  __shared__ float part[8 * 1024];
-  __shared__ float csum[8 * 32];
+constexpr int DW_TM = 64, DW_TN = 32, DW_RING = 8;
+typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
+
+struct DwFrag {
+  float4 a;
+  float2 x;
+};
+
+// Byte offsets: a lane whose vector lies outside the operand carries kBufOob (2^31), a step past
+// the wave's slice adds kDwDead (2^30); the descriptors cover < 2^30 bytes, so either one (or
+// both: 3 * 2^30) fails the range check and the load returns zeros.
+constexpr unsigned kDwDead = 0x40000000u;
+
+template <bool FAST>
+__device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
+                                         const __amdgpu_buffer_rsrc_t& rx, const unsigned (&va)[4],
+                                         const unsigned (&vx)[2], unsigned ba, unsigned bx,
+                                         DwFrag& f) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  if constexpr (FAST) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va[0] + ba), 0, 0);
+    const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
+    f.a = make_float4(f4[0], f4[1], f4[2], f4[3]);
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(vx[0] + bx), 0, 0);
+    const f32x2 f2 = __builtin_bit_cast(f32x2, w);
+    f.x = make_float2(f2[0], f2[1]);
+  } else {
+    float e[4], g[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      e[k] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(va[k] + ba), 0, 0));
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      g[k] = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(vx[k] + bx), 0, 0));
+    f.a = make_float4(e[0], e[1], e[2], e[3]);
+    f.x = make_float2(g[0], g[1]);
+  }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
+                                            const __amdgpu_buffer_rsrc_t& rx,
+                                            const unsigned (&va)[4], const unsigned (&vx)[2],
+                                            unsigned oa, unsigned ox, unsigned sa, unsigned sx,
+                                            int nsteps, dw_f32x4 (&acc)[4][2], float (&cs)[4]) {
+#pragma unroll
+  for (int ja = 0; ja < 4; ++ja) {
+    acc[ja][0] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[ja][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[ja] = 0.f;
+  }
+  DwFrag ring[DW_RING];
+#pragma unroll
+  for (int p = 0; p < DW_RING; ++p) {
+    const bool live = p < nsteps;
+    dw_fetch<FAST>(ra, rx, va, vx, live ? oa + (unsigned)p * sa : kDwDead,
+                   live ? ox + (unsigned)p * sx : kDwDead, ring[p]);
+  }
+  for (int s0 = 0; s0 < nsteps; s0 += DW_RING) {
+#pragma unroll
+    for (int p = 0; p < DW_RING; ++p) {
+      const DwFrag f = ring[p];
+      const int sn = s0 + p + DW_RING;
+      const bool live = sn < nsteps;  // steps past the slice must not read the next wave's rows
+      dw_fetch<FAST>(ra, rx, va, vx, live ? oa + (unsigned)sn * sa : kDwDead,
+                     live ? ox + (unsigned)sn * sx : kDwDead, ring[p]);
+      __builtin_amdgcn_sched_barrier(0);  // keep the refill here, DW_RING steps ahead of its use
+      const float av[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
+      const float xv[2] = {f.x.x, f.x.y};
+#pragma unroll
+      for (int ja = 0; ja < 4; ++ja) {
+        acc[ja][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], xv[0], acc[ja][0], 0, 0, 0);
+        acc[ja][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], xv[1], acc[ja][1], 0, 0, 0);
+        cs[ja] += av[ja];
+      }
+    }
+  }
+}
+
+static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
+  __shared__ float part[4 * DW_TM * DW_TN];  // 32 KB: four partial tiles
+  __shared__ float csum[8 * DW_TM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row offsets stay in SGPRs
   if ((int)blockIdx.x >= a.total_tiles) {
@@ -817,72 +943,197 @@ static __global__ __launch_bounds__(512, 4) void weight_grad_kernel(DwArgs a) {
     if (tid == 0) a.ad.loss_out[0] = part[0] * a.ad.inv_B;
     return;
   }
-  const int h = lane >> 5, l31 = lane & 31;
+  PA_STAMP(a.prof, blockIdx.x, wave, 0);
+  const int c = lane & 15, q = lane >> 4;
   int pi = 0;
   if (a.nprob > 1 && (int)blockIdx.x >= a.p[1].tile0) pi = 1;
   if (a.nprob > 2 && (int)blockIdx.x >= a.p[2].tile0) pi = 2;
   const DwProblem& P = a.p[pi];
   const int t = blockIdx.x - P.tile0;
-  const int i0 = (t / P.tiles_n) * 32, j0 = (t % P.tiles_n) * 32;
-  const bool iok = (i0 + l31) < P.M, jok = (j0 + l31) < P.N;
-  f32x16 acc;
+  const int i0 = (t / P.tiles_n) * DW_TM, j0 = (t % P.tiles_n) * DW_TN;
+  if (P.M == 1) {
+    // Single-output layers (dW3 = dq^T h2, db3 = sum dq): a matrix tile would be 63/64 padding.
+    // 32 columns x 16 row groups per workgroup, sequential fma per thread, row groups summed in
+    // a fixed order through LDS.
+    const int col = j0 + (tid & 31), rg = tid >> 5;
+    const __amdgpu_buffer_rsrc_t rz = buf_rsrc_n(P.dZ, (unsigned)a.B * (unsigned)P.ldz * 4u);
+    const __amdgpu_buffer_rsrc_t rxx = buf_rsrc_n(P.X, (unsigned)a.B * (unsigned)P.ldx * 4u);
+    const unsigned vcol = (col < P.N) ? (unsigned)col * 4u : kBufOob;
+    float accv = 0.f, sdz = 0.f;
+#pragma unroll 8
+    for (int b = rg; b < a.B; b += 16) {
+      const float dz = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rz, (int)((unsigned)(b * P.ldz) * 4u), 0, 0));
+      const float xv = __builtin_bit_cast(
+          float, __builtin_amdgcn_raw_buffer_load_b32(rxx, (int)(vcol + (unsigned)(b * P.ldx) * 4u), 0, 0));
+      accv = fmaf(dz, xv, accv);
+      sdz += dz;
+    }
+    part[rg * 32 + (tid & 31)] = accv;
+    if ((tid & 31) == 0) csum[rg] = sdz;
+    __syncthreads();
+    if (tid < 32 && col < P.N) {
+      float g = part[tid];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float cs = 0.f;
-  // byte sizes stay below 2^31 (max_batch * ld * 4; checked by the host)
+      for (int w = 1; w < 16; ++w) g += part[w * 32 + tid];
+      float* dst = P.dW + col;
+      *dst = g;
+      if (a.ad.enabled) adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, 0, col, g);
+    }
+    if (j0 == 0 && tid == 0) {
+      float g = csum[0];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) g += csum[w];
+      P.db[0] = g;
+      if (a.ad.enabled) adam_fused_bias(a.ad, P.db - a.ad.grad_base, g);
+    }
+    return;
+  }
+  // wave-uniform: whole 16- / 8-byte vectors are inside or outside the operand
+  const bool fa = ((P.ldz & 3) == 0) && ((P.M & 3) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(P.dZ) & 15) == 0);
+  const bool fx = ((P.ldx & 1) == 0) && ((P.N & 1) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(P.X) & 7) == 0);
+  // byte sizes stay below 2^30 (max_batch * ld * 4; checked by the host)
   const __amdgpu_buffer_rsrc_t ra = buf_rsrc_n(P.dZ, (unsigned)a.B * (unsigned)P.ldz * 4u);
   const __amdgpu_buffer_rsrc_t rx = buf_rsrc_n(P.X, (unsigned)a.B * (unsigned)P.ldx * 4u);
-  const unsigned va = iok ? (unsigned)(4 * h * P.ldz + i0 + l31) * 4u : kBufOob;
-  const unsigned vx = jok ? (unsigned)(4 * h * P.ldx + j0 + l31) * 4u : kBufOob;
-  const unsigned sa = (unsigned)P.ldz * 4u, sx = (unsigned)P.ldx * 4u;  // row pitch in bytes
-  for (int base = wave * DW_ROWS; base < a.B; base += 8 * DW_ROWS) {
-    float av[DW_ROWS / 8][4], xv[DW_ROWS / 8][4];
+  const int ua = i0 + 4 * c, cx = j0 + 2 * c;  // first unit / column of this lane's vectors
+  unsigned va[4], vx[2];                       // per-component byte offsets of row q (kBufOob: none)
 #pragma unroll
-    for (int g = 0; g < DW_ROWS / 8; ++g) {
+  for (int e = 0; e < 4; ++e)
+    va[e] = (ua + e < P.M) ? (unsigned)(q * P.ldz + ua + e) * 4u : kBufOob;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned row = (unsigned)(base + g * 8 + j);  // + 4 h inside va / vx
-        av[g][j] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(va + row * sa), 0, 0));
-        xv[g][j] = __builtin_bit_cast(
-            float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(vx + row * sx), 0, 0));
-      }
-    }
+  for (int e = 0; e < 2; ++e)
+    vx[e] = (cx + e < P.N) ? (unsigned)(q * P.ldx + cx + e) * 4u : kBufOob;
+  const unsigned sa = (unsigned)P.ldz * 16u, sx = (unsigned)P.ldx * 16u;  // bytes per 4-row step
+  // this wave's slice of the batch: KS rows (a multiple of 4), nsteps 4-row steps
+  const int nsteps = (a.B + 31) / 32, row0 = wave * nsteps * 4;
+  const unsigned oa = (unsigned)row0 * (unsigned)P.ldz * 4u, ox = (unsigned)row0 * (unsigned)P.ldx * 4u;
+  // Epilogue assignment, fixed now so that the optimizer state can be fetched under the main
+  // loop: thread -> tile row tid >> 3, columns 4 (tid & 7) .. + 3.  evec: the four elements are one
+  // aligned float4 of dW (and of every flat optimizer buffer, which share its offsets).
+  const int erl = tid >> 3, ecg = tid & 7;
+  const int eja = erl & 3, ereg = (erl >> 2) & 3, eq = erl >> 4;
+  const int erow = i0 + erl, ecol = j0 + 4 * ecg;
+  const bool evec = erow < P.M && ecol + 3 < P.N && ((P.ldw & 3) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(P.dW) & 15) == 0);
+  const int64_t eflat = (P.dW + (int64_t)erow * P.ldw + ecol) - a.ad.grad_base;
+  float4 p4, m4, v4, x4;
+  p4 = m4 = v4 = x4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (evec && a.ad.enabled) {
+    p4 = *reinterpret_cast<const float4*>(a.ad.st.p + eflat);
+    m4 = *reinterpret_cast<const float4*>(a.ad.st.m + eflat);
+    v4 = *reinterpret_cast<const float4*>(a.ad.st.v + eflat);
+    if (a.ad.c.amsgrad) x4 = *reinterpret_cast<const float4*>(a.ad.st.vmax + eflat);
+  }
+  dw_f32x4 acc[4][2];
+  float cs[4];
+  PA_STAMP(a.prof, blockIdx.x, wave, 1);
+  if (fa && fx) dw_mainloop<true>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs);
+  else dw_mainloop<false>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs);
+  PA_STAMP(a.prof, blockIdx.x, wave, 2);
+  // ---- partial tiles: (waves 4..7 -> LDS, waves 0..3 add), then (waves 0..3 -> LDS, all sum)
+  // element id of acc[ja][jx][reg] on `lane`: ((ja * 2 + jx) * 4 + reg) * 64 + lane
+  if (wave >= 4) {
+    float* dst = part + (wave - 4) * (DW_TM * DW_TN) + lane;
 #pragma unroll
-    for (int g = 0; g < DW_ROWS / 8; ++g) {
+    for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc = mfma32(av[g][j], xv[g][j], acc);
-        cs += av[g][j];
-      }
-    }
+      for (int jx = 0; jx < 2; ++jx)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[((ja * 2 + jx) * 4 + r) * 64] = acc[ja][jx][r];
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) part[wave * 1024 + r * 64 + lane] = acc[r];
-  cs += __shfl_xor(cs, 32);
-  if (h == 0) csum[wave * 32 + l31] = cs;
+  for (int ja = 0; ja < 4; ++ja) {
+    cs[ja] += __shfl_xor(cs[ja], 16);
+    cs[ja] += __shfl_xor(cs[ja], 32);
+    if (q == 0) csum[wave * DW_TM + 4 * c + ja] = cs[ja];
+  }
+  PA_STAMP(a.prof, blockIdx.x, wave, 3);
   __syncthreads();
+  if (wave < 4) {
+    float* slot = part + wave * (DW_TM * DW_TN) + lane;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int e = tid + q * 512;
-    float s = part[e];
+    for (int ja = 0; ja < 4; ++ja)
 #pragma unroll
-    for (int w = 1; w < 8; ++w) s += part[w * 1024 + e];
-    const int reg = e >> 6, ln = e & 63;
-    const int row = i0 + acc_row(reg, ln >> 5), col = j0 + (ln & 31);
-    if (row < P.M && col < P.N) {
-      float* dst = P.dW + (int64_t)row * P.ldw + col;
-      *dst = s;
-      if (a.ad.enabled) adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, row, col, s);
+      for (int jx = 0; jx < 2; ++jx)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ja][jx][r] += slot[((ja * 2 + jx) * 4 + r) * 64];
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+      for (int jx = 0; jx < 2; ++jx)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[((ja * 2 + jx) * 4 + r) * 64] = acc[ja][jx][r];
+  }
+  PA_STAMP(a.prof, blockIdx.x, wave, 4);
+  __syncthreads();
+  PA_STAMP(a.prof, blockIdx.x, wave, 5);
+  {
+    // thread -> one row, four consecutive columns of the tile (see the prefetch above)
+    float g4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int idx = ((eja * 2 + (e & 1)) * 4 + ereg) * 64 + eq * 16 + 2 * ecg + (e >> 1);
+      float sum = part[idx];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) sum += part[w * (DW_TM * DW_TN) + idx];
+      g4[e] = sum;
+    }
+    if (evec) {
+      *reinterpret_cast<float4*>(P.dW + (int64_t)erow * P.ldw + ecol) =
+          make_float4(g4[0], g4[1], g4[2], g4[3]);
+      if (a.ad.enabled) {
+        float pv[4] = {p4.x, p4.y, p4.z, p4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
+        float vv[4] = {v4.x, v4.y, v4.z, v4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) adam_math(a.ad.c, g4[e], pv[e], mv[e], vv[e], xv[e]);
+        const float4 pn = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        *reinterpret_cast<float4*>(a.ad.st.p + eflat) = pn;
+        *reinterpret_cast<float4*>(a.ad.st.m + eflat) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        *reinterpret_cast<float4*>(a.ad.st.v + eflat) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (a.ad.c.amsgrad)
+          *reinterpret_cast<float4*>(a.ad.st.vmax + eflat) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+        // fragment-major copies: four consecutive k of one unit are one float4 slot
+        if (P.kind == 0) {
+          *reinterpret_cast<float4*>(a.ad.W2f + wf16_index_(erow, ecol, a.ad.nkg_w2)) = pn;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a.ad.W2tf[wf16_index_(ecol + e, erow, a.ad.nkg_w2t)] = pv[e];
+        } else if (P.kind == 1) {
+          *reinterpret_cast<float4*>(a.ad.W1f + wf16_index_(erow, ecol, a.ad.nkg_w1)) = pn;
+        }
+        if (a.ad.soft_next) {  // update_target_network (common/utils.py:214-226)
+          const float4 t4 = *reinterpret_cast<const float4*>(a.ad.tgt + eflat);
+          float4 tn;
+          tn.x = __fadd_rn(__fmul_rn(a.ad.tau, pv[0]), __fmul_rn(a.ad.one_minus_tau, t4.x));
+          tn.y = __fadd_rn(__fmul_rn(a.ad.tau, pv[1]), __fmul_rn(a.ad.one_minus_tau, t4.y));
+          tn.z = __fadd_rn(__fmul_rn(a.ad.tau, pv[2]), __fmul_rn(a.ad.one_minus_tau, t4.z));
+          tn.w = __fadd_rn(__fmul_rn(a.ad.tau, pv[3]), __fmul_rn(a.ad.one_minus_tau, t4.w));
+          *reinterpret_cast<float4*>(a.ad.tgt + eflat) = tn;
+          if (P.kind == 0)
+            *reinterpret_cast<float4*>(a.ad.tW2f + w2f_index(erow, ecol, a.ad.nkg_t)) = tn;
+        }
+      }
+    } else if (erow < P.M) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (ecol + e < P.N) {
+          float* dst = P.dW + (int64_t)erow * P.ldw + ecol + e;
+          *dst = g4[e];
+          if (a.ad.enabled)
+            adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, erow, ecol + e, g4[e]);
+        }
+      }
     }
   }
-  if (j0 == 0 && tid < 32 && (i0 + tid) < P.M) {
+  if (j0 == 0 && tid < DW_TM && (i0 + tid) < P.M) {
     float s = csum[tid];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) s += csum[w * 32 + tid];
+    for (int w = 1; w < 8; ++w) s += csum[w * DW_TM + tid];
     P.db[i0 + tid] = s;
     if (a.ad.enabled) adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 6);
 }
 
 // ---------------------------------------------------------------------------

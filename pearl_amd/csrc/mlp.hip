@@ -224,10 +224,10 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       // its column sums go to scratch so AdamW never moves it
       a.p[0].db = (l == h->L - 1 && h->d.no_last_bias) ? h->dz[(l + 1) & 1] : h->bufs.grad + h->boff[l];
       a.p[0].M = h->d.dims[l + 1]; a.p[0].N = h->d.dims[l];
-      a.p[0].tiles_n = (int)ceil_div(h->d.dims[l], 32);
+      a.p[0].tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
       a.p[0].tile0 = 0;
       a.p[0].kind = 2;
-      a.total_tiles = (int)ceil_div(h->d.dims[l + 1], 32) * a.p[0].tiles_n;
+      a.total_tiles = (int)ceil_div(h->d.dims[l + 1], DW_TM) * a.p[0].tiles_n;
       a.B = B;
       hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
       PA_LAUNCH_CHECK();
@@ -838,10 +838,10 @@ extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* 
   a.p[0].dW = delta_out; a.p[0].ldw = D + 1;
   a.p[0].db = x_scratch + (int64_t)B * D;   // scratch tail: D floats
   a.p[0].M = D; a.p[0].N = D + 1;
-  a.p[0].tiles_n = (int)ceil_div(D + 1, 32);
+  a.p[0].tiles_n = (int)ceil_div(D + 1, DW_TN);
   a.p[0].tile0 = 0;
   a.p[0].kind = 2;
-  a.total_tiles = (int)ceil_div(D, 32) * a.p[0].tiles_n;
+  a.total_tiles = (int)ceil_div(D, DW_TM) * a.p[0].tiles_n;
   a.B = B;
   hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
   PA_LAUNCH_CHECK();

@@ -145,6 +145,7 @@ struct RowArgs {
   const float* y;                       // [B] Bellman targets; null = forward only (probe)
   int y_tagged;                         // y is produced concurrently by another stream (consume_y)
   int* err;                             // device error word for the bounded wait
+  long long* prof;                      // optional phase stamps (tools/prof_chain.py)
   float* H1a; float* H2a;               // [B][H1], [B][H2] relu outputs (weight-gradient operands)
   float* dZ2; float* dZ1;               // [B][H2], [B][H1] pre-activation gradients
   float* q_out; float* dq_out; float* absd_out;  // [B]; q_out may be null
@@ -270,6 +271,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, qd = lane >> 4;
+  PA_STAMP(a.prof, blockIdx.x, wave, 0);
   const int m0 = blockIdx.x * RP_ROWS;
   const int row = m0 + r16;
   const bool rok = row < a.B;
@@ -300,13 +302,16 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
     acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 1);
   __syncthreads();
+  PA_STAMP(a.prof, blockIdx.x, wave, 2);
   WRing R2;
   if constexpr (NG1 > 0) {
     rows16_gemm_static<NG1>(acc, R1, a.W1f, tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
   } else {
     rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 3);
   if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
   float4 h1k[2];  // kept for the ReLU mask of dZ1
 #pragma unroll
@@ -326,13 +331,16 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   float4 w3v[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) w3v[t] = guarded_load4(a.w3, 0, true, u0 + 16 * t, a.H2);
+  PA_STAMP(a.prof, blockIdx.x, wave, 4);
   __syncthreads();
+  PA_STAMP(a.prof, blockIdx.x, wave, 5);
   WRing R3;
   if constexpr (NG2 > 0) {
     rows16_gemm_static<NG2>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   } else {
     rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 6);
   if constexpr (NG3 > 0) {
     if (a.y) ring_fill<NG3>(R3, a.W2tf, tile0, nt1, lane);
   }
@@ -352,7 +360,9 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   part += __shfl_xor(part, 16);
   part += __shfl_xor(part, 32);
   if (qd == 0) qpart[wave * 16 + r16] = part;
+  PA_STAMP(a.prof, blockIdx.x, wave, 7);
   __syncthreads();
+  PA_STAMP(a.prof, blockIdx.x, wave, 8);
   float q = 0.f;
 #pragma unroll
   for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
@@ -362,6 +372,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   // ---- loss and dZ2 = [h2 > 0] * dq * w3
   float yv = q;
   if (rok) yv = a.y_tagged ? consume_y(a.y + row, a.err) : a.y[row];
+  PA_STAMP(a.prof, blockIdx.x, wave, 9);
   const float d = __fsub_rn(q, yv);
   const float dq = __fmul_rn(a.norm, d);
   if (wave == 0 && qd == 0 && rok) {
@@ -380,7 +391,9 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     if (u < PH2 - 4) *reinterpret_cast<float4*>(d2s + r16 * PH2 + u) = z;
     if (rok) store4_guarded(a.dZ2, (int64_t)row * a.H2, u, a.H2, v2, z);
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 10);
   __syncthreads();
+  PA_STAMP(a.prof, blockIdx.x, wave, 11);
   // every wave of the workgroup has consumed y[row]: restore the tag for the buffer's next use
   if (a.y_tagged && wave == 0 && qd == 0 && rok)
     __hip_atomic_store(reinterpret_cast<unsigned*>(const_cast<float*>(a.y)) + row, kYPendingBits,
@@ -393,6 +406,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   } else {
     rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 12);
   if (rok) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -404,6 +418,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
       store4_guarded(a.dZ1, (int64_t)row * a.H1, u0 + 16 * t, a.H1, v1, z);
     }
   }
+  PA_STAMP(a.prof, blockIdx.x, wave, 13);
 }
 
 }  // namespace pa
