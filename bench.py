@@ -84,6 +84,18 @@ def cpu_baseline(budget_s: float = 20.0):
                       f"os.cpu_count()={os.cpu_count()}"}
 
 
+def pmc_traffic(transitions_per_launch):
+    """HBM bytes of one target_fused_kernel launch from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_target.json, written by tools/pmc_traffic.py: FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, per transition)."""
+    path = os.path.join(REPO, "profiles", "r01_pmc_target.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)
+    return d["hbm_bytes_per_transition"] * transitions_per_launch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,14 +153,31 @@ def main():
         dt = float(t.item())
     assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
 
-    timers = {}
-    for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "gather_x", "sample", "online_l2",
-                 "head", "bwd_dx", "rowpass", "bwd_dw", "adamw", "soft_update"):
-        ms, cnt, units = C.c_double(), C.c_int64(), C.c_int64()
-        N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
-        N.check(N.lib().pa_dqn_get_timing_units(nat.handle, name.encode(), C.byref(units)))
-        if cnt.value:
-            timers[name] = {"avg_us": ms.value * 1e3, "n": cnt.value, "units": units.value}
+    def read_timers():
+        out = {}
+        for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "gather_x", "sample",
+                     "online_l2", "head", "bwd_dx", "rowpass", "bwd_dw", "adamw", "soft_update"):
+            ms, cnt, units = C.c_double(), C.c_int64(), C.c_int64()
+            N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
+            N.check(N.lib().pa_dqn_get_timing_units(nat.handle, name.encode(), C.byref(units)))
+            if cnt.value:
+                out[name] = {"avg_us": ms.value * 1e3, "n": cnt.value, "units": units.value}
+        return out
+
+    timers = read_timers()
+    # Calibration pass (outside the timed region): the same target kernel with the chip to itself,
+    # i.e. the single-stream loop, so that the kernel's own efficiency can be told apart from the
+    # CU sharing of the overlapped loop.  N = 1 only: multi-GPU runs stay short.
+    isolated = None
+    if world == 1 and args.timing_level == 1 and os.environ.get("PEARL_AMD_OVERLAP", "1") != "0":
+        N.check(N.lib().pa_dqn_set_overlap(nat.handle, 0))
+        N.check(N.lib().pa_dqn_enable_timing(nat.handle, 1))
+        pl._training_rounds = 200
+        agent.learn()
+        torch.cuda.synchronize(dev)
+        isolated = read_timers().get("target")
+        N.check(N.lib().pa_dqn_set_overlap(nat.handle, 1))
+        pl._training_rounds = args.steps
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
 
     if rank == 0:
@@ -167,19 +196,39 @@ def main():
                        "final_loss": report["loss"][-1]},
         }
         if "target" in timers:
-            # one launch covers a window of rounds (target_update_freq, <= 16): algorithmic flops
-            # of the timed launches / their summed duration
+            # A launch covers several rounds of a target-update window: algorithmic flops of the
+            # timed launches / their summed duration.  In the overlapped loop these launches share
+            # the chip with the online chain (the persistent ones keep off the chain's 64 CUs), so
+            # the live figure is a fraction of the WHOLE chip's peak obtained on part of it; the
+            # calibration pass gives the same kernel with the chip to itself.
+            def kernel_rate(tt):
+                per_launch = tt["units"] / tt["n"]
+                return (FLOP_TARGET_KERNEL_PER_TRANSITION * per_launch / (tt["avg_us"] * 1e-6),
+                        per_launch)
+
             tt = timers["target"]
-            dur = tt["avg_us"] * 1e-6
-            per_launch = tt["units"] / tt["n"]
-            ach = FLOP_TARGET_KERNEL_PER_TRANSITION * per_launch / dur
+            ach, per_launch = kernel_rate(tt)
+            step_rate = FLOP_PER_TRANSITION_STEP * B * args.steps / dt     # per GPU
             line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<32>",
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
-                                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA, "traffic": None,
+                                "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA,
+                                "traffic": pmc_traffic(per_launch),
                                 "avg_launch_us": tt["avg_us"],
                                 "transitions_per_launch": per_launch,
-                                "launches_timed": tt["n"],
-                                "step_frac": FLOP_PER_TRANSITION_STEP * B * args.steps / dt / PEAK_F32_MFMA}
+                                "launches_timed": tt["n"]}
+            if isolated:
+                iach, iper = kernel_rate(isolated)
+                line["roofline"]["concurrent_with"] = ("online chain kernels on the 64 CUs the "
+                                                       "persistent launches keep off (overlapped loop)")
+                line["roofline"]["isolated"] = {
+                    "achieved": iach / 1e12, "frac": iach / PEAK_F32_MFMA,
+                    "avg_launch_us": isolated["avg_us"], "transitions_per_launch": iper,
+                    "launches_timed": isolated["n"],
+                    "note": "same kernel, single-stream loop, chip to itself (outside the timed region)"}
+            # the whole learner step against the same peak: 2.713 MFLOP per transition / wall time
+            line["roofline"]["step"] = {"achieved": step_rate / 1e12,
+                                        "frac": step_rate / PEAK_F32_MFMA,
+                                        "flop_per_transition": FLOP_PER_TRANSITION_STEP}
         if len(timers) > 1:
             line["stage_us"] = {k: round(v["avg_us"], 2) for k, v in timers.items()}
             line["stage_units"] = {k: v["units"] / v["n"] for k, v in timers.items() if v["units"]}

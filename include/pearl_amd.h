@@ -293,6 +293,10 @@ int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* args, void* st
  * pa_dqn_check: PA_ERR_HIP if such a wait expired during the last pa_dqn_learn (results invalid),
  * PA_OK otherwise.  PEARL_AMD_OVERLAP=0 in the environment selects the single-stream loop. */
 int pa_dqn_check(pa_dqn* h);
+/* Select the overlapped (1, default) or the single-stream (0) learn loop for later pa_dqn_learn
+ * calls; both produce bit-identical results.  bench.py uses the single-stream loop to time the
+ * target kernel with the chip to itself. */
+int pa_dqn_set_overlap(pa_dqn* h, int32_t on);
 
 /* Native all-reduce hooks for pa_learn_args, backed by RCCL (ncclAllReduce over xGMI) resolved at
  * run time with dlopen (the library has no link-time dependency on it).  One communicator per

@@ -257,6 +257,7 @@ SIGNATURES = {
     "pa_dqn_apply": (C.c_int, [_P, C.c_int64, _P]),
     "pa_dqn_learn": (C.c_int, [_P, _P, C.POINTER(LearnArgs), _P]),
     "pa_dqn_check": (C.c_int, [_P]),
+    "pa_dqn_set_overlap": (C.c_int, [_P, C.c_int32]),
     "pa_comm_available": (C.c_int, []),
     "pa_comm_unique_id": (C.c_int, [_P]),
     "pa_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, _P]),

@@ -1036,6 +1036,12 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   return PA_OK;
 }
 
+extern "C" int pa_dqn_set_overlap(pa_dqn* h, int32_t on) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  h->overlap = on ? 1 : 0;
+  return PA_OK;
+}
+
 extern "C" int pa_dqn_check(pa_dqn* h) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   PA_REQUIRE(!h->err_host || h->err_host[0] == 0, PA_ERR_HIP,
