@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "online_kernels.hpp"
+#include "target_pp_kernel.hpp"
 #include "host_launch.hpp"
 
 using namespace pa;
@@ -73,6 +74,8 @@ struct pa_dqn {
   int n_reserved, ncu;
   int* tile_ctr;           // [kTileCtrs] work-stealing counters, one per persistent launch
   int ctr_next;
+  int pingpong;            // PEARL_AMD_PINGPONG: 1 (default) target_pp_kernel for the persistent
+                           // launches of learn(), 2 for every launch, 0 never
   long long *prof_row, *prof_dw;  // phase-stamp buffers (pa_debug_set_prof), normally null
   long long* prof_tgt;            // target kernel stamps [tile][8][16] (pa_debug_set_prof_target)
   int prof_tgt_tiles;
@@ -163,6 +166,36 @@ int launch_target_t(const TargetArgs& a, hipStream_t s) {
   return PA_OK;
 }
 
+// One 16-wave workgroup per CU, two teams alternating main loop and epilogue / prologue
+// (target_pp_kernel.hpp).  Always work-stealing: a.tile_ctr must point at a zeroed counter.
+template <int NKG>
+int launch_target_pp_t(const TargetArgs& a, int ncu, hipStream_t s) {
+  static bool configured = false;
+  const size_t smem = target_pp_smem_bytes(a.H1);
+  if (!configured) {
+    int rc = set_max_smem(target_pp_kernel<NKG>, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  // every CU hosts one workgroup; twice as many are offered so that the ones which land on a
+  // reserved CU (and exit) do not leave other CUs empty
+  // (with a partition the full offer is needed whatever the tile count: a short grid could
+  // land on reserved CUs only and process nothing)
+  int grid = 2 * ncu;
+  if (!a.reserved && grid > a.ntiles) grid = a.ntiles;
+  hipLaunchKernelGGL(target_pp_kernel<NKG>, dim3((unsigned)grid), dim3(1024), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+int launch_target_pp(const TargetArgs& a, int ncu, hipStream_t s) {
+  switch (t_nkg(a.H1)) {
+    case 8: return launch_target_pp_t<8>(a, ncu, s);
+    case 16: return launch_target_pp_t<16>(a, ncu, s);
+    default: return launch_target_pp_t<32>(a, ncu, s);
+  }
+}
+
 int launch_target(const TargetArgs& a, hipStream_t s) {
   switch (t_nkg(a.H1)) {
     case 8: return launch_target_t<8>(a, s);
@@ -251,14 +284,17 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
-  if (persistent) {
+  a.prio_main = env_int("PEARL_AMD_PRIO_MAIN", 0);
+  const bool pp = h->pingpong == 2 || (h->pingpong == 1 && persistent);
+  if (persistent || pp) {
     if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream
       PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
       h->ctr_next = 0;
     }
     a.tile_ctr = h->tile_ctr + h->ctr_next++;
-    a.reserved = h->reserved_dev;
+    a.reserved = persistent ? h->reserved_dev : nullptr;
   }
+  if (pp) return launch_target_pp(a, h->ncu, s);
   return launch_target(a, s);
 }
 int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
@@ -614,9 +650,6 @@ int ensure_side(pa_dqn* h) {
   PA_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_chain[0], hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_chain[1], hipEventDisableTiming));
-  PA_HIP(hipMalloc((void**)&h->tile_ctr, kTileCtrs * sizeof(int)));
-  PA_HIP(hipMemset(h->tile_ctr, 0, kTileCtrs * sizeof(int)));
-  h->ctr_next = 0;
   return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", 64), h->side);
 }
 
@@ -724,6 +757,18 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->yw[1], h->wrows);
   PA_WS(h->nextv, h->wrows);
   PA_WS(h->err_dev, 4);
+  PA_WS(h->tile_ctr, kTileCtrs);
+  {
+    hipDeviceProp_t prop;
+    if (hipMemset(h->tile_ctr, 0, kTileCtrs * sizeof(int)) != hipSuccess ||
+        hipGetDeviceProperties(&prop, desc->device) != hipSuccess) {
+      set_error("pa_dqn_create: device query failed");
+      pa_dqn_destroy(h);
+      return PA_ERR_HIP;
+    }
+    h->ncu = prop.multiProcessorCount;
+  }
+  h->pingpong = env_int("PEARL_AMD_PINGPONG", 1);
   if (hipMemset(h->err_dev, 0, 16) != hipSuccess ||
       hipHostMalloc((void**)&h->err_host, 16, hipHostMallocDefault) != hipSuccess) {
     set_error("pa_dqn_create: error-word allocation failed");
