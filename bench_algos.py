@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Throughput of the other hot-path rows of SURVEY.md §8 (a13-a16) on one MI355X, at the shapes of
+BASELINE.json configs[2..4], each next to the reference-pinned CPU oracle on the host cores.
+
+    python bench_algos.py [--steps K] [--cpu-seconds T]      # one JSON line per config
+
+  cfg3  ContinuousSoftActorCritic  S=64, 8-dim action, twin-Q, [256,256], batch 1024
+        (sample from a 200k HBM arena + preprocess + learn_batch, through PolicyLearner.learn)
+  cfg4  PPO + GAE  S=256, 16 actions, rollout 65 536, minibatch 4096
+        (preprocess_replay_buffer = action probabilities, values, GAE scan; then learn())
+  cfg5  NeuralLinearBandit  512-dim contexts, [256,64] trunk, batch 4096 (learn_batch)
+
+bench.py (the headline DQN metric) is the driver's contract; this script only documents that the
+rows built after it run on the device and what they deliver.  The oracle is the checker / baseline
+here, never the thing measured.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+DEV = torch.device("cuda", 0)
+
+
+def sync():
+    torch.cuda.synchronize(DEV)
+
+
+def dspace(n):
+    from pearl_amd import DiscreteActionSpace
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+def timed(fn, warm=1):
+    for _ in range(warm):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    out = fn()
+    sync()
+    return time.perf_counter() - t0, out
+
+
+def bench_sac(steps, cpu_seconds):
+    from oracle.actor_critic_oracle import SacOracle
+    from pearl_amd import BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic, PearlAgent
+    S, A, B, N = 64, 8, 1024, 200_000
+    torch.manual_seed(0)
+    random.seed(0)
+    low, high = -torch.ones(A), torch.ones(A)
+    pl = ContinuousSoftActorCritic(action_space=BoxActionSpace(low, high), state_dim=S,
+                                   actor_hidden_dims=[256, 256], critic_hidden_dims=[256, 256],
+                                   batch_size=B, training_rounds=steps)
+    rb = BasicReplayBuffer(N, sampler="device")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    st = torch.randn(N + 1, S, device=DEV, generator=g)
+    act = torch.rand(N, A, device=DEV, generator=g) * 2 - 1
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=act, reward=(ids % 7).float(), terminated=(ids % 50 == 0),
+                 truncated=torch.zeros(N, dtype=torch.bool, device=DEV), next_state=st[1:])
+    dt, _ = timed(lambda: agent.learn())
+    gpu = B * steps / dt
+    # CPU oracle on the same shapes (one fixed batch: the oracle has no replay of its own)
+    orc = SacOracle({k: v.cpu() for k, v in pl._actor.state_dict().items()},
+                    {k: v.cpu() for k, v in pl._critic.state_dict().items()},
+                    {k: v.cpu() for k, v in pl._critic_target.state_dict().items()}, low, high)
+    batch = dict(state=torch.randn(B, S), action=torch.rand(B, A) * 2 - 1, reward=torch.rand(B),
+                 terminated=torch.zeros(B, dtype=torch.bool), next_state=torch.randn(B, S))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < cpu_seconds:
+        orc.learn_batch(batch, torch.randn(B, A), torch.randn(B, A))
+        n += 1
+    cpu = B * n / (time.perf_counter() - t0)
+    return {"config": "cfg3 ContinuousSoftActorCritic S=64 A=8 twin-Q [256,256] B=1024 replay 200k",
+            "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
+                             "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
+
+
+def bench_ppo(steps, cpu_seconds):
+    from oracle.actor_critic_oracle import PpoOracle
+    from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
+                           ProximalPolicyOptimization)
+    S, A, B, N = 256, 16, 4096, 65_536
+    torch.manual_seed(0)
+    random.seed(0)
+    pl = ProximalPolicyOptimization(action_space=dspace(A), state_dim=S, actor_hidden_dims=[256, 256],
+                                    critic_hidden_dims=[256, 256], training_rounds=steps, batch_size=B,
+                                    epsilon=0.1,
+                                    action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = PPOReplayBuffer(N, sampler="device")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    st = torch.randn(N + 1, S, device=DEV, generator=g)
+    ids = torch.arange(N, device=DEV)
+
+    def fill():
+        rb.clear()
+        rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                     terminated=(ids % 500 == 499), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                     next_state=st[1:], curr_available_actions=dspace(A),
+                     next_available_actions=dspace(A), max_number_actions=A)
+
+    fill()
+    dt_pre, _ = timed(lambda: pl.preprocess_replay_buffer(rb))
+    dt, _ = timed(lambda: pl.learn(rb), warm=0)
+    gpu = B * steps / dt
+    orc = PpoOracle({k: v.cpu() for k, v in pl._actor.state_dict().items()},
+                    {k: v.cpu() for k, v in pl._critic.state_dict().items()}, A, epsilon=0.1)
+    Ns = 4096      # bounded slice of the rollout for the python GAE loop of the oracle
+    scpu = st[:Ns + 1].cpu()
+    onehot = torch.eye(A)[(torch.arange(Ns) % A)]
+    rew, term = (torch.arange(Ns) % 7).float(), (torch.arange(Ns) % 500 == 499)
+    t0 = time.perf_counter()
+    gae, lam_ret, p_old = orc.preprocess(scpu[:Ns], onehot, rew, term,
+                                         torch.zeros(Ns, dtype=torch.bool), scpu[Ns])
+    cpu_pre = Ns / (time.perf_counter() - t0)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < cpu_seconds:
+        orc.learn_batch(scpu[:Ns], onehot, p_old, gae, lam_ret)
+        n += 1
+    cpu = Ns * n / (time.perf_counter() - t0)
+    return {"config": "cfg4 PPO+GAE S=256 A=16 [256,256] rollout 65536 minibatch 4096",
+            "metric": "learner transitions/s through PolicyLearner.learn (minibatch sample + learn_batch)",
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "preprocess_replay_buffer": {"transitions_per_s": N / dt_pre, "ms": 1e3 * dt_pre,
+                                         "what": "action probs + values of 65536 states, GAE / lambda-return scan"},
+            "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
+                             "preprocess_transitions_per_s": cpu_pre,
+                             "sample": f"{n} oracle learn_batch calls on a 4096-transition minibatch; "
+                                       f"GAE loop timed on {Ns} transitions"}}
+
+
+def bench_bandit(steps, cpu_seconds):
+    from oracle.actor_critic_oracle import NeuralLinearOracle
+    from pearl_amd import NeuralLinearBandit, TransitionBatch
+    F, B = 512, 4096
+    torch.manual_seed(0)
+    pl = NeuralLinearBandit(feature_dim=F, hidden_dims=[256, 64], batch_size=B, learning_rate=1e-3)
+    sd0 = {k: v.clone() for k, v in pl.model.state_dict().items()}
+    pl.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(B, F, device=DEV, generator=g)
+    y = torch.rand(B, device=DEV, generator=g)
+    tb = TransitionBatch(state=x, action=torch.zeros(B, 1, device=DEV), reward=y, weight=None)
+
+    def run():
+        for _ in range(steps):
+            pl.learn_batch(tb)
+
+    dt, _ = timed(run)
+    gpu = B * steps / dt
+    orc = NeuralLinearOracle(sd0, lr=1e-3)
+    xc, yc = x.cpu(), y.cpu()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < cpu_seconds:
+        orc.learn_batch(xc, yc, None)
+        n += 1
+    cpu = B * n / (time.perf_counter() - t0)
+    return {"config": "cfg5 NeuralLinearBandit 512-dim contexts trunk [256,64] B=4096",
+            "metric": "contexts/s through learn_batch (NN step + LinUCB A/b/inv(A)/coefs update)",
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
+                             "sample": f"{n} oracle learn_batch calls"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    torch.cuda.set_device(0)
+    for name, fn in (("sac", bench_sac), ("ppo", bench_ppo), ("bandit", bench_bandit)):
+        if args.only and args.only != name:
+            continue
+        out = fn(args.steps, args.cpu_seconds)
+        out.update({"unit": "transitions/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic"})
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
