@@ -1,7 +1,8 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest rc=$?"; tail -4 gpurun_out/pytest_gpu.log
-for i in 1 2 3; do timeout 300 python -m pytest tests/test_gpu_dqn.py -m gpu -q -p no:cacheprovider -x -k "full_size or fused_loop" 2>&1 | tail -1; done
-PEARL_AMD_PINGPONG=2 timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -2
-timeout 120 ./tools/corun_bench > gpurun_out/corun_bench.txt 2>&1; timeout 120 ./tools/mfma_bench > gpurun_out/mfma_bench.txt 2>&1; tail -3 gpurun_out/mfma_bench.txt
+run() { echo "== $*"; env "$@" timeout 300 python bench.py --no-cpu-baseline $EXTRA > gpurun_out/b.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print(round(d['value']/1e6,2),'M/s', round(d['ms_per_step']*1e3,2),'us/step  target frac', round(r.get('frac',0),3), 'launch_us', round(r.get('avg_launch_us',0),1), 'tr/launch', r.get('transitions_per_launch'), 'iso', r.get('isolated',{}).get('frac'), d.get('stage_us'))" || tail -5 gpurun_out/b.log; }
+run PEARL_AMD_HEAD_SOLO=0
+run PEARL_AMD_HEAD_SOLO=1
+run PEARL_AMD_HEAD_SOLO=1 PEARL_AMD_SPLIT_FIRST=2
+run PEARL_AMD_HEAD_SOLO=1 PEARL_AMD_SPLIT_FIRST=4
+timeout 600 python -m pytest tests/test_gpu_dqn.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -3

@@ -153,6 +153,38 @@ def test_data_parallel_loop_with_one_rank_equals_fused_loop(golden, name):
     assert a._training_steps == b._training_steps
 
 
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch"])
+def test_overlapped_loop_equals_single_stream_loop(golden, name):
+    """The two-stream learn loop (target pass on the side stream, Bellman targets handed over as
+    data-tagged words, persistent ping-pong target kernel off the reserved CUs) and the
+    single-stream loop are the same computation: bitwise-equal losses, parameters, targets.
+    Several learn() calls in a row also exercise the tag-restore invariant of the y buffers."""
+    import ctypes as C
+    from pearl_amd import _native as N
+    fx = golden(name)
+    a, b = make_learner(fx), make_learner(fx)
+    rb = fill_arena_buffer(fx, "python")
+    cfg = fx["config"]
+    nb = b._ensure_bound(cfg["B"], cfg["A"])
+    N.check(N.lib().pa_dqn_set_overlap(nb.handle, 0))
+    for seed in (4, 5, 6):
+        random.seed(seed)
+        ra = a.learn(rb)
+        random.seed(seed)
+        rbr = b.learn(rb)
+        assert ra["loss"] == rbr["loss"]
+        N.check(N.lib().pa_dqn_check(a._native.handle))
+    for (k, pa), (_, pb) in zip(a._Q.state_dict().items(), b._Q.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    for (k, pa), (_, pb) in zip(a._Q_target.state_dict().items(), b._Q_target.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    # a stand-alone step in between dirties the tagged buffers; the next learn() must cope
+    batch = rb.sample(cfg["B"])
+    a.learn_batch(a.preprocess_batch(batch))
+    random.seed(9)
+    assert all(np.isfinite(a.learn(rb)["loss"]))
+
+
 def test_device_sampler_learn_matches_oracle(golden):
     """Fast mode: Philox indices on the device; the oracle replays the same index lists."""
     fx = golden("cfg1_cartpole_shape")
