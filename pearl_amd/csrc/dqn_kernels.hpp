@@ -886,12 +886,16 @@ __device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
   }
 }
 
-template <bool FAST>
+// `after_prologue` runs between the ring's first fetches and the main loop: loads that are only
+// needed later (the optimizer state) go there, so that they queue BEHIND the first operands —
+// vector-memory results return in issue order.
+template <bool FAST, typename Hook>
 __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
                                             const __amdgpu_buffer_rsrc_t& rx,
                                             const unsigned (&va)[4], const unsigned (&vx)[2],
                                             unsigned oa, unsigned ox, unsigned sa, unsigned sx,
-                                            int nsteps, dw_f32x4 (&acc)[4][2], float (&cs)[4]) {
+                                            int nsteps, dw_f32x4 (&acc)[4][2], float (&cs)[4],
+                                            Hook after_prologue) {
 #pragma unroll
   for (int ja = 0; ja < 4; ++ja) {
     acc[ja][0] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -905,6 +909,7 @@ __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
     dw_fetch<FAST>(ra, rx, va, vx, live ? oa + (unsigned)p * sa : kDwDead,
                    live ? ox + (unsigned)p * sx : kDwDead, ring[p]);
   }
+  after_prologue();
   for (int s0 = 0; s0 < nsteps; s0 += DW_RING) {
 #pragma unroll
     for (int p = 0; p < DW_RING; ++p) {
@@ -1021,17 +1026,19 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   const int64_t eflat = (P.dW + (int64_t)erow * P.ldw + ecol) - a.ad.grad_base;
   float4 p4, m4, v4, x4;
   p4 = m4 = v4 = x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (evec && a.ad.enabled) {
-    p4 = *reinterpret_cast<const float4*>(a.ad.st.p + eflat);
-    m4 = *reinterpret_cast<const float4*>(a.ad.st.m + eflat);
-    v4 = *reinterpret_cast<const float4*>(a.ad.st.v + eflat);
-    if (a.ad.c.amsgrad) x4 = *reinterpret_cast<const float4*>(a.ad.st.vmax + eflat);
-  }
+  auto prefetch_state = [&]() {
+    if (evec && a.ad.enabled) {
+      p4 = *reinterpret_cast<const float4*>(a.ad.st.p + eflat);
+      m4 = *reinterpret_cast<const float4*>(a.ad.st.m + eflat);
+      v4 = *reinterpret_cast<const float4*>(a.ad.st.v + eflat);
+      if (a.ad.c.amsgrad) x4 = *reinterpret_cast<const float4*>(a.ad.st.vmax + eflat);
+    }
+  };
   dw_f32x4 acc[4][2];
   float cs[4];
   PA_STAMP(a.prof, blockIdx.x, wave, 1);
-  if (fa && fx) dw_mainloop<true>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs);
-  else dw_mainloop<false>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs);
+  if (fa && fx) dw_mainloop<true>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+  else dw_mainloop<false>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
   PA_STAMP(a.prof, blockIdx.x, wave, 2);
   // ---- partial tiles: (waves 4..7 -> LDS, waves 0..3 add), then (waves 0..3 -> LDS, all sum)
   // element id of acc[ja][jx][reg] on `lane`: ((ja * 2 + jx) * 4 + reg) * 64 + lane
