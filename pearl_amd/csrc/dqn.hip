@@ -453,10 +453,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
     a.ad.one_minus_tau = (float)(1.0 - (double)d.tau);
     a.ad.tW2f = h->w2f; a.ad.nkg_t = t_nkg(d.hidden1);
   }
-  const unsigned grid = (unsigned)a.total_tiles + (loss_out ? 1u : 0u);
-  hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
+  return launch_weight_grad(a, loss_out != nullptr, s);
 }
 
 // AdamW on bufs.grad after the data-parallel all-reduce: same optimizer tail as the fused
@@ -1178,8 +1175,5 @@ extern "C" int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X
   a.total_tiles = (int)ceil_div(M, DW_TM) * a.p[0].tiles_n;
   a.nprob = 1;
   a.B = Bn;
-  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0,
-                     reinterpret_cast<hipStream_t>(stream), a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
+  return launch_weight_grad(a, false, reinterpret_cast<hipStream_t>(stream));
 }

@@ -796,6 +796,12 @@ struct DwArgs {
   int nprob, B, total_tiles;
   AdamFuse ad;
   long long* prof;   // optional phase stamps (tools/prof_chain.py): [workgroup][wave][16]
+  // Large batches: `ksplit` workgroups share a tile, each reducing its slice of the batch; they
+  // leave their partial tile in `kscratch` (write-through stores) and take a ticket, the last one
+  // adds the partials in slice order (deterministic) and runs the epilogue.  ksplit = 1: off.
+  int ksplit;
+  float* kscratch;       // [total_tiles][ksplit][DW_TM * DW_TN + DW_TM]
+  unsigned* ktickets;    // [total_tiles], zero between launches
 };
 
 // index of fragment-major slots (defined here, used by online_kernels.hpp as well)
@@ -936,7 +942,9 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   __shared__ float csum[8 * DW_TM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row offsets stay in SGPRs
-  if ((int)blockIdx.x >= a.total_tiles) {
+  const int KSP = a.ksplit > 1 ? a.ksplit : 1;
+  const int wg_tile = (int)blockIdx.x / KSP, kslice = (int)blockIdx.x % KSP;
+  if (wg_tile >= a.total_tiles) {
     // mean |Q - target| of this step (deep_td_learning.py:358-359), fixed summation order
     float s = 0.f;
     for (int i = tid; i < a.ad.nabs; i += 512) s += a.ad.absd[i];
@@ -952,11 +960,12 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
   const int c = lane & 15, q = lane >> 4;
   int pi = 0;
-  if (a.nprob > 1 && (int)blockIdx.x >= a.p[1].tile0) pi = 1;
-  if (a.nprob > 2 && (int)blockIdx.x >= a.p[2].tile0) pi = 2;
+  if (a.nprob > 1 && wg_tile >= a.p[1].tile0) pi = 1;
+  if (a.nprob > 2 && wg_tile >= a.p[2].tile0) pi = 2;
   const DwProblem& P = a.p[pi];
-  const int t = blockIdx.x - P.tile0;
+  const int t = wg_tile - P.tile0;
   const int i0 = (t / P.tiles_n) * DW_TM, j0 = (t % P.tiles_n) * DW_TN;
+  if (P.M == 1 && kslice > 0) return;  // the GEMV path below is not split
   if (P.M == 1) {
     // Single-output layers (dW3 = dq^T h2, db3 = sum dq): a matrix tile would be 63/64 padding.
     // 32 columns x 16 row groups per workgroup, sequential fma per thread, row groups summed in
@@ -1012,8 +1021,10 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   for (int e = 0; e < 2; ++e)
     vx[e] = (cx + e < P.N) ? (unsigned)(q * P.ldx + cx + e) * 4u : kBufOob;
   const unsigned sa = (unsigned)P.ldz * 16u, sx = (unsigned)P.ldx * 16u;  // bytes per 4-row step
-  // this wave's slice of the batch: KS rows (a multiple of 4), nsteps 4-row steps
-  const int nsteps = (a.B + 31) / 32, row0 = wave * nsteps * 4;
+  // this workgroup's slice of the batch (all of it unless ksplit > 1), this wave's share of that:
+  // nsteps 4-row steps
+  const int bslice = ((a.B + KSP - 1) / KSP + 31) / 32 * 32;
+  const int nsteps = bslice / 32, row0 = kslice * bslice + wave * nsteps * 4;
   const unsigned oa = (unsigned)row0 * (unsigned)P.ldz * 4u, ox = (unsigned)row0 * (unsigned)P.ldx * 4u;
   // Epilogue assignment, fixed now so that the optimizer state can be fetched under the main
   // loop: thread -> tile row tid >> 3, columns 4 (tid & 7) .. + 3.  evec: the four elements are one
@@ -1087,6 +1098,48 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
       for (int w = 1; w < 4; ++w) sum += part[w * (DW_TM * DW_TN) + idx];
       g4[e] = sum;
+    }
+    if (KSP > 1) {
+      // ---- split-K: publish this slice's partial tile, last arriver adds them up in slice order
+      __shared__ unsigned is_last;
+      float* mine = a.kscratch + ((int64_t)wg_tile * KSP + kslice) * (DW_TM * DW_TN + DW_TM);
+      {
+        // one 16-byte write-through store per thread (dword write-through stores are one fabric
+        // write each: ~6x the time per byte, MI355X_MICROARCH.md)
+        const f32x4_t v = {g4[0], g4[1], g4[2], g4[3]};
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + tid * 4), "v"(v) : "memory");
+      }
+      if (tid < DW_TM) {
+        float sdb = csum[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) sdb += csum[w * DW_TM + tid];
+        __hip_atomic_store(mine + DW_TM * DW_TN + tid, sdb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are out
+      __syncthreads();
+      if (tid == 0) is_last = (atomicAdd(a.ktickets + wg_tile, 1u) == (unsigned)KSP - 1u) ? 1u : 0u;
+      __syncthreads();
+      if (!is_last) return;
+      const float* base = a.kscratch + (int64_t)wg_tile * KSP * (DW_TM * DW_TN + DW_TM);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float sum = 0.f;
+        for (int k = 0; k < KSP; ++k)
+          sum += __hip_atomic_load(base + (int64_t)k * (DW_TM * DW_TN + DW_TM) + tid * 4 + e,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        g4[e] = sum;
+      }
+      if (tid < DW_TM) {
+        float sdb = 0.f;
+        for (int k = 0; k < KSP; ++k)
+          sdb += __hip_atomic_load(base + (int64_t)k * (DW_TM * DW_TN + DW_TM) + DW_TM * DW_TN + tid,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        csum[tid] = sdb;   // read back by the bias epilogue below (waves 1.. hold zeros there)
+#pragma unroll
+        for (int w = 1; w < 8; ++w) csum[w * DW_TM + tid] = 0.f;
+      }
+      if (tid == 0) a.ktickets[wg_tile] = 0u;
+      __syncthreads();
     }
     if (evec) {
       *reinterpret_cast<float4*>(P.dW + (int64_t)erow * P.ldw + ecol) =

@@ -40,6 +40,46 @@ int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s) {
   return PA_OK;
 }
 
+// weight_grad_kernel with the split-K policy: batches of 2048 rows and more are cut into slices of
+// ~1024 rows per workgroup (a 64 x 32 tile over 4096 rows is 27 us of MFMA on one CU).  The scratch
+// for the partial tiles is one buffer per process, grown on demand; launches are ordered by their
+// stream like every other use of a learner handle.
+inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
+  static float* scratch = nullptr;
+  static unsigned* tickets = nullptr;
+  static size_t scratch_floats = 0, ticket_count = 0;
+  int ks = 1;
+  if (a.B >= 2048) {
+    ks = a.B / 1024;
+    if (ks > 8) ks = 8;
+  }
+  a.ksplit = ks;
+  a.kscratch = nullptr;
+  a.ktickets = nullptr;
+  if (ks > 1) {
+    const size_t need = (size_t)a.total_tiles * ks * (DW_TM * DW_TN + DW_TM);
+    if (need > scratch_floats) {
+      PA_HIP(hipDeviceSynchronize());
+      if (scratch) (void)hipFree(scratch);
+      PA_HIP(hipMalloc((void**)&scratch, need * sizeof(float)));
+      scratch_floats = need;
+    }
+    if ((size_t)a.total_tiles > ticket_count) {
+      PA_HIP(hipDeviceSynchronize());
+      if (tickets) (void)hipFree(tickets);
+      const size_t n = (size_t)a.total_tiles * 2;
+      PA_HIP(hipMalloc((void**)&tickets, n * sizeof(unsigned)));
+      PA_HIP(hipMemset(tickets, 0, n * sizeof(unsigned)));
+      ticket_count = n;
+    }
+    a.kscratch = scratch;
+    a.ktickets = tickets;
+  }
+  const unsigned grid = (unsigned)(a.total_tiles * ks) + (loss_wg ? 1u : 0u);
+  hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
 
 }  // namespace
 }  // namespace pa

@@ -229,8 +229,8 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       a.p[0].kind = 2;
       a.total_tiles = (int)ceil_div(h->d.dims[l + 1], DW_TM) * a.p[0].tiles_n;
       a.B = B;
-      hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
-      PA_LAUNCH_CHECK();
+      int rcw = launch_weight_grad(a, false, s);
+      if (rcw != PA_OK) return rcw;
     }
     if (l > 0 || d_x) {
       // dIn = dZ W_l (masked by relu'(in) for hidden inputs)
@@ -335,8 +335,11 @@ __global__ __launch_bounds__(256) void action_prob_kernel(const float* __restric
 }
 
 // PPO clipped-surrogate actor loss and its gradient w.r.t. the logits (ppo.py:152-183).
-// Single workgroup: the entropy bonus treats the B chosen-action probabilities as ONE categorical
-// distribution (a detached scalar), which needs their batch sum first.
+// The gradient is row-local; only the reported loss needs batch-wide sums (the entropy bonus treats
+// the B chosen-action probabilities as ONE categorical distribution — a detached scalar — which
+// needs their batch sum first).  One workgroup per 256 rows writes its partial sums and its rows'
+// probabilities; the last workgroup to arrive (ticket) adds the partials in block order and forms
+// the entropy term — deterministic, and 4096 rows no longer run on one CU (307 us -> ~10 us).
 struct PpoActorArgs {
   const float* logits; int ldl;
   const float* arep; int lda;
@@ -345,13 +348,18 @@ struct PpoActorArgs {
   float eps, ent_scale;
   float* d_logits; int ldd;
   float* loss_out;
+  float* p_rows;        // [B] scratch: chosen-action probability of every row
+  float* partials;      // [2 * gridDim] scratch: per-block sums of (-min term, p)
+  unsigned* ticket;     // zero on entry, zero again on exit
 };
 
 __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
   __shared__ float red[256];
+  __shared__ unsigned last;
   const float lo = 1.0f - a.eps, hi = 1.0f + a.eps;
   float part_loss = 0.f, part_p = 0.f;
-  for (int b = threadIdx.x; b < a.B; b += 256) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b < a.B) {
     const float* z = a.logits + (int64_t)b * a.ldl;
     const float* ar = a.arep + (int64_t)b * a.lda;
     float m = z[0];
@@ -364,8 +372,9 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
     const float r = p / a.p_old[b];
     const float clip = fminf(fmaxf(r, lo), hi);
     const float s1 = r * g, s2 = clip * g;
-    part_loss += -fminf(s1, s2);
-    part_p += p;
+    part_loss = -fminf(s1, s2);
+    part_p = p;
+    a.p_rows[b] = p;
     // d(-min(s1, s2))/dr: torch.minimum splits ties evenly; clamp passes the gradient inside
     // [lo, hi] (bounds included)
     const float inr = (r >= lo && r <= hi) ? 1.f : 0.f;
@@ -382,20 +391,27 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
       dz[j] = yj * (dp * ar[j] - dot);
     }
   }
-  const float loss = block_sum_256(part_loss, red);
-  const float psum = block_sum_256(part_p, red);
+  const float bl = block_sum_256(part_loss, red);
+  const float bp = block_sum_256(part_p, red);
+  if (threadIdx.x == 0) {
+    a.partials[2 * blockIdx.x] = bl;
+    a.partials[2 * blockIdx.x + 1] = bp;
+    __threadfence();
+    last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();  // the other blocks' partials and p_rows are visible from here on
+  float loss = 0.f, psum = 0.f;
+  for (unsigned k = 0; k < gridDim.x; ++k) {  // block order: fixed
+    loss += __hip_atomic_load(a.partials + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    psum += __hip_atomic_load(a.partials + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // entropy of Categorical(probs = p / sum p) with torch's clamping of probs / logits
   float part_e = 0.f;
   const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
-  for (int b = threadIdx.x; b < a.B; b += 256) {
-    const float* z = a.logits + (int64_t)b * a.ldl;
-    const float* ar = a.arep + (int64_t)b * a.lda;
-    float m = z[0];
-    for (int j = 1; j < a.A; ++j) m = fmaxf(m, z[j]);
-    float s = 0.f;
-    for (int j = 0; j < a.A; ++j) s += expf(z[j] - m);
-    float p = 0.f;
-    for (int j = 0; j < a.A; ++j) p += (expf(z[j] - m) / s) * ar[j];
+  for (int i = threadIdx.x; i < a.B; i += 256) {
+    const float p = __hip_atomic_load(a.p_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const float pn = p / psum;
     const float pc = fminf(fmaxf(pn, tiny), 1.0f - tiny);
     float lg = logf(pc);
@@ -403,7 +419,10 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
     part_e += lg * pn;
   }
   const float ent = -block_sum_256(part_e, red);
-  if (threadIdx.x == 0) a.loss_out[0] = loss - a.ent_scale * ent;
+  if (threadIdx.x == 0) {
+    a.loss_out[0] = loss - a.ent_scale * ent;
+    *a.ticket = 0u;
+  }
 }
 
 // MSELoss(mean) head: loss = mean((pred - target)^2) * scale_loss, d_pred = grad_scale * (pred - target)
@@ -843,8 +862,10 @@ extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* 
   a.p[0].kind = 2;
   a.total_tiles = (int)ceil_div(D, DW_TM) * a.p[0].tiles_n;
   a.B = B;
-  hipLaunchKernelGGL(weight_grad_kernel, dim3((unsigned)a.total_tiles), dim3(512), 0, s, a);
-  PA_LAUNCH_CHECK();
+  {
+    int rcw = launch_weight_grad(a, false, s);
+    if (rcw != PA_OK) return rcw;
+  }
   // delta_A[0][0] = sum_b 1 * 1 * w_b = the weight sum of the batch
   PA_HIP(hipMemcpyAsync(delta_out + (int64_t)D * (D + 1), delta_out, sizeof(float),
                         hipMemcpyDeviceToDevice, s));
@@ -908,7 +929,26 @@ extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* 
   a.logits = logits; a.ldl = ldl; a.arep = action_rep; a.lda = lda; a.p_old = p_old; a.gae = gae;
   a.B = B; a.A = A; a.eps = epsilon; a.ent_scale = entropy_scale;
   a.d_logits = d_logits; a.ldd = ldd; a.loss_out = loss_out;
-  hipLaunchKernelGGL(ppo_actor_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  // scratch (row probabilities, per-block partial sums, ticket): one buffer per process, grown on
+  // demand; calls on different streams at the same time are not supported (as for every handle
+  // of this library)
+  static float* scratch = nullptr;
+  static size_t scratch_floats = 0;
+  const unsigned grid = (unsigned)ceil_div(B, 256);
+  const size_t need = (size_t)B + 2 * grid + 4;
+  if (need > scratch_floats) {
+    if (scratch) {
+      PA_HIP(hipDeviceSynchronize());
+      (void)hipFree(scratch);
+    }
+    PA_HIP(hipMalloc((void**)&scratch, need * 2 * sizeof(float)));
+    PA_HIP(hipMemset(scratch, 0, need * 2 * sizeof(float)));
+    scratch_floats = need * 2;
+  }
+  a.ticket = reinterpret_cast<unsigned*>(scratch);
+  a.partials = scratch + 4;
+  a.p_rows = scratch + 4 + 2 * grid;
+  hipLaunchKernelGGL(ppo_actor_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -1,6 +1,9 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
-run() { echo "== $*"; env "$@" timeout 300 python bench.py --no-cpu-baseline $EXTRA > gpurun_out/b.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print(round(d['value']/1e6,2),'M/s', round(d['ms_per_step']*1e3,2),'us/step  target frac', round(r.get('frac',0),3), 'launch_us', round(r.get('avg_launch_us',0),1), 'tr/launch', r.get('transitions_per_launch'), 'iso', r.get('isolated',{}).get('frac'), d.get('stage_us'))" || tail -5 gpurun_out/b.log; }
-run A=1
-run A=1
-timeout 300 python tools/prof_chain.py 2>&1 | tail -9
+timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_actor_critic.py -m gpu -q --tb=short -p no:cacheprovider -x 2>&1 | tail -3
+timeout 300 python bench_algos.py --only ppo --steps 200 --cpu-seconds 0.5 2>/dev/null | grep '^{' | cut -c1-330
+cd /tmp && export TMPDIR=/tmp
+rm -rf $R/gpurun_out/prof_ppo
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ppo -o a -- python $R/bench_algos.py --only ppo --steps 100 --cpu-seconds 0.1 > $R/gpurun_out/rocprof_ppo.log 2>&1
+python $R/tools/rocpd_summary.py $R/gpurun_out/prof_ppo/a_results.db 2>&1 | head -9
+rm -f $R/gpurun_out/prof_ppo/*.db

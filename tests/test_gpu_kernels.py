@@ -50,7 +50,9 @@ def test_linear_dx_masked(M, N_, K):
 
 
 @pytest.mark.parametrize("M,N_,B", [(256, 256, 1024), (256, 144, 1024), (64, 6, 128), (24, 21, 100),
-                                   (40, 33, 7), (5, 3, 1)])
+                                   (40, 33, 7), (5, 3, 1),
+                                   # split-K path (batch cut across workgroups, ticketed combine)
+                                   (256, 256, 4096), (65, 66, 4099), (1, 256, 2500), (16, 257, 9000)])
 def test_weight_grad(M, N_, B):
     N, lib = _lib()
     dev = torch.device("cuda:0")
@@ -64,6 +66,24 @@ def test_weight_grad(M, N_, B):
                                atol=1e-5 * B ** 0.5)
     torch.testing.assert_close(db.cpu().double(), dz.double().sum(0), rtol=1e-5,
                                atol=1e-5 * B ** 0.5)
+
+
+def test_weight_grad_split_k_is_deterministic():
+    """Two launches of the split-K path give bitwise-equal results (slice-ordered combine) and
+    leave the tickets ready for the next launch."""
+    N, lib = _lib()
+    dev = torch.device("cuda:0")
+    M, N_, B = 128, 96, 4096
+    dz, x = _rand(B, M, seed=3).to(dev), _rand(B, N_, seed=4).to(dev)
+    outs = []
+    for _ in range(3):
+        dw = torch.full((M, N_), float("nan"), device=dev)
+        db = torch.full((M,), float("nan"), device=dev)
+        N.check(lib.pa_debug_weight_grad(dz.data_ptr(), M, x.data_ptr(), N_, dw.data_ptr(), N_,
+                                         db.data_ptr(), M, N_, B, N.stream_ptr(dev)))
+        outs.append((dw.clone(), db.clone()))
+    for dw, db in outs[1:]:
+        assert torch.equal(dw, outs[0][0]) and torch.equal(db, outs[0][1])
 
 
 def test_linear_is_deterministic():
