@@ -209,7 +209,7 @@ def main():
             tt = timers["target"]
             ach, per_launch = kernel_rate(tt)
             step_rate = FLOP_PER_TRANSITION_STEP * B * args.steps / dt     # per GPU
-            line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<32>",
+            line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<32> (classic grid) + target_pp_kernel<32> (persistent launches)",
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA,
                                 "traffic": pmc_traffic(per_launch),
