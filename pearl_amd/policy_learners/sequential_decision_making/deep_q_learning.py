@@ -433,6 +433,8 @@ class DeepQLearning(PolicyLearner):
         cached = getattr(self._native, "comm", None)
         if cached is not None:
             return cached
+        if getattr(self._native, "comm_failed", False):
+            return None     # RCCL bring-up failed on some rank: torch.distributed hooks instead
         lib = N.lib()
         if not lib.pa_comm_available():
             return None
@@ -448,7 +450,15 @@ class DeepQLearning(PolicyLearner):
         raw = bytes(ident.cpu().numpy().tobytes())
         handle = C.c_void_p()
         torch.cuda.synchronize(dev)
-        N.check(lib.pa_comm_create(C.byref(handle), dev.index, world, rank, raw))
+        rc = lib.pa_comm_create(C.byref(handle), dev.index, world, rank, raw)
+        # every rank must take the same path: agree on the outcome before using the communicator
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=on)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if rc == 0:
+                lib.pa_comm_destroy(handle)
+            self._native.comm_failed = True
+            return None
         self._native.comm = handle
         return handle
 

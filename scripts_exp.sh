@@ -1,8 +1,5 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R; mkdir -p gpurun_out
-cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 300 --warmup 50 --no-cpu-baseline --timing-level 0 > $R/gpurun_out/rocprof.log 2>&1
-python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db 2>&1 | head -8
-python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_fused 34
-rm -f $R/gpurun_out/prof/*.db
+run() { echo "== $*"; env "$@" timeout 300 python bench.py --no-cpu-baseline $EXTRA > gpurun_out/b.log 2>&1; echo "rc=$?"; tail -1 gpurun_out/b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline',{}); print(round(d['value']/1e6,2),'M/s', round(d['ms_per_step']*1e3,2),'us/step  target frac', round(r.get('frac',0),3), 'launch_us', round(r.get('avg_launch_us',0),1), 'iso', r.get('isolated',{}).get('frac'))" || tail -5 gpurun_out/b.log; }
+run A=1
+timeout 300 python tools/prof_chain.py 2>&1 | tail -27 | head -17
