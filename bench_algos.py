@@ -172,6 +172,58 @@ def bench_bandit(steps, cpu_seconds):
                              "sample": f"{n} oracle learn_batch calls"}}
 
 
+def bench_push(steps, cpu_seconds):
+    """Ingest: per-transition push() through the pinned staging ring, and
+    push_many() from host tensors (one H2D copy + one scatter kernel) — the PCIe-inclusive side of
+    the boundary; the reference's push costs 287 us per transition on the CPU."""
+    from oracle.pearl_oracle import ReplayOracle
+    from pearl_amd import BasicReplayBuffer
+    S, A, N1, N2 = 128, 16, 20_000, 1_000_000
+    torch.manual_seed(0)
+    states = torch.randn(N1 + 1, S)
+    sp = dspace(A)
+    rb = BasicReplayBuffer(N2, sampler="device")
+    rb.device_for_batches = DEV
+    acts = [torch.tensor([i % A]) for i in range(A)]
+    t0 = time.perf_counter()
+    for i in range(N1):
+        rb.push(state=states[i], action=acts[i % A], reward=float(i % 7), terminated=(i % 50 == 0),
+                truncated=False, curr_available_actions=sp, next_state=states[i + 1],
+                next_available_actions=sp, max_number_actions=A)
+    _ = len(rb)
+    rb.sample(256)          # forces the flush of the staging ring
+    sync()
+    push_rate = N1 / (time.perf_counter() - t0)
+    big = torch.randn(N2 + 1, S).pin_memory()
+    ids = torch.arange(N2)
+    args = dict(action=(ids % A).view(-1, 1), reward=(ids % 7).float(), terminated=(ids % 50 == 0),
+                truncated=torch.zeros(N2, dtype=torch.bool))
+    rb2 = BasicReplayBuffer(N2, sampler="device")
+    rb2.device_for_batches = DEV
+    sync()
+    t0 = time.perf_counter()
+    rb2.push_many(state=big[:-1], next_state=big[1:], curr_available_actions=sp,
+                  next_available_actions=sp, max_number_actions=A, **args)
+    rb2.sample(256)
+    sync()
+    dt = time.perf_counter() - t0
+    row_bytes = 2 * S * 4 + 8 + 4 + 2
+    orc = ReplayOracle(N1)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < cpu_seconds and n < N1:
+        orc.push(states[n], acts[n % A], float(n % 7), n % 50 == 0, False, A, states[n + 1], A, A)
+        n += 1
+    cpu = n / (time.perf_counter() - t0)
+    return {"config": "ingest: cfg2 transitions (128-dim states, 16 actions) into the HBM arena",
+            "metric": "transitions/s through ReplayBuffer.push (host python call per transition)",
+            "value": push_rate, "steps": N1, "ms_per_step": 1e3 / push_rate,
+            "push_many_from_host": {"transitions_per_s": N2 / dt, "GB_per_s": N2 * row_bytes / dt / 1e9,
+                                    "what": "1M transitions from pinned host tensors: H2D copies + scatter kernel, PCIe inclusive"},
+            "cpu_baseline": {"value": cpu, "kind": "port", "cores": 1,
+                             "sample": f"{n} oracle (deque of per-transition tensors) pushes"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
@@ -179,7 +231,8 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    for name, fn in (("sac", bench_sac), ("ppo", bench_ppo), ("bandit", bench_bandit)):
+    for name, fn in (("sac", bench_sac), ("ppo", bench_ppo), ("bandit", bench_bandit),
+                     ("push", bench_push)):
         if args.only and args.only != name:
             continue
         out = fn(args.steps, args.cpu_seconds)
