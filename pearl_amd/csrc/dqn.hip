@@ -284,7 +284,6 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
-  a.prio_main = env_int("PEARL_AMD_PRIO_MAIN", 0);
   const bool pp = h->pingpong == 2 || (h->pingpong == 1 && persistent);
   if (persistent || pp) {
     if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream

@@ -325,7 +325,6 @@ struct TargetArgs {
   int* tile_ctr;             // null: classic grid, tile = blockIdx.x
   int ntiles;
   const uint8_t* reserved;   // [kCuKeys] 1 = this CU belongs to the online chain; may be null
-  int prio_main;             // ping-pong kernel: s_setprio 3 for the team in its main loop
   long long* prof;           // optional phase stamps [tile][wave][16] (tools/prof_chain.py)
 };
 
