@@ -357,8 +357,9 @@ __device__ __forceinline__ void publish_y(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), bits, __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
-// spins: ~0.6 us each; the bound only exists so that a broken producer cannot hang the GPU
-constexpr int kYPollSpins = 1 << 19;
+// spins: ~0.6 us each (about a second in all; the longest legitimate wait seen is 3 ms, a first-use
+// code-object load on the side stream); the bound exists so that a broken producer cannot hang the GPU
+constexpr int kYPollSpins = 1 << 21;
 __device__ __forceinline__ float consume_y(const float* p, int* err) {
   const unsigned* q = reinterpret_cast<const unsigned*>(p);
   unsigned bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
