@@ -15,6 +15,7 @@ import ctypes as C
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+import torch.distributed as dist
 from torch import nn, optim
 
 from ... import _native as N
@@ -24,6 +25,22 @@ Layer = Tuple[List[nn.Parameter], List[nn.Parameter]]  # (weights stacked by row
 
 def layers_of(linears: Sequence[nn.Linear]) -> List[Layer]:
     return [([l.weight], [l.bias]) for l in linears]
+
+
+
+def reduce_gradient_(flat_grad: torch.Tensor, reduce: str = "mean") -> torch.Tensor:
+    """In-place data-parallel reduction of a flat gradient buffer; identity without a process
+    group or with a single rank.  "mean": sum over ranks / world; "sum": sum over ranks."""
+    assert reduce in ("mean", "sum"), reduce
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad
+    world = dist.get_world_size()
+    if world == 1:
+        return flat_grad
+    if reduce == "mean":
+        flat_grad.mul_(1.0 / world)
+    dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+    return flat_grad
 
 
 class FlatMlp:
@@ -198,7 +215,17 @@ class FlatMlp:
                                         N.ptr(d_x), self.dims[0], N.stream_ptr(x.device)))
         return d_x
 
-    def adam(self) -> None:
+    def adam(self, reduce: str = "mean") -> None:
+        """AdamW(amsgrad) step on the flat gradient buffer.
+
+        Data parallelism (not in the reference): when ``torch.distributed`` is
+        initialised every rank holds the gradient of ITS minibatch and parameters stay replicated,
+        so the flat gradient buffer is all-reduced (RCCL over xGMI on GPUs — ONE message per
+        network: PPO 135 696 + 131 841 floats, SAC actor 86 544 + twin critic 169 474) before the
+        optimizer step.  ``reduce`` says how the loss aggregates over the global batch: "mean"
+        (MSE / SAC losses: average of the rank gradients) or "sum" (PPO's summed clipped surrogate,
+        ppo.py:152-183: plain sum).  With one rank this is exactly the single-GPU step."""
+        reduce_gradient_(self.flat["grad"], reduce)
         step = self.adam_steps() + 1
         N.check(N.lib().pa_mlp_adam(self.handle, step, N.stream_ptr(self.device)))
         self._set_adam_steps(step)

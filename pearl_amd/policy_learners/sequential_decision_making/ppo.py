@@ -159,7 +159,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
             B, A, float(self._epsilon), float(self._entropy_bonus_scaling), d_logits.data_ptr(),
             d_logits.stride(0), loss.data_ptr(), N.stream_ptr(dev)))
         actor.backward(state, d_logits, want_dw=True)
-        actor.adam()
+        actor.adam(reduce="sum")   # the surrogate is a SUM over the (global) minibatch
         return loss[0]
 
     def _critic_update(self, batch: TransitionBatch) -> Tensor:

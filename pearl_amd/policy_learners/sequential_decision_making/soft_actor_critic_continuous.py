@@ -23,6 +23,7 @@ from __future__ import annotations
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 from torch import Tensor, nn, optim
 
 from ... import _native as N
@@ -234,6 +235,12 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             al["step"] += 1
             loss = torch.empty(1, dtype=torch.float32, device=dev)
             logp = self._action_batch_log_prob_cache
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # data parallel: the entropy loss depends on the batch only through mean(log_prob);
+                # every rank steps alpha with the GLOBAL mean so the coefficient stays replicated
+                logp = logp.mean().reshape(1)
+                dist.all_reduce(logp, op=dist.ReduceOp.SUM)
+                logp = (logp / dist.get_world_size()).contiguous()
             N.check(N.lib().pa_sac_alpha_step(
                 self._log_entropy.data.data_ptr(), al["exp_avg"].data_ptr(),
                 al["exp_avg_sq"].data_ptr(), al["max_exp_avg_sq"].data_ptr(),

@@ -249,6 +249,41 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _dp_mlp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import reduce_gradient_
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    g = torch.arange(6, dtype=torch.float32) * (rank + 1)      # rank r holds (r + 1) * g
+    mean = reduce_gradient_(g.clone(), "mean").tolist()
+    total = reduce_gradient_(g.clone(), "sum").tolist()
+    q.put((rank, (mean, total)))
+    dist.destroy_process_group()
+
+
+def test_actor_critic_gradient_reduction_mean_and_sum():
+    """FlatMlp.adam's data-parallel step (PPO / SAC / bandit trunk): "mean" for mean-reduced losses,
+    "sum" for PPO's summed surrogate; identity without a process group."""
+    import torch.multiprocessing as mp
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import reduce_gradient_
+    g = torch.arange(6, dtype=torch.float32)
+    assert reduce_gradient_(g.clone(), "mean").tolist() == g.tolist()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_dp_mlp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_mean = (g * (1 + 2) / 2).tolist()
+    want_sum = (g * (1 + 2)).tolist()
+    for r in (0, 1):
+        assert results[r] == (want_mean, want_sum)
+
+
 def test_gradient_allreduce_is_a_mean_over_ranks():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
