@@ -148,12 +148,21 @@ struct ScopedTimer {
   }
 };
 
-template <int NKG>
+// every operand 16-byte aligned with pitches that are multiples of 4, AD <= 16, all eight waves of
+// a workgroup own hidden units in both layers: the kernels' FAST instantiation applies
+bool target_fast_shape(const TargetArgs& a, int nkg) {
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return al(a.U) && al(a.feat) && al(a.W1a) && al(a.b2) && al(a.w3) && (a.ldu & 3) == 0 &&
+         (a.AD & 3) == 0 && a.AD <= 16 && (a.feat_bstride & 3) == 0 && (a.ldw1 & 3) == 0 &&
+         a.H1 == nkg * 8 && a.H2 == 256 && nkg * 8 >= 256;
+}
+
+template <int NKG, bool FAST>
 int launch_target_t(const TargetArgs& a, hipStream_t s) {
   static bool configured = false;
   const size_t smem = target_smem_bytes(a.H1);
   if (!configured) {
-    int rc = set_max_smem(target_fused_kernel<NKG>, smem);
+    int rc = set_max_smem(target_fused_kernel<NKG, FAST>, smem);
     if (rc != PA_OK) return rc;
     configured = true;
   }
@@ -161,7 +170,7 @@ int launch_target_t(const TargetArgs& a, hipStream_t s) {
   // on reserved CUs exit immediately
   const unsigned grid = a.tile_ctr ? (unsigned)(3 * a.ntiles < 3 * 256 ? 3 * a.ntiles : 3 * 256)
                                    : (unsigned)ceil_div(a.B, a.bpw);
-  hipLaunchKernelGGL(target_fused_kernel<NKG>, dim3(grid), dim3(512), smem, s, a);
+  hipLaunchKernelGGL((target_fused_kernel<NKG, FAST>), dim3(grid), dim3(512), smem, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -198,9 +207,11 @@ int launch_target_pp(const TargetArgs& a, int ncu, hipStream_t s) {
 
 int launch_target(const TargetArgs& a, hipStream_t s) {
   switch (t_nkg(a.H1)) {
-    case 8: return launch_target_t<8>(a, s);
-    case 16: return launch_target_t<16>(a, s);
-    default: return launch_target_t<32>(a, s);
+    case 8: return launch_target_t<8, false>(a, s);
+    case 16: return launch_target_t<16, false>(a, s);
+    default:
+      return target_fast_shape(a, 32) ? launch_target_t<32, true>(a, s)
+                                      : launch_target_t<32, false>(a, s);
   }
 }
 

@@ -417,7 +417,10 @@ inline size_t target_smem_bytes(int H1) {
 // Waves per SIMD the kernel is compiled for: 4 (= two co-resident 8-wave workgroups per CU, <= 128
 // VGPRs) for the widest instantiation, so that one workgroup's prologue / epilogue overlaps the
 // other's MFMA stream when a launch covers many 64-row tiles (a window of learn() rounds).
-template <int NKG>
+// FAST: the host has checked that every operand is 16-byte aligned with pitches that are multiples
+// of 4, AD <= 16, H1 = 8 NKG and H2 = 256 (all eight waves own hidden units): the generic guards
+// fold away.  A prologue / epilogue instruction is serial time on this machine.
+template <int NKG, bool FAST>
 __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float* smem) {
   constexpr int H1P = NKG * 8;           // padded layer-2 K (64 / 128 / 256)
   constexpr int PA_ = H1P + 4;           // == 4 mod 32: conflict-free b128 reads AND writes by row
@@ -432,7 +435,7 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
   const int nb = min(a.bpw, a.B - b0);
   const int nrows = nb * a.A;
   const int nt1 = H1P >> 5, nt2 = (a.H2 + 31) >> 5;  // 32-wide tiles of h1 (padded) / h2 columns
-  const bool l1 = wave < nt1, l2 = wave < nt2;
+  const bool l1 = FAST || wave < nt1, l2 = FAST || wave < nt2;
 
   // TRANSPOSED tiles: the weights are the MFMA A operand (i = hidden unit n), the activations the
   // B operand (j = batch row), so an accumulator register holds
@@ -445,7 +448,7 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
 
   // ---- layer 1 operands first (vmcnt retires in order: layer 1 never waits for the W2' stream)
   f32x16 acc[2];
-  const bool vU = ((reinterpret_cast<uintptr_t>(a.U) & 15) == 0) && ((a.ldu & 3) == 0);
+  const bool vU = FAST || (((reinterpret_cast<uintptr_t>(a.U) & 15) == 0) && ((a.ldu & 3) == 0));
   int64_t foff[2];
   bool fok[2];
 #pragma unroll
@@ -466,10 +469,10 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
       acc[tm][4 * q + 2] = u.z; acc[tm][4 * q + 3] = u.w;
     }
   }
-  const bool vfeat = ((reinterpret_cast<uintptr_t>(a.feat) & 15) == 0) && ((a.AD & 3) == 0) &&
-                     ((a.feat_bstride & 3) == 0);
-  const bool vw1 = ((reinterpret_cast<uintptr_t>(a.W1a) & 15) == 0) && ((a.ldw1 & 3) == 0) &&
-                   ((a.AD & 3) == 0);
+  const bool vfeat = FAST || (((reinterpret_cast<uintptr_t>(a.feat) & 15) == 0) &&
+                              ((a.AD & 3) == 0) && ((a.feat_bstride & 3) == 0));
+  const bool vw1 = FAST || (((reinterpret_cast<uintptr_t>(a.W1a) & 15) == 0) &&
+                            ((a.ldw1 & 3) == 0) && ((a.AD & 3) == 0));
   const int wcol = wave * 32 + l31;      // hidden unit this lane feeds as the A operand
   const int64_t woff = (int64_t)wcol * a.ldw1;
   const bool wok = l1 && wcol < a.H1;
@@ -507,8 +510,8 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
   // layer-3 constants of this lane's hidden units: fetched while the last RD k-groups run (they
   // take over the registers of the drained prefetch ring)
   float4 b2v[4], w3v[4];
-  const bool v2 = ((reinterpret_cast<uintptr_t>(a.b2) & 15) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(a.w3) & 15) == 0) && ((a.H2 & 3) == 0);
+  const bool v2 = FAST || (((reinterpret_cast<uintptr_t>(a.b2) & 15) == 0) &&
+                           ((reinterpret_cast<uintptr_t>(a.w3) & 15) == 0) && ((a.H2 & 3) == 0));
   auto l3_load = [&](const float* p, int q) {
     const int n = nq0 + 8 * q;
     return v2 ? ld4_or_zero(p, n, n < a.H2) : guarded_load4(p, 0, true, n, a.H2);
@@ -517,10 +520,12 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
   PA_STAMP(a.prof, tile, wave, 1);
   l1_mfma(fx[0], fw[0]);
   l1_mfma(fx[1], fw[1]);
-  for (int k0 = 16; k0 < a.AD; k0 += 8) {  // wider action representations (rare)
-    float4 x4[2], w4;
-    l1_loads(k0, x4, w4);
-    l1_mfma(x4, w4);
+  if constexpr (!FAST) {
+    for (int k0 = 16; k0 < a.AD; k0 += 8) {  // wider action representations (rare)
+      float4 x4[2], w4;
+      l1_loads(k0, x4, w4);
+      l1_mfma(x4, w4);
+    }
   }
   if (l1) {
     // h1 = relu(acc) -> LDS tile [row][k] (hidden units >= H1 and rows >= nrows are exact zeros)
@@ -621,11 +626,11 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
   if (a.prof && (threadIdx.x & 63) == 0) a.prof[((int64_t)tile * 8 + wave) * 16 + 8] = cu_key();
 }
 
-template <int NKG>
+template <int NKG, bool FAST>
 static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (a.tile_ctr == nullptr) {
-    target_tile<NKG>(a, blockIdx.x, smem);
+    target_tile<NKG, FAST>(a, blockIdx.x, smem);
     return;
   }
   __shared__ int next_tile;
@@ -640,7 +645,7 @@ static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs 
   while (tile < a.ntiles) {
     int ahead = 0;
     if (threadIdx.x == 0) ahead = atomicAdd(a.tile_ctr, 1);
-    target_tile<NKG>(a, tile, smem);
+    target_tile<NKG, FAST>(a, tile, smem);
     if (threadIdx.x == 0) next_tile = ahead;
     __syncthreads();  // publishes next_tile; LDS is reused by the next tile
     tile = next_tile;
