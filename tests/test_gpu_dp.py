@@ -1,0 +1,75 @@
+"""GPU: the data-parallel learn loop with TWO ranks.  One GPU is all a test box has, so both ranks
+share cuda:0 and exchange gradients through torch.distributed's gloo backend (the
+``allreduce_start`` / ``allreduce_wait`` hooks of pa_learn_args calling back into Python — the
+same loop structure the RCCL hooks drive on a multi-GPU node): every rank samples its own arena
+shard, gradients are averaged, parameters and optimizer state must stay bitwise identical across
+ranks, and must differ from what one rank alone would have learned."""
+import os
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    os.environ["PEARL_AMD_TORCH_ALLREDUCE"] = "1"
+    import torch.distributed as dist
+    from pearl_amd import (BasicReplayBuffer, DeepQLearning, DiscreteActionSpace,
+                           OneHotActionTensorRepresentationModule, PearlAgent)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    S, A, B, N = 24, 4, 64, 4000
+    space = DiscreteActionSpace([torch.tensor([k]) for k in range(A)])
+    torch.manual_seed(0)                      # identical initial parameters
+    pl = DeepQLearning(state_dim=S, action_space=space, hidden_dims=[64, 64], training_rounds=23,
+                       batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = BasicReplayBuffer(N, sampler="device")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    g = torch.Generator(device=dev).manual_seed(100 + rank)   # rank-private shard
+    st = torch.randn(N + 1, S, device=dev, generator=g)
+    ids = torch.arange(N, device=dev)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 5).float() + rank,
+                 terminated=(ids % 37 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=dev),
+                 next_state=st[1:], curr_available_actions=space, next_available_actions=space,
+                 max_number_actions=A)
+    random.seed(7 + rank)
+    losses = pl.learn(rb)["loss"] + pl.learn(rb)["loss"]
+    flat = torch.cat([p.detach().reshape(-1) for p in pl._Q.parameters()] +
+                     [p.detach().reshape(-1) for p in pl._Q_target.parameters()]).cpu()
+    mom = torch.cat([pl._optimizer.state[p]["exp_avg"].reshape(-1) for p in pl._Q.parameters()]).cpu()
+    q.put((rank, flat, mom, losses, pl._training_steps))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, flat, mom, losses, steps = q.get(timeout=300)
+        out[rank] = (flat.clone(), mom.clone(), losses, steps)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_two_ranks_keep_identical_parameters():
+    two = _run(2)
+    (f0, m0, l0, s0), (f1, m1, l1, s1) = two[0], two[1]
+    assert s0 == s1 == 46
+    assert torch.equal(f0, f1), "parameters diverged across ranks"
+    assert torch.equal(m0, m1), "optimizer state diverged across ranks"
+    assert all(x == x for x in l0 + l1)                     # finite
+    assert l0 != l1                                         # each rank reports its own shard's loss
+    one = _run(1)[0]
+    assert not torch.equal(one[0], f0), "two-rank training must see the other rank's gradients"
