@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.cuda.set_device(0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("ppo", bench_ppo), ("bandit", bench_bandit),
                      ("push", bench_push)):
         if args.only and args.only != name:
