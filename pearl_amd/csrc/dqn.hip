@@ -925,6 +925,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // fresh work-stealing counters for this call's persistent target launches
   PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
   h->ctr_next = 0;
+  // a bounded wait that expired in an earlier call must not poison this one
+  PA_HIP(hipMemsetAsync(h->err_dev, 0, sizeof(int), s));
+  h->err_host[0] = 0;
   hipStream_t t = overlap ? h->side : s;
   ScopedTimer tm_all(h, "learn", s);
   // ---- the index lists of EVERY round in one go (they do not depend on the parameters)
