@@ -30,7 +30,9 @@ struct pa_mlp {
   int L;
   int64_t woff[PA_MLP_MAX_LAYERS], boff[PA_MLP_MAX_LAYERS], P;
   float* act[PA_MLP_MAX_LAYERS];  // hidden activations kept for the backward pass [max_batch, d]
-  float* dz[2];                   // ping-pong pre-activation gradients [max_batch, max hidden]
+  float* dz[PA_MLP_MAX_LAYERS];   // pre-activation gradient of every hidden layer [max_batch, d]
+                                  // (all kept: the weight gradients of all layers are one launch)
+  float* db_scratch;              // column sums of a bias-free last layer go here
   float* loss_scratch;
   int kept_B;                     // batch size of the kept forward (0 = none)
 };
@@ -93,8 +95,9 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
   (void)hipDeviceSynchronize();
   for (int l = 0; l < PA_MLP_MAX_LAYERS; ++l)
     if (h->act[l]) (void)hipFree(h->act[l]);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < PA_MLP_MAX_LAYERS; ++i)
     if (h->dz[i]) (void)hipFree(h->dz[i]);
+  if (h->db_scratch) (void)hipFree(h->db_scratch);
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   delete h;
   return PA_OK;
@@ -126,8 +129,9 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
   bool ok = true;
   for (int l = 0; l + 1 < h->L; ++l)
     ok = ok && alloc(&h->act[l], (int64_t)desc->max_batch * desc->dims[l + 1]);
-  ok = ok && alloc(&h->dz[0], (int64_t)desc->max_batch * maxh);
-  ok = ok && alloc(&h->dz[1], (int64_t)desc->max_batch * maxh);
+  for (int l = 1; l < h->L; ++l)   // dz[l]: gradient w.r.t. the output of layer l - 1
+    ok = ok && alloc(&h->dz[l], (int64_t)desc->max_batch * desc->dims[l]);
+  ok = ok && alloc(&h->db_scratch, maxh);
   ok = ok && alloc(&h->loss_scratch, 4);
   if (!ok) {
     set_error("hipMalloc(mlp workspace) failed");
@@ -208,37 +212,19 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipSetDevice(h->d.device));
   const float* P = h->bufs.p;
-  const float* dz = d_out;
-  int lddz = ldd;
+  // ---- dX chain first: dzs[l] = gradient w.r.t. the pre-activation output of layer l
+  const float* dzs[PA_MLP_MAX_LAYERS];
+  int ldzs[PA_MLP_MAX_LAYERS];
+  dzs[h->L - 1] = d_out;
+  ldzs[h->L - 1] = ldd;
   for (int l = h->L - 1; l >= 0; --l) {
-    const float* in = l > 0 ? h->act[l - 1] : x;
-    const int ldin = l > 0 ? h->d.dims[l] : ldx;
-    if (want_dw) {
-      DwArgs a;
-      memset(&a, 0, sizeof(a));
-      a.nprob = 1;
-      a.p[0].dZ = dz; a.p[0].ldz = lddz;
-      a.p[0].X = in; a.p[0].ldx = ldin;
-      a.p[0].dW = h->bufs.grad + h->woff[l]; a.p[0].ldw = h->d.dims[l];
-      // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias slot:
-      // its column sums go to scratch so AdamW never moves it
-      a.p[0].db = (l == h->L - 1 && h->d.no_last_bias) ? h->dz[(l + 1) & 1] : h->bufs.grad + h->boff[l];
-      a.p[0].M = h->d.dims[l + 1]; a.p[0].N = h->d.dims[l];
-      a.p[0].tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
-      a.p[0].tile0 = 0;
-      a.p[0].kind = 2;
-      a.total_tiles = (int)ceil_div(h->d.dims[l + 1], DW_TM) * a.p[0].tiles_n;
-      a.B = B;
-      int rcw = launch_weight_grad(a, false, s);
-      if (rcw != PA_OK) return rcw;
-    }
     if (l > 0 || d_x) {
       // dIn = dZ W_l (masked by relu'(in) for hidden inputs)
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      g.A = dz; g.lda = lddz;
+      g.A = dzs[l]; g.lda = ldzs[l];
       g.Bm = P + h->woff[l]; g.ldb = h->d.dims[l];
-      float* dst = l > 0 ? h->dz[l & 1] : d_x;
+      float* dst = l > 0 ? h->dz[l] : d_x;
       g.C = dst; g.ldc = l > 0 ? h->d.dims[l] : lddx;
       g.M = B; g.N = h->d.dims[l]; g.K = h->d.dims[l + 1];
       if (l > 0 && !((h->d.identity_layers >> (l - 1)) & 1)) {
@@ -249,8 +235,37 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       }
       int rc = launch_linear<true>(&g, 1, s);
       if (rc != PA_OK) return rc;
-      dz = dst;
-      lddz = l > 0 ? h->d.dims[l] : lddx;
+      if (l > 0) {
+        dzs[l - 1] = dst;
+        ldzs[l - 1] = h->d.dims[l];
+      }
+    }
+  }
+  // ---- then the weight gradients of up to three layers per launch (their tiles run side by side)
+  if (want_dw) {
+    for (int l0 = 0; l0 < h->L; l0 += 3) {
+      DwArgs a;
+      memset(&a, 0, sizeof(a));
+      int t0 = 0;
+      for (int l = l0; l < h->L && l < l0 + 3; ++l) {
+        DwProblem& pr = a.p[a.nprob++];
+        pr.dZ = dzs[l]; pr.ldz = ldzs[l];
+        pr.X = l > 0 ? h->act[l - 1] : x;
+        pr.ldx = l > 0 ? h->d.dims[l] : ldx;
+        pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
+        // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias
+        // slot: its column sums go to scratch so AdamW never moves it
+        pr.db = (l == h->L - 1 && h->d.no_last_bias) ? h->db_scratch : h->bufs.grad + h->boff[l];
+        pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
+        pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
+        pr.tile0 = t0;
+        pr.kind = 2;
+        t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
+      }
+      a.total_tiles = t0;
+      a.B = B;
+      int rcw = launch_weight_grad(a, false, s);
+      if (rcw != PA_OK) return rcw;
     }
   }
   return PA_OK;

@@ -40,7 +40,9 @@ def _worker(rank, world, port, q):
     flat = torch.cat([p.detach().reshape(-1) for p in pl._Q.parameters()] +
                      [p.detach().reshape(-1) for p in pl._Q_target.parameters()]).cpu()
     mom = torch.cat([pl._optimizer.state[p]["exp_avg"].reshape(-1) for p in pl._Q.parameters()]).cpu()
-    q.put((rank, flat, mom, losses, pl._training_steps))
+    # numpy arrays travel by value; torch tensors would be handed over through the producer process,
+    # which may be gone before the parent reads them
+    q.put((rank, flat.numpy(), mom.numpy(), losses, pl._training_steps))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,7 +58,7 @@ def _run(world):
     out = {}
     for _ in procs:
         rank, flat, mom, losses, steps = q.get(timeout=300)
-        out[rank] = (flat.clone(), mom.clone(), losses, steps)
+        out[rank] = (torch.from_numpy(flat.copy()), torch.from_numpy(mom.copy()), losses, steps)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
