@@ -810,6 +810,78 @@ __global__ __launch_bounds__(1024) void linreg_solve_kernel(SolveArgs a) {
   }
 }
 
+// The same elimination (same pivots, same fp64 operations in the same order: bit-identical
+// result) with the augmented matrix in LDS and four barriers per pivot step instead of seventeen
+// on a global-memory work area: 419 us -> ~70 us for D = 65.  Used whenever [D][2D] doubles fit.
+__global__ __launch_bounds__(1024) void linreg_solve_lds_kernel(SolveArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  const int D = a.D, W = 2 * D, tid = threadIdx.x, lane = tid & 63;
+  double* work = lds_work;          // [D][W]
+  double* prowv = work + D * W;     // [W] normalised pivot row
+  double* colk = prowv + W;         // [D] column k before the elimination
+  __shared__ int prow;
+  for (int e = tid; e < D * W; e += 1024) {
+    const int i = e / W, j = e - i * W;
+    double v;
+    if (j < D) v = (double)a.A[i * D + j] + (i == j ? (double)a.lambda : 0.0);
+    else v = (j - D == i) ? 1.0 : 0.0;
+    work[e] = v;
+  }
+  __syncthreads();
+  for (int k = 0; k < D; ++k) {
+    // pivot search in column k over rows k..D-1 (one wave; largest |v|, lowest row on ties)
+    if (tid < 64) {
+      double best = -1.0;
+      int bi = k;
+      for (int i = k + lane; i < D; i += 64) {
+        const double v = fabs(work[i * W + k]);
+        if (v > best) { best = v; bi = i; }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) {
+        prow = bi;
+        if (!(best > 0.0)) a.singular[0] = 1;
+      }
+    }
+    __syncthreads();
+    const int p = prow;
+    if (p != k) {
+      for (int j = tid; j < W; j += 1024) {
+        const double t = work[k * W + j];
+        work[k * W + j] = work[p * W + j];
+        work[p * W + j] = t;
+      }
+      __syncthreads();
+    }
+    const double piv = work[k * W + k];
+    for (int j = tid; j < W; j += 1024) prowv[j] = work[k * W + j] / piv;
+    for (int i = tid; i < D; i += 1024) colk[i] = work[i * W + k];
+    __syncthreads();
+    // eliminate column k from every other row; row k becomes the normalised pivot row
+    for (int e = tid; e < D * W; e += 1024) {
+      const int i = e / W, j = e - i * W;
+      if (i == k) work[e] = prowv[j];
+      else if (j == k) work[e] = 0.0;
+      else work[e] -= colk[i] * prowv[j];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < D * D; e += 1024) {
+    const int i = e / D, j = e - i * D;
+    a.invA[e] = (float)work[i * W + D + j];
+  }
+  for (int i = tid; i < D; i += 1024) {
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += work[i * W + D + j] * (double)a.bvec[j];
+    a.coefs[i] = (float)s;
+  }
+}
+
 // sigma[b] = sqrt([1 | f_b] inv_A [1 | f_b]^T)      (linear_regression.py:261-270)
 __global__ __launch_bounds__(256) void linreg_sigma_kernel(const float* __restrict__ f, int ldf,
                                                            const float* __restrict__ invA, int B,
@@ -907,7 +979,19 @@ extern "C" int pa_linreg_solve(const float* A, const float* b, float l2_reg_lamb
   a.coefs = coefs_out; a.singular = singular_out;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipMemsetAsync(singular_out, 0, sizeof(int32_t), s));
-  hipLaunchKernelGGL(linreg_solve_kernel, dim3(1), dim3(1024), 0, s, a);
+  const int D = d + 1;
+  const size_t lds = sizeof(double) * ((size_t)D * 2 * D + 2 * D + D);
+  if (lds <= 150 * 1024) {
+    static size_t configured = 0;
+    if (lds > configured) {
+      int rc = set_max_smem(linreg_solve_lds_kernel, lds);
+      if (rc != PA_OK) return rc;
+      configured = lds;
+    }
+    hipLaunchKernelGGL(linreg_solve_lds_kernel, dim3(1), dim3(1024), lds, s, a);
+  } else {
+    hipLaunchKernelGGL(linreg_solve_kernel, dim3(1), dim3(1024), 0, s, a);
+  }
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
