@@ -810,9 +810,10 @@ __global__ __launch_bounds__(1024) void linreg_solve_kernel(SolveArgs a) {
   }
 }
 
-// The same elimination (same pivots, same fp64 operations in the same order: bit-identical
-// result) with the augmented matrix in LDS and four barriers per pivot step instead of seventeen
-// on a global-memory work area: 419 us -> ~70 us for D = 65.  Used whenever [D][2D] doubles fit.
+// The same elimination (same pivots; the pivot row is scaled by one fp64 reciprocal instead of 2D
+// divisions) with the augmented matrix in LDS, the element -> (row, column) map of every thread
+// computed once, and four barriers per pivot step instead of seventeen on a global-memory work
+// area: 419 us -> ~100 us for D = 65.  Used whenever [D][2D] doubles fit.
 __global__ __launch_bounds__(1024) void linreg_solve_lds_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
   const int D = a.D, W = 2 * D, tid = threadIdx.x, lane = tid & 63;
@@ -820,6 +821,10 @@ __global__ __launch_bounds__(1024) void linreg_solve_lds_kernel(SolveArgs a) {
   double* prowv = work + D * W;     // [W] normalised pivot row
   double* colk = prowv + W;         // [D] column k before the elimination
   __shared__ int prow;
+  // this thread's elements e = tid + 1024 t of the [D][W] matrix: (row, column) advance by a fixed
+  // stride, so the k loop needs no integer division
+  const int i_first = tid / W, j_first = tid - i_first * W;
+  const int di = 1024 / W, dj = 1024 - di * W;
   for (int e = tid; e < D * W; e += 1024) {
     const int i = e / W, j = e - i * W;
     double v;
@@ -858,16 +863,21 @@ __global__ __launch_bounds__(1024) void linreg_solve_lds_kernel(SolveArgs a) {
       }
       __syncthreads();
     }
-    const double piv = work[k * W + k];
-    for (int j = tid; j < W; j += 1024) prowv[j] = work[k * W + j] / piv;
+    const double rpiv = 1.0 / work[k * W + k];
+    for (int j = tid; j < W; j += 1024) prowv[j] = (j == k) ? 1.0 : work[k * W + j] * rpiv;
     for (int i = tid; i < D; i += 1024) colk[i] = work[i * W + k];
     __syncthreads();
     // eliminate column k from every other row; row k becomes the normalised pivot row
-    for (int e = tid; e < D * W; e += 1024) {
-      const int i = e / W, j = e - i * W;
-      if (i == k) work[e] = prowv[j];
-      else if (j == k) work[e] = 0.0;
-      else work[e] -= colk[i] * prowv[j];
+    {
+      int i = i_first, j = j_first;
+      for (int e = tid; e < D * W; e += 1024) {
+        if (i == k) work[e] = prowv[j];
+        else if (j == k) work[e] = 0.0;
+        else work[e] -= colk[i] * prowv[j];
+        i += di;
+        j += dj;
+        if (j >= W) { j -= W; ++i; }
+      }
     }
     __syncthreads();
   }
