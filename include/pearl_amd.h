@@ -368,6 +368,15 @@ int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int3
 /* autograd of the kept forward: dW/db into bufs.grad (want_dw) and/or d_x[B, d_0] (nullable). */
 int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
                     int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx, void* stream);
+/* Two networks of the same shape in lock-step (TwinCritic, twin_critic.py:22-91): the same
+ * arithmetic as two pa_mlp_forward / pa_mlp_backward calls, with every layer of both networks in
+ * one launch.  Both read the same input x; d_x1 / d_x2 are both given or both NULL. */
+int pa_mlp_forward2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const float* x, int32_t ldx,
+                    int32_t B, float* out1, int32_t ldo1, float* out2, int32_t ldo2, int32_t keep,
+                    void* stream);
+int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t ldx, int32_t B,
+                     const float* d_out1, int32_t ldd1, const float* d_out2, int32_t ldd2,
+                     int32_t want_dw, float* d_x1, float* d_x2, int32_t lddx, void* stream);
 int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream);
 /* update_target_network (common/utils.py:214-226) */
 int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);

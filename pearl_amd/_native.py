@@ -277,6 +277,10 @@ SIGNATURES = {
     "pa_mlp_copy_activation": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "pa_mlp_backward": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P,
                                   C.c_int32, _P]),
+    "pa_mlp_forward2": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P,
+                                  C.c_int32, C.c_int32, _P]),
+    "pa_mlp_backward2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
+                                   C.c_int32, _P, _P, C.c_int32, _P]),
     "pa_mlp_adam": (C.c_int, [_P, C.c_int64, _P]),
     "pa_mlp_soft_update": (C.c_int, [_P, C.c_float, _P]),
     "pa_softmax_action_prob": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
@@ -372,7 +376,16 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+def _raw_stream(index: int) -> int:
+    return torch.cuda.current_stream(index).cuda_stream
+
+
+# the same value without building a torch.cuda.Stream object per launch (several us each)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", _raw_stream)
+
+
 def stream_ptr(device: torch.device) -> Optional[int]:
     """hipStream_t of torch's current stream on `device`, as an integer."""
-    s = torch.cuda.current_stream(device).cuda_stream
+    idx = device.index
+    s = _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return s if s else None

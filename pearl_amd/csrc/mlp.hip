@@ -271,6 +271,146 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
   return PA_OK;
 }
 
+// ---- two networks of the same shape in lock-step (TwinCritic, twin_critic.py:22-91): every layer of
+// both is ONE launch (linear_kernel and weight_grad_kernel take several problems per launch), which
+// halves the launch count of the twin passes.  Arithmetic per network is unchanged.
+namespace {
+int check_pair(const pa_mlp* h1, const pa_mlp* h2) {
+  PA_REQUIRE(h1 && h2 && h1->bound && h2->bound, PA_ERR_INVALID, "mlp pair: unbound network");
+  PA_REQUIRE(h1->L == h2->L && h1->d.device == h2->d.device &&
+                 h1->d.identity_layers == h2->d.identity_layers &&
+                 h1->d.no_last_bias == h2->d.no_last_bias,
+             PA_ERR_INVALID, "mlp pair: the two networks differ in shape");
+  for (int l = 0; l <= h1->L; ++l)
+    PA_REQUIRE(h1->d.dims[l] == h2->d.dims[l], PA_ERR_INVALID, "mlp pair: layer widths differ");
+  return PA_OK;
+}
+}  // namespace
+
+extern "C" int pa_mlp_forward2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const float* x,
+                               int32_t ldx, int32_t B, float* out1, int32_t ldo1, float* out2,
+                               int32_t ldo2, int32_t keep, void* stream) {
+  int rc = check_pair(h1, h2);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(x && out1 && out2 && B > 0 && B <= h1->d.max_batch && B <= h2->d.max_batch,
+             PA_ERR_INVALID, "pa_mlp_forward2: bad argument (B=%d)", B);
+  pa_mlp* hs[2] = {h1, h2};
+  float* outs[2] = {out1, out2};
+  const int ldos[2] = {ldo1, ldo2};
+  const float* Ps[2];
+  for (int i = 0; i < 2; ++i) {
+    Ps[i] = use_target ? hs[i]->bufs.p_target : hs[i]->bufs.p;
+    PA_REQUIRE(Ps[i], PA_ERR_INVALID, "no target parameters bound");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(h1->d.device));
+  for (int l = 0; l < h1->L; ++l) {
+    const bool last = (l == h1->L - 1);
+    GemmArgs g[2];
+    memset(g, 0, sizeof(g));
+    for (int i = 0; i < 2; ++i) {
+      pa_mlp* h = hs[i];
+      g[i].A = l == 0 ? x : h->act[l - 1];
+      g[i].lda = l == 0 ? ldx : h->d.dims[l];
+      g[i].Bm = Ps[i] + h->woff[l]; g[i].ldb = h->d.dims[l];
+      g[i].C = last ? outs[i] : h->act[l]; g[i].ldc = last ? ldos[i] : h->d.dims[l + 1];
+      g[i].bias = Ps[i] + h->boff[l];
+      g[i].M = B; g[i].N = h->d.dims[l + 1]; g[i].K = h->d.dims[l];
+      const bool relu = !last && !((h->d.identity_layers >> l) & 1);
+      g[i].epi = relu ? EPI_BIAS_RELU : ((last && h->d.no_last_bias) ? EPI_NONE : EPI_BIAS);
+    }
+    rc = launch_linear<false>(g, 2, s);
+    if (rc != PA_OK) return rc;
+  }
+  h1->kept_B = h2->kept_B = keep ? B : 0;
+  return PA_OK;
+}
+
+extern "C" int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t ldx, int32_t B,
+                                const float* d_out1, int32_t ldd1, const float* d_out2, int32_t ldd2,
+                                int32_t want_dw, float* d_x1, float* d_x2, int32_t lddx,
+                                void* stream) {
+  int rc = check_pair(h1, h2);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(h1->kept_B == B && h2->kept_B == B && B > 0, PA_ERR_INVALID,
+             "pa_mlp_backward2: no kept forward of batch %d", B);
+  PA_REQUIRE(x && d_out1 && d_out2 && (!d_x1 == !d_x2), PA_ERR_INVALID, "pa_mlp_backward2: bad argument");
+  PA_REQUIRE(!want_dw || (h1->bufs.grad && h2->bufs.grad), PA_ERR_INVALID, "no gradient buffer bound");
+  pa_mlp* hs[2] = {h1, h2};
+  float* dxs[2] = {d_x1, d_x2};
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(h1->d.device));
+  const int L = h1->L;
+  const float* dzs[2][PA_MLP_MAX_LAYERS];
+  int ldzs[2][PA_MLP_MAX_LAYERS];
+  dzs[0][L - 1] = d_out1; ldzs[0][L - 1] = ldd1;
+  dzs[1][L - 1] = d_out2; ldzs[1][L - 1] = ldd2;
+  for (int l = L - 1; l >= 0; --l) {
+    if (l > 0 || d_x1) {
+      GemmArgs g[2];
+      memset(g, 0, sizeof(g));
+      for (int i = 0; i < 2; ++i) {
+        pa_mlp* h = hs[i];
+        g[i].A = dzs[i][l]; g[i].lda = ldzs[i][l];
+        g[i].Bm = h->bufs.p + h->woff[l]; g[i].ldb = h->d.dims[l];
+        float* dst = l > 0 ? h->dz[l] : dxs[i];
+        g[i].C = dst; g[i].ldc = l > 0 ? h->d.dims[l] : lddx;
+        g[i].M = B; g[i].N = h->d.dims[l]; g[i].K = h->d.dims[l + 1];
+        if (l > 0 && !((h->d.identity_layers >> (l - 1)) & 1)) {
+          g[i].Hmask = h->act[l - 1]; g[i].ldh = h->d.dims[l];
+          g[i].epi = EPI_MASK;
+        } else {
+          g[i].epi = EPI_NONE;
+        }
+        if (l > 0) {
+          dzs[i][l - 1] = dst;
+          ldzs[i][l - 1] = h->d.dims[l];
+        }
+      }
+      rc = launch_linear<true>(g, 2, s);
+      if (rc != PA_OK) return rc;
+    }
+  }
+  if (want_dw) {
+    // 2 L problems, three per launch
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    int t0 = 0;
+    auto flush = [&]() -> int {
+      if (a.nprob == 0) return PA_OK;
+      a.total_tiles = t0;
+      a.B = B;
+      int r = launch_weight_grad(a, false, s);
+      memset(&a, 0, sizeof(a));
+      t0 = 0;
+      return r;
+    };
+    for (int i = 0; i < 2; ++i) {
+      pa_mlp* h = hs[i];
+      for (int l = 0; l < L; ++l) {
+        DwProblem& pr = a.p[a.nprob++];
+        pr.dZ = dzs[i][l]; pr.ldz = ldzs[i][l];
+        pr.X = l > 0 ? h->act[l - 1] : x;
+        pr.ldx = l > 0 ? h->d.dims[l] : ldx;
+        pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
+        pr.db = (l == L - 1 && h->d.no_last_bias) ? h->db_scratch : h->bufs.grad + h->boff[l];
+        pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
+        pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
+        pr.tile0 = t0;
+        pr.kind = 2;
+        t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
+        if (a.nprob == 3) {
+          rc = flush();
+          if (rc != PA_OK) return rc;
+        }
+      }
+    }
+    rc = flush();
+    if (rc != PA_OK) return rc;
+  }
+  return PA_OK;
+}
+
 // optim.AdamW(amsgrad) step `step` (1-based) on bufs.grad.
 extern "C" int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream) {
   PA_REQUIRE(h && h->bound && h->bufs.grad && h->bufs.exp_avg && h->bufs.exp_avg_sq,
@@ -524,26 +664,37 @@ __device__ __forceinline__ void gauss_elem(float mean, float raw, float eps, flo
   u = mean + stdv * eps;
   n = tanhf(u);
 }
+// One thread per (row, action component): a workgroup covers 256 / A rows, the per-row sum of the
+// A log-prob terms is taken in component order by the row's first thread (the same order as a
+// serial loop, so the result does not depend on the launch shape).  Needs A <= 256.
 __global__ __launch_bounds__(256) void gauss_sample_kernel(GaussArgs a) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
-  const float* hd = a.head + (int64_t)b * a.ldh;
-  float lp = 0.f;
-  for (int j = 0; j < a.A; ++j) {
+  __shared__ float terms[256];
+  const int rows_per_wg = 256 / a.A;
+  const int r = threadIdx.x / a.A, j = threadIdx.x - r * a.A;
+  const int b = blockIdx.x * rows_per_wg + r;
+  const bool live = r < rows_per_wg && b < a.B;
+  if (live) {
+    const float* hd = a.head + (int64_t)b * a.ldh;
     float t, ls, sd, u, n;
     const float eps = a.noise[(int64_t)b * a.ldn + j];
-    gauss_elem(hd[j], hd[a.A + j], eps, a.low[j], a.high[j], t, ls, sd, u, n);
-    const float act = (((a.high[j] - a.low[j]) * (n + 1.0f)) / 2.0f) + a.low[j];
+    const float mean = hd[j], lo = a.low[j], hi = a.high[j];
+    gauss_elem(mean, hd[a.A + j], eps, lo, hi, t, ls, sd, u, n);
+    const float act = (((hi - lo) * (n + 1.0f)) / 2.0f) + lo;
     a.action[(int64_t)b * a.lda + j] = act;
     // Normal.log_prob: -((u - mean)^2) / (2 var) - log(std) - log(sqrt(2 pi))
     const float var = sd * sd;
-    const float diff = u - hd[j];
+    const float diff = u - mean;
     float l = -(diff * diff) / (2.0f * var) - logf(sd) - 0.9189385332046727f;
-    const float bound = (a.high[j] - a.low[j]) / 2.0f;
+    const float bound = (hi - lo) / 2.0f;
     l -= logf(bound * (1.0f - n * n) + 1e-6f);
-    lp += l;
+    terms[threadIdx.x] = l;
   }
-  a.log_prob[b] = lp;
+  __syncthreads();
+  if (live && j == 0) {
+    float lp = 0.f;
+    for (int k = 0; k < a.A; ++k) lp += terms[threadIdx.x + k];
+    a.log_prob[b] = lp;
+  }
 }
 
 // Gradient of mean_b(alpha * log_prob_b - q_b) w.r.t. the actor head, given dq_b/da (the critic's
@@ -558,26 +709,26 @@ struct GaussGradArgs {
   float* d_head; int lddh;         // [B, 2A]
 };
 __global__ __launch_bounds__(256) void gauss_grad_kernel(GaussGradArgs a) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= a.B) return;
+  // one thread per (row, action component)
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)a.B * a.A) return;
+  const int b = (int)(e / a.A), j = (int)(e - (int64_t)b * a.A);
   const float* hd = a.head + (int64_t)b * a.ldh;
   const float coef = a.alpha[0] / (float)a.B;   // dL/dlog_prob_b
-  for (int j = 0; j < a.A; ++j) {
-    float t, ls, sd, u, n;
-    const float eps = a.noise[(int64_t)b * a.ldn + j];
-    gauss_elem(hd[j], hd[a.A + j], eps, a.low[j], a.high[j], t, ls, sd, u, n);
-    const float bound = (a.high[j] - a.low[j]) / 2.0f;
-    const float one_m_n2 = 1.0f - n * n;
-    // d log_prob / du (the Normal term is -noise^2/2: constant under the reparameterisation)
-    const float dlp_du = (2.0f * bound * n * one_m_n2) / (bound * one_m_n2 + 1e-6f);
-    const float da_du = bound * one_m_n2;
-    float dla = a.dl_da[(int64_t)b * a.ldda + j];
-    if (a.dl_da2) dla += a.dl_da2[(int64_t)b * a.ldda + j];
-    const float dl_du = coef * dlp_du + dla * da_du;
-    const float dl_dls = dl_du * eps * sd - coef;     // -log(std) term: -1
-    a.d_head[(int64_t)b * a.lddh + j] = dl_du;
-    a.d_head[(int64_t)b * a.lddh + a.A + j] = dl_dls * 3.5f * (1.0f - t * t);
-  }
+  float t, ls, sd, u, n;
+  const float eps = a.noise[(int64_t)b * a.ldn + j];
+  gauss_elem(hd[j], hd[a.A + j], eps, a.low[j], a.high[j], t, ls, sd, u, n);
+  const float bound = (a.high[j] - a.low[j]) / 2.0f;
+  const float one_m_n2 = 1.0f - n * n;
+  // d log_prob / du (the Normal term is -noise^2/2: constant under the reparameterisation)
+  const float dlp_du = (2.0f * bound * n * one_m_n2) / (bound * one_m_n2 + 1e-6f);
+  const float da_du = bound * one_m_n2;
+  float dla = a.dl_da[(int64_t)b * a.ldda + j];
+  if (a.dl_da2) dla += a.dl_da2[(int64_t)b * a.ldda + j];
+  const float dl_du = coef * dlp_du + dla * da_du;
+  const float dl_dls = dl_du * eps * sd - coef;     // -log(std) term: -1
+  a.d_head[(int64_t)b * a.lddh + j] = dl_du;
+  a.d_head[(int64_t)b * a.lddh + a.A + j] = dl_dls * 3.5f * (1.0f - t * t);
 }
 
 // Twin-critic plumbing for SAC (soft_actor_critic_continuous.py:155-231).
@@ -1100,7 +1251,8 @@ extern "C" int pa_gauss_sample(const float* head, int32_t ldh, const float* nois
   GaussArgs a;
   a.head = head; a.ldh = ldh; a.noise = noise; a.ldn = ldn; a.low = low; a.high = high;
   a.B = B; a.A = A; a.action = action; a.lda = lda; a.log_prob = log_prob;
-  hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+  PA_REQUIRE(A <= 256, PA_ERR_UNSUPPORTED, "pa_gauss_sample: action dimension %d > 256", A);
+  hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)ceil_div(B, 256 / A)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -1117,7 +1269,7 @@ extern "C" int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* 
   a.head = head; a.ldh = ldh; a.noise = noise; a.ldn = ldn; a.low = low; a.high = high;
   a.dl_da = dl_daction; a.dl_da2 = dl_daction2; a.ldda = ldda; a.alpha = alpha; a.B = B; a.A = A;
   a.d_head = d_head; a.lddh = lddh;
-  hipLaunchKernelGGL(gauss_grad_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(gauss_grad_kernel, dim3((unsigned)ceil_div((int64_t)B * A, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;

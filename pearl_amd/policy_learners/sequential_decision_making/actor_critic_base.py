@@ -26,9 +26,10 @@ from ...neural_networks.sequential_decision_making.actor_networks import (ActorN
                                                                          VanillaActorNetwork)
 from ...neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
 from ...neural_networks.sequential_decision_making.twin_critic import TwinCritic
+from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import ExplorationModule
-from ..policy_learner import PolicyLearner
+from ..policy_learner import PolicyLearner, _looks_like_batch
 
 
 def make_critic(state_dim: int, hidden_dims: Optional[List[int]], use_twin_critic: bool,
@@ -137,12 +138,42 @@ class ActorCriticBase(PolicyLearner):
 
     # ------------------------------------------------------------------ learn_batch (:309-366)
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        report = self._learn_batch_device(batch)
+        return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in report.items()}
+
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        """learn_batch with the losses left on the device (no host synchronisation)."""
         report = {"actor_loss": self._actor_update(batch)}
         if self._use_critic:
             report["critic_loss"] = self._critic_update(batch)
         if self._use_critic_target:
             self._update_critic_target()
-        return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in report.items()}
+        return report
+
+    def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
+        """PolicyLearner.learn (policy_learner.py:190-231) with the same report — one list of
+        floats per key — but ONE host synchronisation for the whole call instead of one `.item()`
+        per loss per round: the host keeps enqueueing round r+1 while the device runs round r."""
+        if len(replay_buffer) == 0:
+            return {}
+        batch_size = self._clamped_batch_size(replay_buffer)
+        pending: Dict[str, List[Any]] = {}
+        for _ in range(self._training_rounds):
+            self._training_steps += 1
+            batch = replay_buffer.sample(batch_size)
+            if not _looks_like_batch(batch):
+                continue
+            for k, v in self._learn_batch_device(self.preprocess_batch(batch)).items():
+                pending.setdefault(k, []).append(v)
+        report: Dict[str, List[Any]] = {}
+        for k, vals in pending.items():
+            dev_ix = [i for i, v in enumerate(vals) if isinstance(v, torch.Tensor)]
+            if dev_ix:
+                got = torch.stack([vals[i].reshape(()) for i in dev_ix]).tolist()
+                for i, g in zip(dev_ix, got):
+                    vals[i] = g
+            report[k] = vals
+        return report
 
     def preprocess_batch(self, batch: TransitionBatch) -> TransitionBatch:
         safety = getattr(self, "safety_module", None)

@@ -139,6 +139,7 @@ class FlatMlp:
             self.handle, self._desc_key, self._sig = h, key, ()
             self.max_batch = max_b
         if self._sig and self._sig == self._signature():
+            self._steps = self.adam_steps()
             return self
         # ---- flatten
         P = int(N.lib().pa_mlp_param_count(C.byref(self._desc)))
@@ -187,6 +188,15 @@ class FlatMlp:
         N.check(N.lib().pa_mlp_bind(self.handle, C.byref(bufs)))
         self.flat = flat
         self._sig = self._signature()
+        self._steps = steps
+        return self
+
+    def ready(self, batch: int = 0) -> "FlatMlp":
+        """The per-launch check: a bound handle large enough for `batch`.  Whether the torch
+        parameters / optimizer state still alias the flat buffers is re-validated by `ensure`,
+        which learners call once at the top of every learn_batch."""
+        if self.handle is None or not self._sig or batch > self.max_batch:
+            return self.ensure(batch)
         return self
 
     # ------------------------------------------------------------------ ops (all enqueue on torch's stream)
@@ -198,7 +208,7 @@ class FlatMlp:
                 keep: bool = False) -> torch.Tensor:
         assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1 and x.ndim == 2
         B = int(x.shape[0])
-        self.ensure(B)
+        self.ready(B)
         if out is None:
             out = torch.empty(B, self.dims[-1], dtype=torch.float32, device=x.device)
         N.check(N.lib().pa_mlp_forward(self.handle, int(use_target), x.data_ptr(), x.stride(0), B,
@@ -215,6 +225,35 @@ class FlatMlp:
                                         N.ptr(d_x), self.dims[0], N.stream_ptr(x.device)))
         return d_x
 
+    @staticmethod
+    def forward_pair(m1: "FlatMlp", m2: "FlatMlp", x: torch.Tensor, use_target: bool = False,
+                     keep: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Both networks of a twin (same shape) on the same input, one launch per layer."""
+        assert x.dtype == torch.float32 and x.is_cuda and x.stride(-1) == 1 and x.ndim == 2
+        B = int(x.shape[0])
+        m1.ready(B)
+        m2.ready(B)
+        o1 = torch.empty(B, m1.dims[-1], dtype=torch.float32, device=x.device)
+        o2 = torch.empty(B, m2.dims[-1], dtype=torch.float32, device=x.device)
+        N.check(N.lib().pa_mlp_forward2(m1.handle, m2.handle, int(use_target), x.data_ptr(),
+                                        x.stride(0), B, o1.data_ptr(), o1.stride(0), o2.data_ptr(),
+                                        o2.stride(0), int(keep), N.stream_ptr(x.device)))
+        return o1, o2
+
+    @staticmethod
+    def backward_pair(m1: "FlatMlp", m2: "FlatMlp", x: torch.Tensor, d1: torch.Tensor,
+                      d2: torch.Tensor, want_dw: bool = True, want_dx: bool = False):
+        B = int(x.shape[0])
+        dx1 = dx2 = None
+        if want_dx:
+            dx1 = torch.empty(B, m1.dims[0], dtype=torch.float32, device=x.device)
+            dx2 = torch.empty(B, m2.dims[0], dtype=torch.float32, device=x.device)
+        N.check(N.lib().pa_mlp_backward2(
+            m1.handle, m2.handle, x.data_ptr(), x.stride(0), B, d1.data_ptr(),
+            d1.stride(0) if d1.ndim == 2 else 1, d2.data_ptr(), d2.stride(0) if d2.ndim == 2 else 1,
+            int(want_dw), N.ptr(dx1), N.ptr(dx2), m1.dims[0], N.stream_ptr(x.device)))
+        return dx1, dx2
+
     def adam(self, reduce: str = "mean") -> None:
         """AdamW(amsgrad) step on the flat gradient buffer.
 
@@ -226,10 +265,11 @@ class FlatMlp:
         (MSE / SAC losses: average of the rank gradients) or "sum" (PPO's summed clipped surrogate,
         ppo.py:152-183: plain sum).  With one rank this is exactly the single-GPU step."""
         reduce_gradient_(self.flat["grad"], reduce)
-        step = self.adam_steps() + 1
-        N.check(N.lib().pa_mlp_adam(self.handle, step, N.stream_ptr(self.device)))
+        step = self._steps + 1
+        N.check(N.lib().pa_mlp_adam(self.handle, step, N.stream_ptr(self.flat["p"].device)))
         self._set_adam_steps(step)
+        self._steps = step
 
     def soft_update(self, tau: float) -> None:
-        self.ensure()
+        self.ready()
         N.check(N.lib().pa_mlp_soft_update(self.handle, float(tau), N.stream_ptr(self.device)))

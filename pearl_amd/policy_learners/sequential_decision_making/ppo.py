@@ -128,13 +128,15 @@ class ProximalPolicyOptimization(ActorCriticBase):
         self._entropy_bonus_scaling = entropy_bonus_scaling
 
     # ------------------------------------------------------------------ flat views
-    def _nets(self, batch_hint: int = 0):
+    def _nets(self, batch_hint: int = 0, validate: bool = True):
         if not self._flat:
             self._flat["actor"] = FlatMlp(layers_of(self._actor.linear_layers()),
                                           self._actor_optimizer, max(self._batch_size, 1))
             self._flat["critic"] = FlatMlp(layers_of(self._critic.linear_layers()),
                                            self._critic_optimizer, max(self._batch_size, 1))
-        return self._flat["actor"].ensure(batch_hint), self._flat["critic"].ensure(batch_hint)
+        if validate:
+            return self._flat["actor"].ensure(batch_hint), self._flat["critic"].ensure(batch_hint)
+        return self._flat["actor"].ready(batch_hint), self._flat["critic"].ready(batch_hint)
 
     @staticmethod
     def _f32(t: Tensor, dev: torch.device) -> Tensor:
@@ -164,7 +166,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
 
     def _critic_update(self, batch: TransitionBatch) -> Tensor:
         assert isinstance(batch, PPOTransitionBatch) and batch.lam_return is not None
-        _, critic = self._nets(len(batch))
+        _, critic = self._nets(len(batch), validate=False)   # validated in _actor_update
         dev = critic.device
         state = self._f32(batch.state, dev)
         B = state.shape[0]
@@ -181,7 +183,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
     # ------------------------------------------------------------------ learn (ppo.py:194-293)
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         self.preprocess_replay_buffer(replay_buffer)
-        return PolicyLearner.learn(self, replay_buffer)
+        return ActorCriticBase.learn(self, replay_buffer)
 
     def preprocess_replay_buffer(self, replay_buffer: ReplayBuffer) -> None:
         assert isinstance(replay_buffer, PPOReplayBuffer), \

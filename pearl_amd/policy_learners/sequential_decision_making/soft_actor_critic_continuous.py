@@ -84,7 +84,10 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         self.noise_source: Optional[Callable[[int, int, torch.device], Tensor]] = None
 
     # ------------------------------------------------------------------ flat views
-    def _nets(self, batch_hint: int = 0):
+    def _nets(self, batch_hint: int = 0, validate: bool = True):
+        """The flat networks.  `validate` re-checks that the torch parameters and optimizer state
+        still alias the flat buffers (once per learn_batch, in _actor_update); the later stages of
+        the same learn_batch only need bound handles."""
         if not self._flat:
             mb = max(self._batch_size, 1)
             a = self._actor
@@ -96,8 +99,10 @@ class ContinuousSoftActorCritic(ActorCriticBase):
                 self._flat[f"critic{i}"] = FlatMlp(layers_of(c.linear_layers()),
                                                    self._critic_optimizer, mb,
                                                    target_layers=layers_of(ct.linear_layers()))
-        return (self._flat["actor"].ensure(batch_hint), self._flat["critic1"].ensure(batch_hint),
-                self._flat["critic2"].ensure(batch_hint))
+        nets = (self._flat["actor"], self._flat["critic1"], self._flat["critic2"])
+        if validate:
+            return tuple(m.ensure(batch_hint) for m in nets)
+        return tuple(m.ready(batch_hint) for m in nets)
 
     def _alpha_state(self, dev: torch.device) -> Dict[str, Tensor]:
         """Device scalars of the entropy coefficient and (autotune) its AdamW state."""
@@ -127,7 +132,12 @@ class ContinuousSoftActorCritic(ActorCriticBase):
 
     def _bounds(self, dev: torch.device):
         sp = self._actor._action_space
-        return (sp.low.to(dev, torch.float32).contiguous(), sp.high.to(dev, torch.float32).contiguous())
+        hit = self._flat.get("bounds")
+        if hit is None or hit[0] is not sp or hit[1] != dev:
+            hit = (sp, dev, sp.low.to(dev, torch.float32).contiguous(),
+                   sp.high.to(dev, torch.float32).contiguous())
+            self._flat["bounds"] = hit
+        return hit[2], hit[3]
 
     @staticmethod
     def _f32(t: Tensor, dev: torch.device) -> Tensor:
@@ -163,8 +173,8 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         xa[:, :S].copy_(state)
         head, noise, logp = self._sample(actor, state, xa, keep=True)
         self._action_batch_log_prob_cache = logp
-        q1 = c1.forward(xa, keep=True).reshape(B)
-        q2 = c2.forward(xa, keep=True).reshape(B)
+        q1, q2 = FlatMlp.forward_pair(c1, c2, xa, keep=True)   # twin critics: one launch per layer
+        q1, q2 = q1.reshape(B), q2.reshape(B)
         dq1, dq2 = torch.empty_like(q1), torch.empty_like(q2)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         N.check(N.lib().pa_sac_twin(0, q1.data_ptr(), q2.data_ptr(), logp.data_ptr(),
@@ -172,8 +182,7 @@ class ContinuousSoftActorCritic(ActorCriticBase):
                                     dq2.data_ptr(), loss.data_ptr(), s))
         # the reference also forms (then discards) the critics' parameter gradients here
         # (actor_critic_base.py:342-348); only the input gradient matters
-        dx1 = c1.backward(xa, dq1, want_dw=False, want_dx=True)
-        dx2 = c2.backward(xa, dq2, want_dw=False, want_dx=True)
+        dx1, dx2 = FlatMlp.backward_pair(c1, c2, xa, dq1, dq2, want_dw=False, want_dx=True)
         d_head = torch.empty_like(head)
         low, high = self._bounds(dev)
         N.check(N.lib().pa_gauss_actor_grad(
@@ -185,7 +194,7 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         return loss[0]
 
     def _critic_update(self, batch: TransitionBatch) -> Tensor:
-        actor, c1, c2 = self._nets(len(batch))
+        actor, c1, c2 = self._nets(len(batch), validate=False)
         dev = actor.device
         al = self._alpha_state(dev)
         state = self._f32(batch.state, dev)
@@ -197,8 +206,8 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         xn = torch.empty(B, S + A, dtype=torch.float32, device=dev)
         xn[:, :S].copy_(nstate)
         _, _, nlogp = self._sample(actor, nstate, xn, keep=False)
-        nq1 = c1.forward(xn, use_target=True).reshape(B)
-        nq2 = c2.forward(xn, use_target=True).reshape(B)
+        nq1, nq2 = FlatMlp.forward_pair(c1, c2, xn, use_target=True)
+        nq1, nq2 = nq1.reshape(B), nq2.reshape(B)
         y = torch.empty(B, dtype=torch.float32, device=dev)
         reward = self._f32(batch.reward, dev).reshape(B)
         term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
@@ -211,24 +220,25 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         N.check(N.lib().pa_concat_cols(state.data_ptr(), state.stride(0), act.data_ptr(),
                                        act.stride(0), xq.data_ptr(), B, S, A, s))
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        for i, c in enumerate((c1, c2)):
-            q = c.forward(xq, keep=True).reshape(B)
-            dq = torch.empty_like(q)
-            N.check(N.lib().pa_mse_head(q.data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
-                                        dq.data_ptr(), loss.data_ptr(), s))
-            c.backward(xq, dq, want_dw=True)
-            c.adam()
+        qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, keep=True)]
+        dqs = [torch.empty_like(q) for q in qs]
+        for i in range(2):
+            N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
+                                        dqs[i].data_ptr(), loss.data_ptr(), s))
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        c1.adam()
+        c2.adam()
         return loss[0]
 
     def _update_critic_target(self) -> None:
-        _, c1, c2 = self._nets()
+        _, c1, c2 = self._nets(validate=False)
         c1.soft_update(self._critic_soft_update_tau)
         c2.soft_update(self._critic_soft_update_tau)
 
-    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
-        report = super().learn_batch(batch)
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        report = super()._learn_batch_device(batch)
         if self._entropy_autotune:
-            actor, _, _ = self._nets()
+            actor, _, _ = self._nets(validate=False)
             dev = actor.device
             al = self._alpha_state(dev)
             g = self._entropy_optimizer.param_groups[0]

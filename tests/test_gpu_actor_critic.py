@@ -170,3 +170,39 @@ def test_neural_linear_bandit_learn_batch(name):
     N.check(N.lib().pa_linreg_sigma(feats.data_ptr(), feats.stride(0), lr._inv_A.data_ptr(),
                                     xq.shape[0], feats.shape[1], sig.data_ptr(), N.stream_ptr(xq.device)))
     torch.testing.assert_close(sig.cpu(), fx["query"]["sigma"].view(-1), rtol=5e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("dims,B", [([20, 64, 64, 1], 96), ([34, 256, 256, 1], 256), ([7, 33, 1], 5)])
+def test_twin_pair_launches_equal_two_single_passes(dims, B):
+    """pa_mlp_forward2 / pa_mlp_backward2 (TwinCritic, twin_critic.py:22-91) are the same arithmetic
+    as two single-network passes: outputs, input gradients and weight gradients bit-identical."""
+    from torch import nn, optim
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    torch.manual_seed(3)
+
+    def make():
+        lins = [nn.Linear(dims[i], dims[i + 1]).to(DEV) for i in range(len(dims) - 1)]
+        params = [p for l in lins for p in l.parameters()]
+        return FlatMlp(layers_of(lins), optim.AdamW(params, lr=1e-3, amsgrad=True), max_batch=B)
+
+    m1, m2 = make(), make()
+    x = torch.randn(B, dims[0], device=DEV)
+    d1 = torch.randn(B, device=DEV)
+    d2 = torch.randn(B, device=DEV)
+    o1 = m1.forward(x, keep=True).clone()
+    o2 = m2.forward(x, keep=True).clone()
+    dx1 = m1.backward(x, d1, want_dw=True, want_dx=True).clone()
+    dx2 = m2.backward(x, d2, want_dw=True, want_dx=True).clone()
+    g1 = [p.grad.clone() for p in m1._params()]     # views into the flat gradient buffer
+    g2 = [p.grad.clone() for p in m2._params()]
+    m1.flat["grad"].fill_(float("nan"))
+    m2.flat["grad"].fill_(float("nan"))
+    p1, p2 = FlatMlp.forward_pair(m1, m2, x, keep=True)
+    px1, px2 = FlatMlp.backward_pair(m1, m2, x, d1, d2, want_dw=True, want_dx=True)
+    torch.cuda.synchronize()
+    for i, (got, want) in enumerate(((p1, o1), (p2, o2), (px1, dx1), (px2, dx2))):
+        assert torch.equal(got, want), i
+    for m, g in ((m1, g1), (m2, g2)):
+        for p, want in zip(m._params(), g):
+            assert torch.equal(p.grad, want)
+    assert not torch.equal(o1, o2)
