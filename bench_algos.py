@@ -172,6 +172,49 @@ def bench_bandit(steps, cpu_seconds):
                              "sample": f"{n} oracle learn_batch calls"}}
 
 
+def bench_double_dqn(steps, cpu_seconds):
+    """DoubleDQN on BASELINE config 2's shapes: the next action comes from the
+    ONLINE network, so every round is sequential (all-actions pass on all CUs, then the value pass,
+    then the online chain) — no window batching, no overlap."""
+    from oracle.pearl_oracle import DqnOracle
+    from pearl_amd import (BasicReplayBuffer, DoubleDQN, OneHotActionTensorRepresentationModule,
+                           PearlAgent)
+    S, A, B, N = 128, 16, 1024, 1_000_000
+    torch.manual_seed(0)
+    random.seed(0)
+    pl = DoubleDQN(state_dim=S, action_space=dspace(A), hidden_dims=[256, 256], training_rounds=steps,
+                   batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = BasicReplayBuffer(N, sampler="device")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    st = torch.randn(N + 1, S, device=DEV, generator=g)
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=dspace(A),
+                 next_available_actions=dspace(A), max_number_actions=A)
+    dt, _ = timed(lambda: agent.learn())
+    gpu = B * steps / dt
+    orc = DqnOracle({k: v.cpu() for k, v in pl._Q.state_dict().items()},
+                    {k: v.cpu() for k, v in pl._Q_target.state_dict().items()}, double_q=True)
+    idx = torch.randint(0, 1000, (B,))
+    batch = dict(state=torch.randn(B, S), action=torch.eye(A)[idx % A], reward=(idx % 7).float(),
+                 terminated=(idx % 50 == 0), next_state=torch.randn(B, S),
+                 next_available_actions=torch.eye(A).expand(B, A, A),
+                 next_unavailable_actions_mask=torch.zeros(B, A, dtype=torch.bool))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < cpu_seconds:
+        orc.training_steps += 1
+        orc.learn_batch(batch)
+        n += 1
+    cpu = B * n / (time.perf_counter() - t0)
+    return {"config": "cfg2 shapes, DoubleDQN S=128 A=16 [256,256] B=1024 replay 1M",
+            "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
+                             "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
+
+
 def bench_push(steps, cpu_seconds):
     """Ingest: per-transition push() through the pinned staging ring, and
     push_many() from host tensors (one H2D copy + one scatter kernel) — the PCIe-inclusive side of
@@ -233,7 +276,7 @@ def main():
     torch.cuda.set_device(0)
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("ppo", bench_ppo), ("bandit", bench_bandit),
-                     ("push", bench_push)):
+                     ("double_dqn", bench_double_dqn), ("push", bench_push)):
         if args.only and args.only != name:
             continue
         out = fn(args.steps, args.cpu_seconds)

@@ -196,6 +196,9 @@ typedef struct pa_dqn_desc {
   float tau;           /* soft_update_tau (common/utils.py:214-226)             */
   double lr, beta1, beta2, eps, weight_decay; /* optim.AdamW defaults (:183-185) */
   int32_t amsgrad;
+  int32_t double_q;    /* 1: DoubleDQN.get_next_state_values (double_dqn.py:29-57): the next
+                        * action is the ONLINE net's argmax over the available actions, its value
+                        * comes from the target net.  0: DeepQLearning (deep_q_learning.py:130-167) */
 } pa_dqn_desc;
 
 /* Parameter storage, flat fp32.  Layout (floats), every tensor offset rounded

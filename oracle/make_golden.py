@@ -32,6 +32,7 @@ from pearl.action_representation_modules.one_hot_action_representation_module im
     OneHotActionTensorRepresentationModule,
 )
 from pearl.policy_learners.sequential_decision_making.deep_q_learning import DeepQLearning  # noqa: E402
+from pearl.policy_learners.sequential_decision_making.double_dqn import DoubleDQN  # noqa: E402
 from pearl.replay_buffers import BasicReplayBuffer  # noqa: E402
 from pearl.utils.instantiations.spaces.discrete_action import DiscreteActionSpace  # noqa: E402
 
@@ -44,6 +45,11 @@ CONFIGS = {
     "cfg1_cartpole_shape": dict(S=4, A=2, hidden=[64, 64], N=600, B=128, rounds=12, dynamic=False),
     "cfg2_shape_small_batch": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=12,
                                    dynamic=False),
+    # DoubleDQN (double_dqn.py:29-57): files ddqn_<name>.pt
+    "double_tiny_dynamic": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
+                                learner="double"),
+    "double_cfg2_shape_small_batch": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=12,
+                                          dynamic=False, learner="double"),
 }
 
 
@@ -90,7 +96,8 @@ def make(name, cfg):
 
     rep = OneHotActionTensorRepresentationModule(A)
     torch.manual_seed(7)  # the learner's parameter init
-    pl = DeepQLearning(state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
+    double = cfg.get("learner") == "double"
+    pl = (DoubleDQN if double else DeepQLearning)(state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
                        training_rounds=cfg["rounds"], batch_size=B,
                        action_representation_module=rep)
     rb = BasicReplayBuffer(cfg["N"] + 10)
@@ -150,15 +157,17 @@ def make(name, cfg):
                         ("step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")}
     fx["opt_after"] = opt_state
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, f"dqn_{name}.pt")
+    path = os.path.join(OUT, f"ddqn_{name[len('double_'):]}.pt" if double else f"dqn_{name}.pt")
     torch.save(fx, path)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); "
           f"losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")
 
 
 def main():
+    only = sys.argv[1:]          # optional: names of the configurations to (re)generate
     for name, cfg in CONFIGS.items():
-        make(name, cfg)
+        if not only or name in only:
+            make(name, cfg)
 
 
 if __name__ == "__main__":

@@ -131,7 +131,11 @@ class DqnOracle:
 
     def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor],
                  gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.01, tau: float = 0.75, target_update_freq: int = 10):
+                 weight_decay: float = 0.01, tau: float = 0.75, target_update_freq: int = 10,
+                 double_q: bool = False):
+        # double_q: DoubleDQN.get_next_state_values (double_dqn.py:29-57) instead of
+        # DeepQLearning's (deep_q_learning.py:130-167)
+        self.double_q = bool(double_q)
         self.p = {k: params[k].detach().clone().to(F32) for k in PARAM_KEYS}
         self.t = {k: target[k].detach().clone().to(F32) for k in PARAM_KEYS}
         self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
@@ -158,7 +162,16 @@ class DqnOracle:
     def next_state_values(self, next_state, next_avail_rep, next_mask) -> torch.Tensor:
         B, A, _ = next_avail_rep.shape
         s = next_state.unsqueeze(1).expand(B, A, next_state.shape[1])
-        q = self._mlp(self.t, torch.cat([s, next_avail_rep], dim=-1))[2]  # (B, A)
+        xs = torch.cat([s, next_avail_rep], dim=-1)
+        if self.double_q:
+            # a' = argmax_a Q_online(s', a) over the available actions (double_dqn.py:40-48) ...
+            q = self._mlp(self.p, xs)[2].clone()                   # (B, A)
+            q[next_mask] = -float("inf")
+            choice = q.max(1)[1]
+            # ... valued by the target network (double_dqn.py:49-56)
+            chosen = next_avail_rep[torch.arange(B), choice]         # (B, AD)
+            return self._mlp(self.t, torch.cat([next_state, chosen], dim=-1))[2]
+        q = self._mlp(self.t, xs)[2]  # (B, A)
         q = q.clone()
         q[next_mask] = -float("inf")
         return q.max(1)[0]

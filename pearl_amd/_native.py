@@ -140,6 +140,7 @@ class DqnDesc(C.Structure):
         ("eps", C.c_double),
         ("weight_decay", C.c_double),
         ("amsgrad", C.c_int32),
+        ("double_q", C.c_int32),
     ]
 
 

@@ -46,6 +46,11 @@ struct pa_dqn {
   // workspaces (HBM)
   float *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
   float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
+  // Double DQN only (desc.double_q): the same copy of the ONLINE W2, the chosen next actions, and
+  // the row-per-transition value pass through the target network
+  float* w2f_online;
+  int* choice;
+  float *dbl_x, *dbl_a1, *dbl_a2, *dbl_q;
   float *W1f, *W2f16, *W2tf;  // fragment-major copies of the online weights (online_rowpass_kernel)
   // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
   // learn(): the target-network side of a window (gather -> U -> Bellman targets y) runs on a
@@ -255,10 +260,11 @@ int resolve_x(pa_dqn* h, const pa_dqn_batch* b, const float** x, hipStream_t s) 
   return PA_OK;
 }
 
-GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* U) {
-  // U = s' W1s'^T + b1'   (state columns of the target net's first layer)
+GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* U,
+                           const float* params = nullptr) {
+  // U = s' W1s'^T + b1'   (state columns of the first layer; the target net's unless `params`)
   const pa_dqn_desc& d = h->d;
-  const NetPtrs t = net_ptrs(h, h->bufs.q_target);
+  const NetPtrs t = net_ptrs(h, params ? params : h->bufs.q_target);
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = next_state; g.lda = d.state_dim;
@@ -274,9 +280,11 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* 
 // deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
 // U (= W1s' s' + b1' of the same rows) must already be computed.
 int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
-                       hipStream_t s, bool persistent = false) {
+                       hipStream_t s, bool persistent = false, int* argmax = nullptr) {
+  // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
+  // maximum (Double DQN's action choice); always the classic grid
   const pa_dqn_desc& d = h->d;
-  const NetPtrs t = net_ptrs(h, h->bufs.q_target);
+  const NetPtrs t = net_ptrs(h, argmax ? h->bufs.q : h->bufs.q_target);
   ScopedTimer tm(h, "target", s, 1, 4, b->B);
   TargetArgs a;
   memset(&a, 0, sizeof(a));
@@ -286,7 +294,8 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.mask = b->next_mask;
   a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
   a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
-  a.W2f = h->w2f;
+  a.W2f = argmax ? h->w2f_online : h->w2f;
+  a.argmax = argmax;
   a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
   a.reward = b->reward; a.term = b->terminated;
   a.gamma = d.discount;
@@ -295,7 +304,7 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
-  const bool pp = h->pingpong == 2 || (h->pingpong == 1 && persistent);
+  const bool pp = !argmax && (h->pingpong == 2 || (h->pingpong == 1 && persistent));
   if (persistent || pp) {
     if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream
       PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
@@ -333,6 +342,85 @@ int run_repack(pa_dqn* h, bool online, bool target, hipStream_t s) {
   hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
+}
+
+// Double DQN's next-state values and Bellman targets (double_dqn.py:29-57):
+//   a'_b = argmax over the available next actions of Q_ONLINE(s'_b, .)   (masked -> -inf, first max)
+//   v_b  = Q_TARGET(s'_b, a'_b);   y_b = v_b gamma (1 - term_b) + r_b
+// The all-actions pass is target_fused_kernel on the online parameters (its fragment-major W2 copy
+// is rebuilt here: the online net moves every round); the value pass is ONE row per transition
+// through the generic linear kernel on the row-major target parameters.
+int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  PA_REQUIRE(h->w2f_online && b->B <= d.max_batch, PA_ERR_INVALID,
+             "double-Q pass: learner was not created with double_q, or batch above max_batch");
+  h->y_clean = false;
+  int rc;
+  {
+    RepackArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = h->bufs.q; a.q_target = h->bufs.q;     // "target" slot <- the ONLINE W2
+    a.off_w1 = h->off[0]; a.off_w2 = h->off[2];
+    a.IN = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
+    a.pk = packed(h);
+    a.pk.tW2f = h->w2f_online;
+    a.do_online = 0; a.do_target = 1;
+    hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
+    PA_LAUNCH_CHECK();
+  }
+  {
+    ScopedTimer tm(h, "target_l1", s, 2, 1, b->B);
+    GemmArgs g = target_l1_problem(h, b->next_state, b->B, h->Uw[0], h->bufs.q);
+    rc = launch_linear<false>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+  }
+  rc = run_target_fused_u(h, b, h->Uw[0], nullptr, nullptr, s, false, h->choice);
+  if (rc != PA_OK) return rc;
+  ScopedTimer tm(h, "double_value", s, 2, 1, b->B);
+  {
+    const int64_t total = (int64_t)b->B * h->IN;
+    unsigned grid = (unsigned)(ceil_div(total, 256) > 1024 ? 1024 : ceil_div(total, 256));
+    hipLaunchKernelGGL(pack_choice_kernel, dim3(grid), dim3(256), 0, s, b->next_state,
+                       b->next_avail_rep,
+                       b->next_avail_bcast ? (int64_t)0 : (int64_t)b->A * d.action_dim, h->choice,
+                       h->dbl_x, b->B, d.state_dim, d.action_dim);
+    PA_LAUNCH_CHECK();
+  }
+  const NetPtrs t = net_ptrs(h, h->bufs.q_target);
+  const float* in[3] = {h->dbl_x, h->dbl_a1, h->dbl_a2};
+  float* out[3] = {h->dbl_a1, h->dbl_a2, h->dbl_q};
+  const float* W[3] = {t.W1, t.W2, t.W3};
+  const float* bias[3] = {t.b1, t.b2, t.b3};
+  const int K[3] = {h->IN, d.hidden1, d.hidden2}, Nn[3] = {d.hidden1, d.hidden2, 1};
+  for (int l = 0; l < 3; ++l) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = in[l]; g.lda = K[l];
+    g.Bm = W[l]; g.ldb = K[l];
+    g.C = out[l]; g.ldc = Nn[l];
+    g.bias = bias[l];
+    g.M = b->B; g.N = Nn[l]; g.K = K[l];
+    g.epi = l < 2 ? EPI_BIAS_RELU : EPI_BIAS;
+    rc = launch_linear<false>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+  }
+  hipLaunchKernelGGL(bellman_kernel, dim3((unsigned)ceil_div(b->B, 256)), dim3(256), 0, s, h->dbl_q,
+                     b->reward, b->terminated, d.discount, next_v, y, b->B);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+// max_a' Q_target(s', a') (DeepQLearning) or Q_target(s', argmax_a' Q(s', a')) (DoubleDQN) and the
+// Bellman targets of one batch, U computed here.
+int run_next_values(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+  if (h->d.double_q) return run_double_targets(h, b, next_v, y, s);
+  {
+    ScopedTimer tm(h, "target_l1", s);
+    GemmArgs g = target_l1_problem(h, b->next_state, b->B, h->Uw[0]);
+    int rc = launch_linear<false>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+  }
+  return run_target_fused(h, b, next_v, y, s);
 }
 
 // Forward (+ loss + backward to dZ2 / dZ1 when y is given) of the online network.
@@ -531,13 +619,7 @@ int step_impl(pa_dqn* h, const pa_dqn_batch* batch, int do_target_update, int64_
   const float* x = nullptr;
   rc = resolve_x(h, batch, &x, s);
   if (rc != PA_OK) return rc;
-  {
-    ScopedTimer tm(h, "target_l1", s);
-    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B, h->Uw[0]);
-    rc = launch_linear<false>(&g, 1, s);
-    if (rc != PA_OK) return rc;
-  }
-  rc = run_target_fused(h, batch, h->nextv, h->yw[0], s);
+  rc = run_next_values(h, batch, h->nextv, h->yw[0], s);
   if (rc != PA_OK) return rc;
   return online_chain(h, x, batch->B, h->yw[0], false, adam_step, grad_world, loss_out, 0, s);
 }
@@ -721,6 +803,8 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->tick = 0;
   h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->nextv = h->qbuf = h->dq = h->absd =
       h->xpack = h->loss_scratch = h->w2f = h->W1f = h->W2f16 = h->W2tf = nullptr;
+  h->w2f_online = h->dbl_x = h->dbl_a1 = h->dbl_a2 = h->dbl_q = nullptr;
+  h->choice = nullptr;
   h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
   h->bb_x = nullptr;
   h->side = nullptr;
@@ -792,6 +876,14 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
+  if (desc->double_q) {
+    PA_WS(h->w2f_online, w2f_floats(desc->hidden2, desc->hidden1));
+    PA_WS(h->choice, B);
+    PA_WS(h->dbl_x, B * h->IN);
+    PA_WS(h->dbl_a1, B * desc->hidden1);
+    PA_WS(h->dbl_a2, B * desc->hidden2);
+    PA_WS(h->dbl_q, B);
+  }
 #undef PA_WS
   *out = h;
   return PA_OK;
@@ -803,7 +895,8 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
-                  h->W2f16, h->W2tf, h->err_dev, h->reserved_dev, h->tile_ctr};
+                  h->W2f16, h->W2tf, h->err_dev, h->reserved_dev, h->tile_ctr, h->w2f_online,
+                  h->choice, h->dbl_x, h->dbl_a1, h->dbl_a2, h->dbl_q};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->err_host) (void)hipHostFree(h->err_host);
@@ -842,10 +935,7 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
   rc = run_repack(h, q_out != nullptr, next_v_out || target_out, s);
   if (rc != PA_OK) return rc;
   if (next_v_out || target_out) {
-    GemmArgs g = target_l1_problem(h, batch->next_state, batch->B, h->Uw[0]);
-    rc = launch_linear<false>(&g, 1, s);
-    if (rc != PA_OK) return rc;
-    rc = run_target_fused(h, batch, next_v_out, target_out, s);
+    rc = run_next_values(h, batch, next_v_out, target_out, s);
     if (rc != PA_OK) return rc;
   }
   if (q_out) {
@@ -919,7 +1009,11 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // computed on the CUs the chain leaves idle.  Stream-level ordering (events) is only needed
   // once per window: the next window's target pass must see the soft update that the last chain
   // of this window performs.  Bit-identical to the single-stream loop (same kernels, same data).
-  const bool overlap = h->overlap && h->timing < 2;
+  // Double DQN chooses the next action with the ONLINE network, which moves every round: no
+  // window batching and nothing to overlap — each round's targets need the previous round's step.
+  const bool dbl = d.double_q != 0;
+  const bool overlap = h->overlap && h->timing < 2 && !dbl;
+  const int wcap = dbl ? 1 : h->wcap;
   rc = ensure_side(h);
   if (rc != PA_OK) return rc;
   // fresh work-stealing counters for this call's persistent target launches
@@ -975,7 +1069,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   int r = 0, k = 0;
   while (r < R) {
     int w = 1;
-    while (r + w < R && w < h->wcap && !due(r + w)) ++w;
+    while (r + w < R && w < wcap && !due(r + w)) ++w;
     const int rows = w * B;
     const int p = k & 1;
     const pa_dqn::BatchBuf& bb = h->bb[p];
@@ -1032,6 +1126,12 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       b.next_avail_rep = bb.next_avail_rep + row0 * A * d.action_dim;
       b.next_mask = bb.next_mask + row0 * A;
       float* Up = h->Uw[p] + row0 * d.hidden1;
+      if (dbl) {
+        rc = run_double_targets(h, &b, nullptr, h->yw[p] + row0, t);
+        if (rc != PA_OK) return rc;
+        j0 += nj;
+        continue;
+      }
       {
         ScopedTimer tm(h, "target_l1", t, 2, 1, prow);
         GemmArgs g = target_l1_problem(h, b.next_state, prow, Up);

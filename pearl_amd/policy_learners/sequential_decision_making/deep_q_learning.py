@@ -98,6 +98,10 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
 
 
 class DeepQLearning(PolicyLearner):
+    # How the next state is valued (pa_dqn_desc.double_q): False = max over the available next
+    # actions of Q_target (deep_q_learning.py:130-167); True = DoubleDQN's rule (double_dqn.py:29-57)
+    _double_q: bool = False
+
     def __init__(self, action_space: Any = None, hidden_dims: Optional[List[int]] = None,
                  exploration_module: Optional[ExplorationModule] = None,
                  learning_rate: float = 0.001, discount_factor: float = 0.99,
@@ -218,7 +222,7 @@ class DeepQLearning(PolicyLearner):
         opt = self._optimizer.param_groups[0]
         desc_key = (dev.index, S, AD, H1, H2, max_b, max_a, self._discount_factor,
                     self._soft_update_tau, opt["lr"], tuple(opt["betas"]), opt["eps"],
-                    opt["weight_decay"], bool(opt["amsgrad"]))
+                    opt["weight_decay"], bool(opt["amsgrad"]), bool(self._double_q))
         if nat.handle is not None and nat.desc_key != desc_key:
             torch.cuda.synchronize(dev)
             nat.close()
@@ -227,7 +231,8 @@ class DeepQLearning(PolicyLearner):
                              max_batch=max_b, max_actions=max_a, discount=self._discount_factor,
                              tau=self._soft_update_tau, lr=opt["lr"], beta1=opt["betas"][0],
                              beta2=opt["betas"][1], eps=opt["eps"],
-                             weight_decay=opt["weight_decay"], amsgrad=int(opt["amsgrad"]))
+                             weight_decay=opt["weight_decay"], amsgrad=int(opt["amsgrad"]),
+                             double_q=int(bool(self._double_q)))
             handle = C.c_void_p()
             N.check(N.lib().pa_dqn_create(C.byref(handle), C.byref(desc)))
             nat.handle, nat.desc_key, nat.sig = handle, desc_key, ()
@@ -331,7 +336,8 @@ class DeepQLearning(PolicyLearner):
 
     @torch.no_grad()
     def get_next_state_values(self, batch: TransitionBatch, batch_size: int) -> torch.Tensor:
-        """max over available next actions of Q_target(s', a') (deep_q_learning.py:130-167)."""
+        """max over available next actions of Q_target(s', a') (deep_q_learning.py:130-167); for
+        DoubleDQN, Q_target(s', argmax_a' Q(s', a')) (double_dqn.py:29-57)."""
         nb, keep = self._native_batch(batch)
         nat = self._ensure_bound(nb.B, nb.A)
         v = torch.empty(nb.B, dtype=torch.float32, device=keep[0].device)

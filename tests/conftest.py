@@ -35,9 +35,13 @@ def golden():
     import torch
 
     def load(name):
-        return torch.load(os.path.join(GOLDEN_DIR, f"dqn_{name}.pt"), map_location="cpu",
+        # "double:<name>" -> the DoubleDQN fixture ddqn_<name>.pt (config["learner"] == "double")
+        stem = f"ddqn_{name[len('double:'):]}" if name.startswith("double:") else f"dqn_{name}"
+        return torch.load(os.path.join(GOLDEN_DIR, f"{stem}.pt"), map_location="cpu",
                           weights_only=False)
     return load
 
 
-GOLDEN_NAMES = ["tiny", "tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch"]
+DQN_NAMES = ["tiny", "tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch"]
+DOUBLE_NAMES = ["double:tiny_dynamic", "double:cfg2_shape_small_batch"]
+GOLDEN_NAMES = DQN_NAMES + DOUBLE_NAMES

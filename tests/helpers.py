@@ -15,7 +15,8 @@ def fill_oracle_replay(fx) -> ReplayOracle:
 
 
 def oracle_learner(fx) -> DqnOracle:
-    return DqnOracle(fx["params0"], fx["target0"])
+    return DqnOracle(fx["params0"], fx["target0"],
+                     double_q=fx["config"].get("learner") == "double")
 
 
 def batch_pre_as_oracle_dict(fx):

@@ -23,13 +23,14 @@ DEV = "cuda:0"
 
 
 def make_learner(fx, **kw):
-    from pearl_amd import DeepQLearning, OneHotActionTensorRepresentationModule
+    from pearl_amd import DeepQLearning, DoubleDQN, OneHotActionTensorRepresentationModule
     cfg = fx["config"]
+    cls = DoubleDQN if cfg.get("learner") == "double" else DeepQLearning
     args = dict(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
                 training_rounds=cfg["rounds"], batch_size=cfg["B"],
                 action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
     args.update(kw)
-    pl = DeepQLearning(**args)
+    pl = cls(**args)
     pl._Q.load_state_dict(fx["params0"])
     pl._Q_target.load_state_dict(fx["target0"])
     return pl.to(DEV)
@@ -109,7 +110,8 @@ def test_learn_trajectory_python_sampler(golden, name):
     assert random.getstate() == after
 
 
-@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch"])
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch",
+                                  "double:tiny_dynamic", "double:cfg2_shape_small_batch"])
 def test_generic_loop_equals_fused_loop(golden, name):
     """sample() + preprocess_batch() + learn_batch() (API path, per-step .item()) and the fused
     pa_dqn_learn path are the same computation: bitwise-equal parameters."""
@@ -128,7 +130,8 @@ def test_generic_loop_equals_fused_loop(golden, name):
         assert torch.equal(pa, pb), k
 
 
-@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg2_shape_small_batch"])
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg2_shape_small_batch",
+                                  "double:cfg2_shape_small_batch"])
 def test_data_parallel_loop_with_one_rank_equals_fused_loop(golden, name):
     """The data-parallel form of pa_dqn_learn (gradient split at the all-reduce hooks, per-round
     target launches, stand-alone adamw_dqn_kernel) with world = 1 is the same computation as the
@@ -205,15 +208,19 @@ def test_device_sampler_learn_matches_oracle(golden):
         torch.testing.assert_close(pl._Q_target.state_dict()[k].cpu(), orc.t[k], rtol=1e-3, atol=2e-5, msg=k)
 
 
-def test_masked_actions_and_terminal_rows(golden):
+@pytest.mark.parametrize("name", ["tiny_dynamic", "double:tiny_dynamic"])
+def test_masked_actions_and_terminal_rows(golden, name):
     """-inf masking (deep_q_learning.py:164) and the (1 - terminated) factor: all-but-one action
     masked forces the max; terminated rows reduce the target to the reward."""
-    fx = golden("tiny_dynamic")
+    fx = golden(name)
     pl = make_learner(fx)
     b = batch_from(fx, "batch_pre")
     B, A = b.next_unavailable_actions_mask.shape
     b.next_unavailable_actions_mask = torch.ones(B, A, dtype=torch.bool, device=DEV)
     b.next_unavailable_actions_mask[:, 2] = False
+    # a row with NO available next action: max = -inf for DeepQLearning; DoubleDQN's argmax of an
+    # all -inf row is index 0 (torch.max(1)[1]), valued by the target net — finite
+    b.next_unavailable_actions_mask[1, :] = True
     b.terminated = torch.arange(B, device=DEV) % 2 == 0
     out = pl.q_values_and_targets(b)
     orc = oracle_learner(fx)
@@ -225,6 +232,55 @@ def test_masked_actions_and_terminal_rows(golden):
         rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(out["target"].cpu(), orc.bellman_target(d), rtol=1e-5, atol=1e-6)
     assert torch.equal(out["target"].cpu()[0::2], d["reward"][0::2])
+    assert bool(torch.isfinite(out["next_v"][1])) == (fx["config"].get("learner") == "double")
+
+
+def test_double_dqn_differs_from_dqn_and_full_size_learn():
+    """DoubleDQN at BASELINE config-2 size against the CPU oracle on one batch (next-state values
+    and Bellman targets within 1e-5), and a fused learn() that stays finite and moves the target
+    network; the rule really differs from DeepQLearning's max on the same parameters."""
+    from pearl_amd import (BasicReplayBuffer, DeepQLearning, DoubleDQN,
+                           OneHotActionTensorRepresentationModule, PearlAgent)
+    S, A, B, n = 128, 16, 1024, 20_000
+    torch.manual_seed(5)
+    random.seed(5)
+    mk = lambda cls: cls(state_dim=S, action_space=_space(A), hidden_dims=[256, 256],
+                         training_rounds=25, batch_size=B,
+                         action_representation_module=OneHotActionTensorRepresentationModule(A))
+    dd = mk(DoubleDQN)
+    dq = mk(DeepQLearning)
+    dq._Q.load_state_dict(dd._Q.state_dict())
+    # make the target differ from the online net so the two rules disagree
+    with torch.no_grad():
+        for p in dd._Q_target.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    dq._Q_target.load_state_dict(dd._Q_target.state_dict())
+    rb = BasicReplayBuffer(n, sampler="device")
+    agent = PearlAgent(dd, replay_buffer=rb, device_id=0)
+    dq = dq.to(DEV)
+    st = torch.randn(n + 1, S, device=DEV)
+    ids = torch.arange(n, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(n, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=_space(A),
+                 next_available_actions=_space(A), max_number_actions=A)
+    batch = dd.preprocess_batch(rb.sample(B))
+    got = dd.q_values_and_targets(batch)
+    other = dq.q_values_and_targets(batch)
+    orc = O.DqnOracle({k: v.cpu() for k, v in dd._Q.state_dict().items()},
+                      {k: v.cpu() for k, v in dd._Q_target.state_dict().items()}, double_q=True)
+    want = orc.next_state_values(batch.next_state.cpu(), torch.eye(A).expand(B, A, A),
+                                 torch.zeros(B, A, dtype=torch.bool))
+    torch.testing.assert_close(got["next_v"].cpu(), want, rtol=1e-5, atol=1e-6)
+    assert torch.equal(got["q"], other["q"])
+    assert (got["next_v"] <= other["next_v"] + 1e-6).all()      # max >= any choice
+    assert (got["next_v"] < other["next_v"] - 1e-4).any()
+    before = {k: v.clone() for k, v in dd._Q_target.state_dict().items()}
+    report = agent.learn()
+    assert len(report["loss"]) == 25 and all(np.isfinite(report["loss"]))
+    assert any(not torch.equal(v, before[k]) for k, v in dd._Q_target.state_dict().items())
+    for v in dd._Q.state_dict().values():
+        assert torch.isfinite(v).all()
 
 
 def test_default_next_actions_when_batch_has_none(golden):
