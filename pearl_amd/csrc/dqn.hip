@@ -50,7 +50,7 @@ struct pa_dqn {
   // the row-per-transition value pass through the target network
   float* w2f_online;
   int* choice;
-  float *dbl_x, *dbl_a1, *dbl_a2, *dbl_q;
+  float* choice_rep;   // [max_batch][AD] representation of the chosen next action
   float *W1f, *W2f16, *W2tf;  // fragment-major copies of the online weights (online_rowpass_kernel)
   // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
   // learn(): the target-network side of a window (gather -> U -> Bellman targets y) runs on a
@@ -296,6 +296,7 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
   a.W2f = argmax ? h->w2f_online : h->w2f;
   a.argmax = argmax;
+  a.choice_rep = argmax ? h->choice_rep : nullptr;
   a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
   a.reward = b->reward; a.term = b->terminated;
   a.gamma = d.discount;
@@ -347,9 +348,11 @@ int run_repack(pa_dqn* h, bool online, bool target, hipStream_t s) {
 // Double DQN's next-state values and Bellman targets (double_dqn.py:29-57):
 //   a'_b = argmax over the available next actions of Q_ONLINE(s'_b, .)   (masked -> -inf, first max)
 //   v_b  = Q_TARGET(s'_b, a'_b);   y_b = v_b gamma (1 - term_b) + r_b
-// The all-actions pass is target_fused_kernel on the online parameters (its fragment-major W2 copy
-// is rebuilt here: the online net moves every round); the value pass is ONE row per transition
-// through the generic linear kernel on the row-major target parameters.
+// Both passes are target_fused_kernel: first on the ONLINE parameters over all A actions, reporting
+// each row's first maximum and the representation of that action (its fragment-major W2 copy is
+// rebuilt here: the online net moves every round); then on the target parameters with ONE action
+// per transition — the chosen one — whose "row max" is the value and whose epilogue writes y.
+// The two first-layer state products (same s', two parameter sets) share one launch.
 int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   PA_REQUIRE(h->w2f_online && b->B <= d.max_batch, PA_ERR_INVALID,
@@ -370,44 +373,19 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
   }
   {
     ScopedTimer tm(h, "target_l1", s, 2, 1, b->B);
-    GemmArgs g = target_l1_problem(h, b->next_state, b->B, h->Uw[0], h->bufs.q);
-    rc = launch_linear<false>(&g, 1, s);
+    GemmArgs g[2] = {target_l1_problem(h, b->next_state, b->B, h->Uw[0], h->bufs.q),
+                     target_l1_problem(h, b->next_state, b->B, h->Uw[1])};
+    rc = launch_linear<false>(g, 2, s);
     if (rc != PA_OK) return rc;
   }
   rc = run_target_fused_u(h, b, h->Uw[0], nullptr, nullptr, s, false, h->choice);
   if (rc != PA_OK) return rc;
-  ScopedTimer tm(h, "double_value", s, 2, 1, b->B);
-  {
-    const int64_t total = (int64_t)b->B * h->IN;
-    unsigned grid = (unsigned)(ceil_div(total, 256) > 1024 ? 1024 : ceil_div(total, 256));
-    hipLaunchKernelGGL(pack_choice_kernel, dim3(grid), dim3(256), 0, s, b->next_state,
-                       b->next_avail_rep,
-                       b->next_avail_bcast ? (int64_t)0 : (int64_t)b->A * d.action_dim, h->choice,
-                       h->dbl_x, b->B, d.state_dim, d.action_dim);
-    PA_LAUNCH_CHECK();
-  }
-  const NetPtrs t = net_ptrs(h, h->bufs.q_target);
-  const float* in[3] = {h->dbl_x, h->dbl_a1, h->dbl_a2};
-  float* out[3] = {h->dbl_a1, h->dbl_a2, h->dbl_q};
-  const float* W[3] = {t.W1, t.W2, t.W3};
-  const float* bias[3] = {t.b1, t.b2, t.b3};
-  const int K[3] = {h->IN, d.hidden1, d.hidden2}, Nn[3] = {d.hidden1, d.hidden2, 1};
-  for (int l = 0; l < 3; ++l) {
-    GemmArgs g;
-    memset(&g, 0, sizeof(g));
-    g.A = in[l]; g.lda = K[l];
-    g.Bm = W[l]; g.ldb = K[l];
-    g.C = out[l]; g.ldc = Nn[l];
-    g.bias = bias[l];
-    g.M = b->B; g.N = Nn[l]; g.K = K[l];
-    g.epi = l < 2 ? EPI_BIAS_RELU : EPI_BIAS;
-    rc = launch_linear<false>(&g, 1, s);
-    if (rc != PA_OK) return rc;
-  }
-  hipLaunchKernelGGL(bellman_kernel, dim3((unsigned)ceil_div(b->B, 256)), dim3(256), 0, s, h->dbl_q,
-                     b->reward, b->terminated, d.discount, next_v, y, b->B);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
+  pa_dqn_batch one = *b;
+  one.A = 1;
+  one.next_avail_rep = h->choice_rep;
+  one.next_avail_bcast = 0;
+  one.next_mask = nullptr;
+  return run_target_fused_u(h, &one, h->Uw[1], next_v, y, s);
 }
 
 // max_a' Q_target(s', a') (DeepQLearning) or Q_target(s', argmax_a' Q(s', a')) (DoubleDQN) and the
@@ -803,7 +781,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->tick = 0;
   h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->nextv = h->qbuf = h->dq = h->absd =
       h->xpack = h->loss_scratch = h->w2f = h->W1f = h->W2f16 = h->W2tf = nullptr;
-  h->w2f_online = h->dbl_x = h->dbl_a1 = h->dbl_a2 = h->dbl_q = nullptr;
+  h->w2f_online = h->choice_rep = nullptr;
   h->choice = nullptr;
   h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
   h->bb_x = nullptr;
@@ -879,10 +857,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   if (desc->double_q) {
     PA_WS(h->w2f_online, w2f_floats(desc->hidden2, desc->hidden1));
     PA_WS(h->choice, B);
-    PA_WS(h->dbl_x, B * h->IN);
-    PA_WS(h->dbl_a1, B * desc->hidden1);
-    PA_WS(h->dbl_a2, B * desc->hidden2);
-    PA_WS(h->dbl_q, B);
+    PA_WS(h->choice_rep, B * desc->action_dim);
   }
 #undef PA_WS
   *out = h;
@@ -896,7 +871,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
                   h->W2f16, h->W2tf, h->err_dev, h->reserved_dev, h->tile_ctr, h->w2f_online,
-                  h->choice, h->dbl_x, h->dbl_a1, h->dbl_a2, h->dbl_q};
+                  h->choice, h->choice_rep};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->err_host) (void)hipHostFree(h->err_host);

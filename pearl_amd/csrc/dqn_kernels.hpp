@@ -328,6 +328,7 @@ struct TargetArgs {
   long long* prof;           // optional phase stamps [tile][wave][16] (tools/prof_chain.py)
   int* argmax;               // optional [B]: index of the FIRST row maximum (torch.max(1)[1];
                              // Double DQN's action choice, double_dqn.py:47)
+  float* choice_rep;         // with argmax: [B][AD] = feat row of that action (double_dqn.py:48-51)
 };
 
 // (XCC_ID, HW_ID.se_id|sh_id|cu_id) of the compute unit the calling wave runs on
@@ -618,7 +619,13 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
       m = take ? x : m;
       mi = take ? i : mi;
     }
-    if (a.argmax) a.argmax[bb] = mi;
+    if (a.argmax) {
+      a.argmax[bb] = mi;
+      if (a.choice_rep) {
+        const float* src = a.feat + (int64_t)bb * a.feat_bstride + (int64_t)mi * a.AD;
+        for (int j = 0; j < a.AD; ++j) a.choice_rep[(int64_t)bb * a.AD + j] = src[j];
+      }
+    }
     if (a.next_v) a.next_v[bb] = m;
     if (a.y) {
       // (next_v * gamma * (1 - terminated.float())) + reward, one rounding per op
@@ -1286,39 +1293,6 @@ static __global__ __launch_bounds__(256) void pack_x_kernel(const float* __restr
     const int64_t b = e / W;
     const int j = (int)(e - b * W);
     x[e] = (j < S) ? state[b * S + j] : arep[b * AD + (j - S)];
-  }
-}
-
-// Double DQN (double_dqn.py:48-55): x'[b] = next_state[b] || rep(next_available_actions[b, choice[b]])
-static __global__ __launch_bounds__(256) void pack_choice_kernel(
-    const float* __restrict__ next_state, const float* __restrict__ rep, int64_t rep_bstride,
-    const int* __restrict__ choice, float* __restrict__ x, int B, int S, int AD) {
-  const int W = S + AD;
-  const int64_t total = (int64_t)B * W;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * 256) {
-    const int64_t b = e / W;
-    const int j = (int)(e - b * W);
-    x[e] = (j < S) ? next_state[b * S + j]
-                   : rep[b * rep_bstride + (int64_t)choice[b] * AD + (j - S)];
-  }
-}
-
-// y = (next_v * gamma * (1 - terminated.float())) + reward, one rounding per op
-// (deep_td_learning.py:313-317) for next-state values that were computed elsewhere
-static __global__ __launch_bounds__(256) void bellman_kernel(const float* __restrict__ v,
-                                                      const float* __restrict__ reward,
-                                                      const uint8_t* __restrict__ term, float gamma,
-                                                      float* next_v, float* y, int B) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= B) return;
-  const float m = v[b];
-  if (next_v) next_v[b] = m;
-  if (y) {
-    const float live = 1.0f - (term[b] ? 1.0f : 0.0f);
-    const float t0 = __fmul_rn(m, gamma);
-    const float t1 = __fmul_rn(t0, live);
-    y[b] = __fadd_rn(t1, reward[b]);
   }
 }
 
