@@ -103,6 +103,31 @@ class PearlAgent(torch.nn.Module):
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         return self.policy_learner.learn_batch(self.policy_learner.preprocess_batch(batch))
 
+    # -- full-job checkpoint ---------------------------------------
+    def checkpoint(self) -> Dict[str, Any]:
+        """``agent.state_dict()`` (the reference's README.md:23-46 flow) plus what that flow leaves
+        out and an exact resume needs: the value-based learners' AdamW state (the reference's
+        ``DeepTDLearning`` does not serialise its optimizer), the learner's step counter (it times
+        the target-network updates, deep_td_learning.py:283-284) and the replay buffer's contents.
+        ``torch.save``-able; everything is copied to the CPU."""
+        pl = self.policy_learner
+        opt = getattr(pl, "_optimizer", None)
+        cpu = lambda o: torch.utils._pytree.tree_map(
+            lambda v: v.detach().cpu().clone() if isinstance(v, torch.Tensor) else v, o)
+        return {"agent": cpu(self.state_dict()),
+                "optimizer": None if opt is None else cpu(opt.state_dict()),
+                "training_steps": int(pl._training_steps),
+                "replay_buffer": self.replay_buffer.state_dict()}
+
+    def restore(self, ckpt: Dict[str, Any]) -> None:
+        self.load_state_dict(ckpt["agent"])
+        pl = self.policy_learner
+        if ckpt.get("optimizer") is not None:
+            pl._optimizer.load_state_dict(ckpt["optimizer"])
+        pl._training_steps = int(ckpt["training_steps"])
+        self.replay_buffer.load_state_dict(ckpt["replay_buffer"])
+        self.replay_buffer._is_action_continuous = pl._is_action_continuous
+
     def reset(self, observation: Any, available_action_space: Any) -> None:
         self._latest_action = None
         self._subjective_state = observation

@@ -20,7 +20,7 @@ different (equally uniform) stream.
 from __future__ import annotations
 
 import random
-from typing import Any, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import numpy as np
 import torch
@@ -287,6 +287,95 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         if on_device:
             # the source columns must outlive the enqueued scatter kernel
             torch.cuda.current_stream(dev).synchronize()
+
+    # -- checkpoint / resume (the reference does not checkpoint its buffer) --
+    _CKPT_CHUNK = 262_144   # rows per gather / scatter launch (bounds the device temporaries)
+
+    def state_dict(self) -> Dict[str, Any]:
+        """Everything stored, oldest transition first, as CPU tensors (``torch.save``-able):
+        the columns ``sample()`` returns — state, action, reward, terminated, truncated, next_state,
+        per-row available-action tables and masks, cost — plus the layout.  The FIFO position is
+        implicit: ``load_state_dict`` re-inserts the rows in the same logical order."""
+        n = len(self)
+        sd: Dict[str, Any] = {"capacity": self.capacity, "size": n,
+                              "is_action_continuous": bool(self._is_action_continuous),
+                              "has_curr_avail": self._has_curr_avail,
+                              "has_next_avail": self._has_next_avail, "layout": None,
+                              "columns": {}}
+        if self._arena is None or self._layout is None:
+            return sd
+        z = self._layout
+        sd["layout"] = dict(state_shape=tuple(z.state_shape), action_shape=tuple(z.action_shape),
+                            action_dtype=z.action_dtype, reward_dtype=z.reward_dtype,
+                            max_actions=z.max_actions, avail_dim=z.avail_dim,
+                            has_next_state=z.has_next_state, has_cost=z.has_cost)
+        names = ("state", "action", "reward", "terminated", "truncated", "next_state",
+                 "curr_available_actions", "curr_unavailable_actions_mask",
+                 "next_available_actions", "next_unavailable_actions_mask", "cost")
+        parts: Dict[str, list] = {k: [] for k in names}
+        keep_idx, keep_dev = self._last_idx, self._device_for_batches
+        self._device_for_batches = self._arena.device
+        try:
+            for lo in range(0, n, self._CKPT_CHUNK):
+                hi = min(n, lo + self._CKPT_CHUNK)
+                b = self._gather_batch(torch.arange(lo, hi, device=self._arena.device))
+                for k in names:
+                    v = getattr(b, k)
+                    if v is not None:
+                        parts[k].append(v.cpu())
+        finally:
+            self._last_idx, self._device_for_batches = keep_idx, keep_dev
+        sd["columns"] = {k: torch.cat(v) for k, v in parts.items() if v}
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        """Replace the contents with a ``state_dict()``.  A smaller capacity keeps the newest
+        rows, exactly as pushing them one by one would."""
+        self.clear()
+        self._is_action_continuous = bool(sd["is_action_continuous"])
+        if sd["layout"] is None or sd["size"] == 0:
+            return
+        layout = ArenaLayout(**sd["layout"])
+        if self._arena is None:
+            self._has_curr_avail, self._has_next_avail = sd["has_curr_avail"], sd["has_next_avail"]
+        else:
+            assert (self._has_curr_avail, self._has_next_avail) == \
+                (sd["has_curr_avail"], sd["has_next_avail"]), "available-action columns differ"
+        self._ensure_arena(layout)
+        c, n = sd["columns"], int(sd["size"])
+        A = layout.max_actions
+        for lo in range(0, n, self._CKPT_CHUNK):
+            hi = min(n, lo + self._CKPT_CHUNK)
+
+            def col(name: str, dtype: Optional[torch.dtype] = None) -> Optional[Tensor]:
+                v = c.get(name)
+                if v is None:
+                    return None
+                v = v[lo:hi]
+                return v.to(dtype if dtype is not None else v.dtype).contiguous()
+
+            keep = [col("state", torch.float32), col("action"), col("reward"),
+                    col("terminated", torch.uint8), col("truncated", torch.uint8),
+                    col("next_state", torch.float32), col("cost", torch.float32)]
+            cols = N.Columns()
+            cols.state, cols.action, cols.reward = N.ptr(keep[0]), N.ptr(keep[1]), N.ptr(keep[2])
+            cols.terminated, cols.truncated = N.ptr(keep[3]), N.ptr(keep[4])
+            cols.next_state, cols.cost = N.ptr(keep[5]), N.ptr(keep[6])
+            if A:
+                zeros_a = torch.zeros(hi - lo, A, layout.avail_dim, dtype=torch.float32)
+                zeros_m = torch.zeros(hi - lo, A, dtype=torch.uint8)
+                tabs = [col("curr_available_actions", torch.float32),
+                        col("curr_unavailable_actions_mask", torch.uint8),
+                        col("next_available_actions", torch.float32),
+                        col("next_unavailable_actions_mask", torch.uint8)]
+                tabs = [t if t is not None else (zeros_a if i % 2 == 0 else zeros_m)
+                        for i, t in enumerate(tabs)]
+                keep.extend(tabs)
+                cols.curr_avail, cols.curr_mask = tabs[0].data_ptr(), tabs[1].data_ptr()
+                cols.next_avail, cols.next_mask = tabs[2].data_ptr(), tabs[3].data_ptr()
+                cols.avail_bcast = 0
+            self._arena.push_columns(hi - lo, cols, False)
+        self._arena.flush()
 
     # -- sample ----------------------------------------------------------------
     def _draw_host_indices(self, batch_size: int) -> np.ndarray:

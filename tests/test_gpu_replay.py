@@ -182,3 +182,61 @@ def test_full_size_gather_properties():
                        torch.arange(A).float().view(1, A, 1).expand(B, A, 1))
     assert not batch.next_unavailable_actions_mask.any()
     assert idx.unique().numel() == B
+
+
+FIELDS = ("state", "action", "reward", "terminated", "truncated", "next_state",
+          "curr_available_actions", "curr_unavailable_actions_mask", "next_available_actions",
+          "next_unavailable_actions_mask")
+
+
+def _same_batches(rb_a, rb_b, n, seed=3):
+    random.seed(seed)
+    a = rb_a.sample(n)
+    random.seed(seed)
+    b = rb_b.sample(n)
+    for k in FIELDS:
+        x, y = getattr(a, k), getattr(b, k)
+        assert (x is None) == (y is None), k
+        if x is not None:
+            assert x.dtype == y.dtype and torch.equal(x, y), k
+
+
+@pytest.mark.parametrize("capacity", [None, 29])
+def test_replay_buffer_state_dict_round_trip(golden, capacity, tmp_path):
+    """Arena checkpoint: state_dict -> torch.save -> torch.load ->
+    load_state_dict into a fresh buffer reproduces every stored row in FIFO order — also after
+    the ring wrapped (capacity 29 < 48 pushes) and with per-row (dynamic) action tables; a smaller
+    destination keeps the newest rows like a deque(maxlen)."""
+    from pearl_amd import BasicReplayBuffer
+    fx = golden("tiny_dynamic")
+    src = fill_arena_buffer(fx, "python", staging_rows=5, capacity=capacity)
+    path = tmp_path / "rb.pt"
+    torch.save(src.state_dict(), path)
+    sd = torch.load(path, weights_only=False)
+    assert sd["size"] == len(src) and all(not v.is_cuda for v in sd["columns"].values())
+    dst = BasicReplayBuffer(src.capacity, sampler="python")
+    dst.device_for_batches = torch.device("cuda:0")
+    dst.load_state_dict(sd)
+    assert len(dst) == len(src)
+    _same_batches(src, dst, len(src))
+    # keeps working as a FIFO after the restore
+    for rb in (src, dst):
+        rb.push(state=fx["states"][0], action=torch.tensor([1]), reward=2.5, terminated=True,
+                truncated=False, curr_available_actions=_space(2), next_state=fx["states"][1],
+                next_available_actions=_space(3), max_number_actions=fx["config"]["A"])
+    _same_batches(src, dst, len(src), seed=9)
+    # a smaller destination keeps the newest rows
+    small = BasicReplayBuffer(11, sampler="python")
+    small.device_for_batches = torch.device("cuda:0")
+    small.load_state_dict(src.state_dict())
+    assert len(small) == 11
+    ref = BasicReplayBuffer(11, sampler="python")
+    ref.device_for_batches = torch.device("cuda:0")
+    sd2 = src.state_dict()
+    keep = {k: v[-11:] for k, v in sd2["columns"].items()}
+    ref.load_state_dict({**sd2, "size": 11, "columns": keep})
+    _same_batches(small, ref, 11)
+    # an empty buffer round-trips too
+    empty = BasicReplayBuffer(5)
+    empty.load_state_dict(BasicReplayBuffer(5).state_dict())
+    assert len(empty) == 0
