@@ -165,6 +165,12 @@ int pa_arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B,
 /* Only the index draw of pa_arena_sample (for tests of the sampler). */
 int pa_sample_indices(int64_t population, uint64_t seed, uint64_t offset, int32_t B,
                       int64_t* idx_out_dev, int32_t device, void* stream);
+/* The index lists of `rounds` successive sample(B) calls in ONE launch (one workgroup per list):
+ * list r = pa_sample_indices(population, seed, offset0 + r, B) at idx_out_dev + r * B.  What
+ * PolicyLearner.learn (policy_learner.py:162-195) needs for its whole loop; pa_dqn_learn draws its
+ * lists the same way. */
+int pa_sample_indices_rounds(int64_t population, uint64_t seed, uint64_t offset0, int32_t B,
+                             int32_t rounds, int64_t* idx_out_dev, int32_t device, void* stream);
 
 /* out[b] = src[idx[b]] for rows of row_bytes bytes: per-transition columns kept beside the arena in
  * logical order (PPOTransition's gae / lam_return / action_probs, ppo.py:47-82). */
@@ -371,9 +377,10 @@ int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int3
 /* autograd of the kept forward: dW/db into bufs.grad (want_dw) and/or d_x[B, d_0] (nullable). */
 int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
                     int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx, void* stream);
-/* Two networks of the same shape in lock-step (TwinCritic, twin_critic.py:22-91): the same
- * arithmetic as two pa_mlp_forward / pa_mlp_backward calls, with every layer of both networks in
- * one launch.  Both read the same input x; d_x1 / d_x2 are both given or both NULL. */
+/* Two networks of the same depth on the same input in lock-step (TwinCritic, twin_critic.py:22-91;
+ * PPO's actor and critic): the same arithmetic as two pa_mlp_forward / pa_mlp_backward calls, with
+ * every layer of both networks in one launch.  Layer widths may differ.  d_x1 / d_x2 are both
+ * given or both NULL. */
 int pa_mlp_forward2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const float* x, int32_t ldx,
                     int32_t B, float* out1, int32_t ldo1, float* out2, int32_t ldo2, int32_t keep,
                     void* stream);

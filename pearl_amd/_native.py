@@ -246,6 +246,8 @@ SIGNATURES = {
     "pa_arena_gather_device": (C.c_int, [_P, _P, C.c_int32, C.POINTER(BatchOut), _P]),
     "pa_arena_sample": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(BatchOut), _P, _P]),
     "pa_sample_indices": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, _P]),
+    "pa_sample_indices_rounds": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
+                                           _P, C.c_int32, _P]),
     "pa_one_hot": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
     "pa_dqn_param_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pa_dqn_param_offsets": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),

@@ -852,6 +852,16 @@ extern "C" int pa_sample_indices(int64_t population, uint64_t seed, uint64_t off
                                reinterpret_cast<hipStream_t>(stream));
 }
 
+extern "C" int pa_sample_indices_rounds(int64_t population, uint64_t seed, uint64_t offset0,
+                                        int32_t B, int32_t rounds, int64_t* idx_out_dev,
+                                        int32_t device, void* stream) {
+  PA_REQUIRE(idx_out_dev || B == 0 || rounds == 0, PA_ERR_INVALID, "null output");
+  PA_REQUIRE(rounds >= 0, PA_ERR_INVALID, "negative rounds");
+  PA_HIP(hipSetDevice(device));
+  return sample_indices_launch(population, seed, offset0, B, rounds, idx_out_dev,
+                               reinterpret_cast<hipStream_t>(stream));
+}
+
 // out[b] = src[idx[b]] for rows of row_bytes bytes (extra per-transition columns kept next to the
 // arena in logical order, e.g. PPO's gae / lam_return / action_probs, ppo.py:47-82)
 static __global__ __launch_bounds__(256) void gather_rows_kernel(const uint8_t* __restrict__ src,

@@ -271,18 +271,17 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
   return PA_OK;
 }
 
-// ---- two networks of the same shape in lock-step (TwinCritic, twin_critic.py:22-91): every layer of
-// both is ONE launch (linear_kernel and weight_grad_kernel take several problems per launch), which
-// halves the launch count of the twin passes.  Arithmetic per network is unchanged.
+// ---- two networks of the same depth on the same input in lock-step (TwinCritic,
+// twin_critic.py:22-91; PPO's actor and critic, ppo.py:152-192): every layer of both is ONE launch
+// (linear_kernel and weight_grad_kernel take several problems per launch), which halves the launch
+// count of the paired passes.  Arithmetic per network is unchanged.
 namespace {
 int check_pair(const pa_mlp* h1, const pa_mlp* h2) {
   PA_REQUIRE(h1 && h2 && h1->bound && h2->bound, PA_ERR_INVALID, "mlp pair: unbound network");
-  PA_REQUIRE(h1->L == h2->L && h1->d.device == h2->d.device &&
-                 h1->d.identity_layers == h2->d.identity_layers &&
-                 h1->d.no_last_bias == h2->d.no_last_bias,
-             PA_ERR_INVALID, "mlp pair: the two networks differ in shape");
-  for (int l = 0; l <= h1->L; ++l)
-    PA_REQUIRE(h1->d.dims[l] == h2->d.dims[l], PA_ERR_INVALID, "mlp pair: layer widths differ");
+  // same depth and the same input; widths, activations and bias flags are per network (every
+  // problem of a linear_kernel / weight_grad_kernel launch carries its own shape)
+  PA_REQUIRE(h1->L == h2->L && h1->d.device == h2->d.device && h1->d.dims[0] == h2->d.dims[0],
+             PA_ERR_INVALID, "mlp pair: the two networks differ in depth, device or input width");
   return PA_OK;
 }
 }  // namespace
@@ -508,15 +507,32 @@ struct PpoActorArgs {
   unsigned* ticket;     // zero on entry, zero again on exit
 };
 
+// STAGED (2 * 256 * (A + 1) floats of LDS fit): the workgroup's 256 logit / representation rows are
+// staged through LDS with coalesced loads (pitch A + 1: conflict-free row-per-lane access), the
+// row-per-thread arithmetic — unchanged, same operation order — runs out of LDS, and the logit
+// gradients go back the same way.  Row-per-thread global access touches 64 cache lines per load.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float stage[];
   __shared__ float red[256];
   __shared__ unsigned last;
   const float lo = 1.0f - a.eps, hi = 1.0f + a.eps;
   float part_loss = 0.f, part_p = 0.f;
-  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.x * 256;
+  const int b = b0 + threadIdx.x;
+  const int P = a.A + 1;
+  if (STAGED) {
+    for (int e = threadIdx.x; e < 256 * a.A; e += 256) {
+      const int r = e / a.A, j = e - r * a.A;
+      const bool in = b0 + r < a.B;
+      stage[r * P + j] = in ? a.logits[(int64_t)(b0 + r) * a.ldl + j] : 0.f;
+      stage[(256 + r) * P + j] = in ? a.arep[(int64_t)(b0 + r) * a.lda + j] : 0.f;
+    }
+    __syncthreads();
+  }
   if (b < a.B) {
-    const float* z = a.logits + (int64_t)b * a.ldl;
-    const float* ar = a.arep + (int64_t)b * a.lda;
+    const float* z = STAGED ? stage + threadIdx.x * P : a.logits + (int64_t)b * a.ldl;
+    const float* ar = STAGED ? stage + (256 + threadIdx.x) * P : a.arep + (int64_t)b * a.lda;
     float m = z[0];
     for (int j = 1; j < a.A; ++j) m = fmaxf(m, z[j]);
     float s = 0.f;
@@ -540,10 +556,18 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
     const float dp = -dr / a.p_old[b];
     // p = sum_j y_j ar_j, y = softmax(z): dz_j = y_j (dp ar_j - sum_k dp ar_k y_k)
     const float dot = dp * p;
-    float* dz = a.d_logits + (int64_t)b * a.ldd;
+    // STAGED: in place over the row's logits (z[j] is dead once dz[j] is formed)
+    float* dz = STAGED ? stage + threadIdx.x * P : a.d_logits + (int64_t)b * a.ldd;
     for (int j = 0; j < a.A; ++j) {
       const float yj = expf(z[j] - m) / s;
       dz[j] = yj * (dp * ar[j] - dot);
+    }
+  }
+  if (STAGED) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 256 * a.A; e += 256) {
+      const int r = e / a.A, j = e - r * a.A;
+      if (b0 + r < a.B) a.d_logits[(int64_t)(b0 + r) * a.ldd + j] = stage[r * P + j];
     }
   }
   const float bl = block_sum_256(part_loss, red);
@@ -558,15 +582,21 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
   if (!last) return;
   __threadfence();  // the other blocks' partials and p_rows are visible from here on
   float loss = 0.f, psum = 0.f;
+  const float* parts = a.partials;
+#pragma unroll 8
   for (unsigned k = 0; k < gridDim.x; ++k) {  // block order: fixed
-    loss += __hip_atomic_load(a.partials + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    psum += __hip_atomic_load(a.partials + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    loss += __builtin_nontemporal_load(parts + 2 * k);
+    psum += __builtin_nontemporal_load(parts + 2 * k + 1);
   }
   // entropy of Categorical(probs = p / sum p) with torch's clamping of probs / logits
   float part_e = 0.f;
   const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+  // plain loads: the acquire fence above ordered them after every block's release, and unlike
+  // atomic loads the compiler keeps many of them in flight (16 dependent L2 round trips otherwise)
+  const float* prow = a.p_rows;
+#pragma unroll 8
   for (int i = threadIdx.x; i < a.B; i += 256) {
-    const float p = __hip_atomic_load(a.p_rows + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float p = __builtin_nontemporal_load(prow + i);
     const float pn = p / psum;
     const float pc = fminf(fmaxf(pn, tiny), 1.0f - tiny);
     float lg = logf(pc);
@@ -1208,7 +1238,13 @@ extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* 
   a.ticket = reinterpret_cast<unsigned*>(scratch);
   a.partials = scratch + 4;
   a.p_rows = scratch + 4 + 2 * grid;
-  hipLaunchKernelGGL(ppo_actor_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const size_t lds = (size_t)2 * 256 * (A + 1) * sizeof(float);
+  if (lds <= 48 * 1024)
+    hipLaunchKernelGGL(ppo_actor_kernel<true>, dim3(grid), dim3(256), lds,
+                       reinterpret_cast<hipStream_t>(stream), a);
+  else
+    hipLaunchKernelGGL(ppo_actor_kernel<false>, dim3(grid), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

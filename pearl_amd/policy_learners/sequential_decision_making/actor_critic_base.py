@@ -158,13 +158,22 @@ class ActorCriticBase(PolicyLearner):
             return {}
         batch_size = self._clamped_batch_size(replay_buffer)
         pending: Dict[str, List[Any]] = {}
-        for _ in range(self._training_rounds):
-            self._training_steps += 1
-            batch = replay_buffer.sample(batch_size)
-            if not _looks_like_batch(batch):
-                continue
-            for k, v in self._learn_batch_device(self.preprocess_batch(batch)).items():
-                pending.setdefault(k, []).append(v)
+        # device sampler: the index lists of every round in one launch (one workgroup each) instead
+        # of a single-workgroup kernel on the critical path of every round
+        presample = getattr(replay_buffer, "presample", None)
+        if presample is not None:
+            presample(self._training_rounds, batch_size)
+        try:
+            for _ in range(self._training_rounds):
+                self._training_steps += 1
+                batch = replay_buffer.sample(batch_size)
+                if not _looks_like_batch(batch):
+                    continue
+                for k, v in self._learn_batch_device(self.preprocess_batch(batch)).items():
+                    pending.setdefault(k, []).append(v)
+        finally:
+            if presample is not None:
+                replay_buffer.drop_presampled()
         report: Dict[str, List[Any]] = {}
         for k, vals in pending.items():
             dev_ix = [i for i, v in enumerate(vals) if isinstance(v, torch.Tensor)]

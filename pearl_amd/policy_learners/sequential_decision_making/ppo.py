@@ -180,6 +180,39 @@ class ProximalPolicyOptimization(ActorCriticBase):
         critic.adam()
         return loss[0]
 
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        """Actor and critic steps of one minibatch (actor_critic_base.py:309-366 order of effects:
+        the two networks share nothing but the batch, so their passes run in lock-step — every
+        layer of both in one launch — instead of one after the other)."""
+        assert isinstance(batch, PPOTransitionBatch) and batch.action_probs is not None \
+            and batch.lam_return is not None
+        actor, critic = self._nets(len(batch))
+        if actor.dims[0] != critic.dims[0] or len(actor.dims) != len(critic.dims):
+            return super()._learn_batch_device(batch)
+        dev = actor.device
+        s = N.stream_ptr(dev)
+        state = self._f32(batch.state, dev)
+        B = state.shape[0]
+        arep = self._f32(batch.action, dev).reshape(B, -1)
+        A = actor.dims[-1]
+        assert arep.shape[1] == A, "PPO needs the action representation the actor outputs"
+        logits, v = FlatMlp.forward_pair(actor, critic, state, keep=True)
+        d_logits = torch.empty_like(logits)
+        dv = torch.empty(B, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        N.check(N.lib().pa_ppo_actor_loss(
+            logits.data_ptr(), logits.stride(0), arep.data_ptr(), arep.stride(0),
+            self._f32(batch.action_probs, dev).data_ptr(), self._f32(batch.gae, dev).data_ptr(),
+            B, A, float(self._epsilon), float(self._entropy_bonus_scaling), d_logits.data_ptr(),
+            d_logits.stride(0), losses.data_ptr(), s))
+        N.check(N.lib().pa_mse_head(v.data_ptr(), v.stride(0),
+                                    self._f32(batch.lam_return, dev).data_ptr(), B, 2.0 / B, 1.0, 0,
+                                    dv.data_ptr(), losses[1:].data_ptr(), s))
+        FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True)
+        actor.adam(reduce="sum")   # the surrogate is a SUM over the (global) minibatch
+        critic.adam()
+        return {"actor_loss": losses[0], "critic_loss": losses[1]}
+
     # ------------------------------------------------------------------ learn (ppo.py:194-293)
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         self.preprocess_replay_buffer(replay_buffer)

@@ -104,6 +104,7 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         self._has_next_avail = False
         self._space_cache: dict = {}
         self._last_idx: Optional[Tensor] = None
+        self._presampled: Optional[Tuple[Tensor, int, int]] = None   # (lists [R, B], next row, len)
 
     # -- ReplayBuffer interface -------------------------------------------------
     @property
@@ -123,6 +124,7 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         return 0 if self._arena is None else len(self._arena)
 
     def clear(self) -> None:
+        self._presampled = None
         if self._arena is not None:
             self._arena.clear()
 
@@ -382,6 +384,28 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         return np.fromiter(random.sample(range(len(self)), batch_size), dtype=np.int64,
                            count=batch_size)
 
+    def presample(self, rounds: int, batch_size: int) -> bool:
+        """Device sampler only: draw the index lists of the next ``rounds`` ``sample(batch_size)``
+        calls in ONE launch (``sample_indices_kernel`` runs one workgroup per list, so a learner
+        loop does not pay a single-workgroup kernel per round); the following ``sample`` calls of
+        that size consume them in order.  Pushing, clearing or a different batch size drops what
+        is left.  Consumes Python's ``random`` once (the Philox key), like one ``sample``."""
+        self._presampled = None
+        n = len(self)
+        if self.sampler != "device" or self._arena is None or rounds <= 0 or not 0 < batch_size <= n:
+            return False
+        dev = self._arena.device
+        self._arena.flush()
+        lists = torch.empty(int(rounds), int(batch_size), dtype=torch.int64, device=dev)
+        N.check(N.lib().pa_sample_indices_rounds(n, random.getrandbits(64), 0, int(batch_size),
+                                                 int(rounds), lists.data_ptr(), dev.index,
+                                                 N.stream_ptr(dev)))
+        self._presampled = (lists, 0, n)
+        return True
+
+    def drop_presampled(self) -> None:
+        self._presampled = None
+
     def sample(self, batch_size: int) -> TransitionBatch:
         """Uniform sample without replacement -> ``TransitionBatch`` on ``device_for_batches``
         (tensor_based_replay_buffer.py:253-282, :290-400)."""
@@ -389,6 +413,13 @@ class TensorBasedReplayBuffer(ReplayBuffer):
             raise ValueError(
                 f"Can't get a batch of size {batch_size} from a replay buffer with "
                 f"only {len(self)} elements")
+        pre = self._presampled
+        if pre is not None:
+            lists, row, n = pre
+            if int(batch_size) == lists.shape[1] and n == len(self) and row < lists.shape[0]:
+                self._presampled = (lists, row + 1, n)
+                return self._gather_batch(lists[row])
+            self._presampled = None
         return self._gather_batch(None, int(batch_size))
 
     @property

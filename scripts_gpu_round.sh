@@ -14,6 +14,10 @@ PEARL_AMD_OVERLAP=0 timeout 600 python bench.py --timing-level 2 --no-cpu-baseli
 echo "bench l2 rc=$?"; tail -1 gpurun_out/bench_l2.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('stage_us'))"
 timeout 900 python bench.py $BENCH_ARGS > gpurun_out/bench.log 2>&1
 echo "bench rc=$?"; tail -1 gpurun_out/bench.log
+if [ "$SKIP_ALGOS" != "1" ]; then
+timeout 600 python bench_algos.py --steps 300 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
+echo "bench_algos rc=$?"; cut -c1-260 gpurun_out/bench_algos.jsonl
+fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1

@@ -240,3 +240,36 @@ def test_replay_buffer_state_dict_round_trip(golden, capacity, tmp_path):
     empty = BasicReplayBuffer(5)
     empty.load_state_dict(BasicReplayBuffer(5).state_dict())
     assert len(empty) == 0
+
+
+def test_presampled_index_lists_feed_sample_in_order(golden):
+    """presample(rounds, B): one launch draws every round's list (list r == the single-list draw
+    at Philox offset r with the same key); sample(B) then consumes them in order, each a set of
+    distinct in-range indices; another batch size or a clear() drops the rest."""
+    from oracle.pearl_oracle import philox_sample_indices
+    fx = golden("cfg1_cartpole_shape")
+    rb = fill_arena_buffer(fx, "device")
+    n, B, R = len(rb), 64, 5
+    random.seed(21)
+    key = random.getrandbits(64)
+    random.seed(21)
+    assert rb.presample(R, B)
+    lists = []
+    for r in range(R):
+        batch = rb.sample(B)
+        idx = rb.last_indices.cpu()
+        lists.append(idx)
+        assert len(set(idx.tolist())) == B and int(idx.min()) >= 0 and int(idx.max()) < n
+        want = torch.from_numpy(philox_sample_indices(n, key, r, B))
+        assert torch.equal(idx, want)
+        assert torch.equal(batch.state.cpu(), fx["states"][idx])
+    assert not torch.equal(lists[0], lists[1])
+    # exhausted: the next sample draws a fresh list with a fresh key
+    rb.sample(B)
+    assert rb._presampled is None
+    # a different batch size drops the remaining lists
+    assert rb.presample(3, B)
+    rb.sample(B // 2)
+    assert rb._presampled is None
+    # python-sampler buffers never presample (their index stream is Python's `random`)
+    assert not fill_arena_buffer(fx, "python").presample(2, 8)

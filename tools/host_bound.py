@@ -1,35 +1,86 @@
-"""Is ContinuousSoftActorCritic.learn() bound by the host or by the device?  Times `steps` rounds of
-learn() twice: wall time until the last launch is enqueued (host), and until the device is idle."""
-import os, sys, time, random
+"""Host- or device-bound?  For one learner, times `steps` rounds of learn() twice: wall time until the
+last launch is enqueued (host) and until the device is idle; then a cProfile of the host side.
+Usage: python tools/host_bound.py [sac|ppo] [steps]"""
+import cProfile
+import os
+import pstats
+import random
+import sys
+import time
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
+import torch  # noqa: E402
+
 DEV = "cuda:0"
 
 
-def main(steps=300):
+def make_sac(steps):
     from pearl_amd import BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic, PearlAgent
     S, A, B, N = 64, 8, 1024, 200_000
-    torch.manual_seed(0); random.seed(0)
     pl = ContinuousSoftActorCritic(action_space=BoxActionSpace(-torch.ones(A), torch.ones(A)), state_dim=S,
                                    actor_hidden_dims=[256, 256], critic_hidden_dims=[256, 256],
                                    batch_size=B, training_rounds=steps)
     rb = BasicReplayBuffer(N, sampler="device")
-    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
     st = torch.randn(N + 1, S, device=DEV)
     ids = torch.arange(N, device=DEV)
     rb.push_many(state=st[:-1], action=torch.rand(N, A, device=DEV) * 2 - 1, reward=(ids % 7).float(),
                  terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
                  next_state=st[1:])
-    agent.learn(); torch.cuda.synchronize()
+    return lambda: pl.learn(rb)
+
+
+def make_ppo(steps):
+    from pearl_amd import (DiscreteActionSpace, OneHotActionTensorRepresentationModule, PearlAgent,
+                           PPOReplayBuffer, ProximalPolicyOptimization)
+    S, A, B, N = 256, 16, 4096, 65_536
+    sp = DiscreteActionSpace([torch.tensor([k]) for k in range(A)])
+    pl = ProximalPolicyOptimization(action_space=sp, state_dim=S, actor_hidden_dims=[256, 256],
+                                    critic_hidden_dims=[256, 256], training_rounds=steps, batch_size=B,
+                                    epsilon=0.1,
+                                    action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = PPOReplayBuffer(N, sampler="device")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    st = torch.randn(N + 1, S, device=DEV)
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 500 == 499), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=sp, next_available_actions=sp,
+                 max_number_actions=A)
+    pl.preprocess_replay_buffer(rb)
+    if "full" in sys.argv:
+        return lambda: pl.learn(rb)                  # with preprocess_replay_buffer, as agent.learn()
+    from pearl_amd.policy_learners.sequential_decision_making.actor_critic_base import ActorCriticBase
+    return lambda: ActorCriticBase.learn(pl, rb)     # learn() without the one-off rollout pass
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "sac"
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    if "threads32" in sys.argv:
+        torch.set_num_threads(32)
+    torch.manual_seed(0)
+    random.seed(0)
+    learn = {"sac": make_sac, "ppo": make_ppo}[which](steps)
+    if "warm20" in sys.argv:          # a short warm-up instead of a full learn()
+        short = {"sac": make_sac, "ppo": make_ppo}[which](20)
+        short()
+    else:
+        learn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    agent.learn()
+    learn()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print(f"SAC: host enqueue {1e6*(t1-t0)/steps:.0f} us/step, device-idle {1e6*(t2-t0)/steps:.0f} us/step")
-    import cProfile, pstats
-    pr = cProfile.Profile(); pr.enable(); agent.learn(); pr.disable(); torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    print(f"{which}: host enqueue {1e6 * (t1 - t0) / steps:.0f} us/step, "
+          f"device idle after {1e6 * (t2 - t0) / steps:.0f} us/step")
+    pr = cProfile.Profile()
+    pr.enable()
+    learn()
+    pr.disable()
+    torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(16)
 
 
 if __name__ == "__main__":
