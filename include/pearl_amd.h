@@ -421,6 +421,23 @@ int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* noise, int3
                         const float* low, const float* high, const float* dl_daction,
                         const float* dl_daction2, int32_t ldda, const float* alpha, int32_t B,
                         int32_t A, float* d_head, int32_t lddh, void* stream);
+/* Deterministic policies (DDPG ddpg.py:106-156, TD3 td3.py:106-201).
+ * pa_tanh_action: VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485) from the
+ * actor's pre-tanh outputs: a = ((high - low) (tanh(z) + 1)) / 2 + low.  With `noise` ([B, A]
+ * N(0, sigma^2) draws; TD3's target policy smoothing, td3.py:151-175): clamp(noise, -clip, clip)
+ * (high - low) / 2 is added and the sum clamped to [low, high].  `action` may point into a
+ * [B, S + A] critic input (lda = S + A).
+ * pa_tanh_action_grad: d_head = dL/da . da/dz of the un-noised action.
+ * pa_neg_mean_head: DDPG's actor objective, loss = -mean(q), dq = -1/B. */
+int pa_tanh_action(const float* head, int32_t ldh, const float* noise, int32_t ldn,
+                   const float* low, const float* high, float noise_clip, int32_t B, int32_t A,
+                   float* action, int32_t lda, void* stream);
+int pa_tanh_action_grad(const float* head, int32_t ldh, const float* low, const float* high,
+                        const float* dl_daction, int32_t ldda, int32_t B, int32_t A,
+                        float* d_head, int32_t lddh, void* stream);
+int pa_neg_mean_head(const float* q, int32_t ldq, int32_t B, float* dq, float* loss_out,
+                     void* stream);
+
 /* ContinuousSoftActorCritic twin-critic plumbing (soft_actor_critic_continuous.py:155-231).
  * mode 0: loss_out = mean(alpha*log_prob - min(q1,q2)); out1/out2 = dL/dq1, dL/dq2.
  * mode 1: out1 = (min(q1,q2) - alpha*log_prob) * gamma * (1 - terminated) + reward. */

@@ -191,6 +191,81 @@ class SacOracle:
 
 
 # --------------------------------------------------------------------------------------
+# DDPG / TD3
+# --------------------------------------------------------------------------------------
+class DdpgOracle:
+    """DeepDeterministicPolicyGradient (ddpg.py:106-156) and, with ``td3=True``, TD3
+    (td3.py:106-201): tanh actor + target, twin critics + targets, torch autograd + AdamW(amsgrad)."""
+
+    def __init__(self, actor_sd, actor_target_sd, critic_sd, critic_target_sd, low: Tensor,
+                 high: Tensor, gamma: float = 0.99, tau: float = 0.005, lr: float = 1e-3,
+                 td3: bool = False, actor_update_freq: int = 2, noise_clip: float = 0.5) -> None:
+        self.actor = _layers(actor_sd)
+        self.actor_t = [(w.detach().clone(), b.detach().clone()) for w, b in _layers(actor_target_sd)]
+        self.c = [_layers(critic_sd, f"_critic_{i}._model.") for i in (1, 2)]
+        self.ct = [[(w.detach().clone(), b.detach().clone()) for w, b in
+                    _layers(critic_target_sd, f"_critic_{i}._model.")] for i in (1, 2)]
+        self.low, self.high = low, high
+        self.gamma, self.tau = gamma, tau
+        self.td3, self.freq, self.clip = td3, actor_update_freq, noise_clip
+        self.opt_a = _adamw(_flat(self.actor), lr)
+        self.opt_c = _adamw(_flat(self.c[0]) + _flat(self.c[1]), lr)
+        self.training_steps = 0
+        self.last_actor_loss = 0.0
+
+    def policy(self, layers, state: Tensor) -> Tensor:
+        """VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485)."""
+        n = torch.tanh(mlp(layers, state))
+        return (((self.high - self.low) * (n + 1.0)) / 2) + self.low
+
+    @staticmethod
+    def q(layers, state, action) -> Tensor:
+        return mlp(layers, torch.cat([state, action], dim=-1)).view(-1)
+
+    def _soft(self, net, tgt, tau=None) -> None:
+        with torch.no_grad():
+            for (w, b), (tw, tb) in zip(net, tgt):
+                tw.copy_(self.tau * w + (1.0 - self.tau) * tw)
+                tb.copy_(self.tau * b + (1.0 - self.tau) * tb)
+
+    def actor_step(self, s: Tensor) -> float:
+        loss = -self.q(self.c[0], s, self.policy(self.actor, s)).mean()     # ddpg.py:106-121
+        self.opt_a.zero_grad()
+        loss.backward()
+        self.opt_a.step()
+        return loss.item()
+
+    def critic_step(self, batch: Dict[str, Tensor], noise) -> float:
+        s, a, r, term, ns = (batch[k] for k in ("state", "action", "reward", "terminated", "next_state"))
+        self.opt_c.zero_grad()
+        with torch.no_grad():
+            na = self.policy(self.actor_t, ns)
+            if noise is not None:                                            # td3.py:151-175
+                n = torch.clamp(noise, -self.clip, self.clip)
+                n = n * (self.high - self.low) / 2
+                na = torch.clamp(na + n, self.low, self.high)
+            nq = torch.minimum(self.q(self.ct[0], ns, na), self.q(self.ct[1], ns, na))
+            y = (nq * self.gamma * (1 - term.float())) + r
+        mse = torch.nn.MSELoss()
+        loss = (mse(self.q(self.c[0], s, a), y) + mse(self.q(self.c[1], s, a), y)) / 2.0
+        loss.backward()
+        self.opt_c.step()
+        return loss.item()
+
+    def learn_batch(self, batch: Dict[str, Tensor], noise=None) -> Dict[str, float]:
+        due = (not self.td3) or self.training_steps % self.freq == 0
+        if due:
+            self.last_actor_loss = self.actor_step(batch["state"])
+        report = {"actor_loss": self.last_actor_loss,
+                  "critic_loss": self.critic_step(batch, noise if self.td3 else None)}
+        if due:
+            for net, tgt in zip(self.c, self.ct):
+                self._soft(net, tgt)
+            self._soft(self.actor, self.actor_t)
+        return report
+
+
+# --------------------------------------------------------------------------------------
 # neural-linear contextual bandit
 # --------------------------------------------------------------------------------------
 class NeuralLinearOracle:

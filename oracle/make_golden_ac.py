@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors for the actor-critic rows of SURVEY.md §8 (a13-a15): runs the REAL reference
 (/root/reference, CPU) for PPO and continuous SAC on seeded synthetic data and writes
-tests/golden/ppo_*.pt and tests/golden/sac_*.pt.
+tests/golden/ppo_*.pt, tests/golden/sac_*.pt and tests/golden/{ddpg,td3}_*.pt.
 
 TEST INFRASTRUCTURE ONLY (build container; the reference does not travel to the GPU box):
 
@@ -37,6 +37,10 @@ from pearl.policy_learners.sequential_decision_making.ppo import (  # noqa: E402
 from pearl.policy_learners.sequential_decision_making.soft_actor_critic_continuous import (  # noqa: E402
     ContinuousSoftActorCritic,
 )
+from pearl.policy_learners.sequential_decision_making.ddpg import (  # noqa: E402
+    DeepDeterministicPolicyGradient,
+)
+from pearl.policy_learners.sequential_decision_making.td3 import TD3  # noqa: E402
 from pearl.pearl_agent import PearlAgent  # noqa: E402
 from pearl.replay_buffers import BasicReplayBuffer  # noqa: E402
 from pearl.replay_buffers.transition import TransitionBatch  # noqa: E402
@@ -162,6 +166,69 @@ def make_sac(name, cfg):
           f"-> {reports[-1]}")
 
 
+DDPG_CONFIGS = {
+    # name: shapes, K learn_batch calls; td3 adds the delayed actor + target policy smoothing
+    "ddpg_tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=5, td3=False),
+    "ddpg_cfg3_shape_small": dict(S=64, A=8, hidden=[256, 256], B=128, steps=4, td3=False),
+    "td3_tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=6, td3=True),
+    "td3_cfg3_shape_small": dict(S=64, A=8, hidden=[256, 256], B=128, steps=5, td3=True),
+}
+
+
+def make_ddpg(name, cfg):
+    """DDPG (ddpg.py:106-156) / TD3 (td3.py:106-201): one fixed batch, K learn_batch calls with
+    `_training_steps` = 0, 1, 2, ... (what learn() would have set, minus one: TD3's delayed actor
+    keys on it), TD3's smoothing noise replayed from the seed the reference drew it with."""
+    S, A, B, K = cfg["S"], cfg["A"], cfg["B"], cfg["steps"]
+    gen = torch.Generator().manual_seed(123)
+    low = -torch.ones(A) * torch.linspace(1.0, 2.0, A)
+    high = torch.ones(A) * torch.linspace(1.5, 1.0, A)
+    sp = BoxActionSpace(low=low, high=high)
+    batch = dict(
+        state=torch.randn(B, S, generator=gen),
+        action=low + (high - low) * torch.rand(B, A, generator=gen),
+        reward=torch.randn(B, generator=gen),
+        terminated=torch.rand(B, generator=gen) < 0.2,
+        truncated=torch.zeros(B, dtype=torch.bool),
+        next_state=torch.randn(B, S, generator=gen))
+    torch.manual_seed(16)
+    cls = TD3 if cfg["td3"] else DeepDeterministicPolicyGradient
+    pl = cls(action_space=sp, state_dim=S, actor_hidden_dims=cfg["hidden"],
+             critic_hidden_dims=cfg["hidden"], batch_size=B)
+    PearlAgent(policy_learner=pl, replay_buffer=BasicReplayBuffer(10))
+    # the targets start as copies; move them apart so the fixture tells them from the online nets
+    with torch.no_grad():
+        for p in list(pl._actor_target.parameters()) + list(pl._critic_target.parameters()):
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    fx = {"config": dict(cfg), "low": low, "high": high, "batch": batch,
+          "actor0": clone_sd(pl._actor), "actor_target0": clone_sd(pl._actor_target),
+          "critic0": clone_sd(pl._critic), "critic_target0": clone_sd(pl._critic_target)}
+    with torch.no_grad():
+        act = pl._actor.sample_action(batch["state"])
+        q1, q2 = pl._critic.get_q_values(batch["state"], act)
+        nact = pl._actor_target.sample_action(batch["next_state"])
+    fx["probe"] = dict(action=act.clone(), q1=q1.clone(), q2=q2.clone(), next_action=nact.clone())
+    noises, reports = [], []
+    for k in range(K):
+        seed = 3000 + k
+        torch.manual_seed(seed)
+        noises.append(torch.normal(mean=0, std=0.2, size=(B, A)) if cfg["td3"] else None)
+        torch.manual_seed(seed)
+        pl._training_steps = k
+        tb = TransitionBatch(**{k2: v.clone() for k2, v in batch.items()})
+        rep = pl.learn_batch(pl.preprocess_batch(tb))
+        reports.append({k2: float(v) for k2, v in rep.items()})
+    fx["noises"] = noises
+    fx["reports"] = reports
+    for key, mod in (("actor_after", pl._actor), ("actor_target_after", pl._actor_target),
+                     ("critic_after", pl._critic), ("critic_target_after", pl._critic_target)):
+        fx[key] = clone_sd(mod)
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); reports {reports[0]} "
+          f"-> {reports[-1]}")
+
+
 BANDIT_CONFIGS = {
     "tiny": dict(F=7, hidden=[12, 6], B=16, steps=4),
     "cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3),
@@ -199,6 +266,12 @@ def make_bandit(name, cfg):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "ddpg":
+        for name, cfg in DDPG_CONFIGS.items():
+            make_ddpg(name, cfg)
+        return
+    for name, cfg in DDPG_CONFIGS.items():
+        make_ddpg(name, cfg)
     for name, cfg in BANDIT_CONFIGS.items():
         make_bandit(name, cfg)
     if os.environ.get("PEARL_GOLDEN_ONLY") == "bandit":

@@ -8,7 +8,9 @@ There is no CPU or PyTorch fallback for that path: it fails loudly without the l
 """
 from .pearl_agent import PearlAgent  # noqa: F401
 from .replay_buffers import BasicReplayBuffer, TransitionBatch  # noqa: F401
-from .policy_learners.sequential_decision_making import (ContinuousSoftActorCritic,  # noqa: F401
+from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
+                                                         ContinuousSoftActorCritic,
+                                                         DeepDeterministicPolicyGradient,
                                                          DeepQLearning, DoubleDQN, PPOReplayBuffer,
                                                          ProximalPolicyOptimization)
 from .policy_learners.contextual_bandits import NeuralLinearBandit, SquareCBExploration  # noqa: F401

@@ -284,6 +284,11 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, _P]),
     "pa_mlp_backward2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
                                    C.c_int32, _P, _P, C.c_int32, _P]),
+    "pa_tanh_action": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32,
+                                 C.c_int32, _P, C.c_int32, _P]),
+    "pa_tanh_action_grad": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                      _P, C.c_int32, _P]),
+    "pa_neg_mean_head": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
     "pa_mlp_adam": (C.c_int, [_P, C.c_int64, _P]),
     "pa_mlp_soft_update": (C.c_int, [_P, C.c_float, _P]),
     "pa_softmax_action_prob": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),

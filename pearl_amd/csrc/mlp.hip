@@ -761,6 +761,68 @@ __global__ __launch_bounds__(256) void gauss_grad_kernel(GaussGradArgs a) {
   a.d_head[(int64_t)b * a.lddh + a.A + j] = dl_dls * 3.5f * (1.0f - t * t);
 }
 
+// ---- deterministic policies (DDPG / TD3) ------------------------------------------------------
+// VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485): the network's last
+// activation is tanh, then action_scaling (:29-51):  a = ((high - low) (tanh(z) + 1)) / 2 + low.
+// With `noise` (TD3's target policy smoothing, td3.py:151-175): the N(0, sigma^2) draws are clamped
+// to [-clip, clip], rescaled  noise (high - low) / 2, added, and the sum clamped to [low, high].
+struct TanhActArgs {
+  const float* head; int ldh;       // [B, A] pre-tanh outputs of the actor
+  const float* noise; int ldn;      // [B, A] or null
+  const float* low; const float* high;
+  float clip;
+  int B, A;
+  float* action; int lda;           // [B, A] (may point into a [B, S+A] critic input)
+};
+__global__ __launch_bounds__(256) void tanh_action_kernel(TanhActArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)a.B * a.A) return;
+  const int b = (int)(e / a.A), j = (int)(e - (int64_t)b * a.A);
+  const float lo = a.low[j], hi = a.high[j];
+  const float t = tanhf(a.head[(int64_t)b * a.ldh + j]);
+  float act = (((hi - lo) * (t + 1.0f)) / 2.0f) + lo;
+  if (a.noise) {
+    float n = a.noise[(int64_t)b * a.ldn + j];
+    n = fminf(fmaxf(n, -a.clip), a.clip);
+    n = (n * (hi - lo)) / 2.0f;
+    act = fminf(fmaxf(act + n, lo), hi);
+  }
+  a.action[(int64_t)b * a.lda + j] = act;
+}
+
+// d_head = dL/da . da/dz for the un-noised action:  (g / 2) (high - low) (1 - tanh(z)^2)
+struct TanhGradArgs {
+  const float* head; int ldh;
+  const float* low; const float* high;
+  const float* dl_da; int ldda;
+  int B, A;
+  float* d_head; int lddh;
+};
+__global__ __launch_bounds__(256) void tanh_action_grad_kernel(TanhGradArgs a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)a.B * a.A) return;
+  const int b = (int)(e / a.A), j = (int)(e - (int64_t)b * a.A);
+  const float t = tanhf(a.head[(int64_t)b * a.ldh + j]);
+  const float g = a.dl_da[(int64_t)b * a.ldda + j];
+  const float gt = (g / 2.0f) * (a.high[j] - a.low[j]);
+  a.d_head[(int64_t)b * a.lddh + j] = gt * (1.0f - t * t);
+}
+
+// DDPG's actor objective (ddpg.py:106-121): loss = -mean(q1), d loss / d q1 = -1/B
+__global__ __launch_bounds__(256) void neg_mean_head_kernel(const float* __restrict__ q, int ldq,
+                                                            int B, float* __restrict__ dq,
+                                                            float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float part = 0.f;
+  const float g = -1.0f / (float)B;
+  for (int i = threadIdx.x; i < B; i += 256) {
+    part += q[(int64_t)i * ldq];
+    dq[i] = g;
+  }
+  const float sum = block_sum_256(part, red);
+  if (threadIdx.x == 0) loss_out[0] = -(sum / (float)B);
+}
+
 // Twin-critic plumbing for SAC (soft_actor_critic_continuous.py:155-231).
 //   mode 0 (actor loss):  loss = mean(alpha * logp - min(q1, q2)); dq1/dq2 = -w/B with torch.minimum's
 //                         even split on ties
@@ -1307,6 +1369,44 @@ extern "C" int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* 
   a.d_head = d_head; a.lddh = lddh;
   hipLaunchKernelGGL(gauss_grad_kernel, dim3((unsigned)ceil_div((int64_t)B * A, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_tanh_action(const float* head, int32_t ldh, const float* noise, int32_t ldn,
+                              const float* low, const float* high, float noise_clip, int32_t B,
+                              int32_t A, float* action, int32_t lda, void* stream) {
+  PA_REQUIRE(head && low && high && action && B > 0 && A > 0, PA_ERR_INVALID,
+             "pa_tanh_action: bad argument");
+  TanhActArgs a;
+  a.head = head; a.ldh = ldh; a.noise = noise; a.ldn = ldn; a.low = low; a.high = high;
+  a.clip = noise_clip; a.B = B; a.A = A; a.action = action; a.lda = lda;
+  hipLaunchKernelGGL(tanh_action_kernel, dim3((unsigned)ceil_div((int64_t)B * A, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_tanh_action_grad(const float* head, int32_t ldh, const float* low,
+                                   const float* high, const float* dl_daction, int32_t ldda,
+                                   int32_t B, int32_t A, float* d_head, int32_t lddh,
+                                   void* stream) {
+  PA_REQUIRE(head && low && high && dl_daction && d_head && B > 0 && A > 0, PA_ERR_INVALID,
+             "pa_tanh_action_grad: bad argument");
+  TanhGradArgs a;
+  a.head = head; a.ldh = ldh; a.low = low; a.high = high; a.dl_da = dl_daction; a.ldda = ldda;
+  a.B = B; a.A = A; a.d_head = d_head; a.lddh = lddh;
+  hipLaunchKernelGGL(tanh_action_grad_kernel, dim3((unsigned)ceil_div((int64_t)B * A, 256)),
+                     dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_neg_mean_head(const float* q, int32_t ldq, int32_t B, float* dq, float* loss_out,
+                                void* stream) {
+  PA_REQUIRE(q && dq && loss_out && B > 0, PA_ERR_INVALID, "pa_neg_mean_head: bad argument");
+  hipLaunchKernelGGL(neg_mean_head_kernel, dim3(1), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), q, ldq, B, dq, loss_out);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -1,5 +1,6 @@
 """Actor network containers
-(pearl/neural_networks/sequential_decision_making/actor_networks.py:29-73, :107-176, :488-629).
+(pearl/neural_networks/sequential_decision_making/actor_networks.py:29-73, :107-176, :448-485,
+:488-629).
 
 Same constructors, ``state_dict`` keys and torch semantics as the reference.  The learner step
 does not call these ``forward``s: it runs ``pa_mlp_forward`` on a flat view of the parameters and
@@ -58,6 +59,26 @@ class VanillaActorNetwork(ActorNetwork):
                         unavailable_actions_mask: Optional[Tensor] = None) -> Tensor:
         all_action_probs = self.forward(state_batch)
         return torch.sum(all_action_probs * action_batch, dim=1, keepdim=True).view(-1)
+
+    def linear_layers(self) -> List[nn.Linear]:
+        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+
+
+class VanillaContinuousActorNetwork(ActorNetwork):
+    """Deterministic policy: mlp with a tanh output, scaled to the action box (:448-485)."""
+
+    def __init__(self, input_dim: int, hidden_dims: Optional[List[int]], output_dim: int,
+                 action_space: Any) -> None:
+        super().__init__(input_dim, hidden_dims, output_dim, action_space)
+        self._model: nn.Module = mlp_block(input_dim=input_dim, hidden_dims=hidden_dims,
+                                           output_dim=output_dim, last_activation="tanh")
+        self._action_space = action_space
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._model(x)
+
+    def sample_action(self, x: Tensor) -> Tensor:
+        return action_scaling(self._action_space, self._model(x))
 
     def linear_layers(self) -> List[nn.Linear]:
         return [m for m in self._model.modules() if isinstance(m, nn.Linear)]

@@ -50,6 +50,32 @@ class PropensityExploration(ExplorationModule):
         return action_space.actions[idx]
 
 
+class NormalDistributionExploration(ExplorationModule):
+    """Gaussian noise on a continuous action, scaled to the action box and clipped
+    (pearl/policy_learners/exploration_modules/common/normal_distribution_exploration.py:24-78)."""
+
+    def __init__(self, mean: float = 0.0, std_dev: float = 1.0) -> None:
+        super().__init__()
+        self._mean, self._std_dev = mean, std_dev
+
+    def act(self, subjective_state: Any = None, action_space: Any = None, exploit_action: Any = None,
+            values: Optional[torch.Tensor] = None, **kwargs: Any) -> Any:
+        assert exploit_action is not None and hasattr(action_space, "low")
+        dev = exploit_action.device
+        low = action_space.low.detach().clone().to(dev)
+        high = action_space.high.detach().clone().to(dev)
+        assert torch.all(exploit_action >= low) and torch.all(exploit_action <= high)
+        noise = torch.normal(mean=self._mean, std=self._std_dev, size=exploit_action.size(),
+                             device=dev)
+        return torch.clamp(exploit_action + ((high - low) / 2) * noise, low, high)
+
+    def compare(self, other: ExplorationModule) -> str:
+        if not isinstance(other, NormalDistributionExploration):
+            return "other is not an instance of NormalDistributionExploration"
+        return "\n".join(f"{k} is different: {getattr(self, k)} vs {getattr(other, k)}"
+                         for k in ("_mean", "_std_dev") if getattr(self, k) != getattr(other, k))
+
+
 class EGreedyExploration(ExplorationModule):
     def __init__(self, epsilon: float, start_epsilon: Optional[float] = None,
                  end_epsilon: Optional[float] = None, warmup_steps: Optional[int] = None) -> None:

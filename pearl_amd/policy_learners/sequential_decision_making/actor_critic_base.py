@@ -74,8 +74,6 @@ class ActorCriticBase(PolicyLearner):
         if actor_optimizer is not None or critic_optimizer is not None:
             raise NotImplementedError("pearl_amd actor-critic learners own their AdamW(amsgrad) "
                                       "steps; custom optimizers are not supported")
-        if use_actor_target:
-            raise NotImplementedError("pearl_amd: actor target networks (DDPG/TD3) are not built")
         self._state_dim = state_dim
         self._action_space = action_space
         self._use_actor_target = use_actor_target
@@ -97,6 +95,8 @@ class ActorCriticBase(PolicyLearner):
             [{"params": self._actor.parameters(), "lr": actor_learning_rate, "amsgrad": True}])
         self._actor_soft_update_tau = actor_soft_update_tau
         self._critic_soft_update_tau = critic_soft_update_tau
+        if self._use_actor_target:
+            self._actor_target: nn.Module = copy.deepcopy(self._actor)
         if self._use_critic:
             if critic_network_instance is not None:
                 self._critic: nn.Module = critic_network_instance
@@ -148,6 +148,8 @@ class ActorCriticBase(PolicyLearner):
             report["critic_loss"] = self._critic_update(batch)
         if self._use_critic_target:
             self._update_critic_target()
+        if self._use_actor_target:
+            self._update_actor_target()
         return report
 
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
@@ -201,6 +203,9 @@ class ActorCriticBase(PolicyLearner):
     def _update_critic_target(self) -> None:
         raise NotImplementedError
 
+    def _update_actor_target(self) -> None:
+        raise NotImplementedError
+
     # ------------------------------------------------------------------ checkpoints (:411-428)
     def get_extra_state(self) -> Dict[str, Any]:
         state = {"actor_optimizer": self._actor_optimizer.state_dict()}
@@ -225,7 +230,8 @@ class ActorCriticBase(PolicyLearner):
                     diffs.append(f"{attr} is different: {getattr(self, attr)} vs "
                                  f"{getattr(other, attr)}")
             names = ["_actor"] + (["_critic"] if self._use_critic else []) + (
-                ["_critic_target"] if self._use_critic_target else [])
+                ["_critic_target"] if self._use_critic_target else []) + (
+                ["_actor_target"] if self._use_actor_target else [])
             for name in names:
                 mine, theirs = getattr(self, name).state_dict(), getattr(other, name).state_dict()
                 if mine.keys() != theirs.keys():

@@ -1,0 +1,72 @@
+"""TD3 (reference: pearl/policy_learners/sequential_decision_making/td3.py:43-245).
+
+DDPG plus (a) a delayed actor: the actor step and BOTH target updates only run on rounds where
+``_training_steps % actor_update_freq == 0`` (:106-141; the report repeats the last actor loss in
+between), with the actor step BEFORE the critic step of the same round, and (b) target policy
+smoothing: clipped Gaussian noise, rescaled to the action box, on the target actor's action,
+the sum clipped to the box (:143-201).  The noise is the only torch-side random input
+(``torch.normal(0, actor_update_noise)`` like the reference, or ``noise_source`` in parity tests);
+clamp / rescale / add / clip happen in ``pa_tanh_action``.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, Optional
+
+import torch
+from torch import Tensor
+
+from ...replay_buffers.transition import TransitionBatch
+from ..policy_learner import PolicyLearner
+from .ddpg import DeepDeterministicPolicyGradient
+
+
+class TD3(DeepDeterministicPolicyGradient):
+    def __init__(self, action_space: Any, *args: Any, actor_update_freq: int = 2,
+                 actor_update_noise: float = 0.2, actor_update_noise_clip: float = 0.5,
+                 **kwargs: Any) -> None:
+        assert hasattr(action_space, "low") and hasattr(action_space, "high"), \
+            "TD3 needs a box action space"
+        super().__init__(action_space, *args, **kwargs)
+        self._actor_update_freq = actor_update_freq
+        self._actor_update_noise = actor_update_noise
+        self._actor_update_noise_clip = actor_update_noise_clip
+        self._last_actor_loss: Any = 0.0
+        # parity hook: callable (B, A, device) -> N(0, actor_update_noise^2) draws
+        self.noise_source: Optional[Callable[[int, int, torch.device], Tensor]] = None
+
+    def _target_noise(self, B: int, A: int, dev: torch.device):
+        if self.noise_source is not None:
+            noise = self.noise_source(B, A, dev).to(dev, torch.float32).contiguous()
+        else:
+            noise = torch.normal(mean=0.0, std=float(self._actor_update_noise), size=(B, A),
+                                 device=dev)
+        return noise, float(self._actor_update_noise_clip)
+
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        due = self._training_steps % self._actor_update_freq == 0
+        if due:
+            self._last_actor_loss = self._actor_update(batch)
+        else:
+            self._nets(len(batch))     # the per-batch binding validation _actor_update would do
+        report = {"actor_loss": self._last_actor_loss, "critic_loss": self._critic_update(batch)}
+        if due:
+            self._update_critic_target()
+            self._update_actor_target()
+        return report
+
+    def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        report = super().learn_batch(batch)
+        if isinstance(self._last_actor_loss, torch.Tensor):
+            self._last_actor_loss = float(self._last_actor_loss)   # like the reference's .item()
+        return report
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, TD3):
+            diffs.append("other is not an instance of TD3")
+        else:
+            for attr in ("_actor_update_freq", "_actor_update_noise", "_actor_update_noise_clip"):
+                if getattr(self, attr) != getattr(other, attr):
+                    diffs.append(f"{attr} is different: {getattr(self, attr)} vs "
+                                 f"{getattr(other, attr)}")
+        return "\n".join(d for d in diffs if d)

@@ -206,3 +206,82 @@ def test_twin_pair_launches_equal_two_single_passes(dims, B):
         for p, want in zip(m._params(), g):
             assert torch.equal(p.grad, want)
     assert not torch.equal(o1, o2)
+
+
+DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small"]
+
+
+def make_ddpg(fx):
+    from pearl_amd import (TD3, BasicReplayBuffer, BoxActionSpace, DeepDeterministicPolicyGradient,
+                           PearlAgent)
+    cfg = fx["config"]
+    cls = TD3 if cfg["td3"] else DeepDeterministicPolicyGradient
+    pl = cls(action_space=BoxActionSpace(fx["low"], fx["high"]), state_dim=cfg["S"],
+             actor_hidden_dims=cfg["hidden"], critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"])
+    for mod, key in ((pl._actor, "actor0"), (pl._actor_target, "actor_target0"),
+                     (pl._critic, "critic0"), (pl._critic_target, "critic_target0")):
+        mod.load_state_dict(fx[key])
+    PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+    return pl
+
+
+@pytest.mark.parametrize("name", DDPG)
+def test_ddpg_td3_actions_and_qvalues(name):
+    """pa_tanh_action on the online / target actor and the twin critics on [state | action]."""
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    pl = make_ddpg(fx)
+    actor, c1, c2 = pl._nets(fx["config"]["B"])
+    b = sac_batch(fx)
+    S = fx["config"]["S"]
+    xa, _ = pl._policy_input(actor, b.state.contiguous(), use_target=False, keep=False)
+    torch.testing.assert_close(xa[:, S:].cpu(), fx["probe"]["action"], rtol=1e-5, atol=1e-6)
+    assert torch.equal(xa[:, :S], b.state)
+    torch.testing.assert_close(c1.forward(xa).view(-1).cpu(), fx["probe"]["q1"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(c2.forward(xa).view(-1).cpu(), fx["probe"]["q2"], rtol=1e-5, atol=2e-6)
+    xn, _ = pl._policy_input(actor, b.next_state.contiguous(), use_target=True, keep=False)
+    torch.testing.assert_close(xn[:, S:].cpu(), fx["probe"]["next_action"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", DDPG)
+def test_ddpg_td3_learn_batch_trajectory(name):
+    """K learn_batch calls against the reference run: per-call losses (first call at 1e-5), then
+    all four networks.  TD3: `_training_steps` = 0, 1, 2, ... exercises the delayed actor / target
+    updates and the repeated last actor loss; the smoothing noise is the reference's own draws."""
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    pl = make_ddpg(fx)
+    for step, (noise, want) in enumerate(zip(fx["noises"], fx["reports"])):
+        if noise is not None:
+            pl.noise_source = lambda B, A, dev, n=noise: n
+        pl._training_steps = step
+        got = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+        tol = 1e-5 if step == 0 else 5e-4
+        for k in want:
+            assert abs(float(got[k]) - want[k]) <= tol * max(1.0, abs(want[k])), (step, k, float(got[k]), want[k])
+    for name_, mod, key in (("actor", pl._actor, "actor_after"),
+                            ("actor_target", pl._actor_target, "actor_target_after"),
+                            ("critic", pl._critic, "critic_after"),
+                            ("critic_target", pl._critic_target, "critic_target_after")):
+        for k, v in mod.state_dict().items():
+            torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
+
+
+def test_td3_learn_from_replay_defers_readback_and_delays_actor():
+    """TD3.learn() through a device-sampled arena: finite losses, the actor loss only changes on
+    rounds where the actor stepped, and the actor target only moves on those rounds."""
+    from pearl_amd import TD3, BasicReplayBuffer, BoxActionSpace, PearlAgent
+    S, A, B, n = 12, 3, 64, 2000
+    torch.manual_seed(0)
+    random.seed(0)
+    pl = TD3(action_space=BoxActionSpace(-torch.ones(A), torch.ones(A)), state_dim=S,
+             actor_hidden_dims=[32, 32], critic_hidden_dims=[32, 32], batch_size=B, training_rounds=6)
+    rb = BasicReplayBuffer(n, sampler="device")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    st = torch.randn(n + 1, S, device=DEV)
+    rb.push_many(state=st[:-1], action=torch.rand(n, A, device=DEV) * 2 - 1,
+                 reward=torch.randn(n, device=DEV), terminated=torch.zeros(n, dtype=torch.bool, device=DEV),
+                 truncated=torch.zeros(n, dtype=torch.bool, device=DEV), next_state=st[1:])
+    report = agent.learn()
+    al, cl = report["actor_loss"], report["critic_loss"]
+    assert len(al) == len(cl) == 6 and all(map(lambda v: v == v and abs(v) < 1e6, al + cl))
+    # _training_steps runs 1..6 inside learn(): the actor steps on 2, 4, 6
+    assert al[0] == 0.0 and al[1] != 0.0 and al[2] == al[1] and al[3] != al[2] and al[4] == al[3]

@@ -118,3 +118,38 @@ def test_neural_linear_bandit_trajectory(name):
     torch.testing.assert_close(orc.b, after["_linear_regression_layer._b"], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(orc.coefs, after["_linear_regression_layer._coefs"], rtol=1e-3, atol=1e-5)
     torch.testing.assert_close(orc.sigma(fx["query"]["x"]), fx["query"]["sigma"].view(-1), rtol=1e-4, atol=1e-6)
+
+
+DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small"]
+
+
+@pytest.mark.parametrize("name", DDPG)
+def test_ddpg_td3_probe_and_trajectory(name):
+    """DdpgOracle against the reference's DDPG / TD3 runs: deterministic actions, Q-values, the
+    per-call losses (TD3: delayed actor, repeated last actor loss, smoothing noise replayed) and
+    all four networks afterwards."""
+    from oracle.actor_critic_oracle import DdpgOracle
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    orc = DdpgOracle(fx["actor0"], fx["actor_target0"], fx["critic0"], fx["critic_target0"],
+                     fx["low"], fx["high"], td3=fx["config"]["td3"])
+    b = fx["batch"]
+    with torch.no_grad():
+        act = orc.policy(orc.actor, b["state"])
+        torch.testing.assert_close(act, fx["probe"]["action"], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(orc.q(orc.c[0], b["state"], act), fx["probe"]["q1"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(orc.q(orc.c[1], b["state"], act), fx["probe"]["q2"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(orc.policy(orc.actor_t, b["next_state"]), fx["probe"]["next_action"],
+                                   rtol=1e-6, atol=1e-6)
+    for k, (noise, want) in enumerate(zip(fx["noises"], fx["reports"])):
+        orc.training_steps = k
+        got = orc.learn_batch(b, noise)
+        for key in want:
+            assert abs(got[key] - want[key]) <= 2e-5 * max(1.0, abs(want[key])), (k, key, got[key], want[key])
+    for i, (w, bias) in enumerate(orc.actor):
+        torch.testing.assert_close(w.detach(), fx["actor_after"][f"_model.{i}.0.weight"], rtol=1e-4, atol=1e-6)
+    for i, (w, bias) in enumerate(orc.actor_t):
+        torch.testing.assert_close(w, fx["actor_target_after"][f"_model.{i}.0.weight"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(orc.c[1][0][0].detach(),
+                               fx["critic_after"]["_critic_2._model.0.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.ct[0][1][1],
+                               fx["critic_target_after"]["_critic_1._model.1.0.bias"], rtol=1e-5, atol=1e-7)
