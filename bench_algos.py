@@ -124,6 +124,50 @@ def bench_td3(steps, cpu_seconds):
                              "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
 
 
+def bench_dsac(steps, cpu_seconds):
+    """Discrete SoftActorCritic at config 2's shapes (128-dim states, 16 actions,
+    [256,256], batch 1024): the twin critics see 16 384 (state, action) rows per pass."""
+    from oracle.actor_critic_oracle import DiscreteSacOracle
+    from pearl_amd import (BasicReplayBuffer, OneHotActionTensorRepresentationModule, PearlAgent,
+                           SoftActorCritic)
+    S, A, B, N = 128, 16, 1024, 200_000
+    torch.manual_seed(0)
+    random.seed(0)
+    pl = SoftActorCritic(action_space=dspace(A), state_dim=S, actor_hidden_dims=[256, 256],
+                         critic_hidden_dims=[256, 256], batch_size=B, training_rounds=steps,
+                         action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = BasicReplayBuffer(N, sampler="device")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    st = torch.randn(N + 1, S, device=DEV, generator=g)
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=dspace(A),
+                 next_available_actions=dspace(A), max_number_actions=A)
+    dt, _ = timed(lambda: agent.learn())
+    gpu = B * steps / dt
+    sd = lambda m: {k: v.cpu() for k, v in m.state_dict().items()}
+    orc = DiscreteSacOracle(sd(pl._actor), sd(pl._critic), sd(pl._critic_target), A)
+    idx = torch.randint(0, 1000, (B,))
+    eye = torch.eye(A)
+    batch = dict(state=torch.randn(B, S), action=eye[idx % A], reward=(idx % 7).float(),
+                 terminated=(idx % 50 == 0), next_state=torch.randn(B, S),
+                 curr_available_actions=eye.expand(B, A, A), next_available_actions=eye.expand(B, A, A),
+                 curr_unavailable_actions_mask=torch.zeros(B, A, dtype=torch.bool),
+                 next_unavailable_actions_mask=torch.zeros(B, A, dtype=torch.bool))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < cpu_seconds:
+        orc.learn_batch(batch)
+        n += 1
+    cpu = B * n / (time.perf_counter() - t0)
+    return {"config": "cfg2 shapes, discrete SoftActorCritic S=128 A=16 twin-Q [256,256] B=1024",
+            "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
+                             "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
+
+
 def bench_ppo(steps, cpu_seconds):
     from oracle.actor_critic_oracle import PpoOracle
     from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
@@ -316,7 +360,7 @@ def main():
     args = ap.parse_args()
     torch.cuda.set_device(0)
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
-    for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("ppo", bench_ppo), ("bandit", bench_bandit),
+    for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("dsac", bench_dsac), ("ppo", bench_ppo), ("bandit", bench_bandit),
                      ("double_dqn", bench_double_dqn), ("push", bench_push)):
         if args.only and args.only != name:
             continue

@@ -421,6 +421,26 @@ int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* noise, int3
                         const float* low, const float* high, const float* dl_daction,
                         const float* dl_daction2, int32_t ldda, const float* alpha, int32_t B,
                         int32_t A, float* d_head, int32_t lddh, void* stream);
+/* Discrete SoftActorCritic (soft_actor_critic.py:180-287).
+ * pa_expand_state_actions: x[b * A + i] = state[b] || rep[b, i] — the (B, A, S + AD) input of
+ *   TwinCritic.get_q_values on an action set (rep_bstride = A * AD, or 0 for one shared table).
+ * pa_dsac_actor_head: P = softmax(logits); loss = mean over (B, A) of P (alpha log(P + 1e-8) - q),
+ *   q = min(q1, q2) with masked (unavailable) actions at 0 (:254-287); d_logits = its gradient
+ *   through the softmax; h_out[b] = sum_j P log(P + 1e-8) (minus the row's entropy: the input of
+ *   the entropy-coefficient step, :134-151, through pa_sac_alpha_step).
+ * pa_dsac_target: y = (sum_j (q_j - alpha log(P_j + 1e-8)) P_j) gamma (1 - term) + reward
+ *   (:180-252), q and P of the NEXT state. */
+int pa_expand_state_actions(const float* state, int32_t ld_state, const float* rep,
+                            int64_t rep_bstride, int32_t B, int32_t A, int32_t S, int32_t AD,
+                            float* x_out, void* stream);
+int pa_dsac_actor_head(const float* logits, int32_t ldl, const float* q1, const float* q2,
+                       const uint8_t* mask, const float* alpha, int32_t B, int32_t A,
+                       float* d_logits, int32_t ldd, float* loss_out, float* h_out, void* stream);
+int pa_dsac_target(const float* logits, int32_t ldl, const float* q1, const float* q2,
+                   const uint8_t* mask, const float* alpha, const float* reward,
+                   const uint8_t* terminated, float gamma, int32_t B, int32_t A, float* y,
+                   void* stream);
+
 /* Deterministic policies (DDPG ddpg.py:106-156, TD3 td3.py:106-201).
  * pa_tanh_action: VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485) from the
  * actor's pre-tanh outputs: a = ((high - low) (tanh(z) + 1)) / 2 + low.  With `noise` ([B, A]

@@ -191,6 +191,85 @@ class SacOracle:
 
 
 # --------------------------------------------------------------------------------------
+# discrete SAC
+# --------------------------------------------------------------------------------------
+class DiscreteSacOracle:
+    """SoftActorCritic (soft_actor_critic.py:46-330): softmax actor, twin critics on every available
+    action, expected-value target, entropy autotune with Adam(eps=1e-4)."""
+
+    def __init__(self, actor_sd, critic_sd, critic_target_sd, n_actions: int, gamma: float = 0.99,
+                 tau: float = 0.005, lr: float = 1e-4, target_entropy_scale: float = 0.89) -> None:
+        self.actor = _layers(actor_sd)
+        self.c = [_layers(critic_sd, f"_critic_{i}._model.") for i in (1, 2)]
+        self.ct = [[(w.detach().clone(), b.detach().clone()) for w, b in
+                    _layers(critic_target_sd, f"_critic_{i}._model.")] for i in (1, 2)]
+        self.gamma, self.tau = gamma, tau
+        self.log_alpha = torch.zeros(1, requires_grad=True)
+        self.alpha = torch.exp(self.log_alpha).detach()
+        self.target_entropy = -target_entropy_scale * torch.log(1.0 / torch.tensor(n_actions))
+        self.opt_a = _adamw(_flat(self.actor), lr)
+        self.opt_c = _adamw(_flat(self.c[0]) + _flat(self.c[1]), lr)
+        self.opt_e = torch.optim.Adam([self.log_alpha], lr=lr, eps=1e-4)
+
+    def policy(self, state: Tensor) -> Tensor:
+        return torch.softmax(mlp(self.actor, state), dim=-1)
+
+    @staticmethod
+    def q_all(layers, state: Tensor, reps: Tensor) -> Tensor:
+        """Q(s_b, a_i) for every available-action slot: (B, A)."""
+        B, A, _ = reps.shape
+        s = state.unsqueeze(1).expand(B, A, state.shape[1])
+        return mlp(layers, torch.cat([s, reps], dim=-1)).view(B, A)
+
+    @staticmethod
+    def q(layers, state, action) -> Tensor:
+        return mlp(layers, torch.cat([state, action], dim=-1)).view(-1)
+
+    def learn_batch(self, batch: Dict[str, Tensor]) -> Dict[str, float]:
+        s, a, r, term, ns = (batch[k] for k in ("state", "action", "reward", "terminated", "next_state"))
+        # ---- actor (:254-287)
+        qmin = torch.minimum(self.q_all(self.c[0], s, batch["curr_available_actions"]),
+                             self.q_all(self.c[1], s, batch["curr_available_actions"])).detach().clone()
+        if batch.get("curr_unavailable_actions_mask") is not None:
+            qmin[batch["curr_unavailable_actions_mask"]] = 0.0
+        p = self.policy(s)
+        logp = torch.log(p + 1e-8)
+        actor_loss = (p * (self.alpha * logp - qmin)).mean()
+        self.opt_a.zero_grad()
+        actor_loss.backward()
+        self.opt_a.step()
+        p_cache, logp_cache = p.detach(), logp.detach()
+        # ---- critic (:153-252), with the updated actor
+        self.opt_c.zero_grad()
+        with torch.no_grad():
+            nq = torch.minimum(self.q_all(self.ct[0], ns, batch["next_available_actions"]),
+                               self.q_all(self.ct[1], ns, batch["next_available_actions"]))
+            if batch.get("next_unavailable_actions_mask") is not None:
+                nq[batch["next_unavailable_actions_mask"]] = 0.0
+            npi = self.policy(ns)
+            nv = ((nq - self.alpha * torch.log(npi + 1e-8)) * npi).sum(dim=1)
+            y = (nv * self.gamma * (1 - term.float())) + r
+        mse = torch.nn.MSELoss()
+        critic_loss = (mse(self.q(self.c[0], s, a), y) + mse(self.q(self.c[1], s, a), y)) / 2.0
+        critic_loss.backward()
+        self.opt_c.step()
+        with torch.no_grad():
+            for net, tgt in zip(self.c, self.ct):
+                for (w, b), (tw, tb) in zip(net, tgt):
+                    tw.copy_(self.tau * w + (1.0 - self.tau) * tw)
+                    tb.copy_(self.tau * b + (1.0 - self.tau) * tb)
+        # ---- entropy autotune (:134-151)
+        entropy = -(p_cache * logp_cache).sum(1).mean()
+        ent_loss = torch.exp(self.log_alpha) * (entropy - self.target_entropy).detach()
+        self.opt_e.zero_grad()
+        ent_loss.backward()
+        self.opt_e.step()
+        self.alpha = torch.exp(self.log_alpha).detach()
+        return {"actor_loss": actor_loss.item(), "critic_loss": critic_loss.item(),
+                "entropy_coef": ent_loss.item()}
+
+
+# --------------------------------------------------------------------------------------
 # DDPG / TD3
 # --------------------------------------------------------------------------------------
 class DdpgOracle:

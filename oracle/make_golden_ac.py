@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors for the actor-critic rows of SURVEY.md §8 (a13-a15): runs the REAL reference
 (/root/reference, CPU) for PPO and continuous SAC on seeded synthetic data and writes
-tests/golden/ppo_*.pt, tests/golden/sac_*.pt and tests/golden/{ddpg,td3}_*.pt.
+tests/golden/ppo_*.pt, tests/golden/sac_*.pt and tests/golden/{ddpg,td3,dsac}_*.pt.
 
 TEST INFRASTRUCTURE ONLY (build container; the reference does not travel to the GPU box):
 
@@ -39,6 +39,9 @@ from pearl.policy_learners.sequential_decision_making.soft_actor_critic_continuo
 )
 from pearl.policy_learners.sequential_decision_making.ddpg import (  # noqa: E402
     DeepDeterministicPolicyGradient,
+)
+from pearl.policy_learners.sequential_decision_making.soft_actor_critic import (  # noqa: E402
+    SoftActorCritic,
 )
 from pearl.policy_learners.sequential_decision_making.td3 import TD3  # noqa: E402
 from pearl.pearl_agent import PearlAgent  # noqa: E402
@@ -229,6 +232,66 @@ def make_ddpg(name, cfg):
           f"-> {reports[-1]}")
 
 
+DSAC_CONFIGS = {
+    "dsac_tiny": dict(S=5, A=3, hidden=[16, 12], B=16, steps=5, dynamic=True),
+    "dsac_shape_small": dict(S=64, A=8, hidden=[128, 128], B=96, steps=4, dynamic=False),
+}
+
+
+def make_dsac(name, cfg):
+    """Discrete SoftActorCritic (soft_actor_critic.py:46-330): one fixed batch in the shape
+    BasicReplayBuffer.sample() returns (padded available-action tables + masks; `dynamic` varies
+    the number of available actions per row), K learn_batch calls."""
+    S, A, B, K = cfg["S"], cfg["A"], cfg["B"], cfg["steps"]
+    gen = torch.Generator().manual_seed(321)
+    n_curr = torch.randint(1, A + 1, (B,), generator=gen) if cfg["dynamic"] else torch.full((B,), A)
+    n_next = torch.randint(1, A + 1, (B,), generator=gen) if cfg["dynamic"] else torch.full((B,), A)
+    ar = torch.arange(A)
+    table = ar.view(1, A, 1).expand(B, A, 1).float()
+    batch = dict(
+        state=torch.randn(B, S, generator=gen),
+        action=(torch.rand(B, generator=gen) * n_curr).long().clamp(max=A - 1).view(B, 1),
+        reward=torch.randn(B, generator=gen),
+        terminated=torch.rand(B, generator=gen) < 0.2,
+        truncated=torch.zeros(B, dtype=torch.bool),
+        next_state=torch.randn(B, S, generator=gen),
+        curr_available_actions=(table * (ar.view(1, A) < n_curr.view(B, 1)).view(B, A, 1)).clone(),
+        curr_unavailable_actions_mask=ar.view(1, A) >= n_curr.view(B, 1),
+        next_available_actions=(table * (ar.view(1, A) < n_next.view(B, 1)).view(B, A, 1)).clone(),
+        next_unavailable_actions_mask=ar.view(1, A) >= n_next.view(B, 1))
+    torch.manual_seed(26)
+    pl = SoftActorCritic(action_space=space(A), state_dim=S, actor_hidden_dims=cfg["hidden"],
+                         critic_hidden_dims=cfg["hidden"], batch_size=B,
+                         action_representation_module=OneHotActionTensorRepresentationModule(A))
+    PearlAgent(policy_learner=pl, replay_buffer=BasicReplayBuffer(10))
+    with torch.no_grad():
+        for p in pl._critic_target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    fx = {"config": dict(cfg), "batch": batch, "actor0": clone_sd(pl._actor),
+          "critic0": clone_sd(pl._critic), "critic_target0": clone_sd(pl._critic_target)}
+    pre = pl.preprocess_batch(TransitionBatch(**{k: v.clone() for k, v in batch.items()}))
+    with torch.no_grad():
+        fx["probe"] = dict(policy=pl._actor.get_policy_distribution(pre.state).clone(),
+                           next_v=pl._get_next_state_expected_values(pre).clone())
+        q1, q2 = pl._critic.get_q_values(pre.state, pre.curr_available_actions)
+        fx["probe"]["q1"], fx["probe"]["q2"] = q1.clone(), q2.clone()
+    reports = []
+    for k in range(K):
+        tb = TransitionBatch(**{k2: v.clone() for k2, v in batch.items()})
+        rep = pl.learn_batch(pl.preprocess_batch(tb))
+        reports.append({k2: float(v) for k2, v in rep.items()})
+    fx["reports"] = reports
+    fx["actor_after"] = clone_sd(pl._actor)
+    fx["critic_after"] = clone_sd(pl._critic)
+    fx["critic_target_after"] = clone_sd(pl._critic_target)
+    fx["log_entropy_after"] = pl._log_entropy.detach().clone()
+    fx["entropy_coef_after"] = pl._entropy_coef.detach().clone()
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); reports {reports[0]} "
+          f"-> {reports[-1]}")
+
+
 BANDIT_CONFIGS = {
     "tiny": dict(F=7, hidden=[12, 6], B=16, steps=4),
     "cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3),
@@ -266,12 +329,18 @@ def make_bandit(name, cfg):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "dsac":
+        for name, cfg in DSAC_CONFIGS.items():
+            make_dsac(name, cfg)
+        return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "ddpg":
         for name, cfg in DDPG_CONFIGS.items():
             make_ddpg(name, cfg)
         return
     for name, cfg in DDPG_CONFIGS.items():
         make_ddpg(name, cfg)
+    for name, cfg in DSAC_CONFIGS.items():
+        make_dsac(name, cfg)
     for name, cfg in BANDIT_CONFIGS.items():
         make_bandit(name, cfg)
     if os.environ.get("PEARL_GOLDEN_ONLY") == "bandit":

@@ -12,7 +12,8 @@ from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
                                                          ContinuousSoftActorCritic,
                                                          DeepDeterministicPolicyGradient,
                                                          DeepQLearning, DoubleDQN, PPOReplayBuffer,
-                                                         ProximalPolicyOptimization)
+                                                         ProximalPolicyOptimization,
+                                                         SoftActorCritic)
 from .policy_learners.contextual_bandits import NeuralLinearBandit, SquareCBExploration  # noqa: F401
 from .action_representation_modules import OneHotActionTensorRepresentationModule  # noqa: F401
 from .utils.instantiations.spaces import BoxActionSpace, DiscreteActionSpace  # noqa: F401

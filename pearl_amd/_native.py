@@ -284,6 +284,12 @@ SIGNATURES = {
                                   C.c_int32, C.c_int32, _P]),
     "pa_mlp_backward2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,
                                    C.c_int32, _P, _P, C.c_int32, _P]),
+    "pa_expand_state_actions": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_int32, C.c_int32, _P, _P]),
+    "pa_dsac_actor_head": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P,
+                                     C.c_int32, _P, _P, _P]),
+    "pa_dsac_target": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int32,
+                                 C.c_int32, _P, _P]),
     "pa_tanh_action": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32,
                                  C.c_int32, _P, C.c_int32, _P]),
     "pa_tanh_action_grad": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,

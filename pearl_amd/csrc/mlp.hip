@@ -823,6 +823,91 @@ __global__ __launch_bounds__(256) void neg_mean_head_kernel(const float* __restr
   if (threadIdx.x == 0) loss_out[0] = -(sum / (float)B);
 }
 
+// ---- discrete SAC (soft_actor_critic.py:180-287) ----------------------------------------------
+// x[b * A + i] = state[b] || rep(available_actions[b, i])  — the (B, A, S + AD) critic input of
+// TwinCritic.get_q_values on an action set (q_value_networks.py:152-174 expands the state)
+__global__ __launch_bounds__(256) void expand_state_actions_kernel(
+    const float* __restrict__ state, int lds_, const float* __restrict__ rep, int64_t rep_bstride,
+    float* __restrict__ x, int B, int A, int S, int AD) {
+  const int W = S + AD;
+  const int64_t total = (int64_t)B * A * W;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int64_t row = e / W;
+    const int j = (int)(e - row * W);
+    const int64_t b = row / A;
+    const int i = (int)(row - b * A);
+    x[e] = (j < S) ? state[b * lds_ + j] : rep[b * rep_bstride + (int64_t)i * AD + (j - S)];
+  }
+}
+
+// Row-local pieces of both losses.  P = softmax(logits_b) (the policy ignores availability masks,
+// actor_networks.py:136-153), logP = log(P + 1e-8), q = min(q1, q2) with unavailable actions at 0.
+//   mode 0, actor (:254-287): loss = mean over (B, A) of P (alpha logP - q); d_logits through the
+//           softmax; h_b = sum_j P_j logP_j (= -entropy_b, what the autotune step needs, :134-151)
+//   mode 1, target (:180-252): v_b = sum_j (q_j - alpha log(P_j + 1e-8)) P_j;
+//           y_b = v_b gamma (1 - term_b) + r_b
+struct DsacArgs {
+  const float* logits; int ldl;
+  const float* q1; const float* q2;      // [B * A], row b * A + j
+  const uint8_t* mask;                   // [B, A] 1 = unavailable, or null
+  const float* alpha;
+  int B, A, mode;
+  float* d_logits; int ldd; float* loss_out; float* h_out;
+  const float* reward; const uint8_t* term; float gamma; float* y;
+};
+__global__ __launch_bounds__(256) void dsac_kernel(DsacArgs a) {
+  __shared__ float red[256];
+  const float alpha = a.alpha[0];
+  const float inv_n = 1.0f / ((float)a.B * (float)a.A);
+  float part = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float* z = a.logits + (int64_t)b * a.ldl;
+    const float* q1 = a.q1 + (int64_t)b * a.A;
+    const float* q2 = a.q2 + (int64_t)b * a.A;
+    const uint8_t* mk = a.mask ? a.mask + (int64_t)b * a.A : nullptr;
+    float m = z[0];
+    for (int j = 1; j < a.A; ++j) m = fmaxf(m, z[j]);
+    float s = 0.f;
+    for (int j = 0; j < a.A; ++j) s += expf(z[j] - m);
+    if (a.mode == 1) {
+      float v = 0.f;
+      for (int j = 0; j < a.A; ++j) {
+        const float p = expf(z[j] - m) / s;
+        const float q = (mk && mk[j]) ? 0.f : fminf(q1[j], q2[j]);
+        v += (q - alpha * logf(p + 1e-8f)) * p;
+      }
+      const float live = 1.0f - (a.term[b] ? 1.0f : 0.0f);
+      a.y[b] = __fadd_rn(__fmul_rn(__fmul_rn(v, a.gamma), live), a.reward[b]);
+      continue;
+    }
+    float dot = 0.f, h = 0.f;
+    for (int j = 0; j < a.A; ++j) {
+      const float p = expf(z[j] - m) / s;
+      const float lp = logf(p + 1e-8f);
+      const float q = (mk && mk[j]) ? 0.f : fminf(q1[j], q2[j]);
+      const float f = alpha * lp - q;
+      part += p * f;
+      h += p * lp;
+      const float g = (f + p * (alpha / (p + 1e-8f))) * inv_n;   // dL/dP_j
+      dot += g * p;
+    }
+    a.h_out[b] = h;
+    float* dz = a.d_logits + (int64_t)b * a.ldd;
+    for (int j = 0; j < a.A; ++j) {
+      const float p = expf(z[j] - m) / s;
+      const float lp = logf(p + 1e-8f);
+      const float q = (mk && mk[j]) ? 0.f : fminf(q1[j], q2[j]);
+      const float g = ((alpha * lp - q) + p * (alpha / (p + 1e-8f))) * inv_n;
+      dz[j] = p * (g - dot);
+    }
+  }
+  if (a.mode == 0) {
+    const float sum = block_sum_256(part, red);
+    if (threadIdx.x == 0) a.loss_out[0] = sum * inv_n;
+  }
+}
+
 // Twin-critic plumbing for SAC (soft_actor_critic_continuous.py:155-231).
 //   mode 0 (actor loss):  loss = mean(alpha * logp - min(q1, q2)); dq1/dq2 = -w/B with torch.minimum's
 //                         even split on ties
@@ -1369,6 +1454,52 @@ extern "C" int pa_gauss_actor_grad(const float* head, int32_t ldh, const float* 
   a.d_head = d_head; a.lddh = lddh;
   hipLaunchKernelGGL(gauss_grad_kernel, dim3((unsigned)ceil_div((int64_t)B * A, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_expand_state_actions(const float* state, int32_t lds_, const float* rep,
+                                       int64_t rep_bstride, int32_t B, int32_t A, int32_t S,
+                                       int32_t AD, float* x_out, void* stream) {
+  PA_REQUIRE(state && rep && x_out && B > 0 && A > 0 && S > 0 && AD > 0, PA_ERR_INVALID,
+             "pa_expand_state_actions: bad argument");
+  const int64_t total = (int64_t)B * A * (S + AD);
+  const unsigned grid = (unsigned)(ceil_div(total, 256) > 4096 ? 4096 : ceil_div(total, 256));
+  hipLaunchKernelGGL(expand_state_actions_kernel, dim3(grid), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), state, lds_, rep, rep_bstride, x_out, B,
+                     A, S, AD);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_dsac_actor_head(const float* logits, int32_t ldl, const float* q1, const float* q2,
+                                  const uint8_t* mask, const float* alpha, int32_t B, int32_t A,
+                                  float* d_logits, int32_t ldd, float* loss_out, float* h_out,
+                                  void* stream) {
+  PA_REQUIRE(logits && q1 && q2 && alpha && d_logits && loss_out && h_out && B > 0 && A > 0,
+             PA_ERR_INVALID, "pa_dsac_actor_head: bad argument");
+  DsacArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ldl = ldl; a.q1 = q1; a.q2 = q2; a.mask = mask; a.alpha = alpha;
+  a.B = B; a.A = A; a.mode = 0;
+  a.d_logits = d_logits; a.ldd = ldd; a.loss_out = loss_out; a.h_out = h_out;
+  hipLaunchKernelGGL(dsac_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_dsac_target(const float* logits, int32_t ldl, const float* q1, const float* q2,
+                              const uint8_t* mask, const float* alpha, const float* reward,
+                              const uint8_t* terminated, float gamma, int32_t B, int32_t A,
+                              float* y, void* stream) {
+  PA_REQUIRE(logits && q1 && q2 && alpha && reward && terminated && y && B > 0 && A > 0,
+             PA_ERR_INVALID, "pa_dsac_target: bad argument");
+  DsacArgs a;
+  memset(&a, 0, sizeof(a));
+  a.logits = logits; a.ldl = ldl; a.q1 = q1; a.q2 = q2; a.mask = mask; a.alpha = alpha;
+  a.B = B; a.A = A; a.mode = 1;
+  a.reward = reward; a.term = terminated; a.gamma = gamma; a.y = y;
+  hipLaunchKernelGGL(dsac_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -1,0 +1,286 @@
+"""SoftActorCritic for discrete action spaces
+(reference: pearl/policy_learners/sequential_decision_making/soft_actor_critic.py:46-330).
+
+Same constructor, buffers and ``learn_batch`` effects as the reference: a softmax actor
+(``VanillaActorNetwork``), twin Q critics with target copies evaluated on EVERY available action of
+a state, the expected-value Bellman target ``sum_a pi(a|s') (min Q'(s', a) - alpha log pi(a|s'))``
+(:180-252), the actor objective ``mean(pi (alpha log pi - min Q))`` (:254-287), entropy-coefficient
+autotuning with Adam(eps=1e-4) towards ``-0.89 log(1/n)`` (:103-151), and the actor learning-rate
+decay (``ExponentialLR(0.99)`` stepped in ``reset``, :98-101, :128-130).
+
+All arithmetic runs in libpearl_amd on flat parameter views: the (B, A, S+AD) critic input is built
+by ``pa_expand_state_actions``, the twin critics run as paired launches over the B*A rows, the
+row-local softmax / expectation / gradient work is ``pa_dsac_actor_head`` / ``pa_dsac_target``,
+the entropy step ``pa_sac_alpha_step``.  No CPU path.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn, optim
+
+from ... import _native as N
+from ...action_representation_modules import ActionRepresentationModule
+from ...neural_networks.sequential_decision_making.actor_networks import VanillaActorNetwork
+from ...neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
+from ...replay_buffers.transition import TransitionBatch
+from ..exploration import ExplorationModule, PropensityExploration
+from ..policy_learner import PolicyLearner
+from .actor_critic_base import ActorCriticBase
+from .flat_mlp import FlatMlp, layers_of
+
+
+class SoftActorCritic(ActorCriticBase):
+    def __init__(self, action_space: Any, state_dim: Optional[int] = None,
+                 actor_hidden_dims: Optional[List[int]] = None,
+                 critic_hidden_dims: Optional[List[int]] = None,
+                 actor_learning_rate: float = 1e-4, critic_learning_rate: float = 1e-4,
+                 history_summarization_learning_rate: float = 1e-4,
+                 actor_network_type: type = VanillaActorNetwork,
+                 critic_network_type: type = VanillaQValueNetwork,
+                 critic_soft_update_tau: float = 0.005,
+                 exploration_module: Optional[ExplorationModule] = None,
+                 discount_factor: float = 0.99, training_rounds: int = 100, batch_size: int = 128,
+                 entropy_coef: float = 0.2, entropy_autotune: bool = True,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 actor_network_instance: Optional[nn.Module] = None,
+                 critic_network_instance: Optional[nn.Module] = None,
+                 target_entropy_scale: float = 0.89, **kwargs: Any) -> None:
+        if actor_network_type is not VanillaActorNetwork or critic_network_type is not VanillaQValueNetwork:
+            raise NotImplementedError("pearl_amd SoftActorCritic: only VanillaActorNetwork + "
+                                      "VanillaQValueNetwork twin critics have HIP kernels")
+        super().__init__(
+            state_dim=state_dim, action_space=action_space, actor_hidden_dims=actor_hidden_dims,
+            critic_hidden_dims=critic_hidden_dims, actor_learning_rate=actor_learning_rate,
+            critic_learning_rate=critic_learning_rate,
+            history_summarization_learning_rate=history_summarization_learning_rate,
+            actor_network_type=actor_network_type, critic_network_type=critic_network_type,
+            use_actor_target=False, use_critic_target=True, actor_soft_update_tau=0.0,
+            critic_soft_update_tau=critic_soft_update_tau, use_twin_critic=True,
+            exploration_module=(exploration_module if exploration_module is not None
+                                else PropensityExploration()),
+            discount_factor=discount_factor, training_rounds=training_rounds, batch_size=batch_size,
+            is_action_continuous=False, on_policy=False,
+            action_representation_module=action_representation_module,
+            actor_network_instance=actor_network_instance,
+            critic_network_instance=critic_network_instance, **kwargs)
+        # "needed to avoid actor softmax overflow" (:98-101); stepped in reset()
+        self.scheduler = optim.lr_scheduler.ExponentialLR(self._actor_optimizer, gamma=0.99)
+        self._entropy_autotune = entropy_autotune
+        if entropy_autotune:
+            self.register_parameter("_log_entropy", nn.Parameter(torch.zeros(1, requires_grad=True)))
+            self._entropy_optimizer: optim.Optimizer = optim.Adam(
+                [self._log_entropy], lr=self._critic_learning_rate, eps=1e-4)
+            self.register_buffer("_entropy_coef", torch.exp(self._log_entropy).detach())
+            assert hasattr(action_space, "n"), "SoftActorCritic needs a discrete action space"
+            self.register_buffer("_target_entropy",
+                                 -target_entropy_scale * torch.log(1.0 / torch.tensor(action_space.n)))
+        else:
+            self.register_buffer("_entropy_coef", torch.tensor(entropy_coef))
+        self._neg_entropy_rows: Tensor = torch.tensor(0.0)   # sum_a P log(P + 1e-8) per row (:275-276)
+
+    def reset(self, action_space: Any) -> None:
+        self._action_space = action_space
+        self.scheduler.step()
+
+    # ------------------------------------------------------------------ flat views
+    def _nets(self, batch_hint: int = 0, validate: bool = True):
+        """(actor, critic 1, critic 2).  The critics see B * A rows per batch."""
+        if not self._flat:
+            mb = max(self._batch_size, 1)
+            A = int(self.action_representation_module.max_number_actions)
+            self._flat["actor"] = FlatMlp(layers_of(self._actor.linear_layers()),
+                                          self._actor_optimizer, mb)
+            for i, (c, ct) in enumerate(((self._critic._critic_1, self._critic_target._critic_1),
+                                         (self._critic._critic_2, self._critic_target._critic_2)), 1):
+                self._flat[f"critic{i}"] = FlatMlp(layers_of(c.linear_layers()),
+                                                   self._critic_optimizer, mb * A,
+                                                   target_layers=layers_of(ct.linear_layers()))
+        A = self._flat["actor"].dims[-1]
+        nets = (self._flat["actor"], self._flat["critic1"], self._flat["critic2"])
+        hints = (batch_hint, batch_hint * A, batch_hint * A)
+        if validate:
+            return tuple(m.ensure(h) for m, h in zip(nets, hints))
+        return tuple(m.ready(h) for m, h in zip(nets, hints))
+
+    def _alpha_state(self, dev: torch.device) -> Dict[str, Any]:
+        """Device scalars of the entropy coefficient and (autotune) its Adam state."""
+        st = self._flat.get("alpha")
+        if st is not None and st["alpha"].device == dev:
+            return st
+        st = {"alpha": self._entropy_coef.detach().to(dev, torch.float32).reshape(1).clone()}
+        if self._entropy_autotune:
+            ost = self._entropy_optimizer.state.get(self._log_entropy, {})
+            for k in ("exp_avg", "exp_avg_sq"):
+                st[k] = (ost[k].to(dev, torch.float32).reshape(1).clone() if k in ost
+                         else torch.zeros(1, device=dev))
+            st["step"] = int(float(ost["step"])) if "step" in ost else 0
+            if self._log_entropy.device != dev:
+                self._log_entropy.data = self._log_entropy.data.to(dev)
+            self._entropy_optimizer.state[self._log_entropy] = {
+                "step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"],
+                "exp_avg_sq": st["exp_avg_sq"]}
+        self._entropy_coef = st["alpha"].reshape(self._entropy_coef.shape)
+        self._flat["alpha"] = st
+        return st
+
+    def _target_entropy_value(self) -> float:
+        """The target entropy as a host float, read from the (device) buffer once per value — a
+        per-step ``float(buffer)`` is a host synchronisation that stops ``learn()`` from running
+        ahead of the device."""
+        t = self._target_entropy
+        hit = self._flat.get("target_entropy")
+        if hit is None or hit[0] is not t or hit[1] != t._version:
+            hit = (t, t._version, float(t))
+            self._flat["target_entropy"] = hit
+        return hit[2]
+
+    @staticmethod
+    def _f32(t: Tensor, dev: torch.device) -> Tensor:
+        return t.to(device=dev, dtype=torch.float32).contiguous()
+
+    def _all_action_input(self, state: Tensor, rep: Tensor) -> Tensor:
+        """[B * A, S + AD]: every state next to each of its available actions' representation."""
+        B, S = state.shape
+        A, AD = int(rep.shape[-2]), int(rep.shape[-1])
+        x = torch.empty(B * A, S + AD, dtype=torch.float32, device=state.device)
+        N.check(N.lib().pa_expand_state_actions(
+            state.data_ptr(), state.stride(0), rep.data_ptr(), A * AD if rep.ndim == 3 else 0, B, A,
+            S, AD, x.data_ptr(), N.stream_ptr(state.device)))
+        return x
+
+    @staticmethod
+    def _mask_u8(mask: Optional[Tensor], dev: torch.device) -> Optional[Tensor]:
+        return None if mask is None else mask.to(dev).to(torch.uint8).contiguous()
+
+    # ------------------------------------------------------------------ losses
+    def _actor_update(self, batch: TransitionBatch) -> Tensor:
+        actor, c1, c2 = self._nets(len(batch))
+        dev = actor.device
+        al = self._alpha_state(dev)
+        state = self._f32(batch.state, dev)
+        B = state.shape[0]
+        A = actor.dims[-1]
+        s = N.stream_ptr(dev)
+        assert batch.curr_available_actions is not None, "SoftActorCritic needs curr_available_actions"
+        rep = self._f32(batch.curr_available_actions, dev)
+        assert rep.shape[-2] == A, "the actor outputs one logit per available-action slot"
+        # min Q(s, a) for every available action; the reference lets this loss reach the critics'
+        # parameters too, then discards those gradients (actor_critic_base.py:342-348)
+        q1, q2 = FlatMlp.forward_pair(c1, c2, self._all_action_input(state, rep))
+        logits = actor.forward(state, keep=True)
+        d_logits = torch.empty_like(logits)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        h = torch.empty(B, dtype=torch.float32, device=dev)
+        mask = self._mask_u8(batch.curr_unavailable_actions_mask, dev)
+        N.check(N.lib().pa_dsac_actor_head(logits.data_ptr(), logits.stride(0), q1.data_ptr(),
+                                           q2.data_ptr(), N.ptr(mask), al["alpha"].data_ptr(), B, A,
+                                           d_logits.data_ptr(), d_logits.stride(0), loss.data_ptr(),
+                                           h.data_ptr(), s))
+        self._neg_entropy_rows = h
+        actor.backward(state, d_logits, want_dw=True)
+        actor.adam()
+        return loss[0]
+
+    def _critic_update(self, batch: TransitionBatch) -> Tensor:
+        actor, c1, c2 = self._nets(len(batch), validate=False)
+        dev = actor.device
+        al = self._alpha_state(dev)
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        A = actor.dims[-1]
+        s = N.stream_ptr(dev)
+        # ---- expected next-state value under the (already updated) policy (:180-252)
+        assert batch.next_available_actions is not None, "SoftActorCritic needs next_available_actions"
+        nrep = self._f32(batch.next_available_actions, dev)
+        nq1, nq2 = FlatMlp.forward_pair(c1, c2, self._all_action_input(nstate, nrep), use_target=True)
+        nlogits = actor.forward(nstate)
+        y = torch.empty(B, dtype=torch.float32, device=dev)
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
+        nmask = self._mask_u8(batch.next_unavailable_actions_mask, dev)
+        N.check(N.lib().pa_dsac_target(nlogits.data_ptr(), nlogits.stride(0), nq1.data_ptr(),
+                                       nq2.data_ptr(), N.ptr(nmask), al["alpha"].data_ptr(),
+                                       reward.data_ptr(), term.data_ptr(),
+                                       float(self._discount_factor), B, A, y.data_ptr(), s))
+        # ---- (mse(q1, y) + mse(q2, y)) / 2 on the taken action (critic_utils.py:170-203)
+        act = self._f32(batch.action, dev).reshape(B, -1)
+        AD = act.shape[1]
+        xq = torch.empty(B, S + AD, dtype=torch.float32, device=dev)
+        N.check(N.lib().pa_concat_cols(state.data_ptr(), state.stride(0), act.data_ptr(),
+                                       act.stride(0), xq.data_ptr(), B, S, AD, s))
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, keep=True)]
+        dqs = [torch.empty_like(q) for q in qs]
+        for i in range(2):
+            N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
+                                        dqs[i].data_ptr(), loss.data_ptr(), s))
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        c1.adam()
+        c2.adam()
+        return loss[0]
+
+    def _update_critic_target(self) -> None:
+        _, c1, c2 = self._nets(validate=False)
+        c1.soft_update(self._critic_soft_update_tau)
+        c2.soft_update(self._critic_soft_update_tau)
+
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        report = super()._learn_batch_device(batch)
+        if self._entropy_autotune:
+            actor, _, _ = self._nets(validate=False)
+            dev = actor.device
+            al = self._alpha_state(dev)
+            g = self._entropy_optimizer.param_groups[0]
+            al["step"] += 1
+            loss = torch.empty(1, dtype=torch.float32, device=dev)
+            # loss = exp(log_alpha) (entropy - target), entropy = -mean_b sum_a P log(P + 1e-8)
+            #      = mean_b( -exp(log_alpha) (h_b + target) ): pa_sac_alpha_step's form with h as
+            #        the "log-prob" column (:134-151)
+            h = self._neg_entropy_rows
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                h = h.mean().reshape(1)
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                h = (h / dist.get_world_size()).contiguous()
+            N.check(N.lib().pa_sac_alpha_step(
+                self._log_entropy.data.data_ptr(), al["exp_avg"].data_ptr(),
+                al["exp_avg_sq"].data_ptr(), None, al["alpha"].data_ptr(), h.data_ptr(),
+                int(h.numel()), self._target_entropy_value(), g["lr"], g["betas"][0], g["betas"][1],
+                g["eps"], g["weight_decay"], 0, al["step"], loss.data_ptr(), N.stream_ptr(dev)))
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(float(al["step"]))
+            report = {**report, "entropy_coef": loss[0]}
+        return report
+
+    def act(self, subjective_state: Tensor, available_action_space: Any, exploit: bool = False) -> Any:
+        """actor_critic_base.py:245-303 (act-time only; torch expression of the same network)."""
+        with torch.no_grad():
+            probs = self._actor.get_policy_distribution(
+                state_batch=subjective_state,
+                available_actions=self.action_representation_module(
+                    available_action_space.actions_batch.to(subjective_state.device)))
+            exploit_action = available_action_space.actions[int(torch.argmax(probs))]
+        if exploit:
+            return exploit_action
+        return self.exploration_module.act(exploit_action=exploit_action,
+                                           action_space=available_action_space,
+                                           subjective_state=subjective_state, values=probs)
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, SoftActorCritic):
+            diffs.append("other is not an instance of SoftActorCritic")
+        else:
+            if self._entropy_autotune != other._entropy_autotune:
+                diffs.append(f"_entropy_autotune is different: {self._entropy_autotune} vs "
+                             f"{other._entropy_autotune}")
+            if not torch.allclose(self._entropy_coef.cpu(), other._entropy_coef.cpu()):
+                diffs.append(f"_entropy_coef is different: {self._entropy_coef} vs "
+                             f"{other._entropy_coef}")
+            if self._entropy_autotune and not torch.allclose(self._target_entropy.cpu(),
+                                                             other._target_entropy.cpu()):
+                diffs.append(f"_target_entropy is different: {self._target_entropy} vs "
+                             f"{other._target_entropy}")
+        return "\n".join(d for d in diffs if d)

@@ -139,6 +139,17 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             self._flat["bounds"] = hit
         return hit[2], hit[3]
 
+    def _target_entropy_value(self) -> float:
+        """The target entropy as a host float, read from the (device) buffer once per value — a
+        per-step ``float(buffer)`` is a host synchronisation that stops ``learn()`` from running
+        ahead of the device."""
+        t = self._target_entropy
+        hit = self._flat.get("target_entropy")
+        if hit is None or hit[0] is not t or hit[1] != t._version:
+            hit = (t, t._version, float(t))
+            self._flat["target_entropy"] = hit
+        return hit[2]
+
     @staticmethod
     def _f32(t: Tensor, dev: torch.device) -> Tensor:
         return t.to(device=dev, dtype=torch.float32).contiguous()
@@ -255,7 +266,7 @@ class ContinuousSoftActorCritic(ActorCriticBase):
                 self._log_entropy.data.data_ptr(), al["exp_avg"].data_ptr(),
                 al["exp_avg_sq"].data_ptr(), al["max_exp_avg_sq"].data_ptr(),
                 al["alpha"].data_ptr(), logp.data_ptr(), int(logp.numel()),
-                float(self._target_entropy), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                self._target_entropy_value(), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                 g["weight_decay"], int(bool(g["amsgrad"])), al["step"], loss.data_ptr(),
                 N.stream_ptr(dev)))
             self._entropy_optimizer.state[self._log_entropy]["step"].fill_(float(al["step"]))

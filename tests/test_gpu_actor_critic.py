@@ -285,3 +285,73 @@ def test_td3_learn_from_replay_defers_readback_and_delays_actor():
     assert len(al) == len(cl) == 6 and all(map(lambda v: v == v and abs(v) < 1e6, al + cl))
     # _training_steps runs 1..6 inside learn(): the actor steps on 2, 4, 6
     assert al[0] == 0.0 and al[1] != 0.0 and al[2] == al[1] and al[3] != al[2] and al[4] == al[3]
+
+
+def make_dsac(fx):
+    from pearl_amd import (BasicReplayBuffer, OneHotActionTensorRepresentationModule, PearlAgent,
+                           SoftActorCritic)
+    cfg = fx["config"]
+    pl = SoftActorCritic(action_space=dspace(cfg["A"]), state_dim=cfg["S"],
+                         actor_hidden_dims=cfg["hidden"], critic_hidden_dims=cfg["hidden"],
+                         batch_size=cfg["B"],
+                         action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    pl._actor.load_state_dict(fx["actor0"])
+    pl._critic.load_state_dict(fx["critic0"])
+    pl._critic_target.load_state_dict(fx["critic_target0"])
+    PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+    return pl
+
+
+@pytest.mark.parametrize("name", ["dsac_tiny", "dsac_shape_small"])
+def test_discrete_sac_learn_batch_trajectory(name):
+    """SoftActorCritic.learn_batch on the batch shape BasicReplayBuffer.sample() returns (padded
+    action tables + masks, dynamic action counts in `dsac_tiny`) against the reference run: losses
+    and the entropy-coefficient loss per call, then actor / critics / targets / log-alpha."""
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    pl = make_dsac(fx)
+    # the all-action critic input and Q-values of the first batch
+    b = pl.preprocess_batch(sac_batch(fx))
+    actor, c1, c2 = pl._nets(fx["config"]["B"])
+    x = pl._all_action_input(b.state.contiguous(), b.curr_available_actions.contiguous())
+    q1, q2 = (q.view(fx["config"]["B"], -1) for q in
+              __import__("pearl_amd").policy_learners.sequential_decision_making.flat_mlp.FlatMlp
+              .forward_pair(c1, c2, x))
+    torch.testing.assert_close(q1.cpu(), fx["probe"]["q1"], rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(q2.cpu(), fx["probe"]["q2"], rtol=1e-5, atol=2e-6)
+    for step, want in enumerate(fx["reports"]):
+        got = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+        tol = 1e-5 if step == 0 else 5e-4
+        for k in want:
+            assert abs(float(got[k]) - want[k]) <= tol * max(1.0, abs(want[k])), (step, k, float(got[k]), want[k])
+    torch.testing.assert_close(pl._log_entropy.detach().cpu(), fx["log_entropy_after"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pl._entropy_coef.cpu().view(-1), fx["entropy_coef_after"].view(-1), rtol=1e-4, atol=1e-6)
+    for name_, mod, key in (("actor", pl._actor, "actor_after"), ("critic", pl._critic, "critic_after"),
+                            ("critic_target", pl._critic_target, "critic_target_after")):
+        for k, v in mod.state_dict().items():
+            torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
+
+
+def test_discrete_sac_learn_from_replay():
+    """PearlAgent.learn() end to end: arena with per-row action tables -> sample -> preprocess ->
+    learn_batch x rounds, one readback; finite losses and a moving entropy coefficient."""
+    from pearl_amd import (BasicReplayBuffer, OneHotActionTensorRepresentationModule, PearlAgent,
+                           SoftActorCritic)
+    S, A, B, n = 10, 4, 32, 500
+    torch.manual_seed(0)
+    random.seed(0)
+    pl = SoftActorCritic(action_space=dspace(A), state_dim=S, actor_hidden_dims=[32, 32],
+                         critic_hidden_dims=[32, 32], batch_size=B, training_rounds=5,
+                         action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = BasicReplayBuffer(n, sampler="device")
+    agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+    st = torch.randn(n + 1, S, device=DEV)
+    ids = torch.arange(n, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 5).float(),
+                 terminated=(ids % 40 == 0), truncated=torch.zeros(n, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=dspace(A),
+                 next_available_actions=dspace(A), max_number_actions=A)
+    alpha0 = float(pl._entropy_coef)
+    report = agent.learn()
+    for k in ("actor_loss", "critic_loss", "entropy_coef"):
+        assert len(report[k]) == 5 and all(v == v and abs(v) < 1e6 for v in report[k]), k
+    assert float(pl._entropy_coef) != alpha0

@@ -153,3 +153,38 @@ def test_ddpg_td3_probe_and_trajectory(name):
                                fx["critic_after"]["_critic_2._model.0.0.weight"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(orc.ct[0][1][1],
                                fx["critic_target_after"]["_critic_1._model.1.0.bias"], rtol=1e-5, atol=1e-7)
+
+
+def preprocessed_dsac_batch(fx):
+    """PolicyLearner.preprocess_batch (policy_learner.py:197-218) of the stored raw batch."""
+    A = fx["config"]["A"]
+    b = {k: v.clone() for k, v in fx["batch"].items()}
+    b["action"] = onehot(b["action"].view(-1), A)
+    for k in ("curr_available_actions", "next_available_actions"):
+        b[k] = onehot(b[k].squeeze(-1), A)
+    return b
+
+
+@pytest.mark.parametrize("name", ["dsac_tiny", "dsac_shape_small"])
+def test_discrete_sac_probe_and_trajectory(name):
+    from oracle.actor_critic_oracle import DiscreteSacOracle
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    orc = DiscreteSacOracle(fx["actor0"], fx["critic0"], fx["critic_target0"], fx["config"]["A"])
+    b = preprocessed_dsac_batch(fx)
+    with torch.no_grad():
+        torch.testing.assert_close(orc.policy(b["state"]), fx["probe"]["policy"], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(orc.q_all(orc.c[0], b["state"], b["curr_available_actions"]),
+                                   fx["probe"]["q1"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(orc.q_all(orc.c[1], b["state"], b["curr_available_actions"]),
+                                   fx["probe"]["q2"], rtol=1e-5, atol=1e-6)
+    for k, want in enumerate(fx["reports"]):
+        got = orc.learn_batch(b)
+        for key in want:
+            assert abs(got[key] - want[key]) <= 2e-5 * max(1.0, abs(want[key])), (k, key, got[key], want[key])
+    torch.testing.assert_close(orc.log_alpha.detach(), fx["log_entropy_after"], rtol=1e-5, atol=1e-7)
+    for i, (w, _) in enumerate(orc.actor):
+        torch.testing.assert_close(w.detach(), fx["actor_after"][f"_model.{i}.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.c[0][0][0].detach(),
+                               fx["critic_after"]["_critic_1._model.0.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.ct[1][0][0],
+                               fx["critic_target_after"]["_critic_2._model.0.0.weight"], rtol=1e-5, atol=1e-7)
