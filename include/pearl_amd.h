@@ -377,6 +377,16 @@ int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int3
 /* autograd of the kept forward: dW/db into bufs.grad (want_dw) and/or d_x[B, d_0] (nullable). */
 int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
                     int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx, void* stream);
+/* Q(s_b, a_i) of a [S + AD, H1, H2, 1] ReLU critic for every action of an action set,
+ * q_out[b * A + i] (TwinCritic.get_q_values on (B, A, AD) actions, twin_critic.py:75-91,
+ * q_value_networks.py:152-174), through DQN's fused all-actions kernel: no (B A, S + AD) expansion
+ * and no hidden activations in HBM.  rep: [rows, A, AD] (rep_bstride = A * AD) or one shared
+ * [A, AD] table (rep_bstride = 0).  Needs H1, H2 <= 256, A <= 64, rows <= max_batch;
+ * PA_ERR_UNSUPPORTED otherwise (callers then expand the input and use pa_mlp_forward). */
+int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, int32_t ld_state,
+                 const float* rep, int64_t rep_bstride, int32_t rows, int32_t A, int32_t AD,
+                 float* q_out, void* stream);
+
 /* Two networks of the same depth on the same input in lock-step (TwinCritic, twin_critic.py:22-91;
  * PPO's actor and critic): the same arithmetic as two pa_mlp_forward / pa_mlp_backward calls, with
  * every layer of both networks in one launch.  Layer widths may differ.  d_x1 / d_x2 are both

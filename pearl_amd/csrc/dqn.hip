@@ -153,33 +153,6 @@ struct ScopedTimer {
   }
 };
 
-// every operand 16-byte aligned with pitches that are multiples of 4, AD <= 16, all eight waves of
-// a workgroup own hidden units in both layers: the kernels' FAST instantiation applies
-bool target_fast_shape(const TargetArgs& a, int nkg) {
-  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-  return al(a.U) && al(a.feat) && al(a.W1a) && al(a.b2) && al(a.w3) && (a.ldu & 3) == 0 &&
-         (a.AD & 3) == 0 && a.AD <= 16 && (a.feat_bstride & 3) == 0 && (a.ldw1 & 3) == 0 &&
-         a.H1 == nkg * 8 && a.H2 == 256 && nkg * 8 >= 256;
-}
-
-template <int NKG, bool FAST>
-int launch_target_t(const TargetArgs& a, hipStream_t s) {
-  static bool configured = false;
-  const size_t smem = target_smem_bytes(a.H1);
-  if (!configured) {
-    int rc = set_max_smem(target_fused_kernel<NKG, FAST>, smem);
-    if (rc != PA_OK) return rc;
-    configured = true;
-  }
-  // persistent mode: three workgroups per CU are offered; two fit (LDS), the surplus and the ones
-  // on reserved CUs exit immediately
-  const unsigned grid = a.tile_ctr ? (unsigned)(3 * a.ntiles < 3 * 256 ? 3 * a.ntiles : 3 * 256)
-                                   : (unsigned)ceil_div(a.B, a.bpw);
-  hipLaunchKernelGGL((target_fused_kernel<NKG, FAST>), dim3(grid), dim3(512), smem, s, a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
-}
-
 // One 16-wave workgroup per CU, two teams alternating main loop and epilogue / prologue
 // (target_pp_kernel.hpp).  Always work-stealing: a.tile_ctr must point at a zeroed counter.
 template <int NKG>
@@ -210,15 +183,6 @@ int launch_target_pp(const TargetArgs& a, int ncu, hipStream_t s) {
   }
 }
 
-int launch_target(const TargetArgs& a, hipStream_t s) {
-  switch (t_nkg(a.H1)) {
-    case 8: return launch_target_t<8, false>(a, s);
-    case 16: return launch_target_t<16, false>(a, s);
-    default:
-      return target_fast_shape(a, 32) ? launch_target_t<32, true>(a, s)
-                                      : launch_target_t<32, false>(a, s);
-  }
-}
 
 struct NetPtrs {
   const float *W1, *b1, *W2, *b2, *W3, *b3;

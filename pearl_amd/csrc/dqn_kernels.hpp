@@ -329,6 +329,8 @@ struct TargetArgs {
   int* argmax;               // optional [B]: index of the FIRST row maximum (torch.max(1)[1];
                              // Double DQN's action choice, double_dqn.py:47)
   float* choice_rep;         // with argmax: [B][AD] = feat row of that action (double_dqn.py:48-51)
+  float* q_all;              // optional [B * A]: every (transition, action) value before masking
+                             // (TwinCritic.get_q_values on an action set, discrete SAC)
 };
 
 // (XCC_ID, HW_ID.se_id|sh_id|cu_id) of the compute unit the calling wave runs on
@@ -602,6 +604,7 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
 #pragma unroll
     for (int w = 0; w < 8; ++w) q += qpart[w * 64 + tid];
     q += a.b3[0];
+    if (a.q_all && tid < nrows) a.q_all[(int64_t)b0 * a.A + tid] = q;
     if (tid < nrows && a.mask) {
       const int bb = b0 + tid / a.A, i = tid % a.A;
       if (a.mask[(int64_t)bb * a.mask_bstride + i]) q = -INFINITY;

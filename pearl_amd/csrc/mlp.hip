@@ -35,6 +35,10 @@ struct pa_mlp {
   float* db_scratch;              // column sums of a bias-free last layer go here
   float* loss_scratch;
   int kept_B;                     // batch size of the kept forward (0 = none)
+  // pa_mlp_q_all (allocated on first use): fragment-major copy of W2 and the first layer's state
+  // product [max_batch, H1], the two operands target_fused_kernel needs beside the parameters
+  float* qa_w2f;
+  float* qa_u;
 };
 
 namespace {
@@ -99,6 +103,8 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
     if (h->dz[i]) (void)hipFree(h->dz[i]);
   if (h->db_scratch) (void)hipFree(h->db_scratch);
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
+  if (h->qa_w2f) (void)hipFree(h->qa_w2f);
+  if (h->qa_u) (void)hipFree(h->qa_u);
   delete h;
   return PA_OK;
 }
@@ -269,6 +275,62 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
     }
   }
   return PA_OK;
+}
+
+// Q(s_b, a_i) of a state-action critic for EVERY action of an action set, q_out[b * A + i]
+// (TwinCritic.get_q_values on (B, A, AD) actions, twin_critic.py:75-91 / q_value_networks.py:152-174,
+// which the reference computes on the (B, A, S + AD) expansion of the states).  For the
+// two-hidden-layer critics this is exactly what DQN's target_fused_kernel computes before its row
+// max: the state half of layer 1 once per state (U = s W1s^T + b1, one linear launch), the action
+// half, layer 2 out of one LDS tile and layer 3 per 64-row tile of (state, action) pairs — no
+// (B A, S + AD) input and no hidden activations in HBM.  `rows` = number of STATES (<= max_batch).
+extern "C" int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, int32_t ld_state,
+                            const float* rep, int64_t rep_bstride, int32_t rows, int32_t A,
+                            int32_t AD, float* q_out, void* stream) {
+  PA_REQUIRE(h && h->bound && state && rep && q_out && rows > 0 && A > 0 && AD > 0, PA_ERR_INVALID,
+             "pa_mlp_q_all: bad argument");
+  const pa_mlp_desc& d = h->d;
+  const int S = d.dims[0] - AD;
+  PA_REQUIRE(h->L == 3 && d.dims[3] == 1 && S > 0 && d.identity_layers == 0 && !d.no_last_bias &&
+                 d.dims[1] <= 256 && d.dims[2] <= 256 && A <= T_ROWS && rows <= d.max_batch,
+             PA_ERR_UNSUPPORTED,
+             "pa_mlp_q_all: needs a [S + AD, H1 <= 256, H2 <= 256, 1] ReLU critic, A <= %d and "
+             "rows <= max_batch",
+             T_ROWS);
+  const float* P = use_target ? h->bufs.p_target : h->bufs.p;
+  PA_REQUIRE(P, PA_ERR_INVALID, "no target parameters bound");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(d.device));
+  const int H1 = d.dims[1], H2 = d.dims[2];
+  if (!h->qa_w2f) {
+    PA_HIP(hipMalloc((void**)&h->qa_w2f, (size_t)w2f_floats(H2, H1) * sizeof(float)));
+    PA_HIP(hipMalloc((void**)&h->qa_u, (size_t)d.max_batch * H1 * sizeof(float)));
+  }
+  // the parameters may have stepped since the last call: rebuild the fragment-major W2 (3 us)
+  hipLaunchKernelGGL(repack_w2_kernel, dim3(64), dim3(256), 0, s, P + h->woff[1], H2, H1, h->qa_w2f);
+  PA_LAUNCH_CHECK();
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = state; g.lda = ld_state;
+  g.Bm = P + h->woff[0]; g.ldb = d.dims[0];
+  g.C = h->qa_u; g.ldc = H1;
+  g.bias = P + h->boff[0];
+  g.M = rows; g.N = H1; g.K = S;
+  g.epi = EPI_BIAS;
+  int rc = launch_linear<false>(&g, 1, s);
+  if (rc != PA_OK) return rc;
+  TargetArgs a;
+  memset(&a, 0, sizeof(a));
+  a.U = h->qa_u; a.ldu = H1;
+  a.feat = rep; a.feat_bstride = rep_bstride;
+  a.W1a = P + h->woff[0] + S; a.ldw1 = d.dims[0];
+  a.W2f = h->qa_w2f;
+  a.b2 = P + h->boff[1]; a.w3 = P + h->woff[2]; a.b3 = P + h->boff[2];
+  a.q_all = q_out;
+  a.B = rows; a.A = A; a.AD = AD; a.H1 = H1; a.H2 = H2;
+  a.bpw = T_ROWS / A;
+  a.ntiles = (int)ceil_div(rows, a.bpw);
+  return launch_target(a, s);
 }
 
 // ---- two networks of the same depth on the same input in lock-step (TwinCritic,

@@ -225,6 +225,26 @@ class FlatMlp:
                                         N.ptr(d_x), self.dims[0], N.stream_ptr(x.device)))
         return d_x
 
+    def supports_q_all(self, n_actions: int) -> bool:
+        """pa_mlp_q_all's shapes: a [S + AD, H1 <= 256, H2 <= 256, 1] ReLU critic, <= 64 actions."""
+        return (len(self.dims) == 4 and self.dims[3] == 1 and max(self.dims[1:3]) <= 256
+                and self.identity_layers == 0 and len(self.layers[-1][1]) > 0 and n_actions <= 64)
+
+    def q_all(self, state: torch.Tensor, rep: torch.Tensor, use_target: bool = False) -> torch.Tensor:
+        """Q(s_b, a_i) for every action of every state's action set: (B * A,), row b * A + i —
+        TwinCritic.get_q_values on an action set (twin_critic.py:75-91) through the fused
+        all-actions kernel (no (B A, S + AD) input, no hidden activations in HBM)."""
+        assert state.dtype == torch.float32 and state.is_cuda and state.stride(-1) == 1
+        assert rep.dtype == torch.float32 and rep.is_contiguous() and rep.ndim in (2, 3)
+        B = int(state.shape[0])
+        A, AD = int(rep.shape[-2]), int(rep.shape[-1])
+        self.ready(B)
+        out = torch.empty(B * A, dtype=torch.float32, device=state.device)
+        N.check(N.lib().pa_mlp_q_all(self.handle, int(use_target), state.data_ptr(), state.stride(0),
+                                     rep.data_ptr(), A * AD if rep.ndim == 3 else 0, B, A, AD,
+                                     out.data_ptr(), N.stream_ptr(state.device)))
+        return out
+
     @staticmethod
     def forward_pair(m1: "FlatMlp", m2: "FlatMlp", x: torch.Tensor, use_target: bool = False,
                      keep: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:

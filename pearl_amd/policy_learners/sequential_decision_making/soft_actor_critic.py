@@ -8,10 +8,13 @@ a state, the expected-value Bellman target ``sum_a pi(a|s') (min Q'(s', a) - alp
 autotuning with Adam(eps=1e-4) towards ``-0.89 log(1/n)`` (:103-151), and the actor learning-rate
 decay (``ExponentialLR(0.99)`` stepped in ``reset``, :98-101, :128-130).
 
-All arithmetic runs in libpearl_amd on flat parameter views: the (B, A, S+AD) critic input is built
-by ``pa_expand_state_actions``, the twin critics run as paired launches over the B*A rows, the
-row-local softmax / expectation / gradient work is ``pa_dsac_actor_head`` / ``pa_dsac_target``,
-the entropy step ``pa_sac_alpha_step``.  No CPU path.
+All arithmetic runs in libpearl_amd on flat parameter views.  The critics' values on every
+available action come from ``pa_mlp_q_all`` — DQN's fused all-actions kernel (state half of layer 1
+once per state, layers 2-3 out of one LDS tile per 64 (state, action) rows) — for the
+[S+AD, <=256, <=256, 1] critics it supports; other shapes expand the (B, A, S+AD) input
+(``pa_expand_state_actions``) and run the twin critics as paired launches over the B*A rows.  The
+row-local softmax / expectation / gradient work is ``pa_dsac_actor_head`` / ``pa_dsac_target``, the
+entropy step ``pa_sac_alpha_step``.  No CPU path.
 """
 from __future__ import annotations
 
@@ -151,6 +154,15 @@ class SoftActorCritic(ActorCriticBase):
             S, AD, x.data_ptr(), N.stream_ptr(state.device)))
         return x
 
+    def _twin_q_all(self, c1: FlatMlp, c2: FlatMlp, state: Tensor, rep: Tensor, use_target: bool):
+        """(q1, q2), each (B * A,): both critics on every (state, available action) pair."""
+        if c1.supports_q_all(int(rep.shape[-2])) and c2.supports_q_all(int(rep.shape[-2])):
+            return (c1.q_all(state, rep, use_target=use_target),
+                    c2.q_all(state, rep, use_target=use_target))
+        q1, q2 = FlatMlp.forward_pair(c1, c2, self._all_action_input(state, rep),
+                                      use_target=use_target)
+        return q1.reshape(-1), q2.reshape(-1)
+
     @staticmethod
     def _mask_u8(mask: Optional[Tensor], dev: torch.device) -> Optional[Tensor]:
         return None if mask is None else mask.to(dev).to(torch.uint8).contiguous()
@@ -169,7 +181,7 @@ class SoftActorCritic(ActorCriticBase):
         assert rep.shape[-2] == A, "the actor outputs one logit per available-action slot"
         # min Q(s, a) for every available action; the reference lets this loss reach the critics'
         # parameters too, then discards those gradients (actor_critic_base.py:342-348)
-        q1, q2 = FlatMlp.forward_pair(c1, c2, self._all_action_input(state, rep))
+        q1, q2 = self._twin_q_all(c1, c2, state, rep, use_target=False)
         logits = actor.forward(state, keep=True)
         d_logits = torch.empty_like(logits)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
@@ -196,7 +208,7 @@ class SoftActorCritic(ActorCriticBase):
         # ---- expected next-state value under the (already updated) policy (:180-252)
         assert batch.next_available_actions is not None, "SoftActorCritic needs next_available_actions"
         nrep = self._f32(batch.next_available_actions, dev)
-        nq1, nq2 = FlatMlp.forward_pair(c1, c2, self._all_action_input(nstate, nrep), use_target=True)
+        nq1, nq2 = self._twin_q_all(c1, c2, nstate, nrep, use_target=True)
         nlogits = actor.forward(nstate)
         y = torch.empty(B, dtype=torch.float32, device=dev)
         reward = self._f32(batch.reward, dev).reshape(B)

@@ -355,3 +355,29 @@ def test_discrete_sac_learn_from_replay():
     for k in ("actor_loss", "critic_loss", "entropy_coef"):
         assert len(report[k]) == 5 and all(v == v and abs(v) < 1e6 for v in report[k]), k
     assert float(pl._entropy_coef) != alpha0
+
+
+@pytest.mark.parametrize("S,AD,A,hidden,B,bcast", [(128, 16, 16, [256, 256], 300, False),
+                                                   (5, 3, 3, [16, 12], 16, False),
+                                                   (20, 7, 5, [100, 60], 33, True),
+                                                   (64, 8, 64, [128, 256], 9, False)])
+def test_q_all_matches_expanded_forward(S, AD, A, hidden, B, bcast):
+    """pa_mlp_q_all (the fused all-actions kernel) == the critic's plain forward on the expanded
+    (B A, S + AD) input, online and target parameters, to 1e-5."""
+    from torch import nn, optim
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    torch.manual_seed(11)
+    dims = [S + AD] + hidden + [1]
+    mk = lambda: [nn.Linear(dims[i], dims[i + 1]).to(DEV) for i in range(3)]
+    lins, tgt = mk(), mk()
+    m = FlatMlp(layers_of(lins), optim.AdamW([p for l in lins for p in l.parameters()], amsgrad=True),
+                max_batch=B * A, target_layers=layers_of(tgt))
+    assert m.supports_q_all(A)
+    state = torch.randn(B, S, device=DEV)
+    rep = torch.randn(A, AD, device=DEV) if bcast else torch.randn(B, A, AD, device=DEV)
+    full = rep.expand(B, A, AD) if bcast else rep
+    x = torch.cat([state.unsqueeze(1).expand(B, A, S), full], dim=-1).reshape(B * A, S + AD).contiguous()
+    for use_target in (False, True):
+        want = m.forward(x, use_target=use_target).view(-1)
+        got = m.q_all(state, rep, use_target=use_target)
+        torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
