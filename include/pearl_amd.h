@@ -451,6 +451,21 @@ int pa_dsac_target(const float* logits, int32_t ldl, const float* q1, const floa
                    const uint8_t* terminated, float gamma, int32_t B, int32_t A, float* y,
                    void* stream);
 
+/* ImplicitQLearning (implicit_q_learning.py:159-285).
+ * pa_iql_value_head: expectile regression of V(s) (v, pitch ldv) towards a target critic's Q(s, a)
+ *   (tq_value): loss = mean(w d^2), d = tq - v, w = expectile if d > 0 else 1 - expectile (:186-196,
+ *   :271-285), dv = its gradient; adv_out = min(exp((tq_actor - v) temperature), adv_clamp), the
+ *   detached advantage weights of the policy extraction (:203-215).
+ * pa_awr_head: advantage-weighted regression (:197-246).  mode 0 (deterministic actor): x = the
+ *   predicted actions, loss = mean_b(adv_b mean_j (x - action)^2).  mode 1 (softmax actor): x = the
+ *   logits, action one-hot, loss = -mean_b(adv_b log softmax(x)[argmax action]).  dx = d loss / d x. */
+int pa_iql_value_head(const float* tq_value, const float* tq_actor, const float* v, int32_t ldv,
+                      float expectile, float temperature, float adv_clamp, int32_t B, float* dv,
+                      float* adv_out, float* loss_out, void* stream);
+int pa_awr_head(int32_t mode, const float* x, int32_t ldx, const float* action, int32_t lda,
+                const float* adv, int32_t B, int32_t A, float* dx, int32_t lddx, float* loss_out,
+                void* stream);
+
 /* Deterministic policies (DDPG ddpg.py:106-156, TD3 td3.py:106-201).
  * pa_tanh_action: VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485) from the
  * actor's pre-tanh outputs: a = ((high - low) (tanh(z) + 1)) / 2 + low.  With `noise` ([B, A]

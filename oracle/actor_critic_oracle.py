@@ -270,6 +270,76 @@ class DiscreteSacOracle:
 
 
 # --------------------------------------------------------------------------------------
+# implicit Q-learning
+# --------------------------------------------------------------------------------------
+class IqlOracle:
+    """ImplicitQLearning (implicit_q_learning.py:159-285) with a deterministic tanh actor
+    (``continuous=True``: weighted MSE on the action) or a softmax actor (weighted log-likelihood)."""
+
+    def __init__(self, actor_sd, value_sd, critic_sd, critic_target_sd, continuous: bool,
+                 low: Tensor = None, high: Tensor = None, gamma: float = 0.99, tau: float = 0.05,
+                 lr: float = 1e-3, expectile: float = 0.5, temperature: float = 0.5,
+                 adv_clamp: float = 100.0) -> None:
+        self.actor = _layers(actor_sd)
+        self.value = _layers(value_sd)
+        self.c = [_layers(critic_sd, f"_critic_{i}._model.") for i in (1, 2)]
+        self.ct = [[(w.detach().clone(), b.detach().clone()) for w, b in
+                    _layers(critic_target_sd, f"_critic_{i}._model.")] for i in (1, 2)]
+        self.continuous, self.low, self.high = continuous, low, high
+        self.gamma, self.tau = gamma, tau
+        self.expectile, self.temperature, self.adv_clamp = expectile, temperature, adv_clamp
+        self.opt_v = _adamw(_flat(self.value), lr)
+        self.opt_a = _adamw(_flat(self.actor), lr)
+        self.opt_c = _adamw(_flat(self.c[0]) + _flat(self.c[1]), lr)
+
+    @staticmethod
+    def q(layers, state, action) -> Tensor:
+        return mlp(layers, torch.cat([state, action], dim=-1)).view(-1)
+
+    def learn_batch(self, batch: Dict[str, Tensor]) -> Dict[str, float]:
+        """Draws the two target-critic indices from torch's global generator like the reference."""
+        s, a, r, term, ns = (batch[k] for k in ("state", "action", "reward", "terminated", "next_state"))
+        with torch.no_grad():
+            tq = [self.q(self.ct[0], s, a), self.q(self.ct[1], s, a)]
+        # ---- value (:186-196, :271-285)
+        tqv = tq[int(torch.randint(0, 2, (1,)).item())]
+        v = mlp(self.value, s).view(-1)
+        d = tqv - v
+        value_loss = (torch.where(d > 0, self.expectile, 1 - self.expectile) * d.pow(2)).mean()
+        # ---- critic (:248-269)
+        with torch.no_grad():
+            y = (mlp(self.value, ns).view(-1) * self.gamma * (1 - term.float())) + r
+        mse = torch.nn.MSELoss()
+        critic_loss = (mse(self.q(self.c[0], s, a), y) + mse(self.q(self.c[1], s, a), y)) / 2.0
+        # ---- actor (:197-246)
+        tqa = tq[int(torch.randint(0, 2, (1,)).item())]
+        with torch.no_grad():
+            adv = torch.clamp(torch.exp((tqa - mlp(self.value, s).view(-1)) * self.temperature),
+                              max=self.adv_clamp)
+        z = mlp(self.actor, s)
+        if self.continuous:
+            pred = (((self.high - self.low) * (torch.tanh(z) + 1.0)) / 2) + self.low
+            actor_loss = (adv * (pred - a).pow(2).mean(dim=1)).mean()
+        else:
+            p = torch.softmax(z, dim=-1)
+            idx = torch.argmax(a, dim=1).unsqueeze(-1)
+            actor_loss = -(adv * torch.log(torch.gather(p, 1, idx).view(-1))).mean()
+        for o in (self.opt_v, self.opt_a, self.opt_c):
+            o.zero_grad()
+        (value_loss + critic_loss + actor_loss).backward()
+        self.opt_v.step()
+        self.opt_a.step()
+        self.opt_c.step()
+        with torch.no_grad():
+            for net, tgt in zip(self.c, self.ct):
+                for (w, b), (tw, tb) in zip(net, tgt):
+                    tw.copy_(self.tau * w + (1.0 - self.tau) * tw)
+                    tb.copy_(self.tau * b + (1.0 - self.tau) * tb)
+        return {"value_loss": value_loss.item(), "actor_loss": actor_loss.item(),
+                "critic_loss": critic_loss.item()}
+
+
+# --------------------------------------------------------------------------------------
 # DDPG / TD3
 # --------------------------------------------------------------------------------------
 class DdpgOracle:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors for the actor-critic rows of SURVEY.md §8 (a13-a15): runs the REAL reference
 (/root/reference, CPU) for PPO and continuous SAC on seeded synthetic data and writes
-tests/golden/ppo_*.pt, tests/golden/sac_*.pt and tests/golden/{ddpg,td3,dsac}_*.pt.
+tests/golden/ppo_*.pt, tests/golden/sac_*.pt and tests/golden/{ddpg,td3,dsac,iql}_*.pt.
 
 TEST INFRASTRUCTURE ONLY (build container; the reference does not travel to the GPU box):
 
@@ -39,6 +39,13 @@ from pearl.policy_learners.sequential_decision_making.soft_actor_critic_continuo
 )
 from pearl.policy_learners.sequential_decision_making.ddpg import (  # noqa: E402
     DeepDeterministicPolicyGradient,
+)
+from pearl.neural_networks.sequential_decision_making.actor_networks import (  # noqa: E402
+    VanillaActorNetwork,
+    VanillaContinuousActorNetwork,
+)
+from pearl.policy_learners.sequential_decision_making.implicit_q_learning import (  # noqa: E402
+    ImplicitQLearning,
 )
 from pearl.policy_learners.sequential_decision_making.soft_actor_critic import (  # noqa: E402
     SoftActorCritic,
@@ -292,6 +299,63 @@ def make_dsac(name, cfg):
           f"-> {reports[-1]}")
 
 
+IQL_CONFIGS = {
+    "iql_continuous_tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=6, continuous=True,
+                                expectile=0.7),
+    "iql_continuous_shape_small": dict(S=64, A=8, hidden=[128, 128], B=96, steps=4, continuous=True,
+                                       expectile=0.8),
+    "iql_discrete_tiny": dict(S=5, A=3, hidden=[16, 12], B=16, steps=6, continuous=False,
+                              expectile=0.7),
+}
+
+
+def make_iql(name, cfg):
+    """ImplicitQLearning (implicit_q_learning.py:159-285): one fixed batch, K learn_batch calls, each
+    after torch.manual_seed(4000 + k) so the two target-critic draws are reproducible."""
+    S, A, B, K = cfg["S"], cfg["A"], cfg["B"], cfg["steps"]
+    gen = torch.Generator().manual_seed(555)
+    batch = dict(state=torch.randn(B, S, generator=gen), reward=torch.randn(B, generator=gen),
+                 terminated=torch.rand(B, generator=gen) < 0.2,
+                 truncated=torch.zeros(B, dtype=torch.bool),
+                 next_state=torch.randn(B, S, generator=gen))
+    kw = dict(state_dim=S, actor_hidden_dims=cfg["hidden"], critic_hidden_dims=cfg["hidden"],
+              value_critic_hidden_dims=cfg["hidden"], batch_size=B, expectile=cfg["expectile"])
+    low = high = None
+    torch.manual_seed(36)
+    if cfg["continuous"]:
+        low = -torch.ones(A) * torch.linspace(1.0, 2.0, A)
+        high = torch.ones(A) * torch.linspace(1.5, 1.0, A)
+        batch["action"] = low + (high - low) * torch.rand(B, A, generator=gen)
+        pl = ImplicitQLearning(action_space=BoxActionSpace(low=low, high=high),
+                               actor_network_type=VanillaContinuousActorNetwork, **kw)
+    else:
+        batch["action"] = torch.randint(0, A, (B, 1), generator=gen)
+        pl = ImplicitQLearning(action_space=space(A), actor_network_type=VanillaActorNetwork,
+                               action_representation_module=OneHotActionTensorRepresentationModule(A),
+                               **kw)
+    PearlAgent(policy_learner=pl, replay_buffer=BasicReplayBuffer(10))
+    with torch.no_grad():
+        for p in pl._critic_target.parameters():
+            p.add_(0.05 * torch.randn(p.shape, generator=gen))
+    fx = {"config": dict(cfg), "low": low, "high": high, "batch": batch,
+          "actor0": clone_sd(pl._actor), "value0": clone_sd(pl._value_network),
+          "critic0": clone_sd(pl._critic), "critic_target0": clone_sd(pl._critic_target)}
+    reports = []
+    for k in range(K):
+        torch.manual_seed(4000 + k)
+        tb = TransitionBatch(**{k2: v.clone() for k2, v in batch.items()})
+        rep = pl.learn_batch(pl.preprocess_batch(tb))
+        reports.append({k2: float(v) for k2, v in rep.items()})
+    fx["reports"] = reports
+    for key, mod in (("actor_after", pl._actor), ("value_after", pl._value_network),
+                     ("critic_after", pl._critic), ("critic_target_after", pl._critic_target)):
+        fx[key] = clone_sd(mod)
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); reports {reports[0]} "
+          f"-> {reports[-1]}")
+
+
 BANDIT_CONFIGS = {
     "tiny": dict(F=7, hidden=[12, 6], B=16, steps=4),
     "cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3),
@@ -329,6 +393,10 @@ def make_bandit(name, cfg):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "iql":
+        for name, cfg in IQL_CONFIGS.items():
+            make_iql(name, cfg)
+        return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "dsac":
         for name, cfg in DSAC_CONFIGS.items():
             make_dsac(name, cfg)
@@ -341,6 +409,8 @@ def main():
         make_ddpg(name, cfg)
     for name, cfg in DSAC_CONFIGS.items():
         make_dsac(name, cfg)
+    for name, cfg in IQL_CONFIGS.items():
+        make_iql(name, cfg)
     for name, cfg in BANDIT_CONFIGS.items():
         make_bandit(name, cfg)
     if os.environ.get("PEARL_GOLDEN_ONLY") == "bandit":

@@ -11,7 +11,8 @@ from .replay_buffers import BasicReplayBuffer, TransitionBatch  # noqa: F401
 from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
                                                          ContinuousSoftActorCritic,
                                                          DeepDeterministicPolicyGradient,
-                                                         DeepQLearning, DoubleDQN, PPOReplayBuffer,
+                                                         DeepQLearning, DoubleDQN, ImplicitQLearning,
+                                                         PPOReplayBuffer,
                                                          ProximalPolicyOptimization,
                                                          SoftActorCritic)
 from .policy_learners.contextual_bandits import NeuralLinearBandit, SquareCBExploration  # noqa: F401

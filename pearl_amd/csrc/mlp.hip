@@ -970,6 +970,84 @@ __global__ __launch_bounds__(256) void dsac_kernel(DsacArgs a) {
   }
 }
 
+// ---- implicit Q-learning (implicit_q_learning.py:159-285) --------------------------------------
+// Value head (:186-196, :271-285): expectile regression of V(s) towards a target critic's Q(s, a),
+//   loss = mean(w d^2), d = tq_value - v, w = expectile if d > 0 else 1 - expectile; dv = -2 w d / B.
+// Advantage weights of the policy extraction (:203-215), detached in the reference:
+//   adv = min(exp((tq_actor - v) temperature), clamp).
+struct IqlValueArgs {
+  const float* tq_value; const float* tq_actor; const float* v; int ldv;
+  float expectile, temperature, adv_clamp;
+  int B;
+  float* dv; float* adv; float* loss_out;
+};
+__global__ __launch_bounds__(256) void iql_value_kernel(IqlValueArgs a) {
+  __shared__ float red[256];
+  float part = 0.f;
+  const float invB = 1.0f / (float)a.B;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float v = a.v[(int64_t)b * a.ldv];
+    const float d = a.tq_value[b] - v;
+    const float w = d > 0.f ? a.expectile : (1.0f - a.expectile);
+    part += w * (d * d);
+    a.dv[b] = -2.0f * w * d * invB;
+    a.adv[b] = fminf(expf((a.tq_actor[b] - v) * a.temperature), a.adv_clamp);
+  }
+  const float sum = block_sum_256(part, red);
+  if (threadIdx.x == 0) a.loss_out[0] = sum * invB;
+}
+
+// Advantage-weighted regression heads (:197-246).
+//   mode 0, deterministic actor: loss = mean_b(adv_b mean_j (pred - action)^2);
+//           d_pred = adv_b 2 (pred - action) / (A B)
+//   mode 1, softmax actor: idx = argmax_j action_b (one-hot), loss = -mean_b(adv_b log P[idx]);
+//           d_logits_j = -(adv_b / B) ([j == idx] - P_j)
+struct AwrArgs {
+  const float* x; int ldx;           // mode 0: predicted actions [B, A]; mode 1: logits [B, A]
+  const float* action; int lda;      // [B, A]
+  const float* adv;
+  int B, A, mode;
+  float* dx; int lddx; float* loss_out;
+};
+__global__ __launch_bounds__(256) void awr_kernel(AwrArgs a) {
+  __shared__ float red[256];
+  float part = 0.f;
+  const float invB = 1.0f / (float)a.B;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float* x = a.x + (int64_t)b * a.ldx;
+    const float* act = a.action + (int64_t)b * a.lda;
+    float* dx = a.dx + (int64_t)b * a.lddx;
+    const float w = a.adv[b];
+    if (a.mode == 0) {
+      float sq = 0.f;
+      const float g = w * 2.0f * invB / (float)a.A;
+      for (int j = 0; j < a.A; ++j) {
+        const float d = x[j] - act[j];
+        sq += d * d;
+        dx[j] = g * d;
+      }
+      part += w * (sq / (float)a.A);
+    } else {
+      int idx = 0;
+      float best = act[0];
+      for (int j = 1; j < a.A; ++j)
+        if (act[j] > best) { best = act[j]; idx = j; }
+      float m = x[0];
+      for (int j = 1; j < a.A; ++j) m = fmaxf(m, x[j]);
+      float s = 0.f;
+      for (int j = 0; j < a.A; ++j) s += expf(x[j] - m);
+      const float g = -w * invB;
+      for (int j = 0; j < a.A; ++j) {
+        const float p = expf(x[j] - m) / s;
+        dx[j] = g * ((j == idx ? 1.0f : 0.0f) - p);
+        if (j == idx) part += -w * logf(p);
+      }
+    }
+  }
+  const float sum = block_sum_256(part, red);
+  if (threadIdx.x == 0) a.loss_out[0] = sum * invB;
+}
+
 // Twin-critic plumbing for SAC (soft_actor_critic_continuous.py:155-231).
 //   mode 0 (actor loss):  loss = mean(alpha * logp - min(q1, q2)); dq1/dq2 = -w/B with torch.minimum's
 //                         even split on ties
@@ -1562,6 +1640,34 @@ extern "C" int pa_dsac_target(const float* logits, int32_t ldl, const float* q1,
   a.B = B; a.A = A; a.mode = 1;
   a.reward = reward; a.term = terminated; a.gamma = gamma; a.y = y;
   hipLaunchKernelGGL(dsac_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_iql_value_head(const float* tq_value, const float* tq_actor, const float* v,
+                                 int32_t ldv, float expectile, float temperature, float adv_clamp,
+                                 int32_t B, float* dv, float* adv_out, float* loss_out,
+                                 void* stream) {
+  PA_REQUIRE(tq_value && tq_actor && v && dv && adv_out && loss_out && B > 0, PA_ERR_INVALID,
+             "pa_iql_value_head: bad argument");
+  IqlValueArgs a;
+  a.tq_value = tq_value; a.tq_actor = tq_actor; a.v = v; a.ldv = ldv;
+  a.expectile = expectile; a.temperature = temperature; a.adv_clamp = adv_clamp; a.B = B;
+  a.dv = dv; a.adv = adv_out; a.loss_out = loss_out;
+  hipLaunchKernelGGL(iql_value_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_awr_head(int32_t mode, const float* x, int32_t ldx, const float* action,
+                           int32_t lda, const float* adv, int32_t B, int32_t A, float* dx,
+                           int32_t lddx, float* loss_out, void* stream) {
+  PA_REQUIRE(x && action && adv && dx && loss_out && B > 0 && A > 0 && (mode == 0 || mode == 1),
+             PA_ERR_INVALID, "pa_awr_head: bad argument");
+  AwrArgs a;
+  a.x = x; a.ldx = ldx; a.action = action; a.lda = lda; a.adv = adv; a.B = B; a.A = A; a.mode = mode;
+  a.dx = dx; a.lddx = lddx; a.loss_out = loss_out;
+  hipLaunchKernelGGL(awr_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -2,10 +2,11 @@ from .actor_critic_base import ActorCriticBase
 from .deep_q_learning import DeepQLearning
 from .ddpg import DeepDeterministicPolicyGradient
 from .double_dqn import DoubleDQN
+from .implicit_q_learning import ImplicitQLearning
 from .ppo import PPOReplayBuffer, PPOTransitionBatch, ProximalPolicyOptimization
 from .soft_actor_critic import SoftActorCritic
 from .soft_actor_critic_continuous import ContinuousSoftActorCritic
 from .td3 import TD3
 
-__all__ = ["ActorCriticBase", "DeepDeterministicPolicyGradient", "TD3", "DeepQLearning", "DoubleDQN", "PPOReplayBuffer", "PPOTransitionBatch",
+__all__ = ["ActorCriticBase", "DeepDeterministicPolicyGradient", "TD3", "DeepQLearning", "DoubleDQN", "ImplicitQLearning", "PPOReplayBuffer", "PPOTransitionBatch",
            "ProximalPolicyOptimization", "ContinuousSoftActorCritic", "SoftActorCritic"]

@@ -1,0 +1,254 @@
+"""ImplicitQLearning (reference: pearl/policy_learners/sequential_decision_making/
+implicit_q_learning.py:52-351).
+
+Same constructor and ``learn_batch`` effects as the reference: a state-value network trained by
+expectile regression towards ONE randomly chosen target critic (:186-196, :271-285), twin critics
+regressed to ``r + gamma V(s')`` (:248-269), policy extraction by advantage-weighted regression
+(:197-246), all three losses formed on the PRE-step parameters, one backward, then the value /
+actor / critic AdamW(amsgrad) steps and the critic-target soft update (:159-184).
+
+The two ``torch.randint(0, 2, (1,))`` draws that pick the target critic (value loss first, then
+actor loss) are made here exactly as in the reference (host generator, no device work), so a seeded
+run picks the same critics.  Everything else is libpearl_amd on flat parameter views: expectile /
+advantage head ``pa_iql_value_head``, AWR heads ``pa_awr_head``, the deterministic actor's tanh
+scaling ``pa_tanh_action`` / ``pa_tanh_action_grad``, paired twin-critic launches.  Actor types
+with HIP heads: ``VanillaContinuousActorNetwork`` (weighted MSE on the action) and
+``VanillaActorNetwork`` (weighted log-likelihood); the Gaussian actor is not built.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import Tensor, nn, optim
+
+from ... import _native as N
+from ...action_representation_modules import ActionRepresentationModule
+from ...neural_networks.common.value_networks import VanillaValueNetwork
+from ...neural_networks.sequential_decision_making.actor_networks import (
+    VanillaActorNetwork, VanillaContinuousActorNetwork)
+from ...neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
+from ...replay_buffers.transition import TransitionBatch
+from ..exploration import ExplorationModule, NoExploration
+from ..policy_learner import PolicyLearner
+from .actor_critic_base import ActorCriticBase
+from .flat_mlp import FlatMlp, layers_of
+
+
+class ImplicitQLearning(ActorCriticBase):
+    def __init__(self, action_space: Any, state_dim: Optional[int] = None,
+                 actor_hidden_dims: Optional[List[int]] = None,
+                 critic_hidden_dims: Optional[List[int]] = None,
+                 value_critic_hidden_dims: Optional[List[int]] = None,
+                 exploration_module: Optional[ExplorationModule] = None,
+                 actor_network_type: type = VanillaActorNetwork,
+                 critic_network_type: type = VanillaQValueNetwork,
+                 value_network_type: type = VanillaValueNetwork,
+                 value_critic_learning_rate: float = 1e-3, actor_learning_rate: float = 1e-3,
+                 critic_learning_rate: float = 1e-3,
+                 history_summarization_learning_rate: float = 1e-3,
+                 critic_soft_update_tau: float = 0.05, discount_factor: float = 0.99,
+                 training_rounds: int = 5, batch_size: int = 128, expectile: float = 0.5,
+                 temperature_advantage_weighted_regression: float = 0.5,
+                 advantage_clamp: float = 100.0,
+                 action_representation_module: Optional[ActionRepresentationModule] = None,
+                 actor_network_instance: Optional[nn.Module] = None,
+                 critic_network_instance: Optional[nn.Module] = None,
+                 value_network_instance: Optional[nn.Module] = None, **kwargs: Any) -> None:
+        if actor_network_type not in (VanillaActorNetwork, VanillaContinuousActorNetwork):
+            raise NotImplementedError("pearl_amd ImplicitQLearning: HIP policy-extraction heads exist "
+                                      "for VanillaActorNetwork and VanillaContinuousActorNetwork")
+        if critic_network_type is not VanillaQValueNetwork or value_network_type is not VanillaValueNetwork:
+            raise NotImplementedError("pearl_amd ImplicitQLearning: only VanillaQValueNetwork twin "
+                                      "critics and a VanillaValueNetwork have HIP kernels")
+        continuous = bool(getattr(action_space, "is_continuous", hasattr(action_space, "low")))
+        super().__init__(
+            state_dim=state_dim, action_space=action_space, actor_hidden_dims=actor_hidden_dims,
+            critic_hidden_dims=critic_hidden_dims, actor_learning_rate=actor_learning_rate,
+            critic_learning_rate=critic_learning_rate,
+            history_summarization_learning_rate=history_summarization_learning_rate,
+            actor_network_type=actor_network_type, critic_network_type=critic_network_type,
+            use_actor_target=False, use_critic_target=True,
+            critic_soft_update_tau=critic_soft_update_tau, use_twin_critic=True,
+            exploration_module=(exploration_module if exploration_module is not None
+                                else NoExploration()),
+            discount_factor=discount_factor, training_rounds=training_rounds, batch_size=batch_size,
+            is_action_continuous=continuous, on_policy=False,
+            action_representation_module=action_representation_module,
+            actor_network_instance=actor_network_instance,
+            critic_network_instance=critic_network_instance, **kwargs)
+        self._expectile = expectile
+        self._temperature_advantage_weighted_regression = temperature_advantage_weighted_regression
+        self._advantage_clamp = advantage_clamp
+        if value_network_instance is not None:
+            self._value_network: nn.Module = value_network_instance
+        else:
+            assert state_dim is not None and value_critic_hidden_dims is not None
+            self._value_network = value_network_type(input_dim=state_dim,
+                                                     hidden_dims=value_critic_hidden_dims,
+                                                     output_dim=1)
+        self._value_network_optimizer: optim.Optimizer = optim.AdamW(
+            self._value_network.parameters(), lr=value_critic_learning_rate, amsgrad=True)
+
+    # ------------------------------------------------------------------ flat views
+    def _nets(self, batch_hint: int = 0, validate: bool = True):
+        """(actor, value network, critic 1, critic 2)."""
+        if not self._flat:
+            mb = max(self._batch_size, 1)
+            self._flat["actor"] = FlatMlp(layers_of(self._actor.linear_layers()),
+                                          self._actor_optimizer, mb)
+            self._flat["value"] = FlatMlp(layers_of(self._value_network.linear_layers()),
+                                          self._value_network_optimizer, mb)
+            for i, (c, ct) in enumerate(((self._critic._critic_1, self._critic_target._critic_1),
+                                         (self._critic._critic_2, self._critic_target._critic_2)), 1):
+                self._flat[f"critic{i}"] = FlatMlp(layers_of(c.linear_layers()),
+                                                   self._critic_optimizer, mb,
+                                                   target_layers=layers_of(ct.linear_layers()))
+        nets = (self._flat["actor"], self._flat["value"], self._flat["critic1"], self._flat["critic2"])
+        if validate:
+            return tuple(m.ensure(batch_hint) for m in nets)
+        return tuple(m.ready(batch_hint) for m in nets)
+
+    def _bounds(self, dev: torch.device):
+        sp = self._actor._action_space
+        hit = self._flat.get("bounds")
+        if hit is None or hit[0] is not sp or hit[1] != dev:
+            hit = (sp, dev, sp.low.to(dev, torch.float32).contiguous(),
+                   sp.high.to(dev, torch.float32).contiguous())
+            self._flat["bounds"] = hit
+        return hit[2], hit[3]
+
+    @staticmethod
+    def _f32(t: Tensor, dev: torch.device) -> Tensor:
+        return t.to(device=dev, dtype=torch.float32).contiguous()
+
+    # ------------------------------------------------------------------ learn_batch (:159-184)
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        actor, value, c1, c2 = self._nets(len(batch))
+        dev = actor.device
+        lib, s = N.lib(), N.stream_ptr(dev)
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        act = self._f32(batch.action, dev).reshape(B, -1)
+        A = act.shape[1]
+        # which target critic each loss regresses to / weighs with (:189-190, :205-206): the
+        # reference's own two host draws, value loss first
+        pick_value = int(torch.randint(0, 2, (1,)).item())
+        pick_actor = int(torch.randint(0, 2, (1,)).item())
+        xq = torch.empty(B, S + A, dtype=torch.float32, device=dev)
+        N.check(lib.pa_concat_cols(state.data_ptr(), state.stride(0), act.data_ptr(), act.stride(0),
+                                   xq.data_ptr(), B, S, A, s))
+        tq = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, use_target=True)]
+        # V(s') first: the engine keeps ONE forward's activations per network for the backward pass
+        vn = value.forward(nstate).reshape(B)
+        # ---- value loss (:186-196) and the advantage weights (:203-215)
+        v = value.forward(state, keep=True)
+        dv = torch.empty(B, dtype=torch.float32, device=dev)
+        adv = torch.empty(B, dtype=torch.float32, device=dev)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)    # value | critic | actor
+        N.check(lib.pa_iql_value_head(tq[pick_value].data_ptr(), tq[pick_actor].data_ptr(),
+                                      v.data_ptr(), v.stride(0), float(self._expectile),
+                                      float(self._temperature_advantage_weighted_regression),
+                                      float(self._advantage_clamp), B, dv.data_ptr(),
+                                      adv.data_ptr(), losses.data_ptr(), s))
+        # ---- critic loss (:248-269): r + gamma V(s') with the pre-step value network
+        y = torch.empty(B, dtype=torch.float32, device=dev)
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
+        zero = self._flat.get("zeros")
+        if zero is None or zero[0].numel() < B or zero[0].device != dev:
+            zero = (torch.zeros(max(B, 1), dtype=torch.float32, device=dev),
+                    torch.zeros(1, dtype=torch.float32, device=dev))
+            self._flat["zeros"] = zero
+        # pa_sac_twin(mode 1) with q1 = q2 = V(s'), alpha = 0: y = V(s') gamma (1 - term) + r
+        N.check(lib.pa_sac_twin(1, vn.data_ptr(), vn.data_ptr(), zero[0].data_ptr(),
+                                zero[1].data_ptr(), reward.data_ptr(), term.data_ptr(),
+                                float(self._discount_factor), B, y.data_ptr(), None, None, s))
+        qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, keep=True)]
+        dqs = [torch.empty_like(q) for q in qs]
+        for i in range(2):
+            N.check(lib.pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
+                                    dqs[i].data_ptr(), losses[1:].data_ptr(), s))
+        # ---- actor loss (:197-246)
+        head = actor.forward(state, keep=True)
+        d_head = torch.empty_like(head)
+        if isinstance(self._actor, VanillaContinuousActorNetwork):
+            low, high = self._bounds(dev)
+            pred = torch.empty(B, A, dtype=torch.float32, device=dev)
+            N.check(lib.pa_tanh_action(head.data_ptr(), head.stride(0), None, 0, low.data_ptr(),
+                                       high.data_ptr(), 0.0, B, A, pred.data_ptr(), pred.stride(0), s))
+            d_pred = torch.empty_like(pred)
+            N.check(lib.pa_awr_head(0, pred.data_ptr(), pred.stride(0), act.data_ptr(), act.stride(0),
+                                    adv.data_ptr(), B, A, d_pred.data_ptr(), d_pred.stride(0),
+                                    losses[2:].data_ptr(), s))
+            N.check(lib.pa_tanh_action_grad(head.data_ptr(), head.stride(0), low.data_ptr(),
+                                            high.data_ptr(), d_pred.data_ptr(), d_pred.stride(0), B,
+                                            A, d_head.data_ptr(), d_head.stride(0), s))
+        else:
+            assert head.shape[1] == A, "the softmax actor outputs one logit per action slot"
+            N.check(lib.pa_awr_head(1, head.data_ptr(), head.stride(0), act.data_ptr(), act.stride(0),
+                                    adv.data_ptr(), B, A, d_head.data_ptr(), d_head.stride(0),
+                                    losses[2:].data_ptr(), s))
+        # ---- one backward, then the steps in the reference's order (:171-176), target update
+        value.backward(state, dv, want_dw=True)
+        actor.backward(state, d_head, want_dw=True)
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        value.adam()
+        actor.adam()
+        c1.adam()
+        c2.adam()
+        c1.soft_update(self._critic_soft_update_tau)
+        c2.soft_update(self._critic_soft_update_tau)
+        return {"value_loss": losses[0], "actor_loss": losses[2], "critic_loss": losses[1]}
+
+    def _actor_update(self, batch: TransitionBatch) -> Tensor:      # pragma: no cover
+        raise NotImplementedError("ImplicitQLearning forms its three losses in one learn_batch")
+
+    def _critic_update(self, batch: TransitionBatch) -> Tensor:     # pragma: no cover
+        raise NotImplementedError("ImplicitQLearning forms its three losses in one learn_batch")
+
+    # ------------------------------------------------------------------ act (act-time torch)
+    def act(self, subjective_state: Tensor, available_action_space: Any, exploit: bool = False) -> Any:
+        with torch.no_grad():
+            if isinstance(self._actor, VanillaContinuousActorNetwork):
+                exploit_action = self._actor.sample_action(subjective_state)
+                probs = None
+            else:
+                probs = self._actor.get_policy_distribution(
+                    state_batch=subjective_state,
+                    available_actions=self.action_representation_module(
+                        available_action_space.actions_batch.to(subjective_state.device)))
+                exploit_action = available_action_space.actions[int(torch.argmax(probs))]
+        if exploit:
+            return exploit_action
+        return self.exploration_module.act(exploit_action=exploit_action,
+                                           action_space=available_action_space,
+                                           subjective_state=subjective_state, values=probs)
+
+    def get_extra_state(self) -> Dict[str, Any]:
+        state = super().get_extra_state()
+        state["value_optimizer"] = self._value_network_optimizer.state_dict()
+        return state
+
+    def set_extra_state(self, state: Dict[str, Any]) -> None:
+        super().set_extra_state(state)
+        if "value_optimizer" in state:
+            self._value_network_optimizer.load_state_dict(state["value_optimizer"])
+
+    def compare(self, other: PolicyLearner) -> str:
+        diffs = [super().compare(other)]
+        if not isinstance(other, ImplicitQLearning):
+            diffs.append("other is not an instance of ImplicitQLearning")
+        else:
+            for attr in ("_expectile", "_temperature_advantage_weighted_regression",
+                         "_advantage_clamp"):
+                if getattr(self, attr) != getattr(other, attr):
+                    diffs.append(f"{attr} is different: {getattr(self, attr)} vs "
+                                 f"{getattr(other, attr)}")
+            mine, theirs = self._value_network.state_dict(), other._value_network.state_dict()
+            if mine.keys() != theirs.keys() or any(
+                    not torch.allclose(mine[k].cpu().float(), theirs[k].cpu().float(), rtol=1e-5,
+                                       atol=1e-8) for k in mine):
+                diffs.append("_value_network is different")
+        return "\n".join(d for d in diffs if d)

@@ -381,3 +381,48 @@ def test_q_all_matches_expanded_forward(S, AD, A, hidden, B, bcast):
         want = m.forward(x, use_target=use_target).view(-1)
         got = m.q_all(state, rep, use_target=use_target)
         torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
+
+
+IQL = ["iql_continuous_tiny", "iql_continuous_shape_small", "iql_discrete_tiny"]
+
+
+def make_iql(fx):
+    from pearl_amd import (BasicReplayBuffer, BoxActionSpace, ImplicitQLearning,
+                           OneHotActionTensorRepresentationModule, PearlAgent)
+    from pearl_amd.neural_networks.sequential_decision_making.actor_networks import (
+        VanillaActorNetwork, VanillaContinuousActorNetwork)
+    cfg = fx["config"]
+    kw = dict(state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"], critic_hidden_dims=cfg["hidden"],
+              value_critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"], expectile=cfg["expectile"])
+    if cfg["continuous"]:
+        pl = ImplicitQLearning(action_space=BoxActionSpace(fx["low"], fx["high"]),
+                               actor_network_type=VanillaContinuousActorNetwork, **kw)
+    else:
+        pl = ImplicitQLearning(action_space=dspace(cfg["A"]), actor_network_type=VanillaActorNetwork,
+                               action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]),
+                               **kw)
+    for mod, key in ((pl._actor, "actor0"), (pl._value_network, "value0"), (pl._critic, "critic0"),
+                     (pl._critic_target, "critic_target0")):
+        mod.load_state_dict(fx[key])
+    PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+    return pl
+
+
+@pytest.mark.parametrize("name", IQL)
+def test_iql_learn_batch_trajectory(name):
+    """ImplicitQLearning.learn_batch against the reference run: value / actor / critic losses per
+    call (first call at 1e-5; torch seeded like the generator so the same target critics are
+    picked), then actor, value network, critics and critic targets."""
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    pl = make_iql(fx)
+    for step, want in enumerate(fx["reports"]):
+        torch.manual_seed(4000 + step)
+        got = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+        tol = 1e-5 if step == 0 else 5e-4
+        for k in want:
+            assert abs(float(got[k]) - want[k]) <= tol * max(1.0, abs(want[k])), (step, k, float(got[k]), want[k])
+    for name_, mod, key in (("actor", pl._actor, "actor_after"), ("value", pl._value_network, "value_after"),
+                            ("critic", pl._critic, "critic_after"),
+                            ("critic_target", pl._critic_target, "critic_target_after")):
+        for k, v in mod.state_dict().items():
+            torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")

@@ -188,3 +188,38 @@ def test_discrete_sac_probe_and_trajectory(name):
                                fx["critic_after"]["_critic_1._model.0.0.weight"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(orc.ct[1][0][0],
                                fx["critic_target_after"]["_critic_2._model.0.0.weight"], rtol=1e-5, atol=1e-7)
+
+
+IQL = ["iql_continuous_tiny", "iql_continuous_shape_small", "iql_discrete_tiny"]
+
+
+def iql_batch(fx):
+    b = {k: v.clone() for k, v in fx["batch"].items()}
+    if not fx["config"]["continuous"]:
+        b["action"] = onehot(b["action"].view(-1), fx["config"]["A"])      # preprocess_batch
+    return b
+
+
+@pytest.mark.parametrize("name", IQL)
+def test_iql_trajectory(name):
+    """IqlOracle against the reference's ImplicitQLearning: the three losses per call (the two
+    target-critic draws replayed by seeding torch like the generator did) and all networks."""
+    from oracle.actor_critic_oracle import IqlOracle
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    cfg = fx["config"]
+    orc = IqlOracle(fx["actor0"], fx["value0"], fx["critic0"], fx["critic_target0"],
+                    cfg["continuous"], fx["low"], fx["high"], expectile=cfg["expectile"])
+    b = iql_batch(fx)
+    for k, want in enumerate(fx["reports"]):
+        torch.manual_seed(4000 + k)
+        got = orc.learn_batch(b)
+        for key in want:
+            assert abs(got[key] - want[key]) <= 2e-5 * max(1.0, abs(want[key])), (k, key, got[key], want[key])
+    for i, (w, _) in enumerate(orc.actor):
+        torch.testing.assert_close(w.detach(), fx["actor_after"][f"_model.{i}.0.weight"], rtol=1e-4, atol=1e-6)
+    for i, (w, _) in enumerate(orc.value):
+        torch.testing.assert_close(w.detach(), fx["value_after"][f"_model.{i}.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.c[1][0][0].detach(),
+                               fx["critic_after"]["_critic_2._model.0.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.ct[0][0][0],
+                               fx["critic_target_after"]["_critic_1._model.0.0.weight"], rtol=1e-5, atol=1e-7)
