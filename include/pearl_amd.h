@@ -202,9 +202,12 @@ typedef struct pa_dqn_desc {
   float tau;           /* soft_update_tau (common/utils.py:214-226)             */
   double lr, beta1, beta2, eps, weight_decay; /* optim.AdamW defaults (:183-185) */
   int32_t amsgrad;
-  int32_t double_q;    /* 1: DoubleDQN.get_next_state_values (double_dqn.py:29-57): the next
-                        * action is the ONLINE net's argmax over the available actions, its value
-                        * comes from the target net.  0: DeepQLearning (deep_q_learning.py:130-167) */
+  int32_t double_q;    /* how the next state is valued.  0: DeepQLearning (deep_q_learning.py:
+                        * 130-167), max over the available next actions of Q_target.  1: DoubleDQN
+                        * (double_dqn.py:29-57), the ONLINE net's argmax valued by the target net.
+                        * 2: DeepSARSA (deep_sarsa.py:59-78), Q_target(s', next_action) for the
+                        * batch's committed next action (pa_dqn_batch.next_action_rep); stand-alone
+                        * steps only (pa_dqn_step / pa_dqn_qvalues), not pa_dqn_learn             */
 } pa_dqn_desc;
 
 /* Parameter storage, flat fp32.  Layout (floats), every tensor offset rounded
@@ -233,6 +236,8 @@ typedef struct pa_dqn_batch {
   const float* next_avail_rep;  /* [B, A, AD], or [A, AD] when next_avail_bcast             */
   const uint8_t* next_mask;     /* [B, A] (1 = unavailable), or [A] when bcast, or NULL     */
   int32_t next_avail_bcast;
+  const float* next_action_rep; /* [B, AD] rep of the committed next action: DeepSARSA only
+                                 * (pa_dqn_desc.double_q == 2), NULL otherwise               */
 } pa_dqn_batch;
 
 int64_t pa_dqn_param_count(int32_t S, int32_t AD, int32_t H1, int32_t H2);

@@ -32,7 +32,11 @@ from pearl.action_representation_modules.one_hot_action_representation_module im
     OneHotActionTensorRepresentationModule,
 )
 from pearl.policy_learners.sequential_decision_making.deep_q_learning import DeepQLearning  # noqa: E402
+from pearl.policy_learners.sequential_decision_making.deep_sarsa import DeepSARSA  # noqa: E402
 from pearl.policy_learners.sequential_decision_making.double_dqn import DoubleDQN  # noqa: E402
+from pearl.replay_buffers.sequential_decision_making.sarsa_replay_buffer import (  # noqa: E402
+    SARSAReplayBuffer,
+)
 from pearl.replay_buffers import BasicReplayBuffer  # noqa: E402
 from pearl.utils.instantiations.spaces.discrete_action import DiscreteActionSpace  # noqa: E402
 
@@ -163,8 +167,81 @@ def make(name, cfg):
           f"losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")
 
 
+SARSA_CONFIGS = {
+    "sarsa_tiny": dict(S=5, A=3, hidden=[16, 24], N=60, B=12, rounds=12, capacity=200),
+    "sarsa_wrap": dict(S=4, A=4, hidden=[24, 16], N=90, B=16, rounds=11, capacity=37),
+}
+
+
+def make_sarsa(name, cfg):
+    """DeepSARSA + SARSAReplayBuffer (deep_sarsa.py:30-97, sarsa_replay_buffer.py:22-101): episodes
+    of consecutive states (the buffer only completes a transition when the next push continues it),
+    one broken chain (dropped transition), terminal and truncated ends; the stored rows incl.
+    next_action for a known index list, one-batch numerics, a learn() trajectory."""
+    torch.manual_seed(0)
+    random.seed(0)
+    gen = torch.Generator().manual_seed(4321)
+    S, A, B, N = cfg["S"], cfg["A"], cfg["B"], cfg["N"]
+    states = torch.randn(N + 1, S, generator=gen)
+    rows = []
+    for i in range(N):
+        end = (i % 11 == 10)
+        rows.append(dict(i=i, action=int(torch.randint(0, A, (1,), generator=gen)),
+                         reward=float(i % 5) - 1.5, terminated=bool(end and i % 22 == 10),
+                         truncated=bool(end and i % 22 != 10),
+                         # a gap: the successor of transition 17 starts from another state
+                         jump=(i == 18)))
+    rep = OneHotActionTensorRepresentationModule(A)
+    torch.manual_seed(7)
+    pl = DeepSARSA(state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
+                   training_rounds=cfg["rounds"], batch_size=B, action_representation_module=rep)
+    rb = SARSAReplayBuffer(cfg["capacity"])
+    rb._is_action_continuous = False
+    rb.device_for_batches = torch.device("cpu")
+    pushes = []
+    for r in rows:
+        st = states[r["i"]] + (100.0 if r["jump"] else 0.0)
+        pushes.append(dict(state=st.clone(), action=r["action"], reward=r["reward"],
+                           terminated=r["terminated"], truncated=r["truncated"],
+                           next_state=states[r["i"] + 1].clone()))
+        rb.push(state=st, action=torch.tensor([r["action"]]), reward=r["reward"],
+                terminated=r["terminated"], truncated=r["truncated"],
+                curr_available_actions=space(A), next_state=states[r["i"] + 1],
+                next_available_actions=space(A), max_number_actions=A)
+    fx = {"config": dict(cfg), "pushes": pushes, "stored": len(rb)}
+    random.seed(11)
+    idx = random.sample(range(len(rb)), B)
+    random.seed(11)
+    raw = rb.sample(B)
+    fx["sample_seed"], fx["sample_idx"] = 11, torch.tensor(idx)
+    fields = ("state", "action", "reward", "terminated", "truncated", "next_state", "next_action",
+              "curr_available_actions", "curr_unavailable_actions_mask", "next_available_actions",
+              "next_unavailable_actions_mask")
+    fx["batch_raw"] = {k: getattr(raw, k).detach().clone() for k in fields}
+    batch = pl.preprocess_batch(raw)
+    fx["batch_pre"] = {k: getattr(batch, k).detach().clone() for k in fields}
+    fx["params0"], fx["target0"] = clone_sd(pl._Q), clone_sd(pl._Q_target)
+    q = pl._Q.get_q_values(batch.state, batch.action)
+    next_v = pl.get_next_state_values(batch, B)
+    loss, target = pl.loss(batch, q)
+    fx["q"], fx["next_v"], fx["target"] = q.detach().clone(), next_v.detach().clone(), target.detach().clone()
+    random.seed(23)
+    fx["learn_seed"] = 23
+    report = pl.learn(rb)
+    fx["learn_losses"] = torch.tensor(report["loss"])
+    fx["params_after"], fx["target_after"] = clone_sd(pl._Q), clone_sd(pl._Q_target)
+    fx["training_steps_after"] = pl._training_steps
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); stored {len(rb)} of {N} "
+          f"pushes; losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")
+
+
 def main():
     only = sys.argv[1:]          # optional: names of the configurations to (re)generate
+    for name, cfg in SARSA_CONFIGS.items():
+        if not only or name in only:
+            make_sarsa(name, cfg)
     for name, cfg in CONFIGS.items():
         if not only or name in only:
             make(name, cfg)

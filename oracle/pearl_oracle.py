@@ -90,6 +90,8 @@ class ReplayOracle:
     @staticmethod
     def collate(rows: Sequence[dict]) -> Dict[str, torch.Tensor]:
         out = {k: torch.cat([r[k] for r in rows]) for k in ReplayOracle.FIELDS}
+        if rows and "next_action" in rows[0]:
+            out["next_action"] = torch.cat([r["next_action"] for r in rows])
         out["state"] = out["state"].type(F32)
         out["next_state"] = out["next_state"].type(F32)
         return out
@@ -104,6 +106,30 @@ class ReplayOracle:
         return self.collate([self.memory[int(i)] for i in logical_indices])
 
 
+class SarsaReplayOracle(ReplayOracle):
+    """SARSAReplayBuffer (sarsa_replay_buffer.py:22-101): a push is held back until the next push
+    supplies `next_action` (when its state equals the cached next_state); terminal / truncated
+    pushes are stored at once with their own action as a dummy next_action; the cache survives a
+    terminal push."""
+
+    def __init__(self, capacity: int) -> None:
+        super().__init__(capacity)
+        self.cache = None
+
+    def push(self, state, action, reward, terminated, truncated, n_curr: int, next_state,
+             n_next: int, max_number_actions: int) -> None:
+        probe = ReplayOracle(1)
+        ReplayOracle.push(probe, state, action, reward, terminated, truncated, n_curr, next_state,
+                          n_next, max_number_actions)
+        row = probe.memory[0]
+        if self.cache is not None and torch.equal(self.cache["next_state"], row["state"]):
+            self.memory.append(dict(self.cache, next_action=row["action"]))        # :55-71
+        if not (terminated or truncated):
+            self.cache = row                                                        # :72-86
+        else:
+            self.memory.append(dict(row, next_action=row["action"]))               # :87-101
+
+
 def one_hot(x: torch.Tensor, n: int) -> torch.Tensor:
     if x.ndim == 1:
         x = x.unsqueeze(-1)
@@ -113,6 +139,8 @@ def one_hot(x: torch.Tensor, n: int) -> torch.Tensor:
 def preprocess(batch: Dict[str, torch.Tensor], n_actions: int) -> Dict[str, torch.Tensor]:
     out = dict(batch)
     out["action"] = one_hot(batch["action"], n_actions)
+    if batch.get("next_action") is not None:
+        out["next_action"] = one_hot(batch["next_action"], n_actions)
     for k in ("curr_available_actions", "next_available_actions"):
         if batch.get(k) is not None:
             out[k] = one_hot(batch[k], n_actions)
@@ -132,10 +160,11 @@ class DqnOracle:
     def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor],
                  gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01, tau: float = 0.75, target_update_freq: int = 10,
-                 double_q: bool = False):
+                 double_q: bool = False, sarsa: bool = False):
         # double_q: DoubleDQN.get_next_state_values (double_dqn.py:29-57) instead of
-        # DeepQLearning's (deep_q_learning.py:130-167)
+        # DeepQLearning's (deep_q_learning.py:130-167); sarsa: DeepSARSA's (deep_sarsa.py:59-78)
         self.double_q = bool(double_q)
+        self.sarsa = bool(sarsa)
         self.p = {k: params[k].detach().clone().to(F32) for k in PARAM_KEYS}
         self.t = {k: target[k].detach().clone().to(F32) for k in PARAM_KEYS}
         self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
@@ -177,8 +206,11 @@ class DqnOracle:
         return q.max(1)[0]
 
     def bellman_target(self, batch) -> torch.Tensor:
-        nv = self.next_state_values(batch["next_state"], batch["next_available_actions"],
-                                    batch["next_unavailable_actions_mask"])
+        if self.sarsa:      # Q_target(s', committed next action)
+            nv = self._mlp(self.t, torch.cat([batch["next_state"], batch["next_action"]], dim=-1))[2]
+        else:
+            nv = self.next_state_values(batch["next_state"], batch["next_available_actions"],
+                                        batch["next_unavailable_actions_mask"])
         return nv * self.gamma * (1 - batch["terminated"].float()) + batch["reward"]
 
     # -- backward, by hand

@@ -7,11 +7,12 @@ that mirror the reference's ``ReplayBuffer`` / ``PolicyLearner`` / ``PearlAgent`
 There is no CPU or PyTorch fallback for that path: it fails loudly without the library / a GPU.
 """
 from .pearl_agent import PearlAgent  # noqa: F401
-from .replay_buffers import BasicReplayBuffer, TransitionBatch  # noqa: F401
+from .replay_buffers import BasicReplayBuffer, SARSAReplayBuffer, TransitionBatch  # noqa: F401
 from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
                                                          ContinuousSoftActorCritic,
                                                          DeepDeterministicPolicyGradient,
-                                                         DeepQLearning, DoubleDQN, ImplicitQLearning,
+                                                         DeepQLearning, DeepSARSA, DoubleDQN,
+                                                         ImplicitQLearning,
                                                          PPOReplayBuffer,
                                                          ProximalPolicyOptimization,
                                                          SoftActorCritic)

@@ -168,6 +168,7 @@ class DqnBatch(C.Structure):
         ("next_avail_rep", C.c_void_p),
         ("next_mask", C.c_void_p),
         ("next_avail_bcast", C.c_int32),
+        ("next_action_rep", C.c_void_p),
     ]
 
 

@@ -204,8 +204,12 @@ int check_batch(const pa_dqn* h, const pa_dqn_batch* b) {
              h->d.max_actions, T_ROWS);
   PA_REQUIRE(b->x || (b->state && b->action_rep), PA_ERR_INVALID,
              "batch needs x or (state, action_rep)");
-  PA_REQUIRE(b->next_state && b->next_avail_rep && b->reward && b->terminated, PA_ERR_INVALID,
-             "batch needs next_state, next_avail_rep, reward, terminated");
+  PA_REQUIRE(b->next_state && b->reward && b->terminated, PA_ERR_INVALID,
+             "batch needs next_state, reward, terminated");
+  if (h->d.double_q == 2)
+    PA_REQUIRE(b->next_action_rep, PA_ERR_INVALID, "a SARSA batch needs next_action_rep");
+  else
+    PA_REQUIRE(b->next_avail_rep, PA_ERR_INVALID, "batch needs next_avail_rep");
   return PA_OK;
 }
 
@@ -355,6 +359,20 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
 // max_a' Q_target(s', a') (DeepQLearning) or Q_target(s', argmax_a' Q(s', a')) (DoubleDQN) and the
 // Bellman targets of one batch, U computed here.
 int run_next_values(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+  if (h->d.double_q == 2) {
+    // DeepSARSA (deep_sarsa.py:59-78): Q_target(s', a') for the committed next action — the fused
+    // kernel with ONE action per transition
+    h->y_clean = false;
+    GemmArgs g = target_l1_problem(h, b->next_state, b->B, h->Uw[0]);
+    int rc = launch_linear<false>(&g, 1, s);
+    if (rc != PA_OK) return rc;
+    pa_dqn_batch one = *b;
+    one.A = 1;
+    one.next_avail_rep = b->next_action_rep;
+    one.next_avail_bcast = 0;
+    one.next_mask = nullptr;
+    return run_target_fused_u(h, &one, h->Uw[0], next_v, y, s);
+  }
   if (h->d.double_q) return run_double_targets(h, b, next_v, y, s);
   {
     ScopedTimer tm(h, "target_l1", s);
@@ -818,7 +836,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
-  if (desc->double_q) {
+  if (desc->double_q == 1) {
     PA_WS(h->w2f_online, w2f_floats(desc->hidden2, desc->hidden1));
     PA_WS(h->choice, B);
     PA_WS(h->choice_rep, B * desc->action_dim);
@@ -950,6 +968,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // of this window performs.  Bit-identical to the single-stream loop (same kernels, same data).
   // Double DQN chooses the next action with the ONLINE network, which moves every round: no
   // window batching and nothing to overlap — each round's targets need the previous round's step.
+  PA_REQUIRE(d.double_q != 2, PA_ERR_UNSUPPORTED,
+             "pa_dqn_learn: a SARSA learner steps through pa_dqn_step (its batches carry the "
+             "committed next action, which the arena does not store)");
   const bool dbl = d.double_q != 0;
   const bool overlap = h->overlap && h->timing < 2 && !dbl;
   const int wcap = dbl ? 1 : h->wcap;

@@ -98,9 +98,10 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
 
 
 class DeepQLearning(PolicyLearner):
-    # How the next state is valued (pa_dqn_desc.double_q): False = max over the available next
-    # actions of Q_target (deep_q_learning.py:130-167); True = DoubleDQN's rule (double_dqn.py:29-57)
-    _double_q: bool = False
+    # How the next state is valued (pa_dqn_desc.double_q): 0 = max over the available next actions
+    # of Q_target (deep_q_learning.py:130-167); 1 = DoubleDQN's rule (double_dqn.py:29-57);
+    # 2 = DeepSARSA's, Q_target(s', batch.next_action) (deep_sarsa.py:59-78)
+    _double_q: int = 0
 
     def __init__(self, action_space: Any = None, hidden_dims: Optional[List[int]] = None,
                  exploration_module: Optional[ExplorationModule] = None,
@@ -222,7 +223,7 @@ class DeepQLearning(PolicyLearner):
         opt = self._optimizer.param_groups[0]
         desc_key = (dev.index, S, AD, H1, H2, max_b, max_a, self._discount_factor,
                     self._soft_update_tau, opt["lr"], tuple(opt["betas"]), opt["eps"],
-                    opt["weight_decay"], bool(opt["amsgrad"]), bool(self._double_q))
+                    opt["weight_decay"], bool(opt["amsgrad"]), int(self._double_q))
         if nat.handle is not None and nat.desc_key != desc_key:
             torch.cuda.synchronize(dev)
             nat.close()
@@ -232,7 +233,7 @@ class DeepQLearning(PolicyLearner):
                              tau=self._soft_update_tau, lr=opt["lr"], beta1=opt["betas"][0],
                              beta2=opt["betas"][1], eps=opt["eps"],
                              weight_decay=opt["weight_decay"], amsgrad=int(opt["amsgrad"]),
-                             double_q=int(bool(self._double_q)))
+                             double_q=int(self._double_q))
             handle = C.c_void_p()
             N.check(N.lib().pa_dqn_create(C.byref(handle), C.byref(desc)))
             nat.handle, nat.desc_key, nat.sig = handle, desc_key, ()
@@ -312,11 +313,18 @@ class DeepQLearning(PolicyLearner):
         A = nav.shape[-2]
         if mask is not None:
             mask = mask.to(dev).reshape(B, A).to(torch.uint8).contiguous()
+        next_action = None
+        if int(self._double_q) == 2:
+            assert batch.next_action is not None, "SARSA needs to have next action"
+            next_action = f32(batch.next_action).reshape(B, -1)
+            assert next_action.shape[1] == AD, (
+                f"next_action representation has width {next_action.shape[1]}, expected {AD}")
         nb = N.DqnBatch(B=B, A=A, x=None, state=state.data_ptr(), action_rep=action.data_ptr(),
                         reward=reward.data_ptr(), terminated=term.data_ptr(),
                         next_state=next_state.data_ptr(), next_avail_rep=nav.data_ptr(),
-                        next_mask=N.ptr(mask), next_avail_bcast=bcast)
-        return nb, [state, action, next_state, reward, term, nav, mask]
+                        next_mask=N.ptr(mask), next_avail_bcast=bcast,
+                        next_action_rep=N.ptr(next_action))
+        return nb, [state, action, next_state, reward, term, nav, mask, next_action]
 
     # ------------------------------------------------------------------ API
     def _target_update_due(self) -> bool:
@@ -377,6 +385,8 @@ class DeepQLearning(PolicyLearner):
     def _arena_path_ok(self, replay_buffer: ReplayBuffer) -> bool:
         if not isinstance(replay_buffer, TensorBasedReplayBuffer) or replay_buffer.arena is None:
             return False
+        if int(self._double_q) == 2:
+            return False    # SARSA batches carry the committed next action: generic loop
         rep = self.action_representation_module
         z = replay_buffer._layout
         onehot = isinstance(rep, OneHotActionTensorRepresentationModule)

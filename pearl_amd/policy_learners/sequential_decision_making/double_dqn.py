@@ -20,7 +20,7 @@ from .deep_q_learning import DeepQLearning
 
 
 class DoubleDQN(DeepQLearning):
-    _double_q = True
+    _double_q = 1
 
     def compare(self, other: PolicyLearner) -> str:
         diffs = [super().compare(other)]

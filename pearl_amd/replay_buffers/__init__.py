@@ -1,6 +1,7 @@
 from .basic_replay_buffer import BasicReplayBuffer, TensorBasedReplayBuffer
 from .replay_buffer import ReplayBuffer
+from .sarsa_replay_buffer import SARSAReplayBuffer
 from .transition import Transition, TransitionBatch
 
-__all__ = ["BasicReplayBuffer", "TensorBasedReplayBuffer", "ReplayBuffer", "Transition",
+__all__ = ["BasicReplayBuffer", "TensorBasedReplayBuffer", "ReplayBuffer", "SARSAReplayBuffer", "Transition",
            "TransitionBatch"]

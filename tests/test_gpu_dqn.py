@@ -415,3 +415,52 @@ def test_full_size_config2_learn_properties():
         assert torch.equal(a, b), k
     assert all(np.isfinite(l1)) and p1._training_steps == 60
     assert any(not torch.equal(t0[k], v) for k, v in p1._Q_target.state_dict().items())
+
+
+@pytest.mark.parametrize("name", ["sarsa_tiny", "sarsa_wrap"])
+def test_deep_sarsa_and_sarsa_replay_buffer(name):
+    """SARSAReplayBuffer (delayed completion, dropped chain, terminal dummies, FIFO wrap with the
+    next_action side column) + DeepSARSA (Q_target(s', committed action) through the fused kernel
+    with one action per row) against the reference run."""
+    import os
+    from conftest import GOLDEN_DIR
+    from pearl_amd import (DeepSARSA, OneHotActionTensorRepresentationModule, PearlAgent,
+                           SARSAReplayBuffer)
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    cfg = fx["config"]
+    A = cfg["A"]
+    pl = DeepSARSA(state_dim=cfg["S"], action_space=_space(A), hidden_dims=cfg["hidden"],
+                   training_rounds=cfg["rounds"], batch_size=cfg["B"],
+                   action_representation_module=OneHotActionTensorRepresentationModule(A))
+    assert pl.on_policy
+    pl._Q.load_state_dict(fx["params0"])
+    pl._Q_target.load_state_dict(fx["target0"])
+    rb = SARSAReplayBuffer(cfg["capacity"], sampler="python")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    for p in fx["pushes"]:
+        rb.push(state=p["state"], action=torch.tensor([p["action"]]), reward=p["reward"],
+                terminated=p["terminated"], truncated=p["truncated"],
+                curr_available_actions=_space(A), next_state=p["next_state"],
+                next_available_actions=_space(A), max_number_actions=A)
+    assert len(rb) == fx["stored"]
+    random.seed(fx["sample_seed"])
+    raw = rb.sample(cfg["B"])
+    for k, want in fx["batch_raw"].items():
+        got = getattr(raw, k).cpu()
+        assert got.dtype == want.dtype and torch.equal(got, want), k
+    batch = pl.preprocess_batch(raw)
+    for k, want in fx["batch_pre"].items():
+        assert torch.equal(getattr(batch, k).cpu(), want), k
+    out = pl.q_values_and_targets(batch)
+    torch.testing.assert_close(out["q"].cpu(), fx["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["next_v"].cpu(), fx["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["target"].cpu(), fx["target"], rtol=1e-5, atol=1e-6)
+    random.seed(fx["learn_seed"])
+    report = pl.learn(rb)
+    torch.testing.assert_close(torch.tensor(report["loss"]), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    assert pl._training_steps == fx["training_steps_after"]
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(pl._Q.state_dict()[k].cpu(), fx["params_after"][k], rtol=1e-3,
+                                   atol=2e-5, msg=k)
+        torch.testing.assert_close(pl._Q_target.state_dict()[k].cpu(), fx["target_after"][k],
+                                   rtol=1e-3, atol=2e-5, msg=k)

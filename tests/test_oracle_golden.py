@@ -113,3 +113,47 @@ def test_philox_sampler_is_a_uniform_subset_sampler():
     expected = 400 * 5 / 20
     chi2 = ((counts - expected) ** 2 / expected).sum()
     assert chi2 < 43.8  # 99.9th percentile of chi2(19)
+
+
+SARSA = ["sarsa_tiny", "sarsa_wrap"]
+
+
+def load_sarsa(name):
+    from conftest import GOLDEN_DIR
+    import os
+    return torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+
+
+def fill_sarsa_oracle(fx):
+    rb = O.SarsaReplayOracle(fx["config"]["capacity"])
+    A = fx["config"]["A"]
+    for p in fx["pushes"]:
+        rb.push(p["state"], torch.tensor([p["action"]]), p["reward"], p["terminated"], p["truncated"],
+                A, p["next_state"], A, A)
+    return rb
+
+
+@pytest.mark.parametrize("name", SARSA)
+def test_sarsa_replay_and_learner_oracle(name):
+    """SarsaReplayOracle + DqnOracle(sarsa=True) against the reference's SARSAReplayBuffer +
+    DeepSARSA: which pushes end up stored (delayed completion, dropped chain, FIFO wrap), the
+    sampled rows incl. next_action bit-exact, Q / next values / targets, the learn() trajectory."""
+    fx = load_sarsa(name)
+    cfg = fx["config"]
+    rb = fill_sarsa_oracle(fx)
+    assert len(rb) == fx["stored"]
+    raw = rb.sample_at(fx["sample_idx"].tolist())
+    for k, want in fx["batch_raw"].items():
+        assert torch.equal(raw[k], want), k
+    pre = O.preprocess(raw, cfg["A"])
+    for k, want in fx["batch_pre"].items():
+        assert torch.equal(pre[k], want), k
+    pl = O.DqnOracle(fx["params0"], fx["target0"], sarsa=True, tau=0.1)   # deep_td_learning.py:61
+    torch.testing.assert_close(pl.q_values(pre["state"], pre["action"]), fx["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pl.bellman_target(pre), fx["target"], rtol=1e-5, atol=1e-6)
+    random.seed(fx["learn_seed"])
+    losses = pl.learn(rb, cfg["rounds"], cfg["B"], cfg["A"])
+    torch.testing.assert_close(torch.tensor(losses), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(pl.p[k], fx["params_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(pl.t[k], fx["target_after"][k], rtol=1e-3, atol=2e-5, msg=k)
