@@ -237,8 +237,63 @@ def make_sarsa(name, cfg):
           f"pushes; losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")
 
 
+def her_reward(state, action):
+    """Deterministic sparse reward of the HER fixture: 0 when the state part is close to the goal
+    slot, else -1 (any pure function of (state, action) serves the fixture)."""
+    g = state.shape[0] // 2
+    return 0.0 if float((state[:g] - state[g:]).abs().sum()) < 1.5 else -1.0
+
+
+def her_terminated(state, action):
+    g = state.shape[0] // 2
+    return bool(float((state[:g] - state[g:]).abs().sum()) < 0.75)
+
+
+def make_her(name="her_tiny"):
+    """HindsightExperienceReplayBuffer (hindsight_experience_replay_buffer.py:19-160): three
+    episodes (terminated, truncated, unfinished) of states [observation | goal] with goal_dim =
+    observation dim; everything the buffer holds afterwards, oldest first."""
+    from pearl.replay_buffers.sequential_decision_making.hindsight_experience_replay_buffer import (
+        HindsightExperienceReplayBuffer,
+    )
+    G, A, cap = 3, 3, 64
+    gen = torch.Generator().manual_seed(77)
+    fx = {"config": dict(G=G, A=A, capacity=cap), "variants": {}}
+    for variant, term_fn in (("reward_only", None), ("with_terminated_fn", her_terminated)):
+        rb = HindsightExperienceReplayBuffer(cap, G, her_reward, term_fn)
+        rb._is_action_continuous = False
+        rb.device_for_batches = torch.device("cpu")
+        pushes = []
+        lengths, ends = (5, 4, 3), ("terminated", "truncated", None)
+        gen.manual_seed(77)
+        for L, end in zip(lengths, ends):
+            goal = torch.randn(G, generator=gen)
+            obs = torch.randn(L + 1, G, generator=gen)
+            for t in range(L):
+                last = t == L - 1
+                p = dict(state=torch.cat([obs[t], goal]), action=int(torch.randint(0, A, (1,), generator=gen)),
+                         reward=-1.0, terminated=bool(last and end == "terminated"),
+                         truncated=bool(last and end == "truncated"),
+                         next_state=torch.cat([obs[t + 1], goal]))
+                pushes.append({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in p.items()})
+                rb.push(state=p["state"], action=torch.tensor([p["action"]]), reward=p["reward"],
+                        terminated=p["terminated"], truncated=p["truncated"],
+                        curr_available_actions=space(A), next_state=p["next_state"],
+                        next_available_actions=space(A), max_number_actions=A)
+        rows = list(rb.memory)
+        fields = ("state", "action", "reward", "terminated", "truncated", "next_state")
+        fx["variants"][variant] = dict(
+            pushes=pushes, stored=len(rb),
+            contents={k: torch.cat([getattr(r, k) for r in rows]) for k in fields})
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path}; stored {[v['stored'] for v in fx['variants'].values()]} rows")
+
+
 def main():
     only = sys.argv[1:]          # optional: names of the configurations to (re)generate
+    if not only or "her_tiny" in only:
+        make_her()
     for name, cfg in SARSA_CONFIGS.items():
         if not only or name in only:
             make_sarsa(name, cfg)

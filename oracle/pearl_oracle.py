@@ -130,6 +130,33 @@ class SarsaReplayOracle(ReplayOracle):
             self.memory.append(dict(row, next_action=row["action"]))               # :87-101
 
 
+class HerReplayOracle(ReplayOracle):
+    """HindsightExperienceReplayBuffer, "final" strategy
+    (hindsight_experience_replay_buffer.py:19-160): at the end of an episode its transitions are
+    pushed again with the goal slot overwritten by next_state[:-goal_dim] of the last transition and
+    the reward (optionally terminated) recomputed."""
+
+    def __init__(self, capacity: int, goal_dim: int, reward_fn, terminated_fn=None) -> None:
+        super().__init__(capacity)
+        self.goal_dim, self.reward_fn, self.terminated_fn = goal_dim, reward_fn, terminated_fn
+        self.trajectory: list = []
+
+    def push(self, state, action, reward, terminated, truncated, n_curr: int, next_state,
+             n_next: int, max_number_actions: int) -> None:
+        ReplayOracle.push(self, state, action, reward, terminated, truncated, n_curr, next_state,
+                          n_next, max_number_actions)
+        self.trajectory.append((state, action, next_state, n_curr, n_next, terminated, truncated))
+        if terminated or truncated:
+            goal = next_state[: -self.goal_dim]
+            for (st, act, nst, nc, nn_, term, trunc) in self.trajectory:
+                st[-self.goal_dim:] = goal
+                nst[-self.goal_dim:] = goal
+                ReplayOracle.push(self, st, act, self.reward_fn(st, act),
+                                  term if self.terminated_fn is None else self.terminated_fn(st, act),
+                                  trunc, nc, nst, nn_, max_number_actions)
+            self.trajectory = []
+
+
 def one_hot(x: torch.Tensor, n: int) -> torch.Tensor:
     if x.ndim == 1:
         x = x.unsqueeze(-1)

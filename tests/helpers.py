@@ -21,3 +21,14 @@ def oracle_learner(fx) -> DqnOracle:
 
 def batch_pre_as_oracle_dict(fx):
     return {k: v for k, v in fx["batch_pre"].items()}
+
+
+# the pure (state, action) functions oracle/make_golden.py gave the reference's HER buffer
+def her_reward(state, action):
+    g = state.shape[0] // 2
+    return 0.0 if float((state[:g] - state[g:]).abs().sum()) < 1.5 else -1.0
+
+
+def her_terminated(state, action):
+    g = state.shape[0] // 2
+    return bool(float((state[:g] - state[g:]).abs().sum()) < 0.75)

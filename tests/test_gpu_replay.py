@@ -273,3 +273,31 @@ def test_presampled_index_lists_feed_sample_in_order(golden):
     assert rb._presampled is None
     # python-sampler buffers never presample (their index stream is Python's `random`)
     assert not fill_arena_buffer(fx, "python").presample(2, 8)
+
+
+@pytest.mark.parametrize("variant", ["reward_only", "with_terminated_fn"])
+def test_hindsight_experience_replay_buffer(variant):
+    """HindsightExperienceReplayBuffer on the arena against the reference's buffer contents:
+    original pushes plus the goal-relabelled copies pushed at each episode end (reward — and with
+    a terminated_fn also the terminal flag — recomputed), bit-exact and in FIFO order; the
+    unfinished last episode is not relabelled."""
+    import os
+    from conftest import GOLDEN_DIR
+    from helpers import her_reward, her_terminated
+    from pearl_amd import HindsightExperienceReplayBuffer
+    fx = torch.load(os.path.join(GOLDEN_DIR, "her_tiny.pt"), map_location="cpu", weights_only=False)
+    v, cfg = fx["variants"][variant], fx["config"]
+    rb = HindsightExperienceReplayBuffer(cfg["capacity"], cfg["G"], her_reward,
+                                         her_terminated if variant == "with_terminated_fn" else None,
+                                         sampler="python")
+    rb.device_for_batches = torch.device("cuda:0")
+    for p in v["pushes"]:
+        rb.push(state=p["state"].clone(), action=torch.tensor([p["action"]]), reward=p["reward"],
+                terminated=p["terminated"], truncated=p["truncated"],
+                curr_available_actions=_space(cfg["A"]), next_state=p["next_state"].clone(),
+                next_available_actions=_space(cfg["A"]), max_number_actions=cfg["A"])
+    assert len(rb) == v["stored"]
+    cols = rb.state_dict()["columns"]
+    for k, want in v["contents"].items():
+        got = cols[k]
+        assert torch.equal(got.reshape(want.shape).to(want.dtype), want), k

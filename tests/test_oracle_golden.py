@@ -157,3 +157,21 @@ def test_sarsa_replay_and_learner_oracle(name):
     for k in O.PARAM_KEYS:
         torch.testing.assert_close(pl.p[k], fx["params_after"][k], rtol=1e-3, atol=2e-5, msg=k)
         torch.testing.assert_close(pl.t[k], fx["target_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+
+
+@pytest.mark.parametrize("variant", ["reward_only", "with_terminated_fn"])
+def test_her_replay_oracle(variant):
+    """HerReplayOracle against the reference's HindsightExperienceReplayBuffer: every stored row
+    (original pushes + goal-relabelled copies at episode ends), bit-exact, oldest first."""
+    from helpers import her_reward, her_terminated
+    fx = load_sarsa("her_tiny")
+    v, cfg = fx["variants"][variant], fx["config"]
+    rb = O.HerReplayOracle(cfg["capacity"], cfg["G"], her_reward,
+                           her_terminated if variant == "with_terminated_fn" else None)
+    for p in v["pushes"]:
+        rb.push(p["state"].clone(), torch.tensor([p["action"]]), p["reward"], p["terminated"],
+                p["truncated"], cfg["A"], p["next_state"].clone(), cfg["A"], cfg["A"])
+    assert len(rb) == v["stored"]
+    got = rb.sample_at(range(len(rb)))
+    for k, want in v["contents"].items():
+        assert torch.equal(got[k].reshape(want.shape), want), k
