@@ -298,3 +298,102 @@ def test_gradient_allreduce_is_a_mean_over_ranks():
         assert p.exitcode == 0
     want = (torch.arange(8, dtype=torch.float32) * (1 + 2) / 2).tolist()   # mean of g and 2g
     assert results[0] == want and results[1] == want
+
+
+# ---------------------------------------------------------------------------- constructor parity
+def _load_fx(name):
+    return torch.load(os.path.join(REPO, "tests", "golden", f"{name}.pt"), map_location="cpu",
+                      weights_only=False)
+
+
+def _same_sd(module, want, what):
+    sd = module.state_dict()
+    assert list(sd) == list(want), what
+    for k in sd:
+        assert torch.equal(sd[k], want[k]), f"{what}.{k}"
+
+
+def _box(fx):
+    from pearl_amd import BoxActionSpace
+    return BoxActionSpace(fx["low"], fx["high"])
+
+
+def _disc(n):
+    from pearl_amd import DiscreteActionSpace
+    return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
+
+
+@pytest.mark.parametrize("name,seed", [("sac_tiny", 6), ("sac_cfg3_shape_small", 6),
+                                       ("ddpg_tiny", 16), ("td3_cfg3_shape_small", 16),
+                                       ("dsac_tiny", 26), ("dsac_shape_small", 26),
+                                       ("iql_continuous_tiny", 36), ("iql_discrete_tiny", 36),
+                                       ("sarsa_tiny", 7), ("ppo_tiny", 5)])
+def test_actor_critic_family_constructors_match_reference(name, seed):
+    """Same torch seed -> the same initial networks as the reference's constructors (same modules
+    created in the same order with the same initialisers), the same state_dict keys, the same
+    optimizer hyper-parameters and learner defaults.  Runs on the CPU: no kernel is involved."""
+    import pearl_amd as P
+    from pearl_amd.neural_networks.sequential_decision_making.actor_networks import (
+        VanillaActorNetwork, VanillaContinuousActorNetwork)
+    fx = _load_fx(name)
+    cfg = fx["config"]
+    torch.manual_seed(seed)
+    kind = name.split("_")[0]
+    if kind == "sac":
+        pl = P.ContinuousSoftActorCritic(action_space=_box(fx), state_dim=cfg["S"],
+                                         actor_hidden_dims=cfg["hidden"],
+                                         critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"])
+        assert (pl._actor_learning_rate, pl._critic_soft_update_tau, pl.on_policy) == (1e-3, 0.005, False)
+    elif kind in ("ddpg", "td3"):
+        cls = P.TD3 if kind == "td3" else P.DeepDeterministicPolicyGradient
+        pl = cls(action_space=_box(fx), state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"],
+                 critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"])
+        assert pl._use_actor_target and pl._actor_soft_update_tau == 0.005
+        # the fixture's targets were perturbed after construction; fresh targets copy the online nets
+        _same_sd(pl._actor_target, fx["actor0"], "actor_target")
+        if kind == "td3":
+            assert (pl._actor_update_freq, pl._actor_update_noise, pl._actor_update_noise_clip) == (2, 0.2, 0.5)
+    elif kind == "dsac":
+        pl = P.SoftActorCritic(action_space=_disc(cfg["A"]), state_dim=cfg["S"],
+                               actor_hidden_dims=cfg["hidden"], critic_hidden_dims=cfg["hidden"],
+                               batch_size=cfg["B"],
+                               action_representation_module=P.OneHotActionTensorRepresentationModule(cfg["A"]))
+        g = pl._entropy_optimizer.param_groups[0]
+        assert type(pl._entropy_optimizer).__name__ == "Adam" and (g["lr"], g["eps"]) == (1e-4, 1e-4)
+        want = -0.89 * torch.log(1.0 / torch.tensor(cfg["A"]))
+        assert torch.equal(pl._target_entropy, want)
+    elif kind == "iql":
+        kw = dict(state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"], critic_hidden_dims=cfg["hidden"],
+                  value_critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"], expectile=cfg["expectile"])
+        if cfg["continuous"]:
+            pl = P.ImplicitQLearning(action_space=_box(fx),
+                                     actor_network_type=VanillaContinuousActorNetwork, **kw)
+        else:
+            pl = P.ImplicitQLearning(action_space=_disc(cfg["A"]), actor_network_type=VanillaActorNetwork,
+                                     action_representation_module=P.OneHotActionTensorRepresentationModule(cfg["A"]),
+                                     **kw)
+        _same_sd(pl._value_network, fx["value0"], "value")
+        assert pl._critic_soft_update_tau == 0.05 and pl._is_action_continuous == cfg["continuous"]
+    elif kind == "sarsa":
+        pl = P.DeepSARSA(state_dim=cfg["S"], action_space=_disc(cfg["A"]), hidden_dims=cfg["hidden"],
+                         training_rounds=cfg["rounds"], batch_size=cfg["B"],
+                         action_representation_module=P.OneHotActionTensorRepresentationModule(cfg["A"]))
+        _same_sd(pl._Q, fx["params0"], "Q")
+        _same_sd(pl._Q_target, fx["target0"], "Q_target")
+        assert pl.on_policy is True and pl._soft_update_tau == 0.1
+        d = P.DeepSARSA(state_dim=3, action_space=_disc(2), hidden_dims=[4, 4],
+                        action_representation_module=P.OneHotActionTensorRepresentationModule(2))
+        assert (d._training_rounds, d._batch_size) == (100, 128)     # DeepTDLearning's defaults
+        return
+    else:
+        pl = P.ProximalPolicyOptimization(
+            action_space=_disc(cfg["A"]), state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"],
+            critic_hidden_dims=cfg["hidden"], training_rounds=cfg["rounds"], batch_size=cfg["B"],
+            epsilon=cfg["epsilon"],
+            action_representation_module=P.OneHotActionTensorRepresentationModule(cfg["A"]))
+        assert pl.on_policy is True
+    _same_sd(pl._actor, fx["actor0"], "actor")
+    _same_sd(pl._critic, fx["critic0"], "critic")
+    for opt in (pl._actor_optimizer, pl._critic_optimizer):
+        g = opt.param_groups[0]
+        assert type(opt).__name__ == "AdamW" and g["amsgrad"] is True
