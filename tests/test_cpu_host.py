@@ -397,3 +397,51 @@ def test_actor_critic_family_constructors_match_reference(name, seed):
     for opt in (pl._actor_optimizer, pl._critic_optimizer):
         g = opt.param_groups[0]
         assert type(opt).__name__ == "AdamW" and g["amsgrad"] is True
+
+
+def _family(kind, seed):
+    import pearl_amd as P
+    from pearl_amd.neural_networks.sequential_decision_making.actor_networks import (
+        VanillaContinuousActorNetwork)
+    torch.manual_seed(seed)
+    box = P.BoxActionSpace(-torch.ones(2), torch.ones(2))
+    rep = P.OneHotActionTensorRepresentationModule(3)
+    h = dict(actor_hidden_dims=[8, 8], critic_hidden_dims=[8, 8])
+    return {
+        "dqn": lambda: P.DeepQLearning(state_dim=4, action_space=_disc(3), hidden_dims=[8, 8],
+                                       action_representation_module=rep),
+        "ddqn": lambda: P.DoubleDQN(state_dim=4, action_space=_disc(3), hidden_dims=[8, 8],
+                                    action_representation_module=rep),
+        "sarsa": lambda: P.DeepSARSA(state_dim=4, action_space=_disc(3), hidden_dims=[8, 8],
+                                     action_representation_module=rep),
+        "ppo": lambda: P.ProximalPolicyOptimization(action_space=_disc(3), state_dim=4,
+                                                    action_representation_module=rep, **h),
+        "sac": lambda: P.ContinuousSoftActorCritic(action_space=box, state_dim=4, **h),
+        "dsac": lambda: P.SoftActorCritic(action_space=_disc(3), state_dim=4,
+                                          action_representation_module=rep, **h),
+        "ddpg": lambda: P.DeepDeterministicPolicyGradient(action_space=box, state_dim=4, **h),
+        "td3": lambda: P.TD3(action_space=box, state_dim=4, **h),
+        "iql": lambda: P.ImplicitQLearning(action_space=box, state_dim=4,
+                                           value_critic_hidden_dims=[8, 8],
+                                           actor_network_type=VanillaContinuousActorNetwork, **h),
+    }[kind]()
+
+
+@pytest.mark.parametrize("kind", ["dqn", "ddqn", "sarsa", "ppo", "sac", "dsac", "ddpg", "td3", "iql"])
+def test_state_dict_round_trip_and_compare(kind):
+    """The reference's serialization contract (README.md:23-46, test_serialization.py:23-43,
+    test_compare.py): differently initialised learners compare as different; torch.save ->
+    torch.load -> load_state_dict(strict=True) makes compare() return ""; a learner of another class
+    never compares equal."""
+    import io
+    from pearl_amd import BasicReplayBuffer, PearlAgent
+    a = PearlAgent(_family(kind, 1), replay_buffer=BasicReplayBuffer(8))
+    b = PearlAgent(_family(kind, 2), replay_buffer=BasicReplayBuffer(8))
+    assert a.policy_learner.compare(b.policy_learner) != ""
+    buf = io.BytesIO()
+    torch.save(a.state_dict(), buf)
+    buf.seek(0)
+    b.load_state_dict(torch.load(buf, weights_only=False), strict=True)
+    assert a.policy_learner.compare(b.policy_learner) == ""
+    other = _family("dqn" if kind != "dqn" else "ppo", 3)
+    assert a.policy_learner.compare(other) != ""
