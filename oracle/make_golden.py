@@ -49,6 +49,12 @@ CONFIGS = {
     "cfg1_cartpole_shape": dict(S=4, A=2, hidden=[64, 64], N=600, B=128, rounds=12, dynamic=False),
     "cfg2_shape_small_batch": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=12,
                                    dynamic=False),
+    # DeepQLearning(is_conservative=True) (deep_td_learning.py:323-327): files cql_<name>.pt.  Pins
+    # the oracle now; the HIP learner still raises NotImplementedError for is_conservative
+    "cql_tiny_dynamic": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
+                             learner="cql"),
+    "cql_small": dict(S=16, A=6, hidden=[32, 32], N=300, B=64, rounds=12, dynamic=False,
+                      learner="cql"),
     # DoubleDQN (double_dqn.py:29-57): files ddqn_<name>.pt
     "double_tiny_dynamic": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
                                 learner="double"),
@@ -101,7 +107,9 @@ def make(name, cfg):
     rep = OneHotActionTensorRepresentationModule(A)
     torch.manual_seed(7)  # the learner's parameter init
     double = cfg.get("learner") == "double"
-    pl = (DoubleDQN if double else DeepQLearning)(state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
+    cql = cfg.get("learner") == "cql"
+    extra = dict(is_conservative=True, conservative_alpha=2.0) if cql else {}
+    pl = (DoubleDQN if double else DeepQLearning)(**extra, state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
                        training_rounds=cfg["rounds"], batch_size=B,
                        action_representation_module=rep)
     rb = BasicReplayBuffer(cfg["N"] + 10)
@@ -161,7 +169,8 @@ def make(name, cfg):
                         ("step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")}
     fx["opt_after"] = opt_state
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, f"ddqn_{name[len('double_'):]}.pt" if double else f"dqn_{name}.pt")
+    path = os.path.join(OUT, f"ddqn_{name[len('double_'):]}.pt" if double
+                        else (f"{name}.pt" if cql else f"dqn_{name}.pt"))
     torch.save(fx, path)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); "
           f"losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")

@@ -187,11 +187,14 @@ class DqnOracle:
     def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor],
                  gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  weight_decay: float = 0.01, tau: float = 0.75, target_update_freq: int = 10,
-                 double_q: bool = False, sarsa: bool = False):
+                 double_q: bool = False, sarsa: bool = False, conservative_alpha: float = 0.0):
         # double_q: DoubleDQN.get_next_state_values (double_dqn.py:29-57) instead of
         # DeepQLearning's (deep_q_learning.py:130-167); sarsa: DeepSARSA's (deep_sarsa.py:59-78)
         self.double_q = bool(double_q)
         self.sarsa = bool(sarsa)
+        # > 0: DeepTDLearning(is_conservative=True): loss += alpha * compute_cql_loss
+        # (deep_td_learning.py:323-327, loss_fn_utils.py:17-72)
+        self.conservative_alpha = float(conservative_alpha)
         self.p = {k: params[k].detach().clone().to(F32) for k in PARAM_KEYS}
         self.t = {k: target[k].detach().clone().to(F32) for k in PARAM_KEYS}
         self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
@@ -278,11 +281,36 @@ class DqnOracle:
         for k in PARAM_KEYS:
             self.t[k].copy_(self.tau * self.p[k] + (1.0 - self.tau) * self.t[k])
 
+    def cql_loss(self, w: Dict[str, torch.Tensor], batch) -> torch.Tensor:
+        """compute_cql_loss (loss_fn_utils.py:17-72), literally: logsumexp over the Q-values of all
+        (padded, unmasked) current available actions, minus the mean of
+        ``q_all.gather(1, batch.action.long())`` — with a one-hot ``batch.action`` that index matrix
+        holds 0s and 1s, so the second term averages Q(s, a_0) (A - 1 times) and Q(s, a_1) (once)
+        per row whatever action was taken.  Restated as the reference computes it."""
+        ca = batch["curr_available_actions"]
+        B, A, _ = ca.shape
+        s = batch["state"].unsqueeze(1).expand(B, A, batch["state"].shape[1])
+        q_all = self._mlp(w, torch.cat([s, ca], dim=-1))[2].view(B, -1)
+        picked = q_all.gather(1, batch["action"].long())
+        return torch.logsumexp(q_all, dim=-1).mean() - picked.mean()
+
+    def conservative_gradients(self, batch, target: torch.Tensor):
+        """Gradients of  mse(Q(s, a), y) + alpha * cql_loss  by autograd on copies of the parameters."""
+        w = {k: v.detach().clone().requires_grad_(True) for k, v in self.p.items()}
+        q = self._mlp(w, torch.cat([batch["state"], batch["action"]], dim=-1))[2]
+        loss = torch.nn.functional.mse_loss(q, target) + self.conservative_alpha * self.cql_loss(w, batch)
+        grads = torch.autograd.grad(loss, [w[k] for k in PARAM_KEYS])
+        return q.detach(), dict(zip(PARAM_KEYS, grads)), float(loss.detach())
+
     def learn_batch(self, batch) -> float:
         """`batch` is preprocessed (one-hot actions).  Returns mean |Q - target|."""
         if (self.training_steps + 1) % self.freq == 0:
             self.soft_update()
         target = self.bellman_target(batch)
+        if self.conservative_alpha > 0:
+            q, g, _ = self.conservative_gradients(batch, target)
+            self.adamw(g)
+            return float((q - target).abs().mean())
         q, g = self.gradients(batch, target)
         self.adamw(g)
         return float((q - target).abs().mean())

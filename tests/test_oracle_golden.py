@@ -175,3 +175,28 @@ def test_her_replay_oracle(variant):
     got = rb.sample_at(range(len(rb)))
     for k, want in v["contents"].items():
         assert torch.equal(got[k].reshape(want.shape), want), k
+
+
+@pytest.mark.parametrize("name", ["cql_tiny_dynamic", "cql_small"])
+def test_conservative_q_learning_oracle(name):
+    """DqnOracle(conservative_alpha=2) against the reference's DeepQLearning(is_conservative=True):
+    total loss (Bellman MSE + alpha * compute_cql_loss), its gradients and the learn() trajectory.
+    Pins the oracle ahead of the HIP implementation (the learner still refuses is_conservative)."""
+    fx = load_sarsa(name)
+    cfg = fx["config"]
+    pl = O.DqnOracle(fx["params0"], fx["target0"], conservative_alpha=2.0)
+    b = fx["batch_pre"]
+    target = pl.bellman_target(b)
+    torch.testing.assert_close(target, fx["target"], rtol=1e-5, atol=1e-6)
+    q, g, loss = pl.conservative_gradients(b, fx["target"])
+    torch.testing.assert_close(q, fx["q"], rtol=1e-5, atol=1e-6)
+    assert abs(loss - float(fx["mse"])) <= 1e-5 * max(1.0, abs(float(fx["mse"])))
+    for k, want in fx["grads"].items():
+        torch.testing.assert_close(g[k].reshape(want.shape), want, rtol=2e-4, atol=2e-6, msg=k)
+    rb = fill_oracle_replay(fx)
+    random.seed(fx["learn_seed"])
+    losses = pl.learn(rb, cfg["rounds"], cfg["B"], cfg["A"])
+    torch.testing.assert_close(torch.tensor(losses), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    for k in O.PARAM_KEYS:
+        torch.testing.assert_close(pl.p[k], fx["params_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(pl.t[k], fx["target_after"][k], rtol=1e-3, atol=2e-5, msg=k)
