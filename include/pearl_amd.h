@@ -456,6 +456,16 @@ int pa_dsac_target(const float* logits, int32_t ldl, const float* q1, const floa
                    const uint8_t* terminated, float gamma, int32_t B, int32_t A, float* y,
                    void* stream);
 
+/* DeepTDLearning(is_conservative=True) (deep_td_learning.py:292-331, loss_fn_utils.py:17-72).
+ * EXPERIMENTAL: written against the pinned oracle, not yet validated on the GPU; the Python learner
+ * only reaches it with PEARL_AMD_EXPERIMENTAL_CQL=1.  Head of the (B + B A)-row pass: q_rows[0, B)
+ * = Q(s_b, a_b), q_rows[B + b A + i] = Q(s_b, available action i) (padded, unmasked).  dq_rows
+ * gets 2 (q - y) / B on the first B rows and alpha (softmax_i / B - count[b, i] / (B AD)) on the
+ * rest, count = how often i appears in long(action[b, :]) (the reference's gather index);
+ * loss_out[0] = mean |q - y| (the reported loss), loss_out[1] = mse + alpha cql. */
+int pa_cql_head(const float* q_rows, const float* y, const float* action, int32_t lda, int32_t B,
+                int32_t A, int32_t AD, float alpha, float* dq_rows, float* loss_out, void* stream);
+
 /* ImplicitQLearning (implicit_q_learning.py:159-285).
  * pa_iql_value_head: expectile regression of V(s) (v, pitch ldv) towards a target critic's Q(s, a)
  *   (tq_value): loss = mean(w d^2), d = tq - v, w = expectile if d > 0 else 1 - expectile (:186-196,

@@ -293,6 +293,8 @@ SIGNATURES = {
                                      C.c_int32, _P, _P, _P]),
     "pa_dsac_target": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int32,
                                  C.c_int32, _P, _P]),
+    "pa_cql_head": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, _P,
+                              _P, _P]),
     "pa_iql_value_head": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, C.c_float, C.c_float,
                                     C.c_int32, _P, _P, _P, _P]),
     "pa_awr_head": (C.c_int, [C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P,

@@ -1048,6 +1048,55 @@ __global__ __launch_bounds__(256) void awr_kernel(AwrArgs a) {
   if (threadIdx.x == 0) a.loss_out[0] = sum * invB;
 }
 
+// ---- conservative Q-learning (deep_td_learning.py:292-331, loss_fn_utils.py:17-72) -------------
+// One head for the (B + B A)-row pass of DeepQLearning(is_conservative=True):
+//   rows [0, B):  Q(s_b, a_b);  Bellman part  dq = 2 (q - y) / B,  reported loss mean |q - y|
+//   rows B + b A + i:  Q(s_b, available action i) (padded, unmasked — as the reference);
+//     cql = mean_b logsumexp_i q_all[b, i] - mean over (b, j) of q_all[b, long(action[b, j])]
+//     (the reference gathers with batch.action.long(), whatever batch.action holds: with a one-hot
+//     action that is column 0, A - 1 times, and column 1, once);
+//     dq = alpha (softmax_i / B - count[b, i] / (B AD))
+struct CqlArgs {
+  const float* q; const float* y;
+  const float* action; int lda;     // [B, AD] batch.action after preprocess_batch
+  int B, A, AD;
+  float alpha;
+  float* dq; float* loss_out;       // loss_out[0] = mean |q - y|, loss_out[1] = total loss
+};
+__global__ __launch_bounds__(256) void cql_head_kernel(CqlArgs a) {
+  __shared__ float red[256];
+  const float invB = 1.0f / (float)a.B;
+  float abs_part = 0.f, loss_part = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float d = a.q[b] - a.y[b];
+    a.dq[b] = 2.0f * d * invB;
+    abs_part += fabsf(d);
+    loss_part += d * d * invB;
+    const float* qa = a.q + a.B + (int64_t)b * a.A;
+    float* dqa = a.dq + a.B + (int64_t)b * a.A;
+    float m = qa[0];
+    for (int i = 1; i < a.A; ++i) m = fmaxf(m, qa[i]);
+    float s = 0.f;
+    for (int i = 0; i < a.A; ++i) s += expf(qa[i] - m);
+    loss_part += a.alpha * (m + logf(s)) * invB;
+    for (int i = 0; i < a.A; ++i) dqa[i] = a.alpha * (expf(qa[i] - m) / s) * invB;
+    const float w = a.alpha * invB / (float)a.AD;
+    for (int j = 0; j < a.AD; ++j) {
+      const int idx = (int)(long long)a.action[(int64_t)b * a.lda + j];
+      if (idx >= 0 && idx < a.A) {
+        dqa[idx] -= w;
+        loss_part -= w * qa[idx];
+      }
+    }
+  }
+  const float s_abs = block_sum_256(abs_part, red);
+  const float s_loss = block_sum_256(loss_part, red);
+  if (threadIdx.x == 0) {
+    a.loss_out[0] = s_abs * invB;
+    a.loss_out[1] = s_loss;
+  }
+}
+
 // Twin-critic plumbing for SAC (soft_actor_critic_continuous.py:155-231).
 //   mode 0 (actor loss):  loss = mean(alpha * logp - min(q1, q2)); dq1/dq2 = -w/B with torch.minimum's
 //                         even split on ties
@@ -1668,6 +1717,19 @@ extern "C" int pa_awr_head(int32_t mode, const float* x, int32_t ldx, const floa
   a.x = x; a.ldx = ldx; a.action = action; a.lda = lda; a.adv = adv; a.B = B; a.A = A; a.mode = mode;
   a.dx = dx; a.lddx = lddx; a.loss_out = loss_out;
   hipLaunchKernelGGL(awr_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_cql_head(const float* q_rows, const float* y, const float* action, int32_t lda,
+                           int32_t B, int32_t A, int32_t AD, float alpha, float* dq_rows,
+                           float* loss_out, void* stream) {
+  PA_REQUIRE(q_rows && y && action && dq_rows && loss_out && B > 0 && A > 0 && AD > 0,
+             PA_ERR_INVALID, "pa_cql_head: bad argument");
+  CqlArgs a;
+  a.q = q_rows; a.y = y; a.action = action; a.lda = lda; a.B = B; a.A = A; a.AD = AD;
+  a.alpha = alpha; a.dq = dq_rows; a.loss_out = loss_out;
+  hipLaunchKernelGGL(cql_head_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

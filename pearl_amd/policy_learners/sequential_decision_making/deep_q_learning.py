@@ -69,6 +69,9 @@ class _NativeDqn:
         c, self.comm = getattr(self, "comm", None), None
         if c:
             N.lib().pa_comm_destroy(c)
+        q, self.cql = getattr(self, "cql", None), None
+        if q:
+            N.lib().pa_mlp_destroy(q[1])
 
     def __del__(self) -> None:  # pragma: no cover
         try:
@@ -120,8 +123,11 @@ class DeepQLearning(PolicyLearner):
                                 else EGreedyExploration(0.05)),
             on_policy=False, is_action_continuous=False,
             action_representation_module=action_representation_module, action_space=action_space)
-        if is_conservative:
-            raise NotImplementedError("pearl_amd DeepQLearning: the CQL term is not built yet")
+        if is_conservative and os.environ.get("PEARL_AMD_EXPERIMENTAL_CQL") != "1":
+            raise NotImplementedError(
+                "pearl_amd DeepQLearning: the CQL term (is_conservative=True) is written against the "
+                "reference-pinned oracle but not yet validated on the GPU; set "
+                "PEARL_AMD_EXPERIMENTAL_CQL=1 to try it")
         if optimizer is not None:
             raise NotImplementedError(
                 "pearl_amd DeepQLearning owns its AdamW(amsgrad) step; custom optimizers are not "
@@ -366,8 +372,89 @@ class DeepQLearning(PolicyLearner):
     def _dp_world(self) -> int:
         return world_size() if self.data_parallel else 1
 
+    # ------------------------------------------------------------------ CQL (experimental)
+    def _cql_engine(self, nat: _NativeDqn, rows: int, dev: torch.device) -> C.c_void_p:
+        """A generic pa_mlp handle over THIS learner's flat buffers (the two layouts coincide:
+        W1 | b1 | W2 | b2 | W3 | b3, every offset rounded up to 4 floats): forward with kept
+        activations, backward and AdamW for row counts and output gradients the fused DQN kernels
+        do not take."""
+        S, AD, H1, H2 = self._dims()
+        opt = self._optimizer.param_groups[0]
+        key = (id(nat.flat["q"]), rows, opt["lr"], tuple(opt["betas"]), opt["eps"],
+               opt["weight_decay"], bool(opt["amsgrad"]))
+        hit = getattr(nat, "cql", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        if hit is not None:
+            torch.cuda.synchronize(dev)
+            N.lib().pa_mlp_destroy(hit[1])
+        desc = N.MlpDesc(device=dev.index, n_layers=3, max_batch=rows, lr=opt["lr"],
+                         beta1=opt["betas"][0], beta2=opt["betas"][1], eps=opt["eps"],
+                         weight_decay=opt["weight_decay"], amsgrad=int(opt["amsgrad"]),
+                         no_last_bias=0, identity_layers=0)
+        for i, d in enumerate((S + AD, H1, H2, 1)):
+            desc.dims[i] = d
+        assert int(N.lib().pa_mlp_param_count(C.byref(desc))) == nat.flat["q"].numel()
+        h = C.c_void_p()
+        N.check(N.lib().pa_mlp_create(C.byref(h), C.byref(desc)))
+        f = nat.flat
+        bufs = N.MlpBuffers(p=f["q"].data_ptr(), p_target=f["q_target"].data_ptr(),
+                            grad=f["grad"].data_ptr(), exp_avg=f["exp_avg"].data_ptr(),
+                            exp_avg_sq=f["exp_avg_sq"].data_ptr(),
+                            max_exp_avg_sq=f["max_exp_avg_sq"].data_ptr())
+        N.check(N.lib().pa_mlp_bind(h, C.byref(bufs)))
+        nat.cql = (key, h)
+        return h
+
+    def _learn_batch_conservative(self, batch: TransitionBatch) -> Dict[str, Any]:
+        """DeepTDLearning.learn_batch with is_conservative (deep_td_learning.py:292-360):
+        loss = mse(Q(s, a), y) + alpha * compute_cql_loss (loss_fn_utils.py:17-72).  One pass of the
+        generic engine over B + B A rows — the taken pairs, then every (state, available action)
+        pair — with `pa_cql_head` supplying the output gradients."""
+        nb, keep = self._native_batch(batch)
+        nat = self._ensure_bound(nb.B, nb.A)
+        dev = keep[0].device
+        lib, stream = N.lib(), N.stream_ptr(dev)
+        state, action = keep[0], keep[1]
+        B, S = state.shape
+        AD = action.shape[1]
+        assert batch.curr_available_actions is not None, "the CQL term needs curr_available_actions"
+        rep = batch.curr_available_actions.to(dev, torch.float32).contiguous()
+        A = int(rep.shape[-2])
+        assert rep.ndim == 3 and rep.shape[0] == B and rep.shape[2] == AD
+        if self._target_update_due():
+            N.check(lib.pa_dqn_update_target(nat.handle, stream))
+        y = torch.empty(B, dtype=torch.float32, device=dev)
+        N.check(lib.pa_dqn_qvalues(nat.handle, C.byref(nb), None, None, y.data_ptr(), stream))
+        R = B + B * A
+        mlp = self._cql_engine(nat, R, dev)
+        X = torch.empty(R, S + AD, dtype=torch.float32, device=dev)
+        N.check(lib.pa_concat_cols(state.data_ptr(), state.stride(0), action.data_ptr(),
+                                   action.stride(0), X.data_ptr(), B, S, AD, stream))
+        N.check(lib.pa_expand_state_actions(state.data_ptr(), state.stride(0), rep.data_ptr(), A * AD,
+                                            B, A, S, AD, X[B:].data_ptr(), stream))
+        q_rows = torch.empty(R, dtype=torch.float32, device=dev)
+        N.check(lib.pa_mlp_forward(mlp, 0, X.data_ptr(), X.stride(0), R, q_rows.data_ptr(), 1, 1,
+                                   stream))
+        dq = torch.empty(R, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)     # mean |q - y| | total loss
+        N.check(lib.pa_cql_head(q_rows.data_ptr(), y.data_ptr(), action.data_ptr(), action.stride(0),
+                                B, A, AD, float(self._conservative_alpha), dq.data_ptr(),
+                                losses.data_ptr(), stream))
+        N.check(lib.pa_mlp_backward(mlp, X.data_ptr(), X.stride(0), R, dq.data_ptr(), 1, 1, None,
+                                    S + AD, stream))
+        step = self._adam_steps() + 1
+        if self._dp_world() > 1:
+            nat.flat["grad"].mul_(1.0 / self._dp_world())
+            allreduce_sum_(nat.flat["grad"])
+        N.check(lib.pa_mlp_adam(mlp, step, stream))
+        self._set_adam_steps(step)
+        return {"loss": losses[0].item()}
+
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         """One TD(0) update on a preprocessed batch (deep_td_learning.py:333-360)."""
+        if self._is_conservative:
+            return self._learn_batch_conservative(batch)
         nb, keep = self._native_batch(batch)
         nat = self._ensure_bound(nb.B, nb.A)
         dev = keep[0].device
@@ -387,6 +474,8 @@ class DeepQLearning(PolicyLearner):
             return False
         if int(self._double_q) == 2:
             return False    # SARSA batches carry the committed next action: generic loop
+        if self._is_conservative:
+            return False    # the CQL term is a per-batch pass of the generic engine
         rep = self.action_representation_module
         z = replay_buffer._layout
         onehot = isinstance(rep, OneHotActionTensorRepresentationModule)
