@@ -173,7 +173,8 @@ def main():
     # i.e. the single-stream loop, so that the kernel's own efficiency can be told apart from the
     # CU sharing of the overlapped loop.  N = 1 only: multi-GPU runs stay short.
     isolated = None
-    if world == 1 and args.timing_level == 1 and os.environ.get("PEARL_AMD_OVERLAP", "1") != "0":
+    overlapped = os.environ.get("PEARL_AMD_OVERLAP", "1") != "0" and args.timing_level < 2
+    if world == 1 and args.timing_level == 1 and overlapped:
         N.check(N.lib().pa_dqn_set_overlap(nat.handle, 0))
         N.check(N.lib().pa_dqn_enable_timing(nat.handle, 1))
         pl._training_rounds = 200
@@ -199,7 +200,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "final_loss": report["loss"][-1]},
         }
-        if "target" in timers:
+        if "target" in timers or isolated:
             # A launch covers several rounds of a target-update window: algorithmic flops of the
             # timed launches / their summed duration.  In the overlapped loop these launches share
             # the chip with the online chain (the persistent ones keep off the chain's 64 CUs), so
@@ -210,17 +211,25 @@ def main():
                 return (FLOP_TARGET_KERNEL_PER_TRANSITION * per_launch / (tt["avg_us"] * 1e-6),
                         per_launch)
 
-            tt = timers["target"]
+            # live = the launches sampled inside the timed region (the last, largest piece of every
+            # 4th window of the call, first window included); without a live sample (single-stream
+            # loop at timing level >= 2, multi-GPU runs) the calibration pass stands in and says so
+            live = "target" in timers
+            tt = timers["target"] if live else isolated
             ach, per_launch = kernel_rate(tt)
             step_rate = FLOP_PER_TRANSITION_STEP * B * args.steps / dt     # per GPU
-            line["roofline"] = {"bound": "mfma", "kernel": "target_fused_kernel<32> (classic grid) + target_pp_kernel<32> (persistent launches)",
+            line["roofline"] = {"bound": "mfma",
+                                "kernel": ("target_pp_kernel<32> (persistent launch of a target-update "
+                                           "window, overlapped loop)" if live and overlapped
+                                           else "target_fused_kernel<32> (classic grid)"),
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA,
                                 "traffic": pmc_traffic(per_launch),
                                 "avg_launch_us": tt["avg_us"],
                                 "transitions_per_launch": per_launch,
-                                "launches_timed": tt["n"]}
-            if isolated:
+                                "launches_timed": tt["n"],
+                                "source": "timed region" if live else "calibration pass"}
+            if isolated and live:
                 iach, iper = kernel_rate(isolated)
                 line["roofline"]["concurrent_with"] = ("online chain kernels on the 64 CUs the "
                                                        "persistent launches keep off (overlapped loop)")

@@ -299,10 +299,112 @@ def make_her(name="her_tiny"):
     print(f"{name}: wrote {path}; stored {[v['stored'] for v in fx['variants'].values()]} rows")
 
 
+
+def make_bootstrap(name="bootstrap_tiny"):
+    """BootstrapReplayBuffer (bootstrap_replay_buffer.py:23-114): the Bernoulli masks every push
+    draws from torch's global generator, the buffer contents after a FIFO wrap, and one sampled
+    `TransitionWithBootstrapMaskBatch` for a known index list; two variants (no wrap / wrap)."""
+    from pearl.replay_buffers.sequential_decision_making.bootstrap_replay_buffer import (
+        BootstrapReplayBuffer,
+    )
+    from pearl.replay_buffers.transition import filter_batch_by_bootstrap_mask
+    S, A, K, p, B = 5, 4, 6, 0.6, 16
+    fx = {"config": dict(S=S, A=A, K=K, p=p, B=B), "variants": {}}
+    for variant, N, cap in (("plain", 40, 64), ("wrap", 90, 37)):
+        gen = torch.Generator().manual_seed(2024)
+        states = torch.randn(N + 1, S, generator=gen)
+        rb = BootstrapReplayBuffer(cap, p, K)
+        rb._is_action_continuous = False
+        rb.device_for_batches = torch.device("cpu")
+        torch.manual_seed(99)              # the masks come from the global generator
+        for i in range(N):
+            rb.push(state=states[i], action=torch.tensor([i % A]), reward=float(i % 7),
+                    terminated=(i % 10 == 9), truncated=False,
+                    curr_available_actions=space(A), next_state=states[i + 1],
+                    next_available_actions=space(A), max_number_actions=A)
+        masks = torch.cat([t.bootstrap_mask for t in rb.memory])
+        random.seed(11)
+        idx = random.sample(range(len(rb)), B)
+        random.seed(11)
+        batch = rb.sample(B)
+        d = batch_to_dict(batch)
+        d["bootstrap_mask"] = batch.bootstrap_mask.detach().clone()
+        filt = filter_batch_by_bootstrap_mask(batch, torch.tensor(2))
+        fx["variants"][variant] = dict(
+            N=N, capacity=cap, states=states, mask_seed=99, stored=len(rb), masks=masks,
+            sample_seed=11, sample_idx=torch.tensor(idx), batch=d,
+            filtered_z2={k: (None if getattr(filt, k) is None else getattr(filt, k).detach().clone())
+                         for k in ("state", "action", "reward", "terminated", "next_state")})
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path}; stored {[v['stored'] for v in fx['variants'].values()]} rows, "
+          f"mask mean {float(fx['variants']['plain']['masks'].mean()):.3f}")
+
+
+def make_fullbatch(name="dqn_cfg2_fullbatch"):
+    """BASELINE config 2 AT ITS OWN BATCH SIZE (S=128, A=16, hidden [256,256], B=1024): the one-batch
+    quantities of DeepQLearning and DoubleDQN — Q(s,a), next-state values, Bellman targets, MSE,
+    mean |TD|, gradients — on one sampled batch, with a target network that differs from the
+    online one (so that DoubleDQN's argmax and DQN's max disagree).  Only the sampled batch is
+    stored (not the replay contents): the replay contract is pinned by the other fixtures."""
+    S, A, B, N, hidden = 128, 16, 1024, 4096, [256, 256]
+    torch.manual_seed(0)
+    random.seed(0)
+    gen = torch.Generator().manual_seed(1234)
+    cfg = dict(S=S, A=A, hidden=hidden, N=N, B=B, rounds=1, dynamic=False)
+    states, rows = synthetic_transitions(cfg, gen)
+    rep = OneHotActionTensorRepresentationModule(A)
+    rb = BasicReplayBuffer(N + 10)
+    rb._is_action_continuous = False
+    rb.device_for_batches = torch.device("cpu")
+    for r in rows:
+        rb.push(state=states[r["i"]], action=torch.tensor([r["action"]]), reward=r["reward"],
+                terminated=r["terminated"], truncated=r["truncated"],
+                curr_available_actions=space(A), next_state=states[r["i"] + 1],
+                next_available_actions=space(A), max_number_actions=A)
+    random.seed(11)
+    raw = rb.sample(B)
+    fx = {"config": cfg, "batch_raw": batch_to_dict(raw), "learners": {}}
+    for key, cls in (("dqn", DeepQLearning), ("ddqn", DoubleDQN)):
+        torch.manual_seed(7)
+        pl = cls(state_dim=S, action_space=space(A), hidden_dims=hidden, training_rounds=1,
+                 batch_size=B, action_representation_module=rep)
+        torch.manual_seed(8)     # a second, independent initialisation for the target network
+        other = cls(state_dim=S, action_space=space(A), hidden_dims=hidden, training_rounds=1,
+                    batch_size=B, action_representation_module=rep)
+        pl._Q_target.load_state_dict(other._Q.state_dict())
+        import copy
+        batch = pl.preprocess_batch(copy.deepcopy(raw))
+        q = pl._Q.get_q_values(batch.state, batch.action)
+        next_v = pl.get_next_state_values(batch, B)
+        loss, target = pl.loss(batch, q)
+        pl._optimizer.zero_grad()
+        loss.backward()
+        d = dict(q=q.detach().clone(), next_v=next_v.detach().clone(),
+                 target=target.detach().clone(), mse=loss.detach().clone(),
+                 mean_abs_td=(q - target).abs().mean().detach().clone(),
+                 grads={k: p.grad.detach().clone() for k, p in pl._Q.named_parameters()})
+        if key == "dqn":
+            fx["params0"], fx["target0"] = clone_sd(pl._Q), clone_sd(pl._Q_target)
+        else:   # same seeds -> same parameters: stored once
+            for k2, v in clone_sd(pl._Q).items():
+                assert torch.equal(v, fx["params0"][k2])
+        fx["learners"][key] = d
+    assert not torch.equal(fx["learners"]["dqn"]["next_v"], fx["learners"]["ddqn"]["next_v"])
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); mse "
+          f"{float(fx['learners']['dqn']['mse']):.5f} / {float(fx['learners']['ddqn']['mse']):.5f}")
+
+
 def main():
     only = sys.argv[1:]          # optional: names of the configurations to (re)generate
     if not only or "her_tiny" in only:
         make_her()
+    if not only or "bootstrap_tiny" in only:
+        make_bootstrap()
+    if not only or "dqn_cfg2_fullbatch" in only:
+        make_fullbatch()
     for name, cfg in SARSA_CONFIGS.items():
         if not only or name in only:
             make_sarsa(name, cfg)

@@ -12,6 +12,8 @@ CPU baseline of the reference's cost structure:
                                :143-177, :179-251; basic_replay_buffer.py:21-48
   ReplayOracle.sample          tensor_based_replay_buffer.py:253-282 (random.sample on the deque)
   ReplayOracle.collate         tensor_based_replay_buffer.py:290-400
+  BootstrapReplayOracle        sequential_decision_making/bootstrap_replay_buffer.py:23-114,
+                               transition.py:242-301
   one_hot / preprocess         action_representation_modules/one_hot_action_representation_module
                                .py:27-34; policy_learners/policy_learner.py:197-218
   DqnOracle.q_values           neural_networks/sequential_decision_making/q_value_networks.py:152-174
@@ -155,6 +157,46 @@ class HerReplayOracle(ReplayOracle):
                                   term if self.terminated_fn is None else self.terminated_fn(st, act),
                                   trunc, nc, nst, nn_, max_number_actions)
             self.trajectory = []
+
+
+class BootstrapReplayOracle(ReplayOracle):
+    """BootstrapReplayBuffer (bootstrap_replay_buffer.py:23-114): every stored transition carries
+    one (1, ensemble_size) mask drawn with ``torch.bernoulli(tensor(p).repeat(1, K))`` from torch's
+    GLOBAL generator at push time (:64-66); ``sample`` concatenates the masks of the sampled rows
+    (:104) and drops ``cost``."""
+
+    def __init__(self, capacity: int, p: float, ensemble_size: int) -> None:
+        super().__init__(capacity)
+        self.p, self.ensemble_size = p, ensemble_size
+
+    def push(self, state, action, reward, terminated, truncated, n_curr: int, next_state,
+             n_next: int, max_number_actions: int) -> None:
+        probe = ReplayOracle(1)
+        ReplayOracle.push(probe, state, action, reward, terminated, truncated, n_curr, next_state,
+                          n_next, max_number_actions)
+        mask = torch.bernoulli(torch.tensor(self.p).repeat(1, self.ensemble_size))
+        self.memory.append(dict(probe.memory[0], bootstrap_mask=mask))
+
+    @staticmethod
+    def collate(rows: Sequence[dict]) -> Dict[str, torch.Tensor]:
+        out = ReplayOracle.collate(rows)
+        out["bootstrap_mask"] = torch.cat([r["bootstrap_mask"] for r in rows])
+        return out
+
+    def sample_at(self, logical_indices: Sequence[int]) -> Dict[str, torch.Tensor]:
+        return self.collate([self.memory[int(i)] for i in logical_indices])
+
+    def sample(self, batch_size: int) -> Dict[str, torch.Tensor]:
+        if batch_size > len(self):
+            raise ValueError(f"Can't get a batch of size {batch_size} from a replay buffer with "
+                             f"only {len(self)} elements")
+        return self.collate(random.sample(self.memory, batch_size))
+
+
+def filter_by_bootstrap_mask(batch: Dict[str, torch.Tensor], z: int) -> Dict[str, torch.Tensor]:
+    """filter_batch_by_bootstrap_mask (transition.py:252-301): rows whose mask is 1 for member z."""
+    keep = batch["bootstrap_mask"][:, z] == 1
+    return {k: v[keep] for k, v in batch.items() if k != "bootstrap_mask" and v is not None}
 
 
 def one_hot(x: torch.Tensor, n: int) -> torch.Tensor:

@@ -7,8 +7,9 @@ that mirror the reference's ``ReplayBuffer`` / ``PolicyLearner`` / ``PearlAgent`
 There is no CPU or PyTorch fallback for that path: it fails loudly without the library / a GPU.
 """
 from .pearl_agent import PearlAgent  # noqa: F401
-from .replay_buffers import (BasicReplayBuffer, HindsightExperienceReplayBuffer,  # noqa: F401
-                             SARSAReplayBuffer, TransitionBatch)
+from .replay_buffers import (BasicReplayBuffer, BootstrapReplayBuffer,  # noqa: F401
+                             HindsightExperienceReplayBuffer, SARSAReplayBuffer, TransitionBatch,
+                             TransitionWithBootstrapMaskBatch, filter_batch_by_bootstrap_mask)
 from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
                                                          ContinuousSoftActorCritic,
                                                          DeepDeterministicPolicyGradient,

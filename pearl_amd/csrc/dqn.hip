@@ -248,12 +248,16 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* 
 // deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
 // U (= W1s' s' + b1' of the same rows) must already be computed.
 int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
-                       hipStream_t s, bool persistent = false, int* argmax = nullptr) {
+                       hipStream_t s, bool persistent = false, int* argmax = nullptr,
+                       bool sample_timer = true) {
   // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
   // maximum (Double DQN's action choice); always the classic grid
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, argmax ? h->bufs.q : h->bufs.q_target);
-  ScopedTimer tm(h, "target", s, 1, 4, b->B);
+  // level 1: only the launches the caller marks (learn(): the last, largest piece of every 4th
+  // window of a call, the first window included, so that even a 3-window call is sampled);
+  // level 2: every launch
+  ScopedTimer tm(h, "target", s, (sample_timer || h->timing >= 2) ? 1 : 2, 1, b->B);
   TargetArgs a;
   memset(&a, 0, sizeof(a));
   a.U = U; a.ldu = d.hidden1;
@@ -705,6 +709,12 @@ int ensure_side(pa_dqn* h) {
 
 int ensure_idx(pa_dqn* h, int64_t n) {
   if (h->idx_cap >= n) return PA_OK;
+  // grow geometrically with a floor of 256 rounds: a reallocation is a device synchronisation
+  // plus hipFree + hipMalloc (hundreds of microseconds), and it used to land inside the first
+  // learn() call that asked for more rounds than the one before it
+  const int64_t floor_n = (int64_t)256 * h->d.max_batch;
+  if (n < floor_n) n = floor_n;
+  if (n < 2 * h->idx_cap) n = 2 * h->idx_cap;
   if (h->idx_all) {
     PA_HIP(hipDeviceSynchronize());
     (void)hipFree(h->idx_all);
@@ -807,11 +817,12 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->yw[0], h->wrows);
   PA_WS(h->yw[1], h->wrows);
   PA_WS(h->nextv, h->wrows);
-  PA_WS(h->err_dev, 4);
-  PA_WS(h->tile_ctr, kTileCtrs);
+  // one allocation: [kTileCtrs] work-stealing counters | 4-int error word (one memset per call)
+  PA_WS(h->tile_ctr, kTileCtrs + 4);
+  h->err_dev = h->tile_ctr + kTileCtrs;
   {
     hipDeviceProp_t prop;
-    if (hipMemset(h->tile_ctr, 0, kTileCtrs * sizeof(int)) != hipSuccess ||
+    if (hipMemset(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int)) != hipSuccess ||
         hipGetDeviceProperties(&prop, desc->device) != hipSuccess) {
       set_error("pa_dqn_create: device query failed");
       pa_dqn_destroy(h);
@@ -820,8 +831,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
     h->ncu = prop.multiProcessorCount;
   }
   h->pingpong = env_int("PEARL_AMD_PINGPONG", 1);
-  if (hipMemset(h->err_dev, 0, 16) != hipSuccess ||
-      hipHostMalloc((void**)&h->err_host, 16, hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&h->err_host, 16, hipHostMallocDefault) != hipSuccess) {
     set_error("pa_dqn_create: error-word allocation failed");
     pa_dqn_destroy(h);
     return PA_ERR_NOMEM;
@@ -852,7 +862,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
-                  h->W2f16, h->W2tf, h->err_dev, h->reserved_dev, h->tile_ctr, h->w2f_online,
+                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online,
                   h->choice, h->choice_rep};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -976,11 +986,10 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   const int wcap = dbl ? 1 : h->wcap;
   rc = ensure_side(h);
   if (rc != PA_OK) return rc;
-  // fresh work-stealing counters for this call's persistent target launches
-  PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
+  // fresh work-stealing counters for this call's persistent target launches, and a clean error
+  // word (a bounded wait that expired in an earlier call must not poison this one): one memset
+  PA_HIP(hipMemsetAsync(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int), s));
   h->ctr_next = 0;
-  // a bounded wait that expired in an earlier call must not poison this one
-  PA_HIP(hipMemsetAsync(h->err_dev, 0, sizeof(int), s));
   h->err_host[0] = 0;
   hipStream_t t = overlap ? h->side : s;
   ScopedTimer tm_all(h, "learn", s);
@@ -1099,7 +1108,8 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         if (rc != PA_OK) return rc;
       }
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t,
-                              persist && pc == npieces - 1);
+                              persist && pc == npieces - 1, nullptr,
+                              (k % 4) == 0 && pc == npieces - 1);
       if (rc != PA_OK) return rc;
       j0 += nj;
     }

@@ -123,11 +123,6 @@ class DeepQLearning(PolicyLearner):
                                 else EGreedyExploration(0.05)),
             on_policy=False, is_action_continuous=False,
             action_representation_module=action_representation_module, action_space=action_space)
-        if is_conservative and os.environ.get("PEARL_AMD_EXPERIMENTAL_CQL") != "1":
-            raise NotImplementedError(
-                "pearl_amd DeepQLearning: the CQL term (is_conservative=True) is written against the "
-                "reference-pinned oracle but not yet validated on the GPU; set "
-                "PEARL_AMD_EXPERIMENTAL_CQL=1 to try it")
         if optimizer is not None:
             raise NotImplementedError(
                 "pearl_amd DeepQLearning owns its AdamW(amsgrad) step; custom optimizers are not "
@@ -243,7 +238,8 @@ class DeepQLearning(PolicyLearner):
             handle = C.c_void_p()
             N.check(N.lib().pa_dqn_create(C.byref(handle), C.byref(desc)))
             nat.handle, nat.desc_key, nat.sig = handle, desc_key, ()
-            nat.loss_buf = torch.zeros(max(self._training_rounds, 1), dtype=torch.float32,
+            # room for 1024 rounds up front: growing it later is an allocation inside learn()
+            nat.loss_buf = torch.zeros(max(self._training_rounds, 1024), dtype=torch.float32,
                                        device=dev)
         if nat.sig == self._signature() and nat.sig:
             return nat
@@ -499,7 +495,7 @@ class DeepQLearning(PolicyLearner):
         nat = self._ensure_bound(batch_size, arena.layout.max_actions)
         dev = arena.device
         if nat.loss_buf.numel() < rounds:
-            nat.loss_buf = torch.zeros(rounds, dtype=torch.float32, device=dev)
+            nat.loss_buf = torch.zeros(2 * rounds, dtype=torch.float32, device=dev)
         onehot = isinstance(self.action_representation_module,
                             OneHotActionTensorRepresentationModule)
         if rounds == 0:

@@ -87,6 +87,69 @@ def create_action_tensor_and_mask(max_number_actions: Optional[int], available_a
     return table, mask
 
 
+class SideRing:
+    """One extra per-transition column kept NEXT TO the arena in HBM (``next_action`` of the SARSA
+    buffer, the Bernoulli masks of the bootstrap buffer): a ``[capacity, width]`` device ring with
+    the arena's FIFO arithmetic — logical index i (0 = oldest stored row) lives in slot
+    ``(head + i) % capacity`` — mirrored on the host, gathered with ``pa_gather_rows``."""
+
+    def __init__(self, capacity: int) -> None:
+        self.capacity = int(capacity)
+        self.data: Optional[Tensor] = None
+        self.head = 0
+        self.size = 0
+
+    def clear(self) -> None:
+        self.head = self.size = 0
+
+    def _ensure(self, width: int, dtype: torch.dtype, device: torch.device) -> Tensor:
+        if self.data is None:
+            self.data = torch.zeros(self.capacity, width, dtype=dtype, device=device)
+        assert self.data.shape[1] == width, "side column changed its width"
+        return self.data
+
+    def append(self, row: Tensor, device: torch.device) -> None:
+        """Store one row behind the newest one; a full ring drops its oldest row (deque(maxlen))."""
+        flat = row.detach().reshape(-1)
+        data = self._ensure(int(flat.numel()), flat.dtype, device)
+        if self.size < self.capacity:
+            slot = (self.head + self.size) % self.capacity
+            self.size += 1
+        else:
+            slot = self.head
+            self.head = (self.head + 1) % self.capacity
+        data[slot].copy_(flat.to(data.dtype))
+
+    def gather(self, logical_idx: Tensor) -> Tensor:
+        assert self.data is not None, "side column is empty"
+        B = int(logical_idx.numel())
+        phys = ((logical_idx + self.head) % self.capacity).contiguous()
+        width = int(self.data.shape[1])
+        out = torch.empty(B, width, dtype=self.data.dtype, device=self.data.device)
+        if B:
+            N.check(N.lib().pa_gather_rows(self.data.data_ptr(), width * self.data.element_size(),
+                                           phys.data_ptr(), B, out.data_ptr(),
+                                           N.stream_ptr(self.data.device)))
+        return out
+
+    def logical(self) -> Optional[Tensor]:
+        """Every stored row, oldest first, on the CPU (checkpoints)."""
+        if self.data is None:
+            return None
+        idx = (torch.arange(self.size, device=self.data.device) + self.head) % self.capacity
+        return self.data[idx].cpu()
+
+    def load(self, rows: Optional[Tensor], device: torch.device) -> None:
+        """Replace the contents with `rows` (oldest first); a smaller ring keeps the newest."""
+        self.clear()
+        if rows is None or rows.shape[0] == 0:
+            return
+        rows = rows[-self.capacity:]
+        data = self._ensure(int(rows.shape[1]), rows.dtype, device)
+        data[: rows.shape[0]].copy_(rows.to(device))
+        self.size = int(rows.shape[0])
+
+
 class TensorBasedReplayBuffer(ReplayBuffer):
     """Arena-backed counterpart of tensor_based_replay_buffer.py:25-400."""
 
@@ -139,15 +202,19 @@ class TensorBasedReplayBuffer(ReplayBuffer):
             A = max_number_actions
             d = z.avail_dim if z is not None else 1
             return np.zeros((A, d), np.float32), np.zeros((A,), np.uint8)
+        # Keyed on the space OBJECT, validated by identity: the entry holds a strong reference to
+        # the space it was built from, so the id cannot be recycled for another space while the
+        # entry lives (dynamic action spaces are rebuilt every step and CPython reuses addresses
+        # at once).  A hit additionally requires `hit_space is space`.
         key = (id(space), int(space.n), max_number_actions)
         hit = self._space_cache.get(key)
-        if hit is None:
+        if hit is None or hit[2] is not space:
             table, mask = create_action_tensor_and_mask(max_number_actions, space)
-            hit = (_as_host_array(table, np.float32), _as_host_array(mask.to(torch.uint8)))
+            hit = (_as_host_array(table, np.float32), _as_host_array(mask.to(torch.uint8)), space)
             if len(self._space_cache) > 64:
                 self._space_cache.clear()
             self._space_cache[key] = hit
-        return hit
+        return hit[0], hit[1]
 
     def _ensure_arena(self, layout: ArenaLayout) -> None:
         if self._arena is None:

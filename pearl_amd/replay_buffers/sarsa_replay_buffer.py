@@ -19,7 +19,7 @@ import torch
 from torch import Tensor
 
 from .. import _native as N
-from .basic_replay_buffer import BasicReplayBuffer
+from .basic_replay_buffer import BasicReplayBuffer, SideRing
 from .transition import TransitionBatch
 
 
@@ -27,25 +27,13 @@ class SARSAReplayBuffer(BasicReplayBuffer):
     def __init__(self, capacity: int, sampler: str = "device", staging_rows: int = 0) -> None:
         super().__init__(capacity, sampler=sampler, staging_rows=staging_rows)
         self.cache: Optional[Dict[str, Any]] = None
-        self._na: Optional[Tensor] = None      # [capacity, action_elems] next actions, slot order
-        self._na_head = 0
-        self._na_size = 0
+        self._na = SideRing(capacity)      # next actions of the stored rows
 
     # -- storage of one complete (s, a, r, s', a') -------------------------------------------
     def _store(self, args: Dict[str, Any], next_action: Tensor) -> None:
         BasicReplayBuffer.push(self, **args)
-        arena = self._arena
-        assert arena is not None
-        flat = next_action.detach().reshape(-1)
-        if self._na is None:
-            self._na = torch.zeros(self.capacity, flat.numel(), dtype=flat.dtype, device=arena.device)
-        if self._na_size < self.capacity:
-            slot = (self._na_head + self._na_size) % self.capacity
-            self._na_size += 1
-        else:                                   # FIFO eviction of the oldest row
-            slot = self._na_head
-            self._na_head = (self._na_head + 1) % self.capacity
-        self._na[slot].copy_(flat.to(self._na.dtype))
+        assert self._arena is not None
+        self._na.append(next_action, self._arena.device)
 
     @staticmethod
     def _as_state(x: Any) -> Tensor:
@@ -71,17 +59,27 @@ class SARSAReplayBuffer(BasicReplayBuffer):
 
     def clear(self) -> None:
         super().clear()
-        self._na_head = self._na_size = 0
+        self._na.clear()
 
     def sample(self, batch_size: int) -> TransitionBatch:
         batch = super().sample(batch_size)
-        assert self._na is not None
-        idx = self.last_indices
-        phys = ((idx + self._na_head) % self.capacity).contiguous()
-        width = int(self._na.shape[1])
-        out = torch.empty(int(batch_size), width, dtype=self._na.dtype, device=self._na.device)
-        N.check(N.lib().pa_gather_rows(self._na.data_ptr(), width * self._na.element_size(),
-                                       phys.data_ptr(), int(batch_size), out.data_ptr(),
-                                       N.stream_ptr(self._na.device)))
+        out = self._na.gather(self.last_indices)
         batch.next_action = out.reshape(tuple(batch.action.shape)).to(batch.action.device)
         return batch
+
+    # -- checkpoint / resume: the base class saves the arena columns; the next actions of the
+    # stored rows and the pending (not yet stored) transition belong to the state as well
+    def state_dict(self) -> Dict[str, Any]:
+        sd = super().state_dict()
+        sd["next_action"] = self._na.logical()
+        sd["sarsa_cache"] = self.cache
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, Any]) -> None:
+        super().load_state_dict(sd)
+        na = sd.get("next_action")
+        if na is not None:
+            assert self._arena is not None
+            self._na.load(na, self._arena.device)
+            assert self._na.size == len(self), "next_action column and arena differ in length"
+        self.cache = sd.get("sarsa_cache")

@@ -131,3 +131,48 @@ class TransitionBatch(_FieldBag):
 
     def __len__(self) -> int:
         return self.reward.shape[0]
+
+
+class TransitionWithBootstrapMask(Transition):
+    """``Transition`` + the (1, ensemble_size) Bernoulli mask of Bootstrapped DQN
+    (transition.py:242-244)."""
+
+    _fields = _TENSOR_FIELDS + ("bootstrap_mask",)
+
+    def __init__(self, *args, bootstrap_mask: Optional[Tensor] = None, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.bootstrap_mask = bootstrap_mask
+
+
+class TransitionWithBootstrapMaskBatch(TransitionBatch):
+    """``TransitionBatch`` + ``bootstrap_mask`` (batch_size, ensemble_size) (transition.py:247-249)."""
+
+    _fields = TransitionBatch._fields + ("bootstrap_mask",)
+
+    def __init__(self, *args, bootstrap_mask: Optional[Tensor] = None, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.bootstrap_mask = bootstrap_mask
+
+
+def filter_batch_by_bootstrap_mask(batch: TransitionWithBootstrapMaskBatch, z) -> TransitionBatch:
+    """The transitions of `batch` whose mask is active for ensemble member `z`
+    (transition.py:252-301); fields the batch does not carry stay None, ``weight`` / ``cost`` /
+    ``time_diff`` are dropped exactly as the reference drops them."""
+    mask = batch.bootstrap_mask
+
+    def keep(x: Optional[Tensor]) -> Optional[Tensor]:
+        if x is None or mask is None:
+            return None
+        return x[mask[:, z] == 1]
+
+    required = [keep(getattr(batch, k)) for k in ("state", "action", "reward", "terminated",
+                                                  "truncated")]
+    assert all(v is not None for v in required)
+    return TransitionBatch(
+        state=required[0], action=required[1], reward=required[2], terminated=required[3],
+        truncated=required[4], next_state=keep(batch.next_state),
+        next_action=keep(batch.next_action),
+        curr_available_actions=keep(batch.curr_available_actions),
+        curr_unavailable_actions_mask=keep(batch.curr_unavailable_actions_mask),
+        next_available_actions=keep(batch.next_available_actions),
+        next_unavailable_actions_mask=keep(batch.next_unavailable_actions_mask))

@@ -467,11 +467,8 @@ def test_deep_sarsa_and_sarsa_replay_buffer(name):
                                    rtol=1e-3, atol=2e-5, msg=k)
 
 
-@pytest.mark.skipif(os.environ.get("PEARL_AMD_EXPERIMENTAL_CQL") != "1",
-                    reason="the CQL path is written against the pinned oracle but not yet validated "
-                           "on a GPU: run with PEARL_AMD_EXPERIMENTAL_CQL=1")
 @pytest.mark.parametrize("name", ["cql_tiny_dynamic", "cql_small"])
-def test_conservative_q_learning_experimental(name):
+def test_conservative_q_learning(name):
     """DeepQLearning(is_conservative=True) against the reference run: total-loss gradients of one
     batch and the learn() trajectory (generic loop; B + B A rows through the generic engine)."""
     from conftest import GOLDEN_DIR
@@ -499,3 +496,81 @@ def test_conservative_q_learning_experimental(name):
                                    atol=2e-5, msg=k)
         torch.testing.assert_close(pl._Q_target.state_dict()[k].cpu(), fx["target_after"][k],
                                    rtol=1e-3, atol=2e-5, msg=k)
+
+
+def _load(name):
+    from conftest import GOLDEN_DIR
+    return torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+
+
+@pytest.mark.parametrize("learner", ["dqn", "ddqn"])
+def test_fullbatch_reference_parity(learner):
+    """BASELINE config 2 AT ITS OWN BATCH SIZE (S=128, A=16, [256,256], B=1024) against the
+    reference itself (fixture minted by oracle/make_golden.py::make_fullbatch): Q(s,a), next-state
+    values and Bellman targets within rtol 1e-5 — north_star's bar on identical batches — the
+    reported loss, and the gradients of that batch."""
+    from pearl_amd import (DeepQLearning, DoubleDQN, OneHotActionTensorRepresentationModule,
+                           TransitionBatch)
+    fx = _load("dqn_cfg2_fullbatch")
+    cfg, want = fx["config"], fx["learners"][learner]
+    cls = DoubleDQN if learner == "ddqn" else DeepQLearning
+    pl = cls(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
+             training_rounds=1, batch_size=cfg["B"],
+             action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    pl._Q.load_state_dict(fx["params0"])
+    pl._Q_target.load_state_dict(fx["target0"])
+    pl = pl.to(DEV)
+
+    def batch():
+        return pl.preprocess_batch(TransitionBatch(
+            **{k: (None if v is None else v.to(DEV)) for k, v in fx["batch_raw"].items()}))
+
+    assert batch().state.shape == (1024, 128)
+    out = pl.q_values_and_targets(batch())
+    torch.testing.assert_close(out["q"].cpu(), want["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["next_v"].cpu(), want["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["target"].cpu(), want["target"], rtol=1e-5, atol=1e-6)
+    rep = pl.learn_batch(batch())
+    assert abs(rep["loss"] - float(want["mean_abs_td"])) <= 1e-5 * max(1.0, float(want["mean_abs_td"]))
+    for k, p in pl._Q.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), want["grads"][k], rtol=2e-4, atol=2e-6, msg=k)
+
+
+def test_sarsa_buffer_checkpoint_resume_is_exact():
+    """SARSAReplayBuffer.state_dict()/load_state_dict(): the next_action column of the stored rows
+    and the pending (cached) transition survive a round trip into a FRESH buffer — same sampled
+    batches incl. next_action, and the next push completes the cached transition."""
+    from pearl_amd import SARSAReplayBuffer
+    fx = _load("sarsa_wrap")
+    cfg, A = fx["config"], fx["config"]["A"]
+
+    def push(rb, p):
+        rb.push(state=p["state"], action=torch.tensor([p["action"]]), reward=p["reward"],
+                terminated=p["terminated"], truncated=p["truncated"],
+                curr_available_actions=_space(A), next_state=p["next_state"],
+                next_available_actions=_space(A), max_number_actions=A)
+
+    a = SARSAReplayBuffer(cfg["capacity"], sampler="python")
+    a.device_for_batches = torch.device(DEV)
+    cut = len(fx["pushes"]) - 7
+    for p in fx["pushes"][:cut]:
+        push(a, p)
+    sd = a.state_dict()
+    b = SARSAReplayBuffer(cfg["capacity"], sampler="python")
+    b.device_for_batches = torch.device(DEV)
+    b.load_state_dict(sd)
+    assert len(a) == len(b) and (b.cache is None) == (a.cache is None)
+    for p in fx["pushes"][cut:]:
+        push(a, p)
+        push(b, p)
+    assert len(a) == len(b) == fx["stored"]
+    random.seed(3)
+    x = a.sample(cfg["B"])
+    random.seed(3)
+    y = b.sample(cfg["B"])
+    for k in ("state", "action", "reward", "terminated", "truncated", "next_state", "next_action"):
+        assert torch.equal(getattr(x, k), getattr(y, k)), k
+    random.seed(fx["sample_seed"])
+    raw = b.sample(cfg["B"])
+    for k, want in fx["batch_raw"].items():
+        assert torch.equal(getattr(raw, k).cpu(), want), k

@@ -301,3 +301,41 @@ def test_hindsight_experience_replay_buffer(variant):
     for k, want in v["contents"].items():
         got = cols[k]
         assert torch.equal(got.reshape(want.shape).to(want.dtype), want), k
+
+
+@pytest.mark.parametrize("variant", ["plain", "wrap"])
+def test_bootstrap_replay_buffer_matches_reference(variant):
+    """BootstrapReplayBuffer on the arena + the HBM mask column against the reference's buffer:
+    Bernoulli masks (torch's global generator, one draw per push), FIFO wrap, the sampled
+    TransitionWithBootstrapMaskBatch and filter_batch_by_bootstrap_mask — bit-exact; plus a
+    checkpoint round trip into a fresh buffer."""
+    import os
+    from conftest import GOLDEN_DIR
+    from pearl_amd import BootstrapReplayBuffer, filter_batch_by_bootstrap_mask
+    fx = torch.load(os.path.join(GOLDEN_DIR, "bootstrap_tiny.pt"), map_location="cpu",
+                    weights_only=False)
+    cfg, v = fx["config"], fx["variants"][variant]
+    rb = BootstrapReplayBuffer(v["capacity"], cfg["p"], cfg["K"], sampler="python")
+    rb.device_for_batches = torch.device("cuda:0")
+    torch.manual_seed(v["mask_seed"])
+    for i in range(v["N"]):
+        rb.push(state=v["states"][i], action=torch.tensor([i % cfg["A"]]), reward=float(i % 7),
+                terminated=(i % 10 == 9), truncated=False, curr_available_actions=_space(cfg["A"]),
+                next_state=v["states"][i + 1], next_available_actions=_space(cfg["A"]),
+                max_number_actions=cfg["A"])
+    assert len(rb) == v["stored"]
+    assert torch.equal(rb._masks.logical(), v["masks"])
+    random.seed(v["sample_seed"])
+    batch = rb.sample(cfg["B"])
+    assert_batch_equal(batch, v["batch"])
+    assert batch.cost is None
+    filt = filter_batch_by_bootstrap_mask(batch, torch.tensor(2))
+    for k, want in v["filtered_z2"].items():
+        assert torch.equal(getattr(filt, k).cpu(), want), k
+    with pytest.raises(ValueError, match="Can't get a batch of size"):
+        rb.sample(len(rb) + 1)
+    fresh = BootstrapReplayBuffer(v["capacity"], cfg["p"], cfg["K"], sampler="python")
+    fresh.device_for_batches = torch.device("cuda:0")
+    fresh.load_state_dict(rb.state_dict())
+    random.seed(v["sample_seed"])
+    assert_batch_equal(fresh.sample(cfg["B"]), v["batch"])

@@ -200,3 +200,47 @@ def test_conservative_q_learning_oracle(name):
     for k in O.PARAM_KEYS:
         torch.testing.assert_close(pl.p[k], fx["params_after"][k], rtol=1e-3, atol=2e-5, msg=k)
         torch.testing.assert_close(pl.t[k], fx["target_after"][k], rtol=1e-3, atol=2e-5, msg=k)
+
+
+@pytest.mark.parametrize("variant", ["plain", "wrap"])
+def test_bootstrap_replay_oracle(variant):
+    """BootstrapReplayOracle against the reference's BootstrapReplayBuffer: the Bernoulli masks of
+    every stored row (same draws from torch's global generator), the sampled batch incl.
+    bootstrap_mask, and filter_batch_by_bootstrap_mask — all bit-exact."""
+    fx = load_sarsa("bootstrap_tiny")
+    cfg, v = fx["config"], fx["variants"][variant]
+    rb = O.BootstrapReplayOracle(v["capacity"], cfg["p"], cfg["K"])
+    torch.manual_seed(v["mask_seed"])
+    for i in range(v["N"]):
+        rb.push(v["states"][i], torch.tensor([i % cfg["A"]]), float(i % 7), i % 10 == 9, False,
+                cfg["A"], v["states"][i + 1], cfg["A"], cfg["A"])
+    assert len(rb) == v["stored"]
+    assert torch.equal(torch.cat([r["bootstrap_mask"] for r in rb.memory]), v["masks"])
+    random.seed(v["sample_seed"])
+    got = rb.sample(cfg["B"])
+    for k, want in v["batch"].items():
+        if want is None:
+            continue
+        assert got[k].dtype == want.dtype and torch.equal(got[k], want), k
+    filt = O.filter_by_bootstrap_mask(got, 2)
+    for k, want in v["filtered_z2"].items():
+        assert torch.equal(filt[k], want), k
+
+
+@pytest.mark.parametrize("learner", ["dqn", "ddqn"])
+def test_fullbatch_one_batch_numerics(learner):
+    """BASELINE config 2 at its own batch size (B = 1024): the oracle against the reference's
+    Q-values, next-state values, Bellman targets (rtol 1e-5) and gradients on the same batch."""
+    fx = load_sarsa("dqn_cfg2_fullbatch")
+    want = fx["learners"][learner]
+    pl = O.DqnOracle(fx["params0"], fx["target0"], double_q=learner == "ddqn")
+    b = O.preprocess(fx["batch_raw"], fx["config"]["A"])
+    torch.testing.assert_close(pl.q_values(b["state"], b["action"]), want["q"], rtol=1e-5, atol=1e-6)
+    nv = pl.next_state_values(b["next_state"], b["next_available_actions"],
+                              b["next_unavailable_actions_mask"])
+    torch.testing.assert_close(nv, want["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pl.bellman_target(b), want["target"], rtol=1e-5, atol=1e-6)
+    q, g = pl.gradients(b, want["target"])
+    torch.testing.assert_close(((q - want["target"]) ** 2).mean(), want["mse"], rtol=1e-5, atol=1e-6)
+    for k, w in want["grads"].items():
+        torch.testing.assert_close(g[k].reshape(w.shape), w, rtol=2e-4, atol=2e-6, msg=k)
