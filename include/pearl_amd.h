@@ -480,6 +480,13 @@ int pa_iql_value_head(const float* tq_value, const float* tq_actor, const float*
 int pa_awr_head(int32_t mode, const float* x, int32_t ldx, const float* action, int32_t lda,
                 const float* adv, int32_t B, int32_t A, float* dx, int32_t lddx, float* loss_out,
                 void* stream);
+/* IQL policy extraction with a GaussianActorNetwork (implicit_q_learning.py:231-243 through
+ * GaussianActorNetwork.get_log_probability, actor_networks.py:593-629): from the network head
+ * [B, 2A] = mean | raw log_std and the dataset actions, log_prob[b] = log pi(a_b | s_b),
+ * loss_out[0] = -mean_b(adv_b log_prob_b) and d_head = its gradient. */
+int pa_gauss_awr_head(const float* head, int32_t ldh, const float* action, int32_t lda,
+                      const float* low, const float* high, const float* adv, int32_t B, int32_t A,
+                      float* d_head, int32_t lddh, float* log_prob, float* loss_out, void* stream);
 
 /* Deterministic policies (DDPG ddpg.py:106-156, TD3 td3.py:106-201).
  * pa_tanh_action: VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485) from the

@@ -299,6 +299,8 @@ SIGNATURES = {
                                     C.c_int32, _P, _P, _P, _P]),
     "pa_awr_head": (C.c_int, [C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P,
                               C.c_int32, _P, _P]),
+    "pa_gauss_awr_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32,
+                                    _P, C.c_int32, _P, _P, _P]),
     "pa_tanh_action": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32,
                                  C.c_int32, _P, C.c_int32, _P]),
     "pa_tanh_action_grad": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,

@@ -458,7 +458,7 @@ AdamState adam_state(pa_dqn* h) {
 // applies AdamW to it (+ the next step's soft target update when soft_next) and the extra
 // workgroup folds |Q - target| into loss_out.
 int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t adam_step,
-                    float* loss_out, int soft_next, hipStream_t s) {
+                    float* loss_out, int soft_next, hipStream_t s, const float* y_tagged = nullptr) {
   const pa_dqn_desc& d = h->d;
   float* G = h->bufs.grad;
   ScopedTimer tm(h, "bwd_dw", s);
@@ -500,6 +500,8 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_dw : nullptr;
   a.ad.absd = h->absd; a.ad.nabs = B; a.ad.inv_B = (float)(1.0 / (double)B);
   a.ad.loss_out = loss_out;
+  a.ad.y_restore = reinterpret_cast<unsigned*>(const_cast<float*>(y_tagged));
+  a.ad.n_restore = y_tagged ? B : 0;
   if (fuse_adam) {
     PA_REQUIRE(adam_step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)",
                (long long)adam_step);
@@ -562,7 +564,8 @@ int online_chain(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged
   int rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s);
   if (rc != PA_OK) return rc;
   float* lo = loss_out ? loss_out : h->loss_scratch;
-  return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s);
+  return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s,
+                         y_tagged ? y : nullptr);
 }
 
 // One stand-alone learn_batch (pa_dqn_step).  do_target_update: soft update BEFORE the forward

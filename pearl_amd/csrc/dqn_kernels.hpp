@@ -29,6 +29,14 @@ namespace pa {
       (prof)[((int64_t)(wg) * 8 + (wave)) * 16 + (i)] = (long long)wall_clock64();      \
   } while (0)
 
+// Same slot layout, but the SHADER clock (s_memtime): with the wall-clock stamps of the same two
+// points it gives the effective shader frequency of the launch (tools/prof_chain.py).
+#define PA_STAMP_CYC(prof, wg, wave, i)                                                 \
+  do {                                                                                  \
+    if ((prof) && (threadIdx.x & 63) == 0)                                              \
+      (prof)[((int64_t)(wg) * 8 + (wave)) * 16 + (i)] = (long long)clock64();           \
+  } while (0)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -802,6 +810,10 @@ struct AdamFuse {
   int soft_next; float* tgt; float tau, one_minus_tau;
   float* tW2f; int nkg_t;            // target W2, 32x32x2 fragment-major
   const float* absd; int nabs; float inv_B; float* loss_out;  // mean |Q - target| of this step
+  // overlapped learn loop: the Bellman targets of this round have been consumed by the row pass
+  // (the previous launch on this stream); the loss workgroup hands the words back to the producer
+  // by restoring the pending tag (see consume_y / publish_y)
+  unsigned* y_restore; int n_restore;
 };
 
 struct DwProblem {
@@ -976,9 +988,14 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
       __syncthreads();
     }
     if (tid == 0) a.ad.loss_out[0] = part[0] * a.ad.inv_B;
+    if (a.ad.y_restore)
+      for (int i = tid; i < a.ad.n_restore; i += 512)
+        __hip_atomic_store(a.ad.y_restore + i, kYPendingBits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
+  PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
   const int c = lane & 15, q = lane >> 4;
   int pi = 0;
   if (a.nprob > 1 && wg_tile >= a.p[1].tile0) pi = 1;
@@ -1216,6 +1233,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
     if (a.ad.enabled) adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
+  PA_STAMP_CYC(a.prof, blockIdx.x, wave, 15);
 }
 
 // ---------------------------------------------------------------------------

@@ -1048,6 +1048,69 @@ __global__ __launch_bounds__(256) void awr_kernel(AwrArgs a) {
   if (threadIdx.x == 0) a.loss_out[0] = sum * invB;
 }
 
+// ---- IQL policy extraction with a GaussianActorNetwork (implicit_q_learning.py:231-243,
+// actor_networks.py:593-629 get_log_probability): advantage-weighted regression
+//   loss = -mean_b(adv_b log pi(a_b | s_b)),
+//   log pi = sum_j [ Normal(mean_j, std_j).log_prob(atanh(n_j)) - log(bound_j (1 - n_j^2) + 1e-6) ],
+//   n = clip(((a - low) / (high - low)) 2 - 1, -1 + 1e-6, 1 - 1e-6)   (action_unscaling, :54-65)
+// from the head [B, 2A] = mean | raw log_std (log_std = -5 + 3.5 (tanh(raw) + 1), :537-549).
+// The dataset action is a constant: only mean and log_std carry gradient,
+//   d logp / d mean = (u - mean) / var,   d logp / d log_std = (u - mean)^2 / var - 1.
+// One thread per (row, component); the per-row sum is taken in component order by the row's first
+// thread, the batch sum block-ordered through a ticket (same shape as gauss_sample_kernel).
+struct GaussAwrArgs {
+  const float* head; int ldh;
+  const float* action; int lda;
+  const float* low; const float* high;
+  const float* adv;
+  int B, A;
+  float* d_head; int lddh;
+  float* log_prob;              // [B] scratch / probe output
+  float* loss_out;
+};
+__global__ __launch_bounds__(256) void gauss_awr_kernel(GaussAwrArgs a) {
+  __shared__ float terms[256];
+  const int rows_per_wg = 256 / a.A;
+  const int r = threadIdx.x / a.A, j = threadIdx.x - r * a.A;
+  const int b = blockIdx.x * rows_per_wg + r;
+  const bool live = r < rows_per_wg && b < a.B;
+  if (live) {
+    const float* hd = a.head + (int64_t)b * a.ldh;
+    const float mean = hd[j], raw = hd[a.A + j], lo = a.low[j], hi = a.high[j];
+    const float t = tanhf(raw);
+    const float log_std = -5.0f + 3.5f * (t + 1.0f);
+    const float sd = expf(log_std);
+    float n = (((a.action[(int64_t)b * a.lda + j] - lo) / (hi - lo)) * 2.0f) - 1.0f;
+    n = fminf(fmaxf(n, -1.0f + 1e-6f), 1.0f - 1e-6f);
+    const float u = atanhf(n);
+    const float var = sd * sd;
+    const float diff = u - mean;
+    const float bound = (hi - lo) / 2.0f;
+    float l = -(diff * diff) / (2.0f * var) - logf(sd) - 0.9189385332046727f;
+    l -= logf(bound * (1.0f - n * n) + 1e-6f);
+    terms[threadIdx.x] = l;
+    const float g = -a.adv[b] / (float)a.B;       // dL / d logp_b
+    a.d_head[(int64_t)b * a.lddh + j] = g * (diff / var);
+    a.d_head[(int64_t)b * a.lddh + a.A + j] = g * ((diff * diff) / var - 1.0f) * 3.5f * (1.0f - t * t);
+  }
+  __syncthreads();
+  if (live && j == 0) {
+    float lp = 0.f;
+    for (int k = 0; k < a.A; ++k) lp += terms[threadIdx.x + k];
+    a.log_prob[b] = lp;
+  }
+}
+// loss = -mean(adv * log_prob), fixed order (one workgroup)
+__global__ __launch_bounds__(256) void gauss_awr_loss_kernel(const float* __restrict__ adv,
+                                                             const float* __restrict__ logp, int B,
+                                                             float* __restrict__ loss_out) {
+  __shared__ float red[256];
+  float part = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) part += adv[b] * logp[b];
+  const float sum = block_sum_256(part, red);
+  if (threadIdx.x == 0) loss_out[0] = -(sum / (float)B);
+}
+
 // ---- conservative Q-learning (deep_td_learning.py:292-331, loss_fn_utils.py:17-72) -------------
 // One head for the (B + B A)-row pass of DeepQLearning(is_conservative=True):
 //   rows [0, B):  Q(s_b, a_b);  Bellman part  dq = 2 (q - y) / B,  reported loss mean |q - y|
@@ -1717,6 +1780,25 @@ extern "C" int pa_awr_head(int32_t mode, const float* x, int32_t ldx, const floa
   a.x = x; a.ldx = ldx; a.action = action; a.lda = lda; a.adv = adv; a.B = B; a.A = A; a.mode = mode;
   a.dx = dx; a.lddx = lddx; a.loss_out = loss_out;
   hipLaunchKernelGGL(awr_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_gauss_awr_head(const float* head, int32_t ldh, const float* action, int32_t lda,
+                                 const float* low, const float* high, const float* adv, int32_t B,
+                                 int32_t A, float* d_head, int32_t lddh, float* log_prob,
+                                 float* loss_out, void* stream) {
+  PA_REQUIRE(head && action && low && high && adv && d_head && log_prob && loss_out && B > 0 &&
+                 A > 0 && A <= 256,
+             PA_ERR_INVALID, "pa_gauss_awr_head: bad argument");
+  GaussAwrArgs a;
+  a.head = head; a.ldh = ldh; a.action = action; a.lda = lda; a.low = low; a.high = high;
+  a.adv = adv; a.B = B; a.A = A; a.d_head = d_head; a.lddh = lddh; a.log_prob = log_prob;
+  a.loss_out = loss_out;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gauss_awr_kernel, dim3((unsigned)ceil_div(B, 256 / A)), dim3(256), 0, s, a);
+  PA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gauss_awr_loss_kernel, dim3(1), dim3(256), 0, s, adv, log_prob, B, loss_out);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -260,27 +260,85 @@ __device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t
 
 // NG1/NG2/NG3: k-groups of layer 1 (K1), layer 2 (H1) and dX (H2) when known at compile time
 // (0 = run-time loop, any shape).
+//
+// Phase structure (two workgroup barriers; it used to be four plus the x staging):
+//   1. x fragments straight from global memory into MFMA B-operand registers (NG1 > 0; every wave
+//      reads the whole 16-row tile — 9 KB from L1/L2 — so layer 1 starts after ONE exposed memory
+//      latency with no LDS round trip and no barrier), layer 1, h1 -> LDS            [barrier A]
+//   2. layer 2; h2, the head's partial dot products and  s2 = [h2 > 0] w3  -> LDS     [barrier B]
+//   3. G = s2 W2 on the matrix pipe — the backward GEMM does NOT wait for the loss: with
+//      dZ2 = dq (s2) row-wise, dZ1 = (dZ2 W2) [h1 > 0] = dq (s2 W2) [h1 > 0], so the scalar dq of a
+//      row multiplies the finished product.  (Same value up to one fp32 rounding per element:
+//      torch rounds dq w3 first and then accumulates, this accumulates first and rounds dq G.)
+//      Only then: q (cross-wave sum), the Bellman target y — in the overlapped loop this is where
+//      the kernel polls for it, one whole GEMM later than before — loss, dZ2, dZ1.
+// The y tag of the overlapped loop is restored by the next launch of the chain
+// (weight_grad_kernel's loss workgroup), not here: that needed one more barrier.
 template <int NG1, int NG2, int NG3>
 static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P1 = rp_pad(a.K1), PH1 = rp_pad(a.H1), PH2 = rp_pad(a.H2);
-  float* xs = smem;                          // [16][P1]
+  float* xs = smem;                          // [16][P1]   (run-time-shape path only)
   float* h1s = xs + RP_ROWS * P1;            // [16][PH1]
-  float* d2s = h1s + RP_ROWS * PH1;          // [16][PH2]
+  float* d2s = h1s + RP_ROWS * PH1;          // [16][PH2]  s2 = [h2 > 0] w3
   float* qpart = d2s + RP_ROWS * PH2;        // [8][16]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, qd = lane >> 4;
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
+  PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
   const int m0 = blockIdx.x * RP_ROWS;
   const int row = m0 + r16;
   const bool rok = row < a.B;
   const int u0 = wave * 32 + 4 * qd;         // this lane's units: u0 + 16 t + reg, t in {0,1}
   const int tile0 = wave * 2;
   const int nt1 = (a.H1 + 15) >> 4, nt2 = (a.H2 + 15) >> 4;
+  const bool v1 = ((a.H1 & 3) == 0), v2 = ((a.H2 & 3) == 0);
+  f32x4v acc[2];
 
-  // ---- stage the x tile (zero padded to the LDS pitch; the k loops run over whole groups)
-  {
+  // ---- layer 1: h1 = relu(W1 x + b1)
+  if constexpr (NG1 > 0) {
+    // B operand of k-group g: x[row][16 g + 4 qd .. + 3]
+    const bool vx = is_vec_ok(a.x, a.ldx) && ((a.K1 & 3) == 0);
+    float4 xf[NG1];
+#pragma unroll
+    for (int g = 0; g < NG1; ++g) {
+      const int c = 16 * g + 4 * qd;
+      if (vx) xf[g] = ld4_or_zero(a.x, (int64_t)row * a.ldx + c, rok && c < a.K1);
+      else xf[g] = guarded_load4(a.x, (int64_t)row * a.ldx, rok, c, a.K1);
+    }
+    WRing R1;
+    ring_fill<NG1>(R1, a.W1f, tile0, nt1, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
+      acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+    }
+    PA_STAMP(a.prof, blockIdx.x, wave, 1);
+    const bool ok0 = tile0 < nt1, ok1 = tile0 + 1 < nt1;
+    const int64_t base0 = ((int64_t)tile0 * NG1) * 256 + lane * 4;
+    const int64_t base1 = base0 + (int64_t)NG1 * 256;
+#pragma unroll
+    for (int g = 0; g < NG1; ++g) {
+      const float4 w0 = R1.r0[g % RP_PD], w1 = R1.r1[g % RP_PD];
+      if (g + RP_PD < NG1) {
+        R1.r0[g % RP_PD] = ld4_or_zero(a.W1f, base0 + (int64_t)(g + RP_PD) * 256, ok0);
+        R1.r1[g % RP_PD] = ld4_or_zero(a.W1f, base1 + (int64_t)(g + RP_PD) * 256, ok1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 x4 = xf[g];
+      acc[0] = mfma16(w0.x, x4.x, acc[0]);
+      acc[1] = mfma16(w1.x, x4.x, acc[1]);
+      acc[0] = mfma16(w0.y, x4.y, acc[0]);
+      acc[1] = mfma16(w1.y, x4.y, acc[1]);
+      acc[0] = mfma16(w0.z, x4.z, acc[0]);
+      acc[1] = mfma16(w1.z, x4.z, acc[1]);
+      acc[0] = mfma16(w0.w, x4.w, acc[0]);
+      acc[1] = mfma16(w1.w, x4.w, acc[1]);
+    }
+    PA_STAMP(a.prof, blockIdx.x, wave, 2);
+  } else {
+    // any shape: stage the x tile in LDS (zero padded to the pitch; the k loop runs over whole groups)
     const bool vx = is_vec_ok(a.x, a.ldx) && ((a.K1 & 3) == 0);
     const int c4 = (P1 - 4) >> 2;  // float4 slots per row
     for (int e = tid; e < RP_ROWS * c4; e += 512) {
@@ -291,27 +349,17 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
       else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, a.K1);
       *reinterpret_cast<float4*>(xs + r * P1 + c) = v;
     }
-  }
-  const bool v1 = ((a.H1 & 3) == 0), v2 = ((a.H2 & 3) == 0);
-  f32x4v acc[2];
-  WRing R1;
-  if constexpr (NG1 > 0) ring_fill<NG1>(R1, a.W1f, tile0, nt1, lane);  // independent of x
-  // ---- layer 1: h1 = relu(W1 x + b1)
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
-    acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
-  }
-  PA_STAMP(a.prof, blockIdx.x, wave, 1);
-  __syncthreads();
-  PA_STAMP(a.prof, blockIdx.x, wave, 2);
-  WRing R2;
-  if constexpr (NG1 > 0) {
-    rows16_gemm_static<NG1>(acc, R1, a.W1f, tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
-  } else {
+    for (int t = 0; t < 2; ++t) {
+      const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
+      acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+    }
+    PA_STAMP(a.prof, blockIdx.x, wave, 1);
+    __syncthreads();
     rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
+    PA_STAMP(a.prof, blockIdx.x, wave, 2);
   }
-  PA_STAMP(a.prof, blockIdx.x, wave, 3);
+  WRing R2;
   if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
   float4 h1k[2];  // kept for the ReLU mask of dZ1
 #pragma unroll
@@ -331,16 +379,16 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   float4 w3v[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) w3v[t] = guarded_load4(a.w3, 0, true, u0 + 16 * t, a.H2);
+  PA_STAMP(a.prof, blockIdx.x, wave, 3);
+  __syncthreads();                                                      // barrier A: h1 tile
   PA_STAMP(a.prof, blockIdx.x, wave, 4);
-  __syncthreads();
-  PA_STAMP(a.prof, blockIdx.x, wave, 5);
   WRing R3;
   if constexpr (NG2 > 0) {
     rows16_gemm_static<NG2>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   } else {
     rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   }
-  PA_STAMP(a.prof, blockIdx.x, wave, 6);
+  PA_STAMP(a.prof, blockIdx.x, wave, 5);
   if constexpr (NG3 > 0) {
     if (a.y) ring_fill<NG3>(R3, a.W2tf, tile0, nt1, lane);
   }
@@ -348,20 +396,42 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   float part = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
+    const int u = u0 + 16 * t;
     h2k[t] = make_float4(relu_keep_nan(acc[t][0]), relu_keep_nan(acc[t][1]),
                          relu_keep_nan(acc[t][2]), relu_keep_nan(acc[t][3]));
     part = fmaf(h2k[t].x, w3v[t].x, part);
     part = fmaf(h2k[t].y, w3v[t].y, part);
     part = fmaf(h2k[t].z, w3v[t].z, part);
     part = fmaf(h2k[t].w, w3v[t].w, part);
-    if (rok && a.H2a) store4_guarded(a.H2a, (int64_t)row * a.H2, u0 + 16 * t, a.H2, v2, h2k[t]);
+    if (rok && a.H2a) store4_guarded(a.H2a, (int64_t)row * a.H2, u, a.H2, v2, h2k[t]);
+    if (a.y) {
+      // s2 = [h2 > 0] w3: the B operand of the backward GEMM (rows beyond the batch are zero:
+      // their h2 came from a zero x row only if b1/b2 say so, hence the explicit guard)
+      float4 z;
+      z.x = (rok && h2k[t].x > 0.f) ? w3v[t].x : 0.f;
+      z.y = (rok && h2k[t].y > 0.f) ? w3v[t].y : 0.f;
+      z.z = (rok && h2k[t].z > 0.f) ? w3v[t].z : 0.f;
+      z.w = (rok && h2k[t].w > 0.f) ? w3v[t].w : 0.f;
+      if (u < PH2 - 4) *reinterpret_cast<float4*>(d2s + r16 * PH2 + u) = z;
+    }
   }
-  // ---- head: q = w3 . h2 + b3 (lane quarters, then waves, fixed order)
+  // ---- head partials: q = w3 . h2 + b3 (lane quarters, then waves, fixed order)
   part += __shfl_xor(part, 16);
   part += __shfl_xor(part, 32);
   if (qd == 0) qpart[wave * 16 + r16] = part;
+  PA_STAMP(a.prof, blockIdx.x, wave, 6);
+  __syncthreads();                                                      // barrier B: s2, qpart
   PA_STAMP(a.prof, blockIdx.x, wave, 7);
-  __syncthreads();
+  if (a.y) {
+    // ---- G = s2 W2 (scaled by dq below)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+    if constexpr (NG3 > 0) {
+      rows16_gemm_static<NG3>(acc, R3, a.W2tf, tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+    } else {
+      rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+    }
+  }
   PA_STAMP(a.prof, blockIdx.x, wave, 8);
   float q = 0.f;
 #pragma unroll
@@ -369,7 +439,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   q += a.b3[0];
   if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
   if (!a.y) return;
-  // ---- loss and dZ2 = [h2 > 0] * dq * w3
+  // ---- loss, dZ2 = [h2 > 0] * (dq * w3), dZ1 = [h1 > 0] * (dq * G)
   float yv = q;
   if (rok) yv = a.y_tagged ? consume_y(a.y + row, a.err) : a.y[row];
   PA_STAMP(a.prof, blockIdx.x, wave, 9);
@@ -379,46 +449,26 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     a.dq_out[row] = dq;
     a.absd_out[row] = fabsf(d);
   }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int u = u0 + 16 * t;
-    float4 z;
-    z.x = (h2k[t].x > 0.f) ? __fmul_rn(dq, w3v[t].x) : 0.f;
-    z.y = (h2k[t].y > 0.f) ? __fmul_rn(dq, w3v[t].y) : 0.f;
-    z.z = (h2k[t].z > 0.f) ? __fmul_rn(dq, w3v[t].z) : 0.f;
-    z.w = (h2k[t].w > 0.f) ? __fmul_rn(dq, w3v[t].w) : 0.f;
-    if (!rok) z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (u < PH2 - 4) *reinterpret_cast<float4*>(d2s + r16 * PH2 + u) = z;
-    if (rok) store4_guarded(a.dZ2, (int64_t)row * a.H2, u, a.H2, v2, z);
-  }
-  PA_STAMP(a.prof, blockIdx.x, wave, 10);
-  __syncthreads();
-  PA_STAMP(a.prof, blockIdx.x, wave, 11);
-  // every wave of the workgroup has consumed y[row]: restore the tag for the buffer's next use
-  if (a.y_tagged && wave == 0 && qd == 0 && rok)
-    __hip_atomic_store(reinterpret_cast<unsigned*>(const_cast<float*>(a.y)) + row, kYPendingBits,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- dZ1 = (dZ2 W2) * [h1 > 0]
-#pragma unroll
-  for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-  if constexpr (NG3 > 0) {
-    rows16_gemm_static<NG3>(acc, R3, a.W2tf, tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
-  } else {
-    rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
-  }
-  PA_STAMP(a.prof, blockIdx.x, wave, 12);
   if (rok) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      const int u = u0 + 16 * t;
       float4 z;
-      z.x = (h1k[t].x > 0.f) ? acc[t][0] : 0.f;
-      z.y = (h1k[t].y > 0.f) ? acc[t][1] : 0.f;
-      z.z = (h1k[t].z > 0.f) ? acc[t][2] : 0.f;
-      z.w = (h1k[t].w > 0.f) ? acc[t][3] : 0.f;
-      store4_guarded(a.dZ1, (int64_t)row * a.H1, u0 + 16 * t, a.H1, v1, z);
+      z.x = (h2k[t].x > 0.f) ? __fmul_rn(dq, w3v[t].x) : 0.f;
+      z.y = (h2k[t].y > 0.f) ? __fmul_rn(dq, w3v[t].y) : 0.f;
+      z.z = (h2k[t].z > 0.f) ? __fmul_rn(dq, w3v[t].z) : 0.f;
+      z.w = (h2k[t].w > 0.f) ? __fmul_rn(dq, w3v[t].w) : 0.f;
+      store4_guarded(a.dZ2, (int64_t)row * a.H2, u, a.H2, v2, z);
+      float4 g;
+      g.x = (h1k[t].x > 0.f) ? __fmul_rn(dq, acc[t][0]) : 0.f;
+      g.y = (h1k[t].y > 0.f) ? __fmul_rn(dq, acc[t][1]) : 0.f;
+      g.z = (h1k[t].z > 0.f) ? __fmul_rn(dq, acc[t][2]) : 0.f;
+      g.w = (h1k[t].w > 0.f) ? __fmul_rn(dq, acc[t][3]) : 0.f;
+      store4_guarded(a.dZ1, (int64_t)row * a.H1, u, a.H1, v1, g);
     }
   }
-  PA_STAMP(a.prof, blockIdx.x, wave, 13);
+  PA_STAMP(a.prof, blockIdx.x, wave, 10);
+  PA_STAMP_CYC(a.prof, blockIdx.x, wave, 15);
 }
 
 }  // namespace pa

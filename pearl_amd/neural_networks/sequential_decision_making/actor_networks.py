@@ -125,5 +125,18 @@ class GaussianActorNetwork(ActorNetwork):
             log_prob = log_prob.sum(dim=1, keepdim=True)
         return (action, log_prob) if get_log_prob else action
 
+    def get_log_probability(self, state_batch: Tensor, action_batch: Tensor) -> Tensor:
+        """log pi(a | s) of given actions (:593-629)."""
+        epsilon = 1e-6
+        mean, log_std = self.forward(state_batch)
+        normal = Normal(mean, log_std.exp())
+        normalized = torch.clip(action_unscaling(self._action_space, action_batch), -1 + epsilon,
+                                1 - epsilon)
+        log_prob = normal.log_prob(torch.atanh(normalized))
+        log_prob = log_prob - torch.log(self._action_bound * (1 - normalized.pow(2)) + epsilon)
+        if log_prob.dim() == 2:
+            log_prob = log_prob.sum(dim=1, keepdim=True)
+        return log_prob
+
     def trunk_layers(self) -> List[nn.Linear]:
         return [m for m in self._model.modules() if isinstance(m, nn.Linear)]

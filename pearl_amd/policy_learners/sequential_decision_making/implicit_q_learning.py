@@ -13,7 +13,9 @@ run picks the same critics.  Everything else is libpearl_amd on flat parameter v
 advantage head ``pa_iql_value_head``, AWR heads ``pa_awr_head``, the deterministic actor's tanh
 scaling ``pa_tanh_action`` / ``pa_tanh_action_grad``, paired twin-critic launches.  Actor types
 with HIP heads: ``VanillaContinuousActorNetwork`` (weighted MSE on the action) and
-``VanillaActorNetwork`` (weighted log-likelihood); the Gaussian actor is not built.
+``VanillaActorNetwork`` (weighted log-likelihood of the dataset action) and
+``GaussianActorNetwork`` (weighted ``get_log_probability`` of the dataset action, :231-236,
+``pa_gauss_awr_head``).
 """
 from __future__ import annotations
 
@@ -26,7 +28,7 @@ from ... import _native as N
 from ...action_representation_modules import ActionRepresentationModule
 from ...neural_networks.common.value_networks import VanillaValueNetwork
 from ...neural_networks.sequential_decision_making.actor_networks import (
-    VanillaActorNetwork, VanillaContinuousActorNetwork)
+    GaussianActorNetwork, VanillaActorNetwork, VanillaContinuousActorNetwork)
 from ...neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import ExplorationModule, NoExploration
@@ -55,9 +57,11 @@ class ImplicitQLearning(ActorCriticBase):
                  actor_network_instance: Optional[nn.Module] = None,
                  critic_network_instance: Optional[nn.Module] = None,
                  value_network_instance: Optional[nn.Module] = None, **kwargs: Any) -> None:
-        if actor_network_type not in (VanillaActorNetwork, VanillaContinuousActorNetwork):
+        if actor_network_type not in (VanillaActorNetwork, VanillaContinuousActorNetwork,
+                                      GaussianActorNetwork):
             raise NotImplementedError("pearl_amd ImplicitQLearning: HIP policy-extraction heads exist "
-                                      "for VanillaActorNetwork and VanillaContinuousActorNetwork")
+                                      "for VanillaActorNetwork, VanillaContinuousActorNetwork and "
+                                      "GaussianActorNetwork")
         if critic_network_type is not VanillaQValueNetwork or value_network_type is not VanillaValueNetwork:
             raise NotImplementedError("pearl_amd ImplicitQLearning: only VanillaQValueNetwork twin "
                                       "critics and a VanillaValueNetwork have HIP kernels")
@@ -95,8 +99,14 @@ class ImplicitQLearning(ActorCriticBase):
         """(actor, value network, critic 1, critic 2)."""
         if not self._flat:
             mb = max(self._batch_size, 1)
-            self._flat["actor"] = FlatMlp(layers_of(self._actor.linear_layers()),
-                                          self._actor_optimizer, mb)
+            if isinstance(self._actor, GaussianActorNetwork):
+                # fc_mu and fc_std are ONE last layer of 2A rows (as in ContinuousSoftActorCritic)
+                a = self._actor
+                head = ([a.fc_mu.weight, a.fc_std.weight], [a.fc_mu.bias, a.fc_std.bias])
+                actor_layers = layers_of(a.trunk_layers()) + [head]
+            else:
+                actor_layers = layers_of(self._actor.linear_layers())
+            self._flat["actor"] = FlatMlp(actor_layers, self._actor_optimizer, mb)
             self._flat["value"] = FlatMlp(layers_of(self._value_network.linear_layers()),
                                           self._value_network_optimizer, mb)
             for i, (c, ct) in enumerate(((self._critic._critic_1, self._critic_target._critic_1),
@@ -185,6 +195,15 @@ class ImplicitQLearning(ActorCriticBase):
             N.check(lib.pa_tanh_action_grad(head.data_ptr(), head.stride(0), low.data_ptr(),
                                             high.data_ptr(), d_pred.data_ptr(), d_pred.stride(0), B,
                                             A, d_head.data_ptr(), d_head.stride(0), s))
+        elif isinstance(self._actor, GaussianActorNetwork):
+            # stochastic continuous actor: -mean(adv * log pi(a | s)) (:231-236, :260-261)
+            low, high = self._bounds(dev)
+            assert head.shape[1] == 2 * A
+            logp = torch.empty(B, dtype=torch.float32, device=dev)
+            N.check(lib.pa_gauss_awr_head(head.data_ptr(), head.stride(0), act.data_ptr(),
+                                          act.stride(0), low.data_ptr(), high.data_ptr(),
+                                          adv.data_ptr(), B, A, d_head.data_ptr(), d_head.stride(0),
+                                          logp.data_ptr(), losses[2:].data_ptr(), s))
         else:
             assert head.shape[1] == A, "the softmax actor outputs one logit per action slot"
             N.check(lib.pa_awr_head(1, head.data_ptr(), head.stride(0), act.data_ptr(), act.stride(0),
@@ -211,7 +230,7 @@ class ImplicitQLearning(ActorCriticBase):
     # ------------------------------------------------------------------ act (act-time torch)
     def act(self, subjective_state: Tensor, available_action_space: Any, exploit: bool = False) -> Any:
         with torch.no_grad():
-            if isinstance(self._actor, VanillaContinuousActorNetwork):
+            if isinstance(self._actor, (VanillaContinuousActorNetwork, GaussianActorNetwork)):
                 exploit_action = self._actor.sample_action(subjective_state)
                 probs = None
             else:

@@ -33,6 +33,13 @@ def show(title, stamps, names, nwg):
         v = v[st[:, :, i] > 0]
         if v.size:
             print(f"{n:16s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+    # effective shader clock: s_memtime ticks (slots 14, 15) over the wall time between the same
+    # two points (first and last stamp of the wave)
+    last = len(names) - 1
+    ok = (st[:, :, 15] > 0) & (st[:, :, 14] > 0) & (st[:, :, last] > st[:, :, 0])
+    if ok.any():
+        ghz = (st[:, :, 15] - st[:, :, 14])[ok] / ((st[:, :, last] - st[:, :, 0])[ok] * 10.0)
+        print(f"effective shader clock: median {np.median(ghz):.3f} GHz (min {ghz.min():.3f}, max {ghz.max():.3f})")
     if os.environ.get("PROF_PER_WG"):
         last = max(i for i in range(len(names)))
         for w in range(nwg):
