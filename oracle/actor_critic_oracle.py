@@ -274,13 +274,19 @@ class DiscreteSacOracle:
 # --------------------------------------------------------------------------------------
 class IqlOracle:
     """ImplicitQLearning (implicit_q_learning.py:159-285) with a deterministic tanh actor
-    (``continuous=True``: weighted MSE on the action) or a softmax actor (weighted log-likelihood)."""
+    (``continuous=True``: weighted MSE on the action), a softmax actor (``continuous=False``:
+    weighted log-likelihood) or a GaussianActorNetwork (``continuous="gaussian"``: weighted
+    ``get_log_probability`` of the dataset action, :231-236, actor_networks.py:593-629)."""
 
     def __init__(self, actor_sd, value_sd, critic_sd, critic_target_sd, continuous: bool,
                  low: Tensor = None, high: Tensor = None, gamma: float = 0.99, tau: float = 0.05,
                  lr: float = 1e-3, expectile: float = 0.5, temperature: float = 0.5,
                  adv_clamp: float = 100.0) -> None:
         self.actor = _layers(actor_sd)
+        self.head = []
+        if continuous == "gaussian":      # trunk (last activation relu) + fc_mu / fc_std
+            self.head = [actor_sd[k].clone().requires_grad_(True) for k in
+                         ("fc_mu.weight", "fc_mu.bias", "fc_std.weight", "fc_std.bias")]
         self.value = _layers(value_sd)
         self.c = [_layers(critic_sd, f"_critic_{i}._model.") for i in (1, 2)]
         self.ct = [[(w.detach().clone(), b.detach().clone()) for w, b in
@@ -289,12 +295,25 @@ class IqlOracle:
         self.gamma, self.tau = gamma, tau
         self.expectile, self.temperature, self.adv_clamp = expectile, temperature, adv_clamp
         self.opt_v = _adamw(_flat(self.value), lr)
-        self.opt_a = _adamw(_flat(self.actor), lr)
+        self.opt_a = _adamw(_flat(self.actor) + self.head, lr)
         self.opt_c = _adamw(_flat(self.c[0]) + _flat(self.c[1]), lr)
 
     @staticmethod
     def q(layers, state, action) -> Tensor:
         return mlp(layers, torch.cat([state, action], dim=-1)).view(-1)
+
+    def gaussian_log_prob(self, state: Tensor, action: Tensor) -> Tensor:
+        """GaussianActorNetwork.get_log_probability (actor_networks.py:593-629), (B,)."""
+        x = mlp(self.actor, state, last_relu=True)
+        mean = torch.nn.functional.linear(x, self.head[0], self.head[1])
+        log_std = torch.tanh(torch.nn.functional.linear(x, self.head[2], self.head[3]))
+        log_std = -5 + 0.5 * (2 - (-5)) * (log_std + 1)
+        std = log_std.exp()
+        n = torch.clip((((action - self.low) / (self.high - self.low)) * 2) - 1, -1 + 1e-6, 1 - 1e-6)
+        u = torch.atanh(n)
+        log_prob = -((u - mean) ** 2) / (2 * std ** 2) - std.log() - math.log(math.sqrt(2 * math.pi))
+        log_prob = log_prob - torch.log(((self.high - self.low) / 2) * (1 - n.pow(2)) + 1e-6)
+        return log_prob.sum(dim=1)
 
     def learn_batch(self, batch: Dict[str, Tensor]) -> Dict[str, float]:
         """Draws the two target-critic indices from torch's global generator like the reference."""
@@ -316,11 +335,14 @@ class IqlOracle:
         with torch.no_grad():
             adv = torch.clamp(torch.exp((tqa - mlp(self.value, s).view(-1)) * self.temperature),
                               max=self.adv_clamp)
-        z = mlp(self.actor, s)
-        if self.continuous:
+        if self.continuous == "gaussian":
+            actor_loss = -(adv * self.gaussian_log_prob(s, a)).mean()
+        elif self.continuous:
+            z = mlp(self.actor, s)
             pred = (((self.high - self.low) * (torch.tanh(z) + 1.0)) / 2) + self.low
             actor_loss = (adv * (pred - a).pow(2).mean(dim=1)).mean()
         else:
+            z = mlp(self.actor, s)
             p = torch.softmax(z, dim=-1)
             idx = torch.argmax(a, dim=1).unsqueeze(-1)
             actor_loss = -(adv * torch.log(torch.gather(p, 1, idx).view(-1))).mean()

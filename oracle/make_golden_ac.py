@@ -306,6 +306,11 @@ IQL_CONFIGS = {
                                        expectile=0.8),
     "iql_discrete_tiny": dict(S=5, A=3, hidden=[16, 12], B=16, steps=6, continuous=False,
                               expectile=0.7),
+    # GaussianActorNetwork: the stochastic-continuous branch of the policy extraction (:231-236)
+    "iql_gaussian_tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=6, continuous="gaussian",
+                              expectile=0.7),
+    "iql_gaussian_shape_small": dict(S=64, A=8, hidden=[128, 128], B=96, steps=4,
+                                     continuous="gaussian", expectile=0.8),
 }
 
 
@@ -326,8 +331,15 @@ def make_iql(name, cfg):
         low = -torch.ones(A) * torch.linspace(1.0, 2.0, A)
         high = torch.ones(A) * torch.linspace(1.5, 1.0, A)
         batch["action"] = low + (high - low) * torch.rand(B, A, generator=gen)
+        if cfg["continuous"] == "gaussian":
+            from pearl.neural_networks.sequential_decision_making.actor_networks import (
+                GaussianActorNetwork,
+            )
+            atype = GaussianActorNetwork
+        else:
+            atype = VanillaContinuousActorNetwork
         pl = ImplicitQLearning(action_space=BoxActionSpace(low=low, high=high),
-                               actor_network_type=VanillaContinuousActorNetwork, **kw)
+                               actor_network_type=atype, **kw)
     else:
         batch["action"] = torch.randint(0, A, (B, 1), generator=gen)
         pl = ImplicitQLearning(action_space=space(A), actor_network_type=VanillaActorNetwork,
@@ -396,6 +408,11 @@ def main():
     if os.environ.get("PEARL_GOLDEN_ONLY") == "iql":
         for name, cfg in IQL_CONFIGS.items():
             make_iql(name, cfg)
+        return
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "iql_gaussian":
+        for name, cfg in IQL_CONFIGS.items():
+            if "gaussian" in name:
+                make_iql(name, cfg)
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "dsac":
         for name, cfg in DSAC_CONFIGS.items():

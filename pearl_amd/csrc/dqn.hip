@@ -1127,7 +1127,11 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
       if (rc != PA_OK) return rc;
     }
-    for (int j = 0; j < w; ++j) {
+    // diagnostics only (tools/gpu_r02_c.sh): the target side of the loop with the chain left out,
+    // to tell the target kernel's own speed on its share of the chip from co-run interference
+    static const bool no_chain = env_int("PEARL_AMD_DEBUG_NO_CHAIN", 0) != 0;
+    if (no_chain) h->y_clean = false;
+    for (int j = 0; j < w && !no_chain; ++j) {
       const int round = r + j;
       h->cur_round = round;
       const int soft_next = (round + 1 < R) ? due(round + 1) : 0;

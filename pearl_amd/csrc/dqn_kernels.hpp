@@ -458,6 +458,17 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
   // instead of a cross-lane reduction.
   const int nq0 = wave * 32 + 4 * h;     // this lane's hidden units: nq0 + 8*q + j, q,j in 0..3
   PA_STAMP(a.prof, tile, wave, 0);
+  // scalars of the epilogue, requested with the first operands: fetched where they are used they
+  // are one more exposed global round trip each at the end of every tile
+  const float b3v = a.b3[0];
+  unsigned pf_mask = 0, pf_term = 0;
+  float pf_reward = 0.f;
+  if (tid < nrows && a.mask)
+    pf_mask = a.mask[(int64_t)(b0 + tid / a.A) * a.mask_bstride + tid % a.A];
+  if (tid < nb && a.y) {
+    pf_term = a.term[b0 + tid];
+    pf_reward = a.reward[b0 + tid];
+  }
 
   // ---- layer 1 operands first (vmcnt retires in order: layer 1 never waits for the W2' stream)
   f32x16 acc[2];
@@ -611,12 +622,9 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
     float q = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) q += qpart[w * 64 + tid];
-    q += a.b3[0];
+    q += b3v;
     if (a.q_all && tid < nrows) a.q_all[(int64_t)b0 * a.A + tid] = q;
-    if (tid < nrows && a.mask) {
-      const int bb = b0 + tid / a.A, i = tid % a.A;
-      if (a.mask[(int64_t)bb * a.mask_bstride + i]) q = -INFINITY;
-    }
+    if (tid < nrows && pf_mask) q = -INFINITY;
     qv[tid] = q;
   }
   __syncthreads();
@@ -640,10 +648,10 @@ __device__ __forceinline__ void target_tile(const TargetArgs& a, int tile, float
     if (a.next_v) a.next_v[bb] = m;
     if (a.y) {
       // (next_v * gamma * (1 - terminated.float())) + reward, one rounding per op
-      const float live = 1.0f - (a.term[bb] ? 1.0f : 0.0f);
+      const float live = 1.0f - (pf_term ? 1.0f : 0.0f);
       const float t0 = __fmul_rn(m, a.gamma);
       const float t1 = __fmul_rn(t0, live);
-      publish_y(a.y + bb, __fadd_rn(t1, a.reward[bb]));
+      publish_y(a.y + bb, __fadd_rn(t1, pf_reward));
     }
   }
   PA_STAMP(a.prof, tile, wave, 7);

@@ -246,6 +246,52 @@ __device__ __forceinline__ void rows16_gemm_static(f32x4v (&acc)[2], WRing& R,
   }
 }
 
+// The same loop, and in the iterations that have no refill of their own (the last RP_PD k-groups)
+// one k-group of the NEXT weight stream is requested into `Rn`: those loads queue behind this
+// loop's own operands (vector memory returns in issue order) instead of in front of them, and
+// still have the rest of this loop to land.  Slots that do not fit are requested after the loop.
+template <int NKG, int NKGN>
+__device__ __forceinline__ void rows16_gemm_static_pf(f32x4v (&acc)[2], WRing& R,
+                                                      const float* __restrict__ Wf, int tile0,
+                                                      int ntiles, const float* act, int lane,
+                                                      WRing& Rn, const float* __restrict__ Wn,
+                                                      int ntiles_n, bool want_next) {
+  const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
+  const int64_t base0 = ((int64_t)tile0 * NKG) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)NKG * 256;
+  const bool nk0 = want_next && tile0 < ntiles_n, nk1 = want_next && tile0 + 1 < ntiles_n;
+  const int64_t nb0 = ((int64_t)tile0 * NKGN) * 256 + lane * 4;
+  const int64_t nb1 = nb0 + (int64_t)NKGN * 256;
+  constexpr int FREE0 = NKG > RP_PD ? NKG - RP_PD : 0;        // first iteration without a refill
+  constexpr int NSLOT = NKGN < RP_PD ? NKGN : RP_PD;          // slots ring_fill<NKGN> would load
+#pragma unroll
+  for (int g = 0; g < NKG; ++g) {
+    const float4 w0 = R.r0[g % RP_PD], w1 = R.r1[g % RP_PD];
+    if (g + RP_PD < NKG) {
+      R.r0[g % RP_PD] = ld4_or_zero(Wf, base0 + (int64_t)(g + RP_PD) * 256, ok0);
+      R.r1[g % RP_PD] = ld4_or_zero(Wf, base1 + (int64_t)(g + RP_PD) * 256, ok1);
+    } else if (g - FREE0 < NSLOT) {
+      Rn.r0[g - FREE0] = ld4_or_zero(Wn, nb0 + (int64_t)(g - FREE0) * 256, nk0);
+      Rn.r1[g - FREE0] = ld4_or_zero(Wn, nb1 + (int64_t)(g - FREE0) * 256, nk1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float4 x4 = *reinterpret_cast<const float4*>(act + g * 16);
+    acc[0] = mfma16(w0.x, x4.x, acc[0]);
+    acc[1] = mfma16(w1.x, x4.x, acc[1]);
+    acc[0] = mfma16(w0.y, x4.y, acc[0]);
+    acc[1] = mfma16(w1.y, x4.y, acc[1]);
+    acc[0] = mfma16(w0.z, x4.z, acc[0]);
+    acc[1] = mfma16(w1.z, x4.z, acc[1]);
+    acc[0] = mfma16(w0.w, x4.w, acc[0]);
+    acc[1] = mfma16(w1.w, x4.w, acc[1]);
+  }
+#pragma unroll
+  for (int p = NKG - FREE0; p < NSLOT; ++p) {
+    Rn.r0[p] = ld4_or_zero(Wn, nb0 + (int64_t)p * 256, nk0);
+    Rn.r1[p] = ld4_or_zero(Wn, nb1 + (int64_t)p * 256, nk1);
+  }
+}
+
 __device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t row_off, int col,
                                                int ncols, bool vec_ok, const float4& v) {
   if (vec_ok && col + 3 < ncols) {
@@ -296,37 +342,57 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   const bool v1 = ((a.H1 & 3) == 0), v2 = ((a.H2 & 3) == 0);
   f32x4v acc[2];
 
+  // Every kernel starts on a cold L2 (kernel boundaries write back and invalidate it), and under
+  // the load of the co-running target pass one exposed global round trip costs ~2 us here
+  // (tools/prof_chain.py).  So EVERYTHING the tile needs before its first barrier is requested in
+  // one burst at the top — x, all of this wave's W1 fragments, the head of its W2 stream, biases,
+  // w3 — and the W2^T stream of the backward GEMM is requested as soon as layer 1 has released
+  // its registers; vector-memory results return in issue order, so layer 1 never waits for more
+  // than its own operands.
+  WRing R2;
+  float4 b2v[2], w3v[2];
+  const float b3v = a.b3[0];
+  const bool vb = is_vec_ok(a.b1, 4) && is_vec_ok(a.b2, 4) && is_vec_ok(a.w3, 4) && v1 && v2;
+  auto vec4 = [&](const float* p, int col, int n) {
+    return vb ? ld4_or_zero(p, col, col < n) : guarded_load4(p, 0, true, col, n);
+  };
   // ---- layer 1: h1 = relu(W1 x + b1)
   if constexpr (NG1 > 0) {
     // B operand of k-group g: x[row][16 g + 4 qd .. + 3]
     const bool vx = is_vec_ok(a.x, a.ldx) && ((a.K1 & 3) == 0);
-    float4 xf[NG1];
+    float4 xf[NG1], wa[NG1], wb[NG1];
 #pragma unroll
     for (int g = 0; g < NG1; ++g) {
       const int c = 16 * g + 4 * qd;
       if (vx) xf[g] = ld4_or_zero(a.x, (int64_t)row * a.ldx + c, rok && c < a.K1);
       else xf[g] = guarded_load4(a.x, (int64_t)row * a.ldx, rok, c, a.K1);
     }
-    WRing R1;
-    ring_fill<NG1>(R1, a.W1f, tile0, nt1, lane);
+    {
+      const bool ok0 = tile0 < nt1, ok1 = tile0 + 1 < nt1;
+      const int64_t base0 = ((int64_t)tile0 * NG1) * 256 + lane * 4;
+      const int64_t base1 = base0 + (int64_t)NG1 * 256;
+#pragma unroll
+      for (int g = 0; g < NG1; ++g) {
+        wa[g] = ld4_or_zero(a.W1f, base0 + (int64_t)g * 256, ok0);
+        wb[g] = ld4_or_zero(a.W1f, base1 + (int64_t)g * 256, ok1);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
+      const float4 b = vec4(a.b1, u0 + 16 * t, a.H1);
       acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
     }
+    if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      b2v[t] = vec4(a.b2, u0 + 16 * t, a.H2);
+      w3v[t] = vec4(a.w3, u0 + 16 * t, a.H2);
+    }
     PA_STAMP(a.prof, blockIdx.x, wave, 1);
-    const bool ok0 = tile0 < nt1, ok1 = tile0 + 1 < nt1;
-    const int64_t base0 = ((int64_t)tile0 * NG1) * 256 + lane * 4;
-    const int64_t base1 = base0 + (int64_t)NG1 * 256;
+    __builtin_amdgcn_sched_barrier(0);   // the burst above stays above: nothing sinks to its use
 #pragma unroll
     for (int g = 0; g < NG1; ++g) {
-      const float4 w0 = R1.r0[g % RP_PD], w1 = R1.r1[g % RP_PD];
-      if (g + RP_PD < NG1) {
-        R1.r0[g % RP_PD] = ld4_or_zero(a.W1f, base0 + (int64_t)(g + RP_PD) * 256, ok0);
-        R1.r1[g % RP_PD] = ld4_or_zero(a.W1f, base1 + (int64_t)(g + RP_PD) * 256, ok1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      const float4 x4 = xf[g];
+      const float4 x4 = xf[g], w0 = wa[g], w1 = wb[g];
       acc[0] = mfma16(w0.x, x4.x, acc[0]);
       acc[1] = mfma16(w1.x, x4.x, acc[1]);
       acc[0] = mfma16(w0.y, x4.y, acc[0]);
@@ -351,16 +417,21 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const float4 b = guarded_load4(a.b1, 0, true, u0 + 16 * t, a.H1);
+      const float4 b = vec4(a.b1, u0 + 16 * t, a.H1);
       acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+    }
+    if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      b2v[t] = vec4(a.b2, u0 + 16 * t, a.H2);
+      w3v[t] = vec4(a.w3, u0 + 16 * t, a.H2);
     }
     PA_STAMP(a.prof, blockIdx.x, wave, 1);
     __syncthreads();
     rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
     PA_STAMP(a.prof, blockIdx.x, wave, 2);
   }
-  WRing R2;
-  if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
+  WRing R3;   // the backward GEMM's weight stream: requested from inside the layer-2 loop
   float4 h1k[2];  // kept for the ReLU mask of dZ1
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -373,25 +444,20 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   // ---- layer 2: h2 = relu(W2 h1 + b2)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const float4 b = guarded_load4(a.b2, 0, true, u0 + 16 * t, a.H2);
-    acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+    acc[t][0] = b2v[t].x; acc[t][1] = b2v[t].y; acc[t][2] = b2v[t].z; acc[t][3] = b2v[t].w;
   }
-  float4 w3v[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) w3v[t] = guarded_load4(a.w3, 0, true, u0 + 16 * t, a.H2);
   PA_STAMP(a.prof, blockIdx.x, wave, 3);
   __syncthreads();                                                      // barrier A: h1 tile
   PA_STAMP(a.prof, blockIdx.x, wave, 4);
-  WRing R3;
-  if constexpr (NG2 > 0) {
+  if constexpr (NG2 > 0 && NG3 > 0) {
+    rows16_gemm_static_pf<NG2, NG3>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane, R3,
+                                    a.W2tf, nt1, a.y != nullptr);
+  } else if constexpr (NG2 > 0) {
     rows16_gemm_static<NG2>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   } else {
     rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 5);
-  if constexpr (NG3 > 0) {
-    if (a.y) ring_fill<NG3>(R3, a.W2tf, tile0, nt1, lane);
-  }
   float4 h2k[2];
   float part = 0.f;
 #pragma unroll
@@ -422,6 +488,13 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
   __syncthreads();                                                      // barrier B: s2, qpart
   PA_STAMP(a.prof, blockIdx.x, wave, 7);
+  unsigned ybits = kYPendingBits;
+  if (a.y && rok) {
+    // first look at the Bellman target, in flight while the backward GEMM runs
+    ybits = a.y_tagged ? __hip_atomic_load(reinterpret_cast<const unsigned*>(a.y) + row,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                       : __builtin_bit_cast(unsigned, a.y[row]);
+  }
   if (a.y) {
     // ---- G = s2 W2 (scaled by dq below)
 #pragma unroll
@@ -436,12 +509,16 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   float q = 0.f;
 #pragma unroll
   for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
-  q += a.b3[0];
+  q += b3v;
   if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
   if (!a.y) return;
   // ---- loss, dZ2 = [h2 > 0] * (dq * w3), dZ1 = [h1 > 0] * (dq * G)
   float yv = q;
-  if (rok) yv = a.y_tagged ? consume_y(a.y + row, a.err) : a.y[row];
+  if (rok) {
+    // (an untagged y can legitimately hold the tag's bit pattern: only the tagged protocol polls)
+    if (a.y_tagged && ybits == kYPendingBits) yv = consume_y(a.y + row, a.err);
+    else yv = __builtin_bit_cast(float, ybits);
+  }
   PA_STAMP(a.prof, blockIdx.x, wave, 9);
   const float d = __fsub_rn(q, yv);
   const float dq = __fmul_rn(a.norm, d);

@@ -33,7 +33,7 @@ namespace pa {
 
 inline size_t target_pp_smem_bytes(int H1) {
   const int H1P = t_nkg(H1) * 8;
-  return sizeof(float) * ((size_t)2 * T_ROWS * (H1P + 4) + 2 * 8 * 64 + 2 * 64 + 16);
+  return sizeof(float) * ((size_t)2 * T_ROWS * (H1P + 4) + 2 * 8 * 64 + 2 * 64 + 16 + 2 * T_MAXH);
 }
 
 // writers: LDS stores must have landed before the other waves pass the barrier
@@ -62,6 +62,16 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
   float* qv = smem + 2 * T_ROWS * PA_ + 2 * 8 * 64 + team * 64;
   int* ctl = reinterpret_cast<int*>(smem + 2 * T_ROWS * PA_ + 2 * 8 * 64 + 2 * 64);
   // ctl[team]: next tile of the team; ctl[2 + team]: the team still has work in a later phase
+  // Layer-3 constants live in LDS for the whole launch: the epilogue segments sit between
+  // barriers the MAIN-LOOP team also waits at, so a global round trip there (~2 us when the chain
+  // kernels share the memory system) stalls the matrix pipe; an LDS read does not.
+  float* b2s = smem + 2 * T_ROWS * PA_ + 2 * 8 * 64 + 2 * 64 + 16;   // [T_MAXH]
+  float* w3s = b2s + T_MAXH;                                          // [T_MAXH]
+  for (int i = tid; i < T_MAXH; i += 1024) {
+    b2s[i] = ld_or_zero(a.b2, i, i < a.H2);
+    w3s[i] = ld_or_zero(a.w3, i, i < a.H2);
+  }
+  const float b3v = a.b3[0];
 
   const int h = lane >> 5, l31 = lane & 31;
   const int nt1 = H1P >> 5, nt2 = (a.H2 + 31) >> 5;
@@ -102,12 +112,22 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
   f32x16 acc[2];
   int cur = -1;      // tile whose layer-2 result sits in acc (epilogue pending)
   bool exhausted = false;
+  // Per-tile scalars of the epilogue (action mask of row ttid, terminal flag and reward of
+  // transition ttid), fetched in the tile's PROLOGUE and carried through its main loop, and the
+  // team's next tile index, requested one whole epilogue phase before it is needed (a returning
+  // device-scope atomic costs 1-3 us under load).
+  unsigned pf_mask = 0, pf_term = 0;
+  float pf_reward = 0.f;
+  int pend = a.ntiles;
+  if (ttid == 0) pend = atomicAdd(a.tile_ctr, 1);
+  __syncthreads();   // b2s / w3s written (both teams, once)
   if (team == 1) {
     PA_BAR_N();
     PA_BAR_N();
     PA_BAR_N();
     PA_BAR_N();
-    if (ttid == 0) ctl[3] = 0;
+    // the team already holds its first tile index: it must not leave while that index is a tile
+    if (ttid == 0) ctl[3] = (pend < a.ntiles) ? 1 : 0;
     PA_BAR_W();
     if ((ctl[2] | ctl[3]) == 0) return;
   }
@@ -124,17 +144,18 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
     {
       PP_STAMP(0);
       // ================= epilogue of `cur`, prologue of the next tile =================
-      int nxt = a.ntiles;
-      if (ttid == 0 && !exhausted) nxt = atomicAdd(a.tile_ctr, 1);
+      const int nxt = pend;                 // requested during the previous epilogue phase
+      pend = a.ntiles;
+      if (ttid == 0 && !exhausted && nxt < a.ntiles) pend = atomicAdd(a.tile_ctr, 1);
       if (cur >= 0) {
         // layer 3: in-lane over this lane's 16 hidden units, then the other half, then the waves.
         // Its constants are fetched here, not carried from the main loop: this team has slack,
         // the main loop has no registers to spare.
         float4 b2v[4], w3v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          b2v[q] = l2 ? l3_load(a.b2, q) : make_float4(0.f, 0.f, 0.f, 0.f);
-          w3v[q] = l2 ? l3_load(a.w3, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) {   // zeros beyond H2 (waves that own no hidden units)
+          b2v[q] = *reinterpret_cast<const float4*>(b2s + nq0 + 8 * q);
+          w3v[q] = *reinterpret_cast<const float4*>(w3s + nq0 + 8 * q);
         }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
@@ -160,11 +181,8 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
         float q = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) q += qpart[w * 64 + ttid];
-        q += a.b3[0];
-        if (ttid < cnrows && a.mask) {
-          const int bb = cb0 + ttid / a.A, i = ttid % a.A;
-          if (a.mask[(int64_t)bb * a.mask_bstride + i]) q = -INFINITY;
-        }
+        q += b3v;
+        if (ttid < cnrows && pf_mask) q = -INFINITY;
         qv[ttid] = q;
       }
       PA_BAR_W();  // B2
@@ -177,10 +195,10 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
         }
         if (a.next_v) a.next_v[bb] = m;
         if (a.y) {
-          const float live = 1.0f - (a.term[bb] ? 1.0f : 0.0f);
+          const float live = 1.0f - (pf_term ? 1.0f : 0.0f);
           const float t0 = __fmul_rn(m, a.gamma);
           const float t1 = __fmul_rn(t0, live);
-          publish_y(a.y + bb, __fadd_rn(t1, a.reward[bb]));
+          publish_y(a.y + bb, __fadd_rn(t1, pf_reward));
         }
       }
       cur = -1;
@@ -235,6 +253,14 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
         float4 fx[2][2], fw[2];
         l1_loads(0, fx[0], fw[0]);
         l1_loads(8, fx[1], fw[1]);
+        // this tile's epilogue scalars (consumed two phases from now)
+        pf_mask = 0; pf_term = 0; pf_reward = 0.f;
+        if (ttid < nrows && a.mask)
+          pf_mask = a.mask[(int64_t)(b0 + ttid / a.A) * a.mask_bstride + ttid % a.A];
+        if (ttid < nb && a.y) {
+          pf_term = a.term[b0 + ttid];
+          pf_reward = a.reward[b0 + ttid];
+        }
         PA_BAR_W();  // B3: operand loads are in flight; the main loop runs on
         l1_mfma(fx[0], fw[0]);
         l1_mfma(fx[1], fw[1]);

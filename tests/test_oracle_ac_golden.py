@@ -190,7 +190,8 @@ def test_discrete_sac_probe_and_trajectory(name):
                                fx["critic_target_after"]["_critic_2._model.0.0.weight"], rtol=1e-5, atol=1e-7)
 
 
-IQL = ["iql_continuous_tiny", "iql_continuous_shape_small", "iql_discrete_tiny"]
+IQL = ["iql_continuous_tiny", "iql_continuous_shape_small", "iql_discrete_tiny", "iql_gaussian_tiny",
+       "iql_gaussian_shape_small"]
 
 
 def iql_batch(fx):

@@ -18,8 +18,8 @@ import bench  # noqa: E402
 from pearl_amd import (BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule,  # noqa: E402
                        PearlAgent, _native as N)
 
-ROW_NAMES = ["start", "x staged", "bar1", "L1 done", "h1 stored", "bar2", "L2 done", "head part",
-             "bar3", "y consumed", "dZ2 stored", "bar4", "dX done", "end"]
+ROW_NAMES = ["start", "loads issued", "L1 done", "h1 stored", "barA", "L2 done", "s2/head part",
+             "barB", "G=s2 W2 done", "y consumed", "end"]
 DW_NAMES = ["start", "setup", "main loop", "partials out", "stage-1 sum", "bar", "end"]
 
 

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--rounds", default="1,10,20,100")
     ap.add_argument("--replay", type=int, default=1_000_000)
     ap.add_argument("--trace", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="cProfile of 300 one-round learn() calls (host side of the fixed cost)")
     args = ap.parse_args()
     from pearl_amd import (BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule,
                            PearlAgent, _native as N)
@@ -68,6 +70,20 @@ def main():
     N_lib = N.lib
     N.lib = lambda: _Lib()
     try:
+        if args.profile:
+            import cProfile
+            import pstats
+            pl._training_rounds = 1
+            for _ in range(20):
+                agent.learn()
+            pr = cProfile.Profile()
+            pr.enable()
+            for _ in range(300):
+                agent.learn()
+            pr.disable()
+            torch.cuda.synchronize()
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+            return
         if args.trace:
             pl._training_rounds = 20
             for _ in range(3):

@@ -40,7 +40,7 @@ def main():
     for spec in sys.argv[1:] or [""]:
         os.environ.clear()
         os.environ.update(base_env)
-        for kv in filter(None, spec.split(",")):
+        for kv in filter(None, ("" if spec in ("default", '""') else spec).split(",")):
             k, v = kv.split("=")
             os.environ[k] = v
         torch.manual_seed(0)
