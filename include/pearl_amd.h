@@ -488,6 +488,54 @@ int pa_gauss_awr_head(const float* head, int32_t ldh, const float* action, int32
                       const float* low, const float* high, const float* adv, int32_t B, int32_t A,
                       float* d_head, int32_t lddh, float* log_prob, float* loss_out, void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* Row-local heads of the generic TD learner (qheads.hip): DeepQLearning /   */
+/* DoubleDQN / DeepSARSA over Q-network architectures the fused pa_dqn_*      */
+/* kernels do not cover — VanillaQValueNetwork of any depth,                  */
+/* VanillaQValueMultiHeadNetwork (q_value_networks.py:185-249) and            */
+/* DuelingQValueNetwork (:352-508) — around the pa_mlp engine.                */
+/* ------------------------------------------------------------------------ */
+/* get_next_state_values + Bellman target from per-action values [B, A]:
+ *   q_sel == NULL: v = max over unmasked i of q_val[b, i]   (deep_q_learning.py:130-167)
+ *   q_sel != NULL: i* = first argmax over unmasked i of q_sel, v = q_val[b, i*]  (double_dqn.py:29-57)
+ *   A == 1, no mask: v = q_val[b]   (DeepSARSA, deep_sarsa.py:59-97)
+ * y = v gamma (1 - terminated) + reward, one rounding per op (deep_td_learning.py:313-317). */
+int pa_td_target(const float* q_val, int32_t ldv, const float* q_sel, int32_t lds,
+                 const uint8_t* mask, int32_t ldm, const float* reward, const uint8_t* terminated,
+                 float gamma, int32_t B, int32_t A, float* next_v, float* y, void* stream);
+/* dq = grad_scale (q - y) (MSELoss(mean): grad_scale = 2 / (B world)); loss_out2[0] = mean |q - y|
+ * (the reported loss, deep_td_learning.py:358-359), loss_out2[1] = mean (q - y)^2. */
+int pa_td_head(const float* q, int32_t ldq, const float* y, int32_t B, float grad_scale, float* dq,
+               float* loss_out2, void* stream);
+/* Multi-head network: Q(s_b, a_b) = rep[b, :] . f[b, :] (torch.bmm with a one-hot action,
+ * q_value_networks.py:232-238); its gradient d f = dq[b] rep[b, :]; and over an action set
+ * q[b, i] = rep[b, i, :] . f[b, :] (rep_bstride = Q A, or 0 for one shared [Q, A] table). */
+int pa_rows_dot(const float* f, int32_t ldf, const float* rep, int32_t ldr, int32_t B, int32_t A,
+                float* out, void* stream);
+int pa_rows_scale(const float* dq, const float* rep, int32_t ldr, int32_t B, int32_t A, float* out,
+                  int32_t ldo, void* stream);
+int pa_rows_bmm(const float* rep, int64_t rep_bstride, const float* f, int32_t ldf, int32_t B,
+                int32_t Q, int32_t A, float* out, void* stream);
+/* Dueling network (q_value_networks.py:474-506): out[b, i] = (v[b] + adv_q[b, i]) - mean_j adv_mean[b, j]
+ * (adv_mean NULL: the mean runs over the Q query actions themselves).  pa_dueling_grad: the
+ * gradient for the (B + B M)-row advantage pass of the taken-action forward — rows [0, B) get dq,
+ * rows B + b M + i get -dq[b] / M (M = 0: zeros; the value tower's gradient is dq itself).
+ * pa_dueling_feat_grad: dfeat[b, :H] (+)= dX[b, :H] + sum_i dX[B + b M + i, :H]. */
+int pa_dueling_q(const float* v, const float* adv_q, int32_t Q, const float* adv_mean, int32_t M,
+                 int32_t B, float* out, void* stream);
+int pa_dueling_grad(const float* dq, int32_t B, int32_t M, float* d_adv_rows, void* stream);
+int pa_dueling_feat_grad(const float* dX, int32_t ldx, int32_t B, int32_t M, int32_t H,
+                         int32_t accumulate, float* dfeat, int32_t ldf, void* stream);
+
+/* SquareCBExploration.act's probability table (squarecb_exploration.py:59-115), one row per
+ * context: p_a = 1 / (A + gamma (max_a v - v_a)), the arg-max entry rewritten to 1 - (sum of the
+ * row's other entries).  Equal to the reference for B = 1, the only batch size its whole-matrix
+ * complementary sum (:90) yields a distribution for.  argmax_out[B] = torch.max's index per row.
+ * Sampling stays with the caller (torch's generator: a seeded run draws the reference's actions). */
+int pa_squarecb_probs(const float* values, int32_t ldv, int32_t B, int32_t A, float gamma,
+                      int32_t clamp_values, float reward_lb, float reward_ub, float* prob,
+                      int32_t* argmax_out, void* stream);
+
 /* Deterministic policies (DDPG ddpg.py:106-156, TD3 td3.py:106-201).
  * pa_tanh_action: VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485) from the
  * actor's pre-tanh outputs: a = ((high - low) (tanh(z) + 1)) / 2 + low.  With `noise` ([B, A]

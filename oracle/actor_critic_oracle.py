@@ -481,3 +481,22 @@ class NeuralLinearOracle:
     def sigma(self, x: Tensor) -> Tensor:
         X = torch.cat((torch.ones(x.shape[0], 1), self.features(x)), dim=-1)
         return torch.sqrt((torch.matmul(X, self.inv_A) * X).sum(-1))
+
+
+# --------------------------------------------------------------------------------------
+# SquareCB
+# --------------------------------------------------------------------------------------
+def squarecb_probs(values: Tensor, gamma: float, clamp_values: bool = False, reward_lb: float = 0.0,
+                   reward_ub: float = 1.0) -> Tensor:
+    """SquareCBExploration.act's probability table for ONE context (squarecb_exploration.py:71-92;
+    the batch size its whole-matrix complementary sum, :90, is a distribution for): values (1, A)."""
+    A = values.shape[-1]
+    values = values.view(-1, A)
+    assert values.shape[0] == 1
+    if clamp_values:
+        values = torch.clamp(values, min=reward_lb, max=reward_ub)
+    max_val, max_indices = torch.max(values, dim=1)
+    prob = torch.div(1.0, A + gamma * (max_val - values))
+    prob[0, max_indices[0]] = 0.0
+    prob[0, max_indices[0]] = 1.0 - torch.sum(prob)
+    return prob

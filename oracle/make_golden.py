@@ -38,6 +38,11 @@ from pearl.replay_buffers.sequential_decision_making.sarsa_replay_buffer import 
     SARSAReplayBuffer,
 )
 from pearl.replay_buffers import BasicReplayBuffer  # noqa: E402
+from pearl.neural_networks.sequential_decision_making.q_value_networks import (  # noqa: E402
+    DuelingQValueNetwork,
+    VanillaQValueMultiHeadNetwork,
+    VanillaQValueNetwork,
+)
 from pearl.utils.instantiations.spaces.discrete_action import DiscreteActionSpace  # noqa: E402
 
 OUT = os.path.join(REPO, "tests", "golden")
@@ -61,6 +66,29 @@ CONFIGS = {
     "double_cfg2_shape_small_batch": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=12,
                                           dynamic=False, learner="double"),
 }
+
+
+# Q-network architectures beyond "VanillaQValueNetwork with two hidden layers" (files qnet_<name>.pt):
+# other depths (common/utils.py:75-152), VanillaQValueMultiHeadNetwork (q_value_networks.py:185-249),
+# DuelingQValueNetwork (:352-508), each under DeepQLearning and (multi-head, dueling) DoubleDQN.
+QNET_CONFIGS = {
+    "deep3_tiny": dict(S=5, A=5, hidden=[24, 16, 12], N=48, B=16, rounds=11, dynamic=True,
+                       network="vanilla"),
+    "wide_small": dict(S=12, A=4, hidden=[320], N=120, B=32, rounds=6, dynamic=False,
+                       network="vanilla"),
+    "multihead_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
+                           network="multihead"),
+    "multihead_double_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
+                                  network="multihead", learner="double"),
+    "multihead_cfg2_shape": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=8,
+                                 dynamic=False, network="multihead"),
+    "dueling_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
+                         network="dueling"),
+    "dueling_double_small": dict(S=16, A=6, hidden=[32, 32], N=300, B=64, rounds=8, dynamic=False,
+                                 network="dueling", learner="double"),
+}
+NETWORK_TYPES = {"vanilla": VanillaQValueNetwork, "multihead": VanillaQValueMultiHeadNetwork,
+                 "dueling": DuelingQValueNetwork}
 
 
 def synthetic_transitions(cfg, gen):
@@ -109,6 +137,9 @@ def make(name, cfg):
     double = cfg.get("learner") == "double"
     cql = cfg.get("learner") == "cql"
     extra = dict(is_conservative=True, conservative_alpha=2.0) if cql else {}
+    qnet = "network" in cfg
+    if qnet:
+        extra["network_type"] = NETWORK_TYPES[cfg["network"]]
     pl = (DoubleDQN if double else DeepQLearning)(**extra, state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
                        training_rounds=cfg["rounds"], batch_size=B,
                        action_representation_module=rep)
@@ -136,10 +167,20 @@ def make(name, cfg):
     batch = pl.preprocess_batch(raw)
     fx["batch_pre"] = batch_to_dict(batch)
 
+    if qnet:
+        # a target network that differs from the online one from the start (otherwise DoubleDQN's
+        # argmax and the plain max coincide on the first batches)
+        with torch.no_grad():
+            for p_ in pl._Q_target.parameters():
+                p_.add_(0.1 * torch.randn(p_.shape, generator=gen))
     # ---- one-batch numerics (no parameter change)
     fx["params0"] = clone_sd(pl._Q)
     fx["target0"] = clone_sd(pl._Q_target)
-    q = pl._Q.get_q_values(batch.state, batch.action)
+    if qnet:   # exactly what forward() evaluates (deep_td_learning.py:286-290)
+        q = pl._Q.get_q_values(state_batch=batch.state, action_batch=batch.action,
+                               curr_available_actions_batch=batch.curr_available_actions)
+    else:
+        q = pl._Q.get_q_values(batch.state, batch.action)
     next_v = pl.get_next_state_values(batch, B)
     loss, target = pl.loss(batch, q)
     pl._optimizer.zero_grad()
@@ -169,8 +210,9 @@ def make(name, cfg):
                         ("step", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")}
     fx["opt_after"] = opt_state
     os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, f"ddqn_{name[len('double_'):]}.pt" if double
-                        else (f"{name}.pt" if cql else f"dqn_{name}.pt"))
+    path = os.path.join(OUT, f"qnet_{name}.pt" if qnet else
+                        (f"ddqn_{name[len('double_'):]}.pt" if double
+                         else (f"{name}.pt" if cql else f"dqn_{name}.pt")))
     torch.save(fx, path)
     print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); "
           f"losses {report['loss'][0]:.5f} -> {report['loss'][-1]:.5f}")
@@ -410,6 +452,9 @@ def main():
             make_sarsa(name, cfg)
     for name, cfg in CONFIGS.items():
         if not only or name in only:
+            make(name, cfg)
+    for name, cfg in QNET_CONFIGS.items():
+        if not only or name in only or "qnet" in only:
             make(name, cfg)
 
 

@@ -368,6 +368,60 @@ def make_iql(name, cfg):
           f"-> {reports[-1]}")
 
 
+
+def make_squarecb(name="squarecb_tiny"):
+    """SquareCBExploration.act (squarecb_exploration.py:59-115) + NeuralLinearBandit.act /
+    get_scores (neural_linear_bandit.py:227-311): for single contexts (the batch size the
+    reference's rule is defined for) the probability table the action is drawn from — captured at
+    the reference's Categorical(...) call — and the action torch's seeded generator then yields."""
+    import pearl.policy_learners.exploration_modules.contextual_bandits.squarecb_exploration as M
+    from pearl.policy_learners.contextual_bandits.neural_linear_bandit import NeuralLinearBandit
+    captured = []
+    real = M.Categorical
+
+    class Spy(real):
+        def __init__(self, probs=None, **kw):
+            captured.append(probs.detach().clone())
+            super().__init__(probs=probs, **kw)
+
+    M.Categorical = Spy
+    try:
+        gen = torch.Generator().manual_seed(31)
+        cases = []
+        for (A, gamma, clamp) in ((4, 10.0, False), (32, 50.0, False), (6, 3.0, True)):
+            sp = space(A)
+            exp = M.SquareCBExploration(gamma=gamma, reward_lb=0.2, reward_ub=0.7, clamp_values=clamp)
+            for trial in range(4):
+                values = torch.rand(1, A, generator=gen) * 1.2 - 0.1
+                if trial == 3:
+                    values[0, 1] = values[0, 2] = values.max() + 0.05       # a tie: first maximum wins
+                captured.clear()
+                torch.manual_seed(500 + trial)
+                act = exp.act(subjective_state=None, action_space=sp, values=values.clone())
+                cases.append(dict(A=A, gamma=gamma, clamp=clamp, values=values, seed=500 + trial,
+                                  probs=captured[0].clone(), action=int(act)))
+        # the bandit's act / get_scores on top of it
+        F, A = 7, 5
+        torch.manual_seed(9)
+        pl = NeuralLinearBandit(feature_dim=F + 1, hidden_dims=[12, 6], batch_size=8,
+                                exploration_module=M.SquareCBExploration(gamma=20.0),
+                                state_features_only=False)
+        state = torch.randn(F, generator=gen)
+        sp = DiscreteActionSpace([torch.tensor([float(k)]) for k in range(A)])
+        captured.clear()
+        torch.manual_seed(77)
+        action = pl.act(subjective_state=state, available_action_space=sp)
+        scores = pl.get_scores(subjective_state=state, action_space_to_score=sp)
+        bandit = dict(F=F, A=A, model0=clone_sd(pl.model), state=state, seed=77, action=int(action),
+                      probs=captured[0].clone(), scores=scores.detach().clone())
+    finally:
+        M.Categorical = real
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save({"cases": cases, "bandit": bandit}, path)
+    print(f"{name}: wrote {path}; {len(cases)} single-context cases, actions "
+          f"{[c['action'] for c in cases]}, bandit action {bandit['action']}")
+
+
 BANDIT_CONFIGS = {
     "tiny": dict(F=7, hidden=[12, 6], B=16, steps=4),
     "cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3),
@@ -414,6 +468,9 @@ def main():
             if "gaussian" in name:
                 make_iql(name, cfg)
         return
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "squarecb":
+        make_squarecb()
+        return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "dsac":
         for name, cfg in DSAC_CONFIGS.items():
             make_dsac(name, cfg)
@@ -430,6 +487,7 @@ def main():
         make_iql(name, cfg)
     for name, cfg in BANDIT_CONFIGS.items():
         make_bandit(name, cfg)
+    make_squarecb()
     if os.environ.get("PEARL_GOLDEN_ONLY") == "bandit":
         return
     for name, cfg in PPO_CONFIGS.items():

@@ -27,6 +27,8 @@ CPU baseline of the reference's cost structure:
   DqnOracle.soft_update        neural_networks/common/utils.py:214-226
   DqnOracle.learn_batch        deep_td_learning.py:269-290, :333-360
   DqnOracle.learn              policy_learners/policy_learner.py:162-195
+  QNetOracle                   q_value_networks.py:124-249, :352-508 (other depths, multi-head,
+                               dueling) under deep_td_learning.py:269-360 / double_dqn.py:29-57
 
 Parity is PINNED: tests/test_oracle_golden.py checks every function here against fixtures minted by
 running the real reference (oracle/make_golden.py -> tests/golden/dqn_*.pt).
@@ -364,6 +366,123 @@ class DqnOracle:
             self.training_steps += 1
             raw = replay.sample(batch_size) if index_lists is None else replay.sample_at(index_lists[r])
             losses.append(self.learn_batch(preprocess(raw, n_actions)))
+        return losses
+
+
+# --------------------------------------------------------------------------------------
+# Q-network architectures beyond the two-hidden-layer VanillaQValueNetwork
+# --------------------------------------------------------------------------------------
+def _mlp_sd(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """mlp_block (common/utils.py:75-152) from state-dict tensors `prefix`{i}.0.weight/bias:
+    Linear + ReLU for every layer but the last."""
+    i = 0
+    while f"{prefix}{i + 1}.0.weight" in w:
+        x = torch.clamp_min(torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"],
+                                                       w[f"{prefix}{i}.0.bias"]), 0)
+        i += 1
+    return torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"], w[f"{prefix}{i}.0.bias"])
+
+
+class QNetOracle:
+    """DeepQLearning / DoubleDQN (deep_td_learning.py:269-360, deep_q_learning.py:130-167,
+    double_dqn.py:29-57) over
+      kind "vanilla"   VanillaQValueNetwork of any depth           q_value_networks.py:124-182
+      kind "multihead" VanillaQValueMultiHeadNetwork               q_value_networks.py:185-249
+      kind "dueling"   DuelingQValueNetwork                        q_value_networks.py:352-508
+    Forward passes restated from the state-dict tensors; gradients by autograd (these networks have
+    no hand-written backward here); AdamW(amsgrad) and the soft update as in DqnOracle."""
+
+    def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor], kind: str,
+                 double_q: bool = False, gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 0.01, tau: float = 0.75,
+                 target_update_freq: int = 10) -> None:
+        assert kind in ("vanilla", "multihead", "dueling")
+        self.kind, self.double_q = kind, bool(double_q)
+        self.keys = list(params.keys())
+        self.p = {k: params[k].detach().clone().to(F32) for k in self.keys}
+        self.t = {k: target[k].detach().clone().to(F32) for k in self.keys}
+        self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.vmax = {k: torch.zeros_like(v) for k, v in self.p.items()}
+        self.gamma, self.lr, self.betas, self.eps = gamma, lr, betas, eps
+        self.weight_decay, self.tau, self.freq = weight_decay, tau, target_update_freq
+        self.adam_step = 0
+        self.training_steps = 0
+
+    # ---- get_q_values(state (B, S), actions (B, Q, AD) | (B, AD), curr_available (B, M, AD) | None)
+    def q(self, w, state, action, curr_avail=None) -> torch.Tensor:
+        acts = action if action.ndim == 3 else action.unsqueeze(1)
+        B, Q = acts.shape[0], acts.shape[1]
+        if self.kind == "vanilla":
+            s = state.unsqueeze(1).expand(B, Q, state.shape[1])
+            out = _mlp_sd(w, "_model.", torch.cat([s, acts], dim=-1)).squeeze(-1)
+        elif self.kind == "multihead":
+            f = _mlp_sd(w, "_model.", state).unsqueeze(-1)                   # (B, A, 1)
+            out = torch.bmm(acts, f).squeeze(-1)
+        else:
+            feats = _mlp_sd(w, "state_arch._model.", state)
+            value = _mlp_sd(w, "value_arch._model.", feats)                   # (B, 1)
+
+            def adv(a):
+                f = feats.unsqueeze(1).expand(B, a.shape[1], feats.shape[1])
+                return _mlp_sd(w, "advantage_arch._model.", torch.cat([f, a], dim=-1)).squeeze(-1)
+
+            advantage = adv(acts)
+            mean = (advantage if curr_avail is None else adv(curr_avail)).mean(dim=-1, keepdim=True)
+            out = value + advantage - mean
+        return out if action.ndim == 3 else out.squeeze(-1)
+
+    def next_state_values(self, batch) -> torch.Tensor:
+        ns, nav, mask = (batch["next_state"], batch["next_available_actions"],
+                         batch["next_unavailable_actions_mask"])
+        B = ns.shape[0]
+        if self.double_q:
+            qs = self.q(self.p, ns, nav).clone()
+            qs[mask] = -float("inf")
+            choice = qs.max(1)[1]
+            return self.q(self.t, ns, nav[torch.arange(B), choice])
+        qv = self.q(self.t, ns, nav).clone()
+        qv[mask] = -float("inf")
+        return qv.max(1)[0]
+
+    def bellman_target(self, batch) -> torch.Tensor:
+        return self.next_state_values(batch) * self.gamma * (1 - batch["terminated"].float()) + batch["reward"]
+
+    def gradients(self, batch, target):
+        w = {k: v.detach().clone().requires_grad_(True) for k, v in self.p.items()}
+        q = self.q(w, batch["state"], batch["action"], batch.get("curr_available_actions"))
+        loss = torch.nn.functional.mse_loss(q, target)
+        grads = torch.autograd.grad(loss, [w[k] for k in self.keys])
+        return q.detach(), dict(zip(self.keys, grads))
+
+    def adamw(self, grads) -> None:
+        self.adam_step += 1
+        b1, b2 = self.betas
+        bc1, bc2 = 1 - b1 ** self.adam_step, 1 - b2 ** self.adam_step
+        for k in self.keys:
+            p, g = self.p[k], grads[k]
+            p.mul_(1 - self.lr * self.weight_decay)
+            self.m[k].lerp_(g, 1 - b1)
+            self.v[k].mul_(b2).addcmul_(g, g, value=1 - b2)
+            torch.maximum(self.vmax[k], self.v[k], out=self.vmax[k])
+            denom = (self.vmax[k].sqrt() / (bc2 ** 0.5)).add_(self.eps)
+            p.addcdiv_(self.m[k], denom, value=-(self.lr / bc1))
+
+    def learn_batch(self, batch) -> float:
+        if (self.training_steps + 1) % self.freq == 0:
+            for k in self.keys:
+                self.t[k].copy_(self.tau * self.p[k] + (1.0 - self.tau) * self.t[k])
+        with torch.no_grad():
+            target = self.bellman_target(batch)
+        q, g = self.gradients(batch, target)
+        self.adamw(g)
+        return float((q - target).abs().mean())
+
+    def learn(self, replay: ReplayOracle, rounds: int, batch_size: int, n_actions: int) -> List[float]:
+        losses = []
+        for _ in range(rounds):
+            self.training_steps += 1
+            losses.append(self.learn_batch(preprocess(replay.sample(batch_size), n_actions)))
         return losses
 
 

@@ -299,6 +299,18 @@ SIGNATURES = {
                                     C.c_int32, _P, _P, _P, _P]),
     "pa_awr_head": (C.c_int, [C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P,
                               C.c_int32, _P, _P]),
+    "pa_td_target": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_float,
+                               C.c_int32, C.c_int32, _P, _P, _P]),
+    "pa_td_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_float, _P, _P, _P]),
+    "pa_rows_dot": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "pa_rows_scale": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    "pa_rows_bmm": (C.c_int, [_P, C.c_int64, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "pa_dueling_q": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    "pa_dueling_grad": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "pa_dueling_feat_grad": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                       C.c_int32, _P]),
+    "pa_squarecb_probs": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                    C.c_float, C.c_float, _P, _P, _P]),
     "pa_gauss_awr_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32,
                                     _P, C.c_int32, _P, _P, _P]),
     "pa_tanh_action": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_float, C.c_int32,

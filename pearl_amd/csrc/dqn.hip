@@ -63,12 +63,22 @@ struct pa_dqn {
     float* reward;
     uint8_t* term;
   } bb[2];
-  float* bb_x;       // [wrows][IN] state || rep(action) of the current window
+  float* bb_x;       // 2 x [wrows][IN] state || rep(action) of a window (double-buffered like bb)
   int bb_A;          // A the batch buffers were sized for
   float* Uw[2];      // [wrows][H1] per buffer set
   float* yw[2];      // [wrows] Bellman targets, data-tagged (kYPending = not yet produced)
   hipStream_t side;  // target-network stream of learn()
   hipEvent_t ev_start, ev_tail, ev_chain[2];
+  hipEvent_t ev_gather[2];  // side stream: window inputs (incl. x) gathered into buffer set p
+  // Cross-stream hand-offs inside learn() go through a device word, not through events: a queue
+  // that is blocked on another queue's event wakes up 12-17 us after the event fires on this
+  // stack (measured: the target pass of every window started that long after the soft update it
+  // waits for), a one-wave kernel spinning on a word written by a one-wave kernel takes ~3 us.
+  int* sig;          // [4] generation word (monotonic, never reset)
+  int sig_gen;       // last generation handed out
+  int pending_signal;  // generation the NEXT row-pass launch publishes when it starts (0: none)
+  int use_flags;     // PEARL_AMD_FLAG_HOP (default 1); 0 = events as before
+  int lead_persist;  // PEARL_AMD_LEAD_PERSIST: leading target pieces keep off the chain's CUs
   int* err_dev;      // device error word (a bounded wait expired)
   int* err_host;     // pinned mirror, copied at the end of learn()
   int overlap;       // 0: single-stream learn loop (PEARL_AMD_OVERLAP=0 or timing level >= 2)
@@ -184,6 +194,38 @@ int launch_target_pp(const TargetArgs& a, int ncu, hipStream_t s) {
 }
 
 
+// ---- cross-stream hand-off through a device word (see pa_dqn::sig) -------------------------
+static __global__ void signal_kernel(int* flag, int value) {
+  if (threadIdx.x == 0)
+    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Bounded like consume_y: a producer that never runs must not hang the GPU (err word, pa_dqn_check).
+static __global__ void wait_flag_kernel(const int* flag, int value, int* err) {
+  if (threadIdx.x != 0) return;
+  int spins = 0;
+  while ((__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > (1 << 22)) {
+      __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+// Everything enqueued on `to` after this call runs after everything enqueued on `from` before it.
+int stream_hop(pa_dqn* h, hipStream_t from, hipStream_t to, hipEvent_t fallback) {
+  if (!h->use_flags) {
+    PA_HIP(hipEventRecord(fallback, from));
+    PA_HIP(hipStreamWaitEvent(to, fallback, 0));
+    return PA_OK;
+  }
+  const int gen = ++h->sig_gen;
+  hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, from, h->sig, gen);
+  PA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, to, h->sig, gen, h->err_dev);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 struct NetPtrs {
   const float *W1, *b1, *W2, *b2, *W3, *b3;
 };
@@ -249,7 +291,7 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* 
 // U (= W1s' s' + b1' of the same rows) must already be computed.
 int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
                        hipStream_t s, bool persistent = false, int* argmax = nullptr,
-                       bool sample_timer = true) {
+                       bool sample_timer = true, bool no_pingpong = false) {
   // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
   // maximum (Double DQN's action choice); always the classic grid
   const pa_dqn_desc& d = h->d;
@@ -277,7 +319,8 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
-  const bool pp = !argmax && (h->pingpong == 2 || (h->pingpong == 1 && persistent));
+  const bool pp = !argmax && !no_pingpong &&
+                  (h->pingpong == 2 || (h->pingpong == 1 && persistent));
   if (persistent || pp) {
     if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream
       PA_HIP(hipMemsetAsync(h->tile_ctr, 0, kTileCtrs * sizeof(int), s));
@@ -404,6 +447,11 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   a.y = y;
   a.y_tagged = y_tagged ? 1 : 0;
   a.err = h->err_dev;
+  if (h->pending_signal) {
+    a.signal_flag = h->sig;
+    a.signal_value = h->pending_signal;
+    h->pending_signal = 0;
+  }
   a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_row : nullptr;
   a.H1a = y ? h->H1a : nullptr; a.H2a = y ? h->H2a : nullptr;
   a.dZ2 = h->dZ2; a.dZ1 = h->dZ1;
@@ -610,7 +658,7 @@ int ensure_batchbufs(pa_dqn* h, int A) {
   free_batchbufs(h);
   const pa_dqn_desc& d = h->d;
   const int64_t B = h->wrows;
-  PA_HIP(hipMalloc((void**)&h->bb_x, (size_t)(B * h->IN * 4)));
+  PA_HIP(hipMalloc((void**)&h->bb_x, (size_t)(2 * B * h->IN * 4)));
   for (int p = 0; p < 2; ++p) {
     PA_HIP(hipMalloc((void**)&h->bb[p].next_state, (size_t)(B * d.state_dim * 4)));
     PA_HIP(hipMalloc((void**)&h->bb[p].next_avail_rep, (size_t)(B * A * d.action_dim * 4)));
@@ -706,6 +754,8 @@ int ensure_side(pa_dqn* h) {
   PA_HIP(hipEventCreateWithFlags(&h->ev_tail, hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_chain[0], hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_chain[1], hipEventDisableTiming));
+  PA_HIP(hipEventCreateWithFlags(&h->ev_gather[0], hipEventDisableTiming));
+  PA_HIP(hipEventCreateWithFlags(&h->ev_gather[1], hipEventDisableTiming));
   return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", 64), h->side);
 }
 
@@ -782,6 +832,12 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->bb_x = nullptr;
   h->side = nullptr;
   h->ev_start = h->ev_tail = h->ev_chain[0] = h->ev_chain[1] = nullptr;
+  h->ev_gather[0] = h->ev_gather[1] = nullptr;
+  h->sig = nullptr;
+  h->sig_gen = 0;
+  h->pending_signal = 0;
+  h->use_flags = env_int("PEARL_AMD_FLAG_HOP", 1);
+  h->lead_persist = env_int("PEARL_AMD_LEAD_PERSIST", 0);
   h->err_dev = nullptr;
   h->err_host = nullptr;
   h->overlap = env_int("PEARL_AMD_OVERLAP", 1);
@@ -821,11 +877,12 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->yw[1], h->wrows);
   PA_WS(h->nextv, h->wrows);
   // one allocation: [kTileCtrs] work-stealing counters | 4-int error word (one memset per call)
-  PA_WS(h->tile_ctr, kTileCtrs + 4);
+  PA_WS(h->tile_ctr, kTileCtrs + 8);
   h->err_dev = h->tile_ctr + kTileCtrs;
+  h->sig = h->tile_ctr + kTileCtrs + 4;     // outside the per-call memset
   {
     hipDeviceProp_t prop;
-    if (hipMemset(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int)) != hipSuccess ||
+    if (hipMemset(h->tile_ctr, 0, (kTileCtrs + 8) * sizeof(int)) != hipSuccess ||
         hipGetDeviceProperties(&prop, desc->device) != hipSuccess) {
       set_error("pa_dqn_create: device query failed");
       pa_dqn_destroy(h);
@@ -872,7 +929,8 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   if (h->err_host) (void)hipHostFree(h->err_host);
   free_batchbufs(h);
   if (h->side) (void)hipStreamDestroy(h->side);
-  hipEvent_t evs[] = {h->ev_start, h->ev_tail, h->ev_chain[0], h->ev_chain[1]};
+  hipEvent_t evs[] = {h->ev_start, h->ev_tail, h->ev_chain[0], h->ev_chain[1], h->ev_gather[0],
+                      h->ev_gather[1]};
   for (hipEvent_t e : evs)
     if (e) (void)hipEventDestroy(e);
   for (auto& t : h->timers)
@@ -1030,8 +1088,8 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       h->y_clean = true;
     }
     // fresh work-stealing counters for this call's persistent target launches
-    PA_HIP(hipEventRecord(h->ev_start, s));
-    PA_HIP(hipStreamWaitEvent(t, h->ev_start, 0));
+    rc = stream_hop(h, s, t, h->ev_start);
+    if (rc != PA_OK) return rc;
   } else {
     h->y_clean = false;
   }
@@ -1057,13 +1115,31 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       o.terminated = bb.term;
       o.rep_dim = d.action_dim;
       o.rep_onehot = args->rep_onehot;
-      if (!overlap) o.x = h->bb_x;
+      // one gather per window: the chain's x rides the same launch (it used to be a second
+      // gather on the main stream, at the head of every window's bubble)
+      // (not for the first window of a call: there the main stream gathers x itself, so that
+      // its first row pass needs no cross-stream wait and is resident before the target grid)
+      if (!overlap || k > 0) o.x = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
       ScopedTimer tm(h, "gather", t, 2, 1, rows);
       rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, t);
       if (rc != PA_OK) return rc;
+      if (overlap && k > 0) PA_HIP(hipEventRecord(h->ev_gather[p], t));
     }
     // the previous window's last optimizer launch (soft update of the target net) must be done
-    if (overlap && k > 0) PA_HIP(hipStreamWaitEvent(t, h->ev_chain[(k - 1) & 1], 0));
+    if (overlap && k > 0) {
+      if (h->use_flags) {
+        // The word is published by the FIRST row-pass launch of this window, on the main stream:
+        // it starts when the previous window's last optimizer launch (soft update) has completed,
+        // it is resident on the chain's CUs before the target grid below takes every free slot,
+        // and it costs no launch of its own.
+        const int gen = ++h->sig_gen;
+        h->pending_signal = gen;
+        hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev);
+        PA_LAUNCH_CHECK();
+      } else {
+        PA_HIP(hipStreamWaitEvent(t, h->ev_chain[(k - 1) & 1], 0));
+      }
+    }
     // U and the Bellman targets; the first round of the window as its own pair of launches, so
     // the chain can start after one round's worth of target work instead of the whole window's
     // (the first piece runs as a classic grid on every CU — the chain is idle then anyway — the
@@ -1104,23 +1180,40 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         j0 += nj;
         continue;
       }
-      {
-        ScopedTimer tm(h, "target_l1", t, 2, 1, prow);
-        GemmArgs g = target_l1_problem(h, b.next_state, prow, Up);
+      // U = s' W1s'^T + b1': ONE launch for all leading (classic-grid) pieces together — a launch
+      // per piece put a 7-20 us GEMM between every two target launches on this stream — and one
+      // for the persistent remainder
+      if (pc == 0 || pc == npieces - 1) {
+        int cover = nj;
+        if (pc == 0 && npieces > 1) {
+          cover = 0;
+          for (int q = 0; q < npieces - 1; ++q) cover += sched[q];
+        }
+        ScopedTimer tm(h, "target_l1", t, 2, 1, cover * B);
+        GemmArgs g = target_l1_problem(h, b.next_state, cover * B, Up);
         rc = launch_linear<false>(&g, 1, t);
         if (rc != PA_OK) return rc;
       }
-      rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t,
-                              persist && pc == npieces - 1, nullptr,
-                              (k % 4) == 0 && pc == npieces - 1);
+      // Leading pieces: a classic grid takes every CU, the chain's too — the row pass that is
+      // already resident keeps its CUs, but the weight-gradient launch behind it then queues for
+      // slots (measured: 31-52 us instead of 17).  lead_persist runs them as work-stealing tiles of
+      // the two-workgroups-per-CU kernel that stay off the reserved CUs, like the remainder.
+      const bool last = pc == npieces - 1;
+      const bool lead_p = !last && h->lead_persist && persist;
+      rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
+                              nullptr, (k % 4) == 0 && last, lead_p);
       if (rc != PA_OK) return rc;
       j0 += nj;
     }
-    // ---- main stream: x of the window, then the per-round chains
-    if (overlap) {
+    // ---- main stream: the per-round chains.  x of the window was gathered by the side stream
+    // (long ago for every window but the first): the event is normally already complete
+    float* xwin = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
+    if (overlap && k > 0) {
+      PA_HIP(hipStreamWaitEvent(s, h->ev_gather[p], 0));
+    } else if (overlap) {
       pa_batch_out o;
       memset(&o, 0, sizeof(o));
-      o.x = h->bb_x;
+      o.x = xwin;
       o.rep_dim = d.action_dim;
       o.rep_onehot = args->rep_onehot;
       ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
@@ -1131,11 +1224,15 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // to tell the target kernel's own speed on its share of the chip from co-run interference
     static const bool no_chain = env_int("PEARL_AMD_DEBUG_NO_CHAIN", 0) != 0;
     if (no_chain) h->y_clean = false;
+    if (no_chain && h->pending_signal) {
+      hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, h->sig, h->pending_signal);
+      h->pending_signal = 0;
+    }
     for (int j = 0; j < w && !no_chain; ++j) {
       const int round = r + j;
       h->cur_round = round;
       const int soft_next = (round + 1 < R) ? due(round + 1) : 0;
-      const float* xj = h->bb_x + (int64_t)j * B * h->IN;
+      const float* xj = xwin + (int64_t)j * B * h->IN;
       const float* yj = h->yw[p] + (int64_t)j * B;
       float* lo = args->losses_out ? args->losses_out + round : nullptr;
       if (!dp) {
@@ -1155,7 +1252,11 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       rc = run_adamw(h, args->adam_step0 + round + 1, soft_next, s);
       if (rc != PA_OK) return rc;
     }
-    if (overlap) PA_HIP(hipEventRecord(h->ev_chain[p], s));
+    if (overlap) {
+      // the next window's target pass needs this window's last optimizer launch (soft update):
+      // with flags the next window's first row pass says so (above)
+      if (!h->use_flags) PA_HIP(hipEventRecord(h->ev_chain[p], s));
+    }
     r += w;
     ++k;
   }

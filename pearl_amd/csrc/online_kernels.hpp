@@ -145,6 +145,9 @@ struct RowArgs {
   const float* y;                       // [B] Bellman targets; null = forward only (probe)
   int y_tagged;                         // y is produced concurrently by another stream (consume_y)
   int* err;                             // device error word for the bounded wait
+  int* signal_flag; int signal_value;   // optional: published by workgroup 0 as soon as it starts
+                                        // ("everything before this launch on its stream is done":
+                                        // the window hand-off of learn(), see pa_dqn::sig)
   long long* prof;                      // optional phase stamps (tools/prof_chain.py)
   float* H1a; float* H2a;               // [B][H1], [B][H2] relu outputs (weight-gradient operands)
   float* dZ2; float* dZ1;               // [B][H2], [B][H1] pre-activation gradients
@@ -331,6 +334,8 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, qd = lane >> 4;
+  if (a.signal_flag && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(a.signal_flag, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
   const int m0 = blockIdx.x * RP_ROWS;

@@ -69,3 +69,91 @@ class VanillaQValueNetwork(QValueNetwork):
 
     def linear_layers(self) -> List[nn.Linear]:
         return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+
+
+class VanillaQValueMultiHeadNetwork(QValueNetwork):
+    """One output per action: f(s) in R^A, Q(s, a) = onehot(a) . f(s)
+    (q_value_networks.py:185-249).  No (B, A, S + AD) expansion: the learner evaluates the trunk
+    once per state (generic_q.MultiHeadOps)."""
+
+    def __init__(self, state_dim: int, action_dim: int, hidden_dims: List[int], output_dim: int,
+                 use_layer_norm: bool = False) -> None:
+        super().__init__()
+        self._state_dim, self._action_dim, self._output_dim = int(state_dim), int(action_dim), int(output_dim)
+        self._model: nn.Module = mlp_block(input_dim=state_dim, hidden_dims=hidden_dims,
+                                           output_dim=output_dim, use_layer_norm=use_layer_norm)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self._model(x)
+
+    def get_q_values(self, state_batch: Tensor, action_batch: Tensor,
+                     curr_available_actions_batch: Optional[Tensor] = None) -> Tensor:
+        assert self._output_dim == action_batch.shape[-1]
+        assert state_batch.ndim == 2 and action_batch.ndim in (2, 3)
+        acts = action_batch if action_batch.ndim == 3 else action_batch.unsqueeze(1)
+        q = torch.bmm(acts, self.forward(state_batch).unsqueeze(-1)).squeeze(-1)
+        return q if action_batch.ndim == 3 else q.squeeze(-1)
+
+    @property
+    def state_dim(self) -> int:
+        return self._state_dim
+
+    @property
+    def action_dim(self) -> int:
+        return self._action_dim
+
+    def linear_layers(self) -> List[nn.Linear]:
+        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+
+
+class DuelingQValueNetwork(QValueNetwork):
+    """state -> state_arch -> features; value_arch(features) = V(s);
+    advantage_arch([features | action]) = A(s, a); Q = V + A - mean(A)
+    (q_value_networks.py:352-508; same sub-module names, hence the same ``state_dict`` keys)."""
+
+    def __init__(self, state_dim: int, action_dim: int, hidden_dims: List[int], output_dim: int,
+                 value_hidden_dims: Optional[List[int]] = None,
+                 advantage_hidden_dims: Optional[List[int]] = None,
+                 state_hidden_dims: Optional[List[int]] = None) -> None:
+        super().__init__()
+        from ..common.value_networks import VanillaValueNetwork
+        self._state_dim, self._action_dim = int(state_dim), int(action_dim)
+        self.state_arch = VanillaValueNetwork(
+            input_dim=state_dim,
+            hidden_dims=hidden_dims if state_hidden_dims is None else state_hidden_dims,
+            output_dim=hidden_dims[-1])
+        self.value_arch = VanillaValueNetwork(
+            input_dim=hidden_dims[-1],
+            hidden_dims=hidden_dims if value_hidden_dims is None else value_hidden_dims,
+            output_dim=output_dim)
+        self.advantage_arch = VanillaValueNetwork(
+            input_dim=hidden_dims[-1] + action_dim,
+            hidden_dims=hidden_dims if advantage_hidden_dims is None else advantage_hidden_dims,
+            output_dim=output_dim)
+
+    @property
+    def state_dim(self) -> int:
+        return self._state_dim
+
+    @property
+    def action_dim(self) -> int:
+        return self._action_dim
+
+    def get_q_values(self, state_batch: Tensor, action_batch: Tensor,
+                     curr_available_actions_batch: Optional[Tensor] = None) -> Tensor:
+        assert state_batch.ndim == 2 and action_batch.ndim in (2, 3)
+        acts = action_batch if action_batch.ndim == 3 else action_batch.unsqueeze(1)
+        feats = self.state_arch(state_batch)
+        value = self.value_arch(feats)                                    # (B, 1)
+
+        def adv(actions: Tensor) -> Tensor:
+            f = feats.unsqueeze(1).expand(-1, actions.shape[1], -1)
+            return self.advantage_arch(torch.cat([f, actions], dim=-1)).squeeze(-1)
+
+        advantage = adv(acts)
+        if curr_available_actions_batch is None:
+            mean = advantage.mean(dim=-1, keepdim=True)
+        else:
+            mean = adv(curr_available_actions_batch).mean(dim=-1, keepdim=True)
+        q = value + advantage - mean
+        return q if action_batch.ndim == 3 else q.squeeze(-1)

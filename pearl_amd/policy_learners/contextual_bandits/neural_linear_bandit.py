@@ -34,10 +34,18 @@ from ..sequential_decision_making.flat_mlp import FlatMlp, layers_of
 
 class SquareCBExploration(ExplorationModule):
     """p_a = 1 / (K + gamma * gap_a) for a != argmax, the arg-max takes the remainder
-    (squarecb_exploration.py:59-115, including its whole-matrix ``complementary_sum``)."""
+    (squarecb_exploration.py:59-115).  Rows are normalised one by one: identical to the reference
+    for one context per call — the only case its whole-matrix ``complementary_sum`` (:90) and its
+    (B,) - (B, A) broadcast (:84) yield a distribution for — and well-defined for batches.
+
+    The probability table is ``pa_squarecb_probs`` (one launch for the whole batch of contexts)
+    when the values live on a HIP device; the draw itself is the reference's — one
+    ``Categorical(row).sample()`` per row on torch's global CPU generator — so a seeded run picks
+    the reference's actions.  Values on the CPU (unit tests of host logic) take the same rule
+    through torch."""
 
     def __init__(self, gamma: float, reward_lb: float = 0.0, reward_ub: float = 1.0,
-                 clamp_values: bool = False) -> None:
+                 clamp_values: bool = False, randomized_tiebreaking: bool = False) -> None:
         super().__init__()
         self._gamma, self.reward_lb, self.reward_ub = gamma, reward_lb, reward_ub
         self.clamp_values = clamp_values
@@ -48,20 +56,40 @@ class SquareCBExploration(ExplorationModule):
     def get_unnormalize_prob(self, empirical_gaps: Tensor, max_val: Any, action_num: int) -> Tensor:
         return torch.div(1.0, action_num + self._gamma * empirical_gaps)
 
+    def probabilities(self, values: Tensor, n_actions: int) -> Tensor:
+        """(B, n_actions) table the actions are drawn from (:71-92)."""
+        values = values.reshape(-1, n_actions)
+        B = values.shape[0]
+        if values.is_cuda:
+            v = values.to(torch.float32).contiguous()
+            prob = torch.empty(B, n_actions, dtype=torch.float32, device=v.device)
+            arg = torch.empty(B, dtype=torch.int32, device=v.device)
+            N.check(N.lib().pa_squarecb_probs(v.data_ptr(), v.stride(0), B, n_actions,
+                                              float(self._gamma), int(self.clamp_values),
+                                              float(self.reward_lb), float(self.reward_ub),
+                                              prob.data_ptr(), arg.data_ptr(), N.stream_ptr(v.device)))
+            return prob
+        values = self.clamp(values)
+        max_val, max_indices = torch.max(values, dim=1)
+        prob = self.get_unnormalize_prob(max_val.unsqueeze(1) - values, max_val, n_actions)
+        for i in range(B):
+            prob[i, max_indices[i]] = 0.0
+            prob[i, max_indices[i]] = 1.0 - torch.sum(prob[i])
+        return prob
+
     def act(self, subjective_state: Any, action_space: Any, values: Optional[Tensor] = None,
             representation: Any = None, exploit_action: Any = None,
             action_availability_mask: Any = None, **kwargs: Any) -> Tensor:
         assert values is not None
-        values = self.clamp(values.view(-1, action_space.n))
-        max_val, max_indices = torch.max(values, dim=1)
-        empirical_gaps = max_val - values
-        selected = torch.zeros((values.size(0),), dtype=torch.int)
-        prob = self.get_unnormalize_prob(empirical_gaps, max_val, action_space.n)
-        for i in range(values.size(0)):
-            prob[i, max_indices[i]] = 0.0
-            prob[i, max_indices[i]] = 1.0 - torch.sum(prob)
+        prob = self.probabilities(values, action_space.n).cpu()
+        selected = torch.zeros((prob.size(0),), dtype=torch.int)
+        for i in range(prob.size(0)):
             selected[i] = Categorical(prob[i, :]).sample()
         return selected.squeeze(-1)
+
+    def get_scores(self, subjective_state: Any, action_space: Any, values: Tensor,
+                   exploit_action: Any = None, representation: Any = None) -> Tensor:
+        return values.view(-1, action_space.n)           # (:117-126)
 
 
 class NeuralLinearBandit(PolicyLearner):
@@ -202,10 +230,30 @@ class NeuralLinearBandit(PolicyLearner):
         acts = self.action_representation_module(space.actions_batch.to(state)).unsqueeze(0).repeat(B, 1, 1)
         return torch.cat([exp, acts], dim=2)
 
+    @torch.no_grad()
     def get_scores(self, subjective_state: Tensor, action_space_to_score: Any,
                    exploit: bool = False) -> Tensor:
-        raise NotImplementedError("pearl_amd NeuralLinearBandit.get_scores: use the reference's "
-                                  "score-based exploration modules at act time")
+        """Scores of every arm (neural_linear_bandit.py:260-311): features -> model ->
+        exploration_module.get_scores(values) -> output activation (pre-activation values unless
+        ``separate_uncertainty``).  Act-time torch, like ``act``."""
+        assert not exploit, "exploit=True is not yet implemented for NeuralLinearBandit.get_scores"
+        assert hasattr(self.exploration_module, "get_scores"), \
+            "get_scores needs a score-based exploration module"
+        feature = self._concat_actions(subjective_state, action_space_to_score)
+        batch_size = feature.shape[0]
+        ret = self.model.forward_with_intermediate_values(feature.reshape(-1, feature.shape[-1]))
+        if self.separate_uncertainty is False:
+            scores = self.exploration_module.get_scores(
+                subjective_state=ret["nn_output"], values=ret["pred_label_pre_activation"],
+                action_space=action_space_to_score,
+                representation=self.model._linear_regression_layer)
+            scores = self.model.output_activation(scores)
+        else:
+            scores = self.exploration_module.get_scores(
+                subjective_state=ret["nn_output"], values=ret["pred_label"],
+                action_space=action_space_to_score,
+                representation=self.model._linear_regression_layer)
+        return scores.reshape(batch_size, -1).squeeze(-1)
 
     def compare(self, other: PolicyLearner) -> str:
         diffs = [super().compare(other)]

@@ -40,13 +40,14 @@ from torch import optim
 from ... import _native as N
 from ...action_representation_modules import (ActionRepresentationModule,
                                               OneHotActionTensorRepresentationModule)
-from ...neural_networks.sequential_decision_making.q_value_networks import (QValueNetwork,
-                                                                           VanillaQValueNetwork)
+from ...neural_networks.sequential_decision_making.q_value_networks import (
+    DuelingQValueNetwork, QValueNetwork, VanillaQValueMultiHeadNetwork, VanillaQValueNetwork)
 from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
 from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import EGreedyExploration, ExplorationModule
 from ..policy_learner import PolicyLearner
+from .generic_q import GenericTd, make_ops, plain_relu_mlp
 
 _FLAT_NAMES = ("q", "q_target", "grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")
 
@@ -134,29 +135,50 @@ class DeepQLearning(PolicyLearner):
         self._soft_update_tau = soft_update_tau
         self._is_conservative = is_conservative
         self._conservative_alpha = conservative_alpha
+        rep = self.action_representation_module
         if network_instance is not None:
-            if not isinstance(network_instance, VanillaQValueNetwork):
-                raise NotImplementedError("only VanillaQValueNetwork instances are supported")
-            self._Q: VanillaQValueNetwork = network_instance
-        else:
-            if network_type is not VanillaQValueNetwork:
+            if not isinstance(network_instance, (VanillaQValueNetwork, VanillaQValueMultiHeadNetwork,
+                                                 DuelingQValueNetwork)):
                 raise NotImplementedError(
-                    f"pearl_amd DeepQLearning: network_type {network_type.__name__} is not built; "
-                    "only VanillaQValueNetwork has HIP kernels")
+                    f"pearl_amd DeepQLearning: no HIP path for {type(network_instance).__name__} "
+                    "(VanillaQValueNetwork, VanillaQValueMultiHeadNetwork, DuelingQValueNetwork are built)")
+            self._Q: QValueNetwork = network_instance
+        else:
+            # deep_td_learning.py:133-173 make_specified_network
             assert state_dim is not None and hidden_dims is not None
-            self._Q = VanillaQValueNetwork(
-                state_dim=state_dim,
-                action_dim=self.action_representation_module.representation_dim,
-                hidden_dims=list(hidden_dims), output_dim=1)
-        if len(self._Q.linear_layers()) != 3:
-            raise NotImplementedError(
-                "pearl_amd DeepQLearning: exactly two hidden layers are built "
-                f"(got {len(self._Q.linear_layers()) - 1})")
+            if network_type is VanillaQValueMultiHeadNetwork:
+                self._Q = VanillaQValueMultiHeadNetwork(
+                    state_dim=state_dim, action_dim=rep.representation_dim,
+                    hidden_dims=list(hidden_dims), output_dim=rep.max_number_actions)
+            elif network_type in (VanillaQValueNetwork, DuelingQValueNetwork):
+                self._Q = network_type(state_dim=state_dim, action_dim=rep.representation_dim,
+                                       hidden_dims=list(hidden_dims), output_dim=1)
+            else:
+                raise NotImplementedError(
+                    f"pearl_amd DeepQLearning: network_type {network_type.__name__} is not built "
+                    "(VanillaQValueNetwork, VanillaQValueMultiHeadNetwork, DuelingQValueNetwork are)")
+        # Which engine trains it.  Fused MI355X path (pa_dqn_*): VanillaQValueNetwork, two ReLU hidden
+        # layers of at most 256 units.  Everything else the reference's mlp_block can express with
+        # Linear + ReLU goes through the generic pa_mlp engine (generic_q.py); other activations /
+        # norms / dropout are refused here, loudly — never trained as if they were ReLU.
+        self._fused = False
+        if isinstance(self._Q, VanillaQValueNetwork):
+            if not plain_relu_mlp(self._Q._model):
+                raise NotImplementedError(
+                    "pearl_amd DeepQLearning: the Q network is not a plain Linear + ReLU mlp_block "
+                    "(other activations, normalisation, dropout or residual blocks have no HIP kernels)")
+            lin = self._Q.linear_layers()
+            self._fused = (len(lin) == 3 and lin[0].out_features <= 256 and lin[1].out_features <= 256
+                           and lin[2].out_features == 1)
+        if is_conservative and not self._fused:
+            raise NotImplementedError("pearl_amd DeepQLearning: the CQL term is built for the fused "
+                                      "VanillaQValueNetwork path only")
         self._Q_target: VanillaQValueNetwork = copy.deepcopy(self._Q)
         self._optimizer: optim.Optimizer = optim.AdamW(self._Q.parameters(), lr=learning_rate,
                                                        amsgrad=True)
         self._max_batch_size = max_batch_size
         self._native = _NativeDqn()
+        self._generic_td: Optional[GenericTd] = None
         self.data_parallel = True
 
     # ------------------------------------------------------------------ plumbing
@@ -173,28 +195,41 @@ class DeepQLearning(PolicyLearner):
     def reset(self, action_space: Any) -> None:
         self._action_space = action_space
 
+    def _linears(self) -> Tuple[List[torch.nn.Linear], List[torch.nn.Linear]]:
+        """Linear layers of the online and the target network.  Walking the module tree costs
+        ~10 us per call and learn() asks several times per call: cached per module pair."""
+        key = (id(self._Q), id(self._Q_target))
+        hit = self.__dict__.get("_linears_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, self._Q.linear_layers(), self._Q_target.linear_layers())
+            self.__dict__["_linears_cache"] = hit
+        return hit[1], hit[2]
+
     def _dims(self) -> Tuple[int, int, int, int]:
-        l1, l2, _ = self._Q.linear_layers()
+        l1, l2, _ = self._linears()[0]
         return self._Q.state_dim, self._Q.action_dim, l1.out_features, l2.out_features
 
     def _param_pairs(self) -> List[Tuple[torch.nn.Parameter, torch.nn.Parameter]]:
         out = []
-        for lq, lt in zip(self._Q.linear_layers(), self._Q_target.linear_layers()):
+        for lq, lt in zip(*self._linears()):
             out.append((lq.weight, lt.weight))
             out.append((lq.bias, lt.bias))
         return out
 
     def _adam_steps(self) -> int:
-        for p in self._Q.parameters():
-            st = self._optimizer.state.get(p)
+        for pq, _ in self._param_pairs():
+            st = self._optimizer.state.get(pq)
             if st and "step" in st:
                 return int(float(st["step"]))
         return 0
 
     def _set_adam_steps(self, n: int) -> None:
-        for p in self._Q.parameters():
-            st = self._optimizer.state.get(p)
-            if st is not None and "step" in st:
+        # after _ensure_bound every parameter's "step" is the SAME 0-d tensor: one fill_
+        seen = set()
+        for pq, _ in self._param_pairs():
+            st = self._optimizer.state.get(pq)
+            if st is not None and "step" in st and id(st["step"]) not in seen:
+                seen.add(id(st["step"]))
                 st["step"].fill_(float(n))
 
     def _signature(self) -> Tuple:
@@ -210,7 +245,7 @@ class DeepQLearning(PolicyLearner):
         """(Re)build the flat parameter/optimizer buffers and the pa_dqn handle when needed."""
         nat = self._native
         S, AD, H1, H2 = self._dims()
-        p0 = next(self._Q.parameters())
+        p0 = self._linears()[0][0].weight
         if not p0.is_cuda:
             N.require_gpu()
             raise N.NativeError(
@@ -249,6 +284,7 @@ class DeepQLearning(PolicyLearner):
         N.check(N.lib().pa_dqn_param_offsets(S, AD, H1, H2, offs))
         flat = {k: torch.zeros(P, dtype=torch.float32, device=dev) for k in _FLAT_NAMES}
         steps = self._adam_steps()
+        step_t = torch.tensor(float(steps), dtype=torch.float32)   # shared by all six parameters
         with torch.no_grad():
             for (pq, pt), off in zip(self._param_pairs(), list(offs)):
                 n = pq.numel()
@@ -263,7 +299,7 @@ class DeepQLearning(PolicyLearner):
                 pt.data = flat["q_target"][sl].view(pt.shape)
                 pq.grad = flat["grad"][sl].view(pq.shape)
                 self._optimizer.state[pq] = {
-                    "step": torch.tensor(float(steps), dtype=torch.float32),
+                    "step": step_t,
                     "exp_avg": flat["exp_avg"][sl].view(pq.shape),
                     "exp_avg_sq": flat["exp_avg_sq"][sl].view(pq.shape),
                     "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(pq.shape),
@@ -328,6 +364,70 @@ class DeepQLearning(PolicyLearner):
                         next_action_rep=N.ptr(next_action))
         return nb, [state, action, next_state, reward, term, nav, mask, next_action]
 
+    # ------------------------------------------------------------------ generic engine (generic_q.py)
+    def _generic(self) -> GenericTd:
+        g = self._generic_td
+        if g is None or g.ops_key != (id(self._Q), id(self._Q_target), id(self._optimizer)):
+            mb = max(int(self._max_batch_size or 0), int(self._batch_size), 1)
+            g = GenericTd(make_ops(self._Q, self._Q_target, self._optimizer, mb), int(self._double_q),
+                          self._discount_factor, self._soft_update_tau)
+            g.ops_key = (id(self._Q), id(self._Q_target), id(self._optimizer))
+            self._generic_td = g
+        return g
+
+    def __deepcopy__(self, memo: dict) -> "DeepQLearning":
+        # the native handles are per-object: a copy rebuilds its own lazily
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_generic_td", "_linears_cache"):
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    def _generic_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
+        dev = next(self._Q.parameters()).device
+        if dev.type != "cuda":
+            N.require_gpu()
+            raise N.NativeError("pearl_amd DeepQLearning: parameters are on the CPU; move the learner "
+                                "to a HIP device first — there is no CPU learner path")
+
+        def f32(t: torch.Tensor) -> torch.Tensor:
+            return t.to(device=dev, dtype=torch.float32).contiguous()
+
+        state = f32(batch.state)
+        B = state.shape[0]
+        b: Dict[str, Any] = dict(state=state, action=f32(batch.action).reshape(B, -1),
+                                 reward=f32(batch.reward).reshape(B),
+                                 terminated=batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous())
+        assert batch.next_state is not None, "Q-learning needs next_state"
+        b["next_state"] = f32(batch.next_state)
+        ca = batch.curr_available_actions
+        b["curr_avail"] = None if ca is None else f32(ca)
+        nav, mask = batch.next_available_actions, batch.next_unavailable_actions_mask
+        if nav is None:
+            nav = self._default_next_actions(dev)            # (A, AD), shared by every row
+        else:
+            nav = f32(nav)
+        b["next_avail"] = nav
+        b["next_mask"] = (None if mask is None
+                          else mask.to(dev).reshape(B, -1).to(torch.uint8).contiguous())
+        b["next_action"] = None
+        if int(self._double_q) == 2:
+            assert batch.next_action is not None, "SARSA needs to have next action"
+            b["next_action"] = f32(batch.next_action).reshape(B, -1)
+        return b
+
+    def _learn_batch_generic(self, batch: TransitionBatch) -> Dict[str, Any]:
+        g = self._generic()
+        b = self._generic_batch(batch)
+        g.ops.ensure(b["state"].shape[0])
+        losses = torch.empty(2, dtype=torch.float32, device=b["state"].device)
+        g.step(b, self._target_update_due(), losses)
+        return {"loss": losses[0].item()}     # the reference's per-step .item() (:359)
+
     # ------------------------------------------------------------------ API
     def _target_update_due(self) -> bool:
         return (self._training_steps + 1) % self._target_update_freq == 0
@@ -335,6 +435,12 @@ class DeepQLearning(PolicyLearner):
     def forward(self, batch: TransitionBatch) -> torch.Tensor:
         """Q(s, a) of the online network, after the conditional soft target update
         (deep_td_learning.py:269-290)."""
+        if not self._fused:
+            g, b = self._generic(), self._generic_batch(batch)
+            g.ops.ensure(b["state"].shape[0])
+            if self._target_update_due():
+                g.ops.soft_update(self._soft_update_tau)
+            return g.q_values(b)
         nb, keep = self._native_batch(batch)
         nat = self._ensure_bound(nb.B, nb.A)
         stream = N.stream_ptr(keep[0].device)
@@ -348,6 +454,10 @@ class DeepQLearning(PolicyLearner):
     def get_next_state_values(self, batch: TransitionBatch, batch_size: int) -> torch.Tensor:
         """max over available next actions of Q_target(s', a') (deep_q_learning.py:130-167); for
         DoubleDQN, Q_target(s', argmax_a' Q(s', a')) (double_dqn.py:29-57)."""
+        if not self._fused:
+            g, b = self._generic(), self._generic_batch(batch)
+            g.ops.ensure(b["state"].shape[0])
+            return g.targets(b, want_next_v=True)[0]
         nb, keep = self._native_batch(batch)
         nat = self._ensure_bound(nb.B, nb.A)
         v = torch.empty(nb.B, dtype=torch.float32, device=keep[0].device)
@@ -357,6 +467,11 @@ class DeepQLearning(PolicyLearner):
 
     def q_values_and_targets(self, batch: TransitionBatch) -> Dict[str, torch.Tensor]:
         """Parity probe: Q(s,a), max_a' Q_target(s',a') and the Bellman target of a batch."""
+        if not self._fused:
+            g, b = self._generic(), self._generic_batch(batch)
+            g.ops.ensure(b["state"].shape[0])
+            nv, y = g.targets(b, want_next_v=True)
+            return {"q": g.q_values(b), "next_v": nv, "target": y}
         nb, keep = self._native_batch(batch)
         nat = self._ensure_bound(nb.B, nb.A)
         dev = keep[0].device
@@ -449,6 +564,8 @@ class DeepQLearning(PolicyLearner):
 
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         """One TD(0) update on a preprocessed batch (deep_td_learning.py:333-360)."""
+        if not self._fused:
+            return self._learn_batch_generic(batch)
         if self._is_conservative:
             return self._learn_batch_conservative(batch)
         nb, keep = self._native_batch(batch)
@@ -468,6 +585,8 @@ class DeepQLearning(PolicyLearner):
     def _arena_path_ok(self, replay_buffer: ReplayBuffer) -> bool:
         if not isinstance(replay_buffer, TensorBasedReplayBuffer) or replay_buffer.arena is None:
             return False
+        if not self._fused:
+            return False    # generic engine: sample -> preprocess -> learn_batch per round
         if int(self._double_q) == 2:
             return False    # SARSA batches carry the committed next action: generic loop
         if self._is_conservative:

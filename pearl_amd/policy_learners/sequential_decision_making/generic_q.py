@@ -1,0 +1,298 @@
+"""Generic TD(0) step for Q-network architectures the fused ``pa_dqn_*`` kernels do not cover.
+
+``DeepQLearning`` / ``DoubleDQN`` / ``DeepSARSA`` route here when ``_Q`` is not "VanillaQValueNetwork
+with two ReLU hidden layers of at most 256 units" (the shape of the fused MI355X path):
+
+* ``VanillaQValueNetwork`` of any depth / width (common/utils.py:75-152 ``mlp_block``),
+* ``VanillaQValueMultiHeadNetwork`` (q_value_networks.py:185-249): the trunk runs ONCE per state
+  and Q(s, a) is a row-dot with the one-hot action — no ``(B, A, S + AD)`` expansion at all,
+* ``DuelingQValueNetwork`` (q_value_networks.py:352-508): state tower -> value tower + advantage
+  tower, ``Q = V + A - mean(A)``.
+
+Same arithmetic as ``DeepTDLearning.learn_batch`` (deep_td_learning.py:269-360): conditional soft
+target update, Q(s, a), next-state values of the subclass (max / double / SARSA), Bellman target,
+``MSELoss`` backward, one ``AdamW(amsgrad)`` step, report ``mean |Q - target|``.  Every arithmetic
+step is a libpearl_amd call on flat parameter views (``FlatMlp`` = the ``pa_mlp_*`` engine with fp32
+MFMA GEMMs, ``qheads.hip`` for the row-local heads); there is no torch fallback.
+
+The engine keeps ONE forward's activations per network, so all no-grad passes (targets) run before
+the kept online forward.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import Tensor, nn
+
+from ... import _native as N
+from ...neural_networks.sequential_decision_making.q_value_networks import (
+    DuelingQValueNetwork, VanillaQValueMultiHeadNetwork, VanillaQValueNetwork)
+from .flat_mlp import FlatMlp, layers_of
+
+
+def plain_relu_mlp(model: nn.Module) -> bool:
+    """True iff `model` is mlp_block's plain form: [Sequential(Linear, ReLU)] * k + [Sequential(Linear)]
+    — what the pa_mlp engine computes.  Anything else (other activations, norms, dropout, residual
+    blocks) must be refused loudly, not trained as if it were ReLU."""
+    if not isinstance(model, nn.Sequential) or len(model) == 0:
+        return False
+    blocks = list(model)
+    for blk in blocks[:-1]:
+        if not (isinstance(blk, nn.Sequential) and len(blk) == 2 and isinstance(blk[0], nn.Linear)
+                and type(blk[1]) is nn.ReLU):
+            return False
+    last = blocks[-1]
+    return isinstance(last, nn.Sequential) and len(last) == 1 and isinstance(last[0], nn.Linear)
+
+
+def _f32(t: Tensor, dev: torch.device) -> Tensor:
+    return t.to(device=dev, dtype=torch.float32).contiguous()
+
+
+def _new(dev: torch.device, *shape: int) -> Tensor:
+    return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+
+class _Ops:
+    """What an architecture provides to the TD step."""
+    nets: List[FlatMlp]
+
+    def ensure(self, batch_hint: int) -> None:
+        for m in self.nets:
+            m.ensure(batch_hint)
+
+    @property
+    def device(self) -> torch.device:
+        return self.nets[0].device
+
+    def adam(self) -> None:
+        for m in self.nets:
+            m.adam(reduce="mean")
+
+    def soft_update(self, tau: float) -> None:
+        for m in self.nets:
+            m.soft_update(tau)
+
+    # q_taken(state, action_rep, curr_avail_rep) -> (B,), keeps activations; backward(dq)
+    # q_all(state, rep[B, A, AD] | [A, AD], use_target) -> (B, A);  q_one(state, action_rep, use_target) -> (B,)
+
+
+def _expand(state: Tensor, rep: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """x[b * A + i] = state[b] || rep[b, i]  (extend_state_feature.py:12-47 + cat)."""
+    B, S = state.shape
+    A, AD = int(rep.shape[-2]), int(rep.shape[-1])
+    x = _new(state.device, B * A, S + AD) if out is None else out
+    N.check(N.lib().pa_expand_state_actions(state.data_ptr(), state.stride(0), rep.data_ptr(),
+                                            A * AD if rep.ndim == 3 else 0, B, A, S, AD,
+                                            x.data_ptr(), N.stream_ptr(state.device)))
+    return x
+
+
+def _concat(left: Tensor, right: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    B = left.shape[0]
+    x = _new(left.device, B, left.shape[1] + right.shape[1]) if out is None else out
+    N.check(N.lib().pa_concat_cols(left.data_ptr(), left.stride(0), right.data_ptr(),
+                                   right.stride(0), x.data_ptr(), B, left.shape[1], right.shape[1],
+                                   N.stream_ptr(left.device)))
+    return x
+
+
+class VanillaOps(_Ops):
+    def __init__(self, q: VanillaQValueNetwork, q_target: VanillaQValueNetwork, optimizer: Any,
+                 max_batch: int) -> None:
+        self.net = FlatMlp(layers_of(q.linear_layers()), optimizer, max_batch,
+                           target_layers=layers_of(q_target.linear_layers()))
+        self.nets = [self.net]
+        self._x: Optional[Tensor] = None
+
+    def q_taken(self, state: Tensor, action: Tensor, curr_avail: Optional[Tensor]) -> Tensor:
+        self._x = _concat(state, action)
+        return self.net.forward(self._x, keep=True).view(-1)
+
+    def backward(self, dq: Tensor) -> None:
+        self.net.backward(self._x, dq, want_dw=True)
+
+    def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
+        B, A = state.shape[0], int(rep.shape[-2])
+        if self.net.supports_q_all(A):
+            return self.net.q_all(state, rep, use_target=use_target).view(B, A)
+        return self.net.forward(_expand(state, rep), use_target=use_target).view(B, A)
+
+    def q_one(self, state: Tensor, action: Tensor, use_target: bool) -> Tensor:
+        return self.net.forward(_concat(state, action), use_target=use_target).view(-1)
+
+
+class MultiHeadOps(_Ops):
+    def __init__(self, q: VanillaQValueMultiHeadNetwork, q_target: VanillaQValueMultiHeadNetwork,
+                 optimizer: Any, max_batch: int) -> None:
+        self.net = FlatMlp(layers_of(q.linear_layers()), optimizer, max_batch,
+                           target_layers=layers_of(q_target.linear_layers()))
+        self.nets = [self.net]
+        self.A = int(self.net.dims[-1])
+        self._state: Optional[Tensor] = None
+        self._action: Optional[Tensor] = None
+
+    def _dot(self, f: Tensor, rep: Tensor) -> Tensor:
+        B = f.shape[0]
+        assert rep.shape == (B, self.A), (
+            f"multi-head Q network: one-hot actions of width {self.A} expected, got {tuple(rep.shape)}")
+        out = _new(f.device, B)
+        N.check(N.lib().pa_rows_dot(f.data_ptr(), f.stride(0), rep.data_ptr(), rep.stride(0), B,
+                                    self.A, out.data_ptr(), N.stream_ptr(f.device)))
+        return out
+
+    def q_taken(self, state: Tensor, action: Tensor, curr_avail: Optional[Tensor]) -> Tensor:
+        self._state, self._action = state, action
+        return self._dot(self.net.forward(state, keep=True), action)
+
+    def backward(self, dq: Tensor) -> None:
+        st, act = self._state, self._action
+        B = st.shape[0]
+        df = _new(st.device, B, self.A)
+        N.check(N.lib().pa_rows_scale(dq.data_ptr(), act.data_ptr(), act.stride(0), B, self.A,
+                                      df.data_ptr(), df.stride(0), N.stream_ptr(st.device)))
+        self.net.backward(st, df, want_dw=True)
+
+    def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
+        B, Q = state.shape[0], int(rep.shape[-2])
+        assert rep.shape[-1] == self.A
+        f = self.net.forward(state, use_target=use_target)
+        out = _new(state.device, B, Q)
+        N.check(N.lib().pa_rows_bmm(rep.data_ptr(), Q * self.A if rep.ndim == 3 else 0, f.data_ptr(),
+                                    f.stride(0), B, Q, self.A, out.data_ptr(),
+                                    N.stream_ptr(state.device)))
+        return out
+
+    def q_one(self, state: Tensor, action: Tensor, use_target: bool) -> Tensor:
+        return self._dot(self.net.forward(state, use_target=use_target), action)
+
+
+class DuelingOps(_Ops):
+    def __init__(self, q: DuelingQValueNetwork, q_target: DuelingQValueNetwork, optimizer: Any,
+                 max_batch: int) -> None:
+        def mk(a: nn.Module, b: nn.Module) -> FlatMlp:
+            return FlatMlp(layers_of(a.linear_layers()), optimizer, max_batch,
+                           target_layers=layers_of(b.linear_layers()))
+        self.state_net = mk(q.state_arch, q_target.state_arch)
+        self.value_net = mk(q.value_arch, q_target.value_arch)
+        self.adv_net = mk(q.advantage_arch, q_target.advantage_arch)
+        self.nets = [self.state_net, self.value_net, self.adv_net]
+        self.H = int(self.state_net.dims[-1])
+        self._kept: Dict[str, Any] = {}
+
+    def _combine(self, v: Tensor, adv_q: Tensor, Q: int, adv_mean: Optional[Tensor], M: int) -> Tensor:
+        B = v.shape[0]
+        out = _new(v.device, B, Q)
+        N.check(N.lib().pa_dueling_q(v.data_ptr(), adv_q.data_ptr(), Q, N.ptr(adv_mean), M, B,
+                                     out.data_ptr(), N.stream_ptr(v.device)))
+        return out
+
+    def q_taken(self, state: Tensor, action: Tensor, curr_avail: Optional[Tensor]) -> Tensor:
+        """get_q_values(state, action (B, AD), curr_available_actions) (:424-506): the advantage
+        tower sees B taken-action rows followed by B * M available-action rows."""
+        B = state.shape[0]
+        feats = self.state_net.forward(state, keep=True)                      # (B, H)
+        v = self.value_net.forward(feats, keep=True).view(-1)                 # (B,)
+        M = 0 if curr_avail is None else int(curr_avail.shape[-2])
+        x_adv = _new(state.device, B * (1 + M), self.H + action.shape[1])
+        _concat(feats, action, out=x_adv[:B])
+        if M:
+            _expand(feats, curr_avail, out=x_adv[B:])
+        adv = self.adv_net.forward(x_adv, keep=True).view(-1)                 # (B + B M,)
+        self._kept = dict(state=state, feats=feats, x_adv=x_adv, B=B, M=M)
+        return self._combine(v, adv[:B], 1, adv[B:] if M else None, M).view(-1)
+
+    def backward(self, dq: Tensor) -> None:
+        k = self._kept
+        B, M, dev = k["B"], k["M"], dq.device
+        lib, s = N.lib(), N.stream_ptr(dev)
+        d_adv = _new(dev, B * (1 + M))
+        N.check(lib.pa_dueling_grad(dq.data_ptr(), B, M, d_adv.data_ptr(), s))
+        dx_adv = self.adv_net.backward(k["x_adv"], d_adv, want_dw=True, want_dx=True)
+        dfeat = self.value_net.backward(k["feats"], dq, want_dw=True, want_dx=True)   # (B, H)
+        N.check(lib.pa_dueling_feat_grad(dx_adv.data_ptr(), dx_adv.stride(0), B, M, self.H, 1,
+                                         dfeat.data_ptr(), dfeat.stride(0), s))
+        self.state_net.backward(k["state"], dfeat, want_dw=True)
+
+    def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
+        """get_q_values(state, actions (B, Q, AD)) with no separate available-action set: the mean
+        runs over the Q query actions themselves, padded ones included (:474-479)."""
+        B, Q = state.shape[0], int(rep.shape[-2])
+        feats = self.state_net.forward(state, use_target=use_target)
+        v = self.value_net.forward(feats, use_target=use_target).view(-1)
+        adv = self.adv_net.forward(_expand(feats, rep), use_target=use_target).view(-1)
+        return self._combine(v, adv, Q, None, 0)
+
+    def q_one(self, state: Tensor, action: Tensor, use_target: bool) -> Tensor:
+        feats = self.state_net.forward(state, use_target=use_target)
+        v = self.value_net.forward(feats, use_target=use_target).view(-1)
+        adv = self.adv_net.forward(_concat(feats, action), use_target=use_target).view(-1)
+        return self._combine(v, adv, 1, None, 0).view(-1)     # (v + a) - a, as the reference rounds it
+
+
+def make_ops(q: nn.Module, q_target: nn.Module, optimizer: Any, max_batch: int) -> _Ops:
+    if isinstance(q, DuelingQValueNetwork):
+        towers = (q.state_arch._model, q.value_arch._model, q.advantage_arch._model)
+        if not all(plain_relu_mlp(m) for m in towers):
+            raise NotImplementedError("pearl_amd: DuelingQValueNetwork towers must be plain "
+                                      "Linear + ReLU mlp_blocks")
+        return DuelingOps(q, q_target, optimizer, max_batch)
+    if not plain_relu_mlp(getattr(q, "_model", None)):
+        raise NotImplementedError(
+            f"pearl_amd: {type(q).__name__}._model is not a plain Linear + ReLU mlp_block (other "
+            "activations, normalisation, dropout or residual blocks have no HIP kernels)")
+    if isinstance(q, VanillaQValueMultiHeadNetwork):
+        return MultiHeadOps(q, q_target, optimizer, max_batch)
+    if isinstance(q, VanillaQValueNetwork):
+        return VanillaOps(q, q_target, optimizer, max_batch)
+    raise NotImplementedError(f"pearl_amd: no HIP path for Q network type {type(q).__name__}")
+
+
+class GenericTd:
+    """The TD(0) step over an `_Ops`; `rule`: 0 max (DeepQLearning), 1 double (DoubleDQN),
+    2 SARSA (DeepSARSA) — pa_dqn_desc.double_q's encoding."""
+
+    def __init__(self, ops: _Ops, rule: int, gamma: float, tau: float) -> None:
+        self.ops, self.rule, self.gamma, self.tau = ops, int(rule), float(gamma), float(tau)
+
+    def targets(self, b: Dict[str, Any], want_next_v: bool = False):
+        ops, dev = self.ops, b["state"].device
+        B = b["state"].shape[0]
+        lib, s = N.lib(), N.stream_ptr(dev)
+        y = _new(dev, B)
+        nv = _new(dev, B) if want_next_v else None
+        if self.rule == 2:       # Q_target(s', committed next action) (deep_sarsa.py:59-97)
+            v = ops.q_one(b["next_state"], b["next_action"], use_target=True)
+            N.check(lib.pa_td_target(v.data_ptr(), 1, None, 0, None, 0, b["reward"].data_ptr(),
+                                     b["terminated"].data_ptr(), self.gamma, B, 1, N.ptr(nv),
+                                     y.data_ptr(), s))
+            return nv, y
+        nav, mask = b["next_avail"], b["next_mask"]
+        A = int(nav.shape[-2])
+        q_val = ops.q_all(b["next_state"], nav, use_target=True)                     # (B, A)
+        q_sel = ops.q_all(b["next_state"], nav, use_target=False) if self.rule == 1 else None
+        N.check(lib.pa_td_target(q_val.data_ptr(), q_val.stride(0), N.ptr(q_sel),
+                                 q_sel.stride(0) if q_sel is not None else 0, N.ptr(mask), A,
+                                 b["reward"].data_ptr(), b["terminated"].data_ptr(), self.gamma, B,
+                                 A, N.ptr(nv), y.data_ptr(), s))
+        return nv, y
+
+    def q_values(self, b: Dict[str, Any]) -> Tensor:
+        """Q(s, a) of the online network as forward() computes it (with curr_available_actions)."""
+        return self.ops.q_taken(b["state"], b["action"], b["curr_avail"])
+
+    def step(self, b: Dict[str, Any], do_target_update: bool, losses: Tensor) -> None:
+        """One learn_batch; `losses` (2,) receives mean |Q - y| and the MSE."""
+        ops, dev = self.ops, b["state"].device
+        B = b["state"].shape[0]
+        if do_target_update:
+            ops.soft_update(self.tau)                  # before the forward (deep_td_learning.py:283-284)
+        _, y = self.targets(b)
+        q = ops.q_taken(b["state"], b["action"], b["curr_avail"])
+        dq = _new(dev, B)
+        N.check(N.lib().pa_td_head(q.data_ptr(), 1, y.data_ptr(), B, 2.0 / B, dq.data_ptr(),
+                                   losses.data_ptr(), N.stream_ptr(dev)))
+        ops.backward(dq)
+        ops.adam()

@@ -84,14 +84,36 @@ def test_no_gpu_no_fallback():
 
 
 def test_unsupported_configurations_fail_loudly():
+    """What the HIP engines cannot compute is refused at construction — never trained as if it
+    were something else (a non-ReLU network instance used to be trained as ReLU)."""
+    import torch.nn as nn
     from pearl_amd import DeepQLearning, DiscreteActionSpace, OneHotActionTensorRepresentationModule
+    from pearl_amd.neural_networks.sequential_decision_making.q_value_networks import (
+        DuelingQValueNetwork, VanillaQValueMultiHeadNetwork, VanillaQValueNetwork)
     sp = DiscreteActionSpace([torch.tensor([k]) for k in range(3)])
     rep = OneHotActionTensorRepresentationModule(3)
+    kw = dict(state_dim=4, action_space=sp, action_representation_module=rep)
+    # built: other depths / widths and the multi-head / dueling architectures (generic engine)
+    assert DeepQLearning(hidden_dims=[8, 8], **kw)._fused
+    for nt, hd in ((VanillaQValueNetwork, [8, 8, 8]), (VanillaQValueNetwork, [300, 8]),
+                   (VanillaQValueNetwork, [8]), (VanillaQValueMultiHeadNetwork, [8, 8]),
+                   (DuelingQValueNetwork, [8, 6])):
+        assert not DeepQLearning(hidden_dims=hd, network_type=nt, **kw)._fused
+    # the CQL term is built for the fused path (tests/test_gpu_dqn.py::test_conservative_q_learning)
+    DeepQLearning(hidden_dims=[8, 8], is_conservative=True, **kw)
     with pytest.raises(NotImplementedError):
-        DeepQLearning(state_dim=4, action_space=sp, hidden_dims=[8, 8, 8], action_representation_module=rep)
-    # the CQL term is built (tests/test_gpu_dqn.py::test_conservative_q_learning)
-    DeepQLearning(state_dim=4, action_space=sp, hidden_dims=[8, 8], is_conservative=True,
-                  action_representation_module=rep)
+        DeepQLearning(hidden_dims=[8, 8, 8], is_conservative=True, **kw)
+    # refused: a network instance whose hidden activation is not ReLU, or with layer norm
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+    net._model[0][1] = nn.Tanh()
+    with pytest.raises(NotImplementedError, match="plain Linear"):
+        DeepQLearning(network_instance=net, **kw)
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+    net._model[1] = nn.Sequential(nn.Linear(8, 8), nn.LayerNorm(8), nn.ReLU())
+    with pytest.raises(NotImplementedError, match="plain Linear"):
+        DeepQLearning(network_instance=net, **kw)
+    with pytest.raises(NotImplementedError):
+        DeepQLearning(hidden_dims=[8, 8], optimizer=torch.optim.SGD(net.parameters(), lr=0.1), **kw)
 
 
 # ---------------------------------------------------------------------------- batch contract

@@ -428,3 +428,34 @@ def test_iql_learn_batch_trajectory(name):
                             ("critic_target", pl._critic_target, "critic_target_after")):
         for k, v in mod.state_dict().items():
             torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
+
+
+def test_squarecb_kernel_and_bandit_act_scores():
+    """pa_squarecb_probs against the probability table of the reference's SquareCBExploration.act
+    (single contexts incl. a tie and clamped values), the seeded action, batches of contexts, and
+    NeuralLinearBandit.act / get_scores against the reference run."""
+    from pearl_amd import DiscreteActionSpace, NeuralLinearBandit, SquareCBExploration
+    fx = torch.load(os.path.join(GOLDEN_DIR, "squarecb_tiny.pt"), map_location="cpu", weights_only=False)
+    for c in fx["cases"]:
+        sp = DiscreteActionSpace([torch.tensor([k]) for k in range(c["A"])])
+        e = SquareCBExploration(c["gamma"], reward_lb=0.2, reward_ub=0.7, clamp_values=c["clamp"])
+        got = e.probabilities(c["values"].to(DEV), c["A"])
+        assert got.is_cuda
+        torch.testing.assert_close(got.cpu(), c["probs"].view(1, -1), rtol=1e-6, atol=1e-7)
+        torch.manual_seed(c["seed"])
+        assert int(e.act(None, sp, values=c["values"].to(DEV))) == c["action"]
+    e = SquareCBExploration(5.0)
+    v = torch.rand(700, 32)
+    torch.testing.assert_close(e.probabilities(v.to(DEV), 32).cpu(), e.probabilities(v, 32),
+                               rtol=1e-6, atol=1e-7)
+    b = fx["bandit"]
+    pl = NeuralLinearBandit(feature_dim=b["F"] + 1, hidden_dims=[12, 6], batch_size=8,
+                            exploration_module=SquareCBExploration(gamma=20.0),
+                            state_features_only=False)
+    pl.model.load_state_dict(b["model0"])
+    pl.to(DEV)
+    sp = DiscreteActionSpace([torch.tensor([float(k)]) for k in range(b["A"])])
+    torch.manual_seed(b["seed"])
+    assert int(pl.act(b["state"].to(DEV), sp)) == b["action"]
+    torch.testing.assert_close(pl.get_scores(b["state"].to(DEV), sp).cpu(), b["scores"], rtol=1e-5,
+                               atol=1e-6)

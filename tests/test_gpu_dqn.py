@@ -574,3 +574,55 @@ def test_sarsa_buffer_checkpoint_resume_is_exact():
     raw = b.sample(cfg["B"])
     for k, want in fx["batch_raw"].items():
         assert torch.equal(getattr(raw, k).cpu(), want), k
+
+
+QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", "multihead_cfg2_shape",
+         "dueling_tiny", "dueling_double_small"]
+
+
+def make_qnet_learner(fx):
+    from pearl_amd import DeepQLearning, DoubleDQN, OneHotActionTensorRepresentationModule
+    from pearl_amd.neural_networks.sequential_decision_making import q_value_networks as Q
+    cfg = fx["config"]
+    nt = {"vanilla": Q.VanillaQValueNetwork, "multihead": Q.VanillaQValueMultiHeadNetwork,
+          "dueling": Q.DuelingQValueNetwork}[cfg["network"]]
+    cls = DoubleDQN if cfg.get("learner") == "double" else DeepQLearning
+    pl = cls(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
+             training_rounds=cfg["rounds"], batch_size=cfg["B"], network_type=nt,
+             action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    assert not pl._fused
+    pl._Q.load_state_dict(fx["params0"])
+    pl._Q_target.load_state_dict(fx["target0"])
+    return pl.to(DEV)
+
+
+@pytest.mark.parametrize("name", QNETS)
+def test_qnet_architectures(name):
+    """Q-network architectures beyond the fused shape — other depths / widths, multi-head, dueling;
+    DeepQLearning and DoubleDQN rules — through the generic pa_mlp engine (generic_q.py) against
+    the reference: Q(s, a) as forward() evaluates it, next-state values and Bellman targets at rtol
+    1e-5, the gradients of one batch, and the learn() trajectory with the reference's index stream."""
+    from test_oracle_golden import qnet_well_conditioned
+    fx = _load(f"qnet_{name}")
+    cfg = fx["config"]
+    pl = make_qnet_learner(fx)
+    out = pl.q_values_and_targets(batch_from(fx, "batch_pre"))
+    torch.testing.assert_close(out["q"].cpu(), fx["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["next_v"].cpu(), fx["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(out["target"].cpu(), fx["target"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pl.forward(batch_from(fx, "batch_pre")).cpu(), fx["q"], rtol=1e-5, atol=1e-6)
+    probe = copy.deepcopy(pl)
+    rep = probe.learn_batch(batch_from(fx, "batch_pre"))
+    assert abs(rep["loss"] - float(fx["mean_abs_td"])) <= 1e-5 * max(1.0, float(fx["mean_abs_td"]))
+    for k, p in probe._Q.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), fx["grads"][k], rtol=2e-4, atol=2e-6, msg=k)
+    rb = fill_arena_buffer(fx, "python")
+    random.seed(fx["learn_seed"])
+    report = pl.learn(rb)
+    torch.testing.assert_close(torch.tensor(report["loss"]), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    assert pl._training_steps == fx["training_steps_after"]
+    sd, sdt = pl._Q.state_dict(), pl._Q_target.state_dict()
+    for k in fx["params_after"]:
+        ok = qnet_well_conditioned(fx, k)
+        torch.testing.assert_close(sd[k].cpu()[ok], fx["params_after"][k][ok], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(sdt[k].cpu()[ok], fx["target_after"][k][ok], rtol=1e-3, atol=2e-5, msg=k)

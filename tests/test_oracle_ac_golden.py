@@ -224,3 +224,36 @@ def test_iql_trajectory(name):
                                fx["critic_after"]["_critic_2._model.0.0.weight"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(orc.ct[0][0][0],
                                fx["critic_target_after"]["_critic_1._model.0.0.weight"], rtol=1e-5, atol=1e-7)
+
+
+def test_squarecb_oracle():
+    """squarecb_probs against the table the reference's SquareCBExploration.act hands to
+    Categorical (captured by oracle/make_golden_ac.py::make_squarecb), and the seeded draw."""
+    from oracle.actor_critic_oracle import squarecb_probs
+    fx = torch.load(os.path.join(GOLDEN_DIR, "squarecb_tiny.pt"), map_location="cpu", weights_only=False)
+    for c in fx["cases"]:
+        p = squarecb_probs(c["values"].clone(), c["gamma"], c["clamp"], 0.2, 0.7)
+        assert torch.equal(p, c["probs"].view(1, -1))
+        torch.manual_seed(c["seed"])
+        assert int(torch.distributions.Categorical(p[0]).sample()) == c["action"]
+
+
+def test_squarecb_host_rule_matches_reference():
+    """pearl_amd.SquareCBExploration on CPU values (the host-side statement of the rule the kernel
+    implements): the reference's table and the reference's seeded action."""
+    from pearl_amd import DiscreteActionSpace, SquareCBExploration
+    fx = torch.load(os.path.join(GOLDEN_DIR, "squarecb_tiny.pt"), map_location="cpu", weights_only=False)
+    for c in fx["cases"]:
+        sp = DiscreteActionSpace([torch.tensor([k]) for k in range(c["A"])])
+        e = SquareCBExploration(c["gamma"], reward_lb=0.2, reward_ub=0.7, clamp_values=c["clamp"])
+        torch.testing.assert_close(e.probabilities(c["values"].clone(), c["A"]), c["probs"].view(1, -1),
+                                   rtol=1e-6, atol=1e-7)
+        torch.manual_seed(c["seed"])
+        assert int(e.act(None, sp, values=c["values"].clone())) == c["action"]
+    # batches of contexts: every row is the single-context rule of that row
+    e = SquareCBExploration(5.0)
+    v = torch.rand(6, 4)
+    tab = e.probabilities(v, 4)
+    for i in range(6):
+        torch.testing.assert_close(tab[i:i + 1], e.probabilities(v[i:i + 1], 4))
+    assert torch.all(tab >= 0) and torch.allclose(tab.sum(1), torch.ones(6))

@@ -244,3 +244,48 @@ def test_fullbatch_one_batch_numerics(learner):
     torch.testing.assert_close(((q - want["target"]) ** 2).mean(), want["mse"], rtol=1e-5, atol=1e-6)
     for k, w in want["grads"].items():
         torch.testing.assert_close(g[k].reshape(w.shape), w, rtol=2e-4, atol=2e-6, msg=k)
+
+
+QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", "multihead_cfg2_shape",
+         "dueling_tiny", "dueling_double_small"]
+
+
+def qnet_well_conditioned(fx, key) -> torch.Tensor:
+    """Elements of parameter `key` whose trajectory is a function of the algorithm.  In a dueling
+    network Q = V + A - mean(A), anything that shifts A(s, .) by the same amount for every action of
+    a state cancels exactly: the advantage tower's output bias, and the bias of every hidden unit
+    that is active on all rows of a state.  Their true gradient is zero, autograd returns rounding
+    noise (~1e-9) of either sign, and AdamW normalises that noise to steps of +-lr — the
+    reference itself does not reproduce those elements across BLAS builds.  They are recognised by
+    a noise-level gradient on the fixture's first batch and left out of trajectory comparisons."""
+    g = fx["grads"][key]
+    if fx["config"]["network"] != "dueling":
+        return torch.ones_like(g, dtype=torch.bool)
+    return g.abs() > 1e-6
+
+
+@pytest.mark.parametrize("name", QNETS)
+def test_qnet_architectures_oracle(name):
+    """QNetOracle (other depths / multi-head / dueling, DQN and DoubleDQN rules) against the
+    reference: one-batch Q-values, next-state values, targets, gradients, and the learn()
+    trajectory with the reference's own index stream."""
+    fx = load_sarsa(f"qnet_{name}")
+    cfg = fx["config"]
+    pl = O.QNetOracle(fx["params0"], fx["target0"], cfg["network"],
+                      double_q=cfg.get("learner") == "double")
+    b = fx["batch_pre"]
+    torch.testing.assert_close(pl.q(pl.p, b["state"], b["action"], b["curr_available_actions"]),
+                               fx["q"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pl.next_state_values(b), fx["next_v"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(pl.bellman_target(b), fx["target"], rtol=1e-5, atol=1e-6)
+    _, g = pl.gradients(b, fx["target"])
+    for k, want in fx["grads"].items():
+        torch.testing.assert_close(g[k], want, rtol=2e-4, atol=2e-6, msg=k)
+    rb = fill_oracle_replay(fx)
+    random.seed(fx["learn_seed"])
+    losses = pl.learn(rb, cfg["rounds"], cfg["B"], cfg["A"])
+    torch.testing.assert_close(torch.tensor(losses), fx["learn_losses"], rtol=2e-4, atol=1e-5)
+    for k in pl.keys:
+        ok = qnet_well_conditioned(fx, k)
+        torch.testing.assert_close(pl.p[k][ok], fx["params_after"][k][ok], rtol=1e-3, atol=2e-5, msg=k)
+        torch.testing.assert_close(pl.t[k][ok], fx["target_after"][k][ok], rtol=1e-3, atol=2e-5, msg=k)
