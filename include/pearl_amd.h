@@ -503,6 +503,12 @@ int pa_gauss_awr_head(const float* head, int32_t ldh, const float* action, int32
 int pa_td_target(const float* q_val, int32_t ldv, const float* q_sel, int32_t lds,
                  const uint8_t* mask, int32_t ldm, const float* reward, const uint8_t* terminated,
                  float gamma, int32_t B, int32_t A, float* next_v, float* y, void* stream);
+/* DoubleDQN's action choice (double_dqn.py:40-51): idx_out[b] = first argmax over the unmasked
+ * entries of q[b, :], rep_out[b, :AD] = rep[b, idx, :] (rep_bstride = A AD, or 0 for one shared
+ * table).  Either output may be NULL. */
+int pa_argmax_rows(const float* q, int32_t ldq, const uint8_t* mask, int32_t ldm, const float* rep,
+                   int64_t rep_bstride, int32_t B, int32_t A, int32_t AD, int32_t* idx_out,
+                   float* rep_out, void* stream);
 /* dq = grad_scale (q - y) (MSELoss(mean): grad_scale = 2 / (B world)); loss_out2[0] = mean |q - y|
  * (the reported loss, deep_td_learning.py:358-359), loss_out2[1] = mean (q - y)^2. */
 int pa_td_head(const float* q, int32_t ldq, const float* y, int32_t B, float grad_scale, float* dq,

@@ -63,10 +63,14 @@ PPO_CONFIGS = {
     "tiny": dict(S=5, A=3, hidden=[16, 12], N=37, B=8, rounds=6, epsilon=0.1),
     "eps0": dict(S=6, A=4, hidden=[24, 24], N=64, B=64, rounds=4, epsilon=0.0),
     "cfg4_shape_small": dict(S=256, A=16, hidden=[256, 256], N=400, B=128, rounds=5, epsilon=0.1),
+    # BASELINE config 4 at its own minibatch size (4096 of a 4096-transition rollout, one round)
+    "cfg4_fullbatch": dict(S=256, A=16, hidden=[256, 256], N=4096, B=4096, rounds=1, epsilon=0.1),
 }
 SAC_CONFIGS = {
     "tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=5),
     "cfg3_shape_small": dict(S=64, A=8, hidden=[256, 256], B=128, steps=4),
+    # BASELINE config 3 at its own batch size (B = 1024), one learn_batch
+    "cfg3_fullbatch": dict(S=64, A=8, hidden=[256, 256], B=1024, steps=1),
 }
 
 
@@ -467,6 +471,10 @@ def main():
         for name, cfg in IQL_CONFIGS.items():
             if "gaussian" in name:
                 make_iql(name, cfg)
+        return
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "fullbatch":
+        make_ppo("cfg4_fullbatch", PPO_CONFIGS["cfg4_fullbatch"])
+        make_sac("cfg3_fullbatch", SAC_CONFIGS["cfg3_fullbatch"])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "squarecb":
         make_squarecb()

@@ -301,6 +301,8 @@ SIGNATURES = {
                               C.c_int32, _P, _P]),
     "pa_td_target": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P, C.c_float,
                                C.c_int32, C.c_int32, _P, _P, _P]),
+    "pa_argmax_rows": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,
+                                 C.c_int32, _P, _P, _P]),
     "pa_td_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_float, _P, _P, _P]),
     "pa_rows_dot": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "pa_rows_scale": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),

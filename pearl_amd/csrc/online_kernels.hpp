@@ -357,35 +357,33 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   WRing R2;
   float4 b2v[2], w3v[2];
   const float b3v = a.b3[0];
-  const bool vb = is_vec_ok(a.b1, 4) && is_vec_ok(a.b2, 4) && is_vec_ok(a.w3, 4) && v1 && v2;
-  auto vec4 = [&](const float* p, int col, int n) {
-    return vb ? ld4_or_zero(p, col, col < n) : guarded_load4(p, 0, true, col, n);
-  };
+  // b1 / b2 / w3 are tensors of the flat parameter buffer: 16-byte aligned, every tensor padded to
+  // a multiple of four floats with zeros (param_layout), so a float4 that starts inside a tensor
+  // never leaves its slot — one unconditional vector load each, no scalar fallback (the two-path
+  // form made hipcc serialise the burst below behind s_waitcnt).
+  auto vec4 = [&](const float* p, int col, int n) { return ld4_or_zero(p, col, col < n); };
   // ---- layer 1: h1 = relu(W1 x + b1)
   if constexpr (NG1 > 0) {
     // B operand of k-group g: x[row][16 g + 4 qd .. + 3]
     const bool vx = is_vec_ok(a.x, a.ldx) && ((a.K1 & 3) == 0);
-    float4 xf[NG1], wa[NG1], wb[NG1];
+    // Issue order = arrival order (vector memory returns in order): the accumulator seed b1 first,
+    // then k-group by k-group what that group's eight MFMAs consume, so that layer 1 starts on its
+    // first group while the later ones are still in flight.
+    float4 xf[NG1], wa[NG1], wb[NG1], b1v[2];
 #pragma unroll
-    for (int g = 0; g < NG1; ++g) {
-      const int c = 16 * g + 4 * qd;
-      if (vx) xf[g] = ld4_or_zero(a.x, (int64_t)row * a.ldx + c, rok && c < a.K1);
-      else xf[g] = guarded_load4(a.x, (int64_t)row * a.ldx, rok, c, a.K1);
-    }
+    for (int t = 0; t < 2; ++t) b1v[t] = vec4(a.b1, u0 + 16 * t, a.H1);
     {
       const bool ok0 = tile0 < nt1, ok1 = tile0 + 1 < nt1;
       const int64_t base0 = ((int64_t)tile0 * NG1) * 256 + lane * 4;
       const int64_t base1 = base0 + (int64_t)NG1 * 256;
 #pragma unroll
       for (int g = 0; g < NG1; ++g) {
+        const int c = 16 * g + 4 * qd;
+        if (vx) xf[g] = ld4_or_zero(a.x, (int64_t)row * a.ldx + c, rok && c < a.K1);
+        else xf[g] = guarded_load4(a.x, (int64_t)row * a.ldx, rok, c, a.K1);
         wa[g] = ld4_or_zero(a.W1f, base0 + (int64_t)g * 256, ok0);
         wb[g] = ld4_or_zero(a.W1f, base1 + (int64_t)g * 256, ok1);
       }
-    }
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const float4 b = vec4(a.b1, u0 + 16 * t, a.H1);
-      acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
     }
     if constexpr (NG2 > 0) ring_fill<NG2>(R2, a.W2f, tile0, nt2, lane);
 #pragma unroll
@@ -395,6 +393,10 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     }
     PA_STAMP(a.prof, blockIdx.x, wave, 1);
     __builtin_amdgcn_sched_barrier(0);   // the burst above stays above: nothing sinks to its use
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {        // (seeded here, not at the load: the copy waits for b1)
+      acc[t][0] = b1v[t].x; acc[t][1] = b1v[t].y; acc[t][2] = b1v[t].z; acc[t][3] = b1v[t].w;
+    }
 #pragma unroll
     for (int g = 0; g < NG1; ++g) {
       const float4 x4 = xf[g], w0 = wa[g], w1 = wb[g];

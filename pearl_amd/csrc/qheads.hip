@@ -203,12 +203,39 @@ __global__ __launch_bounds__(256) void squarecb_kernel(const float* __restrict__
   for (int a = 0; a < A; ++a) {
     float x = v[a];
     if (clamp_values) x = fminf(fmaxf(x, lb), ub);
-    const float pa_ = (a == mi) ? 0.f : 1.0f / ((float)A + gamma * (m - x));
+    const float pa_ = (a == mi) ? 0.f : __fdiv_rn(1.0f, __fadd_rn((float)A, __fmul_rn(gamma, __fsub_rn(m, x))));
     p[a] = pa_;
     comp += pa_;
   }
   p[mi] = 1.0f - comp;
   argmax_out[b] = mi;
+}
+
+// DoubleDQN's action choice (double_dqn.py:40-51): first argmax over the unmasked entries of the
+// ONLINE network's values, and the representation of that action out of the row's action table.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ q, int ldq,
+                                                          const uint8_t* __restrict__ mask, int ldm,
+                                                          const float* __restrict__ rep,
+                                                          int64_t rep_bstride, int B, int A, int AD,
+                                                          int* __restrict__ idx_out,
+                                                          float* __restrict__ rep_out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const float* sel = q + (int64_t)b * ldq;
+  const uint8_t* mk = mask ? mask + (int64_t)b * ldm : nullptr;
+  float m = (mk && mk[0]) ? -INFINITY : sel[0];
+  int mi = 0;
+  for (int i = 1; i < A; ++i) {
+    const float x = (mk && mk[i]) ? -INFINITY : sel[i];
+    const bool take = (x > m || x != x) && !(m != m);
+    m = take ? x : m;
+    mi = take ? i : mi;
+  }
+  if (idx_out) idx_out[b] = mi;
+  if (rep_out) {
+    const float* src = rep + (int64_t)b * rep_bstride + (int64_t)mi * AD;
+    for (int j = 0; j < AD; ++j) rep_out[(int64_t)b * AD + j] = src[j];
+  }
 }
 
 unsigned grid_for(int64_t n) { return (unsigned)ceil_div(n, 256); }
@@ -311,6 +338,18 @@ extern "C" int pa_squarecb_probs(const float* values, int32_t ldv, int32_t B, in
   hipLaunchKernelGGL(squarecb_kernel, dim3(grid_for(B)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream),
                      values, ldv, B, A, gamma, clamp_values, reward_lb, reward_ub, prob, argmax_out);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_argmax_rows(const float* q, int32_t ldq, const uint8_t* mask, int32_t ldm,
+                              const float* rep, int64_t rep_bstride, int32_t B, int32_t A, int32_t AD,
+                              int32_t* idx_out, float* rep_out, void* stream) {
+  PA_REQUIRE(q && B > 0 && A > 0 && (idx_out || rep_out) && (!rep_out || (rep && AD > 0)),
+             PA_ERR_INVALID, "pa_argmax_rows: bad argument");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(grid_for(B)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), q, ldq, mask, ldm, rep, rep_bstride, B, A,
+                     AD, idx_out, rep_out);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -270,11 +270,23 @@ class GenericTd:
                                      y.data_ptr(), s))
             return nv, y
         nav, mask = b["next_avail"], b["next_mask"]
-        A = int(nav.shape[-2])
+        A, AD = int(nav.shape[-2]), int(nav.shape[-1])
+        if self.rule == 1:
+            # DoubleDQN (double_dqn.py:29-57): a' = argmax over the available next actions of the
+            # ONLINE network, valued by Q_target.get_q_values(s', a') on that ONE action — for a
+            # dueling network that is V + A - A, not an entry of the all-actions table
+            q_sel = ops.q_all(b["next_state"], nav, use_target=False)
+            chosen = _new(dev, B, AD)
+            N.check(lib.pa_argmax_rows(q_sel.data_ptr(), q_sel.stride(0), N.ptr(mask), A,
+                                       nav.data_ptr(), A * AD if nav.ndim == 3 else 0, B, A, AD,
+                                       None, chosen.data_ptr(), s))
+            v = ops.q_one(b["next_state"], chosen, use_target=True)
+            N.check(lib.pa_td_target(v.data_ptr(), 1, None, 0, None, 0, b["reward"].data_ptr(),
+                                     b["terminated"].data_ptr(), self.gamma, B, 1, N.ptr(nv),
+                                     y.data_ptr(), s))
+            return nv, y
         q_val = ops.q_all(b["next_state"], nav, use_target=True)                     # (B, A)
-        q_sel = ops.q_all(b["next_state"], nav, use_target=False) if self.rule == 1 else None
-        N.check(lib.pa_td_target(q_val.data_ptr(), q_val.stride(0), N.ptr(q_sel),
-                                 q_sel.stride(0) if q_sel is not None else 0, N.ptr(mask), A,
+        N.check(lib.pa_td_target(q_val.data_ptr(), q_val.stride(0), None, 0, N.ptr(mask), A,
                                  b["reward"].data_ptr(), b["terminated"].data_ptr(), self.gamma, B,
                                  A, N.ptr(nv), y.data_ptr(), s))
         return nv, y

@@ -32,3 +32,23 @@ def her_reward(state, action):
 def her_terminated(state, action):
     g = state.shape[0] // 2
     return bool(float((state[:g] - state[g:]).abs().sum()) < 0.75)
+
+
+def assert_adam_trajectory_close(got, want, lr, steps, rtol=1e-3, atol=2e-5, max_outlier_frac=2e-3,
+                                 msg=""):
+    """Parameters after `steps` AdamW steps against the reference run.
+
+    AdamW moves a parameter by lr * m / (sqrt(v) + eps): for an element whose gradient is at the
+    level of fp32 summation noise (dead-ish ReLU paths, near-cancelling sums over a large batch)
+    that ratio is a coin flip of size ~lr per step whatever the arithmetic — MKL's blocked sums
+    and the MFMA k-ordered chain legitimately disagree there, and so do two BLAS builds.  So:
+    at most `max_outlier_frac` of the elements may miss (rtol, atol), and none of those by more
+    than the 2.5 * lr * steps such flips can accumulate."""
+    import torch
+    got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    bad = ~torch.isclose(got, want, rtol=rtol, atol=atol)
+    frac = float(bad.float().mean())
+    assert frac <= max_outlier_frac, f"{msg}: {frac:.4%} of the elements outside rtol={rtol}, atol={atol}"
+    if bad.any():
+        worst = float((got - want).abs()[bad].max())
+        assert worst <= 2.5 * lr * steps, f"{msg}: outlier of {worst:.3e} > 2.5 * lr * steps"

@@ -8,8 +8,8 @@ import torch
 from conftest import GOLDEN_DIR
 from oracle.actor_critic_oracle import PpoOracle, SacOracle
 
-PPO = ["tiny", "eps0", "cfg4_shape_small"]
-SAC = ["tiny", "cfg3_shape_small"]
+PPO = ["tiny", "eps0", "cfg4_shape_small", "cfg4_fullbatch"]
+SAC = ["tiny", "cfg3_shape_small", "cfg3_fullbatch"]
 
 
 def load(kind, name):
