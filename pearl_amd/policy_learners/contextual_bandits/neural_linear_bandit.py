@@ -166,7 +166,17 @@ class NeuralLinearBandit(PolicyLearner):
         wsum = torch.empty(1, dtype=torch.float32, device=dev)
         N.check(lib.pa_weighted_mse_head(pred.data_ptr(), pred.stride(0), y.data_ptr(), N.ptr(w), B,
                                          dpred.data_ptr(), loss.data_ptr(), wsum.data_ptr(), s))
-        if w is None or float(wsum.item()) != 0.0:     # all-zero weights: skip the optimizer (:171-175)
+        # all-zero weights: skip the optimizer (:171-175).  Data parallel: the decision is taken on
+        # the GLOBAL weight sum, so every rank enters (or skips) the gradient all-reduce of
+        # net.adam() together — a rank-local decision left the other ranks hanging in it.
+        skip = False
+        if w is not None:
+            ws = wsum
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                ws = wsum.clone()
+                dist.all_reduce(ws)
+            skip = float(ws.item()) == 0.0
+        if not skip:
             net.backward(x, dpred, want_dw=True)
             net.adam()
         # ---- LinUCB update on the detached features

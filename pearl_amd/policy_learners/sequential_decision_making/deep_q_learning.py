@@ -624,7 +624,7 @@ class DeepQLearning(PolicyLearner):
             # (the env override drives the hook path through RCCL with a single rank: a test aid)
             return self._learn_data_parallel(replay_buffer, batch_size, rounds, onehot)
         idx_host = None
-        if replay_buffer.sampler == "python":
+        if replay_buffer.sampler == "python" or batch_size > replay_buffer.DEVICE_SAMPLER_MAX_B:
             n = len(replay_buffer)
             idx_host = np.asarray([random.sample(range(n), batch_size) for _ in range(rounds)],
                                   dtype=np.int64)
@@ -726,7 +726,7 @@ class DeepQLearning(PolicyLearner):
             fn_wait = C.cast(lib.pa_comm_allreduce_wait, C.c_void_p)
             ctx = comm
         idx_host = None
-        if replay_buffer.sampler == "python":
+        if replay_buffer.sampler == "python" or batch_size > replay_buffer.DEVICE_SAMPLER_MAX_B:
             n = len(replay_buffer)
             idx_host = np.asarray([random.sample(range(n), batch_size) for _ in range(rounds)],
                                   dtype=np.int64)

@@ -225,6 +225,22 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         assert layout == self._layout, (
             f"transition layout changed after the first push: {layout} vs {self._layout}")
 
+    def _coerce_dtypes(self, act_dtype: torch.dtype, rew_dtype: torch.dtype):
+        """The arena's columns have ONE dtype each, fixed by the first push; the reference stores
+        per-transition tensors and lets ``torch.cat`` promote (:290-400).  Later pushes are cast to
+        the stored dtype where that is what the promotion would give anyway (python ints /
+        numpy scalars into a float32 reward column, int32 / int64 actions into each other); a float
+        into an integer column would silently truncate and is refused."""
+        z = self._layout
+        if z is None:
+            return act_dtype, rew_dtype
+        for name, new, stored in (("reward", rew_dtype, z.reward_dtype), ("action", act_dtype, z.action_dtype)):
+            if new != stored and new.is_floating_point and not stored.is_floating_point:
+                raise TypeError(
+                    f"pearl_amd replay arena: {name} column was created as {stored} by the first "
+                    f"push and cannot hold a {new} value; push floats from the start")
+        return z.action_dtype, z.reward_dtype
+
     def push(self, state: Any, action: Any, reward: Any, terminated: bool, truncated: bool,
              curr_available_actions: Any = None, next_state: Any = None,
              next_available_actions: Any = None, max_number_actions: Optional[int] = None,
@@ -260,10 +276,11 @@ class TensorBasedReplayBuffer(ReplayBuffer):
             act_dtype = action.dtype
         else:
             act_dtype = torch.as_tensor(action).dtype
-        act = _as_host_array(action, _NP_OF_TORCH[act_dtype])
         rew_dtype = _torch_dtype_of_value(reward)
         if rew_dtype == torch.bool:
             rew_dtype = torch.int64
+        act_dtype, rew_dtype = self._coerce_dtypes(act_dtype, rew_dtype)
+        act = _as_host_array(action, _NP_OF_TORCH[act_dtype])
         rew = _as_host_array(reward, _NP_OF_TORCH[rew_dtype]).reshape(-1)[:1]
         layout = ArenaLayout(
             state_shape=tuple(st.shape), action_shape=tuple(act.shape), action_dtype=act_dtype,
@@ -359,6 +376,7 @@ class TensorBasedReplayBuffer(ReplayBuffer):
 
     # -- checkpoint / resume (the reference does not checkpoint its buffer) --
     _CKPT_CHUNK = 262_144   # rows per gather / scatter launch (bounds the device temporaries)
+    DEVICE_SAMPLER_MAX_B = 8192   # SAMPLE_MAX_B of arena.hip
 
     def state_dict(self) -> Dict[str, Any]:
         """Everything stored, oldest transition first, as CPU tensors (``torch.save``-able):
@@ -459,7 +477,8 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         is left.  Consumes Python's ``random`` once (the Philox key), like one ``sample``."""
         self._presampled = None
         n = len(self)
-        if self.sampler != "device" or self._arena is None or rounds <= 0 or not 0 < batch_size <= n:
+        if self.sampler != "device" or self._arena is None or rounds <= 0 or not 0 < batch_size <= n \
+                or batch_size > self.DEVICE_SAMPLER_MAX_B:
             return False
         dev = self._arena.device
         self._arena.flush()
@@ -530,7 +549,9 @@ class TensorBasedReplayBuffer(ReplayBuffer):
             if idx_dev is not None:
                 arena.gather_device(idx_dev, out)
                 self._last_idx = idx_dev
-            elif self.sampler == "python":
+            elif self.sampler == "python" or B > self.DEVICE_SAMPLER_MAX_B:
+                # (the device sampler draws one list per workgroup and holds at most 8192 indices;
+                # whole-buffer batches — batch_size=-1, large PPO rollouts — take Python's sampler)
                 arena.gather(self._draw_host_indices(B), out)
                 self._last_idx = arena._scratch(B)[:B].clone()
             else:

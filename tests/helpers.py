@@ -46,6 +46,8 @@ def assert_adam_trajectory_close(got, want, lr, steps, rtol=1e-3, atol=2e-5, max
     than the 2.5 * lr * steps such flips can accumulate."""
     import torch
     got, want = got.detach().cpu().float(), want.detach().cpu().float()
+    if got.numel() == 0:
+        return
     bad = ~torch.isclose(got, want, rtol=rtol, atol=atol)
     frac = float(bad.float().mean())
     assert frac <= max_outlier_frac, f"{msg}: {frac:.4%} of the elements outside rtol={rtol}, atol={atol}"

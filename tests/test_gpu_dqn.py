@@ -623,8 +623,26 @@ def test_qnet_architectures(name):
     assert pl._training_steps == fx["training_steps_after"]
     sd, sdt = pl._Q.state_dict(), pl._Q_target.state_dict()
     from helpers import assert_adam_trajectory_close
+    dueling = cfg["network"] == "dueling"
     for k in fx["params_after"]:
         ok = qnet_well_conditioned(fx, k)
-        assert_adam_trajectory_close(sd[k].cpu()[ok], fx["params_after"][k][ok], 1e-3, cfg["rounds"], msg=k)
+        # dueling: Q = V + A - mean(A) cancels every direction that shifts A(s, .) uniformly, so
+        # whole weight columns see noise-level gradients on some batches (see
+        # qnet_well_conditioned); their AdamW trajectory is not reproducible, the FUNCTION is
+        frac = 0.05 if dueling else 2e-3
+        assert_adam_trajectory_close(sd[k].cpu()[ok], fx["params_after"][k][ok], 1e-3, cfg["rounds"],
+                                     max_outlier_frac=frac, msg=k)
         assert_adam_trajectory_close(sdt[k].cpu()[ok], fx["target_after"][k][ok], 1e-3, cfg["rounds"],
-                                     msg=f"target {k}")
+                                     max_outlier_frac=frac, msg=f"target {k}")
+    # function space: the trained networks agree with the reference's trained networks on the
+    # fixture batch (Q(s, a) of the online net, all-action values of the target net)
+    b = fx["batch_pre"]
+    ref = O.QNetOracle(fx["params_after"], fx["target_after"], cfg["network"])
+    mine = O.QNetOracle({k: v.cpu() for k, v in sd.items()}, {k: v.cpu() for k, v in sdt.items()},
+                        cfg["network"])
+    torch.testing.assert_close(mine.q(mine.p, b["state"], b["action"], b["curr_available_actions"]),
+                               ref.q(ref.p, b["state"], b["action"], b["curr_available_actions"]),
+                               rtol=2e-3, atol=2e-4)
+    torch.testing.assert_close(mine.q(mine.t, b["next_state"], b["next_available_actions"]),
+                               ref.q(ref.t, b["next_state"], b["next_available_actions"]),
+                               rtol=2e-3, atol=2e-4)

@@ -339,3 +339,45 @@ def test_bootstrap_replay_buffer_matches_reference(variant):
     fresh.load_state_dict(rb.state_dict())
     random.seed(v["sample_seed"])
     assert_batch_equal(fresh.sample(cfg["B"]), v["batch"])
+
+
+def test_mixed_reward_types_and_oversized_batches():
+    """later pushes are cast to the arena's column dtype where torch.cat's promotion
+    would land there anyway (python int / numpy scalars into a float32 reward column); a float into
+    an integer column is refused instead of truncated; batches above the device sampler's 8192
+    limit (batch_size = -1 on a big buffer) are drawn by Python's sampler instead of failing."""
+    from pearl_amd import BasicReplayBuffer
+    rb = BasicReplayBuffer(20000, sampler="device")
+    rb.device_for_batches = torch.device("cuda:0")
+    sp = _space(3)
+
+    def push(r):
+        rb.push(state=torch.zeros(4), action=torch.tensor([1]), reward=r, terminated=False,
+                truncated=False, curr_available_actions=sp, next_state=torch.ones(4),
+                next_available_actions=sp, max_number_actions=3)
+
+    push(1.5)
+    push(2)
+    push(np.float64(0.25))
+    push(np.int32(7))
+    b = rb.sample(4)
+    assert b.reward.dtype == torch.float32
+    assert sorted(b.reward.cpu().tolist()) == [0.25, 1.5, 2.0, 7.0]
+    ints = BasicReplayBuffer(8, sampler="python")
+    ints.device_for_batches = torch.device("cuda:0")
+    ints.push(state=torch.zeros(4), action=torch.tensor([1]), reward=3, terminated=False,
+              truncated=False, curr_available_actions=sp, next_state=torch.ones(4),
+              next_available_actions=sp, max_number_actions=3)
+    with pytest.raises(TypeError, match="cannot hold"):
+        ints.push(state=torch.zeros(4), action=torch.tensor([1]), reward=0.5, terminated=False,
+                  truncated=False, curr_available_actions=sp, next_state=torch.ones(4),
+                  next_available_actions=sp, max_number_actions=3)
+    n = 9000
+    rb.clear()
+    rb.push_many(state=torch.randn(n, 4), action=torch.ones(n, 1, dtype=torch.int64),
+                 reward=torch.arange(n, dtype=torch.float32), terminated=torch.zeros(n, dtype=torch.bool),
+                 truncated=torch.zeros(n, dtype=torch.bool), next_state=torch.randn(n, 4),
+                 curr_available_actions=sp, next_available_actions=sp, max_number_actions=3)
+    random.seed(0)
+    whole = rb.sample(n)                       # > 8192: host permutation
+    assert sorted(whole.reward.cpu().tolist()) == list(map(float, range(n)))
