@@ -374,6 +374,10 @@ int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets);
 int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc);
 int pa_mlp_destroy(pa_mlp* h);
 int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* bufs);
+/* The caller (or anyone else) may have written the bound parameter buffers since the last call:
+ * cached derived copies (the MFMA fragment-major weights of the row-pass kernels) are rebuilt on
+ * next use.  pa_mlp_bind / pa_mlp_adam / pa_mlp_soft_update invalidate on their own. */
+int pa_mlp_invalidate(pa_mlp* h);
 /* nn.Sequential forward; keep = 1 retains the hidden activations for pa_mlp_backward. */
 int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int32_t ldx, int32_t B,
                    float* out, int32_t ldo, int32_t keep, void* stream);

@@ -320,6 +320,7 @@ SIGNATURES = {
     "pa_tanh_action_grad": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                                       _P, C.c_int32, _P]),
     "pa_neg_mean_head": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "pa_mlp_invalidate": (C.c_int, [_P]),
     "pa_mlp_adam": (C.c_int, [_P, C.c_int64, _P]),
     "pa_mlp_soft_update": (C.c_int, [_P, C.c_float, _P]),
     "pa_softmax_action_prob": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),

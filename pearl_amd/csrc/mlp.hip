@@ -20,6 +20,7 @@
 #include <new>
 
 #include "host_launch.hpp"
+#include "mlp_rowpass.hpp"
 
 using namespace pa;
 
@@ -39,6 +40,14 @@ struct pa_mlp {
   // product [max_batch, H1], the two operands target_fused_kernel needs beside the parameters
   float* qa_w2f;
   float* qa_u;
+  // row-pass path (mlp_rowpass.hpp): fragment-major copies of every layer — online W_l and W_l^T,
+  // target W_l — rebuilt lazily by ONE launch when the parameters may have changed (bind, AdamW,
+  // soft update, pa_mlp_invalidate)
+  bool row_ok;                    // shape fits the row-pass kernels
+  float* wf[PA_MLP_MAX_LAYERS];
+  float* wtf[PA_MLP_MAX_LAYERS];
+  float* wf_t[PA_MLP_MAX_LAYERS];
+  bool packed_ok, packed_t_ok;
 };
 
 namespace {
@@ -105,6 +114,11 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   if (h->qa_w2f) (void)hipFree(h->qa_w2f);
   if (h->qa_u) (void)hipFree(h->qa_u);
+  for (int l = 0; l < PA_MLP_MAX_LAYERS; ++l) {
+    if (h->wf[l]) (void)hipFree(h->wf[l]);
+    if (h->wtf[l]) (void)hipFree(h->wtf[l]);
+    if (h->wf_t[l]) (void)hipFree(h->wf_t[l]);
+  }
   delete h;
   return PA_OK;
 }
@@ -139,6 +153,21 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
     ok = ok && alloc(&h->dz[l], (int64_t)desc->max_batch * desc->dims[l]);
   ok = ok && alloc(&h->db_scratch, maxh);
   ok = ok && alloc(&h->loss_scratch, 4);
+  {
+    static const bool enabled = []() {
+      const char* v = getenv("PEARL_AMD_MLP_ROWPASS");
+      return !(v && *v == '0');
+    }();
+    h->row_ok = enabled && h->L <= ROW_MAX_LAYERS && desc->dims[0] <= ROW_MAX_IN;
+    for (int l = 0; l < h->L; ++l) h->row_ok = h->row_ok && desc->dims[l + 1] <= ROW_MAX_OUT;
+    if (h->row_ok) {
+      for (int l = 0; l < h->L; ++l) {
+        ok = ok && alloc(&h->wf[l], wf16_floats(desc->dims[l + 1], desc->dims[l]));
+        ok = ok && alloc(&h->wf_t[l], wf16_floats(desc->dims[l + 1], desc->dims[l]));
+        ok = ok && alloc(&h->wtf[l], wf16_floats(desc->dims[l], desc->dims[l + 1]));
+      }
+    }
+  }
   if (!ok) {
     set_error("hipMalloc(mlp workspace) failed");
     pa_mlp_destroy(h);
@@ -156,8 +185,97 @@ extern "C" int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* b) {
                "flat buffers must be 16-byte aligned");
   h->bufs = *b;
   h->bound = true;
+  h->packed_ok = h->packed_t_ok = false;
   return PA_OK;
 }
+
+extern "C" int pa_mlp_invalidate(pa_mlp* h) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null mlp");
+  h->packed_ok = h->packed_t_ok = false;
+  return PA_OK;
+}
+
+namespace {
+
+// fragment-major copies of the parameter set a row pass is about to read
+int ensure_packed(pa_mlp* h, bool target, hipStream_t s) {
+  bool& ok = target ? h->packed_t_ok : h->packed_ok;
+  if (ok) return PA_OK;
+  RowPackArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = target ? h->bufs.p_target : h->bufs.p;
+  a.L = h->L;
+  for (int l = 0; l <= h->L; ++l) a.dims[l] = h->d.dims[l];
+  for (int l = 0; l < h->L; ++l) {
+    a.woff[l] = h->woff[l];
+    a.Wf[l] = target ? h->wf_t[l] : h->wf[l];
+    a.Wtf[l] = target ? nullptr : h->wtf[l];
+  }
+  hipLaunchKernelGGL(mlp_rowpack_kernel, dim3(128), dim3(256), 0, s, a);
+  PA_LAUNCH_CHECK();
+  ok = true;
+  return PA_OK;
+}
+
+void fill_fwd(const pa_mlp* h, bool target, float* out, int ldo, bool keep, RowNetFwd& n) {
+  const float* P = target ? h->bufs.p_target : h->bufs.p;
+  n.L = h->L;
+  n.relu = 0;
+  for (int l = 0; l <= h->L; ++l) n.dims[l] = h->d.dims[l];
+  for (int l = 0; l < h->L; ++l) {
+    const bool last = l == h->L - 1;
+    n.Wf[l] = target ? h->wf_t[l] : h->wf[l];
+    n.bias[l] = (last && h->d.no_last_bias) ? nullptr : P + h->boff[l];
+    n.act[l] = (!last && keep) ? h->act[l] : nullptr;
+    if (!last && !((h->d.identity_layers >> l) & 1)) n.relu |= 1 << l;
+  }
+  n.out = out;
+  n.ldo = ldo;
+}
+
+int launch_rowfwd(RowFwdArgs& a, int nnet, int d0max, hipStream_t s) {
+  static size_t configured = 0;
+  const size_t smem = rowfwd_smem_bytes(d0max);
+  if (smem > configured) {
+    int rc = set_max_smem(mlp_rowfwd_kernel, smem);
+    if (rc != PA_OK) return rc;
+    configured = smem;
+  }
+  hipLaunchKernelGGL(mlp_rowfwd_kernel, dim3((unsigned)ceil_div(a.B, RP_ROWS), (unsigned)nnet),
+                     dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+void fill_bwd(const pa_mlp* h, const float* d_out, int ldd, float* d_x, int lddx, RowNetBwd& n) {
+  n.L = h->L;
+  n.relu = 0;
+  for (int l = 0; l <= h->L; ++l) n.dims[l] = h->d.dims[l];
+  for (int l = 0; l < h->L; ++l) {
+    n.Wtf[l] = h->wtf[l];
+    n.act[l] = h->act[l];
+    n.dz[l] = h->dz[l];
+    if (l + 1 < h->L && !((h->d.identity_layers >> l) & 1)) n.relu |= 1 << l;
+  }
+  n.d_out = d_out; n.ldd = ldd;
+  n.d_x = d_x; n.lddx = lddx;
+}
+
+int launch_rowbwd(RowBwdArgs& a, int nnet, hipStream_t s) {
+  static bool configured = false;
+  const size_t smem = rowbwd_smem_bytes();
+  if (!configured) {
+    int rc = set_max_smem(mlp_rowbwd_kernel, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  hipLaunchKernelGGL(mlp_rowbwd_kernel, dim3((unsigned)ceil_div(a.B, RP_ROWS), (unsigned)nnet),
+                     dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+}  // namespace
 
 // out = W_L-1(relu(... relu(W_0 x + b_0) ...)) + b_L-1.  keep = 1 retains the hidden activations for
 // pa_mlp_backward (one kept forward at a time).
@@ -170,6 +288,19 @@ extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int
   PA_REQUIRE(P, PA_ERR_INVALID, "no target parameters bound");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipSetDevice(h->d.device));
+  if (h->row_ok) {
+    // the whole network in one launch (mlp_rowpass.hpp)
+    int rc = ensure_packed(h, use_target != 0, s);
+    if (rc != PA_OK) return rc;
+    RowFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_fwd(h, use_target != 0, out, ldo, keep != 0, a.net[0]);
+    a.x = x; a.ldx = ldx; a.B = B;
+    rc = launch_rowfwd(a, 1, h->d.dims[0], s);
+    if (rc != PA_OK) return rc;
+    h->kept_B = keep ? B : 0;
+    return PA_OK;
+  }
   const float* in = x;
   int ldin = ldx;
   for (int l = 0; l < h->L; ++l) {
@@ -223,7 +354,22 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
   int ldzs[PA_MLP_MAX_LAYERS];
   dzs[h->L - 1] = d_out;
   ldzs[h->L - 1] = ldd;
-  for (int l = h->L - 1; l >= 0; --l) {
+  if (h->row_ok && (h->L > 1 || d_x)) {
+    // pre-activation gradients of every layer (and d_x) in one launch
+    int rc = ensure_packed(h, false, s);
+    if (rc != PA_OK) return rc;
+    RowBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    fill_bwd(h, d_out, ldd, d_x, lddx, a.net[0]);
+    a.B = B;
+    rc = launch_rowbwd(a, 1, s);
+    if (rc != PA_OK) return rc;
+    for (int l = h->L - 1; l > 0; --l) {
+      dzs[l - 1] = h->dz[l];
+      ldzs[l - 1] = h->d.dims[l];
+    }
+  }
+  for (int l = h->L - 1; l >= 0 && !h->row_ok; --l) {
     if (l > 0 || d_x) {
       // dIn = dZ W_l (masked by relu'(in) for hidden inputs)
       GemmArgs g;
@@ -365,6 +511,21 @@ extern "C" int pa_mlp_forward2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipSetDevice(h1->d.device));
+  if (h1->row_ok && h2->row_ok) {
+    // both networks, every layer: one launch (blockIdx.y = network)
+    RowFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int i = 0; i < 2; ++i) {
+      rc = ensure_packed(hs[i], use_target != 0, s);
+      if (rc != PA_OK) return rc;
+      fill_fwd(hs[i], use_target != 0, outs[i], ldos[i], keep != 0, a.net[i]);
+    }
+    a.x = x; a.ldx = ldx; a.B = B;
+    rc = launch_rowfwd(a, 2, h1->d.dims[0], s);
+    if (rc != PA_OK) return rc;
+    h1->kept_B = h2->kept_B = keep ? B : 0;
+    return PA_OK;
+  }
   for (int l = 0; l < h1->L; ++l) {
     const bool last = (l == h1->L - 1);
     GemmArgs g[2];
@@ -406,7 +567,26 @@ extern "C" int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t 
   int ldzs[2][PA_MLP_MAX_LAYERS];
   dzs[0][L - 1] = d_out1; ldzs[0][L - 1] = ldd1;
   dzs[1][L - 1] = d_out2; ldzs[1][L - 1] = ldd2;
-  for (int l = L - 1; l >= 0; --l) {
+  const bool rowp = h1->row_ok && h2->row_ok;
+  if (rowp && (L > 1 || d_x1)) {
+    RowBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    const float* douts[2] = {d_out1, d_out2};
+    const int ldds[2] = {ldd1, ldd2};
+    for (int i = 0; i < 2; ++i) {
+      rc = ensure_packed(hs[i], false, s);
+      if (rc != PA_OK) return rc;
+      fill_bwd(hs[i], douts[i], ldds[i], dxs[i], lddx, a.net[i]);
+      for (int l = L - 1; l > 0; --l) {
+        dzs[i][l - 1] = hs[i]->dz[l];
+        ldzs[i][l - 1] = hs[i]->d.dims[l];
+      }
+    }
+    a.B = B;
+    rc = launch_rowbwd(a, 2, s);
+    if (rc != PA_OK) return rc;
+  }
+  for (int l = L - 1; l >= 0 && !rowp; --l) {
     if (l > 0 || d_x1) {
       GemmArgs g[2];
       memset(g, 0, sizeof(g));
@@ -489,6 +669,7 @@ extern "C" int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream) {
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
+  h->packed_ok = false;
   return PA_OK;
 }
 
@@ -500,6 +681,7 @@ extern "C" int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream) {
                      reinterpret_cast<hipStream_t>(stream), h->bufs.p_target, h->bufs.p, h->P, tau,
                      (float)(1.0 - (double)tau));
   PA_LAUNCH_CHECK();
+  h->packed_t_ok = false;
   return PA_OK;
 }
 

@@ -140,6 +140,9 @@ class FlatMlp:
             self.max_batch = max_b
         if self._sig and self._sig == self._signature():
             self._steps = self.adam_steps()
+            # same storage, but its CONTENTS may have been written through torch since the last
+            # step (load_state_dict copies in place): derived copies are rebuilt on next use
+            N.check(N.lib().pa_mlp_invalidate(self.handle))
             return self
         # ---- flatten
         P = int(N.lib().pa_mlp_param_count(C.byref(self._desc)))

@@ -1,6 +1,8 @@
 #!/bin/bash
-# GPU round: gpu test-suite, smoke, bench (stage timers, serial loop), bench (headline + cpu baseline),
-# rocprofv3 kernel trace of the same command; "pmc" as $1 adds the three counter passes.
+# GPU round: gpu test-suite, smoke, the driver's own bench command (20 steps), the long bench with
+# the CPU baseline, per-call fixed cost of learn(), bench_algos, rocprofv3 kernel trace + timeline
+# of the driver's command; "pmc" as $1 adds the counter passes.  Everything lands in gpurun_out/;
+# copy what should be judged into profiles/ (tracked).
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
 cd $R
@@ -10,13 +12,17 @@ echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
 fi
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2>&1
+echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | cut -c1-1400
+timeout 900 python bench.py $BENCH_ARGS > gpurun_out/bench.log 2>&1
+echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-1400
 PEARL_AMD_OVERLAP=0 timeout 600 python bench.py --timing-level 2 --no-cpu-baseline > gpurun_out/bench_l2.log 2>&1
 echo "bench l2 rc=$?"; tail -1 gpurun_out/bench_l2.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('stage_us'))"
-timeout 900 python bench.py $BENCH_ARGS > gpurun_out/bench.log 2>&1
-echo "bench rc=$?"; tail -1 gpurun_out/bench.log
+timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
 if [ "$SKIP_ALGOS" != "1" ]; then
 timeout 600 python bench_algos.py --steps 300 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
-echo "bench_algos rc=$?"; cut -c1-260 gpurun_out/bench_algos.jsonl
+echo "bench_algos rc=$?"; cut -c1-300 gpurun_out/bench_algos.jsonl
 fi
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof
@@ -26,6 +32,12 @@ python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db > $R/gpurun_o
 python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_fused 40 >> $R/gpurun_out/kernel_stats.txt 2>&1
 head -12 $R/gpurun_out/kernel_stats.txt
 rm -f $R/gpurun_out/prof/*.db
+rm -rf $R/gpurun_out/prof_sc
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_timeline.txt 2>&1
+head -3 $R/gpurun_out/shortcall_timeline.txt
+rm -f $DB
 if [ "$1" == "pmc" ]; then
   export PEARL_AMD_OVERLAP=0
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
