@@ -291,7 +291,8 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* 
 // U (= W1s' s' + b1' of the same rows) must already be computed.
 int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
                        hipStream_t s, bool persistent = false, int* argmax = nullptr,
-                       bool sample_timer = true, bool no_pingpong = false) {
+                       bool sample_timer = true, bool no_pingpong = false,
+                       int prio_first_rows = 0) {
   // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
   // maximum (Double DQN's action choice); always the classic grid
   const pa_dqn_desc& d = h->d;
@@ -319,6 +320,7 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
+  if (prio_first_rows > 0) a.prio_tiles = (int)ceil_div(prio_first_rows, a.bpw);
   const bool pp = !argmax && !no_pingpong &&
                   (h->pingpong == 2 || (h->pingpong == 1 && persistent));
   if (persistent || pp) {
@@ -1200,8 +1202,10 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // the two-workgroups-per-CU kernel that stay off the reserved CUs, like the remainder.
       const bool last = pc == npieces - 1;
       const bool lead_p = !last && h->lead_persist && persist;
+      static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
-                              nullptr, (k % 4) == 0 && last, lead_p);
+                              nullptr, (k % 4) == 0 && last, lead_p,
+                              (prio && pc == 0 && !last) ? B : 0);
       if (rc != PA_OK) return rc;
       j0 += nj;
     }
@@ -1288,6 +1292,16 @@ extern "C" int pa_dqn_enable_timing(pa_dqn* h, int32_t on) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   h->timing = on < 0 ? 0 : on;
   for (auto& t : h->timers) { t.used = 0; t.units = 0; }
+  if (h->timing >= 1) {
+    // the level-1 timer's events exist before the timed call starts (hipEventCreate inside it cost
+    // tens of microseconds of a 20-round learn())
+    Timer* t = find_timer(h, "target");
+    while (t->ev.size() < 64) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) break;
+      t->ev.push_back(e);
+    }
+  }
   return PA_OK;
 }
 

@@ -339,6 +339,9 @@ struct TargetArgs {
   float* choice_rep;         // with argmax: [B][AD] = feat row of that action (double_dqn.py:48-51)
   float* q_all;              // optional [B * A]: every (transition, action) value before masking
                              // (TwinCritic.get_q_values on an action set, discrete SAC)
+  int prio_tiles;            // classic grid: tiles below this index run at raised wave priority (the
+                             // first round of a window, whose targets the online chain waits for,
+                             // shares every CU with a later round's tile)
 };
 
 // (XCC_ID, HW_ID.se_id|sh_id|cu_id) of the compute unit the calling wave runs on
@@ -662,6 +665,7 @@ template <int NKG, bool FAST>
 static __global__ __launch_bounds__(512, 4) void target_fused_kernel(TargetArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (a.tile_ctr == nullptr) {
+    if ((int)blockIdx.x < a.prio_tiles) __builtin_amdgcn_s_setprio(3);
     target_tile<NKG, FAST>(a, blockIdx.x, smem);
     return;
   }

@@ -109,7 +109,14 @@ def test_sac_sampled_action_logprob_qvalues(name):
     _, _, logp = pl._sample(actor, b.state.contiguous(), xa, keep=False)
     # (atol 2e-6: (tanh(u) + 1) cancels near the lower edge of the action box)
     torch.testing.assert_close(xa[:, S:].cpu(), fx["probe"]["action"], rtol=1e-5, atol=2e-6)
-    torch.testing.assert_close(logp.cpu(), fx["probe"]["log_prob"], rtol=1e-5, atol=2e-5)
+    # log pi contains -log(bound (1 - tanh(u)^2) + 1e-6): where a component saturates, one ulp of
+    # u moves it by ~2e-7 / (1 - n^2 + 1e-6) — the reference's own value is no better determined
+    # there.  Tolerance per row from the fixture's normalised actions (ulp of |u| <= 8 ~ 5e-7).
+    n = ((fx["probe"]["action"] - fx["low"]) / (fx["high"] - fx["low"])) * 2 - 1
+    cond = (2e-6 / (1 - n.pow(2) + 1e-6)).sum(dim=1)
+    err = (logp.cpu() - fx["probe"]["log_prob"]).abs()
+    allowed = 2e-5 + 1e-5 * fx["probe"]["log_prob"].abs() + cond
+    assert bool((err <= allowed).all()), (float(err.max()), int(err.argmax()), float(allowed[err.argmax()]))
     torch.testing.assert_close(c1.forward(xa).view(-1).cpu(), fx["probe"]["q1"], rtol=1e-5, atol=2e-6)
     torch.testing.assert_close(c2.forward(xa).view(-1).cpu(), fx["probe"]["q2"], rtol=1e-5, atol=2e-6)
 
