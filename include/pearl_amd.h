@@ -383,7 +383,11 @@ int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int32_t ldx, i
                    float* out, int32_t ldo, int32_t keep, void* stream);
 /* kept output (after ReLU) of hidden layer `layer` of the last keep = 1 forward */
 int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int32_t ldo, void* stream);
-/* autograd of the kept forward: dW/db into bufs.grad (want_dw) and/or d_x[B, d_0] (nullable). */
+/* autograd of the kept forward: d_x[B, d_0] (nullable) and the weight gradients dW/db into
+ * bufs.grad — want_dw 0: none; 1: now; 2: DEFERRED to the next pa_mlp_adam on this network, which
+ * then runs dW, AdamW and the refresh of the row-pass kernels' packed weights as ONE launch per
+ * three layers (x and d_out must stay valid until then), or to pa_mlp_flush_grads (weight gradients
+ * only: a data-parallel step all-reduces bufs.grad before AdamW). */
 int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
                     int32_t ldd, int32_t want_dw, float* d_x, int32_t lddx, void* stream);
 /* Q(s_b, a_i) of a [S + AD, H1, H2, 1] ReLU critic for every action of an action set,
@@ -406,6 +410,7 @@ int pa_mlp_forward2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const float* x, 
 int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t ldx, int32_t B,
                      const float* d_out1, int32_t ldd1, const float* d_out2, int32_t ldd2,
                      int32_t want_dw, float* d_x1, float* d_x2, int32_t lddx, void* stream);
+int pa_mlp_flush_grads(pa_mlp* h, void* stream);
 int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream);
 /* update_target_network (common/utils.py:214-226) */
 int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);

@@ -834,7 +834,11 @@ struct DwProblem {
   float* dW; int ldw;         // [M][N]
   float* db;                  // [M]
   int M, N, tiles_n, tile0;
-  int kind;                   // 0: W2, 1: W1, 2: w3 (which packed copies a parameter feeds)
+  int kind;                   // 0: W2, 1: W1, 2: w3 (which packed copies a parameter feeds);
+                              // 3: a layer of the generic engine, packed copies below
+  float* pkf; int nkgf;       // kind 3: fragment-major W [M units][N]  (wf16 layout) or null
+  float* pktf; int nkgtf;     // kind 3: fragment-major W^T [N units][M] or null
+  int bias_frozen;            // the bias slot is not a parameter (bias-free layer): no AdamW on db
 };
 struct DwArgs {
   DwProblem p[3];
@@ -869,6 +873,11 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
     f.tgt[i] = t;
     if (kind == 0) f.tW2f[w2f_index(row, col, f.nkg_t)] = t;
   }
+}
+// kind 3: refresh the generic engine's fragment-major copies of one weight element
+__device__ __forceinline__ void pack_generic(const DwProblem& P, int row, int col, float p) {
+  if (P.pkf) P.pkf[wf16_index_(row, col, P.nkgf)] = p;
+  if (P.pktf) P.pktf[wf16_index_(col, row, P.nkgtf)] = p;
 }
 __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, float g) {
   const float p = adam_update(f.c, f.st, i, g);
@@ -1043,14 +1052,17 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
       for (int w = 1; w < 16; ++w) g += part[w * 32 + tid];
       float* dst = P.dW + col;
       *dst = g;
-      if (a.ad.enabled) adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, 0, col, g);
+      if (a.ad.enabled) {
+        if (P.kind == 3) pack_generic(P, 0, col, adam_update(a.ad.c, a.ad.st, dst - a.ad.grad_base, g));
+        else adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, 0, col, g);
+      }
     }
     if (j0 == 0 && tid == 0) {
       float g = csum[0];
 #pragma unroll
       for (int w = 1; w < 16; ++w) g += csum[w];
       P.db[0] = g;
-      if (a.ad.enabled) adam_fused_bias(a.ad, P.db - a.ad.grad_base, g);
+      if (a.ad.enabled && !P.bias_frozen) adam_fused_bias(a.ad, P.db - a.ad.grad_base, g);
     }
     return;
   }
@@ -1212,6 +1224,12 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
           for (int e = 0; e < 4; ++e) a.ad.W2tf[wf16_index_(ecol + e, erow, a.ad.nkg_w2t)] = pv[e];
         } else if (P.kind == 1) {
           *reinterpret_cast<float4*>(a.ad.W1f + wf16_index_(erow, ecol, a.ad.nkg_w1)) = pn;
+        } else if (P.kind == 3) {
+          if (P.pkf) *reinterpret_cast<float4*>(P.pkf + wf16_index_(erow, ecol, P.nkgf)) = pn;
+          if (P.pktf) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) P.pktf[wf16_index_(ecol + e, erow, P.nkgtf)] = pv[e];
+          }
         }
         if (a.ad.soft_next) {  // update_target_network (common/utils.py:214-226)
           const float4 t4 = *reinterpret_cast<const float4*>(a.ad.tgt + eflat);
@@ -1231,8 +1249,12 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
         if (ecol + e < P.N) {
           float* dst = P.dW + (int64_t)erow * P.ldw + ecol + e;
           *dst = g4[e];
-          if (a.ad.enabled)
-            adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, erow, ecol + e, g4[e]);
+          if (a.ad.enabled) {
+            if (P.kind == 3)
+              pack_generic(P, erow, ecol + e, adam_update(a.ad.c, a.ad.st, dst - a.ad.grad_base, g4[e]));
+            else
+              adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, erow, ecol + e, g4[e]);
+          }
         }
       }
     }
@@ -1242,7 +1264,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
     for (int w = 1; w < 8; ++w) s += csum[w * DW_TM + tid];
     P.db[i0 + tid] = s;
-    if (a.ad.enabled) adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
+    if (a.ad.enabled && !P.bias_frozen) adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 15);

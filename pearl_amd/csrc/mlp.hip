@@ -48,6 +48,13 @@ struct pa_mlp {
   float* wtf[PA_MLP_MAX_LAYERS];
   float* wf_t[PA_MLP_MAX_LAYERS];
   bool packed_ok, packed_t_ok;
+  // weight gradients deferred to pa_mlp_adam (want_dw = 2): the operands of the kept backward
+  struct Pending {
+    bool active;
+    const float* x; int ldx; int B;
+    const float* dzs[PA_MLP_MAX_LAYERS];
+    int ldzs[PA_MLP_MAX_LAYERS];
+  } pend;
 };
 
 namespace {
@@ -336,6 +343,67 @@ extern "C" int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float
   return PA_OK;
 }
 
+namespace {
+
+// dW/db of every layer of ONE network (three layers per launch).  adam_step > 0: the workgroup
+// that finishes a tile also applies AdamW(amsgrad) to it and refreshes the fragment-major copies
+// the row-pass kernels read (the DQN treatment: no AdamW launch, no repack launch).
+int run_weight_grads(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
+                     const int* ldzs, int64_t adam_step, hipStream_t s) {
+  for (int l0 = 0; l0 < h->L; l0 += 3) {
+    DwArgs a;
+    memset(&a, 0, sizeof(a));
+    int t0 = 0;
+    for (int l = l0; l < h->L && l < l0 + 3; ++l) {
+      DwProblem& pr = a.p[a.nprob++];
+      pr.dZ = dzs[l]; pr.ldz = ldzs[l];
+      pr.X = l > 0 ? h->act[l - 1] : x;
+      pr.ldx = l > 0 ? h->d.dims[l] : ldx;
+      pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
+      // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias
+      // slot: its column sums go to scratch so AdamW never moves it
+      const bool frozen = (l == h->L - 1 && h->d.no_last_bias);
+      pr.db = frozen ? h->db_scratch : h->bufs.grad + h->boff[l];
+      pr.bias_frozen = frozen ? 1 : 0;
+      pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
+      pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
+      pr.tile0 = t0;
+      pr.kind = 2;
+      if (adam_step > 0) {
+        pr.kind = 3;
+        if (h->row_ok) {
+          pr.pkf = h->wf[l]; pr.nkgf = wf16_nkg(h->d.dims[l]);
+          pr.pktf = h->wtf[l]; pr.nkgtf = wf16_nkg(h->d.dims[l + 1]);
+        }
+      }
+      t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
+    }
+    a.total_tiles = t0;
+    a.B = B;
+    if (adam_step > 0) {
+      a.ad.enabled = 1;
+      a.ad.c = adam_scalars(h->d, adam_step);
+      a.ad.st.p = h->bufs.p; a.ad.st.m = h->bufs.exp_avg; a.ad.st.v = h->bufs.exp_avg_sq;
+      a.ad.st.vmax = h->bufs.max_exp_avg_sq;
+      a.ad.grad_base = h->bufs.grad;
+    }
+    int rc = launch_weight_grad(a, false, s);
+    if (rc != PA_OK) return rc;
+  }
+  return PA_OK;
+}
+
+void set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs, const int* ldzs) {
+  h->pend.active = true;
+  h->pend.x = x; h->pend.ldx = ldx; h->pend.B = B;
+  for (int l = 0; l < h->L; ++l) {
+    h->pend.dzs[l] = dzs[l];
+    h->pend.ldzs[l] = ldzs[l];
+  }
+}
+
+}  // namespace
+
 // Backward of the kept forward.  d_out[B, d_L] is the gradient w.r.t. the network output.
 // want_dw: write dW/db of every layer into bufs.grad.  d_x (nullable): gradient w.r.t. the input.
 extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const float* d_out,
@@ -393,33 +461,10 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       }
     }
   }
-  // ---- then the weight gradients of up to three layers per launch (their tiles run side by side)
-  if (want_dw) {
-    for (int l0 = 0; l0 < h->L; l0 += 3) {
-      DwArgs a;
-      memset(&a, 0, sizeof(a));
-      int t0 = 0;
-      for (int l = l0; l < h->L && l < l0 + 3; ++l) {
-        DwProblem& pr = a.p[a.nprob++];
-        pr.dZ = dzs[l]; pr.ldz = ldzs[l];
-        pr.X = l > 0 ? h->act[l - 1] : x;
-        pr.ldx = l > 0 ? h->d.dims[l] : ldx;
-        pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
-        // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias
-        // slot: its column sums go to scratch so AdamW never moves it
-        pr.db = (l == h->L - 1 && h->d.no_last_bias) ? h->db_scratch : h->bufs.grad + h->boff[l];
-        pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
-        pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
-        pr.tile0 = t0;
-        pr.kind = 2;
-        t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
-      }
-      a.total_tiles = t0;
-      a.B = B;
-      int rcw = launch_weight_grad(a, false, s);
-      if (rcw != PA_OK) return rcw;
-    }
-  }
+  // ---- then the weight gradients (three layers per launch), now or — want_dw = 2 — together with
+  // AdamW in pa_mlp_adam
+  if (want_dw == 2) set_pending(h, x, ldx, B, dzs, ldzs);
+  else if (want_dw) return run_weight_grads(h, x, ldx, B, dzs, ldzs, 0, s);
   return PA_OK;
 }
 
@@ -612,44 +657,26 @@ extern "C" int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t 
       if (rc != PA_OK) return rc;
     }
   }
-  if (want_dw) {
-    // 2 L problems, three per launch
-    DwArgs a;
-    memset(&a, 0, sizeof(a));
-    int t0 = 0;
-    auto flush = [&]() -> int {
-      if (a.nprob == 0) return PA_OK;
-      a.total_tiles = t0;
-      a.B = B;
-      int r = launch_weight_grad(a, false, s);
-      memset(&a, 0, sizeof(a));
-      t0 = 0;
-      return r;
-    };
-    for (int i = 0; i < 2; ++i) {
-      pa_mlp* h = hs[i];
-      for (int l = 0; l < L; ++l) {
-        DwProblem& pr = a.p[a.nprob++];
-        pr.dZ = dzs[i][l]; pr.ldz = ldzs[i][l];
-        pr.X = l > 0 ? h->act[l - 1] : x;
-        pr.ldx = l > 0 ? h->d.dims[l] : ldx;
-        pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
-        pr.db = (l == L - 1 && h->d.no_last_bias) ? h->db_scratch : h->bufs.grad + h->boff[l];
-        pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
-        pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
-        pr.tile0 = t0;
-        pr.kind = 2;
-        t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
-        if (a.nprob == 3) {
-          rc = flush();
-          if (rc != PA_OK) return rc;
-        }
-      }
+  for (int i = 0; i < 2 && want_dw; ++i) {
+    if (want_dw == 2) {
+      set_pending(hs[i], x, ldx, B, dzs[i], ldzs[i]);
+    } else {
+      rc = run_weight_grads(hs[i], x, ldx, B, dzs[i], ldzs[i], 0, s);
+      if (rc != PA_OK) return rc;
     }
-    rc = flush();
-    if (rc != PA_OK) return rc;
   }
   return PA_OK;
+}
+
+// Weight gradients a want_dw = 2 backward left pending, without the optimizer (data parallel: the
+// gradient is all-reduced before AdamW).
+extern "C" int pa_mlp_flush_grads(pa_mlp* h, void* stream) {
+  PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "mlp has no bound parameter buffers");
+  if (!h->pend.active) return PA_OK;
+  PA_HIP(hipSetDevice(h->d.device));
+  h->pend.active = false;
+  return run_weight_grads(h, h->pend.x, h->pend.ldx, h->pend.B, h->pend.dzs, h->pend.ldzs, 0,
+                          reinterpret_cast<hipStream_t>(stream));
 }
 
 // optim.AdamW(amsgrad) step `step` (1-based) on bufs.grad.
@@ -659,6 +686,13 @@ extern "C" int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream) {
   PA_REQUIRE(!h->d.amsgrad || h->bufs.max_exp_avg_sq, PA_ERR_INVALID, "amsgrad needs max_exp_avg_sq");
   PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1");
   PA_HIP(hipSetDevice(h->d.device));
+  if (h->pend.active) {
+    // the kept backward's weight gradients and this step in one pass; the fragment-major copies
+    // stay current (refreshed by the same epilogue) if they were current before
+    h->pend.active = false;
+    return run_weight_grads(h, h->pend.x, h->pend.ldx, h->pend.B, h->pend.dzs, h->pend.ldzs, step,
+                            reinterpret_cast<hipStream_t>(stream));
+  }
   AdamArgs a;
   memset(&a, 0, sizeof(a));
   a.st.p = h->bufs.p; a.st.m = h->bufs.exp_avg; a.st.v = h->bufs.exp_avg_sq;
@@ -677,6 +711,22 @@ extern "C" int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream) {
 extern "C" int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream) {
   PA_REQUIRE(h && h->bound && h->bufs.p_target, PA_ERR_INVALID, "no target parameters bound");
   PA_HIP(hipSetDevice(h->d.device));
+  if (h->row_ok && h->packed_t_ok) {
+    RowSoftArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tgt = h->bufs.p_target; a.src = h->bufs.p; a.n = h->P;
+    a.tau = tau; a.one_minus_tau = (float)(1.0 - (double)tau);
+    a.L = h->L;
+    for (int l = 0; l <= h->L; ++l) a.dims[l] = h->d.dims[l];
+    for (int l = 0; l < h->L; ++l) {
+      a.woff[l] = h->woff[l];
+      a.Wf[l] = h->wf_t[l];
+    }
+    hipLaunchKernelGGL(mlp_soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+    PA_LAUNCH_CHECK();
+    return PA_OK;     // the target's packed copies were refreshed in place
+  }
   hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), h->bufs.p_target, h->bufs.p, h->P, tau,
                      (float)(1.0 - (double)tau));

@@ -234,4 +234,30 @@ static __global__ __launch_bounds__(256) void mlp_rowpack_kernel(RowPackArgs a) 
   }
 }
 
+// theta' <- tau theta + (1 - tau) theta' (common/utils.py:214-226) with the target's fragment-major
+// copies refreshed in the same pass (no repack launch before the next target forward).
+struct RowSoftArgs {
+  float* tgt; const float* src;
+  int64_t n;
+  float tau, one_minus_tau;
+  int64_t woff[ROW_MAX_LAYERS];
+  int dims[ROW_MAX_LAYERS + 1];
+  int L;
+  float* Wf[ROW_MAX_LAYERS];           // target packed copies, or all null
+};
+static __global__ __launch_bounds__(256) void mlp_soft_update_kernel(RowSoftArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  const float t = __fadd_rn(__fmul_rn(a.tau, a.src[i]), __fmul_rn(a.one_minus_tau, a.tgt[i]));
+  a.tgt[i] = t;
+  for (int l = 0; l < a.L; ++l) {
+    const int64_t e = i - a.woff[l];
+    if (a.Wf[l] && e >= 0 && e < (int64_t)a.dims[l + 1] * a.dims[l]) {
+      const int row = (int)(e / a.dims[l]), col = (int)(e - (int64_t)row * a.dims[l]);
+      a.Wf[l][wf16_index(row, col, wf16_nkg(a.dims[l]))] = t;
+      break;
+    }
+  }
+}
+
 }  // namespace pa

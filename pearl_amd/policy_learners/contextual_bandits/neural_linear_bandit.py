@@ -177,7 +177,7 @@ class NeuralLinearBandit(PolicyLearner):
                 dist.all_reduce(ws)
             skip = float(ws.item()) == 0.0
         if not skip:
-            net.backward(x, dpred, want_dw=True)
+            net.backward(x, dpred, want_dw=True, defer=True)
             net.adam()
         # ---- LinUCB update on the detached features
         xs = torch.empty(B * D + D, dtype=torch.float32, device=dev)

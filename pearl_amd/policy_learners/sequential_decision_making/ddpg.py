@@ -137,7 +137,7 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         N.check(N.lib().pa_tanh_action_grad(head.data_ptr(), head.stride(0), low.data_ptr(),
                                             high.data_ptr(), da.data_ptr(), dx.stride(0), B, A,
                                             d_head.data_ptr(), d_head.stride(0), s))
-        actor.backward(state, d_head, want_dw=True)
+        actor.backward(state, d_head, want_dw=True, defer=True)
         actor.adam()
         return loss[0]
 
@@ -180,7 +180,7 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         for i in range(2):
             N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
                                         dqs[i].data_ptr(), loss.data_ptr(), s))
-        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
         c1.adam()
         c2.adam()
         return loss[0]

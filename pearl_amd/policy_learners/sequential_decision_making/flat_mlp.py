@@ -141,8 +141,11 @@ class FlatMlp:
         if self._sig and self._sig == self._signature():
             self._steps = self.adam_steps()
             # same storage, but its CONTENTS may have been written through torch since the last
-            # step (load_state_dict copies in place): derived copies are rebuilt on next use
-            N.check(N.lib().pa_mlp_invalidate(self.handle))
+            # step (load_state_dict copies in place; every in-place torch op bumps the tensor's
+            # version counter, our own kernels do not): derived copies are rebuilt on next use
+            if self._flat_versions() != getattr(self, "_versions", None):
+                N.check(N.lib().pa_mlp_invalidate(self.handle))
+                self._versions = self._flat_versions()
             return self
         # ---- flatten
         P = int(N.lib().pa_mlp_param_count(C.byref(self._desc)))
@@ -192,7 +195,12 @@ class FlatMlp:
         self.flat = flat
         self._sig = self._signature()
         self._steps = steps
+        self._versions = self._flat_versions()
+        self._pending_x = None
         return self
+
+    def _flat_versions(self) -> Tuple:
+        return tuple(t._version for k, t in self.flat.items() if k in ("p", "p_target"))
 
     def ready(self, batch: int = 0) -> "FlatMlp":
         """The per-launch check: a bound handle large enough for `batch`.  Whether the torch
@@ -219,12 +227,24 @@ class FlatMlp:
                                        N.stream_ptr(x.device)))
         return out
 
+    def _dw_mode(self, want_dw: bool, defer: bool, x: torch.Tensor, d_out: torch.Tensor) -> int:
+        """0: no weight gradients; 1: now; 2: deferred to adam(), where ONE launch per three layers
+        does dW, AdamW and the refresh of the row-pass kernels' packed weights (single process
+        only: a data-parallel step all-reduces the gradient between the two)."""
+        if not want_dw:
+            return 0
+        if defer:
+            self._pending_x = (x, d_out)     # both operands must outlive the deferred launch
+            return 2
+        return 1
+
     def backward(self, x: torch.Tensor, d_out: torch.Tensor, want_dw: bool = True,
-                 want_dx: bool = False) -> Optional[torch.Tensor]:
+                 want_dx: bool = False, defer: bool = False) -> Optional[torch.Tensor]:
         B = int(x.shape[0])
         d_x = torch.empty(B, self.dims[0], dtype=torch.float32, device=x.device) if want_dx else None
         N.check(N.lib().pa_mlp_backward(self.handle, x.data_ptr(), x.stride(0), B, d_out.data_ptr(),
-                                        d_out.stride(0) if d_out.ndim == 2 else 1, int(want_dw),
+                                        d_out.stride(0) if d_out.ndim == 2 else 1,
+                                        self._dw_mode(want_dw, defer, x, d_out),
                                         N.ptr(d_x), self.dims[0], N.stream_ptr(x.device)))
         return d_x
 
@@ -265,8 +285,11 @@ class FlatMlp:
 
     @staticmethod
     def backward_pair(m1: "FlatMlp", m2: "FlatMlp", x: torch.Tensor, d1: torch.Tensor,
-                      d2: torch.Tensor, want_dw: bool = True, want_dx: bool = False):
+                      d2: torch.Tensor, want_dw: bool = True, want_dx: bool = False,
+                      defer: bool = False):
         B = int(x.shape[0])
+        mode = m1._dw_mode(want_dw, defer, x, d1)
+        m2._dw_mode(want_dw, defer, x, d2)
         dx1 = dx2 = None
         if want_dx:
             dx1 = torch.empty(B, m1.dims[0], dtype=torch.float32, device=x.device)
@@ -274,7 +297,7 @@ class FlatMlp:
         N.check(N.lib().pa_mlp_backward2(
             m1.handle, m2.handle, x.data_ptr(), x.stride(0), B, d1.data_ptr(),
             d1.stride(0) if d1.ndim == 2 else 1, d2.data_ptr(), d2.stride(0) if d2.ndim == 2 else 1,
-            int(want_dw), N.ptr(dx1), N.ptr(dx2), m1.dims[0], N.stream_ptr(x.device)))
+            mode, N.ptr(dx1), N.ptr(dx2), m1.dims[0], N.stream_ptr(x.device)))
         return dx1, dx2
 
     def adam(self, reduce: str = "mean") -> None:
@@ -287,11 +310,18 @@ class FlatMlp:
         optimizer step.  ``reduce`` says how the loss aggregates over the global batch: "mean"
         (MSE / SAC losses: average of the rank gradients) or "sum" (PPO's summed clipped surrogate,
         ppo.py:152-183: plain sum).  With one rank this is exactly the single-GPU step."""
-        reduce_gradient_(self.flat["grad"], reduce)
+        stream = N.stream_ptr(self.flat["p"].device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # the all-reduce needs the local gradient first: deferred weight gradients run now,
+            # without the fused optimizer
+            N.check(N.lib().pa_mlp_flush_grads(self.handle, stream))
+            reduce_gradient_(self.flat["grad"], reduce)
         step = self._steps + 1
-        N.check(N.lib().pa_mlp_adam(self.handle, step, N.stream_ptr(self.flat["p"].device)))
+        N.check(N.lib().pa_mlp_adam(self.handle, step, stream))
+        self._pending_x = None
         self._set_adam_steps(step)
         self._steps = step
+        self._versions = self._flat_versions()     # our own kernels wrote the buffers: not "external"
 
     def soft_update(self, tau: float) -> None:
         self.ready()

@@ -112,7 +112,7 @@ class VanillaOps(_Ops):
         return self.net.forward(self._x, keep=True).view(-1)
 
     def backward(self, dq: Tensor) -> None:
-        self.net.backward(self._x, dq, want_dw=True)
+        self.net.backward(self._x, dq, want_dw=True, defer=True)
 
     def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
         B, A = state.shape[0], int(rep.shape[-2])
@@ -153,7 +153,7 @@ class MultiHeadOps(_Ops):
         df = _new(st.device, B, self.A)
         N.check(N.lib().pa_rows_scale(dq.data_ptr(), act.data_ptr(), act.stride(0), B, self.A,
                                       df.data_ptr(), df.stride(0), N.stream_ptr(st.device)))
-        self.net.backward(st, df, want_dw=True)
+        self.net.backward(st, df, want_dw=True, defer=True)
 
     def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
         B, Q = state.shape[0], int(rep.shape[-2])
@@ -210,11 +210,11 @@ class DuelingOps(_Ops):
         lib, s = N.lib(), N.stream_ptr(dev)
         d_adv = _new(dev, B * (1 + M))
         N.check(lib.pa_dueling_grad(dq.data_ptr(), B, M, d_adv.data_ptr(), s))
-        dx_adv = self.adv_net.backward(k["x_adv"], d_adv, want_dw=True, want_dx=True)
-        dfeat = self.value_net.backward(k["feats"], dq, want_dw=True, want_dx=True)   # (B, H)
+        dx_adv = self.adv_net.backward(k["x_adv"], d_adv, want_dw=True, want_dx=True, defer=True)
+        dfeat = self.value_net.backward(k["feats"], dq, want_dw=True, want_dx=True, defer=True)   # (B, H)
         N.check(lib.pa_dueling_feat_grad(dx_adv.data_ptr(), dx_adv.stride(0), B, M, self.H, 1,
                                          dfeat.data_ptr(), dfeat.stride(0), s))
-        self.state_net.backward(k["state"], dfeat, want_dw=True)
+        self.state_net.backward(k["state"], dfeat, want_dw=True, defer=True)
 
     def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
         """get_q_values(state, actions (B, Q, AD)) with no separate available-action set: the mean

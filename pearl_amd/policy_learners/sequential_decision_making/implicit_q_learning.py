@@ -210,9 +210,9 @@ class ImplicitQLearning(ActorCriticBase):
                                     adv.data_ptr(), B, A, d_head.data_ptr(), d_head.stride(0),
                                     losses[2:].data_ptr(), s))
         # ---- one backward, then the steps in the reference's order (:171-176), target update
-        value.backward(state, dv, want_dw=True)
-        actor.backward(state, d_head, want_dw=True)
-        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        value.backward(state, dv, want_dw=True, defer=True)
+        actor.backward(state, d_head, want_dw=True, defer=True)
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
         value.adam()
         actor.adam()
         c1.adam()

@@ -160,7 +160,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
             self._f32(batch.action_probs, dev).data_ptr(), self._f32(batch.gae, dev).data_ptr(),
             B, A, float(self._epsilon), float(self._entropy_bonus_scaling), d_logits.data_ptr(),
             d_logits.stride(0), loss.data_ptr(), N.stream_ptr(dev)))
-        actor.backward(state, d_logits, want_dw=True)
+        actor.backward(state, d_logits, want_dw=True, defer=True)
         actor.adam(reduce="sum")   # the surrogate is a SUM over the (global) minibatch
         return loss[0]
 
@@ -176,7 +176,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
         N.check(N.lib().pa_mse_head(v.data_ptr(), v.stride(0),
                                     self._f32(batch.lam_return, dev).data_ptr(), B, 2.0 / B, 1.0, 0,
                                     dv.data_ptr(), loss.data_ptr(), N.stream_ptr(dev)))
-        critic.backward(state, dv, want_dw=True)
+        critic.backward(state, dv, want_dw=True, defer=True)
         critic.adam()
         return loss[0]
 
@@ -208,7 +208,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
         N.check(N.lib().pa_mse_head(v.data_ptr(), v.stride(0),
                                     self._f32(batch.lam_return, dev).data_ptr(), B, 2.0 / B, 1.0, 0,
                                     dv.data_ptr(), losses[1:].data_ptr(), s))
-        FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True)
+        FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True, defer=True)
         actor.adam(reduce="sum")   # the surrogate is a SUM over the (global) minibatch
         critic.adam()
         return {"actor_loss": losses[0], "critic_loss": losses[1]}

@@ -192,7 +192,7 @@ class SoftActorCritic(ActorCriticBase):
                                            d_logits.data_ptr(), d_logits.stride(0), loss.data_ptr(),
                                            h.data_ptr(), s))
         self._neg_entropy_rows = h
-        actor.backward(state, d_logits, want_dw=True)
+        actor.backward(state, d_logits, want_dw=True, defer=True)
         actor.adam()
         return loss[0]
 
@@ -230,7 +230,7 @@ class SoftActorCritic(ActorCriticBase):
         for i in range(2):
             N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
                                         dqs[i].data_ptr(), loss.data_ptr(), s))
-        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
         c1.adam()
         c2.adam()
         return loss[0]

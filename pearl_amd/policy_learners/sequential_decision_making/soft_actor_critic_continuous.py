@@ -200,7 +200,7 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             head.data_ptr(), head.stride(0), noise.data_ptr(), noise.stride(0), low.data_ptr(),
             high.data_ptr(), dx1[:, S:].data_ptr(), dx2[:, S:].data_ptr(), dx1.stride(0),
             al["alpha"].data_ptr(), B, A, d_head.data_ptr(), d_head.stride(0), s))
-        actor.backward(state, d_head, want_dw=True)
+        actor.backward(state, d_head, want_dw=True, defer=True)
         actor.adam()
         return loss[0]
 
@@ -236,7 +236,7 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         for i in range(2):
             N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
                                         dqs[i].data_ptr(), loss.data_ptr(), s))
-        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True)
+        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
         c1.adam()
         c2.adam()
         return loss[0]
