@@ -245,6 +245,18 @@ def main():
         if len(timers) > 1:
             line["stage_us"] = {k: round(v["avg_us"], 2) for k, v in timers.items()}
             line["stage_units"] = {k: v["units"] / v["n"] for k, v in timers.items() if v["units"]}
+        if dist.is_initialized():
+            # what the gradient exchange actually ran on: the rank count RCCL itself reports for the
+            # communicator the learn loop's hooks used (ncclCommCount), not the one asked for
+            comm = getattr(pl._native, "comm", None)
+            info = {"library": "rccl (native pa_comm_* hooks)" if comm is not None
+                    else "torch.distributed all_reduce hooks", "ranks_requested": world}
+            if comm is not None:
+                n_seen, me = C.c_int32(-1), C.c_int32(-1)
+                N.check(N.lib().pa_comm_info(comm, C.byref(n_seen), C.byref(me)))
+                info["ranks_observed"] = n_seen.value
+            info["allreduce_floats_per_round"] = int(pl._native.flat["grad"].numel())
+            line["comm"] = info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -362,7 +362,7 @@ def main():
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("dsac", bench_dsac), ("ppo", bench_ppo), ("bandit", bench_bandit),
                      ("double_dqn", bench_double_dqn), ("push", bench_push)):
-        if args.only and args.only != name:
+        if args.only and name not in args.only.split(","):
             continue
         out = fn(args.steps, args.cpu_seconds)
         out.update({"unit": "transitions/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic"})

@@ -176,6 +176,10 @@ int pa_sample_indices_rounds(int64_t population, uint64_t seed, uint64_t offset0
  * logical order (PPOTransition's gae / lam_return / action_probs, ppo.py:47-82). */
 int pa_gather_rows(const void* src_dev, int32_t row_bytes, const int64_t* idx_dev, int32_t B,
                    void* out_dev, void* stream);
+/* out[p][b] = src[p * plane_stride + idx[b]]: `planes` float columns of equal length gathered with
+ * one index list in one launch (PPOTransition's gae / lam_return / action_probs, ppo.py:47-82). */
+int pa_gather_planes(const float* src_dev, int64_t plane_stride, int32_t planes,
+                     const int64_t* idx_dev, int32_t B, float* out_dev, void* stream);
 
 /* OneHotActionTensorRepresentationModule.forward
  * (one_hot_action_representation_module.py:27-34): idx[n] -> out[n, num_classes]. */
@@ -322,6 +326,8 @@ int pa_comm_available(void);
 int pa_comm_unique_id(void* id128_out);
 int pa_comm_create(pa_comm** out, int32_t device, int32_t world, int32_t rank, const void* id128);
 int pa_comm_destroy(pa_comm* c);
+/* the rank count / rank RCCL itself reports for the communicator (ncclCommCount, ncclCommUserRank) */
+int pa_comm_info(pa_comm* c, int32_t* ranks_out, int32_t* rank_out);
 int pa_comm_allreduce_start(void* comm, float* buf, int64_t n, void* stream);
 int pa_comm_allreduce_wait(void* comm, void* stream);
 
@@ -414,6 +420,44 @@ int pa_mlp_flush_grads(pa_mlp* h, void* stream);
 int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream);
 /* update_target_network (common/utils.py:214-226) */
 int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* One ContinuousSoftActorCritic.learn_batch as one call                      */
+/* (soft_actor_critic_continuous.py:131-231, actor_critic_base.py:309-366):   */
+/* actor update, critic update, critic-target soft update, entropy step, in   */
+/* the reference's order — the same launches, sequenced in C (sac_step.hip).   */
+/* The actor is the [S, ..., 2A] network whose last layer stacks fc_mu | fc_std;*/
+/* the critics are [S + A, ..., 1].  Single process: a data-parallel step      */
+/* all-reduces between backward and AdamW and stays with the per-launch API.   */
+/* ------------------------------------------------------------------------ */
+typedef struct pa_sac_step_args {
+  pa_mlp* actor; pa_mlp* critic1; pa_mlp* critic2;
+  const float* state; int32_t ld_state;        /* [B, S] */
+  const float* action; int32_t ld_action;      /* [B, A] the batch's actions */
+  const float* reward;                         /* [B] */
+  const uint8_t* terminated;                   /* [B] */
+  const float* next_state; int32_t ld_next_state;
+  const float* noise_actor;                    /* [B, A] standard-normal draws of the actor update */
+  const float* noise_critic;                   /* [B, A] ... of the Bellman target's next action */
+  const float* low; const float* high;         /* [A] action box */
+  float* alpha;                                /* device scalar: entropy coefficient */
+  float* log_alpha;                            /* NULL: fixed coefficient (no autotune) */
+  float* alpha_m; float* alpha_v; float* alpha_vmax;
+  float target_entropy;
+  double alpha_lr, alpha_beta1, alpha_beta2, alpha_eps, alpha_weight_decay;
+  int32_t alpha_amsgrad;
+  int64_t alpha_step;                          /* AdamW step number of this entropy update */
+  int32_t B, S, A;
+  float gamma, tau;
+  int64_t actor_step, critic_step;             /* AdamW step numbers (1-based) of this update */
+  float* scratch;                              /* pa_sac_scratch_floats(B, S, A) floats, 16-byte aligned */
+  float* losses;                               /* [3] actor loss, critic loss, entropy loss */
+  float* log_prob_out;                         /* optional [B]: log-prob of the actor update's sample */
+} pa_sac_step_args;
+int64_t pa_sac_scratch_floats(int32_t B, int32_t S, int32_t A);
+int pa_sac_step(const pa_sac_step_args* args, void* stream);
+/* tuning aid (tools/prof_sac.py): in-kernel phase stamps of the two fused row kernels */
+int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
 
 /* VanillaActorNetwork.get_action_prob (actor_networks.py:155-176): softmax(logits) . action_rep.
  * probs_out [B, A] may be NULL. */

@@ -203,6 +203,35 @@ class MlpBuffers(C.Structure):
     ]
 
 
+class SacStepArgs(C.Structure):
+    """pa_sac_step_args (include/pearl_amd.h)."""
+    _fields_ = [
+        ("actor", C.c_void_p), ("critic1", C.c_void_p), ("critic2", C.c_void_p),
+        ("state", C.c_void_p), ("ld_state", C.c_int32),
+        ("action", C.c_void_p), ("ld_action", C.c_int32),
+        ("reward", C.c_void_p),
+        ("terminated", C.c_void_p),
+        ("next_state", C.c_void_p), ("ld_next_state", C.c_int32),
+        ("noise_actor", C.c_void_p),
+        ("noise_critic", C.c_void_p),
+        ("low", C.c_void_p), ("high", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("log_alpha", C.c_void_p),
+        ("alpha_m", C.c_void_p), ("alpha_v", C.c_void_p), ("alpha_vmax", C.c_void_p),
+        ("target_entropy", C.c_float),
+        ("alpha_lr", C.c_double), ("alpha_beta1", C.c_double), ("alpha_beta2", C.c_double),
+        ("alpha_eps", C.c_double), ("alpha_weight_decay", C.c_double),
+        ("alpha_amsgrad", C.c_int32),
+        ("alpha_step", C.c_int64),
+        ("B", C.c_int32), ("S", C.c_int32), ("A", C.c_int32),
+        ("gamma", C.c_float), ("tau", C.c_float),
+        ("actor_step", C.c_int64), ("critic_step", C.c_int64),
+        ("scratch", C.c_void_p),
+        ("losses", C.c_void_p),
+        ("log_prob_out", C.c_void_p),
+    ]
+
+
 class LearnArgs(C.Structure):
     _fields_ = [
         ("rounds", C.c_int32),
@@ -249,6 +278,7 @@ SIGNATURES = {
     "pa_sample_indices": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, _P, C.c_int32, _P]),
     "pa_sample_indices_rounds": (C.c_int, [C.c_int64, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32,
                                            _P, C.c_int32, _P]),
+    "pa_gather_planes": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int32, _P, _P]),
     "pa_one_hot": (C.c_int, [_P, C.c_int32, C.c_int64, C.c_int32, _P, _P]),
     "pa_dqn_param_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pa_dqn_param_offsets": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
@@ -266,6 +296,7 @@ SIGNATURES = {
     "pa_comm_unique_id": (C.c_int, [_P]),
     "pa_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_comm_destroy": (C.c_int, [_P]),
+    "pa_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pa_comm_allreduce_start": (C.c_int, [_P, _P, C.c_int64, _P]),
     "pa_comm_allreduce_wait": (C.c_int, [_P, _P]),
     "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
@@ -334,6 +365,9 @@ SIGNATURES = {
     "pa_gauss_actor_grad": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, _P,
                                       C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     "pa_sac_twin": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, _P]),
+    "pa_sac_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "pa_sac_step": (C.c_int, [C.POINTER(SacStepArgs), _P]),
+    "pa_debug_sac_prof": (C.c_int, [_P, _P]),
     "pa_sac_alpha_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_double,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                     C.c_int64, _P, _P]),

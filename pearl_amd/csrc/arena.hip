@@ -886,6 +886,31 @@ extern "C" int pa_gather_rows(const void* src_dev, int32_t row_bytes, const int6
   return PA_OK;
 }
 
+// out[p][b] = src[p][idx[b]] for `planes` float vectors of one length laid out `plane_stride`
+// floats apart: the three per-transition columns of PPOTransition in ONE launch (a launch each
+// cost 4.5 us apiece in a 190 us PPO step)
+static __global__ __launch_bounds__(256) void gather_planes_kernel(const float* __restrict__ src,
+                                                                   int64_t plane_stride, int planes,
+                                                                   const int64_t* __restrict__ idx,
+                                                                   int B, float* __restrict__ out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  const int64_t i = idx[b];
+  for (int p = 0; p < planes; ++p) out[(int64_t)p * B + b] = src[p * plane_stride + i];
+}
+
+extern "C" int pa_gather_planes(const float* src_dev, int64_t plane_stride, int32_t planes,
+                                const int64_t* idx_dev, int32_t B, float* out_dev, void* stream) {
+  PA_REQUIRE(src_dev && idx_dev && out_dev && planes > 0 && plane_stride >= 0 && B >= 0,
+             PA_ERR_INVALID, "pa_gather_planes: bad argument");
+  if (B == 0) return PA_OK;
+  hipLaunchKernelGGL(gather_planes_kernel, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), src_dev, plane_stride, planes, idx_dev, B,
+                     out_dev);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 extern "C" int pa_one_hot(const void* idx_dev, int32_t idx_dtype, int64_t n, int32_t num_classes,
                           float* out_dev, void* stream) {
   PA_REQUIRE(num_classes > 0 && n >= 0, PA_ERR_INVALID, "bad one-hot shape");

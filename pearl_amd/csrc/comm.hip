@@ -24,6 +24,7 @@ typedef int (*fn_init_rank)(NcclComm*, int, NcclId, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t);
 typedef int (*fn_destroy)(NcclComm);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(NcclComm, int*);
 
 struct Rccl {
   void* lib = nullptr;
@@ -32,6 +33,7 @@ struct Rccl {
   fn_allreduce allreduce = nullptr;
   fn_destroy destroy = nullptr;
   fn_errstr errstr = nullptr;
+  fn_count count = nullptr, user_rank = nullptr;   // optional
 };
 
 Rccl* rccl() {
@@ -51,6 +53,8 @@ Rccl* rccl() {
   r.allreduce = (fn_allreduce)dlsym(r.lib, "ncclAllReduce");
   r.destroy = (fn_destroy)dlsym(r.lib, "ncclCommDestroy");
   r.errstr = (fn_errstr)dlsym(r.lib, "ncclGetErrorString");
+  r.count = (fn_count)dlsym(r.lib, "ncclCommCount");
+  r.user_rank = (fn_count)dlsym(r.lib, "ncclCommUserRank");
   if (!r.get_id || !r.init_rank || !r.allreduce || !r.destroy) {
     r.lib = nullptr;
     return nullptr;
@@ -160,4 +164,18 @@ extern "C" int pa_comm_allreduce_wait(void* ctx, void* stream) {
   if (!c) return 1;
   if (c->inline_mode) return 0;
   return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->done, 0) == hipSuccess ? 0 : 1;
+}
+
+// What the communicator itself reports (ncclCommCount / ncclCommUserRank): the rank count RCCL
+// observed, as opposed to the one the caller asked for.  -1 where the library has no such query.
+extern "C" int pa_comm_info(pa_comm* c, int32_t* ranks_out, int32_t* rank_out) {
+  PA_REQUIRE(c, PA_ERR_INVALID, "pa_comm_info: null communicator");
+  Rccl* r = rccl();
+  PA_REQUIRE(r, PA_ERR_UNSUPPORTED, "RCCL is not available");
+  int n = -1, me = -1;
+  if (r->count) PA_NCCL(r->count(c->comm, &n));
+  if (r->user_rank) PA_NCCL(r->user_rank(c->comm, &me));
+  if (ranks_out) *ranks_out = n;
+  if (rank_out) *rank_out = me;
+  return PA_OK;
 }

@@ -21,41 +21,11 @@
 
 #include "host_launch.hpp"
 #include "mlp_rowpass.hpp"
+#include "mlp_internal.hpp"
 
 using namespace pa;
 
-struct pa_mlp {
-  pa_mlp_desc d;
-  pa_mlp_buffers bufs;
-  bool bound;
-  int L;
-  int64_t woff[PA_MLP_MAX_LAYERS], boff[PA_MLP_MAX_LAYERS], P;
-  float* act[PA_MLP_MAX_LAYERS];  // hidden activations kept for the backward pass [max_batch, d]
-  float* dz[PA_MLP_MAX_LAYERS];   // pre-activation gradient of every hidden layer [max_batch, d]
-                                  // (all kept: the weight gradients of all layers are one launch)
-  float* db_scratch;              // column sums of a bias-free last layer go here
-  float* loss_scratch;
-  int kept_B;                     // batch size of the kept forward (0 = none)
-  // pa_mlp_q_all (allocated on first use): fragment-major copy of W2 and the first layer's state
-  // product [max_batch, H1], the two operands target_fused_kernel needs beside the parameters
-  float* qa_w2f;
-  float* qa_u;
-  // row-pass path (mlp_rowpass.hpp): fragment-major copies of every layer — online W_l and W_l^T,
-  // target W_l — rebuilt lazily by ONE launch when the parameters may have changed (bind, AdamW,
-  // soft update, pa_mlp_invalidate)
-  bool row_ok;                    // shape fits the row-pass kernels
-  float* wf[PA_MLP_MAX_LAYERS];
-  float* wtf[PA_MLP_MAX_LAYERS];
-  float* wf_t[PA_MLP_MAX_LAYERS];
-  bool packed_ok, packed_t_ok;
-  // weight gradients deferred to pa_mlp_adam (want_dw = 2): the operands of the kept backward
-  struct Pending {
-    bool active;
-    const float* x; int ldx; int B;
-    const float* dzs[PA_MLP_MAX_LAYERS];
-    int ldzs[PA_MLP_MAX_LAYERS];
-  } pend;
-};
+// struct pa_mlp: mlp_internal.hpp (shared with sac_step.hip)
 
 namespace {
 
@@ -801,6 +771,96 @@ struct PpoActorArgs {
   unsigned* ticket;     // zero on entry, zero again on exit
 };
 
+// ---- element-parallel form (A <= 256): one thread per (row, action) -------------------------
+// The row-per-thread kernel below is instruction-issue bound — ~300 instructions per logit on ONE
+// wave per SIMD of 16 CUs, 21 us for 4096 x 16 — so here a workgroup covers 256 / A rows, every
+// thread owns one logit, and the per-row reductions (max, sum of exp, chosen-action probability)
+// are serial loops over the row's LDS slots in action order: the same values in the same order as
+// the serial loop, on 16x the lanes.
+__global__ __launch_bounds__(256) void ppo_actor_elem_kernel(PpoActorArgs a) {
+  __shared__ float va[256], vb[256], red[256];
+  __shared__ unsigned last;
+  const float lo = 1.0f - a.eps, hi = 1.0f + a.eps;
+  const int rpw = 256 / a.A;
+  const int r = threadIdx.x / a.A, j = threadIdx.x - r * a.A;
+  const int b = blockIdx.x * rpw + r;
+  const bool live = r < rpw && b < a.B;
+  const float z = live ? a.logits[(int64_t)b * a.ldl + j] : 0.f;
+  const float ar = live ? a.arep[(int64_t)b * a.lda + j] : 0.f;
+  const float g = live ? a.gae[b] : 0.f;
+  const float pold = live ? a.p_old[b] : 1.f;
+  const int base = r * a.A;
+  va[threadIdx.x] = z;
+  __syncthreads();
+  float m = 0.f, s = 0.f, p = 0.f;
+  if (live) {
+    m = va[base];
+    for (int k = 1; k < a.A; ++k) m = fmaxf(m, va[base + k]);
+  }
+  const float e = expf(z - m);
+  vb[threadIdx.x] = e;
+  __syncthreads();
+  if (live)
+    for (int k = 0; k < a.A; ++k) s += vb[base + k];
+  const float y = live ? e / s : 0.f;
+  va[threadIdx.x] = y * ar;       // every thread is past its reads of va (barrier above)
+  __syncthreads();
+  float part_loss = 0.f, part_p = 0.f;
+  if (live) {
+    for (int k = 0; k < a.A; ++k) p += va[base + k];
+    const float rt = p / pold;
+    const float clip = fminf(fmaxf(rt, lo), hi);
+    const float s1 = rt * g, s2 = clip * g;
+    const float inr = (rt >= lo && rt <= hi) ? 1.f : 0.f;
+    float dr;
+    if (s1 < s2) dr = g;
+    else if (s1 > s2) dr = g * inr;
+    else dr = 0.5f * g + 0.5f * g * inr;
+    const float dp = -dr / pold;
+    const float dot = dp * p;
+    a.d_logits[(int64_t)b * a.ldd + j] = y * (dp * ar - dot);
+    if (j == 0) {
+      part_loss = -fminf(s1, s2);
+      part_p = p;
+      a.p_rows[b] = p;
+    }
+  }
+  const float bl = block_sum_256(part_loss, red);
+  const float bp = block_sum_256(part_p, red);
+  if (threadIdx.x == 0) {
+    a.partials[2 * blockIdx.x] = bl;
+    a.partials[2 * blockIdx.x + 1] = bp;
+    __threadfence();
+    last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();  // the other blocks' partials and p_rows are visible from here on
+  float pl = 0.f, pp = 0.f;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += 256) {   // fixed order: strided, then the tree
+    pl += __builtin_nontemporal_load(a.partials + 2 * k);
+    pp += __builtin_nontemporal_load(a.partials + 2 * k + 1);
+  }
+  const float loss = block_sum_256(pl, red);
+  const float psum = block_sum_256(pp, red);
+  float part_e = 0.f;
+  const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+#pragma unroll 8
+  for (int i = threadIdx.x; i < a.B; i += 256) {
+    const float pr = __builtin_nontemporal_load(a.p_rows + i);
+    const float pn = pr / psum;
+    const float pc = fminf(fmaxf(pn, tiny), 1.0f - tiny);
+    float lg = logf(pc);
+    lg = fmaxf(lg, -3.4028234663852886e+38f);
+    part_e += lg * pn;
+  }
+  const float ent = -block_sum_256(part_e, red);
+  if (threadIdx.x == 0) {
+    a.loss_out[0] = loss - a.ent_scale * ent;
+    *a.ticket = 0u;
+  }
+}
+
 // STAGED (2 * 256 * (A + 1) floats of LDS fit): the workgroup's 256 logit / representation rows are
 // staged through LDS with coalesced loads (pitch A + 1: conflict-free row-per-lane access), the
 // row-per-thread arithmetic — unchanged, same operation order — runs out of LDS, and the logit
@@ -825,14 +885,26 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
     __syncthreads();
   }
   if (b < a.B) {
-    const float* z = STAGED ? stage + threadIdx.x * P : a.logits + (int64_t)b * a.ldl;
+    // STAGED: the row's exp / softmax values replace its logits in LDS as they are formed, so each
+    // is computed once (same values, same summation order as recomputing them in every pass — and a
+    // third of the transcendental work on what is a one-wave-per-SIMD, latency-bound kernel)
+    float* zs = stage + threadIdx.x * P;
+    const float* z = STAGED ? zs : a.logits + (int64_t)b * a.ldl;
     const float* ar = STAGED ? stage + (256 + threadIdx.x) * P : a.arep + (int64_t)b * a.lda;
     float m = z[0];
     for (int j = 1; j < a.A; ++j) m = fmaxf(m, z[j]);
     float s = 0.f;
-    for (int j = 0; j < a.A; ++j) s += expf(z[j] - m);
+    for (int j = 0; j < a.A; ++j) {
+      const float e = expf(z[j] - m);
+      if (STAGED) zs[j] = e;
+      s += e;
+    }
     float p = 0.f;
-    for (int j = 0; j < a.A; ++j) p += (expf(z[j] - m) / s) * ar[j];
+    for (int j = 0; j < a.A; ++j) {
+      const float yj = (STAGED ? zs[j] : expf(z[j] - m)) / s;
+      if (STAGED) zs[j] = yj;
+      p += yj * ar[j];
+    }
     const float g = a.gae[b];
     const float r = p / a.p_old[b];
     const float clip = fminf(fmaxf(r, lo), hi);
@@ -850,10 +922,10 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
     const float dp = -dr / a.p_old[b];
     // p = sum_j y_j ar_j, y = softmax(z): dz_j = y_j (dp ar_j - sum_k dp ar_k y_k)
     const float dot = dp * p;
-    // STAGED: in place over the row's logits (z[j] is dead once dz[j] is formed)
-    float* dz = STAGED ? stage + threadIdx.x * P : a.d_logits + (int64_t)b * a.ldd;
+    // STAGED: in place over the row's softmax values
+    float* dz = STAGED ? zs : a.d_logits + (int64_t)b * a.ldd;
     for (int j = 0; j < a.A; ++j) {
-      const float yj = expf(z[j] - m) / s;
+      const float yj = STAGED ? zs[j] : expf(z[j] - m) / s;
       dz[j] = yj * (dp * ar[j] - dot);
     }
   }
@@ -1855,7 +1927,8 @@ extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* 
   // of this library)
   static float* scratch = nullptr;
   static size_t scratch_floats = 0;
-  const unsigned grid = (unsigned)ceil_div(B, 256);
+  const bool elem = A <= 256;
+  const unsigned grid = elem ? (unsigned)ceil_div(B, 256 / A) : (unsigned)ceil_div(B, 256);
   const size_t need = (size_t)B + 2 * grid + 4;
   if (need > scratch_floats) {
     if (scratch) {
@@ -1870,7 +1943,10 @@ extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* 
   a.partials = scratch + 4;
   a.p_rows = scratch + 4 + 2 * grid;
   const size_t lds = (size_t)2 * 256 * (A + 1) * sizeof(float);
-  if (lds <= 48 * 1024)
+  if (elem)
+    hipLaunchKernelGGL(ppo_actor_elem_kernel, dim3(grid), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a);
+  else if (lds <= 48 * 1024)
     hipLaunchKernelGGL(ppo_actor_kernel<true>, dim3(grid), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), a);
   else
@@ -2135,3 +2211,14 @@ extern "C" int pa_concat_cols(const float* left, int32_t ldl, const float* right
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
+
+
+// ---- internal entry points for the fused learner steps (sac_step.hip) ---------------------------
+namespace pa {
+int mlp_ensure_packed(pa_mlp* h, bool target, hipStream_t s) { return ensure_packed(h, target, s); }
+void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
+                     const int* ldzs) {
+  set_pending(h, x, ldx, B, dzs, ldzs);
+  h->kept_B = B;
+}
+}  // namespace pa

@@ -1,0 +1,47 @@
+// Internals of the generic MLP engine shared between mlp.hip and the fused learner steps
+// (sac_step.hip).  Not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/pearl_amd.h"
+
+struct pa_mlp {
+  pa_mlp_desc d;
+  pa_mlp_buffers bufs;
+  bool bound;
+  int L;
+  int64_t woff[PA_MLP_MAX_LAYERS], boff[PA_MLP_MAX_LAYERS], P;
+  float* act[PA_MLP_MAX_LAYERS];  // hidden activations kept for the backward pass [max_batch, d]
+  float* dz[PA_MLP_MAX_LAYERS];   // pre-activation gradient of every hidden layer [max_batch, d]
+                                  // (all kept: the weight gradients of all layers are one launch)
+  float* db_scratch;              // column sums of a bias-free last layer go here
+  float* loss_scratch;
+  int kept_B;                     // batch size of the kept forward (0 = none)
+  // pa_mlp_q_all (allocated on first use): fragment-major copy of W2 and the first layer's state
+  // product [max_batch, H1], the two operands target_fused_kernel needs beside the parameters
+  float* qa_w2f;
+  float* qa_u;
+  // row-pass path (mlp_rowpass.hpp): fragment-major copies of every layer — online W_l and W_l^T,
+  // target W_l — rebuilt lazily by ONE launch when the parameters may have changed (bind, AdamW,
+  // soft update, pa_mlp_invalidate)
+  bool row_ok;                    // shape fits the row-pass kernels
+  float* wf[PA_MLP_MAX_LAYERS];
+  float* wtf[PA_MLP_MAX_LAYERS];
+  float* wf_t[PA_MLP_MAX_LAYERS];
+  bool packed_ok, packed_t_ok;
+  // weight gradients deferred to pa_mlp_adam (want_dw = 2): the operands of the kept backward
+  struct Pending {
+    bool active;
+    const float* x; int ldx; int B;
+    const float* dzs[PA_MLP_MAX_LAYERS];
+    int ldzs[PA_MLP_MAX_LAYERS];
+  } pend;
+};
+
+namespace pa {
+// fragment-major copies of the online (or target) parameters are current after this
+int mlp_ensure_packed(pa_mlp* h, bool target, hipStream_t s);
+// the operands of a backward pass whose weight gradients pa_mlp_adam will form (want_dw = 2)
+void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
+                     const int* ldzs);
+}  // namespace pa

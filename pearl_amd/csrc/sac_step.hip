@@ -1,0 +1,363 @@
+// One ContinuousSoftActorCritic.learn_batch as ONE C-ABI call
+// (pearl/policy_learners/sequential_decision_making/soft_actor_critic_continuous.py:131-231 on top of
+// actor_critic_base.py:309-366): actor update -> critic update -> critic-target soft update ->
+// entropy-coefficient step, in the reference's order, every arithmetic step the same pa_* launch the
+// Python-sequenced path issues (bit-identical results).
+//
+// Why it exists: the step is ~22 short launches.  Sequenced from Python — a ctypes call, a torch
+// allocation or two and a handful of attribute lookups per launch — the host needed 330 us per step
+// while the kernels summed to ~250 us (tools/host_bound.py): the learner was host-bound.  Here the
+// host side of a launch is a C++ function call; the caller passes its batch, the two noise draws
+// and one scratch buffer.
+#include <stdint.h>
+#include <string.h>
+
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "host_launch.hpp"
+#include "mlp_internal.hpp"
+#include "sac_rows.hpp"
+
+using namespace pa;
+
+#define PA_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != PA_OK) return _rc; \
+  } while (0)
+
+
+namespace {
+// scratch carve-up (floats); every piece 16-byte aligned
+struct SacScratch {
+  float *xa, *head, *logp, *q1, *q2, *dq1, *dq2, *dx1, *dx2, *d_head;
+  float *xn, *head_n, *nlogp, *nq1, *nq2, *y, *xq, *qa, *qb, *dqa, *dqb;
+};
+int64_t a4(int64_t x) { return (x + 3) & ~int64_t(3); }
+int64_t carve(SacScratch* s, float* base, int64_t B, int64_t S, int64_t A) {
+  int64_t o = 0;
+  auto take = [&](float** p, int64_t n) {
+    if (p && base) *p = base + o;
+    o += a4(n);
+  };
+  take(s ? &s->xa : nullptr, B * (S + A));
+  take(s ? &s->head : nullptr, B * 2 * A);
+  take(s ? &s->logp : nullptr, B);
+  take(s ? &s->q1 : nullptr, B);
+  take(s ? &s->q2 : nullptr, B);
+  take(s ? &s->dq1 : nullptr, B);
+  take(s ? &s->dq2 : nullptr, B);
+  take(s ? &s->dx1 : nullptr, B * (S + A));
+  take(s ? &s->dx2 : nullptr, B * (S + A));
+  take(s ? &s->d_head : nullptr, B * 2 * A);
+  take(s ? &s->xn : nullptr, B * (S + A));
+  take(s ? &s->head_n : nullptr, B * 2 * A);
+  take(s ? &s->nlogp : nullptr, B);
+  take(s ? &s->nq1 : nullptr, B);
+  take(s ? &s->nq2 : nullptr, B);
+  take(s ? &s->y : nullptr, B);
+  take(s ? &s->xq : nullptr, B * (S + A));
+  take(s ? &s->qa : nullptr, B);
+  take(s ? &s->qb : nullptr, B);
+  take(s ? &s->dqa : nullptr, B);
+  take(s ? &s->dqb : nullptr, B);
+  return o;
+}
+}  // namespace
+
+int64_t carve_fused_size(int64_t B, int64_t S, int64_t A);
+extern "C" int64_t pa_sac_scratch_floats(int32_t B, int32_t S, int32_t A) {
+  const int64_t a = carve(nullptr, nullptr, B, S, A), b = carve_fused_size(B, S, A);
+  return a > b ? a : b;
+}
+
+
+namespace {
+
+// ---- the fused form (sac_rows.hpp): two row launches + the weight-gradient launches --------------
+bool fused_enabled() {   // read per call: tests compare the two forms in one process
+  const char* v = getenv("PEARL_AMD_SAC_FUSED");
+  return !(v && *v == '0');
+}
+
+bool relu3(const pa_mlp* h) {
+  return h->bound && h->row_ok && h->L == 3 && h->d.identity_layers == 0 && !h->d.no_last_bias &&
+         h->bufs.grad && h->bufs.exp_avg;
+}
+
+bool fused_ok(const pa_sac_step_args* a) {
+  if (!fused_enabled()) return false;
+  const pa_mlp *ac = a->actor, *c1 = a->critic1, *c2 = a->critic2;
+  if (!relu3(ac) || !relu3(c1) || !relu3(c2)) return false;
+  if (!c1->bufs.p_target || !c2->bufs.p_target) return false;
+  if (a->A < 1 || a->A > 16 || a->S + a->A > ROW_MAX_IN) return false;
+  if (ac->d.dims[0] != a->S || ac->d.dims[3] != 2 * a->A) return false;
+  for (const pa_mlp* c : {c1, c2}) {
+    if (c->d.dims[0] != a->S + a->A || c->d.dims[3] != 1) return false;
+    if (c->d.dims[1] != c1->d.dims[1] || c->d.dims[2] != c1->d.dims[2]) return false;
+  }
+  const int B = a->B;
+  return B <= ac->d.max_batch && B <= c1->d.max_batch && B <= c2->d.max_batch;
+}
+
+void fill_net(const pa_mlp* h, bool target, SacMlp3& n) {
+  const float* P = target ? h->bufs.p_target : h->bufs.p;
+  float* const* wf = target ? h->wf_t : h->wf;
+  n.W1f = wf[0]; n.b1 = P + h->boff[0];
+  n.W2f = wf[1]; n.b2 = P + h->boff[1];
+  n.W3f = wf[2]; n.b3 = P + h->boff[2];
+  n.w3 = P + h->woff[2];
+  n.W1tf = h->wtf[0]; n.W2tf = h->wtf[1]; n.W3tf = h->wtf[2];
+  n.act1 = h->act[0]; n.act2 = h->act[1];
+  n.dz1 = h->dz[1]; n.dz2 = h->dz[2];
+  n.K0 = h->d.dims[0]; n.H1 = h->d.dims[1]; n.H2 = h->d.dims[2]; n.DO = h->d.dims[3];
+}
+
+// hidden widths all one k-group count -> the unrolled instantiation
+int static_groups(const pa_mlp* ac, const pa_mlp* c) {
+  const int g = wf16_nkg(ac->d.dims[1]);
+  if (g != 16) return 0;
+  for (const pa_mlp* h : {ac, c})
+    if (wf16_nkg(h->d.dims[1]) != g || wf16_nkg(h->d.dims[2]) != g) return 0;
+  return g;
+}
+
+struct FusedScratch {
+  float *d_head, *logp, *xq, *q1, *q2, *dq1, *dq2;
+};
+int64_t carve_fused(FusedScratch* s, float* base, int64_t B, int64_t S, int64_t A) {
+  int64_t o = 0;
+  auto take = [&](float** p, int64_t n) {
+    if (s && base) *p = base + o;
+    o += a4(n);
+  };
+  take(s ? &s->d_head : nullptr, B * 2 * A);
+  take(s ? &s->logp : nullptr, B);
+  take(s ? &s->xq : nullptr, B * (S + A));
+  take(s ? &s->q1 : nullptr, B);
+  take(s ? &s->q2 : nullptr, B);
+  take(s ? &s->dq1 : nullptr, B);
+  take(s ? &s->dq2 : nullptr, B);
+  return o;
+}
+
+// tickets / per-tile partial sums of the two row kernels: one buffer per process, grown on demand
+// (calls are ordered by their stream, like every use of a learner handle)
+int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
+  static float* buf = nullptr;
+  static int cap = 0;
+  if (tiles > cap) {
+    if (buf) {
+      PA_HIP(hipDeviceSynchronize());
+      (void)hipFree(buf);
+    }
+    const int n = tiles * 2;
+    PA_HIP(hipMalloc((void**)&buf, ((size_t)2 * n + 8) * sizeof(float)));
+    PA_HIP(hipMemset(buf, 0, ((size_t)2 * n + 8) * sizeof(float)));
+    cap = n;
+  }
+  ta->ticket = reinterpret_cast<unsigned*>(buf);
+  tb->ticket = reinterpret_cast<unsigned*>(buf) + 4;
+  ta->partials = buf + 8;
+  tb->partials = buf + 8 + cap;
+  return PA_OK;
+}
+
+template <int NGH>
+int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s) {
+  static size_t configured = 0;
+  const size_t smem = sac_rows_smem_floats(W) * sizeof(float);
+  if (smem > configured) {
+    int rc = set_max_smem(sac_rows_a_kernel<NGH>, smem);
+    if (rc != PA_OK) return rc;
+    rc = set_max_smem(sac_rows_b_kernel<NGH>, smem);
+    if (rc != PA_OK) return rc;
+    configured = smem;
+  }
+  if (ra) {
+    const unsigned tiles = (unsigned)ceil_div(ra->B, RP_ROWS);
+    hipLaunchKernelGGL(sac_rows_a_kernel<NGH>, dim3(tiles, 3), dim3(512), smem, s, *ra);
+  } else {
+    const unsigned tiles = (unsigned)ceil_div(rb->B, RP_ROWS);
+    hipLaunchKernelGGL(sac_rows_b_kernel<NGH>, dim3(tiles), dim3(512), smem, s, *rb);
+  }
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+AdamScalars scalar_adam(double lr, double b1, double b2, double eps, double wd, int amsgrad,
+                        int64_t step) {
+  const double bc1 = 1.0 - pow(b1, (double)step);
+  const double bc2 = 1.0 - pow(b2, (double)step);
+  AdamScalars c;
+  c.decay = (float)(1.0 - lr * wd);
+  c.w1 = (float)(1.0 - b1);
+  c.beta2 = (float)b2;
+  c.omb2 = (float)(1.0 - b2);
+  c.bc2_sqrt = (float)sqrt(bc2);
+  c.neg_step = (float)(-(lr / bc1));
+  c.eps = (float)eps;
+  c.amsgrad = amsgrad;
+  return c;
+}
+
+long long* g_prof_a = nullptr;
+long long* g_prof_b = nullptr;
+
+int fused_step(const pa_sac_step_args* a, hipStream_t s) {
+  pa_mlp *ac = a->actor, *c1 = a->critic1, *c2 = a->critic2;
+  const int B = a->B, S = a->S, A = a->A, W = S + A;
+  PA_HIP(hipSetDevice(ac->d.device));
+  FusedScratch w;
+  memset(&w, 0, sizeof(w));
+  carve_fused(&w, a->scratch, B, S, A);
+  const int tiles = (int)ceil_div(B, RP_ROWS);
+  SacTicket ta, tb;
+  PA_TRY(tickets(tiles, &ta, &tb));
+  PA_TRY(mlp_ensure_packed(ac, false, s));
+  PA_TRY(mlp_ensure_packed(c1, false, s));
+  PA_TRY(mlp_ensure_packed(c2, false, s));
+  PA_TRY(mlp_ensure_packed(c1, true, s));
+  PA_TRY(mlp_ensure_packed(c2, true, s));
+  const int ngh = static_groups(ac, c1);
+  // ---------------------------------------------------------------- rows A
+  SacRowsAArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  fill_net(ac, false, ra.actor);
+  fill_net(c1, false, ra.critic[0]);
+  fill_net(c2, false, ra.critic[1]);
+  ra.state = a->state; ra.ld_state = a->ld_state;
+  ra.action = a->action; ra.ld_action = a->ld_action;
+  ra.noise = a->noise_actor; ra.ld_noise = A;
+  ra.low = a->low; ra.high = a->high; ra.alpha = a->alpha;
+  ra.B = B; ra.S = S; ra.A = A;
+  ra.d_head = w.d_head; ra.logp = w.logp; ra.xq = w.xq;
+  ra.q[0] = w.q1; ra.q[1] = w.q2;
+  ra.tk = ta;
+  ra.loss_out = a->losses + 0;
+  ra.prof = g_prof_a;
+  PA_TRY(ngh == 16 ? launch_rows<16>(&ra, nullptr, W, s) : launch_rows<0>(&ra, nullptr, W, s));
+  // ---------------------------------------------------------------- actor: dW + AdamW
+  {
+    const float* dzs[3] = {ac->dz[1], ac->dz[2], w.d_head};
+    const int ldzs[3] = {ac->d.dims[1], ac->d.dims[2], 2 * A};
+    mlp_set_pending(ac, a->state, a->ld_state, B, dzs, ldzs);
+    PA_TRY(pa_mlp_adam(ac, a->actor_step, s));
+  }
+  // ---------------------------------------------------------------- rows B
+  SacRowsBArgs rb;
+  memset(&rb, 0, sizeof(rb));
+  fill_net(ac, false, rb.actor);
+  fill_net(c1, true, rb.target[0]);
+  fill_net(c2, true, rb.target[1]);
+  rb.dz1[0] = c1->dz[1]; rb.dz2[0] = c1->dz[2];
+  rb.dz1[1] = c2->dz[1]; rb.dz2[1] = c2->dz[2];
+  rb.H1c = c1->d.dims[1]; rb.H2c = c1->d.dims[2];
+  rb.next_state = a->next_state; rb.ld_next = a->ld_next_state;
+  rb.noise = a->noise_critic; rb.ld_noise = A;
+  rb.low = a->low; rb.high = a->high; rb.alpha_in = a->alpha;
+  rb.reward = a->reward; rb.term = a->terminated; rb.gamma = a->gamma;
+  rb.q[0] = w.q1; rb.q[1] = w.q2;
+  rb.dq[0] = w.dq1; rb.dq[1] = w.dq2;
+  rb.B = B; rb.S = S; rb.A = A;
+  rb.tk = tb;
+  rb.loss_out = a->losses + 1;
+  rb.prof = g_prof_b;
+  if (a->log_alpha) {
+    rb.log_alpha = a->log_alpha; rb.am = a->alpha_m; rb.av = a->alpha_v; rb.avmax = a->alpha_vmax;
+    rb.alpha = a->alpha;
+    rb.logp = w.logp; rb.target_entropy = a->target_entropy;
+    rb.ac = scalar_adam(a->alpha_lr, a->alpha_beta1, a->alpha_beta2, a->alpha_eps,
+                        a->alpha_weight_decay, a->alpha_amsgrad, a->alpha_step);
+    rb.alpha_loss_out = a->losses + 2;
+  }
+  PA_TRY(ngh == 16 ? launch_rows<16>(nullptr, &rb, W, s) : launch_rows<0>(nullptr, &rb, W, s));
+  // ---------------------------------------------------------------- critics: dW + AdamW, targets
+  pa_mlp* cs[2] = {c1, c2};
+  float* dqs[2] = {w.dq1, w.dq2};
+  for (int i = 0; i < 2; ++i) {
+    const float* dzs[3] = {cs[i]->dz[1], cs[i]->dz[2], dqs[i]};
+    const int ldzs[3] = {cs[i]->d.dims[1], cs[i]->d.dims[2], 1};
+    mlp_set_pending(cs[i], w.xq, W, B, dzs, ldzs);
+    PA_TRY(pa_mlp_adam(cs[i], a->critic_step, s));
+  }
+  PA_TRY(pa_mlp_soft_update(c1, a->tau, s));
+  PA_TRY(pa_mlp_soft_update(c2, a->tau, s));
+  if (a->log_prob_out)
+    PA_HIP(hipMemcpyAsync(a->log_prob_out, w.logp, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  return PA_OK;
+}
+
+}  // namespace
+
+int64_t carve_fused_size(int64_t B, int64_t S, int64_t A) { return carve_fused(nullptr, nullptr, B, S, A); }
+
+extern "C" int pa_sac_step(const pa_sac_step_args* a, void* stream) {
+  PA_REQUIRE(a && a->actor && a->critic1 && a->critic2 && a->state && a->action && a->reward &&
+                 a->terminated && a->next_state && a->noise_actor && a->noise_critic && a->low &&
+                 a->high && a->alpha && a->scratch && a->losses && a->B > 0 && a->S > 0 && a->A > 0,
+             PA_ERR_INVALID, "pa_sac_step: bad argument");
+  if (fused_ok(a)) return fused_step(a, reinterpret_cast<hipStream_t>(stream));
+  const int B = a->B, S = a->S, A = a->A, W = S + A;
+  SacScratch w;
+  memset(&w, 0, sizeof(w));
+  carve(&w, a->scratch, B, S, A);
+  // ---------------------------------------------------------------- actor update (:208-231)
+  // xa = [state | sampled action]: the state columns now, the action columns by the sampling head
+  PA_HIP(hipMemcpy2DAsync(w.xa, (size_t)W * 4, a->state, (size_t)a->ld_state * 4, (size_t)S * 4,
+                          (size_t)B, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)));
+  PA_TRY(pa_mlp_forward(a->actor, 0, a->state, a->ld_state, B, w.head, 2 * A, 1, stream));
+  PA_TRY(pa_gauss_sample(w.head, 2 * A, a->noise_actor, A, a->low, a->high, B, A, w.xa + S, W, w.logp,
+                         stream));
+  PA_TRY(pa_mlp_forward2(a->critic1, a->critic2, 0, w.xa, W, B, w.q1, 1, w.q2, 1, 1, stream));
+  PA_TRY(pa_sac_twin(0, w.q1, w.q2, w.logp, a->alpha, nullptr, nullptr, 0.f, B, w.dq1, w.dq2,
+                     a->losses + 0, stream));
+  // only the critics' INPUT gradient matters here (the reference forms and discards their
+  // parameter gradients, actor_critic_base.py:342-348)
+  PA_TRY(pa_mlp_backward2(a->critic1, a->critic2, w.xa, W, B, w.dq1, 1, w.dq2, 1, 0, w.dx1, w.dx2, W,
+                          stream));
+  PA_TRY(pa_gauss_actor_grad(w.head, 2 * A, a->noise_actor, A, a->low, a->high, w.dx1 + S, w.dx2 + S,
+                             W, a->alpha, B, A, w.d_head, 2 * A, stream));
+  PA_TRY(pa_mlp_backward(a->actor, a->state, a->ld_state, B, w.d_head, 2 * A, 2, nullptr, 0, stream));
+  PA_TRY(pa_mlp_adam(a->actor, a->actor_step, stream));
+  // ---------------------------------------------------------------- critic update (:155-206)
+  PA_HIP(hipMemcpy2DAsync(w.xn, (size_t)W * 4, a->next_state, (size_t)a->ld_next_state * 4,
+                          (size_t)S * 4, (size_t)B, hipMemcpyDeviceToDevice,
+                          reinterpret_cast<hipStream_t>(stream)));
+  PA_TRY(pa_mlp_forward(a->actor, 0, a->next_state, a->ld_next_state, B, w.head_n, 2 * A, 0, stream));
+  PA_TRY(pa_gauss_sample(w.head_n, 2 * A, a->noise_critic, A, a->low, a->high, B, A, w.xn + S, W,
+                         w.nlogp, stream));
+  PA_TRY(pa_mlp_forward2(a->critic1, a->critic2, 1, w.xn, W, B, w.nq1, 1, w.nq2, 1, 0, stream));
+  PA_TRY(pa_sac_twin(1, w.nq1, w.nq2, w.nlogp, a->alpha, a->reward, a->terminated, a->gamma, B, w.y,
+                     nullptr, nullptr, stream));
+  PA_TRY(pa_concat_cols(a->state, a->ld_state, a->action, a->ld_action, w.xq, B, S, A, stream));
+  PA_TRY(pa_mlp_forward2(a->critic1, a->critic2, 0, w.xq, W, B, w.qa, 1, w.qb, 1, 1, stream));
+  PA_TRY(pa_mse_head(w.qa, 1, w.y, B, 1.0f / (float)B, 0.5f, 0, w.dqa, a->losses + 1, stream));
+  PA_TRY(pa_mse_head(w.qb, 1, w.y, B, 1.0f / (float)B, 0.5f, 1, w.dqb, a->losses + 1, stream));
+  PA_TRY(pa_mlp_backward2(a->critic1, a->critic2, w.xq, W, B, w.dqa, 1, w.dqb, 1, 2, nullptr, nullptr,
+                          0, stream));
+  PA_TRY(pa_mlp_adam(a->critic1, a->critic_step, stream));
+  PA_TRY(pa_mlp_adam(a->critic2, a->critic_step, stream));
+  // ---------------------------------------------------------------- targets, entropy coefficient
+  PA_TRY(pa_mlp_soft_update(a->critic1, a->tau, stream));
+  PA_TRY(pa_mlp_soft_update(a->critic2, a->tau, stream));
+  if (a->log_alpha) {
+    PA_TRY(pa_sac_alpha_step(a->log_alpha, a->alpha_m, a->alpha_v, a->alpha_vmax, a->alpha, w.logp, B,
+                             a->target_entropy, a->alpha_lr, a->alpha_beta1, a->alpha_beta2,
+                             a->alpha_eps, a->alpha_weight_decay, a->alpha_amsgrad, a->alpha_step,
+                             a->losses + 2, stream));
+  }
+  if (a->log_prob_out)
+    PA_HIP(hipMemcpyAsync(a->log_prob_out, w.logp, (size_t)B * 4, hipMemcpyDeviceToDevice,
+                          reinterpret_cast<hipStream_t>(stream)));
+  return PA_OK;
+}
+
+// tools/prof_sac.py: device buffers for the row kernels' phase stamps
+// ([3 * tiles][8 waves][32] and [tiles][8][32] long long; null = off)
+extern "C" int pa_debug_sac_prof(long long* rows_a, long long* rows_b) {
+  g_prof_a = rows_a;
+  g_prof_b = rows_b;
+  return PA_OK;
+}

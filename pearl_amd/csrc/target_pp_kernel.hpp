@@ -100,10 +100,6 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
     const f32x4_t f = __builtin_bit_cast(f32x4_t, v);
     return make_float4(f[0], f[1], f[2], f[3]);
   };
-  auto l3_load = [&](const float* p, int q) {
-    const int n = nq0 + 8 * q;
-    return v2 ? ld4_or_zero(p, n, n < a.H2) : guarded_load4(p, 0, true, n, a.H2);
-  };
 
   // A team's life is  prologue -> main loop -> epilogue -> prologue -> ...; one loop iteration
   // below is an (epilogue + prologue) phase followed by a main-loop phase, so the weight ring

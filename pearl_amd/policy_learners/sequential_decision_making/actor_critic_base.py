@@ -171,7 +171,7 @@ class ActorCriticBase(PolicyLearner):
                 batch = replay_buffer.sample(batch_size)
                 if not _looks_like_batch(batch):
                     continue
-                for k, v in self._learn_batch_device(self.preprocess_batch(batch)).items():
+                for k, v in self._learn_batch_device(self._preprocess_for_learn(batch)).items():
                     pending.setdefault(k, []).append(v)
         finally:
             if presample is not None:
@@ -185,6 +185,18 @@ class ActorCriticBase(PolicyLearner):
                     vals[i] = g
             report[k] = vals
         return report
+
+    # batch fields this learner's learn_batch never reads: learn() — which owns the batches it
+    # samples — does not spend launches on representing them (PPO: two (B, A, A) one-hot tensors
+    # per minibatch, 9 us of a 190 us step).  preprocess_batch itself is unchanged.
+    _fields_unused_by_learn_batch: tuple = ()
+
+    def _preprocess_for_learn(self, batch: TransitionBatch) -> TransitionBatch:
+        if self._fields_unused_by_learn_batch and \
+                type(self).preprocess_batch is ActorCriticBase.preprocess_batch:
+            for name in self._fields_unused_by_learn_batch:
+                setattr(batch, name, None)
+        return self.preprocess_batch(batch)
 
     def preprocess_batch(self, batch: TransitionBatch) -> TransitionBatch:
         safety = getattr(self, "safety_module", None)

@@ -323,6 +323,14 @@ class FlatMlp:
         self._steps = step
         self._versions = self._flat_versions()     # our own kernels wrote the buffers: not "external"
 
+    def stepped_natively(self) -> None:
+        """Bookkeeping after an AdamW step the library sequenced itself (pa_sac_step)."""
+        step = self._steps + 1
+        self._pending_x = None
+        self._set_adam_steps(step)
+        self._steps = step
+        self._versions = self._flat_versions()
+
     def soft_update(self, tau: float) -> None:
         self.ready()
         N.check(N.lib().pa_mlp_soft_update(self.handle, float(tau), N.stream_ptr(self.device)))

@@ -67,20 +67,22 @@ class PPOReplayBuffer(TensorBasedReplayBuffer):
 
     def set_extra(self, gae: Tensor, lam_return: Tensor, action_probs: Tensor) -> None:
         assert gae.numel() == lam_return.numel() == action_probs.numel() == len(self)
-        self.extra = {"gae": gae.contiguous(), "lam_return": lam_return.contiguous(),
-                      "action_probs": action_probs.contiguous()}
+        # one (3, n) matrix: the three columns are gathered by ONE launch per minibatch
+        self._planes = torch.stack([gae.reshape(-1).float(), lam_return.reshape(-1).float(),
+                                    action_probs.reshape(-1).float()]).contiguous()
+        self.extra = {"gae": self._planes[0], "lam_return": self._planes[1],
+                      "action_probs": self._planes[2]}
 
     def sample(self, batch_size: int) -> PPOTransitionBatch:
         batch = super().sample(batch_size)
         idx = self.last_indices
         assert self.extra, "PPOReplayBuffer.sample before preprocess_replay_buffer"
-        out = {}
-        for k, src in self.extra.items():
-            dst = torch.empty(batch_size, dtype=torch.float32, device=src.device)
-            N.check(N.lib().pa_gather_rows(src.data_ptr(), 4, idx.data_ptr(), int(batch_size),
-                                           dst.data_ptr(), N.stream_ptr(src.device)))
-            out[k] = dst
-        return PPOTransitionBatch.from_parent(batch, **out)
+        src = self._planes
+        dst = torch.empty(3, batch_size, dtype=torch.float32, device=src.device)
+        N.check(N.lib().pa_gather_planes(src.data_ptr(), src.stride(0), 3, idx.data_ptr(),
+                                         int(batch_size), dst.data_ptr(), N.stream_ptr(src.device)))
+        return PPOTransitionBatch.from_parent(batch, gae=dst[0], lam_return=dst[1],
+                                              action_probs=dst[2])
 
     def rollout(self) -> TransitionBatch:
         """The whole buffer in logical order (index 0 = oldest) as one batch."""
@@ -126,6 +128,9 @@ class ProximalPolicyOptimization(ActorCriticBase):
         self._epsilon = epsilon
         self._trace_decay_param = trace_decay_param
         self._entropy_bonus_scaling = entropy_bonus_scaling
+
+    # ppo.py:152-192 reads state, action, gae, lam_return and action_probs only
+    _fields_unused_by_learn_batch = ("curr_available_actions", "next_available_actions", "next_action")
 
     # ------------------------------------------------------------------ flat views
     def _nets(self, batch_hint: int = 0, validate: bool = True):

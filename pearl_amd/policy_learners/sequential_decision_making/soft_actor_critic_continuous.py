@@ -20,6 +20,8 @@ The reparameterisation noise is the one torch-side input: ``torch.randn`` on the
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
@@ -246,7 +248,85 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         c1.soft_update(self._critic_soft_update_tau)
         c2.soft_update(self._critic_soft_update_tau)
 
+    # ------------------------------------------------------------------ one-call step
+    def _one_call_ok(self) -> bool:
+        """pa_sac_step sequences the whole learn_batch in C.  It is the single-process step of
+        exactly this class: a data-parallel step all-reduces between backward and AdamW, and a
+        subclass that overrides a stage keeps the per-stage path."""
+        if os.environ.get("PEARL_AMD_SAC_ONE_CALL", "1") == "0":
+            return False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        cls = type(self)
+        base = ContinuousSoftActorCritic
+        return (cls._actor_update is base._actor_update and cls._critic_update is base._critic_update
+                and cls._update_critic_target is base._update_critic_target
+                and self._use_critic and self._use_critic_target and not self._use_actor_target)
+
+    def _learn_batch_one_call(self, batch: TransitionBatch) -> Dict[str, Any]:
+        actor, c1, c2 = self._nets(len(batch))
+        dev = actor.device
+        al = self._alpha_state(dev)
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        A = actor.dims[-1] // 2
+        act = self._f32(batch.action, dev).reshape(B, A)
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = batch.terminated.to(dev).reshape(B)
+        term = (term.view(torch.uint8) if term.dtype == torch.bool else term.to(torch.uint8)).contiguous()
+        if self.noise_source is None:
+            noise = torch.randn(2, B, A, device=dev, dtype=torch.float32)
+            noise_a, noise_c = noise[0], noise[1]
+        else:   # parity: the reference draws the actor update's noise first, then the target's
+            noise_a, noise_c = self._noise(B, A, dev), self._noise(B, A, dev)
+        ws = self._flat.get("one_call")
+        if ws is None or ws["key"] != (dev, B, S, A):
+            n = int(N.lib().pa_sac_scratch_floats(B, S, A))
+            ws = {"key": (dev, B, S, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
+                  "args": N.SacStepArgs()}
+            self._flat["one_call"] = ws
+        low, high = self._bounds(dev)
+        logp = torch.empty(B, dtype=torch.float32, device=dev)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        a = ws["args"]
+        a.actor, a.critic1, a.critic2 = actor.handle, c1.handle, c2.handle
+        a.state, a.ld_state = state.data_ptr(), state.stride(0)
+        a.action, a.ld_action = act.data_ptr(), act.stride(0)
+        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
+        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a.noise_actor, a.noise_critic = noise_a.data_ptr(), noise_c.data_ptr()
+        a.low, a.high = low.data_ptr(), high.data_ptr()
+        a.alpha = al["alpha"].data_ptr()
+        if self._entropy_autotune:
+            g = self._entropy_optimizer.param_groups[0]
+            al["step"] += 1
+            a.log_alpha = self._log_entropy.data.data_ptr()
+            a.alpha_m, a.alpha_v = al["exp_avg"].data_ptr(), al["exp_avg_sq"].data_ptr()
+            a.alpha_vmax = al["max_exp_avg_sq"].data_ptr()
+            a.target_entropy = self._target_entropy_value()
+            a.alpha_lr, a.alpha_beta1, a.alpha_beta2 = g["lr"], g["betas"][0], g["betas"][1]
+            a.alpha_eps, a.alpha_weight_decay = g["eps"], g["weight_decay"]
+            a.alpha_amsgrad, a.alpha_step = int(bool(g["amsgrad"])), al["step"]
+        else:
+            a.log_alpha = None
+        a.B, a.S, a.A = B, S, A
+        a.gamma, a.tau = float(self._discount_factor), float(self._critic_soft_update_tau)
+        a.actor_step, a.critic_step = actor._steps + 1, c1._steps + 1
+        a.scratch, a.losses, a.log_prob_out = ws["scratch"].data_ptr(), losses.data_ptr(), logp.data_ptr()
+        N.check(N.lib().pa_sac_step(C.byref(a), N.stream_ptr(dev)))
+        for m in (actor, c1, c2):
+            m.stepped_natively()
+        self._action_batch_log_prob_cache = logp
+        report = {"actor_loss": losses[0], "critic_loss": losses[1]}
+        if self._entropy_autotune:
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(float(al["step"]))
+            report["entropy_coef"] = losses[2]
+        return report
+
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        if self._one_call_ok():
+            return self._learn_batch_one_call(batch)
         report = super()._learn_batch_device(batch)
         if self._entropy_autotune:
             actor, _, _ = self._nets(validate=False)

@@ -140,6 +140,51 @@ def test_sac_learn_batch_trajectory(name):
             torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
 
 
+@pytest.mark.parametrize("name", ["tiny", "cfg3_shape_small", "cfg3_fullbatch"])
+@pytest.mark.parametrize("form", ["one_call_sequenced", "fused_rows"])
+def test_sac_step_forms_agree(name, form, monkeypatch):
+    """The three forms of one learn_batch — a launch per stage from Python, the same launches
+    sequenced by pa_sac_step, and the two fused row kernels (sac_rows.hpp) — on the same batch and
+    noise: the first two are the same launches (bit-identical), the fused form reorders roundings
+    (dq * (s2 W2) instead of (dq s2) W2; per-tile loss sums)."""
+    fx = load("sac", name)
+    outs = {}
+    for which in ("per_stage", form):
+        monkeypatch.setenv("PEARL_AMD_SAC_ONE_CALL", "0" if which == "per_stage" else "1")
+        monkeypatch.setenv("PEARL_AMD_SAC_FUSED", "1" if which == "fused_rows" else "0")
+        pl = make_sac(fx)
+        reports = []
+        for na, nc in fx["noises"]:
+            seq = iter([na, nc])
+            pl.noise_source = lambda B, A, dev: next(seq)
+            reports.append(pl.learn_batch(pl.preprocess_batch(sac_batch(fx))))
+        torch.cuda.synchronize()
+        outs[which] = (reports, {f"{n}.{k}": v.detach().cpu().clone()
+                                 for n, m in (("actor", pl._actor), ("critic", pl._critic),
+                                              ("target", pl._critic_target))
+                                 for k, v in m.state_dict().items()},
+                       pl._entropy_coef.detach().cpu().clone(),
+                       pl._action_batch_log_prob_cache.detach().cpu().clone())
+    (ra, pa_, ea, la), (rb, pb, eb, lb) = outs["per_stage"], outs[form]
+    exact = form == "one_call_sequenced"
+    for x, y in zip(ra, rb):
+        assert x.keys() == y.keys()
+        for k in x:
+            if exact:
+                assert float(x[k]) == float(y[k]), (k, x[k], y[k])
+            else:
+                assert abs(float(x[k]) - float(y[k])) <= 2e-5 * max(1.0, abs(float(x[k]))), (k, x[k], y[k])
+    from helpers import assert_adam_trajectory_close
+    for k in pa_:
+        if exact:
+            assert torch.equal(pa_[k], pb[k]), k
+        else:
+            assert_adam_trajectory_close(pb[k], pa_[k], 1e-3, len(fx["noises"]), max_outlier_frac=2e-3, msg=k)
+    torch.testing.assert_close(ea, eb, rtol=0 if exact else 1e-5, atol=0 if exact else 1e-7)
+    # (log pi of a saturated action component is ill-conditioned: see the probe test above)
+    torch.testing.assert_close(la, lb, rtol=0 if exact else 5e-5, atol=0 if exact else 3e-4)
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg5_shape_small"])
 def test_neural_linear_bandit_learn_batch(name):
     """NeuralLinearBandit.learn_batch: weighted-MSE NN step + LinUCB A / b / inv(A) / coefs update
