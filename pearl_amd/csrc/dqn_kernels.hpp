@@ -838,12 +838,23 @@ struct DwProblem {
                               // 3: a layer of the generic engine, packed copies below
   float* pkf; int nkgf;       // kind 3: fragment-major W [M units][N]  (wf16 layout) or null
   float* pktf; int nkgtf;     // kind 3: fragment-major W^T [N units][M] or null
+  float* pkf_t;               // kind 3 + soft update: the TARGET's fragment-major W (pkf layout) or null
   int bias_frozen;            // the bias slot is not a parameter (bias-free layer): no AdamW on db
+  int net;                    // kind 3: which network's optimizer state (0: ad, 1: net2)
 };
+// A second network in the same launch (twin critics: one launch instead of two half-empty ones).
+// Same AdamW hyper-parameters and step as `ad` (one optimizer), its own flat buffers.
+struct DwNet2 {
+  AdamState st;
+  const float* grad_base;
+  float* tgt;
+};
+constexpr int DW_MAX_PROB = 6;
 struct DwArgs {
-  DwProblem p[3];
+  DwProblem p[DW_MAX_PROB];
   int nprob, B, total_tiles;
   AdamFuse ad;
+  DwNet2 net2;
   long long* prof;   // optional phase stamps (tools/prof_chain.py): [workgroup][wave][16]
   // Large batches: `ksplit` workgroups share a tile, each reducing its slice of the batch; they
   // leave their partial tile in `kscratch` (write-through stores) and take a ticket, the last one
@@ -878,6 +889,24 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
 __device__ __forceinline__ void pack_generic(const DwProblem& P, int row, int col, float p) {
   if (P.pkf) P.pkf[wf16_index_(row, col, P.nkgf)] = p;
   if (P.pktf) P.pktf[wf16_index_(col, row, P.nkgtf)] = p;
+}
+// kind 3, one scalar parameter: AdamW, packed copies, and (soft) the target with its packed copy
+__device__ __forceinline__ void adam_generic_weight(const AdamFuse& f, const AdamState& st, float* tgt,
+                                                    const DwProblem& P, int64_t i, int row, int col,
+                                                    float g) {
+  const float p = adam_update(f.c, st, i, g);
+  pack_generic(P, row, col, p);
+  if (f.soft_next && tgt) {
+    const float t = __fadd_rn(__fmul_rn(f.tau, p), __fmul_rn(f.one_minus_tau, tgt[i]));
+    tgt[i] = t;
+    if (P.pkf_t) P.pkf_t[wf16_index_(row, col, P.nkgf)] = t;
+  }
+}
+__device__ __forceinline__ void adam_generic_bias(const AdamFuse& f, const AdamState& st, float* tgt,
+                                                  int64_t i, float g) {
+  const float p = adam_update(f.c, st, i, g);
+  if (f.soft_next && tgt)
+    tgt[i] = __fadd_rn(__fmul_rn(f.tau, p), __fmul_rn(f.one_minus_tau, tgt[i]));
 }
 __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, float g) {
   const float p = adam_update(f.c, f.st, i, g);
@@ -1019,9 +1048,19 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
   const int c = lane & 15, q = lane >> 4;
   int pi = 0;
-  if (a.nprob > 1 && wg_tile >= a.p[1].tile0) pi = 1;
-  if (a.nprob > 2 && wg_tile >= a.p[2].tile0) pi = 2;
+#pragma unroll
+  for (int k = 1; k < DW_MAX_PROB; ++k)
+    if (a.nprob > k && wg_tile >= a.p[k].tile0) pi = k;
   const DwProblem& P = a.p[pi];
+  // the optimizer state this problem's parameters live in (wave-uniform selects)
+  AdamState st = a.ad.st;
+  const float* gbase = a.ad.grad_base;
+  float* tgt = a.ad.tgt;
+  if (P.net) {
+    st = a.net2.st;
+    gbase = a.net2.grad_base;
+    tgt = a.net2.tgt;
+  }
   const int t = wg_tile - P.tile0;
   const int i0 = (t / P.tiles_n) * DW_TM, j0 = (t % P.tiles_n) * DW_TN;
   if (P.M == 1 && kslice > 0) return;  // the GEMV path below is not split
@@ -1053,7 +1092,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
       float* dst = P.dW + col;
       *dst = g;
       if (a.ad.enabled) {
-        if (P.kind == 3) pack_generic(P, 0, col, adam_update(a.ad.c, a.ad.st, dst - a.ad.grad_base, g));
+        if (P.kind == 3) adam_generic_weight(a.ad, st, tgt, P, dst - gbase, 0, col, g);
         else adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, 0, col, g);
       }
     }
@@ -1062,7 +1101,10 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
       for (int w = 1; w < 16; ++w) g += csum[w];
       P.db[0] = g;
-      if (a.ad.enabled && !P.bias_frozen) adam_fused_bias(a.ad, P.db - a.ad.grad_base, g);
+      if (a.ad.enabled && !P.bias_frozen) {
+        if (P.kind == 3) adam_generic_bias(a.ad, st, tgt, P.db - gbase, g);
+        else adam_fused_bias(a.ad, P.db - a.ad.grad_base, g);
+      }
     }
     return;
   }
@@ -1096,15 +1138,15 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   const int erow = i0 + erl, ecol = j0 + 4 * ecg;
   const bool evec = erow < P.M && ecol + 3 < P.N && ((P.ldw & 3) == 0) &&
                     ((reinterpret_cast<uintptr_t>(P.dW) & 15) == 0);
-  const int64_t eflat = (P.dW + (int64_t)erow * P.ldw + ecol) - a.ad.grad_base;
+  const int64_t eflat = (P.dW + (int64_t)erow * P.ldw + ecol) - gbase;
   float4 p4, m4, v4, x4;
   p4 = m4 = v4 = x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto prefetch_state = [&]() {
     if (evec && a.ad.enabled) {
-      p4 = *reinterpret_cast<const float4*>(a.ad.st.p + eflat);
-      m4 = *reinterpret_cast<const float4*>(a.ad.st.m + eflat);
-      v4 = *reinterpret_cast<const float4*>(a.ad.st.v + eflat);
-      if (a.ad.c.amsgrad) x4 = *reinterpret_cast<const float4*>(a.ad.st.vmax + eflat);
+      p4 = *reinterpret_cast<const float4*>(st.p + eflat);
+      m4 = *reinterpret_cast<const float4*>(st.m + eflat);
+      v4 = *reinterpret_cast<const float4*>(st.v + eflat);
+      if (a.ad.c.amsgrad) x4 = *reinterpret_cast<const float4*>(st.vmax + eflat);
     }
   };
   dw_f32x4 acc[4][2];
@@ -1212,11 +1254,11 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) adam_math(a.ad.c, g4[e], pv[e], mv[e], vv[e], xv[e]);
         const float4 pn = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        *reinterpret_cast<float4*>(a.ad.st.p + eflat) = pn;
-        *reinterpret_cast<float4*>(a.ad.st.m + eflat) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-        *reinterpret_cast<float4*>(a.ad.st.v + eflat) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        *reinterpret_cast<float4*>(st.p + eflat) = pn;
+        *reinterpret_cast<float4*>(st.m + eflat) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+        *reinterpret_cast<float4*>(st.v + eflat) = make_float4(vv[0], vv[1], vv[2], vv[3]);
         if (a.ad.c.amsgrad)
-          *reinterpret_cast<float4*>(a.ad.st.vmax + eflat) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+          *reinterpret_cast<float4*>(st.vmax + eflat) = make_float4(xv[0], xv[1], xv[2], xv[3]);
         // fragment-major copies: four consecutive k of one unit are one float4 slot
         if (P.kind == 0) {
           *reinterpret_cast<float4*>(a.ad.W2f + wf16_index_(erow, ecol, a.ad.nkg_w2)) = pn;
@@ -1231,16 +1273,18 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
             for (int e = 0; e < 4; ++e) P.pktf[wf16_index_(ecol + e, erow, P.nkgtf)] = pv[e];
           }
         }
-        if (a.ad.soft_next) {  // update_target_network (common/utils.py:214-226)
-          const float4 t4 = *reinterpret_cast<const float4*>(a.ad.tgt + eflat);
+        if (a.ad.soft_next && tgt) {  // update_target_network (common/utils.py:214-226)
+          const float4 t4 = *reinterpret_cast<const float4*>(tgt + eflat);
           float4 tn;
           tn.x = __fadd_rn(__fmul_rn(a.ad.tau, pv[0]), __fmul_rn(a.ad.one_minus_tau, t4.x));
           tn.y = __fadd_rn(__fmul_rn(a.ad.tau, pv[1]), __fmul_rn(a.ad.one_minus_tau, t4.y));
           tn.z = __fadd_rn(__fmul_rn(a.ad.tau, pv[2]), __fmul_rn(a.ad.one_minus_tau, t4.z));
           tn.w = __fadd_rn(__fmul_rn(a.ad.tau, pv[3]), __fmul_rn(a.ad.one_minus_tau, t4.w));
-          *reinterpret_cast<float4*>(a.ad.tgt + eflat) = tn;
+          *reinterpret_cast<float4*>(tgt + eflat) = tn;
           if (P.kind == 0)
             *reinterpret_cast<float4*>(a.ad.tW2f + w2f_index(erow, ecol, a.ad.nkg_t)) = tn;
+          else if (P.kind == 3 && P.pkf_t)
+            *reinterpret_cast<float4*>(P.pkf_t + wf16_index_(erow, ecol, P.nkgf)) = tn;
         }
       }
     } else if (erow < P.M) {
@@ -1251,7 +1295,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
           *dst = g4[e];
           if (a.ad.enabled) {
             if (P.kind == 3)
-              pack_generic(P, erow, ecol + e, adam_update(a.ad.c, a.ad.st, dst - a.ad.grad_base, g4[e]));
+              adam_generic_weight(a.ad, st, tgt, P, dst - gbase, erow, ecol + e, g4[e]);
             else
               adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, erow, ecol + e, g4[e]);
           }
@@ -1264,7 +1308,10 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
     for (int w = 1; w < 8; ++w) s += csum[w * DW_TM + tid];
     P.db[i0 + tid] = s;
-    if (a.ad.enabled && !P.bias_frozen) adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
+    if (a.ad.enabled && !P.bias_frozen) {
+      if (P.kind == 3) adam_generic_bias(a.ad, st, tgt, (P.db + i0 + tid) - gbase, s);
+      else adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
+    }
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 15);

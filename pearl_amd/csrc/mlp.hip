@@ -315,52 +315,88 @@ extern "C" int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float
 
 namespace {
 
-// dW/db of every layer of ONE network (three layers per launch).  adam_step > 0: the workgroup
-// that finishes a tile also applies AdamW(amsgrad) to it and refreshes the fragment-major copies
-// the row-pass kernels read (the DQN treatment: no AdamW launch, no repack launch).
-int run_weight_grads(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
-                     const int* ldzs, int64_t adam_step, hipStream_t s) {
-  for (int l0 = 0; l0 < h->L; l0 += 3) {
+// dW/db of every layer of one network — or of TWO networks that share an optimizer (twin
+// critics) — in one launch per three layers.  adam_step > 0: the workgroup that finishes a tile
+// also applies AdamW(amsgrad) to it and refreshes the fragment-major copies the row-pass kernels
+// read (the DQN treatment: no AdamW launch, no repack launch); soft_tau >= 0 on top of that: the
+// target parameters (and their packed copies, when current) take their soft update in the same
+// epilogue (update_target_network, common/utils.py:214-226).
+struct DwOperands {
+  const float* x; int ldx;
+  const float* const* dzs; const int* ldzs;
+};
+int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B, int64_t adam_step,
+                       float soft_tau, hipStream_t s) {
+  pa_mlp* h0 = hs[0];
+  const int L = h0->L;
+  for (int l0 = 0; l0 < L; l0 += 3) {
     DwArgs a;
     memset(&a, 0, sizeof(a));
     int t0 = 0;
-    for (int l = l0; l < h->L && l < l0 + 3; ++l) {
-      DwProblem& pr = a.p[a.nprob++];
-      pr.dZ = dzs[l]; pr.ldz = ldzs[l];
-      pr.X = l > 0 ? h->act[l - 1] : x;
-      pr.ldx = l > 0 ? h->d.dims[l] : ldx;
-      pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
-      // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias
-      // slot: its column sums go to scratch so AdamW never moves it
-      const bool frozen = (l == h->L - 1 && h->d.no_last_bias);
-      pr.db = frozen ? h->db_scratch : h->bufs.grad + h->boff[l];
-      pr.bias_frozen = frozen ? 1 : 0;
-      pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
-      pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
-      pr.tile0 = t0;
-      pr.kind = 2;
-      if (adam_step > 0) {
-        pr.kind = 3;
-        if (h->row_ok) {
-          pr.pkf = h->wf[l]; pr.nkgf = wf16_nkg(h->d.dims[l]);
-          pr.pktf = h->wtf[l]; pr.nkgtf = wf16_nkg(h->d.dims[l + 1]);
+    for (int ni = 0; ni < nnet; ++ni) {
+      pa_mlp* h = hs[ni];
+      for (int l = l0; l < L && l < l0 + 3; ++l) {
+        DwProblem& pr = a.p[a.nprob++];
+        pr.dZ = ops[ni].dzs[l]; pr.ldz = ops[ni].ldzs[l];
+        pr.X = l > 0 ? h->act[l - 1] : ops[ni].x;
+        pr.ldx = l > 0 ? h->d.dims[l] : ops[ni].ldx;
+        pr.dW = h->bufs.grad + h->woff[l]; pr.ldw = h->d.dims[l];
+        // a bias-free last layer (NeuralLinearRegression.linear_layer_e2e) keeps a zero bias
+        // slot: its column sums go to scratch so AdamW never moves it
+        const bool frozen = (l == L - 1 && h->d.no_last_bias);
+        pr.db = frozen ? h->db_scratch : h->bufs.grad + h->boff[l];
+        pr.bias_frozen = frozen ? 1 : 0;
+        pr.M = h->d.dims[l + 1]; pr.N = h->d.dims[l];
+        pr.tiles_n = (int)ceil_div(h->d.dims[l], DW_TN);
+        pr.tile0 = t0;
+        pr.kind = 2;
+        pr.net = ni;
+        if (adam_step > 0) {
+          pr.kind = 3;
+          if (h->row_ok) {
+            pr.pkf = h->wf[l]; pr.nkgf = wf16_nkg(h->d.dims[l]);
+            pr.pktf = h->wtf[l]; pr.nkgtf = wf16_nkg(h->d.dims[l + 1]);
+            if (soft_tau >= 0.f && h->packed_t_ok) pr.pkf_t = h->wf_t[l];
+          }
         }
+        t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
       }
-      t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
     }
     a.total_tiles = t0;
     a.B = B;
     if (adam_step > 0) {
       a.ad.enabled = 1;
-      a.ad.c = adam_scalars(h->d, adam_step);
-      a.ad.st.p = h->bufs.p; a.ad.st.m = h->bufs.exp_avg; a.ad.st.v = h->bufs.exp_avg_sq;
-      a.ad.st.vmax = h->bufs.max_exp_avg_sq;
-      a.ad.grad_base = h->bufs.grad;
+      a.ad.c = adam_scalars(h0->d, adam_step);
+      a.ad.st.p = h0->bufs.p; a.ad.st.m = h0->bufs.exp_avg; a.ad.st.v = h0->bufs.exp_avg_sq;
+      a.ad.st.vmax = h0->bufs.max_exp_avg_sq;
+      a.ad.grad_base = h0->bufs.grad;
+      if (nnet > 1) {
+        pa_mlp* h1 = hs[1];
+        a.net2.st.p = h1->bufs.p; a.net2.st.m = h1->bufs.exp_avg; a.net2.st.v = h1->bufs.exp_avg_sq;
+        a.net2.st.vmax = h1->bufs.max_exp_avg_sq;
+        a.net2.grad_base = h1->bufs.grad;
+      }
+      if (soft_tau >= 0.f) {
+        a.ad.soft_next = 1;
+        a.ad.tau = soft_tau;
+        a.ad.one_minus_tau = (float)(1.0 - (double)soft_tau);
+        a.ad.tgt = h0->bufs.p_target;
+        if (nnet > 1) a.net2.tgt = hs[1]->bufs.p_target;
+      }
     }
     int rc = launch_weight_grad(a, false, s);
     if (rc != PA_OK) return rc;
   }
+  if (adam_step > 0 && soft_tau >= 0.f)
+    for (int ni = 0; ni < nnet; ++ni)
+      if (!hs[ni]->row_ok) hs[ni]->packed_t_ok = false;
   return PA_OK;
+}
+
+int run_weight_grads(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
+                     const int* ldzs, int64_t adam_step, hipStream_t s) {
+  DwOperands op = {x, ldx, dzs, ldzs};
+  return run_weight_grads_n(&h, &op, 1, B, adam_step, -1.f, s);
 }
 
 void set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs, const int* ldzs) {
@@ -2220,5 +2256,26 @@ void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* con
                      const int* ldzs) {
   set_pending(h, x, ldx, B, dzs, ldzs);
   h->kept_B = B;
+}
+bool mlp_pair_fusable(const pa_mlp* a, const pa_mlp* b, bool soft) {
+  if (!a->pend.active || !b->pend.active || a->pend.B != b->pend.B) return false;
+  if (a->L != b->L || a->L > 3) return false;
+  const pa_mlp_desc &x = a->d, &y = b->d;
+  if (x.lr != y.lr || x.beta1 != y.beta1 || x.beta2 != y.beta2 || x.eps != y.eps ||
+      x.weight_decay != y.weight_decay || x.amsgrad != y.amsgrad)
+    return false;
+  for (const pa_mlp* h : {a, b}) {
+    if (!h->bufs.grad || !h->bufs.exp_avg || !h->bufs.exp_avg_sq) return false;
+    if (h->d.amsgrad && !h->bufs.max_exp_avg_sq) return false;
+    if (soft && !h->bufs.p_target) return false;
+  }
+  return true;
+}
+int mlp_adam_pair(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, hipStream_t s) {
+  pa_mlp* hs[2] = {a, b};
+  DwOperands ops[2] = {{a->pend.x, a->pend.ldx, a->pend.dzs, a->pend.ldzs},
+                       {b->pend.x, b->pend.ldx, b->pend.dzs, b->pend.ldzs}};
+  a->pend.active = b->pend.active = false;
+  return run_weight_grads_n(hs, ops, 2, a->pend.B, step, soft_tau, s);
 }
 }  // namespace pa

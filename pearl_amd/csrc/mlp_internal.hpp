@@ -44,4 +44,8 @@ int mlp_ensure_packed(pa_mlp* h, bool target, hipStream_t s);
 // the operands of a backward pass whose weight gradients pa_mlp_adam will form (want_dw = 2)
 void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
                      const int* ldzs);
+// Two networks with pending weight gradients and ONE optimizer configuration (twin critics):
+// dW + AdamW (+ soft target update when soft_tau >= 0) of both in one launch.
+bool mlp_pair_fusable(const pa_mlp* a, const pa_mlp* b, bool soft);
+int mlp_adam_pair(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, hipStream_t s);
 }  // namespace pa

@@ -19,9 +19,10 @@
 //   [the actor's weight gradients + AdamW: weight_grad_kernel, as before]
 //   sac_rows_b   grid (tiles)
 //     updated actor(s') -> (a', log pi') -> target critics -> y (:155-176); dq_c = (q_c - y) / B;
-//     rows of s2 / G scaled by dq_c in place; the last workgroup to finish adds up the critic loss
-//     and takes the entropy-coefficient step (:134-151).
-//   [the critics' weight gradients + AdamW + soft updates, as before]
+//     rows of s2 / G scaled by dq_c in place.
+//   [both critics' weight gradients + AdamW + soft target updates: ONE weight_grad_kernel launch]
+//   sac_finish   one workgroup: the two losses from the per-tile partial sums, and the
+//     entropy-coefficient step (:134-151).
 //
 // Tiles and operand layouts are mlp_rowpass.hpp's (16 rows x 256 units per workgroup, 8 waves x 2
 // unit tiles, fragment-major weights).  NGH > 0: every hidden layer is NGH k-groups wide and its
@@ -45,8 +46,7 @@ struct SacMlp3 {
 };
 
 struct SacTicket {
-  float* partials;        // [tiles][2]
-  unsigned* ticket;       // zero between launches
+  float* partials;        // [tiles] per-tile loss sums (sac_finish_kernel adds them up)
 };
 
 struct SacRowsAArgs {
@@ -62,7 +62,6 @@ struct SacRowsAArgs {
   float* xq;                             // [B][S + A]
   float* q[2];                           // [B] critics at (s, a_batch)
   SacTicket tk;
-  float* loss_out;                       // actor loss
   long long* prof;
 };
 
@@ -79,10 +78,6 @@ struct SacRowsBArgs {
   float* dq[2];                          // [B]
   int B, S, A;
   SacTicket tk;
-  float* loss_out;                       // critic loss
-  // entropy coefficient (null log_alpha: fixed)
-  float* log_alpha; float* am; float* av; float* avmax; float* alpha;
-  const float* logp; float target_entropy; AdamScalars ac; float* alpha_loss_out;
   long long* prof;
 };
 
@@ -95,11 +90,12 @@ struct SacRowsBArgs {
 
 constexpr int SR_HEADP = 36;     // LDS pitch of 32-wide row vectors (head, head gradient, partials)
 constexpr int SR_DHP = 68;       // pitch of the head-gradient tile when it is a GEMM operand
+constexpr int SR_CST = 776;      // per network: b1[256] | b2[256] | w3 or b3[256] | critic b3 | pad
 
-// LDS: xs [16][P0] | hA hB hC [16][PH] | red [8][16][SR_HEADP] | small
+// LDS: xs [16][P0] | hA hB hC [16][PH] | red [8][16][SR_HEADP] | dhS | qred | small | cst[3]
 __host__ __device__ inline size_t sac_rows_smem_floats(int k0) {
   return (size_t)RP_ROWS * (rp_pad(k0) + 3 * row_hid_pitch()) + 8 * RP_ROWS * SR_HEADP +
-         RP_ROWS * SR_DHP + 8 * RP_ROWS + 8 * RP_ROWS;
+         RP_ROWS * SR_DHP + 8 * RP_ROWS + 8 * RP_ROWS + 3 * SR_CST;
 }
 
 struct SrLane {
@@ -113,10 +109,63 @@ __device__ __forceinline__ SrLane sr_lane() {
   return L;
 }
 
-__device__ __forceinline__ void sr_bias(f32x4v (&acc)[2], const float* b, int N, int u0) {
+// Biases and the critics' last-layer rows go through LDS once per workgroup: read from global
+// memory right before the GEMM they seed, each cost an exposed round trip (~1 us) per layer.
+// Two steps — request into registers, store to LDS — so that a kernel can put ALL its start-up
+// requests (input tile, constants of every network) in flight before it waits for the first.
+struct SrConsts {
+  float v[2];
+  float b3;
+};
+__device__ __forceinline__ void sr_consts_load(SrConsts& c, const SacMlp3& n, bool critic, int tid) {
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int e = tid + it * 512;
+    const int which = e >> 8, u = e & 255;
+    const float b1 = ld_or_zero(n.b1, u, which == 0 && u < n.H1);
+    const float b2 = ld_or_zero(n.b2, u, which == 1 && u < n.H2);
+    const float w3 = ld_or_zero(critic ? n.w3 : n.b3, u, which == 2 && u < (critic ? n.H2 : n.DO));
+    c.v[it] = which == 0 ? b1 : (which == 1 ? b2 : w3);     // (e >= 768: all three read as zero)
+  }
+  c.b3 = ld_or_zero(n.b3, 0, critic && tid == 0);
+}
+__device__ __forceinline__ void sr_consts_store(float* cst, const SrConsts& c, int tid) {
+  cst[tid] = c.v[0];
+  if (tid + 512 < 768) cst[tid + 512] = c.v[1];
+  if (tid == 0) cst[768] = c.b3;
+}
+// the input tile: at most SR_XV float4 per thread in registers (wider inputs: a plain loop)
+constexpr int SR_XV = 2;
+struct SrTile {
+  float4 v[SR_XV];
+};
+__device__ __forceinline__ bool sr_tile_fits(int P0) { return RP_ROWS * ((P0 - 4) >> 2) <= 512 * SR_XV; }
+__device__ __forceinline__ void sr_tile_load(SrTile& t, const float* x, int ldx, int S, int m0, int B,
+                                             int P0, int tid) {
+  const int c4 = (P0 - 4) >> 2;
+  const bool vx = is_vec_ok(x, ldx) && ((S & 3) == 0);
+#pragma unroll
+  for (int it = 0; it < SR_XV; ++it) {
+    const int e = tid + it * 512;
+    const int r = e / c4, c = (e - r * c4) * 4;
+    const bool ok = e < RP_ROWS * c4 && (m0 + r) < B;
+    if (vx) t.v[it] = ld4_or_zero(x, (int64_t)(m0 + r) * ldx + c, ok && c < S);
+    else t.v[it] = guarded_load4(x, (int64_t)(m0 + r) * ldx, ok, c, S);
+  }
+}
+__device__ __forceinline__ void sr_tile_store(const SrTile& t, float* xs, int P0, int tid) {
+  const int c4 = (P0 - 4) >> 2;
+#pragma unroll
+  for (int it = 0; it < SR_XV; ++it) {
+    const int e = tid + it * 512;
+    const int r = e / c4, c = (e - r * c4) * 4;
+    if (e < RP_ROWS * c4) *reinterpret_cast<float4*>(xs + r * P0 + c) = t.v[it];
+  }
+}
+__device__ __forceinline__ void sr_bias(f32x4v (&acc)[2], const float* cb, int u0) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const float4 v = guarded_load4(b, 0, true, u0 + 16 * t, N);
+    const float4 v = *reinterpret_cast<const float4*>(cb + u0 + 16 * t);
     acc[t][0] = v.x; acc[t][1] = v.y; acc[t][2] = v.z; acc[t][3] = v.w;
   }
 }
@@ -125,14 +174,34 @@ __device__ __forceinline__ void sr_zero(f32x4v (&acc)[2]) {
   for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
 }
 
+// ---- weight streams ------------------------------------------------------------------------------
+// Hidden layers (NGH k-groups, unrolled): the ring is filled with the first k-groups of the NEXT
+// hidden GEMM's stream inside the last iterations of the current one (the slot a k-group was read
+// from is refilled at once — rows16_gemm_static_pf with both rings the same registers), so a GEMM
+// never starts on a cold ring.  First layers (NG1 <= 8 k-groups): their own small ring, filled a
+// whole phase early.  NGH / NG1 = 0: run-time loops, weights requested when the GEMM starts.
 template <int NGH>
 __device__ __forceinline__ void sr_prefetch(WRing& R, const float* Wf, int tile0, int nt, int lane) {
   if constexpr (NGH > 0) ring_fill<NGH>(R, Wf, tile0, nt, lane);
 }
 template <int NGH>
 __device__ __forceinline__ void sr_gemm(f32x4v (&acc)[2], WRing& R, const float* Wf, int nkg,
-                                        int tile0, int nt, const float* actp, int lane) {
-  if constexpr (NGH > 0) rows16_gemm_static<NGH>(acc, R, Wf, tile0, nt, actp, lane);
+                                        int tile0, int nt, const float* actp, int lane,
+                                        const float* Wnext, int nt_next) {
+  if constexpr (NGH > 0)
+    rows16_gemm_static_pf<NGH, NGH>(acc, R, Wf, tile0, nt, actp, lane, R, Wnext, nt_next,
+                                    Wnext != nullptr);
+  else rows16_gemm<4>(acc, Wf, nkg, tile0, nt, actp, lane);
+}
+template <int NG1>
+__device__ __forceinline__ void sr_l1_fill(WRing& R1, const float* Wf, int tile0, int nt, int lane) {
+  if constexpr (NG1 > 0) ring_fill<NG1>(R1, Wf, tile0, nt, lane);
+}
+template <int NG1>
+__device__ __forceinline__ void sr_l1_gemm(f32x4v (&acc)[2], WRing& R1, const float* Wf, int nkg,
+                                           int tile0, int nt, const float* actp, int lane) {
+  static_assert(NG1 <= RP_PD, "a first layer's k-groups must fit the ring");
+  if constexpr (NG1 > 0) rows16_gemm_static<NG1>(acc, R1, Wf, tile0, nt, actp, lane);
   else rows16_gemm<4>(acc, Wf, nkg, tile0, nt, actp, lane);
 }
 
@@ -170,32 +239,40 @@ __device__ __forceinline__ void sr_mask_out(const f32x4v (&acc)[2], unsigned m, 
 }
 
 // Narrow output (<= 2 unit tiles starting at t_lo), K split over the eight waves: wave w takes
-// k-groups w and w + 8 (a hidden layer has at most 16), the partial tiles go to red[wave].
-__device__ __forceinline__ void sr_narrow_part(const float* Wf, int nkg, int t_lo, int ntl,
-                                               const float* actp, float* red, const SrLane& L) {
-  f32x4v acc[2];
-  sr_zero(acc);
+// k-groups w and w + 8 (a hidden layer has at most 16), the partial tiles go to red[wave].  The
+// four weight fragments are requested ahead of time (sr_narrow_load).
+struct SrNarrowW {
+  float4 w00, w10, w01, w11;
+};
+__device__ __forceinline__ void sr_narrow_load(SrNarrowW& w, const float* Wf, int nkg, int t_lo,
+                                               int ntl, const SrLane& L) {
   const int g0 = L.wave, g1 = L.wave + 8;
   const bool k0 = g0 < nkg, k1 = g1 < nkg;
   const int64_t b0 = ((int64_t)t_lo * nkg) * 256 + L.lane * 4;
   const int64_t b1 = b0 + (int64_t)nkg * 256;
-  const float4 w00 = ld4_or_zero(Wf, b0 + (int64_t)g0 * 256, k0 && ntl > 0);
-  const float4 w10 = ld4_or_zero(Wf, b1 + (int64_t)g0 * 256, k0 && ntl > 1);
-  const float4 w01 = ld4_or_zero(Wf, b0 + (int64_t)g1 * 256, k1 && ntl > 0);
-  const float4 w11 = ld4_or_zero(Wf, b1 + (int64_t)g1 * 256, k1 && ntl > 1);
-  if (k0) {
+  w.w00 = ld4_or_zero(Wf, b0 + (int64_t)g0 * 256, k0 && ntl > 0);
+  w.w10 = ld4_or_zero(Wf, b1 + (int64_t)g0 * 256, k0 && ntl > 1);
+  w.w01 = ld4_or_zero(Wf, b0 + (int64_t)g1 * 256, k1 && ntl > 0);
+  w.w11 = ld4_or_zero(Wf, b1 + (int64_t)g1 * 256, k1 && ntl > 1);
+}
+__device__ __forceinline__ void sr_narrow_mma(const SrNarrowW& w, int nkg, const float* actp,
+                                              float* red, const SrLane& L) {
+  f32x4v acc[2];
+  sr_zero(acc);
+  const int g0 = L.wave, g1 = L.wave + 8;
+  if (g0 < nkg) {
     const float4 x4 = *reinterpret_cast<const float4*>(actp + g0 * 16);
-    acc[0] = mfma16(w00.x, x4.x, acc[0]); acc[1] = mfma16(w10.x, x4.x, acc[1]);
-    acc[0] = mfma16(w00.y, x4.y, acc[0]); acc[1] = mfma16(w10.y, x4.y, acc[1]);
-    acc[0] = mfma16(w00.z, x4.z, acc[0]); acc[1] = mfma16(w10.z, x4.z, acc[1]);
-    acc[0] = mfma16(w00.w, x4.w, acc[0]); acc[1] = mfma16(w10.w, x4.w, acc[1]);
+    acc[0] = mfma16(w.w00.x, x4.x, acc[0]); acc[1] = mfma16(w.w10.x, x4.x, acc[1]);
+    acc[0] = mfma16(w.w00.y, x4.y, acc[0]); acc[1] = mfma16(w.w10.y, x4.y, acc[1]);
+    acc[0] = mfma16(w.w00.z, x4.z, acc[0]); acc[1] = mfma16(w.w10.z, x4.z, acc[1]);
+    acc[0] = mfma16(w.w00.w, x4.w, acc[0]); acc[1] = mfma16(w.w10.w, x4.w, acc[1]);
   }
-  if (k1) {
+  if (g1 < nkg) {
     const float4 x4 = *reinterpret_cast<const float4*>(actp + g1 * 16);
-    acc[0] = mfma16(w01.x, x4.x, acc[0]); acc[1] = mfma16(w11.x, x4.x, acc[1]);
-    acc[0] = mfma16(w01.y, x4.y, acc[0]); acc[1] = mfma16(w11.y, x4.y, acc[1]);
-    acc[0] = mfma16(w01.z, x4.z, acc[0]); acc[1] = mfma16(w11.z, x4.z, acc[1]);
-    acc[0] = mfma16(w01.w, x4.w, acc[0]); acc[1] = mfma16(w11.w, x4.w, acc[1]);
+    acc[0] = mfma16(w.w01.x, x4.x, acc[0]); acc[1] = mfma16(w.w11.x, x4.x, acc[1]);
+    acc[0] = mfma16(w.w01.y, x4.y, acc[0]); acc[1] = mfma16(w.w11.y, x4.y, acc[1]);
+    acc[0] = mfma16(w.w01.z, x4.z, acc[0]); acc[1] = mfma16(w.w11.z, x4.z, acc[1]);
+    acc[0] = mfma16(w.w01.w, x4.w, acc[0]); acc[1] = mfma16(w.w11.w, x4.w, acc[1]);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -209,51 +286,89 @@ __device__ __forceinline__ float sr_narrow_get(const float* red, int r, int c) {
   return s;
 }
 
+// Wide output, at most two k-groups (the actor's d h2 = d head W3): fragments requested early
+struct SrSmallW {
+  float4 a0, a1, b0, b1;     // tile0 / tile0 + 1, k-group 0 / 1
+};
+__device__ __forceinline__ void sr_small_load(SrSmallW& w, const float* Wf, int nkg, int tile0,
+                                              int nt, int lane) {
+  const int64_t base0 = ((int64_t)tile0 * nkg) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)nkg * 256;
+  w.a0 = ld4_or_zero(Wf, base0, tile0 < nt);
+  w.b0 = ld4_or_zero(Wf, base1, tile0 + 1 < nt);
+  w.a1 = ld4_or_zero(Wf, base0 + 256, tile0 < nt && nkg > 1);
+  w.b1 = ld4_or_zero(Wf, base1 + 256, tile0 + 1 < nt && nkg > 1);
+}
+__device__ __forceinline__ void sr_small_gemm(f32x4v (&acc)[2], const SrSmallW& w, int nkg,
+                                              const float* actp) {
+  {
+    const float4 x4 = *reinterpret_cast<const float4*>(actp);
+    acc[0] = mfma16(w.a0.x, x4.x, acc[0]); acc[1] = mfma16(w.b0.x, x4.x, acc[1]);
+    acc[0] = mfma16(w.a0.y, x4.y, acc[0]); acc[1] = mfma16(w.b0.y, x4.y, acc[1]);
+    acc[0] = mfma16(w.a0.z, x4.z, acc[0]); acc[1] = mfma16(w.b0.z, x4.z, acc[1]);
+    acc[0] = mfma16(w.a0.w, x4.w, acc[0]); acc[1] = mfma16(w.b0.w, x4.w, acc[1]);
+  }
+  if (nkg > 1) {
+    const float4 x4 = *reinterpret_cast<const float4*>(actp + 16);
+    acc[0] = mfma16(w.a1.x, x4.x, acc[0]); acc[1] = mfma16(w.b1.x, x4.x, acc[1]);
+    acc[0] = mfma16(w.a1.y, x4.y, acc[0]); acc[1] = mfma16(w.b1.y, x4.y, acc[1]);
+    acc[0] = mfma16(w.a1.z, x4.z, acc[0]); acc[1] = mfma16(w.b1.z, x4.z, acc[1]);
+    acc[0] = mfma16(w.a1.w, x4.w, acc[0]); acc[1] = mfma16(w.b1.w, x4.w, acc[1]);
+  }
+}
+
 // state (or next state) tile -> xs[:, 0:S], zeros up to the pitch
 __device__ __forceinline__ void sr_stage(const float* x, int ldx, int S, int m0, int B, float* xs,
-                                         int P0, int tid, int col0) {
+                                         int P0, int tid) {
   const int c4 = (P0 - 4) >> 2;
-  const bool vx = is_vec_ok(x, ldx) && ((S & 3) == 0) && ((col0 & 3) == 0);
+  const bool vx = is_vec_ok(x, ldx) && ((S & 3) == 0);
   for (int e = tid; e < RP_ROWS * c4; e += 512) {
     const int r = e / c4, c = (e - r * c4) * 4;
     const bool ok = (m0 + r) < B;
-    if (c < col0) continue;
     float4 v;
-    if (vx) v = ld4_or_zero(x, (int64_t)(m0 + r) * ldx + (c - col0), ok && (c - col0) < S);
-    else v = guarded_load4(x, (int64_t)(m0 + r) * ldx, ok, c - col0, S);
+    if (vx) v = ld4_or_zero(x, (int64_t)(m0 + r) * ldx + c, ok && c < S);
+    else v = guarded_load4(x, (int64_t)(m0 + r) * ldx, ok, c, S);
     *reinterpret_cast<float4*>(xs + r * P0 + c) = v;
   }
 }
 
+// What a network pass requests for whoever runs next
+struct SrNext {
+  const float* W1; int nt1;      // first-layer stream for the small ring (after this pass's layer 1)
+  const float* Wh; int nth;      // hidden stream for the ring (inside this pass's last hidden GEMM)
+};
+
 // One critic on the tile in xs: q, and (WANT_G) the unit gradients  s2 = [h2 > 0] w3 and
 // Gm = (s2 W2) [h1 > 0] — Gm stays in hC.  KEEP: h1, h2, s2, Gm also go to the network's kept
 // buffers.  Opens with a barrier (xs complete, hA / hB / hC free); the caller puts a barrier
-// between this and its first read of hC / qred.  The ring must hold W2f's first k-groups on entry
-// (NGH > 0) and holds `Wnext`'s on return.
-template <int NGH, bool WANT_G, bool KEEP>
-__device__ __forceinline__ void sr_critic(const SacMlp3& n, const float* xs, int P0, float* hA,
-                                          float* hB, float* hC, float* qred, WRing& R,
-                                          const SrLane& L, int64_t row, bool rok,
-                                          const float* Wnext, int nt_next, long long* prof = nullptr,
-                                          int wg = 0, int slot = 0) {
+// between this and its first read of hC / qred.  On entry R1 holds W1f and R holds W2f's first
+// k-groups (static instantiations).
+template <int NGH, int NG1, bool WANT_G, bool KEEP, bool EARLY1 = true>
+__device__ __forceinline__ void sr_critic(const SacMlp3& n, const float* cst, const float* xs,
+                                          int P0, float* hA, float* hB, float* hC, float* qred,
+                                          WRing& R, WRing& R1, const SrLane& L, int64_t row,
+                                          bool rok, const SrNext& nx, long long* prof, int wg,
+                                          int slot) {
   const int PH = row_hid_pitch();
   const int nt1 = (n.H1 + 15) >> 4, nt2 = (n.H2 + 15) >> 4;
   f32x4v acc[2];
-  // ---- layer 1
-  sr_bias(acc, n.b1, n.H1, L.u0);
+  // ---- layer 1 (the constants may have been staged by other threads just now: read them
+  // after the barrier)
   __syncthreads();
-  rows16_gemm<4>(acc, n.W1f, wf16_nkg(n.K0), L.tile0, nt1, xs + L.r16 * P0 + 4 * L.qd, L.lane);
+  sr_bias(acc, cst, L.u0);
+  sr_l1_gemm<NG1>(acc, R1, n.W1f, wf16_nkg(n.K0), L.tile0, nt1, xs + L.r16 * P0 + 4 * L.qd, L.lane);
+  // the next pass's first-layer stream: at once, or (register pressure) after this pass's GEMMs
+  if (EARLY1 && nx.W1) sr_l1_fill<NG1>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
   const unsigned m1 = sr_relu_out(acc, hA, PH, L, KEEP ? n.act1 : nullptr, row, n.H1, rok);
   SR_STAMP(prof, wg, slot);
   // ---- layer 2, the head's dot product, s2
-  sr_bias(acc, n.b2, n.H2, L.u0);
+  sr_bias(acc, cst + 256, L.u0);
   float4 w3v[2];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) w3v[t] = guarded_load4(n.w3, 0, true, L.u0 + 16 * t, n.H2);
+  for (int t = 0; t < 2; ++t) w3v[t] = *reinterpret_cast<const float4*>(cst + 512 + L.u0 + 16 * t);
   __syncthreads();
-  sr_gemm<NGH>(acc, R, n.W2f, wf16_nkg(n.H1), L.tile0, nt2, hA + L.r16 * PH + 4 * L.qd, L.lane);
-  if (WANT_G) sr_prefetch<NGH>(R, n.W2tf, L.tile0, nt1, L.lane);
-  else if (Wnext) sr_prefetch<NGH>(R, Wnext, L.tile0, nt_next, L.lane);
+  sr_gemm<NGH>(acc, R, n.W2f, wf16_nkg(n.H1), L.tile0, nt2, hA + L.r16 * PH + 4 * L.qd, L.lane,
+               WANT_G ? n.W2tf : nx.Wh, WANT_G ? nt1 : nx.nth);
   float qp = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -280,15 +395,16 @@ __device__ __forceinline__ void sr_critic(const SacMlp3& n, const float* xs, int
     // ---- Gm = (s2 W2) [h1 > 0]
     sr_zero(acc);
     __syncthreads();
-    sr_gemm<NGH>(acc, R, n.W2tf, wf16_nkg(n.H2), L.tile0, nt1, hB + L.r16 * PH + 4 * L.qd, L.lane);
-    if (Wnext) sr_prefetch<NGH>(R, Wnext, L.tile0, nt_next, L.lane);
+    sr_gemm<NGH>(acc, R, n.W2tf, wf16_nkg(n.H2), L.tile0, nt1, hB + L.r16 * PH + 4 * L.qd, L.lane,
+                 nx.Wh, nx.nth);
     sr_mask_out(acc, m1, hC, PH, L, KEEP ? n.dz1 : nullptr, row, n.H1, rok);
     SR_STAMP(prof, wg, slot + 2);
   }
+  if (!EARLY1 && nx.W1) sr_l1_fill<NG1>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
 }
 // q of row r from the eight waves' partial dot products (after a barrier)
-__device__ __forceinline__ float sr_q(const float* qred, int r, const float* b3) {
-  float q = b3[0];
+__device__ __forceinline__ float sr_q(const float* qred, int r, const float* cst) {
+  float q = cst[768];
 #pragma unroll
   for (int w = 0; w < 8; ++w) q += qred[w * RP_ROWS + r];
   return q;
@@ -296,30 +412,36 @@ __device__ __forceinline__ float sr_q(const float* qred, int r, const float* b3)
 
 // The actor on the tile in xs[:, 0:S]: head [16][2A] summed into headS (pitch SR_HEADP).  KEEP: the
 // hidden activations also go to act1 / act2 and the ReLU masks are returned.  Opens with a
-// barrier; closes with the barrier after which headS is complete.  Ring: holds W2f on entry.
-template <int NGH, bool KEEP>
-__device__ __forceinline__ void sr_actor_fwd(const SacMlp3& n, const float* xs, int P0, float* hA,
-                                             float* hB, float* red, float* headS, WRing& R,
-                                             const SrLane& L, int64_t row, bool rok, unsigned& m1,
-                                             unsigned& m2, const float* Wnext, int nt_next) {
+// barrier; closes with the barrier after which headS is complete.  On entry R1 holds W1f, R holds
+// W2f.
+template <int NGH, int NG1, int NG1N, bool KEEP>
+__device__ __forceinline__ void sr_actor_fwd(const SacMlp3& n, const float* cst, const float* xs,
+                                             int P0, float* hA, float* hB, float* red, float* headS,
+                                             WRing& R, WRing& R1, const SrLane& L, int64_t row,
+                                             bool rok, unsigned& m1, unsigned& m2,
+                                             const SrNext& nx) {
   const int PH = row_hid_pitch();
   const int nt1 = (n.H1 + 15) >> 4, nt2 = (n.H2 + 15) >> 4;
   f32x4v acc[2];
-  sr_bias(acc, n.b1, n.H1, L.u0);
   __syncthreads();
-  rows16_gemm<4>(acc, n.W1f, wf16_nkg(n.K0), L.tile0, nt1, xs + L.r16 * P0 + 4 * L.qd, L.lane);
+  sr_bias(acc, cst, L.u0);
+  sr_l1_gemm<NG1>(acc, R1, n.W1f, wf16_nkg(n.K0), L.tile0, nt1, xs + L.r16 * P0 + 4 * L.qd, L.lane);
+  // the head's fragments (needed after layer 2) and, after layer 2, the next pass's first layer
+  SrNarrowW hw;
+  sr_narrow_load(hw, n.W3f, wf16_nkg(n.H2), 0, (n.DO + 15) >> 4, L);
   m1 = sr_relu_out(acc, hA, PH, L, KEEP ? n.act1 : nullptr, row, n.H1, rok);
-  sr_bias(acc, n.b2, n.H2, L.u0);
+  sr_bias(acc, cst + 256, L.u0);
   __syncthreads();
-  sr_gemm<NGH>(acc, R, n.W2f, wf16_nkg(n.H1), L.tile0, nt2, hA + L.r16 * PH + 4 * L.qd, L.lane);
-  if (Wnext) sr_prefetch<NGH>(R, Wnext, L.tile0, nt_next, L.lane);
+  sr_gemm<NGH>(acc, R, n.W2f, wf16_nkg(n.H1), L.tile0, nt2, hA + L.r16 * PH + 4 * L.qd, L.lane,
+               nx.Wh, nx.nth);
+  if (nx.W1) sr_l1_fill<NG1N>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
   m2 = sr_relu_out(acc, hB, PH, L, KEEP ? n.act2 : nullptr, row, n.H2, rok);
   __syncthreads();
-  sr_narrow_part(n.W3f, wf16_nkg(n.H2), 0, (n.DO + 15) >> 4, hB + L.r16 * PH + 4 * L.qd, red, L);
+  sr_narrow_mma(hw, wf16_nkg(n.H2), hB + L.r16 * PH + 4 * L.qd, red, L);
   __syncthreads();
   if (L.tid < RP_ROWS * 32) {
     const int r = L.tid >> 5, c = L.tid & 31;
-    headS[r * SR_HEADP + c] = c < n.DO ? sr_narrow_get(red, r, c) + n.b3[c] : 0.f;
+    headS[r * SR_HEADP + c] = c < n.DO ? sr_narrow_get(red, r, c) + cst[512 + c] : 0.f;
   }
   __syncthreads();
 }
@@ -348,20 +470,19 @@ __device__ __forceinline__ float sr_sample(const float* headS, int r, int j, int
   return l;
 }
 
-// sum of 512 per-thread values: fixed order (LDS tree over the first 256 + 256 slots)
-__device__ __forceinline__ float sr_block_sum(float v, float* red512) {
-  red512[threadIdx.x] = v;
-  __syncthreads();
-  for (int w = 256; w >= 1; w >>= 1) {
-    if ((int)threadIdx.x < w) red512[threadIdx.x] += red512[threadIdx.x + w];
-    __syncthreads();
+// Per-tile loss partial: rowsum[0..15] (LDS) added in row order.  The launch's total is formed by
+// sac_finish_kernel at the end of the step — a ticket + fence per workgroup and a serial sum in the
+// last one cost ~2 us on every tile's critical path and ~9 us on the last.
+__device__ __forceinline__ void sr_tile_partial(const float* rowsum, float* partials, unsigned tile) {
+  if (threadIdx.x == 0) {
+    float p = 0.f;
+#pragma unroll
+    for (int r = 0; r < RP_ROWS; ++r) p += rowsum[r];
+    partials[tile] = p;
   }
-  const float r = red512[0];
-  __syncthreads();
-  return r;
 }
 
-template <int NGH>
+template <int NGH, int NGA, int NGC>
 __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
@@ -374,11 +495,12 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   float* red = hC + RP_ROWS * PH;                  // [8][16][SR_HEADP]
   float* dhS = red + 8 * RP_ROWS * SR_HEADP;       // [16][SR_DHP]
   float* qred = dhS + RP_ROWS * SR_DHP;            // [8][16]
-  float* small = qred + 8 * RP_ROWS;               // [8][16]: q1 q2 logp lossrow ...
+  float* small = qred + 8 * RP_ROWS;               // [8][16]: q1 q2 logp lossrow
+  float* cst = small + 8 * RP_ROWS;                // [3][SR_CST]: actor, critic 1, critic 2
   const int m0 = blockIdx.x * RP_ROWS;
   const int64_t row = m0 + L.r16;
   const bool rok = row < a.B;
-  WRing R;
+  WRing R, R1;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   SR_STAMP(a.prof, wg, 0);
 
@@ -386,7 +508,10 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     // ---------------------------------------------------------------- critic c at (s, a_batch)
     const int c = blockIdx.y - 1;
     const SacMlp3& n = a.critic[c];
+    sr_l1_fill<NGC>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
     sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
+    SrConsts kc;
+    sr_consts_load(kc, n, true, L.tid);
     // xs = state || action, zero padded
     {
       const int c4 = (P0 - 4) >> 2;
@@ -397,9 +522,10 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int col = cc + k;
-          v[k] = col < a.S ? ld_or_zero(a.state, (int64_t)(m0 + r) * a.ld_state + col, ok)
-                           : ld_or_zero(a.action, (int64_t)(m0 + r) * a.ld_action + (col - a.S),
-                                        ok && col < W);
+          const float vs = ld_or_zero(a.state, (int64_t)(m0 + r) * a.ld_state + col, ok && col < a.S);
+          const float va = ld_or_zero(a.action, (int64_t)(m0 + r) * a.ld_action + (col - a.S),
+                                      ok && col >= a.S && col < W);
+          v[k] = col < a.S ? vs : va;
         }
         *reinterpret_cast<float4*>(xs + r * P0 + cc) = make_float4(v[0], v[1], v[2], v[3]);
         if (c == 0 && ok) {
@@ -409,30 +535,50 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
         }
       }
     }
+    sr_consts_store(cst, kc, L.tid);
     SR_STAMP(a.prof, wg, 1);
-    sr_critic<NGH, true, true>(n, xs, P0, hA, hB, hC, qred, R, L, row, rok, nullptr, 0, a.prof, wg, 4);
+    SrNext none;
+    none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
+    sr_critic<NGH, NGC, true, true>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                    a.prof, wg, 4);
     __syncthreads();
-    if (L.tid < RP_ROWS && m0 + L.tid < a.B) a.q[c][m0 + L.tid] = sr_q(qred, L.tid, n.b3);
+    if (L.tid < RP_ROWS && m0 + L.tid < a.B) a.q[c][m0 + L.tid] = sr_q(qred, L.tid, cst);
     SR_STAMP(a.prof, wg, 15);
     return;
   }
 
   // ------------------------------------------------------------------ actor update rows
   const SacMlp3& n = a.actor;
+  sr_l1_fill<NGA>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
   sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
-  // noise of this thread's (row, component), requested before anything else
+  // noise of this thread's (row, component), requested before anything else needs it
   const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
   const bool sok = L.tid < RP_ROWS * a.A;
   const bool srok = sok && (m0 + sr) < a.B;
   const float eps = ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok);
   const float lo = ld_or_zero(a.low, sj, sok), hi = ld_or_zero(a.high, sj, sok);
   const float alpha = a.alpha[0];
-  sr_stage(a.state, a.ld_state, a.S, m0, a.B, xs, P0, L.tid, 0);
+  {
+    // every start-up request in flight before the first wait
+    SrTile xt;
+    SrConsts k0, k1, k2;
+    const bool fits = sr_tile_fits(P0);
+    if (fits) sr_tile_load(xt, a.state, a.ld_state, a.S, m0, a.B, P0, L.tid);
+    sr_consts_load(k0, n, false, L.tid);
+    sr_consts_load(k1, a.critic[0], true, L.tid);
+    sr_consts_load(k2, a.critic[1], true, L.tid);
+    if (fits) sr_tile_store(xt, xs, P0, L.tid);
+    else sr_stage(a.state, a.ld_state, a.S, m0, a.B, xs, P0, L.tid);
+    sr_consts_store(cst, k0, L.tid);
+    sr_consts_store(cst + SR_CST, k1, L.tid);
+    sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
+  }
   SR_STAMP(a.prof, wg, 1);
   unsigned m1a, m2a;
   float* headS = dhS;   // [16][SR_HEADP]; dhS proper is written only after the head was consumed
-  sr_actor_fwd<NGH, true>(n, xs, P0, hA, hB, red, headS, R, L, row, rok, m1a, m2a,
-                          a.critic[0].W2f, (a.critic[0].H2 + 15) >> 4);
+  sr_actor_fwd<NGH, NGA, NGC, true>(
+      n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
+      SrNext{a.critic[0].W1f, (a.critic[0].H1 + 15) >> 4, a.critic[0].W2f, (a.critic[0].H2 + 15) >> 4});
   SR_STAMP(a.prof, wg, 2);
   // ---- sample: action -> xs[:, S:], log pi
   SrGauss G;
@@ -452,22 +598,27 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   gx[0] = gx[1] = 0.f;
   const int t_lo = a.S >> 4;
   const int ntl = ((W + 15) >> 4) - t_lo;       // <= 2 (A <= 16)
+  SrSmallW w3t;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const SacMlp3& q = a.critic[c];
-    sr_critic<NGH, true, false>(q, xs, P0, hA, hB, hC, qred, R, L, row, rok,
-                                c == 0 ? a.critic[1].W2f : n.W2tf,
-                                c == 0 ? (a.critic[1].H2 + 15) >> 4 : (n.H1 + 15) >> 4, a.prof, wg,
-                                4 + 4 * c);
+    SrNarrowW gw;
+    sr_narrow_load(gw, q.W1tf, wf16_nkg(q.H1), t_lo, ntl, L);
+    SrNext nx;
+    nx.W1 = c == 0 ? a.critic[1].W1f : nullptr; nx.nt1 = (a.critic[1].H1 + 15) >> 4;
+    nx.Wh = c == 0 ? a.critic[1].W2f : n.W2tf;
+    nx.nth = c == 0 ? (a.critic[1].H2 + 15) >> 4 : (n.H1 + 15) >> 4;
+    sr_critic<NGH, NGC, true, false>(q, cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R, R1, L,
+                                     row, rok, nx, a.prof, wg, 4 + 4 * c);
+    if (c == 1) sr_small_load(w3t, n.W3tf, wf16_nkg(n.DO), L.tile0, (n.H2 + 15) >> 4, L.lane);
     __syncthreads();
-    if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, q.b3);
-    sr_narrow_part(q.W1tf, wf16_nkg(q.H1), t_lo, ntl, hC + L.r16 * PH + 4 * L.qd, red, L);
+    if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, cst + (1 + c) * SR_CST);
+    sr_narrow_mma(gw, wf16_nkg(q.H1), hC + L.r16 * PH + 4 * L.qd, red, L);
     __syncthreads();
     if (sok) gx[c] = sr_narrow_get(red, sr, (a.S & 15) + sj);
     SR_STAMP(a.prof, wg, 7 + 4 * c);
   }
   // ---- twin rule, loss, head gradient (twin_kernel mode 0, gauss_grad_kernel)
-  float lossrow = 0.f;
   if (sok) {
     const float q1 = small[sr], q2 = small[RP_ROWS + sr];
     const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
@@ -487,8 +638,8 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     if (srok) {
       a.d_head[(int64_t)(m0 + sr) * 2 * a.A + sj] = d_mu;
       a.d_head[(int64_t)(m0 + sr) * 2 * a.A + a.A + sj] = d_ls;
-      if (sj == 0) lossrow = alpha * small[2 * RP_ROWS + sr] - fminf(q1, q2);
     }
+    if (sj == 0) small[3 * RP_ROWS + sr] = srok ? alpha * small[2 * RP_ROWS + sr] - fminf(q1, q2) : 0.f;
   }
   SR_STAMP(a.prof, wg, 12);
   // zero the rest of the head-gradient tile (k padding of the next GEMM)
@@ -500,39 +651,21 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   f32x4v acc[2];
   sr_zero(acc);
   __syncthreads();
-  rows16_gemm<4>(acc, n.W3tf, wf16_nkg(n.DO), L.tile0, (n.H2 + 15) >> 4,
-                 dhS + L.r16 * SR_DHP + 4 * L.qd, L.lane);
+  sr_small_gemm(acc, w3t, wf16_nkg(n.DO), dhS + L.r16 * SR_DHP + 4 * L.qd);
   sr_mask_out(acc, m2a, hA, PH, L, n.dz2, row, n.H2, rok);
   SR_STAMP(a.prof, wg, 13);
   sr_zero(acc);
   __syncthreads();
   sr_gemm<NGH>(acc, R, n.W2tf, wf16_nkg(n.H2), L.tile0, (n.H1 + 15) >> 4,
-               hA + L.r16 * PH + 4 * L.qd, L.lane);
+               hA + L.r16 * PH + 4 * L.qd, L.lane, nullptr, 0);
   sr_mask_out(acc, m1a, nullptr, PH, L, n.dz1, row, n.H1, rok);
   SR_STAMP(a.prof, wg, 14);
-  // ---- actor loss: per-tile partial, the last workgroup adds them in tile order
-  __syncthreads();
-  const float part = sr_block_sum(lossrow, hB);
-  __shared__ unsigned last;
-  if (L.tid == 0) {
-    a.tk.partials[blockIdx.x] = part;
-    __threadfence();
-    last = (atomicAdd(a.tk.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-  }
-  __syncthreads();
+  // ---- actor loss: this tile's partial
+  sr_tile_partial(small + 3 * RP_ROWS, a.tk.partials, blockIdx.x);
   SR_STAMP(a.prof, wg, 15);
-  if (!last) return;
-  __threadfence();
-  float p = 0.f;
-  for (unsigned k = L.tid; k < gridDim.x; k += 512) p += __builtin_nontemporal_load(a.tk.partials + k);
-  const float total = sr_block_sum(p, hB);
-  if (L.tid == 0) {
-    a.loss_out[0] = total / (float)a.B;
-    *a.tk.ticket = 0u;
-  }
 }
 
-template <int NGH>
+template <int NGH, int NGA, int NGC>
 __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
@@ -546,13 +679,15 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   float* headS = red + 8 * RP_ROWS * SR_HEADP;
   float* qred = headS + RP_ROWS * SR_DHP;
   float* small = qred + 8 * RP_ROWS;
+  float* cst = small + 8 * RP_ROWS;
   const int m0 = blockIdx.x * RP_ROWS;
   const int64_t row = m0 + L.r16;
   const bool rok = row < a.B;
-  WRing R;
+  WRing R, R1;
   const int wg = blockIdx.x;
   SR_STAMP(a.prof, wg, 0);
   const SacMlp3& n = a.actor;
+  sr_l1_fill<NGA>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
   sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
   const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
   const bool sok = L.tid < RP_ROWS * a.A;
@@ -560,11 +695,32 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   const float eps = ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok);
   const float lo = ld_or_zero(a.low, sj, sok), hi = ld_or_zero(a.high, sj, sok);
   const float alpha = a.alpha_in[0];
-  sr_stage(a.next_state, a.ld_next, a.S, m0, a.B, xs, P0, L.tid, 0);
+  {
+    SrTile xt;
+    SrConsts k0, k1, k2;
+    const bool fits = sr_tile_fits(P0);
+    if (fits) sr_tile_load(xt, a.next_state, a.ld_next, a.S, m0, a.B, P0, L.tid);
+    sr_consts_load(k0, n, false, L.tid);
+    sr_consts_load(k1, a.target[0], true, L.tid);
+    sr_consts_load(k2, a.target[1], true, L.tid);
+    if (fits) sr_tile_store(xt, xs, P0, L.tid);
+    else sr_stage(a.next_state, a.ld_next, a.S, m0, a.B, xs, P0, L.tid);
+    sr_consts_store(cst, k0, L.tid);
+    sr_consts_store(cst + SR_CST, k1, L.tid);
+    sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
+  }
+  // this tile's Bellman-error inputs
+  float qa = 0.f, qb = 0.f, rew = 0.f, live = 0.f;
+  if (L.tid < RP_ROWS && m0 + L.tid < a.B) {
+    const int b = m0 + L.tid;
+    qa = a.q[0][b]; qb = a.q[1][b]; rew = a.reward[b];
+    live = 1.0f - (a.term[b] ? 1.0f : 0.0f);
+  }
   SR_STAMP(a.prof, wg, 1);
   unsigned m1a, m2a;
-  sr_actor_fwd<NGH, false>(n, xs, P0, hA, hB, red, headS, R, L, row, rok, m1a, m2a, a.target[0].W2f,
-                           (a.target[0].H2 + 15) >> 4);
+  sr_actor_fwd<NGH, NGA, NGC, false>(
+      n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
+      SrNext{a.target[0].W1f, (a.target[0].H1 + 15) >> 4, a.target[0].W2f, (a.target[0].H2 + 15) >> 4});
   SR_STAMP(a.prof, wg, 2);
   SrGauss G;
   float* terms = red;
@@ -576,35 +732,52 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
     small[2 * RP_ROWS + L.tid] = lp;
   }
   SR_STAMP(a.prof, wg, 3);
+  // the rows of s2 / Gm this workgroup will scale: requested now, needed after y
+  constexpr int SCALE_IT = 2;     // 16 rows x 256 / 4 floats = 1024 float4 per array
+  float4 pre[2][2][SCALE_IT];
+  const bool pre_ok = (a.H1c == 256) && (a.H2c == 256);
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    sr_critic<NGH, false, false>(a.target[c], xs, P0, hA, hB, hC, qred, R, L, row, rok,
-                                 c == 0 ? a.target[1].W2f : nullptr, (a.target[1].H2 + 15) >> 4,
-                                 a.prof, wg, 4 + 4 * c);
+    SrNext nx;
+    nx.W1 = c == 0 ? a.target[1].W1f : nullptr; nx.nt1 = (a.target[1].H1 + 15) >> 4;
+    nx.Wh = c == 0 ? a.target[1].W2f : nullptr; nx.nth = (a.target[1].H2 + 15) >> 4;
+    sr_critic<NGH, NGC, false, false>(a.target[c], cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R,
+                                      R1, L, row, rok, nx, a.prof, wg, 4 + 4 * c);
+    if (c == 1 && pre_ok) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+          for (int it = 0; it < SCALE_IT; ++it) {
+            const int e = L.tid + it * 512;
+            const int r = e >> 6, cc = (e & 63) * 4;
+            const float* base = which == 0 ? a.dz2[k] : a.dz1[k];
+            pre[k][which][it] = ld4_or_zero(base, (int64_t)(m0 + r) * 256 + cc, (m0 + r) < a.B);
+          }
+    }
     __syncthreads();
-    if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, a.target[c].b3);
+    if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, cst + (1 + c) * SR_CST);
   }
-  __syncthreads();
   // ---- y, the Bellman errors, the critic loss rows (twin_kernel mode 1, mse_head_kernel)
-  float lossrow = 0.f;
   if (L.tid < RP_ROWS) {
     const int b = m0 + L.tid;
-    float d1 = 0.f, d2 = 0.f;
+    float d1 = 0.f, d2 = 0.f, lr = 0.f;
     if (b < a.B) {
       const float mn = fminf(small[L.tid], small[RP_ROWS + L.tid]);
       const float v = mn - alpha * small[2 * RP_ROWS + L.tid];
-      const float live = 1.0f - (a.term[b] ? 1.0f : 0.0f);
-      const float y = __fadd_rn(__fmul_rn(__fmul_rn(v, a.gamma), live), a.reward[b]);
-      const float e1 = __fsub_rn(a.q[0][b], y), e2 = __fsub_rn(a.q[1][b], y);
+      const float y = __fadd_rn(__fmul_rn(__fmul_rn(v, a.gamma), live), rew);
+      const float e1 = __fsub_rn(qa, y), e2 = __fsub_rn(qb, y);
       const float gs = 1.0f / (float)a.B;
       d1 = __fmul_rn(gs, e1);
       d2 = __fmul_rn(gs, e2);
       a.dq[0][b] = d1;
       a.dq[1][b] = d2;
-      lossrow = e1 * e1 + e2 * e2;
+      lr = e1 * e1 + e2 * e2;
     }
     small[3 * RP_ROWS + L.tid] = d1;
     small[4 * RP_ROWS + L.tid] = d2;
+    small[5 * RP_ROWS + L.tid] = lr;
   }
   __syncthreads();
   SR_STAMP(a.prof, wg, 12);
@@ -615,6 +788,19 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
       float* base = which == 0 ? a.dz2[c] : a.dz1[c];
+      if (pre_ok) {
+#pragma unroll
+        for (int it = 0; it < SCALE_IT; ++it) {
+          const int e = L.tid + it * 512;
+          const int r = e >> 6, cc = (e & 63) * 4;
+          if (m0 + r >= a.B) continue;
+          float4 v = pre[c][which][it];
+          const float s = dqs[r];
+          v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+          *reinterpret_cast<float4*>(base + (int64_t)(m0 + r) * 256 + cc) = v;
+        }
+        continue;
+      }
       const int Hn = which == 0 ? a.H2c : a.H1c;
       const int c4 = (Hn + 3) >> 2;
       const bool vec = (Hn & 3) == 0;
@@ -634,47 +820,60 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
     }
   }
   SR_STAMP(a.prof, wg, 13);
-  // ---- critic loss + entropy coefficient: the last workgroup to finish
-  const float part = sr_block_sum(lossrow, hB);
-  __shared__ unsigned last;
-  if (L.tid == 0) {
-    a.tk.partials[blockIdx.x] = part;
-    __threadfence();
-    last = (atomicAdd(a.tk.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
-  }
-  __syncthreads();
+  // ---- critic loss: this tile's partial
+  sr_tile_partial(small + 5 * RP_ROWS, a.tk.partials, blockIdx.x);
   SR_STAMP(a.prof, wg, 15);
-  if (!last) return;
-  __threadfence();
-  float p = 0.f;
-  for (unsigned k = L.tid; k < gridDim.x; k += 512) p += __builtin_nontemporal_load(a.tk.partials + k);
-  const float total = sr_block_sum(p, hB);
-  if (L.tid == 0) {
-    // ((q1 - y)^2 + (q2 - y)^2 summed) / B / 2  ==  (mse1 + mse2) / 2   (critic_utils.py:170-203)
-    a.loss_out[0] = (total / (float)a.B) * 0.5f;
-    *a.tk.ticket = 0u;
-  }
-  if (a.log_alpha) {
-    // alpha_kernel's arithmetic: 256 strided partial sums, the same tree
-    const float ea = expf(a.log_alpha[0]);
-    float pa = 0.f;
-    if (L.tid < 256)
-      for (int b = L.tid; b < a.B; b += 256)
-        pa += -ea * (__builtin_nontemporal_load(a.logp + b) + a.target_entropy);
-    hB[L.tid] = L.tid < 256 ? pa : 0.f;
+}
+
+// End of the step (one workgroup): the two losses from the per-tile partials, in tile order, and
+// the entropy-coefficient step (:134-151) with alpha_kernel's arithmetic.
+struct SacFinishArgs {
+  const float* part_a; const float* part_b; int tiles; int B;
+  float* actor_loss; float* critic_loss;
+  float* log_alpha; float* am; float* av; float* avmax; float* alpha;
+  const float* logp; float target_entropy; AdamScalars ac; float* alpha_loss_out;
+};
+static __global__ __launch_bounds__(256) void sac_finish_kernel(SacFinishArgs a) {
+  __shared__ float red[256];
+  __shared__ float pa_[256], pb_[256];
+  const int tid = threadIdx.x;
+  float sa = 0.f, sb = 0.f;
+  // tiles in order within a thread, threads in order afterwards: a fixed summation order
+  for (int base = 0; base < a.tiles; base += 256) {
+    pa_[tid] = base + tid < a.tiles ? a.part_a[base + tid] : 0.f;
+    pb_[tid] = base + tid < a.tiles ? a.part_b[base + tid] : 0.f;
     __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-      if (L.tid < w) hB[L.tid] += hB[L.tid + w];
-      __syncthreads();
+    if (tid == 0) {
+      const int n = a.tiles - base < 256 ? a.tiles - base : 256;
+      for (int k = 0; k < n; ++k) {
+        sa += pa_[k];
+        sb += pb_[k];
+      }
     }
-    if (L.tid == 0) {
-      const float g = hB[0] / (float)a.B;
-      if (a.alpha_loss_out) a.alpha_loss_out[0] = g;
-      AdamState st;
-      st.p = a.log_alpha; st.m = a.am; st.v = a.av; st.vmax = a.avmax;
-      const float pnew = adam_update(a.ac, st, 0, g);
-      a.alpha[0] = expf(pnew);
-    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.actor_loss[0] = sa / (float)a.B;
+    // ((q1 - y)^2 + (q2 - y)^2 summed) / B / 2  ==  (mse1 + mse2) / 2   (critic_utils.py:170-203)
+    a.critic_loss[0] = (sb / (float)a.B) * 0.5f;
+  }
+  if (!a.log_alpha) return;
+  const float ea = expf(a.log_alpha[0]);
+  float part = 0.f;
+  for (int b = tid; b < a.B; b += 256) part += -ea * (a.logp[b] + a.target_entropy);
+  red[tid] = part;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float g = red[0] / (float)a.B;
+    if (a.alpha_loss_out) a.alpha_loss_out[0] = g;
+    AdamState st;
+    st.p = a.log_alpha; st.m = a.am; st.v = a.av; st.vmax = a.avmax;
+    const float pnew = adam_update(a.ac, st, 0, g);
+    a.alpha[0] = expf(pnew);
   }
 }
 

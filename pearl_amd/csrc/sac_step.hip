@@ -142,7 +142,7 @@ int64_t carve_fused(FusedScratch* s, float* base, int64_t B, int64_t S, int64_t 
   return o;
 }
 
-// tickets / per-tile partial sums of the two row kernels: one buffer per process, grown on demand
+// per-tile partial loss sums of the two row kernels: one buffer per process, grown on demand
 // (calls are ordered by their stream, like every use of a learner handle)
 int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
   static float* buf = nullptr;
@@ -153,34 +153,32 @@ int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
       (void)hipFree(buf);
     }
     const int n = tiles * 2;
-    PA_HIP(hipMalloc((void**)&buf, ((size_t)2 * n + 8) * sizeof(float)));
-    PA_HIP(hipMemset(buf, 0, ((size_t)2 * n + 8) * sizeof(float)));
+    PA_HIP(hipMalloc((void**)&buf, (size_t)2 * n * sizeof(float)));
+    PA_HIP(hipMemset(buf, 0, (size_t)2 * n * sizeof(float)));
     cap = n;
   }
-  ta->ticket = reinterpret_cast<unsigned*>(buf);
-  tb->ticket = reinterpret_cast<unsigned*>(buf) + 4;
-  ta->partials = buf + 8;
-  tb->partials = buf + 8 + cap;
+  ta->partials = buf;
+  tb->partials = buf + cap;
   return PA_OK;
 }
 
-template <int NGH>
+template <int NGH, int NGA, int NGC>
 int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s) {
   static size_t configured = 0;
   const size_t smem = sac_rows_smem_floats(W) * sizeof(float);
   if (smem > configured) {
-    int rc = set_max_smem(sac_rows_a_kernel<NGH>, smem);
+    int rc = set_max_smem(sac_rows_a_kernel<NGH, NGA, NGC>, smem);
     if (rc != PA_OK) return rc;
-    rc = set_max_smem(sac_rows_b_kernel<NGH>, smem);
+    rc = set_max_smem(sac_rows_b_kernel<NGH, NGA, NGC>, smem);
     if (rc != PA_OK) return rc;
     configured = smem;
   }
   if (ra) {
     const unsigned tiles = (unsigned)ceil_div(ra->B, RP_ROWS);
-    hipLaunchKernelGGL(sac_rows_a_kernel<NGH>, dim3(tiles, 3), dim3(512), smem, s, *ra);
+    hipLaunchKernelGGL((sac_rows_a_kernel<NGH, NGA, NGC>), dim3(tiles, 3), dim3(512), smem, s, *ra);
   } else {
     const unsigned tiles = (unsigned)ceil_div(rb->B, RP_ROWS);
-    hipLaunchKernelGGL(sac_rows_b_kernel<NGH>, dim3(tiles), dim3(512), smem, s, *rb);
+    hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC>), dim3(tiles), dim3(512), smem, s, *rb);
   }
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -232,12 +230,17 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   ra.noise = a->noise_actor; ra.ld_noise = A;
   ra.low = a->low; ra.high = a->high; ra.alpha = a->alpha;
   ra.B = B; ra.S = S; ra.A = A;
-  ra.d_head = w.d_head; ra.logp = w.logp; ra.xq = w.xq;
+  float* logp = a->log_prob_out ? a->log_prob_out : w.logp;   // no copy afterwards
+  ra.d_head = w.d_head; ra.logp = logp; ra.xq = w.xq;
   ra.q[0] = w.q1; ra.q[1] = w.q2;
   ra.tk = ta;
-  ra.loss_out = a->losses + 0;
   ra.prof = g_prof_a;
-  PA_TRY(ngh == 16 ? launch_rows<16>(&ra, nullptr, W, s) : launch_rows<0>(&ra, nullptr, W, s));
+  // instantiations: every loop unrolled (hidden 256, S = 49..64, S + A = 65..80: the benchmark
+  // shape), hidden layers unrolled only, all run-time
+  const int form = ngh != 16 ? 0 : (wf16_nkg(S) == 4 && wf16_nkg(W) == 5 ? 2 : 1);
+  PA_TRY((form == 2   ? launch_rows<16, 4, 5>(&ra, nullptr, W, s)
+          : form == 1 ? launch_rows<16, 0, 0>(&ra, nullptr, W, s)
+                      : launch_rows<0, 0, 0>(&ra, nullptr, W, s)));
   // ---------------------------------------------------------------- actor: dW + AdamW
   {
     const float* dzs[3] = {ac->dz[1], ac->dz[2], w.d_head};
@@ -262,17 +265,10 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   rb.dq[0] = w.dq1; rb.dq[1] = w.dq2;
   rb.B = B; rb.S = S; rb.A = A;
   rb.tk = tb;
-  rb.loss_out = a->losses + 1;
   rb.prof = g_prof_b;
-  if (a->log_alpha) {
-    rb.log_alpha = a->log_alpha; rb.am = a->alpha_m; rb.av = a->alpha_v; rb.avmax = a->alpha_vmax;
-    rb.alpha = a->alpha;
-    rb.logp = w.logp; rb.target_entropy = a->target_entropy;
-    rb.ac = scalar_adam(a->alpha_lr, a->alpha_beta1, a->alpha_beta2, a->alpha_eps,
-                        a->alpha_weight_decay, a->alpha_amsgrad, a->alpha_step);
-    rb.alpha_loss_out = a->losses + 2;
-  }
-  PA_TRY(ngh == 16 ? launch_rows<16>(nullptr, &rb, W, s) : launch_rows<0>(nullptr, &rb, W, s));
+  PA_TRY((form == 2   ? launch_rows<16, 4, 5>(nullptr, &rb, W, s)
+          : form == 1 ? launch_rows<16, 0, 0>(nullptr, &rb, W, s)
+                      : launch_rows<0, 0, 0>(nullptr, &rb, W, s)));
   // ---------------------------------------------------------------- critics: dW + AdamW, targets
   pa_mlp* cs[2] = {c1, c2};
   float* dqs[2] = {w.dq1, w.dq2};
@@ -280,12 +276,31 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
     const float* dzs[3] = {cs[i]->dz[1], cs[i]->dz[2], dqs[i]};
     const int ldzs[3] = {cs[i]->d.dims[1], cs[i]->d.dims[2], 1};
     mlp_set_pending(cs[i], w.xq, W, B, dzs, ldzs);
-    PA_TRY(pa_mlp_adam(cs[i], a->critic_step, s));
   }
-  PA_TRY(pa_mlp_soft_update(c1, a->tau, s));
-  PA_TRY(pa_mlp_soft_update(c2, a->tau, s));
-  if (a->log_prob_out)
-    PA_HIP(hipMemcpyAsync(a->log_prob_out, w.logp, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+  if (mlp_pair_fusable(c1, c2, true)) {
+    // both critics' weight gradients, AdamW and soft target updates: one launch
+    PA_TRY(mlp_adam_pair(c1, c2, a->critic_step, a->tau, s));
+  } else {
+    PA_TRY(pa_mlp_adam(c1, a->critic_step, s));
+    PA_TRY(pa_mlp_adam(c2, a->critic_step, s));
+    PA_TRY(pa_mlp_soft_update(c1, a->tau, s));
+    PA_TRY(pa_mlp_soft_update(c2, a->tau, s));
+  }
+  // ---------------------------------------------------------------- losses, entropy coefficient
+  SacFinishArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.part_a = ta.partials; fa.part_b = tb.partials; fa.tiles = tiles; fa.B = B;
+  fa.actor_loss = a->losses + 0; fa.critic_loss = a->losses + 1;
+  if (a->log_alpha) {
+    fa.log_alpha = a->log_alpha; fa.am = a->alpha_m; fa.av = a->alpha_v; fa.avmax = a->alpha_vmax;
+    fa.alpha = a->alpha;
+    fa.logp = logp; fa.target_entropy = a->target_entropy;
+    fa.ac = scalar_adam(a->alpha_lr, a->alpha_beta1, a->alpha_beta2, a->alpha_eps,
+                        a->alpha_weight_decay, a->alpha_amsgrad, a->alpha_step);
+    fa.alpha_loss_out = a->losses + 2;
+  }
+  hipLaunchKernelGGL(sac_finish_kernel, dim3(1), dim3(256), 0, s, fa);
+  PA_LAUNCH_CHECK();
   return PA_OK;
 }
 

@@ -30,6 +30,7 @@ from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import ExplorationModule
 from ..policy_learner import PolicyLearner, _looks_like_batch
+from .flat_mlp import FlatMlp
 
 
 def make_critic(state_dim: int, hidden_dims: Optional[List[int]], use_twin_critic: bool,
@@ -166,6 +167,10 @@ class ActorCriticBase(PolicyLearner):
         if presample is not None:
             presample(self._training_rounds, batch_size)
         try:
+            for m in self._flat.values():      # validated on the first step, trusted until the end
+                if isinstance(m, FlatMlp):
+                    m._loop_validated = False
+            FlatMlp.in_learn_loop = True
             for _ in range(self._training_rounds):
                 self._training_steps += 1
                 batch = replay_buffer.sample(batch_size)
@@ -174,6 +179,7 @@ class ActorCriticBase(PolicyLearner):
                 for k, v in self._learn_batch_device(self._preprocess_for_learn(batch)).items():
                     pending.setdefault(k, []).append(v)
         finally:
+            FlatMlp.leave_learn_loop()
             if presample is not None:
                 replay_buffer.drop_presampled()
         report: Dict[str, List[Any]] = {}

@@ -95,11 +95,34 @@ class FlatMlp:
                 return int(float(st["step"]))
         return 0
 
+    # While a learner's learn() loop owns the networks (FlatMlp.in_learn_loop), the torch-side step
+    # counters — one 0-d tensor per parameter, 6 fill_() calls per network per step — are written
+    # once at the end of the loop instead of after every step, and the per-step re-validation of the
+    # parameter / optimizer-state aliasing is skipped (nothing else runs between the steps).
+    in_learn_loop = False
+
     def _set_adam_steps(self, n: int) -> None:
+        if FlatMlp.in_learn_loop:
+            self._steps_dirty = n
+            FlatMlp._dirty.add(self)
+            return
+        self._steps_dirty = None
         for p in self._params():
             st = self.optimizer.state.get(p)
             if st is not None and "step" in st:
                 st["step"].fill_(float(n))
+
+    _dirty: set = set()
+
+    @staticmethod
+    def leave_learn_loop() -> None:
+        """End of a learn() loop: write the deferred step counters."""
+        FlatMlp.in_learn_loop = False
+        pending, FlatMlp._dirty = FlatMlp._dirty, set()
+        for m in pending:
+            n = getattr(m, "_steps_dirty", None)
+            if n is not None and m.optimizer is not None:
+                m._set_adam_steps(n)
 
     def _signature(self) -> Tuple:
         sig = []
@@ -112,6 +135,12 @@ class FlatMlp:
         return tuple(sig)
 
     def ensure(self, batch_hint: int = 0) -> "FlatMlp":
+        if FlatMlp.in_learn_loop and self.handle is not None and self._sig \
+                and batch_hint <= self.max_batch and getattr(self, "_loop_validated", False):
+            return self
+        self._loop_validated = FlatMlp.in_learn_loop
+        if getattr(self, "_steps_dirty", None) is not None and not FlatMlp.in_learn_loop:
+            self._set_adam_steps(self._steps_dirty)
         p0 = self._params()[0]
         if not p0.is_cuda:
             N.require_gpu()
@@ -139,7 +168,8 @@ class FlatMlp:
             self.handle, self._desc_key, self._sig = h, key, ()
             self.max_batch = max_b
         if self._sig and self._sig == self._signature():
-            self._steps = self.adam_steps()
+            if getattr(self, "_steps_dirty", None) is None:
+                self._steps = self.adam_steps()
             # same storage, but its CONTENTS may have been written through torch since the last
             # step (load_state_dict copies in place; every in-place torch op bumps the tensor's
             # version counter, our own kernels do not): derived copies are rebuilt on next use
