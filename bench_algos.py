@@ -37,6 +37,25 @@ def dspace(n):
     return DiscreteActionSpace([torch.tensor([k]) for k in range(n)])
 
 
+PEAK_F32_MFMA = 157.3e12   # dense fp32 MFMA, MI355X_MICROARCH.md
+
+
+def mlp_macs(dims):
+    return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+
+
+def step_roofline(flop_per_transition, transitions, seconds, kernel=None):
+    """fp32-MFMA roofline of a learner step: algorithmic flops (2 per multiply-add of every layer
+    GEMM the reference's forward / backward performs) over wall time."""
+    ach = flop_per_transition * transitions / seconds
+    out = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+           "frac": ach / PEAK_F32_MFMA, "traffic": None, "flop_per_transition": flop_per_transition,
+           "scope": "whole learner step (wall time of learn())"}
+    if kernel:
+        out["kernel"] = kernel
+    return out
+
+
 def timed(fn, warm=1):
     for _ in range(warm):
         fn()
@@ -65,8 +84,39 @@ def bench_sac(steps, cpu_seconds):
     ids = torch.arange(N, device=DEV)
     rb.push_many(state=st[:-1], action=act, reward=(ids % 7).float(), terminated=(ids % 50 == 0),
                  truncated=torch.zeros(N, dtype=torch.bool, device=DEV), next_state=st[1:])
-    dt, _ = timed(lambda: agent.learn())
+    import ctypes as C
+    from pearl_amd import _native as N_
+    agent.learn()                      # warm-up
+    sync()
+    N_.check(N_.lib().pa_sac_timing(1))
+    dt, _ = timed(lambda: agent.learn(), warm=0)
+    ua, ub, nt = C.c_double(), C.c_double(), C.c_int64()
+    N_.check(N_.lib().pa_sac_timing_read(C.byref(ua), C.byref(ub), C.byref(nt)))
+    N_.check(N_.lib().pa_sac_timing(0))
     gpu = B * steps / dt
+    # algorithmic flops per transition (2 per multiply-add): what the reference's autograd does
+    H = 256
+    actor, critic = mlp_macs([S, H, H, 2 * A]), mlp_macs([S + A, H, H, 1])
+    bwd_dx = lambda dims: sum(a * b for a, b in zip(dims[1:-1], dims[2:]))       # dX of layers >= 1
+    f_actor_upd = 2 * (actor + 2 * critic + 2 * (bwd_dx([S + A, H, H, 1]) + H * A)   # critics: fwd + dx
+                       + bwd_dx([S, H, H, 2 * A]) + actor)                           # actor: dX + dW
+    f_critic_upd = 2 * (actor + 2 * critic                                           # targets
+                        + 2 * (critic + bwd_dx([S + A, H, H, 1]) + critic))          # online: fwd, dX, dW
+    flop_step = f_actor_upd + f_critic_upd
+    # the dominant kernel, sac_rows_a (actor rows || both critics at (s, a_batch)): its own flops
+    f_rows_a = 2 * (actor + 2 * (critic + H * H + H * A) + 2 * A * H + H * H       # actor rows
+                    + 2 * (critic + H * H))                                         # critic rows
+    roof = step_roofline(flop_step, B * steps, dt)
+    if nt.value:
+        ka = f_rows_a * B / (ua.value * 1e-6)
+        roof.update({"kernel": "sac_rows_a_kernel<16,4,5> (actor-update rows || critics at (s, a_batch))",
+                     "achieved": ka / 1e12, "frac": ka / PEAK_F32_MFMA, "avg_launch_us": ua.value,
+                     "flop_per_launch": f_rows_a * B, "launches_timed": nt.value,
+                     "scope": "dominant kernel, HIP events on the learner stream inside the timed learn()",
+                     "other_kernels_us": {"sac_rows_b_kernel": ub.value},
+                     "step": {"achieved": flop_step * B * steps / dt / 1e12,
+                              "frac": flop_step * B * steps / dt / PEAK_F32_MFMA,
+                              "flop_per_transition": flop_step}})
     # CPU oracle on the same shapes (one fixed batch: the oracle has no replay of its own)
     orc = SacOracle({k: v.cpu() for k, v in pl._actor.state_dict().items()},
                     {k: v.cpu() for k, v in pl._critic.state_dict().items()},
@@ -80,7 +130,7 @@ def bench_sac(steps, cpu_seconds):
     cpu = B * n / (time.perf_counter() - t0)
     return {"config": "cfg3 ContinuousSoftActorCritic S=64 A=8 twin-Q [256,256] B=1024 replay 200k",
             "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
-            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps, "roofline": roof,
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
 
@@ -216,6 +266,13 @@ def bench_ppo(steps, cpu_seconds):
     return {"config": "cfg4 PPO+GAE S=256 A=16 [256,256] rollout 65536 minibatch 4096",
             "metric": "learner transitions/s through PolicyLearner.learn (minibatch sample + learn_batch)",
             "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "roofline": step_roofline(
+                # actor [S,256,256,A] + critic [S,256,256,1]: forward, dX of layers >= 1, dW of all
+                2 * sum(2 * mlp_macs(d) + sum(a * b for a, b in zip(d[1:-1], d[2:]))
+                        for d in ([S, 256, 256, A], [S, 256, 256, 1])),
+                B * steps, dt,
+                kernel="weight_grad_kernel (2 launches of ~26 us per step; per-kernel durations: "
+                       "profiles/r02_ppo_kernel_stats.txt)"),
             "preprocess_replay_buffer": {"transitions_per_s": N / dt_pre, "ms": 1e3 * dt_pre,
                                          "what": "action probs + values of 65536 states, GAE / lambda-return scan"},
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),

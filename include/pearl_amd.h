@@ -458,6 +458,9 @@ int64_t pa_sac_scratch_floats(int32_t B, int32_t S, int32_t A);
 int pa_sac_step(const pa_sac_step_args* args, void* stream);
 /* tuning aid (tools/prof_sac.py): in-kernel phase stamps of the two fused row kernels */
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
+/* HIP-event timing of the two fused row launches (first 64 steps after enabling): bench lines */
+int pa_sac_timing(int32_t enable);
+int pa_sac_timing_read(double* rows_a_us, double* rows_b_us, int64_t* steps);
 
 /* VanillaActorNetwork.get_action_prob (actor_networks.py:155-176): softmax(logits) . action_rep.
  * probs_out [B, A] may be NULL. */

@@ -368,6 +368,8 @@ SIGNATURES = {
     "pa_sac_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "pa_sac_step": (C.c_int, [C.POINTER(SacStepArgs), _P]),
     "pa_debug_sac_prof": (C.c_int, [_P, _P]),
+    "pa_sac_timing": (C.c_int, [C.c_int32]),
+    "pa_sac_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_sac_alpha_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_double,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                     C.c_int64, _P, _P]),

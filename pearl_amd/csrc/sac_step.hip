@@ -203,6 +203,16 @@ AdamScalars scalar_adam(double lr, double b1, double b2, double eps, double wd, 
 long long* g_prof_a = nullptr;
 long long* g_prof_b = nullptr;
 
+// Live kernel timing for the bench line (bench_algos.py): HIP events on the learner's stream around
+// the two row launches of the first kTimedSteps steps after pa_sac_timing(1).
+constexpr int kTimedSteps = 64;
+struct RowTimers {
+  bool on = false;
+  int n = 0;
+  hipEvent_t ev[kTimedSteps][4];
+  bool made = false;
+} g_tm;
+
 int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   pa_mlp *ac = a->actor, *c1 = a->critic1, *c2 = a->critic2;
   const int B = a->B, S = a->S, A = a->A, W = S + A;
@@ -238,9 +248,12 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   // instantiations: every loop unrolled (hidden 256, S = 49..64, S + A = 65..80: the benchmark
   // shape), hidden layers unrolled only, all run-time
   const int form = ngh != 16 ? 0 : (wf16_nkg(S) == 4 && wf16_nkg(W) == 5 ? 2 : 1);
+  const bool timed = g_tm.on && g_tm.n < kTimedSteps;
+  if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][0], s));
   PA_TRY((form == 2   ? launch_rows<16, 4, 5>(&ra, nullptr, W, s)
           : form == 1 ? launch_rows<16, 0, 0>(&ra, nullptr, W, s)
                       : launch_rows<0, 0, 0>(&ra, nullptr, W, s)));
+  if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][1], s));
   // ---------------------------------------------------------------- actor: dW + AdamW
   {
     const float* dzs[3] = {ac->dz[1], ac->dz[2], w.d_head};
@@ -266,9 +279,14 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   rb.B = B; rb.S = S; rb.A = A;
   rb.tk = tb;
   rb.prof = g_prof_b;
+  if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][2], s));
   PA_TRY((form == 2   ? launch_rows<16, 4, 5>(nullptr, &rb, W, s)
           : form == 1 ? launch_rows<16, 0, 0>(nullptr, &rb, W, s)
                       : launch_rows<0, 0, 0>(nullptr, &rb, W, s)));
+  if (timed) {
+    PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][3], s));
+    ++g_tm.n;
+  }
   // ---------------------------------------------------------------- critics: dW + AdamW, targets
   pa_mlp* cs[2] = {c1, c2};
   float* dqs[2] = {w.dq1, w.dq2};
@@ -374,5 +392,34 @@ extern "C" int pa_sac_step(const pa_sac_step_args* a, void* stream) {
 extern "C" int pa_debug_sac_prof(long long* rows_a, long long* rows_b) {
   g_prof_a = rows_a;
   g_prof_b = rows_b;
+  return PA_OK;
+}
+
+// HIP-event timing of the two fused row launches (bench_algos.py's roofline object)
+extern "C" int pa_sac_timing(int32_t enable) {
+  if (enable && !g_tm.made) {
+    for (int i = 0; i < kTimedSteps; ++i)
+      for (int k = 0; k < 4; ++k) PA_HIP(hipEventCreate(&g_tm.ev[i][k]));
+    g_tm.made = true;
+  }
+  g_tm.on = enable != 0;
+  g_tm.n = 0;
+  return PA_OK;
+}
+// average launch durations (us) over the steps timed so far; synchronises with their events
+extern "C" int pa_sac_timing_read(double* rows_a_us, double* rows_b_us, int64_t* steps) {
+  PA_REQUIRE(rows_a_us && rows_b_us && steps, PA_ERR_INVALID, "null output");
+  double sa = 0.0, sb = 0.0;
+  for (int i = 0; i < g_tm.n; ++i) {
+    float ms = 0.f;
+    PA_HIP(hipEventSynchronize(g_tm.ev[i][3]));
+    PA_HIP(hipEventElapsedTime(&ms, g_tm.ev[i][0], g_tm.ev[i][1]));
+    sa += ms;
+    PA_HIP(hipEventElapsedTime(&ms, g_tm.ev[i][2], g_tm.ev[i][3]));
+    sb += ms;
+  }
+  *steps = g_tm.n;
+  *rows_a_us = g_tm.n ? 1e3 * sa / g_tm.n : 0.0;
+  *rows_b_us = g_tm.n ? 1e3 * sb / g_tm.n : 0.0;
   return PA_OK;
 }

@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU round: gpu test-suite, smoke, the driver's own bench command (20 steps), the long bench with
 # the CPU baseline, per-call fixed cost of learn(), bench_algos, rocprofv3 kernel trace + timeline
-# of the driver's command; "pmc" as $1 adds the counter passes.  Everything lands in gpurun_out/;
+# of the driver's command, the 1-rank RCCL run + all-reduce latency, SAC / PPO kernel summaries;
+# "pmc" as $1 adds the counter passes.  Everything lands in gpurun_out/;
 # copy what should be judged into profiles/ (tracked).
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
@@ -24,7 +25,27 @@ if [ "$SKIP_ALGOS" != "1" ]; then
 timeout 600 python bench_algos.py --steps 300 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
 echo "bench_algos rc=$?"; cut -c1-300 gpurun_out/bench_algos.jsonl
 fi
+# multi-GPU readiness on one GPU: the driver's torchrun command line with the data-parallel loop
+# forced on (1-rank RCCL communicator: every round's gradient goes through ncclAllReduce), and
+# the latency of that one collective
+PEARL_AMD_FORCE_DP=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+  --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2000 --warmup 200 --no-cpu-baseline \
+  > gpurun_out/bench_dp1.log 2> gpurun_out/bench_dp1.err
+echo "bench dp1 rc=$?"; tail -1 gpurun_out/bench_dp1.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d.get('comm'))"
+timeout 300 python tools/allreduce_latency.py > gpurun_out/allreduce_latency.json 2> gpurun_out/allreduce_latency.err
+echo "allreduce rc=$?"; cat gpurun_out/allreduce_latency.json
+# the fused SAC step: in-kernel phase stamps
+timeout 300 python tools/prof_sac.py > gpurun_out/prof_sac.txt 2>&1
+echo "prof_sac rc=$?"; grep -E "whole launch|^end" gpurun_out/prof_sac.txt
 cd /tmp && export TMPDIR=/tmp
+for w in sac ppo; do
+  rm -rf $R/gpurun_out/prof_$w
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0.5 > $R/gpurun_out/rocprof_$w.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+  echo "rocprof $w rc=$?"; head -8 $R/gpurun_out/${w}_kernel_stats.txt
+  rm -f $DB
+done
 rm -rf $R/gpurun_out/prof
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof rc=$?"; tail -1 $R/gpurun_out/rocprof.log | cut -c1-200
