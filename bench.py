@@ -143,19 +143,7 @@ def main():
 
     if args.warmup > 0:
         agent.learn()
-    pl._training_rounds = args.steps
     nat = pl._ensure_bound(B, A)
-    N.check(N.lib().pa_dqn_enable_timing(nat.handle, args.timing_level))
-    barrier()
-    t0 = time.perf_counter()
-    report = agent.learn()          # exactly `steps` rounds; returns after its single host sync
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
 
     def read_timers():
         out = {}
@@ -168,21 +156,38 @@ def main():
                 out[name] = {"avg_us": ms.value * 1e3, "n": cnt.value, "units": units.value}
         return out
 
-    timers = read_timers()
-    # Calibration pass (outside the timed region): the same target kernel with the chip to itself,
-    # i.e. the single-stream loop, so that the kernel's own efficiency can be told apart from the
-    # CU sharing of the overlapped loop.  N = 1 only: multi-GPU runs stay short.
+    # Calibration pass (outside the timed region, BEFORE it): the same target kernel with the chip to
+    # itself, i.e. the single-stream loop, so that the kernel's own efficiency can be told apart
+    # from the CU sharing of the overlapped loop.  N = 1 only: multi-GPU runs stay short.  It runs
+    # first because a GPU that has been idle takes its first millisecond of work at reduced clocks
+    # (tools/firstcall.py: the same 20-round call costs 1.18 ms cold, 1.07 ms in steady state,
+    # 1.43 ms after half a second of idling) — the line says so in `untimed_rounds_before`.
     isolated = None
     overlapped = os.environ.get("PEARL_AMD_OVERLAP", "1") != "0" and args.timing_level < 2
+    calib_rounds = 0
     if world == 1 and args.timing_level == 1 and overlapped:
+        calib_rounds = 200
         N.check(N.lib().pa_dqn_set_overlap(nat.handle, 0))
         N.check(N.lib().pa_dqn_enable_timing(nat.handle, 1))
-        pl._training_rounds = 200
+        pl._training_rounds = calib_rounds
         agent.learn()
         torch.cuda.synchronize(dev)
         isolated = read_timers().get("target")
         N.check(N.lib().pa_dqn_set_overlap(nat.handle, 1))
-        pl._training_rounds = args.steps
+    pl._training_rounds = args.steps
+    N.check(N.lib().pa_dqn_enable_timing(nat.handle, args.timing_level))
+    barrier()
+    t0 = time.perf_counter()
+    report = agent.learn()          # exactly `steps` rounds; returns after its single host sync
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert len(report["loss"]) == args.steps and all(x == x for x in report["loss"])
+
+    timers = read_timers()
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
 
     if rank == 0:
@@ -190,7 +195,8 @@ def main():
         line = {
             "metric": "learner transitions/sec (DQN batch=1024, [256,256] MLP)",
             "value": value, "unit": "transitions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "warmup": args.warmup, "untimed_rounds_before": args.warmup + calib_rounds,
+            "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: DeepQLearning synthetic 128-dim obs / "
@@ -237,7 +243,7 @@ def main():
                     "achieved": iach / 1e12, "frac": iach / PEAK_F32_MFMA,
                     "avg_launch_us": isolated["avg_us"], "transitions_per_launch": iper,
                     "launches_timed": isolated["n"],
-                    "note": "same kernel, single-stream loop, chip to itself (outside the timed region)"}
+                    "note": "same kernel, single-stream loop, chip to itself (calibration pass before the timed region)"}
             # the whole learner step against the same peak: 2.713 MFLOP per transition / wall time
             line["roofline"]["step"] = {"achieved": step_rate / 1e12,
                                         "frac": step_rate / PEAK_F32_MFMA,

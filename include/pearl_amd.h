@@ -251,6 +251,9 @@ int pa_dqn_param_offsets(int32_t S, int32_t AD, int32_t H1, int32_t H2, int64_t*
 int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc);
 int pa_dqn_destroy(pa_dqn* h);
 int pa_dqn_bind(pa_dqn* h, const pa_dqn_buffers* bufs);
+/* The bound flat buffers were written from outside the library (e.g. torch in-place ops): derived
+ * copies (fragment-major weights) are rebuilt by the next call that needs them. */
+int pa_dqn_invalidate(pa_dqn* h);
 
 /* Parity probe: Q(s,a) of the online net (q_out[B]), max_a' Q_target(s',a')
  * (next_v_out[B]) and the Bellman target (target_out[B]).  Any output may be NULL. */

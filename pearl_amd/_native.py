@@ -285,6 +285,7 @@ SIGNATURES = {
     "pa_dqn_create": (C.c_int, [C.POINTER(_P), C.POINTER(DqnDesc)]),
     "pa_dqn_destroy": (C.c_int, [_P]),
     "pa_dqn_bind": (C.c_int, [_P, C.POINTER(DqnBuffers)]),
+    "pa_dqn_invalidate": (C.c_int, [_P]),
     "pa_dqn_qvalues": (C.c_int, [_P, C.POINTER(DqnBatch), _P, _P, _P, _P]),
     "pa_dqn_update_target": (C.c_int, [_P, _P]),
     "pa_dqn_step": (C.c_int, [_P, C.POINTER(DqnBatch), C.c_int32, C.c_int64, C.c_int32, _P, _P]),

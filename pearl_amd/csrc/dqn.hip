@@ -79,6 +79,10 @@ struct pa_dqn {
   int pending_signal;  // generation the NEXT row-pass launch publishes when it starts (0: none)
   int use_flags;     // PEARL_AMD_FLAG_HOP (default 1); 0 = events as before
   int lead_persist;  // PEARL_AMD_LEAD_PERSIST: leading target pieces keep off the chain's CUs
+  // the fragment-major copies (online + target) match the flat parameters: true after a learn()
+  // whose every round refreshed them in its optimizer epilogue; cleared by anything else that
+  // writes parameters (bind, step, apply, update_target, pa_dqn_invalidate)
+  bool packed_ok;
   int* err_dev;      // device error word (a bounded wait expired)
   int* err_host;     // pinned mirror, copied at the end of learn()
   int overlap;       // 0: single-stream learn loop (PEARL_AMD_OVERLAP=0 or timing level >= 2)
@@ -842,6 +846,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->lead_persist = env_int("PEARL_AMD_LEAD_PERSIST", 0);
   h->err_dev = nullptr;
   h->err_host = nullptr;
+  h->packed_ok = false;
   h->overlap = env_int("PEARL_AMD_OVERLAP", 1);
   h->split_first = env_int("PEARL_AMD_SPLIT_FIRST", 3);
   h->y_clean = false;
@@ -953,6 +958,15 @@ extern "C" int pa_dqn_bind(pa_dqn* h, const pa_dqn_buffers* bufs) {
                "flat buffers must be 16-byte aligned");
   h->bufs = *bufs;
   h->bound = true;
+  h->packed_ok = false;
+  return PA_OK;
+}
+
+// The flat parameter buffers were written from outside the library (torch in-place ops): derived
+// copies are rebuilt by the next call that needs them.
+extern "C" int pa_dqn_invalidate(pa_dqn* h) {
+  PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
+  h->packed_ok = false;
   return PA_OK;
 }
 
@@ -981,6 +995,7 @@ extern "C" int pa_dqn_qvalues(pa_dqn* h, const pa_dqn_batch* batch, float* q_out
 extern "C" int pa_dqn_update_target(pa_dqn* h, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
+  h->packed_ok = false;
   return run_soft_update(h, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -989,6 +1004,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
                            void* stream) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   PA_HIP(hipSetDevice(h->d.device));
+  h->packed_ok = false;
   return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out,
                    reinterpret_cast<hipStream_t>(stream));
 }
@@ -996,6 +1012,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
 extern "C" int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
+  h->packed_ok = false;
   return run_adamw(h, adam_step, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1072,12 +1089,19 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
   auto due = [&](int r) { return ((args->training_steps0 + r + 2) % args->target_update_freq) == 0; };
   // the first round's soft update runs stand-alone; later ones ride the previous optimizer launch
+  bool stale_target = !h->packed_ok;
   if (due(0)) {
     rc = run_soft_update(h, s);
     if (rc != PA_OK) return rc;
+    stale_target = true;
   }
-  rc = run_repack(h, true, true, s);
-  if (rc != PA_OK) return rc;
+  // back-to-back learn() calls: the previous call's optimizer epilogues left the packed copies
+  // current (6 us on the critical path of every call otherwise)
+  if (!h->packed_ok || stale_target) {
+    rc = run_repack(h, !h->packed_ok, stale_target, s);
+    if (rc != PA_OK) return rc;
+  }
+  h->packed_ok = false;   // until this call has completed its last round
   if (overlap) {
     // Tagged hand-off invariant: every word of both y buffers is kYPendingBits whenever no target
     // pass is in flight.  The consumer (online_rowpass_kernel) restores the tag after reading, so
@@ -1264,6 +1288,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     r += w;
     ++k;
   }
+  // single-process rounds end in weight_grad_kernel's fused optimizer epilogue, which refreshes
+  // every packed copy (target included, on soft-update rounds)
+  h->packed_ok = !dp && !dbl;
   if (overlap) {
     // everything the side stream did is ordered before whatever the caller enqueues next
     PA_HIP(hipEventRecord(h->ev_tail, t));

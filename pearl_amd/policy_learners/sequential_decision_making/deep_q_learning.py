@@ -613,8 +613,18 @@ class DeepQLearning(PolicyLearner):
         arena = replay_buffer.arena
         nat = self._ensure_bound(batch_size, arena.layout.max_actions)
         dev = arena.device
-        if nat.loss_buf.numel() < rounds:
-            nat.loss_buf = torch.zeros(2 * rounds, dtype=torch.float32, device=dev)
+        # Parameters written through torch since the last call (load_state_dict copies in place; every
+        # in-place torch op bumps the tensor's version counter, our kernels do not): the library's
+        # derived copies are stale.  Otherwise back-to-back calls skip their rebuild.
+        # (the Parameters alias the flat buffers' storage but keep their own version counters)
+        ver = tuple(v for pq, pt in self._param_pairs() for v in (pq._version, pt._version))
+        if ver != getattr(nat, "versions", None):
+            N.check(N.lib().pa_dqn_invalidate(nat.handle))
+            nat.versions = ver
+        # learn() reports every round's loss: the optimizer kernel stores them straight into pinned,
+        # device-mapped host memory (4 bytes per round over PCIe, fire-and-forget), so the end of the
+        # call is one stream synchronisation — no device-to-host copy, no pageable staging
+        self._loss_host(nat, rounds)
         onehot = isinstance(self.action_representation_module,
                             OneHotActionTensorRepresentationModule)
         if rounds == 0:
@@ -633,14 +643,21 @@ class DeepQLearning(PolicyLearner):
             target_update_freq=int(self._target_update_freq),
             training_steps0=int(self._training_steps), adam_step0=self._adam_steps(),
             seed=random.getrandbits(64) if idx_host is None else 0, offset0=0,
-            losses_out=nat.loss_buf.data_ptr(),
+            losses_out=nat.loss_host.data_ptr(),
             idx_host=None if idx_host is None else idx_host.ctypes.data)
         N.check(N.lib().pa_dqn_learn(nat.handle, arena.handle, C.byref(args), N.stream_ptr(dev)))
         self._training_steps += rounds
         self._set_adam_steps(args.adam_step0 + rounds)
-        losses = nat.loss_buf[:rounds].tolist()  # the single host sync of this call
+        torch.cuda.current_stream(dev).synchronize()   # the single host sync of this call
+        losses = nat.loss_host[:rounds].tolist()
         N.check(N.lib().pa_dqn_check(nat.handle))
         return {"loss": losses}
+
+    @staticmethod
+    def _loss_host(nat: "_NativeDqn", rounds: int) -> torch.Tensor:
+        if getattr(nat, "loss_host", None) is None or nat.loss_host.numel() < rounds:
+            nat.loss_host = torch.zeros(max(2 * rounds, 1024), dtype=torch.float32, pin_memory=True)
+        return nat.loss_host
 
     def _native_comm(self, dev: torch.device) -> Optional[C.c_void_p]:
         """One RCCL communicator per process for the native all-reduce hooks (pa_comm_*): rank 0
@@ -692,6 +709,7 @@ class DeepQLearning(PolicyLearner):
         shard with their own index stream; parameters stay identical across ranks."""
         nat, arena = self._native, replay_buffer.arena
         dev = arena.device
+        self._loss_host(nat, rounds)
         world = int(force_world) if force_world is not None else self._dp_world()
         grad = nat.flat["grad"]
         state: Dict[str, Any] = {"work": None, "error": None}
@@ -735,7 +753,7 @@ class DeepQLearning(PolicyLearner):
             target_update_freq=int(self._target_update_freq),
             training_steps0=int(self._training_steps), adam_step0=self._adam_steps(),
             seed=random.getrandbits(64) if idx_host is None else 0, offset0=0,
-            losses_out=nat.loss_buf.data_ptr(),
+            losses_out=nat.loss_host.data_ptr(),
             idx_host=None if idx_host is None else idx_host.ctypes.data,
             grad_world=world, allreduce_start=fn_start, allreduce_wait=fn_wait, allreduce_ctx=ctx)
         rc = N.lib().pa_dqn_learn(nat.handle, arena.handle, C.byref(args), N.stream_ptr(dev))
@@ -744,7 +762,8 @@ class DeepQLearning(PolicyLearner):
         N.check(rc)
         self._training_steps += rounds
         self._set_adam_steps(args.adam_step0 + rounds)
-        losses = nat.loss_buf[:rounds].tolist()
+        torch.cuda.current_stream(dev).synchronize()
+        losses = nat.loss_host[:rounds].tolist()
         N.check(N.lib().pa_dqn_check(nat.handle))
         return {"loss": losses}
 

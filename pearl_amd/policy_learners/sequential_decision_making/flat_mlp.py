@@ -230,7 +230,14 @@ class FlatMlp:
         return self
 
     def _flat_versions(self) -> Tuple:
-        return tuple(t._version for k, t in self.flat.items() if k in ("p", "p_target"))
+        """Version counters of the PARAMETER tensors (online and target).  They alias the flat
+        buffers' storage but keep their own counters (``param.data = view`` does not share them), and
+        they are what ``load_state_dict`` / torch optimizers write through.  Writes through a
+        ``.data`` alias are not versioned by torch at all: nothing can see those."""
+        vs = [p._version for p in self._params()]
+        if self.target_layers is not None:
+            vs.extend(p._version for ws, bs in self.target_layers for p in (*ws, *bs))
+        return tuple(vs)
 
     def ready(self, batch: int = 0) -> "FlatMlp":
         """The per-launch check: a bound handle large enough for `batch`.  Whether the torch

@@ -140,6 +140,42 @@ def test_sac_learn_batch_trajectory(name):
             torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
 
 
+def test_parameters_written_through_torch_are_seen_by_the_kernels():
+    """The row-pass kernels read fragment-major COPIES of the weights, kept current by the fused
+    optimizer epilogues.  Anything torch writes in place into a Parameter (load_state_dict, a torch
+    optimizer, manual surgery) must invalidate them: the Parameters' version counters say so."""
+    fx = load("sac", "cfg3_shape_small")
+    pl = make_sac(fx)
+    na, nc = fx["noises"][0]
+    seq = iter([na, nc])
+    pl.noise_source = lambda B, A, dev: next(seq)
+    pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))          # packed copies are current now
+    actor, c1, _ = pl._nets(fx["config"]["B"])
+    x = sac_batch(fx).state.contiguous()
+    before = actor.forward(x).clone()
+    with torch.no_grad():
+        for p in pl._actor.parameters():
+            p.mul_(0.5)
+    actor, _, _ = pl._nets(fx["config"]["B"])                      # ensure(): sees the version bump
+    after = actor.forward(x)
+    with torch.no_grad():
+        h = pl._actor._model(x) if hasattr(pl._actor, "_model") else None
+        if h is not None:
+            want = torch.cat([pl._actor.fc_mu(h), pl._actor.fc_std(h)], dim=1)
+            torch.testing.assert_close(after, want, rtol=1e-4, atol=1e-5)
+    assert not torch.allclose(before, after)
+    # and load_state_dict (param.copy_ under no_grad) is seen the same way
+    sd = {k: v.clone() * 2.0 for k, v in pl._actor.state_dict().items()}
+    pl._actor.load_state_dict(sd)
+    actor, _, _ = pl._nets(fx["config"]["B"])
+    torch.testing.assert_close(actor.forward(x), before, rtol=0, atol=0)   # (x 0.5 x 2 is exact)
+    with torch.no_grad():
+        if h is not None:
+            h2 = pl._actor._model(x)
+            want2 = torch.cat([pl._actor.fc_mu(h2), pl._actor.fc_std(h2)], dim=1)
+            torch.testing.assert_close(actor.forward(x), want2, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg3_shape_small", "cfg3_fullbatch"])
 @pytest.mark.parametrize("form", ["one_call_sequenced", "fused_rows"])
 def test_sac_step_forms_agree(name, form, monkeypatch):
