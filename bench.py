@@ -90,9 +90,9 @@ def cpu_baseline(budget_s: float = 20.0):
 
 def pmc_traffic(transitions_per_launch):
     """HBM bytes of one target_fused_kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_target.json, written by tools/pmc_traffic.py: FETCH_SIZE doubled as
+    (profiles/r02_pmc_target.json, written by tools/pmc_traffic.py: FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE, per transition)."""
-    path = os.path.join(REPO, "profiles", "r01_pmc_target.json")
+    path = os.path.join(REPO, "profiles", "r02_pmc_target.json")
     if not os.path.exists(path):
         return None
     with open(path) as f:
