@@ -141,8 +141,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.warmup > 0:
-        agent.learn()
     nat = pl._ensure_bound(B, A)
 
     def read_timers():
@@ -156,9 +154,9 @@ def main():
                 out[name] = {"avg_us": ms.value * 1e3, "n": cnt.value, "units": units.value}
         return out
 
-    # Calibration pass (outside the timed region, BEFORE it): the same target kernel with the chip to
-    # itself, i.e. the single-stream loop, so that the kernel's own efficiency can be told apart
-    # from the CU sharing of the overlapped loop.  N = 1 only: multi-GPU runs stay short.  It runs
+    # Calibration pass (outside the timed region, BEFORE it and before the warm-up rounds): the same
+    # target kernel with the chip to itself, i.e. the single-stream loop, so that the kernel's own
+    # efficiency can be told apart from the CU sharing of the overlapped loop.  N = 1 only: multi-GPU runs stay short.  It runs
     # first because a GPU that has been idle takes its first millisecond of work at reduced clocks
     # (tools/firstcall.py: the same 20-round call costs 1.18 ms cold, 1.07 ms in steady state,
     # 1.43 ms after half a second of idling) — the line says so in `untimed_rounds_before`.
@@ -174,6 +172,11 @@ def main():
         torch.cuda.synchronize(dev)
         isolated = read_timers().get("target")
         N.check(N.lib().pa_dqn_set_overlap(nat.handle, 1))
+        N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
+    # the W warm-up rounds, through the same loop the timed region uses, right before it
+    if args.warmup > 0:
+        pl._training_rounds = args.warmup
+        agent.learn()
     pl._training_rounds = args.steps
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, args.timing_level))
     barrier()

@@ -421,6 +421,10 @@ int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t ldx, int32_
                      int32_t want_dw, float* d_x1, float* d_x2, int32_t lddx, void* stream);
 int pa_mlp_flush_grads(pa_mlp* h, void* stream);
 int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream);
+/* Twin networks with one optimizer configuration (twin critics), both with deferred weight
+ * gradients: dW + AdamW of both in one launch and, with soft_tau >= 0, their soft target updates
+ * in the same epilogue.  PA_ERR_UNSUPPORTED when the pair does not qualify. */
+int pa_mlp_adam2(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, void* stream);
 /* update_target_network (common/utils.py:214-226) */
 int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);
 

@@ -1257,7 +1257,89 @@ struct DsacArgs {
   int B, A, mode;
   float* d_logits; int ldd; float* loss_out; float* h_out;
   const float* reward; const uint8_t* term; float gamma; float* y;
+  float* partials; unsigned* ticket;     // element-parallel form, mode 0
 };
+// Element-parallel form (A <= 256): one thread per (row, action), 256 / A rows per workgroup; the
+// per-row reductions are serial loops over the row's LDS slots in action order — the arithmetic of
+// the row-per-thread kernel below, which for 1024 x 16 ran 16 384 softmax elements on ONE
+// workgroup (67 us a launch, two launches a step: 29 % of discrete SAC's step).
+__global__ __launch_bounds__(256) void dsac_elem_kernel(DsacArgs a) {
+  __shared__ float va[256], vb[256], vc[256], red[256];
+  __shared__ unsigned last;
+  const float alpha = a.alpha[0];
+  const float inv_n = 1.0f / ((float)a.B * (float)a.A);
+  const int rpw = 256 / a.A;
+  const int r = threadIdx.x / a.A, j = threadIdx.x - r * a.A;
+  const int b = blockIdx.x * rpw + r;
+  const bool live = r < rpw && b < a.B;
+  const int base = r * a.A;
+  const float z = live ? a.logits[(int64_t)b * a.ldl + j] : 0.f;
+  float q = 0.f;
+  if (live && !(a.mask && a.mask[(int64_t)b * a.A + j]))
+    q = fminf(a.q1[(int64_t)b * a.A + j], a.q2[(int64_t)b * a.A + j]);
+  va[threadIdx.x] = z;
+  __syncthreads();
+  float m = 0.f, s = 0.f;
+  if (live) {
+    m = va[base];
+    for (int k = 1; k < a.A; ++k) m = fmaxf(m, va[base + k]);
+  }
+  const float e = expf(z - m);
+  vb[threadIdx.x] = e;
+  __syncthreads();
+  if (live)
+    for (int k = 0; k < a.A; ++k) s += vb[base + k];
+  const float p = live ? e / s : 0.f;
+  if (a.mode == 1) {
+    va[threadIdx.x] = (q - alpha * logf(p + 1e-8f)) * p;
+    __syncthreads();
+    if (live && j == 0) {
+      float v = 0.f;
+      for (int k = 0; k < a.A; ++k) v += va[base + k];
+      const float lv = 1.0f - (a.term[b] ? 1.0f : 0.0f);
+      a.y[b] = __fadd_rn(__fmul_rn(__fmul_rn(v, a.gamma), lv), a.reward[b]);
+    }
+    return;
+  }
+  const float lp = logf(p + 1e-8f);
+  const float f = alpha * lp - q;
+  const float g = (f + p * (alpha / (p + 1e-8f))) * inv_n;   // dL/dP_j
+  va[threadIdx.x] = p * f;
+  vc[threadIdx.x] = g * p;
+  __syncthreads();            // (every thread is past its reads of vb: the barrier above the p line)
+  vb[threadIdx.x] = p * lp;
+  float dot = 0.f;
+  if (live)
+    for (int k = 0; k < a.A; ++k) dot += vc[base + k];
+  if (live) a.d_logits[(int64_t)b * a.ldd + j] = p * (g - dot);
+  __syncthreads();
+  float part = 0.f;
+  if (live && j == 0) {
+    float h = 0.f;
+    for (int k = 0; k < a.A; ++k) {
+      part += va[base + k];
+      h += vb[base + k];
+    }
+    a.h_out[b] = h;
+  }
+  const float bl = block_sum_256(part, red);
+  if (threadIdx.x == 0) {
+    a.partials[blockIdx.x] = bl;
+    __threadfence();
+    last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float pl = 0.f;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += 256)
+    pl += __builtin_nontemporal_load(a.partials + k);
+  const float sum = block_sum_256(pl, red);
+  if (threadIdx.x == 0) {
+    a.loss_out[0] = sum * inv_n;
+    *a.ticket = 0u;
+  }
+}
 __global__ __launch_bounds__(256) void dsac_kernel(DsacArgs a) {
   __shared__ float red[256];
   const float alpha = a.alpha[0];
@@ -1657,6 +1739,7 @@ struct SolveArgs {
   double* work;          // [D][2D]
   float* invA; float* coefs;
   int* singular;         // set to 1 if a pivot vanished
+  const int* only_if;    // non-null: run only when this device word is non-zero (fallback launch)
 };
 __global__ __launch_bounds__(1024) void linreg_solve_kernel(SolveArgs a) {
   __shared__ double pv[1024];
@@ -1736,6 +1819,7 @@ __global__ __launch_bounds__(1024) void linreg_solve_kernel(SolveArgs a) {
 // area: 419 us -> ~100 us for D = 65.  Used whenever [D][2D] doubles fit.
 __global__ __launch_bounds__(1024) void linreg_solve_lds_kernel(SolveArgs a) {
   extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  if (a.only_if && a.only_if[0] == 0) return;      // the pivot-free kernel succeeded
   const int D = a.D, W = 2 * D, tid = threadIdx.x, lane = tid & 63;
   double* work = lds_work;          // [D][W]
   double* prowv = work + D * W;     // [W] normalised pivot row
@@ -1808,6 +1892,84 @@ __global__ __launch_bounds__(1024) void linreg_solve_lds_kernel(SolveArgs a) {
   for (int i = tid; i < D; i += 1024) {
     double s = 0.0;
     for (int j = 0; j < D; ++j) s += work[i * W + D + j] * (double)a.bvec[j];
+    a.coefs[i] = (float)s;
+  }
+}
+
+// A + lambda I of the regression is symmetric positive definite (a weighted Gram matrix plus a
+// ridge), and Gauss-Jordan on an SPD matrix needs no pivoting: every pivot is a Schur-complement
+// diagonal, positive.  Without row exchanges each thread can keep ONE COLUMN of the augmented system
+// in registers for the whole solve, provided every register index is static — which a ROTATING
+// frame gives: at step k the logical row (k + r) mod DR lives in register r, so the pivot row is
+// always register 0, the update writes row r into register r - 1, and the finished pivot row
+// re-enters at the end; after DR steps the frame is back where it started.  The system is padded
+// to DR = 72 rows with an identity block (the inverse of diag(M, I) is diag(inv M, I)).  A pivot
+// step is then: the owner of column k publishes its registers through LDS, one barrier, and 71
+// fused multiply-adds per thread out of registers — a 2.4 KB loop.  181 us (the LDS kernel above:
+// four barriers and ~25 LDS operations per element per step across 16 waves) -> ~45 us for D = 65.
+// (A fully unrolled version with fixed rows was tried first: 200 KB of straight-line code ran at
+// instruction-fetch speed, 550 us.)  A pivot that is not positive (lambda = 0 with rank-deficient
+// data, or a negative weight) raises `need_pivot`; the pivoting kernel above then runs as a second
+// launch that otherwise exits at once.
+constexpr int SOLVE_DR = 72;
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void linreg_solve_spd_kernel(SolveArgs a, int* need_pivot) {
+  extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  constexpr int DR = SOLVE_DR, W = 2 * SOLVE_DR;
+  const int D = a.D, t = threadIdx.x;
+  double* bcast = lds_work;                   // [2][DR]: the pivot column, double-buffered
+  double* work = lds_work + 2 * DR;           // [DR][W]: staging of the input, then of the result
+  __shared__ int bad;
+  if (t == 0) bad = 0;
+  const bool own = t < W;
+  // diag(A + lambda I, I) | I  staged through LDS with coalesced loads
+  for (int e = t; e < DR * W; e += 192) {
+    const int i = e / W, j = e - i * W;
+    double v;
+    if (j < DR) {
+      if (i < D && j < D) v = (double)a.A[i * D + j] + (i == j ? (double)a.lambda : 0.0);
+      else v = (i == j) ? 1.0 : 0.0;
+    } else {
+      v = (j - DR == i) ? 1.0 : 0.0;
+    }
+    work[e] = v;
+  }
+  __syncthreads();
+  double col[DR];
+#pragma unroll
+  for (int r = 0; r < DR; ++r) col[r] = own ? work[r * W + t] : 0.0;
+  __syncthreads();
+  for (int k = 0; k < DR; ++k) {
+    double* bc = bcast + (k & 1) * DR;
+    if (t == k) {
+#pragma unroll
+      for (int r = 0; r < DR; ++r) bc[r] = col[r];
+    }
+    __syncthreads();
+    const double piv = bc[0];
+    if (!(piv > 0.0) && t == 0) bad = 1;
+    const double pr = col[0] * (1.0 / piv);
+#pragma unroll
+    for (int r = 1; r < DR; ++r) col[r - 1] = __builtin_fma(-bc[r], pr, col[r]);
+    col[DR - 1] = pr;
+  }
+  // ---- outputs: inv(A + lambda I) = rows / columns < D of the right half; coefs = inv b
+  if (own) {
+#pragma unroll
+    for (int r = 0; r < DR; ++r) work[r * W + t] = col[r];
+  }
+  __syncthreads();
+  if (bad) {
+    if (t == 0) need_pivot[0] = 1;
+    return;
+  }
+  for (int e = t; e < D * D; e += 192) {
+    const int i = e / D, j = e - i * D;
+    a.invA[e] = (float)work[i * W + DR + j];
+  }
+  for (int i = t; i < D; i += 192) {
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += work[i * W + DR + j] * (double)a.bvec[j];
     a.coefs[i] = (float)s;
   }
 }
@@ -1911,6 +2073,27 @@ extern "C" int pa_linreg_solve(const float* A, const float* b, float l2_reg_lamb
   PA_HIP(hipMemsetAsync(singular_out, 0, sizeof(int32_t), s));
   const int D = d + 1;
   const size_t lds = sizeof(double) * ((size_t)D * 2 * D + 2 * D + D);
+  a.only_if = nullptr;
+  static const bool spd_on = []() {
+    const char* v = getenv("PEARL_AMD_SOLVE_SPD");
+    return !(v && *v == '0');
+  }();
+  if (spd_on && D <= SOLVE_DR) {
+    // SPD fast path; `work` (caller's fp64 scratch, unused by the LDS kernels) carries the
+    // "a pivot was not positive" word that arms the pivoting kernel below
+    int* need_pivot = reinterpret_cast<int*>(work);
+    PA_HIP(hipMemsetAsync(need_pivot, 0, sizeof(int), s));
+    const size_t lds_spd = sizeof(double) * (2 * SOLVE_DR + (size_t)SOLVE_DR * 2 * SOLVE_DR);
+    static size_t configured_spd = 0;
+    if (lds_spd > configured_spd) {
+      int rc = set_max_smem(linreg_solve_spd_kernel, lds_spd);
+      if (rc != PA_OK) return rc;
+      configured_spd = lds_spd;
+    }
+    hipLaunchKernelGGL(linreg_solve_spd_kernel, dim3(1), dim3(192), lds_spd, s, a, need_pivot);
+    PA_LAUNCH_CHECK();
+    a.only_if = need_pivot;
+  }
   if (lds <= 150 * 1024) {
     static size_t configured = 0;
     if (lds > configured) {
@@ -2068,6 +2251,35 @@ extern "C" int pa_expand_state_actions(const float* state, int32_t lds_, const f
   return PA_OK;
 }
 
+namespace {
+int launch_dsac(DsacArgs& a, hipStream_t s) {
+  if (a.A > 256) {
+    hipLaunchKernelGGL(dsac_kernel, dim3(1), dim3(256), 0, s, a);
+    PA_LAUNCH_CHECK();
+    return PA_OK;
+  }
+  // per-block partial sums + ticket: one buffer per process, grown on demand (calls are ordered
+  // by their stream, like every use of a learner handle)
+  static float* scratch = nullptr;
+  static size_t cap = 0;
+  const unsigned grid = (unsigned)ceil_div(a.B, 256 / a.A);
+  if ((size_t)grid + 4 > cap) {
+    if (scratch) {
+      PA_HIP(hipDeviceSynchronize());
+      (void)hipFree(scratch);
+    }
+    cap = 2 * ((size_t)grid + 4);
+    PA_HIP(hipMalloc((void**)&scratch, cap * sizeof(float)));
+    PA_HIP(hipMemset(scratch, 0, cap * sizeof(float)));
+  }
+  a.ticket = reinterpret_cast<unsigned*>(scratch);
+  a.partials = scratch + 4;
+  hipLaunchKernelGGL(dsac_elem_kernel, dim3(grid), dim3(256), 0, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+}  // namespace
+
 extern "C" int pa_dsac_actor_head(const float* logits, int32_t ldl, const float* q1, const float* q2,
                                   const uint8_t* mask, const float* alpha, int32_t B, int32_t A,
                                   float* d_logits, int32_t ldd, float* loss_out, float* h_out,
@@ -2079,9 +2291,7 @@ extern "C" int pa_dsac_actor_head(const float* logits, int32_t ldl, const float*
   a.logits = logits; a.ldl = ldl; a.q1 = q1; a.q2 = q2; a.mask = mask; a.alpha = alpha;
   a.B = B; a.A = A; a.mode = 0;
   a.d_logits = d_logits; a.ldd = ldd; a.loss_out = loss_out; a.h_out = h_out;
-  hipLaunchKernelGGL(dsac_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
+  return launch_dsac(a, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pa_dsac_target(const float* logits, int32_t ldl, const float* q1, const float* q2,
@@ -2095,9 +2305,7 @@ extern "C" int pa_dsac_target(const float* logits, int32_t ldl, const float* q1,
   a.logits = logits; a.ldl = ldl; a.q1 = q1; a.q2 = q2; a.mask = mask; a.alpha = alpha;
   a.B = B; a.A = A; a.mode = 1;
   a.reward = reward; a.term = terminated; a.gamma = gamma; a.y = y;
-  hipLaunchKernelGGL(dsac_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
-  PA_LAUNCH_CHECK();
-  return PA_OK;
+  return launch_dsac(a, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pa_iql_value_head(const float* tq_value, const float* tq_actor, const float* v,
@@ -2248,6 +2456,21 @@ extern "C" int pa_concat_cols(const float* left, int32_t ldl, const float* right
   return PA_OK;
 }
 
+
+// Twin networks that share one optimizer configuration (twin critics), both with weight gradients
+// deferred by pa_mlp_backward*(want_dw = 2): dW + AdamW of BOTH in one launch per three layers and,
+// with soft_tau >= 0, their soft target updates in the same epilogue (update_target_network,
+// common/utils.py:214-226).  PA_ERR_UNSUPPORTED when the pair does not qualify (the caller then
+// steps them one by one).
+extern "C" int pa_mlp_adam2(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, void* stream) {
+  PA_REQUIRE(a && b && a != b && a->bound && b->bound && step >= 1, PA_ERR_INVALID,
+             "pa_mlp_adam2: bad argument");
+  PA_REQUIRE(pa::mlp_pair_fusable(a, b, soft_tau >= 0.f), PA_ERR_UNSUPPORTED,
+             "pa_mlp_adam2: the networks do not share shape, batch and optimizer configuration, or "
+             "have no deferred weight gradients");
+  PA_HIP(hipSetDevice(a->d.device));
+  return pa::mlp_adam_pair(a, b, step, soft_tau, reinterpret_cast<hipStream_t>(stream));
+}
 
 // ---- internal entry points for the fused learner steps (sac_step.hip) ---------------------------
 namespace pa {

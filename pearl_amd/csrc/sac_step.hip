@@ -370,11 +370,16 @@ extern "C" int pa_sac_step(const pa_sac_step_args* a, void* stream) {
   PA_TRY(pa_mse_head(w.qb, 1, w.y, B, 1.0f / (float)B, 0.5f, 1, w.dqb, a->losses + 1, stream));
   PA_TRY(pa_mlp_backward2(a->critic1, a->critic2, w.xq, W, B, w.dqa, 1, w.dqb, 1, 2, nullptr, nullptr,
                           0, stream));
-  PA_TRY(pa_mlp_adam(a->critic1, a->critic_step, stream));
-  PA_TRY(pa_mlp_adam(a->critic2, a->critic_step, stream));
-  // ---------------------------------------------------------------- targets, entropy coefficient
-  PA_TRY(pa_mlp_soft_update(a->critic1, a->tau, stream));
-  PA_TRY(pa_mlp_soft_update(a->critic2, a->tau, stream));
+  // ---------------------------------------------------------------- AdamW, targets
+  if (mlp_pair_fusable(a->critic1, a->critic2, true)) {
+    PA_TRY(pa_mlp_adam2(a->critic1, a->critic2, a->critic_step, a->tau, stream));
+  } else {
+    PA_TRY(pa_mlp_adam(a->critic1, a->critic_step, stream));
+    PA_TRY(pa_mlp_adam(a->critic2, a->critic_step, stream));
+    PA_TRY(pa_mlp_soft_update(a->critic1, a->tau, stream));
+    PA_TRY(pa_mlp_soft_update(a->critic2, a->tau, stream));
+  }
+  // ---------------------------------------------------------------- entropy coefficient
   if (a->log_alpha) {
     PA_TRY(pa_sac_alpha_step(a->log_alpha, a->alpha_m, a->alpha_v, a->alpha_vmax, a->alpha, w.logp, B,
                              a->target_entropy, a->alpha_lr, a->alpha_beta1, a->alpha_beta2,

@@ -146,7 +146,13 @@ class ActorCriticBase(PolicyLearner):
         """learn_batch with the losses left on the device (no host synchronisation)."""
         report = {"actor_loss": self._actor_update(batch)}
         if self._use_critic:
-            report["critic_loss"] = self._critic_update(batch)
+            # the critics' soft target update follows their AdamW step with nothing in between:
+            # twin critics take both in one launch (_step_twin_critics)
+            self._target_update_follows = bool(self._use_critic_target)
+            try:
+                report["critic_loss"] = self._critic_update(batch)
+            finally:
+                self._target_update_follows = False
         if self._use_critic_target:
             self._update_critic_target()
         if self._use_actor_target:
@@ -209,6 +215,23 @@ class ActorCriticBase(PolicyLearner):
         if safety is not None and hasattr(safety, "lambda_constraint"):
             batch.reward = batch.reward - safety.lambda_constraint * batch.cost
         return super().preprocess_batch(batch)
+
+    _target_update_follows = False     # set around _critic_update by _learn_batch_device
+    _critic_target_done = False        # the soft update already rode the critics' AdamW launch
+
+    def _step_twin_critics(self, c1: FlatMlp, c2: FlatMlp) -> None:
+        """AdamW of the twin critics (deferred weight gradients).  When this learn_batch goes on to
+        soft-update their targets, that update rides the same launch (FlatMlp.adam_pair) and
+        `_update_critic_target` finds it done."""
+        tau = self._critic_soft_update_tau if self._target_update_follows else None
+        self._critic_target_done = FlatMlp.adam_pair(c1, c2, tau)
+
+    def _twin_target_update(self, c1: FlatMlp, c2: FlatMlp) -> None:
+        if self._critic_target_done:
+            self._critic_target_done = False
+            return
+        c1.soft_update(self._critic_soft_update_tau)
+        c2.soft_update(self._critic_soft_update_tau)
 
     @abstractmethod
     def _actor_update(self, batch: TransitionBatch) -> torch.Tensor:

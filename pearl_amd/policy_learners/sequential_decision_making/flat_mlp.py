@@ -360,6 +360,32 @@ class FlatMlp:
         self._steps = step
         self._versions = self._flat_versions()     # our own kernels wrote the buffers: not "external"
 
+    @staticmethod
+    def adam_pair(m1: "FlatMlp", m2: "FlatMlp", soft_tau: Optional[float] = None) -> bool:
+        """AdamW step of twin networks (twin critics: one optimizer, same shape) whose weight
+        gradients were deferred by ``backward_pair(defer=True)``: ONE launch forms both networks'
+        gradients, applies AdamW and — with ``soft_tau`` — the soft update of both targets
+        (pa_mlp_adam2).  Returns True when the soft update was part of it; otherwise the caller
+        performs it as usual.  Falls back to two single steps whenever the pair does not qualify
+        (data-parallel runs all-reduce between backward and AdamW)."""
+        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if single and m1._pending_x is not None and m2._pending_x is not None \
+                and m1._steps == m2._steps and (soft_tau is None or (
+                    m1.target_layers is not None and m2.target_layers is not None)):
+            step = m1._steps + 1
+            rc = N.lib().pa_mlp_adam2(m1.handle, m2.handle, step,
+                                      -1.0 if soft_tau is None else float(soft_tau),
+                                      N.stream_ptr(m1.flat["p"].device))
+            if rc == 0:
+                for m in (m1, m2):
+                    m.stepped_natively()
+                return soft_tau is not None
+            if rc != N.PA_ERR_UNSUPPORTED:
+                N.check(rc)
+        m1.adam()
+        m2.adam()
+        return False
+
     def stepped_natively(self) -> None:
         """Bookkeeping after an AdamW step the library sequenced itself (pa_sac_step)."""
         step = self._steps + 1

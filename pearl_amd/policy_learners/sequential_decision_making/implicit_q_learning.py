@@ -215,10 +215,9 @@ class ImplicitQLearning(ActorCriticBase):
         FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
         value.adam()
         actor.adam()
-        c1.adam()
-        c2.adam()
-        c1.soft_update(self._critic_soft_update_tau)
-        c2.soft_update(self._critic_soft_update_tau)
+        if not FlatMlp.adam_pair(c1, c2, self._critic_soft_update_tau):
+            c1.soft_update(self._critic_soft_update_tau)
+            c2.soft_update(self._critic_soft_update_tau)
         return {"value_loss": losses[0], "actor_loss": losses[2], "critic_loss": losses[1]}
 
     def _actor_update(self, batch: TransitionBatch) -> Tensor:      # pragma: no cover

@@ -239,14 +239,12 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
                                         dqs[i].data_ptr(), loss.data_ptr(), s))
         FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
-        c1.adam()
-        c2.adam()
+        self._step_twin_critics(c1, c2)
         return loss[0]
 
     def _update_critic_target(self) -> None:
         _, c1, c2 = self._nets(validate=False)
-        c1.soft_update(self._critic_soft_update_tau)
-        c2.soft_update(self._critic_soft_update_tau)
+        self._twin_target_update(c1, c2)
 
     # ------------------------------------------------------------------ one-call step
     def _one_call_ok(self) -> bool:

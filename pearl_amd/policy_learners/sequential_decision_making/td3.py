@@ -48,7 +48,11 @@ class TD3(DeepDeterministicPolicyGradient):
             self._last_actor_loss = self._actor_update(batch)
         else:
             self._nets(len(batch))     # the per-batch binding validation _actor_update would do
-        report = {"actor_loss": self._last_actor_loss, "critic_loss": self._critic_update(batch)}
+        self._target_update_follows = due    # then the critics' soft update rides their AdamW launch
+        try:
+            report = {"actor_loss": self._last_actor_loss, "critic_loss": self._critic_update(batch)}
+        finally:
+            self._target_update_follows = False
         if due:
             self._update_critic_target()
             self._update_actor_target()
