@@ -301,6 +301,89 @@ def test_twin_pair_launches_equal_two_single_passes(dims, B):
     assert not torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize("dims,B", [([20, 64, 64, 1], 96), ([72, 256, 256, 1], 1024), ([7, 33, 1], 5)])
+@pytest.mark.parametrize("soft", [False, True])
+def test_twin_adam_pair_equals_two_single_steps(dims, B, soft):
+    """FlatMlp.adam_pair (pa_mlp_adam2: both critics' weight gradients + AdamW (+ soft target update)
+    in ONE weight_grad launch, second optimizer state selected per problem) is the same arithmetic as
+    two single steps followed by two soft updates: parameters, optimizer state and targets bitwise."""
+    import copy
+    from torch import nn, optim
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    torch.manual_seed(5)
+
+    def make_pair():
+        nets = [[nn.Linear(dims[i], dims[i + 1]).to(DEV) for i in range(len(dims) - 1)] for _ in range(2)]
+        tgts = [copy.deepcopy(n) for n in nets]
+        for t in tgts:
+            for l in t:
+                l.weight.data.mul_(0.9)
+        opt = optim.AdamW([p for n in nets for l in n for p in l.parameters()], lr=1e-3, amsgrad=True)
+        return [FlatMlp(layers_of(n), opt, max_batch=B, target_layers=layers_of(t))
+                for n, t in zip(nets, tgts)], nets, tgts
+
+    x = torch.randn(B, dims[0], device=DEV)
+    d1, d2 = torch.randn(B, device=DEV), torch.randn(B, device=DEV)
+    out = []
+    for form in ("pair", "single"):
+        torch.manual_seed(5)
+        (m1, m2), nets, tgts = make_pair()
+        for step in range(3):
+            FlatMlp.forward_pair(m1, m2, x, keep=True)
+            FlatMlp.backward_pair(m1, m2, x, d1, d2, want_dw=True, defer=True)
+            if form == "pair":
+                fused = FlatMlp.adam_pair(m1, m2, 0.05 if soft else None)
+                assert fused == soft
+            else:
+                m1.adam()
+                m2.adam()
+                if soft:
+                    m1.soft_update(0.05)
+                    m2.soft_update(0.05)
+        torch.cuda.synchronize()
+        # the packed copies the row kernels read must be current too: compare a fresh forward
+        o1, o2 = FlatMlp.forward_pair(m1, m2, x)
+        t1, t2 = FlatMlp.forward_pair(m1, m2, x, use_target=True)
+        out.append(([p.detach().clone() for n in nets + tgts for l in n for p in l.parameters()],
+                    {k: v.clone() for m in (m1, m2) for k, v in m.flat.items()},
+                    [o1.clone(), o2.clone(), t1.clone(), t2.clone()]))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(out[0][2], out[1][2]):
+        assert torch.equal(a, b)
+
+
+def test_linreg_solve_spd_fast_path_and_pivoting_fallback():
+    """pa_linreg_solve: the pivot-free register-column kernel on an SPD system, and the pivoting
+    kernel when a pivot is not positive (an indefinite matrix a negative weight could produce)."""
+    from pearl_amd import _native as N
+    d = 64
+    D = d + 1
+    torch.manual_seed(11)
+    xg = torch.randn(512, D, dtype=torch.float64)
+    spd = (xg.t() @ xg).float()
+    q, _ = torch.linalg.qr(torch.randn(D, D, dtype=torch.float64))
+    eig = torch.linspace(1.0, 3.0, D, dtype=torch.float64)
+    eig[::7] *= -1.0                                     # indefinite, well conditioned
+    indef = (q @ torch.diag(eig) @ q.t()).float()
+    for name, A, lam in (("spd", spd, 1.0), ("indefinite", indef, 0.0)):
+        Ad = A.to(DEV).contiguous()
+        b = torch.randn(D, device=DEV)
+        work = torch.empty(D * 2 * D, dtype=torch.float64, device=DEV)
+        inv = torch.zeros(D, D, device=DEV)
+        coefs = torch.zeros(D, device=DEV)
+        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+        N.check(N.lib().pa_linreg_solve(Ad.data_ptr(), b.data_ptr(), lam, d, work.data_ptr(),
+                                        inv.data_ptr(), coefs.data_ptr(), flag.data_ptr(),
+                                        N.stream_ptr(Ad.device)))
+        want = torch.linalg.inv(A.double() + lam * torch.eye(D, dtype=torch.float64))
+        torch.testing.assert_close(inv.cpu().double(), want, rtol=1e-4, atol=1e-6 * float(want.abs().max()),
+                                   msg=name)
+        torch.testing.assert_close(coefs.cpu().double(), want @ b.cpu().double(), rtol=1e-3,
+                                   atol=1e-5 * float((want @ b.cpu().double()).abs().max()), msg=name)
+        assert int(flag.item()) == 0
+
+
 DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small"]
 
 
