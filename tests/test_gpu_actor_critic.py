@@ -140,6 +140,53 @@ def test_sac_learn_batch_trajectory(name):
             torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
 
 
+@pytest.mark.parametrize("S,A,hidden,B", [(17, 6, [256, 256], 100),     # hidden unrolled, first layers run-time
+                                          (10, 3, [32, 48], 50),          # everything run-time, ragged tile
+                                          (64, 8, [256, 256], 1000),      # the benchmark instantiation, ragged
+                                          (33, 16, [250, 256], 37)])      # widest action head, 250 = 16 k-groups
+def test_sac_fused_rows_agree_with_sequenced_on_other_shapes(S, A, hidden, B, monkeypatch):
+    """sac_rows.hpp has three instantiations (all loops unrolled / hidden layers only / run-time)
+    and row guards for batches that are not a multiple of 16: self-consistency against the sequenced
+    launches on shapes the reference-minted fixtures do not cover."""
+    from pearl_amd import (BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic, PearlAgent,
+                           TransitionBatch)
+    g = torch.Generator().manual_seed(S * 131 + A)
+    batch = dict(state=torch.randn(B, S, generator=g), action=torch.rand(B, A, generator=g) * 2 - 1,
+                 reward=torch.randn(B, generator=g), terminated=torch.rand(B, generator=g) < 0.2,
+                 next_state=torch.randn(B, S, generator=g))
+    noises = [(torch.randn(B, A, generator=g), torch.randn(B, A, generator=g)) for _ in range(3)]
+    outs = {}
+    for form in ("sequenced", "fused"):
+        monkeypatch.setenv("PEARL_AMD_SAC_ONE_CALL", "1")
+        monkeypatch.setenv("PEARL_AMD_SAC_FUSED", "1" if form == "fused" else "0")
+        torch.manual_seed(7)
+        pl = ContinuousSoftActorCritic(action_space=BoxActionSpace(-torch.ones(A), 2 * torch.ones(A)),
+                                       state_dim=S, actor_hidden_dims=hidden, critic_hidden_dims=hidden,
+                                       batch_size=B)
+        PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+        reports = []
+        for na, nc in noises:
+            seq = iter([na, nc])
+            pl.noise_source = lambda B_, A_, dev: next(seq)
+            tb = TransitionBatch(**{k: v.to(DEV) for k, v in batch.items()})
+            reports.append({k: float(v) for k, v in pl.learn_batch(pl.preprocess_batch(tb)).items()})
+        torch.cuda.synchronize()
+        outs[form] = (reports, {f"{n}.{k}": v.detach().cpu().clone()
+                                for n, m in (("actor", pl._actor), ("critic", pl._critic),
+                                             ("target", pl._critic_target))
+                                for k, v in m.state_dict().items()},
+                      pl._entropy_coef.detach().cpu().clone())
+    (ra, pa_, ea), (rb, pb, eb) = outs["sequenced"], outs["fused"]
+    for x, y in zip(ra, rb):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 5e-5 * max(1.0, abs(x[k])), (k, x[k], y[k])
+    from helpers import assert_adam_trajectory_close
+    for k in pa_:
+        assert torch.isfinite(pb[k]).all(), k
+        assert_adam_trajectory_close(pb[k], pa_[k], 1e-3, len(noises), max_outlier_frac=5e-3, msg=k)
+    torch.testing.assert_close(ea, eb, rtol=1e-5, atol=1e-7)
+
+
 def test_parameters_written_through_torch_are_seen_by_the_kernels():
     """The row-pass kernels read fragment-major COPIES of the weights, kept current by the fused
     optimizer epilogues.  Anything torch writes in place into a Parameter (load_state_dict, a torch
