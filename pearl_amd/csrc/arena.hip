@@ -555,6 +555,18 @@ int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const p
 
 using namespace pa;
 
+namespace pa {
+int bind_process_device(int device) {
+  static int bound = -1;
+  if (bound < 0) bound = device;
+  PA_REQUIRE(bound == device, PA_ERR_UNSUPPORTED,
+             "pearl_amd: one process drives one GPU — this process is bound to HIP device %d and "
+             "cannot create a handle on device %d (launch one process per device)",
+             bound, device);
+  return PA_OK;
+}
+}  // namespace pa
+
 extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {
   PA_REQUIRE(out && desc, PA_ERR_INVALID, "pa_arena_create: null argument");
   PA_REQUIRE(desc->capacity > 0, PA_ERR_INVALID, "capacity must be positive");
@@ -569,6 +581,10 @@ extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {
              "HIP device %d not available (%d visible): the replay arena lives in HBM and has "
              "no CPU fallback",
              desc->device, ndev);
+  {
+    int rc_dev = bind_process_device(desc->device);
+    if (rc_dev != PA_OK) return rc_dev;
+  }
   PA_HIP(hipSetDevice(desc->device));
   pa_arena* a = new (std::nothrow) pa_arena();
   PA_REQUIRE(a, PA_ERR_NOMEM, "out of host memory");

@@ -11,6 +11,11 @@ namespace pa {
 
 // ---- error plumbing ------------------------------------------------------
 void set_error(const char* fmt, ...);
+// One process drives one GPU (the launch model of this library: torch.distributed, one rank per
+// device).  Several pieces of per-process state rely on it — kernel attributes set once, scratch
+// buffers grown on demand — so the first handle created pins the process to its device and a
+// handle for another device is refused, loudly, instead of misbehaving later.
+int bind_process_device(int device);
 
 #define PA_HIP(expr)                                                             \
   do {                                                                           \

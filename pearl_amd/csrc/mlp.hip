@@ -22,6 +22,7 @@
 #include "host_launch.hpp"
 #include "mlp_rowpass.hpp"
 #include "mlp_internal.hpp"
+#include "sac_rows.hpp"
 
 using namespace pa;
 
@@ -107,6 +108,10 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
   PA_REQUIRE(desc->device >= 0 && desc->device < ndev, PA_ERR_HIP,
              "HIP device %d not available (%d visible): pa_mlp is HIP-only and has no CPU fallback",
              desc->device, ndev);
+  {
+    int rc_dev = bind_process_device(desc->device);
+    if (rc_dev != PA_OK) return rc_dev;
+  }
   pa_mlp* h = new (std::nothrow) pa_mlp();
   PA_REQUIRE(h, PA_ERR_NOMEM, "out of host memory");
   memset(h, 0, sizeof(*h));
@@ -252,6 +257,74 @@ int launch_rowbwd(RowBwdArgs& a, int nnet, hipStream_t s) {
   return PA_OK;
 }
 
+// ---- the [K0, H1, H2, DO] forward through sac_rows.hpp's building blocks (rows3_fwd_kernel) -------
+bool rows3_enabled() {
+  static const bool on = []() {
+    const char* v = getenv("PEARL_AMD_ROWS3");
+    return !(v && *v == '0');
+  }();
+  return on;
+}
+bool rows3_shape(const pa_mlp* h) {
+  return h->row_ok && h->L == 3 && h->d.identity_layers == 0 && !h->d.no_last_bias &&
+         h->d.dims[1] <= 256 && h->d.dims[2] <= 256 && h->d.dims[3] <= 32 &&
+         h->d.dims[0] <= ROW_MAX_IN;
+}
+// all networks of a launch: same kind (critics: one output; or heads of 2..32 outputs), a grid that
+// fits the chip once (beyond that — PPO's 4096-row minibatch — the three-workgroups-per-CU generic
+// kernel is already MFMA-bound)
+bool rows3_usable(pa_mlp* const* hs, int nnet, int B) {
+  if (!rows3_enabled() || (int64_t)ceil_div(B, RP_ROWS) * nnet > 256) return false;
+  for (int i = 0; i < nnet; ++i) {
+    if (!rows3_shape(hs[i])) return false;
+    if ((hs[i]->d.dims[3] == 1) != (hs[0]->d.dims[3] == 1)) return false;
+    if (hs[i]->d.dims[0] != hs[0]->d.dims[0]) return false;
+  }
+  return true;
+}
+void fill_rows3(const pa_mlp* h, bool target, bool keep, SacMlp3& n) {
+  const float* P = target ? h->bufs.p_target : h->bufs.p;
+  float* const* wf = target ? h->wf_t : h->wf;
+  memset(&n, 0, sizeof(n));
+  n.W1f = wf[0]; n.b1 = P + h->boff[0];
+  n.W2f = wf[1]; n.b2 = P + h->boff[1];
+  n.W3f = wf[2]; n.b3 = P + h->boff[2];
+  n.w3 = P + h->woff[2];
+  n.act1 = keep ? h->act[0] : nullptr;
+  n.act2 = keep ? h->act[1] : nullptr;
+  n.K0 = h->d.dims[0]; n.H1 = h->d.dims[1]; n.H2 = h->d.dims[2]; n.DO = h->d.dims[3];
+}
+template <int NGH, bool CRITIC>
+int launch_rows3_t(const Rows3FwdArgs& a, int nnet, int k0, hipStream_t s) {
+  static size_t configured = 0;
+  const size_t smem = sac_rows_smem_floats(k0) * sizeof(float);
+  if (smem > configured) {
+    int rc = set_max_smem(rows3_fwd_kernel<NGH, CRITIC>, smem);
+    if (rc != PA_OK) return rc;
+    configured = smem;
+  }
+  hipLaunchKernelGGL((rows3_fwd_kernel<NGH, CRITIC>), dim3((unsigned)ceil_div(a.B, RP_ROWS), (unsigned)nnet),
+                     dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+int launch_rows3(pa_mlp* const* hs, int nnet, bool target, const float* x, int ldx, int B,
+                 float* const* outs, const int* ldos, bool keep, hipStream_t s) {
+  Rows3FwdArgs a;
+  memset(&a, 0, sizeof(a));
+  bool st = true;
+  for (int i = 0; i < nnet; ++i) {
+    fill_rows3(hs[i], target, keep, a.net[i]);
+    a.out[i] = outs[i]; a.ldo[i] = ldos[i];
+    st = st && wf16_nkg(hs[i]->d.dims[1]) == 16 && wf16_nkg(hs[i]->d.dims[2]) == 16;
+  }
+  a.x = x; a.ldx = ldx; a.B = B;
+  const bool critic = hs[0]->d.dims[3] == 1;
+  const int k0 = hs[0]->d.dims[0];
+  if (critic) return st ? launch_rows3_t<16, true>(a, nnet, k0, s) : launch_rows3_t<0, true>(a, nnet, k0, s);
+  return st ? launch_rows3_t<16, false>(a, nnet, k0, s) : launch_rows3_t<0, false>(a, nnet, k0, s);
+}
+
 }  // namespace
 
 // out = W_L-1(relu(... relu(W_0 x + b_0) ...)) + b_L-1.  keep = 1 retains the hidden activations for
@@ -269,6 +342,14 @@ extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int
     // the whole network in one launch (mlp_rowpass.hpp)
     int rc = ensure_packed(h, use_target != 0, s);
     if (rc != PA_OK) return rc;
+    if (rows3_usable(&h, 1, B)) {
+      float* outs[1] = {out};
+      const int ldos[1] = {ldo};
+      rc = launch_rows3(&h, 1, use_target != 0, x, ldx, B, outs, ldos, keep != 0, s);
+      if (rc != PA_OK) return rc;
+      h->kept_B = keep ? B : 0;
+      return PA_OK;
+    }
     RowFwdArgs a;
     memset(&a, 0, sizeof(a));
     fill_fwd(h, use_target != 0, out, ldo, keep != 0, a.net[0]);
@@ -569,8 +650,14 @@ extern "C" int pa_mlp_forward2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const
     for (int i = 0; i < 2; ++i) {
       rc = ensure_packed(hs[i], use_target != 0, s);
       if (rc != PA_OK) return rc;
-      fill_fwd(hs[i], use_target != 0, outs[i], ldos[i], keep != 0, a.net[i]);
     }
+    if (rows3_usable(hs, 2, B)) {
+      rc = launch_rows3(hs, 2, use_target != 0, x, ldx, B, outs, ldos, keep != 0, s);
+      if (rc != PA_OK) return rc;
+      h1->kept_B = h2->kept_B = keep ? B : 0;
+      return PA_OK;
+    }
+    for (int i = 0; i < 2; ++i) fill_fwd(hs[i], use_target != 0, outs[i], ldos[i], keep != 0, a.net[i]);
     a.x = x; a.ldx = ldx; a.B = B;
     rc = launch_rowfwd(a, 2, h1->d.dims[0], s);
     if (rc != PA_OK) return rc;

@@ -379,7 +379,7 @@ __device__ __forceinline__ void sr_critic(const SacMlp3& n, const float* cst, co
     qp += h.y * w3v[t].y;
     qp += h.z * w3v[t].z;
     qp += h.w * w3v[t].w;
-    if (KEEP && rok) store4_guarded(n.act2, row * n.H2, u, n.H2, (n.H2 & 3) == 0, h);
+    if (KEEP && rok && n.act2) store4_guarded(n.act2, row * n.H2, u, n.H2, (n.H2 & 3) == 0, h);
     if (WANT_G) {
       const float4 s2 = make_float4(h.x > 0.f ? w3v[t].x : 0.f, h.y > 0.f ? w3v[t].y : 0.f,
                                     h.z > 0.f ? w3v[t].z : 0.f, h.w > 0.f ? w3v[t].w : 0.f);
@@ -874,6 +874,69 @@ static __global__ __launch_bounds__(256) void sac_finish_kernel(SacFinishArgs a)
     st.p = a.log_alpha; st.m = a.am; st.v = a.av; st.vmax = a.avmax;
     const float pnew = adam_update(a.ac, st, 0, g);
     a.alpha[0] = expf(pnew);
+  }
+}
+
+// ---- any [K0, H1, H2, DO] ReLU network forward through the same building blocks ------------------
+// pa_mlp_forward / _forward2 for the shapes every actor and critic of the family has (two hidden
+// layers <= 256; one output — a critic, whose last layer is a dot product in the layer-2 epilogue —
+// or up to 32 — an actor head, K split over the waves).  The generic mlp_rowfwd_kernel spends 19 us
+// on such a twin forward at B = 1024: biases fetched from global memory before each GEMM, rolled
+// weight loops that expose one memory latency per four k-groups, and a full GEMM pass for a 1- or
+// 16-wide last layer; this one 10-12 us.
+struct Rows3FwdArgs {
+  SacMlp3 net[2];
+  const float* x; int ldx;
+  int B;
+  float* out[2]; int ldo[2];
+  long long* prof;
+};
+template <int NGH, bool CRITIC>
+__global__ __launch_bounds__(512) void rows3_fwd_kernel(Rows3FwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const SrLane L = sr_lane();
+  const SacMlp3& n = a.net[blockIdx.y];
+  const int P0 = rp_pad(n.K0), PH = row_hid_pitch();
+  float* xs = smem;
+  float* hA = xs + RP_ROWS * P0;
+  float* hB = hA + RP_ROWS * PH;
+  float* hC = hB + RP_ROWS * PH;
+  float* red = hC + RP_ROWS * PH;
+  float* headS = red + 8 * RP_ROWS * SR_HEADP;
+  float* qred = headS + RP_ROWS * SR_DHP;
+  float* small = qred + 8 * RP_ROWS;
+  float* cst = small + 8 * RP_ROWS;
+  const int m0 = blockIdx.x * RP_ROWS;
+  const int64_t row = m0 + L.r16;
+  const bool rok = row < a.B;
+  WRing R, R1;
+  sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
+  {
+    SrTile xt;
+    SrConsts k0;
+    const bool fits = sr_tile_fits(P0);
+    if (fits) sr_tile_load(xt, a.x, a.ldx, n.K0, m0, a.B, P0, L.tid);
+    sr_consts_load(k0, n, CRITIC, L.tid);
+    if (fits) sr_tile_store(xt, xs, P0, L.tid);
+    else sr_stage(a.x, a.ldx, n.K0, m0, a.B, xs, P0, L.tid);
+    sr_consts_store(cst, k0, L.tid);
+  }
+  SrNext none;
+  none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
+  if constexpr (CRITIC) {
+    sr_critic<NGH, 0, false, true>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                   nullptr, 0, 0);
+    __syncthreads();
+    if (L.tid < RP_ROWS && m0 + L.tid < a.B)
+      a.out[blockIdx.y][(int64_t)(m0 + L.tid) * a.ldo[blockIdx.y]] = sr_q(qred, L.tid, cst);
+  } else {
+    unsigned m1, m2;
+    sr_actor_fwd<NGH, 0, 0, true>(n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1, m2, none);
+    for (int e = L.tid; e < RP_ROWS * n.DO; e += 512) {
+      const int r = e / n.DO, c = e - r * n.DO;
+      if (m0 + r < a.B)
+        a.out[blockIdx.y][(int64_t)(m0 + r) * a.ldo[blockIdx.y] + c] = headS[r * SR_HEADP + c];
+    }
   }
 }
 

@@ -233,8 +233,15 @@ class ProximalPolicyOptimization(ActorCriticBase):
         dev = actor.device
         state = self._f32(self._history_summarization_module(roll.state), dev)
         arep = self._f32(self.action_representation_module(roll.action), dev).reshape(n, -1)
-        values = critic.forward(state).reshape(n).contiguous()
-        logits = actor.forward(state)
+        # the SAME launch shape learn_batch uses for these two networks: with epsilon = 0 the clipped
+        # surrogate passes a gradient only where the probability ratio is exactly 1, i.e. where this
+        # forward and learn_batch's agree to the bit
+        if actor.dims[0] == critic.dims[0] and len(actor.dims) == len(critic.dims):
+            logits, values = FlatMlp.forward_pair(actor, critic, state)
+            values = values.reshape(n).contiguous()
+        else:
+            values = critic.forward(state).reshape(n).contiguous()
+            logits = actor.forward(state)
         aprob = torch.empty(n, dtype=torch.float32, device=dev)
         s = N.stream_ptr(dev)
         N.check(N.lib().pa_softmax_action_prob(logits.data_ptr(), logits.stride(0), arep.data_ptr(),

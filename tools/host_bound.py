@@ -30,6 +30,22 @@ def make_sac(steps):
     return lambda: pl.learn(rb)
 
 
+def make_td3(steps):
+    from pearl_amd import TD3, BasicReplayBuffer, BoxActionSpace, PearlAgent
+    S, A, B, N = 64, 8, 1024, 200_000
+    pl = TD3(action_space=BoxActionSpace(-torch.ones(A), torch.ones(A)), state_dim=S,
+             actor_hidden_dims=[256, 256], critic_hidden_dims=[256, 256], batch_size=B,
+             training_rounds=steps)
+    rb = BasicReplayBuffer(N, sampler="device")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    st = torch.randn(N + 1, S, device=DEV)
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=torch.rand(N, A, device=DEV) * 2 - 1, reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                 next_state=st[1:])
+    return lambda: pl.learn(rb)
+
+
 def make_ppo(steps):
     from pearl_amd import (DiscreteActionSpace, OneHotActionTensorRepresentationModule, PearlAgent,
                            PPOReplayBuffer, ProximalPolicyOptimization)
@@ -61,9 +77,9 @@ def main():
         torch.set_num_threads(32)
     torch.manual_seed(0)
     random.seed(0)
-    learn = {"sac": make_sac, "ppo": make_ppo}[which](steps)
+    learn = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3}[which](steps)
     if "warm20" in sys.argv:          # a short warm-up instead of a full learn()
-        short = {"sac": make_sac, "ppo": make_ppo}[which](20)
+        short = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3}[which](20)
         short()
     else:
         learn()
@@ -80,7 +96,7 @@ def main():
     learn()
     pr.disable()
     torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(16)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(int(os.environ.get('TOPN', '16')))
 
 
 if __name__ == "__main__":
