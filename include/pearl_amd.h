@@ -463,6 +463,36 @@ typedef struct pa_sac_step_args {
 } pa_sac_step_args;
 int64_t pa_sac_scratch_floats(int32_t B, int32_t S, int32_t A);
 int pa_sac_step(const pa_sac_step_args* args, void* stream);
+/* ------------------------------------------------------------------------ */
+/* One DeepDeterministicPolicyGradient / TD3 learn_batch as one call          */
+/* (ddpg.py:106-147, td3.py:105-175 on actor_critic_base.py:309-366): the same */
+/* launches the per-stage path issues, sequenced in C.  The actor is            */
+/* [S, ..., A] (tanh + action scaling applied by pa_tanh_action), the critics    */
+/* [S + A, ..., 1], every network with its target copy bound.  Single process.   */
+/* ------------------------------------------------------------------------ */
+typedef struct pa_ddpg_step_args {
+  pa_mlp* actor; pa_mlp* critic1; pa_mlp* critic2;
+  const float* state; int32_t ld_state;
+  const float* action; int32_t ld_action;
+  const float* reward;
+  const uint8_t* terminated;
+  const float* next_state; int32_t ld_next_state;
+  const float* target_noise;     /* [B, A] N(0, sigma^2) draws of TD3's target smoothing, or NULL */
+  float noise_clip;
+  const float* low; const float* high;
+  const float* zeros;            /* at least B device floats of 0 */
+  int32_t B, S, A;
+  float gamma;
+  int32_t do_actor;              /* update the actor this step (TD3: every actor_update_freq-th) */
+  int32_t do_targets;            /* soft-update the critic targets and the actor target */
+  float critic_tau, actor_tau;
+  int64_t actor_step, critic_step;   /* AdamW step numbers (1-based) of this update */
+  float* scratch;                /* pa_ddpg_scratch_floats(B, S, A) floats, 16-byte aligned */
+  float* losses;                 /* [2] actor loss (written when do_actor), critic loss */
+} pa_ddpg_step_args;
+int64_t pa_ddpg_scratch_floats(int32_t B, int32_t S, int32_t A);
+int pa_ddpg_step(const pa_ddpg_step_args* args, void* stream);
+
 /* tuning aid (tools/prof_sac.py): in-kernel phase stamps of the two fused row kernels */
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
 /* HIP-event timing of the two fused row launches (first 64 steps after enabling): bench lines */

@@ -232,6 +232,29 @@ class SacStepArgs(C.Structure):
     ]
 
 
+class DdpgStepArgs(C.Structure):
+    """pa_ddpg_step_args (include/pearl_amd.h)."""
+    _fields_ = [
+        ("actor", C.c_void_p), ("critic1", C.c_void_p), ("critic2", C.c_void_p),
+        ("state", C.c_void_p), ("ld_state", C.c_int32),
+        ("action", C.c_void_p), ("ld_action", C.c_int32),
+        ("reward", C.c_void_p),
+        ("terminated", C.c_void_p),
+        ("next_state", C.c_void_p), ("ld_next_state", C.c_int32),
+        ("target_noise", C.c_void_p),
+        ("noise_clip", C.c_float),
+        ("low", C.c_void_p), ("high", C.c_void_p),
+        ("zeros", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("A", C.c_int32),
+        ("gamma", C.c_float),
+        ("do_actor", C.c_int32), ("do_targets", C.c_int32),
+        ("critic_tau", C.c_float), ("actor_tau", C.c_float),
+        ("actor_step", C.c_int64), ("critic_step", C.c_int64),
+        ("scratch", C.c_void_p),
+        ("losses", C.c_void_p),
+    ]
+
+
 class LearnArgs(C.Structure):
     _fields_ = [
         ("rounds", C.c_int32),
@@ -369,6 +392,8 @@ SIGNATURES = {
     "pa_sac_twin": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, _P]),
     "pa_sac_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "pa_sac_step": (C.c_int, [C.POINTER(SacStepArgs), _P]),
+    "pa_ddpg_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "pa_ddpg_step": (C.c_int, [C.POINTER(DdpgStepArgs), _P]),
     "pa_debug_sac_prof": (C.c_int, [_P, _P]),
     "pa_sac_timing": (C.c_int, [C.c_int32]),
     "pa_sac_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -428,3 +428,98 @@ extern "C" int pa_sac_timing_read(double* rows_a_us, double* rows_b_us, int64_t*
   *rows_b_us = g_tm.n ? 1e3 * sb / g_tm.n : 0.0;
   return PA_OK;
 }
+
+// =============================================================================================
+// DDPG / TD3: one learn_batch as one call
+// (pearl/policy_learners/sequential_decision_making/ddpg.py:106-147, td3.py:105-175 on
+// actor_critic_base.py:309-366).  The same launches the per-stage Python path issues, in its order
+// (bit-identical results): that path needed ~185 us of host time per step for ~160 us of kernels.
+// =============================================================================================
+namespace {
+struct DdpgScratch {
+  float *xa, *head, *q1, *dq, *dx, *d_head, *xn, *head_n, *nq1, *nq2, *y, *xq, *qa, *qb, *dqa, *dqb;
+};
+int64_t carve_ddpg(DdpgScratch* s, float* base, int64_t B, int64_t S, int64_t A) {
+  int64_t o = 0;
+  auto take = [&](float** p, int64_t n) {
+    if (s && base) *p = base + o;
+    o += a4(n);
+  };
+  take(s ? &s->xa : nullptr, B * (S + A));
+  take(s ? &s->head : nullptr, B * A);
+  take(s ? &s->q1 : nullptr, B);
+  take(s ? &s->dq : nullptr, B);
+  take(s ? &s->dx : nullptr, B * (S + A));
+  take(s ? &s->d_head : nullptr, B * A);
+  take(s ? &s->xn : nullptr, B * (S + A));
+  take(s ? &s->head_n : nullptr, B * A);
+  take(s ? &s->nq1 : nullptr, B);
+  take(s ? &s->nq2 : nullptr, B);
+  take(s ? &s->y : nullptr, B);
+  take(s ? &s->xq : nullptr, B * (S + A));
+  take(s ? &s->qa : nullptr, B);
+  take(s ? &s->qb : nullptr, B);
+  take(s ? &s->dqa : nullptr, B);
+  take(s ? &s->dqb : nullptr, B);
+  return o;
+}
+}  // namespace
+
+extern "C" int64_t pa_ddpg_scratch_floats(int32_t B, int32_t S, int32_t A) {
+  return carve_ddpg(nullptr, nullptr, B, S, A);
+}
+
+extern "C" int pa_ddpg_step(const pa_ddpg_step_args* a, void* stream) {
+  PA_REQUIRE(a && a->actor && a->critic1 && a->critic2 && a->state && a->action && a->reward &&
+                 a->terminated && a->next_state && a->low && a->high && a->zeros && a->scratch &&
+                 a->losses && a->B > 0 && a->S > 0 && a->A > 0,
+             PA_ERR_INVALID, "pa_ddpg_step: bad argument");
+  const int B = a->B, S = a->S, A = a->A, W = S + A;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  DdpgScratch w;
+  memset(&w, 0, sizeof(w));
+  carve_ddpg(&w, a->scratch, B, S, A);
+  // ---------------------------------------------------------------- actor update (ddpg.py:106-121)
+  if (a->do_actor) {
+    PA_HIP(hipMemcpy2DAsync(w.xa, (size_t)W * 4, a->state, (size_t)a->ld_state * 4, (size_t)S * 4,
+                            (size_t)B, hipMemcpyDeviceToDevice, s));
+    PA_TRY(pa_mlp_forward(a->actor, 0, a->state, a->ld_state, B, w.head, A, 1, stream));
+    PA_TRY(pa_tanh_action(w.head, A, nullptr, 0, a->low, a->high, 0.f, B, A, w.xa + S, W, stream));
+    PA_TRY(pa_mlp_forward(a->critic1, 0, w.xa, W, B, w.q1, 1, 1, stream));
+    PA_TRY(pa_neg_mean_head(w.q1, 1, B, w.dq, a->losses + 0, stream));
+    // only critic 1's INPUT gradient matters (actor_critic_base.py:342-348)
+    PA_TRY(pa_mlp_backward(a->critic1, w.xa, W, B, w.dq, 1, 0, w.dx, W, stream));
+    PA_TRY(pa_tanh_action_grad(w.head, A, a->low, a->high, w.dx + S, W, B, A, w.d_head, A, stream));
+    PA_TRY(pa_mlp_backward(a->actor, a->state, a->ld_state, B, w.d_head, A, 2, nullptr, 0, stream));
+    PA_TRY(pa_mlp_adam(a->actor, a->actor_step, stream));
+  }
+  // ---------------------------------------------------------------- critic update (ddpg.py:123-147)
+  PA_HIP(hipMemcpy2DAsync(w.xn, (size_t)W * 4, a->next_state, (size_t)a->ld_next_state * 4,
+                          (size_t)S * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
+  PA_TRY(pa_mlp_forward(a->actor, 1, a->next_state, a->ld_next_state, B, w.head_n, A, 0, stream));
+  PA_TRY(pa_tanh_action(w.head_n, A, a->target_noise, A, a->low, a->high, a->noise_clip, B, A,
+                        w.xn + S, W, stream));
+  PA_TRY(pa_mlp_forward2(a->critic1, a->critic2, 1, w.xn, W, B, w.nq1, 1, w.nq2, 1, 0, stream));
+  // pa_sac_twin(mode 1) with alpha = 0, log_prob = 0:  y = min(q1', q2') gamma (1 - term) + r
+  PA_TRY(pa_sac_twin(1, w.nq1, w.nq2, a->zeros, a->zeros, a->reward, a->terminated, a->gamma, B, w.y,
+                     nullptr, nullptr, stream));
+  PA_TRY(pa_concat_cols(a->state, a->ld_state, a->action, a->ld_action, w.xq, B, S, A, stream));
+  PA_TRY(pa_mlp_forward2(a->critic1, a->critic2, 0, w.xq, W, B, w.qa, 1, w.qb, 1, 1, stream));
+  PA_TRY(pa_mse_head(w.qa, 1, w.y, B, 1.0f / (float)B, 0.5f, 0, w.dqa, a->losses + 1, stream));
+  PA_TRY(pa_mse_head(w.qb, 1, w.y, B, 1.0f / (float)B, 0.5f, 1, w.dqb, a->losses + 1, stream));
+  PA_TRY(pa_mlp_backward2(a->critic1, a->critic2, w.xq, W, B, w.dqa, 1, w.dqb, 1, 2, nullptr, nullptr,
+                          0, stream));
+  const bool soft = a->do_targets != 0;
+  if (mlp_pair_fusable(a->critic1, a->critic2, soft)) {
+    PA_TRY(pa_mlp_adam2(a->critic1, a->critic2, a->critic_step, soft ? a->critic_tau : -1.f, stream));
+  } else {
+    PA_TRY(pa_mlp_adam(a->critic1, a->critic_step, stream));
+    PA_TRY(pa_mlp_adam(a->critic2, a->critic_step, stream));
+    if (soft) {
+      PA_TRY(pa_mlp_soft_update(a->critic1, a->critic_tau, stream));
+      PA_TRY(pa_mlp_soft_update(a->critic2, a->critic_tau, stream));
+    }
+  }
+  if (soft) PA_TRY(pa_mlp_soft_update(a->actor, a->actor_tau, stream));
+  return PA_OK;
+}

@@ -13,9 +13,12 @@ input), its gradient ``pa_tanh_action_grad`` on the critic's input gradient
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Any, Callable, Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 from torch import Tensor, nn
 
 from ... import _native as N
@@ -140,6 +143,74 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         actor.backward(state, d_head, want_dw=True, defer=True)
         actor.adam()
         return loss[0]
+
+    # ------------------------------------------------------------------ one-call step
+    def _one_call_ok(self) -> bool:
+        """pa_ddpg_step sequences the whole learn_batch in C (the per-stage path below needed ~185 us
+        of host time per step for ~160 us of kernels).  Single process, and only for the stages as
+        this class defines them: a data-parallel step all-reduces between backward and AdamW, and a
+        subclass that overrides a stage keeps the per-stage path."""
+        if os.environ.get("PEARL_AMD_DDPG_ONE_CALL", "1") == "0":
+            return False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        cls, base = type(self), DeepDeterministicPolicyGradient
+        return (cls._actor_update is base._actor_update and cls._critic_update is base._critic_update
+                and cls._update_critic_target is base._update_critic_target
+                and cls._update_actor_target is base._update_actor_target
+                and cls._policy_input is base._policy_input
+                and self._use_critic and self._use_critic_target and self._use_actor_target)
+
+    def _learn_one_call(self, batch: TransitionBatch, do_actor: bool, do_targets: bool):
+        actor, c1, c2 = self._nets(len(batch))
+        dev = actor.device
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        A = actor.dims[-1]
+        act = self._f32(batch.action, dev).reshape(B, A)
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = batch.terminated.to(dev).reshape(B)
+        term = (term.view(torch.uint8) if term.dtype == torch.bool else term.to(torch.uint8)).contiguous()
+        noise, clip = self._target_noise(B, A, dev)
+        ws = self._flat.get("one_call")
+        if ws is None or ws["key"] != (dev, B, S, A):
+            n = int(N.lib().pa_ddpg_scratch_floats(B, S, A))
+            ws = {"key": (dev, B, S, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
+                  "zeros": torch.zeros(max(B, 1), dtype=torch.float32, device=dev),
+                  "args": N.DdpgStepArgs()}
+            self._flat["one_call"] = ws
+        low, high = self._bounds(dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        a = ws["args"]
+        a.actor, a.critic1, a.critic2 = actor.handle, c1.handle, c2.handle
+        a.state, a.ld_state = state.data_ptr(), state.stride(0)
+        a.action, a.ld_action = act.data_ptr(), act.stride(0)
+        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
+        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        if noise is not None:
+            noise = noise.to(dev, torch.float32).contiguous()
+            assert noise.shape == (B, A)
+        a.target_noise, a.noise_clip = N.ptr(noise), float(clip)
+        a.low, a.high, a.zeros = low.data_ptr(), high.data_ptr(), ws["zeros"].data_ptr()
+        a.B, a.S, a.A = B, S, A
+        a.gamma = float(self._discount_factor)
+        a.do_actor, a.do_targets = int(do_actor), int(do_targets)
+        a.critic_tau, a.actor_tau = float(self._critic_soft_update_tau), float(self._actor_soft_update_tau)
+        a.actor_step, a.critic_step = actor._steps + 1, c1._steps + 1
+        a.scratch, a.losses = ws["scratch"].data_ptr(), losses.data_ptr()
+        N.check(N.lib().pa_ddpg_step(C.byref(a), N.stream_ptr(dev)))
+        if do_actor:
+            actor.stepped_natively()
+        c1.stepped_natively()
+        c2.stepped_natively()
+        return (losses[0] if do_actor else None), losses[1]
+
+    def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        if self._one_call_ok():
+            al, cl = self._learn_one_call(batch, True, True)
+            return {"actor_loss": al, "critic_loss": cl}
+        return super()._learn_batch_device(batch)
 
     def _target_noise(self, B: int, A: int, dev: torch.device):
         """(noise, clip) added to the target policy's action; DDPG adds none (ddpg.py:123-131)."""

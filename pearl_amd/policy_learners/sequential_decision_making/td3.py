@@ -44,6 +44,11 @@ class TD3(DeepDeterministicPolicyGradient):
 
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
         due = self._training_steps % self._actor_update_freq == 0
+        if self._one_call_ok() and type(self)._target_noise is TD3._target_noise:
+            actor_loss, critic_loss = self._learn_one_call(batch, due, due)
+            if due:
+                self._last_actor_loss = actor_loss
+            return {"actor_loss": self._last_actor_loss, "critic_loss": critic_loss}
         if due:
             self._last_actor_loss = self._actor_update(batch)
         else:
