@@ -489,6 +489,34 @@ def test_ddpg_td3_learn_batch_trajectory(name):
             torch.testing.assert_close(v.cpu(), fx[key][k], rtol=2e-3, atol=3e-5, msg=f"{name_}.{k}")
 
 
+@pytest.mark.parametrize("name", DDPG)
+def test_ddpg_td3_one_call_step_is_the_per_stage_step(name, monkeypatch):
+    """pa_ddpg_step (one C call per learn_batch) issues the launches of the per-stage Python path in
+    its order: losses, all four networks and the optimizer state bit-identical."""
+    fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    outs = []
+    for one_call in ("0", "1"):
+        monkeypatch.setenv("PEARL_AMD_DDPG_ONE_CALL", one_call)
+        pl = make_ddpg(fx)
+        reports = []
+        for step, noise in enumerate(fx["noises"]):
+            if noise is not None:
+                pl.noise_source = lambda B, A, dev, n=noise: n
+            pl._training_steps = step
+            reports.append({k: float(v) for k, v in
+                            pl.learn_batch(pl.preprocess_batch(sac_batch(fx))).items()})
+        torch.cuda.synchronize()
+        outs.append((reports, [v.detach().cpu().clone() for mod in (pl._actor, pl._actor_target,
+                                                                    pl._critic, pl._critic_target)
+                               for v in mod.state_dict().values()],
+                     [st[k].detach().cpu().clone() for opt in (pl._actor_optimizer, pl._critic_optimizer)
+                      for st in opt.state.values() for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq")]))
+    (ra, pa_, oa), (rb, pb, ob) = outs
+    assert ra == rb
+    for x, y in zip(pa_ + oa, pb + ob):
+        assert torch.equal(x, y)
+
+
 def test_td3_learn_from_replay_defers_readback_and_delays_actor():
     """TD3.learn() through a device-sampled arena: finite losses, the actor loss only changes on
     rounds where the actor stepped, and the actor target only moves on those rounds."""
