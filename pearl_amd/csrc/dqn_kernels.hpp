@@ -849,12 +849,24 @@ struct DwNet2 {
   const float* grad_base;
   float* tgt;
 };
+// Optional extra workgroup of a weight-gradient launch: end-of-step scalar work that would
+// otherwise be a launch of its own.  kind 1 = continuous SAC's step tail (sac_rows.hpp): the two
+// losses from per-tile partial sums, in tile order, and the entropy-coefficient AdamW step
+// (soft_actor_critic_continuous.py:134-151) with alpha_kernel's arithmetic.
+struct TailJob {
+  int kind;
+  const float* part_a; const float* part_b; int tiles; int B;
+  float* actor_loss; float* critic_loss;
+  float* log_alpha; float* am; float* av; float* avmax; float* alpha;
+  const float* logp; float target_entropy; AdamScalars ac; float* alpha_loss_out;
+};
 constexpr int DW_MAX_PROB = 6;
 struct DwArgs {
   DwProblem p[DW_MAX_PROB];
   int nprob, B, total_tiles;
   AdamFuse ad;
   DwNet2 net2;
+  TailJob tail;
   long long* prof;   // optional phase stamps (tools/prof_chain.py): [workgroup][wave][16]
   // Large batches: `ksplit` workgroups share a tile, each reducing its slice of the batch; they
   // leave their partial tile in `kscratch` (write-through stores) and take a ticket, the last one
@@ -1020,6 +1032,49 @@ __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
   }
 }
 
+__device__ __forceinline__ void sac_step_tail(const TailJob& t, float* lds, int tid) {
+  float sa = 0.f, sb = 0.f;
+  for (int base = 0; base < t.tiles; base += 256) {
+    if (tid < 256) {
+      lds[tid] = base + tid < t.tiles ? t.part_a[base + tid] : 0.f;
+      lds[256 + tid] = base + tid < t.tiles ? t.part_b[base + tid] : 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const int n = t.tiles - base < 256 ? t.tiles - base : 256;
+      for (int k = 0; k < n; ++k) {
+        sa += lds[k];
+        sb += lds[256 + k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    t.actor_loss[0] = sa / (float)t.B;
+    // ((q1 - y)^2 + (q2 - y)^2 summed) / B / 2  ==  (mse1 + mse2) / 2   (critic_utils.py:170-203)
+    t.critic_loss[0] = (sb / (float)t.B) * 0.5f;
+  }
+  if (!t.log_alpha) return;
+  const float ea = expf(t.log_alpha[0]);
+  float part = 0.f;
+  if (tid < 256)
+    for (int b = tid; b < t.B; b += 256) part += -ea * (t.logp[b] + t.target_entropy);
+  if (tid < 256) lds[tid] = part;
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if (tid < w) lds[tid] += lds[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float g = lds[0] / (float)t.B;
+    if (t.alpha_loss_out) t.alpha_loss_out[0] = g;
+    AdamState st;
+    st.p = t.log_alpha; st.m = t.am; st.v = t.av; st.vmax = t.avmax;
+    const float pnew = adam_update(t.ac, st, 0, g);
+    t.alpha[0] = expf(pnew);
+  }
+}
+
 static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   __shared__ float part[4 * DW_TM * DW_TN];  // 32 KB: four partial tiles
   __shared__ float csum[8 * DW_TM];
@@ -1028,6 +1083,10 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   const int KSP = a.ksplit > 1 ? a.ksplit : 1;
   const int wg_tile = (int)blockIdx.x / KSP, kslice = (int)blockIdx.x % KSP;
   if (wg_tile >= a.total_tiles) {
+    if (a.tail.kind == 1) {
+      sac_step_tail(a.tail, part, tid);
+      return;
+    }
     // mean |Q - target| of this step (deep_td_learning.py:358-359), fixed summation order
     float s = 0.f;
     for (int i = tid; i < a.ad.nabs; i += 512) s += a.ad.absd[i];

@@ -407,7 +407,7 @@ struct DwOperands {
   const float* const* dzs; const int* ldzs;
 };
 int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B, int64_t adam_step,
-                       float soft_tau, hipStream_t s) {
+                       float soft_tau, hipStream_t s, const TailJob* tail = nullptr) {
   pa_mlp* h0 = hs[0];
   const int L = h0->L;
   for (int l0 = 0; l0 < L; l0 += 3) {
@@ -465,7 +465,10 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
         if (nnet > 1) a.net2.tgt = hs[1]->bufs.p_target;
       }
     }
-    int rc = launch_weight_grad(a, false, s);
+    // the step's scalar tail rides the last launch as one extra workgroup
+    const bool with_tail = tail && l0 + 3 >= L;
+    if (with_tail) a.tail = *tail;
+    int rc = launch_weight_grad(a, with_tail, s);
     if (rc != PA_OK) return rc;
   }
   if (adam_step > 0 && soft_tau >= 0.f)
@@ -2556,7 +2559,7 @@ extern "C" int pa_mlp_adam2(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, 
              "pa_mlp_adam2: the networks do not share shape, batch and optimizer configuration, or "
              "have no deferred weight gradients");
   PA_HIP(hipSetDevice(a->d.device));
-  return pa::mlp_adam_pair(a, b, step, soft_tau, reinterpret_cast<hipStream_t>(stream));
+  return pa::mlp_adam_pair(a, b, step, soft_tau, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
 // ---- internal entry points for the fused learner steps (sac_step.hip) ---------------------------
@@ -2581,11 +2584,12 @@ bool mlp_pair_fusable(const pa_mlp* a, const pa_mlp* b, bool soft) {
   }
   return true;
 }
-int mlp_adam_pair(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, hipStream_t s) {
+int mlp_adam_pair(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, hipStream_t s,
+                  const TailJob* tail) {
   pa_mlp* hs[2] = {a, b};
   DwOperands ops[2] = {{a->pend.x, a->pend.ldx, a->pend.dzs, a->pend.ldzs},
                        {b->pend.x, b->pend.ldx, b->pend.dzs, b->pend.ldzs}};
   a->pend.active = b->pend.active = false;
-  return run_weight_grads_n(hs, ops, 2, a->pend.B, step, soft_tau, s);
+  return run_weight_grads_n(hs, ops, 2, a->pend.B, step, soft_tau, s, tail);
 }
 }  // namespace pa

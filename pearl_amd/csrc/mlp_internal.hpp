@@ -47,5 +47,8 @@ void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* con
 // Two networks with pending weight gradients and ONE optimizer configuration (twin critics):
 // dW + AdamW (+ soft target update when soft_tau >= 0) of both in one launch.
 bool mlp_pair_fusable(const pa_mlp* a, const pa_mlp* b, bool soft);
-int mlp_adam_pair(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, hipStream_t s);
+struct TailJob;
+// `tail` (nullable): end-of-step scalar work that rides the launch as one extra workgroup
+int mlp_adam_pair(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, hipStream_t s,
+                  const TailJob* tail);
 }  // namespace pa

@@ -295,28 +295,36 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
     const int ldzs[3] = {cs[i]->d.dims[1], cs[i]->d.dims[2], 1};
     mlp_set_pending(cs[i], w.xq, W, B, dzs, ldzs);
   }
-  if (mlp_pair_fusable(c1, c2, true)) {
-    // both critics' weight gradients, AdamW and soft target updates: one launch
-    PA_TRY(mlp_adam_pair(c1, c2, a->critic_step, a->tau, s));
-  } else {
-    PA_TRY(pa_mlp_adam(c1, a->critic_step, s));
-    PA_TRY(pa_mlp_adam(c2, a->critic_step, s));
-    PA_TRY(pa_mlp_soft_update(c1, a->tau, s));
-    PA_TRY(pa_mlp_soft_update(c2, a->tau, s));
-  }
   // ---------------------------------------------------------------- losses, entropy coefficient
+  TailJob tj;
+  memset(&tj, 0, sizeof(tj));
+  tj.kind = 1;
+  tj.part_a = ta.partials; tj.part_b = tb.partials; tj.tiles = tiles; tj.B = B;
+  tj.actor_loss = a->losses + 0; tj.critic_loss = a->losses + 1;
+  if (a->log_alpha) {
+    tj.log_alpha = a->log_alpha; tj.am = a->alpha_m; tj.av = a->alpha_v; tj.avmax = a->alpha_vmax;
+    tj.alpha = a->alpha;
+    tj.logp = logp; tj.target_entropy = a->target_entropy;
+    tj.ac = scalar_adam(a->alpha_lr, a->alpha_beta1, a->alpha_beta2, a->alpha_eps,
+                        a->alpha_weight_decay, a->alpha_amsgrad, a->alpha_step);
+    tj.alpha_loss_out = a->losses + 2;
+  }
+  if (mlp_pair_fusable(c1, c2, true)) {
+    // both critics' weight gradients, AdamW, soft target updates AND the step's scalar tail (one
+    // extra workgroup): one launch
+    return mlp_adam_pair(c1, c2, a->critic_step, a->tau, s, &tj);
+  }
+  PA_TRY(pa_mlp_adam(c1, a->critic_step, s));
+  PA_TRY(pa_mlp_adam(c2, a->critic_step, s));
+  PA_TRY(pa_mlp_soft_update(c1, a->tau, s));
+  PA_TRY(pa_mlp_soft_update(c2, a->tau, s));
   SacFinishArgs fa;
   memset(&fa, 0, sizeof(fa));
-  fa.part_a = ta.partials; fa.part_b = tb.partials; fa.tiles = tiles; fa.B = B;
-  fa.actor_loss = a->losses + 0; fa.critic_loss = a->losses + 1;
-  if (a->log_alpha) {
-    fa.log_alpha = a->log_alpha; fa.am = a->alpha_m; fa.av = a->alpha_v; fa.avmax = a->alpha_vmax;
-    fa.alpha = a->alpha;
-    fa.logp = logp; fa.target_entropy = a->target_entropy;
-    fa.ac = scalar_adam(a->alpha_lr, a->alpha_beta1, a->alpha_beta2, a->alpha_eps,
-                        a->alpha_weight_decay, a->alpha_amsgrad, a->alpha_step);
-    fa.alpha_loss_out = a->losses + 2;
-  }
+  fa.part_a = tj.part_a; fa.part_b = tj.part_b; fa.tiles = tiles; fa.B = B;
+  fa.actor_loss = tj.actor_loss; fa.critic_loss = tj.critic_loss;
+  fa.log_alpha = tj.log_alpha; fa.am = tj.am; fa.av = tj.av; fa.avmax = tj.avmax; fa.alpha = tj.alpha;
+  fa.logp = tj.logp; fa.target_entropy = tj.target_entropy; fa.ac = tj.ac;
+  fa.alpha_loss_out = tj.alpha_loss_out;
   hipLaunchKernelGGL(sac_finish_kernel, dim3(1), dim3(256), 0, s, fa);
   PA_LAUNCH_CHECK();
   return PA_OK;

@@ -177,6 +177,7 @@ class ActorCriticBase(PolicyLearner):
                 if isinstance(m, FlatMlp):
                     m._loop_validated = False
             FlatMlp.in_learn_loop = True
+            self._begin_learn_loop(self._training_rounds, batch_size)
             for _ in range(self._training_rounds):
                 self._training_steps += 1
                 batch = replay_buffer.sample(batch_size)
@@ -185,6 +186,7 @@ class ActorCriticBase(PolicyLearner):
                 for k, v in self._learn_batch_device(self._preprocess_for_learn(batch)).items():
                     pending.setdefault(k, []).append(v)
         finally:
+            self._end_learn_loop()
             FlatMlp.leave_learn_loop()
             if presample is not None:
                 replay_buffer.drop_presampled()
@@ -215,6 +217,12 @@ class ActorCriticBase(PolicyLearner):
         if safety is not None and hasattr(safety, "lambda_constraint"):
             batch.reward = batch.reward - safety.lambda_constraint * batch.cost
         return super().preprocess_batch(batch)
+
+    def _begin_learn_loop(self, rounds: int, batch_size: int) -> None:
+        """Hook: per-call preparation a learner can amortise over the rounds of one learn()."""
+
+    def _end_learn_loop(self) -> None:
+        """Hook: undo _begin_learn_loop."""
 
     _target_update_follows = False     # set around _critic_update by _learn_batch_device
     _critic_target_done = False        # the soft update already rode the critics' AdamW launch

@@ -274,7 +274,13 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         term = batch.terminated.to(dev).reshape(B)
         term = (term.view(torch.uint8) if term.dtype == torch.bool else term.to(torch.uint8)).contiguous()
         if self.noise_source is None:
-            noise = torch.randn(2, B, A, device=dev, dtype=torch.float32)
+            ring = self._flat.get("noise_ring")
+            if ring is not None and ring["next"] < ring["buf"].shape[0] and \
+                    ring["buf"].shape[2:] == (B, A) and ring["buf"].device == dev:
+                noise = ring["buf"][ring["next"]]     # drawn for the whole learn() call at once
+                ring["next"] += 1
+            else:
+                noise = torch.randn(2, B, A, device=dev, dtype=torch.float32)
             noise_a, noise_c = noise[0], noise[1]
         else:   # parity: the reference draws the actor update's noise first, then the target's
             noise_a, noise_c = self._noise(B, A, dev), self._noise(B, A, dev)
@@ -321,6 +327,22 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             self._entropy_optimizer.state[self._log_entropy]["step"].fill_(float(al["step"]))
             report["entropy_coef"] = losses[2]
         return report
+
+    def _begin_learn_loop(self, rounds: int, batch_size: int) -> None:
+        """The reparameterisation noise of every round of this learn() call in ONE generator launch
+        (2 draws of (B, A) per round) instead of one launch per round on the step's critical path."""
+        self._flat.pop("noise_ring", None)
+        if self.noise_source is None and self._one_call_ok() and rounds > 1 and self._flat.get("actor"):
+            actor = self._flat["actor"]
+            if actor.handle is not None:
+                A = actor.dims[-1] // 2
+                n = rounds * 2 * batch_size * A
+                if n <= (1 << 26):      # 256 MB of fp32 at most
+                    self._flat["noise_ring"] = {"next": 0, "buf": torch.randn(
+                        rounds, 2, batch_size, A, device=actor.device, dtype=torch.float32)}
+
+    def _end_learn_loop(self) -> None:
+        self._flat.pop("noise_ring", None)
 
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
         if self._one_call_ok():
