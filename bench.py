@@ -174,6 +174,8 @@ def main():
         N.check(N.lib().pa_dqn_set_overlap(nat.handle, 1))
         N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
     # the W warm-up rounds, through the same loop the timed region uses, right before it
+    if world > 1:
+        barrier()      # ranks fill their arenas at different speeds: start the rounds together
     if args.warmup > 0:
         pl._training_rounds = args.warmup
         agent.learn()

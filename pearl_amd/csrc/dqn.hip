@@ -204,12 +204,17 @@ static __global__ void signal_kernel(int* flag, int value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Bounded like consume_y: a producer that never runs must not hang the GPU (err word, pa_dqn_check).
+// The bound is wall-clock time (the constant 100 MHz counter), and generous: in a data-parallel
+// run the producer — the learner stream — can legitimately sit in a collective for seconds (RCCL's
+// first-call set-up, a rank that is still filling its arena).
 static __global__ void wait_flag_kernel(const int* flag, int value, int* err) {
   if (threadIdx.x != 0) return;
+  constexpr long long kLimitTicks = 120LL * 100000000LL;     // 120 s
+  const long long t0 = (long long)wall_clock64();
   int spins = 0;
   while ((__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
     __builtin_amdgcn_s_sleep(8);
-    if (++spins > (1 << 22)) {
+    if ((++spins & 1023) == 0 && (long long)wall_clock64() - t0 > kLimitTicks) {
       __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       break;
     }

@@ -696,6 +696,12 @@ class DeepQLearning(PolicyLearner):
                 lib.pa_comm_destroy(handle)
             self._native.comm_failed = True
             return None
+        # RCCL sets a communicator up on its first collective (channels, proxies: up to seconds
+        # with 8 ranks): do that here, not inside the first learn() round
+        warm = torch.zeros(256, dtype=torch.float32, device=dev)
+        N.check(lib.pa_comm_allreduce_start(handle, warm.data_ptr(), warm.numel(), N.stream_ptr(dev)))
+        N.check(lib.pa_comm_allreduce_wait(handle, N.stream_ptr(dev)))
+        torch.cuda.synchronize(dev)
         self._native.comm = handle
         return handle
 
