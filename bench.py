@@ -164,10 +164,13 @@ def main():
     overlapped = os.environ.get("PEARL_AMD_OVERLAP", "1") != "0" and args.timing_level < 2
     calib_rounds = 0
     if world == 1 and args.timing_level == 1 and overlapped:
-        calib_rounds = 200
+        calib_rounds = 300
         N.check(N.lib().pa_dqn_set_overlap(nat.handle, 0))
+        N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
+        pl._training_rounds = 100    # (the GPU comes out of idle: these launches are not timed)
+        agent.learn()
         N.check(N.lib().pa_dqn_enable_timing(nat.handle, 1))
-        pl._training_rounds = calib_rounds
+        pl._training_rounds = 200
         agent.learn()
         torch.cuda.synchronize(dev)
         isolated = read_timers().get("target")
