@@ -84,7 +84,7 @@ struct pa_dqn {
   // writes parameters (bind, step, apply, update_target, pa_dqn_invalidate)
   bool packed_ok;
   int* err_dev;      // device error word (a bounded wait expired)
-  int* err_host;     // pinned mirror, copied at the end of learn()
+  int* err_host;     // pinned, device-mapped twin: a kernel that sets err_dev sets it too (no copy)
   int overlap;       // 0: single-stream learn loop (PEARL_AMD_OVERLAP=0 or timing level >= 2)
   int split_first;   // rounds of a window whose target pass is issued first, as its own launch
   bool y_clean;      // both yw buffers hold kYPendingBits everywhere (tagged hand-off invariant)
@@ -207,7 +207,7 @@ static __global__ void signal_kernel(int* flag, int value) {
 // The bound is wall-clock time (the constant 100 MHz counter), and generous: in a data-parallel
 // run the producer — the learner stream — can legitimately sit in a collective for seconds (RCCL's
 // first-call set-up, a rank that is still filling its arena).
-static __global__ void wait_flag_kernel(const int* flag, int value, int* err) {
+static __global__ void wait_flag_kernel(const int* flag, int value, int* err, int* err_host) {
   if (threadIdx.x != 0) return;
   constexpr long long kLimitTicks = 120LL * 100000000LL;     // 120 s
   const long long t0 = (long long)wall_clock64();
@@ -216,6 +216,7 @@ static __global__ void wait_flag_kernel(const int* flag, int value, int* err) {
     __builtin_amdgcn_s_sleep(8);
     if ((++spins & 1023) == 0 && (long long)wall_clock64() - t0 > kLimitTicks) {
       __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (err_host) __hip_atomic_store(err_host, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
@@ -230,7 +231,7 @@ int stream_hop(pa_dqn* h, hipStream_t from, hipStream_t to, hipEvent_t fallback)
   const int gen = ++h->sig_gen;
   hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, from, h->sig, gen);
   PA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, to, h->sig, gen, h->err_dev);
+  hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, to, h->sig, gen, h->err_dev, h->err_host);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -458,6 +459,7 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   a.y = y;
   a.y_tagged = y_tagged ? 1 : 0;
   a.err = h->err_dev;
+  a.err_host = h->err_host;
   if (h->pending_signal) {
     a.signal_flag = h->sig;
     a.signal_value = h->pending_signal;
@@ -1169,7 +1171,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         // and it costs no launch of its own.
         const int gen = ++h->sig_gen;
         h->pending_signal = gen;
-        hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev);
+        hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev, h->err_host);
         PA_LAUNCH_CHECK();
       } else {
         PA_HIP(hipStreamWaitEvent(t, h->ev_chain[(k - 1) & 1], 0));
@@ -1304,7 +1306,6 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // everything the side stream did is ordered before whatever the caller enqueues next
     PA_HIP(hipEventRecord(h->ev_tail, t));
     PA_HIP(hipStreamWaitEvent(s, h->ev_tail, 0));
-    PA_HIP(hipMemcpyAsync(h->err_host, h->err_dev, 4, hipMemcpyDeviceToHost, s));
   }
   return PA_OK;
 }

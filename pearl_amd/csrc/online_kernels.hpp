@@ -145,6 +145,7 @@ struct RowArgs {
   const float* y;                       // [B] Bellman targets; null = forward only (probe)
   int y_tagged;                         // y is produced concurrently by another stream (consume_y)
   int* err;                             // device error word for the bounded wait
+  int* err_host;                        // its pinned, device-mapped host twin (written on failure)
   int* signal_flag; int signal_value;   // optional: published by workgroup 0 as soon as it starts
                                         // ("everything before this launch on its stream is done":
                                         // the window hand-off of learn(), see pa_dqn::sig)
@@ -523,7 +524,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   float yv = q;
   if (rok) {
     // (an untagged y can legitimately hold the tag's bit pattern: only the tagged protocol polls)
-    if (a.y_tagged && ybits == kYPendingBits) yv = consume_y(a.y + row, a.err);
+    if (a.y_tagged && ybits == kYPendingBits) yv = consume_y(a.y + row, a.err, a.err_host);
     else yv = __builtin_bit_cast(float, ybits);
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 9);
