@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void sac_step_tail(const TailJob& t, float* lds, int 
     __syncthreads();
   }
   if (tid == 0) {
-    t.actor_loss[0] = sa / (float)t.B;
+    if (t.actor_loss) t.actor_loss[0] = sa / (float)t.B;
     // ((q1 - y)^2 + (q2 - y)^2 summed) / B / 2  ==  (mse1 + mse2) / 2   (critic_utils.py:170-203)
     t.critic_loss[0] = (sb / (float)t.B) * 0.5f;
   }

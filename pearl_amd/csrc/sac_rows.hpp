@@ -62,6 +62,8 @@ struct SacRowsAArgs {
   float* xq;                             // [B][S + A]
   float* q[2];                           // [B] critics at (s, a_batch)
   SacTicket tk;
+  int actor_rows;                        // 1: role 0 = actor update rows; 0: critic roles only
+                                         // (TD3 on a step without an actor update)
   long long* prof;
 };
 
@@ -74,6 +76,7 @@ struct SacRowsBArgs {
   const float* low; const float* high;
   const float* alpha_in;
   const float* reward; const uint8_t* term; float gamma;
+  float noise_clip;                      // HEAD 1 (DDPG / TD3): target-policy smoothing clamp
   const float* q[2];
   float* dq[2];                          // [B]
   int B, S, A;
@@ -482,7 +485,10 @@ __device__ __forceinline__ void sr_tile_partial(const float* rowsum, float* part
   }
 }
 
-template <int NGH, int NGA, int NGC>
+// HEAD 0: tanh-Gaussian policy, twin-critic actor loss (continuous SAC).
+// HEAD 1: deterministic tanh policy, actor loss -mean Q1(s, pi(s)) (DDPG / TD3, ddpg.py:106-121):
+//         the head is [A] wide, no log-probability, one critic pass, d loss / d q = -1/B.
+template <int NGH, int NGA, int NGC, int HEAD>
 __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
@@ -504,9 +510,10 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   SR_STAMP(a.prof, wg, 0);
 
-  if (blockIdx.y > 0) {
+  const int role = (int)blockIdx.y + (a.actor_rows ? 0 : 1);
+  if (role > 0) {
     // ---------------------------------------------------------------- critic c at (s, a_batch)
-    const int c = blockIdx.y - 1;
+    const int c = role - 1;
     const SacMlp3& n = a.critic[c];
     sr_l1_fill<NGC>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
     sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
@@ -555,9 +562,10 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
   const bool sok = L.tid < RP_ROWS * a.A;
   const bool srok = sok && (m0 + sr) < a.B;
-  const float eps = ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok);
+  const float eps = HEAD == 0 ? ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok) : 0.f;
   const float lo = ld_or_zero(a.low, sj, sok), hi = ld_or_zero(a.high, sj, sok);
-  const float alpha = a.alpha[0];
+  const float alpha = HEAD == 0 ? a.alpha[0] : 0.f;
+  constexpr int NCRIT = HEAD == 0 ? 2 : 1;
   {
     // every start-up request in flight before the first wait
     SrTile xt;
@@ -566,12 +574,12 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     if (fits) sr_tile_load(xt, a.state, a.ld_state, a.S, m0, a.B, P0, L.tid);
     sr_consts_load(k0, n, false, L.tid);
     sr_consts_load(k1, a.critic[0], true, L.tid);
-    sr_consts_load(k2, a.critic[1], true, L.tid);
+    if (NCRIT > 1) sr_consts_load(k2, a.critic[1], true, L.tid);
     if (fits) sr_tile_store(xt, xs, P0, L.tid);
     else sr_stage(a.state, a.ld_state, a.S, m0, a.B, xs, P0, L.tid);
     sr_consts_store(cst, k0, L.tid);
     sr_consts_store(cst + SR_CST, k1, L.tid);
-    sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
+    if (NCRIT > 1) sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
   }
   SR_STAMP(a.prof, wg, 1);
   unsigned m1a, m2a;
@@ -584,13 +592,21 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   SrGauss G;
   G.t = G.sd = G.n = G.eps = G.bound = 0.f;
   float* terms = red;                       // [16][16]
-  if (sok) terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
-  __syncthreads();
-  if (L.tid < RP_ROWS) {
-    float lp = 0.f;
-    for (int k = 0; k < a.A; ++k) lp += terms[L.tid * 16 + k];
-    small[2 * RP_ROWS + L.tid] = lp;
-    if (m0 + L.tid < a.B) a.logp[m0 + L.tid] = lp;
+  if constexpr (HEAD == 0) {
+    if (sok) terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
+    __syncthreads();
+    if (L.tid < RP_ROWS) {
+      float lp = 0.f;
+      for (int k = 0; k < a.A; ++k) lp += terms[L.tid * 16 + k];
+      small[2 * RP_ROWS + L.tid] = lp;
+      if (m0 + L.tid < a.B) a.logp[m0 + L.tid] = lp;
+    }
+  } else {
+    // VanillaContinuousActorNetwork.sample_action (actor_networks.py:448-485, action_scaling :29-51)
+    if (sok) {
+      G.t = tanhf(headS[sr * SR_HEADP + sj]);
+      xs[sr * P0 + a.S + sj] = (((hi - lo) * (G.t + 1.0f)) / 2.0f) + lo;
+    }
   }
   SR_STAMP(a.prof, wg, 3);
   // ---- both critics at (s, a): q_c and gx_c = Gm_c W1_c[:, S:]
@@ -600,17 +616,19 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   const int ntl = ((W + 15) >> 4) - t_lo;       // <= 2 (A <= 16)
   SrSmallW w3t;
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < NCRIT; ++c) {
     const SacMlp3& q = a.critic[c];
+    constexpr int CN = NCRIT - 1;        // the next critic, when there is one
+    const bool lastc = c == NCRIT - 1;
     SrNarrowW gw;
     sr_narrow_load(gw, q.W1tf, wf16_nkg(q.H1), t_lo, ntl, L);
     SrNext nx;
-    nx.W1 = c == 0 ? a.critic[1].W1f : nullptr; nx.nt1 = (a.critic[1].H1 + 15) >> 4;
-    nx.Wh = c == 0 ? a.critic[1].W2f : n.W2tf;
-    nx.nth = c == 0 ? (a.critic[1].H2 + 15) >> 4 : (n.H1 + 15) >> 4;
+    nx.W1 = lastc ? nullptr : a.critic[CN].W1f; nx.nt1 = (a.critic[CN].H1 + 15) >> 4;
+    nx.Wh = lastc ? n.W2tf : a.critic[CN].W2f;
+    nx.nth = lastc ? (n.H1 + 15) >> 4 : (a.critic[CN].H2 + 15) >> 4;
     sr_critic<NGH, NGC, true, false>(q, cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R, R1, L,
                                      row, rok, nx, a.prof, wg, 4 + 4 * c);
-    if (c == 1) sr_small_load(w3t, n.W3tf, wf16_nkg(n.DO), L.tile0, (n.H2 + 15) >> 4, L.lane);
+    if (lastc) sr_small_load(w3t, n.W3tf, wf16_nkg(n.DO), L.tile0, (n.H2 + 15) >> 4, L.lane);
     __syncthreads();
     if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, cst + (1 + c) * SR_CST);
     sr_narrow_mma(gw, wf16_nkg(q.H1), hC + L.r16 * PH + 4 * L.qd, red, L);
@@ -619,7 +637,17 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     SR_STAMP(a.prof, wg, 7 + 4 * c);
   }
   // ---- twin rule, loss, head gradient (twin_kernel mode 0, gauss_grad_kernel)
-  if (sok) {
+  if constexpr (HEAD == 1) {
+    // -mean Q1: d loss / d q = -1/B; d head = (g / 2) (high - low) (1 - tanh^2)  (tanh_action_grad)
+    if (sok) {
+      const float g = (-1.0f / (float)a.B) * gx[0];
+      const float gt = (g / 2.0f) * (hi - lo);
+      const float d = srok ? gt * (1.0f - G.t * G.t) : 0.f;
+      dhS[sr * SR_DHP + sj] = d;
+      if (srok) a.d_head[(int64_t)(m0 + sr) * a.A + sj] = d;
+      if (sj == 0) small[3 * RP_ROWS + sr] = srok ? -small[sr] : 0.f;
+    }
+  } else if (sok) {
     const float q1 = small[sr], q2 = small[RP_ROWS + sr];
     const float w1 = q1 < q2 ? 1.f : (q1 == q2 ? 0.5f : 0.f);
     const float dq1 = -w1 / (float)a.B, dq2 = -(1.f - w1) / (float)a.B;
@@ -645,7 +673,7 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   // zero the rest of the head-gradient tile (k padding of the next GEMM)
   for (int e = L.tid; e < RP_ROWS * SR_DHP; e += 512) {
     const int cc = e % SR_DHP;
-    if (cc >= 2 * a.A) dhS[e] = 0.f;
+    if (cc >= n.DO) dhS[e] = 0.f;
   }
   // ---- actor backward: d z2 = (d head W3) [h2 > 0], d z1 = (d z2 W2) [h1 > 0]
   f32x4v acc[2];
@@ -665,7 +693,9 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   SR_STAMP(a.prof, wg, 15);
 }
 
-template <int NGH, int NGA, int NGC>
+// HEAD 1: `actor` is the TARGET policy, the next action is its tanh-scaled output plus the clamped
+// smoothing noise (td3.py:151-175; none for DDPG), and y = min(q1', q2') gamma (1 - term) + r.
+template <int NGH, int NGA, int NGC, int HEAD>
 __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
@@ -692,9 +722,9 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
   const bool sok = L.tid < RP_ROWS * a.A;
   const bool srok = sok && (m0 + sr) < a.B;
-  const float eps = ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok);
+  const float eps = ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok && a.noise != nullptr);
   const float lo = ld_or_zero(a.low, sj, sok), hi = ld_or_zero(a.high, sj, sok);
-  const float alpha = a.alpha_in[0];
+  const float alpha = HEAD == 0 ? a.alpha_in[0] : 0.f;
   {
     SrTile xt;
     SrConsts k0, k1, k2;
@@ -722,14 +752,30 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
       n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
       SrNext{a.target[0].W1f, (a.target[0].H1 + 15) >> 4, a.target[0].W2f, (a.target[0].H2 + 15) >> 4});
   SR_STAMP(a.prof, wg, 2);
-  SrGauss G;
-  float* terms = red;
-  if (sok) terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
-  __syncthreads();
-  if (L.tid < RP_ROWS) {
-    float lp = 0.f;
-    for (int k = 0; k < a.A; ++k) lp += terms[L.tid * 16 + k];
-    small[2 * RP_ROWS + L.tid] = lp;
+  if constexpr (HEAD == 0) {
+    SrGauss G;
+    float* terms = red;
+    if (sok) terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
+    __syncthreads();
+    if (L.tid < RP_ROWS) {
+      float lp = 0.f;
+      for (int k = 0; k < a.A; ++k) lp += terms[L.tid * 16 + k];
+      small[2 * RP_ROWS + L.tid] = lp;
+    }
+  } else {
+    // tanh_action_kernel: a = ((high - low)(tanh z + 1)) / 2 + low; with noise: the draws clamped
+    // to [-clip, clip], rescaled by (high - low) / 2, added, the sum clamped to [low, high]
+    if (sok) {
+      const float t = tanhf(headS[sr * SR_HEADP + sj]);
+      float act = (((hi - lo) * (t + 1.0f)) / 2.0f) + lo;
+      if (a.noise) {
+        float nz = fminf(fmaxf(eps, -a.noise_clip), a.noise_clip);
+        nz = (nz * (hi - lo)) / 2.0f;
+        act = fminf(fmaxf(act + nz, lo), hi);
+      }
+      xs[sr * P0 + a.S + sj] = act;
+    }
+    if (L.tid < RP_ROWS) small[2 * RP_ROWS + L.tid] = 0.f;
   }
   SR_STAMP(a.prof, wg, 3);
   // the rows of s2 / Gm this workgroup will scale: requested now, needed after y
@@ -853,7 +899,7 @@ static __global__ __launch_bounds__(256) void sac_finish_kernel(SacFinishArgs a)
     __syncthreads();
   }
   if (tid == 0) {
-    a.actor_loss[0] = sa / (float)a.B;
+    if (a.actor_loss) a.actor_loss[0] = sa / (float)a.B;
     // ((q1 - y)^2 + (q2 - y)^2 summed) / B / 2  ==  (mse1 + mse2) / 2   (critic_utils.py:170-203)
     a.critic_loss[0] = (sb / (float)a.B) * 0.5f;
   }

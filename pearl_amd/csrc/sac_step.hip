@@ -162,23 +162,24 @@ int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
   return PA_OK;
 }
 
-template <int NGH, int NGA, int NGC>
+template <int NGH, int NGA, int NGC, int HEAD = 0>
 int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s) {
   static size_t configured = 0;
   const size_t smem = sac_rows_smem_floats(W) * sizeof(float);
   if (smem > configured) {
-    int rc = set_max_smem(sac_rows_a_kernel<NGH, NGA, NGC>, smem);
+    int rc = set_max_smem(sac_rows_a_kernel<NGH, NGA, NGC, HEAD>, smem);
     if (rc != PA_OK) return rc;
-    rc = set_max_smem(sac_rows_b_kernel<NGH, NGA, NGC>, smem);
+    rc = set_max_smem(sac_rows_b_kernel<NGH, NGA, NGC, HEAD>, smem);
     if (rc != PA_OK) return rc;
     configured = smem;
   }
   if (ra) {
     const unsigned tiles = (unsigned)ceil_div(ra->B, RP_ROWS);
-    hipLaunchKernelGGL((sac_rows_a_kernel<NGH, NGA, NGC>), dim3(tiles, 3), dim3(512), smem, s, *ra);
+    hipLaunchKernelGGL((sac_rows_a_kernel<NGH, NGA, NGC, HEAD>), dim3(tiles, ra->actor_rows ? 3 : 2),
+                       dim3(512), smem, s, *ra);
   } else {
     const unsigned tiles = (unsigned)ceil_div(rb->B, RP_ROWS);
-    hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC>), dim3(tiles), dim3(512), smem, s, *rb);
+    hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD>), dim3(tiles), dim3(512), smem, s, *rb);
   }
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -244,6 +245,7 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   ra.d_head = w.d_head; ra.logp = logp; ra.xq = w.xq;
   ra.q[0] = w.q1; ra.q[1] = w.q2;
   ra.tk = ta;
+  ra.actor_rows = 1;
   ra.prof = g_prof_a;
   // instantiations: every loop unrolled (hidden 256, S = 49..64, S + A = 65..80: the benchmark
   // shape), hidden layers unrolled only, all run-time
@@ -473,8 +475,148 @@ int64_t carve_ddpg(DdpgScratch* s, float* base, int64_t B, int64_t S, int64_t A)
 }
 }  // namespace
 
+namespace {
+// ---- the fused form: sac_rows.hpp with HEAD = 1 -------------------------------------------------
+bool ddpg_fused_ok(const pa_ddpg_step_args* a) {
+  const char* v = getenv("PEARL_AMD_DDPG_FUSED");     // read per call: tests compare the forms
+  if (v && *v == '0') return false;
+  const pa_mlp *ac = a->actor, *c1 = a->critic1, *c2 = a->critic2;
+  if (!relu3(ac) || !relu3(c1) || !relu3(c2)) return false;
+  if (!ac->bufs.p_target || !c1->bufs.p_target || !c2->bufs.p_target) return false;
+  if (a->A < 1 || a->A > 16 || a->S + a->A > ROW_MAX_IN) return false;
+  if (ac->d.dims[0] != a->S || ac->d.dims[3] != a->A) return false;
+  for (const pa_mlp* c : {c1, c2}) {
+    if (c->d.dims[0] != a->S + a->A || c->d.dims[3] != 1) return false;
+    if (c->d.dims[1] != c1->d.dims[1] || c->d.dims[2] != c1->d.dims[2]) return false;
+  }
+  return a->B <= ac->d.max_batch && a->B <= c1->d.max_batch && a->B <= c2->d.max_batch;
+}
+
+struct DdpgFusedScratch {
+  float *d_head, *xq, *q1, *q2, *dq1, *dq2, *logp_unused;
+};
+int64_t carve_ddpg_fused(DdpgFusedScratch* s, float* base, int64_t B, int64_t S, int64_t A) {
+  int64_t o = 0;
+  auto take = [&](float** p, int64_t n) {
+    if (s && base) *p = base + o;
+    o += a4(n);
+  };
+  take(s ? &s->d_head : nullptr, B * A);
+  take(s ? &s->xq : nullptr, B * (S + A));
+  take(s ? &s->q1 : nullptr, B);
+  take(s ? &s->q2 : nullptr, B);
+  take(s ? &s->dq1 : nullptr, B);
+  take(s ? &s->dq2 : nullptr, B);
+  take(s ? &s->logp_unused : nullptr, B);
+  return o;
+}
+
+template <int NGH, int NGA, int NGC>
+int launch_rows_ddpg(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s) {
+  return launch_rows<NGH, NGA, NGC, 1>(ra, rb, W, s);
+}
+
+int ddpg_fused_step(const pa_ddpg_step_args* a, hipStream_t s) {
+  pa_mlp *ac = a->actor, *c1 = a->critic1, *c2 = a->critic2;
+  const int B = a->B, S = a->S, A = a->A, W = S + A;
+  PA_HIP(hipSetDevice(ac->d.device));
+  DdpgFusedScratch w;
+  memset(&w, 0, sizeof(w));
+  carve_ddpg_fused(&w, a->scratch, B, S, A);
+  const int tiles = (int)ceil_div(B, RP_ROWS);
+  SacTicket ta, tb;
+  PA_TRY(tickets(tiles, &ta, &tb));
+  PA_TRY(mlp_ensure_packed(ac, false, s));
+  PA_TRY(mlp_ensure_packed(ac, true, s));
+  PA_TRY(mlp_ensure_packed(c1, false, s));
+  PA_TRY(mlp_ensure_packed(c2, false, s));
+  PA_TRY(mlp_ensure_packed(c1, true, s));
+  PA_TRY(mlp_ensure_packed(c2, true, s));
+  const int ngh = static_groups(ac, c1);
+  const int form = ngh != 16 ? 0 : (wf16_nkg(S) == 4 && wf16_nkg(W) == 5 ? 2 : 1);
+  // ---------------------------------------------------------------- rows A
+  SacRowsAArgs ra;
+  memset(&ra, 0, sizeof(ra));
+  fill_net(ac, false, ra.actor);
+  fill_net(c1, false, ra.critic[0]);
+  fill_net(c2, false, ra.critic[1]);
+  ra.state = a->state; ra.ld_state = a->ld_state;
+  ra.action = a->action; ra.ld_action = a->ld_action;
+  ra.low = a->low; ra.high = a->high;
+  ra.B = B; ra.S = S; ra.A = A;
+  ra.d_head = w.d_head; ra.logp = w.logp_unused; ra.xq = w.xq;
+  ra.q[0] = w.q1; ra.q[1] = w.q2;
+  ra.tk = ta;
+  ra.actor_rows = a->do_actor ? 1 : 0;
+  PA_TRY((form == 2   ? launch_rows_ddpg<16, 4, 5>(&ra, nullptr, W, s)
+          : form == 1 ? launch_rows_ddpg<16, 0, 0>(&ra, nullptr, W, s)
+                      : launch_rows_ddpg<0, 0, 0>(&ra, nullptr, W, s)));
+  // ---------------------------------------------------------------- actor: dW + AdamW
+  if (a->do_actor) {
+    const float* dzs[3] = {ac->dz[1], ac->dz[2], w.d_head};
+    const int ldzs[3] = {ac->d.dims[1], ac->d.dims[2], A};
+    mlp_set_pending(ac, a->state, a->ld_state, B, dzs, ldzs);
+    PA_TRY(pa_mlp_adam(ac, a->actor_step, s));
+  }
+  // ---------------------------------------------------------------- rows B (TARGET policy)
+  SacRowsBArgs rb;
+  memset(&rb, 0, sizeof(rb));
+  fill_net(ac, true, rb.actor);
+  fill_net(c1, true, rb.target[0]);
+  fill_net(c2, true, rb.target[1]);
+  rb.dz1[0] = c1->dz[1]; rb.dz2[0] = c1->dz[2];
+  rb.dz1[1] = c2->dz[1]; rb.dz2[1] = c2->dz[2];
+  rb.H1c = c1->d.dims[1]; rb.H2c = c1->d.dims[2];
+  rb.next_state = a->next_state; rb.ld_next = a->ld_next_state;
+  rb.noise = a->target_noise; rb.ld_noise = A; rb.noise_clip = a->noise_clip;
+  rb.low = a->low; rb.high = a->high;
+  rb.reward = a->reward; rb.term = a->terminated; rb.gamma = a->gamma;
+  rb.q[0] = w.q1; rb.q[1] = w.q2;
+  rb.dq[0] = w.dq1; rb.dq[1] = w.dq2;
+  rb.B = B; rb.S = S; rb.A = A;
+  rb.tk = tb;
+  PA_TRY((form == 2   ? launch_rows_ddpg<16, 4, 5>(nullptr, &rb, W, s)
+          : form == 1 ? launch_rows_ddpg<16, 0, 0>(nullptr, &rb, W, s)
+                      : launch_rows_ddpg<0, 0, 0>(nullptr, &rb, W, s)));
+  // ---------------------------------------------------------------- critics: dW + AdamW, targets
+  pa_mlp* cs[2] = {c1, c2};
+  float* dqs[2] = {w.dq1, w.dq2};
+  for (int i = 0; i < 2; ++i) {
+    const float* dzs[3] = {cs[i]->dz[1], cs[i]->dz[2], dqs[i]};
+    const int ldzs[3] = {cs[i]->d.dims[1], cs[i]->d.dims[2], 1};
+    mlp_set_pending(cs[i], w.xq, W, B, dzs, ldzs);
+  }
+  const bool soft = a->do_targets != 0;
+  TailJob tj;
+  memset(&tj, 0, sizeof(tj));
+  tj.kind = 1;
+  tj.part_a = ta.partials; tj.part_b = tb.partials; tj.tiles = tiles; tj.B = B;
+  tj.actor_loss = a->do_actor ? a->losses + 0 : nullptr;
+  tj.critic_loss = a->losses + 1;
+  if (mlp_pair_fusable(c1, c2, soft)) {
+    PA_TRY(mlp_adam_pair(c1, c2, a->critic_step, soft ? a->critic_tau : -1.f, s, &tj));
+  } else {
+    PA_TRY(pa_mlp_adam(c1, a->critic_step, s));
+    PA_TRY(pa_mlp_adam(c2, a->critic_step, s));
+    if (soft) {
+      PA_TRY(pa_mlp_soft_update(c1, a->critic_tau, s));
+      PA_TRY(pa_mlp_soft_update(c2, a->critic_tau, s));
+    }
+    SacFinishArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.part_a = tj.part_a; fa.part_b = tj.part_b; fa.tiles = tiles; fa.B = B;
+    fa.actor_loss = tj.actor_loss; fa.critic_loss = tj.critic_loss;
+    hipLaunchKernelGGL(sac_finish_kernel, dim3(1), dim3(256), 0, s, fa);
+    PA_LAUNCH_CHECK();
+  }
+  if (soft) PA_TRY(pa_mlp_soft_update(ac, a->actor_tau, s));
+  return PA_OK;
+}
+}  // namespace
+
 extern "C" int64_t pa_ddpg_scratch_floats(int32_t B, int32_t S, int32_t A) {
-  return carve_ddpg(nullptr, nullptr, B, S, A);
+  const int64_t x = carve_ddpg(nullptr, nullptr, B, S, A), y = carve_ddpg_fused(nullptr, nullptr, B, S, A);
+  return x > y ? x : y;
 }
 
 extern "C" int pa_ddpg_step(const pa_ddpg_step_args* a, void* stream) {
@@ -482,8 +624,9 @@ extern "C" int pa_ddpg_step(const pa_ddpg_step_args* a, void* stream) {
                  a->terminated && a->next_state && a->low && a->high && a->zeros && a->scratch &&
                  a->losses && a->B > 0 && a->S > 0 && a->A > 0,
              PA_ERR_INVALID, "pa_ddpg_step: bad argument");
-  const int B = a->B, S = a->S, A = a->A, W = S + A;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (ddpg_fused_ok(a)) return ddpg_fused_step(a, s);
+  const int B = a->B, S = a->S, A = a->A, W = S + A;
   DdpgScratch w;
   memset(&w, 0, sizeof(w));
   carve_ddpg(&w, a->scratch, B, S, A);

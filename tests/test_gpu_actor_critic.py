@@ -494,6 +494,7 @@ def test_ddpg_td3_one_call_step_is_the_per_stage_step(name, monkeypatch):
     """pa_ddpg_step (one C call per learn_batch) issues the launches of the per-stage Python path in
     its order: losses, all four networks and the optimizer state bit-identical."""
     fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
+    monkeypatch.setenv("PEARL_AMD_DDPG_FUSED", "0")       # the sequenced launches inside pa_ddpg_step
     outs = []
     for one_call in ("0", "1"):
         monkeypatch.setenv("PEARL_AMD_DDPG_ONE_CALL", one_call)
@@ -515,6 +516,50 @@ def test_ddpg_td3_one_call_step_is_the_per_stage_step(name, monkeypatch):
     assert ra == rb
     for x, y in zip(pa_ + oa, pb + ob):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("td3", [False, True])
+@pytest.mark.parametrize("S,A,hidden,B", [(64, 8, [256, 256], 1024), (17, 6, [256, 256], 100),
+                                          (10, 3, [32, 48], 50), (33, 16, [250, 256], 37)])
+def test_ddpg_td3_fused_rows_agree_with_sequenced(td3, S, A, hidden, B, monkeypatch):
+    """The fused row kernels with the deterministic-policy head (sac_rows.hpp, HEAD = 1) against the
+    sequenced launches of pa_ddpg_step: all instantiations, ragged batches, TD3's delayed actor /
+    target updates and smoothing noise."""
+    from pearl_amd import (TD3, BasicReplayBuffer, BoxActionSpace, DeepDeterministicPolicyGradient,
+                           PearlAgent, TransitionBatch)
+    g = torch.Generator().manual_seed(S * 17 + A + int(td3))
+    batch = dict(state=torch.randn(B, S, generator=g), action=torch.rand(B, A, generator=g) * 3 - 1,
+                 reward=torch.randn(B, generator=g), terminated=torch.rand(B, generator=g) < 0.2,
+                 next_state=torch.randn(B, S, generator=g))
+    noises = [0.2 * torch.randn(B, A, generator=g) for _ in range(4)]
+    outs = {}
+    for form in ("sequenced", "fused"):
+        monkeypatch.setenv("PEARL_AMD_DDPG_ONE_CALL", "1")
+        monkeypatch.setenv("PEARL_AMD_DDPG_FUSED", "1" if form == "fused" else "0")
+        torch.manual_seed(11)
+        cls = TD3 if td3 else DeepDeterministicPolicyGradient
+        pl = cls(action_space=BoxActionSpace(-torch.ones(A), 2 * torch.ones(A)), state_dim=S,
+                 actor_hidden_dims=hidden, critic_hidden_dims=hidden, batch_size=B)
+        PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+        reports = []
+        for step, nz in enumerate(noises):
+            pl.noise_source = lambda B_, A_, dev, n=nz: n
+            pl._training_steps = step
+            tb = TransitionBatch(**{k: v.to(DEV) for k, v in batch.items()})
+            reports.append({k: float(v) for k, v in pl.learn_batch(pl.preprocess_batch(tb)).items()})
+        torch.cuda.synchronize()
+        outs[form] = (reports, {f"{n}.{k}": v.detach().cpu().clone()
+                                for n, m in (("actor", pl._actor), ("actor_target", pl._actor_target),
+                                             ("critic", pl._critic), ("critic_target", pl._critic_target))
+                                for k, v in m.state_dict().items()})
+    (ra, pa_), (rb, pb) = outs["sequenced"], outs["fused"]
+    for x, y in zip(ra, rb):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 5e-5 * max(1.0, abs(x[k])), (k, x[k], y[k])
+    from helpers import assert_adam_trajectory_close
+    for k in pa_:
+        assert torch.isfinite(pb[k]).all(), k
+        assert_adam_trajectory_close(pb[k], pa_[k], 1e-3, len(noises), max_outlier_frac=5e-3, msg=k)
 
 
 def test_td3_learn_from_replay_defers_readback_and_delays_actor():
