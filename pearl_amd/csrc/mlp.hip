@@ -2036,11 +2036,19 @@ void linreg_solve_spd_kernel(SolveArgs a, int* need_pivot) {
       for (int r = 0; r < DR; ++r) bc[r] = col[r];
     }
     __syncthreads();
-    const double piv = bc[0];
+    // the pivot column, two doubles per LDS read (every lane reads the same address: broadcast)
+    double f[DR];
+#pragma unroll
+    for (int r = 0; r < DR; r += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(bc + r);
+      f[r] = v.x;
+      f[r + 1] = v.y;
+    }
+    const double piv = f[0];
     if (!(piv > 0.0) && t == 0) bad = 1;
     const double pr = col[0] * (1.0 / piv);
 #pragma unroll
-    for (int r = 1; r < DR; ++r) col[r - 1] = __builtin_fma(-bc[r], pr, col[r]);
+    for (int r = 1; r < DR; ++r) col[r - 1] = __builtin_fma(-f[r], pr, col[r]);
     col[DR - 1] = pr;
   }
   // ---- outputs: inv(A + lambda I) = rows / columns < D of the right half; coefs = inv b
