@@ -170,6 +170,16 @@ def bench_td3(steps, cpu_seconds):
     return {"config": "cfg3 shapes, TD3 S=64 A=8 twin-Q [256,256] B=1024 replay 200k",
             "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
             "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            # critic update every step (target policy + 2 target critics forward; 2 online critics
+            # forward, dX, dW), actor update every second step (actor forward / dX / dW, critic 1
+            # forward + dX)
+            "roofline": step_roofline(
+                2 * (mlp_macs([S, 256, 256, A]) + 2 * mlp_macs([S + A, 256, 256, 1])
+                     + 2 * (2 * mlp_macs([S + A, 256, 256, 1]) + 256 * 256)
+                     + 0.5 * (2 * mlp_macs([S, 256, 256, A]) + 256 * 256 + 256 * A
+                              + mlp_macs([S + A, 256, 256, 1]) + 256 * 256 + 256 * (S + A))),
+                B * steps, dt, kernel="sac_rows_a/b_kernel<16,4,5,1> + weight_grad_kernel (fused rows, "
+                                      "deterministic-policy head)"),
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
 
