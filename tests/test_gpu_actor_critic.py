@@ -143,7 +143,9 @@ def test_sac_learn_batch_trajectory(name):
 @pytest.mark.parametrize("S,A,hidden,B", [(17, 6, [256, 256], 100),     # hidden unrolled, first layers run-time
                                           (10, 3, [32, 48], 50),          # everything run-time, ragged tile
                                           (64, 8, [256, 256], 1000),      # the benchmark instantiation, ragged
-                                          (33, 16, [250, 256], 37)])      # widest action head, 250 = 16 k-groups
+                                          (33, 16, [250, 256], 37),       # widest action head, 250 = 16 k-groups
+                                          (64, 8, [256, 256], 4096),      # split-K weight gradients + the tail
+                                          (5, 2, [16, 16], 1)])           # a single row
 def test_sac_fused_rows_agree_with_sequenced_on_other_shapes(S, A, hidden, B, monkeypatch):
     """sac_rows.hpp has three instantiations (all loops unrolled / hidden layers only / run-time)
     and row guards for batches that are not a multiple of 16: self-consistency against the sequenced
