@@ -1,5 +1,6 @@
 // Host-side launch helpers shared by dqn.hip and mlp.hip.
 #pragma once
+#include <stdlib.h>
 #include "dqn_kernels.hpp"
 
 namespace pa {
@@ -92,7 +93,12 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
   int ks = 1;
   if (a.B >= 2048) {
     ks = a.B / 512;
-    const int fit = a.total_tiles > 0 ? 256 / a.total_tiles : 1;
+    static const int slots = []() {
+      const char* v = getenv("PEARL_AMD_DW_SLOTS");
+      const int n = v ? atoi(v) : 256;
+      return n > 0 ? n : 256;
+    }();
+    const int fit = a.total_tiles > 0 ? slots / a.total_tiles : 1;
     if (ks > fit) ks = fit;
     if (ks > 8) ks = 8;
     if (ks < 1) ks = 1;

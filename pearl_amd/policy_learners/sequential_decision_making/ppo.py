@@ -17,9 +17,11 @@ Mirror of pearl/policy_learners/sequential_decision_making/ppo.py:47-329.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 from torch import Tensor, nn
 
 from ... import _native as N
@@ -214,8 +216,13 @@ class ProximalPolicyOptimization(ActorCriticBase):
                                     self._f32(batch.lam_return, dev).data_ptr(), B, 2.0 / B, 1.0, 0,
                                     dv.data_ptr(), losses[1:].data_ptr(), s))
         FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True, defer=True)
-        actor.adam(reduce="sum")   # the surrogate is a SUM over the (global) minibatch
-        critic.adam()
+        if os.environ.get("PEARL_AMD_PPO_PAIR", "1") == "1" and not (
+                dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            # both networks' weight gradients + AdamW in one launch (same AdamW configuration only)
+            FlatMlp.adam_pair(actor, critic, None)
+        else:
+            actor.adam(reduce="sum")   # the surrogate is a SUM over the (global) minibatch
+            critic.adam()
         return {"actor_loss": losses[0], "critic_loss": losses[1]}
 
     # ------------------------------------------------------------------ learn (ppo.py:194-293)
