@@ -179,6 +179,11 @@ def main():
     # the W warm-up rounds, through the same loop the timed region uses, right before it
     if world > 1:
         barrier()      # ranks fill their arenas at different speeds: start the rounds together
+        # the same number of untimed rounds as the single-GPU run's calibration pass, so that every
+        # N starts its timed region from the same GPU state (clocks, RCCL channels)
+        calib_rounds = 300
+        pl._training_rounds = calib_rounds
+        agent.learn()
     if args.warmup > 0:
         pl._training_rounds = args.warmup
         agent.learn()
