@@ -64,8 +64,39 @@ struct SacRowsAArgs {
   SacTicket tk;
   int actor_rows;                        // 1: role 0 = actor update rows; 0: critic roles only
                                          // (TD3 on a step without an actor update)
+  // HEAD 0, split = 1: the second critic at (s, pi(s)) runs in a helper workgroup of the same launch
+  // (grid 4 x tiles: actor rows, helper, critic 1 rows, critic 2 rows).  The sampled action travels
+  // to the helper and (q2, gx2) travel back as data-tagged words (publish_y / consume_y, the
+  // DQN loop's hand-off): xact [tiles][16][16], xres [tiles][16][17], pre-filled with the tag and
+  // restored to it by the reader.
+  int split;
+  float* xact; float* xres;
+  int* err; int* err_host;
   long long* prof;
 };
+constexpr int SR_XACT = RP_ROWS * 16;
+constexpr int SR_XRES = RP_ROWS * 17;
+// consume_y with a short sleep (the partner is ~1 us away, not a stream away) + tag restore
+__device__ __forceinline__ float sr_take(float* p, int* err, int* err_host) {
+  unsigned* q = reinterpret_cast<unsigned*>(p);
+  unsigned bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (bits == kYPendingBits) {
+    const int limit = (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+                          ? 0 : (1 << 23);
+    int spins = 0;
+    while (bits == kYPendingBits && spins < limit) {
+      __builtin_amdgcn_s_sleep(2);
+      bits = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++spins;
+    }
+    if (bits == kYPendingBits) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (err_host) __hip_atomic_store(err_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __hip_atomic_store(q, kYPendingBits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __builtin_bit_cast(float, bits);
+}
 
 struct SacRowsBArgs {
   SacMlp3 actor, target[2];
@@ -488,7 +519,7 @@ __device__ __forceinline__ void sr_tile_partial(const float* rowsum, float* part
 // HEAD 0: tanh-Gaussian policy, twin-critic actor loss (continuous SAC).
 // HEAD 1: deterministic tanh policy, actor loss -mean Q1(s, pi(s)) (DDPG / TD3, ddpg.py:106-121):
 //         the head is [A] wide, no log-probability, one critic pass, d loss / d q = -1/B.
-template <int NGH, int NGA, int NGC, int HEAD>
+template <int NGH, int NGA, int NGC, int HEAD, bool SPLIT = false>
 __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
@@ -503,14 +534,64 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   float* qred = dhS + RP_ROWS * SR_DHP;            // [8][16]
   float* small = qred + 8 * RP_ROWS;               // [8][16]: q1 q2 logp lossrow
   float* cst = small + 8 * RP_ROWS;                // [3][SR_CST]: actor, critic 1, critic 2
-  const int m0 = blockIdx.x * RP_ROWS;
+  // roles: 0 actor update rows, 1 / 2 critic c at (s, a_batch), 3 (split) critic 2 at (s, pi(s))
+  constexpr bool split = HEAD == 0 && SPLIT;
+  int tile = (int)blockIdx.x, role = (int)blockIdx.y + (a.actor_rows ? 0 : 1);
+  int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  if (split) {
+    // the long roles first in dispatch order: actor rows, helper, then the two short ones
+    const int r4 = (int)blockIdx.x & 3;
+    tile = (int)blockIdx.x >> 2;
+    role = r4 == 0 ? 0 : (r4 == 1 ? 3 : r4 - 1);
+    wg = role * (int)(gridDim.x >> 2) + tile;
+  }
+  const int m0 = tile * RP_ROWS;
   const int64_t row = m0 + L.r16;
   const bool rok = row < a.B;
   WRing R, R1;
-  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   SR_STAMP(a.prof, wg, 0);
 
-  const int role = (int)blockIdx.y + (a.actor_rows ? 0 : 1);
+  if constexpr (split) {
+    if (role == 3) {
+      // ------------------------------------------------- helper: critic 2 at (s, the fresh action)
+      const SacMlp3& n = a.critic[1];
+      sr_l1_fill<NGC>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
+      sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
+      const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
+      const bool sok = L.tid < RP_ROWS * a.A;
+      {
+        SrTile xt;
+        SrConsts kc;
+        const bool fits = sr_tile_fits(P0);
+        if (fits) sr_tile_load(xt, a.state, a.ld_state, a.S, m0, a.B, P0, L.tid);
+        sr_consts_load(kc, n, true, L.tid);
+        if (fits) sr_tile_store(xt, xs, P0, L.tid);
+        else sr_stage(a.state, a.ld_state, a.S, m0, a.B, xs, P0, L.tid);
+        sr_consts_store(cst, kc, L.tid);
+      }
+      const int t_lo = a.S >> 4;
+      const int ntl = ((W + 15) >> 4) - t_lo;
+      SrNarrowW gw;
+      sr_narrow_load(gw, n.W1tf, wf16_nkg(n.H1), t_lo, ntl, L);
+      SR_STAMP(a.prof, wg, 1);
+      __syncthreads();   // the staged zeros of xs[:, S:] are down before the action lands on them
+      if (sok) xs[sr * P0 + a.S + sj] = sr_take(a.xact + (int64_t)tile * SR_XACT + sr * 16 + sj, a.err, a.err_host);
+      SR_STAMP(a.prof, wg, 3);
+      SrNext none;
+      none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
+      sr_critic<NGH, NGC, true, false>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                       a.prof, wg, 4);
+      __syncthreads();
+      if (L.tid < RP_ROWS)
+        publish_y(a.xres + (int64_t)tile * SR_XRES + L.tid * 17 + 16, sr_q(qred, L.tid, cst));
+      sr_narrow_mma(gw, wf16_nkg(n.H1), hC + L.r16 * PH + 4 * L.qd, red, L);
+      __syncthreads();
+      if (sok)
+        publish_y(a.xres + (int64_t)tile * SR_XRES + sr * 17 + sj, sr_narrow_get(red, sr, (a.S & 15) + sj));
+      SR_STAMP(a.prof, wg, 15);
+      return;
+    }
+  }
   if (role > 0) {
     // ---------------------------------------------------------------- critic c at (s, a_batch)
     const int c = role - 1;
@@ -565,7 +646,7 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   const float eps = HEAD == 0 ? ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok) : 0.f;
   const float lo = ld_or_zero(a.low, sj, sok), hi = ld_or_zero(a.high, sj, sok);
   const float alpha = HEAD == 0 ? a.alpha[0] : 0.f;
-  constexpr int NCRIT = HEAD == 0 ? 2 : 1;
+  constexpr int NCRIT = (HEAD == 0 && !split) ? 2 : 1;   // split: the helper runs critic 2
   {
     // every start-up request in flight before the first wait
     SrTile xt;
@@ -593,7 +674,10 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   G.t = G.sd = G.n = G.eps = G.bound = 0.f;
   float* terms = red;                       // [16][16]
   if constexpr (HEAD == 0) {
-    if (sok) terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
+    if (sok) {
+      terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
+      if (split) publish_y(a.xact + (int64_t)tile * SR_XACT + sr * 16 + sj, xs[sr * P0 + a.S + sj]);
+    }
     __syncthreads();
     if (L.tid < RP_ROWS) {
       float lp = 0.f;
@@ -635,6 +719,13 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     __syncthreads();
     if (sok) gx[c] = sr_narrow_get(red, sr, (a.S & 15) + sj);
     SR_STAMP(a.prof, wg, 7 + 4 * c);
+  }
+  if constexpr (split) {
+    if (L.tid < RP_ROWS)
+      small[RP_ROWS + L.tid] = sr_take(a.xres + (int64_t)tile * SR_XRES + L.tid * 17 + 16, a.err, a.err_host);
+    if (sok) gx[1] = sr_take(a.xres + (int64_t)tile * SR_XRES + sr * 17 + sj, a.err, a.err_host);
+    __syncthreads();
+    SR_STAMP(a.prof, wg, 11);
   }
   // ---- twin rule, loss, head gradient (twin_kernel mode 0, gauss_grad_kernel)
   if constexpr (HEAD == 1) {
@@ -689,7 +780,7 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   sr_mask_out(acc, m1a, nullptr, PH, L, n.dz1, row, n.H1, rok);
   SR_STAMP(a.prof, wg, 14);
   // ---- actor loss: this tile's partial
-  sr_tile_partial(small + 3 * RP_ROWS, a.tk.partials, blockIdx.x);
+  sr_tile_partial(small + 3 * RP_ROWS, a.tk.partials, tile);
   SR_STAMP(a.prof, wg, 15);
 }
 

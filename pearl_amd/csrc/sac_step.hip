@@ -162,6 +162,42 @@ int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
   return PA_OK;
 }
 
+// The split launch's exchange words (sac_rows.hpp, SacRowsAArgs::split): one buffer per process,
+// pre-filled with the pending tag; readers restore the tag, so a step leaves it as it found it.
+struct Exchange {
+  float* xact = nullptr;
+  float* xres = nullptr;
+  int* err = nullptr;
+  int* err_host = nullptr;
+  int cap = 0;
+} g_xch;
+int exchange(int tiles, hipStream_t s) {
+  if (!g_xch.err) {
+    PA_HIP(hipMalloc((void**)&g_xch.err, 16));
+    PA_HIP(hipMemset(g_xch.err, 0, 16));
+    PA_HIP(hipHostMalloc((void**)&g_xch.err_host, 16, hipHostMallocDefault));
+    g_xch.err_host[0] = 0;
+  }
+  if (tiles > g_xch.cap) {
+    if (g_xch.xact) {
+      PA_HIP(hipDeviceSynchronize());
+      (void)hipFree(g_xch.xact);
+      g_xch.xact = nullptr;
+    }
+    const int n = tiles * 2;
+    const size_t words = (size_t)n * (SR_XACT + SR_XRES);
+    PA_HIP(hipMalloc((void**)&g_xch.xact, words * sizeof(float)));
+    PA_HIP(hipMemsetD32Async((hipDeviceptr_t)g_xch.xact, (int)kYPendingBits, words, s));
+    g_xch.xres = g_xch.xact + (size_t)n * SR_XACT;
+    g_xch.cap = n;
+  }
+  return PA_OK;
+}
+bool split_enabled() {
+  const char* v = getenv("PEARL_AMD_SAC_SPLIT");     // read per call: tests compare the forms
+  return !(v && v[0] == '0');
+}
+
 template <int NGH, int NGA, int NGC, int HEAD = 0>
 int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s) {
   static size_t configured = 0;
@@ -175,6 +211,20 @@ int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream
   }
   if (ra) {
     const unsigned tiles = (unsigned)ceil_div(ra->B, RP_ROWS);
+    if constexpr (HEAD == 0) {
+      if (ra->split) {
+        static size_t configured_split = 0;
+        if (smem > configured_split) {
+          const int rc = set_max_smem(sac_rows_a_kernel<NGH, NGA, NGC, 0, true>, smem);
+          if (rc != PA_OK) return rc;
+          configured_split = smem;
+        }
+        hipLaunchKernelGGL((sac_rows_a_kernel<NGH, NGA, NGC, 0, true>), dim3(4 * tiles), dim3(512),
+                           smem, s, *ra);
+        PA_LAUNCH_CHECK();
+        return PA_OK;
+      }
+    }
     hipLaunchKernelGGL((sac_rows_a_kernel<NGH, NGA, NGC, HEAD>), dim3(tiles, ra->actor_rows ? 3 : 2),
                        dim3(512), smem, s, *ra);
   } else {
@@ -247,6 +297,16 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   ra.tk = ta;
   ra.actor_rows = 1;
   ra.prof = g_prof_a;
+  // the second critic of the actor loss in a helper workgroup, while every workgroup of the launch
+  // is resident at once (a waiting workgroup must never keep its partner off the chip)
+  if (split_enabled() && 4 * tiles <= 256 && A <= 16) {
+    PA_TRY(exchange(tiles, s));
+    PA_REQUIRE(g_xch.err_host[0] == 0, PA_ERR_HIP,
+               "an earlier SAC step's workgroup hand-off expired (code %d)", g_xch.err_host[0]);
+    ra.split = 1;
+    ra.xact = g_xch.xact; ra.xres = g_xch.xres;
+    ra.err = g_xch.err; ra.err_host = g_xch.err_host;
+  }
   // instantiations: every loop unrolled (hidden 256, S = 49..64, S + A = 65..80: the benchmark
   // shape), hidden layers unrolled only, all run-time
   const int form = ngh != 16 ? 0 : (wf16_nkg(S) == 4 && wf16_nkg(W) == 5 ? 2 : 1);

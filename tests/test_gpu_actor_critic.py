@@ -270,6 +270,39 @@ def test_sac_step_forms_agree(name, form, monkeypatch):
     torch.testing.assert_close(la, lb, rtol=0 if exact else 5e-5, atol=0 if exact else 3e-4)
 
 
+@pytest.mark.parametrize("name", ["tiny", "cfg3_shape_small", "cfg3_fullbatch"])
+def test_sac_split_actor_rows_are_bitwise_the_unsplit_ones(name, monkeypatch):
+    """sac_rows_a_kernel<…, SPLIT>: the actor loss's second critic runs in a helper workgroup of the
+    same launch; the action goes over and (q2, d q2 / d a) come back as tagged words.  Same
+    arithmetic in the same order, so every output is bit-identical to the unsplit launch — over
+    several steps, which also checks that the readers put the tags back."""
+    fx = load("sac", name)
+    outs = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("PEARL_AMD_SAC_ONE_CALL", "1")
+        monkeypatch.setenv("PEARL_AMD_SAC_FUSED", "1")
+        monkeypatch.setenv("PEARL_AMD_SAC_SPLIT", split)
+        pl = make_sac(fx)
+        reports = []
+        for rep in range(3):
+            for na, nc in fx["noises"]:
+                seq = iter([na, nc])
+                pl.noise_source = lambda B, A, dev: next(seq)
+                r = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+                reports.append({k: float(v) for k, v in r.items()})
+        torch.cuda.synchronize()
+        outs[split] = (reports, {f"{n}.{k}": v.detach().cpu().clone()
+                                 for n, m in (("actor", pl._actor), ("critic", pl._critic),
+                                              ("target", pl._critic_target))
+                                 for k, v in m.state_dict().items()},
+                       pl._entropy_coef.detach().cpu().clone())
+    (r0, p0, e0), (r1, p1, e1) = outs["0"], outs["1"]
+    assert r0 == r1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    assert torch.equal(e0, e1)
+
+
 @pytest.mark.parametrize("name", ["tiny", "cfg5_shape_small"])
 def test_neural_linear_bandit_learn_batch(name):
     """NeuralLinearBandit.learn_batch: weighted-MSE NN step + LinUCB A / b / inv(A) / coefs update

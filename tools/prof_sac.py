@@ -14,6 +14,10 @@ from host_bound import make_sac  # noqa: E402
 NAMES_A = {0: "start", 1: "staged", 2: "actor fwd (head in LDS)", 3: "sampled", 4: "c1 L1", 5: "c1 L2",
            6: "c1 G", 7: "c1 gx", 8: "c2 L1", 9: "c2 L2", 10: "c2 G", 11: "c2 gx", 12: "head grad",
            13: "dz2 (d head W3)", 14: "dz1", 15: "end"}
+NAMES_A_SPLIT = {0: "start", 1: "staged", 2: "actor fwd (head in LDS)", 3: "sampled + sent", 4: "c1 L1",
+                 5: "c1 L2", 6: "c1 G", 7: "c1 gx", 11: "q2, gx2 received", 12: "head grad",
+                 13: "dz2 (d head W3)", 14: "dz1", 15: "end"}
+NAMES_H = {0: "start", 1: "staged", 3: "action received", 4: "c2 L1", 5: "c2 L2", 6: "c2 G", 15: "sent, end"}
 NAMES_C = {0: "start", 1: "staged", 4: "L1", 5: "L2", 6: "G", 15: "end"}
 NAMES_B = {0: "start", 1: "staged", 2: "actor fwd", 3: "sampled", 4: "t1 L1", 5: "t1 L2", 8: "t2 L1",
            9: "t2 L2", 12: "y, dq", 13: "scaled", 15: "end"}
@@ -36,16 +40,20 @@ def main():
     learn = make_sac(8)
     learn()
     torch.cuda.synchronize()
-    pa = torch.zeros(3 * tiles * 8 * 32, dtype=torch.int64, device="cuda:0")
+    split = os.environ.get("PEARL_AMD_SAC_SPLIT", "1") != "0"
+    pa = torch.zeros(4 * tiles * 8 * 32, dtype=torch.int64, device="cuda:0")
     pb = torch.zeros(tiles * 8 * 32, dtype=torch.int64, device="cuda:0")
     N.check(N.lib().pa_debug_sac_prof(pa.data_ptr(), pb.data_ptr()))
     learn()
     torch.cuda.synchronize()
     N.check(N.lib().pa_debug_sac_prof(None, None))
-    a = pa.cpu().numpy().reshape(3, tiles, 8, 32)
+    a = pa.cpu().numpy().reshape(4, tiles, 8, 32)[: 4 if split else 3]
     b = pb.cpu().numpy().reshape(tiles, 8, 32)
-    table("sac_rows_a, actor rows", a[0], NAMES_A)
-    table("sac_rows_a, critic rows (both)", a[1:].reshape(2 * tiles, 8, 32), NAMES_C)
+    table("sac_rows_a, actor rows", a[0], NAMES_A_SPLIT if split else NAMES_A)
+    table("sac_rows_a, critic rows (both)", a[1:3].reshape(2 * tiles, 8, 32), NAMES_C)
+    if split:
+        # the helper's clock origin is the launch's, like every table here
+        table("sac_rows_a, helper rows (critic 2 at the fresh action)", a[3], NAMES_H)
     t0 = a[:, :, :, 0].min()
     print(f"whole launch: {(a[:, :, :, 15].max() - t0) / 100.0:.2f} us "
           f"(actor rows end {(a[0, :, :, 15].max() - t0) / 100.0:.2f}, critic rows end "
