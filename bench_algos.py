@@ -15,6 +15,7 @@ rows built after it run on the device and what they deliver.  The oracle is the 
 here, never the thing measured.
 """
 import argparse
+import gc
 import json
 import os
 import random
@@ -57,13 +58,24 @@ def step_roofline(flop_per_transition, transitions, seconds, kernel=None):
 
 
 def timed(fn, warm=1):
+    """Wall time of one fn() call.  Like `timeit`, without the cyclic garbage collector inside the
+    timed region: a generation-2 pass over a torch process's heap is ~80 ms — 800 SAC steps — and
+    lands wherever the allocation counter happens to trip (measured: always inside the second
+    learn() call of the SAC bench, tools/debug_loop.py)."""
     for _ in range(warm):
         fn()
     sync()
-    t0 = time.perf_counter()
-    out = fn()
-    sync()
-    return time.perf_counter() - t0, out
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        t0 = time.perf_counter()
+        out = fn()
+        sync()
+        return time.perf_counter() - t0, out
+    finally:
+        if was:
+            gc.enable()
 
 
 def bench_sac(steps, cpu_seconds):

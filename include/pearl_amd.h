@@ -493,6 +493,32 @@ typedef struct pa_ddpg_step_args {
 int64_t pa_ddpg_scratch_floats(int32_t B, int32_t S, int32_t A);
 int pa_ddpg_step(const pa_ddpg_step_args* args, void* stream);
 
+/* ------------------------------------------------------------------------ */
+/* PolicyLearner.learn (policy_learner.py:190-231) of the learners above as    */
+/* one call: training_rounds x (gather the round's presampled index list from  */
+/* the arena into one batch of workspace; the step).  `step0` describes round  */
+/* 0 and reads the workspace (state / action / reward / terminated /           */
+/* next_state pointers equal `batch`'s); per round the call advances the       */
+/* AdamW step numbers, the noise and the losses pointers.  Actions and rewards */
+/* in the arena must be float32.                                               */
+/* ------------------------------------------------------------------------ */
+typedef struct pa_ac_loop_args {
+  int32_t rounds;
+  const int64_t* idx_lists;      /* device [rounds][B] logical indices (pa_sample_indices_rounds) */
+  pa_batch_out batch;            /* device workspace of ONE batch, reused by every round */
+  const float* noise;            /* device [rounds][noise_stride]: SAC [2][B][A] standard normal
+                                    (actor update, Bellman target); TD3 [B][A] N(0, sigma^2); NULL: none */
+  int64_t noise_stride;
+  float* losses;                 /* device [rounds][losses_stride]; per round the step's `losses` */
+  int32_t losses_stride;
+  int32_t actor_update_freq;     /* TD3: actor step + target updates on rounds where               */
+  int64_t training_step0;        /* (training_step0 + r + 1) % actor_update_freq == 0; <= 1: all   */
+} pa_ac_loop_args;
+int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
+                 void* stream);
+int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
+                  void* stream);
+
 /* tuning aid (tools/prof_sac.py): in-kernel phase stamps of the two fused row kernels */
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
 /* HIP-event timing of the two fused row launches (first 64 steps after enabling): bench lines */

@@ -255,6 +255,21 @@ class DdpgStepArgs(C.Structure):
     ]
 
 
+class AcLoopArgs(C.Structure):
+    """pa_ac_loop_args (include/pearl_amd.h)."""
+    _fields_ = [
+        ("rounds", C.c_int32),
+        ("idx_lists", C.c_void_p),
+        ("batch", BatchOut),
+        ("noise", C.c_void_p),
+        ("noise_stride", C.c_int64),
+        ("losses", C.c_void_p),
+        ("losses_stride", C.c_int32),
+        ("actor_update_freq", C.c_int32),
+        ("training_step0", C.c_int64),
+    ]
+
+
 class LearnArgs(C.Structure):
     _fields_ = [
         ("rounds", C.c_int32),
@@ -394,6 +409,8 @@ SIGNATURES = {
     "pa_sac_step": (C.c_int, [C.POINTER(SacStepArgs), _P]),
     "pa_ddpg_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "pa_ddpg_step": (C.c_int, [C.POINTER(DdpgStepArgs), _P]),
+    "pa_sac_learn": (C.c_int, [C.POINTER(SacStepArgs), _P, C.POINTER(AcLoopArgs), _P]),
+    "pa_ddpg_learn": (C.c_int, [C.POINTER(DdpgStepArgs), _P, C.POINTER(AcLoopArgs), _P]),
     "pa_debug_sac_prof": (C.c_int, [_P, _P]),
     "pa_sac_timing": (C.c_int, [C.c_int32]),
     "pa_sac_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

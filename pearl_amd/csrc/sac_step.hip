@@ -734,3 +734,79 @@ extern "C" int pa_ddpg_step(const pa_ddpg_step_args* a, void* stream) {
   if (soft) PA_TRY(pa_mlp_soft_update(a->actor, a->actor_tau, stream));
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// PolicyLearner.learn() for the twin-critic continuous-control learners (policy_learner.py:190-231:
+// training_rounds x (sample, preprocess, learn_batch)) as ONE call: per round the arena's gather
+// of the presampled index list into one batch of workspace, then the step.  Nothing here that the
+// per-round calls do not do; what goes away is ~80 us of interpreter per round, which after the
+// fused row kernels was more than the device needs for the step.
+// ------------------------------------------------------------------------------------------------
+namespace {
+int loop_args_ok(const pa_ac_loop_args* lp, pa_arena* arena, int B) {
+  PA_REQUIRE(lp && arena, PA_ERR_INVALID, "null loop arguments");
+  PA_REQUIRE(lp->rounds >= 0 && lp->idx_lists && lp->losses && lp->losses_stride >= 2, PA_ERR_INVALID,
+             "bad loop arguments");
+  PA_REQUIRE(lp->batch.state && lp->batch.action && lp->batch.reward && lp->batch.terminated &&
+                 lp->batch.next_state,
+             PA_ERR_INVALID, "the loop's batch workspace needs state, action, reward, terminated, next_state");
+  PA_REQUIRE(B > 0, PA_ERR_INVALID, "bad batch size");
+  return PA_OK;
+}
+}  // namespace
+
+extern "C" int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* lp,
+                            void* stream) {
+  PA_REQUIRE(step0, PA_ERR_INVALID, "null step arguments");
+  PA_TRY(loop_args_ok(lp, arena, step0->B));
+  PA_REQUIRE(lp->noise && lp->noise_stride >= 2ll * step0->B * step0->A, PA_ERR_INVALID,
+             "pa_sac_learn: noise is [rounds][2][B][A]");
+  PA_REQUIRE(step0->state == lp->batch.state && step0->next_state == lp->batch.next_state &&
+                 (const void*)step0->action == lp->batch.action &&
+                 (const void*)step0->reward == lp->batch.reward &&
+                 step0->terminated == lp->batch.terminated,
+             PA_ERR_INVALID, "pa_sac_learn: the step reads the loop's batch workspace");
+  pa_sac_step_args a = *step0;
+  const int64_t BA = (int64_t)a.B * a.A;
+  for (int r = 0; r < lp->rounds; ++r) {
+    PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * a.B, a.B, &lp->batch, stream));
+    a.noise_actor = lp->noise + (int64_t)r * lp->noise_stride;
+    a.noise_critic = a.noise_actor + BA;
+    a.actor_step = step0->actor_step + r;
+    a.critic_step = step0->critic_step + r;
+    a.alpha_step = step0->alpha_step + r;
+    a.losses = lp->losses + (int64_t)r * lp->losses_stride;
+    PA_TRY(pa_sac_step(&a, stream));
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena,
+                             const pa_ac_loop_args* lp, void* stream) {
+  PA_REQUIRE(step0, PA_ERR_INVALID, "null step arguments");
+  PA_TRY(loop_args_ok(lp, arena, step0->B));
+  PA_REQUIRE(!lp->noise || lp->noise_stride >= (int64_t)step0->B * step0->A, PA_ERR_INVALID,
+             "pa_ddpg_learn: noise is [rounds][B][A]");
+  PA_REQUIRE(step0->state == lp->batch.state && step0->next_state == lp->batch.next_state &&
+                 (const void*)step0->action == lp->batch.action &&
+                 (const void*)step0->reward == lp->batch.reward &&
+                 step0->terminated == lp->batch.terminated,
+             PA_ERR_INVALID, "pa_ddpg_learn: the step reads the loop's batch workspace");
+  pa_ddpg_step_args a = *step0;
+  int64_t actor_steps = 0;
+  const int freq = lp->actor_update_freq > 1 ? lp->actor_update_freq : 1;
+  for (int r = 0; r < lp->rounds; ++r) {
+    PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * a.B, a.B, &lp->batch, stream));
+    // TD3 (td3.py:106-141): the actor step and both target updates on every freq-th training step
+    const bool due = ((lp->training_step0 + r + 1) % freq) == 0;
+    a.do_actor = due;
+    a.do_targets = due;
+    a.target_noise = lp->noise ? lp->noise + (int64_t)r * lp->noise_stride : nullptr;
+    a.actor_step = step0->actor_step + actor_steps;
+    a.critic_step = step0->critic_step + r;
+    a.losses = lp->losses + (int64_t)r * lp->losses_stride;
+    PA_TRY(pa_ddpg_step(&a, stream));
+    if (due) ++actor_steps;
+  }
+  return PA_OK;
+}

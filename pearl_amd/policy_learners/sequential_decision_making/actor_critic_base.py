@@ -13,12 +13,14 @@ parameters (``FlatMlp``); nothing in the step is a torch op.
 from __future__ import annotations
 
 import copy
+import os
 from abc import abstractmethod
 from typing import Any, Dict, List, Optional
 
 import torch
 from torch import nn, optim
 
+from ... import _native as N
 from ...action_representation_modules import ActionRepresentationModule
 from ...neural_networks.common.utils import xavier_init_weights
 from ...neural_networks.common.value_networks import VanillaValueNetwork
@@ -176,6 +178,9 @@ class ActorCriticBase(PolicyLearner):
             for m in self._flat.values():      # validated on the first step, trusted until the end
                 if isinstance(m, FlatMlp):
                     m._loop_validated = False
+            native = self._learn_native_loop(replay_buffer, batch_size)
+            if native is not None:
+                return native
             FlatMlp.in_learn_loop = True
             self._begin_learn_loop(self._training_rounds, batch_size)
             for _ in range(self._training_rounds):
@@ -217,6 +222,72 @@ class ActorCriticBase(PolicyLearner):
         if safety is not None and hasattr(safety, "lambda_constraint"):
             batch.reward = batch.reward - safety.lambda_constraint * batch.cost
         return super().preprocess_batch(batch)
+
+    def _learn_native_loop(self, replay_buffer: ReplayBuffer, batch_size: int
+                           ) -> Optional[Dict[str, List[Any]]]:
+        """Hook: the whole learn() call — every round's gather and step — sequenced by the library
+        (pa_sac_learn / pa_ddpg_learn); None: this call takes the per-round loop below."""
+        return None
+
+    def _arena_loop_plan(self, replay_buffer: ReplayBuffer, batch_size: int, dev: torch.device,
+                         S: int, A: int) -> Optional[Dict[str, Any]]:
+        """What the native loops need from the replay buffer — its arena, the presampled index
+        lists of this call, one batch of workspace — or None when a round of this call is not
+        exactly `sample -> the library's own preprocess_batch -> learn_batch` on float32 rows."""
+        from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
+        from ..policy_learner import IdentityHistorySummarizationModule
+        if os.environ.get("PEARL_AMD_AC_LOOP", "1") == "0":
+            return None
+        rb = replay_buffer
+        if not isinstance(rb, TensorBasedReplayBuffer) or rb.arena is None \
+                or type(rb).sample is not TensorBasedReplayBuffer.sample \
+                or type(rb)._gather_batch is not TensorBasedReplayBuffer._gather_batch:
+            return None
+        pre = rb._presampled
+        rounds = int(self._training_rounds)
+        if pre is None or pre[1] != 0 or tuple(pre[0].shape) != (rounds, batch_size) or rounds <= 0:
+            return None
+        z, arena = rb._layout, rb.arena
+        if arena.device != dev or rb._device_for_batches != dev:
+            return None
+        if not (z.has_next_state and not z.has_cost and len(z.state_shape) <= 1 and z.state_dim == S
+                and z.action_dtype == torch.float32 and z.action_elems == A
+                and z.reward_dtype == torch.float32 and rb._is_action_continuous):
+            return None
+        if type(self).preprocess_batch is not ActorCriticBase.preprocess_batch \
+                or type(self)._preprocess_for_learn is not ActorCriticBase._preprocess_for_learn \
+                or type(self._history_summarization_module) is not IdentityHistorySummarizationModule \
+                or type(self.action_representation_module).__name__ != "IdentityActionRepresentationModule":
+            return None
+        if hasattr(getattr(self, "safety_module", None), "lambda_constraint"):
+            return None
+        ws = self._flat.get("loop_ws")
+        key = (dev, batch_size, S, A)
+        if ws is None or ws["key"] != key:
+            def new(shape, dtype=torch.float32):
+                return torch.empty(shape, dtype=dtype, device=dev)
+            ws = {"key": key, "state": new((batch_size, S)), "action": new((batch_size, A)),
+                  "reward": new((batch_size,)), "term": new((batch_size,), torch.uint8),
+                  "trunc": new((batch_size,), torch.uint8), "next": new((batch_size, S))}
+            self._flat["loop_ws"] = ws
+        out = N.BatchOut()
+        out.state, out.action, out.reward = ws["state"].data_ptr(), ws["action"].data_ptr(), ws["reward"].data_ptr()
+        out.terminated, out.truncated = ws["term"].data_ptr(), ws["trunc"].data_ptr()
+        out.next_state = ws["next"].data_ptr()
+        return {"arena": arena, "lists": pre[0], "rounds": rounds, "ws": ws, "out": out}
+
+    def _loop_losses(self, rounds: int, width: int) -> torch.Tensor:
+        """[rounds, width] zeros in pinned, device-mapped host memory: the step kernels store each
+        round's losses straight into it (a few bytes per round over PCIe, fire-and-forget), so the
+        end of a native loop is one stream synchronisation and no device-to-host copy (the same
+        arrangement as DeepQLearning.learn's loss buffer)."""
+        buf = self._flat.get("loss_host")
+        if buf is None or buf.numel() < rounds * width:
+            buf = torch.zeros(max(2 * rounds * width, 4096), dtype=torch.float32, pin_memory=True)
+            self._flat["loss_host"] = buf
+        out = buf[:rounds * width].view(rounds, width)
+        out.zero_()
+        return out
 
     def _begin_learn_loop(self, rounds: int, batch_size: int) -> None:
         """Hook: per-call preparation a learner can amortise over the rounds of one learn()."""

@@ -161,6 +161,40 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
                 and cls._policy_input is base._policy_input
                 and self._use_critic and self._use_critic_target and self._use_actor_target)
 
+    def _one_call_ws(self, dev: torch.device, B: int, S: int, A: int) -> Dict[str, Any]:
+        ws = self._flat.get("one_call")
+        if ws is None or ws["key"] != (dev, B, S, A):
+            n = int(N.lib().pa_ddpg_scratch_floats(B, S, A))
+            ws = {"key": (dev, B, S, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
+                  "zeros": torch.zeros(max(B, 1), dtype=torch.float32, device=dev),
+                  "args": N.DdpgStepArgs()}
+            self._flat["one_call"] = ws
+        return ws
+
+    def _step_args(self, ws: Dict[str, Any], actor: FlatMlp, c1: FlatMlp, c2: FlatMlp,
+                   state: Tensor, act: Tensor, reward: Tensor, term: Tensor, nstate: Tensor,
+                   losses: Tensor, clip: float) -> "N.DdpgStepArgs":
+        """pa_ddpg_step_args of the next step on these batch tensors (noise pointer and the
+        do_actor / do_targets switches left to the caller)."""
+        dev = actor.device
+        B, S = state.shape
+        A = actor.dims[-1]
+        low, high = self._bounds(dev)
+        a = ws["args"]
+        a.actor, a.critic1, a.critic2 = actor.handle, c1.handle, c2.handle
+        a.state, a.ld_state = state.data_ptr(), state.stride(0)
+        a.action, a.ld_action = act.data_ptr(), act.stride(0)
+        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
+        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a.noise_clip = float(clip)
+        a.low, a.high, a.zeros = low.data_ptr(), high.data_ptr(), ws["zeros"].data_ptr()
+        a.B, a.S, a.A = B, S, A
+        a.gamma = float(self._discount_factor)
+        a.critic_tau, a.actor_tau = float(self._critic_soft_update_tau), float(self._actor_soft_update_tau)
+        a.actor_step, a.critic_step = actor._steps + 1, c1._steps + 1
+        a.scratch, a.losses = ws["scratch"].data_ptr(), losses.data_ptr()
+        return a
+
     def _learn_one_call(self, batch: TransitionBatch, do_actor: bool, do_targets: bool):
         actor, c1, c2 = self._nets(len(batch))
         dev = actor.device
@@ -173,38 +207,89 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         term = batch.terminated.to(dev).reshape(B)
         term = (term.view(torch.uint8) if term.dtype == torch.bool else term.to(torch.uint8)).contiguous()
         noise, clip = self._target_noise(B, A, dev)
-        ws = self._flat.get("one_call")
-        if ws is None or ws["key"] != (dev, B, S, A):
-            n = int(N.lib().pa_ddpg_scratch_floats(B, S, A))
-            ws = {"key": (dev, B, S, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
-                  "zeros": torch.zeros(max(B, 1), dtype=torch.float32, device=dev),
-                  "args": N.DdpgStepArgs()}
-            self._flat["one_call"] = ws
-        low, high = self._bounds(dev)
+        ws = self._one_call_ws(dev, B, S, A)
         losses = torch.empty(2, dtype=torch.float32, device=dev)
-        a = ws["args"]
-        a.actor, a.critic1, a.critic2 = actor.handle, c1.handle, c2.handle
-        a.state, a.ld_state = state.data_ptr(), state.stride(0)
-        a.action, a.ld_action = act.data_ptr(), act.stride(0)
-        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
-        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a = self._step_args(ws, actor, c1, c2, state, act, reward, term, nstate, losses, clip)
         if noise is not None:
             noise = noise.to(dev, torch.float32).contiguous()
             assert noise.shape == (B, A)
-        a.target_noise, a.noise_clip = N.ptr(noise), float(clip)
-        a.low, a.high, a.zeros = low.data_ptr(), high.data_ptr(), ws["zeros"].data_ptr()
-        a.B, a.S, a.A = B, S, A
-        a.gamma = float(self._discount_factor)
+        a.target_noise = N.ptr(noise)
         a.do_actor, a.do_targets = int(do_actor), int(do_targets)
-        a.critic_tau, a.actor_tau = float(self._critic_soft_update_tau), float(self._actor_soft_update_tau)
-        a.actor_step, a.critic_step = actor._steps + 1, c1._steps + 1
-        a.scratch, a.losses = ws["scratch"].data_ptr(), losses.data_ptr()
         N.check(N.lib().pa_ddpg_step(C.byref(a), N.stream_ptr(dev)))
         if do_actor:
             actor.stepped_natively()
         c1.stepped_natively()
         c2.stepped_natively()
         return (losses[0] if do_actor else None), losses[1]
+
+    # ------------------------------------------------------------------ learn() as one call
+    _NOISE_CHUNK = 1 << 26       # floats of target-smoothing noise drawn at once (256 MB)
+    _actor_update_freq = 1       # (TD3 sets its own)
+
+    def _loop_noise(self, rounds: int, B: int, A: int, dev: torch.device):
+        """(noise [rounds, B, A] or None, clip) for `rounds` steps of the native loop; False when
+        this learner's noise cannot be drawn ahead (a parity `noise_source`, an overridden
+        `_target_noise`)."""
+        if type(self)._target_noise is not DeepDeterministicPolicyGradient._target_noise:
+            return False
+        return None, 0.0
+
+    def _native_loop_is_mine(self) -> bool:
+        cls, base = type(self), DeepDeterministicPolicyGradient
+        return (cls._learn_batch_device is base._learn_batch_device
+                and cls._learn_one_call is base._learn_one_call
+                and cls.learn_batch is ActorCriticBase.learn_batch)
+
+    def _learn_native_loop(self, replay_buffer: Any, batch_size: int) -> Optional[Dict[str, List[Any]]]:
+        """learn() as pa_ddpg_learn calls: every round's gather + step sequenced in C — the rounds
+        the per-round loop would run (same index lists, same kernels, TD3's delayed actor by the
+        same rule); the smoothing noise is drawn for many rounds at once."""
+        if not self._one_call_ok() or not self._native_loop_is_mine():
+            return None
+        actor, c1, c2 = self._nets(batch_size)
+        dev = actor.device
+        B, S, A = int(batch_size), actor.dims[0], actor.dims[-1]
+        if self._loop_noise(0, B, A, dev) is False:
+            return None
+        plan = self._arena_loop_plan(replay_buffer, B, dev, S, A)
+        if plan is None:
+            return None
+        rounds, w = plan["rounds"], plan["ws"]
+        ws = self._one_call_ws(dev, B, S, A)
+        losses = self._loop_losses(rounds, 2)
+        freq = max(int(self._actor_update_freq), 1)
+        lp = N.AcLoopArgs()
+        lp.batch = plan["out"]
+        lp.losses_stride, lp.noise_stride = 2, B * A
+        lp.actor_update_freq = freq
+        chunk = max(1, self._NOISE_CHUNK // (B * A))
+        step0 = int(self._training_steps)
+        done = 0
+        while done < rounds:
+            n = min(chunk, rounds - done)
+            noise, clip = self._loop_noise(n, B, A, dev)
+            a = self._step_args(ws, actor, c1, c2, w["state"], w["action"], w["reward"], w["term"],
+                                w["next"], losses, clip)
+            lp.rounds = n
+            lp.idx_lists = plan["lists"][done].data_ptr()
+            lp.noise, lp.losses = N.ptr(noise), losses[done].data_ptr()
+            lp.training_step0 = step0 + done
+            N.check(N.lib().pa_ddpg_learn(C.byref(a), plan["arena"].handle, C.byref(lp),
+                                          N.stream_ptr(dev)))
+            actor.stepped_natively(sum(1 for r in range(n) if (step0 + done + r + 1) % freq == 0))
+            c1.stepped_natively(n)
+            c2.stepped_natively(n)
+            done += n
+        self._training_steps += rounds
+        replay_buffer._presampled = (plan["lists"], rounds, len(replay_buffer))   # all consumed
+        replay_buffer._last_idx = plan["lists"][rounds - 1]
+        torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        got = [losses[:, k].tolist() for k in range(2)]     # per key: one list of floats
+        return self._loop_report(got, step0, freq)
+
+    def _loop_report(self, got: List[List[float]], step0: int, freq: int) -> Dict[str, List[Any]]:
+        """got: [actor losses, critic losses] of the rounds."""
+        return {"actor_loss": got[0], "critic_loss": got[1]}
 
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
         if self._one_call_ok():

@@ -386,9 +386,12 @@ class FlatMlp:
         m2.adam()
         return False
 
-    def stepped_natively(self) -> None:
-        """Bookkeeping after an AdamW step the library sequenced itself (pa_sac_step)."""
-        step = self._steps + 1
+    def stepped_natively(self, n: int = 1) -> None:
+        """Bookkeeping after ``n`` AdamW steps the library sequenced itself (pa_sac_step,
+        pa_sac_learn)."""
+        if n <= 0:
+            return
+        step = self._steps + n
         self._pending_x = None
         self._set_adam_steps(step)
         self._steps = step

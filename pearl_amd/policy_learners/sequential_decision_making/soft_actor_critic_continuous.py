@@ -261,10 +261,54 @@ class ContinuousSoftActorCritic(ActorCriticBase):
                 and cls._update_critic_target is base._update_critic_target
                 and self._use_critic and self._use_critic_target and not self._use_actor_target)
 
+    def _step_args(self, ws: Dict[str, Any], actor: FlatMlp, c1: FlatMlp, c2: FlatMlp,
+                   state: Tensor, act: Tensor, reward: Tensor, term: Tensor, nstate: Tensor,
+                   losses: Tensor, logp: Tensor) -> "N.SacStepArgs":
+        """pa_sac_step_args of the next step on these batch tensors (noise pointers left to the
+        caller); advances the entropy optimizer's step count by one."""
+        dev = actor.device
+        al = self._alpha_state(dev)
+        B, S = state.shape
+        A = actor.dims[-1] // 2
+        low, high = self._bounds(dev)
+        a = ws["args"]
+        a.actor, a.critic1, a.critic2 = actor.handle, c1.handle, c2.handle
+        a.state, a.ld_state = state.data_ptr(), state.stride(0)
+        a.action, a.ld_action = act.data_ptr(), act.stride(0)
+        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
+        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a.low, a.high = low.data_ptr(), high.data_ptr()
+        a.alpha = al["alpha"].data_ptr()
+        if self._entropy_autotune:
+            g = self._entropy_optimizer.param_groups[0]
+            al["step"] += 1
+            a.log_alpha = self._log_entropy.data.data_ptr()
+            a.alpha_m, a.alpha_v = al["exp_avg"].data_ptr(), al["exp_avg_sq"].data_ptr()
+            a.alpha_vmax = al["max_exp_avg_sq"].data_ptr()
+            a.target_entropy = self._target_entropy_value()
+            a.alpha_lr, a.alpha_beta1, a.alpha_beta2 = g["lr"], g["betas"][0], g["betas"][1]
+            a.alpha_eps, a.alpha_weight_decay = g["eps"], g["weight_decay"]
+            a.alpha_amsgrad, a.alpha_step = int(bool(g["amsgrad"])), al["step"]
+        else:
+            a.log_alpha = None
+        a.B, a.S, a.A = B, S, A
+        a.gamma, a.tau = float(self._discount_factor), float(self._critic_soft_update_tau)
+        a.actor_step, a.critic_step = actor._steps + 1, c1._steps + 1
+        a.scratch, a.losses, a.log_prob_out = ws["scratch"].data_ptr(), losses.data_ptr(), logp.data_ptr()
+        return a
+
+    def _one_call_ws(self, dev: torch.device, B: int, S: int, A: int) -> Dict[str, Any]:
+        ws = self._flat.get("one_call")
+        if ws is None or ws["key"] != (dev, B, S, A):
+            n = int(N.lib().pa_sac_scratch_floats(B, S, A))
+            ws = {"key": (dev, B, S, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
+                  "args": N.SacStepArgs()}
+            self._flat["one_call"] = ws
+        return ws
+
     def _learn_batch_one_call(self, batch: TransitionBatch) -> Dict[str, Any]:
         actor, c1, c2 = self._nets(len(batch))
         dev = actor.device
-        al = self._alpha_state(dev)
         state = self._f32(batch.state, dev)
         nstate = self._f32(batch.next_state, dev)
         B, S = state.shape
@@ -284,48 +328,76 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             noise_a, noise_c = noise[0], noise[1]
         else:   # parity: the reference draws the actor update's noise first, then the target's
             noise_a, noise_c = self._noise(B, A, dev), self._noise(B, A, dev)
-        ws = self._flat.get("one_call")
-        if ws is None or ws["key"] != (dev, B, S, A):
-            n = int(N.lib().pa_sac_scratch_floats(B, S, A))
-            ws = {"key": (dev, B, S, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
-                  "args": N.SacStepArgs()}
-            self._flat["one_call"] = ws
-        low, high = self._bounds(dev)
+        ws = self._one_call_ws(dev, B, S, A)
         logp = torch.empty(B, dtype=torch.float32, device=dev)
         losses = torch.empty(3, dtype=torch.float32, device=dev)
-        a = ws["args"]
-        a.actor, a.critic1, a.critic2 = actor.handle, c1.handle, c2.handle
-        a.state, a.ld_state = state.data_ptr(), state.stride(0)
-        a.action, a.ld_action = act.data_ptr(), act.stride(0)
-        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
-        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a = self._step_args(ws, actor, c1, c2, state, act, reward, term, nstate, losses, logp)
         a.noise_actor, a.noise_critic = noise_a.data_ptr(), noise_c.data_ptr()
-        a.low, a.high = low.data_ptr(), high.data_ptr()
-        a.alpha = al["alpha"].data_ptr()
-        if self._entropy_autotune:
-            g = self._entropy_optimizer.param_groups[0]
-            al["step"] += 1
-            a.log_alpha = self._log_entropy.data.data_ptr()
-            a.alpha_m, a.alpha_v = al["exp_avg"].data_ptr(), al["exp_avg_sq"].data_ptr()
-            a.alpha_vmax = al["max_exp_avg_sq"].data_ptr()
-            a.target_entropy = self._target_entropy_value()
-            a.alpha_lr, a.alpha_beta1, a.alpha_beta2 = g["lr"], g["betas"][0], g["betas"][1]
-            a.alpha_eps, a.alpha_weight_decay = g["eps"], g["weight_decay"]
-            a.alpha_amsgrad, a.alpha_step = int(bool(g["amsgrad"])), al["step"]
-        else:
-            a.log_alpha = None
-        a.B, a.S, a.A = B, S, A
-        a.gamma, a.tau = float(self._discount_factor), float(self._critic_soft_update_tau)
-        a.actor_step, a.critic_step = actor._steps + 1, c1._steps + 1
-        a.scratch, a.losses, a.log_prob_out = ws["scratch"].data_ptr(), losses.data_ptr(), logp.data_ptr()
         N.check(N.lib().pa_sac_step(C.byref(a), N.stream_ptr(dev)))
         for m in (actor, c1, c2):
             m.stepped_natively()
         self._action_batch_log_prob_cache = logp
         report = {"actor_loss": losses[0], "critic_loss": losses[1]}
         if self._entropy_autotune:
-            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(float(al["step"]))
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(
+                float(self._alpha_state(dev)["step"]))
             report["entropy_coef"] = losses[2]
+        return report
+
+    _NOISE_CHUNK = 1 << 26       # floats of reparameterisation noise drawn at once (256 MB)
+
+    def _learn_native_loop(self, replay_buffer: Any, batch_size: int) -> Optional[Dict[str, List[Any]]]:
+        """learn() as pa_sac_learn calls: every round's gather + step sequenced in C (the
+        interpreter's ~80 us per round is more than the device needs for the step).  The rounds
+        are the ones the per-round loop would run — same index lists, same kernels; the noise is
+        drawn for many rounds at once, as `_begin_learn_loop` already does."""
+        cls, base = type(self), ContinuousSoftActorCritic
+        if self.noise_source is not None or not self._one_call_ok() \
+                or cls._learn_batch_device is not base._learn_batch_device \
+                or cls._learn_batch_one_call is not base._learn_batch_one_call \
+                or cls.learn_batch is not ActorCriticBase.learn_batch:
+            return None
+        actor, c1, c2 = self._nets(batch_size)
+        dev = actor.device
+        B, S, A = int(batch_size), actor.dims[0], actor.dims[-1] // 2
+        plan = self._arena_loop_plan(replay_buffer, B, dev, S, A)
+        if plan is None:
+            return None
+        rounds, w = plan["rounds"], plan["ws"]
+        ws = self._one_call_ws(dev, B, S, A)
+        losses = self._loop_losses(rounds, 3)
+        logp = torch.empty(B, dtype=torch.float32, device=dev)
+        lp = N.AcLoopArgs()
+        lp.batch = plan["out"]
+        lp.losses_stride, lp.noise_stride = 3, 2 * B * A
+        chunk = max(1, self._NOISE_CHUNK // (2 * B * A))
+        done = 0
+        while done < rounds:
+            n = min(chunk, rounds - done)
+            noise = torch.randn(n, 2, B, A, device=dev, dtype=torch.float32)
+            a = self._step_args(ws, actor, c1, c2, w["state"], w["action"], w["reward"], w["term"],
+                                w["next"], losses, logp)
+            lp.rounds = n
+            lp.idx_lists = plan["lists"][done].data_ptr()
+            lp.noise, lp.losses = noise.data_ptr(), losses[done].data_ptr()
+            N.check(N.lib().pa_sac_learn(C.byref(a), plan["arena"].handle, C.byref(lp),
+                                         N.stream_ptr(dev)))
+            for m in (actor, c1, c2):
+                m.stepped_natively(n)
+            if self._entropy_autotune:
+                self._alpha_state(dev)["step"] += n - 1      # (_step_args counted the first)
+            done += n
+        self._training_steps += rounds
+        replay_buffer._presampled = (plan["lists"], rounds, len(replay_buffer))   # all consumed
+        replay_buffer._last_idx = plan["lists"][rounds - 1]
+        self._action_batch_log_prob_cache = logp
+        torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        got = [losses[:, k].tolist() for k in range(3)]     # per key: one list of floats
+        report: Dict[str, List[Any]] = {"actor_loss": got[0], "critic_loss": got[1]}
+        if self._entropy_autotune:
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(
+                float(self._alpha_state(dev)["step"]))
+            report["entropy_coef"] = got[2]
         return report
 
     def _begin_learn_loop(self, rounds: int, batch_size: int) -> None:

@@ -38,9 +38,30 @@ class TD3(DeepDeterministicPolicyGradient):
         if self.noise_source is not None:
             noise = self.noise_source(B, A, dev).to(dev, torch.float32).contiguous()
         else:
-            noise = torch.normal(mean=0.0, std=float(self._actor_update_noise), size=(B, A),
-                                 device=dev)
+            ring = self._flat.get("noise_ring")
+            if ring is not None and ring["next"] < ring["buf"].shape[0] and \
+                    ring["buf"].shape[1:] == (B, A) and ring["buf"].device == dev:
+                noise = ring["buf"][ring["next"]]     # drawn for the whole learn() call at once
+                ring["next"] += 1
+            else:
+                noise = torch.normal(mean=0.0, std=float(self._actor_update_noise), size=(B, A),
+                                     device=dev)
         return noise, float(self._actor_update_noise_clip)
+
+    def _begin_learn_loop(self, rounds: int, batch_size: int) -> None:
+        """The smoothing noise of every round of this learn() call in ONE generator launch."""
+        self._flat.pop("noise_ring", None)
+        actor = self._flat.get("actor")
+        if self.noise_source is None and rounds > 1 and actor is not None and actor.handle is not None \
+                and type(self)._target_noise is TD3._target_noise:
+            A = actor.dims[-1]
+            if rounds * batch_size * A <= self._NOISE_CHUNK:
+                self._flat["noise_ring"] = {"next": 0, "buf": torch.normal(
+                    mean=0.0, std=float(self._actor_update_noise), size=(rounds, batch_size, A),
+                    device=actor.device)}
+
+    def _end_learn_loop(self) -> None:
+        self._flat.pop("noise_ring", None)
 
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
         due = self._training_steps % self._actor_update_freq == 0
@@ -62,6 +83,33 @@ class TD3(DeepDeterministicPolicyGradient):
             self._update_critic_target()
             self._update_actor_target()
         return report
+
+    # ------------------------------------------------------------------ learn() as one call (ddpg.py)
+    def _native_loop_is_mine(self) -> bool:
+        cls = type(self)
+        return (cls._learn_batch_device is TD3._learn_batch_device
+                and cls._learn_one_call is DeepDeterministicPolicyGradient._learn_one_call
+                and cls.learn_batch is TD3.learn_batch)
+
+    def _loop_noise(self, rounds: int, B: int, A: int, dev: torch.device):
+        if self.noise_source is not None or type(self)._target_noise is not TD3._target_noise:
+            return False
+        if rounds <= 0:
+            return None, float(self._actor_update_noise_clip)
+        return (torch.normal(mean=0.0, std=float(self._actor_update_noise), size=(rounds, B, A),
+                             device=dev), float(self._actor_update_noise_clip))
+
+    def _loop_report(self, got, step0: int, freq: int) -> Dict[str, Any]:
+        # the report repeats the last actor loss on the rounds without an actor step (td3.py:106-141)
+        last = self._last_actor_loss
+        last = float(last) if isinstance(last, torch.Tensor) else last
+        actor_losses = []
+        for r, g in enumerate(got[0]):
+            if (step0 + r + 1) % freq == 0:
+                last = g
+            actor_losses.append(last)
+        self._last_actor_loss = last
+        return {"actor_loss": actor_losses, "critic_loss": got[1]}
 
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         report = super().learn_batch(batch)

@@ -791,3 +791,101 @@ def test_squarecb_kernel_and_bandit_act_scores():
     assert int(pl.act(b["state"].to(DEV), sp)) == b["action"]
     torch.testing.assert_close(pl.get_scores(b["state"].to(DEV), sp).cpu(), b["scores"], rtol=1e-5,
                                atol=1e-6)
+
+
+def _continuous_setup(kind, rounds, B=64, S=12, A=3, n=5000, hidden=(32, 32)):
+    import random
+    from pearl_amd import (TD3, BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic,
+                           DeepDeterministicPolicyGradient, PearlAgent)
+    torch.manual_seed(5)
+    random.seed(5)
+    space = BoxActionSpace(-torch.ones(A), 2 * torch.ones(A))
+    kw = dict(action_space=space, state_dim=S, actor_hidden_dims=list(hidden),
+              critic_hidden_dims=list(hidden), batch_size=B, training_rounds=rounds)
+    pl = {"sac": ContinuousSoftActorCritic, "ddpg": DeepDeterministicPolicyGradient, "td3": TD3}[kind](**kw)
+    rb = BasicReplayBuffer(n, sampler="device")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    st = torch.randn(n + 1, S, device=DEV)
+    ids = torch.arange(n, device=DEV)
+    rb.push_many(state=st[:-1], action=torch.rand(n, A, device=DEV) * 3 - 1, reward=(ids % 7).float(),
+                 terminated=(ids % 11 == 0), truncated=torch.zeros(n, dtype=torch.bool, device=DEV),
+                 next_state=st[1:])
+    return pl, rb
+
+
+def _learner_state(pl):
+    out = {k: v.detach().cpu().clone() for k, v in pl.state_dict().items()
+           if isinstance(v, torch.Tensor)}
+    for name in ("_actor_optimizer", "_critic_optimizer", "_entropy_optimizer"):
+        opt = getattr(pl, name, None)
+        if opt is None:
+            continue
+        for i, st in enumerate(opt.state_dict()["state"].values()):
+            for k, v in st.items():
+                out[f"{name}.{i}.{k}"] = torch.as_tensor(v).detach().cpu().clone()
+    return out
+
+
+@pytest.mark.parametrize("kind,shape", [("sac", dict()), ("td3", dict()), ("ddpg", dict()),
+                                        ("sac", dict(B=1024, S=64, A=8, n=20000, hidden=(256, 256))),
+                                        ("td3", dict(B=1024, S=64, A=8, n=20000, hidden=(256, 256)))])
+def test_native_learn_loop_is_the_per_round_loop(kind, shape, monkeypatch):
+    """pa_sac_learn / pa_ddpg_learn sequence learn()'s rounds — gather of the presampled list, then
+    the step — in C.  Same index lists (Python's `random` seeds the Philox key), same noise (one
+    generator call for the whole learn() in both forms), same kernels: two consecutive learn()
+    calls leave bit-identical reports, parameters, targets and optimizer state; TD3's delayed
+    actor follows `_training_steps` across the calls."""
+    import random
+    got = {}
+    for loop in ("0", "1"):
+        monkeypatch.setenv("PEARL_AMD_AC_LOOP", loop)
+        pl, rb = _continuous_setup(kind, rounds=7, **shape)
+        torch.manual_seed(11)
+        random.seed(11)
+        reports = [pl.learn(rb), pl.learn(rb)]
+        torch.cuda.synchronize()
+        got[loop] = (reports, _learner_state(pl), pl._training_steps,
+                     rb.last_indices.cpu().clone())
+    (r0, s0, t0, i0), (r1, s1, t1, i1) = got["0"], got["1"]
+    assert t0 == t1 == 14
+    assert r0 == r1, (r0, r1)
+    assert all(len(v) == 7 for rep in r1 for v in rep.values())
+    assert s0.keys() == s1.keys()
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+    assert torch.equal(i0, i1)
+
+
+def test_native_learn_loop_steps_aside(monkeypatch):
+    """learn() takes the per-round loop whenever a round is not exactly the library's own
+    sample -> preprocess_batch -> learn_batch: a subclass that overrides a hook, a parity noise
+    source, a buffer that hands batches to the CPU."""
+    from pearl_amd import ContinuousSoftActorCritic
+    calls = []
+    real = ContinuousSoftActorCritic._arena_loop_plan
+
+    def spy(self, *a, **k):
+        plan = real(self, *a, **k)
+        calls.append(plan is not None)
+        return plan
+
+    monkeypatch.setattr(ContinuousSoftActorCritic, "_arena_loop_plan", spy)
+    pl, rb = _continuous_setup("sac", rounds=3)
+    pl.learn(rb)
+    assert calls == [True]
+    # an overridden preprocess_batch: the per-round loop must call it
+    seen = []
+
+    class Mine(ContinuousSoftActorCritic):
+        def preprocess_batch(self, batch):
+            seen.append(len(batch))
+            return super().preprocess_batch(batch)
+
+    pl.__class__ = Mine
+    pl.learn(rb)
+    assert seen == [64, 64, 64] and calls == [True, False]
+    pl.__class__ = ContinuousSoftActorCritic
+    pl.noise_source = lambda B, A, dev: torch.zeros(B, A, device=dev)
+    n0 = len(calls)
+    rep = pl.learn(rb)
+    assert len(calls) == n0 and len(rep["actor_loss"]) == 3      # not even planned

@@ -39,7 +39,7 @@ def main(path, needle="target_fused", n=60):
               f"{(rows[-1][2] - rows[k0][1]) / 1000:.1f} us first start -> last end")
         show(rows[k0:], rows[k0][1])
         return
-    k0 = len(rows) // 2
+    k0 = len(rows) // 4
     for i in range(k0, len(rows)):
         if needle in rows[i][0]:
             k0 = i
