@@ -112,6 +112,10 @@ struct SacRowsBArgs {
   float* dq[2];                          // [B]
   int B, S, A;
   SacTicket tk;
+  // SPLIT instantiation: the second target critic runs in a helper workgroup (grid 2 x tiles); the
+  // next action goes over and q2' comes back through the exchange words of SacRowsAArgs
+  float* xact; float* xres;
+  int* err; int* err_host;
   long long* prof;
 };
 
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
 
 // HEAD 1: `actor` is the TARGET policy, the next action is its tanh-scaled output plus the clamped
 // smoothing noise (td3.py:151-175; none for DDPG), and y = min(q1', q2') gamma (1 - term) + r.
-template <int NGH, int NGA, int NGC, int HEAD>
+template <int NGH, int NGA, int NGC, int HEAD, bool SPLIT = false>
 __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
@@ -801,17 +805,49 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   float* qred = headS + RP_ROWS * SR_DHP;
   float* small = qred + 8 * RP_ROWS;
   float* cst = small + 8 * RP_ROWS;
-  const int m0 = blockIdx.x * RP_ROWS;
+  const int tile = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+  const int m0 = tile * RP_ROWS;
   const int64_t row = m0 + L.r16;
   const bool rok = row < a.B;
   WRing R, R1;
-  const int wg = blockIdx.x;
+  const int wg = SPLIT ? ((int)blockIdx.x & 1) * (int)(gridDim.x >> 1) + tile : (int)blockIdx.x;
   SR_STAMP(a.prof, wg, 0);
+  const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
+  const bool sok = L.tid < RP_ROWS * a.A;
+  if constexpr (SPLIT) {
+    if (blockIdx.x & 1) {
+      // ------------------------------------------------- helper: target critic 2 at (s', a')
+      const SacMlp3& q = a.target[1];
+      sr_l1_fill<NGC>(R1, q.W1f, L.tile0, (q.H1 + 15) >> 4, L.lane);
+      sr_prefetch<NGH>(R, q.W2f, L.tile0, (q.H2 + 15) >> 4, L.lane);
+      {
+        SrTile xt;
+        SrConsts kc;
+        const bool fits = sr_tile_fits(P0);
+        if (fits) sr_tile_load(xt, a.next_state, a.ld_next, a.S, m0, a.B, P0, L.tid);
+        sr_consts_load(kc, q, true, L.tid);
+        if (fits) sr_tile_store(xt, xs, P0, L.tid);
+        else sr_stage(a.next_state, a.ld_next, a.S, m0, a.B, xs, P0, L.tid);
+        sr_consts_store(cst, kc, L.tid);
+      }
+      SR_STAMP(a.prof, wg, 1);
+      __syncthreads();   // the staged zeros of xs[:, S:] are down before the action lands on them
+      if (sok) xs[sr * P0 + a.S + sj] = sr_take(a.xact + (int64_t)tile * SR_XACT + sr * 16 + sj, a.err, a.err_host);
+      SR_STAMP(a.prof, wg, 3);
+      SrNext none;
+      none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
+      sr_critic<NGH, NGC, false, false>(q, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                        a.prof, wg, 8);
+      __syncthreads();
+      if (L.tid < RP_ROWS)
+        publish_y(a.xres + (int64_t)tile * SR_XRES + L.tid * 17 + 16, sr_q(qred, L.tid, cst));
+      SR_STAMP(a.prof, wg, 15);
+      return;
+    }
+  }
   const SacMlp3& n = a.actor;
   sr_l1_fill<NGA>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
   sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
-  const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
-  const bool sok = L.tid < RP_ROWS * a.A;
   const bool srok = sok && (m0 + sr) < a.B;
   const float eps = ld_or_zero(a.noise, (int64_t)(m0 + sr) * a.ld_noise + sj, srok && a.noise != nullptr);
   const float lo = ld_or_zero(a.low, sj, sok), hi = ld_or_zero(a.high, sj, sok);
@@ -823,12 +859,12 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
     if (fits) sr_tile_load(xt, a.next_state, a.ld_next, a.S, m0, a.B, P0, L.tid);
     sr_consts_load(k0, n, false, L.tid);
     sr_consts_load(k1, a.target[0], true, L.tid);
-    sr_consts_load(k2, a.target[1], true, L.tid);
+    if (!SPLIT) sr_consts_load(k2, a.target[1], true, L.tid);
     if (fits) sr_tile_store(xt, xs, P0, L.tid);
     else sr_stage(a.next_state, a.ld_next, a.S, m0, a.B, xs, P0, L.tid);
     sr_consts_store(cst, k0, L.tid);
     sr_consts_store(cst + SR_CST, k1, L.tid);
-    sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
+    if (!SPLIT) sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
   }
   // this tile's Bellman-error inputs
   float qa = 0.f, qb = 0.f, rew = 0.f, live = 0.f;
@@ -846,7 +882,10 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   if constexpr (HEAD == 0) {
     SrGauss G;
     float* terms = red;
-    if (sok) terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
+    if (sok) {
+      terms[sr * 16 + sj] = sr_sample(headS, sr, sj, a.A, eps, lo, hi, xs, P0, a.S, G);
+      if (SPLIT) publish_y(a.xact + (int64_t)tile * SR_XACT + sr * 16 + sj, xs[sr * P0 + a.S + sj]);
+    }
     __syncthreads();
     if (L.tid < RP_ROWS) {
       float lp = 0.f;
@@ -865,6 +904,7 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
         act = fminf(fmaxf(act + nz, lo), hi);
       }
       xs[sr * P0 + a.S + sj] = act;
+      if (SPLIT) publish_y(a.xact + (int64_t)tile * SR_XACT + sr * 16 + sj, act);
     }
     if (L.tid < RP_ROWS) small[2 * RP_ROWS + L.tid] = 0.f;
   }
@@ -873,14 +913,16 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   constexpr int SCALE_IT = 2;     // 16 rows x 256 / 4 floats = 1024 float4 per array
   float4 pre[2][2][SCALE_IT];
   const bool pre_ok = (a.H1c == 256) && (a.H2c == 256);
+  constexpr int NT = SPLIT ? 1 : 2;      // target critics run here (SPLIT: the helper runs the second)
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
+  for (int c = 0; c < NT; ++c) {
     SrNext nx;
-    nx.W1 = c == 0 ? a.target[1].W1f : nullptr; nx.nt1 = (a.target[1].H1 + 15) >> 4;
-    nx.Wh = c == 0 ? a.target[1].W2f : nullptr; nx.nth = (a.target[1].H2 + 15) >> 4;
+    const bool more = c + 1 < NT;
+    nx.W1 = more ? a.target[1].W1f : nullptr; nx.nt1 = (a.target[1].H1 + 15) >> 4;
+    nx.Wh = more ? a.target[1].W2f : nullptr; nx.nth = (a.target[1].H2 + 15) >> 4;
     sr_critic<NGH, NGC, false, false>(a.target[c], cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R,
                                       R1, L, row, rok, nx, a.prof, wg, 4 + 4 * c);
-    if (c == 1 && pre_ok) {
+    if (c == NT - 1 && pre_ok) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -895,6 +937,12 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
     }
     __syncthreads();
     if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, cst + (1 + c) * SR_CST);
+  }
+  if constexpr (SPLIT) {
+    // (read below by the thread that writes it here)
+    if (L.tid < RP_ROWS)
+      small[RP_ROWS + L.tid] = sr_take(a.xres + (int64_t)tile * SR_XRES + L.tid * 17 + 16, a.err, a.err_host);
+    SR_STAMP(a.prof, wg, 11);
   }
   // ---- y, the Bellman errors, the critic loss rows (twin_kernel mode 1, mse_head_kernel)
   if (L.tid < RP_ROWS) {
@@ -958,7 +1006,7 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   }
   SR_STAMP(a.prof, wg, 13);
   // ---- critic loss: this tile's partial
-  sr_tile_partial(small + 5 * RP_ROWS, a.tk.partials, blockIdx.x);
+  sr_tile_partial(small + 5 * RP_ROWS, a.tk.partials, tile);
   SR_STAMP(a.prof, wg, 15);
 }
 

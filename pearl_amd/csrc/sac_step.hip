@@ -229,7 +229,18 @@ int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream
                        dim3(512), smem, s, *ra);
   } else {
     const unsigned tiles = (unsigned)ceil_div(rb->B, RP_ROWS);
-    hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD>), dim3(tiles), dim3(512), smem, s, *rb);
+    if (rb->xact) {
+      static size_t configured_split_b = 0;
+      if (smem > configured_split_b) {
+        const int rc = set_max_smem(sac_rows_b_kernel<NGH, NGA, NGC, HEAD, true>, smem);
+        if (rc != PA_OK) return rc;
+        configured_split_b = smem;
+      }
+      hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD, true>), dim3(2 * tiles), dim3(512),
+                         smem, s, *rb);
+    } else {
+      hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD>), dim3(tiles), dim3(512), smem, s, *rb);
+    }
   }
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -341,6 +352,10 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   rb.B = B; rb.S = S; rb.A = A;
   rb.tk = tb;
   rb.prof = g_prof_b;
+  if (ra.split) {
+    rb.xact = g_xch.xact; rb.xres = g_xch.xres;
+    rb.err = g_xch.err; rb.err_host = g_xch.err_host;
+  }
   if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][2], s));
   PA_TRY((form == 2   ? launch_rows<16, 4, 5>(nullptr, &rb, W, s)
           : form == 1 ? launch_rows<16, 0, 0>(nullptr, &rb, W, s)
@@ -635,6 +650,14 @@ int ddpg_fused_step(const pa_ddpg_step_args* a, hipStream_t s) {
   rb.dq[0] = w.dq1; rb.dq[1] = w.dq2;
   rb.B = B; rb.S = S; rb.A = A;
   rb.tk = tb;
+  // the second target critic in a helper workgroup (every workgroup of the launch resident at once)
+  if (split_enabled() && 2 * tiles <= 256 && A <= 16) {
+    PA_TRY(exchange(tiles, s));
+    PA_REQUIRE(g_xch.err_host[0] == 0, PA_ERR_HIP,
+               "an earlier step's workgroup hand-off expired (code %d)", g_xch.err_host[0]);
+    rb.xact = g_xch.xact; rb.xres = g_xch.xres;
+    rb.err = g_xch.err; rb.err_host = g_xch.err_host;
+  }
   PA_TRY((form == 2   ? launch_rows_ddpg<16, 4, 5>(nullptr, &rb, W, s)
           : form == 1 ? launch_rows_ddpg<16, 0, 0>(nullptr, &rb, W, s)
                       : launch_rows_ddpg<0, 0, 0>(nullptr, &rb, W, s)));

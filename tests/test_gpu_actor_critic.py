@@ -597,6 +597,44 @@ def test_ddpg_td3_fused_rows_agree_with_sequenced(td3, S, A, hidden, B, monkeypa
         assert_adam_trajectory_close(pb[k], pa_[k], 1e-3, len(noises), max_outlier_frac=5e-3, msg=k)
 
 
+@pytest.mark.parametrize("S,A,hidden,B", [(64, 8, [256, 256], 1024), (17, 6, [256, 256], 100),
+                                          (10, 3, [32, 48], 50)])
+def test_td3_split_target_rows_are_bitwise_the_unsplit_ones(S, A, hidden, B, monkeypatch):
+    """sac_rows_b_kernel<…, SPLIT> with the deterministic head: the second target critic in a helper
+    workgroup (next action over, q2' back as tagged words) — bit-identical to the unsplit launch
+    over several steps (the readers put the tags back)."""
+    from pearl_amd import TD3, BasicReplayBuffer, BoxActionSpace, PearlAgent, TransitionBatch
+    g = torch.Generator().manual_seed(S * 19 + A)
+    batch = dict(state=torch.randn(B, S, generator=g), action=torch.rand(B, A, generator=g) * 3 - 1,
+                 reward=torch.randn(B, generator=g), terminated=torch.rand(B, generator=g) < 0.2,
+                 next_state=torch.randn(B, S, generator=g))
+    noises = [0.2 * torch.randn(B, A, generator=g) for _ in range(6)]
+    outs = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("PEARL_AMD_DDPG_ONE_CALL", "1")
+        monkeypatch.setenv("PEARL_AMD_DDPG_FUSED", "1")
+        monkeypatch.setenv("PEARL_AMD_SAC_SPLIT", split)
+        torch.manual_seed(11)
+        pl = TD3(action_space=BoxActionSpace(-torch.ones(A), 2 * torch.ones(A)), state_dim=S,
+                 actor_hidden_dims=hidden, critic_hidden_dims=hidden, batch_size=B)
+        PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+        reports = []
+        for step, nz in enumerate(noises):
+            pl.noise_source = lambda B_, A_, dev, n=nz: n
+            pl._training_steps = step
+            tb = TransitionBatch(**{k: v.to(DEV) for k, v in batch.items()})
+            reports.append({k: float(v) for k, v in pl.learn_batch(pl.preprocess_batch(tb)).items()})
+        torch.cuda.synchronize()
+        outs[split] = (reports, {f"{n}.{k}": v.detach().cpu().clone()
+                                 for n, m in (("actor", pl._actor), ("actor_target", pl._actor_target),
+                                              ("critic", pl._critic), ("critic_target", pl._critic_target))
+                                 for k, v in m.state_dict().items()})
+    (r0, p0), (r1, p1) = outs["0"], outs["1"]
+    assert r0 == r1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+
+
 def test_td3_learn_from_replay_defers_readback_and_delays_actor():
     """TD3.learn() through a device-sampled arena: finite losses, the actor loss only changes on
     rounds where the actor stepped, and the actor target only moves on those rounds."""

@@ -19,6 +19,9 @@ NAMES_A_SPLIT = {0: "start", 1: "staged", 2: "actor fwd (head in LDS)", 3: "samp
                  13: "dz2 (d head W3)", 14: "dz1", 15: "end"}
 NAMES_H = {0: "start", 1: "staged", 3: "action received", 4: "c2 L1", 5: "c2 L2", 6: "c2 G", 15: "sent, end"}
 NAMES_C = {0: "start", 1: "staged", 4: "L1", 5: "L2", 6: "G", 15: "end"}
+NAMES_B_SPLIT = {0: "start", 1: "staged", 2: "actor fwd", 3: "sampled + sent", 4: "t1 L1", 5: "t1 L2",
+                 11: "q2' received", 12: "y, dq", 13: "scaled", 15: "end"}
+NAMES_BH = {0: "start", 1: "staged", 3: "action received", 8: "t2 L1", 9: "t2 L2", 15: "sent, end"}
 NAMES_B = {0: "start", 1: "staged", 2: "actor fwd", 3: "sampled", 4: "t1 L1", 5: "t1 L2", 8: "t2 L1",
            9: "t2 L2", 12: "y, dq", 13: "scaled", 15: "end"}
 
@@ -42,13 +45,14 @@ def main():
     torch.cuda.synchronize()
     split = os.environ.get("PEARL_AMD_SAC_SPLIT", "1") != "0"
     pa = torch.zeros(4 * tiles * 8 * 32, dtype=torch.int64, device="cuda:0")
-    pb = torch.zeros(tiles * 8 * 32, dtype=torch.int64, device="cuda:0")
+    pb = torch.zeros(2 * tiles * 8 * 32, dtype=torch.int64, device="cuda:0")
     N.check(N.lib().pa_debug_sac_prof(pa.data_ptr(), pb.data_ptr()))
     learn()
     torch.cuda.synchronize()
     N.check(N.lib().pa_debug_sac_prof(None, None))
     a = pa.cpu().numpy().reshape(4, tiles, 8, 32)[: 4 if split else 3]
-    b = pb.cpu().numpy().reshape(tiles, 8, 32)
+    b2 = pb.cpu().numpy().reshape(2, tiles, 8, 32)
+    b = b2[0]
     table("sac_rows_a, actor rows", a[0], NAMES_A_SPLIT if split else NAMES_A)
     table("sac_rows_a, critic rows (both)", a[1:3].reshape(2 * tiles, 8, 32), NAMES_C)
     if split:
@@ -58,7 +62,9 @@ def main():
     print(f"whole launch: {(a[:, :, :, 15].max() - t0) / 100.0:.2f} us "
           f"(actor rows end {(a[0, :, :, 15].max() - t0) / 100.0:.2f}, critic rows end "
           f"{(a[1:, :, :, 15].max() - t0) / 100.0:.2f})")
-    table("sac_rows_b", b, NAMES_B)
+    table("sac_rows_b", b, NAMES_B_SPLIT if split else NAMES_B)
+    if split:
+        table("sac_rows_b, helper rows (target critic 2)", b2[1], NAMES_BH)
 
 
 if __name__ == "__main__":
