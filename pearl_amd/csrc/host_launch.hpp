@@ -91,8 +91,18 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
   // (72 tiles x 4 slices = 288 left 32 CUs with two workgroups each and everyone waiting for them:
   // 33.7 us per PPO network at B = 4096 against 14.5 us for the same tiles at B = 1024)
   int ks = 1;
-  if (a.B >= 2048) {
-    ks = a.B / 512;
+  static const int min_b = []() {
+    const char* v = getenv("PEARL_AMD_DW_MINB");
+    const int n = v ? atoi(v) : 2048;
+    return n > 0 ? n : 2048;
+  }();
+  static const int slice_rows = []() {
+    const char* v = getenv("PEARL_AMD_DW_SLICE");
+    const int n = v ? atoi(v) : 512;
+    return n >= 64 ? n : 512;
+  }();
+  if (a.B >= min_b) {
+    ks = a.B / slice_rows;
     static const int slots = []() {
       const char* v = getenv("PEARL_AMD_DW_SLOTS");
       const int n = v ? atoi(v) : 256;
