@@ -536,6 +536,13 @@ int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* action_rep,
                       const float* p_old, const float* gae, int32_t B, int32_t A, float epsilon,
                       float entropy_scale, float* d_logits, int32_t ldd, float* loss_out,
                       void* stream);
+/* The actor head above and the critic's MSE head of the same minibatch (ppo.py:152-192,
+ * critic_utils.py:139-168) in one launch; losses[0] = actor loss, losses[1] = critic loss;
+ * d_value = (2 / B)(value - value_target).  Same values as pa_ppo_actor_loss + pa_mse_head. */
+int pa_ppo_heads(const float* logits, int32_t ldl, const float* action_rep, int32_t lda,
+                 const float* p_old, const float* gae, int32_t B, int32_t A, float epsilon,
+                 float entropy_scale, float* d_logits, int32_t ldd, const float* value, int32_t ldv,
+                 const float* value_target, float* d_value, float* losses, void* stream);
 /* nn.MSELoss head (critic_utils.py:139-203): d_pred = grad_scale * (pred - target);
  * loss_out (=|+=) mean((pred - target)^2) * loss_scale. */
 int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B, float grad_scale,

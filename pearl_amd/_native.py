@@ -398,6 +398,8 @@ SIGNATURES = {
     "pa_softmax_action_prob": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "pa_ppo_actor_loss": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32,
                                     C.c_float, C.c_float, _P, C.c_int32, _P, _P]),
+    "pa_ppo_heads": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32,
+                               C.c_float, C.c_float, _P, C.c_int32, _P, C.c_int32, _P, _P, _P, _P]),
     "pa_mse_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_float, C.c_float, C.c_int32, _P, _P, _P]),
     "pa_ppo_gae": (C.c_int, [_P, _P, _P, _P, _P, C.c_float, C.c_float, C.c_int64, _P, _P, _P]),
     "pa_gauss_sample": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P,

@@ -884,7 +884,34 @@ __global__ __launch_bounds__(256) void action_prob_kernel(const float* __restric
 // needs their batch sum first).  One workgroup per 256 rows writes its partial sums and its rows'
 // probabilities; the last workgroup to arrive (ticket) adds the partials in block order and forms
 // the entropy term — deterministic, and 4096 rows no longer run on one CU (307 us -> ~10 us).
+// MSELoss(mean) head: loss = mean((pred - target)^2) * scale_loss, d_pred = grad_scale * (pred - target)
+struct MseArgs {
+  const float* pred; int ldp;
+  const float* target;
+  int B;
+  float grad_scale;   // 2 / B (single critic) or 1 / B (each of the twin critics: (mse1 + mse2) / 2)
+  float* d_pred;
+  float* loss_out;    // += or = mean squared error * loss_scale
+  float loss_scale;
+  int accumulate;
+};
+__device__ __forceinline__ void mse_head_body(const MseArgs& a, float* red) {
+  float part = 0.f;
+  for (int b = threadIdx.x; b < a.B; b += 256) {
+    const float d = __fsub_rn(a.pred[(int64_t)b * a.ldp], a.target[b]);
+    part += d * d;
+    if (a.d_pred) a.d_pred[b] = __fmul_rn(a.grad_scale, d);
+  }
+  const float s = block_sum_256(part, red);
+  if (threadIdx.x == 0 && a.loss_out) {
+    const float v = (s / (float)a.B) * a.loss_scale;
+    a.loss_out[0] = a.accumulate ? a.loss_out[0] + v : v;
+  }
+}
+
 struct PpoActorArgs {
+  MseArgs critic;       // has_critic: the value head of the same minibatch rides the launch as one
+  int has_critic;       // extra workgroup (the LAST block; pa_ppo_heads)
   const float* logits; int ldl;
   const float* arep; int lda;
   const float* p_old; const float* gae;
@@ -906,6 +933,11 @@ struct PpoActorArgs {
 __global__ __launch_bounds__(256) void ppo_actor_elem_kernel(PpoActorArgs a) {
   __shared__ float va[256], vb[256], red[256];
   __shared__ unsigned last;
+  const unsigned nact = gridDim.x - (a.has_critic ? 1u : 0u);   // blocks of the actor head
+  if (blockIdx.x == nact) {
+    mse_head_body(a.critic, red);
+    return;
+  }
   const float lo = 1.0f - a.eps, hi = 1.0f + a.eps;
   const int rpw = 256 / a.A;
   const int r = threadIdx.x / a.A, j = threadIdx.x - r * a.A;
@@ -957,13 +989,13 @@ __global__ __launch_bounds__(256) void ppo_actor_elem_kernel(PpoActorArgs a) {
     a.partials[2 * blockIdx.x] = bl;
     a.partials[2 * blockIdx.x + 1] = bp;
     __threadfence();
-    last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    last = (atomicAdd(a.ticket, 1u) == nact - 1) ? 1u : 0u;
   }
   __syncthreads();
   if (!last) return;
   __threadfence();  // the other blocks' partials and p_rows are visible from here on
   float pl = 0.f, pp = 0.f;
-  for (unsigned k = threadIdx.x; k < gridDim.x; k += 256) {   // fixed order: strided, then the tree
+  for (unsigned k = threadIdx.x; k < nact; k += 256) {   // fixed order: strided, then the tree
     pl += __builtin_nontemporal_load(a.partials + 2 * k);
     pp += __builtin_nontemporal_load(a.partials + 2 * k + 1);
   }
@@ -1102,30 +1134,9 @@ __global__ __launch_bounds__(256) void ppo_actor_kernel(PpoActorArgs a) {
   }
 }
 
-// MSELoss(mean) head: loss = mean((pred - target)^2) * scale_loss, d_pred = grad_scale * (pred - target)
-struct MseArgs {
-  const float* pred; int ldp;
-  const float* target;
-  int B;
-  float grad_scale;   // 2 / B (single critic) or 1 / B (each of the twin critics: (mse1 + mse2) / 2)
-  float* d_pred;
-  float* loss_out;    // += or = mean squared error * loss_scale
-  float loss_scale;
-  int accumulate;
-};
 __global__ __launch_bounds__(256) void mse_head_kernel(MseArgs a) {
   __shared__ float red[256];
-  float part = 0.f;
-  for (int b = threadIdx.x; b < a.B; b += 256) {
-    const float d = __fsub_rn(a.pred[(int64_t)b * a.ldp], a.target[b]);
-    part += d * d;
-    if (a.d_pred) a.d_pred[b] = __fmul_rn(a.grad_scale, d);
-  }
-  const float s = block_sum_256(part, red);
-  if (threadIdx.x == 0 && a.loss_out) {
-    const float v = (s / (float)a.B) * a.loss_scale;
-    a.loss_out[0] = a.accumulate ? a.loss_out[0] + v : v;
-  }
+  mse_head_body(a, red);
 }
 
 // GAE / truncated lambda return (ppo.py:271-293).  The reference walks the rollout from the newest
@@ -2229,13 +2240,43 @@ extern "C" int pa_softmax_action_prob(const float* logits, int32_t ldl, const fl
   return PA_OK;
 }
 
+namespace {
+int ppo_actor_launch(const float* logits, int32_t ldl, const float* action_rep, int32_t lda,
+                     const float* p_old, const float* gae, int32_t B, int32_t A, float epsilon,
+                     float entropy_scale, float* d_logits, int32_t ldd, float* loss_out,
+                     const MseArgs* critic, void* stream);
+}
 extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* action_rep,
                                  int32_t lda, const float* p_old, const float* gae, int32_t B,
                                  int32_t A, float epsilon, float entropy_scale, float* d_logits,
                                  int32_t ldd, float* loss_out, void* stream) {
+  return ppo_actor_launch(logits, ldl, action_rep, lda, p_old, gae, B, A, epsilon, entropy_scale,
+                          d_logits, ldd, loss_out, nullptr, stream);
+}
+// The actor head and the critic's MSE head of one PPO minibatch (ppo.py:152-192) in ONE launch:
+// the value head (a single workgroup: serial sum in fixed order) runs beside the actor head's
+// blocks instead of after them.  Same values as pa_ppo_actor_loss + pa_mse_head(…, 2 / B, 1, 0, …).
+extern "C" int pa_ppo_heads(const float* logits, int32_t ldl, const float* action_rep, int32_t lda,
+                            const float* p_old, const float* gae, int32_t B, int32_t A,
+                            float epsilon, float entropy_scale, float* d_logits, int32_t ldd,
+                            const float* value, int32_t ldv, const float* value_target,
+                            float* d_value, float* losses, void* stream) {
+  PA_REQUIRE(value && value_target && d_value && losses, PA_ERR_INVALID, "pa_ppo_heads: bad argument");
+  MseArgs m;
+  m.pred = value; m.ldp = ldv; m.target = value_target; m.B = B; m.grad_scale = 2.0f / (float)B;
+  m.d_pred = d_value; m.loss_out = losses + 1; m.loss_scale = 1.0f; m.accumulate = 0;
+  return ppo_actor_launch(logits, ldl, action_rep, lda, p_old, gae, B, A, epsilon, entropy_scale,
+                          d_logits, ldd, losses, &m, stream);
+}
+namespace {
+int ppo_actor_launch(const float* logits, int32_t ldl, const float* action_rep, int32_t lda,
+                     const float* p_old, const float* gae, int32_t B, int32_t A, float epsilon,
+                     float entropy_scale, float* d_logits, int32_t ldd, float* loss_out,
+                     const MseArgs* critic, void* stream) {
   PA_REQUIRE(logits && action_rep && p_old && gae && d_logits && loss_out && B > 0 && A > 0,
              PA_ERR_INVALID, "pa_ppo_actor_loss: bad argument");
   PpoActorArgs a;
+  memset(&a, 0, sizeof(a));
   a.logits = logits; a.ldl = ldl; a.arep = action_rep; a.lda = lda; a.p_old = p_old; a.gae = gae;
   a.B = B; a.A = A; a.eps = epsilon; a.ent_scale = entropy_scale;
   a.d_logits = d_logits; a.ldd = ldd; a.loss_out = loss_out;
@@ -2260,10 +2301,19 @@ extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* 
   a.partials = scratch + 4;
   a.p_rows = scratch + 4 + 2 * grid;
   const size_t lds = (size_t)2 * 256 * (A + 1) * sizeof(float);
-  if (elem)
-    hipLaunchKernelGGL(ppo_actor_elem_kernel, dim3(grid), dim3(256), 0,
+  if (critic && !elem) {   // wide action sets: the row-per-thread kernels, then the value head
+    hipLaunchKernelGGL(mse_head_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       *critic);
+    PA_LAUNCH_CHECK();
+  }
+  if (elem) {
+    if (critic) {
+      a.critic = *critic;
+      a.has_critic = 1;
+    }
+    hipLaunchKernelGGL(ppo_actor_elem_kernel, dim3(grid + (critic ? 1u : 0u)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
-  else if (lds <= 48 * 1024)
+  } else if (lds <= 48 * 1024)
     hipLaunchKernelGGL(ppo_actor_kernel<true>, dim3(grid), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), a);
   else
@@ -2272,6 +2322,7 @@ extern "C" int pa_ppo_actor_loss(const float* logits, int32_t ldl, const float* 
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
+}  // namespace
 
 extern "C" int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B,
                            float grad_scale, float loss_scale, int32_t accumulate, float* d_pred,

@@ -207,14 +207,13 @@ class ProximalPolicyOptimization(ActorCriticBase):
         d_logits = torch.empty_like(logits)
         dv = torch.empty(B, dtype=torch.float32, device=dev)
         losses = torch.empty(2, dtype=torch.float32, device=dev)
-        N.check(N.lib().pa_ppo_actor_loss(
+        # both heads in one launch: the value head's single workgroup runs beside the actor head
+        N.check(N.lib().pa_ppo_heads(
             logits.data_ptr(), logits.stride(0), arep.data_ptr(), arep.stride(0),
             self._f32(batch.action_probs, dev).data_ptr(), self._f32(batch.gae, dev).data_ptr(),
             B, A, float(self._epsilon), float(self._entropy_bonus_scaling), d_logits.data_ptr(),
-            d_logits.stride(0), losses.data_ptr(), s))
-        N.check(N.lib().pa_mse_head(v.data_ptr(), v.stride(0),
-                                    self._f32(batch.lam_return, dev).data_ptr(), B, 2.0 / B, 1.0, 0,
-                                    dv.data_ptr(), losses[1:].data_ptr(), s))
+            d_logits.stride(0), v.data_ptr(), v.stride(0),
+            self._f32(batch.lam_return, dev).data_ptr(), dv.data_ptr(), losses.data_ptr(), s))
         FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True, defer=True)
         if os.environ.get("PEARL_AMD_PPO_PAIR", "1") == "1" and not (
                 dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):

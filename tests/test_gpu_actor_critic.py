@@ -927,3 +927,43 @@ def test_native_learn_loop_steps_aside(monkeypatch):
     n0 = len(calls)
     rep = pl.learn(rb)
     assert len(calls) == n0 and len(rep["actor_loss"]) == 3      # not even planned
+
+
+@pytest.mark.parametrize("B,A", [(4096, 16), (37, 5), (1, 3), (300, 300)])
+def test_ppo_heads_one_launch_is_the_two_heads(B, A):
+    """pa_ppo_heads (actor head + the critic's MSE head as one extra workgroup of the same launch)
+    against pa_ppo_actor_loss followed by pa_mse_head: every output bit-identical; A = 300 takes
+    the row-per-thread actor kernels (value head launched beside them)."""
+    from pearl_amd import _native as N
+    g = torch.Generator().manual_seed(B * 31 + A)
+    logits = torch.randn(B, A, generator=g).to(DEV)
+    arep = torch.eye(A)[torch.randint(0, A, (B,), generator=g)].to(DEV)
+    p_old = (torch.rand(B, generator=g) * 0.8 + 0.1).to(DEV)
+    gae = torch.randn(B, generator=g).to(DEV)
+    v = torch.randn(B, 1, generator=g).to(DEV)
+    ret = torch.randn(B, generator=g).to(DEV)
+    s = N.stream_ptr(torch.device(DEV))
+    outs = []
+    for fused in (False, True):
+        d_logits = torch.full((B, A), float("nan"), device=DEV)
+        dv = torch.full((B,), float("nan"), device=DEV)
+        losses = torch.full((2,), float("nan"), device=DEV)
+        for _ in range(2):       # twice: the ticket is back at zero after a launch
+            if fused:
+                N.check(N.lib().pa_ppo_heads(logits.data_ptr(), A, arep.data_ptr(), A, p_old.data_ptr(),
+                                             gae.data_ptr(), B, A, 0.1, 0.01, d_logits.data_ptr(), A,
+                                             v.data_ptr(), 1, ret.data_ptr(), dv.data_ptr(),
+                                             losses.data_ptr(), s))
+            else:
+                N.check(N.lib().pa_ppo_actor_loss(logits.data_ptr(), A, arep.data_ptr(), A,
+                                                  p_old.data_ptr(), gae.data_ptr(), B, A, 0.1, 0.01,
+                                                  d_logits.data_ptr(), A, losses.data_ptr(), s))
+                N.check(N.lib().pa_mse_head(v.data_ptr(), 1, ret.data_ptr(), B, 2.0 / B, 1.0, 0,
+                                            dv.data_ptr(), losses[1:].data_ptr(), s))
+        torch.cuda.synchronize()
+        outs.append((d_logits.cpu(), dv.cpu(), losses.cpu()))
+    for x, y in zip(*outs):
+        assert torch.isfinite(x).all()
+        assert torch.equal(x, y)
+    want = ((v.reshape(B) - ret) ** 2).mean().cpu()
+    torch.testing.assert_close(outs[1][2][1], want, rtol=1e-5, atol=1e-6)
