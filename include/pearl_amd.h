@@ -505,7 +505,7 @@ int pa_ddpg_step(const pa_ddpg_step_args* args, void* stream);
 typedef struct pa_ac_loop_args {
   int32_t rounds;
   const int64_t* idx_lists;      /* device [rounds][B] logical indices (pa_sample_indices_rounds) */
-  pa_batch_out batch;            /* device workspace of ONE batch, reused by every round */
+  pa_batch_out batch;            /* device workspace of one batch (G batches: gather_rounds) */
   const float* noise;            /* device [rounds][noise_stride]: SAC [2][B][A] standard normal
                                     (actor update, Bellman target); TD3 [B][A] N(0, sigma^2); NULL: none */
   int64_t noise_stride;
@@ -513,6 +513,9 @@ typedef struct pa_ac_loop_args {
   int32_t losses_stride;
   int32_t actor_update_freq;     /* TD3: actor step + target updates on rounds where               */
   int64_t training_step0;        /* (training_step0 + r + 1) % actor_update_freq == 0; <= 1: all   */
+  int32_t gather_rounds;         /* G > 1: `batch` holds G x B rows and ONE gather launch fills the  */
+                                 /* batches of G consecutive rounds (G x B <= rows in the arena);    */
+                                 /* round r steps on rows [(r % G) B, (r % G + 1) B)                 */
 } pa_ac_loop_args;
 int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
                  void* stream);

@@ -267,6 +267,7 @@ class AcLoopArgs(C.Structure):
         ("losses_stride", C.c_int32),
         ("actor_update_freq", C.c_int32),
         ("training_step0", C.c_int64),
+        ("gather_rounds", C.c_int32),
     ]
 
 

@@ -791,8 +791,21 @@ extern "C" int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, cons
              PA_ERR_INVALID, "pa_sac_learn: the step reads the loop's batch workspace");
   pa_sac_step_args a = *step0;
   const int64_t BA = (int64_t)a.B * a.A;
+  const int G = lp->gather_rounds > 1 ? lp->gather_rounds : 1;
   for (int r = 0; r < lp->rounds; ++r) {
-    PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * a.B, a.B, &lp->batch, stream));
+    // the batches of G rounds in ONE gather launch (the lists are contiguous), then G steps on
+    // consecutive slices of the workspace
+    const int slot = r % G;
+    if (slot == 0) {
+      const int n = lp->rounds - r < G ? lp->rounds - r : G;
+      PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * a.B, n * a.B, &lp->batch, stream));
+    }
+    const int64_t row0 = (int64_t)slot * a.B;
+    a.state = step0->state + row0 * step0->ld_state;
+    a.next_state = step0->next_state + row0 * step0->ld_next_state;
+    a.action = step0->action + row0 * step0->ld_action;
+    a.reward = step0->reward + row0;
+    a.terminated = step0->terminated + row0;
     a.noise_actor = lp->noise + (int64_t)r * lp->noise_stride;
     a.noise_critic = a.noise_actor + BA;
     a.actor_step = step0->actor_step + r;
@@ -818,8 +831,19 @@ extern "C" int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena,
   pa_ddpg_step_args a = *step0;
   int64_t actor_steps = 0;
   const int freq = lp->actor_update_freq > 1 ? lp->actor_update_freq : 1;
+  const int G = lp->gather_rounds > 1 ? lp->gather_rounds : 1;
   for (int r = 0; r < lp->rounds; ++r) {
-    PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * a.B, a.B, &lp->batch, stream));
+    const int slot = r % G;
+    if (slot == 0) {
+      const int n = lp->rounds - r < G ? lp->rounds - r : G;
+      PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * a.B, n * a.B, &lp->batch, stream));
+    }
+    const int64_t row0 = (int64_t)slot * a.B;
+    a.state = step0->state + row0 * step0->ld_state;
+    a.next_state = step0->next_state + row0 * step0->ld_next_state;
+    a.action = step0->action + row0 * step0->ld_action;
+    a.reward = step0->reward + row0;
+    a.terminated = step0->terminated + row0;
     // TD3 (td3.py:106-141): the actor step and both target updates on every freq-th training step
     const bool due = ((lp->training_step0 + r + 1) % freq) == 0;
     a.do_actor = due;

@@ -229,6 +229,8 @@ class ActorCriticBase(PolicyLearner):
         (pa_sac_learn / pa_ddpg_learn); None: this call takes the per-round loop below."""
         return None
 
+    _LOOP_GATHER_BYTES = 64 << 20     # batch workspace of a native learn loop
+
     def _arena_loop_plan(self, replay_buffer: ReplayBuffer, batch_size: int, dev: torch.device,
                          S: int, A: int) -> Optional[Dict[str, Any]]:
         """What the native loops need from the replay buffer — its arena, the presampled index
@@ -261,14 +263,21 @@ class ActorCriticBase(PolicyLearner):
             return None
         if hasattr(getattr(self, "safety_module", None), "lambda_constraint"):
             return None
+        # workspace for the batches of G consecutive rounds: ONE gather launch fills them (5 us a
+        # round as a launch of its own at B = 1024, ~0.3 us as a slice of a 64 MB gather)
+        row_bytes = 4 * (2 * S + A + 1) + 2
+        G = max(1, min(rounds, self._LOOP_GATHER_BYTES // (row_bytes * batch_size),
+                       len(rb) // batch_size))
         ws = self._flat.get("loop_ws")
-        key = (dev, batch_size, S, A)
+        key = (dev, batch_size, S, A, G)
         if ws is None or ws["key"] != key:
+            n = G * batch_size
+
             def new(shape, dtype=torch.float32):
                 return torch.empty(shape, dtype=dtype, device=dev)
-            ws = {"key": key, "state": new((batch_size, S)), "action": new((batch_size, A)),
-                  "reward": new((batch_size,)), "term": new((batch_size,), torch.uint8),
-                  "trunc": new((batch_size,), torch.uint8), "next": new((batch_size, S))}
+            ws = {"key": key, "G": G, "state": new((n, S)), "action": new((n, A)),
+                  "reward": new((n,)), "term": new((n,), torch.uint8),
+                  "trunc": new((n,), torch.uint8), "next": new((n, S))}
             self._flat["loop_ws"] = ws
         out = N.BatchOut()
         out.state, out.action, out.reward = ws["state"].data_ptr(), ws["action"].data_ptr(), ws["reward"].data_ptr()

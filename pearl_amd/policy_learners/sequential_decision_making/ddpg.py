@@ -260,6 +260,7 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         freq = max(int(self._actor_update_freq), 1)
         lp = N.AcLoopArgs()
         lp.batch = plan["out"]
+        lp.gather_rounds = w["G"]
         lp.losses_stride, lp.noise_stride = 2, B * A
         lp.actor_update_freq = freq
         chunk = max(1, self._NOISE_CHUNK // (B * A))
@@ -268,8 +269,8 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         while done < rounds:
             n = min(chunk, rounds - done)
             noise, clip = self._loop_noise(n, B, A, dev)
-            a = self._step_args(ws, actor, c1, c2, w["state"], w["action"], w["reward"], w["term"],
-                                w["next"], losses, clip)
+            a = self._step_args(ws, actor, c1, c2, w["state"][:B], w["action"][:B], w["reward"][:B],
+                                w["term"][:B], w["next"][:B], losses, clip)
             lp.rounds = n
             lp.idx_lists = plan["lists"][done].data_ptr()
             lp.noise, lp.losses = N.ptr(noise), losses[done].data_ptr()

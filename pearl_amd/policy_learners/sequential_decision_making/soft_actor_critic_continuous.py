@@ -369,14 +369,15 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         logp = torch.empty(B, dtype=torch.float32, device=dev)
         lp = N.AcLoopArgs()
         lp.batch = plan["out"]
+        lp.gather_rounds = w["G"]
         lp.losses_stride, lp.noise_stride = 3, 2 * B * A
         chunk = max(1, self._NOISE_CHUNK // (2 * B * A))
         done = 0
         while done < rounds:
             n = min(chunk, rounds - done)
             noise = torch.randn(n, 2, B, A, device=dev, dtype=torch.float32)
-            a = self._step_args(ws, actor, c1, c2, w["state"], w["action"], w["reward"], w["term"],
-                                w["next"], losses, logp)
+            a = self._step_args(ws, actor, c1, c2, w["state"][:B], w["action"][:B], w["reward"][:B],
+                                w["term"][:B], w["next"][:B], losses, logp)
             lp.rounds = n
             lp.idx_lists = plan["lists"][done].data_ptr()
             lp.noise, lp.losses = noise.data_ptr(), losses[done].data_ptr()

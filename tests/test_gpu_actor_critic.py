@@ -894,6 +894,31 @@ def test_native_learn_loop_is_the_per_round_loop(kind, shape, monkeypatch):
     assert torch.equal(i0, i1)
 
 
+@pytest.mark.parametrize("kind", ["sac", "td3"])
+def test_native_learn_loop_gathers_in_groups_of_rounds(kind, monkeypatch):
+    """The loop gathers the batches of G consecutive rounds with one launch; with a workspace that
+    holds 3 of the 7 rounds (gathers of 3, 3 and 1 batches) the call is still the per-round loop,
+    bit for bit."""
+    import random
+    from pearl_amd.policy_learners.sequential_decision_making.actor_critic_base import ActorCriticBase
+    B, S, A = 64, 12, 3
+    monkeypatch.setattr(ActorCriticBase, "_LOOP_GATHER_BYTES", (4 * (2 * S + A + 1) + 2) * B * 3)
+    got = {}
+    for loop in ("0", "1"):
+        monkeypatch.setenv("PEARL_AMD_AC_LOOP", loop)
+        pl, rb = _continuous_setup(kind, rounds=7, B=B, S=S, A=A)
+        torch.manual_seed(3)
+        random.seed(3)
+        rep = pl.learn(rb)
+        torch.cuda.synchronize()
+        if loop == "1":
+            assert pl._flat["loop_ws"]["G"] == 3
+        got[loop] = (rep, _learner_state(pl))
+    assert got["0"][0] == got["1"][0]
+    for k in got["0"][1]:
+        assert torch.equal(got["0"][1][k], got["1"][1][k]), k
+
+
 def test_native_learn_loop_steps_aside(monkeypatch):
     """learn() takes the per-round loop whenever a round is not exactly the library's own
     sample -> preprocess_batch -> learn_batch: a subclass that overrides a hook, a parity noise
