@@ -173,7 +173,13 @@ class ActorCriticBase(PolicyLearner):
         # of a single-workgroup kernel on the critical path of every round
         presample = getattr(replay_buffer, "presample", None)
         if presample is not None:
-            presample(self._training_rounds, batch_size)
+            from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
+            if isinstance(replay_buffer, TensorBasedReplayBuffer) \
+                    and os.environ.get("PEARL_AMD_PREGATHER", "1") != "0":
+                # ... and one gather launch for the batches of as many rounds as fit the workspace
+                presample(self._training_rounds, batch_size, pregather_bytes=self._LOOP_GATHER_BYTES)
+            else:
+                presample(self._training_rounds, batch_size)
         try:
             for m in self._flat.values():      # validated on the first step, trusted until the end
                 if isinstance(m, FlatMlp):

@@ -77,12 +77,25 @@ class PPOReplayBuffer(TensorBasedReplayBuffer):
 
     def sample(self, batch_size: int) -> PPOTransitionBatch:
         batch = super().sample(batch_size)
-        idx = self.last_indices
         assert self.extra, "PPOReplayBuffer.sample before preprocess_replay_buffer"
         src = self._planes
-        dst = torch.empty(3, batch_size, dtype=torch.float32, device=src.device)
-        N.check(N.lib().pa_gather_planes(src.data_ptr(), src.stride(0), 3, idx.data_ptr(),
-                                         int(batch_size), dst.data_ptr(), N.stream_ptr(src.device)))
+        pg, k = self._pregathered, self._pg_slot
+        if k is not None and pg is not None:
+            # the rounds that share a gather share the gather of the three columns as well
+            dst = pg["extras"].get("planes")
+            if dst is None or pg["extras"].get("planes_src") is not src:
+                idx = pg["idx_flat"]
+                dst = torch.empty(3, idx.numel(), dtype=torch.float32, device=src.device)
+                N.check(N.lib().pa_gather_planes(src.data_ptr(), src.stride(0), 3, idx.data_ptr(),
+                                                 int(idx.numel()), dst.data_ptr(),
+                                                 N.stream_ptr(src.device)))
+                pg["extras"]["planes"], pg["extras"]["planes_src"] = dst, src
+            dst = dst[:, k * batch_size:(k + 1) * batch_size]
+        else:
+            idx = self.last_indices
+            dst = torch.empty(3, batch_size, dtype=torch.float32, device=src.device)
+            N.check(N.lib().pa_gather_planes(src.data_ptr(), src.stride(0), 3, idx.data_ptr(),
+                                             int(batch_size), dst.data_ptr(), N.stream_ptr(src.device)))
         return PPOTransitionBatch.from_parent(batch, gae=dst[0], lam_return=dst[1],
                                               action_probs=dst[2])
 

@@ -168,6 +168,9 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         self._space_cache: dict = {}
         self._last_idx: Optional[Tensor] = None
         self._presampled: Optional[Tuple[Tensor, int, int]] = None   # (lists [R, B], next row, len)
+        self._pregather_bytes = 0
+        self._pregathered: Optional[dict] = None    # batches of G presampled rounds, gathered at once
+        self._pg_slot: Optional[int] = None         # slot of the last sample() inside _pregathered
 
     # -- ReplayBuffer interface -------------------------------------------------
     @property
@@ -188,6 +191,7 @@ class TensorBasedReplayBuffer(ReplayBuffer):
 
     def clear(self) -> None:
         self._presampled = None
+        self._pregathered = None
         if self._arena is not None:
             self._arena.clear()
 
@@ -469,13 +473,19 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         return np.fromiter(random.sample(range(len(self)), batch_size), dtype=np.int64,
                            count=batch_size)
 
-    def presample(self, rounds: int, batch_size: int) -> bool:
+    def presample(self, rounds: int, batch_size: int, pregather_bytes: int = 0) -> bool:
         """Device sampler only: draw the index lists of the next ``rounds`` ``sample(batch_size)``
         calls in ONE launch (``sample_indices_kernel`` runs one workgroup per list, so a learner
         loop does not pay a single-workgroup kernel per round); the following ``sample`` calls of
         that size consume them in order.  Pushing, clearing or a different batch size drops what
-        is left.  Consumes Python's ``random`` once (the Philox key), like one ``sample``."""
+        is left.  Consumes Python's ``random`` once (the Philox key), like one ``sample``.
+
+        ``pregather_bytes`` > 0: those ``sample`` calls also share their gather — one launch fills
+        the batches of as many consecutive rounds as fit in that many bytes, and each call returns
+        its rows of it (views; the same values a gather of its own would produce)."""
         self._presampled = None
+        self._pregathered = None
+        self._pregather_bytes = 0
         n = len(self)
         if self.sampler != "device" or self._arena is None or rounds <= 0 or not 0 < batch_size <= n \
                 or batch_size > self.DEVICE_SAMPLER_MAX_B:
@@ -487,10 +497,43 @@ class TensorBasedReplayBuffer(ReplayBuffer):
                                                  int(rounds), lists.data_ptr(), dev.index,
                                                  N.stream_ptr(dev)))
         self._presampled = (lists, 0, n)
+        if pregather_bytes > 0 and self._device_for_batches == dev:
+            self._pregather_bytes = int(pregather_bytes)
         return True
 
     def drop_presampled(self) -> None:
         self._presampled = None
+        self._pregathered = None
+        self._pregather_bytes = 0
+
+    def _row_bytes(self) -> int:
+        """Bytes of one gathered transition (upper bound, for sizing a shared gather)."""
+        z = self._layout
+        n = 4 * z.state_dim * (2 if z.has_next_state else 1) + 8 * z.action_elems + 8 + 2 + 4
+        if z.max_actions and not self._is_action_continuous:
+            n += (int(self._has_curr_avail) + int(self._has_next_avail)) * z.max_actions * (4 * z.avail_dim + 1)
+        return n
+
+    def _pregathered_batch(self, lists: Tensor, row: int) -> TransitionBatch:
+        B = int(lists.shape[1])
+        pg = self._pregathered
+        if pg is None or not pg["row0"] <= row < pg["row0"] + pg["G"]:
+            G = max(1, min(int(lists.shape[0]) - row, self._pregather_bytes // (self._row_bytes() * B),
+                           len(self) // B))
+            idx_flat = lists[row:row + G].reshape(-1)
+            pg = {"row0": row, "G": G, "idx_flat": idx_flat, "big": self._gather_batch(idx_flat),
+                  "extras": {}}
+            self._pregathered = pg
+        k = row - pg["row0"]
+        self._pg_slot = k
+        self._last_idx = lists[row]
+        big = pg["big"]
+        fields = {}
+        for name in big._fields:
+            v = getattr(big, name)
+            fields[name] = v[k * B:(k + 1) * B] if isinstance(v, Tensor) and v.dim() > 0 \
+                and v.shape[0] == pg["G"] * B else v
+        return type(big)(**fields)
 
     def sample(self, batch_size: int) -> TransitionBatch:
         """Uniform sample without replacement -> ``TransitionBatch`` on ``device_for_batches``
@@ -500,12 +543,15 @@ class TensorBasedReplayBuffer(ReplayBuffer):
                 f"Can't get a batch of size {batch_size} from a replay buffer with "
                 f"only {len(self)} elements")
         pre = self._presampled
+        self._pg_slot = None
         if pre is not None:
             lists, row, n = pre
             if int(batch_size) == lists.shape[1] and n == len(self) and row < lists.shape[0]:
                 self._presampled = (lists, row + 1, n)
+                if self._pregather_bytes > 0:
+                    return self._pregathered_batch(lists, row)
                 return self._gather_batch(lists[row])
-            self._presampled = None
+            self.drop_presampled()
         return self._gather_batch(None, int(batch_size))
 
     @property

@@ -992,3 +992,75 @@ def test_ppo_heads_one_launch_is_the_two_heads(B, A):
         assert torch.equal(x, y)
     want = ((v.reshape(B) - ret) ** 2).mean().cpu()
     torch.testing.assert_close(outs[1][2][1], want, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind", ["ppo", "td3_per_round"])
+def test_shared_gather_of_presampled_rounds_is_the_per_round_gather(kind, monkeypatch):
+    """learn()'s per-round loop: the batches of consecutive presampled rounds come out of ONE gather
+    launch (views of it) instead of one launch each — same rows, so the call is bit-identical; a
+    workspace of 3 rounds for 7 exercises the regrouping (3 + 3 + 1)."""
+    import random
+    from pearl_amd.policy_learners.sequential_decision_making.actor_critic_base import ActorCriticBase
+    monkeypatch.setenv("PEARL_AMD_AC_LOOP", "0")
+    got = {}
+    for pre in ("0", "1"):
+        monkeypatch.setenv("PEARL_AMD_PREGATHER", pre)
+        torch.manual_seed(2)
+        random.seed(2)
+        if kind == "ppo":
+            from pearl_amd import (DiscreteActionSpace, OneHotActionTensorRepresentationModule,
+                                   PearlAgent, PPOReplayBuffer, ProximalPolicyOptimization)
+            S, A, B, n = 10, 4, 32, 400
+            sp = DiscreteActionSpace([torch.tensor([k]) for k in range(A)])
+            pl = ProximalPolicyOptimization(action_space=sp, state_dim=S, actor_hidden_dims=[32, 32],
+                                            critic_hidden_dims=[32, 32], training_rounds=7, batch_size=B,
+                                            epsilon=0.1,
+                                            action_representation_module=OneHotActionTensorRepresentationModule(A))
+            rb = PPOReplayBuffer(n, sampler="device")
+            PearlAgent(pl, replay_buffer=rb, device_id=0)
+            st = torch.randn(n + 1, S, device=DEV)
+            ids = torch.arange(n, device=DEV)
+            rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                         terminated=(ids % 50 == 49), truncated=torch.zeros(n, dtype=torch.bool, device=DEV),
+                         next_state=st[1:], curr_available_actions=sp, next_available_actions=sp,
+                         max_number_actions=A)
+            row = (4 * S * 2 + 8 + 8 + 2 + 4 + 2 * A * 5) * B
+        else:
+            pl, rb = _continuous_setup("td3", rounds=7)
+            row = (4 * 12 * 2 + 8 * 3 + 8 + 2 + 4) * 64
+        monkeypatch.setattr(ActorCriticBase, "_LOOP_GATHER_BYTES", 3 * row)
+        reports = [pl.learn(rb), pl.learn(rb)]
+        torch.cuda.synchronize()
+        if pre == "1":
+            assert rb._pregather_bytes == 0 and rb._pregathered is None     # dropped at the end
+        got[pre] = (reports, _learner_state(pl))
+    assert got["0"][0] == got["1"][0]
+    for k in got["0"][1]:
+        assert torch.equal(got["0"][1][k], got["1"][1][k]), k
+
+
+def test_pregathered_samples_are_views_of_one_gather():
+    from pearl_amd import BasicReplayBuffer
+    import random
+    n, S, A, B = 300, 5, 2, 16
+    rb = BasicReplayBuffer(n, sampler="device")
+    rb.device_for_batches = torch.device(DEV)
+    rb.is_action_continuous = True
+    st = torch.randn(n + 1, S, device=DEV)
+    ids = torch.arange(n, device=DEV)
+    rb.push_many(state=st[:-1], action=torch.rand(n, A, device=DEV), reward=ids.float(),
+                 terminated=(ids % 9 == 0), truncated=torch.zeros(n, dtype=torch.bool, device=DEV),
+                 next_state=st[1:])
+    random.seed(1)
+    assert rb.presample(5, B, pregather_bytes=rb._row_bytes() * B * 2)
+    lists = rb._presampled[0].clone()
+    for r in range(5):
+        b = rb.sample(B)
+        assert rb._pregathered["G"] == (2 if r < 4 else 1)
+        assert torch.equal(rb.last_indices, lists[r])
+        assert torch.equal(b.reward, lists[r].float())                 # reward == logical index
+        assert torch.equal(b.state, st[:-1][lists[r]]) and torch.equal(b.next_state, st[1:][lists[r]])
+    rb.push(state=st[0], action=torch.rand(A), reward=0.0, next_state=st[1], curr_available_actions=None,
+            next_available_actions=None, terminated=False, truncated=False)
+    b = rb.sample(B)                      # a push drops what was presampled / pregathered
+    assert rb._presampled is None and rb._pregathered is None and len(b) == B
