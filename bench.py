@@ -9,6 +9,7 @@ A "step" is one round of learn(): device-side sample + gather(+one-hot) + learn_
 batch of 1024 transitions that are already resident in HBM.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import random
@@ -189,11 +190,16 @@ def main():
         agent.learn()
     pl._training_rounds = args.steps
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, args.timing_level))
+    # (like `timeit`: no cyclic-GC pass inside the timed region — a generation-2 pass over a torch
+    # process's heap is ~80 ms, eighty times the 20-round region the driver times)
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     report = agent.learn()          # exactly `steps` rounds; returns after its single host sync
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
