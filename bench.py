@@ -161,6 +161,12 @@ def main():
     # first because a GPU that has been idle takes its first millisecond of work at reduced clocks
     # (tools/firstcall.py: the same 20-round call costs 1.18 ms cold, 1.07 ms in steady state,
     # 1.43 ms after half a second of idling) — the line says so in `untimed_rounds_before`.
+    # Like `timeit`: no cyclic-GC pass inside the timed region (a generation-2 pass over a torch
+    # process's heap is ~80 ms, eighty times the 20-round region the driver times).  Collected
+    # HERE, before the untimed rounds: 80 ms of host work right before the timed region would let
+    # the GPU fall idle again (measured: 15.8 M transitions/s instead of 20 M for the 20-round call).
+    gc.collect()
+    gc.disable()
     isolated = None
     overlapped = os.environ.get("PEARL_AMD_OVERLAP", "1") != "0" and args.timing_level < 2
     calib_rounds = 0
@@ -190,10 +196,6 @@ def main():
         agent.learn()
     pl._training_rounds = args.steps
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, args.timing_level))
-    # (like `timeit`: no cyclic-GC pass inside the timed region — a generation-2 pass over a torch
-    # process's heap is ~80 ms, eighty times the 20-round region the driver times)
-    gc.collect()
-    gc.disable()
     barrier()
     t0 = time.perf_counter()
     report = agent.learn()          # exactly `steps` rounds; returns after its single host sync
