@@ -121,7 +121,7 @@ def bench_sac(steps, cpu_seconds):
     roof = step_roofline(flop_step, B * steps, dt)
     if nt.value:
         ka = f_rows_a * B / (ua.value * 1e-6)
-        roof.update({"kernel": "sac_rows_a_kernel<16,4,5> (actor-update rows || critics at (s, a_batch))",
+        roof.update({"kernel": "sac_rows_a_kernel<16,4,5,0,SPLIT> (actor-update rows || helper: critic 2 at the fresh action || critics at (s, a_batch))",
                      "achieved": ka / 1e12, "frac": ka / PEAK_F32_MFMA, "avg_launch_us": ua.value,
                      "flop_per_launch": f_rows_a * B, "launches_timed": nt.value,
                      "scope": "dominant kernel, HIP events on the learner stream inside the timed learn()",
@@ -293,8 +293,8 @@ def bench_ppo(steps, cpu_seconds):
                 2 * sum(2 * mlp_macs(d) + sum(a * b for a, b in zip(d[1:-1], d[2:]))
                         for d in ([S, 256, 256, A], [S, 256, 256, 1])),
                 B * steps, dt,
-                kernel="weight_grad_kernel (2 launches of ~26 us per step; per-kernel durations: "
-                       "profiles/r02_ppo_kernel_stats.txt)"),
+                kernel="mlp_rowfwd_kernel 43 us + weight_grad_kernel 43 us + mlp_rowbwd_kernel 25 us per "
+                       "step (per-kernel durations: profiles/r02_ppo_kernel_stats.txt)"),
             "preprocess_replay_buffer": {"transitions_per_s": N / dt_pre, "ms": 1e3 * dt_pre,
                                          "what": "action probs + values of 65536 states, GAE / lambda-return scan"},
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
