@@ -236,6 +236,17 @@ def bench_dsac(steps, cpu_seconds):
     return {"config": "cfg2 shapes, discrete SoftActorCritic S=128 A=16 twin-Q [256,256] B=1024",
             "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
             "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            # actor update (soft_actor_critic.py:153-208): actor forward / dX / dW, both critics on
+            # all A actions (no gradient); critic update (:210-287): actor at s', both TARGET critics
+            # on all A actions, both online critics at (s, a): forward, dX, dW.  An all-actions pass
+            # is counted with the one-hot structure of its first layer, as for DQN:
+            # the state part once per row, hidden + output layers once per (row, action).
+            "roofline": step_roofline(
+                2 * (3 * mlp_macs([S, 256, 256, A]) + 256 * 256 + 256 * A
+                     + 4 * (S * 256 + A * (256 * 256 + 256))
+                     + 2 * (2 * mlp_macs([S + A, 256, 256, 1]) + 256 * 256 + 256)),
+                B * steps, dt, kernel="target_fused_kernel (4 all-actions passes per step) + generic "
+                                      "row passes; per-kernel durations: profiles/r02_dsac_kernel_stats.txt"),
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
 
@@ -332,6 +343,13 @@ def bench_bandit(steps, cpu_seconds):
     return {"config": "cfg5 NeuralLinearBandit 512-dim contexts trunk [256,64] B=4096",
             "metric": "contexts/s through learn_batch (NN step + LinUCB A/b/inv(A)/coefs update)",
             "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            # trunk forward + dW + dX of its second layer, the 65-wide head, A += x x^T, b += x r
+            # (fp32 MFMA); the 65 x 65 fp64 Gauss-Jordan solve (97 us of the step, one workgroup, no
+            # matrix pipe for fp64 at this size) is what bounds the step, not these flops
+            "roofline": dict(step_roofline(
+                2 * (2 * mlp_macs([F, 256, 64]) + 256 * 64 + 3 * 65 + 65 * 65), B * steps, dt,
+                kernel="linreg_solve_spd_kernel (97 us, fp64, one workgroup) + mlp row passes + "
+                       "weight_grad_kernel"), note="bound by the serial fp64 solve, not by MFMA"),
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls"}}
 
@@ -375,6 +393,14 @@ def bench_double_dqn(steps, cpu_seconds):
     return {"config": "cfg2 shapes, DoubleDQN S=128 A=16 [256,256] B=1024 replay 1M",
             "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
             "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            # DQN's count with the all-actions pass on the ONLINE network and a
+            # single-action pass on the target network (double_dqn.py:29-57): online forward, dW +
+            # dX, online all-actions (argmax), target value of the chosen action
+            "roofline": step_roofline(
+                2 * (2 * mlp_macs([S + A, 256, 256, 1]) + 256 * 256 + 256
+                     + S * 256 + A * (256 * 256 + 256) + S * 256 + 256 * 256 + 256),
+                B * steps, dt, kernel="target_fused_kernel (online all-actions pass, then the value "
+                                      "pass) + online_rowpass_kernel + weight_grad_kernel, one stream"),
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
 
@@ -427,6 +453,14 @@ def bench_push(steps, cpu_seconds):
             "value": push_rate, "steps": N1, "ms_per_step": 1e3 / push_rate,
             "push_many_from_host": {"transitions_per_s": N2 / dt, "GB_per_s": N2 * row_bytes / dt / 1e9,
                                     "what": "1M transitions from pinned host tensors: H2D copies + scatter kernel, PCIe inclusive"},
+            # ingest is a copy: the batched path moves row_bytes per transition over PCIe and writes
+            # them once to HBM; its bound is the host link (PCIe gen5 x16, ~64 GB/s), not HBM
+            "roofline": {"bound": "hbm", "achieved": N2 * row_bytes / dt / 1e9, "peak": 8000.0,
+                         "unit": "GB/s", "frac": N2 * row_bytes / dt / 8e12, "traffic": None,
+                         "bytes_per_transition": row_bytes,
+                         "scope": "push_many from pinned host tensors, PCIe inclusive (the per-transition "
+                                  "push() line above is interpreter-bound: one Python call per transition)",
+                         "pcie_frac": N2 * row_bytes / dt / 64e9},
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": 1,
                              "sample": f"{n} oracle (deque of per-transition tensors) pushes"}}
 
