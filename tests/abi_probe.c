@@ -15,5 +15,20 @@ int main(void) {
   O(pa_dqn_batch, x); O(pa_dqn_batch, next_avail_bcast); O(pa_dqn_batch, next_action_rep);
   O(pa_dqn_desc, double_q); O(pa_learn_args, training_steps0);
   O(pa_learn_args, seed); O(pa_learn_args, losses_out); O(pa_learn_args, idx_host);
+  P(pa_mlp_desc); P(pa_mlp_buffers); P(pa_sac_step_args); P(pa_ddpg_step_args); P(pa_ac_loop_args);
+  O(pa_mlp_desc, max_batch); O(pa_mlp_desc, lr); O(pa_mlp_desc, identity_layers);
+  O(pa_mlp_buffers, max_exp_avg_sq);
+  O(pa_sac_step_args, ld_state); O(pa_sac_step_args, terminated); O(pa_sac_step_args, noise_critic);
+  O(pa_sac_step_args, target_entropy); O(pa_sac_step_args, alpha_lr); O(pa_sac_step_args, alpha_amsgrad);
+  O(pa_sac_step_args, alpha_step); O(pa_sac_step_args, B); O(pa_sac_step_args, gamma);
+  O(pa_sac_step_args, actor_step); O(pa_sac_step_args, scratch); O(pa_sac_step_args, log_prob_out);
+  O(pa_ddpg_step_args, target_noise); O(pa_ddpg_step_args, noise_clip); O(pa_ddpg_step_args, low);
+  O(pa_ddpg_step_args, zeros); O(pa_ddpg_step_args, B); O(pa_ddpg_step_args, gamma);
+  O(pa_ddpg_step_args, do_actor); O(pa_ddpg_step_args, critic_tau); O(pa_ddpg_step_args, actor_step);
+  O(pa_ddpg_step_args, losses);
+  O(pa_ac_loop_args, idx_lists); O(pa_ac_loop_args, batch); O(pa_ac_loop_args, noise);
+  O(pa_ac_loop_args, noise_stride); O(pa_ac_loop_args, losses); O(pa_ac_loop_args, losses_stride);
+  O(pa_ac_loop_args, actor_update_freq); O(pa_ac_loop_args, training_step0);
+  O(pa_ac_loop_args, gather_rounds);
   return 0;
 }

@@ -40,7 +40,9 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     facts = dict(line.rsplit(" ", 1) for line in out.strip().splitlines())
     pairs = {"pa_arena_desc": N.ArenaDesc, "pa_transition": N.Transition, "pa_columns": N.Columns,
              "pa_batch_out": N.BatchOut, "pa_dqn_desc": N.DqnDesc, "pa_dqn_buffers": N.DqnBuffers,
-             "pa_dqn_batch": N.DqnBatch, "pa_learn_args": N.LearnArgs}
+             "pa_dqn_batch": N.DqnBatch, "pa_learn_args": N.LearnArgs, "pa_mlp_desc": N.MlpDesc,
+             "pa_mlp_buffers": N.MlpBuffers, "pa_sac_step_args": N.SacStepArgs,
+             "pa_ddpg_step_args": N.DdpgStepArgs, "pa_ac_loop_args": N.AcLoopArgs}
     for cname, ctype in pairs.items():
         assert C.sizeof(ctype) == int(facts[cname]), cname
     for key, value in facts.items():
@@ -320,6 +322,43 @@ def test_gradient_allreduce_is_a_mean_over_ranks():
         assert p.exitcode == 0
     want = (torch.arange(8, dtype=torch.float32) * (1 + 2) / 2).tolist()   # mean of g and 2g
     assert results[0] == want and results[1] == want
+
+
+def _native_loop_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pearl_amd import TD3, BoxActionSpace, ContinuousSoftActorCritic
+    space = BoxActionSpace(-torch.ones(2), torch.ones(2))
+    kw = dict(action_space=space, state_dim=5, actor_hidden_dims=[8, 8], critic_hidden_dims=[8, 8],
+              batch_size=4, training_rounds=3)
+    learners = [ContinuousSoftActorCritic(**kw), TD3(**kw)]
+    alone = [pl._one_call_ok() for pl in learners]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    # (the hook returns before it looks at the replay buffer)
+    together = [(pl._one_call_ok(), pl._learn_native_loop(object(), 4)) for pl in learners]
+    q.put((rank, (alone, together)))
+    dist.destroy_process_group()
+
+
+def test_native_learn_loops_step_aside_under_data_parallelism():
+    """pa_sac_learn / pa_ddpg_learn (and the one-call steps under them) are single-process paths: a
+    data-parallel step all-reduces between backward and AdamW, so with a process group of more
+    than one rank learn() keeps the per-round, per-stage loop on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_native_loop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        alone, together = results[r]
+        assert alone == [True, True]
+        assert together == [(False, None), (False, None)]
 
 
 # ---------------------------------------------------------------------------- constructor parity
