@@ -361,6 +361,27 @@ def test_native_learn_loops_step_aside_under_data_parallelism():
         assert together == [(False, None), (False, None)]
 
 
+def test_td3_loop_report_repeats_the_last_actor_loss():
+    """TD3's report carries the LAST actor loss on rounds without an actor step (td3.py:106-141);
+    the one-call learn() reconstructs that from the per-round losses and the step counter, across
+    calls."""
+    from pearl_amd import TD3, BoxActionSpace
+    pl = TD3(action_space=BoxActionSpace(-torch.ones(2), torch.ones(2)), state_dim=5,
+             actor_hidden_dims=[8, 8], critic_hidden_dims=[8, 8], batch_size=4, training_rounds=5,
+             actor_update_freq=2)
+    pl._last_actor_loss = 7.0
+    # training steps 1..5: actor steps on 2 and 4 (losses written there; zeros elsewhere)
+    rep = pl._loop_report([[0.0, 1.5, 0.0, 2.5, 0.0], [10.0, 11.0, 12.0, 13.0, 14.0]], step0=0, freq=2)
+    assert rep == {"actor_loss": [7.0, 1.5, 1.5, 2.5, 2.5], "critic_loss": [10.0, 11.0, 12.0, 13.0, 14.0]}
+    assert pl._last_actor_loss == 2.5
+    # next call starts after training step 5: steps 6 and 8 are due, 7 is not
+    rep = pl._loop_report([[3.5, 0.0, 4.5], [1.0, 2.0, 3.0]], step0=5, freq=2)
+    assert rep["actor_loss"] == [3.5, 3.5, 4.5]
+    # a device scalar left by the per-round path is read once
+    pl._last_actor_loss = torch.tensor(4.0)
+    assert pl._loop_report([[0.0], [1.0]], step0=0, freq=2)["actor_loss"] == [4.0]
+
+
 # ---------------------------------------------------------------------------- constructor parity
 def _load_fx(name):
     return torch.load(os.path.join(REPO, "tests", "golden", f"{name}.pt"), map_location="cpu",
