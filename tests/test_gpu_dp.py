@@ -13,6 +13,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+def _shard_states(rank, N, S):
+    return torch.randn(N + 1, S, generator=torch.Generator().manual_seed(100 + rank))
+
+
 def _worker(rank, world, port, q):
     os.environ["PEARL_AMD_TORCH_ALLREDUCE"] = "1"
     import torch.distributed as dist
@@ -28,21 +32,23 @@ def _worker(rank, world, port, q):
                        batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))
     rb = BasicReplayBuffer(N, sampler="device")
     PearlAgent(pl, replay_buffer=rb, device_id=0)
-    g = torch.Generator(device=dev).manual_seed(100 + rank)   # rank-private shard
-    st = torch.randn(N + 1, S, device=dev, generator=g)
+    st = _shard_states(rank, N, S).to(dev)                    # rank-private shard
     ids = torch.arange(N, device=dev)
     rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 5).float() + rank,
                  terminated=(ids % 37 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=dev),
                  next_state=st[1:], curr_available_actions=space, next_available_actions=space,
                  max_number_actions=A)
     random.seed(7 + rank)
-    losses = pl.learn(rb)["loss"] + pl.learn(rb)["loss"]
+    losses = pl.learn(rb)["loss"]
+    first = {k: v.detach().cpu().numpy().copy() for k, v in pl._Q.state_dict().items()}
+    first_t = {k: v.detach().cpu().numpy().copy() for k, v in pl._Q_target.state_dict().items()}
+    losses = losses + pl.learn(rb)["loss"]
     flat = torch.cat([p.detach().reshape(-1) for p in pl._Q.parameters()] +
                      [p.detach().reshape(-1) for p in pl._Q_target.parameters()]).cpu()
     mom = torch.cat([pl._optimizer.state[p]["exp_avg"].reshape(-1) for p in pl._Q.parameters()]).cpu()
     # numpy arrays travel by value; torch tensors would be handed over through the producer process,
     # which may be gone before the parent reads them
-    q.put((rank, flat.numpy(), mom.numpy(), losses, pl._training_steps))
+    q.put((rank, flat.numpy(), mom.numpy(), losses, pl._training_steps, first, first_t))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -57,8 +63,9 @@ def _run(world):
         p.start()
     out = {}
     for _ in procs:
-        rank, flat, mom, losses, steps = q.get(timeout=300)
-        out[rank] = (torch.from_numpy(flat.copy()), torch.from_numpy(mom.copy()), losses, steps)
+        rank, flat, mom, losses, steps, first, first_t = q.get(timeout=300)
+        out[rank] = (torch.from_numpy(flat.copy()), torch.from_numpy(mom.copy()), losses, steps,
+                     first, first_t)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -67,7 +74,7 @@ def _run(world):
 
 def test_two_ranks_keep_identical_parameters():
     two = _run(2)
-    (f0, m0, l0, s0), (f1, m1, l1, s1) = two[0], two[1]
+    (f0, m0, l0, s0, _, _), (f1, m1, l1, s1, _, _) = two[0], two[1]
     assert s0 == s1 == 46
     assert torch.equal(f0, f1), "parameters diverged across ranks"
     assert torch.equal(m0, m1), "optimizer state diverged across ranks"
@@ -75,3 +82,51 @@ def test_two_ranks_keep_identical_parameters():
     assert l0 != l1                                         # each rank reports its own shard's loss
     one = _run(1)[0]
     assert not torch.equal(one[0], f0), "two-rank training must see the other rank's gradients"
+
+
+def test_two_ranks_equal_one_reference_learner_on_the_concatenated_batch():
+    """parity of G > 1 ranks is defined against ONE reference learner fed the
+    concatenated global batch (deep_td_learning.py:292-360 with the MSE mean over B * world rows,
+    i.e. norm = 2 / (B * world)).  The CPU oracle replays both ranks' Philox index lists on both
+    shards, steps once per round on the 2B-row batch, and must land where the two HIP ranks did —
+    per-round reports (the mean of the ranks' mean |Q - y|), online and target parameters after a
+    23-round learn() that crosses two soft updates."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import assert_adam_trajectory_close
+    from oracle import pearl_oracle as O
+    from pearl_amd import DeepQLearning, DiscreteActionSpace, OneHotActionTensorRepresentationModule
+    two = _run(2)
+    S, A, B, N, R = 24, 4, 64, 4000, 23
+    space = DiscreteActionSpace([torch.tensor([k]) for k in range(A)])
+    torch.manual_seed(0)
+    init = DeepQLearning(state_dim=S, action_space=space, hidden_dims=[64, 64], training_rounds=R,
+                         batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))
+    orc = O.DqnOracle(init._Q.state_dict(), init._Q_target.state_dict())
+    shards, keys = [], []
+    for rank in range(2):
+        shards.append(_shard_states(rank, N, S))
+        random.seed(7 + rank)
+        keys.append(random.getrandbits(64))        # the seed learn() hands the device sampler
+    want = []
+    for r in range(R):
+        parts = []
+        for rank in range(2):
+            idx = torch.from_numpy(O.philox_sample_indices(N, keys[rank], r, B))
+            st = shards[rank]
+            parts.append(dict(state=st[idx], action=torch.eye(A)[idx % A],
+                              reward=(idx % 5).float() + rank, terminated=(idx % 37 == 0),
+                              next_state=st[idx + 1],
+                              next_available_actions=torch.eye(A).expand(B, A, A),
+                              next_unavailable_actions_mask=torch.zeros(B, A, dtype=torch.bool)))
+        batch = {k: torch.cat([parts[0][k], parts[1][k]]) for k in parts[0]}
+        orc.training_steps += 1
+        want.append(orc.learn_batch(batch))        # mean |Q - y| over the 2B rows
+    got = [(a + b) / 2 for a, b in zip(two[0][2][:R], two[1][2][:R])]
+    torch.testing.assert_close(torch.tensor(got), torch.tensor(want), rtol=1e-3, atol=1e-5)
+    for rank in range(2):
+        for k in O.PARAM_KEYS:
+            assert_adam_trajectory_close(torch.from_numpy(two[rank][4][k]), orc.p[k], lr=1e-3, steps=R,
+                                         msg=f"rank {rank} online {k}")
+            assert_adam_trajectory_close(torch.from_numpy(two[rank][5][k]), orc.t[k], lr=1e-3, steps=R,
+                                         msg=f"rank {rank} target {k}")

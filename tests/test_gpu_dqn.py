@@ -15,7 +15,7 @@ import pytest
 import torch
 
 from conftest import GOLDEN_NAMES
-from helpers import fill_oracle_replay, oracle_learner
+from helpers import assert_adam_trajectory_close, fill_oracle_replay, oracle_learner
 from oracle import pearl_oracle as O
 from test_gpu_replay import _space, fill_arena_buffer
 
@@ -356,8 +356,10 @@ def test_agent_checkpoint_resume_is_exact(golden, name, tmp_path):
 
 def test_full_size_config2_learn_properties():
     """BASELINE config 2 at full size (N=1M, B=1024, [256,256]):
-    * the first steps of the fused device-sampled learn() equal the CPU oracle replaying the same
-      Philox index lists on the same data (Q-value-level parity at the benchmark's exact shape);
+    * 25 rounds of the fused device-sampled learn() — the overlapped two-stream loop, three
+      target-update windows, two soft updates, the window hand-off word and a second persistent
+      target launch all inside — equal the CPU oracle replaying the same Philox index lists on the
+      same data (Q-value-level parity at the benchmark's exact shape, VERDICT r2 weak-1);
     * two identical runs are bitwise identical (deterministic reductions, no atomics);
     * losses stay finite and the target network moves only through soft updates."""
     from pearl_amd import BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule
@@ -382,15 +384,18 @@ def test_full_size_config2_learn_properties():
                              action_representation_module=OneHotActionTensorRepresentationModule(A)).to(dev)
 
     # -- parity with the oracle at full size
-    pl = fresh(4)
+    ROUNDS = 25
+    pl = fresh(ROUNDS)
+    assert os.environ.get("PEARL_AMD_OVERLAP", "1") != "0", "this test is about the overlapped loop"
     orc = O.DqnOracle({k: v.cpu() for k, v in pl._Q.state_dict().items()},
                       {k: v.cpu() for k, v in pl._Q_target.state_dict().items()})
+    tgt0 = {k: v.clone() for k, v in orc.t.items()}
     random.seed(5)
     key = random.getrandbits(64)
     random.seed(5)
     got = pl.learn(rb)["loss"]
     want = []
-    for r in range(4):
+    for r in range(ROUNDS):
         idx = torch.from_numpy(O.philox_sample_indices(N, key, r, B))
         batch = dict(state=st_cpu[idx], action=torch.eye(A)[idx % A], reward=(idx % 7).float(),
                      terminated=(idx % 50 == 0), next_state=st_cpu[idx + 1],
@@ -398,9 +403,14 @@ def test_full_size_config2_learn_properties():
                      next_unavailable_actions_mask=torch.zeros(B, A, dtype=torch.bool))
         orc.training_steps += 1
         want.append(orc.learn_batch(batch))
-    torch.testing.assert_close(torch.tensor(got), torch.tensor(want), rtol=1e-4, atol=1e-5)
+    # the oracle crossed two soft updates (rounds 8 and 18 open with one: (steps + 1) % 10 == 0)
+    assert any(not torch.equal(tgt0[k], orc.t[k]) for k in tgt0) and orc.training_steps == ROUNDS
+    torch.testing.assert_close(torch.tensor(got[:4]), torch.tensor(want[:4]), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(torch.tensor(got), torch.tensor(want), rtol=1e-3, atol=1e-5)
     for k, v in pl._Q.state_dict().items():
-        torch.testing.assert_close(v.cpu(), orc.p[k], rtol=1e-3, atol=2e-5, msg=k)
+        assert_adam_trajectory_close(v, orc.p[k], lr=1e-3, steps=ROUNDS, msg=f"online {k}")
+    for k, v in pl._Q_target.state_dict().items():
+        assert_adam_trajectory_close(v, orc.t[k], lr=1e-3, steps=ROUNDS, msg=f"target {k}")
 
     # -- determinism + sanity over 60 steps
     def run():
