@@ -27,6 +27,19 @@ S, A, HIDDEN, N_REPLAY, B = 128, 16, [256, 256], 1_000_000, 1024
 FLOP_PER_TRANSITION_STEP = 2.713e6          # whole learn step, one-hot-structured layer 1
 FLOP_TARGET_KERNEL_PER_TRANSITION = (2 * A * 256 * 256 + 2 * A * 256)   # layer 2 + layer 3 of the target net
 PEAK_F32_MFMA = 157.3e12                    # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0                       # MI355X_MICROARCH.md, HBM3E spec peak (6.3 TB/s achievable)
+
+
+def gather_bytes(with_x: bool, tables: bool) -> int:
+    """Algorithmic HBM bytes per transition of one window gather of the DQN learn loop (cfg2):
+    read  next_state 512 + reward 4 + terminated 1  (+ state 512 + action 8 when the launch also
+          writes the chain's x)  (+ the row's padded next-action table 64 + mask 16 when rows do
+          not share one table);
+    write next_state 512 + reward 4 + terminated 1  (+ x = state || one-hot(action) 576)
+          (+ one-hot (A, A) table 1024 + mask 16)."""
+    rd = 4 * S + 4 + 1 + ((4 * S + 8) if with_x else 0) + ((4 * A + A) if tables else 0)
+    wr = 4 * S + 4 + 1 + (4 * (S + A) if with_x else 0) + ((4 * A * A + A) if tables else 0)
+    return rd + wr
 
 
 def space(n):
@@ -89,6 +102,27 @@ def cpu_baseline(budget_s: float = 20.0):
                       f"os.cpu_count()={os.cpu_count()}"}
 
 
+def reference_cpu_baseline(budget_s: float = 15.0):
+    """cpu_baseline.kind == "reference": the reference's own PearlAgent.learn() in a child process
+    that sees no GPU (pearl/utils/device.py:48-59 would otherwise put it on cuda:0), from
+    oracle/_ref (staged by oracle/stage_ref.sh) — oracle/ref_cpu_baseline.py.  None when the
+    reference is not staged or the child fails; the caller then times the port."""
+    import subprocess
+    script = os.path.join(REPO, "oracle", "ref_cpu_baseline.py")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, script, "--seconds", str(budget_s), "--threads",
+                              str(min(32, os.cpu_count() or 1))], env=env, capture_output=True,
+                             text=True, timeout=240)
+        last = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+        d = json.loads(last[-1]) if last else {}
+        return d if "value" in d else None
+    except Exception:
+        return None
+
+
 def pmc_traffic(transitions_per_launch):
     """HBM bytes of one target_fused_kernel launch from the committed rocprofv3 PMC passes
     (profiles/r02_pmc_target.json, written by tools/pmc_traffic.py: FETCH_SIZE doubled as
@@ -146,7 +180,7 @@ def main():
 
     def read_timers():
         out = {}
-        for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "gather_x", "sample",
+        for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "gather_nox", "gather_x", "sample",
                      "online_l2", "head", "bwd_dx", "rowpass", "bwd_dw", "adamw", "soft_update"):
             ms, cnt, units = C.c_double(), C.c_int64(), C.c_int64()
             N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
@@ -210,6 +244,24 @@ def main():
 
     timers = read_timers()
     N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
+    # Disclosed second figure, AFTER the timed region: the same loop as one long call (2000 rounds),
+    # i.e. without the per-call fixed cost and the first-window bubble a 20-round call carries.  Not
+    # `value` — the driver's line stays the K rounds it asked for.
+    steady = None
+    if world == 1 and args.steps < 1000 and args.timing_level <= 1:
+        gc.disable()
+        pl._training_rounds = 2000
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        rep2 = agent.learn()
+        torch.cuda.synchronize(dev)
+        dt2 = time.perf_counter() - t1
+        gc.enable()
+        assert len(rep2["loss"]) == 2000 and all(x == x for x in rep2["loss"])
+        steady = {"rounds": 2000, "value": B * 2000 / dt2, "unit": "transitions/s",
+                  "ms_per_step": 1e3 * dt2 / 2000,
+                  "step_frac": FLOP_PER_TRANSITION_STEP * B * 2000 / dt2 / PEAK_F32_MFMA,
+                  "note": "one 2000-round learn() call run after the timed region (not `value`)"}
 
     if rank == 0:
         value = B * args.steps * world / dt
@@ -269,6 +321,22 @@ def main():
             line["roofline"]["step"] = {"achieved": step_rate / 1e12,
                                         "frac": step_rate / PEAK_F32_MFMA,
                                         "flop_per_transition": FLOP_PER_TRANSITION_STEP}
+        gt = timers.get("gather") or timers.get("gather_nox")
+        if gt and "roofline" in line:
+            # The sample + gather (+ one-hot) kernel that replaces tensor_based_replay_buffer.py:253-400:
+            # HBM-bound.  Algorithmic bytes per transition of the timed launches (what the launch must
+            # move: SURVEY.md §8d's 2 132 B = rows read + learner views written, plus the per-row
+            # action table / mask when the arena's rows do not share one): see gather_bytes().
+            with_x = "gather" in timers
+            per_tr = gather_bytes(with_x, tables=not bool(getattr(rb, "shared_action_table", False)))
+            per_launch = gt["units"] / gt["n"]
+            gbs = per_tr * per_launch / (gt["avg_us"] * 1e-6) / 1e9
+            line["roofline"]["gather"] = {
+                "bound": "hbm", "kernel": "gather_kernel (window gather of the learn loop, side stream)",
+                "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "bytes_per_transition": per_tr, "transitions_per_launch": per_launch,
+                "avg_launch_us": gt["avg_us"], "launches_timed": gt["n"],
+                "writes_x": with_x, "source": "timed region"}
         if len(timers) > 1:
             line["stage_us"] = {k: round(v["avg_us"], 2) for k, v in timers.items()}
             line["stage_units"] = {k: v["units"] / v["n"] for k, v in timers.items() if v["units"]}
@@ -284,8 +352,12 @@ def main():
                 info["ranks_observed"] = n_seen.value
             info["allreduce_floats_per_round"] = int(pl._native.flat["grad"].numel())
             line["comm"] = info
+        if steady is not None:
+            line["steady_state"] = steady
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+            # the real reference when it is staged (oracle/_ref), the reference-pinned port otherwise
+            base = reference_cpu_baseline()
+            line["cpu_baseline"] = base if base is not None else cpu_baseline()
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -148,6 +148,11 @@ int64_t pa_arena_capacity(const pa_arena* a);
 int64_t pa_arena_head(const pa_arena* a);
 /* ReplayBuffer.clear (:287-288) */
 int pa_arena_clear(pa_arena* a);
+/* 1 when every row stored so far carries the SAME padded next-action table and mask — what
+ * create_action_tensor_and_mask (tensor_based_replay_buffer.py:179-251) produces for a static
+ * action space; tracked on push / push_many, reset by clear.  pa_dqn_learn then feeds the target
+ * pass one broadcast table (stride 0) and the window gather skips the (B, A, rep) rows. */
+int32_t pa_arena_shared_next_table(const pa_arena* a);
 /* Parity mode of sample() (:253-282): caller supplies the B logical indices it
  * drew with random.sample(range(len), B) (host pointer, int64).  Returns
  * PA_ERR_VALUE if B > len.  idx_dev_scratch: device int64[B] scratch. */

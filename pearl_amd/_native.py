@@ -311,6 +311,7 @@ SIGNATURES = {
     "pa_arena_capacity": (C.c_int64, [_P]),
     "pa_arena_head": (C.c_int64, [_P]),
     "pa_arena_clear": (C.c_int, [_P]),
+    "pa_arena_shared_next_table": (C.c_int32, [_P]),
     "pa_arena_gather": (C.c_int, [_P, _P, C.c_int32, C.POINTER(BatchOut), _P, _P]),
     "pa_arena_gather_device": (C.c_int, [_P, _P, C.c_int32, C.POINTER(BatchOut), _P]),
     "pa_arena_sample": (C.c_int, [_P, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(BatchOut), _P, _P]),

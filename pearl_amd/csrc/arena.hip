@@ -658,6 +658,15 @@ extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {
     pa_arena_destroy(a);
     return PA_ERR_HIP;
   }
+  if (desc->max_actions > 0) {
+    a->sh_next_avail = static_cast<float*>(calloc((size_t)desc->max_actions * desc->avail_dim, 4));
+    a->sh_next_mask = static_cast<uint8_t*>(calloc((size_t)desc->max_actions, 1));
+    if (!a->sh_next_avail || !a->sh_next_mask) {
+      set_error("out of host memory");
+      pa_arena_destroy(a);
+      return PA_ERR_NOMEM;
+    }
+  }
   *out = a;
   return PA_OK;
 }
@@ -673,6 +682,8 @@ extern "C" int pa_arena_destroy(pa_arena* a) {
     if (p) (void)hipFree(p);
   if (a->stage_host) (void)hipHostFree(a->stage_host);
   if (a->stage_done) (void)hipEventDestroy(a->stage_done);
+  free(a->sh_next_avail);
+  free(a->sh_next_mask);
   delete a;
   return PA_OK;
 }
@@ -686,7 +697,28 @@ extern "C" int pa_arena_clear(pa_arena* a) {
   a->head = 0;
   a->size = 0;
   a->staged = 0;
+  a->shared_next = 0;
   return PA_OK;
+}
+
+// Track whether every stored row shares one next-action table (host pointers).
+static void note_next_table(pa_arena* a, const float* next_avail, const uint8_t* next_mask) {
+  const pa_arena_desc& d = a->d;
+  if (d.max_actions <= 0 || a->shared_next == 2) return;
+  const size_t av = (size_t)d.max_actions * d.avail_dim * 4, mk = (size_t)d.max_actions;
+  if (a->shared_next == 0) {
+    memcpy(a->sh_next_avail, next_avail, av);
+    memcpy(a->sh_next_mask, next_mask, mk);
+    a->shared_next = 1;
+    a->shared_gen += 1;
+  } else if (memcmp(a->sh_next_avail, next_avail, av) != 0 ||
+             memcmp(a->sh_next_mask, next_mask, mk) != 0) {
+    a->shared_next = 2;
+  }
+}
+
+extern "C" int32_t pa_arena_shared_next_table(const pa_arena* a) {
+  return (a && a->shared_next == 1) ? 1 : 0;
 }
 
 extern "C" int pa_arena_push(pa_arena* a, const pa_transition* t) {
@@ -723,6 +755,7 @@ extern "C" int pa_arena_push(pa_arena* a, const pa_transition* t) {
     memcpy(row + a->off_next_avail, t->next_avail, av);
     memcpy(row + a->off_curr_mask, t->curr_mask, (size_t)d.max_actions);
     memcpy(row + a->off_next_mask, t->next_mask, (size_t)d.max_actions);
+    note_next_table(a, t->next_avail, t->next_mask);
   }
   a->staged += 1;
   ring_advance(a, 1);
@@ -789,6 +822,25 @@ extern "C" int pa_arena_push_many_device(pa_arena* a, int64_t n, const pa_column
     sc.next_avail = cols->next_avail + k * d.max_actions * d.avail_dim;
     sc.curr_mask = cols->curr_mask + k * d.max_actions;
     sc.next_mask = cols->next_mask + k * d.max_actions;
+  }
+  if (d.max_actions > 0 && a->shared_next != 2) {
+    if (cols->avail_bcast) {
+      // one table for the whole ingest: fetch its 80-odd bytes and compare / adopt (a bulk
+      // ingest can afford one small synchronous copy)
+      const size_t av = (size_t)d.max_actions * d.avail_dim * 4;
+      float* tab = static_cast<float*>(malloc(av));
+      uint8_t* msk = static_cast<uint8_t*>(malloc((size_t)d.max_actions));
+      bool ok = tab && msk;
+      if (ok) ok = hipMemcpy(tab, cols->next_avail, av, hipMemcpyDeviceToHost) == hipSuccess &&
+                   hipMemcpy(msk, cols->next_mask, (size_t)d.max_actions, hipMemcpyDeviceToHost) ==
+                       hipSuccess;
+      if (ok) note_next_table(a, tab, msk);
+      else a->shared_next = 2;
+      free(tab);
+      free(msk);
+    } else {
+      a->shared_next = 2;   // per-row tables on the device: not inspected
+    }
   }
   // account for the skipped rows exactly as successive appends would
   ring_advance(a, skip);

@@ -97,6 +97,15 @@ struct pa_arena {
   bool stage_busy;         // the pinned ring may still be read by that copy
   hipStream_t ingest_stream;  // stream of the last ingest
   bool has_ingest;
+  // "every stored row carries the same padded next-action table + mask" (a static action space:
+  // tensor_based_replay_buffer.py:179-251 builds the same (A, action_dim) table for every push).
+  // 0: no row seen yet, 1: shared (host copies below), 2: rows differ / unknown (per-row device
+  // ingest).  The DQN learn loop then hands the target kernel ONE table with stride 0 instead of
+  // materialising (B, A, A) one-hot rows per window (pa_dqn_learn).
+  int shared_next;
+  int shared_gen;             // bumped whenever the shared table is (re)set
+  float* sh_next_avail;       // [max_actions * avail_dim] host
+  uint8_t* sh_next_mask;      // [max_actions] host
 };
 
 namespace pa {

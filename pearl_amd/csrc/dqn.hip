@@ -91,6 +91,13 @@ struct pa_dqn {
   // CU partition of the overlapped loop: the persistent target kernel stays off `n_reserved` CUs
   uint8_t* reserved_dev;   // [kCuKeys] or null (no partition)
   int n_reserved, ncu;
+  // the arena's shared next-action table as the target kernel reads it: rep(table) [A][AD] and the
+  // mask [A], rebuilt on the host when (arena, generation, representation) change
+  float* sh_rep;           // device
+  uint8_t* sh_mask;        // device
+  uint8_t* sh_stage;       // pinned host staging for both
+  const pa_arena* sh_arena;
+  int sh_gen, sh_onehot, sh_A, sh_enable;
   int* tile_ctr;           // [kTileCtrs] work-stealing counters, one per persistent launch
   int ctr_next;
   int pingpong;            // PEARL_AMD_PINGPONG: 1 (default) target_pp_kernel for the persistent
@@ -773,6 +780,37 @@ int ensure_side(pa_dqn* h) {
 }
 
 
+// rep(shared next-action table) [A][AD] + mask [A] on the device, for TargetArgs.feat with stride 0.
+// one-hot: rep[i][j] = (j == (long)table[i][0])  (one_hot_action_representation_module.py:27-34 on the
+// padded table of tensor_based_replay_buffer.py:179-251); identity: rep = table.
+int ensure_shared_table(pa_dqn* h, const pa_arena* arena, int rep_onehot, hipStream_t s) {
+  const pa_dqn_desc& d = h->d;
+  const int A = arena->d.max_actions, AD = d.action_dim, avd = arena->d.avail_dim;
+  if (h->sh_arena == arena && h->sh_gen == arena->shared_gen && h->sh_onehot == rep_onehot &&
+      h->sh_A == A)
+    return PA_OK;
+  const size_t rep_bytes = (size_t)d.max_actions * AD * 4, mask_bytes = (size_t)d.max_actions;
+  if (!h->sh_rep) {
+    PA_HIP(hipMalloc((void**)&h->sh_rep, rep_bytes));
+    PA_HIP(hipMalloc((void**)&h->sh_mask, (mask_bytes + 15) & ~size_t(15)));
+    PA_HIP(hipHostMalloc((void**)&h->sh_stage, rep_bytes + mask_bytes, hipHostMallocDefault));
+  } else {
+    PA_HIP(hipStreamSynchronize(s));   // an earlier copy out of the staging buffer may be in flight
+    if (h->side) PA_HIP(hipStreamSynchronize(h->side));
+  }
+  float* rep = reinterpret_cast<float*>(h->sh_stage);
+  for (int i = 0; i < A; ++i)
+    for (int j = 0; j < AD; ++j) {
+      if (rep_onehot) rep[i * AD + j] = ((long long)arena->sh_next_avail[(size_t)i * avd] == j) ? 1.f : 0.f;
+      else rep[i * AD + j] = arena->sh_next_avail[(size_t)i * avd + j];
+    }
+  memcpy(h->sh_stage + rep_bytes, arena->sh_next_mask, (size_t)A);
+  PA_HIP(hipMemcpyAsync(h->sh_rep, rep, (size_t)A * AD * 4, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemcpyAsync(h->sh_mask, h->sh_stage + rep_bytes, (size_t)A, hipMemcpyHostToDevice, s));
+  h->sh_arena = arena; h->sh_gen = arena->shared_gen; h->sh_onehot = rep_onehot; h->sh_A = A;
+  return PA_OK;
+}
+
 int ensure_idx(pa_dqn* h, int64_t n) {
   if (h->idx_cap >= n) return PA_OK;
   // grow geometrically with a floor of 256 rounds: a reallocation is a device synchronisation
@@ -866,6 +904,9 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->ncu = 0;
   h->tile_ctr = nullptr;
   h->ctr_next = 0;
+  h->sh_rep = nullptr; h->sh_mask = nullptr; h->sh_stage = nullptr;
+  h->sh_arena = nullptr; h->sh_gen = -1; h->sh_onehot = -1; h->sh_A = 0;
+  h->sh_enable = env_int("PEARL_AMD_SHARED_TABLE", 1);
   h->prof_row = h->prof_dw = nullptr;
   h->prof_tgt = nullptr;
   h->prof_tgt_tiles = 0;
@@ -945,6 +986,9 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->err_host) (void)hipHostFree(h->err_host);
+  if (h->sh_stage) (void)hipHostFree(h->sh_stage);
+  if (h->sh_rep) (void)hipFree(h->sh_rep);
+  if (h->sh_mask) (void)hipFree(h->sh_mask);
   free_batchbufs(h);
   if (h->side) (void)hipStreamDestroy(h->side);
   hipEvent_t evs[] = {h->ev_start, h->ev_tail, h->ev_chain[0], h->ev_chain[1], h->ev_gather[0],
@@ -1082,6 +1126,16 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   PA_HIP(hipMemsetAsync(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int), s));
   h->ctr_next = 0;
   h->err_host[0] = 0;
+  // Static action space: every stored row carries the same padded next-action table, so the
+  // target pass reads ONE [A, AD] table with stride 0 and the window gather neither reads the
+  // per-row tables nor writes (rows, A, AD) one-hot rows (1 120 B less per transition on the
+  // gather, 1 040 B less read per transition by the target kernel).  Same values: bit-identical.
+  const bool shared_tab = h->sh_enable && arena->shared_next == 1 &&
+                          (args->rep_onehot ? arena->d.avail_dim == 1 : arena->d.avail_dim == d.action_dim);
+  if (shared_tab) {
+    rc = ensure_shared_table(h, arena, args->rep_onehot, s);   // ordered before the hop to `t` below
+    if (rc != PA_OK) return rc;
+  }
   hipStream_t t = overlap ? h->side : s;
   ScopedTimer tm_all(h, "learn", s);
   // ---- the index lists of EVERY round in one go (they do not depend on the parameters)
@@ -1141,13 +1195,17 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     const int p = k & 1;
     const pa_dqn::BatchBuf& bb = h->bb[p];
     if (h->timing) h->tick++;
+    // level-1 timers: every 4th window of a long call, every window (and every target launch) of
+    // a short one, so that even the driver's 20-round call carries >= 4 sampled launches
+    const bool short_call = R < 100;
+    const bool sample_w = short_call || (k % 4) == 0;
     // ---- side stream: target inputs of the window
     {
       pa_batch_out o;
       memset(&o, 0, sizeof(o));
       o.next_state = bb.next_state;
-      o.next_avail_rep = bb.next_avail_rep;
-      o.next_mask = bb.next_mask;
+      o.next_avail_rep = shared_tab ? nullptr : bb.next_avail_rep;
+      o.next_mask = shared_tab ? nullptr : bb.next_mask;
       o.reward_f32 = bb.reward;
       o.terminated = bb.term;
       o.rep_dim = d.action_dim;
@@ -1157,7 +1215,10 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // (not for the first window of a call: there the main stream gathers x itself, so that
       // its first row pass needs no cross-stream wait and is resident before the target grid)
       if (!overlap || k > 0) o.x = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
-      ScopedTimer tm(h, "gather", t, 2, 1, rows);
+      // level 1 samples the gather like the target launches (every 4th window; every window of a
+      // short call): bench.py's HBM roofline of the sample + gather kernel.  "gather_nox": the
+      // launch of a call's first window, which leaves x to the main stream.
+      ScopedTimer tm(h, o.x ? "gather" : "gather_nox", t, sample_w ? 1 : 2, 1, rows);
       rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, t);
       if (rc != PA_OK) return rc;
       if (overlap && k > 0) PA_HIP(hipEventRecord(h->ev_gather[p], t));
@@ -1208,8 +1269,14 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       b.reward = bb.reward + row0;
       b.terminated = bb.term + row0;
       b.next_state = bb.next_state + row0 * d.state_dim;
-      b.next_avail_rep = bb.next_avail_rep + row0 * A * d.action_dim;
-      b.next_mask = bb.next_mask + row0 * A;
+      if (shared_tab) {
+        b.next_avail_rep = h->sh_rep;
+        b.next_mask = h->sh_mask;
+        b.next_avail_bcast = 1;
+      } else {
+        b.next_avail_rep = bb.next_avail_rep + row0 * A * d.action_dim;
+        b.next_mask = bb.next_mask + row0 * A;
+      }
       float* Up = h->Uw[p] + row0 * d.hidden1;
       if (dbl) {
         rc = run_double_targets(h, &b, nullptr, h->yw[p] + row0, t);
@@ -1239,7 +1306,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const bool lead_p = !last && h->lead_persist && persist;
       static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
-                              nullptr, (k % 4) == 0 && last, lead_p,
+                              nullptr, sample_w && (last || short_call), lead_p,
                               (prio && pc == 0 && !last) ? B : 0);
       if (rc != PA_OK) return rc;
       j0 += nj;
@@ -1332,11 +1399,13 @@ extern "C" int pa_dqn_enable_timing(pa_dqn* h, int32_t on) {
   if (h->timing >= 1) {
     // the level-1 timer's events exist before the timed call starts (hipEventCreate inside it cost
     // tens of microseconds of a 20-round learn())
-    Timer* t = find_timer(h, "target");
-    while (t->ev.size() < 64) {
-      hipEvent_t e;
-      if (hipEventCreate(&e) != hipSuccess) break;
-      t->ev.push_back(e);
+    for (const char* name : {"target", "gather", "gather_nox"}) {
+      Timer* t = find_timer(h, name);
+      while (t->ev.size() < 64) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        t->ev.push_back(e);
+      }
     }
   }
   return PA_OK;

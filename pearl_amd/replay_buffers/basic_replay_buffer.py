@@ -199,6 +199,14 @@ class TensorBasedReplayBuffer(ReplayBuffer):
     def arena(self) -> Optional[HbmArena]:
         return self._arena
 
+    @property
+    def shared_action_table(self) -> bool:
+        """Every stored row carries the same padded next-action table and mask (a static action
+        space): DeepQLearning.learn then feeds the target pass ONE table instead of gathering
+        (B, A, rep) rows per window (pa_arena_shared_next_table)."""
+        return self._arena is not None and bool(
+            N.lib().pa_arena_shared_next_table(self._arena.handle))
+
     # -- push ------------------------------------------------------------------
     def _padded_tables(self, max_number_actions: int, space: Any) -> Tuple[np.ndarray, np.ndarray]:
         if space is None:

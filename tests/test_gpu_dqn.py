@@ -131,6 +131,52 @@ def test_generic_loop_equals_fused_loop(golden, name):
         assert torch.equal(pa, pb), k
 
 
+@pytest.mark.parametrize("name", ["cfg1_cartpole_shape", "cfg2_shape_small_batch",
+                                  "double:cfg2_shape_small_batch"])
+def test_shared_action_table_loop_is_bitwise_the_per_row_loop(golden, name, monkeypatch):
+    """A static action space stores the same padded next-action table in every row: the arena
+    notices (pa_arena_shared_next_table), the learn loop feeds the target pass ONE table with
+    stride 0 and its window gather skips the (rows, A, rep) one-hot rows.  Same values, same
+    arithmetic: bitwise the loop that materialises them (PEARL_AMD_SHARED_TABLE=0).  A row with
+    a different table switches the arena back for good."""
+    fx = golden(name)
+    rb = fill_arena_buffer(fx, "python")
+    assert rb.shared_action_table
+    a = make_learner(fx)
+    random.seed(4)
+    ra = a.learn(rb)
+    monkeypatch.setenv("PEARL_AMD_SHARED_TABLE", "0")
+    b = make_learner(fx)
+    random.seed(4)
+    rbr = b.learn(rb)
+    assert ra["loss"] == rbr["loss"]
+    for (k, pa), (_, pb) in zip(a._Q.state_dict().items(), b._Q.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    for (k, pa), (_, pb) in zip(a._Q_target.state_dict().items(), b._Q_target.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    monkeypatch.delenv("PEARL_AMD_SHARED_TABLE")
+    cfg, states = fx["config"], fx["states"]
+    if cfg["A"] > 1:
+        rb.push(state=states[0], action=torch.tensor([0]), reward=0.0, terminated=False,
+                truncated=False, curr_available_actions=_space(cfg["A"]), next_state=states[1],
+                next_available_actions=_space(cfg["A"] - 1), max_number_actions=cfg["A"])
+        assert not rb.shared_action_table
+        c, d = make_learner(fx), make_learner(fx)
+        random.seed(9)
+        rc = c.learn(rb)
+        from pearl_amd.policy_learners.policy_learner import PolicyLearner
+        random.seed(9)
+        rd = PolicyLearner.learn(d, rb)
+        assert rc["loss"] == rd["loss"]
+
+
+def test_dynamic_action_spaces_never_take_the_shared_table(golden):
+    rb = fill_arena_buffer(golden("tiny_dynamic"), "python")
+    assert not rb.shared_action_table
+    rb.clear()
+    assert not rb.shared_action_table      # nothing stored: nothing to share
+
+
 @pytest.mark.parametrize("name", ["tiny_dynamic", "cfg2_shape_small_batch",
                                   "double:cfg2_shape_small_batch"])
 def test_data_parallel_loop_with_one_rank_equals_fused_loop(golden, name):
