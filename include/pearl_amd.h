@@ -433,6 +433,14 @@ int pa_mlp_adam2(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, void* strea
 /* update_target_network (common/utils.py:214-226) */
 int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);
 
+/* Call after synchronising the stream a fused actor-critic step / learn loop ran on
+ * (pa_sac_step, pa_sac_learn, pa_ddpg_step, pa_ddpg_learn): PA_ERR_HIP if a bounded in-launch
+ * workgroup hand-off of that learner expired.  The step then skipped its AdamW / soft-update
+ * epilogues (parameters intact) and its reported losses are invalid.  `actor`: the learner's
+ * actor network handle.  No reference counterpart (a robustness hook of the fused kernels that
+ * replace soft_actor_critic_continuous.py:131-231 / ddpg.py:105-156). */
+int pa_ac_check(pa_mlp* actor);
+
 /* ------------------------------------------------------------------------ */
 /* One ContinuousSoftActorCritic.learn_batch as one call                      */
 /* (soft_actor_critic_continuous.py:131-231, actor_critic_base.py:309-366):   */

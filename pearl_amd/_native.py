@@ -411,6 +411,7 @@ SIGNATURES = {
     "pa_sac_twin": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P, C.c_float, C.c_int32, _P, _P, _P, _P]),
     "pa_sac_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "pa_sac_step": (C.c_int, [C.POINTER(SacStepArgs), _P]),
+    "pa_ac_check": (C.c_int, [_P]),
     "pa_ddpg_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "pa_ddpg_step": (C.c_int, [C.POINTER(DdpgStepArgs), _P]),
     "pa_sac_learn": (C.c_int, [C.POINTER(SacStepArgs), _P, C.POINTER(AcLoopArgs), _P]),

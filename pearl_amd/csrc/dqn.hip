@@ -19,6 +19,7 @@
 #include "online_kernels.hpp"
 #include "target_pp_kernel.hpp"
 #include "host_launch.hpp"
+#include "sampler.hpp"
 
 using namespace pa;
 
@@ -241,6 +242,24 @@ int stream_hop(pa_dqn* h, hipStream_t from, hipStream_t to, hipEvent_t fallback)
   hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, to, h->sig, gen, h->err_dev, h->err_host);
   PA_LAUNCH_CHECK();
   return PA_OK;
+}
+
+// The first launch of a learn() call: workgroups [0, rounds) draw the index lists of all rounds
+// (sampler.hpp), the workgroups behind them rebuild EVERY fragment-major weight copy from the
+// row-major parameters.  The two halves are independent, so the rebuild — 6 us as a launch of its
+// own — hides under the sampler's ~11 us, and learn() no longer has to guess whether somebody wrote
+// the parameters since the last call (torch's version counters miss writes through `.data`, which
+// is the reference's own update_target_network idiom, common/utils.py:214-226).
+constexpr int kPrologueRepackWgs = 48;
+static __global__ __launch_bounds__(SAMPLE_THREADS) void learn_prologue_kernel(SampleArgs sa, int rounds,
+                                                                              RepackArgs ra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long table[];
+  if ((int)blockIdx.x < rounds) {
+    sample_indices_block(sa, (int)blockIdx.x, table);
+    return;
+  }
+  repack_body(ra, (int64_t)((int)blockIdx.x - rounds) * SAMPLE_THREADS + threadIdx.x,
+              (int64_t)kPrologueRepackWgs * SAMPLE_THREADS);
 }
 
 struct NetPtrs {
@@ -1138,33 +1157,46 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   }
   hipStream_t t = overlap ? h->side : s;
   ScopedTimer tm_all(h, "learn", s);
-  // ---- the index lists of EVERY round in one go (they do not depend on the parameters)
+  // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
+  // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
+  auto due = [&](int r) { return ((args->training_steps0 + r + 2) % args->target_update_freq) == 0; };
+  // the first round's soft update runs stand-alone; later ones ride the previous optimizer launch
+  if (due(0)) {
+    rc = run_soft_update(h, s);
+    if (rc != PA_OK) return rc;
+  }
+  // ---- the index lists of EVERY round in one go (they do not depend on the parameters), and
+  // every packed weight copy rebuilt from the parameters as they are NOW (learn_prologue_kernel)
+  RepackArgs rpk;
+  memset(&rpk, 0, sizeof(rpk));
+  rpk.q = h->bufs.q; rpk.q_target = h->bufs.q_target;
+  rpk.off_w1 = h->off[0]; rpk.off_w2 = h->off[2];
+  rpk.IN = h->IN; rpk.H1 = d.hidden1; rpk.H2 = d.hidden2;
+  rpk.pk = packed(h);
+  rpk.do_online = 1; rpk.do_target = 1;
   if (args->idx_host) {
     for (int64_t i = 0; i < (int64_t)R * B; ++i)
       PA_REQUIRE(args->idx_host[i] >= 0 && args->idx_host[i] < arena->size, PA_ERR_INVALID,
                  "index %lld out of range [0, %lld)", (long long)args->idx_host[i],
                  (long long)arena->size);
     PA_HIP(hipMemcpyAsync(h->idx_all, args->idx_host, (size_t)R * B * 8, hipMemcpyHostToDevice, s));
+    rc = run_repack(h, true, true, s);
+    if (rc != PA_OK) return rc;
   } else {
     ScopedTimer tm(h, "sample", s);
-    rc = sample_indices_launch(arena->size, args->seed, args->offset0, B, R, h->idx_all, s);
+    rc = sample_check(arena->size, B);
     if (rc != PA_OK) return rc;
-  }
-  // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
-  // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
-  auto due = [&](int r) { return ((args->training_steps0 + r + 2) % args->target_update_freq) == 0; };
-  // the first round's soft update runs stand-alone; later ones ride the previous optimizer launch
-  bool stale_target = !h->packed_ok;
-  if (due(0)) {
-    rc = run_soft_update(h, s);
-    if (rc != PA_OK) return rc;
-    stale_target = true;
-  }
-  // back-to-back learn() calls: the previous call's optimizer epilogues left the packed copies
-  // current (6 us on the critical path of every call otherwise)
-  if (!h->packed_ok || stale_target) {
-    rc = run_repack(h, !h->packed_ok, stale_target, s);
-    if (rc != PA_OK) return rc;
+    const SampleArgs sa = sample_args(arena->size, args->seed, args->offset0, B, h->idx_all);
+    static size_t configured = 0;
+    const size_t smem = sample_smem_bytes(sa.hs);
+    if (smem > configured) {
+      rc = set_max_smem(learn_prologue_kernel, smem);
+      if (rc != PA_OK) return rc;
+      configured = smem;
+    }
+    hipLaunchKernelGGL(learn_prologue_kernel, dim3((unsigned)(R + kPrologueRepackWgs)),
+                       dim3(SAMPLE_THREADS), smem, s, sa, R, rpk);
+    PA_LAUNCH_CHECK();
   }
   h->packed_ok = false;   // until this call has completed its last round
   if (overlap) {

@@ -831,6 +831,10 @@ struct AdamFuse {
   // (the previous launch on this stream); the loss workgroup hands the words back to the producer
   // by restoring the pending tag (see consume_y / publish_y)
   unsigned* y_restore; int n_restore;
+  // optional device word: non-zero = an in-launch hand-off upstream of these gradients expired
+  // (sac_rows.hpp helper workgroups), the operands hold pending tags -> form the gradients but do
+  // NOT step the optimizer or touch the target network with them
+  const int* guard;
 };
 
 struct DwProblem {
@@ -1110,6 +1114,9 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
+  // (a local, not a write to the by-value argument: that would copy the whole struct to scratch)
+  const bool adam_on = a.ad.enabled && !(a.ad.guard && __hip_atomic_load(a.ad.guard, __ATOMIC_RELAXED,
+                                                                         __HIP_MEMORY_SCOPE_AGENT) != 0);
   const int c = lane & 15, q = lane >> 4;
   int pi = 0;
 #pragma unroll
@@ -1155,7 +1162,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
       for (int w = 1; w < 16; ++w) g += part[w * 32 + tid];
       float* dst = P.dW + col;
       *dst = g;
-      if (a.ad.enabled) {
+      if (adam_on) {
         if (P.kind == 3) adam_generic_weight(a.ad, st, tgt, P, dst - gbase, 0, col, g);
         else adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, 0, col, g);
       }
@@ -1165,7 +1172,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
       for (int w = 1; w < 16; ++w) g += csum[w];
       P.db[0] = g;
-      if (a.ad.enabled && !P.bias_frozen) {
+      if (adam_on && !P.bias_frozen) {
         if (P.kind == 3) adam_generic_bias(a.ad, st, tgt, P.db - gbase, g);
         else adam_fused_bias(a.ad, P.db - a.ad.grad_base, g);
       }
@@ -1206,7 +1213,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   float4 p4, m4, v4, x4;
   p4 = m4 = v4 = x4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto prefetch_state = [&]() {
-    if (evec && a.ad.enabled) {
+    if (evec && adam_on) {
       p4 = *reinterpret_cast<const float4*>(st.p + eflat);
       m4 = *reinterpret_cast<const float4*>(st.m + eflat);
       v4 = *reinterpret_cast<const float4*>(st.v + eflat);
@@ -1312,7 +1319,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
     if (evec) {
       *reinterpret_cast<float4*>(P.dW + (int64_t)erow * P.ldw + ecol) =
           make_float4(g4[0], g4[1], g4[2], g4[3]);
-      if (a.ad.enabled) {
+      if (adam_on) {
         float pv[4] = {p4.x, p4.y, p4.z, p4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w};
         float vv[4] = {v4.x, v4.y, v4.z, v4.w}, xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
@@ -1357,7 +1364,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
         if (ecol + e < P.N) {
           float* dst = P.dW + (int64_t)erow * P.ldw + ecol + e;
           *dst = g4[e];
-          if (a.ad.enabled) {
+          if (adam_on) {
             if (P.kind == 3)
               adam_generic_weight(a.ad, st, tgt, P, dst - gbase, erow, ecol + e, g4[e]);
             else
@@ -1372,7 +1379,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
 #pragma unroll
     for (int w = 1; w < 8; ++w) s += csum[w * DW_TM + tid];
     P.db[i0 + tid] = s;
-    if (a.ad.enabled && !P.bias_frozen) {
+    if (adam_on && !P.bias_frozen) {
       if (P.kind == 3) adam_generic_bias(a.ad, st, tgt, (P.db + i0 + tid) - gbase, s);
       else adam_fused_bias(a.ad, (P.db + i0 + tid) - a.ad.grad_base, s);
     }

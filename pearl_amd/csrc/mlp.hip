@@ -92,6 +92,7 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   if (h->qa_w2f) (void)hipFree(h->qa_w2f);
   if (h->qa_u) (void)hipFree(h->qa_u);
+  if (h->aux && h->aux_free) h->aux_free(h->aux);
   for (int l = 0; l < PA_MLP_MAX_LAYERS; ++l) {
     if (h->wf[l]) (void)hipFree(h->wf[l]);
     if (h->wtf[l]) (void)hipFree(h->wtf[l]);
@@ -447,6 +448,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
     a.B = B;
     if (adam_step > 0) {
       a.ad.enabled = 1;
+      a.ad.guard = h0->adam_guard ? h0->adam_guard : (nnet > 1 ? hs[1]->adam_guard : nullptr);
       a.ad.c = adam_scalars(h0->d, adam_step);
       a.ad.st.p = h0->bufs.p; a.ad.st.m = h0->bufs.exp_avg; a.ad.st.v = h0->bufs.exp_avg_sq;
       a.ad.st.vmax = h0->bufs.max_exp_avg_sq;

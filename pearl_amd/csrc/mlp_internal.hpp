@@ -36,6 +36,13 @@ struct pa_mlp {
     const float* dzs[PA_MLP_MAX_LAYERS];
     int ldzs[PA_MLP_MAX_LAYERS];
   } pend;
+  // set by a fused learner step whose rows exchange data between workgroups of one launch
+  // (sac_step.hip): the device error word of that exchange; pa_mlp_adam hands it to the
+  // weight-gradient kernel, which then leaves the optimizer alone (AdamFuse::guard)
+  const int* adam_guard;
+  // per-network state owned by such a step (its exchange buffers), released with the network
+  void* aux;
+  void (*aux_free)(void*);
 };
 
 namespace pa {

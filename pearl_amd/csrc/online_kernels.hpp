@@ -60,9 +60,9 @@ struct RepackArgs {
   int do_online, do_target;
 };
 
-static __global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a) {
-  const int64_t gsz = (int64_t)gridDim.x * 256;
-  const int64_t t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// thread t0 of gsz cooperating threads (any grid shape: the learn loop's prologue launch runs this
+// body in the workgroups behind its sampler blocks)
+__device__ __forceinline__ void repack_body(const RepackArgs& a, int64_t t0, int64_t gsz) {
   if (a.do_online) {
     {  // W1f
       const int nkg = wf16_nkg(a.IN);
@@ -133,6 +133,10 @@ static __global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a)
       reinterpret_cast<float4*>(a.pk.tW2f)[e] = v;
     }
   }
+}
+
+static __global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a) {
+  repack_body(a, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
 // ---- the row pass ---------------------------------------------------------------------------

@@ -162,7 +162,8 @@ int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
   return PA_OK;
 }
 
-// The split launch's exchange words (sac_rows.hpp, SacRowsAArgs::split): one buffer per process,
+// The split launch's exchange words (sac_rows.hpp, SacRowsAArgs::split): one buffer set PER LEARNER
+// (owned by its actor network, released with it — two learners on two streams never share words),
 // pre-filled with the pending tag; readers restore the tag, so a step leaves it as it found it.
 struct Exchange {
   float* xact = nullptr;
@@ -170,28 +171,63 @@ struct Exchange {
   int* err = nullptr;
   int* err_host = nullptr;
   int cap = 0;
-} g_xch;
-int exchange(int tiles, hipStream_t s) {
-  if (!g_xch.err) {
-    PA_HIP(hipMalloc((void**)&g_xch.err, 16));
-    PA_HIP(hipMemset(g_xch.err, 0, 16));
-    PA_HIP(hipHostMalloc((void**)&g_xch.err_host, 16, hipHostMallocDefault));
-    g_xch.err_host[0] = 0;
+};
+void exchange_free(void* p) {
+  Exchange* x = static_cast<Exchange*>(p);
+  if (!x) return;
+  if (x->xact) (void)hipFree(x->xact);
+  if (x->err) (void)hipFree(x->err);
+  if (x->err_host) (void)hipHostFree(x->err_host);
+  delete x;
+}
+int exchange(pa_mlp* owner, int tiles, hipStream_t s, Exchange** out) {
+  Exchange* x = static_cast<Exchange*>(owner->aux);
+  if (!x) {
+    x = new (std::nothrow) Exchange();
+    PA_REQUIRE(x, PA_ERR_NOMEM, "out of host memory");
+    owner->aux = x;
+    owner->aux_free = exchange_free;
   }
-  if (tiles > g_xch.cap) {
-    if (g_xch.xact) {
+  if (!x->err) {
+    PA_HIP(hipMalloc((void**)&x->err, 16));
+    PA_HIP(hipMemset(x->err, 0, 16));
+    PA_HIP(hipHostMalloc((void**)&x->err_host, 16, hipHostMallocDefault));
+    x->err_host[0] = 0;
+  }
+  if (tiles > x->cap) {
+    if (x->xact) {
       PA_HIP(hipDeviceSynchronize());
-      (void)hipFree(g_xch.xact);
-      g_xch.xact = nullptr;
+      (void)hipFree(x->xact);
+      x->xact = nullptr;
     }
     const int n = tiles * 2;
     const size_t words = (size_t)n * (SR_XACT + SR_XRES);
-    PA_HIP(hipMalloc((void**)&g_xch.xact, words * sizeof(float)));
-    PA_HIP(hipMemsetD32Async((hipDeviceptr_t)g_xch.xact, (int)kYPendingBits, words, s));
-    g_xch.xres = g_xch.xact + (size_t)n * SR_XACT;
-    g_xch.cap = n;
+    PA_HIP(hipMalloc((void**)&x->xact, words * sizeof(float)));
+    PA_HIP(hipMemsetD32Async((hipDeviceptr_t)x->xact, (int)kYPendingBits, words, s));
+    x->xres = x->xact + (size_t)n * SR_XACT;
+    x->cap = n;
   }
+  *out = x;
   return PA_OK;
+}
+// Workgroups of a split launch wait for each other, so ALL of them must be resident at once: the
+// bound is what THIS device (a partition, a CU-masked queue's parent) offers — its compute-unit
+// count, one row workgroup per CU (their LDS and 8 waves x >128 VGPRs admit no second) — not a
+// constant.  PEARL_AMD_SPLIT_MAX_WGS lowers it for processes that share the GPU with other work.
+int resident_row_wgs(int device) {
+  static int cached_dev = -1, cached = 0;
+  if (cached_dev != device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    cached = prop.multiProcessorCount;
+    const char* v = getenv("PEARL_AMD_SPLIT_MAX_WGS");
+    if (v && *v && atoi(v) < cached) cached = atoi(v);
+    cached_dev = device;
+  }
+  return cached;
 }
 bool split_enabled() {
   const char* v = getenv("PEARL_AMD_SAC_SPLIT");     // read per call: tests compare the forms
@@ -310,13 +346,19 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   ra.prof = g_prof_a;
   // the second critic of the actor loss in a helper workgroup, while every workgroup of the launch
   // is resident at once (a waiting workgroup must never keep its partner off the chip)
-  if (split_enabled() && 4 * tiles <= 256 && A <= 16) {
-    PA_TRY(exchange(tiles, s));
-    PA_REQUIRE(g_xch.err_host[0] == 0, PA_ERR_HIP,
-               "an earlier SAC step's workgroup hand-off expired (code %d)", g_xch.err_host[0]);
+  Exchange* xch = nullptr;
+  ac->adam_guard = c1->adam_guard = c2->adam_guard = nullptr;
+  if (split_enabled() && 4 * tiles <= resident_row_wgs(ac->d.device) && A <= 16) {
+    PA_TRY(exchange(ac, tiles, s, &xch));
+    PA_REQUIRE(xch->err_host[0] == 0, PA_ERR_HIP,
+               "an earlier SAC step's workgroup hand-off expired (code %d): the parameters were "
+               "left untouched by that step; re-create the learner", xch->err_host[0]);
     ra.split = 1;
-    ra.xact = g_xch.xact; ra.xres = g_xch.xres;
-    ra.err = g_xch.err; ra.err_host = g_xch.err_host;
+    ra.xact = xch->xact; ra.xres = xch->xres;
+    ra.err = xch->err; ra.err_host = xch->err_host;
+    // an expired hand-off leaves pending tags (NaNs) in the gradients: the optimizer launches of
+    // this step then skip AdamW and the soft update (AdamFuse::guard)
+    ac->adam_guard = c1->adam_guard = c2->adam_guard = xch->err;
   }
   // instantiations: every loop unrolled (hidden 256, S = 49..64, S + A = 65..80: the benchmark
   // shape), hidden layers unrolled only, all run-time
@@ -353,8 +395,8 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   rb.tk = tb;
   rb.prof = g_prof_b;
   if (ra.split) {
-    rb.xact = g_xch.xact; rb.xres = g_xch.xres;
-    rb.err = g_xch.err; rb.err_host = g_xch.err_host;
+    rb.xact = xch->xact; rb.xres = xch->xres;
+    rb.err = xch->err; rb.err_host = xch->err_host;
   }
   if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][2], s));
   PA_TRY((form == 2   ? launch_rows<16, 4, 5>(nullptr, &rb, W, s)
@@ -389,7 +431,9 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   if (mlp_pair_fusable(c1, c2, true)) {
     // both critics' weight gradients, AdamW, soft target updates AND the step's scalar tail (one
     // extra workgroup): one launch
-    return mlp_adam_pair(c1, c2, a->critic_step, a->tau, s, &tj);
+    const int rc_pair = mlp_adam_pair(c1, c2, a->critic_step, a->tau, s, &tj);
+    ac->adam_guard = c1->adam_guard = c2->adam_guard = nullptr;   // (see the end of this function)
+    return rc_pair;
   }
   PA_TRY(pa_mlp_adam(c1, a->critic_step, s));
   PA_TRY(pa_mlp_adam(c2, a->critic_step, s));
@@ -404,6 +448,9 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   fa.alpha_loss_out = tj.alpha_loss_out;
   hipLaunchKernelGGL(sac_finish_kernel, dim3(1), dim3(256), 0, s, fa);
   PA_LAUNCH_CHECK();
+  // the launches above hold the guard by value; the networks must not keep a pointer into
+  // another network's exchange (they may be destroyed in any order)
+  ac->adam_guard = c1->adam_guard = c2->adam_guard = nullptr;
   return PA_OK;
 }
 
@@ -651,12 +698,16 @@ int ddpg_fused_step(const pa_ddpg_step_args* a, hipStream_t s) {
   rb.B = B; rb.S = S; rb.A = A;
   rb.tk = tb;
   // the second target critic in a helper workgroup (every workgroup of the launch resident at once)
-  if (split_enabled() && 2 * tiles <= 256 && A <= 16) {
-    PA_TRY(exchange(tiles, s));
-    PA_REQUIRE(g_xch.err_host[0] == 0, PA_ERR_HIP,
-               "an earlier step's workgroup hand-off expired (code %d)", g_xch.err_host[0]);
-    rb.xact = g_xch.xact; rb.xres = g_xch.xres;
-    rb.err = g_xch.err; rb.err_host = g_xch.err_host;
+  ac->adam_guard = c1->adam_guard = c2->adam_guard = nullptr;
+  if (split_enabled() && 2 * tiles <= resident_row_wgs(ac->d.device) && A <= 16) {
+    Exchange* xch = nullptr;
+    PA_TRY(exchange(ac, tiles, s, &xch));
+    PA_REQUIRE(xch->err_host[0] == 0, PA_ERR_HIP,
+               "an earlier step's workgroup hand-off expired (code %d): the parameters were left "
+               "untouched by that step; re-create the learner", xch->err_host[0]);
+    rb.xact = xch->xact; rb.xres = xch->xres;
+    rb.err = xch->err; rb.err_host = xch->err_host;
+    c1->adam_guard = c2->adam_guard = xch->err;
   }
   PA_TRY((form == 2   ? launch_rows_ddpg<16, 4, 5>(nullptr, &rb, W, s)
           : form == 1 ? launch_rows_ddpg<16, 0, 0>(nullptr, &rb, W, s)
@@ -693,9 +744,26 @@ int ddpg_fused_step(const pa_ddpg_step_args* a, hipStream_t s) {
     PA_LAUNCH_CHECK();
   }
   if (soft) PA_TRY(pa_mlp_soft_update(ac, a->actor_tau, s));
+  // the launches above hold the guard by value; the networks must not keep a pointer into
+  // another network's exchange (they may be destroyed in any order)
+  ac->adam_guard = c1->adam_guard = c2->adam_guard = nullptr;
   return PA_OK;
 }
 }  // namespace
+
+// After the stream the fused steps ran on has been synchronised: did a workgroup hand-off of a
+// split launch expire?  (The affected step skipped its optimizer launches' AdamW — AdamFuse::guard
+// — so the parameters are intact, but its report is not.)  `actor` = the learner's actor network.
+extern "C" int pa_ac_check(pa_mlp* actor) {
+  PA_REQUIRE(actor, PA_ERR_INVALID, "null network");
+  const Exchange* x = static_cast<const Exchange*>(actor->aux);
+  PA_REQUIRE(!x || !x->err_host || x->err_host[0] == 0, PA_ERR_HIP,
+             "a fused actor-critic step's workgroup hand-off expired (code %d): that step did not "
+             "update the parameters and its losses are invalid (is the GPU shared with other work? "
+             "PEARL_AMD_SAC_SPLIT=0 selects the unsplit kernels)",
+             x->err_host[0]);
+  return PA_OK;
+}
 
 extern "C" int64_t pa_ddpg_scratch_floats(int32_t B, int32_t S, int32_t A) {
   const int64_t x = carve_ddpg(nullptr, nullptr, B, S, A), y = carve_ddpg_fused(nullptr, nullptr, B, S, A);

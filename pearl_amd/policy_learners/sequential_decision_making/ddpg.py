@@ -285,6 +285,7 @@ class DeepDeterministicPolicyGradient(ActorCriticBase):
         replay_buffer._presampled = (plan["lists"], rounds, len(replay_buffer))   # all consumed
         replay_buffer._last_idx = plan["lists"][rounds - 1]
         torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        N.check(N.lib().pa_ac_check(actor.handle))             # a split launch's hand-off expired?
         got = [losses[:, k].tolist() for k in range(2)]     # per key: one list of floats
         return self._loop_report(got, step0, freq)
 

@@ -393,6 +393,7 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         replay_buffer._last_idx = plan["lists"][rounds - 1]
         self._action_batch_log_prob_cache = logp
         torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        N.check(N.lib().pa_ac_check(actor.handle))             # a split launch's hand-off expired?
         got = [losses[:, k].tolist() for k in range(3)]     # per key: one list of floats
         report: Dict[str, List[Any]] = {"actor_loss": got[0], "critic_loss": got[1]}
         if self._entropy_autotune:
