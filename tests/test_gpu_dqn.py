@@ -170,6 +170,36 @@ def test_shared_action_table_loop_is_bitwise_the_per_row_loop(golden, name, monk
         assert rc["loss"] == rd["loss"]
 
 
+def test_parameters_written_through_dot_data_are_seen_by_the_next_learn(golden):
+    """`p.data.copy_()` / `p.data.mul_()` — the reference's own update_target_network
+    idiom (common/utils.py:214-226) — do not bump torch's version counters.  learn() rebuilds its
+    packed weight copies from the parameters at the start of EVERY call, so such writes (online
+    and target network) are honoured exactly like version-bumping in-place ops."""
+    fx = golden("cfg2_shape_small_batch")
+    rb = fill_arena_buffer(fx, "python")
+    a, b = make_learner(fx), make_learner(fx)
+    for pl in (a, b):
+        random.seed(1)
+        pl.learn(rb)                      # the packed copies are live in both learners now
+    with torch.no_grad():
+        for p in list(a._Q.parameters()) + list(a._Q_target.parameters()):
+            p.data.mul_(0.5)              # invisible to p._version
+        for p in list(b._Q.parameters()) + list(b._Q_target.parameters()):
+            p.mul_(0.5)                   # bumps p._version
+    random.seed(2)
+    ra = a.learn(rb)
+    random.seed(2)
+    rbr = b.learn(rb)
+    assert ra["loss"] == rbr["loss"]
+    for (k, pa), (_, pb) in zip(a._Q.state_dict().items(), b._Q.state_dict().items()):
+        assert torch.equal(pa, pb), k
+    c = make_learner(fx)
+    random.seed(1)
+    c.learn(rb)
+    random.seed(2)
+    assert c.learn(rb)["loss"] != ra["loss"]     # and the halving did matter
+
+
 def test_dynamic_action_spaces_never_take_the_shared_table(golden):
     rb = fill_arena_buffer(golden("tiny_dynamic"), "python")
     assert not rb.shared_action_table
