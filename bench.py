@@ -294,13 +294,17 @@ def main():
             # 4th window of the call, first window included); without a live sample (single-stream
             # loop at timing level >= 2, multi-GPU runs) the calibration pass stands in and says so
             live = "target" in timers
+            split_on = os.environ.get("PEARL_AMD_TARGET_SPLIT", "1") != "0"
             tt = timers["target"] if live else isolated
             ach, per_launch = kernel_rate(tt)
             step_rate = FLOP_PER_TRANSITION_STEP * B * args.steps / dt     # per GPU
             line["roofline"] = {"bound": "mfma",
-                                "kernel": ("target_pp_kernel<32> (persistent launch of a target-update "
-                                           "window, overlapped loop)" if live and overlapped
-                                           else "target_fused_kernel<32> (classic grid)"),
+                                "kernel": (("target_split_kernel (bf16x3 split MFMA, fp32 accuracy)"
+                                            if split_on else "target_pp_kernel<32>") +
+                                           " (persistent launch of a target-update window, "
+                                           "overlapped loop)" if live and overlapped
+                                           else ("target_split_kernel" if split_on else
+                                                 "target_fused_kernel<32>") + " (classic grid)"),
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA,
                                 "traffic": pmc_traffic(per_launch),

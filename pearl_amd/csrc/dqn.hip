@@ -47,6 +47,8 @@ struct pa_dqn {
   // workspaces (HBM)
   float *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
   float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
+  void* w2sp;  // the same matrix as bf16 split planes (target_split_kernel), H1 = H2 = 256 only
+  int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
   // Double DQN only (desc.double_q): the same copy of the ONLINE W2, the chosen next actions, and
   // the row-per-transition value pass through the target network
   float* w2f_online;
@@ -346,6 +348,8 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
   a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
   a.W2f = argmax ? h->w2f_online : h->w2f;
+  // (Double DQN's argmax pass runs on the ONLINE parameters, whose split planes are not kept)
+  a.W2sp = (argmax || !h->use_split) ? nullptr : h->w2sp;
   a.argmax = argmax;
   a.choice_rep = argmax ? h->choice_rep : nullptr;
   a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
@@ -357,7 +361,8 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.ntiles = (int)ceil_div(b->B, a.bpw);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
   if (prio_first_rows > 0) a.prio_tiles = (int)ceil_div(prio_first_rows, a.bpw);
-  const bool pp = !argmax && !no_pingpong &&
+  const bool split = a.W2sp && t_nkg(a.H1) == 32 && target_fast_shape(a, 32);
+  const bool pp = !argmax && !no_pingpong && !split &&
                   (h->pingpong == 2 || (h->pingpong == 1 && persistent));
   if (persistent || pp) {
     if (h->ctr_next >= kTileCtrs) {  // ordered after every earlier launch on this stream
@@ -378,6 +383,7 @@ int run_target_fused(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, 
 PackedW packed(pa_dqn* h) {
   PackedW pk;
   pk.W1f = h->W1f; pk.W2f = h->W2f16; pk.W2tf = h->W2tf; pk.tW2f = h->w2f;
+  pk.tW2sp = h->w2sp;
   return pk;
 }
 
@@ -420,6 +426,7 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
     a.IN = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
     a.pk = packed(h);
     a.pk.tW2f = h->w2f_online;
+    a.pk.tW2sp = nullptr;                        // the split planes stay the TARGET network's
     a.do_online = 0; a.do_target = 1;
     hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
     PA_LAUNCH_CHECK();
@@ -603,6 +610,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
     a.ad.tgt = h->bufs.q_target; a.ad.tau = d.tau;
     a.ad.one_minus_tau = (float)(1.0 - (double)d.tau);
     a.ad.tW2f = h->w2f; a.ad.nkg_t = t_nkg(d.hidden1);
+    a.ad.tW2sp = h->w2sp;
   }
   return launch_weight_grad(a, loss_out != nullptr, s);
 }
@@ -624,6 +632,7 @@ int run_adamw(pa_dqn* h, int64_t step, int soft_next, hipStream_t s) {
   a.f.soft_next = soft_next;
   a.f.tgt = h->bufs.q_target; a.f.tau = d.tau; a.f.one_minus_tau = (float)(1.0 - (double)d.tau);
   a.f.tW2f = h->w2f; a.f.nkg_t = t_nkg(d.hidden1);
+  a.f.tW2sp = h->w2sp;
   a.g = h->bufs.grad;
   a.n = h->P;
   for (int i = 0; i < 6; ++i) a.off[i] = h->off[i];
@@ -901,6 +910,8 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->H1a = h->H2a = h->dZ2 = h->dZ1 = h->nextv = h->qbuf = h->dq = h->absd =
       h->xpack = h->loss_scratch = h->w2f = h->W1f = h->W2f16 = h->W2tf = nullptr;
   h->w2f_online = h->choice_rep = nullptr;
+  h->w2sp = nullptr;
+  h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->choice = nullptr;
   h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
   h->bb_x = nullptr;
@@ -981,6 +992,11 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->xpack, B * h->IN);
   PA_WS(h->loss_scratch, 4);
   PA_WS(h->w2f, w2f_floats(desc->hidden2, desc->hidden1));
+  if (desc->hidden1 == TS_H && desc->hidden2 == TS_H) {
+    float* sp = nullptr;
+    PA_WS(sp, w2sp_bytes() / 4);
+    h->w2sp = sp;
+  }
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
@@ -1000,7 +1016,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
-                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online,
+                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp,
                   h->choice, h->choice_rep};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1227,8 +1243,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     const int p = k & 1;
     const pa_dqn::BatchBuf& bb = h->bb[p];
     if (h->timing) h->tick++;
-    // level-1 timers: every 4th window of a long call, every window (and every target launch) of
-    // a short one, so that even the driver's 20-round call carries >= 4 sampled launches
+    // level-1 timers: every 4th window of a long call, every window of a short one (the last,
+    // largest target launch of the window and its gather — neither sits on the chain's critical
+    // path), so that even the driver's 20-round call carries several sampled launches
     const bool short_call = R < 100;
     const bool sample_w = short_call || (k % 4) == 0;
     // ---- side stream: target inputs of the window
@@ -1250,7 +1267,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // level 1 samples the gather like the target launches (every 4th window; every window of a
       // short call): bench.py's HBM roofline of the sample + gather kernel.  "gather_nox": the
       // launch of a call's first window, which leaves x to the main stream.
-      ScopedTimer tm(h, o.x ? "gather" : "gather_nox", t, sample_w ? 1 : 2, 1, rows);
+      // (not the first window's of an overlapped call: that gather opens the call's critical path,
+      // and an event record costs ~6 us of idle stream)
+      ScopedTimer tm(h, o.x ? "gather" : "gather_nox", t, (sample_w && o.x) ? 1 : 2, 1, rows);
       rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, t);
       if (rc != PA_OK) return rc;
       if (overlap && k > 0) PA_HIP(hipEventRecord(h->ev_gather[p], t));
@@ -1338,7 +1357,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const bool lead_p = !last && h->lead_persist && persist;
       static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
-                              nullptr, sample_w && (last || short_call), lead_p,
+                              nullptr, sample_w && last, lead_p,
                               (prio && pc == 0 && !last) ? B : 0);
       if (rc != PA_OK) return rc;
       j0 += nj;

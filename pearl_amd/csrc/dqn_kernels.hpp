@@ -323,6 +323,8 @@ struct TargetArgs {
   const uint8_t* mask; int64_t mask_bstride;// [B][A], 1 = unavailable; may be null
   const float* W1a; int ldw1;               // W1' + S (action columns), row pitch S+AD
   const float* W2f;                         // fragment-major W2' (see w2f_index)
+  const void* W2sp;                         // optional: W2' as bf16 split planes (w2sp_index):
+                                            // target_split_kernel instead of the fp32-MFMA kernels
   const float* b2; const float* w3; const float* b3;
   const float* reward; const uint8_t* term;
   float gamma;
@@ -410,6 +412,56 @@ __host__ __device__ inline int64_t w2f_index(int n, int k, int nkg) {
 __host__ __device__ inline int64_t w2f_floats(int H2, int H1) {
   return (int64_t)((H2 + 31) / 32) * t_nkg(H1) * 256;
 }
+
+// ---- the target W2 as bf16 split planes (target_split_kernel.hpp: the layer-2 product on the bf16
+// matrix pipe at fp32 accuracy) ------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TS_H = 256;            // H1 = H2 = 256 (the FAST shape of target_tile)
+constexpr int TS_KS = TS_H / 16;     // k-steps of v_mfma_f32_32x32x16_bf16
+constexpr int TS_LDP = TS_H + 8;     // bf16 pitch of a plane row: 528 B = 4 dwords mod 64 banks
+constexpr int TS_RD = 4;             // k-steps of weights in flight per wave
+
+__host__ __device__ inline int64_t w2sp_bytes() { return (int64_t)8 * TS_KS * 3 * 64 * 16; }
+// bf16 element index of split s of W2'[n][k] in the fragment-major planes:
+//   slot ((wave * KS + kstep) * 3 + s) * 64 + lane holds the 8 bf16 that lane feeds one MFMA as its
+//   A operand: unit n = 32 wave + (lane & 31), k = 16 kstep + 8 (lane >> 5) + e
+__host__ __device__ inline int64_t w2sp_index(int n, int k, int s) {
+  const int w = n >> 5, lane = (n & 31) + 32 * ((k >> 3) & 1), g = k >> 4, e = k & 7;
+  return ((((int64_t)(w * TS_KS + g) * 3 + s) * 64) + lane) * 8 + e;
+}
+
+__host__ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;                        // round to nearest even
+  const float r = x - (float)hi;         // exact
+  mid = (__bf16)r;
+  lo = (__bf16)(r - (float)mid);         // exact difference; the last conversion is exact too
+}
+
+// four consecutive k (k % 4 == 0) of one unit: one 8-byte store per plane
+__device__ __forceinline__ void store_w2sp4(void* base, int n, int k, const float4& v) {
+  __bf16* p = static_cast<__bf16*>(base);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4 q[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __bf16 a, b, c;
+    split3(x[j], a, b, c);
+    q[0][j] = a; q[1][j] = b; q[2][j] = c;
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) *reinterpret_cast<bf16x4*>(p + w2sp_index(n, k, s)) = q[s];
+}
+__device__ __forceinline__ void store_w2sp1(void* base, int n, int k, float v) {
+  __bf16* p = static_cast<__bf16*>(base);
+  __bf16 a, b, c;
+  split3(v, a, b, c);
+  p[w2sp_index(n, k, 0)] = a;
+  p[w2sp_index(n, k, 1)] = b;
+  p[w2sp_index(n, k, 2)] = c;
+}
+
 
 static __global__ __launch_bounds__(256) void repack_w2_kernel(const float* __restrict__ W2, int H2,
                                                         int H1, float* __restrict__ W2f) {
@@ -826,6 +878,7 @@ struct AdamFuse {
   int nkg_w1, nkg_w2, nkg_w2t;
   int soft_next; float* tgt; float tau, one_minus_tau;
   float* tW2f; int nkg_t;            // target W2, 32x32x2 fragment-major
+  void* tW2sp;                       // target W2 as bf16 split planes (null: not kept)
   const float* absd; int nabs; float inv_B; float* loss_out;  // mean |Q - target| of this step
   // overlapped learn loop: the Bellman targets of this round have been consumed by the row pass
   // (the previous launch on this stream); the loss workgroup hands the words back to the producer
@@ -903,7 +956,10 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
   if (f.soft_next) {  // update_target_network (common/utils.py:214-226)
     const float t = __fadd_rn(__fmul_rn(f.tau, p), __fmul_rn(f.one_minus_tau, f.tgt[i]));
     f.tgt[i] = t;
-    if (kind == 0) f.tW2f[w2f_index(row, col, f.nkg_t)] = t;
+    if (kind == 0) {
+      f.tW2f[w2f_index(row, col, f.nkg_t)] = t;
+      if (f.tW2sp) store_w2sp1(f.tW2sp, row, col, t);
+    }
   }
 }
 // kind 3: refresh the generic engine's fragment-major copies of one weight element
@@ -1352,9 +1408,10 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
           tn.z = __fadd_rn(__fmul_rn(a.ad.tau, pv[2]), __fmul_rn(a.ad.one_minus_tau, t4.z));
           tn.w = __fadd_rn(__fmul_rn(a.ad.tau, pv[3]), __fmul_rn(a.ad.one_minus_tau, t4.w));
           *reinterpret_cast<float4*>(tgt + eflat) = tn;
-          if (P.kind == 0)
+          if (P.kind == 0) {
             *reinterpret_cast<float4*>(a.ad.tW2f + w2f_index(erow, ecol, a.ad.nkg_t)) = tn;
-          else if (P.kind == 3 && P.pkf_t)
+            if (a.ad.tW2sp) store_w2sp4(a.ad.tW2sp, erow, ecol, tn);
+          } else if (P.kind == 3 && P.pkf_t)
             *reinterpret_cast<float4*>(P.pkf_t + wf16_index_(erow, ecol, P.nkgf)) = tn;
         }
       }

@@ -2,6 +2,7 @@
 #pragma once
 #include <stdlib.h>
 #include "dqn_kernels.hpp"
+#include "target_split_kernel.hpp"
 
 namespace pa {
 namespace {
@@ -68,8 +69,26 @@ int launch_target_t(const TargetArgs& a, hipStream_t s) {
   return PA_OK;
 }
 
+// target_split_kernel: one workgroup per CU (99 KB of LDS); persistent mode offers two per CU so
+// that the ones landing on reserved CUs (and exiting) leave no other CU empty
+inline int launch_target_split(const TargetArgs& a, hipStream_t s) {
+  static bool configured = false;
+  const size_t smem = target_split_smem_bytes();
+  if (!configured) {
+    int rc = set_max_smem(target_split_kernel, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
+  if (a.tile_ctr) grid = a.reserved ? 512u : (unsigned)(a.ntiles < 256 ? a.ntiles : 256);
+  hipLaunchKernelGGL(target_split_kernel, dim3(grid), dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 // classic grid (or, with a.tile_ctr, persistent tiles) of target_fused_kernel for the shape at hand
 inline int launch_target(const TargetArgs& a, hipStream_t s) {
+  if (a.W2sp && t_nkg(a.H1) == 32 && target_fast_shape(a, 32)) return launch_target_split(a, s);
   switch (t_nkg(a.H1)) {
     case 8: return launch_target_t<8, false>(a, s);
     case 16: return launch_target_t<16, false>(a, s);

@@ -50,6 +50,7 @@ struct PackedW {
   float* W2f;    // online W2  [H2 units][H1]        (layer 2)
   float* W2tf;   // online W2^T [H1 units][H2]       (dX = dZ2 W2)
   float* tW2f;   // target W2, 32x32x2 fragment-major (target_fused_kernel)
+  void* tW2sp;   // target W2 as bf16 split planes (target_split_kernel); null: not kept
 };
 
 struct RepackArgs {
@@ -131,6 +132,9 @@ __device__ __forceinline__ void repack_body(const RepackArgs& a, int64_t t0, int
       v.z = (n < a.H2 && k + 2 < a.H1) ? W[(int64_t)n * a.H1 + k + 2] : 0.f;
       v.w = (n < a.H2 && k + 3 < a.H1) ? W[(int64_t)n * a.H1 + k + 3] : 0.f;
       reinterpret_cast<float4*>(a.pk.tW2f)[e] = v;
+      // (only whole matrices take the split kernel: H1 = H2 = 256, see target_fast_shape)
+      if (a.pk.tW2sp && n < a.H2 && k + 3 < a.H1 && a.H1 == TS_H && a.H2 == TS_H)
+        store_w2sp4(a.pk.tW2sp, n, k, v);
     }
   }
 }

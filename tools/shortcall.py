@@ -17,6 +17,7 @@ tools/rocpd_timeline.py --last-call).
 """
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import random
@@ -98,6 +99,8 @@ def main():
             torch.cuda.synchronize()
             enq["t"] = 0.0
             wall = host = 0.0
+            gc.collect()
+            gc.disable()     # like timeit: a generation-2 pass (~80 ms in a torch process) is not the call
             for _ in range(args.calls):
                 t0 = time.perf_counter()
                 agent.learn()
@@ -106,6 +109,7 @@ def main():
                 t2 = time.perf_counter()
                 host += t1 - t0
                 wall += t2 - t0
+            gc.enable()
             n = args.calls
             rows.append({"rounds": r, "wall_us": 1e6 * wall / n, "host_us": 1e6 * host / n,
                          "enqueue_us": 1e6 * enq["t"] / n, "per_round_us": 1e6 * wall / n / r,
