@@ -49,6 +49,7 @@ struct pa_dqn {
   float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
   void* w2sp;  // the same matrix as bf16 split planes (target_split_kernel), H1 = H2 = 256 only
   int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
+  int dw_tm;      // PEARL_AMD_DW_TM: rows per weight-gradient tile, 64 or 32 (0 = by the CU partition)
   // Double DQN only (desc.double_q): the same copy of the ONLINE W2, the chosen next actions, and
   // the row-per-transition value pass through the target network
   float* w2f_online;
@@ -559,6 +560,16 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   DwArgs a;
   memset(&a, 0, sizeof(a));
   a.nprob = 3;
+  // 32-row tiles (twice the workgroups, half the MFMA time each) when the chain has the CUs for
+  // them: the partition of the overlapped loop reserves at least one CU per workgroup
+  int TM = DW_TM;
+  {
+    const int tiles32 = (int)(ceil_div(d.hidden2, 32) * ceil_div(d.hidden1, DW_TN) +
+                              ceil_div(d.hidden1, 32) * ceil_div(h->IN, DW_TN) +
+                              ceil_div(d.hidden2, DW_TN)) + 1;
+    if (h->dw_tm == 32 || (h->dw_tm == 0 && h->reserved_dev && h->n_reserved >= tiles32)) TM = 32;
+  }
+  a.tm = TM;
   // dW2 = dZ2^T H1a, db2
   a.p[0].dZ = h->dZ2; a.p[0].ldz = d.hidden2;
   a.p[0].X = h->H1a; a.p[0].ldx = d.hidden1;
@@ -568,7 +579,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   a.p[0].tiles_n = (int)ceil_div(d.hidden1, DW_TN);
   a.p[0].tile0 = 0;
   a.p[0].kind = 0;
-  int t0 = (int)ceil_div(d.hidden2, DW_TM) * a.p[0].tiles_n;
+  int t0 = (int)ceil_div(d.hidden2, TM) * a.p[0].tiles_n;
   // dW1 = dZ1^T x, db1
   a.p[1].dZ = h->dZ1; a.p[1].ldz = d.hidden1;
   a.p[1].X = x; a.p[1].ldx = h->IN;
@@ -578,7 +589,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   a.p[1].tiles_n = (int)ceil_div(h->IN, DW_TN);
   a.p[1].tile0 = t0;
   a.p[1].kind = 1;
-  t0 += (int)ceil_div(d.hidden1, DW_TM) * a.p[1].tiles_n;
+  t0 += (int)ceil_div(d.hidden1, TM) * a.p[1].tiles_n;
   // dW3 = dq^T H2a, db3 = sum dq   (dq is a [B][1] "dZ")
   a.p[2].dZ = h->dq; a.p[2].ldz = 1;
   a.p[2].X = h->H2a; a.p[2].ldx = d.hidden2;
@@ -912,6 +923,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->w2f_online = h->choice_rep = nullptr;
   h->w2sp = nullptr;
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
+  h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->choice = nullptr;
   h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
   h->bb_x = nullptr;

@@ -934,6 +934,10 @@ struct DwArgs {
   // leave their partial tile in `kscratch` (write-through stores) and take a ticket, the last one
   // adds the partials in slice order (deterministic) and runs the epilogue.  ksplit = 1: off.
   int ksplit;
+  // rows (output units) per tile: 0 / 64 = DW_TM, or 32 — the same kernel with two units per lane
+  // instead of four: twice the workgroups for launches that have the CUs for them (the DQN chain
+  // once the target pass needs fewer: 105 workgroups, 3.5 us of MFMA each instead of 7)
+  int tm;
   float* kscratch;       // [total_tiles][ksplit][DW_TM * DW_TN + DW_TM]
   unsigned* ktickets;    // [total_tiles], zero between launches
 };
@@ -1013,8 +1017,9 @@ __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, fl
 constexpr int DW_TM = 64, DW_TN = 32, DW_RING = 8;
 typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
 
+template <int UPL>
 struct DwFrag {
-  float4 a;
+  float a[UPL];   // UPL consecutive units of one batch row (one 16- or 8-byte load)
   float2 x;
 };
 
@@ -1023,31 +1028,36 @@ struct DwFrag {
 // both: 3 * 2^30) fails the range check and the load returns zeros.
 constexpr unsigned kDwDead = 0x40000000u;
 
-template <bool FAST>
+template <bool FAST, int UPL>
 __device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
-                                         const __amdgpu_buffer_rsrc_t& rx, const unsigned (&va)[4],
+                                         const __amdgpu_buffer_rsrc_t& rx, const unsigned (&va)[UPL],
                                          const unsigned (&vx)[2], unsigned ba, unsigned bx,
-                                         DwFrag& f) {
+                                         DwFrag<UPL>& f) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   if constexpr (FAST) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va[0] + ba), 0, 0);
-    const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
-    f.a = make_float4(f4[0], f4[1], f4[2], f4[3]);
+    if constexpr (UPL == 4) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va[0] + ba), 0, 0);
+      const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
+      f.a[0] = f4[0]; f.a[1] = f4[1]; f.a[2] = f4[2]; f.a[3] = f4[3];
+    } else {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ra, (int)(va[0] + ba), 0, 0);
+      const f32x2 f2 = __builtin_bit_cast(f32x2, v);
+      f.a[0] = f2[0]; f.a[1] = f2[1];
+    }
     const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(vx[0] + bx), 0, 0);
     const f32x2 f2 = __builtin_bit_cast(f32x2, w);
     f.x = make_float2(f2[0], f2[1]);
   } else {
-    float e[4], g[2];
+    float g[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      e[k] = __builtin_bit_cast(
+    for (int k = 0; k < UPL; ++k)
+      f.a[k] = __builtin_bit_cast(
           float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(va[k] + ba), 0, 0));
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       g[k] = __builtin_bit_cast(
           float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(vx[k] + bx), 0, 0));
-    f.a = make_float4(e[0], e[1], e[2], e[3]);
     f.x = make_float2(g[0], g[1]);
   }
 }
@@ -1055,43 +1065,42 @@ __device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
 // `after_prologue` runs between the ring's first fetches and the main loop: loads that are only
 // needed later (the optimizer state) go there, so that they queue BEHIND the first operands —
 // vector-memory results return in issue order.
-template <bool FAST, typename Hook>
+template <bool FAST, int UPL, typename Hook>
 __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
                                             const __amdgpu_buffer_rsrc_t& rx,
-                                            const unsigned (&va)[4], const unsigned (&vx)[2],
+                                            const unsigned (&va)[UPL], const unsigned (&vx)[2],
                                             unsigned oa, unsigned ox, unsigned sa, unsigned sx,
-                                            int nsteps, dw_f32x4 (&acc)[4][2], float (&cs)[4],
+                                            int nsteps, dw_f32x4 (&acc)[UPL][2], float (&cs)[UPL],
                                             Hook after_prologue) {
 #pragma unroll
-  for (int ja = 0; ja < 4; ++ja) {
+  for (int ja = 0; ja < UPL; ++ja) {
     acc[ja][0] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
     acc[ja][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
     cs[ja] = 0.f;
   }
-  DwFrag ring[DW_RING];
+  DwFrag<UPL> ring[DW_RING];
 #pragma unroll
   for (int p = 0; p < DW_RING; ++p) {
     const bool live = p < nsteps;
-    dw_fetch<FAST>(ra, rx, va, vx, live ? oa + (unsigned)p * sa : kDwDead,
-                   live ? ox + (unsigned)p * sx : kDwDead, ring[p]);
+    dw_fetch<FAST, UPL>(ra, rx, va, vx, live ? oa + (unsigned)p * sa : kDwDead,
+                        live ? ox + (unsigned)p * sx : kDwDead, ring[p]);
   }
   after_prologue();
   for (int s0 = 0; s0 < nsteps; s0 += DW_RING) {
 #pragma unroll
     for (int p = 0; p < DW_RING; ++p) {
-      const DwFrag f = ring[p];
+      const DwFrag<UPL> f = ring[p];
       const int sn = s0 + p + DW_RING;
       const bool live = sn < nsteps;  // steps past the slice must not read the next wave's rows
-      dw_fetch<FAST>(ra, rx, va, vx, live ? oa + (unsigned)sn * sa : kDwDead,
-                     live ? ox + (unsigned)sn * sx : kDwDead, ring[p]);
+      dw_fetch<FAST, UPL>(ra, rx, va, vx, live ? oa + (unsigned)sn * sa : kDwDead,
+                          live ? ox + (unsigned)sn * sx : kDwDead, ring[p]);
       __builtin_amdgcn_sched_barrier(0);  // keep the refill here, DW_RING steps ahead of its use
-      const float av[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
       const float xv[2] = {f.x.x, f.x.y};
 #pragma unroll
-      for (int ja = 0; ja < 4; ++ja) {
-        acc[ja][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], xv[0], acc[ja][0], 0, 0, 0);
-        acc[ja][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], xv[1], acc[ja][1], 0, 0, 0);
-        cs[ja] += av[ja];
+      for (int ja = 0; ja < UPL; ++ja) {
+        acc[ja][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ja], xv[0], acc[ja][0], 0, 0, 0);
+        acc[ja][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ja], xv[1], acc[ja][1], 0, 0, 0);
+        cs[ja] += f.a[ja];
       }
     }
   }
@@ -1140,9 +1149,11 @@ __device__ __forceinline__ void sac_step_tail(const TailJob& t, float* lds, int 
   }
 }
 
-static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
-  __shared__ float part[4 * DW_TM * DW_TN];  // 32 KB: four partial tiles
-  __shared__ float csum[8 * DW_TM];
+// UPL = units per lane: 4 -> 64-row tiles (one 16-byte load of dZ per step), 2 -> 32-row tiles
+// (8-byte loads); everything below is written for TM = 16 UPL.
+template <int UPL>
+__device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, float* csum) {
+  constexpr int TM = 16 * UPL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row offsets stay in SGPRs
   const int KSP = a.ksplit > 1 ? a.ksplit : 1;
@@ -1189,7 +1200,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
     tgt = a.net2.tgt;
   }
   const int t = wg_tile - P.tile0;
-  const int i0 = (t / P.tiles_n) * DW_TM, j0 = (t % P.tiles_n) * DW_TN;
+  const int i0 = (t / P.tiles_n) * TM, j0 = (t % P.tiles_n) * DW_TN;
   if (P.M == 1 && kslice > 0) return;  // the GEMV path below is not split
   if (P.M == 1) {
     // Single-output layers (dW3 = dq^T h2, db3 = sum dq): a matrix tile would be 63/64 padding.
@@ -1236,17 +1247,17 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
     return;
   }
   // wave-uniform: whole 16- / 8-byte vectors are inside or outside the operand
-  const bool fa = ((P.ldz & 3) == 0) && ((P.M & 3) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(P.dZ) & 15) == 0);
+  const bool fa = ((P.ldz & (UPL - 1)) == 0) && ((P.M & (UPL - 1)) == 0) &&
+                  ((reinterpret_cast<uintptr_t>(P.dZ) & (4 * UPL - 1)) == 0);
   const bool fx = ((P.ldx & 1) == 0) && ((P.N & 1) == 0) &&
                   ((reinterpret_cast<uintptr_t>(P.X) & 7) == 0);
   // byte sizes stay below 2^30 (max_batch * ld * 4; checked by the host)
   const __amdgpu_buffer_rsrc_t ra = buf_rsrc_n(P.dZ, (unsigned)a.B * (unsigned)P.ldz * 4u);
   const __amdgpu_buffer_rsrc_t rx = buf_rsrc_n(P.X, (unsigned)a.B * (unsigned)P.ldx * 4u);
-  const int ua = i0 + 4 * c, cx = j0 + 2 * c;  // first unit / column of this lane's vectors
-  unsigned va[4], vx[2];                       // per-component byte offsets of row q (kBufOob: none)
+  const int ua = i0 + UPL * c, cx = j0 + 2 * c;  // first unit / column of this lane's vectors
+  unsigned va[UPL], vx[2];                       // per-component byte offsets of row q (kBufOob: none)
 #pragma unroll
-  for (int e = 0; e < 4; ++e)
+  for (int e = 0; e < UPL; ++e)
     va[e] = (ua + e < P.M) ? (unsigned)(q * P.ldz + ua + e) * 4u : kBufOob;
 #pragma unroll
   for (int e = 0; e < 2; ++e)
@@ -1260,10 +1271,12 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   // Epilogue assignment, fixed now so that the optimizer state can be fetched under the main
   // loop: thread -> tile row tid >> 3, columns 4 (tid & 7) .. + 3.  evec: the four elements are one
   // aligned float4 of dW (and of every flat optimizer buffer, which share its offsets).
+  // (32-row tiles: the upper half of the workgroup has no epilogue element)
+  const bool eact = tid < TM * 8;
   const int erl = tid >> 3, ecg = tid & 7;
-  const int eja = erl & 3, ereg = (erl >> 2) & 3, eq = erl >> 4;
+  const int eja = erl % UPL, ereg = (erl / UPL) & 3, eq = erl / (4 * UPL);
   const int erow = i0 + erl, ecol = j0 + 4 * ecg;
-  const bool evec = erow < P.M && ecol + 3 < P.N && ((P.ldw & 3) == 0) &&
+  const bool evec = eact && erow < P.M && ecol + 3 < P.N && ((P.ldw & 3) == 0) &&
                     ((reinterpret_cast<uintptr_t>(P.dW) & 15) == 0);
   const int64_t eflat = (P.dW + (int64_t)erow * P.ldw + ecol) - gbase;
   float4 p4, m4, v4, x4;
@@ -1276,41 +1289,41 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
       if (a.ad.c.amsgrad) x4 = *reinterpret_cast<const float4*>(st.vmax + eflat);
     }
   };
-  dw_f32x4 acc[4][2];
-  float cs[4];
+  dw_f32x4 acc[UPL][2];
+  float cs[UPL];
   PA_STAMP(a.prof, blockIdx.x, wave, 1);
-  if (fa && fx) dw_mainloop<true>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
-  else dw_mainloop<false>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+  if (fa && fx) dw_mainloop<true, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+  else dw_mainloop<false, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
   PA_STAMP(a.prof, blockIdx.x, wave, 2);
   // ---- partial tiles: (waves 4..7 -> LDS, waves 0..3 add), then (waves 0..3 -> LDS, all sum)
   // element id of acc[ja][jx][reg] on `lane`: ((ja * 2 + jx) * 4 + reg) * 64 + lane
   if (wave >= 4) {
-    float* dst = part + (wave - 4) * (DW_TM * DW_TN) + lane;
+    float* dst = part + (wave - 4) * (TM * DW_TN) + lane;
 #pragma unroll
-    for (int ja = 0; ja < 4; ++ja)
+    for (int ja = 0; ja < UPL; ++ja)
 #pragma unroll
       for (int jx = 0; jx < 2; ++jx)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[((ja * 2 + jx) * 4 + r) * 64] = acc[ja][jx][r];
   }
 #pragma unroll
-  for (int ja = 0; ja < 4; ++ja) {
+  for (int ja = 0; ja < UPL; ++ja) {
     cs[ja] += __shfl_xor(cs[ja], 16);
     cs[ja] += __shfl_xor(cs[ja], 32);
-    if (q == 0) csum[wave * DW_TM + 4 * c + ja] = cs[ja];
+    if (q == 0) csum[wave * TM + UPL * c + ja] = cs[ja];
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 3);
   __syncthreads();
   if (wave < 4) {
-    float* slot = part + wave * (DW_TM * DW_TN) + lane;
+    float* slot = part + wave * (TM * DW_TN) + lane;
 #pragma unroll
-    for (int ja = 0; ja < 4; ++ja)
+    for (int ja = 0; ja < UPL; ++ja)
 #pragma unroll
       for (int jx = 0; jx < 2; ++jx)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ja][jx][r] += slot[((ja * 2 + jx) * 4 + r) * 64];
 #pragma unroll
-    for (int ja = 0; ja < 4; ++ja)
+    for (int ja = 0; ja < UPL; ++ja)
 #pragma unroll
       for (int jx = 0; jx < 2; ++jx)
 #pragma unroll
@@ -1324,50 +1337,52 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
     float g4[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int idx = ((eja * 2 + (e & 1)) * 4 + ereg) * 64 + eq * 16 + 2 * ecg + (e >> 1);
+      // (threads without an epilogue element read slot 0: in range, unused)
+      const int idx = eact ? ((eja * 2 + (e & 1)) * 4 + ereg) * 64 + eq * 16 + 2 * ecg + (e >> 1) : 0;
       float sum = part[idx];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) sum += part[w * (DW_TM * DW_TN) + idx];
+      for (int w = 1; w < 4; ++w) sum += part[w * (TM * DW_TN) + idx];
       g4[e] = sum;
     }
     if (KSP > 1) {
       // ---- split-K: publish this slice's partial tile, last arriver adds them up in slice order
       __shared__ unsigned is_last;
-      float* mine = a.kscratch + ((int64_t)wg_tile * KSP + kslice) * (DW_TM * DW_TN + DW_TM);
+      float* mine = a.kscratch + ((int64_t)wg_tile * KSP + kslice) * (TM * DW_TN + TM);
       {
         // one 16-byte write-through store per thread (dword write-through stores are one fabric
         // write each: ~6x the time per byte, MI355X_MICROARCH.md)
         const f32x4_t v = {g4[0], g4[1], g4[2], g4[3]};
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + tid * 4), "v"(v) : "memory");
+        if (eact)
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(mine + tid * 4), "v"(v) : "memory");
       }
-      if (tid < DW_TM) {
+      if (tid < TM) {
         float sdb = csum[tid];
 #pragma unroll
-        for (int w = 1; w < 8; ++w) sdb += csum[w * DW_TM + tid];
-        __hip_atomic_store(mine + DW_TM * DW_TN + tid, sdb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int w = 1; w < 8; ++w) sdb += csum[w * TM + tid];
+        __hip_atomic_store(mine + TM * DW_TN + tid, sdb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores are out
       __syncthreads();
       if (tid == 0) is_last = (atomicAdd(a.ktickets + wg_tile, 1u) == (unsigned)KSP - 1u) ? 1u : 0u;
       __syncthreads();
       if (!is_last) return;
-      const float* base = a.kscratch + (int64_t)wg_tile * KSP * (DW_TM * DW_TN + DW_TM);
+      const float* base = a.kscratch + (int64_t)wg_tile * KSP * (TM * DW_TN + TM);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float sum = 0.f;
-        for (int k = 0; k < KSP; ++k)
-          sum += __hip_atomic_load(base + (int64_t)k * (DW_TM * DW_TN + DW_TM) + tid * 4 + e,
+        for (int k = 0; k < KSP && eact; ++k)
+          sum += __hip_atomic_load(base + (int64_t)k * (TM * DW_TN + TM) + tid * 4 + e,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         g4[e] = sum;
       }
-      if (tid < DW_TM) {
+      if (tid < TM) {
         float sdb = 0.f;
         for (int k = 0; k < KSP; ++k)
-          sdb += __hip_atomic_load(base + (int64_t)k * (DW_TM * DW_TN + DW_TM) + DW_TM * DW_TN + tid,
+          sdb += __hip_atomic_load(base + (int64_t)k * (TM * DW_TN + TM) + TM * DW_TN + tid,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         csum[tid] = sdb;   // read back by the bias epilogue below (waves 1.. hold zeros there)
 #pragma unroll
-        for (int w = 1; w < 8; ++w) csum[w * DW_TM + tid] = 0.f;
+        for (int w = 1; w < 8; ++w) csum[w * TM + tid] = 0.f;
       }
       if (tid == 0) a.ktickets[wg_tile] = 0u;
       __syncthreads();
@@ -1415,7 +1430,7 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
             *reinterpret_cast<float4*>(P.pkf_t + wf16_index_(erow, ecol, P.nkgf)) = tn;
         }
       }
-    } else if (erow < P.M) {
+    } else if (eact && erow < P.M) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         if (ecol + e < P.N) {
@@ -1431,10 +1446,10 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
       }
     }
   }
-  if (j0 == 0 && tid < DW_TM && (i0 + tid) < P.M) {
+  if (j0 == 0 && tid < TM && (i0 + tid) < P.M) {
     float s = csum[tid];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) s += csum[w * DW_TM + tid];
+    for (int w = 1; w < 8; ++w) s += csum[w * TM + tid];
     P.db[i0 + tid] = s;
     if (adam_on && !P.bias_frozen) {
       if (P.kind == 3) adam_generic_bias(a.ad, st, tgt, (P.db + i0 + tid) - gbase, s);
@@ -1443,6 +1458,20 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 15);
+}
+
+
+static __global__ __launch_bounds__(512, 2) void weight_grad_kernel(DwArgs a) {
+  __shared__ float part[4 * DW_TM * DW_TN];  // 32 KB: four partial tiles
+  __shared__ float csum[8 * DW_TM];
+  weight_grad_body<4>(a, part, csum);
+}
+// DwArgs::tm == 32 (two kernels, not one with a branch: the merged body allocated 208 registers
+// against 158 / 103 for the two on their own)
+static __global__ __launch_bounds__(512, 2) void weight_grad_kernel32(DwArgs a) {
+  __shared__ float part[4 * 32 * DW_TN];
+  __shared__ float csum[8 * 32];
+  weight_grad_body<2>(a, part, csum);
 }
 
 // ---------------------------------------------------------------------------

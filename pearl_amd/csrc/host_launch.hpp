@@ -155,7 +155,8 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
     a.ktickets = tickets;
   }
   const unsigned grid = (unsigned)(a.total_tiles * ks) + (loss_wg ? 1u : 0u);
-  hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
+  if (a.tm == 32) hipLaunchKernelGGL(weight_grad_kernel32, dim3(grid), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

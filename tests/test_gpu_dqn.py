@@ -200,6 +200,27 @@ def test_parameters_written_through_dot_data_are_seen_by_the_next_learn(golden):
     assert c.learn(rb)["loss"] != ra["loss"]     # and the halving did matter
 
 
+@pytest.mark.parametrize("name", ["tiny_dynamic", "cfg1_cartpole_shape", "cfg2_shape_small_batch"])
+def test_weight_gradient_tile_shapes_are_bitwise_identical(golden, name, monkeypatch):
+    """weight_grad_kernel32 (32-row tiles, two units per lane: twice the workgroups for a chain
+    that owns enough CUs) forms every element with the same per-wave fma chain and the same
+    cross-wave order as the 64-row kernel: bitwise-equal training."""
+    fx = golden(name)
+    rb = fill_arena_buffer(fx, "python")
+    out = []
+    for tm in ("64", "32"):
+        monkeypatch.setenv("PEARL_AMD_DW_TM", tm)
+        pl = make_learner(fx)
+        random.seed(4)
+        rep = pl.learn(rb)
+        out.append((rep["loss"], {k: v.clone() for k, v in pl._Q.state_dict().items()},
+                    {k: v.clone() for k, v in pl._Q_target.state_dict().items()}))
+    assert out[0][0] == out[1][0]
+    for i in (1, 2):
+        for k in out[0][i]:
+            assert torch.equal(out[0][i][k], out[1][i][k]), k
+
+
 def test_dynamic_action_spaces_never_take_the_shared_table(golden):
     rb = fill_arena_buffer(golden("tiny_dynamic"), "python")
     assert not rb.shared_action_table
