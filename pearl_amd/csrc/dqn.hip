@@ -50,6 +50,7 @@ struct pa_dqn {
   void* w2sp;  // the same matrix as bf16 split planes (target_split_kernel), H1 = H2 = 256 only
   int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
   int dw_tm;      // PEARL_AMD_DW_TM: rows per weight-gradient tile, 64 or 32 (0 = by the CU partition)
+  int rp_split;   // PEARL_AMD_ROWPASS_SPLIT (default 1): window-first row pass as forward + backward
   // Double DQN only (desc.double_q): the same copy of the ONLINE W2, the chosen next actions, and
   // the row-per-transition value pass through the target network
   float* w2f_online;
@@ -477,8 +478,10 @@ int run_next_values(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, h
 }
 
 // Forward (+ loss + backward to dZ2 / dZ1 when y is given) of the online network.
+// phase: 0 = one launch; 1 / 2 = the forward / backward halves as two launches (PH of
+// online_rowpass_kernel; only for the <9, 16, 16> shape, see rowpass_can_split)
 int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, float* q_out,
-                int world, hipStream_t s) {
+                int world, hipStream_t s, int phase = 0) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
   ScopedTimer tm(h, "rowpass", s);
@@ -494,7 +497,7 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   a.y_tagged = y_tagged ? 1 : 0;
   a.err = h->err_dev;
   a.err_host = h->err_host;
-  if (h->pending_signal) {
+  if (h->pending_signal && phase != 2) {
     a.signal_flag = h->sig;
     a.signal_value = h->pending_signal;
     h->pending_signal = 0;
@@ -502,7 +505,8 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_row : nullptr;
   a.H1a = y ? h->H1a : nullptr; a.H2a = y ? h->H2a : nullptr;
   a.dZ2 = h->dZ2; a.dZ1 = h->dZ1;
-  a.q_out = q_out; a.dq_out = h->dq; a.absd_out = h->absd;
+  a.q_out = phase == 2 ? nullptr : q_out; a.dq_out = h->dq; a.absd_out = h->absd;
+  a.q_in = phase == 2 ? q_out : nullptr;
   a.norm = (float)(2.0 / ((double)B * (double)world));
   a.B = B; a.K1 = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
   const dim3 grid((unsigned)ceil_div(B, RP_ROWS));
@@ -518,11 +522,27 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
     }                                                                                        \
     hipLaunchKernelGGL((online_rowpass_kernel<N1, N2, N3>), grid, dim3(512), smem, s, a);    \
   } while (0)
-  if (g2 == 16 && g3 == 16 && g1 == 9) PA_ROWPASS(9, 16, 16);
+#define PA_ROWPASS_PH(PH_)                                                                   \
+  do {                                                                                       \
+    static size_t configured = 0;                                                            \
+    if (smem > configured) {                                                                 \
+      int rc = set_max_smem(online_rowpass_kernel<9, 16, 16, PH_>, smem);                    \
+      if (rc != PA_OK) return rc;                                                            \
+      configured = smem;                                                                     \
+    }                                                                                        \
+    hipLaunchKernelGGL((online_rowpass_kernel<9, 16, 16, PH_>), grid, dim3(512), smem, s, a); \
+  } while (0)
+  if (phase != 0) {
+    PA_REQUIRE(g1 == 9 && g2 == 16 && g3 == 16 && y && q_out, PA_ERR_INVALID,
+               "split row pass: shape or arguments not covered");
+    if (phase == 1) PA_ROWPASS_PH(1);
+    else PA_ROWPASS_PH(2);
+  } else if (g2 == 16 && g3 == 16 && g1 == 9) PA_ROWPASS(9, 16, 16);
   else if (g2 == 16 && g3 == 16) PA_ROWPASS(0, 16, 16);
   else if (g2 == 4 && g3 == 4 && g1 == 1) PA_ROWPASS(1, 4, 4);
   else PA_ROWPASS(0, 0, 0);
 #undef PA_ROWPASS
+#undef PA_ROWPASS_PH
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
@@ -664,11 +684,26 @@ int run_soft_update(pa_dqn* h, hipStream_t s) {
 // Everything of one learn_batch that depends on the ONLINE parameters, given the Bellman targets
 // y[B] of the batch: row pass (forward, loss, dZ2, dZ1) -> weight gradients (+ AdamW).
 // soft_next: fuse the NEXT step's soft target update into this step's optimizer tail.
+bool rowpass_can_split(const pa_dqn* h) {
+  return h->rp_split && wf16_nkg(h->IN) == 9 && wf16_nkg(h->d.hidden1) == 16 &&
+         wf16_nkg(h->d.hidden2) == 16;
+}
+
+// split_rowpass: the row pass as forward + backward launches (the first round of a window, whose
+// targets are still being computed: the forward's CUs go back to the target tiles meanwhile)
 int online_chain(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, int64_t adam_step,
-                 int grad_world, float* loss_out, int soft_next, hipStream_t s) {
+                 int grad_world, float* loss_out, int soft_next, hipStream_t s,
+                 bool split_rowpass = false) {
   // grad_world < 0: data-parallel split requested explicitly (|grad_world| ranks, AdamW later)
   const int world = grad_world < 0 ? -grad_world : grad_world;
-  int rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s);
+  int rc;
+  if (split_rowpass && rowpass_can_split(h)) {
+    rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s, 1);
+    if (rc != PA_OK) return rc;
+    rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s, 2);
+  } else {
+    rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s);
+  }
   if (rc != PA_OK) return rc;
   float* lo = loss_out ? loss_out : h->loss_scratch;
   return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s,
@@ -815,7 +850,10 @@ int ensure_side(pa_dqn* h) {
   PA_HIP(hipEventCreateWithFlags(&h->ev_chain[1], hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_gather[0], hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_gather[1], hipEventDisableTiming));
-  return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", 64), h->side);
+  // with the bf16x3 target kernel the target side needs far fewer CUs: the chain keeps one per
+  // workgroup of its widest launch (105 weight-gradient tiles of 32 rows + the loss workgroup)
+  return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", (h->use_split && h->w2sp) ? 112 : 64),
+                      h->side);
 }
 
 
@@ -924,6 +962,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->w2sp = nullptr;
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
+  h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
   h->choice = nullptr;
   h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
   h->bb_x = nullptr;
@@ -1405,13 +1444,15 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const float* yj = h->yw[p] + (int64_t)j * B;
       float* lo = args->losses_out ? args->losses_out + round : nullptr;
       if (!dp) {
-        rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, 1, lo, soft_next, s);
+        rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, 1, lo, soft_next, s,
+                          overlap && j == 0);
         if (rc != PA_OK) return rc;
         continue;
       }
       // data parallel: local gradients (pre-scaled by 1/world) -> SUM all-reduce -> AdamW.  The
       // exchange hides behind the target work of the side stream.
-      rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, -world, lo, 0, s);
+      rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, -world, lo, 0, s,
+                        overlap && j == 0);
       if (rc != PA_OK) return rc;
       PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
                  PA_ERR_HIP, "allreduce_start hook failed");

@@ -161,6 +161,7 @@ struct RowArgs {
   float* H1a; float* H2a;               // [B][H1], [B][H2] relu outputs (weight-gradient operands)
   float* dZ2; float* dZ1;               // [B][H2], [B][H1] pre-activation gradients
   float* q_out; float* dq_out; float* absd_out;  // [B]; q_out may be null
+  const float* q_in;                    // PH == 2: Q(s, a) of the forward launch (its q_out)
   float norm;                           // 2 / (B * world)
   int B, K1, H1, H2;
 };
@@ -332,7 +333,15 @@ __device__ __forceinline__ void store4_guarded(float* __restrict__ base, int64_t
 //      the kernel polls for it, one whole GEMM later than before — loss, dZ2, dZ1.
 // The y tag of the overlapped loop is restored by the next launch of the chain
 // (weight_grad_kernel's loss workgroup), not here: that needed one more barrier.
-template <int NG1, int NG2, int NG3>
+//
+// PH: 0 = the whole pass.  1 / 2 = the same pass as TWO launches cut where it needs the Bellman
+// target: 1 = forward (layers 1-2, head; leaves h1, h2, q in HBM and exits — its CUs are free while
+// the targets are computed), 2 = backward (rebuilds s2 from the stored h2, G = s2 W2, then loss,
+// dZ2, dZ1 exactly as PH 0).  learn() uses the pair for the FIRST round of a target-update window:
+// that round's targets cannot exist before the soft update of the previous optimizer launch, and a
+// whole pass that sits on its 64 CUs polling for them keeps a quarter of the round's target tiles
+// waiting for a second turn.  Same values in the same order: bit-identical to PH 0.
+template <int NG1, int NG2, int NG3, int PH = 0>
 static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int P1 = rp_pad(a.K1), PH1 = rp_pad(a.H1), PH2 = rp_pad(a.H2);
@@ -363,14 +372,41 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   // w3 — and the W2^T stream of the backward GEMM is requested as soon as layer 1 has released
   // its registers; vector-memory results return in issue order, so layer 1 never waits for more
   // than its own operands.
-  WRing R2;
-  float4 b2v[2], w3v[2];
+  WRing R3;   // the backward GEMM's weight stream: requested from inside the layer-2 loop
+  float4 h1k[2];  // kept for the ReLU mask of dZ1
+  float4 h2k[2];
+  float4 w3v[2];
   const float b3v = a.b3[0];
+  auto vec4 = [&](const float* p, int col, int n) { return ld4_or_zero(p, col, col < n); };
+  float part = 0.f;
+  if constexpr (PH == 2) {
+    // ---- backward launch: this lane's h1, h2 of the forward launch, s2 = [h2 > 0] w3 -> LDS
+    const int64_t r1 = (int64_t)row * a.H1, r2 = (int64_t)row * a.H2;
+    if constexpr (NG3 > 0) ring_fill<NG3>(R3, a.W2tf, tile0, nt1, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int u = u0 + 16 * t;
+      h1k[t] = ld4_or_zero(a.H1a, r1 + u, rok && u < a.H1);
+      h2k[t] = ld4_or_zero(a.H2a, r2 + u, rok && u < a.H2);
+      w3v[t] = vec4(a.w3, u, a.H2);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int u = u0 + 16 * t;
+      float4 z;
+      z.x = (rok && h2k[t].x > 0.f) ? w3v[t].x : 0.f;
+      z.y = (rok && h2k[t].y > 0.f) ? w3v[t].y : 0.f;
+      z.z = (rok && h2k[t].z > 0.f) ? w3v[t].z : 0.f;
+      z.w = (rok && h2k[t].w > 0.f) ? w3v[t].w : 0.f;
+      if (u < PH2 - 4) *reinterpret_cast<float4*>(d2s + r16 * PH2 + u) = z;
+    }
+  } else {
+  WRing R2;
+  float4 b2v[2];
   // b1 / b2 / w3 are tensors of the flat parameter buffer: 16-byte aligned, every tensor padded to
   // a multiple of four floats with zeros (param_layout), so a float4 that starts inside a tensor
   // never leaves its slot — one unconditional vector load each, no scalar fallback (the two-path
   // form made hipcc serialise the burst below behind s_waitcnt).
-  auto vec4 = [&](const float* p, int col, int n) { return ld4_or_zero(p, col, col < n); };
   // ---- layer 1: h1 = relu(W1 x + b1)
   if constexpr (NG1 > 0) {
     // B operand of k-group g: x[row][16 g + 4 qd .. + 3]
@@ -447,8 +483,6 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
     PA_STAMP(a.prof, blockIdx.x, wave, 2);
   }
-  WRing R3;   // the backward GEMM's weight stream: requested from inside the layer-2 loop
-  float4 h1k[2];  // kept for the ReLU mask of dZ1
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int u = u0 + 16 * t;
@@ -467,15 +501,13 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   PA_STAMP(a.prof, blockIdx.x, wave, 4);
   if constexpr (NG2 > 0 && NG3 > 0) {
     rows16_gemm_static_pf<NG2, NG3>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane, R3,
-                                    a.W2tf, nt1, a.y != nullptr);
+                                    a.W2tf, nt1, PH == 0 && a.y != nullptr);
   } else if constexpr (NG2 > 0) {
     rows16_gemm_static<NG2>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   } else {
     rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 5);
-  float4 h2k[2];
-  float part = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int u = u0 + 16 * t;
@@ -486,7 +518,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     part = fmaf(h2k[t].z, w3v[t].z, part);
     part = fmaf(h2k[t].w, w3v[t].w, part);
     if (rok && a.H2a) store4_guarded(a.H2a, (int64_t)row * a.H2, u, a.H2, v2, h2k[t]);
-    if (a.y) {
+    if (PH == 0 && a.y) {
       // s2 = [h2 > 0] w3: the B operand of the backward GEMM (rows beyond the batch are zero:
       // their h2 came from a zero x row only if b1/b2 say so, hence the explicit guard)
       float4 z;
@@ -497,13 +529,26 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
       if (u < PH2 - 4) *reinterpret_cast<float4*>(d2s + r16 * PH2 + u) = z;
     }
   }
+  }  // PH != 2
   // ---- head partials: q = w3 . h2 + b3 (lane quarters, then waves, fixed order)
-  part += __shfl_xor(part, 16);
-  part += __shfl_xor(part, 32);
-  if (qd == 0) qpart[wave * 16 + r16] = part;
+  if constexpr (PH != 2) {
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    if (qd == 0) qpart[wave * 16 + r16] = part;
+  }
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
   __syncthreads();                                                      // barrier B: s2, qpart
   PA_STAMP(a.prof, blockIdx.x, wave, 7);
+  if constexpr (PH == 1) {
+    // forward launch: Q(s, a) for the backward launch (and the report), nothing else
+    float qf = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) qf += qpart[w * 16 + r16];
+    qf += b3v;
+    if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = qf;
+    PA_STAMP(a.prof, blockIdx.x, wave, 10);
+    return;
+  }
   unsigned ybits = kYPendingBits;
   if (a.y && rok) {
     // first look at the Bellman target, in flight while the backward GEMM runs
@@ -523,10 +568,14 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 8);
   float q = 0.f;
+  if constexpr (PH == 2) {
+    q = rok ? a.q_in[row] : 0.f;
+  } else {
 #pragma unroll
-  for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
-  q += b3v;
-  if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
+    for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
+    q += b3v;
+    if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
+  }
   if (!a.y) return;
   // ---- loss, dZ2 = [h2 > 0] * (dq * w3), dZ1 = [h1 > 0] * (dq * G)
   float yv = q;

@@ -74,3 +74,32 @@ if [ "$MODE" == "c" ]; then
   head -8 $R/gpurun_out/kernel_stats.txt
   rm -f $R/gpurun_out/prof/*.db
 fi
+if [ "$MODE" == "d" ]; then
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -30 gpurun_out/pytest_gpu.log
+  run() { # name, env...
+    local name=$1; shift
+    env "$@" timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_$name.log 2> gpurun_out/bench_$name.err
+    echo "bench $name rc=$? $(tail -1 gpurun_out/bench_$name.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value']/1e6,2),'M tr/s  us/step',round(d['ms_per_step']*1e3,2),' target: us',round(r['avg_launch_us'],1),'tr/launch',r['transitions_per_launch'],'frac',round(r['frac'],3),' iso',round(r.get('isolated',{}).get('frac',0),3))" 2>&1)"
+  }
+  run dflt X=1
+  run nosplitrp PEARL_AMD_ROWPASS_SPLIT=0
+  run leadp PEARL_AMD_LEAD_PERSIST=1
+  run sf1 PEARL_AMD_SPLIT_FIRST=1
+  run sf12 PEARL_AMD_SPLIT_FIRST=12
+  run sf2 PEARL_AMD_SPLIT_FIRST=2
+  run r128 PEARL_AMD_RESERVED_CUS=128
+  run r64 PEARL_AMD_RESERVED_CUS=64 PEARL_AMD_DW_TM=32
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state'))"
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+  echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
+  echo "rocprof rc=$?"
+  python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db > $R/gpurun_out/kernel_stats.txt 2>&1
+  python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_split 70 >> $R/gpurun_out/kernel_stats.txt 2>&1
+  head -9 $R/gpurun_out/kernel_stats.txt
+  rm -f $R/gpurun_out/prof/*.db
+fi
