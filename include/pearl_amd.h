@@ -430,6 +430,13 @@ int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream);
  * gradients: dW + AdamW of both in one launch and, with soft_tau >= 0, their soft target updates
  * in the same epilogue.  PA_ERR_UNSUPPORTED when the pair does not qualify. */
 int pa_mlp_adam2(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, void* stream);
+/* Data-parallel step of two networks that share a batch (PPO's actor and critic, ppo.py:152-199,
+ * under torch.distributed): pa_mlp_flush_grads2 forms BOTH networks' deferred weight gradients in
+ * one launch without stepping the optimizer; the caller all-reduces the gradient buffers (ONE
+ * message when they are adjacent in memory: FlatMlp.join_grads); pa_mlp_adamw2 then applies
+ * AdamW(amsgrad) step_a / step_b to both in one launch.  No reference counterpart. */
+int pa_mlp_flush_grads2(pa_mlp* a, pa_mlp* b, void* stream);
+int pa_mlp_adamw2(pa_mlp* a, pa_mlp* b, int64_t step_a, int64_t step_b, void* stream);
 /* update_target_network (common/utils.py:214-226) */
 int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream);
 

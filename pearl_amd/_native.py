@@ -396,6 +396,8 @@ SIGNATURES = {
     "pa_mlp_flush_grads": (C.c_int, [_P, _P]),
     "pa_mlp_adam": (C.c_int, [_P, C.c_int64, _P]),
     "pa_mlp_adam2": (C.c_int, [_P, _P, C.c_int64, C.c_float, _P]),
+    "pa_mlp_flush_grads2": (C.c_int, [_P, _P, _P]),
+    "pa_mlp_adamw2": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "pa_mlp_soft_update": (C.c_int, [_P, C.c_float, _P]),
     "pa_softmax_action_prob": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
     "pa_ppo_actor_loss": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_int32,

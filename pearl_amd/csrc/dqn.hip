@@ -851,8 +851,10 @@ int ensure_side(pa_dqn* h) {
   PA_HIP(hipEventCreateWithFlags(&h->ev_gather[0], hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&h->ev_gather[1], hipEventDisableTiming));
   // with the bf16x3 target kernel the target side needs far fewer CUs: the chain keeps one per
-  // workgroup of its widest launch (105 weight-gradient tiles of 32 rows + the loss workgroup)
-  return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", (h->use_split && h->w2sp) ? 112 : 64),
+  // workgroup of its widest launch (112 weight-gradient tiles of 32 rows + the loss workgroup;
+  // measured: 112 reserved -> 25.3 M transitions/s with 64-row tiles, 128 -> 27.8 M, 144 -> 25.0 M,
+  // where the target side becomes the bound)
+  return cu_partition(h, env_int("PEARL_AMD_RESERVED_CUS", (h->use_split && h->w2sp) ? 128 : 64),
                       h->side);
 }
 

@@ -1503,6 +1503,15 @@ static __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   (void)adam_update(a.c, a.st, i, a.g[i]);
 }
 
+// Two networks' stand-alone AdamW in one launch (blockIdx.y picks the network): the data-parallel
+// step of a pair of networks (PPO's actor + critic) after ONE all-reduce of both gradient buffers.
+static __global__ __launch_bounds__(256) void adamw2_kernel(AdamArgs a0, AdamArgs a1) {
+  const AdamArgs& a = blockIdx.y == 0 ? a0 : a1;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n) return;
+  (void)adam_update(a.c, a.st, i, a.g[i]);
+}
+
 // AdamW on the flat DQN gradient buffer AFTER a data-parallel all-reduce, with the same optimizer
 // tail as the fused weight-gradient kernel: fragment-major copies refreshed, optional soft update
 // of the target network for the next step.  The parameter index is decoded back to (tensor, row,

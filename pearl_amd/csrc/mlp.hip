@@ -2623,6 +2623,49 @@ extern "C" int pa_mlp_adam2(pa_mlp* a, pa_mlp* b, int64_t step, float soft_tau, 
   return pa::mlp_adam_pair(a, b, step, soft_tau, reinterpret_cast<hipStream_t>(stream), nullptr);
 }
 
+// The data-parallel step of such a pair (PPO's actor + critic under torch.distributed): the two
+// networks' deferred weight gradients WITHOUT the optimizer in one launch ...
+extern "C" int pa_mlp_flush_grads2(pa_mlp* a, pa_mlp* b, void* stream) {
+  PA_REQUIRE(a && b && a != b && a->bound && b->bound, PA_ERR_INVALID, "pa_mlp_flush_grads2: bad argument");
+  PA_REQUIRE(a->pend.active && b->pend.active && a->pend.B == b->pend.B && a->L == b->L && a->L <= 3,
+             PA_ERR_UNSUPPORTED,
+             "pa_mlp_flush_grads2: the networks have no deferred weight gradients of one batch");
+  PA_HIP(hipSetDevice(a->d.device));
+  pa_mlp* hs[2] = {a, b};
+  DwOperands ops[2] = {{a->pend.x, a->pend.ldx, a->pend.dzs, a->pend.ldzs},
+                       {b->pend.x, b->pend.ldx, b->pend.dzs, b->pend.ldzs}};
+  a->pend.active = b->pend.active = false;
+  return run_weight_grads_n(hs, ops, 2, a->pend.B, 0, -1.f, reinterpret_cast<hipStream_t>(stream));
+}
+// ... and, after the caller's all-reduce of the gradient buffers, AdamW(amsgrad) step `step` of
+// both in one launch (each with its own optimizer configuration).
+extern "C" int pa_mlp_adamw2(pa_mlp* a, pa_mlp* b, int64_t step_a, int64_t step_b, void* stream) {
+  PA_REQUIRE(a && b && a != b && a->bound && b->bound && step_a >= 1 && step_b >= 1, PA_ERR_INVALID,
+             "pa_mlp_adamw2: bad argument");
+  AdamArgs args[2];
+  pa_mlp* hs[2] = {a, b};
+  const int64_t steps[2] = {step_a, step_b};
+  for (int i = 0; i < 2; ++i) {
+    pa_mlp* h = hs[i];
+    PA_REQUIRE(h->bufs.grad && h->bufs.exp_avg && h->bufs.exp_avg_sq &&
+                   (!h->d.amsgrad || h->bufs.max_exp_avg_sq) && !h->pend.active,
+               PA_ERR_INVALID, "pa_mlp_adamw2: optimizer buffers not bound, or gradients still deferred");
+    memset(&args[i], 0, sizeof(AdamArgs));
+    args[i].st.p = h->bufs.p; args[i].st.m = h->bufs.exp_avg; args[i].st.v = h->bufs.exp_avg_sq;
+    args[i].st.vmax = h->bufs.max_exp_avg_sq;
+    args[i].g = h->bufs.grad;
+    args[i].n = h->P;
+    args[i].c = adam_scalars(h->d, steps[i]);
+    h->packed_ok = false;
+  }
+  PA_HIP(hipSetDevice(a->d.device));
+  const int64_t nmax = a->P > b->P ? a->P : b->P;
+  hipLaunchKernelGGL(adamw2_kernel, dim3((unsigned)ceil_div(nmax, 256), 2), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), args[0], args[1]);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 // ---- internal entry points for the fused learner steps (sac_step.hip) ---------------------------
 namespace pa {
 int mlp_ensure_packed(pa_mlp* h, bool target, hipStream_t s) { return ensure_packed(h, target, s); }
