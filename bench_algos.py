@@ -252,19 +252,26 @@ def bench_dsac(steps, cpu_seconds):
 
 
 def bench_ppo(steps, cpu_seconds):
+    """Single process, or — under `torchrun --nproc-per-node N bench_algos.py --only ppo` —
+    BASELINE config 4's data-parallel form: every rank owns a rollout shard of 65 536 transitions
+    and steps on its own minibatch of 4096; actor + critic gradients travel as ONE RCCL message
+    per step (FlatMlp.adam_pair_data_parallel).  value = B * steps * world / max-over-ranks time."""
+    import torch.distributed as dist
     from oracle.actor_critic_oracle import PpoOracle
     from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
-                           ProximalPolicyOptimization)
+                           ProximalPolicyOptimization, _comm)
     S, A, B, N = 256, 16, 4096, 65_536
-    torch.manual_seed(0)
-    random.seed(0)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    torch.manual_seed(0)                 # identical initial parameters on every rank
+    random.seed(1000 + rank)             # rank-private minibatch stream
     pl = ProximalPolicyOptimization(action_space=dspace(A), state_dim=S, actor_hidden_dims=[256, 256],
                                     critic_hidden_dims=[256, 256], training_rounds=steps, batch_size=B,
                                     epsilon=0.1,
                                     action_representation_module=OneHotActionTensorRepresentationModule(A))
     rb = PPOReplayBuffer(N, sampler="device")
-    PearlAgent(pl, replay_buffer=rb, device_id=0)
-    g = torch.Generator(device=DEV).manual_seed(0)
+    PearlAgent(pl, replay_buffer=rb, device_id=DEV.index)
+    g = torch.Generator(device=DEV).manual_seed(rank)       # rank-private rollout shard
     st = torch.randn(N + 1, S, device=DEV, generator=g)
     ids = torch.arange(N, device=DEV)
 
@@ -279,8 +286,32 @@ def bench_ppo(steps, cpu_seconds):
     dt_pre, _ = timed(lambda: pl.preprocess_replay_buffer(rb))
     # one full learn() as warm-up (first-call allocations, scratch growth), then the timed one;
     # both include preprocess_replay_buffer (1.4 ms), as every PPO learn() does
-    dt, _ = timed(lambda: pl.learn(rb), warm=1)
-    gpu = B * steps / dt
+    if world > 1:
+        pl.learn(rb)                      # warm-up (incl. the communicator's first collective)
+        sync()
+        dist.barrier()
+        sync()
+        gc.collect()
+        gc.disable()
+        t0 = time.perf_counter()
+        pl.learn(rb)
+        sync()
+        dist.barrier()
+        sync()
+        dt = time.perf_counter() - t0
+        gc.enable()
+        t = torch.tensor([dt], device=DEV, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    else:
+        dt, _ = timed(lambda: pl.learn(rb), warm=1)
+    gpu = B * steps * world / dt
+    comm = _comm.comm_info() if dist.is_initialized() else None
+    if comm is not None:
+        comm["allreduce_floats_per_step"] = int(sum(m.flat["grad"].numel() for m in pl._flat.values()))
+        comm["messages_per_step"] = 1
+    if rank != 0:
+        return None
     orc = PpoOracle({k: v.cpu() for k, v in pl._actor.state_dict().items()},
                     {k: v.cpu() for k, v in pl._critic.state_dict().items()}, A, epsilon=0.1)
     Ns = 4096      # bounded slice of the rollout for the python GAE loop of the oracle
@@ -298,12 +329,13 @@ def bench_ppo(steps, cpu_seconds):
     cpu = Ns * n / (time.perf_counter() - t0)
     return {"config": "cfg4 PPO+GAE S=256 A=16 [256,256] rollout 65536 minibatch 4096",
             "metric": "learner transitions/s through PolicyLearner.learn (minibatch sample + learn_batch)",
-            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps, "n_gpus": world,
+            "scaling": "weak", "comm": comm,
             "roofline": step_roofline(
                 # actor [S,256,256,A] + critic [S,256,256,1]: forward, dX of layers >= 1, dW of all
                 2 * sum(2 * mlp_macs(d) + sum(a * b for a, b in zip(d[1:-1], d[2:]))
                         for d in ([S, 256, 256, A], [S, 256, 256, 1])),
-                B * steps, dt,
+                B * steps, dt,      # per GPU
                 kernel="mlp_rowfwd_kernel 43 us + weight_grad_kernel 43 us + mlp_rowbwd_kernel 25 us per "
                        "step (per-kernel durations: profiles/r02_ppo_kernel_stats.txt)"),
             "preprocess_replay_buffer": {"transitions_per_s": N / dt_pre, "ms": 1e3 * dt_pre,
@@ -471,15 +503,37 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
-    torch.cuda.set_device(0)
+    global DEV
+    # torchrun --nproc-per-node N bench_algos.py --only ppo: one rank per GPU over RCCL (config 4's
+    # data-parallel form); PEARL_AMD_FORCE_DP=1 drives the same path through a 1-rank communicator
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or os.environ.get("PEARL_AMD_FORCE_DP") == "1":
+        import torch.distributed as dist
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        DEV = torch.device("cuda", local_rank)
+        torch.cuda.set_device(DEV)
+        dist.init_process_group("nccl", rank=int(os.environ.get("RANK", "0")), world_size=world,
+                                device_id=DEV)
+        if not args.only:
+            args.only = "ppo"
+        assert args.only == "ppo", "the multi-process form is built for --only ppo"
+    torch.cuda.set_device(DEV)
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("dsac", bench_dsac), ("ppo", bench_ppo), ("bandit", bench_bandit),
                      ("double_dqn", bench_double_dqn), ("push", bench_push)):
         if args.only and name not in args.only.split(","):
             continue
         out = fn(args.steps, args.cpu_seconds)
-        out.update({"unit": "transitions/s", "n_gpus": 1, "dtype": "f32", "data": "synthetic"})
+        if out is None:       # ranks > 0 of a multi-process run
+            continue
+        out.setdefault("n_gpus", 1)
+        out.update({"unit": "transitions/s", "dtype": "f32", "data": "synthetic"})
         print(json.dumps(out), flush=True)
+    if world > 1 or os.environ.get("PEARL_AMD_FORCE_DP") == "1":
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,101 @@
+"""One RCCL communicator per process for the native all-reduce hooks (``pa_comm_*``, comm.hip).
+
+Data parallelism is not in the reference: every rank owns a replay shard and a
+local batch, parameters stay replicated, and the only exchange is the flat gradient buffer once per
+step.  ``native_comm`` brings the communicator up once (rank 0 mints the RCCL unique id,
+``torch.distributed`` broadcasts its 128 bytes, every rank agrees on the outcome) and hands the
+same handle to every learner of the process; ``allreduce_sum_`` reduces a flat fp32 tensor in place
+on torch's current stream through it, or through ``torch.distributed.all_reduce`` when RCCL cannot
+be loaded, the backend is gloo (CPU tests, two ranks on one GPU) or
+``PEARL_AMD_TORCH_ALLREDUCE=1``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _native as N
+
+_state = {"handle": None, "failed": False, "device": None}
+
+
+def world_size() -> int:
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def native_comm(dev: torch.device) -> Optional[C.c_void_p]:
+    if os.environ.get("PEARL_AMD_TORCH_ALLREDUCE") == "1":
+        return None
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if _state["handle"] is not None:
+        return _state["handle"]
+    if _state["failed"]:
+        return None     # RCCL bring-up failed on some rank: torch.distributed instead
+    lib = N.lib()
+    if dist.get_backend() != "nccl" or not lib.pa_comm_available():
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (C.c_char * 128)()
+        N.check(lib.pa_comm_unique_id(buf))
+        ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+    ident = ident.to(dev)
+    dist.broadcast(ident, src=0)
+    raw = bytes(ident.cpu().numpy().tobytes())
+    handle = C.c_void_p()
+    torch.cuda.synchronize(dev)
+    rc = lib.pa_comm_create(C.byref(handle), dev.index, world, rank, raw)
+    # every rank must take the same path: agree on the outcome before using the communicator
+    ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if rc == 0:
+            lib.pa_comm_destroy(handle)
+        _state["failed"] = True
+        return None
+    # RCCL sets a communicator up on its first collective (channels, proxies: up to seconds with
+    # 8 ranks): do that here, not inside the first learner step
+    warm = torch.zeros(256, dtype=torch.float32, device=dev)
+    N.check(lib.pa_comm_allreduce_start(handle, warm.data_ptr(), warm.numel(), N.stream_ptr(dev)))
+    N.check(lib.pa_comm_allreduce_wait(handle, N.stream_ptr(dev)))
+    torch.cuda.synchronize(dev)
+    _state["handle"], _state["device"] = handle, dev
+    return handle
+
+
+def comm_info() -> dict:
+    """What the gradient exchange of this process runs on (bench lines report it): the rank count
+    RCCL itself reports for the communicator, not the one that was asked for."""
+    info = {"ranks_requested": world_size()}
+    h = _state["handle"]
+    if h is None:
+        info["library"] = "torch.distributed all_reduce" if world_size() > 1 or (
+            dist.is_available() and dist.is_initialized()) else "none (single process)"
+        return info
+    n_seen, me = C.c_int32(-1), C.c_int32(-1)
+    N.check(N.lib().pa_comm_info(h, C.byref(n_seen), C.byref(me)))
+    info.update(library="rccl (native pa_comm_* hooks)", ranks_observed=n_seen.value, rank=me.value)
+    return info
+
+
+def allreduce_sum_(flat: torch.Tensor, force: bool = False) -> torch.Tensor:
+    """SUM over the data-parallel group, in place, ONE message.  Identity with a single rank unless
+    ``force`` (a 1-rank communicator still goes through RCCL: the bench's readiness run)."""
+    if world_size() <= 1 and not force:
+        return flat
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat
+    h = native_comm(flat.device) if flat.is_cuda else None
+    if h is not None:
+        s = N.stream_ptr(flat.device)
+        N.check(N.lib().pa_comm_allreduce_start(h, flat.data_ptr(), flat.numel(), s))
+        N.check(N.lib().pa_comm_allreduce_wait(h, s))
+        return flat
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    return flat

@@ -12,6 +12,8 @@
 // All of it is byte movement: HBM-bound, coalesced row copies, no MFMA.
 #include <stdarg.h>
 
+#include <atomic>
+
 #include <new>
 
 #include "common.hpp"
@@ -467,14 +469,27 @@ int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const p
 using namespace pa;
 
 namespace pa {
+// One process drives one GPU (launch-time kernel attributes and scratch buffers are per process).
+// The binding is taken by the first handle and RELEASED when the last handle of the process is
+// destroyed, so that a later learner — an evaluation pass on another device, a notebook cell, a
+// test suite walking over devices — can bind anew.  Atomic: handles may be created from several
+// threads.
+static std::atomic<int> g_bound_device{-1};
+static std::atomic<int> g_live_handles{0};
 int bind_process_device(int device) {
-  static int bound = -1;
-  if (bound < 0) bound = device;
-  PA_REQUIRE(bound == device, PA_ERR_UNSUPPORTED,
-             "pearl_amd: one process drives one GPU — this process is bound to HIP device %d and "
-             "cannot create a handle on device %d (launch one process per device)",
-             bound, device);
+  int expected = -1;
+  if (!g_bound_device.compare_exchange_strong(expected, device) && expected != device) {
+    set_error("pearl_amd: one process drives one GPU at a time — this process holds handles on HIP "
+              "device %d and cannot create one on device %d (destroy them first, or launch one "
+              "process per device)",
+              expected, device);
+    return PA_ERR_UNSUPPORTED;
+  }
+  g_live_handles.fetch_add(1);
   return PA_OK;
+}
+void release_process_device() {
+  if (g_live_handles.fetch_sub(1) == 1) g_bound_device.store(-1);
 }
 }  // namespace pa
 
@@ -492,14 +507,18 @@ extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {
              "HIP device %d not available (%d visible): the replay arena lives in HBM and has "
              "no CPU fallback",
              desc->device, ndev);
-  {
-    int rc_dev = bind_process_device(desc->device);
-    if (rc_dev != PA_OK) return rc_dev;
-  }
   PA_HIP(hipSetDevice(desc->device));
   pa_arena* a = new (std::nothrow) pa_arena();
   PA_REQUIRE(a, PA_ERR_NOMEM, "out of host memory");
   memset(a, 0, sizeof(*a));
+  {
+    // (after the handle exists: every later failure goes through pa_arena_destroy, which releases)
+    int rc_dev = bind_process_device(desc->device);
+    if (rc_dev != PA_OK) {
+      delete a;
+      return rc_dev;
+    }
+  }
   a->d = *desc;
   a->action_size = dtype_size(desc->action_dtype);
   a->reward_size = dtype_size(desc->reward_dtype);
@@ -596,6 +615,7 @@ extern "C" int pa_arena_destroy(pa_arena* a) {
   free(a->sh_next_avail);
   free(a->sh_next_mask);
   delete a;
+  release_process_device();
   return PA_OK;
 }
 

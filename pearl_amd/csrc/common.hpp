@@ -16,6 +16,8 @@ void set_error(const char* fmt, ...);
 // buffers grown on demand — so the first handle created pins the process to its device and a
 // handle for another device is refused, loudly, instead of misbehaving later.
 int bind_process_device(int device);
+// every successful bind_process_device is paired with one release when its handle is destroyed
+void release_process_device();
 
 #define PA_HIP(expr)                                                             \
   do {                                                                           \

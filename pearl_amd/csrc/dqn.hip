@@ -940,13 +940,16 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
              "HIP device %d not available (%d visible): the learner step is HIP-only and has no "
              "CPU fallback",
              desc->device, ndev);
-  {
-    int rc_dev = bind_process_device(desc->device);
-    if (rc_dev != PA_OK) return rc_dev;
-  }
   PA_HIP(hipSetDevice(desc->device));
   pa_dqn* h = new (std::nothrow) pa_dqn();
   PA_REQUIRE(h, PA_ERR_NOMEM, "out of host memory");
+  {
+    int rc_dev = bind_process_device(desc->device);
+    if (rc_dev != PA_OK) {
+      delete h;
+      return rc_dev;
+    }
+  }
   h->d = *desc;
   h->bound = false;
   memset(&h->bufs, 0, sizeof(h->bufs));
@@ -1086,6 +1089,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   for (auto& t : h->timers)
     for (auto e : t.ev) (void)hipEventDestroy(e);
   delete h;
+  release_process_device();
   return PA_OK;
 }
 

@@ -99,6 +99,7 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
     if (h->wf_t[l]) (void)hipFree(h->wf_t[l]);
   }
   delete h;
+  release_process_device();
   return PA_OK;
 }
 
@@ -109,10 +110,6 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
   PA_REQUIRE(desc->device >= 0 && desc->device < ndev, PA_ERR_HIP,
              "HIP device %d not available (%d visible): pa_mlp is HIP-only and has no CPU fallback",
              desc->device, ndev);
-  {
-    int rc_dev = bind_process_device(desc->device);
-    if (rc_dev != PA_OK) return rc_dev;
-  }
   pa_mlp* h = new (std::nothrow) pa_mlp();
   PA_REQUIRE(h, PA_ERR_NOMEM, "out of host memory");
   memset(h, 0, sizeof(*h));
@@ -122,6 +119,14 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
   if (rc != PA_OK) {
     delete h;
     return rc;
+  }
+  {
+    // (from here on every failure goes through pa_mlp_destroy, which releases the binding)
+    int rc_dev = bind_process_device(desc->device);
+    if (rc_dev != PA_OK) {
+      delete h;
+      return rc_dev;
+    }
   }
   PA_HIP(hipSetDevice(desc->device));
   int maxh = 1;

@@ -67,9 +67,7 @@ class _NativeDqn:
         h, self.handle = self.handle, None
         if h:
             N.lib().pa_dqn_destroy(h)
-        c, self.comm = getattr(self, "comm", None), None
-        if c:
-            N.lib().pa_comm_destroy(c)
+        self.comm = None      # the communicator belongs to the process (pearl_amd/_comm.py)
         q, self.cql = getattr(self, "cql", None), None
         if q:
             N.lib().pa_mlp_destroy(q[1])
@@ -660,50 +658,14 @@ class DeepQLearning(PolicyLearner):
         return nat.loss_host
 
     def _native_comm(self, dev: torch.device) -> Optional[C.c_void_p]:
-        """One RCCL communicator per process for the native all-reduce hooks (pa_comm_*): rank 0
-        mints the unique id, torch.distributed broadcasts its 128 bytes.  None when RCCL cannot
-        be loaded or PEARL_AMD_TORCH_ALLREDUCE=1 (then torch.distributed.all_reduce is used)."""
-        if os.environ.get("PEARL_AMD_TORCH_ALLREDUCE") == "1":
-            return None
-        if not (dist.is_available() and dist.is_initialized()):
-            return None
-        cached = getattr(self._native, "comm", None)
-        if cached is not None:
-            return cached
-        if getattr(self._native, "comm_failed", False):
-            return None     # RCCL bring-up failed on some rank: torch.distributed hooks instead
-        lib = N.lib()
-        if not lib.pa_comm_available():
-            return None
-        rank, world = dist.get_rank(), dist.get_world_size()
-        ident = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = (C.c_char * 128)()
-            N.check(lib.pa_comm_unique_id(buf))
-            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        on = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        ident = ident.to(on)
-        dist.broadcast(ident, src=0)
-        raw = bytes(ident.cpu().numpy().tobytes())
-        handle = C.c_void_p()
-        torch.cuda.synchronize(dev)
-        rc = lib.pa_comm_create(C.byref(handle), dev.index, world, rank, raw)
-        # every rank must take the same path: agree on the outcome before using the communicator
-        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=on)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
-            if rc == 0:
-                lib.pa_comm_destroy(handle)
-            self._native.comm_failed = True
-            return None
-        # RCCL sets a communicator up on its first collective (channels, proxies: up to seconds
-        # with 8 ranks): do that here, not inside the first learn() round
-        warm = torch.zeros(256, dtype=torch.float32, device=dev)
-        N.check(lib.pa_comm_allreduce_start(handle, warm.data_ptr(), warm.numel(), N.stream_ptr(dev)))
-        N.check(lib.pa_comm_allreduce_wait(handle, N.stream_ptr(dev)))
-        torch.cuda.synchronize(dev)
-        self._native.comm = handle
-        return handle
+        """The process's RCCL communicator for the native all-reduce hooks (pearl_amd/_comm.py: one
+        per process, shared by every learner).  None when RCCL cannot be loaded, the process group
+        is not RCCL-backed, or PEARL_AMD_TORCH_ALLREDUCE=1 (then torch.distributed.all_reduce
+        hooks are used)."""
+        from ... import _comm
+        h = _comm.native_comm(dev)
+        self._native.comm = h          # (bench.py reads it back; owned by _comm, never destroyed here)
+        return h
 
     def _learn_data_parallel(self, replay_buffer: TensorBasedReplayBuffer, batch_size: int,
                              rounds: int, onehot: bool, force_world: Optional[int] = None

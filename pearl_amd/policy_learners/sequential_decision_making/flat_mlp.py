@@ -360,6 +360,67 @@ class FlatMlp:
         self._steps = step
         self._versions = self._flat_versions()     # our own kernels wrote the buffers: not "external"
 
+    # ------------------------------------------------------------------ data-parallel pairs
+    @staticmethod
+    def join_grads(m1: "FlatMlp", m2: "FlatMlp") -> torch.Tensor:
+        """Both networks' flat gradient buffers as two halves of ONE allocation, so that a
+        data-parallel step exchanges them as one message (PPO's actor 135 696 +
+        critic 131 841 floats).  Idempotent; redone when a network re-flattened itself."""
+        g1, g2 = m1.flat["grad"], m2.flat["grad"]
+        joint = getattr(m1, "_joint_grad", None)
+        if joint is not None and joint is getattr(m2, "_joint_grad", None) \
+                and g1.data_ptr() == joint.data_ptr() \
+                and g2.data_ptr() == joint.data_ptr() + 4 * g1.numel():
+            return joint
+        n1, n2 = g1.numel(), g2.numel()
+        assert n1 % 4 == 0, "flat buffers are padded to 16 bytes"
+        joint = torch.zeros(n1 + n2, dtype=torch.float32, device=g1.device)
+        for m, lo, n in ((m1, 0, n1), (m2, n1, n2)):
+            old = m.flat["grad"]
+            new = joint[lo:lo + n]
+            new.copy_(old)
+            for q in m._params():
+                if q.grad is not None:
+                    off = (q.grad.data_ptr() - old.data_ptr()) // 4
+                    q.grad = new[off:off + q.numel()].view(q.shape)
+            m.flat["grad"] = new
+            f = m.flat
+            bufs = N.MlpBuffers(p=f["p"].data_ptr(), p_target=N.ptr(f.get("p_target")),
+                                grad=new.data_ptr(), exp_avg=N.ptr(f.get("exp_avg")),
+                                exp_avg_sq=N.ptr(f.get("exp_avg_sq")),
+                                max_exp_avg_sq=N.ptr(f.get("max_exp_avg_sq")))
+            torch.cuda.current_stream(new.device).synchronize()
+            N.check(N.lib().pa_mlp_bind(m.handle, C.byref(bufs)))
+            m._joint_grad = joint
+        return joint
+
+    @staticmethod
+    def adam_pair_data_parallel(m1: "FlatMlp", m2: "FlatMlp", force: bool = False) -> None:
+        """The data-parallel step of two networks that share a batch (PPO's actor + critic):
+        both networks' deferred weight gradients in ONE launch (pa_mlp_flush_grads2), ONE all-reduce
+        of the joined gradient buffers (RCCL through the native hooks, _comm.allreduce_sum_), ONE
+        AdamW launch for both (pa_mlp_adamw2).  The caller has already scaled the heads so that the
+        SUM over ranks is the global-batch gradient (PPO: the surrogate is a sum, the critic's MSE
+        head is divided by B * world)."""
+        from ... import _comm
+        dev = m1.flat["p"].device
+        stream = N.stream_ptr(dev)
+        joint = FlatMlp.join_grads(m1, m2)
+        rc = N.lib().pa_mlp_flush_grads2(m1.handle, m2.handle, stream)
+        if rc == N.PA_ERR_UNSUPPORTED:
+            N.check(N.lib().pa_mlp_flush_grads(m1.handle, stream))
+            N.check(N.lib().pa_mlp_flush_grads(m2.handle, stream))
+        else:
+            N.check(rc)
+        _comm.allreduce_sum_(joint, force=force)
+        s1, s2 = m1._steps + 1, m2._steps + 1
+        N.check(N.lib().pa_mlp_adamw2(m1.handle, m2.handle, s1, s2, stream))
+        for m, st in ((m1, s1), (m2, s2)):
+            m._pending_x = None
+            m._set_adam_steps(st)
+            m._steps = st
+            m._versions = m._flat_versions()
+
     @staticmethod
     def adam_pair(m1: "FlatMlp", m2: "FlatMlp", soft_tau: Optional[float] = None) -> bool:
         """AdamW step of twin networks (twin critics: one optimizer, same shape) whose weight

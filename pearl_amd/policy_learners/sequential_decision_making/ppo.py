@@ -24,6 +24,7 @@ import torch
 import torch.distributed as dist
 from torch import Tensor, nn
 
+from ... import _comm
 from ... import _native as N
 from ...action_representation_modules import ActionRepresentationModule
 from ...neural_networks.common.value_networks import VanillaValueNetwork
@@ -220,6 +221,14 @@ class ProximalPolicyOptimization(ActorCriticBase):
         d_logits = torch.empty_like(logits)
         dv = torch.empty(B, dtype=torch.float32, device=dev)
         losses = torch.empty(2, dtype=torch.float32, device=dev)
+        # Data parallel (BASELINE config 4; not in the reference): every rank steps on
+        # its own minibatch of its rollout shard.  The surrogate is a SUM over the global minibatch
+        # (ppo.py:176-183), the critic loss a MEAN (critic_utils.py:139-167): the critic's head is
+        # scaled by 1 / world here, so that ONE SUM all-reduce of both gradient buffers is the
+        # gradient of the reference learner on the concatenated minibatch.
+        world = _comm.world_size() if getattr(self, "data_parallel", True) else 1
+        dp = world > 1 or (os.environ.get("PEARL_AMD_FORCE_DP") == "1" and dist.is_available()
+                           and dist.is_initialized())
         # both heads in one launch: the value head's single workgroup runs beside the actor head
         N.check(N.lib().pa_ppo_heads(
             logits.data_ptr(), logits.stride(0), arep.data_ptr(), arep.stride(0),
@@ -227,8 +236,12 @@ class ProximalPolicyOptimization(ActorCriticBase):
             B, A, float(self._epsilon), float(self._entropy_bonus_scaling), d_logits.data_ptr(),
             d_logits.stride(0), v.data_ptr(), v.stride(0),
             self._f32(batch.lam_return, dev).data_ptr(), dv.data_ptr(), losses.data_ptr(), s))
+        if dp and world > 1:
+            dv.mul_(1.0 / world)      # (2 / B) (v - R) -> (2 / (B world)) (v - R), exact for world = 2^k
         FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True, defer=True)
-        if os.environ.get("PEARL_AMD_PPO_PAIR", "1") == "1" and not (
+        if dp:
+            FlatMlp.adam_pair_data_parallel(actor, critic, force=True)
+        elif os.environ.get("PEARL_AMD_PPO_PAIR", "1") == "1" and not (
                 dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             # both networks' weight gradients + AdamW in one launch (same AdamW configuration only)
             FlatMlp.adam_pair(actor, critic, None)

@@ -257,6 +257,10 @@ class TensorBasedReplayBuffer(ReplayBuffer):
              curr_available_actions: Any = None, next_state: Any = None,
              next_available_actions: Any = None, max_number_actions: Optional[int] = None,
              cost: Optional[float] = None) -> None:
+        # a push changes what a logical index means (FIFO eviction shifts every row of a full
+        # buffer while len() stays put): index lists / batches drawn before it are stale
+        if self._presampled is not None or self._pregathered is not None:
+            self.drop_presampled()
         A = 0
         curr_tab = curr_mask = next_tab = next_mask = None
         avail_dim = 0
@@ -331,6 +335,8 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         Same per-row semantics as n successive ``push`` calls with one (static) action space.
         Tensors may live on the arena's device (no host round trip) or on the CPU.
         """
+        if self._presampled is not None or self._pregathered is not None:
+            self.drop_presampled()       # (see push)
         n = int(state.shape[0])
         A = 0
         avail_dim = 0

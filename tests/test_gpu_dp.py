@@ -130,3 +130,115 @@ def test_two_ranks_equal_one_reference_learner_on_the_concatenated_batch():
                                          msg=f"rank {rank} online {k}")
             assert_adam_trajectory_close(torch.from_numpy(two[rank][5][k]), orc.t[k], lr=1e-3, steps=R,
                                          msg=f"rank {rank} target {k}")
+
+
+# ---------------------------------------------------------------------------------------------
+# PPO (BASELINE config 4): actor + critic gradients as one message per step
+# ---------------------------------------------------------------------------------------------
+PPO_S, PPO_A, PPO_B, PPO_N, PPO_R = 12, 4, 64, 512, 3
+
+
+def _ppo_shard(rank):
+    g = torch.Generator().manual_seed(500 + rank)
+    st = torch.randn(PPO_N + 1, PPO_S, generator=g)
+    ids = torch.arange(PPO_N)
+    return st, ids % PPO_A, (ids % 5).float() * 0.25 + rank, (ids % 61 == 60)
+
+
+def _ppo_learner():
+    from pearl_amd import (DiscreteActionSpace, OneHotActionTensorRepresentationModule,
+                           ProximalPolicyOptimization)
+    space = DiscreteActionSpace([torch.tensor([k]) for k in range(PPO_A)])
+    torch.manual_seed(0)                      # identical initial parameters on every rank
+    return ProximalPolicyOptimization(
+        action_space=space, state_dim=PPO_S, actor_hidden_dims=[32, 32], critic_hidden_dims=[32, 32],
+        training_rounds=PPO_R, batch_size=PPO_B, epsilon=0.2,
+        action_representation_module=OneHotActionTensorRepresentationModule(PPO_A)), space
+
+
+def _ppo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pearl_amd import PearlAgent, PPOReplayBuffer
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pl, space = _ppo_learner()
+    rb = PPOReplayBuffer(PPO_N, sampler="device")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    st, act, rew, term = _ppo_shard(rank)
+    rb.push_many(state=st[:-1].to(dev), action=act.view(-1, 1).to(dev), reward=rew.to(dev),
+                 terminated=term.to(dev), truncated=torch.zeros(PPO_N, dtype=torch.bool, device=dev),
+                 next_state=st[1:].to(dev), curr_available_actions=space,
+                 next_available_actions=space, max_number_actions=PPO_A)
+    random.seed(70 + rank)
+    report = pl.learn(rb)
+    torch.cuda.synchronize()
+    sd = {f"actor.{k}": v.detach().cpu().numpy().copy() for k, v in pl._actor.state_dict().items()}
+    sd.update({f"critic.{k}": v.detach().cpu().numpy().copy()
+               for k, v in pl._critic.state_dict().items()})
+    joint = pl._flat["actor"].flat["grad"].data_ptr() + 4 * pl._flat["actor"].flat["grad"].numel() \
+        == pl._flat["critic"].flat["grad"].data_ptr()
+    q.put((rank, sd, [float(x) for x in report["critic_loss"]], bool(joint)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ppo_two_ranks_equal_one_reference_learner_on_the_concatenated_minibatch():
+    """Two HIP ranks, each on its own rollout shard and minibatch stream, one SUM all-reduce of the
+    joined actor + critic gradient buffers per step — against ONE oracle learner (ppo.py:152-199
+    restated) stepping on the concatenated 2B-row minibatch: the surrogate is a sum over the global
+    minibatch, the critic loss its mean."""
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import assert_adam_trajectory_close
+    from oracle import pearl_oracle as O
+    from oracle.actor_critic_oracle import PpoOracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_ppo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, sd, closs, joint = q.get(timeout=300)
+        out[rank] = (sd, closs, joint)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert out[0][2] and out[1][2], "the two gradient buffers must be one allocation (one message)"
+    for k in out[0][0]:
+        assert (out[0][0][k] == out[1][0][k]).all(), f"ranks diverged: {k}"
+    pl, _ = _ppo_learner()
+    orc = PpoOracle(pl._actor.state_dict(), pl._critic.state_dict(), PPO_A, epsilon=0.2)
+    shards, pre, keys = [], [], []
+    for rank in range(2):
+        st, act, rew, term = _ppo_shard(rank)
+        onehot = torch.eye(PPO_A)[act]
+        shards.append((st, onehot))
+        pre.append(orc.preprocess(st[:-1], onehot, rew, term, torch.zeros(PPO_N, dtype=torch.bool),
+                                  st[PPO_N]))
+        random.seed(70 + rank)
+        keys.append(random.getrandbits(64))        # the key learn() hands the device sampler
+    want_c = []
+    for r in range(PPO_R):
+        rows = []
+        for rank in range(2):
+            idx = torch.from_numpy(O.philox_sample_indices(PPO_N, keys[rank], r, PPO_B))
+            st, onehot = shards[rank]
+            gae, lam_ret, p_old = pre[rank]
+            rows.append((st[idx], onehot[idx], p_old[idx], gae[idx], lam_ret[idx]))
+        cat = [torch.cat([a, b]) for a, b in zip(*rows)]
+        _, lc = orc.learn_batch(*cat)
+        want_c.append(lc)
+    got_c = [(a + b) / 2 for a, b in zip(out[0][1], out[1][1])]
+    torch.testing.assert_close(torch.tensor(got_c), torch.tensor(want_c), rtol=1e-3, atol=1e-5)
+    want = {}
+    for name, layers in (("actor", orc.actor), ("critic", orc.critic)):
+        for i, (w, b) in enumerate(layers):
+            want[f"{name}._model.{i}.0.weight"], want[f"{name}._model.{i}.0.bias"] = w, b
+    for k, v in want.items():
+        assert k in out[0][0], (k, list(out[0][0])[:4])
+        assert_adam_trajectory_close(torch.from_numpy(out[0][0][k]), v.detach(), lr=1e-4, steps=PPO_R,
+                                     rtol=1e-3, atol=2e-6, msg=k)

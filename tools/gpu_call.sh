@@ -103,3 +103,28 @@ if [ "$MODE" == "d" ]; then
   head -9 $R/gpurun_out/kernel_stats.txt
   rm -f $R/gpurun_out/prof/*.db
 fi
+if [ "$MODE" == "e" ]; then
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -30 gpurun_out/pytest_gpu.log
+  run() { # name, env...
+    local name=$1; shift
+    env "$@" timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_$name.log 2> gpurun_out/bench_$name.err
+    echo "bench $name rc=$? $(tail -1 gpurun_out/bench_$name.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value']/1e6,2),'M tr/s  us/step',round(d['ms_per_step']*1e3,2),' target: us',round(r['avg_launch_us'],1),'tr/launch',r['transitions_per_launch'],'frac',round(r['frac'],3),' iso',round(r.get('isolated',{}).get('frac',0),3))" 2>&1)"
+  }
+  run dflt X=1
+  run sf12 PEARL_AMD_SPLIT_FIRST=12
+  run sf2 PEARL_AMD_SPLIT_FIRST=2
+  run leadp PEARL_AMD_LEAD_PERSIST=1
+  run r120 PEARL_AMD_RESERVED_CUS=120
+  run r136 PEARL_AMD_RESERVED_CUS=136
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state'))"
+  PEARL_AMD_SPLIT_FIRST=12 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20_sf12.log 2> gpurun_out/bench_s20_sf12.err
+  echo "bench s20 sf12 rc=$?"; tail -1 gpurun_out/bench_s20_sf12.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state'))"
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+  echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
+  timeout 300 python bench_algos.py --steps 200 --only ppo --cpu-seconds 1 > gpurun_out/ppo_single.jsonl 2> gpurun_out/ppo_single.err
+  echo "ppo single rc=$?"; cut -c1-400 gpurun_out/ppo_single.jsonl
+  PEARL_AMD_FORCE_DP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench_algos.py --steps 200 --only ppo --cpu-seconds 1 > gpurun_out/ppo_dp1.jsonl 2> gpurun_out/ppo_dp1.err
+  echo "ppo dp1 rc=$?"; cut -c1-600 gpurun_out/ppo_dp1.jsonl; tail -3 gpurun_out/ppo_dp1.err
+fi
