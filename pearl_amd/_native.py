@@ -446,6 +446,13 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PEARL_AMD_LIB: a diagnostic build of the SAME library (the AddressSanitizer one of
+    # `make -C pearl_amd/csrc asan`); never a fallback — the file must exist and export every symbol
+    path = os.environ.get("PEARL_AMD_LIB") or LIB_PATH
+    if path != LIB_PATH:
+        if not os.path.exists(path):
+            raise ImportError(f"pearl_amd: PEARL_AMD_LIB={path} does not exist")
+        return _load(path)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"pearl_amd: {LIB_PATH} is missing. Build it with "
@@ -453,7 +460,12 @@ def lib() -> C.CDLL:
             "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the replay/"
             "learner hot path."
         )
-    handle = C.CDLL(LIB_PATH)
+    return _load(LIB_PATH)
+
+
+def _load(path: str) -> C.CDLL:
+    global _lib
+    handle = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the .so does not export it
         fn.restype = res

@@ -256,12 +256,16 @@ int stream_hop(pa_dqn* h, hipStream_t from, hipStream_t to, hipEvent_t fallback)
 // is the reference's own update_target_network idiom, common/utils.py:214-226).
 constexpr int kPrologueRepackWgs = 48;
 static __global__ __launch_bounds__(SAMPLE_THREADS) void learn_prologue_kernel(SampleArgs sa, int rounds,
-                                                                              RepackArgs ra) {
+                                                                              RepackArgs ra, int* zero,
+                                                                              int nzero) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long table[];
   if ((int)blockIdx.x < rounds) {
     sample_indices_block(sa, (int)blockIdx.x, table);
     return;
   }
+  // (the call's work-stealing counters and error word: a memset launch of their own otherwise)
+  if ((int)blockIdx.x == rounds)
+    for (int i = threadIdx.x; i < nzero; i += SAMPLE_THREADS) zero[i] = 0;
   repack_body(ra, (int64_t)((int)blockIdx.x - rounds) * SAMPLE_THREADS + threadIdx.x,
               (int64_t)kPrologueRepackWgs * SAMPLE_THREADS);
 }
@@ -983,7 +987,9 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->err_host = nullptr;
   h->packed_ok = false;
   h->overlap = env_int("PEARL_AMD_OVERLAP", 1);
-  h->split_first = env_int("PEARL_AMD_SPLIT_FIRST", 3);
+  // 12 = "1 round, then 2 rounds, then the rest": measured best with the bf16x3 target kernel
+  // (20-round call 23.2 M transitions/s against 22.0 M with one leading piece of 3 rounds)
+  h->split_first = env_int("PEARL_AMD_SPLIT_FIRST", 12);
   h->y_clean = false;
   h->reserved_dev = nullptr;
   h->n_reserved = 0;
@@ -1214,8 +1220,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   rc = ensure_side(h);
   if (rc != PA_OK) return rc;
   // fresh work-stealing counters for this call's persistent target launches, and a clean error
-  // word (a bounded wait that expired in an earlier call must not poison this one): one memset
-  PA_HIP(hipMemsetAsync(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int), s));
+  // word (a bounded wait that expired in an earlier call must not poison this one): zeroed by the
+  // prologue launch below (device sampler) or one memset (host index lists)
+  if (args->idx_host) PA_HIP(hipMemsetAsync(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int), s));
   h->ctr_next = 0;
   h->err_host[0] = 0;
   // Static action space: every stored row carries the same padded next-action table, so the
@@ -1268,7 +1275,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       configured = smem;
     }
     hipLaunchKernelGGL(learn_prologue_kernel, dim3((unsigned)(R + kPrologueRepackWgs)),
-                       dim3(SAMPLE_THREADS), smem, s, sa, R, rpk);
+                       dim3(SAMPLE_THREADS), smem, s, sa, R, rpk, h->tile_ctr, kTileCtrs + 4);
     PA_LAUNCH_CHECK();
   }
   h->packed_ok = false;   // until this call has completed its last round

@@ -128,3 +128,21 @@ if [ "$MODE" == "e" ]; then
   PEARL_AMD_FORCE_DP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench_algos.py --steps 200 --only ppo --cpu-seconds 1 > gpurun_out/ppo_dp1.jsonl 2> gpurun_out/ppo_dp1.err
   echo "ppo dp1 rc=$?"; cut -c1-600 gpurun_out/ppo_dp1.jsonl; tail -3 gpurun_out/ppo_dp1.err
 fi
+if [ "$MODE" == "f" ]; then
+  # does device ASan work here at all?
+  HSA_XNACK=1 timeout 60 tools/asan_probe > gpurun_out/asan_probe.txt 2>&1; echo "asan probe rc=$?"; tail -15 gpurun_out/asan_probe.txt | cut -c1-200
+  timeout 900 bash tools/asan_run.sh python tools/stress_ppo.py 3 > gpurun_out/asan_stress_ppo.txt 2>&1; echo "asan stress rc=$?"; tail -25 gpurun_out/asan_stress_ppo.txt | cut -c1-250
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state'))"
+  PEARL_AMD_LEAD_PERSIST=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20_lp.log 2> gpurun_out/bench_s20_lp.err
+  echo "bench s20 leadp rc=$?"; tail -1 gpurun_out/bench_s20_lp.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state'))"
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+  echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_sc
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_timeline.txt 2>&1
+  head -80 $R/gpurun_out/shortcall_timeline.txt | cut -c1-130
+  rm -f $DB
+fi
