@@ -16,6 +16,10 @@ from ..common.utils import _ACTIVATIONS
 from ..common.value_networks import VanillaValueNetwork
 
 
+def _join_before_state_dict(module, prefix, keep_vars) -> None:
+    module.join_solve()
+
+
 class LinearRegression(nn.Module):
     def __init__(self, feature_dim: int, l2_reg_lambda: float = 1.0, gamma: float = 1.0,
                  force_pinv: bool = False) -> None:
@@ -30,6 +34,27 @@ class LinearRegression(nn.Module):
         self.register_buffer("_sum_weight", torch.zeros(1))
         self.register_buffer("_inv_A", torch.zeros(feature_dim + 1, feature_dim + 1))
         self.register_buffer("_coefs", torch.zeros(feature_dim + 1))
+        # The learner refreshes `_inv_A` / `_coefs` on a side stream (the fp64 solve is one serial
+        # workgroup and nothing in the next learn_batch reads its result): `_solve_done` is the event
+        # of the latest refresh, and every read of the two buffers — attribute access, state_dict —
+        # first makes torch's current stream wait for it.
+        self.__dict__["_solve_done"] = None
+        self.register_state_dict_pre_hook(_join_before_state_dict)
+
+    def __getstate__(self):
+        self.join_solve()                 # (an event is neither picklable nor deep-copyable)
+        return self.__dict__
+
+    def join_solve(self) -> None:
+        ev = self.__dict__.get("_solve_done")
+        if ev is not None:
+            torch.cuda.current_stream(self._buffers["_A"].device).wait_event(ev)
+            self.__dict__["_solve_done"] = None
+
+    def __getattr__(self, name: str):
+        if name in ("_inv_A", "_coefs"):
+            self.join_solve()
+        return super().__getattr__(name)
 
     @property
     def A(self) -> Tensor:

@@ -16,6 +16,8 @@ The regression operates on the features computed BEFORE the optimizer step, as i
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -188,8 +190,9 @@ class NeuralLinearBandit(PolicyLearner):
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(delta)          # delta_A | delta_b | delta_sum_weight in ONE message
         for name in ("_A", "_b", "_sum_weight", "_inv_A", "_coefs"):
-            buf = getattr(lr, name)
+            buf = lr._buffers[name]       # (not getattr: reading _inv_A / _coefs joins the solve)
             if buf.device != dev or not buf.is_contiguous():
+                lr.join_solve()
                 setattr(lr, name, buf.to(dev).contiguous())
         N.check(lib.pa_linreg_apply(delta.data_ptr(), d, lr._A.data_ptr(), lr._b.data_ptr(),
                                     lr._sum_weight.data_ptr(), s))
@@ -200,13 +203,50 @@ class NeuralLinearBandit(PolicyLearner):
                 "loss": loss[0], "mu_scores": p.mean()}
 
     def _solve(self, lr: Any, dev: torch.device) -> None:
+        """inv(A + lambda I) and coefs = inv_A b (linear_regression.py:252-270 calculate_coefs) — OFF
+        the learner's critical path: the fp64 Gauss-Jordan solve is ONE serial workgroup (97 us of a
+        240 us step) and nothing in the next learn_batch reads `_inv_A` / `_coefs`; they are read at
+        act time.  So the step snapshots (A, b) on the learner stream (two small copies) and the
+        solve runs on a side stream; readers of the two buffers join it
+        (LinearRegression.join_solve: attribute access, state_dict).  PEARL_AMD_BANDIT_ASYNC_SOLVE=0:
+        in-stream as before."""
         d = lr._feature_dim
         D = d + 1
-        work = torch.empty(D * 2 * D, dtype=torch.float64, device=dev)
-        flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        N.check(N.lib().pa_linreg_solve(lr._A.data_ptr(), lr._b.data_ptr(), float(lr.l2_reg_lambda), d,
-                                        work.data_ptr(), lr._inv_A.data_ptr(), lr._coefs.data_ptr(),
-                                        flag.data_ptr(), N.stream_ptr(dev)))
+        st = self.__dict__.get("_solve_state")
+        if st is None or st["dev"] != dev or st["D"] != D:
+            st = {"dev": dev, "D": D, "side": torch.cuda.Stream(dev), "slot": 0,
+                  "snap": [(torch.empty(D, D, dtype=torch.float32, device=dev),
+                            torch.empty(D, dtype=torch.float32, device=dev)) for _ in range(2)],
+                  "work": [torch.empty(D * 2 * D, dtype=torch.float64, device=dev) for _ in range(2)],
+                  "flag": torch.zeros(2, dtype=torch.int32, device=dev),
+                  "busy": [None, None]}
+            self.__dict__["_solve_state"] = st
+        inv_A, coefs = lr._buffers["_inv_A"], lr._buffers["_coefs"]     # (no join: we are the writer)
+        if os.environ.get("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1") == "0":
+            lr.join_solve()
+            N.check(N.lib().pa_linreg_solve(lr._A.data_ptr(), lr._b.data_ptr(), float(lr.l2_reg_lambda),
+                                            d, st["work"][0].data_ptr(), inv_A.data_ptr(),
+                                            coefs.data_ptr(), st["flag"].data_ptr(), N.stream_ptr(dev)))
+            return
+        main = torch.cuda.current_stream(dev)
+        i = st["slot"]
+        st["slot"] = 1 - i
+        if st["busy"][i] is not None:
+            main.wait_event(st["busy"][i])        # the solve that last read this snapshot (two back)
+        A_s, b_s = st["snap"][i]
+        A_s.copy_(lr._A)
+        b_s.copy_(lr._b)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side = st["side"]
+        side.wait_event(ready)
+        N.check(N.lib().pa_linreg_solve(A_s.data_ptr(), b_s.data_ptr(), float(lr.l2_reg_lambda), d,
+                                        st["work"][i].data_ptr(), inv_A.data_ptr(), coefs.data_ptr(),
+                                        st["flag"][i:].data_ptr(), side.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(side)
+        st["busy"][i] = done
+        lr.__dict__["_solve_done"] = done
 
     def _maybe_apply_discounting(self) -> None:
         lr = self.model._linear_regression_layer

@@ -146,3 +146,23 @@ if [ "$MODE" == "f" ]; then
   head -80 $R/gpurun_out/shortcall_timeline.txt | cut -c1-130
   rm -f $DB
 fi
+if [ "$MODE" == "g" ]; then
+  # (1) poor man's sanitizer for the PPO fault: every torch tensor its own hipMalloc (page-granular,
+  # unmapped neighbours) + serialized kernels; (2) standalone device-ASan probe; (3) bandit async solve
+  export LD_LIBRARY_PATH=$(dirname $(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)):$LD_LIBRARY_PATH
+  HSA_XNACK=1 timeout 60 tools/asan_probe > gpurun_out/asan_probe.txt 2>&1; echo "asan probe rc=$?"; tail -12 gpurun_out/asan_probe.txt | cut -c1-200
+  PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 900 python -X faulthandler tools/stress_ppo.py 12 > gpurun_out/nocache_stress_ppo.txt 2>&1; echo "nocache stress rc=$?"; tail -4 gpurun_out/nocache_stress_ppo.txt | cut -c1-200
+  PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 1500 python -m pytest tests/test_gpu_actor_critic.py -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/nocache_pytest_ac.log 2>&1; echo "nocache pytest ac rc=$?"; tail -5 gpurun_out/nocache_pytest_ac.log
+  PYTORCH_NO_CUDA_MEMORY_CACHING=1 timeout 900 python bench_algos.py --steps 30 --only ppo,sac,td3,dsac,bandit --cpu-seconds 0.3 > gpurun_out/nocache_bench_algos.jsonl 2> gpurun_out/nocache_bench_algos.err; echo "nocache bench_algos rc=$?"; cut -c1-160 gpurun_out/nocache_bench_algos.jsonl; tail -3 gpurun_out/nocache_bench_algos.err
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -8 gpurun_out/pytest_gpu.log
+  timeout 300 python bench_algos.py --steps 300 --only bandit --cpu-seconds 1 > gpurun_out/bandit_async.jsonl 2> gpurun_out/bandit_async.err; echo "bandit rc=$?"; cut -c1-300 gpurun_out/bandit_async.jsonl
+  PEARL_AMD_BANDIT_ASYNC_SOLVE=0 timeout 300 python bench_algos.py --steps 300 --only bandit --cpu-seconds 1 > gpurun_out/bandit_sync.jsonl 2> gpurun_out/bandit_sync.err; echo "bandit sync rc=$?"; cut -c1-300 gpurun_out/bandit_sync.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_sc
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_timeline.txt 2>&1
+  head -90 $R/gpurun_out/shortcall_timeline.txt | cut -c1-130
+  rm -f $DB
+fi

@@ -33,7 +33,7 @@ def show(rows, base):
 def main(path, needle="target_fused", n=60):
     rows = rows_of(path)
     if needle == "--last-call":
-        k0 = max(i for i, r in enumerate(rows) if "sample_indices_kernel" in r[0])
+        k0 = max(i for i, r in enumerate(rows) if ("sample_indices_kernel" in r[0] or "learn_prologue_kernel" in r[0]))
         k0 = max(0, k0 - 3)
         print(f"last learn() call: {len(rows) - k0} device operations, "
               f"{(rows[-1][2] - rows[k0][1]) / 1000:.1f} us first start -> last end")
