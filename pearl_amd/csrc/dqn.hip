@@ -695,23 +695,31 @@ bool rowpass_can_split(const pa_dqn* h) {
 
 // split_rowpass: the row pass as forward + backward launches (the first round of a window, whose
 // targets are still being computed: the forward's CUs go back to the target tiles meanwhile)
+// (the two halves of online_chain, for callers that enqueue something between them)
+int chain_front(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, int grad_world,
+                hipStream_t s, bool split_rowpass) {
+  const int world = grad_world < 0 ? -grad_world : grad_world;
+  return run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s,
+                     (split_rowpass && rowpass_can_split(h)) ? 1 : 0);
+}
+int chain_back(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, int64_t adam_step,
+               int grad_world, float* loss_out, int soft_next, hipStream_t s, bool split_rowpass) {
+  const int world = grad_world < 0 ? -grad_world : grad_world;
+  if (split_rowpass && rowpass_can_split(h)) {
+    int rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s, 2);
+    if (rc != PA_OK) return rc;
+  }
+  float* lo = loss_out ? loss_out : h->loss_scratch;
+  return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s,
+                         y_tagged ? y : nullptr);
+}
 int online_chain(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged, int64_t adam_step,
                  int grad_world, float* loss_out, int soft_next, hipStream_t s,
                  bool split_rowpass = false) {
   // grad_world < 0: data-parallel split requested explicitly (|grad_world| ranks, AdamW later)
-  const int world = grad_world < 0 ? -grad_world : grad_world;
-  int rc;
-  if (split_rowpass && rowpass_can_split(h)) {
-    rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s, 1);
-    if (rc != PA_OK) return rc;
-    rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s, 2);
-  } else {
-    rc = run_rowpass(h, x, B, y, y_tagged, h->qbuf, world, s);
-  }
+  int rc = chain_front(h, x, B, y, y_tagged, grad_world, s, split_rowpass);
   if (rc != PA_OK) return rc;
-  float* lo = loss_out ? loss_out : h->loss_scratch;
-  return run_weight_grad(h, x, B, grad_world == 1, adam_step, lo, soft_next, s,
-                         y_tagged ? y : nullptr);
+  return chain_back(h, x, B, y, y_tagged, adam_step, grad_world, loss_out, soft_next, s, split_rowpass);
 }
 
 // One stand-alone learn_batch (pa_dqn_step).  do_target_update: soft update BEFORE the forward
@@ -1299,6 +1307,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // The target network is constant between two soft updates, and the index lists of all rounds
   // are already known: gather and run the (dominant) target-network pass for a whole WINDOW of
   // rounds at once.
+  bool head_emitted = false, front_emitted = false;   // first window's main-stream head (see emit_head)
   int r = 0, k = 0;
   while (r < R) {
     int w = 1;
@@ -1362,6 +1371,28 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // its first targets — the last one runs as persistent tiles that stay off the chain's CUs.
     // Small leading pieces shorten the wait of round 0 (one round = one workgroup per CU, ~20 us),
     // and the second piece is sized so that it is done when round 0's chain is.
+    // main-stream head of the call's first window (see the hook in the piece loop below): x of the
+    // whole window, then the front half of round 0's chain
+    float* xwin = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
+    static const bool no_chain_dbg = env_int("PEARL_AMD_DEBUG_NO_CHAIN", 0) != 0;
+    const int gw_chain = dp ? -world : 1;
+    auto emit_head = [&]() -> int {
+      head_emitted = true;
+      pa_batch_out o;
+      memset(&o, 0, sizeof(o));
+      o.x = xwin;
+      o.rep_dim = d.action_dim;
+      o.rep_onehot = args->rep_onehot;
+      {
+        ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
+        int rc2 = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
+        if (rc2 != PA_OK) return rc2;
+      }
+      if (no_chain_dbg) return PA_OK;
+      h->cur_round = r;
+      front_emitted = true;
+      return chain_front(h, xwin, B, h->yw[p], true, gw_chain, s, true);
+    };
     int sched[4] = {w, 0, 0, 0}, npieces = 1;
     if (overlap && h->split_first > 0) {
       int digits[3], nd = 0;
@@ -1425,25 +1456,27 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
                               (prio && pc == 0 && !last) ? B : 0);
       if (rc != PA_OK) return rc;
       j0 += nj;
+      // The call's first window: the host is the pacemaker here (nothing is queued ahead), and the
+      // chain's own head — gather of x, forward of round 0: 25 us of device time — must not wait
+      // behind the ~45 us of host time the remaining side-stream launches of the window take to
+      // enqueue (rocprof: x was gathered 45 us after the first targets existed).  So: first
+      // target piece, THEN the main stream's head, then the rest of the window's target work.
+      if (overlap && k == 0 && pc == 0 && !head_emitted && !no_chain_dbg) {
+        rc = emit_head();
+        if (rc != PA_OK) return rc;
+      }
     }
     // ---- main stream: the per-round chains.  x of the window was gathered by the side stream
     // (long ago for every window but the first): the event is normally already complete
-    float* xwin = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
     if (overlap && k > 0) {
       PA_HIP(hipStreamWaitEvent(s, h->ev_gather[p], 0));
-    } else if (overlap) {
-      pa_batch_out o;
-      memset(&o, 0, sizeof(o));
-      o.x = xwin;
-      o.rep_dim = d.action_dim;
-      o.rep_onehot = args->rep_onehot;
-      ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
-      rc = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
+    } else if (overlap && !head_emitted) {
+      rc = emit_head();      // (no leading piece ran the hook: a one-piece window)
       if (rc != PA_OK) return rc;
     }
-    // diagnostics only (tools/gpu_r02_c.sh): the target side of the loop with the chain left out,
-    // to tell the target kernel's own speed on its share of the chip from co-run interference
-    static const bool no_chain = env_int("PEARL_AMD_DEBUG_NO_CHAIN", 0) != 0;
+    // diagnostics only: the target side of the loop with the chain left out, to tell the target
+    // kernel's own speed on its share of the chip from co-run interference
+    const bool no_chain = no_chain_dbg;
     if (no_chain) h->y_clean = false;
     if (no_chain && h->pending_signal) {
       hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, s, h->sig, h->pending_signal);
@@ -1456,16 +1489,19 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const float* xj = xwin + (int64_t)j * B * h->IN;
       const float* yj = h->yw[p] + (int64_t)j * B;
       float* lo = args->losses_out ? args->losses_out + round : nullptr;
+      const bool split_rp = overlap && j == 0;
+      if (!(k == 0 && j == 0 && front_emitted)) {
+        rc = chain_front(h, xj, B, yj, overlap, gw_chain, s, split_rp);
+        if (rc != PA_OK) return rc;
+      }
       if (!dp) {
-        rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, 1, lo, soft_next, s,
-                          overlap && j == 0);
+        rc = chain_back(h, xj, B, yj, overlap, args->adam_step0 + round + 1, 1, lo, soft_next, s, split_rp);
         if (rc != PA_OK) return rc;
         continue;
       }
       // data parallel: local gradients (pre-scaled by 1/world) -> SUM all-reduce -> AdamW.  The
       // exchange hides behind the target work of the side stream.
-      rc = online_chain(h, xj, B, yj, overlap, args->adam_step0 + round + 1, -world, lo, 0, s,
-                        overlap && j == 0);
+      rc = chain_back(h, xj, B, yj, overlap, args->adam_step0 + round + 1, -world, lo, 0, s, split_rp);
       if (rc != PA_OK) return rc;
       PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
                  PA_ERR_HIP, "allreduce_start hook failed");

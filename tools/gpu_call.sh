@@ -166,3 +166,39 @@ if [ "$MODE" == "g" ]; then
   head -90 $R/gpurun_out/shortcall_timeline.txt | cut -c1-130
   rm -f $DB
 fi
+if [ "$MODE" == "pmc" ]; then
+  # separate counter passes (kernel trace + --pmc only) over the single-stream loop
+  export PEARL_AMD_OVERLAP=0
+  cd /tmp && export TMPDIR=/tmp
+  for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    rm -rf $R/gpurun_out/pmc_$tag
+    timeout 600 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_$tag -o dqn --output-format csv -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --timing-level 0 > $R/gpurun_out/pmc_$tag.log 2>&1
+    echo "pmc $tag rc=$?"
+  done
+  F=$(ls $R/gpurun_out/pmc_FETCH_SIZE/*counter_collection.csv $R/gpurun_out/pmc_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
+  W=$(ls $R/gpurun_out/pmc_WRITE_SIZE/*counter_collection.csv $R/gpurun_out/pmc_WRITE_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
+  python $R/tools/pmc_traffic.py $F $W --kernel target_split_kernel --transitions 10240 --algorithmic 1033 --note "U row 1024 + reward 4 + term 1 + y 4 per transition; the shared [A, AD] action table and W2' planes (393 KB) stay in L2" > $R/gpurun_out/pmc_target.json; cat $R/gpurun_out/pmc_target.json
+  python $R/tools/pmc_traffic.py $F $W --kernel gather_kernel --transitions 10240 --algorithmic 2130 --note "window gather: next_state + reward + term read and written, state + action read, x written" > $R/gpurun_out/pmc_gather.json; cat $R/gpurun_out/pmc_gather.json
+  python $R/tools/pmc_summary.py $(ls $R/gpurun_out/pmc_*/*counter_collection.csv $R/gpurun_out/pmc_*/*/*counter_collection.csv 2>/dev/null) > $R/gpurun_out/pmc_summary.txt 2>&1; head -40 $R/gpurun_out/pmc_summary.txt | cut -c1-260
+  rm -f $R/gpurun_out/pmc_*/*kernel_trace.csv
+fi
+if [ "$MODE" == "h" ]; then
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -8 gpurun_out/pytest_gpu.log
+  for i in 1 2 3; do
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20_$i.log 2> gpurun_out/bench_s20_$i.err
+    echo "bench s20 #$i rc=$?"; tail -1 gpurun_out/bench_s20_$i.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state',{}).get('value'))"
+  done
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+  echo "shortcall rc=$?"; cut -c1-200 gpurun_out/shortcall.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_sc
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_timeline.txt 2>&1
+  head -24 $R/gpurun_out/shortcall_timeline.txt | cut -c1-130
+  rm -f $DB
+  cd $R
+  bash tools/gpu_call.sh pmc
+fi
