@@ -1321,6 +1321,33 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // path), so that even the driver's 20-round call carries several sampled launches
     const bool short_call = R < 100;
     const bool sample_w = short_call || (k % 4) == 0;
+    // main-stream head of the call's first window (see the hook in the piece loop below): x of the
+    // whole window, then the front half of round 0's chain
+    float* xwin = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
+    static const bool no_chain_dbg = env_int("PEARL_AMD_DEBUG_NO_CHAIN", 0) != 0;
+    const int gw_chain = dp ? -world : 1;
+    auto emit_gather_x = [&]() -> int {
+      pa_batch_out o;
+      memset(&o, 0, sizeof(o));
+      o.x = xwin;
+      o.rep_dim = d.action_dim;
+      o.rep_onehot = args->rep_onehot;
+      ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
+      return arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
+    };
+    auto emit_head = [&]() -> int {
+      head_emitted = true;
+      if (no_chain_dbg) return PA_OK;
+      h->cur_round = r;
+      front_emitted = true;
+      return chain_front(h, xwin, B, h->yw[p], true, gw_chain, s, true);
+    };
+    // (x of the call's first window: it needs nothing from the side stream, so it goes out first —
+    // one launch ahead of the side stream's critical gather -> U -> first target piece)
+    if (overlap && k == 0) {
+      rc = emit_gather_x();
+      if (rc != PA_OK) return rc;
+    }
     // ---- side stream: target inputs of the window
     {
       pa_batch_out o;
@@ -1371,28 +1398,6 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // its first targets — the last one runs as persistent tiles that stay off the chain's CUs.
     // Small leading pieces shorten the wait of round 0 (one round = one workgroup per CU, ~20 us),
     // and the second piece is sized so that it is done when round 0's chain is.
-    // main-stream head of the call's first window (see the hook in the piece loop below): x of the
-    // whole window, then the front half of round 0's chain
-    float* xwin = h->bb_x + (overlap ? (int64_t)p * h->wrows * h->IN : 0);
-    static const bool no_chain_dbg = env_int("PEARL_AMD_DEBUG_NO_CHAIN", 0) != 0;
-    const int gw_chain = dp ? -world : 1;
-    auto emit_head = [&]() -> int {
-      head_emitted = true;
-      pa_batch_out o;
-      memset(&o, 0, sizeof(o));
-      o.x = xwin;
-      o.rep_dim = d.action_dim;
-      o.rep_onehot = args->rep_onehot;
-      {
-        ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
-        int rc2 = arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
-        if (rc2 != PA_OK) return rc2;
-      }
-      if (no_chain_dbg) return PA_OK;
-      h->cur_round = r;
-      front_emitted = true;
-      return chain_front(h, xwin, B, h->yw[p], true, gw_chain, s, true);
-    };
     int sched[4] = {w, 0, 0, 0}, npieces = 1;
     if (overlap && h->split_first > 0) {
       int digits[3], nd = 0;

@@ -102,6 +102,25 @@ class PolicyLearner(nn.Module, ABC):
         n = len(replay_buffer)
         return n if (self._batch_size == -1 or n < self._batch_size) else self._batch_size
 
+    def invalidate_native_copies(self) -> None:
+        """Tell the HIP library that parameters were written behind its back.
+
+        The learners keep derived copies of the weights (MFMA fragment-major layouts, bf16 split
+        planes).  ``learn()`` rebuilds them from the parameters at the start of every call, and
+        ``learn_batch()`` notices writes that bump torch's version counters (``load_state_dict``,
+        in-place ops, a torch optimizer).  Writes through ``param.data`` — the reference's own
+        ``update_target_network`` idiom (common/utils.py:214-226) — are invisible to those counters:
+        after such a write, call this before the next ``learn_batch()``.  (No reference counterpart.)"""
+        flat = getattr(self, "_flat", None)
+        if isinstance(flat, dict):
+            for m in flat.values():
+                if hasattr(m, "invalidate"):
+                    m.invalidate()
+        nat = getattr(self, "_native", None)
+        if nat is not None and getattr(nat, "handle", None) is not None:
+            from .. import _native as N
+            N.check(N.lib().pa_dqn_invalidate(nat.handle))
+
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         if len(replay_buffer) == 0:
             return {}

@@ -184,6 +184,10 @@ class ActorCriticBase(PolicyLearner):
             for m in self._flat.values():      # validated on the first step, trusted until the end
                 if isinstance(m, FlatMlp):
                     m._loop_validated = False
+                    # every learn() call rebuilds the library's derived weight copies from the
+                    # parameters as they are now (one launch per network per CALL): torch's version
+                    # counters — the per-step check — cannot see writes through `.data`
+                    m.invalidate()
             native = self._learn_native_loop(replay_buffer, batch_size)
             if native is not None:
                 return native

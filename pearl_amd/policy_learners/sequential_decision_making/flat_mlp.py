@@ -229,6 +229,12 @@ class FlatMlp:
         self._pending_x = None
         return self
 
+    def invalidate(self) -> None:
+        """The parameters were (or may have been) written from outside the library: its derived
+        copies (MFMA fragment-major weights) are rebuilt by the next launch that needs them."""
+        if self.handle is not None:
+            N.check(N.lib().pa_mlp_invalidate(self.handle))
+
     def _flat_versions(self) -> Tuple:
         """Version counters of the PARAMETER tensors (online and target).  They alias the flat
         buffers' storage but keep their own counters (``param.data = view`` does not share them), and

@@ -202,3 +202,20 @@ if [ "$MODE" == "h" ]; then
   cd $R
   bash tools/gpu_call.sh pmc
 fi
+if [ "$MODE" == "i" ]; then
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log
+  for i in 1 2; do
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20_$i.log 2> gpurun_out/bench_s20_$i.err
+    echo "bench s20 #$i rc=$?"; tail -1 gpurun_out/bench_s20_$i.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state',{}).get('value'), d['roofline'].get('executed'))"
+  done
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+  echo "shortcall rc=$?"; cut -c1-200 gpurun_out/shortcall.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_sc
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_timeline.txt 2>&1
+  head -20 $R/gpurun_out/shortcall_timeline.txt | cut -c1-130
+  rm -f $DB
+fi
