@@ -180,6 +180,9 @@ struct GatherArgs {
   int64_t head, capacity;
   int32_t B, S, A, avail_dim, action_elems, action_dtype, reward_dtype;
   int32_t state_bytes, action_bytes, reward_bytes, avail_bytes, mask_bytes;
+  // optional: published by the first wave as soon as the launch starts ("everything before this
+  // launch on its stream is done": the call-start hand-off of pa_dqn_learn, one launch less)
+  int* signal_flag; int signal_value;
 };
 
 // One wave per sampled transition: coalesced 16-byte copies of the state rows,
@@ -189,6 +192,8 @@ struct GatherArgs {
 __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g.signal_flag && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(g.signal_flag, g.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (b >= g.B) return;
   int64_t slot = g.head + g.idx[b];
   if (slot >= g.capacity) slot -= g.capacity;
@@ -375,9 +380,11 @@ static int wait_ring_free(pa_arena* a) {
 }
 
 int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa_batch_out* out,
-                        hipStream_t s) {
+                        hipStream_t s, int* signal_flag, int signal_value) {
   GatherArgs g;
   memset(&g, 0, sizeof(g));
+  g.signal_flag = signal_flag;
+  g.signal_value = signal_value;
   g.c = a->c;
   g.o = *out;
   g.idx = idx_dev;

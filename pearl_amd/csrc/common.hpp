@@ -113,7 +113,7 @@ struct pa_arena {
 namespace pa {
 // Enqueue sample/gather into `out` (used by pa_dqn_learn).  Implemented in arena.hip.
 int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa_batch_out* out,
-                        hipStream_t s);
+                        hipStream_t s, int* signal_flag = nullptr, int signal_value = 0);
 int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const pa_batch_out* out,
                  int64_t* idx_out_dev, hipStream_t s);
 // Philox draw of `rounds` samples of B distinct indices (round r uses counter offset + r).

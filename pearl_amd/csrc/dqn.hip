@@ -48,6 +48,7 @@ struct pa_dqn {
   float *H1a, *H2a, *dZ2, *dZ1, *y, *nextv, *qbuf, *dq, *absd, *xpack, *loss_scratch;
   float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
   void* w2sp;  // the same matrix as bf16 split planes (target_split_kernel), H1 = H2 = 256 only
+  void* w2sp_online;  // Double DQN: split planes of the ONLINE W2 (rebuilt with w2f_online every round)
   int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
   int dw_tm;      // PEARL_AMD_DW_TM: rows per weight-gradient tile, 64 or 32 (0 = by the CU partition)
   int rp_split;   // PEARL_AMD_ROWPASS_SPLIT (default 1): window-first row pass as forward + backward
@@ -354,8 +355,8 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.mask_bstride = b->next_avail_bcast ? 0 : b->A;
   a.W1a = t.W1 + d.state_dim; a.ldw1 = h->IN;
   a.W2f = argmax ? h->w2f_online : h->w2f;
-  // (Double DQN's argmax pass runs on the ONLINE parameters, whose split planes are not kept)
-  a.W2sp = (argmax || !h->use_split) ? nullptr : h->w2sp;
+  // (Double DQN's argmax pass runs on the ONLINE parameters: their planes are rebuilt per round)
+  a.W2sp = !h->use_split ? nullptr : (argmax ? h->w2sp_online : h->w2sp);
   a.argmax = argmax;
   a.choice_rep = argmax ? h->choice_rep : nullptr;
   a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
@@ -432,7 +433,7 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
     a.IN = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
     a.pk = packed(h);
     a.pk.tW2f = h->w2f_online;
-    a.pk.tW2sp = nullptr;                        // the split planes stay the TARGET network's
+    a.pk.tW2sp = h->w2sp_online;                 // (never h->w2sp: those stay the TARGET network's)
     a.do_online = 0; a.do_target = 1;
     hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
     PA_LAUNCH_CHECK();
@@ -977,6 +978,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
       h->xpack = h->loss_scratch = h->w2f = h->W1f = h->W2f16 = h->W2tf = nullptr;
   h->w2f_online = h->choice_rep = nullptr;
   h->w2sp = nullptr;
+  h->w2sp_online = nullptr;
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
@@ -1071,6 +1073,11 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
   if (desc->double_q == 1) {
+    if (h->w2sp) {
+      float* sp = nullptr;
+      PA_WS(sp, w2sp_bytes() / 4);
+      h->w2sp_online = sp;
+    }
     PA_WS(h->w2f_online, w2f_floats(desc->hidden2, desc->hidden1));
     PA_WS(h->choice, B);
     PA_WS(h->choice_rep, B * desc->action_dim);
@@ -1086,7 +1093,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
-                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp,
+                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp, h->w2sp_online,
                   h->choice, h->choice_rep};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1244,6 +1251,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     if (rc != PA_OK) return rc;
   }
   hipStream_t t = overlap ? h->side : s;
+  int start_gen = 0;      // generation the first x gather publishes (call-start hand-off), 0: none
   ScopedTimer tm_all(h, "learn", s);
   // PolicyLearner.learn pre-increments _training_steps (policy_learner.py:183);
   // forward() soft-updates when (_training_steps + 1) % freq == 0 (:283-284).
@@ -1298,9 +1306,17 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
                                  (size_t)h->wrows, s));
       h->y_clean = true;
     }
-    // fresh work-stealing counters for this call's persistent target launches
-    rc = stream_hop(h, s, t, h->ev_start);
-    if (rc != PA_OK) return rc;
+    // the side stream starts behind everything enqueued on `s` so far (index lists, repack): with
+    // the device-word hand-off the word is published by the first launch of the main stream's
+    // head, the gather of x (no signal launch of its own)
+    if (h->use_flags) {
+      start_gen = ++h->sig_gen;
+      hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, start_gen, h->err_dev, h->err_host);
+      PA_LAUNCH_CHECK();
+    } else {
+      rc = stream_hop(h, s, t, h->ev_start);
+      if (rc != PA_OK) return rc;
+    }
   } else {
     h->y_clean = false;
   }
@@ -1333,7 +1349,10 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       o.rep_dim = d.action_dim;
       o.rep_onehot = args->rep_onehot;
       ScopedTimer tm(h, "gather_x", s, 2, 1, rows);
-      return arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s);
+      const int gen = start_gen;
+      start_gen = 0;
+      return arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s,
+                                 gen ? h->sig : nullptr, gen);
     };
     auto emit_head = [&]() -> int {
       head_emitted = true;

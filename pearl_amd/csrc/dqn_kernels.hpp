@@ -464,7 +464,8 @@ __device__ __forceinline__ void store_w2sp1(void* base, int n, int k, float v) {
 
 
 static __global__ __launch_bounds__(256) void repack_w2_kernel(const float* __restrict__ W2, int H2,
-                                                        int H1, float* __restrict__ W2f) {
+                                                        int H1, float* __restrict__ W2f,
+                                                        void* W2sp = nullptr) {
   const int nkg = t_nkg(H1);
   const int64_t total = w2f_floats(H2, H1) / 4;  // float4 slots
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
@@ -479,6 +480,8 @@ static __global__ __launch_bounds__(256) void repack_w2_kernel(const float* __re
     v.z = (n < H2 && k + 2 < H1) ? W2[(int64_t)n * H1 + k + 2] : 0.f;
     v.w = (n < H2 && k + 3 < H1) ? W2[(int64_t)n * H1 + k + 3] : 0.f;
     reinterpret_cast<float4*>(W2f)[e] = v;
+    // the bf16 split planes of the same matrix (target_split_kernel), whole 256 x 256 matrices only
+    if (W2sp && H1 == TS_H && H2 == TS_H) store_w2sp4(W2sp, n, k, v);
   }
 }
 

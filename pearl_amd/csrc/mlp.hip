@@ -92,6 +92,7 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   if (h->qa_w2f) (void)hipFree(h->qa_w2f);
   if (h->qa_u) (void)hipFree(h->qa_u);
+  if (h->qa_w2sp) (void)hipFree(h->qa_w2sp);
   if (h->aux && h->aux_free) h->aux_free(h->aux);
   for (int l = 0; l < PA_MLP_MAX_LAYERS; ++l) {
     if (h->wf[l]) (void)hipFree(h->wf[l]);
@@ -590,12 +591,21 @@ extern "C" int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, i
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   PA_HIP(hipSetDevice(d.device));
   const int H1 = d.dims[1], H2 = d.dims[2];
+  // 256 x 256 hidden layers take the bf16x3 split kernel (target_split_kernel.hpp: fp32 accuracy at
+  // 2.67x the fp32 matrix rate) — PEARL_AMD_TARGET_SPLIT=0: the fp32-MFMA kernel for every shape
+  static const bool use_split = []() {
+    const char* v = getenv("PEARL_AMD_TARGET_SPLIT");
+    return !(v && *v == '0');
+  }();
+  const bool split = use_split && H1 == TS_H && H2 == TS_H;
   if (!h->qa_w2f) {
     PA_HIP(hipMalloc((void**)&h->qa_w2f, (size_t)w2f_floats(H2, H1) * sizeof(float)));
     PA_HIP(hipMalloc((void**)&h->qa_u, (size_t)d.max_batch * H1 * sizeof(float)));
   }
+  if (split && !h->qa_w2sp) PA_HIP(hipMalloc(&h->qa_w2sp, (size_t)w2sp_bytes()));
   // the parameters may have stepped since the last call: rebuild the fragment-major W2 (3 us)
-  hipLaunchKernelGGL(repack_w2_kernel, dim3(64), dim3(256), 0, s, P + h->woff[1], H2, H1, h->qa_w2f);
+  hipLaunchKernelGGL(repack_w2_kernel, dim3(64), dim3(256), 0, s, P + h->woff[1], H2, H1, h->qa_w2f,
+                     split ? h->qa_w2sp : nullptr);
   PA_LAUNCH_CHECK();
   GemmArgs g;
   memset(&g, 0, sizeof(g));
@@ -613,6 +623,7 @@ extern "C" int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, i
   a.feat = rep; a.feat_bstride = rep_bstride;
   a.W1a = P + h->woff[0] + S; a.ldw1 = d.dims[0];
   a.W2f = h->qa_w2f;
+  a.W2sp = split ? h->qa_w2sp : nullptr;
   a.b2 = P + h->boff[1]; a.w3 = P + h->woff[2]; a.b3 = P + h->boff[2];
   a.q_all = q_out;
   a.B = rows; a.A = A; a.AD = AD; a.H1 = H1; a.H2 = H2;

@@ -21,6 +21,7 @@ struct pa_mlp {
   // product [max_batch, H1], the two operands target_fused_kernel needs beside the parameters
   float* qa_w2f;
   float* qa_u;
+  void* qa_w2sp;                  // the same W2 as bf16 split planes (H1 = H2 = 256)
   // row-pass path (mlp_rowpass.hpp): fragment-major copies of every layer — online W_l and W_l^T,
   // target W_l — rebuilt lazily by ONE launch when the parameters may have changed (bind, AdamW,
   // soft update, pa_mlp_invalidate)

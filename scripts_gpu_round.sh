@@ -13,9 +13,9 @@ echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
 fi
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2>&1
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
 echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | cut -c1-1400
-timeout 900 python bench.py $BENCH_ARGS > gpurun_out/bench.log 2>&1
+timeout 900 python bench.py $BENCH_ARGS --no-cpu-baseline > gpurun_out/bench.log 2> gpurun_out/bench.err
 echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-1400
 PEARL_AMD_OVERLAP=0 timeout 600 python bench.py --timing-level 2 --no-cpu-baseline > gpurun_out/bench_l2.log 2>&1
 echo "bench l2 rc=$?"; tail -1 gpurun_out/bench_l2.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('stage_us'))"
@@ -34,6 +34,12 @@ PEARL_AMD_FORCE_DP=1 timeout 600 python -m torch.distributed.run --nnodes=1 --np
 echo "bench dp1 rc=$?"; tail -1 gpurun_out/bench_dp1.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d.get('comm'))"
 timeout 300 python tools/allreduce_latency.py > gpurun_out/allreduce_latency.json 2> gpurun_out/allreduce_latency.err
 echo "allreduce rc=$?"; cat gpurun_out/allreduce_latency.json
+# PPO (BASELINE config 4) through the driver-style torchrun line with a 1-rank RCCL communicator:
+# actor + critic gradients as ONE ncclAllReduce per step
+PEARL_AMD_FORCE_DP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+  --master-addr 127.0.0.1 --master-port 29541 bench_algos.py --steps 200 --only ppo --cpu-seconds 1 \
+  > gpurun_out/ppo_dp1.jsonl 2> gpurun_out/ppo_dp1.err
+echo "ppo dp1 rc=$?"; grep '^{' gpurun_out/ppo_dp1.jsonl | cut -c1-300
 # the fused SAC step: in-kernel phase stamps
 timeout 300 python tools/prof_sac.py > gpurun_out/prof_sac.txt 2>&1
 echo "prof_sac rc=$?"; grep -E "whole launch|^end" gpurun_out/prof_sac.txt
@@ -50,7 +56,7 @@ rm -rf $R/gpurun_out/prof
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof rc=$?"; tail -1 $R/gpurun_out/rocprof.log | cut -c1-200
 python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db > $R/gpurun_out/kernel_stats.txt 2>&1
-python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_fused 40 >> $R/gpurun_out/kernel_stats.txt 2>&1
+python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_split 60 >> $R/gpurun_out/kernel_stats.txt 2>&1
 head -12 $R/gpurun_out/kernel_stats.txt
 rm -f $R/gpurun_out/prof/*.db
 rm -rf $R/gpurun_out/prof_sc
@@ -60,11 +66,5 @@ python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_time
 head -3 $R/gpurun_out/shortcall_timeline.txt
 rm -f $DB
 if [ "$1" == "pmc" ]; then
-  export PEARL_AMD_OVERLAP=0
-  for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES" "FETCH_SIZE" "WRITE_SIZE GRBM_GUI_ACTIVE"; do
-    tag=$(echo $set | cut -d' ' -f1)
-    rm -rf $R/gpurun_out/pmc_$tag
-    timeout 600 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_$tag -o dqn --output-format csv -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --timing-level 0 > $R/gpurun_out/pmc_$tag.log 2>&1
-    echo "pmc $tag rc=$?"
-  done
+  cd $R && bash tools/gpu_call.sh pmc
 fi
