@@ -335,8 +335,9 @@ def main():
                     "note": "executed bf16-MFMA FLOPs against the dense bf16 peak (2.5 PFLOP/s)"}
             if isolated and live:
                 iach, iper = kernel_rate(isolated)
-                line["roofline"]["concurrent_with"] = ("online chain kernels on the 64 CUs the "
-                                                       "persistent launches keep off (overlapped loop)")
+                line["roofline"]["concurrent_with"] = (
+                    "online chain kernels on the CUs the persistent launches keep off (overlapped loop; "
+                    + os.environ.get("PEARL_AMD_RESERVED_CUS", "128" if split_on else "64") + " of 256)")
                 line["roofline"]["isolated"] = {
                     "achieved": iach / 1e12, "frac": iach / PEAK_F32_MFMA,
                     "avg_launch_us": isolated["avg_us"], "transitions_per_launch": iper,
