@@ -417,10 +417,26 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
                        float soft_tau, hipStream_t s, const TailJob* tail = nullptr) {
   pa_mlp* h0 = hs[0];
   const int L = h0->L;
+  // 32-row tiles (weight_grad_kernel32: twice the workgroups, half the MFMA time each, bitwise the
+  // same sums) when the launch would otherwise leave most of the chip idle: small batches (no
+  // split-K) whose 32-row tiling still fits one workgroup per CU.  PEARL_AMD_MLP_DW_TM=64: never.
+  static const int dw_tm_env = []() {
+    const char* v = getenv("PEARL_AMD_MLP_DW_TM");
+    return v && *v ? atoi(v) : 0;
+  }();
   for (int l0 = 0; l0 < L; l0 += 3) {
     DwArgs a;
     memset(&a, 0, sizeof(a));
     int t0 = 0;
+    int TM = DW_TM;
+    {
+      int tiles32 = 0;
+      for (int ni = 0; ni < nnet; ++ni)
+        for (int l = l0; l < L && l < l0 + 3; ++l)
+          tiles32 += (int)(ceil_div(hs[ni]->d.dims[l + 1], 32) * ceil_div(hs[ni]->d.dims[l], DW_TN));
+      if (dw_tm_env == 32 || (dw_tm_env == 0 && B < 2048 && tiles32 + 1 <= 232)) TM = 32;
+    }
+    a.tm = TM;
     for (int ni = 0; ni < nnet; ++ni) {
       pa_mlp* h = hs[ni];
       for (int l = l0; l < L && l < l0 + 3; ++l) {
@@ -447,7 +463,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
             if (soft_tau >= 0.f && h->packed_t_ok) pr.pkf_t = h->wf_t[l];
           }
         }
-        t0 += (int)ceil_div(h->d.dims[l + 1], DW_TM) * pr.tiles_n;
+        t0 += (int)ceil_div(h->d.dims[l + 1], TM) * pr.tiles_n;
       }
     }
     a.total_tiles = t0;
