@@ -49,6 +49,8 @@ struct pa_dqn {
   float* w2f;  // fragment-major copy of the target net's W2 (target_fused_kernel's weight operand)
   void* w2sp;  // the same matrix as bf16 split planes (target_split_kernel), H1 = H2 = 256 only
   void* w2sp_online;  // Double DQN: split planes of the ONLINE W2 (rebuilt with w2f_online every round)
+  void* w1sp;  // the target W1's state columns as split planes: the split tile forms U itself
+  int fuse_u;  // PEARL_AMD_FUSE_U (default 1): no first-layer GEMM launch in front of split target passes
   int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
   int dw_tm;      // PEARL_AMD_DW_TM: rows per weight-gradient tile, 64 or 32 (0 = by the CU partition)
   int rp_split;   // PEARL_AMD_ROWPASS_SPLIT (default 1): window-first row pass as forward + backward
@@ -331,21 +333,22 @@ GemmArgs target_l1_problem(pa_dqn* h, const float* next_state, int rows, float* 
   return g;
 }
 
+// The split tile forms U = W1s' s' + b1' itself (target_split_kernel.hpp) when the pass runs on the
+// TARGET parameters, the planes exist, and a 64-row tile holds at most 32 transitions (A >= 2):
+// no first-layer GEMM launch, no [rows][H1] round trip through HBM.
+bool fuse_u_ok(const pa_dqn* h, int A) {
+  return h->fuse_u && h->use_split && h->w2sp && h->w1sp && A >= 2 && T_ROWS / A <= 32 &&
+         target_split_fusable_S(h->d.state_dim);
+}
+
 // max_a' Q_target(s', a') and the Bellman target  (deep_q_learning.py:130-167,
 // deep_td_learning.py:313-317) for b->B transitions (a whole window of rounds inside learn());
 // U (= W1s' s' + b1' of the same rows) must already be computed.
-int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
-                       hipStream_t s, bool persistent = false, int* argmax = nullptr,
-                       bool sample_timer = true, bool no_pingpong = false,
-                       int prio_first_rows = 0) {
-  // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
-  // maximum (Double DQN's action choice); always the classic grid
+// The operands of one target pass; `fused_u` (out): the split tile forms U itself.
+TargetArgs make_target_args(const pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v,
+                            float* y, int* argmax, bool* split_out, bool* fused_u) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs t = net_ptrs(h, argmax ? h->bufs.q : h->bufs.q_target);
-  // level 1: only the launches the caller marks (learn(): the last, largest piece of every 4th
-  // window of a call, the first window included, so that even a 3-window call is sampled);
-  // level 2: every launch
-  ScopedTimer tm(h, "target", s, (sample_timer || h->timing >= 2) ? 1 : 2, 1, b->B);
   TargetArgs a;
   memset(&a, 0, sizeof(a));
   a.U = U; a.ldu = d.hidden1;
@@ -366,9 +369,39 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   a.B = b->B; a.A = b->A; a.AD = d.action_dim; a.H1 = d.hidden1; a.H2 = d.hidden2;
   a.bpw = T_ROWS / b->A;
   a.ntiles = (int)ceil_div(b->B, a.bpw);
+  const bool split = a.W2sp && t_nkg(a.H1) == 32 && target_fast_shape(a, 32);
+  const bool fuse = split && !argmax && fuse_u_ok(h, b->A) && b->next_state;
+  if (fuse) {
+    a.W1sp = h->w1sp;
+    a.next_state = b->next_state; a.ld_next = d.state_dim;
+    a.b1 = t.b1;
+    a.S = d.state_dim;
+  }
+  if (split_out) *split_out = split;
+  if (fused_u) *fused_u = fuse;
+  return a;
+}
+// Will run_target_fused_u on this batch form U in the tile?  (callers skip the first-layer GEMM)
+bool target_fuses_u(const pa_dqn* h, const pa_dqn_batch* b) {
+  bool fuse = false;
+  (void)make_target_args(h, b, h->Uw[0], nullptr, nullptr, nullptr, nullptr, &fuse);
+  return fuse;
+}
+
+int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
+                       hipStream_t s, bool persistent = false, int* argmax = nullptr,
+                       bool sample_timer = true, bool no_pingpong = false,
+                       int prio_first_rows = 0) {
+  // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
+  // maximum (Double DQN's action choice); always the classic grid
+  // level 1: only the launches the caller marks (learn(): the last, largest piece of every 4th
+  // window of a call, the first window included, so that even a 3-window call is sampled);
+  // level 2: every launch
+  ScopedTimer tm(h, "target", s, (sample_timer || h->timing >= 2) ? 1 : 2, 1, b->B);
+  bool split = false;
+  TargetArgs a = make_target_args(h, b, U, next_v, y, argmax, &split, nullptr);
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
   if (prio_first_rows > 0) a.prio_tiles = (int)ceil_div(prio_first_rows, a.bpw);
-  const bool split = a.W2sp && t_nkg(a.H1) == 32 && target_fast_shape(a, 32);
   const bool pp = !argmax && !no_pingpong && !split &&
                   (h->pingpong == 2 || (h->pingpong == 1 && persistent));
   if (persistent || pp) {
@@ -391,6 +424,7 @@ PackedW packed(pa_dqn* h) {
   PackedW pk;
   pk.W1f = h->W1f; pk.W2f = h->W2f16; pk.W2tf = h->W2tf; pk.tW2f = h->w2f;
   pk.tW2sp = h->w2sp;
+  pk.tW1sp = h->w1sp; pk.sp_S = h->d.state_dim;
   return pk;
 }
 
@@ -434,6 +468,7 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
     a.pk = packed(h);
     a.pk.tW2f = h->w2f_online;
     a.pk.tW2sp = h->w2sp_online;                 // (never h->w2sp: those stay the TARGET network's)
+    a.pk.tW1sp = nullptr;
     a.do_online = 0; a.do_target = 1;
     hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
     PA_LAUNCH_CHECK();
@@ -473,7 +508,7 @@ int run_next_values(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, h
     return run_target_fused_u(h, &one, h->Uw[0], next_v, y, s);
   }
   if (h->d.double_q) return run_double_targets(h, b, next_v, y, s);
-  {
+  if (!target_fuses_u(h, b)) {       // (the split tile forms U itself otherwise)
     ScopedTimer tm(h, "target_l1", s);
     GemmArgs g = target_l1_problem(h, b->next_state, b->B, h->Uw[0]);
     int rc = launch_linear<false>(&g, 1, s);
@@ -647,6 +682,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
     a.ad.one_minus_tau = (float)(1.0 - (double)d.tau);
     a.ad.tW2f = h->w2f; a.ad.nkg_t = t_nkg(d.hidden1);
     a.ad.tW2sp = h->w2sp;
+    a.ad.tW1sp = h->w1sp; a.ad.sp_S = d.state_dim;
   }
   return launch_weight_grad(a, loss_out != nullptr, s);
 }
@@ -669,6 +705,7 @@ int run_adamw(pa_dqn* h, int64_t step, int soft_next, hipStream_t s) {
   a.f.tgt = h->bufs.q_target; a.f.tau = d.tau; a.f.one_minus_tau = (float)(1.0 - (double)d.tau);
   a.f.tW2f = h->w2f; a.f.nkg_t = t_nkg(d.hidden1);
   a.f.tW2sp = h->w2sp;
+  a.f.tW1sp = h->w1sp; a.f.sp_S = d.state_dim;
   a.g = h->bufs.grad;
   a.n = h->P;
   for (int i = 0; i < 6; ++i) a.off[i] = h->off[i];
@@ -979,6 +1016,8 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->w2f_online = h->choice_rep = nullptr;
   h->w2sp = nullptr;
   h->w2sp_online = nullptr;
+  h->w1sp = nullptr;
+  h->fuse_u = env_int("PEARL_AMD_FUSE_U", 1);
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
@@ -1068,6 +1107,11 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
     float* sp = nullptr;
     PA_WS(sp, w2sp_bytes() / 4);
     h->w2sp = sp;
+    if ((desc->state_dim & 15) == 0 && desc->state_dim <= TS_H) {
+      float* sp1 = nullptr;
+      PA_WS(sp1, wsp_bytes(desc->state_dim >> 4) / 4);
+      h->w1sp = sp1;
+    }
   }
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
@@ -1093,7 +1137,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   (void)hipDeviceSynchronize();
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
-                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp, h->w2sp_online,
+                  h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp, h->w2sp_online, h->w1sp,
                   h->choice, h->choice_rep};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1457,7 +1501,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // U = s' W1s'^T + b1': ONE launch for all leading (classic-grid) pieces together — a launch
       // per piece put a 7-20 us GEMM between every two target launches on this stream — and one
       // for the persistent remainder
-      if (pc == 0 || pc == npieces - 1) {
+      if ((pc == 0 || pc == npieces - 1) && !target_fuses_u(h, &b)) {
         int cover = nj;
         if (pc == 0 && npieces > 1) {
           cover = 0;

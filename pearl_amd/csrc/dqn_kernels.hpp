@@ -325,6 +325,13 @@ struct TargetArgs {
   const float* W2f;                         // fragment-major W2' (see w2f_index)
   const void* W2sp;                         // optional: W2' as bf16 split planes (w2sp_index):
                                             // target_split_kernel instead of the fp32-MFMA kernels
+  // optional (target_split_kernel only): the first-layer state product computed in the tile —
+  // U[b] = W1s' s'[b] + b1' as a bf16x3 product of the tile's distinct states — instead of read
+  // from `U`: no first-layer GEMM launch in front of the target pass, no [rows][H1] round trip
+  const void* W1sp;                         // W1'[:, :S] as split planes (wsp_index, ks = S / 16)
+  const float* next_state; int ld_next;     // s' [B][S]
+  const float* b1;                          // b1' [H1]
+  int S;                                    // state width (multiple of 16, <= 256) when W1sp is set
   const float* b2; const float* w3; const float* b3;
   const float* reward; const uint8_t* term;
   float gamma;
@@ -423,14 +430,16 @@ constexpr int TS_KS = TS_H / 16;     // k-steps of v_mfma_f32_32x32x16_bf16
 constexpr int TS_LDP = TS_H + 8;     // bf16 pitch of a plane row: 528 B = 4 dwords mod 64 banks
 constexpr int TS_RD = 4;             // k-steps of weights in flight per wave
 
-__host__ __device__ inline int64_t w2sp_bytes() { return (int64_t)8 * TS_KS * 3 * 64 * 16; }
-// bf16 element index of split s of W2'[n][k] in the fragment-major planes:
-//   slot ((wave * KS + kstep) * 3 + s) * 64 + lane holds the 8 bf16 that lane feeds one MFMA as its
+// Split planes of a weight matrix W[n][k] with ks = K / 16 k-steps (8 waves x 32 units = 256 rows):
+//   slot ((wave * ks + kstep) * 3 + s) * 64 + lane holds the 8 bf16 that lane feeds one MFMA as its
 //   A operand: unit n = 32 wave + (lane & 31), k = 16 kstep + 8 (lane >> 5) + e
-__host__ __device__ inline int64_t w2sp_index(int n, int k, int s) {
+__host__ __device__ inline int64_t wsp_bytes(int ks) { return (int64_t)8 * ks * 3 * 64 * 16; }
+__host__ __device__ inline int64_t wsp_index(int n, int k, int s, int ks) {
   const int w = n >> 5, lane = (n & 31) + 32 * ((k >> 3) & 1), g = k >> 4, e = k & 7;
-  return ((((int64_t)(w * TS_KS + g) * 3 + s) * 64) + lane) * 8 + e;
+  return ((((int64_t)(w * ks + g) * 3 + s) * 64) + lane) * 8 + e;
 }
+__host__ __device__ inline int64_t w2sp_bytes() { return wsp_bytes(TS_KS); }
+__host__ __device__ inline int64_t w2sp_index(int n, int k, int s) { return wsp_index(n, k, s, TS_KS); }
 
 __host__ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
   hi = (__bf16)x;                        // round to nearest even
@@ -440,7 +449,7 @@ __host__ __device__ __forceinline__ void split3(float x, __bf16& hi, __bf16& mid
 }
 
 // four consecutive k (k % 4 == 0) of one unit: one 8-byte store per plane
-__device__ __forceinline__ void store_w2sp4(void* base, int n, int k, const float4& v) {
+__device__ __forceinline__ void store_wsp4(void* base, int n, int k, const float4& v, int ks) {
   __bf16* p = static_cast<__bf16*>(base);
   const float x[4] = {v.x, v.y, v.z, v.w};
   bf16x4 q[3];
@@ -451,17 +460,22 @@ __device__ __forceinline__ void store_w2sp4(void* base, int n, int k, const floa
     q[0][j] = a; q[1][j] = b; q[2][j] = c;
   }
 #pragma unroll
-  for (int s = 0; s < 3; ++s) *reinterpret_cast<bf16x4*>(p + w2sp_index(n, k, s)) = q[s];
+  for (int s = 0; s < 3; ++s) *reinterpret_cast<bf16x4*>(p + wsp_index(n, k, s, ks)) = q[s];
 }
-__device__ __forceinline__ void store_w2sp1(void* base, int n, int k, float v) {
+__device__ __forceinline__ void store_wsp1(void* base, int n, int k, float v, int ks) {
   __bf16* p = static_cast<__bf16*>(base);
   __bf16 a, b, c;
   split3(v, a, b, c);
-  p[w2sp_index(n, k, 0)] = a;
-  p[w2sp_index(n, k, 1)] = b;
-  p[w2sp_index(n, k, 2)] = c;
+  p[wsp_index(n, k, 0, ks)] = a;
+  p[wsp_index(n, k, 1, ks)] = b;
+  p[wsp_index(n, k, 2, ks)] = c;
 }
-
+__device__ __forceinline__ void store_w2sp4(void* base, int n, int k, const float4& v) {
+  store_wsp4(base, n, k, v, TS_KS);
+}
+__device__ __forceinline__ void store_w2sp1(void* base, int n, int k, float v) {
+  store_wsp1(base, n, k, v, TS_KS);
+}
 
 static __global__ __launch_bounds__(256) void repack_w2_kernel(const float* __restrict__ W2, int H2,
                                                         int H1, float* __restrict__ W2f,
@@ -882,6 +896,7 @@ struct AdamFuse {
   int soft_next; float* tgt; float tau, one_minus_tau;
   float* tW2f; int nkg_t;            // target W2, 32x32x2 fragment-major
   void* tW2sp;                       // target W2 as bf16 split planes (null: not kept)
+  void* tW1sp; int sp_S;             // target W1[:, :sp_S] as split planes (null: not kept)
   const float* absd; int nabs; float inv_B; float* loss_out;  // mean |Q - target| of this step
   // overlapped learn loop: the Bellman targets of this round have been consumed by the row pass
   // (the previous launch on this stream); the loss workgroup hands the words back to the producer
@@ -966,6 +981,8 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
     if (kind == 0) {
       f.tW2f[w2f_index(row, col, f.nkg_t)] = t;
       if (f.tW2sp) store_w2sp1(f.tW2sp, row, col, t);
+    } else if (kind == 1 && f.tW1sp && col < f.sp_S) {
+      store_wsp1(f.tW1sp, row, col, t, f.sp_S >> 4);
     }
   }
 }
@@ -1429,6 +1446,9 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
           if (P.kind == 0) {
             *reinterpret_cast<float4*>(a.ad.tW2f + w2f_index(erow, ecol, a.ad.nkg_t)) = tn;
             if (a.ad.tW2sp) store_w2sp4(a.ad.tW2sp, erow, ecol, tn);
+          } else if (P.kind == 1 && a.ad.tW1sp) {
+            // (sp_S is a multiple of 16 and ecol of 4: a float4 is inside or outside the state part)
+            if (ecol < a.ad.sp_S) store_wsp4(a.ad.tW1sp, erow, ecol, tn, a.ad.sp_S >> 4);
           } else if (P.kind == 3 && P.pkf_t)
             *reinterpret_cast<float4*>(P.pkf_t + wf16_index_(erow, ecol, P.nkgf)) = tn;
         }

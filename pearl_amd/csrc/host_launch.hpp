@@ -71,19 +71,33 @@ int launch_target_t(const TargetArgs& a, hipStream_t s) {
 
 // target_split_kernel: one workgroup per CU (99 KB of LDS); persistent mode offers two per CU so
 // that the ones landing on reserved CUs (and exiting) leave no other CU empty
-inline int launch_target_split(const TargetArgs& a, hipStream_t s) {
+template <int KS1>
+int launch_target_split_t(const TargetArgs& a, hipStream_t s) {
   static bool configured = false;
   const size_t smem = target_split_smem_bytes();
   if (!configured) {
-    int rc = set_max_smem(target_split_kernel, smem);
+    int rc = set_max_smem(target_split_kernel<KS1>, smem);
     if (rc != PA_OK) return rc;
     configured = true;
   }
   unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
   if (a.tile_ctr) grid = a.reserved ? 512u : (unsigned)(a.ntiles < 256 ? a.ntiles : 256);
-  hipLaunchKernelGGL(target_split_kernel, dim3(grid), dim3(512), smem, s, a);
+  hipLaunchKernelGGL(target_split_kernel<KS1>, dim3(grid), dim3(512), smem, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
+}
+// state widths the tile can form U from itself (compile-time k-step counts)
+inline bool target_split_fusable_S(int S) { return S == 64 || S == 128 || S == 256; }
+inline int launch_target_split(const TargetArgs& a, hipStream_t s) {
+  if (!a.W1sp) return launch_target_split_t<0>(a, s);
+  switch (a.S) {
+    case 64: return launch_target_split_t<4>(a, s);
+    case 128: return launch_target_split_t<8>(a, s);
+    case 256: return launch_target_split_t<16>(a, s);
+    default:
+      set_error("target_split_kernel: fused first layer not built for S = %d", a.S);
+      return PA_ERR_UNSUPPORTED;
+  }
 }
 
 // classic grid (or, with a.tile_ctr, persistent tiles) of target_fused_kernel for the shape at hand

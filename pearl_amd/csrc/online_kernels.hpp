@@ -51,6 +51,8 @@ struct PackedW {
   float* W2tf;   // online W2^T [H1 units][H2]       (dX = dZ2 W2)
   float* tW2f;   // target W2, 32x32x2 fragment-major (target_fused_kernel)
   void* tW2sp;   // target W2 as bf16 split planes (target_split_kernel); null: not kept
+  void* tW1sp;   // target W1[:, :S] as bf16 split planes (the tile's own first-layer product); null: not kept
+  int sp_S;      // S of tW1sp (multiple of 16)
 };
 
 struct RepackArgs {
@@ -135,6 +137,17 @@ __device__ __forceinline__ void repack_body(const RepackArgs& a, int64_t t0, int
       // (only whole matrices take the split kernel: H1 = H2 = 256, see target_fast_shape)
       if (a.pk.tW2sp && n < a.H2 && k + 3 < a.H1 && a.H1 == TS_H && a.H2 == TS_H)
         store_w2sp4(a.pk.tW2sp, n, k, v);
+    }
+    if (a.pk.tW1sp && a.H1 == TS_H) {
+      // the state columns of the target W1 (row pitch IN) as split planes, four k per thread
+      const int S = a.pk.sp_S, ks = S >> 4;
+      const float* W1 = a.q_target + a.off_w1;
+      const int64_t total1 = (int64_t)a.H1 * (S >> 2);
+      for (int64_t e = t0; e < total1; e += gsz) {
+        const int n = (int)(e / (S >> 2)), k = (int)(e % (S >> 2)) * 4;
+        const float* src = W1 + (int64_t)n * a.IN + k;
+        store_wsp4(a.pk.tW1sp, n, k, make_float4(src[0], src[1], src[2], src[3]), ks);
+      }
     }
   }
 }

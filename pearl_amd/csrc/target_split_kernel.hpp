@@ -39,6 +39,8 @@ inline size_t target_split_smem_bytes() {
 
 // Same contract as target_tile<32, true>: the host has checked target_fast_shape (16-byte aligned
 // operands, AD <= 16 and a multiple of 4, H1 = H2 = 256).
+// KS1 > 0: the tile forms U itself from S = 16 KS1 state columns (a.W1sp etc. set); 0: U is read.
+template <int KS1>
 __device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile, unsigned char* smem) {
   __bf16* planes = reinterpret_cast<__bf16*>(smem);                        // [3][64][TS_LDP]
   float* qpart = reinterpret_cast<float*>(smem + (size_t)3 * T_ROWS * TS_LDP * 2);   // [8][64]
@@ -65,21 +67,104 @@ __device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile,
   f32x16 acc[2];
   int64_t foff[2];
   bool fok[2];
+  int rowb[2];     // tile-local transition of this lane's row (0 for rows past the tile)
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
     const int row = tm * 32 + l31;
     const bool rok = row < nrows;
     const int rr = rok ? row : 0;
-    const int bb = b0 + rr / a.A;
+    rowb[tm] = rr / a.A;
+    const int bb = b0 + rowb[tm];
     fok[tm] = rok;
     foff[tm] = (int64_t)bb * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
+    if constexpr (KS1 == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nq0 + 8 * q;
+        const float4 u = ld4_or_zero(a.U, (int64_t)bb * a.ldu + n, rok);
+        acc[tm][4 * q + 0] = u.x; acc[tm][4 * q + 1] = u.y;
+        acc[tm][4 * q + 2] = u.z; acc[tm][4 * q + 3] = u.w;
+      }
+    }
+  }
+  if constexpr (KS1 > 0) {
+    // ---- U[b] = W1s' s'[b] + b1' for the tile's <= 32 distinct transitions, in the tile: the states
+    // split three ways into LDS planes (the h1 planes' space, rows = transitions), a bf16x3 product
+    // with the W1s' planes (one 32-column MFMA tile: column j = transition j), then every row of the
+    // tile fetches its transition's column with a lane shuffle.  (host: bpw <= 32, S % 16 == 0, S <= 256)
+    constexpr int ks1 = KS1, s4 = 4 * KS1;       // S = 16 KS1 (compile time: every offset an immediate)
+    for (int e = tid; e < 32 * s4; e += 512) {
+      const int t = e / s4, k = (e - t * s4) * 4;
+      const float4 v = ld4_or_zero(a.next_state, (int64_t)(b0 + t) * a.ld_next + k, t < nb);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+      bf16x4 p[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __bf16 x0, x1, x2;
+        split3(xv[j], x0, x1, x2);
+        p[0][j] = x0; p[1][j] = x1; p[2][j] = x2;
+      }
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp)
+        *reinterpret_cast<bf16x4*>(planes + (size_t)(sp * T_ROWS + t) * TS_LDP + k) = p[sp];
+    }
+    // this lane's 16 bias values (added at the end), and the first W1s' k-steps
+    float4 b1v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b1v[q] = ld4_or_zero(a.b1, nq0 + 8 * q, true);
+    bf16x8 ring1[TS_RD][3];
+    const unsigned w1base = (unsigned)((wave * ks1 * 3 * 64 + lane) * 16);
+#pragma unroll
+    for (int g = 0; g < TS_RD && g < ks1; ++g)
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp)
+        ring1[g][sp] = ld_bf16x8(a.W1sp, w1base + (unsigned)(g * 3 + sp) * 1024u);
+    __syncthreads();
+    f32x16 cu[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cu[c][r] = 0.f;
+    const __bf16* sp0 = planes + (size_t)l31 * TS_LDP + 8 * h;
+#pragma unroll
+    for (int g = 0; g < ks1; ++g) {
+      bf16x8 wa[3];
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp) wa[sp] = ring1[g % TS_RD][sp];
+      if (g + TS_RD < ks1) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          ring1[g % TS_RD][sp] = ld_bf16x8(a.W1sp, w1base + (unsigned)((g + TS_RD) * 3 + sp) * 1024u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        bf16x8 b[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          b[sp] = *reinterpret_cast<const bf16x8*>(sp0 + (size_t)sp * T_ROWS * TS_LDP + 16 * g);
+        cu[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], b[2], cu[2], 0, 0, 0);
+        cu[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[2], b[0], cu[2], 0, 0, 0);
+        cu[2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], b[1], cu[2], 0, 0, 0);
+        cu[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], b[1], cu[1], 0, 0, 0);
+        cu[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[1], b[0], cu[1], 0, 0, 0);
+        cu[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[0], b[0], cu[0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // U[unit][transition = l31] of this lane -> acc[tm][unit] of the lane that owns row 32 tm + l31
+    // (same lane half: a unit's half is a property of the unit)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int n = nq0 + 8 * q;
-      const float4 u = ld4_or_zero(a.U, (int64_t)bb * a.ldu + n, rok);
-      acc[tm][4 * q + 0] = u.x; acc[tm][4 * q + 1] = u.y;
-      acc[tm][4 * q + 2] = u.z; acc[tm][4 * q + 3] = u.w;
+      const float bq4[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        const float u = ((cu[2][r] + cu[1][r]) + cu[0][r]) + bq4[j];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm) acc[tm][r] = __shfl(u, rowb[tm] + 32 * h, 64);
+      }
     }
+    __syncthreads();   // every wave is done with the state planes: h1 may overwrite them
   }
   const int wcol = wave * 32 + l31;      // hidden unit this lane feeds as the A operand
   const int64_t woff = (int64_t)wcol * a.ldw1;
@@ -249,11 +334,12 @@ __device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile,
 
 // Classic grid (tile = blockIdx.x) or, with a.tile_ctr, persistent work-stealing tiles that stay
 // off the CUs reserved for the online chain — the two modes of target_fused_kernel.
+template <int KS1>
 static __global__ __launch_bounds__(512, 2) void target_split_kernel(TargetArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_split[];
   if (a.tile_ctr == nullptr) {
     if ((int)blockIdx.x < a.prio_tiles) __builtin_amdgcn_s_setprio(3);
-    target_tile_split(a, blockIdx.x, smem_split);
+    target_tile_split<KS1>(a, blockIdx.x, smem_split);
     return;
   }
   __shared__ int next_tile;
@@ -264,7 +350,7 @@ static __global__ __launch_bounds__(512, 2) void target_split_kernel(TargetArgs 
   while (tile < a.ntiles) {
     int ahead = 0;
     if (threadIdx.x == 0) ahead = atomicAdd(a.tile_ctr, 1);   // in flight under this tile
-    target_tile_split(a, tile, smem_split);
+    target_tile_split<KS1>(a, tile, smem_split);
     if (threadIdx.x == 0) next_tile = ahead;
     __syncthreads();  // publishes next_tile; the planes are reused by the next tile
     tile = next_tile;
