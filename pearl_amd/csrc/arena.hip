@@ -198,13 +198,39 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
   int64_t slot = g.head + g.idx[b];
   if (slot >= g.capacity) slot -= g.capacity;
   const uint8_t* st = reinterpret_cast<const uint8_t*>(g.c.state) + slot * g.state_bytes;
-  if (g.o.state)
-    copy_bytes_wave(reinterpret_cast<uint8_t*>(g.o.state) + (int64_t)b * g.state_bytes, st,
-                    g.state_bytes, lane);
-  if (g.o.next_state)
-    copy_bytes_wave(reinterpret_cast<uint8_t*>(g.o.next_state) + (int64_t)b * g.state_bytes,
-                    reinterpret_cast<const uint8_t*>(g.c.next_state) + slot * g.state_bytes,
-                    g.state_bytes, lane);
+  // The two big rows of a transition travel TOGETHER: lanes 0-31 move the state row (into
+  // o.state and / or the state part of x), lanes 32-63 the next_state row, 16 bytes per lane and
+  // pass — one load instruction where there were two half-empty ones, twice the bytes in flight per
+  // wave.  (x rows are 16-byte aligned when (S + rep_dim) % 4 == 0.)
+  const int R0 = g.o.rep_dim;
+  const bool pair = g.o.next_state && (g.o.state || g.o.x) && (g.state_bytes & 15) == 0 &&
+                    (!g.o.x || ((g.S + R0) & 3) == 0);
+  bool x_state_done = false;
+  if (pair) {
+    const int half = lane >> 5, l = lane & 31;
+    const float4* src = reinterpret_cast<const float4*>(
+        half ? reinterpret_cast<const uint8_t*>(g.c.next_state) + slot * g.state_bytes : st);
+    float4* d0 = half ? reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.next_state) +
+                                                  (int64_t)b * g.state_bytes)
+                      : (g.o.state ? reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.state) +
+                                                               (int64_t)b * g.state_bytes)
+                                   : nullptr);
+    float4* d1 = (!half && g.o.x) ? reinterpret_cast<float4*>(g.o.x + (int64_t)b * (g.S + R0)) : nullptr;
+    for (int i = l; i < (g.state_bytes >> 4); i += 32) {
+      const float4 v = src[i];
+      if (d0) d0[i] = v;
+      if (d1) d1[i] = v;
+    }
+    x_state_done = true;
+  } else {
+    if (g.o.state)
+      copy_bytes_wave(reinterpret_cast<uint8_t*>(g.o.state) + (int64_t)b * g.state_bytes, st,
+                      g.state_bytes, lane);
+    if (g.o.next_state)
+      copy_bytes_wave(reinterpret_cast<uint8_t*>(g.o.next_state) + (int64_t)b * g.state_bytes,
+                      reinterpret_cast<const uint8_t*>(g.c.next_state) + slot * g.state_bytes,
+                      g.state_bytes, lane);
+  }
   const uint8_t* act = g.c.action + slot * g.action_bytes;
   if (g.o.action)
     copy_bytes_wave(reinterpret_cast<uint8_t*>(g.o.action) + (int64_t)b * g.action_bytes, act,
@@ -246,7 +272,8 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
   if (g.o.x) {
     float* xrow = g.o.x + (int64_t)b * (g.S + R);
     const float* srow = reinterpret_cast<const float*>(st);
-    for (int i = lane; i < g.S; i += 64) xrow[i] = srow[i];
+    if (!x_state_done)
+      for (int i = lane; i < g.S; i += 64) xrow[i] = srow[i];
     if (g.o.rep_onehot) {
       const int64_t a = load_index_value(act, g.action_dtype);
       for (int j = lane; j < R; j += 64) xrow[g.S + j] = (j == a) ? 1.0f : 0.0f;

@@ -388,10 +388,22 @@ bool target_fuses_u(const pa_dqn* h, const pa_dqn_batch* b) {
   return fuse;
 }
 
+// U of a batch with the split tile's own arithmetic, as a launch (u_split_kernel): for target passes
+// that are throughput work (the persistent remainder of a window) and read U like the fp32 tiles do
+int run_u_split(pa_dqn* h, const pa_dqn_batch* b, float* U, hipStream_t s) {
+  bool fuse = false;
+  TargetArgs a = make_target_args(h, b, U, nullptr, nullptr, nullptr, nullptr, &fuse);
+  PA_REQUIRE(fuse, PA_ERR_INVALID, "run_u_split: batch does not qualify");
+  ScopedTimer tm(h, "target_l1", s, 2, 1, b->B);
+  return launch_u_split(a, U, s);
+}
+
+// read_u: U has been computed by run_u_split (or, for batches that never fuse, by the fp32 GEMM):
+// the tile reads it instead of forming it
 int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
                        hipStream_t s, bool persistent = false, int* argmax = nullptr,
                        bool sample_timer = true, bool no_pingpong = false,
-                       int prio_first_rows = 0) {
+                       int prio_first_rows = 0, bool read_u = false) {
   // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
   // maximum (Double DQN's action choice); always the classic grid
   // level 1: only the launches the caller marks (learn(): the last, largest piece of every 4th
@@ -400,6 +412,7 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   ScopedTimer tm(h, "target", s, (sample_timer || h->timing >= 2) ? 1 : 2, 1, b->B);
   bool split = false;
   TargetArgs a = make_target_args(h, b, U, next_v, y, argmax, &split, nullptr);
+  if (read_u) a.W1sp = nullptr;
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
   if (prio_first_rows > 0) a.prio_tiles = (int)ceil_div(prio_first_rows, a.bpw);
   const bool pp = !argmax && !no_pingpong && !split &&
@@ -1501,7 +1514,16 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // U = s' W1s'^T + b1': ONE launch for all leading (classic-grid) pieces together — a launch
       // per piece put a 7-20 us GEMM between every two target launches on this stream — and one
       // for the persistent remainder
-      if ((pc == 0 || pc == npieces - 1) && !target_fuses_u(h, &b)) {
+      // (batches that qualify form U with the split tile's arithmetic: in the tile for the leading,
+      // latency-bound pieces, as one u_split_kernel launch for a long persistent remainder — the
+      // same bits either way)
+      const bool fuses = target_fuses_u(h, &b);
+      const bool read_u = fuses && pc == npieces - 1 && nj >= 4;
+      if (read_u) {
+        rc = run_u_split(h, &b, Up, t);
+        if (rc != PA_OK) return rc;
+      }
+      if ((pc == 0 || pc == npieces - 1) && !fuses) {
         int cover = nj;
         if (pc == 0 && npieces > 1) {
           cover = 0;
@@ -1521,7 +1543,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
                               nullptr, sample_w && last, lead_p,
-                              (prio && pc == 0 && !last) ? B : 0);
+                              (prio && pc == 0 && !last) ? B : 0, read_u);
       if (rc != PA_OK) return rc;
       j0 += nj;
       // The call's first window: the host is the pacemaker here (nothing is queued ahead), and the

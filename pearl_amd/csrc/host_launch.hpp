@@ -86,6 +86,31 @@ int launch_target_split_t(const TargetArgs& a, hipStream_t s) {
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
+// U = W1s' s' + b1' for a.B transitions with the split tile's own arithmetic (bit-identical to what
+// the fused tile forms), as one launch: 32 transitions per workgroup
+template <int KS1>
+int launch_u_split_t(const TargetArgs& a, float* U, hipStream_t s) {
+  static bool configured = false;
+  const size_t smem = target_split_smem_bytes();
+  if (!configured) {
+    int rc = set_max_smem(u_split_kernel<KS1>, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  hipLaunchKernelGGL(u_split_kernel<KS1>, dim3((unsigned)ceil_div(a.B, 32)), dim3(512), smem, s, a, U);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+inline int launch_u_split(const TargetArgs& a, float* U, hipStream_t s) {
+  switch (a.S) {
+    case 64: return launch_u_split_t<4>(a, U, s);
+    case 128: return launch_u_split_t<8>(a, U, s);
+    case 256: return launch_u_split_t<16>(a, U, s);
+    default:
+      set_error("u_split_kernel: not built for S = %d", a.S);
+      return PA_ERR_UNSUPPORTED;
+  }
+}
 // state widths the tile can form U from itself (compile-time k-step counts)
 inline bool target_split_fusable_S(int S) { return S == 64 || S == 128 || S == 256; }
 inline int launch_target_split(const TargetArgs& a, hipStream_t s) {

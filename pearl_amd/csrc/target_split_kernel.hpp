@@ -39,59 +39,19 @@ inline size_t target_split_smem_bytes() {
 
 // Same contract as target_tile<32, true>: the host has checked target_fast_shape (16-byte aligned
 // operands, AD <= 16 and a multiple of 4, H1 = H2 = 256).
-// KS1 > 0: the tile forms U itself from S = 16 KS1 state columns (a.W1sp etc. set); 0: U is read.
+// U[n][j] = sum_k W1s'[n][k] s'[b0 + j][k] + b1'[n] for the 32 transitions b0 .. b0 + 31 (nb of them
+// real) as a bf16x3 product: the states split three ways into LDS planes (rows = transitions; the
+// h1 planes' space), one 32-column MFMA tile per wave against the W1s' planes, one accumulator per
+// magnitude class.  Returns this lane's 16 values: unit 32 wave + 8 (r >> 2) + 4 (lane >> 5) + (r & 3),
+// transition lane & 31.  Deterministic per (unit, transition): the fused tile and u_split_kernel
+// produce the same bits.  Ends with every wave still reading nothing: callers barrier before they
+// reuse the planes.
 template <int KS1>
-__device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile, unsigned char* smem) {
-  __bf16* planes = reinterpret_cast<__bf16*>(smem);                        // [3][64][TS_LDP]
-  float* qpart = reinterpret_cast<float*>(smem + (size_t)3 * T_ROWS * TS_LDP * 2);   // [8][64]
-  float* qv = qpart + 8 * 64;                                              // [64]
-
+__device__ __forceinline__ void split_u_columns(const TargetArgs& a, int b0, int nb, __bf16* planes,
+                                                float (&u16)[16]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
-  const int b0 = tile * a.bpw;
-  const int nb = min(a.bpw, a.B - b0);
-  const int nrows = nb * a.A;
-  const int nq0 = wave * 32 + 4 * h;     // this lane's hidden units: nq0 + 8*q + j, q,j in 0..3
-  PA_STAMP(a.prof, tile, wave, 0);
-  const float b3v = a.b3[0];
-  unsigned pf_mask = 0, pf_term = 0;
-  float pf_reward = 0.f;
-  if (tid < nrows && a.mask)
-    pf_mask = a.mask[(int64_t)(b0 + tid / a.A) * a.mask_bstride + tid % a.A];
-  if (tid < nb && a.y) {
-    pf_term = a.term[b0 + tid];
-    pf_reward = a.reward[b0 + tid];
-  }
-
-  // ---- layer 1 (fp32 MFMA, K = AD <= 16): h1 = relu(U[b] + W1a' rep(b, i)), as in target_tile
-  f32x16 acc[2];
-  int64_t foff[2];
-  bool fok[2];
-  int rowb[2];     // tile-local transition of this lane's row (0 for rows past the tile)
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int row = tm * 32 + l31;
-    const bool rok = row < nrows;
-    const int rr = rok ? row : 0;
-    rowb[tm] = rr / a.A;
-    const int bb = b0 + rowb[tm];
-    fok[tm] = rok;
-    foff[tm] = (int64_t)bb * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
-    if constexpr (KS1 == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = nq0 + 8 * q;
-        const float4 u = ld4_or_zero(a.U, (int64_t)bb * a.ldu + n, rok);
-        acc[tm][4 * q + 0] = u.x; acc[tm][4 * q + 1] = u.y;
-        acc[tm][4 * q + 2] = u.z; acc[tm][4 * q + 3] = u.w;
-      }
-    }
-  }
-  if constexpr (KS1 > 0) {
-    // ---- U[b] = W1s' s'[b] + b1' for the tile's <= 32 distinct transitions, in the tile: the states
-    // split three ways into LDS planes (the h1 planes' space, rows = transitions), a bf16x3 product
-    // with the W1s' planes (one 32-column MFMA tile: column j = transition j), then every row of the
-    // tile fetches its transition's column with a lane shuffle.  (host: bpw <= 32, S % 16 == 0, S <= 256)
+  const int nq0 = wave * 32 + 4 * h;
     constexpr int ks1 = KS1, s4 = 4 * KS1;       // S = 16 KS1 (compile time: every offset an immediate)
     for (int e = tid; e < 32 * s4; e += 512) {
       const int t = e / s4, k = (e - t * s4) * 4;
@@ -151,19 +111,97 @@ __device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile,
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float bq4[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * q + j;
+      u16[r] = ((cu[2][r] + cu[1][r]) + cu[0][r]) + bq4[j];
+    }
+  }
+}
+
+// The same product as a launch of its own: U[b][n] for B transitions, 32 per workgroup (the
+// persistent remainder of a window reads U instead of forming it: its tiles are throughput work).
+template <int KS1>
+static __global__ __launch_bounds__(512, 2) void u_split_kernel(TargetArgs a, float* __restrict__ U) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_u[];   // the tile's plane layout
+  const int b0 = (int)blockIdx.x * 32;
+  const int nb = min(32, a.B - b0);
+  float u16[16];
+  split_u_columns<KS1>(a, b0, nb, reinterpret_cast<__bf16*>(smem_u), u16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+  if (l31 < nb) {
+    float* dst = U + (int64_t)(b0 + l31) * a.ldu + wave * 32 + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4*>(dst + 8 * q) =
+          make_float4(u16[4 * q], u16[4 * q + 1], u16[4 * q + 2], u16[4 * q + 3]);
+  }
+}
+
+// KS1 > 0: the tile forms U itself from S = 16 KS1 state columns (a.W1sp etc. set); 0: U is read.
+template <int KS1>
+__device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile, unsigned char* smem) {
+  __bf16* planes = reinterpret_cast<__bf16*>(smem);                        // [3][64][TS_LDP]
+  float* qpart = reinterpret_cast<float*>(smem + (size_t)3 * T_ROWS * TS_LDP * 2);   // [8][64]
+  float* qv = qpart + 8 * 64;                                              // [64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int b0 = tile * a.bpw;
+  const int nb = min(a.bpw, a.B - b0);
+  const int nrows = nb * a.A;
+  const int nq0 = wave * 32 + 4 * h;     // this lane's hidden units: nq0 + 8*q + j, q,j in 0..3
+  PA_STAMP(a.prof, tile, wave, 0);
+  const float b3v = a.b3[0];
+  unsigned pf_mask = 0, pf_term = 0;
+  float pf_reward = 0.f;
+  if (tid < nrows && a.mask)
+    pf_mask = a.mask[(int64_t)(b0 + tid / a.A) * a.mask_bstride + tid % a.A];
+  if (tid < nb && a.y) {
+    pf_term = a.term[b0 + tid];
+    pf_reward = a.reward[b0 + tid];
+  }
+
+  // ---- layer 1 (fp32 MFMA, K = AD <= 16): h1 = relu(U[b] + W1a' rep(b, i)), as in target_tile
+  f32x16 acc[2];
+  int64_t foff[2];
+  bool fok[2];
+  int rowb[2];     // tile-local transition of this lane's row (0 for rows past the tile)
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+    const int row = tm * 32 + l31;
+    const bool rok = row < nrows;
+    const int rr = rok ? row : 0;
+    rowb[tm] = rr / a.A;
+    const int bb = b0 + rowb[tm];
+    fok[tm] = rok;
+    foff[tm] = (int64_t)bb * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
+    if constexpr (KS1 == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = nq0 + 8 * q;
+        const float4 u = ld4_or_zero(a.U, (int64_t)bb * a.ldu + n, rok);
+        acc[tm][4 * q + 0] = u.x; acc[tm][4 * q + 1] = u.y;
+        acc[tm][4 * q + 2] = u.z; acc[tm][4 * q + 3] = u.w;
+      }
+    }
+  }
+  if constexpr (KS1 > 0) {
+    // ---- U[b] = W1s' s'[b] + b1' for the tile's <= 32 distinct transitions, in the tile: the states
+    // split three ways into LDS planes (the h1 planes' space, rows = transitions), a bf16x3 product
+    // with the W1s' planes (one 32-column MFMA tile: column j = transition j), then every row of the
+    // tile fetches its transition's column with a lane shuffle.  (host: bpw <= 32, S % 16 == 0, S <= 256)
+    float u16[16];
+    split_u_columns<KS1>(a, b0, nb, planes, u16);
     // U[unit][transition = l31] of this lane -> acc[tm][unit] of the lane that owns row 32 tm + l31
     // (same lane half: a unit's half is a property of the unit)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float bq4[4] = {b1v[q].x, b1v[q].y, b1v[q].z, b1v[q].w};
+    for (int r = 0; r < 16; ++r)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 4 * q + j;
-        const float u = ((cu[2][r] + cu[1][r]) + cu[0][r]) + bq4[j];
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) acc[tm][r] = __shfl(u, rowb[tm] + 32 * h, 64);
-      }
-    }
+      for (int tm = 0; tm < 2; ++tm) acc[tm][r] = __shfl(u16[r], rowb[tm] + 32 * h, 64);
     __syncthreads();   // every wave is done with the state planes: h1 may overwrite them
   }
   const int wcol = wave * 32 + l31;      // hidden unit this lane feeds as the A operand

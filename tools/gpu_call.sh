@@ -238,3 +238,28 @@ if [ "$MODE" == "j" ]; then
   echo "shortcall rc=$?"; cut -c1-200 gpurun_out/shortcall.jsonl
   timeout 300 python bench_algos.py --steps 300 --only sac,td3,double_dqn --cpu-seconds 0.5 > gpurun_out/bench_algos_j.jsonl 2> gpurun_out/bench_algos_j.err; echo "algos rc=$?"; cut -c1-260 gpurun_out/bench_algos_j.jsonl
 fi
+if [ "$MODE" == "k" ]; then
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -12 gpurun_out/pytest_gpu.log
+  run() { # name, env...
+    local name=$1; shift
+    env "$@" timeout 300 python bench.py --no-cpu-baseline > gpurun_out/bench_$name.log 2> gpurun_out/bench_$name.err
+    echo "bench $name rc=$? $(tail -1 gpurun_out/bench_$name.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print(round(d['value']/1e6,2),'M tr/s  us/step',round(d['ms_per_step']*1e3,2),' target: us',round(r['avg_launch_us'],1),'tr/launch',r['transitions_per_launch'],'frac',round(r['frac'],3),' iso',round(r.get('isolated',{}).get('frac',0),3), ' gather', round(r.get('gather',{}).get('avg_launch_us',0),1))" 2>&1)"
+  }
+  run hyb X=1
+  run nofuse PEARL_AMD_FUSE_U=0
+  run hyb2 X=1
+  for v in 1 0 1; do
+    PEARL_AMD_FUSE_U=$v timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20_f$v.log 2> gpurun_out/bench_s20_f$v.err
+    echo "bench s20 fuse=$v rc=$?"; tail -1 gpurun_out/bench_s20_f$v.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state',{}).get('value'))"
+  done
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
+  echo "shortcall rc=$?"; cut -c1-200 gpurun_out/shortcall.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline > $R/gpurun_out/rocprof.log 2>&1
+  python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db > $R/gpurun_out/kernel_stats.txt 2>&1
+  python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_split 40 >> $R/gpurun_out/kernel_stats.txt 2>&1
+  head -12 $R/gpurun_out/kernel_stats.txt | cut -c1-150
+  rm -f $R/gpurun_out/prof/*.db
+fi
