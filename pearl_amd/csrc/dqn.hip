@@ -50,7 +50,13 @@ struct pa_dqn {
   void* w2sp;  // the same matrix as bf16 split planes (target_split_kernel), H1 = H2 = 256 only
   void* w2sp_online;  // Double DQN: split planes of the ONLINE W2 (rebuilt with w2f_online every round)
   void* w1sp;  // the target W1's state columns as split planes: the split tile forms U itself
-  int fuse_u;  // PEARL_AMD_FUSE_U (default 1): no first-layer GEMM launch in front of split target passes
+  int fuse_u;  // PEARL_AMD_FUSE_U (default 0): the split tiles form U themselves (no first-layer GEMM
+               // launch in front of the leading pieces).  Bit-identical, all tests green, measured
+               // SLOWER as built: the in-tile product puts a second exposed memory latency, two
+               // barriers and 64 lane shuffles in front of the tile's own operand loads (leading
+               // 1-round piece 26 us against 8 + 15.5 with the GEMM launch; 27.2 vs 28.6 M
+               // transitions/s over 2000 rounds) — kept as a switch for the version that issues the
+               // tile's loads ahead of the product.
   int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
   int dw_tm;      // PEARL_AMD_DW_TM: rows per weight-gradient tile, 64 or 32 (0 = by the CU partition)
   int rp_split;   // PEARL_AMD_ROWPASS_SPLIT (default 1): window-first row pass as forward + backward
@@ -1030,7 +1036,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->w2sp = nullptr;
   h->w2sp_online = nullptr;
   h->w1sp = nullptr;
-  h->fuse_u = env_int("PEARL_AMD_FUSE_U", 1);
+  h->fuse_u = env_int("PEARL_AMD_FUSE_U", 0);
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
@@ -1389,9 +1395,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     const int p = k & 1;
     const pa_dqn::BatchBuf& bb = h->bb[p];
     if (h->timing) h->tick++;
-    // level-1 timers: every 4th window of a long call, every window of a short one (the last,
-    // largest target launch of the window and its gather — neither sits on the chain's critical
-    // path), so that even the driver's 20-round call carries several sampled launches
+    // level-1 timers: every 4th window of a long call, every window of a short one (its target
+    // launches but the first — that one opens the window's critical path — and its gather), so that
+    // even the driver's 20-round call carries four or more sampled launches
     const bool short_call = R < 100;
     const bool sample_w = short_call || (k % 4) == 0;
     // main-stream head of the call's first window (see the hook in the piece loop below): x of the
@@ -1542,7 +1548,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const bool lead_p = !last && h->lead_persist && persist;
       static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
-                              nullptr, sample_w && last, lead_p,
+                              nullptr, sample_w && (last || (short_call && pc >= 1)), lead_p,
                               (prio && pc == 0 && !last) ? B : 0, read_u);
       if (rc != PA_OK) return rc;
       j0 += nj;

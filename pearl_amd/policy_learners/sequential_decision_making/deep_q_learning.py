@@ -222,12 +222,12 @@ class DeepQLearning(PolicyLearner):
         return 0
 
     def _set_adam_steps(self, n: int) -> None:
-        # after _ensure_bound every parameter's "step" is the SAME 0-d tensor: one fill_
-        seen = set()
+        # one 0-d step tensor PER parameter, as torch.optim keeps them (a shared tensor would be
+        # advanced six times by a torch-side optimizer.step() and serialised six times): six scalar
+        # fills once per learn() call
         for pq, _ in self._param_pairs():
             st = self._optimizer.state.get(pq)
-            if st is not None and "step" in st and id(st["step"]) not in seen:
-                seen.add(id(st["step"]))
+            if st is not None and "step" in st:
                 st["step"].fill_(float(n))
 
     def _signature(self) -> Tuple:
@@ -282,7 +282,6 @@ class DeepQLearning(PolicyLearner):
         N.check(N.lib().pa_dqn_param_offsets(S, AD, H1, H2, offs))
         flat = {k: torch.zeros(P, dtype=torch.float32, device=dev) for k in _FLAT_NAMES}
         steps = self._adam_steps()
-        step_t = torch.tensor(float(steps), dtype=torch.float32)   # shared by all six parameters
         with torch.no_grad():
             for (pq, pt), off in zip(self._param_pairs(), list(offs)):
                 n = pq.numel()
@@ -297,7 +296,7 @@ class DeepQLearning(PolicyLearner):
                 pt.data = flat["q_target"][sl].view(pt.shape)
                 pq.grad = flat["grad"][sl].view(pq.shape)
                 self._optimizer.state[pq] = {
-                    "step": step_t,
+                    "step": torch.tensor(float(steps), dtype=torch.float32),
                     "exp_avg": flat["exp_avg"][sl].view(pq.shape),
                     "exp_avg_sq": flat["exp_avg_sq"][sl].view(pq.shape),
                     "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(pq.shape),
