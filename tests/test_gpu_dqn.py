@@ -55,6 +55,33 @@ def test_q_values_and_targets(golden, name):
     assert torch.equal(nv, out["next_v"])
 
 
+@pytest.mark.parametrize("switch", [("PEARL_AMD_TARGET_SPLIT", "0"), ("PEARL_AMD_FUSE_U", "1")])
+def test_target_kernel_variants_hold_the_reference_fixtures(golden, switch, monkeypatch):
+    """The target pass has three builds of the same arithmetic contract: the default bf16x3 split
+    kernel reading U, the fp32-MFMA kernels (PEARL_AMD_TARGET_SPLIT=0), and the split kernel that
+    also forms the first-layer state product in the tile (PEARL_AMD_FUSE_U=1).  Each holds the
+    reference-minted next-state values and Bellman targets at the same 1e-5, and each variant's
+    fused learn() loop equals its own per-step loop bitwise."""
+    from pearl_amd.policy_learners.policy_learner import PolicyLearner
+    monkeypatch.setenv(*switch)
+    for name in ("cfg2_shape_small_batch", "double:cfg2_shape_small_batch"):
+        fx = golden(name)
+        pl = make_learner(fx)
+        out = pl.q_values_and_targets(batch_from(fx, "batch_pre"))
+        torch.testing.assert_close(out["next_v"].cpu(), fx["next_v"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(out["target"].cpu(), fx["target"], rtol=1e-5, atol=1e-6)
+    fx = golden("cfg2_shape_small_batch")
+    a, b = make_learner(fx), make_learner(fx)
+    rb = fill_arena_buffer(fx, "python")
+    random.seed(4)
+    ra = a.learn(rb)
+    random.seed(4)
+    rbr = PolicyLearner.learn(b, rb)
+    assert ra["loss"] == rbr["loss"]
+    for (k, pa), (_, pb) in zip(a._Q.state_dict().items(), b._Q.state_dict().items()):
+        assert torch.equal(pa, pb), k
+
+
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_learn_batch_gradients_and_first_step(golden, name):
     """One learn_batch: reported loss, gradients (p.grad views of the flat buffer) and the
