@@ -263,3 +263,67 @@ if [ "$MODE" == "k" ]; then
   head -12 $R/gpurun_out/kernel_stats.txt | cut -c1-150
   rm -f $R/gpurun_out/prof/*.db
 fi
+if [ "$MODE" == "l" ]; then
+  timeout 900 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -12 gpurun_out/pytest_gpu.log
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state',{}).get('value'), d['roofline']['launches_timed'], d['roofline'].get('gather'))"
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_dsac
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_dsac -o t -- python $R/bench_algos.py --steps 100 --only dsac --cpu-seconds 0.3 > $R/gpurun_out/rocprof_dsac.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_dsac/*.db $R/gpurun_out/prof_dsac/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/dsac_kernel_stats.txt 2>&1
+  head -24 $R/gpurun_out/dsac_kernel_stats.txt | cut -c1-150
+  rm -f $DB
+fi
+if [ "$MODE" == "m" ]; then
+  for ring in 8 16 32; do
+    PEARL_AMD_DW_RING=$ring timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_ring$ring.log 2> gpurun_out/bench_ring$ring.err
+    echo "ring $ring rc=$?"; tail -1 gpurun_out/bench_ring$ring.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state',{}).get('value'))"
+  done
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "tile_shapes or overlapped or generic_loop or full_size or fixtures" > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
+  cd /tmp && export TMPDIR=/tmp
+  for ring in 16 32; do
+    rm -rf $R/gpurun_out/prof_ring$ring
+    PEARL_AMD_DW_RING=$ring timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ring$ring -o t -- python $R/bench.py --gpus 1 --steps 400 --warmup 20 --no-cpu-baseline > $R/gpurun_out/rocprof_ring$ring.log 2>&1
+    DB=$(ls $R/gpurun_out/prof_ring$ring/*.db $R/gpurun_out/prof_ring$ring/*/*.db 2>/dev/null | head -1)
+    python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/ring${ring}_kernel_stats.txt 2>&1
+    head -8 $R/gpurun_out/ring${ring}_kernel_stats.txt | cut -c1-150
+    rm -f $DB
+  done
+fi
+if [ "$MODE" == "n" ]; then
+  for cfg in "8 0" "8 1" "16 1"; do
+    set -- $cfg
+    PEARL_AMD_DW_RING=$1 PEARL_AMD_DW_XCD_ORDER=$2 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_x$1_$2.log 2> gpurun_out/bench_x$1_$2.err
+    echo "ring $1 xcd $2 rc=$?"; tail -1 gpurun_out/bench_x$1_$2.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d.get('steady_state',{}).get('value'))"
+  done
+  timeout 600 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x -k "tile_shapes or overlapped or generic_loop or full_size or fixtures or weight" > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_x
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_x -o t -- python $R/bench.py --gpus 1 --steps 400 --warmup 20 --no-cpu-baseline > $R/gpurun_out/rocprof_x.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_x/*.db $R/gpurun_out/prof_x/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/xcd_kernel_stats.txt 2>&1
+  head -8 $R/gpurun_out/xcd_kernel_stats.txt | cut -c1-150
+  rm -f $DB
+fi
+if [ "$MODE" == "o" ]; then
+  for r in 13 25; do
+    PROF_ROUND=$r timeout 300 python tools/prof_chain.py > gpurun_out/prof_chain_r$r.txt 2>&1
+    cat gpurun_out/prof_chain_r$r.txt
+  done
+  PEARL_AMD_DW_XCD_ORDER=0 PROF_ROUND=13 timeout 300 python tools/prof_chain.py > gpurun_out/prof_chain_r13_noxcd.txt 2>&1
+  tail -12 gpurun_out/prof_chain_r13_noxcd.txt
+  PEARL_AMD_OVERLAP=0 PROF_ROUND=13 timeout 300 python tools/prof_chain.py > gpurun_out/prof_chain_r13_serial.txt 2>&1
+  tail -12 gpurun_out/prof_chain_r13_serial.txt
+fi
+if [ "$MODE" == "p" ]; then
+  timeout 120 tools/chain_boundary_bench 400 > gpurun_out/chain_boundary_bench.txt 2>&1
+  cat gpurun_out/chain_boundary_bench.txt
+  PROF_ROUND=13 timeout 300 python tools/prof_chain.py 2>&1 | grep -v amdgpu.ids > gpurun_out/prof_chain_r13.txt
+  head -3 gpurun_out/prof_chain_r13.txt
+  PROF_ROUND=14 timeout 300 python tools/prof_chain.py 2>&1 | grep "kernel boundary"
+  PROF_ROUND=26 timeout 300 python tools/prof_chain.py 2>&1 | grep "kernel boundary"
+fi

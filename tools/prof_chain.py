@@ -71,8 +71,16 @@ def main():
     agent.learn()
     torch.cuda.synchronize()
     N.check(N.lib().pa_debug_set_prof(nat.handle, None, None, -1))
+    ndw = int(os.environ.get("PROF_DW_WGS", "112"))
+    r = row[:64].cpu().numpy().astype(np.int64)
+    d = dw[:ndw].cpu().numpy().astype(np.int64)
+    row_end = r[:, :, len(ROW_NAMES) - 1].max()
+    dw_start = d[:, :, 0][d[:, :, 0] > 0]
+    print(f"kernel boundary inside the round (same 100 MHz clock): last row-pass wave ended -> first "
+          f"weight-gradient wave started {(dw_start.min() - row_end) / 100.0:.2f} us, -> median wave "
+          f"{(np.median(dw_start) - row_end) / 100.0:.2f} us, -> last {(dw_start.max() - row_end) / 100.0:.2f} us")
     show("online_rowpass_kernel", row, ROW_NAMES, 64)
-    show("weight_grad_kernel", dw, DW_NAMES, 52)
+    show("weight_grad_kernel", dw, DW_NAMES, int(os.environ.get("PROF_DW_WGS", "112")))
 
 
 if __name__ == "__main__":
