@@ -30,6 +30,24 @@ struct Bufs {
   float* result;
 };
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// WT: 16-byte write-through stores (sc0 sc1): the bytes leave the XCD's L2 while the phase runs, so
+// the end-of-kernel / release write-back finds nothing dirty
+template <bool WT>
+__device__ __forceinline__ void store4(float4* p, float a, float b, float c, float d) {
+  if constexpr (WT) {
+    const f32x4_t v = {a, b, c, d};
+#ifdef NOP_AFTER
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 4" ::"v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+  } else {
+    *p = make_float4(a, b, c, d);
+  }
+}
+
+template <bool WT>
 __device__ __forceinline__ void phase_a(const Bufs& b, int wg, int round, int tid) {
   // read all of phase B's output (NB * WB floats), 16 bytes per lane and load
   float acc = 0.f;
@@ -51,10 +69,11 @@ __device__ __forceinline__ void phase_a(const Bufs& b, int wg, int round, int ti
   float4* dst = reinterpret_cast<float4*>(b.slabA + (size_t)wg * SA);
   for (int i = tid; i < SA / 4; i += 512) {
     const float v = s + (float)((i + wg + round) & 255) * 0.001f;
-    dst[i] = make_float4(v, v + 1.f, v + 2.f, v + 3.f);
+    store4<WT>(dst + i, v, v + 1.f, v + 2.f, v + 3.f);
   }
 }
 
+template <bool WT>
 __device__ __forceinline__ void phase_b(const Bufs& b, int wg, int round, int tid) {
   // a 1/8 slice of every phase-A slab (a dW tile reads 2 of 16 column blocks of every row)
   float acc = 0.f;
@@ -78,18 +97,24 @@ __device__ __forceinline__ void phase_b(const Bufs& b, int wg, int round, int ti
   float4* dst = reinterpret_cast<float4*>(b.outB + (size_t)wg * WB);
   for (int i = tid; i < WB / 4; i += 512) {
     const float v = s + (float)((i + wg) & 63) * 0.01f;
-    dst[i] = make_float4(v, v, v, v);
+    store4<WT>(dst + i, v, v, v, v);
   }
 }
 
-__global__ __launch_bounds__(512) void kernel_a(Bufs b, int round) { phase_a(b, blockIdx.x, round, threadIdx.x); }
-__global__ __launch_bounds__(512) void kernel_b(Bufs b, int round) { phase_b(b, blockIdx.x, round, threadIdx.x); }
+template <bool WT>
+__global__ __launch_bounds__(512) void kernel_a(Bufs b, int round) { phase_a<WT>(b, blockIdx.x, round, threadIdx.x); }
+template <bool WT>
+__global__ __launch_bounds__(512) void kernel_b(Bufs b, int round) { phase_b<WT>(b, blockIdx.x, round, threadIdx.x); }
+__global__ void empty_kernel() {}
 
 // ---- grid barriers (all NWG workgroups resident: one per CU on 128 CUs) -------------------------
 __device__ __forceinline__ unsigned ld_relaxed(const unsigned* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void barrier_flat(unsigned* bar, unsigned& gen, int tid) {
+#ifndef NO_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the asm stores are invisible to the compiler's counters)
+#endif
   __syncthreads();
   if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -104,6 +129,9 @@ __device__ __forceinline__ void barrier_flat(unsigned* bar, unsigned& gen, int t
   __syncthreads();
 }
 __device__ __forceinline__ void barrier_xcd(unsigned* bar, unsigned& gen, int xcc, int tid) {
+#ifndef NO_WAIT
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __syncthreads();
   if (tid == 0) {
     const unsigned target = gen + 1;
@@ -131,16 +159,16 @@ __global__ void census_kernel(unsigned* bar) {
 
 // mode 0: no synchronisation between phases (WRONG results; the cost of the phases themselves)
 // mode 1: flat barrier   mode 2: XCD-hierarchical barrier
-template <int MODE>
+template <int MODE, bool WT>
 __global__ __launch_bounds__(512) void persistent_kernel(Bufs b, int rounds) {
   const int wg = blockIdx.x, tid = threadIdx.x;
   const int xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) & 7;
   unsigned gen = 0;
   for (int r = 0; r < rounds; ++r) {
-    if (wg < NA) phase_a(b, wg, r, tid);
+    if (wg < NA) phase_a<WT>(b, wg, r, tid);
     if (MODE == 1) barrier_flat(b.bar, gen, tid);
     if (MODE == 2) barrier_xcd(b.bar, gen, xcc, tid);
-    if (wg < NB) phase_b(b, wg, r, tid);
+    if (wg < NB) phase_b<WT>(b, wg, r, tid);
     if (MODE == 1) barrier_flat(b.bar, gen, tid);
     if (MODE == 2) barrier_xcd(b.bar, gen, xcc, tid);
   }
@@ -172,6 +200,7 @@ static float checksum(const Bufs& b) {
 }
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IONBF, 0);
   const int rounds = argc > 1 ? atoi(argv[1]) : 400;
   Bufs b;
   CK(hipMalloc((void**)&b.slabA, (size_t)NA * SA * 4));
@@ -190,34 +219,55 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   float ms;
-  for (int rep = 0; rep < 2; ++rep) {   // second repetition is the reported one (warm clocks)
-    // ---- two launches per round
-    reset(b);
+  // back-to-back dependent EMPTY launches: the floor of a boundary with nothing to write back
+  for (int rep = 0; rep < 2; ++rep) {
     CK(hipEventRecord(e0, 0));
-    for (int r = 0; r < rounds; ++r) {
-      hipLaunchKernelGGL(kernel_a, dim3(NA), dim3(512), 0, 0, b, r);
-      hipLaunchKernelGGL(kernel_b, dim3(NB), dim3(512), 0, 0, b, r);
-    }
+    for (int r = 0; r < 2 * rounds; ++r) hipLaunchKernelGGL(empty_kernel, dim3(NB), dim3(512), 0, 0);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1));
-    const float ref = checksum(b);
-    if (rep) printf("two launches per round      : %7.2f us/round   checksum %.6e\n", 1e3f * ms / rounds, ref);
-    // ---- persistent variants
-    for (int mode = 0; mode < 3; ++mode) {
+    if (rep) printf("empty launch, back to back            : %7.2f us each\n", 1e3f * ms / (2 * rounds));
+  }
+  for (int wt = 0; wt < 2; ++wt) {
+    printf("-- %s stores\n", wt ? "write-through (sc0 sc1)" : "plain");
+    for (int rep = 0; rep < 2; ++rep) {   // second repetition is the reported one (warm clocks)
+      // ---- two launches per round
       reset(b);
       CK(hipEventRecord(e0, 0));
-      if (mode == 0) hipLaunchKernelGGL(persistent_kernel<0>, dim3(NWG), dim3(512), 0, 0, b, rounds);
-      if (mode == 1) hipLaunchKernelGGL(persistent_kernel<1>, dim3(NWG), dim3(512), 0, 0, b, rounds);
-      if (mode == 2) hipLaunchKernelGGL(persistent_kernel<2>, dim3(NWG), dim3(512), 0, 0, b, rounds);
+      for (int r = 0; r < rounds; ++r) {
+        if (wt) {
+          hipLaunchKernelGGL(kernel_a<true>, dim3(NA), dim3(512), 0, 0, b, r);
+          hipLaunchKernelGGL(kernel_b<true>, dim3(NB), dim3(512), 0, 0, b, r);
+        } else {
+          hipLaunchKernelGGL(kernel_a<false>, dim3(NA), dim3(512), 0, 0, b, r);
+          hipLaunchKernelGGL(kernel_b<false>, dim3(NB), dim3(512), 0, 0, b, r);
+        }
+      }
       CK(hipEventRecord(e1, 0));
       CK(hipEventSynchronize(e1));
       CK(hipEventElapsedTime(&ms, e0, e1));
-      const float cs = checksum(b);
-      const char* names[3] = {"persistent, NO barrier (wrong)", "persistent, flat barrier    ", "persistent, XCD barrier     "};
-      if (rep)
-        printf("%s: %7.2f us/round   checksum %.6e%s\n", names[mode], 1e3f * ms / rounds, cs,
-               mode && cs != ref ? "   MISMATCH" : "");
+      const float ref = checksum(b);
+      if (rep) printf("two launches per round                : %7.2f us/round   checksum %.6e\n", 1e3f * ms / rounds, ref);
+      // ---- persistent variants
+      for (int mode = 0; mode < 3; ++mode) {
+        reset(b);
+        CK(hipEventRecord(e0, 0));
+        if (mode == 0 && !wt) hipLaunchKernelGGL((persistent_kernel<0, false>), dim3(NWG), dim3(512), 0, 0, b, rounds);
+        if (mode == 1 && !wt) hipLaunchKernelGGL((persistent_kernel<1, false>), dim3(NWG), dim3(512), 0, 0, b, rounds);
+        if (mode == 2 && !wt) hipLaunchKernelGGL((persistent_kernel<2, false>), dim3(NWG), dim3(512), 0, 0, b, rounds);
+        if (mode == 0 && wt) hipLaunchKernelGGL((persistent_kernel<0, true>), dim3(NWG), dim3(512), 0, 0, b, rounds);
+        if (mode == 1 && wt) hipLaunchKernelGGL((persistent_kernel<1, true>), dim3(NWG), dim3(512), 0, 0, b, rounds);
+        if (mode == 2 && wt) hipLaunchKernelGGL((persistent_kernel<2, true>), dim3(NWG), dim3(512), 0, 0, b, rounds);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const float cs = checksum(b);
+        const char* names[3] = {"persistent, NO barrier (wrong results)", "persistent, flat barrier              ",
+                                "persistent, XCD-hierarchical barrier  "};
+        if (rep)
+          printf("%s: %7.2f us/round   checksum %.6e%s\n", names[mode], 1e3f * ms / rounds, cs,
+                 mode && cs != ref ? "   MISMATCH" : "");
+      }
     }
   }
   return 0;
