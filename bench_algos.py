@@ -497,6 +497,83 @@ def bench_push(steps, cpu_seconds):
                              "sample": f"{n} oracle (deque of per-transition tensors) pushes"}}
 
 
+def bench_feeder(steps, cpu_seconds):
+    """Batched observe (second half; pearl_agent.py:169-211): E = 4096 cfg2-shaped
+    environments that live on the device, one batched epsilon-greedy act + one push_many per vector
+    step (pearl_amd/vector_env.py), against E = 1 `agent.act` + `agent.observe` per transition."""
+    from pearl_amd import (BasicReplayBuffer, BatchedActionResult, BatchedEnvironment, DeepQLearning,
+                           OneHotActionTensorRepresentationModule, PearlAgent, VectorEnvFeeder)
+    from pearl_amd.pearl_agent import ActionResult
+    S, A, E = 128, 16, 4096
+    sp = dspace(A)
+
+    class Sim(BatchedEnvironment):
+        def __init__(self, n):
+            self.n = n
+            self.t = 0
+
+        def reset(self, seed=None):
+            torch.manual_seed(0)
+            self.x = torch.randn(self.n, S, device=DEV)
+            return self.x, sp
+
+        def step(self, actions):
+            self.t += 1
+            a = actions.reshape(self.n)
+            self.x = torch.roll(self.x, 1, dims=1) * 0.99 + torch.nn.functional.one_hot(a, S).float()
+            reward = self.x.gather(1, a.reshape(-1, 1)).reshape(-1)
+            done = torch.zeros(self.n, dtype=torch.bool, device=DEV)
+            return BatchedActionResult(observation=self.x, reward=reward, terminated=done, truncated=done)
+
+    def make(n_replay):
+        torch.manual_seed(0)
+        pl = DeepQLearning(state_dim=S, action_space=sp, hidden_dims=[256, 256], training_rounds=1,
+                           batch_size=1024,
+                           action_representation_module=OneHotActionTensorRepresentationModule(A))
+        return PearlAgent(pl, replay_buffer=BasicReplayBuffer(n_replay, sampler="device"), device_id=DEV.index)
+
+    out = {}
+    for exploit in (False, True):
+        agent = make(1_000_000)
+        f = VectorEnvFeeder(agent, Sim(E))
+        f.reset()
+        f.run(3, exploit=exploit)
+        sync()
+        n = max(20, steps // 4)
+        t0 = time.perf_counter()
+        f.run(n, exploit=exploit)
+        sync()
+        out["exploit" if exploit else "explore"] = E * n / (time.perf_counter() - t0)
+    # the reference's shape of the same loop: one environment, one act + one observe per transition
+    agent = make(100_000)
+    sim = Sim(1)
+    obs, _ = sim.reset()
+    agent.reset(obs[0], sp)
+    t0 = time.perf_counter()
+    n1 = 0
+    while time.perf_counter() - t0 < min(cpu_seconds, 4.0):
+        a = agent.act(exploit=False)
+        r = sim.step(torch.as_tensor(a).reshape(1))
+        agent.observe(ActionResult(observation=r.observation[0], reward=float(r.reward[0]),
+                                   terminated=False, truncated=False))
+        n1 += 1
+    sync()
+    single = n1 / (time.perf_counter() - t0)
+    row_bytes = 2 * S * 4 + 8 + 4 + 2
+    return {"config": f"batched observe: {E} device-resident cfg2 environments, DQN act (eps 0.05) + push_many per vector step",
+            "metric": "transitions/s through act_many + env.step + push_many", "value": out["explore"],
+            "steps": max(20, steps // 4), "ms_per_step": 1e3 * E / out["explore"],
+            "exploit_only": out["exploit"],
+            "one_env_act_observe_per_transition": single,
+            "roofline": {"bound": "hbm", "achieved": out["explore"] * row_bytes / 1e9, "peak": 8000.0,
+                         "unit": "GB/s", "frac": out["explore"] * row_bytes / 8e12, "traffic": None,
+                         "bytes_per_transition": row_bytes,
+                         "scope": "interpreter-bound: ~a dozen launches and one Python loop over E "
+                                  "exploration draws per vector step; the arena write itself is one scatter launch"},
+            "cpu_baseline": {"value": single, "kind": "port", "cores": 1,
+                             "sample": f"{n1} act + observe calls of one pearl_amd agent (the reference's loop shape)"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
@@ -522,7 +599,7 @@ def main():
     torch.cuda.set_device(DEV)
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("dsac", bench_dsac), ("ppo", bench_ppo), ("bandit", bench_bandit),
-                     ("double_dqn", bench_double_dqn), ("push", bench_push)):
+                     ("double_dqn", bench_double_dqn), ("push", bench_push), ("feeder", bench_feeder)):
         if args.only and name not in args.only.split(","):
             continue
         out = fn(args.steps, args.cpu_seconds)

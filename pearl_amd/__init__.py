@@ -21,5 +21,6 @@ from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
 from .policy_learners.contextual_bandits import NeuralLinearBandit, SquareCBExploration  # noqa: F401
 from .action_representation_modules import OneHotActionTensorRepresentationModule  # noqa: F401
 from .utils.instantiations.spaces import BoxActionSpace, DiscreteActionSpace  # noqa: F401
+from .vector_env import BatchedActionResult, BatchedEnvironment, VectorEnvFeeder  # noqa: F401
 
 __version__ = "0.1.0"

@@ -754,6 +754,52 @@ class DeepQLearning(PolicyLearner):
             subjective_state=subjective_state, action_space=available_action_space,
             exploit_action=exploit_action, values=q_values)
 
+    def act_many(self, states: torch.Tensor, available_action_space: Any,
+                 exploit: bool = False) -> torch.Tensor:
+        """``act`` for E states that share one action space (pearl_amd.vector_env): ONE
+        (E, A, S + AD) forward, row-wise argmax, then the exploration module row by row in row
+        order — epsilon-greedy consumes one ``random.random()`` per row and one
+        ``action_space.sample()`` per exploring row, exactly the draws E successive ``act`` calls
+        make (epsilon_greedy_exploration.py:28-102).  Returns the (E, *action_shape) actions on
+        the states' device."""
+        assert hasattr(available_action_space, "actions_batch") and states.ndim == 2
+        E = int(states.shape[0])
+        with torch.no_grad():
+            table = available_action_space.actions_batch.to(states.device)      # (A, *action_shape)
+            reps = self.action_representation_module(table.to(states)).to(states.dtype)
+            q_values = self._Q.get_q_values(states, reps.unsqueeze(0).expand(E, *reps.shape))
+            greedy = torch.argmax(q_values, dim=1)
+            actions = table[greedy]
+        if exploit:
+            return actions
+        ex = self.exploration_module
+        if isinstance(ex, EGreedyExploration):
+            if ex._epsilon_scheduling and ex.time_step < ex.warmup_steps:
+                rows = []
+                for e in range(E):      # the warm-up moves epsilon with every call
+                    if ex.time_step < ex.warmup_steps:
+                        frac = ex.time_step / ex.warmup_steps
+                        ex.curr_epsilon = ex.start_epsilon + (ex.end_epsilon - ex.start_epsilon) * frac
+                    ex.time_step += 1
+                    if random.random() < ex.curr_epsilon:
+                        rows.append(e)
+            else:
+                eps, rnd = ex.curr_epsilon, random.random
+                rows = [e for e, u in enumerate([rnd() for _ in range(E)]) if u < eps]
+                ex.time_step += E
+            if rows:
+                # (the sampled element back to its index: one small index copy instead of a stack
+                #  of len(rows) action tensors)
+                index_of = {id(a): k for k, a in enumerate(available_action_space.actions)}
+                picks = [index_of[id(available_action_space.sample(None))] for _ in rows]
+                actions = actions.clone()
+                actions[torch.tensor(rows, device=actions.device)] = table[
+                    torch.tensor(picks, device=actions.device)]
+            return actions
+        out = [ex.act(subjective_state=states[e:e + 1], action_space=available_action_space,
+                      exploit_action=actions[e], values=q_values[e]) for e in range(E)]
+        return torch.stack([torch.as_tensor(a).to(actions.device) for a in out])
+
     def compare(self, other: PolicyLearner) -> str:
         diffs = [super().compare(other)]
         if not isinstance(other, DeepQLearning):

@@ -327,3 +327,9 @@ if [ "$MODE" == "p" ]; then
   PROF_ROUND=14 timeout 300 python tools/prof_chain.py 2>&1 | grep "kernel boundary"
   PROF_ROUND=26 timeout 300 python tools/prof_chain.py 2>&1 | grep "kernel boundary"
 fi
+if [ "$MODE" == "s" ]; then
+  timeout 600 python -m pytest tests/test_vector_env.py -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_vec.log 2>&1
+  echo "pytest rc=$?"; tail -12 gpurun_out/pytest_vec.log
+  timeout 600 python bench_algos.py --only feeder --steps 200 > gpurun_out/bench_feeder.jsonl 2> gpurun_out/bench_feeder.err
+  echo "feeder rc=$?"; cat gpurun_out/bench_feeder.jsonl | cut -c1-900; tail -5 gpurun_out/bench_feeder.err
+fi
