@@ -413,6 +413,12 @@ int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B, const flo
 int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, int32_t ld_state,
                  const float* rep, int64_t rep_bstride, int32_t rows, int32_t A, int32_t AD,
                  float* q_out, void* stream);
+/* pa_mlp_q_all for the two critics of a twin (one shape, one input) with the shareable launches
+ * shared: one repack launch, one first-layer GEMM launch with two problems.  Same values as two
+ * pa_mlp_q_all calls (twin_critic.py:75-91). */
+int pa_mlp_q_all2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const float* state, int32_t ld_state,
+                  const float* rep, int64_t rep_bstride, int32_t rows, int32_t A, int32_t AD,
+                  float* q1_out, float* q2_out, void* stream);
 
 /* Two networks of the same depth on the same input in lock-step (TwinCritic, twin_critic.py:22-91;
  * PPO's actor and critic): the same arithmetic as two pa_mlp_forward / pa_mlp_backward calls, with

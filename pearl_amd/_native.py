@@ -355,6 +355,8 @@ SIGNATURES = {
                                   C.c_int32, _P]),
     "pa_mlp_q_all": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, _P, _P]),
+    "pa_mlp_q_all2": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,
+                                C.c_int32, _P, _P, _P]),
     "pa_mlp_forward2": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P,
                                   C.c_int32, C.c_int32, _P]),
     "pa_mlp_backward2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32,

@@ -499,6 +499,33 @@ static __global__ __launch_bounds__(256) void repack_w2_kernel(const float* __re
   }
 }
 
+// two matrices of one shape in one launch (blockIdx.y): the twin critics' all-actions passes
+static __global__ __launch_bounds__(256) void repack_w2_pair_kernel(const float* __restrict__ W2a,
+                                                             const float* __restrict__ W2b, int H2,
+                                                             int H1, float* __restrict__ W2fa,
+                                                             float* __restrict__ W2fb, void* spa,
+                                                             void* spb) {
+  const float* W2 = blockIdx.y ? W2b : W2a;
+  float* W2f = blockIdx.y ? W2fb : W2fa;
+  void* W2sp = blockIdx.y ? spb : spa;
+  const int nkg = t_nkg(H1);
+  const int64_t total = w2f_floats(H2, H1) / 4;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * 256) {
+    const int lane = (int)(e & 63);
+    const int64_t tg = e >> 6;
+    const int g = (int)(tg % nkg), t = (int)(tg / nkg);
+    const int n = t * 32 + (lane & 31), k = g * 8 + 4 * (lane >> 5);
+    float4 v;
+    v.x = (n < H2 && k < H1) ? W2[(int64_t)n * H1 + k] : 0.f;
+    v.y = (n < H2 && k + 1 < H1) ? W2[(int64_t)n * H1 + k + 1] : 0.f;
+    v.z = (n < H2 && k + 2 < H1) ? W2[(int64_t)n * H1 + k + 2] : 0.f;
+    v.w = (n < H2 && k + 3 < H1) ? W2[(int64_t)n * H1 + k + 3] : 0.f;
+    reinterpret_cast<float4*>(W2f)[e] = v;
+    if (W2sp && H1 == TS_H && H2 == TS_H) store_w2sp4(W2sp, n, k, v);
+  }
+}
+
 inline size_t target_smem_bytes(int H1) {
   const int H1P = t_nkg(H1) * 8;
   return sizeof(float) * ((size_t)T_ROWS * (H1P + 4) + 8 * 64 + 64);

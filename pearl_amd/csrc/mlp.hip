@@ -648,6 +648,83 @@ extern "C" int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, i
   return launch_target(a, s);
 }
 
+// Both critics of a twin on every action of an action set (TwinCritic.get_q_values,
+// twin_critic.py:75-91): pa_mlp_q_all twice with the launches that can be shared shared — one repack
+// launch and one first-layer GEMM launch (two problems) instead of two each.
+extern "C" int pa_mlp_q_all2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const float* state,
+                             int32_t ld_state, const float* rep, int64_t rep_bstride, int32_t rows,
+                             int32_t A, int32_t AD, float* q1_out, float* q2_out, void* stream) {
+  PA_REQUIRE(h1 && h2 && h1->bound && h2->bound && state && rep && q1_out && q2_out && rows > 0 &&
+                 A > 0 && AD > 0,
+             PA_ERR_INVALID, "pa_mlp_q_all2: bad argument");
+  pa_mlp* hs[2] = {h1, h2};
+  float* outs[2] = {q1_out, q2_out};
+  const pa_mlp_desc& d = h1->d;
+  const int S = d.dims[0] - AD, H1 = d.dims[1], H2 = d.dims[2];
+  const float* Ps[2];
+  for (int i = 0; i < 2; ++i) {
+    const pa_mlp_desc& di = hs[i]->d;
+    PA_REQUIRE(hs[i]->L == 3 && di.dims[3] == 1 && S > 0 && di.identity_layers == 0 &&
+                   !di.no_last_bias && di.dims[0] == d.dims[0] && di.dims[1] == H1 &&
+                   di.dims[2] == H2 && di.device == d.device && H1 <= 256 && H2 <= 256 &&
+                   A <= T_ROWS && rows <= di.max_batch,
+               PA_ERR_UNSUPPORTED,
+               "pa_mlp_q_all2: needs two [S + AD, H1 <= 256, H2 <= 256, 1] ReLU critics of one shape, "
+               "A <= %d and rows <= max_batch", T_ROWS);
+    Ps[i] = use_target ? hs[i]->bufs.p_target : hs[i]->bufs.p;
+    PA_REQUIRE(Ps[i], PA_ERR_INVALID, "no target parameters bound");
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  PA_HIP(hipSetDevice(d.device));
+  static const bool use_split = []() {
+    const char* v = getenv("PEARL_AMD_TARGET_SPLIT");
+    return !(v && *v == '0');
+  }();
+  const bool split = use_split && H1 == TS_H && H2 == TS_H;
+  for (int i = 0; i < 2; ++i) {
+    pa_mlp* h = hs[i];
+    if (!h->qa_w2f) {
+      PA_HIP(hipMalloc((void**)&h->qa_w2f, (size_t)w2f_floats(H2, H1) * sizeof(float)));
+      PA_HIP(hipMalloc((void**)&h->qa_u, (size_t)h->d.max_batch * H1 * sizeof(float)));
+    }
+    if (split && !h->qa_w2sp) PA_HIP(hipMalloc(&h->qa_w2sp, (size_t)w2sp_bytes()));
+  }
+  hipLaunchKernelGGL(repack_w2_pair_kernel, dim3(64, 2), dim3(256), 0, s, Ps[0] + h1->woff[1],
+                     Ps[1] + h2->woff[1], H2, H1, h1->qa_w2f, h2->qa_w2f,
+                     split ? h1->qa_w2sp : nullptr, split ? h2->qa_w2sp : nullptr);
+  PA_LAUNCH_CHECK();
+  GemmArgs g[2];
+  memset(g, 0, sizeof(g));
+  for (int i = 0; i < 2; ++i) {
+    g[i].A = state; g[i].lda = ld_state;
+    g[i].Bm = Ps[i] + hs[i]->woff[0]; g[i].ldb = d.dims[0];
+    g[i].C = hs[i]->qa_u; g[i].ldc = H1;
+    g[i].bias = Ps[i] + hs[i]->boff[0];
+    g[i].M = rows; g[i].N = H1; g[i].K = S;
+    g[i].epi = EPI_BIAS;
+  }
+  int rc = launch_linear<false>(g, 2, s);
+  if (rc != PA_OK) return rc;
+  for (int i = 0; i < 2; ++i) {
+    pa_mlp* h = hs[i];
+    TargetArgs a;
+    memset(&a, 0, sizeof(a));
+    a.U = h->qa_u; a.ldu = H1;
+    a.feat = rep; a.feat_bstride = rep_bstride;
+    a.W1a = Ps[i] + h->woff[0] + S; a.ldw1 = d.dims[0];
+    a.W2f = h->qa_w2f;
+    a.W2sp = split ? h->qa_w2sp : nullptr;
+    a.b2 = Ps[i] + h->boff[1]; a.w3 = Ps[i] + h->woff[2]; a.b3 = Ps[i] + h->boff[2];
+    a.q_all = outs[i];
+    a.B = rows; a.A = A; a.AD = AD; a.H1 = H1; a.H2 = H2;
+    a.bpw = T_ROWS / A;
+    a.ntiles = (int)ceil_div(rows, a.bpw);
+    rc = launch_target(a, s);
+    if (rc != PA_OK) return rc;
+  }
+  return PA_OK;
+}
+
 // ---- two networks of the same depth on the same input in lock-step (TwinCritic,
 // twin_critic.py:22-91; PPO's actor and critic, ppo.py:152-192): every layer of both is ONE launch
 // (linear_kernel and weight_grad_kernel take several problems per launch), which halves the launch

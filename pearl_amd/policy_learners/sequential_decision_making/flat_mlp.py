@@ -312,6 +312,24 @@ class FlatMlp:
         return out
 
     @staticmethod
+    def q_all_pair(m1: "FlatMlp", m2: "FlatMlp", state: torch.Tensor, rep: torch.Tensor,
+                   use_target: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``q_all`` of both critics of a twin in one call (pa_mlp_q_all2: the repack and the
+        first-layer GEMM of the two networks share a launch each)."""
+        assert state.dtype == torch.float32 and state.is_cuda and state.stride(-1) == 1
+        assert rep.dtype == torch.float32 and rep.is_contiguous() and rep.ndim in (2, 3)
+        B = int(state.shape[0])
+        A, AD = int(rep.shape[-2]), int(rep.shape[-1])
+        m1.ready(B)
+        m2.ready(B)
+        out = torch.empty(2, B * A, dtype=torch.float32, device=state.device)
+        N.check(N.lib().pa_mlp_q_all2(m1.handle, m2.handle, int(use_target), state.data_ptr(),
+                                      state.stride(0), rep.data_ptr(), A * AD if rep.ndim == 3 else 0,
+                                      B, A, AD, out[0].data_ptr(), out[1].data_ptr(),
+                                      N.stream_ptr(state.device)))
+        return out[0], out[1]
+
+    @staticmethod
     def forward_pair(m1: "FlatMlp", m2: "FlatMlp", x: torch.Tensor, use_target: bool = False,
                      keep: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
         """Both networks of a twin (same shape) on the same input, one launch per layer."""

@@ -157,6 +157,8 @@ class SoftActorCritic(ActorCriticBase):
     def _twin_q_all(self, c1: FlatMlp, c2: FlatMlp, state: Tensor, rep: Tensor, use_target: bool):
         """(q1, q2), each (B * A,): both critics on every (state, available action) pair."""
         if c1.supports_q_all(int(rep.shape[-2])) and c2.supports_q_all(int(rep.shape[-2])):
+            if c1.dims == c2.dims:
+                return FlatMlp.q_all_pair(c1, c2, state, rep, use_target=use_target)
             return (c1.q_all(state, rep, use_target=use_target),
                     c2.q_all(state, rep, use_target=use_target))
         q1, q2 = FlatMlp.forward_pair(c1, c2, self._all_action_input(state, rep),
@@ -165,7 +167,12 @@ class SoftActorCritic(ActorCriticBase):
 
     @staticmethod
     def _mask_u8(mask: Optional[Tensor], dev: torch.device) -> Optional[Tensor]:
-        return None if mask is None else mask.to(dev).to(torch.uint8).contiguous()
+        """The (B, A) availability mask as bytes: a bool tensor is reinterpreted (same storage, no
+        launch), anything else converted."""
+        if mask is None:
+            return None
+        m = mask.to(dev).contiguous()
+        return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
 
     # ------------------------------------------------------------------ losses
     def _actor_update(self, batch: TransitionBatch) -> Tensor:
@@ -212,7 +219,7 @@ class SoftActorCritic(ActorCriticBase):
         nlogits = actor.forward(nstate)
         y = torch.empty(B, dtype=torch.float32, device=dev)
         reward = self._f32(batch.reward, dev).reshape(B)
-        term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
+        term = self._mask_u8(batch.terminated.reshape(B), dev)
         nmask = self._mask_u8(batch.next_unavailable_actions_mask, dev)
         N.check(N.lib().pa_dsac_target(nlogits.data_ptr(), nlogits.stride(0), nq1.data_ptr(),
                                        nq2.data_ptr(), N.ptr(nmask), al["alpha"].data_ptr(),

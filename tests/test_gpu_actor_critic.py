@@ -752,6 +752,28 @@ def test_q_all_matches_expanded_forward(S, AD, A, hidden, B, bcast):
         torch.testing.assert_close(got, want, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("S,AD,A,hidden,B", [(128, 16, 16, [256, 256], 300), (20, 7, 5, [100, 60], 33)])
+def test_twin_q_all_is_two_q_all_calls(S, AD, A, hidden, B):
+    """pa_mlp_q_all2 (shared repack and first-layer launches) == pa_mlp_q_all per critic, bitwise."""
+    from torch import nn, optim
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    torch.manual_seed(12)
+    dims = [S + AD] + hidden + [1]
+    nets = []
+    for _ in range(2):
+        mk = lambda: [nn.Linear(dims[i], dims[i + 1]).to(DEV) for i in range(3)]
+        lins, tgt = mk(), mk()
+        nets.append(FlatMlp(layers_of(lins),
+                            optim.AdamW([p for l in lins for p in l.parameters()], amsgrad=True),
+                            max_batch=B * A, target_layers=layers_of(tgt)))
+    state = torch.randn(B, S, device=DEV)
+    rep = torch.randn(B, A, AD, device=DEV)
+    for use_target in (False, True):
+        q1, q2 = FlatMlp.q_all_pair(nets[0], nets[1], state, rep, use_target=use_target)
+        assert torch.equal(q1, nets[0].q_all(state, rep, use_target=use_target))
+        assert torch.equal(q2, nets[1].q_all(state, rep, use_target=use_target))
+
+
 IQL = ["iql_continuous_tiny", "iql_continuous_shape_small", "iql_discrete_tiny", "iql_gaussian_tiny",
        "iql_gaussian_shape_small"]
 
