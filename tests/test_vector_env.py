@@ -124,6 +124,28 @@ def test_act_many_is_e_act_calls_with_the_same_exploration_draws():
                        torch.stack([pl.act(states[e], sp, exploit=True) for e in range(32)]))
 
 
+def test_act_many_follows_the_epsilon_warm_up_of_sequential_calls():
+    """Epsilon scheduling (epsilon_greedy_exploration.py:61-75) moves epsilon with every act():
+    row e of act_many sees the epsilon the e-th sequential call would, across the end of the
+    warm-up as well."""
+    def fresh():
+        pl = learner()
+        pl.exploration_module = EGreedyExploration(0.05, start_epsilon=0.9, end_epsilon=0.1, warmup_steps=20)
+        return pl
+    states = torch.randn(48, S)
+    pl = fresh()
+    random.seed(11)
+    sp = space(seed=5)
+    want = torch.stack([pl.act(states[e], sp, exploit=False) for e in range(48)])
+    eps_want, t_want = pl.exploration_module.curr_epsilon, pl.exploration_module.time_step
+    pl = fresh()
+    random.seed(11)
+    sp = space(seed=5)
+    got = torch.cat([pl.act_many(states[:30], sp), pl.act_many(states[30:], sp)])
+    assert torch.equal(want, got)
+    assert (pl.exploration_module.curr_epsilon, pl.exploration_module.time_step) == (eps_want, t_want)
+
+
 def test_feeder_pushes_what_e_sequential_agents_push():
     pl = learner()
     sp = space()
