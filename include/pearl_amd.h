@@ -572,6 +572,33 @@ int pa_ppo_heads(const float* logits, int32_t ldl, const float* action_rep, int3
                  const float* p_old, const float* gae, int32_t B, int32_t A, float epsilon,
                  float entropy_scale, float* d_logits, int32_t ldd, const float* value, int32_t ldv,
                  const float* value_target, float* d_value, float* losses, void* stream);
+
+/* ---- fused row steps (pearl_amd/csrc/mlp_rowstep.hpp): forward (activations kept) + the
+ * row-local part of the loss + backward down to every pre-activation gradient, ONE launch for two
+ * networks on the same input.  They leave both networks' weight gradients pending exactly like
+ * pa_mlp_backward2(want_dw = 2): follow with pa_mlp_adam2, or pa_mlp_flush_grads2 -> all-reduce ->
+ * pa_mlp_adamw2.  Gradients are bit-identical to pa_mlp_forward2 -> heads -> pa_mlp_backward2; the
+ * reported losses are summed per 16-row tile and then in tile order (equal to rounding). */
+/* 1 when the two networks qualify: every layer <= 256 wide, same depth and input width;
+ * ppo_actions > 0: h1 is an actor with that many (<= 32) outputs and h2 a one-output critic;
+ * ppo_actions == 0: two one-output critics.  0 also under PEARL_AMD_ROWSTEP=0. */
+int pa_rowstep_supported(const pa_mlp* h1, const pa_mlp* h2, int32_t ppo_actions);
+/* ProximalPolicyOptimization's actor and critic steps of one minibatch (ppo.py:152-192,
+ * actor_critic_base.py:309-366; critic_utils.py:139-167): what pa_mlp_forward2(keep) ->
+ * pa_ppo_heads -> pa_mlp_backward2(want_dw = 2) compute.  d_value = value_grad_scale (v - target)
+ * (2 / B, or 2 / (B world) under data parallelism); losses[0] = actor, losses[1] = critic.
+ * logits_out / value_out may be NULL. */
+int pa_ppo_rowstep(pa_mlp* actor, pa_mlp* critic, const float* x, int32_t ldx, int32_t B,
+                   const float* action_rep, int32_t lda, const float* p_old, const float* gae,
+                   float epsilon, float entropy_scale, const float* value_target,
+                   float value_grad_scale, float* logits_out, int32_t ldl, float* value_out,
+                   int32_t ldv, float* d_logits, int32_t ldd, float* d_value, float* losses,
+                   void* stream);
+/* Twin critics against one target (twin_critic_action_value_loss, critic_utils.py:170-203):
+ * d_q_i = grad_scale (q_i - target), loss_out[0] = loss_scale (mse_1 + mse_2).  q*_out may be NULL. */
+int pa_mse_rowstep2(pa_mlp* c1, pa_mlp* c2, const float* x, int32_t ldx, int32_t B,
+                    const float* target, float grad_scale, float loss_scale, float* q1_out,
+                    float* q2_out, float* d_q1, float* d_q2, float* loss_out, void* stream);
 /* nn.MSELoss head (critic_utils.py:139-203): d_pred = grad_scale * (pred - target);
  * loss_out (=|+=) mean((pred - target)^2) * loss_scale. */
 int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B, float grad_scale,

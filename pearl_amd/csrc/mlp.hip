@@ -21,6 +21,7 @@
 
 #include "host_launch.hpp"
 #include "mlp_rowpass.hpp"
+#include "mlp_rowstep.hpp"
 #include "mlp_internal.hpp"
 #include "sac_rows.hpp"
 
@@ -873,6 +874,163 @@ extern "C" int pa_mlp_backward2(pa_mlp* h1, pa_mlp* h2, const float* x, int32_t 
     }
   }
   return PA_OK;
+}
+
+// ---- forward + loss head + backward of one or two networks as ONE launch (mlp_rowstep.hpp) ------
+namespace {
+bool rowstep_enabled() {
+  static const bool on = []() {
+    const char* v = getenv("PEARL_AMD_ROWSTEP");
+    return !(v && *v == '0');
+  }();
+  return on;
+}
+// per process: per-tile partial sums of both networks, the chosen-action probabilities, the ticket
+struct RowStepScratch {
+  float* buf = nullptr;
+  size_t floats = 0;
+};
+int rowstep_scratch(RowStepScratch& sc, size_t need) {
+  if (need <= sc.floats) return PA_OK;
+  if (sc.buf) {
+    PA_HIP(hipDeviceSynchronize());
+    (void)hipFree(sc.buf);
+    sc.buf = nullptr;
+    sc.floats = 0;
+  }
+  PA_HIP(hipMalloc((void**)&sc.buf, need * 2 * sizeof(float)));
+  PA_HIP(hipMemset(sc.buf, 0, need * 2 * sizeof(float)));
+  sc.floats = need * 2;
+  return PA_OK;
+}
+// heads[i].d_out / target / ... filled by the caller; p_rows, partials and the ticket are set here
+int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, RowHead* heads,
+                float* const* outs, const int* ldos, float* losses, int sum_losses, hipStream_t s) {
+  static RowStepScratch sc;
+  RowStepArgs a;
+  memset(&a, 0, sizeof(a));
+  const unsigned gx = (unsigned)ceil_div(B, RP_ROWS);
+  int rc = rowstep_scratch(sc, (size_t)4 + 4 * gx + 2 * (size_t)B);
+  if (rc != PA_OK) return rc;
+  a.ticket = reinterpret_cast<unsigned*>(sc.buf);
+  a.partials = sc.buf + 4;
+  int d0max = 0;
+  for (int i = 0; i < nnet; ++i) {
+    pa_mlp* h = hs[i];
+    PA_REQUIRE(h->row_ok && B > 0 && B <= h->d.max_batch, PA_ERR_UNSUPPORTED,
+               "row step: network outside the row-pass kernels' shapes, or batch above max_batch");
+    rc = ensure_packed(h, false, s);
+    if (rc != PA_OK) return rc;
+    fill_fwd(h, false, outs[i], ldos[i], true, a.fwd[i]);
+    fill_bwd(h, nullptr, 0, nullptr, 0, a.bwd[i]);
+    a.head[i] = heads[i];
+    a.head[i].p_rows = sc.buf + 4 + 4 * gx + (size_t)i * B;
+    d0max = h->d.dims[0] > d0max ? h->d.dims[0] : d0max;
+  }
+  a.x = x; a.ldx = ldx; a.B = B;
+  a.losses = losses;
+  a.sum_losses = sum_losses;
+  static size_t configured = 0;
+  const size_t smem = rowstep_smem_bytes(d0max);
+  if (smem > configured) {
+    rc = set_max_smem(mlp_rowstep_kernel, smem);
+    if (rc != PA_OK) return rc;
+    configured = smem;
+  }
+  hipLaunchKernelGGL(mlp_rowstep_kernel, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  // the state a kept forward + a want_dw = 2 backward leave behind: the weight gradients (and
+  // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
+  for (int i = 0; i < nnet; ++i) {
+    pa_mlp* h = hs[i];
+    const int L = h->L;
+    const float* dzs[PA_MLP_MAX_LAYERS];
+    int ldzs[PA_MLP_MAX_LAYERS];
+    dzs[L - 1] = heads[i].d_out; ldzs[L - 1] = heads[i].ldd;
+    for (int l = L - 1; l > 0; --l) {
+      dzs[l - 1] = h->dz[l];
+      ldzs[l - 1] = h->d.dims[l];
+    }
+    h->kept_B = B;
+    set_pending(h, x, ldx, B, dzs, ldzs);
+  }
+  return PA_OK;
+}
+}  // namespace
+
+// 1 when pa_ppo_rowstep / pa_mse_rowstep2 take these networks (shapes the row-pass kernels cover;
+// PEARL_AMD_ROWSTEP=0: never): callers fall back to forward2 -> heads -> backward2 otherwise.
+extern "C" int pa_rowstep_supported(const pa_mlp* h1, const pa_mlp* h2, int32_t ppo_actions) {
+  if (!rowstep_enabled() || !h1 || !h2 || !h1->bound || !h2->bound) return 0;
+  if (!h1->row_ok || !h2->row_ok || h1->L != h2->L || h1->d.dims[0] != h2->d.dims[0]) return 0;
+  if (ppo_actions > 0 && (h1->d.dims[h1->L] != ppo_actions || ppo_actions > 32 ||
+                          h2->d.dims[h2->L] != 1))
+    return 0;
+  if (ppo_actions == 0 && (h1->d.dims[h1->L] != 1 || h2->d.dims[h2->L] != 1)) return 0;
+  return 1;
+}
+
+// One PPO minibatch step down to the pre-activation gradients (ppo.py:152-192 on
+// actor_critic_base.py:309-366): actor and critic forward (activations kept), the surrogate's and
+// the value loss's row-local gradients, both backward passes — ONE launch.  Leaves both networks'
+// weight gradients pending like pa_mlp_backward2(want_dw = 2): follow with pa_mlp_adam2 (or
+// pa_mlp_flush_grads2 -> all-reduce -> pa_mlp_adamw2).  d_value = value_grad_scale (v - target);
+// losses[0] = actor loss, losses[1] = critic loss (mean squared error).
+extern "C" int pa_ppo_rowstep(pa_mlp* actor, pa_mlp* critic, const float* x, int32_t ldx, int32_t B,
+                              const float* action_rep, int32_t lda, const float* p_old,
+                              const float* gae, float epsilon, float entropy_scale,
+                              const float* value_target, float value_grad_scale, float* logits_out,
+                              int32_t ldl, float* value_out, int32_t ldv, float* d_logits,
+                              int32_t ldd, float* d_value, float* losses, void* stream) {
+  PA_REQUIRE(actor && critic && x && action_rep && p_old && gae && value_target && d_logits &&
+                 d_value && losses && B > 0,
+             PA_ERR_INVALID, "pa_ppo_rowstep: bad argument");
+  PA_REQUIRE(pa_rowstep_supported(actor, critic, actor->d.dims[actor->L]), PA_ERR_UNSUPPORTED,
+             "pa_ppo_rowstep: needs an actor with <= 32 outputs and a one-output critic of the same "
+             "depth and input width, every layer <= 256 wide");
+  PA_HIP(hipSetDevice(actor->d.device));
+  pa_mlp* hs[2] = {actor, critic};
+  RowHead heads[2];
+  memset(heads, 0, sizeof(heads));
+  heads[0].kind = RS_HEAD_PPO;
+  heads[0].d_out = d_logits; heads[0].ldd = ldd;
+  heads[0].arep = action_rep; heads[0].lda = lda; heads[0].p_old = p_old; heads[0].gae = gae;
+  heads[0].eps = epsilon; heads[0].ent_scale = entropy_scale;
+  heads[1].kind = RS_HEAD_MSE;
+  heads[1].d_out = d_value; heads[1].ldd = 1;
+  heads[1].target = value_target; heads[1].grad_scale = value_grad_scale; heads[1].loss_scale = 1.0f;
+  float* outs[2] = {logits_out, value_out};
+  const int ldos[2] = {ldl, ldv};
+  return run_rowstep(hs, 2, x, ldx, B, heads, outs, ldos, losses, 0,
+                     reinterpret_cast<hipStream_t>(stream));
+}
+
+// Twin critics on (state, action) rows against one target (twin_critic_action_value_loss,
+// critic_utils.py:170-203): forward (kept), d_q_i = grad_scale (q_i - target), backward — one
+// launch; loss_out[0] = loss_scale (mse_1 + mse_2).  Weight gradients pending as above.
+extern "C" int pa_mse_rowstep2(pa_mlp* c1, pa_mlp* c2, const float* x, int32_t ldx, int32_t B,
+                               const float* target, float grad_scale, float loss_scale,
+                               float* q1_out, float* q2_out, float* d_q1, float* d_q2,
+                               float* loss_out, void* stream) {
+  PA_REQUIRE(c1 && c2 && x && target && d_q1 && d_q2 && loss_out && B > 0, PA_ERR_INVALID,
+             "pa_mse_rowstep2: bad argument");
+  PA_REQUIRE(pa_rowstep_supported(c1, c2, 0), PA_ERR_UNSUPPORTED,
+             "pa_mse_rowstep2: needs two one-output networks of the same depth and input width, "
+             "every layer <= 256 wide");
+  PA_HIP(hipSetDevice(c1->d.device));
+  pa_mlp* hs[2] = {c1, c2};
+  RowHead heads[2];
+  memset(heads, 0, sizeof(heads));
+  float* dqs[2] = {d_q1, d_q2};
+  for (int i = 0; i < 2; ++i) {
+    heads[i].kind = RS_HEAD_MSE;
+    heads[i].d_out = dqs[i]; heads[i].ldd = 1;
+    heads[i].target = target; heads[i].grad_scale = grad_scale; heads[i].loss_scale = loss_scale;
+  }
+  float* outs[2] = {q1_out, q2_out};
+  const int ldos[2] = {1, 1};
+  return run_rowstep(hs, 2, x, ldx, B, heads, outs, ldos, loss_out, 1,
+                     reinterpret_cast<hipStream_t>(stream));
 }
 
 // Weight gradients a want_dw = 2 backward left pending, without the optimizer (data parallel: the

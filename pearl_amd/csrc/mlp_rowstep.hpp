@@ -1,0 +1,329 @@
+// One launch for forward + loss head + backward of a network (or of two networks on the same
+// input: PPO's actor and critic, ppo.py:152-192; twin critics, critic_utils.py:170-203) for 16 batch
+// rows per workgroup: mlp_rowfwd_kernel's layer loop (activations kept for the weight gradients),
+// the row-local part of the loss on the output tile while it is still in LDS, and
+// mlp_rowbwd_kernel's layer loop on the head's gradient tile.  What it removes from a step is two
+// launches and the boundaries between them (3-4 us each on this machine), the
+// head's own launch, and the global round trip of the output / output-gradient tiles.
+//
+// The per-row arithmetic of the heads is that of their stand-alone kernels in mlp.hip
+// (ppo_actor_elem_kernel, mse_head_body): the same expressions in the same order, so the
+// gradients are bit-identical; the batch sums of the reported losses are taken per 16-row tile and
+// then in tile order by the last workgroup to finish (ticket), i.e. grouped differently from the
+// stand-alone kernels (equal to rounding).
+#pragma once
+#include "mlp_rowpass.hpp"
+
+namespace pa {
+
+enum { RS_HEAD_MSE = 1, RS_HEAD_PPO = 2 };
+
+struct RowHead {
+  int kind;
+  float* d_out; int ldd;        // [B][d_L]: gradient w.r.t. the network output (operand of the
+                                // last layer's weight gradient)
+  // RS_HEAD_MSE (single_critic_state_value_loss / twin_critic_action_value_loss,
+  // critic_utils.py:139-203): d = out - target, d_out = grad_scale d, loss = mean d^2 * loss_scale
+  const float* target; float grad_scale; float loss_scale;
+  // RS_HEAD_PPO (ProximalPolicyOptimization._actor_loss, ppo.py:152-183), d_L = A <= 32
+  const float* arep; int lda;   // [B][A] representation of the taken action
+  const float* p_old;           // [B]
+  const float* gae;             // [B]
+  float eps, ent_scale;
+  float* p_rows;                // [B] scratch: chosen-action probability of every row
+};
+
+struct RowStepArgs {
+  RowNetFwd fwd[2];
+  RowNetBwd bwd[2];             // (d_out / ldd unused: the head's LDS tile is the operand)
+  RowHead head[2];
+  const float* x; int ldx;
+  int B;
+  float* partials;              // [2 networks][gridDim.x][2]
+  unsigned* ticket;             // zero on entry, zero again on exit
+  float* losses;                // [2]: one per network — or, sum_losses, losses[0] = both
+  int sum_losses;
+};
+
+constexpr int RS_SCR = 5 * 512;   // floats of head scratch behind the row-pass tiles
+inline size_t rowstep_smem_bytes(int d0) { return rowfwd_smem_bytes(d0) + sizeof(float) * RS_SCR; }
+
+__device__ __forceinline__ float block_sum_512(float v, float* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int w = 256; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
+// two sums with one set of barriers (red: 1024 floats)
+__device__ __forceinline__ float2 block_sum2_512(float v0, float v1, float* red) {
+  red[threadIdx.x] = v0;
+  red[512 + threadIdx.x] = v1;
+  __syncthreads();
+  for (int w = 256; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[threadIdx.x] += red[threadIdx.x + w];
+      red[512 + threadIdx.x] += red[512 + threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  const float2 r = make_float2(red[0], red[512]);
+  __syncthreads();
+  return r;
+}
+// Hand-off of a few words to whichever workgroup finishes last: write-through (agent-scope) stores
+// and L2-bypassing loads, ordered by the workgroup barrier's wait for outstanding stores and a
+// relaxed ticket — NOT __threadfence(): an agent-scope release writes the whole XCD L2 back, and
+// every one of 512 workgroups doing that behind megabytes of freshly stored activations made the
+// fused launch slower than the three it replaces (151 vs 143 us per PPO step).
+__device__ __forceinline__ void st_through(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_through(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int net = blockIdx.y;
+  const RowNetFwd& n = a.fwd[net];
+  const RowNetBwd& nb = a.bwd[net];
+  const RowHead& hd = a.head[net];
+  const int P0 = rp_pad(n.dims[0]), PH = row_hid_pitch();
+  float* xs = smem;
+  float* hb[2] = {xs + RP_ROWS * P0, xs + RP_ROWS * P0 + RP_ROWS * PH};
+  float* scr = xs + RP_ROWS * P0 + 2 * RP_ROWS * PH;   // va | vb | vc | red[2], 512 floats each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, qd = lane >> 4;
+  const int m0 = blockIdx.x * RP_ROWS;
+  const int row = m0 + r16;
+  const bool rok = row < a.B;
+  const int u0 = wave * 32 + 4 * qd;
+  const int tile0 = wave * 2;
+  // ---------------------------------------------------------------- forward (mlp_rowfwd_kernel)
+  {
+    const bool vx = is_vec_ok(a.x, a.ldx) && ((n.dims[0] & 3) == 0);
+    const int c4 = (P0 - 4) >> 2;
+    for (int e = tid; e < RP_ROWS * c4; e += 512) {
+      const int r = e / c4, c = (e - r * c4) * 4;
+      const bool ok = (m0 + r) < a.B;
+      float4 v;
+      if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
+      else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
+      *reinterpret_cast<float4*>(xs + r * P0 + c) = v;
+    }
+  }
+  const float* in = xs;
+  int pin = P0;
+  for (int l = 0; l < n.L; ++l) {
+    const int K = n.dims[l], N = n.dims[l + 1];
+    const int nt = (N + 15) >> 4;
+    f32x4v acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n.bias[l]) b = guarded_load4(n.bias[l], 0, true, u0 + 16 * t, N);
+      acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+    }
+    __syncthreads();
+    rows16_gemm<4>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
+    const bool last = l == n.L - 1;
+    const bool relu = (n.relu >> l) & 1;
+    float* nxt = hb[l & 1];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int u = u0 + 16 * t;
+      float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+      if (relu) v = make_float4(relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z),
+                                relu_keep_nan(v.w));
+      // (the output tile stays in LDS as well: the head reads it from there)
+      if (u < PH - 4) *reinterpret_cast<float4*>(nxt + r16 * PH + u) = v;
+      if (!last) {
+        if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
+      } else if (rok && n.out) {
+        store4_guarded(n.out, (int64_t)row * n.ldo, u, N,
+                       is_vec_ok(n.out, n.ldo) && (N & 3) == 0, v);
+      }
+    }
+    in = nxt;
+    pin = PH;
+  }
+  __syncthreads();
+  // ---------------------------------------------------------------- head: d_out tile into hb[0]
+  const float* ot = hb[(n.L - 1) & 1];   // [16][PH] network output of this tile
+  const int DL = n.dims[n.L];
+  float* va = scr;
+  float* vb = scr + 512;
+  float* red = scr + 3 * 512;
+  float dval = 0.f, part0 = 0.f, part1 = 0.f;
+  int hr = 0, hj = 0;
+  bool hlive = false;
+  if (hd.kind == RS_HEAD_PPO) {
+    // one thread per (row, action) — ppo_actor_elem_kernel with 16 rows per workgroup
+    const int A = DL;
+    hr = tid / A; hj = tid - hr * A;
+    const int b = m0 + hr;
+    hlive = hr < RP_ROWS && b < a.B;
+    const float lo = 1.0f - hd.eps, hi = 1.0f + hd.eps;
+    const float z = (hr < RP_ROWS) ? ot[hr * PH + hj] : 0.f;
+    const float ar = hlive ? hd.arep[(int64_t)b * hd.lda + hj] : 0.f;
+    const float g = hlive ? hd.gae[b] : 0.f;
+    const float pold = hlive ? hd.p_old[b] : 1.f;
+    const int base = hr * A;
+    if (hr < RP_ROWS) va[tid] = z;
+    __syncthreads();
+    float m = 0.f, s = 0.f, p = 0.f;
+    if (hlive) {
+      m = va[base];
+      for (int k = 1; k < A; ++k) m = fmaxf(m, va[base + k]);
+    }
+    const float e = expf(z - m);
+    if (hr < RP_ROWS) vb[tid] = e;
+    __syncthreads();
+    if (hlive)
+      for (int k = 0; k < A; ++k) s += vb[base + k];
+    const float y = hlive ? e / s : 0.f;
+    if (hr < RP_ROWS) va[tid] = y * ar;
+    __syncthreads();
+    if (hlive) {
+      for (int k = 0; k < A; ++k) p += va[base + k];
+      const float rt = p / pold;
+      const float clip = fminf(fmaxf(rt, lo), hi);
+      const float s1 = rt * g, s2 = clip * g;
+      const float inr = (rt >= lo && rt <= hi) ? 1.f : 0.f;
+      float dr;
+      if (s1 < s2) dr = g;
+      else if (s1 > s2) dr = g * inr;
+      else dr = 0.5f * g + 0.5f * g * inr;
+      const float dp = -dr / pold;
+      const float dot = dp * p;
+      dval = y * (dp * ar - dot);
+      if (hj == 0) {
+        part0 = -fminf(s1, s2);
+        part1 = p;
+        st_through(hd.p_rows + b, p);
+      }
+    }
+  } else {   // RS_HEAD_MSE: one thread per row, output column 0
+    hr = tid; hj = 0;
+    const int b = m0 + hr;
+    hlive = hr < RP_ROWS && b < a.B;
+    if (hlive) {
+      const float d = __fsub_rn(ot[hr * PH], hd.target[b]);
+      dval = __fmul_rn(hd.grad_scale, d);
+      part0 = d * d;
+    }
+  }
+  __syncthreads();   // every read of the output tile is done: hb[0] may be overwritten
+  {
+    const int c4 = (rp_pad(DL) - 4) >> 2;
+    for (int e = tid; e < RP_ROWS * c4; e += 512) {
+      const int r = e / c4, c = (e - r * c4) * 4;
+      *reinterpret_cast<float4*>(hb[0] + r * PH + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  if (hlive) {
+    hb[0][hr * PH + hj] = dval;
+    hd.d_out[(int64_t)(m0 + hr) * hd.ldd + hj] = dval;
+  }
+  {
+    const float2 s01 = block_sum2_512(part0, part1, red);   // (its barriers also publish the tile)
+    if (tid == 0) {
+      float* pp = a.partials + ((int64_t)net * gridDim.x + blockIdx.x) * 2;
+      st_through(pp, s01.x);
+      st_through(pp + 1, s01.y);
+    }
+  }
+  // ---------------------------------------------------------------- backward (mlp_rowbwd_kernel)
+  in = hb[0];
+  int cur = 0;
+  for (int l = nb.L - 1; l >= 0; --l) {
+    if (l == 0 && !nb.d_x) break;
+    const int K = nb.dims[l + 1], N = nb.dims[l];
+    const int nt = (N + 15) >> 4;
+    const bool mask = l > 0 && ((nb.relu >> (l - 1)) & 1);
+    float* nxt = hb[cur ^ 1];
+    __syncthreads();
+    for (int c0 = 0; c0 < nt; c0 += 16) {
+      f32x4v acc[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
+      rows16_gemm<4>(acc, nb.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, lane);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int u = c0 * 16 + u0 + 16 * t;
+        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
+        if (l > 0) {
+          if (mask) {
+            const float4 hm = guarded_load4(nb.act[l - 1], (int64_t)row * N, rok, u, N);
+            v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
+            v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+          }
+          if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (u < PH - 4) *reinterpret_cast<float4*>(nxt + r16 * PH + u) = v;
+          if (rok) store4_guarded(nb.dz[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
+        } else if (rok) {
+          store4_guarded(nb.d_x, (int64_t)row * nb.lddx, u, N,
+                         is_vec_ok(nb.d_x, nb.lddx) && (N & 3) == 0, v);
+        }
+      }
+    }
+    in = nxt;
+    cur ^= 1;
+  }
+  // ---------------------------------------------------------------- losses: last workgroup
+  __shared__ unsigned is_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned total = gridDim.x * gridDim.y;
+    is_last = (__hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+               total - 1u) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  float both = 0.f;
+  for (int k = 0; k < (int)gridDim.y; ++k) {
+    const RowHead& h = a.head[k];
+    const float* pp = a.partials + (int64_t)k * gridDim.x * 2;
+    float p0 = 0.f, p1 = 0.f;
+    for (unsigned i = tid; i < gridDim.x; i += 512) {   // fixed order: strided, then the tree
+      p0 += ld_through(pp + 2 * i);
+      p1 += ld_through(pp + 2 * i + 1);
+    }
+    const float2 s01 = block_sum2_512(p0, p1, red);
+    const float s0 = s01.x, s1 = s01.y;
+    float loss;
+    if (h.kind == RS_HEAD_PPO) {
+      // - entropy_scale * H(Categorical(p_batch)): the chosen-action probabilities of the whole
+      // minibatch as ONE categorical (ppo.py:179-182; a detached scalar)
+      float part_e = 0.f;
+      const float tiny = 1.1920928955078125e-07f;  // torch.finfo(float32).eps
+      for (int i = tid; i < a.B; i += 512) {
+        const float pr = ld_through(h.p_rows + i);
+        const float pn = pr / s1;
+        const float pc = fminf(fmaxf(pn, tiny), 1.0f - tiny);
+        float lg = logf(pc);
+        lg = fmaxf(lg, -3.4028234663852886e+38f);
+        part_e += lg * pn;
+      }
+      const float ent = -block_sum_512(part_e, red);
+      loss = s0 - h.ent_scale * ent;
+    } else {
+      loss = (s0 / (float)a.B) * h.loss_scale;
+    }
+    both += loss;
+    if (tid == 0 && !a.sum_losses) a.losses[k] = loss;
+  }
+  if (tid == 0) {
+    if (a.sum_losses) a.losses[0] = both;
+    __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+}  // namespace pa

@@ -345,6 +345,53 @@ class FlatMlp:
         return o1, o2
 
     @staticmethod
+    def rowstep_supported(m1: "FlatMlp", m2: "FlatMlp", ppo_actions: int = 0) -> bool:
+        """The two networks qualify for the fused forward + head + backward launch
+        (pa_ppo_rowstep / pa_mse_rowstep2; PEARL_AMD_ROWSTEP=0: never)."""
+        return bool(N.lib().pa_rowstep_supported(m1.handle, m2.handle, int(ppo_actions)))
+
+    @staticmethod
+    def ppo_rowstep(actor: "FlatMlp", critic: "FlatMlp", x: torch.Tensor, arep: torch.Tensor,
+                    p_old: torch.Tensor, gae: torch.Tensor, epsilon: float, entropy_scale: float,
+                    value_target: torch.Tensor, value_grad_scale: float) -> torch.Tensor:
+        """forward_pair(keep) -> pa_ppo_heads -> backward_pair(defer) as one launch; returns the
+        (2,) losses (actor, critic).  The weight gradients are pending: adam_pair next."""
+        B = int(x.shape[0])
+        actor.ready(B)
+        critic.ready(B)
+        dev = x.device
+        d_logits = torch.empty(B, actor.dims[-1], dtype=torch.float32, device=dev)
+        dv = torch.empty(B, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
+        N.check(N.lib().pa_ppo_rowstep(
+            actor.handle, critic.handle, x.data_ptr(), x.stride(0), B, arep.data_ptr(),
+            arep.stride(0), p_old.data_ptr(), gae.data_ptr(), float(epsilon), float(entropy_scale),
+            value_target.data_ptr(), float(value_grad_scale), None, 0, None, 0, d_logits.data_ptr(),
+            d_logits.stride(0), dv.data_ptr(), losses.data_ptr(), N.stream_ptr(dev)))
+        actor._pending_x = (x, d_logits)     # operands of the deferred weight-gradient launch
+        critic._pending_x = (x, dv)
+        return losses
+
+    @staticmethod
+    def mse_rowstep_pair(c1: "FlatMlp", c2: "FlatMlp", x: torch.Tensor, target: torch.Tensor,
+                         grad_scale: float, loss_scale: float) -> torch.Tensor:
+        """forward_pair(keep) -> two MSE heads -> backward_pair(defer) of twin critics as one
+        launch; returns the (1,) loss ``loss_scale (mse_1 + mse_2)``."""
+        B = int(x.shape[0])
+        c1.ready(B)
+        c2.ready(B)
+        dev = x.device
+        dq = torch.empty(2, B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(N.lib().pa_mse_rowstep2(c1.handle, c2.handle, x.data_ptr(), x.stride(0), B,
+                                        target.data_ptr(), float(grad_scale), float(loss_scale), None,
+                                        None, dq[0].data_ptr(), dq[1].data_ptr(), loss.data_ptr(),
+                                        N.stream_ptr(dev)))
+        c1._pending_x = (x, dq)
+        c2._pending_x = (x, dq)
+        return loss
+
+    @staticmethod
     def backward_pair(m1: "FlatMlp", m2: "FlatMlp", x: torch.Tensor, d1: torch.Tensor,
                       d2: torch.Tensor, want_dw: bool = True, want_dx: bool = False,
                       defer: bool = False):

@@ -217,10 +217,6 @@ class ProximalPolicyOptimization(ActorCriticBase):
         arep = self._f32(batch.action, dev).reshape(B, -1)
         A = actor.dims[-1]
         assert arep.shape[1] == A, "PPO needs the action representation the actor outputs"
-        logits, v = FlatMlp.forward_pair(actor, critic, state, keep=True)
-        d_logits = torch.empty_like(logits)
-        dv = torch.empty(B, dtype=torch.float32, device=dev)
-        losses = torch.empty(2, dtype=torch.float32, device=dev)
         # Data parallel (BASELINE config 4; not in the reference): every rank steps on
         # its own minibatch of its rollout shard.  The surrogate is a SUM over the global minibatch
         # (ppo.py:176-183), the critic loss a MEAN (critic_utils.py:139-167): the critic's head is
@@ -229,6 +225,18 @@ class ProximalPolicyOptimization(ActorCriticBase):
         world = _comm.world_size() if getattr(self, "data_parallel", True) else 1
         dp = world > 1 or (os.environ.get("PEARL_AMD_FORCE_DP") == "1" and dist.is_available()
                            and dist.is_initialized())
+        if FlatMlp.rowstep_supported(actor, critic, A):
+            # forward, both heads and both backward passes in ONE launch (mlp_rowstep.hpp); the
+            # critic's head is scaled by 1 / world there
+            losses = FlatMlp.ppo_rowstep(
+                actor, critic, state, arep, self._f32(batch.action_probs, dev),
+                self._f32(batch.gae, dev), float(self._epsilon), float(self._entropy_bonus_scaling),
+                self._f32(batch.lam_return, dev), 2.0 / (B * (world if dp else 1)))
+            return self._ppo_optimizer_step(actor, critic, dp, losses)
+        logits, v = FlatMlp.forward_pair(actor, critic, state, keep=True)
+        d_logits = torch.empty_like(logits)
+        dv = torch.empty(B, dtype=torch.float32, device=dev)
+        losses = torch.empty(2, dtype=torch.float32, device=dev)
         # both heads in one launch: the value head's single workgroup runs beside the actor head
         N.check(N.lib().pa_ppo_heads(
             logits.data_ptr(), logits.stride(0), arep.data_ptr(), arep.stride(0),
@@ -239,6 +247,11 @@ class ProximalPolicyOptimization(ActorCriticBase):
         if dp and world > 1:
             dv.mul_(1.0 / world)      # (2 / B) (v - R) -> (2 / (B world)) (v - R), exact for world = 2^k
         FlatMlp.backward_pair(actor, critic, state, d_logits, dv, want_dw=True, defer=True)
+        return self._ppo_optimizer_step(actor, critic, dp, losses)
+
+    def _ppo_optimizer_step(self, actor: FlatMlp, critic: FlatMlp, dp: bool,
+                            losses: torch.Tensor) -> Dict[str, Any]:
+        """Weight gradients + AdamW of both networks (the backward passes left them pending)."""
         if dp:
             FlatMlp.adam_pair_data_parallel(actor, critic, force=True)
         elif os.environ.get("PEARL_AMD_PPO_PAIR", "1") == "1" and not (

@@ -231,6 +231,11 @@ class SoftActorCritic(ActorCriticBase):
         xq = torch.empty(B, S + AD, dtype=torch.float32, device=dev)
         N.check(N.lib().pa_concat_cols(state.data_ptr(), state.stride(0), act.data_ptr(),
                                        act.stride(0), xq.data_ptr(), B, S, AD, s))
+        if FlatMlp.rowstep_supported(c1, c2):
+            # both critics' forward, MSE heads and backward in one launch (mlp_rowstep.hpp)
+            loss = FlatMlp.mse_rowstep_pair(c1, c2, xq, y, 1.0 / B, 0.5)
+            self._step_twin_critics(c1, c2)
+            return loss[0]
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, keep=True)]
         dqs = [torch.empty_like(q) for q in qs]

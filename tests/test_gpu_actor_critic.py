@@ -435,6 +435,107 @@ def test_twin_adam_pair_equals_two_single_steps(dims, B, soft):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("S,A,hidden,B", [(256, 16, [256, 256], 4096), (12, 5, [40, 24], 37),
+                                           (64, 32, [128, 64, 32], 100)])
+def test_ppo_rowstep_equals_forward_heads_backward(S, A, hidden, B):
+    """pa_ppo_rowstep (forward + both heads + both backward passes in ONE launch) against
+    forward_pair(keep) -> pa_ppo_heads -> backward_pair(defer): the gradients and therefore the
+    stepped parameters and optimizer state are bitwise the same, the reported losses equal to
+    rounding (their batch sums are grouped per 16-row tile)."""
+    import copy
+    from torch import nn, optim
+    from pearl_amd import _native as N
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    torch.manual_seed(21)
+    da = [S] + hidden + [A]
+    dc = [S] + hidden + [1]
+    x = torch.randn(B, S, device=DEV)
+    arep = torch.nn.functional.one_hot(torch.randint(0, A, (B,), device=DEV), A).float()
+    p_old = torch.rand(B, device=DEV) * 0.5 + 0.05
+    gae = torch.randn(B, device=DEV)
+    lam = torch.randn(B, device=DEV)
+    out = []
+    for form in ("fused", "three"):
+        torch.manual_seed(22)
+        an = [nn.Linear(da[i], da[i + 1]).to(DEV) for i in range(len(da) - 1)]
+        cn = [nn.Linear(dc[i], dc[i + 1]).to(DEV) for i in range(len(dc) - 1)]
+        ao = optim.AdamW([p for l in an for p in l.parameters()], lr=1e-3, amsgrad=True)
+        co = optim.AdamW([p for l in cn for p in l.parameters()], lr=1e-3, amsgrad=True)
+        actor = FlatMlp(layers_of(an), ao, max_batch=B).ensure(B)
+        critic = FlatMlp(layers_of(cn), co, max_batch=B).ensure(B)
+        assert FlatMlp.rowstep_supported(actor, critic, A)
+        reports = []
+        for step in range(3):
+            if form == "fused":
+                losses = FlatMlp.ppo_rowstep(actor, critic, x, arep, p_old, gae, 0.1, 0.01, lam, 2.0 / B)
+            else:
+                logits, v = FlatMlp.forward_pair(actor, critic, x, keep=True)
+                d_logits, dv = torch.empty_like(logits), torch.empty(B, device=DEV)
+                losses = torch.empty(2, device=DEV)
+                N.check(N.lib().pa_ppo_heads(
+                    logits.data_ptr(), logits.stride(0), arep.data_ptr(), arep.stride(0),
+                    p_old.data_ptr(), gae.data_ptr(), B, A, 0.1, 0.01, d_logits.data_ptr(),
+                    d_logits.stride(0), v.data_ptr(), v.stride(0), lam.data_ptr(), dv.data_ptr(),
+                    losses.data_ptr(), N.stream_ptr(x.device)))
+                FlatMlp.backward_pair(actor, critic, x, d_logits, dv, want_dw=True, defer=True)
+            FlatMlp.adam_pair(actor, critic, None)
+            reports.append(losses.clone())
+        torch.cuda.synchronize()
+        out.append(([p.detach().clone() for l in an + cn for p in l.parameters()],
+                    {k: v.clone() for m in (actor, critic) for k, v in m.flat.items()}, reports))
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+    for a, b in zip(out[0][2], out[1][2]):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dims,B", [([144, 256, 256, 1], 1024), ([9, 20, 1], 50)])
+def test_twin_mse_rowstep_equals_forward_heads_backward(dims, B):
+    """pa_mse_rowstep2 against forward_pair(keep) -> two pa_mse_head -> backward_pair(defer)."""
+    from torch import nn, optim
+    from pearl_amd import _native as N
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    x = torch.randn(B, dims[0], device=DEV)
+    y = torch.randn(B, device=DEV)
+    out = []
+    for form in ("fused", "three"):
+        torch.manual_seed(23)
+        nets = [[nn.Linear(dims[i], dims[i + 1]).to(DEV) for i in range(len(dims) - 1)] for _ in range(2)]
+        opt = optim.AdamW([p for n in nets for l in n for p in l.parameters()], lr=1e-3, amsgrad=True)
+        c1, c2 = [FlatMlp(layers_of(n), opt, max_batch=B).ensure(B) for n in nets]
+        assert FlatMlp.rowstep_supported(c1, c2)
+        reports = []
+        for step in range(3):
+            if form == "fused":
+                loss = FlatMlp.mse_rowstep_pair(c1, c2, x, y, 1.0 / B, 0.5)
+            else:
+                qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, x, keep=True)]
+                dqs = [torch.empty_like(q) for q in qs]
+                loss = torch.empty(1, device=DEV)
+                for i in range(2):
+                    N.check(N.lib().pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5,
+                                                int(i > 0), dqs[i].data_ptr(), loss.data_ptr(),
+                                                N.stream_ptr(x.device)))
+                FlatMlp.backward_pair(c1, c2, x, dqs[0], dqs[1], want_dw=True, defer=True)
+            FlatMlp.adam_pair(c1, c2, None)
+            reports.append(loss.clone())
+        torch.cuda.synchronize()
+        out.append(([p.detach().clone() for n in nets for l in n for p in l.parameters()], reports))
+    # The fused launch runs the generic row kernels' arithmetic.  Shapes the stand-alone forward
+    # gives to rows3_fwd_kernel (three layers, <= 1024 rows: another summation order of the same
+    # dot products) agree to rounding; every other shape bitwise.
+    rows3 = len(dims) == 4 and B <= 1024
+    for a, b in zip(out[0][0], out[1][0]):
+        if rows3:
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=2e-6)
+        else:
+            assert torch.equal(a, b)
+    for a, b in zip(out[0][1], out[1][1]):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-7)
+
+
 def test_linreg_solve_spd_fast_path_and_pivoting_fallback():
     """pa_linreg_solve: the pivot-free register-column kernel on an SPD system, and the pivoting
     kernel when a pivot is not positive (an indefinite matrix a negative weight could produce)."""
