@@ -599,6 +599,17 @@ int pa_ppo_rowstep(pa_mlp* actor, pa_mlp* critic, const float* x, int32_t ldx, i
 int pa_mse_rowstep2(pa_mlp* c1, pa_mlp* c2, const float* x, int32_t ldx, int32_t B,
                     const float* target, float grad_scale, float loss_scale, float* q1_out,
                     float* q2_out, float* d_q1, float* d_q2, float* loss_out, void* stream);
+/* Discrete SoftActorCritic (soft_actor_critic.py:180-287) on the same fused launch.
+ * pa_dsac_actor_rowstep: actor forward (kept) -> pa_dsac_actor_head's row math -> backward; the
+ * weight gradients stay pending for pa_mlp_adam.  pa_dsac_target_rowstep: actor forward on the next
+ * states -> pa_dsac_target's row math -> y; nothing kept.  pa_rowstep_supported(actor, NULL, A). */
+int pa_dsac_actor_rowstep(pa_mlp* actor, const float* x, int32_t ldx, int32_t B, const float* q1,
+                          const float* q2, const uint8_t* mask, const float* alpha, float* d_logits,
+                          int32_t ldd, float* h_out, float* loss_out, void* stream);
+int pa_dsac_target_rowstep(pa_mlp* actor, const float* next_state, int32_t ldx, int32_t B,
+                           const float* q1, const float* q2, const uint8_t* mask, const float* alpha,
+                           const float* reward, const uint8_t* term, float gamma, float* y,
+                           void* stream);
 /* nn.MSELoss head (critic_utils.py:139-203): d_pred = grad_scale * (pred - target);
  * loss_out (=|+=) mean((pred - target)^2) * loss_scale. */
 int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B, float grad_scale,

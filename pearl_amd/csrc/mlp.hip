@@ -921,8 +921,10 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
                "row step: network outside the row-pass kernels' shapes, or batch above max_batch");
     rc = ensure_packed(h, false, s);
     if (rc != PA_OK) return rc;
-    fill_fwd(h, false, outs[i], ldos[i], true, a.fwd[i]);
+    const bool fwd_only = heads[i].kind == RS_HEAD_DSAC_TARGET;
+    fill_fwd(h, false, outs[i], ldos[i], !fwd_only, a.fwd[i]);
     fill_bwd(h, nullptr, 0, nullptr, 0, a.bwd[i]);
+    if (fwd_only) a.bwd[i].L = 0;
     a.head[i] = heads[i];
     a.head[i].p_rows = sc.buf + 4 + 4 * gx + (size_t)i * B;
     d0max = h->d.dims[0] > d0max ? h->d.dims[0] : d0max;
@@ -943,6 +945,7 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
   for (int i = 0; i < nnet; ++i) {
     pa_mlp* h = hs[i];
+    if (heads[i].kind == RS_HEAD_DSAC_TARGET) continue;   // forward only: nothing kept, nothing pending
     const int L = h->L;
     const float* dzs[PA_MLP_MAX_LAYERS];
     int ldzs[PA_MLP_MAX_LAYERS];
@@ -961,6 +964,8 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
 // 1 when pa_ppo_rowstep / pa_mse_rowstep2 take these networks (shapes the row-pass kernels cover;
 // PEARL_AMD_ROWSTEP=0: never): callers fall back to forward2 -> heads -> backward2 otherwise.
 extern "C" int pa_rowstep_supported(const pa_mlp* h1, const pa_mlp* h2, int32_t ppo_actions) {
+  if (rowstep_enabled() && h1 && !h2 && ppo_actions > 0)   // one softmax actor (discrete SAC)
+    return h1->bound && h1->row_ok && h1->d.dims[h1->L] == ppo_actions && ppo_actions <= 32;
   if (!rowstep_enabled() || !h1 || !h2 || !h1->bound || !h2->bound) return 0;
   if (!h1->row_ok || !h2->row_ok || h1->L != h2->L || h1->d.dims[0] != h2->d.dims[0]) return 0;
   if (ppo_actions > 0 && (h1->d.dims[h1->L] != ppo_actions || ppo_actions > 32 ||
@@ -1002,6 +1007,53 @@ extern "C" int pa_ppo_rowstep(pa_mlp* actor, pa_mlp* critic, const float* x, int
   float* outs[2] = {logits_out, value_out};
   const int ldos[2] = {ldl, ldv};
   return run_rowstep(hs, 2, x, ldx, B, heads, outs, ldos, losses, 0,
+                     reinterpret_cast<hipStream_t>(stream));
+}
+
+// Discrete SoftActorCritic's actor step down to the pre-activation gradients
+// (soft_actor_critic.py:254-287): forward (kept) -> softmax policy loss against min(q1, q2) on every
+// action -> backward, one launch; what pa_mlp_forward(keep) -> pa_dsac_actor_head -> pa_mlp_backward
+// (want_dw = 2) compute.  The weight gradients stay pending for pa_mlp_adam.
+extern "C" int pa_dsac_actor_rowstep(pa_mlp* actor, const float* x, int32_t ldx, int32_t B,
+                                     const float* q1, const float* q2, const uint8_t* mask,
+                                     const float* alpha, float* d_logits, int32_t ldd, float* h_out,
+                                     float* loss_out, void* stream) {
+  PA_REQUIRE(actor && x && q1 && q2 && alpha && d_logits && h_out && loss_out && B > 0,
+             PA_ERR_INVALID, "pa_dsac_actor_rowstep: bad argument");
+  PA_REQUIRE(pa_rowstep_supported(actor, nullptr, actor->d.dims[actor->L]), PA_ERR_UNSUPPORTED,
+             "pa_dsac_actor_rowstep: needs an actor with <= 32 outputs, every layer <= 256 wide");
+  PA_HIP(hipSetDevice(actor->d.device));
+  pa_mlp* hs[1] = {actor};
+  RowHead head;
+  memset(&head, 0, sizeof(head));
+  head.kind = RS_HEAD_DSAC_ACTOR;
+  head.d_out = d_logits; head.ldd = ldd;
+  head.q1 = q1; head.q2 = q2; head.mask = mask; head.alpha = alpha; head.h_out = h_out;
+  float* outs[1] = {nullptr};
+  const int ldos[1] = {0};
+  return run_rowstep(hs, 1, x, ldx, B, &head, outs, ldos, loss_out, 1,
+                     reinterpret_cast<hipStream_t>(stream));
+}
+// The expected next-state value under the policy and the Bellman target
+// (soft_actor_critic.py:180-252): actor forward on the next states -> y, one launch, nothing kept.
+extern "C" int pa_dsac_target_rowstep(pa_mlp* actor, const float* next_state, int32_t ldx, int32_t B,
+                                      const float* q1, const float* q2, const uint8_t* mask,
+                                      const float* alpha, const float* reward, const uint8_t* term,
+                                      float gamma, float* y, void* stream) {
+  PA_REQUIRE(actor && next_state && q1 && q2 && alpha && reward && term && y && B > 0,
+             PA_ERR_INVALID, "pa_dsac_target_rowstep: bad argument");
+  PA_REQUIRE(pa_rowstep_supported(actor, nullptr, actor->d.dims[actor->L]), PA_ERR_UNSUPPORTED,
+             "pa_dsac_target_rowstep: needs an actor with <= 32 outputs, every layer <= 256 wide");
+  PA_HIP(hipSetDevice(actor->d.device));
+  pa_mlp* hs[1] = {actor};
+  RowHead head;
+  memset(&head, 0, sizeof(head));
+  head.kind = RS_HEAD_DSAC_TARGET;
+  head.q1 = q1; head.q2 = q2; head.mask = mask; head.alpha = alpha;
+  head.reward = reward; head.term = term; head.gamma = gamma; head.y = y;
+  float* outs[1] = {nullptr};
+  const int ldos[1] = {0};
+  return run_rowstep(hs, 1, next_state, ldx, B, &head, outs, ldos, nullptr, 1,
                      reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -16,7 +16,7 @@
 
 namespace pa {
 
-enum { RS_HEAD_MSE = 1, RS_HEAD_PPO = 2 };
+enum { RS_HEAD_MSE = 1, RS_HEAD_PPO = 2, RS_HEAD_DSAC_ACTOR = 3, RS_HEAD_DSAC_TARGET = 4 };
 
 struct RowHead {
   int kind;
@@ -31,6 +31,13 @@ struct RowHead {
   const float* gae;             // [B]
   float eps, ent_scale;
   float* p_rows;                // [B] scratch: chosen-action probability of every row
+  // RS_HEAD_DSAC_ACTOR / _TARGET (discrete SoftActorCritic._actor_loss / _get_next_state_expected_
+  // values + Bellman target, soft_actor_critic.py:180-287), d_L = A <= 32: dsac_elem_kernel's row math
+  const float* q1; const float* q2;      // [B * A], row b * A + j
+  const uint8_t* mask;                   // [B, A] 1 = unavailable, or null
+  const float* alpha;
+  float* h_out;                          // actor: [B] sum_j P_j log(P_j + 1e-8)
+  const float* reward; const uint8_t* term; float gamma; float* y;   // target (no backward)
 };
 
 struct RowStepArgs {
@@ -208,6 +215,67 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
         st_through(hd.p_rows + b, p);
       }
     }
+  } else if (hd.kind == RS_HEAD_DSAC_ACTOR || hd.kind == RS_HEAD_DSAC_TARGET) {
+    // one thread per (row, action) — dsac_elem_kernel with 16 rows per workgroup
+    const int A = DL;
+    float* vc = scr + 2 * 512;
+    hr = tid / A; hj = tid - hr * A;
+    const int b = m0 + hr;
+    hlive = hr < RP_ROWS && b < a.B;
+    const float alpha = hd.alpha[0];
+    const float inv_n = 1.0f / ((float)a.B * (float)A);
+    const int base = hr * A;
+    const float z = (hr < RP_ROWS) ? ot[hr * PH + hj] : 0.f;
+    float q = 0.f;
+    if (hlive && !(hd.mask && hd.mask[(int64_t)b * A + hj]))
+      q = fminf(hd.q1[(int64_t)b * A + hj], hd.q2[(int64_t)b * A + hj]);
+    if (hr < RP_ROWS) va[tid] = z;
+    __syncthreads();
+    float m = 0.f, s = 0.f;
+    if (hlive) {
+      m = va[base];
+      for (int k = 1; k < A; ++k) m = fmaxf(m, va[base + k]);
+    }
+    const float e = expf(z - m);
+    if (hr < RP_ROWS) vb[tid] = e;
+    __syncthreads();
+    if (hlive)
+      for (int k = 0; k < A; ++k) s += vb[base + k];
+    const float p = hlive ? e / s : 0.f;
+    if (hd.kind == RS_HEAD_DSAC_TARGET) {
+      if (hr < RP_ROWS) va[tid] = (q - alpha * logf(p + 1e-8f)) * p;
+      __syncthreads();
+      if (hlive && hj == 0) {
+        float v = 0.f;
+        for (int k = 0; k < A; ++k) v += va[base + k];
+        const float lv = 1.0f - (hd.term[b] ? 1.0f : 0.0f);
+        hd.y[b] = __fadd_rn(__fmul_rn(__fmul_rn(v, hd.gamma), lv), hd.reward[b]);
+      }
+      hlive = false;   // no gradient tile
+    } else {
+      const float lp = logf(p + 1e-8f);
+      const float f = alpha * lp - q;
+      const float g = (f + p * (alpha / (p + 1e-8f))) * inv_n;   // dL/dP_j
+      if (hr < RP_ROWS) {
+        va[tid] = p * f;
+        vc[tid] = g * p;
+      }
+      __syncthreads();            // (every thread is past its reads of vb: the barrier above the p line)
+      if (hr < RP_ROWS) vb[tid] = p * lp;
+      float dot = 0.f;
+      if (hlive)
+        for (int k = 0; k < A; ++k) dot += vc[base + k];
+      dval = p * (g - dot);
+      __syncthreads();
+      if (hlive && hj == 0) {
+        float h = 0.f;
+        for (int k = 0; k < A; ++k) {
+          part0 += va[base + k];
+          h += vb[base + k];
+        }
+        hd.h_out[b] = h;
+      }
+    }
   } else {   // RS_HEAD_MSE: one thread per row, output column 0
     hr = tid; hj = 0;
     const int b = m0 + hr;
@@ -314,14 +382,16 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       }
       const float ent = -block_sum_512(part_e, red);
       loss = s0 - h.ent_scale * ent;
+    } else if (h.kind == RS_HEAD_DSAC_ACTOR) {
+      loss = s0 * (1.0f / ((float)a.B * (float)a.fwd[k].dims[a.fwd[k].L]));
     } else {
       loss = (s0 / (float)a.B) * h.loss_scale;
     }
     both += loss;
-    if (tid == 0 && !a.sum_losses) a.losses[k] = loss;
+    if (tid == 0 && !a.sum_losses && a.losses) a.losses[k] = loss;
   }
   if (tid == 0) {
-    if (a.sum_losses) a.losses[0] = both;
+    if (a.sum_losses && a.losses) a.losses[0] = both;
     __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

@@ -189,11 +189,23 @@ class SoftActorCritic(ActorCriticBase):
         # min Q(s, a) for every available action; the reference lets this loss reach the critics'
         # parameters too, then discards those gradients (actor_critic_base.py:342-348)
         q1, q2 = self._twin_q_all(c1, c2, state, rep, use_target=False)
-        logits = actor.forward(state, keep=True)
-        d_logits = torch.empty_like(logits)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         h = torch.empty(B, dtype=torch.float32, device=dev)
         mask = self._mask_u8(batch.curr_unavailable_actions_mask, dev)
+        if N.lib().pa_rowstep_supported(actor.handle, None, A):
+            # forward, the policy loss's row math and the backward pass in one launch
+            d_logits = torch.empty(B, A, dtype=torch.float32, device=dev)
+            actor.ready(B)
+            N.check(N.lib().pa_dsac_actor_rowstep(
+                actor.handle, state.data_ptr(), state.stride(0), B, q1.data_ptr(), q2.data_ptr(),
+                N.ptr(mask), al["alpha"].data_ptr(), d_logits.data_ptr(), d_logits.stride(0),
+                h.data_ptr(), loss.data_ptr(), s))
+            actor._pending_x = (state, d_logits)
+            self._neg_entropy_rows = h
+            actor.adam()
+            return loss[0]
+        logits = actor.forward(state, keep=True)
+        d_logits = torch.empty_like(logits)
         N.check(N.lib().pa_dsac_actor_head(logits.data_ptr(), logits.stride(0), q1.data_ptr(),
                                            q2.data_ptr(), N.ptr(mask), al["alpha"].data_ptr(), B, A,
                                            d_logits.data_ptr(), d_logits.stride(0), loss.data_ptr(),
@@ -216,15 +228,22 @@ class SoftActorCritic(ActorCriticBase):
         assert batch.next_available_actions is not None, "SoftActorCritic needs next_available_actions"
         nrep = self._f32(batch.next_available_actions, dev)
         nq1, nq2 = self._twin_q_all(c1, c2, nstate, nrep, use_target=True)
-        nlogits = actor.forward(nstate)
         y = torch.empty(B, dtype=torch.float32, device=dev)
         reward = self._f32(batch.reward, dev).reshape(B)
         term = self._mask_u8(batch.terminated.reshape(B), dev)
         nmask = self._mask_u8(batch.next_unavailable_actions_mask, dev)
-        N.check(N.lib().pa_dsac_target(nlogits.data_ptr(), nlogits.stride(0), nq1.data_ptr(),
-                                       nq2.data_ptr(), N.ptr(nmask), al["alpha"].data_ptr(),
-                                       reward.data_ptr(), term.data_ptr(),
-                                       float(self._discount_factor), B, A, y.data_ptr(), s))
+        if N.lib().pa_rowstep_supported(actor.handle, None, A):
+            actor.ready(B)
+            N.check(N.lib().pa_dsac_target_rowstep(
+                actor.handle, nstate.data_ptr(), nstate.stride(0), B, nq1.data_ptr(), nq2.data_ptr(),
+                N.ptr(nmask), al["alpha"].data_ptr(), reward.data_ptr(), term.data_ptr(),
+                float(self._discount_factor), y.data_ptr(), s))
+        else:
+            nlogits = actor.forward(nstate)
+            N.check(N.lib().pa_dsac_target(nlogits.data_ptr(), nlogits.stride(0), nq1.data_ptr(),
+                                           nq2.data_ptr(), N.ptr(nmask), al["alpha"].data_ptr(),
+                                           reward.data_ptr(), term.data_ptr(),
+                                           float(self._discount_factor), B, A, y.data_ptr(), s))
         # ---- (mse(q1, y) + mse(q2, y)) / 2 on the taken action (critic_utils.py:170-203)
         act = self._f32(batch.action, dev).reshape(B, -1)
         AD = act.shape[1]

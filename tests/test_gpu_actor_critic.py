@@ -536,6 +536,69 @@ def test_twin_mse_rowstep_equals_forward_heads_backward(dims, B):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("dims,B,masked", [([20, 48, 6], 70, True), ([128, 256, 256, 16], 1024, False)])
+def test_dsac_rowsteps_equal_forward_head_backward(dims, B, masked):
+    """pa_dsac_actor_rowstep / pa_dsac_target_rowstep against forward -> pa_dsac_actor_head ->
+    backward and forward -> pa_dsac_target (bitwise where the stand-alone forward is the generic row
+    kernel; to rounding for the three-layer shape rows3_fwd_kernel takes)."""
+    from torch import nn, optim
+    from pearl_amd import _native as N
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    A = dims[-1]
+    torch.manual_seed(31)
+    x = torch.randn(B, dims[0], device=DEV)
+    q1, q2 = torch.randn(B * A, device=DEV), torch.randn(B * A, device=DEV)
+    mask = (torch.rand(B, A, device=DEV) < 0.2).to(torch.uint8) if masked else None
+    alpha = torch.tensor([0.2], device=DEV)
+    reward = torch.randn(B, device=DEV)
+    term = (torch.rand(B, device=DEV) < 0.1).to(torch.uint8)
+    s = N.stream_ptr(x.device)
+    out = []
+    for form in ("fused", "three"):
+        torch.manual_seed(32)
+        net = [nn.Linear(dims[i], dims[i + 1]).to(DEV) for i in range(len(dims) - 1)]
+        opt = optim.AdamW([p for l in net for p in l.parameters()], lr=1e-3, amsgrad=True)
+        m = FlatMlp(layers_of(net), opt, max_batch=B).ensure(B)
+        assert N.lib().pa_rowstep_supported(m.handle, None, A)
+        y = torch.empty(B, device=DEV)
+        loss, h = torch.empty(1, device=DEV), torch.empty(B, device=DEV)
+        d_logits = torch.empty(B, A, device=DEV)
+        if form == "fused":
+            N.check(N.lib().pa_dsac_target_rowstep(m.handle, x.data_ptr(), x.stride(0), B, q1.data_ptr(),
+                                                   q2.data_ptr(), N.ptr(mask), alpha.data_ptr(),
+                                                   reward.data_ptr(), term.data_ptr(), 0.99,
+                                                   y.data_ptr(), s))
+            N.check(N.lib().pa_dsac_actor_rowstep(m.handle, x.data_ptr(), x.stride(0), B, q1.data_ptr(),
+                                                  q2.data_ptr(), N.ptr(mask), alpha.data_ptr(),
+                                                  d_logits.data_ptr(), A, h.data_ptr(),
+                                                  loss.data_ptr(), s))
+            m._pending_x = (x, d_logits)
+        else:
+            logits = m.forward(x)
+            N.check(N.lib().pa_dsac_target(logits.data_ptr(), logits.stride(0), q1.data_ptr(),
+                                           q2.data_ptr(), N.ptr(mask), alpha.data_ptr(),
+                                           reward.data_ptr(), term.data_ptr(), 0.99, B, A,
+                                           y.data_ptr(), s))
+            logits = m.forward(x, keep=True)
+            N.check(N.lib().pa_dsac_actor_head(logits.data_ptr(), logits.stride(0), q1.data_ptr(),
+                                               q2.data_ptr(), N.ptr(mask), alpha.data_ptr(), B, A,
+                                               d_logits.data_ptr(), A, loss.data_ptr(), h.data_ptr(), s))
+            m.backward(x, d_logits, want_dw=True, defer=True)
+        m.adam()
+        torch.cuda.synchronize()
+        out.append(([p.detach().clone() for l in net for p in l.parameters()], y.clone(), h.clone(),
+                    d_logits.clone(), loss.clone()))
+    exact = len(dims) != 4
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b) if exact else torch.allclose(a, b, rtol=1e-4, atol=2e-6)
+    for i in (1, 2, 3):
+        if exact:
+            assert torch.equal(out[0][i], out[1][i]), i
+        else:
+            torch.testing.assert_close(out[0][i], out[1][i], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(out[0][4], out[1][4], rtol=2e-5, atol=1e-7)
+
+
 def test_linreg_solve_spd_fast_path_and_pivoting_fallback():
     """pa_linreg_solve: the pivot-free register-column kernel on an SPD system, and the pivoting
     kernel when a pivot is not positive (an indefinite matrix a negative weight could produce)."""
