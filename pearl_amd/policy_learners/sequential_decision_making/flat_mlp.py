@@ -374,7 +374,8 @@ class FlatMlp:
 
     @staticmethod
     def mse_rowstep_pair(c1: "FlatMlp", c2: "FlatMlp", x: torch.Tensor, target: torch.Tensor,
-                         grad_scale: float, loss_scale: float) -> torch.Tensor:
+                         grad_scale: float, loss_scale: float,
+                         loss_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """forward_pair(keep) -> two MSE heads -> backward_pair(defer) of twin critics as one
         launch; returns the (1,) loss ``loss_scale (mse_1 + mse_2)``."""
         B = int(x.shape[0])
@@ -382,7 +383,7 @@ class FlatMlp:
         c2.ready(B)
         dev = x.device
         dq = torch.empty(2, B, dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        loss = loss_out if loss_out is not None else torch.empty(1, dtype=torch.float32, device=dev)
         N.check(N.lib().pa_mse_rowstep2(c1.handle, c2.handle, x.data_ptr(), x.stride(0), B,
                                         target.data_ptr(), float(grad_scale), float(loss_scale), None,
                                         None, dq[0].data_ptr(), dq[1].data_ptr(), loss.data_ptr(),

@@ -175,11 +175,17 @@ class ImplicitQLearning(ActorCriticBase):
         N.check(lib.pa_sac_twin(1, vn.data_ptr(), vn.data_ptr(), zero[0].data_ptr(),
                                 zero[1].data_ptr(), reward.data_ptr(), term.data_ptr(),
                                 float(self._discount_factor), B, y.data_ptr(), None, None, s))
-        qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, keep=True)]
-        dqs = [torch.empty_like(q) for q in qs]
-        for i in range(2):
-            N.check(lib.pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
-                                    dqs[i].data_ptr(), losses[1:].data_ptr(), s))
+        # the critics' forward, MSE heads and backward: one launch when the pair qualifies
+        # (mlp_rowstep.hpp; nothing steps before the end of this method, so the order is free)
+        critics_fused = FlatMlp.rowstep_supported(c1, c2)
+        if critics_fused:
+            FlatMlp.mse_rowstep_pair(c1, c2, xq, y, 1.0 / B, 0.5, loss_out=losses[1:2])
+        else:
+            qs = [q.reshape(B) for q in FlatMlp.forward_pair(c1, c2, xq, keep=True)]
+            dqs = [torch.empty_like(q) for q in qs]
+            for i in range(2):
+                N.check(lib.pa_mse_head(qs[i].data_ptr(), 1, y.data_ptr(), B, 1.0 / B, 0.5, int(i > 0),
+                                        dqs[i].data_ptr(), losses[1:].data_ptr(), s))
         # ---- actor loss (:197-246)
         head = actor.forward(state, keep=True)
         d_head = torch.empty_like(head)
@@ -212,7 +218,8 @@ class ImplicitQLearning(ActorCriticBase):
         # ---- one backward, then the steps in the reference's order (:171-176), target update
         value.backward(state, dv, want_dw=True, defer=True)
         actor.backward(state, d_head, want_dw=True, defer=True)
-        FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
+        if not critics_fused:
+            FlatMlp.backward_pair(c1, c2, xq, dqs[0], dqs[1], want_dw=True, defer=True)
         value.adam()
         actor.adam()
         if not FlatMlp.adam_pair(c1, c2, self._critic_soft_update_tau):

@@ -7,6 +7,7 @@
 #   chain   phase stamps of the two chain kernels + kernel boundary vs grid barrier (r03_g_*)
 #   feeder  batched-observe tests and bench line (r03_h_*)
 #   dsac    discrete SAC: parity tests, bench line, kernel stats
+#   rowstep gpu suite + PPO / discrete SAC with and without the fused row step (r03_j_*)
 #   variants  target-kernel builds A/B: bf16x3 split (default) | fp32 MFMA | U formed in the tile
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd $R; mkdir -p gpurun_out
@@ -72,4 +73,16 @@ if [ "$MODE" == "variants" ]; then
     env $2 timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/bench_$1.log 2> gpurun_out/bench_$1.err
     echo "$1 rc=$?"; line gpurun_out/bench_$1.log
   done
+fi
+if [ "$MODE" == "rowstep" ]; then
+  timeout 1200 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log
+  for rs in 1 0; do
+    PEARL_AMD_ROWSTEP=$rs timeout 600 python bench_algos.py --only ppo,dsac --steps 300 --cpu-seconds 1 > gpurun_out/bench_rowstep$rs.jsonl 2>/dev/null
+    echo "ROWSTEP=$rs"; python -c "
+import json
+for l in open('gpurun_out/bench_rowstep$rs.jsonl'):
+    d=json.loads(l); print(' ', d['config'][:50], round(d['value']/1e6,2), 'M', round(d['ms_per_step']*1e3,1), 'us')"
+  done
+  stats ppo_rowstep python $R/bench_algos.py --steps 200 --only ppo --cpu-seconds 0.3
 fi
