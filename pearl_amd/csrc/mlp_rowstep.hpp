@@ -52,6 +52,10 @@ struct RowStepArgs {
   int sum_losses;
 };
 
+#ifndef RS_PD_VALUE
+#define RS_PD_VALUE 4
+#endif
+constexpr int RS_PD = RS_PD_VALUE;   // weight k-groups in flight per wave and tile
 constexpr int RS_SCR = 5 * 512;   // floats of head scratch behind the row-pass tiles
 inline size_t rowstep_smem_bytes(int d0) { return rowfwd_smem_bytes(d0) + sizeof(float) * RS_SCR; }
 
@@ -137,7 +141,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
     }
     __syncthreads();
-    rows16_gemm<4>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
+    rows16_gemm<RS_PD>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
     const bool last = l == n.L - 1;
     const bool relu = (n.relu >> l) & 1;
     float* nxt = hb[l & 1];
@@ -321,7 +325,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       f32x4v acc[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-      rows16_gemm<4>(acc, nb.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, lane);
+      rows16_gemm<RS_PD>(acc, nb.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int u = c0 * 16 + u0 + 16 * t;
