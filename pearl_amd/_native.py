@@ -356,6 +356,7 @@ SIGNATURES = {
     "pa_mlp_q_all": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,
                                C.c_int32, _P, _P]),
     "pa_rowstep_supported": (C.c_int, [_P, _P, C.c_int32]),
+    "pa_debug_rowstep_prof": (C.c_int, [_P]),
     "pa_ppo_rowstep": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_float,
                                  C.c_float, _P, C.c_float, _P, C.c_int32, _P, C.c_int32, _P,
                                  C.c_int32, _P, _P, _P]),

@@ -904,12 +904,24 @@ int rowstep_scratch(RowStepScratch& sc, size_t need) {
   return PA_OK;
 }
 // heads[i].d_out / target / ... filled by the caller; p_rows, partials and the ticket are set here
+long long* g_rowstep_prof = nullptr;   // pa_debug_rowstep_prof
 int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, RowHead* heads,
                 float* const* outs, const int* ldos, float* losses, int sum_losses, hipStream_t s) {
   static RowStepScratch sc;
   RowStepArgs a;
   memset(&a, 0, sizeof(a));
-  const unsigned gx = (unsigned)ceil_div(B, RP_ROWS);
+  // 32 rows per workgroup (one workgroup per CU, every weight fragment used for two row tiles)
+  // once the 16-row tiling would put more than one workgroup on a CU; the (row, action) heads need
+  // rows x actions <= 512 threads.  PEARL_AMD_ROWSTEP_RT=1|2 forces either.
+  static const int rt_env = []() {
+    const char* v = getenv("PEARL_AMD_ROWSTEP_RT");
+    return v && *v ? atoi(v) : 0;
+  }();
+  int RT = (ceil_div(B, RP_ROWS) * nnet > 256) ? 2 : 1;
+  if (rt_env == 1 || rt_env == 2) RT = rt_env;
+  for (int i = 0; i < nnet; ++i)
+    if (heads[i].kind != RS_HEAD_MSE && hs[i]->d.dims[hs[i]->L] * 2 * RP_ROWS > 512) RT = 1;
+  const unsigned gx = (unsigned)ceil_div(B, RP_ROWS * RT);
   int rc = rowstep_scratch(sc, (size_t)4 + 4 * gx + 2 * (size_t)B);
   if (rc != PA_OK) return rc;
   a.ticket = reinterpret_cast<unsigned*>(sc.buf);
@@ -932,14 +944,16 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   a.x = x; a.ldx = ldx; a.B = B;
   a.losses = losses;
   a.sum_losses = sum_losses;
-  static size_t configured = 0;
-  const size_t smem = rowstep_smem_bytes(d0max);
-  if (smem > configured) {
-    rc = set_max_smem(mlp_rowstep_kernel, smem);
+  a.prof = g_rowstep_prof;
+  static size_t configured[3] = {0, 0, 0};
+  const size_t smem = RT == 2 ? rowstep_smem_bytes_t<2>(d0max) : rowstep_smem_bytes_t<1>(d0max);
+  if (smem > configured[RT]) {
+    rc = RT == 2 ? set_max_smem(mlp_rowstep_kernel<2>, smem) : set_max_smem(mlp_rowstep_kernel<1>, smem);
     if (rc != PA_OK) return rc;
-    configured = smem;
+    configured[RT] = smem;
   }
-  hipLaunchKernelGGL(mlp_rowstep_kernel, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+  if (RT == 2) hipLaunchKernelGGL(mlp_rowstep_kernel<2>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+  else hipLaunchKernelGGL(mlp_rowstep_kernel<1>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
   PA_LAUNCH_CHECK();
   // the state a kept forward + a want_dw = 2 backward leave behind: the weight gradients (and
   // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
@@ -960,6 +974,13 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   return PA_OK;
 }
 }  // namespace
+
+// tuning aid (tools/prof_rowstep.py): in-kernel phase stamps of the next fused row-step launches,
+// [workgroup][8 waves][16] wall-clock ticks; NULL switches them off
+extern "C" int pa_debug_rowstep_prof(long long* stamps) {
+  g_rowstep_prof = stamps;
+  return PA_OK;
+}
 
 // 1 when pa_ppo_rowstep / pa_mse_rowstep2 take these networks (shapes the row-pass kernels cover;
 // PEARL_AMD_ROWSTEP=0: never): callers fall back to forward2 -> heads -> backward2 otherwise.

@@ -82,7 +82,8 @@ static __global__ __launch_bounds__(512) void mlp_rowfwd_kernel(RowFwdArgs a) {
       acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
     }
     __syncthreads();   // the input tile of this layer is complete (x staging / previous epilogue)
-    rows16_gemm<4>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
+    // (a wave whose unit tiles lie beyond the layer's width has nothing to add to its bias)
+    if (tile0 < nt) rows16_gemm<4>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
     const bool last = l == n.L - 1;
     const bool relu = (n.relu >> l) & 1;
     float* nxt = hb[l & 1];
@@ -159,7 +160,8 @@ static __global__ __launch_bounds__(512) void mlp_rowbwd_kernel(RowBwdArgs a) {
       f32x4v acc[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-      rows16_gemm<4>(acc, n.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, lane);
+      if (c0 + tile0 < nt)
+        rows16_gemm<4>(acc, n.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, lane);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int u = c0 * 16 + u0 + 16 * t;

@@ -50,14 +50,18 @@ struct RowStepArgs {
   unsigned* ticket;             // zero on entry, zero again on exit
   float* losses;                // [2]: one per network — or, sum_losses, losses[0] = both
   int sum_losses;
+  long long* prof;              // optional phase stamps [workgroup (x + y gridDim.x)][wave][16] (tools/prof_rowstep.py)
 };
 
 #ifndef RS_PD_VALUE
 #define RS_PD_VALUE 4
 #endif
 constexpr int RS_PD = RS_PD_VALUE;   // weight k-groups in flight per wave and tile
+#ifndef RS_PD2_VALUE
+#define RS_PD2_VALUE 4
+#endif
+constexpr int RS_PD2 = RS_PD2_VALUE;  // the same for the 32-row form (one workgroup per CU: registers to spare)
 constexpr int RS_SCR = 5 * 512;   // floats of head scratch behind the row-pass tiles
-inline size_t rowstep_smem_bytes(int d0) { return rowfwd_smem_bytes(d0) + sizeof(float) * RS_SCR; }
 
 __device__ __forceinline__ float block_sum_512(float v, float* red) {
   red[threadIdx.x] = v;
@@ -98,28 +102,90 @@ __device__ __forceinline__ float ld_through(const float* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// acc[t][rt] += sum_k Wf[tile0 + t][k] * act[row + 16 rt][k] for RT row tiles of 16 rows: every
+// weight fragment that comes through the CU's L1 feeds 4 RT MFMAs per unit tile instead of 4.
+// (PMC on the 16-row form at PPO's 4096 rows: 1.18 M one-KiB wave loads per launch = 35 us of the
+// CU's 64 B/clk L1 fill next to 33 us of MFMA, and the two do not overlap well — 69 us.)
+// The first PD k-groups of a wave's two unit tiles: issued BEFORE the barrier that completes the
+// layer's input tile (weights do not depend on it), so their latency runs under the wait.
+template <int PD>
+struct RowW {
+  float4 r0[PD], r1[PD];
+};
+template <int PD>
+__device__ __forceinline__ void rowsN_fill(RowW<PD>& R, const float* __restrict__ Wf, int nkg, int tile0,
+                                           int ntiles, int lane) {
+  const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
+  const int64_t base0 = ((int64_t)tile0 * nkg) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)nkg * 256;
+#pragma unroll
+  for (int p = 0; p < PD; ++p) {
+    R.r0[p] = ld4_or_zero(Wf, base0 + (int64_t)p * 256, ok0 && p < nkg);
+    R.r1[p] = ld4_or_zero(Wf, base1 + (int64_t)p * 256, ok1 && p < nkg);
+  }
+}
+template <int PD, int RT>
+__device__ __forceinline__ void rowsN_gemm(f32x4v (&acc)[2][RT], RowW<PD>& R, const float* __restrict__ Wf,
+                                           int nkg, int tile0, int ntiles, const float* act, int pitch,
+                                           int lane) {
+  const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
+  const int64_t base0 = ((int64_t)tile0 * nkg) * 256 + lane * 4;
+  const int64_t base1 = base0 + (int64_t)nkg * 256;
+  const int nkgp = (nkg + PD - 1) / PD * PD;
+  for (int g0 = 0; g0 < nkgp; g0 += PD) {
+#pragma unroll
+    for (int p = 0; p < PD; ++p) {
+      const int g = g0 + p;
+      const float4 w0 = R.r0[p], w1 = R.r1[p];
+      R.r0[p] = ld4_or_zero(Wf, base0 + (int64_t)(g + PD) * 256, ok0 && (g + PD) < nkg);
+      R.r1[p] = ld4_or_zero(Wf, base1 + (int64_t)(g + PD) * 256, ok1 && (g + PD) < nkg);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const float4 x4 = *reinterpret_cast<const float4*>(act + rt * 16 * pitch + g * 16);
+        acc[0][rt] = mfma16(w0.x, x4.x, acc[0][rt]);
+        acc[1][rt] = mfma16(w1.x, x4.x, acc[1][rt]);
+        acc[0][rt] = mfma16(w0.y, x4.y, acc[0][rt]);
+        acc[1][rt] = mfma16(w1.y, x4.y, acc[1][rt]);
+        acc[0][rt] = mfma16(w0.z, x4.z, acc[0][rt]);
+        acc[1][rt] = mfma16(w1.z, x4.z, acc[1][rt]);
+        acc[0][rt] = mfma16(w0.w, x4.w, acc[0][rt]);
+        acc[1][rt] = mfma16(w1.w, x4.w, acc[1][rt]);
+      }
+    }
+  }
+}
+
+template <int RT>
+inline size_t rowstep_smem_bytes_t(int d0) {
+  return sizeof(float) * ((size_t)RT * RP_ROWS * (rp_pad(d0) + 2 * row_hid_pitch()) + RS_SCR);
+}
+
+// RT row tiles of 16 rows per workgroup (1: up to three workgroups per CU; 2: 32 rows, one
+// workgroup per CU, half the weight traffic per row — for launches of more than 256 tiles)
+template <int RT>
 static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ROWS = RP_ROWS * RT;
   const int net = blockIdx.y;
   const RowNetFwd& n = a.fwd[net];
   const RowNetBwd& nb = a.bwd[net];
   const RowHead& hd = a.head[net];
   const int P0 = rp_pad(n.dims[0]), PH = row_hid_pitch();
   float* xs = smem;
-  float* hb[2] = {xs + RP_ROWS * P0, xs + RP_ROWS * P0 + RP_ROWS * PH};
-  float* scr = xs + RP_ROWS * P0 + 2 * RP_ROWS * PH;   // va | vb | vc | red[2], 512 floats each
+  float* hb[2] = {xs + ROWS * P0, xs + ROWS * P0 + ROWS * PH};
+  float* scr = xs + ROWS * P0 + 2 * ROWS * PH;   // va | vb | vc | red[2], 512 floats each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, qd = lane >> 4;
-  const int m0 = blockIdx.x * RP_ROWS;
-  const int row = m0 + r16;
-  const bool rok = row < a.B;
+  const int m0 = blockIdx.x * ROWS;
   const int u0 = wave * 32 + 4 * qd;
   const int tile0 = wave * 2;
+  const int pwg = blockIdx.x + blockIdx.y * gridDim.x;
+  PA_STAMP(a.prof, pwg, wave, 0);
   // ---------------------------------------------------------------- forward (mlp_rowfwd_kernel)
   {
     const bool vx = is_vec_ok(a.x, a.ldx) && ((n.dims[0] & 3) == 0);
     const int c4 = (P0 - 4) >> 2;
-    for (int e = tid; e < RP_ROWS * c4; e += 512) {
+    for (int e = tid; e < ROWS * c4; e += 512) {
       const int r = e / c4, c = (e - r * c4) * 4;
       const bool ok = (m0 + r) < a.B;
       float4 v;
@@ -133,39 +199,57 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   for (int l = 0; l < n.L; ++l) {
     const int K = n.dims[l], N = n.dims[l + 1];
     const int nt = (N + 15) >> 4;
-    f32x4v acc[2];
+    f32x4v acc[2][RT];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
       if (n.bias[l]) b = guarded_load4(n.bias[l], 0, true, u0 + 16 * t, N);
-      acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        acc[t][rt][0] = b.x; acc[t][rt][1] = b.y; acc[t][rt][2] = b.z; acc[t][rt][3] = b.w;
+      }
     }
+    // (waves whose unit tiles lie beyond the layer's width skip the loop: a 256 -> 16 head used to
+    //  cost every wave a full layer of MFMAs on zero weights — 8.6 us of PPO's 69 us launch)
+    constexpr int PDW = RT == 2 ? RS_PD2 : RS_PD;
+    RowW<PDW> R;
+    if (tile0 < nt) rowsN_fill<PDW>(R, n.Wf[l], wf16_nkg(K), tile0, nt, lane);
     __syncthreads();
-    rows16_gemm<RS_PD>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
+    PA_STAMP(a.prof, pwg, wave, 1 + 2 * l);   // layer l: operands staged
+    if (tile0 < nt)
+      rowsN_gemm<PDW, RT>(acc, R, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, pin, lane);
+    PA_STAMP(a.prof, pwg, wave, 2 + 2 * l);   // layer l: GEMM done
     const bool last = l == n.L - 1;
     const bool relu = (n.relu >> l) & 1;
     float* nxt = hb[l & 1];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int u = u0 + 16 * t;
-      float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-      if (relu) v = make_float4(relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z),
-                                relu_keep_nan(v.w));
-      // (the output tile stays in LDS as well: the head reads it from there)
-      if (u < PH - 4) *reinterpret_cast<float4*>(nxt + r16 * PH + u) = v;
-      if (!last) {
-        if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
-      } else if (rok && n.out) {
-        store4_guarded(n.out, (int64_t)row * n.ldo, u, N,
-                       is_vec_ok(n.out, n.ldo) && (N & 3) == 0, v);
+    for (int rt = 0; rt < RT; ++rt) {
+      const int lr = r16 + 16 * rt;
+      const int row = m0 + lr;
+      const bool rok = row < a.B;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int u = u0 + 16 * t;
+        float4 v = make_float4(acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]);
+        if (relu) v = make_float4(relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z),
+                                  relu_keep_nan(v.w));
+        // (the output tile stays in LDS as well: the head reads it from there)
+        if (u < PH - 4) *reinterpret_cast<float4*>(nxt + lr * PH + u) = v;
+        if (!last) {
+          if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
+        } else if (rok && n.out) {
+          store4_guarded(n.out, (int64_t)row * n.ldo, u, N,
+                         is_vec_ok(n.out, n.ldo) && (N & 3) == 0, v);
+        }
       }
     }
     in = nxt;
     pin = PH;
   }
   __syncthreads();
+  PA_STAMP(a.prof, pwg, wave, 9);             // forward done
   // ---------------------------------------------------------------- head: d_out tile into hb[0]
-  const float* ot = hb[(n.L - 1) & 1];   // [16][PH] network output of this tile
+  const float* ot = hb[(n.L - 1) & 1];   // [ROWS][PH] network output of this tile
   const int DL = n.dims[n.L];
   float* va = scr;
   float* vb = scr + 512;
@@ -174,18 +258,18 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   int hr = 0, hj = 0;
   bool hlive = false;
   if (hd.kind == RS_HEAD_PPO) {
-    // one thread per (row, action) — ppo_actor_elem_kernel with 16 rows per workgroup
+    // one thread per (row, action) — ppo_actor_elem_kernel with ROWS rows per workgroup
     const int A = DL;
     hr = tid / A; hj = tid - hr * A;
     const int b = m0 + hr;
-    hlive = hr < RP_ROWS && b < a.B;
+    hlive = hr < ROWS && b < a.B;
     const float lo = 1.0f - hd.eps, hi = 1.0f + hd.eps;
-    const float z = (hr < RP_ROWS) ? ot[hr * PH + hj] : 0.f;
+    const float z = (hr < ROWS) ? ot[hr * PH + hj] : 0.f;
     const float ar = hlive ? hd.arep[(int64_t)b * hd.lda + hj] : 0.f;
     const float g = hlive ? hd.gae[b] : 0.f;
     const float pold = hlive ? hd.p_old[b] : 1.f;
     const int base = hr * A;
-    if (hr < RP_ROWS) va[tid] = z;
+    if (hr < ROWS) va[tid] = z;
     __syncthreads();
     float m = 0.f, s = 0.f, p = 0.f;
     if (hlive) {
@@ -193,12 +277,12 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       for (int k = 1; k < A; ++k) m = fmaxf(m, va[base + k]);
     }
     const float e = expf(z - m);
-    if (hr < RP_ROWS) vb[tid] = e;
+    if (hr < ROWS) vb[tid] = e;
     __syncthreads();
     if (hlive)
       for (int k = 0; k < A; ++k) s += vb[base + k];
     const float y = hlive ? e / s : 0.f;
-    if (hr < RP_ROWS) va[tid] = y * ar;
+    if (hr < ROWS) va[tid] = y * ar;
     __syncthreads();
     if (hlive) {
       for (int k = 0; k < A; ++k) p += va[base + k];
@@ -220,20 +304,20 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       }
     }
   } else if (hd.kind == RS_HEAD_DSAC_ACTOR || hd.kind == RS_HEAD_DSAC_TARGET) {
-    // one thread per (row, action) — dsac_elem_kernel with 16 rows per workgroup
+    // one thread per (row, action) — dsac_elem_kernel with ROWS rows per workgroup
     const int A = DL;
     float* vc = scr + 2 * 512;
     hr = tid / A; hj = tid - hr * A;
     const int b = m0 + hr;
-    hlive = hr < RP_ROWS && b < a.B;
+    hlive = hr < ROWS && b < a.B;
     const float alpha = hd.alpha[0];
     const float inv_n = 1.0f / ((float)a.B * (float)A);
     const int base = hr * A;
-    const float z = (hr < RP_ROWS) ? ot[hr * PH + hj] : 0.f;
+    const float z = (hr < ROWS) ? ot[hr * PH + hj] : 0.f;
     float q = 0.f;
     if (hlive && !(hd.mask && hd.mask[(int64_t)b * A + hj]))
       q = fminf(hd.q1[(int64_t)b * A + hj], hd.q2[(int64_t)b * A + hj]);
-    if (hr < RP_ROWS) va[tid] = z;
+    if (hr < ROWS) va[tid] = z;
     __syncthreads();
     float m = 0.f, s = 0.f;
     if (hlive) {
@@ -241,13 +325,13 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       for (int k = 1; k < A; ++k) m = fmaxf(m, va[base + k]);
     }
     const float e = expf(z - m);
-    if (hr < RP_ROWS) vb[tid] = e;
+    if (hr < ROWS) vb[tid] = e;
     __syncthreads();
     if (hlive)
       for (int k = 0; k < A; ++k) s += vb[base + k];
     const float p = hlive ? e / s : 0.f;
     if (hd.kind == RS_HEAD_DSAC_TARGET) {
-      if (hr < RP_ROWS) va[tid] = (q - alpha * logf(p + 1e-8f)) * p;
+      if (hr < ROWS) va[tid] = (q - alpha * logf(p + 1e-8f)) * p;
       __syncthreads();
       if (hlive && hj == 0) {
         float v = 0.f;
@@ -260,12 +344,12 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       const float lp = logf(p + 1e-8f);
       const float f = alpha * lp - q;
       const float g = (f + p * (alpha / (p + 1e-8f))) * inv_n;   // dL/dP_j
-      if (hr < RP_ROWS) {
+      if (hr < ROWS) {
         va[tid] = p * f;
         vc[tid] = g * p;
       }
       __syncthreads();            // (every thread is past its reads of vb: the barrier above the p line)
-      if (hr < RP_ROWS) vb[tid] = p * lp;
+      if (hr < ROWS) vb[tid] = p * lp;
       float dot = 0.f;
       if (hlive)
         for (int k = 0; k < A; ++k) dot += vc[base + k];
@@ -283,7 +367,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   } else {   // RS_HEAD_MSE: one thread per row, output column 0
     hr = tid; hj = 0;
     const int b = m0 + hr;
-    hlive = hr < RP_ROWS && b < a.B;
+    hlive = hr < ROWS && b < a.B;
     if (hlive) {
       const float d = __fsub_rn(ot[hr * PH], hd.target[b]);
       dval = __fmul_rn(hd.grad_scale, d);
@@ -293,7 +377,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   __syncthreads();   // every read of the output tile is done: hb[0] may be overwritten
   {
     const int c4 = (rp_pad(DL) - 4) >> 2;
-    for (int e = tid; e < RP_ROWS * c4; e += 512) {
+    for (int e = tid; e < ROWS * c4; e += 512) {
       const int r = e / c4, c = (e - r * c4) * 4;
       *reinterpret_cast<float4*>(hb[0] + r * PH + c) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -311,6 +395,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       st_through(pp + 1, s01.y);
     }
   }
+  PA_STAMP(a.prof, pwg, wave, 10);            // head done
   // ---------------------------------------------------------------- backward (mlp_rowbwd_kernel)
   in = hb[0];
   int cur = 0;
@@ -320,34 +405,63 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     const int nt = (N + 15) >> 4;
     const bool mask = l > 0 && ((nb.relu >> (l - 1)) & 1);
     float* nxt = hb[cur ^ 1];
+    constexpr int PDW = RT == 2 ? RS_PD2 : RS_PD;
+    RowW<PDW> R;
+    if (tile0 < nt) rowsN_fill<PDW>(R, nb.Wtf[l], wf16_nkg(K), tile0, nt, lane);
+    // the ReLU masks of the first chunk (this lane's own stores of the forward pass): requested
+    // before the GEMM instead of after it
+    float4 hmq[RT][2];
+    if (mask) {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int row = m0 + r16 + 16 * rt;
+          hmq[rt][t] = guarded_load4(nb.act[l - 1], (int64_t)row * N, row < a.B, u0 + 16 * t, N);
+        }
+    }
     __syncthreads();
     for (int c0 = 0; c0 < nt; c0 += 16) {
-      f32x4v acc[2];
+      f32x4v acc[2][RT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
-      rows16_gemm<RS_PD>(acc, nb.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, lane);
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int u = c0 * 16 + u0 + 16 * t;
-        float4 v = make_float4(acc[t][0], acc[t][1], acc[t][2], acc[t][3]);
-        if (l > 0) {
-          if (mask) {
-            const float4 hm = guarded_load4(nb.act[l - 1], (int64_t)row * N, rok, u, N);
-            v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
-            v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+        for (int rt = 0; rt < RT; ++rt)
+          acc[t][rt][0] = acc[t][rt][1] = acc[t][rt][2] = acc[t][rt][3] = 0.f;
+      if (c0 > 0 && c0 + tile0 < nt) rowsN_fill<PDW>(R, nb.Wtf[l], wf16_nkg(K), c0 + tile0, nt, lane);
+      if (c0 + tile0 < nt)
+        rowsN_gemm<PDW, RT>(acc, R, nb.Wtf[l], wf16_nkg(K), c0 + tile0, nt, in + r16 * PH + 4 * qd, PH,
+                            lane);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int lr = r16 + 16 * rt;
+        const int row = m0 + lr;
+        const bool rok = row < a.B;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int u = c0 * 16 + u0 + 16 * t;
+          float4 v = make_float4(acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]);
+          if (l > 0) {
+            if (mask) {
+              const float4 hm = c0 == 0 ? hmq[rt][t]
+                                        : guarded_load4(nb.act[l - 1], (int64_t)row * N, rok, u, N);
+              v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
+              v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+            }
+            if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < PH - 4) *reinterpret_cast<float4*>(nxt + lr * PH + u) = v;
+            if (rok) store4_guarded(nb.dz[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
+          } else if (rok) {
+            store4_guarded(nb.d_x, (int64_t)row * nb.lddx, u, N,
+                           is_vec_ok(nb.d_x, nb.lddx) && (N & 3) == 0, v);
           }
-          if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (u < PH - 4) *reinterpret_cast<float4*>(nxt + r16 * PH + u) = v;
-          if (rok) store4_guarded(nb.dz[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
-        } else if (rok) {
-          store4_guarded(nb.d_x, (int64_t)row * nb.lddx, u, N,
-                         is_vec_ok(nb.d_x, nb.lddx) && (N & 3) == 0, v);
         }
       }
     }
     in = nxt;
     cur ^= 1;
   }
+  PA_STAMP(a.prof, pwg, wave, 11);            // backward done
   // ---------------------------------------------------------------- losses: last workgroup
   __shared__ unsigned is_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores have landed
@@ -358,6 +472,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
                total - 1u) ? 1u : 0u;
   }
   __syncthreads();
+  PA_STAMP(a.prof, pwg, wave, 12);            // ticket taken
   if (!is_last) return;
   float both = 0.f;
   for (int k = 0; k < (int)gridDim.y; ++k) {
