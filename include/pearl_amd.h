@@ -612,6 +612,12 @@ int pa_dsac_target_rowstep(pa_mlp* actor, const float* next_state, int32_t ldx, 
                            const float* q1, const float* q2, const uint8_t* mask, const float* alpha,
                            const float* reward, const uint8_t* term, float gamma, float* y,
                            void* stream);
+/* The neural-linear bandit's network step with unit weights (neural_linear_bandit.py:176-199) on the
+ * same launch: d_pred = 2 (pred - y) / B, loss_out[0] = mean (pred - y)^2; the kept activations
+ * serve pa_mlp_copy_activation as after pa_mlp_forward(keep); pred_out [B] may be NULL.
+ * pa_rowstep_supported(net, NULL, 0). */
+int pa_wmse_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
+                    float* pred_out, float* d_pred, float* loss_out, void* stream);
 /* nn.MSELoss head (critic_utils.py:139-203): d_pred = grad_scale * (pred - target);
  * loss_out (=|+=) mean((pred - target)^2) * loss_scale. */
 int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B, float grad_scale,

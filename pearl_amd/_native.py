@@ -364,6 +364,7 @@ SIGNATURES = {
                                         _P, _P, _P]),
     "pa_dsac_target_rowstep": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
                                          C.c_float, _P, _P]),
+    "pa_wmse_rowstep": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "pa_mse_rowstep2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_float, C.c_float, _P, _P,
                                   _P, _P, _P, _P]),
     "pa_mlp_q_all2": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,

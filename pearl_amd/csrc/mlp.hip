@@ -920,7 +920,9 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   int RT = (ceil_div(B, RP_ROWS) * nnet > 256) ? 2 : 1;
   if (rt_env == 1 || rt_env == 2) RT = rt_env;
   for (int i = 0; i < nnet; ++i)
-    if (heads[i].kind != RS_HEAD_MSE && hs[i]->d.dims[hs[i]->L] * 2 * RP_ROWS > 512) RT = 1;
+    if (heads[i].kind != RS_HEAD_MSE && heads[i].kind != RS_HEAD_WMSE1 &&
+        hs[i]->d.dims[hs[i]->L] * 2 * RP_ROWS > 512)
+      RT = 1;
   const unsigned gx = (unsigned)ceil_div(B, RP_ROWS * RT);
   int rc = rowstep_scratch(sc, (size_t)4 + 4 * gx + 2 * (size_t)B);
   if (rc != PA_OK) return rc;
@@ -987,6 +989,8 @@ extern "C" int pa_debug_rowstep_prof(long long* stamps) {
 extern "C" int pa_rowstep_supported(const pa_mlp* h1, const pa_mlp* h2, int32_t ppo_actions) {
   if (rowstep_enabled() && h1 && !h2 && ppo_actions > 0)   // one softmax actor (discrete SAC)
     return h1->bound && h1->row_ok && h1->d.dims[h1->L] == ppo_actions && ppo_actions <= 32;
+  if (rowstep_enabled() && h1 && !h2 && ppo_actions == 0)  // one single-output network (bandit)
+    return h1->bound && h1->row_ok && h1->d.dims[h1->L] == 1;
   if (!rowstep_enabled() || !h1 || !h2 || !h1->bound || !h2->bound) return 0;
   if (!h1->row_ok || !h2->row_ok || h1->L != h2->L || h1->d.dims[0] != h2->d.dims[0]) return 0;
   if (ppo_actions > 0 && (h1->d.dims[h1->L] != ppo_actions || ppo_actions > 32 ||
@@ -1075,6 +1079,29 @@ extern "C" int pa_dsac_target_rowstep(pa_mlp* actor, const float* next_state, in
   float* outs[1] = {nullptr};
   const int ldos[1] = {0};
   return run_rowstep(hs, 1, next_state, ldx, B, &head, outs, ldos, nullptr, 1,
+                     reinterpret_cast<hipStream_t>(stream));
+}
+
+// The neural-linear bandit's network step with unit weights (neural_linear_bandit.py:176-199):
+// forward (kept: pa_mlp_copy_activation still serves the features) -> d_pred = 2 (pred - y) / B ->
+// backward, one launch; loss_out[0] = mean (pred - y)^2.  What pa_mlp_forward(keep) ->
+// pa_weighted_mse_head(w = NULL) -> pa_mlp_backward(want_dw = 2) compute.
+extern "C" int pa_wmse_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
+                               float* pred_out, float* d_pred, float* loss_out, void* stream) {
+  PA_REQUIRE(net && x && y && d_pred && loss_out && B > 0, PA_ERR_INVALID,
+             "pa_wmse_rowstep: bad argument");
+  PA_REQUIRE(pa_rowstep_supported(net, nullptr, 0), PA_ERR_UNSUPPORTED,
+             "pa_wmse_rowstep: needs a one-output network, every layer <= 256 wide");
+  PA_HIP(hipSetDevice(net->d.device));
+  pa_mlp* hs[1] = {net};
+  RowHead head;
+  memset(&head, 0, sizeof(head));
+  head.kind = RS_HEAD_WMSE1;
+  head.d_out = d_pred; head.ldd = 1;
+  head.target = y;
+  float* outs[1] = {pred_out};       // [B] predictions (may be null)
+  const int ldos[1] = {1};
+  return run_rowstep(hs, 1, x, ldx, B, &head, outs, ldos, loss_out, 1,
                      reinterpret_cast<hipStream_t>(stream));
 }
 

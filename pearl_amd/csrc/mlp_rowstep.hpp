@@ -16,7 +16,8 @@
 
 namespace pa {
 
-enum { RS_HEAD_MSE = 1, RS_HEAD_PPO = 2, RS_HEAD_DSAC_ACTOR = 3, RS_HEAD_DSAC_TARGET = 4 };
+enum { RS_HEAD_MSE = 1, RS_HEAD_PPO = 2, RS_HEAD_DSAC_ACTOR = 3, RS_HEAD_DSAC_TARGET = 4,
+       RS_HEAD_WMSE1 = 5 };   // wmse_kernel with unit weights (neural_linear_bandit.py:176-199)
 
 struct RowHead {
   int kind;
@@ -368,7 +369,12 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     hr = tid; hj = 0;
     const int b = m0 + hr;
     hlive = hr < ROWS && b < a.B;
-    if (hlive) {
+    if (hlive && hd.kind == RS_HEAD_WMSE1) {
+      // wmse_kernel's expressions with w = 1 and sum w = B
+      const float d = ot[hr * PH] - hd.target[b];
+      dval = (2.0f * d * 1.0f) / (float)a.B;
+      part0 = (d * d) * 1.0f;
+    } else if (hlive) {
       const float d = __fsub_rn(ot[hr * PH], hd.target[b]);
       dval = __fmul_rn(hd.grad_scale, d);
       part0 = d * d;
@@ -503,6 +509,8 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       loss = s0 - h.ent_scale * ent;
     } else if (h.kind == RS_HEAD_DSAC_ACTOR) {
       loss = s0 * (1.0f / ((float)a.B * (float)a.fwd[k].dims[a.fwd[k].L]));
+    } else if (h.kind == RS_HEAD_WMSE1) {
+      loss = s0 / (float)a.B;
     } else {
       loss = (s0 / (float)a.B) * h.loss_scale;
     }

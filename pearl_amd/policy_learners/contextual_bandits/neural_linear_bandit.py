@@ -155,19 +155,29 @@ class NeuralLinearBandit(PolicyLearner):
         B = x.shape[0]
         y = batch.reward.to(dev, torch.float32).reshape(B).contiguous()
         w = None if batch.weight is None else batch.weight.to(dev, torch.float32).reshape(B).contiguous()
-        pred = net.forward(x, keep=True)                       # (B, 1); features stay in the engine
-        # features of this forward (before the optimizer step) feed the regression: copy them out
         lr = self.model._linear_regression_layer
         d = lr._feature_dim
         D = d + 1
         feats = torch.empty(B, d, dtype=torch.float32, device=dev)
-        N.check(lib.pa_mlp_copy_activation(net.handle, len(net.layers) - 2, B, feats.data_ptr(),
-                                           feats.stride(0), s))
         dpred = torch.empty(B, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         wsum = torch.empty(1, dtype=torch.float32, device=dev)
-        N.check(lib.pa_weighted_mse_head(pred.data_ptr(), pred.stride(0), y.data_ptr(), N.ptr(w), B,
-                                         dpred.data_ptr(), loss.data_ptr(), wsum.data_ptr(), s))
+        fused = w is None and bool(lib.pa_rowstep_supported(net.handle, None, 0))
+        if fused:
+            # unit weights: forward (kept), the loss gradient and the backward pass in one launch
+            # (mlp_rowstep.hpp); the weight gradients stay pending for net.adam()
+            net.ready(B)
+            pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
+            N.check(lib.pa_wmse_rowstep(net.handle, x.data_ptr(), x.stride(0), B, y.data_ptr(),
+                                        pred.data_ptr(), dpred.data_ptr(), loss.data_ptr(), s))
+            net._pending_x = (x, dpred)
+        else:
+            pred = net.forward(x, keep=True)                   # (B, 1); features stay in the engine
+            N.check(lib.pa_weighted_mse_head(pred.data_ptr(), pred.stride(0), y.data_ptr(), N.ptr(w), B,
+                                             dpred.data_ptr(), loss.data_ptr(), wsum.data_ptr(), s))
+        # features of this forward (before the optimizer step) feed the regression: copy them out
+        N.check(lib.pa_mlp_copy_activation(net.handle, len(net.layers) - 2, B, feats.data_ptr(),
+                                           feats.stride(0), s))
         # all-zero weights: skip the optimizer (:171-175).  Data parallel: the decision is taken on
         # the GLOBAL weight sum, so every rank enters (or skips) the gradient all-reduce of
         # net.adam() together — a rank-local decision left the other ranks hanging in it.
@@ -179,7 +189,8 @@ class NeuralLinearBandit(PolicyLearner):
                 dist.all_reduce(ws)
             skip = float(ws.item()) == 0.0
         if not skip:
-            net.backward(x, dpred, want_dw=True, defer=True)
+            if not fused:
+                net.backward(x, dpred, want_dw=True, defer=True)
             net.adam()
         # ---- LinUCB update on the detached features
         xs = torch.empty(B * D + D, dtype=torch.float32, device=dev)
