@@ -552,6 +552,7 @@ int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena, const pa_ac_l
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
 /* the same for the fused row step (mlp_rowstep.hpp): [workgroup][8][16] ticks of the next launches */
 int pa_debug_rowstep_prof(long long* stamps);
+int pa_debug_mlp_dw_prof(long long* stamps);   /* weight_grad_kernel launches of the MLP engine */
 /* HIP-event timing of the two fused row launches (first 64 steps after enabling): bench lines */
 int pa_sac_timing(int32_t enable);
 int pa_sac_timing_read(double* rows_a_us, double* rows_b_us, int64_t* steps);

@@ -357,6 +357,7 @@ SIGNATURES = {
                                C.c_int32, _P, _P]),
     "pa_rowstep_supported": (C.c_int, [_P, _P, C.c_int32]),
     "pa_debug_rowstep_prof": (C.c_int, [_P]),
+    "pa_debug_mlp_dw_prof": (C.c_int, [_P]),
     "pa_ppo_rowstep": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_float,
                                  C.c_float, _P, C.c_float, _P, C.c_int32, _P, C.c_int32, _P,
                                  C.c_int32, _P, _P, _P]),

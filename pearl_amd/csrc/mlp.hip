@@ -410,6 +410,7 @@ namespace {
 // read (the DQN treatment: no AdamW launch, no repack launch); soft_tau >= 0 on top of that: the
 // target parameters (and their packed copies, when current) take their soft update in the same
 // epilogue (update_target_network, common/utils.py:214-226).
+long long* g_mlp_dw_prof = nullptr;   // pa_debug_mlp_dw_prof
 struct DwOperands {
   const float* x; int ldx;
   const float* const* dzs; const int* ldzs;
@@ -435,6 +436,10 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
       for (int ni = 0; ni < nnet; ++ni)
         for (int l = l0; l < L && l < l0 + 3; ++l)
           tiles32 += (int)(ceil_div(hs[ni]->d.dims[l + 1], 32) * ceil_div(hs[ni]->d.dims[l], DW_TN));
+      // (big batches stay on 64-row tiles: at PPO's 4096 rows the 32-row tiling is 272 workgroups,
+      //  every one of them MFMA-bound — a 16-row output layer's padded tile as much as a full one —
+      //  and the 16 CUs that get two finish at 45 us against 27 for the rest: no gain over 144
+      //  64-row tiles at 43 us; stamps in tools/prof_rowstep.py)
       if (dw_tm_env == 32 || (dw_tm_env == 0 && B < 2048 && tiles32 + 1 <= 232)) TM = 32;
     }
     a.tm = TM;
@@ -469,6 +474,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
     }
     a.total_tiles = t0;
     a.B = B;
+    a.prof = g_mlp_dw_prof;
     if (adam_step > 0) {
       a.ad.enabled = 1;
       a.ad.guard = h0->adam_guard ? h0->adam_guard : (nnet > 1 ? hs[1]->adam_guard : nullptr);
@@ -977,6 +983,11 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
 }
 }  // namespace
 
+// the same for the engine's weight-gradient launches (weight_grad_kernel's stamps, [workgroup][8][16])
+extern "C" int pa_debug_mlp_dw_prof(long long* stamps) {
+  g_mlp_dw_prof = stamps;
+  return PA_OK;
+}
 // tuning aid (tools/prof_rowstep.py): in-kernel phase stamps of the next fused row-step launches,
 // [workgroup][8 waves][16] wall-clock ticks; NULL switches them off
 extern "C" int pa_debug_rowstep_prof(long long* stamps) {

@@ -41,12 +41,15 @@ def main():
         step()
     torch.cuda.synchronize()
     stamps = torch.zeros(int(os.environ.get("PROF_WGS", "1024")), 8, 16, dtype=torch.int64, device=dev)
+    dw = torch.zeros(1024, 8, 16, dtype=torch.int64, device=dev)
     if not os.environ.get("PROF_OFF"):
         N.check(N.lib().pa_debug_rowstep_prof(stamps.data_ptr()))
+        N.check(N.lib().pa_debug_mlp_dw_prof(dw.data_ptr()))
     print("warm-up done", flush=True)
     step()
     torch.cuda.synchronize()
     N.check(N.lib().pa_debug_rowstep_prof(None))
+    N.check(N.lib().pa_debug_mlp_dw_prof(None))
     st = stamps.cpu().numpy().astype(np.int64)
     print("highest workgroup slot written:", int(np.nonzero((st != 0).any(axis=(1, 2)))[0].max()))
     live = st[:, :, 0] > 0
@@ -59,6 +62,29 @@ def main():
         v = v[(st[:, :, i] > 0) & live]
         if v.size:
             print(f"{name:16s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+    show_dw(dw)
+
+
+def show_dw(dw):
+    names = ["start", "setup", "main loop", "partials out", "stage-1 sum", "bar", "end"]
+    st = dw.cpu().numpy().astype(np.int64)
+    live = st[:, :, 0] > 0
+    if not live.any():
+        return
+    t0 = st[:, :, 0][live].min()
+    print(f"== weight_grad_kernel of the same step: {int(live.any(axis=1).sum())} workgroups; us since its first wave")
+    print(f"{'phase':16s} {'min':>8s} {'median':>8s} {'max':>8s}")
+    for i, name in enumerate(names):
+        v = (st[:, :, i] - t0) / 100.0
+        v = v[(st[:, :, i] > 0) & live]
+        if v.size:
+            print(f"{name:16s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+    # which workgroups are the late ones, and when did they START (a late start = it waited for a CU)
+    end = (st[:, :, 6].max(axis=1) - t0) / 100.0
+    start = (np.where(st[:, :, 0] > 0, st[:, :, 0], 1 << 62).min(axis=1) - t0) / 100.0
+    late = [i for i in range(st.shape[0]) if live[i].any() and end[i] > np.median(end[live.any(axis=1)]) * 1.3]
+    print("late workgroups (index: start -> end us):",
+          ", ".join(f"{i}: {start[i]:.1f} -> {end[i]:.1f}" for i in late[:40]))
 
 
 if __name__ == "__main__":
