@@ -97,6 +97,8 @@ struct pa_dqn {
   // whose every round refreshed them in its optimizer epilogue; cleared by anything else that
   // writes parameters (bind, step, apply, update_target, pa_dqn_invalidate)
   bool packed_ok;
+  bool online_tgt_ok;   // Double DQN: w2f_online / w2sp_online hold the current online W2 (kept by the
+                        // optimizer epilogue of the previous round of this call / step)
   int* err_dev;      // device error word (a bounded wait expired)
   int* err_host;     // pinned, device-mapped twin: a kernel that sets err_dev sets it too (no copy)
   int overlap;       // 0: single-stream learn loop (PEARL_AMD_OVERLAP=0 or timing level >= 2)
@@ -478,7 +480,7 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
              "double-Q pass: learner was not created with double_q, or batch above max_batch");
   h->y_clean = false;
   int rc;
-  {
+  if (!h->online_tgt_ok) {
     RepackArgs a;
     memset(&a, 0, sizeof(a));
     a.q = h->bufs.q; a.q_target = h->bufs.q;     // "target" slot <- the ONLINE W2
@@ -702,6 +704,13 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
     a.ad.tW2f = h->w2f; a.ad.nkg_t = t_nkg(d.hidden1);
     a.ad.tW2sp = h->w2sp;
     a.ad.tW1sp = h->w1sp; a.ad.sp_S = d.state_dim;
+    static const bool keep_online = env_int("PEARL_AMD_DDQN_KEEP_ONLINE", 1) != 0;
+    if (d.double_q == 1 && h->w2f_online && keep_online) {
+      // the argmax pass of the next round reads these: no repack launch in front of it
+      a.ad.oW2f = h->w2f_online;
+      a.ad.oW2sp = h->use_split ? h->w2sp_online : nullptr;
+      h->online_tgt_ok = true;
+    }
   }
   return launch_weight_grad(a, loss_out != nullptr, s);
 }
@@ -712,6 +721,7 @@ int run_adamw(pa_dqn* h, int64_t step, int soft_next, hipStream_t s) {
   const pa_dqn_desc& d = h->d;
   PA_REQUIRE(step >= 1, PA_ERR_INVALID, "adam step must be >= 1 (got %lld)", (long long)step);
   ScopedTimer tm(h, "adamw", s);
+  h->online_tgt_ok = false;   // (this kernel does not keep Double DQN's online copies: repack next round)
   AdamDqnArgs a;
   memset(&a, 0, sizeof(a));
   a.f.enabled = 1;
@@ -1054,6 +1064,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->err_dev = nullptr;
   h->err_host = nullptr;
   h->packed_ok = false;
+  h->online_tgt_ok = false;
   h->overlap = env_int("PEARL_AMD_OVERLAP", 1);
   // 12 = "1 round, then 2 rounds, then the rest": measured best with the bf16x3 target kernel
   // (20-round call 23.2 M transitions/s against 22.0 M with one leading piece of 3 rounds)
@@ -1190,6 +1201,7 @@ extern "C" int pa_dqn_bind(pa_dqn* h, const pa_dqn_buffers* bufs) {
   h->bufs = *bufs;
   h->bound = true;
   h->packed_ok = false;
+  h->online_tgt_ok = false;
   return PA_OK;
 }
 
@@ -1198,6 +1210,7 @@ extern "C" int pa_dqn_bind(pa_dqn* h, const pa_dqn_buffers* bufs) {
 extern "C" int pa_dqn_invalidate(pa_dqn* h) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   h->packed_ok = false;
+  h->online_tgt_ok = false;
   return PA_OK;
 }
 
@@ -1227,6 +1240,7 @@ extern "C" int pa_dqn_update_target(pa_dqn* h, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
   h->packed_ok = false;
+  h->online_tgt_ok = false;
   return run_soft_update(h, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1236,6 +1250,7 @@ extern "C" int pa_dqn_step(pa_dqn* h, const pa_dqn_batch* batch, int32_t do_targ
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
   PA_HIP(hipSetDevice(h->d.device));
   h->packed_ok = false;
+  h->online_tgt_ok = false;
   return step_impl(h, batch, do_target_update, adam_step, grad_world, mean_abs_td_out,
                    reinterpret_cast<hipStream_t>(stream));
 }
@@ -1244,6 +1259,7 @@ extern "C" int pa_dqn_apply(pa_dqn* h, int64_t adam_step, void* stream) {
   PA_REQUIRE(h && h->bound, PA_ERR_INVALID, "learner has no bound parameter buffers");
   PA_HIP(hipSetDevice(h->d.device));
   h->packed_ok = false;
+  h->online_tgt_ok = false;
   return run_adamw(h, adam_step, 0, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -1357,7 +1373,8 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
                        dim3(SAMPLE_THREADS), smem, s, sa, R, rpk, h->tile_ctr, kTileCtrs + 4);
     PA_LAUNCH_CHECK();
   }
-  h->packed_ok = false;   // until this call has completed its last round
+  h->packed_ok = false;
+  h->online_tgt_ok = false;   // until this call has completed its last round
   if (overlap) {
     // Tagged hand-off invariant: every word of both y buffers is kYPendingBits whenever no target
     // pass is in flight.  The consumer (online_rowpass_kernel) restores the tag after reading, so

@@ -924,6 +924,8 @@ struct AdamFuse {
   float* tW2f; int nkg_t;            // target W2, 32x32x2 fragment-major
   void* tW2sp;                       // target W2 as bf16 split planes (null: not kept)
   void* tW1sp; int sp_S;             // target W1[:, :sp_S] as split planes (null: not kept)
+  float* oW2f; void* oW2sp;          // Double DQN: the ONLINE W2 in the target tile's layouts (w2f_index,
+                                     // split planes) for the argmax pass; null: not kept
   const float* absd; int nabs; float inv_B; float* loss_out;  // mean |Q - target| of this step
   // overlapped learn loop: the Bellman targets of this round have been consumed by the row pass
   // (the previous launch on this stream); the loss workgroup hands the words back to the producer
@@ -999,6 +1001,10 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
   if (kind == 0) {         // W2[n = row][k = col]
     f.W2f[wf16_index_(row, col, f.nkg_w2)] = p;
     f.W2tf[wf16_index_(col, row, f.nkg_w2t)] = p;
+    if (f.oW2f) {
+      f.oW2f[w2f_index(row, col, f.nkg_t)] = p;
+      if (f.oW2sp) store_w2sp1(f.oW2sp, row, col, p);
+    }
   } else if (kind == 1) {  // W1[n = row][k = col]
     f.W1f[wf16_index_(row, col, f.nkg_w1)] = p;
   }
@@ -1453,6 +1459,10 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
           *reinterpret_cast<float4*>(a.ad.W2f + wf16_index_(erow, ecol, a.ad.nkg_w2)) = pn;
 #pragma unroll
           for (int e = 0; e < 4; ++e) a.ad.W2tf[wf16_index_(ecol + e, erow, a.ad.nkg_w2t)] = pv[e];
+          if (a.ad.oW2f) {   // Double DQN's argmax pass reads the online W2 through the target tile
+            *reinterpret_cast<float4*>(a.ad.oW2f + w2f_index(erow, ecol, a.ad.nkg_t)) = pn;
+            if (a.ad.oW2sp) store_w2sp4(a.ad.oW2sp, erow, ecol, pn);
+          }
         } else if (P.kind == 1) {
           *reinterpret_cast<float4*>(a.ad.W1f + wf16_index_(erow, ecol, a.ad.nkg_w1)) = pn;
         } else if (P.kind == 3) {
