@@ -117,9 +117,11 @@ class VectorEnvFeeder:
         self.agent.policy_learner.reset(self._spaces[0])
 
     # ------------------------------------------------------------------ helpers
-    def _static_space(self) -> Optional[Any]:
+    def _static_space(self) -> Tuple[bool, Any]:
+        """(every environment shows the same action-space object, that object) — the object may be
+        None (continuous control without an explicit space)."""
         s0 = self._spaces[0]
-        return s0 if all(s is s0 for s in self._spaces) else None
+        return all(s is s0 for s in self._spaces), s0
 
     def _states_tensor(self) -> Tensor:
         dev = self.agent.device
@@ -187,8 +189,8 @@ class VectorEnvFeeder:
     def _step_list(self, exploit: bool) -> List[ActionResult]:
         pl, rb = self.agent.policy_learner, self.agent.replay_buffer
         E = self.num_envs
-        static = self._static_space()
-        if static is not None:
+        is_static, static = self._static_space()
+        if is_static:
             actions = act_many(pl, self._states_tensor(), static, exploit)
         else:
             dev = self.agent.device
@@ -201,7 +203,7 @@ class VectorEnvFeeder:
             results.append(r)
             next_spaces.append(self._spaces[e] if r.available_action_space is None
                                else r.available_action_space)
-        batchable = static is not None and all(s is static for s in next_spaces)
+        batchable = is_static and all(s is static for s in next_spaces)
         if batchable:
             from .replay_buffers.basic_replay_buffer import _torch_dtype_of_value
             a0 = torch.as_tensor(actions[0])

@@ -175,6 +175,68 @@ def test_dynamic_action_spaces_fall_back_to_per_row_push():
     same_rows(ref.rows, rec.rows)
 
 
+class _ContinuousLearner(torch.nn.Module):
+    """The attributes the agent / feeder read from a policy learner, with a deterministic
+    continuous policy: a = tanh(mean(state)) in every dimension."""
+
+    def __init__(self, dim=2):
+        super().__init__()
+        self._is_action_continuous = True
+        self.on_policy = False
+        self.dim = dim
+        self.action_representation_module = None
+        self.resets = 0
+
+    def reset(self, action_space):
+        self.resets += 1
+
+    def act(self, state, action_space, exploit=False):
+        return torch.tanh(torch.as_tensor(state).float().mean()).repeat(self.dim)
+
+
+class _BoxEnv:
+    def __init__(self, eid):
+        self.eid, self.t = eid, 0
+
+    def reset(self, seed=None):
+        self.t = 0
+        return torch.full((S,), float(self.eid)), None
+
+    def step(self, action):
+        self.t += 1
+        return ActionResult(observation=torch.full((S,), float(self.eid) + 0.1 * self.t),
+                            reward=float(action.sum()), terminated=False, truncated=self.t % 2 == 0)
+
+
+def test_continuous_actions_go_through_act_row_by_row_and_one_push_many():
+    """A learner without act_many (continuous control): E act() calls, still ONE push_many per
+    vector step with no action tables (pearl_agent.py:196-201: max_number_actions is None)."""
+    pl = _ContinuousLearner()
+
+    class Rec(Recorder):
+        def push_many(self, state, action, reward, terminated, truncated, next_state=None,
+                      curr_available_actions=None, next_available_actions=None,
+                      max_number_actions=None, cost=None):
+            self.calls.append("push_many")
+            assert max_number_actions is None and curr_available_actions is None
+            assert action.shape == (3, 2) and action.dtype == torch.float32
+            self.rows.extend((state[e].clone(), action[e].clone(), float(reward[e]), bool(truncated[e]))
+                             for e in range(3))
+
+    rec = Rec()
+    rec._is_action_continuous = True
+    feeder = VectorEnvFeeder(PearlAgent(pl, replay_buffer=rec), [_BoxEnv(e) for e in range(3)],
+                             pin_memory=False)
+    feeder.reset()
+    feeder.run(4)
+    assert rec.calls == ["push_many"] * 4 and pl.resets == 1
+    # row order = environment order; environment 2's action is tanh(2) / tanh(2.1) / reset -> tanh(2)
+    a = [rec.rows[i][1][0].item() for i in (2, 5, 8, 11)]
+    want = [torch.tanh(torch.tensor(2.0)).item(), torch.tanh(torch.tensor(2.0) + 0.1).item()]
+    assert a == pytest.approx(want + want)
+    assert sum(r[3] for r in rec.rows) == 6 and feeder.episodes == 6
+
+
 class DeviceSim(BatchedEnvironment):
     """E environments as tensors on one device: x' = roll(x) + 0.1 onehot(action); reward = x'[a];
     every `horizon`-th step terminates all rows and restarts them from fresh states."""
