@@ -128,15 +128,53 @@ def pmc_traffic(transitions_per_launch, split_on):
     """HBM bytes of one target-kernel launch from committed rocprofv3 PMC passes (separate --pmc runs
     of the single-stream loop; tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950, + WRITE_SIZE, per transition).  Counters cannot be collected inside this
-    run, so the line names the file the figure comes from; None when no pass exists for the kernel
-    that ran."""
-    name = "r03_pmc_target.json" if split_on else "r02_pmc_target.json"
-    path = os.path.join(REPO, "profiles", name)
+    run, so the line names the file the figure comes from and the kernel that pass measured; None
+    when no pass exists for the kernel that ran."""
+    names = ["r04_pmc_target.json", "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"]
+    for name in names:
+        path = os.path.join(REPO, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                d = json.load(f)
+            kernel = d.get("kernel", "target_split_kernel" if split_on else "target_fused_kernel<32>")
+            return (d["hbm_bytes_per_transition"] * transitions_per_launch, f"profiles/{name}",
+                    kernel + " (single-stream loop, separate rocprofv3 --pmc passes)")
+    return None, None, None
+
+
+def parity_probe(dev):
+    """Observed error of the HIP path against the reference ITSELF on BASELINE config 2's own batch
+    (tests/golden/dqn_cfg2_fullbatch.pt: outputs of the real reference, minted by
+    oracle/make_golden.py): Q(s, a), max_a' Q_target(s', a') and the Bellman target of 1024
+    transitions.  north_star's bar is 1e-5 relative; fresh networks have |Q| ~ 0.1 with values
+    crossing zero, where an elementwise relative error has no meaning (a dot product's rounding is
+    relative to sum |terms|), so `max_rel` is taken over the elements with |ref| >= 1 % of max |ref|
+    and `max_abs_over_scale` = max |diff| / max |ref| over all of them."""
+    from pearl_amd import (DeepQLearning, OneHotActionTensorRepresentationModule, TransitionBatch)
+    path = os.path.join(REPO, "tests", "golden", "dqn_cfg2_fullbatch.pt")
     if not os.path.exists(path):
-        return None, None
-    with open(path) as f:
-        d = json.load(f)
-    return d["hbm_bytes_per_transition"] * transitions_per_launch, f"profiles/{name}"
+        return None
+    fx = torch.load(path, map_location="cpu", weights_only=False)
+    cfg, want = fx["config"], fx["learners"]["dqn"]
+    pl = DeepQLearning(state_dim=cfg["S"], action_space=space(cfg["A"]), hidden_dims=cfg["hidden"],
+                       training_rounds=1, batch_size=cfg["B"],
+                       action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+    pl._Q.load_state_dict(fx["params0"])
+    pl._Q_target.load_state_dict(fx["target0"])
+    pl = pl.to(dev)
+    batch = pl.preprocess_batch(TransitionBatch(
+        **{k: (None if v is None else v.to(dev)) for k, v in fx["batch_raw"].items()}))
+    out = pl.q_values_and_targets(batch)
+    res = {"fixture": "tests/golden/dqn_cfg2_fullbatch.pt (outputs of the reference, B=1024)",
+           "rel_floor": "|ref| >= 0.01 max|ref|"}
+    for k, name in (("q", "q"), ("next_v", "next_v"), ("target", "target")):
+        got, ref = out[k].double().cpu(), want[k].double()
+        d = (got - ref).abs()
+        big = ref.abs() >= 0.01 * ref.abs().max()
+        res[f"max_rel_{name}"] = float((d[big] / ref.abs()[big]).max())
+        res[f"max_abs_over_scale_{name}"] = float(d.max() / ref.abs().max())
+    res["max_rel_q_values"] = max(res["max_rel_q"], res["max_rel_next_v"])
+    return res
 
 
 def main():
@@ -145,6 +183,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the SAC / PPO / bandit block (BASELINE configs[2..4]) after the timed region")
     ap.add_argument("--timing-level", type=int, default=1)
     args = ap.parse_args()
 
@@ -303,7 +343,7 @@ def main():
             split_on = os.environ.get("PEARL_AMD_TARGET_SPLIT", "1") != "0"
             tt = timers["target"] if live else isolated
             ach, per_launch = kernel_rate(tt)
-            traffic, traffic_src = pmc_traffic(per_launch, split_on)
+            traffic, traffic_src, traffic_kernel = pmc_traffic(per_launch, split_on)
             step_rate = FLOP_PER_TRANSITION_STEP * B * args.steps / dt     # per GPU
             line["roofline"] = {"bound": "mfma",
                                 "kernel": (("target_split_kernel (bf16x3 split MFMA, fp32 accuracy)"
@@ -315,6 +355,7 @@ def main():
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA,
                                 "traffic": traffic, "traffic_source": traffic_src,
+                                "traffic_kernel": traffic_kernel,
                                 "avg_launch_us": tt["avg_us"],
                                 "transitions_per_launch": per_launch,
                                 "launches_timed": tt["n"],
@@ -328,6 +369,11 @@ def main():
                 exe = 6.0 * 2 * A * 256 * 256 + 2 * A * 256 * A + 2 * A * 256
                 line["roofline"]["precision"] = (
                     "fp32 results; layer 2 on v_mfma_f32_32x32x16_bf16 with bf16x3 operand splits")
+                # the primary figure against the pipe the kernel runs on: fp32-accurate products cost
+                # six bf16 MFMA products each, so the ceiling for ALGORITHMIC fp32 FLOPs on the bf16
+                # pipe is 2.5 PF / 6 = 416.7 TF (`frac` above can exceed 1 against the fp32 peak)
+                line["roofline"]["peak_pipe"] = PEAK_BF16_MFMA / 6 / 1e12
+                line["roofline"]["frac_pipe"] = ach / (PEAK_BF16_MFMA / 6)
                 line["roofline"]["executed"] = {
                     "flop_per_transition": exe, "achieved": ach / 1e12 * exe / FLOP_TARGET_KERNEL_PER_TRANSITION,
                     "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
@@ -340,6 +386,7 @@ def main():
                     + os.environ.get("PEARL_AMD_RESERVED_CUS", "128" if split_on else "64") + " of 256)")
                 line["roofline"]["isolated"] = {
                     "achieved": iach / 1e12, "frac": iach / PEAK_F32_MFMA,
+                    "frac_pipe": iach / (PEAK_BF16_MFMA / 6) if split_on else iach / PEAK_F32_MFMA,
                     "avg_launch_us": isolated["avg_us"], "transitions_per_launch": iper,
                     "launches_timed": isolated["n"],
                     "note": "same kernel, single-stream loop, chip to itself (calibration pass before the timed region)"}
@@ -380,6 +427,17 @@ def main():
             line["comm"] = info
         if steady is not None:
             line["steady_state"] = steady
+        if world == 1 and args.timing_level <= 1:
+            try:
+                line["parity"] = parity_probe(dev)
+            except Exception as e:
+                line["parity"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        if world == 1 and not args.no_other_configs and args.timing_level <= 1:
+            # BASELINE.json configs[2..4] in the same record (not `value`): bench_algos.driver_block
+            import bench_algos
+            bench_algos.DEV = dev
+            line["other_configs"] = bench_algos.driver_block(
+                cpu_seconds=0.0 if args.no_cpu_baseline else 4.0)
         if world == 1 and not args.no_cpu_baseline:
             # the real reference when it is staged (oracle/_ref), the reference-pinned port otherwise
             base = reference_cpu_baseline()

@@ -39,6 +39,7 @@ def dspace(n):
 
 
 PEAK_F32_MFMA = 157.3e12   # dense fp32 MFMA, MI355X_MICROARCH.md
+PEAK_SPLIT_MFMA = 2500e12 / 6   # fp32 results on the bf16 pipe: six bf16 products per fp32 product
 
 
 def mlp_macs(dims):
@@ -54,6 +55,50 @@ def step_roofline(flop_per_transition, transitions, seconds, kernel=None):
            "scope": "whole learner step (wall time of learn())"}
     if kernel:
         out["kernel"] = kernel
+    return out
+
+
+def engine_kernel_times(run_steps):
+    """HIP-event durations of the MLP engine's two launches of a step — the fused row step
+    (forward + loss head + backward, mlp_rowstep.hpp) and the weight gradients + AdamW
+    (weight_grad_kernel) — over a few steps run for that purpose (pa_mlp_timing: an event record
+    costs ~6 us of GPU idle, so these steps are not the ones `value` is taken from)."""
+    import ctypes as C
+    from pearl_amd import _native as N_
+    N_.check(N_.lib().pa_mlp_timing(1))
+    run_steps()
+    sync()
+    out = {}
+    for which, name in ((0, "rowstep"), (1, "weight_grad")):
+        us, n = C.c_double(), C.c_int64()
+        N_.check(N_.lib().pa_mlp_timing_read(which, C.byref(us), C.byref(n)))
+        if n.value:
+            out[name] = {"avg_us": us.value, "launches": n.value}
+    N_.check(N_.lib().pa_mlp_timing(0))
+    return out
+
+
+def engine_kernels(times, dims_list, rows, split_rowstep=False, split_dw=False):
+    """Per-kernel roofline entries of an MLP-engine step from engine_kernel_times(): algorithmic
+    FLOPs (2 per multiply-add; row step = forward of every layer + dX of layers >= 1, weight
+    gradients = dW of every layer) of `rows` rows through the networks `dims_list`, over the
+    launch duration, against the fp32-MFMA peak (`frac`, the contract figure) and against the rate
+    of the pipe the kernel runs on (`frac_pipe`: the same peak for fp32 MFMA, 2.5 PF / 6 for the
+    bf16x3 split form)."""
+    f_row = 2 * sum(mlp_macs(d) + sum(a * b for a, b in zip(d[1:-1], d[2:])) for d in dims_list)
+    f_dw = 2 * sum(mlp_macs(d) for d in dims_list)
+    out = []
+    for name, f, split, label in (("rowstep", f_row, split_rowstep, "mlp_rowstep_kernel (forward + head + backward)"),
+                                  ("weight_grad", f_dw, split_dw, "weight_grad_kernel (dW + AdamW)")):
+        if name not in times:
+            continue
+        rate = f * rows / (times[name]["avg_us"] * 1e-6)
+        pipe = PEAK_SPLIT_MFMA if split else PEAK_F32_MFMA
+        out.append({"kernel": label, "avg_launch_us": times[name]["avg_us"],
+                    "launches_timed": times[name]["launches"], "flop_per_launch": f * rows,
+                    "achieved": rate / 1e12, "unit": "TFLOP/s", "frac": rate / PEAK_F32_MFMA,
+                    "frac_pipe": rate / pipe,
+                    "pipe": "bf16x3 split MFMA (2.5 PF / 6)" if split else "fp32 MFMA"})
     return out
 
 
@@ -306,6 +351,15 @@ def bench_ppo(steps, cpu_seconds):
     else:
         dt, _ = timed(lambda: pl.learn(rb), warm=1)
     gpu = B * steps * world / dt
+    kernels = []
+    if world == 1:
+        keep = pl._training_rounds
+        pl._training_rounds = 16
+        kernels = engine_kernels(engine_kernel_times(lambda: pl.learn(rb)),
+                                 ([S, 256, 256, A], [S, 256, 256, 1]), B,
+                                 split_rowstep=os.environ.get("PEARL_AMD_ROWSTEP_SPLIT", "1") != "0"
+                                 and bool(getattr(pl, "_rowstep_split_active", False)))
+        pl._training_rounds = keep
     comm = _comm.comm_info() if dist.is_initialized() else None
     if comm is not None:
         comm["allreduce_floats_per_step"] = int(sum(m.flat["grad"].numel() for m in pl._flat.values()))
@@ -338,6 +392,7 @@ def bench_ppo(steps, cpu_seconds):
                 B * steps, dt,      # per GPU
                 kernel="mlp_rowfwd_kernel 43 us + weight_grad_kernel 43 us + mlp_rowbwd_kernel 25 us per "
                        "step (per-kernel durations: profiles/r02_ppo_kernel_stats.txt)"),
+            "kernels": kernels,
             "preprocess_replay_buffer": {"transitions_per_s": N / dt_pre, "ms": 1e3 * dt_pre,
                                          "what": "action probs + values of 65536 states, GAE / lambda-return scan"},
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
@@ -365,6 +420,8 @@ def bench_bandit(steps, cpu_seconds):
 
     dt, _ = timed(run)
     gpu = B * steps / dt
+    kernels = engine_kernels(engine_kernel_times(lambda: [pl.learn_batch(tb) for _ in range(16)]),
+                             ([F, 256, 64, 1],), B)
     orc = NeuralLinearOracle(sd0, lr=1e-3)
     xc, yc = x.cpu(), y.cpu()
     n, t0 = 0, time.perf_counter()
@@ -382,6 +439,7 @@ def bench_bandit(steps, cpu_seconds):
                 2 * (2 * mlp_macs([F, 256, 64]) + 256 * 64 + 3 * 65 + 65 * 65), B * steps, dt,
                 kernel="linreg_solve_spd_kernel (97 us, fp64, one workgroup) + mlp row passes + "
                        "weight_grad_kernel"), note="bound by the serial fp64 solve, not by MFMA"),
+            "kernels": kernels,
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls"}}
 
@@ -572,6 +630,68 @@ def bench_feeder(steps, cpu_seconds):
                                   "exploration draws per vector step; the arena write itself is one scatter launch"},
             "cpu_baseline": {"value": single, "kind": "port", "cores": 1,
                              "sample": f"{n1} act + observe calls of one pearl_amd agent (the reference's loop shape)"}}
+
+
+def reference_baselines(configs, seconds, threads=32):
+    """cpu_baseline.kind == "reference" for configs 3 / 4 / 5: the reference's own learners timed by
+    oracle/ref_cpu_baseline.py in ONE child process that sees no GPU; {} when the reference is not
+    staged (oracle/_ref) or the child fails."""
+    import subprocess
+    script = os.path.join(REPO, "oracle", "ref_cpu_baseline.py")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, script, "--config", ",".join(configs), "--seconds",
+                              str(seconds), "--threads", str(min(threads, os.cpu_count() or 1))],
+                             env=env, capture_output=True, text=True, timeout=300)
+        rows = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+        return {r["config"]: r for r in rows if "value" in r}
+    except Exception:
+        return {}
+
+
+def driver_block(cpu_seconds=4.0):
+    """bench.py's `other_configs`: BASELINE.json configs[2..4] (SAC / PPO / bandit on one MI355X)
+    measured in the driver's own bench run — value through learn(), whole-step roofline fraction,
+    the dominant kernel timed live with HIP events, and the REFERENCE's CPU path on the same host
+    (VERDICT r3 N3).  Bounded: a few hundred steps per config, one child process for the three
+    reference legs."""
+    rows = []
+    for name, fn, steps in (("sac", bench_sac, 300), ("ppo", bench_ppo, 100), ("bandit", bench_bandit, 100)):
+        try:
+            r = fn(steps, 0.0)
+        except Exception as e:      # a failure here must not take the headline line with it
+            rows.append({"config": name, "error": f"{type(e).__name__}: {e}"[:300]})
+            continue
+        roof = r["roofline"]
+        step = roof.get("step", roof)
+        row = {"config": name, "workload": r["config"], "metric": r["metric"], "value": r["value"],
+               "unit": "contexts/s" if name == "bandit" else "transitions/s",
+               "steps": steps, "ms_per_step": r["ms_per_step"], "step_frac": step["frac"],
+               "flop_per_transition": step["flop_per_transition"]}
+        ks = r.get("kernels") or []
+        if name == "sac" and "avg_launch_us" in roof:
+            ks = [{"kernel": roof["kernel"], "avg_launch_us": roof["avg_launch_us"],
+                   "launches_timed": roof["launches_timed"], "achieved": roof["achieved"],
+                   "unit": "TFLOP/s", "frac": roof["frac"], "frac_pipe": roof["frac"], "pipe": "fp32 MFMA"}]
+        if ks:
+            dom = max(ks, key=lambda k: k["avg_launch_us"])
+            row.update({"kernel": dom["kernel"], "kernel_us": dom["avg_launch_us"],
+                        "kernel_frac": dom["frac"], "kernel_frac_pipe": dom["frac_pipe"],
+                        "kernel_pipe": dom["pipe"], "kernels": ks})
+        if "preprocess_replay_buffer" in r:
+            row["preprocess_replay_buffer"] = r["preprocess_replay_buffer"]
+        rows.append(row)
+    ref = reference_baselines([r["config"] for r in rows], cpu_seconds) if cpu_seconds > 0 else {}
+    for r in rows:
+        base = ref.get(r["config"])
+        if base is not None:
+            base.pop("config", None)
+            r["cpu_baseline"] = base
+            if "value" in r:
+                r["vs_cpu_reference"] = r["value"] / base["value"]
+    return rows
 
 
 def main():

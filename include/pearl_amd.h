@@ -556,6 +556,10 @@ int pa_debug_mlp_dw_prof(long long* stamps);   /* weight_grad_kernel launches of
 /* HIP-event timing of the two fused row launches (first 64 steps after enabling): bench lines */
 int pa_sac_timing(int32_t enable);
 int pa_sac_timing_read(double* rows_a_us, double* rows_b_us, int64_t* steps);
+/* the same for the MLP engine (PPO, bandit, twin-critic steps): the first 64 fused row-step launches
+ * (which = 0) and weight-gradient (+ AdamW) launches (which = 1) after enabling */
+int pa_mlp_timing(int32_t enable);
+int pa_mlp_timing_read(int32_t which, double* avg_us, int64_t* launches);
 
 /* VanillaActorNetwork.get_action_prob (actor_networks.py:155-176): softmax(logits) . action_rep.
  * probs_out [B, A] may be NULL. */
@@ -619,6 +623,17 @@ int pa_dsac_target_rowstep(pa_mlp* actor, const float* next_state, int32_t ldx, 
  * pa_rowstep_supported(net, NULL, 0). */
 int pa_wmse_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
                     float* pred_out, float* d_pred, float* loss_out, void* stream);
+/* The same launch for every criterion / output activation NeuralLinearBandit accepts
+ * (loss_type, output_activation_name: neural_linear_bandit.py:68-72, :176-199;
+ * neural_networks/common/utils.py:60-72 LossType): pred = act(z), d_pred = d mean(criterion) / d z.
+ * pred_pre_out [B] (the network output z) and pred_out [B] (act(z)) may be NULL; with a linear
+ * activation they are the same values. */
+enum { PA_LOSS_MSE = 0, PA_LOSS_MAE = 1, PA_LOSS_BCE = 2 };   /* nn.functional.mse_loss / l1_loss /
+                                                                binary_cross_entropy, reduction none */
+enum { PA_OUT_LINEAR = 0, PA_OUT_SIGMOID = 1 };
+int pa_wloss_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
+                     int32_t loss_kind, int32_t out_act, float* pred_pre_out, float* pred_out,
+                     float* d_pred, float* loss_out, void* stream);
 /* nn.MSELoss head (critic_utils.py:139-203): d_pred = grad_scale * (pred - target);
  * loss_out (=|+=) mean((pred - target)^2) * loss_scale. */
 int pa_mse_head(const float* pred, int32_t ldp, const float* target, int32_t B, float grad_scale,
@@ -777,6 +792,14 @@ int pa_sac_alpha_step(float* log_alpha, float* exp_avg, float* exp_avg_sq, float
  * sum w (pred - y)^2 / sum w and its gradient; w may be NULL (ones); wsum_out may be NULL. */
 int pa_weighted_mse_head(const float* pred, int32_t ldp, const float* y, const float* w, int32_t B,
                          float* d_pred, float* loss_out, float* wsum_out, void* stream);
+/* The general form (neural_linear_bandit.py:176-199 with LossType MSE / MAE / CROSS_ENTROPY and a
+ * linear or sigmoid output activation): pred holds the network output z, pred_out [B] (may be
+ * NULL) receives act(z), d_pred = d loss / d z with torch's backward formulas
+ * (mse_loss / l1_loss / binary_cross_entropy with its -100 log clamp and 1e-12 denominator clamp;
+ * sigmoid), loss_out = sum w criterion / sum w. */
+int pa_weighted_loss_head(const float* pred, int32_t ldp, const float* y, const float* w, int32_t B,
+                          int32_t loss_kind, int32_t out_act, float* pred_out, float* d_pred,
+                          float* loss_out, float* wsum_out, void* stream);
 /* LinearRegression.learn_batch (neural_networks/contextual_bandit/linear_regression.py:192-219)
  * in three steps so that the host can all-reduce the packed delta in between (:207-210):
  *   pa_linreg_delta: delta[D][D+1] = [1|f]^T [ [1|f] w | y w ], delta[D*(D+1)] = sum w   (D = d+1)

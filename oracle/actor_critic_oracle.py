@@ -445,7 +445,8 @@ class NeuralLinearOracle:
     neural_linear_regression.py:125-157) and LinearRegression.learn_batch / calculate_coefs /
     calculate_sigma (linear_regression.py:192-219, :252-270)."""
 
-    def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0) -> None:
+    def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0,
+                 loss_type: str = "mse", output_activation: str = "linear") -> None:
         self.trunk = _layers(model_sd, "_nn_layers._model.")
         self.e2e = model_sd["linear_layer_e2e.weight"].clone().requires_grad_(True)
         d = self.e2e.shape[1]
@@ -454,15 +455,20 @@ class NeuralLinearOracle:
         self.inv_A, self.coefs = torch.zeros(d + 1, d + 1), torch.zeros(d + 1)
         self.lam = l2_reg_lambda
         self.opt = torch.optim.AdamW(_flat(self.trunk) + [self.e2e], lr=lr, amsgrad=True)
+        # LossType.function() (neural_networks/common/utils.py:60-72) and the model's output
+        # activation (neural_linear_regression.py:79-81)
+        self.criterion = {"mse": torch.nn.functional.mse_loss, "mae": torch.nn.functional.l1_loss,
+                          "cross_entropy": torch.nn.functional.binary_cross_entropy}[loss_type]
+        self.out_act = {"linear": lambda z: z, "sigmoid": torch.sigmoid}[output_activation]
 
     def features(self, x: Tensor) -> Tensor:
         return mlp(self.trunk, x)          # the trunk's own last layer has no activation
 
     def learn_batch(self, x: Tensor, y: Tensor, w) -> Dict[str, Tensor]:
         f = self.features(x)
-        pred = torch.nn.functional.linear(f, self.e2e)
+        pred = self.out_act(torch.nn.functional.linear(f, self.e2e))
         weight = torch.ones_like(y) if w is None else w
-        loss = torch.nn.functional.mse_loss(pred.view(y.shape), y, reduction="none")
+        loss = self.criterion(pred.view(y.shape), y, reduction="none")
         loss = (loss * weight).sum() / weight.sum()
         self.opt.zero_grad()
         loss.backward()

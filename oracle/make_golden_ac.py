@@ -27,6 +27,8 @@ sys.path.insert(0, REF)
 
 import torch  # noqa: E402
 
+import fixture_inputs as FI  # noqa: E402  (oracle/fixture_inputs.py)
+
 from pearl.action_representation_modules.one_hot_action_representation_module import (  # noqa: E402
     OneHotActionTensorRepresentationModule,
 )
@@ -65,6 +67,10 @@ PPO_CONFIGS = {
     "cfg4_shape_small": dict(S=256, A=16, hidden=[256, 256], N=400, B=128, rounds=5, epsilon=0.1),
     # BASELINE config 4 at its own minibatch size (4096 of a 4096-transition rollout, one round)
     "cfg4_fullbatch": dict(S=256, A=16, hidden=[256, 256], N=4096, B=4096, rounds=1, epsilon=0.1),
+}
+# BASELINE config 4's rollout size: preprocess_replay_buffer only (make_ppo_rollout)
+PPO_ROLLOUT_CONFIGS = {
+    "cfg4_rollout64k": dict(S=256, A=16, hidden=[256, 256], N=65536, B=4096, epsilon=0.1, input_seed=4),
 }
 SAC_CONFIGS = {
     "tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=5),
@@ -186,6 +192,9 @@ DDPG_CONFIGS = {
     "ddpg_cfg3_shape_small": dict(S=64, A=8, hidden=[256, 256], B=128, steps=4, td3=False),
     "td3_tiny": dict(S=5, A=2, hidden=[16, 12], B=16, steps=6, td3=True),
     "td3_cfg3_shape_small": dict(S=64, A=8, hidden=[256, 256], B=128, steps=5, td3=True),
+    # the bench shape (bench_algos.py --only td3): B = 1024, two calls = one with and one without
+    # the delayed actor / target updates
+    "td3_cfg3_fullbatch": dict(S=64, A=8, hidden=[256, 256], B=1024, steps=2, td3=True),
 }
 
 
@@ -246,6 +255,8 @@ def make_ddpg(name, cfg):
 DSAC_CONFIGS = {
     "dsac_tiny": dict(S=5, A=3, hidden=[16, 12], B=16, steps=5, dynamic=True),
     "dsac_shape_small": dict(S=64, A=8, hidden=[128, 128], B=96, steps=4, dynamic=False),
+    # the bench shape (bench_algos.py --only dsac: config-2 shapes): 16 actions, [256, 256], B = 1024
+    "dsac_cfg2_fullbatch": dict(S=128, A=16, hidden=[256, 256], B=1024, steps=1, dynamic=False),
 }
 
 
@@ -315,6 +326,9 @@ IQL_CONFIGS = {
                               expectile=0.7),
     "iql_gaussian_shape_small": dict(S=64, A=8, hidden=[128, 128], B=96, steps=4,
                                      continuous="gaussian", expectile=0.8),
+    # hidden [256, 256] at B = 1024 (the shapes the fused twin-critic step runs at)
+    "iql_continuous_fullbatch": dict(S=64, A=8, hidden=[256, 256], B=1024, steps=1, continuous=True,
+                                     expectile=0.8),
 }
 
 
@@ -429,25 +443,43 @@ def make_squarecb(name="squarecb_tiny"):
 BANDIT_CONFIGS = {
     "tiny": dict(F=7, hidden=[12, 6], B=16, steps=4),
     "cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3),
+    # BASELINE config 5 at its own batch size (B = 4096 contexts of 512 features, hidden [256, 64]):
+    # the contexts are regenerated from `input_seed` (oracle/fixture_inputs.py), not stored
+    "cfg5_fullbatch": dict(F=512, hidden=[256, 64], B=4096, steps=2, input_seed=5),
+    # the other criteria of LossType (neural_networks/common/utils.py:60-72) and the sigmoid
+    # output activation cross-entropy requires (neural_linear_bandit.py:181-186)
+    "mae_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, loss="mae"),
+    "bce_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, loss="cross_entropy", out="sigmoid"),
+    "mse_sigmoid_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, out="sigmoid"),
+    "mae_cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3, loss="mae", input_seed=6),
+    "bce_cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3, loss="cross_entropy",
+                                 out="sigmoid", input_seed=7),
 }
 
 
 def make_bandit(name, cfg):
     from pearl.policy_learners.contextual_bandits.neural_linear_bandit import NeuralLinearBandit
     F, B, K = cfg["F"], cfg["B"], cfg["steps"]
+    loss, out = cfg.get("loss", "mse"), cfg.get("out", "linear")
+    seeded = "input_seed" in cfg
     gen = torch.Generator().manual_seed(77)
     torch.manual_seed(8)
     pl = NeuralLinearBandit(feature_dim=F, hidden_dims=cfg["hidden"], batch_size=B,
-                            learning_rate=1e-3)
+                            learning_rate=1e-3, loss_type=loss, output_activation_name=out)
     fx = {"config": dict(cfg), "model0": clone_sd(pl.model), "batches": [], "reports": []}
     wtrue = torch.randn(F, generator=gen) / F ** 0.5
     for k in range(K):
-        x = torch.randn(B, F, generator=gen)
+        x = FI.bandit_contexts(cfg, k) if seeded else torch.randn(B, F, generator=gen)
         r = torch.sigmoid(x @ wtrue) + 0.05 * torch.randn(B, generator=gen)
+        if loss == "cross_entropy":
+            r = r.clamp(0.0, 1.0)                 # labels in [0, 1] (:181-183)
         w = None if k % 2 == 0 else torch.rand(B, generator=gen) + 0.5
         tb = TransitionBatch(state=x, action=torch.zeros(B, 1), reward=r, weight=w)
         rep = pl.learn_batch(tb)
-        fx["batches"].append(dict(state=x, reward=r, weight=w))
+        if seeded:      # the contexts are rebuilt where the fixture is used; labels / weights are small
+            fx["batches"].append(dict(state_checksum=FI.checksum(x), reward=r, weight=w))
+        else:
+            fx["batches"].append(dict(state=x, reward=r, weight=w))
         fx["reports"].append(dict(loss=float(rep["loss"]), mu=float(rep["mu_scores"]),
                                   prediction=rep["prediction"].clone()))
     fx["model_after"] = clone_sd(pl.model)
@@ -459,6 +491,83 @@ def make_bandit(name, cfg):
     torch.save(fx, path)
     print(f"bandit {name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); losses "
           f"{[round(r['loss'], 5) for r in fx['reports']]}")
+
+
+def make_squarecb_cfg5(name="squarecb_cfg5"):
+    """BASELINE config 5's act path: 512-dim contexts, 32 arms (arm features appended to the
+    context, state_features_only=False), NeuralLinearBandit(hidden [256, 64]) scored by
+    SquareCBExploration with the benchmark's gamma = sqrt(T d) (cb_benchmark_config.py:111-118).
+    For several single contexts: the probability table at the reference's Categorical(...) call,
+    the action torch's seeded generator yields, and get_scores."""
+    import pearl.policy_learners.exploration_modules.contextual_bandits.squarecb_exploration as M
+    from pearl.policy_learners.contextual_bandits.neural_linear_bandit import NeuralLinearBandit
+    captured = []
+    real = M.Categorical
+
+    class Spy(real):
+        def __init__(self, probs=None, **kw):
+            captured.append(probs.detach().clone())
+            super().__init__(probs=probs, **kw)
+
+    M.Categorical = Spy
+    try:
+        F, A, AD = 512, 32, 4
+        gamma = float((10000 * (F + AD)) ** 0.5)
+        torch.manual_seed(19)
+        pl = NeuralLinearBandit(feature_dim=F + AD, hidden_dims=[256, 64], batch_size=4096,
+                                exploration_module=M.SquareCBExploration(gamma=gamma),
+                                state_features_only=False)
+        gen = torch.Generator().manual_seed(41)
+        arms = torch.randn(A, AD, generator=gen)
+        sp = DiscreteActionSpace([arms[k].clone() for k in range(A)])
+        cases = []
+        for trial in range(6):
+            state = torch.randn(F, generator=gen)
+            captured.clear()
+            torch.manual_seed(900 + trial)
+            action = pl.act(subjective_state=state, available_action_space=sp)
+            scores = pl.get_scores(subjective_state=state, action_space_to_score=sp)
+            cases.append(dict(state=state, seed=900 + trial, action=int(action),
+                              probs=captured[0].clone(), scores=scores.detach().clone()))
+        fx = dict(F=F, A=A, AD=AD, gamma=gamma, arms=arms, model0=clone_sd(pl.model), cases=cases)
+    finally:
+        M.Categorical = real
+    path = os.path.join(OUT, f"{name}.pt")
+    torch.save(fx, path)
+    print(f"{name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); actions "
+          f"{[c['action'] for c in cases]}")
+
+
+def make_ppo_rollout(name, cfg):
+    """BASELINE config 4's preprocessing at its own rollout size (ppo.py:211-293,
+    replay_buffer_utils.py:37-128): what preprocess_replay_buffer attaches to each of the 65 536
+    transitions.  The rollout is regenerated from `input_seed` where the fixture is used."""
+    S, A, N = cfg["S"], cfg["A"], cfg["N"]
+    states, actions, rewards, term, trunc = FI.ppo_rollout(cfg)
+    torch.manual_seed(5)
+    pl = ProximalPolicyOptimization(
+        action_space=space(A), state_dim=S, actor_hidden_dims=cfg["hidden"],
+        critic_hidden_dims=cfg["hidden"], training_rounds=1, batch_size=cfg["B"],
+        epsilon=cfg["epsilon"], action_representation_module=OneHotActionTensorRepresentationModule(A))
+    rb = PPOReplayBuffer(N + 5)
+    PearlAgent(policy_learner=pl, replay_buffer=rb)
+    sp = space(A)
+    for i in range(N):
+        rb.push(state=states[i], action=torch.tensor([int(actions[i])]), reward=float(rewards[i]),
+                terminated=bool(term[i]), truncated=bool(trunc[i]),
+                curr_available_actions=sp, next_state=states[i + 1],
+                next_available_actions=sp, max_number_actions=A)
+    pl.preprocess_replay_buffer(rb)
+    fx = {"config": dict(cfg), "actor0": clone_sd(pl._actor), "critic0": clone_sd(pl._critic),
+          "checksums": dict(states=FI.checksum(states), actions=FI.checksum(actions),
+                            rewards=FI.checksum(rewards)),
+          "gae": torch.cat([t.gae for t in rb.memory]).detach().clone(),
+          "lam_return": torch.cat([t.lam_return for t in rb.memory]).detach().clone(),
+          "action_probs": torch.cat([t.action_probs for t in rb.memory]).detach().clone().view(-1)}
+    path = os.path.join(OUT, f"ppo_{name}.pt")
+    torch.save(fx, path)
+    print(f"ppo {name}: wrote {path} ({os.path.getsize(path) / 1e6:.2f} MB); gae[:3] "
+          f"{fx['gae'][:3].tolist()}")
 
 
 def main():
@@ -475,6 +584,18 @@ def main():
     if os.environ.get("PEARL_GOLDEN_ONLY") == "fullbatch":
         make_ppo("cfg4_fullbatch", PPO_CONFIGS["cfg4_fullbatch"])
         make_sac("cfg3_fullbatch", SAC_CONFIGS["cfg3_fullbatch"])
+        return
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "round4":
+        # the fixtures round 4 added (VERDICT r3 "untested configs"); everything else untouched
+        for name in ("cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
+                     "mae_cfg5_shape_small", "bce_cfg5_shape_small"):
+            make_bandit(name, BANDIT_CONFIGS[name])
+        make_squarecb_cfg5()
+        make_ddpg("td3_cfg3_fullbatch", DDPG_CONFIGS["td3_cfg3_fullbatch"])
+        make_dsac("dsac_cfg2_fullbatch", DSAC_CONFIGS["dsac_cfg2_fullbatch"])
+        make_iql("iql_continuous_fullbatch", IQL_CONFIGS["iql_continuous_fullbatch"])
+        for name, cfg in PPO_ROLLOUT_CONFIGS.items():
+            make_ppo_rollout(name, cfg)
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "squarecb":
         make_squarecb()
@@ -496,8 +617,11 @@ def main():
     for name, cfg in BANDIT_CONFIGS.items():
         make_bandit(name, cfg)
     make_squarecb()
+    make_squarecb_cfg5()
     if os.environ.get("PEARL_GOLDEN_ONLY") == "bandit":
         return
+    for name, cfg in PPO_ROLLOUT_CONFIGS.items():
+        make_ppo_rollout(name, cfg)
     for name, cfg in PPO_CONFIGS.items():
         make_ppo(name, cfg)
     for name, cfg in SAC_CONFIGS.items():

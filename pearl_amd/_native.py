@@ -366,6 +366,8 @@ SIGNATURES = {
     "pa_dsac_target_rowstep": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P,
                                          C.c_float, _P, _P]),
     "pa_wmse_rowstep": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "pa_wloss_rowstep": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P,
+                                   _P, _P]),
     "pa_mse_rowstep2": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, C.c_float, C.c_float, _P, _P,
                                   _P, _P, _P, _P]),
     "pa_mlp_q_all2": (C.c_int, [_P, _P, C.c_int32, _P, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32,
@@ -436,10 +438,14 @@ SIGNATURES = {
     "pa_debug_sac_prof": (C.c_int, [_P, _P]),
     "pa_sac_timing": (C.c_int, [C.c_int32]),
     "pa_sac_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "pa_mlp_timing": (C.c_int, [C.c_int32]),
+    "pa_mlp_timing_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_sac_alpha_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_double,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                     C.c_int64, _P, _P]),
     "pa_weighted_mse_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "pa_weighted_loss_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P,
+                                        _P, _P, _P]),
     "pa_linreg_delta": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_apply": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_solve": (C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P, _P]),

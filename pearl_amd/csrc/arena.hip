@@ -503,28 +503,29 @@ int arena_sample(pa_arena* a, uint64_t seed, uint64_t offset, int32_t B, const p
 using namespace pa;
 
 namespace pa {
-// One process drives one GPU (launch-time kernel attributes and scratch buffers are per process).
-// The binding is taken by the first handle and RELEASED when the last handle of the process is
-// destroyed, so that a later learner — an evaluation pass on another device, a notebook cell, a
-// test suite walking over devices — can bind anew.  Atomic: handles may be created from several
-// threads.
+// One process drives one GPU, for the life of the process: launch-time kernel attributes
+// (max dynamic LDS, set once per kernel behind `static configured` guards) and the library's scratch
+// buffers / tickets (row-step partials, split-K slabs, the solve's work space) are per-process
+// statics that live on the device of the first handle.  The binding is therefore PERMANENT once
+// taken — releasing it when the last handle is destroyed (as round 3 did) let a later handle bind
+// another device and hand its kernels scratch pointers of the first one.  A process
+// that wants another GPU is another process (torchrun's model).  Atomic: handles may be created
+// from several threads.
 static std::atomic<int> g_bound_device{-1};
 static std::atomic<int> g_live_handles{0};
 int bind_process_device(int device) {
   int expected = -1;
   if (!g_bound_device.compare_exchange_strong(expected, device) && expected != device) {
-    set_error("pearl_amd: one process drives one GPU at a time — this process holds handles on HIP "
-              "device %d and cannot create one on device %d (destroy them first, or launch one "
-              "process per device)",
+    set_error("pearl_amd: one process drives one GPU — this process is bound to HIP device %d "
+              "(its first handle) and cannot create a handle on device %d; launch one process per "
+              "device",
               expected, device);
     return PA_ERR_UNSUPPORTED;
   }
   g_live_handles.fetch_add(1);
   return PA_OK;
 }
-void release_process_device() {
-  if (g_live_handles.fetch_sub(1) == 1) g_bound_device.store(-1);
-}
+void release_process_device() { g_live_handles.fetch_sub(1); }
 }  // namespace pa
 
 extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {
@@ -675,7 +676,11 @@ static void note_next_table(pa_arena* a, const float* next_avail, const uint8_t*
     memcpy(a->sh_next_avail, next_avail, av);
     memcpy(a->sh_next_mask, next_mask, mk);
     a->shared_next = 1;
-    a->shared_gen += 1;
+    // a PROCESS-wide generation: a buffer destroyed and re-created at the same heap address with
+    // another static action table must not hit a learner's (arena pointer, generation) cache of
+    // the old one
+    static std::atomic<int> next_gen{0};
+    a->shared_gen = next_gen.fetch_add(1) + 1;
   } else if (memcmp(a->sh_next_avail, next_avail, av) != 0 ||
              memcmp(a->sh_next_mask, next_mask, mk) != 0) {
     a->shared_next = 2;
@@ -796,9 +801,12 @@ extern "C" int pa_arena_push_many_device(pa_arena* a, int64_t n, const pa_column
       float* tab = static_cast<float*>(malloc(av));
       uint8_t* msk = static_cast<uint8_t*>(malloc((size_t)d.max_actions));
       bool ok = tab && msk;
-      if (ok) ok = hipMemcpy(tab, cols->next_avail, av, hipMemcpyDeviceToHost) == hipSuccess &&
-                   hipMemcpy(msk, cols->next_mask, (size_t)d.max_actions, hipMemcpyDeviceToHost) ==
-                       hipSuccess;
+      // (on the CALLER's stream, then a wait for it: the tables were uploaded on that stream, and
+      //  a null-stream copy is not ordered behind work of a non-blocking stream — ADVICE r3)
+      if (ok) ok = hipMemcpyAsync(tab, cols->next_avail, av, hipMemcpyDeviceToHost, s) == hipSuccess &&
+                   hipMemcpyAsync(msk, cols->next_mask, (size_t)d.max_actions, hipMemcpyDeviceToHost,
+                                  s) == hipSuccess &&
+                   hipStreamSynchronize(s) == hipSuccess;
       if (ok) note_next_table(a, tab, msk);
       else a->shared_next = 2;
       free(tab);

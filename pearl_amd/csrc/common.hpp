@@ -105,7 +105,7 @@ struct pa_arena {
   // ingest).  The DQN learn loop then hands the target kernel ONE table with stride 0 instead of
   // materialising (B, A, A) one-hot rows per window (pa_dqn_learn).
   int shared_next;
-  int shared_gen;             // bumped whenever the shared table is (re)set
+  int shared_gen;             // a process-wide generation number, new whenever the shared table is (re)set
   float* sh_next_avail;       // [max_actions * avail_dim] host
   uint8_t* sh_next_mask;      // [max_actions] host
 };

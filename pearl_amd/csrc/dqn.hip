@@ -1113,6 +1113,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   {
     hipDeviceProp_t prop;
     if (hipMemset(h->tile_ctr, 0, (kTileCtrs + 8) * sizeof(int)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess ||
         hipGetDeviceProperties(&prop, desc->device) != hipSuccess) {
       set_error("pa_dqn_create: device query failed");
       pa_dqn_destroy(h);

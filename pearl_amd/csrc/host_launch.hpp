@@ -187,7 +187,7 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
       if (tickets) (void)hipFree(tickets);
       const size_t n = (size_t)a.total_tiles * 2;
       PA_HIP(hipMalloc((void**)&tickets, n * sizeof(unsigned)));
-      PA_HIP(hipMemset(tickets, 0, n * sizeof(unsigned)));
+      PA_HIP(hipMemsetAsync(tickets, 0, n * sizeof(unsigned), s));
       ticket_count = n;
     }
     a.kscratch = scratch;

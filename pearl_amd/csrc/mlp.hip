@@ -411,6 +411,29 @@ namespace {
 // target parameters (and their packed copies, when current) take their soft update in the same
 // epilogue (update_target_network, common/utils.py:214-226).
 long long* g_mlp_dw_prof = nullptr;   // pa_debug_mlp_dw_prof
+// Live kernel timing for the bench lines (bench_algos.py, bench.py's other_configs): HIP events on
+// the launch stream around the first kMlpTimed fused row-step launches (slot 0) and weight-gradient
+// launches (slot 1) after pa_mlp_timing(1).  An event record costs ~6 us of GPU idle on this stack:
+// the timed steps are not the ones a throughput figure is taken from.
+constexpr int kMlpTimed = 64;
+struct MlpTimers {
+  bool on = false, made = false;
+  int n[2] = {0, 0};
+  hipEvent_t ev[2][kMlpTimed][2];
+} g_mt;
+struct MlpTimedLaunch {
+  int slot, i;
+  hipStream_t s;
+  MlpTimedLaunch(int slot_, hipStream_t s_) : slot(slot_), i(-1), s(s_) {
+    if (g_mt.on && g_mt.n[slot] < kMlpTimed) {
+      i = g_mt.n[slot]++;
+      (void)hipEventRecord(g_mt.ev[slot][i][0], s);
+    }
+  }
+  ~MlpTimedLaunch() {
+    if (i >= 0) (void)hipEventRecord(g_mt.ev[slot][i][1], s);
+  }
+};
 struct DwOperands {
   const float* x; int ldx;
   const float* const* dzs; const int* ldzs;
@@ -499,7 +522,11 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
     // the step's scalar tail rides the last launch as one extra workgroup
     const bool with_tail = tail && l0 + 3 >= L;
     if (with_tail) a.tail = *tail;
-    int rc = launch_weight_grad(a, with_tail, s);
+    int rc;
+    {
+      MlpTimedLaunch timed(1, s);
+      rc = launch_weight_grad(a, with_tail, s);
+    }
     if (rc != PA_OK) return rc;
   }
   if (adam_step > 0 && soft_tau >= 0.f)
@@ -896,7 +923,7 @@ struct RowStepScratch {
   float* buf = nullptr;
   size_t floats = 0;
 };
-int rowstep_scratch(RowStepScratch& sc, size_t need) {
+int rowstep_scratch(RowStepScratch& sc, size_t need, hipStream_t s) {
   if (need <= sc.floats) return PA_OK;
   if (sc.buf) {
     PA_HIP(hipDeviceSynchronize());
@@ -905,7 +932,10 @@ int rowstep_scratch(RowStepScratch& sc, size_t need) {
     sc.floats = 0;
   }
   PA_HIP(hipMalloc((void**)&sc.buf, need * 2 * sizeof(float)));
-  PA_HIP(hipMemset(sc.buf, 0, need * 2 * sizeof(float)));
+  // zeroed ON THE LAUNCH STREAM: a null-stream memset is not ordered against a launch on a
+  // non-blocking stream, and the first launch after a grow could have seen a non-zero ticket
+  // 
+  PA_HIP(hipMemsetAsync(sc.buf, 0, need * 2 * sizeof(float), s));
   sc.floats = need * 2;
   return PA_OK;
 }
@@ -930,7 +960,7 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
         hs[i]->d.dims[hs[i]->L] * 2 * RP_ROWS > 512)
       RT = 1;
   const unsigned gx = (unsigned)ceil_div(B, RP_ROWS * RT);
-  int rc = rowstep_scratch(sc, (size_t)4 + 4 * gx + 2 * (size_t)B);
+  int rc = rowstep_scratch(sc, (size_t)4 + 4 * gx + 2 * (size_t)B, s);
   if (rc != PA_OK) return rc;
   a.ticket = reinterpret_cast<unsigned*>(sc.buf);
   a.partials = sc.buf + 4;
@@ -960,8 +990,11 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
     if (rc != PA_OK) return rc;
     configured[RT] = smem;
   }
-  if (RT == 2) hipLaunchKernelGGL(mlp_rowstep_kernel<2>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
-  else hipLaunchKernelGGL(mlp_rowstep_kernel<1>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+  {
+    MlpTimedLaunch timed(0, s);
+    if (RT == 2) hipLaunchKernelGGL(mlp_rowstep_kernel<2>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+    else hipLaunchKernelGGL(mlp_rowstep_kernel<1>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+  }
   PA_LAUNCH_CHECK();
   // the state a kept forward + a want_dw = 2 backward leave behind: the weight gradients (and
   // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
@@ -982,6 +1015,35 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   return PA_OK;
 }
 }  // namespace
+
+// HIP-event timing of the engine's fused row-step and weight-gradient launches (see MlpTimers)
+extern "C" int pa_mlp_timing(int32_t enable) {
+  if (enable && !g_mt.made) {
+    for (int k = 0; k < 2; ++k)
+      for (int i = 0; i < kMlpTimed; ++i)
+        for (int e = 0; e < 2; ++e) PA_HIP(hipEventCreate(&g_mt.ev[k][i][e]));
+    g_mt.made = true;
+  }
+  g_mt.on = enable != 0;
+  g_mt.n[0] = g_mt.n[1] = 0;
+  return PA_OK;
+}
+// which: 0 = fused row step, 1 = weight gradients (+ AdamW); average duration over the launches
+// timed so far; synchronises with their events
+extern "C" int pa_mlp_timing_read(int32_t which, double* avg_us, int64_t* launches) {
+  PA_REQUIRE((which == 0 || which == 1) && avg_us && launches, PA_ERR_INVALID,
+             "pa_mlp_timing_read: bad argument");
+  double sum = 0.0;
+  for (int i = 0; i < g_mt.n[which]; ++i) {
+    float ms = 0.f;
+    PA_HIP(hipEventSynchronize(g_mt.ev[which][i][1]));
+    PA_HIP(hipEventElapsedTime(&ms, g_mt.ev[which][i][0], g_mt.ev[which][i][1]));
+    sum += ms;
+  }
+  *launches = g_mt.n[which];
+  *avg_us = g_mt.n[which] ? 1e3 * sum / g_mt.n[which] : 0.0;
+  return PA_OK;
+}
 
 // the same for the engine's weight-gradient launches (weight_grad_kernel's stamps, [workgroup][8][16])
 extern "C" int pa_debug_mlp_dw_prof(long long* stamps) {
@@ -1094,15 +1156,19 @@ extern "C" int pa_dsac_target_rowstep(pa_mlp* actor, const float* next_state, in
 }
 
 // The neural-linear bandit's network step with unit weights (neural_linear_bandit.py:176-199):
-// forward (kept: pa_mlp_copy_activation still serves the features) -> d_pred = 2 (pred - y) / B ->
-// backward, one launch; loss_out[0] = mean (pred - y)^2.  What pa_mlp_forward(keep) ->
-// pa_weighted_mse_head(w = NULL) -> pa_mlp_backward(want_dw = 2) compute.
-extern "C" int pa_wmse_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
-                               float* pred_out, float* d_pred, float* loss_out, void* stream) {
+// forward (kept: pa_mlp_copy_activation still serves the features) -> the criterion's gradient
+// (d_pred = 2 (pred - y) / B for MSE) -> backward, one launch; loss_out[0] = mean criterion.  What
+// pa_mlp_forward(keep) -> pa_weighted_loss_head(w = NULL) -> pa_mlp_backward(want_dw = 2) compute.
+extern "C" int pa_wloss_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
+                                int32_t loss_kind, int32_t out_act, float* pred_pre_out,
+                                float* pred_out, float* d_pred, float* loss_out, void* stream) {
   PA_REQUIRE(net && x && y && d_pred && loss_out && B > 0, PA_ERR_INVALID,
-             "pa_wmse_rowstep: bad argument");
+             "pa_wloss_rowstep: bad argument");
+  PA_REQUIRE(loss_kind >= PA_LOSS_MSE && loss_kind <= PA_LOSS_BCE && out_act >= PA_OUT_LINEAR &&
+             out_act <= PA_OUT_SIGMOID, PA_ERR_UNSUPPORTED,
+             "pa_wloss_rowstep: loss is mse / mae / cross-entropy, output activation linear / sigmoid");
   PA_REQUIRE(pa_rowstep_supported(net, nullptr, 0), PA_ERR_UNSUPPORTED,
-             "pa_wmse_rowstep: needs a one-output network, every layer <= 256 wide");
+             "pa_wloss_rowstep: needs a one-output network, every layer <= 256 wide");
   PA_HIP(hipSetDevice(net->d.device));
   pa_mlp* hs[1] = {net};
   RowHead head;
@@ -1110,10 +1176,19 @@ extern "C" int pa_wmse_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t
   head.kind = RS_HEAD_WMSE1;
   head.d_out = d_pred; head.ldd = 1;
   head.target = y;
-  float* outs[1] = {pred_out};       // [B] predictions (may be null)
+  head.loss_kind = loss_kind; head.out_act = out_act;
+  head.out_post = out_act == PA_OUT_LINEAR ? nullptr : pred_out;
+  // [B] network outputs (pre-activation); with a linear output activation they ARE the predictions
+  float* outs[1] = {out_act == PA_OUT_LINEAR && !pred_pre_out ? pred_out : pred_pre_out};
   const int ldos[1] = {1};
   return run_rowstep(hs, 1, x, ldx, B, &head, outs, ldos, loss_out, 1,
                      reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pa_wmse_rowstep(pa_mlp* net, const float* x, int32_t ldx, int32_t B, const float* y,
+                               float* pred_out, float* d_pred, float* loss_out, void* stream) {
+  return pa_wloss_rowstep(net, x, ldx, B, y, PA_LOSS_MSE, PA_OUT_LINEAR, nullptr, pred_out, d_pred,
+                          loss_out, stream);
 }
 
 // Twin critics on (state, action) rows against one target (twin_critic_action_value_loss,
@@ -2142,28 +2217,40 @@ __global__ __launch_bounds__(256) void concat_kernel(const float* __restrict__ s
 
 namespace {
 
-// Weighted MSE of the neural-linear bandit (neural_linear_bandit.py:176-199):
-//   loss = sum_b w_b (pred_b - y_b)^2 / sum_b w_b;  d_pred_b = 2 w_b (pred_b - y_b) / sum w
+// Weighted loss of the neural-linear bandit (neural_linear_bandit.py:176-199; LossType,
+// neural_networks/common/utils.py:60-72): pred = act(z), l_b = criterion(pred_b, y_b) unreduced,
+//   loss = sum_b w_b l_b / sum_b w_b;  d_z_b = dl_b/dpred_b * (w_b / sum w) * act'(z_b)
+// with torch's own backward formulas (one rounding per torch op):
+//   mse_loss   l = (p - y)^2                 dl/dp = 2 (p - y) g
+//   l1_loss    l = |p - y|                   dl/dp = sign(p - y) g
+//   binary_cross_entropy
+//              l = (y - 1) max(log(1 - p), -100) - y max(log p, -100)
+//                                            dl/dp = g (p - y) / max((1 - p) p, 1e-12)
+//   sigmoid    p = 1 / (1 + exp(-z))         dz = dp (1 - p) p
+// wloss_row is shared with the fused row step (mlp_rowstep.hpp, RS_HEAD_WMSE1).
 struct WmseArgs {
   const float* pred; int ldp; const float* y; const float* w;  // w may be null (= ones)
   int B;
   float* d_pred; float* loss_out; float* wsum_out;
+  int loss_kind, out_act;      // PA_LOSS_*, PA_OUT_*
+  float* pred_out;             // [B] post-activation predictions, or null
 };
 __global__ __launch_bounds__(256) void wmse_kernel(WmseArgs a) {
   __shared__ float red[256];
   float pw = 0.f, pl = 0.f;
   for (int b = threadIdx.x; b < a.B; b += 256) {
     const float w = a.w ? a.w[b] : 1.0f;
-    const float d = a.pred[(int64_t)b * a.ldp] - a.y[b];
+    const float p = wloss_act(a.pred[(int64_t)b * a.ldp], a.out_act);
     pw += w;
-    pl += (d * d) * w;
+    pl += wloss_value(p, a.y[b], a.loss_kind) * w;
   }
   const float wsum = block_sum_256(pw, red);
   const float lsum = block_sum_256(pl, red);
   for (int b = threadIdx.x; b < a.B; b += 256) {
     const float w = a.w ? a.w[b] : 1.0f;
-    const float d = a.pred[(int64_t)b * a.ldp] - a.y[b];
-    a.d_pred[b] = (wsum != 0.f) ? (2.0f * d * w) / wsum : 0.f;
+    const float p = wloss_act(a.pred[(int64_t)b * a.ldp], a.out_act);
+    if (a.pred_out) a.pred_out[b] = p;
+    a.d_pred[b] = (wsum != 0.f) ? wloss_grad(p, a.y[b], w, wsum, a.loss_kind, a.out_act) : 0.f;
   }
   if (threadIdx.x == 0) {
     a.loss_out[0] = (wsum != 0.f) ? lsum / wsum : 0.f;
@@ -2488,17 +2575,27 @@ __global__ __launch_bounds__(256) void linreg_sigma_kernel(const float* __restri
 
 }  // namespace
 
-extern "C" int pa_weighted_mse_head(const float* pred, int32_t ldp, const float* y, const float* w,
-                                    int32_t B, float* d_pred, float* loss_out, float* wsum_out,
-                                    void* stream) {
+extern "C" int pa_weighted_loss_head(const float* pred, int32_t ldp, const float* y, const float* w,
+                                     int32_t B, int32_t loss_kind, int32_t out_act, float* pred_out,
+                                     float* d_pred, float* loss_out, float* wsum_out, void* stream) {
   PA_REQUIRE(pred && y && d_pred && loss_out && B > 0, PA_ERR_INVALID,
-             "pa_weighted_mse_head: bad argument");
+             "pa_weighted_loss_head: bad argument");
+  PA_REQUIRE(loss_kind >= PA_LOSS_MSE && loss_kind <= PA_LOSS_BCE && out_act >= PA_OUT_LINEAR &&
+             out_act <= PA_OUT_SIGMOID, PA_ERR_UNSUPPORTED,
+             "pa_weighted_loss_head: loss is mse / mae / cross-entropy, output activation linear / sigmoid");
   WmseArgs a;
   a.pred = pred; a.ldp = ldp; a.y = y; a.w = w; a.B = B; a.d_pred = d_pred; a.loss_out = loss_out;
-  a.wsum_out = wsum_out;
+  a.wsum_out = wsum_out; a.loss_kind = loss_kind; a.out_act = out_act; a.pred_out = pred_out;
   hipLaunchKernelGGL(wmse_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
+}
+
+extern "C" int pa_weighted_mse_head(const float* pred, int32_t ldp, const float* y, const float* w,
+                                    int32_t B, float* d_pred, float* loss_out, float* wsum_out,
+                                    void* stream) {
+  return pa_weighted_loss_head(pred, ldp, y, w, B, PA_LOSS_MSE, PA_OUT_LINEAR, nullptr, d_pred,
+                               loss_out, wsum_out, stream);
 }
 
 extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* y, const float* w,
@@ -2674,7 +2771,7 @@ int ppo_actor_launch(const float* logits, int32_t ldl, const float* action_rep, 
       (void)hipFree(scratch);
     }
     PA_HIP(hipMalloc((void**)&scratch, need * 2 * sizeof(float)));
-    PA_HIP(hipMemset(scratch, 0, need * 2 * sizeof(float)));
+    PA_HIP(hipMemsetAsync(scratch, 0, need * 2 * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
     scratch_floats = need * 2;
   }
   a.ticket = reinterpret_cast<unsigned*>(scratch);
@@ -2799,7 +2896,7 @@ int launch_dsac(DsacArgs& a, hipStream_t s) {
     }
     cap = 2 * ((size_t)grid + 4);
     PA_HIP(hipMalloc((void**)&scratch, cap * sizeof(float)));
-    PA_HIP(hipMemset(scratch, 0, cap * sizeof(float)));
+    PA_HIP(hipMemsetAsync(scratch, 0, cap * sizeof(float), s));
   }
   a.ticket = reinterpret_cast<unsigned*>(scratch);
   a.partials = scratch + 4;

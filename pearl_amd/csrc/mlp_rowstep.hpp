@@ -19,6 +19,32 @@ namespace pa {
 enum { RS_HEAD_MSE = 1, RS_HEAD_PPO = 2, RS_HEAD_DSAC_ACTOR = 3, RS_HEAD_DSAC_TARGET = 4,
        RS_HEAD_WMSE1 = 5 };   // wmse_kernel with unit weights (neural_linear_bandit.py:176-199)
 
+// Row math of the neural-linear bandit's weighted loss (see wmse_kernel in mlp.hip): output
+// activation, unreduced criterion and d loss / d z, in torch's op order.
+__device__ __forceinline__ float wloss_act(float z, int out_act) {
+  return out_act == PA_OUT_SIGMOID ? 1.0f / (1.0f + expf(-z)) : z;
+}
+__device__ __forceinline__ float wloss_value(float p, float y, int kind) {
+  if (kind == PA_LOSS_MAE) return fabsf(p - y);
+  if (kind == PA_LOSS_BCE)
+    return (y - 1.0f) * fmaxf(log1pf(-p), -100.0f) - y * fmaxf(logf(p), -100.0f);
+  const float d = p - y;
+  return d * d;
+}
+__device__ __forceinline__ float wloss_grad(float p, float y, float w, float wsum, int kind,
+                                            int out_act) {
+  float dp;
+  if (kind == PA_LOSS_MSE) {
+    dp = (2.0f * (p - y) * w) / wsum;
+  } else {
+    const float g = (1.0f / wsum) * w;
+    const float d = p - y;
+    if (kind == PA_LOSS_MAE) dp = (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f)) * g;
+    else dp = (g * d) / fmaxf((1.0f - p) * p, 1e-12f);
+  }
+  return out_act == PA_OUT_SIGMOID ? (dp * (1.0f - p)) * p : dp;
+}
+
 struct RowHead {
   int kind;
   float* d_out; int ldd;        // [B][d_L]: gradient w.r.t. the network output (operand of the
@@ -39,6 +65,9 @@ struct RowHead {
   const float* alpha;
   float* h_out;                          // actor: [B] sum_j P_j log(P_j + 1e-8)
   const float* reward; const uint8_t* term; float gamma; float* y;   // target (no backward)
+  // RS_HEAD_WMSE1: criterion and output activation (PA_LOSS_*, PA_OUT_*); out_post [B] receives
+  // the post-activation predictions when the activation is not linear
+  int loss_kind, out_act; float* out_post;
 };
 
 struct RowStepArgs {
@@ -371,9 +400,10 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     hlive = hr < ROWS && b < a.B;
     if (hlive && hd.kind == RS_HEAD_WMSE1) {
       // wmse_kernel's expressions with w = 1 and sum w = B
-      const float d = ot[hr * PH] - hd.target[b];
-      dval = (2.0f * d * 1.0f) / (float)a.B;
-      part0 = (d * d) * 1.0f;
+      const float p = wloss_act(ot[hr * PH], hd.out_act);
+      if (hd.out_post) hd.out_post[b] = p;
+      dval = wloss_grad(p, hd.target[b], 1.0f, (float)a.B, hd.loss_kind, hd.out_act);
+      part0 = wloss_value(p, hd.target[b], hd.loss_kind) * 1.0f;
     } else if (hlive) {
       const float d = __fsub_rn(ot[hr * PH], hd.target[b]);
       dval = __fmul_rn(hd.grad_scale, d);

@@ -155,6 +155,7 @@ int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
     const int n = tiles * 2;
     PA_HIP(hipMalloc((void**)&buf, (size_t)2 * n * sizeof(float)));
     PA_HIP(hipMemset(buf, 0, (size_t)2 * n * sizeof(float)));
+    PA_HIP(hipDeviceSynchronize());   // (a rare grow: ordered against every stream)
     cap = n;
   }
   ta->partials = buf;
@@ -191,6 +192,7 @@ int exchange(pa_mlp* owner, int tiles, hipStream_t s, Exchange** out) {
   if (!x->err) {
     PA_HIP(hipMalloc((void**)&x->err, 16));
     PA_HIP(hipMemset(x->err, 0, 16));
+    PA_HIP(hipDeviceSynchronize());
     PA_HIP(hipHostMalloc((void**)&x->err_host, 16, hipHostMallocDefault));
     x->err_host[0] = 0;
   }

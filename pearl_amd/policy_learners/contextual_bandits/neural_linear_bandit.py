@@ -16,6 +16,7 @@ The regression operates on the features computed BEFORE the optimizer step, as i
 """
 from __future__ import annotations
 
+import copy
 import os
 
 from typing import Any, Dict, List, Optional
@@ -94,6 +95,10 @@ class SquareCBExploration(ExplorationModule):
         return values.view(-1, action_space.n)           # (:117-126)
 
 
+_LOSS_KINDS = {"mse": 0, "mae": 1, "cross_entropy": 2}        # PA_LOSS_* (include/pearl_amd.h)
+_OUT_ACTS = {"linear": 0, "sigmoid": 1}                        # PA_OUT_*
+
+
 class NeuralLinearBandit(PolicyLearner):
     def __init__(self, feature_dim: int, hidden_dims: List[int],
                  exploration_module: Optional[ExplorationModule] = None,
@@ -105,8 +110,15 @@ class NeuralLinearBandit(PolicyLearner):
                  output_activation_name: str = "linear", nn_e2e: bool = True,
                  separate_uncertainty: bool = False, **mlp_kwargs: Any) -> None:
         assert len(hidden_dims) >= 1
-        if str(getattr(loss_type, "value", loss_type)).lower() != "mse":
-            raise NotImplementedError("pearl_amd NeuralLinearBandit: only the MSE loss has HIP kernels")
+        # LossType (neural_networks/common/utils.py:60-72): "mse" | "mae" | "cross_entropy", a str or
+        # an enum member with that value
+        self.loss_type = str(getattr(loss_type, "value", loss_type)).lower()
+        if self.loss_type not in _LOSS_KINDS:
+            raise ValueError(f"{loss_type!r} is not a valid LossType")
+        if self.loss_type == "cross_entropy":
+            # the reference asserts this at learn time (:186); a linear output fails its [0, 1] check
+            assert output_activation_name == "sigmoid", \
+                "the cross-entropy loss needs output_activation_name='sigmoid'"
         super().__init__(training_rounds=training_rounds, batch_size=batch_size,
                          exploration_module=exploration_module, on_policy=False,
                          is_action_continuous=False,
@@ -122,7 +134,30 @@ class NeuralLinearBandit(PolicyLearner):
         self.apply_discounting_interval = apply_discounting_interval
         self.last_sum_weight_when_discounted = 0.0
         self.separate_uncertainty = separate_uncertainty
+        self._out_act = _OUT_ACTS[output_activation_name]
         self._flat: Dict[str, Any] = {}
+
+    # Native handles (`_flat`) and the side stream / events of the asynchronous solve
+    # (`_solve_state`: torch.cuda.Event is neither picklable nor deep-copyable) are per-object
+    # run-time state: a copy, a pickle or torch.save(agent) leaves them behind and the next
+    # learn_batch rebuilds them (copy.deepcopy(learner) raised after the first step).
+    def _portable_state(self, memo=None) -> Dict[str, Any]:
+        self.model._linear_regression_layer.join_solve()
+        out = {}
+        for k, v in self.__dict__.items():
+            if k == "_solve_state":
+                continue
+            out[k] = {} if k == "_flat" else (copy.deepcopy(v, memo) if memo is not None else v)
+        return out
+
+    def __deepcopy__(self, memo: dict) -> "NeuralLinearBandit":
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__dict__.update(self._portable_state(memo))
+        return new
+
+    def __getstate__(self) -> Dict[str, Any]:
+        return self._portable_state()
 
     @property
     def feature_dim(self) -> int:
@@ -162,19 +197,26 @@ class NeuralLinearBandit(PolicyLearner):
         dpred = torch.empty(B, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         wsum = torch.empty(1, dtype=torch.float32, device=dev)
+        kind, oact = _LOSS_KINDS[self.loss_type], self._out_act
+        if kind == 2:
+            # the reference's own checks (:181-186); predictions of a sigmoid are in [0, 1] already
+            assert bool(torch.all(y >= 0)) and bool(torch.all(y <= 1)), \
+                "cross-entropy needs labels in [0, 1]"
         fused = w is None and bool(lib.pa_rowstep_supported(net.handle, None, 0))
+        pred = torch.empty(B, 1, dtype=torch.float32, device=dev)      # act(network output)
         if fused:
             # unit weights: forward (kept), the loss gradient and the backward pass in one launch
             # (mlp_rowstep.hpp); the weight gradients stay pending for net.adam()
             net.ready(B)
-            pred = torch.empty(B, 1, dtype=torch.float32, device=dev)
-            N.check(lib.pa_wmse_rowstep(net.handle, x.data_ptr(), x.stride(0), B, y.data_ptr(),
-                                        pred.data_ptr(), dpred.data_ptr(), loss.data_ptr(), s))
+            N.check(lib.pa_wloss_rowstep(net.handle, x.data_ptr(), x.stride(0), B, y.data_ptr(),
+                                         kind, oact, None, pred.data_ptr(), dpred.data_ptr(),
+                                         loss.data_ptr(), s))
             net._pending_x = (x, dpred)
         else:
-            pred = net.forward(x, keep=True)                   # (B, 1); features stay in the engine
-            N.check(lib.pa_weighted_mse_head(pred.data_ptr(), pred.stride(0), y.data_ptr(), N.ptr(w), B,
-                                             dpred.data_ptr(), loss.data_ptr(), wsum.data_ptr(), s))
+            z = net.forward(x, keep=True)                      # (B, 1); features stay in the engine
+            N.check(lib.pa_weighted_loss_head(z.data_ptr(), z.stride(0), y.data_ptr(), N.ptr(w), B,
+                                              kind, oact, pred.data_ptr(), dpred.data_ptr(),
+                                              loss.data_ptr(), wsum.data_ptr(), s))
         # features of this forward (before the optimizer step) feed the regression: copy them out
         N.check(lib.pa_mlp_copy_activation(net.handle, len(net.layers) - 2, B, feats.data_ptr(),
                                            feats.stride(0), s))

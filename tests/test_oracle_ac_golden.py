@@ -104,23 +104,67 @@ def test_sac_probe_and_trajectory(name):
                                fx["critic_target_after"]["_critic_2._model.0.0.weight"], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["tiny", "cfg5_shape_small"])
+BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
+          "mae_cfg5_shape_small", "bce_cfg5_shape_small"]
+
+
+def bandit_batches(fx):
+    """The (state, reward, weight) batches of a bandit fixture; seeded fixtures store a checksum of
+    the contexts instead of the contexts (oracle/fixture_inputs.py)."""
+    from oracle import fixture_inputs as FI
+    for k, b in enumerate(fx["batches"]):
+        if "state" in b:
+            yield b["state"], b["reward"], b["weight"]
+        else:
+            x = FI.bandit_contexts(fx["config"], k)
+            assert FI.checksum(x) == b["state_checksum"], "regenerated contexts differ from the minted ones"
+            yield x, b["reward"], b["weight"]
+
+
+@pytest.mark.parametrize("name", BANDIT)
 def test_neural_linear_bandit_trajectory(name):
     from oracle.actor_critic_oracle import NeuralLinearOracle
     fx = load("bandit", name)
-    orc = NeuralLinearOracle(fx["model0"], lr=1e-3)
-    for b, want in zip(fx["batches"], fx["reports"]):
-        got = orc.learn_batch(b["state"], b["reward"], b["weight"])
+    cfg = fx["config"]
+    orc = NeuralLinearOracle(fx["model0"], lr=1e-3, loss_type=cfg.get("loss", "mse"),
+                             output_activation=cfg.get("out", "linear"))
+    for (x, r, w), want in zip(bandit_batches(fx), fx["reports"]):
+        got = orc.learn_batch(x, r, w)
         assert abs(float(got["loss"]) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
         torch.testing.assert_close(got["prediction"], want["prediction"], rtol=1e-5, atol=1e-6)
     after = fx["model_after"]
     torch.testing.assert_close(orc.A, after["_linear_regression_layer._A"], rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(orc.b, after["_linear_regression_layer._b"], rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(orc.coefs, after["_linear_regression_layer._coefs"], rtol=1e-3, atol=1e-5)
-    torch.testing.assert_close(orc.sigma(fx["query"]["x"]), fx["query"]["sigma"].view(-1), rtol=1e-4, atol=1e-6)
+    # (the oracle inverts in fp32 like the reference: its own backward error is the method's)
+    from helpers import assert_linear_solve_close
+    assert_linear_solve_close(orc.coefs, orc.A, orc.b, 1.0, after["_linear_regression_layer._coefs"],
+                              max_backward=5e-5, msg=name)
+    torch.testing.assert_close(orc.sigma(fx["query"]["x"]), fx["query"]["sigma"].view(-1), rtol=2e-4, atol=1e-6)
+    for i, (w_, b_) in enumerate(orc.trunk):
+        torch.testing.assert_close(w_.detach(), after[f"_nn_layers._model.{i}.0.weight"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(orc.e2e.detach(), after["linear_layer_e2e.weight"], rtol=1e-4, atol=1e-6)
 
 
-DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small"]
+def test_ppo_rollout64k_preprocess():
+    """BASELINE config 4's rollout size (65 536 transitions): GAE / lambda returns / action
+    probabilities of the reference's preprocess_replay_buffer (ppo.py:211-293) — episodes of 97
+    transitions, truncations every 131st, the bootstrap from the state after the last transition."""
+    from oracle import fixture_inputs as FI
+    fx = load("ppo", "cfg4_rollout64k")
+    cfg = fx["config"]
+    states, actions, rewards, term, trunc = FI.ppo_rollout(cfg)
+    assert FI.checksum(states) == fx["checksums"]["states"]
+    assert FI.checksum(actions) == fx["checksums"]["actions"]
+    assert FI.checksum(rewards) == fx["checksums"]["rewards"]
+    N = cfg["N"]
+    orc = PpoOracle(fx["actor0"], fx["critic0"], cfg["A"], epsilon=cfg["epsilon"])
+    gae, ret, ap = orc.preprocess(states[:N], onehot(actions, cfg["A"]), rewards, term, trunc, states[N])
+    torch.testing.assert_close(gae, fx["gae"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ret, fx["lam_return"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ap, fx["action_probs"], rtol=1e-6, atol=1e-7)
+
+
+DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small", "td3_cfg3_fullbatch"]
 
 
 @pytest.mark.parametrize("name", DDPG)
@@ -165,7 +209,7 @@ def preprocessed_dsac_batch(fx):
     return b
 
 
-@pytest.mark.parametrize("name", ["dsac_tiny", "dsac_shape_small"])
+@pytest.mark.parametrize("name", ["dsac_tiny", "dsac_shape_small", "dsac_cfg2_fullbatch"])
 def test_discrete_sac_probe_and_trajectory(name):
     from oracle.actor_critic_oracle import DiscreteSacOracle
     fx = torch.load(os.path.join(GOLDEN_DIR, f"{name}.pt"), map_location="cpu", weights_only=False)
@@ -191,7 +235,7 @@ def test_discrete_sac_probe_and_trajectory(name):
 
 
 IQL = ["iql_continuous_tiny", "iql_continuous_shape_small", "iql_discrete_tiny", "iql_gaussian_tiny",
-       "iql_gaussian_shape_small"]
+       "iql_gaussian_shape_small", "iql_continuous_fullbatch"]
 
 
 def iql_batch(fx):
@@ -257,3 +301,23 @@ def test_squarecb_host_rule_matches_reference():
     for i in range(6):
         torch.testing.assert_close(tab[i:i + 1], e.probabilities(v[i:i + 1], 4))
     assert torch.all(tab >= 0) and torch.allclose(tab.sum(1), torch.ones(6))
+
+
+def test_squarecb_cfg5_act_and_scores():
+    """BASELINE config 5's act path on the oracle: 32 arms with arm features appended to 512-dim
+    contexts, NeuralLinearBandit [256, 64] values -> the SquareCB table the reference handed to
+    Categorical, the seeded draw, and get_scores (neural_linear_bandit.py:227-311)."""
+    from oracle.actor_critic_oracle import NeuralLinearOracle, squarecb_probs
+    fx = torch.load(os.path.join(GOLDEN_DIR, "squarecb_cfg5.pt"), map_location="cpu", weights_only=False)
+    orc = NeuralLinearOracle(fx["model0"])
+    A = fx["A"]
+    for c in fx["cases"]:
+        feats = torch.cat([c["state"].view(1, -1).expand(A, -1), fx["arms"]], dim=1)
+        with torch.no_grad():
+            values = torch.nn.functional.linear(orc.features(feats), orc.e2e).view(1, A)
+        torch.testing.assert_close(values.view(-1), c["scores"].view(-1), rtol=1e-6, atol=1e-7)
+        p = squarecb_probs(values.clone(), fx["gamma"])
+        torch.testing.assert_close(p, c["probs"].view(1, -1), rtol=1e-5, atol=1e-8)
+        assert abs(float(p.sum()) - 1.0) < 1e-5 and float(p.min()) >= 0.0
+        torch.manual_seed(c["seed"])
+        assert int(torch.distributions.Categorical(c["probs"].view(-1)).sample()) == c["action"]
