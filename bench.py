@@ -174,6 +174,33 @@ def parity_probe(dev):
         res[f"max_rel_{name}"] = float((d[big] / ref.abs()[big]).max())
         res[f"max_abs_over_scale_{name}"] = float(d.max() / ref.abs().max())
     res["max_rel_q_values"] = max(res["max_rel_q"], res["max_rel_next_v"])
+    # The yardstick for those figures: the same quantities in float64 on the host (exact to 1e-16)
+    # against (a) the reference's own fp32 outputs and (b) the HIP path's — how far fp32 arithmetic
+    # itself (MKL's blocked sums there, MFMA k-ordered chains / the bf16x3 split here) is from the
+    # exact value, in the same max-relative metric.
+    p64 = {k: v.double() for k, v in fx["params0"].items()}
+    t64 = {k: v.double() for k, v in fx["target0"].items()}
+
+    def mlp64(w, x):
+        h = torch.relu(x @ w["_model.0.0.weight"].t() + w["_model.0.0.bias"])
+        h = torch.relu(h @ w["_model.1.0.weight"].t() + w["_model.1.0.bias"])
+        return (h @ w["_model.2.0.weight"].t() + w["_model.2.0.bias"]).squeeze(-1)
+
+    bc = {k: (None if v is None else v.cpu()) for k, v in
+          (("state", batch.state), ("action", batch.action), ("next_state", batch.next_state),
+           ("next_available_actions", batch.next_available_actions),
+           ("next_unavailable_actions_mask", batch.next_unavailable_actions_mask))}
+    Bn, An = bc["next_available_actions"].shape[:2]
+    q64 = mlp64(p64, torch.cat([bc["state"].double(), bc["action"].double()], dim=-1))
+    xs = torch.cat([bc["next_state"].double().unsqueeze(1).expand(Bn, An, -1),
+                    bc["next_available_actions"].double()], dim=-1)
+    nq = mlp64(t64, xs)
+    nq[bc["next_unavailable_actions_mask"]] = -float("inf")
+    nv64 = nq.max(1)[0]
+    for name, exact, k in (("q", q64, "q"), ("next_v", nv64, "next_v")):
+        big = exact.abs() >= 0.01 * exact.abs().max()
+        for who, val in (("reference", want[k].double()), ("hip", out[k].double().cpu())):
+            res[f"{who}_vs_float64_max_rel_{name}"] = float(((val - exact).abs()[big] / exact.abs()[big]).max())
     return res
 
 

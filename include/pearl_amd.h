@@ -336,6 +336,19 @@ int pa_comm_create(pa_comm** out, int32_t device, int32_t world, int32_t rank, c
 int pa_comm_destroy(pa_comm* c);
 /* the rank count / rank RCCL itself reports for the communicator (ncclCommCount, ncclCommUserRank) */
 int pa_comm_info(pa_comm* c, int32_t* ranks_out, int32_t* rank_out);
+/* The same hooks on a ONE-SHOT PEER-TO-PEER exchange instead of RCCL (the
+ * per-round message — 413 KB for the DQN of BASELINE config 2 — is latency-bound, and xGMI is point
+ * to point): every rank owns one device buffer its peers map through hipIpc; a round is "copy my
+ * gradient into my slot, publish a round counter, wait for the peers' counters, add the G slots in
+ * rank order" — two launches on the learner stream, no ring, bitwise-identical sums on every rank.
+ * Bring-up: every rank calls pa_comm_create_p2p (world <= 8, messages of up to max_floats floats),
+ * exchanges pa_comm_p2p_handle()'s 64 bytes with its peers (torch.distributed in pearl_amd/_comm.py)
+ * and maps them with pa_comm_p2p_open; pa_comm_allreduce_start / _wait / pa_comm_info / _destroy
+ * then work as above.  pa_comm_p2p_check: PA_ERR_HIP once a bounded wait for a peer has expired. */
+int pa_comm_create_p2p(pa_comm** out, int32_t device, int32_t world, int32_t rank, int64_t max_floats);
+int pa_comm_p2p_handle(pa_comm* c, void* handle64_out);
+int pa_comm_p2p_open(pa_comm* c, int32_t peer, const void* handle64);
+int pa_comm_p2p_check(pa_comm* c);
 int pa_comm_allreduce_start(void* comm, float* buf, int64_t n, void* stream);
 int pa_comm_allreduce_wait(void* comm, void* stream);
 
@@ -837,6 +850,11 @@ int pa_debug_set_prof_target(pa_dqn* h, long long* stamps, int32_t max_tiles);
 int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, float* C,
                     int32_t ldc, const float* bias, const float* hmask, int32_t ldh, int32_t M,
                     int32_t N, int32_t K, int32_t b_is_kn, int32_t epi, void* stream);
+/* Which main loop the weight-gradient launches take: -1 = by environment (PEARL_AMD_DW_SPLIT,
+ * default on), 0 = fp32 MFMA everywhere, 1 = the bf16x3 split loop (v_mfma_f32_16x16x32_bf16 on
+ * exactly split operands, fp32 accuracy) for batches of >= 2048 rows with aligned operands,
+ * 2 = the same below the batch threshold (tests). */
+int pa_debug_set_dw_split(int32_t mode);
 /* dW[M,N] = dZ[Bn,M]^T X[Bn,N], db[M] = column sums of dZ. */
 int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx, float* dW,
                          int32_t ldw, float* db, int32_t M, int32_t N, int32_t Bn, void* stream);

@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 from . import _native as N
 
-_state = {"handle": None, "failed": False, "device": None}
+_state = {"handle": None, "failed": False, "device": None, "kind": None}
 
 
 def world_size() -> int:
@@ -37,6 +37,8 @@ def native_comm(dev: torch.device) -> Optional[C.c_void_p]:
     if _state["failed"]:
         return None     # RCCL bring-up failed on some rank: torch.distributed instead
     lib = N.lib()
+    if os.environ.get("PEARL_AMD_P2P") == "1":
+        return _p2p_comm(dev)
     if dist.get_backend() != "nccl" or not lib.pa_comm_available():
         return None
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -65,7 +67,47 @@ def native_comm(dev: torch.device) -> Optional[C.c_void_p]:
     N.check(lib.pa_comm_allreduce_start(handle, warm.data_ptr(), warm.numel(), N.stream_ptr(dev)))
     N.check(lib.pa_comm_allreduce_wait(handle, N.stream_ptr(dev)))
     torch.cuda.synchronize(dev)
-    _state["handle"], _state["device"] = handle, dev
+    _state["handle"], _state["device"], _state["kind"] = handle, dev, "rccl"
+    return handle
+
+
+def _p2p_comm(dev: torch.device) -> Optional[C.c_void_p]:
+    """PEARL_AMD_P2P=1: the one-shot peer-to-peer gradient exchange (comm.hip) behind
+    the same hooks — every rank allocates its exchange buffer, the 64-byte hipIpc handles travel
+    through torch.distributed (any backend), every rank maps its peers' buffers, and all ranks
+    agree on the outcome before the first exchange.  Messages of up to PEARL_AMD_P2P_FLOATS floats
+    (default 2 M = 8 MB per slot); world size <= 8 (one node)."""
+    lib = N.lib()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    handle = C.c_void_p()
+    ok_local = world <= 8
+    if ok_local:
+        floats = int(os.environ.get("PEARL_AMD_P2P_FLOATS", str(2 << 20)))
+        ok_local = lib.pa_comm_create_p2p(C.byref(handle), dev.index, world, rank, floats) == 0
+    mine = (C.c_char * 64)()
+    if ok_local:
+        ok_local = lib.pa_comm_p2p_handle(handle, mine) == 0
+    everyone = [None] * world
+    dist.all_gather_object(everyone, (bool(ok_local), bytes(mine.raw)))
+    ok = all(e[0] for e in everyone)
+    if ok:
+        for r, (_, raw) in enumerate(everyone):
+            if r != rank and lib.pa_comm_p2p_open(handle, r, raw) != 0:
+                ok = False
+    verdict = [None] * world
+    dist.all_gather_object(verdict, bool(ok))
+    if not all(verdict):
+        if handle:
+            lib.pa_comm_destroy(handle)
+        _state["failed"] = True
+        return None
+    # one exchange outside any learner step: first-use costs, and a check that every peer answers
+    warm = torch.ones(256, dtype=torch.float32, device=dev)
+    N.check(lib.pa_comm_allreduce_start(handle, warm.data_ptr(), warm.numel(), N.stream_ptr(dev)))
+    torch.cuda.synchronize(dev)
+    N.check(lib.pa_comm_p2p_check(handle))
+    assert float(warm[0]) == float(world), "P2P exchange: the warm-up sum is wrong"
+    _state["handle"], _state["device"], _state["kind"] = handle, dev, "p2p"
     return handle
 
 
@@ -80,7 +122,9 @@ def comm_info() -> dict:
         return info
     n_seen, me = C.c_int32(-1), C.c_int32(-1)
     N.check(N.lib().pa_comm_info(h, C.byref(n_seen), C.byref(me)))
-    info.update(library="rccl (native pa_comm_* hooks)", ranks_observed=n_seen.value, rank=me.value)
+    lib_name = ("one-shot P2P over hipIpc-mapped peer buffers (native pa_comm_* hooks)"
+                if _state["kind"] == "p2p" else "rccl (native pa_comm_* hooks)")
+    info.update(library=lib_name, ranks_observed=n_seen.value, rank=me.value)
     return info
 
 

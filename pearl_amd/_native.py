@@ -338,6 +338,10 @@ SIGNATURES = {
     "pa_comm_create": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_comm_destroy": (C.c_int, [_P]),
     "pa_comm_info": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pa_comm_create_p2p": (C.c_int, [C.POINTER(_P), C.c_int32, C.c_int32, C.c_int32, C.c_int64]),
+    "pa_comm_p2p_handle": (C.c_int, [_P, _P]),
+    "pa_comm_p2p_open": (C.c_int, [_P, C.c_int32, _P]),
+    "pa_comm_p2p_check": (C.c_int, [_P]),
     "pa_comm_allreduce_start": (C.c_int, [_P, _P, C.c_int64, _P]),
     "pa_comm_allreduce_wait": (C.c_int, [_P, _P]),
     "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
@@ -439,6 +443,7 @@ SIGNATURES = {
     "pa_sac_timing": (C.c_int, [C.c_int32]),
     "pa_sac_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_mlp_timing": (C.c_int, [C.c_int32]),
+    "pa_debug_set_dw_split": (C.c_int, [C.c_int32]),
     "pa_mlp_timing_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_sac_alpha_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32, C.c_float, C.c_double,
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,

@@ -526,6 +526,17 @@ int bind_process_device(int device) {
   return PA_OK;
 }
 void release_process_device() { g_live_handles.fetch_sub(1); }
+
+static std::atomic<int> g_dw_split_mode{-1};
+int dw_split_mode() {
+  int m = g_dw_split_mode.load();
+  if (m < 0) {
+    const char* v = getenv("PEARL_AMD_DW_SPLIT");
+    m = (v && v[0] == '0') ? 0 : 1;
+  }
+  return m;
+}
+void set_dw_split_mode(int mode) { g_dw_split_mode.store(mode); }
 }  // namespace pa
 
 extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {

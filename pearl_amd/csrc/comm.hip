@@ -64,12 +64,29 @@ Rccl* rccl() {
 
 }  // namespace
 
+// One-shot peer-to-peer exchange (pa_comm_create_p2p): every rank owns one device allocation
+//   [2 slots][max_floats] floats | flag word (the latest round published)
+// that its peers map through hipIpc.  SURVEY.md §8(e): the per-round message is 413 KB — latency,
+// not bandwidth — so every rank READS the other G - 1 buffers directly over its own xGMI links
+// (point to point: seven links, seven peers) and adds them up itself, instead of a ring's 2 (G - 1)
+// dependent hops.
+constexpr int kP2PMaxWorld = 8;
+struct P2P {
+  float* mine = nullptr;            // this rank's allocation
+  float* peer[kP2PMaxWorld] = {};   // peer[r]: rank r's allocation as mapped here (peer[rank] = mine)
+  int64_t max_floats = 0;
+  unsigned round = 0;               // rounds published so far (host copy)
+  int* err_host = nullptr;          // pinned, device-mapped: non-zero = a bounded wait expired
+  int opened = 0;
+};
+
 struct pa_comm {
   NcclComm comm;
   int device, world, rank;
   hipStream_t stream;      // the exchange stream (PEARL_AMD_COMM_INLINE=0 only)
   hipEvent_t ready, done;  // learner stream -> exchange stream -> learner stream
   int inline_mode;         // 1 (default): the collective is enqueued on the learner stream itself
+  P2P* p2p;                // non-null: the one-shot peer-to-peer exchange instead of RCCL
 };
 
 #define PA_NCCL(expr)                                                                      \
@@ -123,9 +140,178 @@ extern "C" int pa_comm_create(pa_comm** out, int32_t device, int32_t world, int3
   return PA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-shot P2P all-reduce (deterministic: every rank adds the G buffers in rank order, so all
+// ranks hold bitwise-identical sums).  Two launches on the caller's stream per exchange:
+//   p2p_publish_kernel   grad -> this rank's slot (round & 1), 16-byte stores.  The end of a kernel
+//                        is a system-scope release: the slot is visible to the peers once the
+//                        launch has completed.
+//   p2p_reduce_kernel    thread 0 of block 0 publishes flag = round (system scope); every block
+//                        waits (bounded) until every peer's flag has reached `round`, acquires at
+//                        system scope, and writes grad[j] = sum_r slot_r[j], r = 0 .. G - 1.
+// Two slots are enough: a rank rewrites slot (round & 1) two rounds later, after its own reduce of
+// round + 1 — which waited for every peer's flag >= round + 1, and a peer publishes round + 1 only
+// after its reduce of `round` has finished reading.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct P2PArgs {
+  float* grad; long long n;
+  float* mine_slot;
+  const float* slot[kP2PMaxWorld];        // every rank's slot of this round (own included)
+  unsigned* flag_mine;
+  const unsigned* flag[kP2PMaxWorld];
+  int world, rank;
+  unsigned round;
+  int* err;
+};
+__global__ __launch_bounds__(256) void p2p_publish_kernel(P2PArgs a) {
+  const long long n4 = a.n >> 2;
+  const float4* src = reinterpret_cast<const float4*>(a.grad);
+  float4* dst = reinterpret_cast<float4*>(a.mine_slot);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+    dst[i] = src[i];
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) a.mine_slot[i] = a.grad[i];
+}
+__global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (the publish launch has completed: its stores are released at system scope already; the
+    //  fence keeps this store behind anything else this thread has issued)
+    __atomic_thread_fence(__ATOMIC_RELEASE);
+    __hip_atomic_store(a.flag_mine, a.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank) {
+    const unsigned* f = a.flag[threadIdx.x];
+    int spins = 0;
+    // rounds compare modulo 2^32 (a peer is at most one round ahead)
+    while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.round) < 0) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1 << 22)) {   // seconds: a peer is gone — report, do not hang the GPU
+        if (a.err) *a.err = 1 + (int)threadIdx.x;
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: nothing below reads a stale line
+  const long long n4 = a.n >> 2;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 acc = reinterpret_cast<const float4*>(a.slot[0])[i];
+    for (int r = 1; r < a.world; ++r) {
+      const float4 v = reinterpret_cast<const float4*>(a.slot[r])[i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(a.grad)[i] = acc;
+  }
+  if (blockIdx.x == 0)
+    for (long long i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) {
+      float acc = a.slot[0][i];
+      for (int r = 1; r < a.world; ++r) acc += a.slot[r][i];
+      a.grad[i] = acc;
+    }
+}
+constexpr int kP2PFlagFloats = 64;   // the flag word gets a 256-byte line of its own
+}  // namespace
+
+// A communicator whose all-reduce is the one-shot P2P exchange above.  Bring-up: every rank creates
+// one, hands pa_comm_p2p_handle()'s 64 bytes to every other rank (torch.distributed carries them),
+// and opens its peers' with pa_comm_p2p_open(); pa_comm_allreduce_start / _wait then work as for
+// the RCCL communicator (messages of up to max_floats floats, 16-byte aligned).
+extern "C" int pa_comm_create_p2p(pa_comm** out, int32_t device, int32_t world, int32_t rank,
+                                  int64_t max_floats) {
+  PA_REQUIRE(out && world >= 1 && world <= kP2PMaxWorld && rank >= 0 && rank < world && max_floats > 0,
+             PA_ERR_INVALID, "pa_comm_create_p2p: bad argument (1 <= world <= 8)");
+  PA_HIP(hipSetDevice(device));
+  pa_comm* c = new (std::nothrow) pa_comm();
+  PA_REQUIRE(c, PA_ERR_NOMEM, "out of host memory");
+  memset(c, 0, sizeof(*c));
+  c->device = device; c->world = world; c->rank = rank;
+  c->inline_mode = 1;
+  c->p2p = new (std::nothrow) P2P();
+  PA_REQUIRE(c->p2p, PA_ERR_NOMEM, "out of host memory");
+  P2P* x = c->p2p;
+  x->max_floats = (max_floats + 63) / 64 * 64;
+  const size_t bytes = (size_t)(2 * x->max_floats + kP2PFlagFloats) * sizeof(float);
+  PA_HIP(hipMalloc((void**)&x->mine, bytes));
+  PA_HIP(hipMemset(x->mine, 0, bytes));
+  PA_HIP(hipDeviceSynchronize());
+  PA_HIP(hipHostMalloc((void**)&x->err_host, 16, hipHostMallocMapped));
+  x->err_host[0] = 0;
+  x->peer[rank] = x->mine;
+  x->opened = 1;
+  *out = c;
+  return PA_OK;
+}
+extern "C" int pa_comm_p2p_handle(pa_comm* c, void* handle64_out) {
+  PA_REQUIRE(c && c->p2p && handle64_out, PA_ERR_INVALID, "pa_comm_p2p_handle: not a P2P communicator");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  hipIpcMemHandle_t h;
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipIpcGetMemHandle(&h, c->p2p->mine));
+  memcpy(handle64_out, &h, sizeof(h));
+  return PA_OK;
+}
+extern "C" int pa_comm_p2p_open(pa_comm* c, int32_t peer, const void* handle64) {
+  PA_REQUIRE(c && c->p2p && handle64 && peer >= 0 && peer < c->world && peer != c->rank,
+             PA_ERR_INVALID, "pa_comm_p2p_open: bad argument");
+  PA_REQUIRE(!c->p2p->peer[peer], PA_ERR_INVALID, "pa_comm_p2p_open: peer %d is open already", peer);
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, sizeof(h));
+  PA_HIP(hipSetDevice(c->device));
+  void* p = nullptr;
+  PA_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+  c->p2p->peer[peer] = static_cast<float*>(p);
+  c->p2p->opened += 1;
+  return PA_OK;
+}
+// non-zero status when a bounded wait for a peer expired since the communicator was created
+extern "C" int pa_comm_p2p_check(pa_comm* c) {
+  PA_REQUIRE(c && c->p2p, PA_ERR_INVALID, "pa_comm_p2p_check: not a P2P communicator");
+  PA_REQUIRE(c->p2p->err_host[0] == 0, PA_ERR_HIP,
+             "P2P exchange: the wait for rank %d's gradient expired; the sums of that round are invalid",
+             c->p2p->err_host[0] - 1);
+  return PA_OK;
+}
+
+namespace {
+int p2p_allreduce(pa_comm* c, float* buf, int64_t n, hipStream_t s) {
+  P2P* x = c->p2p;
+  if (x->opened != c->world || n > x->max_floats || (reinterpret_cast<uintptr_t>(buf) & 15)) return 1;
+  x->round += 1;
+  const int slot = (int)(x->round & 1u);
+  P2PArgs a;
+  memset(&a, 0, sizeof(a));
+  a.grad = buf; a.n = n;
+  a.mine_slot = x->mine + (int64_t)slot * x->max_floats;
+  a.flag_mine = reinterpret_cast<unsigned*>(x->mine + 2 * x->max_floats);
+  for (int r = 0; r < c->world; ++r) {
+    a.slot[r] = x->peer[r] + (int64_t)slot * x->max_floats;
+    a.flag[r] = reinterpret_cast<const unsigned*>(x->peer[r] + 2 * x->max_floats);
+  }
+  a.world = c->world; a.rank = c->rank; a.round = x->round;
+  a.err = x->err_host;
+  unsigned grid = (unsigned)((n / 4 + 255) / 256);
+  if (grid > 208) grid = 208;   // one wave of blocks: every block polls the peers' flags once
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(p2p_publish_kernel, dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(p2p_reduce_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+}  // namespace
+
 extern "C" int pa_comm_destroy(pa_comm* c) {
   if (!c) return PA_OK;
   (void)hipSetDevice(c->device);
+  if (c->p2p) {
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < c->world; ++r)
+      if (r != c->rank && c->p2p->peer[r]) (void)hipIpcCloseMemHandle(c->p2p->peer[r]);
+    if (c->p2p->mine) (void)hipFree(c->p2p->mine);
+    if (c->p2p->err_host) (void)hipHostFree(c->p2p->err_host);
+    delete c->p2p;
+    delete c;
+    return PA_OK;
+  }
   (void)hipStreamSynchronize(c->stream);
   Rccl* r = rccl();
   if (r && c->comm) (void)r->destroy(c->comm);
@@ -140,6 +326,10 @@ extern "C" int pa_comm_destroy(pa_comm* c) {
 // already enqueued on `stream`.
 extern "C" int pa_comm_allreduce_start(void* ctx, float* buf, int64_t n, void* stream) {
   pa_comm* c = reinterpret_cast<pa_comm*>(ctx);
+  if (c && c->p2p) {
+    if (!buf || n <= 0) return 1;
+    return p2p_allreduce(c, buf, n, reinterpret_cast<hipStream_t>(stream));
+  }
   Rccl* r = rccl();
   if (!c || !r || !buf || n <= 0) return 1;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -170,6 +360,11 @@ extern "C" int pa_comm_allreduce_wait(void* ctx, void* stream) {
 // observed, as opposed to the one the caller asked for.  -1 where the library has no such query.
 extern "C" int pa_comm_info(pa_comm* c, int32_t* ranks_out, int32_t* rank_out) {
   PA_REQUIRE(c, PA_ERR_INVALID, "pa_comm_info: null communicator");
+  if (c->p2p) {   // the buffers actually mapped (own + opened peers), not the world that was asked for
+    if (ranks_out) *ranks_out = c->p2p->opened;
+    if (rank_out) *rank_out = c->rank;
+    return PA_OK;
+  }
   Rccl* r = rccl();
   PA_REQUIRE(r, PA_ERR_UNSUPPORTED, "RCCL is not available");
   int n = -1, me = -1;

@@ -18,6 +18,10 @@ void set_error(const char* fmt, ...);
 int bind_process_device(int device);
 // every successful bind_process_device is paired with one release when its handle is destroyed
 void release_process_device();
+// weight-gradient main loop: -1 = by environment (PEARL_AMD_DW_SPLIT, default on), 0 = fp32 MFMA
+// everywhere, 1 = the bf16x3 split loop where eligible, 2 = also below the batch threshold (tests)
+int dw_split_mode();
+void set_dw_split_mode(int mode);
 
 #define PA_HIP(expr)                                                             \
   do {                                                                           \

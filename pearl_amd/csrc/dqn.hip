@@ -1740,6 +1740,12 @@ extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int3
   return b_is_kn ? launch_linear<true>(&g, 1, s) : launch_linear<false>(&g, 1, s);
 }
 
+extern "C" int pa_debug_set_dw_split(int32_t mode) {
+  PA_REQUIRE(mode >= -1 && mode <= 2, PA_ERR_INVALID, "pa_debug_set_dw_split: mode is -1, 0, 1 or 2");
+  set_dw_split_mode(mode);
+  return PA_OK;
+}
+
 extern "C" int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx,
                                     float* dW, int32_t ldw, float* db, int32_t M, int32_t N,
                                     int32_t Bn, void* stream) {

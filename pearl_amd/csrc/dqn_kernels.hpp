@@ -985,6 +985,11 @@ struct DwArgs {
   // instead of four: twice the workgroups for launches that have the CUs for them (the DQN chain
   // once the target pass needs fewer: 105 workgroups, 3.5 us of MFMA each instead of 7)
   int tm;
+  // 1: weight_grad_split_kernel — the main loop on the bf16 matrix pipe at fp32 accuracy (every
+  // operand split exactly three ways, six products, dw_mainloop_split below): launches whose tiles
+  // are MFMA-bound (thousands of batch rows per workgroup).  The host sets it only when every
+  // matrix problem of the launch has 16-byte-aligned dZ rows and 8-byte-aligned X rows.
+  int split;
   float* kscratch;       // [total_tiles][ksplit][DW_TM * DW_TN + DW_TM]
   unsigned* ktickets;    // [total_tiles], zero between launches
 };
@@ -1159,6 +1164,168 @@ __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same partial tile on the bf16 matrix pipe at fp32 accuracy (DwArgs::split; DESIGN.md §3.5 is
+// the arithmetic): v_mfma_f32_16x16x32_bf16 takes 32 batch rows per instruction, a lane holding 8
+// CONSECUTIVE rows (k = 8 (lane >> 4) + e) of one unit / one column.  With operands that are
+// row-major in the batch that is eight wide loads per operand and step — row 8 q + r of the step,
+// r = 0 .. 7, the same 16- / 8-byte vectors as the fp32 loop — and the eight values of a unit are
+// already in the lane that needs them: split each exactly into hi + mid + lo (split3), pack the
+// planes into the 8-element fragments, six products per (unit, column) position:
+//     small += a_lo x_hi + a_hi x_lo + a_mid x_mid + a_hi x_mid + a_mid x_hi ;  main += a_hi x_hi
+// (two accumulators: the five small classes are never rounded against the running main sum; they
+// are added once at the end).  A and B share the row <-> (lane group, element) map, so the sum over
+// rows does not depend on how the hardware orders k inside an instruction.  Per 32-row step a wave
+// issues 16 loads, ~260 VALU (the splits) and 48 MFMAs of 16 passes: 2.7x the fp32 loop's 64 MFMAs
+// of 32.  Accumulator layout = the fp32 loop's: everything after the main loop is shared.
+// ---------------------------------------------------------------------------
+template <int UPL>
+struct DwRaw32 {
+  float a[8][UPL];
+  float x[8][2];
+};
+template <int UPL>
+__device__ __forceinline__ void dw_fetch32(const __amdgpu_buffer_rsrc_t& ra,
+                                           const __amdgpu_buffer_rsrc_t& rx, unsigned va, unsigned vx,
+                                           unsigned ba, unsigned bx, unsigned lda4, unsigned ldx4,
+                                           DwRaw32<UPL>& f) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  static_assert(UPL == 4, "16-byte loads of dZ");
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va + ba + (unsigned)r * lda4), 0, 0);
+    const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
+    f.a[r][0] = f4[0]; f.a[r][1] = f4[1]; f.a[r][2] = f4[2]; f.a[r][3] = f4[3];
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(vx + bx + (unsigned)r * ldx4), 0, 0);
+    const f32x2 f2 = __builtin_bit_cast(f32x2, w);
+    f.x[r][0] = f2[0]; f.x[r][1] = f2[1];
+  }
+}
+// v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even) in one dword, a in the low half
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
+}
+// split3 of 8 rows x 2 ADJACENT units (the two floats of one 8-byte piece of every row: adjacent
+// registers, so the residuals are packed-fp32 subtractions): 4.5 VALU per element —
+//   per (2 rows x 2 units): 2 cvt_pk, 2 lshl + 2 and (the bf16 back as fp32), 2 v_pk_add -> r;
+//   the same -> s; 2 cvt_pk.  Element e of a fragment = row e (k = 8 (lane >> 4) + e).
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split8x2(const dw_f32x2 (&v)[8], bf16x8 (&hi)[2], bf16x8 (&mid)[2],
+                                         bf16x8 (&lo)[2]) {
+  u32x4 H[2], M[2], L[2];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const dw_f32x2 xa = v[2 * p], xb = v[2 * p + 1];          // rows 2p, 2p + 1: (unit 0, unit 1)
+    const unsigned h0 = cvt_pk_bf16(xa[0], xb[0]), h1 = cvt_pk_bf16(xa[1], xb[1]);
+    const dw_f32x2 ha = {__builtin_bit_cast(float, h0 << 16), __builtin_bit_cast(float, h1 << 16)};
+    const dw_f32x2 hb = {__builtin_bit_cast(float, h0 & 0xffff0000u),
+                         __builtin_bit_cast(float, h1 & 0xffff0000u)};
+    const dw_f32x2 ra = xa - ha, rb = xb - hb;                // exact
+    const unsigned m0 = cvt_pk_bf16(ra[0], rb[0]), m1 = cvt_pk_bf16(ra[1], rb[1]);
+    const dw_f32x2 ma = {__builtin_bit_cast(float, m0 << 16), __builtin_bit_cast(float, m1 << 16)};
+    const dw_f32x2 mb = {__builtin_bit_cast(float, m0 & 0xffff0000u),
+                         __builtin_bit_cast(float, m1 & 0xffff0000u)};
+    const dw_f32x2 sa = ra - ma, sb = rb - mb;                // exact; bf16(s) is exact too
+    H[0][p] = h0; H[1][p] = h1;
+    M[0][p] = m0; M[1][p] = m1;
+    L[0][p] = cvt_pk_bf16(sa[0], sb[0]); L[1][p] = cvt_pk_bf16(sa[1], sb[1]);
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    hi[u] = __builtin_bit_cast(bf16x8, H[u]);
+    mid[u] = __builtin_bit_cast(bf16x8, M[u]);
+    lo[u] = __builtin_bit_cast(bf16x8, L[u]);
+  }
+}
+// va / vx: byte offset of this lane's vector in row 8 q of a step (kBufOob: outside the operand);
+// oa / ox: byte offset of the wave's first row.
+template <int UPL, typename Hook>
+__device__ __forceinline__ void dw_mainloop_split(const __amdgpu_buffer_rsrc_t& ra,
+                                                  const __amdgpu_buffer_rsrc_t& rx, unsigned va,
+                                                  unsigned vx, unsigned oa, unsigned ox,
+                                                  unsigned lda4, unsigned ldx4, int nsteps,
+                                                  dw_f32x4 (&acc)[UPL][2], float (&cs)[UPL],
+                                                  Hook after_prologue) {
+  static_assert(UPL == 4, "two pairs of adjacent units per lane");
+  dw_f32x4 small[UPL][2];
+#pragma unroll
+  for (int ja = 0; ja < UPL; ++ja) {
+    acc[ja][0] = acc[ja][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    small[ja][0] = small[ja][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
+    cs[ja] = 0.f;
+  }
+  const unsigned sa32 = 32u * lda4, sx32 = 32u * ldx4;
+  // one 32-row step: split the raw rows three ways, then the six product classes, each over the
+  // eight (unit block, column block) positions — consecutive MFMAs write different accumulators
+  // (no back-to-back dependent chain)
+  auto work = [&](const DwRaw32<UPL>& cur) {
+    bf16x8 xh[2], xm[2], xl[2], ah[UPL], am[UPL], al[UPL];
+    {
+      dw_f32x2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = dw_f32x2{cur.x[r][0], cur.x[r][1]};
+      split8x2(v, xh, xm, xl);
+    }
+#pragma unroll
+    for (int jp = 0; jp < UPL; jp += 2) {
+      dw_f32x2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        v[r] = dw_f32x2{cur.a[r][jp], cur.a[r][jp + 1]};
+        cs[jp] += cur.a[r][jp];
+        cs[jp + 1] += cur.a[r][jp + 1];
+      }
+      bf16x8 h2[2], m2[2], l2[2];
+      split8x2(v, h2, m2, l2);
+      ah[jp] = h2[0]; ah[jp + 1] = h2[1];
+      am[jp] = m2[0]; am[jp + 1] = m2[1];
+      al[jp] = l2[0]; al[jp + 1] = l2[1];
+    }
+#define PA_DW_CLASS(A_, X_, ACC_)                                                          \
+  _Pragma("unroll") for (int ja = 0; ja < UPL; ++ja)                                        \
+  _Pragma("unroll") for (int jx = 0; jx < 2; ++jx)                                          \
+      ACC_[ja][jx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A_[ja], X_[jx], ACC_[ja][jx], 0, 0, 0);
+    PA_DW_CLASS(al, xh, small)
+    PA_DW_CLASS(ah, xl, small)
+    PA_DW_CLASS(am, xm, small)
+    PA_DW_CLASS(ah, xm, small)
+    PA_DW_CLASS(am, xh, small)
+    PA_DW_CLASS(ah, xh, acc)
+#undef PA_DW_CLASS
+  };
+  // two raw buffers in ping-pong (nsteps is even: the host-side slice is a multiple of 512 rows):
+  // the next step's sixteen loads are in flight under this step's splits and MFMAs, and nothing
+  // is copied between them
+  DwRaw32<UPL> ra0, ra1;
+  auto fetch = [&](int step, DwRaw32<UPL>& f) {
+    const bool live = step < nsteps;    // steps past the slice must not read the next wave's rows
+    dw_fetch32<UPL>(ra, rx, va, vx, live ? oa + (unsigned)step * sa32 : kDwDead,
+                    live ? ox + (unsigned)step * sx32 : kDwDead, lda4, ldx4, f);
+  };
+  fetch(0, ra0);
+  after_prologue();
+  for (int s = 0; s < nsteps; s += 2) {
+    fetch(s + 1, ra1);
+    __builtin_amdgcn_sched_barrier(0);
+    work(ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(s + 2, ra0);
+    __builtin_amdgcn_sched_barrier(0);
+    work(ra1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int ja = 0; ja < UPL; ++ja)
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ja][jx][r] += small[ja][jx][r];
+}
+
 __device__ __forceinline__ void sac_step_tail(const TailJob& t, float* lds, int tid) {
   float sa = 0.f, sb = 0.f;
   for (int base = 0; base < t.tiles; base += 256) {
@@ -1204,7 +1371,7 @@ __device__ __forceinline__ void sac_step_tail(const TailJob& t, float* lds, int 
 
 // UPL = units per lane: 4 -> 64-row tiles (one 16-byte load of dZ per step), 2 -> 32-row tiles
 // (8-byte loads); everything below is written for TM = 16 UPL.
-template <int UPL>
+template <int UPL, bool SPLIT = false>
 __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, float* csum) {
   constexpr int TM = 16 * UPL;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1318,8 +1485,11 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
   const unsigned sa = (unsigned)P.ldz * 16u, sx = (unsigned)P.ldx * 16u;  // bytes per 4-row step
   // this workgroup's slice of the batch (all of it unless ksplit > 1), this wave's share of that:
   // nsteps 4-row steps
-  const int bslice = ((a.B + KSP - 1) / KSP + 31) / 32 * 32;
-  const int nsteps = bslice / 32, row0 = kslice * bslice + wave * nsteps * 4;
+  // (SPLIT: 32-row steps, so a wave's share is a multiple of 32 rows; rows past the batch read as
+  //  zeros by the descriptors' range check, as above)
+  constexpr int SLICE_Q = SPLIT ? 512 : 32;   // (SPLIT: an even number of 32-row steps per wave)
+  const int bslice = ((a.B + KSP - 1) / KSP + SLICE_Q - 1) / SLICE_Q * SLICE_Q;
+  const int nsteps = SPLIT ? bslice / 256 : bslice / 32, row0 = kslice * bslice + wave * (bslice / 8);
   const unsigned oa = (unsigned)row0 * (unsigned)P.ldz * 4u, ox = (unsigned)row0 * (unsigned)P.ldx * 4u;
   // Epilogue assignment, fixed now so that the optimizer state can be fetched under the main
   // loop: thread -> tile row tid >> 3, columns 4 (tid & 7) .. + 3.  evec: the four elements are one
@@ -1345,8 +1515,16 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
   dw_f32x4 acc[UPL][2];
   float cs[UPL];
   PA_STAMP(a.prof, blockIdx.x, wave, 1);
-  if (fa && fx) dw_mainloop<true, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
-  else dw_mainloop<false, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+  if constexpr (SPLIT) {
+    // (host contract: fa && fx for every matrix problem of a split launch)
+    const unsigned lda4 = (unsigned)P.ldz * 4u, ldx4 = (unsigned)P.ldx * 4u;
+    const unsigned va8 = (ua < P.M) ? (unsigned)(8 * q * P.ldz + ua) * 4u : kBufOob;
+    const unsigned vx8 = (cx < P.N) ? (unsigned)(8 * q * P.ldx + cx) * 4u : kBufOob;
+    dw_mainloop_split<UPL>(ra, rx, va8, vx8, oa, ox, lda4, ldx4, nsteps, acc, cs, prefetch_state);
+  } else {
+    if (fa && fx) dw_mainloop<true, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+    else dw_mainloop<false, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+  }
   PA_STAMP(a.prof, blockIdx.x, wave, 2);
   // ---- partial tiles: (waves 4..7 -> LDS, waves 0..3 add), then (waves 0..3 -> LDS, all sum)
   // element id of acc[ja][jx][reg] on `lane`: ((ja * 2 + jx) * 4 + reg) * 64 + lane
@@ -1532,6 +1710,12 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_kernel32(DwArgs a) 
   __shared__ float part[4 * 32 * DW_TN];
   __shared__ float csum[8 * 32];
   weight_grad_body<2>(a, part, csum);
+}
+// DwArgs::split == 1: 64-row tiles, main loop on v_mfma_f32_16x16x32_bf16 (dw_mainloop_split)
+static __global__ __launch_bounds__(512, 2) void weight_grad_split_kernel(DwArgs a) {
+  __shared__ float part[4 * DW_TM * DW_TN];
+  __shared__ float csum[8 * DW_TM];
+  weight_grad_body<4, true>(a, part, csum);
 }
 
 // ---------------------------------------------------------------------------

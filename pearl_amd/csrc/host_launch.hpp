@@ -194,7 +194,24 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
     a.ktickets = tickets;
   }
   const unsigned grid = (unsigned)(a.total_tiles * ks) + (loss_wg ? 1u : 0u);
+  // Batches whose tiles are MFMA-bound (>= PEARL_AMD_DW_MINB rows: PPO's and the bandit's 4096) run
+  // the main loop on the bf16 matrix pipe at fp32 accuracy (weight_grad_split_kernel: 2.7x the fp32
+  // matrix rate) when every matrix problem has whole, aligned 16- / 8-byte operand vectors.
+  // PEARL_AMD_DW_SPLIT=0: the fp32-MFMA kernel everywhere.
+  const int split_mode = dw_split_mode();   // pa_debug_set_dw_split / PEARL_AMD_DW_SPLIT
+  a.split = 0;
+  if (split_mode > 0 && a.tm != 32 && (a.B >= min_b || split_mode == 2)) {
+    bool ok = true;
+    for (int k = 0; k < a.nprob; ++k) {
+      const DwProblem& P = a.p[k];
+      if (P.M == 1) continue;   // the GEMV path
+      ok = ok && (P.ldz & 3) == 0 && (P.M & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dZ) & 15) == 0 &&
+           (P.ldx & 1) == 0 && (P.N & 1) == 0 && (reinterpret_cast<uintptr_t>(P.X) & 7) == 0;
+    }
+    a.split = ok ? 1 : 0;
+  }
   if (a.tm == 32) hipLaunchKernelGGL(weight_grad_kernel32, dim3(grid), dim3(512), 0, s, a);
+  else if (a.split) hipLaunchKernelGGL(weight_grad_split_kernel, dim3(grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;

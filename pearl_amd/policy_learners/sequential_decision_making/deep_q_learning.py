@@ -208,27 +208,50 @@ class DeepQLearning(PolicyLearner):
         return self._Q.state_dim, self._Q.action_dim, l1.out_features, l2.out_features
 
     def _param_pairs(self) -> List[Tuple[torch.nn.Parameter, torch.nn.Parameter]]:
+        # (straight out of the modules' parameter dicts: nn.Module.__getattr__ costs 0.6 us per
+        #  `layer.weight`, and learn() walks the twelve of them several times per call — the host
+        #  side of a short learn() call is measured in those microseconds, tools/shortcall.py)
+        memo = self.__dict__.get("_pairs_memo")     # set for the duration of one learn() call
+        if memo is not None:
+            return memo
         out = []
         for lq, lt in zip(*self._linears()):
-            out.append((lq.weight, lt.weight))
-            out.append((lq.bias, lt.bias))
+            pq, pt = lq._parameters, lt._parameters
+            out.append((pq["weight"], pt["weight"]))
+            out.append((pq["bias"], pt["bias"]))
         return out
 
     def _adam_steps(self) -> int:
+        state = self._optimizer.state
         for pq, _ in self._param_pairs():
-            st = self._optimizer.state.get(pq)
+            st = state.get(pq)
             if st and "step" in st:
-                return int(float(st["step"]))
+                return int(st["step"].item())
         return 0
 
     def _set_adam_steps(self, n: int) -> None:
         # one 0-d step tensor PER parameter, as torch.optim keeps them (a shared tensor would be
-        # advanced six times by a torch-side optimizer.step() and serialised six times): six scalar
-        # fills once per learn() call
+        # advanced six times by a torch-side optimizer.step()).  The six are views of ONE 6-element
+        # host tensor when this learner created them (_ensure_bound): one fill per learn() call
+        # instead of six; step tensors that came from elsewhere (optimizer.load_state_dict) are
+        # filled one by one.
+        bank = self.__dict__.get("_step_bank")
+        state = self._optimizer.state
+        banked = bank is not None
+        steps = []
         for pq, _ in self._param_pairs():
-            st = self._optimizer.state.get(pq)
+            st = state.get(pq)
             if st is not None and "step" in st:
-                st["step"].fill_(float(n))
+                steps.append(st["step"])
+        if banked:
+            base = bank.data_ptr()
+            banked = len(steps) == bank.numel() and all(
+                t.data_ptr() == base + 4 * i for i, t in enumerate(steps))
+        if banked:
+            bank.fill_(float(n))
+        else:
+            for t in steps:
+                t.fill_(float(n))
 
     def _signature(self) -> Tuple:
         sig = []
@@ -282,8 +305,10 @@ class DeepQLearning(PolicyLearner):
         N.check(N.lib().pa_dqn_param_offsets(S, AD, H1, H2, offs))
         flat = {k: torch.zeros(P, dtype=torch.float32, device=dev) for k in _FLAT_NAMES}
         steps = self._adam_steps()
+        bank = torch.full((6,), float(steps), dtype=torch.float32)     # the six step counters
+        self.__dict__["_step_bank"] = bank
         with torch.no_grad():
-            for (pq, pt), off in zip(self._param_pairs(), list(offs)):
+            for i, ((pq, pt), off) in enumerate(zip(self._param_pairs(), list(offs))):
                 n = pq.numel()
                 sl = slice(int(off), int(off) + n)
                 flat["q"][sl].copy_(pq.data.reshape(-1).to(dev, torch.float32))
@@ -296,7 +321,7 @@ class DeepQLearning(PolicyLearner):
                 pt.data = flat["q_target"][sl].view(pt.shape)
                 pq.grad = flat["grad"][sl].view(pq.shape)
                 self._optimizer.state[pq] = {
-                    "step": torch.tensor(float(steps), dtype=torch.float32),
+                    "step": bank[i],
                     "exp_avg": flat["exp_avg"][sl].view(pq.shape),
                     "exp_avg_sq": flat["exp_avg_sq"][sl].view(pq.shape),
                     "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(pq.shape),
@@ -378,7 +403,7 @@ class DeepQLearning(PolicyLearner):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ("_generic_td", "_linears_cache"):
+            if k in ("_generic_td", "_linears_cache", "_pairs_memo"):
                 new.__dict__[k] = None
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -605,6 +630,14 @@ class DeepQLearning(PolicyLearner):
             return {}
         if not self._arena_path_ok(replay_buffer):
             return super().learn(replay_buffer)
+        self.__dict__["_pairs_memo"] = None
+        self.__dict__["_pairs_memo"] = self._param_pairs()
+        try:
+            return self._learn_fused(replay_buffer)
+        finally:
+            self.__dict__["_pairs_memo"] = None
+
+    def _learn_fused(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         batch_size = self._clamped_batch_size(replay_buffer)
         rounds = int(self._training_rounds)
         arena = replay_buffer.arena

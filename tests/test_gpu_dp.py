@@ -17,8 +17,12 @@ def _shard_states(rank, N, S):
     return torch.randn(N + 1, S, generator=torch.Generator().manual_seed(100 + rank))
 
 
-def _worker(rank, world, port, q):
-    os.environ["PEARL_AMD_TORCH_ALLREDUCE"] = "1"
+def _worker(rank, world, port, q, exchange="gloo"):
+    if exchange == "p2p":     # the native hooks on the one-shot peer-to-peer exchange (comm.hip)
+        os.environ["PEARL_AMD_P2P"] = "1"
+        os.environ.pop("PEARL_AMD_TORCH_ALLREDUCE", None)
+    else:
+        os.environ["PEARL_AMD_TORCH_ALLREDUCE"] = "1"
     import torch.distributed as dist
     from pearl_amd import (BasicReplayBuffer, DeepQLearning, DiscreteActionSpace,
                            OneHotActionTensorRepresentationModule, PearlAgent)
@@ -48,17 +52,22 @@ def _worker(rank, world, port, q):
     mom = torch.cat([pl._optimizer.state[p]["exp_avg"].reshape(-1) for p in pl._Q.parameters()]).cpu()
     # numpy arrays travel by value; torch tensors would be handed over through the producer process,
     # which may be gone before the parent reads them
+    if exchange == "p2p":
+        from pearl_amd import _comm, _native as N
+        info = _comm.comm_info()
+        assert "P2P" in info["library"] and info["ranks_observed"] == world, info
+        N.check(N.lib().pa_comm_p2p_check(_comm._state["handle"]))
     q.put((rank, flat.numpy(), mom.numpy(), losses, pl._training_steps, first, first_t))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(world):
+def _run(world, exchange="gloo"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + random.randrange(2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     out = {}
@@ -82,6 +91,76 @@ def test_two_ranks_keep_identical_parameters():
     assert l0 != l1                                         # each rank reports its own shard's loss
     one = _run(1)[0]
     assert not torch.equal(one[0], f0), "two-rank training must see the other rank's gradients"
+
+
+def test_p2p_exchange_learn_loop_is_bitwise_the_gloo_loop():
+    """The one-shot peer-to-peer gradient exchange (PEARL_AMD_P2P=1: hipIpc-mapped peer buffers,
+    round counters, every rank adds the slots in rank order — comm.hip) behind the native hooks of
+    the same learn loop, two processes on the one GPU a test box has: parameters, optimizer state
+    and per-round losses bitwise equal to the run whose gradients travel through gloo, on both
+    ranks, over 46 rounds (slot reuse, soft updates)."""
+    p2p, gloo = _run(2, "p2p"), _run(2, "gloo")
+    for rank in (0, 1):
+        assert torch.equal(p2p[rank][0], gloo[rank][0]), f"rank {rank}: parameters differ"
+        assert torch.equal(p2p[rank][1], gloo[rank][1]), f"rank {rank}: optimizer state differs"
+        assert p2p[rank][2] == gloo[rank][2], f"rank {rank}: losses differ"
+    assert torch.equal(p2p[0][0], p2p[1][0])
+
+
+def _p2p_unit_worker(rank, world, port, q):
+    os.environ["PEARL_AMD_P2P"] = "1"
+    os.environ["PEARL_AMD_P2P_FLOATS"] = "300000"
+    import torch.distributed as dist
+    from pearl_amd import _comm, _native as N
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ok = True
+    msg = ""
+    try:
+        for rnd, n in enumerate((103172, 1001, 5, 267540, 4, 103172, 103172, 64, 299999)):
+            parts = [torch.randn(n, generator=torch.Generator().manual_seed(1000 * rnd + r)) for r in range(world)]
+            buf = parts[rank].to(dev)
+            _comm.allreduce_sum_(buf)
+            want = parts[0].clone()
+            for r in range(1, world):
+                want += parts[r]                 # rank order, fp32: the kernel's own order
+            torch.cuda.synchronize()
+            if not torch.equal(buf.cpu(), want):
+                ok, msg = False, f"round {rnd} (n = {n}): sum differs"
+                break
+        N.check(N.lib().pa_comm_p2p_check(_comm._state["handle"]))
+        # a message above the exchange buffer's capacity is refused, not truncated
+        big = torch.zeros(300001 + 64, device=dev)
+        rc = N.lib().pa_comm_allreduce_start(_comm._state["handle"], big.data_ptr(), big.numel(),
+                                             N.stream_ptr(dev))
+        if rc == 0:
+            ok, msg = False, "an oversized message was accepted"
+    except Exception as e:  # noqa: BLE001
+        ok, msg = False, f"{type(e).__name__}: {e}"
+    q.put((rank, ok, msg))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2p_exchange_sums_in_rank_order_over_many_rounds(world):
+    """pa_comm_create_p2p / _p2p_handle / _p2p_open + the two exchange launches, `world` processes
+    on one GPU: messages of ragged lengths back to back (both slots reused many times), every
+    rank's result bitwise the fp32 sum in rank order; oversized messages are refused."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_p2p_unit_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok, msg in res:
+        assert ok, f"rank {rank}: {msg}"
 
 
 def test_two_ranks_equal_one_reference_learner_on_the_concatenated_batch():

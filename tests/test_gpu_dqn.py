@@ -547,11 +547,14 @@ def test_full_size_200_round_loss_curve_against_the_oracle(full_size_arena):
     print("\nrounds      HIP vs oracle   oracle vs permuted oracle")
     for lo, hi, a, b in rows:
         print(f"{lo:3d}-{hi:3d}     {a:.3e}       {b:.3e}")
-    # the first window: no drift yet — the arithmetic itself (bf16x3 target pass, MFMA k-order)
-    assert rows[0][2] <= 1e-4, rows
+    # the first windows: no drift yet — the arithmetic itself (bf16x3 target pass, MFMA k-order).
+    # Measured on MI355X (profiles/r04_a_loss_curve_200_rounds.txt): 1.2e-7 / 2.9e-6 / 4.6e-5 /
+    # 2.4e-4 / 2.7e-4 per block against 1.1e-6 / 1.0e-5 / 5.4e-5 / 2.0e-4 / 5.8e-4 for the oracle
+    # pair — the HIP loop is as close to the oracle as the oracle is to itself.
+    assert rows[0][2] <= 5e-6, rows
     for lo, hi, a, b in rows:
-        assert a <= max(50.0 * b, 1e-4), (lo, hi, a, b)
-    assert float(rel_hip.max()) <= 2e-2
+        assert a <= max(8.0 * b, 5e-6), (lo, hi, a, b)
+    assert float(rel_hip.max()) <= 5e-3
     # the function learned: Q(s, a) of a fresh batch under the three parameter sets (evaluated by
     # one piece of code, so that only the parameters differ)
     idx = torch.from_numpy(O.philox_sample_indices(N, key, ROUNDS + 7, B))
@@ -564,7 +567,7 @@ def test_full_size_200_round_loss_curve_against_the_oracle(full_size_arena):
     d_hip = float((q_hip - q_orc).abs().max()) / scale
     d_self = float((q_twin - q_orc).abs().max()) / scale
     print(f"final Q on a fresh batch: HIP vs oracle {d_hip:.3e}, oracle pair {d_self:.3e} (of max |Q|)")
-    assert d_hip <= max(50.0 * d_self, 1e-3)
+    assert d_hip <= max(8.0 * d_self, 1e-3)
 
 
 def test_full_size_config2_learn_properties(full_size_arena):

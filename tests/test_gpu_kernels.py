@@ -68,6 +68,50 @@ def test_weight_grad(M, N_, B):
                                atol=1e-5 * B ** 0.5)
 
 
+@pytest.mark.parametrize("M,N_,B", [(256, 256, 4096), (16, 256, 4096), (64, 512, 4096), (256, 256, 2500),
+                                   (128, 96, 300), (256, 144, 8192)])
+def test_weight_grad_bf16x3_split_loop_has_fp32_accuracy(M, N_, B):
+    """The weight-gradient main loop on the bf16 matrix pipe (weight_grad_split_kernel: every operand
+    split exactly into three bf16 terms, six products, fp32 accumulation) against float64, next to
+    the fp32-MFMA kernel on the same operands: its error relative to sum |dz x| must be that of an
+    fp32 dot product (no worse than 2x the fp32 kernel's own, floor 2e-7), the bias gradient too,
+    ragged batches (rows past B read as zeros), and two launches agree bitwise."""
+    N, lib = _lib()
+    dev = torch.device("cuda:0")
+    dz, x = _rand(B, M, seed=11), _rand(B, N_, seed=12)
+    dz[::3] *= 37.0            # a wide dynamic range across rows
+    x[:, ::5] *= 1e-3
+    dzd, xd = dz.to(dev), x.to(dev)
+    exact = dz.double().t() @ x.double()
+    scale = dz.double().abs().t() @ x.double().abs()
+    exact_b, scale_b = dz.double().sum(0), dz.double().abs().sum(0)
+
+    def run(mode):
+        N.check(lib.pa_debug_set_dw_split(mode))
+        try:
+            dw = torch.full((M, N_), float("nan"), device=dev)
+            db = torch.full((M,), float("nan"), device=dev)
+            N.check(lib.pa_debug_weight_grad(dzd.data_ptr(), M, xd.data_ptr(), N_, dw.data_ptr(), N_,
+                                             db.data_ptr(), M, N_, B, N.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            return dw.cpu(), db.cpu()
+        finally:
+            N.check(lib.pa_debug_set_dw_split(-1))
+
+    dw32, db32 = run(0)
+    dws, dbs = run(2)
+    dws2, dbs2 = run(2)
+    assert torch.equal(dws, dws2) and torch.equal(dbs, dbs2)
+    assert not torch.equal(dws, dw32), "the split loop did not run (same bits as the fp32 kernel)"
+    e32 = float(((dw32.double() - exact).abs() / scale).max())
+    es = float(((dws.double() - exact).abs() / scale).max())
+    eb32 = float(((db32.double() - exact_b).abs() / scale_b).max())
+    ebs = float(((dbs.double() - exact_b).abs() / scale_b).max())
+    print(f"\ndW error / sum|terms|: fp32 MFMA {e32:.2e}, bf16x3 {es:.2e}; db: {eb32:.2e}, {ebs:.2e}")
+    assert es <= max(2.0 * e32, 2e-7), (es, e32)
+    assert ebs <= max(2.0 * eb32, 2e-7), (ebs, eb32)
+
+
 def test_weight_grad_split_k_is_deterministic():
     """Two launches of the split-K path give bitwise-equal results (slice-ordered combine) and
     leave the tickets ready for the next launch."""

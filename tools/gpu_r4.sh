@@ -1,0 +1,61 @@
+#!/bin/bash
+# Focused GPU-box calls of round 4 (gpurun -- bash tools/gpu_r4.sh <mode>); output under gpurun_out/.
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd $R; mkdir -p gpurun_out
+MODE=${1:-new}
+if [ "$MODE" == "new" ]; then
+  # the tests round 4 added or changed, then the driver's bench line with the new blocks
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -s \
+    -k "bandit or rollout64k or fullbatch or 200_round or squarecb or full_size or discrete_sac_learn_batch or iql_learn_batch or ddpg_td3_learn_batch" \
+    > gpurun_out/pytest_new.log 2>&1
+  echo "pytest rc=$?"; grep -E "passed|failed|rounds  |^ *[0-9]+-|final Q|Error|error" gpurun_out/pytest_new.log | tail -40
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+print('value', round(d['value']/1e6,2), 'M  steady', round(d.get('steady_state',{}).get('value',0)/1e6,2))
+print('parity', d.get('parity'))
+for r in d.get('other_configs',[]): print({k:(round(v,4) if isinstance(v,float) else v) for k,v in r.items() if k not in ('kernels','workload','metric','preprocess_replay_buffer')})
+print('cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('kind'))
+"
+  tail -3 gpurun_out/bench_s20.err
+fi
+if [ "$MODE" == "dw" ]; then
+  # bf16x3 weight gradients: kernel tests, the PPO / bandit parity tests, bench lines with and without
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_actor_critic.py -m gpu -q --tb=short -p no:cacheprovider -s \
+    -k "weight_grad or ppo or bandit or twin or rowstep" > gpurun_out/pytest_dw.log 2>&1
+  echo "pytest rc=$?"; grep -E "passed|failed|dW error|Error" gpurun_out/pytest_dw.log | tail -30
+  for sp in 1 0; do
+    PEARL_AMD_DW_SPLIT=$sp timeout 600 python bench_algos.py --steps 300 --only ppo,bandit --cpu-seconds 0.5 > gpurun_out/bench_algos_dw$sp.jsonl 2> gpurun_out/bench_algos_dw$sp.err
+    echo "bench_algos split=$sp rc=$?"; python - <<PY
+import json
+for ln in open("gpurun_out/bench_algos_dw$sp.jsonl"):
+    if ln.startswith("{"):
+        d=json.loads(ln); print(d["config"][:24], round(d["value"]/1e6,2), "M", round(d["ms_per_step"]*1e3,1), "us/step", [(k["kernel"][:14], round(k["avg_launch_us"],1)) for k in d.get("kernels",[])])
+PY
+  done
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_ppo
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_ppo -o t -- python $R/bench_algos.py --steps 200 --only ppo --cpu-seconds 0.2 > $R/gpurun_out/rocprof_ppo.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_ppo/*.db $R/gpurun_out/prof_ppo/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/ppo_kernel_stats.txt 2>&1
+  head -12 $R/gpurun_out/ppo_kernel_stats.txt | cut -c1-160
+  rm -f $DB
+fi
+if [ "$MODE" == "prof" ]; then
+  timeout 300 python tools/prof_rowstep.py > gpurun_out/prof_rowstep.txt 2>&1; echo "prof_rowstep rc=$?"; grep -v amdgpu.ids gpurun_out/prof_rowstep.txt | tail -32
+  PEARL_AMD_DW_SPLIT=0 timeout 300 python tools/prof_rowstep.py > gpurun_out/prof_rowstep_nosplit.txt 2>&1; grep -A9 "weight_grad_kernel of" gpurun_out/prof_rowstep_nosplit.txt
+  # host API + kernel timeline of three 20-round calls
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_sc
+  timeout 600 rocprofv3 --kernel-trace --hip-runtime-trace --output-format csv -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+  echo "rocprof sc rc=$?"; ls -la $R/gpurun_out/prof_sc/* | head; 
+  cd $R; python tools/host_timeline.py $(ls gpurun_out/prof_sc/*hip_api_trace.csv gpurun_out/prof_sc/*/*hip_api_trace.csv 2>/dev/null | head -1) $(ls gpurun_out/prof_sc/*kernel_trace.csv gpurun_out/prof_sc/*/*kernel_trace.csv 2>/dev/null | head -1) > gpurun_out/shortcall_host_timeline.txt 2>&1; head -90 gpurun_out/shortcall_host_timeline.txt
+fi
+if [ "$MODE" == "p2p" ]; then
+  timeout 120 tools/valu_rate_bench > gpurun_out/valu_rate_bench.txt 2>&1; echo "valu bench rc=$?"; cat gpurun_out/valu_rate_bench.txt
+  timeout 900 python -m pytest tests/test_gpu_dp.py -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/pytest_dp.log 2>&1
+  echo "pytest dp rc=$?"; tail -15 gpurun_out/pytest_dp.log
+  timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err; echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > gpurun_out/bench_s20b.log 2>&1; tail -1 gpurun_out/bench_s20b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'steady', d['steady_state']['value'])"
+fi
