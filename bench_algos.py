@@ -98,7 +98,9 @@ def engine_kernels(times, dims_list, rows, split_rowstep=False, split_dw=False):
                     "launches_timed": times[name]["launches"], "flop_per_launch": f * rows,
                     "achieved": rate / 1e12, "unit": "TFLOP/s", "frac": rate / PEAK_F32_MFMA,
                     "frac_pipe": rate / pipe,
-                    "pipe": "bf16x3 split MFMA (2.5 PF / 6)" if split else "fp32 MFMA"})
+                    "pipe": ("bf16x3 split MFMA (2.5 PF / 6)" + (": forward layers; backward on fp32 MFMA"
+                                                                   if name == "rowstep" else ""))
+                    if split else "fp32 MFMA"})
     return out
 
 
@@ -355,10 +357,11 @@ def bench_ppo(steps, cpu_seconds):
     if world == 1:
         keep = pl._training_rounds
         pl._training_rounds = 16
-        kernels = engine_kernels(engine_kernel_times(lambda: pl.learn(rb)),
-                                 ([S, 256, 256, A], [S, 256, 256, 1]), B,
-                                 split_rowstep=os.environ.get("PEARL_AMD_ROWSTEP_SPLIT", "1") != "0"
-                                 and bool(getattr(pl, "_rowstep_split_active", False)))
+        times = engine_kernel_times(lambda: pl.learn(rb))
+        from pearl_amd import _native as N_
+        kernels = engine_kernels(times, ([S, 256, 256, A], [S, 256, 256, 1]), B,
+                                 split_rowstep=bool(N_.lib().pa_rowstep_last_split()),
+                                 split_dw=os.environ.get("PEARL_AMD_DW_SPLIT", "1") != "0")
         pl._training_rounds = keep
     comm = _comm.comm_info() if dist.is_initialized() else None
     if comm is not None:
@@ -420,8 +423,11 @@ def bench_bandit(steps, cpu_seconds):
 
     dt, _ = timed(run)
     gpu = B * steps / dt
-    kernels = engine_kernels(engine_kernel_times(lambda: [pl.learn_batch(tb) for _ in range(16)]),
-                             ([F, 256, 64, 1],), B)
+    times = engine_kernel_times(lambda: [pl.learn_batch(tb) for _ in range(16)])
+    from pearl_amd import _native as N_
+    kernels = engine_kernels(times, ([F, 256, 64, 1],), B,
+                             split_rowstep=bool(N_.lib().pa_rowstep_last_split()),
+                             split_dw=os.environ.get("PEARL_AMD_DW_SPLIT", "1") != "0")
     orc = NeuralLinearOracle(sd0, lr=1e-3)
     xc, yc = x.cpu(), y.cpu()
     n, t0 = 0, time.perf_counter()

@@ -563,6 +563,13 @@ int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena, const pa_ac_l
 
 /* tuning aid (tools/prof_sac.py): in-kernel phase stamps of the two fused row kernels */
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
+/* Fused row steps of 32 rows per workgroup (launches of more than 256 row tiles: PPO's 4096-row
+ * minibatch) run their forward GEMMs on the bf16 matrix pipe at fp32 accuracy (bf16x3 split operands,
+ * mlp_rowstep.hpp) when every layer input is at most 256 wide.  mode -1: that default; 0: the fp32
+ * MFMA forward everywhere (also PEARL_AMD_ROWSTEP_SPLIT=0).  pa_rowstep_last_split: 1 when the most
+ * recent fused row step took the bf16x3 forward (bench lines report the pipe). */
+int pa_debug_set_rowstep_split(int32_t mode);
+int pa_rowstep_last_split(void);
 /* the same for the fused row step (mlp_rowstep.hpp): [workgroup][8][16] ticks of the next launches */
 int pa_debug_rowstep_prof(long long* stamps);
 int pa_debug_mlp_dw_prof(long long* stamps);   /* weight_grad_kernel launches of the MLP engine */

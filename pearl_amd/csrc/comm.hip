@@ -232,7 +232,19 @@ extern "C" int pa_comm_create_p2p(pa_comm** out, int32_t device, int32_t world, 
   P2P* x = c->p2p;
   x->max_floats = (max_floats + 63) / 64 * 64;
   const size_t bytes = (size_t)(2 * x->max_floats + kP2PFlagFloats) * sizeof(float);
-  PA_HIP(hipMalloc((void**)&x->mine, bytes));
+  // Fine-grained device memory when the runtime hands it out (peer reads over xGMI are then
+  // coherent without relying on cache maintenance at all); ordinary coarse-grained memory otherwise
+  // or under PEARL_AMD_P2P_COARSE=1 — the protocol's system-scope release (end of the publish
+  // launch) / acquire (after the flag wait) pair is what makes that correct.
+  {
+    const char* v = getenv("PEARL_AMD_P2P_COARSE");
+    const bool coarse = v && *v == '1';
+    if (coarse || hipExtMallocWithFlags((void**)&x->mine, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      x->mine = nullptr;
+      PA_HIP(hipMalloc((void**)&x->mine, bytes));
+    }
+  }
   PA_HIP(hipMemset(x->mine, 0, bytes));
   PA_HIP(hipDeviceSynchronize());
   PA_HIP(hipHostMalloc((void**)&x->err_host, 16, hipHostMallocMapped));

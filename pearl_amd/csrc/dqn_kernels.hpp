@@ -470,6 +470,41 @@ __device__ __forceinline__ void store_wsp1(void* base, int n, int k, float v, in
   p[wsp_index(n, k, 1, ks)] = b;
   p[wsp_index(n, k, 2, ks)] = c;
 }
+// Split planes of a weight matrix W[n][k] as the A operand of v_mfma_f32_16x16x32_bf16, for the
+// generic MLP engine's fused row step (mlp_rowstep.hpp): tiles of 16 units, k-steps of 32;
+//   slot ((tile * nks + kstep) * 3 + plane) * 64 + lane,  lane = 16 ((k >> 3) & 3) + (n & 15),
+// holds the 8 bf16  k = 32 kstep + 8 (lane >> 4) + e  of unit n = 16 tile + (lane & 15): one
+// coalesced 1 KiB load per (tile, k-step, plane).  Zero beyond N / K.
+__host__ __device__ inline int wsp16_nks(int K) { return (K + 31) >> 5; }
+__host__ __device__ inline int64_t wsp16_bytes(int N, int K) {
+  return (int64_t)((N + 15) >> 4) * wsp16_nks(K) * 3 * 64 * 16;
+}
+__host__ __device__ inline int64_t wsp16_index(int n, int k, int plane, int nks) {
+  return (((((int64_t)(n >> 4) * nks + (k >> 5)) * 3 + plane) * 64) + ((k >> 3) & 3) * 16 + (n & 15)) * 8 +
+         (k & 7);
+}
+// four consecutive k (k % 4 == 0) of one unit: one 8-byte store per plane
+__device__ __forceinline__ void store_wsp16_4(void* base, int n, int k, const float4& v, int nks) {
+  __bf16* p = static_cast<__bf16*>(base);
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4 q[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __bf16 a, b, c;
+    split3(x[j], a, b, c);
+    q[0][j] = a; q[1][j] = b; q[2][j] = c;
+  }
+#pragma unroll
+  for (int s = 0; s < 3; ++s) *reinterpret_cast<bf16x4*>(p + wsp16_index(n, k, s, nks)) = q[s];
+}
+__device__ __forceinline__ void store_wsp16_1(void* base, int n, int k, float v, int nks) {
+  __bf16* p = static_cast<__bf16*>(base);
+  __bf16 a, b, c;
+  split3(v, a, b, c);
+  p[wsp16_index(n, k, 0, nks)] = a;
+  p[wsp16_index(n, k, 1, nks)] = b;
+  p[wsp16_index(n, k, 2, nks)] = c;
+}
 __device__ __forceinline__ void store_w2sp4(void* base, int n, int k, const float4& v) {
   store_wsp4(base, n, k, v, TS_KS);
 }
@@ -948,6 +983,7 @@ struct DwProblem {
   float* pkf; int nkgf;       // kind 3: fragment-major W [M units][N]  (wf16 layout) or null
   float* pktf; int nkgtf;     // kind 3: fragment-major W^T [N units][M] or null
   float* pkf_t;               // kind 3 + soft update: the TARGET's fragment-major W (pkf layout) or null
+  void* pks; int nks;         // kind 3: W as bf16x3 split planes for v_mfma_f32_16x16x32_bf16 (wsp16_index) or null
   int bias_frozen;            // the bias slot is not a parameter (bias-free layer): no AdamW on db
   int net;                    // kind 3: which network's optimizer state (0: ad, 1: net2)
 };
@@ -1028,6 +1064,7 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
 __device__ __forceinline__ void pack_generic(const DwProblem& P, int row, int col, float p) {
   if (P.pkf) P.pkf[wf16_index_(row, col, P.nkgf)] = p;
   if (P.pktf) P.pktf[wf16_index_(col, row, P.nkgtf)] = p;
+  if (P.pks) store_wsp16_1(P.pks, row, col, p, P.nks);
 }
 // kind 3, one scalar parameter: AdamW, packed copies, and (soft) the target with its packed copy
 __device__ __forceinline__ void adam_generic_weight(const AdamFuse& f, const AdamState& st, float* tgt,
@@ -1645,6 +1682,7 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
           *reinterpret_cast<float4*>(a.ad.W1f + wf16_index_(erow, ecol, a.ad.nkg_w1)) = pn;
         } else if (P.kind == 3) {
           if (P.pkf) *reinterpret_cast<float4*>(P.pkf + wf16_index_(erow, ecol, P.nkgf)) = pn;
+          if (P.pks) store_wsp16_4(P.pks, erow, ecol, pn, P.nks);
           if (P.pktf) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) P.pktf[wf16_index_(ecol + e, erow, P.nkgtf)] = pv[e];

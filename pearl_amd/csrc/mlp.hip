@@ -99,6 +99,7 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
     if (h->wf[l]) (void)hipFree(h->wf[l]);
     if (h->wtf[l]) (void)hipFree(h->wtf[l]);
     if (h->wf_t[l]) (void)hipFree(h->wf_t[l]);
+    if (h->wsp[l]) (void)hipFree(h->wsp[l]);
   }
   delete h;
   release_process_device();
@@ -155,6 +156,7 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
         ok = ok && alloc(&h->wf[l], wf16_floats(desc->dims[l + 1], desc->dims[l]));
         ok = ok && alloc(&h->wf_t[l], wf16_floats(desc->dims[l + 1], desc->dims[l]));
         ok = ok && alloc(&h->wtf[l], wf16_floats(desc->dims[l], desc->dims[l + 1]));
+        ok = ok && hipMalloc(&h->wsp[l], (size_t)wsp16_bytes(desc->dims[l + 1], desc->dims[l])) == hipSuccess;
       }
     }
   }
@@ -200,6 +202,7 @@ int ensure_packed(pa_mlp* h, bool target, hipStream_t s) {
     a.woff[l] = h->woff[l];
     a.Wf[l] = target ? h->wf_t[l] : h->wf[l];
     a.Wtf[l] = target ? nullptr : h->wtf[l];
+    a.Wsp[l] = target ? nullptr : h->wsp[l];
   }
   hipLaunchKernelGGL(mlp_rowpack_kernel, dim3(128), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
@@ -215,6 +218,7 @@ void fill_fwd(const pa_mlp* h, bool target, float* out, int ldo, bool keep, RowN
   for (int l = 0; l < h->L; ++l) {
     const bool last = l == h->L - 1;
     n.Wf[l] = target ? h->wf_t[l] : h->wf[l];
+    n.Wsp[l] = target ? nullptr : h->wsp[l];
     n.bias[l] = (last && h->d.no_last_bias) ? nullptr : P + h->boff[l];
     n.act[l] = (!last && keep) ? h->act[l] : nullptr;
     if (!last && !((h->d.identity_layers >> l) & 1)) n.relu |= 1 << l;
@@ -489,6 +493,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
           if (h->row_ok) {
             pr.pkf = h->wf[l]; pr.nkgf = wf16_nkg(h->d.dims[l]);
             pr.pktf = h->wtf[l]; pr.nkgtf = wf16_nkg(h->d.dims[l + 1]);
+            pr.pks = h->wsp[l]; pr.nks = wsp16_nks(h->d.dims[l]);
             if (soft_tau >= 0.f && h->packed_t_ok) pr.pkf_t = h->wf_t[l];
           }
         }
@@ -941,6 +946,9 @@ int rowstep_scratch(RowStepScratch& sc, size_t need, hipStream_t s) {
 }
 // heads[i].d_out / target / ... filled by the caller; p_rows, partials and the ticket are set here
 long long* g_rowstep_prof = nullptr;   // pa_debug_rowstep_prof
+int g_rowstep_last_split = 0;          // 1: the last fused row step ran the bf16x3 forward
+int g_rowstep_split_mode = -1;         // pa_debug_set_rowstep_split: -1 default (on), 0 off
+int rowstep_split_mode() { return g_rowstep_split_mode; }
 int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, RowHead* heads,
                 float* const* outs, const int* ldos, float* losses, int sum_losses, hipStream_t s) {
   static RowStepScratch sc;
@@ -983,18 +991,34 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   a.losses = losses;
   a.sum_losses = sum_losses;
   a.prof = g_rowstep_prof;
-  static size_t configured[3] = {0, 0, 0};
-  const size_t smem = RT == 2 ? rowstep_smem_bytes_t<2>(d0max) : rowstep_smem_bytes_t<1>(d0max);
-  if (smem > configured[RT]) {
-    rc = RT == 2 ? set_max_smem(mlp_rowstep_kernel<2>, smem) : set_max_smem(mlp_rowstep_kernel<1>, smem);
+  // 32-row launches whose every layer input is at most 256 wide run their forward GEMMs on the bf16
+  // matrix pipe at fp32 accuracy (mlp_rowstep_kernel<2, true>, mlp_rowstep.hpp).
+  // PEARL_AMD_ROWSTEP_SPLIT=0: the fp32-MFMA forward everywhere.
+  static const bool split_env = []() {
+    const char* v = getenv("PEARL_AMD_ROWSTEP_SPLIT");
+    return !(v && *v == '0');
+  }();
+  bool splitf = split_env && RT == 2 && rowstep_split_mode() != 0;
+  for (int i = 0; i < nnet && splitf; ++i)
+    for (int l = 0; l < hs[i]->L; ++l)
+      splitf = splitf && hs[i]->d.dims[l] <= ROW_MAX_OUT && hs[i]->wsp[l] != nullptr;
+  static size_t configured[4] = {0, 0, 0, 0};
+  const int slot = splitf ? 3 : RT;
+  const size_t smem = splitf ? rowstep_split_smem_bytes()
+                             : (RT == 2 ? rowstep_smem_bytes_t<2>(d0max) : rowstep_smem_bytes_t<1>(d0max));
+  if (smem > configured[slot]) {
+    rc = splitf ? set_max_smem(mlp_rowstep_kernel<2, true>, smem)
+                : (RT == 2 ? set_max_smem(mlp_rowstep_kernel<2>, smem) : set_max_smem(mlp_rowstep_kernel<1>, smem));
     if (rc != PA_OK) return rc;
-    configured[RT] = smem;
+    configured[slot] = smem;
   }
   {
     MlpTimedLaunch timed(0, s);
-    if (RT == 2) hipLaunchKernelGGL(mlp_rowstep_kernel<2>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+    if (splitf) hipLaunchKernelGGL((mlp_rowstep_kernel<2, true>), dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
+    else if (RT == 2) hipLaunchKernelGGL(mlp_rowstep_kernel<2>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
     else hipLaunchKernelGGL(mlp_rowstep_kernel<1>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
   }
+  g_rowstep_last_split = splitf ? 1 : 0;
   PA_LAUNCH_CHECK();
   // the state a kept forward + a want_dw = 2 backward leave behind: the weight gradients (and
   // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
@@ -1050,6 +1074,15 @@ extern "C" int pa_debug_mlp_dw_prof(long long* stamps) {
   g_mlp_dw_prof = stamps;
   return PA_OK;
 }
+// which forward the fused row steps take: -1 = default (bf16x3 where eligible), 0 = fp32 MFMA;
+// pa_rowstep_last_split: 1 when the most recent fused row step ran the bf16x3 forward
+extern "C" int pa_debug_set_rowstep_split(int32_t mode) {
+  PA_REQUIRE(mode >= -1 && mode <= 1, PA_ERR_INVALID, "pa_debug_set_rowstep_split: mode is -1, 0 or 1");
+  g_rowstep_split_mode = mode;
+  return PA_OK;
+}
+extern "C" int pa_rowstep_last_split(void) { return g_rowstep_last_split; }
+
 // tuning aid (tools/prof_rowstep.py): in-kernel phase stamps of the next fused row-step launches,
 // [workgroup][8 waves][16] wall-clock ticks; NULL switches them off
 extern "C" int pa_debug_rowstep_prof(long long* stamps) {

@@ -29,6 +29,10 @@ struct pa_mlp {
   float* wf[PA_MLP_MAX_LAYERS];
   float* wtf[PA_MLP_MAX_LAYERS];
   float* wf_t[PA_MLP_MAX_LAYERS];
+  // the online W_l as bf16x3 split planes (wsp16_index, dqn_kernels.hpp): the fused row step's
+  // forward GEMMs on the bf16 matrix pipe (mlp_rowstep.hpp, launches of 32 rows per workgroup);
+  // kept current with wf (repack launch, optimizer epilogue)
+  void* wsp[PA_MLP_MAX_LAYERS];
   bool packed_ok, packed_t_ok;
   // weight gradients deferred to pa_mlp_adam (want_dw = 2): the operands of the kept backward
   struct Pending {

@@ -24,6 +24,7 @@ constexpr int ROW_MAX_IN = 512;     // width of the network input (staged once i
 
 struct RowNetFwd {
   const float* Wf[ROW_MAX_LAYERS];     // fragment-major W_l [d_{l+1} units][d_l]
+  const void* Wsp[ROW_MAX_LAYERS];     // the same as bf16x3 split planes (wsp16_index) or null
   const float* bias[ROW_MAX_LAYERS];   // null: no bias (bias-free last layer)
   float* act[ROW_MAX_LAYERS];          // kept hidden outputs [B][d_{l+1}] (null: not kept)
   float* out; int ldo;                 // [B][d_L]
@@ -194,6 +195,7 @@ struct RowPackArgs {
   int L;
   float* Wf[ROW_MAX_LAYERS];           // [d_{l+1} units][d_l]
   float* Wtf[ROW_MAX_LAYERS];          // [d_l units][d_{l+1}] or null
+  void* Wsp[ROW_MAX_LAYERS];           // W_l as bf16x3 split planes (wsp16_index) or null
 };
 static __global__ __launch_bounds__(256) void mlp_rowpack_kernel(RowPackArgs a) {
   const int64_t gsz = (int64_t)gridDim.x * 256;
@@ -215,6 +217,27 @@ static __global__ __launch_bounds__(256) void mlp_rowpack_kernel(RowPackArgs a) 
         v.z = (u < N && k + 2 < K) ? W[(int64_t)u * K + k + 2] : 0.f;
         v.w = (u < N && k + 3 < K) ? W[(int64_t)u * K + k + 3] : 0.f;
         reinterpret_cast<float4*>(a.Wf[l])[e] = v;
+      }
+    }
+    if (a.Wsp[l]) {   // one thread per 16-byte slot of every plane: 8 consecutive k of one unit
+      const int nks = wsp16_nks(K);
+      const int64_t total = wsp16_bytes(N, K) / 16;
+      for (int64_t e = t0; e < total; e += gsz) {
+        const int lane = (int)(e & 63);
+        const int64_t tg = e >> 6;
+        const int plane = (int)(tg % 3);
+        const int64_t ts = tg / 3;
+        const int s = (int)(ts % nks), T = (int)(ts / nks);
+        const int u = T * 16 + (lane & 15), k0 = s * 32 + 8 * (lane >> 4);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = (u < N && k0 + j < K) ? W[(int64_t)u * K + k0 + j] : 0.f;
+          __bf16 hi, mid, lo;
+          split3(x, hi, mid, lo);
+          v[j] = plane == 0 ? hi : (plane == 1 ? mid : lo);
+        }
+        reinterpret_cast<bf16x8*>(a.Wsp[l])[e] = v;
       }
     }
     if (a.Wtf[l]) {   // "unit" = input index k of W_l, reduction over its output units

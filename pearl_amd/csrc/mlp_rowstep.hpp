@@ -190,11 +190,118 @@ inline size_t rowstep_smem_bytes_t(int d0) {
   return sizeof(float) * ((size_t)RT * RP_ROWS * (rp_pad(d0) + 2 * row_hid_pitch()) + RS_SCR);
 }
 
+// ---- forward GEMMs on the bf16 matrix pipe at fp32 accuracy (SPLITF instantiation) ---------------
+// Launches of 32 rows per workgroup (one workgroup per CU: thousands of rows — PPO's 4096-row
+// minibatch) are bound by the fp32 MFMA rate in their 256 x 256 layers (10 us per layer and
+// workgroup against 7.8 us of MFMA).  The SPLITF kernel runs every forward layer as a bf16x3
+// product (each fp32 operand split exactly into three bf16 terms, six products,
+// fp32 accumulation): weights from the engine's split planes (wsp16_index: one coalesced 1 KiB load
+// per unit tile, k-step of 32 and plane — kept current by the repack pass and the optimizer
+// epilogue), activations as three bf16 planes in LDS, written by the lane that produced the value;
+// v_mfma_f32_16x16x32_bf16, 24 per k-step and wave instead of 64 fp32 MFMAs of twice the cycles.
+// The backward half is the fp32 kernel's (its tiles alias the planes, dead by then).
+constexpr int RS_PP = ROW_MAX_OUT + 8;   // bf16 pitch of a plane row: 528 B = 4 dwords mod 64 banks
+constexpr int RS_PLANE_BYTES = 3 * 2 * RP_ROWS * RS_PP * 2;   // three planes of 32 rows
+inline size_t rowstep_split_smem_bytes() {
+  return (size_t)2 * RS_PLANE_BYTES + sizeof(float) * ((size_t)2 * RP_ROWS * row_hid_pitch() + RS_SCR);
+}
+// four consecutive units of one row -> the three planes (one ds_write_b64 each)
+__device__ __forceinline__ void rs_store_planes4(__bf16* planes, int rows, int row, int col, const float4& v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4 q[3];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __bf16 a, b, c;
+    split3(x[j], a, b, c);
+    q[0][j] = a; q[1][j] = b; q[2][j] = c;
+  }
+#pragma unroll
+  for (int sp = 0; sp < 3; ++sp)
+    *reinterpret_cast<bf16x4*>(planes + ((size_t)sp * rows + row) * RS_PP + col) = q[sp];
+}
+constexpr int RS_SPD = 2;   // k-steps of weight planes in flight per wave
+struct RowWS {
+  bf16x8 w[RS_SPD][2][3];
+};
+__device__ __forceinline__ bf16x8 rs_ld_plane(const void* base, int64_t slot, bool ok) {
+  // (slot = index of a 16-byte fragment; out-of-range slots read as zeros through the raw buffer load)
+  const float4 v = ld4_or_zero(static_cast<const float*>(base), slot * 4, ok);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void rs_fill(RowWS& R, const void* Wsp, int nks, int tile0, int ntiles, int lane) {
+#pragma unroll
+  for (int p = 0; p < RS_SPD; ++p)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int sp = 0; sp < 3; ++sp)
+        R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + p) * 3 + sp) * 64 + lane,
+                                    tile0 + t < ntiles && p < nks);
+}
+// accm / accs[t][rt] += W planes (tiles tile0, tile0 + 1) x activation planes (RT row tiles), all k
+template <int RT>
+__device__ __forceinline__ void rs_gemm(f32x4v (&accm)[2][RT], f32x4v (&accs)[2][RT], RowWS& R,
+                                        const void* Wsp, int nks, int tile0, int ntiles,
+                                        const __bf16* act, int lane) {
+  const int r16 = lane & 15, qd = lane >> 4;
+  const int nksp = (nks + RS_SPD - 1) / RS_SPD * RS_SPD;
+  for (int s0 = 0; s0 < nksp; s0 += RS_SPD) {
+#pragma unroll
+    for (int p = 0; p < RS_SPD; ++p) {
+      const int s = s0 + p;
+      bf16x8 wa[2][3];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) {
+          wa[t][sp] = R.w[p][t][sp];
+          R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + s + RS_SPD) * 3 + sp) * 64 + lane,
+                                      tile0 + t < ntiles && s + RS_SPD < nks);
+        }
+      // (the ring is a whole number of k-steps deep: a step past the layer's last one has zero
+      //  weights but would read activation columns nobody wrote — 0 x garbage — so it is skipped)
+      if (s >= nks) continue;
+      bf16x8 b[RT][3];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+          b[rt][sp] = *reinterpret_cast<const bf16x8*>(
+              act + ((size_t)sp * RT * RP_ROWS + r16 + 16 * rt) * RS_PP + 32 * s + 8 * qd);
+      __builtin_amdgcn_sched_barrier(0);   // this k-step's loads are issued ahead of its MFMAs
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][2], b[rt][0], accs[t][rt], 0, 0, 0);
+          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][0], b[rt][2], accs[t][rt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][1], b[rt][1], accs[t][rt], 0, 0, 0);
+          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][0], b[rt][1], accs[t][rt], 0, 0, 0);
+        }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][1], b[rt][0], accs[t][rt], 0, 0, 0);
+          accm[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][0], b[rt][0], accm[t][rt], 0, 0, 0);
+        }
+    }
+  }
+}
+
 // RT row tiles of 16 rows per workgroup (1: up to three workgroups per CU; 2: 32 rows, one
 // workgroup per CU, half the weight traffic per row — for launches of more than 256 tiles)
-template <int RT>
+// SPLITF (RT = 2 only): the forward layers as bf16x3 products (see above).  LDS then: two plane
+// buffers (the backward's two fp32 tiles alias them), the fp32 output tile, the head scratch.
+template <int RT, bool SPLITF = false>
 static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  static_assert(!SPLITF || RT == 2, "the split forward is built for 32 rows per workgroup");
   constexpr int ROWS = RP_ROWS * RT;
   const int net = blockIdx.y;
   const RowNetFwd& n = a.fwd[net];
@@ -204,6 +311,17 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   float* xs = smem;
   float* hb[2] = {xs + ROWS * P0, xs + ROWS * P0 + ROWS * PH};
   float* scr = xs + ROWS * P0 + 2 * ROWS * PH;   // va | vb | vc | red[2], 512 floats each
+  __bf16* pl[2] = {nullptr, nullptr};            // SPLITF: the two activation plane buffers
+  float* otile = nullptr;                        // SPLITF: fp32 output tile of the last layer
+  if constexpr (SPLITF) {
+    unsigned char* base = reinterpret_cast<unsigned char*>(smem);
+    pl[0] = reinterpret_cast<__bf16*>(base);
+    pl[1] = reinterpret_cast<__bf16*>(base + RS_PLANE_BYTES);
+    hb[0] = reinterpret_cast<float*>(base);                       // (backward: planes are dead)
+    hb[1] = reinterpret_cast<float*>(base + RS_PLANE_BYTES);
+    otile = reinterpret_cast<float*>(base + 2 * RS_PLANE_BYTES);
+    scr = otile + ROWS * PH;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, qd = lane >> 4;
   const int m0 = blockIdx.x * ROWS;
@@ -211,6 +329,75 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   const int tile0 = wave * 2;
   const int pwg = blockIdx.x + blockIdx.y * gridDim.x;
   PA_STAMP(a.prof, pwg, wave, 0);
+  if constexpr (SPLITF) {
+    // ------------------------------------------------------------ forward, bf16x3 (see rs_gemm)
+    {
+      // x tile -> planes 0, split by the staging thread; zero up to the next multiple of 32 columns
+      const bool vx = is_vec_ok(a.x, a.ldx) && ((n.dims[0] & 3) == 0);
+      const int kp4 = ((n.dims[0] + 31) & ~31) >> 2;
+      for (int e = tid; e < ROWS * kp4; e += 512) {
+        const int r = e / kp4, c = (e - r * kp4) * 4;
+        const bool ok = (m0 + r) < a.B;
+        float4 v;
+        if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
+        else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
+        rs_store_planes4(pl[0], ROWS, r, c, v);
+      }
+    }
+    for (int l = 0; l < n.L; ++l) {
+      const int K = n.dims[l], N = n.dims[l + 1];
+      const int nt = (N + 15) >> 4, nks = wsp16_nks(K);
+      f32x4v accm[2][RT], accs[2][RT];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n.bias[l]) b = guarded_load4(n.bias[l], 0, true, u0 + 16 * t, N);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          accm[t][rt][0] = b.x; accm[t][rt][1] = b.y; accm[t][rt][2] = b.z; accm[t][rt][3] = b.w;
+          accs[t][rt][0] = accs[t][rt][1] = accs[t][rt][2] = accs[t][rt][3] = 0.f;
+        }
+      }
+      RowWS R;
+      if (tile0 < nt) rs_fill(R, n.Wsp[l], nks, tile0, nt, lane);
+      __syncthreads();
+      PA_STAMP(a.prof, pwg, wave, 1 + 2 * l);   // layer l: operands staged
+      if (tile0 < nt) rs_gemm<RT>(accm, accs, R, n.Wsp[l], nks, tile0, nt, pl[l & 1], lane);
+      PA_STAMP(a.prof, pwg, wave, 2 + 2 * l);   // layer l: GEMM done
+      const bool last = l == n.L - 1;
+      const bool relu = (n.relu >> l) & 1;
+      __bf16* nxt = pl[(l + 1) & 1];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const int lr = r16 + 16 * rt;
+        const int row = m0 + lr;
+        const bool rok = row < a.B;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int u = u0 + 16 * t;
+          // bias + main products first, the five small classes added once at the end
+          float4 v = make_float4(accm[t][rt][0] + accs[t][rt][0], accm[t][rt][1] + accs[t][rt][1],
+                                 accm[t][rt][2] + accs[t][rt][2], accm[t][rt][3] + accs[t][rt][3]);
+          if (relu) v = make_float4(relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z),
+                                    relu_keep_nan(v.w));
+          if (!last) {
+            // (every wave writes its 32 columns: units beyond N are exact zeros — zero weights,
+            //  zero bias — i.e. the next layer's zero-padded k-steps)
+            rs_store_planes4(nxt, ROWS, lr, u, v);
+            if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
+          } else {
+            if (u < PH - 4) *reinterpret_cast<float4*>(otile + lr * PH + u) = v;
+            if (rok && n.out)
+              store4_guarded(n.out, (int64_t)row * n.ldo, u, N,
+                             is_vec_ok(n.out, n.ldo) && (N & 3) == 0, v);
+          }
+        }
+      }
+    }
+  }
+  const float* in = xs;
+  int pin = P0;
+  if constexpr (!SPLITF) {
   // ---------------------------------------------------------------- forward (mlp_rowfwd_kernel)
   {
     const bool vx = is_vec_ok(a.x, a.ldx) && ((n.dims[0] & 3) == 0);
@@ -224,8 +411,6 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       *reinterpret_cast<float4*>(xs + r * P0 + c) = v;
     }
   }
-  const float* in = xs;
-  int pin = P0;
   for (int l = 0; l < n.L; ++l) {
     const int K = n.dims[l], N = n.dims[l + 1];
     const int nt = (N + 15) >> 4;
@@ -276,10 +461,11 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     in = nxt;
     pin = PH;
   }
+  }   // !SPLITF
   __syncthreads();
   PA_STAMP(a.prof, pwg, wave, 9);             // forward done
   // ---------------------------------------------------------------- head: d_out tile into hb[0]
-  const float* ot = hb[(n.L - 1) & 1];   // [ROWS][PH] network output of this tile
+  const float* ot = SPLITF ? otile : hb[(n.L - 1) & 1];   // [ROWS][PH] network output of this tile
   const int DL = n.dims[n.L];
   float* va = scr;
   float* vb = scr + 512;

@@ -575,8 +575,20 @@ def test_ppo_rowstep_equals_forward_heads_backward(S, A, hidden, B):
     """pa_ppo_rowstep (forward + both heads + both backward passes in ONE launch) against
     forward_pair(keep) -> pa_ppo_heads -> backward_pair(defer): the gradients and therefore the
     stepped parameters and optimizer state are bitwise the same, the reported losses equal to
-    rounding (their batch sums are grouped per 16-row tile)."""
+    rounding (their batch sums are grouped per 16-row tile).  (With the fp32-MFMA forward on both
+    sides: 32-row launches default to the bf16x3 forward, which is compared separately —
+    test_ppo_rowstep_bf16x3_forward_has_fp32_accuracy.)"""
     import copy
+    from torch import nn, optim
+    from pearl_amd import _native as N
+    N.check(N.lib().pa_debug_set_rowstep_split(0))
+    try:
+        _ppo_rowstep_vs_three_launches(S, A, hidden, B)
+    finally:
+        N.check(N.lib().pa_debug_set_rowstep_split(-1))
+
+
+def _ppo_rowstep_vs_three_launches(S, A, hidden, B):
     from torch import nn, optim
     from pearl_amd import _native as N
     from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
@@ -623,6 +635,88 @@ def test_ppo_rowstep_equals_forward_heads_backward(S, A, hidden, B):
         assert torch.equal(out[0][1][k], out[1][1][k]), k
     for a, b in zip(out[0][2], out[1][2]):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("S,A,hidden,B", [(256, 16, [256, 256], 4096), (100, 5, [200, 72], 4500),
+                                           (32, 3, [64, 64, 64], 8200)])
+def test_ppo_rowstep_bf16x3_forward_has_fp32_accuracy(S, A, hidden, B):
+    """The fused row step's bf16x3 forward (32-row launches: every operand split exactly three ways,
+    six products on v_mfma_f32_16x16x32_bf16, fp32 accumulation; weights from the engine's split
+    planes, which the optimizer epilogue keeps current) against the fp32-MFMA forward of the same
+    launch with float64 on the host as the yardstick: the logits and values the launch itself wrote
+    are no further from float64 than 2x the fp32 kernel's own error (floor 3e-7 of the output
+    scale) — at the first step (planes from the repack pass) AND at the third (planes refreshed
+    twice by the AdamW epilogue) — ragged batch sizes, widths that are not multiples of 32, a
+    three-hidden-layer network; the two paths' parameters stay within the Adam-trajectory bound,
+    and two runs of the bf16x3 path are bitwise identical."""
+    from torch import nn, optim
+    from helpers import assert_adam_trajectory_close
+    from pearl_amd import _native as N
+    from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of
+    torch.manual_seed(31)
+    da, dc = [S] + hidden + [A], [S] + hidden + [1]
+    x = torch.randn(B, S, device=DEV)
+    arep = torch.nn.functional.one_hot(torch.randint(0, A, (B,), device=DEV), A).float()
+    p_old = torch.rand(B, device=DEV) * 0.5 + 0.05
+    gae, lam = torch.randn(B, device=DEV), torch.randn(B, device=DEV)
+    xs = x.double().cpu()
+
+    def exact(layers):
+        h = xs
+        for i, l in enumerate(layers):
+            h = h @ l.weight.detach().double().cpu().t() + l.bias.detach().double().cpu()
+            if i + 1 < len(layers):
+                h = torch.relu(h)
+        return h
+
+    def run(mode):
+        N.check(N.lib().pa_debug_set_rowstep_split(mode))
+        try:
+            torch.manual_seed(32)
+            an = [nn.Linear(da[i], da[i + 1]).to(DEV) for i in range(len(da) - 1)]
+            cn = [nn.Linear(dc[i], dc[i + 1]).to(DEV) for i in range(len(dc) - 1)]
+            ao = optim.AdamW([p for l in an for p in l.parameters()], lr=1e-3, amsgrad=True)
+            co = optim.AdamW([p for l in cn for p in l.parameters()], lr=1e-3, amsgrad=True)
+            actor = FlatMlp(layers_of(an), ao, max_batch=B).ensure(B)
+            critic = FlatMlp(layers_of(cn), co, max_batch=B).ensure(B)
+            errs, used = [], 0
+            for step in range(3):
+                want_l, want_v = exact(an), exact(cn)         # from the parameters as they are NOW
+                actor.ready(B)
+                critic.ready(B)
+                logits = torch.empty(B, A, device=DEV)
+                value = torch.empty(B, 1, device=DEV)
+                d_logits, dv = torch.empty(B, A, device=DEV), torch.empty(B, device=DEV)
+                losses = torch.empty(2, device=DEV)
+                N.check(N.lib().pa_ppo_rowstep(
+                    actor.handle, critic.handle, x.data_ptr(), x.stride(0), B, arep.data_ptr(),
+                    arep.stride(0), p_old.data_ptr(), gae.data_ptr(), 0.1, 0.01, lam.data_ptr(),
+                    2.0 / B, logits.data_ptr(), logits.stride(0), value.data_ptr(), value.stride(0),
+                    d_logits.data_ptr(), d_logits.stride(0), dv.data_ptr(), losses.data_ptr(),
+                    N.stream_ptr(x.device)))
+                used = int(N.lib().pa_rowstep_last_split())
+                actor._pending_x, critic._pending_x = (x, d_logits), (x, dv)
+                FlatMlp.adam_pair(actor, critic, None)
+                torch.cuda.synchronize()
+                errs.append((float((logits.double().cpu() - want_l).abs().max() / want_l.abs().max()),
+                             float((value.double().cpu() - want_v).abs().max() / want_v.abs().max())))
+            return used, errs, [p.detach().clone() for l in an + cn for p in l.parameters()]
+        finally:
+            N.check(N.lib().pa_debug_set_rowstep_split(-1))
+
+    used32, e32, p32 = run(0)
+    useds, es, ps = run(-1)
+    _, _, ps2 = run(-1)
+    assert used32 == 0 and useds == 1, "the bf16x3 forward did not run for this launch"
+    print("\nlogits / value error vs float64 (of the output scale), steps 1..3:")
+    print("  fp32 MFMA forward:", " ".join(f"{a:.1e}/{b:.1e}" for a, b in e32))
+    print("  bf16x3 forward:   ", " ".join(f"{a:.1e}/{b:.1e}" for a, b in es))
+    for (a32, b32), (as_, bs) in zip(e32, es):
+        assert as_ <= max(2.0 * a32, 3e-7) and bs <= max(2.0 * b32, 3e-7), (e32, es)
+    for a, b in zip(ps, ps2):
+        assert torch.equal(a, b)
+    for a, b in zip(ps, p32):
+        assert_adam_trajectory_close(a, b, 1e-3, 3, rtol=1e-3, atol=2e-5, msg="bf16x3 vs fp32 forward")
 
 
 @pytest.mark.parametrize("dims,B", [([144, 256, 256, 1], 1024), ([9, 20, 1], 50)])

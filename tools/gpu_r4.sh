@@ -59,3 +59,46 @@ if [ "$MODE" == "p2p" ]; then
   timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err; echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
   timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > gpurun_out/bench_s20b.log 2>&1; tail -1 gpurun_out/bench_s20b.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('value', d['value'], 'steady', d['steady_state']['value'])"
 fi
+if [ "$MODE" == "pyprof" ]; then
+  timeout 300 python tools/shortcall.py --profile > gpurun_out/shortcall_profile.txt 2>&1; grep -v amdgpu gpurun_out/shortcall_profile.txt | head -60
+fi
+if [ "$MODE" == "hostcost" ]; then
+  timeout 300 python tools/host_cost.py > gpurun_out/host_cost.txt 2>&1; grep -v amdgpu gpurun_out/host_cost.txt
+fi
+if [ "$MODE" == "rs" ]; then
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -m gpu -q --tb=short -p no:cacheprovider -x \
+    -k "ppo or bandit or twin or rowstep or dsac or discrete" > gpurun_out/pytest_rs.log 2>&1
+  echo "pytest rc=$?"; tail -12 gpurun_out/pytest_rs.log
+  for sp in 1 0; do
+    PEARL_AMD_ROWSTEP_SPLIT=$sp timeout 600 python bench_algos.py --steps 300 --only ppo,bandit --cpu-seconds 0.5 > gpurun_out/bench_algos_rs$sp.jsonl 2> gpurun_out/bench_algos_rs$sp.err
+    echo "bench_algos rowstep split=$sp rc=$?"; python - <<PY
+import json
+for ln in open("gpurun_out/bench_algos_rs$sp.jsonl"):
+    if ln.startswith("{"):
+        d=json.loads(ln); print(d["config"][:24], round(d["value"]/1e6,2), "M", round(d["ms_per_step"]*1e3,1), "us/step", [(k["kernel"][:14], round(k["avg_launch_us"],1), k["pipe"][:6]) for k in d.get("kernels",[])])
+PY
+  done
+  timeout 300 python tools/prof_rowstep.py > gpurun_out/prof_rowstep_rs.txt 2>&1; grep -v amdgpu.ids gpurun_out/prof_rowstep_rs.txt | sed -n 3,16p
+fi
+if [ "$MODE" == "rs2" ]; then
+  timeout 600 python -m pytest tests/test_gpu_actor_critic.py -m gpu -q --tb=short -p no:cacheprovider -x -s \
+    -k "ppo_rowstep or ppo_learn_trajectory or ppo_preprocess or bandit_learn_batch or ppo_heads" > gpurun_out/pytest_rs2.log 2>&1
+  echo "pytest rc=$?"; grep -E "passed|failed|error vs float64|fp32 MFMA forward|bf16x3 forward|Error" gpurun_out/pytest_rs2.log | tail -20
+fi
+if [ "$MODE" == "rs3" ]; then
+  timeout 600 python -m pytest tests/test_gpu_actor_critic.py tests/test_gpu_dp.py -m gpu -q --tb=short -p no:cacheprovider -x -s \
+    -k "ppo_rowstep_bf16x3 or p2p" > gpurun_out/pytest_rs3.log 2>&1
+  echo "pytest rc=$?"; grep -E "passed|failed|error vs float64|fp32 MFMA forward|bf16x3 forward|Error" gpurun_out/pytest_rs3.log | tail -20
+fi
+if [ "$MODE" == "bandit" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  for w in bandit sac; do
+    rm -rf $R/gpurun_out/prof_$w
+    timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0.2 > $R/gpurun_out/rocprof_$w.log 2>&1
+    DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+    python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+    echo "rocprof $w rc=$?"; head -16 $R/gpurun_out/${w}_kernel_stats.txt | cut -c1-150
+    python $R/tools/rocpd_timeline.py $DB mlp_rowstep 30 > $R/gpurun_out/${w}_timeline.txt 2>&1; head -40 $R/gpurun_out/${w}_timeline.txt | cut -c1-150
+    rm -f $DB
+  done
+fi
