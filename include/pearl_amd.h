@@ -410,6 +410,9 @@ int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int32_t ldx, i
                    float* out, int32_t ldo, int32_t keep, void* stream);
 /* kept output (after ReLU) of hidden layer `layer` of the last keep = 1 forward */
 int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float* out, int32_t ldo, void* stream);
+/* the kept activation in place: device pointer and row pitch (floats) of hidden layer `layer`'s
+ * output [kept batch][d]; valid until the next forward of this network (AdamW does not touch it) */
+int pa_mlp_activation(pa_mlp* h, int32_t layer, float** ptr_out, int32_t* ld_out);
 /* autograd of the kept forward: d_x[B, d_0] (nullable) and the weight gradients dW/db into
  * bufs.grad — want_dw 0: none; 1: now; 2: DEFERRED to the next pa_mlp_adam on this network, which
  * then runs dW, AdamW and the refresh of the row-pass kernels' packed weights as ONE launch per
@@ -830,8 +833,17 @@ int pa_weighted_loss_head(const float* pred, int32_t ldp, const float* y, const 
  *   pa_linreg_sigma: sqrt([1|f] inv_A [1|f]^T) per row (:261-270) */
 int pa_linreg_delta(const float* features, int32_t ldf, const float* y, const float* w, int32_t B,
                     int32_t d, float* x_scratch, float* r_scratch, float* delta_out, void* stream);
+/* pa_linreg_delta with vector-aligned scratch rows (x_scratch[B*Dp + D], Dp = D rounded up to 4;
+ * r_scratch[B*Rp], Rp = D + 1 rounded up to 2; both 16-byte aligned): the same delta, and batches of
+ * >= 2048 contexts then take the bf16x3 weight-gradient loop for X^T R as well */
+int pa_linreg_delta2(const float* features, int32_t ldf, const float* y, const float* w, int32_t B,
+                     int32_t d, float* x_scratch, float* r_scratch, float* delta_out, void* stream);
 int pa_linreg_apply(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
                     void* stream);
+/* the same, also writing the updated A [D][D] and b [D] into a snapshot pair (both or none): the
+ * operands of a solve that runs off the learner's stream while the next step updates A and b */
+int pa_linreg_apply2(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
+                     float* A_snap, float* b_snap, void* stream);
 int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t d, double* work,
                     float* inv_A_out, float* coefs_out, int32_t* singular_out, void* stream);
 int pa_linreg_sigma(const float* features, int32_t ldf, const float* inv_A, int32_t B, int32_t d,

@@ -451,6 +451,9 @@ SIGNATURES = {
                                     C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
                                     C.c_int64, _P, _P]),
     "pa_weighted_mse_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
+    "pa_linreg_delta2": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "pa_linreg_apply2": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "pa_mlp_activation": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "pa_weighted_loss_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                         _P, _P, _P]),
     "pa_linreg_delta": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),

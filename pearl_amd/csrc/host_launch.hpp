@@ -205,8 +205,11 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
     for (int k = 0; k < a.nprob; ++k) {
       const DwProblem& P = a.p[k];
       if (P.M == 1) continue;   // the GEMV path
-      ok = ok && (P.ldz & 3) == 0 && (P.M & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dZ) & 15) == 0 &&
-           (P.ldx & 1) == 0 && (P.N & 1) == 0 && (reinterpret_cast<uintptr_t>(P.X) & 7) == 0;
+      // (row pitches of whole vectors: a vector that straddles M or N reads pad / neighbour
+      //  columns of its own row — inside the allocation — into accumulator rows / columns beyond
+      //  the problem, which the epilogue never stores)
+      ok = ok && (P.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dZ) & 15) == 0 &&
+           (P.ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(P.X) & 7) == 0;
     }
     a.split = ok ? 1 : 0;
   }

@@ -406,6 +406,17 @@ extern "C" int pa_mlp_copy_activation(pa_mlp* h, int32_t layer, int32_t B, float
   return PA_OK;
 }
 
+// The kept activation itself (device pointer and row pitch in floats) instead of a copy: valid until
+// the next forward of this network; the optimizer step does not touch it.
+extern "C" int pa_mlp_activation(pa_mlp* h, int32_t layer, float** ptr_out, int32_t* ld_out) {
+  PA_REQUIRE(h && ptr_out && ld_out && layer >= 0 && layer + 1 < h->L && h->act[layer], PA_ERR_INVALID,
+             "pa_mlp_activation: no such kept activation");
+  PA_REQUIRE(h->kept_B > 0, PA_ERR_INVALID, "pa_mlp_activation: no forward with keep = 1 precedes it");
+  *ptr_out = h->act[layer];
+  *ld_out = h->d.dims[layer + 1];
+  return PA_OK;
+}
+
 namespace {
 
 // dW/db of every layer of one network — or of TWO networks that share an optimizer (twin
@@ -453,7 +464,11 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
     const char* v = getenv("PEARL_AMD_MLP_DW_TM");
     return v && *v ? atoi(v) : 0;
   }();
-  for (int l0 = 0; l0 < L; l0 += 3) {
+  // up to DW_MAX_PROB problems per launch: three layers each for a pair of networks, every layer of
+  // one network with up to six (the bandit's four-layer trunk + head used to be two launches, the
+  // second a 17 us single-output GEMV on two workgroups)
+  const int LPL = DW_MAX_PROB / nnet;
+  for (int l0 = 0; l0 < L; l0 += LPL) {
     DwArgs a;
     memset(&a, 0, sizeof(a));
     int t0 = 0;
@@ -461,7 +476,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
     {
       int tiles32 = 0;
       for (int ni = 0; ni < nnet; ++ni)
-        for (int l = l0; l < L && l < l0 + 3; ++l)
+        for (int l = l0; l < L && l < l0 + LPL; ++l)
           tiles32 += (int)(ceil_div(hs[ni]->d.dims[l + 1], 32) * ceil_div(hs[ni]->d.dims[l], DW_TN));
       // (big batches stay on 64-row tiles: at PPO's 4096 rows the 32-row tiling is 272 workgroups,
       //  every one of them MFMA-bound — a 16-row output layer's padded tile as much as a full one —
@@ -472,7 +487,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
     a.tm = TM;
     for (int ni = 0; ni < nnet; ++ni) {
       pa_mlp* h = hs[ni];
-      for (int l = l0; l < L && l < l0 + 3; ++l) {
+      for (int l = l0; l < L && l < l0 + LPL; ++l) {
         DwProblem& pr = a.p[a.nprob++];
         pr.dZ = ops[ni].dzs[l]; pr.ldz = ops[ni].ldzs[l];
         pr.X = l > 0 ? h->act[l - 1] : ops[ni].x;
@@ -525,7 +540,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
       }
     }
     // the step's scalar tail rides the last launch as one extra workgroup
-    const bool with_tail = tail && l0 + 3 >= L;
+    const bool with_tail = tail && l0 + LPL >= L;
     if (with_tail) a.tail = *tail;
     int rc;
     {
@@ -2293,40 +2308,48 @@ __global__ __launch_bounds__(256) void wmse_kernel(WmseArgs a) {
 
 // LinearRegression.learn_batch operands (linear_regression.py:192-219): X = [1 | nn_out] and
 // R = [X * w | y * w], so that X^T R = [delta_A (before symmetrisation) | delta_b].
+// (ldX >= D, ldR >= D + 1: row pitches; pad columns are written as zeros)
 __global__ __launch_bounds__(256) void linreg_operands_kernel(const float* __restrict__ f, int ldf,
                                                               const float* __restrict__ y,
                                                               const float* __restrict__ w, int B,
-                                                              int d, float* __restrict__ X,
-                                                              float* __restrict__ R) {
+                                                              int d, float* __restrict__ X, int ldX,
+                                                              float* __restrict__ R, int ldR) {
   const int D = d + 1;
-  const int64_t total = (int64_t)B * (D + 1);
+  const int W = ldR > ldX ? ldR : ldX;
+  const int64_t total = (int64_t)B * W;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * 256) {
-    const int64_t b = e / (D + 1);
-    const int j = (int)(e - b * (D + 1));
+    const int64_t b = e / W;
+    const int j = (int)(e - b * W);
     const float wb = w ? w[b] : 1.0f;
-    if (j < D) {
-      const float x = (j == 0) ? 1.0f : f[b * ldf + (j - 1)];
-      X[b * D + j] = x;
-      R[b * (D + 1) + j] = x * wb;
-    } else {
-      R[b * (D + 1) + D] = y[b] * wb;
-    }
+    const float x = (j == 0) ? 1.0f : (j < D ? f[b * ldf + (j - 1)] : 0.f);
+    if (j < ldX) X[b * ldX + j] = x;
+    if (j < ldR) R[b * ldR + j] = j < D ? x * wb : (j == D ? y[b] * wb : 0.f);
   }
 }
 
 // A += (dA + dA^T) / 2; b += db; sum_weight += dsw     (linear_regression.py:204-216)
+// A_snap / b_snap (nullable): the updated A and b written a second time — the operands of the
+// asynchronous solve (two device-to-device copy launches otherwise)
 __global__ __launch_bounds__(256) void linreg_apply_kernel(const float* __restrict__ delta, int D,
                                                            float* __restrict__ A,
                                                            float* __restrict__ bvec,
-                                                           float* __restrict__ sw) {
+                                                           float* __restrict__ sw,
+                                                           float* __restrict__ A_snap,
+                                                           float* __restrict__ b_snap) {
   const int64_t total = (int64_t)D * D;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * 256) {
     const int i = (int)(e / D), j = (int)(e - (int64_t)i * D);
     const float s = (delta[(int64_t)i * (D + 1) + j] + delta[(int64_t)j * (D + 1) + i]) / 2.0f;
-    A[e] += s;
-    if (j == 0) bvec[i] += delta[(int64_t)i * (D + 1) + D];
+    const float an = A[e] + s;
+    A[e] = an;
+    if (A_snap) A_snap[e] = an;
+    if (j == 0) {
+      const float bn = bvec[i] + delta[(int64_t)i * (D + 1) + D];
+      bvec[i] = bn;
+      if (b_snap) b_snap[i] = bn;
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) sw[0] += delta[(int64_t)D * (D + 1)];
 }
@@ -2631,29 +2654,32 @@ extern "C" int pa_weighted_mse_head(const float* pred, int32_t ldp, const float*
                                loss_out, wsum_out, stream);
 }
 
-extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* y, const float* w,
-                               int32_t B, int32_t d, float* x_scratch, float* r_scratch,
-                               float* delta_out, void* stream) {
-  PA_REQUIRE(features && y && x_scratch && r_scratch && delta_out && B > 0 && d > 0, PA_ERR_INVALID,
-             "pa_linreg_delta: bad argument");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// padded: 0 = the packed layout of the original entry point (X [B][D], R [B][D + 1]); 1 = row
+// pitches rounded up to whole 16- / 8-byte vectors (X [B][Dp], Dp = D rounded up to 4; R [B][Rp],
+// Rp = D + 1 rounded up to 2; pad columns zero), which is what lets batches of >= 2048 contexts take
+// the bf16x3 weight-gradient loop for this GEMM too
+static int linreg_delta_impl(const float* features, int32_t ldf, const float* y, const float* w,
+                             int32_t B, int32_t d, float* x_scratch, float* r_scratch,
+                             float* delta_out, int padded, hipStream_t s) {
   const int D = d + 1;
-  const int64_t total = (int64_t)B * (D + 1);
+  const int ldX = padded ? (D + 3) & ~3 : D, ldR = padded ? (D + 2) & ~1 : D + 1;
+  const int W = ldR > ldX ? ldR : ldX;
+  const int64_t total = (int64_t)B * W;
   const unsigned grid = (unsigned)(ceil_div(total, 256) > 2048 ? 2048 : ceil_div(total, 256));
   hipLaunchKernelGGL(linreg_operands_kernel, dim3(grid), dim3(256), 0, s, features, ldf, y, w, B, d,
-                     x_scratch, r_scratch);
+                     x_scratch, ldX, r_scratch, ldR);
   PA_LAUNCH_CHECK();
   // X^T R = [delta_A | delta_b] ([D][D+1]); the "bias" output of the kernel (column sums of X) is
   // written behind it and its first entry (the ones column sum) is NOT the weight sum, so the
   // weight sum rides as delta_out[D * (D + 1)] = sum_b R[b][0] = sum_b w_b: it is column 0 of
-  // row 0 of delta_A as well; copy it in the apply kernel instead.
+  // row 0 of delta_A as well.
   DwArgs a;
   memset(&a, 0, sizeof(a));
   a.nprob = 1;
-  a.p[0].dZ = x_scratch; a.p[0].ldz = D;
-  a.p[0].X = r_scratch; a.p[0].ldx = D + 1;
+  a.p[0].dZ = x_scratch; a.p[0].ldz = ldX;
+  a.p[0].X = r_scratch; a.p[0].ldx = ldR;
   a.p[0].dW = delta_out; a.p[0].ldw = D + 1;
-  a.p[0].db = x_scratch + (int64_t)B * D;   // scratch tail: D floats
+  a.p[0].db = x_scratch + (int64_t)B * ldX;   // scratch tail: D floats
   a.p[0].M = D; a.p[0].N = D + 1;
   a.p[0].tiles_n = (int)ceil_div(D + 1, DW_TN);
   a.p[0].tile0 = 0;
@@ -2669,15 +2695,39 @@ extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* 
                         hipMemcpyDeviceToDevice, s));
   return PA_OK;
 }
+extern "C" int pa_linreg_delta(const float* features, int32_t ldf, const float* y, const float* w,
+                               int32_t B, int32_t d, float* x_scratch, float* r_scratch,
+                               float* delta_out, void* stream) {
+  PA_REQUIRE(features && y && x_scratch && r_scratch && delta_out && B > 0 && d > 0, PA_ERR_INVALID,
+             "pa_linreg_delta: bad argument");
+  return linreg_delta_impl(features, ldf, y, w, B, d, x_scratch, r_scratch, delta_out, 0,
+                           reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pa_linreg_delta2(const float* features, int32_t ldf, const float* y, const float* w,
+                                int32_t B, int32_t d, float* x_scratch, float* r_scratch,
+                                float* delta_out, void* stream) {
+  PA_REQUIRE(features && y && x_scratch && r_scratch && delta_out && B > 0 && d > 0, PA_ERR_INVALID,
+             "pa_linreg_delta2: bad argument");
+  PA_REQUIRE(((reinterpret_cast<uintptr_t>(x_scratch) | reinterpret_cast<uintptr_t>(r_scratch)) & 15) == 0,
+             PA_ERR_INVALID, "pa_linreg_delta2: scratch buffers must be 16-byte aligned");
+  return linreg_delta_impl(features, ldf, y, w, B, d, x_scratch, r_scratch, delta_out, 1,
+                           reinterpret_cast<hipStream_t>(stream));
+}
 
-extern "C" int pa_linreg_apply(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
-                               void* stream) {
+extern "C" int pa_linreg_apply2(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
+                                float* A_snap, float* b_snap, void* stream) {
   PA_REQUIRE(delta && A && b && sum_weight && d > 0, PA_ERR_INVALID, "pa_linreg_apply: bad argument");
+  PA_REQUIRE((A_snap == nullptr) == (b_snap == nullptr), PA_ERR_INVALID,
+             "pa_linreg_apply2: both snapshots or none");
   const int D = d + 1;
   hipLaunchKernelGGL(linreg_apply_kernel, dim3((unsigned)ceil_div((int64_t)D * D, 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), delta, D, A, b, sum_weight);
+                     reinterpret_cast<hipStream_t>(stream), delta, D, A, b, sum_weight, A_snap, b_snap);
   PA_LAUNCH_CHECK();
   return PA_OK;
+}
+extern "C" int pa_linreg_apply(const float* delta, int32_t d, float* A, float* b, float* sum_weight,
+                               void* stream) {
+  return pa_linreg_apply2(delta, d, A, b, sum_weight, nullptr, nullptr, stream);
 }
 
 extern "C" int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t d,

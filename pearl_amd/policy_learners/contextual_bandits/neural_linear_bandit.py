@@ -17,6 +17,7 @@ The regression operates on the features computed BEFORE the optimizer step, as i
 from __future__ import annotations
 
 import copy
+import ctypes as C
 import os
 
 from typing import Any, Dict, List, Optional
@@ -193,7 +194,6 @@ class NeuralLinearBandit(PolicyLearner):
         lr = self.model._linear_regression_layer
         d = lr._feature_dim
         D = d + 1
-        feats = torch.empty(B, d, dtype=torch.float32, device=dev)
         dpred = torch.empty(B, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         wsum = torch.empty(1, dtype=torch.float32, device=dev)
@@ -217,9 +217,11 @@ class NeuralLinearBandit(PolicyLearner):
             N.check(lib.pa_weighted_loss_head(z.data_ptr(), z.stride(0), y.data_ptr(), N.ptr(w), B,
                                               kind, oact, pred.data_ptr(), dpred.data_ptr(),
                                               loss.data_ptr(), wsum.data_ptr(), s))
-        # features of this forward (before the optimizer step) feed the regression: copy them out
-        N.check(lib.pa_mlp_copy_activation(net.handle, len(net.layers) - 2, B, feats.data_ptr(),
-                                           feats.stride(0), s))
+        # features of this forward (before the optimizer step) feed the regression: read in place
+        # (the kept activation is not touched by the optimizer step; a copy launch otherwise)
+        feats_ptr, feats_ld = C.c_void_p(), C.c_int32()
+        N.check(lib.pa_mlp_activation(net.handle, len(net.layers) - 2, C.byref(feats_ptr),
+                                      C.byref(feats_ld)))
         # all-zero weights: skip the optimizer (:171-175).  Data parallel: the decision is taken on
         # the GLOBAL weight sum, so every rank enters (or skips) the gradient all-reduce of
         # net.adam() together — a rank-local decision left the other ranks hanging in it.
@@ -235,10 +237,10 @@ class NeuralLinearBandit(PolicyLearner):
                 net.backward(x, dpred, want_dw=True, defer=True)
             net.adam()
         # ---- LinUCB update on the detached features
-        xs = torch.empty(B * D + D, dtype=torch.float32, device=dev)
-        rs = torch.empty(B * (D + 1), dtype=torch.float32, device=dev)
+        xs = torch.empty(B * ((D + 3) & ~3) + D, dtype=torch.float32, device=dev)     # rows of whole
+        rs = torch.empty(B * ((D + 2) & ~1), dtype=torch.float32, device=dev)         # 16- / 8-byte vectors
         delta = torch.empty(D * (D + 1) + 1, dtype=torch.float32, device=dev)
-        N.check(lib.pa_linreg_delta(feats.data_ptr(), feats.stride(0), y.data_ptr(), N.ptr(w), B, d,
+        N.check(lib.pa_linreg_delta2(feats_ptr, feats_ld.value, y.data_ptr(), N.ptr(w), B, d,
                                     xs.data_ptr(), rs.data_ptr(), delta.data_ptr(), s))
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(delta)          # delta_A | delta_b | delta_sum_weight in ONE message
@@ -247,24 +249,21 @@ class NeuralLinearBandit(PolicyLearner):
             if buf.device != dev or not buf.is_contiguous():
                 lr.join_solve()
                 setattr(lr, name, buf.to(dev).contiguous())
-        N.check(lib.pa_linreg_apply(delta.data_ptr(), d, lr._A.data_ptr(), lr._b.data_ptr(),
-                                    lr._sum_weight.data_ptr(), s))
-        self._solve(lr, dev)
+        # A, b, sum_weight updated in place; the same launch also writes the (A, b) snapshot the
+        # asynchronous solve reads (two copy launches otherwise)
+        snap = self._solve_slot(lr, dev)
+        N.check(lib.pa_linreg_apply2(delta.data_ptr(), d, lr._A.data_ptr(), lr._b.data_ptr(),
+                                     lr._sum_weight.data_ptr(),
+                                     None if snap is None else snap[0].data_ptr(),
+                                     None if snap is None else snap[1].data_ptr(), s))
+        self._solve(lr, dev, snap)
         self._maybe_apply_discounting()
         p = pred.detach().reshape(B, -1)
         return {"label": y, "prediction": p, "weight": w if w is not None else torch.ones_like(y),
                 "loss": loss[0], "mu_scores": p.mean()}
 
-    def _solve(self, lr: Any, dev: torch.device) -> None:
-        """inv(A + lambda I) and coefs = inv_A b (linear_regression.py:252-270 calculate_coefs) — OFF
-        the learner's critical path: the fp64 Gauss-Jordan solve is ONE serial workgroup (97 us of a
-        240 us step) and nothing in the next learn_batch reads `_inv_A` / `_coefs`; they are read at
-        act time.  So the step snapshots (A, b) on the learner stream (two small copies) and the
-        solve runs on a side stream; readers of the two buffers join it
-        (LinearRegression.join_solve: attribute access, state_dict).  PEARL_AMD_BANDIT_ASYNC_SOLVE=0:
-        in-stream as before."""
-        d = lr._feature_dim
-        D = d + 1
+    def _solve_state_for(self, lr: Any, dev: torch.device) -> Dict[str, Any]:
+        D = lr._feature_dim + 1
         st = self.__dict__.get("_solve_state")
         if st is None or st["dev"] != dev or st["D"] != D:
             st = {"dev": dev, "D": D, "side": torch.cuda.Stream(dev), "slot": 0,
@@ -272,8 +271,34 @@ class NeuralLinearBandit(PolicyLearner):
                             torch.empty(D, dtype=torch.float32, device=dev)) for _ in range(2)],
                   "work": [torch.empty(D * 2 * D, dtype=torch.float64, device=dev) for _ in range(2)],
                   "flag": torch.zeros(2, dtype=torch.int32, device=dev),
-                  "busy": [None, None]}
+                  "busy": [None, None], "cur": None}
             self.__dict__["_solve_state"] = st
+        return st
+
+    def _solve_slot(self, lr: Any, dev: torch.device):
+        """The (A, b) snapshot pair the NEXT asynchronous solve reads, made safe to overwrite (the
+        solve that last read it — two steps back — has finished as far as the learner stream is
+        concerned); None when the solve runs in-stream (PEARL_AMD_BANDIT_ASYNC_SOLVE=0)."""
+        if os.environ.get("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1") == "0":
+            return None
+        st = self._solve_state_for(lr, dev)
+        i = st["slot"]
+        st["slot"] = 1 - i
+        st["cur"] = i
+        if st["busy"][i] is not None:
+            torch.cuda.current_stream(dev).wait_event(st["busy"][i])
+        return st["snap"][i]
+
+    def _solve(self, lr: Any, dev: torch.device, snap=None) -> None:
+        """inv(A + lambda I) and coefs = inv_A b (linear_regression.py:252-270 calculate_coefs) — OFF
+        the learner's critical path: the fp64 Gauss-Jordan solve is ONE serial workgroup (97 us of a
+        240 us step) and nothing in the next learn_batch reads `_inv_A` / `_coefs`; they are read at
+        act time.  So the step leaves a snapshot of (A, b) on the learner stream (written by the
+        apply launch itself: `snap`, from _solve_slot) and the solve runs on a side stream; readers
+        of the two buffers join it (LinearRegression.join_solve: attribute access, state_dict).
+        PEARL_AMD_BANDIT_ASYNC_SOLVE=0: in-stream as before."""
+        d = lr._feature_dim
+        st = self._solve_state_for(lr, dev)
         inv_A, coefs = lr._buffers["_inv_A"], lr._buffers["_coefs"]     # (no join: we are the writer)
         if os.environ.get("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1") == "0":
             lr.join_solve()
@@ -282,13 +307,13 @@ class NeuralLinearBandit(PolicyLearner):
                                             coefs.data_ptr(), st["flag"].data_ptr(), N.stream_ptr(dev)))
             return
         main = torch.cuda.current_stream(dev)
-        i = st["slot"]
-        st["slot"] = 1 - i
-        if st["busy"][i] is not None:
-            main.wait_event(st["busy"][i])        # the solve that last read this snapshot (two back)
-        A_s, b_s = st["snap"][i]
-        A_s.copy_(lr._A)
-        b_s.copy_(lr._b)
+        if snap is None:
+            # (a caller that changed A / b itself — discounting: take the snapshot with two copies)
+            snap = self._solve_slot(lr, dev)
+            snap[0].copy_(lr._A)
+            snap[1].copy_(lr._b)
+        i = st["cur"]
+        A_s, b_s = snap
         ready = torch.cuda.Event()
         ready.record(main)
         side = st["side"]

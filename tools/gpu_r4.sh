@@ -102,3 +102,17 @@ if [ "$MODE" == "bandit" ]; then
     rm -f $DB
   done
 fi
+if [ "$MODE" == "bandit2" ]; then
+  timeout 600 python -m pytest tests/test_gpu_actor_critic.py -m gpu -q --tb=short -p no:cacheprovider -x \
+    -k "bandit or linreg or squarecb or dsac_rowsteps or twin_adam or qnet" > gpurun_out/pytest_b2.log 2>&1
+  echo "pytest rc=$?"; tail -5 gpurun_out/pytest_b2.log
+  timeout 600 python -m pytest tests/test_gpu_dqn.py -m gpu -q --tb=short -p no:cacheprovider -x -k "qnet or generic or deep3 or dueling or multihead" > gpurun_out/pytest_b3.log 2>&1
+  echo "pytest rc=$?"; tail -3 gpurun_out/pytest_b3.log
+  timeout 600 python bench_algos.py --steps 300 --only bandit,dsac --cpu-seconds 0.5 > gpurun_out/bench_algos_b2.jsonl 2> gpurun_out/bench_algos_b2.err
+  python - <<PY
+import json
+for ln in open("gpurun_out/bench_algos_b2.jsonl"):
+    if ln.startswith("{"):
+        d=json.loads(ln); print(d["config"][:30], round(d["value"]/1e6,2), "M", round(d["ms_per_step"]*1e3,1), "us/step", [(k["kernel"][:14], round(k["avg_launch_us"],1), k["pipe"][:6]) for k in d.get("kernels",[])])
+PY
+fi
