@@ -874,6 +874,11 @@ int pa_debug_linear(const float* A, int32_t lda, const float* B, int32_t ldb, fl
  * exactly split operands, fp32 accuracy) for batches of >= 2048 rows with aligned operands,
  * 2 = the same below the batch threshold (tests). */
 int pa_debug_set_dw_split(int32_t mode);
+/* Tile shape of the bf16x3 target kernel: 32 = 32-row tiles on four waves, two workgroups per CU (one
+ * workgroup's prologue / epilogue runs beside the other's main loop); 64 = the 64-row, eight-wave
+ * tile; 0 = the default: per pass (32 for Double DQN's stand-alone passes, 64 for the DQN window
+ * loop), or what PEARL_AMD_TARGET_ROWS says.  Bitwise-identical results either way. */
+int pa_debug_set_target_rows(int32_t rows);
 /* dW[M,N] = dZ[Bn,M]^T X[Bn,N], db[M] = column sums of dZ. */
 int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx, float* dW,
                          int32_t ldw, float* db, int32_t M, int32_t N, int32_t Bn, void* stream);

@@ -444,6 +444,7 @@ SIGNATURES = {
     "pa_sac_timing_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "pa_mlp_timing": (C.c_int, [C.c_int32]),
     "pa_debug_set_dw_split": (C.c_int, [C.c_int32]),
+    "pa_debug_set_target_rows": (C.c_int, [C.c_int32]),
     "pa_debug_set_rowstep_split": (C.c_int, [C.c_int32]),
     "pa_rowstep_last_split": (C.c_int, []),
     "pa_mlp_timing_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

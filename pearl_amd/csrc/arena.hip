@@ -537,6 +537,18 @@ int dw_split_mode() {
   return m;
 }
 void set_dw_split_mode(int mode) { g_dw_split_mode.store(mode); }
+
+static std::atomic<int> g_target_rows{0};
+int target_rows_mode() {
+  int m = g_target_rows.load();
+  if (m == 0) {
+    const char* v = getenv("PEARL_AMD_TARGET_ROWS");
+    const int e = v ? atoi(v) : 0;
+    m = (e == 32 || e == 64) ? e : -1;       // -1: per pass (TargetArgs::rows_hint)
+  }
+  return m < 0 ? 0 : m;
+}
+void set_target_rows_mode(int rows) { g_target_rows.store(rows); }
 }  // namespace pa
 
 extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {

@@ -22,6 +22,10 @@ void release_process_device();
 // everywhere, 1 = the bf16x3 split loop where eligible, 2 = also below the batch threshold (tests)
 int dw_split_mode();
 void set_dw_split_mode(int mode);
+// rows per tile of the bf16x3 target kernel: 32 (two 4-wave workgroups per CU) or 64 everywhere, or
+// 0 = per pass (TargetArgs::rows_hint; the default unless PEARL_AMD_TARGET_ROWS says otherwise)
+int target_rows_mode();
+void set_target_rows_mode(int rows);
 
 #define PA_HIP(expr)                                                             \
   do {                                                                           \

@@ -411,7 +411,7 @@ int run_u_split(pa_dqn* h, const pa_dqn_batch* b, float* U, hipStream_t s) {
 int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* next_v, float* y,
                        hipStream_t s, bool persistent = false, int* argmax = nullptr,
                        bool sample_timer = true, bool no_pingpong = false,
-                       int prio_first_rows = 0, bool read_u = false) {
+                       int prio_first_rows = 0, bool read_u = false, int rows_hint = 0) {
   // argmax != null: the pass runs on the ONLINE parameters and only reports each row's first
   // maximum (Double DQN's action choice); always the classic grid
   // level 1: only the launches the caller marks (learn(): the last, largest piece of every 4th
@@ -421,6 +421,7 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
   bool split = false;
   TargetArgs a = make_target_args(h, b, U, next_v, y, argmax, &split, nullptr);
   if (read_u) a.W1sp = nullptr;
+  a.rows_hint = rows_hint;
   a.prof = (h->prof_tgt && a.ntiles <= h->prof_tgt_tiles) ? h->prof_tgt : nullptr;
   if (prio_first_rows > 0) a.prio_tiles = (int)ceil_div(prio_first_rows, a.bpw);
   const bool pp = !argmax && !no_pingpong && !split &&
@@ -501,14 +502,14 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
     rc = launch_linear<false>(g, 2, s);
     if (rc != PA_OK) return rc;
   }
-  rc = run_target_fused_u(h, b, h->Uw[0], nullptr, nullptr, s, false, h->choice);
+  rc = run_target_fused_u(h, b, h->Uw[0], nullptr, nullptr, s, false, h->choice, true, false, 0, false, 32);
   if (rc != PA_OK) return rc;
   pa_dqn_batch one = *b;
   one.A = 1;
   one.next_avail_rep = h->choice_rep;
   one.next_avail_bcast = 0;
   one.next_mask = nullptr;
-  return run_target_fused_u(h, &one, h->Uw[1], next_v, y, s);
+  return run_target_fused_u(h, &one, h->Uw[1], next_v, y, s, false, nullptr, true, false, 0, false, 32);
 }
 
 // max_a' Q_target(s', a') (DeepQLearning) or Q_target(s', argmax_a' Q(s', a')) (DoubleDQN) and the
@@ -1738,6 +1739,13 @@ extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int3
   PA_REQUIRE(epi == EPI_NONE || (epi == EPI_MASK ? hmask != nullptr : bias != nullptr), PA_ERR_INVALID,
              "epilogue %d needs %s", epi, epi == EPI_MASK ? "hmask" : "bias");
   return b_is_kn ? launch_linear<true>(&g, 1, s) : launch_linear<false>(&g, 1, s);
+}
+
+extern "C" int pa_debug_set_target_rows(int32_t rows) {
+  PA_REQUIRE(rows == 0 || rows == 32 || rows == 64, PA_ERR_INVALID,
+             "pa_debug_set_target_rows: 0 (environment / default), 32 or 64");
+  set_target_rows_mode(rows);
+  return PA_OK;
 }
 
 extern "C" int pa_debug_set_dw_split(int32_t mode) {

@@ -348,6 +348,8 @@ struct TargetArgs {
   float* choice_rep;         // with argmax: [B][AD] = feat row of that action (double_dqn.py:48-51)
   float* q_all;              // optional [B * A]: every (transition, action) value before masking
                              // (TwinCritic.get_q_values on an action set, discrete SAC)
+  int rows_hint;             // 32: this pass prefers the 32-row, four-wave tile (two workgroups per CU:
+                             // stand-alone passes — Double DQN, all-actions values); 0: the 64-row tile
   int prio_tiles;            // classic grid: tiles below this index run at raised wave priority (the
                              // first round of a window, whose targets the online chain waits for,
                              // shares every CU with a later round's tile)

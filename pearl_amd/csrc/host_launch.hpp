@@ -111,9 +111,43 @@ inline int launch_u_split(const TargetArgs& a, float* U, hipStream_t s) {
       return PA_ERR_UNSUPPORTED;
   }
 }
+// target_split32_kernel: 32-row tiles on four waves, two workgroups per CU (target_split_kernel.hpp).
+// Takes the 64-row tile's arguments and re-derives the tile geometry.  Tiles that read U, A <= 32.
+// Default: the passes that ask for it (TargetArgs::rows_hint — Double DQN's two passes, the
+// all-actions passes of pa_mlp_q_all: +11 % on DoubleDQN); the DQN window loop keeps the 64-row tile
+// (its persistent launches share the chip with the online chain: 27.5 M against 26.4 M in steady
+// state, same box).  PEARL_AMD_TARGET_ROWS=32|64 / pa_debug_set_target_rows: either one everywhere.
+inline bool target_split32_ok(const TargetArgs& a) {
+  const int mode = target_rows_mode();   // 0: per pass (a.rows_hint), 32 / 64: everywhere
+  const bool want = mode == 32 || (mode == 0 && a.rows_hint == 32);
+  return want && !a.W1sp && a.A <= TS32_ROWS && a.prof == nullptr;
+}
+inline int launch_target_split32(const TargetArgs& a64, hipStream_t s) {
+  static bool configured = false;
+  const size_t smem = target_split32_smem_bytes();
+  if (!configured) {
+    int rc = set_max_smem(target_split32_kernel, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  TargetArgs a = a64;
+  const int prio_rows = a64.prio_tiles * a64.bpw;
+  a.bpw = TS32_ROWS / a.A;
+  a.ntiles = (int)ceil_div(a.B, a.bpw);
+  a.prio_tiles = prio_rows > 0 ? (int)ceil_div(prio_rows, a.bpw) : 0;
+  a.prof = nullptr;
+  unsigned grid = (unsigned)a.ntiles;
+  // persistent mode: two workgroups per CU are resident; offer enough that the ones landing on
+  // reserved CUs (and exiting) leave no other CU short
+  if (a.tile_ctr) grid = a.reserved ? 1024u : (unsigned)(a.ntiles < 512 ? a.ntiles : 512);
+  hipLaunchKernelGGL(target_split32_kernel, dim3(grid), dim3(256), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
 // state widths the tile can form U from itself (compile-time k-step counts)
 inline bool target_split_fusable_S(int S) { return S == 64 || S == 128 || S == 256; }
 inline int launch_target_split(const TargetArgs& a, hipStream_t s) {
+  if (target_split32_ok(a)) return launch_target_split32(a, s);
   if (!a.W1sp) return launch_target_split_t<0>(a, s);
   switch (a.S) {
     case 64: return launch_target_split_t<4>(a, s);

@@ -395,4 +395,236 @@ static __global__ __launch_bounds__(512, 2) void target_split_kernel(TargetArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same tile for 32 rows and FOUR waves (256 threads): two workgroups share a CU (51 KB of LDS
+// each), so one workgroup's prologue and epilogue — U / table loads, the K = 16 layer, the three-way
+// split, the layer-3 reductions, the barriers: 7 of the 64-row tile's 13 us with one workgroup per
+// CU — run beside the other's main loop (+11 % on DoubleDQN's stand-alone
+// passes, +7 % on the live launches of the DQN loop; nothing on the isolated rate, which is bound by
+// issue — MFMA and VALU share a port — and by the doubled weight traffic per row, not by latency).  Wave w owns unit
+// blocks 2 w and 2 w + 1 (64 hidden units) of the one 32-row block.  Same arithmetic in the same
+// order per (row, unit): layer 1 and the six-product k loop are per element, and the layer-3 sums
+// are kept per 32-unit block and added over the eight blocks in block order exactly as the 64-row
+// tile adds its eight waves' partials — the two kernels produce the same bits
+// (tests/test_gpu_dqn.py::test_target_split_tile_shapes_are_bitwise_identical).
+// Reads U (no fused first layer).  a.bpw = 32 / A, a.ntiles accordingly (launch_target_split32).
+// ---------------------------------------------------------------------------------------------
+constexpr int TS32_ROWS = 32;
+constexpr int TS32_RD = 2;             // k-steps of weights in flight per wave and unit block
+inline size_t target_split32_smem_bytes() {
+  return (size_t)3 * TS32_ROWS * TS_LDP * 2 + sizeof(float) * (8 * TS32_ROWS + TS32_ROWS) + 16;
+}
+__device__ __forceinline__ void target_tile_split32(const TargetArgs& a, int tile, unsigned char* smem) {
+  __bf16* planes = reinterpret_cast<__bf16*>(smem);                              // [3][32][TS_LDP]
+  float* qpart = reinterpret_cast<float*>(smem + (size_t)3 * TS32_ROWS * TS_LDP * 2);   // [8 blocks][32]
+  float* qv = qpart + 8 * TS32_ROWS;                                             // [32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int b0 = tile * a.bpw;
+  const int nb = min(a.bpw, a.B - b0);
+  const int nrows = nb * a.A;
+  const float b3v = a.b3[0];
+  unsigned pf_mask = 0, pf_term = 0;
+  float pf_reward = 0.f;
+  if (tid < nrows && a.mask)
+    pf_mask = a.mask[(int64_t)(b0 + tid / a.A) * a.mask_bstride + tid % a.A];
+  if (tid < nb && a.y) {
+    pf_term = a.term[b0 + tid];
+    pf_reward = a.reward[b0 + tid];
+  }
+  // ---- layer 1 (fp32 MFMA, K = AD <= 16): h1 = relu(U[b] + W1a' rep(b, i))
+  const bool rok = l31 < nrows;
+  const int rr = rok ? l31 : 0;
+  const int bb = b0 + rr / a.A;
+  const int64_t foff = (int64_t)bb * a.feat_bstride + (int64_t)(rr % a.A) * a.AD;
+  f32x16 acc[2];
+  int nq0[2];
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) {
+    nq0[ub] = (2 * wave + ub) * 32 + 4 * h;    // this lane's hidden units of block ub: nq0 + 8 q + j
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 u = ld4_or_zero(a.U, (int64_t)bb * a.ldu + nq0[ub] + 8 * q, rok);
+      acc[ub][4 * q + 0] = u.x; acc[ub][4 * q + 1] = u.y;
+      acc[ub][4 * q + 2] = u.z; acc[ub][4 * q + 3] = u.w;
+    }
+  }
+  float4 fx[2], fw[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int k = 8 * kk + 4 * h;
+    fx[kk] = ld4_or_zero(a.feat, foff + k, rok && k < a.AD);
+#pragma unroll
+    for (int ub = 0; ub < 2; ++ub)
+      fw[ub][kk] = ld4_or_zero(a.W1a, (int64_t)((2 * wave + ub) * 32 + l31) * a.ldw1 + k, k < a.AD);
+  }
+  // ---- layer-2 weights: the first k-steps of this wave's two unit blocks
+  bf16x8 ring[TS32_RD][2][3];
+  unsigned wbase[2];
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) {
+    wbase[ub] = (unsigned)(((2 * wave + ub) * TS_KS * 3 * 64 + lane) * 16);   // bytes; slot stride 1 KiB
+#pragma unroll
+    for (int g = 0; g < TS32_RD; ++g)
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        ring[g][ub][s] = ld_bf16x8(a.W2sp, wbase[ub] + (unsigned)(g * 3 + s) * 1024u);
+  }
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      acc[ub] = mfma32(fw[ub][kk].x, fx[kk].x, acc[ub]);
+      acc[ub] = mfma32(fw[ub][kk].y, fx[kk].y, acc[ub]);
+      acc[ub] = mfma32(fw[ub][kk].z, fx[kk].z, acc[ub]);
+      acc[ub] = mfma32(fw[ub][kk].w, fx[kk].w, acc[ub]);
+    }
+  // h1 = relu(acc), split three ways by the lane that owns it -> the LDS planes [s][row][k]
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) {
+    __bf16* dst = planes + (size_t)l31 * TS_LDP + nq0[ub];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bf16x4 p[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        __bf16 x0, x1, x2;
+        split3(relu_keep_nan(acc[ub][4 * q + j]), x0, x1, x2);
+        p[0][j] = x0; p[1][j] = x1; p[2][j] = x2;
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        *reinterpret_cast<bf16x4*>(dst + (size_t)s * TS32_ROWS * TS_LDP + 8 * q) = p[s];
+    }
+  }
+  __syncthreads();
+  // ---- layer 2: six bf16 products per k-step and unit block, one accumulator per magnitude class
+  f32x16 c3[2][3];
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c3[ub][c][r] = 0.f;
+  {
+    const __bf16* bp0 = planes + (size_t)l31 * TS_LDP + 8 * h;
+    bf16x8 bq[2][3];   // the h1 operands run one k-step ahead of their use
+    auto ldb = [&](int g, bf16x8 (&b)[3]) {
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+        b[s] = *reinterpret_cast<const bf16x8*>(bp0 + (size_t)s * TS32_ROWS * TS_LDP + 16 * g);
+    };
+    ldb(0, bq[0]);
+#pragma unroll
+    for (int g = 0; g < TS_KS; ++g) {
+      bf16x8 wa[2][3];
+#pragma unroll
+      for (int ub = 0; ub < 2; ++ub)
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          wa[ub][s] = ring[g % TS32_RD][ub][s];
+          if (g + TS32_RD < TS_KS)
+            ring[g % TS32_RD][ub][s] = ld_bf16x8(a.W2sp, wbase[ub] + (unsigned)((g + TS32_RD) * 3 + s) * 1024u);
+        }
+      if (g + 1 < TS_KS) ldb(g + 1, bq[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);   // loads stay here, ahead of this k-step's MFMAs
+      bf16x8 (&b)[3] = bq[g & 1];
+#pragma unroll
+      for (int ub = 0; ub < 2; ++ub) {
+        c3[ub][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ub][0], b[2], c3[ub][2], 0, 0, 0);
+        c3[ub][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ub][2], b[0], c3[ub][2], 0, 0, 0);
+        c3[ub][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ub][1], b[1], c3[ub][2], 0, 0, 0);
+        c3[ub][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ub][0], b[1], c3[ub][1], 0, 0, 0);
+        c3[ub][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ub][1], b[0], c3[ub][1], 0, 0, 0);
+        c3[ub][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ub][0], b[0], c3[ub][0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // nothing of the next k-step is hoisted above this one
+    }
+  }
+  // ---- layer 3: per 32-unit block — in-lane over this lane's 16 units, then the other half — so that
+  // the eight block partials of a row are the eight wave partials of the 64-row tile
+#pragma unroll
+  for (int ub = 0; ub < 2; ++ub) {
+    float4 b2v[4], w3v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      b2v[q] = ld4_or_zero(a.b2, nq0[ub] + 8 * q, true);
+      w3v[q] = ld4_or_zero(a.w3, nq0[ub] + 8 * q, true);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float bq4[4] = {b2v[q].x, b2v[q].y, b2v[q].z, b2v[q].w};
+      const float wq4[4] = {w3v[q].x, w3v[q].y, w3v[q].z, w3v[q].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * q + j;
+        const float z = (c3[ub][2][r] + c3[ub][1][r]) + c3[ub][0][r];   // smallest classes first
+        sum = fmaf(relu_keep_nan(z + bq4[j]), wq4[j], sum);
+      }
+    }
+    sum += __shfl_xor(sum, 32);
+    if (h == 0) qpart[(2 * wave + ub) * TS32_ROWS + l31] = sum;
+  }
+  __syncthreads();
+  if (tid < TS32_ROWS) {
+    float q = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) q += qpart[w * TS32_ROWS + tid];
+    q += b3v;
+    if (a.q_all && tid < nrows) a.q_all[(int64_t)b0 * a.A + tid] = q;
+    if (tid < nrows && pf_mask) q = -INFINITY;
+    qv[tid] = q;
+  }
+  __syncthreads();
+  if (tid < nb) {
+    const int bt = b0 + tid;
+    float m = qv[tid * a.A];
+    int mi = 0;
+    for (int i = 1; i < a.A; ++i) {
+      const float x = qv[tid * a.A + i];
+      const bool take = (x > m || x != x) && !(m != m);  // first maximum; the first NaN wins
+      m = take ? x : m;
+      mi = take ? i : mi;
+    }
+    if (a.argmax) {
+      a.argmax[bt] = mi;
+      if (a.choice_rep) {
+        const float* src = a.feat + (int64_t)bt * a.feat_bstride + (int64_t)mi * a.AD;
+        for (int j = 0; j < a.AD; ++j) a.choice_rep[(int64_t)bt * a.AD + j] = src[j];
+      }
+    }
+    if (a.next_v) a.next_v[bt] = m;
+    if (a.y) {
+      const float live = 1.0f - (pf_term ? 1.0f : 0.0f);
+      const float t0 = __fmul_rn(m, a.gamma);
+      const float t1 = __fmul_rn(t0, live);
+      publish_y(a.y + bt, __fadd_rn(t1, pf_reward));
+    }
+  }
+}
+
+// Classic grid or persistent work-stealing tiles, as target_split_kernel; two workgroups per CU.
+static __global__ __launch_bounds__(256, 2) void target_split32_kernel(TargetArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_split32[];
+  if (a.tile_ctr == nullptr) {
+    if ((int)blockIdx.x < a.prio_tiles) __builtin_amdgcn_s_setprio(3);
+    target_tile_split32(a, blockIdx.x, smem_split32);
+    return;
+  }
+  __shared__ int next_tile32;
+  if (a.reserved && a.reserved[cu_key()]) return;
+  if (threadIdx.x == 0) next_tile32 = atomicAdd(a.tile_ctr, 1);
+  __syncthreads();
+  int tile = next_tile32;
+  while (tile < a.ntiles) {
+    int ahead = 0;
+    if (threadIdx.x == 0) ahead = atomicAdd(a.tile_ctr, 1);   // in flight under this tile
+    target_tile_split32(a, tile, smem_split32);
+    if (threadIdx.x == 0) next_tile32 = ahead;
+    __syncthreads();  // publishes next_tile; the planes are reused by the next tile
+    tile = next_tile32;
+  }
+}
+
 }  // namespace pa

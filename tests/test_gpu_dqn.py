@@ -55,6 +55,57 @@ def test_q_values_and_targets(golden, name):
     assert torch.equal(nv, out["next_v"])
 
 
+@pytest.mark.parametrize("name", ["cfg2_shape_small_batch", "double:cfg2_shape_small_batch", "tiny_dynamic",
+                                  "double:tiny_dynamic"])
+def test_target_split_tile_shapes_are_bitwise_identical(golden, name):
+    """The bf16x3 target pass as 32-row tiles on four waves (two workgroups per CU: Double DQN's
+    passes since round 4) and as the 64-row eight-wave tile: same arithmetic in the same order per (row, unit) and
+    the same order of the layer-3 block partials, so next-state values, Bellman targets, Double DQN's
+    action choice and whole learn() trajectories agree to the bit."""
+    from pearl_amd import _native as N
+    fx = golden(name)
+    outs = []
+    for rows in (32, 64):
+        N.check(N.lib().pa_debug_set_target_rows(rows))
+        try:
+            pl = make_learner(fx)
+            out = pl.q_values_and_targets(batch_from(fx, "batch_pre"))
+            torch.cuda.synchronize()
+            outs.append({k: v.clone() for k, v in out.items()})
+        finally:
+            N.check(N.lib().pa_debug_set_target_rows(0))
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    torch.testing.assert_close(outs[0]["next_v"].cpu(), fx["next_v"], rtol=1e-5, atol=1e-6)
+
+
+def test_target_split_tile_shapes_learn_bitwise_at_full_size(full_size_arena):
+    """40 rounds of the overlapped loop at BASELINE config 2's size (persistent work-stealing tiles,
+    leading classic grids, the tagged hand-off) with 32-row and with 64-row target tiles: identical
+    losses and parameters, bit for bit."""
+    from pearl_amd import DeepQLearning, OneHotActionTensorRepresentationModule, _native as N
+    rb, _ = full_size_arena
+    S, A, B = 128, 16, 1024
+    res = []
+    for rows in (32, 64):
+        N.check(N.lib().pa_debug_set_target_rows(rows))
+        try:
+            torch.manual_seed(0)
+            pl = DeepQLearning(state_dim=S, action_space=_space(A), hidden_dims=[256, 256],
+                               training_rounds=40, batch_size=B,
+                               action_representation_module=OneHotActionTensorRepresentationModule(A)).to(DEV)
+            random.seed(3)
+            losses = pl.learn(rb)["loss"]
+            torch.cuda.synchronize()
+            res.append((losses, [p.detach().clone() for p in pl._Q.parameters()] +
+                        [p.detach().clone() for p in pl._Q_target.parameters()]))
+        finally:
+            N.check(N.lib().pa_debug_set_target_rows(0))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("switch", [("PEARL_AMD_TARGET_SPLIT", "0"), ("PEARL_AMD_FUSE_U", "1")])
 def test_target_kernel_variants_hold_the_reference_fixtures(golden, switch, monkeypatch):
     """The target pass has three builds of the same arithmetic contract: the default bf16x3 split

@@ -116,3 +116,25 @@ for ln in open("gpurun_out/bench_algos_b2.jsonl"):
         d=json.loads(ln); print(d["config"][:30], round(d["value"]/1e6,2), "M", round(d["ms_per_step"]*1e3,1), "us/step", [(k["kernel"][:14], round(k["avg_launch_us"],1), k["pipe"][:6]) for k in d.get("kernels",[])])
 PY
 fi
+if [ "$MODE" == "alltests" ]; then
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -12 gpurun_out/pytest_gpu.log | cut -c1-300
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+fi
+if [ "$MODE" == "t32" ]; then
+  timeout 900 python -m pytest tests/test_gpu_dqn.py -m gpu -q --tb=short -p no:cacheprovider -x \
+    -k "tile_shapes or q_values_and_targets or variants or overlapped_loop or generic_loop or fullbatch or double" > gpurun_out/pytest_t32.log 2>&1
+  echo "pytest rc=$?"; tail -6 gpurun_out/pytest_t32.log | cut -c1-220
+  for rows in 32 64; do
+    PEARL_AMD_TARGET_ROWS=$rows timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > gpurun_out/bench_rows$rows.log 2> gpurun_out/bench_rows$rows.err
+    echo "rows=$rows rc=$?"; tail -1 gpurun_out/bench_rows$rows.log | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('value', round(d['value']/1e6,2), 'steady', round(d['steady_state']['value']/1e6,2), 'live frac', round(r['frac'],3), 'us', round(r['avg_launch_us'],1), 'isolated', round(r['isolated']['achieved'],1), 'TF frac_pipe', round(r['isolated'].get('frac_pipe',0),3))"
+    PEARL_AMD_TARGET_ROWS=$rows timeout 300 python bench_algos.py --steps 200 --only double_dqn,dsac --cpu-seconds 0.3 2>/dev/null | python -c "
+import sys,json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d=json.loads(ln); print('  ', d['config'][:40], round(d['value']/1e6,2), 'M')"
+  done
+fi
