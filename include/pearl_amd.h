@@ -846,6 +846,37 @@ int pa_linreg_apply2(const float* delta, int32_t d, float* A, float* b, float* s
                      float* A_snap, float* b_snap, void* stream);
 int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t d, double* work,
                     float* inv_A_out, float* coefs_out, int32_t* singular_out, void* stream);
+/* One NeuralLinearBandit.learn_batch on unit weights in a single process, as ONE call
+ * (pearl/policy_learners/contextual_bandits/neural_linear_bandit.py:139-214): pa_wloss_rowstep, the
+ * LinUCB operands from the kept features (pa_linreg_delta2's), ONE weight-gradient launch forming
+ * the network's gradients with AdamW step `adam_step` AND the moment update [delta_A | delta_b],
+ * then pa_linreg_apply2 (the batch's weight sum read from delta_A[0][0]).  Four launches, plus
+ * the solve's two on the side stream when one is given.
+ *   pred [B]: act(network output); d_pred [B]: scratch that must stay untouched until the call's
+ *   launches have run; scalars [2]: the loss, then the batch mean of pred;
+ *   x_scratch / r_scratch / delta: as pa_linreg_delta2 (delta [D*(D+1)], D = d + 1);
+ *   A [D][D], b [D], sum_weight [1], A_snap / b_snap (both or none): as pa_linreg_apply2.
+ * PA_ERR_UNSUPPORTED when pa_rowstep_supported(net, NULL, 0) is 0 (callers then issue the calls
+ * above one by one). */
+typedef struct pa_bandit_step_args {
+  pa_mlp* net;
+  const float* x; int32_t ldx; int32_t B;
+  const float* y;
+  int32_t loss_kind, out_act;   /* PA_LOSS_*, PA_OUT_* */
+  int64_t adam_step;            /* 1-based */
+  float* pred; float* d_pred; float* scalars;
+  int32_t d;                    /* feature width of the regression = the trunk's output width */
+  float* x_scratch; float* r_scratch; float* delta;
+  float* A; float* b; float* sum_weight; float* A_snap; float* b_snap;
+  /* optional (side_stream null: none): pa_linreg_solve of the snapshot on a second stream, so that
+   * the serial fp64 solve runs beside the next step.  ev_slot_free (nullable hipEvent_t): `stream`
+   * waits for it before the snapshot is overwritten (the solve that last read this snapshot pair);
+   * ev_ready / ev_done (hipEvent_t, created by the caller): recorded on `stream` after the update
+   * and on side_stream after the solve.  Needs A_snap / b_snap. */
+  void* side_stream; void* ev_slot_free; void* ev_ready; void* ev_done;
+  float l2_reg_lambda; double* work; float* inv_A; float* coefs; int32_t* singular;
+} pa_bandit_step_args;
+int pa_bandit_step(const pa_bandit_step_args* args, void* stream);
 int pa_linreg_sigma(const float* features, int32_t ldf, const float* inv_A, int32_t B, int32_t d,
                     float* sigma_out, void* stream);
 /* out[B, nl + nr] = left[B, nl] || right[B, nr]   (q_value_networks.py:166-168 torch.cat) */

@@ -192,6 +192,25 @@ class MlpDesc(C.Structure):
     ]
 
 
+class BanditStepArgs(C.Structure):
+    _fields_ = [
+        ("net", C.c_void_p),
+        ("x", C.c_void_p), ("ldx", C.c_int32), ("B", C.c_int32),
+        ("y", C.c_void_p),
+        ("loss_kind", C.c_int32), ("out_act", C.c_int32),
+        ("adam_step", C.c_int64),
+        ("pred", C.c_void_p), ("d_pred", C.c_void_p), ("scalars", C.c_void_p),
+        ("d", C.c_int32),
+        ("x_scratch", C.c_void_p), ("r_scratch", C.c_void_p), ("delta", C.c_void_p),
+        ("A", C.c_void_p), ("b", C.c_void_p), ("sum_weight", C.c_void_p),
+        ("A_snap", C.c_void_p), ("b_snap", C.c_void_p),
+        ("side_stream", C.c_void_p), ("ev_slot_free", C.c_void_p), ("ev_ready", C.c_void_p),
+        ("ev_done", C.c_void_p),
+        ("l2_reg_lambda", C.c_float), ("work", C.c_void_p), ("inv_A", C.c_void_p),
+        ("coefs", C.c_void_p), ("singular", C.c_void_p),
+    ]
+
+
 class MlpBuffers(C.Structure):
     _fields_ = [
         ("p", C.c_void_p),
@@ -454,6 +473,7 @@ SIGNATURES = {
     "pa_weighted_mse_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_delta2": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_apply2": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "pa_bandit_step": (C.c_int, [_P, _P]),
     "pa_mlp_activation": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "pa_weighted_loss_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                         _P, _P, _P]),

@@ -988,6 +988,8 @@ struct DwProblem {
   void* pks; int nks;         // kind 3: W as bf16x3 split planes for v_mfma_f32_16x16x32_bf16 (wsp16_index) or null
   int bias_frozen;            // the bias slot is not a parameter (bias-free layer): no AdamW on db
   int net;                    // kind 3: which network's optimizer state (0: ad, 1: net2)
+  int raw;                    // a plain X^T dZ product riding an optimizer launch: dW / db stored, no AdamW
+                              // (the bandit's LinUCB moment update next to its network's gradients)
 };
 // A second network in the same launch (twin critics: one launch instead of two half-empty ones).
 // Same AdamW hyper-parameters and step as `ad` (one optimizer), its own flat buffers.
@@ -1441,14 +1443,15 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
   // (a local, not a write to the by-value argument: that would copy the whole struct to scratch)
-  const bool adam_on = a.ad.enabled && !(a.ad.guard && __hip_atomic_load(a.ad.guard, __ATOMIC_RELAXED,
-                                                                         __HIP_MEMORY_SCOPE_AGENT) != 0);
+  const bool adam_all = a.ad.enabled && !(a.ad.guard && __hip_atomic_load(a.ad.guard, __ATOMIC_RELAXED,
+                                                                          __HIP_MEMORY_SCOPE_AGENT) != 0);
   const int c = lane & 15, q = lane >> 4;
   int pi = 0;
 #pragma unroll
   for (int k = 1; k < DW_MAX_PROB; ++k)
     if (a.nprob > k && wg_tile >= a.p[k].tile0) pi = k;
   const DwProblem& P = a.p[pi];
+  const bool adam_on = adam_all && !P.raw;
   // the optimizer state this problem's parameters live in (wave-uniform selects)
   AdamState st = a.ad.st;
   const float* gbase = a.ad.grad_base;

@@ -67,7 +67,8 @@ struct RowHead {
   const float* reward; const uint8_t* term; float gamma; float* y;   // target (no backward)
   // RS_HEAD_WMSE1: criterion and output activation (PA_LOSS_*, PA_OUT_*); out_post [B] receives
   // the post-activation predictions when the activation is not linear
-  int loss_kind, out_act; float* out_post;
+  // mean_out (nullable): the batch mean of the post-activation predictions
+  int loss_kind, out_act; float* out_post; float* mean_out;
 };
 
 struct RowStepArgs {
@@ -590,6 +591,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       if (hd.out_post) hd.out_post[b] = p;
       dval = wloss_grad(p, hd.target[b], 1.0f, (float)a.B, hd.loss_kind, hd.out_act);
       part0 = wloss_value(p, hd.target[b], hd.loss_kind) * 1.0f;
+      part1 = p;
     } else if (hlive) {
       const float d = __fsub_rn(ot[hr * PH], hd.target[b]);
       dval = __fmul_rn(hd.grad_scale, d);
@@ -727,6 +729,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       loss = s0 * (1.0f / ((float)a.B * (float)a.fwd[k].dims[a.fwd[k].L]));
     } else if (h.kind == RS_HEAD_WMSE1) {
       loss = s0 / (float)a.B;
+      if (tid == 0 && h.mean_out) *h.mean_out = s1 / (float)a.B;
     } else {
       loss = (s0 / (float)a.B) * h.loss_scale;
     }

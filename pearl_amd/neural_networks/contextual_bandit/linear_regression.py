@@ -34,10 +34,12 @@ class LinearRegression(nn.Module):
         self.register_buffer("_sum_weight", torch.zeros(1))
         self.register_buffer("_inv_A", torch.zeros(feature_dim + 1, feature_dim + 1))
         self.register_buffer("_coefs", torch.zeros(feature_dim + 1))
-        # The learner refreshes `_inv_A` / `_coefs` on a side stream (the fp64 solve is one serial
-        # workgroup and nothing in the next learn_batch reads its result): `_solve_done` is the event
-        # of the latest refresh, and every read of the two buffers — attribute access, state_dict —
-        # first makes torch's current stream wait for it.
+        # The learner refreshes `_inv_A` / `_coefs` on side streams (the fp64 solve is one serial
+        # workgroup and nothing in the next learn_batch reads its result; two solves may be in
+        # flight, each writing its own pair of result buffers): `_solve_done` is (event, inv_A,
+        # coefs) of the latest refresh, and every read of the two buffers — attribute access,
+        # state_dict — first makes torch's current stream wait for the event and copies the
+        # results in.
         self.__dict__["_solve_done"] = None
         self.register_state_dict_pre_hook(_join_before_state_dict)
         # writers of the buffers join it too: a solve still in flight on the side stream
@@ -50,10 +52,10 @@ class LinearRegression(nn.Module):
 
     def drain_solve(self) -> None:
         """Host-side wait for the latest solve (before anything rewrites the buffers it writes)."""
-        ev = self.__dict__.get("_solve_done")
-        if ev is not None:
-            ev.synchronize()
-            self.__dict__["_solve_done"] = None
+        pend = self.__dict__.get("_solve_done")
+        if pend is not None:
+            pend[0].synchronize()
+            self._take_solve(pend)
 
     def _apply(self, fn, *args, **kwargs):
         self.drain_solve()
@@ -64,10 +66,23 @@ class LinearRegression(nn.Module):
         return self.__dict__
 
     def join_solve(self) -> None:
-        ev = self.__dict__.get("_solve_done")
-        if ev is not None:
-            torch.cuda.current_stream(self._buffers["_A"].device).wait_event(ev)
-            self.__dict__["_solve_done"] = None
+        pend = self.__dict__.get("_solve_done")
+        if pend is not None:
+            torch.cuda.current_stream(pend[1].device).wait_event(pend[0])
+            self._take_solve(pend)
+
+    def _take_solve(self, pend) -> None:
+        """The finished (as far as the current stream is concerned) solve's results become the
+        buffers' contents."""
+        self.__dict__["_solve_done"] = None
+        _, inv_A, coefs = pend
+        with torch.no_grad():
+            if self._buffers["_inv_A"].device == inv_A.device:
+                self._buffers["_inv_A"].copy_(inv_A)
+                self._buffers["_coefs"].copy_(coefs)
+            else:       # (buffers moved since the solve was enqueued)
+                self._buffers["_inv_A"] = inv_A.clone()
+                self._buffers["_coefs"] = coefs.clone()
 
     def __getattr__(self, name: str):
         if name in ("_inv_A", "_coefs"):

@@ -194,15 +194,23 @@ class NeuralLinearBandit(PolicyLearner):
         lr = self.model._linear_regression_layer
         d = lr._feature_dim
         D = d + 1
-        dpred = torch.empty(B, dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        wsum = torch.empty(1, dtype=torch.float32, device=dev)
         kind, oact = _LOSS_KINDS[self.loss_type], self._out_act
         if kind == 2:
             # the reference's own checks (:181-186); predictions of a sigmoid are in [0, 1] already
             assert bool(torch.all(y >= 0)) and bool(torch.all(y <= 1)), \
                 "cross-entropy needs labels in [0, 1]"
-        fused = w is None and bool(lib.pa_rowstep_supported(net.handle, None, 0))
+        for name in ("_A", "_b", "_sum_weight", "_inv_A", "_coefs"):
+            buf = lr._buffers[name]       # (not getattr: reading _inv_A / _coefs joins the solve)
+            if buf.device != dev or not buf.is_contiguous():
+                lr.join_solve()
+                setattr(lr, name, buf.to(dev).contiguous())
+        fused = w is None and self._rowstep_ok(net)
+        if fused and not (dist.is_available() and dist.is_initialized()) \
+                and os.environ.get("PEARL_AMD_BANDIT_ONE_CALL", "1") != "0":
+            return self._learn_batch_one_call(net, x, y, lr, kind, oact)
+        dpred = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        wsum = torch.empty(1, dtype=torch.float32, device=dev)
         pred = torch.empty(B, 1, dtype=torch.float32, device=dev)      # act(network output)
         if fused:
             # unit weights: forward (kept), the loss gradient and the backward pass in one launch
@@ -244,11 +252,6 @@ class NeuralLinearBandit(PolicyLearner):
                                     xs.data_ptr(), rs.data_ptr(), delta.data_ptr(), s))
         if dist.is_available() and dist.is_initialized():
             dist.all_reduce(delta)          # delta_A | delta_b | delta_sum_weight in ONE message
-        for name in ("_A", "_b", "_sum_weight", "_inv_A", "_coefs"):
-            buf = lr._buffers[name]       # (not getattr: reading _inv_A / _coefs joins the solve)
-            if buf.device != dev or not buf.is_contiguous():
-                lr.join_solve()
-                setattr(lr, name, buf.to(dev).contiguous())
         # A, b, sum_weight updated in place; the same launch also writes the (A, b) snapshot the
         # asynchronous solve reads (two copy launches otherwise)
         snap = self._solve_slot(lr, dev)
@@ -262,16 +265,111 @@ class NeuralLinearBandit(PolicyLearner):
         return {"label": y, "prediction": p, "weight": w if w is not None else torch.ones_like(y),
                 "loss": loss[0], "mu_scores": p.mean()}
 
+    def _rowstep_ok(self, net: FlatMlp) -> bool:
+        """pa_rowstep_supported for this network's handle (a shape property: asked once per handle)."""
+        memo = self._flat.get("rowstep_ok")
+        key = net.handle.value
+        if memo is None or memo[0] != key:
+            memo = (key, bool(N.lib().pa_rowstep_supported(net.handle, None, 0)))
+            self._flat["rowstep_ok"] = memo
+        return memo[1]
+
+    def _workspace(self, B: int, D: int, dev: torch.device, stream: int) -> Dict[str, Any]:
+        """Scratch of the one-call step, kept between steps: everything in it is written and read by
+        launches of ONE stream (the key), so the next step's launches are ordered behind this
+        step's.  The unit weights of the report live here too (read-only by convention; the
+        reference returns a fresh ``ones_like`` every step)."""
+        ws = self._flat.get("ws")
+        key = (B, D, dev.index, stream)
+        if ws is None or ws["key"] != key:
+            f32 = dict(dtype=torch.float32, device=dev)
+            ws = {"key": key,
+                  "dpred": torch.empty(B, **f32),
+                  "xs": torch.empty(B * ((D + 3) & ~3) + D, **f32),      # rows of whole 16- /
+                  "rs": torch.empty(B * ((D + 2) & ~1), **f32),          # 8-byte vectors
+                  "delta": torch.empty(D * (D + 1) + 1, **f32),
+                  "ones": torch.ones(B, **f32),
+                  "args": N.BanditStepArgs()}
+            a = ws["args"]
+            a.B, a.d = B, D - 1
+            a.d_pred, a.x_scratch, a.r_scratch, a.delta = (ws[k].data_ptr() for k in
+                                                           ("dpred", "xs", "rs", "delta"))
+            self._flat["ws"] = ws
+        return ws
+
+    def _learn_batch_one_call(self, net: FlatMlp, x: Tensor, y: Tensor, lr: Any, kind: int,
+                              oact: int) -> Dict[str, Any]:
+        """Unit weights, single process, a network the fused row step takes: the whole step is
+        ``pa_bandit_step`` — four launches, the LinUCB moment update riding the weight-gradient /
+        AdamW launch — and the solve on its side stream.  The report's tensors are views of one
+        fresh allocation per step (predictions, loss, mean prediction)."""
+        dev = x.device
+        B = x.shape[0]
+        s = N.stream_ptr(dev)
+        ws = self._workspace(B, lr._feature_dim + 1, dev, s)
+        out = torch.empty(B + 2, dtype=torch.float32, device=dev)
+        step = net.next_adam_step()
+        a = ws["args"]
+        a.net = net.handle.value
+        a.x, a.ldx, a.y = x.data_ptr(), x.stride(0), y.data_ptr()
+        a.loss_kind, a.out_act, a.adam_step = kind, oact, step
+        a.pred = out.data_ptr()
+        a.scalars = a.pred + 4 * B
+        bufs = lr._buffers
+        a.A, a.b, a.sum_weight = bufs["_A"].data_ptr(), bufs["_b"].data_ptr(), bufs["_sum_weight"].data_ptr()
+        if os.environ.get("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1") == "0":
+            a.A_snap = a.b_snap = a.side_stream = None
+            N.check(N.lib().pa_bandit_step(C.byref(a), s))
+            self._solve(lr, dev, None)
+        else:
+            # the solve of this step's (A, b) snapshot on the side stream, enqueued by the same call
+            # (_solve / _solve_slot: the same protocol through torch's stream API)
+            st = self._solve_state_for(lr, dev)
+            i = st["slot"]
+            st["slot"] = 1 - i
+            st["cur"] = i
+            snap, (h_ready, h_done) = st["snap"][i], st["evh"][i]
+            a.A_snap, a.b_snap = snap[0].data_ptr(), snap[1].data_ptr()
+            a.side_stream = st["side"][i].cuda_stream
+            a.ev_slot_free = h_done if st["busy"][i] is not None else None
+            a.ev_ready, a.ev_done = h_ready, h_done
+            a.l2_reg_lambda = float(lr.l2_reg_lambda)
+            a.work = st["work"][i].data_ptr()
+            inv_i, coefs_i = st["out"][i]
+            a.inv_A, a.coefs = inv_i.data_ptr(), coefs_i.data_ptr()
+            a.singular = st["flag"].data_ptr() + 4 * i
+            N.check(N.lib().pa_bandit_step(C.byref(a), s))
+            done = st["ev"][i][1]
+            st["busy"][i] = done
+            lr.__dict__["_solve_done"] = (done, inv_i, coefs_i)
+        net.stepped(step)
+        self._maybe_apply_discounting()
+        return {"label": y, "prediction": out[:B].view(B, 1), "weight": ws["ones"], "loss": out[B],
+                "mu_scores": out[B + 1]}
+
     def _solve_state_for(self, lr: Any, dev: torch.device) -> Dict[str, Any]:
         D = lr._feature_dim + 1
         st = self.__dict__.get("_solve_state")
         if st is None or st["dev"] != dev or st["D"] != D:
-            st = {"dev": dev, "D": D, "side": torch.cuda.Stream(dev), "slot": 0,
+            # two slots, each with its own stream, (A, b) snapshot, work area and RESULT pair: two
+            # solves can be in flight (one serial workgroup each, ~100 us beside the learner's
+            # launches against an ~80 us step); the regression layer copies the latest result into
+            # its buffers when something reads them (LinearRegression.join_solve)
+            st = {"dev": dev, "D": D, "side": [torch.cuda.Stream(dev) for _ in range(2)], "slot": 0,
+                  "out": [(torch.zeros(D, D, dtype=torch.float32, device=dev),
+                           torch.zeros(D, dtype=torch.float32, device=dev)) for _ in range(2)],
                   "snap": [(torch.empty(D, D, dtype=torch.float32, device=dev),
                             torch.empty(D, dtype=torch.float32, device=dev)) for _ in range(2)],
                   "work": [torch.empty(D * 2 * D, dtype=torch.float64, device=dev) for _ in range(2)],
                   "flag": torch.zeros(2, dtype=torch.int32, device=dev),
+                  # per slot: "snapshot written" and "solve finished", recorded anew every use
+                  "ev": [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)],
                   "busy": [None, None], "cur": None}
+            # (an event has no handle before its first record: the raw handles go to pa_bandit_step)
+            for pair, side in zip(st["ev"], st["side"]):
+                for ev in pair:
+                    ev.record(side)
+            st["evh"] = [tuple(ev.cuda_event for ev in pair) for pair in st["ev"]]
             self.__dict__["_solve_state"] = st
         return st
 
@@ -294,14 +392,15 @@ class NeuralLinearBandit(PolicyLearner):
         the learner's critical path: the fp64 Gauss-Jordan solve is ONE serial workgroup (97 us of a
         240 us step) and nothing in the next learn_batch reads `_inv_A` / `_coefs`; they are read at
         act time.  So the step leaves a snapshot of (A, b) on the learner stream (written by the
-        apply launch itself: `snap`, from _solve_slot) and the solve runs on a side stream; readers
-        of the two buffers join it (LinearRegression.join_solve: attribute access, state_dict).
+        apply launch itself: `snap`, from _solve_slot) and the solve runs on the slot's side stream,
+        writing the slot's result pair; readers of the two buffers join it and take the result
+        (LinearRegression.join_solve: attribute access, state_dict).
         PEARL_AMD_BANDIT_ASYNC_SOLVE=0: in-stream as before."""
         d = lr._feature_dim
         st = self._solve_state_for(lr, dev)
-        inv_A, coefs = lr._buffers["_inv_A"], lr._buffers["_coefs"]     # (no join: we are the writer)
         if os.environ.get("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1") == "0":
             lr.join_solve()
+            inv_A, coefs = lr._buffers["_inv_A"], lr._buffers["_coefs"]
             N.check(N.lib().pa_linreg_solve(lr._A.data_ptr(), lr._b.data_ptr(), float(lr.l2_reg_lambda),
                                             d, st["work"][0].data_ptr(), inv_A.data_ptr(),
                                             coefs.data_ptr(), st["flag"].data_ptr(), N.stream_ptr(dev)))
@@ -314,17 +413,17 @@ class NeuralLinearBandit(PolicyLearner):
             snap[1].copy_(lr._b)
         i = st["cur"]
         A_s, b_s = snap
-        ready = torch.cuda.Event()
+        ready, done = st["ev"][i]
         ready.record(main)
-        side = st["side"]
+        side = st["side"][i]
         side.wait_event(ready)
+        inv_i, coefs_i = st["out"][i]
         N.check(N.lib().pa_linreg_solve(A_s.data_ptr(), b_s.data_ptr(), float(lr.l2_reg_lambda), d,
-                                        st["work"][i].data_ptr(), inv_A.data_ptr(), coefs.data_ptr(),
+                                        st["work"][i].data_ptr(), inv_i.data_ptr(), coefs_i.data_ptr(),
                                         st["flag"][i:].data_ptr(), side.cuda_stream))
-        done = torch.cuda.Event()
         done.record(side)
         st["busy"][i] = done
-        lr.__dict__["_solve_done"] = done
+        lr.__dict__["_solve_done"] = (done, inv_i, coefs_i)
 
     def _maybe_apply_discounting(self) -> None:
         lr = self.model._linear_regression_layer

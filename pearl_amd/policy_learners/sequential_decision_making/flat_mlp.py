@@ -107,6 +107,10 @@ class FlatMlp:
             FlatMlp._dirty.add(self)
             return
         self._steps_dirty = None
+        bank = getattr(self, "_step_bank", None)
+        if bank is not None:
+            bank.fill_(float(n))      # every parameter's 0-d "step" tensor is a view of it
+            return
         for p in self._params():
             st = self.optimizer.state.get(p)
             if st is not None and "step" in st:
@@ -188,6 +192,13 @@ class FlatMlp:
             names.append("p_target")
         flat = {k: torch.zeros(P, dtype=torch.float32, device=dev) for k in names}
         steps = self.adam_steps()
+        # torch keeps one 0-d host "step" tensor per parameter: views of ONE host tensor here, so the
+        # bookkeeping after every native optimizer step is one fill_ (torch's own AdamW steps them
+        # in place, which views take)
+        n_params = len(self._params())
+        self._step_bank = torch.full((n_params,), float(steps), dtype=torch.float32) \
+            if self.optimizer is not None else None
+        bank_i = 0
         with torch.no_grad():
             for li, (ws, bs) in enumerate(self.layers):
                 for kind, plist in ((0, ws), (1, bs)):
@@ -207,7 +218,7 @@ class FlatMlp:
                         p.grad = flat["grad"][sl].view(p.shape)
                         if self.optimizer is not None:
                             self.optimizer.state[p] = {
-                                "step": torch.tensor(float(steps), dtype=torch.float32),
+                                "step": self._step_bank[bank_i],
                                 "exp_avg": flat["exp_avg"][sl].view(p.shape),
                                 "exp_avg_sq": flat["exp_avg_sq"][sl].view(p.shape),
                                 "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(p.shape),
@@ -217,6 +228,7 @@ class FlatMlp:
                             flat["p_target"][sl].copy_(pt.data.reshape(-1).to(dev, torch.float32))
                             pt.data = flat["p_target"][sl].view(pt.shape)
                         o += n
+                        bank_i += 1
         bufs = N.MlpBuffers(p=flat["p"].data_ptr(), p_target=N.ptr(flat.get("p_target")),
                             grad=flat["grad"].data_ptr(), exp_avg=N.ptr(flat.get("exp_avg")),
                             exp_avg_sq=N.ptr(flat.get("exp_avg_sq")),
@@ -425,8 +437,15 @@ class FlatMlp:
             # without the fused optimizer
             N.check(N.lib().pa_mlp_flush_grads(self.handle, stream))
             reduce_gradient_(self.flat["grad"], reduce)
-        step = self._steps + 1
+        step = self.next_adam_step()
         N.check(N.lib().pa_mlp_adam(self.handle, step, stream))
+        self.stepped(step)
+
+    def next_adam_step(self) -> int:
+        return self._steps + 1
+
+    def stepped(self, step: int) -> None:
+        """Bookkeeping after a native launch applied optimizer step `step` to this network."""
         self._pending_x = None
         self._set_adam_steps(step)
         self._steps = step

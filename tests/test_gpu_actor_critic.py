@@ -401,6 +401,89 @@ def test_neural_linear_bandit_learn_batch(name):
         torch.testing.assert_close(pl.model(xq).cpu().view(-1), fx["query"]["mu"].view(-1), rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("B,F,hidden,loss,out", [(4096, 512, [256, 64], "mse", "linear"),
+                                                 (300, 24, [32, 16], "cross_entropy", "sigmoid"),
+                                                 (2048, 40, [64, 64, 32], "mae", "linear")])
+def test_bandit_one_call_step_equals_the_call_by_call_step(B, F, hidden, loss, out, monkeypatch):
+    """pa_bandit_step (unit weights, one process: row step, LinUCB operands, ONE weight-gradient
+    launch carrying the network's gradients + AdamW and the moment update X^T R, apply, the solve on
+    a side stream) against the same step issued call by call (PEARL_AMD_BANDIT_ONE_CALL=0): the
+    same reports and state after several steps — the gradient kernels slice the batch differently
+    when the moment update shares the launch, so sums agree to rounding, not bitwise — and the
+    report of every step is its own storage (the reference returns fresh tensors)."""
+    from pearl_amd import NeuralLinearBandit, TransitionBatch
+    torch.manual_seed(3)
+    base = NeuralLinearBandit(feature_dim=F, hidden_dims=hidden, batch_size=B, learning_rate=1e-3,
+                              loss_type=loss, output_activation_name=out)
+    sd0 = {k: v.clone() for k, v in base.model.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.randn(B, F, generator=g), torch.rand(B, generator=g)) for _ in range(5)]
+
+    def run(one_call):
+        monkeypatch.setenv("PEARL_AMD_BANDIT_ONE_CALL", "1" if one_call else "0")
+        pl = NeuralLinearBandit(feature_dim=F, hidden_dims=hidden, batch_size=B, learning_rate=1e-3,
+                                loss_type=loss, output_activation_name=out)
+        pl.model.load_state_dict(sd0)
+        pl.to(DEV)
+        reps = []
+        for x, r in batches:
+            reps.append(pl.learn_batch(TransitionBatch(state=x.to(DEV), action=torch.zeros(B, 1, device=DEV),
+                                                       reward=r.to(DEV), weight=None)))
+        return pl, reps
+
+    pa, ra = run(True)
+    pb, rb = run(False)
+    assert len({r["prediction"].data_ptr() for r in ra}) == len(ra)
+    for step, (a, b) in enumerate(zip(ra, rb)):
+        assert a["prediction"].shape == b["prediction"].shape == (B, 1)
+        torch.testing.assert_close(a["prediction"], b["prediction"], rtol=1e-4, atol=1e-5, msg=str(step))
+        assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-5 * max(1.0, abs(float(b["loss"])))
+        assert abs(float(a["mu_scores"]) - float(a["prediction"].mean())) <= 1e-6
+        assert abs(float(a["mu_scores"]) - float(b["mu_scores"])) <= 1e-5
+        assert torch.equal(a["weight"], torch.ones(B, device=DEV)) and torch.equal(a["label"], b["label"])
+    la, lb = pa.model._linear_regression_layer, pb.model._linear_regression_layer
+    for key in ("_A", "_b", "_sum_weight"):
+        va, vb = getattr(la, key), getattr(lb, key)
+        torch.testing.assert_close(va, vb, rtol=1e-5, atol=2e-6 * float(vb.abs().max()), msg=key)
+    assert float(la._sum_weight) == 5 * B
+    D = la._A.shape[0]
+    eye = (la._A.double() + torch.eye(D, device=DEV, dtype=torch.float64)) @ la._inv_A.double()
+    torch.testing.assert_close(eye.cpu(), torch.eye(D, dtype=torch.float64), rtol=0, atol=1e-4)
+    from helpers import assert_adam_trajectory_close, assert_linear_solve_close
+    assert_linear_solve_close(la._coefs, la._A, la._b, 1.0, lb._coefs.cpu(), msg="coefs")
+    for (k, va), (_, vb) in zip(pa.model.state_dict().items(), pb.model.state_dict().items()):
+        if "_linear_regression_layer" not in k:
+            assert_adam_trajectory_close(va, vb.cpu(), 1e-3, 5, rtol=1e-3, atol=2e-5,
+                                         max_outlier_frac=2e-3, msg=k)
+    # the torch-side optimizer state is the native one: five steps on every parameter
+    for st in pa.optimizer.state.values():
+        assert float(st["step"]) == 5.0
+
+
+def test_bandit_inverse_is_the_latest_one_with_two_solves_in_flight():
+    """Two asynchronous solves can be in flight (one per slot, own stream and result pair): whatever
+    reads `_inv_A` / `_coefs` gets the result for the LATEST A and b, at every step count."""
+    from pearl_amd import NeuralLinearBandit, TransitionBatch
+    from helpers import assert_linear_solve_close
+    B, F = 1024, 48
+    torch.manual_seed(11)
+    pl = NeuralLinearBandit(feature_dim=F, hidden_dims=[64, 24], batch_size=B, learning_rate=1e-3)
+    pl.to(DEV)
+    lr = pl.model._linear_regression_layer
+    g = torch.Generator().manual_seed(2)
+    D = lr._A.shape[0]
+    for n in range(1, 8):
+        x, r = torch.randn(B, F, generator=g).to(DEV), torch.rand(B, generator=g).to(DEV)
+        pl.learn_batch(TransitionBatch(state=x, action=torch.zeros(B, 1, device=DEV), reward=r, weight=None))
+        if n in (1, 2, 5, 7):
+            eye = (lr._A.double() + torch.eye(D, device=DEV, dtype=torch.float64)) @ lr._inv_A.double()
+            torch.testing.assert_close(eye.cpu(), torch.eye(D, dtype=torch.float64), rtol=0, atol=1e-4,
+                                       msg=f"after {n} steps")
+            want = torch.linalg.solve(lr._A.double() + torch.eye(D, device=DEV, dtype=torch.float64),
+                                      lr._b.double())
+            assert_linear_solve_close(lr._coefs, lr._A, lr._b, 1.0, want, msg=f"after {n} steps")
+
+
 def test_bandit_deepcopy_pickle_and_load_state_dict_after_a_step():
     """A NeuralLinearBandit that has stepped (side stream + events of the asynchronous solve alive)
     can be deep-copied, pickled and torch.save'd (it raised "cannot pickle 'Event'"), the
@@ -475,6 +558,7 @@ def test_bandit_loss_heads_match_torch_autograd(loss, out, B, weighted):
     N.check(N.lib().pa_weighted_loss_head(z.data_ptr(), 1, y.data_ptr(), N.ptr(w), B, kinds[loss],
                                           int(out == "sigmoid"), pred.data_ptr(), d.data_ptr(),
                                           lo.data_ptr(), ws.data_ptr(), N.stream_ptr(z.device)))
+    ref = ref.detach()
     assert abs(float(lo) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
     torch.testing.assert_close(pred, p.detach(), rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(d, zr.grad, rtol=1e-5, atol=1e-6 * float(zr.grad.abs().max()))

@@ -138,3 +138,28 @@ for ln in sys.stdin:
         d=json.loads(ln); print('  ', d['config'][:40], round(d['value']/1e6,2), 'M')"
   done
 fi
+if [ "$MODE" == "bandit3" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_bandit
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bandit -o t -- python $R/bench_algos.py --steps 200 --only bandit --cpu-seconds 0.2 > $R/gpurun_out/rocprof_bandit.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_bandit/*.db $R/gpurun_out/prof_bandit/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/bandit_kernel_stats.txt 2>&1
+  head -14 $R/gpurun_out/bandit_kernel_stats.txt | cut -c1-150
+  python $R/tools/rocpd_timeline.py $DB mlp_rowstep 26 > $R/gpurun_out/bandit_timeline.txt 2>&1; sed -n 5,32p $R/gpurun_out/bandit_timeline.txt | cut -c1-140
+  rm -f $DB
+  cd $R; TOPN=22 timeout 300 python tools/host_bound.py bandit 2>&1 | grep -v amdgpu | tail -34
+fi
+if [ "$MODE" == "bandit4" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "bandit or squarecb or neural_linear" 2>&1 | tail -8
+  timeout 300 python bench_algos.py --steps 300 --only bandit --cpu-seconds 0.2 2>$R/gpurun_out/bench_bandit4.err | tee $R/gpurun_out/bench_bandit4.jsonl | python tools/algo_line.py 2>/dev/null || tail -3 $R/gpurun_out/bench_bandit4.err
+  TOPN=24 timeout 300 python tools/host_bound.py bandit 2>&1 | grep -v amdgpu | tail -36
+  cd /tmp && export TMPDIR=/tmp
+  rm -rf $R/gpurun_out/prof_bandit
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_bandit -o t -- python $R/bench_algos.py --steps 200 --only bandit --cpu-seconds 0.2 > $R/gpurun_out/rocprof_bandit.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_bandit/*.db $R/gpurun_out/prof_bandit/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/bandit_kernel_stats.txt 2>&1
+  head -14 $R/gpurun_out/bandit_kernel_stats.txt | cut -c1-150
+  python $R/tools/rocpd_timeline.py $DB mlp_rowstep 26 > $R/gpurun_out/bandit_timeline.txt 2>&1; sed -n 5,24p $R/gpurun_out/bandit_timeline.txt | cut -c1-140
+  rm -f $DB
+fi

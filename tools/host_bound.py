@@ -70,6 +70,20 @@ def make_ppo(steps):
     return lambda: ActorCriticBase.learn(pl, rb)     # learn() without the one-off rollout pass
 
 
+def make_bandit(steps):
+    from pearl_amd import NeuralLinearBandit, TransitionBatch
+    F, B = 512, 4096
+    pl = NeuralLinearBandit(feature_dim=F, hidden_dims=[256, 64], batch_size=B, learning_rate=1e-3)
+    pl.to(DEV)
+    tb = TransitionBatch(state=torch.randn(B, F, device=DEV), action=torch.zeros(B, 1, device=DEV),
+                         reward=torch.rand(B, device=DEV), weight=None)
+
+    def run():
+        for _ in range(steps):
+            pl.learn_batch(tb)
+    return run
+
+
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "sac"
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
@@ -77,9 +91,9 @@ def main():
         torch.set_num_threads(32)
     torch.manual_seed(0)
     random.seed(0)
-    learn = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3}[which](steps)
+    learn = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3, "bandit": make_bandit}[which](steps)
     if "warm20" in sys.argv:          # a short warm-up instead of a full learn()
-        short = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3}[which](20)
+        short = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3, "bandit": make_bandit}[which](20)
         short()
     else:
         learn()
