@@ -564,6 +564,27 @@ int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, const pa_ac_loo
 int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
                   void* stream);
 
+/* ProximalPolicyOptimization.learn's training rounds as ONE call (policy_learner.py:190-231 around
+ * ppo.py:152-192; after preprocess_replay_buffer).  Per group of gather_rounds rounds: one arena
+ * gather of x = state || one-hot(action) rows and one pa_gather_planes of the three per-transition
+ * columns; per round: pa_ppo_rowstep, then pa_mlp_adam2 (or two pa_mlp_adam when the optimizers
+ * differ).  The arena's actions are indices (one element per transition). */
+typedef struct pa_ppo_learn_args {
+  pa_mlp* actor; pa_mlp* critic;
+  int32_t B, S, A;
+  int32_t rounds, gather_rounds;       /* gather_rounds x B <= rows in the arena */
+  const int64_t* idx_lists;            /* device [rounds][B] logical indices */
+  const float* planes; int64_t plane_stride;  /* device [3][plane_stride]: gae, lam_return,
+                                                 action_probs in logical (rollout) order */
+  float* x;                            /* workspace [gather_rounds * B][S + A] */
+  float* planes_ws;                    /* workspace [3][gather_rounds * B] */
+  float epsilon, entropy_scale, value_grad_scale;
+  float* d_logits; float* d_value;     /* scratch [B][A], [B] */
+  float* losses; int64_t losses_stride;/* [rounds][losses_stride >= 2]: actor loss, critic loss */
+  int64_t actor_step, critic_step;     /* AdamW step of the first round (1-based) */
+} pa_ppo_learn_args;
+int pa_ppo_learn(const pa_ppo_learn_args* args, pa_arena* arena, void* stream);
+
 /* tuning aid (tools/prof_sac.py): in-kernel phase stamps of the two fused row kernels */
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
 /* Fused row steps of 32 rows per workgroup (launches of more than 256 row tiles: PPO's 4096-row

@@ -192,6 +192,21 @@ class MlpDesc(C.Structure):
     ]
 
 
+class PpoLearnArgs(C.Structure):
+    _fields_ = [
+        ("actor", C.c_void_p), ("critic", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("A", C.c_int32),
+        ("rounds", C.c_int32), ("gather_rounds", C.c_int32),
+        ("idx_lists", C.c_void_p),
+        ("planes", C.c_void_p), ("plane_stride", C.c_int64),
+        ("x", C.c_void_p), ("planes_ws", C.c_void_p),
+        ("epsilon", C.c_float), ("entropy_scale", C.c_float), ("value_grad_scale", C.c_float),
+        ("d_logits", C.c_void_p), ("d_value", C.c_void_p),
+        ("losses", C.c_void_p), ("losses_stride", C.c_int64),
+        ("actor_step", C.c_int64), ("critic_step", C.c_int64),
+    ]
+
+
 class BanditStepArgs(C.Structure):
     _fields_ = [
         ("net", C.c_void_p),
@@ -474,6 +489,7 @@ SIGNATURES = {
     "pa_linreg_delta2": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_apply2": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "pa_bandit_step": (C.c_int, [_P, _P]),
+    "pa_ppo_learn": (C.c_int, [_P, _P, _P]),
     "pa_mlp_activation": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "pa_weighted_loss_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                         _P, _P, _P]),

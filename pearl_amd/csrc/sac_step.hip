@@ -927,3 +927,59 @@ extern "C" int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena,
   }
   return PA_OK;
 }
+
+// ProximalPolicyOptimization.learn's training rounds (actor_critic_base.py / policy_learner.py:190-231
+// around ppo.py:152-192) sequenced in C: per group of `gather_rounds` rounds ONE gather launch writes
+// state || one-hot(action) rows (the learner-side view of the gather kernel: preprocess_batch's
+// action representation costs no launch) and one more gathers the three per-transition columns
+// (gae, lam_return, action_probs); per round the fused row step of actor + critic
+// (pa_ppo_rowstep) and ONE weight-gradient + AdamW launch for both (pa_mlp_adam2; two pa_mlp_adam
+// launches when the two optimizers differ).  The same launches, on the same index lists, as the
+// per-round Python loop — which spent 112 us of host time per 107 us round (tools/host_bound.py).
+extern "C" int pa_ppo_learn(const pa_ppo_learn_args* g, pa_arena* arena, void* stream) {
+  PA_REQUIRE(g && arena && g->actor && g->critic && g->idx_lists && g->planes && g->x &&
+                 g->planes_ws && g->d_logits && g->d_value && g->losses,
+             PA_ERR_INVALID, "pa_ppo_learn: null argument");
+  PA_REQUIRE(g->B > 0 && g->S > 0 && g->A > 0 && g->rounds >= 0 && g->losses_stride >= 2 &&
+                 g->actor_step >= 1 && g->critic_step >= 1 && g->plane_stride > 0,
+             PA_ERR_INVALID, "pa_ppo_learn: bad sizes");
+  PA_REQUIRE(g->actor->d.dims[0] == g->S && g->critic->d.dims[0] == g->S &&
+                 g->actor->d.dims[g->actor->L] == g->A,
+             PA_ERR_INVALID, "pa_ppo_learn: S / A are not the networks' input / output widths");
+  PA_REQUIRE(pa_rowstep_supported(g->actor, g->critic, g->A), PA_ERR_UNSUPPORTED,
+             "pa_ppo_learn: the networks are outside the fused row step's shapes");
+  const int G = g->gather_rounds > 1 ? g->gather_rounds : 1;
+  const int ldx = g->S + g->A;
+  pa_batch_out out;
+  memset(&out, 0, sizeof(out));
+  out.x = g->x;
+  out.rep_dim = g->A;
+  out.rep_onehot = 1;
+  for (int r = 0; r < g->rounds; ++r) {
+    const int slot = r % G;
+    if (slot == 0) {
+      const int n = g->rounds - r < G ? g->rounds - r : G;
+      const int64_t* idx = g->idx_lists + (int64_t)r * g->B;
+      PA_TRY(pa_arena_gather_device(arena, idx, n * g->B, &out, stream));
+      // (pitch of the gathered planes = the rows gathered by THIS launch)
+      PA_TRY(pa_gather_planes(g->planes, g->plane_stride, 3, idx, n * g->B, g->planes_ws, stream));
+    }
+    const int nrows = (g->rounds - (r - slot) < G ? g->rounds - (r - slot) : G) * g->B;
+    const int64_t row0 = (int64_t)slot * g->B;
+    const float* x = g->x + row0 * ldx;
+    const float* gae = g->planes_ws + row0;
+    const float* lam_return = g->planes_ws + nrows + row0;
+    const float* p_old = g->planes_ws + 2ll * nrows + row0;
+    PA_TRY(pa_ppo_rowstep(g->actor, g->critic, x, ldx, g->B, x + g->S, ldx, p_old, gae, g->epsilon,
+                          g->entropy_scale, lam_return, g->value_grad_scale, nullptr, 0, nullptr, 0,
+                          g->d_logits, g->A, g->d_value, g->losses + (int64_t)r * g->losses_stride,
+                          stream));
+    if (g->actor_step == g->critic_step && mlp_pair_fusable(g->actor, g->critic, false)) {
+      PA_TRY(pa_mlp_adam2(g->actor, g->critic, g->actor_step + r, -1.f, stream));
+    } else {
+      PA_TRY(pa_mlp_adam(g->actor, g->actor_step + r, stream));
+      PA_TRY(pa_mlp_adam(g->critic, g->critic_step + r, stream));
+    }
+  }
+  return PA_OK;
+}

@@ -268,6 +268,81 @@ class ProximalPolicyOptimization(ActorCriticBase):
         self.preprocess_replay_buffer(replay_buffer)
         return ActorCriticBase.learn(self, replay_buffer)
 
+    def _learn_native_loop(self, replay_buffer: ReplayBuffer, batch_size: int
+                           ) -> Optional[Dict[str, List[Any]]]:
+        """The training rounds of learn() as ONE pa_ppo_learn call: the rounds the per-round loop
+        would run — same index lists, same fused row step and weight-gradient / AdamW launches —
+        with the batches of up to 16 rounds gathered by one launch that writes
+        state || one-hot(action) rows directly (the per-round loop spent 112 us of interpreter
+        time per 107 us round, plus a one-hot launch and a gather of fields learn_batch never
+        reads).  None: this call takes the per-round loop (data parallel, another action
+        representation / history summarisation / preprocess_batch, a replay buffer subclass)."""
+        from ...action_representation_modules import OneHotActionTensorRepresentationModule
+        from ..policy_learner import IdentityHistorySummarizationModule
+        if os.environ.get("PEARL_AMD_AC_LOOP", "1") == "0":
+            return None
+        cls, base = type(self), ProximalPolicyOptimization
+        rb = replay_buffer
+        if cls._learn_batch_device is not base._learn_batch_device \
+                or cls._ppo_optimizer_step is not base._ppo_optimizer_step \
+                or cls.preprocess_batch is not ActorCriticBase.preprocess_batch \
+                or cls._preprocess_for_learn is not ActorCriticBase._preprocess_for_learn \
+                or cls.learn_batch is not ActorCriticBase.learn_batch \
+                or type(rb) is not PPOReplayBuffer or rb.arena is None or not rb.extra:
+            return None
+        if (dist.is_available() and dist.is_initialized()) or os.environ.get("PEARL_AMD_FORCE_DP") == "1":
+            return None
+        arm = self.action_representation_module
+        if type(arm) is not OneHotActionTensorRepresentationModule \
+                or type(self._history_summarization_module) is not IdentityHistorySummarizationModule \
+                or hasattr(getattr(self, "safety_module", None), "lambda_constraint"):
+            return None
+        actor, critic = self._nets(batch_size)
+        dev = actor.device
+        B, S, A = int(batch_size), actor.dims[0], actor.dims[-1]
+        rounds = int(self._training_rounds)
+        pre, z, arena = rb._presampled, rb._layout, rb.arena
+        if pre is None or pre[1] != 0 or tuple(pre[0].shape) != (rounds, B) or rounds <= 0 \
+                or arena.device != dev or rb._device_for_batches != dev \
+                or len(z.state_shape) > 1 or z.state_dim != S or z.action_elems != 1 \
+                or z.action_dtype.is_floating_point or arm.max_number_actions != A \
+                or critic.dims[0] != S or len(actor.dims) != len(critic.dims) \
+                or not FlatMlp.rowstep_supported(actor, critic, A) \
+                or os.environ.get("PEARL_AMD_PPO_PAIR", "1") != "1":
+            return None
+        planes = rb._planes
+        if planes.device != dev or planes.shape[1] != len(rb):
+            return None
+        G = max(1, min(rounds, self._LOOP_GATHER_BYTES // ((4 * (S + A) + 12) * B), len(rb) // B))
+        ws = self._flat.get("loop_ws")
+        key = (dev, B, S, A, G)
+        if ws is None or ws["key"] != key:
+            f32 = dict(dtype=torch.float32, device=dev)
+            ws = {"key": key, "x": torch.empty(G * B, S + A, **f32),
+                  "planes": torch.empty(3, G * B, **f32), "d_logits": torch.empty(B, A, **f32),
+                  "dv": torch.empty(B, **f32), "args": N.PpoLearnArgs()}
+            self._flat["loop_ws"] = ws
+        losses = self._loop_losses(rounds, 2)
+        a = ws["args"]
+        a.actor, a.critic = actor.handle.value, critic.handle.value
+        a.B, a.S, a.A, a.rounds, a.gather_rounds = B, S, A, rounds, G
+        a.idx_lists = pre[0].data_ptr()
+        a.planes, a.plane_stride = planes.data_ptr(), planes.stride(0)
+        a.x, a.planes_ws = ws["x"].data_ptr(), ws["planes"].data_ptr()
+        a.epsilon, a.entropy_scale = float(self._epsilon), float(self._entropy_bonus_scaling)
+        a.value_grad_scale = 2.0 / B
+        a.d_logits, a.d_value = ws["d_logits"].data_ptr(), ws["dv"].data_ptr()
+        a.losses, a.losses_stride = losses.data_ptr(), 2
+        a.actor_step, a.critic_step = actor.next_adam_step(), critic.next_adam_step()
+        N.check(N.lib().pa_ppo_learn(C.byref(a), arena.handle, N.stream_ptr(dev)))
+        for m in (actor, critic):
+            m.stepped_natively(rounds)
+        self._training_steps += rounds
+        rb._presampled = (pre[0], rounds, len(rb))          # all consumed
+        rb._last_idx = pre[0][rounds - 1]
+        torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        return {"actor_loss": losses[:, 0].tolist(), "critic_loss": losses[:, 1].tolist()}
+
     def preprocess_replay_buffer(self, replay_buffer: ReplayBuffer) -> None:
         assert isinstance(replay_buffer, PPOReplayBuffer), \
             "pearl_amd PPO needs a pearl_amd PPOReplayBuffer"

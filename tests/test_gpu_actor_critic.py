@@ -112,6 +112,57 @@ def test_ppo_learn_trajectory(name):
     assert len(rb) == 0
 
 
+@pytest.mark.parametrize("S,A,hidden,B,N,rounds", [(24, 5, [32, 32], 64, 400, 9),
+                                                   (256, 16, [256, 256], 4096, 20000, 7)])
+def test_ppo_native_learn_loop_is_bitwise_the_per_round_loop(S, A, hidden, B, N, rounds, monkeypatch):
+    """learn() through pa_ppo_learn (one call: grouped gathers writing state || one-hot(action)
+    rows, the fused row step and the paired weight-gradient / AdamW launch per round) against the
+    per-round Python loop (PEARL_AMD_AC_LOOP=0) on the same device-sampled index lists: the same
+    launches on the same rows, so losses and parameters are bitwise equal; step counters, the
+    training-step count and the buffer's last indices as the per-round loop leaves them."""
+    from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
+                           ProximalPolicyOptimization, _native as N_)
+    g = torch.Generator().manual_seed(4)
+    states = torch.randn(N + 1, S, generator=g)
+    ids = torch.arange(N)
+
+    def run(native):
+        monkeypatch.setenv("PEARL_AMD_AC_LOOP", "1" if native else "0")
+        torch.manual_seed(0)
+        pl = ProximalPolicyOptimization(
+            action_space=dspace(A), state_dim=S, actor_hidden_dims=hidden, critic_hidden_dims=hidden,
+            training_rounds=rounds, batch_size=B, epsilon=0.1,
+            action_representation_module=OneHotActionTensorRepresentationModule(A))
+        rb = PPOReplayBuffer(N, sampler="device")
+        PearlAgent(pl, replay_buffer=rb, device_id=0)
+        rb.push_many(state=states[:-1].to(DEV), action=(ids % A).view(-1, 1).to(DEV),
+                     reward=(ids % 7).float().to(DEV), terminated=(ids % 50 == 49).to(DEV),
+                     truncated=torch.zeros(N, dtype=torch.bool, device=DEV), next_state=states[1:].to(DEV),
+                     curr_available_actions=dspace(A), next_available_actions=dspace(A),
+                     max_number_actions=A)
+        reports = []
+        for call in range(2):
+            random.seed(77 + call)
+            reports.append(pl.learn(rb))
+        return pl, rb, reports
+
+    pa, rba, ra = run(True)
+    pb, rbb, rb_ = run(False)
+    for x, y in zip(ra, rb_):
+        assert x.keys() == y.keys() == {"actor_loss", "critic_loss"}
+        for k in x:
+            assert len(x[k]) == rounds and x[k] == y[k], k
+    for net in ("_actor", "_critic"):
+        for (k, va), (_, vb) in zip(getattr(pa, net).state_dict().items(), getattr(pb, net).state_dict().items()):
+            assert torch.equal(va, vb), f"{net}.{k}"
+    assert pa._training_steps == pb._training_steps == 2 * rounds
+    assert torch.equal(rba.last_indices, rbb.last_indices)
+    for opt_a, opt_b in ((pa._actor_optimizer, pb._actor_optimizer), (pa._critic_optimizer, pb._critic_optimizer)):
+        for sa, sb in zip(opt_a.state.values(), opt_b.state.values()):
+            assert float(sa["step"]) == float(sb["step"]) == 2 * rounds
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"])
+
+
 def make_sac(fx):
     from pearl_amd import BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic, PearlAgent
     cfg = fx["config"]

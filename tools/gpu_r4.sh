@@ -163,3 +163,16 @@ if [ "$MODE" == "bandit4" ]; then
   python $R/tools/rocpd_timeline.py $DB mlp_rowstep 26 > $R/gpurun_out/bandit_timeline.txt 2>&1; sed -n 5,24p $R/gpurun_out/bandit_timeline.txt | cut -c1-140
   rm -f $DB
 fi
+if [ "$MODE" == "bandit5" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "bandit or squarecb or neural_linear or linreg" 2>&1 | tail -8
+  timeout 300 python bench_algos.py --steps 300 --only bandit --cpu-seconds 0.2 2>$R/gpurun_out/bench_bandit5.err | tee $R/gpurun_out/bench_bandit5.jsonl | python tools/algo_line.py
+  for w in ppo sac; do TOPN=14 timeout 300 python tools/host_bound.py $w 2>&1 | grep -v amdgpu | tail -24; done
+fi
+if [ "$MODE" == "ppo2" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "ppo" 2>&1 | tail -8
+  timeout 300 python bench_algos.py --steps 300 --only ppo --cpu-seconds 0.2 2>$R/gpurun_out/bench_ppo2.err | tee $R/gpurun_out/bench_ppo2.jsonl | python tools/algo_line.py
+  PEARL_AMD_AC_LOOP=0 timeout 300 python bench_algos.py --steps 300 --only ppo --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py
+  TOPN=10 timeout 300 python tools/host_bound.py ppo 2>&1 | grep -v amdgpu | tail -18
+fi
