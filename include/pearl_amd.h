@@ -589,9 +589,11 @@ int pa_ppo_learn(const pa_ppo_learn_args* args, pa_arena* arena, void* stream);
 int pa_debug_sac_prof(long long* rows_a, long long* rows_b);
 /* Fused row steps of 32 rows per workgroup (launches of more than 256 row tiles: PPO's 4096-row
  * minibatch) run their forward GEMMs on the bf16 matrix pipe at fp32 accuracy (bf16x3 split operands,
- * mlp_rowstep.hpp) when every layer input is at most 256 wide.  mode -1: that default; 0: the fp32
- * MFMA forward everywhere (also PEARL_AMD_ROWSTEP_SPLIT=0).  pa_rowstep_last_split: 1 when the most
- * recent fused row step took the bf16x3 forward (bench lines report the pipe). */
+ * mlp_rowstep.hpp) when every layer input is at most 256 wide — and, when no input gradient is asked
+ * for, their backward GEMMs as well (W^T planes; PEARL_AMD_ROWSTEP_SPLIT_BWD=0: forward only).
+ * mode -1: that default; 0: fp32 MFMA everywhere (also PEARL_AMD_ROWSTEP_SPLIT=0); 1: bf16x3 forward,
+ * fp32-MFMA backward.  pa_rowstep_last_split: what the most recent fused row step ran — 0: fp32,
+ * 1: bf16x3 forward, 2: bf16x3 forward and backward (bench lines report the pipe). */
 int pa_debug_set_rowstep_split(int32_t mode);
 int pa_rowstep_last_split(void);
 /* the same for the fused row step (mlp_rowstep.hpp): [workgroup][8][16] ticks of the next launches */

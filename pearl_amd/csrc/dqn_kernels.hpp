@@ -986,6 +986,7 @@ struct DwProblem {
   float* pktf; int nkgtf;     // kind 3: fragment-major W^T [N units][M] or null
   float* pkf_t;               // kind 3 + soft update: the TARGET's fragment-major W (pkf layout) or null
   void* pks; int nks;         // kind 3: W as bf16x3 split planes for v_mfma_f32_16x16x32_bf16 (wsp16_index) or null
+  void* pkts; int nkts;       // kind 3: W^T the same way ([N units][M]) or null
   int bias_frozen;            // the bias slot is not a parameter (bias-free layer): no AdamW on db
   int net;                    // kind 3: which network's optimizer state (0: ad, 1: net2)
   int raw;                    // a plain X^T dZ product riding an optimizer launch: dW / db stored, no AdamW
@@ -1069,6 +1070,7 @@ __device__ __forceinline__ void pack_generic(const DwProblem& P, int row, int co
   if (P.pkf) P.pkf[wf16_index_(row, col, P.nkgf)] = p;
   if (P.pktf) P.pktf[wf16_index_(col, row, P.nkgtf)] = p;
   if (P.pks) store_wsp16_1(P.pks, row, col, p, P.nks);
+  if (P.pkts) store_wsp16_1(P.pkts, col, row, p, P.nkts);
 }
 // kind 3, one scalar parameter: AdamW, packed copies, and (soft) the target with its packed copy
 __device__ __forceinline__ void adam_generic_weight(const AdamFuse& f, const AdamState& st, float* tgt,
@@ -1691,6 +1693,10 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
           if (P.pktf) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) P.pktf[wf16_index_(ecol + e, erow, P.nkgtf)] = pv[e];
+          }
+          if (P.pkts) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) store_wsp16_1(P.pkts, ecol + e, erow, pv[e], P.nkts);
           }
         }
         if (a.ad.soft_next && tgt) {  // update_target_network (common/utils.py:214-226)

@@ -100,6 +100,7 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
     if (h->wtf[l]) (void)hipFree(h->wtf[l]);
     if (h->wf_t[l]) (void)hipFree(h->wf_t[l]);
     if (h->wsp[l]) (void)hipFree(h->wsp[l]);
+    if (h->wtsp[l]) (void)hipFree(h->wtsp[l]);
   }
   delete h;
   release_process_device();
@@ -157,6 +158,8 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
         ok = ok && alloc(&h->wf_t[l], wf16_floats(desc->dims[l + 1], desc->dims[l]));
         ok = ok && alloc(&h->wtf[l], wf16_floats(desc->dims[l], desc->dims[l + 1]));
         ok = ok && hipMalloc(&h->wsp[l], (size_t)wsp16_bytes(desc->dims[l + 1], desc->dims[l])) == hipSuccess;
+        if (l >= 1)
+          ok = ok && hipMalloc(&h->wtsp[l], (size_t)wsp16_bytes(desc->dims[l], desc->dims[l + 1])) == hipSuccess;
       }
     }
   }
@@ -203,6 +206,7 @@ int ensure_packed(pa_mlp* h, bool target, hipStream_t s) {
     a.Wf[l] = target ? h->wf_t[l] : h->wf[l];
     a.Wtf[l] = target ? nullptr : h->wtf[l];
     a.Wsp[l] = target ? nullptr : h->wsp[l];
+    a.Wtsp[l] = target ? nullptr : h->wtsp[l];
   }
   hipLaunchKernelGGL(mlp_rowpack_kernel, dim3(128), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
@@ -247,6 +251,7 @@ void fill_bwd(const pa_mlp* h, const float* d_out, int ldd, float* d_x, int lddx
   for (int l = 0; l <= h->L; ++l) n.dims[l] = h->d.dims[l];
   for (int l = 0; l < h->L; ++l) {
     n.Wtf[l] = h->wtf[l];
+    n.Wtsp[l] = h->wtsp[l];
     n.act[l] = h->act[l];
     n.dz[l] = h->dz[l];
     if (l + 1 < h->L && !((h->d.identity_layers >> l) & 1)) n.relu |= 1 << l;
@@ -513,6 +518,7 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
             pr.pkf = h->wf[l]; pr.nkgf = wf16_nkg(h->d.dims[l]);
             pr.pktf = h->wtf[l]; pr.nkgtf = wf16_nkg(h->d.dims[l + 1]);
             pr.pks = h->wsp[l]; pr.nks = wsp16_nks(h->d.dims[l]);
+            pr.pkts = h->wtsp[l]; pr.nkts = wsp16_nks(h->d.dims[l + 1]);
             if (soft_tau >= 0.f && h->packed_t_ok) pr.pkf_t = h->wf_t[l];
           }
         }
@@ -1043,6 +1049,16 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   for (int i = 0; i < nnet && splitf; ++i)
     for (int l = 0; l < hs[i]->L; ++l)
       splitf = splitf && hs[i]->d.dims[l] <= ROW_MAX_OUT && hs[i]->wsp[l] != nullptr;
+  // ... and then the backward GEMMs too (W_l^T planes, dz planes in LDS); a network without them
+  // (or PEARL_AMD_ROWSTEP_SPLIT_BWD=0) keeps the fp32-MFMA backward
+  static const bool splitb_env = []() {
+    const char* v = getenv("PEARL_AMD_ROWSTEP_SPLIT_BWD");
+    return !(v && *v == '0');
+  }();
+  bool splitb = splitf && splitb_env && rowstep_split_mode() != 1;
+  for (int i = 0; i < nnet && splitb; ++i)
+    for (int l = 1; l < hs[i]->L; ++l) splitb = splitb && hs[i]->wtsp[l] != nullptr;
+  a.split_bwd = splitb ? 1 : 0;
   static size_t configured[4] = {0, 0, 0, 0};
   const int slot = splitf ? 3 : RT;
   const size_t smem = splitf ? rowstep_split_smem_bytes()
@@ -1059,7 +1075,7 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
     else if (RT == 2) hipLaunchKernelGGL(mlp_rowstep_kernel<2>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
     else hipLaunchKernelGGL(mlp_rowstep_kernel<1>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
   }
-  g_rowstep_last_split = splitf ? 1 : 0;
+  g_rowstep_last_split = splitf ? (splitb ? 2 : 1) : 0;
   PA_LAUNCH_CHECK();
   // the state a kept forward + a want_dw = 2 backward leave behind: the weight gradients (and
   // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
@@ -1115,8 +1131,9 @@ extern "C" int pa_debug_mlp_dw_prof(long long* stamps) {
   g_mlp_dw_prof = stamps;
   return PA_OK;
 }
-// which forward the fused row steps take: -1 = default (bf16x3 where eligible), 0 = fp32 MFMA;
-// pa_rowstep_last_split: 1 when the most recent fused row step ran the bf16x3 forward
+// which GEMMs the fused row steps take: -1 = default (bf16x3 forward and backward where eligible),
+// 0 = fp32 MFMA, 1 = bf16x3 forward with the fp32-MFMA backward;
+// pa_rowstep_last_split: what the most recent fused row step ran — 0 fp32, 1 bf16x3 forward, 2 both
 extern "C" int pa_debug_set_rowstep_split(int32_t mode) {
   PA_REQUIRE(mode >= -1 && mode <= 1, PA_ERR_INVALID, "pa_debug_set_rowstep_split: mode is -1, 0 or 1");
   g_rowstep_split_mode = mode;

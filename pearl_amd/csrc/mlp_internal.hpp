@@ -33,6 +33,8 @@ struct pa_mlp {
   // forward GEMMs on the bf16 matrix pipe (mlp_rowstep.hpp, launches of 32 rows per workgroup);
   // kept current with wf (repack launch, optimizer epilogue)
   void* wsp[PA_MLP_MAX_LAYERS];
+  // ... and W_l^T ([d_l units][d_{l+1}]) the same way, l >= 1: the row step's backward GEMMs
+  void* wtsp[PA_MLP_MAX_LAYERS];
   bool packed_ok, packed_t_ok;
   // weight gradients deferred to pa_mlp_adam (want_dw = 2): the operands of the kept backward
   struct Pending {

@@ -111,6 +111,7 @@ static __global__ __launch_bounds__(512) void mlp_rowfwd_kernel(RowFwdArgs a) {
 // ---- backward: pre-activation gradients of every layer (+ the input gradient) ------------------
 struct RowNetBwd {
   const float* Wtf[ROW_MAX_LAYERS];    // fragment-major W_l^T [d_l units][d_{l+1}]  (l >= 1; l = 0 for d_x)
+  const void* Wtsp[ROW_MAX_LAYERS];    // the same as bf16x3 split planes (wsp16_index) or null
   const float* act[ROW_MAX_LAYERS];    // kept hidden outputs of the forward (ReLU masks)
   float* dz[ROW_MAX_LAYERS];           // dz[l] = gradient w.r.t. the pre-activation of layer l - 1,
                                        // [B][d_l], l = 1 .. L - 1  (weight-gradient operands)
@@ -196,6 +197,7 @@ struct RowPackArgs {
   float* Wf[ROW_MAX_LAYERS];           // [d_{l+1} units][d_l]
   float* Wtf[ROW_MAX_LAYERS];          // [d_l units][d_{l+1}] or null
   void* Wsp[ROW_MAX_LAYERS];           // W_l as bf16x3 split planes (wsp16_index) or null
+  void* Wtsp[ROW_MAX_LAYERS];          // W_l^T as split planes ([d_l units][d_{l+1}]) or null
 };
 static __global__ __launch_bounds__(256) void mlp_rowpack_kernel(RowPackArgs a) {
   const int64_t gsz = (int64_t)gridDim.x * 256;
@@ -238,6 +240,27 @@ static __global__ __launch_bounds__(256) void mlp_rowpack_kernel(RowPackArgs a) 
           v[j] = plane == 0 ? hi : (plane == 1 ? mid : lo);
         }
         reinterpret_cast<bf16x8*>(a.Wsp[l])[e] = v;
+      }
+    }
+    if (a.Wtsp[l]) {  // the transpose: unit = input index k of W_l, 8 consecutive output units per slot
+      const int nks = wsp16_nks(N);
+      const int64_t total = wsp16_bytes(K, N) / 16;
+      for (int64_t e = t0; e < total; e += gsz) {
+        const int lane = (int)(e & 63);
+        const int64_t tg = e >> 6;
+        const int plane = (int)(tg % 3);
+        const int64_t ts = tg / 3;
+        const int s = (int)(ts % nks), T = (int)(ts / nks);
+        const int k = T * 16 + (lane & 15), u0 = s * 32 + 8 * (lane >> 4);
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = (k < K && u0 + j < N) ? W[(int64_t)(u0 + j) * K + k] : 0.f;
+          __bf16 hi, mid, lo;
+          split3(x, hi, mid, lo);
+          v[j] = plane == 0 ? hi : (plane == 1 ? mid : lo);
+        }
+        reinterpret_cast<bf16x8*>(a.Wtsp[l])[e] = v;
       }
     }
     if (a.Wtf[l]) {   // "unit" = input index k of W_l, reduction over its output units

@@ -81,6 +81,7 @@ struct RowStepArgs {
   unsigned* ticket;             // zero on entry, zero again on exit
   float* losses;                // [2]: one per network — or, sum_losses, losses[0] = both
   int sum_losses;
+  int split_bwd;                // SPLITF kernel: the backward GEMMs as bf16x3 products too (RowNetBwd::Wtsp)
   long long* prof;              // optional phase stamps [workgroup (x + y gridDim.x)][wave][16] (tools/prof_rowstep.py)
 };
 
@@ -599,7 +600,19 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     }
   }
   __syncthreads();   // every read of the output tile is done: hb[0] may be overwritten
-  {
+  // SPLITF + split_bwd: the backward GEMMs are bf16x3 products as well — d_out goes into plane
+  // buffer 0 as three bf16 planes (zero up to the next multiple of 32 columns: whole k-steps)
+  bool sbw = false;
+  if constexpr (SPLITF) sbw = a.split_bwd != 0;
+  if (sbw) {
+    if constexpr (SPLITF) {
+      const int c8 = ((DL + 31) & ~31) >> 3;
+      for (int e = tid; e < 3 * ROWS * c8; e += 512) {
+        const int pr = e / c8, c = (e - pr * c8) * 8;      // pr = plane * ROWS + row
+        *reinterpret_cast<float4*>(pl[0] + (size_t)pr * RS_PP + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  } else {
     const int c4 = (rp_pad(DL) - 4) >> 2;
     for (int e = tid; e < ROWS * c4; e += 512) {
       const int r = e / c4, c = (e - r * c4) * 4;
@@ -608,7 +621,17 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   }
   __syncthreads();
   if (hlive) {
-    hb[0][hr * PH + hj] = dval;
+    if (sbw) {
+      if constexpr (SPLITF) {
+        __bf16 s0, s1, s2;
+        split3(dval, s0, s1, s2);
+        pl[0][((size_t)0 * ROWS + hr) * RS_PP + hj] = s0;
+        pl[0][((size_t)1 * ROWS + hr) * RS_PP + hj] = s1;
+        pl[0][((size_t)2 * ROWS + hr) * RS_PP + hj] = s2;
+      }
+    } else {
+      hb[0][hr * PH + hj] = dval;
+    }
     hd.d_out[(int64_t)(m0 + hr) * hd.ldd + hj] = dval;
   }
   {
@@ -620,10 +643,70 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     }
   }
   PA_STAMP(a.prof, pwg, wave, 10);            // head done
+  // ---------------------------------------------------------------- backward, bf16x3
+  // dz_{l} = (dz_{l+1} W_l) o relu': the forward's rs_gemm with W_l^T planes as the weights and the
+  // dz planes as the activations (both split exactly: fp32 accuracy, §3.5).  Layers l >= 1 only —
+  // the host sets split_bwd when no input gradient is asked for.
+  if constexpr (SPLITF) {
+    if (sbw) {
+      int curp = 0;
+      for (int l = nb.L - 1; l >= 1; --l) {
+        const int K = nb.dims[l + 1], N = nb.dims[l];
+        const int nt = (N + 15) >> 4, nks = wsp16_nks(K);
+        const bool mask = (nb.relu >> (l - 1)) & 1;
+        __bf16* nxtp = pl[curp ^ 1];
+        f32x4v accm[2][RT], accs[2][RT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            accm[t][rt][0] = accm[t][rt][1] = accm[t][rt][2] = accm[t][rt][3] = 0.f;
+            accs[t][rt][0] = accs[t][rt][1] = accs[t][rt][2] = accs[t][rt][3] = 0.f;
+          }
+        RowWS R;
+        if (tile0 < nt) rs_fill(R, nb.Wtsp[l], nks, tile0, nt, lane);
+        float4 hmq[RT][2];
+        if (mask) {
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int row = m0 + r16 + 16 * rt;
+              hmq[rt][t] = guarded_load4(nb.act[l - 1], (int64_t)row * N, row < a.B, u0 + 16 * t, N);
+            }
+        }
+        __syncthreads();
+        if (tile0 < nt) rs_gemm<RT>(accm, accs, R, nb.Wtsp[l], nks, tile0, nt, pl[curp], lane);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int lr = r16 + 16 * rt;
+          const int row = m0 + lr;
+          const bool rok = row < a.B;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int u = u0 + 16 * t;
+            float4 v = make_float4(accm[t][rt][0] + accs[t][rt][0], accm[t][rt][1] + accs[t][rt][1],
+                                   accm[t][rt][2] + accs[t][rt][2], accm[t][rt][3] + accs[t][rt][3]);
+            if (mask) {
+              const float4 hm = hmq[rt][t];
+              v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
+              v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+            }
+            if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            // (units beyond N: zero weights -> exact zeros, the next layer's padded k-steps)
+            if (l > 1) rs_store_planes4(nxtp, ROWS, lr, u, v);
+            if (rok) store4_guarded(nb.dz[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
+          }
+        }
+        curp ^= 1;
+      }
+    }
+  }
   // ---------------------------------------------------------------- backward (mlp_rowbwd_kernel)
   in = hb[0];
   int cur = 0;
   for (int l = nb.L - 1; l >= 0; --l) {
+    if (sbw) break;
     if (l == 0 && !nb.d_x) break;
     const int K = nb.dims[l + 1], N = nb.dims[l];
     const int nt = (N + 15) >> 4;

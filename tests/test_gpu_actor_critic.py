@@ -815,6 +815,17 @@ def test_ppo_rowstep_bf16x3_forward_has_fp32_accuracy(S, A, hidden, B):
             actor = FlatMlp(layers_of(an), ao, max_batch=B).ensure(B)
             critic = FlatMlp(layers_of(cn), co, max_batch=B).ensure(B)
             errs, used = [], 0
+            # float64 gradient of the critic's loss mean (v - lam)^2 at the initial parameters: the
+            # yardstick of the backward pass (its GEMMs are bf16x3 products too in the split launch)
+            ws = [l.weight.detach().double().cpu().requires_grad_() for l in cn]
+            bs = [l.bias.detach().double().cpu() for l in cn]
+            h = xs
+            for i, (w_, b_) in enumerate(zip(ws, bs)):
+                h = h @ w_.t() + b_
+                if i + 1 < len(ws):
+                    h = torch.relu(h)
+            ((h.view(-1) - lam.double().cpu()) ** 2).mean().backward()
+            gerr = None
             for step in range(3):
                 want_l, want_v = exact(an), exact(cn)         # from the parameters as they are NOW
                 actor.ready(B)
@@ -835,19 +846,26 @@ def test_ppo_rowstep_bf16x3_forward_has_fp32_accuracy(S, A, hidden, B):
                 torch.cuda.synchronize()
                 errs.append((float((logits.double().cpu() - want_l).abs().max() / want_l.abs().max()),
                              float((value.double().cpu() - want_v).abs().max() / want_v.abs().max())))
-            return used, errs, [p.detach().clone() for l in an + cn for p in l.parameters()]
+                if gerr is None:      # the gradient buffer of step 1, layer by layer
+                    gerr = [float((l.weight.grad.double().cpu() - w_.grad).abs().max() / w_.grad.abs().max())
+                            for l, w_ in zip(cn, ws)]
+            return used, errs, [p.detach().clone() for l in an + cn for p in l.parameters()], gerr
         finally:
             N.check(N.lib().pa_debug_set_rowstep_split(-1))
 
-    used32, e32, p32 = run(0)
-    useds, es, ps = run(-1)
-    _, _, ps2 = run(-1)
-    assert used32 == 0 and useds == 1, "the bf16x3 forward did not run for this launch"
+    used32, e32, p32, g32 = run(0)
+    useds, es, ps, gs = run(-1)
+    _, _, ps2, _ = run(-1)
+    assert used32 == 0 and useds == 2, "the bf16x3 forward + backward did not run for this launch"
     print("\nlogits / value error vs float64 (of the output scale), steps 1..3:")
     print("  fp32 MFMA forward:", " ".join(f"{a:.1e}/{b:.1e}" for a, b in e32))
     print("  bf16x3 forward:   ", " ".join(f"{a:.1e}/{b:.1e}" for a, b in es))
+    print("  critic dW error vs float64 per layer: fp32 MFMA", " ".join(f"{g:.1e}" for g in g32),
+          "| bf16x3", " ".join(f"{g:.1e}" for g in gs))
     for (a32, b32), (as_, bs) in zip(e32, es):
         assert as_ <= max(2.0 * a32, 3e-7) and bs <= max(2.0 * b32, 3e-7), (e32, es)
+    for a, b in zip(g32, gs):
+        assert b <= max(2.0 * a, 1e-6), (g32, gs)
     for a, b in zip(ps, ps2):
         assert torch.equal(a, b)
     for a, b in zip(ps, p32):

@@ -176,3 +176,17 @@ if [ "$MODE" == "ppo2" ]; then
   PEARL_AMD_AC_LOOP=0 timeout 300 python bench_algos.py --steps 300 --only ppo --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py
   TOPN=10 timeout 300 python tools/host_bound.py ppo 2>&1 | grep -v amdgpu | tail -18
 fi
+if [ "$MODE" == "ppo3" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -s -k "ppo or rowstep" 2>&1 | grep -v "^$" | tail -22
+  for m in 1 0; do
+    PEARL_AMD_ROWSTEP_SPLIT_BWD=$m timeout 300 python bench_algos.py --steps 300 --only ppo --cpu-seconds 0.2 2>$R/gpurun_out/bench_ppo3_$m.err | tee $R/gpurun_out/bench_ppo3_$m.jsonl | python tools/algo_line.py
+  done
+fi
+if [ "$MODE" == "slots" ]; then
+  cd $R
+  for sl in 256 576 1152 2304; do
+    echo "== PEARL_AMD_DW_SLOTS=$sl"
+    PEARL_AMD_DW_SLOTS=$sl timeout 300 python bench_algos.py --steps 300 --only ppo,bandit --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py
+  done
+fi
