@@ -129,6 +129,8 @@ typedef struct pa_batch_out {
   float* reward_f32;        /* [B] reward converted to float32                           */
   int32_t rep_dim;          /* representation width                                      */
   int32_t rep_onehot;       /* 1: rep = one-hot(index) (one_hot_action_representation_module.py:27-34); 0: identity */
+  float* curr_avail_rep;    /* [B, A, rep_dim]: rep(current available actions) (discrete SAC's
+                               actor update reads the critics on every available action)       */
 } pa_batch_out;
 
 int pa_arena_create(pa_arena** out, const pa_arena_desc* desc);
@@ -562,6 +564,43 @@ typedef struct pa_ac_loop_args {
 int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
                  void* stream);
 int pa_ddpg_learn(const pa_ddpg_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
+                  void* stream);
+
+/* Discrete SoftActorCritic.learn_batch as ONE call (soft_actor_critic.py:153-287 on
+ * actor_critic_base.py:309-366): twin all-actions pass (online) -> actor row step + AdamW -> twin
+ * all-actions pass (target, next states) -> Bellman targets under the updated policy -> twin critics'
+ * row step on xq = state || rep(action) -> weight gradients + AdamW (+ soft target update, tau >= 0)
+ * -> entropy coefficient (log_alpha non-NULL).  The same launches as the per-stage entry points
+ * above issue, in the same order: bit-identical.  PA_ERR_UNSUPPORTED when a network is outside the
+ * fused row steps' shapes.  scratch: pa_dsac_scratch_floats(B, A) floats.
+ * curr_rep / next_rep: rep(available actions) per row [B][A][AD] (bstride A * AD) or ONE [A][AD]
+ * table (bstride 0); masks [B][A] (1 = unavailable) or NULL; h_out [B] (nullable): sum_a P log(P + 1e-8). */
+typedef struct pa_dsac_step_args {
+  pa_mlp* actor; pa_mlp* critic1; pa_mlp* critic2;
+  int32_t B, S, A, AD;
+  const float* state; int32_t ld_state;
+  const float* next_state; int32_t ld_next_state;
+  const float* xq; int32_t ld_xq;
+  const float* reward; const uint8_t* terminated;
+  const float* curr_rep; int64_t curr_rep_bstride;
+  const float* next_rep; int64_t next_rep_bstride;
+  const uint8_t* curr_mask; const uint8_t* next_mask;
+  float gamma, tau;                     /* tau < 0: no soft update of the targets in this step */
+  float* alpha;                         /* device scalar: the entropy coefficient */
+  float* log_alpha; float* alpha_m; float* alpha_v;   /* autotune (log_alpha NULL: fixed) */
+  float target_entropy;
+  double alpha_lr, alpha_beta1, alpha_beta2, alpha_eps, alpha_weight_decay;
+  int64_t alpha_step, actor_step, critic_step;        /* 1-based optimizer steps of THIS call */
+  float* scratch; float* losses;        /* losses [3]: actor, critic, entropy-coefficient */
+  float* h_out;
+} pa_dsac_step_args;
+int64_t pa_dsac_scratch_floats(int32_t B, int32_t A);
+int pa_dsac_step(const pa_dsac_step_args* args, void* stream);
+/* SoftActorCritic.learn's rounds as one call: per group of loop->gather_rounds rounds one gather
+ * launch writes state, next_state, x, reward_f32, terminated, both masks and both rep(available
+ * actions) views of `loop->batch` (the workspace `step0` points into, dense rows), then pa_dsac_step
+ * per round; losses [rounds][losses_stride >= 3].  loop->noise is unused. */
+int pa_dsac_learn(const pa_dsac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
                   void* stream);
 
 /* ProximalPolicyOptimization.learn's training rounds as ONE call (policy_learner.py:190-231 around

@@ -120,6 +120,7 @@ class BatchOut(C.Structure):
         ("reward_f32", C.c_void_p),
         ("rep_dim", C.c_int32),
         ("rep_onehot", C.c_int32),
+        ("curr_avail_rep", C.c_void_p),
     ]
 
 
@@ -189,6 +190,29 @@ class MlpDesc(C.Structure):
         ("amsgrad", C.c_int32),
         ("no_last_bias", C.c_int32),
         ("identity_layers", C.c_int32),
+    ]
+
+
+class DsacStepArgs(C.Structure):
+    _fields_ = [
+        ("actor", C.c_void_p), ("critic1", C.c_void_p), ("critic2", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("A", C.c_int32), ("AD", C.c_int32),
+        ("state", C.c_void_p), ("ld_state", C.c_int32),
+        ("next_state", C.c_void_p), ("ld_next_state", C.c_int32),
+        ("xq", C.c_void_p), ("ld_xq", C.c_int32),
+        ("reward", C.c_void_p), ("terminated", C.c_void_p),
+        ("curr_rep", C.c_void_p), ("curr_rep_bstride", C.c_int64),
+        ("next_rep", C.c_void_p), ("next_rep_bstride", C.c_int64),
+        ("curr_mask", C.c_void_p), ("next_mask", C.c_void_p),
+        ("gamma", C.c_float), ("tau", C.c_float),
+        ("alpha", C.c_void_p),
+        ("log_alpha", C.c_void_p), ("alpha_m", C.c_void_p), ("alpha_v", C.c_void_p),
+        ("target_entropy", C.c_float),
+        ("alpha_lr", C.c_double), ("alpha_beta1", C.c_double), ("alpha_beta2", C.c_double),
+        ("alpha_eps", C.c_double), ("alpha_weight_decay", C.c_double),
+        ("alpha_step", C.c_int64), ("actor_step", C.c_int64), ("critic_step", C.c_int64),
+        ("scratch", C.c_void_p), ("losses", C.c_void_p),
+        ("h_out", C.c_void_p),
     ]
 
 
@@ -490,6 +514,9 @@ SIGNATURES = {
     "pa_linreg_apply2": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "pa_bandit_step": (C.c_int, [_P, _P]),
     "pa_ppo_learn": (C.c_int, [_P, _P, _P]),
+    "pa_dsac_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "pa_dsac_step": (C.c_int, [_P, _P]),
+    "pa_dsac_learn": (C.c_int, [_P, _P, _P, _P]),
     "pa_mlp_activation": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32)]),
     "pa_weighted_loss_head": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                         _P, _P, _P]),

@@ -289,9 +289,12 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
       }
     }
   }
-  if (g.o.next_avail_rep && g.A > 0) {
-    const float* na = g.c.next_avail + slot * (int64_t)(g.A * g.avail_dim);
-    float* orow = g.o.next_avail_rep + (int64_t)b * g.A * R;
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    float* rep_out = which ? g.o.curr_avail_rep : g.o.next_avail_rep;
+    if (!rep_out || g.A <= 0) continue;
+    const float* na = (which ? g.c.curr_avail : g.c.next_avail) + slot * (int64_t)(g.A * g.avail_dim);
+    float* orow = rep_out + (int64_t)b * g.A * R;
     if (g.o.rep_onehot) {
       for (int e = lane; e < g.A * R; e += 64) {
         const int i = e / R, j = e - i * R;
@@ -431,19 +434,19 @@ int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa
   g.mask_bytes = a->d.max_actions;
   if (!a->d.has_next_state) g.o.next_state = nullptr;
   if (!a->d.has_cost) g.o.cost = nullptr;
-  if (out->x || out->next_avail_rep) {
+  if (out->x || out->next_avail_rep || out->curr_avail_rep) {
     PA_REQUIRE(out->rep_dim > 0, PA_ERR_INVALID, "gather: rep_dim must be > 0 for fused views");
     if (out->rep_onehot) {
       PA_REQUIRE(a->d.action_elems == 1, PA_ERR_UNSUPPORTED,
                  "one-hot representation needs scalar actions (action_elems=%d)",
                  a->d.action_elems);
-      PA_REQUIRE(!out->next_avail_rep || a->d.avail_dim == 1, PA_ERR_UNSUPPORTED,
+      PA_REQUIRE(!(out->next_avail_rep || out->curr_avail_rep) || a->d.avail_dim == 1, PA_ERR_UNSUPPORTED,
                  "one-hot representation needs avail_dim == 1 (got %d)", a->d.avail_dim);
     } else {
       PA_REQUIRE(out->rep_dim == a->d.action_elems, PA_ERR_INVALID,
                  "identity representation: rep_dim %d != action_elems %d", out->rep_dim,
                  a->d.action_elems);
-      PA_REQUIRE(!out->next_avail_rep || a->d.avail_dim == out->rep_dim, PA_ERR_INVALID,
+      PA_REQUIRE(!(out->next_avail_rep || out->curr_avail_rep) || a->d.avail_dim == out->rep_dim, PA_ERR_INVALID,
                  "identity representation: rep_dim %d != avail_dim %d", out->rep_dim,
                  a->d.avail_dim);
     }

@@ -983,3 +983,126 @@ extern "C" int pa_ppo_learn(const pa_ppo_learn_args* g, pa_arena* arena, void* s
   }
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Discrete SoftActorCritic.learn_batch as ONE call (soft_actor_critic.py:153-287 on top of
+// actor_critic_base.py:309-366): the launches the per-stage Python path issues, in its order —
+//   twin all-actions pass (online)   pa_mlp_q_all2            min Q(s, .) for the policy loss
+//   actor row step + AdamW           pa_dsac_actor_rowstep, pa_mlp_adam
+//   twin all-actions pass (target)   pa_mlp_q_all2            on the next states
+//   Bellman targets                  pa_dsac_target_rowstep   (actor forward at s' inside)
+//   twin critics row step            pa_mse_rowstep2          on x = state || rep(action)
+//   weight gradients + AdamW (+ soft target update)           pa_mlp_adam2, or the single-network calls
+//   entropy coefficient              pa_sac_alpha_step        (autotune)
+// — bit-identical to that path.  Why: its interpreter cost (231 us per step) equals the device time
+// of the step (tools/host_bound.py dsac); this is a C++ function call per launch.
+extern "C" int64_t pa_dsac_scratch_floats(int32_t B, int32_t A) {
+  return 5ll * B * A + 4ll * B;
+}
+
+extern "C" int pa_dsac_step(const pa_dsac_step_args* g, void* stream) {
+  PA_REQUIRE(g && g->actor && g->critic1 && g->critic2 && g->state && g->next_state && g->xq &&
+                 g->reward && g->terminated && g->curr_rep && g->next_rep && g->alpha && g->scratch &&
+                 g->losses,
+             PA_ERR_INVALID, "pa_dsac_step: null argument");
+  PA_REQUIRE(g->B > 0 && g->A > 0 && g->AD > 0 && g->actor_step >= 1 && g->critic_step >= 1,
+             PA_ERR_INVALID, "pa_dsac_step: bad sizes / steps");
+  PA_REQUIRE(g->actor->d.dims[g->actor->L] == g->A, PA_ERR_INVALID,
+             "pa_dsac_step: the actor outputs one logit per available-action slot");
+  PA_REQUIRE(pa_rowstep_supported(g->actor, nullptr, g->A) && pa_rowstep_supported(g->critic1, g->critic2, 0),
+             PA_ERR_UNSUPPORTED, "pa_dsac_step: networks outside the fused row steps' shapes");
+  const int B = g->B, A = g->A;
+  const int64_t BA = (int64_t)B * A;
+  float* q1 = g->scratch;
+  float* q2 = q1 + BA;
+  float* nq1 = q2 + BA;
+  float* nq2 = nq1 + BA;
+  float* d_logits = nq2 + BA;
+  float* h = g->h_out ? g->h_out : d_logits + BA;
+  float* y = d_logits + BA + B;
+  float* dq1 = y + B;
+  float* dq2 = dq1 + B;
+  // ---- actor update (:153-208)
+  PA_TRY(pa_mlp_q_all2(g->critic1, g->critic2, 0, g->state, g->ld_state, g->curr_rep,
+                       g->curr_rep_bstride, B, A, g->AD, q1, q2, stream));
+  PA_TRY(pa_dsac_actor_rowstep(g->actor, g->state, g->ld_state, B, q1, q2, g->curr_mask, g->alpha,
+                               d_logits, A, h, g->losses + 0, stream));
+  PA_TRY(pa_mlp_adam(g->actor, g->actor_step, stream));
+  // ---- critic update (:210-287): targets under the UPDATED policy, then the twin critics
+  PA_TRY(pa_mlp_q_all2(g->critic1, g->critic2, 1, g->next_state, g->ld_next_state, g->next_rep,
+                       g->next_rep_bstride, B, A, g->AD, nq1, nq2, stream));
+  PA_TRY(pa_dsac_target_rowstep(g->actor, g->next_state, g->ld_next_state, B, nq1, nq2, g->next_mask,
+                                g->alpha, g->reward, g->terminated, g->gamma, y, stream));
+  PA_TRY(pa_mse_rowstep2(g->critic1, g->critic2, g->xq, g->ld_xq, B, y, 1.0f / (float)B, 0.5f, nullptr,
+                         nullptr, dq1, dq2, g->losses + 1, stream));
+  if (mlp_pair_fusable(g->critic1, g->critic2, g->tau >= 0.f)) {
+    PA_TRY(pa_mlp_adam2(g->critic1, g->critic2, g->critic_step, g->tau, stream));
+  } else {
+    PA_TRY(pa_mlp_adam(g->critic1, g->critic_step, stream));
+    PA_TRY(pa_mlp_adam(g->critic2, g->critic_step, stream));
+    if (g->tau >= 0.f) {
+      PA_TRY(pa_mlp_soft_update(g->critic1, g->tau, stream));
+      PA_TRY(pa_mlp_soft_update(g->critic2, g->tau, stream));
+    }
+  }
+  // ---- entropy coefficient (:134-151 of the continuous learner's form; h = sum_a P log(P + 1e-8))
+  if (g->log_alpha) {
+    PA_REQUIRE(g->alpha_m && g->alpha_v && g->alpha_step >= 1, PA_ERR_INVALID,
+               "pa_dsac_step: the entropy optimizer's state is missing");
+    PA_TRY(pa_sac_alpha_step(g->log_alpha, g->alpha_m, g->alpha_v, nullptr, g->alpha, h, B,
+                             g->target_entropy, g->alpha_lr, g->alpha_beta1, g->alpha_beta2,
+                             g->alpha_eps, g->alpha_weight_decay, 0, g->alpha_step, g->losses + 2,
+                             stream));
+  }
+  return PA_OK;
+}
+
+// SoftActorCritic.learn's rounds in one call: per group of gather_rounds rounds ONE gather launch
+// writes everything a step reads — state, next_state, x = state || rep(action), float reward,
+// terminated, the availability masks and rep(available actions) of both states (the learner-side
+// views of the gather kernel: no one-hot / concat launches) — then pa_dsac_step on consecutive
+// slices.  `step0` points at the first slice of that workspace.
+extern "C" int pa_dsac_learn(const pa_dsac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* lp,
+                             void* stream) {
+  PA_REQUIRE(step0 && lp && arena && lp->idx_lists && lp->losses && lp->losses_stride >= 3 &&
+                 lp->rounds >= 0,
+             PA_ERR_INVALID, "pa_dsac_learn: bad loop arguments");
+  const pa_batch_out& o = lp->batch;
+  PA_REQUIRE(o.state == step0->state && o.next_state == step0->next_state && o.x == step0->xq &&
+                 o.reward_f32 == step0->reward && o.terminated == step0->terminated &&
+                 o.curr_avail_rep == step0->curr_rep && o.next_avail_rep == step0->next_rep &&
+                 o.curr_mask == step0->curr_mask && o.next_mask == step0->next_mask &&
+                 o.rep_dim == step0->AD,
+             PA_ERR_INVALID, "pa_dsac_learn: the step reads the loop's batch workspace");
+  PA_REQUIRE(step0->curr_rep_bstride == (int64_t)step0->A * step0->AD &&
+                 step0->next_rep_bstride == (int64_t)step0->A * step0->AD &&
+                 step0->ld_state == step0->S && step0->ld_next_state == step0->S &&
+                 step0->ld_xq == step0->S + step0->AD,
+             PA_ERR_INVALID, "pa_dsac_learn: workspace rows are dense");
+  pa_dsac_step_args a = *step0;
+  const int B = a.B, G = lp->gather_rounds > 1 ? lp->gather_rounds : 1;
+  const int64_t AAD = (int64_t)a.A * a.AD;
+  for (int r = 0; r < lp->rounds; ++r) {
+    const int slot = r % G;
+    if (slot == 0) {
+      const int n = lp->rounds - r < G ? lp->rounds - r : G;
+      PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * B, n * B, &lp->batch, stream));
+    }
+    const int64_t row0 = (int64_t)slot * B;
+    a.state = step0->state + row0 * a.S;
+    a.next_state = step0->next_state + row0 * a.S;
+    a.xq = step0->xq + row0 * (a.S + a.AD);
+    a.reward = step0->reward + row0;
+    a.terminated = step0->terminated + row0;
+    a.curr_rep = step0->curr_rep + row0 * AAD;
+    a.next_rep = step0->next_rep + row0 * AAD;
+    a.curr_mask = step0->curr_mask ? step0->curr_mask + row0 * a.A : nullptr;
+    a.next_mask = step0->next_mask ? step0->next_mask + row0 * a.A : nullptr;
+    a.actor_step = step0->actor_step + r;
+    a.critic_step = step0->critic_step + r;
+    a.alpha_step = step0->alpha_step + r;
+    a.losses = lp->losses + (int64_t)r * lp->losses_stride;
+    PA_TRY(pa_dsac_step(&a, stream));
+  }
+  return PA_OK;
+}

@@ -18,6 +18,8 @@ entropy step ``pa_sac_alpha_step``.  No CPU path.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -269,7 +271,209 @@ class SoftActorCritic(ActorCriticBase):
         _, c1, c2 = self._nets(validate=False)
         self._twin_target_update(c1, c2)
 
+    # ------------------------------------------------------------------ one-call step
+    def _one_call_ok(self, actor: FlatMlp, c1: FlatMlp, c2: FlatMlp) -> bool:
+        """pa_dsac_step sequences the whole learn_batch in C.  It is the single-process step of
+        exactly this class on networks the fused row steps and the all-actions kernel take; a
+        data-parallel step all-reduces between backward and AdamW, and a subclass that overrides a
+        stage keeps the per-stage path."""
+        if os.environ.get("PEARL_AMD_DSAC_ONE_CALL", "1") == "0":
+            return False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        cls, base = type(self), SoftActorCritic
+        if not (cls._actor_update is base._actor_update and cls._critic_update is base._critic_update
+                and cls._update_critic_target is base._update_critic_target
+                and self._use_critic and self._use_critic_target and not self._use_actor_target):
+            return False
+        memo = self._flat.get("one_call_ok")
+        key = (actor.handle.value, c1.handle.value, c2.handle.value)
+        if memo is None or memo[0] != key:
+            A = actor.dims[-1]
+            ok = (bool(N.lib().pa_rowstep_supported(actor.handle, None, A))
+                  and FlatMlp.rowstep_supported(c1, c2) and c1.dims == c2.dims
+                  and c1.supports_q_all(A) and c2.supports_q_all(A))
+            memo = (key, ok)
+            self._flat["one_call_ok"] = memo
+        return memo[1]
+
+    def _one_call_ws(self, dev: torch.device, B: int, A: int) -> Dict[str, Any]:
+        ws = self._flat.get("one_call")
+        if ws is None or ws["key"] != (dev, B, A):
+            n = int(N.lib().pa_dsac_scratch_floats(B, A))
+            ws = {"key": (dev, B, A), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
+                  "args": N.DsacStepArgs()}
+            self._flat["one_call"] = ws
+        return ws
+
+    def _step_args(self, ws: Dict[str, Any], actor: FlatMlp, c1: FlatMlp, c2: FlatMlp, B: int, S: int,
+                   AD: int, losses: Tensor, h: Tensor) -> "N.DsacStepArgs":
+        """pa_dsac_step_args of the next step (batch pointers left to the caller); advances the
+        entropy optimizer's step count by one."""
+        dev = actor.device
+        al = self._alpha_state(dev)
+        a = ws["args"]
+        a.actor, a.critic1, a.critic2 = actor.handle.value, c1.handle.value, c2.handle.value
+        a.B, a.S, a.A, a.AD = B, S, actor.dims[-1], AD
+        a.gamma, a.tau = float(self._discount_factor), float(self._critic_soft_update_tau)
+        a.alpha = al["alpha"].data_ptr()
+        if self._entropy_autotune:
+            g = self._entropy_optimizer.param_groups[0]
+            al["step"] += 1
+            a.log_alpha = self._log_entropy.data.data_ptr()
+            a.alpha_m, a.alpha_v = al["exp_avg"].data_ptr(), al["exp_avg_sq"].data_ptr()
+            a.target_entropy = self._target_entropy_value()
+            a.alpha_lr, a.alpha_beta1, a.alpha_beta2 = g["lr"], g["betas"][0], g["betas"][1]
+            a.alpha_eps, a.alpha_weight_decay = g["eps"], g["weight_decay"]
+            a.alpha_step = al["step"]
+        else:
+            a.log_alpha = None
+        a.actor_step, a.critic_step = actor.next_adam_step(), c1.next_adam_step()
+        a.scratch, a.losses, a.h_out = ws["scratch"].data_ptr(), losses.data_ptr(), h.data_ptr()
+        return a
+
+    def _learn_batch_one_call(self, batch: TransitionBatch, actor: FlatMlp, c1: FlatMlp,
+                              c2: FlatMlp) -> Dict[str, Any]:
+        dev = actor.device
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        A = actor.dims[-1]
+        s = N.stream_ptr(dev)
+        assert batch.curr_available_actions is not None, "SoftActorCritic needs curr_available_actions"
+        assert batch.next_available_actions is not None, "SoftActorCritic needs next_available_actions"
+        rep = self._f32(batch.curr_available_actions, dev)
+        nrep = self._f32(batch.next_available_actions, dev)
+        assert rep.shape[-2] == A, "the actor outputs one logit per available-action slot"
+        act = self._f32(batch.action, dev).reshape(B, -1)
+        AD = act.shape[1]
+        xq = torch.empty(B, S + AD, dtype=torch.float32, device=dev)
+        N.check(N.lib().pa_concat_cols(state.data_ptr(), state.stride(0), act.data_ptr(),
+                                       act.stride(0), xq.data_ptr(), B, S, AD, s))
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = self._mask_u8(batch.terminated.reshape(B), dev)
+        mask = self._mask_u8(batch.curr_unavailable_actions_mask, dev)
+        nmask = self._mask_u8(batch.next_unavailable_actions_mask, dev)
+        ws = self._one_call_ws(dev, B, A)
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        h = torch.empty(B, dtype=torch.float32, device=dev)
+        a = self._step_args(ws, actor, c1, c2, B, S, AD, losses, h)
+        a.state, a.ld_state = state.data_ptr(), state.stride(0)
+        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a.xq, a.ld_xq = xq.data_ptr(), xq.stride(0)
+        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
+        a.curr_rep, a.curr_rep_bstride = rep.data_ptr(), (A * AD if rep.ndim == 3 else 0)
+        a.next_rep, a.next_rep_bstride = nrep.data_ptr(), (A * AD if nrep.ndim == 3 else 0)
+        a.curr_mask, a.next_mask = N.ptr(mask), N.ptr(nmask)
+        N.check(N.lib().pa_dsac_step(C.byref(a), s))
+        for m in (actor, c1, c2):
+            m.stepped_natively()
+        self._neg_entropy_rows = h
+        report = {"actor_loss": losses[0], "critic_loss": losses[1]}
+        if self._entropy_autotune:
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(
+                float(self._alpha_state(dev)["step"]))
+            report["entropy_coef"] = losses[2]
+        return report
+
+    def _learn_native_loop(self, replay_buffer: Any, batch_size: int) -> Optional[Dict[str, List[Any]]]:
+        """learn() as ONE pa_dsac_learn call: every round's gather + step sequenced in C.  The
+        rounds are the ones the per-round loop would run — same index lists, same kernels; one
+        gather launch per group of rounds writes the learner-side views directly (state || one-hot
+        action rows, the one-hot representation of both availability tables), so the per-round
+        one-hot and concat launches are gone as well.  None: this call takes the per-round loop."""
+        from ...action_representation_modules import OneHotActionTensorRepresentationModule
+        from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
+        from ..policy_learner import IdentityHistorySummarizationModule
+        if os.environ.get("PEARL_AMD_AC_LOOP", "1") == "0":
+            return None
+        cls, base = type(self), SoftActorCritic
+        rb = replay_buffer
+        if cls._learn_batch_device is not base._learn_batch_device \
+                or cls._learn_batch_one_call is not base._learn_batch_one_call \
+                or cls.preprocess_batch is not ActorCriticBase.preprocess_batch \
+                or cls._preprocess_for_learn is not ActorCriticBase._preprocess_for_learn \
+                or cls.learn_batch is not ActorCriticBase.learn_batch \
+                or not isinstance(rb, TensorBasedReplayBuffer) or rb.arena is None \
+                or type(rb).sample is not TensorBasedReplayBuffer.sample \
+                or type(rb)._gather_batch is not TensorBasedReplayBuffer._gather_batch:
+            return None
+        arm = self.action_representation_module
+        if type(arm) is not OneHotActionTensorRepresentationModule \
+                or type(self._history_summarization_module) is not IdentityHistorySummarizationModule \
+                or hasattr(getattr(self, "safety_module", None), "lambda_constraint"):
+            return None
+        actor, c1, c2 = self._nets(batch_size)
+        if not self._one_call_ok(actor, c1, c2):
+            return None
+        dev = actor.device
+        B, S, A = int(batch_size), actor.dims[0], actor.dims[-1]
+        AD = int(arm.max_number_actions)
+        rounds = int(self._training_rounds)
+        pre, z, arena = rb._presampled, rb._layout, rb.arena
+        if pre is None or pre[1] != 0 or tuple(pre[0].shape) != (rounds, B) or rounds <= 0 \
+                or arena.device != dev or rb._device_for_batches != dev \
+                or len(z.state_shape) > 1 or z.state_dim != S or not z.has_next_state or z.has_cost \
+                or z.action_elems != 1 or z.action_dtype.is_floating_point or z.avail_dim != 1 \
+                or z.max_actions != A or rb._is_action_continuous \
+                or not (rb._has_curr_avail and rb._has_next_avail) or c1.dims[0] != S + AD:
+            return None
+        row_bytes = 4 * (2 * S + (S + AD) + 1 + 2 * A * AD) + 1 + 2 * A
+        G = max(1, min(rounds, self._LOOP_GATHER_BYTES // (row_bytes * B), len(rb) // B))
+        ws = self._flat.get("loop_ws")
+        key = (dev, B, S, A, AD, G)
+        if ws is None or ws["key"] != key:
+            n = G * B
+
+            def new(shape, dtype=torch.float32):
+                return torch.empty(shape, dtype=dtype, device=dev)
+            ws = {"key": key, "state": new((n, S)), "next": new((n, S)), "x": new((n, S + AD)),
+                  "reward": new((n,)), "term": new((n,), torch.uint8),
+                  "cmask": new((n, A), torch.uint8), "nmask": new((n, A), torch.uint8),
+                  "crep": new((n, A, AD)), "nrep": new((n, A, AD))}
+            self._flat["loop_ws"] = ws
+        lp = N.AcLoopArgs()
+        o = lp.batch
+        o.state, o.next_state, o.x = ws["state"].data_ptr(), ws["next"].data_ptr(), ws["x"].data_ptr()
+        o.reward_f32, o.terminated = ws["reward"].data_ptr(), ws["term"].data_ptr()
+        o.curr_mask, o.next_mask = ws["cmask"].data_ptr(), ws["nmask"].data_ptr()
+        o.curr_avail_rep, o.next_avail_rep = ws["crep"].data_ptr(), ws["nrep"].data_ptr()
+        o.rep_dim, o.rep_onehot = AD, 1
+        losses = self._loop_losses(rounds, 3)
+        h = torch.empty(B, dtype=torch.float32, device=dev)
+        one = self._one_call_ws(dev, B, A)
+        a = self._step_args(one, actor, c1, c2, B, S, AD, losses, h)
+        a.state, a.ld_state, a.next_state, a.ld_next_state = o.state, S, o.next_state, S
+        a.xq, a.ld_xq = o.x, S + AD
+        a.reward, a.terminated = o.reward_f32, o.terminated
+        a.curr_rep, a.curr_rep_bstride, a.next_rep, a.next_rep_bstride = (
+            o.curr_avail_rep, A * AD, o.next_avail_rep, A * AD)
+        a.curr_mask, a.next_mask = o.curr_mask, o.next_mask
+        lp.rounds, lp.gather_rounds = rounds, G
+        lp.idx_lists = pre[0].data_ptr()
+        lp.losses, lp.losses_stride = losses.data_ptr(), 3
+        N.check(N.lib().pa_dsac_learn(C.byref(a), arena.handle, C.byref(lp), N.stream_ptr(dev)))
+        for m in (actor, c1, c2):
+            m.stepped_natively(rounds)
+        if self._entropy_autotune:
+            self._alpha_state(dev)["step"] += rounds - 1       # (_step_args counted the first)
+        self._training_steps += rounds
+        rb._presampled = (pre[0], rounds, len(rb))              # all consumed
+        rb._last_idx = pre[0][rounds - 1]
+        self._neg_entropy_rows = h
+        torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        got = [losses[:, k].tolist() for k in range(3)]
+        report: Dict[str, List[Any]] = {"actor_loss": got[0], "critic_loss": got[1]}
+        if self._entropy_autotune:
+            self._entropy_optimizer.state[self._log_entropy]["step"].fill_(
+                float(self._alpha_state(dev)["step"]))
+            report["entropy_coef"] = got[2]
+        return report
+
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
+        actor, c1, c2 = self._nets(len(batch))
+        if self._one_call_ok(actor, c1, c2):
+            return self._learn_batch_one_call(batch, actor, c1, c2)
         report = super()._learn_batch_device(batch)
         if self._entropy_autotune:
             actor, _, _ = self._nets(validate=False)

@@ -1282,6 +1282,75 @@ def test_discrete_sac_learn_from_replay():
     assert float(pl._entropy_coef) != alpha0
 
 
+@pytest.mark.parametrize("S,A,hidden,B,n,rounds,dynamic", [(10, 4, [32, 32], 32, 500, 7, True),
+                                                           (128, 16, [256, 256], 1024, 9000, 5, False)])
+def test_discrete_sac_one_call_and_native_loop_are_bitwise_the_per_stage_path(S, A, hidden, B, n, rounds,
+                                                                               dynamic, monkeypatch):
+    """SoftActorCritic three ways on the same device-sampled index lists: learn() as one
+    pa_dsac_learn call (grouped gathers writing the learner-side views, pa_dsac_step per round),
+    the per-round loop with pa_dsac_step per learn_batch (PEARL_AMD_AC_LOOP=0), and the per-stage
+    Python path (also PEARL_AMD_DSAC_ONE_CALL=0).  The same launches on the same rows: reports,
+    parameters, targets, entropy coefficient and optimizer state are bitwise equal.  `dynamic`:
+    rows with fewer available actions than slots (padded tables + masks)."""
+    from pearl_amd import (BasicReplayBuffer, DiscreteActionSpace, OneHotActionTensorRepresentationModule,
+                           PearlAgent, SoftActorCritic)
+    g = torch.Generator().manual_seed(8)
+    states = torch.randn(n + 1, S, generator=g)
+    ids = torch.arange(n)
+
+    def run(loop, one_call):
+        monkeypatch.setenv("PEARL_AMD_AC_LOOP", "1" if loop else "0")
+        monkeypatch.setenv("PEARL_AMD_DSAC_ONE_CALL", "1" if one_call else "0")
+        torch.manual_seed(0)
+        pl = SoftActorCritic(action_space=dspace(A), state_dim=S, actor_hidden_dims=hidden,
+                             critic_hidden_dims=hidden, batch_size=B, training_rounds=rounds,
+                             action_representation_module=OneHotActionTensorRepresentationModule(A))
+        rb = BasicReplayBuffer(n, sampler="device")
+        agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+        if dynamic:
+            small = DiscreteActionSpace([torch.tensor([k]) for k in range(A - 1)])
+            half = n // 2
+            for lo, hi, sp in ((0, half, dspace(A)), (half, n, small)):
+                rb.push_many(state=states[lo:hi].to(DEV), action=(ids[lo:hi] % (A - 1)).view(-1, 1).to(DEV),
+                             reward=(ids[lo:hi] % 5).float().to(DEV), terminated=(ids[lo:hi] % 40 == 0).to(DEV),
+                             truncated=torch.zeros(hi - lo, dtype=torch.bool, device=DEV),
+                             next_state=states[lo + 1:hi + 1].to(DEV), curr_available_actions=sp,
+                             next_available_actions=sp, max_number_actions=A)
+        else:
+            rb.push_many(state=states[:-1].to(DEV), action=(ids % A).view(-1, 1).to(DEV),
+                         reward=(ids % 5).float().to(DEV), terminated=(ids % 40 == 0).to(DEV),
+                         truncated=torch.zeros(n, dtype=torch.bool, device=DEV), next_state=states[1:].to(DEV),
+                         curr_available_actions=dspace(A), next_available_actions=dspace(A),
+                         max_number_actions=A)
+        reports = []
+        for call in range(2):
+            random.seed(50 + call)
+            reports.append(agent.learn())
+        return pl, rb, reports
+
+    ref_pl, ref_rb, ref_rep = run(False, False)
+    for loop, one_call in ((True, True), (False, True)):
+        pl, rb, rep = run(loop, one_call)
+        for x, y in zip(rep, ref_rep):
+            assert x.keys() == y.keys() == {"actor_loss", "critic_loss", "entropy_coef"}
+            for k in x:
+                assert len(x[k]) == rounds and x[k] == y[k], (loop, one_call, k)
+        for mod in ("_actor", "_critic", "_critic_target"):
+            for (k, va), (_, vb) in zip(getattr(pl, mod).state_dict().items(),
+                                        getattr(ref_pl, mod).state_dict().items()):
+                assert torch.equal(va, vb), (loop, one_call, f"{mod}.{k}")
+        assert torch.equal(pl._log_entropy.detach(), ref_pl._log_entropy.detach())
+        assert torch.equal(pl._entropy_coef, ref_pl._entropy_coef)
+        assert pl._training_steps == ref_pl._training_steps == 2 * rounds
+        assert torch.equal(rb.last_indices, ref_rb.last_indices)
+        for oa, ob in ((pl._actor_optimizer, ref_pl._actor_optimizer),
+                       (pl._critic_optimizer, ref_pl._critic_optimizer),
+                       (pl._entropy_optimizer, ref_pl._entropy_optimizer)):
+            for sa, sb in zip(oa.state.values(), ob.state.values()):
+                assert float(sa["step"]) == float(sb["step"]) == 2 * rounds
+                assert torch.equal(sa["exp_avg"], sb["exp_avg"])
+
+
 @pytest.mark.parametrize("S,AD,A,hidden,B,bcast", [(128, 16, 16, [256, 256], 300, False),
                                                    (5, 3, 3, [16, 12], 16, False),
                                                    (20, 7, 5, [100, 60], 33, True),

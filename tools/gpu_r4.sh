@@ -190,3 +190,25 @@ if [ "$MODE" == "slots" ]; then
     PEARL_AMD_DW_SLOTS=$sl timeout 300 python bench_algos.py --steps 300 --only ppo,bandit --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py
   done
 fi
+if [ "$MODE" == "hb2" ]; then
+  cd $R
+  for w in dsac iql ddqn td3; do TOPN=1 timeout 300 python tools/host_bound.py $w 200 2>&1 | grep "host enqueue"; done
+fi
+if [ "$MODE" == "dsacprof" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  for w in dsac; do
+    rm -rf $R/gpurun_out/prof_$w
+    timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0.2 > $R/gpurun_out/rocprof_$w.log 2>&1
+    DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+    python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+    head -24 $R/gpurun_out/${w}_kernel_stats.txt | cut -c1-150
+    python $R/tools/rocpd_timeline.py $DB dsac_actor 40 > $R/gpurun_out/${w}_timeline.txt 2>&1; sed -n 5,50p $R/gpurun_out/${w}_timeline.txt | cut -c1-150
+    rm -f $DB
+  done
+fi
+if [ "$MODE" == "dsac2" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py tests/test_gpu_replay.py -q -x -k "sac or gather or replay" 2>&1 | tail -8
+  timeout 300 python bench_algos.py --steps 300 --only dsac --cpu-seconds 0.2 2>$R/gpurun_out/bench_dsac2.err | tee $R/gpurun_out/bench_dsac2.jsonl | python tools/algo_line.py
+  PEARL_AMD_AC_LOOP=0 PEARL_AMD_DSAC_ONE_CALL=0 timeout 300 python bench_algos.py --steps 300 --only dsac --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py
+fi

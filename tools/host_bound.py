@@ -70,6 +70,58 @@ def make_ppo(steps):
     return lambda: ActorCriticBase.learn(pl, rb)     # learn() without the one-off rollout pass
 
 
+def _discrete_buffer(S, A, N):
+    from pearl_amd import BasicReplayBuffer, DiscreteActionSpace
+    sp = DiscreteActionSpace([torch.tensor([k]) for k in range(A)])
+    rb = BasicReplayBuffer(N, sampler="device")
+    return sp, rb
+
+
+def _fill_discrete(rb, sp, S, A, N):
+    st = torch.randn(N + 1, S, device=DEV)
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=sp, next_available_actions=sp,
+                 max_number_actions=A)
+
+
+def make_dsac(steps):
+    from pearl_amd import OneHotActionTensorRepresentationModule, PearlAgent, SoftActorCritic
+    S, A, B, N = 128, 16, 1024, 200_000
+    sp, rb = _discrete_buffer(S, A, N)
+    pl = SoftActorCritic(action_space=sp, state_dim=S, actor_hidden_dims=[256, 256],
+                         critic_hidden_dims=[256, 256], batch_size=B, training_rounds=steps,
+                         action_representation_module=OneHotActionTensorRepresentationModule(A))
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    _fill_discrete(rb, sp, S, A, N)
+    return lambda: pl.learn(rb)
+
+
+def make_ddqn(steps):
+    from pearl_amd import DoubleDQN, OneHotActionTensorRepresentationModule, PearlAgent
+    S, A, B, N = 128, 16, 1024, 200_000
+    sp, rb = _discrete_buffer(S, A, N)
+    pl = DoubleDQN(state_dim=S, action_space=sp, hidden_dims=[256, 256], training_rounds=steps,
+                   batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    _fill_discrete(rb, sp, S, A, N)
+    return lambda: pl.learn(rb)
+
+
+def make_iql(steps):
+    from pearl_amd import ImplicitQLearning, OneHotActionTensorRepresentationModule, PearlAgent
+    S, A, B, N = 128, 16, 1024, 200_000
+    sp, rb = _discrete_buffer(S, A, N)
+    pl = ImplicitQLearning(action_space=sp, state_dim=S, actor_hidden_dims=[256, 256],
+                           critic_hidden_dims=[256, 256], value_critic_hidden_dims=[256, 256],
+                           batch_size=B, training_rounds=steps,
+                           action_representation_module=OneHotActionTensorRepresentationModule(A))
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    _fill_discrete(rb, sp, S, A, N)
+    return lambda: pl.learn(rb)
+
+
 def make_bandit(steps):
     from pearl_amd import NeuralLinearBandit, TransitionBatch
     F, B = 512, 4096
@@ -91,9 +143,11 @@ def main():
         torch.set_num_threads(32)
     torch.manual_seed(0)
     random.seed(0)
-    learn = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3, "bandit": make_bandit}[which](steps)
+    makers = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3, "bandit": make_bandit,
+              "dsac": make_dsac, "ddqn": make_ddqn, "iql": make_iql}
+    learn = makers[which](steps)
     if "warm20" in sys.argv:          # a short warm-up instead of a full learn()
-        short = {"sac": make_sac, "ppo": make_ppo, "td3": make_td3, "bandit": make_bandit}[which](20)
+        short = makers[which](20)
         short()
     else:
         learn()
