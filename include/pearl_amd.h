@@ -603,6 +603,41 @@ int pa_dsac_step(const pa_dsac_step_args* args, void* stream);
 int pa_dsac_learn(const pa_dsac_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
                   void* stream);
 
+/* ImplicitQLearning.learn_batch as ONE call (implicit_q_learning.py:159-269): target critics at
+ * (s, a) -> V(s') -> V(s) -> expectile value head + advantage weights -> y = r + gamma V(s') -> twin
+ * critics' row step -> actor forward + policy-extraction head -> backward of value and actor ->
+ * AdamW of value, actor, critics (+ soft target update, tau >= 0).  The launches of the per-stage
+ * entry points above in the same order: bit-identical.  actor_kind 0: VanillaContinuousActorNetwork
+ * (tanh-squashed, pa_tanh_action / pa_awr_head(0) / pa_tanh_action_grad), 1: GaussianActorNetwork
+ * (pa_gauss_awr_head; the actor outputs 2A), 2: softmax actor (pa_awr_head(1)).  action [B][A]: the
+ * representation of the taken action; xq [B][S + A] = state || action or NULL (formed in scratch).
+ * pick_value / pick_actor (0 / 1): which target critic the value loss regresses to and which weighs
+ * the policy extraction — the reference's two host draws (:189-190, :205-206).  zeros: B + 1 device
+ * zeros.  losses [3]: value, critic, actor.  PA_ERR_UNSUPPORTED when the critics are outside the
+ * fused row step's shapes. */
+typedef struct pa_iql_step_args {
+  pa_mlp* actor; pa_mlp* value; pa_mlp* critic1; pa_mlp* critic2;
+  int32_t B, S, A, actor_kind;
+  const float* state; int32_t ld_state;
+  const float* next_state; int32_t ld_next_state;
+  const float* action; int32_t ld_action;
+  const float* xq; int32_t ld_xq;
+  const float* reward; const uint8_t* terminated;
+  const float* low; const float* high;
+  int32_t pick_value, pick_actor;
+  float expectile, temperature, adv_clamp, gamma, tau;
+  int64_t actor_step, value_step, critic_step;
+  const float* zeros;
+  float* scratch;                       /* pa_iql_scratch_floats(B, S, A, actor output width) */
+  float* losses;
+} pa_iql_step_args;
+int64_t pa_iql_scratch_floats(int32_t B, int32_t S, int32_t A, int32_t head_width);
+int pa_iql_step(const pa_iql_step_args* args, void* stream);
+/* ImplicitQLearning.learn's rounds as one call: grouped gathers (state, next_state, x, reward_f32,
+ * terminated of loop->batch; action = x + S), pa_iql_step per round; picks: host int32 [rounds][2]. */
+int pa_iql_learn(const pa_iql_step_args* step0, pa_arena* arena, const pa_ac_loop_args* loop,
+                 const int32_t* picks, void* stream);
+
 /* ProximalPolicyOptimization.learn's training rounds as ONE call (policy_learner.py:190-231 around
  * ppo.py:152-192; after preprocess_replay_buffer).  Per group of gather_rounds rounds: one arena
  * gather of x = state || one-hot(action) rows and one pa_gather_planes of the three per-transition

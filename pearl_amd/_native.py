@@ -216,6 +216,24 @@ class DsacStepArgs(C.Structure):
     ]
 
 
+class IqlStepArgs(C.Structure):
+    _fields_ = [
+        ("actor", C.c_void_p), ("value", C.c_void_p), ("critic1", C.c_void_p), ("critic2", C.c_void_p),
+        ("B", C.c_int32), ("S", C.c_int32), ("A", C.c_int32), ("actor_kind", C.c_int32),
+        ("state", C.c_void_p), ("ld_state", C.c_int32),
+        ("next_state", C.c_void_p), ("ld_next_state", C.c_int32),
+        ("action", C.c_void_p), ("ld_action", C.c_int32),
+        ("xq", C.c_void_p), ("ld_xq", C.c_int32),
+        ("reward", C.c_void_p), ("terminated", C.c_void_p),
+        ("low", C.c_void_p), ("high", C.c_void_p),
+        ("pick_value", C.c_int32), ("pick_actor", C.c_int32),
+        ("expectile", C.c_float), ("temperature", C.c_float), ("adv_clamp", C.c_float),
+        ("gamma", C.c_float), ("tau", C.c_float),
+        ("actor_step", C.c_int64), ("value_step", C.c_int64), ("critic_step", C.c_int64),
+        ("zeros", C.c_void_p), ("scratch", C.c_void_p), ("losses", C.c_void_p),
+    ]
+
+
 class PpoLearnArgs(C.Structure):
     _fields_ = [
         ("actor", C.c_void_p), ("critic", C.c_void_p),
@@ -514,6 +532,9 @@ SIGNATURES = {
     "pa_linreg_apply2": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P, _P]),
     "pa_bandit_step": (C.c_int, [_P, _P]),
     "pa_ppo_learn": (C.c_int, [_P, _P, _P]),
+    "pa_iql_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pa_iql_step": (C.c_int, [_P, _P]),
+    "pa_iql_learn": (C.c_int, [_P, _P, _P, _P, _P]),
     "pa_dsac_scratch_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "pa_dsac_step": (C.c_int, [_P, _P]),
     "pa_dsac_learn": (C.c_int, [_P, _P, _P, _P]),

@@ -1106,3 +1106,136 @@ extern "C" int pa_dsac_learn(const pa_dsac_step_args* step0, pa_arena* arena, co
   }
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// ImplicitQLearning.learn_batch as ONE call (implicit_q_learning.py:159-269): the launches of the
+// per-stage Python path in its order — target critics at (s, a), V(s'), V(s) (kept), the expectile
+// value head + advantage weights, y = r + gamma V(s'), the twin critics' row step, the actor's
+// forward and policy-extraction head (tanh-squashed / Gaussian / softmax), the two backward passes,
+// then the optimizer steps in the reference's order (value, actor, critics + soft target update).
+// Bit-identical to that path; the two host draws that pick the target critic of the value loss and
+// of the advantage weights stay with the caller (pick_value, pick_actor).
+extern "C" int64_t pa_iql_scratch_floats(int32_t B, int32_t S, int32_t A, int32_t head_width) {
+  return (int64_t)B * (S + A) + 10ll * B + 2ll * B * head_width + 2ll * B * A;
+}
+
+extern "C" int pa_iql_step(const pa_iql_step_args* g, void* stream) {
+  PA_REQUIRE(g && g->actor && g->value && g->critic1 && g->critic2 && g->state && g->next_state &&
+                 g->action && g->reward && g->terminated && g->zeros && g->scratch && g->losses,
+             PA_ERR_INVALID, "pa_iql_step: null argument");
+  PA_REQUIRE(g->B > 0 && g->S > 0 && g->A > 0 && g->actor_kind >= 0 && g->actor_kind <= 2 &&
+                 (g->pick_value | g->pick_actor) >= 0 && g->pick_value <= 1 && g->pick_actor <= 1 &&
+                 g->actor_step >= 1 && g->value_step >= 1 && g->critic_step >= 1,
+             PA_ERR_INVALID, "pa_iql_step: bad sizes / picks / steps");
+  PA_REQUIRE(g->actor_kind == 2 || (g->low && g->high), PA_ERR_INVALID,
+             "pa_iql_step: continuous actors need the action bounds");
+  const int B = g->B, S = g->S, A = g->A;
+  const int HW = g->actor->d.dims[g->actor->L];
+  PA_REQUIRE(HW == (g->actor_kind == 1 ? 2 * A : A), PA_ERR_INVALID,
+             "pa_iql_step: the actor's output width does not fit its kind");
+  PA_REQUIRE(pa_rowstep_supported(g->critic1, g->critic2, 0), PA_ERR_UNSUPPORTED,
+             "pa_iql_step: the critics are outside the fused row step's shapes");
+  float* p = g->scratch;
+  float* xq_own = p; p += (int64_t)B * (S + A);
+  float* tq[2]; tq[0] = p; p += B; tq[1] = p; p += B;
+  float* vn = p; p += B;
+  float* v = p; p += B;
+  float* dv = p; p += B;
+  float* adv = p; p += B;
+  float* y = p; p += B;
+  float* dq1 = p; p += B;
+  float* dq2 = p; p += B;
+  float* logp = p; p += B;
+  float* head = p; p += (int64_t)B * HW;
+  float* d_head = p; p += (int64_t)B * HW;
+  float* pred = p; p += (int64_t)B * A;
+  float* d_pred = p;
+  const float* xq = g->xq;
+  int ld_xq = g->ld_xq;
+  if (!xq) {
+    PA_TRY(pa_concat_cols(g->state, g->ld_state, g->action, g->ld_action, xq_own, B, S, A, stream));
+    xq = xq_own;
+    ld_xq = S + A;
+  }
+  PA_TRY(pa_mlp_forward2(g->critic1, g->critic2, 1, xq, ld_xq, B, tq[0], 1, tq[1], 1, 0, stream));
+  // V(s') first: the engine keeps ONE forward's activations per network for the backward pass
+  PA_TRY(pa_mlp_forward(g->value, 0, g->next_state, g->ld_next_state, B, vn, 1, 0, stream));
+  PA_TRY(pa_mlp_forward(g->value, 0, g->state, g->ld_state, B, v, 1, 1, stream));
+  PA_TRY(pa_iql_value_head(tq[g->pick_value], tq[g->pick_actor], v, 1, g->expectile, g->temperature,
+                           g->adv_clamp, B, dv, adv, g->losses + 0, stream));
+  // y = V(s') gamma (1 - term) + r: pa_sac_twin(mode 1) with q1 = q2 = V(s'), alpha = 0
+  PA_TRY(pa_sac_twin(1, vn, vn, g->zeros, g->zeros + B, g->reward, g->terminated, g->gamma, B, y,
+                     nullptr, nullptr, stream));
+  PA_TRY(pa_mse_rowstep2(g->critic1, g->critic2, xq, ld_xq, B, y, 1.0f / (float)B, 0.5f, nullptr,
+                         nullptr, dq1, dq2, g->losses + 1, stream));
+  PA_TRY(pa_mlp_forward(g->actor, 0, g->state, g->ld_state, B, head, HW, 1, stream));
+  if (g->actor_kind == 0) {
+    PA_TRY(pa_tanh_action(head, HW, nullptr, 0, g->low, g->high, 0.0f, B, A, pred, A, stream));
+    PA_TRY(pa_awr_head(0, pred, A, g->action, g->ld_action, adv, B, A, d_pred, A, g->losses + 2, stream));
+    PA_TRY(pa_tanh_action_grad(head, HW, g->low, g->high, d_pred, A, B, A, d_head, HW, stream));
+  } else if (g->actor_kind == 1) {
+    PA_TRY(pa_gauss_awr_head(head, HW, g->action, g->ld_action, g->low, g->high, adv, B, A, d_head, HW,
+                             logp, g->losses + 2, stream));
+  } else {
+    PA_TRY(pa_awr_head(1, head, HW, g->action, g->ld_action, adv, B, A, d_head, HW, g->losses + 2, stream));
+  }
+  // one backward each (weight gradients deferred to the optimizer launches), then the steps in the
+  // reference's order (:171-176) and the critics' soft target update
+  PA_TRY(pa_mlp_backward(g->value, g->state, g->ld_state, B, dv, 1, 2, nullptr, 0, stream));
+  PA_TRY(pa_mlp_backward(g->actor, g->state, g->ld_state, B, d_head, HW, 2, nullptr, 0, stream));
+  PA_TRY(pa_mlp_adam(g->value, g->value_step, stream));
+  PA_TRY(pa_mlp_adam(g->actor, g->actor_step, stream));
+  if (mlp_pair_fusable(g->critic1, g->critic2, g->tau >= 0.f)) {
+    PA_TRY(pa_mlp_adam2(g->critic1, g->critic2, g->critic_step, g->tau, stream));
+  } else {
+    PA_TRY(pa_mlp_adam(g->critic1, g->critic_step, stream));
+    PA_TRY(pa_mlp_adam(g->critic2, g->critic_step, stream));
+    if (g->tau >= 0.f) {
+      PA_TRY(pa_mlp_soft_update(g->critic1, g->tau, stream));
+      PA_TRY(pa_mlp_soft_update(g->critic2, g->tau, stream));
+    }
+  }
+  return PA_OK;
+}
+
+// ImplicitQLearning.learn's rounds in one call: per group of gather_rounds rounds one gather launch
+// (state, next_state, x = state || rep(action), float reward, terminated), then pa_iql_step per
+// round on consecutive slices; picks [rounds][2] (host): the caller's draws, value loss first.
+extern "C" int pa_iql_learn(const pa_iql_step_args* step0, pa_arena* arena, const pa_ac_loop_args* lp,
+                            const int32_t* picks, void* stream) {
+  PA_REQUIRE(step0 && lp && arena && picks && lp->idx_lists && lp->losses && lp->losses_stride >= 3 &&
+                 lp->rounds >= 0,
+             PA_ERR_INVALID, "pa_iql_learn: bad loop arguments");
+  const pa_batch_out& o = lp->batch;
+  PA_REQUIRE(o.state == step0->state && o.next_state == step0->next_state && o.x && o.x == step0->xq &&
+                 o.reward_f32 == step0->reward && o.terminated == step0->terminated &&
+                 o.rep_dim == step0->A && step0->action == step0->xq + step0->S,
+             PA_ERR_INVALID, "pa_iql_learn: the step reads the loop's batch workspace");
+  PA_REQUIRE(step0->ld_state == step0->S && step0->ld_next_state == step0->S &&
+                 step0->ld_xq == step0->S + step0->A && step0->ld_action == step0->S + step0->A,
+             PA_ERR_INVALID, "pa_iql_learn: workspace rows are dense");
+  pa_iql_step_args a = *step0;
+  const int B = a.B, G = lp->gather_rounds > 1 ? lp->gather_rounds : 1;
+  for (int r = 0; r < lp->rounds; ++r) {
+    const int slot = r % G;
+    if (slot == 0) {
+      const int n = lp->rounds - r < G ? lp->rounds - r : G;
+      PA_TRY(pa_arena_gather_device(arena, lp->idx_lists + (int64_t)r * B, n * B, &lp->batch, stream));
+    }
+    const int64_t row0 = (int64_t)slot * B;
+    a.state = step0->state + row0 * a.S;
+    a.next_state = step0->next_state + row0 * a.S;
+    a.xq = step0->xq + row0 * (a.S + a.A);
+    a.action = a.xq + a.S;
+    a.reward = step0->reward + row0;
+    a.terminated = step0->terminated + row0;
+    a.pick_value = picks[2 * r];
+    a.pick_actor = picks[2 * r + 1];
+    a.actor_step = step0->actor_step + r;
+    a.value_step = step0->value_step + r;
+    a.critic_step = step0->critic_step + r;
+    a.losses = lp->losses + (int64_t)r * lp->losses_stride;
+    PA_TRY(pa_iql_step(&a, stream));
+  }
+  return PA_OK;
+}

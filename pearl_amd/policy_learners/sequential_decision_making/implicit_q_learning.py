@@ -19,9 +19,12 @@ with HIP heads: ``VanillaContinuousActorNetwork`` (weighted MSE on the action) a
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 from torch import Tensor, nn, optim
 
 from ... import _native as N
@@ -132,9 +135,175 @@ class ImplicitQLearning(ActorCriticBase):
     def _f32(t: Tensor, dev: torch.device) -> Tensor:
         return t.to(device=dev, dtype=torch.float32).contiguous()
 
+    # ------------------------------------------------------------------ one-call step
+    def _actor_kind(self) -> int:
+        """pa_iql_step's actor_kind: 0 tanh-squashed deterministic, 1 Gaussian, 2 softmax."""
+        if isinstance(self._actor, VanillaContinuousActorNetwork):
+            return 0
+        return 1 if isinstance(self._actor, GaussianActorNetwork) else 2
+
+    def _one_call_ok(self, c1: FlatMlp, c2: FlatMlp) -> bool:
+        """pa_iql_step sequences the whole learn_batch in C: the single-process step on critics the
+        fused row step takes (PEARL_AMD_IQL_ONE_CALL=0: the per-stage path)."""
+        if os.environ.get("PEARL_AMD_IQL_ONE_CALL", "1") == "0":
+            return False
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        memo = self._flat.get("one_call_ok")
+        key = (c1.handle.value, c2.handle.value)
+        if memo is None or memo[0] != key:
+            memo = (key, FlatMlp.rowstep_supported(c1, c2))
+            self._flat["one_call_ok"] = memo
+        return memo[1]
+
+    def _step_args(self, nets, B: int, S: int, A: int, losses: Tensor) -> "N.IqlStepArgs":
+        """pa_iql_step_args of the next step (batch pointers and the two picks left to the caller)."""
+        actor, value, c1, c2 = nets
+        dev = actor.device
+        HW = actor.dims[-1]
+        ws = self._flat.get("one_call")
+        if ws is None or ws["key"] != (dev, B, S, A, HW):
+            n = int(N.lib().pa_iql_scratch_floats(B, S, A, HW))
+            ws = {"key": (dev, B, S, A, HW), "scratch": torch.empty(n, dtype=torch.float32, device=dev),
+                  "zeros": torch.zeros(B + 1, dtype=torch.float32, device=dev),
+                  "args": N.IqlStepArgs()}
+            self._flat["one_call"] = ws
+        a = ws["args"]
+        a.actor, a.value = actor.handle.value, value.handle.value
+        a.critic1, a.critic2 = c1.handle.value, c2.handle.value
+        a.B, a.S, a.A, a.actor_kind = B, S, A, self._actor_kind()
+        if a.actor_kind != 2:
+            low, high = self._bounds(dev)
+            a.low, a.high = low.data_ptr(), high.data_ptr()
+        else:
+            a.low = a.high = None
+        a.expectile = float(self._expectile)
+        a.temperature = float(self._temperature_advantage_weighted_regression)
+        a.adv_clamp, a.gamma = float(self._advantage_clamp), float(self._discount_factor)
+        a.tau = float(self._critic_soft_update_tau)
+        a.actor_step, a.value_step = actor.next_adam_step(), value.next_adam_step()
+        a.critic_step = c1.next_adam_step()
+        a.zeros, a.scratch, a.losses = ws["zeros"].data_ptr(), ws["scratch"].data_ptr(), losses.data_ptr()
+        return a
+
+    def _learn_batch_one_call(self, batch: TransitionBatch, nets) -> Dict[str, Any]:
+        actor = nets[0]
+        dev = actor.device
+        state = self._f32(batch.state, dev)
+        nstate = self._f32(batch.next_state, dev)
+        B, S = state.shape
+        act = self._f32(batch.action, dev).reshape(B, -1)
+        A = act.shape[1]
+        # the reference's own two host draws, value loss first (:189-190, :205-206)
+        pick_value = int(torch.randint(0, 2, (1,)).item())
+        pick_actor = int(torch.randint(0, 2, (1,)).item())
+        reward = self._f32(batch.reward, dev).reshape(B)
+        term = batch.terminated.to(dev).reshape(B).to(torch.uint8).contiguous()
+        losses = torch.empty(3, dtype=torch.float32, device=dev)    # value | critic | actor
+        a = self._step_args(nets, B, S, A, losses)
+        a.state, a.ld_state = state.data_ptr(), state.stride(0)
+        a.next_state, a.ld_next_state = nstate.data_ptr(), nstate.stride(0)
+        a.action, a.ld_action = act.data_ptr(), act.stride(0)
+        a.xq, a.ld_xq = None, 0
+        a.reward, a.terminated = reward.data_ptr(), term.data_ptr()
+        a.pick_value, a.pick_actor = pick_value, pick_actor
+        N.check(N.lib().pa_iql_step(C.byref(a), N.stream_ptr(dev)))
+        for m in nets:
+            m.stepped_natively()
+        return {"value_loss": losses[0], "actor_loss": losses[2], "critic_loss": losses[1]}
+
+    def _learn_native_loop(self, replay_buffer: Any, batch_size: int) -> Optional[Dict[str, List[Any]]]:
+        """learn() as ONE pa_iql_learn call: every round's gather + step sequenced in C (the
+        per-round loop spends 234 us of interpreter time per ~165 us of device work).  The rounds
+        the per-round loop would run — same index lists, same kernels, the same host draws in the
+        same order.  None: this call takes the per-round loop."""
+        from ...action_representation_modules import OneHotActionTensorRepresentationModule
+        from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
+        from ..policy_learner import IdentityHistorySummarizationModule
+        if os.environ.get("PEARL_AMD_AC_LOOP", "1") == "0":
+            return None
+        cls, base = type(self), ImplicitQLearning
+        rb = replay_buffer
+        if cls._learn_batch_device is not base._learn_batch_device \
+                or cls._learn_batch_one_call is not base._learn_batch_one_call \
+                or cls.preprocess_batch is not ActorCriticBase.preprocess_batch \
+                or cls._preprocess_for_learn is not ActorCriticBase._preprocess_for_learn \
+                or cls.learn_batch is not ActorCriticBase.learn_batch \
+                or not isinstance(rb, TensorBasedReplayBuffer) or rb.arena is None \
+                or type(rb).sample is not TensorBasedReplayBuffer.sample \
+                or type(rb)._gather_batch is not TensorBasedReplayBuffer._gather_batch \
+                or type(self._history_summarization_module) is not IdentityHistorySummarizationModule \
+                or hasattr(getattr(self, "safety_module", None), "lambda_constraint"):
+            return None
+        nets = self._nets(batch_size)
+        actor, value, c1, c2 = nets
+        if not self._one_call_ok(c1, c2):
+            return None
+        dev = actor.device
+        B, S = int(batch_size), actor.dims[0]
+        A = c1.dims[0] - S                     # width of the action representation
+        arm = self.action_representation_module
+        rounds = int(self._training_rounds)
+        pre, z, arena = rb._presampled, rb._layout, rb.arena
+        if pre is None or pre[1] != 0 or tuple(pre[0].shape) != (rounds, B) or rounds <= 0 \
+                or arena.device != dev or rb._device_for_batches != dev or A <= 0 \
+                or len(z.state_shape) > 1 or z.state_dim != S or not z.has_next_state or z.has_cost:
+            return None
+        if type(arm) is OneHotActionTensorRepresentationModule:
+            if z.action_elems != 1 or z.action_dtype.is_floating_point or arm.max_number_actions != A:
+                return None
+            onehot = 1
+        elif type(arm).__name__ == "IdentityActionRepresentationModule":
+            if z.action_elems != A or z.action_dtype != torch.float32:
+                return None
+            onehot = 0
+        else:
+            return None
+        G = max(1, min(rounds, self._LOOP_GATHER_BYTES // ((4 * (3 * S + A + 1) + 1) * B), len(rb) // B))
+        ws = self._flat.get("loop_ws")
+        key = (dev, B, S, A, G)
+        if ws is None or ws["key"] != key:
+            n = G * B
+
+            def new(shape, dtype=torch.float32):
+                return torch.empty(shape, dtype=dtype, device=dev)
+            ws = {"key": key, "state": new((n, S)), "next": new((n, S)), "x": new((n, S + A)),
+                  "reward": new((n,)), "term": new((n,), torch.uint8)}
+            self._flat["loop_ws"] = ws
+        lp = N.AcLoopArgs()
+        o = lp.batch
+        o.state, o.next_state, o.x = ws["state"].data_ptr(), ws["next"].data_ptr(), ws["x"].data_ptr()
+        o.reward_f32, o.terminated = ws["reward"].data_ptr(), ws["term"].data_ptr()
+        o.rep_dim, o.rep_onehot = A, onehot
+        losses = self._loop_losses(rounds, 3)
+        a = self._step_args(nets, B, S, A, losses)
+        a.state, a.ld_state, a.next_state, a.ld_next_state = o.state, S, o.next_state, S
+        a.xq, a.ld_xq = o.x, S + A
+        a.action, a.ld_action = o.x + 4 * S, S + A
+        a.reward, a.terminated = o.reward_f32, o.terminated
+        # the two draws of every round, in the per-round loop's order
+        picks = (C.c_int32 * (2 * rounds))()
+        for r in range(2 * rounds):
+            picks[r] = int(torch.randint(0, 2, (1,)).item())
+        lp.rounds, lp.gather_rounds = rounds, G
+        lp.idx_lists = pre[0].data_ptr()
+        lp.losses, lp.losses_stride = losses.data_ptr(), 3
+        N.check(N.lib().pa_iql_learn(C.byref(a), arena.handle, C.byref(lp), picks, N.stream_ptr(dev)))
+        for m in nets:
+            m.stepped_natively(rounds)
+        self._training_steps += rounds
+        rb._presampled = (pre[0], rounds, len(rb))              # all consumed
+        rb._last_idx = pre[0][rounds - 1]
+        torch.cuda.current_stream(dev).synchronize()           # the single host sync of this call
+        got = [losses[:, k].tolist() for k in range(3)]
+        return {"value_loss": got[0], "actor_loss": got[2], "critic_loss": got[1]}
+
     # ------------------------------------------------------------------ learn_batch (:159-184)
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
-        actor, value, c1, c2 = self._nets(len(batch))
+        nets = self._nets(len(batch))
+        actor, value, c1, c2 = nets
+        if self._one_call_ok(c1, c2):
+            return self._learn_batch_one_call(batch, nets)
         dev = actor.device
         lib, s = N.lib(), N.stream_ptr(dev)
         state = self._f32(batch.state, dev)

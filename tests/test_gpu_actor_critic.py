@@ -1427,6 +1427,77 @@ def make_iql(fx):
     return pl
 
 
+@pytest.mark.parametrize("kind,S,A,hidden,B,n,rounds", [("softmax", 12, 5, [32, 32], 48, 600, 6),
+                                                         ("tanh", 17, 3, [64, 32], 64, 700, 5),
+                                                         ("gaussian", 17, 3, [64, 32], 64, 700, 5),
+                                                         ("softmax", 128, 16, [256, 256], 1024, 9000, 4)])
+def test_iql_one_call_and_native_loop_are_bitwise_the_per_stage_path(kind, S, A, hidden, B, n, rounds,
+                                                                      monkeypatch):
+    """ImplicitQLearning three ways on the same device-sampled index lists and the same host draws
+    (torch seeded per learn() call): learn() as one pa_iql_learn call, the per-round loop with
+    pa_iql_step per learn_batch (PEARL_AMD_AC_LOOP=0), and the per-stage Python path (also
+    PEARL_AMD_IQL_ONE_CALL=0) — for the softmax, tanh-squashed and Gaussian actors.  Reports,
+    every network, the critic targets and the optimizer state are bitwise equal."""
+    from pearl_amd import (BasicReplayBuffer, BoxActionSpace, ImplicitQLearning,
+                           OneHotActionTensorRepresentationModule, PearlAgent)
+    from pearl_amd.neural_networks.sequential_decision_making.actor_networks import (
+        GaussianActorNetwork, VanillaActorNetwork, VanillaContinuousActorNetwork)
+    g = torch.Generator().manual_seed(9)
+    states = torch.randn(n + 1, S, generator=g)
+    cont_actions = torch.rand(n, A, generator=g) * 2 - 1
+    ids = torch.arange(n)
+
+    def run(loop, one_call):
+        monkeypatch.setenv("PEARL_AMD_AC_LOOP", "1" if loop else "0")
+        monkeypatch.setenv("PEARL_AMD_IQL_ONE_CALL", "1" if one_call else "0")
+        torch.manual_seed(0)
+        kw = dict(state_dim=S, actor_hidden_dims=hidden, critic_hidden_dims=hidden,
+                  value_critic_hidden_dims=hidden, batch_size=B, training_rounds=rounds, expectile=0.7)
+        if kind == "softmax":
+            pl = ImplicitQLearning(action_space=dspace(A), actor_network_type=VanillaActorNetwork,
+                                   action_representation_module=OneHotActionTensorRepresentationModule(A), **kw)
+        else:
+            pl = ImplicitQLearning(action_space=BoxActionSpace(-torch.ones(A), torch.ones(A)),
+                                   actor_network_type=(GaussianActorNetwork if kind == "gaussian"
+                                                       else VanillaContinuousActorNetwork), **kw)
+        rb = BasicReplayBuffer(n, sampler="device")
+        agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+        common = dict(state=states[:-1].to(DEV), reward=(ids % 5).float().to(DEV),
+                      terminated=(ids % 40 == 0).to(DEV),
+                      truncated=torch.zeros(n, dtype=torch.bool, device=DEV), next_state=states[1:].to(DEV))
+        if kind == "softmax":
+            rb.push_many(action=(ids % A).view(-1, 1).to(DEV), curr_available_actions=dspace(A),
+                         next_available_actions=dspace(A), max_number_actions=A, **common)
+        else:
+            rb.push_many(action=cont_actions.to(DEV), **common)
+        reports = []
+        for call in range(2):
+            random.seed(60 + call)
+            torch.manual_seed(70 + call)
+            reports.append(agent.learn())
+        return pl, rb, reports
+
+    ref_pl, ref_rb, ref_rep = run(False, False)
+    for loop, one_call in ((True, True), (False, True)):
+        pl, rb, rep = run(loop, one_call)
+        for x, y in zip(rep, ref_rep):
+            assert x.keys() == y.keys() == {"value_loss", "actor_loss", "critic_loss"}
+            for k in x:
+                assert len(x[k]) == rounds and x[k] == y[k], (loop, one_call, k)
+        for mod in ("_actor", "_value_network", "_critic", "_critic_target"):
+            for (k, va), (_, vb) in zip(getattr(pl, mod).state_dict().items(),
+                                        getattr(ref_pl, mod).state_dict().items()):
+                assert torch.equal(va, vb), (loop, one_call, f"{mod}.{k}")
+        assert pl._training_steps == ref_pl._training_steps == 2 * rounds
+        assert torch.equal(rb.last_indices, ref_rb.last_indices)
+        for oa, ob in ((pl._actor_optimizer, ref_pl._actor_optimizer),
+                       (pl._value_network_optimizer, ref_pl._value_network_optimizer),
+                       (pl._critic_optimizer, ref_pl._critic_optimizer)):
+            for sa, sb in zip(oa.state.values(), ob.state.values()):
+                assert float(sa["step"]) == float(sb["step"]) == 2 * rounds
+                assert torch.equal(sa["exp_avg"], sb["exp_avg"])
+
+
 @pytest.mark.parametrize("name", IQL)
 def test_iql_learn_batch_trajectory(name):
     """ImplicitQLearning.learn_batch against the reference run: value / actor / critic losses per

@@ -212,3 +212,8 @@ if [ "$MODE" == "dsac2" ]; then
   timeout 300 python bench_algos.py --steps 300 --only dsac --cpu-seconds 0.2 2>$R/gpurun_out/bench_dsac2.err | tee $R/gpurun_out/bench_dsac2.jsonl | python tools/algo_line.py
   PEARL_AMD_AC_LOOP=0 PEARL_AMD_DSAC_ONE_CALL=0 timeout 300 python bench_algos.py --steps 300 --only dsac --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py
 fi
+if [ "$MODE" == "iql2" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "iql" 2>&1 | tail -8
+  for w in iql; do TOPN=1 timeout 300 python tools/host_bound.py $w 200 2>&1 | grep "host enqueue"; PEARL_AMD_AC_LOOP=0 PEARL_AMD_IQL_ONE_CALL=0 TOPN=1 timeout 300 python tools/host_bound.py $w 200 2>&1 | grep "host enqueue"; done
+fi
