@@ -13,7 +13,7 @@ if [ "$SKIP_STRESS" != "1" ]; then
 PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 300 python tools/stress_ppo.py 8 > gpurun_out/nocache_stress.txt 2>&1
 echo "stress rc=$?"; tail -2 gpurun_out/nocache_stress.txt
 PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider \
-  -k "rowstep or weight_grad or bandit_learn_batch or ppo_learn_trajectory or p2p_exchange_sums" > gpurun_out/nocache_tests.txt 2>&1
+  -k "rowstep or weight_grad or bandit_learn_batch or ppo_learn_trajectory or p2p_exchange_sums or one_call or native_learn_loop or two_solves" > gpurun_out/nocache_tests.txt 2>&1
 echo "stress tests rc=$?"; tail -2 gpurun_out/nocache_tests.txt
 fi
 if [ "$SKIP_TESTS" != "1" ]; then
@@ -52,7 +52,7 @@ PEARL_AMD_FORCE_DP=1 timeout 300 python -m torch.distributed.run --nnodes=1 --np
   > gpurun_out/ppo_dp1.jsonl 2> gpurun_out/ppo_dp1.err
 echo "ppo dp1 rc=$?"; grep '^{' gpurun_out/ppo_dp1.jsonl | cut -c1-300
 cd /tmp && export TMPDIR=/tmp
-for w in sac ppo bandit; do
+for w in sac ppo bandit dsac; do
   rm -rf $R/gpurun_out/prof_$w
   timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0.5 > $R/gpurun_out/rocprof_$w.log 2>&1
   DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
