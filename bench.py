@@ -444,8 +444,10 @@ def main():
             # what the gradient exchange actually ran on: the rank count RCCL itself reports for the
             # communicator the learn loop's hooks used (ncclCommCount), not the one asked for
             comm = getattr(pl._native, "comm", None)
-            info = {"library": "rccl (native pa_comm_* hooks)" if comm is not None
-                    else "torch.distributed all_reduce hooks", "ranks_requested": world}
+            from pearl_amd import _comm
+            info = {"library": (_comm.comm_info().get("library", "rccl (native pa_comm_* hooks)")
+                                if comm is not None else "torch.distributed all_reduce hooks"),
+                    "ranks_requested": world}
             if comm is not None:
                 n_seen, me = C.c_int32(-1), C.c_int32(-1)
                 N.check(N.lib().pa_comm_info(comm, C.byref(n_seen), C.byref(me)))

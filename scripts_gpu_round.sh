@@ -12,7 +12,9 @@ cd $R
 if [ "$SKIP_STRESS" != "1" ]; then
 PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 300 python tools/stress_ppo.py 8 > gpurun_out/nocache_stress.txt 2>&1
 echo "stress rc=$?"; tail -2 gpurun_out/nocache_stress.txt
-PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider \
+# (not tests/test_gpu_dqn.py: the overlapped DQN loop hands data between two streams inside a call,
+#  which a serialized queue turns into an expired bounded wait — by construction, not a fault)
+PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 600 python -m pytest tests/test_gpu_actor_critic.py tests/test_gpu_kernels.py tests/test_gpu_dp.py -m gpu -q -x -p no:cacheprovider \
   -k "rowstep or weight_grad or bandit_learn_batch or ppo_learn_trajectory or p2p_exchange_sums or one_call or native_learn_loop or two_solves" > gpurun_out/nocache_tests.txt 2>&1
 echo "stress tests rc=$?"; tail -2 gpurun_out/nocache_tests.txt
 fi
