@@ -217,3 +217,13 @@ if [ "$MODE" == "iql2" ]; then
   timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "iql" 2>&1 | tail -8
   for w in iql; do TOPN=1 timeout 300 python tools/host_bound.py $w 200 2>&1 | grep "host enqueue"; PEARL_AMD_AC_LOOP=0 PEARL_AMD_IQL_ONE_CALL=0 TOPN=1 timeout 300 python tools/host_bound.py $w 200 2>&1 | grep "host enqueue"; done
 fi
+if [ "$MODE" == "stress2" ]; then
+  cd $R
+  PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 900 python -m pytest tests/test_gpu_actor_critic.py tests/test_gpu_kernels.py tests/test_gpu_dp.py -m gpu -q -x -p no:cacheprovider \
+    -k "rowstep or weight_grad or bandit_learn_batch or ppo_learn_trajectory or p2p_exchange_sums or one_call or native_learn_loop or two_solves" > gpurun_out/nocache_tests.txt 2>&1
+  echo "stress tests rc=$?"; tail -3 gpurun_out/nocache_tests.txt
+  PEARL_AMD_P2P=1 PEARL_AMD_FORCE_DP=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 \
+    --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2000 --warmup 200 --no-cpu-baseline --no-other-configs \
+    > gpurun_out/bench_dp1_p2p.log 2> gpurun_out/bench_dp1_p2p.err
+  echo "bench dp1 p2p rc=$?"; tail -1 gpurun_out/bench_dp1_p2p.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d.get('comm'))"
+fi
