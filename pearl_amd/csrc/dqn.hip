@@ -1312,7 +1312,11 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
              "committed next action, which the arena does not store)");
   const bool dbl = d.double_q != 0;
   const bool overlap = h->overlap && h->timing < 2 && !dbl;
-  const int wcap = dbl ? 1 : h->wcap;
+  // Double DQN: the rounds stay sequential, but the INPUTS of a window of rounds — x, next states,
+  // rewards, terminals, tables: none depends on the parameters — are still gathered by one launch
+  // (PEARL_AMD_DDQN_WINDOW=0: one gather per round, as before; same values either way)
+  const bool ddqn_window = env_int("PEARL_AMD_DDQN_WINDOW", 1) != 0;
+  const int wcap = (dbl && !ddqn_window) ? 1 : h->wcap;
   rc = ensure_side(h);
   if (rc != PA_OK) return rc;
   // fresh work-stealing counters for this call's persistent target launches, and a clean error
@@ -1530,9 +1534,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         b.next_mask = bb.next_mask + row0 * A;
       }
       float* Up = h->Uw[p] + row0 * d.hidden1;
-      if (dbl) {
-        rc = run_double_targets(h, &b, nullptr, h->yw[p] + row0, t);
-        if (rc != PA_OK) return rc;
+      if (dbl) {   // per round, inside the chain loop below: the argmax pass needs the previous round's step
         j0 += nj;
         continue;
       }
@@ -1605,6 +1607,27 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const float* yj = h->yw[p] + (int64_t)j * B;
       float* lo = args->losses_out ? args->losses_out + round : nullptr;
       const bool split_rp = overlap && j == 0;
+      if (dbl) {
+        // Q_target(s', argmax_a Q_online(s', a)) and the Bellman targets of THIS round, with the
+        // online parameters as the previous round left them
+        const int64_t row0 = (int64_t)j * B;
+        pa_dqn_batch b;
+        memset(&b, 0, sizeof(b));
+        b.B = B; b.A = A;
+        b.reward = bb.reward + row0;
+        b.terminated = bb.term + row0;
+        b.next_state = bb.next_state + row0 * d.state_dim;
+        if (shared_tab) {
+          b.next_avail_rep = h->sh_rep;
+          b.next_mask = h->sh_mask;
+          b.next_avail_bcast = 1;
+        } else {
+          b.next_avail_rep = bb.next_avail_rep + row0 * A * d.action_dim;
+          b.next_mask = bb.next_mask + row0 * A;
+        }
+        rc = run_double_targets(h, &b, nullptr, h->yw[p] + row0, s);
+        if (rc != PA_OK) return rc;
+      }
       if (!(k == 0 && j == 0 && front_emitted)) {
         rc = chain_front(h, xj, B, yj, overlap, gw_chain, s, split_rp);
         if (rc != PA_OK) return rc;

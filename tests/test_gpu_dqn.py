@@ -459,6 +459,51 @@ def test_double_dqn_differs_from_dqn_and_full_size_learn():
         assert torch.isfinite(v).all()
 
 
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_double_dqn_window_gather_is_bitwise_the_per_round_gather(dynamic, monkeypatch):
+    """Double DQN's learn(): the inputs of a window of rounds gathered by one launch (default) against
+    one gather per round (PEARL_AMD_DDQN_WINDOW=0) — same index lists, same kernels on the same
+    rows: losses and parameters bitwise equal, over several target-network updates; `dynamic`:
+    per-row action tables (rows with fewer available actions than slots)."""
+    from pearl_amd import (BasicReplayBuffer, DiscreteActionSpace, DoubleDQN,
+                           OneHotActionTensorRepresentationModule, PearlAgent)
+    S, A, B, n, rounds = 128, 16, 1024, 20_000, 27
+    g = torch.Generator().manual_seed(6)
+    st = torch.randn(n + 1, S, generator=g)
+    ids = torch.arange(n)
+
+    def run(window):
+        monkeypatch.setenv("PEARL_AMD_DDQN_WINDOW", "1" if window else "0")
+        torch.manual_seed(5)
+        pl = DoubleDQN(state_dim=S, action_space=_space(A), hidden_dims=[256, 256], training_rounds=rounds,
+                       batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))
+        rb = BasicReplayBuffer(n, sampler="device")
+        agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+        spaces = [(0, n, _space(A))]
+        if dynamic:
+            small = DiscreteActionSpace([torch.tensor([k]) for k in range(A - 3)])
+            spaces = [(0, n // 2, _space(A)), (n // 2, n, small)]
+        for lo, hi, sp in spaces:
+            rb.push_many(state=st[lo:hi].to(DEV), action=(ids[lo:hi] % (A - 3)).view(-1, 1).to(DEV),
+                         reward=(ids[lo:hi] % 7).float().to(DEV), terminated=(ids[lo:hi] % 50 == 0).to(DEV),
+                         truncated=torch.zeros(hi - lo, dtype=torch.bool, device=DEV),
+                         next_state=st[lo + 1:hi + 1].to(DEV), curr_available_actions=sp,
+                         next_available_actions=sp, max_number_actions=A)
+        reports = []
+        for call in range(2):
+            random.seed(31 + call)
+            reports.append(agent.learn())
+        return pl, reports
+
+    pa, ra = run(True)
+    pb, rb_ = run(False)
+    for x, y in zip(ra, rb_):
+        assert len(x["loss"]) == rounds and x["loss"] == y["loss"]
+    for net in ("_Q", "_Q_target"):
+        for (k, va), (_, vb) in zip(getattr(pa, net).state_dict().items(), getattr(pb, net).state_dict().items()):
+            assert torch.equal(va, vb), f"{net}.{k}"
+
+
 def test_default_next_actions_when_batch_has_none(golden):
     """next_available_actions = None -> all actions of the learner's space
     (deep_td_learning.py:362-416)."""

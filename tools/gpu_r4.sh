@@ -227,3 +227,19 @@ if [ "$MODE" == "stress2" ]; then
     > gpurun_out/bench_dp1_p2p.log 2> gpurun_out/bench_dp1_p2p.err
   echo "bench dp1 p2p rc=$?"; tail -1 gpurun_out/bench_dp1_p2p.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d.get('comm'))"
 fi
+if [ "$MODE" == "ddqnprof" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  w=double_dqn
+  rm -rf $R/gpurun_out/prof_$w
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0.2 > $R/gpurun_out/rocprof_$w.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+  head -16 $R/gpurun_out/${w}_kernel_stats.txt | cut -c1-150
+  python $R/tools/rocpd_timeline.py $DB weight_grad 40 > $R/gpurun_out/${w}_timeline.txt 2>&1; sed -n 1,50p $R/gpurun_out/${w}_timeline.txt | cut -c1-150
+  rm -f $DB
+fi
+if [ "$MODE" == "ddqn2" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_dqn.py -q -x -k "double or ddqn or qnet or sarsa" 2>&1 | tail -5
+  for w in 1 0; do PEARL_AMD_DDQN_WINDOW=$w timeout 300 python bench_algos.py --steps 300 --only double_dqn --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py; done
+fi
