@@ -475,7 +475,12 @@ int run_repack(pa_dqn* h, bool online, bool target, hipStream_t s) {
 // rebuilt here: the online net moves every round); then on the target parameters with ONE action
 // per transition — the chosen one — whose "row max" is the value and whose epilogue writes y.
 // The two first-layer state products (same s', two parameter sets) share one launch.
-int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s) {
+// value_stream (learn() with two streams): the value pass runs THERE, released by the device word
+// the next row-pass launch on `s` publishes when it starts (= the argmax pass has completed), and
+// hands y over as data-tagged words — so it runs beside the row pass's forward half instead of in
+// front of it (8.6 us of a 70 us round).  The caller launches that row pass next, with tagged y.
+int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y, hipStream_t s,
+                       hipStream_t value_stream = nullptr) {
   const pa_dqn_desc& d = h->d;
   PA_REQUIRE(h->w2f_online && b->B <= d.max_batch, PA_ERR_INVALID,
              "double-Q pass: learner was not created with double_q, or batch above max_batch");
@@ -509,7 +514,16 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
   one.next_avail_rep = h->choice_rep;
   one.next_avail_bcast = 0;
   one.next_mask = nullptr;
-  return run_target_fused_u(h, &one, h->Uw[1], next_v, y, s, false, nullptr, true, false, 0, false, 32);
+  hipStream_t vs = s;
+  if (value_stream) {
+    const int gen = ++h->sig_gen;
+    h->pending_signal = gen;
+    hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, value_stream, h->sig, gen, h->err_dev,
+                       h->err_host);
+    PA_LAUNCH_CHECK();
+    vs = value_stream;
+  }
+  return run_target_fused_u(h, &one, h->Uw[1], next_v, y, vs, false, nullptr, true, false, 0, false, 32);
 }
 
 // max_a' Q_target(s', a') (DeepQLearning) or Q_target(s', argmax_a' Q(s', a')) (DoubleDQN) and the
@@ -1317,6 +1331,10 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // (PEARL_AMD_DDQN_WINDOW=0: one gather per round, as before; same values either way)
   const bool ddqn_window = env_int("PEARL_AMD_DDQN_WINDOW", 1) != 0;
   const int wcap = (dbl && !ddqn_window) ? 1 : h->wcap;
+  // ... and the value pass Q_target(s', a*) of a round runs on the side stream beside the row
+  // pass's forward half (data-tagged y, as in the DQN loop; PEARL_AMD_DDQN_OVERLAP=0: in front of it)
+  const bool dbl2 = dbl && h->overlap && h->timing < 2 && h->use_flags &&
+                    env_int("PEARL_AMD_DDQN_OVERLAP", 1) != 0;
   rc = ensure_side(h);
   if (rc != PA_OK) return rc;
   // fresh work-stealing counters for this call's persistent target launches, and a clean error
@@ -1402,6 +1420,13 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     } else {
       rc = stream_hop(h, s, t, h->ev_start);
       if (rc != PA_OK) return rc;
+    }
+  } else if (dbl2) {
+    if (!h->y_clean) {
+      for (int p = 0; p < 2; ++p)
+        PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->yw[p]), (int)kYPendingBits,
+                                 (size_t)h->wrows, s));
+      h->y_clean = true;
     }
   } else {
     h->y_clean = false;
@@ -1625,21 +1650,22 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
           b.next_avail_rep = bb.next_avail_rep + row0 * A * d.action_dim;
           b.next_mask = bb.next_mask + row0 * A;
         }
-        rc = run_double_targets(h, &b, nullptr, h->yw[p] + row0, s);
+        rc = run_double_targets(h, &b, nullptr, h->yw[p] + row0, s, dbl2 ? h->side : nullptr);
         if (rc != PA_OK) return rc;
       }
+      const bool tagged = overlap || dbl2;
       if (!(k == 0 && j == 0 && front_emitted)) {
-        rc = chain_front(h, xj, B, yj, overlap, gw_chain, s, split_rp);
+        rc = chain_front(h, xj, B, yj, tagged, gw_chain, s, split_rp);
         if (rc != PA_OK) return rc;
       }
       if (!dp) {
-        rc = chain_back(h, xj, B, yj, overlap, args->adam_step0 + round + 1, 1, lo, soft_next, s, split_rp);
+        rc = chain_back(h, xj, B, yj, tagged, args->adam_step0 + round + 1, 1, lo, soft_next, s, split_rp);
         if (rc != PA_OK) return rc;
         continue;
       }
       // data parallel: local gradients (pre-scaled by 1/world) -> SUM all-reduce -> AdamW.  The
       // exchange hides behind the target work of the side stream.
-      rc = chain_back(h, xj, B, yj, overlap, args->adam_step0 + round + 1, -world, lo, 0, s, split_rp);
+      rc = chain_back(h, xj, B, yj, tagged, args->adam_step0 + round + 1, -world, lo, 0, s, split_rp);
       if (rc != PA_OK) return rc;
       PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
                  PA_ERR_HIP, "allreduce_start hook failed");
@@ -1660,9 +1686,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // single-process rounds end in weight_grad_kernel's fused optimizer epilogue, which refreshes
   // every packed copy (target included, on soft-update rounds)
   h->packed_ok = !dp && !dbl;
-  if (overlap) {
+  if (overlap || dbl2) {
     // everything the side stream did is ordered before whatever the caller enqueues next
-    PA_HIP(hipEventRecord(h->ev_tail, t));
+    PA_HIP(hipEventRecord(h->ev_tail, dbl2 ? h->side : t));
     PA_HIP(hipStreamWaitEvent(s, h->ev_tail, 0));
   }
   return PA_OK;

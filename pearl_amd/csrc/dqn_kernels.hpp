@@ -348,9 +348,6 @@ struct TargetArgs {
   float* choice_rep;         // with argmax: [B][AD] = feat row of that action (double_dqn.py:48-51)
   float* q_all;              // optional [B * A]: every (transition, action) value before masking
                              // (TwinCritic.get_q_values on an action set, discrete SAC)
-  const float* q_lookup;     // optional [B * A], with argmax: the row's value (next_v, y) is
-                             // q_lookup[b][argmax_b] instead of this pass's own maximum — Double DQN's
-                             // Q_target(s', argmax_a Q_online(s', a)) from target values computed ahead
   int rows_hint;             // 32: this pass prefers the 32-row, four-wave tile (two workgroups per CU:
                              // stand-alone passes — Double DQN, all-actions values); 0: the 64-row tile
   int prio_tiles;            // classic grid: tiles below this index run at raised wave priority (the

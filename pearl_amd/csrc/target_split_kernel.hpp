@@ -357,7 +357,6 @@ __device__ __forceinline__ void target_tile_split(const TargetArgs& a, int tile,
         for (int j = 0; j < a.AD; ++j) a.choice_rep[(int64_t)bb * a.AD + j] = src[j];
       }
     }
-    if (a.q_lookup) m = a.q_lookup[(int64_t)bb * a.A + mi];
     if (a.next_v) a.next_v[bb] = m;
     if (a.y) {
       // (next_v * gamma * (1 - terminated.float())) + reward, one rounding per op
@@ -595,7 +594,6 @@ __device__ __forceinline__ void target_tile_split32(const TargetArgs& a, int til
         for (int j = 0; j < a.AD; ++j) a.choice_rep[(int64_t)bt * a.AD + j] = src[j];
       }
     }
-    if (a.q_lookup) m = a.q_lookup[(int64_t)bt * a.A + mi];
     if (a.next_v) a.next_v[bt] = m;
     if (a.y) {
       const float live = 1.0f - (pf_term ? 1.0f : 0.0f);

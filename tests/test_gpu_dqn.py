@@ -461,8 +461,10 @@ def test_double_dqn_differs_from_dqn_and_full_size_learn():
 
 @pytest.mark.parametrize("dynamic", [False, True])
 def test_double_dqn_window_gather_is_bitwise_the_per_round_gather(dynamic, monkeypatch):
-    """Double DQN's learn(): the inputs of a window of rounds gathered by one launch (default) against
-    one gather per round (PEARL_AMD_DDQN_WINDOW=0) — same index lists, same kernels on the same
+    """Double DQN's learn(): the inputs of a window of rounds gathered by one launch, and every
+    round's value pass Q_target(s', a*) on the side stream beside the row pass's forward half with
+    data-tagged Bellman targets (default), against one gather per round and everything on one stream
+    (PEARL_AMD_DDQN_WINDOW=0, PEARL_AMD_DDQN_OVERLAP=0) — same index lists, same kernels on the same
     rows: losses and parameters bitwise equal, over several target-network updates; `dynamic`:
     per-row action tables (rows with fewer available actions than slots)."""
     from pearl_amd import (BasicReplayBuffer, DiscreteActionSpace, DoubleDQN,
@@ -474,6 +476,7 @@ def test_double_dqn_window_gather_is_bitwise_the_per_round_gather(dynamic, monke
 
     def run(window):
         monkeypatch.setenv("PEARL_AMD_DDQN_WINDOW", "1" if window else "0")
+        monkeypatch.setenv("PEARL_AMD_DDQN_OVERLAP", "1" if window else "0")
         torch.manual_seed(5)
         pl = DoubleDQN(state_dim=S, action_space=_space(A), hidden_dims=[256, 256], training_rounds=rounds,
                        batch_size=B, action_representation_module=OneHotActionTensorRepresentationModule(A))

@@ -241,5 +241,5 @@ fi
 if [ "$MODE" == "ddqn2" ]; then
   cd $R
   timeout 900 python -m pytest tests/test_gpu_dqn.py -q -x -k "double or ddqn or qnet or sarsa" 2>&1 | tail -5
-  for w in 1 0; do PEARL_AMD_DDQN_WINDOW=$w timeout 300 python bench_algos.py --steps 300 --only double_dqn --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py; done
+  for w in 1 0; do PEARL_AMD_DDQN_OVERLAP=$w timeout 300 python bench_algos.py --steps 300 --only double_dqn --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py; done
 fi
