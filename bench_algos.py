@@ -456,8 +456,9 @@ def bench_bandit(steps, cpu_seconds):
 
 def bench_double_dqn(steps, cpu_seconds):
     """DoubleDQN on BASELINE config 2's shapes: the next action comes from the
-    ONLINE network, so every round is sequential (all-actions pass on all CUs, then the value pass,
-    then the online chain) — no window batching, no overlap."""
+    ONLINE network, so every round is sequential (all-actions pass on all CUs, then the online chain
+    with the value pass beside the row pass's forward half) — the inputs of a window of rounds
+    share a gather, the target work cannot be batched."""
     from oracle.pearl_oracle import DqnOracle
     from pearl_amd import (BasicReplayBuffer, DoubleDQN, OneHotActionTensorRepresentationModule,
                            PearlAgent)
