@@ -243,3 +243,18 @@ if [ "$MODE" == "ddqn2" ]; then
   timeout 900 python -m pytest tests/test_gpu_dqn.py -q -x -k "double or ddqn or qnet or sarsa" 2>&1 | tail -5
   for w in 1 0; do PEARL_AMD_DDQN_OVERLAP=$w timeout 300 python bench_algos.py --steps 300 --only double_dqn --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py; done
 fi
+if [ "$MODE" == "final" ]; then
+  cd $R
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+  echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+print('value', round(d['value']/1e6,2), 'M  steady', round(d.get('steady_state',{}).get('value',0)/1e6,2), ' frac', round(d['roofline']['frac'],3), 'frac_pipe', round(d['roofline'].get('frac_pipe',0),3), 'traffic src', d['roofline'].get('traffic_source'))
+for r in d.get('other_configs',[]): print(' ', r.get('config'), round(r.get('value',0)/1e6,2), 'M', 'step_frac', round(r.get('step_frac',0),3), 'kernel_us', round(r.get('kernel_us',0),1), 'cpu', round((r.get('cpu_baseline') or {}).get('value',0)))"
+  timeout 600 python bench_algos.py --steps 300 --cpu-seconds 2 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
+  echo "bench_algos rc=$?"; python tools/algo_line.py < gpurun_out/bench_algos.jsonl
+fi
