@@ -534,8 +534,8 @@ static std::atomic<int> g_dw_split_mode{-1};
 int dw_split_mode() {
   int m = g_dw_split_mode.load();
   if (m < 0) {
-    const char* v = getenv("PEARL_AMD_DW_SPLIT");
-    m = (v && v[0] == '0') ? 0 : 1;
+    const char* v = getenv("PEARL_AMD_DW_SPLIT");      // 0: never, 1 (default): from PEARL_AMD_DW_MINB rows on,
+    m = (v && v[0] == '0') ? 0 : ((v && v[0] == '2') ? 2 : 1);   // 2: every launch with 64-row tiles (tuning)
   }
   return m;
 }

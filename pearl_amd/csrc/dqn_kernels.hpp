@@ -1234,12 +1234,18 @@ __device__ __forceinline__ void dw_fetch32(const __amdgpu_buffer_rsrc_t& ra,
                                            DwRaw32<UPL>& f) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  static_assert(UPL == 4, "16-byte loads of dZ");
+  static_assert(UPL == 4 || UPL == 2, "16- / 8-byte loads of dZ");
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va + ba + (unsigned)r * lda4), 0, 0);
-    const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
-    f.a[r][0] = f4[0]; f.a[r][1] = f4[1]; f.a[r][2] = f4[2]; f.a[r][3] = f4[3];
+    if constexpr (UPL == 4) {
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va + ba + (unsigned)r * lda4), 0, 0);
+      const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
+      f.a[r][0] = f4[0]; f.a[r][1] = f4[1]; f.a[r][2] = f4[2]; f.a[r][3] = f4[3];
+    } else {
+      const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ra, (int)(va + ba + (unsigned)r * lda4), 0, 0);
+      const f32x2 f2a = __builtin_bit_cast(f32x2, v);
+      f.a[r][0] = f2a[0]; f.a[r][1] = f2a[1];
+    }
     const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)(vx + bx + (unsigned)r * ldx4), 0, 0);
     const f32x2 f2 = __builtin_bit_cast(f32x2, w);
     f.x[r][0] = f2[0]; f.x[r][1] = f2[1];
@@ -1293,7 +1299,7 @@ __device__ __forceinline__ void dw_mainloop_split(const __amdgpu_buffer_rsrc_t& 
                                                   unsigned lda4, unsigned ldx4, int nsteps,
                                                   dw_f32x4 (&acc)[UPL][2], float (&cs)[UPL],
                                                   Hook after_prologue) {
-  static_assert(UPL == 4, "two pairs of adjacent units per lane");
+  static_assert(UPL == 4 || UPL == 2, "pairs of adjacent units per lane");
   dw_f32x4 small[UPL][2];
 #pragma unroll
   for (int ja = 0; ja < UPL; ++ja) {
@@ -1765,6 +1771,12 @@ static __global__ __launch_bounds__(512, 2) void weight_grad_split_kernel(DwArgs
   __shared__ float part[4 * DW_TM * DW_TN];
   __shared__ float csum[8 * DW_TM];
   weight_grad_body<4, true>(a, part, csum);
+}
+// ... and 32-row tiles (tm == 32): the DQN chain's 113-workgroup launch
+static __global__ __launch_bounds__(512, 2) void weight_grad_split_kernel32(DwArgs a) {
+  __shared__ float part[4 * 32 * DW_TN];
+  __shared__ float csum[8 * 32];
+  weight_grad_body<2, true>(a, part, csum);
 }
 
 // ---------------------------------------------------------------------------

@@ -234,20 +234,30 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
   // PEARL_AMD_DW_SPLIT=0: the fp32-MFMA kernel everywhere.
   const int split_mode = dw_split_mode();   // pa_debug_set_dw_split / PEARL_AMD_DW_SPLIT
   a.split = 0;
-  if (split_mode > 0 && a.tm != 32 && (a.B >= min_b || split_mode == 2)) {
+  // (32-row tiles — the DQN chain's launch — from PEARL_AMD_DW_MINB32 = 1024 rows on: 0.7 us of a
+  //  36 us round; smaller batches keep the fp32 loop, whose sums the tile-shape
+  //  and loop-equivalence tests compare bitwise)
+  static const int min_b32 = []() {
+    const char* v = getenv("PEARL_AMD_DW_MINB32");
+    const int n = v ? atoi(v) : 1024;
+    return n > 0 ? n : 1024;
+  }();
+  if (split_mode > 0 && ((a.tm != 32 && a.B >= min_b) || (a.tm == 32 && a.B >= min_b32) || split_mode == 2)) {
     bool ok = true;
+    const unsigned za = a.tm == 32 ? 7u : 15u;   // dZ vectors: two / four units
     for (int k = 0; k < a.nprob; ++k) {
       const DwProblem& P = a.p[k];
       if (P.M == 1) continue;   // the GEMV path
       // (row pitches of whole vectors: a vector that straddles M or N reads pad / neighbour
       //  columns of its own row — inside the allocation — into accumulator rows / columns beyond
       //  the problem, which the epilogue never stores)
-      ok = ok && (P.ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(P.dZ) & 15) == 0 &&
+      ok = ok && (P.ldz & (za >> 2)) == 0 && (reinterpret_cast<uintptr_t>(P.dZ) & za) == 0 &&
            (P.ldx & 1) == 0 && (reinterpret_cast<uintptr_t>(P.X) & 7) == 0;
     }
     a.split = ok ? 1 : 0;
   }
-  if (a.tm == 32) hipLaunchKernelGGL(weight_grad_kernel32, dim3(grid), dim3(512), 0, s, a);
+  if (a.tm == 32 && a.split) hipLaunchKernelGGL(weight_grad_split_kernel32, dim3(grid), dim3(512), 0, s, a);
+  else if (a.tm == 32) hipLaunchKernelGGL(weight_grad_kernel32, dim3(grid), dim3(512), 0, s, a);
   else if (a.split) hipLaunchKernelGGL(weight_grad_split_kernel, dim3(grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);
   PA_LAUNCH_CHECK();

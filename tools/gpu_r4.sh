@@ -258,3 +258,21 @@ for r in d.get('other_configs',[]): print(' ', r.get('config'), round(r.get('val
   timeout 600 python bench_algos.py --steps 300 --cpu-seconds 2 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
   echo "bench_algos rc=$?"; python tools/algo_line.py < gpurun_out/bench_algos.jsonl
 fi
+if [ "$MODE" == "chainsplit" ]; then
+  cd $R
+  timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -s -k "weight_grad" 2>&1 | tail -12
+  for cfg in "PEARL_AMD_DW_SPLIT=2" "default"; do
+    echo "== $cfg"
+    if [ "$cfg" == "default" ]; then E=""; else E="$cfg"; fi
+    env $E timeout 300 python bench.py --gpus 1 --steps 2000 --warmup 200 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('value', round(d['value']/1e6,2), 'M', round(d['ms_per_step']*1e3,2), 'us/round', 'final_loss', d['config'].get('final_loss'))"
+  done
+fi
+if [ "$MODE" == "split32tests" ]; then
+  cd $R
+  timeout 1500 python -m pytest tests/test_gpu_dqn.py tests/test_gpu_dp.py tests/test_reference_binding.py tests/test_gpu_kernels.py -q -x --tb=short 2>&1 | tail -15
+  timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.read()); print('value', round(d['value']/1e6,2), 'steady', round(d['steady_state']['value']/1e6,2))"
+fi
