@@ -30,5 +30,18 @@ int main(void) {
   O(pa_ac_loop_args, noise_stride); O(pa_ac_loop_args, losses); O(pa_ac_loop_args, losses_stride);
   O(pa_ac_loop_args, actor_update_freq); O(pa_ac_loop_args, training_step0);
   O(pa_ac_loop_args, gather_rounds);
+  O(pa_batch_out, curr_avail_rep);
+  P(pa_bandit_step_args); P(pa_ppo_learn_args); P(pa_dsac_step_args); P(pa_iql_step_args);
+  O(pa_bandit_step_args, adam_step); O(pa_bandit_step_args, d); O(pa_bandit_step_args, b_snap);
+  O(pa_bandit_step_args, side_stream); O(pa_bandit_step_args, l2_reg_lambda);
+  O(pa_bandit_step_args, singular);
+  O(pa_ppo_learn_args, idx_lists); O(pa_ppo_learn_args, plane_stride); O(pa_ppo_learn_args, epsilon);
+  O(pa_ppo_learn_args, losses_stride); O(pa_ppo_learn_args, critic_step);
+  O(pa_dsac_step_args, xq); O(pa_dsac_step_args, curr_rep_bstride); O(pa_dsac_step_args, next_mask);
+  O(pa_dsac_step_args, tau); O(pa_dsac_step_args, target_entropy); O(pa_dsac_step_args, alpha_lr);
+  O(pa_dsac_step_args, critic_step); O(pa_dsac_step_args, h_out);
+  O(pa_iql_step_args, actor_kind); O(pa_iql_step_args, ld_xq); O(pa_iql_step_args, high);
+  O(pa_iql_step_args, pick_actor); O(pa_iql_step_args, tau); O(pa_iql_step_args, critic_step);
+  O(pa_iql_step_args, losses);
   return 0;
 }

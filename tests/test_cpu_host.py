@@ -42,7 +42,9 @@ def test_ctypes_structs_match_c_layout(tmp_path):
              "pa_batch_out": N.BatchOut, "pa_dqn_desc": N.DqnDesc, "pa_dqn_buffers": N.DqnBuffers,
              "pa_dqn_batch": N.DqnBatch, "pa_learn_args": N.LearnArgs, "pa_mlp_desc": N.MlpDesc,
              "pa_mlp_buffers": N.MlpBuffers, "pa_sac_step_args": N.SacStepArgs,
-             "pa_ddpg_step_args": N.DdpgStepArgs, "pa_ac_loop_args": N.AcLoopArgs}
+             "pa_ddpg_step_args": N.DdpgStepArgs, "pa_ac_loop_args": N.AcLoopArgs,
+             "pa_bandit_step_args": N.BanditStepArgs, "pa_ppo_learn_args": N.PpoLearnArgs,
+             "pa_dsac_step_args": N.DsacStepArgs, "pa_iql_step_args": N.IqlStepArgs}
     for cname, ctype in pairs.items():
         assert C.sizeof(ctype) == int(facts[cname]), cname
     for key, value in facts.items():
