@@ -1686,6 +1686,9 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // single-process rounds end in weight_grad_kernel's fused optimizer epilogue, which refreshes
   // every packed copy (target included, on soft-update rounds)
   h->packed_ok = !dp && !dbl;
+  // (Double DQN with the tagged hand-off: every round's targets were consumed and their tags
+  //  restored by that round's weight-gradient launch, whatever run_double_targets noted)
+  if (dbl2) h->y_clean = true;
   if (overlap || dbl2) {
     // everything the side stream did is ordered before whatever the caller enqueues next
     PA_HIP(hipEventRecord(h->ev_tail, dbl2 ? h->side : t));
