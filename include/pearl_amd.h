@@ -947,8 +947,9 @@ int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t
  * (pearl/policy_learners/contextual_bandits/neural_linear_bandit.py:139-214): pa_wloss_rowstep, the
  * LinUCB operands from the kept features (pa_linreg_delta2's), ONE weight-gradient launch forming
  * the network's gradients with AdamW step `adam_step` AND the moment update [delta_A | delta_b],
- * then pa_linreg_apply2 (the batch's weight sum read from delta_A[0][0]).  Four launches, plus
- * the solve's two on the side stream when one is given.
+ * then pa_linreg_apply2 (the batch's weight sum read from delta_A[0][0]).  Three launches (the row
+ * step writes the operands itself unless it takes the bf16x3 forward), plus the solve's two on the
+ * side stream when one is given.
  *   pred [B]: act(network output); d_pred [B]: scratch that must stay untouched until the call's
  *   launches have run; scalars [2]: the loss, then the batch mean of pred;
  *   x_scratch / r_scratch / delta: as pa_linreg_delta2 (delta [D*(D+1)], D = d + 1);

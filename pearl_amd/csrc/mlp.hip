@@ -2847,6 +2847,13 @@ extern "C" int pa_bandit_step(const pa_bandit_step_args* g, void* stream) {
   head.loss_kind = g->loss_kind; head.out_act = g->out_act;
   head.out_post = g->out_act == PA_OUT_LINEAR ? nullptr : g->pred;
   head.mean_out = g->scalars + 1;
+  // the LinUCB operands straight from the row step's feature tile (fp32-forward launches: the
+  // bf16x3 forward keeps no fp32 feature tile in LDS, linreg_operands_kernel runs then)
+  {
+    const LinregPitch lp = linreg_pitch(g->d + 1, 1);
+    head.lin_x = g->x_scratch; head.lin_r = g->r_scratch;
+    head.ldX = lp.ldX; head.ldR = lp.ldR;
+  }
   // (a linear output: the network outputs ARE the predictions; a sigmoid: the pre-activation
   //  outputs are not kept)
   float* outs[1] = {g->out_act == PA_OUT_LINEAR ? g->pred : nullptr};
@@ -2855,9 +2862,11 @@ extern "C" int pa_bandit_step(const pa_bandit_step_args* g, void* stream) {
   if (rc != PA_OK) return rc;
   PA_REQUIRE(net->pend.active, PA_ERR_INVALID, "pa_bandit_step: the row step left no pending gradients");
   // the features of THIS forward (the trunk's output, kept by the row step) feed the regression
-  rc = linreg_operands(net->act[net->L - 2], net->d.dims[net->L - 1], g->y, nullptr, g->B, g->d,
-                       g->x_scratch, g->r_scratch, 1, s);
-  if (rc != PA_OK) return rc;
+  if (g_rowstep_last_split != 0) {
+    rc = linreg_operands(net->act[net->L - 2], net->d.dims[net->L - 1], g->y, nullptr, g->B, g->d,
+                         g->x_scratch, g->r_scratch, 1, s);
+    if (rc != PA_OK) return rc;
+  }
   const DwProblem extra = linreg_delta_problem(g->B, g->d, g->x_scratch, g->r_scratch, g->delta, 1);
   net->pend.active = false;
   DwOperands op = {net->pend.x, net->pend.ldx, net->pend.dzs, net->pend.ldzs};

@@ -69,6 +69,10 @@ struct RowHead {
   // the post-activation predictions when the activation is not linear
   // mean_out (nullable): the batch mean of the post-activation predictions
   int loss_kind, out_act; float* out_post; float* mean_out;
+  // lin_x / lin_r (nullable; fp32-forward launches only, L >= 2): the LinUCB operands of the rows'
+  // FEATURES (the output of layer L - 2, still in LDS): X[b] = [1 | f_b | 0..] (pitch ldX) and
+  // R[b] = [1 | f_b | y_b | 0..] (pitch ldR) — linreg_operands_kernel with unit weights, no launch
+  float* lin_x; float* lin_r; int ldX, ldR;
 };
 
 struct RowStepArgs {
@@ -466,6 +470,21 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   }   // !SPLITF
   __syncthreads();
   PA_STAMP(a.prof, pwg, wave, 9);             // forward done
+  if constexpr (!SPLITF) {
+    if (hd.kind == RS_HEAD_WMSE1 && hd.lin_x && n.L >= 2) {
+      const int D = n.dims[n.L - 1] + 1;
+      const int W = hd.ldR > hd.ldX ? hd.ldR : hd.ldX;
+      const float* ft = hb[(n.L - 2) & 1];      // [ROWS][PH] features of this tile (post-activation)
+      for (int e = tid; e < ROWS * W; e += 512) {
+        const int r = e / W, j = e - r * W;
+        const int b = m0 + r;
+        if (b >= a.B) continue;
+        const float x = (j == 0) ? 1.0f : (j < D ? ft[r * PH + (j - 1)] : 0.f);
+        if (j < hd.ldX) hd.lin_x[(int64_t)b * hd.ldX + j] = x;
+        if (j < hd.ldR) hd.lin_r[(int64_t)b * hd.ldR + j] = j < D ? x : (j == D ? hd.target[b] : 0.f);
+      }
+    }
+  }
   // ---------------------------------------------------------------- head: d_out tile into hb[0]
   const float* ot = SPLITF ? otile : hb[(n.L - 1) & 1];   // [ROWS][PH] network output of this tile
   const int DL = n.dims[n.L];
