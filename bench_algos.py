@@ -439,16 +439,16 @@ def bench_bandit(steps, cpu_seconds):
             "metric": "contexts/s through learn_batch (NN step + LinUCB A/b/inv(A)/coefs update)",
             "value": gpu, "steps": steps, "ms_per_step": 1e3 * dt / steps,
             # trunk forward + dW + dX of its second layer, the 65-wide head, A += x x^T, b += x r.
-            # The step is pa_bandit_step: four launches on the learner stream (row step, LinUCB
-            # operands, weight gradients + AdamW + the moment update in ONE launch, apply); the
+            # The step is pa_bandit_step: three launches on the learner stream (row step incl. the
+            # LinUCB operands, weight gradients + AdamW + the moment update in ONE launch, apply); the
             # 65 x 65 fp64 solve (one workgroup, ~100 us) runs on two alternating side streams
             # beside the next steps and no longer bounds the step
             "roofline": dict(step_roofline(
                 2 * (2 * mlp_macs([F, 256, 64]) + 256 * 64 + 3 * 65 + 65 * 65), B * steps, dt,
                 kernel="mlp_rowstep_kernel + weight_grad_split_kernel (network dW + AdamW + X^T R) "
                        "+ linreg operands / apply; linreg_solve_spd_kernel off the learner stream"),
-                note="bound by the learner stream's four launches (row step 43 us, weight "
-                     "gradients 26 us, two 5 us elementwise launches)"),
+                note="bound by the learner stream's three launches (row step 45 us, weight "
+                     "gradients + moment update 27 us, apply 4 us)"),
             "kernels": kernels,
             "cpu_baseline": {"value": cpu, "kind": "port", "cores": torch.get_num_threads(),
                              "sample": f"{n} oracle learn_batch calls"}}
