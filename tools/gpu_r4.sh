@@ -288,3 +288,17 @@ if [ "$MODE" == "prof2" ]; then
   head -12 $R/gpurun_out/kernel_stats.txt | cut -c1-150
   rm -f $R/gpurun_out/prof/*.db
 fi
+if [ "$MODE" == "prof3" ]; then
+  cd $R
+  timeout 600 python bench_algos.py --steps 300 --cpu-seconds 2 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
+  echo "bench_algos rc=$?"; python tools/algo_line.py < gpurun_out/bench_algos.jsonl
+  cd /tmp && export TMPDIR=/tmp
+  for w in sac ppo bandit dsac double_dqn; do
+    rm -rf $R/gpurun_out/prof_$w
+    timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0.5 > $R/gpurun_out/rocprof_$w.log 2>&1
+    DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+    python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+    echo "rocprof $w rc=$?"; head -5 $R/gpurun_out/${w}_kernel_stats.txt | cut -c1-150
+    rm -f $DB
+  done
+fi
