@@ -535,6 +535,32 @@ def test_bandit_inverse_is_the_latest_one_with_two_solves_in_flight():
             assert_linear_solve_close(lr._coefs, lr._A, lr._b, 1.0, want, msg=f"after {n} steps")
 
 
+def test_bandit_in_stream_solve_equals_the_side_stream_solve(monkeypatch):
+    """PEARL_AMD_BANDIT_ASYNC_SOLVE=0 (the LinUCB solve on the learner's stream, straight into the
+    layer's buffers) against the default (two alternating side streams with their own result pairs,
+    copied in when read): the same kernels on the same (A, b) -> bitwise equal inverse and
+    coefficients, for the one-call step and for a weighted batch (call-by-call path)."""
+    from pearl_amd import NeuralLinearBandit, TransitionBatch
+    B, F = 512, 20
+    g = torch.Generator().manual_seed(12)
+    batches = [(torch.randn(B, F, generator=g), torch.rand(B, generator=g),
+                None if k != 2 else torch.rand(B, generator=g) + 0.1) for k in range(4)]
+
+    def run(async_solve):
+        monkeypatch.setenv("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1" if async_solve else "0")
+        torch.manual_seed(1)
+        pl = NeuralLinearBandit(feature_dim=F, hidden_dims=[32, 12], batch_size=B, learning_rate=1e-3)
+        pl.to(DEV)
+        for x, r, w in batches:
+            pl.learn_batch(TransitionBatch(state=x.to(DEV), action=torch.zeros(B, 1, device=DEV),
+                                           reward=r.to(DEV), weight=None if w is None else w.to(DEV)))
+        lr = pl.model._linear_regression_layer
+        return [t.clone() for t in (lr._A, lr._b, lr._inv_A, lr._coefs)]
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b)
+
+
 def test_bandit_deepcopy_pickle_and_load_state_dict_after_a_step():
     """A NeuralLinearBandit that has stepped (side stream + events of the asynchronous solve alive)
     can be deep-copied, pickled and torch.save'd (it raised "cannot pickle 'Event'"), the

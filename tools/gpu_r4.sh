@@ -302,3 +302,7 @@ if [ "$MODE" == "prof3" ]; then
     rm -f $DB
   done
 fi
+if [ "$MODE" == "bandit6" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "bandit" 2>&1 | tail -8
+fi
