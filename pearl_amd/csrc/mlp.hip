@@ -1702,22 +1702,61 @@ struct GaeArgs {
 __global__ __launch_bounds__(256) void gae_kernel(GaeArgs a) {
   const int64_t i1 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i1 >= a.N) return;
-  const bool boundary = (i1 == a.N - 1) || a.term[i1] || a.trunc[i1];
+  const bool boundary = (i1 == a.N - 1) | (((unsigned)a.term[i1] | (unsigned)a.trunc[i1]) != 0);
   if (!boundary) return;
+  // The walk is a chain of dependent fp32 operations, but nothing it LOADS depends on the chain:
+  // first find where the walk ends (the previous boundary; four flag pairs per trip instead of one
+  // dependent load per element), then run it in blocks of four whose loads are all issued before
+  // the block's arithmetic — 0.42 us per element (one exposed memory latency each) otherwise,
+  // 210 us for 500-transition episodes.  The arithmetic and its order are unchanged.
+  int64_t lo = i1;          // first element of this walk (inclusive)
+  while (lo > 0) {
+    bool d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = lo - 1 - k;
+      const int64_t jc = j >= 0 ? j : 0;          // (unconditional loads: no short-circuit branches)
+      const unsigned f = (unsigned)a.term[jc] | (unsigned)a.trunc[jc];
+      d[k] = (j < 0) | (f != 0);
+    }
+    int k = 0;
+    while (k < 4 && !d[k]) ++k;
+    lo -= k;
+    if (k < 4) break;
+  }
   float gae = 0.f;
-  for (int64_t i = i1; i >= 0; --i) {
-    const bool done = a.term[i] || a.trunc[i];
-    if (i != i1 && done) break;  // the previous boundary owns the rest
-    const float nv = (i == a.N - 1) ? a.next_value_last[0] : a.values[i + 1];
+  auto step = [&](int64_t i, float nv, float rw, float vi, bool term, bool done) {
     // td = reward + gamma * next_value * (~terminated) - V[i]
     const float t0 = __fmul_rn(a.gamma, nv);
-    const float t1 = __fmul_rn(t0, a.term[i] ? 0.f : 1.f);
-    const float t2 = __fadd_rn(a.reward[i], t1);
-    const float td = __fsub_rn(t2, a.values[i]);
+    const float t1 = __fmul_rn(t0, term ? 0.f : 1.f);
+    const float t2 = __fadd_rn(rw, t1);
+    const float td = __fsub_rn(t2, vi);
     const float c = done ? 0.f : a.gl;
     gae = __fadd_rn(td, __fmul_rn(c, gae));
     a.gae[i] = gae;
-    a.lam_return[i] = __fadd_rn(gae, a.values[i]);
+    a.lam_return[i] = __fadd_rn(gae, vi);
+  };
+  int64_t i = i1;
+  for (; i - 3 >= lo; i -= 4) {
+    float nv[4], rw[4], vi[4];
+    bool tm[4], dn[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t j = i - k;
+      nv[k] = (j == a.N - 1) ? a.next_value_last[0] : a.values[j + 1];
+      rw[k] = a.reward[j];
+      vi[k] = a.values[j];
+      const unsigned t8 = a.term[j], u8 = a.trunc[j];
+      tm[k] = t8 != 0;
+      dn[k] = (t8 | u8) != 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) step(i - k, nv[k], rw[k], vi[k], tm[k], dn[k]);
+  }
+  for (; i >= lo; --i) {
+    const unsigned t8 = a.term[i], u8 = a.trunc[i];
+    step(i, (i == a.N - 1) ? a.next_value_last[0] : a.values[i + 1], a.reward[i], a.values[i], t8 != 0,
+         (t8 | u8) != 0);
   }
 }
 

@@ -306,3 +306,22 @@ if [ "$MODE" == "bandit6" ]; then
   cd $R
   timeout 900 python -m pytest tests/test_gpu_actor_critic.py -q -x -k "bandit" 2>&1 | tail -8
 fi
+if [ "$MODE" == "gae" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_actor_critic.py tests/test_gpu_kernels.py -q -x -k "ppo or gae" 2>&1 | tail -4
+  timeout 300 python bench_algos.py --steps 100 --only ppo --cpu-seconds 0.2 2>/dev/null | python -c "
+import sys,json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d=json.loads(ln); print(round(d['value']/1e6,2), 'M', d.get('preprocess_replay_buffer'))"
+fi
+if [ "$MODE" == "gaeprof" ]; then
+  cd /tmp && export TMPDIR=/tmp
+  w=ppo
+  rm -rf $R/gpurun_out/prof_$w
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 50 --only $w --cpu-seconds 0.2 > $R/gpurun_out/rocprof_$w.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats2.txt 2>&1
+  head -22 $R/gpurun_out/${w}_kernel_stats2.txt | cut -c1-150
+  rm -f $DB
+fi
