@@ -325,3 +325,16 @@ if [ "$MODE" == "gaeprof" ]; then
   head -22 $R/gpurun_out/${w}_kernel_stats2.txt | cut -c1-150
   rm -f $DB
 fi
+if [ "$MODE" == "final2" ]; then
+  cd $R
+  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+  echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+  echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
+  timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
+  echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "
+import sys,json
+d=json.loads(sys.stdin.read())
+print('value', round(d['value']/1e6,2), 'M  steady', round(d.get('steady_state',{}).get('value',0)/1e6,2), ' frac', round(d['roofline']['frac'],3), 'frac_pipe', round(d['roofline'].get('frac_pipe',0),3))
+for r in d.get('other_configs',[]): print(' ', r.get('config'), round(r.get('value',0)/1e6,2), 'M', 'step_frac', round(r.get('step_frac',0),3), 'kernel_us', round(r.get('kernel_us',0),1), 'cpu', round((r.get('cpu_baseline') or {}).get('value',0)))"
+fi
