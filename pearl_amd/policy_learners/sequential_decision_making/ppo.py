@@ -108,6 +108,32 @@ class PPOReplayBuffer(TensorBasedReplayBuffer):
         idx = torch.arange(n, dtype=torch.int64, device=arena.device)
         return self._gather_batch(idx)
 
+    def rollout_inputs(self):
+        """What preprocess_replay_buffer reads of the rollout (ppo.py:211-293), in logical order:
+        state, action, reward, terminated, truncated of every transition and the next state of the
+        NEWEST one — one gather that leaves out the other 65 535 next states and both action tables
+        (`rollout()` copies 3x the bytes), plus a one-row gather."""
+        n = len(self)
+        arena, z = self.arena, self._layout
+        assert arena is not None and z is not None and n > 0
+        dev = arena.device
+        idx = torch.arange(n, dtype=torch.int64, device=dev)
+        state = torch.empty(n, z.state_dim, dtype=torch.float32, device=dev)
+        action = torch.empty((n,) + z.action_shape, dtype=z.action_dtype, device=dev)
+        reward = torch.empty(n, dtype=z.reward_dtype, device=dev)
+        term = torch.empty(n, dtype=torch.bool, device=dev)
+        trunc = torch.empty(n, dtype=torch.bool, device=dev)
+        out = N.BatchOut()
+        out.state, out.action, out.reward = state.data_ptr(), action.data_ptr(), reward.data_ptr()
+        out.terminated, out.truncated = term.data_ptr(), trunc.data_ptr()
+        arena.gather_device(idx, out)
+        last_next = torch.empty(1, z.state_dim, dtype=torch.float32, device=dev)
+        one = N.BatchOut()
+        one.next_state = last_next.data_ptr()
+        arena.gather_device(idx[n - 1:], one)
+        shape = (lambda m: (m,) + z.state_shape if len(z.state_shape) else (m, 1))
+        return state.view(shape(n)), action, reward, term, trunc, last_next.view(shape(1))
+
 
 class ProximalPolicyOptimization(ActorCriticBase):
     def __init__(self, action_space: Any, state_dim: Optional[int] = None,
@@ -348,11 +374,17 @@ class ProximalPolicyOptimization(ActorCriticBase):
             "pearl_amd PPO needs a pearl_amd PPOReplayBuffer"
         n = len(replay_buffer)
         assert n > 0
-        roll = replay_buffer.rollout()
+        if type(replay_buffer).rollout is PPOReplayBuffer.rollout and replay_buffer._layout.has_next_state:
+            r_state, r_action, r_reward, r_term, r_trunc, r_last_next = replay_buffer.rollout_inputs()
+        else:       # (a subclass with its own notion of the rollout)
+            roll = replay_buffer.rollout()
+            r_state, r_action, r_reward, r_term, r_trunc = (roll.state, roll.action, roll.reward,
+                                                           roll.terminated, roll.truncated)
+            r_last_next = roll.next_state[n - 1:n]
         actor, critic = self._nets(n)
         dev = actor.device
-        state = self._f32(self._history_summarization_module(roll.state), dev)
-        arep = self._f32(self.action_representation_module(roll.action), dev).reshape(n, -1)
+        state = self._f32(self._history_summarization_module(r_state), dev)
+        arep = self._f32(self.action_representation_module(r_action), dev).reshape(n, -1)
         # the SAME launch shape learn_batch uses for these two networks: with epsilon = 0 the clipped
         # surrogate passes a gradient only where the probability ratio is exactly 1, i.e. where this
         # forward and learn_batch's agree to the bit
@@ -368,13 +400,16 @@ class ProximalPolicyOptimization(ActorCriticBase):
                                                arep.stride(0), n, actor.dims[-1], None,
                                                aprob.data_ptr(), s))
         # value of the newest transition's next state bootstraps the recurrence (ppo.py:255-269)
-        last_next = self._f32(self._history_summarization_module(roll.next_state[n - 1:n]), dev)
+        last_next = self._f32(self._history_summarization_module(r_last_next), dev)
         next_value = critic.forward(last_next).reshape(1)
         gae = torch.empty(n, dtype=torch.float32, device=dev)
         lam_return = torch.empty(n, dtype=torch.float32, device=dev)
-        reward = self._f32(roll.reward, dev).reshape(n)
-        term = roll.terminated.to(dev).reshape(n).to(torch.uint8).contiguous()
-        trunc = roll.truncated.to(dev).reshape(n).to(torch.uint8).contiguous()
+        reward = self._f32(r_reward, dev).reshape(n)
+
+        def as_u8(flags: Tensor) -> Tensor:      # a bool tensor is its bytes (no conversion launch)
+            f = flags.to(dev).reshape(n).contiguous()
+            return f.view(torch.uint8) if f.dtype == torch.bool else f.to(torch.uint8)
+        term, trunc = as_u8(r_term), as_u8(r_trunc)
         N.check(N.lib().pa_ppo_gae(reward.data_ptr(), term.data_ptr(), trunc.data_ptr(),
                                    values.data_ptr(), next_value.data_ptr(),
                                    float(self._discount_factor), float(self._trace_decay_param), n,

@@ -338,3 +338,7 @@ d=json.loads(sys.stdin.read())
 print('value', round(d['value']/1e6,2), 'M  steady', round(d.get('steady_state',{}).get('value',0)/1e6,2), ' frac', round(d['roofline']['frac'],3), 'frac_pipe', round(d['roofline'].get('frac_pipe',0),3))
 for r in d.get('other_configs',[]): print(' ', r.get('config'), round(r.get('value',0)/1e6,2), 'M', 'step_frac', round(r.get('step_frac',0),3), 'kernel_us', round(r.get('kernel_us',0),1), 'cpu', round((r.get('cpu_baseline') or {}).get('value',0)))"
 fi
+if [ "$MODE" == "ppo4" ]; then
+  cd $R
+  for st in 100 300 100; do timeout 300 python bench_algos.py --steps $st --only ppo --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py; done
+fi
