@@ -332,7 +332,7 @@ def bench_ppo(steps, cpu_seconds):
     fill()
     dt_pre, _ = timed(lambda: pl.preprocess_replay_buffer(rb))
     # one full learn() as warm-up (first-call allocations, scratch growth), then the timed one;
-    # both include preprocess_replay_buffer (1.4 ms), as every PPO learn() does
+    # both include preprocess_replay_buffer (1.2 ms), as every PPO learn() does
     if world > 1:
         pl.learn(rb)                      # warm-up (incl. the communicator's first collective)
         sync()

@@ -342,3 +342,7 @@ if [ "$MODE" == "ppo4" ]; then
   cd $R
   for st in 100 300 100; do timeout 300 python bench_algos.py --steps $st --only ppo --cpu-seconds 0.2 2>/dev/null | python tools/algo_line.py; done
 fi
+if [ "$MODE" == "dp" ]; then
+  cd $R
+  timeout 900 python -m pytest tests/test_gpu_dp.py tests/test_vector_env.py tests/test_gpu_replay.py -m gpu -q -x 2>&1 | tail -4
+fi
