@@ -996,8 +996,10 @@ long long* g_rowstep_prof = nullptr;   // pa_debug_rowstep_prof
 int g_rowstep_last_split = 0;          // 1: the last fused row step ran the bf16x3 forward
 int g_rowstep_split_mode = -1;         // pa_debug_set_rowstep_split: -1 default (on), 0 off
 int rowstep_split_mode() { return g_rowstep_split_mode; }
+// split_out (nullable): what THIS launch ran — 0 fp32, 1 bf16x3 forward, 2 forward and backward
 int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, RowHead* heads,
-                float* const* outs, const int* ldos, float* losses, int sum_losses, hipStream_t s) {
+                float* const* outs, const int* ldos, float* losses, int sum_losses, hipStream_t s,
+                int* split_out = nullptr) {
   static RowStepScratch sc;
   RowStepArgs a;
   memset(&a, 0, sizeof(a));
@@ -1076,6 +1078,7 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
     else hipLaunchKernelGGL(mlp_rowstep_kernel<1>, dim3(gx, (unsigned)nnet), dim3(512), smem, s, a);
   }
   g_rowstep_last_split = splitf ? (splitb ? 2 : 1) : 0;
+  if (split_out) *split_out = g_rowstep_last_split;
   PA_LAUNCH_CHECK();
   // the state a kept forward + a want_dw = 2 backward leave behind: the weight gradients (and
   // AdamW) of the next pa_mlp_adam / pa_mlp_adam2 / pa_mlp_flush_grads2 on these networks
@@ -2897,11 +2900,12 @@ extern "C" int pa_bandit_step(const pa_bandit_step_args* g, void* stream) {
   //  outputs are not kept)
   float* outs[1] = {g->out_act == PA_OUT_LINEAR ? g->pred : nullptr};
   const int ldos[1] = {1};
-  int rc = run_rowstep(hs, 1, g->x, g->ldx, g->B, &head, outs, ldos, g->scalars, 1, s);
+  int ran_split = 0;
+  int rc = run_rowstep(hs, 1, g->x, g->ldx, g->B, &head, outs, ldos, g->scalars, 1, s, &ran_split);
   if (rc != PA_OK) return rc;
   PA_REQUIRE(net->pend.active, PA_ERR_INVALID, "pa_bandit_step: the row step left no pending gradients");
   // the features of THIS forward (the trunk's output, kept by the row step) feed the regression
-  if (g_rowstep_last_split != 0) {
+  if (ran_split != 0) {
     rc = linreg_operands(net->act[net->L - 2], net->d.dims[net->L - 1], g->y, nullptr, g->B, g->d,
                          g->x_scratch, g->r_scratch, 1, s);
     if (rc != PA_OK) return rc;
