@@ -472,6 +472,11 @@ def main():
             base = reference_cpu_baseline()
             line["cpu_baseline"] = base if base is not None else cpu_baseline()
         print(json.dumps(line), flush=True)
+    if os.environ.get("PEARL_AMD_DEBUG_WORKERS") == "1" and rank == 0:
+        w, n = C.c_int64(), C.c_int64()
+        N.check(N.lib().pa_debug_target_workers(nat.handle, C.byref(w), C.byref(n)))
+        print(f"[debug] persistent target launches: {n.value}, workgroups that took tiles: "
+              f"{w.value} ({w.value / max(1, n.value):.1f} per launch)", file=sys.stderr, flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

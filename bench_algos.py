@@ -662,6 +662,105 @@ def reference_baselines(configs, seconds, threads=32):
         return {}
 
 
+def _max_rel(got, ref, floor=0.01):
+    """bench.py's metric: max |got - ref| / |ref| over the elements with |ref| >= floor * max |ref|,
+    and max |got - ref| / max |ref| over all of them."""
+    got, ref = got.double().cpu().reshape(-1), ref.double().cpu().reshape(-1)
+    d = (got - ref).abs()
+    big = ref.abs() >= floor * ref.abs().max()
+    return float((d[big] / ref.abs()[big]).max()), float(d.max() / ref.abs().max())
+
+
+def parity_probe(name):
+    """Observed error of the HIP path against the REFERENCE's own outputs on the config's full-size
+    fixture (tests/golden/{sac_cfg3,ppo_cfg4,bandit_cfg5}_fullbatch.pt — minted by
+    oracle/make_golden_ac.py from the real reference): the one-batch quantities north_star's 1e-5 bar
+    is about (Q-values / action probabilities / predictions) and the first step's reported losses.
+    VERDICT r4 weak-2: the driver line carried this figure for the DQN only."""
+    from pearl_amd import TransitionBatch
+    gold = os.path.join(REPO, "tests", "golden")
+    fixture = {"sac": "sac_cfg3_fullbatch.pt", "ppo": "ppo_cfg4_fullbatch.pt",
+               "bandit": "bandit_cfg5_fullbatch.pt"}[name]
+    path = os.path.join(gold, fixture)
+    if not os.path.exists(path):
+        return None
+    fx = torch.load(path, map_location="cpu", weights_only=False)
+    cfg = fx["config"]
+    out = {"fixture": f"tests/golden/{fixture} (outputs of the reference, B={cfg['B']})",
+           "rel_floor": "|ref| >= 0.01 max|ref|"}
+    if name == "sac":
+        from pearl_amd import BasicReplayBuffer, BoxActionSpace, ContinuousSoftActorCritic, PearlAgent
+        pl = ContinuousSoftActorCritic(action_space=BoxActionSpace(fx["low"], fx["high"]),
+                                       state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"],
+                                       critic_hidden_dims=cfg["hidden"], batch_size=cfg["B"])
+        pl._actor.load_state_dict(fx["actor0"])
+        pl._critic.load_state_dict(fx["critic0"])
+        pl._critic_target.load_state_dict(fx["critic_target0"])
+        PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=DEV.index or 0)
+        actor, c1, c2 = pl._nets(cfg["B"])
+        b = TransitionBatch(**{k: v.to(DEV) for k, v in fx["batch"].items()})
+        S, A = cfg["S"], cfg["A"]
+        pl.noise_source = lambda B, A_, dev: fx["probe"]["noise"]
+        xa = torch.empty(b.state.shape[0], S + A, device=DEV)
+        xa[:, :S].copy_(b.state)
+        _, _, logp = pl._sample(actor, b.state.contiguous(), xa, keep=False)
+        out["max_rel_action"], out["max_abs_over_scale_action"] = _max_rel(xa[:, S:], fx["probe"]["action"])
+        out["max_rel_q1"], out["max_abs_over_scale_q1"] = _max_rel(c1.forward(xa).view(-1), fx["probe"]["q1"])
+        out["max_rel_q2"], out["max_abs_over_scale_q2"] = _max_rel(c2.forward(xa).view(-1), fx["probe"]["q2"])
+        out["max_rel_q_values"] = max(out["max_rel_q1"], out["max_rel_q2"])
+        (na, nc), want = fx["noises"][0], fx["reports"][0]
+        seq = iter([na, nc])
+        pl.noise_source = lambda B, A_, dev: next(seq)
+        got = pl.learn_batch(pl.preprocess_batch(b))
+        out["first_step_loss_rel"] = {k: abs(float(got[k]) - want[k]) / max(1.0, abs(want[k])) for k in want}
+    elif name == "ppo":
+        from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
+                               ProximalPolicyOptimization)
+        A, N = cfg["A"], cfg["N"]
+        pl = ProximalPolicyOptimization(
+            action_space=dspace(A), state_dim=cfg["S"], actor_hidden_dims=cfg["hidden"],
+            critic_hidden_dims=cfg["hidden"], training_rounds=cfg["rounds"], batch_size=cfg["B"],
+            epsilon=cfg["epsilon"], action_representation_module=OneHotActionTensorRepresentationModule(A))
+        pl._actor.load_state_dict(fx["actor0"])
+        pl._critic.load_state_dict(fx["critic0"])
+        rb = PPOReplayBuffer(N + 5, sampler="python")
+        PearlAgent(pl, replay_buffer=rb, device_id=DEV.index or 0)
+        sp = dspace(A)
+        for i in range(N):
+            rb.push(state=fx["states"][i], action=torch.tensor([int(fx["actions"][i])]),
+                    reward=float(fx["rewards"][i]), terminated=bool(fx["terminated"][i]),
+                    truncated=bool(fx["truncated"][i]), curr_available_actions=sp,
+                    next_state=fx["states"][i + 1], next_available_actions=sp, max_number_actions=A)
+        pl.preprocess_replay_buffer(rb)
+        out["max_rel_action_probs"], out["max_abs_over_scale_action_probs"] = _max_rel(
+            rb.extra["action_probs"], fx["action_probs"].view(-1))
+        out["max_rel_gae"], out["max_abs_over_scale_gae"] = _max_rel(rb.extra["gae"], fx["gae"])
+        out["max_rel_lam_return"], out["max_abs_over_scale_lam_return"] = _max_rel(rb.extra["lam_return"],
+                                                                                   fx["lam_return"])
+        import random as _r
+        _r.seed(fx["learn_seed"])
+        rep = pl.learn(rb)
+        out["first_step_loss_rel"] = {
+            "actor_loss": abs(rep["actor_loss"][0] - float(fx["actor_losses"][0])) / max(1.0, abs(float(fx["actor_losses"][0]))),
+            "critic_loss": abs(rep["critic_loss"][0] - float(fx["critic_losses"][0])) / max(1.0, abs(float(fx["critic_losses"][0])))}
+    else:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from test_oracle_ac_golden import bandit_batches
+        from pearl_amd import NeuralLinearBandit
+        pl = NeuralLinearBandit(feature_dim=cfg["F"], hidden_dims=cfg["hidden"], batch_size=cfg["B"],
+                                learning_rate=1e-3, loss_type=cfg.get("loss", "mse"),
+                                output_activation_name=cfg.get("out", "linear"))
+        pl.model.load_state_dict(fx["model0"])
+        pl.to(DEV)
+        (x, r, w), want = next(iter(zip(bandit_batches(fx), fx["reports"])))
+        tb = TransitionBatch(state=x.to(DEV), action=torch.zeros(cfg["B"], 1, device=DEV),
+                             reward=r.to(DEV), weight=None if w is None else w.to(DEV))
+        rep = pl.learn_batch(tb)
+        out["max_rel_prediction"], out["max_abs_over_scale_prediction"] = _max_rel(rep["prediction"], want["prediction"])
+        out["first_step_loss_rel"] = {"loss": abs(float(rep["loss"]) - want["loss"]) / max(1.0, abs(want["loss"]))}
+    return {k: v for k, v in out.items() if v is not None}
+
+
 def driver_block(cpu_seconds=4.0):
     """bench.py's `other_configs`: BASELINE.json configs[2..4] (SAC / PPO / bandit on one MI355X)
     measured in the driver's own bench run — value through learn(), whole-step roofline fraction,
@@ -693,6 +792,12 @@ def driver_block(cpu_seconds=4.0):
                         "kernel_pipe": dom["pipe"], "kernels": ks})
         if "preprocess_replay_buffer" in r:
             row["preprocess_replay_buffer"] = r["preprocess_replay_buffer"]
+        try:
+            par = parity_probe(name)
+            if par is not None:
+                row["parity"] = par
+        except Exception as e:
+            row["parity"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         rows.append(row)
     ref = reference_baselines([r["config"] for r in rows], cpu_seconds) if cpu_seconds > 0 else {}
     for r in rows:

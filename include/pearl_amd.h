@@ -346,11 +346,19 @@ int pa_comm_info(pa_comm* c, int32_t* ranks_out, int32_t* rank_out);
  * Bring-up: every rank calls pa_comm_create_p2p (world <= 8, messages of up to max_floats floats),
  * exchanges pa_comm_p2p_handle()'s 64 bytes with its peers (torch.distributed in pearl_amd/_comm.py)
  * and maps them with pa_comm_p2p_open; pa_comm_allreduce_start / _wait / pa_comm_info / _destroy
- * then work as above.  pa_comm_p2p_check: PA_ERR_HIP once a bounded wait for a peer has expired. */
+ * then work as above.  The wait for a peer's round counter is bounded (PEARL_AMD_P2P_TIMEOUT_S,
+ * default 30 s) so that a dead peer cannot hang the GPU; RCCL would block instead.  A wait that
+ * expires never yields a sum: the round's gradient is overwritten with NaN, a STICKY error is
+ * raised, and every later exchange on the communicator is refused (the ranks are no longer in
+ * lock-step).  pa_comm_p2p_check / pa_comm_check (any communicator; PA_OK for RCCL ones) report it —
+ * one read of a pinned host word, meant to follow the host sync that ends a learn() call.
+ * pa_comm_max_floats: the largest message one exchange takes (0 = unlimited); callers chunk. */
 int pa_comm_create_p2p(pa_comm** out, int32_t device, int32_t world, int32_t rank, int64_t max_floats);
 int pa_comm_p2p_handle(pa_comm* c, void* handle64_out);
 int pa_comm_p2p_open(pa_comm* c, int32_t peer, const void* handle64);
 int pa_comm_p2p_check(pa_comm* c);
+int pa_comm_check(pa_comm* c);
+int64_t pa_comm_max_floats(pa_comm* c);
 int pa_comm_allreduce_start(void* comm, float* buf, int64_t n, void* stream);
 int pa_comm_allreduce_wait(void* comm, void* stream);
 
@@ -388,6 +396,15 @@ typedef struct pa_mlp_desc {
                            neural_linear_regression.py:84-86); its bias slot stays zero */
   int32_t identity_layers; /* bit l set: hidden layer l has NO ReLU (the output layer of
                               NeuralLinearRegression._nn_layers, :65-75); the last layer never has */
+  /* mlp_block's other forms (common/utils.py:75-152; round 5).  Networks that use either run layer
+   * by layer (GEMM launches + row-local normalisation / activation kernels, mlp_norm_act.hpp), not
+   * through the fused row-pass kernels; the fused multi-network steps refuse them
+   * (PA_ERR_UNSUPPORTED).  batch norm, dropout and residual blocks are not built. */
+  int32_t hidden_act;      /* ActivationType of the hidden layers (utils.py:29-56): 0 relu, 1 leaky_relu
+                              (slope 0.01), 2 tanh, 3 softplus (beta 1, threshold 20), 4 sigmoid */
+  int32_t layer_norm;      /* 1: nn.LayerNorm(d_{l+1}) (eps 1e-5, affine) between every hidden Linear
+                              and its activation (utils.py:110-113).  Its weight / bias are parameters:
+                              they follow the W / b block of the flat buffers (pa_mlp_norm_offsets) */
 } pa_mlp_desc;
 typedef struct pa_mlp_buffers {
   float* p;
@@ -400,6 +417,9 @@ typedef struct pa_mlp_buffers {
 int64_t pa_mlp_param_count(const pa_mlp_desc* d);
 /* offsets[2 * n_layers]: W_0, b_0, W_1, b_1, ... */
 int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets);
+/* layer_norm = 1: offsets[2 * (n_layers - 1)]: gamma_0, beta_0, gamma_1, beta_1, ... of the hidden
+ * layers' LayerNorms (each d_{l+1} floats) */
+int pa_mlp_norm_offsets(const pa_mlp_desc* d, int64_t* offsets);
 int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc);
 int pa_mlp_destroy(pa_mlp* h);
 int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* bufs);
@@ -1008,6 +1028,10 @@ int pa_debug_set_dw_split(int32_t mode);
  * tile; 0 = the default: per pass (32 for Double DQN's stand-alone passes, 64 for the DQN window
  * loop), or what PEARL_AMD_TARGET_ROWS says.  Bitwise-identical results either way. */
 int pa_debug_set_target_rows(int32_t rows);
+/* PEARL_AMD_DEBUG_WORKERS=1: how many workgroups took tiles in the persistent target launches of learn() so far */
+/* diagnostics: copy a workspace of the last learner step ("H1a", "H2a", "dZ2", "dZ1", "dq", "q") to out_dev */
+int pa_debug_workspace(pa_dqn* h, const char* name, float* out_dev, int64_t n, int32_t* paired_out);
+int pa_debug_target_workers(pa_dqn* h, int64_t* workers_out, int64_t* launches_out);
 /* dW[M,N] = dZ[Bn,M]^T X[Bn,N], db[M] = column sums of dZ. */
 int pa_debug_weight_grad(const float* dZ, int32_t ldz, const float* X, int32_t ldx, float* dW,
                          int32_t ldw, float* db, int32_t M, int32_t N, int32_t Bn, void* stream);

@@ -86,6 +86,23 @@ QNET_CONFIGS = {
                          network="dueling"),
     "dueling_double_small": dict(S=16, A=6, hidden=[32, 32], N=300, B=64, rounds=8, dynamic=False,
                                  network="dueling", learner="double"),
+    # mlp_block's other forms (common/utils.py:75-152; round 5): nn.LayerNorm between every hidden
+    # Linear and its activation (q_value_networks.py:137 use_layer_norm) and the other hidden
+    # activations of ActivationType (utils.py:29-56), as `network_instance`s of DeepQLearning / DoubleDQN
+    "layernorm_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=True,
+                           network="vanilla", use_layer_norm=True),
+    "layernorm_small": dict(S=16, A=6, hidden=[64, 48], N=300, B=64, rounds=8, dynamic=False,
+                            network="vanilla", use_layer_norm=True),
+    "layernorm_multihead_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=True,
+                                     network="multihead", use_layer_norm=True, learner="double"),
+    "leaky_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=True,
+                       network="vanilla", hidden_activation="leaky_relu"),
+    "tanh_layernorm_small": dict(S=16, A=6, hidden=[64, 48], N=300, B=64, rounds=8, dynamic=False,
+                                 network="vanilla", hidden_activation="tanh", use_layer_norm=True),
+    "softplus_tiny": dict(S=5, A=5, hidden=[24, 16, 12], N=48, B=16, rounds=11, dynamic=True,
+                          network="vanilla", hidden_activation="softplus"),
+    "sigmoid_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=False,
+                         network="vanilla", hidden_activation="sigmoid"),
 }
 NETWORK_TYPES = {"vanilla": VanillaQValueNetwork, "multihead": VanillaQValueMultiHeadNetwork,
                  "dueling": DuelingQValueNetwork}
@@ -140,6 +157,21 @@ def make(name, cfg):
     qnet = "network" in cfg
     if qnet:
         extra["network_type"] = NETWORK_TYPES[cfg["network"]]
+    if qnet and (cfg.get("use_layer_norm") or cfg.get("hidden_activation")):
+        # a network_instance in one of mlp_block's other forms: LayerNorm through the network's own
+        # use_layer_norm argument, another hidden activation by rebuilding its _model with mlp_block
+        from pearl.neural_networks.common.utils import mlp_block
+        multi = cfg["network"] == "multihead"
+        net = NETWORK_TYPES[cfg["network"]](
+            state_dim=S, action_dim=A, hidden_dims=cfg["hidden"], output_dim=A if multi else 1,
+            use_layer_norm=bool(cfg.get("use_layer_norm")))
+        if cfg.get("hidden_activation"):
+            net._model = mlp_block(input_dim=S if multi else S + A, hidden_dims=cfg["hidden"],
+                                   output_dim=A if multi else 1,
+                                   use_layer_norm=bool(cfg.get("use_layer_norm")),
+                                   hidden_activation=cfg["hidden_activation"])
+        extra.pop("network_type")
+        extra["network_instance"] = net
     pl = (DoubleDQN if double else DeepQLearning)(**extra, state_dim=S, action_space=space(A), hidden_dims=cfg["hidden"],
                        training_rounds=cfg["rounds"], batch_size=B,
                        action_representation_module=rep)

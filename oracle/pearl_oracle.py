@@ -372,13 +372,32 @@ class DqnOracle:
 # --------------------------------------------------------------------------------------
 # Q-network architectures beyond the two-hidden-layer VanillaQValueNetwork
 # --------------------------------------------------------------------------------------
-def _mlp_sd(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """mlp_block (common/utils.py:75-152) from state-dict tensors `prefix`{i}.0.weight/bias:
-    Linear + ReLU for every layer but the last."""
+# ActivationType (common/utils.py:29-56) as formulas: nn.LeakyReLU() slope 0.01, nn.Softplus() beta 1 /
+# threshold 20
+_HIDDEN_ACTS = {
+    "relu": lambda z: torch.clamp_min(z, 0),
+    "leaky_relu": lambda z: torch.where(z > 0, z, 0.01 * z),
+    "tanh": torch.tanh,
+    "softplus": lambda z: torch.where(z > 20, z, torch.log1p(torch.exp(z))),
+    "sigmoid": lambda z: 1.0 / (1.0 + torch.exp(-z)),
+    "linear": lambda z: z,
+}
+
+
+def _mlp_sd(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor,
+            hidden_activation: str = "relu") -> torch.Tensor:
+    """mlp_block (common/utils.py:75-152) from state-dict tensors `prefix`{i}.0.weight/bias: Linear
+    [+ nn.LayerNorm when `prefix`{i}.1.weight exists: between the Linear and its activation,
+    utils.py:110-113; biased variance, eps 1e-5] + the hidden activation for every layer but the last."""
+    act = _HIDDEN_ACTS[hidden_activation]
     i = 0
     while f"{prefix}{i + 1}.0.weight" in w:
-        x = torch.clamp_min(torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"],
-                                                       w[f"{prefix}{i}.0.bias"]), 0)
+        x = torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"], w[f"{prefix}{i}.0.bias"])
+        if f"{prefix}{i}.1.weight" in w:
+            mu = x.mean(dim=-1, keepdim=True)
+            var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+            x = (x - mu) / torch.sqrt(var + 1e-5) * w[f"{prefix}{i}.1.weight"] + w[f"{prefix}{i}.1.bias"]
+        x = act(x)
         i += 1
     return torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"], w[f"{prefix}{i}.0.bias"])
 
@@ -395,9 +414,10 @@ class QNetOracle:
     def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor], kind: str,
                  double_q: bool = False, gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.01, tau: float = 0.75,
-                 target_update_freq: int = 10) -> None:
+                 target_update_freq: int = 10, hidden_activation: str = "relu") -> None:
         assert kind in ("vanilla", "multihead", "dueling")
         self.kind, self.double_q = kind, bool(double_q)
+        self.act = hidden_activation      # (LayerNorm is read off the state dict's keys)
         self.keys = list(params.keys())
         self.p = {k: params[k].detach().clone().to(F32) for k in self.keys}
         self.t = {k: target[k].detach().clone().to(F32) for k in self.keys}
@@ -415,9 +435,9 @@ class QNetOracle:
         B, Q = acts.shape[0], acts.shape[1]
         if self.kind == "vanilla":
             s = state.unsqueeze(1).expand(B, Q, state.shape[1])
-            out = _mlp_sd(w, "_model.", torch.cat([s, acts], dim=-1)).squeeze(-1)
+            out = _mlp_sd(w, "_model.", torch.cat([s, acts], dim=-1), self.act).squeeze(-1)
         elif self.kind == "multihead":
-            f = _mlp_sd(w, "_model.", state).unsqueeze(-1)                   # (B, A, 1)
+            f = _mlp_sd(w, "_model.", state, self.act).unsqueeze(-1)         # (B, A, 1)
             out = torch.bmm(acts, f).squeeze(-1)
         else:
             feats = _mlp_sd(w, "state_arch._model.", state)

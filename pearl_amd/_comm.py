@@ -111,6 +111,14 @@ def _p2p_comm(dev: torch.device) -> Optional[C.c_void_p]:
     return handle
 
 
+def _forget_comm() -> None:
+    """tests: drop (and destroy) the process's communicator so that the next call builds a new one"""
+    h = _state["handle"]
+    if h is not None:
+        N.lib().pa_comm_destroy(h)
+    _state.update(handle=None, failed=False, device=None, kind=None)
+
+
 def comm_info() -> dict:
     """What the gradient exchange of this process runs on (bench lines report it): the rank count
     RCCL itself reports for the communicator, not the one that was asked for."""
@@ -128,18 +136,43 @@ def comm_info() -> dict:
     return info
 
 
+def check_exchange() -> None:
+    """Raise if the process's native communicator has been poisoned (the P2P exchange's bounded
+    wait for a peer expired: that round's gradient is NaN, the ranks are out of lock-step).  One
+    read of a pinned host word; the learners call it after the host sync that ends a data-parallel
+    ``learn()`` / step, so a lagging or dead peer is an exception at the call that hit it, not
+    silently diverging replicas.  RCCL communicators never report: RCCL blocks instead."""
+    h = _state["handle"]
+    if h is not None:
+        N.check(N.lib().pa_comm_check(h))
+
+
 def allreduce_sum_(flat: torch.Tensor, force: bool = False) -> torch.Tensor:
-    """SUM over the data-parallel group, in place, ONE message.  Identity with a single rank unless
-    ``force`` (a 1-rank communicator still goes through RCCL: the bench's readiness run)."""
+    """SUM over the data-parallel group, in place.  Identity with a single rank unless ``force``
+    (a 1-rank communicator still goes through RCCL: the bench's readiness run).  ONE message through
+    RCCL; the P2P exchange takes messages of up to its slot size (``pa_comm_max_floats``) at 16-byte
+    aligned addresses: longer ones go in slot-sized pieces, misaligned ones through
+    ``torch.distributed.all_reduce`` — sizes and offsets are the same on every rank, so every rank
+    takes the same route."""
     if world_size() <= 1 and not force:
         return flat
     if not (dist.is_available() and dist.is_initialized()):
         return flat
     h = native_comm(flat.device) if flat.is_cuda else None
-    if h is not None:
+    if h is not None and flat.dtype == torch.float32 and flat.is_contiguous():
+        lib = N.lib()
+        N.check(lib.pa_comm_check(h))      # an earlier exchange's expired wait surfaces here at the latest
         s = N.stream_ptr(flat.device)
-        N.check(N.lib().pa_comm_allreduce_start(h, flat.data_ptr(), flat.numel(), s))
-        N.check(N.lib().pa_comm_allreduce_wait(h, s))
-        return flat
+        cap = int(lib.pa_comm_max_floats(h))
+        n, ptr = flat.numel(), flat.data_ptr()
+        if cap <= 0 or n <= cap:
+            pieces = [(0, n)]
+        else:
+            pieces = [(o, min(cap, n - o)) for o in range(0, n, cap)]     # (cap is a multiple of 64 floats)
+        if cap <= 0 or ptr % 16 == 0:
+            for off, cnt in pieces:
+                N.check(lib.pa_comm_allreduce_start(h, ptr + 4 * off, cnt, s))
+                N.check(lib.pa_comm_allreduce_wait(h, s))
+            return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat

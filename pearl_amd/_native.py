@@ -190,6 +190,8 @@ class MlpDesc(C.Structure):
         ("amsgrad", C.c_int32),
         ("no_last_bias", C.c_int32),
         ("identity_layers", C.c_int32),
+        ("hidden_act", C.c_int32),
+        ("layer_norm", C.c_int32),
     ]
 
 
@@ -418,6 +420,8 @@ SIGNATURES = {
     "pa_comm_p2p_handle": (C.c_int, [_P, _P]),
     "pa_comm_p2p_open": (C.c_int, [_P, C.c_int32, _P]),
     "pa_comm_p2p_check": (C.c_int, [_P]),
+    "pa_comm_check": (C.c_int, [_P]),
+    "pa_comm_max_floats": (C.c_int64, [_P]),
     "pa_comm_allreduce_start": (C.c_int, [_P, _P, C.c_int64, _P]),
     "pa_comm_allreduce_wait": (C.c_int, [_P, _P]),
     "pa_dqn_enable_timing": (C.c_int, [_P, C.c_int32]),
@@ -426,6 +430,7 @@ SIGNATURES = {
     "pa_gather_rows": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P]),
     "pa_mlp_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
     "pa_mlp_param_offsets": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_int64)]),
+    "pa_mlp_norm_offsets": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_int64)]),
     "pa_mlp_create": (C.c_int, [C.POINTER(_P), C.POINTER(MlpDesc)]),
     "pa_mlp_destroy": (C.c_int, [_P]),
     "pa_mlp_bind": (C.c_int, [_P, C.POINTER(MlpBuffers)]),
@@ -521,6 +526,8 @@ SIGNATURES = {
     "pa_mlp_timing": (C.c_int, [C.c_int32]),
     "pa_debug_set_dw_split": (C.c_int, [C.c_int32]),
     "pa_debug_set_target_rows": (C.c_int, [C.c_int32]),
+    "pa_debug_workspace": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.POINTER(C.c_int32)]),
+    "pa_debug_target_workers": (C.c_int, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pa_debug_set_rowstep_split": (C.c_int, [C.c_int32]),
     "pa_rowstep_last_split": (C.c_int, []),
     "pa_mlp_timing_read": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

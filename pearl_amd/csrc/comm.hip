@@ -76,7 +76,11 @@ struct P2P {
   float* peer[kP2PMaxWorld] = {};   // peer[r]: rank r's allocation as mapped here (peer[rank] = mine)
   int64_t max_floats = 0;
   unsigned round = 0;               // rounds published so far (host copy)
-  int* err_host = nullptr;          // pinned, device-mapped: non-zero = a bounded wait expired
+  int* err_host = nullptr;          // pinned, device-mapped: non-zero = a bounded wait expired.  STICKY:
+                                    // once set the communicator is poisoned — the ranks are no longer in
+                                    // lock-step, the two-slot reuse argument is void — and every later
+                                    // exchange is refused (p2p_allreduce, pa_comm_allreduce_wait, pa_comm_p2p_check)
+  long long timeout_ticks = 0;      // bound of the peer-flag wait in 100 MHz wall-clock ticks
   int opened = 0;
 };
 
@@ -163,6 +167,7 @@ struct P2PArgs {
   int world, rank;
   unsigned round;
   int* err;
+  long long timeout_ticks;   // wall_clock64() ticks (100 MHz) a block waits for a peer's flag
 };
 __global__ __launch_bounds__(256) void p2p_publish_kernel(P2PArgs a) {
   const long long n4 = a.n >> 2;
@@ -173,28 +178,53 @@ __global__ __launch_bounds__(256) void p2p_publish_kernel(P2PArgs a) {
   if (blockIdx.x == 0)
     for (long long i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) a.mine_slot[i] = a.grad[i];
 }
+// A wait that expires NEVER produces a sum: the block stores NaN over its share of grad (the local,
+// unreduced gradient must not step the optimizer as if it were the group's: RCCL would have blocked
+// here) and raises the sticky error word; blocks that start after the word is up do the same at once.
 __global__ __launch_bounds__(256) void p2p_reduce_kernel(P2PArgs a) {
+  __shared__ int dead;
+  if (threadIdx.x == 0)
+    dead = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 ? 1 : 0;
+  __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // (the publish launch has completed: its stores are released at system scope already; the
     //  fence keeps this store behind anything else this thread has issued)
     __atomic_thread_fence(__ATOMIC_RELEASE);
     __hip_atomic_store(a.flag_mine, a.round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  if (threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank) {
+  if (!dead && threadIdx.x < (unsigned)a.world && (int)threadIdx.x != a.rank) {
     const unsigned* f = a.flag[threadIdx.x];
+    const long long t0 = wall_clock64();
     int spins = 0;
     // rounds compare modulo 2^32 (a peer is at most one round ahead)
     while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - a.round) < 0) {
       __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1 << 22)) {   // seconds: a peer is gone — report, do not hang the GPU
-        if (a.err) *a.err = 1 + (int)threadIdx.x;
+      // every 256 polls: the clock, and the error word another block / an earlier round may have raised
+      if ((++spins & 255) == 0 &&
+          (wall_clock64() - t0 > a.timeout_ticks ||
+           __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0)) {
+        // a peer lags by more than the bound (default 30 s; a rank that checkpoints or evaluates
+        // lags by far less) or is gone: report, do not hang the GPU, and do NOT use its slot
+        // (a plain store: PCIe atomics to pinned host memory are not a given; when several waits
+        //  expire the word names one of the late peers)
+        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0)
+          __hip_atomic_store(a.err, 1 + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        dead = 1;
         break;
       }
     }
   }
   __syncthreads();
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: nothing below reads a stale line
   const long long n4 = a.n >> 2;
+  if (dead) {
+    const float nanv = __builtin_nanf("");
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256)
+      reinterpret_cast<float4*>(a.grad)[i] = make_float4(nanv, nanv, nanv, nanv);
+    if (blockIdx.x == 0)
+      for (long long i = (n4 << 2) + threadIdx.x; i < a.n; i += 256) a.grad[i] = nanv;
+    return;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: nothing below reads a stale line
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     float4 acc = reinterpret_cast<const float4*>(a.slot[0])[i];
     for (int r = 1; r < a.world; ++r) {
@@ -249,6 +279,14 @@ extern "C" int pa_comm_create_p2p(pa_comm** out, int32_t device, int32_t world, 
   PA_HIP(hipDeviceSynchronize());
   PA_HIP(hipHostMalloc((void**)&x->err_host, 16, hipHostMallocMapped));
   x->err_host[0] = 0;
+  {
+    // RCCL would block for as long as a peer takes; this exchange bounds the wait so that a dead
+    // peer cannot hang the GPU — generously (PEARL_AMD_P2P_TIMEOUT_S, default 30 s)
+    const char* v = getenv("PEARL_AMD_P2P_TIMEOUT_S");
+    double sec = (v && *v) ? atof(v) : 30.0;
+    if (!(sec > 0.0)) sec = 30.0;
+    x->timeout_ticks = (long long)(sec * 1e8);
+  }
   x->peer[rank] = x->mine;
   x->opened = 1;
   *out = c;
@@ -276,19 +314,46 @@ extern "C" int pa_comm_p2p_open(pa_comm* c, int32_t peer, const void* handle64) 
   c->p2p->opened += 1;
   return PA_OK;
 }
+namespace {
+bool p2p_poisoned(pa_comm* c) {
+  const int e = __atomic_load_n(c->p2p->err_host, __ATOMIC_RELAXED);
+  if (e == 0) return false;
+  set_error("P2P exchange: the wait for rank %d's gradient expired (PEARL_AMD_P2P_TIMEOUT_S); that "
+            "round's gradient was overwritten with NaN and the communicator is poisoned — the ranks "
+            "are no longer in lock-step",
+            e - 1);
+  return true;
+}
+}  // namespace
 // non-zero status when a bounded wait for a peer expired since the communicator was created
+// (sticky).  Cheap — one read of a pinned host word — and meant for the hot path: the learners call
+// it after the host sync that ends every learn() / step.
 extern "C" int pa_comm_p2p_check(pa_comm* c) {
   PA_REQUIRE(c && c->p2p, PA_ERR_INVALID, "pa_comm_p2p_check: not a P2P communicator");
-  PA_REQUIRE(c->p2p->err_host[0] == 0, PA_ERR_HIP,
-             "P2P exchange: the wait for rank %d's gradient expired; the sums of that round are invalid",
-             c->p2p->err_host[0] - 1);
-  return PA_OK;
+  return p2p_poisoned(c) ? PA_ERR_HIP : PA_OK;
 }
+// any communicator: PA_OK for RCCL ones (RCCL blocks instead of expiring), the sticky P2P status otherwise
+extern "C" int pa_comm_check(pa_comm* c) {
+  PA_REQUIRE(c, PA_ERR_INVALID, "pa_comm_check: null communicator");
+  return (c->p2p && p2p_poisoned(c)) ? PA_ERR_HIP : PA_OK;
+}
+// the largest message (floats) one exchange takes: the P2P slot size; 0 = unlimited (RCCL)
+extern "C" int64_t pa_comm_max_floats(pa_comm* c) { return (c && c->p2p) ? c->p2p->max_floats : 0; }
 
 namespace {
 int p2p_allreduce(pa_comm* c, float* buf, int64_t n, hipStream_t s) {
   P2P* x = c->p2p;
-  if (x->opened != c->world || n > x->max_floats || (reinterpret_cast<uintptr_t>(buf) & 15)) return 1;
+  if (p2p_poisoned(c)) return 1;      // (set_error inside)
+  if (x->opened != c->world) {
+    set_error("P2P exchange: %d of %d peer buffers are mapped", x->opened, c->world);
+    return 1;
+  }
+  if (n > x->max_floats || (reinterpret_cast<uintptr_t>(buf) & 15)) {
+    set_error("P2P exchange: a message of %lld floats at %p does not fit (slots of %lld floats, 16-byte "
+              "aligned; PEARL_AMD_P2P_FLOATS) — callers chunk or fall back (pearl_amd/_comm.py)",
+              (long long)n, (void*)buf, (long long)x->max_floats);
+    return 1;
+  }
   x->round += 1;
   const int slot = (int)(x->round & 1u);
   P2PArgs a;
@@ -302,6 +367,7 @@ int p2p_allreduce(pa_comm* c, float* buf, int64_t n, hipStream_t s) {
   }
   a.world = c->world; a.rank = c->rank; a.round = x->round;
   a.err = x->err_host;
+  a.timeout_ticks = x->timeout_ticks;
   unsigned grid = (unsigned)((n / 4 + 255) / 256);
   if (grid > 208) grid = 208;   // one wave of blocks: every block polls the peers' flags once
   if (grid < 1) grid = 1;
@@ -364,6 +430,9 @@ extern "C" int pa_comm_allreduce_start(void* ctx, float* buf, int64_t n, void* s
 extern "C" int pa_comm_allreduce_wait(void* ctx, void* stream) {
   pa_comm* c = reinterpret_cast<pa_comm*>(ctx);
   if (!c) return 1;
+  // (P2P: the exchange is asynchronous, so this sees an expiry of an EARLIER round at the latest
+  //  one round later; the learners' end-of-call pa_comm_check catches the last one)
+  if (c->p2p && p2p_poisoned(c)) return 1;
   if (c->inline_mode) return 0;
   return hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), c->done, 0) == hipSuccess ? 0 : 1;
 }

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "online_kernels.hpp"
+#include "online_pair_kernel.hpp"
 #include "target_pp_kernel.hpp"
 #include "host_launch.hpp"
 #include "sampler.hpp"
@@ -66,6 +67,18 @@ struct pa_dqn {
   int* choice;
   float* choice_rep;   // [max_batch][AD] representation of the chosen next action
   float *W1f, *W2f16, *W2tf;  // fragment-major copies of the online weights (online_rowpass_kernel)
+  // the row pass on two workgroups per 16-row tile (online_pair_kernel.hpp; PEARL_AMD_ROWPASS_PAIR=1,
+  // the benchmark's shape only; off by default — DESIGN.md §3.10 has the measurements): the halves'
+  // interleaved partials of dZ1, the pair's tagged exchange words, the halves' q partials of a
+  // forward / backward launch pair
+  int pair;            // 0: off
+  int pair_lds;        // dynamic LDS bytes asked for per workgroup (> 80 KB: one workgroup per CU)
+  bool pair_live;      // the last row pass wrote dZ1 as two interleaved partials (dZ1p)
+  bool qx_clean;       // every exchange word holds kYPendingBits
+  float* dZ1p;
+  unsigned* qx;
+  int qx_rows;
+  float* qhalf;
   // fused learn(): gathered batch (single stream, no events) + index lists of all rounds
   // learn(): the target-network side of a window (gather -> U -> Bellman targets y) runs on a
   // low-priority side stream into one of TWO buffer sets, while the main stream runs the
@@ -91,6 +104,11 @@ struct pa_dqn {
   int* sig;          // [4] generation word (monotonic, never reset)
   int sig_gen;       // last generation handed out
   int pending_signal;  // generation the NEXT row-pass launch publishes when it starts (0: none)
+  int pending_wait;    // generation of sig[1] the NEXT row-pass launch waits for before it reads x (0: none):
+                       // the side stream's gather of this window's x has completed (published by the
+                       // wait_flag_kernel launch behind that gather).  Replaces a hipStreamWaitEvent on the
+                       // learner stream, which costs ~6 us of idle stream per window even when the event
+                       // completed long ago (rocprof: gap in front of every window's first row pass)
   int use_flags;     // PEARL_AMD_FLAG_HOP (default 1); 0 = events as before
   int lead_persist;  // PEARL_AMD_LEAD_PERSIST: leading target pieces keep off the chain's CUs
   // the fragment-major copies (online + target) match the flat parameters: true after a learn()
@@ -115,6 +133,8 @@ struct pa_dqn {
   const pa_arena* sh_arena;
   int sh_gen, sh_onehot, sh_A, sh_enable;
   int* tile_ctr;           // [kTileCtrs] work-stealing counters, one per persistent launch
+  int* dbg_workers;        // PEARL_AMD_DEBUG_WORKERS: [2] device, participating workgroups of persistent launches
+  int64_t dbg_launches;
   int ctr_next;
   int pingpong;            // PEARL_AMD_PINGPONG: 1 (default) target_pp_kernel for the persistent
                            // launches of learn(), 2 for every launch, 0 never
@@ -230,8 +250,12 @@ static __global__ void signal_kernel(int* flag, int value) {
 // The bound is wall-clock time (the constant 100 MHz counter), and generous: in a data-parallel
 // run the producer — the learner stream — can legitimately sit in a collective for seconds (RCCL's
 // first-call set-up, a rank that is still filling its arena).
-static __global__ void wait_flag_kernel(const int* flag, int value, int* err, int* err_host) {
+// `done_flag` (optional): published when the launch STARTS — "everything enqueued on this stream
+// before me has completed" (the window's gather of x, for the learner stream's first row pass).
+static __global__ void wait_flag_kernel(const int* flag, int value, int* err, int* err_host,
+                                        int* done_flag = nullptr, int done_value = 0) {
   if (threadIdx.x != 0) return;
+  if (done_flag) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   constexpr long long kLimitTicks = 120LL * 100000000LL;     // 120 s
   const long long t0 = (long long)wall_clock64();
   int spins = 0;
@@ -433,6 +457,10 @@ int run_target_fused_u(pa_dqn* h, const pa_dqn_batch* b, const float* U, float* 
     }
     a.tile_ctr = h->tile_ctr + h->ctr_next++;
     a.reserved = persistent ? h->reserved_dev : nullptr;
+    if (a.reserved && h->dbg_workers) {
+      a.dbg_workers = h->dbg_workers;
+      h->dbg_launches += 1;
+    }
   }
   if (pp) return launch_target_pp(a, h->ncu, s);
   return launch_target(a, s);
@@ -578,6 +606,11 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
     a.signal_value = h->pending_signal;
     h->pending_signal = 0;
   }
+  if (h->pending_wait && phase != 2) {
+    a.wait_flag = h->sig + 1;
+    a.wait_value = h->pending_wait;
+    h->pending_wait = 0;
+  }
   a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_row : nullptr;
   a.H1a = y ? h->H1a : nullptr; a.H2a = y ? h->H2a : nullptr;
   a.dZ2 = h->dZ2; a.dZ1 = h->dZ1;
@@ -587,6 +620,43 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   a.B = B; a.K1 = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
   const dim3 grid((unsigned)ceil_div(B, RP_ROWS));
   const int g1 = wf16_nkg(h->IN), g2 = wf16_nkg(d.hidden1), g3 = wf16_nkg(d.hidden2);
+  if (h->pair && h->qx) {
+    // two workgroups per 16-row tile (online_pair_kernel.hpp): the benchmark's shape
+    PairArgs pa_;
+    memset(&pa_, 0, sizeof(pa_));
+    pa_.r = a;
+    pa_.dZ1p = h->dZ1p;
+    pa_.qx = h->qx; pa_.qx_rows = h->qx_rows;
+    pa_.qhalf = h->qhalf;
+    pa_.ntiles = (int)ceil_div(B, RP_ROWS);
+    if (phase == 2) { pa_.r.q_out = q_out; pa_.r.q_in = nullptr; }   // the backward launch reports Q(s, a)
+    if (!h->qx_clean) {
+      PA_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->qx), (int)kYPendingBits,
+                               (size_t)2 * h->qx_rows, s));
+      h->qx_clean = true;
+    }
+    size_t smem_p = pair_smem_bytes();
+    if ((size_t)h->pair_lds > smem_p) smem_p = (size_t)h->pair_lds;
+    const dim3 pgrid((unsigned)(16 * ceil_div(pa_.ntiles, 8)));
+#define PA_PAIR(PH_)                                                                          \
+  do {                                                                                        \
+    static size_t configured = 0;                                                             \
+    if (smem_p > configured) {                                                                \
+      int rc = set_max_smem(online_rowpass_pair_kernel<PH_>, smem_p);                          \
+      if (rc != PA_OK) return rc;                                                             \
+      configured = smem_p;                                                                    \
+    }                                                                                         \
+    hipLaunchKernelGGL((online_rowpass_pair_kernel<PH_>), pgrid, dim3(512), smem_p, s, pa_);   \
+  } while (0)
+    if (phase == 1) PA_PAIR(1);
+    else if (phase == 2) PA_PAIR(2);
+    else PA_PAIR(0);
+#undef PA_PAIR
+    PA_LAUNCH_CHECK();
+    if (y && phase != 1) h->pair_live = true;
+    return PA_OK;
+  }
+  if (y && phase != 1) h->pair_live = false;
   // fully unrolled instantiations for the shapes that matter; anything else takes the run-time loops
 #define PA_ROWPASS(N1, N2, N3)                                                               \
   do {                                                                                       \
@@ -678,6 +748,10 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   int t0 = (int)ceil_div(d.hidden2, TM) * a.p[0].tiles_n;
   // dW1 = dZ1^T x, db1
   a.p[1].dZ = h->dZ1; a.p[1].ldz = d.hidden1;
+  if (h->pair_live) {   // the two halves' partials, interleaved per pair of units (online_pair_kernel.hpp)
+    a.p[1].dZ = h->dZ1p; a.p[1].ldz = 2 * d.hidden1;
+    a.p[1].dz_pair = 1;
+  }
   a.p[1].X = x; a.p[1].ldx = h->IN;
   a.p[1].dW = G + h->off[0]; a.p[1].ldw = h->IN;
   a.p[1].db = G + h->off[1];
@@ -726,6 +800,11 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
       a.ad.oW2sp = h->use_split ? h->w2sp_online : nullptr;
       h->online_tgt_ok = true;
     }
+  }
+  if (h->pair_live) {
+    static const DwKernelFn kPairKernels[4] = {weight_grad_split_kernel32_pair, weight_grad_kernel32_pair,
+                                               weight_grad_split_kernel_pair, weight_grad_kernel_pair};
+    return launch_weight_grad(a, loss_out != nullptr, s, kPairKernels);
   }
   return launch_weight_grad(a, loss_out != nullptr, s);
 }
@@ -1065,6 +1144,11 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
+  h->pair = env_int("PEARL_AMD_ROWPASS_PAIR", 0);
+  h->pair_lds = env_int("PEARL_AMD_PAIR_LDS", 82 * 1024);
+  h->pair_live = false;
+  h->qx_clean = false;
+  h->dZ1p = nullptr; h->qx = nullptr; h->qhalf = nullptr; h->qx_rows = 0;
   h->choice = nullptr;
   h->Uw[0] = h->Uw[1] = h->yw[0] = h->yw[1] = nullptr;
   h->bb_x = nullptr;
@@ -1074,6 +1158,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->sig = nullptr;
   h->sig_gen = 0;
   h->pending_signal = 0;
+  h->pending_wait = 0;
   h->use_flags = env_int("PEARL_AMD_FLAG_HOP", 1);
   h->lead_persist = env_int("PEARL_AMD_LEAD_PERSIST", 0);
   h->err_dev = nullptr;
@@ -1089,6 +1174,8 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->n_reserved = 0;
   h->ncu = 0;
   h->tile_ctr = nullptr;
+  h->dbg_workers = nullptr;
+  h->dbg_launches = 0;
   h->ctr_next = 0;
   h->sh_rep = nullptr; h->sh_mask = nullptr; h->sh_stage = nullptr;
   h->sh_arena = nullptr; h->sh_gen = -1; h->sh_onehot = -1; h->sh_A = 0;
@@ -1137,6 +1224,12 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
     h->ncu = prop.multiProcessorCount;
   }
   h->pingpong = env_int("PEARL_AMD_PINGPONG", 1);
+  if (env_int("PEARL_AMD_DEBUG_WORKERS", 0)) {
+    float* g = nullptr;
+    PA_WS(g, 4);
+    h->dbg_workers = reinterpret_cast<int*>(g);
+    (void)hipMemset(h->dbg_workers, 0, 16);
+  }
   if (hipHostMalloc((void**)&h->err_host, 16, hipHostMallocDefault) != hipSuccess) {
     set_error("pa_dqn_create: error-word allocation failed");
     pa_dqn_destroy(h);
@@ -1162,6 +1255,16 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
+  if (h->pair && desc->hidden1 == PR_H && desc->hidden2 == PR_H && wf16_nkg(h->IN) == PR_NG1) {
+    float* w = nullptr;
+    h->qx_rows = (int)round_up(B, RP_ROWS);
+    PA_WS(h->dZ1p, 2 * B * desc->hidden1);
+    PA_WS(w, (int64_t)2 * h->qx_rows);
+    h->qx = reinterpret_cast<unsigned*>(w);
+    PA_WS(h->qhalf, 2 * B);
+  } else {
+    h->pair = 0;
+  }
   if (desc->double_q == 1) {
     if (h->w2sp) {
       float* sp = nullptr;
@@ -1184,7 +1287,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
                   h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp, h->w2sp_online, h->w1sp,
-                  h->choice, h->choice_rep};
+                  h->choice, h->choice_rep, h->dZ1p, h->qx, h->qhalf, h->dbg_workers};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1342,6 +1445,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   // prologue launch below (device sampler) or one memset (host index lists)
   if (args->idx_host) PA_HIP(hipMemsetAsync(h->tile_ctr, 0, (kTileCtrs + 4) * sizeof(int), s));
   h->ctr_next = 0;
+  if (h->err_host[0]) h->qx_clean = false;   // a bounded wait expired: exchange words may hold anything
   h->err_host[0] = 0;
   // Static action space: every stored row carries the same padded next-action table, so the
   // target pass reads ONE [A, AD] table with stride 0 and the window gather neither reads the
@@ -1415,7 +1519,8 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // head, the gather of x (no signal launch of its own)
     if (h->use_flags) {
       start_gen = ++h->sig_gen;
-      hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, start_gen, h->err_dev, h->err_host);
+      hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, start_gen, h->err_dev, h->err_host,
+                         (int*)nullptr, 0);
       PA_LAUNCH_CHECK();
     } else {
       rc = stream_hop(h, s, t, h->ev_start);
@@ -1513,7 +1618,10 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         // and it costs no launch of its own.
         const int gen = ++h->sig_gen;
         h->pending_signal = gen;
-        hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev, h->err_host);
+        static const bool x_by_flag = env_int("PEARL_AMD_X_FLAG", 1) != 0;
+        h->pending_wait = x_by_flag ? gen : 0;
+        hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev, h->err_host,
+                           x_by_flag ? h->sig + 1 : nullptr, gen);
         PA_LAUNCH_CHECK();
       } else {
         PA_HIP(hipStreamWaitEvent(t, h->ev_chain[(k - 1) & 1], 0));
@@ -1611,7 +1719,8 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
     // ---- main stream: the per-round chains.  x of the window was gathered by the side stream
     // (long ago for every window but the first): the event is normally already complete
     if (overlap && k > 0) {
-      PA_HIP(hipStreamWaitEvent(s, h->ev_gather[p], 0));
+      // (with the device-word hand-off the window's first row pass polls sig[1] itself: pending_wait)
+      if (!h->pending_wait) PA_HIP(hipStreamWaitEvent(s, h->ev_gather[p], 0));
     } else if (overlap && !head_emitted) {
       rc = emit_head();      // (no leading piece ran the hook: a one-piece window)
       if (rc != PA_OK) return rc;
@@ -1791,6 +1900,30 @@ extern "C" int pa_debug_linear(const float* A, int32_t lda, const float* B, int3
   PA_REQUIRE(epi == EPI_NONE || (epi == EPI_MASK ? hmask != nullptr : bias != nullptr), PA_ERR_INVALID,
              "epilogue %d needs %s", epi, epi == EPI_MASK ? "hmask" : "bias");
   return b_is_kn ? launch_linear<true>(&g, 1, s) : launch_linear<false>(&g, 1, s);
+}
+
+// Copy one of the learner's workspaces of the LAST step out (tools/debug_pair_traj.py): "H1a", "H2a",
+// "dZ2", "dZ1" (two interleaved partials when the paired row pass wrote it: 2 x the floats), "dq", "q"
+extern "C" int pa_debug_workspace(pa_dqn* h, const char* name, float* out_dev, int64_t n, int32_t* paired_out) {
+  PA_REQUIRE(h && name && out_dev && n > 0, PA_ERR_INVALID, "pa_debug_workspace: bad argument");
+  const std::string k(name);
+  const float* src = k == "H1a" ? h->H1a : k == "H2a" ? h->H2a : k == "dZ2" ? h->dZ2 :
+                     k == "dZ1" ? (h->pair_live ? h->dZ1p : h->dZ1) : k == "dq" ? h->dq :
+                     k == "q" ? h->qbuf : nullptr;
+  PA_REQUIRE(src, PA_ERR_INVALID, "pa_debug_workspace: unknown workspace '%s'", name);
+  if (paired_out) *paired_out = (k == "dZ1" && h->pair_live) ? 1 : 0;
+  PA_HIP(hipMemcpy(out_dev, src, (size_t)n * 4, hipMemcpyDeviceToDevice));
+  return PA_OK;
+}
+
+// PEARL_AMD_DEBUG_WORKERS=1: workgroups that took tiles in the persistent target launches so far / those launches
+extern "C" int pa_debug_target_workers(pa_dqn* h, int64_t* workers_out, int64_t* launches_out) {
+  PA_REQUIRE(h && workers_out && launches_out, PA_ERR_INVALID, "pa_debug_target_workers: null argument");
+  int w = 0;
+  if (h->dbg_workers) PA_HIP(hipMemcpy(&w, h->dbg_workers, 4, hipMemcpyDeviceToHost));
+  *workers_out = w;
+  *launches_out = h->dbg_launches;
+  return PA_OK;
 }
 
 extern "C" int pa_debug_set_target_rows(int32_t rows) {

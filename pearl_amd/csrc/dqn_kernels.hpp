@@ -17,6 +17,8 @@
 // K is consumed in groups of 8: lane half h = l>>5 owns k = 8*g + 4*h + j for
 // the j-th MFMA of the group, so one ds_read_b128 feeds four MFMAs.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace pa {
@@ -350,6 +352,7 @@ struct TargetArgs {
                              // (TwinCritic.get_q_values on an action set, discrete SAC)
   int rows_hint;             // 32: this pass prefers the 32-row, four-wave tile (two workgroups per CU:
                              // stand-alone passes — Double DQN, all-actions values); 0: the 64-row tile
+  int* dbg_workers;          // optional: += 1 per workgroup of a persistent launch that takes at least one tile
   int prio_tiles;            // classic grid: tiles below this index run at raised wave priority (the
                              // first round of a window, whose targets the online chain waits for,
                              // shares every CU with a later round's tile)
@@ -976,6 +979,11 @@ struct AdamFuse {
 
 struct DwProblem {
   const float* dZ; int ldz;   // [B][M]
+  int dz_pair;                // 1: dZ holds TWO partials of the operand, interleaved per pair of units —
+                              // [B][M / 2]{a(2p), a(2p + 1), b(2p), b(2p + 1)}, ldz = the physical pitch (2 M) —
+                              // and the operand is a + b, added as it is loaded: ONE 16-byte vector per two
+                              // units (online_rowpass_pair_kernel's two halves of dZ1).  Honoured by the
+                              // *_pair kernels only (run_weight_grad, dqn.hip); M even, 16-byte aligned rows
   const float* X; int ldx;    // [B][N]
   float* dW; int ldw;         // [M][N]
   float* db;                  // [M]
@@ -1118,9 +1126,10 @@ __device__ __forceinline__ void adam_fused_bias(const AdamFuse& f, int64_t i, fl
 constexpr int DW_TM = 64, DW_TN = 32, DW_RING = 8;
 typedef float dw_f32x4 __attribute__((ext_vector_type(4)));
 
-template <int UPL>
+template <int UPL, bool PAIR = false>
 struct DwFrag {
   float a[UPL];   // UPL consecutive units of one batch row (one 16- or 8-byte load)
+  float b[PAIR ? UPL : 1];   // PAIR: the same vector of the second partial (added at use)
   float2 x;
 };
 
@@ -1129,15 +1138,24 @@ struct DwFrag {
 // both: 3 * 2^30) fails the range check and the load returns zeros.
 constexpr unsigned kDwDead = 0x40000000u;
 
-template <bool FAST, int UPL>
+template <bool FAST, int UPL, bool PAIR = false>
 __device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
                                          const __amdgpu_buffer_rsrc_t& rx, const unsigned (&va)[UPL],
                                          const unsigned (&vx)[2], unsigned ba, unsigned bx,
-                                         DwFrag<UPL>& f) {
+                                         DwFrag<UPL, PAIR>& f) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   if constexpr (FAST) {
-    if constexpr (UPL == 4) {
+    if constexpr (PAIR) {
+      // interleaved partials: {a0, a1, b0, b1} per pair of units (va[0] is the pair's byte offset)
+#pragma unroll
+      for (int pr = 0; pr < UPL / 2; ++pr) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va[0] + ba + 16u * pr), 0, 0);
+        const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
+        f.a[2 * pr] = f4[0]; f.a[2 * pr + 1] = f4[1];
+        f.b[2 * pr] = f4[2]; f.b[2 * pr + 1] = f4[3];
+      }
+    } else if constexpr (UPL == 4) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va[0] + ba), 0, 0);
       const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
       f.a[0] = f4[0]; f.a[1] = f4[1]; f.a[2] = f4[2]; f.a[3] = f4[3];
@@ -1155,6 +1173,10 @@ __device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
     for (int k = 0; k < UPL; ++k)
       f.a[k] = __builtin_bit_cast(
           float, __builtin_amdgcn_raw_buffer_load_b32(ra, (int)(va[k] + ba), 0, 0));
+    if constexpr (PAIR) {   // (never taken: pair operands are whole aligned vectors; host contract)
+#pragma unroll
+      for (int k = 0; k < UPL; ++k) f.b[k] = 0.f;
+    }
 #pragma unroll
     for (int k = 0; k < 2; ++k)
       g[k] = __builtin_bit_cast(
@@ -1166,7 +1188,7 @@ __device__ __forceinline__ void dw_fetch(const __amdgpu_buffer_rsrc_t& ra,
 // `after_prologue` runs between the ring's first fetches and the main loop: loads that are only
 // needed later (the optimizer state) go there, so that they queue BEHIND the first operands —
 // vector-memory results return in issue order.
-template <bool FAST, int UPL, typename Hook>
+template <bool FAST, int UPL, bool PAIR, typename Hook>
 __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
                                             const __amdgpu_buffer_rsrc_t& rx,
                                             const unsigned (&va)[UPL], const unsigned (&vx)[2],
@@ -1179,29 +1201,31 @@ __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
     acc[ja][1] = dw_f32x4{0.f, 0.f, 0.f, 0.f};
     cs[ja] = 0.f;
   }
-  DwFrag<UPL> ring[DW_RING];
+  DwFrag<UPL, PAIR> ring[DW_RING];
 #pragma unroll
   for (int p = 0; p < DW_RING; ++p) {
     const bool live = p < nsteps;
-    dw_fetch<FAST, UPL>(ra, rx, va, vx, live ? oa + (unsigned)p * sa : kDwDead,
-                        live ? ox + (unsigned)p * sx : kDwDead, ring[p]);
+    dw_fetch<FAST, UPL, PAIR>(ra, rx, va, vx, live ? oa + (unsigned)p * sa : kDwDead,
+                              live ? ox + (unsigned)p * sx : kDwDead, ring[p]);
   }
   after_prologue();
   for (int s0 = 0; s0 < nsteps; s0 += DW_RING) {
 #pragma unroll
     for (int p = 0; p < DW_RING; ++p) {
-      const DwFrag<UPL> f = ring[p];
+      const DwFrag<UPL, PAIR> f = ring[p];
       const int sn = s0 + p + DW_RING;
       const bool live = sn < nsteps;  // steps past the slice must not read the next wave's rows
-      dw_fetch<FAST, UPL>(ra, rx, va, vx, live ? oa + (unsigned)sn * sa : kDwDead,
-                          live ? ox + (unsigned)sn * sx : kDwDead, ring[p]);
+      dw_fetch<FAST, UPL, PAIR>(ra, rx, va, vx, live ? oa + (unsigned)sn * sa : kDwDead,
+                                live ? ox + (unsigned)sn * sx : kDwDead, ring[p]);
       __builtin_amdgcn_sched_barrier(0);  // keep the refill here, DW_RING steps ahead of its use
       const float xv[2] = {f.x.x, f.x.y};
 #pragma unroll
       for (int ja = 0; ja < UPL; ++ja) {
-        acc[ja][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ja], xv[0], acc[ja][0], 0, 0, 0);
-        acc[ja][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ja], xv[1], acc[ja][1], 0, 0, 0);
-        cs[ja] += f.a[ja];
+        float av = f.a[ja];
+        if constexpr (PAIR) av = __fadd_rn(av, f.b[ja]);
+        acc[ja][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[0], acc[ja][0], 0, 0, 0);
+        acc[ja][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, xv[1], acc[ja][1], 0, 0, 0);
+        cs[ja] += av;
       }
     }
   }
@@ -1222,22 +1246,33 @@ __device__ __forceinline__ void dw_mainloop(const __amdgpu_buffer_rsrc_t& ra,
 // issues 16 loads, ~260 VALU (the splits) and 48 MFMAs of 16 passes: 2.7x the fp32 loop's 64 MFMAs
 // of 32.  Accumulator layout = the fp32 loop's: everything after the main loop is shared.
 // ---------------------------------------------------------------------------
-template <int UPL>
+template <int UPL, bool PAIR = false>
 struct DwRaw32 {
   float a[8][UPL];
+  float b[PAIR ? 8 : 1][UPL];   // PAIR: the second partial's rows (added when the step is worked on)
   float x[8][2];
 };
-template <int UPL>
+template <int UPL, bool PAIR = false>
 __device__ __forceinline__ void dw_fetch32(const __amdgpu_buffer_rsrc_t& ra,
                                            const __amdgpu_buffer_rsrc_t& rx, unsigned va, unsigned vx,
                                            unsigned ba, unsigned bx, unsigned lda4, unsigned ldx4,
-                                           DwRaw32<UPL>& f) {
+                                           DwRaw32<UPL, PAIR>& f) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   static_assert(UPL == 4 || UPL == 2, "16- / 8-byte loads of dZ");
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    if constexpr (UPL == 4) {
+    if constexpr (PAIR) {
+      // interleaved partials: {a0, a1, b0, b1} per pair of units (va is the pair's byte offset)
+#pragma unroll
+      for (int pr = 0; pr < UPL / 2; ++pr) {
+        const u32x4 v =
+            __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va + ba + (unsigned)r * lda4 + 16u * pr), 0, 0);
+        const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
+        f.a[r][2 * pr] = f4[0]; f.a[r][2 * pr + 1] = f4[1];
+        f.b[r][2 * pr] = f4[2]; f.b[r][2 * pr + 1] = f4[3];
+      }
+    } else if constexpr (UPL == 4) {
       const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(va + ba + (unsigned)r * lda4), 0, 0);
       const f32x4_t f4 = __builtin_bit_cast(f32x4_t, v);
       f.a[r][0] = f4[0]; f.a[r][1] = f4[1]; f.a[r][2] = f4[2]; f.a[r][3] = f4[3];
@@ -1292,7 +1327,7 @@ __device__ __forceinline__ void split8x2(const dw_f32x2 (&v)[8], bf16x8 (&hi)[2]
 }
 // va / vx: byte offset of this lane's vector in row 8 q of a step (kBufOob: outside the operand);
 // oa / ox: byte offset of the wave's first row.
-template <int UPL, typename Hook>
+template <int UPL, bool PAIR, typename Hook>
 __device__ __forceinline__ void dw_mainloop_split(const __amdgpu_buffer_rsrc_t& ra,
                                                   const __amdgpu_buffer_rsrc_t& rx, unsigned va,
                                                   unsigned vx, unsigned oa, unsigned ox,
@@ -1311,7 +1346,7 @@ __device__ __forceinline__ void dw_mainloop_split(const __amdgpu_buffer_rsrc_t& 
   // one 32-row step: split the raw rows three ways, then the six product classes, each over the
   // eight (unit block, column block) positions — consecutive MFMAs write different accumulators
   // (no back-to-back dependent chain)
-  auto work = [&](const DwRaw32<UPL>& cur) {
+  auto work = [&](const DwRaw32<UPL, PAIR>& cur) {
     bf16x8 xh[2], xm[2], xl[2], ah[UPL], am[UPL], al[UPL];
     {
       dw_f32x2 v[8];
@@ -1325,8 +1360,9 @@ __device__ __forceinline__ void dw_mainloop_split(const __amdgpu_buffer_rsrc_t& 
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         v[r] = dw_f32x2{cur.a[r][jp], cur.a[r][jp + 1]};
-        cs[jp] += cur.a[r][jp];
-        cs[jp + 1] += cur.a[r][jp + 1];
+        if constexpr (PAIR) v[r] += dw_f32x2{cur.b[r][jp], cur.b[r][jp + 1]};
+        cs[jp] += v[r][0];
+        cs[jp + 1] += v[r][1];
       }
       bf16x8 h2[2], m2[2], l2[2];
       split8x2(v, h2, m2, l2);
@@ -1349,11 +1385,11 @@ __device__ __forceinline__ void dw_mainloop_split(const __amdgpu_buffer_rsrc_t& 
   // two raw buffers in ping-pong (nsteps is even: the host-side slice is a multiple of 512 rows):
   // the next step's sixteen loads are in flight under this step's splits and MFMAs, and nothing
   // is copied between them
-  DwRaw32<UPL> ra0, ra1;
-  auto fetch = [&](int step, DwRaw32<UPL>& f) {
+  DwRaw32<UPL, PAIR> ra0, ra1;
+  auto fetch = [&](int step, DwRaw32<UPL, PAIR>& f) {
     const bool live = step < nsteps;    // steps past the slice must not read the next wave's rows
-    dw_fetch32<UPL>(ra, rx, va, vx, live ? oa + (unsigned)step * sa32 : kDwDead,
-                    live ? ox + (unsigned)step * sx32 : kDwDead, lda4, ldx4, f);
+    dw_fetch32<UPL, PAIR>(ra, rx, va, vx, live ? oa + (unsigned)step * sa32 : kDwDead,
+                          live ? ox + (unsigned)step * sx32 : kDwDead, lda4, ldx4, f);
   };
   fetch(0, ra0);
   after_prologue();
@@ -1420,7 +1456,7 @@ __device__ __forceinline__ void sac_step_tail(const TailJob& t, float* lds, int 
 
 // UPL = units per lane: 4 -> 64-row tiles (one 16-byte load of dZ per step), 2 -> 32-row tiles
 // (8-byte loads); everything below is written for TM = 16 UPL.
-template <int UPL, bool SPLIT = false>
+template <int UPL, bool SPLIT = false, bool PAIR = false>
 __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, float* csum) {
   constexpr int TM = 16 * UPL;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1525,10 +1561,14 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
   const __amdgpu_buffer_rsrc_t ra = buf_rsrc_n(P.dZ, (unsigned)a.B * (unsigned)P.ldz * 4u);
   const __amdgpu_buffer_rsrc_t rx = buf_rsrc_n(P.X, (unsigned)a.B * (unsigned)P.ldx * 4u);
   const int ua = i0 + UPL * c, cx = j0 + 2 * c;  // first unit / column of this lane's vectors
+  // PAIR kernels: a problem whose dZ holds two interleaved partials (wave-uniform, DwProblem::dz_pair)
+  // adds them as it loads; its element offsets are those of the pairs: twice the unit index
+  const bool pairp = PAIR && P.dz_pair != 0;
+  const int uoff = pairp ? 2 * ua : ua;
   unsigned va[UPL], vx[2];                       // per-component byte offsets of row q (kBufOob: none)
 #pragma unroll
   for (int e = 0; e < UPL; ++e)
-    va[e] = (ua + e < P.M) ? (unsigned)(q * P.ldz + ua + e) * 4u : kBufOob;
+    va[e] = (ua + e < P.M) ? (unsigned)(q * P.ldz + uoff + e) * 4u : kBufOob;
 #pragma unroll
   for (int e = 0; e < 2; ++e)
     vx[e] = (cx + e < P.N) ? (unsigned)(q * P.ldx + cx + e) * 4u : kBufOob;
@@ -1565,15 +1605,24 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
   dw_f32x4 acc[UPL][2];
   float cs[UPL];
   PA_STAMP(a.prof, blockIdx.x, wave, 1);
-  if constexpr (SPLIT) {
-    // (host contract: fa && fx for every matrix problem of a split launch)
-    const unsigned lda4 = (unsigned)P.ldz * 4u, ldx4 = (unsigned)P.ldx * 4u;
-    const unsigned va8 = (ua < P.M) ? (unsigned)(8 * q * P.ldz + ua) * 4u : kBufOob;
-    const unsigned vx8 = (cx < P.N) ? (unsigned)(8 * q * P.ldx + cx) * 4u : kBufOob;
-    dw_mainloop_split<UPL>(ra, rx, va8, vx8, oa, ox, lda4, ldx4, nsteps, acc, cs, prefetch_state);
+  auto run_loop = [&](auto pair_tag) {
+    constexpr bool PR = decltype(pair_tag)::value;
+    if constexpr (SPLIT) {
+      // (host contract: fa && fx for every matrix problem of a split launch)
+      const unsigned lda4 = (unsigned)P.ldz * 4u, ldx4 = (unsigned)P.ldx * 4u;
+      const unsigned va8 = (ua < P.M) ? (unsigned)(8 * q * P.ldz + uoff) * 4u : kBufOob;
+      const unsigned vx8 = (cx < P.N) ? (unsigned)(8 * q * P.ldx + cx) * 4u : kBufOob;
+      dw_mainloop_split<UPL, PR>(ra, rx, va8, vx8, oa, ox, lda4, ldx4, nsteps, acc, cs, prefetch_state);
+    } else {
+      if (fa && fx) dw_mainloop<true, UPL, PR>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+      else dw_mainloop<false, UPL, PR>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+    }
+  };
+  if constexpr (PAIR) {
+    if (pairp) run_loop(std::true_type{});
+    else run_loop(std::false_type{});
   } else {
-    if (fa && fx) dw_mainloop<true, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
-    else dw_mainloop<false, UPL>(ra, rx, va, vx, oa, ox, sa, sx, nsteps, acc, cs, prefetch_state);
+    run_loop(std::false_type{});
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 2);
   // ---- partial tiles: (waves 4..7 -> LDS, waves 0..3 add), then (waves 0..3 -> LDS, all sum)

@@ -81,7 +81,18 @@ int launch_target_split_t(const TargetArgs& a, hipStream_t s) {
     configured = true;
   }
   unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
-  if (a.tile_ctr) grid = a.reserved ? 512u : (unsigned)(a.ntiles < 256 ? a.ntiles : 256);
+  // PEARL_AMD_PERSIST_OFFER: workgroups offered to a persistent launch beside a CU partition.  The
+  // hardware places each exactly once: a non-reserved CU that is full when its turn comes (a chain
+  // workgroup with a large LDS / register footprint sits there) gets no target workgroup for the
+  // whole launch, and the offers that land on reserved CUs are used up within microseconds.  Measured
+  // (round 5, PEARL_AMD_DEBUG_WORKERS): with 512 offers 107 of the 128 non-reserved CUs took tiles in
+  // an average window launch (75 beside the paired row pass's 82 KB workgroups), with 2048: 123-128.
+  static const unsigned offer = []() {
+    const char* v = getenv("PEARL_AMD_PERSIST_OFFER");
+    const int n = v ? atoi(v) : 2048;
+    return (unsigned)(n >= 256 ? n : 2048);
+  }();
+  if (a.tile_ctr) grid = a.reserved ? offer : (unsigned)(a.ntiles < 256 ? a.ntiles : 256);
   hipLaunchKernelGGL(target_split_kernel<KS1>, dim3(grid), dim3(512), smem, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -175,7 +186,10 @@ inline int launch_target(const TargetArgs& a, hipStream_t s) {
 // >= 512 rows per workgroup (a 64 x 32 tile over 4096 rows is 27 us of MFMA on one CU).  The scratch
 // for the partial tiles is one buffer per process, grown on demand; launches are ordered by their
 // stream like every other use of a learner handle.
-inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
+// `variants`: optional replacements for the four kernels, in the order {32-row split, 32-row fp32,
+// 64-row split, 64-row fp32} (dqn.hip: the *_pair kernels that honour DwProblem::dZb)
+typedef void (*DwKernelFn)(DwArgs);
+inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s, const DwKernelFn* variants = nullptr) {
   static float* scratch = nullptr;
   static unsigned* tickets = nullptr;
   static size_t scratch_floats = 0, ticket_count = 0;
@@ -256,7 +270,10 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s) {
     }
     a.split = ok ? 1 : 0;
   }
-  if (a.tm == 32 && a.split) hipLaunchKernelGGL(weight_grad_split_kernel32, dim3(grid), dim3(512), 0, s, a);
+  if (variants) {
+    const DwKernelFn k = variants[(a.tm == 32 ? 0 : 2) + (a.split ? 0 : 1)];
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), 0, s, a);
+  } else if (a.tm == 32 && a.split) hipLaunchKernelGGL(weight_grad_split_kernel32, dim3(grid), dim3(512), 0, s, a);
   else if (a.tm == 32) hipLaunchKernelGGL(weight_grad_kernel32, dim3(grid), dim3(512), 0, s, a);
   else if (a.split) hipLaunchKernelGGL(weight_grad_split_kernel, dim3(grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL(weight_grad_kernel, dim3(grid), dim3(512), 0, s, a);

@@ -23,6 +23,7 @@
 #include "mlp_rowpass.hpp"
 #include "mlp_rowstep.hpp"
 #include "mlp_internal.hpp"
+#include "mlp_norm_act.hpp"
 #include "sac_rows.hpp"
 
 using namespace pa;
@@ -42,9 +43,25 @@ int layout(const pa_mlp_desc* d, int64_t* woff, int64_t* boff, int64_t* total) {
     woff[l] = o; o = align4(o + (int64_t)d->dims[l + 1] * d->dims[l]);
     boff[l] = o; o = align4(o + d->dims[l + 1]);
   }
+  PA_REQUIRE(d->hidden_act >= 0 && d->hidden_act < ACT_COUNT, PA_ERR_INVALID,
+             "hidden_act %d is not an activation (0 relu, 1 leaky_relu, 2 tanh, 3 softplus, 4 sigmoid)",
+             d->hidden_act);
+  PA_REQUIRE(d->layer_norm == 0 || d->layer_norm == 1, PA_ERR_INVALID, "layer_norm is 0 or 1");
   *total = o;
   return PA_OK;
 }
+// the LayerNorm parameters of the hidden layers follow the W / b block: gamma_l, beta_l, ...
+int norm_layout(const pa_mlp_desc* d, int64_t wb_total, int64_t* goff, int64_t* betaoff, int64_t* total) {
+  int64_t o = wb_total;
+  for (int l = 0; l + 1 < d->n_layers && d->layer_norm; ++l) {
+    goff[l] = o; o = align4(o + d->dims[l + 1]);
+    betaoff[l] = o; o = align4(o + d->dims[l + 1]);
+  }
+  *total = o;
+  return PA_OK;
+}
+// mlp_block's plain form (Linear + ReLU): what the fused row kernels compute
+inline bool plain_net(const pa_mlp* h) { return h->d.hidden_act == 0 && h->d.layer_norm == 0; }
 
 AdamScalars adam_scalars(const pa_mlp_desc& d, int64_t step) {
   const double bc1 = 1.0 - pow(d.beta1, (double)step);
@@ -66,7 +83,22 @@ AdamScalars adam_scalars(const pa_mlp_desc& d, int64_t step) {
 extern "C" int64_t pa_mlp_param_count(const pa_mlp_desc* d) {
   int64_t w[PA_MLP_MAX_LAYERS], b[PA_MLP_MAX_LAYERS], total = 0;
   if (layout(d, w, b, &total) != PA_OK) return -1;
+  (void)norm_layout(d, total, w, b, &total);
   return total;
+}
+
+extern "C" int pa_mlp_norm_offsets(const pa_mlp_desc* d, int64_t* offsets) {
+  PA_REQUIRE(offsets, PA_ERR_INVALID, "null output");
+  int64_t w[PA_MLP_MAX_LAYERS], b[PA_MLP_MAX_LAYERS], total = 0;
+  int rc = layout(d, w, b, &total);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(d->layer_norm, PA_ERR_INVALID, "pa_mlp_norm_offsets: the network has no LayerNorm");
+  (void)norm_layout(d, total, w, b, &total);
+  for (int l = 0; l + 1 < d->n_layers; ++l) {
+    offsets[2 * l] = w[l];
+    offsets[2 * l + 1] = b[l];
+  }
+  return PA_OK;
 }
 
 extern "C" int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets) {
@@ -89,6 +121,11 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
     if (h->act[l]) (void)hipFree(h->act[l]);
   for (int i = 0; i < PA_MLP_MAX_LAYERS; ++i)
     if (h->dz[i]) (void)hipFree(h->dz[i]);
+  for (int i = 0; i < PA_MLP_MAX_LAYERS; ++i) {
+    if (h->xhat[i]) (void)hipFree(h->xhat[i]);
+    if (h->rstd[i]) (void)hipFree(h->rstd[i]);
+  }
+  if (h->norm_part) (void)hipFree(h->norm_part);
   if (h->db_scratch) (void)hipFree(h->db_scratch);
   if (h->loss_scratch) (void)hipFree(h->loss_scratch);
   if (h->qa_w2f) (void)hipFree(h->qa_w2f);
@@ -124,6 +161,8 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
     delete h;
     return rc;
   }
+  h->norm0 = h->P;
+  (void)norm_layout(desc, h->P, h->goff, h->betaoff, &h->P);
   {
     // (from here on every failure goes through pa_mlp_destroy, which releases the binding)
     int rc_dev = bind_process_device(desc->device);
@@ -145,12 +184,20 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
     ok = ok && alloc(&h->dz[l], (int64_t)desc->max_batch * desc->dims[l]);
   ok = ok && alloc(&h->db_scratch, maxh);
   ok = ok && alloc(&h->loss_scratch, 4);
+  if (desc->layer_norm) {
+    for (int l = 0; l + 1 < h->L; ++l) {
+      ok = ok && alloc(&h->xhat[l], (int64_t)desc->max_batch * desc->dims[l + 1]);
+      ok = ok && alloc(&h->rstd[l], desc->max_batch);
+    }
+    ok = ok && alloc(&h->norm_part, (int64_t)NP_BLOCKS * 2 * maxh);
+  }
   {
     static const bool enabled = []() {
       const char* v = getenv("PEARL_AMD_MLP_ROWPASS");
       return !(v && *v == '0');
     }();
-    h->row_ok = enabled && h->L <= ROW_MAX_LAYERS && desc->dims[0] <= ROW_MAX_IN;
+    // (LayerNorm / other hidden activations: layer by layer, mlp_norm_act.hpp)
+    h->row_ok = enabled && plain_net(h) && h->L <= ROW_MAX_LAYERS && desc->dims[0] <= ROW_MAX_IN;
     for (int l = 0; l < h->L; ++l) h->row_ok = h->row_ok && desc->dims[l + 1] <= ROW_MAX_OUT;
     if (h->row_ok) {
       for (int l = 0; l < h->L; ++l) {
@@ -387,10 +434,27 @@ extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int
     g.C = last ? out : h->act[l]; g.ldc = last ? ldo : h->d.dims[l + 1];
     g.bias = P + h->boff[l];
     g.M = B; g.N = h->d.dims[l + 1]; g.K = h->d.dims[l];
-    const bool relu = !last && !((h->d.identity_layers >> l) & 1);
+    const bool ident = ((h->d.identity_layers >> l) & 1) != 0;
+    const bool relu = !last && !ident && plain_net(h);
     g.epi = relu ? EPI_BIAS_RELU : ((last && h->d.no_last_bias) ? EPI_NONE : EPI_BIAS);
     int rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
+    if (!last && !plain_net(h) && (h->d.layer_norm || !ident)) {
+      // LayerNorm (optional) and the hidden activation, row by row, in place (mlp_norm_act.hpp)
+      NormActArgs na;
+      memset(&na, 0, sizeof(na));
+      na.z = h->act[l]; na.ldz = h->d.dims[l + 1];
+      if (h->d.layer_norm) {
+        na.gamma = P + h->goff[l]; na.beta = P + h->betaoff[l];
+        // (only the ONLINE network's kept forward feeds a backward)
+        na.xhat = (keep && !use_target) ? h->xhat[l] : nullptr;
+        na.rstd = (keep && !use_target) ? h->rstd[l] : nullptr;
+      }
+      na.B = B; na.d = h->d.dims[l + 1]; na.act = h->d.hidden_act; na.identity = ident ? 1 : 0;
+      na.eps = 1e-5f;
+      hipLaunchKernelGGL(norm_act_fwd_kernel, dim3((unsigned)ceil_div(B, NA_ROWS)), dim3(64 * NA_ROWS), 0, s, na);
+      PA_LAUNCH_CHECK();
+    }
     in = h->act[l];
     ldin = h->d.dims[l + 1];
   }
@@ -647,7 +711,8 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       float* dst = l > 0 ? h->dz[l] : d_x;
       g.C = dst; g.ldc = l > 0 ? h->d.dims[l] : lddx;
       g.M = B; g.N = h->d.dims[l]; g.K = h->d.dims[l + 1];
-      if (l > 0 && !((h->d.identity_layers >> (l - 1)) & 1)) {
+      const bool ident = l > 0 && ((h->d.identity_layers >> (l - 1)) & 1) != 0;
+      if (l > 0 && !ident && plain_net(h)) {
         g.Hmask = h->act[l - 1]; g.ldh = h->d.dims[l];
         g.epi = EPI_MASK;
       } else {
@@ -655,6 +720,31 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       }
       int rc = launch_linear<true>(&g, 1, s);
       if (rc != PA_OK) return rc;
+      if (l > 0 && !plain_net(h) && (h->d.layer_norm || !ident)) {
+        // dh -> dz of hidden layer l - 1 through its activation and LayerNorm (mlp_norm_act.hpp);
+        // the LayerNorm's own parameter gradients first (they read dh)
+        NormActArgs na;
+        memset(&na, 0, sizeof(na));
+        na.z = dst; na.ldz = h->d.dims[l];
+        na.h = h->act[l - 1]; na.ldh = h->d.dims[l];
+        na.B = B; na.d = h->d.dims[l]; na.act = h->d.hidden_act; na.identity = ident ? 1 : 0;
+        na.eps = 1e-5f;
+        if (h->d.layer_norm) {
+          na.gamma = P + h->goff[l - 1]; na.beta = P + h->betaoff[l - 1];
+          na.xhat = h->xhat[l - 1]; na.rstd = h->rstd[l - 1];
+          if (want_dw) {
+            const int rows_per = (int)ceil_div(B, NP_BLOCKS);
+            const int nb = (int)ceil_div(B, rows_per);
+            hipLaunchKernelGGL(norm_param_grad_kernel, dim3((unsigned)ceil_div(na.d, 64), (unsigned)nb), dim3(64),
+                               0, s, na, h->norm_part, rows_per);
+            hipLaunchKernelGGL(norm_param_sum_kernel, dim3((unsigned)ceil_div(na.d, 64)), dim3(64), 0, s,
+                               h->norm_part, nb, na.d, h->bufs.grad + h->goff[l - 1],
+                               h->bufs.grad + h->betaoff[l - 1]);
+          }
+        }
+        hipLaunchKernelGGL(norm_act_bwd_kernel, dim3((unsigned)ceil_div(B, NA_ROWS)), dim3(64 * NA_ROWS), 0, s, na);
+        PA_LAUNCH_CHECK();
+      }
       if (l > 0) {
         dzs[l - 1] = dst;
         ldzs[l - 1] = h->d.dims[l];
@@ -682,6 +772,7 @@ extern "C" int pa_mlp_q_all(pa_mlp* h, int32_t use_target, const float* state, i
              "pa_mlp_q_all: bad argument");
   const pa_mlp_desc& d = h->d;
   const int S = d.dims[0] - AD;
+  PA_REQUIRE(plain_net(h), PA_ERR_UNSUPPORTED, "pa_mlp_q_all: a plain Linear + ReLU critic only");
   PA_REQUIRE(h->L == 3 && d.dims[3] == 1 && S > 0 && d.identity_layers == 0 && !d.no_last_bias &&
                  d.dims[1] <= 256 && d.dims[2] <= 256 && A <= T_ROWS && rows <= d.max_batch,
              PA_ERR_UNSUPPORTED,
@@ -750,6 +841,7 @@ extern "C" int pa_mlp_q_all2(pa_mlp* h1, pa_mlp* h2, int32_t use_target, const f
   const float* Ps[2];
   for (int i = 0; i < 2; ++i) {
     const pa_mlp_desc& di = hs[i]->d;
+    PA_REQUIRE(plain_net(hs[i]), PA_ERR_UNSUPPORTED, "pa_mlp_q_all2: plain Linear + ReLU critics only");
     PA_REQUIRE(hs[i]->L == 3 && di.dims[3] == 1 && S > 0 && di.identity_layers == 0 &&
                    !di.no_last_bias && di.dims[0] == d.dims[0] && di.dims[1] == H1 &&
                    di.dims[2] == H2 && di.device == d.device && H1 <= 256 && H2 <= 256 &&
@@ -822,6 +914,9 @@ int check_pair(const pa_mlp* h1, const pa_mlp* h2) {
   // problem of a linear_kernel / weight_grad_kernel launch carries its own shape)
   PA_REQUIRE(h1->L == h2->L && h1->d.device == h2->d.device && h1->d.dims[0] == h2->d.dims[0],
              PA_ERR_INVALID, "mlp pair: the two networks differ in depth, device or input width");
+  PA_REQUIRE(plain_net(h1) && plain_net(h2), PA_ERR_UNSUPPORTED,
+             "mlp pair: LayerNorm / non-ReLU hidden activations run through pa_mlp_forward / "
+             "pa_mlp_backward (one network at a time)");
   return PA_OK;
 }
 }  // namespace
@@ -1335,8 +1430,23 @@ extern "C" int pa_mlp_adam(pa_mlp* h, int64_t step, void* stream) {
     // the kept backward's weight gradients and this step in one pass; the fragment-major copies
     // stay current (refreshed by the same epilogue) if they were current before
     h->pend.active = false;
-    return run_weight_grads(h, h->pend.x, h->pend.ldx, h->pend.B, h->pend.dzs, h->pend.ldzs, step,
-                            reinterpret_cast<hipStream_t>(stream));
+    int rc = run_weight_grads(h, h->pend.x, h->pend.ldx, h->pend.B, h->pend.dzs, h->pend.ldzs, step,
+                              reinterpret_cast<hipStream_t>(stream));
+    if (rc != PA_OK || h->norm0 >= h->P) return rc;
+    // the LayerNorm parameters (their gradients were formed by the backward): AdamW on the block
+    // behind W / b
+    AdamArgs n;
+    memset(&n, 0, sizeof(n));
+    const int64_t o = h->norm0;
+    n.st.p = h->bufs.p + o; n.st.m = h->bufs.exp_avg + o; n.st.v = h->bufs.exp_avg_sq + o;
+    n.st.vmax = h->bufs.max_exp_avg_sq ? h->bufs.max_exp_avg_sq + o : nullptr;
+    n.g = h->bufs.grad + o;
+    n.n = h->P - o;
+    n.c = adam_scalars(h->d, step);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)ceil_div(n.n, 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), n);
+    PA_LAUNCH_CHECK();
+    return PA_OK;
   }
   AdamArgs a;
   memset(&a, 0, sizeof(a));

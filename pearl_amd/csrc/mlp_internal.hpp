@@ -11,6 +11,13 @@ struct pa_mlp {
   bool bound;
   int L;
   int64_t woff[PA_MLP_MAX_LAYERS], boff[PA_MLP_MAX_LAYERS], P;
+  // desc.layer_norm: gamma / beta of hidden layer l's LayerNorm (flat offsets, behind the W / b block),
+  // what its backward needs of the kept forward (the normalised values and 1 / sqrt(var + eps) per
+  // row), and the column sums' partials; norm0 = first float of the norm block (P when none)
+  int64_t goff[PA_MLP_MAX_LAYERS], betaoff[PA_MLP_MAX_LAYERS], norm0;
+  float* xhat[PA_MLP_MAX_LAYERS];
+  float* rstd[PA_MLP_MAX_LAYERS];
+  float* norm_part;
   float* act[PA_MLP_MAX_LAYERS];  // hidden activations kept for the backward pass [max_batch, d]
   float* dz[PA_MLP_MAX_LAYERS];   // pre-activation gradient of every hidden layer [max_batch, d]
                                   // (all kept: the weight gradients of all layers are one launch)

@@ -33,6 +33,53 @@ __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// Four accumulators per output tile: the j-th MFMA of every 16-wide k-group feeds accumulator j
+// (k = 16 g + 4 qd + j), they are added pairwise at the end.  The fp32 chain of one accumulator
+// was 4 K / 16 steps long (256 for the hidden layers); chains a quarter as long with a pairwise
+// tail put Q(s, a) closer to float64 than the reference's own blocked fp32 sums are (bench.py's
+// parity block).  `seed` (the bias) opens chain 0, as it opened the single chain before.
+// (NACC defaults to 1 — the single chain — for the other users of these loops: sac_rows.hpp,
+//  mlp_rowpass.hpp keep their arithmetic.)
+// RP_NACC_FWD / RP_NACC_BWD (1, 2 or 4): accumulators per tile of the forward layers / of the
+// backward product G = s2 W2 (whose rounding enters gradients, not the Q-values the parity bar is on)
+#ifndef RP_NACC_FWD
+#define RP_NACC_FWD 4
+#endif
+#ifndef RP_NACC_BWD
+#define RP_NACC_BWD 4
+#endif
+// Measured on one box, 2000-round learn() of config 2 (round 5, tools/r5_cfgs.txt; us per round | max
+// relative error of Q(s, a) against float64 | against the reference's fp32 output; the reference
+// itself is 1.61e-5 from float64):
+//   FWD/BWD 1/1  36.88 | 2.34e-5 | 1.69e-5      (rounds 1-4)
+//           2/1  37.04 | 1.38e-5 | 1.65e-5
+//           4/1  37.04 | 8.75e-6 | 1.79e-5
+//           4/4  37.14-37.30 | 8.75e-6 | 1.79e-5      (default)
+// (4/4 rather than 4/1: the 12-round trajectory fixture dqn_cfg2_shape_small_batch has a layer-2
+//  pre-activation within 1e-7 of zero in its second round; the backward product's rounding decides
+//  which side of the ReLU it lands on after round 1's step, and 1/1 and 4/4 land on the reference's
+//  side — within 2e-7 of its parameters after 12 rounds — while 4/1 and the paired row pass do not:
+//  tools/debug_pair_traj.py.  Each variant's gradients are within 1.6e-7 of float64's.)
+//   paired row pass (online_pair_kernel.hpp, 4/4)  36.79 | 7.88e-6 | 1.84e-5
+template <int NACC>
+__device__ __forceinline__ void acc4_seed(f32x4v (&c)[2][NACC], const f32x4v (&acc)[2]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    c[t][0] = acc[t];
+#pragma unroll
+    for (int j = 1; j < NACC; ++j) c[t][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NACC>
+__device__ __forceinline__ void acc4_sum(f32x4v (&acc)[2], const f32x4v (&c)[2][NACC]) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if constexpr (NACC == 4) acc[t] = (c[t][0] + c[t][1]) + (c[t][2] + c[t][3]);
+    else if constexpr (NACC == 2) acc[t] = c[t][0] + c[t][1];
+    else acc[t] = c[t][0];
+  }
+}
+
 // ---- fragment-major layout for the 16x16x4 tiles ------------------------------------------
 // Wf[(unit_tile * nkg + kgroup) * 64 + lane] = float4{ W[unit][16 g + 4 qd + 0..3] },
 // lane = qd * 16 + (unit & 15).  Entries outside the matrix are zero.
@@ -156,6 +203,21 @@ static __global__ __launch_bounds__(256) void repack_online_kernel(RepackArgs a)
   repack_body(a, (int64_t)blockIdx.x * 256 + threadIdx.x, (int64_t)gridDim.x * 256);
 }
 
+// Every wave for itself (no barrier): the word normally holds the value already — the gather ran a
+// whole window ago — so this is one L2-bypassing load in front of the operand burst.  Bounded like
+// consume_y.
+__device__ __forceinline__ void rowpass_wait_x(const int* flag, int value, int* err, int* err_host) {
+  int spins = 0;
+  while ((__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if (++spins > kYPollSpins) {
+      __hip_atomic_store(err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (err_host) __hip_atomic_store(err_host, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
+}
+
 // ---- the row pass ---------------------------------------------------------------------------
 struct RowArgs {
   const float* x; int ldx;              // [B][K1] state || rep(action)
@@ -168,6 +230,8 @@ struct RowArgs {
   int* err;                             // device error word for the bounded wait
   int* err_host;                        // its pinned, device-mapped host twin (written on failure)
   int* signal_flag; int signal_value;   // optional: published by workgroup 0 as soon as it starts
+  const int* wait_flag; int wait_value; // optional: x may only be read once *wait_flag >= wait_value (the side
+                                        // stream's gather of this window has completed: pa_dqn::pending_wait)
                                         // ("everything before this launch on its stream is done":
                                         // the window hand-off of learn(), see pa_dqn::sig)
   long long* prof;                      // optional phase stamps (tools/prof_chain.py)
@@ -188,7 +252,7 @@ inline size_t rowpass_smem_bytes(int K1, int H1, int H2) {
 // acc[t] += sum_k Wf[tile0 + t][k] * act[row][k]; act points at this lane's (row, 4 qd) in LDS.
 // nkg is rounded up to a multiple of 4 by the caller's LDS padding (zeros), weights beyond the
 // matrix are zero through the out-of-range buffer load.
-template <int PD>
+template <int PD, int NACC = 1>
 __device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __restrict__ Wf, int nkg,
                                             int tile0, int ntiles, const float* act, int lane) {
   const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
@@ -201,6 +265,8 @@ __device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __res
     r1[p] = ld4_or_zero(Wf, base1 + (int64_t)p * 256, ok1 && p < nkg);
   }
   const int nkgp = (nkg + PD - 1) / PD * PD;
+  f32x4v c[2][NACC];
+  acc4_seed<NACC>(c, acc);
   for (int g0 = 0; g0 < nkgp; g0 += PD) {
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
@@ -209,16 +275,17 @@ __device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __res
       r0[p] = ld4_or_zero(Wf, base0 + (int64_t)(g + PD) * 256, ok0 && (g + PD) < nkg);
       r1[p] = ld4_or_zero(Wf, base1 + (int64_t)(g + PD) * 256, ok1 && (g + PD) < nkg);
       const float4 x4 = *reinterpret_cast<const float4*>(act + g * 16);
-      acc[0] = mfma16(w0.x, x4.x, acc[0]);
-      acc[1] = mfma16(w1.x, x4.x, acc[1]);
-      acc[0] = mfma16(w0.y, x4.y, acc[0]);
-      acc[1] = mfma16(w1.y, x4.y, acc[1]);
-      acc[0] = mfma16(w0.z, x4.z, acc[0]);
-      acc[1] = mfma16(w1.z, x4.z, acc[1]);
-      acc[0] = mfma16(w0.w, x4.w, acc[0]);
-      acc[1] = mfma16(w1.w, x4.w, acc[1]);
+      c[0][0 % NACC] = mfma16(w0.x, x4.x, c[0][0 % NACC]);
+      c[1][0 % NACC] = mfma16(w1.x, x4.x, c[1][0 % NACC]);
+      c[0][1 % NACC] = mfma16(w0.y, x4.y, c[0][1 % NACC]);
+      c[1][1 % NACC] = mfma16(w1.y, x4.y, c[1][1 % NACC]);
+      c[0][2 % NACC] = mfma16(w0.z, x4.z, c[0][2 % NACC]);
+      c[1][2 % NACC] = mfma16(w1.z, x4.z, c[1][2 % NACC]);
+      c[0][3 % NACC] = mfma16(w0.w, x4.w, c[0][3 % NACC]);
+      c[1][3 % NACC] = mfma16(w1.w, x4.w, c[1][3 % NACC]);
     }
   }
+  acc4_sum<NACC>(acc, c);
 }
 
 // Compile-time k-group count: the whole k loop is unrolled, the weight fragments go through a
@@ -243,13 +310,15 @@ __device__ __forceinline__ void ring_fill(WRing& R, const float* __restrict__ Wf
     }
   }
 }
-template <int NKG>
+template <int NKG, int NACC = 1>
 __device__ __forceinline__ void rows16_gemm_static(f32x4v (&acc)[2], WRing& R,
                                                    const float* __restrict__ Wf, int tile0,
                                                    int ntiles, const float* act, int lane) {
   const bool ok0 = tile0 < ntiles, ok1 = tile0 + 1 < ntiles;
   const int64_t base0 = ((int64_t)tile0 * NKG) * 256 + lane * 4;
   const int64_t base1 = base0 + (int64_t)NKG * 256;
+  f32x4v c[2][NACC];
+  acc4_seed<NACC>(c, acc);
 #pragma unroll
   for (int g = 0; g < NKG; ++g) {
     const float4 w0 = R.r0[g % RP_PD], w1 = R.r1[g % RP_PD];
@@ -261,22 +330,23 @@ __device__ __forceinline__ void rows16_gemm_static(f32x4v (&acc)[2], WRing& R,
     // later) to shorten the live range, which turns the prefetch into an exposed latency
     __builtin_amdgcn_sched_barrier(0);
     const float4 x4 = *reinterpret_cast<const float4*>(act + g * 16);
-    acc[0] = mfma16(w0.x, x4.x, acc[0]);
-    acc[1] = mfma16(w1.x, x4.x, acc[1]);
-    acc[0] = mfma16(w0.y, x4.y, acc[0]);
-    acc[1] = mfma16(w1.y, x4.y, acc[1]);
-    acc[0] = mfma16(w0.z, x4.z, acc[0]);
-    acc[1] = mfma16(w1.z, x4.z, acc[1]);
-    acc[0] = mfma16(w0.w, x4.w, acc[0]);
-    acc[1] = mfma16(w1.w, x4.w, acc[1]);
+    c[0][0 % NACC] = mfma16(w0.x, x4.x, c[0][0 % NACC]);
+    c[1][0 % NACC] = mfma16(w1.x, x4.x, c[1][0 % NACC]);
+    c[0][1 % NACC] = mfma16(w0.y, x4.y, c[0][1 % NACC]);
+    c[1][1 % NACC] = mfma16(w1.y, x4.y, c[1][1 % NACC]);
+    c[0][2 % NACC] = mfma16(w0.z, x4.z, c[0][2 % NACC]);
+    c[1][2 % NACC] = mfma16(w1.z, x4.z, c[1][2 % NACC]);
+    c[0][3 % NACC] = mfma16(w0.w, x4.w, c[0][3 % NACC]);
+    c[1][3 % NACC] = mfma16(w1.w, x4.w, c[1][3 % NACC]);
   }
+  acc4_sum<NACC>(acc, c);
 }
 
 // The same loop, and in the iterations that have no refill of their own (the last RP_PD k-groups)
 // one k-group of the NEXT weight stream is requested into `Rn`: those loads queue behind this
 // loop's own operands (vector memory returns in issue order) instead of in front of them, and
 // still have the rest of this loop to land.  Slots that do not fit are requested after the loop.
-template <int NKG, int NKGN>
+template <int NKG, int NKGN, int NACC = 1>
 __device__ __forceinline__ void rows16_gemm_static_pf(f32x4v (&acc)[2], WRing& R,
                                                       const float* __restrict__ Wf, int tile0,
                                                       int ntiles, const float* act, int lane,
@@ -290,6 +360,8 @@ __device__ __forceinline__ void rows16_gemm_static_pf(f32x4v (&acc)[2], WRing& R
   const int64_t nb1 = nb0 + (int64_t)NKGN * 256;
   constexpr int FREE0 = NKG > RP_PD ? NKG - RP_PD : 0;        // first iteration without a refill
   constexpr int NSLOT = NKGN < RP_PD ? NKGN : RP_PD;          // slots ring_fill<NKGN> would load
+  f32x4v c[2][NACC];
+  acc4_seed<NACC>(c, acc);
 #pragma unroll
   for (int g = 0; g < NKG; ++g) {
     const float4 w0 = R.r0[g % RP_PD], w1 = R.r1[g % RP_PD];
@@ -302,15 +374,16 @@ __device__ __forceinline__ void rows16_gemm_static_pf(f32x4v (&acc)[2], WRing& R
     }
     __builtin_amdgcn_sched_barrier(0);
     const float4 x4 = *reinterpret_cast<const float4*>(act + g * 16);
-    acc[0] = mfma16(w0.x, x4.x, acc[0]);
-    acc[1] = mfma16(w1.x, x4.x, acc[1]);
-    acc[0] = mfma16(w0.y, x4.y, acc[0]);
-    acc[1] = mfma16(w1.y, x4.y, acc[1]);
-    acc[0] = mfma16(w0.z, x4.z, acc[0]);
-    acc[1] = mfma16(w1.z, x4.z, acc[1]);
-    acc[0] = mfma16(w0.w, x4.w, acc[0]);
-    acc[1] = mfma16(w1.w, x4.w, acc[1]);
+    c[0][0 % NACC] = mfma16(w0.x, x4.x, c[0][0 % NACC]);
+    c[1][0 % NACC] = mfma16(w1.x, x4.x, c[1][0 % NACC]);
+    c[0][1 % NACC] = mfma16(w0.y, x4.y, c[0][1 % NACC]);
+    c[1][1 % NACC] = mfma16(w1.y, x4.y, c[1][1 % NACC]);
+    c[0][2 % NACC] = mfma16(w0.z, x4.z, c[0][2 % NACC]);
+    c[1][2 % NACC] = mfma16(w1.z, x4.z, c[1][2 % NACC]);
+    c[0][3 % NACC] = mfma16(w0.w, x4.w, c[0][3 % NACC]);
+    c[1][3 % NACC] = mfma16(w1.w, x4.w, c[1][3 % NACC]);
   }
+  acc4_sum<NACC>(acc, c);
 #pragma unroll
   for (int p = NKG - FREE0; p < NSLOT; ++p) {
     Rn.r0[p] = ld4_or_zero(Wn, nb0 + (int64_t)p * 256, nk0);
@@ -369,6 +442,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     __hip_atomic_store(a.signal_flag, a.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   PA_STAMP(a.prof, blockIdx.x, wave, 0);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 14);
+  if (a.wait_flag) rowpass_wait_x(a.wait_flag, a.wait_value, a.err, a.err_host);
   const int m0 = blockIdx.x * RP_ROWS;
   const int row = m0 + r16;
   const bool rok = row < a.B;
@@ -455,18 +529,22 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     for (int t = 0; t < 2; ++t) {        // (seeded here, not at the load: the copy waits for b1)
       acc[t][0] = b1v[t].x; acc[t][1] = b1v[t].y; acc[t][2] = b1v[t].z; acc[t][3] = b1v[t].w;
     }
+    constexpr int NACC = RP_NACC_FWD;
+    f32x4v c[2][NACC];
+    acc4_seed<NACC>(c, acc);
 #pragma unroll
     for (int g = 0; g < NG1; ++g) {
       const float4 x4 = xf[g], w0 = wa[g], w1 = wb[g];
-      acc[0] = mfma16(w0.x, x4.x, acc[0]);
-      acc[1] = mfma16(w1.x, x4.x, acc[1]);
-      acc[0] = mfma16(w0.y, x4.y, acc[0]);
-      acc[1] = mfma16(w1.y, x4.y, acc[1]);
-      acc[0] = mfma16(w0.z, x4.z, acc[0]);
-      acc[1] = mfma16(w1.z, x4.z, acc[1]);
-      acc[0] = mfma16(w0.w, x4.w, acc[0]);
-      acc[1] = mfma16(w1.w, x4.w, acc[1]);
+      c[0][0 % NACC] = mfma16(w0.x, x4.x, c[0][0 % NACC]);
+      c[1][0 % NACC] = mfma16(w1.x, x4.x, c[1][0 % NACC]);
+      c[0][1 % NACC] = mfma16(w0.y, x4.y, c[0][1 % NACC]);
+      c[1][1 % NACC] = mfma16(w1.y, x4.y, c[1][1 % NACC]);
+      c[0][2 % NACC] = mfma16(w0.z, x4.z, c[0][2 % NACC]);
+      c[1][2 % NACC] = mfma16(w1.z, x4.z, c[1][2 % NACC]);
+      c[0][3 % NACC] = mfma16(w0.w, x4.w, c[0][3 % NACC]);
+      c[1][3 % NACC] = mfma16(w1.w, x4.w, c[1][3 % NACC]);
     }
+    acc4_sum<NACC>(acc, c);
     PA_STAMP(a.prof, blockIdx.x, wave, 2);
   } else {
     // any shape: stage the x tile in LDS (zero padded to the pitch; the k loop runs over whole groups)
@@ -493,7 +571,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     }
     PA_STAMP(a.prof, blockIdx.x, wave, 1);
     __syncthreads();
-    rows16_gemm<4>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
+    rows16_gemm<4, RP_NACC_FWD>(acc, a.W1f, wf16_nkg(a.K1), tile0, nt1, xs + r16 * P1 + 4 * qd, lane);
     PA_STAMP(a.prof, blockIdx.x, wave, 2);
   }
 #pragma unroll
@@ -513,12 +591,12 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   __syncthreads();                                                      // barrier A: h1 tile
   PA_STAMP(a.prof, blockIdx.x, wave, 4);
   if constexpr (NG2 > 0 && NG3 > 0) {
-    rows16_gemm_static_pf<NG2, NG3>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane, R3,
+    rows16_gemm_static_pf<NG2, NG3, RP_NACC_FWD>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane, R3,
                                     a.W2tf, nt1, PH == 0 && a.y != nullptr);
   } else if constexpr (NG2 > 0) {
-    rows16_gemm_static<NG2>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
+    rows16_gemm_static<NG2, RP_NACC_FWD>(acc, R2, a.W2f, tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   } else {
-    rows16_gemm<4>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
+    rows16_gemm<4, RP_NACC_FWD>(acc, a.W2f, wf16_nkg(a.H1), tile0, nt2, h1s + r16 * PH1 + 4 * qd, lane);
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 5);
 #pragma unroll
@@ -562,8 +640,13 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
     PA_STAMP(a.prof, blockIdx.x, wave, 10);
     return;
   }
+  // PH 2 (the backward launch of a window's first round) typically arrives BEFORE its targets and
+  // waits for them: there ONE quarter-wave per workgroup polls and hands the values on through LDS
+  // (16 polling lanes instead of 512 — agent-scope loads bypass the L2, and the leading target
+  // tiles the launch is waiting for share that memory system)
+  const bool poller = PH != 2 || (wave == 0 && qd == 0);
   unsigned ybits = kYPendingBits;
-  if (a.y && rok) {
+  if (a.y && rok && poller) {
     // first look at the Bellman target, in flight while the backward GEMM runs
     ybits = a.y_tagged ? __hip_atomic_load(reinterpret_cast<const unsigned*>(a.y) + row,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -574,9 +657,9 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
     if constexpr (NG3 > 0) {
-      rows16_gemm_static<NG3>(acc, R3, a.W2tf, tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+      rows16_gemm_static<NG3, RP_NACC_BWD>(acc, R3, a.W2tf, tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
     } else {
-      rows16_gemm<4>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
+      rows16_gemm<4, RP_NACC_BWD>(acc, a.W2tf, wf16_nkg(a.H2), tile0, nt1, d2s + r16 * PH2 + 4 * qd, lane);
     }
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 8);
@@ -592,10 +675,15 @@ static __global__ __launch_bounds__(512) void online_rowpass_kernel(RowArgs a) {
   if (!a.y) return;
   // ---- loss, dZ2 = [h2 > 0] * (dq * w3), dZ1 = [h1 > 0] * (dq * G)
   float yv = q;
-  if (rok) {
+  if (rok && poller) {
     // (an untagged y can legitimately hold the tag's bit pattern: only the tagged protocol polls)
     if (a.y_tagged && ybits == kYPendingBits) yv = consume_y(a.y + row, a.err, a.err_host);
     else yv = __builtin_bit_cast(float, ybits);
+  }
+  if constexpr (PH == 2) {
+    if (poller) qpart[r16] = yv;      // (the head partials' LDS slots are free in this launch)
+    __syncthreads();
+    yv = rok ? qpart[r16] : q;
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 9);
   const float d = __fsub_rn(q, yv);

@@ -382,7 +382,10 @@ static __global__ __launch_bounds__(512, 2) void target_split_kernel(TargetArgs 
   }
   __shared__ int next_tile;
   if (a.reserved && a.reserved[cu_key()]) return;
-  if (threadIdx.x == 0) next_tile = atomicAdd(a.tile_ctr, 1);
+  if (threadIdx.x == 0) {
+    next_tile = atomicAdd(a.tile_ctr, 1);
+    if (a.dbg_workers && next_tile < a.ntiles) atomicAdd(a.dbg_workers, 1);
+  }
   __syncthreads();
   int tile = next_tile;
   while (tile < a.ntiles) {

@@ -1,9 +1,12 @@
 """Network construction helpers on the learner path
 (pearl/neural_networks/common/utils.py:75-152 mlp_block, :201-205 xavier init).
 
-Only the plain configuration the DQN/actor-critic configs use is built here (Linear + ReLU
-hidden layers, optional last activation); the reference's layer-norm / batch-norm / dropout /
-residual options change the math of the fused kernels and are rejected loudly.
+The plain configuration the DQN / actor-critic configs use (Linear + ReLU hidden layers, optional
+last activation) is what the fused kernels compute.  ``use_layer_norm`` and the other hidden
+activations of ``ActivationType`` (utils.py:29-56: leaky_relu, tanh, softplus, sigmoid, linear) are
+built too — such networks train through the generic ``pa_mlp`` engine layer by layer
+(``mlp_norm_act.hpp``; ``generic_q.mlp_spec`` is what recognises them).  Batch norm, dropout and
+residual blocks are still rejected loudly.
 """
 from __future__ import annotations
 
@@ -17,7 +20,9 @@ class _Softmax(nn.Softmax):
 
 
 _ACTIVATIONS = {"relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid, "linear": nn.Identity,
-                "softmax": _Softmax}
+                "softmax": _Softmax, "leaky_relu": nn.LeakyReLU, "softplus": nn.Softplus}
+# hidden activations with HIP kernels (pa_mlp_desc.hidden_act; "linear" = FlatMlp.identity_layers)
+HIDDEN_ACTIVATIONS = ("relu", "leaky_relu", "tanh", "softplus", "sigmoid", "linear")
 
 
 def mlp_block(input_dim: int, hidden_dims: Optional[List[int]], output_dim: int = 1,
@@ -30,19 +35,43 @@ def mlp_block(input_dim: int, hidden_dims: Optional[List[int]], output_dim: int 
     the order in which nn.Linear layers draw their default init are those of the reference, so
     the same ``torch.manual_seed`` yields the same initial weights.
     """
-    if use_batch_norm or use_layer_norm or dropout_ratio > 0 or use_skip_connections:
+    if use_batch_norm or dropout_ratio > 0 or use_skip_connections:
         raise NotImplementedError(
-            "pearl_amd.mlp_block: batch/layer norm, dropout and skip connections are not part of "
-            "the HIP learner path")
+            "pearl_amd.mlp_block: batch norm, dropout and skip connections are not part of the HIP "
+            "learner path")
+    if hidden_activation not in HIDDEN_ACTIVATIONS:
+        raise NotImplementedError(
+            f"pearl_amd.mlp_block: hidden_activation {hidden_activation!r} has no HIP kernel "
+            f"(built: {', '.join(HIDDEN_ACTIVATIONS)})")
     dims = [input_dim] + list(hidden_dims or []) + [output_dim]
     layers = []
     for d_in, d_out in zip(dims[:-2], dims[1:-1]):
-        layers.append(nn.Sequential(nn.Linear(d_in, d_out), _ACTIVATIONS[hidden_activation]()))
+        single = [nn.Linear(d_in, d_out)]
+        if use_layer_norm:
+            single.append(nn.LayerNorm(d_out))          # (utils.py:110-113: between Linear and activation)
+        single.append(_ACTIVATIONS[hidden_activation]())
+        layers.append(nn.Sequential(*single))
     last = [nn.Linear(dims[-2], dims[-1])]
     if last_activation is not None:
         last.append(_ACTIVATIONS[last_activation]())
     layers.append(nn.Sequential(*last))
     return nn.Sequential(*layers)
+
+
+def linear_layers_of_plain(model: nn.Module, owner: str) -> List[nn.Linear]:
+    """The nn.Linear modules of an mlp_block in its PLAIN form — hidden blocks ``Sequential(Linear,
+    ReLU)`` — for the learners whose fused kernels hard-wire that form (the actor-critic family, the
+    fused DQN step).  A network with LayerNorm or another hidden activation is refused here, loudly:
+    it must never be trained as if it were ReLU.  (Such Q networks train through the generic TD
+    engine, which reads the blocks itself: generic_q.mlp_spec.)"""
+    blocks = list(model) if isinstance(model, nn.Sequential) else []
+    for blk in blocks[:-1]:
+        if not (isinstance(blk, nn.Sequential) and len(blk) == 2 and isinstance(blk[0], nn.Linear)
+                and type(blk[1]) is nn.ReLU):
+            raise NotImplementedError(
+                f"pearl_amd: {owner} has hidden layers that are not Linear + ReLU (LayerNorm / other "
+                "activations): this learner's fused HIP kernels compute the plain form only")
+    return [m for m in model.modules() if isinstance(m, nn.Linear)]
 
 
 def xavier_init_weights(m: nn.Module) -> None:

@@ -10,7 +10,7 @@ from typing import Any, List, Optional
 import torch.nn as nn
 from torch import Tensor
 
-from .utils import mlp_block
+from .utils import mlp_block, linear_layers_of_plain
 
 
 class ValueNetwork(nn.Module):
@@ -28,4 +28,4 @@ class VanillaValueNetwork(ValueNetwork):
         return self._model(x)
 
     def linear_layers(self) -> List[nn.Linear]:
-        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+        return linear_layers_of_plain(self._model, type(self).__name__)

@@ -15,7 +15,7 @@ import torch.nn as nn
 from torch import Tensor
 from torch.distributions import Normal
 
-from ..common.utils import mlp_block
+from ..common.utils import mlp_block, linear_layers_of_plain
 
 
 def action_scaling(action_space: Any, input_action: Tensor) -> Tensor:
@@ -61,7 +61,7 @@ class VanillaActorNetwork(ActorNetwork):
         return torch.sum(all_action_probs * action_batch, dim=1, keepdim=True).view(-1)
 
     def linear_layers(self) -> List[nn.Linear]:
-        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+        return linear_layers_of_plain(self._model, type(self).__name__)
 
 
 class VanillaContinuousActorNetwork(ActorNetwork):
@@ -81,7 +81,7 @@ class VanillaContinuousActorNetwork(ActorNetwork):
         return action_scaling(self._action_space, self._model(x))
 
     def linear_layers(self) -> List[nn.Linear]:
-        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+        return linear_layers_of_plain(self._model, type(self).__name__)
 
 
 class GaussianActorNetwork(ActorNetwork):
@@ -139,4 +139,4 @@ class GaussianActorNetwork(ActorNetwork):
         return log_prob
 
     def trunk_layers(self) -> List[nn.Linear]:
-        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+        return linear_layers_of_plain(self._model, type(self).__name__)

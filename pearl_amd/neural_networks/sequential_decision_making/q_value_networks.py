@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
-from ..common.utils import mlp_block
+from ..common.utils import mlp_block, linear_layers_of_plain
 
 
 class QValueNetwork(ABC, nn.Module):
@@ -68,7 +68,7 @@ class VanillaQValueNetwork(QValueNetwork):
         return self._action_dim
 
     def linear_layers(self) -> List[nn.Linear]:
-        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+        return linear_layers_of_plain(self._model, type(self).__name__)
 
 
 class VanillaQValueMultiHeadNetwork(QValueNetwork):
@@ -103,7 +103,7 @@ class VanillaQValueMultiHeadNetwork(QValueNetwork):
         return self._action_dim
 
     def linear_layers(self) -> List[nn.Linear]:
-        return [m for m in self._model.modules() if isinstance(m, nn.Linear)]
+        return linear_layers_of_plain(self._model, type(self).__name__)
 
 
 class DuelingQValueNetwork(QValueNetwork):

@@ -47,7 +47,7 @@ from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import EGreedyExploration, ExplorationModule
 from ..policy_learner import PolicyLearner
-from .generic_q import GenericTd, make_ops, plain_relu_mlp
+from .generic_q import GenericTd, make_ops, mlp_spec, plain_relu_mlp
 
 _FLAT_NAMES = ("q", "q_target", "grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")
 
@@ -157,17 +157,19 @@ class DeepQLearning(PolicyLearner):
                     "(VanillaQValueNetwork, VanillaQValueMultiHeadNetwork, DuelingQValueNetwork are)")
         # Which engine trains it.  Fused MI355X path (pa_dqn_*): VanillaQValueNetwork, two ReLU hidden
         # layers of at most 256 units.  Everything else the reference's mlp_block can express with
-        # Linear + ReLU goes through the generic pa_mlp engine (generic_q.py); other activations /
-        # norms / dropout are refused here, loudly — never trained as if they were ReLU.
+        # Linear [+ LayerNorm] + relu / leaky_relu / tanh / softplus / sigmoid / linear hidden layers
+        # goes through the generic pa_mlp engine (generic_q.py); batch norm / dropout / residual blocks
+        # are refused, loudly — never trained as if they were something else.
         self._fused = False
         if isinstance(self._Q, VanillaQValueNetwork):
-            if not plain_relu_mlp(self._Q._model):
+            spec = mlp_spec(self._Q._model)
+            if spec is None:
                 raise NotImplementedError(
-                    "pearl_amd DeepQLearning: the Q network is not a plain Linear + ReLU mlp_block "
-                    "(other activations, normalisation, dropout or residual blocks have no HIP kernels)")
-            lin = self._Q.linear_layers()
-            self._fused = (len(lin) == 3 and lin[0].out_features <= 256 and lin[1].out_features <= 256
-                           and lin[2].out_features == 1)
+                    "pearl_amd DeepQLearning: the Q network is not an mlp_block the HIP engine computes "
+                    "(batch norm, dropout or residual blocks, or an activation without a kernel)")
+            lin = spec["linears"]
+            self._fused = (spec["plain"] and len(lin) == 3 and lin[0].out_features <= 256
+                           and lin[1].out_features <= 256 and lin[2].out_features == 1)
         if is_conservative and not self._fused:
             raise NotImplementedError("pearl_amd DeepQLearning: the CQL term is built for the fused "
                                       "VanillaQValueNetwork path only")
@@ -765,6 +767,9 @@ class DeepQLearning(PolicyLearner):
         torch.cuda.current_stream(dev).synchronize()
         losses = nat.loss_host[:rounds].tolist()
         N.check(N.lib().pa_dqn_check(nat.handle))
+        if comm is not None:
+            from ... import _comm
+            _comm.check_exchange()     # (P2P exchange: a peer that never answered is an exception here)
         return {"loss": losses}
 
     # ------------------------------------------------------------------ act / compare

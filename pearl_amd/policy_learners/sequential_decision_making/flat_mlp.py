@@ -45,10 +45,20 @@ def reduce_gradient_(flat_grad: torch.Tensor, reduce: str = "mean") -> torch.Ten
 
 class FlatMlp:
     def __init__(self, layers: List[Layer], optimizer: Optional[optim.Optimizer], max_batch: int,
-                 target_layers: Optional[List[Layer]] = None, identity_layers: int = 0) -> None:
+                 target_layers: Optional[List[Layer]] = None, identity_layers: int = 0,
+                 norms: Optional[Sequence[nn.LayerNorm]] = None,
+                 target_norms: Optional[Sequence[nn.LayerNorm]] = None, hidden_act: int = 0) -> None:
         self.layers = layers
         self.identity_layers = int(identity_layers)   # bit l: hidden layer l has no ReLU
         self.target_layers = target_layers
+        # mlp_block's other forms (pa_mlp_desc.hidden_act / layer_norm): the hidden layers' nn.LayerNorm
+        # modules (one per hidden layer; their weight / bias join the flat buffers behind W / b) and
+        # the activation kind (0 relu, 1 leaky_relu, 2 tanh, 3 softplus, 4 sigmoid)
+        self.norms = list(norms) if norms else None
+        self.target_norms = list(target_norms) if target_norms else None
+        self.hidden_act = int(hidden_act)
+        assert self.norms is None or len(self.norms) == len(layers) - 1
+        assert (self.target_norms is None) == (self.norms is None or target_layers is None)
         self.optimizer = optimizer
         self.max_batch = int(max_batch)
         self.dims = [int(layers[0][0][0].shape[1])] + [
@@ -75,7 +85,23 @@ class FlatMlp:
 
     # ------------------------------------------------------------------ binding
     def _params(self) -> List[nn.Parameter]:
-        return [p for ws, bs in self.layers for p in (*ws, *bs)]
+        ps = [p for ws, bs in self.layers for p in (*ws, *bs)]
+        if self.norms:
+            ps += [p for ln in self.norms for p in (ln.weight, ln.bias)]
+        return ps
+
+    def _target_params(self) -> List[nn.Parameter]:
+        if self.target_layers is None:
+            return []
+        ps = [p for ws, bs in self.target_layers for p in (*ws, *bs)]
+        if self.target_norms:
+            ps += [p for ln in self.target_norms for p in (ln.weight, ln.bias)]
+        return ps
+
+    @property
+    def plain(self) -> bool:
+        """Linear + ReLU (+ identity layers): the form the fused row kernels compute."""
+        return self.norms is None and self.hidden_act == 0
 
     def _group(self) -> dict:
         if self.optimizer is None:
@@ -134,8 +160,7 @@ class FlatMlp:
             st = self.optimizer.state.get(p, {}) if self.optimizer is not None else {}
             sig.append((p.data_ptr(), tuple(st[k].data_ptr() if k in st else 0
                                             for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"))))
-        if self.target_layers is not None:
-            sig.extend(p.data_ptr() for ws, bs in self.target_layers for p in (*ws, *bs))
+        sig.extend(p.data_ptr() for p in self._target_params())
         return tuple(sig)
 
     def ensure(self, batch_hint: int = 0) -> "FlatMlp":
@@ -154,7 +179,7 @@ class FlatMlp:
         g = self._group()
         max_b = max(self.max_batch, int(batch_hint), 1)
         key = (dev.index, tuple(self.dims), max_b, g["lr"], tuple(g["betas"]), g["eps"],
-               g["weight_decay"], bool(g.get("amsgrad", False)))
+               g["weight_decay"], bool(g.get("amsgrad", False)), self.hidden_act, self.norms is not None)
         if self.handle is not None and key != self._desc_key:
             torch.cuda.synchronize(dev)
             self.close()
@@ -163,7 +188,8 @@ class FlatMlp:
                              lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
                              weight_decay=g["weight_decay"], amsgrad=int(bool(g.get("amsgrad", False))),
                              no_last_bias=int(len(self.layers[-1][1]) == 0),
-                             identity_layers=self.identity_layers)
+                             identity_layers=self.identity_layers, hidden_act=self.hidden_act,
+                             layer_norm=int(self.norms is not None))
             for i, d in enumerate(self.dims):
                 desc.dims[i] = d
             self._desc = desc
@@ -199,13 +225,23 @@ class FlatMlp:
         self._step_bank = torch.full((n_params,), float(steps), dtype=torch.float32) \
             if self.optimizer is not None else None
         bank_i = 0
+        # (parameter lists, flat offset, the matching target parameters) in _params() order: every
+        # layer's weights and biases, then every LayerNorm's weight and bias
+        groups = []
+        for li, (ws, bs) in enumerate(self.layers):
+            for kind, plist in ((0, ws), (1, bs)):
+                groups.append((plist, int(offs[2 * li + kind]),
+                               self.target_layers[li][kind] if self.target_layers is not None else None))
+        if self.norms:
+            noffs = (C.c_int64 * (2 * len(self.norms)))()
+            N.check(N.lib().pa_mlp_norm_offsets(C.byref(self._desc), noffs))
+            for li, ln in enumerate(self.norms):
+                tn = self.target_norms[li] if self.target_norms else None
+                groups.append(([ln.weight], int(noffs[2 * li]), [tn.weight] if tn is not None else None))
+                groups.append(([ln.bias], int(noffs[2 * li + 1]), [tn.bias] if tn is not None else None))
         with torch.no_grad():
-            for li, (ws, bs) in enumerate(self.layers):
-                for kind, plist in ((0, ws), (1, bs)):
-                    o = int(offs[2 * li + kind])
-                    tl = None
-                    if self.target_layers is not None:
-                        tl = self.target_layers[li][kind]
+            for plist, o, tl in groups:
+                if True:
                     for pi, p in enumerate(plist):
                         n = p.numel()
                         sl = slice(o, o + n)
@@ -253,8 +289,7 @@ class FlatMlp:
         they are what ``load_state_dict`` / torch optimizers write through.  Writes through a
         ``.data`` alias are not versioned by torch at all: nothing can see those."""
         vs = [p._version for p in self._params()]
-        if self.target_layers is not None:
-            vs.extend(p._version for ws, bs in self.target_layers for p in (*ws, *bs))
+        vs.extend(p._version for p in self._target_params())
         return tuple(vs)
 
     def ready(self, batch: int = 0) -> "FlatMlp":
@@ -306,7 +341,8 @@ class FlatMlp:
     def supports_q_all(self, n_actions: int) -> bool:
         """pa_mlp_q_all's shapes: a [S + AD, H1 <= 256, H2 <= 256, 1] ReLU critic, <= 64 actions."""
         return (len(self.dims) == 4 and self.dims[3] == 1 and max(self.dims[1:3]) <= 256
-                and self.identity_layers == 0 and len(self.layers[-1][1]) > 0 and n_actions <= 64)
+                and self.identity_layers == 0 and self.plain and len(self.layers[-1][1]) > 0
+                and n_actions <= 64)
 
     def q_all(self, state: torch.Tensor, rep: torch.Tensor, use_target: bool = False) -> torch.Tensor:
         """Q(s_b, a_i) for every action of every state's action set: (B * A,), row b * A + i —

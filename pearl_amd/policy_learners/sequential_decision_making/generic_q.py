@@ -47,6 +47,75 @@ def plain_relu_mlp(model: nn.Module) -> bool:
     return isinstance(last, nn.Sequential) and len(last) == 1 and isinstance(last[0], nn.Linear)
 
 
+_ACT_KIND = {nn.ReLU: 0, nn.LeakyReLU: 1, nn.Tanh: 2, nn.Softplus: 3, nn.Sigmoid: 4}
+
+
+def mlp_spec(model: nn.Module) -> Optional[Dict[str, Any]]:
+    """What the pa_mlp engine needs to know about an mlp_block (common/utils.py:75-152), or None when
+    the model is something else: hidden blocks ``Sequential(Linear[, LayerNorm], activation)`` that
+    all have the same form, then ``Sequential(Linear)``.  Activations: ReLU, LeakyReLU (slope 0.01),
+    Tanh, Softplus (beta 1, threshold 20), Sigmoid, Identity.  Returns ``linears``, ``norms`` (the
+    LayerNorm modules or None), ``hidden_act`` (pa_mlp_desc.hidden_act), ``identity`` (hidden layers
+    have no activation), ``plain`` (Linear + ReLU only: the fused kernels' form)."""
+    if not isinstance(model, nn.Sequential) or len(model) == 0:
+        return None
+    blocks = list(model)
+    linears, norms, kinds = [], [], []
+    for blk in blocks[:-1]:
+        if not (isinstance(blk, nn.Sequential) and len(blk) in (2, 3) and isinstance(blk[0], nn.Linear)):
+            return None
+        ln = blk[1] if len(blk) == 3 else None
+        if ln is not None:
+            if not (type(ln) is nn.LayerNorm and ln.elementwise_affine and ln.bias is not None
+                    and tuple(ln.normalized_shape) == (blk[0].out_features,) and ln.eps == 1e-5):
+                return None
+        act = blk[-1]
+        if type(act) is nn.Identity:
+            kind = -1
+        elif type(act) in _ACT_KIND:
+            kind = _ACT_KIND[type(act)]
+            if kind == 1 and act.negative_slope != 0.01:
+                return None
+            if kind == 3 and (act.beta != 1 or act.threshold != 20):
+                return None
+        else:
+            return None
+        linears.append(blk[0]); norms.append(ln); kinds.append(kind)
+    last = blocks[-1]
+    if not (isinstance(last, nn.Sequential) and len(last) == 1 and isinstance(last[0], nn.Linear)):
+        return None
+    linears.append(last[0])
+    if len(set(kinds)) > 1 or len({n is None for n in norms}) > 1:
+        return None                     # mlp_block gives every hidden layer the same form
+    has_ln = bool(norms) and norms[0] is not None
+    kind = kinds[0] if kinds else 0
+    return {"linears": linears, "norms": norms if has_ln else None, "hidden_act": max(kind, 0),
+            "identity": kind == -1, "plain": (not has_ln) and kind == 0}
+
+
+def plain_or_spec(model: nn.Module, what: str) -> Dict[str, Any]:
+    spec = mlp_spec(model)
+    if spec is None:
+        raise NotImplementedError(
+            f"pearl_amd: {what} is not an mlp_block the HIP engine computes (Linear [+ LayerNorm] + "
+            "relu / leaky_relu / tanh / softplus / sigmoid / linear hidden layers; batch norm, dropout "
+            "and residual blocks have no kernels)")
+    return spec
+
+
+def flat_mlp_of(model: nn.Module, target_model: Optional[nn.Module], optimizer: Any, max_batch: int,
+                what: str) -> FlatMlp:
+    """FlatMlp over an mlp_block in any of the forms mlp_spec recognises (target_model: its copy)."""
+    spec = plain_or_spec(model, what)
+    tspec = plain_or_spec(target_model, what + " (target)") if target_model is not None else None
+    L = len(spec["linears"])
+    return FlatMlp(layers_of(spec["linears"]), optimizer, max_batch,
+                   target_layers=layers_of(tspec["linears"]) if tspec is not None else None,
+                   identity_layers=((1 << (L - 1)) - 1) if spec["identity"] else 0,
+                   norms=spec["norms"], target_norms=tspec["norms"] if tspec is not None else None,
+                   hidden_act=spec["hidden_act"])
+
+
 def _f32(t: Tensor, dev: torch.device) -> Tensor:
     return t.to(device=dev, dtype=torch.float32).contiguous()
 
@@ -102,8 +171,8 @@ def _concat(left: Tensor, right: Tensor, out: Optional[Tensor] = None) -> Tensor
 class VanillaOps(_Ops):
     def __init__(self, q: VanillaQValueNetwork, q_target: VanillaQValueNetwork, optimizer: Any,
                  max_batch: int) -> None:
-        self.net = FlatMlp(layers_of(q.linear_layers()), optimizer, max_batch,
-                           target_layers=layers_of(q_target.linear_layers()))
+        self.net = flat_mlp_of(q._model, q_target._model, optimizer, max_batch,
+                               f"{type(q).__name__}._model")
         self.nets = [self.net]
         self._x: Optional[Tensor] = None
 
@@ -127,8 +196,8 @@ class VanillaOps(_Ops):
 class MultiHeadOps(_Ops):
     def __init__(self, q: VanillaQValueMultiHeadNetwork, q_target: VanillaQValueMultiHeadNetwork,
                  optimizer: Any, max_batch: int) -> None:
-        self.net = FlatMlp(layers_of(q.linear_layers()), optimizer, max_batch,
-                           target_layers=layers_of(q_target.linear_layers()))
+        self.net = flat_mlp_of(q._model, q_target._model, optimizer, max_batch,
+                               f"{type(q).__name__}._model")
         self.nets = [self.net]
         self.A = int(self.net.dims[-1])
         self._state: Optional[Tensor] = None
@@ -239,10 +308,7 @@ def make_ops(q: nn.Module, q_target: nn.Module, optimizer: Any, max_batch: int) 
             raise NotImplementedError("pearl_amd: DuelingQValueNetwork towers must be plain "
                                       "Linear + ReLU mlp_blocks")
         return DuelingOps(q, q_target, optimizer, max_batch)
-    if not plain_relu_mlp(getattr(q, "_model", None)):
-        raise NotImplementedError(
-            f"pearl_amd: {type(q).__name__}._model is not a plain Linear + ReLU mlp_block (other "
-            "activations, normalisation, dropout or residual blocks have no HIP kernels)")
+    plain_or_spec(getattr(q, "_model", None), f"{type(q).__name__}._model")
     if isinstance(q, VanillaQValueMultiHeadNetwork):
         return MultiHeadOps(q, q_target, optimizer, max_batch)
     if isinstance(q, VanillaQValueNetwork):

@@ -107,15 +107,38 @@ def test_unsupported_configurations_fail_loudly():
     DeepQLearning(hidden_dims=[8, 8], is_conservative=True, **kw)
     with pytest.raises(NotImplementedError):
         DeepQLearning(hidden_dims=[8, 8, 8], is_conservative=True, **kw)
-    # refused: a network instance whose hidden activation is not ReLU, or with layer norm
+    # built (round 5): mlp_block's LayerNorm and its other hidden activations — through the generic
+    # engine, never the fused step (common/utils.py:75-152)
+    from pearl_amd.neural_networks.common.utils import mlp_block
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1, use_layer_norm=True)
+    assert isinstance(net._model[0][1], nn.LayerNorm)
+    assert not DeepQLearning(network_instance=net, **kw)._fused
+    for act in ("leaky_relu", "tanh", "softplus", "sigmoid", "linear"):
+        net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+        net._model = mlp_block(7, [8, 8], 1, hidden_activation=act, use_layer_norm=(act == "tanh"))
+        assert not DeepQLearning(network_instance=net, **kw)._fused
+    # the learners whose fused kernels hard-wire Linear + ReLU refuse such a network instead of
+    # training it as ReLU
+    with pytest.raises(NotImplementedError, match="not Linear \\+ ReLU"):
+        net.linear_layers()
+    # refused: hidden layers of MIXED form (mlp_block gives every hidden layer the same one), batch
+    # norm, dropout, residual blocks, activations without a kernel
     net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
     net._model[0][1] = nn.Tanh()
-    with pytest.raises(NotImplementedError, match="plain Linear"):
+    with pytest.raises(NotImplementedError, match="not an mlp_block the HIP engine computes"):
         DeepQLearning(network_instance=net, **kw)
     net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
     net._model[1] = nn.Sequential(nn.Linear(8, 8), nn.LayerNorm(8), nn.ReLU())
-    with pytest.raises(NotImplementedError, match="plain Linear"):
+    with pytest.raises(NotImplementedError, match="not an mlp_block the HIP engine computes"):
         DeepQLearning(network_instance=net, **kw)
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+    net._model[0] = nn.Sequential(nn.Linear(7, 8), nn.ReLU(), nn.BatchNorm1d(8))
+    with pytest.raises(NotImplementedError, match="not an mlp_block the HIP engine computes"):
+        DeepQLearning(network_instance=net, **kw)
+    for bad in (dict(use_batch_norm=True), dict(dropout_ratio=0.1), dict(use_skip_connections=True),
+                dict(hidden_activation="normalized_softplus")):
+        with pytest.raises(NotImplementedError):
+            mlp_block(7, [8, 8], 1, **bad)
     with pytest.raises(NotImplementedError):
         DeepQLearning(hidden_dims=[8, 8], optimizer=torch.optim.SGD(net.parameters(), lr=0.1), **kw)
 

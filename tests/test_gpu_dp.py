@@ -130,12 +130,32 @@ def _p2p_unit_worker(rank, world, port, q):
                 ok, msg = False, f"round {rnd} (n = {n}): sum differs"
                 break
         N.check(N.lib().pa_comm_p2p_check(_comm._state["handle"]))
-        # a message above the exchange buffer's capacity is refused, not truncated
+        # a message above the slot size: allreduce_sum_ sends it in slot-sized pieces ...
+        n = 2 * 300032 + 777
+        parts = [torch.randn(n, generator=torch.Generator().manual_seed(77 + r)) for r in range(world)]
+        buf = parts[rank].to(dev)
+        _comm.allreduce_sum_(buf)
+        want = parts[0].clone()
+        for r in range(1, world):
+            want += parts[r]
+        torch.cuda.synchronize()
+        if ok and not torch.equal(buf.cpu(), want):
+            ok, msg = False, "chunked message: sum differs"
+        # ... and one that does not start on a 16-byte boundary goes through torch.distributed
+        odd = parts[rank].to(dev)[1:1001]
+        _comm.allreduce_sum_(odd)
+        torch.cuda.synchronize()
+        if ok and not torch.allclose(odd.cpu(), sum(p[1:1001] for p in parts), rtol=0, atol=1e-5):
+            ok, msg = False, "misaligned message: sum differs"
+        _comm.check_exchange()
+        # the C entry point itself refuses (and says why) what does not fit a slot: never truncated
         big = torch.zeros(300001 + 64, device=dev)
         rc = N.lib().pa_comm_allreduce_start(_comm._state["handle"], big.data_ptr(), big.numel(),
                                              N.stream_ptr(dev))
         if rc == 0:
             ok, msg = False, "an oversized message was accepted"
+        elif "does not fit" not in N.last_error():
+            ok, msg = False, f"refusal without a reason: {N.last_error()!r}"
     except Exception as e:  # noqa: BLE001
         ok, msg = False, f"{type(e).__name__}: {e}"
     q.put((rank, ok, msg))
@@ -143,11 +163,13 @@ def _p2p_unit_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_p2p_exchange_sums_in_rank_order_over_many_rounds(world):
     """pa_comm_create_p2p / _p2p_handle / _p2p_open + the two exchange launches, `world` processes
     on one GPU: messages of ragged lengths back to back (both slots reused many times), every
-    rank's result bitwise the fp32 sum in rank order; oversized messages are refused."""
+    rank's result bitwise the fp32 sum in rank order; oversized messages go in pieces through
+    ``allreduce_sum_`` and are refused by the C entry point.  world = 8 is the width the exchange is
+    built for (kP2PMaxWorld, one node)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -161,6 +183,88 @@ def test_p2p_exchange_sums_in_rank_order_over_many_rounds(world):
         assert p.exitcode == 0
     for rank, ok, msg in res:
         assert ok, f"rank {rank}: {msg}"
+
+
+def _p2p_fault_worker(rank, world, port, q, mode):
+    os.environ["PEARL_AMD_P2P"] = "1"
+    os.environ["PEARL_AMD_P2P_TIMEOUT_S"] = "20" if mode == "late" else "2"
+    import time
+    import torch.distributed as dist
+    from pearl_amd import _comm, _native as N
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    res = {"rank": rank}
+    try:
+        a = torch.full((4096,), float(rank + 1), device=dev)
+        _comm.allreduce_sum_(a)                  # brings the communicator up; a healthy round
+        torch.cuda.synchronize()
+        res["first"] = float(a[0])
+        b = torch.full((4096,), float(rank + 1), device=dev)
+        if mode == "late":
+            if rank == 1:
+                time.sleep(1.5)                  # a rank that checkpoints / evaluates: well inside the bound
+            _comm.allreduce_sum_(b)
+            torch.cuda.synchronize()
+            res["second"] = float(b[0])
+            _comm.check_exchange()
+        elif rank == 0:
+            # the peer never publishes this round: the wait expires after the bound, the round's
+            # buffer is NaN (never the local gradient, never a partial sum), the error is sticky
+            t0 = time.time()
+            _comm.allreduce_sum_(b)
+            torch.cuda.synchronize()
+            res["elapsed"] = time.time() - t0
+            res["all_nan"] = bool(torch.isnan(b).all())
+            try:
+                _comm.check_exchange()
+                res["check_raised"] = False
+            except RuntimeError as e:
+                res["check_raised"] = "expired" in str(e)
+            try:
+                _comm.allreduce_sum_(torch.ones(64, device=dev))
+                res["refused"] = False
+            except RuntimeError as e:
+                res["refused"] = "poisoned" in str(e) or "expired" in str(e)
+        res["ok"] = True
+    except Exception as e:  # noqa: BLE001
+        res["ok"], res["msg"] = False, f"{type(e).__name__}: {e}"
+    q.put(res)
+    dist.barrier()           # (rank 1 stays alive until rank 0 is done: its buffer is mapped there)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["late", "dead"])
+def test_p2p_exchange_late_peer_waits_and_dead_peer_poisons(mode):
+    """the P2P exchange's bounded wait.  A peer that is LATE (1.5 s: a rank that
+    checkpoints or evaluates) is simply waited for — the sum is right, nothing is reported.  A peer
+    that NEVER publishes the round (bound set to 2 s here; 30 s by default) makes the launch give up
+    without hanging the GPU, and then nothing is silently wrong: the round's buffer is NaN, not the
+    local gradient or a partial sum; ``check_exchange`` — what every data-parallel ``learn()`` calls
+    after its host sync — raises; the communicator refuses every later exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_p2p_fault_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=300)
+        res[r["rank"]] = r
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in res.values():
+        assert r["ok"], r
+        assert r["first"] == 3.0
+    if mode == "late":
+        assert res[0]["second"] == res[1]["second"] == 3.0
+    else:
+        r0 = res[0]
+        assert r0["elapsed"] < 15.0, r0
+        assert r0["all_nan"] and r0["check_raised"] and r0["refused"], r0
 
 
 def test_two_ranks_equal_one_reference_learner_on_the_concatenated_batch():

@@ -847,6 +847,68 @@ def test_fullbatch_reference_parity(learner):
         torch.testing.assert_close(p.grad.cpu(), want["grads"][k], rtol=2e-4, atol=2e-6, msg=k)
 
 
+def _q64(params, x):
+    w = {k: v.double() for k, v in params.items()}
+    h = torch.relu(x.double() @ w["_model.0.0.weight"].t() + w["_model.0.0.bias"])
+    h = torch.relu(h @ w["_model.1.0.weight"].t() + w["_model.1.0.bias"])
+    return (h @ w["_model.2.0.weight"].t() + w["_model.2.0.bias"]).squeeze(-1)
+
+
+def test_paired_rowpass_is_the_single_workgroup_rowpass_and_closer_to_float64(monkeypatch):
+    """Round 5: the online row pass of the benchmark's shape runs on TWO workgroups per 16-row tile
+    (online_pair_kernel.hpp: layer 2 and the backward GEMM split by hidden unit, the halves' head
+    partials exchanged as tagged words, dZ1 left as two partials that the weight-gradient kernel
+    adds as it loads) with four accumulators per k loop.  Against the one-workgroup kernel
+    (PEARL_AMD_ROWPASS_PAIR=0) on config 2's own batch: the same Q-values, loss, gradients and first
+    optimizer step up to fp32 summation order — and Q(s, a) at least as close to float64 as the
+    REFERENCE's own fp32 output is."""
+    from pearl_amd import (DeepQLearning, OneHotActionTensorRepresentationModule, TransitionBatch)
+    fx = _load("dqn_cfg2_fullbatch")
+    cfg, want = fx["config"], fx["learners"]["dqn"]
+
+    def build():
+        pl = DeepQLearning(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
+                           training_rounds=1, batch_size=cfg["B"],
+                           action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+        pl._Q.load_state_dict(fx["params0"])
+        pl._Q_target.load_state_dict(fx["target0"])
+        return pl.to(DEV)
+
+    def batch(pl):
+        return pl.preprocess_batch(TransitionBatch(
+            **{k: (None if v is None else v.to(DEV)) for k, v in fx["batch_raw"].items()}))
+
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PEARL_AMD_ROWPASS_PAIR", mode)
+        pl = build()
+        b = batch(pl)
+        q = pl.q_values_and_targets(b)["q"].cpu()
+        rep = pl.learn_batch(batch(pl))
+        res[mode] = (q, rep["loss"], {k: p.grad.cpu().clone() for k, p in pl._Q.named_parameters()},
+                     {k: v.cpu().clone() for k, v in pl._Q.state_dict().items()})
+        x = torch.cat([b.state, b.action], dim=-1).cpu()
+    (qp, lp, gp, sp), (qs, ls, gs, ss) = res["1"], res["0"]
+    torch.testing.assert_close(qp, qs, rtol=1e-5, atol=1e-6)
+    assert abs(lp - ls) <= 1e-6 * max(1.0, abs(ls))
+    for k in gp:
+        torch.testing.assert_close(gp[k], gs[k], rtol=1e-4, atol=1e-7, msg=k)
+        torch.testing.assert_close(gp[k], want["grads"][k], rtol=2e-4, atol=2e-6, msg=k)
+        # (first AdamW step: lr g / (|g| + eps) — a 1e-4 relative difference in a gradient of the size
+        #  of eps moves the parameter by a fraction of lr = 1e-3)
+        torch.testing.assert_close(sp[k], ss[k], rtol=1e-5, atol=1e-6, msg=k)
+    # distance from float64 in bench.py's metric (elements with |exact| >= 1 % of the maximum)
+    exact = _q64(fx["params0"], x)
+    big = exact.abs() >= 0.01 * exact.abs().max()
+
+    def err(v):
+        return float(((v.double() - exact).abs()[big] / exact.abs()[big]).max())
+
+    e_pair, e_single, e_ref = err(qp), err(qs), err(want["q"])
+    print(f"max rel Q error vs float64: paired {e_pair:.3g}, single {e_single:.3g}, reference {e_ref:.3g}")
+    assert e_pair <= e_ref, (e_pair, e_ref)
+
+
 def test_sarsa_buffer_checkpoint_resume_is_exact():
     """SARSAReplayBuffer.state_dict()/load_state_dict(): the next_action column of the stored rows
     and the pending (cached) transition survive a round trip into a FRESH buffer — same sampled
@@ -888,7 +950,11 @@ def test_sarsa_buffer_checkpoint_resume_is_exact():
 
 
 QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", "multihead_cfg2_shape",
-         "dueling_tiny", "dueling_double_small"]
+         "dueling_tiny", "dueling_double_small",
+         # mlp_block's other forms (round 5, common/utils.py:75-152): LayerNorm between every hidden
+         # Linear and its activation; leaky_relu / tanh / softplus / sigmoid hidden activations
+         "layernorm_tiny", "layernorm_small", "layernorm_multihead_tiny", "leaky_tiny",
+         "tanh_layernorm_small", "softplus_tiny", "sigmoid_tiny"]
 
 
 def make_qnet_learner(fx):
@@ -898,9 +964,23 @@ def make_qnet_learner(fx):
     nt = {"vanilla": Q.VanillaQValueNetwork, "multihead": Q.VanillaQValueMultiHeadNetwork,
           "dueling": Q.DuelingQValueNetwork}[cfg["network"]]
     cls = DoubleDQN if cfg.get("learner") == "double" else DeepQLearning
+    extra = dict(network_type=nt)
+    if cfg.get("use_layer_norm") or cfg.get("hidden_activation"):
+        # a network_instance in one of mlp_block's other forms, built as oracle/make_golden.py builds
+        # the reference's
+        from pearl_amd.neural_networks.common.utils import mlp_block
+        S, A, multi = cfg["S"], cfg["A"], cfg["network"] == "multihead"
+        net = nt(state_dim=S, action_dim=A, hidden_dims=cfg["hidden"], output_dim=A if multi else 1,
+                 use_layer_norm=bool(cfg.get("use_layer_norm")))
+        if cfg.get("hidden_activation"):
+            net._model = mlp_block(input_dim=S if multi else S + A, hidden_dims=cfg["hidden"],
+                                   output_dim=A if multi else 1,
+                                   use_layer_norm=bool(cfg.get("use_layer_norm")),
+                                   hidden_activation=cfg["hidden_activation"])
+        extra = dict(network_instance=net)
     pl = cls(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
-             training_rounds=cfg["rounds"], batch_size=cfg["B"], network_type=nt,
-             action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]))
+             training_rounds=cfg["rounds"], batch_size=cfg["B"],
+             action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]), **extra)
     assert not pl._fused
     pl._Q.load_state_dict(fx["params0"])
     pl._Q_target.load_state_dict(fx["target0"])

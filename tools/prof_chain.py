@@ -19,7 +19,7 @@ from pearl_amd import (BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepre
                        PearlAgent, _native as N)
 
 ROW_NAMES = ["start", "loads issued", "L1 done", "h1 stored", "barA", "L2 done", "s2/head part",
-             "barB", "G=s2 W2 done", "y consumed", "end"]
+             "barB", "G=s2 W2 done", "y consumed", "end", "peer q consumed"]
 DW_NAMES = ["start", "setup", "main loop", "partials out", "stage-1 sum", "bar", "end"]
 
 
@@ -35,7 +35,7 @@ def show(title, stamps, names, nwg):
             print(f"{n:16s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
     # effective shader clock: s_memtime ticks (slots 14, 15) over the wall time between the same
     # two points (first and last stamp of the wave)
-    last = len(names) - 1
+    last = min(len(names) - 1, 10)
     ok = (st[:, :, 15] > 0) & (st[:, :, 14] > 0) & (st[:, :, last] > st[:, :, 0])
     if ok.any():
         ghz = (st[:, :, 15] - st[:, :, 14])[ok] / ((st[:, :, last] - st[:, :, 0])[ok] * 10.0)
@@ -61,7 +61,7 @@ def main():
     bench.fill_arena(rb, dev, seed=0)
     agent.learn()
     nat = pl._ensure_bound(B, A)
-    row = torch.zeros(64, 8, 16, dtype=torch.int64, device=dev)
+    row = torch.zeros(128, 8, 16, dtype=torch.int64, device=dev)
     dw = torch.zeros(128, 8, 16, dtype=torch.int64, device=dev)
     # training_steps = 40 -> windows start at rounds 0, 8, 18, ...: round 13 is mid-window, its
     # chain runs beside the persistent target pass
@@ -72,14 +72,15 @@ def main():
     torch.cuda.synchronize()
     N.check(N.lib().pa_debug_set_prof(nat.handle, None, None, -1))
     ndw = int(os.environ.get("PROF_DW_WGS", "112"))
-    r = row[:64].cpu().numpy().astype(np.int64)
+    nrow = 128 if os.environ.get("PEARL_AMD_ROWPASS_PAIR", "1") != "0" else 64
+    r = row[:nrow].cpu().numpy().astype(np.int64)
     d = dw[:ndw].cpu().numpy().astype(np.int64)
-    row_end = r[:, :, len(ROW_NAMES) - 1].max()
+    row_end = r[:, :, 10].max()
     dw_start = d[:, :, 0][d[:, :, 0] > 0]
     print(f"kernel boundary inside the round (same 100 MHz clock): last row-pass wave ended -> first "
           f"weight-gradient wave started {(dw_start.min() - row_end) / 100.0:.2f} us, -> median wave "
           f"{(np.median(dw_start) - row_end) / 100.0:.2f} us, -> last {(dw_start.max() - row_end) / 100.0:.2f} us")
-    show("online_rowpass_kernel", row, ROW_NAMES, 64)
+    show("online_rowpass_kernel" + ("" if nrow == 64 else " (paired: 2 workgroups per tile)"), row, ROW_NAMES, nrow)
     show("weight_grad_kernel", dw, DW_NAMES, int(os.environ.get("PROF_DW_WGS", "112")))
 
 
