@@ -103,6 +103,12 @@ QNET_CONFIGS = {
                           network="vanilla", hidden_activation="softplus"),
     "sigmoid_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=False,
                          network="vanilla", hidden_activation="sigmoid"),
+    # the CQL term (deep_td_learning.py:323-327, loss_fn_utils.py:17-72) on networks beyond the fused
+    # shape: a deeper Vanilla network and one with LayerNorm (generic TD engine, round 5)
+    "cql_deep3_tiny": dict(S=5, A=5, hidden=[24, 16, 12], N=48, B=16, rounds=11, dynamic=True,
+                           network="vanilla", learner="cql"),
+    "cql_layernorm_small": dict(S=16, A=6, hidden=[64, 48], N=300, B=64, rounds=8, dynamic=False,
+                                network="vanilla", learner="cql", use_layer_norm=True),
 }
 NETWORK_TYPES = {"vanilla": VanillaQValueNetwork, "multihead": VanillaQValueMultiHeadNetwork,
                  "dueling": DuelingQValueNetwork}

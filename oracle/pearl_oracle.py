@@ -414,9 +414,12 @@ class QNetOracle:
     def __init__(self, params: Dict[str, torch.Tensor], target: Dict[str, torch.Tensor], kind: str,
                  double_q: bool = False, gamma: float = 0.99, lr: float = 1e-3, betas=(0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.01, tau: float = 0.75,
-                 target_update_freq: int = 10, hidden_activation: str = "relu") -> None:
+                 target_update_freq: int = 10, hidden_activation: str = "relu",
+                 cql_alpha: Optional[float] = None) -> None:
         assert kind in ("vanilla", "multihead", "dueling")
         self.kind, self.double_q = kind, bool(double_q)
+        # is_conservative (deep_td_learning.py:323-327): loss += alpha * compute_cql_loss
+        self.cql_alpha = cql_alpha
         self.act = hidden_activation      # (LayerNorm is read off the state dict's keys)
         self.keys = list(params.keys())
         self.p = {k: params[k].detach().clone().to(F32) for k in self.keys}
@@ -472,6 +475,12 @@ class QNetOracle:
         w = {k: v.detach().clone().requires_grad_(True) for k, v in self.p.items()}
         q = self.q(w, batch["state"], batch["action"], batch.get("curr_available_actions"))
         loss = torch.nn.functional.mse_loss(q, target)
+        if self.cql_alpha is not None:
+            # compute_cql_loss (loss_fn_utils.py:17-72): the all-actions table, the reference's
+            # gather with long(one-hot action) as the index, logsumexp mean minus the gathered mean
+            q_all = self.q(w, batch["state"], batch["curr_available_actions"]).view(q.shape[0], -1)
+            in_batch = q_all.gather(1, batch["action"].long())
+            loss = loss + self.cql_alpha * (torch.logsumexp(q_all, dim=-1).mean() - in_batch.mean())
         grads = torch.autograd.grad(loss, [w[k] for k in self.keys])
         return q.detach(), dict(zip(self.keys, grads))
 

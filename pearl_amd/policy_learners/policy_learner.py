@@ -173,3 +173,36 @@ class PolicyLearner(nn.Module, ABC):
             if reason:
                 diffs.append(f"{label} is different: {reason}")
         return "\n".join(diffs)
+
+
+def accept_optimizer(optimizer: Any, params: Any, who: str) -> Any:
+    """A caller-supplied optimizer (deep_td_learning.py:183-185, actor_critic_base.py:159-211: the
+    reference uses whatever it is handed).  The HIP learner steps the parameters itself, with
+    torch.optim.AdamW's arithmetic and the hyper-parameters read from the optimizer's parameter group
+    (lr, betas, eps, weight_decay, amsgrad) — so what can be honoured is exactly: ``optim.AdamW``, or
+    ``optim.Adam`` with weight_decay 0 (the same update), over the learner network's own parameters in
+    ONE group, without maximize / capturable / differentiable.  The optimizer object stays the owner of
+    the state (``state_dict`` / ``load_state_dict`` / per-parameter ``step`` keep working); anything
+    else is refused, loudly — never silently replaced by AdamW."""
+    import torch.optim as optim
+    params = list(params)
+    ok_type = type(optimizer) is optim.AdamW or (
+        type(optimizer) is optim.Adam and all(g["weight_decay"] == 0 for g in optimizer.param_groups))
+    if not ok_type:
+        raise NotImplementedError(
+            f"pearl_amd {who}: the HIP step implements torch.optim.AdamW (or Adam with weight_decay 0); "
+            f"got {type(optimizer).__name__}")
+    if len(optimizer.param_groups) != 1:
+        raise NotImplementedError(f"pearl_amd {who}: one parameter group expected, got "
+                                  f"{len(optimizer.param_groups)}")
+    g = optimizer.param_groups[0]
+    theirs = list(g["params"])
+    if len(theirs) != len(params) or any(a is not b for a, b in zip(theirs, params)):
+        raise NotImplementedError(
+            f"pearl_amd {who}: the optimizer must own exactly the learner network's parameters, in "
+            "their order (build it from network.parameters())")
+    for flag in ("maximize", "capturable", "differentiable"):
+        if g.get(flag, False):
+            raise NotImplementedError(f"pearl_amd {who}: optimizer option {flag}=True is not built")
+    g.setdefault("amsgrad", False)
+    return optimizer

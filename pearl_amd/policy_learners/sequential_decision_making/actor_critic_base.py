@@ -31,7 +31,7 @@ from ...neural_networks.sequential_decision_making.twin_critic import TwinCritic
 from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import ExplorationModule
-from ..policy_learner import PolicyLearner, _looks_like_batch
+from ..policy_learner import PolicyLearner, _looks_like_batch, accept_optimizer
 from .flat_mlp import FlatMlp
 
 
@@ -74,9 +74,6 @@ class ActorCriticBase(PolicyLearner):
                          exploration_module=exploration_module,
                          action_representation_module=action_representation_module,
                          action_space=action_space)
-        if actor_optimizer is not None or critic_optimizer is not None:
-            raise NotImplementedError("pearl_amd actor-critic learners own their AdamW(amsgrad) "
-                                      "steps; custom optimizers are not supported")
         self._state_dim = state_dim
         self._action_space = action_space
         self._use_actor_target = use_actor_target
@@ -94,8 +91,12 @@ class ActorCriticBase(PolicyLearner):
                             else rep.max_number_actions),
                 action_space=action_space)
         self._actor.apply(xavier_init_weights)
-        self._actor_optimizer: optim.Optimizer = optim.AdamW(
-            [{"params": self._actor.parameters(), "lr": actor_learning_rate, "amsgrad": True}])
+        if actor_optimizer is not None:     # (actor_critic_base.py:159-167: used as handed over)
+            self._actor_optimizer: optim.Optimizer = accept_optimizer(
+                actor_optimizer, self._actor.parameters(), f"{type(self).__name__} (actor)")
+        else:
+            self._actor_optimizer = optim.AdamW(
+                [{"params": self._actor.parameters(), "lr": actor_learning_rate, "amsgrad": True}])
         self._actor_soft_update_tau = actor_soft_update_tau
         self._critic_soft_update_tau = critic_soft_update_tau
         if self._use_actor_target:
@@ -109,8 +110,12 @@ class ActorCriticBase(PolicyLearner):
                                            hidden_dims=critic_hidden_dims,
                                            use_twin_critic=use_twin_critic,
                                            network_type=critic_network_type)
-            self._critic_optimizer: optim.Optimizer = optim.AdamW(
-                [{"params": self._critic.parameters(), "lr": critic_learning_rate, "amsgrad": True}])
+            if critic_optimizer is not None:     # (actor_critic_base.py:200-211)
+                self._critic_optimizer: optim.Optimizer = accept_optimizer(
+                    critic_optimizer, self._critic.parameters(), f"{type(self).__name__} (critic)")
+            else:
+                self._critic_optimizer = optim.AdamW(
+                    [{"params": self._critic.parameters(), "lr": critic_learning_rate, "amsgrad": True}])
             if self._use_critic_target:
                 self._critic_target: nn.Module = copy.deepcopy(self._critic)
         self._discount_factor = discount_factor

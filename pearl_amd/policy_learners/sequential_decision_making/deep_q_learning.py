@@ -46,7 +46,7 @@ from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
 from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import EGreedyExploration, ExplorationModule
-from ..policy_learner import PolicyLearner
+from ..policy_learner import PolicyLearner, accept_optimizer
 from .generic_q import GenericTd, make_ops, mlp_spec, plain_relu_mlp
 
 _FLAT_NAMES = ("q", "q_target", "grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")
@@ -122,10 +122,6 @@ class DeepQLearning(PolicyLearner):
                                 else EGreedyExploration(0.05)),
             on_policy=False, is_action_continuous=False,
             action_representation_module=action_representation_module, action_space=action_space)
-        if optimizer is not None:
-            raise NotImplementedError(
-                "pearl_amd DeepQLearning owns its AdamW(amsgrad) step; custom optimizers are not "
-                "supported")
         self._action_space = action_space
         self._learning_rate = learning_rate
         self._discount_factor = discount_factor
@@ -170,12 +166,18 @@ class DeepQLearning(PolicyLearner):
             lin = spec["linears"]
             self._fused = (spec["plain"] and len(lin) == 3 and lin[0].out_features <= 256
                            and lin[1].out_features <= 256 and lin[2].out_features == 1)
-        if is_conservative and not self._fused:
-            raise NotImplementedError("pearl_amd DeepQLearning: the CQL term is built for the fused "
-                                      "VanillaQValueNetwork path only")
+        if is_conservative and not isinstance(self._Q, VanillaQValueNetwork):
+            raise NotImplementedError(
+                "pearl_amd DeepQLearning: the CQL term (loss_fn_utils.py:17-72) is built for "
+                f"VanillaQValueNetwork (any depth / form), not for {type(self._Q).__name__}")
         self._Q_target: VanillaQValueNetwork = copy.deepcopy(self._Q)
-        self._optimizer: optim.Optimizer = optim.AdamW(self._Q.parameters(), lr=learning_rate,
-                                                       amsgrad=True)
+        if optimizer is not None:
+            # (deep_td_learning.py:183-185: used as handed over; see accept_optimizer for what the HIP
+            #  step can honour)
+            self._optimizer: optim.Optimizer = accept_optimizer(optimizer, self._Q.parameters(),
+                                                                type(self).__name__)
+        else:
+            self._optimizer = optim.AdamW(self._Q.parameters(), lr=learning_rate, amsgrad=True)
         self._max_batch_size = max_batch_size
         self._native = _NativeDqn()
         self._generic_td: Optional[GenericTd] = None
@@ -326,8 +328,9 @@ class DeepQLearning(PolicyLearner):
                     "step": bank[i],
                     "exp_avg": flat["exp_avg"][sl].view(pq.shape),
                     "exp_avg_sq": flat["exp_avg_sq"][sl].view(pq.shape),
-                    "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(pq.shape),
                 }
+                if opt["amsgrad"]:      # (torch keeps it only then: optim/adam.py _init_group)
+                    self._optimizer.state[pq]["max_exp_avg_sq"] = flat["max_exp_avg_sq"][sl].view(pq.shape)
         bufs = N.DqnBuffers(**{k: flat[k].data_ptr() for k in _FLAT_NAMES})
         N.check(N.lib().pa_dqn_bind(nat.handle, C.byref(bufs)))
         nat.flat = flat
@@ -394,7 +397,8 @@ class DeepQLearning(PolicyLearner):
         if g is None or g.ops_key != (id(self._Q), id(self._Q_target), id(self._optimizer)):
             mb = max(int(self._max_batch_size or 0), int(self._batch_size), 1)
             g = GenericTd(make_ops(self._Q, self._Q_target, self._optimizer, mb), int(self._double_q),
-                          self._discount_factor, self._soft_update_tau)
+                          self._discount_factor, self._soft_update_tau,
+                          cql_alpha=self._conservative_alpha if self._is_conservative else None)
             g.ops_key = (id(self._Q), id(self._Q_target), id(self._optimizer))
             self._generic_td = g
         return g

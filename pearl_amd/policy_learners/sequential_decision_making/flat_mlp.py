@@ -257,8 +257,10 @@ class FlatMlp:
                                 "step": self._step_bank[bank_i],
                                 "exp_avg": flat["exp_avg"][sl].view(p.shape),
                                 "exp_avg_sq": flat["exp_avg_sq"][sl].view(p.shape),
-                                "max_exp_avg_sq": flat["max_exp_avg_sq"][sl].view(p.shape),
                             }
+                            if g.get("amsgrad", False):     # (torch keeps it only then)
+                                self.optimizer.state[p]["max_exp_avg_sq"] = \
+                                    flat["max_exp_avg_sq"][sl].view(p.shape)
                         if tl is not None:
                             pt = tl[pi]
                             flat["p_target"][sl].copy_(pt.data.reshape(-1).to(dev, torch.float32))

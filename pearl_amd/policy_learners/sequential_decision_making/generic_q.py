@@ -183,6 +183,18 @@ class VanillaOps(_Ops):
     def backward(self, dq: Tensor) -> None:
         self.net.backward(self._x, dq, want_dw=True, defer=True)
 
+    def cql_rows(self, state: Tensor, action: Tensor, rep: Tensor) -> Tensor:
+        """Q of the B taken (state, action) rows followed by every (state, available action) row —
+        B + B A rows in ONE kept forward: what the MSE term and compute_cql_loss's all-actions table
+        (loss_fn_utils.py:52-58) need; `backward` then takes pa_cql_head's row gradients."""
+        B, S = state.shape
+        A, AD = int(rep.shape[-2]), int(rep.shape[-1])
+        X = _new(state.device, B + B * A, S + AD)
+        _concat(state, action, out=X[:B])
+        _expand(state, rep, out=X[B:])
+        self._x = X
+        return self.net.forward(X, keep=True).view(-1)
+
     def q_all(self, state: Tensor, rep: Tensor, use_target: bool) -> Tensor:
         B, A = state.shape[0], int(rep.shape[-2])
         if self.net.supports_q_all(A):
@@ -320,8 +332,15 @@ class GenericTd:
     """The TD(0) step over an `_Ops`; `rule`: 0 max (DeepQLearning), 1 double (DoubleDQN),
     2 SARSA (DeepSARSA) — pa_dqn_desc.double_q's encoding."""
 
-    def __init__(self, ops: _Ops, rule: int, gamma: float, tau: float) -> None:
+    def __init__(self, ops: _Ops, rule: int, gamma: float, tau: float,
+                 cql_alpha: Optional[float] = None) -> None:
         self.ops, self.rule, self.gamma, self.tau = ops, int(rule), float(gamma), float(tau)
+        # is_conservative (deep_td_learning.py:323-327): loss += alpha * compute_cql_loss
+        self.cql_alpha = None if cql_alpha is None else float(cql_alpha)
+        if self.cql_alpha is not None and not hasattr(ops, "cql_rows"):
+            raise NotImplementedError(
+                f"pearl_amd: the CQL term is built for VanillaQValueNetwork (any depth / form), not "
+                f"for {type(ops).__name__[:-3]} networks")
 
     def targets(self, b: Dict[str, Any], want_next_v: bool = False):
         ops, dev = self.ops, b["state"].device
@@ -368,6 +387,20 @@ class GenericTd:
         if do_target_update:
             ops.soft_update(self.tau)                  # before the forward (deep_td_learning.py:283-284)
         _, y = self.targets(b)
+        if self.cql_alpha is not None:
+            # mse(Q(s, a), y) + alpha (mean_b logsumexp_i Q(s_b, a_i) - mean of the reference's gather)
+            # (loss_fn_utils.py:17-72) over B + B A rows of one kept forward
+            rep = b["curr_avail"]
+            assert rep is not None and rep.ndim == 3, "the CQL term needs curr_available_actions"
+            A, AD = int(rep.shape[-2]), int(rep.shape[-1])
+            q_rows = ops.cql_rows(b["state"], b["action"], rep)
+            dq_rows = _new(dev, B + B * A)
+            N.check(N.lib().pa_cql_head(q_rows.data_ptr(), y.data_ptr(), b["action"].data_ptr(),
+                                        b["action"].stride(0), B, A, AD, self.cql_alpha,
+                                        dq_rows.data_ptr(), losses.data_ptr(), N.stream_ptr(dev)))
+            ops.backward(dq_rows)
+            ops.adam()
+            return
         q = ops.q_taken(b["state"], b["action"], b["curr_avail"])
         dq = _new(dev, B)
         N.check(N.lib().pa_td_head(q.data_ptr(), 1, y.data_ptr(), B, 2.0 / B, dq.data_ptr(),

@@ -103,10 +103,13 @@ def test_unsupported_configurations_fail_loudly():
                    (VanillaQValueNetwork, [8]), (VanillaQValueMultiHeadNetwork, [8, 8]),
                    (DuelingQValueNetwork, [8, 6])):
         assert not DeepQLearning(hidden_dims=hd, network_type=nt, **kw)._fused
-    # the CQL term is built for the fused path (tests/test_gpu_dqn.py::test_conservative_q_learning)
+    # the CQL term: VanillaQValueNetwork of any depth / form (fused shape: test_conservative_q_learning;
+    # beyond it the generic engine, qnet_cql_* fixtures); multi-head / dueling networks are refused
     DeepQLearning(hidden_dims=[8, 8], is_conservative=True, **kw)
-    with pytest.raises(NotImplementedError):
-        DeepQLearning(hidden_dims=[8, 8, 8], is_conservative=True, **kw)
+    assert not DeepQLearning(hidden_dims=[8, 8, 8], is_conservative=True, **kw)._fused
+    for nt in (VanillaQValueMultiHeadNetwork, DuelingQValueNetwork):
+        with pytest.raises(NotImplementedError, match="CQL"):
+            DeepQLearning(hidden_dims=[8, 8], network_type=nt, is_conservative=True, **kw)
     # built (round 5): mlp_block's LayerNorm and its other hidden activations — through the generic
     # engine, never the fused step (common/utils.py:75-152)
     from pearl_amd.neural_networks.common.utils import mlp_block
@@ -576,3 +579,46 @@ def test_padded_action_tables_survive_recycled_space_ids():
     a = rb._padded_tables(4, sp)
     b = rb._padded_tables(4, sp)
     assert a[0] is b[0]
+
+
+def test_optimizer_argument_is_honoured_or_refused():
+    """deep_td_learning.py:183-185 / actor_critic_base.py:159-211 take a caller's optimizer.  The HIP
+    step has torch.optim.AdamW's arithmetic with the hyper-parameters of the optimizer's group, so an
+    AdamW (any lr / betas / eps / weight_decay / amsgrad) or an Adam without weight decay over the
+    network's own parameters is used as handed over; anything else is refused, loudly."""
+    from pearl_amd import (ContinuousSoftActorCritic, BoxActionSpace, DeepQLearning, DiscreteActionSpace,
+                           OneHotActionTensorRepresentationModule)
+    from pearl_amd.neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
+    sp = DiscreteActionSpace([torch.tensor([k]) for k in range(3)])
+    kw = dict(action_space=sp, action_representation_module=OneHotActionTensorRepresentationModule(3))
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+    opt = torch.optim.AdamW(net.parameters(), lr=3e-4, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.05)
+    pl = DeepQLearning(network_instance=net, optimizer=opt, **kw)
+    assert pl.optimizer is opt and pl._fused
+    g = pl.optimizer.param_groups[0]
+    assert (g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"], g["amsgrad"]) == (3e-4, (0.8, 0.99), 1e-6, 0.05, False)
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+    DeepQLearning(network_instance=net, optimizer=torch.optim.Adam(net.parameters(), lr=1e-3), **kw)
+    for bad in (torch.optim.SGD(net.parameters(), lr=0.1),
+                torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.01),
+                torch.optim.AdamW(list(net.parameters())[:2], lr=1e-3),
+                torch.optim.AdamW([{"params": list(net.parameters())[:2]}, {"params": list(net.parameters())[2:]}]),
+                torch.optim.AdamW(net.parameters(), lr=1e-3, maximize=True)):
+        with pytest.raises(NotImplementedError):
+            DeepQLearning(network_instance=net, optimizer=bad, **kw)
+    # actor-critic: the actor's and the critic's optimizers
+    from pearl_amd.neural_networks.sequential_decision_making.actor_networks import GaussianActorNetwork
+    from pearl_amd.neural_networks.sequential_decision_making.twin_critic import TwinCritic
+    space = BoxActionSpace(-torch.ones(2), torch.ones(2))
+    actor = GaussianActorNetwork(input_dim=5, hidden_dims=[8, 8], output_dim=2, action_space=space)
+    critic = TwinCritic(state_dim=5, action_dim=2, hidden_dims=[8, 8])
+    ao = torch.optim.AdamW(actor.parameters(), lr=2e-4, amsgrad=True)
+    co = torch.optim.AdamW(critic.parameters(), lr=5e-4, weight_decay=0.0)
+    sac = ContinuousSoftActorCritic(action_space=space, actor_network_instance=actor,
+                                    critic_network_instance=critic, actor_optimizer=ao, critic_optimizer=co)
+    assert sac._actor_optimizer is ao and sac._critic_optimizer is co
+    assert sac._actor_learning_rate == 2e-4 and sac._critic_learning_rate == 5e-4
+    with pytest.raises(NotImplementedError):
+        ContinuousSoftActorCritic(action_space=space, actor_network_instance=actor,
+                                  critic_network_instance=critic,
+                                  actor_optimizer=torch.optim.RMSprop(actor.parameters()))

@@ -909,6 +909,41 @@ def test_paired_rowpass_is_the_single_workgroup_rowpass_and_closer_to_float64(mo
     assert e_pair <= e_ref, (e_pair, e_ref)
 
 
+@pytest.mark.parametrize("hidden,opt_kw", [([32, 24], dict(lr=3e-4, betas=(0.8, 0.99), eps=1e-6, weight_decay=0.05)),
+                                           ([32, 24], dict(lr=2e-3, amsgrad=True, weight_decay=0.0)),
+                                           ([16, 16, 16], dict(lr=1e-3, betas=(0.95, 0.9), weight_decay=0.02))])
+def test_caller_supplied_adamw_is_the_step_that_runs(hidden, opt_kw):
+    """deep_td_learning.py:183-185: `optimizer=` is used as handed over.  The HIP step reads the
+    optimizer's group (lr, betas, eps, weight_decay, amsgrad) — fused path and generic engine — and
+    must move the parameters exactly where torch.optim.AdamW moves a CPU copy given the same
+    gradients, for three steps (bias corrections, amsgrad's running maximum, decoupled decay)."""
+    from pearl_amd import DeepQLearning, OneHotActionTensorRepresentationModule, TransitionBatch
+    from pearl_amd.neural_networks.sequential_decision_making.q_value_networks import VanillaQValueNetwork
+    S, A, B = 6, 4, 48
+    g = torch.Generator().manual_seed(5)
+    torch.manual_seed(3)
+    net = VanillaQValueNetwork(state_dim=S, action_dim=A, hidden_dims=hidden, output_dim=1)
+    shadow = copy.deepcopy(net)
+    opt = torch.optim.AdamW(net.parameters(), **opt_kw)
+    sopt = torch.optim.AdamW(shadow.parameters(), **opt_kw)
+    pl = DeepQLearning(action_space=_space(A), network_instance=net, optimizer=opt, batch_size=B,
+                       action_representation_module=OneHotActionTensorRepresentationModule(A)).to(DEV)
+    assert pl._fused == (len(hidden) == 2)
+    for step in range(3):
+        tb = TransitionBatch(state=torch.randn(B, S, generator=g), action=torch.randint(0, A, (B, 1), generator=g),
+                             reward=torch.randn(B, generator=g), terminated=torch.rand(B, generator=g) < 0.1,
+                             truncated=torch.zeros(B, dtype=torch.bool), next_state=torch.randn(B, S, generator=g),
+                             curr_available_actions=None, next_available_actions=None)
+        pl.learn_batch(pl.preprocess_batch(tb.to(DEV) if hasattr(tb, "to") else tb))
+        for (k, p), ps in zip(pl._Q.named_parameters(), shadow.parameters()):
+            ps.grad = p.grad.detach().cpu().clone()
+        sopt.step()
+        for (k, p), ps in zip(pl._Q.named_parameters(), shadow.parameters()):
+            torch.testing.assert_close(p.detach().cpu(), ps.detach(), rtol=2e-6, atol=1e-7, msg=f"step {step} {k}")
+        st = opt.state[next(iter(pl._Q.parameters()))]
+        assert float(st["step"]) == step + 1 and ("max_exp_avg_sq" in st) == bool(opt_kw.get("amsgrad"))
+
+
 def test_sarsa_buffer_checkpoint_resume_is_exact():
     """SARSAReplayBuffer.state_dict()/load_state_dict(): the next_action column of the stored rows
     and the pending (cached) transition survive a round trip into a FRESH buffer — same sampled
@@ -954,7 +989,9 @@ QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", 
          # mlp_block's other forms (round 5, common/utils.py:75-152): LayerNorm between every hidden
          # Linear and its activation; leaky_relu / tanh / softplus / sigmoid hidden activations
          "layernorm_tiny", "layernorm_small", "layernorm_multihead_tiny", "leaky_tiny",
-         "tanh_layernorm_small", "softplus_tiny", "sigmoid_tiny"]
+         "tanh_layernorm_small", "softplus_tiny", "sigmoid_tiny",
+         # is_conservative beyond the fused shape: B + B A rows through the generic engine
+         "cql_deep3_tiny", "cql_layernorm_small"]
 
 
 def make_qnet_learner(fx):
@@ -978,6 +1015,8 @@ def make_qnet_learner(fx):
                                    use_layer_norm=bool(cfg.get("use_layer_norm")),
                                    hidden_activation=cfg["hidden_activation"])
         extra = dict(network_instance=net)
+    if cfg.get("learner") == "cql":
+        extra.update(is_conservative=True, conservative_alpha=2.0)
     pl = cls(state_dim=cfg["S"], action_space=_space(cfg["A"]), hidden_dims=cfg["hidden"],
              training_rounds=cfg["rounds"], batch_size=cfg["B"],
              action_representation_module=OneHotActionTensorRepresentationModule(cfg["A"]), **extra)

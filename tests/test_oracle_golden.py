@@ -250,7 +250,9 @@ QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", 
          "dueling_tiny", "dueling_double_small",
          # mlp_block's other forms (round 5): LayerNorm, leaky_relu / tanh / softplus / sigmoid
          "layernorm_tiny", "layernorm_small", "layernorm_multihead_tiny", "leaky_tiny",
-         "tanh_layernorm_small", "softplus_tiny", "sigmoid_tiny"]
+         "tanh_layernorm_small", "softplus_tiny", "sigmoid_tiny",
+         # the CQL term beyond the fused shape
+         "cql_deep3_tiny", "cql_layernorm_small"]
 
 
 def qnet_well_conditioned(fx, key) -> torch.Tensor:
@@ -276,7 +278,8 @@ def test_qnet_architectures_oracle(name):
     cfg = fx["config"]
     pl = O.QNetOracle(fx["params0"], fx["target0"], cfg["network"],
                       double_q=cfg.get("learner") == "double",
-                      hidden_activation=cfg.get("hidden_activation", "relu"))
+                      hidden_activation=cfg.get("hidden_activation", "relu"),
+                      cql_alpha=2.0 if cfg.get("learner") == "cql" else None)
     b = fx["batch_pre"]
     torch.testing.assert_close(pl.q(pl.p, b["state"], b["action"], b["curr_available_actions"]),
                                fx["q"], rtol=1e-5, atol=1e-6)
