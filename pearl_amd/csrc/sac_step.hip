@@ -142,24 +142,14 @@ int64_t carve_fused(FusedScratch* s, float* base, int64_t B, int64_t S, int64_t 
   return o;
 }
 
-// per-tile partial loss sums of the two row kernels: one buffer per process, grown on demand
-// (calls are ordered by their stream, like every use of a learner handle)
-int tickets(int tiles, SacTicket* ta, SacTicket* tb) {
-  static float* buf = nullptr;
-  static int cap = 0;
-  if (tiles > cap) {
-    if (buf) {
-      PA_HIP(hipDeviceSynchronize());
-      (void)hipFree(buf);
-    }
-    const int n = tiles * 2;
-    PA_HIP(hipMalloc((void**)&buf, (size_t)2 * n * sizeof(float)));
-    PA_HIP(hipMemset(buf, 0, (size_t)2 * n * sizeof(float)));
-    PA_HIP(hipDeviceSynchronize());   // (a rare grow: ordered against every stream)
-    cap = n;
-  }
+// per-tile partial loss sums of the two row kernels: one buffer per stream (stream_scratch,
+// common.hpp), grown on demand — two learners on two streams do not share them
+int tickets(int tiles, SacTicket* ta, SacTicket* tb, hipStream_t s) {
+  const size_t half = (size_t)2 * tiles;
+  float* buf = stream_scratch(SCR_SAC_TICKETS, s, 2 * half);
+  if (!buf) return PA_ERR_NOMEM;
   ta->partials = buf;
-  tb->partials = buf + cap;
+  tb->partials = buf + half;
   return PA_OK;
 }
 
@@ -322,7 +312,7 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   carve_fused(&w, a->scratch, B, S, A);
   const int tiles = (int)ceil_div(B, RP_ROWS);
   SacTicket ta, tb;
-  PA_TRY(tickets(tiles, &ta, &tb));
+  PA_TRY(tickets(tiles, &ta, &tb, s));
   PA_TRY(mlp_ensure_packed(ac, false, s));
   PA_TRY(mlp_ensure_packed(c1, false, s));
   PA_TRY(mlp_ensure_packed(c2, false, s));
@@ -649,7 +639,7 @@ int ddpg_fused_step(const pa_ddpg_step_args* a, hipStream_t s) {
   carve_ddpg_fused(&w, a->scratch, B, S, A);
   const int tiles = (int)ceil_div(B, RP_ROWS);
   SacTicket ta, tb;
-  PA_TRY(tickets(tiles, &ta, &tb));
+  PA_TRY(tickets(tiles, &ta, &tb, s));
   PA_TRY(mlp_ensure_packed(ac, false, s));
   PA_TRY(mlp_ensure_packed(ac, true, s));
   PA_TRY(mlp_ensure_packed(c1, false, s));

@@ -134,13 +134,24 @@ class FlatMlp:
             return
         self._steps_dirty = None
         bank = getattr(self, "_step_bank", None)
-        if bank is not None:
+        if bank is not None and self._steps_are_banked(bank):
             bank.fill_(float(n))      # every parameter's 0-d "step" tensor is a view of it
             return
         for p in self._params():
             st = self.optimizer.state.get(p)
             if st is not None and "step" in st:
                 st["step"].fill_(float(n))
+
+    def _steps_are_banked(self, bank: torch.Tensor) -> bool:
+        """The optimizer's per-parameter "step" tensors are still the views of the bank this object
+        handed out (optimizer.load_state_dict replaces them while the moment tensors may stay aliased:
+        _signature() does not see that) — otherwise they are filled one by one."""
+        lo, hi = bank.data_ptr(), bank.data_ptr() + bank.numel() * bank.element_size()
+        for p in self._params():
+            st = self.optimizer.state.get(p)
+            if st is None or "step" not in st or not (lo <= st["step"].data_ptr() < hi):
+                return False
+        return True
 
     _dirty: set = set()
 

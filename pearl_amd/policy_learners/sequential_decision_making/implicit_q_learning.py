@@ -149,6 +149,11 @@ class ImplicitQLearning(ActorCriticBase):
             return False
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return False
+        # pa_iql_step takes ONE critic step count (c1's) for both twins: with counters that differ
+        # (a partially restored optimizer state) c2 would get c1's bias correction — the per-stage
+        # path steps each critic with its own count
+        if getattr(c1, "_steps", 0) != getattr(c2, "_steps", 0):
+            return False
         memo = self._flat.get("one_call_ok")
         key = (c1.handle.value, c2.handle.value)
         if memo is None or memo[0] != key:

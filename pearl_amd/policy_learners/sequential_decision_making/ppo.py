@@ -385,9 +385,12 @@ class ProximalPolicyOptimization(ActorCriticBase):
         dev = actor.device
         state = self._f32(self._history_summarization_module(r_state), dev)
         arep = self._f32(self.action_representation_module(r_action), dev).reshape(n, -1)
-        # the SAME launch shape learn_batch uses for these two networks: with epsilon = 0 the clipped
-        # surrogate passes a gradient only where the probability ratio is exactly 1, i.e. where this
-        # forward and learn_batch's agree to the bit
+        # One pair launch over the whole rollout.  (It used to matter that this forward is learn_batch's
+        # to the bit — with epsilon = 0 the clipped surrogate passes a gradient only where the ratio is
+        # exactly 1.  That holds while learn_batch takes the fp32 forward; minibatches that fill the
+        # chip (ceil(B / 16) * 2 > 256 tiles) take the fused row step's bf16x3 forward, whose logits
+        # differ from these in the last bits — as the reference's own minibatch forward differs from
+        # its rollout forward when MKL blocks the two shapes differently.  epsilon > 0 does not care.)
         if actor.dims[0] == critic.dims[0] and len(actor.dims) == len(critic.dims):
             logits, values = FlatMlp.forward_pair(actor, critic, state)
             values = values.reshape(n).contiguous()

@@ -286,6 +286,8 @@ class SoftActorCritic(ActorCriticBase):
                 and cls._update_critic_target is base._update_critic_target
                 and self._use_critic and self._use_critic_target and not self._use_actor_target):
             return False
+        if getattr(c1, "_steps", 0) != getattr(c2, "_steps", 0):
+            return False     # pa_dsac_step steps both twins with c1's count (see ImplicitQLearning)
         memo = self._flat.get("one_call_ok")
         key = (actor.handle.value, c1.handle.value, c2.handle.value)
         if memo is None or memo[0] != key:
