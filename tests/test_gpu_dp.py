@@ -425,3 +425,91 @@ def test_ppo_two_ranks_equal_one_reference_learner_on_the_concatenated_minibatch
         assert k in out[0][0], (k, list(out[0][0])[:4])
         assert_adam_trajectory_close(torch.from_numpy(out[0][0][k]), v.detach(), lr=1e-4, steps=PPO_R,
                                      rtol=1e-3, atol=2e-6, msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
+# NeuralLinearBandit (BASELINE config 5): network gradients averaged, LinUCB moments summed
+# ---------------------------------------------------------------------------------------------
+NB_F, NB_HID, NB_B, NB_STEPS = 24, [32, 16], 96, 4
+
+
+def _bandit_batches(rank):
+    g = torch.Generator().manual_seed(900 + rank)
+    return [(torch.randn(NB_B, NB_F, generator=g), torch.rand(NB_B, generator=g) + 0.25 * rank)
+            for _ in range(NB_STEPS)]
+
+
+def _bandit_learner():
+    from pearl_amd import NeuralLinearBandit
+    torch.manual_seed(0)                      # identical initial parameters on every rank
+    return NeuralLinearBandit(feature_dim=NB_F, hidden_dims=NB_HID, batch_size=NB_B, learning_rate=1e-3)
+
+
+def _bandit_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pearl_amd import TransitionBatch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pl = _bandit_learner().to(dev)
+    losses = []
+    for x, y in _bandit_batches(rank):
+        rep = pl.learn_batch(TransitionBatch(state=x.to(dev), action=torch.zeros(NB_B, 1, device=dev),
+                                             reward=y.to(dev), weight=None))
+        losses.append(float(rep["loss"]))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu().numpy().copy() for k, v in pl.model.state_dict().items()}
+    q.put((rank, sd, losses))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bandit_two_ranks_equal_one_reference_learner_on_the_concatenated_batch():
+    """VERDICT r4 missing-6: the bandit's data-parallel step on the GPU.  Two HIP ranks, each with its
+    own contexts: the network gradient is averaged over the ranks (one all-reduce), the LinUCB deltas
+    delta_A | delta_b | delta_sum_weight travel as ONE summed message (the reference's three
+    all_reduce calls, linear_regression.py:207-210).  Both ranks must end with bitwise the same model,
+    and with what ONE oracle learner (neural_linear_bandit.py:159-225 restated) reaches on the
+    concatenated 2B-row batches: A, b, sum_weight to summation order, the network along AdamW's
+    trajectory bound."""
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import assert_adam_trajectory_close, assert_linear_solve_close
+    from oracle.actor_critic_oracle import NeuralLinearOracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + random.randrange(2000)
+    procs = [ctx.Process(target=_bandit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, sd, losses = q.get(timeout=300)
+        out[rank] = (sd, losses)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for k in out[0][0]:
+        assert (out[0][0][k] == out[1][0][k]).all(), f"ranks diverged: {k}"
+    orc = NeuralLinearOracle(_bandit_learner().model.state_dict(), lr=1e-3)
+    b0, b1 = _bandit_batches(0), _bandit_batches(1)
+    want = []
+    for (x0, y0), (x1, y1) in zip(b0, b1):
+        want.append(float(orc.learn_batch(torch.cat([x0, x1]), torch.cat([y0, y1]), None)["loss"]))
+    # each rank reports its own shard's loss; their mean is the global batch's
+    got = [(a + b) / 2 for a, b in zip(out[0][1], out[1][1])]
+    torch.testing.assert_close(torch.tensor(got), torch.tensor(want), rtol=2e-4, atol=1e-5)
+    sd = {k: torch.from_numpy(v) for k, v in out[0][0].items()}
+    A, b = sd["_linear_regression_layer._A"], sd["_linear_regression_layer._b"]
+    torch.testing.assert_close(A, orc.A, rtol=1e-4, atol=2e-5 * float(orc.A.abs().max()))
+    torch.testing.assert_close(b, orc.b, rtol=1e-4, atol=2e-5 * float(orc.b.abs().max()))
+    assert float(sd["_linear_regression_layer._sum_weight"]) == 2 * NB_B * NB_STEPS
+    assert_linear_solve_close(sd["_linear_regression_layer._coefs"], A, b, 1.0, orc.coefs, msg="coefs")
+    trunk = [t for pair in orc.trunk for t in pair]
+    names = [k for k in sd if k.startswith("_nn_layers.")]
+    assert len(names) == len(trunk)
+    for k, t in zip(names, trunk):
+        assert_adam_trajectory_close(sd[k], t.detach(), 1e-3, NB_STEPS, rtol=1e-3, atol=2e-5, msg=k)
+    assert_adam_trajectory_close(sd["linear_layer_e2e.weight"], orc.e2e.detach(), 1e-3, NB_STEPS,
+                                 rtol=1e-3, atol=2e-5, msg="e2e")
