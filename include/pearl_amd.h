@@ -402,9 +402,11 @@ typedef struct pa_mlp_desc {
    * (PA_ERR_UNSUPPORTED).  batch norm, dropout and residual blocks are not built. */
   int32_t hidden_act;      /* ActivationType of the hidden layers (utils.py:29-56): 0 relu, 1 leaky_relu
                               (slope 0.01), 2 tanh, 3 softplus (beta 1, threshold 20), 4 sigmoid */
-  int32_t layer_norm;      /* 1: nn.LayerNorm(d_{l+1}) (eps 1e-5, affine) between every hidden Linear
-                              and its activation (utils.py:110-113).  Its weight / bias are parameters:
-                              they follow the W / b block of the flat buffers (pa_mlp_norm_offsets) */
+  int32_t layer_norm;      /* bit l set: nn.LayerNorm(d_{l+1}) (eps 1e-5, affine) between hidden Linear l
+                              and its activation (utils.py:110-113; mlp_block sets it for every hidden
+                              layer, the bandit's trunk for all but its activation-free output layer).
+                              The weights / biases are parameters: they follow the W / b block of the
+                              flat buffers (pa_mlp_norm_offsets) */
 } pa_mlp_desc;
 typedef struct pa_mlp_buffers {
   float* p;
@@ -417,8 +419,8 @@ typedef struct pa_mlp_buffers {
 int64_t pa_mlp_param_count(const pa_mlp_desc* d);
 /* offsets[2 * n_layers]: W_0, b_0, W_1, b_1, ... */
 int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets);
-/* layer_norm = 1: offsets[2 * (n_layers - 1)]: gamma_0, beta_0, gamma_1, beta_1, ... of the hidden
- * layers' LayerNorms (each d_{l+1} floats) */
+/* layer_norm != 0: offsets[2 * (n_layers - 1)]: gamma_l, beta_l of hidden layer l's LayerNorm (each
+ * d_{l+1} floats) at [2 l], [2 l + 1]; -1 for hidden layers without one */
 int pa_mlp_norm_offsets(const pa_mlp_desc* d, int64_t* offsets);
 int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc);
 int pa_mlp_destroy(pa_mlp* h);

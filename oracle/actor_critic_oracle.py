@@ -446,15 +446,25 @@ class NeuralLinearOracle:
     calculate_sigma (linear_regression.py:192-219, :252-270)."""
 
     def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0,
-                 loss_type: str = "mse", output_activation: str = "linear") -> None:
+                 loss_type: str = "mse", output_activation: str = "linear",
+                 hidden_activation: str = "relu") -> None:
         self.trunk = _layers(model_sd, "_nn_layers._model.")
+        # mlp_block's other forms (common/utils.py:75-152): nn.LayerNorm between a hidden Linear and
+        # its activation when the state dict has `{i}.1.weight`; the hidden activation by name
+        pre = "_nn_layers._model."
+        self.norms = [(model_sd[f"{pre}{i}.1.weight"].clone().requires_grad_(True),
+                       model_sd[f"{pre}{i}.1.bias"].clone().requires_grad_(True))
+                      if f"{pre}{i}.1.weight" in model_sd else None for i in range(len(self.trunk) - 1)]
+        from oracle.pearl_oracle import _HIDDEN_ACTS
+        self.hidden_act = _HIDDEN_ACTS[hidden_activation]
         self.e2e = model_sd["linear_layer_e2e.weight"].clone().requires_grad_(True)
         d = self.e2e.shape[1]
         self.A, self.b = torch.zeros(d + 1, d + 1), torch.zeros(d + 1)
         self.sum_weight = torch.zeros(1)
         self.inv_A, self.coefs = torch.zeros(d + 1, d + 1), torch.zeros(d + 1)
         self.lam = l2_reg_lambda
-        self.opt = torch.optim.AdamW(_flat(self.trunk) + [self.e2e], lr=lr, amsgrad=True)
+        self.opt = torch.optim.AdamW(_flat(self.trunk) + [t for n in self.norms if n for t in n] + [self.e2e],
+                                     lr=lr, amsgrad=True)
         # LossType.function() (neural_networks/common/utils.py:60-72) and the model's output
         # activation (neural_linear_regression.py:79-81)
         self.criterion = {"mse": torch.nn.functional.mse_loss, "mae": torch.nn.functional.l1_loss,
@@ -462,7 +472,16 @@ class NeuralLinearOracle:
         self.out_act = {"linear": lambda z: z, "sigmoid": torch.sigmoid}[output_activation]
 
     def features(self, x: Tensor) -> Tensor:
-        return mlp(self.trunk, x)          # the trunk's own last layer has no activation
+        # the trunk's own last layer has no activation (and no LayerNorm)
+        for i, (w, b) in enumerate(self.trunk):
+            x = torch.nn.functional.linear(x, w, b)
+            if i + 1 < len(self.trunk):
+                if self.norms[i] is not None:
+                    mu = x.mean(dim=-1, keepdim=True)
+                    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+                    x = (x - mu) / torch.sqrt(var + 1e-5) * self.norms[i][0] + self.norms[i][1]
+                x = self.hidden_act(x)
+        return x
 
     def learn_batch(self, x: Tensor, y: Tensor, w) -> Dict[str, Tensor]:
         f = self.features(x)

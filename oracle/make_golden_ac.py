@@ -454,6 +454,11 @@ BANDIT_CONFIGS = {
     "mae_cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3, loss="mae", input_seed=6),
     "bce_cfg5_shape_small": dict(F=512, hidden=[256, 64], B=256, steps=3, loss="cross_entropy",
                                  out="sigmoid", input_seed=7),
+    # mlp_block's other forms in the bandit's trunk (neural_linear_bandit.py:84-85, :110-111; round 5)
+    "layernorm_tiny": dict(F=7, hidden=[12, 10, 6], B=16, steps=4, mlp=dict(use_layer_norm=True)),
+    "leaky_layernorm_small": dict(F=40, hidden=[64, 48, 16], B=128, steps=3,
+                                  mlp=dict(use_layer_norm=True, hidden_activation="leaky_relu")),
+    "tanh_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(hidden_activation="tanh")),
 }
 
 
@@ -465,7 +470,8 @@ def make_bandit(name, cfg):
     gen = torch.Generator().manual_seed(77)
     torch.manual_seed(8)
     pl = NeuralLinearBandit(feature_dim=F, hidden_dims=cfg["hidden"], batch_size=B,
-                            learning_rate=1e-3, loss_type=loss, output_activation_name=out)
+                            learning_rate=1e-3, loss_type=loss, output_activation_name=out,
+                            **cfg.get("mlp", {}))
     fx = {"config": dict(cfg), "model0": clone_sd(pl.model), "batches": [], "reports": []}
     wtrue = torch.randn(F, generator=gen) / F ** 0.5
     for k in range(K):
@@ -584,6 +590,10 @@ def main():
     if os.environ.get("PEARL_GOLDEN_ONLY") == "fullbatch":
         make_ppo("cfg4_fullbatch", PPO_CONFIGS["cfg4_fullbatch"])
         make_sac("cfg3_fullbatch", SAC_CONFIGS["cfg3_fullbatch"])
+        return
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "round5":
+        for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny"):
+            make_bandit(name, BANDIT_CONFIGS[name])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round4":
         # the fixtures round 4 added (VERDICT r3 "untested configs"); everything else untouched

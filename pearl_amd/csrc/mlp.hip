@@ -46,14 +46,18 @@ int layout(const pa_mlp_desc* d, int64_t* woff, int64_t* boff, int64_t* total) {
   PA_REQUIRE(d->hidden_act >= 0 && d->hidden_act < ACT_COUNT, PA_ERR_INVALID,
              "hidden_act %d is not an activation (0 relu, 1 leaky_relu, 2 tanh, 3 softplus, 4 sigmoid)",
              d->hidden_act);
-  PA_REQUIRE(d->layer_norm == 0 || d->layer_norm == 1, PA_ERR_INVALID, "layer_norm is 0 or 1");
+  PA_REQUIRE(d->layer_norm >= 0 && (d->n_layers <= 1 ? d->layer_norm == 0
+                                                       : d->layer_norm < (1 << (d->n_layers - 1))),
+             PA_ERR_INVALID, "layer_norm is a bit mask over the %d hidden layers", d->n_layers - 1);
   *total = o;
   return PA_OK;
 }
 // the LayerNorm parameters of the hidden layers follow the W / b block: gamma_l, beta_l, ...
 int norm_layout(const pa_mlp_desc* d, int64_t wb_total, int64_t* goff, int64_t* betaoff, int64_t* total) {
   int64_t o = wb_total;
-  for (int l = 0; l + 1 < d->n_layers && d->layer_norm; ++l) {
+  for (int l = 0; l + 1 < d->n_layers; ++l) {
+    goff[l] = betaoff[l] = -1;
+    if (!((d->layer_norm >> l) & 1)) continue;
     goff[l] = o; o = align4(o + d->dims[l + 1]);
     betaoff[l] = o; o = align4(o + d->dims[l + 1]);
   }
@@ -186,6 +190,7 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
   ok = ok && alloc(&h->loss_scratch, 4);
   if (desc->layer_norm) {
     for (int l = 0; l + 1 < h->L; ++l) {
+      if (!((desc->layer_norm >> l) & 1)) continue;
       ok = ok && alloc(&h->xhat[l], (int64_t)desc->max_batch * desc->dims[l + 1]);
       ok = ok && alloc(&h->rstd[l], desc->max_batch);
     }
@@ -439,12 +444,13 @@ extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int
     g.epi = relu ? EPI_BIAS_RELU : ((last && h->d.no_last_bias) ? EPI_NONE : EPI_BIAS);
     int rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
-    if (!last && !plain_net(h) && (h->d.layer_norm || !ident)) {
+    const bool ln = !last && ((h->d.layer_norm >> l) & 1);
+    if (!last && !plain_net(h) && (ln || !ident)) {
       // LayerNorm (optional) and the hidden activation, row by row, in place (mlp_norm_act.hpp)
       NormActArgs na;
       memset(&na, 0, sizeof(na));
       na.z = h->act[l]; na.ldz = h->d.dims[l + 1];
-      if (h->d.layer_norm) {
+      if (ln) {
         na.gamma = P + h->goff[l]; na.beta = P + h->betaoff[l];
         // (only the ONLINE network's kept forward feeds a backward)
         na.xhat = (keep && !use_target) ? h->xhat[l] : nullptr;
@@ -720,7 +726,8 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       }
       int rc = launch_linear<true>(&g, 1, s);
       if (rc != PA_OK) return rc;
-      if (l > 0 && !plain_net(h) && (h->d.layer_norm || !ident)) {
+      const bool ln = l > 0 && ((h->d.layer_norm >> (l - 1)) & 1);
+      if (l > 0 && !plain_net(h) && (ln || !ident)) {
         // dh -> dz of hidden layer l - 1 through its activation and LayerNorm (mlp_norm_act.hpp);
         // the LayerNorm's own parameter gradients first (they read dh)
         NormActArgs na;
@@ -729,7 +736,7 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
         na.h = h->act[l - 1]; na.ldh = h->d.dims[l];
         na.B = B; na.d = h->d.dims[l]; na.act = h->d.hidden_act; na.identity = ident ? 1 : 0;
         na.eps = 1e-5f;
-        if (h->d.layer_norm) {
+        if (ln) {
           na.gamma = P + h->goff[l - 1]; na.beta = P + h->betaoff[l - 1];
           na.xhat = h->xhat[l - 1]; na.rstd = h->rstd[l - 1];
           if (want_dw) {

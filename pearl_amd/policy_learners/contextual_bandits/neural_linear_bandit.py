@@ -175,11 +175,20 @@ class NeuralLinearBandit(PolicyLearner):
 
     def _net(self, batch_hint: int = 0) -> FlatMlp:
         if "net" not in self._flat:
-            layers = layers_of(self.model._nn_layers.linear_layers())
+            # the trunk in any of mlp_block's forms the engine computes (use_layer_norm /
+            # hidden_activation of neural_linear_bandit.py:84-85, :110-111; generic_q.mlp_spec)
+            from ..sequential_decision_making.generic_q import plain_or_spec
+            spec = plain_or_spec(self.model._nn_layers._model, "NeuralLinearBandit's _nn_layers")
+            layers = layers_of(spec["linears"])
             layers.append(([self.model.linear_layer_e2e.weight], []))     # bias-free last layer
-            # the trunk's own output layer (index len-2) has no activation (last_activation=None)
+            # the trunk's own output layer (index len-2) has no activation (last_activation=None) and
+            # no LayerNorm; hidden_activation="linear" leaves every hidden layer without one
+            n_hidden = len(layers) - 1
+            ident = ((1 << n_hidden) - 1) if spec["identity"] else (1 << (n_hidden - 1))
+            norms = (list(spec["norms"]) + [None]) if spec["norms"] else None
             self._flat["net"] = FlatMlp(layers, self._optimizer, max(self._batch_size, 1),
-                                        identity_layers=1 << (len(layers) - 2))
+                                        identity_layers=ident, norms=norms,
+                                        hidden_act=spec["hidden_act"])
         return self._flat["net"].ensure(batch_hint)
 
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:

@@ -54,11 +54,13 @@ class FlatMlp:
         # mlp_block's other forms (pa_mlp_desc.hidden_act / layer_norm): the hidden layers' nn.LayerNorm
         # modules (one per hidden layer; their weight / bias join the flat buffers behind W / b) and
         # the activation kind (0 relu, 1 leaky_relu, 2 tanh, 3 softplus, 4 sigmoid)
-        self.norms = list(norms) if norms else None
-        self.target_norms = list(target_norms) if target_norms else None
+        # (entries may be None: a hidden layer without a LayerNorm — the bandit trunk's output layer)
+        self.norms = list(norms) if norms and any(n is not None for n in norms) else None
+        self.target_norms = list(target_norms) if (target_norms and self.norms) else None
         self.hidden_act = int(hidden_act)
         assert self.norms is None or len(self.norms) == len(layers) - 1
         assert (self.target_norms is None) == (self.norms is None or target_layers is None)
+        self.norm_mask = sum(1 << i for i, n in enumerate(self.norms or []) if n is not None)
         self.optimizer = optimizer
         self.max_batch = int(max_batch)
         self.dims = [int(layers[0][0][0].shape[1])] + [
@@ -87,7 +89,7 @@ class FlatMlp:
     def _params(self) -> List[nn.Parameter]:
         ps = [p for ws, bs in self.layers for p in (*ws, *bs)]
         if self.norms:
-            ps += [p for ln in self.norms for p in (ln.weight, ln.bias)]
+            ps += [p for ln in self.norms if ln is not None for p in (ln.weight, ln.bias)]
         return ps
 
     def _target_params(self) -> List[nn.Parameter]:
@@ -95,7 +97,7 @@ class FlatMlp:
             return []
         ps = [p for ws, bs in self.target_layers for p in (*ws, *bs)]
         if self.target_norms:
-            ps += [p for ln in self.target_norms for p in (ln.weight, ln.bias)]
+            ps += [p for ln in self.target_norms if ln is not None for p in (ln.weight, ln.bias)]
         return ps
 
     @property
@@ -190,7 +192,7 @@ class FlatMlp:
         g = self._group()
         max_b = max(self.max_batch, int(batch_hint), 1)
         key = (dev.index, tuple(self.dims), max_b, g["lr"], tuple(g["betas"]), g["eps"],
-               g["weight_decay"], bool(g.get("amsgrad", False)), self.hidden_act, self.norms is not None)
+               g["weight_decay"], bool(g.get("amsgrad", False)), self.hidden_act, self.norm_mask)
         if self.handle is not None and key != self._desc_key:
             torch.cuda.synchronize(dev)
             self.close()
@@ -200,7 +202,7 @@ class FlatMlp:
                              weight_decay=g["weight_decay"], amsgrad=int(bool(g.get("amsgrad", False))),
                              no_last_bias=int(len(self.layers[-1][1]) == 0),
                              identity_layers=self.identity_layers, hidden_act=self.hidden_act,
-                             layer_norm=int(self.norms is not None))
+                             layer_norm=self.norm_mask)
             for i, d in enumerate(self.dims):
                 desc.dims[i] = d
             self._desc = desc
@@ -247,6 +249,8 @@ class FlatMlp:
             noffs = (C.c_int64 * (2 * len(self.norms)))()
             N.check(N.lib().pa_mlp_norm_offsets(C.byref(self._desc), noffs))
             for li, ln in enumerate(self.norms):
+                if ln is None:
+                    continue
                 tn = self.target_norms[li] if self.target_norms else None
                 groups.append(([ln.weight], int(noffs[2 * li]), [tn.weight] if tn is not None else None))
                 groups.append(([ln.bias], int(noffs[2 * li + 1]), [tn.bias] if tn is not None else None))

@@ -389,7 +389,10 @@ def test_sac_split_actor_rows_are_bitwise_the_unsplit_ones(name, monkeypatch):
 
 
 BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
-          "mae_cfg5_shape_small", "bce_cfg5_shape_small"]
+          "mae_cfg5_shape_small", "bce_cfg5_shape_small",
+          # mlp_block's other forms in the trunk (neural_linear_bandit.py:84-85; round 5): LayerNorm,
+          # leaky_relu, tanh — the generic engine's layer-by-layer path (mlp_norm_act.hpp)
+          "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny"]
 
 
 @pytest.mark.parametrize("name", BANDIT)
@@ -406,7 +409,7 @@ def test_neural_linear_bandit_learn_batch(name):
     cfg = fx["config"]
     pl = NeuralLinearBandit(feature_dim=cfg["F"], hidden_dims=cfg["hidden"], batch_size=cfg["B"],
                             learning_rate=1e-3, loss_type=cfg.get("loss", "mse"),
-                            output_activation_name=cfg.get("out", "linear"))
+                            output_activation_name=cfg.get("out", "linear"), **cfg.get("mlp", {}))
     pl.model.load_state_dict(fx["model0"])
     pl.to(DEV)
     for step, ((x, r, w), want) in enumerate(zip(bandit_batches(fx), fx["reports"])):

@@ -105,7 +105,9 @@ def test_sac_probe_and_trajectory(name):
 
 
 BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
-          "mae_cfg5_shape_small", "bce_cfg5_shape_small"]
+          "mae_cfg5_shape_small", "bce_cfg5_shape_small",
+          # mlp_block's other forms in the trunk (round 5): LayerNorm, leaky_relu, tanh
+          "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny"]
 
 
 def bandit_batches(fx):
@@ -127,7 +129,8 @@ def test_neural_linear_bandit_trajectory(name):
     fx = load("bandit", name)
     cfg = fx["config"]
     orc = NeuralLinearOracle(fx["model0"], lr=1e-3, loss_type=cfg.get("loss", "mse"),
-                             output_activation=cfg.get("out", "linear"))
+                             output_activation=cfg.get("out", "linear"),
+                             hidden_activation=cfg.get("mlp", {}).get("hidden_activation", "relu"))
     for (x, r, w), want in zip(bandit_batches(fx), fx["reports"]):
         got = orc.learn_batch(x, r, w)
         assert abs(float(got["loss"]) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
@@ -142,6 +145,10 @@ def test_neural_linear_bandit_trajectory(name):
     torch.testing.assert_close(orc.sigma(fx["query"]["x"]), fx["query"]["sigma"].view(-1), rtol=2e-4, atol=1e-6)
     for i, (w_, b_) in enumerate(orc.trunk):
         torch.testing.assert_close(w_.detach(), after[f"_nn_layers._model.{i}.0.weight"], rtol=1e-4, atol=1e-6)
+    for i, n in enumerate(orc.norms):
+        if n is not None:
+            torch.testing.assert_close(n[0].detach(), after[f"_nn_layers._model.{i}.1.weight"], rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(n[1].detach(), after[f"_nn_layers._model.{i}.1.bias"], rtol=1e-4, atol=1e-6)
     torch.testing.assert_close(orc.e2e.detach(), after["linear_layer_e2e.weight"], rtol=1e-4, atol=1e-6)
 
 
