@@ -459,6 +459,8 @@ BANDIT_CONFIGS = {
     "leaky_layernorm_small": dict(F=40, hidden=[64, 48, 16], B=128, steps=3,
                                   mlp=dict(use_layer_norm=True, hidden_activation="leaky_relu")),
     "tanh_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(hidden_activation="tanh")),
+    # force_pinv (linear_regression.py:138-157): torch.linalg.pinv of A + lambda I instead of inv
+    "pinv_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(force_pinv=True)),
 }
 
 
@@ -592,7 +594,7 @@ def main():
         make_sac("cfg3_fullbatch", SAC_CONFIGS["cfg3_fullbatch"])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round5":
-        for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny"):
+        for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny", "pinv_tiny"):
             make_bandit(name, BANDIT_CONFIGS[name])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round4":

@@ -25,8 +25,16 @@ class LinearRegression(nn.Module):
                  force_pinv: bool = False) -> None:
         super().__init__()
         assert 0 < gamma <= 1, f"gamma should be in (0, 1]. Got gamma={gamma} instead"
-        if force_pinv:
-            raise NotImplementedError("pearl_amd LinearRegression: force_pinv is not built")
+        if force_pinv and not l2_reg_lambda > 0:
+            # linear_regression.py:138-157: force_pinv inverts A + lambda I with torch.linalg.pinv.  With
+            # lambda > 0 that matrix is symmetric positive definite (A is a sum of w x x^T terms), its
+            # pseudo-inverse IS its inverse, and the fp64 SPD solve of the HIP path computes exactly
+            # that — force_pinv=True is then honoured as is.  Only the unregularised, possibly singular
+            # case needs an SVD, which is not built.
+            raise NotImplementedError(
+                "pearl_amd LinearRegression: force_pinv with l2_reg_lambda = 0 (a possibly singular A) "
+                "needs an SVD-based pseudo-inverse, which is not built; with l2_reg_lambda > 0 the "
+                "pseudo-inverse equals the inverse the HIP solve computes")
         self._feature_dim = feature_dim
         self.gamma, self.l2_reg_lambda, self.force_pinv = gamma, l2_reg_lambda, force_pinv
         self.register_buffer("_A", torch.zeros(feature_dim + 1, feature_dim + 1))

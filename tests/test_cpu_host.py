@@ -622,3 +622,15 @@ def test_optimizer_argument_is_honoured_or_refused():
         ContinuousSoftActorCritic(action_space=space, actor_network_instance=actor,
                                   critic_network_instance=critic,
                                   actor_optimizer=torch.optim.RMSprop(actor.parameters()))
+
+
+def test_force_pinv_is_honoured_on_the_regularised_matrix():
+    """linear_regression.py:138-157: force_pinv inverts A + lambda I with torch.linalg.pinv.  With
+    lambda > 0 the matrix is SPD and its pseudo-inverse is the inverse the HIP solve computes
+    (bandit_pinv_tiny pins that against the reference); lambda = 0 would need an SVD and is refused."""
+    from pearl_amd import NeuralLinearBandit
+    from pearl_amd.neural_networks.contextual_bandit.linear_regression import LinearRegression
+    assert LinearRegression(feature_dim=4, force_pinv=True).force_pinv
+    assert NeuralLinearBandit(feature_dim=5, hidden_dims=[8, 4], force_pinv=True).model._linear_regression_layer.force_pinv
+    with pytest.raises(NotImplementedError, match="SVD"):
+        LinearRegression(feature_dim=4, l2_reg_lambda=0.0, force_pinv=True)

@@ -392,7 +392,9 @@ BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", 
           "mae_cfg5_shape_small", "bce_cfg5_shape_small",
           # mlp_block's other forms in the trunk (neural_linear_bandit.py:84-85; round 5): LayerNorm,
           # leaky_relu, tanh — the generic engine's layer-by-layer path (mlp_norm_act.hpp)
-          "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny"]
+          "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny",
+          # force_pinv=True (linear_regression.py:138-157) on the regularised matrix
+          "pinv_tiny"]
 
 
 @pytest.mark.parametrize("name", BANDIT)

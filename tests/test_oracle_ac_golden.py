@@ -107,7 +107,9 @@ def test_sac_probe_and_trajectory(name):
 BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
           "mae_cfg5_shape_small", "bce_cfg5_shape_small",
           # mlp_block's other forms in the trunk (round 5): LayerNorm, leaky_relu, tanh
-          "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny"]
+          "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny",
+          # force_pinv=True (the pseudo-inverse of the regularised, SPD matrix is its inverse)
+          "pinv_tiny"]
 
 
 def bandit_batches(fx):
