@@ -1,9 +1,18 @@
+#!/bin/bash
+# timelines for offline reading: the 20-round DQN call, PPO / SAC steps (rocprofv3 kernel traces)
+R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/prof
-PEARL_AMD_ROWPASS_PAIR=1 PEARL_AMD_PAIR_LDS=0 PEARL_AMD_PERSIST_OFFER=4096 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-other-configs > $R/gpurun_out/rocprof.log 2>&1
-python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db > $R/gpurun_out/kernel_stats_pair2.txt 2>&1
-python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db rowpass 70 >> $R/gpurun_out/kernel_stats_pair2.txt 2>&1
-head -9 $R/gpurun_out/kernel_stats_pair2.txt | cut -c1-150
-grep "stream=" $R/gpurun_out/kernel_stats_pair2.txt | tail -64 | cut -c1-130
-rm -f $R/gpurun_out/prof/*.db
+rm -rf $R/gpurun_out/prof_sc
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/shortcall_timeline.txt 2>&1
+rm -f $DB
+for w in ppo sac; do
+  rm -rf $R/gpurun_out/prof_$w
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$w -o t -- python $R/bench_algos.py --steps 200 --only $w --cpu-seconds 0 > $R/gpurun_out/rocprof_$w.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_$w/*.db $R/gpurun_out/prof_$w/*/*.db 2>/dev/null | head -1)
+  python $R/tools/rocpd_summary.py $DB > $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+  python $R/tools/rocpd_timeline.py $DB rowstep 40 >> $R/gpurun_out/${w}_kernel_stats.txt 2>&1
+  rm -f $DB
+done
+cd $R && timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err; cat gpurun_out/shortcall.jsonl
