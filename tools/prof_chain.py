@@ -72,7 +72,7 @@ def main():
     torch.cuda.synchronize()
     N.check(N.lib().pa_debug_set_prof(nat.handle, None, None, -1))
     ndw = int(os.environ.get("PROF_DW_WGS", "112"))
-    nrow = 128 if os.environ.get("PEARL_AMD_ROWPASS_PAIR", "1") != "0" else 64
+    nrow = 128 if os.environ.get("PEARL_AMD_ROWPASS_PAIR", "0") == "1" else 64
     r = row[:nrow].cpu().numpy().astype(np.int64)
     d = dw[:ndw].cpu().numpy().astype(np.int64)
     row_end = r[:, :, 10].max()
