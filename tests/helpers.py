@@ -77,3 +77,12 @@ def assert_linear_solve_close(coefs, A, b, lam, want_coefs, max_backward=2e-6, m
     bound = 4.0 * cond * 2.0 ** -24
     assert fwd <= bound, f"{msg}: forward difference {fwd:.3e} > 4 cond eps = {bound:.3e} (cond {cond:.3g})"
     return eta, fwd, cond
+
+
+def free_port() -> int:
+    """A TCP port nothing listens on right now (bind to 0 and read it back): rendezvous ports picked
+    with ``random`` collide once an earlier test has seeded the global generator."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return int(s.getsockname()[1])

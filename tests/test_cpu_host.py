@@ -7,6 +7,14 @@ import subprocess
 import sys
 
 import pytest
+
+
+def _free_port() -> int:
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import free_port
+    return free_port()
 import torch
 
 from conftest import GOLDEN_NAMES, REPO
@@ -322,7 +330,7 @@ def test_actor_critic_gradient_reduction_mean_and_sum():
     assert reduce_gradient_(g.clone(), "mean").tolist() == g.tolist()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_dp_mlp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -340,7 +348,7 @@ def test_gradient_allreduce_is_a_mean_over_ranks():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -375,7 +383,7 @@ def test_native_learn_loops_step_aside_under_data_parallelism():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_native_loop_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -8,6 +8,14 @@ import os
 import random
 
 import pytest
+
+
+def _free_port() -> int:
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import free_port
+    return free_port()
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -66,7 +74,7 @@ def _run(world, exchange="gloo"):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
@@ -173,7 +181,7 @@ def test_p2p_exchange_sums_in_rank_order_over_many_rounds(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_p2p_unit_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -245,7 +253,7 @@ def test_p2p_exchange_late_peer_waits_and_dead_peer_poisons(mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_p2p_fault_worker, args=(r, 2, port, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
@@ -379,7 +387,7 @@ def test_ppo_two_ranks_equal_one_reference_learner_on_the_concatenated_minibatch
     from oracle.actor_critic_oracle import PpoOracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_ppo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -479,7 +487,7 @@ def test_bandit_two_ranks_equal_one_reference_learner_on_the_concatenated_batch(
     from oracle.actor_critic_oracle import NeuralLinearOracle
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + random.randrange(2000)
+    port = _free_port()
     procs = [ctx.Process(target=_bandit_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
