@@ -8,19 +8,20 @@ import sys
 
 import pytest
 
-
-def _free_port() -> int:
-    import os
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from helpers import free_port
-    return free_port()
 import torch
 
 from conftest import GOLDEN_NAMES, REPO
 
 
 # ---------------------------------------------------------------------------- C ABI
+def _free_port() -> int:
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import free_port
+    return free_port()
+
+
 def _header_functions():
     text = open(os.path.join(REPO, "include", "pearl_amd.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)

@@ -9,6 +9,10 @@ import random
 
 import pytest
 
+import torch
+
+pytestmark = pytest.mark.gpu
+
 
 def _free_port() -> int:
     import os
@@ -16,9 +20,6 @@ def _free_port() -> int:
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from helpers import free_port
     return free_port()
-import torch
-
-pytestmark = pytest.mark.gpu
 
 
 def _shard_states(rank, N, S):
