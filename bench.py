@@ -130,7 +130,7 @@ def pmc_traffic(transitions_per_launch, split_on):
     prescribes for gfx950, + WRITE_SIZE, per transition).  Counters cannot be collected inside this
     run, so the line names the file the figure comes from and the kernel that pass measured; None
     when no pass exists for the kernel that ran."""
-    names = ["r04_pmc_target.json", "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"]
+    names = ["r05_pmc_target.json", "r04_pmc_target.json", "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"]
     for name in names:
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU round (round 4): a fresh-box stress FIRST (every torch tensor its own page-granular hipMalloc,
+# GPU round (rounds 4-5): a fresh-box stress FIRST (every torch tensor its own page-granular hipMalloc,
 # kernels serialized: a stray access faults with context instead of landing in allocator slack —
 # DESIGN.md §14.0), the gpu test-suite, smoke, the driver's own bench command (20 steps; carries
 # parity, other_configs and the reference CPU baselines), the long bench, per-call fixed cost of
@@ -21,9 +21,9 @@ fi
 if [ "$SKIP_TESTS" != "1" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
+fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
-fi
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_s20.log 2> gpurun_out/bench_s20.err
 echo "bench s20 rc=$?"; tail -1 gpurun_out/bench_s20.log | python -c "
 import sys,json

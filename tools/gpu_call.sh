@@ -36,7 +36,7 @@ if [ "$MODE" == "pmc" ]; then
   for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE"; do
     tag=$(echo $set | cut -d' ' -f1)
     rm -rf $R/gpurun_out/pmc_$tag
-    timeout 600 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_$tag -o dqn --output-format csv -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --timing-level 0 > $R/gpurun_out/pmc_$tag.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/pmc_$tag -o dqn --output-format csv -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-other-configs --timing-level 0 > $R/gpurun_out/pmc_$tag.log 2>&1
     echo "pmc $tag rc=$?"
   done
   F=$(ls $R/gpurun_out/pmc_FETCH_SIZE/*counter_collection.csv $R/gpurun_out/pmc_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
