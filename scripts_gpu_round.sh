@@ -17,6 +17,11 @@ echo "stress rc=$?"; tail -2 gpurun_out/nocache_stress.txt
 PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 600 python -m pytest tests/test_gpu_actor_critic.py tests/test_gpu_kernels.py tests/test_gpu_dp.py -m gpu -q -x -p no:cacheprovider \
   -k "rowstep or weight_grad or bandit_learn_batch or ppo_learn_trajectory or p2p_exchange_sums or one_call or native_learn_loop or two_solves" > gpurun_out/nocache_tests.txt 2>&1
 echo "stress tests rc=$?"; tail -2 gpurun_out/nocache_tests.txt
+# round 5's new kernels that do not need the two-stream loop: the paired row pass (stand-alone step),
+# LayerNorm / activation kernels of the generic engine, the CQL rows, caller-supplied optimizers
+PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 600 python -m pytest tests/test_gpu_dqn.py -m gpu -q -x -p no:cacheprovider \
+  -k "qnet or paired or caller_supplied or conservative" >> gpurun_out/nocache_tests.txt 2>&1
+echo "stress tests (round 5 kernels) rc=$?"; tail -2 gpurun_out/nocache_tests.txt
 fi
 if [ "$SKIP_TESTS" != "1" ]; then
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
