@@ -7,7 +7,8 @@ Every copy says which commit produced it (two r04 files pred
 code and nothing could tell): text files get a first line `# pearl_amd HEAD <sha> ...`, a JSON
 object a `_stamp` key, JSON-lines files a first `{"_stamp": ...}` line.  The GPU box has no .git,
 so the stamp is taken HERE, right after the call: commit first, measure, then run this — it
-refuses to stamp a dirty tree unless --allow-dirty (then the stamp says so).
+refuses to stamp a dirty tree unless --allow-dirty (then the stamp says so); --head=<commit> names
+the commit of an earlier call whose files are copied later.
 """
 import json
 import os
@@ -27,6 +28,10 @@ def main():
     allow_dirty = "--allow-dirty" in sys.argv
     prefix, items = args[0], args[1:]
     sha = git("rev-parse", "--short=12", "HEAD")
+    for a in sys.argv[1:]:
+        if a.startswith("--head="):     # the files come from an EARLIER call: name the commit it ran on
+            sha = git("rev-parse", "--short=12", a.split("=", 1)[1])
+            allow_dirty = True
     dirty = [ln for ln in git("status", "--porcelain", "--", "pearl_amd", "bench.py", "bench_algos.py",
                               "include", "tools", "oracle", "tests").splitlines() if ln.strip()]
     if dirty and not allow_dirty:
