@@ -50,8 +50,11 @@ def main():
         text = open(sp, errors="replace").read()
         lines = [ln for ln in text.splitlines() if ln.strip()]
         if dst.endswith(".json"):
-            js = [ln for ln in lines if ln.startswith("{")]
-            obj = json.loads(js[-1]) if js else {"raw": text[-2000:]}
+            try:
+                obj = json.loads(text)                 # a (possibly indented) JSON document
+            except ValueError:
+                js = [ln for ln in lines if ln.startswith("{")]      # a log whose last line is one
+                obj = json.loads(js[-1]) if js else {"raw": text[-2000:]}
             obj["_stamp"] = stamp
             out = json.dumps(obj) + "\n"
         elif dst.endswith(".jsonl"):
