@@ -2804,6 +2804,113 @@ void linreg_solve_spd_kernel(SolveArgs a, int* need_pivot) {
   }
 }
 
+// Round 5: the same elimination IN PLACE, each column shared by NS lanes.
+// The right half of the augmented system above is never more than bookkeeping: before step k its
+// column k is still the unit vector e_k, after step k it holds column k of the partial inverse, and
+// the left half's column k is dead from then on.  So column k of ONE [DR][DR] matrix can carry both
+// (classic in-place Gauss-Jordan): the owner of column k publishes it, then continues as if it held
+// e_k.  Every surviving fused multiply-add has the same operands in the same order as in
+// linreg_solve_spd_kernel, so the two kernels agree bit for bit (tests/test_gpu_actor_critic.py);
+// half of the columns are gone, and with them half of the work.
+// The freed lanes split each column's rows: lane c * NS + h keeps frame rows [h HR, (h + 1) HR),
+// HR = DR / NS, of column c.  The rotating frame crosses the lane boundary once per step — the
+// updated first row of part h + 1 becomes the last row of part h — and the pivot row's entry lives in
+// part 0: two DPP moves inside a quad (no LDS, no barrier).  A pivot step is then HR - 1 FMAs and
+// HR / 2 + 1 LDS reads per lane instead of 71 and 36.
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+constexpr int quad_perm(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+
+template <int NS, bool PRIO>
+__global__ __launch_bounds__(SOLVE_DR * NS)
+void linreg_solve_spd_inplace_kernel(SolveArgs a, int* need_pivot) {
+  static_assert(NS == 2 || NS == 4, "a column's parts exchange rows inside one quad");
+  extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  constexpr int DR = SOLVE_DR, HR = DR / NS, NT = DR * NS;
+  static_assert(HR * NS == DR && HR % 2 == 0, "parts of whole double2s");
+  const int D = a.D, t = threadIdx.x, c = t / NS, h = t % NS;
+  double* bcast = lds_work;                   // [2][DR]: the pivot column, double-buffered
+  double* work = lds_work + 2 * DR;           // [DR][DR]: staging of the input, then of the result
+  __shared__ int bad;
+  if (PRIO) __builtin_amdgcn_s_setprio(3);    // (as above: the solve shares its CU with the next step)
+  if (t == 0) {
+    bad = 0;
+    need_pivot[0] = 0;
+    a.singular[0] = 0;
+  }
+  // diag(A + lambda I, I) staged through LDS with coalesced loads
+  for (int e = t; e < DR * DR; e += NT) {
+    const int i = e / DR, j = e - i * DR;
+    double v;
+    if (i < D && j < D) v = (double)a.A[i * D + j] + (i == j ? (double)a.lambda : 0.0);
+    else v = (i == j) ? 1.0 : 0.0;
+    work[e] = v;
+  }
+  __syncthreads();
+  double col[HR];
+#pragma unroll
+  for (int r = 0; r < HR; ++r) col[r] = work[(h * HR + r) * DR + c];
+  __syncthreads();
+  for (int k = 0; k < D; ++k) {
+    double* bc = bcast + (k & 1) * DR;
+    const bool owner = c == k;
+    if (owner) {
+#pragma unroll
+      for (int r = 0; r < HR; r += 2)
+        *reinterpret_cast<double2*>(bc + h * HR + r) = make_double2(col[r], col[r + 1]);
+    }
+    __syncthreads();
+    double f[HR];
+#pragma unroll
+    for (int r = 0; r < HR; r += 2) {
+      const double2 v = *reinterpret_cast<const double2*>(bc + h * HR + r);
+      f[r] = v.x;
+      f[r + 1] = v.y;
+    }
+    const double piv = bc[0];
+    if (!(piv > 0.0) && t == 0) bad = 1;
+    if (owner) {                              // from here on this column is e_k's
+#pragma unroll
+      for (int r = 0; r < HR; ++r) col[r] = 0.0;
+      if (h == 0) col[0] = 1.0;
+    }
+    // the pivot row's entry of this column: part 0's first register, to every part of the column
+    const double pr = dpp_quad<NS == 2 ? quad_perm(0, 0, 2, 2) : quad_perm(0, 0, 0, 0)>(col[0] * (1.0 / piv));
+    // part h + 1's updated first row is part h's new last row (lane + 1 of the quad)
+    const double first = __builtin_fma(-f[0], pr, col[0]);
+    const double from_next = dpp_quad<NS == 2 ? quad_perm(1, 0, 3, 2) : quad_perm(1, 2, 3, 3)>(first);
+#pragma unroll
+    for (int r = 1; r < HR; ++r) col[r - 1] = __builtin_fma(-f[r], pr, col[r]);
+    col[HR - 1] = (h == NS - 1) ? pr : from_next;
+  }
+  // after D steps register r of part h holds logical row (D + h HR + r) mod DR
+#pragma unroll
+  for (int r = 0; r < HR; ++r) {
+    int row = D + h * HR + r;
+    if (row >= DR) row -= DR;
+    work[row * DR + c] = col[r];
+  }
+  __syncthreads();
+  if (bad) {
+    if (t == 0) need_pivot[0] = 1;
+    return;
+  }
+  for (int e = t; e < D * D; e += NT) {
+    const int i = e / D, j = e - i * D;
+    a.invA[e] = (float)work[i * DR + j];
+  }
+  for (int i = t; i < D; i += NT) {
+    double s = 0.0;
+    for (int j = 0; j < D; ++j) s += work[i * DR + j] * (double)a.bvec[j];
+    a.coefs[i] = (float)s;
+  }
+}
+
 // sigma[b] = sqrt([1 | f_b] inv_A [1 | f_b]^T)      (linear_regression.py:261-270)
 __global__ __launch_bounds__(256) void linreg_sigma_kernel(const float* __restrict__ f, int ldf,
                                                            const float* __restrict__ invA, int B,
@@ -3059,14 +3166,35 @@ extern "C" int pa_linreg_solve(const float* A, const float* b, float l2_reg_lamb
     // "a pivot was not positive" word that arms the pivoting kernel below
     // (the kernel clears both status words itself: two 5 us memset launches less in the chain)
     int* need_pivot = reinterpret_cast<int*>(work);
-    const size_t lds_spd = sizeof(double) * (2 * SOLVE_DR + (size_t)SOLVE_DR * 2 * SOLVE_DR);
-    static size_t configured_spd = 0;
-    if (lds_spd > configured_spd) {
-      int rc = set_max_smem(linreg_solve_spd_kernel, lds_spd);
-      if (rc != PA_OK) return rc;
-      configured_spd = lds_spd;
+    // PEARL_AMD_SOLVE_SPLIT: lanes per column of the in-place kernel (2 or 4, default 4); 1 = the augmented
+    // kernel of round 4 (kept: the bit-for-bit comparison of tests/ runs against it)
+    const int split = []() {
+      const char* v = getenv("PEARL_AMD_SOLVE_SPLIT");
+      return (v && *v) ? atoi(v) : 4;
+    }();
+    PA_REQUIRE(split == 1 || split == 2 || split == 4, PA_ERR_INVALID,
+               "PEARL_AMD_SOLVE_SPLIT must be 1, 2 or 4");
+    if (split == 1) {
+      const size_t lds_spd = sizeof(double) * (2 * SOLVE_DR + (size_t)SOLVE_DR * 2 * SOLVE_DR);
+      static size_t configured_spd = 0;
+      if (lds_spd > configured_spd) {
+        int rc = set_max_smem(linreg_solve_spd_kernel, lds_spd);
+        if (rc != PA_OK) return rc;
+        configured_spd = lds_spd;
+      }
+      hipLaunchKernelGGL(linreg_solve_spd_kernel, dim3(1), dim3(192), lds_spd, s, a, need_pivot);
+    } else {
+      const size_t lds_in = sizeof(double) * (2 * SOLVE_DR + (size_t)SOLVE_DR * SOLVE_DR);   // 41.6 KB
+      // no raised priority by default: the solve is off the learner stream's chain, and five waves that
+      // go first at the issue ports of the CU they share cost the next step's row pass 2.5 % (measured:
+      // bandit 46.9 M contexts/s with, 48.3 M without — what the augmented kernel's three waves gave)
+      const char* pv = getenv("PEARL_AMD_SOLVE_PRIO");
+      const bool prio = pv && *pv == '1';
+      void (*k)(SolveArgs, int*) =
+          split == 2 ? (prio ? linreg_solve_spd_inplace_kernel<2, true> : linreg_solve_spd_inplace_kernel<2, false>)
+                     : (prio ? linreg_solve_spd_inplace_kernel<4, true> : linreg_solve_spd_inplace_kernel<4, false>);
+      hipLaunchKernelGGL(k, dim3(1), dim3(SOLVE_DR * split), lds_in, s, a, need_pivot);
     }
-    hipLaunchKernelGGL(linreg_solve_spd_kernel, dim3(1), dim3(192), lds_spd, s, a, need_pivot);
     PA_LAUNCH_CHECK();
     a.only_if = need_pivot;
   } else {

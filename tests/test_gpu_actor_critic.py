@@ -1066,11 +1066,27 @@ def test_dsac_rowsteps_equal_forward_head_backward(dims, B, masked):
     torch.testing.assert_close(out[0][4], out[1][4], rtol=2e-5, atol=1e-7)
 
 
-def test_linreg_solve_spd_fast_path_and_pivoting_fallback():
-    """pa_linreg_solve: the pivot-free register-column kernel on an SPD system, and the pivoting
-    kernel when a pivot is not positive (an indefinite matrix a negative weight could produce)."""
+def _solve(A, b, lam, d):
     from pearl_amd import _native as N
-    d = 64
+    D = d + 1
+    Ad = A.to(DEV).contiguous()
+    work = torch.empty(D * 2 * D, dtype=torch.float64, device=DEV)
+    inv = torch.zeros(D, D, device=DEV)
+    coefs = torch.zeros(D, device=DEV)
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    N.check(N.lib().pa_linreg_solve(Ad.data_ptr(), b.data_ptr(), lam, d, work.data_ptr(),
+                                    inv.data_ptr(), coefs.data_ptr(), flag.data_ptr(),
+                                    N.stream_ptr(Ad.device)))
+    return inv.cpu(), coefs.cpu(), int(flag.item())
+
+
+@pytest.mark.parametrize("d", [64, 71, 20, 1])
+def test_linreg_solve_spd_fast_path_and_pivoting_fallback(d, monkeypatch):
+    """pa_linreg_solve: the pivot-free register-column kernels on an SPD system — the in-place kernel
+    with 4 (default) and 2 lanes per column, and round 4's augmented kernel: the same fused
+    multiply-adds in the same order, so the three agree BIT FOR BIT — and the pivoting kernel when a
+    pivot is not positive (an indefinite matrix a negative weight could produce).  d + 1 = 65 is the
+    bandit's system, 72 the largest the register kernels take, 2 the smallest."""
     D = d + 1
     torch.manual_seed(11)
     xg = torch.randn(512, D, dtype=torch.float64)
@@ -1080,21 +1096,21 @@ def test_linreg_solve_spd_fast_path_and_pivoting_fallback():
     eig[::7] *= -1.0                                     # indefinite, well conditioned
     indef = (q @ torch.diag(eig) @ q.t()).float()
     for name, A, lam in (("spd", spd, 1.0), ("indefinite", indef, 0.0)):
-        Ad = A.to(DEV).contiguous()
         b = torch.randn(D, device=DEV)
-        work = torch.empty(D * 2 * D, dtype=torch.float64, device=DEV)
-        inv = torch.zeros(D, D, device=DEV)
-        coefs = torch.zeros(D, device=DEV)
-        flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-        N.check(N.lib().pa_linreg_solve(Ad.data_ptr(), b.data_ptr(), lam, d, work.data_ptr(),
-                                        inv.data_ptr(), coefs.data_ptr(), flag.data_ptr(),
-                                        N.stream_ptr(Ad.device)))
+        got = {}
+        for split in ("4", "2", "1"):
+            monkeypatch.setenv("PEARL_AMD_SOLVE_SPLIT", split)
+            got[split] = _solve(A, b, lam, d)
+        inv, coefs, flag = got["4"]
         want = torch.linalg.inv(A.double() + lam * torch.eye(D, dtype=torch.float64))
-        torch.testing.assert_close(inv.cpu().double(), want, rtol=1e-4, atol=1e-6 * float(want.abs().max()),
+        torch.testing.assert_close(inv.double(), want, rtol=1e-4, atol=1e-6 * float(want.abs().max()),
                                    msg=name)
-        torch.testing.assert_close(coefs.cpu().double(), want @ b.cpu().double(), rtol=1e-3,
+        torch.testing.assert_close(coefs.double(), want @ b.cpu().double(), rtol=1e-3,
                                    atol=1e-5 * float((want @ b.cpu().double()).abs().max()), msg=name)
-        assert int(flag.item()) == 0
+        assert flag == 0
+        for split in ("2", "1"):
+            assert torch.equal(got[split][0], inv) and torch.equal(got[split][1], coefs), (name, split)
+            assert got[split][2] == 0
 
 
 DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small", "td3_cfg3_fullbatch"]

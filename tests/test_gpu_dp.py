@@ -522,3 +522,124 @@ def test_bandit_two_ranks_equal_one_reference_learner_on_the_concatenated_batch(
         assert_adam_trajectory_close(sd[k], t.detach(), 1e-3, NB_STEPS, rtol=1e-3, atol=2e-5, msg=k)
     assert_adam_trajectory_close(sd["linear_layer_e2e.weight"], orc.e2e.detach(), 1e-3, NB_STEPS,
                                  rtol=1e-3, atol=2e-5, msg="e2e")
+
+
+# ---------------------------------------------------------------------------------------------
+# ContinuousSoftActorCritic (BASELINE config 3): actor / twin-critic gradients and mean(log pi)
+# ---------------------------------------------------------------------------------------------
+SAC_S, SAC_A, SAC_HID, SAC_B, SAC_STEPS = 11, 3, [32, 32], 48, 3
+
+
+def _sac_data(rank):
+    g = torch.Generator().manual_seed(1300 + rank)
+    steps = []
+    for _ in range(SAC_STEPS):
+        batch = dict(state=torch.randn(SAC_B, SAC_S, generator=g),
+                     action=torch.rand(SAC_B, SAC_A, generator=g) * 2 - 1,
+                     reward=torch.randn(SAC_B, generator=g) + 0.5 * rank,
+                     terminated=torch.rand(SAC_B, generator=g) < 0.1,
+                     next_state=torch.randn(SAC_B, SAC_S, generator=g))
+        noise = (torch.randn(SAC_B, SAC_A, generator=g), torch.randn(SAC_B, SAC_A, generator=g))
+        steps.append((batch, noise))
+    return steps
+
+
+def _sac_learner():
+    from pearl_amd import BoxActionSpace, ContinuousSoftActorCritic
+    torch.manual_seed(0)                      # identical initial parameters on every rank
+    low, high = -torch.ones(SAC_A), torch.ones(SAC_A)
+    return ContinuousSoftActorCritic(action_space=BoxActionSpace(low, high), state_dim=SAC_S,
+                                     actor_hidden_dims=SAC_HID, critic_hidden_dims=SAC_HID,
+                                     batch_size=SAC_B), low, high
+
+
+def _sac_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from pearl_amd import BasicReplayBuffer, PearlAgent, TransitionBatch
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pl, _, _ = _sac_learner()
+    PearlAgent(pl, replay_buffer=BasicReplayBuffer(10), device_id=0)
+    reports = []
+    for batch, (na, nc) in _sac_data(rank):
+        seq = iter([na.to(dev), nc.to(dev)])
+        pl.noise_source = lambda B, A, d: next(seq)
+        rep = pl.learn_batch(pl.preprocess_batch(TransitionBatch(**{k: v.to(dev) for k, v in batch.items()})))
+        reports.append({k: float(v) for k, v in rep.items()})
+    torch.cuda.synchronize()
+    sd = {}
+    for name, mod in (("actor", pl._actor), ("critic", pl._critic), ("critic_target", pl._critic_target)):
+        sd.update({f"{name}.{k}": v.detach().cpu().numpy().copy() for k, v in mod.state_dict().items()})
+    sd["log_entropy"] = pl._log_entropy.detach().cpu().numpy().copy()
+    q.put((rank, sd, reports))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sac_two_ranks_equal_one_reference_learner_on_the_concatenated_batch():
+    """SAC's data-parallel step on the GPU.  Two HIP ranks, each with its own batch
+    and reparameterisation noise: actor and twin-critic gradients are averaged over the ranks before
+    AdamW (both losses are means over the global batch), the entropy coefficient steps on the GLOBAL
+    mean of log pi.  Both ranks must end with bitwise the same actor / critics / targets / log alpha,
+    and with what ONE oracle learner (soft_actor_critic_continuous.py:134-231 restated) reaches on the
+    concatenated 2B-row batch with the concatenated noise."""
+    import sys
+    import torch.multiprocessing as mp
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import assert_adam_trajectory_close
+    from oracle.actor_critic_oracle import SacOracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sac_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in procs:
+        rank, sd, reports = q.get(timeout=300)
+        out[rank] = (sd, reports)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for k in out[0][0]:
+        assert (out[0][0][k] == out[1][0][k]).all(), f"ranks diverged: {k}"
+    pl, low, high = _sac_learner()
+    orc = SacOracle(pl._actor.state_dict(), pl._critic.state_dict(), pl._critic_target.state_dict(),
+                    low, high)
+    d0, d1 = _sac_data(0), _sac_data(1)
+    for step, ((b0, n0), (b1, n1)) in enumerate(zip(d0, d1)):
+        batch = {k: torch.cat([b0[k], b1[k]]) for k in b0}
+        want = orc.learn_batch(batch, torch.cat([n0[0], n1[0]]), torch.cat([n0[1], n1[1]]))
+        tol = 2e-5 if step == 0 else 5e-4
+        for k in ("actor_loss", "critic_loss"):     # each rank reports its shard's mean
+            got = (out[0][1][step][k] + out[1][1][step][k]) / 2
+            assert abs(got - want[k]) <= tol * max(1.0, abs(want[k])), (step, k, got, want[k])
+        # the entropy loss is formed from the global mean(log pi): the same number on both ranks
+        assert out[0][1][step]["entropy_coef"] == out[1][1][step]["entropy_coef"]
+        assert abs(out[0][1][step]["entropy_coef"] - want["entropy_coef"]) <= tol * max(
+            1.0, abs(want["entropy_coef"])), (step, out[0][1][step]["entropy_coef"], want["entropy_coef"])
+    sd = {k: torch.from_numpy(v) for k, v in out[0][0].items()}
+    torch.testing.assert_close(sd["log_entropy"].view(-1), orc.log_alpha.detach().view(-1), rtol=1e-4, atol=1e-6)
+    n_hidden = len(SAC_HID)
+    for i, (w, b) in enumerate(orc.trunk):
+        assert_adam_trajectory_close(sd[f"actor._model.{i}.0.weight"], w.detach(), 1e-3, SAC_STEPS,
+                                     rtol=1e-3, atol=2e-5, msg=f"actor trunk {i} W")
+        assert_adam_trajectory_close(sd[f"actor._model.{i}.0.bias"], b.detach(), 1e-3, SAC_STEPS,
+                                     rtol=1e-3, atol=2e-5, msg=f"actor trunk {i} b")
+    for k, t in zip(("fc_mu.weight", "fc_mu.bias", "fc_std.weight", "fc_std.bias"), orc.head):
+        assert_adam_trajectory_close(sd[f"actor.{k}"], t.detach(), 1e-3, SAC_STEPS, rtol=1e-3, atol=2e-5,
+                                     msg=f"actor {k}")
+    for ci in (1, 2):
+        assert len(orc.c[ci - 1]) == n_hidden + 1
+        for li, (w, b) in enumerate(orc.c[ci - 1]):
+            pre = f"critic._critic_{ci}._model.{li}.0."
+            assert_adam_trajectory_close(sd[pre + "weight"], w.detach(), 1e-3, SAC_STEPS, rtol=1e-3,
+                                         atol=2e-5, msg=pre + "weight")
+            assert_adam_trajectory_close(sd[pre + "bias"], b.detach(), 1e-3, SAC_STEPS, rtol=1e-3,
+                                         atol=2e-5, msg=pre + "bias")
+            tpre = pre.replace("critic.", "critic_target.", 1)
+            tw, tb = orc.ct[ci - 1][li]
+            # the target moved tau = 0.005 of the way to the online network per step
+            torch.testing.assert_close(sd[tpre + "weight"], tw, rtol=1e-4, atol=1e-6, msg=tpre + "weight")
+            torch.testing.assert_close(sd[tpre + "bias"], tb, rtol=1e-4, atol=1e-6, msg=tpre + "bias")
