@@ -447,7 +447,11 @@ class NeuralLinearOracle:
 
     def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0,
                  loss_type: str = "mse", output_activation: str = "linear",
-                 hidden_activation: str = "relu") -> None:
+                 hidden_activation: str = "relu", nn_e2e: bool = True) -> None:
+        # nn_e2e=False (neural_linear_regression.py:100-105, :140-147): mu from the LinUCB regression's
+        # coefficients (buffers: the loss reaches the trunk through them, linear_layer_e2e gets no
+        # gradient and AdamW skips it)
+        self.nn_e2e = nn_e2e
         self.trunk = _layers(model_sd, "_nn_layers._model.")
         # mlp_block's other forms (common/utils.py:75-152): nn.LayerNorm between a hidden Linear and
         # its activation when the state dict has `{i}.1.weight`; the hidden activation by name
@@ -485,7 +489,11 @@ class NeuralLinearOracle:
 
     def learn_batch(self, x: Tensor, y: Tensor, w) -> Dict[str, Tensor]:
         f = self.features(x)
-        pred = self.out_act(torch.nn.functional.linear(f, self.e2e))
+        if self.nn_e2e:
+            pred = self.out_act(torch.nn.functional.linear(f, self.e2e))
+        else:   # LinearRegression.forward (linear_regression.py:221-250): [1 | f] coefs
+            pred = self.out_act(torch.matmul(torch.cat((torch.ones(x.shape[0], 1), f), dim=-1),
+                                             self.coefs.detach()).unsqueeze(-1))
         weight = torch.ones_like(y) if w is None else w
         loss = self.criterion(pred.view(y.shape), y, reduction="none")
         loss = (loss * weight).sum() / weight.sum()

@@ -461,6 +461,12 @@ BANDIT_CONFIGS = {
     "tanh_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(hidden_activation="tanh")),
     # force_pinv (linear_regression.py:138-157): torch.linalg.pinv of A + lambda I instead of inv
     "pinv_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(force_pinv=True)),
+    # nn_e2e=False (neural_linear_regression.py:100-105): mu from the regression's coefficients; the
+    # trunk learns through them, linear_layer_e2e never moves
+    "lin_head_tiny": dict(F=7, hidden=[12, 6], B=16, steps=5, mlp=dict(nn_e2e=False)),
+    "lin_head_small": dict(F=40, hidden=[64, 16], B=128, steps=4, mlp=dict(nn_e2e=False)),
+    "lin_head_sigmoid_tiny": dict(F=7, hidden=[12, 6], B=16, steps=5, out="sigmoid",
+                                  mlp=dict(nn_e2e=False)),
 }
 
 
@@ -594,7 +600,8 @@ def main():
         make_sac("cfg3_fullbatch", SAC_CONFIGS["cfg3_fullbatch"])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round5":
-        for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny", "pinv_tiny"):
+        for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny", "pinv_tiny",
+                     "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny"):
             make_bandit(name, BANDIT_CONFIGS[name])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round4":

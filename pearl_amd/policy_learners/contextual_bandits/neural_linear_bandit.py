@@ -174,13 +174,29 @@ class NeuralLinearBandit(PolicyLearner):
         self._history_summarization_module = value
 
     def _net(self, batch_hint: int = 0) -> FlatMlp:
+        if "head" in self._flat and "net" in self._flat and \
+                self._flat["head"][0].device != self.model.linear_layer_e2e.weight.device:
+            self._flat.pop("net").close()          # the model moved: the head tensors follow it
         if "net" not in self._flat:
             # the trunk in any of mlp_block's forms the engine computes (use_layer_norm /
             # hidden_activation of neural_linear_bandit.py:84-85, :110-111; generic_q.mlp_spec)
             from ..sequential_decision_making.generic_q import plain_or_spec
             spec = plain_or_spec(self.model._nn_layers._model, "NeuralLinearBandit's _nn_layers")
             layers = layers_of(spec["linears"])
-            layers.append(([self.model.linear_layer_e2e.weight], []))     # bias-free last layer
+            frozen = not self.model.nn_e2e
+            if frozen:
+                # nn_e2e=False (neural_linear_regression.py:100-105): mu = [1 | features] coefs, the
+                # LinUCB regression's coefficients — buffers, not parameters: the loss reaches the trunk
+                # THROUGH them, they get no gradient step, and `linear_layer_e2e` is left alone (its
+                # .grad stays None in the reference, which AdamW skips).  To the engine that is a last
+                # layer with weight coefs[1:] and bias coefs[0] that the optimizer does not own
+                # (FlatMlp.frozen_last); `_load_head` rewrites it from the current coefs before a step.
+                d = self.model._linear_regression_layer._feature_dim
+                dev0 = spec["linears"][0].weight.device
+                self._flat["head"] = (torch.zeros(1, d, device=dev0), torch.zeros(1, device=dev0))
+                layers.append(([self._flat["head"][0]], [self._flat["head"][1]]))
+            else:
+                layers.append(([self.model.linear_layer_e2e.weight], []))     # bias-free last layer
             # the trunk's own output layer (index len-2) has no activation (last_activation=None) and
             # no LayerNorm; hidden_activation="linear" leaves every hidden layer without one
             n_hidden = len(layers) - 1
@@ -188,8 +204,24 @@ class NeuralLinearBandit(PolicyLearner):
             norms = (list(spec["norms"]) + [None]) if spec["norms"] else None
             self._flat["net"] = FlatMlp(layers, self._optimizer, max(self._batch_size, 1),
                                         identity_layers=ident, norms=norms,
-                                        hidden_act=spec["hidden_act"])
-        return self._flat["net"].ensure(batch_hint)
+                                        hidden_act=spec["hidden_act"], frozen_last=frozen)
+        if self.model.nn_e2e:
+            return self._flat["net"].ensure(batch_hint)
+        self._load_head()
+        net = self._flat["net"].ensure(batch_hint)
+        net.invalidate()      # (inside a learn() loop `ensure` does not look at version counters)
+        return net
+
+    def _load_head(self) -> None:
+        """nn_e2e=False: the engine's last layer <- the regression's current coefficients (reading
+        them joins the solve of the previous step: this mode's forward depends on it, as the
+        reference's does).  In-place torch copies: `ensure` sees the version change and has the
+        engine rebuild its derived copies of the weights."""
+        w, b = self._flat["head"]
+        coefs = self.model._linear_regression_layer._coefs
+        with torch.no_grad():
+            w.copy_(coefs[1:].to(w.device).view(1, -1))
+            b.copy_(coefs[:1].to(b.device))
 
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         net = self._net(len(batch))
@@ -213,7 +245,8 @@ class NeuralLinearBandit(PolicyLearner):
             if buf.device != dev or not buf.is_contiguous():
                 lr.join_solve()
                 setattr(lr, name, buf.to(dev).contiguous())
-        fused = w is None and self._rowstep_ok(net)
+        # (nn_e2e=False steps through the general sequence: forward, loss head, backward, AdamW)
+        fused = w is None and self.model.nn_e2e and self._rowstep_ok(net)
         if fused and not (dist.is_available() and dist.is_initialized()) \
                 and os.environ.get("PEARL_AMD_BANDIT_ONE_CALL", "1") != "0":
             return self._learn_batch_one_call(net, x, y, lr, kind, oact)

@@ -47,8 +47,14 @@ class FlatMlp:
     def __init__(self, layers: List[Layer], optimizer: Optional[optim.Optimizer], max_batch: int,
                  target_layers: Optional[List[Layer]] = None, identity_layers: int = 0,
                  norms: Optional[Sequence[nn.LayerNorm]] = None,
-                 target_norms: Optional[Sequence[nn.LayerNorm]] = None, hidden_act: int = 0) -> None:
+                 target_norms: Optional[Sequence[nn.LayerNorm]] = None, hidden_act: int = 0,
+                 frozen_last: bool = False) -> None:
         self.layers = layers
+        # the last layer's tensors are NOT parameters of the caller's optimizer (the bandit's
+        # nn_e2e=False head: the regression's coefficients, rewritten by the caller before every
+        # step): they live in the flat buffers like any layer, but get no optimizer state entry and
+        # no .grad, and whatever the engine's AdamW does to their slots is the caller's to overwrite
+        self.frozen_last = bool(frozen_last)
         self.identity_layers = int(identity_layers)   # bit l: hidden layer l has no ReLU
         self.target_layers = target_layers
         # mlp_block's other forms (pa_mlp_desc.hidden_act / layer_norm): the hidden layers' nn.LayerNorm
@@ -92,6 +98,14 @@ class FlatMlp:
             ps += [p for ln in self.norms if ln is not None for p in (ln.weight, ln.bias)]
         return ps
 
+    def _frozen(self) -> List[torch.Tensor]:
+        return [p for p in (*self.layers[-1][0], *self.layers[-1][1])] if self.frozen_last else []
+
+    def _optimized(self) -> List[nn.Parameter]:
+        """The tensors the caller's optimizer owns (everything but a frozen last layer)."""
+        fz = self._frozen()
+        return [p for p in self._params() if not any(p is q for q in fz)]
+
     def _target_params(self) -> List[nn.Parameter]:
         if self.target_layers is None:
             return []
@@ -117,7 +131,7 @@ class FlatMlp:
     def adam_steps(self) -> int:
         if self.optimizer is None:
             return 0
-        for p in self._params():
+        for p in self._optimized():
             st = self.optimizer.state.get(p)
             if st and "step" in st:
                 return int(float(st["step"]))
@@ -139,7 +153,7 @@ class FlatMlp:
         if bank is not None and self._steps_are_banked(bank):
             bank.fill_(float(n))      # every parameter's 0-d "step" tensor is a view of it
             return
-        for p in self._params():
+        for p in self._optimized():
             st = self.optimizer.state.get(p)
             if st is not None and "step" in st:
                 st["step"].fill_(float(n))
@@ -149,7 +163,7 @@ class FlatMlp:
         handed out (optimizer.load_state_dict replaces them while the moment tensors may stay aliased:
         _signature() does not see that) — otherwise they are filled one by one."""
         lo, hi = bank.data_ptr(), bank.data_ptr() + bank.numel() * bank.element_size()
-        for p in self._params():
+        for p in self._optimized():
             st = self.optimizer.state.get(p)
             if st is None or "step" not in st or not (lo <= st["step"].data_ptr() < hi):
                 return False
@@ -169,8 +183,10 @@ class FlatMlp:
 
     def _signature(self) -> Tuple:
         sig = []
+        frozen = self._frozen()
         for p in self._params():
-            st = self.optimizer.state.get(p, {}) if self.optimizer is not None else {}
+            st = self.optimizer.state.get(p, {}) if (self.optimizer is not None and not any(
+                p is q for q in frozen)) else {}
             sig.append((p.data_ptr(), tuple(st[k].data_ptr() if k in st else 0
                                             for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"))))
         sig.extend(p.data_ptr() for p in self._target_params())
@@ -254,6 +270,7 @@ class FlatMlp:
                 tn = self.target_norms[li] if self.target_norms else None
                 groups.append(([ln.weight], int(noffs[2 * li]), [tn.weight] if tn is not None else None))
                 groups.append(([ln.bias], int(noffs[2 * li + 1]), [tn.bias] if tn is not None else None))
+        frozen = self._frozen()
         with torch.no_grad():
             for plist, o, tl in groups:
                 if True:
@@ -261,6 +278,11 @@ class FlatMlp:
                         n = p.numel()
                         sl = slice(o, o + n)
                         flat["p"][sl].copy_(p.data.reshape(-1).to(dev, torch.float32))
+                        if any(p is q for q in frozen):
+                            p.data = flat["p"][sl].view(p.shape)
+                            o += n
+                            bank_i += 1
+                            continue
                         st = (self.optimizer.state.get(p) or {}) if self.optimizer is not None else {}
                         for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
                             if k in st and k in flat:

@@ -643,3 +643,23 @@ def test_force_pinv_is_honoured_on_the_regularised_matrix():
     assert NeuralLinearBandit(feature_dim=5, hidden_dims=[8, 4], force_pinv=True).model._linear_regression_layer.force_pinv
     with pytest.raises(NotImplementedError, match="SVD"):
         LinearRegression(feature_dim=4, l2_reg_lambda=0.0, force_pinv=True)
+
+
+def test_neural_linear_regression_without_e2e_head_predicts_from_the_regression():
+    """NeuralLinearRegression(nn_e2e=False) (neural_linear_regression.py:100-105, :140-147): mu is the
+    LinUCB regression's [1 | features] coefs, not linear_layer_e2e's output — the act-time torch
+    expression of the mode whose learner step the HIP engine runs with a frozen last layer."""
+    from pearl_amd.neural_networks.contextual_bandit.linear_regression import NeuralLinearRegression
+    torch.manual_seed(3)
+    model = NeuralLinearRegression(feature_dim=7, hidden_dims=[12, 6], nn_e2e=False,
+                                   output_activation_name="sigmoid")
+    model._linear_regression_layer._coefs.copy_(torch.randn(7))
+    x = torch.randn(5, 7)
+    out = model.forward_with_intermediate_values(x)
+    feats = out["nn_output"]
+    want = torch.cat((torch.ones(5, 1), feats), dim=1) @ model._linear_regression_layer._coefs
+    torch.testing.assert_close(out["pred_label_pre_activation"].view(-1), want)
+    torch.testing.assert_close(out["pred_label"].view(-1), torch.sigmoid(want))
+    e2e = NeuralLinearRegression(feature_dim=7, hidden_dims=[12, 6])
+    out2 = e2e.forward_with_intermediate_values(x)
+    torch.testing.assert_close(out2["pred_label_pre_activation"], e2e.linear_layer_e2e(out2["nn_output"]))

@@ -394,7 +394,10 @@ BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", 
           # leaky_relu, tanh — the generic engine's layer-by-layer path (mlp_norm_act.hpp)
           "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny",
           # force_pinv=True (linear_regression.py:138-157) on the regularised matrix
-          "pinv_tiny"]
+          "pinv_tiny",
+          # nn_e2e=False (neural_linear_regression.py:100-105): the engine's last layer is the
+          # regression's coefficients, reloaded before every step and owned by no optimizer
+          "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny"]
 
 
 @pytest.mark.parametrize("name", BANDIT)

@@ -109,7 +109,9 @@ BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", 
           # mlp_block's other forms in the trunk (round 5): LayerNorm, leaky_relu, tanh
           "layernorm_tiny", "leaky_layernorm_small", "tanh_tiny",
           # force_pinv=True (the pseudo-inverse of the regularised, SPD matrix is its inverse)
-          "pinv_tiny"]
+          "pinv_tiny",
+          # nn_e2e=False: mu from the regression's coefficients, the trunk learns through them
+          "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny"]
 
 
 def bandit_batches(fx):
@@ -132,7 +134,8 @@ def test_neural_linear_bandit_trajectory(name):
     cfg = fx["config"]
     orc = NeuralLinearOracle(fx["model0"], lr=1e-3, loss_type=cfg.get("loss", "mse"),
                              output_activation=cfg.get("out", "linear"),
-                             hidden_activation=cfg.get("mlp", {}).get("hidden_activation", "relu"))
+                             hidden_activation=cfg.get("mlp", {}).get("hidden_activation", "relu"),
+                             nn_e2e=cfg.get("mlp", {}).get("nn_e2e", True))
     for (x, r, w), want in zip(bandit_batches(fx), fx["reports"]):
         got = orc.learn_batch(x, r, w)
         assert abs(float(got["loss"]) - want["loss"]) <= 1e-5 * max(1.0, abs(want["loss"]))
