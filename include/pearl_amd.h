@@ -965,6 +965,13 @@ int pa_linreg_apply2(const float* delta, int32_t d, float* A, float* b, float* s
                      float* A_snap, float* b_snap, void* stream);
 int pa_linreg_solve(const float* A, const float* b, float l2_reg_lambda, int32_t d, double* work,
                     float* inv_A_out, float* coefs_out, int32_t* singular_out, void* stream);
+/* force_pinv (linear_regression.py:138-157): inv_A = torch.linalg.pinv(A + lambda I, hermitian=True) —
+ * eigenvalues by a one-sided Jacobi iteration in fp64, those at or below (d + 1) * eps(float32) of the
+ * largest dropped (torch's default rtol) — and coefs = inv_A b; *rank_out = the number kept.  For the
+ * unregularised, possibly singular regression; with lambda > 0 pa_linreg_solve computes the same
+ * matrix faster.  d + 1 <= 72. */
+int pa_linreg_pinv(const float* A, const float* b, float l2_reg_lambda, int32_t d, float* inv_A_out,
+                   float* coefs_out, int32_t* rank_out, void* stream);
 /* One NeuralLinearBandit.learn_batch on unit weights in a single process, as ONE call
  * (pearl/policy_learners/contextual_bandits/neural_linear_bandit.py:139-214): pa_wloss_rowstep, the
  * LinUCB operands from the kept features (pa_linreg_delta2's), ONE weight-gradient launch forming

@@ -447,7 +447,9 @@ class NeuralLinearOracle:
 
     def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0,
                  loss_type: str = "mse", output_activation: str = "linear",
-                 hidden_activation: str = "relu", nn_e2e: bool = True) -> None:
+                 hidden_activation: str = "relu", nn_e2e: bool = True, force_pinv: bool = False) -> None:
+        # force_pinv (linear_regression.py:138-157): torch.linalg.pinv(hermitian=True) instead of inv
+        self.force_pinv = force_pinv
         # nn_e2e=False (neural_linear_regression.py:100-105, :140-147): mu from the LinUCB regression's
         # coefficients (buffers: the loss reaches the trunk through them, linear_layer_e2e gets no
         # gradient and AdamW skips it)
@@ -506,7 +508,8 @@ class NeuralLinearOracle:
         self.A += (dA + dA.t()) / 2
         self.b += torch.matmul(X.t(), yc * wc).squeeze(-1)
         self.sum_weight += weight.sum()
-        self.inv_A = torch.linalg.inv(self.A + self.lam * torch.eye(self.A.shape[0]))
+        M = self.A + self.lam * torch.eye(self.A.shape[0])
+        self.inv_A = torch.linalg.pinv(M, hermitian=True) if self.force_pinv else torch.linalg.inv(M)
         self.coefs = torch.matmul(self.inv_A, self.b)
         return {"loss": loss.detach(), "prediction": pred.detach()}
 

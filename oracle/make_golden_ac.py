@@ -467,6 +467,12 @@ BANDIT_CONFIGS = {
     "lin_head_small": dict(F=40, hidden=[64, 16], B=128, steps=4, mlp=dict(nn_e2e=False)),
     "lin_head_sigmoid_tiny": dict(F=7, hidden=[12, 6], B=16, steps=5, out="sigmoid",
                                   mlp=dict(nn_e2e=False)),
+    # force_pinv on the UNREGULARISED regression with fewer contexts than coefficients (16 < 21,
+    # 48 < 65): A = sum x x^T is singular whatever the data — the case the pseudo-inverse exists for
+    "pinv_singular_tiny": dict(F=7, hidden=[12, 20], B=8, steps=2,
+                               mlp=dict(force_pinv=True, l2_reg_lambda_linear=0.0)),
+    "pinv_singular_small": dict(F=40, hidden=[48, 64], B=16, steps=3,
+                                mlp=dict(force_pinv=True, l2_reg_lambda_linear=0.0)),
 }
 
 
@@ -601,7 +607,8 @@ def main():
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round5":
         for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny", "pinv_tiny",
-                     "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny"):
+                     "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny",
+                     "pinv_singular_tiny", "pinv_singular_small"):
             make_bandit(name, BANDIT_CONFIGS[name])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round4":

@@ -551,6 +551,7 @@ SIGNATURES = {
     "pa_linreg_delta": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_apply": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_solve": (C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P, _P]),
+    "pa_linreg_pinv": (C.c_int, [_P, _P, C.c_float, C.c_int32, _P, _P, _P, _P]),
     "pa_linreg_sigma": (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     "pa_concat_cols": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "pa_debug_set_prof": (C.c_int, [_P, _P, _P, C.c_int32]),

@@ -2911,6 +2911,156 @@ void linreg_solve_spd_inplace_kernel(SolveArgs a, int* need_pivot) {
   }
 }
 
+// force_pinv with l2_reg_lambda = 0 (linear_regression.py:138-157): torch.linalg.pinv(A, hermitian=True)
+// of a possibly singular A — eigh, then 1 / lambda_j for the eigenvalues above rtol * max |lambda|
+// (rtol = D * eps of float32, torch's default), zero for the rest.  Here: a one-sided (Hestenes) Jacobi
+// iteration in fp64 on the columns of G = M V (V orthogonal, starts as I): a rotation of columns p, q
+// of G and V that makes G's two columns orthogonal; when all pairs are, M V = V Lambda, i.e.
+// lambda_j = v_j . g_j.  Pairs of one round-robin round are disjoint, so 36 groups of 16 lanes rotate
+// 36 pairs between two barriers; 71 rounds are a sweep, 6 - 10 sweeps converge to fp64 rounding.
+// The matrix is padded to order 72 with zeros (their eigenvalue 0 is dropped like every other null
+// direction).  One workgroup, ~1 ms: this is the rarely used corner of the bandit (an unregularised,
+// rank-deficient regression), built for completeness, not for speed.
+constexpr int PINV_N = 72, PINV_LD = 73, PINV_GROUPS = PINV_N / 2, PINV_THREADS = PINV_GROUPS * 16;
+struct PinvArgs {
+  const float* A; const float* bvec; float lambda; int D; float rtol;
+  float* invA; float* coefs; int* rank; int max_sweeps;
+};
+__device__ __forceinline__ double group16_sum(double v) {
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) v += __shfl_xor(v, o);     // (xor butterfly: every lane ends with the same bits)
+  return v;
+}
+__global__ __launch_bounds__(PINV_THREADS) void linreg_pinv_kernel(PinvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double lds_work[];
+  constexpr int N = PINV_N, LD = PINV_LD;
+  double* G = lds_work;               // column j of M V at G + j * LD
+  double* V = G + N * LD;             // column j of V
+  double* lam = V + N * LD;           // [N] eigenvalues, then their pseudo-inverse weights
+  double* proj = lam + N;             // [N] w_j (v_j . b)
+  __shared__ int rotated;
+  __shared__ double cut, scale2;
+  const int D = a.D, t = threadIdx.x, grp = t >> 4, l16 = t & 15;
+  // M = A + lambda I from the LOWER triangle (what eigh reads), zero padding; V = I
+  for (int e = t; e < N * N; e += PINV_THREADS) {
+    const int j = e / N, i = e - j * N;
+    double m = 0.0;
+    if (i < D && j < D) {
+      const int hi = i > j ? i : j, lo = i > j ? j : i;
+      m = (double)a.A[hi * D + lo] + (i == j ? (double)a.lambda : 0.0);
+    }
+    G[j * LD + i] = m;
+    V[j * LD + i] = (i == j) ? 1.0 : 0.0;
+  }
+  if (t == 0) scale2 = 0.0;
+  __syncthreads();
+  // the largest squared column norm: columns below 1e-14 of it (norm) are numerically null and are
+  // left alone (rotating one against a real column would move that column by 1e-14 of an angle)
+  if (t < N) {
+    double n2 = 0.0;
+    for (int i = 0; i < N; ++i) n2 = __builtin_fma(G[t * LD + i], G[t * LD + i], n2);
+    lam[t] = n2;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double m = 0.0;
+    for (int j = 0; j < N; ++j) m = lam[j] > m ? lam[j] : m;
+    scale2 = m;
+  }
+  __syncthreads();
+  const double null2 = 1e-28 * scale2;
+  for (int sweep = 0; sweep < a.max_sweeps; ++sweep) {
+    if (t == 0) rotated = 0;
+    __syncthreads();
+    for (int step = 0; step < N - 1; ++step) {
+      // round-robin round `step`: player N - 1 stays, the others sit on a circle of N - 1 seats
+      int pa_, pb_;
+      if (grp == 0) {
+        pa_ = N - 1;
+        pb_ = step;
+      } else {
+        pa_ = (step + grp) % (N - 1);
+        pb_ = (step - grp + (N - 1)) % (N - 1);
+      }
+      const int p = pa_ < pb_ ? pa_ : pb_, q = pa_ < pb_ ? pb_ : pa_;
+      double* gp = G + p * LD;
+      double* gq = G + q * LD;
+      double al = 0.0, be = 0.0, ga = 0.0;
+      for (int i = l16; i < N; i += 16) {
+        const double x = gp[i], y = gq[i];
+        al = __builtin_fma(x, x, al);
+        be = __builtin_fma(y, y, be);
+        ga = __builtin_fma(x, y, ga);
+      }
+      al = group16_sum(al);
+      be = group16_sum(be);
+      ga = group16_sum(ga);
+      if (al > null2 && be > null2 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+        const double zeta = (be - al) / (2.0 * ga);
+        const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + tt * tt), sn = c * tt;
+        double* vp = V + p * LD;
+        double* vq = V + q * LD;
+        for (int i = l16; i < N; i += 16) {
+          const double x = gp[i], y = gq[i];
+          gp[i] = c * x - sn * y;
+          gq[i] = sn * x + c * y;
+          const double u = vp[i], w = vq[i];
+          vp[i] = c * u - sn * w;
+          vq[i] = sn * u + c * w;
+        }
+        if (l16 == 0) rotated = 1;
+      }
+      __syncthreads();
+    }
+    const int again = rotated;
+    __syncthreads();
+    if (!again) break;
+  }
+  // lambda_j = v_j . g_j ; proj_j = v_j . b
+  for (int j = grp; j < N; j += PINV_GROUPS) {
+    double l = 0.0, pb = 0.0;
+    for (int i = l16; i < N; i += 16) {
+      const double v = V[j * LD + i];
+      l = __builtin_fma(v, G[j * LD + i], l);
+      if (i < D) pb = __builtin_fma(v, (double)a.bvec[i], pb);
+    }
+    l = group16_sum(l);
+    pb = group16_sum(pb);
+    if (l16 == 0) {
+      lam[j] = l;
+      proj[j] = pb;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    double m = 0.0;
+    for (int j = 0; j < N; ++j) m = fabs(lam[j]) > m ? fabs(lam[j]) : m;
+    cut = (double)a.rtol * m;
+    int r = 0;
+    for (int j = 0; j < N; ++j) r += fabs(lam[j]) > cut ? 1 : 0;
+    a.rank[0] = r;
+  }
+  __syncthreads();
+  if (t < N) {
+    const double w = fabs(lam[t]) > cut ? 1.0 / lam[t] : 0.0;
+    lam[t] = w;
+    proj[t] *= w;
+  }
+  __syncthreads();
+  for (int e = t; e < D * D; e += PINV_THREADS) {
+    const int r = e / D, c = e - r * D;
+    double sum = 0.0;
+    for (int j = 0; j < N; ++j) sum = __builtin_fma(lam[j] * V[j * LD + r], V[j * LD + c], sum);
+    a.invA[e] = (float)sum;
+  }
+  for (int r = t; r < D; r += PINV_THREADS) {
+    double sum = 0.0;
+    for (int j = 0; j < N; ++j) sum = __builtin_fma(proj[j], V[j * LD + r], sum);
+    a.coefs[r] = (float)sum;
+  }
+}
+
 // sigma[b] = sqrt([1 | f_b] inv_A [1 | f_b]^T)      (linear_regression.py:261-270)
 __global__ __launch_bounds__(256) void linreg_sigma_kernel(const float* __restrict__ f, int ldf,
                                                            const float* __restrict__ invA, int B,
@@ -3211,6 +3361,29 @@ extern "C" int pa_linreg_solve(const float* A, const float* b, float l2_reg_lamb
   } else {
     hipLaunchKernelGGL(linreg_solve_kernel, dim3(1), dim3(1024), 0, s, a);
   }
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_linreg_pinv(const float* A, const float* b, float l2_reg_lambda, int32_t d,
+                              float* inv_A_out, float* coefs_out, int32_t* rank_out, void* stream) {
+  PA_REQUIRE(A && b && inv_A_out && coefs_out && rank_out && d > 0, PA_ERR_INVALID,
+             "pa_linreg_pinv: bad argument");
+  PA_REQUIRE(d + 1 <= PINV_N, PA_ERR_UNSUPPORTED,
+             "pa_linreg_pinv: the Jacobi kernel holds systems up to order 72 (got %d)", d + 1);
+  PinvArgs a;
+  a.A = A; a.bvec = b; a.lambda = l2_reg_lambda; a.D = d + 1;
+  a.rtol = (float)(d + 1) * 1.1920929e-07f;      // torch.linalg.pinv's default: max(m, n) * eps(float32)
+  a.invA = inv_A_out; a.coefs = coefs_out; a.rank = rank_out; a.max_sweeps = 40;
+  const size_t lds = sizeof(double) * (2 * (size_t)PINV_N * PINV_LD + 2 * PINV_N);
+  static bool configured = false;
+  if (!configured) {
+    int rc = set_max_smem(linreg_pinv_kernel, lds);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  hipLaunchKernelGGL(linreg_pinv_kernel, dim3(1), dim3(PINV_THREADS), lds,
+                     reinterpret_cast<hipStream_t>(stream), a);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

@@ -25,16 +25,15 @@ class LinearRegression(nn.Module):
                  force_pinv: bool = False) -> None:
         super().__init__()
         assert 0 < gamma <= 1, f"gamma should be in (0, 1]. Got gamma={gamma} instead"
-        if force_pinv and not l2_reg_lambda > 0:
-            # linear_regression.py:138-157: force_pinv inverts A + lambda I with torch.linalg.pinv.  With
-            # lambda > 0 that matrix is symmetric positive definite (A is a sum of w x x^T terms), its
-            # pseudo-inverse IS its inverse, and the fp64 SPD solve of the HIP path computes exactly
-            # that — force_pinv=True is then honoured as is.  Only the unregularised, possibly singular
-            # case needs an SVD, which is not built.
+        # force_pinv (linear_regression.py:138-157): torch.linalg.pinv of A + lambda I instead of inv.  With
+        # lambda > 0 that matrix is symmetric positive definite (A is a sum of w x x^T terms), its
+        # pseudo-inverse IS its inverse, and the fp64 SPD solve computes exactly that; with lambda = 0
+        # (a possibly singular A) the learner runs pa_linreg_pinv — eigenvalues by Jacobi rotations,
+        # torch's default cut-off — for systems up to order 72.
+        if force_pinv and not l2_reg_lambda > 0 and feature_dim + 1 > 72:
             raise NotImplementedError(
-                "pearl_amd LinearRegression: force_pinv with l2_reg_lambda = 0 (a possibly singular A) "
-                "needs an SVD-based pseudo-inverse, which is not built; with l2_reg_lambda > 0 the "
-                "pseudo-inverse equals the inverse the HIP solve computes")
+                "pearl_amd LinearRegression: force_pinv with l2_reg_lambda = 0 is built for feature_dim "
+                f"<= 71 (pa_linreg_pinv holds the system in one workgroup's LDS; got {feature_dim})")
         self._feature_dim = feature_dim
         self.gamma, self.l2_reg_lambda, self.force_pinv = gamma, l2_reg_lambda, force_pinv
         self.register_buffer("_A", torch.zeros(feature_dim + 1, feature_dim + 1))
@@ -96,6 +95,11 @@ class LinearRegression(nn.Module):
         if name in ("_inv_A", "_coefs"):
             self.join_solve()
         return super().__getattr__(name)
+
+    @property
+    def uses_pinv(self) -> bool:
+        """The pseudo-inverse kernel instead of the SPD solve (force_pinv on an unregularised system)."""
+        return bool(self.force_pinv) and not self.l2_reg_lambda > 0
 
     @property
     def A(self) -> Tensor:

@@ -247,7 +247,7 @@ class NeuralLinearBandit(PolicyLearner):
                 setattr(lr, name, buf.to(dev).contiguous())
         # (nn_e2e=False steps through the general sequence: forward, loss head, backward, AdamW)
         fused = w is None and self.model.nn_e2e and self._rowstep_ok(net)
-        if fused and not (dist.is_available() and dist.is_initialized()) \
+        if fused and not lr.uses_pinv and not (dist.is_available() and dist.is_initialized()) \
                 and os.environ.get("PEARL_AMD_BANDIT_ONE_CALL", "1") != "0":
             return self._learn_batch_one_call(net, x, y, lr, kind, oact)
         dpred = torch.empty(B, dtype=torch.float32, device=dev)
@@ -440,9 +440,15 @@ class NeuralLinearBandit(PolicyLearner):
         PEARL_AMD_BANDIT_ASYNC_SOLVE=0: in-stream as before."""
         d = lr._feature_dim
         st = self._solve_state_for(lr, dev)
+        pinv = lr.uses_pinv     # force_pinv on an unregularised system: pa_linreg_pinv (same slots / streams)
         if os.environ.get("PEARL_AMD_BANDIT_ASYNC_SOLVE", "1") == "0":
             lr.join_solve()
             inv_A, coefs = lr._buffers["_inv_A"], lr._buffers["_coefs"]
+            if pinv:
+                N.check(N.lib().pa_linreg_pinv(lr._A.data_ptr(), lr._b.data_ptr(), float(lr.l2_reg_lambda),
+                                               d, inv_A.data_ptr(), coefs.data_ptr(),
+                                               st["flag"].data_ptr(), N.stream_ptr(dev)))
+                return
             N.check(N.lib().pa_linreg_solve(lr._A.data_ptr(), lr._b.data_ptr(), float(lr.l2_reg_lambda),
                                             d, st["work"][0].data_ptr(), inv_A.data_ptr(),
                                             coefs.data_ptr(), st["flag"].data_ptr(), N.stream_ptr(dev)))
@@ -460,9 +466,14 @@ class NeuralLinearBandit(PolicyLearner):
         side = st["side"][i]
         side.wait_event(ready)
         inv_i, coefs_i = st["out"][i]
-        N.check(N.lib().pa_linreg_solve(A_s.data_ptr(), b_s.data_ptr(), float(lr.l2_reg_lambda), d,
-                                        st["work"][i].data_ptr(), inv_i.data_ptr(), coefs_i.data_ptr(),
-                                        st["flag"][i:].data_ptr(), side.cuda_stream))
+        if pinv:
+            N.check(N.lib().pa_linreg_pinv(A_s.data_ptr(), b_s.data_ptr(), float(lr.l2_reg_lambda), d,
+                                           inv_i.data_ptr(), coefs_i.data_ptr(),
+                                           st["flag"][i:].data_ptr(), side.cuda_stream))
+        else:
+            N.check(N.lib().pa_linreg_solve(A_s.data_ptr(), b_s.data_ptr(), float(lr.l2_reg_lambda), d,
+                                            st["work"][i].data_ptr(), inv_i.data_ptr(), coefs_i.data_ptr(),
+                                            st["flag"][i:].data_ptr(), side.cuda_stream))
         done.record(side)
         st["busy"][i] = done
         lr.__dict__["_solve_done"] = (done, inv_i, coefs_i)

@@ -1116,6 +1116,112 @@ def test_linreg_solve_spd_fast_path_and_pivoting_fallback(d, monkeypatch):
             assert got[split][2] == 0
 
 
+def _pinv(A, b, lam, d):
+    from pearl_amd import _native as N
+    D = d + 1
+    Ad, bd = A.to(DEV).contiguous(), b.to(DEV).contiguous()
+    inv = torch.zeros(D, D, device=DEV)
+    coefs = torch.zeros(D, device=DEV)
+    rank = torch.full((1,), -1, dtype=torch.int32, device=DEV)
+    N.check(N.lib().pa_linreg_pinv(Ad.data_ptr(), bd.data_ptr(), lam, d, inv.data_ptr(), coefs.data_ptr(),
+                                   rank.data_ptr(), N.stream_ptr(Ad.device)))
+    return inv.cpu(), coefs.cpu(), int(rank.item())
+
+
+def _torch_pinv64(A, lam):
+    """torch.linalg.pinv as LinearRegression.pinv calls it (linear_regression.py:138-150: hermitian,
+    default rtol = max(m, n) * eps of the INPUT dtype, float32), evaluated in float64."""
+    D = A.shape[0]
+    M = torch.tril(A.double()) + torch.tril(A.double(), -1).t() + lam * torch.eye(D, dtype=torch.float64)
+    return torch.linalg.pinv(M, hermitian=True, rtol=D * 1.1920929e-07)
+
+
+@pytest.mark.parametrize("D,rank", [(65, 40), (65, 65), (21, 13), (72, 30), (10, 1), (2, 1), (2, 2)])
+def test_linreg_pinv_kernel_is_torchs_pseudo_inverse(D, rank):
+    """pa_linreg_pinv (fp64 one-sided Jacobi in one workgroup) against torch.linalg.pinv(hermitian=True)
+    with torch's default cut-off, on symmetric positive semi-definite matrices of a prescribed rank whose
+    non-zero eigenvalues sit well above the cut-off (what the kernel must get right; eigenvalues AT the
+    cut-off are a coin toss in any arithmetic): the pseudo-inverse, coefs = pinv b, and the rank; with a
+    ridge the pseudo-inverse is the inverse pa_linreg_solve computes."""
+    d = D - 1
+    g = torch.Generator().manual_seed(100 * D + rank)
+    q, _ = torch.linalg.qr(torch.randn(D, D, dtype=torch.float64, generator=g))
+    ev = torch.zeros(D, dtype=torch.float64)
+    ev[:rank] = torch.linspace(0.5, 50.0, rank, dtype=torch.float64)
+    A = (q @ torch.diag(ev) @ q.t())
+    A = ((A + A.t()) / 2).float()
+    b = (A.double() @ torch.randn(D, dtype=torch.float64, generator=g)).float()      # in the range of A
+    inv, coefs, got_rank = _pinv(A, b, 0.0, d)
+    want = _torch_pinv64(A, 0.0)
+    assert got_rank == rank
+    torch.testing.assert_close(inv.double(), want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+    wc = want @ b.double()
+    torch.testing.assert_close(coefs.double(), wc, rtol=1e-5, atol=1e-6 * float(wc.abs().max()))
+    # Moore-Penrose: A P A = A, P A P = P, (A P) symmetric — on the kernel's own output
+    P, Ad = inv.double(), A.double()
+    torch.testing.assert_close(Ad @ P @ Ad, Ad, rtol=0, atol=2e-5 * float(Ad.abs().max()))
+    torch.testing.assert_close(P @ Ad @ P, P, rtol=0, atol=2e-5 * float(P.abs().max()))
+    torch.testing.assert_close(Ad @ P, (Ad @ P).t(), rtol=0, atol=2e-5)
+    # with a ridge: the inverse
+    inv_r, coefs_r, rank_r = _pinv(A, b, 0.5, d)
+    assert rank_r == D
+    inv_s, coefs_s, _ = _solve(A, b.to(DEV), 0.5, d)
+    torch.testing.assert_close(inv_r, inv_s, rtol=1e-5, atol=1e-6 * float(inv_s.abs().max()))
+    torch.testing.assert_close(coefs_r, coefs_s, rtol=1e-5, atol=1e-6 * float(coefs_s.abs().max()))
+
+
+@pytest.mark.parametrize("name", ["pinv_singular_tiny", "pinv_singular_small"])
+def test_bandit_force_pinv_on_a_singular_regression(name):
+    """NeuralLinearBandit(force_pinv=True, l2_reg_lambda_linear=0) with fewer contexts than coefficients
+    (linear_regression.py:138-157: torch.linalg.pinv of a singular A).  Against the reference: the NN
+    step (losses, predictions, trunk, e2e layer) and A / b / sum_weight.  `_inv_A` / `_coefs` are held
+    to the EXACT pseudo-inverse (float64, torch's cut-off) of the learner's own A and b: the
+    reference's fp32 eigh is itself 0.5 % (tiny) / 15 % (small) away from that on its own matrix —
+    eigenvalues of 1e-4 next to a cut-off of 7e-5 — so its digits are not a target; the distance to
+    it is printed."""
+    from pearl_amd import NeuralLinearBandit, TransitionBatch
+    from helpers import assert_adam_trajectory_close
+    from test_oracle_ac_golden import bandit_batches
+    fx = load("bandit", name)
+    cfg = fx["config"]
+    pl = NeuralLinearBandit(feature_dim=cfg["F"], hidden_dims=cfg["hidden"], batch_size=cfg["B"],
+                            learning_rate=1e-3, **cfg["mlp"])
+    pl.model.load_state_dict(fx["model0"])
+    pl.to(DEV)
+    for step, ((x, r, w), want) in enumerate(zip(bandit_batches(fx), fx["reports"])):
+        tb = TransitionBatch(state=x.to(DEV), action=torch.zeros(cfg["B"], 1, device=DEV),
+                             reward=r.to(DEV), weight=None if w is None else w.to(DEV))
+        rep = pl.learn_batch(tb)
+        assert abs(float(rep["loss"]) - want["loss"]) <= 2e-4 * max(1.0, abs(want["loss"])), step
+        torch.testing.assert_close(rep["prediction"].cpu(), want["prediction"], rtol=1e-3, atol=2e-4)
+    after = fx["model_after"]
+    lr = pl.model._linear_regression_layer
+    for key, buf in (("_A", lr._A), ("_b", lr._b)):
+        want = after[f"_linear_regression_layer.{key}"]
+        torch.testing.assert_close(buf.cpu(), want, rtol=1e-5, atol=2e-5 * float(want.abs().max()), msg=key)
+    A, b = lr._A.cpu(), lr._b.cpu()
+    exact = _torch_pinv64(A, 0.0)
+    D = A.shape[0]
+    ev = torch.linalg.eigvalsh(A.double()).abs()
+    cut = D * 1.1920929e-07 * float(ev.max())
+    # (an eigenvalue of the learner's A within 1e-6 relative of the cut-off would make the comparison
+    #  itself ill-posed; it is not the case for these inputs)
+    assert float(((ev - cut).abs() / cut).min()) > 1e-6
+    torch.testing.assert_close(lr._inv_A.cpu().double(), exact, rtol=1e-5, atol=2e-6 * float(exact.abs().max()))
+    wc = exact @ b.double()
+    torch.testing.assert_close(lr._coefs.cpu().double(), wc, rtol=1e-5, atol=2e-6 * float(wc.abs().max()))
+    ref_inv = after["_linear_regression_layer._inv_A"].double()
+    print(f"{name}: |inv_A - reference| / max = "
+          f"{float((lr._inv_A.cpu().double() - ref_inv).abs().max() / ref_inv.abs().max()):.3e}; the reference's "
+          f"own distance from the exact pseudo-inverse of ITS matrix: "
+          f"{float((_torch_pinv64(after['_linear_regression_layer._A'], 0.0) - ref_inv).abs().max() / ref_inv.abs().max()):.3e}")
+    for k, v in pl.model._nn_layers.state_dict().items():
+        assert_adam_trajectory_close(v, after[f"_nn_layers.{k}"], 1e-3, cfg["steps"], rtol=1e-3, atol=2e-5,
+                                     max_outlier_frac=0.0, msg=k)
+    assert_adam_trajectory_close(pl.model.linear_layer_e2e.weight, after["linear_layer_e2e.weight"],
+                                 1e-3, cfg["steps"], rtol=1e-3, atol=2e-5, max_outlier_frac=0.0, msg="e2e")
+
+
 DDPG = ["ddpg_tiny", "ddpg_cfg3_shape_small", "td3_tiny", "td3_cfg3_shape_small", "td3_cfg3_fullbatch"]
 
 
