@@ -441,7 +441,7 @@ def bench_bandit(steps, cpu_seconds):
             # trunk forward + dW + dX of its second layer, the 65-wide head, A += x x^T, b += x r.
             # The step is pa_bandit_step: three launches on the learner stream (row step incl. the
             # LinUCB operands, weight gradients + AdamW + the moment update in ONE launch, apply); the
-            # 65 x 65 fp64 solve (one workgroup, ~100 us) runs on two alternating side streams
+            # 65 x 65 fp64 solve (one workgroup, 45 us; 98 us before the in-place kernel) runs on two alternating side streams
             # beside the next steps and no longer bounds the step
             "roofline": dict(step_roofline(
                 2 * (2 * mlp_macs([F, 256, 64]) + 256 * 64 + 3 * 65 + 65 * 65), B * steps, dt,

@@ -394,7 +394,7 @@ class NeuralLinearBandit(PolicyLearner):
         st = self.__dict__.get("_solve_state")
         if st is None or st["dev"] != dev or st["D"] != D:
             # two slots, each with its own stream, (A, b) snapshot, work area and RESULT pair: two
-            # solves can be in flight (one serial workgroup each, ~100 us beside the learner's
+            # solves can be in flight (one serial workgroup each, 45 - 100 us beside the learner's
             # launches against an ~80 us step); the regression layer copies the latest result into
             # its buffers when something reads them (LinearRegression.join_solve)
             st = {"dev": dev, "D": D, "side": [torch.cuda.Stream(dev) for _ in range(2)], "slot": 0,
@@ -431,7 +431,7 @@ class NeuralLinearBandit(PolicyLearner):
 
     def _solve(self, lr: Any, dev: torch.device, snap=None) -> None:
         """inv(A + lambda I) and coefs = inv_A b (linear_regression.py:252-270 calculate_coefs) — OFF
-        the learner's critical path: the fp64 Gauss-Jordan solve is ONE serial workgroup (97 us of a
+        the learner's critical path: the fp64 Gauss-Jordan solve is ONE serial workgroup (45 us — 97 us in round 4 — of a
         240 us step) and nothing in the next learn_batch reads `_inv_A` / `_coefs`; they are read at
         act time.  So the step leaves a snapshot of (A, b) on the learner stream (written by the
         apply launch itself: `snap`, from _solve_slot) and the solve runs on the slot's side stream,
