@@ -446,7 +446,7 @@ def bench_bandit(steps, cpu_seconds):
             "roofline": dict(step_roofline(
                 2 * (2 * mlp_macs([F, 256, 64]) + 256 * 64 + 3 * 65 + 65 * 65), B * steps, dt,
                 kernel="mlp_rowstep_kernel + weight_grad_split_kernel (network dW + AdamW + X^T R) "
-                       "+ linreg operands / apply; linreg_solve_spd_kernel off the learner stream"),
+                       "+ linreg operands / apply; linreg_solve_spd_inplace_kernel off the learner stream"),
                 note="bound by the learner stream's three launches (row step 45 us, weight "
                      "gradients + moment update 27 us, apply 4 us)"),
             "kernels": kernels,
