@@ -364,7 +364,9 @@ int pa_comm_allreduce_wait(void* comm, void* stream);
 
 /* Kernel timing of the last pa_dqn_learn / pa_dqn_step when timing is enabled
  * (HIP events on the launch stream; used by bench.py's roofline block). */
-/* level 0: off; 1: only the dominant kernel ("target"); 2: every stage.  Resets the counters. */
+/* level 0: off; 1: only the dominant kernel ("target"); 2: every stage.  Resets the counters.
+ * level | 4 (with level 1): also "rowpass" and "bwd_dw" — the online chain's two launches — of one
+ * mid-window round of every sampled window of the overlapped loop (bench.py's roofline.chain). */
 int pa_dqn_enable_timing(pa_dqn* h, int32_t level);
 /* names: "target" (every 4th launch at level 1), "target_l1", "l1_dual", "online_l1", "gather",
  * "sample", "online_l2", "head", "bwd_dx", "bwd_dw", "adamw", "soft_update", "learn"

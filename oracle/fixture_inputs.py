@@ -83,3 +83,36 @@ def ppo_rollout(cfg):
     rewards = normalish((N,), seed * 100 + 3)
     i = torch.arange(N)
     return states, actions, rewards, (i % 97 == 96), (i % 131 == 57)
+
+
+def sac_box(cfg):
+    """The action box of a seeded continuous-SAC fixture (asymmetric, per-dimension bounds)."""
+    A = cfg["A"]
+    return -torch.ones(A) * torch.linspace(1.0, 2.0, A), torch.ones(A) * torch.linspace(1.5, 1.0, A)
+
+
+def sac_transitions(cfg):
+    """The transitions of a seeded continuous-SAC fixture: states (N + 1, S), actions (N, A) inside
+    the box, rewards (N,), terminated (N,) — every 11th transition ends an episode."""
+    N, S, A, seed = cfg["N"], cfg["S"], cfg["A"], cfg["input_seed"]
+    low, high = sac_box(cfg)
+    states = normalish((N + 1, S), seed * 100 + 1)
+    actions = low + (high - low) * uniform((N, A), seed * 100 + 2)
+    rewards = normalish((N,), seed * 100 + 3)
+    return states, actions, rewards, (torch.arange(N) % 11 == 10)
+
+
+def divergence(got, want):
+    """Per-tensor statistics of how far two parameter sets are apart: the yardstick the long-run
+    fixtures carry (twin vs reference) and the tests recompute (HIP vs reference)."""
+    out = {}
+    for k, w in want.items():
+        g = got[k].detach().cpu().double().view(-1)
+        w = w.detach().cpu().double().view(-1)
+        if w.numel() == 0:
+            continue
+        d = (g - w).abs()
+        out[k] = dict(max_abs=float(d.max()), mean_abs=float(d.mean()),
+                      rms=float(d.pow(2).mean().sqrt()), ref_rms=float(w.pow(2).mean().sqrt()),
+                      ref_max=float(w.abs().max()))
+    return out

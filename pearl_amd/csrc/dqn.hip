@@ -149,6 +149,9 @@ struct pa_dqn {
   int64_t tick;      // steps seen while timing (sparse sampling of the level-1 timer)
   // timing
   int timing;  // 0 off, 1 dominant kernel only, 2 every stage
+  int timing_chain;  // level | 4: also the online chain (row pass, weight gradients) of ONE mid-window
+                     // round of every sampled window (roofline.chain of the bench line)
+  bool chain_sample; // the chain launches being enqueued belong to such a round
   std::deque<Timer> timers;  // deque: references stay valid while nested timers are added
 };
 
@@ -588,7 +591,7 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
                 int world, hipStream_t s, int phase = 0) {
   const pa_dqn_desc& d = h->d;
   const NetPtrs q = net_ptrs(h, h->bufs.q);
-  ScopedTimer tm(h, "rowpass", s);
+  ScopedTimer tm(h, "rowpass", s, h->chain_sample ? 1 : 2, 1, B);
   const size_t smem = rowpass_smem_bytes(h->IN, d.hidden1, d.hidden2);
   RowArgs a;
   memset(&a, 0, sizeof(a));
@@ -722,7 +725,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
                     float* loss_out, int soft_next, hipStream_t s, const float* y_tagged = nullptr) {
   const pa_dqn_desc& d = h->d;
   float* G = h->bufs.grad;
-  ScopedTimer tm(h, "bwd_dw", s);
+  ScopedTimer tm(h, "bwd_dw", s, h->chain_sample ? 1 : 2, 1, B);
   DwArgs a;
   memset(&a, 0, sizeof(a));
   a.nprob = 3;
@@ -1129,6 +1132,8 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->IN = desc->state_dim + desc->action_dim;
   param_layout(desc->state_dim, desc->action_dim, desc->hidden1, desc->hidden2, h->off, &h->P);
   h->timing = 0;
+  h->timing_chain = 0;
+  h->chain_sample = false;
   h->bb_A = 0;
   memset(&h->bb, 0, sizeof(h->bb));
   h->idx_all = nullptr;
@@ -1765,6 +1770,11 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         if (rc != PA_OK) return rc;
       }
       const bool tagged = overlap || dbl2;
+      // roofline.chain: the two chain launches of one round in the middle of a sampled window
+      // (four event records, ~6 us of idle each: one round in forty carries them)
+      h->chain_sample = h->timing_chain && h->timing == 1 && sample_w && !split_rp && !dbl && !dp &&
+                        j == (w > 1 ? w / 2 : 0) && !(k == 0 && j == 0 && front_emitted);
+      struct ChainSampleOff { pa_dqn* h; ~ChainSampleOff() { h->chain_sample = false; } } cs_off{h};
       if (!(k == 0 && j == 0 && front_emitted)) {
         rc = chain_front(h, xj, B, yj, tagged, gw_chain, s, split_rp);
         if (rc != PA_OK) return rc;
@@ -1825,7 +1835,9 @@ extern "C" int pa_dqn_check(pa_dqn* h) {
 
 extern "C" int pa_dqn_enable_timing(pa_dqn* h, int32_t on) {
   PA_REQUIRE(h, PA_ERR_INVALID, "null learner");
-  h->timing = on < 0 ? 0 : on;
+  h->timing = on < 0 ? 0 : (on & 3);
+  h->timing_chain = on < 0 ? 0 : ((on >> 2) & 1);
+  h->chain_sample = false;
   for (auto& t : h->timers) { t.used = 0; t.units = 0; }
   if (h->timing >= 1) {
     // the level-1 timer's events exist before the timed call starts (hipEventCreate inside it cost

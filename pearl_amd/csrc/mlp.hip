@@ -1134,6 +1134,15 @@ int run_rowstep(pa_mlp* const* hs, int nnet, const float* x, int ldx, int B, Row
   for (int i = 0; i < nnet && splitf; ++i)
     for (int l = 0; l < hs[i]->L; ++l)
       splitf = splitf && hs[i]->d.dims[l] <= ROW_MAX_OUT && hs[i]->wsp[l] != nullptr;
+  // PPO with epsilon = 0 (the reference's default, ppo.py:105): clamp(ratio, 1, 1) passes a gradient
+  // only where ratio * gae <= gae, and in the first round after preprocess_replay_buffer the
+  // reference's ratio is EXACTLY 1 in every row (its minibatch forward reproduces its rollout
+  // forward bit for bit: ppo_cfg4_eps0.pt records 4096 of 4096).  That needs this forward to be
+  // the rollout's arithmetic — the fp32-MFMA row pass, bitwise forward_pair's — so such a step
+  // does not take the bf16x3 forward (whose logits differ from the rollout's in the last bits
+  // and would switch the gradient of about half the rows off).
+  for (int i = 0; i < nnet; ++i)
+    if (heads[i].kind == RS_HEAD_PPO && heads[i].eps == 0.f) splitf = false;
   // ... and then the backward GEMMs too (W_l^T planes, dz planes in LDS); a network without them
   // (or PEARL_AMD_ROWSTEP_SPLIT_BWD=0) keeps the fp32-MFMA backward
   static const bool splitb_env = []() {

@@ -82,7 +82,10 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         else:
             self.register_buffer("_entropy_coef", torch.tensor(entropy_coef))
         self._action_batch_log_prob_cache: Tensor = torch.tensor(0.0)
-        # parity hook: callable (B, A, device) -> standard-normal tensor; default torch.randn
+        # parity hook: callable (B, A, device) -> standard-normal tensor; default torch.randn.
+        # A source that also has `.rounds(first_round, n, B, A, device) -> [n, 2, B, A]` (actor
+        # draw, then critic-target draw, per round — the order the reference consumes torch's
+        # generator in) keeps learn() on the native loop.
         self.noise_source: Optional[Callable[[int, int, torch.device], Tensor]] = None
 
     # ------------------------------------------------------------------ flat views
@@ -352,7 +355,8 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         are the ones the per-round loop would run — same index lists, same kernels; the noise is
         drawn for many rounds at once, as `_begin_learn_loop` already does."""
         cls, base = type(self), ContinuousSoftActorCritic
-        if self.noise_source is not None or not self._one_call_ok() \
+        noise_rounds = getattr(self.noise_source, "rounds", None)
+        if (self.noise_source is not None and noise_rounds is None) or not self._one_call_ok() \
                 or cls._learn_batch_device is not base._learn_batch_device \
                 or cls._learn_batch_one_call is not base._learn_batch_one_call \
                 or cls.learn_batch is not ActorCriticBase.learn_batch:
@@ -375,7 +379,11 @@ class ContinuousSoftActorCritic(ActorCriticBase):
         done = 0
         while done < rounds:
             n = min(chunk, rounds - done)
-            noise = torch.randn(n, 2, B, A, device=dev, dtype=torch.float32)
+            if noise_rounds is not None:
+                noise = noise_rounds(done, n, B, A, dev).to(dev, torch.float32).contiguous()
+                assert tuple(noise.shape) == (n, 2, B, A)
+            else:
+                noise = torch.randn(n, 2, B, A, device=dev, dtype=torch.float32)
             a = self._step_args(ws, actor, c1, c2, w["state"][:B], w["action"][:B], w["reward"][:B],
                                 w["term"][:B], w["next"][:B], losses, logp)
             lp.rounds = n

@@ -488,10 +488,11 @@ class TensorBasedReplayBuffer(ReplayBuffer):
                            count=batch_size)
 
     def presample(self, rounds: int, batch_size: int, pregather_bytes: int = 0) -> bool:
-        """Device sampler only: draw the index lists of the next ``rounds`` ``sample(batch_size)``
-        calls in ONE launch (``sample_indices_kernel`` runs one workgroup per list, so a learner
-        loop does not pay a single-workgroup kernel per round); the following ``sample`` calls of
-        that size consume them in order.  Pushing, clearing or a different batch size drops what
+        """Draw the index lists of the next ``rounds`` ``sample(batch_size)`` calls at once — device
+        sampler: ONE launch (``sample_indices_kernel`` runs one workgroup per list, so a learner
+        loop does not pay a single-workgroup kernel per round); python sampler: ``rounds`` draws of
+        ``random.sample`` uploaded as one tensor — the following ``sample`` calls of that size
+        consume them in order.  Pushing, clearing or a different batch size drops what
         is left.  Consumes Python's ``random`` once (the Philox key), like one ``sample``.
 
         ``pregather_bytes`` > 0: those ``sample`` calls also share their gather — one launch fills
@@ -501,15 +502,24 @@ class TensorBasedReplayBuffer(ReplayBuffer):
         self._pregathered = None
         self._pregather_bytes = 0
         n = len(self)
-        if self.sampler != "device" or self._arena is None or rounds <= 0 or not 0 < batch_size <= n \
-                or batch_size > self.DEVICE_SAMPLER_MAX_B:
+        if self._arena is None or rounds <= 0 or not 0 < batch_size <= n:
             return False
         dev = self._arena.device
-        self._arena.flush()
-        lists = torch.empty(int(rounds), int(batch_size), dtype=torch.int64, device=dev)
-        N.check(N.lib().pa_sample_indices_rounds(n, random.getrandbits(64), 0, int(batch_size),
-                                                 int(rounds), lists.data_ptr(), dev.index,
-                                                 N.stream_ptr(dev)))
+        if self.sampler == "python":
+            # parity mode: the lists `rounds` consecutive sample() calls would draw, drawn now — the
+            # same consumption of Python's MT19937 stream as the reference's learn loop, whose
+            # rounds touch `random` nowhere else (tensor_based_replay_buffer.py:276)
+            self._arena.flush()
+            host = np.stack([self._draw_host_indices(int(batch_size)) for _ in range(int(rounds))])
+            lists = torch.from_numpy(host).to(dev)
+        elif batch_size > self.DEVICE_SAMPLER_MAX_B:
+            return False
+        else:
+            self._arena.flush()
+            lists = torch.empty(int(rounds), int(batch_size), dtype=torch.int64, device=dev)
+            N.check(N.lib().pa_sample_indices_rounds(n, random.getrandbits(64), 0, int(batch_size),
+                                                     int(rounds), lists.data_ptr(), dev.index,
+                                                     N.stream_ptr(dev)))
         self._presampled = (lists, 0, n)
         if pregather_bytes > 0 and self._device_for_batches == dev:
             self._pregather_bytes = int(pregather_bytes)

@@ -90,6 +90,52 @@ def test_ppo_rollout64k_preprocess_replay_buffer():
     torch.testing.assert_close(rb.extra["lam_return"].cpu(), fx["lam_return"], rtol=1e-5, atol=4e-6)
 
 
+def test_ppo_gae_kernel_on_the_references_known_answer():
+    """The reference's own known-answer test for preprocess_replay_buffer
+    (test/unit/with_pytorch/test_ppo.py:48-115) on the GPU path — gae_kernel through
+    PPOReplayBuffer + preprocess_replay_buffer: state_dim 1, three actions, hidden [64, 64],
+    discount 0.6, trace decay 0.5, rewards 4, 6, 5, no episode end;
+        gae2 = 5 + 0.6 v3 - v2,  gae1 = 6 + 0.6 v2 - v1 + 0.3 gae2,  gae0 = 4 + 0.6 v1 - v0 + 0.3 gae1,
+        lam_return_i = gae_i + v_i
+    with v_i from the learner's own critic, evaluated by torch in float64."""
+    from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
+                           ProximalPolicyOptimization)
+    torch.manual_seed(0)
+    sp = dspace(3)
+    pl = ProximalPolicyOptimization(
+        state_dim=1, action_space=sp, actor_hidden_dims=[64, 64], critic_hidden_dims=[64, 64],
+        training_rounds=10, batch_size=500, epsilon=0.1, discount_factor=0.6, trace_decay_param=0.5,
+        action_representation_module=OneHotActionTensorRepresentationModule(3))
+    rb = PPOReplayBuffer(10, sampler="python")
+    PearlAgent(pl, replay_buffer=rb, device_id=0)
+    rewards = [4.0, 6.0, 5.0]
+    for i, r in enumerate(rewards):
+        rb.push(state=torch.tensor([i * 1.0]), action=torch.tensor([i]), reward=r,
+                next_state=torch.tensor([i * 1.0]), curr_available_actions=sp,
+                next_available_actions=sp, terminated=False, truncated=False, max_number_actions=3)
+    layers = [(l.weight.detach().double().cpu(), l.bias.detach().double().cpu())
+              for l in pl._critic.linear_layers()]
+
+    def v(s):
+        h = torch.tensor([[s]], dtype=torch.float64)
+        for i, (w, b) in enumerate(layers):
+            h = h @ w.t() + b
+            if i + 1 < len(layers):
+                h = torch.relu(h)
+        return float(h)
+
+    v0, v1, v2, v3 = v(0.0), v(1.0), v(2.0), v(2.0)      # (the KAT's next_state of step 2 is state 2)
+    gae2 = 5 + 0.6 * v3 - v2
+    gae1 = 6 + 0.6 * v2 - v1 + 0.6 * 0.5 * gae2
+    gae0 = 4 + 0.6 * v1 - v0 + 0.6 * 0.5 * gae1
+    pl.preprocess_replay_buffer(rb)
+    got_gae, got_ret = rb.extra["gae"].cpu().double(), rb.extra["lam_return"].cpu().double()
+    want_gae = torch.tensor([gae0, gae1, gae2], dtype=torch.float64)
+    want_ret = want_gae + torch.tensor([v0, v1, v2], dtype=torch.float64)
+    torch.testing.assert_close(got_gae, want_gae, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(got_ret, want_ret, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["tiny", "eps0", "cfg4_shape_small", "cfg4_fullbatch"])
 def test_ppo_learn_trajectory(name):
     fx = load("ppo", name)
