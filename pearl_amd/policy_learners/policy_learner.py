@@ -9,8 +9,11 @@ this generic loop for any other ``ReplayBuffer``.
 """
 from __future__ import annotations
 
+import functools
+import os
+import time
 from abc import ABC, abstractmethod
-from typing import Any, Dict, List, Optional
+from typing import Any, Callable, Dict, List, Optional
 
 import torch
 import torch.nn as nn
@@ -48,6 +51,52 @@ class IdentityHistorySummarizationModule(nn.Module):
             "other is not an instance of IdentityHistorySummarizationModule")
 
 
+def perf_reported(learn: Callable[..., Dict[str, Any]]) -> Callable[..., Dict[str, Any]]:
+    """Opt-in performance fields of ``learn()``'s report (the dict the reference
+    aggregates at policy_learner.py:181-195).  With ``learner.performance_report`` False — the
+    default — the wrapped ``learn`` runs untouched: same keys as the reference, no extra
+    synchronisation, no timers.  With it True the report of a non-empty call gains, as one-element
+    lists (the report is a dict of lists):
+
+      perf/transitions_per_s   batch_size x rounds of this call / its wall time
+      perf/learn_wall_us       wall time of the call (host clock around it; the call's own final
+                               synchronisation included, plus one device synchronisation after it)
+      perf/rounds              rounds this call ran
+      perf/kernel_us/<stage>   average duration of the stage's launches inside this call, from the
+                               library's HIP-event timers (``pa_dqn_get_timing``, ``pa_mlp_timing_read``,
+                               ``pa_sac_timing_read``): what rocprofv3's kernel trace shows for the
+                               same launches, without a profiler attached
+    """
+    @functools.wraps(learn)
+    def wrapper(self: "PolicyLearner", replay_buffer: ReplayBuffer) -> Dict[str, Any]:
+        if not self.performance_report or self.__dict__.get("_perf_active"):
+            return learn(self, replay_buffer)
+        self.__dict__["_perf_active"] = True
+        try:
+            steps0 = self._training_steps
+            self._perf_begin()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            report = learn(self, replay_buffer)
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            stages = self._perf_end()
+            rounds = self._training_steps - steps0
+            if report and rounds > 0:
+                bs = self._clamped_batch_size(replay_buffer) if len(replay_buffer) else self._batch_size
+                report["perf/transitions_per_s"] = [bs * rounds / dt]
+                report["perf/learn_wall_us"] = [dt * 1e6]
+                report["perf/rounds"] = [rounds]
+                for k, v in stages.items():
+                    report[f"perf/kernel_us/{k}"] = [v]
+            return report
+        finally:
+            self.__dict__["_perf_active"] = False
+    return wrapper
+
+
 def _looks_like_batch(obj: Any) -> bool:
     return isinstance(obj, TransitionBatch) or all(
         hasattr(obj, k) for k in ("state", "action", "reward", "terminated", "next_state"))
@@ -74,6 +123,9 @@ class PolicyLearner(nn.Module, ABC):
         self._training_rounds = training_rounds
         self._batch_size = batch_size
         self._training_steps = 0
+        # opt-in performance fields of learn()'s report (perf_reported above); PEARL_AMD_PERF_REPORT=1
+        # switches them on for every learner of the process
+        self.performance_report: bool = os.environ.get("PEARL_AMD_PERF_REPORT") == "1"
         self.on_policy = on_policy
         self._is_action_continuous = is_action_continuous
         self.distribution_enabled: bool = (torch.distributed.is_available()
@@ -121,6 +173,28 @@ class PolicyLearner(nn.Module, ABC):
             from .. import _native as N
             N.check(N.lib().pa_dqn_invalidate(nat.handle))
 
+    # -- hooks of the opt-in performance report: switch the library's event timers on / read them
+    def _perf_begin(self) -> None:
+        """Default: the generic MLP engine's timers (fused row step, weight gradients + AdamW)."""
+        from .. import _native as N
+        if torch.cuda.is_available():
+            N.check(N.lib().pa_mlp_timing(1))
+
+    def _perf_end(self) -> Dict[str, float]:
+        import ctypes as C
+        from .. import _native as N
+        out: Dict[str, float] = {}
+        if not torch.cuda.is_available():
+            return out
+        for which, name in ((0, "row_step"), (1, "weight_grad_adamw")):
+            us, n = C.c_double(), C.c_int64()
+            N.check(N.lib().pa_mlp_timing_read(which, C.byref(us), C.byref(n)))
+            if n.value:
+                out[name] = us.value
+        N.check(N.lib().pa_mlp_timing(0))
+        return out
+
+    @perf_reported
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         if len(replay_buffer) == 0:
             return {}

@@ -31,7 +31,7 @@ from ...neural_networks.sequential_decision_making.twin_critic import TwinCritic
 from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import ExplorationModule
-from ..policy_learner import PolicyLearner, _looks_like_batch, accept_optimizer
+from ..policy_learner import PolicyLearner, _looks_like_batch, accept_optimizer, perf_reported
 from .flat_mlp import FlatMlp
 
 
@@ -166,6 +166,7 @@ class ActorCriticBase(PolicyLearner):
             self._update_actor_target()
         return report
 
+    @perf_reported
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         """PolicyLearner.learn (policy_learner.py:190-231) with the same report — one list of
         floats per key — but ONE host synchronisation for the whole call instead of one `.item()`

@@ -46,7 +46,7 @@ from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
 from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import EGreedyExploration, ExplorationModule
-from ..policy_learner import PolicyLearner, accept_optimizer
+from ..policy_learner import PolicyLearner, accept_optimizer, perf_reported
 from .generic_q import GenericTd, make_ops, mlp_spec, plain_relu_mlp
 
 _FLAT_NAMES = ("q", "q_target", "grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq")
@@ -630,6 +630,35 @@ class DeepQLearning(PolicyLearner):
             z.action_elems == self._Q.action_dim and z.avail_dim == self._Q.action_dim
         # anything else goes through the generic sample -> preprocess -> learn_batch loop
 
+    # performance report (policy_learner.perf_reported): the fused loop's own event timers at level
+    # 1 | 4 — the sampled target-pass and gather launches of the side stream and one mid-window
+    # round's chain launches — which leave the overlapped two-stream loop as it is
+    _PERF_STAGES = (("target", "target_pass"), ("gather", "gather"), ("gather_nox", "gather"),
+                    ("rowpass", "row_pass"), ("bwd_dw", "weight_grad_adamw"))
+
+    def _perf_begin(self) -> None:
+        nat = getattr(self, "_native", None)
+        mine = nat is not None and getattr(nat, "handle", None) is not None and self._fused
+        self.__dict__["_perf_dqn"] = mine      # (a learner not bound yet reports no stages this call)
+        if mine:
+            N.check(N.lib().pa_dqn_enable_timing(nat.handle, 5))
+        else:
+            super()._perf_begin()
+
+    def _perf_end(self) -> Dict[str, float]:
+        if not self.__dict__.get("_perf_dqn"):
+            return super()._perf_end()
+        nat = self._native
+        out: Dict[str, float] = {}
+        for name, key in self._PERF_STAGES:
+            ms, cnt = C.c_double(), C.c_int64()
+            N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                out[key] = ms.value * 1e3
+        N.check(N.lib().pa_dqn_enable_timing(nat.handle, 0))
+        return out
+
+    @perf_reported
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         """``training_rounds`` x (sample, preprocess, learn_batch) — policy_learner.py:162-195."""
         if len(replay_buffer) == 0:

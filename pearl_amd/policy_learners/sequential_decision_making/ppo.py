@@ -33,7 +33,7 @@ from ...replay_buffers.basic_replay_buffer import TensorBasedReplayBuffer
 from ...replay_buffers.replay_buffer import ReplayBuffer
 from ...replay_buffers.transition import TransitionBatch
 from ..exploration import ExplorationModule, PropensityExploration
-from ..policy_learner import PolicyLearner
+from ..policy_learner import PolicyLearner, perf_reported
 from .actor_critic_base import ActorCriticBase
 from .flat_mlp import FlatMlp, layers_of
 
@@ -290,6 +290,7 @@ class ProximalPolicyOptimization(ActorCriticBase):
         return {"actor_loss": losses[0], "critic_loss": losses[1]}
 
     # ------------------------------------------------------------------ learn (ppo.py:194-293)
+    @perf_reported
     def learn(self, replay_buffer: ReplayBuffer) -> Dict[str, Any]:
         self.preprocess_replay_buffer(replay_buffer)
         return ActorCriticBase.learn(self, replay_buffer)

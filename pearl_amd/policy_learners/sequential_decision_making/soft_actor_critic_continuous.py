@@ -410,6 +410,20 @@ class ContinuousSoftActorCritic(ActorCriticBase):
             report["entropy_coef"] = got[2]
         return report
 
+    # performance report (policy_learner.perf_reported): the fused row launches of pa_sac_step
+    def _perf_begin(self) -> None:
+        super()._perf_begin()
+        N.check(N.lib().pa_sac_timing(1))
+
+    def _perf_end(self) -> Dict[str, float]:
+        out = super()._perf_end()
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        N.check(N.lib().pa_sac_timing_read(C.byref(a), C.byref(b), C.byref(n)))
+        if n.value:
+            out["sac_rows_a"], out["sac_rows_b"] = a.value, b.value
+        N.check(N.lib().pa_sac_timing(0))
+        return out
+
     def _begin_learn_loop(self, rounds: int, batch_size: int) -> None:
         """The reparameterisation noise of every round of this learn() call in ONE generator launch
         (2 draws of (B, A) per round) instead of one launch per round on the step's critical path."""
