@@ -155,3 +155,208 @@ def test_hip_learner_tracks_the_reference_learner_on_identical_data(reference):
     for k, v in ref._Q_target.state_dict().items():
         torch.testing.assert_close(hip.impl._Q_target.state_dict()[k].cpu(), v, rtol=1e-3, atol=2e-5,
                                    msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
+# PPO and ContinuousSoftActorCritic behind the reference's ABCs (VERDICT r5 missing-2)
+# ---------------------------------------------------------------------------------------------
+def _ppo_pair(S=6, A=4, hidden=(24, 24), rounds=5, batch=32, eps=0.1):
+    from pearl.action_representation_modules.one_hot_action_representation_module import (
+        OneHotActionTensorRepresentationModule)
+    from pearl.policy_learners.sequential_decision_making.ppo import (PPOReplayBuffer,
+                                                                       ProximalPolicyOptimization)
+    from pearl.utils.instantiations.spaces.discrete_action import DiscreteActionSpace
+
+    from reference_binding import HipPPO, HipPPOReplayBuffer
+    space = DiscreteActionSpace([torch.tensor([k]) for k in range(A)])
+    torch.manual_seed(4)
+    ref = ProximalPolicyOptimization(
+        state_dim=S, action_space=space, actor_hidden_dims=list(hidden), critic_hidden_dims=list(hidden),
+        training_rounds=rounds, batch_size=batch, epsilon=eps,
+        action_representation_module=OneHotActionTensorRepresentationModule(A))
+    hip = HipPPO(state_dim=S, action_space=space, actor_hidden_dims=list(hidden),
+                 critic_hidden_dims=list(hidden), training_rounds=rounds, batch_size=batch, epsilon=eps,
+                 action_representation_module=OneHotActionTensorRepresentationModule(A))
+    hip.impl._actor.load_state_dict(ref._actor.state_dict())
+    hip.impl._critic.load_state_dict(ref._critic.state_dict())
+    return ref, hip, space, PPOReplayBuffer, HipPPOReplayBuffer
+
+
+@pytest.mark.gpu
+def test_real_pearl_agent_drives_hip_ppo_on_policy(reference):
+    """The reference's unmodified PearlAgent with HipPPO + HipPPOReplayBuffer: observe -> learn
+    (rollout pass + pa_ppo_learn; then the agent's own on-policy `replay_buffer.clear()`,
+    pearl_agent.py:217-218) -> act with and without exploitation."""
+    from pearl.api.action_result import ActionResult
+    from pearl.pearl_agent import PearlAgent
+    from pearl.policy_learners.policy_learner import PolicyLearner
+    from pearl.replay_buffers.replay_buffer import ReplayBuffer
+    S, A = 6, 4
+    _, pl, space, _, HipPPOReplayBuffer = _ppo_pair(S, A, rounds=3, batch=16)
+    rb = HipPPOReplayBuffer(128)
+    assert isinstance(pl, PolicyLearner) and isinstance(rb, ReplayBuffer) and pl.on_policy
+    agent = PearlAgent(policy_learner=pl, replay_buffer=rb, device_id=0)
+    agent.reset(torch.zeros(S), space)
+    gen = torch.Generator().manual_seed(0)
+    for i in range(50):
+        agent._latest_action = torch.tensor([i % A])
+        agent.observe(ActionResult(observation=torch.randn(S, generator=gen), reward=float(i % 3) - 1.0,
+                                   terminated=(i % 13 == 12), truncated=(i % 17 == 16),
+                                   available_action_space=space))
+    assert len(rb) == 50
+    before = {k: v.clone() for k, v in pl.impl._actor.state_dict().items()}
+    random.seed(0)
+    report = agent.learn()
+    assert set(report) == {"actor_loss", "critic_loss"}          # the reference's report keys
+    assert all(len(v) == 3 and all(x == x for x in v) for v in report.values())
+    assert pl._training_steps == 3 and len(rb) == 0              # on-policy: cleared by the agent
+    assert any(not torch.equal(before[k], v) for k, v in pl.impl._actor.state_dict().items())
+    assert pl.impl._flat, "the HIP engine never bound the networks"
+    acts = {int(agent.act(exploit=False)) for _ in range(30)}
+    assert acts <= set(range(A)) and int(agent.act(exploit=True)) in range(A)
+
+
+@pytest.mark.gpu
+def test_hip_ppo_tracks_the_reference_ppo_on_identical_data(reference):
+    """One learn() of the reference's own ProximalPolicyOptimization (CPU) and of HipPPO: same
+    initial networks, same rollout, same `random.sample` stream — GAE / lambda-returns / old action
+    probabilities, the per-round reports and the parameters agree."""
+    ref, hip, space, PPOReplayBuffer, HipPPOReplayBuffer = _ppo_pair()
+    S, A, N_ = 6, 4, 96
+    hip.impl.to(torch.device("cuda", 0))
+    rb_ref, rb_hip = PPOReplayBuffer(N_), HipPPOReplayBuffer(N_)
+    rb_hip.device_for_batches = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(2)
+    st = torch.randn(N_ + 1, S, generator=gen)
+    rw = torch.randn(N_, generator=gen)
+    for i in range(N_):
+        kw = dict(state=st[i], action=torch.tensor([(i * 7) % A]), reward=float(rw[i]),
+                  terminated=(i % 19 == 18), truncated=(i % 23 == 11), curr_available_actions=space,
+                  next_state=st[i + 1], next_available_actions=space, max_number_actions=A)
+        rb_ref.push(**kw)
+        rb_hip.push(**kw)
+    random.seed(21)
+    want = ref.learn(rb_ref)
+    random.seed(21)
+    got = hip.learn(rb_hip)
+    extra = rb_hip.impl.extra
+    torch.testing.assert_close(extra["gae"].cpu(), torch.cat([t.gae for t in rb_ref.memory]).view(-1),
+                               rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(extra["action_probs"].cpu(),
+                               torch.cat([t.action_probs for t in rb_ref.memory]).view(-1), rtol=1e-5, atol=1e-7)
+    for k in ("actor_loss", "critic_loss"):
+        torch.testing.assert_close(torch.tensor(got[k]), torch.tensor([float(x) for x in want[k]]),
+                                   rtol=2e-4, atol=2e-4, msg=k)
+    for name in ("_actor", "_critic"):
+        for k, v in getattr(ref, name).state_dict().items():
+            torch.testing.assert_close(getattr(hip.impl, name).state_dict()[k].cpu(), v, rtol=1e-3,
+                                       atol=2e-5, msg=f"{name}.{k}")
+
+
+def _sac_pair(S=7, A=3, hidden=(32, 32), rounds=4, batch=24):
+    from pearl.policy_learners.sequential_decision_making.soft_actor_critic_continuous import (
+        ContinuousSoftActorCritic)
+    from pearl.utils.instantiations.spaces.box_action import BoxActionSpace
+
+    from reference_binding import HipContinuousSAC
+    space = BoxActionSpace(low=-torch.ones(A) * torch.tensor([1.0, 2.0, 0.5]),
+                           high=torch.ones(A) * torch.tensor([1.5, 1.0, 0.5]))
+    torch.manual_seed(9)
+    ref = ContinuousSoftActorCritic(state_dim=S, action_space=space, actor_hidden_dims=list(hidden),
+                                    critic_hidden_dims=list(hidden), training_rounds=rounds,
+                                    batch_size=batch)
+    hip = HipContinuousSAC(state_dim=S, action_space=space, actor_hidden_dims=list(hidden),
+                           critic_hidden_dims=list(hidden), training_rounds=rounds, batch_size=batch)
+    hip.impl._actor.load_state_dict(ref._actor.state_dict())
+    hip.impl._critic.load_state_dict(ref._critic.state_dict())
+    hip.impl._critic_target.load_state_dict(ref._critic_target.state_dict())
+    return ref, hip, space
+
+
+@pytest.mark.gpu
+def test_real_pearl_agent_drives_hip_continuous_sac(reference):
+    """The reference's unmodified PearlAgent with HipContinuousSAC + HipReplayBuffer: continuous
+    actions through observe (no max_number_actions, pearl_agent.py:199-203), learn() = pa_sac_learn,
+    act inside the action box."""
+    from pearl.api.action_result import ActionResult
+    from pearl.pearl_agent import PearlAgent
+
+    from reference_binding import HipReplayBuffer
+    S, A = 7, 3
+    _, pl, space = _sac_pair(S, A)
+    rb = HipReplayBuffer(256, sampler="device")
+    agent = PearlAgent(policy_learner=pl, replay_buffer=rb, device_id=0)
+    assert rb._is_action_continuous is True and not pl.on_policy
+    agent.reset(torch.zeros(S), space)
+    gen = torch.Generator().manual_seed(5)
+    for i in range(60):
+        agent._latest_action = space.low + (space.high - space.low) * torch.rand(A, generator=gen)
+        agent.observe(ActionResult(observation=torch.randn(S, generator=gen), reward=float(i % 4),
+                                   terminated=(i % 11 == 10), truncated=False,
+                                   available_action_space=space))
+    assert len(rb) == 60
+    before = {k: v.clone() for k, v in pl.impl._critic.state_dict().items()}
+    random.seed(3)
+    torch.manual_seed(3)
+    report = agent.learn()
+    assert set(report) == {"actor_loss", "critic_loss", "entropy_coef"}
+    assert all(len(v) == 4 and all(x == x for x in v) for v in report.values())
+    assert pl._training_steps == 4 and len(rb) == 60             # off-policy: the buffer stays
+    assert any(not torch.equal(before[k], v) for k, v in pl.impl._critic.state_dict().items())
+    a = torch.as_tensor(agent.act(exploit=True)).cpu().view(-1)
+    assert a.shape == (A,) and bool((a >= space.low - 1e-6).all()) and bool((a <= space.high + 1e-6).all())
+
+
+@pytest.mark.gpu
+def test_hip_sac_tracks_the_reference_sac_on_identical_data_and_noise(reference):
+    """One learn() of the reference's own ContinuousSoftActorCritic (CPU; its reparameterisation
+    noise comes from torch's seeded global generator) and of HipContinuousSAC fed the same draws:
+    reports and parameters agree."""
+    from pearl.replay_buffers.basic_replay_buffer import BasicReplayBuffer
+
+    from reference_binding import HipReplayBuffer
+    S, A, N_, B, R = 7, 3, 120, 24, 4
+    ref, hip, space = _sac_pair(S, A, rounds=R, batch=B)
+    hip.impl.to(torch.device("cuda", 0))
+    rb_ref, rb_hip = BasicReplayBuffer(N_), HipReplayBuffer(N_)
+    for rb in (rb_ref, rb_hip):
+        rb._is_action_continuous = True
+    rb_hip.device_for_batches = torch.device("cuda", 0)
+    gen = torch.Generator().manual_seed(6)
+    st = torch.randn(N_ + 1, S, generator=gen)
+    for i in range(N_):
+        kw = dict(state=st[i], action=space.low + (space.high - space.low) * torch.rand(A, generator=gen),
+                  reward=float(torch.randn((), generator=gen)), terminated=(i % 9 == 8), truncated=False,
+                  curr_available_actions=space, next_state=st[i + 1], next_available_actions=space)
+        rb_ref.push(**kw)
+        rb_hip.push(**kw)
+    torch.manual_seed(77)
+    noise = torch.stack([torch.stack([torch.normal(torch.zeros(B, A), torch.ones(B, A)) for _ in range(2)])
+                         for _ in range(R)])
+
+    class Replay:
+        calls = 0
+
+        def __call__(self, b, a, dev):
+            r, j = divmod(self.calls, 2)
+            Replay.calls += 1
+            return noise[r, j]
+
+        def rounds(self, first, n, b, a, dev):
+            Replay.calls += 2 * n
+            return noise[first:first + n].to(dev)
+
+    hip.impl.noise_source = Replay()
+    random.seed(31)
+    torch.manual_seed(77)
+    want = ref.learn(rb_ref)
+    random.seed(31)
+    got = hip.learn(rb_hip)
+    assert Replay.calls == 2 * R
+    for k in ("actor_loss", "critic_loss", "entropy_coef"):
+        torch.testing.assert_close(torch.tensor(got[k]), torch.tensor([float(x) for x in want[k]]),
+                                   rtol=5e-4, atol=5e-5, msg=k)
+    for name in ("_actor", "_critic", "_critic_target"):
+        for k, v in getattr(ref, name).state_dict().items():
+            torch.testing.assert_close(getattr(hip.impl, name).state_dict()[k].cpu(), v, rtol=2e-3,
+                                       atol=3e-5, msg=f"{name}.{k}")
