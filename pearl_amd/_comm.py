@@ -147,6 +147,18 @@ def check_exchange() -> None:
         N.check(N.lib().pa_comm_check(h))
 
 
+def check_exchange_after_sync() -> None:
+    """``check_exchange`` for the per-step data-parallel paths (FlatMlp.adam -> allreduce_sum_): a
+    no-op unless an exchange went through the native communicator since the last check.  Call it
+    AFTER a host synchronisation that covers that exchange (a loss ``.item()``, the ``tolist()`` at
+    the end of learn()): the poison word is written by the device, and only a completed step can
+    have set it.  Without a following sync the check happens before the next exchange at the
+    latest (``allreduce_sum_`` below)."""
+    if _state.get("unchecked"):
+        _state["unchecked"] = False
+        check_exchange()
+
+
 def allreduce_sum_(flat: torch.Tensor, force: bool = False) -> torch.Tensor:
     """SUM over the data-parallel group, in place.  Identity with a single rank unless ``force``
     (a 1-rank communicator still goes through RCCL: the bench's readiness run).  ONE message through
@@ -170,6 +182,7 @@ def allreduce_sum_(flat: torch.Tensor, force: bool = False) -> torch.Tensor:
         else:
             pieces = [(o, min(cap, n - o)) for o in range(0, n, cap)]     # (cap is a multiple of 64 floats)
         if cap <= 0 or ptr % 16 == 0:
+            _state["unchecked"] = True
             for off, cnt in pieces:
                 N.check(lib.pa_comm_allreduce_start(h, ptr + 4 * off, cnt, s))
                 N.check(lib.pa_comm_allreduce_wait(h, s))

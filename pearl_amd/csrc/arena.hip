@@ -14,6 +14,7 @@
 
 #include <atomic>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <utility>
 
@@ -559,11 +560,17 @@ void set_target_rows_mode(int rows) { g_target_rows.store(rows); }
 namespace {
 struct ScratchBuf { float* p = nullptr; size_t floats = 0; };
 std::mutex g_scratch_mu;
-std::map<std::pair<int, hipStream_t>, ScratchBuf> g_scratch;
+// keyed by (device, slot, stream): the null stream's handle is the same value on every device
+// (ADVICE r5), and a buffer must live on the device whose launches use it.  Entries of destroyed
+// streams stay until the process ends (a few KB each; a recycled handle value on the same device
+// simply reuses the buffer, which only that stream's launches touch).
+std::map<std::tuple<int, int, hipStream_t>, ScratchBuf> g_scratch;
 }  // namespace
 float* stream_scratch(int slot, hipStream_t s, size_t floats) {
   std::lock_guard<std::mutex> lock(g_scratch_mu);
-  ScratchBuf& b = g_scratch[std::make_pair(slot, s)];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { set_error("stream_scratch: hipGetDevice failed"); return nullptr; }
+  ScratchBuf& b = g_scratch[std::make_tuple(dev, slot, s)];
   if (floats <= b.floats) return b.p;
   if (b.p) {
     // only this stream's launches use the old buffer

@@ -25,15 +25,18 @@ class LinearRegression(nn.Module):
                  force_pinv: bool = False) -> None:
         super().__init__()
         assert 0 < gamma <= 1, f"gamma should be in (0, 1]. Got gamma={gamma} instead"
-        # force_pinv (linear_regression.py:138-157): torch.linalg.pinv of A + lambda I instead of inv.  With
-        # lambda > 0 that matrix is symmetric positive definite (A is a sum of w x x^T terms), its
-        # pseudo-inverse IS its inverse, and the fp64 SPD solve computes exactly that; with lambda = 0
-        # (a possibly singular A) the learner runs pa_linreg_pinv — eigenvalues by Jacobi rotations,
-        # torch's default cut-off — for systems up to order 72.
-        if force_pinv and not l2_reg_lambda > 0 and feature_dim + 1 > 72:
+        # force_pinv (linear_regression.py:138-157): torch.linalg.pinv of A + lambda I instead of inv.
+        # Every such system goes through pa_linreg_pinv — eigenvalues by Jacobi rotations in fp64,
+        # torch's default cut-off (eigenvalues at or below D * eps(float32) of the largest are dropped)
+        # — whatever lambda is: with lambda > 0 the matrix is positive definite and its pseudo-inverse
+        # is its inverse only while max eig(A) < lambda / (D eps), i.e. up to ~1e5 weighted samples
+        # at lambda = 1; beyond that torch zeroes the directions near lambda where an inverse keeps
+        # 1 / lambda, and inv_A / coefs / the UCB sigma would part from the reference.
+        # The kernel holds the system in one workgroup's LDS: order <= 72.
+        if force_pinv and feature_dim + 1 > 72:
             raise NotImplementedError(
-                "pearl_amd LinearRegression: force_pinv with l2_reg_lambda = 0 is built for feature_dim "
-                f"<= 71 (pa_linreg_pinv holds the system in one workgroup's LDS; got {feature_dim})")
+                "pearl_amd LinearRegression: force_pinv is built for feature_dim <= 71 "
+                f"(pa_linreg_pinv holds the system in one workgroup's LDS; got {feature_dim})")
         self._feature_dim = feature_dim
         self.gamma, self.l2_reg_lambda, self.force_pinv = gamma, l2_reg_lambda, force_pinv
         self.register_buffer("_A", torch.zeros(feature_dim + 1, feature_dim + 1))
@@ -98,8 +101,8 @@ class LinearRegression(nn.Module):
 
     @property
     def uses_pinv(self) -> bool:
-        """The pseudo-inverse kernel instead of the SPD solve (force_pinv on an unregularised system)."""
-        return bool(self.force_pinv) and not self.l2_reg_lambda > 0
+        """The pseudo-inverse kernel instead of the SPD solve (force_pinv, any lambda)."""
+        return bool(self.force_pinv)
 
     @property
     def A(self) -> Tensor:

@@ -222,6 +222,9 @@ class NeuralLinearBandit(PolicyLearner):
         with torch.no_grad():
             w.copy_(coefs[1:].to(w.device).view(1, -1))
             b.copy_(coefs[:1].to(b.device))
+        net = self._flat.get("net")
+        if net is not None:
+            net.frozen_reloaded()
 
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         net = self._net(len(batch))

@@ -20,6 +20,7 @@ from typing import Any, Dict, List, Optional
 import torch
 from torch import nn, optim
 
+from ... import _comm
 from ... import _native as N
 from ...action_representation_modules import ActionRepresentationModule
 from ...neural_networks.common.utils import xavier_init_weights
@@ -147,7 +148,9 @@ class ActorCriticBase(PolicyLearner):
     # ------------------------------------------------------------------ learn_batch (:309-366)
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         report = self._learn_batch_device(batch)
-        return {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in report.items()}
+        out = {k: (v.item() if isinstance(v, torch.Tensor) else v) for k, v in report.items()}
+        _comm.check_exchange_after_sync()     # (data parallel: a P2P peer that never answered)
+        return out
 
     def _learn_batch_device(self, batch: TransitionBatch) -> Dict[str, Any]:
         """learn_batch with the losses left on the device (no host synchronisation)."""
@@ -219,6 +222,7 @@ class ActorCriticBase(PolicyLearner):
                 for i, g in zip(dev_ix, got):
                     vals[i] = g
             report[k] = vals
+        _comm.check_exchange_after_sync()     # (after the tolist() above synchronised the call)
         return report
 
     # batch fields this learner's learn_batch never reads: learn() — which owns the batches it

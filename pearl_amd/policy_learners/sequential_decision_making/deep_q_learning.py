@@ -588,7 +588,11 @@ class DeepQLearning(PolicyLearner):
             allreduce_sum_(nat.flat["grad"])
         N.check(lib.pa_mlp_adam(mlp, step, stream))
         self._set_adam_steps(step)
-        return {"loss": losses[0].item()}
+        loss = losses[0].item()
+        if self._dp_world() > 1:
+            from ... import _comm
+            _comm.check_exchange_after_sync()
+        return {"loss": loss}
 
     def learn_batch(self, batch: TransitionBatch) -> Dict[str, Any]:
         """One TD(0) update on a preprocessed batch (deep_td_learning.py:333-360)."""
@@ -608,7 +612,11 @@ class DeepQLearning(PolicyLearner):
             allreduce_sum_(nat.flat["grad"])
             N.check(N.lib().pa_dqn_apply(nat.handle, step, stream))
         self._set_adam_steps(step)
-        return {"loss": nat.loss_buf[0].item()}  # the reference's per-step .item() (:359)
+        loss = nat.loss_buf[0].item()            # the reference's per-step .item() (:359)
+        if world > 1:
+            from ... import _comm
+            _comm.check_exchange_after_sync()    # (P2P exchange: a peer that never answered)
+        return {"loss": loss}
 
     def _arena_path_ok(self, replay_buffer: ReplayBuffer) -> bool:
         if not isinstance(replay_buffer, TensorBasedReplayBuffer) or replay_buffer.arena is None:

@@ -55,6 +55,11 @@ class FlatMlp:
         # step): they live in the flat buffers like any layer, but get no optimizer state entry and
         # no .grad, and whatever the engine's AdamW does to their slots is the caller's to overwrite
         self.frozen_last = bool(frozen_last)
+        # the engine's AdamW launch also writes the frozen layer's slots (it knows no per-layer
+        # ranges): after a step they hold optimizer-perturbed values until the owner reloads them
+        # (`frozen_reloaded`).  `ensure` — the entry every use of the network goes through — refuses
+        # a network whose frozen slots are stale instead of computing with them.
+        self._frozen_stale = False
         self.identity_layers = int(identity_layers)   # bit l: hidden layer l has no ReLU
         self.target_layers = target_layers
         # mlp_block's other forms (pa_mlp_desc.hidden_act / layer_norm): the hidden layers' nn.LayerNorm
@@ -192,7 +197,15 @@ class FlatMlp:
         sig.extend(p.data_ptr() for p in self._target_params())
         return tuple(sig)
 
+    def frozen_reloaded(self) -> None:
+        """The owner rewrote the frozen last layer's tensors since the last optimizer step."""
+        self._frozen_stale = False
+
     def ensure(self, batch_hint: int = 0) -> "FlatMlp":
+        if self.frozen_last and self._frozen_stale:
+            raise RuntimeError(
+                "pearl_amd FlatMlp: the frozen last layer was not reloaded after the last optimizer "
+                "step (its slots hold AdamW-perturbed values): reload it and call frozen_reloaded()")
         if FlatMlp.in_learn_loop and self.handle is not None and self._sig \
                 and batch_hint <= self.max_batch and getattr(self, "_loop_validated", False):
             return self
@@ -525,6 +538,7 @@ class FlatMlp:
         self._set_adam_steps(step)
         self._steps = step
         self._versions = self._flat_versions()     # our own kernels wrote the buffers: not "external"
+        self._frozen_stale = self.frozen_last
 
     # ------------------------------------------------------------------ data-parallel pairs
     @staticmethod

@@ -634,20 +634,22 @@ def test_optimizer_argument_is_honoured_or_refused():
 
 
 def test_force_pinv_is_honoured():
-    """linear_regression.py:138-157: force_pinv inverts A + lambda I with torch.linalg.pinv.  With
-    lambda > 0 the matrix is SPD and its pseudo-inverse is the inverse the HIP solve computes
-    (bandit_pinv_tiny pins that against the reference); with lambda = 0 the learner runs pa_linreg_pinv
-    (`uses_pinv`; bandit_pinv_singular_*), which holds systems up to order 72 — beyond that it says so."""
+    """linear_regression.py:138-157: force_pinv inverts A + lambda I with torch.linalg.pinv.  Every
+    such system runs pa_linreg_pinv (`uses_pinv`), whatever lambda is — torch's cut-off drops
+    eigen-directions near lambda once max eig(A) > lambda / (D eps), where an SPD inverse keeps
+    1 / lambda (bandit_pinv_tiny / bandit_pinv_singular_* pin it against the reference).
+    The kernel holds systems up to order 72 — beyond that the learner says so, for any lambda."""
     from pearl_amd import NeuralLinearBandit
     from pearl_amd.neural_networks.contextual_bandit.linear_regression import LinearRegression
     assert LinearRegression(feature_dim=4, force_pinv=True).force_pinv
-    assert not LinearRegression(feature_dim=4, force_pinv=True).uses_pinv
+    assert LinearRegression(feature_dim=4, force_pinv=True).uses_pinv
     lr = NeuralLinearBandit(feature_dim=5, hidden_dims=[8, 4], force_pinv=True,
                             l2_reg_lambda_linear=0.0).model._linear_regression_layer
     assert lr.force_pinv and lr.uses_pinv
     assert not LinearRegression(feature_dim=4, l2_reg_lambda=0.0).uses_pinv
-    with pytest.raises(NotImplementedError, match="feature_dim"):
-        LinearRegression(feature_dim=72, l2_reg_lambda=0.0, force_pinv=True)
+    for lam in (0.0, 1.0):
+        with pytest.raises(NotImplementedError, match="feature_dim"):
+            LinearRegression(feature_dim=72, l2_reg_lambda=lam, force_pinv=True)
 
 
 def test_neural_linear_regression_without_e2e_head_predicts_from_the_regression():

@@ -1216,6 +1216,34 @@ def test_linreg_pinv_kernel_is_torchs_pseudo_inverse(D, rank):
     torch.testing.assert_close(coefs_r, coefs_s, rtol=1e-5, atol=1e-6 * float(coefs_s.abs().max()))
 
 
+def test_linreg_pinv_with_a_ridge_drops_the_directions_torch_drops():
+    """force_pinv with lambda > 0 is NOT the inverse once max eig(A) exceeds
+    lambda / (D eps): torch.linalg.pinv's default cut-off (D * eps(float32) * largest eigenvalue)
+    then removes the eigen-directions of A + lambda I that sit at lambda — a rank-deficient A after
+    ~1e6 weighted samples — giving them weight 0 where an SPD inverse keeps 1 / lambda.
+    pa_linreg_pinv takes lambda and applies that cut-off: rank, inv_A and coefs are torch's."""
+    D, rank, lam = 40, 25, 1.0
+    d = D - 1
+    g = torch.Generator().manual_seed(17)
+    q, _ = torch.linalg.qr(torch.randn(D, D, dtype=torch.float64, generator=g))
+    ev = torch.zeros(D, dtype=torch.float64)
+    ev[:rank] = torch.logspace(3, 7, rank, dtype=torch.float64)     # max eig 1e7 > lam / (D eps) = 2.1e5
+    A = (q @ torch.diag(ev) @ q.t())
+    A = ((A + A.t()) / 2).float()
+    b = (A.double() @ torch.randn(D, dtype=torch.float64, generator=g)).float()
+    inv, coefs, got_rank = _pinv(A, b, lam, d)
+    want = _torch_pinv64(A, lam)
+    cut = D * 2.0 ** -23 * float(torch.linalg.eigvalsh(A.double() + lam * torch.eye(D, dtype=torch.float64)).max())
+    assert cut > lam + 1e-3, "the case must put lambda below torch's cut-off"
+    assert got_rank == rank                                  # the D - rank directions at lambda are dropped
+    torch.testing.assert_close(inv.double(), want, rtol=1e-4, atol=1e-6 * float(want.abs().max()))
+    wc = want @ b.double()
+    torch.testing.assert_close(coefs.double(), wc, rtol=1e-4, atol=1e-5 * float(wc.abs().max()))
+    # ... and it is far from the inverse there: 1 / lambda in the dropped directions
+    inv_s, _, _ = _solve(A, b.to(DEV), lam, d)
+    assert float((inv_s.double().cpu() - want).abs().max()) > 0.1
+
+
 @pytest.mark.parametrize("name", ["pinv_singular_tiny", "pinv_singular_small"])
 def test_bandit_force_pinv_on_a_singular_regression(name):
     """NeuralLinearBandit(force_pinv=True, l2_reg_lambda_linear=0) with fewer contexts than coefficients

@@ -313,13 +313,15 @@ def test_bandit_cfg5_20_steps_against_the_reference():
     nn_keys = [k for k in f64 if k.startswith("_nn_layers") or k.startswith("linear_layer_e2e")]
     check_params({k: sd[k] for k in nn_keys}, {k: fx["model_after"][k] for k in nn_keys},
                  {k: f64[k] for k in nn_keys}, 1e-3, K, "bandit cfg5 network")
-    # LinUCB moments: sums of 81 920 rank-1 terms; A and b against float64, relative to their scale
+    # LinUCB moments: sums of 81 920 rank-1 terms; A and b against float64, relative to their scale.
+    # A chained fp32 sum of n terms carries ~sqrt(n) 2^-24 = 1.7e-5 of the terms' scale; measured
+    # 1.7e-6 of max |A| here, MKL's blocked sums 1.2e-7: held to 4e-6 (or 4x the reference's).
     for key in ("_linear_regression_layer._A", "_linear_regression_layer._b"):
         scale = float(f64[key].abs().max())
         e_hip = float((sd[key].double() - f64[key]).abs().max()) / scale
         e_ref = float((fx["model_after"][key].double() - f64[key]).abs().max()) / scale
         print(f"  {key}: max error / max |.|  HIP {e_hip:.2e}  reference {e_ref:.2e}")
-        assert e_hip <= K_PARAM * e_ref + 2.0 ** -22
+        assert e_hip <= max(K_PARAM * e_ref, 4e-6)
     # what the regression is for: sigma and mu of fresh contexts
     xq = FI.normalish((64, F), cfg["input_seed"] * 100 + 99).to(DEV)
     with torch.no_grad():
