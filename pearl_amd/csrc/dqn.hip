@@ -774,6 +774,22 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
   a.p[2].kind = 2;
   t0 += a.p[2].tiles_n;
   a.total_tiles = t0;
+  // TIMING EXPERIMENT ONLY (results are wrong: the left-out layers never step): what a launch costs
+  // that carries only the tiles the next round's layer 1 waits for (1: W1), or only the ones whose
+  // operands exist before dZ1 does (2: W2 + w3) — the two halves of a weight-gradient launch split
+  // by dependency (profiles/r06_b_dw_by_dependency.txt)
+  static const int dw_only = env_int("PEARL_AMD_DEBUG_DW_ONLY", 0);
+  if (dw_only == 1) {
+    a.p[0] = a.p[1];
+    a.p[0].tile0 = 0;
+    a.nprob = 1;
+    a.total_tiles = (int)ceil_div(d.hidden1, TM) * a.p[0].tiles_n;
+  } else if (dw_only == 2) {
+    a.p[1] = a.p[2];
+    a.p[1].tile0 = (int)ceil_div(d.hidden2, TM) * a.p[0].tiles_n;
+    a.nprob = 2;
+    a.total_tiles = a.p[1].tile0 + a.p[1].tiles_n;
+  }
   a.B = B;
   a.prof = (h->prof_round < 0 || h->prof_round == h->cur_round) ? h->prof_dw : nullptr;
   a.ad.absd = h->absd; a.ad.nabs = B; a.ad.inv_B = (float)(1.0 / (double)B);

@@ -215,6 +215,15 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s, const DwKe
     if (ks > 8) ks = 8;
     if (ks < 1) ks = 1;
   }
+  {
+    // TIMING EXPERIMENT ONLY: a forced slice count for the DQN chain's launch (see
+    // PEARL_AMD_DEBUG_DW_ONLY in dqn.hip) — whether the CUs a dependency split frees buy anything
+    static const int force_ks = []() {
+      const char* v = getenv("PEARL_AMD_DEBUG_DW_KS");
+      return v ? atoi(v) : 0;
+    }();
+    if (force_ks >= 1 && force_ks <= 8 && a.B == 1024) ks = force_ks;
+  }
   a.ksplit = ks;
   a.kscratch = nullptr;
   a.ktickets = nullptr;

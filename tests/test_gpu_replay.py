@@ -271,8 +271,25 @@ def test_presampled_index_lists_feed_sample_in_order(golden):
     assert rb.presample(3, B)
     rb.sample(B // 2)
     assert rb._presampled is None
-    # python-sampler buffers never presample (their index stream is Python's `random`)
-    assert not fill_arena_buffer(fx, "python").presample(2, 8)
+    # python-sampler buffers presample by drawing the lists of the next calls NOW, from Python's
+    # `random` — the stream `rounds` consecutive sample() calls (and the reference's learn loop,
+    # tensor_based_replay_buffer.py:276) consume: same lists, same generator state afterwards
+    pa, pb = fill_arena_buffer(fx, "python"), fill_arena_buffer(fx, "python")
+    random.seed(33)
+    assert pa.presample(2, 8)
+    got = []
+    for _ in range(2):
+        pa.sample(8)
+        got.append(pa.last_indices.cpu().tolist())
+    state_a = random.getstate()
+    random.seed(33)
+    want = []
+    for _ in range(2):
+        pb.sample(8)
+        want.append(pb.last_indices.cpu().tolist())
+    assert got == want and random.getstate() == state_a
+    random.seed(33)
+    assert want == [random.sample(range(len(pb)), 8) for _ in range(2)]
 
 
 @pytest.mark.parametrize("variant", ["reward_only", "with_terminated_fn"])

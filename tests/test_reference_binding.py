@@ -164,8 +164,11 @@ def _stand_alone(ref_learner):
     """What PearlAgent.__init__ would give the reference's learner (pearl_agent.py:95), without
     the agent: on the GPU box the agent would move it to cuda:0 (utils/device.py:48-59), and the
     comparison wants the reference's own CPU arithmetic."""
+    from pearl.history_summarization_modules.identity_history_summarization_module import (
+        IdentityHistorySummarizationModule)
     from pearl.safety_modules.identity_safety_module import IdentitySafetyModule
     ref_learner.safety_module = IdentitySafetyModule()
+    ref_learner.set_history_summarization_module(IdentityHistorySummarizationModule())
 
 
 def _ppo_pair(S=6, A=4, hidden=(24, 24), rounds=5, batch=32, eps=0.1):
