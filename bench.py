@@ -274,7 +274,7 @@ def main():
 
     def read_timers():
         out = {}
-        for name in ("target", "target_l1", "l1_dual", "online_l1", "gather", "gather_nox", "gather_x", "sample",
+        for name in ("allreduce", "target", "target_l1", "l1_dual", "online_l1", "gather", "gather_nox", "gather_x", "sample",
                      "online_l2", "head", "bwd_dx", "rowpass", "bwd_dw", "adamw", "soft_update"):
             ms, cnt, units = C.c_double(), C.c_int64(), C.c_int64()
             N.check(N.lib().pa_dqn_get_timing(nat.handle, name.encode(), C.byref(ms), C.byref(cnt)))
@@ -511,6 +511,17 @@ def main():
                 N.check(N.lib().pa_comm_info(comm, C.byref(n_seen), C.byref(me)))
                 info["ranks_observed"] = n_seen.value
             info["allreduce_floats_per_round"] = int(pl._native.flat["grad"].numel())
+            ar = timers.get("allreduce")
+            if ar:
+                # per-round exchange time as the learner stream sees it (HIP events around
+                # allreduce_start .. allreduce_wait, sampled: one mid-window round in forty), and
+                # what it is of a round: the first real N-GPU run yields the overlap figure directly
+                info["exchange_us"] = ar["avg_us"]
+                info["exchange_rounds_timed"] = ar["n"]
+                info["exchange_frac_of_round"] = ar["avg_us"] / (1e3 * dt / args.steps)
+                info["exchange_GBps_per_rank"] = 4.0 * info["allreduce_floats_per_round"] / (ar["avg_us"] * 1e-6) / 1e9
+            info["exchange_stream"] = "learner stream (between the weight-gradient launch and AdamW; the " \
+                                      "target pass of the following rounds runs beside it on the side stream)"
             line["comm"] = info
         if steady is not None:
             line["steady_state"] = steady

@@ -566,6 +566,75 @@ def bench_push(steps, cpu_seconds):
                              "sample": f"{n} oracle (deque of per-transition tensors) pushes"}}
 
 
+def bench_gather(steps, cpu_seconds):
+    """The sample / gather kernel at an HBM-bound size: inside the DQN loop a
+    window gather moves 22 MB per launch and is launch-bound; here ONE launch gathers 262 144 random
+    rows of a 1 M-row cfg2 arena — every stored column of a transition, as
+    `_create_transition_batch` returns them (tensor_based_replay_buffer.py:290-400) — 628 MB of
+    algorithmic traffic (each byte read once, written once), and the learn loop's own form
+    (next_state + reward + flags + x = state || one-hot(action): SURVEY.md §8d's 2 132 B) at the
+    same row count.  HIP events on the launch stream, best and median of `steps` launches."""
+    from pearl_amd import BasicReplayBuffer, _native as N
+    S, A, NR, ROWS = 128, 16, 1_000_000, 262_144
+    sp = dspace(A)
+    rb = BasicReplayBuffer(NR, sampler="device")
+    rb.device_for_batches = DEV
+    g = torch.Generator(device=DEV).manual_seed(0)
+    chunk = 250_000
+    for c in range(0, NR, chunk):
+        st = torch.randn(chunk + 1, S, device=DEV, generator=g)
+        ids = torch.arange(c, c + chunk, device=DEV)
+        rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                     terminated=(ids % 50 == 0), truncated=torch.zeros(chunk, dtype=torch.bool, device=DEV),
+                     next_state=st[1:], curr_available_actions=sp, next_available_actions=sp,
+                     max_number_actions=A)
+    idx = torch.randperm(NR, device=DEV, generator=g)[:ROWS].contiguous()
+    z = rb._layout
+    row = 4 * z.state_dim * 2 + 8 * z.action_elems + 4 + 2 + 2 * z.max_actions * (4 * z.avail_dim + 1)
+    n = max(10, min(int(steps), 50))
+
+    def run(fn):
+        fn()
+        sync()
+        ts = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        ts.sort()
+        return ts[0], ts[len(ts) // 2]
+
+    best, med = run(lambda: rb._gather_batch(idx))
+    # the learn loop's form: pa_arena_gather_device with x = state || one-hot(action) and no tables
+    x = torch.empty(ROWS, S + A, device=DEV)
+    nxt = torch.empty(ROWS, S, device=DEV)
+    rew = torch.empty(ROWS, device=DEV)
+    term = torch.empty(ROWS, dtype=torch.uint8, device=DEV)
+    out = N.BatchOut()
+    out.x, out.next_state, out.reward_f32, out.terminated = x.data_ptr(), nxt.data_ptr(), rew.data_ptr(), term.data_ptr()
+    out.rep_dim, out.rep_onehot = A, 1
+    loop_row = (4 * S + 8 + 4 * S + 4 + 1) + (4 * (S + A) + 4 * S + 4 + 1)       # read + written = 2 130 B
+    best2, med2 = run(lambda: rb.arena.gather_device(idx, out))
+    ach = 2 * row * ROWS / med / 1e9
+    return {"config": f"gather: {ROWS} random rows of a 1M-row cfg2 arena in ONE launch",
+            "metric": "transitions/s through one gather launch (every stored column, tables and masks included)",
+            "value": ROWS / med, "steps": n, "ms_per_step": 1e3 * med,
+            "roofline": {"bound": "hbm", "kernel": "gather_kernel", "achieved": ach, "peak": 8000.0,
+                         "unit": "GB/s", "frac": ach / 8000.0, "frac_of_achievable_6300": ach / 6300.0,
+                         "bytes_per_transition": 2 * row, "launch_bytes": 2 * row * ROWS,
+                         "best_GBps": 2 * row * ROWS / best / 1e9, "traffic": None,
+                         "scope": "median of the timed launches; rows are 512-byte contiguous runs at random "
+                                  "offsets of a 1.2 GB arena, written to contiguous outputs"},
+            "learn_loop_form": {"what": "next_state + reward + terminated + x = state || one-hot(action) "
+                                        "(the window gather of pa_dqn_learn), same rows",
+                                "bytes_per_transition": loop_row, "ms": 1e3 * med2,
+                                "GBps": loop_row * ROWS / med2 / 1e9, "best_GBps": loop_row * ROWS / best2 / 1e9,
+                                "frac": loop_row * ROWS / med2 / 8e12}}
+
+
 def bench_feeder(steps, cpu_seconds):
     """Batched observe (second half; pearl_agent.py:169-211): E = 4096 cfg2-shaped
     environments that live on the device, one batched epsilon-greedy act + one push_many per vector
@@ -835,7 +904,8 @@ def main():
     torch.cuda.set_device(DEV)
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("dsac", bench_dsac), ("ppo", bench_ppo), ("bandit", bench_bandit),
-                     ("double_dqn", bench_double_dqn), ("push", bench_push), ("feeder", bench_feeder)):
+                     ("double_dqn", bench_double_dqn), ("push", bench_push), ("feeder", bench_feeder),
+                     ("gather", bench_gather)):
         if args.only and name not in args.only.split(","):
             continue
         out = fn(args.steps, args.cpu_seconds)

@@ -368,7 +368,9 @@ int pa_comm_allreduce_wait(void* comm, void* stream);
  * level | 4 (with level 1): also "rowpass" and "bwd_dw" — the online chain's two launches — of one
  * mid-window round of every sampled window of the overlapped loop (bench.py's roofline.chain). */
 int pa_dqn_enable_timing(pa_dqn* h, int32_t level);
-/* names: "target" (every 4th launch at level 1), "target_l1", "l1_dual", "online_l1", "gather",
+/* names: "allreduce" (data-parallel loop: allreduce_start .. allreduce_wait on the learner stream, one
+ * mid-window round per sampled window at level 1),
+ * "target" (every 4th launch at level 1), "target_l1", "l1_dual", "online_l1", "gather",
  * "sample", "online_l2", "head", "bwd_dx", "bwd_dw", "adamw", "soft_update", "learn"
  * -> average milliseconds per timed launch and the number of timed launches */
 int pa_dqn_get_timing(pa_dqn* h, const char* name, double* avg_ms, int64_t* count);

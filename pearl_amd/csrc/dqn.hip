@@ -1804,11 +1804,17 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // exchange hides behind the target work of the side stream.
       rc = chain_back(h, xj, B, yj, tagged, args->adam_step0 + round + 1, -world, lo, 0, s, split_rp);
       if (rc != PA_OK) return rc;
-      PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
-                 PA_ERR_HIP, "allreduce_start hook failed");
-      if (args->allreduce_wait)
-        PA_REQUIRE(args->allreduce_wait(args->allreduce_ctx, stream) == 0, PA_ERR_HIP,
-                   "allreduce_wait hook failed");
+      {
+        // "allreduce": the gradient exchange as the learner stream sees it — from the point the
+        // stream reaches allreduce_start to the point its wait on the exchange is over — on one
+        // mid-window round of every sampled window (level 1; bench.py's comm.exchange_us)
+        ScopedTimer tm_ar(h, "allreduce", s, (sample_w && j == (w > 1 ? w / 2 : 0)) ? 1 : 2, 1, B);
+        PA_REQUIRE(args->allreduce_start(args->allreduce_ctx, h->bufs.grad, h->P, stream) == 0,
+                   PA_ERR_HIP, "allreduce_start hook failed");
+        if (args->allreduce_wait)
+          PA_REQUIRE(args->allreduce_wait(args->allreduce_ctx, stream) == 0, PA_ERR_HIP,
+                     "allreduce_wait hook failed");
+      }
       rc = run_adamw(h, args->adam_step0 + round + 1, soft_next, s);
       if (rc != PA_OK) return rc;
     }
