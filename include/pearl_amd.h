@@ -895,6 +895,17 @@ int pa_dueling_q(const float* v, const float* adv_q, int32_t Q, const float* adv
 int pa_dueling_grad(const float* dq, int32_t B, int32_t M, float* d_adv_rows, void* stream);
 int pa_dueling_feat_grad(const float* dX, int32_t ldx, int32_t B, int32_t M, int32_t H,
                          int32_t accumulate, float* dfeat, int32_t ldf, void* stream);
+/* The CQL term (utils/functional_utils/learning/loss_fn_utils.py:17-72) on the Q networks that
+ * evaluate every action from one pass.  Dueling: the all-actions table Q_all[b, i] = V + A_avail[b, i]
+ * - mean_k A_avail[b, k] reads the taken-action forward's own advantage rows, so ONE kept pass serves
+ * the MSE term and the table; pa_dueling_cql_grad adds their gradients: d_value[b] = dq[b] +
+ * sum_i dq_all[b, i]; d_adv rows [0, B) = dq; rows B + b M + i = -dq[b] / M + dq_all[b, i] -
+ * (sum_k dq_all[b, k]) / M.  Multi-head: the table is rep[b, i, :] . f[b, :] (pa_rows_bmm);
+ * pa_rows_bmm_t is its transpose, df[b, j] (+)= sum_i dq_all[b, i] rep[b, i, j]. */
+int pa_dueling_cql_grad(const float* dq, const float* dq_all, int32_t B, int32_t M, float* d_adv_rows,
+                        float* d_value, void* stream);
+int pa_rows_bmm_t(const float* dq_all, const float* rep, int64_t rep_bstride, int32_t B, int32_t Q,
+                  int32_t A, int32_t accumulate, float* df, int32_t ldf, void* stream);
 
 /* SquareCBExploration.act's probability table (squarecb_exploration.py:59-115), one row per
  * context: p_a = 1 / (A + gamma (max_a v - v_a)), the arg-max entry rewritten to 1 - (sum of the

@@ -109,6 +109,17 @@ QNET_CONFIGS = {
                            network="vanilla", learner="cql"),
     "cql_layernorm_small": dict(S=16, A=6, hidden=[64, 48], N=300, B=64, rounds=8, dynamic=False,
                                 network="vanilla", learner="cql", use_layer_norm=True),
+    # ... and on the other QValueNetwork types compute_cql_loss accepts (loss_fn_utils.py:17-72 works
+    # on any get_q_values; round 6): multi-head (one forward, the table is a bmm with the one-hot
+    # actions) and dueling (the table's advantage mean runs over the queried actions themselves)
+    "cql_multihead_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=True,
+                               network="multihead", learner="cql"),
+    "cql_multihead_small": dict(S=16, A=6, hidden=[64, 48], N=300, B=64, rounds=8, dynamic=False,
+                                network="multihead", learner="cql"),
+    "cql_dueling_tiny": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=11, dynamic=True,
+                             network="dueling", learner="cql"),
+    "cql_dueling_small": dict(S=16, A=6, hidden=[32, 32], N=300, B=64, rounds=8, dynamic=False,
+                              network="dueling", learner="cql"),
 }
 NETWORK_TYPES = {"vanilla": VanillaQValueNetwork, "multihead": VanillaQValueMultiHeadNetwork,
                  "dueling": DuelingQValueNetwork}

@@ -485,6 +485,9 @@ SIGNATURES = {
     "pa_dueling_grad": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "pa_dueling_feat_grad": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                        C.c_int32, _P]),
+    "pa_dueling_cql_grad": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "pa_rows_bmm_t": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                C.c_int32, _P]),
     "pa_squarecb_probs": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                     C.c_float, C.c_float, _P, _P, _P]),
     "pa_gauss_awr_head": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, _P, _P, C.c_int32, C.c_int32,

@@ -14,6 +14,7 @@
 //   pa_dueling_q        Q = V + A - mean(A)  (q_value_networks.py:474-506)
 //   pa_dueling_grad     gradient of that for the taken-action rows + the available-action rows
 //   pa_dueling_feat_grad  sum of the advantage tower's input gradients over the rows of a state
+//   pa_dueling_cql_grad, pa_rows_bmm_t   the CQL term's all-actions table on dueling / multi-head nets
 #include <math.h>
 
 #include "common.hpp"
@@ -162,6 +163,46 @@ __global__ __launch_bounds__(256) void dueling_grad_kernel(const float* __restri
     const int b = (int)((e - B) / M);
     d_adv[e] = -(dq[b] / (float)M);
   }
+}
+
+// The CQL term on a dueling network (loss_fn_utils.py:52-58 calls get_q_values(state, curr_available
+// actions) with no separate available set: Q_all[b, i] = V + A_avail[b, i] - mean_k A_avail[b, k]) next
+// to the MSE term's taken-action forward: both read the SAME advantage rows, so one kept pass serves
+// both and the gradients add —
+//   d V[b]          = dq[b] + sum_i dqa[b, i]
+//   d A_taken[b]    = dq[b]
+//   d A_avail[b, i] = -dq[b] / M + dqa[b, i] - (sum_k dqa[b, k]) / M
+__global__ __launch_bounds__(256) void dueling_cql_grad_kernel(const float* __restrict__ dq,
+                                                               const float* __restrict__ dqa, int B,
+                                                               int M, float* __restrict__ d_adv,
+                                                               float* __restrict__ d_v) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)B * (1 + M);
+  if (e >= total) return;
+  const int b = e < B ? (int)e : (int)((e - B) / M);
+  float s = 0.f;
+  for (int k = 0; k < M; ++k) s += dqa[(int64_t)b * M + k];
+  if (e < B) {
+    d_adv[e] = dq[e];
+    d_v[e] = dq[e] + s;
+  } else {
+    d_adv[e] = (dqa[e - B] - s / (float)M) - dq[b] / (float)M;
+  }
+}
+
+// The transpose of rows_bmm for the backward of a multi-head table: df[b, j] (+)= sum_i dqa[b, i] rep[b, i, j]
+__global__ __launch_bounds__(256) void rows_bmm_t_kernel(const float* __restrict__ dqa,
+                                                         const float* __restrict__ rep,
+                                                         int64_t rep_bstride, int B, int Q, int A,
+                                                         int accumulate, float* __restrict__ df, int ldf) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * A) return;
+  const int b = (int)(e / A), j = (int)(e - (int64_t)b * A);
+  const float* r = rep + (int64_t)b * rep_bstride + j;
+  float s = 0.f;
+  for (int i = 0; i < Q; ++i) s = fmaf(dqa[(int64_t)b * Q + i], r[(int64_t)i * A], s);
+  float* dst = df + (int64_t)b * ldf + j;
+  *dst = accumulate ? (*dst + s) : s;
 }
 
 // dfeat[b, :] (+)= dX[b, :H] + sum_i dX[B + b M + i, :H]   (in row order)
@@ -316,6 +357,27 @@ extern "C" int pa_dueling_grad(const float* dq, int32_t B, int32_t M, float* d_a
   PA_REQUIRE(dq && d_adv_rows && B > 0 && M >= 0, PA_ERR_INVALID, "pa_dueling_grad: bad argument");
   hipLaunchKernelGGL(dueling_grad_kernel, dim3(grid_for((int64_t)B * (1 + M))), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dq, B, M, d_adv_rows);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_dueling_cql_grad(const float* dq, const float* dq_all, int32_t B, int32_t M,
+                                   float* d_adv_rows, float* d_value, void* stream) {
+  PA_REQUIRE(dq && dq_all && d_adv_rows && d_value && B > 0 && M > 0, PA_ERR_INVALID,
+             "pa_dueling_cql_grad: bad argument");
+  hipLaunchKernelGGL(dueling_cql_grad_kernel, dim3(grid_for((int64_t)B * (1 + M))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dq, dq_all, B, M, d_adv_rows, d_value);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
+extern "C" int pa_rows_bmm_t(const float* dq_all, const float* rep, int64_t rep_bstride, int32_t B,
+                             int32_t Q, int32_t A, int32_t accumulate, float* df, int32_t ldf,
+                             void* stream) {
+  PA_REQUIRE(dq_all && rep && df && B > 0 && Q > 0 && A > 0, PA_ERR_INVALID, "pa_rows_bmm_t: bad argument");
+  hipLaunchKernelGGL(rows_bmm_t_kernel, dim3(grid_for((int64_t)B * A)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dq_all, rep, rep_bstride, B, Q, A, accumulate,
+                     df, ldf);
   PA_LAUNCH_CHECK();
   return PA_OK;
 }

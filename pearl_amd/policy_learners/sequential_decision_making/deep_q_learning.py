@@ -166,10 +166,6 @@ class DeepQLearning(PolicyLearner):
             lin = spec["linears"]
             self._fused = (spec["plain"] and len(lin) == 3 and lin[0].out_features <= 256
                            and lin[1].out_features <= 256 and lin[2].out_features == 1)
-        if is_conservative and not isinstance(self._Q, VanillaQValueNetwork):
-            raise NotImplementedError(
-                "pearl_amd DeepQLearning: the CQL term (loss_fn_utils.py:17-72) is built for "
-                f"VanillaQValueNetwork (any depth / form), not for {type(self._Q).__name__}")
         self._Q_target: VanillaQValueNetwork = copy.deepcopy(self._Q)
         if optimizer is not None:
             # (deep_td_learning.py:183-185: used as handed over; see accept_optimizer for what the HIP

@@ -991,7 +991,9 @@ QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", 
          "layernorm_tiny", "layernorm_small", "layernorm_multihead_tiny", "leaky_tiny",
          "tanh_layernorm_small", "softplus_tiny", "sigmoid_tiny",
          # is_conservative beyond the fused shape: B + B A rows through the generic engine
-         "cql_deep3_tiny", "cql_layernorm_small"]
+         "cql_deep3_tiny", "cql_layernorm_small",
+         # ... and on the other QValueNetwork types (round 6)
+         "cql_multihead_tiny", "cql_multihead_small", "cql_dueling_tiny", "cql_dueling_small"]
 
 
 def make_qnet_learner(fx):
