@@ -1591,18 +1591,31 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       return arena_gather_device(arena, h->idx_all + (int64_t)r * B, rows, &o, s,
                                  gen ? h->sig : nullptr, gen);
     };
+    // (round 6, profiles/r06_c_first_window.txt) two orders / forms of the call's first chain launch:
+    // PEARL_AMD_HEAD_EARLY (default 1): the head goes out right behind the gather of x, BEFORE the side
+    // stream's gather / U / first target piece (the host is the pacemaker of a call's first 50 us:
+    // each launch costs it ~5 us, and the forward half needs nothing from the side stream) — a 1-round
+    // call 142.9 -> 135.9 us, a 20-round call 845 -> 835 us; PEARL_AMD_FIRST_UNSPLIT=1: the call's very
+    // first row pass as ONE launch that waits for its targets inside (tagged y) instead of forward +
+    // backward launches — measured, no gain (141.5 / 842 us), off
+    static const bool head_early = env_int("PEARL_AMD_HEAD_EARLY", 1) != 0;
+    static const bool first_unsplit = env_int("PEARL_AMD_FIRST_UNSPLIT", 0) != 0;
     auto emit_head = [&]() -> int {
       head_emitted = true;
       if (no_chain_dbg) return PA_OK;
       h->cur_round = r;
       front_emitted = true;
-      return chain_front(h, xwin, B, h->yw[p], true, gw_chain, s, true);
+      return chain_front(h, xwin, B, h->yw[p], true, gw_chain, s, !first_unsplit);
     };
     // (x of the call's first window: it needs nothing from the side stream, so it goes out first —
     // one launch ahead of the side stream's critical gather -> U -> first target piece)
     if (overlap && k == 0) {
       rc = emit_gather_x();
       if (rc != PA_OK) return rc;
+      if (head_early && !dbl) {
+        rc = emit_head();
+        if (rc != PA_OK) return rc;
+      }
     }
     // ---- side stream: target inputs of the window
     {
@@ -1763,7 +1776,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const float* xj = xwin + (int64_t)j * B * h->IN;
       const float* yj = h->yw[p] + (int64_t)j * B;
       float* lo = args->losses_out ? args->losses_out + round : nullptr;
-      const bool split_rp = overlap && j == 0;
+      const bool split_rp = overlap && j == 0 && !(k == 0 && first_unsplit);
       if (dbl) {
         // Q_target(s', argmax_a Q_online(s', a)) and the Bellman targets of THIS round, with the
         // online parameters as the previous round left them
