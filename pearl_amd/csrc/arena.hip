@@ -311,6 +311,148 @@ __global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
   }
 }
 
+// ---- the same gather for launches that are HBM-bound (tens of thousands of rows) -----------------
+// gather_kernel keeps ONE transition's bytes in flight per wave (its 1 KiB state || next_state load,
+// then a dependent chain of small loads): right for the learn loop's 10 240-row window gathers, which
+// are launch-bound, and 0.31-0.49 of the achievable 6.3 TB/s once a launch moves hundreds of MB
+// (profiles/r06_d_gather_hbm_bound.txt).  Here a wave takes RPW = 4 transitions: their four indices by
+// one load (lane r reads index r), their four state || next_state rows by four loads issued back to
+// back before any store, and every small column by a 16-lane group per transition — all four rows'
+// action / reward / flag / table loads leave in the same instructions.  Same bytes, same values.
+template <int GW>
+__device__ __forceinline__ void copy_bytes_group(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+                                                 int nbytes, int l) {
+  if (((nbytes | (int)(uintptr_t)dst | (int)(uintptr_t)src) & 15) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int i = l; i < (nbytes >> 4); i += GW) d4[i] = s4[i];
+  } else if (((nbytes | (int)(uintptr_t)dst | (int)(uintptr_t)src) & 3) == 0) {
+    const uint32_t* s1 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d1 = reinterpret_cast<uint32_t*>(dst);
+    for (int i = l; i < (nbytes >> 2); i += GW) d1[i] = s1[i];
+  } else {
+    for (int i = l; i < nbytes; i += GW) dst[i] = src[i];
+  }
+}
+
+constexpr int GATHER_RPW = 4;
+__global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs g) {
+  constexpr int RPW = GATHER_RPW, GW = 64 / RPW;
+  const int lane = threadIdx.x & 63;
+  const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+  if (g.signal_flag && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(g.signal_flag, g.signal_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (b0 >= g.B) return;
+  long long mine = -1;
+  if (lane < RPW && b0 + lane < g.B) {
+    mine = g.head + g.idx[b0 + lane];
+    if (mine >= g.capacity) mine -= g.capacity;
+  }
+  long long slot[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) slot[r] = __shfl(mine, r);
+  const int R0 = g.o.rep_dim;
+  // ---- the big rows (the host takes this kernel only when gather_kernel's `pair` condition holds)
+  {
+    const int half = lane >> 5, l = lane & 31;
+    const int n16 = g.state_bytes >> 4;
+    for (int i = l; i < n16; i += 32) {
+      float4 v[RPW];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if (slot[r] < 0) continue;
+        const uint8_t* base = half ? reinterpret_cast<const uint8_t*>(g.c.next_state)
+                                   : reinterpret_cast<const uint8_t*>(g.c.state);
+        v[r] = reinterpret_cast<const float4*>(base + slot[r] * g.state_bytes)[i];
+      }
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        if (slot[r] < 0) continue;
+        const int64_t b = b0 + r;
+        if (half) {
+          reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.next_state) + b * g.state_bytes)[i] = v[r];
+        } else {
+          if (g.o.state)
+            reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.state) + b * g.state_bytes)[i] = v[r];
+          if (g.o.x) reinterpret_cast<float4*>(g.o.x + b * (g.S + R0))[i] = v[r];
+        }
+      }
+    }
+  }
+  // ---- everything else: one 16-lane group per transition
+  const int grp = lane / GW, l = lane - grp * GW;
+  const int64_t b = b0 + grp;
+  const long long sl = slot[0] * (grp == 0) + slot[1] * (grp == 1) + slot[2] * (grp == 2) + slot[3] * (grp == 3);
+  if (b >= g.B || sl < 0) return;
+  const uint8_t* act = g.c.action + sl * g.action_bytes;
+  if (g.o.action)
+    copy_bytes_group<GW>(reinterpret_cast<uint8_t*>(g.o.action) + b * g.action_bytes, act, g.action_bytes, l);
+  const uint8_t* rw = g.c.reward + sl * g.reward_bytes;
+  if (g.o.reward)
+    copy_bytes_group<GW>(reinterpret_cast<uint8_t*>(g.o.reward) + b * g.reward_bytes, rw, g.reward_bytes, l);
+  if (l == 0) {
+    if (g.o.terminated) g.o.terminated[b] = g.c.terminated[sl];
+    if (g.o.truncated) g.o.truncated[b] = g.c.truncated[sl];
+    if (g.o.cost) g.o.cost[b] = g.c.cost[sl];
+    if (g.o.reward_f32) {
+      float r;
+      if (g.reward_dtype == PA_F32) r = *reinterpret_cast<const float*>(rw);
+      else if (g.reward_dtype == PA_F64) r = (float)*reinterpret_cast<const double*>(rw);
+      else r = (float)load_index_value(rw, g.reward_dtype);
+      g.o.reward_f32[b] = r;
+    }
+  }
+  if (g.A > 0) {
+    if (g.o.curr_avail)
+      copy_bytes_group<GW>(reinterpret_cast<uint8_t*>(g.o.curr_avail) + b * g.avail_bytes,
+                           reinterpret_cast<const uint8_t*>(g.c.curr_avail) + sl * g.avail_bytes,
+                           g.avail_bytes, l);
+    if (g.o.next_avail)
+      copy_bytes_group<GW>(reinterpret_cast<uint8_t*>(g.o.next_avail) + b * g.avail_bytes,
+                           reinterpret_cast<const uint8_t*>(g.c.next_avail) + sl * g.avail_bytes,
+                           g.avail_bytes, l);
+    if (g.o.curr_mask)
+      copy_bytes_group<GW>(g.o.curr_mask + b * g.mask_bytes, g.c.curr_mask + sl * g.mask_bytes,
+                           g.mask_bytes, l);
+    if (g.o.next_mask)
+      copy_bytes_group<GW>(g.o.next_mask + b * g.mask_bytes, g.c.next_mask + sl * g.mask_bytes,
+                           g.mask_bytes, l);
+  }
+  const int R = g.o.rep_dim;
+  if (g.o.x) {
+    float* xrow = g.o.x + b * (g.S + R);
+    if (g.o.rep_onehot) {
+      const int64_t a = load_index_value(act, g.action_dtype);
+      for (int j = l; j < R; j += GW) xrow[g.S + j] = (j == a) ? 1.0f : 0.0f;
+    } else {
+      for (int j = l; j < R; j += GW) {
+        float v;
+        const uint8_t* p = act + (int64_t)j * (g.action_bytes / g.action_elems);
+        if (g.action_dtype == PA_F32) v = *reinterpret_cast<const float*>(p);
+        else if (g.action_dtype == PA_F64) v = (float)*reinterpret_cast<const double*>(p);
+        else v = (float)load_index_value(p, g.action_dtype);
+        xrow[g.S + j] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    float* rep_out = which ? g.o.curr_avail_rep : g.o.next_avail_rep;
+    if (!rep_out || g.A <= 0) continue;
+    const float* na = (which ? g.c.curr_avail : g.c.next_avail) + sl * (int64_t)(g.A * g.avail_dim);
+    float* orow = rep_out + b * g.A * R;
+    if (g.o.rep_onehot) {
+      for (int e = l; e < g.A * R; e += GW) {
+        const int i = e / R, j = e - i * R;
+        const int64_t a = (int64_t)na[i * g.avail_dim];
+        orow[e] = (j == a) ? 1.0f : 0.0f;
+      }
+    } else {
+      for (int e = l; e < g.A * R; e += GW) orow[e] = na[e];
+    }
+  }
+}
+
 // --------------------------------------------------------------------------
 // Philox4x32-10 and the without-replacement index sampler: sampler.hpp
 // Block r of the grid draws the sample of round r (Philox counter offset + r) into
@@ -456,7 +598,20 @@ int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa
     }
   }
   if (B == 0) return PA_OK;
-  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, g);
+  // Launches that move enough bytes to be HBM-bound take four transitions per wave
+  // (gather_multi_kernel); PEARL_AMD_GATHER_MULTI_MINB: the row count from which (default 32768,
+  // 0 = never).  Needs gather_kernel's `pair` condition: both big rows wanted, whole 16-byte vectors.
+  static const int64_t multi_minb = []() {
+    const char* v = getenv("PEARL_AMD_GATHER_MULTI_MINB");
+    return v && *v ? (int64_t)atoll(v) : (int64_t)32768;
+  }();
+  const bool pair = g.o.next_state && (g.o.state || g.o.x) && (g.state_bytes & 15) == 0 &&
+                    (!g.o.x || ((g.S + g.o.rep_dim) & 3) == 0);
+  if (multi_minb > 0 && B >= multi_minb && pair) {
+    hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)ceil_div(B, 4 * GATHER_RPW)), dim3(256), 0, s, g);
+  } else {
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, g);
+  }
   PA_LAUNCH_CHECK();
   return PA_OK;
 }
