@@ -335,9 +335,9 @@ __device__ __forceinline__ void copy_bytes_group(uint8_t* __restrict__ dst, cons
   }
 }
 
-constexpr int GATHER_RPW = 4;
+template <int RPW>
 __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs g) {
-  constexpr int RPW = GATHER_RPW, GW = 64 / RPW;
+  constexpr int GW = 64 / RPW;
   const int lane = threadIdx.x & 63;
   const int64_t b0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
   if (g.signal_flag && blockIdx.x == 0 && threadIdx.x == 0)
@@ -382,7 +382,9 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs g) {
   // ---- everything else: one 16-lane group per transition
   const int grp = lane / GW, l = lane - grp * GW;
   const int64_t b = b0 + grp;
-  const long long sl = slot[0] * (grp == 0) + slot[1] * (grp == 1) + slot[2] * (grp == 2) + slot[3] * (grp == 3);
+  long long sl = -1;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) sl = (grp == r) ? slot[r] : sl;
   if (b >= g.B || sl < 0) return;
   const uint8_t* act = g.c.action + sl * g.action_bytes;
   if (g.o.action)
@@ -607,8 +609,13 @@ int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa
   }();
   const bool pair = g.o.next_state && (g.o.state || g.o.x) && (g.state_bytes & 15) == 0 &&
                     (!g.o.x || ((g.S + g.o.rep_dim) & 3) == 0);
+  static const int rpw = []() {
+    const char* v = getenv("PEARL_AMD_GATHER_RPW");
+    return v && atoi(v) == 8 ? 8 : 4;
+  }();
   if (multi_minb > 0 && B >= multi_minb && pair) {
-    hipLaunchKernelGGL(gather_multi_kernel, dim3((unsigned)ceil_div(B, 4 * GATHER_RPW)), dim3(256), 0, s, g);
+    if (rpw == 8) hipLaunchKernelGGL(gather_multi_kernel<8>, dim3((unsigned)ceil_div(B, 32)), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL(gather_multi_kernel<4>, dim3((unsigned)ceil_div(B, 16)), dim3(256), 0, s, g);
   } else {
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, g);
   }

@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
-for cfg in "X=0" "PEARL_AMD_HEAD_EARLY=1" "PEARL_AMD_FIRST_UNSPLIT=1" "PEARL_AMD_HEAD_EARLY=1 PEARL_AMD_FIRST_UNSPLIT=1" "X=0" "PEARL_AMD_HEAD_EARLY=1 PEARL_AMD_FIRST_UNSPLIT=1"; do
+for cfg in "PEARL_AMD_GATHER_RPW=4" "PEARL_AMD_GATHER_RPW=8"; do
 echo "== $cfg"
-env $cfg timeout 300 python tools/shortcall.py --calls 40 --rounds 1,3,10,20 2>/dev/null | python -c "
+env $cfg timeout 900 python -m pytest tests/test_gpu_replay.py -m gpu -q --tb=short -p no:cacheprovider -k large_gathers 2>&1 | tail -2
+env $cfg timeout 600 python bench_algos.py --only gather --steps 30 2>&1 | grep '^{' | python -c "
 import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('  rounds %3d wall %7.1f us  host %7.1f enq %6.1f  %.2f M' % (d['rounds'], d['wall_us'], d['host_us'], d['enqueue_us'], d['transitions_per_s']/1e6))"
+d=json.loads(sys.stdin.read()); r=d['roofline']; l=d['learn_loop_form']
+print('gather all columns: %.1f GB/s median (%.1f best) frac %.3f of 8 TB/s, %.3f of 6.3; %.3f ms' % (r['achieved'], r['best_GBps'], r['frac'], r['frac_of_achievable_6300'], d['ms_per_step']))
+print('learn-loop form: %.1f GB/s (%.1f best), %.3f ms' % (l['GBps'], l['best_GBps'], l['ms']))"
 done
