@@ -151,7 +151,7 @@ def pmc_traffic(transitions_per_launch, split_on):
     prescribes for gfx950, + WRITE_SIZE, per transition).  Counters cannot be collected inside this
     run, so the line names the file the figure comes from and the kernel that pass measured; None
     when no pass exists for the kernel that ran."""
-    names = ["r05_pmc_target.json", "r04_pmc_target.json", "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"]
+    names = ["r06_pmc_target.json", "r05_pmc_target.json", "r04_pmc_target.json", "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"]
     for name in names:
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
@@ -518,7 +518,7 @@ def main():
                 # what it is of a round: the first real N-GPU run yields the overlap figure directly
                 info["exchange_us"] = ar["avg_us"]
                 info["exchange_rounds_timed"] = ar["n"]
-                info["exchange_frac_of_round"] = ar["avg_us"] / (1e3 * dt / args.steps)
+                info["exchange_frac_of_round"] = ar["avg_us"] / (1e6 * dt / args.steps)
                 info["exchange_GBps_per_rank"] = 4.0 * info["allreduce_floats_per_round"] / (ar["avg_us"] * 1e-6) / 1e9
             info["exchange_stream"] = "learner stream (between the weight-gradient launch and AdamW; the " \
                                       "target pass of the following rounds runs beside it on the side stream)"

@@ -24,8 +24,11 @@ PYTORCH_NO_CUDA_MEMORY_CACHING=1 AMD_SERIALIZE_KERNEL=3 timeout 600 python -m py
 echo "stress tests (round 5 kernels) rc=$?"; tail -2 gpurun_out/nocache_tests.txt
 fi
 if [ "$SKIP_TESTS" != "1" ]; then
-timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+timeout 2400 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
 echo "pytest rc=$?"; tail -5 gpurun_out/pytest_gpu.log
+# the long-run / dynamic-range tables of round 6 (printed by the tests themselves)
+timeout 900 python -m pytest tests/test_gpu_long_runs.py tests/test_gpu_numerics_range.py tests/test_gpu_perf_report.py -m gpu -q --tb=short -p no:cacheprovider -s > gpurun_out/long_runs.txt 2>&1
+echo "long runs rc=$?"; tail -2 gpurun_out/long_runs.txt
 fi
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
 echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
@@ -42,7 +45,7 @@ echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-400
 timeout 300 python tools/shortcall.py > gpurun_out/shortcall.jsonl 2> gpurun_out/shortcall.err
 echo "shortcall rc=$?"; cat gpurun_out/shortcall.jsonl
 if [ "$SKIP_ALGOS" != "1" ]; then
-timeout 600 python bench_algos.py --steps 300 --cpu-seconds 2 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
+timeout 900 python bench_algos.py --steps 300 --cpu-seconds 2 > gpurun_out/bench_algos.jsonl 2> gpurun_out/bench_algos.err
 echo "bench_algos rc=$?"; cut -c1-260 gpurun_out/bench_algos.jsonl
 fi
 # multi-GPU readiness on one GPU: the driver's torchrun command line with the data-parallel loop
