@@ -357,26 +357,28 @@ __global__ __launch_bounds__(256) void gather_multi_kernel(GatherArgs g) {
     const int half = lane >> 5, l = lane & 31;
     const int n16 = g.state_bytes >> 4;
     for (int i = l; i < n16; i += 32) {
-      float4 v[RPW];
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if (slot[r] < 0) continue;
-        const uint8_t* base = half ? reinterpret_cast<const uint8_t*>(g.c.next_state)
-                                   : reinterpret_cast<const uint8_t*>(g.c.state);
-        v[r] = reinterpret_cast<const float4*>(base + slot[r] * g.state_bytes)[i];
-      }
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        if (slot[r] < 0) continue;
+      // (rows past B — only in the launch's last wave — re-read row 0 of the wave and store nothing:
+      //  no branch around a load; four named values, not an array: the compiler parked an array in LDS)
+      const uint8_t* base = half ? reinterpret_cast<const uint8_t*>(g.c.next_state)
+                                 : reinterpret_cast<const uint8_t*>(g.c.state);
+      auto ld = [&](int r) {
+        const long long sr = slot[r] < 0 ? slot[0] : slot[r];
+        return reinterpret_cast<const float4*>(base + sr * g.state_bytes)[i];
+      };
+      auto st = [&](int r, const float4& v) {
         const int64_t b = b0 + r;
+        if (slot[r] < 0) return;
         if (half) {
-          reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.next_state) + b * g.state_bytes)[i] = v[r];
+          reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.next_state) + b * g.state_bytes)[i] = v;
         } else {
           if (g.o.state)
-            reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.state) + b * g.state_bytes)[i] = v[r];
-          if (g.o.x) reinterpret_cast<float4*>(g.o.x + b * (g.S + R0))[i] = v[r];
+            reinterpret_cast<float4*>(reinterpret_cast<uint8_t*>(g.o.state) + b * g.state_bytes)[i] = v;
+          if (g.o.x) reinterpret_cast<float4*>(g.o.x + b * (g.S + R0))[i] = v;
         }
-      }
+      };
+      static_assert(RPW == 4, "four named rows");
+      const float4 v0 = ld(0), v1 = ld(1), v2 = ld(2), v3 = ld(3);
+      st(0, v0); st(1, v1); st(2, v2); st(3, v3);
     }
   }
   // ---- everything else: one 16-lane group per transition
@@ -609,13 +611,9 @@ int arena_gather_device(pa_arena* a, const int64_t* idx_dev, int32_t B, const pa
   }();
   const bool pair = g.o.next_state && (g.o.state || g.o.x) && (g.state_bytes & 15) == 0 &&
                     (!g.o.x || ((g.S + g.o.rep_dim) & 3) == 0);
-  static const int rpw = []() {
-    const char* v = getenv("PEARL_AMD_GATHER_RPW");
-    return v && atoi(v) == 8 ? 8 : 4;
-  }();
   if (multi_minb > 0 && B >= multi_minb && pair) {
-    if (rpw == 8) hipLaunchKernelGGL(gather_multi_kernel<8>, dim3((unsigned)ceil_div(B, 32)), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL(gather_multi_kernel<4>, dim3((unsigned)ceil_div(B, 16)), dim3(256), 0, s, g);
+    // (eight per wave was measured too: 2.4 / 2.7 TB/s against 3.2 / 4.1 — 127 VGPRs and spills)
+    hipLaunchKernelGGL(gather_multi_kernel<4>, dim3((unsigned)ceil_div(B, 16)), dim3(256), 0, s, g);
   } else {
     hipLaunchKernelGGL(gather_kernel, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, s, g);
   }
