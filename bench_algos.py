@@ -506,6 +506,54 @@ def bench_double_dqn(steps, cpu_seconds):
                              "sample": f"{n} oracle learn_batch calls on one batch (no sampling cost)"}}
 
 
+def bench_dqn_generic(steps, cpu_seconds):
+    """What the GENERIC TD engine costs beyond the fused shape: DeepQLearning on
+    BASELINE config 2's data with Q networks the fused `pa_dqn_*` path does not take — three hidden
+    layers, a multi-head network, a dueling network — through `generic_q.py` (pa_mlp forward /
+    backward / fused dW + AdamW, head kernels; the per-round Python loop), next to the fused path on
+    the same buffer."""
+    from pearl_amd import (BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule,
+                           PearlAgent)
+    from pearl_amd.neural_networks.sequential_decision_making import q_value_networks as Q
+    S, A, B, N = 128, 16, 1024, 200_000
+    rb = BasicReplayBuffer(N, sampler="device")
+    rb.device_for_batches = DEV
+    g = torch.Generator(device=DEV).manual_seed(0)
+    st = torch.randn(N + 1, S, device=DEV, generator=g)
+    ids = torch.arange(N, device=DEV)
+    rb.push_many(state=st[:-1], action=(ids % A).view(-1, 1), reward=(ids % 7).float(),
+                 terminated=(ids % 50 == 0), truncated=torch.zeros(N, dtype=torch.bool, device=DEV),
+                 next_state=st[1:], curr_available_actions=dspace(A),
+                 next_available_actions=dspace(A), max_number_actions=A)
+    rows = {}
+    for name, kw in (("fused [256, 256]", dict(hidden_dims=[256, 256])),
+                     ("generic: Vanilla [256, 256, 256]", dict(hidden_dims=[256, 256, 256])),
+                     ("generic: multi-head [256, 256]", dict(hidden_dims=[256, 256],
+                                                              network_type=Q.VanillaQValueMultiHeadNetwork)),
+                     ("generic: dueling [256, 256]", dict(hidden_dims=[256, 256],
+                                                           network_type=Q.DuelingQValueNetwork))):
+        torch.manual_seed(0)
+        random.seed(0)
+        n = steps if name.startswith("fused") else max(20, min(steps, 100))
+        pl = DeepQLearning(state_dim=S, action_space=dspace(A), training_rounds=n, batch_size=B,
+                           action_representation_module=OneHotActionTensorRepresentationModule(A), **kw)
+        agent = PearlAgent(pl, replay_buffer=rb, device_id=0)
+        dt, _ = timed(lambda: agent.learn())
+        rows[name] = {"transitions_per_s": B * n / dt, "us_per_round": 1e6 * dt / n, "rounds": n,
+                      "fused": bool(pl._fused)}
+    main_key = "generic: Vanilla [256, 256, 256]"
+    return {"config": "cfg2 data, DeepQLearning beyond the fused shape (generic TD engine) S=128 A=16 B=1024",
+            "metric": "learner transitions/s through PolicyLearner.learn (sample+preprocess+learn_batch)",
+            "value": rows[main_key]["transitions_per_s"], "steps": rows[main_key]["rounds"],
+            "ms_per_step": rows[main_key]["us_per_round"] * 1e-3, "networks": rows,
+            # three hidden layers: online fwd + dW + dX on B rows, target all-actions pass on B A rows
+            "roofline": step_roofline(
+                2 * (3 * mlp_macs([S + A, 256, 256, 256, 1]) - (S + A) * 256
+                     + A * mlp_macs([S + A, 256, 256, 256, 1])),
+                B * rows[main_key]["rounds"], rows[main_key]["us_per_round"] * 1e-6 * rows[main_key]["rounds"],
+                kernel="pa_mlp forward / backward / weight_grad kernels, per-round Python loop")}
+
+
 def bench_push(steps, cpu_seconds):
     """Ingest: per-transition push() through the pinned staging ring, and
     push_many() from host tensors (one H2D copy + one scatter kernel) — the PCIe-inclusive side of
@@ -905,7 +953,7 @@ def main():
     torch.set_num_threads(min(32, os.cpu_count() or 1))   # the CPU oracle's best pool size (bench.py)
     for name, fn in (("sac", bench_sac), ("td3", bench_td3), ("dsac", bench_dsac), ("ppo", bench_ppo), ("bandit", bench_bandit),
                      ("double_dqn", bench_double_dqn), ("push", bench_push), ("feeder", bench_feeder),
-                     ("gather", bench_gather)):
+                     ("gather", bench_gather), ("dqn_generic", bench_dqn_generic)):
         if args.only and name not in args.only.split(","):
             continue
         out = fn(args.steps, args.cpu_seconds)

@@ -403,7 +403,7 @@ typedef struct pa_mlp_desc {
   /* mlp_block's other forms (common/utils.py:75-152; round 5).  Networks that use either run layer
    * by layer (GEMM launches + row-local normalisation / activation kernels, mlp_norm_act.hpp), not
    * through the fused row-pass kernels; the fused multi-network steps refuse them
-   * (PA_ERR_UNSUPPORTED).  batch norm, dropout and residual blocks are not built. */
+   * (PA_ERR_UNSUPPORTED). */
   int32_t hidden_act;      /* ActivationType of the hidden layers (utils.py:29-56): 0 relu, 1 leaky_relu
                               (slope 0.01), 2 tanh, 3 softplus (beta 1, threshold 20), 4 sigmoid */
   int32_t layer_norm;      /* bit l set: nn.LayerNorm(d_{l+1}) (eps 1e-5, affine) between hidden Linear l
@@ -411,6 +411,18 @@ typedef struct pa_mlp_desc {
                               layer, the bandit's trunk for all but its activation-free output layer).
                               The weights / biases are parameters: they follow the W / b block of the
                               flat buffers (pa_mlp_norm_offsets) */
+  /* round 6: the remaining options of mlp_block (utils.py:113-126, :142-144), layer by layer as well */
+  int32_t batch_norm;      /* bit l set: nn.BatchNorm1d(d_{l+1}) (eps 1e-5, momentum 0.1, affine, TRAINING
+                              mode: statistics of the batch at hand — the reference never switches its
+                              networks to eval) AFTER hidden layer l's activation (utils.py:119-121).  gamma /
+                              beta are parameters behind the LayerNorm block (pa_mlp_bn_offsets); the
+                              running statistics are the caller's buffers (pa_mlp_bind_batch_norm) */
+  int32_t dropout;         /* bit l set: nn.Dropout between hidden layer l's (LayerNorm and) activation
+                              (utils.py:114-116).  The keep mask of every forward is the caller's
+                              (pa_mlp_set_dropout: [B][d_{l+1}] floats, 0 or 1 / (1 - p)) */
+  int32_t residual;        /* bit l set (l = 0 .. n_layers - 1): layer l's block is wrapped in
+                              ResidualWrapper — out = in + block(in), d_l == d_{l+1}
+                              (utils.py:122-131, :142-150; residual_wrapper.py:13-29) */
 } pa_mlp_desc;
 typedef struct pa_mlp_buffers {
   float* p;
@@ -426,6 +438,19 @@ int pa_mlp_param_offsets(const pa_mlp_desc* d, int64_t* offsets);
 /* layer_norm != 0: offsets[2 * (n_layers - 1)]: gamma_l, beta_l of hidden layer l's LayerNorm (each
  * d_{l+1} floats) at [2 l], [2 l + 1]; -1 for hidden layers without one */
 int pa_mlp_norm_offsets(const pa_mlp_desc* d, int64_t* offsets);
+/* batch_norm != 0: offsets[2 * (n_layers - 1)]: weight_l, bias_l of hidden layer l's BatchNorm1d (each
+ * d_{l+1} floats); -1 for hidden layers without one */
+int pa_mlp_bn_offsets(const pa_mlp_desc* d, int64_t* offsets);
+/* The running statistics of hidden layer `layer`'s BatchNorm1d of the online (use_target = 0) or
+ * target network: running_mean / running_var [d_{l+1}] floats and num_batches_tracked (one int64),
+ * updated by every forward as torch's training-mode batch_norm does (momentum 0.1, unbiased
+ * variance); any may be NULL (then not updated). */
+int pa_mlp_bind_batch_norm(pa_mlp* h, int32_t use_target, int32_t layer, float* running_mean,
+                           float* running_var, int64_t* num_batches_tracked);
+/* The dropout keep mask of hidden layer `layer` for the NEXT forward(s): [B][d_{l+1}] floats, 0 or
+ * 1 / (1 - p); the kept forward's mask must stay alive until its backward.  NULL: no dropout
+ * (evaluation). */
+int pa_mlp_set_dropout(pa_mlp* h, int32_t layer, const float* mask, int32_t ldm);
 int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc);
 int pa_mlp_destroy(pa_mlp* h);
 int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* bufs);

@@ -447,20 +447,34 @@ class NeuralLinearOracle:
 
     def __init__(self, model_sd, lr: float = 3e-4, l2_reg_lambda: float = 1.0,
                  loss_type: str = "mse", output_activation: str = "linear",
-                 hidden_activation: str = "relu", nn_e2e: bool = True, force_pinv: bool = False) -> None:
+                 hidden_activation: str = "relu", nn_e2e: bool = True, force_pinv: bool = False,
+                 use_batch_norm: bool = False, dropout_ratio: float = 0.0,
+                 use_skip_connections: bool = False) -> None:
         # force_pinv (linear_regression.py:138-157): torch.linalg.pinv(hermitian=True) instead of inv
         self.force_pinv = force_pinv
         # nn_e2e=False (neural_linear_regression.py:100-105, :140-147): mu from the LinUCB regression's
         # coefficients (buffers: the loss reaches the trunk through them, linear_layer_e2e gets no
         # gradient and AdamW skips it)
         self.nn_e2e = nn_e2e
-        self.trunk = _layers(model_sd, "_nn_layers._model.")
+        # mlp_block's remaining options (common/utils.py:113-131, :142-150): nn.Dropout between
+        # (LayerNorm and) activation, nn.BatchNorm1d AFTER the activation (training mode: the reference
+        # never switches to eval), ResidualWrapper around a layer whose in / out widths agree (its
+        # state-dict keys then carry a `module.` level)
+        self.p_drop, self.use_bn = float(dropout_ratio), bool(use_batch_norm)
+        self.masks: List[Tensor] = []      # dropout keep masks of the NEXT forward, hidden layer order
+        if use_batch_norm or dropout_ratio > 0 or use_skip_connections:
+            self._init_general(model_sd)
+        else:
+            self.wrapped, self.bn = None, None
+        self.trunk = self.trunk if getattr(self, "wrapped", None) else _layers(model_sd, "_nn_layers._model.")
         # mlp_block's other forms (common/utils.py:75-152): nn.LayerNorm between a hidden Linear and
         # its activation when the state dict has `{i}.1.weight`; the hidden activation by name
         pre = "_nn_layers._model."
-        self.norms = [(model_sd[f"{pre}{i}.1.weight"].clone().requires_grad_(True),
-                       model_sd[f"{pre}{i}.1.bias"].clone().requires_grad_(True))
-                      if f"{pre}{i}.1.weight" in model_sd else None for i in range(len(self.trunk) - 1)]
+        bases = self._bases if getattr(self, "wrapped", None) else [f"{pre}{i}." for i in range(len(self.trunk))]
+        self.norms = [(model_sd[f"{b}1.weight"].clone().requires_grad_(True),
+                       model_sd[f"{b}1.bias"].clone().requires_grad_(True))
+                      if (f"{b}1.weight" in model_sd and f"{b}1.running_mean" not in model_sd) else None
+                      for b in bases[:-1]]
         from oracle.pearl_oracle import _HIDDEN_ACTS
         self.hidden_act = _HIDDEN_ACTS[hidden_activation]
         self.e2e = model_sd["linear_layer_e2e.weight"].clone().requires_grad_(True)
@@ -469,15 +483,46 @@ class NeuralLinearOracle:
         self.sum_weight = torch.zeros(1)
         self.inv_A, self.coefs = torch.zeros(d + 1, d + 1), torch.zeros(d + 1)
         self.lam = l2_reg_lambda
-        self.opt = torch.optim.AdamW(_flat(self.trunk) + [t for n in self.norms if n for t in n] + [self.e2e],
-                                     lr=lr, amsgrad=True)
+        bn_params = [t for b in (self.bn or []) if b for t in (b["weight"], b["bias"])]
+        self.opt = torch.optim.AdamW(_flat(self.trunk) + [t for n in self.norms if n for t in n] + bn_params
+                                     + [self.e2e], lr=lr, amsgrad=True)
         # LossType.function() (neural_networks/common/utils.py:60-72) and the model's output
         # activation (neural_linear_regression.py:79-81)
         self.criterion = {"mse": torch.nn.functional.mse_loss, "mae": torch.nn.functional.l1_loss,
                           "cross_entropy": torch.nn.functional.binary_cross_entropy}[loss_type]
         self.out_act = {"linear": lambda z: z, "sigmoid": torch.sigmoid}[output_activation]
 
-    def features(self, x: Tensor) -> Tensor:
+    def _init_general(self, sd) -> None:
+        pre, i = "_nn_layers._model.", 0
+        self.trunk, self.wrapped, bases = [], [], []
+        while any(k.startswith(f"{pre}{i}.") for k in sd):
+            wrapped = f"{pre}{i}.module.0.weight" in sd
+            base = f"{pre}{i}." + ("module." if wrapped else "")
+            self.trunk.append((sd[base + "0.weight"].clone().requires_grad_(True),
+                               sd[base + "0.bias"].clone().requires_grad_(True)))
+            self.wrapped.append(wrapped)
+            bases.append(base)
+            i += 1
+        self.wrapped = self.wrapped or [False]
+        self._bases = bases
+        self.bn = []
+        for li, base in enumerate(bases[:-1]):
+            has_ln = (base + "1.weight") in sd and sd[base + "1.weight"].ndim == 1 and \
+                (base + "1.running_mean") not in sd
+            idx = 1 + int(has_ln) + int(self.p_drop > 0) + 1
+            if self.use_bn:
+                b = f"{base}{idx}."
+                self.bn.append(dict(weight=sd[b + "weight"].clone().requires_grad_(True),
+                                    bias=sd[b + "bias"].clone().requires_grad_(True),
+                                    running_mean=sd[b + "running_mean"].clone(),
+                                    running_var=sd[b + "running_var"].clone(),
+                                    nbt=sd[b + "num_batches_tracked"].clone(), key=b))
+            else:
+                self.bn.append(None)
+
+    def features(self, x: Tensor, train: bool = True) -> Tensor:
+        if getattr(self, "wrapped", None):
+            return self._features_general(x, train)
         # the trunk's own last layer has no activation (and no LayerNorm)
         for i, (w, b) in enumerate(self.trunk):
             x = torch.nn.functional.linear(x, w, b)
@@ -487,6 +532,30 @@ class NeuralLinearOracle:
                     var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
                     x = (x - mu) / torch.sqrt(var + 1e-5) * self.norms[i][0] + self.norms[i][1]
                 x = self.hidden_act(x)
+        return x
+
+    def _features_general(self, x: Tensor, train: bool) -> Tensor:
+        F = torch.nn.functional
+        for i, (w, b) in enumerate(self.trunk):
+            inp = x
+            x = F.linear(x, w, b)
+            if i + 1 < len(self.trunk):
+                if self.norms[i] is not None:
+                    mu = x.mean(dim=-1, keepdim=True)
+                    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+                    x = (x - mu) / torch.sqrt(var + 1e-5) * self.norms[i][0] + self.norms[i][1]
+                if self.p_drop > 0 and train:
+                    keep = self.masks.pop(0)               # the reference's draw (torch's dropout:
+                    x = x * keep.div(1.0 - self.p_drop)    #  input * bernoulli(1 - p).div_(1 - p))
+                x = self.hidden_act(x)
+                if self.bn[i] is not None:
+                    bn = self.bn[i]
+                    x = F.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"],
+                                     training=train, momentum=0.1, eps=1e-5)
+                    if train:
+                        bn["nbt"] += 1
+            if self.wrapped[i]:
+                x = inp + x
         return x
 
     def learn_batch(self, x: Tensor, y: Tensor, w) -> Dict[str, Tensor]:
@@ -514,8 +583,8 @@ class NeuralLinearOracle:
         return {"loss": loss.detach(), "prediction": pred.detach()}
 
     @torch.no_grad()
-    def sigma(self, x: Tensor) -> Tensor:
-        X = torch.cat((torch.ones(x.shape[0], 1), self.features(x)), dim=-1)
+    def sigma(self, x: Tensor, train: bool = True) -> Tensor:
+        X = torch.cat((torch.ones(x.shape[0], 1), self.features(x, train)), dim=-1)
         return torch.sqrt((torch.matmul(X, self.inv_A) * X).sum(-1))
 
 

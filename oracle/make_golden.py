@@ -55,7 +55,7 @@ CONFIGS = {
     "cfg2_shape_small_batch": dict(S=128, A=16, hidden=[256, 256], N=900, B=192, rounds=12,
                                    dynamic=False),
     # DeepQLearning(is_conservative=True) (deep_td_learning.py:323-327): files cql_<name>.pt.  Pins
-    # the oracle now; the HIP learner still raises NotImplementedError for is_conservative
+    # the oracle and the HIP learner's CQL path (tests/test_gpu_dqn.py::test_conservative_q_learning)
     "cql_tiny_dynamic": dict(S=5, A=5, hidden=[24, 16], N=48, B=16, rounds=13, dynamic=True,
                              learner="cql"),
     "cql_small": dict(S=16, A=6, hidden=[32, 32], N=300, B=64, rounds=12, dynamic=False,

@@ -473,6 +473,18 @@ BANDIT_CONFIGS = {
                                mlp=dict(force_pinv=True, l2_reg_lambda_linear=0.0)),
     "pinv_singular_small": dict(F=40, hidden=[48, 64], B=16, steps=3,
                                 mlp=dict(force_pinv=True, l2_reg_lambda_linear=0.0)),
+    # mlp_block's remaining options in the trunk (common/utils.py:113-131, :142-150; round 6): batch
+    # norm after the activation (training mode throughout: the reference never calls eval()), dropout
+    # between (LayerNorm and) activation — the keep masks the reference drew are recorded — and skip
+    # connections around layers whose widths agree (incl. the trunk's own output layer)
+    "bn_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(use_batch_norm=True)),
+    "dropout_tiny": dict(F=7, hidden=[12, 6], B=16, steps=4, mlp=dict(dropout_ratio=0.25)),
+    "skip_tiny": dict(F=8, hidden=[8, 8, 8], B=16, steps=4, mlp=dict(use_skip_connections=True)),
+    "bn_ln_dropout_skip_small": dict(F=40, hidden=[40, 40, 16, 16], B=128, steps=3,
+                                     mlp=dict(use_batch_norm=True, use_layer_norm=True, dropout_ratio=0.1,
+                                              use_skip_connections=True, hidden_activation="leaky_relu")),
+    "bn_cfg5_shape": dict(F=512, hidden=[256, 64], B=4096, steps=2, input_seed=25,
+                          mlp=dict(use_batch_norm=True, use_skip_connections=True)),
 }
 
 
@@ -488,7 +500,18 @@ def make_bandit(name, cfg):
                             **cfg.get("mlp", {}))
     fx = {"config": dict(cfg), "model0": clone_sd(pl.model), "batches": [], "reports": []}
     wtrue = torch.randn(F, generator=gen) / F ** 0.5
+    # dropout: record the keep masks of every nn.Dropout call (forward order = hidden layer order);
+    # the arithmetic is torch's own (input * bernoulli_(1 - p).div_(1 - p))
+    drops, real_drop = [], torch.nn.Dropout.forward
+    if cfg.get("mlp", {}).get("dropout_ratio", 0.0) > 0:
+        def recording_dropout(self, x):
+            assert self.training
+            keep = torch.empty_like(x).bernoulli_(1 - self.p)
+            drops[-1].append(keep.clone())
+            return x * keep.div(1 - self.p)
+        torch.nn.Dropout.forward = recording_dropout
     for k in range(K):
+        drops.append([])
         x = FI.bandit_contexts(cfg, k) if seeded else torch.randn(B, F, generator=gen)
         r = torch.sigmoid(x @ wtrue) + 0.05 * torch.randn(B, generator=gen)
         if loss == "cross_entropy":
@@ -502,8 +525,14 @@ def make_bandit(name, cfg):
             fx["batches"].append(dict(state=x, reward=r, weight=w))
         fx["reports"].append(dict(loss=float(rep["loss"]), mu=float(rep["mu_scores"]),
                                   prediction=rep["prediction"].clone()))
+    torch.nn.Dropout.forward = real_drop
+    if any(drops):
+        fx["drop_masks"] = drops
     fx["model_after"] = clone_sd(pl.model)
     xq = torch.randn(9, F, generator=gen)
+    if any(cfg.get("mlp", {}).get(k) for k in ("use_batch_norm", "dropout_ratio")):
+        pl.model.eval()      # the query: running statistics, no dropout (what a user who serves the model does)
+        fx["query_eval"] = True
     with torch.no_grad():
         fx["query"] = dict(x=xq, sigma=pl.model.calculate_sigma(xq).clone(),
                            mu=pl.model(xq).clone())
@@ -604,6 +633,10 @@ def main():
     if os.environ.get("PEARL_GOLDEN_ONLY") == "fullbatch":
         make_ppo("cfg4_fullbatch", PPO_CONFIGS["cfg4_fullbatch"])
         make_sac("cfg3_fullbatch", SAC_CONFIGS["cfg3_fullbatch"])
+        return
+    if os.environ.get("PEARL_GOLDEN_ONLY") == "round6":
+        for name in ("bn_tiny", "dropout_tiny", "skip_tiny", "bn_ln_dropout_skip_small", "bn_cfg5_shape"):
+            make_bandit(name, BANDIT_CONFIGS[name])
         return
     if os.environ.get("PEARL_GOLDEN_ONLY") == "round5":
         for name in ("layernorm_tiny", "leaky_layernorm_small", "tanh_tiny", "pinv_tiny",

@@ -192,6 +192,9 @@ class MlpDesc(C.Structure):
         ("identity_layers", C.c_int32),
         ("hidden_act", C.c_int32),
         ("layer_norm", C.c_int32),
+        ("batch_norm", C.c_int32),
+        ("dropout", C.c_int32),
+        ("residual", C.c_int32),
     ]
 
 
@@ -431,6 +434,9 @@ SIGNATURES = {
     "pa_mlp_param_count": (C.c_int64, [C.POINTER(MlpDesc)]),
     "pa_mlp_param_offsets": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_int64)]),
     "pa_mlp_norm_offsets": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_int64)]),
+    "pa_mlp_bn_offsets": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(C.c_int64)]),
+    "pa_mlp_bind_batch_norm": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "pa_mlp_set_dropout": (C.c_int, [_P, C.c_int32, _P, C.c_int32]),
     "pa_mlp_create": (C.c_int, [C.POINTER(_P), C.POINTER(MlpDesc)]),
     "pa_mlp_destroy": (C.c_int, [_P]),
     "pa_mlp_bind": (C.c_int, [_P, C.POINTER(MlpBuffers)]),

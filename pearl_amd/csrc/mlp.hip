@@ -49,6 +49,14 @@ int layout(const pa_mlp_desc* d, int64_t* woff, int64_t* boff, int64_t* total) {
   PA_REQUIRE(d->layer_norm >= 0 && (d->n_layers <= 1 ? d->layer_norm == 0
                                                        : d->layer_norm < (1 << (d->n_layers - 1))),
              PA_ERR_INVALID, "layer_norm is a bit mask over the %d hidden layers", d->n_layers - 1);
+  const int hidden_bits = d->n_layers <= 1 ? 0 : (1 << (d->n_layers - 1)) - 1;
+  PA_REQUIRE((d->batch_norm & ~hidden_bits) == 0 && (d->dropout & ~hidden_bits) == 0, PA_ERR_INVALID,
+             "batch_norm / dropout are bit masks over the %d hidden layers", d->n_layers - 1);
+  PA_REQUIRE((d->residual & ~((1 << d->n_layers) - 1)) == 0, PA_ERR_INVALID,
+             "residual is a bit mask over the %d layers", d->n_layers);
+  for (int l = 0; l < d->n_layers; ++l)
+    PA_REQUIRE(!((d->residual >> l) & 1) || d->dims[l] == d->dims[l + 1], PA_ERR_INVALID,
+               "residual layer %d needs d_in == d_out (%d vs %d)", l, d->dims[l], d->dims[l + 1]);
   *total = o;
   return PA_OK;
 }
@@ -64,8 +72,27 @@ int norm_layout(const pa_mlp_desc* d, int64_t wb_total, int64_t* goff, int64_t* 
   *total = o;
   return PA_OK;
 }
+// ... and the BatchNorm1d weights / biases follow the LayerNorm block
+int bn_layout(const pa_mlp_desc* d, int64_t ln_total, int64_t* goff, int64_t* boff, int64_t* total) {
+  int64_t o = ln_total;
+  for (int l = 0; l + 1 < d->n_layers; ++l) {
+    goff[l] = boff[l] = -1;
+    if (!((d->batch_norm >> l) & 1)) continue;
+    goff[l] = o; o = align4(o + d->dims[l + 1]);
+    boff[l] = o; o = align4(o + d->dims[l + 1]);
+  }
+  *total = o;
+  return PA_OK;
+}
 // mlp_block's plain form (Linear + ReLU): what the fused row kernels compute
-inline bool plain_net(const pa_mlp* h) { return h->d.hidden_act == 0 && h->d.layer_norm == 0; }
+inline bool plain_net(const pa_mlp* h) {
+  return h->d.hidden_act == 0 && h->d.layer_norm == 0 && h->d.batch_norm == 0 && h->d.dropout == 0 &&
+         h->d.residual == 0;
+}
+// layer-by-layer forms that need the row-local kernel between a hidden GEMM and the next one
+inline bool rowlocal_net(const pa_mlp* h) {
+  return h->d.hidden_act != 0 || h->d.layer_norm != 0 || h->d.dropout != 0;
+}
 
 AdamScalars adam_scalars(const pa_mlp_desc& d, int64_t step) {
   const double bc1 = 1.0 - pow(d.beta1, (double)step);
@@ -88,7 +115,23 @@ extern "C" int64_t pa_mlp_param_count(const pa_mlp_desc* d) {
   int64_t w[PA_MLP_MAX_LAYERS], b[PA_MLP_MAX_LAYERS], total = 0;
   if (layout(d, w, b, &total) != PA_OK) return -1;
   (void)norm_layout(d, total, w, b, &total);
+  (void)bn_layout(d, total, w, b, &total);
   return total;
+}
+
+extern "C" int pa_mlp_bn_offsets(const pa_mlp_desc* d, int64_t* offsets) {
+  PA_REQUIRE(offsets, PA_ERR_INVALID, "null output");
+  int64_t w[PA_MLP_MAX_LAYERS], b[PA_MLP_MAX_LAYERS], total = 0;
+  int rc = layout(d, w, b, &total);
+  if (rc != PA_OK) return rc;
+  PA_REQUIRE(d->batch_norm, PA_ERR_INVALID, "pa_mlp_bn_offsets: the network has no BatchNorm1d");
+  (void)norm_layout(d, total, w, b, &total);
+  (void)bn_layout(d, total, w, b, &total);
+  for (int l = 0; l + 1 < d->n_layers; ++l) {
+    offsets[2 * l] = w[l];
+    offsets[2 * l + 1] = b[l];
+  }
+  return PA_OK;
 }
 
 extern "C" int pa_mlp_norm_offsets(const pa_mlp_desc* d, int64_t* offsets) {
@@ -125,6 +168,14 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
     if (h->act[l]) (void)hipFree(h->act[l]);
   for (int i = 0; i < PA_MLP_MAX_LAYERS; ++i)
     if (h->dz[i]) (void)hipFree(h->dz[i]);
+  for (int i = 0; i < PA_MLP_MAX_LAYERS; ++i) {
+    if (h->hpre[i]) (void)hipFree(h->hpre[i]);
+    if (h->bn_mean[i]) (void)hipFree(h->bn_mean[i]);
+    if (h->bn_rstd[i]) (void)hipFree(h->bn_rstd[i]);
+  }
+  for (int i = 0; i <= PA_MLP_MAX_LAYERS; ++i)
+    if (h->dres[i]) (void)hipFree(h->dres[i]);
+  if (h->bn_tmp) (void)hipFree(h->bn_tmp);
   for (int i = 0; i < PA_MLP_MAX_LAYERS; ++i) {
     if (h->xhat[i]) (void)hipFree(h->xhat[i]);
     if (h->rstd[i]) (void)hipFree(h->rstd[i]);
@@ -167,6 +218,7 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
   }
   h->norm0 = h->P;
   (void)norm_layout(desc, h->P, h->goff, h->betaoff, &h->P);
+  (void)bn_layout(desc, h->P, h->bn_goff, h->bn_boff, &h->P);
   {
     // (from here on every failure goes through pa_mlp_destroy, which releases the binding)
     int rc_dev = bind_process_device(desc->device);
@@ -196,6 +248,22 @@ extern "C" int pa_mlp_create(pa_mlp** out, const pa_mlp_desc* desc) {
     }
     ok = ok && alloc(&h->norm_part, (int64_t)NP_BLOCKS * 2 * maxh);
   }
+  // the activation's own output, kept where something behind it (BatchNorm, the residual add)
+  // overwrites act[l]: act' is formed from it
+  for (int l = 0; l + 1 < h->L; ++l)
+    if (((desc->batch_norm | desc->residual) >> l) & 1)
+      ok = ok && alloc(&h->hpre[l], (int64_t)desc->max_batch * desc->dims[l + 1]);
+  if (desc->batch_norm) {
+    for (int l = 0; l + 1 < h->L; ++l) {
+      if (!((desc->batch_norm >> l) & 1)) continue;
+      ok = ok && alloc(&h->bn_mean[l], desc->dims[l + 1]);
+      ok = ok && alloc(&h->bn_rstd[l], desc->dims[l + 1]);
+    }
+    if (!h->norm_part) ok = ok && alloc(&h->norm_part, (int64_t)NP_BLOCKS * 2 * maxh);
+    ok = ok && alloc(&h->bn_tmp, (int64_t)4 * maxh);
+  }
+  for (int l = 0; l < h->L; ++l)
+    if ((desc->residual >> l) & 1) ok = ok && alloc(&h->dres[l], (int64_t)desc->max_batch * desc->dims[l + 1]);
   {
     static const bool enabled = []() {
       const char* v = getenv("PEARL_AMD_MLP_ROWPASS");
@@ -233,6 +301,27 @@ extern "C" int pa_mlp_bind(pa_mlp* h, const pa_mlp_buffers* b) {
   h->bufs = *b;
   h->bound = true;
   h->packed_ok = h->packed_t_ok = false;
+  return PA_OK;
+}
+
+extern "C" int pa_mlp_bind_batch_norm(pa_mlp* h, int32_t use_target, int32_t layer, float* running_mean,
+                                      float* running_var, int64_t* num_batches_tracked) {
+  PA_REQUIRE(h && layer >= 0 && layer + 1 < h->L && ((h->d.batch_norm >> layer) & 1), PA_ERR_INVALID,
+             "pa_mlp_bind_batch_norm: hidden layer %d has no BatchNorm1d", layer);
+  const int w = use_target ? 1 : 0;
+  h->bn_run_mean[w][layer] = running_mean;
+  h->bn_run_var[w][layer] = running_var;
+  h->bn_nbt[w][layer] = reinterpret_cast<long long*>(num_batches_tracked);
+  return PA_OK;
+}
+
+extern "C" int pa_mlp_set_dropout(pa_mlp* h, int32_t layer, const float* mask, int32_t ldm) {
+  PA_REQUIRE(h && layer >= 0 && layer + 1 < h->L && ((h->d.dropout >> layer) & 1), PA_ERR_INVALID,
+             "pa_mlp_set_dropout: hidden layer %d has no Dropout", layer);
+  PA_REQUIRE(!mask || ldm >= h->d.dims[layer + 1], PA_ERR_INVALID, "pa_mlp_set_dropout: mask pitch %d < %d",
+             ldm, h->d.dims[layer + 1]);
+  h->drop_mask[layer] = mask;
+  h->drop_ld[layer] = ldm;
   return PA_OK;
 }
 
@@ -445,20 +534,64 @@ extern "C" int pa_mlp_forward(pa_mlp* h, int32_t use_target, const float* x, int
     int rc = launch_linear<false>(&g, 1, s);
     if (rc != PA_OK) return rc;
     const bool ln = !last && ((h->d.layer_norm >> l) & 1);
-    if (!last && !plain_net(h) && (ln || !ident)) {
-      // LayerNorm (optional) and the hidden activation, row by row, in place (mlp_norm_act.hpp)
+    const bool drop = !last && ((h->d.dropout >> l) & 1) && h->drop_mask[l] != nullptr;
+    const bool kept = keep && !use_target;   // (only the ONLINE network's kept forward feeds a backward)
+    if (!last && kept) {
+      h->drop_kept[l] = drop ? h->drop_mask[l] : nullptr;
+      h->drop_kept_ld[l] = h->drop_ld[l];
+    }
+    if (!last && !plain_net(h) && (ln || !ident || drop)) {
+      // LayerNorm (optional), dropout (optional) and the hidden activation, row by row, in place
+      // (mlp_norm_act.hpp)
       NormActArgs na;
       memset(&na, 0, sizeof(na));
       na.z = h->act[l]; na.ldz = h->d.dims[l + 1];
       if (ln) {
         na.gamma = P + h->goff[l]; na.beta = P + h->betaoff[l];
-        // (only the ONLINE network's kept forward feeds a backward)
-        na.xhat = (keep && !use_target) ? h->xhat[l] : nullptr;
-        na.rstd = (keep && !use_target) ? h->rstd[l] : nullptr;
+        na.xhat = kept ? h->xhat[l] : nullptr;
+        na.rstd = kept ? h->rstd[l] : nullptr;
       }
+      if (drop) { na.drop = h->drop_mask[l]; na.ldd = h->drop_ld[l]; }
       na.B = B; na.d = h->d.dims[l + 1]; na.act = h->d.hidden_act; na.identity = ident ? 1 : 0;
       na.eps = 1e-5f;
       hipLaunchKernelGGL(norm_act_fwd_kernel, dim3((unsigned)ceil_div(B, NA_ROWS)), dim3(64 * NA_ROWS), 0, s, na);
+      PA_LAUNCH_CHECK();
+    }
+    if (!last && ((h->d.batch_norm >> l) & 1)) {
+      // BatchNorm1d after the activation, training mode: the statistics of THIS batch (utils.py:119-121)
+      const int which = use_target ? 1 : 0, dd = h->d.dims[l + 1];
+      BnArgs b;
+      memset(&b, 0, sizeof(b));
+      b.y = h->act[l]; b.ldy = dd;
+      b.hpre = kept ? h->hpre[l] : nullptr;
+      b.gamma = P + h->bn_goff[l]; b.beta = P + h->bn_boff[l];
+      b.mean = kept ? h->bn_mean[l] : h->bn_tmp;
+      b.rstd = kept ? h->bn_rstd[l] : h->bn_tmp + dd;
+      b.run_mean = h->bn_run_mean[which][l]; b.run_var = h->bn_run_var[which][l]; b.nbt = h->bn_nbt[which][l];
+      b.part = h->norm_part; b.B = B; b.d = dd; b.eps = 1e-5f; b.momentum = 0.1f;
+      const int rows_per = (int)ceil_div(B, NP_BLOCKS);
+      const int nb = (int)ceil_div(B, rows_per);
+      const dim3 gcol((unsigned)ceil_div(dd, 64), (unsigned)nb), g1((unsigned)ceil_div(dd, 64));
+      hipLaunchKernelGGL(col_partial_kernel, gcol, dim3(64), 0, s, (const float*)b.y, b.ldy, B, dd,
+                         (const float*)nullptr, b.part, rows_per, 0);
+      hipLaunchKernelGGL(bn_stats_kernel, g1, dim3(64), 0, s, b, nb, 0);
+      hipLaunchKernelGGL(col_partial_kernel, gcol, dim3(64), 0, s, (const float*)b.y, b.ldy, B, dd,
+                         (const float*)b.mean, b.part, rows_per, 1);
+      hipLaunchKernelGGL(bn_stats_kernel, g1, dim3(64), 0, s, b, nb, 1);
+      hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3((unsigned)ceil_div((int64_t)B * dd, 256)), dim3(256), 0, s, b);
+      PA_LAUNCH_CHECK();
+    }
+    if ((h->d.residual >> l) & 1) {
+      // ResidualWrapper: out = in + block(in) (d_l == d_{l+1})
+      float* dst = last ? out : h->act[l];
+      const int ldd_ = last ? ldo : h->d.dims[l + 1];
+      if (!last && kept && !((h->d.batch_norm >> l) & 1)) {   // (BatchNorm has kept it already)
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)ceil_div((int64_t)B * h->d.dims[l + 1], 256)), dim3(256),
+                           0, s, h->hpre[l], h->d.dims[l + 1], (const float*)h->act[l], h->d.dims[l + 1], B,
+                           h->d.dims[l + 1], 0);
+      }
+      hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)ceil_div((int64_t)B * h->d.dims[l + 1], 256)), dim3(256),
+                         0, s, dst, ldd_, in, ldin, B, h->d.dims[l + 1], 1);
       PA_LAUNCH_CHECK();
     }
     in = h->act[l];
@@ -726,16 +859,54 @@ extern "C" int pa_mlp_backward(pa_mlp* h, const float* x, int32_t ldx, int32_t B
       }
       int rc = launch_linear<true>(&g, 1, s);
       if (rc != PA_OK) return rc;
+      if ((h->d.residual >> l) & 1) {
+        // layer l's block was wrapped: its input also received d out directly
+        const float* dsrc = (l == h->L - 1) ? d_out : h->dres[l];
+        const int lds_ = (l == h->L - 1) ? ldd : h->d.dims[l + 1];
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)ceil_div((int64_t)B * h->d.dims[l], 256)), dim3(256),
+                           0, s, dst, (int)g.ldc, dsrc, lds_, B, h->d.dims[l], 1);
+        PA_LAUNCH_CHECK();
+      }
+      if (l > 0 && ((h->d.residual >> (l - 1)) & 1)) {
+        // d out of hidden layer l - 1, before its own block's backward rewrites it in place
+        hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)ceil_div((int64_t)B * h->d.dims[l], 256)), dim3(256),
+                           0, s, h->dres[l - 1], h->d.dims[l], (const float*)dst, h->d.dims[l], B, h->d.dims[l], 0);
+        PA_LAUNCH_CHECK();
+      }
+      if (l > 0 && ((h->d.batch_norm >> (l - 1)) & 1)) {
+        // through the BatchNorm1d behind hidden layer l - 1's activation (torch's batch_norm backward)
+        const int dd = h->d.dims[l];
+        BnArgs b;
+        memset(&b, 0, sizeof(b));
+        b.y = dst; b.ldy = dd; b.hpre = h->hpre[l - 1];
+        b.gamma = P + h->bn_goff[l - 1];
+        b.mean = h->bn_mean[l - 1]; b.rstd = h->bn_rstd[l - 1];
+        b.part = h->norm_part; b.B = B; b.d = dd;
+        float* dgam = want_dw ? h->bufs.grad + h->bn_goff[l - 1] : h->bn_tmp + 2 * dd;
+        float* dbet = want_dw ? h->bufs.grad + h->bn_boff[l - 1] : h->bn_tmp + 3 * dd;
+        const int rows_per = (int)ceil_div(B, NP_BLOCKS);
+        const int nb = (int)ceil_div(B, rows_per);
+        hipLaunchKernelGGL(bn_param_grad_kernel, dim3((unsigned)ceil_div(dd, 64), (unsigned)nb), dim3(64), 0, s, b, rows_per);
+        hipLaunchKernelGGL(norm_param_sum_kernel, dim3((unsigned)ceil_div(dd, 64)), dim3(64), 0, s,
+                           (const float*)h->norm_part, nb, dd, dgam, dbet);
+        hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3((unsigned)ceil_div((int64_t)B * dd, 256)), dim3(256), 0, s,
+                           b, (const float*)dgam, (const float*)dbet);
+        PA_LAUNCH_CHECK();
+      }
       const bool ln = l > 0 && ((h->d.layer_norm >> (l - 1)) & 1);
-      if (l > 0 && !plain_net(h) && (ln || !ident)) {
+      const bool drop = l > 0 && h->drop_kept[l - 1] != nullptr;
+      if (l > 0 && !plain_net(h) && (ln || !ident || drop)) {
         // dh -> dz of hidden layer l - 1 through its activation and LayerNorm (mlp_norm_act.hpp);
         // the LayerNorm's own parameter gradients first (they read dh)
         NormActArgs na;
         memset(&na, 0, sizeof(na));
         na.z = dst; na.ldz = h->d.dims[l];
-        na.h = h->act[l - 1]; na.ldh = h->d.dims[l];
+        // the activation's OUTPUT: in front of the BatchNorm / residual add when the layer has them
+        na.h = (((h->d.batch_norm | h->d.residual) >> (l - 1)) & 1) ? h->hpre[l - 1] : h->act[l - 1];
+        na.ldh = h->d.dims[l];
         na.B = B; na.d = h->d.dims[l]; na.act = h->d.hidden_act; na.identity = ident ? 1 : 0;
         na.eps = 1e-5f;
+        if (drop) { na.drop = h->drop_kept[l - 1]; na.ldd = h->drop_kept_ld[l - 1]; }
         if (ln) {
           na.gamma = P + h->goff[l - 1]; na.beta = P + h->betaoff[l - 1];
           na.xhat = h->xhat[l - 1]; na.rstd = h->rstd[l - 1];

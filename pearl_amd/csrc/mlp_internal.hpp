@@ -18,6 +18,23 @@ struct pa_mlp {
   float* xhat[PA_MLP_MAX_LAYERS];
   float* rstd[PA_MLP_MAX_LAYERS];
   float* norm_part;
+  // desc.batch_norm: weight / bias offsets (behind the LayerNorm block), the activation output in front
+  // of the BatchNorm (its backward and the activation's need it), the batch's column mean and
+  // 1 / sqrt(var + eps), the caller's running statistics [online | target]
+  int64_t bn_goff[PA_MLP_MAX_LAYERS], bn_boff[PA_MLP_MAX_LAYERS];
+  float* hpre[PA_MLP_MAX_LAYERS];
+  float* bn_mean[PA_MLP_MAX_LAYERS];
+  float* bn_rstd[PA_MLP_MAX_LAYERS];
+  float* bn_tmp;                  // [4][max width]: statistics of forwards that are not kept; d gamma / d beta
+                                  // of a backward that writes no parameter gradients
+  float* bn_run_mean[2][PA_MLP_MAX_LAYERS];
+  float* bn_run_var[2][PA_MLP_MAX_LAYERS];
+  long long* bn_nbt[2][PA_MLP_MAX_LAYERS];
+  // desc.dropout: the caller's keep masks for the next forward, and the kept forward's
+  const float* drop_mask[PA_MLP_MAX_LAYERS]; int drop_ld[PA_MLP_MAX_LAYERS];
+  const float* drop_kept[PA_MLP_MAX_LAYERS]; int drop_kept_ld[PA_MLP_MAX_LAYERS];
+  // desc.residual: d out of a wrapped block, saved in front of the block's own backward
+  float* dres[PA_MLP_MAX_LAYERS + 1];
   float* act[PA_MLP_MAX_LAYERS];  // hidden activations kept for the backward pass [max_batch, d]
   float* dz[PA_MLP_MAX_LAYERS];   // pre-activation gradient of every hidden layer [max_batch, d]
                                   // (all kept: the weight gradients of all layers are one launch)

@@ -5,14 +5,17 @@ The plain configuration the DQN / actor-critic configs use (Linear + ReLU hidden
 last activation) is what the fused kernels compute.  ``use_layer_norm`` and the other hidden
 activations of ``ActivationType`` (utils.py:29-56: leaky_relu, tanh, softplus, sigmoid, linear) are
 built too — such networks train through the generic ``pa_mlp`` engine layer by layer
-(``mlp_norm_act.hpp``; ``generic_q.mlp_spec`` is what recognises them).  Batch norm, dropout and
-residual blocks are still rejected loudly.
+(``mlp_norm_act.hpp``; ``generic_q.mlp_spec`` is what recognises them).  Since round 6 so are batch
+norm, dropout and skip connections (utils.py:113-131, :142-150), in the same layer-by-layer path.
 """
 from __future__ import annotations
 
+import logging
 from typing import List, Optional
 
 import torch.nn as nn
+
+from .residual_wrapper import ResidualWrapper
 
 class _Softmax(nn.Softmax):
     def __init__(self) -> None:
@@ -35,10 +38,6 @@ def mlp_block(input_dim: int, hidden_dims: Optional[List[int]], output_dim: int 
     the order in which nn.Linear layers draw their default init are those of the reference, so
     the same ``torch.manual_seed`` yields the same initial weights.
     """
-    if use_batch_norm or dropout_ratio > 0 or use_skip_connections:
-        raise NotImplementedError(
-            "pearl_amd.mlp_block: batch norm, dropout and skip connections are not part of the HIP "
-            "learner path")
     if hidden_activation not in HIDDEN_ACTIVATIONS:
         raise NotImplementedError(
             f"pearl_amd.mlp_block: hidden_activation {hidden_activation!r} has no HIP kernel "
@@ -49,12 +48,30 @@ def mlp_block(input_dim: int, hidden_dims: Optional[List[int]], output_dim: int 
         single = [nn.Linear(d_in, d_out)]
         if use_layer_norm:
             single.append(nn.LayerNorm(d_out))          # (utils.py:110-113: between Linear and activation)
+        if dropout_ratio > 0:
+            single.append(nn.Dropout(p=dropout_ratio))  # (:114-116)
         single.append(_ACTIVATIONS[hidden_activation]())
-        layers.append(nn.Sequential(*single))
+        if use_batch_norm:
+            single.append(nn.BatchNorm1d(d_out))        # (:119-121: AFTER the activation)
+        block: nn.Module = nn.Sequential(*single)
+        if use_skip_connections:                        # (:122-131)
+            if d_in == d_out:
+                block = ResidualWrapper(block)
+            else:
+                logging.warning("Skip connections are enabled, but layer in_dim (%d) != out_dim (%d). "
+                                "Skip connection will not be added for this layer", d_in, d_out)
+        layers.append(block)
     last = [nn.Linear(dims[-2], dims[-1])]
     if last_activation is not None:
         last.append(_ACTIVATIONS[last_activation]())
-    layers.append(nn.Sequential(*last))
+    last_block: nn.Module = nn.Sequential(*last)
+    if use_skip_connections:                            # (:142-150)
+        if dims[-2] == dims[-1]:
+            last_block = ResidualWrapper(last_block)
+        else:
+            logging.warning("Skip connections are enabled, but layer in_dim (%d) != out_dim (%d). "
+                            "Skip connection will not be added for this layer", dims[-2], dims[-1])
+    layers.append(last_block)
     return nn.Sequential(*layers)
 
 
@@ -70,7 +87,12 @@ def linear_layers_of_plain(model: nn.Module, owner: str) -> List[nn.Linear]:
                 and type(blk[1]) is nn.ReLU):
             raise NotImplementedError(
                 f"pearl_amd: {owner} has hidden layers that are not Linear + ReLU (LayerNorm / other "
-                "activations): this learner's fused HIP kernels compute the plain form only")
+                "activations / batch norm / dropout / skip connections): this learner's fused HIP "
+                "kernels compute the plain form only")
+    if blocks and not (isinstance(blocks[-1], nn.Sequential) and isinstance(blocks[-1][0], nn.Linear)):
+        raise NotImplementedError(
+            f"pearl_amd: {owner}'s last layer is wrapped (skip connection): this learner's fused HIP "
+            "kernels compute the plain form only")
     return [m for m in model.modules() if isinstance(m, nn.Linear)]
 
 

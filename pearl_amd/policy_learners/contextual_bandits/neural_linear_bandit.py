@@ -202,9 +202,14 @@ class NeuralLinearBandit(PolicyLearner):
             n_hidden = len(layers) - 1
             ident = ((1 << n_hidden) - 1) if spec["identity"] else (1 << (n_hidden - 1))
             norms = (list(spec["norms"]) + [None]) if spec["norms"] else None
+            # (round 6) batch norm / dropout sit on the trunk's hidden layers only; a skip connection
+            # may also wrap the trunk's own output layer (index n_hidden - 1 here)
+            bnorms = (list(spec["bnorms"]) + [None]) if spec["bnorms"] else None
+            drops = [spec["dropout"]] * (n_hidden - 1) + [0.0]
             self._flat["net"] = FlatMlp(layers, self._optimizer, max(self._batch_size, 1),
                                         identity_layers=ident, norms=norms,
-                                        hidden_act=spec["hidden_act"], frozen_last=frozen)
+                                        hidden_act=spec["hidden_act"], frozen_last=frozen,
+                                        bnorms=bnorms, dropout=drops, residual=spec["residual"])
         if self.model.nn_e2e:
             return self._flat["net"].ensure(batch_hint)
         self._load_head()

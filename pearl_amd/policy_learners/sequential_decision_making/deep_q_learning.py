@@ -163,6 +163,12 @@ class DeepQLearning(PolicyLearner):
                 raise NotImplementedError(
                     "pearl_amd DeepQLearning: the Q network is not an mlp_block the HIP engine computes "
                     "(batch norm, dropout or residual blocks, or an activation without a kernel)")
+            if spec["bnorms"]:
+                raise NotImplementedError(
+                    "pearl_amd DeepQLearning: BatchNorm1d inside a VanillaQValueNetwork — the reference's "
+                    "own forward raises there (get_q_values feeds a (B, A, S + AD) tensor, which is not "
+                    "BatchNorm1d's (N, C) / (N, C, L): q_value_networks.py:152-174); multi-head networks "
+                    "take batch norm")
             lin = spec["linears"]
             self._fused = (spec["plain"] and len(lin) == 3 and lin[0].out_features <= 256
                            and lin[1].out_features <= 256 and lin[2].out_features == 1)

@@ -12,7 +12,7 @@ list of biases: one nn.Linear normally, two for the Gaussian actor head where ``
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -48,7 +48,9 @@ class FlatMlp:
                  target_layers: Optional[List[Layer]] = None, identity_layers: int = 0,
                  norms: Optional[Sequence[nn.LayerNorm]] = None,
                  target_norms: Optional[Sequence[nn.LayerNorm]] = None, hidden_act: int = 0,
-                 frozen_last: bool = False) -> None:
+                 frozen_last: bool = False, bnorms: Optional[Sequence[Optional[nn.BatchNorm1d]]] = None,
+                 target_bnorms: Optional[Sequence[Optional[nn.BatchNorm1d]]] = None,
+                 dropout: Any = 0.0, residual: int = 0) -> None:
         self.layers = layers
         # the last layer's tensors are NOT parameters of the caller's optimizer (the bandit's
         # nn_e2e=False head: the regression's coefficients, rewritten by the caller before every
@@ -72,6 +74,28 @@ class FlatMlp:
         assert self.norms is None or len(self.norms) == len(layers) - 1
         assert (self.target_norms is None) == (self.norms is None or target_layers is None)
         self.norm_mask = sum(1 << i for i, n in enumerate(self.norms or []) if n is not None)
+        # round 6 — the remaining options of mlp_block (pa_mlp_desc.batch_norm / dropout / residual):
+        # the hidden layers' nn.BatchNorm1d modules (weight / bias join the flat buffers behind the
+        # LayerNorm block; running_mean / running_var / num_batches_tracked stay the modules' buffers
+        # and are updated by the kernels), the dropout probability per hidden layer, and the mask of
+        # layers wrapped in a ResidualWrapper
+        n_hidden = len(layers) - 1
+        self.bnorms = list(bnorms) if bnorms and any(b is not None for b in bnorms) else None
+        self.target_bnorms = list(target_bnorms) if (target_bnorms and self.bnorms) else None
+        assert self.bnorms is None or len(self.bnorms) == n_hidden
+        assert (self.target_bnorms is None) == (self.bnorms is None or target_layers is None)
+        self.bn_mask = sum(1 << i for i, b in enumerate(self.bnorms or []) if b is not None)
+        ps = list(dropout) if isinstance(dropout, (list, tuple)) else [float(dropout)] * n_hidden
+        assert len(ps) == n_hidden and all(0.0 <= p < 1.0 for p in ps)
+        self.dropout = [float(p) for p in ps]
+        self.drop_mask = sum(1 << i for i, p in enumerate(self.dropout) if p > 0.0)
+        self.residual = int(residual)
+        # dropout keep masks: callable(layer, use_target, B, d, device) -> [B, d] float tensor of 0 / 1
+        # (None: torch's generator on the device); parity tests replay the reference's draws.
+        # `training` False switches dropout off (nn.Module.eval() on the owning network)
+        self.dropout_source: Optional[Any] = None
+        self.training = True
+        self._drop_live: Dict[Tuple[int, bool], torch.Tensor] = {}
         self.optimizer = optimizer
         self.max_batch = int(max_batch)
         self.dims = [int(layers[0][0][0].shape[1])] + [
@@ -101,6 +125,8 @@ class FlatMlp:
         ps = [p for ws, bs in self.layers for p in (*ws, *bs)]
         if self.norms:
             ps += [p for ln in self.norms if ln is not None for p in (ln.weight, ln.bias)]
+        if self.bnorms:
+            ps += [p for bn in self.bnorms if bn is not None for p in (bn.weight, bn.bias)]
         return ps
 
     def _frozen(self) -> List[torch.Tensor]:
@@ -117,12 +143,23 @@ class FlatMlp:
         ps = [p for ws, bs in self.target_layers for p in (*ws, *bs)]
         if self.target_norms:
             ps += [p for ln in self.target_norms if ln is not None for p in (ln.weight, ln.bias)]
+        if self.target_bnorms:
+            ps += [p for bn in self.target_bnorms if bn is not None for p in (bn.weight, bn.bias)]
         return ps
 
     @property
     def plain(self) -> bool:
         """Linear + ReLU (+ identity layers): the form the fused row kernels compute."""
-        return self.norms is None and self.hidden_act == 0
+        return (self.norms is None and self.hidden_act == 0 and self.bnorms is None
+                and self.drop_mask == 0 and self.residual == 0)
+
+    def _bn_buffers(self) -> List[torch.Tensor]:
+        out = []
+        for group in (self.bnorms, self.target_bnorms):
+            for bn in (group or []):
+                if bn is not None:
+                    out += [bn.running_mean, bn.running_var, bn.num_batches_tracked]
+        return out
 
     def _group(self) -> dict:
         if self.optimizer is None:
@@ -195,6 +232,7 @@ class FlatMlp:
             sig.append((p.data_ptr(), tuple(st[k].data_ptr() if k in st else 0
                                             for k in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"))))
         sig.extend(p.data_ptr() for p in self._target_params())
+        sig.extend(b.data_ptr() for b in self._bn_buffers())
         return tuple(sig)
 
     def frozen_reloaded(self) -> None:
@@ -221,7 +259,8 @@ class FlatMlp:
         g = self._group()
         max_b = max(self.max_batch, int(batch_hint), 1)
         key = (dev.index, tuple(self.dims), max_b, g["lr"], tuple(g["betas"]), g["eps"],
-               g["weight_decay"], bool(g.get("amsgrad", False)), self.hidden_act, self.norm_mask)
+               g["weight_decay"], bool(g.get("amsgrad", False)), self.hidden_act, self.norm_mask,
+               self.bn_mask, self.drop_mask, self.residual)
         if self.handle is not None and key != self._desc_key:
             torch.cuda.synchronize(dev)
             self.close()
@@ -231,7 +270,8 @@ class FlatMlp:
                              weight_decay=g["weight_decay"], amsgrad=int(bool(g.get("amsgrad", False))),
                              no_last_bias=int(len(self.layers[-1][1]) == 0),
                              identity_layers=self.identity_layers, hidden_act=self.hidden_act,
-                             layer_norm=self.norm_mask)
+                             layer_norm=self.norm_mask, batch_norm=self.bn_mask, dropout=self.drop_mask,
+                             residual=self.residual)
             for i, d in enumerate(self.dims):
                 desc.dims[i] = d
             self._desc = desc
@@ -283,6 +323,15 @@ class FlatMlp:
                 tn = self.target_norms[li] if self.target_norms else None
                 groups.append(([ln.weight], int(noffs[2 * li]), [tn.weight] if tn is not None else None))
                 groups.append(([ln.bias], int(noffs[2 * li + 1]), [tn.bias] if tn is not None else None))
+        if self.bnorms:
+            boffs = (C.c_int64 * (2 * len(self.bnorms)))()
+            N.check(N.lib().pa_mlp_bn_offsets(C.byref(self._desc), boffs))
+            for li, bn in enumerate(self.bnorms):
+                if bn is None:
+                    continue
+                tb = self.target_bnorms[li] if self.target_bnorms else None
+                groups.append(([bn.weight], int(boffs[2 * li]), [tb.weight] if tb is not None else None))
+                groups.append(([bn.bias], int(boffs[2 * li + 1]), [tb.bias] if tb is not None else None))
         frozen = self._frozen()
         with torch.no_grad():
             for plist, o, tl in groups:
@@ -322,6 +371,17 @@ class FlatMlp:
                             exp_avg_sq=N.ptr(flat.get("exp_avg_sq")),
                             max_exp_avg_sq=N.ptr(flat.get("max_exp_avg_sq")))
         N.check(N.lib().pa_mlp_bind(self.handle, C.byref(bufs)))
+        # the BatchNorm1d modules' running statistics: updated in place by every forward
+        for which, group in ((0, self.bnorms), (1, self.target_bnorms)):
+            for li, bn in enumerate(group or []):
+                if bn is None:
+                    continue
+                for b in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+                    assert b.device == dev, "BatchNorm1d buffers must live on the network's device"
+                assert bn.running_mean.dtype == torch.float32 and bn.num_batches_tracked.dtype == torch.int64
+                N.check(N.lib().pa_mlp_bind_batch_norm(
+                    self.handle, which, li, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                    bn.num_batches_tracked.data_ptr()))
         self.flat = flat
         self._sig = self._signature()
         self._steps = steps
@@ -364,10 +424,33 @@ class FlatMlp:
         self.ready(B)
         if out is None:
             out = torch.empty(B, self.dims[-1], dtype=torch.float32, device=x.device)
+        if self.drop_mask:
+            self._set_dropout_masks(B, bool(use_target), bool(keep), x.device)
         N.check(N.lib().pa_mlp_forward(self.handle, int(use_target), x.data_ptr(), x.stride(0), B,
                                        out.data_ptr(), out.stride(0), int(keep),
                                        N.stream_ptr(x.device)))
         return out
+
+    def _set_dropout_masks(self, B: int, use_target: bool, keep: bool, dev: torch.device) -> None:
+        """nn.Dropout in training mode (utils.py:114-116; the reference never switches its networks
+        to eval, so every forward — online, target, act-time — draws): one keep mask per dropout layer
+        for this forward, scaled by 1 / (1 - p), handed to the engine; the kept forward's masks stay
+        alive until its backward."""
+        for li, p in enumerate(self.dropout):
+            if p <= 0.0:
+                continue
+            if not self.training:
+                N.check(N.lib().pa_mlp_set_dropout(self.handle, li, None, 0))
+                continue
+            d = self.dims[li + 1]
+            if self.dropout_source is not None:
+                keep01 = self.dropout_source(li, use_target, B, d, dev).to(dev, torch.float32)
+            else:
+                keep01 = torch.empty(B, d, dtype=torch.float32, device=dev).bernoulli_(1.0 - p)
+            mask = (keep01 * (1.0 / (1.0 - p))).contiguous()
+            assert tuple(mask.shape) == (B, d)
+            self._drop_live[(li, keep and not use_target)] = mask      # (alive past the launch)
+            N.check(N.lib().pa_mlp_set_dropout(self.handle, li, mask.data_ptr(), mask.stride(0)))
 
     def _dw_mode(self, want_dw: bool, defer: bool, x: torch.Tensor, d_out: torch.Tensor) -> int:
         """0: no weight gradients; 1: now; 2: deferred to adam(), where ONE launch per three layers

@@ -52,24 +52,44 @@ _ACT_KIND = {nn.ReLU: 0, nn.LeakyReLU: 1, nn.Tanh: 2, nn.Softplus: 3, nn.Sigmoid
 
 def mlp_spec(model: nn.Module) -> Optional[Dict[str, Any]]:
     """What the pa_mlp engine needs to know about an mlp_block (common/utils.py:75-152), or None when
-    the model is something else: hidden blocks ``Sequential(Linear[, LayerNorm], activation)`` that
-    all have the same form, then ``Sequential(Linear)``.  Activations: ReLU, LeakyReLU (slope 0.01),
-    Tanh, Softplus (beta 1, threshold 20), Sigmoid, Identity.  Returns ``linears``, ``norms`` (the
-    LayerNorm modules or None), ``hidden_act`` (pa_mlp_desc.hidden_act), ``identity`` (hidden layers
-    have no activation), ``plain`` (Linear + ReLU only: the fused kernels' form)."""
+    the model is something else: hidden blocks ``Sequential(Linear[, LayerNorm][, Dropout], activation
+    [, BatchNorm1d])`` that all have the same form, each possibly inside a ``ResidualWrapper``, then
+    ``Sequential(Linear)`` (possibly wrapped too).  Activations: ReLU, LeakyReLU (slope 0.01), Tanh,
+    Softplus (beta 1, threshold 20), Sigmoid, Identity.  Returns ``linears``, ``norms`` (the LayerNorm
+    modules or None), ``bnorms`` (the BatchNorm1d modules or None), ``dropout`` (p of the hidden
+    layers' nn.Dropout, 0.0 without), ``residual`` (bit l: layer l is wrapped), ``hidden_act``
+    (pa_mlp_desc.hidden_act), ``identity`` (hidden layers have no activation), ``plain`` (Linear +
+    ReLU only: the fused kernels' form)."""
+    from ...neural_networks.common.residual_wrapper import ResidualWrapper
     if not isinstance(model, nn.Sequential) or len(model) == 0:
         return None
     blocks = list(model)
-    linears, norms, kinds = [], [], []
-    for blk in blocks[:-1]:
-        if not (isinstance(blk, nn.Sequential) and len(blk) in (2, 3) and isinstance(blk[0], nn.Linear)):
+    linears, norms, bnorms, drops, kinds = [], [], [], [], []
+    residual = 0
+    for li, blk in enumerate(blocks[:-1]):
+        if isinstance(blk, ResidualWrapper):
+            residual |= 1 << li
+            blk = blk.module
+        if not (isinstance(blk, nn.Sequential) and 2 <= len(blk) <= 5 and isinstance(blk[0], nn.Linear)):
             return None
-        ln = blk[1] if len(blk) == 3 else None
-        if ln is not None:
-            if not (type(ln) is nn.LayerNorm and ln.elementwise_affine and ln.bias is not None
-                    and tuple(ln.normalized_shape) == (blk[0].out_features,) and ln.eps == 1e-5):
-                return None
-        act = blk[-1]
+        rest = list(blk)[1:]
+        ln = rest.pop(0) if rest and type(rest[0]) is nn.LayerNorm else None
+        dr = rest.pop(0) if rest and type(rest[0]) is nn.Dropout else None
+        if not rest:
+            return None
+        act = rest.pop(0)
+        bn = rest.pop(0) if rest and type(rest[0]) is nn.BatchNorm1d else None
+        if rest:
+            return None
+        d_out = blk[0].out_features
+        if ln is not None and not (ln.elementwise_affine and ln.bias is not None
+                                   and tuple(ln.normalized_shape) == (d_out,) and ln.eps == 1e-5):
+            return None
+        if bn is not None and not (bn.affine and bn.track_running_stats and bn.num_features == d_out
+                                   and bn.eps == 1e-5 and bn.momentum == 0.1):
+            return None
+        if dr is not None and not (0.0 < dr.p < 1.0 and not dr.inplace):
+            return None
         if type(act) is nn.Identity:
             kind = -1
         elif type(act) in _ACT_KIND:
@@ -80,26 +100,37 @@ def mlp_spec(model: nn.Module) -> Optional[Dict[str, Any]]:
                 return None
         else:
             return None
-        linears.append(blk[0]); norms.append(ln); kinds.append(kind)
+        linears.append(blk[0]); norms.append(ln); bnorms.append(bn); kinds.append(kind)
+        drops.append(float(dr.p) if dr is not None else 0.0)
     last = blocks[-1]
+    if isinstance(last, ResidualWrapper):
+        residual |= 1 << (len(blocks) - 1)
+        last = last.module
     if not (isinstance(last, nn.Sequential) and len(last) == 1 and isinstance(last[0], nn.Linear)):
         return None
     linears.append(last[0])
-    if len(set(kinds)) > 1 or len({n is None for n in norms}) > 1:
+    if len(set(kinds)) > 1 or len({n is None for n in norms}) > 1 or len({b is None for b in bnorms}) > 1 \
+            or len(set(drops)) > 1:
         return None                     # mlp_block gives every hidden layer the same form
+    for l in range(len(linears)):
+        if (residual >> l) & 1 and linears[l].in_features != linears[l].out_features:
+            return None
     has_ln = bool(norms) and norms[0] is not None
+    has_bn = bool(bnorms) and bnorms[0] is not None
+    p_drop = drops[0] if drops else 0.0
     kind = kinds[0] if kinds else 0
-    return {"linears": linears, "norms": norms if has_ln else None, "hidden_act": max(kind, 0),
-            "identity": kind == -1, "plain": (not has_ln) and kind == 0}
+    return {"linears": linears, "norms": norms if has_ln else None, "bnorms": bnorms if has_bn else None,
+            "dropout": p_drop, "residual": residual, "hidden_act": max(kind, 0), "identity": kind == -1,
+            "plain": (not has_ln) and (not has_bn) and p_drop == 0.0 and residual == 0 and kind == 0}
 
 
 def plain_or_spec(model: nn.Module, what: str) -> Dict[str, Any]:
     spec = mlp_spec(model)
     if spec is None:
         raise NotImplementedError(
-            f"pearl_amd: {what} is not an mlp_block the HIP engine computes (Linear [+ LayerNorm] + "
-            "relu / leaky_relu / tanh / softplus / sigmoid / linear hidden layers; batch norm, dropout "
-            "and residual blocks have no kernels)")
+            f"pearl_amd: {what} is not an mlp_block the HIP engine computes (Linear [+ LayerNorm] [+ Dropout] "
+            "+ relu / leaky_relu / tanh / softplus / sigmoid / linear [+ BatchNorm1d] hidden layers of one "
+            "form, optionally with skip connections)")
     return spec
 
 
@@ -113,7 +144,9 @@ def flat_mlp_of(model: nn.Module, target_model: Optional[nn.Module], optimizer: 
                    target_layers=layers_of(tspec["linears"]) if tspec is not None else None,
                    identity_layers=((1 << (L - 1)) - 1) if spec["identity"] else 0,
                    norms=spec["norms"], target_norms=tspec["norms"] if tspec is not None else None,
-                   hidden_act=spec["hidden_act"])
+                   hidden_act=spec["hidden_act"], bnorms=spec["bnorms"],
+                   target_bnorms=tspec["bnorms"] if tspec is not None else None,
+                   dropout=spec["dropout"], residual=spec["residual"])
 
 
 def _f32(t: Tensor, dev: torch.device) -> Tensor:

@@ -16,7 +16,7 @@ int main(void) {
   O(pa_dqn_desc, double_q); O(pa_learn_args, training_steps0);
   O(pa_learn_args, seed); O(pa_learn_args, losses_out); O(pa_learn_args, idx_host);
   P(pa_mlp_desc); P(pa_mlp_buffers); P(pa_sac_step_args); P(pa_ddpg_step_args); P(pa_ac_loop_args);
-  O(pa_mlp_desc, max_batch); O(pa_mlp_desc, lr); O(pa_mlp_desc, identity_layers); O(pa_mlp_desc, hidden_act); O(pa_mlp_desc, layer_norm);
+  O(pa_mlp_desc, max_batch); O(pa_mlp_desc, lr); O(pa_mlp_desc, identity_layers); O(pa_mlp_desc, hidden_act); O(pa_mlp_desc, layer_norm); O(pa_mlp_desc, batch_norm); O(pa_mlp_desc, residual);
   O(pa_mlp_buffers, max_exp_avg_sq);
   O(pa_sac_step_args, ld_state); O(pa_sac_step_args, terminated); O(pa_sac_step_args, noise_critic);
   O(pa_sac_step_args, target_entropy); O(pa_sac_step_args, alpha_lr); O(pa_sac_step_args, alpha_amsgrad);

@@ -133,8 +133,8 @@ def test_unsupported_configurations_fail_loudly():
     # training it as ReLU
     with pytest.raises(NotImplementedError, match="not Linear \\+ ReLU"):
         net.linear_layers()
-    # refused: hidden layers of MIXED form (mlp_block gives every hidden layer the same one), batch
-    # norm, dropout, residual blocks, activations without a kernel
+    # refused: hidden layers of MIXED form (mlp_block gives every hidden layer the same one),
+    # activations without a kernel
     net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
     net._model[0][1] = nn.Tanh()
     with pytest.raises(NotImplementedError, match="not an mlp_block the HIP engine computes"):
@@ -147,10 +147,38 @@ def test_unsupported_configurations_fail_loudly():
     net._model[0] = nn.Sequential(nn.Linear(7, 8), nn.ReLU(), nn.BatchNorm1d(8))
     with pytest.raises(NotImplementedError, match="not an mlp_block the HIP engine computes"):
         DeepQLearning(network_instance=net, **kw)
-    for bad in (dict(use_batch_norm=True), dict(dropout_ratio=0.1), dict(use_skip_connections=True),
-                dict(hidden_activation="normalized_softplus")):
-        with pytest.raises(NotImplementedError):
-            mlp_block(7, [8, 8], 1, **bad)
+    with pytest.raises(NotImplementedError):
+        mlp_block(7, [8, 8], 1, hidden_activation="normalized_softplus")
+    # built (round 6): mlp_block's batch norm, dropout and skip connections (utils.py:113-131, :142-150)
+    # — the module tree and state_dict keys are the reference's
+    from pearl_amd.neural_networks.common.residual_wrapper import ResidualWrapper
+    from pearl_amd.policy_learners.sequential_decision_making.generic_q import mlp_spec
+    m = mlp_block(8, [8, 6], 6, use_batch_norm=True, use_layer_norm=True, dropout_ratio=0.25,
+                  use_skip_connections=True)
+    assert isinstance(m[0], ResidualWrapper) and not isinstance(m[1], ResidualWrapper) \
+        and isinstance(m[2], ResidualWrapper)                   # 8 -> 8 wrapped, 8 -> 6 not, 6 -> 6 wrapped
+    assert [type(x).__name__ for x in m[0].module] == ["Linear", "LayerNorm", "Dropout", "ReLU", "BatchNorm1d"]
+    assert list(m.state_dict())[:9] == [
+        "0.module.0.weight", "0.module.0.bias", "0.module.1.weight", "0.module.1.bias", "0.module.4.weight",
+        "0.module.4.bias", "0.module.4.running_mean", "0.module.4.running_var", "0.module.4.num_batches_tracked"]
+    spec = mlp_spec(m)
+    assert spec["residual"] == 0b101 and spec["dropout"] == 0.25 and not spec["plain"]
+    assert all(isinstance(b, nn.BatchNorm1d) for b in spec["bnorms"]) and len(spec["norms"]) == 2
+    assert mlp_spec(mlp_block(7, [8, 8], 1))["plain"]
+    # a skip connection on the last layer must not slip through the plain-form learners
+    from pearl_amd.neural_networks.common.value_networks import VanillaValueNetwork
+    with pytest.raises(NotImplementedError, match="plain form"):
+        VanillaValueNetwork(4, [8, 8], 8, use_skip_connections=True).linear_layers()
+    # BatchNorm1d in a VanillaQValueNetwork: the reference's own forward raises (its (B, A, S + AD)
+    # input is not BatchNorm1d's (N, C) / (N, C, L)), so the learner refuses it; multi-head networks
+    # (2-D state input) take it
+    net = VanillaQValueNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=1)
+    net._model = mlp_block(7, [8, 8], 1, use_batch_norm=True)
+    with pytest.raises(NotImplementedError, match="BatchNorm1d"):
+        DeepQLearning(network_instance=net, **kw)
+    mh = VanillaQValueMultiHeadNetwork(state_dim=4, action_dim=3, hidden_dims=[8, 8], output_dim=3)
+    mh._model = mlp_block(4, [8, 8], 3, use_batch_norm=True, dropout_ratio=0.1, use_skip_connections=True)
+    assert not DeepQLearning(network_instance=mh, **kw)._fused
     with pytest.raises(NotImplementedError):
         DeepQLearning(hidden_dims=[8, 8], optimizer=torch.optim.SGD(net.parameters(), lr=0.1), **kw)
 

@@ -443,7 +443,12 @@ BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", 
           "pinv_tiny",
           # nn_e2e=False (neural_linear_regression.py:100-105): the engine's last layer is the
           # regression's coefficients, reloaded before every step and owned by no optimizer
-          "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny"]
+          "lin_head_tiny", "lin_head_small", "lin_head_sigmoid_tiny",
+          # mlp_block's remaining options (common/utils.py:113-131, :142-150; round 6): BatchNorm1d after
+          # the activation (training mode, running statistics updated by the kernels), Dropout (the
+          # reference's recorded keep masks), skip connections — alone, all together with LayerNorm and
+          # leaky_relu, and batch norm + skip at BASELINE config 5's own shape (4096 x 512)
+          "bn_tiny", "dropout_tiny", "skip_tiny", "bn_ln_dropout_skip_small", "bn_cfg5_shape"]
 
 
 @pytest.mark.parametrize("name", BANDIT)
@@ -463,10 +468,17 @@ def test_neural_linear_bandit_learn_batch(name):
                             output_activation_name=cfg.get("out", "linear"), **cfg.get("mlp", {}))
     pl.model.load_state_dict(fx["model0"])
     pl.to(DEV)
+    if "drop_masks" in fx:      # replay the reference's dropout draws (one trunk forward per learn_batch)
+        queue = []
+        pl._net(cfg["B"]).dropout_source = lambda li, tgt, B_, d, dev: queue.pop(0)
     for step, ((x, r, w), want) in enumerate(zip(bandit_batches(fx), fx["reports"])):
         tb = TransitionBatch(state=x.to(DEV), action=torch.zeros(cfg["B"], 1, device=DEV),
                              reward=r.to(DEV), weight=None if w is None else w.to(DEV))
+        if "drop_masks" in fx:
+            queue.extend(fx["drop_masks"][step])
         rep = pl.learn_batch(tb)
+        if "drop_masks" in fx:
+            assert not queue, "the step did not consume one mask per dropout layer"
         tol = 1e-5 if step == 0 else 2e-4
         assert abs(float(rep["loss"]) - want["loss"]) <= tol * max(1.0, abs(want["loss"])), step
         torch.testing.assert_close(rep["prediction"].cpu(), want["prediction"],
@@ -494,6 +506,8 @@ def test_neural_linear_bandit_learn_batch(name):
                                      max_outlier_frac=0.0 if cfg["B"] < 4096 else 2e-3, msg=k)
     assert_adam_trajectory_close(pl.model.linear_layer_e2e.weight, after["linear_layer_e2e.weight"],
                                  1e-3, steps, rtol=1e-3, atol=2e-5, max_outlier_frac=0.0, msg="e2e")
+    if fx.get("query_eval"):
+        pl.model.eval()      # (the fixture's query ran in eval mode: running statistics, no dropout)
     # sigma = sqrt(x^T inv_A x) on the learner's own features
     xq = fx["query"]["x"].to(DEV)
     with torch.no_grad():
