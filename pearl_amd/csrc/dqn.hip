@@ -1737,9 +1737,14 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       const bool last = pc == npieces - 1;
       const bool lead_p = !last && h->lead_persist && persist;
       static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
+      // PEARL_AMD_LEAD_ROWS=32: the leading (latency-bound, 16- / 32-tile) pieces on the 32-row,
+      // four-wave tile — twice the workgroups, half the rows each, bitwise the 64-row tile
+      // (1: only the window's first piece)
+      static const int lead_rows = env_int("PEARL_AMD_LEAD_ROWS", 0);
+      const int hint = (!last && (lead_rows == 32 || (lead_rows == 1 && pc == 0))) ? 32 : 0;
       rc = run_target_fused_u(h, &b, Up, nullptr, h->yw[p] + row0, t, (persist && last) || lead_p,
                               nullptr, sample_w && (last || (short_call && pc >= 1)), lead_p,
-                              (prio && pc == 0 && !last) ? B : 0, read_u);
+                              (prio && pc == 0 && !last) ? B : 0, read_u, hint);
       if (rc != PA_OK) return rc;
       j0 += nj;
       // The call's first window: the host is the pacemaker here (nothing is queued ahead), and the
