@@ -30,7 +30,12 @@ PPO cfg4 32 rounds 5.4e-6 vs 3.6e-6 (ratio 1.5, last-layer bias 7.3; with the fp
 PEARL_AMD_TEST_ROWSTEP_SPLIT=0 — 1.02: the difference is the bf16x3 row step, not the order of sums);
 PPO epsilon = 0, 6 rounds 3.9e-7 vs 1.1e-8 and bandit cfg5 20 steps 7.5e-6 vs 4.1e-7: the reference
 is at rounding level there and the HIP loop is 20-35x further — 0.07 % / 0.04 % of the AdamW travel,
-heavy-tailed (max / rms ~ 19: elements whose gradient is at the level of AdamW's eps)."""
+heavy-tailed (max / rms ~ 19: elements whose gradient is at the level of AdamW's eps).  That ratio
+measures WHEN the first noise-level event happens, not how sums are formed
+(profiles/r06_e_long_run_distance_is_event_driven.txt): the HIP gradients of step 1 are closer to
+float64 than MKL's in every tensor, for four steps the HIP run is twice as close as a CPU fp32 run,
+both jump by the same 1.2e-7 at one step and grow with the dynamics from there — and two CPU runs of
+the same torch code on two hosts end 6.6x apart from each other."""
 import os
 import random
 
