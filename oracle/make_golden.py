@@ -120,6 +120,15 @@ QNET_CONFIGS = {
                              network="dueling", learner="cql"),
     "cql_dueling_small": dict(S=16, A=6, hidden=[32, 32], N=300, B=64, rounds=8, dynamic=False,
                               network="dueling", learner="cql"),
+    # mlp_block's skip connections / batch norm (common/utils.py:113-131; round 6) as network_instances:
+    # a Vanilla network whose hidden layers are all wrapped (S + A = 10 -> 10 -> 10 -> 10 -> 1), and a
+    # multi-head network with BatchNorm1d after every hidden activation plus skip connections (a
+    # VanillaQValueNetwork cannot carry BatchNorm1d: its (B, A, S + AD) input is not the layer's)
+    "skip_deep_tiny": dict(S=5, A=5, hidden=[10, 10, 10], N=48, B=16, rounds=11, dynamic=True,
+                           network="vanilla", mlp=dict(use_skip_connections=True)),
+    "bn_skip_multihead_small": dict(S=16, A=6, hidden=[16, 16], N=300, B=64, rounds=8, dynamic=False,
+                                    network="multihead", learner="double",
+                                    mlp=dict(use_batch_norm=True, use_skip_connections=True)),
 }
 NETWORK_TYPES = {"vanilla": VanillaQValueNetwork, "multihead": VanillaQValueMultiHeadNetwork,
                  "dueling": DuelingQValueNetwork}
@@ -174,7 +183,16 @@ def make(name, cfg):
     qnet = "network" in cfg
     if qnet:
         extra["network_type"] = NETWORK_TYPES[cfg["network"]]
-    if qnet and (cfg.get("use_layer_norm") or cfg.get("hidden_activation")):
+    if qnet and cfg.get("mlp"):
+        from pearl.neural_networks.common.utils import mlp_block
+        multi = cfg["network"] == "multihead"
+        net = NETWORK_TYPES[cfg["network"]](state_dim=S, action_dim=A, hidden_dims=cfg["hidden"],
+                                            output_dim=A if multi else 1)
+        net._model = mlp_block(input_dim=S if multi else S + A, hidden_dims=cfg["hidden"],
+                               output_dim=A if multi else 1, **cfg["mlp"])
+        extra.pop("network_type")
+        extra["network_instance"] = net
+    elif qnet and (cfg.get("use_layer_norm") or cfg.get("hidden_activation")):
         # a network_instance in one of mlp_block's other forms: LayerNorm through the network's own
         # use_layer_norm argument, another hidden activation by rebuilding its _model with mlp_block
         from pearl.neural_networks.common.utils import mlp_block

@@ -384,22 +384,47 @@ _HIDDEN_ACTS = {
 }
 
 
+def _is_buffer_key(k: str) -> bool:
+    return k.endswith(("running_mean", "running_var", "num_batches_tracked"))
+
+
 def _mlp_sd(w: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor,
             hidden_activation: str = "relu") -> torch.Tensor:
-    """mlp_block (common/utils.py:75-152) from state-dict tensors `prefix`{i}.0.weight/bias: Linear
-    [+ nn.LayerNorm when `prefix`{i}.1.weight exists: between the Linear and its activation,
-    utils.py:110-113; biased variance, eps 1e-5] + the hidden activation for every layer but the last."""
+    """mlp_block (common/utils.py:75-152) from state-dict tensors: per hidden block Linear
+    [+ nn.LayerNorm: between the Linear and its activation, utils.py:110-113; biased variance, eps
+    1e-5] + the hidden activation [+ nn.BatchNorm1d AFTER it, :119-121, in TRAINING mode: the
+    statistics of the batch at hand — the reference never switches to eval()], the whole block inside a
+    ResidualWrapper (`{i}.module.` keys, :122-131) when its widths agree; then the last Linear
+    (possibly wrapped, :142-150).  (Dropout, which has no tensors, is not restated here.)"""
     act = _HIDDEN_ACTS[hidden_activation]
+
+    def base_of(i):
+        b = f"{prefix}{i}."
+        return (b + "module.", True) if (b + "module.0.weight") in w else (b, False)
+
     i = 0
-    while f"{prefix}{i + 1}.0.weight" in w:
-        x = torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"], w[f"{prefix}{i}.0.bias"])
-        if f"{prefix}{i}.1.weight" in w:
+    while f"{prefix}{i + 1}.0.weight" in w or f"{prefix}{i + 1}.module.0.weight" in w:
+        b, wrapped = base_of(i)
+        inp = x
+        x = torch.nn.functional.linear(x, w[b + "0.weight"], w[b + "0.bias"])
+        if (b + "1.weight") in w:        # index 1 with tensors: the LayerNorm (an activation has none)
             mu = x.mean(dim=-1, keepdim=True)
             var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
-            x = (x - mu) / torch.sqrt(var + 1e-5) * w[f"{prefix}{i}.1.weight"] + w[f"{prefix}{i}.1.bias"]
+            x = (x - mu) / torch.sqrt(var + 1e-5) * w[b + "1.weight"] + w[b + "1.bias"]
         x = act(x)
+        # index >= 2 with tensors: the BatchNorm1d behind the activation ([Linear, act, BN],
+        # [Linear, LN, act, BN], [Linear, (LN,) Dropout, act, BN])
+        bn = next((f"{b}{j}." for j in (2, 3, 4) if f"{b}{j}.weight" in w), None)
+        if bn is not None:
+            assert x.ndim == 2, "BatchNorm1d inside an mlp_block takes (N, C) inputs"
+            x = torch.nn.functional.batch_norm(x, None, None, w[bn + "weight"], w[bn + "bias"], training=True,
+                                               momentum=0.1, eps=1e-5)
+        if wrapped:
+            x = inp + x
         i += 1
-    return torch.nn.functional.linear(x, w[f"{prefix}{i}.0.weight"], w[f"{prefix}{i}.0.bias"])
+    b, wrapped = base_of(i)
+    out = torch.nn.functional.linear(x, w[b + "0.weight"], w[b + "0.bias"])
+    return x + out if wrapped else out
 
 
 class QNetOracle:
@@ -421,7 +446,9 @@ class QNetOracle:
         # is_conservative (deep_td_learning.py:323-327): loss += alpha * compute_cql_loss
         self.cql_alpha = cql_alpha
         self.act = hidden_activation      # (LayerNorm is read off the state dict's keys)
-        self.keys = list(params.keys())
+        # (parameters only: a BatchNorm1d's running statistics are buffers no optimizer or soft update
+        #  touches, and training-mode batch norm does not read them)
+        self.keys = [k for k in params.keys() if not _is_buffer_key(k)]
         self.p = {k: params[k].detach().clone().to(F32) for k in self.keys}
         self.t = {k: target[k].detach().clone().to(F32) for k in self.keys}
         self.m = {k: torch.zeros_like(v) for k, v in self.p.items()}

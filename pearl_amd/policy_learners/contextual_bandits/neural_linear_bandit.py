@@ -210,6 +210,8 @@ class NeuralLinearBandit(PolicyLearner):
                                         identity_layers=ident, norms=norms,
                                         hidden_act=spec["hidden_act"], frozen_last=frozen,
                                         bnorms=bnorms, dropout=drops, residual=spec["residual"])
+            if spec["dropout_modules"]:
+                self._flat["net"].dropout_modules = (list(spec["dropout_modules"]) + [None], None)
         if self.model.nn_e2e:
             return self._flat["net"].ensure(batch_hint)
         self._load_head()

@@ -92,9 +92,10 @@ class FlatMlp:
         self.residual = int(residual)
         # dropout keep masks: callable(layer, use_target, B, d, device) -> [B, d] float tensor of 0 / 1
         # (None: torch's generator on the device); parity tests replay the reference's draws.
-        # `training` False switches dropout off (nn.Module.eval() on the owning network)
+        # `dropout_modules` (the nn.Dropout modules, online then target, when the owner hands them
+        # over): a module in eval() mode draws nothing, as in torch
         self.dropout_source: Optional[Any] = None
-        self.training = True
+        self.dropout_modules: Optional[Tuple[Sequence[Any], Optional[Sequence[Any]]]] = None
         self._drop_live: Dict[Tuple[int, bool], torch.Tensor] = {}
         self.optimizer = optimizer
         self.max_batch = int(max_batch)
@@ -240,6 +241,15 @@ class FlatMlp:
         self._frozen_stale = False
 
     def ensure(self, batch_hint: int = 0) -> "FlatMlp":
+        for group in (self.bnorms, self.target_bnorms):
+            for bn in (group or []):
+                if bn is not None and not bn.training:
+                    # the engine's BatchNorm1d is the TRAINING-mode one (statistics of the batch at hand:
+                    # what the reference's learners run, they never call eval()); learning on a network
+                    # that was switched to eval() would silently use other statistics than torch
+                    raise NotImplementedError(
+                        "pearl_amd FlatMlp: a BatchNorm1d of this network is in eval() mode; the HIP "
+                        "learner step computes training-mode batch statistics (call .train() first)")
         if self.frozen_last and self._frozen_stale:
             raise RuntimeError(
                 "pearl_amd FlatMlp: the frozen last layer was not reloaded after the last optimizer "
@@ -439,8 +449,9 @@ class FlatMlp:
         for li, p in enumerate(self.dropout):
             if p <= 0.0:
                 continue
-            if not self.training:
-                N.check(N.lib().pa_mlp_set_dropout(self.handle, li, None, 0))
+            mods = self.dropout_modules[1 if use_target else 0] if self.dropout_modules else None
+            if mods is not None and mods[li] is not None and not mods[li].training:
+                N.check(N.lib().pa_mlp_set_dropout(self.handle, li, None, 0))     # eval(): identity
                 continue
             d = self.dims[li + 1]
             if self.dropout_source is not None:

@@ -64,7 +64,7 @@ def mlp_spec(model: nn.Module) -> Optional[Dict[str, Any]]:
     if not isinstance(model, nn.Sequential) or len(model) == 0:
         return None
     blocks = list(model)
-    linears, norms, bnorms, drops, kinds = [], [], [], [], []
+    linears, norms, bnorms, drops, kinds, drop_mods = [], [], [], [], [], []
     residual = 0
     for li, blk in enumerate(blocks[:-1]):
         if isinstance(blk, ResidualWrapper):
@@ -102,6 +102,7 @@ def mlp_spec(model: nn.Module) -> Optional[Dict[str, Any]]:
             return None
         linears.append(blk[0]); norms.append(ln); bnorms.append(bn); kinds.append(kind)
         drops.append(float(dr.p) if dr is not None else 0.0)
+        drop_mods.append(dr)
     last = blocks[-1]
     if isinstance(last, ResidualWrapper):
         residual |= 1 << (len(blocks) - 1)
@@ -120,7 +121,8 @@ def mlp_spec(model: nn.Module) -> Optional[Dict[str, Any]]:
     p_drop = drops[0] if drops else 0.0
     kind = kinds[0] if kinds else 0
     return {"linears": linears, "norms": norms if has_ln else None, "bnorms": bnorms if has_bn else None,
-            "dropout": p_drop, "residual": residual, "hidden_act": max(kind, 0), "identity": kind == -1,
+            "dropout": p_drop, "dropout_modules": drop_mods if p_drop > 0 else None,
+            "residual": residual, "hidden_act": max(kind, 0), "identity": kind == -1,
             "plain": (not has_ln) and (not has_bn) and p_drop == 0.0 and residual == 0 and kind == 0}
 
 
@@ -140,13 +142,16 @@ def flat_mlp_of(model: nn.Module, target_model: Optional[nn.Module], optimizer: 
     spec = plain_or_spec(model, what)
     tspec = plain_or_spec(target_model, what + " (target)") if target_model is not None else None
     L = len(spec["linears"])
-    return FlatMlp(layers_of(spec["linears"]), optimizer, max_batch,
+    net = FlatMlp(layers_of(spec["linears"]), optimizer, max_batch,
                    target_layers=layers_of(tspec["linears"]) if tspec is not None else None,
                    identity_layers=((1 << (L - 1)) - 1) if spec["identity"] else 0,
                    norms=spec["norms"], target_norms=tspec["norms"] if tspec is not None else None,
                    hidden_act=spec["hidden_act"], bnorms=spec["bnorms"],
                    target_bnorms=tspec["bnorms"] if tspec is not None else None,
                    dropout=spec["dropout"], residual=spec["residual"])
+    if spec["dropout_modules"]:
+        net.dropout_modules = (spec["dropout_modules"], tspec["dropout_modules"] if tspec is not None else None)
+    return net
 
 
 def _f32(t: Tensor, dev: torch.device) -> Tensor:

@@ -254,7 +254,9 @@ QNETS = ["deep3_tiny", "wide_small", "multihead_tiny", "multihead_double_tiny", 
          # the CQL term beyond the fused shape
          "cql_deep3_tiny", "cql_layernorm_small",
          # ... and on the other QValueNetwork types (round 6)
-         "cql_multihead_tiny", "cql_multihead_small", "cql_dueling_tiny", "cql_dueling_small"]
+         "cql_multihead_tiny", "cql_multihead_small", "cql_dueling_tiny", "cql_dueling_small",
+         # skip connections / batch norm as network instances (round 6)
+         "skip_deep_tiny", "bn_skip_multihead_small"]
 
 
 def qnet_well_conditioned(fx, key) -> torch.Tensor:
