@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import warnings
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -88,7 +89,11 @@ class SoftActorCritic(ActorCriticBase):
 
     def reset(self, action_space: Any) -> None:
         self._action_space = action_space
-        self.scheduler.step()
+        with warnings.catch_warnings():
+            # (torch counts optimizer.step() calls to warn about the order; the actor's AdamW step runs in
+            #  the HIP optimizer epilogue, torch's own step() is never called)
+            warnings.filterwarnings("ignore", message="Detected call of `lr_scheduler.step\\(\\)` before")
+            self.scheduler.step()
 
     # ------------------------------------------------------------------ flat views
     def _nets(self, batch_hint: int = 0, validate: bool = True):

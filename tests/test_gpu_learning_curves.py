@@ -1,0 +1,341 @@
+"""Learning curves through the whole drop-in path: ``PearlAgent.act -> observe -> learn`` on control tasks.
+
+The reference's only end-to-end tests of the hot path are its integration tests
+(test/integration/test_integration.py:104-134 DQN, :442-476 PPO, :630-662 continuous SAC): a small agent
+must reach a target return on CartPole-v1 / Pendulum-v1 within a bounded number of episodes, driven by
+``target_return_is_reached`` / ``run_episode``
+(pearl/utils/functional_utils/train_and_eval/online_learning.py:166-232, :235-311).  gymnasium is not
+installed here, so the two tasks are restated below from their published dynamics (Barto, Sutton & Anderson
+1983 for the cart-pole with the constants of the "v1" task: 500-step limit, 12 degrees / 2.4 m; the
+torque-limited pendulum swing-up with g = 10, 200-step limit) — plain numpy, no reference code involved.
+
+Every agent below is built from pearl_amd classes only, with the reference tests' hyper-parameters; the episode
+loop is the reference's (each episode's seed = seed + total steps so far; learn at the end of an episode or
+every k steps; the action spaces' own generators are seeded, so a run is reproducible).  What this pins that the fixtures cannot: the learners on a GROWING buffer (batch larger than
+the buffer at first), thousands of short ``learn()`` calls interleaved with pushes, act-time reads of
+parameters the HIP optimizer has just written, PPO's buffer being cleared after every ``learn()``, and that
+the arithmetic really is the algorithm — a sign error in a gradient passes no learning curve.
+"""
+import math
+import random
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- the two tasks ---------------------------------------------------------------------------
+class _Result:
+    def __init__(self, observation, reward, terminated, truncated):
+        self.observation, self.reward = observation, reward
+        self.terminated, self.truncated = terminated, truncated
+        self.info, self.cost, self.available_action_space = None, None, None
+
+    @property
+    def done(self):
+        return bool(self.terminated or self.truncated)
+
+
+class CartPole:
+    """Pole balancing on a cart: state (x, x', theta, theta'), actions push left / right with 10 N, Euler
+    steps of 20 ms, reward 1 per step, ends when |theta| > 12 degrees or |x| > 2.4 m, truncated at 500."""
+    GRAVITY, M_CART, M_POLE, HALF_LEN, FORCE, DT = 9.8, 1.0, 0.1, 0.5, 10.0, 0.02
+    THETA_MAX, X_MAX, LIMIT = 12 * 2 * math.pi / 360, 2.4, 500
+
+    def __init__(self):
+        from pearl_amd import DiscreteActionSpace
+        self.action_space = DiscreteActionSpace([torch.tensor([0]), torch.tensor([1])], seed=0)
+        self.state_dim = 4
+
+    def reset(self, seed=None):
+        self.rng = np.random.default_rng(seed)
+        self.s = self.rng.uniform(-0.05, 0.05, size=4)
+        self.t = 0
+        return torch.tensor(self.s, dtype=torch.float32), self.action_space
+
+    def step(self, action):
+        a = int(torch.as_tensor(action).reshape(-1)[0])
+        x, xd, th, thd = self.s
+        f = self.FORCE if a == 1 else -self.FORCE
+        total = self.M_CART + self.M_POLE
+        pml = self.M_POLE * self.HALF_LEN
+        c, s = math.cos(th), math.sin(th)
+        tmp = (f + pml * thd * thd * s) / total
+        thacc = (self.GRAVITY * s - c * tmp) / (self.HALF_LEN * (4.0 / 3.0 - self.M_POLE * c * c / total))
+        xacc = tmp - pml * thacc * c / total
+        self.s = np.array([x + self.DT * xd, xd + self.DT * xacc, th + self.DT * thd, thd + self.DT * thacc])
+        self.t += 1
+        terminated = bool(abs(self.s[0]) > self.X_MAX or abs(self.s[2]) > self.THETA_MAX)
+        return _Result(torch.tensor(self.s, dtype=torch.float32), 1.0, terminated,
+                       self.t >= self.LIMIT and not terminated)
+
+
+class Pendulum:
+    """Torque-limited swing-up: observation (cos th, sin th, th'), one action in [-2, 2], reward
+    -(th^2 + 0.1 th'^2 + 0.001 u^2) with th normalised to [-pi, pi), 50 ms steps, 200 steps."""
+    G, M, L, DT, MAX_SPEED, MAX_TORQUE, LIMIT = 10.0, 1.0, 1.0, 0.05, 8.0, 2.0, 200
+
+    def __init__(self):
+        from pearl_amd import BoxActionSpace
+        self.action_space = BoxActionSpace(low=torch.tensor([-2.0]), high=torch.tensor([2.0]), seed=0)
+        self.state_dim = 3
+
+    def _obs(self):
+        return torch.tensor([math.cos(self.th), math.sin(self.th), self.thd], dtype=torch.float32)
+
+    def reset(self, seed=None):
+        self.rng = np.random.default_rng(seed)
+        self.th = float(self.rng.uniform(-math.pi, math.pi))
+        self.thd = float(self.rng.uniform(-1.0, 1.0))
+        self.t = 0
+        return self._obs(), self.action_space
+
+    def step(self, action):
+        u = float(np.clip(float(torch.as_tensor(action).reshape(-1)[0]), -self.MAX_TORQUE, self.MAX_TORQUE))
+        thn = ((self.th + math.pi) % (2 * math.pi)) - math.pi
+        cost = thn * thn + 0.1 * self.thd * self.thd + 0.001 * u * u
+        self.thd = self.thd + (3 * self.G / (2 * self.L) * math.sin(self.th) + 3.0 / (self.M * self.L ** 2) * u) * self.DT
+        self.thd = float(np.clip(self.thd, -self.MAX_SPEED, self.MAX_SPEED))
+        self.th = self.th + self.thd * self.DT
+        self.t += 1
+        return _Result(self._obs(), -cost, False, self.t >= self.LIMIT)
+
+
+# ---- online_learning.py:166-311, for objects with the agent / environment interfaces -----------
+def run_episode(agent, env, learn_after_episode, learn_every_k_steps, total_steps, seed):
+    observation, action_space = env.reset(seed=seed + total_steps)
+    agent.reset(observation, action_space)
+    ret, steps, done = 0.0, 0, False
+    while not done:
+        action = agent.act(exploit=False)
+        action = action.cpu() if isinstance(action, torch.Tensor) else action
+        result = env.step(action)
+        ret += result.reward
+        agent.observe(result)
+        done = result.done
+        steps += 1
+        if learn_after_episode:
+            if done:
+                agent.learn()
+        elif (total_steps + steps) % learn_every_k_steps == 0:
+            agent.learn()
+    return ret, steps
+
+
+def target_return_is_reached(agent, env, target_return, max_episodes, learn_after_episode,
+                             learn_every_k_steps=1, check_moving_average=False, seed=42, budget_s=900.0):
+    """-> (reached, returns).  ``check_moving_average``: the mean of the last 10 returns (the reference's
+    latest_moving_average) instead of the episode's own."""
+    returns, total_steps, t0 = [], 0, time.time()
+    for _ in range(max_episodes):
+        ret, steps = run_episode(agent, env, learn_after_episode, learn_every_k_steps, total_steps, seed)
+        total_steps += steps
+        returns.append(ret)
+        value = float(np.mean(returns[-10:])) if check_moving_average else ret
+        if value >= target_return:
+            return True, returns
+        if time.time() - t0 > budget_s:
+            break
+    return False, returns
+
+
+def _seed(n):
+    random.seed(n)
+    np.random.seed(n)
+    torch.manual_seed(n)
+
+
+def _report(name, ok, returns, t0):
+    print(f"\n[{name}] reached={ok} after {len(returns)} episodes, {time.time() - t0:.1f} s; "
+          f"last returns {[round(float(r), 1) for r in returns[-5:]]}")
+
+
+def test_dqn_reaches_500_on_cartpole():
+    """test_integration.py:104-134: DeepQLearning, hidden [64, 64], 20 training rounds after every episode,
+    BasicReplayBuffer(10 000) with the default Philox device sampler (index lists drawn in the learn loop's
+    prologue kernel); return 500 within 1000 episodes."""
+    from pearl_amd import (BasicReplayBuffer, DeepQLearning, OneHotActionTensorRepresentationModule,
+                           PearlAgent)
+    _seed(0)
+    env = CartPole()
+    agent = PearlAgent(
+        policy_learner=DeepQLearning(
+            state_dim=env.state_dim, action_space=env.action_space, hidden_dims=[64, 64],
+            training_rounds=20,
+            action_representation_module=OneHotActionTensorRepresentationModule(max_number_actions=2)),
+        replay_buffer=BasicReplayBuffer(10_000), device_id=0)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=True)
+    _report("dqn cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_double_dqn_with_the_host_sampler_reaches_500_on_cartpole():
+    """The same task through the parity sampler (``sampler="python"``: ``random.sample`` index lists drawn on
+    the host like the reference's, uploaded per call) and DoubleDQN's per-round argmax pass."""
+    from pearl_amd import (BasicReplayBuffer, DoubleDQN, OneHotActionTensorRepresentationModule, PearlAgent)
+    _seed(1)
+    env = CartPole()
+    agent = PearlAgent(
+        policy_learner=DoubleDQN(
+            state_dim=env.state_dim, action_space=env.action_space, hidden_dims=[64, 64],
+            training_rounds=20,
+            action_representation_module=OneHotActionTensorRepresentationModule(max_number_actions=2)),
+        replay_buffer=BasicReplayBuffer(10_000, sampler="python"), device_id=0)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=True)
+    _report("double dqn cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_ppo_reaches_500_on_cartpole():
+    """test_integration.py:442-476: PPO, actor / critic [64, 64], 20 training rounds, batch 32, epsilon 0.1,
+    PPOReplayBuffer(10 000), learn every 200 steps; return 500 within 1000 episodes."""
+    from pearl_amd import (OneHotActionTensorRepresentationModule, PearlAgent, PPOReplayBuffer,
+                           ProximalPolicyOptimization)
+    _seed(0)
+    env = CartPole()
+    agent = PearlAgent(
+        policy_learner=ProximalPolicyOptimization(
+            action_space=env.action_space, state_dim=env.state_dim, actor_hidden_dims=[64, 64],
+            critic_hidden_dims=[64, 64], training_rounds=20, batch_size=32, epsilon=0.1,
+            action_representation_module=OneHotActionTensorRepresentationModule(max_number_actions=2)),
+        replay_buffer=PPOReplayBuffer(10_000), device_id=0)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=False,
+                                           learn_every_k_steps=200)
+    _report("ppo cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_continuous_sac_reaches_minus_250_on_pendulum():
+    """test_integration.py:630-662: ContinuousSoftActorCritic, [64, 64] networks, 50 training rounds of batch
+    100 after every episode, entropy coefficient 0.1, learning rates 1e-3, BasicReplayBuffer(100 000);
+    return >= -250 within 1500 episodes."""
+    from pearl_amd import BasicReplayBuffer, ContinuousSoftActorCritic, PearlAgent
+    _seed(0)
+    env = Pendulum()
+    agent = PearlAgent(
+        policy_learner=ContinuousSoftActorCritic(
+            state_dim=env.state_dim, action_space=env.action_space, actor_hidden_dims=[64, 64],
+            critic_hidden_dims=[64, 64], training_rounds=50, batch_size=100, entropy_coef=0.1,
+            actor_learning_rate=0.001, critic_learning_rate=0.001),
+        replay_buffer=BasicReplayBuffer(100_000), device_id=0)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, -250, 1500, learn_after_episode=True)
+    _report("continuous sac pendulum", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def _cartpole_q_agent(learner_cls, buffer, seed, **kw):
+    from pearl_amd import OneHotActionTensorRepresentationModule, PearlAgent
+    _seed(seed)
+    env = CartPole()
+    kw.setdefault("training_rounds", 20)
+    learner = learner_cls(
+        state_dim=env.state_dim, action_space=env.action_space,
+        action_representation_module=OneHotActionTensorRepresentationModule(max_number_actions=2), **kw)
+    return env, PearlAgent(policy_learner=learner, replay_buffer=buffer, device_id=0)
+
+
+def test_multi_head_dqn_reaches_500_on_cartpole():
+    """test_integration.py:136-173: DeepQLearning on a VanillaQValueMultiHeadNetwork instance (one head per
+    action: the generic TD engine's multi-head ops)."""
+    from pearl_amd import BasicReplayBuffer, DeepQLearning
+    from pearl_amd.neural_networks.sequential_decision_making.q_value_networks import (
+        VanillaQValueMultiHeadNetwork)
+    env, agent = _cartpole_q_agent(
+        DeepQLearning, BasicReplayBuffer(10_000), 0, hidden_dims=[64, 64],
+        network_instance=VanillaQValueMultiHeadNetwork(state_dim=4, action_dim=2, hidden_dims=[64, 64],
+                                                       output_dim=2))
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=True)
+    _report("multi-head dqn cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_dueling_dqn_reaches_500_on_cartpole():
+    """test_integration.py:362-403: DeepQLearning on a DuelingQValueNetwork instance, 10 training rounds,
+    soft_update_tau 0.75 (the reference allows 10 000 episodes; the budget below is 2 000)."""
+    from pearl_amd import BasicReplayBuffer, DeepQLearning
+    from pearl_amd.neural_networks.sequential_decision_making.q_value_networks import DuelingQValueNetwork
+    env, agent = _cartpole_q_agent(
+        DeepQLearning, BasicReplayBuffer(10_000), 0, training_rounds=10, soft_update_tau=0.75,
+        batch_size=128,
+        network_instance=DuelingQValueNetwork(state_dim=4, action_dim=2, hidden_dims=[64, 64], output_dim=1))
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 2000, learn_after_episode=True)
+    _report("dueling dqn cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_sarsa_reaches_500_on_cartpole():
+    """test_integration.py:243-273: DeepSARSA on a SARSAReplayBuffer(10 000), 20 training rounds."""
+    from pearl_amd import DeepSARSA, SARSAReplayBuffer
+    env, agent = _cartpole_q_agent(DeepSARSA, SARSAReplayBuffer(10_000), 0, hidden_dims=[64, 64])
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=True)
+    _report("sarsa cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_conservative_dqn_reaches_500_on_cartpole_online():
+    """test_integration.py:719-752: DeepQLearning with ``is_conservative=True`` trained online (a sanity
+    check of the CQL term's sign and scale, as in the reference)."""
+    from pearl_amd import BasicReplayBuffer, DeepQLearning
+    env, agent = _cartpole_q_agent(DeepQLearning, BasicReplayBuffer(10_000), 0, hidden_dims=[64, 64],
+                                   is_conservative=True)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=True)
+    _report("cql online cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+def test_discrete_sac_reaches_500_on_cartpole():
+    """test_integration.py:534-568: SoftActorCritic (discrete), three hidden layers of 64, 100 training rounds
+    of batch 100 after every episode, entropy coefficient 0.1, learning rates 1e-4 / 3e-4,
+    BasicReplayBuffer(50 000)."""
+    from pearl_amd import (BasicReplayBuffer, OneHotActionTensorRepresentationModule, PearlAgent,
+                           SoftActorCritic)
+    _seed(0)
+    env = CartPole()
+    agent = PearlAgent(
+        policy_learner=SoftActorCritic(
+            state_dim=env.state_dim, action_space=env.action_space, actor_hidden_dims=[64, 64, 64],
+            critic_hidden_dims=[64, 64, 64], training_rounds=100, batch_size=100, entropy_coef=0.1,
+            actor_learning_rate=0.0001, critic_learning_rate=0.0003,
+            action_representation_module=OneHotActionTensorRepresentationModule(max_number_actions=2)),
+        replay_buffer=BasicReplayBuffer(50_000), device_id=0)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, 500, 1000, learn_after_episode=True)
+    _report("discrete sac cartpole", ok, returns, t0)
+    assert ok, f"best return {max(returns)} in {len(returns)} episodes"
+
+
+@pytest.mark.parametrize("which", ["ddpg", "td3"])
+def test_ddpg_and_td3_reach_minus_250_on_pendulum(which):
+    """test_integration.py:754-790 (DDPG) and :792-828 (TD3): [400, 300] actor / critic — wider than one
+    row-pass tile, so the generic engine's layer-by-layer path — 5 training rounds after every episode, soft
+    updates with tau 0.05, Gaussian exploration noise (std 0.2), BasicReplayBuffer(50 000); the moving
+    average of the last 10 returns reaches -250 within 1000 episodes."""
+    from pearl_amd import TD3, BasicReplayBuffer, DeepDeterministicPolicyGradient, PearlAgent
+    from pearl_amd.policy_learners.exploration import NormalDistributionExploration
+    _seed(0)
+    env = Pendulum()
+    cls = DeepDeterministicPolicyGradient if which == "ddpg" else TD3
+    agent = PearlAgent(
+        policy_learner=cls(
+            state_dim=env.state_dim, action_space=env.action_space, actor_hidden_dims=[400, 300],
+            critic_hidden_dims=[400, 300], critic_learning_rate=1e-3 if which == "ddpg" else 1e-2,
+            actor_learning_rate=1e-3, training_rounds=5, actor_soft_update_tau=0.05,
+            critic_soft_update_tau=0.05,
+            exploration_module=NormalDistributionExploration(mean=0, std_dev=0.2)),
+        replay_buffer=BasicReplayBuffer(50_000), device_id=0)
+    t0 = time.time()
+    ok, returns = target_return_is_reached(agent, env, -250, 1000, learn_after_episode=True,
+                                           check_moving_average=True)
+    _report(f"{which} pendulum", ok, returns, t0)
+    assert ok, f"best moving average {max(np.convolve(returns, np.ones(10) / 10, 'valid'))} in {len(returns)} episodes"

@@ -1,10 +1,12 @@
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_r6.sh quick 2>&1 | grep -E "^==|^value"
-for cfg in "X=0" "PEARL_AMD_LEAD_ROWS=32" "PEARL_AMD_LEAD_ROWS=1"; do
-echo "== shortcall $cfg"
-env $cfg timeout 300 python tools/shortcall.py --calls 40 --rounds 1,20 2>/dev/null | python -c "
-import sys,json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d=json.loads(l); print('  rounds %3d wall %7.1f us' % (d['rounds'], d['wall_us']))"
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for cfg in "X=0" "PEARL_AMD_X_FLAG=1"; do
+  rm -rf $R/gpurun_out/prof_sc
+  env $cfg timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_sc -o sc -- python $R/tools/shortcall.py --trace > $R/gpurun_out/rocprof_sc.log 2>&1
+  DB=$(ls $R/gpurun_out/prof_sc/*.db $R/gpurun_out/prof_sc/*/*.db 2>/dev/null | head -1)
+  tag=$(echo $cfg | tr -c 'A-Za-z0-9' '_')
+  python $R/tools/rocpd_timeline.py $DB --last-call > $R/gpurun_out/sc_timeline_$tag.txt 2>&1
+  echo "== $cfg"; grep -B3 -A6 "16, 16, 1>" $R/gpurun_out/sc_timeline_$tag.txt | cut -c1-110
+  rm -f $DB
 done
