@@ -18,7 +18,8 @@ from .policy_learners.sequential_decision_making import (TD3,  # noqa: F401
                                                          PPOReplayBuffer,
                                                          ProximalPolicyOptimization,
                                                          SoftActorCritic)
-from .policy_learners.contextual_bandits import NeuralLinearBandit, SquareCBExploration  # noqa: F401
+from .policy_learners.contextual_bandits import (NeuralLinearBandit, SquareCBExploration,  # noqa: F401
+                                                 UCBExploration)
 from .action_representation_modules import OneHotActionTensorRepresentationModule  # noqa: F401
 from .utils.instantiations.spaces import BoxActionSpace, DiscreteActionSpace  # noqa: F401
 from .vector_env import BatchedActionResult, BatchedEnvironment, VectorEnvFeeder  # noqa: F401

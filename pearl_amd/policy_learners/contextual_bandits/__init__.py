@@ -1,3 +1,3 @@
-from .neural_linear_bandit import NeuralLinearBandit, SquareCBExploration
+from .neural_linear_bandit import NeuralLinearBandit, SquareCBExploration, UCBExploration
 
-__all__ = ["NeuralLinearBandit", "SquareCBExploration"]
+__all__ = ["NeuralLinearBandit", "SquareCBExploration", "UCBExploration"]

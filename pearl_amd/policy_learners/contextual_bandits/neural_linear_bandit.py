@@ -96,6 +96,47 @@ class SquareCBExploration(ExplorationModule):
         return values.view(-1, action_space.n)           # (:117-126)
 
 
+class UCBExploration(ExplorationModule):
+    """score = value + alpha * sigma, the arg-max arm is played (ucb_exploration.py:27-95 on
+    score_exploration_base.py:47-101 with NO_TIEBREAKING).  ``sigma`` comes from the regression head
+    (``representation.calculate_sigma``: sqrt(x^T A^-1 x), pa_linreg_sigma on a HIP device); NaNs count
+    as zero like the reference's.  An availability mask (1 = present) restricts the arg-max."""
+
+    def __init__(self, alpha: float, randomized_tiebreaking: Any = None) -> None:
+        super().__init__()
+        if randomized_tiebreaking not in (None, False, 0) and \
+                getattr(randomized_tiebreaking, "name", "") != "NO_TIEBREAKING":
+            raise NotImplementedError("pearl_amd UCBExploration: randomized tie-breaking is not built")
+        self._alpha = alpha
+
+    def sigma(self, subjective_state: Tensor, representation: Any) -> Tensor:
+        sigma = representation.calculate_sigma(subjective_state)
+        return torch.where(torch.isnan(sigma), torch.zeros_like(sigma), sigma)
+
+    def get_scores(self, subjective_state: Any, action_space: Any, values: Tensor,
+                   exploit_action: Any = None, representation: Any = None) -> Tensor:
+        n = int(action_space.n)
+        values = values.view(-1, n)
+        sigma = self.sigma(subjective_state, representation).view(values.shape)
+        return (values + self._alpha * sigma).view(-1, n)
+
+    def act(self, subjective_state: Any, action_space: Any, values: Optional[Tensor] = None,
+            representation: Any = None, exploit_action: Any = None,
+            action_availability_mask: Optional[Tensor] = None, **kwargs: Any) -> Tensor:
+        assert values is not None and values.shape[-1] == action_space.n
+        scores = self.get_scores(subjective_state, action_space, values, representation=representation)
+        if action_availability_mask is not None:
+            present = action_availability_mask.to(scores.device).bool().view(scores.shape)
+            scores = scores.masked_fill(~present, float("-inf"))
+        index = torch.argmax(scores, dim=1)
+        return torch.nn.functional.embedding(index, action_space.actions_batch.to(index.device))
+
+    def compare(self, other: Any) -> str:
+        if not isinstance(other, UCBExploration):
+            return "other is not an instance of UCBExploration"
+        return "" if self._alpha == other._alpha else f"_alpha is different: {self._alpha} vs {other._alpha}"
+
+
 _LOSS_KINDS = {"mse": 0, "mae": 1, "cross_entropy": 2}        # PA_LOSS_* (include/pearl_amd.h)
 _OUT_ACTS = {"linear": 0, "sigmoid": 1}                        # PA_OUT_*
 
