@@ -1,6 +1,9 @@
-"""The reference's own unit tests of NeuralLinearBandit, on the HIP learner.
+"""The reference's own unit tests of the learners on the path, on the HIP learners.
 
-test/unit/with_pytorch/test_neural_linear_bandits.py:41-245, restated for pearl_amd's classes on ``cuda:0``:
+test/unit/with_pytorch/test_deep_td_learning.py:29-105 (DoubleDQN / DeepSARSA next-state values on a network
+with ONE hidden layer of width 3) and
+
+test/unit/with_pytorch/test_neural_linear_bandits.py:41-245 (NeuralLinearBandit), restated for pearl_amd's classes on ``cuda:0``:
 state-dict exactness (rtol = atol = 0), 1000 ``learn_batch`` calls on y = sum(x) reaching the reference's loss
 thresholds for the MSE / MAE / cross-entropy criteria — with the reference's one-row, zero-weight "null batch"
 as the second call and its dropout ratio of 1e-4 —, the ``get_scores`` / ``act`` shapes under UCB exploration,
@@ -122,3 +125,66 @@ def test_discounting_shrinks_the_moments():
     assert float(lr.A[0, 0]) < 100 * float(batch.weight.sum())
     assert float(lr._b[0]) < 100 * float((batch.reward * batch.weight).sum())
     assert float(lr.A[0, 0]) > 0
+
+
+# ---- test_deep_td_learning.py ---------------------------------------------------------------------
+def _td_batch():
+    from pearl_amd import BasicReplayBuffer, DiscreteActionSpace
+    space = DiscreteActionSpace(actions=list(torch.arange(3).view(-1, 1)), seed=0)
+    rb = BasicReplayBuffer(24, sampler="python")
+    rb.device_for_batches = torch.device(DEV)
+    for _ in range(24):
+        rb.push(state=torch.randn(10), action=space.sample(), reward=torch.randint(1, (1,)),
+                next_state=torch.randn(10), curr_available_actions=space, next_available_actions=space,
+                terminated=False, truncated=False, max_number_actions=3)
+    return space, rb
+
+
+def test_double_dqn_next_state_values_differ_from_dqn_with_the_same_weights():
+    """:56-91 — hidden_dims=[3]: one hidden layer, three units (the generic TD engine's smallest case)."""
+    import copy
+    import random
+    from pearl_amd import DeepQLearning, DoubleDQN, OneHotActionTensorRepresentationModule
+    torch.manual_seed(0)
+    random.seed(0)
+    space, rb = _td_batch()
+    batch = rb.sample(24)
+    mk = lambda cls: cls(state_dim=10, action_space=space, hidden_dims=[3], training_rounds=1,
+                         action_representation_module=OneHotActionTensorRepresentationModule(
+                             max_number_actions=3)).to(DEV)
+    ddqn, dqn = mk(DoubleDQN), mk(DeepQLearning)
+    differ = False
+    for _ in range(10):
+        for net in (ddqn._Q, ddqn._Q_target):
+            for m in net.modules():
+                if isinstance(m, torch.nn.Linear):
+                    torch.nn.init.xavier_normal_(m.weight)
+        double_value = ddqn.get_next_state_values(ddqn.preprocess_batch(copy.deepcopy(batch)), 24)
+        dqn._Q.load_state_dict(ddqn._Q.state_dict())
+        dqn._Q_target.load_state_dict(ddqn._Q_target.state_dict())
+        vanilla_value = dqn.get_next_state_values(dqn.preprocess_batch(copy.deepcopy(batch)), 24)
+        assert double_value.shape == vanilla_value.shape == (24,)
+        # Q_target(s', argmax_a Q(s', a)) <= max_a Q_target(s', a), row by row
+        assert bool(torch.all(double_value <= vanilla_value + 1e-6))
+        differ = bool(torch.any(double_value != vanilla_value))
+        if differ:
+            break
+    assert differ
+
+
+def test_sarsa_next_state_values_shape():
+    """:93-105"""
+    import random
+    from pearl_amd import DeepSARSA, OneHotActionTensorRepresentationModule
+    from pearl_amd.policy_learners.exploration import EGreedyExploration
+    torch.manual_seed(0)
+    random.seed(0)
+    space, rb = _td_batch()
+    batch = rb.sample(24)
+    batch.next_action = batch.action
+    sarsa = DeepSARSA(state_dim=10, action_space=space, hidden_dims=[3], training_rounds=1,
+                      exploration_module=EGreedyExploration(0.05),
+                      action_representation_module=OneHotActionTensorRepresentationModule(
+                          max_number_actions=3)).to(DEV)
+    v = sarsa.get_next_state_values(batch=sarsa.preprocess_batch(batch), batch_size=24)
+    assert v.shape == (24,)
