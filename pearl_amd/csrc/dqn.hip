@@ -18,6 +18,7 @@
 
 #include "online_kernels.hpp"
 #include "online_pair_kernel.hpp"
+#include "online_f16_kernel.hpp"
 #include "target_pp_kernel.hpp"
 #include "host_launch.hpp"
 #include "sampler.hpp"
@@ -67,6 +68,11 @@ struct pa_dqn {
   int* choice;
   float* choice_rep;   // [max_batch][AD] representation of the chosen next action
   float *W1f, *W2f16, *W2tf;  // fragment-major copies of the online weights (online_rowpass_kernel)
+  // the row pass on the fp16 matrix pipe (online_f16_kernel.hpp): max |w| per unit of the online weights,
+  // two buffers of [H1 | H2 | H1] words (the optimizer launch fills the one the next row pass reads)
+  int rp_h2;           // PEARL_AMD_ROWPASS_H2 (default 1; 0 = the fp32-MFMA row pass)
+  unsigned* umax;
+  int umax_cur;        // which buffer holds the maxima of the parameters as they are now
   // the row pass on two workgroups per 16-row tile (online_pair_kernel.hpp; PEARL_AMD_ROWPASS_PAIR=1,
   // the benchmark's shape only; off by default — DESIGN.md §3.10 has the measurements): the halves'
   // interleaved partials of dZ1, the pair's tagged exchange words, the halves' q partials of a
@@ -481,6 +487,21 @@ PackedW packed(pa_dqn* h) {
   return pk;
 }
 
+// The fp16 row pass's row maxima (online_f16_kernel.hpp): a rebuild writes the buffer the next row
+// pass reads and clears the other; an optimizer launch accumulates into the other buffer, clears the
+// one just read, and the two swap.
+void repack_umax(pa_dqn* h, RepackArgs& a) {
+  if (!h->umax) return;
+  a.umax_out = h->umax + (size_t)h->umax_cur * HF_UMAX;
+  a.umax_zero = h->umax + (size_t)(h->umax_cur ^ 1) * HF_UMAX;
+}
+void optimizer_umax(pa_dqn* h, AdamFuse& f) {
+  if (!h->umax) return;
+  f.umax_acc = h->umax + (size_t)(h->umax_cur ^ 1) * HF_UMAX;
+  f.umax_clear = h->umax + (size_t)h->umax_cur * HF_UMAX;
+  h->umax_cur ^= 1;
+}
+
 // Rebuild the fragment-major weight copies from the row-major parameters.  Needed whenever the
 // parameters may have been changed by someone else (checkpoint load, stand-alone soft update,
 // the data-parallel AdamW); inside the fused learn loop the optimizer tail keeps them current.
@@ -493,6 +514,7 @@ int run_repack(pa_dqn* h, bool online, bool target, hipStream_t s) {
   a.IN = h->IN; a.H1 = d.hidden1; a.H2 = d.hidden2;
   a.pk = packed(h);
   a.do_online = online; a.do_target = target;
+  if (online) repack_umax(h, a);
   hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   return PA_OK;
@@ -595,6 +617,8 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   const size_t smem = rowpass_smem_bytes(h->IN, d.hidden1, d.hidden2);
   RowArgs a;
   memset(&a, 0, sizeof(a));
+  const bool use_h2 = h->umax && !(h->pair && h->qx);
+  if (use_h2) a.umax = h->umax + (size_t)h->umax_cur * HF_UMAX;
   a.x = x; a.ldx = h->IN;
   a.W1f = h->W1f; a.b1 = q.b1;
   a.W2f = h->W2f16; a.b2 = q.b2;
@@ -660,6 +684,14 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
     return PA_OK;
   }
   if (y && phase != 1) h->pair_live = false;
+  if (use_h2) {
+    const size_t smem2 = rowpass_h2_smem_bytes();
+    if (phase == 1) hipLaunchKernelGGL((online_rowpass_h2_kernel<1>), grid, dim3(512), smem2, s, a);
+    else if (phase == 2) hipLaunchKernelGGL((online_rowpass_h2_kernel<2>), grid, dim3(512), smem2, s, a);
+    else hipLaunchKernelGGL((online_rowpass_h2_kernel<0>), grid, dim3(512), smem2, s, a);
+    PA_LAUNCH_CHECK();
+    return PA_OK;
+  }
   // fully unrolled instantiations for the shapes that matter; anything else takes the run-time loops
 #define PA_ROWPASS(N1, N2, N3)                                                               \
   do {                                                                                       \
@@ -812,6 +844,7 @@ int run_weight_grad(pa_dqn* h, const float* x, int B, bool fuse_adam, int64_t ad
     a.ad.tW2f = h->w2f; a.ad.nkg_t = t_nkg(d.hidden1);
     a.ad.tW2sp = h->w2sp;
     a.ad.tW1sp = h->w1sp; a.ad.sp_S = d.state_dim;
+    optimizer_umax(h, a.ad);
     static const bool keep_online = env_int("PEARL_AMD_DDQN_KEEP_ONLINE", 1) != 0;
     if (d.double_q == 1 && h->w2f_online && keep_online) {
       // the argmax pass of the next round reads these: no repack launch in front of it
@@ -848,6 +881,7 @@ int run_adamw(pa_dqn* h, int64_t step, int soft_next, hipStream_t s) {
   a.f.tW2f = h->w2f; a.f.nkg_t = t_nkg(d.hidden1);
   a.f.tW2sp = h->w2sp;
   a.f.tW1sp = h->w1sp; a.f.sp_S = d.state_dim;
+  optimizer_umax(h, a.f);
   a.g = h->bufs.grad;
   a.n = h->P;
   for (int i = 0; i < 6; ++i) a.off[i] = h->off[i];
@@ -1165,6 +1199,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->use_split = env_int("PEARL_AMD_TARGET_SPLIT", 1);
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
+  h->rp_h2 = env_int("PEARL_AMD_ROWPASS_H2", 1);
   h->pair = env_int("PEARL_AMD_ROWPASS_PAIR", 0);
   h->pair_lds = env_int("PEARL_AMD_PAIR_LDS", 82 * 1024);
   h->pair_live = false;
@@ -1276,6 +1311,12 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
+  if (h->rp_h2 && desc->hidden1 == HF_UNITS && desc->hidden2 == HF_UNITS && wf16_nkg(h->IN) == 9) {
+    float* w = nullptr;
+    PA_WS(w, 2 * HF_UMAX);
+    h->umax = reinterpret_cast<unsigned*>(w);
+    PA_HIP(hipMemset(h->umax, 0, sizeof(unsigned) * 2 * HF_UMAX));
+  }
   if (h->pair && desc->hidden1 == PR_H && desc->hidden2 == PR_H && wf16_nkg(h->IN) == PR_NG1) {
     float* w = nullptr;
     h->qx_rows = (int)round_up(B, RP_ROWS);
@@ -1308,7 +1349,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
                   h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp, h->w2sp_online, h->w1sp,
-                  h->choice, h->choice_rep, h->dZ1p, h->qx, h->qhalf, h->dbg_workers};
+                  h->choice, h->choice_rep, h->dZ1p, h->qx, h->qhalf, h->dbg_workers, h->umax};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1498,6 +1539,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
   rpk.IN = h->IN; rpk.H1 = d.hidden1; rpk.H2 = d.hidden2;
   rpk.pk = packed(h);
   rpk.do_online = 1; rpk.do_target = 1;
+  repack_umax(h, rpk);
   if (args->idx_host) {
     for (int64_t i = 0; i < (int64_t)R * B; ++i)
       PA_REQUIRE(args->idx_host[i] >= 0 && args->idx_host[i] < arena->size, PA_ERR_INVALID,

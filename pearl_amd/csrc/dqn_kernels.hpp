@@ -894,6 +894,38 @@ static __global__ __launch_bounds__(256) void head_loss_kernel(HeadArgs a) {
   }
 }
 
+// ---- per-row maxima of the online weights (the scales of online_f16_kernel.hpp) -----------------
+// umax buffer: [H1] rows of W1 | [H2] rows of W2, bit patterns of max |w| (unsigned order = float order)
+constexpr int HF_UNITS = 256;
+constexpr int HF_UMAX = 2 * HF_UNITS;
+__device__ __forceinline__ unsigned abs_bits(float v) { return __float_as_uint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned umaxu(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umax4(const float4& v) {
+  return umaxu(umaxu(abs_bits(v.x), abs_bits(v.y)), umaxu(abs_bits(v.z), abs_bits(v.w)));
+}
+__device__ __forceinline__ void umax_atomic(unsigned* p, unsigned m) {
+  (void)__hip_atomic_fetch_max(p, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// From the row-major parameters, one wave per row (any grid: wave w0 of nw cooperating waves).
+// `out`: the buffer the next row pass reads; `zero`: the other buffer of the pair, cleared for the
+// atomic maxima of the next optimizer launch.
+__device__ __forceinline__ void unit_max_body(const float* __restrict__ q, int64_t off_w1, int64_t off_w2,
+                                              int IN, int H1, int H2, unsigned* __restrict__ out,
+                                              unsigned* __restrict__ zero, int64_t w0, int64_t nw, int lane) {
+  for (int64_t unit = w0; unit < H1 + H2; unit += nw) {
+    const float* W = unit < H1 ? q + off_w1 + unit * IN : q + off_w2 + (unit - H1) * H1;
+    const int K = unit < H1 ? IN : H1;
+    unsigned m = 0u;
+    for (int k = lane; k < K; k += 64) m = umaxu(m, abs_bits(W[k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = umaxu(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) {
+      out[unit] = m;
+      if (zero) zero[unit] = 0u;
+    }
+  }
+}
+
 // AdamW(amsgrad=True), the op order of torch/optim/adam.py::_single_tensor_adam
 // (param.mul_, exp_avg.lerp_, exp_avg_sq.mul_().addcmul_, maximum, sqrt/div/add,
 // addcdiv_), one rounding per op as ATen's CPU kernels do.
@@ -975,6 +1007,10 @@ struct AdamFuse {
   // (sac_rows.hpp helper workgroups), the operands hold pending tags -> form the gradients but do
   // NOT step the optimizer or touch the target network with them
   const int* guard;
+  // online_f16_kernel.hpp's row scales: the new max |w| of every row of W1 / W2 goes (atomic max) into
+  // umax_acc — the buffer the NEXT row pass reads, zero on entry — and umax_clear, the buffer the last
+  // row pass read, is zeroed for the launch after this one.  null: not kept.
+  unsigned* umax_acc; unsigned* umax_clear;
 };
 
 struct DwProblem {
@@ -1049,8 +1085,8 @@ __host__ __device__ inline int64_t wf16_index_(int unit, int k, int nkg) {
          (k & 3);
 }
 
-__device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, int64_t i, int row,
-                                                  int col, float g) {
+__device__ __forceinline__ float adam_fused_weight(const AdamFuse& f, int kind, int64_t i, int row,
+                                                   int col, float g) {
   const float p = adam_update(f.c, f.st, i, g);
   if (kind == 0) {         // W2[n = row][k = col]
     f.W2f[wf16_index_(row, col, f.nkg_w2)] = p;
@@ -1072,6 +1108,7 @@ __device__ __forceinline__ void adam_fused_weight(const AdamFuse& f, int kind, i
       store_wsp1(f.tW1sp, row, col, t, f.sp_S >> 4);
     }
   }
+  return p;
 }
 // kind 3: refresh the generic engine's fragment-major copies of one weight element
 __device__ __forceinline__ void pack_generic(const DwProblem& P, int row, int col, float p) {
@@ -1478,6 +1515,8 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
       __syncthreads();
     }
     if (tid == 0) a.ad.loss_out[0] = part[0] * a.ad.inv_B;
+    if (a.ad.umax_clear)
+      for (int i = tid; i < HF_UMAX; i += 512) a.ad.umax_clear[i] = 0u;
     if (a.ad.y_restore)
       for (int i = tid; i < a.ad.n_restore; i += 512)
         __hip_atomic_store(a.ad.y_restore + i, kYPendingBits, __ATOMIC_RELAXED,
@@ -1717,6 +1756,7 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
       if (tid == 0) a.ktickets[wg_tile] = 0u;
       __syncthreads();
     }
+    unsigned um_m = 0u;   // max |new weight| of this thread's elements (row scales of the fp16 row pass)
     if (evec) {
       *reinterpret_cast<float4*>(P.dW + (int64_t)erow * P.ldw + ecol) =
           make_float4(g4[0], g4[1], g4[2], g4[3]);
@@ -1726,6 +1766,7 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
 #pragma unroll
         for (int e = 0; e < 4; ++e) adam_math(a.ad.c, g4[e], pv[e], mv[e], vv[e], xv[e]);
         const float4 pn = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        um_m = umax4(pn);
         *reinterpret_cast<float4*>(st.p + eflat) = pn;
         *reinterpret_cast<float4*>(st.m + eflat) = make_float4(mv[0], mv[1], mv[2], mv[3]);
         *reinterpret_cast<float4*>(st.v + eflat) = make_float4(vv[0], vv[1], vv[2], vv[3]);
@@ -1782,10 +1823,18 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
             if (P.kind == 3)
               adam_generic_weight(a.ad, st, tgt, P, dst - gbase, erow, ecol + e, g4[e]);
             else
-              adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, erow, ecol + e, g4[e]);
+              um_m = umaxu(um_m, abs_bits(adam_fused_weight(a.ad, P.kind, dst - a.ad.grad_base, erow,
+                                                            ecol + e, g4[e])));
           }
         }
       }
+    }
+    if (a.ad.umax_acc && adam_on && P.kind <= 1) {   // (workgroup-uniform)
+      // the eight threads of a tile row are adjacent lanes
+      um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 1));
+      um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 2));
+      um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 4));
+      if (eact && ecg == 0 && erow < P.M) umax_atomic(a.ad.umax_acc + (P.kind == 0 ? HF_UNITS : 0) + erow, um_m);
     }
   }
   if (j0 == 0 && tid < TM && (i0 + tid) < P.M) {
@@ -1879,18 +1928,40 @@ struct AdamDqnArgs {
 };
 static __global__ __launch_bounds__(256) void adamw_dqn_kernel(AdamDqnArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.n) return;
-  const float g = a.g[i];
-  if (i >= a.off[0] && i < a.off[0] + (int64_t)a.H1 * a.IN) {
-    const int64_t e = i - a.off[0];
-    adam_fused_weight(a.f, 1, i, (int)(e / a.IN), (int)(e % a.IN), g);
-  } else if (i >= a.off[2] && i < a.off[2] + (int64_t)a.H2 * a.H1) {
-    const int64_t e = i - a.off[2];
-    adam_fused_weight(a.f, 0, i, (int)(e / a.H1), (int)(e % a.H1), g);
-  } else if (i >= a.off[4] && i < a.off[4] + a.H2) {
-    adam_fused_weight(a.f, 2, i, 0, (int)(i - a.off[4]), g);
-  } else {
-    adam_fused_bias(a.f, i, g);   // biases (and the zero alignment gaps)
+  int uid = -1;        // slot of this element's row in the umax buffer (weights of W1 / W2 only)
+  unsigned um = 0u;
+  if (i < a.n) {
+    const float g = a.g[i];
+    if (i >= a.off[0] && i < a.off[0] + (int64_t)a.H1 * a.IN) {
+      const int64_t e = i - a.off[0];
+      uid = (int)(e / a.IN);
+      um = abs_bits(adam_fused_weight(a.f, 1, i, uid, (int)(e % a.IN), g));
+    } else if (i >= a.off[2] && i < a.off[2] + (int64_t)a.H2 * a.H1) {
+      const int64_t e = i - a.off[2];
+      const int row = (int)(e / a.H1);
+      uid = HF_UNITS + row;
+      um = abs_bits(adam_fused_weight(a.f, 0, i, row, (int)(e % a.H1), g));
+    } else if (i >= a.off[4] && i < a.off[4] + a.H2) {
+      (void)adam_fused_weight(a.f, 2, i, 0, (int)(i - a.off[4]), g);
+    } else {
+      adam_fused_bias(a.f, i, g);   // biases (and the zero alignment gaps)
+    }
+  }
+  if (a.f.umax_acc) {   // (grid-uniform)
+    // one atomic per row and wave: the lanes of each row present in the wave reduce among themselves
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = __ballot(uid >= 0);
+    while (rem) {
+      const int leader = __ffsll((long long)rem) - 1;
+      const int u = __shfl(uid, leader);
+      const bool mine = uid == u;
+      unsigned v = mine ? um : 0u;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v = umaxu(v, (unsigned)__shfl_xor((int)v, o));
+      if (lane == leader) umax_atomic(a.f.umax_acc + u, v);
+      rem &= ~__ballot(mine);
+    }
+    if (i < HF_UMAX) a.f.umax_clear[i] = 0u;
   }
 }
 

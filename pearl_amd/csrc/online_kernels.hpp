@@ -108,6 +108,7 @@ struct RepackArgs {
   int IN, H1, H2;
   PackedW pk;
   int do_online, do_target;
+  unsigned* umax_out; unsigned* umax_zero;   // do_online: row maxima of W1 / W2 (unit_max_body); null: not kept
 };
 
 // thread t0 of gsz cooperating threads (any grid shape: the learn loop's prologue launch runs this
@@ -165,6 +166,9 @@ __device__ __forceinline__ void repack_body(const RepackArgs& a, int64_t t0, int
         reinterpret_cast<float4*>(a.pk.W2tf)[e] = v;
       }
     }
+    if (a.umax_out)
+      unit_max_body(a.q, a.off_w1, a.off_w2, a.IN, a.H1, a.H2, a.umax_out, a.umax_zero, t0 >> 6, gsz >> 6,
+                    (int)(t0 & 63));
   }
   if (a.do_target) {
     const int nkg = t_nkg(a.H1);
@@ -235,6 +239,7 @@ struct RowArgs {
                                         // ("everything before this launch on its stream is done":
                                         // the window hand-off of learn(), see pa_dqn::sig)
   long long* prof;                      // optional phase stamps (tools/prof_chain.py)
+  const unsigned* umax;                 // online_rowpass_h2_kernel: max |w| per unit (online_f16_kernel.hpp)
   float* H1a; float* H2a;               // [B][H1], [B][H2] relu outputs (weight-gradient operands)
   float* dZ2; float* dZ1;               // [B][H2], [B][H1] pre-activation gradients
   float* q_out; float* dq_out; float* absd_out;  // [B]; q_out may be null

@@ -181,6 +181,159 @@ def test_target_split_kernel_non_finite_rows(monkeypatch):
         assert not torch.isfinite(got["target"].cpu()[7])            # terminated + inf: inf * 0
 
 
+# ------------------------------------------------------------------- online_rowpass_h2_kernel
+# The online row pass on the fp16 matrix pipe (pearl_amd/csrc/online_f16_kernel.hpp): operands scaled by
+# powers of two into fp16's range, two fp16 terms each, three products.  Same three properties, against
+# the fp32-MFMA row pass (PEARL_AMD_ROWPASS_H2=0) and float64; plus weight ROWS spread over forty
+# decades (the per-row scales come from maxima the optimizer epilogue / repack maintain) and the
+# gradients of one learn_batch (the backward product carries W2's row scales on the other operand).
+def _dqn_h2(monkeypatch, h2, seed=0, unit_decades=None):
+    monkeypatch.setenv("PEARL_AMD_ROWPASS_H2", h2)
+    pl = _dqn(monkeypatch, "1", seed=seed)
+    if unit_decades is not None:
+        # rows of W1 / W2 scaled by 10^k (k cycling through the range), the NEXT layer's columns by
+        # 10^-k: the same function in exact arithmetic, every unit's pre-activation at another scale
+        lo, hi = unit_decades
+        with torch.no_grad():
+            for net in (pl._Q, pl._Q_target):
+                lin = [m for m in net.modules() if isinstance(m, torch.nn.Linear)]
+                for i in (0, 1):
+                    n = lin[i].weight.shape[0]
+                    f = (10.0 ** (torch.arange(n) % (hi - lo + 1) + lo).double()).float().to(DEV)
+                    lin[i].weight.mul_(f.view(-1, 1))
+                    lin[i].bias.mul_(f)
+                    lin[i + 1].weight.div_(f.view(1, -1))
+    return pl
+
+
+def _online_layers(pl, dtype=torch.float64):
+    sd = {k: v.detach().cpu().to(dtype) for k, v in pl._Q.state_dict().items()}
+    ws = [k for k in sd if k.endswith("weight")]
+    return [(sd[w], sd[w[:-6] + "bias"]) for w in ws]
+
+
+def _q_host(pl, batch, dtype):
+    layers = _online_layers(pl, dtype)
+    x = torch.cat([batch.state.cpu().to(dtype), batch.action.cpu().to(dtype)], -1)
+    return exact_mlp(x, layers).view(-1), abs_bound(x, layers).view(-1)
+
+
+def _batch_with_states(state):
+    b = _dqn_batch(torch.randn(state.shape[0], 128, generator=torch.Generator().manual_seed(9)))
+    b.state = state.to(DEV)
+    return b
+
+
+@pytest.mark.parametrize("unit_decades", [None, (-2, 2)])
+def test_rowpass_h2_over_forty_decades(monkeypatch, unit_decades):
+    """Q(s, a) (q_value_networks.py:152-174) through online_rowpass_h2_kernel with states scaled row by
+    row from 1e-20 to 1e+20 (and, second case, hidden units whose weight rows span four decades: a term keeps its 22 bits while it is within 2^-17 of its row's maximum, its precision is 2^-40 of that maximum below),
+    against the fp32-MFMA row pass and float64."""
+    B = 256
+    g = torch.Generator().manual_seed(11)
+    st = torch.randn(B, 128, generator=g) * row_scales(B).view(B, 1)
+    out = {}
+    for h2 in ("1", "0"):
+        pl = _dqn_h2(monkeypatch, h2, unit_decades=unit_decades)
+        batch = _batch_with_states(st)
+        out[h2] = pl.q_values_and_targets(batch)["q"].double().cpu()
+    q64, bound = _q_host(pl, batch, torch.float64)
+    e_h2 = (out["1"] - q64).abs() / bound
+    e_f32 = (out["0"] - q64).abs() / bound
+    print(f"\nQ(s, a) error / sum|terms| over 40 decades (unit decades {unit_decades}): fp16x2 "
+          f"{float(e_h2.max()):.2e}, fp32 MFMA {float(e_f32.max()):.2e}")
+    assert not torch.equal(out["1"], out["0"]), "the fp16 row pass did not run"
+    assert torch.isfinite(out["1"]).all()
+    assert float(e_h2.max()) <= max(2.0 * float(e_f32.max()), 3e-7)
+    sc = torch.log10(row_scales(B).double()).round().long()
+    for k in (-20, -10, 0, 10, 20):
+        rows = sc == k
+        assert float(e_h2[rows].max()) <= max(2.0 * float(e_f32[rows].max()), 3e-7), k
+
+
+def test_rowpass_h2_subnormal_rows(monkeypatch):
+    """States at 1e-28 .. 1e-40 through a network without biases or action columns: row maxima below
+    the scaling's clamp (2^-112) keep their fp32 exponent and lose fp16 terms instead — never garbage."""
+    B = 256
+    g = torch.Generator().manual_seed(12)
+    st = torch.randn(B, 128, generator=g) * row_scales(B, -40, -28).view(B, 1)
+    monkeypatch.setenv("PEARL_AMD_ROWPASS_H2", "1")
+    pl = _dqn(monkeypatch, "1", zero_bias=True)
+    batch = _batch_with_states(st)
+    # (an activation row's precision is relative to the row's maximum, and x = state || rep(action):
+    #  a one-hot 1.0 next to states of 1e-30 leaves them below 2^-40 of the maximum — as it leaves
+    #  them below the rounding of any fp32 sum that contains the action's term.  The clamp path is
+    #  what this test is about: no action representation in the row)
+    batch.action = torch.zeros_like(batch.action)
+    got = pl.q_values_and_targets(batch)["q"].double().cpu()
+    q64, bound = _q_host(pl, batch, torch.float64)
+    assert torch.isfinite(got).all()
+    err = (got - q64).abs()
+    tiny = 2.0 ** -126
+    assert float(q64.abs().max()) > 1e4 * tiny
+    # rows whose maximum is below 2^-112 are scaled by the clamp's 2^126: their terms sit up to 2^14
+    # below fp16's normal range, i.e. an absolute error of ~2^-24 of 2^-112 per term
+    assert bool((err <= 1e-5 * q64.abs() + 3e-7 * bound + 512 * 2.0 ** -136).all()), float(err.max())
+
+
+def test_rowpass_h2_non_finite_rows(monkeypatch):
+    """Rows with +inf / -inf / NaN in the state: the other rows are bit-identical to the clean launch
+    (the activation scales are per row), the poisoned rows are non-finite wherever torch's fp32
+    result is, NaN where it is NaN."""
+    B = 256
+    g = torch.Generator().manual_seed(13)
+    clean = torch.randn(B, 128, generator=g)
+    st = clean.clone()
+    bad = {7: float("inf"), 40: float("-inf"), 41: float("nan"), 130: float("inf"), 255: float("nan")}
+    for r, v in bad.items():
+        st[r, (r * 5) % 128] = v
+    st[130, 3] = float("-inf")
+    for h2 in ("1", "0"):
+        pl = _dqn_h2(monkeypatch, h2)
+        ref = pl.q_values_and_targets(_batch_with_states(clean))["q"].cpu()
+        batch = _batch_with_states(st)
+        got = pl.q_values_and_targets(batch)["q"].cpu()
+        rows = torch.ones(B, dtype=torch.bool)
+        rows[list(bad)] = False
+        assert torch.equal(got[rows], ref[rows]), h2
+        q32, _ = _q_host(pl, batch, torch.float32)
+        for r in bad:
+            if not torch.isfinite(q32[r]):
+                assert not torch.isfinite(got[r]), (h2, r, float(got[r]), float(q32[r]))
+            if torch.isnan(q32[r]):
+                assert torch.isnan(got[r]), (h2, r)
+
+
+@pytest.mark.parametrize("unit_decades", [None, (-2, 2)])
+def test_rowpass_h2_gradients_match_float64_as_the_fp32_pass_does(monkeypatch, unit_decades):
+    """One learn_batch on states spread over eight decades: every gradient tensor is as close to
+    float64 autograd as the fp32-MFMA row pass puts it (the backward product G = s2 W2 runs on fp16
+    terms with W2's row scales moved onto s2)."""
+    B = 256
+    g = torch.Generator().manual_seed(14)
+    st = torch.randn(B, 128, generator=g) * row_scales(B, -4, 4).view(B, 1)
+    grads = {}
+    for h2 in ("1", "0"):
+        pl = _dqn_h2(monkeypatch, h2, unit_decades=unit_decades)
+        batch = _batch_with_states(st)
+        y = pl.q_values_and_targets(batch)["target"].double().cpu()
+        if h2 == "1":
+            layers = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in _online_layers(pl)]
+            x = torch.cat([batch.state.cpu().double(), batch.action.cpu().double()], -1)
+            loss = ((exact_mlp(x, layers).view(-1) - y) ** 2).mean()
+            loss.backward()
+            want = [t.grad for wb in layers for t in wb]
+        pl.learn_batch(batch)
+        grads[h2] = [p.grad.double().cpu() for p in pl._Q.parameters()]
+    assert len(want) == len(grads["1"])
+    for i, (w64, a, b) in enumerate(zip(want, grads["1"], grads["0"])):
+        assert torch.isfinite(a).all(), i
+        scale = float(w64.abs().max())
+        e_h2, e_f32 = float((a - w64).abs().max()) / scale, float((b - w64).abs().max()) / scale
+        print(f"\ngradient tensor {i} (unit decades {unit_decades}): max error / max|g| fp16x2 {e_h2:.2e}, fp32 {e_f32:.2e}")
+        assert e_h2 <= max(3.0 * e_f32, 2e-6), (i, e_h2, e_f32)
+
+
 # ------------------------------------------------------------------- weight-gradient split loops
 def _dw(dz, x, mode):
     from pearl_amd import _native as N

@@ -201,6 +201,177 @@ double run(const float* h1, const bf16x8* Wsp, const float* W, float* out, int g
   return ms * 1e-3;
 }
 
+// ---------------------------------------------------------------------------------------------
+// fp16x2 variant (round 6): every operand scaled by an exact power of two (per h1 row, per weight
+// unit) into fp16's range, split into TWO fp16 terms (2 x 11 = 22 significand bits + the sign of
+// lo: |x - hi - lo| <= 2^-24 |x|), three products per k-step  hi*hi | hi*lo + lo*hi  on
+// v_mfma_f32_32x32x16_f16, the result unscaled with one ldexp.  Half the matrix instructions and
+// two thirds of the planes of the bf16x3 form.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// exponent field e of max|x| (clamped) -> the row / unit is scaled by 2^(141 - e): max lands in [2^14, 2^15)
+__host__ __device__ inline int scale_field(float mx) {
+  unsigned b;
+  memcpy(&b, &mx, 4);
+  int e = (int)((b >> 23) & 0xff);
+  if (e == 255) return 141;               // inf / NaN rows: no scaling, the non-finite value travels
+  return e < 15 ? 15 : e;
+}
+__host__ __device__ inline float pow2_field(int f) {   // 2^(f - 127), f in [1, 254]
+  unsigned b = (unsigned)f << 23;
+  float r;
+  memcpy(&r, &b, 4);
+  return r;
+}
+__host__ __device__ inline void split2h(float xs, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)xs;
+  lo = (_Float16)(xs - (float)hi);
+}
+
+__global__ void pack_wh_kernel(const float* __restrict__ W, f16x8* __restrict__ Wsp, int* __restrict__ wfield) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;   // (w, g, lane)
+  if (e >= 8 * KS * 64) return;
+  const int lane = e & 63, g = (e >> 6) % KS, w = e / (64 * KS);
+  const int unit = 32 * w + (lane & 31), k0 = 16 * g + 8 * (lane >> 5);
+  float mx = 0.f;
+  for (int k = 0; k < K; ++k) mx = fmaxf(mx, fabsf(W[unit * K + k]));
+  const int f = scale_field(mx);
+  const float sc = pow2_field(268 - f);
+  if (g == 0 && lane < 32) wfield[unit] = f;
+  f16x8 p[2];
+  for (int j = 0; j < 8; ++j) {
+    _Float16 a, b;
+    split2h(W[unit * K + k0 + j] * sc, a, b);
+    p[0][j] = a; p[1][j] = b;
+  }
+  for (int s = 0; s < 2; ++s) Wsp[((size_t)(w * KS + g) * 2 + s) * 64 + lane] = p[s];
+}
+
+template <int NACC, int RD>
+__global__ __launch_bounds__(512, 2) void tile_h_kernel(const float* __restrict__ h1,
+                                                        const f16x8* __restrict__ Wsp,
+                                                        const int* __restrict__ wfield,
+                                                        float* __restrict__ out, int tiles,
+                                                        int write_out, int zero) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* planes = reinterpret_cast<_Float16*>(smem_raw);   // [2][ROWS][LDP]
+  __shared__ unsigned rowmax[ROWS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  float total = 0.f;
+  for (int t = 0; t < tiles; ++t) {
+    if (tid < ROWS) rowmax[tid] = 0u;
+    __syncthreads();
+    float4 keep[ROWS * K / 4 / 512];
+#pragma unroll
+    for (int i = 0; i < ROWS * K / 4 / 512; ++i) {
+      const int e = tid + 512 * i;
+      const int r = e / (K / 4), c = (e % (K / 4)) * 4;
+      keep[i] = *reinterpret_cast<const float4*>(h1 + r * K + c);
+      const float m = fmaxf(fmaxf(fabsf(keep[i].x), fabsf(keep[i].y)), fmaxf(fabsf(keep[i].z), fabsf(keep[i].w)));
+      atomicMax(&rowmax[r], __float_as_uint(m));     // non-negative floats order as unsigned
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ROWS * K / 4 / 512; ++i) {
+      const int e = tid + 512 * i;
+      const int r = e / (K / 4), c = (e % (K / 4)) * 4;
+      const float sc = pow2_field(268 - scale_field(__uint_as_float(rowmax[r])));
+      const float x[4] = {keep[i].x * sc, keep[i].y * sc, keep[i].z * sc, keep[i].w * sc};
+      f16x4 q0, q1;
+      for (int j = 0; j < 4; ++j) { _Float16 a, b; split2h(x[j], a, b); q0[j] = a; q1[j] = b; }
+      *reinterpret_cast<f16x4*>(planes + ((size_t)0 * ROWS + r) * LDP + c) = q0;
+      *reinterpret_cast<f16x4*>(planes + ((size_t)1 * ROWS + r) * LDP + c) = q1;
+    }
+    __syncthreads();
+    f32x16 acc[2][NACC];
+    for (int tm = 0; tm < 2; ++tm)
+      for (int c = 0; c < NACC; ++c)
+        for (int r = 0; r < 16; ++r) acc[tm][c][r] = 0.f;
+    f16x8 ring[RD][2];
+    const f16x8* wp = Wsp + (size_t)wave * KS * 2 * 64 + lane + (size_t)zero * t;
+#pragma unroll
+    for (int g = 0; g < RD; ++g)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) ring[g][s] = wp[(size_t)(g * 2 + s) * 64];
+    const _Float16* bp0 = planes + (size_t)l31 * LDP + 8 * hh;
+    const _Float16* bp1 = bp0 + (size_t)32 * LDP;
+    f16x8 bq[2][2][2];
+    auto ldb = [&](int g, f16x8 (&b)[2][2]) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        b[0][s] = *reinterpret_cast<const f16x8*>(bp0 + (size_t)s * ROWS * LDP + 16 * g);
+        b[1][s] = *reinterpret_cast<const f16x8*>(bp1 + (size_t)s * ROWS * LDP + 16 * g);
+      }
+    };
+    ldb(0, bq[0]);
+#pragma unroll
+    for (int g = 0; g < KS; ++g) {
+      f16x8 a[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) a[s] = ring[g % RD][s];
+      if (g + RD < KS) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) ring[g % RD][s] = wp[(size_t)((g + RD) * 2 + s) * 64];
+      }
+      if (g + 1 < KS) ldb(g + 1, bq[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      f16x8 (&b)[2][2] = bq[g & 1];
+      constexpr int c0 = 0, c1 = NACC == 2 ? 1 : 0;
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm) {
+        acc[tm][c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[tm][1], acc[tm][c1], 0, 0, 0);
+        acc[tm][c1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[tm][0], acc[tm][c1], 0, 0, 0);
+        acc[tm][c0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[tm][0], acc[tm][c0], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+      const int row = 32 * tm + l31;
+      const int rf = scale_field(__uint_as_float(rowmax[row]));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[tm][NACC - 1][r];
+        if (NACC == 2) v += acc[tm][0][r];
+        const int unit = 32 * wave + 8 * (r >> 2) + 4 * hh + (r & 3);
+        v = ldexpf(v, rf + wfield[unit] - 282);
+        if (write_out && t == 0) out[row * H + unit] = v;
+        total += v;
+      }
+    }
+    __syncthreads();
+  }
+  if (!write_out) out[(size_t)blockIdx.x * 512 + tid] = total;
+}
+
+template <int NACC, int RD>
+double run_h(const float* h1, const f16x8* Wsp, const int* wfield, float* out, int grid, int tiles,
+             std::vector<float>* first) {
+  const size_t smem = (size_t)2 * ROWS * LDP * 2;
+  CHECK(hipFuncSetAttribute((const void*)tile_h_kernel<NACC, RD>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  if (first) {
+    hipLaunchKernelGGL((tile_h_kernel<NACC, RD>), dim3(1), dim3(512), smem, 0, h1, Wsp, wfield, out, 1, 1, 0);
+    CHECK(hipDeviceSynchronize());
+    first->resize(ROWS * H);
+    CHECK(hipMemcpy(first->data(), out, ROWS * H * 4, hipMemcpyDeviceToHost));
+  }
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((tile_h_kernel<NACC, RD>), dim3(grid), dim3(512), smem, 0, h1, Wsp, wfield, out, tiles, 0, 0);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+  }
+  float ms = 0;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1e-3;
+}
+
 int main() {
   std::vector<float> h1(ROWS * K), W(H * K);
   srand(1);
@@ -263,5 +434,37 @@ int main() {
   s = run<3, 2, false>(dh1, dWsp, dW, dout, ncu, tiles, &got);      report("bf16x3 3acc rd2 1wg/cu", s, ncu, got);
   s = run<3, 4, false>(dh1, dWsp, dW, dout, 2 * ncu, tiles, &got);  report("bf16x3 3acc rd4 2 waves of wgs", s, 2 * ncu, got);
   s = run<3, 4, false>(dh1, dWsp, dW, dout, 192, tiles, &got);      report("bf16x3 3acc rd4 192 wgs", s, 192, got);
+  {
+    f16x8* dWh;
+    int* dwf;
+    CHECK(hipMalloc(&dWh, (size_t)8 * KS * 2 * 64 * 16));
+    CHECK(hipMalloc(&dwf, H * 4));
+    hipLaunchKernelGGL(pack_wh_kernel, dim3((8 * KS * 64 + 255) / 256), dim3(256), 0, 0, dW, dWh, dwf);
+    CHECK(hipDeviceSynchronize());
+    s = run_h<2, 4>(dh1, dWh, dwf, dout, ncu, tiles, &got);      report("fp16x2 2acc rd4 1wg/cu", s, ncu, got);
+    s = run_h<1, 4>(dh1, dWh, dwf, dout, ncu, tiles, &got);      report("fp16x2 1acc rd4 1wg/cu", s, ncu, got);
+    s = run_h<2, 2>(dh1, dWh, dwf, dout, ncu, tiles, &got);      report("fp16x2 2acc rd2 1wg/cu", s, ncu, got);
+    s = run_h<2, 4>(dh1, dWh, dwf, dout, 2 * ncu, tiles, &got);  report("fp16x2 2acc rd4 2 wgs/cu", s, 2 * ncu, got);
+    // the same data with rows / units scaled far outside fp16's range (exact powers of two):
+    // the error relative to sum |a b| must not move
+    std::vector<float> h1s(h1), Ws(W);
+    for (int r = 0; r < ROWS; ++r) { const float f = ldexpf(1.f, (r % 9 - 4) * 15); for (int k = 0; k < K; ++k) h1s[r * K + k] *= f; }
+    for (int u = 0; u < H; ++u) { const float f = ldexpf(1.f, (u % 7 - 3) * 12); for (int k = 0; k < K; ++k) Ws[u * K + k] *= f; }
+    // one tiny and one moderately small element in every row (lo underflows into fp16 subnormals)
+    for (int r = 0; r < ROWS; ++r) { h1s[r * K + 7] *= 1e-6f; h1s[r * K + 11] *= 3e-5f; }
+    for (int r = 0; r < ROWS; ++r)
+      for (int u = 0; u < H; ++u) {
+        double s2 = 0, m = 0;
+        for (int k = 0; k < K; ++k) { s2 += (double)h1s[r * K + k] * Ws[u * K + k]; m += fabs((double)h1s[r * K + k] * Ws[u * K + k]); }
+        ref[r * H + u] = s2; mag[r * H + u] = m;
+      }
+    CHECK(hipMemcpy(dh1, h1s.data(), ROWS * K * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(dW, Ws.data(), H * K * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(pack_wh_kernel, dim3((8 * KS * 64 + 255) / 256), dim3(256), 0, 0, dW, dWh, dwf);
+    hipLaunchKernelGGL(pack_w_kernel, dim3((8 * KS * 64 + 255) / 256), dim3(256), 0, 0, dW, dWsp);
+    CHECK(hipDeviceSynchronize());
+    s = run_h<2, 4>(dh1, dWh, dwf, dout, ncu, tiles, &got);      report("fp16x2 2acc rd4, rows/units scaled 2^+-60", s, ncu, got);
+    s = run<3, 4, false>(dh1, dWsp, dW, dout, ncu, tiles, &got); report("bf16x3 3acc rd4, rows/units scaled 2^+-60", s, ncu, got);
+  }
   return 0;
 }
