@@ -116,7 +116,9 @@ struct pa_dqn {
                        // learner stream, which costs ~6 us of idle stream per window even when the event
                        // completed long ago (rocprof: gap in front of every window's first row pass)
   int use_flags;     // PEARL_AMD_FLAG_HOP (default 1); 0 = events as before
-  int lead_persist;  // PEARL_AMD_LEAD_PERSIST: leading target pieces keep off the chain's CUs
+  int lead_persist;  // PEARL_AMD_LEAD_PERSIST: leading target pieces keep off the chain's CUs (1: all of them;
+                     // 2, the default since round 6: all but a window's first — the first weight-gradient
+                     // launch of a window no longer queues for slots behind the second piece's grid)
   // the fragment-major copies (online + target) match the flat parameters: true after a learn()
   // whose every round refreshed them in its optimizer epilogue; cleared by anything else that
   // writes parameters (bind, step, apply, update_target, pa_dqn_invalidate)
@@ -687,7 +689,7 @@ int run_rowpass(pa_dqn* h, const float* x, int B, const float* y, bool y_tagged,
   if (use_h2) {
     const size_t smem2 = rowpass_h2_smem_bytes();
     if (phase == 1) hipLaunchKernelGGL((online_rowpass_h2_kernel<1>), grid, dim3(512), smem2, s, a);
-    else if (phase == 2) hipLaunchKernelGGL((online_rowpass_h2_kernel<2>), grid, dim3(512), smem2, s, a);
+    else if (phase == 2) hipLaunchKernelGGL(rowpass_scale_kernel, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((online_rowpass_h2_kernel<0>), grid, dim3(512), smem2, s, a);
     PA_LAUNCH_CHECK();
     return PA_OK;
@@ -1216,7 +1218,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->pending_signal = 0;
   h->pending_wait = 0;
   h->use_flags = env_int("PEARL_AMD_FLAG_HOP", 1);
-  h->lead_persist = env_int("PEARL_AMD_LEAD_PERSIST", 0);
+  h->lead_persist = env_int("PEARL_AMD_LEAD_PERSIST", 2);
   h->err_dev = nullptr;
   h->err_host = nullptr;
   h->packed_ok = false;
@@ -1777,7 +1779,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       // slots (measured: 31-52 us instead of 17).  lead_persist runs them as work-stealing tiles of
       // the two-workgroups-per-CU kernel that stay off the reserved CUs, like the remainder.
       const bool last = pc == npieces - 1;
-      const bool lead_p = !last && h->lead_persist && persist;
+      const bool lead_p = !last && persist && (h->lead_persist == 1 || (h->lead_persist == 2 && pc >= 1));
       static const int prio = env_int("PEARL_AMD_PRIO_FIRST", 1);
       // PEARL_AMD_LEAD_ROWS=32: the leading (latency-bound, 16- / 32-tile) pieces on the 32-row,
       // four-wave tile — twice the workgroups, half the rows each, bitwise the 64-row tile

@@ -275,19 +275,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_h2_kernel(RowArgs a
     *reinterpret_cast<f16x8*>(s2h + plane_off + 32 * wave) = hi;
     *reinterpret_cast<f16x8*>(s2l + plane_off + 32 * wave) = lo;
   };
-  if constexpr (PH == 2) {
-    const int64_t r1 = (int64_t)row * a.H1, r2 = (int64_t)row * a.H2;
-    ring_fill<NG3>(R3, a.W2tf, tile0, 16, lane);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int u = u0 + 16 * t;
-      h1k[t] = ld4_or_zero(a.H1a, r1 + u, rok);
-      h2k[t] = ld4_or_zero(a.H2a, r2 + u, rok);
-      w3v[t] = vec4(a.w3, u, a.H2);
-    }
-    head_scale();
-    store_s2();
-  } else {
+  {
     WRing R2;
     float4 b1v[2], b2v[2];
     float4 xf[2 * NS1], wa[2 * NS1], wb[2 * NS1];
@@ -377,7 +365,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_h2_kernel(RowArgs a
       f32x4v c[2][HF_NACC];
       h2_zero(c);
       rows16_gemm_h2<NG2, NG3, false>(c, R2, a.W2f, tile0, lane, F2.sA, nullptr, h1h + plane_off,
-                                      h1l + plane_off, R3, a.W2tf, PH == 0 && a.y != nullptr);
+                                      h1l + plane_off, R3, a.W2tf, a.y != nullptr);
       h2_finish(acc, c, fh, F2.fC, b2v);
     }
     PA_STAMP(a.prof, blockIdx.x, wave, 5);
@@ -392,7 +380,7 @@ static __global__ __launch_bounds__(512) void online_rowpass_h2_kernel(RowArgs a
       part = fmaf(h2k[t].w, w3v[t].w, part);
       if (rok && a.H2a) *reinterpret_cast<float4*>(a.H2a + (int64_t)row * a.H2 + u) = h2k[t];
     }
-    if (PH == 0 && a.y) store_s2();
+    if (a.y) store_s2();
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);
     if (qd == 0) qpart[wave * 16 + r16] = part;
@@ -400,18 +388,9 @@ static __global__ __launch_bounds__(512) void online_rowpass_h2_kernel(RowArgs a
   PA_STAMP(a.prof, blockIdx.x, wave, 6);
   __syncthreads();                                                        // barrier B: s2, qpart
   PA_STAMP(a.prof, blockIdx.x, wave, 7);
-  if constexpr (PH == 1) {
-    float qf = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) qf += qpart[w * 16 + r16];
-    qf += b3v;
-    if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = qf;
-    PA_STAMP(a.prof, blockIdx.x, wave, 10);
-    return;
-  }
-  const bool poller = PH != 2 || (wave == 0 && qd == 0);
   unsigned ybits = kYPendingBits;
-  if (a.y && rok && poller) {
+  if (PH == 0 && a.y && rok) {
+    // first look at the Bellman target, in flight while the backward GEMM runs
     ybits = a.y_tagged ? __hip_atomic_load(reinterpret_cast<const unsigned*>(a.y) + row,
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                        : __builtin_bit_cast(unsigned, a.y[row]);
@@ -430,24 +409,40 @@ static __global__ __launch_bounds__(512) void online_rowpass_h2_kernel(RowArgs a
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 8);
   float q = 0.f;
-  if constexpr (PH == 2) {
-    q = rok ? a.q_in[row] : 0.f;
-  } else {
 #pragma unroll
-    for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
-    q += b3v;
-    if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
-  }
+  for (int w = 0; w < 8; ++w) q += qpart[w * 16 + r16];
+  q += b3v;
+  if (wave == 0 && qd == 0 && rok && a.q_out) a.q_out[row] = q;
   if (!a.y) return;
+  if constexpr (PH == 1) {
+    // the forward launch of a window's first round: everything that does not need the Bellman
+    // target, i.e. also the masked backward factors  s2 = [h2 > 0] w3  and  G [h1 > 0]  (in the
+    // places of dZ2 / dZ1); rowpass_scale_kernel multiplies them by dq once the targets exist
+    if (rok) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int u = u0 + 16 * t;
+        float4 z;
+        z.x = (h2k[t].x > 0.f) ? w3v[t].x : 0.f;
+        z.y = (h2k[t].y > 0.f) ? w3v[t].y : 0.f;
+        z.z = (h2k[t].z > 0.f) ? w3v[t].z : 0.f;
+        z.w = (h2k[t].w > 0.f) ? w3v[t].w : 0.f;
+        *reinterpret_cast<float4*>(a.dZ2 + (int64_t)row * a.H2 + u) = z;
+        float4 g;
+        g.x = (h1k[t].x > 0.f) ? acc[t][0] : 0.f;
+        g.y = (h1k[t].y > 0.f) ? acc[t][1] : 0.f;
+        g.z = (h1k[t].z > 0.f) ? acc[t][2] : 0.f;
+        g.w = (h1k[t].w > 0.f) ? acc[t][3] : 0.f;
+        *reinterpret_cast<float4*>(a.dZ1 + (int64_t)row * a.H1 + u) = g;
+      }
+    }
+    PA_STAMP(a.prof, blockIdx.x, wave, 10);
+    return;
+  }
   float yv = q;
-  if (rok && poller) {
+  if (rok) {
     if (a.y_tagged && ybits == kYPendingBits) yv = consume_y(a.y + row, a.err, a.err_host);
     else yv = __builtin_bit_cast(float, ybits);
-  }
-  if constexpr (PH == 2) {
-    if (poller) qpart[r16] = yv;
-    __syncthreads();
-    yv = rok ? qpart[r16] : q;
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 9);
   const float d = __fsub_rn(q, yv);
@@ -476,6 +471,55 @@ static __global__ __launch_bounds__(512) void online_rowpass_h2_kernel(RowArgs a
   }
   PA_STAMP(a.prof, blockIdx.x, wave, 10);
   PA_STAMP_CYC(a.prof, blockIdx.x, wave, 15);
+}
+
+
+// The backward launch of a window's first round (after online_rowpass_h2_kernel<1>): dq = norm (q - y)
+// per row once its Bellman target exists, dZ2 = dq s2 and dZ1 = dq G [h1 > 0] in place — the values
+// online_rowpass_h2_kernel<0> stores (one fp32 rounding per element, zeros where the mask is closed).
+// Sixteen rows per workgroup; no weights, 12 registers: it is resident beside the leading target
+// tiles (which own their CUs' register files against the full row pass) and ends ~2 us after the
+// window's first targets exist, where the backward half of the row pass took 7.6 us from there.
+// ONE quarter-wave per workgroup polls (agent-scope loads bypass the L2 and share the memory system
+// with the tiles the launch is waiting for).
+static __global__ __launch_bounds__(256) void rowpass_scale_kernel(RowArgs a) {
+  __shared__ float dqs[RP_ROWS];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * RP_ROWS;
+  // this thread's operands first: they do not depend on the target.  Row r of the tile is 128
+  // float4 (dZ2 | dZ1, H1 = H2 = 256); thread t owns float4 (t & 127) of rows (t >> 7) + 2 i
+  float4 v[8];
+  const int c = tid & 127, r0 = tid >> 7;
+  float* base = c < 64 ? a.dZ2 : a.dZ1;
+  const int cc = (c & 63) * 4;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = m0 + r0 + 2 * i;
+    v[i] = ld4_or_zero(base, (int64_t)row * HF_UNITS + cc, row < a.B);
+  }
+  if (tid < RP_ROWS) {
+    const int row = m0 + tid;
+    float dq = 0.f;
+    if (row < a.B) {
+      const float q = a.q_in[row];
+      const float yv = a.y_tagged ? consume_y(a.y + row, a.err, a.err_host) : a.y[row];
+      const float d = __fsub_rn(q, yv);
+      dq = __fmul_rn(a.norm, d);
+      a.dq_out[row] = dq;
+      a.absd_out[row] = fabsf(d);
+    }
+    dqs[tid] = dq;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = m0 + r0 + 2 * i;
+    if (row >= a.B) continue;
+    const float dq = dqs[r0 + 2 * i];
+    auto sc = [&](float x) { return x != 0.f ? __fmul_rn(dq, x) : 0.f; };
+    *reinterpret_cast<float4*>(base + (int64_t)row * HF_UNITS + cc) =
+        make_float4(sc(v[i].x), sc(v[i].y), sc(v[i].z), sc(v[i].w));
+  }
 }
 
 }  // namespace pa
