@@ -37,14 +37,15 @@ FLOP_DW_PER_TRANSITION = 2 * (144 * 256 + 256 * 256 + 256)                      
 def pmc_chain():
     """Matrix-pipe busy fraction of the chain's kernels from the newest committed PMC pass
     (tools/pmc_summary.py --chain-json; separate rocprofv3 --pmc runs, never inside this run)."""
-    for name in ("r06_pmc_chain.json", "r05_pmc_chain.json"):
+    for name in ("r06_z_pmc_chain.json", "r06_pmc_chain.json", "r05_pmc_chain.json"):
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
                 d = json.load(f)
             out = {}
             for k, v in d.get("kernels", {}).items():
-                key = ("rowpass" if "online_rowpass_kernel" in k and ", 0>" in k else
+                key = ("rowpass" if ("online_rowpass_h2_kernel<0>" in k or
+                                     ("online_rowpass_kernel" in k and ", 0>" in k)) else
                        "weight_grad" if "weight_grad" in k else None)
                 if key:
                     out[key] = v["mfma_busy_frac"]
@@ -145,13 +146,25 @@ def reference_cpu_baseline(budget_s: float = 15.0):
         return None
 
 
+def target_dtype():
+    """The arithmetic the path computes in: fp32 results everywhere; the two GEMM-heavy kernels run
+    their products on the 16-bit matrix pipe on exactly split operands."""
+    if os.environ.get("PEARL_AMD_TARGET_SPLIT", "1") == "0":
+        return "f32"
+    h2t = os.environ.get("PEARL_AMD_TARGET_H2", "1") != "0" and os.environ.get("PEARL_AMD_FUSE_U", "0") == "0"
+    h2r = os.environ.get("PEARL_AMD_ROWPASS_H2", "1") != "0"
+    return ("f32 (target layer 2: " + ("fp16x2" if h2t else "bf16x3") + "-split MFMA; online row pass: " +
+            ("fp16x2-split MFMA" if h2r else "fp32 MFMA") + "; fp32 accumulate)")
+
+
 def pmc_traffic(transitions_per_launch, split_on):
     """HBM bytes of one target-kernel launch from committed rocprofv3 PMC passes (separate --pmc runs
     of the single-stream loop; tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md
     prescribes for gfx950, + WRITE_SIZE, per transition).  Counters cannot be collected inside this
     run, so the line names the file the figure comes from and the kernel that pass measured; None
     when no pass exists for the kernel that ran."""
-    names = ["r06_pmc_target.json", "r05_pmc_target.json", "r04_pmc_target.json", "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"]
+    names = (["r06_z_pmc_target.json", "r06_pmc_target.json", "r05_pmc_target.json", "r04_pmc_target.json",
+              "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"])
     for name in names:
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
@@ -371,8 +384,7 @@ def main():
             "warmup": args.warmup, "untimed_rounds_before": args.warmup + calib_rounds,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (target layer 2: bf16x3-split MFMA, fp32 accumulate)" if os.environ.get(
-                "PEARL_AMD_TARGET_SPLIT", "1") != "0" else "f32",
+            "dtype": target_dtype(),
             "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: DeepQLearning synthetic 128-dim obs / "
                                    "16 discrete actions, hidden=[256,256], replay 1M, batch=1024",
@@ -397,16 +409,21 @@ def main():
             # loop at timing level >= 2, multi-GPU runs) the calibration pass stands in and says so
             live = "target" in timers
             split_on = os.environ.get("PEARL_AMD_TARGET_SPLIT", "1") != "0"
+            h2_on = split_on and os.environ.get("PEARL_AMD_TARGET_H2", "1") != "0" and os.environ.get(
+                "PEARL_AMD_FUSE_U", "0") == "0"
+            # products per fp32 product on the 16-bit matrix pipe: 3 (fp16x2 split) or 6 (bf16x3 split)
+            nprod = 3.0 if h2_on else 6.0
+            tile_name = ("target_h2_kernel (fp16x2 split MFMA, fp32 accuracy)" if h2_on
+                         else "target_split_kernel (bf16x3 split MFMA, fp32 accuracy)")
             tt = timers["target"] if live else isolated
             ach, per_launch = kernel_rate(tt)
             traffic, traffic_src, traffic_kernel = pmc_traffic(per_launch, split_on)
             step_rate = FLOP_PER_TRANSITION_STEP * B * args.steps / dt     # per GPU
             line["roofline"] = {"bound": "mfma",
-                                "kernel": (("target_split_kernel (bf16x3 split MFMA, fp32 accuracy)"
-                                            if split_on else "target_pp_kernel<32>") +
+                                "kernel": ((tile_name if split_on else "target_pp_kernel<32>") +
                                            " (persistent launch of a target-update window, "
                                            "overlapped loop)" if live and overlapped
-                                           else ("target_split_kernel" if split_on else
+                                           else (tile_name if split_on else
                                                  "target_fused_kernel<32>") + " (classic grid)"),
                                 "achieved": ach / 1e12, "peak": PEAK_F32_MFMA / 1e12,
                                 "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA,
@@ -419,22 +436,28 @@ def main():
             if split_on:
                 # `achieved` / `frac` count ALGORITHMIC fp32 FLOPs against the fp32-MFMA peak — the
                 # contract figure of SURVEY.md §8(d), comparable across rounds.  The kernel executes
-                # its layer-2 product as six bf16 MFMA products per fp32 product (three-way exact
-                # operand split, fp32 accumulate: results at fp32 accuracy, 1e-5 Q-value parity in
-                # tests/): against the dense bf16 peak the same launches read as below.
-                exe = 6.0 * 2 * A * 256 * 256 + 2 * A * 256 * A + 2 * A * 256
+                # its layer-2 product as `nprod` 16-bit MFMA products per fp32 product — round 6: three
+                # (operands scaled into fp16's range and split two ways, target_h2_kernel); rounds 3-5: six
+                # (three-way exact bf16 split) — fp32 accumulate, results at fp32 accuracy, 1e-5 Q-value
+                # parity in tests/: against the dense 16-bit peak the same launches read as below.
+                exe = nprod * 2 * A * 256 * 256 + 2 * A * 256 * A + 2 * A * 256
                 line["roofline"]["precision"] = (
-                    "fp32 results; layer 2 on v_mfma_f32_32x32x16_bf16 with bf16x3 operand splits")
-                # the primary figure against the pipe the kernel runs on: fp32-accurate products cost
-                # six bf16 MFMA products each, so the ceiling for ALGORITHMIC fp32 FLOPs on the bf16
-                # pipe is 2.5 PF / 6 = 416.7 TF (`frac` above can exceed 1 against the fp32 peak)
-                line["roofline"]["peak_pipe"] = PEAK_BF16_MFMA / 6 / 1e12
-                line["roofline"]["frac_pipe"] = ach / (PEAK_BF16_MFMA / 6)
+                    "fp32 results; layer 2 on v_mfma_f32_32x32x16_f16 with fp16x2 operand splits (3 products)"
+                    if h2_on else
+                    "fp32 results; layer 2 on v_mfma_f32_32x32x16_bf16 with bf16x3 operand splits (6 products)")
+                # the figure against the pipe the kernel runs on: an fp32-accurate product costs `nprod`
+                # 16-bit MFMA products, so the ceiling for ALGORITHMIC fp32 FLOPs on that pipe is
+                # 2.5 PF / nprod (`frac` above can exceed 1 against the fp32 peak).  NOTE: halving the
+                # executed products (round 6) doubles this ceiling — frac_pipe of round 6 is not
+                # comparable with earlier rounds' (416.7 TF); `achieved` and `frac` are
+                line["roofline"]["products_per_fp32_product"] = nprod
+                line["roofline"]["peak_pipe"] = PEAK_BF16_MFMA / nprod / 1e12
+                line["roofline"]["frac_pipe"] = ach / (PEAK_BF16_MFMA / nprod)
                 line["roofline"]["executed"] = {
                     "flop_per_transition": exe, "achieved": ach / 1e12 * exe / FLOP_TARGET_KERNEL_PER_TRANSITION,
                     "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                     "frac": ach * exe / FLOP_TARGET_KERNEL_PER_TRANSITION / PEAK_BF16_MFMA,
-                    "note": "executed bf16-MFMA FLOPs against the dense bf16 peak (2.5 PFLOP/s)"}
+                    "note": "executed 16-bit MFMA FLOPs against the dense bf16 / fp16 peak (2.5 PFLOP/s)"}
             if isolated and live:
                 iach, iper = kernel_rate(isolated)
                 line["roofline"]["concurrent_with"] = (
@@ -442,7 +465,7 @@ def main():
                     + os.environ.get("PEARL_AMD_RESERVED_CUS", "128" if split_on else "64") + " of 256)")
                 line["roofline"]["isolated"] = {
                     "achieved": iach / 1e12, "frac": iach / PEAK_F32_MFMA,
-                    "frac_pipe": iach / (PEAK_BF16_MFMA / 6) if split_on else iach / PEAK_F32_MFMA,
+                    "frac_pipe": iach / (PEAK_BF16_MFMA / nprod) if split_on else iach / PEAK_F32_MFMA,
                     "avg_launch_us": isolated["avg_us"], "transitions_per_launch": iper,
                     "launches_timed": isolated["n"],
                     "note": "same kernel, single-stream loop, chip to itself (calibration pass before the timed region)"}
@@ -463,7 +486,9 @@ def main():
             fl_rp, fl_dw = FLOP_ROWPASS_PER_TRANSITION * B, FLOP_DW_PER_TRANSITION * B
             line["roofline"]["chain"] = {
                 "bound": "mfma (latency-bound as built: 64 + 113 workgroups on 256 CUs)",
-                "rowpass": {"kernel": "online_rowpass_kernel", "avg_launch_us": rp["avg_us"],
+                "rowpass": {"kernel": ("online_rowpass_h2_kernel (fp16x2 split MFMA, fp32 accuracy)"
+                                       if os.environ.get("PEARL_AMD_ROWPASS_H2", "1") != "0" else "online_rowpass_kernel"),
+                            "avg_launch_us": rp["avg_us"],
                             "launches_timed": rp["n"], "flop": fl_rp,
                             "achieved": fl_rp / (rp["avg_us"] * 1e-6) / 1e12,
                             "frac": fl_rp / (rp["avg_us"] * 1e-6) / PEAK_F32_MFMA,

@@ -60,6 +60,9 @@ struct pa_dqn {
                // transitions/s over 2000 rounds) — kept as a switch for the version that issues the
                // tile's loads ahead of the product.
   int use_split;  // PEARL_AMD_TARGET_SPLIT (default 1): the bf16x3 kernel where its shape applies
+  int use_h2t;    // PEARL_AMD_TARGET_H2 (default 1): the fp16x2 tile (target_h2_kernel.hpp) for plain DQN's passes
+  void* w2h;      // target W2 as scaled fp16 hi / lo planes
+  int* w2hf;      // ... and the scale field of every unit
   int dw_tm;      // PEARL_AMD_DW_TM: rows per weight-gradient tile, 64 or 32 (0 = by the CU partition)
   int rp_split;   // PEARL_AMD_ROWPASS_SPLIT (default 1): window-first row pass as forward + backward
   // Double DQN only (desc.double_q): the same copy of the ONLINE W2, the chosen next actions, and
@@ -279,6 +282,34 @@ static __global__ void wait_flag_kernel(const int* flag, int value, int* err, in
     }
   }
 }
+// The same wait at the head of a target-update window, by a launch that then rebuilds the fp16 planes of
+// the target W2 (target_h2_kernel.hpp: the soft update that the word announces changed their scales):
+// 64 workgroups x 4 waves, one wave per row of W2'; every wave waits for itself.  Resident before the
+// word flips, ~1 us of work after it — a pack launch of its own would sit on the window's critical path.
+static __global__ __launch_bounds__(256) void wait_pack_kernel(const int* flag, int value, int* err, int* err_host,
+                                                               int* done_flag, int done_value, W2hPack p) {
+  if (done_flag && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(done_flag, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  constexpr long long kLimitTicks = 120LL * 100000000LL;     // 120 s
+  const long long t0 = (long long)wall_clock64();
+  int spins = 0;
+  while ((__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+    __builtin_amdgcn_s_sleep(8);
+    if ((++spins & 1023) == 0 && (long long)wall_clock64() - t0 > kLimitTicks) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err_host) __hip_atomic_store(err_host, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+  }
+  target_w2h_pack<true>(p, (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), (int64_t)gridDim.x * 4, threadIdx.x & 63);
+}
+W2hPack w2h_pack_args(const pa_dqn* h) {
+  W2hPack p;
+  p.W2 = h->bufs.q_target + h->off[2]; p.planes = h->w2h; p.fields = h->w2hf;
+  return p;
+}
 // Everything enqueued on `to` after this call runs after everything enqueued on `from` before it.
 int stream_hop(pa_dqn* h, hipStream_t from, hipStream_t to, hipEvent_t fallback) {
   if (!h->use_flags) {
@@ -403,6 +434,7 @@ TargetArgs make_target_args(const pa_dqn* h, const pa_dqn_batch* b, const float*
   a.W2f = argmax ? h->w2f_online : h->w2f;
   // (Double DQN's argmax pass runs on the ONLINE parameters: their planes are rebuilt per round)
   a.W2sp = !h->use_split ? nullptr : (argmax ? h->w2sp_online : h->w2sp);
+  if (h->use_h2t && h->w2h && !argmax) { a.W2h = h->w2h; a.w2hf = h->w2hf; }
   a.argmax = argmax;
   a.choice_rep = argmax ? h->choice_rep : nullptr;
   a.b2 = t.b2; a.w3 = t.W3; a.b3 = t.b3;
@@ -486,6 +518,7 @@ PackedW packed(pa_dqn* h) {
   pk.W1f = h->W1f; pk.W2f = h->W2f16; pk.W2tf = h->W2tf; pk.tW2f = h->w2f;
   pk.tW2sp = h->w2sp;
   pk.tW1sp = h->w1sp; pk.sp_S = h->d.state_dim;
+  pk.tW2h = h->use_h2t ? h->w2h : nullptr; pk.tW2hf = h->w2hf;
   return pk;
 }
 
@@ -551,6 +584,7 @@ int run_double_targets(pa_dqn* h, const pa_dqn_batch* b, float* next_v, float* y
     a.pk.tW2f = h->w2f_online;
     a.pk.tW2sp = h->w2sp_online;                 // (never h->w2sp: those stay the TARGET network's)
     a.pk.tW1sp = nullptr;
+    a.pk.tW2h = nullptr;
     a.do_online = 0; a.do_target = 1;
     hipLaunchKernelGGL(repack_online_kernel, dim3(128), dim3(256), 0, s, a);
     PA_LAUNCH_CHECK();
@@ -1202,6 +1236,7 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
   h->dw_tm = env_int("PEARL_AMD_DW_TM", 0);
   h->rp_split = env_int("PEARL_AMD_ROWPASS_SPLIT", 1);
   h->rp_h2 = env_int("PEARL_AMD_ROWPASS_H2", 1);
+  h->use_h2t = env_int("PEARL_AMD_TARGET_H2", 1);
   h->pair = env_int("PEARL_AMD_ROWPASS_PAIR", 0);
   h->pair_lds = env_int("PEARL_AMD_PAIR_LDS", 82 * 1024);
   h->pair_live = false;
@@ -1310,6 +1345,16 @@ extern "C" int pa_dqn_create(pa_dqn** out, const pa_dqn_desc* desc) {
       h->w1sp = sp1;
     }
   }
+  // (not beside PEARL_AMD_FUSE_U: that experiment's tiles form U with the bf16x3 arithmetic)
+  if (h->use_h2t && h->use_split && !h->fuse_u && desc->hidden1 == TS_H && desc->hidden2 == TS_H && desc->double_q == 0) {
+    float* w = nullptr;
+    PA_WS(w, w2h_bytes() / 4);
+    h->w2h = w;
+    PA_WS(w, TS_H);
+    h->w2hf = reinterpret_cast<int*>(w);
+  } else {
+    h->use_h2t = 0;
+  }
   PA_WS(h->W1f, wf16_floats(desc->hidden1, h->IN));
   PA_WS(h->W2f16, wf16_floats(desc->hidden2, desc->hidden1));
   PA_WS(h->W2tf, wf16_floats(desc->hidden1, desc->hidden2));
@@ -1351,7 +1396,7 @@ extern "C" int pa_dqn_destroy(pa_dqn* h) {
   void* ptrs[] = {h->Uw[0], h->Uw[1], h->H1a, h->H2a, h->dZ2, h->dZ1, h->yw[0], h->yw[1], h->nextv,
                   h->qbuf, h->dq, h->absd, h->xpack, h->loss_scratch, h->idx_all, h->w2f, h->W1f,
                   h->W2f16, h->W2tf, h->reserved_dev, h->tile_ctr, h->w2f_online, h->w2sp, h->w2sp_online, h->w1sp,
-                  h->choice, h->choice_rep, h->dZ1p, h->qx, h->qhalf, h->dbg_workers, h->umax};
+                  h->choice, h->choice_rep, h->dZ1p, h->qx, h->qhalf, h->dbg_workers, h->umax, h->w2h, h->w2hf};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->err_host) (void)hipHostFree(h->err_host);
@@ -1700,12 +1745,24 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         //  on one box, 20-round calls within noise — so the event of rounds 1-4 stays the default)
         static const bool x_by_flag = env_int("PEARL_AMD_X_FLAG", 0) != 0;
         h->pending_wait = x_by_flag ? gen : 0;
-        hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev, h->err_host,
-                           x_by_flag ? h->sig + 1 : nullptr, gen);
+        if (h->use_h2t && h->w2h)
+          hipLaunchKernelGGL(wait_pack_kernel, dim3(64), dim3(256), 0, t, h->sig, gen, h->err_dev, h->err_host,
+                             x_by_flag ? h->sig + 1 : nullptr, gen, w2h_pack_args(h));
+        else
+          hipLaunchKernelGGL(wait_flag_kernel, dim3(1), dim3(64), 0, t, h->sig, gen, h->err_dev, h->err_host,
+                             x_by_flag ? h->sig + 1 : nullptr, gen);
         PA_LAUNCH_CHECK();
       } else {
         PA_HIP(hipStreamWaitEvent(t, h->ev_chain[(k - 1) & 1], 0));
+        if (h->use_h2t && h->w2h) {
+          hipLaunchKernelGGL(target_pack_kernel, dim3(64), dim3(256), 0, t, w2h_pack_args(h));
+          PA_LAUNCH_CHECK();
+        }
       }
+    } else if (!overlap && k > 0 && h->use_h2t && h->w2h) {
+      // single stream: the previous window's last optimizer launch (soft update) is simply earlier on `s`
+      hipLaunchKernelGGL(target_pack_kernel, dim3(64), dim3(256), 0, t, w2h_pack_args(h));
+      PA_LAUNCH_CHECK();
     }
     // U and the Bellman targets; the first round of the window as its own pair of launches, so
     // the chain can start after one round's worth of target work instead of the whole window's

@@ -327,6 +327,8 @@ struct TargetArgs {
   const float* W2f;                         // fragment-major W2' (see w2f_index)
   const void* W2sp;                         // optional: W2' as bf16 split planes (w2sp_index):
                                             // target_split_kernel instead of the fp32-MFMA kernels
+  const void* W2h; const int* w2hf;         // optional: W2' as scaled fp16 hi / lo planes + the scale field of
+                                            // every unit (target_h2_kernel.hpp): target_h2_kernel
   // optional (target_split_kernel only): the first-layer state product computed in the tile —
   // U[b] = W1s' s'[b] + b1' as a bf16x3 product of the tile's distinct states — instead of read
   // from `U`: no first-layer GEMM launch in front of the target pass, no [rows][H1] round trip

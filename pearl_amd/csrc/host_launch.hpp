@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include "dqn_kernels.hpp"
 #include "target_split_kernel.hpp"
+#include "target_h2_kernel.hpp"
 
 namespace pa {
 namespace {
@@ -170,8 +171,34 @@ inline int launch_target_split(const TargetArgs& a, hipStream_t s) {
   }
 }
 
+// target_h2_kernel: the 64-row tile on the fp16 matrix pipe; grids as launch_target_split_t
+inline int launch_target_h2(const TargetArgs& a, hipStream_t s) {
+  static bool configured = false;
+  const size_t smem = target_h2_smem_bytes();
+  if (!configured) {
+    int rc = set_max_smem(target_h2_kernel, smem);
+    if (rc != PA_OK) return rc;
+    configured = true;
+  }
+  unsigned grid = (unsigned)ceil_div(a.B, a.bpw);
+  static const unsigned offer = []() {
+    const char* v = getenv("PEARL_AMD_PERSIST_OFFER");
+    const int n = v ? atoi(v) : 2048;
+    return (unsigned)(n >= 256 ? n : 2048);
+  }();
+  if (a.tile_ctr) grid = a.reserved ? offer : (unsigned)(a.ntiles < 256 ? a.ntiles : 256);
+  hipLaunchKernelGGL(target_h2_kernel, dim3(grid), dim3(512), smem, s, a);
+  PA_LAUNCH_CHECK();
+  return PA_OK;
+}
+
 // classic grid (or, with a.tile_ctr, persistent tiles) of target_fused_kernel for the shape at hand
 inline int launch_target(const TargetArgs& a, hipStream_t s) {
+  // (a forced tile shape — PEARL_AMD_TARGET_ROWS, rows_hint — means the bf16x3 kernels: their 32- and
+  //  64-row forms are the pair the tile-shape tests compare)
+  if (a.W2h && !a.W1sp && t_nkg(a.H1) == 32 && target_fast_shape(a, 32) && target_rows_mode() == 0 &&
+      a.rows_hint == 0)
+    return launch_target_h2(a, s);
   if (a.W2sp && t_nkg(a.H1) == 32 && target_fast_shape(a, 32)) return launch_target_split(a, s);
   switch (t_nkg(a.H1)) {
     case 8: return launch_target_t<8, false>(a, s);

@@ -35,33 +35,14 @@
 // Shape: K1 <= 144 (nine k-groups), H1 = H2 = 256 — the instantiation <9, 16, 16> of the fp32 kernel.
 #pragma once
 #include "online_kernels.hpp"
+#include "h2_common.hpp"
 
 namespace pa {
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ f32x4v mfma16h(const f16x8& a, const f16x8& b, f32x4v c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-// exponent field of a magnitude (sign bit cleared) -> the field the scaling works with
-__host__ __device__ inline int h2_field(unsigned abs_bits) {
-  const int e = (int)(abs_bits >> 23) & 0xff;
-  return e == 255 ? 141 : (e < 15 ? 15 : e);
-}
-// 2^(141 - field): the maximum lands in [2^14, 2^15)
-__device__ __forceinline__ float h2_scale(int field) {
-  return __uint_as_float((unsigned)(268 - field) << 23);
-}
-// (templates: inline asm with "v" constraints must not be parsed by the host pass)
-template <int D = 0>
-__device__ __forceinline__ void h2_pair(float x0, float x1, float s0, float s1, unsigned& hi, unsigned& lo) {
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "v"(s0));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "v"(s1));
-  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "v"(s0), "v"(hi));
-  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "v"(s1), "v"(hi));
-}
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 // eight fp32 values (two float4 of one lane's k-step) times exact powers of two -> hi, lo
 template <int D = 0>
 __device__ __forceinline__ void h2_split8(const float4& a, const float4& b, float s, f16x8& hi, f16x8& lo) {

@@ -24,6 +24,7 @@
 // MFMA of the group, so ONE float4 per operand feeds four MFMAs.
 #pragma once
 #include "dqn_kernels.hpp"
+#include "target_h2_kernel.hpp"
 
 namespace pa {
 
@@ -100,6 +101,7 @@ struct PackedW {
   void* tW2sp;   // target W2 as bf16 split planes (target_split_kernel); null: not kept
   void* tW1sp;   // target W1[:, :S] as bf16 split planes (the tile's own first-layer product); null: not kept
   int sp_S;      // S of tW1sp (multiple of 16)
+  void* tW2h; int* tW2hf;   // target W2 as scaled fp16 planes + unit scale fields (target_h2_kernel.hpp); null: not kept
 };
 
 struct RepackArgs {
@@ -188,6 +190,11 @@ __device__ __forceinline__ void repack_body(const RepackArgs& a, int64_t t0, int
       // (only whole matrices take the split kernel: H1 = H2 = 256, see target_fast_shape)
       if (a.pk.tW2sp && n < a.H2 && k + 3 < a.H1 && a.H1 == TS_H && a.H2 == TS_H)
         store_w2sp4(a.pk.tW2sp, n, k, v);
+    }
+    if (a.pk.tW2h && a.H1 == TS_H && a.H2 == TS_H) {
+      W2hPack pk;
+      pk.W2 = a.q_target + a.off_w2; pk.planes = a.pk.tW2h; pk.fields = a.pk.tW2hf;
+      target_w2h_pack<false>(pk, t0 >> 6, gsz >> 6, (int)(t0 & 63));
     }
     if (a.pk.tW1sp && a.H1 == TS_H) {
       // the state columns of the target W1 (row pitch IN) as split planes, four k per thread

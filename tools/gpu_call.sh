@@ -41,7 +41,9 @@ if [ "$MODE" == "pmc" ]; then
   done
   F=$(ls $R/gpurun_out/pmc_FETCH_SIZE/*counter_collection.csv $R/gpurun_out/pmc_FETCH_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
   W=$(ls $R/gpurun_out/pmc_WRITE_SIZE/*counter_collection.csv $R/gpurun_out/pmc_WRITE_SIZE/*/*counter_collection.csv 2>/dev/null | head -1)
-  python $R/tools/pmc_traffic.py $F $W --kernel target_split_kernel --transitions 10240 --algorithmic 1033 --note "U row 1024 + reward 4 + term 1 + y 4 per transition; the shared [A, AD] action table and W2' planes (393 KB) stay in L2" > $R/gpurun_out/pmc_target.json; cat $R/gpurun_out/pmc_target.json
+  TK=target_h2_kernel; PL="262 KB"
+  if [ "$PEARL_AMD_TARGET_H2" == "0" ]; then TK=target_split_kernel; PL="393 KB"; fi
+  python $R/tools/pmc_traffic.py $F $W --kernel $TK --transitions 10240 --algorithmic 1033 --note "U row 1024 + reward 4 + term 1 + y 4 per transition; the shared [A, AD] action table and W2' planes ($PL) stay in L2" > $R/gpurun_out/pmc_target.json; cat $R/gpurun_out/pmc_target.json
   python $R/tools/pmc_traffic.py $F $W --kernel gather_kernel --transitions 10240 --algorithmic 2130 --note "window gather: next_state + reward + term read and written, state + action read, x written" > $R/gpurun_out/pmc_gather.json; cat $R/gpurun_out/pmc_gather.json
   python $R/tools/pmc_summary.py --chain-json $R/gpurun_out/pmc_chain.json $(ls $R/gpurun_out/pmc_*/*counter_collection.csv $R/gpurun_out/pmc_*/*/*counter_collection.csv 2>/dev/null) > $R/gpurun_out/pmc_summary.txt 2>&1; head -40 $R/gpurun_out/pmc_summary.txt | cut -c1-260; cat $R/gpurun_out/pmc_chain.json
   rm -f $R/gpurun_out/pmc_*/*kernel_trace.csv

@@ -35,7 +35,8 @@ def main(paths):
         out = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs), per-launch averages, "
                           "separate rocprofv3 --pmc passes of the single-stream loop", "kernels": {}}
         for name, cs in acc.items():
-            key = next((k for k in ("online_rowpass_kernel", "weight_grad", "target_split_kernel")
+            key = next((k for k in ("online_rowpass_h2_kernel", "online_rowpass_kernel", "weight_grad",
+                                    "target_h2_kernel", "target_split_kernel")
                         if k in name), None)
             if key is None or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs or "GRBM_GUI_ACTIVE" not in cs:
                 continue
