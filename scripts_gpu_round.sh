@@ -74,7 +74,7 @@ rm -rf $R/gpurun_out/prof
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o dqn -- python $R/bench.py --steps 500 --warmup 50 --no-cpu-baseline --no-other-configs > $R/gpurun_out/rocprof.log 2>&1
 echo "rocprof rc=$?"; tail -1 $R/gpurun_out/rocprof.log | cut -c1-200
 python $R/tools/rocpd_summary.py $R/gpurun_out/prof/dqn_results.db > $R/gpurun_out/kernel_stats.txt 2>&1
-python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_split 60 >> $R/gpurun_out/kernel_stats.txt 2>&1
+python $R/tools/rocpd_timeline.py $R/gpurun_out/prof/dqn_results.db target_h2 60 >> $R/gpurun_out/kernel_stats.txt 2>&1
 head -12 $R/gpurun_out/kernel_stats.txt | cut -c1-150
 rm -f $R/gpurun_out/prof/*.db
 rm -rf $R/gpurun_out/prof_sc
