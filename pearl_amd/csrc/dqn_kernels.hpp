@@ -1037,6 +1037,14 @@ struct DwProblem {
   int net;                    // kind 3: which network's optimizer state (0: ad, 1: net2)
   int raw;                    // a plain X^T dZ product riding an optimizer launch: dW / db stored, no AdamW
                               // (the bandit's LinUCB moment update next to its network's gradients)
+  // kind 3, fp16x2 row kernels of the generic engine (sac_rows.hpp, H2 instantiations): max |w| per ROW
+  // of this layer after the step, as AdamFuse::umax_acc / umax_clear keep it for the DQN networks —
+  // atomic max into um_acc (zero on entry: the buffer the NEXT row launch reads), um_clear (the buffer
+  // the last one read) zeroed for the launch after; *_t: the same for the soft-updated target.  M
+  // entries each; null: not kept.  Host contract: every element of such a problem is on the float4
+  // epilogue path (N % 4 == 0, aligned rows).
+  unsigned* um_acc; unsigned* um_clear;
+  unsigned* um_acc_t; unsigned* um_clear_t;
 };
 // A second network in the same launch (twin critics: one launch instead of two half-empty ones).
 // Same AdamW hyper-parameters and step as `ad` (one optimizer), its own flat buffers.
@@ -1759,6 +1767,7 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
       __syncthreads();
     }
     unsigned um_m = 0u;   // max |new weight| of this thread's elements (row scales of the fp16 row pass)
+    unsigned um_t = 0u;   // ... of the soft-updated target's (kind 3)
     if (evec) {
       *reinterpret_cast<float4*>(P.dW + (int64_t)erow * P.ldw + ecol) =
           make_float4(g4[0], g4[1], g4[2], g4[3]);
@@ -1813,7 +1822,14 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
             if (ecol < a.ad.sp_S) store_wsp4(a.ad.tW1sp, erow, ecol, tn, a.ad.sp_S >> 4);
           } else if (P.kind == 3 && P.pkf_t)
             *reinterpret_cast<float4*>(P.pkf_t + wf16_index_(erow, ecol, P.nkgf)) = tn;
+          um_t = umax4(tn);
+        } else if (P.um_acc_t && tgt) {
+          um_t = umax4(*reinterpret_cast<const float4*>(tgt + eflat));   // no soft update: as it is
         }
+      } else if (P.um_acc) {
+        // (a tripped guard: the parameters stay as they are, and so do their maxima)
+        um_m = umax4(*reinterpret_cast<const float4*>(st.p + eflat));
+        if (P.um_acc_t && tgt) um_t = umax4(*reinterpret_cast<const float4*>(tgt + eflat));
       }
     } else if (eact && erow < P.M) {
 #pragma unroll
@@ -1837,6 +1853,22 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
       um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 2));
       um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 4));
       if (eact && ecg == 0 && erow < P.M) umax_atomic(a.ad.umax_acc + (P.kind == 0 ? HF_UNITS : 0) + erow, um_m);
+    }
+    if (P.um_acc && !P.raw) {   // (workgroup-uniform)
+      um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 1));
+      um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 2));
+      um_m = umaxu(um_m, (unsigned)__shfl_xor((int)um_m, 4));
+      um_t = umaxu(um_t, (unsigned)__shfl_xor((int)um_t, 1));
+      um_t = umaxu(um_t, (unsigned)__shfl_xor((int)um_t, 2));
+      um_t = umaxu(um_t, (unsigned)__shfl_xor((int)um_t, 4));
+      if (eact && ecg == 0 && erow < P.M) {
+        umax_atomic(P.um_acc + erow, um_m);
+        if (P.um_acc_t) umax_atomic(P.um_acc_t + erow, um_t);
+        if (j0 == 0) {
+          if (P.um_clear) P.um_clear[erow] = 0u;
+          if (P.um_clear_t) P.um_clear_t[erow] = 0u;
+        }
+      }
     }
   }
   if (j0 == 0 && tid < TM && (i0 + tid) < P.M) {

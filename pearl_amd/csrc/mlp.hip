@@ -187,6 +187,8 @@ extern "C" int pa_mlp_destroy(pa_mlp* h) {
   if (h->qa_u) (void)hipFree(h->qa_u);
   if (h->qa_w2sp) (void)hipFree(h->qa_w2sp);
   if (h->aux && h->aux_free) h->aux_free(h->aux);
+  for (int w = 0; w < 2; ++w)
+    if (h->um[w]) (void)hipFree(h->um[w]);
   for (int l = 0; l < PA_MLP_MAX_LAYERS; ++l) {
     if (h->wf[l]) (void)hipFree(h->wf[l]);
     if (h->wtf[l]) (void)hipFree(h->wtf[l]);
@@ -352,6 +354,43 @@ int ensure_packed(pa_mlp* h, bool target, hipStream_t s) {
   hipLaunchKernelGGL(mlp_rowpack_kernel, dim3(128), dim3(256), 0, s, a);
   PA_LAUNCH_CHECK();
   ok = true;
+  h->um_ok[target ? 1 : 0] = false;   // whatever made the copies stale changed the parameters
+  return PA_OK;
+}
+
+// max |w| per row of layer 1's weights -> out[0 .. M), zero[0 .. M) cleared: one wave per row
+__global__ __launch_bounds__(256) void mlp_unit_max_kernel(const float* __restrict__ W, int M, int K,
+                                                           unsigned* __restrict__ out,
+                                                           unsigned* __restrict__ zero) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+  for (int64_t unit = w0; unit < M; unit += nw) {
+    unsigned m = 0u;
+    for (int k = lane; k < K; k += 64) m = umaxu(m, abs_bits(W[unit * K + k]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = umaxu(m, (unsigned)__shfl_xor((int)m, o));
+    if (lane == 0) {
+      out[unit] = m;
+      zero[unit] = 0u;
+    }
+  }
+}
+int ensure_um(pa_mlp* h, bool target, hipStream_t s) {
+  const int w = target ? 1 : 0;
+  PA_REQUIRE(h->L >= 2 && h->row_ok, PA_ERR_INVALID, "no hidden layer to keep row maxima of");
+  const int M = h->d.dims[2], K = h->d.dims[1];
+  if (!h->um[w]) {
+    PA_HIP(hipMalloc((void**)&h->um[w], sizeof(unsigned) * 2 * (size_t)M));
+    h->um_ok[w] = false;
+  }
+  if (h->um_ok[w]) return PA_OK;
+  const float* P = target ? h->bufs.p_target : h->bufs.p;
+  PA_REQUIRE(P, PA_ERR_INVALID, "no parameters bound");
+  h->um_cur[w] = 0;
+  hipLaunchKernelGGL(mlp_unit_max_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, s,
+                     P + h->woff[1], M, K, h->um[w], h->um[w] + M);
+  PA_LAUNCH_CHECK();
+  h->um_ok[w] = true;
   return PA_OK;
 }
 
@@ -723,6 +762,29 @@ int run_weight_grads_n(pa_mlp* const* hs, const DwOperands* ops, int nnet, int B
             pr.pks = h->wsp[l]; pr.nks = wsp16_nks(h->d.dims[l]);
             pr.pkts = h->wtsp[l]; pr.nkts = wsp16_nks(h->d.dims[l + 1]);
             if (soft_tau >= 0.f && h->packed_t_ok) pr.pkf_t = h->wf_t[l];
+          }
+          // row maxima for the fp16x2 row kernels, while something keeps them (mlp_ensure_um)
+          if (l == 1 && h->um[0] && h->um_ok[0]) {
+            const int M = h->d.dims[2];
+            const bool vec_ok = (h->d.dims[1] & 3) == 0 && (h->woff[1] & 3) == 0;
+            if (vec_ok) {
+              pr.um_clear = h->um[0] + (size_t)h->um_cur[0] * M;
+              h->um_cur[0] ^= 1;
+              pr.um_acc = h->um[0] + (size_t)h->um_cur[0] * M;
+            } else {
+              h->um_ok[0] = false;
+            }
+            if (soft_tau >= 0.f && h->um[1] && h->um_ok[1]) {
+              if (vec_ok && pr.um_acc && h->packed_t_ok && h->bufs.p_target) {
+                pr.um_clear_t = h->um[1] + (size_t)h->um_cur[1] * M;
+                h->um_cur[1] ^= 1;
+                pr.um_acc_t = h->um[1] + (size_t)h->um_cur[1] * M;
+              } else {
+                h->um_ok[1] = false;
+              }
+            }
+          } else if (l == 1 && soft_tau >= 0.f) {
+            h->um_ok[1] = false;
           }
         }
         t0 += (int)ceil_div(h->d.dims[l + 1], TM) * pr.tiles_n;
@@ -1648,6 +1710,7 @@ extern "C" int pa_mlp_soft_update(pa_mlp* h, float tau, void* stream) {
     hipLaunchKernelGGL(mlp_soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     PA_LAUNCH_CHECK();
+    h->um_ok[1] = false;
     return PA_OK;     // the target's packed copies were refreshed in place
   }
   hipLaunchKernelGGL(soft_update_kernel, dim3((unsigned)ceil_div(h->P, 256)), dim3(256), 0,
@@ -3996,6 +4059,7 @@ extern "C" int pa_mlp_adamw2(pa_mlp* a, pa_mlp* b, int64_t step_a, int64_t step_
 // ---- internal entry points for the fused learner steps (sac_step.hip) ---------------------------
 namespace pa {
 int mlp_ensure_packed(pa_mlp* h, bool target, hipStream_t s) { return ensure_packed(h, target, s); }
+int mlp_ensure_um(pa_mlp* h, bool target, hipStream_t s) { return ensure_um(h, target, s); }
 void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
                      const int* ldzs) {
   set_pending(h, x, ldx, B, dzs, ldzs);

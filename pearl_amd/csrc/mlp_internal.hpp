@@ -60,6 +60,15 @@ struct pa_mlp {
   // ... and W_l^T ([d_l units][d_{l+1}]) the same way, l >= 1: the row step's backward GEMMs
   void* wtsp[PA_MLP_MAX_LAYERS];
   bool packed_ok, packed_t_ok;
+  // fp16x2 row kernels (sac_rows.hpp, H2 instantiations): max |w| per row of layer 1's weights (the
+  // hidden 256 x 256 layer of a three-layer network), bit patterns — [online | target] x two buffers
+  // of dims[2] entries (um_cur: the one that describes the parameters as they are; the other is zero,
+  // ready for the atomic maxima of the next fused optimizer launch).  Allocated and computed on
+  // first use (mlp_ensure_um); kept current by the weight-gradient launch's AdamW / soft-update
+  // epilogue while um_ok; every other way the parameters change clears um_ok with packed_ok.
+  unsigned* um[2];
+  int um_cur[2];
+  bool um_ok[2];
   // weight gradients deferred to pa_mlp_adam (want_dw = 2): the operands of the kept backward
   struct Pending {
     bool active;
@@ -79,6 +88,12 @@ struct pa_mlp {
 namespace pa {
 // fragment-major copies of the online (or target) parameters are current after this
 int mlp_ensure_packed(pa_mlp* h, bool target, hipStream_t s);
+// row maxima of layer 1's weights (online or target) are current after this; the buffer to read
+int mlp_ensure_um(pa_mlp* h, bool target, hipStream_t s);
+inline const unsigned* mlp_um(const pa_mlp* h, bool target) {
+  const int w = target ? 1 : 0;
+  return (h->um[w] && h->um_ok[w]) ? h->um[w] + (size_t)h->um_cur[w] * h->d.dims[2] : nullptr;
+}
 // the operands of a backward pass whose weight gradients pa_mlp_adam will form (want_dw = 2)
 void mlp_set_pending(pa_mlp* h, const float* x, int ldx, int B, const float* const* dzs,
                      const int* ldzs);

@@ -29,6 +29,7 @@
 // loops are unrolled through a register ring filled one phase early; NGH = 0: any width <= 256.
 #pragma once
 #include "mlp_rowpass.hpp"
+#include "online_f16_kernel.hpp"
 
 namespace pa {
 
@@ -43,6 +44,8 @@ struct SacMlp3 {
   float* act1; float* act2;              // kept ReLU outputs [B][H1], [B][H2]
   float* dz1; float* dz2;                // pre-activation gradients [B][H1], [B][H2]
   int K0, H1, H2, DO;
+  const unsigned* um;                    // H2 instantiations: max |w| per row of W2 (bit patterns, [H2]),
+                                         // kept by mlp.hip (mlp_ensure_um, the optimizer epilogue)
 };
 
 struct SacTicket {
@@ -73,6 +76,11 @@ struct SacRowsAArgs {
   float* xact; float* xres;
   int* err; int* err_host;
   long long* prof;
+  // split launches inside a native learn loop: the actor's forward on this batch was run by the
+  // previous step's sac_rows_b launch (its idle workgroups; SacRowsBArgs::pre_state) — the head
+  // [B][2A] is here, the hidden activations in the actor's kept buffers.  null: run it here.
+  const float* pre_head;
+  const unsigned* pre_mask;              // [tiles][512][2]: the forward's ReLU masks, lane by lane
 };
 constexpr int SR_XACT = RP_ROWS * 16;
 constexpr int SR_XRES = RP_ROWS * 17;
@@ -117,6 +125,12 @@ struct SacRowsBArgs {
   float* xact; float* xres;
   int* err; int* err_host;
   long long* prof;
+  // SPLIT instantiation, optional third role (grid 3 x tiles): the actor's forward on the NEXT
+  // step's states — it depends on nothing this launch or the critics' optimizer launch behind it
+  // change — with the activations kept and the head written to pre_head (SacRowsAArgs::pre_head)
+  const float* pre_state; int ld_pre;
+  float* pre_head;
+  unsigned* pre_mask;
 };
 
 // phase stamps (tools/prof_sac.py): 32 slots per wave, 100 MHz wall clock; null outside the tool
@@ -134,6 +148,92 @@ constexpr int SR_CST = 776;      // per network: b1[256] | b2[256] | w3 or b3[25
 __host__ __device__ inline size_t sac_rows_smem_floats(int k0) {
   return (size_t)RP_ROWS * (rp_pad(k0) + 3 * row_hid_pitch()) + 8 * RP_ROWS * SR_HEADP +
          RP_ROWS * SR_DHP + 8 * RP_ROWS + 8 * RP_ROWS + 3 * SR_CST;
+}
+
+// ---- H2 instantiations: the 256 x 256 GEMMs on the fp16 matrix pipe at fp32 accuracy ----------------
+// online_f16_kernel.hpp's scheme (operands scaled by exact powers of two, split into two fp16 terms,
+// three partial products, fp32 accumulators per magnitude class) for every hidden GEMM of the two
+// row kernels: the actor's and the critics' layer 2, the critics' G = s2 W2, the actor's
+// d z1 = d z2 W2.  First layers, heads and the narrow products stay on the fp32 pipe.  Hidden widths
+// are exactly 256.  Extra LDS behind the fp32 layout:
+//   usc [3][256]   2^(141 - e_n) per row n of W2, one array per network slot (the cst slots)
+//   pA  hi | lo    [16][HF_PITCH] halves: h1, or the actor's scaled d z2 (consumer layout)
+//   pB  hi | lo    the critics' scaled s2
+//   rmaxw [8][16]  per-wave row maxima
+constexpr int SR_USC = 256;
+__host__ __device__ inline size_t sac_rows_h2_smem_bytes(int k0) {
+  return sac_rows_smem_floats(k0) * sizeof(float) + sizeof(float) * 3 * SR_USC +
+         sizeof(_Float16) * 4 * RP_ROWS * HF_PITCH + sizeof(unsigned) * 8 * RP_ROWS;
+}
+struct SrH2 {
+  float* usc;                 // slot 0
+  _Float16 *pAh, *pAl, *pBh, *pBl;
+  unsigned* rmaxw;
+};
+__device__ __forceinline__ SrH2 sr_h2_carve(float* smem, int k0) {
+  SrH2 X;
+  X.usc = smem + sac_rows_smem_floats(k0);
+  X.pAh = reinterpret_cast<_Float16*>(X.usc + 3 * SR_USC);
+  X.pAl = X.pAh + RP_ROWS * HF_PITCH;
+  X.pBh = X.pAl + RP_ROWS * HF_PITCH;
+  X.pBl = X.pBh + RP_ROWS * HF_PITCH;
+  X.rmaxw = reinterpret_cast<unsigned*>(X.pBl + RP_ROWS * HF_PITCH);
+  return X;
+}
+// row maxima -> unit scales in LDS: request (with the other start-up loads), store later
+__device__ __forceinline__ unsigned sr_usc_load(const unsigned* um, int tid) {
+  return __builtin_bit_cast(unsigned, ld_or_zero(reinterpret_cast<const float*>(um), tid, tid < SR_USC));
+}
+__device__ __forceinline__ void sr_usc_store(float* usc, unsigned v, int tid) {
+  if (tid < SR_USC) usc[tid] = h2_scale(h2_field(v));
+}
+__device__ __forceinline__ int sr_field_of(float scale) { return 268 - (int)(__float_as_uint(scale) >> 23); }
+__device__ __forceinline__ float sr_inv(float scale) { return __uint_as_float((254u << 23) - __float_as_uint(scale)); }
+// this lane's view of a network's unit scales (online_f16_kernel.hpp's HalfFields, read from LDS)
+__device__ __forceinline__ HalfFields sr_fields(const float* usc, int wave, int r16, int qd) {
+  HalfFields f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    f.sA[t] = usc[32 * wave + 16 * t + r16];
+    const float4 v = *reinterpret_cast<const float4*>(usc + 32 * wave + 16 * t + 4 * qd);
+    f.fC[t][0] = sr_field_of(v.x); f.fC[t][1] = sr_field_of(v.y);
+    f.fC[t][2] = sr_field_of(v.z); f.fC[t][3] = sr_field_of(v.w);
+  }
+  return f;
+}
+// (the two halves on their own: sA is live across the GEMM, fC only behind it)
+__device__ __forceinline__ void sr_fields_A(float (&sA)[2], const float* usc, int wave, int r16) {
+  sA[0] = usc[32 * wave + r16];
+  sA[1] = usc[32 * wave + 16 + r16];
+}
+__device__ __forceinline__ void sr_fields_C(int (&fC)[2][4], const float* usc, int wave, int qd) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float4 v = *reinterpret_cast<const float4*>(usc + 32 * wave + 16 * t + 4 * qd);
+    fC[t][0] = sr_field_of(v.x); fC[t][1] = sr_field_of(v.y);
+    fC[t][2] = sr_field_of(v.z); fC[t][3] = sr_field_of(v.w);
+  }
+}
+// the row's maximum across the eight waves: per-wave maxima to LDS (the caller's barrier follows)
+__device__ __forceinline__ void sr_rowmax_put(unsigned m, unsigned* rmaxw, int wave, int r16, int qd) {
+  m = umaxu(m, (unsigned)__shfl_xor((int)m, 16));
+  m = umaxu(m, (unsigned)__shfl_xor((int)m, 32));
+  if (qd == 0) rmaxw[wave * RP_ROWS + r16] = m;
+}
+__device__ __forceinline__ int sr_rowmax_field(const unsigned* rmaxw, int r16) {
+  unsigned m = rmaxw[r16];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = umaxu(m, rmaxw[w * RP_ROWS + r16]);
+  return h2_field(m);
+}
+// this lane's eight values (units u0 + 16 t + j of its row: k-step `wave` of the consumer) -> planes
+__device__ __forceinline__ void sr_planes_put(const float4 (&v)[2], float scale, _Float16* ph, _Float16* pl,
+                                              int r16, int qd, int wave) {
+  f16x8 hi, lo;
+  h2_split8(v[0], v[1], scale, hi, lo);
+  const int off = r16 * HF_PITCH + 8 * qd + 32 * wave;
+  *reinterpret_cast<f16x8*>(ph + off) = hi;
+  *reinterpret_cast<f16x8*>(pl + off) = lo;
 }
 
 struct SrLane {
@@ -440,6 +540,114 @@ __device__ __forceinline__ void sr_critic(const SacMlp3& n, const float* cst, co
   }
   if (!EARLY1 && nx.W1) sr_l1_fill<NG1>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
 }
+// sr_critic with layer 2 and G on the fp16 matrix pipe (H1 = H2 = 256).  `usc`: this network's unit
+// scales (staged before the opening barrier).  h1 lives in the A planes, the scaled s2 in the B
+// planes; Gm still goes to hC as fp32 (the narrow product behind it is an fp32 one).
+template <int NG1, bool WANT_G, bool KEEP, bool EARLY1 = true>
+__device__ __forceinline__ void sr_critic_h2(const SacMlp3& n, const float* cst, const float* usc,
+                                             const float* xs, int P0, const SrH2& X, float* hC,
+                                             float* qred, WRing& R, WRing& R1, const SrLane& L,
+                                             int64_t row, bool rok, const SrNext& nx, long long* prof,
+                                             int wg, int slot) {
+  const int PH = row_hid_pitch();
+  const int plane_off = L.r16 * HF_PITCH + 8 * L.qd;
+  f32x4v acc[2];
+  __syncthreads();
+  sr_bias(acc, cst, L.u0);
+  sr_l1_gemm<NG1>(acc, R1, n.W1f, wf16_nkg(n.K0), L.tile0, 16, xs + L.r16 * P0 + 4 * L.qd, L.lane);
+  if (EARLY1 && nx.W1) sr_l1_fill<NG1>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
+  // ---- h1: kept in registers until its row maximum is known
+  float4 h1k[2];
+  unsigned m1 = 0, hm = 0u;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int u = L.u0 + 16 * t;
+    h1k[t] = make_float4(relu_keep_nan(acc[t][0]), relu_keep_nan(acc[t][1]), relu_keep_nan(acc[t][2]),
+                         relu_keep_nan(acc[t][3]));
+    m1 |= (h1k[t].x > 0.f ? 1u : 0u) << (4 * t) | (h1k[t].y > 0.f ? 2u : 0u) << (4 * t) |
+          (h1k[t].z > 0.f ? 4u : 0u) << (4 * t) | (h1k[t].w > 0.f ? 8u : 0u) << (4 * t);
+    hm = umaxu(hm, umax4(h1k[t]));
+    if (KEEP && rok && n.act1) store4_guarded(n.act1, row * n.H1, u, n.H1, true, h1k[t]);
+  }
+  sr_rowmax_put(hm, X.rmaxw, L.wave, L.r16, L.qd);
+  float sA2[2];
+  sr_fields_A(sA2, usc, L.wave, L.r16);
+  // the backward product's B operand is s2[n] 2^-e_n = [h2 > 0] w3[n] 2^(e_n - 141); its own scale
+  // comes from max |w3[n] 2^(e_n - 141)|: every wave forms all 256 (64 lanes x 4)
+  int f3 = 0;
+  if (WANT_G) {
+    const float4 w3a = *reinterpret_cast<const float4*>(cst + 512 + 4 * L.lane);
+    const float4 ua = *reinterpret_cast<const float4*>(usc + 4 * L.lane);
+    unsigned m = umax4(make_float4(w3a.x * sr_inv(ua.x), w3a.y * sr_inv(ua.y), w3a.z * sr_inv(ua.z),
+                                   w3a.w * sr_inv(ua.w)));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = umaxu(m, (unsigned)__shfl_xor((int)m, o));
+    f3 = h2_field(m);
+  }
+  SR_STAMP(prof, wg, slot);
+  __syncthreads();                                                        // row maxima
+  const int fh = sr_rowmax_field(X.rmaxw, L.r16);
+  sr_planes_put(h1k, h2_scale(fh), X.pAh, X.pAl, L.r16, L.qd, L.wave);
+  __syncthreads();                                                        // h1 planes
+  // ---- layer 2, the head's dot product, s2
+  int fC2[2][4];
+  {
+    f32x4v c[2][HF_NACC];
+    h2_zero(c);
+    rows16_gemm_h2<16, 16, false>(c, R, n.W2f, L.tile0, L.lane, sA2, nullptr, X.pAh + plane_off,
+                                  X.pAl + plane_off, R, WANT_G ? n.W2tf : nx.Wh,
+                                  WANT_G ? true : nx.Wh != nullptr);
+    sr_fields_C(fC2, usc, L.wave, L.qd);
+    float4 b2v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b2v[t] = *reinterpret_cast<const float4*>(cst + 256 + L.u0 + 16 * t);
+    h2_finish(acc, c, fh, fC2, b2v);
+  }
+  float4 w3v[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) w3v[t] = *reinterpret_cast<const float4*>(cst + 512 + L.u0 + 16 * t);
+  float qp = 0.f;
+  float4 z[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int u = L.u0 + 16 * t;
+    const float4 h = make_float4(relu_keep_nan(acc[t][0]), relu_keep_nan(acc[t][1]),
+                                 relu_keep_nan(acc[t][2]), relu_keep_nan(acc[t][3]));
+    qp += h.x * w3v[t].x;
+    qp += h.y * w3v[t].y;
+    qp += h.z * w3v[t].z;
+    qp += h.w * w3v[t].w;
+    if (KEEP && rok && n.act2) store4_guarded(n.act2, row * n.H2, u, n.H2, true, h);
+    if (WANT_G) {
+      const float4 s2 = make_float4(h.x > 0.f ? w3v[t].x : 0.f, h.y > 0.f ? w3v[t].y : 0.f,
+                                    h.z > 0.f ? w3v[t].z : 0.f, h.w > 0.f ? w3v[t].w : 0.f);
+      if (KEEP && rok) store4_guarded(n.dz2, row * n.H2, u, n.H2, true, s2);
+      auto inv = [](int field) { return __uint_as_float((unsigned)(field - 14) << 23); };
+      z[t] = make_float4(s2.x * inv(fC2[t][0]), s2.y * inv(fC2[t][1]), s2.z * inv(fC2[t][2]),
+                         s2.w * inv(fC2[t][3]));
+    }
+  }
+  if (WANT_G) sr_planes_put(z, h2_scale(f3), X.pBh, X.pBl, L.r16, L.qd, L.wave);
+  qp += __shfl_xor(qp, 16);
+  qp += __shfl_xor(qp, 32);
+  if (L.qd == 0) qred[L.wave * RP_ROWS + L.r16] = qp;
+  SR_STAMP(prof, wg, slot + 1);
+  if (WANT_G) {
+    // ---- Gm = (s2 W2) [h1 > 0]: the weights' scale depends on the reduction index
+    __syncthreads();
+    f32x4v c[2][HF_NACC];
+    h2_zero(c);
+    const float unused[2] = {0.f, 0.f};
+    rows16_gemm_h2<16, 16, true>(c, R, n.W2tf, L.tile0, L.lane, unused, usc + 4 * L.qd,
+                                 X.pBh + plane_off, X.pBl + plane_off, R, nx.Wh, nx.Wh != nullptr);
+    const float4 zero2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const int fG[2][4] = {{141, 141, 141, 141}, {141, 141, 141, 141}};
+    h2_finish(acc, c, f3, fG, zero2);
+    sr_mask_out(acc, m1, hC, PH, L, KEEP ? n.dz1 : nullptr, row, n.H1, rok);
+    SR_STAMP(prof, wg, slot + 2);
+  }
+  if (!EARLY1 && nx.W1) sr_l1_fill<NG1>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
+}
 // q of row r from the eight waves' partial dot products (after a barrier)
 __device__ __forceinline__ float sr_q(const float* qred, int r, const float* cst) {
   float q = cst[768];
@@ -472,6 +680,66 @@ __device__ __forceinline__ void sr_actor_fwd(const SacMlp3& n, const float* cst,
   __syncthreads();
   sr_gemm<NGH>(acc, R, n.W2f, wf16_nkg(n.H1), L.tile0, nt2, hA + L.r16 * PH + 4 * L.qd, L.lane,
                nx.Wh, nx.nth);
+  if (nx.W1) sr_l1_fill<NG1N>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
+  m2 = sr_relu_out(acc, hB, PH, L, KEEP ? n.act2 : nullptr, row, n.H2, rok);
+  __syncthreads();
+  sr_narrow_mma(hw, wf16_nkg(n.H2), hB + L.r16 * PH + 4 * L.qd, red, L);
+  __syncthreads();
+  if (L.tid < RP_ROWS * 32) {
+    const int r = L.tid >> 5, c = L.tid & 31;
+    headS[r * SR_HEADP + c] = c < n.DO ? sr_narrow_get(red, r, c) + cst[512 + c] : 0.f;
+  }
+  __syncthreads();
+}
+
+// sr_actor_fwd with layer 2 on the fp16 matrix pipe (H1 = H2 = 256); h2 goes to hB as fp32 (the
+// head's narrow product is an fp32 one).
+template <int NG1, int NG1N, bool KEEP>
+__device__ __forceinline__ void sr_actor_fwd_h2(const SacMlp3& n, const float* cst, const float* usc,
+                                                const float* xs, int P0, const SrH2& X, float* hB,
+                                                float* red, float* headS, WRing& R, WRing& R1,
+                                                const SrLane& L, int64_t row, bool rok, unsigned& m1,
+                                                unsigned& m2, const SrNext& nx) {
+  const int PH = row_hid_pitch();
+  const int plane_off = L.r16 * HF_PITCH + 8 * L.qd;
+  f32x4v acc[2];
+  __syncthreads();
+  sr_bias(acc, cst, L.u0);
+  sr_l1_gemm<NG1>(acc, R1, n.W1f, wf16_nkg(n.K0), L.tile0, 16, xs + L.r16 * P0 + 4 * L.qd, L.lane);
+  SrNarrowW hw;
+  sr_narrow_load(hw, n.W3f, wf16_nkg(n.H2), 0, (n.DO + 15) >> 4, L);
+  float4 h1k[2];
+  unsigned hm = 0u;
+  m1 = 0;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int u = L.u0 + 16 * t;
+    h1k[t] = make_float4(relu_keep_nan(acc[t][0]), relu_keep_nan(acc[t][1]), relu_keep_nan(acc[t][2]),
+                         relu_keep_nan(acc[t][3]));
+    m1 |= (h1k[t].x > 0.f ? 1u : 0u) << (4 * t) | (h1k[t].y > 0.f ? 2u : 0u) << (4 * t) |
+          (h1k[t].z > 0.f ? 4u : 0u) << (4 * t) | (h1k[t].w > 0.f ? 8u : 0u) << (4 * t);
+    hm = umaxu(hm, umax4(h1k[t]));
+    if (KEEP && rok && n.act1) store4_guarded(n.act1, row * n.H1, u, n.H1, true, h1k[t]);
+  }
+  sr_rowmax_put(hm, X.rmaxw, L.wave, L.r16, L.qd);
+  float sA2[2];
+  sr_fields_A(sA2, usc, L.wave, L.r16);
+  __syncthreads();                                                        // row maxima
+  const int fh = sr_rowmax_field(X.rmaxw, L.r16);
+  sr_planes_put(h1k, h2_scale(fh), X.pAh, X.pAl, L.r16, L.qd, L.wave);
+  __syncthreads();                                                        // h1 planes
+  {
+    f32x4v c[2][HF_NACC];
+    h2_zero(c);
+    rows16_gemm_h2<16, 16, false>(c, R, n.W2f, L.tile0, L.lane, sA2, nullptr, X.pAh + plane_off,
+                                  X.pAl + plane_off, R, nx.Wh, nx.Wh != nullptr);
+    int fC2[2][4];
+    sr_fields_C(fC2, usc, L.wave, L.qd);
+    float4 b2v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b2v[t] = *reinterpret_cast<const float4*>(cst + 256 + L.u0 + 16 * t);
+    h2_finish(acc, c, fh, fC2, b2v);
+  }
   if (nx.W1) sr_l1_fill<NG1N>(R1, nx.W1, L.tile0, nx.nt1, L.lane);
   m2 = sr_relu_out(acc, hB, PH, L, KEEP ? n.act2 : nullptr, row, n.H2, rok);
   __syncthreads();
@@ -523,12 +791,15 @@ __device__ __forceinline__ void sr_tile_partial(const float* rowsum, float* part
 // HEAD 0: tanh-Gaussian policy, twin-critic actor loss (continuous SAC).
 // HEAD 1: deterministic tanh policy, actor loss -mean Q1(s, pi(s)) (DDPG / TD3, ddpg.py:106-121):
 //         the head is [A] wide, no log-probability, one critic pass, d loss / d q = -1/B.
-template <int NGH, int NGA, int NGC, int HEAD, bool SPLIT = false>
+template <int NGH, int NGA, int NGC, int HEAD, bool SPLIT = false, bool H2 = false>
 __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
+  static_assert(!H2 || (NGH == 16 && HEAD == 0), "H2: hidden 256, continuous SAC");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
   const int W = a.S + a.A;
   const int P0 = rp_pad(W), PH = row_hid_pitch();
+  SrH2 X;
+  if constexpr (H2) X = sr_h2_carve(smem, W);
   float* xs = smem;
   float* hA = xs + RP_ROWS * P0;
   float* hB = hA + RP_ROWS * PH;
@@ -566,12 +837,15 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
       {
         SrTile xt;
         SrConsts kc;
+        unsigned uv = 0u;
         const bool fits = sr_tile_fits(P0);
         if (fits) sr_tile_load(xt, a.state, a.ld_state, a.S, m0, a.B, P0, L.tid);
         sr_consts_load(kc, n, true, L.tid);
+        if constexpr (H2) uv = sr_usc_load(n.um, L.tid);
         if (fits) sr_tile_store(xt, xs, P0, L.tid);
         else sr_stage(a.state, a.ld_state, a.S, m0, a.B, xs, P0, L.tid);
         sr_consts_store(cst, kc, L.tid);
+        if constexpr (H2) sr_usc_store(X.usc, uv, L.tid);
       }
       const int t_lo = a.S >> 4;
       const int ntl = ((W + 15) >> 4) - t_lo;
@@ -583,8 +857,12 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
       SR_STAMP(a.prof, wg, 3);
       SrNext none;
       none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
-      sr_critic<NGH, NGC, true, false>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+      if constexpr (H2)
+        sr_critic_h2<NGC, true, false>(n, cst, X.usc, xs, P0, X, hC, qred, R, R1, L, row, rok, none,
                                        a.prof, wg, 4);
+      else
+        sr_critic<NGH, NGC, true, false>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                         a.prof, wg, 4);
       __syncthreads();
       if (L.tid < RP_ROWS)
         publish_y(a.xres + (int64_t)tile * SR_XRES + L.tid * 17 + 16, sr_q(qred, L.tid, cst));
@@ -604,6 +882,8 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
     SrConsts kc;
     sr_consts_load(kc, n, true, L.tid);
+    unsigned uv = 0u;
+    if constexpr (H2) uv = sr_usc_load(n.um, L.tid);
     // xs = state || action, zero padded
     {
       const int c4 = (P0 - 4) >> 2;
@@ -628,11 +908,16 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
       }
     }
     sr_consts_store(cst, kc, L.tid);
+    if constexpr (H2) sr_usc_store(X.usc, uv, L.tid);
     SR_STAMP(a.prof, wg, 1);
     SrNext none;
     none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
-    sr_critic<NGH, NGC, true, true>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+    if constexpr (H2)
+      sr_critic_h2<NGC, true, true>(n, cst, X.usc, xs, P0, X, hC, qred, R, R1, L, row, rok, none,
                                     a.prof, wg, 4);
+    else
+      sr_critic<NGH, NGC, true, true>(n, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                      a.prof, wg, 4);
     __syncthreads();
     if (L.tid < RP_ROWS && m0 + L.tid < a.B) a.q[c][m0 + L.tid] = sr_q(qred, L.tid, cst);
     SR_STAMP(a.prof, wg, 15);
@@ -641,8 +926,10 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
 
   // ------------------------------------------------------------------ actor update rows
   const SacMlp3& n = a.actor;
-  sr_l1_fill<NGA>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
-  sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
+  if (!(split && a.pre_head)) {
+    sr_l1_fill<NGA>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
+    sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
+  }
   // noise of this thread's (row, component), requested before anything else needs it
   const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
   const bool sok = L.tid < RP_ROWS * a.A;
@@ -660,18 +947,53 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     sr_consts_load(k0, n, false, L.tid);
     sr_consts_load(k1, a.critic[0], true, L.tid);
     if (NCRIT > 1) sr_consts_load(k2, a.critic[1], true, L.tid);
+    unsigned u0v = 0u, u1v = 0u, u2v = 0u;
+    if constexpr (H2) {
+      u0v = sr_usc_load(n.um, L.tid);
+      u1v = sr_usc_load(a.critic[0].um, L.tid);
+      if (NCRIT > 1) u2v = sr_usc_load(a.critic[1].um, L.tid);
+    }
     if (fits) sr_tile_store(xt, xs, P0, L.tid);
     else sr_stage(a.state, a.ld_state, a.S, m0, a.B, xs, P0, L.tid);
     sr_consts_store(cst, k0, L.tid);
     sr_consts_store(cst + SR_CST, k1, L.tid);
     if (NCRIT > 1) sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
+    if constexpr (H2) {
+      sr_usc_store(X.usc, u0v, L.tid);
+      sr_usc_store(X.usc + SR_USC, u1v, L.tid);
+      if (NCRIT > 1) sr_usc_store(X.usc + 2 * SR_USC, u2v, L.tid);
+    }
   }
   SR_STAMP(a.prof, wg, 1);
   unsigned m1a, m2a;
   float* headS = dhS;   // [16][SR_HEADP]; dhS proper is written only after the head was consumed
-  sr_actor_fwd<NGH, NGA, NGC, true>(
-      n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
-      SrNext{a.critic[0].W1f, (a.critic[0].H1 + 15) >> 4, a.critic[0].W2f, (a.critic[0].H2 + 15) >> 4});
+  if (split && a.pre_head) {
+    // the forward ran in the previous step's sac_rows_b launch: head from memory, the ReLU masks
+    // from the kept activations; the rings take the first critic's streams (what the forward
+    // leaves in them).  (Workgroup-uniform.)
+    // (the head and the masks first: vector memory returns in issue order, and they are all the
+    //  sampling waits for)
+    const int hr = L.tid >> 5, hc = L.tid & 31;
+    const float hv = ld_or_zero(a.pre_head, (int64_t)(m0 + hr) * n.DO + hc,
+                                L.tid < RP_ROWS * 32 && hc < n.DO && (m0 + hr) < a.B);
+    const uint2 mk = *reinterpret_cast<const uint2*>(a.pre_mask + ((int64_t)tile * 512 + L.tid) * 2);
+    __builtin_amdgcn_sched_barrier(0);
+    sr_l1_fill<NGC>(R1, a.critic[0].W1f, L.tile0, (a.critic[0].H1 + 15) >> 4, L.lane);
+    sr_prefetch<NGH>(R, a.critic[0].W2f, L.tile0, (a.critic[0].H2 + 15) >> 4, L.lane);
+    __builtin_amdgcn_sched_barrier(0);
+    if (L.tid < RP_ROWS * 32) headS[hr * SR_HEADP + hc] = hv;
+    m1a = mk.x;
+    m2a = mk.y;
+    __syncthreads();
+  } else {
+    const SrNext nxa{a.critic[0].W1f, (a.critic[0].H1 + 15) >> 4, a.critic[0].W2f, (a.critic[0].H2 + 15) >> 4};
+    if constexpr (H2)
+      sr_actor_fwd_h2<NGA, NGC, true>(n, cst, X.usc, xs, P0, X, hB, red, headS, R, R1, L, row, rok, m1a,
+                                      m2a, nxa);
+    else
+      sr_actor_fwd<NGH, NGA, NGC, true>(n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
+                                        nxa);
+  }
   SR_STAMP(a.prof, wg, 2);
   // ---- sample: action -> xs[:, S:], log pi
   SrGauss G;
@@ -714,8 +1036,12 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
     nx.W1 = lastc ? nullptr : a.critic[CN].W1f; nx.nt1 = (a.critic[CN].H1 + 15) >> 4;
     nx.Wh = lastc ? n.W2tf : a.critic[CN].W2f;
     nx.nth = lastc ? (n.H1 + 15) >> 4 : (a.critic[CN].H2 + 15) >> 4;
-    sr_critic<NGH, NGC, true, false>(q, cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R, R1, L,
-                                     row, rok, nx, a.prof, wg, 4 + 4 * c);
+    if constexpr (H2)
+      sr_critic_h2<NGC, true, false>(q, cst + (1 + c) * SR_CST, X.usc + (1 + c) * SR_USC, xs, P0, X, hC,
+                                     qred, R, R1, L, row, rok, nx, a.prof, wg, 4 + 4 * c);
+    else
+      sr_critic<NGH, NGC, true, false>(q, cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R, R1, L,
+                                       row, rok, nx, a.prof, wg, 4 + 4 * c);
     if (lastc) sr_small_load(w3t, n.W3tf, wf16_nkg(n.DO), L.tile0, (n.H2 + 15) >> 4, L.lane);
     __syncthreads();
     if (L.tid < RP_ROWS) small[c * RP_ROWS + L.tid] = sr_q(qred, L.tid, cst + (1 + c) * SR_CST);
@@ -775,12 +1101,49 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
   sr_zero(acc);
   __syncthreads();
   sr_small_gemm(acc, w3t, wf16_nkg(n.DO), dhS + L.r16 * SR_DHP + 4 * L.qd);
-  sr_mask_out(acc, m2a, hA, PH, L, n.dz2, row, n.H2, rok);
-  SR_STAMP(a.prof, wg, 13);
-  sr_zero(acc);
-  __syncthreads();
-  sr_gemm<NGH>(acc, R, n.W2tf, wf16_nkg(n.H2), L.tile0, (n.H1 + 15) >> 4,
-               hA + L.r16 * PH + 4 * L.qd, L.lane, nullptr, 0);
+  if constexpr (H2) {
+    // d z1 = (d z2 W2) [h1 > 0] on the fp16 pipe: the reduction runs over the rows of W2, so their
+    // scales ride on d z2 (d z2[n] 2^(e_n - 141), its own scale from the row's maximum) and the
+    // weight fragments take a scale per element (sr_critic_h2's G)
+    sr_mask_out(acc, m2a, nullptr, PH, L, n.dz2, row, n.H2, rok);
+    int fCa[2][4];
+    sr_fields_C(fCa, X.usc, L.wave, L.qd);
+    float4 z[2];
+    unsigned zm = 0u;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const unsigned mt = m2a >> (4 * t);
+      auto inv = [](int field) { return __uint_as_float((unsigned)(field - 14) << 23); };
+      z[t] = make_float4((rok && (mt & 1u)) ? acc[t][0] * inv(fCa[t][0]) : 0.f,
+                         (rok && (mt & 2u)) ? acc[t][1] * inv(fCa[t][1]) : 0.f,
+                         (rok && (mt & 4u)) ? acc[t][2] * inv(fCa[t][2]) : 0.f,
+                         (rok && (mt & 8u)) ? acc[t][3] * inv(fCa[t][3]) : 0.f);
+      zm = umaxu(zm, umax4(z[t]));
+    }
+    sr_rowmax_put(zm, X.rmaxw, L.wave, L.r16, L.qd);
+    SR_STAMP(a.prof, wg, 13);
+    __syncthreads();
+    const int fz = sr_rowmax_field(X.rmaxw, L.r16);
+    sr_planes_put(z, h2_scale(fz), X.pAh, X.pAl, L.r16, L.qd, L.wave);
+    __syncthreads();
+    f32x4v c[2][HF_NACC];
+    h2_zero(c);
+    const float unused[2] = {0.f, 0.f};
+    const int plane_off = L.r16 * HF_PITCH + 8 * L.qd;
+    WRing none;
+    rows16_gemm_h2<16, 0, true>(c, R, n.W2tf, L.tile0, L.lane, unused, X.usc + 4 * L.qd,
+                                X.pAh + plane_off, X.pAl + plane_off, none, nullptr, false);
+    const float4 zero2[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    const int fG[2][4] = {{141, 141, 141, 141}, {141, 141, 141, 141}};
+    h2_finish(acc, c, fz, fG, zero2);
+  } else {
+    sr_mask_out(acc, m2a, hA, PH, L, n.dz2, row, n.H2, rok);
+    SR_STAMP(a.prof, wg, 13);
+    sr_zero(acc);
+    __syncthreads();
+    sr_gemm<NGH>(acc, R, n.W2tf, wf16_nkg(n.H2), L.tile0, (n.H1 + 15) >> 4,
+                 hA + L.r16 * PH + 4 * L.qd, L.lane, nullptr, 0);
+  }
   sr_mask_out(acc, m1a, nullptr, PH, L, n.dz1, row, n.H1, rok);
   SR_STAMP(a.prof, wg, 14);
   // ---- actor loss: this tile's partial
@@ -790,12 +1153,15 @@ __global__ __launch_bounds__(512) void sac_rows_a_kernel(SacRowsAArgs a) {
 
 // HEAD 1: `actor` is the TARGET policy, the next action is its tanh-scaled output plus the clamped
 // smoothing noise (td3.py:151-175; none for DDPG), and y = min(q1', q2') gamma (1 - term) + r.
-template <int NGH, int NGA, int NGC, int HEAD, bool SPLIT = false>
+template <int NGH, int NGA, int NGC, int HEAD, bool SPLIT = false, bool H2 = false>
 __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
+  static_assert(!H2 || (NGH == 16 && HEAD == 0), "H2: hidden 256, continuous SAC");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const SrLane L = sr_lane();
   const int W = a.S + a.A;
   const int P0 = rp_pad(W), PH = row_hid_pitch();
+  SrH2 X;
+  if constexpr (H2) X = sr_h2_carve(smem, W);
   float* xs = smem;
   float* hA = xs + RP_ROWS * P0;
   float* hB = hA + RP_ROWS * PH;
@@ -805,17 +1171,55 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   float* qred = headS + RP_ROWS * SR_DHP;
   float* small = qred + 8 * RP_ROWS;
   float* cst = small + 8 * RP_ROWS;
-  const int tile = SPLIT ? (int)blockIdx.x >> 1 : (int)blockIdx.x;
+  const int nrole = SPLIT ? (a.pre_state ? 3 : 2) : 1;
+  const int tile = (int)blockIdx.x / nrole, brole = (int)blockIdx.x - tile * nrole;
   const int m0 = tile * RP_ROWS;
   const int64_t row = m0 + L.r16;
   const bool rok = row < a.B;
   WRing R, R1;
-  const int wg = SPLIT ? ((int)blockIdx.x & 1) * (int)(gridDim.x >> 1) + tile : (int)blockIdx.x;
+  const int wg = SPLIT ? brole * (int)(gridDim.x / nrole) + tile : (int)blockIdx.x;
+  if constexpr (SPLIT) {
+    if (brole == 2) {
+      // ------------------------------------------------- the next step's actor forward (pre_state)
+      const SacMlp3& n = a.actor;
+      sr_l1_fill<NGA>(R1, n.W1f, L.tile0, (n.H1 + 15) >> 4, L.lane);
+      sr_prefetch<NGH>(R, n.W2f, L.tile0, (n.H2 + 15) >> 4, L.lane);
+      {
+        SrTile xt;
+        SrConsts kc;
+        unsigned uv = 0u;
+        const bool fits = sr_tile_fits(P0);
+        if (fits) sr_tile_load(xt, a.pre_state, a.ld_pre, a.S, m0, a.B, P0, L.tid);
+        sr_consts_load(kc, n, false, L.tid);
+        if constexpr (H2) uv = sr_usc_load(n.um, L.tid);
+        if (fits) sr_tile_store(xt, xs, P0, L.tid);
+        else sr_stage(a.pre_state, a.ld_pre, a.S, m0, a.B, xs, P0, L.tid);
+        sr_consts_store(cst, kc, L.tid);
+        if constexpr (H2) sr_usc_store(X.usc, uv, L.tid);
+      }
+      SrNext none;
+      none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
+      unsigned pm1, pm2;
+      float* headP = red + 8 * RP_ROWS * SR_HEADP;
+      if constexpr (H2)
+        sr_actor_fwd_h2<NGA, 0, true>(n, cst, X.usc, xs, P0, X, hB, red, headP, R, R1, L, row, rok, pm1, pm2,
+                                      none);
+      else
+        sr_actor_fwd<NGH, NGA, 0, true>(n, cst, xs, P0, hA, hB, red, headP, R, R1, L, row, rok, pm1, pm2,
+                                        none);
+      for (int e = L.tid; e < RP_ROWS * n.DO; e += 512) {
+        const int r = e / n.DO, c = e - r * n.DO;
+        if (m0 + r < a.B) a.pre_head[(int64_t)(m0 + r) * n.DO + c] = headP[r * SR_HEADP + c];
+      }
+      *reinterpret_cast<uint2*>(a.pre_mask + ((int64_t)tile * 512 + L.tid) * 2) = make_uint2(pm1, pm2);
+      return;
+    }
+  }
   SR_STAMP(a.prof, wg, 0);
   const int sr = L.tid / a.A, sj = L.tid - sr * a.A;
   const bool sok = L.tid < RP_ROWS * a.A;
   if constexpr (SPLIT) {
-    if (blockIdx.x & 1) {
+    if (brole == 1) {
       // ------------------------------------------------- helper: target critic 2 at (s', a')
       const SacMlp3& q = a.target[1];
       sr_l1_fill<NGC>(R1, q.W1f, L.tile0, (q.H1 + 15) >> 4, L.lane);
@@ -823,12 +1227,15 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
       {
         SrTile xt;
         SrConsts kc;
+        unsigned uv = 0u;
         const bool fits = sr_tile_fits(P0);
         if (fits) sr_tile_load(xt, a.next_state, a.ld_next, a.S, m0, a.B, P0, L.tid);
         sr_consts_load(kc, q, true, L.tid);
+        if constexpr (H2) uv = sr_usc_load(q.um, L.tid);
         if (fits) sr_tile_store(xt, xs, P0, L.tid);
         else sr_stage(a.next_state, a.ld_next, a.S, m0, a.B, xs, P0, L.tid);
         sr_consts_store(cst, kc, L.tid);
+        if constexpr (H2) sr_usc_store(X.usc, uv, L.tid);
       }
       SR_STAMP(a.prof, wg, 1);
       __syncthreads();   // the staged zeros of xs[:, S:] are down before the action lands on them
@@ -836,8 +1243,12 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
       SR_STAMP(a.prof, wg, 3);
       SrNext none;
       none.W1 = nullptr; none.nt1 = 0; none.Wh = nullptr; none.nth = 0;
-      sr_critic<NGH, NGC, false, false>(q, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+      if constexpr (H2)
+        sr_critic_h2<NGC, false, false>(q, cst, X.usc, xs, P0, X, hC, qred, R, R1, L, row, rok, none,
                                         a.prof, wg, 8);
+      else
+        sr_critic<NGH, NGC, false, false>(q, cst, xs, P0, hA, hB, hC, qred, R, R1, L, row, rok, none,
+                                          a.prof, wg, 8);
       __syncthreads();
       if (L.tid < RP_ROWS)
         publish_y(a.xres + (int64_t)tile * SR_XRES + L.tid * 17 + 16, sr_q(qred, L.tid, cst));
@@ -860,11 +1271,22 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
     sr_consts_load(k0, n, false, L.tid);
     sr_consts_load(k1, a.target[0], true, L.tid);
     if (!SPLIT) sr_consts_load(k2, a.target[1], true, L.tid);
+    unsigned u0v = 0u, u1v = 0u, u2v = 0u;
+    if constexpr (H2) {
+      u0v = sr_usc_load(n.um, L.tid);
+      u1v = sr_usc_load(a.target[0].um, L.tid);
+      if (!SPLIT) u2v = sr_usc_load(a.target[1].um, L.tid);
+    }
     if (fits) sr_tile_store(xt, xs, P0, L.tid);
     else sr_stage(a.next_state, a.ld_next, a.S, m0, a.B, xs, P0, L.tid);
     sr_consts_store(cst, k0, L.tid);
     sr_consts_store(cst + SR_CST, k1, L.tid);
     if (!SPLIT) sr_consts_store(cst + 2 * SR_CST, k2, L.tid);
+    if constexpr (H2) {
+      sr_usc_store(X.usc, u0v, L.tid);
+      sr_usc_store(X.usc + SR_USC, u1v, L.tid);
+      if (!SPLIT) sr_usc_store(X.usc + 2 * SR_USC, u2v, L.tid);
+    }
   }
   // this tile's Bellman-error inputs
   float qa = 0.f, qb = 0.f, rew = 0.f, live = 0.f;
@@ -875,9 +1297,15 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
   }
   SR_STAMP(a.prof, wg, 1);
   unsigned m1a, m2a;
-  sr_actor_fwd<NGH, NGA, NGC, false>(
-      n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
-      SrNext{a.target[0].W1f, (a.target[0].H1 + 15) >> 4, a.target[0].W2f, (a.target[0].H2 + 15) >> 4});
+  {
+    const SrNext nxa{a.target[0].W1f, (a.target[0].H1 + 15) >> 4, a.target[0].W2f, (a.target[0].H2 + 15) >> 4};
+    if constexpr (H2)
+      sr_actor_fwd_h2<NGA, NGC, false>(n, cst, X.usc, xs, P0, X, hB, red, headS, R, R1, L, row, rok, m1a,
+                                       m2a, nxa);
+    else
+      sr_actor_fwd<NGH, NGA, NGC, false>(n, cst, xs, P0, hA, hB, red, headS, R, R1, L, row, rok, m1a, m2a,
+                                         nxa);
+  }
   SR_STAMP(a.prof, wg, 2);
   if constexpr (HEAD == 0) {
     SrGauss G;
@@ -920,8 +1348,12 @@ __global__ __launch_bounds__(512) void sac_rows_b_kernel(SacRowsBArgs a) {
     const bool more = c + 1 < NT;
     nx.W1 = more ? a.target[1].W1f : nullptr; nx.nt1 = (a.target[1].H1 + 15) >> 4;
     nx.Wh = more ? a.target[1].W2f : nullptr; nx.nth = (a.target[1].H2 + 15) >> 4;
-    sr_critic<NGH, NGC, false, false>(a.target[c], cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R,
-                                      R1, L, row, rok, nx, a.prof, wg, 4 + 4 * c);
+    if constexpr (H2)
+      sr_critic_h2<NGC, false, false>(a.target[c], cst + (1 + c) * SR_CST, X.usc + (1 + c) * SR_USC, xs,
+                                      P0, X, hC, qred, R, R1, L, row, rok, nx, a.prof, wg, 4 + 4 * c);
+    else
+      sr_critic<NGH, NGC, false, false>(a.target[c], cst + (1 + c) * SR_CST, xs, P0, hA, hB, hC, qred, R,
+                                        R1, L, row, rok, nx, a.prof, wg, 4 + 4 * c);
     if (c == NT - 1 && pre_ok) {
 #pragma unroll
       for (int k = 0; k < 2; ++k)

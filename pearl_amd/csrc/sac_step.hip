@@ -112,6 +112,17 @@ void fill_net(const pa_mlp* h, bool target, SacMlp3& n) {
   n.act1 = h->act[0]; n.act2 = h->act[1];
   n.dz1 = h->dz[1]; n.dz2 = h->dz[2];
   n.K0 = h->d.dims[0]; n.H1 = h->d.dims[1]; n.H2 = h->d.dims[2]; n.DO = h->d.dims[3];
+  n.um = mlp_um(h, target);    // (null unless something asked for them: mlp_ensure_um)
+}
+// the fp16x2 instantiations of the row kernels (sac_rows.hpp, H2): hidden layers exactly 256 wide
+bool h2_enabled() {
+  const char* v = getenv("PEARL_AMD_SAC_H2");      // read per call: tests compare the forms
+  return !(v && v[0] == '0');
+}
+bool h2_shape(const pa_mlp* ac, const pa_mlp* c1, const pa_mlp* c2) {
+  for (const pa_mlp* h : {ac, c1, c2})
+    if (h->d.dims[1] != 256 || h->d.dims[2] != 256 || (h->woff[1] & 3) != 0) return false;
+  return true;
 }
 
 // hidden widths all one k-group count -> the unrolled instantiation
@@ -162,11 +173,30 @@ struct Exchange {
   int* err = nullptr;
   int* err_host = nullptr;
   int cap = 0;
+  // the actor's forward on the NEXT step's states, run by this step's sac_rows_b launch
+  // (SacRowsBArgs::pre_state): valid for exactly the step that follows inside one pa_sac_learn call
+  float* pre_head = nullptr;
+  int64_t pre_cap = 0;
+  bool pre_valid = false;
+  const float* pre_state = nullptr;
+  int pre_ld = 0, pre_B = 0;
 };
+// set by pa_sac_learn around a step that is followed by another one of the same call: the states the
+// next step will read (same batch size)
+struct NextHint {
+  const float* state = nullptr;
+  int ld = 0;
+};
+thread_local NextHint g_next_hint;
+bool pre_enabled() {
+  const char* v = getenv("PEARL_AMD_SAC_PRE");     // read per call: tests compare the forms
+  return !(v && v[0] == '0');
+}
 void exchange_free(void* p) {
   Exchange* x = static_cast<Exchange*>(p);
   if (!x) return;
   if (x->xact) (void)hipFree(x->xact);
+  if (x->pre_head) (void)hipFree(x->pre_head);
   if (x->err) (void)hipFree(x->err);
   if (x->err_host) (void)hipHostFree(x->err_host);
   delete x;
@@ -227,7 +257,31 @@ bool split_enabled() {
 }
 
 template <int NGH, int NGA, int NGC, int HEAD = 0>
-int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s) {
+int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream_t s, bool h2 = false) {
+  if constexpr (NGH == 16 && HEAD == 0) {
+    if (h2) {   // split launches only (fused_step)
+      static size_t configured_h2 = 0;
+      const size_t smem2 = sac_rows_h2_smem_bytes(W);
+      if (smem2 > configured_h2) {
+        int rc = set_max_smem(sac_rows_a_kernel<NGH, NGA, NGC, 0, true, true>, smem2);
+        if (rc != PA_OK) return rc;
+        rc = set_max_smem(sac_rows_b_kernel<NGH, NGA, NGC, 0, true, true>, smem2);
+        if (rc != PA_OK) return rc;
+        configured_h2 = smem2;
+      }
+      if (ra) {
+        const unsigned tiles = (unsigned)ceil_div(ra->B, RP_ROWS);
+        hipLaunchKernelGGL((sac_rows_a_kernel<NGH, NGA, NGC, 0, true, true>), dim3(4 * tiles), dim3(512),
+                           smem2, s, *ra);
+      } else {
+        const unsigned tiles = (unsigned)ceil_div(rb->B, RP_ROWS);
+        hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, 0, true, true>),
+                           dim3((rb->pre_state ? 3 : 2) * tiles), dim3(512), smem2, s, *rb);
+      }
+      PA_LAUNCH_CHECK();
+      return PA_OK;
+    }
+  }
   static size_t configured = 0;
   const size_t smem = sac_rows_smem_floats(W) * sizeof(float);
   if (smem > configured) {
@@ -264,8 +318,8 @@ int launch_rows(const SacRowsAArgs* ra, const SacRowsBArgs* rb, int W, hipStream
         if (rc != PA_OK) return rc;
         configured_split_b = smem;
       }
-      hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD, true>), dim3(2 * tiles), dim3(512),
-                         smem, s, *rb);
+      hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD, true>),
+                         dim3((rb->pre_state ? 3 : 2) * tiles), dim3(512), smem, s, *rb);
     } else {
       hipLaunchKernelGGL((sac_rows_b_kernel<NGH, NGA, NGC, HEAD>), dim3(tiles), dim3(512), smem, s, *rb);
     }
@@ -319,6 +373,20 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   PA_TRY(mlp_ensure_packed(c1, true, s));
   PA_TRY(mlp_ensure_packed(c2, true, s));
   const int ngh = static_groups(ac, c1);
+  // the fp16x2 kernels run with the split launches (decided below, same conditions): their row
+  // maxima are made current here and kept so by this step's optimizer launches
+  const bool want_split = split_enabled() && 4 * tiles <= resident_row_wgs(ac->d.device) && A <= 16;
+  const bool h2 = want_split && ngh == 16 && h2_enabled() && h2_shape(ac, c1, c2);
+  if (h2) {
+    PA_TRY(mlp_ensure_um(ac, false, s));
+    PA_TRY(mlp_ensure_um(c1, false, s));
+    PA_TRY(mlp_ensure_um(c2, false, s));
+    PA_TRY(mlp_ensure_um(c1, true, s));
+    PA_TRY(mlp_ensure_um(c2, true, s));
+  } else {
+    // nobody reads them: the optimizer launches need not keep them
+    ac->um_ok[0] = c1->um_ok[0] = c2->um_ok[0] = c1->um_ok[1] = c2->um_ok[1] = false;
+  }
   // ---------------------------------------------------------------- rows A
   SacRowsAArgs ra;
   memset(&ra, 0, sizeof(ra));
@@ -340,7 +408,7 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   // is resident at once (a waiting workgroup must never keep its partner off the chip)
   Exchange* xch = nullptr;
   ac->adam_guard = c1->adam_guard = c2->adam_guard = nullptr;
-  if (split_enabled() && 4 * tiles <= resident_row_wgs(ac->d.device) && A <= 16) {
+  if (want_split) {
     PA_TRY(exchange(ac, tiles, s, &xch));
     PA_REQUIRE(xch->err_host[0] == 0, PA_ERR_HIP,
                "an earlier SAC step's workgroup hand-off expired (code %d): the parameters were "
@@ -351,14 +419,20 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
     // an expired hand-off leaves pending tags (NaNs) in the gradients: the optimizer launches of
     // this step then skip AdamW and the soft update (AdamFuse::guard)
     ac->adam_guard = c1->adam_guard = c2->adam_guard = xch->err;
+    // the previous step of this learn loop ran the actor's forward on exactly these states
+    if (xch->pre_valid && xch->pre_state == a->state && xch->pre_ld == a->ld_state && xch->pre_B == B) {
+      ra.pre_head = xch->pre_head;
+      ra.pre_mask = reinterpret_cast<const unsigned*>(xch->pre_head + a4((int64_t)B * 2 * A));
+    }
+    xch->pre_valid = false;
   }
   // instantiations: every loop unrolled (hidden 256, S = 49..64, S + A = 65..80: the benchmark
   // shape), hidden layers unrolled only, all run-time
   const int form = ngh != 16 ? 0 : (wf16_nkg(S) == 4 && wf16_nkg(W) == 5 ? 2 : 1);
   const bool timed = g_tm.on && g_tm.n < kTimedSteps;
   if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][0], s));
-  PA_TRY((form == 2   ? launch_rows<16, 4, 5>(&ra, nullptr, W, s)
-          : form == 1 ? launch_rows<16, 0, 0>(&ra, nullptr, W, s)
+  PA_TRY((form == 2   ? launch_rows<16, 4, 5>(&ra, nullptr, W, s, h2)
+          : form == 1 ? launch_rows<16, 0, 0>(&ra, nullptr, W, s, h2)
                       : launch_rows<0, 0, 0>(&ra, nullptr, W, s)));
   if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][1], s));
   // ---------------------------------------------------------------- actor: dW + AdamW
@@ -386,17 +460,41 @@ int fused_step(const pa_sac_step_args* a, hipStream_t s) {
   rb.B = B; rb.S = S; rb.A = A;
   rb.tk = tb;
   rb.prof = g_prof_b;
+  bool pre_launched = false;
   if (ra.split) {
     rb.xact = xch->xact; rb.xres = xch->xres;
     rb.err = xch->err; rb.err_host = xch->err_host;
+    // a step follows inside this learn call: its actor forward rides this launch's idle workgroups
+    if (g_next_hint.state && pre_enabled() && 3 * tiles <= resident_row_wgs(ac->d.device)) {
+      const int64_t head_floats = a4((int64_t)B * 2 * A);
+      const int64_t need = head_floats + (int64_t)tiles * 512 * 2;   // + the ReLU masks, lane by lane
+      if (need > xch->pre_cap) {
+        if (xch->pre_head) {
+          PA_HIP(hipDeviceSynchronize());
+          (void)hipFree(xch->pre_head);
+          xch->pre_head = nullptr;
+          xch->pre_cap = 0;
+        }
+        PA_HIP(hipMalloc((void**)&xch->pre_head, (size_t)need * sizeof(float)));
+        xch->pre_cap = need;
+      }
+      rb.pre_state = g_next_hint.state; rb.ld_pre = g_next_hint.ld;
+      rb.pre_head = xch->pre_head;
+      rb.pre_mask = reinterpret_cast<unsigned*>(xch->pre_head + head_floats);
+      pre_launched = true;
+    }
   }
   if (timed) PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][2], s));
-  PA_TRY((form == 2   ? launch_rows<16, 4, 5>(nullptr, &rb, W, s)
-          : form == 1 ? launch_rows<16, 0, 0>(nullptr, &rb, W, s)
+  PA_TRY((form == 2   ? launch_rows<16, 4, 5>(nullptr, &rb, W, s, h2)
+          : form == 1 ? launch_rows<16, 0, 0>(nullptr, &rb, W, s, h2)
                       : launch_rows<0, 0, 0>(nullptr, &rb, W, s)));
   if (timed) {
     PA_HIP(hipEventRecord(g_tm.ev[g_tm.n][3], s));
     ++g_tm.n;
+  }
+  if (pre_launched) {
+    xch->pre_valid = true;
+    xch->pre_state = rb.pre_state; xch->pre_ld = rb.ld_pre; xch->pre_B = B;
   }
   // ---------------------------------------------------------------- critics: dW + AdamW, targets
   pa_mlp* cs[2] = {c1, c2};
@@ -872,7 +970,14 @@ extern "C" int pa_sac_learn(const pa_sac_step_args* step0, pa_arena* arena, cons
     a.critic_step = step0->critic_step + r;
     a.alpha_step = step0->alpha_step + r;
     a.losses = lp->losses + (int64_t)r * lp->losses_stride;
-    PA_TRY(pa_sac_step(&a, stream));
+    // the next step's states, when they are already gathered (same group): its actor forward rides
+    // this step's second row launch (fused_step)
+    const bool next_here = r + 1 < lp->rounds && slot + 1 < G;
+    g_next_hint.state = next_here ? a.state + (int64_t)a.B * step0->ld_state : nullptr;
+    g_next_hint.ld = step0->ld_state;
+    const int rc = pa_sac_step(&a, stream);
+    g_next_hint.state = nullptr;
+    if (rc != PA_OK) return rc;
   }
   return PA_OK;
 }

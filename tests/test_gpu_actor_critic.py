@@ -409,6 +409,9 @@ def test_sac_split_actor_rows_are_bitwise_the_unsplit_ones(name, monkeypatch):
     several steps, which also checks that the readers put the tags back."""
     fx = load("sac", name)
     outs = {}
+    # (the fp32-MFMA instantiations: the fp16x2 ones exist for split launches only — their own tests
+    #  are below)
+    monkeypatch.setenv("PEARL_AMD_SAC_H2", "0")
     for split in ("0", "1"):
         monkeypatch.setenv("PEARL_AMD_SAC_ONE_CALL", "1")
         monkeypatch.setenv("PEARL_AMD_SAC_FUSED", "1")
@@ -432,6 +435,61 @@ def test_sac_split_actor_rows_are_bitwise_the_unsplit_ones(name, monkeypatch):
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k
     assert torch.equal(e0, e1)
+
+
+def _sac_run(fx, reps, invalidate_at=None):
+    pl = make_sac(fx)
+    reports = []
+    step = 0
+    for rep in range(reps):
+        for na, nc in fx["noises"]:
+            if invalidate_at is not None and step == invalidate_at:
+                for net in pl._flat.values():
+                    if hasattr(net, "invalidate"):
+                        net.invalidate()
+            seq = iter([na, nc])
+            pl.noise_source = lambda B, A, dev: next(seq)
+            r = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+            reports.append({k: float(v) for k, v in r.items()})
+            step += 1
+    torch.cuda.synchronize()
+    params = {f"{n}.{k}": v.detach().cpu().clone()
+              for n, m in (("actor", pl._actor), ("critic", pl._critic), ("target", pl._critic_target))
+              for k, v in m.state_dict().items()}
+    return reports, params, pl._entropy_coef.detach().cpu().clone()
+
+
+@pytest.mark.parametrize("name", ["cfg3_shape_small", "cfg3_fullbatch"])
+def test_sac_fp16x2_rows_agree_with_the_fp32_rows_and_keep_their_row_maxima(name, monkeypatch):
+    """sac_rows_*_kernel<…, H2>: the 256 x 256 GEMMs of the two row launches as fp16x2 split products
+    (online_f16_kernel.hpp's scheme).  (a) Several steps against the fp32-MFMA instantiations: the
+    difference is that of two fp32 summation orders (the tolerances test_sac_step_forms_agree uses
+    between the fused and the per-stage forms).  (b) The row maxima of W2 that scale the operands are
+    kept by the optimizer launches' epilogues (atomic maxima, two buffers per network): a run that
+    drops them in the middle — pa_mlp_invalidate: repack, maxima recomputed from the parameters —
+    must be BITWISE the run that never did, or the kept maxima are not the parameters' maxima."""
+    fx = load("sac", name)
+    assert list(fx["config"]["hidden"]) == [256, 256]
+    monkeypatch.setenv("PEARL_AMD_SAC_ONE_CALL", "1")
+    monkeypatch.setenv("PEARL_AMD_SAC_FUSED", "1")
+    monkeypatch.setenv("PEARL_AMD_SAC_SPLIT", "1")
+    monkeypatch.setenv("PEARL_AMD_SAC_H2", "1")
+    n = len(fx["noises"])
+    rh, ph, eh = _sac_run(fx, 3)
+    ri, pi, ei = _sac_run(fx, 3, invalidate_at=n + 1 if n > 1 else 1)
+    assert rh == ri
+    for k in ph:
+        assert torch.equal(ph[k], pi[k]), k
+    assert torch.equal(eh, ei)
+    monkeypatch.setenv("PEARL_AMD_SAC_H2", "0")
+    rf, pf, ef = _sac_run(fx, 3)
+    for x, y in zip(rf, rh):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 2e-5 * max(1.0, abs(x[k])), (k, x[k], y[k])
+    from helpers import assert_adam_trajectory_close
+    for k in pf:
+        assert_adam_trajectory_close(ph[k], pf[k], 1e-3, 3 * n, max_outlier_frac=2e-3, msg=k)
+    torch.testing.assert_close(ef, eh, rtol=1e-5, atol=1e-7)
 
 
 BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
