@@ -335,6 +335,10 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   const int tile0 = wave * 2;
   const int pwg = blockIdx.x + blockIdx.y * gridDim.x;
   PA_STAMP(a.prof, pwg, wave, 0);
+  // ReLU masks of this lane's own outputs, 16 bits per layer (bit 8 rt + 4 t + e of layer l at
+  // 16 l): the backward's lane owns the same (row, unit) slots, so it needs no look at the kept
+  // activations (a 16-dword re-read per lane and layer in front of a barrier before)
+  unsigned long long fmask = 0ull;
   if constexpr (SPLITF) {
     // ------------------------------------------------------------ forward, bf16x3 (see rs_gemm)
     {
@@ -386,6 +390,8 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
                                  accm[t][rt][2] + accs[t][rt][2], accm[t][rt][3] + accs[t][rt][3]);
           if (relu) v = make_float4(relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z),
                                     relu_keep_nan(v.w));
+          fmask |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) |
+                                        (v.w > 0.f ? 8u : 0u)) << (16 * l + 8 * rt + 4 * t);
           if (!last) {
             // (every wave writes its 32 columns: units beyond N are exact zeros — zero weights,
             //  zero bias — i.e. the next layer's zero-padded k-steps)
@@ -454,6 +460,8 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
         float4 v = make_float4(acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]);
         if (relu) v = make_float4(relu_keep_nan(v.x), relu_keep_nan(v.y), relu_keep_nan(v.z),
                                   relu_keep_nan(v.w));
+        fmask |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) |
+                                      (v.w > 0.f ? 8u : 0u)) << (16 * l + 8 * rt + 4 * t);
         // (the output tile stays in LDS as well: the head reads it from there)
         if (u < PH - 4) *reinterpret_cast<float4*>(nxt + lr * PH + u) = v;
         if (!last) {
@@ -684,16 +692,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
           }
         RowWS R;
         if (tile0 < nt) rs_fill(R, nb.Wtsp[l], nks, tile0, nt, lane);
-        float4 hmq[RT][2];
-        if (mask) {
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const int row = m0 + r16 + 16 * rt;
-              hmq[rt][t] = guarded_load4(nb.act[l - 1], (int64_t)row * N, row < a.B, u0 + 16 * t, N);
-            }
-        }
+        const unsigned lm = (unsigned)(fmask >> (16 * (l - 1))) & 0xffffu;
         __syncthreads();
         if (tile0 < nt) rs_gemm<RT>(accm, accs, R, nb.Wtsp[l], nks, tile0, nt, pl[curp], lane);
 #pragma unroll
@@ -707,9 +706,9 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
             float4 v = make_float4(accm[t][rt][0] + accs[t][rt][0], accm[t][rt][1] + accs[t][rt][1],
                                    accm[t][rt][2] + accs[t][rt][2], accm[t][rt][3] + accs[t][rt][3]);
             if (mask) {
-              const float4 hm = hmq[rt][t];
-              v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
-              v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+              const unsigned mt = lm >> (8 * rt + 4 * t);
+              v.x = (mt & 1u) ? v.x : 0.f; v.y = (mt & 2u) ? v.y : 0.f;
+              v.z = (mt & 4u) ? v.z : 0.f; v.w = (mt & 8u) ? v.w : 0.f;
             }
             if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             // (units beyond N: zero weights -> exact zeros, the next layer's padded k-steps)
@@ -734,18 +733,8 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     constexpr int PDW = RT == 2 ? RS_PD2 : RS_PD;
     RowW<PDW> R;
     if (tile0 < nt) rowsN_fill<PDW>(R, nb.Wtf[l], wf16_nkg(K), tile0, nt, lane);
-    // the ReLU masks of the first chunk (this lane's own stores of the forward pass): requested
-    // before the GEMM instead of after it
-    float4 hmq[RT][2];
-    if (mask) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int row = m0 + r16 + 16 * rt;
-          hmq[rt][t] = guarded_load4(nb.act[l - 1], (int64_t)row * N, row < a.B, u0 + 16 * t, N);
-        }
-    }
+    // the ReLU masks of the first chunk: this lane's own outputs of the forward pass (fmask)
+    const unsigned lm = l > 0 ? (unsigned)(fmask >> (16 * (l - 1))) & 0xffffu : 0u;
     __syncthreads();
     for (int c0 = 0; c0 < nt; c0 += 16) {
       f32x4v acc[2][RT];
@@ -769,10 +758,15 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
           float4 v = make_float4(acc[t][rt][0], acc[t][rt][1], acc[t][rt][2], acc[t][rt][3]);
           if (l > 0) {
             if (mask) {
-              const float4 hm = c0 == 0 ? hmq[rt][t]
-                                        : guarded_load4(nb.act[l - 1], (int64_t)row * N, rok, u, N);
-              v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
-              v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+              if (c0 == 0) {
+                const unsigned mt = lm >> (8 * rt + 4 * t);
+                v.x = (mt & 1u) ? v.x : 0.f; v.y = (mt & 2u) ? v.y : 0.f;
+                v.z = (mt & 4u) ? v.z : 0.f; v.w = (mt & 8u) ? v.w : 0.f;
+              } else {
+                const float4 hm = guarded_load4(nb.act[l - 1], (int64_t)row * N, rok, u, N);
+                v.x = hm.x > 0.f ? v.x : 0.f; v.y = hm.y > 0.f ? v.y : 0.f;
+                v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
+              }
             }
             if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (u < PH - 4) *reinterpret_cast<float4*>(nxt + lr * PH + u) = v;
