@@ -1087,6 +1087,11 @@ struct DwArgs {
   int split;
   float* kscratch;       // [total_tiles][ksplit][DW_TM * DW_TN + DW_TM]
   unsigned* ktickets;    // [total_tiles], zero between launches
+  // 1: consecutive tiles (the column tiles of one block of units, which read the same dZ panel) run
+  // on ONE XCD — workgroup b goes to XCD b mod 8, so tile = (b mod 8) * (tiles / 8) + b / 8.  Set by
+  // the host for launches whose operand panels are re-read from memory (thousands of batch rows)
+  // and whose tile count is a multiple of 8.
+  int xcd_order;
 };
 
 // index of fragment-major slots (defined here, used by online_kernels.hpp as well)
@@ -1509,7 +1514,9 @@ __device__ __forceinline__ void weight_grad_body(const DwArgs& a, float* part, f
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row offsets stay in SGPRs
   const int KSP = a.ksplit > 1 ? a.ksplit : 1;
-  const int wg_tile = (int)blockIdx.x / KSP, kslice = (int)blockIdx.x % KSP;
+  int wg_tile = (int)blockIdx.x / KSP;
+  const int kslice = (int)blockIdx.x % KSP;
+  if (a.xcd_order && wg_tile < a.total_tiles) wg_tile = (wg_tile & 7) * (a.total_tiles >> 3) + (wg_tile >> 3);
   if (wg_tile >= a.total_tiles) {
     if (a.tail.kind == 1) {
       sac_step_tail(a.tail, part, tid);

@@ -252,6 +252,13 @@ inline int launch_weight_grad(DwArgs& a, bool loss_wg, hipStream_t s, const DwKe
     if (force_ks >= 1 && force_ks <= 8 && a.B == 1024) ks = force_ks;
   }
   a.ksplit = ks;
+  {
+    static const int xcd_env = []() {
+      const char* v = getenv("PEARL_AMD_DW_XCD_ORDER");
+      return v ? atoi(v) : 0;
+    }();
+    a.xcd_order = (xcd_env != 0 && ks == 1 && a.B >= min_b && (a.total_tiles & 7) == 0) ? 1 : 0;
+  }
   a.kscratch = nullptr;
   a.ktickets = nullptr;
   if (ks > 1) {

@@ -492,6 +492,62 @@ def test_sac_fp16x2_rows_agree_with_the_fp32_rows_and_keep_their_row_maxima(name
     torch.testing.assert_close(ef, eh, rtol=1e-5, atol=1e-7)
 
 
+def _rescale_hidden_units(fx, decades):
+    """The same networks with hidden layer 2's units rescaled by 10^k, k cycling over
+    [-decades, decades]: rows of W2 and b2 times s, the next layer's columns divided by s.  ReLU is
+    positively homogeneous, so every output is the same function of the input — with per-row weight
+    maxima, activations and pre-activation gradients that span 2 * decades orders of magnitude."""
+    fx = dict(fx)
+    H = 256
+    s = (10.0 ** ((torch.arange(H) % (2 * decades + 1)) - decades).double()).float()
+
+    def net(sd, w2, b2, nxt):
+        sd = {k: v.clone() for k, v in sd.items()}
+        sd[w2] = sd[w2] * s[:, None]
+        sd[b2] = sd[b2] * s
+        for k in nxt:
+            sd[k] = sd[k] / s[None, :]
+        return sd
+
+    fx["actor0"] = net(fx["actor0"], "_model.1.0.weight", "_model.1.0.bias", ["fc_mu.weight", "fc_std.weight"])
+    for key in ("critic0", "critic_target0"):
+        sd = fx[key]
+        for pre in ("_critic_1.", "_critic_2.", "_critic_networks_combined.0.", "_critic_networks_combined.1."):
+            if pre + "_model.1.0.weight" in sd:
+                sd = net(sd, pre + "_model.1.0.weight", pre + "_model.1.0.bias", [pre + "_model.2.0.weight"])
+        fx[key] = sd
+    return fx
+
+
+@pytest.mark.parametrize("decades", [3, 6])
+def test_sac_fp16x2_rows_over_a_dozen_decades_of_unit_scales(decades, monkeypatch):
+    """The fp16x2 split scales every operand by an exact power of two taken from its row's maximum
+    (weights: per unit, kept by the optimizer epilogue; activations and d z2: per batch row, found in
+    the kernel), and rides the per-unit scale on the other operand where the reduction runs over
+    the units (G = s2 W2, d z1 = d z2 W2).  With hidden units rescaled over 2 x `decades` orders of
+    magnitude the first step's losses, log-probabilities and q-values must still be the fp32-MFMA
+    kernels' to the tolerance two fp32 summation orders have on the unscaled networks."""
+    fx = _rescale_hidden_units(load("sac", "cfg3_shape_small"), decades)
+    monkeypatch.setenv("PEARL_AMD_SAC_ONE_CALL", "1")
+    monkeypatch.setenv("PEARL_AMD_SAC_FUSED", "1")
+    monkeypatch.setenv("PEARL_AMD_SAC_SPLIT", "1")
+    got = {}
+    for h2 in ("1", "0"):
+        monkeypatch.setenv("PEARL_AMD_SAC_H2", h2)
+        pl = make_sac(fx)
+        na, nc = fx["noises"][0]
+        seq = iter([na, nc])
+        pl.noise_source = lambda B, A, dev: next(seq)
+        r = pl.learn_batch(pl.preprocess_batch(sac_batch(fx)))
+        torch.cuda.synchronize()
+        got[h2] = ({k: float(v) for k, v in r.items()},
+                   pl._action_batch_log_prob_cache.detach().cpu().clone())
+    (rh, lh), (rf, lf) = got["1"], got["0"]
+    for k in rf:
+        assert rh[k] == rh[k] and abs(rh[k] - rf[k]) <= 2e-5 * max(1.0, abs(rf[k])), (k, rh[k], rf[k])
+    torch.testing.assert_close(lh, lf, rtol=5e-5, atol=3e-4)
+
+
 BANDIT = ["tiny", "cfg5_shape_small", "cfg5_fullbatch", "mae_tiny", "bce_tiny", "mse_sigmoid_tiny",
           "mae_cfg5_shape_small", "bce_cfg5_shape_small",
           # mlp_block's other forms in the trunk (neural_linear_bandit.py:84-85; round 5): LayerNorm,
