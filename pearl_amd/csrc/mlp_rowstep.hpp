@@ -225,7 +225,10 @@ __device__ __forceinline__ void rs_store_planes4(__bf16* planes, int rows, int r
   for (int sp = 0; sp < 3; ++sp)
     *reinterpret_cast<bf16x4*>(planes + ((size_t)sp * rows + row) * RS_PP + col) = q[sp];
 }
-constexpr int RS_SPD = 2;   // k-steps of weight planes in flight per wave
+#ifndef RS_SPD_VALUE
+#define RS_SPD_VALUE 2
+#endif
+constexpr int RS_SPD = RS_SPD_VALUE;   // k-steps of weight planes in flight per wave
 struct RowWS {
   bf16x8 w[RS_SPD][2][3];
 };

@@ -51,7 +51,9 @@ def test_dqn_report_is_the_references_by_default_and_gains_perf_fields_on_reques
     assert all(isinstance(v, list) and len(v) == 1 for v in perf.values())
     assert perf["perf/rounds"] == [25]
     tps, wall = perf["perf/transitions_per_s"][0], perf["perf/learn_wall_us"][0]
-    assert abs(tps - 256 * 25 / (wall * 1e-6)) <= 1e-6 * tps and 1e5 < tps < 1e9
+    # (a consistency check, not a speed claim: a cold box has taken 84 ms for this call — lazy
+    #  allocations of the first timed learn() — where a warm one takes 1.5 ms)
+    assert abs(tps - 256 * 25 / (wall * 1e-6)) <= 1e-6 * tps and 1e3 < tps < 1e9
     stages = {k.rsplit("/", 1)[1]: v[0] for k, v in perf.items() if k.startswith("perf/kernel_us/")}
     assert {"target_pass", "row_pass", "weight_grad_adamw"} <= set(stages), stages
     assert all(0.5 < v < 5000 for v in stages.values()), stages
