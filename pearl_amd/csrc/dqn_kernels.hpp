@@ -432,6 +432,32 @@ __host__ __device__ inline int64_t w2f_floats(int H2, int H1) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// LDS access through a pointer the compiler can no longer trace back to the __shared__ array (tile
+// buffers picked by a run-time layer index: the generic engine's row kernels).  Such an access is
+// compiled as a FLAT instruction, which counts on vmcnt AND lgkmcnt: every wait for an LDS operand
+// then also waits for every global load in flight — the weight ring of the GEMM loop is drained
+// in front of each k-step (s_waitcnt vmcnt(0) lgkmcnt(0) ahead of every MFMA group in the ISA of
+// mlp_rowstep_kernel up to round 6).  The explicit address-space cast makes it ds_read / ds_write.
+// (concrete typedefs: hipcc drops the attribute from a dependent type in a template)
+typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
+typedef __attribute__((address_space(3))) float lds_f32_t;
+typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8_t;
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4_t;
+typedef __attribute__((address_space(3))) __bf16 lds_bf16_t;
+__device__ __forceinline__ float4 lds_ld4(const float* p) {
+  const f32x4_t v = *(const lds_f32x4_t*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void lds_st4(float* p, const float4& v) {
+  const f32x4_t q = {v.x, v.y, v.z, v.w};
+  *(lds_f32x4_t*)p = q;
+}
+__device__ __forceinline__ float lds_ld(const float* p) { return *(const lds_f32_t*)p; }
+__device__ __forceinline__ void lds_st(float* p, float v) { *(lds_f32_t*)p = v; }
+__device__ __forceinline__ bf16x8 lds_ld_bf16x8(const __bf16* p) { return *(const lds_bf16x8_t*)p; }
+__device__ __forceinline__ void lds_st_bf16x4(__bf16* p, const bf16x4& v) { *(lds_bf16x4_t*)p = v; }
+__device__ __forceinline__ void lds_st_bf16(__bf16* p, __bf16 v) { *(lds_bf16_t*)p = v; }
+
 constexpr int TS_H = 256;            // H1 = H2 = 256 (the FAST shape of target_tile)
 constexpr int TS_KS = TS_H / 16;     // k-steps of v_mfma_f32_32x32x16_bf16
 constexpr int TS_LDP = TS_H + 8;     // bf16 pitch of a plane row: 528 B = 4 dwords mod 64 banks

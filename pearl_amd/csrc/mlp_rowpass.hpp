@@ -67,7 +67,7 @@ static __global__ __launch_bounds__(512) void mlp_rowfwd_kernel(RowFwdArgs a) {
       float4 v;
       if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
       else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
-      *reinterpret_cast<float4*>(xs + r * P0 + c) = v;
+      lds_st4(xs + r * P0 + c, v);
     }
   }
   const float* in = xs;
@@ -96,7 +96,7 @@ static __global__ __launch_bounds__(512) void mlp_rowfwd_kernel(RowFwdArgs a) {
                                 relu_keep_nan(v.w));
       if (!last) {
         // units beyond N are exact zeros (zero weights, zero bias): the next layer's padded k groups
-        if (u < PH - 4) *reinterpret_cast<float4*>(nxt + r16 * PH + u) = v;
+        if (u < PH - 4) lds_st4(nxt + r16 * PH + u, v);
         if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
       } else if (rok) {
         store4_guarded(n.out, (int64_t)row * n.ldo, u, N,
@@ -145,7 +145,7 @@ static __global__ __launch_bounds__(512) void mlp_rowbwd_kernel(RowBwdArgs a) {
     for (int e = tid; e < RP_ROWS * c4; e += 512) {
       const int r = e / c4, c = (e - r * c4) * 4;
       const float4 v = guarded_load4(n.d_out, (int64_t)(m0 + r) * n.ldd, (m0 + r) < a.B, c, DL);
-      *reinterpret_cast<float4*>(hb[0] + r * PH + c) = v;
+      lds_st4(hb[0] + r * PH + c, v);
     }
   }
   const float* in = hb[0];
@@ -175,7 +175,7 @@ static __global__ __launch_bounds__(512) void mlp_rowbwd_kernel(RowBwdArgs a) {
             v.z = hm.z > 0.f ? v.z : 0.f; v.w = hm.w > 0.f ? v.w : 0.f;
           }
           if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (u < PH - 4) *reinterpret_cast<float4*>(nxt + r16 * PH + u) = v;
+          if (u < PH - 4) lds_st4(nxt + r16 * PH + u, v);
           if (rok) store4_guarded(n.dz[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
         } else if (rok) {
           store4_guarded(n.d_x, (int64_t)row * n.lddx, u, N,

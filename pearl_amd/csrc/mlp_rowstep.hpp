@@ -172,12 +172,15 @@ __device__ __forceinline__ void rowsN_gemm(f32x4v (&acc)[2][RT], RowW<PD>& R, co
 #pragma unroll
     for (int p = 0; p < PD; ++p) {
       const int g = g0 + p;
+      // A ring slot is consumed where it lies and refilled BEHIND its MFMAs (the scheduling barrier
+      // keeps the loads there): the slot's registers are the same in every trip of this rolled loop.
+      // Refilled ahead of its use, the slot needs a second set of registers, and hipcc rotates the
+      // ring at the loop's back edge with v_mov behind s_waitcnt vmcnt(0) — the whole ring drained
+      // once per trip.
       const float4 w0 = R.r0[p], w1 = R.r1[p];
-      R.r0[p] = ld4_or_zero(Wf, base0 + (int64_t)(g + PD) * 256, ok0 && (g + PD) < nkg);
-      R.r1[p] = ld4_or_zero(Wf, base1 + (int64_t)(g + PD) * 256, ok1 && (g + PD) < nkg);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const float4 x4 = *reinterpret_cast<const float4*>(act + rt * 16 * pitch + g * 16);
+        const float4 x4 = lds_ld4(act + rt * 16 * pitch + g * 16);
         acc[0][rt] = mfma16(w0.x, x4.x, acc[0][rt]);
         acc[1][rt] = mfma16(w1.x, x4.x, acc[1][rt]);
         acc[0][rt] = mfma16(w0.y, x4.y, acc[0][rt]);
@@ -187,6 +190,10 @@ __device__ __forceinline__ void rowsN_gemm(f32x4v (&acc)[2][RT], RowW<PD>& R, co
         acc[0][rt] = mfma16(w0.w, x4.w, acc[0][rt]);
         acc[1][rt] = mfma16(w1.w, x4.w, acc[1][rt]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      R.r0[p] = ld4_or_zero(Wf, base0 + (int64_t)(g + PD) * 256, ok0 && (g + PD) < nkg);
+      R.r1[p] = ld4_or_zero(Wf, base1 + (int64_t)(g + PD) * 256, ok1 && (g + PD) < nkg);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -223,7 +230,7 @@ __device__ __forceinline__ void rs_store_planes4(__bf16* planes, int rows, int r
   }
 #pragma unroll
   for (int sp = 0; sp < 3; ++sp)
-    *reinterpret_cast<bf16x4*>(planes + ((size_t)sp * rows + row) * RS_PP + col) = q[sp];
+    lds_st_bf16x4(planes + ((size_t)sp * rows + row) * RS_PP + col, q[sp]);
 }
 #ifndef RS_SPD_VALUE
 #define RS_SPD_VALUE 2
@@ -258,47 +265,49 @@ __device__ __forceinline__ void rs_gemm(f32x4v (&accm)[2][RT], f32x4v (&accs)[2]
 #pragma unroll
     for (int p = 0; p < RS_SPD; ++p) {
       const int s = s0 + p;
-      bf16x8 wa[2][3];
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) {
-          wa[t][sp] = R.w[p][t][sp];
-          R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + s + RS_SPD) * 3 + sp) * 64 + lane,
-                                      tile0 + t < ntiles && s + RS_SPD < nks);
-        }
       // (the ring is a whole number of k-steps deep: a step past the layer's last one has zero
       //  weights but would read activation columns nobody wrote — 0 x garbage — so it is skipped)
-      if (s >= nks) continue;
-      bf16x8 b[RT][3];
+      if (s < nks) {
+        bf16x8 b[RT][3];
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+          for (int sp = 0; sp < 3; ++sp)
+            b[rt][sp] = lds_ld_bf16x8(
+                act + ((size_t)sp * RT * RP_ROWS + r16 + 16 * rt) * RS_PP + 32 * s + 8 * qd);
+        __builtin_amdgcn_sched_barrier(0);   // this k-step's LDS reads are issued ahead of its MFMAs
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[p][t][2], b[rt][0], accs[t][rt], 0, 0, 0);
+            accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[p][t][0], b[rt][2], accs[t][rt], 0, 0, 0);
+          }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[p][t][1], b[rt][1], accs[t][rt], 0, 0, 0);
+            accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[p][t][0], b[rt][1], accs[t][rt], 0, 0, 0);
+          }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[p][t][1], b[rt][0], accs[t][rt], 0, 0, 0);
+            accm[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(R.w[p][t][0], b[rt][0], accm[t][rt], 0, 0, 0);
+          }
+      }
+      // the slot is refilled BEHIND its MFMAs, into the registers they have just read (see
+      // rowsN_gemm: refilled ahead of them, the ring is rotated with v_mov behind vmcnt(0) once per trip)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp)
-          b[rt][sp] = *reinterpret_cast<const bf16x8*>(
-              act + ((size_t)sp * RT * RP_ROWS + r16 + 16 * rt) * RS_PP + 32 * s + 8 * qd);
-      __builtin_amdgcn_sched_barrier(0);   // this k-step's loads are issued ahead of its MFMAs
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][2], b[rt][0], accs[t][rt], 0, 0, 0);
-          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][0], b[rt][2], accs[t][rt], 0, 0, 0);
-        }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][1], b[rt][1], accs[t][rt], 0, 0, 0);
-          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][0], b[rt][1], accs[t][rt], 0, 0, 0);
-        }
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          accs[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][1], b[rt][0], accs[t][rt], 0, 0, 0);
-          accm[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[t][0], b[rt][0], accm[t][rt], 0, 0, 0);
-        }
+          R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + s + RS_SPD) * 3 + sp) * 64 + lane,
+                                      tile0 + t < ntiles && s + RS_SPD < nks);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -401,13 +410,14 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
             rs_store_planes4(nxt, ROWS, lr, u, v);
             if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
           } else {
-            if (u < PH - 4) *reinterpret_cast<float4*>(otile + lr * PH + u) = v;
+            if (u < PH - 4) lds_st4(otile + lr * PH + u, v);
             if (rok && n.out)
               store4_guarded(n.out, (int64_t)row * n.ldo, u, N,
                              is_vec_ok(n.out, n.ldo) && (N & 3) == 0, v);
           }
         }
       }
+      if (l < 2) PA_STAMP(a.prof, pwg, wave, 13 + l);   // epilogue of layer l done (before the barrier)
     }
   }
   const float* in = xs;
@@ -423,7 +433,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       float4 v;
       if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
       else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
-      *reinterpret_cast<float4*>(xs + r * P0 + c) = v;
+      lds_st4(xs + r * P0 + c, v);
     }
   }
   for (int l = 0; l < n.L; ++l) {
@@ -466,7 +476,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
         fmask |= (unsigned long long)((v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) |
                                       (v.w > 0.f ? 8u : 0u)) << (16 * l + 8 * rt + 4 * t);
         // (the output tile stays in LDS as well: the head reads it from there)
-        if (u < PH - 4) *reinterpret_cast<float4*>(nxt + lr * PH + u) = v;
+        if (u < PH - 4) lds_st4(nxt + lr * PH + u, v);
         if (!last) {
           if (rok && n.act[l]) store4_guarded(n.act[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
         } else if (rok && n.out) {
@@ -490,7 +500,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
         const int r = e / W, j = e - r * W;
         const int b = m0 + r;
         if (b >= a.B) continue;
-        const float x = (j == 0) ? 1.0f : (j < D ? ft[r * PH + (j - 1)] : 0.f);
+        const float x = (j == 0) ? 1.0f : (j < D ? lds_ld(ft + r * PH + (j - 1)) : 0.f);
         if (j < hd.ldX) hd.lin_x[(int64_t)b * hd.ldX + j] = x;
         if (j < hd.ldR) hd.lin_r[(int64_t)b * hd.ldR + j] = j < D ? x : (j == D ? hd.target[b] : 0.f);
       }
@@ -512,7 +522,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     const int b = m0 + hr;
     hlive = hr < ROWS && b < a.B;
     const float lo = 1.0f - hd.eps, hi = 1.0f + hd.eps;
-    const float z = (hr < ROWS) ? ot[hr * PH + hj] : 0.f;
+    const float z = (hr < ROWS) ? lds_ld(ot + hr * PH + hj) : 0.f;
     const float ar = hlive ? hd.arep[(int64_t)b * hd.lda + hj] : 0.f;
     const float g = hlive ? hd.gae[b] : 0.f;
     const float pold = hlive ? hd.p_old[b] : 1.f;
@@ -561,7 +571,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     const float alpha = hd.alpha[0];
     const float inv_n = 1.0f / ((float)a.B * (float)A);
     const int base = hr * A;
-    const float z = (hr < ROWS) ? ot[hr * PH + hj] : 0.f;
+    const float z = (hr < ROWS) ? lds_ld(ot + hr * PH + hj) : 0.f;
     float q = 0.f;
     if (hlive && !(hd.mask && hd.mask[(int64_t)b * A + hj]))
       q = fminf(hd.q1[(int64_t)b * A + hj], hd.q2[(int64_t)b * A + hj]);
@@ -618,13 +628,13 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     hlive = hr < ROWS && b < a.B;
     if (hlive && hd.kind == RS_HEAD_WMSE1) {
       // wmse_kernel's expressions with w = 1 and sum w = B
-      const float p = wloss_act(ot[hr * PH], hd.out_act);
+      const float p = wloss_act(lds_ld(ot + hr * PH), hd.out_act);
       if (hd.out_post) hd.out_post[b] = p;
       dval = wloss_grad(p, hd.target[b], 1.0f, (float)a.B, hd.loss_kind, hd.out_act);
       part0 = wloss_value(p, hd.target[b], hd.loss_kind) * 1.0f;
       part1 = p;
     } else if (hlive) {
-      const float d = __fsub_rn(ot[hr * PH], hd.target[b]);
+      const float d = __fsub_rn(lds_ld(ot + hr * PH), hd.target[b]);
       dval = __fmul_rn(hd.grad_scale, d);
       part0 = d * d;
     }
@@ -639,14 +649,14 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       const int c8 = ((DL + 31) & ~31) >> 3;
       for (int e = tid; e < 3 * ROWS * c8; e += 512) {
         const int pr = e / c8, c = (e - pr * c8) * 8;      // pr = plane * ROWS + row
-        *reinterpret_cast<float4*>(pl[0] + (size_t)pr * RS_PP + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        lds_st4(reinterpret_cast<float*>(pl[0] + (size_t)pr * RS_PP + c), make_float4(0.f, 0.f, 0.f, 0.f));
       }
     }
   } else {
     const int c4 = (rp_pad(DL) - 4) >> 2;
     for (int e = tid; e < ROWS * c4; e += 512) {
       const int r = e / c4, c = (e - r * c4) * 4;
-      *reinterpret_cast<float4*>(hb[0] + r * PH + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+      lds_st4(hb[0] + r * PH + c, make_float4(0.f, 0.f, 0.f, 0.f));
     }
   }
   __syncthreads();
@@ -772,7 +782,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
               }
             }
             if (!rok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < PH - 4) *reinterpret_cast<float4*>(nxt + lr * PH + u) = v;
+            if (u < PH - 4) lds_st4(nxt + lr * PH + u, v);
             if (rok) store4_guarded(nb.dz[l], (int64_t)row * N, u, N, (N & 3) == 0, v);
           } else if (rok) {
             store4_guarded(nb.d_x, (int64_t)row * nb.lddx, u, N,

@@ -16,8 +16,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pearl_amd import _native as N  # noqa: E402
 from pearl_amd.policy_learners.sequential_decision_making.flat_mlp import FlatMlp, layers_of  # noqa: E402
 
-NAMES = {0: "start", 1: "L1 staged", 2: "L1 gemm", 3: "L2 staged", 4: "L2 gemm", 5: "L3 staged",
-         6: "L3 gemm", 9: "forward done", 10: "head done", 11: "backward done", 12: "ticket"}
+NAMES = {0: "start", 1: "L1 staged", 2: "L1 gemm", 13: "L1 epilogue", 3: "L2 staged", 4: "L2 gemm",
+         14: "L2 epilogue", 5: "L3 staged", 6: "L3 gemm", 9: "forward done", 10: "head done",
+         11: "backward done", 12: "ticket"}
 
 
 def main():
