@@ -439,6 +439,14 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // in front of each k-step (s_waitcnt vmcnt(0) lgkmcnt(0) ahead of every MFMA group in the ISA of
 // mlp_rowstep_kernel up to round 6).  The explicit address-space cast makes it ds_read / ds_write.
 // (concrete typedefs: hipcc drops the attribute from a dependent type in a template)
+// Every global access of this wave has completed (s_waitcnt vmcnt(0) as an instruction the
+// compiler's wait-count pass SEES, unlike inline asm).  Used in front of a weight-ring loop whose
+// wave still has global STORES in flight (the previous layer's kept activations): gfx9 counts loads
+// and stores on one counter and may complete them out of order with respect to each other, so with
+// a store pending anywhere on the way into the loop hipcc turns the loop's first partial wait of
+// every trip into vmcnt(0) — the ring drained once per trip.  A workgroup barrier does not wait for
+// stores on this target; after it they have all but landed, and the loop's waits become partial.
+__device__ __forceinline__ void vm_drain() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 typedef __attribute__((address_space(3))) f32x4_t lds_f32x4_t;
 typedef __attribute__((address_space(3))) float lds_f32_t;
 typedef __attribute__((address_space(3))) bf16x8 lds_bf16x8_t;

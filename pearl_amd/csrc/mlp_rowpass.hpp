@@ -83,6 +83,7 @@ static __global__ __launch_bounds__(512) void mlp_rowfwd_kernel(RowFwdArgs a) {
       acc[t][0] = b.x; acc[t][1] = b.y; acc[t][2] = b.z; acc[t][3] = b.w;
     }
     __syncthreads();   // the input tile of this layer is complete (x staging / previous epilogue)
+    vm_drain();         // (kept-activation stores of the layer before: see vm_drain)
     // (a wave whose unit tiles lie beyond the layer's width has nothing to add to its bias)
     if (tile0 < nt) rows16_gemm<4>(acc, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, lane);
     const bool last = l == n.L - 1;
@@ -157,6 +158,7 @@ static __global__ __launch_bounds__(512) void mlp_rowbwd_kernel(RowBwdArgs a) {
     const bool mask = l > 0 && ((n.relu >> (l - 1)) & 1);
     float* nxt = hb[cur ^ 1];
     __syncthreads();
+    vm_drain();         // (kept-activation stores of the layer before: see vm_drain)
     // layer 0's input may be wider than one pass of 8 waves x 32 units: chunks of 256 units
     for (int c0 = 0; c0 < nt; c0 += 16) {
       f32x4v acc[2];

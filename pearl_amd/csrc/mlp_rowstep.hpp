@@ -244,22 +244,27 @@ __device__ __forceinline__ bf16x8 rs_ld_plane(const void* base, int64_t slot, bo
   const float4 v = ld4_or_zero(static_cast<const float*>(base), slot * 4, ok);
   return __builtin_bit_cast(bf16x8, v);
 }
-__device__ __forceinline__ void rs_fill(RowWS& R, const void* Wsp, int nks, int tile0, int ntiles, int lane) {
+// (ks0 / kstr: this wave's k-steps are ks0, ks0 + kstr, ... — 0 / 1 everywhere but in a narrow last
+//  layer, whose k-steps are dealt out to the eight waves: see the forward loop of the kernel)
+__device__ __forceinline__ void rs_fill(RowWS& R, const void* Wsp, int nks, int tile0, int ntiles, int lane,
+                                        int ks0 = 0, int kstr = 1) {
 #pragma unroll
   for (int p = 0; p < RS_SPD; ++p)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int sp = 0; sp < 3; ++sp)
-        R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + p) * 3 + sp) * 64 + lane,
-                                    tile0 + t < ntiles && p < nks);
+        R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + ks0 + p * kstr) * 3 + sp) * 64 + lane,
+                                    tile0 + t < ntiles && ks0 + p * kstr < nks);
 }
 // accm / accs[t][rt] += W planes (tiles tile0, tile0 + 1) x activation planes (RT row tiles), all k
 template <int RT>
 __device__ __forceinline__ void rs_gemm(f32x4v (&accm)[2][RT], f32x4v (&accs)[2][RT], RowWS& R,
-                                        const void* Wsp, int nks, int tile0, int ntiles,
-                                        const __bf16* act, int lane) {
+                                        const void* Wsp, int nks_all, int tile0, int ntiles,
+                                        const __bf16* act, int lane, int ks0 = 0, int kstr = 1) {
   const int r16 = lane & 15, qd = lane >> 4;
+  // local k-step i is k-step ks0 + i kstr of the layer; nks = how many this wave has
+  const int nks = ks0 < nks_all ? (nks_all - ks0 + kstr - 1) / kstr : 0;
   const int nksp = (nks + RS_SPD - 1) / RS_SPD * RS_SPD;
   for (int s0 = 0; s0 < nksp; s0 += RS_SPD) {
 #pragma unroll
@@ -274,7 +279,7 @@ __device__ __forceinline__ void rs_gemm(f32x4v (&accm)[2][RT], f32x4v (&accs)[2]
 #pragma unroll
           for (int sp = 0; sp < 3; ++sp)
             b[rt][sp] = lds_ld_bf16x8(
-                act + ((size_t)sp * RT * RP_ROWS + r16 + 16 * rt) * RS_PP + 32 * s + 8 * qd);
+                act + ((size_t)sp * RT * RP_ROWS + r16 + 16 * rt) * RS_PP + 32 * (ks0 + s * kstr) + 8 * qd);
         __builtin_amdgcn_sched_barrier(0);   // this k-step's LDS reads are issued ahead of its MFMAs
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -305,7 +310,7 @@ __device__ __forceinline__ void rs_gemm(f32x4v (&accm)[2][RT], f32x4v (&accs)[2]
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int sp = 0; sp < 3; ++sp)
-          R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + s + RS_SPD) * 3 + sp) * 64 + lane,
+          R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks_all + ks0 + (s + RS_SPD) * kstr) * 3 + sp) * 64 + lane,
                                       tile0 + t < ntiles && s + RS_SPD < nks);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -380,13 +385,53 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
           accs[t][rt][0] = accs[t][rt][1] = accs[t][rt][2] = accs[t][rt][3] = 0.f;
         }
       }
-      RowWS R;
-      if (tile0 < nt) rs_fill(R, n.Wsp[l], nks, tile0, nt, lane);
-      __syncthreads();
-      PA_STAMP(a.prof, pwg, wave, 1 + 2 * l);   // layer l: operands staged
-      if (tile0 < nt) rs_gemm<RT>(accm, accs, R, n.Wsp[l], nks, tile0, nt, pl[l & 1], lane);
-      PA_STAMP(a.prof, pwg, wave, 2 + 2 * l);   // layer l: GEMM done
       const bool last = l == n.L - 1;
+      // A narrow last layer (one pair of unit tiles: PPO's 16 action logits, a critic's single value)
+      // used to be wave 0's alone — all k-steps of the layer behind a two-deep ring, ~3 us of exposed
+      // memory round trips with seven waves waiting at the barrier.  Its k-steps are dealt out to the
+      // eight waves instead (wave w: k-steps w, w + 8, ...); the partial tiles meet in the plane
+      // buffer this layer does not read (the input of the layer before: dead) and wave 0 adds them
+      // in wave order — deterministic, rounded differently from one long chain.
+      const bool kdeal = last && nt <= 2 && nks >= 4;
+      RowWS R;
+      if (kdeal) rs_fill(R, n.Wsp[l], nks, 0, nt, lane, wave, 8);
+      else if (tile0 < nt) rs_fill(R, n.Wsp[l], nks, tile0, nt, lane);
+      __syncthreads();
+      vm_drain();   // (stores of the epilogue before + the ring prefetched under the barrier: see vm_drain)
+      PA_STAMP(a.prof, pwg, wave, 1 + 2 * l);   // layer l: operands staged
+      if (kdeal) {
+        // (the bias rides wave 0's partial tile: the other waves' accumulators start from the bias
+        //  of their OWN columns, which lie beyond the layer's width — zeros)
+        rs_gemm<RT>(accm, accs, R, n.Wsp[l], nks, 0, nt, pl[l & 1], lane, wave, 8);
+        float* part = reinterpret_cast<float*>(pl[(l + 1) & 1]);   // [8 waves][2 t][RT][64 lanes] float4
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            lds_st4(part + (((wave * 2 + t) * RT + rt) * 64 + lane) * 4,
+                    make_float4(accm[t][rt][0] + accs[t][rt][0], accm[t][rt][1] + accs[t][rt][1],
+                                accm[t][rt][2] + accs[t][rt][2], accm[t][rt][3] + accs[t][rt][3]));
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt) {
+            float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wave == 0) {
+              sum = lds_ld4(part + (((0 * 2 + t) * RT + rt) * 64 + lane) * 4);
+              for (int w = 1; w < 8; ++w) {
+                const float4 q = lds_ld4(part + (((w * 2 + t) * RT + rt) * 64 + lane) * 4);
+                sum.x += q.x; sum.y += q.y; sum.z += q.z; sum.w += q.w;
+              }
+            }
+            // (waves 1-7 go on with exact zeros: their own 32 columns lie beyond the layer's width)
+            accm[t][rt][0] = sum.x; accm[t][rt][1] = sum.y; accm[t][rt][2] = sum.z; accm[t][rt][3] = sum.w;
+            accs[t][rt][0] = accs[t][rt][1] = accs[t][rt][2] = accs[t][rt][3] = 0.f;
+          }
+      } else if (tile0 < nt) {
+        rs_gemm<RT>(accm, accs, R, n.Wsp[l], nks, tile0, nt, pl[l & 1], lane);
+      }
+      PA_STAMP(a.prof, pwg, wave, 2 + 2 * l);   // layer l: GEMM done
       const bool relu = (n.relu >> l) & 1;
       __bf16* nxt = pl[(l + 1) & 1];
 #pragma unroll
@@ -455,6 +500,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     RowW<PDW> R;
     if (tile0 < nt) rowsN_fill<PDW>(R, n.Wf[l], wf16_nkg(K), tile0, nt, lane);
     __syncthreads();
+    vm_drain();   // (stores of the epilogue before + the ring prefetched under the barrier: see vm_drain)
     PA_STAMP(a.prof, pwg, wave, 1 + 2 * l);   // layer l: operands staged
     if (tile0 < nt)
       rowsN_gemm<PDW, RT>(acc, R, n.Wf[l], wf16_nkg(K), tile0, nt, in + r16 * pin + 4 * qd, pin, lane);
@@ -707,6 +753,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
         if (tile0 < nt) rs_fill(R, nb.Wtsp[l], nks, tile0, nt, lane);
         const unsigned lm = (unsigned)(fmask >> (16 * (l - 1))) & 0xffffu;
         __syncthreads();
+        vm_drain();   // (stores of the epilogue before + the ring prefetched under the barrier: see vm_drain)
         if (tile0 < nt) rs_gemm<RT>(accm, accs, R, nb.Wtsp[l], nks, tile0, nt, pl[curp], lane);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -749,6 +796,7 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
     // the ReLU masks of the first chunk: this lane's own outputs of the forward pass (fmask)
     const unsigned lm = l > 0 ? (unsigned)(fmask >> (16 * (l - 1))) & 0xffffu : 0u;
     __syncthreads();
+    vm_drain();   // (stores of the epilogue before + the ring prefetched under the barrier: see vm_drain)
     for (int c0 = 0; c0 < nt; c0 += 16) {
       f32x4v acc[2][RT];
 #pragma unroll

@@ -286,16 +286,18 @@ __device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __res
       // (the slot is refilled behind its MFMAs, into the registers they have just read: refilled
       //  ahead of them, hipcc rotates the ring at the back edge of this rolled loop with v_mov
       //  behind s_waitcnt vmcnt(0) — see rowsN_gemm, mlp_rowstep.hpp)
-      const float4 w0 = r0[p], w1 = r1[p];
-      const float4 x4 = lds_ld4(act + g * 16);
-      c[0][0 % NACC] = mfma16(w0.x, x4.x, c[0][0 % NACC]);
-      c[1][0 % NACC] = mfma16(w1.x, x4.x, c[1][0 % NACC]);
-      c[0][1 % NACC] = mfma16(w0.y, x4.y, c[0][1 % NACC]);
-      c[1][1 % NACC] = mfma16(w1.y, x4.y, c[1][1 % NACC]);
-      c[0][2 % NACC] = mfma16(w0.z, x4.z, c[0][2 % NACC]);
-      c[1][2 % NACC] = mfma16(w1.z, x4.z, c[1][2 % NACC]);
-      c[0][3 % NACC] = mfma16(w0.w, x4.w, c[0][3 % NACC]);
-      c[1][3 % NACC] = mfma16(w1.w, x4.w, c[1][3 % NACC]);
+      if (g < nkg) {
+        const float4 w0 = r0[p], w1 = r1[p];
+        const float4 x4 = lds_ld4(act + g * 16);
+        c[0][0 % NACC] = mfma16(w0.x, x4.x, c[0][0 % NACC]);
+        c[1][0 % NACC] = mfma16(w1.x, x4.x, c[1][0 % NACC]);
+        c[0][1 % NACC] = mfma16(w0.y, x4.y, c[0][1 % NACC]);
+        c[1][1 % NACC] = mfma16(w1.y, x4.y, c[1][1 % NACC]);
+        c[0][2 % NACC] = mfma16(w0.z, x4.z, c[0][2 % NACC]);
+        c[1][2 % NACC] = mfma16(w1.z, x4.z, c[1][2 % NACC]);
+        c[0][3 % NACC] = mfma16(w0.w, x4.w, c[0][3 % NACC]);
+        c[1][3 % NACC] = mfma16(w1.w, x4.w, c[1][3 % NACC]);
+      }
       __builtin_amdgcn_sched_barrier(0);
       r0[p] = ld4_or_zero(Wf, base0 + (int64_t)(g + PD) * 256, ok0 && (g + PD) < nkg);
       r1[p] = ld4_or_zero(Wf, base1 + (int64_t)(g + PD) * 256, ok1 && (g + PD) < nkg);

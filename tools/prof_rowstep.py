@@ -80,6 +80,17 @@ def show_dw(dw):
         v = v[(st[:, :, i] > 0) & live]
         if v.size:
             print(f"{name:16s} {v.min():8.2f} {np.median(v):8.2f} {v.max():8.2f}")
+    # the main loop per workgroup (slowest wave), by tile (blockIdx / ksplit, ksplit = 2 at B = 4096:
+    # tiles 0-15 W1 actor, 16-31 W2 actor, 32-35 W3 actor, 36-.. critic), slice and XCD (blockIdx mod 8)
+    ml = (st[:, :, 2].max(axis=1) - np.where(st[:, :, 1] > 0, st[:, :, 1], 1 << 62).min(axis=1)) / 100.0
+    wgs = [i for i in range(st.shape[0]) if live[i].any()]
+    ks = int(os.environ.get("PROF_KS", "2"))
+    print("main loop us per workgroup (tile: slice0 slice1 ...):")
+    for t in range((len(wgs) + ks - 1) // ks):
+        row = [ml[t * ks + k] for k in range(ks) if t * ks + k < len(wgs)]
+        print(f"  tile {t:3d}: " + " ".join(f"{v:6.2f}" for v in row))
+    by_xcd = [[ml[i] for i in wgs if i % 8 == x] for x in range(8)]
+    print("main loop us by XCD (mean / max):", ", ".join(f"{np.mean(v):.1f}/{np.max(v):.1f}" for v in by_xcd if v))
     # which workgroups are the late ones, and when did they START (a late start = it waited for a CU)
     end = (st[:, :, 6].max(axis=1) - t0) / 100.0
     start = (np.where(st[:, :, 0] > 0, st[:, :, 0], 1 << 62).min(axis=1) - t0) / 100.0
