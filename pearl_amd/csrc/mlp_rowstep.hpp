@@ -358,17 +358,34 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   unsigned long long fmask = 0ull;
   if constexpr (SPLITF) {
     // ------------------------------------------------------------ forward, bf16x3 (see rs_gemm)
+    // layer 0's first weight fragments are asked for ahead of the input tile (neither depends on
+    // the other: one memory round trip under the other's)
+    RowWS R;
+    const int nt_0 = (n.dims[1] + 15) >> 4, nks_0 = wsp16_nks(n.dims[0]);
+    const bool pre0 = !(n.L == 1 && nt_0 <= 2 && nks_0 >= 4);   // (not a k-dealt single layer)
+    if (pre0 && tile0 < nt_0) rs_fill(R, n.Wsp[0], nks_0, tile0, nt_0, lane);
     {
       // x tile -> planes 0, split by the staging thread; zero up to the next multiple of 32 columns
       const bool vx = is_vec_ok(a.x, a.ldx) && ((n.dims[0] & 3) == 0);
       const int kp4 = ((n.dims[0] + 31) & ~31) >> 2;
-      for (int e = tid; e < ROWS * kp4; e += 512) {
-        const int r = e / kp4, c = (e - r * kp4) * 4;
-        const bool ok = (m0 + r) < a.B;
-        float4 v;
-        if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
-        else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
-        rs_store_planes4(pl[0], ROWS, r, c, v);
+      // (four vectors of the tile requested before the first is split: a thread's trips through this
+      //  loop were four to eight DEPENDENT memory round trips — 4.5 us in front of layer 1's barrier)
+      for (int e0 = tid; e0 < ROWS * kp4; e0 += 4 * 512) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + j * 512;
+          const int r = e / kp4, c = (e - r * kp4) * 4;
+          const bool ok = e < ROWS * kp4 && (m0 + r) < a.B;
+          if (vx) v[j] = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
+          else v[j] = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = e0 + j * 512;
+          const int r = e / kp4, c = (e - r * kp4) * 4;
+          if (e < ROWS * kp4) rs_store_planes4(pl[0], ROWS, r, c, v[j]);
+        }
       }
     }
     for (int l = 0; l < n.L; ++l) {
@@ -393,8 +410,8 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
       // buffer this layer does not read (the input of the layer before: dead) and wave 0 adds them
       // in wave order — deterministic, rounded differently from one long chain.
       const bool kdeal = last && nt <= 2 && nks >= 4;
-      RowWS R;
-      if (kdeal) rs_fill(R, n.Wsp[l], nks, 0, nt, lane, wave, 8);
+      if (l == 0 && pre0) {
+      } else if (kdeal) rs_fill(R, n.Wsp[l], nks, 0, nt, lane, wave, 8);
       else if (tile0 < nt) rs_fill(R, n.Wsp[l], nks, tile0, nt, lane);
       __syncthreads();
       vm_drain();   // (stores of the epilogue before + the ring prefetched under the barrier: see vm_drain)
@@ -472,13 +489,22 @@ static __global__ __launch_bounds__(512) void mlp_rowstep_kernel(RowStepArgs a) 
   {
     const bool vx = is_vec_ok(a.x, a.ldx) && ((n.dims[0] & 3) == 0);
     const int c4 = (P0 - 4) >> 2;
-    for (int e = tid; e < ROWS * c4; e += 512) {
-      const int r = e / c4, c = (e - r * c4) * 4;
-      const bool ok = (m0 + r) < a.B;
-      float4 v;
-      if (vx) v = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
-      else v = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
-      lds_st4(xs + r * P0 + c, v);
+    for (int e0 = tid; e0 < ROWS * c4; e0 += 4 * 512) {   // (four vectors in flight: see the split form)
+      float4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * 512;
+        const int r = e / c4, c = (e - r * c4) * 4;
+        const bool ok = e < ROWS * c4 && (m0 + r) < a.B;
+        if (vx) v[j] = ld4_or_zero(a.x, (int64_t)(m0 + r) * a.ldx + c, ok && c < n.dims[0]);
+        else v[j] = guarded_load4(a.x, (int64_t)(m0 + r) * a.ldx, ok, c, n.dims[0]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = e0 + j * 512;
+        const int r = e / c4, c = (e - r * c4) * 4;
+        if (e < ROWS * c4) lds_st4(xs + r * P0 + c, v[j]);
+      }
     }
   }
   for (int l = 0; l < n.L; ++l) {
