@@ -158,6 +158,7 @@ __device__ __forceinline__ void rowsN_fill(RowW<PD>& R, const float* __restrict_
   for (int p = 0; p < PD; ++p) {
     R.r0[p] = ld4_or_zero(Wf, base0 + (int64_t)p * 256, ok0 && p < nkg);
     R.r1[p] = ld4_or_zero(Wf, base1 + (int64_t)p * 256, ok1 && p < nkg);
+    __builtin_amdgcn_sched_barrier(0);   // (slot order = issue order: see rows16_gemm)
   }
 }
 template <int PD, int RT>
@@ -249,13 +250,15 @@ __device__ __forceinline__ bf16x8 rs_ld_plane(const void* base, int64_t slot, bo
 __device__ __forceinline__ void rs_fill(RowWS& R, const void* Wsp, int nks, int tile0, int ntiles, int lane,
                                         int ks0 = 0, int kstr = 1) {
 #pragma unroll
-  for (int p = 0; p < RS_SPD; ++p)
+  for (int p = 0; p < RS_SPD; ++p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int sp = 0; sp < 3; ++sp)
         R.w[p][t][sp] = rs_ld_plane(Wsp, (((int64_t)(tile0 + t) * nks + ks0 + p * kstr) * 3 + sp) * 64 + lane,
                                     tile0 + t < ntiles && ks0 + p * kstr < nks);
+    __builtin_amdgcn_sched_barrier(0);   // (slot order = issue order: see rows16_gemm)
+  }
 }
 // accm / accs[t][rt] += W planes (tiles tile0, tile0 + 1) x activation planes (RT row tiles), all k
 template <int RT>

@@ -275,6 +275,9 @@ __device__ __forceinline__ void rows16_gemm(f32x4v (&acc)[2], const float* __res
   for (int p = 0; p < PD; ++p) {
     r0[p] = ld4_or_zero(Wf, base0 + (int64_t)p * 256, ok0 && p < nkg);
     r1[p] = ld4_or_zero(Wf, base1 + (int64_t)p * 256, ok1 && p < nkg);
+    // (slot order = issue order: hipcc otherwise issues slot 0's loads LAST, and the loop's first
+    //  wait — merged with this entry state — becomes vmcnt(0) in every trip)
+    __builtin_amdgcn_sched_barrier(0);
   }
   const int nkgp = (nkg + PD - 1) / PD * PD;
   f32x4v c[2][NACC];
