@@ -37,7 +37,8 @@ FLOP_DW_PER_TRANSITION = 2 * (144 * 256 + 256 * 256 + 256)                      
 def pmc_chain():
     """Matrix-pipe busy fraction of the chain's kernels from the newest committed PMC pass
     (tools/pmc_summary.py --chain-json; separate rocprofv3 --pmc runs, never inside this run)."""
-    for name in ("r06_z_pmc_chain.json", "r06_pmc_chain.json", "r05_pmc_chain.json"):
+    for name in ("r06_final_pmc_chain.json", "r06_zzz_pmc_chain.json", "r06_z_pmc_chain.json", "r06_pmc_chain.json",
+                 "r05_pmc_chain.json"):
         path = os.path.join(REPO, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:
@@ -163,7 +164,7 @@ def pmc_traffic(transitions_per_launch, split_on):
     prescribes for gfx950, + WRITE_SIZE, per transition).  Counters cannot be collected inside this
     run, so the line names the file the figure comes from and the kernel that pass measured; None
     when no pass exists for the kernel that ran."""
-    names = (["r06_z_pmc_target.json", "r06_pmc_target.json", "r05_pmc_target.json", "r04_pmc_target.json",
+    names = (["r06_final_pmc_target.json", "r06_zzz_pmc_target.json", "r06_z_pmc_target.json", "r06_pmc_target.json", "r05_pmc_target.json", "r04_pmc_target.json",
               "r03_pmc_target.json"] if split_on else ["r02_pmc_target.json"])
     for name in names:
         path = os.path.join(REPO, "profiles", name)
