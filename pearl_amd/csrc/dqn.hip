@@ -1607,11 +1607,7 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
       if (rc != PA_OK) return rc;
       configured = smem;
     }
-    // TIMING EXPERIMENT ONLY (PEARL_AMD_DEBUG_PROLOGUE=1): one repack workgroup instead of 48 — it
-    // still zeroes the counters, the packed copies keep the (valid) contents the previous call's
-    // optimizer epilogues left — to tell the sampler's share of the launch from the rebuild's
-    static const int dbg_prologue = env_int("PEARL_AMD_DEBUG_PROLOGUE", 0);
-    hipLaunchKernelGGL(learn_prologue_kernel, dim3((unsigned)(R + (dbg_prologue == 1 ? 1 : kPrologueRepackWgs))),
+    hipLaunchKernelGGL(learn_prologue_kernel, dim3((unsigned)(R + kPrologueRepackWgs)),
                        dim3(SAMPLE_THREADS), smem, s, sa, R, rpk, h->tile_ctr, kTileCtrs + 4);
     PA_LAUNCH_CHECK();
   }

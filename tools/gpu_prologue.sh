@@ -1,5 +1,6 @@
 #!/bin/bash
-# prologue launch of learn(): the sampler's share against the rebuild's (PEARL_AMD_DEBUG_PROLOGUE=1: one repack workgroup)
+# prologue launch of learn(): the sampler's share against the rebuild's.  The PEARL_AMD_DEBUG_PROLOGUE knob it drove (one repack
+# workgroup instead of 48) was a timing experiment and is no longer in the library (record: profiles/r06_m_prologue_sampler.txt).
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for v in 0 1; do
