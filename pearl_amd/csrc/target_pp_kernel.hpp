@@ -82,8 +82,6 @@ static __global__ __launch_bounds__(1024, 4) void target_pp_kernel(TargetArgs a)
                      ((a.feat_bstride & 3) == 0);
   const bool vw1 = ((reinterpret_cast<uintptr_t>(a.W1a) & 15) == 0) && ((a.ldw1 & 3) == 0) &&
                    ((a.AD & 3) == 0);
-  const bool v2 = ((reinterpret_cast<uintptr_t>(a.b2) & 15) == 0) &&
-                  ((reinterpret_cast<uintptr_t>(a.w3) & 15) == 0) && ((a.H2 & 3) == 0);
   const int wcol = wave * 32 + l31;
   const int64_t woff = (int64_t)wcol * a.ldw1;
   const bool wok = l1 && wcol < a.H1;
