@@ -1828,7 +1828,12 @@ extern "C" int pa_dqn_learn(pa_dqn* h, pa_arena* arena, const pa_learn_args* arg
         }
         ScopedTimer tm(h, "target_l1", t, 2, 1, cover * B);
         GemmArgs g = target_l1_problem(h, b.next_state, cover * B, Up);
-        rc = launch_linear<false>(&g, 1, t);
+        // PEARL_AMD_U_EXCLUSIVE=1 (experiment): the remainder's U launch — a classic grid over every
+        // CU — asks for more LDS than a CU with a resident row-pass workgroup has left (163 840 -
+        // 35 840 B), so it stays off the chain's CUs while a row pass runs
+        static const int u_excl = env_int("PEARL_AMD_U_EXCLUSIVE", 0);
+        const size_t pad = (u_excl && persist && pc == npieces - 1 && npieces > 1) ? (size_t)129024 : 0;
+        rc = launch_linear<false>(&g, 1, t, pad);
         if (rc != PA_OK) return rc;
       }
       // Leading pieces: a classic grid takes every CU, the chain's too — the row pass that is

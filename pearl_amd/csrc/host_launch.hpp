@@ -16,8 +16,10 @@ int set_max_smem(K kernel, size_t bytes) {
 }
 
 // One launch, one or two independent problems (blockIdx.z).
+// min_smem: request at least this much dynamic LDS per workgroup (unused by the kernel) — a launch
+// that must not share a CU with another kernel's resident workgroups asks for more than they leave.
 template <bool B_KS>
-int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s) {
+int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s, size_t min_smem = 0) {
   constexpr int KW = 4;
   static size_t configured = 0;
   auto kern = linear_kernel<B_KS, KW>;
@@ -32,6 +34,7 @@ int launch_linear(const GemmArgs* probs, int nprob, hipStream_t s) {
     gx = (int)ceil_div(probs[i].N, G_BN) > gx ? (int)ceil_div(probs[i].N, G_BN) : gx;
     gy = (int)ceil_div(probs[i].M, G_BM) > gy ? (int)ceil_div(probs[i].M, G_BM) : gy;
   }
+  smem = min_smem > smem ? min_smem : smem;
   if (smem > configured) {
     int rc = set_max_smem(kern, smem);
     if (rc != PA_OK) return rc;
