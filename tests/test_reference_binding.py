@@ -257,7 +257,7 @@ def test_hip_ppo_tracks_the_reference_ppo_on_identical_data(reference):
     torch.testing.assert_close(extra["action_probs"].cpu(),
                                torch.cat([t.action_probs for t in rb_ref.memory]).view(-1), rtol=1e-5, atol=1e-7)
     for k in ("actor_loss", "critic_loss"):
-        torch.testing.assert_close(torch.tensor(got[k]), torch.tensor([float(x) for x in want[k]]),
+        torch.testing.assert_close(torch.tensor(got[k]), torch.tensor([float(x.detach()) if torch.is_tensor(x) else float(x) for x in want[k]]),
                                    rtol=2e-4, atol=2e-4, msg=k)
     for name in ("_actor", "_critic"):
         for k, v in getattr(ref, name).state_dict().items():
@@ -367,7 +367,7 @@ def test_hip_sac_tracks_the_reference_sac_on_identical_data_and_noise(reference)
     got = hip.learn(rb_hip)
     assert Replay.calls == 2 * R
     for k in ("actor_loss", "critic_loss", "entropy_coef"):
-        torch.testing.assert_close(torch.tensor(got[k]), torch.tensor([float(x) for x in want[k]]),
+        torch.testing.assert_close(torch.tensor(got[k]), torch.tensor([float(x.detach()) if torch.is_tensor(x) else float(x) for x in want[k]]),
                                    rtol=5e-4, atol=5e-5, msg=k)
     for name in ("_actor", "_critic", "_critic_target"):
         for k, v in getattr(ref, name).state_dict().items():
